@@ -1,0 +1,202 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke().  Nothing under meryl_amd/ may import this package.
+See oracle/oracle.h for what each function restates (reference file:line).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+CANONICAL, FORWARD, REVERSE = 0, 1, 2
+
+
+def build(force=False):
+    """Compile liboracle.so with the committed Makefile (gcc/g++ only)."""
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_count.c", "oracle_port.cpp", "oracle.h", "Makefile")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class _Config(ctypes.Structure):
+    _fields_ = [
+        ("k", ctypes.c_uint32),
+        ("n_kmers_estimate", ctypes.c_uint64),
+        ("memory_allowed", ctypes.c_uint64),
+        ("count_suffix_length", ctypes.c_uint32),
+        ("page_size", ctypes.c_uint32),
+        ("sizeof_count_array", ctypes.c_uint32),
+        ("use_simple", ctypes.c_int),
+        ("w_prefix", ctypes.c_uint32),
+        ("n_prefix", ctypes.c_uint64),
+        ("w_data", ctypes.c_uint32),
+        ("n_batches", ctypes.c_uint32),
+        ("memory_used", ctypes.c_uint64),
+        ("memory_simple", ctypes.c_uint64),
+        ("memory_complex", ctypes.c_uint64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = ctypes.CDLL(_LIB_PATH)
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    L.orc_base_code.argtypes = [ctypes.c_char]
+    L.orc_base_code.restype = ctypes.c_int
+    L.orc_enumerate_kmers.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+    L.orc_enumerate_kmers.restype = ctypes.c_uint64
+    L.orc_count_brute.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                  ctypes.POINTER(u64p), ctypes.POINTER(u64p), ctypes.POINTER(u32p),
+                                  u64p, u64p]
+    L.orc_count_brute.restype = ctypes.c_int
+    L.orc_count_threaded_collect.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                             ctypes.c_uint32, ctypes.c_int,
+                                             ctypes.POINTER(u64p), ctypes.POINTER(u64p), ctypes.POINTER(u32p),
+                                             u64p, u64p]
+    L.orc_count_threaded_collect.restype = ctypes.c_int
+    L.orc_count_threaded.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                     ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                     u64p, u64p]
+    L.orc_count_threaded.restype = ctypes.c_int
+    L.orc_free.argtypes = [ctypes.c_void_p]
+    L.orc_free.restype = None
+    L.orc_kmer_to_string.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_char_p]
+    L.orc_kmer_to_string.restype = None
+    L.orc_homopoly_compress.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char]
+    L.orc_homopoly_compress.restype = ctypes.c_uint64
+    L.orc_configure_counting.argtypes = [ctypes.POINTER(_Config)]
+    L.orc_configure_counting.restype = ctypes.c_int
+    L.orc_synth_reads.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                  ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    L.orc_synth_reads.restype = ctypes.c_uint64
+    _lib = L
+    return L
+
+
+def _as_bytes(bases):
+    if isinstance(bases, str):
+        return bases.encode("ascii")
+    if isinstance(bases, np.ndarray):
+        return bases.tobytes()
+    return bytes(bases)
+
+
+def _take(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    arr = np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+    lib().orc_free(ctypes.cast(ptr, ctypes.c_void_p))
+    return arr
+
+
+def enumerate_kmers(bases, k, mode=CANONICAL):
+    """All k-mer instances in input order -> (hi, lo) uint64 arrays."""
+    b = _as_bytes(bases)
+    L = lib()
+    n = L.orc_enumerate_kmers(b, len(b), k, mode, None, None, 0)
+    hi = np.zeros(n, dtype=np.uint64)
+    lo = np.zeros(n, dtype=np.uint64)
+    if n:
+        L.orc_enumerate_kmers(b, len(b), k, mode, hi.ctypes.data, lo.ctypes.data, n)
+    return hi, lo
+
+
+def count_brute(bases, k, mode=CANONICAL):
+    """Brute-force count -> (keys_hi, keys_lo, counts, n_instances)."""
+    b = _as_bytes(bases)
+    L = lib()
+    hi = ctypes.POINTER(ctypes.c_uint64)()
+    lo = ctypes.POINTER(ctypes.c_uint64)()
+    cn = ctypes.POINTER(ctypes.c_uint32)()
+    nd = ctypes.c_uint64(0)
+    ni = ctypes.c_uint64(0)
+    rc = L.orc_count_brute(b, len(b), k, mode, ctypes.byref(hi), ctypes.byref(lo), ctypes.byref(cn),
+                           ctypes.byref(nd), ctypes.byref(ni))
+    if rc != 0:
+        raise RuntimeError("orc_count_brute failed rc=%d" % rc)
+    # hi/lo were malloc'd with n_instances entries; only the first nd are meaningful
+    return (_take(hi, nd.value, np.uint64), _take(lo, nd.value, np.uint64),
+            _take(cn, nd.value, np.uint32), ni.value)
+
+
+def count_threaded(bases, k, w_prefix, mode=CANONICAL, threads=0):
+    """Reference-algorithm restatement -> (keys_hi, keys_lo, counts, n_instances)."""
+    b = _as_bytes(bases)
+    L = lib()
+    hi = ctypes.POINTER(ctypes.c_uint64)()
+    lo = ctypes.POINTER(ctypes.c_uint64)()
+    cn = ctypes.POINTER(ctypes.c_uint32)()
+    nd = ctypes.c_uint64(0)
+    ni = ctypes.c_uint64(0)
+    rc = L.orc_count_threaded_collect(b, len(b), k, mode, w_prefix, threads,
+                                      ctypes.byref(hi), ctypes.byref(lo), ctypes.byref(cn),
+                                      ctypes.byref(nd), ctypes.byref(ni))
+    if rc != 0:
+        raise RuntimeError("orc_count_threaded_collect failed rc=%d" % rc)
+    return (_take(hi, nd.value, np.uint64), _take(lo, nd.value, np.uint64),
+            _take(cn, nd.value, np.uint32), ni.value)
+
+
+def time_threaded(bases, k, w_prefix, mode=CANONICAL, threads=0):
+    """Run the port with no collection (pure timing) -> (n_distinct, n_instances)."""
+    b = _as_bytes(bases)
+    nd = ctypes.c_uint64(0)
+    ni = ctypes.c_uint64(0)
+    rc = lib().orc_count_threaded(b, len(b), k, mode, w_prefix, threads, None, None,
+                                  ctypes.byref(nd), ctypes.byref(ni))
+    if rc != 0:
+        raise RuntimeError("orc_count_threaded failed rc=%d" % rc)
+    return nd.value, ni.value
+
+
+def kmer_to_string(hi, lo, k):
+    buf = ctypes.create_string_buffer(k + 1)
+    lib().orc_kmer_to_string(int(hi), int(lo), k, buf)
+    return buf.value.decode("ascii")
+
+
+def homopoly_compress(bases, last_byte=b"\0"):
+    b = _as_bytes(bases)
+    out = ctypes.create_string_buffer(len(b) + 1)
+    n = lib().orc_homopoly_compress(b, len(b), out, last_byte)
+    return out.raw[:n]
+
+
+def configure_counting(k, n_kmers_estimate, memory_bytes, count_suffix_length=0,
+                       page_size=4096, sizeof_count_array=3232):
+    c = _Config()
+    c.k = k
+    c.n_kmers_estimate = n_kmers_estimate
+    c.memory_allowed = memory_bytes
+    c.count_suffix_length = count_suffix_length
+    c.page_size = page_size
+    c.sizeof_count_array = sizeof_count_array
+    rc = lib().orc_configure_counting(ctypes.byref(c))
+    if rc != 0:
+        raise RuntimeError("orc_configure_counting failed rc=%d" % rc)
+    return {f: getattr(c, f) for f, _ in _Config._fields_}
+
+
+def synth_reads(seed, genome_len, first_read, n_reads, read_len=150, sub_rate_ppm=5000, n_rate_ppm=100):
+    out = np.zeros(n_reads * (read_len + 1), dtype=np.uint8)
+    n = lib().orc_synth_reads(seed, genome_len, first_read, n_reads, read_len, sub_rate_ppm, n_rate_ppm,
+                              out.ctypes.data)
+    assert n == out.size
+    return out
