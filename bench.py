@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- measures BASELINE.json's metric (distinct k-mers counted / sec,
+whole job) for the `meryl count` hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R]
+
+A "step" is one full pass of the hot path (per-file histogram -> pack+scatter ->
+per-file LSB radix sort -> run-length count -> block offsets) over one batch of
+synthetic reads that is already resident in HBM when the timed region starts.
+Default workload = BASELINE.json configs[1]: k=21, 10 Gbp of synthetic 150 bp
+reads (30x of a 333,333,334 bp genome, 0.5 % substitutions, 0.01 % N) on one
+MI355X.  With --gpus N (launched by torch.distributed.run, one rank per GPU)
+every rank counts the same amount of its own reads (weak scaling); the 64 files
+are cut into contiguous per-rank ranges and k-mers are routed to their owner by
+one all_to_all over RCCL/xGMI.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the
+radix scatter pass (algorithmic 8 B read + 8 B write per key), timed with HIP
+events on the library's own stream during the timed steps.  `cpu_baseline` is
+the CPU restatement of the reference algorithm (oracle/, kind "port") timed on
+this box's host cores over a bounded sample of the same workload shape.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K = 21
+GENOME_LEN = 333_333_334
+READ_LEN = 150
+DEFAULT_READS = 66_666_667          # 10.0 Gbp
+SEED = 2
+HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(sample_reads, threads):
+    """Reference-algorithm port (oracle/oracle_port.cpp) on the host cores.
+    Sample keeps the workload's shape (150 bp reads at 30x) on a smaller genome."""
+    import oracle
+    oracle.build()
+    genome = max(READ_LEN * 4, sample_reads * READ_LEN // 30)
+    bases = oracle.synth_reads(SEED, genome, 0, sample_reads, READ_LEN, 5000, 100).tobytes()
+    cfg = oracle.configure_counting(K, 10_000_000_000, 64 << 30)      # the workload's geometry (wPrefix 18)
+    t0 = time.perf_counter()
+    nd, ni = oracle.time_threaded(bases, K, cfg["w_prefix"], oracle.CANONICAL, threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": nd / dt, "unit": "distinct k-mers/s", "cores": threads, "kind": "port",
+        "sample": "%d x %d bp reads at 30x of a %d bp synthetic genome (%.2f Gbp), k=%d, wPrefix=%d; "
+                  "%d instances, %d distinct in %.2f s (%.3g instances/s)"
+                  % (sample_reads, READ_LEN, genome, len(bases) / 1e9, K, cfg["w_prefix"], ni, nd, dt, ni / dt),
+        "instances_per_s": ni / dt, "seconds": dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=DEFAULT_READS, help="reads per GPU (default = 10 Gbp)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from meryl_amd import build, capi, count
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+              % (args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (no CPU fallback exists for the count path)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    build.build()
+    capi.lib()
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- synthetic input, generated in HBM ----
+    reads = args.reads
+    bases = count.dev_synth_reads(SEED, GENOME_LEN, rank * reads, reads, READ_LEN, 5000, 100)
+    torch.cuda.synchronize()
+    n_bases = bases.numel()
+
+    prof_acc = {"pass_ms": 0.0, "pass_launches": 0, "pass_keys": 0, "stage_ms": [0.0] * capi.NUM_STAGES}
+    result = {}
+
+    if world == 1:
+        cfg = capi.configure(K, 10_000_000_000 if reads == DEFAULT_READS else n_bases, 64 << 30)
+        sess = count.Session(cfg, local_rank)
+        sess.push_bases_device(bases)
+        sess.set_profiling(True)
+
+        def step(timed):
+            sess.count()
+            if timed:
+                p = sess.profile()
+                prof_acc["pass_ms"] += p.sort_pass_ms_total
+                prof_acc["pass_launches"] += p.sort_pass_launches
+                prof_acc["pass_keys"] += p.sort_pass_keys
+                for i in range(capi.NUM_STAGES):
+                    prof_acc["stage_ms"][i] += p.stage_ms[i]
+            info = sess.info()
+            result["n_distinct"] = info.n_distinct
+            result["n_instances"] = info.n_instances
+            result["w_prefix"] = info.w_prefix
+    else:
+        def step(timed):
+            uniq, cnts, _ = count.count_sharded(bases, K)
+            result["n_distinct_local"] = uniq.numel()
+            result["n_instances_local"] = int(cnts.to(torch.int64).sum().item()) if not timed else 0
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    # max over ranks, totals over ranks
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        d = torch.tensor([result["n_distinct_local"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(d)
+        result["n_distinct"] = int(d.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        n_distinct = result["n_distinct"]
+        line = {
+            "metric": "distinct k-mers counted/sec (whole node)",
+            "value": n_distinct / (dt / args.steps),
+            "unit": "distinct k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": "meryl count k=21 on synthetic short reads: %d x %d bp reads per GPU (%.2f Gbp per GPU, "
+                            "30x of a %d bp genome, 0.5%% substitutions, 0.01%% N), inputs resident in HBM"
+                            % (reads, READ_LEN, reads * READ_LEN / 1e9, GENOME_LEN),
+                "k": K, "reads_per_gpu": reads, "bases_per_gpu": n_bases,
+                "n_distinct": n_distinct,
+                "parallelism": "1 GPU" if world == 1 else "%d GPUs: 64 files in contiguous per-rank ranges, all_to_all" % world,
+            },
+        }
+        if world == 1:
+            n_inst = result["n_instances"]
+            line["config"]["n_instances"] = n_inst
+            line["config"]["w_prefix"] = result["w_prefix"]
+            line["instances_per_s"] = n_inst / (dt / args.steps)
+            if prof_acc["pass_launches"]:
+                bytes_alg = 16.0 * prof_acc["pass_keys"]                 # 8 B read + 8 B write per key per pass
+                secs = prof_acc["pass_ms"] / 1e3
+                achieved = bytes_alg / secs / 1e9
+                line["roofline"] = {
+                    "kernel": "radix_scatter_kernel (one LSB radix pass)",
+                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "launches": prof_acc["pass_launches"],
+                    "avg_launch_ms": prof_acc["pass_ms"] / prof_acc["pass_launches"],
+                    "algorithmic_bytes_per_launch": bytes_alg / prof_acc["pass_launches"],
+                }
+            line["stage_ms_per_step"] = {capi.STAGE_NAMES[i]: prof_acc["stage_ms"][i] / args.steps
+                                         for i in range(capi.NUM_STAGES)}
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_sample_reads, os.cpu_count() or 1)
+        print(json.dumps(line))
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,235 @@
+/*
+ * meryl_gpu_count.h -- C ABI of the MI355X-native `meryl count` engine.
+ *
+ * This is the drop-in boundary for the reference's counting engine
+ * (marbl/meryl, paths relative to the reference root):
+ *
+ *   upstream   bool merylInput::loadBases(char *seq, uint64 maxLength,
+ *                                         uint64 &seqLength, bool &endOfSequence)
+ *              src/meryl/merylInput.H:67-70, called from
+ *              src/meryl/merylOp-countThreads.C:180-182
+ *   engine     merylOperation::configureCounting()  src/meryl/merylOp-count.C:300-403
+ *              merylOperation::countThreads()       src/meryl/merylOp-countThreads.C:385-474
+ *   downstream merylFileWriter::initialize(wPrefix) / numberOfFiles() /
+ *              firstPrefixInFile() / lastPrefixInFile()
+ *              merylBlockWriter::addBlock(prefix, nKmers, suffixes, counts)
+ *              call sites src/meryl/merylOp-countThreads.C:404,453-464,
+ *              src/meryl/merylCountArray.C:472-475
+ *
+ * A maintainer replaces the body of countThreads() with: mgc_open, a loop of
+ * mgc_push_bases over merylInput::loadBases, then mgc_finish whose callback
+ * calls merylBlockWriter::addBlock -- see INTEGRATION.md.
+ *
+ * Plain C types only: pointers and sizes, no C++/torch types.  Functions
+ * return MGC_OK (0) or a negative MGC_E* code instead of the reference's
+ * fprintf(stderr)+exit(1); mgc_last_error() gives the text.
+ *
+ * Pointers named d_* are DEVICE pointers (HBM of the current HIP device);
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ */
+#ifndef MERYL_GPU_COUNT_H
+#define MERYL_GPU_COUNT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGC_OK            0
+#define MGC_EINVAL       -1    /* bad argument (k, mode, NULL pointer, capacity) */
+#define MGC_ENOMEM       -2    /* host or device allocation failed */
+#define MGC_EHIP         -3    /* a HIP runtime call or kernel failed */
+#define MGC_ESTATE       -4    /* call out of order (e.g. finish before count) */
+#define MGC_EUNSUPPORTED -5    /* valid in the reference, not implemented here yet */
+#define MGC_ETIMEOUT     -6    /* an in-kernel bounded spin expired (never hangs) */
+
+/* opCount / opCountForward / opCountReverse, src/meryl/merylOp.H:40-42 and
+ * src/meryl/merylOp-countThreads.C:241-258 */
+#define MGC_MODE_CANONICAL 0
+#define MGC_MODE_FORWARD   1
+#define MGC_MODE_REVERSE   2
+
+#define MGC_NUM_FILES_BITS 6   /* 64 files: src/meryl/merylOp-count.C:185-187, documentation/source/usage.rst:18 */
+#define MGC_NUM_FILES      64
+
+/* ------------------------------------------------------------------------
+ * Configuration -- replaces merylOperation::configureCounting
+ * (src/meryl/merylOp-count.C:300-403).  Pure host arithmetic.
+ * ---------------------------------------------------------------------- */
+typedef struct mgc_count_config {
+  /* in */
+  uint32_t k;                     /* kmerTiny::merSize(), 1..64 (this build computes k <= 32) */
+  int32_t  mode;                  /* MGC_MODE_* */
+  uint64_t n_kmers_estimate;      /* n= / guesstimateNumberOfkmersInInput (:317,449) */
+  uint64_t memory_allowed;        /* memory= in bytes (merylCommandBuilder.C:299-302) */
+  uint32_t threads;               /* threads= (host threads used by mgc_finish) */
+  uint32_t count_suffix_length;   /* count-suffix= length; forces simple mode (:379-382) */
+  uint32_t homopoly_compress;     /* `compress` (merylInput.C:261-262) */
+  uint32_t page_size;             /* 0 -> 4096 (getPageSize()) */
+  uint32_t sizeof_count_array;    /* 0 -> 3232 (sizeof(merylCountArray), merylCountArray.H:44,71-74) */
+  /* out */
+  int32_t  use_simple;            /* :368-382 */
+  uint32_t w_prefix;              /* wPrefix_ */
+  uint64_t n_prefix;              /* nPrefix_ */
+  uint32_t w_data;                /* wData_ = 2k - wPrefix */
+  uint32_t n_batches;             /* incl. the reference's post-increment quirk (:355-358) */
+  uint64_t memory_used;           /* what the "Configured ... mode for %.3f GB" line prints (:398-401) */
+} mgc_count_config;
+
+int mgc_configure_counting(mgc_count_config *cfg);
+
+/* Formats the Canu-parsed line of src/meryl/merylOp-count.C:398-401 into buf. */
+int mgc_format_configured_line(const mgc_count_config *cfg, char *buf, size_t buflen);
+
+/* ------------------------------------------------------------------------
+ * Device-level operators (stateless; caller owns all memory).  These are the
+ * hot path: the HIP kernels that replace insertKmers (merylOp-countThreads.C:
+ * 235-280), merylCountArray::add/get (merylCountArray.C:490-847) and
+ * countSingleKmers (merylCountArray.C:323-365).  Keys are full k-mers
+ * (prefix<<wData | suffix) as uint64, k <= 32.
+ * ---------------------------------------------------------------------- */
+
+/* Number of partition buckets is 2^bucket_bits, bucket = key >> (2k-bucket_bits);
+ * bucket_bits = 6 gives the reference's 64 files, 0 a single bucket. */
+#define MGC_MAX_BUCKET_BITS 10
+
+/* Scratch needed by mgc_dev_kmer_histogram / mgc_dev_kmer_partition. */
+size_t mgc_dev_partition_workspace_bytes(uint32_t bucket_bits);
+
+/* Pass 1: count k-mer instances per bucket.  Writes d_bucket_counts[2^bucket_bits]
+ * (uint64, overwritten) and fills the workspace with the per-workgroup counts
+ * pass 2 needs.  Bases are ASCII; any byte that is not ACGTacgt (e.g. the '.'
+ * breakers of merylOp-countThreads.C:196,214-215, or N) breaks the k-mer. */
+int mgc_dev_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
+                           uint32_t bucket_bits, uint64_t *d_bucket_counts,
+                           void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Pass 2: pack every k-mer instance (2 bits/base, A0 C1 T2 G3, first base most
+ * significant), pick fmer/rmer per `mode`, and scatter it into its bucket's
+ * region: bucket b occupies d_keys[d_bucket_starts[b] ...).  d_bucket_starts
+ * holds 2^bucket_bits uint64 offsets (in keys) chosen by the caller from the
+ * pass-1 counts (any layout with enough room per bucket).  Must be called
+ * with the same bases/k/mode/bucket_bits and the workspace left by pass 1.
+ * Order inside a bucket is unspecified (the sort follows). */
+int mgc_dev_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
+                           uint32_t bucket_bits, const uint64_t *d_bucket_starts,
+                           uint64_t *d_keys, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* LSB radix sort of uint64 keys on bits [begin_bit, end_bit).  Ping-pongs
+ * between d_keys and d_alt (both n keys); *result_in_alt tells where the
+ * sorted keys ended up. */
+size_t mgc_dev_sort_workspace_bytes(uint64_t n);
+int mgc_dev_radix_sort_u64(uint64_t *d_keys, uint64_t *d_alt, uint64_t n,
+                           uint32_t begin_bit, uint32_t end_bit,
+                           void *d_workspace, size_t workspace_bytes,
+                           int *result_in_alt, void *stream);
+
+/* Run-length count of a sorted key array (countSingleKmers' two passes,
+ * merylCountArray.C:334-358).  Step 1 returns the number of distinct keys
+ * (synchronises the stream); step 2 writes d_unique[n_distinct] and
+ * d_counts[n_distinct] (uint32, wraps mod 2^32 like merylCountArray.C:357). */
+size_t mgc_dev_rle_workspace_bytes(uint64_t n);
+int mgc_dev_rle_count(const uint64_t *d_sorted, uint64_t n, void *d_workspace, size_t workspace_bytes,
+                      uint64_t *n_distinct, void *stream);
+int mgc_dev_rle_emit(const uint64_t *d_sorted, uint64_t n, void *d_workspace, size_t workspace_bytes,
+                     uint64_t *d_unique, uint32_t *d_counts, void *stream);
+
+/* d_block_start[p] = index of the first distinct key with (key >> w_data) >= p,
+ * for p in [0, n_prefix]; block p of the database is
+ * [d_block_start[p], d_block_start[p+1]) -- the (prefix, nKmers) of addBlock. */
+int mgc_dev_block_offsets(const uint64_t *d_unique, uint64_t n_distinct, uint32_t w_data,
+                          uint64_t n_prefix, uint64_t *d_block_start, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Session -- replaces merylOperation::countThreads
+ * (src/meryl/merylOp-countThreads.C:385-474).
+ * ---------------------------------------------------------------------- */
+typedef struct mgc_session mgc_session;
+
+/* cfg must have been through mgc_configure_counting (w_prefix decides the
+ * block structure, countThreads.C:404).  device < 0 keeps the current device. */
+mgc_session *mgc_open(const mgc_count_config *cfg, int device);
+void         mgc_close(mgc_session *s);
+const char  *mgc_last_error(const mgc_session *s);   /* s may be NULL: last open/config error */
+
+/* Same contract as merylInput::loadBases's output (merylInput.H:67-70): a run
+ * of bases of the current sequence; end_of_sequence != 0 appends the '.'
+ * breaker the reference's loader appends (merylOp-countThreads.C:214-215).
+ * Bases are copied; the caller may reuse the buffer on return. */
+int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int end_of_sequence);
+
+/* Bases already resident in HBM (breakers included).  The buffer is borrowed
+ * until mgc_count returns.  May be called once per session. */
+int mgc_push_bases_device(mgc_session *s, const uint8_t *d_bases, uint64_t n_bases);
+
+/* Runs histogram -> partition -> per-file radix sort -> run-length count ->
+ * block offsets over everything pushed.  Results stay in HBM. */
+int mgc_count(mgc_session *s);
+
+typedef struct mgc_result_info {
+  uint64_t n_bases;
+  uint64_t n_instances;           /* k-mer instances (sum of counts) */
+  uint64_t n_distinct;
+  uint32_t w_prefix, w_data;
+  uint64_t n_prefix;
+  uint64_t file_instances[MGC_NUM_FILES];   /* instances per file = the 6-bit histogram */
+} mgc_result_info;
+int mgc_get_result_info(const mgc_session *s, mgc_result_info *info);
+
+/* Device views of the result (valid until mgc_close / the next mgc_count). */
+int mgc_get_result_device(const mgc_session *s, const uint64_t **d_unique, const uint32_t **d_counts,
+                          const uint64_t **d_block_start);
+
+/* Copies the result to host arrays sized from mgc_get_result_info
+ * (keys/counts: n_distinct; block_start: n_prefix+1).  Any pointer may be NULL. */
+int mgc_copy_result(const mgc_session *s, uint64_t *keys, uint32_t *counts, uint64_t *block_start);
+
+/* Delivery in the reference's addBlock convention (merylCountArray.C:472-475;
+ * merylOp-countThreads.C:452-459): for every file ff, for every prefix of the
+ * file in ascending order -- empty blocks included -- cb(ctx, prefix, nKmers,
+ * suffix_lo, suffix_hi, counts).  Suffixes are the low w_data bits of the
+ * k-mer split in two uint64 halves (suffix_hi is NULL while k <= 32); the
+ * callee must not keep the pointers (caller-owned, as in the reference).
+ * Files are delivered from up to `host_threads` threads concurrently, one
+ * file per thread, exactly like the reference's `omp parallel for` over files. */
+typedef int (*mgc_block_cb)(void *ctx, uint64_t prefix, uint64_t n_kmers,
+                            const uint64_t *suffix_lo, const uint64_t *suffix_hi,
+                            const uint32_t *counts);
+int mgc_finish(mgc_session *s, mgc_block_cb cb, void *ctx, int host_threads);
+
+/* Per-stage device timings of the last mgc_count (HIP events on the session's
+ * stream).  Enable before mgc_count. */
+#define MGC_STAGE_HISTOGRAM 0
+#define MGC_STAGE_PARTITION 1
+#define MGC_STAGE_SORT      2
+#define MGC_STAGE_RLE       3
+#define MGC_STAGE_BLOCKS    4
+#define MGC_NUM_STAGES      5
+typedef struct mgc_profile {
+  double   stage_ms[MGC_NUM_STAGES];
+  uint32_t stage_launches[MGC_NUM_STAGES];
+  double   sort_pass_ms_total;     /* sum over the radix scatter-pass kernels only */
+  uint32_t sort_pass_launches;
+  uint64_t sort_pass_keys;         /* keys moved by those launches (sum of n per launch) */
+  double   total_ms;
+} mgc_profile;
+int mgc_set_profiling(mgc_session *s, int enable);
+int mgc_get_profile(const mgc_session *s, mgc_profile *p);
+
+/* ------------------------------------------------------------------------
+ * Bench/test utility: deterministic synthetic reads generated in HBM
+ * (byte-identical to oracle/oracle_count.c orc_synth_reads).
+ * ---------------------------------------------------------------------- */
+int mgc_dev_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
+                        uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,
+                        uint8_t *d_out, void *stream);
+
+/* Library/ABI version: major<<16 | minor. */
+uint32_t mgc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERYL_GPU_COUNT_H */

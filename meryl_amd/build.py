@@ -1,0 +1,52 @@
+"""Build recipe for the native library (gfx950 only, in-tree).
+
+    python -m meryl_amd.build            # builds meryl_amd/libmeryl_gpu_count.so
+
+hipcc cross-compiles for gfx950 without a GPU.  The built .so stays in-tree
+(git-ignored) so that it travels with the source snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmeryl_gpu_count.so")
+SOURCES = ["mgc_kernels.hip", "mgc_api.cpp", "meryl_db.cpp"]
+HEADERS = ["mgc_device.h", "meryl_db.h", os.path.join("..", "..", "include", "meryl_gpu_count.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the native library cannot be built")
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS if os.path.exists(os.path.join(CSRC, f))]
+    deps.append(os.path.abspath(__file__))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP/C++ source into libmeryl_gpu_count.so.  Returns its path."""
+    if not force and not _stale():
+        return LIB
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    cmd = [hipcc()] + FLAGS + ["-o", LIB + ".tmp"] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,185 @@
+"""ctypes binding of include/meryl_gpu_count.h.
+
+Loads meryl_amd/libmeryl_gpu_count.so and fails loudly when it is missing or
+an expected symbol is absent -- there is no Python/CPU fallback for any compute
+entry point.  Device pointers are plain integers (e.g. torch_tensor.data_ptr()).
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+MGC_OK, MGC_EINVAL, MGC_ENOMEM, MGC_EHIP, MGC_ESTATE, MGC_EUNSUPPORTED, MGC_ETIMEOUT = 0, -1, -2, -3, -4, -5, -6
+MODE_CANONICAL, MODE_FORWARD, MODE_REVERSE = 0, 1, 2
+NUM_FILES = 64
+NUM_STAGES = 5
+STAGE_NAMES = ("histogram", "partition", "sort", "rle", "blocks")
+
+# every extern "C" symbol include/meryl_gpu_count.h declares
+SYMBOLS = (
+    "mgc_configure_counting", "mgc_format_configured_line",
+    "mgc_dev_partition_workspace_bytes", "mgc_dev_kmer_histogram", "mgc_dev_kmer_partition",
+    "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort_u64",
+    "mgc_dev_rle_workspace_bytes", "mgc_dev_rle_count", "mgc_dev_rle_emit", "mgc_dev_block_offsets",
+    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_count",
+    "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish",
+    "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_version",
+)
+
+
+class CountConfig(ctypes.Structure):
+    _fields_ = [
+        ("k", ctypes.c_uint32),
+        ("mode", ctypes.c_int32),
+        ("n_kmers_estimate", ctypes.c_uint64),
+        ("memory_allowed", ctypes.c_uint64),
+        ("threads", ctypes.c_uint32),
+        ("count_suffix_length", ctypes.c_uint32),
+        ("homopoly_compress", ctypes.c_uint32),
+        ("page_size", ctypes.c_uint32),
+        ("sizeof_count_array", ctypes.c_uint32),
+        ("use_simple", ctypes.c_int32),
+        ("w_prefix", ctypes.c_uint32),
+        ("n_prefix", ctypes.c_uint64),
+        ("w_data", ctypes.c_uint32),
+        ("n_batches", ctypes.c_uint32),
+        ("memory_used", ctypes.c_uint64),
+    ]
+
+
+class ResultInfo(ctypes.Structure):
+    _fields_ = [
+        ("n_bases", ctypes.c_uint64),
+        ("n_instances", ctypes.c_uint64),
+        ("n_distinct", ctypes.c_uint64),
+        ("w_prefix", ctypes.c_uint32),
+        ("w_data", ctypes.c_uint32),
+        ("n_prefix", ctypes.c_uint64),
+        ("file_instances", ctypes.c_uint64 * NUM_FILES),
+    ]
+
+
+class Profile(ctypes.Structure):
+    _fields_ = [
+        ("stage_ms", ctypes.c_double * NUM_STAGES),
+        ("stage_launches", ctypes.c_uint32 * NUM_STAGES),
+        ("sort_pass_ms_total", ctypes.c_double),
+        ("sort_pass_launches", ctypes.c_uint32),
+        ("sort_pass_keys", ctypes.c_uint64),
+        ("total_ms", ctypes.c_double),
+    ]
+
+
+class DbInfo(ctypes.Structure):
+    _fields_ = [
+        ("k", ctypes.c_uint32),
+        ("prefix_size", ctypes.c_uint32),
+        ("suffix_size", ctypes.c_uint32),
+        ("num_files_bits", ctypes.c_uint32),
+        ("num_blocks_bits", ctypes.c_uint32),
+        ("flags", ctypes.c_uint32),
+        ("num_unique", ctypes.c_uint64),
+        ("num_distinct", ctypes.c_uint64),
+        ("num_total", ctypes.c_uint64),
+        ("hist_len", ctypes.c_uint64),
+    ]
+
+
+BLOCK_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                            ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                            ctypes.POINTER(ctypes.c_uint32))
+
+
+class MgcError(RuntimeError):
+    def __init__(self, rc, what, detail=""):
+        self.rc = rc
+        super().__init__("%s failed rc=%d %s" % (what, rc, detail))
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it is not built -- by design."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "native library %s is missing: run `python -m meryl_amd.build` "
+            "(there is no CPU fallback for the count path)" % path)
+    L = ctypes.CDLL(path)
+    missing = [s for s in SYMBOLS if not hasattr(L, s)]
+    if missing:
+        raise RuntimeError("native library %s lacks symbols: %s" % (path, ", ".join(missing)))
+    vp, u64, u32, i32, sz = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_size_t
+    P = ctypes.POINTER
+
+    def sig(name, restype, *argtypes):
+        f = getattr(L, name)
+        f.restype = restype
+        f.argtypes = list(argtypes)
+
+    sig("mgc_version", u32)
+    sig("mgc_configure_counting", i32, P(CountConfig))
+    sig("mgc_format_configured_line", i32, P(CountConfig), ctypes.c_char_p, sz)
+    sig("mgc_dev_partition_workspace_bytes", sz, u32)
+    sig("mgc_dev_kmer_histogram", i32, vp, u64, u32, i32, u32, vp, vp, sz, vp)
+    sig("mgc_dev_kmer_partition", i32, vp, u64, u32, i32, u32, vp, vp, vp, sz, vp)
+    sig("mgc_dev_sort_workspace_bytes", sz, u64)
+    sig("mgc_dev_radix_sort_u64", i32, vp, vp, u64, u32, u32, vp, sz, P(i32), vp)
+    sig("mgc_dev_rle_workspace_bytes", sz, u64)
+    sig("mgc_dev_rle_count", i32, vp, u64, vp, sz, P(u64), vp)
+    sig("mgc_dev_rle_emit", i32, vp, u64, vp, sz, vp, vp, vp)
+    sig("mgc_dev_block_offsets", i32, vp, u64, u32, u64, vp, vp)
+    sig("mgc_dev_synth_reads", i32, u64, u64, u64, u64, u32, u32, u32, vp, vp)
+    sig("mgc_open", vp, P(CountConfig), i32)
+    sig("mgc_close", None, vp)
+    sig("mgc_last_error", ctypes.c_char_p, vp)
+    sig("mgc_push_bases", i32, vp, ctypes.c_char_p, sz, i32)
+    sig("mgc_push_bases_device", i32, vp, vp, u64)
+    sig("mgc_count", i32, vp)
+    sig("mgc_get_result_info", i32, vp, P(ResultInfo))
+    sig("mgc_get_result_device", i32, vp, P(vp), P(vp), P(vp))
+    sig("mgc_copy_result", i32, vp, vp, vp, vp)
+    sig("mgc_finish", i32, vp, BLOCK_CB, vp, i32)
+    sig("mgc_set_profiling", i32, vp, i32)
+    sig("mgc_get_profile", i32, vp, P(Profile))
+    _lib = L
+    return L
+
+
+def last_error(handle=None):
+    s = lib().mgc_last_error(handle)
+    return s.decode("utf-8", "replace") if s else ""
+
+
+def check(rc, what, handle=None):
+    if rc != MGC_OK:
+        raise MgcError(rc, what, last_error(handle))
+
+
+def configure(k, n_kmers_estimate, memory_bytes, mode=MODE_CANONICAL, threads=0, count_suffix_length=0,
+              homopoly_compress=0):
+    """mgc_configure_counting -> filled CountConfig."""
+    c = CountConfig()
+    c.k = k
+    c.mode = mode
+    c.n_kmers_estimate = int(n_kmers_estimate)
+    c.memory_allowed = int(memory_bytes)
+    c.threads = threads
+    c.count_suffix_length = count_suffix_length
+    c.homopoly_compress = homopoly_compress
+    check(lib().mgc_configure_counting(ctypes.byref(c)), "mgc_configure_counting")
+    return c
+
+
+def configured_line(cfg):
+    buf = ctypes.create_string_buffer(256)
+    check(lib().mgc_format_configured_line(ctypes.byref(cfg), buf, 256), "mgc_format_configured_line")
+    return buf.value.decode("ascii")

@@ -1,0 +1,279 @@
+"""Python plumbing over the C-ABI: torch owns device memory and streams, the
+native library (include/meryl_gpu_count.h) does all the work.
+
+Single GPU : `Session` (mgc_open / mgc_push_bases[_device] / mgc_count / ...)
+             or the stateless `dev_*` operators on torch tensors.
+Multi GPU  : `count_sharded` -- one process per GPU; every rank packs its own
+             reads, the 64 files are split into contiguous per-rank ranges and
+             k-mers are routed to their owning rank with all_to_all_single
+             (RCCL on GPUs, gloo in the CPU tests), then each rank sorts and
+             run-length counts the files it owns.
+"""
+import ctypes
+
+import numpy as np
+
+from . import capi
+
+try:  # torch is plumbing only (device buffers, streams, torch.distributed)
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else ctypes.c_void_p(0)
+
+
+def _u64(n, device):
+    # torch has no general uint64 arithmetic; int64 storage is bit-identical
+    return torch.empty(int(n), dtype=torch.int64, device=device)
+
+
+# ---------------------------------------------------------------------------
+# stateless device operators
+# ---------------------------------------------------------------------------
+def dev_synth_reads(seed, genome_len, first_read, n_reads, read_len=150, sub_rate_ppm=5000, n_rate_ppm=100,
+                    device="cuda"):
+    out = torch.empty(int(n_reads) * (read_len + 1), dtype=torch.uint8, device=device)
+    capi.check(capi.lib().mgc_dev_synth_reads(seed, genome_len, first_read, n_reads, read_len, sub_rate_ppm,
+                                              n_rate_ppm, _ptr(out), _stream_ptr()), "mgc_dev_synth_reads")
+    return out
+
+
+def dev_kmer_partition(bases, k, mode=capi.MODE_CANONICAL, bucket_bits=6):
+    """bases: uint8 cuda tensor -> (keys int64[N] grouped by bucket, counts int64[2^bucket_bits] on host)."""
+    L = capi.lib()
+    dev = bases.device
+    nb = 1 << bucket_bits
+    ws_bytes = L.mgc_dev_partition_workspace_bytes(bucket_bits)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    counts = _u64(nb, dev)
+    capi.check(L.mgc_dev_kmer_histogram(_ptr(bases), bases.numel(), k, mode, bucket_bits, _ptr(counts), _ptr(ws),
+                                        ws_bytes, _stream_ptr()), "mgc_dev_kmer_histogram")
+    h_counts = counts.cpu().numpy().astype(np.uint64)
+    starts = np.zeros(nb, dtype=np.uint64)
+    starts[1:] = np.cumsum(h_counts)[:-1]
+    n = int(h_counts.sum())
+    d_starts = torch.from_numpy(starts.astype(np.int64)).to(dev)
+    keys = _u64(n, dev)
+    capi.check(L.mgc_dev_kmer_partition(_ptr(bases), bases.numel(), k, mode, bucket_bits, _ptr(d_starts), _ptr(keys),
+                                        _ptr(ws), ws_bytes, _stream_ptr()), "mgc_dev_kmer_partition")
+    return keys, h_counts
+
+
+def dev_radix_sort(keys, begin_bit, end_bit):
+    """Sorts an int64 cuda tensor (as uint64) on bits [begin_bit, end_bit); returns the sorted tensor."""
+    L = capi.lib()
+    n = keys.numel()
+    if n == 0:
+        return keys
+    alt = torch.empty_like(keys)
+    ws_bytes = L.mgc_dev_sort_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=keys.device)
+    in_alt = ctypes.c_int(0)
+    capi.check(L.mgc_dev_radix_sort_u64(_ptr(keys), _ptr(alt), n, begin_bit, end_bit, _ptr(ws), ws_bytes,
+                                        ctypes.byref(in_alt), _stream_ptr()), "mgc_dev_radix_sort_u64")
+    return alt if in_alt.value else keys
+
+
+def dev_run_length(sorted_keys):
+    """(unique int64[D], counts int32[D]) of a sorted int64 (uint64) cuda tensor."""
+    L = capi.lib()
+    n = sorted_keys.numel()
+    dev = sorted_keys.device
+    ws_bytes = L.mgc_dev_rle_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    nd = ctypes.c_uint64(0)
+    capi.check(L.mgc_dev_rle_count(_ptr(sorted_keys), n, _ptr(ws), ws_bytes, ctypes.byref(nd), _stream_ptr()),
+               "mgc_dev_rle_count")
+    uniq = _u64(nd.value, dev)
+    cnts = torch.empty(nd.value, dtype=torch.int32, device=dev)
+    capi.check(L.mgc_dev_rle_emit(_ptr(sorted_keys), n, _ptr(ws), ws_bytes, _ptr(uniq), _ptr(cnts), _stream_ptr()),
+               "mgc_dev_rle_emit")
+    return uniq, cnts
+
+
+def dev_block_offsets(unique, w_data, n_prefix):
+    out = _u64(n_prefix + 1, unique.device)
+    capi.check(capi.lib().mgc_dev_block_offsets(_ptr(unique), unique.numel(), w_data, n_prefix, _ptr(out),
+                                                _stream_ptr()), "mgc_dev_block_offsets")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# session (mirrors merylOperation::countThreads, merylOp-countThreads.C:385-474)
+# ---------------------------------------------------------------------------
+class Session:
+    def __init__(self, cfg, device=-1):
+        self.cfg = cfg
+        self._h = capi.lib().mgc_open(ctypes.byref(cfg), device)
+        if not self._h:
+            raise capi.MgcError(-1, "mgc_open", capi.last_error(None))
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            capi.lib().mgc_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def push_bases(self, bases, end_of_sequence=True):
+        b = bases.encode("ascii") if isinstance(bases, str) else bytes(bases)
+        capi.check(capi.lib().mgc_push_bases(self._h, b, len(b), 1 if end_of_sequence else 0), "mgc_push_bases",
+                   self._h)
+
+    def push_bases_device(self, t):
+        self._keep.append(t)
+        capi.check(capi.lib().mgc_push_bases_device(self._h, _ptr(t), t.numel()), "mgc_push_bases_device", self._h)
+
+    def set_profiling(self, on=True):
+        capi.check(capi.lib().mgc_set_profiling(self._h, 1 if on else 0), "mgc_set_profiling", self._h)
+
+    def count(self):
+        capi.check(capi.lib().mgc_count(self._h), "mgc_count", self._h)
+
+    def info(self):
+        r = capi.ResultInfo()
+        capi.check(capi.lib().mgc_get_result_info(self._h, ctypes.byref(r)), "mgc_get_result_info", self._h)
+        return r
+
+    def profile(self):
+        p = capi.Profile()
+        capi.check(capi.lib().mgc_get_profile(self._h, ctypes.byref(p)), "mgc_get_profile", self._h)
+        return p
+
+    def result(self):
+        """(keys uint64[D], counts uint32[D], block_start uint64[n_prefix+1]) as numpy arrays."""
+        r = self.info()
+        keys = np.zeros(r.n_distinct, dtype=np.uint64)
+        counts = np.zeros(r.n_distinct, dtype=np.uint32)
+        bstart = np.zeros(r.n_prefix + 1, dtype=np.uint64)
+        capi.check(capi.lib().mgc_copy_result(self._h, keys.ctypes.data, counts.ctypes.data, bstart.ctypes.data),
+                   "mgc_copy_result", self._h)
+        return keys, counts, bstart
+
+    def finish(self, callback, host_threads=1):
+        """callback(prefix, n_kmers, suffixes uint64[n], counts uint32[n]) per block, addBlock order."""
+        err = []
+
+        def _cb(ctx, prefix, n, slo, shi, cnt):
+            try:
+                s = np.ctypeslib.as_array(slo, shape=(n,)).copy() if n else np.zeros(0, np.uint64)
+                c = np.ctypeslib.as_array(cnt, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+                callback(int(prefix), int(n), s, c)
+                return 0
+            except Exception as e:  # pragma: no cover
+                err.append(e)
+                return -1
+
+        cb = capi.BLOCK_CB(_cb)
+        rc = capi.lib().mgc_finish(self._h, cb, None, host_threads)
+        if err:
+            raise err[0]
+        capi.check(rc, "mgc_finish", self._h)
+
+
+def count_bases(bases, k, mode=capi.MODE_CANONICAL, n_estimate=None, memory_gb=4.0, device=-1, profiling=False):
+    """Host convenience: bases is str/bytes (with '.' breakers) or a uint8 cuda tensor."""
+    n = bases.numel() if (torch is not None and isinstance(bases, torch.Tensor)) else len(bases)
+    cfg = capi.configure(k, n_estimate if n_estimate else max(n, 1), int(memory_gb * (1 << 30)), mode)
+    with Session(cfg, device) as s:
+        if torch is not None and isinstance(bases, torch.Tensor):
+            s.push_bases_device(bases)
+        else:
+            s.push_bases(bases, end_of_sequence=False)
+        s.set_profiling(profiling)
+        s.count()
+        keys, counts, bstart = s.result()
+        info = s.info()
+        prof = s.profile() if profiling else None
+    return keys, counts, bstart, info, prof
+
+
+# ---------------------------------------------------------------------------
+# multi-GPU: contiguous file ranges per rank + all_to_all
+# ---------------------------------------------------------------------------
+def balanced_file_ranges(file_counts, world):
+    """Contiguous ranges of the 64 files, one per rank, cut so that every rank
+    owns about the same number of k-mer instances (canonical prefixes are
+    skewed towards A/C, so equal file counts would not balance).  Every rank
+    gets at least one file.  Returns world+1 cut points in [0, 64]."""
+    fc = np.asarray(file_counts, dtype=np.float64)
+    nf = len(fc)
+    if world > nf:
+        raise ValueError("more ranks (%d) than files (%d)" % (world, nf))
+    cum = np.concatenate([[0.0], np.cumsum(fc)])
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        lo, hi = cuts[-1] + 1, nf - (world - r)          # leave one file for every later rank
+        target = total * r / world
+        cand = np.arange(lo, hi + 1)
+        cuts.append(int(cand[np.argmin(np.abs(cum[cand] - target))]))
+    cuts.append(nf)
+    return cuts
+
+
+def exchange_plan(local_file_counts, cuts):
+    """Per-destination send counts (in keys) for this rank's partitioned keys."""
+    c = np.asarray(local_file_counts, dtype=np.int64)
+    return [int(c[cuts[r]:cuts[r + 1]].sum()) for r in range(len(cuts) - 1)]
+
+
+def owned_sort_bits(k, first_file, end_file):
+    """Bits an owner must sort: everything below the 6 file bits plus the file
+    bits in which its (contiguous) files differ."""
+    if end_file - first_file <= 1:
+        return 2 * k - 6
+    return 2 * k - 6 + int(first_file ^ (end_file - 1)).bit_length()
+
+
+class HipOps:
+    """The device operators count_sharded drives (all HIP, via the C-ABI)."""
+    partition = staticmethod(dev_kmer_partition)
+    radix_sort = staticmethod(dev_radix_sort)
+    run_length = staticmethod(dev_run_length)
+
+    @staticmethod
+    def empty_keys(n, like):
+        return _u64(n, like.device)
+
+
+def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
+    """Collective.  Every rank passes ITS OWN reads (uint8 tensor on its GPU);
+    returns this rank's share of the database: (unique keys int64, counts int32,
+    (first_file, end_file)).  The concatenation over ranks, in rank order, is
+    the ascending (key, count) stream a single-GPU count of all reads gives.
+    `ops` exists so the routing logic can be exercised without a GPU (the gloo
+    tests inject CPU stand-ins); the product default is the HIP operators."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+
+    keys, local_counts = ops.partition(bases, k, mode, 6)                        # grouped by file, ascending
+    # one small all-gather gives every rank the same 64-bin histogram -> same cut points
+    fc = torch.from_numpy(np.asarray(local_counts).astype(np.int64)).to(keys.device)
+    all_counts = [torch.empty_like(fc) for _ in range(world)]
+    dist.all_gather(all_counts, fc, group=group)
+    per_rank = torch.stack(all_counts).cpu().numpy()                             # [world][64]
+    cuts = balanced_file_ranges(per_rank.sum(axis=0), world)
+
+    send = exchange_plan(local_counts, cuts)                                     # keys to each destination
+    recv = [int(per_rank[src, cuts[rank]:cuts[rank + 1]].sum()) for src in range(world)]
+    inbox = ops.empty_keys(sum(recv), keys)
+    dist.all_to_all_single(inbox, keys, output_split_sizes=recv, input_split_sizes=send, group=group)
+    del keys
+
+    sorted_keys = ops.radix_sort(inbox, 0, owned_sort_bits(k, cuts[rank], cuts[rank + 1]))
+    uniq, cnts = ops.run_length(sorted_keys)
+    return uniq, cnts, (cuts[rank], cuts[rank + 1])

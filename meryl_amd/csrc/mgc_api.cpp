@@ -1,0 +1,613 @@
+// mgc_api.cpp -- C-ABI layer (include/meryl_gpu_count.h) over the gfx950 kernels.
+//
+// Host-side mirror of the reference's counting engine:
+//   mgc_configure_counting  <-> merylOperation::configureCounting  src/meryl/merylOp-count.C:300-403
+//   mgc_open/push/count/finish <-> merylOperation::countThreads     src/meryl/merylOp-countThreads.C:385-474
+// There is NO CPU fallback in here: every compute entry point launches HIP
+// kernels and fails with MGC_EHIP if the device or the code object is missing.
+#include "../../include/meryl_gpu_count.h"
+#include "mgc_device.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+void set_err(std::string *dst, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (dst) *dst = buf;
+  g_last_error = buf;
+}
+
+#define HIP_TRY(s, expr)                                                                         \
+  do {                                                                                           \
+    hipError_t e__ = (expr);                                                                     \
+    if (e__ != hipSuccess) {                                                                     \
+      set_err((s) ? &(s)->err : nullptr, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,           \
+              hipGetErrorString(e__));                                                           \
+      return (e__ == hipErrorOutOfMemory) ? MGC_ENOMEM : MGC_EHIP;                               \
+    }                                                                                            \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// configureCounting restated (src/meryl/merylOp-count.C:118-403).  This is the
+// product's own copy; oracle/oracle_count.c holds an independent restatement
+// used by the tests to cross-check it.
+// ---------------------------------------------------------------------------
+
+uint64_t number_of_bits64(uint64_t v) {      // countNumberOfBits64 [meryl-utility]
+  uint64_t b = 0;
+  while (v) { b++; v >>= 1; }
+  return b;
+}
+
+// findExpectedSimpleSize, merylOp-count.C:118-165; lowBits_t is uint16 (merylOp-countSimple.C:41-48)
+uint64_t expected_simple_size(uint32_t k, uint64_t n_est, uint32_t suffix_len) {
+  if (2 * k - 2 * suffix_len > 42) return UINT64_MAX;                            // :142
+  const uint64_t low_bits  = 16;
+  const uint64_t n_entries = (uint64_t)1 << (2 * k - 2 * suffix_len);            // :124
+  const uint64_t exp_max   = (uint64_t)(0.004 * (double)n_est);                  // :126
+  const uint64_t exp_bits  = number_of_bits64(exp_max) + 1;                      // :127
+  const uint64_t extra     = (exp_bits < low_bits) ? 0 : (exp_bits - low_bits);  // :128
+  return (n_entries * low_bits + n_entries * extra) / 8;                         // :130-132
+}
+
+// findBestPrefixSize, merylOp-count.C:173-227
+void best_prefix_size(const mgc_count_config &c, uint64_t n_est, uint64_t mem_allowed, uint32_t *best,
+                      uint64_t *mem_used) {
+  const uint32_t k = c.k;
+  const uint32_t seg_bits = c.page_size * 8, seg_bytes = c.page_size;            // pagesPerSegment()==1
+  *best = 0;
+  *mem_used = UINT64_MAX;
+  for (uint32_t wp = 1; wp < 2 * k - 1; wp++) {                                  // :197
+    const uint64_t n_prefix = (uint64_t)1 << wp;
+    const uint64_t kpp = n_est / n_prefix + 1;                                   // :199
+    const uint64_t kps = seg_bits / (2 * k - wp);                                // :200
+    const uint64_t spp = kpp / kps + 1;                                          // :201
+    if (wp + number_of_bits64(spp) + number_of_bits64(seg_bytes) >= 64) break;   // :203
+    const uint64_t struct_mem = (uint64_t)c.sizeof_count_array * n_prefix + 8 * n_prefix * spp;   // :206-207
+    const uint64_t data_min   = n_prefix * seg_bytes;                            // :208
+    const uint64_t total      = struct_mem + n_prefix * spp * seg_bytes;         // :209-210
+    if (struct_mem + data_min > mem_allowed) break;                              // :216
+    if ((wp > 9) && (total + (uint64_t)16 * wp * 1024 * 1024 < *mem_used)) {     // :219
+      *mem_used = total;
+      *best = wp;
+    }
+    if (total > (uint64_t)16 * *mem_used) break;                                 // :224 (uint64 wrap kept)
+  }
+}
+
+}  // namespace
+
+extern "C" uint32_t mgc_version(void) { return (0u << 16) | 1u; }
+
+extern "C" int mgc_configure_counting(mgc_count_config *c) {
+  if (!c) return MGC_EINVAL;
+  if (c->k == 0 || c->k > 64) {                                                  // :311-312 (fatal there)
+    set_err(nullptr, "ERROR: Kmer size not supplied with modifier k=<kmer-size>.");
+    return MGC_EINVAL;
+  }
+  if (c->mode < 0 || c->mode > 2) return MGC_EINVAL;
+  if (c->page_size == 0) c->page_size = 4096;
+  if (c->sizeof_count_array == 0) c->sizeof_count_array = 3232;
+
+  c->use_simple = 0; c->w_prefix = 0; c->n_prefix = 0; c->w_data = 0; c->n_batches = 1; c->memory_used = 0;
+
+  const uint64_t mem_simple = expected_simple_size(c->k, c->n_kmers_estimate, c->count_suffix_length);   // :340
+  uint64_t mem_complex = UINT64_MAX;
+  uint32_t best = 0, n_batches = 1;
+
+  if (c->k > 5) {                                                                // :353
+    for (n_batches = 1; mem_complex > c->memory_allowed; n_batches++) {          // :354-355
+      best_prefix_size(*c, c->n_kmers_estimate / n_batches, c->memory_allowed, &best, &mem_complex);
+      if (n_batches > (1u << 20)) {
+        set_err(nullptr, "configureCounting: no prefix size fits in %lu bytes", (unsigned long)c->memory_allowed);
+        return MGC_EINVAL;
+      }
+    }
+    c->w_prefix = best;                                                          // findBestValues :273-276
+    c->n_prefix = (uint64_t)1 << best;
+    c->w_data   = 2 * c->k - best;
+  }
+  if ((mem_simple < mem_complex) && (mem_simple < c->memory_allowed)) {          // :368-372
+    c->use_simple = 1; c->memory_used = mem_simple;
+  } else {
+    c->use_simple = 0; c->memory_used = mem_complex;
+  }
+  if (c->count_suffix_length > 0) { c->use_simple = 1; c->memory_used = mem_simple; }   // :379-382
+  c->n_batches = n_batches;
+  return MGC_OK;
+}
+
+extern "C" int mgc_format_configured_line(const mgc_count_config *c, char *buf, size_t buflen) {
+  if (!c || !buf) return MGC_EINVAL;
+  const uint64_t m = (c->memory_used < c->memory_allowed) ? c->memory_used : c->memory_allowed;
+  snprintf(buf, buflen, "Configured %s mode for %.3f GB memory per batch, and up to %u batch%s.",   // :398-401
+           c->use_simple ? "simple" : "complex", m / 1024.0 / 1024.0 / 1024.0, c->n_batches,
+           (c->n_batches == 1) ? "" : "es");
+  return MGC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Stateless device operators
+// ---------------------------------------------------------------------------
+namespace {
+int hip_rc(hipError_t e, const char *what) {
+  if (e == hipSuccess) return MGC_OK;
+  set_err(nullptr, "%s: %s", what, hipGetErrorString(e));
+  return (e == hipErrorOutOfMemory) ? MGC_ENOMEM : MGC_EHIP;
+}
+bool key_args_ok(uint32_t k, int mode, uint32_t bucket_bits) {
+  if (k == 0 || k > 32) { set_err(nullptr, "k=%u: this build packs k <= 32 (uint64 keys)", k); return false; }
+  if (mode < 0 || mode > 2) { set_err(nullptr, "bad mode %d", mode); return false; }
+  if (bucket_bits > MGC_MAX_BUCKET_BITS || bucket_bits > 2 * k) { set_err(nullptr, "bad bucket_bits %u", bucket_bits); return false; }
+  return true;
+}
+}  // namespace
+
+extern "C" size_t mgc_dev_partition_workspace_bytes(uint32_t bucket_bits) {
+  return mgc::kp_workspace_bytes(bucket_bits);
+}
+
+extern "C" int mgc_dev_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
+                                      uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, size_t ws_bytes,
+                                      void *stream) {
+  if (!key_args_ok(k, mode, bucket_bits)) return (k > 32 && k <= 64) ? MGC_EUNSUPPORTED : MGC_EINVAL;
+  if ((!d_bases && n_bases) || !d_bucket_counts || !d_ws || ws_bytes < mgc::kp_workspace_bytes(bucket_bits)) return MGC_EINVAL;
+  return hip_rc(mgc::launch_kmer_histogram(d_bases, n_bases, k, mode, bucket_bits, d_bucket_counts, d_ws,
+                                           (hipStream_t)stream), "kmer_histogram");
+}
+
+extern "C" int mgc_dev_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
+                                      uint32_t bucket_bits, const uint64_t *d_bucket_starts, uint64_t *d_keys,
+                                      void *d_ws, size_t ws_bytes, void *stream) {
+  if (!key_args_ok(k, mode, bucket_bits)) return (k > 32 && k <= 64) ? MGC_EUNSUPPORTED : MGC_EINVAL;
+  if ((!d_bases && n_bases) || !d_bucket_starts || !d_ws || ws_bytes < mgc::kp_workspace_bytes(bucket_bits)) return MGC_EINVAL;
+  return hip_rc(mgc::launch_kmer_partition(d_bases, n_bases, k, mode, bucket_bits, d_bucket_starts, d_keys, d_ws,
+                                           (hipStream_t)stream), "kmer_partition");
+}
+
+extern "C" size_t mgc_dev_sort_workspace_bytes(uint64_t n) { return mgc::sort_workspace_bytes(n) + 256; }
+
+extern "C" int mgc_dev_radix_sort_u64(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, uint32_t begin_bit,
+                                      uint32_t end_bit, void *d_ws, size_t ws_bytes, int *result_in_alt,
+                                      void *stream) {
+  if (!result_in_alt || begin_bit > end_bit || end_bit > 64) return MGC_EINVAL;
+  *result_in_alt = 0;
+  if (n == 0 || begin_bit == end_bit) return MGC_OK;
+  if (!d_keys || !d_alt || !d_ws || ws_bytes < mgc::sort_workspace_bytes(n) + 256) return MGC_EINVAL;
+  mgc::SortPlan plan;
+  mgc::make_sort_plan(begin_bit, end_bit, &plan);
+  // the last 256 bytes of the workspace hold the look-back error word
+  uint32_t *d_err = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_ws) + mgc::sort_workspace_bytes(n));
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(d_err, 0, 4, st);
+  if (e != hipSuccess) return hip_rc(e, "radix_sort memset");
+  e = mgc::launch_radix_sort(d_keys, d_alt, n, plan, d_ws, ws_bytes - 256, d_err, result_in_alt, st, nullptr);
+  if (e != hipSuccess) return hip_rc(e, "radix_sort");
+  uint32_t h_err = 0;
+  e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return hip_rc(e, "radix_sort sync");
+  if (h_err) { set_err(nullptr, "radix sort look-back timed out"); return MGC_ETIMEOUT; }
+  return MGC_OK;
+}
+
+extern "C" size_t mgc_dev_rle_workspace_bytes(uint64_t n) { return mgc::rle_workspace_bytes(n); }
+
+extern "C" int mgc_dev_rle_count(const uint64_t *d_sorted, uint64_t n, void *d_ws, size_t ws_bytes,
+                                 uint64_t *n_distinct, void *stream) {
+  if (!n_distinct || !d_ws || ws_bytes < mgc::rle_workspace_bytes(n) || (!d_sorted && n)) return MGC_EINVAL;
+  hipError_t e = mgc::launch_rle_count(d_sorted, n, d_ws, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_rc(e, "rle_count");
+  return hip_rc(mgc::rle_read_total(d_ws, n_distinct, (hipStream_t)stream), "rle_count sync");
+}
+
+extern "C" int mgc_dev_rle_emit(const uint64_t *d_sorted, uint64_t n, void *d_ws, size_t ws_bytes,
+                                uint64_t *d_unique, uint32_t *d_counts, void *stream) {
+  if (!d_ws || ws_bytes < mgc::rle_workspace_bytes(n) || (n && (!d_sorted || !d_unique || !d_counts))) return MGC_EINVAL;
+  return hip_rc(mgc::launch_rle_emit(d_sorted, n, d_ws, d_unique, d_counts, (hipStream_t)stream), "rle_emit");
+}
+
+extern "C" int mgc_dev_block_offsets(const uint64_t *d_unique, uint64_t n_distinct, uint32_t w_data,
+                                     uint64_t n_prefix, uint64_t *d_block_start, void *stream) {
+  if (!d_block_start || w_data >= 64 || (n_distinct && !d_unique)) return MGC_EINVAL;
+  return hip_rc(mgc::launch_block_offsets(d_unique, n_distinct, w_data, n_prefix, d_block_start, (hipStream_t)stream),
+                "block_offsets");
+}
+
+extern "C" int mgc_dev_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
+                                   uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm, uint8_t *d_out,
+                                   void *stream) {
+  if (!d_out || read_len == 0 || genome_len < read_len) return MGC_EINVAL;
+  return hip_rc(mgc::launch_synth_reads(seed, genome_len, first_read, n_reads, read_len, sub_rate_ppm, n_rate_ppm,
+                                        d_out, (hipStream_t)stream), "synth_reads");
+}
+
+// ---------------------------------------------------------------------------
+// Session
+// ---------------------------------------------------------------------------
+struct mgc_session {
+  mgc_count_config cfg;
+  int              device = -1;
+  hipStream_t      stream = nullptr;
+  std::string      err;
+
+  // input
+  std::vector<char> host_bases;          // mgc_push_bases accumulates here (pinned staging is a later round)
+  uint8_t          *d_bases_own = nullptr;
+  const uint8_t    *d_bases = nullptr;
+  uint64_t          n_bases = 0;
+  bool              borrowed = false;
+
+  // result
+  bool      counted = false;
+  uint64_t  n_instances = 0, n_distinct = 0;
+  uint64_t  file_instances[MGC_NUM_FILES];
+  uint64_t *d_unique = nullptr;
+  uint32_t *d_counts = nullptr;
+  uint64_t *d_block_start = nullptr;
+
+  // device arena: buffers survive between mgc_count calls (grow-only), so a
+  // repeated count does not pay hipMalloc/hipFree of tens of GB every time
+  struct Buf { void *p = nullptr; size_t cap = 0; };
+  enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_NUM };
+  Buf buf[B_NUM];
+  hipError_t ensure(int which, size_t bytes) {
+    Buf &b = buf[which];
+    if (bytes < 256) bytes = 256;
+    if (b.cap >= bytes) return hipSuccess;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e == hipSuccess) b.cap = bytes;
+    return e;
+  }
+  void free_arena() { for (auto &b : buf) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; } }
+
+  // profiling
+  bool        profiling = false;
+  mgc_profile prof;
+
+  void free_result() {            // result views point into the arena
+    d_unique = nullptr; d_counts = nullptr; d_block_start = nullptr;
+    counted = false;
+  }
+};
+
+extern "C" const char *mgc_last_error(const mgc_session *s) {
+  return s ? s->err.c_str() : g_last_error.c_str();
+}
+
+extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
+  if (!cfg) { set_err(nullptr, "mgc_open: NULL config"); return nullptr; }
+  if (cfg->k == 0 || cfg->k > 64 || cfg->w_prefix < MGC_NUM_FILES_BITS || cfg->w_prefix >= 2 * cfg->k ||
+      cfg->w_data != 2 * cfg->k - cfg->w_prefix) {
+    set_err(nullptr, "mgc_open: config has not been through mgc_configure_counting (k=%u wPrefix=%u wData=%u)",
+            cfg->k, cfg->w_prefix, cfg->w_data);
+    return nullptr;
+  }
+  if (cfg->k > 32) { set_err(nullptr, "mgc_open: k=%u > 32 needs 128-bit keys (not in this build)", cfg->k); return nullptr; }
+  if (cfg->use_simple || cfg->count_suffix_length) {
+    // The reference would pick countSimple (merylOp-count.C:368-382), which yields a
+    // different block geometry (merylOp-countSimple.C:172-175).  Not built yet.
+    set_err(nullptr, "mgc_open: simple (direct-index) mode is not implemented");
+    return nullptr;
+  }
+  if (cfg->homopoly_compress) { set_err(nullptr, "mgc_open: `compress` is not implemented yet"); return nullptr; }
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    set_err(nullptr, "mgc_open: no HIP device (%s)", hipGetErrorString(e));
+    return nullptr;
+  }
+  mgc_session *s = new mgc_session();
+  s->cfg = *cfg;
+  if (device >= 0) {
+    e = hipSetDevice(device);
+    if (e != hipSuccess) { set_err(nullptr, "hipSetDevice(%d): %s", device, hipGetErrorString(e)); delete s; return nullptr; }
+    s->device = device;
+  } else {
+    (void)hipGetDevice(&s->device);
+  }
+  e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { set_err(nullptr, "hipStreamCreate: %s", hipGetErrorString(e)); delete s; return nullptr; }
+  memset(&s->prof, 0, sizeof(s->prof));
+  memset(s->file_instances, 0, sizeof(s->file_instances));
+  return s;
+}
+
+extern "C" void mgc_close(mgc_session *s) {
+  if (!s) return;
+  s->free_result();
+  s->free_arena();
+  if (s->d_bases_own) (void)hipFree(s->d_bases_own);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+extern "C" int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int end_of_sequence) {
+  if (!s || (!bases && len)) return MGC_EINVAL;
+  if (s->borrowed || s->counted) { set_err(&s->err, "mgc_push_bases after device input / count"); return MGC_ESTATE; }
+  s->host_bases.insert(s->host_bases.end(), bases, bases + len);
+  if (end_of_sequence) s->host_bases.push_back('.');        // merylOp-countThreads.C:214-215
+  return MGC_OK;
+}
+
+extern "C" int mgc_push_bases_device(mgc_session *s, const uint8_t *d_bases, uint64_t n_bases) {
+  if (!s || (!d_bases && n_bases)) return MGC_EINVAL;
+  if (s->borrowed || !s->host_bases.empty() || s->counted) { set_err(&s->err, "device input must be the only input"); return MGC_ESTATE; }
+  s->d_bases = d_bases;
+  s->n_bases = n_bases;
+  s->borrowed = true;
+  return MGC_OK;
+}
+
+extern "C" int mgc_set_profiling(mgc_session *s, int enable) {
+  if (!s) return MGC_EINVAL;
+  s->profiling = enable != 0;
+  return MGC_OK;
+}
+
+extern "C" int mgc_get_profile(const mgc_session *s, mgc_profile *p) {
+  if (!s || !p) return MGC_EINVAL;
+  *p = s->prof;
+  return MGC_OK;
+}
+
+namespace {
+struct DevBuf {                                   // frees on scope exit
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 256); }
+  template <typename T> T *as() { return reinterpret_cast<T *>(p); }
+  void *release() { void *q = p; p = nullptr; return q; }
+};
+
+struct StageTimer {
+  bool on;
+  hipStream_t st;
+  hipEvent_t ev[MGC_NUM_STAGES][2];
+  bool used[MGC_NUM_STAGES];
+  StageTimer(bool enable, hipStream_t s) : on(enable), st(s) {
+    for (int i = 0; i < MGC_NUM_STAGES; i++) {
+      used[i] = false;
+      if (on) { (void)hipEventCreate(&ev[i][0]); (void)hipEventCreate(&ev[i][1]); }
+    }
+  }
+  ~StageTimer() {
+    if (on) for (int i = 0; i < MGC_NUM_STAGES; i++) { (void)hipEventDestroy(ev[i][0]); (void)hipEventDestroy(ev[i][1]); }
+  }
+  void begin(int i) { if (on) { (void)hipEventRecord(ev[i][0], st); used[i] = true; } }
+  void end(int i)   { if (on) (void)hipEventRecord(ev[i][1], st); }
+};
+}  // namespace
+
+extern "C" int mgc_count(mgc_session *s) {
+  if (!s) return MGC_EINVAL;
+  s->free_result();
+  HIP_TRY(s, hipSetDevice(s->device));
+  hipStream_t st = s->stream;
+  const mgc_count_config &c = s->cfg;
+  const uint32_t k = c.k;
+  const uint32_t bucket_bits = MGC_NUM_FILES_BITS;
+  const uint32_t nb = MGC_NUM_FILES;
+  memset(&s->prof, 0, sizeof(s->prof));
+
+  // ---- input into HBM ----
+  if (!s->borrowed) {
+    s->n_bases = s->host_bases.size();
+    if (s->d_bases_own) { (void)hipFree(s->d_bases_own); s->d_bases_own = nullptr; }
+    if (s->n_bases) {
+      HIP_TRY(s, hipMalloc((void **)&s->d_bases_own, s->n_bases));
+      HIP_TRY(s, hipMemcpyAsync(s->d_bases_own, s->host_bases.data(), s->n_bases, hipMemcpyHostToDevice, st));
+    }
+    s->d_bases = s->d_bases_own;
+  }
+
+  hipEvent_t ev_all[2];
+  if (s->profiling) { (void)hipEventCreate(&ev_all[0]); (void)hipEventCreate(&ev_all[1]); (void)hipEventRecord(ev_all[0], st); }
+  StageTimer tm(s->profiling, st);
+
+  // ---- pass 1: per-file histogram ----
+  HIP_TRY(s, s->ensure(mgc_session::B_PART_WS, mgc::kp_workspace_bytes(bucket_bits)));
+  HIP_TRY(s, s->ensure(mgc_session::B_META, sizeof(uint64_t) * nb * 2));
+  void *part_ws = s->buf[mgc_session::B_PART_WS].p;
+  uint64_t *d_counts64 = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_META].p), *d_starts = d_counts64 + nb;
+  tm.begin(MGC_STAGE_HISTOGRAM);
+  HIP_TRY(s, mgc::launch_kmer_histogram(s->d_bases, s->n_bases, k, c.mode, bucket_bits, d_counts64, part_ws, st));
+  tm.end(MGC_STAGE_HISTOGRAM);
+  s->prof.stage_launches[MGC_STAGE_HISTOGRAM] = 1;
+  uint64_t h_counts[MGC_NUM_FILES], h_starts[MGC_NUM_FILES + 1];
+  HIP_TRY(s, hipMemcpyAsync(h_counts, d_counts64, sizeof(h_counts), hipMemcpyDeviceToHost, st));
+  HIP_TRY(s, hipStreamSynchronize(st));
+  uint64_t N = 0, max_bucket = 0;
+  for (uint32_t b = 0; b < nb; b++) {
+    h_starts[b] = N;
+    N += h_counts[b];
+    max_bucket = std::max(max_bucket, h_counts[b]);
+    s->file_instances[b] = h_counts[b];
+  }
+  h_starts[nb] = N;
+  s->n_instances = N;
+
+  // ---- pass 2: pack + scatter into per-file regions ----
+  mgc::SortPlan plan;
+  mgc::make_sort_plan(0, 2 * k - bucket_bits, &plan);
+  const bool odd = (plan.num_passes & 1u) != 0;
+  HIP_TRY(s, s->ensure(mgc_session::B_X, sizeof(uint64_t) * N));
+  HIP_TRY(s, s->ensure(mgc_session::B_Y, sizeof(uint64_t) * (odd ? N : max_bucket)));
+  uint64_t *X = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_X].p);
+  uint64_t *Y = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_Y].p);
+  HIP_TRY(s, hipMemcpyAsync(d_starts, h_starts, sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
+  tm.begin(MGC_STAGE_PARTITION);
+  HIP_TRY(s, mgc::launch_kmer_partition(s->d_bases, s->n_bases, k, c.mode, bucket_bits, d_starts, X, part_ws, st));
+  tm.end(MGC_STAGE_PARTITION);
+  s->prof.stage_launches[MGC_STAGE_PARTITION] = 2;
+
+  // ---- per-file LSB radix sort of the low 2k-6 bits ----
+  const size_t sort_ws_bytes = mgc::sort_workspace_bytes(max_bucket) + 256;
+  HIP_TRY(s, s->ensure(mgc_session::B_SORT_WS, sort_ws_bytes));
+  void *sort_ws = s->buf[mgc_session::B_SORT_WS].p;
+  uint32_t *d_err = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(sort_ws) + sort_ws_bytes - 256);
+  HIP_TRY(s, hipMemsetAsync(d_err, 0, 4, st));
+
+  std::vector<hipEvent_t> pass_ev;
+  if (s->profiling) {
+    pass_ev.resize((size_t)nb * plan.num_passes * 2);
+    for (auto &e : pass_ev) (void)hipEventCreate(&e);
+  }
+  tm.begin(MGC_STAGE_SORT);
+  uint32_t sort_launch_groups = 0;
+  for (uint32_t b = 0; b < nb; b++) {
+    if (h_counts[b] == 0) continue;
+    uint64_t *src = X + h_starts[b];
+    uint64_t *alt = odd ? (Y + h_starts[b]) : Y;
+    int in_alt = 0;
+    hipEvent_t *pe = s->profiling ? &pass_ev[(size_t)b * plan.num_passes * 2] : nullptr;
+    HIP_TRY(s, mgc::launch_radix_sort(src, alt, h_counts[b], plan, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe));
+    sort_launch_groups++;
+    (void)in_alt;     // odd pass count: every file ends in Y at the same offsets; even: back in X
+  }
+  tm.end(MGC_STAGE_SORT);
+  uint64_t *d_sorted = odd ? Y : X;
+
+  // ---- run-length count ----
+  HIP_TRY(s, s->ensure(mgc_session::B_RLE_WS, mgc::rle_workspace_bytes(N)));
+  void *rle_ws = s->buf[mgc_session::B_RLE_WS].p;
+  tm.begin(MGC_STAGE_RLE);
+  HIP_TRY(s, mgc::launch_rle_count(d_sorted, N, rle_ws, st));
+  uint64_t nd = 0;
+  HIP_TRY(s, mgc::rle_read_total(rle_ws, &nd, st));
+  s->n_distinct = nd;
+  HIP_TRY(s, s->ensure(mgc_session::B_UNIQUE, sizeof(uint64_t) * nd));
+  HIP_TRY(s, s->ensure(mgc_session::B_COUNTS, sizeof(uint32_t) * nd));
+  s->d_unique = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_UNIQUE].p);
+  s->d_counts = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_COUNTS].p);
+  HIP_TRY(s, mgc::launch_rle_emit(d_sorted, N, rle_ws, s->d_unique, s->d_counts, st));
+  tm.end(MGC_STAGE_RLE);
+  s->prof.stage_launches[MGC_STAGE_RLE] = 3;
+
+  // ---- block offsets ----
+  HIP_TRY(s, s->ensure(mgc_session::B_BLOCKS, sizeof(uint64_t) * (c.n_prefix + 1)));
+  s->d_block_start = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_BLOCKS].p);
+  tm.begin(MGC_STAGE_BLOCKS);
+  HIP_TRY(s, mgc::launch_block_offsets(s->d_unique, nd, c.w_data, c.n_prefix, s->d_block_start, st));
+  tm.end(MGC_STAGE_BLOCKS);
+  s->prof.stage_launches[MGC_STAGE_BLOCKS] = 1;
+
+  uint32_t h_err = 0;
+  HIP_TRY(s, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
+  if (s->profiling) (void)hipEventRecord(ev_all[1], st);
+  HIP_TRY(s, hipStreamSynchronize(st));
+  if (h_err) { set_err(&s->err, "radix sort look-back timed out"); return MGC_ETIMEOUT; }
+
+  if (s->profiling) {
+    float ms = 0;
+    for (int i = 0; i < MGC_NUM_STAGES; i++)
+      if (tm.used[i] && hipEventElapsedTime(&ms, tm.ev[i][0], tm.ev[i][1]) == hipSuccess) s->prof.stage_ms[i] = ms;
+    if (hipEventElapsedTime(&ms, ev_all[0], ev_all[1]) == hipSuccess) s->prof.total_ms = ms;
+    s->prof.stage_launches[MGC_STAGE_SORT] = sort_launch_groups * (plan.num_passes + 2);
+    for (uint32_t b = 0; b < nb; b++) {
+      if (h_counts[b] == 0) continue;
+      for (uint32_t p = 0; p < plan.num_passes; p++) {
+        hipEvent_t *pe = &pass_ev[((size_t)b * plan.num_passes + p) * 2];
+        if (hipEventElapsedTime(&ms, pe[0], pe[1]) == hipSuccess) {
+          s->prof.sort_pass_ms_total += ms;
+          s->prof.sort_pass_launches++;
+          s->prof.sort_pass_keys += h_counts[b];
+        }
+      }
+    }
+    for (auto &e : pass_ev) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(ev_all[0]); (void)hipEventDestroy(ev_all[1]);
+  }
+  s->counted = true;
+  return MGC_OK;
+}
+
+extern "C" int mgc_get_result_info(const mgc_session *s, mgc_result_info *info) {
+  if (!s || !info) return MGC_EINVAL;
+  if (!s->counted) return MGC_ESTATE;
+  info->n_bases = s->n_bases;
+  info->n_instances = s->n_instances;
+  info->n_distinct = s->n_distinct;
+  info->w_prefix = s->cfg.w_prefix;
+  info->w_data = s->cfg.w_data;
+  info->n_prefix = s->cfg.n_prefix;
+  memcpy(info->file_instances, s->file_instances, sizeof(info->file_instances));
+  return MGC_OK;
+}
+
+extern "C" int mgc_get_result_device(const mgc_session *s, const uint64_t **d_unique, const uint32_t **d_counts,
+                                     const uint64_t **d_block_start) {
+  if (!s) return MGC_EINVAL;
+  if (!s->counted) return MGC_ESTATE;
+  if (d_unique) *d_unique = s->d_unique;
+  if (d_counts) *d_counts = s->d_counts;
+  if (d_block_start) *d_block_start = s->d_block_start;
+  return MGC_OK;
+}
+
+extern "C" int mgc_copy_result(const mgc_session *cs, uint64_t *keys, uint32_t *counts, uint64_t *block_start) {
+  mgc_session *s = const_cast<mgc_session *>(cs);
+  if (!s) return MGC_EINVAL;
+  if (!s->counted) return MGC_ESTATE;
+  HIP_TRY(s, hipSetDevice(s->device));
+  if (keys && s->n_distinct)   HIP_TRY(s, hipMemcpy(keys, s->d_unique, sizeof(uint64_t) * s->n_distinct, hipMemcpyDeviceToHost));
+  if (counts && s->n_distinct) HIP_TRY(s, hipMemcpy(counts, s->d_counts, sizeof(uint32_t) * s->n_distinct, hipMemcpyDeviceToHost));
+  if (block_start)             HIP_TRY(s, hipMemcpy(block_start, s->d_block_start, sizeof(uint64_t) * (s->cfg.n_prefix + 1), hipMemcpyDeviceToHost));
+  return MGC_OK;
+}
+
+extern "C" int mgc_finish(mgc_session *s, mgc_block_cb cb, void *ctx, int host_threads) {
+  if (!s || !cb) return MGC_EINVAL;
+  if (!s->counted) { set_err(&s->err, "mgc_finish before mgc_count"); return MGC_ESTATE; }
+  const uint64_t nd = s->n_distinct, np = s->cfg.n_prefix;
+  std::vector<uint64_t> keys(nd), bstart(np + 1);
+  std::vector<uint32_t> counts(nd);
+  int rc = mgc_copy_result(s, keys.data(), counts.data(), bstart.data());
+  if (rc != MGC_OK) return rc;
+
+  const uint32_t w_data = s->cfg.w_data;
+  const uint64_t mask = (w_data == 64) ? ~0ull : ((1ull << w_data) - 1ull);
+  const uint64_t per_file = np / MGC_NUM_FILES;             // firstPrefixInFile/lastPrefixInFile
+  if (host_threads <= 0) host_threads = (int)(s->cfg.threads ? s->cfg.threads : std::thread::hardware_concurrency());
+  host_threads = std::max(1, std::min(host_threads, MGC_NUM_FILES));
+
+  std::atomic<uint32_t> next_file(0);
+  std::atomic<int> status(MGC_OK);
+  auto worker = [&]() {
+    std::vector<uint64_t> suffix;
+    for (;;) {
+      const uint32_t ff = next_file.fetch_add(1);            // dynamic,1 like the reference's omp schedule
+      if (ff >= MGC_NUM_FILES || status.load() != MGC_OK) return;
+      for (uint64_t pp = ff * per_file; pp < (ff + 1) * per_file; pp++) {
+        const uint64_t b = bstart[pp], e = bstart[pp + 1];
+        suffix.resize(e - b);
+        for (uint64_t i = b; i < e; i++) suffix[i - b] = keys[i] & mask;
+        const int r = cb(ctx, pp, e - b, suffix.data(), nullptr, counts.data() + b);   // empty blocks included
+        if (r != 0) { status.store(r); return; }
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < host_threads; t++) pool.emplace_back(worker);
+  worker();
+  for (auto &t : pool) t.join();
+  return status.load();
+}

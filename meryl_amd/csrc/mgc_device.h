@@ -1,0 +1,69 @@
+// mgc_device.h -- internal launch interface between the C-ABI layer
+// (mgc_api.cpp) and the gfx950 kernels (mgc_kernels.hip).  Not installed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mgc {
+
+// ---- k-mer extraction / partition (mgc_kernels.hip) -----------------------
+constexpr int      KP_BLOCK       = 256;                 // threads per workgroup
+constexpr int      KP_ITEMS       = 16;                  // window starts per thread
+constexpr int      KP_TILE        = KP_BLOCK * KP_ITEMS; // 4096 starts per tile
+constexpr int      KP_MAX_BUCKETS = 1024;
+
+// Persistent grid size used by both passes (they must agree).
+uint32_t kp_grid_size(uint64_t n_bases);
+size_t   kp_workspace_bytes(uint32_t bucket_bits);
+
+hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
+                                 uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st);
+hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
+                                 uint32_t bucket_bits, const uint64_t *d_bucket_starts, uint64_t *d_keys,
+                                 void *d_ws, hipStream_t st);
+
+// ---- radix sort ------------------------------------------------------------
+struct SortPlan {
+  uint32_t radix_bits;      // digit width of the kernel template in use (8 or 9)
+  uint32_t block;           // threads per workgroup
+  uint32_t kpt;             // keys per thread
+  uint32_t tile;            // block*kpt
+  uint32_t mode;            // 0 = onesweep (decoupled look-back), 1 = classic (tile histogram + scan)
+  uint32_t num_passes;
+  uint32_t pass_shift[16];
+  uint32_t pass_bits[16];
+};
+
+// Chooses digit widths for bits [begin_bit, end_bit); honours MGC_RADIX_BITS /
+// MGC_SORT_MODE / MGC_SORT_KPT environment overrides (bench experiments).
+void   make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan);
+size_t sort_workspace_bytes(uint64_t n);
+
+struct SortTiming {           // optional per-pass event timing
+  hipEvent_t *ev;             // 2*num_passes events, or nullptr
+};
+
+// Sorts n keys; returns where the result is via *result_in_alt.  d_error is a
+// device uint32 the kernels set on a look-back timeout (checked by the caller).
+hipError_t launch_radix_sort(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, const SortPlan &plan,
+                             void *d_ws, size_t ws_bytes, uint32_t *d_error, int *result_in_alt,
+                             hipStream_t st, hipEvent_t *pass_events /* 2 per pass or null */);
+
+// ---- run-length count ------------------------------------------------------
+size_t     rle_workspace_bytes(uint64_t n);
+hipError_t launch_rle_count(const uint64_t *d_sorted, uint64_t n, void *d_ws, hipStream_t st);
+// after launch_rle_count + stream sync: number of distinct keys sits at ws[0]
+hipError_t rle_read_total(const void *d_ws, uint64_t *n_distinct, hipStream_t st);
+hipError_t launch_rle_emit(const uint64_t *d_sorted, uint64_t n, void *d_ws, uint64_t *d_unique,
+                           uint32_t *d_counts, hipStream_t st);
+
+hipError_t launch_block_offsets(const uint64_t *d_unique, uint64_t n_distinct, uint32_t w_data,
+                                uint64_t n_prefix, uint64_t *d_block_start, hipStream_t st);
+
+hipError_t launch_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
+                              uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,
+                              uint8_t *d_out, hipStream_t st);
+
+}  // namespace mgc

@@ -1,0 +1,1069 @@
+// mgc_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the meryl `count` hot path.
+//
+// What each kernel replaces in the reference (paths relative to the reference root):
+//   kmer_hist_kernel / kmer_partition_kernel
+//       kmerIterator + insertKmers            src/meryl/merylOp-countThreads.C:235-280
+//       (2-bit pack A0 C1 T2 G3, reverse complement, canonical pick, prefix split;
+//        the per-bucket spin-lock + bit-packed append of merylCountArray.C:490-728
+//        becomes a histogram + lock-free scatter into per-file regions)
+//   radix_* kernels
+//       unpack + std::sort of each bucket      src/meryl/merylCountArray.C:276-289,330
+//   rle_* kernels
+//       the two run-length passes              src/meryl/merylCountArray.C:334-358
+//   block_offsets_kernel
+//       the per-prefix (prefix, nKmers) split that feeds addBlock
+//                                              src/meryl/merylCountArray.C:472-475
+//
+// All of it is integer / byte work bounded by HBM bandwidth: loads are 16 B (bases) or
+// 8 B per lane coalesced, every reorder is staged through LDS so stores leave as
+// contiguous runs, ranking uses 64-lane ballots, cross-workgroup prefixes use 8-byte
+// {flag,epoch,value} granules with agent-scope relaxed atomics (no fences needed:
+// the datum is the flag).  Wave = 64 everywhere.
+#include "mgc_device.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace mgc {
+
+typedef unsigned long long u64;
+typedef unsigned int       u32;
+
+#define MGC_CHECK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return e__; } while (0)
+
+// ============================================================================
+//  Block-level helpers (wave = 64)
+// ============================================================================
+
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
+
+// Exclusive prefix sum over one value per thread.  s_tmp: >= BLOCK/64 + 1 entries.
+// Every thread of the block must call it.  Leaves the block total in *total.
+template <int BLOCK, typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T *s_tmp, T *total) {
+  constexpr int NW = BLOCK / 64;
+  const u32 lane = lane_id(), w = wave_id();
+  T x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T y = __shfl_up(x, d);
+    if ((int)lane >= d) x += y;
+  }
+  __syncthreads();                       // s_tmp may still be read from a previous call
+  if (lane == 63) s_tmp[w] = x;
+  __syncthreads();
+  T wave_base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    T t = s_tmp[i];
+    if (i < (int)w) wave_base += t;
+    tot += t;
+  }
+  *total = tot;
+  return wave_base + x - v;
+}
+
+// ============================================================================
+//  k-mer extraction (k <= 32, keys are uint64)
+// ============================================================================
+
+// 4 ASCII bytes (byte 0 = first base) -> 8 bits of 2-bit codes, first base most
+// significant.  code = (ascii >> 1) & 3 gives A0 C1 T2 G3 for both cases.
+__device__ __forceinline__ u32 enc4(u32 w) {
+  return (((w >> 1) & 0x03030303u) * 0x40100401u) >> 24;
+}
+// exact per-byte zero detector: 0x80 in every byte of x that is zero
+__device__ __forceinline__ u32 zero_bytes(u32 x) {
+  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+// 4 ASCII bytes -> 4-bit mask, bit 3 = byte 0 is NOT one of ACGTacgt
+__device__ __forceinline__ u32 inv4(u32 w) {
+  const u32 u = w & 0xDFDFDFDFu;                     // fold case
+  const u32 ok = zero_bytes(u ^ 0x41414141u) | zero_bytes(u ^ 0x43434343u) |
+                 zero_bytes(u ^ 0x47474747u) | zero_bytes(u ^ 0x54545454u);
+  const u32 g = ((~ok) & 0x80808080u) >> 7;
+  return ((g * 0x08040201u) >> 24) & 0xFu;
+}
+
+__device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ bases, u64 pos, u64 n, bool aligned) {
+  if (aligned && pos + 16 <= n)
+    return *reinterpret_cast<const uint4 *>(bases + pos);
+  u32 w[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    w[i] = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const u64 p = pos + (u64)(i * 4 + b);
+      const u32 c = (p < n) ? (u32)bases[p] : (u32)'.';
+      w[i] |= c << (8 * b);
+    }
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ void encode16(uint4 v, u32 &codes, u32 &inval) {
+  codes = (enc4(v.x) << 24) | (enc4(v.y) << 16) | (enc4(v.z) << 8) | enc4(v.w);
+  inval = (inv4(v.x) << 12) | (inv4(v.y) << 8) | (inv4(v.z) << 4) | inv4(v.w);
+}
+
+// reverse complement of a right-aligned k-mer (complement = xor 2 per base)
+__device__ __forceinline__ u64 revcomp64(u64 f, u32 key_shift /* 64-2k */) {
+  u64 x = __brevll(f ^ 0xAAAAAAAAAAAAAAAAull);       // reverses bases AND the two bits of each base
+  x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+  return x >> key_shift;
+}
+
+constexpr int KP_WORDS = KP_TILE / 16 + 4;            // 16 bases per staged word + 64-base halo
+
+// Stage one tile of bases as 2-bit codes + invalid masks in LDS.
+__device__ __forceinline__ void kp_stage_tile(const uint8_t *__restrict__ bases, u64 n, u64 tile0, bool aligned,
+                                              u32 *s_codes, u32 *s_inval) {
+  const u32 t = threadIdx.x;
+  {
+    u32 c, iv;
+    encode16(load16(bases, tile0 + (u64)t * 16, n, aligned), c, iv);
+    s_codes[t] = c; s_inval[t] = iv;
+  }
+  if (t < 4) {
+    u32 c, iv;
+    encode16(load16(bases, tile0 + (u64)KP_TILE + (u64)t * 16, n, aligned), c, iv);
+    s_codes[KP_BLOCK + t] = c; s_inval[KP_BLOCK + t] = iv;
+  }
+}
+
+// The 16 k-mers starting at tile positions threadIdx.x*16 .. +15.  Returns the
+// bit mask of positions that hold a complete k-mer.
+__device__ __forceinline__ u32 kp_thread_kmers(const u32 *s_codes, const u32 *s_inval, u32 k, int mode,
+                                               u64 (&keys)[KP_ITEMS]) {
+  const u32 t = threadIdx.x;
+  const u64 A = ((u64)s_codes[t] << 32) | (u64)s_codes[t + 1];      // bases 0..31 of the thread's window
+  const u64 B = (u64)s_codes[t + 2] << 32;                          // bases 32..47
+  const u64 I = ((u64)s_inval[t] << 48) | ((u64)s_inval[t + 1] << 32) | ((u64)s_inval[t + 2] << 16);
+  const u32 key_shift = 64 - 2 * k;
+  const u32 top_shift = 2 * k - 2;
+  u32 vmask = 0;
+  u64 r = 0;
+#pragma unroll
+  for (int j = 0; j < KP_ITEMS; j++) {
+    const u64 top = (j == 0) ? A : ((A << (2 * j)) | (B >> (64 - 2 * j)));
+    const u64 f   = top >> key_shift;
+    if (j == 0) r = revcomp64(f, key_shift);
+    else        r = (r >> 2) | ((((f & 3ull) ^ 2ull)) << top_shift);
+    const bool ok = (((I << j) >> (64 - k)) == 0ull);
+    u64 key;
+    if      (mode == 1) key = f;
+    else if (mode == 2) key = r;
+    else                key = (f < r) ? f : r;
+    keys[j] = key;
+    vmask |= (ok ? 1u : 0u) << j;
+  }
+  return vmask;
+}
+
+__device__ __forceinline__ void kp_tile_range(u64 num_tiles, u64 &t_begin, u64 &t_end) {
+  const u64 per = (num_tiles + gridDim.x - 1) / gridDim.x;
+  t_begin = (u64)blockIdx.x * per;
+  t_end   = t_begin + per;
+  if (t_begin > num_tiles) t_begin = num_tiles;
+  if (t_end   > num_tiles) t_end   = num_tiles;
+}
+
+// Pass 1: per-workgroup and global per-bucket instance counts.
+__global__ __launch_bounds__(KP_BLOCK)
+void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
+                      u64 num_tiles, u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts) {
+  __shared__ u32 s_codes[KP_WORDS];
+  __shared__ u32 s_inval[KP_WORDS];
+  __shared__ u32 s_hist[KP_MAX_BUCKETS];
+
+  const u32  nb = 1u << bucket_bits;
+  const u32  bucket_shift = 2 * k - bucket_bits;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
+
+  for (u32 b = threadIdx.x; b < nb; b += KP_BLOCK) s_hist[b] = 0;
+  __syncthreads();
+
+  u64 t_begin, t_end;
+  kp_tile_range(num_tiles, t_begin, t_end);
+  u32 my_count = 0;
+
+  for (u64 tile = t_begin; tile < t_end; tile++) {
+    kp_stage_tile(bases, n, tile * KP_TILE, aligned, s_codes, s_inval);
+    __syncthreads();
+    u64 keys[KP_ITEMS];
+    const u32 vmask = kp_thread_kmers(s_codes, s_inval, k, mode, keys);
+    if (nb == 1) {
+      my_count += __popc(vmask);
+    } else {
+#pragma unroll
+      for (int j = 0; j < KP_ITEMS; j++)
+        if ((vmask >> j) & 1u) atomicAdd(&s_hist[(u32)(keys[j] >> bucket_shift)], 1u);
+    }
+    __syncthreads();
+  }
+  if (nb == 1) atomicAdd(&s_hist[0], my_count);
+  __syncthreads();
+
+  for (u32 b = threadIdx.x; b < nb; b += KP_BLOCK) {
+    const u64 v = s_hist[b];
+    block_hist[(u64)blockIdx.x * nb + b] = v;
+    if (v) atomicAdd(&bucket_counts[b], v);
+  }
+}
+
+// Turns per-workgroup counts into per-workgroup absolute write cursors.
+__global__ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 *__restrict__ bucket_starts) {
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  u64 run = bucket_starts[b];
+  for (u32 g = 0; g < grid; g++) {
+    const u64 t = block_hist[(u64)g * nb + b];
+    block_hist[(u64)g * nb + b] = run;
+    run += t;
+  }
+}
+
+// Pass 2: pack + scatter.  Each workgroup owns private cursors (from pass 1),
+// so there are no global atomics and the result layout is deterministic up to
+// the order inside a (workgroup, tile, bucket) run.
+__global__ __launch_bounds__(KP_BLOCK)
+void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
+                           u64 num_tiles, const u64 *__restrict__ block_base, u64 *__restrict__ out) {
+  __shared__ u64 s_keys[KP_TILE];
+  __shared__ u64 s_cursor[KP_MAX_BUCKETS];
+  __shared__ u32 s_cnt[KP_MAX_BUCKETS];
+  __shared__ u32 s_base[KP_MAX_BUCKETS];
+  __shared__ u32 s_codes[KP_WORDS];
+  __shared__ u32 s_inval[KP_WORDS];
+  __shared__ u32 s_tmp[KP_BLOCK / 64 + 1];
+
+  const u32  nb = 1u << bucket_bits;
+  const u32  bucket_shift = 2 * k - bucket_bits;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
+  const u32  tid = threadIdx.x;
+
+  for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] = block_base[(u64)blockIdx.x * nb + b];
+
+  u64 t_begin, t_end;
+  kp_tile_range(num_tiles, t_begin, t_end);
+
+  for (u64 tile = t_begin; tile < t_end; tile++) {
+    for (u32 b = tid; b < nb; b += KP_BLOCK) s_cnt[b] = 0;
+    kp_stage_tile(bases, n, tile * KP_TILE, aligned, s_codes, s_inval);
+    __syncthreads();
+
+    u64 keys[KP_ITEMS];
+    const u32 vmask = kp_thread_kmers(s_codes, s_inval, k, mode, keys);
+    u32 total = 0;
+
+    if (nb == 1) {
+      // plain compaction: exclusive scan of per-thread counts
+      const u32 c = __popc(vmask);
+      const u32 base = block_excl_scan<KP_BLOCK, u32>(c, s_tmp, &total);
+      u32 o = base;
+#pragma unroll
+      for (int j = 0; j < KP_ITEMS; j++)
+        if ((vmask >> j) & 1u) s_keys[o++] = keys[j];
+      if (tid == 0) { s_base[0] = 0; s_cnt[0] = total; }
+      __syncthreads();
+    } else {
+      // rank inside the bucket with LDS atomics (order inside a bucket is free)
+      u32 ranks[KP_ITEMS];
+#pragma unroll
+      for (int j = 0; j < KP_ITEMS; j++) {
+        ranks[j] = 0;
+        if ((vmask >> j) & 1u) ranks[j] = atomicAdd(&s_cnt[(u32)(keys[j] >> bucket_shift)], 1u);
+      }
+      __syncthreads();
+      // exclusive scan of the bucket counts, 4 consecutive buckets per thread
+      u32 v[4], sum = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u32 b = tid * 4 + q;
+        v[q] = (b < nb) ? s_cnt[b] : 0u;
+        sum += v[q];
+      }
+      u32 run = block_excl_scan<KP_BLOCK, u32>(sum, s_tmp, &total);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u32 b = tid * 4 + q;
+        if (b < nb) s_base[b] = run;
+        run += v[q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < KP_ITEMS; j++)
+        if ((vmask >> j) & 1u) s_keys[s_base[(u32)(keys[j] >> bucket_shift)] + ranks[j]] = keys[j];
+      __syncthreads();
+    }
+
+    // contiguous runs per bucket leave as coalesced stores
+    for (u32 i = tid; i < total; i += KP_BLOCK) {
+      const u64 key = s_keys[i];
+      const u32 b   = (nb == 1) ? 0u : (u32)(key >> bucket_shift);
+      out[s_cursor[b] + (u64)(i - s_base[b])] = key;
+    }
+    __syncthreads();
+    for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] += s_cnt[b];
+    __syncthreads();
+  }
+}
+
+uint32_t kp_grid_size(uint64_t n_bases) {
+  const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
+  uint64_t g = num_tiles < 2048 ? num_tiles : 2048;
+  return (uint32_t)(g ? g : 1);
+}
+
+size_t kp_workspace_bytes(uint32_t bucket_bits) {
+  return (size_t)2048 * ((size_t)1 << bucket_bits) * sizeof(uint64_t);
+}
+
+hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
+                                 uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st) {
+  const uint32_t nb = 1u << bucket_bits;
+  MGC_CHECK(hipMemsetAsync(d_bucket_counts, 0, sizeof(uint64_t) * nb, st));
+  if (n_bases == 0) return hipSuccess;
+  const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
+  const uint32_t grid = kp_grid_size(n_bases);
+  hipLaunchKernelGGL(kmer_hist_kernel, dim3(grid), dim3(KP_BLOCK), 0, st,
+                     d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
+                     reinterpret_cast<u64 *>(d_ws), reinterpret_cast<u64 *>(d_bucket_counts));
+  return hipGetLastError();
+}
+
+hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
+                                 uint32_t bucket_bits, const uint64_t *d_bucket_starts, uint64_t *d_keys,
+                                 void *d_ws, hipStream_t st) {
+  if (n_bases == 0) return hipSuccess;
+  const uint32_t nb = 1u << bucket_bits;
+  const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
+  const uint32_t grid = kp_grid_size(n_bases);
+  hipLaunchKernelGGL(kmer_scan_kernel, dim3((nb + 255) / 256), dim3(256), 0, st,
+                     reinterpret_cast<u64 *>(d_ws), grid, nb, reinterpret_cast<const u64 *>(d_bucket_starts));
+  MGC_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(kmer_partition_kernel, dim3(grid), dim3(KP_BLOCK), 0, st,
+                     d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
+                     reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys));
+  return hipGetLastError();
+}
+
+// ============================================================================
+//  LSB radix sort of uint64 keys
+// ============================================================================
+//
+// One pass = one stable counting sort on a digit of <= RB bits:
+//   * keys of a tile (BLOCK*KPT consecutive keys) are loaded wave-striped, so a
+//     wave reads 512 contiguous bytes per instruction;
+//   * each wave ranks its keys with RB ballots per key (peers holding the same
+//     digit) against a wave-private LDS digit counter -- data-independent cost,
+//     stable by construction;
+//   * digit totals of the tile are prefix-summed; in ONESWEEP mode the tile's
+//     global digit bases come from a decoupled look-back over earlier tiles'
+//     8-byte status granules, in CLASSIC mode from a precomputed table;
+//   * keys are permuted through LDS into digit order and leave as contiguous
+//     runs (one run per digit), i.e. coalesced 8 B/lane stores.
+// Algorithmic HBM traffic per pass: 8 B read + 8 B write per key (ONESWEEP; the
+// digit histograms of all passes are taken in one extra 8 B/key read up front).
+
+constexpr int      RS_MAX_PASSES = 16;
+constexpr int      RS_MAX_RADIX  = 512;
+constexpr u64      ST_VALUE_MASK = (1ull << 48) - 1;
+constexpr u32      RS_SPIN_LIMIT = 1u << 24;
+
+struct SortHeader {                       // lives at the start of the sort workspace
+  u64 ghist[RS_MAX_PASSES][RS_MAX_RADIX]; // digit counts per pass
+  u64 gbase[RS_MAX_PASSES][RS_MAX_RADIX]; // exclusive digit bases per pass
+  u64 row_total[RS_MAX_RADIX];            // classic mode scratch
+  u32 ticket[RS_MAX_PASSES];
+  u32 pad[16];
+};
+
+struct PassList { u32 n; u32 shift[RS_MAX_PASSES]; u32 mask[RS_MAX_PASSES]; };
+
+// Digit histograms of every pass in one read of the keys.
+__global__ __launch_bounds__(256)
+void radix_hist_kernel(const u64 *__restrict__ in, u64 n, PassList pl, u64 *__restrict__ ghist) {
+  __shared__ u32 s_h[RS_MAX_PASSES * RS_MAX_RADIX / 2];   // up to 8 passes x 512 or 16 x 256 digits
+  const u32 np = pl.n;
+  // row stride: 512 if any mask needs it, else 256 (keeps 16 passes of 8 bits in 16 KB... )
+  u32 stride = 256;
+  for (u32 p = 0; p < np; p++) if (pl.mask[p] > 255u) stride = 512;
+  for (u32 i = threadIdx.x; i < np * stride; i += 256) s_h[i] = 0;
+  __syncthreads();
+
+  const u64 gstride = (u64)gridDim.x * 256;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += gstride) {
+    const u64 key = in[i];
+    for (u32 p = 0; p < np; p++)
+      atomicAdd(&s_h[p * stride + ((u32)(key >> pl.shift[p]) & pl.mask[p])], 1u);
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < np * stride; i += 256) {
+    const u32 v = s_h[i];
+    if (v) atomicAdd(&ghist[(u64)(i / stride) * RS_MAX_RADIX + (i % stride)], (u64)v);
+  }
+}
+
+// Exclusive scan over the digits of each pass (one workgroup per pass).
+__global__ __launch_bounds__(RS_MAX_RADIX)
+void radix_digit_scan_kernel(const u64 *__restrict__ ghist, u64 *__restrict__ gbase) {
+  __shared__ u64 s_tmp[RS_MAX_RADIX / 64 + 1];
+  const u32 p = blockIdx.x;
+  const u64 v = ghist[(u64)p * RS_MAX_RADIX + threadIdx.x];
+  u64 total;
+  const u64 e = block_excl_scan<RS_MAX_RADIX, u64>(v, s_tmp, &total);
+  gbase[(u64)p * RS_MAX_RADIX + threadIdx.x] = e;
+}
+
+template <int RB>
+__device__ __forceinline__ u64 match_digit(u32 d) {
+  u64 peers = ~0ull;
+#pragma unroll
+  for (int b = 0; b < RB; b++) {
+    const bool bit = (d >> b) & 1u;
+    const u64  m   = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+__device__ __forceinline__ void status_store(u64 *p, u64 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 status_load(u64 *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int RB, int BLOCK, int KPT>
+struct RadixSmem {
+  static constexpr int R     = 1 << RB;
+  static constexpr int NW    = BLOCK / 64;
+  static constexpr int TILE  = BLOCK * KPT;
+  // region 0 is shared between the wave histograms (ranking) and the key exchange
+  static constexpr size_t REGION0 = ((size_t)TILE * 8 > (size_t)NW * R * 4) ? (size_t)TILE * 8 : (size_t)NW * R * 4;
+  static constexpr size_t OFF_GBASE = REGION0;                 // u64[R]
+  static constexpr size_t OFF_DBASE = OFF_GBASE + (size_t)R * 8;   // u32[R]
+  static constexpr size_t OFF_TMP   = OFF_DBASE + (size_t)R * 4;   // u32[NW+1] scan scratch + misc
+  static constexpr size_t BYTES     = OFF_TMP + 64 * 4;
+};
+
+template <int RB, int BLOCK, int KPT, bool LOOKBACK>
+__global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256)     // two workgroups per CU (LDS allows it): <= 128 VGPRs
+void radix_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 n, u32 shift, u32 dmask,
+                          const u64 *__restrict__ gbase,      // LOOKBACK: exclusive digit bases of this pass
+                          u64 *__restrict__ status,           // LOOKBACK: [num_tiles][R] granules
+                          u32 *__restrict__ ticket, u32 epoch, u32 *__restrict__ error_flag,
+                          const u64 *__restrict__ tile_offs,  // !LOOKBACK: [R][num_tiles] absolute offsets
+                          u64 num_tiles) {
+  using SM = RadixSmem<RB, BLOCK, KPT>;
+  constexpr int R = SM::R, NW = SM::NW, TILE = SM::TILE;
+  static_assert(BLOCK >= R, "one thread per digit needed");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64 *s_keys  = reinterpret_cast<u64 *>(smem);
+  u32 *s_whist = reinterpret_cast<u32 *>(smem);                       // aliases s_keys (see barriers)
+  u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
+  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
+  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
+
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+
+  // Tile id: a ticket guarantees that every lower-numbered tile has started,
+  // hence is resident and will publish -- the look-back cannot deadlock.
+  u64 tile;
+  if (LOOKBACK) {
+    if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    tile = s_tmp[32];
+  } else {
+    tile = blockIdx.x;
+  }
+
+  for (u32 i = tid; i < (u32)(NW * R); i += BLOCK) s_whist[i] = 0;
+  __syncthreads();
+
+  // ---- load (wave-striped: 512 contiguous bytes per wave instruction) ----
+  const u64  tile_base = tile * (u64)TILE;
+  const bool full      = (tile_base + TILE <= n);
+  const u64  wave_base = tile_base + (u64)w * (64 * KPT) + lane;
+  u64 keys[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const u64 idx = wave_base + (u64)j * 64;
+    keys[j] = (full || idx < n) ? in[idx] : ~0ull;    // padding sorts to the end of the last digit
+  }
+
+  // ---- rank inside the wave ----
+  volatile u32 *wh = s_whist + w * R;
+  const u64 lt_mask = (1ull << lane) - 1ull;
+  u32 ranks[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const u32 d     = (u32)(keys[j] >> shift) & dmask;
+    const u64 peers = match_digit<RB>(d);
+    const u32 lower = __popcll(peers & lt_mask);
+    const u32 base  = wh[d];                           // every peer reads the same word (broadcast)
+    if (lower == 0) wh[d] = base + (u32)__popcll(peers);   // leader bumps it after the wave's read
+    ranks[j] = base + lower;
+  }
+  __syncthreads();
+
+  // ---- digit totals of the tile, wave-exclusive bases ----
+  u32 count = 0;
+  if (tid < (u32)R) {
+    u32 acc = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ww++) {
+      const u32 t = s_whist[ww * R + tid];
+      s_whist[ww * R + tid] = acc;
+      acc += t;
+    }
+    count = acc;
+  }
+  u32 tile_total;
+  const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tile_total);
+  if (tid < (u32)R) s_dbase[tid] = excl;
+
+  const u32 n_valid = full ? (u32)TILE : (u32)(n - tile_base);
+
+  if (tid < (u32)R) {
+    u64 g;
+    if (LOOKBACK) {
+      // padding keys all carry the top digit; do not publish them
+      const u32 pub = (tid == dmask) ? count - ((u32)TILE - n_valid) : count;
+      const u64 ep  = (u64)(epoch & 0x3FFFu) << 48;
+      u64 prev = 0;
+      if (tile == 0) {
+        status_store(&status[tid], (2ull << 62) | ep | (u64)pub);
+      } else {
+        status_store(&status[tile * R + tid], (1ull << 62) | ep | (u64)pub);
+        u64 t = tile - 1;
+        while (true) {
+          u64 wv;
+          u32 spins = 0;
+          while (true) {
+            wv = status_load(&status[t * R + tid]);
+            if (((wv >> 48) & 0x3FFFull) == (u64)(epoch & 0x3FFFu) && (wv >> 62) != 0ull) break;
+            if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); wv = (2ull << 62); break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          prev += wv & ST_VALUE_MASK;
+          if ((wv >> 62) == 2ull) break;
+          t--;
+        }
+        status_store(&status[tile * R + tid], (2ull << 62) | ep | (prev + (u64)pub));
+      }
+      g = gbase[tid] + prev;
+    } else {
+      g = tile_offs[(u64)tid * num_tiles + tile];
+    }
+    s_gbase[tid] = g - (u64)excl;          // so that out index = s_gbase[d] + position in sorted tile
+  }
+  __syncthreads();
+
+  // ---- final position of every key inside the sorted tile ----
+  u32 pos[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const u32 d = (u32)(keys[j] >> shift) & dmask;
+    pos[j] = s_dbase[d] + s_whist[w * R + d] + ranks[j];
+  }
+  __syncthreads();                          // s_whist is dead; its storage becomes s_keys
+#pragma unroll
+  for (int j = 0; j < KPT; j++) s_keys[pos[j]] = keys[j];
+  __syncthreads();
+
+  // ---- contiguous runs leave coalesced ----
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const u32 i = (u32)j * BLOCK + tid;
+    if (i < n_valid) {
+      const u64 key = s_keys[i];
+      const u32 d   = (u32)(key >> shift) & dmask;
+      out[s_gbase[d] + (u64)i] = key;
+    }
+  }
+}
+
+// ---- classic mode: per-tile digit histogram + row scan ----------------------
+template <int RB, int BLOCK, int KPT>
+__global__ __launch_bounds__(BLOCK)
+void radix_tile_hist_kernel(const u64 *__restrict__ in, u64 n, u32 shift, u32 dmask, u32 *__restrict__ tile_hist,
+                            u64 num_tiles) {
+  constexpr int R = 1 << RB, TILE = BLOCK * KPT;
+  __shared__ u32 s_h[R];
+  const u32 tid = threadIdx.x;
+  for (u32 i = tid; i < (u32)R; i += BLOCK) s_h[i] = 0;
+  __syncthreads();
+  const u64 tile_base = (u64)blockIdx.x * TILE;
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const u64 idx = tile_base + (u64)j * BLOCK + tid;
+    if (idx < n) atomicAdd(&s_h[(u32)(in[idx] >> shift) & dmask], 1u);
+  }
+  __syncthreads();
+  for (u32 i = tid; i < (u32)R; i += BLOCK) tile_hist[(u64)i * num_tiles + blockIdx.x] = s_h[i];
+}
+
+// One workgroup per digit: exclusive scan of its row of tile counts (-> u64),
+// and the row total.
+__global__ __launch_bounds__(1024)
+void radix_row_scan_kernel(const u32 *__restrict__ tile_hist, u64 *__restrict__ tile_offs, u64 *__restrict__ row_total,
+                           u64 num_tiles) {
+  __shared__ u64 s_tmp[1024 / 64 + 1];
+  const u64 row = (u64)blockIdx.x * num_tiles;
+  u64 carry = 0;
+  for (u64 c = 0; c < num_tiles; c += 1024) {
+    const u64 t = c + threadIdx.x;
+    const u64 v = (t < num_tiles) ? (u64)tile_hist[row + t] : 0ull;
+    u64 tot;
+    const u64 e = block_excl_scan<1024, u64>(v, s_tmp, &tot);
+    if (t < num_tiles) tile_offs[row + t] = carry + e;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+}
+
+// Adds the exclusive digit base (scan of row totals) to every row.
+__global__ __launch_bounds__(256)
+void radix_row_add_kernel(u64 *__restrict__ tile_offs, const u64 *__restrict__ row_total, u32 R, u64 num_tiles) {
+  const u32 d = blockIdx.y;
+  u64 base = 0;
+  for (u32 i = 0; i < d; i++) base += row_total[i];
+  const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (t < num_tiles) tile_offs[(u64)d * num_tiles + t] += base;
+  (void)R;
+}
+
+// ---- host side ---------------------------------------------------------------
+
+static int env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+void make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan) {
+  memset(plan, 0, sizeof(*plan));
+  int rb   = env_int("MGC_RADIX_BITS", 8);
+  int mode = env_int("MGC_SORT_MODE", 0);
+  int kpt  = env_int("MGC_SORT_KPT", 16);
+  if (rb != 8 && rb != 9) rb = 8;
+  if (kpt != 8 && kpt != 16) kpt = 16;
+  plan->radix_bits = (uint32_t)rb;
+  plan->block      = 512;
+  plan->kpt        = (uint32_t)kpt;
+  plan->tile       = plan->block * plan->kpt;
+  plan->mode       = mode ? 1u : 0u;
+  const uint32_t nbits = (end_bit > begin_bit) ? end_bit - begin_bit : 0;
+  uint32_t passes = (nbits + rb - 1) / rb;
+  if (passes > RS_MAX_PASSES) passes = RS_MAX_PASSES;
+  plan->num_passes = passes;
+  uint32_t bit = begin_bit;
+  for (uint32_t p = 0; p < passes; p++) {
+    uint32_t b = nbits / passes + ((p < nbits % passes) ? 1u : 0u);
+    plan->pass_shift[p] = bit;
+    plan->pass_bits[p]  = b;
+    bit += b;
+  }
+}
+
+static inline uint64_t max_tiles_for(uint64_t n) { return (n + 4095) / 4096 + 1; }   // tile >= 4096 keys
+
+size_t sort_workspace_bytes(uint64_t n) {
+  // header + the larger of {onesweep status granules, classic tile_hist + tile_offs}
+  const uint64_t t = max_tiles_for(n);
+  return sizeof(SortHeader) + 1024 + (size_t)t * RS_MAX_RADIX * (sizeof(uint32_t) + sizeof(uint64_t));
+}
+
+template <int RB, int BLOCK, int KPT>
+static hipError_t run_passes(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, const SortPlan &plan, void *d_ws,
+                             uint32_t *d_error, int *result_in_alt, hipStream_t st, hipEvent_t *pass_events) {
+  using SM = RadixSmem<RB, BLOCK, KPT>;
+  constexpr int R = 1 << RB, TILE = BLOCK * KPT;
+  SortHeader *hdr = reinterpret_cast<SortHeader *>(d_ws);
+  unsigned char *body = reinterpret_cast<unsigned char *>(d_ws) + ((sizeof(SortHeader) + 255) / 256) * 256;
+  const uint64_t num_tiles = (n + TILE - 1) / TILE;
+
+  static bool attr_done_a = false, attr_done_b = false;
+  if (!attr_done_a) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<RB, BLOCK, KPT, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::BYTES);
+    attr_done_a = true;
+  }
+  if (!attr_done_b) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<RB, BLOCK, KPT, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::BYTES);
+    attr_done_b = true;
+  }
+
+  u64 *src = reinterpret_cast<u64 *>(d_keys), *dst = reinterpret_cast<u64 *>(d_alt);
+  int in_alt = 0;
+
+  if (plan.mode == 0) {
+    // ---- onesweep ----
+    u64 *status = reinterpret_cast<u64 *>(body);
+    MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
+    MGC_CHECK(hipMemsetAsync(status, 0, (size_t)num_tiles * R * sizeof(u64), st));
+    PassList pl;
+    pl.n = plan.num_passes;
+    for (uint32_t p = 0; p < plan.num_passes; p++) {
+      pl.shift[p] = plan.pass_shift[p];
+      pl.mask[p]  = (1u << plan.pass_bits[p]) - 1u;
+    }
+    uint64_t hgrid = (n + 256 * 16 - 1) / (256 * 16);
+    if (hgrid > 2048) hgrid = 2048;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3((uint32_t)hgrid), dim3(256), 0, st, src, (u64)n, pl, &hdr->ghist[0][0]);
+    MGC_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(plan.num_passes), dim3(RS_MAX_RADIX), 0, st,
+                       &hdr->ghist[0][0], &hdr->gbase[0][0]);
+    MGC_CHECK(hipGetLastError());
+    for (uint32_t p = 0; p < plan.num_passes; p++) {
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
+      hipLaunchKernelGGL((radix_scatter_kernel<RB, BLOCK, KPT, true>), dim3((uint32_t)num_tiles), dim3(BLOCK),
+                         SM::BYTES, st, src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                         &hdr->gbase[p][0], status, &hdr->ticket[p], p + 1, d_error,
+                         (const u64 *)nullptr, (u64)num_tiles);
+      MGC_CHECK(hipGetLastError());
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
+      u64 *t = src; src = dst; dst = t; in_alt ^= 1;
+    }
+  } else {
+    // ---- classic: histogram / scan / scatter per pass ----
+    u32 *tile_hist = reinterpret_cast<u32 *>(body);
+    u64 *tile_offs = reinterpret_cast<u64 *>(body + (((size_t)num_tiles * R * sizeof(u32) + 255) / 256) * 256);
+    for (uint32_t p = 0; p < plan.num_passes; p++) {
+      const uint32_t shift = plan.pass_shift[p], dmask = (1u << plan.pass_bits[p]) - 1u;
+      hipLaunchKernelGGL((radix_tile_hist_kernel<RB, BLOCK, KPT>), dim3((uint32_t)num_tiles), dim3(BLOCK), 0, st,
+                         src, (u64)n, shift, dmask, tile_hist, (u64)num_tiles);
+      MGC_CHECK(hipGetLastError());
+      hipLaunchKernelGGL(radix_row_scan_kernel, dim3(R), dim3(1024), 0, st, tile_hist, tile_offs,
+                         &hdr->row_total[0], (u64)num_tiles);
+      MGC_CHECK(hipGetLastError());
+      hipLaunchKernelGGL(radix_row_add_kernel, dim3((uint32_t)((num_tiles + 255) / 256), R), dim3(256), 0, st,
+                         tile_offs, &hdr->row_total[0], (u32)R, (u64)num_tiles);
+      MGC_CHECK(hipGetLastError());
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
+      hipLaunchKernelGGL((radix_scatter_kernel<RB, BLOCK, KPT, false>), dim3((uint32_t)num_tiles), dim3(BLOCK),
+                         SM::BYTES, st, src, dst, (u64)n, shift, dmask, (const u64 *)nullptr, (u64 *)nullptr,
+                         (u32 *)nullptr, 0u, d_error, tile_offs, (u64)num_tiles);
+      MGC_CHECK(hipGetLastError());
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
+      u64 *t = src; src = dst; dst = t; in_alt ^= 1;
+    }
+  }
+  *result_in_alt = in_alt;
+  return hipSuccess;
+}
+
+hipError_t launch_radix_sort(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, const SortPlan &plan,
+                             void *d_ws, size_t ws_bytes, uint32_t *d_error, int *result_in_alt,
+                             hipStream_t st, hipEvent_t *pass_events) {
+  *result_in_alt = 0;
+  if (n == 0 || plan.num_passes == 0) return hipSuccess;
+  if (ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
+  if (plan.radix_bits == 9) {
+    if (plan.kpt == 8) return run_passes<9, 512, 8>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);
+    return run_passes<9, 512, 16>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);
+  }
+  if (plan.kpt == 8) return run_passes<8, 512, 8>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);
+  return run_passes<8, 512, 16>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);
+}
+
+// ============================================================================
+//  Run-length count of sorted keys
+// ============================================================================
+
+constexpr int RL_BLOCK = 256;
+constexpr int RL_KPT   = 16;
+constexpr int RL_TILE  = RL_BLOCK * RL_KPT;
+constexpr u64 RL_INF   = ~0ull;
+
+// workspace: [0] total distinct, [8..): tile_offs u64[T+1], tile_next u64[T+1]
+struct RleWs {
+  u64 *total, *tile_offs, *tile_next;
+  u64  num_tiles;
+};
+static inline RleWs rle_ws(void *d_ws, uint64_t n) {
+  RleWs w;
+  w.num_tiles = (n + RL_TILE - 1) / RL_TILE;
+  w.total     = reinterpret_cast<u64 *>(d_ws);
+  w.tile_offs = w.total + 8;
+  w.tile_next = w.tile_offs + w.num_tiles + 1;
+  return w;
+}
+size_t rle_workspace_bytes(uint64_t n) {
+  const uint64_t t = (n + RL_TILE - 1) / RL_TILE;
+  return (size_t)(8 + 2 * (t + 1)) * sizeof(uint64_t);
+}
+
+// per tile: number of run heads and position of the first head
+__global__ __launch_bounds__(RL_BLOCK)
+void rle_count_kernel(const u64 *__restrict__ in, u64 n, u64 *__restrict__ tile_cnt, u64 *__restrict__ tile_first) {
+  __shared__ u32 s_cnt[RL_BLOCK / 64];
+  __shared__ u64 s_min[RL_BLOCK / 64];
+  const u64 tile_base = (u64)blockIdx.x * RL_TILE;
+  u32 c = 0;
+  u64 first = RL_INF;
+#pragma unroll
+  for (int j = 0; j < RL_KPT; j++) {
+    const u64 idx = tile_base + (u64)j * RL_BLOCK + threadIdx.x;
+    if (idx < n) {
+      const u64 key = in[idx];
+      const bool head = (idx == 0) || (in[idx - 1] != key);
+      if (head) { c++; if (idx < first) first = idx; }
+    }
+  }
+  // wave reduce
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    c += __shfl_down(c, d);
+    const u64 o = __shfl_down(first, d);
+    first = (o < first) ? o : first;
+  }
+  if (lane_id() == 0) { s_cnt[wave_id()] = c; s_min[wave_id()] = first; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 tc = 0; u64 tf = RL_INF;
+    for (int i = 0; i < RL_BLOCK / 64; i++) { tc += s_cnt[i]; tf = (s_min[i] < tf) ? s_min[i] : tf; }
+    tile_cnt[blockIdx.x]   = tc;
+    tile_first[blockIdx.x] = tf;
+  }
+}
+
+// single workgroup: exclusive scan of tile counts, suffix-min of first heads
+__global__ __launch_bounds__(1024)
+void rle_tile_scan_kernel(u64 *__restrict__ tile_offs, u64 *__restrict__ tile_next, u64 num_tiles, u64 n,
+                          u64 *__restrict__ total) {
+  __shared__ u64 s_tmp[1024 / 64 + 1];
+  __shared__ u64 s_carry;
+  u64 carry = 0;
+  for (u64 c = 0; c < num_tiles; c += 1024) {
+    const u64 t = c + threadIdx.x;
+    const u64 v = (t < num_tiles) ? tile_offs[t] : 0ull;
+    u64 tot;
+    const u64 e = block_excl_scan<1024, u64>(v, s_tmp, &tot);
+    if (t < num_tiles) tile_offs[t] = carry + e;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) { tile_offs[num_tiles] = carry; *total = carry; }
+
+  // backwards: tile_next[t] = min(first head of tiles >= t), tile_next[num_tiles] = n
+  if (threadIdx.x == 0) { tile_next[num_tiles] = n; s_carry = n; }
+  __syncthreads();
+  const u64 chunks = (num_tiles + 1023) / 1024;
+  for (u64 ci = 0; ci < chunks; ci++) {
+    const u64 c_end = num_tiles - ci * 1024;                 // exclusive end of this chunk
+    const bool has  = (threadIdx.x < c_end);
+    const u64 t     = has ? (c_end - 1 - threadIdx.x) : 0;   // reversed: thread 0 takes the last tile
+    u64 x = has ? tile_next[t] : RL_INF;
+    // inclusive min-scan over the reversed order
+    const u32 lane = lane_id(), w = wave_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const u64 y = __shfl_up(x, d);
+      if ((int)lane >= d) x = (y < x) ? y : x;
+    }
+    __syncthreads();
+    if (lane == 63) s_tmp[w] = x;
+    __syncthreads();
+    u64 pre = s_carry;
+    for (u32 i = 0; i < w; i++) pre = (s_tmp[i] < pre) ? s_tmp[i] : pre;
+    x = (pre < x) ? pre : x;
+    if (has) tile_next[t] = x;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = x;
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ u32 rl_pad(u32 i) { return i + (i >> 4); }
+
+__global__ __launch_bounds__(RL_BLOCK)
+void rle_emit_kernel(const u64 *__restrict__ in, u64 n, const u64 *__restrict__ tile_offs,
+                     const u64 *__restrict__ tile_next, u64 *__restrict__ out_keys, u32 *__restrict__ out_counts) {
+  __shared__ u64 s_keys[RL_TILE + 1 + (RL_TILE + 1) / 16 + 1];
+  __shared__ u32 s_tmp[RL_BLOCK / 64 + 1];
+  __shared__ u64 s_wmin[RL_BLOCK / 64];
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const u64 tile_base = (u64)blockIdx.x * RL_TILE;
+
+  // coalesced load; logical slot 0 holds the key preceding the tile
+  if (tid == 0) s_keys[rl_pad(0)] = (tile_base > 0) ? in[tile_base - 1] : 0ull;
+#pragma unroll
+  for (int j = 0; j < RL_KPT; j++) {
+    const u32 i   = (u32)j * RL_BLOCK + tid;
+    const u64 idx = tile_base + i;
+    s_keys[rl_pad(i + 1)] = (idx < n) ? in[idx] : 0ull;
+  }
+  __syncthreads();
+
+  // blocked: thread owns RL_KPT consecutive keys
+  u64 keys[RL_KPT];
+  u32 flags = 0;
+  u64 prev = s_keys[rl_pad(tid * RL_KPT)];
+#pragma unroll
+  for (int j = 0; j < RL_KPT; j++) {
+    const u32 i   = tid * RL_KPT + j;
+    const u64 idx = tile_base + i;
+    keys[j] = s_keys[rl_pad(i + 1)];
+    const bool head = (idx < n) && ((idx == 0) || (keys[j] != prev));
+    flags |= (head ? 1u : 0u) << j;
+    prev = keys[j];
+  }
+
+  const u32 c = __popc(flags);
+  u32 tile_heads;
+  const u32 slot0 = block_excl_scan<RL_BLOCK, u32>(c, s_tmp, &tile_heads);
+
+  // position of the next head after this thread's keys
+  const u64 fh = flags ? (tile_base + (u64)tid * RL_KPT + (u32)(__ffs(flags) - 1)) : RL_INF;
+  u64 x = fh;                                   // inclusive suffix-min inside the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u64 y = __shfl_down(x, d);
+    if ((int)lane + d < 64) x = (y < x) ? y : x;
+  }
+  if (lane == 0) s_wmin[w] = x;
+  __syncthreads();
+  u64 after = tile_next[blockIdx.x + 1];        // first head in any later tile (or n)
+  for (int ww = RL_BLOCK / 64 - 1; ww > (int)w; ww--) after = (s_wmin[ww] < after) ? s_wmin[ww] : after;
+  u64 e = __shfl_down(x, 1);
+  if (lane == 63) e = RL_INF;
+  u64 next = (e < after) ? e : after;
+
+  const u64 out_base = tile_offs[blockIdx.x] + slot0;
+#pragma unroll
+  for (int j = RL_KPT - 1; j >= 0; j--) {
+    if ((flags >> j) & 1u) {
+      const u64 idx  = tile_base + (u64)tid * RL_KPT + j;
+      const u64 slot = out_base + __popc(flags & ((1u << j) - 1u));
+      out_keys[slot]   = keys[j];
+      out_counts[slot] = (u32)(next - idx);     // wraps mod 2^32 like the reference's uint32 ++
+      next = idx;
+    }
+  }
+}
+
+hipError_t launch_rle_count(const uint64_t *d_sorted, uint64_t n, void *d_ws, hipStream_t st) {
+  RleWs w = rle_ws(d_ws, n);
+  if (n == 0) return hipMemsetAsync(w.total, 0, sizeof(u64), st);
+  hipLaunchKernelGGL(rle_count_kernel, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
+                     reinterpret_cast<const u64 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next);
+  MGC_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(rle_tile_scan_kernel, dim3(1), dim3(1024), 0, st, w.tile_offs, w.tile_next, (u64)w.num_tiles,
+                     (u64)n, w.total);
+  return hipGetLastError();
+}
+
+hipError_t rle_read_total(const void *d_ws, uint64_t *n_distinct, hipStream_t st) {
+  MGC_CHECK(hipMemcpyAsync(n_distinct, d_ws, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  return hipStreamSynchronize(st);
+}
+
+hipError_t launch_rle_emit(const uint64_t *d_sorted, uint64_t n, void *d_ws, uint64_t *d_unique,
+                           uint32_t *d_counts, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  RleWs w = rle_ws(d_ws, n);
+  hipLaunchKernelGGL(rle_emit_kernel, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
+                     reinterpret_cast<const u64 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next,
+                     reinterpret_cast<u64 *>(d_unique), d_counts);
+  return hipGetLastError();
+}
+
+// ============================================================================
+//  Block offsets: first distinct key of every prefix
+// ============================================================================
+__global__ void block_offsets_kernel(const u64 *__restrict__ keys, u64 nd, u32 w_data, u64 n_prefix,
+                                     u64 *__restrict__ block_start) {
+  const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n_prefix) return;
+  if (p == n_prefix) { block_start[p] = nd; return; }
+  const u64 target = p << w_data;
+  u64 lo = 0, hi = nd;
+  while (lo < hi) {
+    const u64 mid = lo + ((hi - lo) >> 1);
+    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  block_start[p] = lo;
+}
+
+hipError_t launch_block_offsets(const uint64_t *d_unique, uint64_t n_distinct, uint32_t w_data,
+                                uint64_t n_prefix, uint64_t *d_block_start, hipStream_t st) {
+  const uint64_t threads = n_prefix + 1;
+  hipLaunchKernelGGL(block_offsets_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st,
+                     reinterpret_cast<const u64 *>(d_unique), (u64)n_distinct, w_data, (u64)n_prefix,
+                     reinterpret_cast<u64 *>(d_block_start));
+  return hipGetLastError();
+}
+
+// ============================================================================
+//  Synthetic reads (byte-identical to oracle/oracle_count.c orc_synth_reads)
+// ============================================================================
+__host__ __device__ __forceinline__ u64 splitmix64(u64 x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+
+struct SynthParams {
+  u64 s_genome, s_read, s_error, span, first_read, total_bytes, sub_thresh, n_thresh;
+  u32 read_len;
+};
+
+__device__ __forceinline__ u32 synth_byte(const SynthParams &P, u64 o) {
+  const u64 stride = (u64)P.read_len + 1;
+  const u64 rr = o / stride;
+  const u32 j  = (u32)(o - rr * stride);
+  if (j == P.read_len) return (u32)'.';
+  const u64 r     = P.first_read + rr;
+  const u64 hr    = splitmix64(P.s_read ^ r);
+  const u64 start = __umul64hi(hr, P.span);
+  const bool rev  = (hr & 1ull) != 0;
+  const u64 gpos  = rev ? (start + P.read_len - 1 - j) : (start + j);
+  u32 code = (u32)(splitmix64(P.s_genome ^ gpos) & 3ull);
+  if (rev) code ^= 2u;
+  const u64 he = splitmix64(P.s_error ^ (r * (u64)P.read_len + j));
+  const u32 e1 = (u32)he, e2 = (u32)(he >> 32);
+  if ((u64)e1 < P.sub_thresh) code = (code + 1u + (e1 % 3u)) & 3u;
+  const u32 acgt = 0x47544341u;                 // 'A','C','T','G' little-endian
+  return ((u64)e2 < P.n_thresh) ? (u32)'N' : ((acgt >> (8 * code)) & 0xFFu);
+}
+
+__global__ __launch_bounds__(256)
+void synth_reads_kernel(SynthParams P, uint8_t *__restrict__ out) {
+  const u64 o4 = ((u64)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (o4 >= P.total_bytes) return;
+  if (o4 + 4 <= P.total_bytes) {
+    u32 w = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) w |= synth_byte(P, o4 + b) << (8 * b);
+    *reinterpret_cast<u32 *>(out + o4) = w;
+  } else {
+    for (u64 o = o4; o < P.total_bytes; o++) out[o] = (uint8_t)synth_byte(P, o);
+  }
+}
+
+hipError_t launch_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
+                              uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,
+                              uint8_t *d_out, hipStream_t st) {
+  if (n_reads == 0) return hipSuccess;
+  SynthParams P;
+  P.s_genome    = splitmix64(seed + 0ull * 0x632be59bd9b4e019ull);
+  P.s_read      = splitmix64(seed + 1ull * 0x632be59bd9b4e019ull);
+  P.s_error     = splitmix64(seed + 2ull * 0x632be59bd9b4e019ull);
+  P.span        = genome_len - read_len + 1;
+  P.first_read  = first_read;
+  P.read_len    = read_len;
+  P.total_bytes = n_reads * ((uint64_t)read_len + 1);
+  P.sub_thresh  = (uint64_t)sub_rate_ppm * 4294967296ull / 1000000ull;
+  P.n_thresh    = (uint64_t)n_rate_ppm * 4294967296ull / 1000000ull;
+  const uint64_t threads = (P.total_bytes + 3) / 4;
+  hipLaunchKernelGGL(synth_reads_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st, P, d_out);
+  return hipGetLastError();
+}
+
+}  // namespace mgc

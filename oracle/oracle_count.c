@@ -296,30 +296,32 @@ static inline uint64_t splitmix64(uint64_t x) {
   x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
   return x ^ (x >> 31);
 }
-static inline uint64_t synth_hash(uint64_t seed, uint64_t stream, uint64_t idx) {
-  return splitmix64(splitmix64(seed + stream * 0x632be59bd9b4e019ull) ^ idx);
-}
 
 uint64_t orc_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                          uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm, char *out) {
   static const char acgt[4] = { 'A', 'C', 'T', 'G' };
-  const uint64_t span = genome_len - read_len + 1;
+  const uint64_t span       = genome_len - read_len + 1;
+  const uint64_t sub_thresh = (uint64_t)sub_rate_ppm * 4294967296ull / 1000000ull;   /* compare against 32 random bits */
+  const uint64_t n_thresh   = (uint64_t)n_rate_ppm   * 4294967296ull / 1000000ull;
+  const uint64_t s_genome   = splitmix64(seed + 0 * 0x632be59bd9b4e019ull);
+  const uint64_t s_read     = splitmix64(seed + 1 * 0x632be59bd9b4e019ull);
+  const uint64_t s_error    = splitmix64(seed + 2 * 0x632be59bd9b4e019ull);
   uint64_t o = 0;
   for (uint64_t rr = 0; rr < n_reads; rr++) {
     const uint64_t r     = first_read + rr;
-    const uint64_t hr    = synth_hash(seed, 1, r);
-    const uint64_t start = (hr >> 1) % span;
+    const uint64_t hr    = splitmix64(s_read ^ r);
+    const uint64_t start = (uint64_t)(((unsigned __int128)hr * span) >> 64);   /* multiply-high range reduction */
     const int      rev   = (int)(hr & 1);
     for (uint32_t j = 0; j < read_len; j++) {
       uint64_t gpos = rev ? (start + read_len - 1 - j) : (start + j);
-      uint32_t code = (uint32_t)(synth_hash(seed, 0, gpos) & 3);
+      uint32_t code = (uint32_t)(splitmix64(s_genome ^ gpos) & 3);
       if (rev) code ^= 2;
-      const uint64_t he = synth_hash(seed, 2, r * read_len + j);
-      const uint32_t e1 = (uint32_t)(he % 1000000u);
-      const uint32_t e2 = (uint32_t)((he >> 32) % 1000000u);
-      if (e1 < sub_rate_ppm)
-        code = (code + 1 + (uint32_t)((he >> 20) % 3)) & 3;
-      out[o++] = (e2 < n_rate_ppm) ? 'N' : acgt[code];
+      const uint64_t he = splitmix64(s_error ^ (r * read_len + j));
+      const uint32_t e1 = (uint32_t)he;
+      const uint32_t e2 = (uint32_t)(he >> 32);
+      if ((uint64_t)e1 < sub_thresh)
+        code = (code + 1 + (e1 % 3)) & 3;
+      out[o++] = ((uint64_t)e2 < n_thresh) ? 'N' : acgt[code];
     }
     out[o++] = '.';
   }

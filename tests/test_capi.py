@@ -1,0 +1,112 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds (hipcc
+cross-compiles gfx950 without a GPU), loads, exports every symbol the header
+declares, and its host-side logic (configureCounting restatement, argument
+checking, error behaviour) matches the oracle.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "meryl_gpu_count.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(m(?:gc|db)_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(n for n in names if not n.endswith("_cb")))
+
+
+def test_header_symbols_exported(native_lib):
+    from meryl_amd import capi
+    names = declared_functions()
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(native_lib, n)]
+    assert not missing, missing
+    # the binding's own list covers the header
+    assert set(names) <= set(capi.SYMBOLS), set(names) - set(capi.SYMBOLS)
+
+
+def test_library_is_in_tree_and_gfx950(native_lib):
+    from meryl_amd import capi
+    path = capi.library_path()
+    assert path.startswith(ROOT) and os.path.exists(path)
+    blob = open(path, "rb").read()
+    assert b"gfx950" in blob, "code object for gfx950 missing from the shared library"
+    assert native_lib.mgc_version() >= 1
+
+
+def test_configure_matches_oracle(native_lib, oracle_lib):
+    from meryl_amd import capi
+    rng = np.random.default_rng(5)
+    GB = 1 << 30
+    combos = [(21, 4641652, 4 * GB), (21, 10_000_000_000, 64 * GB), (21, 90_000_000_000, 256 * GB),
+              (31, 90_000_000_000, 256 * GB), (51, 150_000_000_000, 256 * GB), (22, 5_000_000, 1 * GB)]
+    for _ in range(300):
+        k = int(rng.integers(6, 65))
+        n = int(10 ** rng.uniform(3, 11.5))
+        mem = int(2 ** rng.uniform(28, 41))
+        combos.append((k, n, mem))
+    for k, n, mem in combos:
+        c = capi.configure(k, n, mem)
+        o = oracle_lib.configure_counting(k, n, mem)
+        got = (c.use_simple, c.w_prefix, c.n_prefix, c.w_data, c.n_batches, c.memory_used)
+        want = (o["use_simple"], o["w_prefix"], o["n_prefix"], o["w_data"], o["n_batches"], o["memory_used"])
+        assert got == want, (k, n, mem, got, want)
+
+
+def test_configured_line_format(native_lib):
+    # the Canu-parsed line, src/meryl/merylOp-count.C:398-401
+    from meryl_amd import capi
+    c = capi.configure(21, 10_000_000_000, 64 << 30)
+    line = capi.configured_line(c)
+    assert re.fullmatch(r"Configured complex mode for \d+\.\d{3} GB memory per batch, and up to \d+ batch(es)?\.", line)
+
+
+def test_error_codes_not_exit(native_lib):
+    from meryl_amd import capi
+    c = capi.CountConfig()
+    c.k = 0                                   # the reference exits(1) here (merylOp-count.C:311-312)
+    assert native_lib.mgc_configure_counting(ctypes.byref(c)) == capi.MGC_EINVAL
+    assert b"Kmer size" in native_lib.mgc_last_error(None)
+    assert native_lib.mgc_configure_counting(None) == capi.MGC_EINVAL
+    c.k = 21
+    c.mode = 7
+    assert native_lib.mgc_configure_counting(ctypes.byref(c)) == capi.MGC_EINVAL
+    # unconfigured config is refused before any device work
+    c2 = capi.CountConfig()
+    c2.k = 21
+    assert not native_lib.mgc_open(ctypes.byref(c2), -1)
+    assert b"mgc_configure_counting" in native_lib.mgc_last_error(None)
+    # argument checks of the device operators happen before any launch
+    assert native_lib.mgc_dev_kmer_histogram(None, 10, 0, 0, 6, None, None, 0, None) == capi.MGC_EINVAL
+    assert native_lib.mgc_dev_kmer_histogram(None, 10, 40, 0, 6, None, None, 0, None) == capi.MGC_EUNSUPPORTED
+    ia = ctypes.c_int(0)
+    assert native_lib.mgc_dev_radix_sort_u64(None, None, 5, 10, 4, None, 0, ctypes.byref(ia), None) == capi.MGC_EINVAL
+    assert native_lib.mgc_dev_radix_sort_u64(None, None, 0, 0, 42, None, 0, ctypes.byref(ia), None) == capi.MGC_OK
+
+
+def test_workspace_sizes_monotone(native_lib):
+    prev = 0
+    for n in (0, 1, 4096, 10**6, 10**9):
+        w = native_lib.mgc_dev_sort_workspace_bytes(n)
+        assert w >= prev
+        prev = w
+    assert native_lib.mgc_dev_partition_workspace_bytes(6) == 2048 * 64 * 8
+    assert native_lib.mgc_dev_rle_workspace_bytes(0) > 0
+
+
+def test_product_never_imports_oracle():
+    # the oracle is a checker: nothing under meryl_amd/ or include/ may reference it
+    bad = []
+    for base in ("meryl_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                    txt = open(os.path.join(dp, f), errors="replace").read()
+                    if re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M) or "liboracle" in txt or "oracle.h" in txt:
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
