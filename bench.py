@@ -45,9 +45,16 @@ def cpu_baseline(sample_reads, threads):
     genome = max(READ_LEN * 4, sample_reads * READ_LEN // 30)
     bases = oracle.synth_reads(SEED, genome, 0, sample_reads, READ_LEN, 5000, 100).tobytes()
     cfg = oracle.configure_counting(K, 10_000_000_000, 64 << 30)      # the workload's geometry (wPrefix 18)
-    t0 = time.perf_counter()
-    nd, ni = oracle.time_threaded(bases, K, cfg["w_prefix"], oracle.CANONICAL, threads)
-    dt = time.perf_counter() - t0
+    # the reference's spin-locked buckets do not scale to every core count: time a few
+    # thread counts (all <= the box's cores) and report the best one
+    best = None
+    for th in sorted({min(threads, t) for t in (16, 64, threads)}):
+        t0 = time.perf_counter()
+        nd, ni = oracle.time_threaded(bases, K, cfg["w_prefix"], oracle.CANONICAL, th)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, th, nd, ni)
+    dt, threads, nd, ni = best
     return {
         "value": nd / dt, "unit": "distinct k-mers/s", "cores": threads, "kind": "port",
         "sample": "%d x %d bp reads at 30x of a %d bp synthetic genome (%.2f Gbp), k=%d, wPrefix=%d; "
@@ -63,7 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=DEFAULT_READS, help="reads per GPU (default = 10 Gbp)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

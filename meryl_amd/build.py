@@ -15,7 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmeryl_gpu_count.so")
 SOURCES = ["mgc_kernels.hip", "mgc_api.cpp", "meryl_db.cpp"]
 HEADERS = ["mgc_device.h", "meryl_db.h", os.path.join("..", "..", "include", "meryl_gpu_count.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+# -no-hip-rt: the library carries no DT_NEEDED on a particular libamdhip64; it binds to the
+# HIP runtime already in the process (torch's bundled one under Python -- two HIP/HSA runtimes
+# in one process cannot share streams or ordering -- or /opt/rocm's for the standalone CLI).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-no-hip-rt",
          "-Wall", "-Wno-unused-function"]
 
 

@@ -24,6 +24,10 @@ SYMBOLS = (
     "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_count",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_version",
+    # include/meryl_db.h
+    "mdb_writer_open", "mdb_writer_add_block", "mdb_writer_close", "mdb_last_error",
+    "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_close",
+    "mdb_free", "mgc_write_database",
 )
 
 
@@ -103,6 +107,30 @@ def library_path():
     return _build.LIB
 
 
+def _load_hip_runtime():
+    """The native library is linked without a HIP runtime of its own (-no-hip-rt)
+    and binds to the one already in the process.  Under Python that must be the
+    runtime torch uses (its bundled libamdhip64.so), so that torch's device
+    pointers, streams and ordering are valid inside the library; without torch it
+    is /opt/rocm's."""
+    cands = []
+    try:
+        import torch  # noqa: F401  (loads its bundled ROCm runtime)
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    cands += [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so"), "libamdhip64.so"]
+    for c in cands:
+        if os.path.sep in c and not os.path.exists(c):
+            continue
+        try:
+            ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+            return c
+        except OSError:
+            continue
+    raise RuntimeError("no HIP runtime (libamdhip64.so) could be loaded; the count path has no CPU fallback")
+
+
 def lib():
     """The loaded C-ABI library.  Raises if it is not built -- by design."""
     global _lib
@@ -113,6 +141,7 @@ def lib():
         raise RuntimeError(
             "native library %s is missing: run `python -m meryl_amd.build` "
             "(there is no CPU fallback for the count path)" % path)
+    _load_hip_runtime()
     L = ctypes.CDLL(path)
     missing = [s for s in SYMBOLS if not hasattr(L, s)]
     if missing:
@@ -150,6 +179,17 @@ def lib():
     sig("mgc_finish", i32, vp, BLOCK_CB, vp, i32)
     sig("mgc_set_profiling", i32, vp, i32)
     sig("mgc_get_profile", i32, vp, P(Profile))
+    sig("mdb_writer_open", vp, ctypes.c_char_p, u32, u32)
+    sig("mdb_writer_add_block", i32, vp, u64, u64, vp, vp, vp)
+    sig("mdb_writer_close", i32, vp)
+    sig("mdb_last_error", ctypes.c_char_p)
+    sig("mdb_reader_open", vp, ctypes.c_char_p)
+    sig("mdb_reader_info", i32, vp, P(DbInfo))
+    sig("mdb_reader_histogram", i32, vp, vp, vp)
+    sig("mdb_reader_read_file", i32, vp, u32, P(vp), P(vp), P(vp), P(u64))
+    sig("mdb_reader_close", None, vp)
+    sig("mdb_free", None, vp)
+    sig("mgc_write_database", i32, vp, ctypes.c_char_p, i32)
     _lib = L
     return L
 

@@ -133,6 +133,9 @@ class Session:
                    self._h)
 
     def push_bases_device(self, t):
+        # the session runs on its own HIP stream: whatever produced `t` on torch's
+        # stream must be complete before mgc_count reads it
+        torch.cuda.current_stream().synchronize()
         self._keep.append(t)
         capi.check(capi.lib().mgc_push_bases_device(self._h, _ptr(t), t.numel()), "mgc_push_bases_device", self._h)
 

@@ -214,15 +214,30 @@ void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode,
   }
 }
 
-// Turns per-workgroup counts into per-workgroup absolute write cursors.
-__global__ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 *__restrict__ bucket_starts) {
-  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb) return;
-  u64 run = bucket_starts[b];
-  for (u32 g = 0; g < grid; g++) {
-    const u64 t = block_hist[(u64)g * nb + b];
-    block_hist[(u64)g * nb + b] = run;
-    run += t;
+// Turns per-workgroup counts into per-workgroup absolute write cursors
+// (one workgroup per bucket scans that bucket's column of block_hist).
+__global__ __launch_bounds__(256)
+void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 *__restrict__ bucket_starts) {
+  __shared__ u64 s_tmp[256 / 64 + 1];
+  const u32 b = blockIdx.x;
+  u64 carry = bucket_starts[b];
+  for (u32 base = 0; base < grid; base += 256 * 8) {
+    u64 v[8], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const u32 g = base + threadIdx.x * 8 + q;
+      v[q] = (g < grid) ? block_hist[(u64)g * nb + b] : 0ull;
+      sum += v[q];
+    }
+    u64 tot;
+    u64 run = carry + block_excl_scan<256, u64>(sum, s_tmp, &tot);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const u32 g = base + threadIdx.x * 8 + q;
+      if (g < grid) block_hist[(u64)g * nb + b] = run;
+      run += v[q];
+    }
+    carry += tot;
   }
 }
 
@@ -342,7 +357,7 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
   const uint32_t nb = 1u << bucket_bits;
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
   const uint32_t grid = kp_grid_size(n_bases);
-  hipLaunchKernelGGL(kmer_scan_kernel, dim3((nb + 255) / 256), dim3(256), 0, st,
+  hipLaunchKernelGGL(kmer_scan_kernel, dim3(nb), dim3(256), 0, st,
                      reinterpret_cast<u64 *>(d_ws), grid, nb, reinterpret_cast<const u64 *>(d_bucket_starts));
   MGC_CHECK(hipGetLastError());
   hipLaunchKernelGGL(kmer_partition_kernel, dim3(grid), dim3(KP_BLOCK), 0, st,

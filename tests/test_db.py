@@ -1,0 +1,163 @@
+"""CPU tests of the database writer/reader (host C++ behind include/meryl_db.h).
+
+What is checked: the structural facts the reference tree pins (64+64+1 files,
+names, master-index parameters, block header fields, uBits/bBits rule of
+documentation/source/usage.rst:13-45) via an INDEPENDENT pure-Python parser of
+the bytes, and a write -> read round trip against the oracle's counts.  The
+byte layout itself is a restatement of the absent meryl-utility writer and is
+PARITY UNPINNED (no reference-made database exists to diff against)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from helpers import random_reads
+
+
+class Bits:
+    """independent MSB-first bit reader over little-endian uint64 words"""
+
+    def __init__(self, words):
+        self.w = [int(x) for x in words]
+        self.pos = 0
+
+    def get(self, n):
+        v = 0
+        for _ in range(n):
+            word, off = divmod(self.pos, 64)
+            v = (v << 1) | ((self.w[word] >> (63 - off)) & 1)
+            self.pos += 1
+        return v
+
+    def unary(self):
+        v = 0
+        while self.get(1) == 0:
+            v += 1
+        return v
+
+
+def read_stuffed(f):
+    lenmax, nblocks, nmax = struct.unpack("<QII", f.read(16))
+    bgn = struct.unpack("<%dQ" % nblocks, f.read(8 * nblocks))
+    ln = struct.unpack("<%dQ" % nblocks, f.read(8 * nblocks))
+    words = []
+    for i in range(nblocks):
+        nw, nalloc = struct.unpack("<QQ", f.read(16))
+        assert nw == (ln[i] + 63) // 64 and nalloc == lenmax // 64
+        words += list(struct.unpack("<%dQ" % nw, f.read(8 * nw)))
+    return words, sum(ln)
+
+
+def make_db(tmp_path, oracle_lib, k, w_prefix, bases, name="db"):
+    from meryl_amd import db
+    hi, lo, cn, ni = oracle_lib.count_threaded(bases, k, w_prefix, threads=2)
+    keys = [(int(h) << 64) | int(l) for h, l in zip(hi, lo)]
+    w_data = 2 * k - w_prefix
+    path = str(tmp_path / name)
+    w = db.Writer(path, k, w_prefix)
+    by_prefix = {}
+    for key, c in zip(keys, cn):
+        by_prefix.setdefault(key >> w_data, []).append((key & ((1 << w_data) - 1), int(c)))
+    for p in range(1 << w_prefix):                       # addBlock for every prefix, empty ones too
+        items = by_prefix.get(p, [])
+        suf = [s for s, _ in items]
+        w.add_block(p, [s & 0xFFFFFFFFFFFFFFFF for s in suf], [c for _, c in items],
+                    [s >> 64 for s in suf] if w_data > 64 else None)
+    w.close()
+    return path, keys, [int(c) for c in cn], ni
+
+
+@pytest.mark.parametrize("k,wp", [(21, 10), (16, 12), (31, 10), (32, 11), (51, 10), (64, 12), (8, 10)])
+def test_roundtrip_and_structure(tmp_path, native_lib, oracle_lib, k, wp):
+    from meryl_amd import db
+    rng = np.random.default_rng(k)
+    bases = random_reads(rng, 150, 40, 300) + ("ACGT" * 50 + ".") * 5
+    path, keys, counts, ni = make_db(tmp_path, oracle_lib, k, wp, bases)
+
+    # structure: 64 data + 64 index + master (reference.rst:73-77), binary-digit names
+    names = sorted(os.listdir(path))
+    assert len(names) == 129 and "merylIndex" in names
+    assert "0x000000.merylData" in names and "0x111111.merylIndex" in names
+
+    # master index parameters (usage.rst:15-19), parsed independently
+    with open(os.path.join(path, "merylIndex"), "rb") as f:
+        words, nbits = read_stuffed(f)
+    b = Bits(words)
+    m1, m2 = b.get(64), b.get(64)
+    assert struct.pack("<Q", m1) == b"merylInd" and struct.pack("<Q", m2)[:6] == b"ex__v."
+    assert (b.get(32), b.get(32), b.get(32), b.get(32)) == (wp, 2 * k - wp, 6, wp - 6)
+    b.get(32)
+    n_unique, n_distinct, n_total, n_pairs = b.get(64), b.get(64), b.get(64), b.get(64)
+    assert n_distinct == len(keys) and n_total == ni == sum(counts)
+    assert n_unique == sum(1 for c in counts if c == 1)
+    hist = {b.get(64): b.get(64) for _ in range(n_pairs)}
+    vals, occ = np.unique(np.array(counts), return_counts=True)
+    assert hist == {int(v): int(o) for v, o in zip(vals, occ)}
+
+    # first data file: block headers (usage.rst:33-45) parsed independently
+    nblocks = 1 << (wp - 6)
+    with open(os.path.join(path, "0x000000.merylIndex"), "rb") as f:
+        idx = [struct.unpack("<QQQ", f.read(24)) for _ in range(nblocks)]
+    w_data = 2 * k - wp
+    got = []
+    with open(os.path.join(path, "0x000000.merylData"), "rb") as f:
+        for bp, pos, n in idx:
+            f.seek(pos)
+            words, _ = read_stuffed(f)
+            b = Bits(words + [0, 0])
+            assert struct.pack("<Q", b.get(64)) == b"merylDat" and struct.pack("<Q", b.get(64)) == b"aFile00\n"
+            prefix, nk = b.get(64), b.get(64)
+            kcode, ub, bb, k1, ccode, c1, c2 = b.get(8), b.get(32), b.get(32), b.get(64), b.get(8), b.get(64), b.get(64)
+            assert (prefix, nk) == (bp, n) and kcode == 1 and ccode == 1 and ub + bb == w_data
+            assert (1 << ub) >= max(nk, 1) and (ub == 0 or (1 << (ub - 1)) < nk)      # uBits = ceil(log2(nKmers))
+            top, sufs = 0, []
+            for _ in range(nk):
+                top += b.unary()
+                sufs.append((top << bb) | b.get(bb))
+            cnts = [b.get(32) for _ in range(nk)]
+            got += [((prefix << w_data) | s, c) for s, c in zip(sufs, cnts)]
+    want = [(key, c) for key, c in zip(keys, counts) if (key >> (2 * k - 6)) == 0]
+    assert got == want
+
+    # round trip through the C reader, all 64 files
+    r = db.Reader(path)
+    assert (r.info.k, r.info.prefix_size, r.info.suffix_size) == (k, wp, 2 * k - wp)
+    lo, hi, cn = r.read_all()
+    assert [(int(h) << 64) | int(l) for h, l in zip(hi, lo)] == keys
+    assert [int(c) for c in cn] == counts
+    hv, ho = r.histogram()
+    assert {int(v): int(o) for v, o in zip(hv, ho)} == hist
+    r.close()
+
+
+def test_usage_rst_header_example(tmp_path, native_lib):
+    # usage.rst:33-37: a block with nKmers=22363 and suffixSize=104 has uBits=15, bBits=89
+    from meryl_amd import db
+    k, wp = 57, 10
+    path = str(tmp_path / "hdr")
+    w = db.Writer(path, k, wp)
+    n = 22363
+    w.add_block(0, np.arange(n, dtype=np.uint64) * np.uint64(977), np.ones(n, dtype=np.uint32), np.zeros(n, dtype=np.uint64))
+    w.close()
+    with open(os.path.join(path, "0x000000.merylData"), "rb") as f:
+        words, _ = read_stuffed(f)
+    b = Bits(words)
+    b.get(64); b.get(64)
+    assert b.get(64) == 0 and b.get(64) == n
+    assert b.get(8) == 1 and (b.get(32), b.get(32)) == (15, 89)
+
+
+def test_writer_rejects_bad_use(tmp_path, native_lib):
+    from meryl_amd import db
+    with pytest.raises(db.DbError):
+        db.Writer(str(tmp_path / "x"), 21, 5)                 # prefix must cover the 6 file bits
+    w = db.Writer(str(tmp_path / "y"), 21, 10)
+    w.add_block(3, [1, 2], [1, 1])
+    with pytest.raises(db.DbError):
+        w.add_block(2, [1], [1])                              # ascending prefixes per file
+    with pytest.raises(db.DbError):
+        w.add_block(1 << 10, [1], [1])                        # prefix out of range
+    w.close()
+    with pytest.raises(db.DbError):
+        db.Reader(str(tmp_path / "nonexistent"))

@@ -244,3 +244,23 @@ def test_full_size_properties(ops, torch_cuda):
     pref = (keys >> np.uint64(cfg.w_data)).astype(np.int64)
     assert np.array_equal(np.searchsorted(pref, np.arange(cfg.n_prefix + 1)), bstart.astype(np.int64))
     assert sum(info.file_instances) == info.n_instances
+
+
+def test_write_database_roundtrip(ops, oracle_lib, torch_cuda, tmp_path):
+    # count on the GPU -> 64-file database on disk -> read back == oracle stream
+    from meryl_amd import capi, db
+    bases = oracle_lib.synth_reads(6, 100_000, 0, 8000)
+    cfg = capi.configure(21, bases.size, 1 << 30)
+    d = torch_cuda.from_numpy(bases).cuda()
+    path = str(tmp_path / "gpu.meryl")
+    with ops.Session(cfg) as s:
+        s.push_bases_device(d)
+        s.count()
+        db.write_database(s, path, host_threads=8)
+    assert len(os.listdir(path)) == 129
+    r = db.Reader(path)
+    lo, hi, cn = r.read_all()
+    _, wlo, wcn, wni = oracle_lib.count_brute(bases.tobytes(), 21)
+    assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn) and not hi.any()
+    assert r.info.num_total == wni and r.info.num_distinct == len(wlo) and r.info.prefix_size == cfg.w_prefix
+    r.close()
