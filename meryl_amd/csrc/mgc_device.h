@@ -31,6 +31,9 @@ struct SortPlan {
   uint32_t kpt;             // keys per thread
   uint32_t tile;            // block*kpt
   uint32_t mode;            // 0 = onesweep (decoupled look-back), 1 = classic (tile histogram + scan)
+  uint32_t match;           // 0 = ballot match, 1 = LDS mask match (ranking inside a wave)
+  uint32_t lookback;        // 1 = walk before the LDS exchange, 2 = window after it
+  uint32_t flags;           // bit1: non-temporal key loads (experiments)
   uint32_t num_passes;
   uint32_t pass_shift[16];
   uint32_t pass_bits[16];

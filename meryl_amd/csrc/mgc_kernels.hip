@@ -386,7 +386,6 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
 
 constexpr int      RS_MAX_PASSES = 16;
 constexpr int      RS_MAX_RADIX  = 512;
-constexpr u64      ST_VALUE_MASK = (1ull << 48) - 1;
 constexpr u32      RS_SPIN_LIMIT = 1u << 24;
 
 struct SortHeader {                       // lives at the start of the sort workspace
@@ -453,28 +452,49 @@ __device__ __forceinline__ u64 status_load(u64 *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int RB, int BLOCK, int KPT>
+// Look-back status granule: one 8-byte word carries TWO digits, each as
+// flag(2) | value(30); flag 1 = tile aggregate, 2 = inclusive prefix.  Half as many
+// fabric transactions as one granule per digit, and a digit pair is published by one
+// store, so no fence is needed (the datum is the flag).  Values < 2^30: the look-back
+// path handles n < 2^30 keys per sort call, larger calls take the classic path.
+__device__ __forceinline__ u64 st_pack(u32 f0, u32 v0, u32 f1, u32 v1) {
+  return ((u64)((f1 << 30) | v1) << 32) | (u64)((f0 << 30) | v0);
+}
+
+typedef __attribute__((address_space(3))) u64 lds_u64;
+typedef __attribute__((address_space(3))) u32 lds_u32;
+
+template <int RB, int BLOCK, int KPT, int LB = 0>
 struct RadixSmem {
   static constexpr int R     = 1 << RB;
   static constexpr int NW    = BLOCK / 64;
   static constexpr int TILE  = BLOCK * KPT;
-  // region 0 is shared between the wave histograms (ranking) and the key exchange
-  static constexpr size_t REGION0 = ((size_t)TILE * 8 > (size_t)NW * R * 4) ? (size_t)TILE * 8 : (size_t)NW * R * 4;
-  static constexpr size_t OFF_GBASE = REGION0;                 // u64[R]
+  // region 0 is shared between the ranking scratch (wave digit counters u32[NW][R] followed by
+  // wave match masks u64[NW][R]) and the key exchange buffer
+  static constexpr size_t RANK_BYTES = (size_t)NW * R * 12;
+  static constexpr size_t REGION0 = ((size_t)TILE * 8 > RANK_BYTES) ? (size_t)TILE * 8 : RANK_BYTES;
+  static constexpr size_t OFF_GBASE = REGION0;                     // u64[R]
   static constexpr size_t OFF_DBASE = OFF_GBASE + (size_t)R * 8;   // u32[R]
-  static constexpr size_t OFF_TMP   = OFF_DBASE + (size_t)R * 4;   // u32[NW+1] scan scratch + misc
-  static constexpr size_t BYTES     = OFF_TMP + 64 * 4;
+  static constexpr size_t OFF_CNT   = OFF_DBASE + (size_t)R * 4;   // u32[R]
+  static constexpr size_t OFF_TMP   = OFF_CNT + (size_t)R * 4;     // u32[64] scan scratch + misc
+  static constexpr size_t OFF_WIN   = OFF_TMP + 64 * 4;            // u64[LB_WINDOW][R/2] look-back window (LB == 2)
+  static constexpr size_t WIN_BYTES = (LB == 2) ? ((RB == 9 && BLOCK == 512) ? 4096 : 8192) : 0;
+  static constexpr size_t BYTES     = OFF_WIN + WIN_BYTES;
+  // workgroups per CU the LDS budget admits (160 KiB per CU), capped at 2
+  static constexpr int    WG_PER_CU = (2 * BYTES <= 160 * 1024) ? 2 : 1;
+  static constexpr int    MIN_WAVES_PER_SIMD = (WG_PER_CU * BLOCK) / 256;
 };
 
-template <int RB, int BLOCK, int KPT, bool LOOKBACK>
-__global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256)     // two workgroups per CU (LDS allows it): <= 128 VGPRs
+template <int RB, int BLOCK, int KPT, int LB, int MATCH>
+__global__ __launch_bounds__(BLOCK, (RadixSmem<RB, BLOCK, KPT, LB>::MIN_WAVES_PER_SIMD))
 void radix_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 n, u32 shift, u32 dmask,
                           const u64 *__restrict__ gbase,      // LOOKBACK: exclusive digit bases of this pass
-                          u64 *__restrict__ status,           // LOOKBACK: [num_tiles][R] granules
-                          u32 *__restrict__ ticket, u32 epoch, u32 *__restrict__ error_flag,
+                          u64 *__restrict__ status,           // LOOKBACK: [num_tiles][R/2] granules of this pass (zeroed)
+                          u32 *__restrict__ ticket, u32 *__restrict__ error_flag,
+                          u32 flags,                          // bit0: XCD-chunked tile order, bit1: non-temporal key loads
                           const u64 *__restrict__ tile_offs,  // !LOOKBACK: [R][num_tiles] absolute offsets
                           u64 num_tiles) {
-  using SM = RadixSmem<RB, BLOCK, KPT>;
+  using SM = RadixSmem<RB, BLOCK, KPT, LB>;
   constexpr int R = SM::R, NW = SM::NW, TILE = SM::TILE;
   static_assert(BLOCK >= R, "one thread per digit needed");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -482,12 +502,14 @@ void radix_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64
   u32 *s_whist = reinterpret_cast<u32 *>(smem);                       // aliases s_keys (see barriers)
   u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
   u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
+  u32 *s_cnt   = reinterpret_cast<u32 *>(smem + SM::OFF_CNT);
   u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
 
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
 
-  // Tile id: a ticket guarantees that every lower-numbered tile has started,
-  // hence is resident and will publish -- the look-back cannot deadlock.
+  constexpr bool LOOKBACK = (LB != 0);
+  // Tile ids are tickets: every lower-numbered tile has started, hence is resident and will
+  // publish its aggregate -- the look-back cannot deadlock (spins are bounded anyway).
   u64 tile;
   if (LOOKBACK) {
     if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
@@ -497,7 +519,7 @@ void radix_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64
     tile = blockIdx.x;
   }
 
-  for (u32 i = tid; i < (u32)(NW * R); i += BLOCK) s_whist[i] = 0;
+  for (u32 i = tid; i < (u32)(NW * R * 3); i += BLOCK) s_whist[i] = 0;   // counters + match masks
   __syncthreads();
 
   // ---- load (wave-striped: 512 contiguous bytes per wave instruction) ----
@@ -508,25 +530,52 @@ void radix_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64
 #pragma unroll
   for (int j = 0; j < KPT; j++) {
     const u64 idx = wave_base + (u64)j * 64;
-    keys[j] = (full || idx < n) ? in[idx] : ~0ull;    // padding sorts to the end of the last digit
+    keys[j] = (full || idx < n) ? ((flags & 2u) ? __builtin_nontemporal_load(in + idx) : in[idx])
+                                : ~0ull;               // padding sorts to the end of the last digit
   }
 
-  // ---- rank inside the wave ----
-  volatile u32 *wh = s_whist + w * R;
+  // ---- rank inside the wave (stable: by lane order inside a row, rows in order) ----
   const u64 lt_mask = (1ull << lane) - 1ull;
-  u32 ranks[KPT];
+  u32 ranks[KPT / 2];                                  // two 16-bit ranks per register (rank < TILE <= 2^14)
+  if (MATCH == 0) {
+    // peers by RB ballots per key: data-independent cost, VALU heavy
+    lds_u32 *wh = (lds_u32 *)(smem) + w * R;
 #pragma unroll
-  for (int j = 0; j < KPT; j++) {
-    const u32 d     = (u32)(keys[j] >> shift) & dmask;
-    const u64 peers = match_digit<RB>(d);
-    const u32 lower = __popcll(peers & lt_mask);
-    const u32 base  = wh[d];                           // every peer reads the same word (broadcast)
-    if (lower == 0) wh[d] = base + (u32)__popcll(peers);   // leader bumps it after the wave's read
-    ranks[j] = base + lower;
+    for (int j = 0; j < KPT; j++) {
+      const u32 d     = (u32)(keys[j] >> shift) & dmask;
+      const u64 peers = match_digit<RB>(d);
+      const u32 lower = __popcll(peers & lt_mask);
+      const u32 base  = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (lower == 0) __hip_atomic_store(&wh[d], base + (u32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (j & 1) ranks[j / 2] |= (base + lower) << 16;
+      else       ranks[j / 2]  = (base + lower);
+    }
+  } else {
+    // peers through a wave-private LDS mask per digit: every lane ORs its lane bit into
+    // mask[digit], reads the mask back (LDS executes a wave's instructions in order), and the
+    // lowest peer bumps the running digit counter and clears the mask for the next row.
+    lds_u32 *wh = (lds_u32 *)(smem) + w * R;
+    lds_u64 *mk = (lds_u64 *)(smem + (size_t)NW * R * 4) + w * R;
+    const u64 lane_bit = 1ull << lane;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 d = (u32)(keys[j] >> shift) & dmask;
+      __hip_atomic_fetch_or(&mk[d], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u64 peers = __hip_atomic_load(&mk[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u32 base  = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u32 lower = __popcll(peers & lt_mask);
+      if (lower == 0) {
+        __hip_atomic_store(&wh[d], base + (u32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_store(&mk[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      if (j & 1) ranks[j / 2] |= (base + lower) << 16;
+      else       ranks[j / 2]  = (base + lower);
+    }
   }
   __syncthreads();
 
   // ---- digit totals of the tile, wave-exclusive bases ----
+  const u32 n_valid = full ? (u32)TILE : (u32)(n - tile_base);
   u32 count = 0;
   if (tid < (u32)R) {
     u32 acc = 0;
@@ -537,59 +586,143 @@ void radix_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64
       acc += t;
     }
     count = acc;
+    // padding keys all carry the top digit; they are not published to later tiles
+    s_cnt[tid] = (tid == dmask) ? count - ((u32)TILE - n_valid) : count;
   }
   u32 tile_total;
   const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tile_total);
   if (tid < (u32)R) s_dbase[tid] = excl;
 
-  const u32 n_valid = full ? (u32)TILE : (u32)(n - tile_base);
-
-  if (tid < (u32)R) {
-    u64 g;
-    if (LOOKBACK) {
-      // padding keys all carry the top digit; do not publish them
-      const u32 pub = (tid == dmask) ? count - ((u32)TILE - n_valid) : count;
-      const u64 ep  = (u64)(epoch & 0x3FFFu) << 48;
-      u64 prev = 0;
-      if (tile == 0) {
-        status_store(&status[tid], (2ull << 62) | ep | (u64)pub);
-      } else {
-        status_store(&status[tile * R + tid], (1ull << 62) | ep | (u64)pub);
-        u64 t = tile - 1;
-        while (true) {
-          u64 wv;
-          u32 spins = 0;
-          while (true) {
-            wv = status_load(&status[t * R + tid]);
-            if (((wv >> 48) & 0x3FFFull) == (u64)(epoch & 0x3FFFu) && (wv >> 62) != 0ull) break;
-            if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); wv = (2ull << 62); break; }
-            __builtin_amdgcn_s_sleep(1);
+  // granules of this tile: publish the aggregate as early as possible
+  constexpr int G = R / 2;                              // granules per tile (two digits each)
+  u64 *mine = status + (LOOKBACK ? tile * (u64)G + tid : 0);
+  if (LOOKBACK) {
+    __syncthreads();                                    // s_cnt / s_dbase visible
+    if (tid < (u32)G) {
+      const u32 c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+      status_store(mine, (tile == 0) ? st_pack(2, c0, 2, c1) : st_pack(1, c0, 1, c1));
+      if constexpr (LB == 1) {
+        // serial walk per digit pair, four predecessors in flight per round
+        u32 p0 = 0, p1 = 0;
+        if (tile != 0) {
+          bool need0 = true, need1 = true;
+          u64  t = tile - 1;
+          u32  spins = 0;
+          while (need0 || need1) {
+            u64 g[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              g[i] = (t >= (u64)i) ? status_load(status + (t - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
+            u32 used = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              if (need0 || need1) {
+                const u32 lo = (u32)g[i], hi = (u32)(g[i] >> 32);
+                const u32 f0 = lo >> 30, f1 = hi >> 30;
+                if (f0 == 0 || f1 == 0) break;
+                if (need0) { p0 += lo & 0x3FFFFFFFu; if (f0 == 2) need0 = false; }
+                if (need1) { p1 += hi & 0x3FFFFFFFu; if (f1 == 2) need1 = false; }
+                used++;
+              }
+            }
+            t -= (used <= t) ? used : t;
+            if (used == 0) {
+              if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); break; }
+              __builtin_amdgcn_s_sleep(1);
+            }
           }
-          prev += wv & ST_VALUE_MASK;
-          if ((wv >> 62) == 2ull) break;
-          t--;
+          status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
         }
-        status_store(&status[tile * R + tid], (2ull << 62) | ep | (prev + (u64)pub));
+        s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
+        s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
       }
-      g = gbase[tid] + prev;
-    } else {
-      g = tile_offs[(u64)tid * num_tiles + tile];
     }
-    s_gbase[tid] = g - (u64)excl;          // so that out index = s_gbase[d] + position in sorted tile
+    if (LB == 1) __syncthreads();
+  } else {
+    if (tid < (u32)R) s_gbase[tid] = tile_offs[(u64)tid * num_tiles + tile] - (u64)excl;
+    __syncthreads();
   }
-  __syncthreads();
 
   // ---- final position of every key inside the sorted tile ----
-  u32 pos[KPT];
 #pragma unroll
-  for (int j = 0; j < KPT; j++) {
+  for (int j = 0; j < KPT; j++) {           // ranks[] becomes positions in place (still < TILE)
     const u32 d = (u32)(keys[j] >> shift) & dmask;
-    pos[j] = s_dbase[d] + s_whist[w * R + d] + ranks[j];
+    const u32 add = s_dbase[d] + s_whist[w * R + d];
+    ranks[j / 2] += (j & 1) ? (add << 16) : add;
   }
   __syncthreads();                          // s_whist is dead; its storage becomes s_keys
 #pragma unroll
-  for (int j = 0; j < KPT; j++) s_keys[pos[j]] = keys[j];
-  __syncthreads();
+  for (int j = 0; j < KPT; j++) s_keys[(j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu)] = keys[j];
+  __syncthreads();                          // keys now live in LDS only: registers are free for the look-back
+
+  if constexpr (LB == 2) {
+    // window-parallel look-back after the exchange (keys live in LDS only, registers are free):
+    // all waves fetch the granules of the next LB_WINDOW predecessors with coalesced loads into
+    // LDS, the R/2 digit-pair threads consume the ready prefix.
+    constexpr int TPL = BLOCK / G;                      // predecessor tiles covered by one load per thread
+    constexpr int WIN0 = (int)(SM::WIN_BYTES / ((size_t)G * 8));
+    constexpr int LB_WINDOW = (WIN0 < TPL) ? TPL : WIN0;
+    constexpr int LPT = LB_WINDOW / TPL;
+    static_assert(LB_WINDOW % TPL == 0 && LPT >= 1, "window must be a multiple of the tiles one load covers");
+    static_assert((size_t)LB_WINDOW * G * 8 <= SM::WIN_BYTES, "look-back window does not fit");
+    u64 *s_win = reinterpret_cast<u64 *>(smem + SM::OFF_WIN);
+    u32 *s_q   = s_tmp + 40;
+    u32 *s_all = s_tmp + 41;
+    u32 c0 = 0, c1 = 0, p0 = 0, p1 = 0;
+    bool need0 = false, need1 = false;
+    if (tid < (u32)G) {
+      c0 = s_cnt[2 * tid]; c1 = s_cnt[2 * tid + 1];
+      need0 = need1 = (tile != 0);
+    }
+    if (tile != 0) {                                    // uniform
+      const u32 sub = tid / G, g = tid % G;
+      u64 t_next = tile - 1;
+      u32 spins = 0;
+      while (true) {
+#pragma unroll
+        for (int i = 0; i < LPT; i++) {
+          const u32 idx = sub + (u32)(TPL * i);
+          s_win[idx * G + g] = (t_next >= (u64)idx) ? status_load(status + (t_next - idx) * (u64)G + g)
+                                                    : st_pack(2, 0, 2, 0);
+        }
+        if (tid == 0) { *s_q = LB_WINDOW; *s_all = 1u; }
+        __syncthreads();
+        if (tid < (u32)G) {
+          u32 q = 0;
+          for (; q < (u32)LB_WINDOW; q++) {
+            const u64 v = s_win[q * G + tid];
+            if (((u32)v >> 30) == 0u || ((u32)(v >> 62)) == 0u) break;
+          }
+          if (q < (u32)LB_WINDOW) atomicMin(s_q, q);
+        }
+        __syncthreads();
+        const u32 q = *s_q;
+        if (tid < (u32)G) {
+          for (u32 i = 0; i < q && (need0 || need1); i++) {
+            const u64 v = s_win[i * G + tid];
+            const u32 lo = (u32)v, hi = (u32)(v >> 32);
+            if (need0) { p0 += lo & 0x3FFFFFFFu; if ((lo >> 30) == 2u) need0 = false; }
+            if (need1) { p1 += hi & 0x3FFFFFFFu; if ((hi >> 30) == 2u) need1 = false; }
+          }
+          if (need0 || need1) *s_all = 0u;
+        }
+        __syncthreads();
+        if (*s_all) break;
+        t_next -= (q <= t_next) ? q : t_next;
+        if (q == 0) {
+          if (++spins > RS_SPIN_LIMIT) { if (tid == 0) atomicExch(error_flag, 1u); break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+      }
+    }
+    if (tid < (u32)G) {
+      if (tile != 0) status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
+      s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
+      s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
+    }
+    __syncthreads();
+  }
 
   // ---- contiguous runs leave coalesced ----
 #pragma unroll
@@ -662,16 +795,24 @@ static int env_int(const char *name, int dflt) {
 
 void make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan) {
   memset(plan, 0, sizeof(*plan));
-  int rb   = env_int("MGC_RADIX_BITS", 8);
-  int mode = env_int("MGC_SORT_MODE", 0);
-  int kpt  = env_int("MGC_SORT_KPT", 16);
+  // defaults = the fastest measured combination on MI355X (profiles/r01 notes in DESIGN.md):
+  // 9-bit digits, one 1024-thread workgroup per CU with 16 keys per thread (16384-key tiles),
+  // LDS-mask ranking, window look-back after the exchange
+  int rb    = env_int("MGC_RADIX_BITS", 9);
+  int mode  = env_int("MGC_SORT_MODE", 0);
+  int kpt   = env_int("MGC_SORT_KPT", 16);
+  int block = env_int("MGC_SORT_BLOCK", 1024);
   if (rb != 8 && rb != 9) rb = 8;
   if (kpt != 8 && kpt != 16) kpt = 16;
+  if (block != 512 && block != 1024) block = 512;
   plan->radix_bits = (uint32_t)rb;
-  plan->block      = 512;
+  plan->block      = (uint32_t)block;
   plan->kpt        = (uint32_t)kpt;
   plan->tile       = plan->block * plan->kpt;
   plan->mode       = mode ? 1u : 0u;
+  plan->match      = env_int("MGC_SORT_MATCH", 1) ? 1u : 0u;
+  plan->lookback   = (env_int("MGC_SORT_LB", 2) == 2) ? 2u : 1u;
+  plan->flags      = (uint32_t)env_int("MGC_SORT_FLAGS", 0);
   const uint32_t nbits = (end_bit > begin_bit) ? end_bit - begin_bit : 0;
   uint32_t passes = (nbits + rb - 1) / rb;
   if (passes > RS_MAX_PASSES) passes = RS_MAX_PASSES;
@@ -688,40 +829,39 @@ void make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan) {
 static inline uint64_t max_tiles_for(uint64_t n) { return (n + 4095) / 4096 + 1; }   // tile >= 4096 keys
 
 size_t sort_workspace_bytes(uint64_t n) {
-  // header + the larger of {onesweep status granules, classic tile_hist + tile_offs}
+  // header + the larger of {look-back granules (one pass at a time), classic tile_hist + tile_offs}
   const uint64_t t = max_tiles_for(n);
   return sizeof(SortHeader) + 1024 + (size_t)t * RS_MAX_RADIX * (sizeof(uint32_t) + sizeof(uint64_t));
 }
 
-template <int RB, int BLOCK, int KPT>
+template <int RB, int BLOCK, int KPT, int MATCH, int LBK>
 static hipError_t run_passes(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, const SortPlan &plan, void *d_ws,
                              uint32_t *d_error, int *result_in_alt, hipStream_t st, hipEvent_t *pass_events) {
-  using SM = RadixSmem<RB, BLOCK, KPT>;
+  using SM  = RadixSmem<RB, BLOCK, KPT, LBK>;
+  using SM0 = RadixSmem<RB, BLOCK, KPT, 0>;
   constexpr int R = 1 << RB, TILE = BLOCK * KPT;
   SortHeader *hdr = reinterpret_cast<SortHeader *>(d_ws);
   unsigned char *body = reinterpret_cast<unsigned char *>(d_ws) + ((sizeof(SortHeader) + 255) / 256) * 256;
   const uint64_t num_tiles = (n + TILE - 1) / TILE;
 
-  static bool attr_done_a = false, attr_done_b = false;
-  if (!attr_done_a) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<RB, BLOCK, KPT, true>),
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<RB, BLOCK, KPT, LBK, MATCH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::BYTES);
-    attr_done_a = true;
-  }
-  if (!attr_done_b) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<RB, BLOCK, KPT, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::BYTES);
-    attr_done_b = true;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<RB, BLOCK, KPT, 0, MATCH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM0::BYTES);
+    attr_done = true;
   }
 
   u64 *src = reinterpret_cast<u64 *>(d_keys), *dst = reinterpret_cast<u64 *>(d_alt);
   int in_alt = 0;
+  // look-back granules hold 30-bit values: larger calls take the classic path
+  const bool lookback = (plan.mode == 0) && (n < (1ull << 30));
 
-  if (plan.mode == 0) {
-    // ---- onesweep ----
+  if (lookback) {
     u64 *status = reinterpret_cast<u64 *>(body);
+    const size_t status_bytes = (size_t)num_tiles * (R / 2) * sizeof(u64);
     MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
-    MGC_CHECK(hipMemsetAsync(status, 0, (size_t)num_tiles * R * sizeof(u64), st));
     PassList pl;
     pl.n = plan.num_passes;
     for (uint32_t p = 0; p < plan.num_passes; p++) {
@@ -736,10 +876,11 @@ static hipError_t run_passes(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, cons
                        &hdr->ghist[0][0], &hdr->gbase[0][0]);
     MGC_CHECK(hipGetLastError());
     for (uint32_t p = 0; p < plan.num_passes; p++) {
+      MGC_CHECK(hipMemsetAsync(status, 0, status_bytes, st));
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
-      hipLaunchKernelGGL((radix_scatter_kernel<RB, BLOCK, KPT, true>), dim3((uint32_t)num_tiles), dim3(BLOCK),
-                         SM::BYTES, st, src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
-                         &hdr->gbase[p][0], status, &hdr->ticket[p], p + 1, d_error,
+      hipLaunchKernelGGL((radix_scatter_kernel<RB, BLOCK, KPT, LBK, MATCH>), dim3((uint32_t)num_tiles),
+                         dim3(BLOCK), SM::BYTES, st, src, dst, (u64)n, plan.pass_shift[p],
+                         (1u << plan.pass_bits[p]) - 1u, &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, plan.flags,
                          (const u64 *)nullptr, (u64)num_tiles);
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
@@ -761,9 +902,9 @@ static hipError_t run_passes(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, cons
                          tile_offs, &hdr->row_total[0], (u32)R, (u64)num_tiles);
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
-      hipLaunchKernelGGL((radix_scatter_kernel<RB, BLOCK, KPT, false>), dim3((uint32_t)num_tiles), dim3(BLOCK),
-                         SM::BYTES, st, src, dst, (u64)n, shift, dmask, (const u64 *)nullptr, (u64 *)nullptr,
-                         (u32 *)nullptr, 0u, d_error, tile_offs, (u64)num_tiles);
+      hipLaunchKernelGGL((radix_scatter_kernel<RB, BLOCK, KPT, 0, MATCH>), dim3((uint32_t)num_tiles), dim3(BLOCK),
+                         SM0::BYTES, st, src, dst, (u64)n, shift, dmask, (const u64 *)nullptr, (u64 *)nullptr,
+                         (u32 *)nullptr, d_error, plan.flags, tile_offs, (u64)num_tiles);
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
       u64 *t = src; src = dst; dst = t; in_alt ^= 1;
@@ -779,12 +920,25 @@ hipError_t launch_radix_sort(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, cons
   *result_in_alt = 0;
   if (n == 0 || plan.num_passes == 0) return hipSuccess;
   if (ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
+#define MGC_RUN(RB_, BLOCK_, KPT_)                                                                              \
+  do {                                                                                                       \
+    if (plan.match == 0)                                                                                     \
+      return run_passes<RB_, BLOCK_, KPT_, 0, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+    if (plan.lookback == 2)                                                                                  \
+      return run_passes<RB_, BLOCK_, KPT_, 1, 2>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+    return run_passes<RB_, BLOCK_, KPT_, 1, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);   \
+  } while (0)
   if (plan.radix_bits == 9) {
-    if (plan.kpt == 8) return run_passes<9, 512, 8>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);
-    return run_passes<9, 512, 16>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);
+    if (plan.block == 1024 && plan.kpt == 8) MGC_RUN(9, 1024, 8);
+    if (plan.block == 1024) MGC_RUN(9, 1024, 16);
+    if (plan.kpt == 8) MGC_RUN(9, 512, 8);
+    MGC_RUN(9, 512, 16);
   }
-  if (plan.kpt == 8) return run_passes<8, 512, 8>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);
-  return run_passes<8, 512, 16>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);
+  if (plan.block == 1024 && plan.kpt == 8) MGC_RUN(8, 1024, 8);
+  if (plan.block == 1024) MGC_RUN(8, 1024, 16);
+  if (plan.kpt == 8) MGC_RUN(8, 512, 8);
+  MGC_RUN(8, 512, 16);
+#undef MGC_RUN
 }
 
 // ============================================================================

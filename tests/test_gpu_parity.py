@@ -95,15 +95,22 @@ def test_radix_sort_matches_numpy(ops, torch_cuda, n, bits, monkeypatch):
     lo, hi = bits
     a = rng.integers(0, 2**63, size=n, dtype=np.int64).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n).astype(np.uint64)
     mask = np.uint64(((1 << (hi - lo)) - 1) << lo) if hi - lo < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
-    for mode in ("0", "1"):                                      # onesweep and classic
-        for rb in ("8", "9"):
-            monkeypatch.setenv("MGC_SORT_MODE", mode)
-            monkeypatch.setenv("MGC_RADIX_BITS", rb)
-            t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
-            out = _as_u64(ops.dev_radix_sort(t, lo, hi))
-            # stable sort on the selected bits == numpy stable argsort on the masked key
-            order = np.argsort((a & mask) >> np.uint64(lo), kind="stable")
-            assert np.array_equal(out, a[order]), (n, bits, mode, rb)
+    # stable sort on the selected bits == numpy stable argsort on the masked key
+    want = a[np.argsort((a & mask) >> np.uint64(lo), kind="stable")]
+    # every kernel variant: look-back / classic, 8 / 9-bit digits, ballot / LDS-mask ranking, tile shapes
+    for mode, rb, match, kpt, block, lb in [("0", "8", "1", "16", "512", "1"), ("0", "9", "1", "16", "512", "2"),
+                                            ("1", "8", "1", "16", "512", "1"), ("1", "9", "0", "16", "512", "1"),
+                                            ("0", "8", "0", "16", "512", "1"), ("0", "8", "1", "8", "512", "2"),
+                                            ("0", "8", "1", "16", "1024", "2"), ("0", "9", "1", "16", "1024", "1")]:
+        monkeypatch.setenv("MGC_SORT_LB", lb)
+        monkeypatch.setenv("MGC_SORT_MODE", mode)
+        monkeypatch.setenv("MGC_RADIX_BITS", rb)
+        monkeypatch.setenv("MGC_SORT_MATCH", match)
+        monkeypatch.setenv("MGC_SORT_KPT", kpt)
+        monkeypatch.setenv("MGC_SORT_BLOCK", block)
+        t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
+        out = _as_u64(ops.dev_radix_sort(t, lo, hi))
+        assert np.array_equal(out, want), (n, bits, mode, rb, match, kpt, block, lb)
 
 
 def test_radix_sort_skewed_digits(ops, torch_cuda):
@@ -112,9 +119,12 @@ def test_radix_sort_skewed_digits(ops, torch_cuda):
     for a in (np.zeros(n, np.uint64), np.full(n, 0xFFFFFFFFFFFFFFFF, np.uint64),
               np.arange(n, dtype=np.uint64), np.arange(n, dtype=np.uint64)[::-1].copy(),
               (np.arange(n, dtype=np.uint64) % np.uint64(2)) << np.uint64(35)):
-        t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
-        out = _as_u64(ops.dev_radix_sort(t, 0, 64))
-        assert np.array_equal(out, np.sort(a, kind="stable"))
+        for match in ("0", "1"):
+            os.environ["MGC_SORT_MATCH"] = match
+            t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
+            out = _as_u64(ops.dev_radix_sort(t, 0, 64))
+            assert np.array_equal(out, np.sort(a, kind="stable"))
+        os.environ.pop("MGC_SORT_MATCH", None)
 
 
 @pytest.mark.parametrize("n,card", [(0, 1), (1, 1), (5000, 1), (5000, 5000), (300_001, 1000), (1_000_000, 50_000)])
