@@ -60,7 +60,7 @@ extern "C" {
  * ---------------------------------------------------------------------- */
 typedef struct mgc_count_config {
   /* in */
-  uint32_t k;                     /* kmerTiny::merSize(), 1..64 (this build computes k <= 32) */
+  uint32_t k;                     /* kmerTiny::merSize(), 1..64 */
   int32_t  mode;                  /* MGC_MODE_* */
   uint64_t n_kmers_estimate;      /* n= / guesstimateNumberOfkmersInInput (:317,449) */
   uint64_t memory_allowed;        /* memory= in bytes (merylCommandBuilder.C:299-302) */
@@ -88,7 +88,9 @@ int mgc_format_configured_line(const mgc_count_config *cfg, char *buf, size_t bu
  * hot path: the HIP kernels that replace insertKmers (merylOp-countThreads.C:
  * 235-280), merylCountArray::add/get (merylCountArray.C:490-847) and
  * countSingleKmers (merylCountArray.C:323-365).  Keys are full k-mers
- * (prefix<<wData | suffix) as uint64, k <= 32.
+ * (prefix<<wData | suffix): uint64 for k <= 32 (key_words = 1), 16-byte
+ * little-endian {lo, hi} pairs for k in 33..64 (key_words = 2) -- the same
+ * 128-bit kmdata the reference uses (src/tests/merylCountArrayTest.C:27-31).
  * ---------------------------------------------------------------------- */
 
 /* Number of partition buckets is 2^bucket_bits, bucket = key >> (2k-bucket_bits);
@@ -115,31 +117,31 @@ int mgc_dev_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k,
  * Order inside a bucket is unspecified (the sort follows). */
 int mgc_dev_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                            uint32_t bucket_bits, const uint64_t *d_bucket_starts,
-                           uint64_t *d_keys, void *d_workspace, size_t workspace_bytes, void *stream);
+                           void *d_keys, void *d_workspace, size_t workspace_bytes, void *stream);
 
-/* LSB radix sort of uint64 keys on bits [begin_bit, end_bit).  Ping-pongs
- * between d_keys and d_alt (both n keys); *result_in_alt tells where the
- * sorted keys ended up. */
+/* LSB radix sort of keys (key_words 1 or 2) on bits [begin_bit, end_bit).
+ * Ping-pongs between d_keys and d_alt (both n keys); *result_in_alt tells
+ * where the sorted keys ended up. */
 size_t mgc_dev_sort_workspace_bytes(uint64_t n);
-int mgc_dev_radix_sort_u64(uint64_t *d_keys, uint64_t *d_alt, uint64_t n,
-                           uint32_t begin_bit, uint32_t end_bit,
-                           void *d_workspace, size_t workspace_bytes,
-                           int *result_in_alt, void *stream);
+int mgc_dev_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words,
+                       uint32_t begin_bit, uint32_t end_bit,
+                       void *d_workspace, size_t workspace_bytes,
+                       int *result_in_alt, void *stream);
 
 /* Run-length count of a sorted key array (countSingleKmers' two passes,
  * merylCountArray.C:334-358).  Step 1 returns the number of distinct keys
  * (synchronises the stream); step 2 writes d_unique[n_distinct] and
  * d_counts[n_distinct] (uint32, wraps mod 2^32 like merylCountArray.C:357). */
 size_t mgc_dev_rle_workspace_bytes(uint64_t n);
-int mgc_dev_rle_count(const uint64_t *d_sorted, uint64_t n, void *d_workspace, size_t workspace_bytes,
-                      uint64_t *n_distinct, void *stream);
-int mgc_dev_rle_emit(const uint64_t *d_sorted, uint64_t n, void *d_workspace, size_t workspace_bytes,
-                     uint64_t *d_unique, uint32_t *d_counts, void *stream);
+int mgc_dev_rle_count(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_workspace,
+                      size_t workspace_bytes, uint64_t *n_distinct, void *stream);
+int mgc_dev_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_workspace,
+                     size_t workspace_bytes, void *d_unique, uint32_t *d_counts, void *stream);
 
 /* d_block_start[p] = index of the first distinct key with (key >> w_data) >= p,
  * for p in [0, n_prefix]; block p of the database is
  * [d_block_start[p], d_block_start[p+1]) -- the (prefix, nKmers) of addBlock. */
-int mgc_dev_block_offsets(const uint64_t *d_unique, uint64_t n_distinct, uint32_t w_data,
+int mgc_dev_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,
                           uint64_t n_prefix, uint64_t *d_block_start, void *stream);
 
 /* ------------------------------------------------------------------------
@@ -179,12 +181,14 @@ typedef struct mgc_result_info {
 int mgc_get_result_info(const mgc_session *s, mgc_result_info *info);
 
 /* Device views of the result (valid until mgc_close / the next mgc_count). */
-int mgc_get_result_device(const mgc_session *s, const uint64_t **d_unique, const uint32_t **d_counts,
-                          const uint64_t **d_block_start);
+int mgc_get_result_device(const mgc_session *s, const void **d_unique, const uint32_t **d_counts,
+                          const uint64_t **d_block_start, uint32_t *key_words);
 
 /* Copies the result to host arrays sized from mgc_get_result_info
- * (keys/counts: n_distinct; block_start: n_prefix+1).  Any pointer may be NULL. */
-int mgc_copy_result(const mgc_session *s, uint64_t *keys, uint32_t *counts, uint64_t *block_start);
+ * (keys_lo/keys_hi/counts: n_distinct; block_start: n_prefix+1).  Any pointer
+ * may be NULL; keys_hi is zero-filled for k <= 32. */
+int mgc_copy_result(const mgc_session *s, uint64_t *keys_lo, uint64_t *keys_hi, uint32_t *counts,
+                    uint64_t *block_start);
 
 /* Delivery in the reference's addBlock convention (merylCountArray.C:472-475;
  * merylOp-countThreads.C:452-459): for every file ff, for every prefix of the

@@ -19,7 +19,7 @@ STAGE_NAMES = ("histogram", "partition", "sort", "rle", "blocks")
 SYMBOLS = (
     "mgc_configure_counting", "mgc_format_configured_line",
     "mgc_dev_partition_workspace_bytes", "mgc_dev_kmer_histogram", "mgc_dev_kmer_partition",
-    "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort_u64",
+    "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort",
     "mgc_dev_rle_workspace_bytes", "mgc_dev_rle_count", "mgc_dev_rle_emit", "mgc_dev_block_offsets",
     "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_count",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish",
@@ -161,11 +161,11 @@ def lib():
     sig("mgc_dev_kmer_histogram", i32, vp, u64, u32, i32, u32, vp, vp, sz, vp)
     sig("mgc_dev_kmer_partition", i32, vp, u64, u32, i32, u32, vp, vp, vp, sz, vp)
     sig("mgc_dev_sort_workspace_bytes", sz, u64)
-    sig("mgc_dev_radix_sort_u64", i32, vp, vp, u64, u32, u32, vp, sz, P(i32), vp)
+    sig("mgc_dev_radix_sort", i32, vp, vp, u64, u32, u32, u32, vp, sz, P(i32), vp)
     sig("mgc_dev_rle_workspace_bytes", sz, u64)
-    sig("mgc_dev_rle_count", i32, vp, u64, vp, sz, P(u64), vp)
-    sig("mgc_dev_rle_emit", i32, vp, u64, vp, sz, vp, vp, vp)
-    sig("mgc_dev_block_offsets", i32, vp, u64, u32, u64, vp, vp)
+    sig("mgc_dev_rle_count", i32, vp, u64, u32, vp, sz, P(u64), vp)
+    sig("mgc_dev_rle_emit", i32, vp, u64, u32, vp, sz, vp, vp, vp)
+    sig("mgc_dev_block_offsets", i32, vp, u64, u32, u32, u64, vp, vp)
     sig("mgc_dev_synth_reads", i32, u64, u64, u64, u64, u32, u32, u32, vp, vp)
     sig("mgc_open", vp, P(CountConfig), i32)
     sig("mgc_close", None, vp)
@@ -174,8 +174,8 @@ def lib():
     sig("mgc_push_bases_device", i32, vp, vp, u64)
     sig("mgc_count", i32, vp)
     sig("mgc_get_result_info", i32, vp, P(ResultInfo))
-    sig("mgc_get_result_device", i32, vp, P(vp), P(vp), P(vp))
-    sig("mgc_copy_result", i32, vp, vp, vp, vp)
+    sig("mgc_get_result_device", i32, vp, P(vp), P(vp), P(vp), P(u32))
+    sig("mgc_copy_result", i32, vp, vp, vp, vp, vp)
     sig("mgc_finish", i32, vp, BLOCK_CB, vp, i32)
     sig("mgc_set_profiling", i32, vp, i32)
     sig("mgc_get_profile", i32, vp, P(Profile))

@@ -45,8 +45,14 @@ def dev_synth_reads(seed, genome_len, first_read, n_reads, read_len=150, sub_rat
     return out
 
 
+def key_words(k):
+    """uint64 keys for k <= 32, 16-byte {lo, hi} pairs for k in 33..64."""
+    return 2 if k > 32 else 1
+
+
 def dev_kmer_partition(bases, k, mode=capi.MODE_CANONICAL, bucket_bits=6):
-    """bases: uint8 cuda tensor -> (keys int64[N] grouped by bucket, counts int64[2^bucket_bits] on host)."""
+    """bases: uint8 cuda tensor -> (keys grouped by bucket, counts uint64[2^bucket_bits] on host).
+    keys is int64[N] for k <= 32 and int64[N, 2] ({lo, hi} rows) for k > 32."""
     L = capi.lib()
     dev = bases.device
     nb = 1 << bucket_bits
@@ -60,47 +66,55 @@ def dev_kmer_partition(bases, k, mode=capi.MODE_CANONICAL, bucket_bits=6):
     starts[1:] = np.cumsum(h_counts)[:-1]
     n = int(h_counts.sum())
     d_starts = torch.from_numpy(starts.astype(np.int64)).to(dev)
-    keys = _u64(n, dev)
+    keys = _u64(n * key_words(k), dev)
+    if k > 32:
+        keys = keys.view(n, 2)
     capi.check(L.mgc_dev_kmer_partition(_ptr(bases), bases.numel(), k, mode, bucket_bits, _ptr(d_starts), _ptr(keys),
                                         _ptr(ws), ws_bytes, _stream_ptr()), "mgc_dev_kmer_partition")
     return keys, h_counts
 
 
 def dev_radix_sort(keys, begin_bit, end_bit):
-    """Sorts an int64 cuda tensor (as uint64) on bits [begin_bit, end_bit); returns the sorted tensor."""
+    """Sorts keys on bits [begin_bit, end_bit): an int64[N] cuda tensor (as uint64) or an
+    int64[N, 2] tensor of {lo, hi} rows (128-bit keys).  Returns the sorted tensor."""
     L = capi.lib()
-    n = keys.numel()
+    kw = 2 if keys.dim() == 2 else 1
+    n = keys.shape[0]
     if n == 0:
         return keys
     alt = torch.empty_like(keys)
     ws_bytes = L.mgc_dev_sort_workspace_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=keys.device)
     in_alt = ctypes.c_int(0)
-    capi.check(L.mgc_dev_radix_sort_u64(_ptr(keys), _ptr(alt), n, begin_bit, end_bit, _ptr(ws), ws_bytes,
-                                        ctypes.byref(in_alt), _stream_ptr()), "mgc_dev_radix_sort_u64")
+    capi.check(L.mgc_dev_radix_sort(_ptr(keys), _ptr(alt), n, kw, begin_bit, end_bit, _ptr(ws), ws_bytes,
+                                    ctypes.byref(in_alt), _stream_ptr()), "mgc_dev_radix_sort")
     return alt if in_alt.value else keys
 
 
 def dev_run_length(sorted_keys):
-    """(unique int64[D], counts int32[D]) of a sorted int64 (uint64) cuda tensor."""
+    """(unique, counts int32[D]) of a sorted key tensor (int64[N] or int64[N, 2])."""
     L = capi.lib()
-    n = sorted_keys.numel()
+    kw = 2 if sorted_keys.dim() == 2 else 1
+    n = sorted_keys.shape[0]
     dev = sorted_keys.device
     ws_bytes = L.mgc_dev_rle_workspace_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     nd = ctypes.c_uint64(0)
-    capi.check(L.mgc_dev_rle_count(_ptr(sorted_keys), n, _ptr(ws), ws_bytes, ctypes.byref(nd), _stream_ptr()),
+    capi.check(L.mgc_dev_rle_count(_ptr(sorted_keys), n, kw, _ptr(ws), ws_bytes, ctypes.byref(nd), _stream_ptr()),
                "mgc_dev_rle_count")
-    uniq = _u64(nd.value, dev)
+    uniq = _u64(nd.value * kw, dev)
+    if kw == 2:
+        uniq = uniq.view(nd.value, 2)
     cnts = torch.empty(nd.value, dtype=torch.int32, device=dev)
-    capi.check(L.mgc_dev_rle_emit(_ptr(sorted_keys), n, _ptr(ws), ws_bytes, _ptr(uniq), _ptr(cnts), _stream_ptr()),
+    capi.check(L.mgc_dev_rle_emit(_ptr(sorted_keys), n, kw, _ptr(ws), ws_bytes, _ptr(uniq), _ptr(cnts), _stream_ptr()),
                "mgc_dev_rle_emit")
     return uniq, cnts
 
 
 def dev_block_offsets(unique, w_data, n_prefix):
     out = _u64(n_prefix + 1, unique.device)
-    capi.check(capi.lib().mgc_dev_block_offsets(_ptr(unique), unique.numel(), w_data, n_prefix, _ptr(out),
+    kw = 2 if unique.dim() == 2 else 1
+    capi.check(capi.lib().mgc_dev_block_offsets(_ptr(unique), unique.shape[0], kw, w_data, n_prefix, _ptr(out),
                                                 _stream_ptr()), "mgc_dev_block_offsets")
     return out
 
@@ -156,24 +170,38 @@ class Session:
         return p
 
     def result(self):
-        """(keys uint64[D], counts uint32[D], block_start uint64[n_prefix+1]) as numpy arrays."""
+        """(keys uint64[D] (low 64 bits), counts uint32[D], block_start uint64[n_prefix+1]) as numpy
+        arrays; for k > 32 use result_wide() to get the high halves too."""
+        lo, _, counts, bstart = self.result_wide()
+        return lo, counts, bstart
+
+    def result_wide(self):
+        """(keys_lo, keys_hi, counts, block_start)"""
         r = self.info()
-        keys = np.zeros(r.n_distinct, dtype=np.uint64)
+        lo = np.zeros(r.n_distinct, dtype=np.uint64)
+        hi = np.zeros(r.n_distinct, dtype=np.uint64)
         counts = np.zeros(r.n_distinct, dtype=np.uint32)
         bstart = np.zeros(r.n_prefix + 1, dtype=np.uint64)
-        capi.check(capi.lib().mgc_copy_result(self._h, keys.ctypes.data, counts.ctypes.data, bstart.ctypes.data),
-                   "mgc_copy_result", self._h)
-        return keys, counts, bstart
+        capi.check(capi.lib().mgc_copy_result(self._h, lo.ctypes.data, hi.ctypes.data, counts.ctypes.data,
+                                              bstart.ctypes.data), "mgc_copy_result", self._h)
+        return lo, hi, counts, bstart
 
     def finish(self, callback, host_threads=1):
-        """callback(prefix, n_kmers, suffixes uint64[n], counts uint32[n]) per block, addBlock order."""
+        """callback(prefix, n_kmers, suffix_lo uint64[n], counts uint32[n][, suffix_hi]) per block,
+        addBlock order; suffix_hi is passed (5th argument) only when the callback accepts it."""
+        import inspect
         err = []
+        wants_hi = len(inspect.signature(callback).parameters) >= 5
 
         def _cb(ctx, prefix, n, slo, shi, cnt):
             try:
                 s = np.ctypeslib.as_array(slo, shape=(n,)).copy() if n else np.zeros(0, np.uint64)
                 c = np.ctypeslib.as_array(cnt, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
-                callback(int(prefix), int(n), s, c)
+                if wants_hi:
+                    h = np.ctypeslib.as_array(shi, shape=(n,)).copy() if (n and shi) else np.zeros(n, np.uint64)
+                    callback(int(prefix), int(n), s, c, h)
+                else:
+                    callback(int(prefix), int(n), s, c)
                 return 0
             except Exception as e:  # pragma: no cover
                 err.append(e)
@@ -249,6 +277,8 @@ class HipOps:
 
     @staticmethod
     def empty_keys(n, like):
+        if like.dim() == 2:
+            return _u64(2 * n, like.device).view(int(n), 2)
         return _u64(n, like.device)
 
 

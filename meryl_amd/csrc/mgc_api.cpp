@@ -152,7 +152,7 @@ int hip_rc(hipError_t e, const char *what) {
   return (e == hipErrorOutOfMemory) ? MGC_ENOMEM : MGC_EHIP;
 }
 bool key_args_ok(uint32_t k, int mode, uint32_t bucket_bits) {
-  if (k == 0 || k > 32) { set_err(nullptr, "k=%u: this build packs k <= 32 (uint64 keys)", k); return false; }
+  if (k == 0 || k > 64) { set_err(nullptr, "k=%u out of range (1..64)", k); return false; }
   if (mode < 0 || mode > 2) { set_err(nullptr, "bad mode %d", mode); return false; }
   if (bucket_bits > MGC_MAX_BUCKET_BITS || bucket_bits > 2 * k) { set_err(nullptr, "bad bucket_bits %u", bucket_bits); return false; }
   return true;
@@ -166,16 +166,16 @@ extern "C" size_t mgc_dev_partition_workspace_bytes(uint32_t bucket_bits) {
 extern "C" int mgc_dev_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                                       uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, size_t ws_bytes,
                                       void *stream) {
-  if (!key_args_ok(k, mode, bucket_bits)) return (k > 32 && k <= 64) ? MGC_EUNSUPPORTED : MGC_EINVAL;
+  if (!key_args_ok(k, mode, bucket_bits)) return MGC_EINVAL;
   if ((!d_bases && n_bases) || !d_bucket_counts || !d_ws || ws_bytes < mgc::kp_workspace_bytes(bucket_bits)) return MGC_EINVAL;
   return hip_rc(mgc::launch_kmer_histogram(d_bases, n_bases, k, mode, bucket_bits, d_bucket_counts, d_ws,
                                            (hipStream_t)stream), "kmer_histogram");
 }
 
 extern "C" int mgc_dev_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
-                                      uint32_t bucket_bits, const uint64_t *d_bucket_starts, uint64_t *d_keys,
+                                      uint32_t bucket_bits, const uint64_t *d_bucket_starts, void *d_keys,
                                       void *d_ws, size_t ws_bytes, void *stream) {
-  if (!key_args_ok(k, mode, bucket_bits)) return (k > 32 && k <= 64) ? MGC_EUNSUPPORTED : MGC_EINVAL;
+  if (!key_args_ok(k, mode, bucket_bits)) return MGC_EINVAL;
   if ((!d_bases && n_bases) || !d_bucket_starts || !d_ws || ws_bytes < mgc::kp_workspace_bytes(bucket_bits)) return MGC_EINVAL;
   return hip_rc(mgc::launch_kmer_partition(d_bases, n_bases, k, mode, bucket_bits, d_bucket_starts, d_keys, d_ws,
                                            (hipStream_t)stream), "kmer_partition");
@@ -183,10 +183,9 @@ extern "C" int mgc_dev_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, 
 
 extern "C" size_t mgc_dev_sort_workspace_bytes(uint64_t n) { return mgc::sort_workspace_bytes(n) + 256; }
 
-extern "C" int mgc_dev_radix_sort_u64(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, uint32_t begin_bit,
-                                      uint32_t end_bit, void *d_ws, size_t ws_bytes, int *result_in_alt,
-                                      void *stream) {
-  if (!result_in_alt || begin_bit > end_bit || end_bit > 64) return MGC_EINVAL;
+extern "C" int mgc_dev_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, uint32_t begin_bit,
+                                  uint32_t end_bit, void *d_ws, size_t ws_bytes, int *result_in_alt, void *stream) {
+  if (!result_in_alt || begin_bit > end_bit || (key_words != 1 && key_words != 2) || end_bit > 64 * key_words) return MGC_EINVAL;
   *result_in_alt = 0;
   if (n == 0 || begin_bit == end_bit) return MGC_OK;
   if (!d_keys || !d_alt || !d_ws || ws_bytes < mgc::sort_workspace_bytes(n) + 256) return MGC_EINVAL;
@@ -197,7 +196,7 @@ extern "C" int mgc_dev_radix_sort_u64(uint64_t *d_keys, uint64_t *d_alt, uint64_
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(d_err, 0, 4, st);
   if (e != hipSuccess) return hip_rc(e, "radix_sort memset");
-  e = mgc::launch_radix_sort(d_keys, d_alt, n, plan, d_ws, ws_bytes - 256, d_err, result_in_alt, st, nullptr);
+  e = mgc::launch_radix_sort(d_keys, d_alt, n, key_words, plan, d_ws, ws_bytes - 256, d_err, result_in_alt, st, nullptr);
   if (e != hipSuccess) return hip_rc(e, "radix_sort");
   uint32_t h_err = 0;
   e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st);
@@ -209,25 +208,28 @@ extern "C" int mgc_dev_radix_sort_u64(uint64_t *d_keys, uint64_t *d_alt, uint64_
 
 extern "C" size_t mgc_dev_rle_workspace_bytes(uint64_t n) { return mgc::rle_workspace_bytes(n); }
 
-extern "C" int mgc_dev_rle_count(const uint64_t *d_sorted, uint64_t n, void *d_ws, size_t ws_bytes,
+extern "C" int mgc_dev_rle_count(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_ws, size_t ws_bytes,
                                  uint64_t *n_distinct, void *stream) {
-  if (!n_distinct || !d_ws || ws_bytes < mgc::rle_workspace_bytes(n) || (!d_sorted && n)) return MGC_EINVAL;
-  hipError_t e = mgc::launch_rle_count(d_sorted, n, d_ws, (hipStream_t)stream);
+  if (!n_distinct || !d_ws || ws_bytes < mgc::rle_workspace_bytes(n) || (!d_sorted && n) ||
+      (key_words != 1 && key_words != 2)) return MGC_EINVAL;
+  hipError_t e = mgc::launch_rle_count(d_sorted, n, key_words, d_ws, (hipStream_t)stream);
   if (e != hipSuccess) return hip_rc(e, "rle_count");
   return hip_rc(mgc::rle_read_total(d_ws, n_distinct, (hipStream_t)stream), "rle_count sync");
 }
 
-extern "C" int mgc_dev_rle_emit(const uint64_t *d_sorted, uint64_t n, void *d_ws, size_t ws_bytes,
-                                uint64_t *d_unique, uint32_t *d_counts, void *stream) {
-  if (!d_ws || ws_bytes < mgc::rle_workspace_bytes(n) || (n && (!d_sorted || !d_unique || !d_counts))) return MGC_EINVAL;
-  return hip_rc(mgc::launch_rle_emit(d_sorted, n, d_ws, d_unique, d_counts, (hipStream_t)stream), "rle_emit");
+extern "C" int mgc_dev_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_ws, size_t ws_bytes,
+                                void *d_unique, uint32_t *d_counts, void *stream) {
+  if (!d_ws || ws_bytes < mgc::rle_workspace_bytes(n) || (n && (!d_sorted || !d_unique || !d_counts)) ||
+      (key_words != 1 && key_words != 2)) return MGC_EINVAL;
+  return hip_rc(mgc::launch_rle_emit(d_sorted, n, key_words, d_ws, d_unique, d_counts, (hipStream_t)stream), "rle_emit");
 }
 
-extern "C" int mgc_dev_block_offsets(const uint64_t *d_unique, uint64_t n_distinct, uint32_t w_data,
+extern "C" int mgc_dev_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,
                                      uint64_t n_prefix, uint64_t *d_block_start, void *stream) {
-  if (!d_block_start || w_data >= 64 || (n_distinct && !d_unique)) return MGC_EINVAL;
-  return hip_rc(mgc::launch_block_offsets(d_unique, n_distinct, w_data, n_prefix, d_block_start, (hipStream_t)stream),
-                "block_offsets");
+  if (!d_block_start || (key_words != 1 && key_words != 2) || w_data >= 64 * key_words || (n_distinct && !d_unique))
+    return MGC_EINVAL;
+  return hip_rc(mgc::launch_block_offsets(d_unique, n_distinct, key_words, w_data, n_prefix, d_block_start,
+                                          (hipStream_t)stream), "block_offsets");
 }
 
 extern "C" int mgc_dev_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
@@ -258,9 +260,10 @@ struct mgc_session {
   bool      counted = false;
   uint64_t  n_instances = 0, n_distinct = 0;
   uint64_t  file_instances[MGC_NUM_FILES];
-  uint64_t *d_unique = nullptr;
+  void     *d_unique = nullptr;           // uint64[D] (k <= 32) or {lo,hi}[D] (k > 32)
   uint32_t *d_counts = nullptr;
   uint64_t *d_block_start = nullptr;
+  uint32_t  key_words = 1;
 
   // device arena: buffers survive between mgc_count calls (grow-only), so a
   // repeated count does not pay hipMalloc/hipFree of tens of GB every time
@@ -300,7 +303,6 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
             cfg->k, cfg->w_prefix, cfg->w_data);
     return nullptr;
   }
-  if (cfg->k > 32) { set_err(nullptr, "mgc_open: k=%u > 32 needs 128-bit keys (not in this build)", cfg->k); return nullptr; }
   if (cfg->use_simple || cfg->count_suffix_length) {
     // The reference would pick countSimple (merylOp-count.C:368-382), which yields a
     // different block geometry (merylOp-countSimple.C:172-175).  Not built yet.
@@ -317,6 +319,7 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
   }
   mgc_session *s = new mgc_session();
   s->cfg = *cfg;
+  s->key_words = (cfg->k > 32) ? 2u : 1u;
   if (device >= 0) {
     e = hipSetDevice(device);
     if (e != hipSuccess) { set_err(nullptr, "hipSetDevice(%d): %s", device, hipGetErrorString(e)); delete s; return nullptr; }
@@ -406,6 +409,8 @@ extern "C" int mgc_count(mgc_session *s) {
   const uint32_t k = c.k;
   const uint32_t bucket_bits = MGC_NUM_FILES_BITS;
   const uint32_t nb = MGC_NUM_FILES;
+  const uint32_t kw = s->key_words;
+  const size_t   kbytes = sizeof(uint64_t) * kw;
   memset(&s->prof, 0, sizeof(s->prof));
 
   // ---- input into HBM ----
@@ -449,13 +454,13 @@ extern "C" int mgc_count(mgc_session *s) {
   mgc::SortPlan plan;
   mgc::make_sort_plan(0, 2 * k - bucket_bits, &plan);
   const bool odd = (plan.num_passes & 1u) != 0;
-  HIP_TRY(s, s->ensure(mgc_session::B_X, sizeof(uint64_t) * N));
-  HIP_TRY(s, s->ensure(mgc_session::B_Y, sizeof(uint64_t) * (odd ? N : max_bucket)));
-  uint64_t *X = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_X].p);
-  uint64_t *Y = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_Y].p);
+  HIP_TRY(s, s->ensure(mgc_session::B_X, kbytes * N));
+  HIP_TRY(s, s->ensure(mgc_session::B_Y, kbytes * (odd ? N : max_bucket)));
+  unsigned char *X = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_X].p);
+  unsigned char *Y = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_Y].p);
   HIP_TRY(s, hipMemcpyAsync(d_starts, h_starts, sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
   tm.begin(MGC_STAGE_PARTITION);
-  HIP_TRY(s, mgc::launch_kmer_partition(s->d_bases, s->n_bases, k, c.mode, bucket_bits, d_starts, X, part_ws, st));
+  HIP_TRY(s, mgc::launch_kmer_partition(s->d_bases, s->n_bases, k, c.mode, bucket_bits, d_starts, (void *)X, part_ws, st));
   tm.end(MGC_STAGE_PARTITION);
   s->prof.stage_launches[MGC_STAGE_PARTITION] = 2;
 
@@ -475,30 +480,30 @@ extern "C" int mgc_count(mgc_session *s) {
   uint32_t sort_launch_groups = 0;
   for (uint32_t b = 0; b < nb; b++) {
     if (h_counts[b] == 0) continue;
-    uint64_t *src = X + h_starts[b];
-    uint64_t *alt = odd ? (Y + h_starts[b]) : Y;
+    void *src = X + kbytes * h_starts[b];
+    void *alt = odd ? (void *)(Y + kbytes * h_starts[b]) : (void *)Y;
     int in_alt = 0;
     hipEvent_t *pe = s->profiling ? &pass_ev[(size_t)b * plan.num_passes * 2] : nullptr;
-    HIP_TRY(s, mgc::launch_radix_sort(src, alt, h_counts[b], plan, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe));
+    HIP_TRY(s, mgc::launch_radix_sort(src, alt, h_counts[b], kw, plan, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe));
     sort_launch_groups++;
     (void)in_alt;     // odd pass count: every file ends in Y at the same offsets; even: back in X
   }
   tm.end(MGC_STAGE_SORT);
-  uint64_t *d_sorted = odd ? Y : X;
+  void *d_sorted = odd ? (void *)Y : (void *)X;
 
   // ---- run-length count ----
   HIP_TRY(s, s->ensure(mgc_session::B_RLE_WS, mgc::rle_workspace_bytes(N)));
   void *rle_ws = s->buf[mgc_session::B_RLE_WS].p;
   tm.begin(MGC_STAGE_RLE);
-  HIP_TRY(s, mgc::launch_rle_count(d_sorted, N, rle_ws, st));
+  HIP_TRY(s, mgc::launch_rle_count(d_sorted, N, kw, rle_ws, st));
   uint64_t nd = 0;
   HIP_TRY(s, mgc::rle_read_total(rle_ws, &nd, st));
   s->n_distinct = nd;
-  HIP_TRY(s, s->ensure(mgc_session::B_UNIQUE, sizeof(uint64_t) * nd));
+  HIP_TRY(s, s->ensure(mgc_session::B_UNIQUE, kbytes * nd));
   HIP_TRY(s, s->ensure(mgc_session::B_COUNTS, sizeof(uint32_t) * nd));
-  s->d_unique = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_UNIQUE].p);
+  s->d_unique = s->buf[mgc_session::B_UNIQUE].p;
   s->d_counts = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_COUNTS].p);
-  HIP_TRY(s, mgc::launch_rle_emit(d_sorted, N, rle_ws, s->d_unique, s->d_counts, st));
+  HIP_TRY(s, mgc::launch_rle_emit(d_sorted, N, kw, rle_ws, s->d_unique, s->d_counts, st));
   tm.end(MGC_STAGE_RLE);
   s->prof.stage_launches[MGC_STAGE_RLE] = 3;
 
@@ -506,7 +511,7 @@ extern "C" int mgc_count(mgc_session *s) {
   HIP_TRY(s, s->ensure(mgc_session::B_BLOCKS, sizeof(uint64_t) * (c.n_prefix + 1)));
   s->d_block_start = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_BLOCKS].p);
   tm.begin(MGC_STAGE_BLOCKS);
-  HIP_TRY(s, mgc::launch_block_offsets(s->d_unique, nd, c.w_data, c.n_prefix, s->d_block_start, st));
+  HIP_TRY(s, mgc::launch_block_offsets(s->d_unique, nd, kw, c.w_data, c.n_prefix, s->d_block_start, st));
   tm.end(MGC_STAGE_BLOCKS);
   s->prof.stage_launches[MGC_STAGE_BLOCKS] = 1;
 
@@ -553,24 +558,39 @@ extern "C" int mgc_get_result_info(const mgc_session *s, mgc_result_info *info) 
   return MGC_OK;
 }
 
-extern "C" int mgc_get_result_device(const mgc_session *s, const uint64_t **d_unique, const uint32_t **d_counts,
-                                     const uint64_t **d_block_start) {
+extern "C" int mgc_get_result_device(const mgc_session *s, const void **d_unique, const uint32_t **d_counts,
+                                     const uint64_t **d_block_start, uint32_t *key_words) {
   if (!s) return MGC_EINVAL;
   if (!s->counted) return MGC_ESTATE;
   if (d_unique) *d_unique = s->d_unique;
   if (d_counts) *d_counts = s->d_counts;
   if (d_block_start) *d_block_start = s->d_block_start;
+  if (key_words) *key_words = s->key_words;
   return MGC_OK;
 }
 
-extern "C" int mgc_copy_result(const mgc_session *cs, uint64_t *keys, uint32_t *counts, uint64_t *block_start) {
+extern "C" int mgc_copy_result(const mgc_session *cs, uint64_t *keys_lo, uint64_t *keys_hi, uint32_t *counts,
+                               uint64_t *block_start) {
   mgc_session *s = const_cast<mgc_session *>(cs);
   if (!s) return MGC_EINVAL;
   if (!s->counted) return MGC_ESTATE;
   HIP_TRY(s, hipSetDevice(s->device));
-  if (keys && s->n_distinct)   HIP_TRY(s, hipMemcpy(keys, s->d_unique, sizeof(uint64_t) * s->n_distinct, hipMemcpyDeviceToHost));
-  if (counts && s->n_distinct) HIP_TRY(s, hipMemcpy(counts, s->d_counts, sizeof(uint32_t) * s->n_distinct, hipMemcpyDeviceToHost));
-  if (block_start)             HIP_TRY(s, hipMemcpy(block_start, s->d_block_start, sizeof(uint64_t) * (s->cfg.n_prefix + 1), hipMemcpyDeviceToHost));
+  const uint64_t nd = s->n_distinct;
+  if (nd && (keys_lo || keys_hi)) {
+    if (s->key_words == 1) {
+      if (keys_lo) HIP_TRY(s, hipMemcpy(keys_lo, s->d_unique, sizeof(uint64_t) * nd, hipMemcpyDeviceToHost));
+      if (keys_hi) memset(keys_hi, 0, sizeof(uint64_t) * nd);
+    } else {
+      std::vector<uint64_t> tmp(2 * nd);                   // {lo,hi} pairs
+      HIP_TRY(s, hipMemcpy(tmp.data(), s->d_unique, sizeof(uint64_t) * 2 * nd, hipMemcpyDeviceToHost));
+      for (uint64_t i = 0; i < nd; i++) {
+        if (keys_lo) keys_lo[i] = tmp[2 * i];
+        if (keys_hi) keys_hi[i] = tmp[2 * i + 1];
+      }
+    }
+  }
+  if (counts && nd) HIP_TRY(s, hipMemcpy(counts, s->d_counts, sizeof(uint32_t) * nd, hipMemcpyDeviceToHost));
+  if (block_start)  HIP_TRY(s, hipMemcpy(block_start, s->d_block_start, sizeof(uint64_t) * (s->cfg.n_prefix + 1), hipMemcpyDeviceToHost));
   return MGC_OK;
 }
 
@@ -578,13 +598,16 @@ extern "C" int mgc_finish(mgc_session *s, mgc_block_cb cb, void *ctx, int host_t
   if (!s || !cb) return MGC_EINVAL;
   if (!s->counted) { set_err(&s->err, "mgc_finish before mgc_count"); return MGC_ESTATE; }
   const uint64_t nd = s->n_distinct, np = s->cfg.n_prefix;
-  std::vector<uint64_t> keys(nd), bstart(np + 1);
+  const bool wide = s->key_words == 2;
+  std::vector<uint64_t> klo(nd), khi(wide ? nd : 0), bstart(np + 1);
   std::vector<uint32_t> counts(nd);
-  int rc = mgc_copy_result(s, keys.data(), counts.data(), bstart.data());
+  int rc = mgc_copy_result(s, klo.data(), wide ? khi.data() : nullptr, counts.data(), bstart.data());
   if (rc != MGC_OK) return rc;
 
+  // suffix = low w_data bits of the k-mer (wDataMask, merylOp-count.C:282-286)
   const uint32_t w_data = s->cfg.w_data;
-  const uint64_t mask = (w_data == 64) ? ~0ull : ((1ull << w_data) - 1ull);
+  const uint64_t mask_lo = (w_data >= 64) ? ~0ull : ((1ull << w_data) - 1ull);
+  const uint64_t mask_hi = (w_data <= 64) ? 0ull : ((w_data >= 128) ? ~0ull : ((1ull << (w_data - 64)) - 1ull));
   const uint64_t per_file = np / MGC_NUM_FILES;             // firstPrefixInFile/lastPrefixInFile
   if (host_threads <= 0) host_threads = (int)(s->cfg.threads ? s->cfg.threads : std::thread::hardware_concurrency());
   host_threads = std::max(1, std::min(host_threads, MGC_NUM_FILES));
@@ -592,15 +615,19 @@ extern "C" int mgc_finish(mgc_session *s, mgc_block_cb cb, void *ctx, int host_t
   std::atomic<uint32_t> next_file(0);
   std::atomic<int> status(MGC_OK);
   auto worker = [&]() {
-    std::vector<uint64_t> suffix;
+    std::vector<uint64_t> slo, shi;
     for (;;) {
       const uint32_t ff = next_file.fetch_add(1);            // dynamic,1 like the reference's omp schedule
       if (ff >= MGC_NUM_FILES || status.load() != MGC_OK) return;
       for (uint64_t pp = ff * per_file; pp < (ff + 1) * per_file; pp++) {
         const uint64_t b = bstart[pp], e = bstart[pp + 1];
-        suffix.resize(e - b);
-        for (uint64_t i = b; i < e; i++) suffix[i - b] = keys[i] & mask;
-        const int r = cb(ctx, pp, e - b, suffix.data(), nullptr, counts.data() + b);   // empty blocks included
+        slo.resize(e - b);
+        for (uint64_t i = b; i < e; i++) slo[i - b] = klo[i] & mask_lo;
+        if (wide) {
+          shi.resize(e - b);
+          for (uint64_t i = b; i < e; i++) shi[i - b] = khi[i] & mask_hi;
+        }
+        const int r = cb(ctx, pp, e - b, slo.data(), wide ? shi.data() : nullptr, counts.data() + b);   // empty blocks too
         if (r != 0) { status.store(r); return; }
       }
     }

@@ -20,8 +20,9 @@ size_t   kp_workspace_bytes(uint32_t bucket_bits);
 
 hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                                  uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st);
+// keys are uint64 for k <= 32, 16-byte little-endian {lo,hi} for k in 33..64 (key_words 1 / 2)
 hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
-                                 uint32_t bucket_bits, const uint64_t *d_bucket_starts, uint64_t *d_keys,
+                                 uint32_t bucket_bits, const uint64_t *d_bucket_starts, void *d_keys,
                                  void *d_ws, hipStream_t st);
 
 // ---- radix sort ------------------------------------------------------------
@@ -50,19 +51,19 @@ struct SortTiming {           // optional per-pass event timing
 
 // Sorts n keys; returns where the result is via *result_in_alt.  d_error is a
 // device uint32 the kernels set on a look-back timeout (checked by the caller).
-hipError_t launch_radix_sort(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, const SortPlan &plan,
+hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan,
                              void *d_ws, size_t ws_bytes, uint32_t *d_error, int *result_in_alt,
                              hipStream_t st, hipEvent_t *pass_events /* 2 per pass or null */);
 
 // ---- run-length count ------------------------------------------------------
 size_t     rle_workspace_bytes(uint64_t n);
-hipError_t launch_rle_count(const uint64_t *d_sorted, uint64_t n, void *d_ws, hipStream_t st);
+hipError_t launch_rle_count(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_ws, hipStream_t st);
 // after launch_rle_count + stream sync: number of distinct keys sits at ws[0]
 hipError_t rle_read_total(const void *d_ws, uint64_t *n_distinct, hipStream_t st);
-hipError_t launch_rle_emit(const uint64_t *d_sorted, uint64_t n, void *d_ws, uint64_t *d_unique,
+hipError_t launch_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_ws, void *d_unique,
                            uint32_t *d_counts, hipStream_t st);
 
-hipError_t launch_block_offsets(const uint64_t *d_unique, uint64_t n_distinct, uint32_t w_data,
+hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,
                                 uint64_t n_prefix, uint64_t *d_block_start, hipStream_t st);
 
 hipError_t launch_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,

@@ -30,6 +30,35 @@ namespace mgc {
 typedef unsigned long long u64;
 typedef unsigned int       u32;
 
+typedef unsigned __int128 u128;
+
+// 128-bit key (k in 33..64): little-endian halves, so memory order == integer order of lo|hi<<64
+struct alignas(16) K128 { u64 lo, hi; };
+
+template <typename K> struct KeyOps;
+template <> struct KeyOps<u64> {
+  static constexpr int WORDS = 1;
+  static __device__ __forceinline__ u32  digit(u64 k, u32 shift, u32 mask) { return (u32)(k >> shift) & mask; }
+  static __device__ __forceinline__ u32  bucket(u64 k, u32 shift) { return (u32)(k >> shift); }
+  static __device__ __forceinline__ u64  pad() { return ~0ull; }
+  static __device__ __forceinline__ u64  zero() { return 0ull; }
+  static __device__ __forceinline__ bool ne(u64 a, u64 b) { return a != b; }
+  static __device__ __forceinline__ bool lt(u64 a, u64 b) { return a < b; }
+  static __device__ __forceinline__ u64  prefix_floor(u64 p, u32 w_data) { return p << w_data; }
+};
+template <> struct KeyOps<K128> {
+  static constexpr int WORDS = 2;
+  static __device__ __forceinline__ u128 v(K128 k) { return ((u128)k.hi << 64) | (u128)k.lo; }
+  static __device__ __forceinline__ K128 mk(u128 x) { K128 k; k.lo = (u64)x; k.hi = (u64)(x >> 64); return k; }
+  static __device__ __forceinline__ u32  digit(K128 k, u32 shift, u32 mask) { return (u32)(v(k) >> shift) & mask; }
+  static __device__ __forceinline__ u32  bucket(K128 k, u32 shift) { return (u32)(v(k) >> shift); }
+  static __device__ __forceinline__ K128 pad() { K128 k; k.lo = ~0ull; k.hi = ~0ull; return k; }
+  static __device__ __forceinline__ K128 zero() { K128 k; k.lo = 0; k.hi = 0; return k; }
+  static __device__ __forceinline__ bool ne(K128 a, K128 b) { return (a.lo != b.lo) || (a.hi != b.hi); }
+  static __device__ __forceinline__ bool lt(K128 a, K128 b) { return (a.hi < b.hi) || (a.hi == b.hi && a.lo < b.lo); }
+  static __device__ __forceinline__ K128 prefix_floor(u64 p, u32 w_data) { return mk((u128)p << w_data); }
+};
+
 #define MGC_CHECK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return e__; } while (0)
 
 // ============================================================================
@@ -163,6 +192,44 @@ __device__ __forceinline__ u32 kp_thread_kmers(const u32 *s_codes, const u32 *s_
   return vmask;
 }
 
+// Same for k in 33..64: the thread's window is 80 bases (five staged words).
+__device__ __forceinline__ u32 kp_thread_kmers(const u32 *s_codes, const u32 *s_inval, u32 k, int mode,
+                                               K128 (&keys)[KP_ITEMS]) {
+  const u32 t = threadIdx.x;
+  const u128 A = ((u128)s_codes[t] << 96) | ((u128)s_codes[t + 1] << 64) | ((u128)s_codes[t + 2] << 32) |
+                 (u128)s_codes[t + 3];                               // bases 0..63 of the window
+  const u128 B = (u128)s_codes[t + 4] << 96;                         // bases 64..79
+  const u128 I = ((u128)s_inval[t] << 112) | ((u128)s_inval[t + 1] << 96) | ((u128)s_inval[t + 2] << 80) |
+                 ((u128)s_inval[t + 3] << 64) | ((u128)s_inval[t + 4] << 48);
+  const u32 key_shift = 128 - 2 * k;
+  const u32 top_shift = 2 * k - 2;
+  u32 vmask = 0;
+  u128 r = 0;
+#pragma unroll
+  for (int j = 0; j < KP_ITEMS; j++) {
+    const u128 top = (j == 0) ? A : ((A << (2 * j)) | (B >> (128 - 2 * j)));
+    const u128 f   = top >> key_shift;
+    if (j == 0) {
+      // reverse complement: complement, reverse all 128 bits, swap the two bits of every base
+      const u128 c = f ^ (((u128)0xAAAAAAAAAAAAAAAAull << 64) | (u128)0xAAAAAAAAAAAAAAAAull);
+      u64 lo = __brevll((u64)(c >> 64)), hi = __brevll((u64)c);       // halves swap when reversed
+      lo = ((lo >> 1) & 0x5555555555555555ull) | ((lo & 0x5555555555555555ull) << 1);
+      hi = ((hi >> 1) & 0x5555555555555555ull) | ((hi & 0x5555555555555555ull) << 1);
+      r = (((u128)hi << 64) | (u128)lo) >> key_shift;
+    } else {
+      r = (r >> 2) | ((u128)(((u64)f & 3ull) ^ 2ull) << top_shift);
+    }
+    const bool ok = (((I << j) >> (128 - k)) == (u128)0);
+    u128 key;
+    if      (mode == 1) key = f;
+    else if (mode == 2) key = r;
+    else                key = (f < r) ? f : r;
+    keys[j] = KeyOps<K128>::mk(key);
+    vmask |= (ok ? 1u : 0u) << j;
+  }
+  return vmask;
+}
+
 __device__ __forceinline__ void kp_tile_range(u64 num_tiles, u64 &t_begin, u64 &t_end) {
   const u64 per = (num_tiles + gridDim.x - 1) / gridDim.x;
   t_begin = (u64)blockIdx.x * per;
@@ -172,6 +239,7 @@ __device__ __forceinline__ void kp_tile_range(u64 num_tiles, u64 &t_begin, u64 &
 }
 
 // Pass 1: per-workgroup and global per-bucket instance counts.
+template <typename K>
 __global__ __launch_bounds__(KP_BLOCK)
 void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
                       u64 num_tiles, u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts) {
@@ -193,14 +261,14 @@ void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode,
   for (u64 tile = t_begin; tile < t_end; tile++) {
     kp_stage_tile(bases, n, tile * KP_TILE, aligned, s_codes, s_inval);
     __syncthreads();
-    u64 keys[KP_ITEMS];
+    K keys[KP_ITEMS];
     const u32 vmask = kp_thread_kmers(s_codes, s_inval, k, mode, keys);
     if (nb == 1) {
       my_count += __popc(vmask);
     } else {
 #pragma unroll
       for (int j = 0; j < KP_ITEMS; j++)
-        if ((vmask >> j) & 1u) atomicAdd(&s_hist[(u32)(keys[j] >> bucket_shift)], 1u);
+        if ((vmask >> j) & 1u) atomicAdd(&s_hist[KeyOps<K>::bucket(keys[j], bucket_shift)], 1u);
     }
     __syncthreads();
   }
@@ -244,10 +312,12 @@ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 
 // Pass 2: pack + scatter.  Each workgroup owns private cursors (from pass 1),
 // so there are no global atomics and the result layout is deterministic up to
 // the order inside a (workgroup, tile, bucket) run.
+template <typename K>
 __global__ __launch_bounds__(KP_BLOCK)
 void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
-                           u64 num_tiles, const u64 *__restrict__ block_base, u64 *__restrict__ out) {
-  __shared__ u64 s_keys[KP_TILE];
+                           u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kp_dyn_smem[];
+  K *s_keys = reinterpret_cast<K *>(kp_dyn_smem);                   // K[KP_TILE]
   __shared__ u64 s_cursor[KP_MAX_BUCKETS];
   __shared__ u32 s_cnt[KP_MAX_BUCKETS];
   __shared__ u32 s_base[KP_MAX_BUCKETS];
@@ -270,7 +340,7 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
     kp_stage_tile(bases, n, tile * KP_TILE, aligned, s_codes, s_inval);
     __syncthreads();
 
-    u64 keys[KP_ITEMS];
+    K keys[KP_ITEMS];
     const u32 vmask = kp_thread_kmers(s_codes, s_inval, k, mode, keys);
     u32 total = 0;
 
@@ -290,7 +360,7 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
 #pragma unroll
       for (int j = 0; j < KP_ITEMS; j++) {
         ranks[j] = 0;
-        if ((vmask >> j) & 1u) ranks[j] = atomicAdd(&s_cnt[(u32)(keys[j] >> bucket_shift)], 1u);
+        if ((vmask >> j) & 1u) ranks[j] = atomicAdd(&s_cnt[KeyOps<K>::bucket(keys[j], bucket_shift)], 1u);
       }
       __syncthreads();
       // exclusive scan of the bucket counts, 4 consecutive buckets per thread
@@ -311,14 +381,14 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < KP_ITEMS; j++)
-        if ((vmask >> j) & 1u) s_keys[s_base[(u32)(keys[j] >> bucket_shift)] + ranks[j]] = keys[j];
+        if ((vmask >> j) & 1u) s_keys[s_base[KeyOps<K>::bucket(keys[j], bucket_shift)] + ranks[j]] = keys[j];
       __syncthreads();
     }
 
     // contiguous runs per bucket leave as coalesced stores
     for (u32 i = tid; i < total; i += KP_BLOCK) {
-      const u64 key = s_keys[i];
-      const u32 b   = (nb == 1) ? 0u : (u32)(key >> bucket_shift);
+      const K   key = s_keys[i];
+      const u32 b   = (nb == 1) ? 0u : KeyOps<K>::bucket(key, bucket_shift);
       out[s_cursor[b] + (u64)(i - s_base[b])] = key;
     }
     __syncthreads();
@@ -344,14 +414,19 @@ hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint3
   if (n_bases == 0) return hipSuccess;
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
   const uint32_t grid = kp_grid_size(n_bases);
-  hipLaunchKernelGGL(kmer_hist_kernel, dim3(grid), dim3(KP_BLOCK), 0, st,
-                     d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
-                     reinterpret_cast<u64 *>(d_ws), reinterpret_cast<u64 *>(d_bucket_counts));
+  if (k <= 32)
+    hipLaunchKernelGGL(kmer_hist_kernel<u64>, dim3(grid), dim3(KP_BLOCK), 0, st,
+                       d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
+                       reinterpret_cast<u64 *>(d_ws), reinterpret_cast<u64 *>(d_bucket_counts));
+  else
+    hipLaunchKernelGGL(kmer_hist_kernel<K128>, dim3(grid), dim3(KP_BLOCK), 0, st,
+                       d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
+                       reinterpret_cast<u64 *>(d_ws), reinterpret_cast<u64 *>(d_bucket_counts));
   return hipGetLastError();
 }
 
 hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
-                                 uint32_t bucket_bits, const uint64_t *d_bucket_starts, uint64_t *d_keys,
+                                 uint32_t bucket_bits, const uint64_t *d_bucket_starts, void *d_keys,
                                  void *d_ws, hipStream_t st) {
   if (n_bases == 0) return hipSuccess;
   const uint32_t nb = 1u << bucket_bits;
@@ -360,9 +435,20 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
   hipLaunchKernelGGL(kmer_scan_kernel, dim3(nb), dim3(256), 0, st,
                      reinterpret_cast<u64 *>(d_ws), grid, nb, reinterpret_cast<const u64 *>(d_bucket_starts));
   MGC_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(kmer_partition_kernel, dim3(grid), dim3(KP_BLOCK), 0, st,
-                     d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
-                     reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys));
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_partition_kernel<K128>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
+    attr_done = true;
+  }
+  if (k <= 32)
+    hipLaunchKernelGGL(kmer_partition_kernel<u64>, dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st,
+                       d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
+                       reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys));
+  else
+    hipLaunchKernelGGL(kmer_partition_kernel<K128>, dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K128), st,
+                       d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
+                       reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K128 *>(d_keys));
   return hipGetLastError();
 }
 
@@ -399,9 +485,10 @@ struct SortHeader {                       // lives at the start of the sort work
 struct PassList { u32 n; u32 shift[RS_MAX_PASSES]; u32 mask[RS_MAX_PASSES]; };
 
 // Digit histograms of every pass in one read of the keys.
+template <typename K>
 __global__ __launch_bounds__(256)
-void radix_hist_kernel(const u64 *__restrict__ in, u64 n, PassList pl, u64 *__restrict__ ghist) {
-  __shared__ u32 s_h[RS_MAX_PASSES * RS_MAX_RADIX / 2];   // up to 8 passes x 512 or 16 x 256 digits
+void radix_hist_kernel(const K *__restrict__ in, u64 n, PassList pl, u64 *__restrict__ ghist) {
+  __shared__ u32 s_h[RS_MAX_PASSES * RS_MAX_RADIX];       // up to 16 passes x 512 digits
   const u32 np = pl.n;
   // row stride: 512 if any mask needs it, else 256 (keeps 16 passes of 8 bits in 16 KB... )
   u32 stride = 256;
@@ -411,9 +498,9 @@ void radix_hist_kernel(const u64 *__restrict__ in, u64 n, PassList pl, u64 *__re
 
   const u64 gstride = (u64)gridDim.x * 256;
   for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += gstride) {
-    const u64 key = in[i];
+    const K key = in[i];
     for (u32 p = 0; p < np; p++)
-      atomicAdd(&s_h[p * stride + ((u32)(key >> pl.shift[p]) & pl.mask[p])], 1u);
+      atomicAdd(&s_h[p * stride + KeyOps<K>::digit(key, pl.shift[p], pl.mask[p])], 1u);
   }
   __syncthreads();
   for (u32 i = threadIdx.x; i < np * stride; i += 256) {
@@ -464,7 +551,7 @@ __device__ __forceinline__ u64 st_pack(u32 f0, u32 v0, u32 f1, u32 v1) {
 typedef __attribute__((address_space(3))) u64 lds_u64;
 typedef __attribute__((address_space(3))) u32 lds_u32;
 
-template <int RB, int BLOCK, int KPT, int LB = 0>
+template <typename K, int RB, int BLOCK, int KPT, int LB = 0>
 struct RadixSmem {
   static constexpr int R     = 1 << RB;
   static constexpr int NW    = BLOCK / 64;
@@ -472,7 +559,7 @@ struct RadixSmem {
   // region 0 is shared between the ranking scratch (wave digit counters u32[NW][R] followed by
   // wave match masks u64[NW][R]) and the key exchange buffer
   static constexpr size_t RANK_BYTES = (size_t)NW * R * 12;
-  static constexpr size_t REGION0 = ((size_t)TILE * 8 > RANK_BYTES) ? (size_t)TILE * 8 : RANK_BYTES;
+  static constexpr size_t REGION0 = ((size_t)TILE * sizeof(K) > RANK_BYTES) ? (size_t)TILE * sizeof(K) : RANK_BYTES;
   static constexpr size_t OFF_GBASE = REGION0;                     // u64[R]
   static constexpr size_t OFF_DBASE = OFF_GBASE + (size_t)R * 8;   // u32[R]
   static constexpr size_t OFF_CNT   = OFF_DBASE + (size_t)R * 4;   // u32[R]
@@ -485,20 +572,21 @@ struct RadixSmem {
   static constexpr int    MIN_WAVES_PER_SIMD = (WG_PER_CU * BLOCK) / 256;
 };
 
-template <int RB, int BLOCK, int KPT, int LB, int MATCH>
-__global__ __launch_bounds__(BLOCK, (RadixSmem<RB, BLOCK, KPT, LB>::MIN_WAVES_PER_SIMD))
-void radix_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 n, u32 shift, u32 dmask,
+template <typename K, int RB, int BLOCK, int KPT, int LB, int MATCH>
+__global__ __launch_bounds__(BLOCK, (RadixSmem<K, RB, BLOCK, KPT, LB>::MIN_WAVES_PER_SIMD))
+void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, u32 shift, u32 dmask,
                           const u64 *__restrict__ gbase,      // LOOKBACK: exclusive digit bases of this pass
                           u64 *__restrict__ status,           // LOOKBACK: [num_tiles][R/2] granules of this pass (zeroed)
                           u32 *__restrict__ ticket, u32 *__restrict__ error_flag,
                           u32 flags,                          // bit0: XCD-chunked tile order, bit1: non-temporal key loads
                           const u64 *__restrict__ tile_offs,  // !LOOKBACK: [R][num_tiles] absolute offsets
                           u64 num_tiles) {
-  using SM = RadixSmem<RB, BLOCK, KPT, LB>;
+  using SM = RadixSmem<K, RB, BLOCK, KPT, LB>;
+  using KO = KeyOps<K>;
   constexpr int R = SM::R, NW = SM::NW, TILE = SM::TILE;
   static_assert(BLOCK >= R, "one thread per digit needed");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u64 *s_keys  = reinterpret_cast<u64 *>(smem);
+  K   *s_keys  = reinterpret_cast<K *>(smem);
   u32 *s_whist = reinterpret_cast<u32 *>(smem);                       // aliases s_keys (see barriers)
   u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
   u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
@@ -526,13 +614,13 @@ void radix_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64
   const u64  tile_base = tile * (u64)TILE;
   const bool full      = (tile_base + TILE <= n);
   const u64  wave_base = tile_base + (u64)w * (64 * KPT) + lane;
-  u64 keys[KPT];
+  K keys[KPT];
 #pragma unroll
   for (int j = 0; j < KPT; j++) {
     const u64 idx = wave_base + (u64)j * 64;
-    keys[j] = (full || idx < n) ? ((flags & 2u) ? __builtin_nontemporal_load(in + idx) : in[idx])
-                                : ~0ull;               // padding sorts to the end of the last digit
+    keys[j] = (full || idx < n) ? in[idx] : KO::pad();  // padding sorts to the end of the last digit
   }
+  (void)flags;
 
   // ---- rank inside the wave (stable: by lane order inside a row, rows in order) ----
   const u64 lt_mask = (1ull << lane) - 1ull;
@@ -542,7 +630,7 @@ void radix_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64
     lds_u32 *wh = (lds_u32 *)(smem) + w * R;
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
-      const u32 d     = (u32)(keys[j] >> shift) & dmask;
+      const u32 d     = KO::digit(keys[j], shift, dmask);
       const u64 peers = match_digit<RB>(d);
       const u32 lower = __popcll(peers & lt_mask);
       const u32 base  = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -559,7 +647,7 @@ void radix_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64
     const u64 lane_bit = 1ull << lane;
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
-      const u32 d = (u32)(keys[j] >> shift) & dmask;
+      const u32 d = KO::digit(keys[j], shift, dmask);
       __hip_atomic_fetch_or(&mk[d], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       const u64 peers = __hip_atomic_load(&mk[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       const u32 base  = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -646,7 +734,7 @@ void radix_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64
   // ---- final position of every key inside the sorted tile ----
 #pragma unroll
   for (int j = 0; j < KPT; j++) {           // ranks[] becomes positions in place (still < TILE)
-    const u32 d = (u32)(keys[j] >> shift) & dmask;
+    const u32 d = KO::digit(keys[j], shift, dmask);
     const u32 add = s_dbase[d] + s_whist[w * R + d];
     ranks[j / 2] += (j & 1) ? (add << 16) : add;
   }
@@ -729,17 +817,17 @@ void radix_scatter_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64
   for (int j = 0; j < KPT; j++) {
     const u32 i = (u32)j * BLOCK + tid;
     if (i < n_valid) {
-      const u64 key = s_keys[i];
-      const u32 d   = (u32)(key >> shift) & dmask;
+      const K   key = s_keys[i];
+      const u32 d   = KO::digit(key, shift, dmask);
       out[s_gbase[d] + (u64)i] = key;
     }
   }
 }
 
 // ---- classic mode: per-tile digit histogram + row scan ----------------------
-template <int RB, int BLOCK, int KPT>
+template <typename K, int RB, int BLOCK, int KPT>
 __global__ __launch_bounds__(BLOCK)
-void radix_tile_hist_kernel(const u64 *__restrict__ in, u64 n, u32 shift, u32 dmask, u32 *__restrict__ tile_hist,
+void radix_tile_hist_kernel(const K *__restrict__ in, u64 n, u32 shift, u32 dmask, u32 *__restrict__ tile_hist,
                             u64 num_tiles) {
   constexpr int R = 1 << RB, TILE = BLOCK * KPT;
   __shared__ u32 s_h[R];
@@ -750,7 +838,7 @@ void radix_tile_hist_kernel(const u64 *__restrict__ in, u64 n, u32 shift, u32 dm
 #pragma unroll
   for (int j = 0; j < KPT; j++) {
     const u64 idx = tile_base + (u64)j * BLOCK + tid;
-    if (idx < n) atomicAdd(&s_h[(u32)(in[idx] >> shift) & dmask], 1u);
+    if (idx < n) atomicAdd(&s_h[KeyOps<K>::digit(in[idx], shift, dmask)], 1u);
   }
   __syncthreads();
   for (u32 i = tid; i < (u32)R; i += BLOCK) tile_hist[(u64)i * num_tiles + blockIdx.x] = s_h[i];
@@ -834,11 +922,11 @@ size_t sort_workspace_bytes(uint64_t n) {
   return sizeof(SortHeader) + 1024 + (size_t)t * RS_MAX_RADIX * (sizeof(uint32_t) + sizeof(uint64_t));
 }
 
-template <int RB, int BLOCK, int KPT, int MATCH, int LBK>
-static hipError_t run_passes(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, const SortPlan &plan, void *d_ws,
+template <typename K, int RB, int BLOCK, int KPT, int MATCH, int LBK>
+static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws,
                              uint32_t *d_error, int *result_in_alt, hipStream_t st, hipEvent_t *pass_events) {
-  using SM  = RadixSmem<RB, BLOCK, KPT, LBK>;
-  using SM0 = RadixSmem<RB, BLOCK, KPT, 0>;
+  using SM  = RadixSmem<K, RB, BLOCK, KPT, LBK>;
+  using SM0 = RadixSmem<K, RB, BLOCK, KPT, 0>;
   constexpr int R = 1 << RB, TILE = BLOCK * KPT;
   SortHeader *hdr = reinterpret_cast<SortHeader *>(d_ws);
   unsigned char *body = reinterpret_cast<unsigned char *>(d_ws) + ((sizeof(SortHeader) + 255) / 256) * 256;
@@ -846,14 +934,14 @@ static hipError_t run_passes(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, cons
 
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<RB, BLOCK, KPT, LBK, MATCH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<K, RB, BLOCK, KPT, LBK, MATCH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<RB, BLOCK, KPT, 0, MATCH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<K, RB, BLOCK, KPT, 0, MATCH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM0::BYTES);
     attr_done = true;
   }
 
-  u64 *src = reinterpret_cast<u64 *>(d_keys), *dst = reinterpret_cast<u64 *>(d_alt);
+  K *src = reinterpret_cast<K *>(d_keys), *dst = reinterpret_cast<K *>(d_alt);
   int in_alt = 0;
   // look-back granules hold 30-bit values: larger calls take the classic path
   const bool lookback = (plan.mode == 0) && (n < (1ull << 30));
@@ -870,7 +958,8 @@ static hipError_t run_passes(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, cons
     }
     uint64_t hgrid = (n + 256 * 16 - 1) / (256 * 16);
     if (hgrid > 2048) hgrid = 2048;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3((uint32_t)hgrid), dim3(256), 0, st, src, (u64)n, pl, &hdr->ghist[0][0]);
+    hipLaunchKernelGGL(radix_hist_kernel<K>, dim3((uint32_t)hgrid), dim3(256), 0, st, (const K *)src, (u64)n, pl,
+                       &hdr->ghist[0][0]);
     MGC_CHECK(hipGetLastError());
     hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(plan.num_passes), dim3(RS_MAX_RADIX), 0, st,
                        &hdr->ghist[0][0], &hdr->gbase[0][0]);
@@ -878,13 +967,13 @@ static hipError_t run_passes(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, cons
     for (uint32_t p = 0; p < plan.num_passes; p++) {
       MGC_CHECK(hipMemsetAsync(status, 0, status_bytes, st));
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
-      hipLaunchKernelGGL((radix_scatter_kernel<RB, BLOCK, KPT, LBK, MATCH>), dim3((uint32_t)num_tiles),
-                         dim3(BLOCK), SM::BYTES, st, src, dst, (u64)n, plan.pass_shift[p],
+      hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, LBK, MATCH>), dim3((uint32_t)num_tiles),
+                         dim3(BLOCK), SM::BYTES, st, (const K *)src, dst, (u64)n, plan.pass_shift[p],
                          (1u << plan.pass_bits[p]) - 1u, &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, plan.flags,
                          (const u64 *)nullptr, (u64)num_tiles);
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
-      u64 *t = src; src = dst; dst = t; in_alt ^= 1;
+      K *t = src; src = dst; dst = t; in_alt ^= 1;
     }
   } else {
     // ---- classic: histogram / scan / scatter per pass ----
@@ -892,8 +981,8 @@ static hipError_t run_passes(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, cons
     u64 *tile_offs = reinterpret_cast<u64 *>(body + (((size_t)num_tiles * R * sizeof(u32) + 255) / 256) * 256);
     for (uint32_t p = 0; p < plan.num_passes; p++) {
       const uint32_t shift = plan.pass_shift[p], dmask = (1u << plan.pass_bits[p]) - 1u;
-      hipLaunchKernelGGL((radix_tile_hist_kernel<RB, BLOCK, KPT>), dim3((uint32_t)num_tiles), dim3(BLOCK), 0, st,
-                         src, (u64)n, shift, dmask, tile_hist, (u64)num_tiles);
+      hipLaunchKernelGGL((radix_tile_hist_kernel<K, RB, BLOCK, KPT>), dim3((uint32_t)num_tiles), dim3(BLOCK), 0, st,
+                         (const K *)src, (u64)n, shift, dmask, tile_hist, (u64)num_tiles);
       MGC_CHECK(hipGetLastError());
       hipLaunchKernelGGL(radix_row_scan_kernel, dim3(R), dim3(1024), 0, st, tile_hist, tile_offs,
                          &hdr->row_total[0], (u64)num_tiles);
@@ -902,42 +991,47 @@ static hipError_t run_passes(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, cons
                          tile_offs, &hdr->row_total[0], (u32)R, (u64)num_tiles);
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
-      hipLaunchKernelGGL((radix_scatter_kernel<RB, BLOCK, KPT, 0, MATCH>), dim3((uint32_t)num_tiles), dim3(BLOCK),
-                         SM0::BYTES, st, src, dst, (u64)n, shift, dmask, (const u64 *)nullptr, (u64 *)nullptr,
+      hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, 0, MATCH>), dim3((uint32_t)num_tiles), dim3(BLOCK),
+                         SM0::BYTES, st, (const K *)src, dst, (u64)n, shift, dmask, (const u64 *)nullptr, (u64 *)nullptr,
                          (u32 *)nullptr, d_error, plan.flags, tile_offs, (u64)num_tiles);
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
-      u64 *t = src; src = dst; dst = t; in_alt ^= 1;
+      K *t = src; src = dst; dst = t; in_alt ^= 1;
     }
   }
   *result_in_alt = in_alt;
   return hipSuccess;
 }
 
-hipError_t launch_radix_sort(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, const SortPlan &plan,
+hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan,
                              void *d_ws, size_t ws_bytes, uint32_t *d_error, int *result_in_alt,
                              hipStream_t st, hipEvent_t *pass_events) {
   *result_in_alt = 0;
   if (n == 0 || plan.num_passes == 0) return hipSuccess;
   if (ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
-#define MGC_RUN(RB_, BLOCK_, KPT_)                                                                              \
+#define MGC_RUN(K_, RB_, BLOCK_, KPT_)                                                                       \
   do {                                                                                                       \
     if (plan.match == 0)                                                                                     \
-      return run_passes<RB_, BLOCK_, KPT_, 0, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 0, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
     if (plan.lookback == 2)                                                                                  \
-      return run_passes<RB_, BLOCK_, KPT_, 1, 2>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
-    return run_passes<RB_, BLOCK_, KPT_, 1, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);   \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 2>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+    return run_passes<K_, RB_, BLOCK_, KPT_, 1, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);   \
   } while (0)
-  if (plan.radix_bits == 9) {
-    if (plan.block == 1024 && plan.kpt == 8) MGC_RUN(9, 1024, 8);
-    if (plan.block == 1024) MGC_RUN(9, 1024, 16);
-    if (plan.kpt == 8) MGC_RUN(9, 512, 8);
-    MGC_RUN(9, 512, 16);
+  if (key_words == 2) {
+    // 128-bit keys: 8 keys per thread keep the tile at 128 KiB of LDS (one workgroup per CU)
+    if (plan.radix_bits == 9) MGC_RUN(K128, 9, 1024, 8);
+    MGC_RUN(K128, 8, 1024, 8);
   }
-  if (plan.block == 1024 && plan.kpt == 8) MGC_RUN(8, 1024, 8);
-  if (plan.block == 1024) MGC_RUN(8, 1024, 16);
-  if (plan.kpt == 8) MGC_RUN(8, 512, 8);
-  MGC_RUN(8, 512, 16);
+  if (plan.radix_bits == 9) {
+    if (plan.block == 1024 && plan.kpt == 8) MGC_RUN(u64, 9, 1024, 8);
+    if (plan.block == 1024) MGC_RUN(u64, 9, 1024, 16);
+    if (plan.kpt == 8) MGC_RUN(u64, 9, 512, 8);
+    MGC_RUN(u64, 9, 512, 16);
+  }
+  if (plan.block == 1024 && plan.kpt == 8) MGC_RUN(u64, 8, 1024, 8);
+  if (plan.block == 1024) MGC_RUN(u64, 8, 1024, 16);
+  if (plan.kpt == 8) MGC_RUN(u64, 8, 512, 8);
+  MGC_RUN(u64, 8, 512, 16);
 #undef MGC_RUN
 }
 
@@ -946,42 +1040,45 @@ hipError_t launch_radix_sort(uint64_t *d_keys, uint64_t *d_alt, uint64_t n, cons
 // ============================================================================
 
 constexpr int RL_BLOCK = 256;
-constexpr int RL_KPT   = 16;
-constexpr int RL_TILE  = RL_BLOCK * RL_KPT;
 constexpr u64 RL_INF   = ~0ull;
+template <typename K> struct RlTile { static constexpr int KPT = 16; };   // 4096 keys per tile
+template <> struct RlTile<K128>     { static constexpr int KPT = 8;  };   // 2048 (static LDS stays < 64 KiB)
 
 // workspace: [0] total distinct, [8..): tile_offs u64[T+1], tile_next u64[T+1]
 struct RleWs {
   u64 *total, *tile_offs, *tile_next;
   u64  num_tiles;
 };
-static inline RleWs rle_ws(void *d_ws, uint64_t n) {
+static inline RleWs rle_ws(void *d_ws, uint64_t n, uint32_t key_words) {
+  const uint64_t tile = (uint64_t)RL_BLOCK * (key_words == 2 ? RlTile<K128>::KPT : RlTile<u64>::KPT);
   RleWs w;
-  w.num_tiles = (n + RL_TILE - 1) / RL_TILE;
+  w.num_tiles = (n + tile - 1) / tile;
   w.total     = reinterpret_cast<u64 *>(d_ws);
   w.tile_offs = w.total + 8;
   w.tile_next = w.tile_offs + w.num_tiles + 1;
   return w;
 }
 size_t rle_workspace_bytes(uint64_t n) {
-  const uint64_t t = (n + RL_TILE - 1) / RL_TILE;
+  const uint64_t t = (n + 2047) / 2048;                // smallest tile in use
   return (size_t)(8 + 2 * (t + 1)) * sizeof(uint64_t);
 }
 
 // per tile: number of run heads and position of the first head
+template <typename K>
 __global__ __launch_bounds__(RL_BLOCK)
-void rle_count_kernel(const u64 *__restrict__ in, u64 n, u64 *__restrict__ tile_cnt, u64 *__restrict__ tile_first) {
+void rle_count_kernel(const K *__restrict__ in, u64 n, u64 *__restrict__ tile_cnt, u64 *__restrict__ tile_first) {
+  constexpr int KPT = RlTile<K>::KPT, TILE = RL_BLOCK * KPT;
   __shared__ u32 s_cnt[RL_BLOCK / 64];
   __shared__ u64 s_min[RL_BLOCK / 64];
-  const u64 tile_base = (u64)blockIdx.x * RL_TILE;
+  const u64 tile_base = (u64)blockIdx.x * TILE;
   u32 c = 0;
   u64 first = RL_INF;
 #pragma unroll
-  for (int j = 0; j < RL_KPT; j++) {
+  for (int j = 0; j < KPT; j++) {
     const u64 idx = tile_base + (u64)j * RL_BLOCK + threadIdx.x;
     if (idx < n) {
-      const u64 key = in[idx];
-      const bool head = (idx == 0) || (in[idx - 1] != key);
+      const K key = in[idx];
+      const bool head = (idx == 0) || KeyOps<K>::ne(in[idx - 1], key);
       if (head) { c++; if (idx < first) first = idx; }
     }
   }
@@ -1050,35 +1147,38 @@ void rle_tile_scan_kernel(u64 *__restrict__ tile_offs, u64 *__restrict__ tile_ne
 
 __device__ __forceinline__ u32 rl_pad(u32 i) { return i + (i >> 4); }
 
+template <typename K>
 __global__ __launch_bounds__(RL_BLOCK)
-void rle_emit_kernel(const u64 *__restrict__ in, u64 n, const u64 *__restrict__ tile_offs,
-                     const u64 *__restrict__ tile_next, u64 *__restrict__ out_keys, u32 *__restrict__ out_counts) {
-  __shared__ u64 s_keys[RL_TILE + 1 + (RL_TILE + 1) / 16 + 1];
+void rle_emit_kernel(const K *__restrict__ in, u64 n, const u64 *__restrict__ tile_offs,
+                     const u64 *__restrict__ tile_next, u64 out_base0, K *__restrict__ out_keys,
+                     u32 *__restrict__ out_counts) {
+  constexpr int RL_KPT = RlTile<K>::KPT, RL_TILE = RL_BLOCK * RL_KPT;
+  __shared__ K s_keys[RL_TILE + 1 + (RL_TILE + 1) / 16 + 1];
   __shared__ u32 s_tmp[RL_BLOCK / 64 + 1];
   __shared__ u64 s_wmin[RL_BLOCK / 64];
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const u64 tile_base = (u64)blockIdx.x * RL_TILE;
 
   // coalesced load; logical slot 0 holds the key preceding the tile
-  if (tid == 0) s_keys[rl_pad(0)] = (tile_base > 0) ? in[tile_base - 1] : 0ull;
+  if (tid == 0) s_keys[rl_pad(0)] = (tile_base > 0) ? in[tile_base - 1] : KeyOps<K>::zero();
 #pragma unroll
   for (int j = 0; j < RL_KPT; j++) {
     const u32 i   = (u32)j * RL_BLOCK + tid;
     const u64 idx = tile_base + i;
-    s_keys[rl_pad(i + 1)] = (idx < n) ? in[idx] : 0ull;
+    s_keys[rl_pad(i + 1)] = (idx < n) ? in[idx] : KeyOps<K>::zero();
   }
   __syncthreads();
 
   // blocked: thread owns RL_KPT consecutive keys
-  u64 keys[RL_KPT];
+  K keys[RL_KPT];
   u32 flags = 0;
-  u64 prev = s_keys[rl_pad(tid * RL_KPT)];
+  K prev = s_keys[rl_pad(tid * RL_KPT)];
 #pragma unroll
   for (int j = 0; j < RL_KPT; j++) {
     const u32 i   = tid * RL_KPT + j;
     const u64 idx = tile_base + i;
     keys[j] = s_keys[rl_pad(i + 1)];
-    const bool head = (idx < n) && ((idx == 0) || (keys[j] != prev));
+    const bool head = (idx < n) && ((idx == 0) || KeyOps<K>::ne(keys[j], prev));
     flags |= (head ? 1u : 0u) << j;
     prev = keys[j];
   }
@@ -1103,7 +1203,7 @@ void rle_emit_kernel(const u64 *__restrict__ in, u64 n, const u64 *__restrict__ 
   if (lane == 63) e = RL_INF;
   u64 next = (e < after) ? e : after;
 
-  const u64 out_base = tile_offs[blockIdx.x] + slot0;
+  const u64 out_base = out_base0 + tile_offs[blockIdx.x] + slot0;
 #pragma unroll
   for (int j = RL_KPT - 1; j >= 0; j--) {
     if ((flags >> j) & 1u) {
@@ -1116,11 +1216,15 @@ void rle_emit_kernel(const u64 *__restrict__ in, u64 n, const u64 *__restrict__ 
   }
 }
 
-hipError_t launch_rle_count(const uint64_t *d_sorted, uint64_t n, void *d_ws, hipStream_t st) {
-  RleWs w = rle_ws(d_ws, n);
+hipError_t launch_rle_count(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_ws, hipStream_t st) {
+  RleWs w = rle_ws(d_ws, n, key_words);
   if (n == 0) return hipMemsetAsync(w.total, 0, sizeof(u64), st);
-  hipLaunchKernelGGL(rle_count_kernel, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
-                     reinterpret_cast<const u64 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next);
+  if (key_words == 2)
+    hipLaunchKernelGGL(rle_count_kernel<K128>, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
+                       reinterpret_cast<const K128 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next);
+  else
+    hipLaunchKernelGGL(rle_count_kernel<u64>, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
+                       reinterpret_cast<const u64 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next);
   MGC_CHECK(hipGetLastError());
   hipLaunchKernelGGL(rle_tile_scan_kernel, dim3(1), dim3(1024), 0, st, w.tile_offs, w.tile_next, (u64)w.num_tiles,
                      (u64)n, w.total);
@@ -1132,39 +1236,49 @@ hipError_t rle_read_total(const void *d_ws, uint64_t *n_distinct, hipStream_t st
   return hipStreamSynchronize(st);
 }
 
-hipError_t launch_rle_emit(const uint64_t *d_sorted, uint64_t n, void *d_ws, uint64_t *d_unique,
+hipError_t launch_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_ws, void *d_unique,
                            uint32_t *d_counts, hipStream_t st) {
   if (n == 0) return hipSuccess;
-  RleWs w = rle_ws(d_ws, n);
-  hipLaunchKernelGGL(rle_emit_kernel, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
-                     reinterpret_cast<const u64 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next,
-                     reinterpret_cast<u64 *>(d_unique), d_counts);
+  RleWs w = rle_ws(d_ws, n, key_words);
+  if (key_words == 2)
+    hipLaunchKernelGGL(rle_emit_kernel<K128>, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
+                       reinterpret_cast<const K128 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next, (u64)0,
+                       reinterpret_cast<K128 *>(d_unique), d_counts);
+  else
+    hipLaunchKernelGGL(rle_emit_kernel<u64>, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
+                       reinterpret_cast<const u64 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next, (u64)0,
+                       reinterpret_cast<u64 *>(d_unique), d_counts);
   return hipGetLastError();
 }
 
 // ============================================================================
 //  Block offsets: first distinct key of every prefix
 // ============================================================================
-__global__ void block_offsets_kernel(const u64 *__restrict__ keys, u64 nd, u32 w_data, u64 n_prefix,
+template <typename K>
+__global__ void block_offsets_kernel(const K *__restrict__ keys, u64 nd, u32 w_data, u64 n_prefix,
                                      u64 *__restrict__ block_start) {
   const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (p > n_prefix) return;
   if (p == n_prefix) { block_start[p] = nd; return; }
-  const u64 target = p << w_data;
+  const K target = KeyOps<K>::prefix_floor(p, w_data);
   u64 lo = 0, hi = nd;
   while (lo < hi) {
     const u64 mid = lo + ((hi - lo) >> 1);
-    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+    if (KeyOps<K>::lt(keys[mid], target)) lo = mid + 1; else hi = mid;
   }
   block_start[p] = lo;
 }
 
-hipError_t launch_block_offsets(const uint64_t *d_unique, uint64_t n_distinct, uint32_t w_data,
+hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,
                                 uint64_t n_prefix, uint64_t *d_block_start, hipStream_t st) {
   const uint64_t threads = n_prefix + 1;
-  hipLaunchKernelGGL(block_offsets_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st,
-                     reinterpret_cast<const u64 *>(d_unique), (u64)n_distinct, w_data, (u64)n_prefix,
-                     reinterpret_cast<u64 *>(d_block_start));
+  const dim3 grid((uint32_t)((threads + 255) / 256));
+  if (key_words == 2)
+    hipLaunchKernelGGL(block_offsets_kernel<K128>, grid, dim3(256), 0, st, reinterpret_cast<const K128 *>(d_unique),
+                       (u64)n_distinct, w_data, (u64)n_prefix, reinterpret_cast<u64 *>(d_block_start));
+  else
+    hipLaunchKernelGGL(block_offsets_kernel<u64>, grid, dim3(256), 0, st, reinterpret_cast<const u64 *>(d_unique),
+                       (u64)n_distinct, w_data, (u64)n_prefix, reinterpret_cast<u64 *>(d_block_start));
   return hipGetLastError();
 }
 

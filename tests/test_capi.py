@@ -83,10 +83,14 @@ def test_error_codes_not_exit(native_lib):
     assert b"mgc_configure_counting" in native_lib.mgc_last_error(None)
     # argument checks of the device operators happen before any launch
     assert native_lib.mgc_dev_kmer_histogram(None, 10, 0, 0, 6, None, None, 0, None) == capi.MGC_EINVAL
-    assert native_lib.mgc_dev_kmer_histogram(None, 10, 40, 0, 6, None, None, 0, None) == capi.MGC_EUNSUPPORTED
+    assert native_lib.mgc_dev_kmer_histogram(None, 10, 65, 0, 6, None, None, 0, None) == capi.MGC_EINVAL
+    assert native_lib.mgc_dev_kmer_histogram(None, 10, 40, 0, 6, None, None, 0, None) == capi.MGC_EINVAL   # NULL bases
     ia = ctypes.c_int(0)
-    assert native_lib.mgc_dev_radix_sort_u64(None, None, 5, 10, 4, None, 0, ctypes.byref(ia), None) == capi.MGC_EINVAL
-    assert native_lib.mgc_dev_radix_sort_u64(None, None, 0, 0, 42, None, 0, ctypes.byref(ia), None) == capi.MGC_OK
+    assert native_lib.mgc_dev_radix_sort(None, None, 5, 1, 10, 4, None, 0, ctypes.byref(ia), None) == capi.MGC_EINVAL
+    assert native_lib.mgc_dev_radix_sort(None, None, 5, 1, 0, 65, None, 0, ctypes.byref(ia), None) == capi.MGC_EINVAL
+    assert native_lib.mgc_dev_radix_sort(None, None, 5, 3, 0, 64, None, 0, ctypes.byref(ia), None) == capi.MGC_EINVAL
+    assert native_lib.mgc_dev_radix_sort(None, None, 0, 1, 0, 42, None, 0, ctypes.byref(ia), None) == capi.MGC_OK
+    assert native_lib.mgc_dev_radix_sort(None, None, 0, 2, 0, 128, None, 0, ctypes.byref(ia), None) == capi.MGC_OK
 
 
 def test_workspace_sizes_monotone(native_lib):

@@ -13,7 +13,7 @@ from helpers import MODES, expected_arrays, random_reads
 
 pytestmark = pytest.mark.gpu
 
-CASES = [c for c in golden_cases() if c["k"] <= 32]
+CASES = golden_cases()
 
 
 @pytest.fixture(scope="module")
@@ -41,6 +41,14 @@ def _as_u64(t):
     return t.cpu().numpy().view(np.uint64)
 
 
+def _as_int(t):
+    """key tensor (int64[N] or int64[N, 2] {lo, hi}) -> list of Python ints"""
+    a = _as_u64(t)
+    if a.ndim == 2:
+        return [(int(h) << 64) | int(l) for l, h in a]
+    return [int(x) for x in a]
+
+
 def test_native_library_loaded_not_fallback(native_lib):
     # the HIP extension must be the thing that runs: in-tree .so mapped into this process
     from meryl_amd import capi
@@ -56,21 +64,23 @@ def test_synth_reads_match_oracle(ops, oracle_lib, torch_cuda):
 
 
 @pytest.mark.parametrize("bucket_bits", [0, 6, 10])
-@pytest.mark.parametrize("k,mode", [(21, 0), (5, 0), (32, 0), (31, 1), (17, 2), (1, 0), (3, 0)])
+@pytest.mark.parametrize("k,mode", [(21, 0), (5, 0), (32, 0), (31, 1), (17, 2), (1, 0), (3, 0),
+                                    (33, 0), (51, 0), (64, 0), (47, 1), (64, 2)])
 def test_pack_partition_matches_oracle(ops, oracle_lib, torch_cuda, k, mode, bucket_bits):
     if bucket_bits > 2 * k:
         pytest.skip("more bucket bits than key bits")
     rng = np.random.default_rng(k * 7 + mode)
     bases = random_reads(rng, 400, 1, 300)
     keys, counts = ops.dev_kmer_partition(_dev_bases(torch_cuda, bases), k, mode, bucket_bits)
-    got = _as_u64(keys)
-    _, want = oracle_lib.enumerate_kmers(bases, k, mode)
-    assert got.size == want.size == int(counts.sum())
-    assert np.array_equal(np.sort(got), np.sort(want))          # same multiset of instances
+    got = _as_int(keys)
+    whi, wlo = oracle_lib.enumerate_kmers(bases, k, mode)
+    want = [(int(h) << 64) | int(l) for h, l in zip(whi, wlo)]
+    assert len(got) == len(want) == int(counts.sum())
+    assert sorted(got) == sorted(want)                           # same multiset of instances
     # grouped by bucket in ascending bucket order, sizes as reported
-    b = (got >> np.uint64(2 * k - bucket_bits)) if bucket_bits else np.zeros_like(got)
-    assert np.all(np.diff(b.astype(np.int64)) >= 0)
-    assert np.array_equal(np.bincount(b.astype(np.int64), minlength=1 << bucket_bits), counts.astype(np.int64))
+    b = np.array([x >> (2 * k - bucket_bits) for x in got], dtype=np.int64) if bucket_bits else np.zeros(len(got), np.int64)
+    assert np.all(np.diff(b) >= 0)
+    assert np.array_equal(np.bincount(b, minlength=1 << bucket_bits), counts.astype(np.int64))
 
 
 def test_pack_unaligned_and_tiny_inputs(ops, oracle_lib, torch_cuda):
@@ -148,6 +158,36 @@ def test_run_length_long_runs_cross_tiles(ops, torch_cuda):
     assert np.array_equal(_as_u64(u), wu) and np.array_equal(c.cpu().numpy().view(np.uint32), wc.astype(np.uint32))
 
 
+@pytest.mark.parametrize("n", [0, 1, 777, 8192, 8193, 200_003])
+@pytest.mark.parametrize("bits", [(0, 128), (0, 102), (60, 70), (64, 96), (3, 40)])
+def test_radix_sort_u128_matches_numpy(ops, torch_cuda, n, bits, monkeypatch):
+    rng = np.random.default_rng(n + bits[1])
+    lo, hi = bits
+    a = rng.integers(0, 2**63, size=(n, 2), dtype=np.int64).astype(np.uint64) * np.uint64(2) + \
+        rng.integers(0, 2, size=(n, 2)).astype(np.uint64)
+    vals = [(int(h) << 64) | int(l) for l, h in a]
+    mask = ((1 << (hi - lo)) - 1) << lo
+    order = sorted(range(n), key=lambda i: (vals[i] & mask, i))          # stable on the selected bits
+    want = [vals[i] for i in order]
+    for rb, mode in (("8", "0"), ("9", "0"), ("8", "1")):
+        monkeypatch.setenv("MGC_RADIX_BITS", rb)
+        monkeypatch.setenv("MGC_SORT_MODE", mode)
+        t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
+        assert _as_int(ops.dev_radix_sort(t, lo, hi)) == want, (n, bits, rb, mode)
+
+
+def test_run_length_u128(ops, torch_cuda):
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 2**62, size=(3000, 2), dtype=np.int64).astype(np.uint64)
+    reps = rng.integers(1, 40, size=3000)
+    vals = sorted(((int(h) << 64) | int(l), int(r)) for (l, h), r in zip(base, reps))
+    flat = np.array([[v & (2**64 - 1), v >> 64] for v, r in vals for _ in range(r)], dtype=np.uint64)
+    t = torch_cuda.from_numpy(flat.view(np.int64).copy()).cuda()
+    u, c = ops.dev_run_length(t)
+    assert _as_int(u) == [v for v, _ in vals]
+    assert c.cpu().numpy().tolist() == [r for _, r in vals]
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_golden_cases(ops, torch_cuda, case):
     # the committed golden vectors (incl. the reference's GGAGCT table)
@@ -162,7 +202,8 @@ def test_golden_cases(ops, torch_cuda, case):
         with ops.Session(cfg) as s:
             s.push_bases(case["bases"], end_of_sequence=False)
             s.count()
-            keys, counts, bstart = s.result()
+            klo, khi, counts, bstart = s.result_wide()
+            keys = [(int(h) << 64) | int(l) for h, l in zip(khi, klo)]
             info = s.info()
         assert info.n_instances == case["n_instances"] and info.n_distinct == len(ek)
         assert bstart[0] == 0 and bstart[-1] == len(ek) and np.all(np.diff(bstart.astype(np.int64)) >= 0)
@@ -172,9 +213,36 @@ def test_golden_cases(ops, torch_cuda, case):
         bb = min(6, 2 * k)
         part, _ = ops.dev_kmer_partition(_dev_bases(torch_cuda, case["bases"]), k, MODES[case["mode"]], bb)
         u, c = ops.dev_run_length(ops.dev_radix_sort(part, 0, 2 * k))
-        keys, counts = _as_u64(u), c.cpu().numpy().view(np.uint32)
+        keys, counts = _as_int(u), c.cpu().numpy().view(np.uint32)
     assert [int(x) for x in keys] == ek
     assert [int(x) for x in counts] == ec
+
+
+@pytest.mark.parametrize("k,mode,n_reads", [(33, 0, 3000), (51, 0, 4000), (64, 1, 2000)])
+def test_session_wide_keys_match_oracle(ops, oracle_lib, torch_cuda, k, mode, n_reads, tmp_path):
+    # k in 33..64: 128-bit keys end to end, including the addBlock stream and the database
+    from meryl_amd import capi, db
+    bases = oracle_lib.synth_reads(8, 150_000, 0, n_reads)
+    cfg = capi.configure(k, bases.size, 1 << 30, mode)
+    d = torch_cuda.from_numpy(bases).cuda()
+    blocks = []
+    path = str(tmp_path / "wide.meryl")
+    with ops.Session(cfg) as s:
+        s.push_bases_device(d)
+        s.count()
+        klo, khi, counts, bstart = s.result_wide()
+        s.finish(lambda p, n, slo, cnt, shi: blocks.append((p, slo, shi, cnt)), host_threads=4)
+        db.write_database(s, path, host_threads=4)
+    whi, wlo, wcn, wni = oracle_lib.count_brute(bases.tobytes(), k, mode)
+    assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+    blocks.sort(key=lambda b: b[0])
+    assert [b[0] for b in blocks] == list(range(cfg.n_prefix))
+    re = [((p << cfg.w_data) | (int(h) << 64) | int(l)) for p, slo, shi, _ in blocks for l, h in zip(slo, shi)]
+    assert re == [(int(h) << 64) | int(l) for h, l in zip(whi, wlo)]
+    r = db.Reader(path)
+    lo, hi, cn = r.read_all()
+    assert np.array_equal(lo, wlo) and np.array_equal(hi, whi) and np.array_equal(cn, wcn) and r.info.k == k
+    r.close()
 
 
 @pytest.mark.parametrize("k,mode,n_reads", [(21, 0, 20000), (22, 0, 3000), (31, 0, 3000), (32, 1, 2000), (16, 2, 2000), (8, 0, 2000)])
