@@ -144,6 +144,15 @@ int mgc_dev_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words, void 
 int mgc_dev_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,
                           uint64_t n_prefix, uint64_t *d_block_start, void *stream);
 
+/* Homopolymer compression of a base stream (the `compress` word: merylInput.C:
+ * 237-240,261-268 calls homopolyCompress() on every chunk loadBases returns,
+ * carrying the last byte across chunks of a sequence).  Drops every byte equal,
+ * ignoring case, to the byte before it; d_out needs n bytes; *n_out = new length.
+ * The session applies this itself when cfg.homopoly_compress is set. */
+size_t mgc_dev_homopoly_workspace_bytes(uint64_t n);
+int mgc_dev_homopoly_compress(const uint8_t *d_in, uint64_t n, uint8_t *d_out, uint64_t *n_out,
+                              void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------
  * Session -- replaces merylOperation::countThreads
  * (src/meryl/merylOp-countThreads.C:385-474).

@@ -24,6 +24,7 @@ SYMBOLS = (
     "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_count",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_version",
+    "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress",
     # include/meryl_db.h
     "mdb_writer_open", "mdb_writer_add_block", "mdb_writer_close", "mdb_last_error",
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_close",
@@ -166,6 +167,8 @@ def lib():
     sig("mgc_dev_rle_count", i32, vp, u64, u32, vp, sz, P(u64), vp)
     sig("mgc_dev_rle_emit", i32, vp, u64, u32, vp, sz, vp, vp, vp)
     sig("mgc_dev_block_offsets", i32, vp, u64, u32, u32, u64, vp, vp)
+    sig("mgc_dev_homopoly_workspace_bytes", sz, u64)
+    sig("mgc_dev_homopoly_compress", i32, vp, u64, vp, P(u64), vp, sz, vp)
     sig("mgc_dev_synth_reads", i32, u64, u64, u64, u64, u32, u32, u32, vp, vp)
     sig("mgc_open", vp, P(CountConfig), i32)
     sig("mgc_close", None, vp)

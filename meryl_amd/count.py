@@ -45,6 +45,19 @@ def dev_synth_reads(seed, genome_len, first_read, n_reads, read_len=150, sub_rat
     return out
 
 
+def dev_homopoly_compress(bases):
+    """uint8 cuda tensor -> homopolymer-compressed uint8 cuda tensor (`compress`)."""
+    L = capi.lib()
+    n = bases.numel()
+    out = torch.empty(n, dtype=torch.uint8, device=bases.device)
+    ws_bytes = L.mgc_dev_homopoly_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=bases.device)
+    n_out = ctypes.c_uint64(0)
+    capi.check(L.mgc_dev_homopoly_compress(_ptr(bases), n, _ptr(out), ctypes.byref(n_out), _ptr(ws), ws_bytes,
+                                           _stream_ptr()), "mgc_dev_homopoly_compress")
+    return out[:n_out.value]
+
+
 def key_words(k):
     """uint64 keys for k <= 32, 16-byte {lo, hi} pairs for k in 33..64."""
     return 2 if k > 32 else 1

@@ -232,6 +232,18 @@ extern "C" int mgc_dev_block_offsets(const void *d_unique, uint64_t n_distinct, 
                                           (hipStream_t)stream), "block_offsets");
 }
 
+extern "C" size_t mgc_dev_homopoly_workspace_bytes(uint64_t n) { return mgc::hpc_workspace_bytes(n); }
+
+extern "C" int mgc_dev_homopoly_compress(const uint8_t *d_in, uint64_t n, uint8_t *d_out, uint64_t *n_out, void *d_ws,
+                                         size_t ws_bytes, void *stream) {
+  if (!n_out || !d_ws || ws_bytes < mgc::hpc_workspace_bytes(n) || (n && (!d_in || !d_out))) return MGC_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = mgc::launch_homopoly_compress(d_in, n, d_out, d_ws, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(n_out, d_ws, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  return hip_rc(e, "homopoly_compress");
+}
+
 extern "C" int mgc_dev_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                                    uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm, uint8_t *d_out,
                                    void *stream) {
@@ -268,7 +280,7 @@ struct mgc_session {
   // device arena: buffers survive between mgc_count calls (grow-only), so a
   // repeated count does not pay hipMalloc/hipFree of tens of GB every time
   struct Buf { void *p = nullptr; size_t cap = 0; };
-  enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_NUM };
+  enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_HPC, B_HPC_WS, B_NUM };
   Buf buf[B_NUM];
   hipError_t ensure(int which, size_t bytes) {
     Buf &b = buf[which];
@@ -309,7 +321,6 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
     set_err(nullptr, "mgc_open: simple (direct-index) mode is not implemented");
     return nullptr;
   }
-  if (cfg->homopoly_compress) { set_err(nullptr, "mgc_open: `compress` is not implemented yet"); return nullptr; }
 
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -424,6 +435,22 @@ extern "C" int mgc_count(mgc_session *s) {
     s->d_bases = s->d_bases_own;
   }
 
+  // ---- `compress`: homopolymer-compress the base stream on the device (merylInput.C:261-268) ----
+  const uint8_t *d_bases = s->d_bases;
+  uint64_t n_bases = s->n_bases;
+  if (c.homopoly_compress && n_bases) {
+    HIP_TRY(s, s->ensure(mgc_session::B_HPC, n_bases));
+    HIP_TRY(s, s->ensure(mgc_session::B_HPC_WS, mgc::hpc_workspace_bytes(n_bases)));
+    uint8_t *d_hpc = reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_HPC].p);
+    void *hws = s->buf[mgc_session::B_HPC_WS].p;
+    HIP_TRY(s, mgc::launch_homopoly_compress(d_bases, n_bases, d_hpc, hws, st));
+    uint64_t n_out = 0;
+    HIP_TRY(s, hipMemcpyAsync(&n_out, hws, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+    d_bases = d_hpc;
+    n_bases = n_out;
+  }
+
   hipEvent_t ev_all[2];
   if (s->profiling) { (void)hipEventCreate(&ev_all[0]); (void)hipEventCreate(&ev_all[1]); (void)hipEventRecord(ev_all[0], st); }
   StageTimer tm(s->profiling, st);
@@ -434,7 +461,7 @@ extern "C" int mgc_count(mgc_session *s) {
   void *part_ws = s->buf[mgc_session::B_PART_WS].p;
   uint64_t *d_counts64 = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_META].p), *d_starts = d_counts64 + nb;
   tm.begin(MGC_STAGE_HISTOGRAM);
-  HIP_TRY(s, mgc::launch_kmer_histogram(s->d_bases, s->n_bases, k, c.mode, bucket_bits, d_counts64, part_ws, st));
+  HIP_TRY(s, mgc::launch_kmer_histogram(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, part_ws, st));
   tm.end(MGC_STAGE_HISTOGRAM);
   s->prof.stage_launches[MGC_STAGE_HISTOGRAM] = 1;
   uint64_t h_counts[MGC_NUM_FILES], h_starts[MGC_NUM_FILES + 1];
@@ -460,7 +487,7 @@ extern "C" int mgc_count(mgc_session *s) {
   unsigned char *Y = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_Y].p);
   HIP_TRY(s, hipMemcpyAsync(d_starts, h_starts, sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
   tm.begin(MGC_STAGE_PARTITION);
-  HIP_TRY(s, mgc::launch_kmer_partition(s->d_bases, s->n_bases, k, c.mode, bucket_bits, d_starts, (void *)X, part_ws, st));
+  HIP_TRY(s, mgc::launch_kmer_partition(d_bases, n_bases, k, c.mode, bucket_bits, d_starts, (void *)X, part_ws, st));
   tm.end(MGC_STAGE_PARTITION);
   s->prof.stage_launches[MGC_STAGE_PARTITION] = 2;
 

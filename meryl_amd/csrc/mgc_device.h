@@ -66,6 +66,11 @@ hipError_t launch_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words,
 hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,
                                 uint64_t n_prefix, uint64_t *d_block_start, hipStream_t st);
 
+// ---- homopolymer compression -------------------------------------------------
+size_t     hpc_workspace_bytes(uint64_t n);
+// compressed length lands in the first uint64 of the workspace
+hipError_t launch_homopoly_compress(const uint8_t *d_in, uint64_t n, uint8_t *d_out, void *d_ws, hipStream_t st);
+
 hipError_t launch_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                               uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,
                               uint8_t *d_out, hipStream_t st);

@@ -1036,6 +1036,135 @@ hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key
 }
 
 // ============================================================================
+//  Multi-block scans over uint64 arrays (in place)
+//    forward exclusive sum   : a[i] <- sum_{j<i} a[j]          (total returned in *total)
+//    reverse inclusive min   : a[i] <- min(a[i], a[i+1], ..., a[n-1], init)
+//  Three phases per level (local scan + block totals, recurse on the totals, add back);
+//  4096 entries per workgroup, so two levels cover 16 M entries.
+// ============================================================================
+constexpr int SC_BLOCK = 1024;
+constexpr int SC_ITEMS = 4;
+constexpr int SC_CHUNK = SC_BLOCK * SC_ITEMS;
+
+template <bool MIN_REVERSE>
+__global__ __launch_bounds__(SC_BLOCK)
+void scan_local_kernel(u64 *__restrict__ a, u64 n, u64 *__restrict__ block_tot) {
+  __shared__ u64 s_tmp[SC_BLOCK / 64 + 1];
+  const u64 chunk0 = (u64)blockIdx.x * SC_CHUNK;
+  u64 v[SC_ITEMS];
+  if (!MIN_REVERSE) {
+    u64 sum = 0;
+#pragma unroll
+    for (int q = 0; q < SC_ITEMS; q++) {
+      const u64 i = chunk0 + (u64)threadIdx.x * SC_ITEMS + q;
+      v[q] = (i < n) ? a[i] : 0ull;
+      sum += v[q];
+    }
+    u64 tot;
+    u64 run = block_excl_scan<SC_BLOCK, u64>(sum, s_tmp, &tot);
+#pragma unroll
+    for (int q = 0; q < SC_ITEMS; q++) {
+      const u64 i = chunk0 + (u64)threadIdx.x * SC_ITEMS + q;
+      if (i < n) a[i] = run;
+      run += v[q];
+    }
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
+  } else {
+    // thread t owns entries (reversed inside the chunk) so that a forward min-scan over t is a suffix min
+    const u32 rt = SC_BLOCK - 1 - threadIdx.x;
+    u64 m = ~0ull;
+#pragma unroll
+    for (int q = SC_ITEMS - 1; q >= 0; q--) {
+      const u64 i = chunk0 + (u64)rt * SC_ITEMS + q;
+      v[q] = (i < n) ? a[i] : ~0ull;
+      m = (v[q] < m) ? v[q] : m;
+      v[q] = m;                                       // suffix min inside the thread's items
+    }
+    // inclusive min-scan across threads (thread 0 holds the LAST items of the chunk)
+    const u32 lane = lane_id(), w = wave_id();
+    u64 x = m;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const u64 y = __shfl_up(x, d);
+      if ((int)lane >= d) x = (y < x) ? y : x;
+    }
+    __syncthreads();
+    if (lane == 63) s_tmp[w] = x;
+    __syncthreads();
+    u64 pre = ~0ull;                                  // min over earlier threads (= later entries)
+    for (u32 i = 0; i < w; i++) pre = (s_tmp[i] < pre) ? s_tmp[i] : pre;
+    const u64 y = __shfl_up(x, 1);
+    u64 before = (lane == 0) ? pre : ((y < pre) ? y : pre);
+#pragma unroll
+    for (int q = 0; q < SC_ITEMS; q++) {
+      const u64 i = chunk0 + (u64)rt * SC_ITEMS + q;
+      const u64 r = (v[q] < before) ? v[q] : before;
+      if (i < n) a[i] = r;
+    }
+    if (threadIdx.x == SC_BLOCK - 1) {                // owner of the chunk's first entries: chunk minimum
+      const u64 tot = (x < pre) ? x : pre;
+      block_tot[blockIdx.x] = tot;
+    }
+  }
+}
+
+template <bool MIN_REVERSE>
+__global__ __launch_bounds__(SC_BLOCK)
+void scan_add_kernel(u64 *__restrict__ a, u64 n, const u64 *__restrict__ block_tot, u64 nblocks, u64 init) {
+  // forward sum : add the exclusive prefix of the block totals (block_tot already scanned)
+  // reverse min : combine with the suffix min of the LATER blocks' minima (block_tot already scanned) and init
+  const u64 b = blockIdx.x;
+  u64 carry;
+  if (!MIN_REVERSE) carry = block_tot[b];
+  else              carry = (b + 1 < nblocks) ? ((block_tot[b + 1] < init) ? block_tot[b + 1] : init) : init;
+#pragma unroll
+  for (int q = 0; q < SC_ITEMS; q++) {
+    const u64 i = b * SC_CHUNK + (u64)threadIdx.x * SC_ITEMS + q;
+    if (i < n) {
+      if (!MIN_REVERSE) a[i] += carry;
+      else { const u64 x = a[i]; a[i] = (x < carry) ? x : carry; }
+    }
+  }
+}
+
+__global__ void scan_store_total_kernel(const u64 *__restrict__ last_tot, u64 *__restrict__ total) { *total = *last_tot; }
+
+// scratch needs (n/4096 + n/4096^2 + 8) uint64
+static size_t scan_scratch_elems(uint64_t n) {
+  uint64_t e = 8, m = n;
+  while (m > 1) { m = (m + SC_CHUNK - 1) / SC_CHUNK; e += m + 1; if (m == 1) break; }
+  return (size_t)e + 8;
+}
+
+template <bool MIN_REVERSE>
+static hipError_t scan_u64_inplace(u64 *a, uint64_t n, u64 *scratch, u64 *d_total /* may be null */, u64 init,
+                                   hipStream_t st) {
+  if (n == 0) {
+    if (d_total) return hipMemsetAsync(d_total, 0, sizeof(u64), st);
+    return hipSuccess;
+  }
+  const uint64_t nblocks = (n + SC_CHUNK - 1) / SC_CHUNK;
+  hipLaunchKernelGGL(scan_local_kernel<MIN_REVERSE>, dim3((uint32_t)nblocks), dim3(SC_BLOCK), 0, st, a, (u64)n, scratch);
+  MGC_CHECK(hipGetLastError());
+  if (nblocks > 1 || MIN_REVERSE) {
+    // level 2: scan the block totals (forward: exclusive sum; reverse: suffix min), then fold them back
+    if (!MIN_REVERSE) {
+      MGC_CHECK(scan_u64_inplace<false>(scratch, nblocks, scratch + nblocks + 1, d_total, 0, st));
+    } else if (nblocks > 1) {
+      MGC_CHECK(scan_u64_inplace<true>(scratch, nblocks, scratch + nblocks + 1, nullptr, ~0ull, st));
+    }
+    hipLaunchKernelGGL(scan_add_kernel<MIN_REVERSE>, dim3((uint32_t)nblocks), dim3(SC_BLOCK), 0, st, a, (u64)n,
+                       (const u64 *)scratch, (u64)nblocks, init);
+    MGC_CHECK(hipGetLastError());
+  } else {
+    if (!MIN_REVERSE) {
+      if (d_total) { hipLaunchKernelGGL(scan_store_total_kernel, dim3(1), dim3(1), 0, st, (const u64 *)scratch, d_total); MGC_CHECK(hipGetLastError()); }
+    }
+  }
+  return hipSuccess;
+}
+
+// ============================================================================
 //  Run-length count of sorted keys
 // ============================================================================
 
@@ -1044,9 +1173,9 @@ constexpr u64 RL_INF   = ~0ull;
 template <typename K> struct RlTile { static constexpr int KPT = 16; };   // 4096 keys per tile
 template <> struct RlTile<K128>     { static constexpr int KPT = 8;  };   // 2048 (static LDS stays < 64 KiB)
 
-// workspace: [0] total distinct, [8..): tile_offs u64[T+1], tile_next u64[T+1]
+// workspace: [0] total distinct, [8..): tile_offs u64[T+1], tile_next u64[T+1], scan scratch
 struct RleWs {
-  u64 *total, *tile_offs, *tile_next;
+  u64 *total, *tile_offs, *tile_next, *scratch;
   u64  num_tiles;
 };
 static inline RleWs rle_ws(void *d_ws, uint64_t n, uint32_t key_words) {
@@ -1056,11 +1185,12 @@ static inline RleWs rle_ws(void *d_ws, uint64_t n, uint32_t key_words) {
   w.total     = reinterpret_cast<u64 *>(d_ws);
   w.tile_offs = w.total + 8;
   w.tile_next = w.tile_offs + w.num_tiles + 1;
+  w.scratch   = w.tile_next + w.num_tiles + 1;
   return w;
 }
 size_t rle_workspace_bytes(uint64_t n) {
   const uint64_t t = (n + 2047) / 2048;                // smallest tile in use
-  return (size_t)(8 + 2 * (t + 1)) * sizeof(uint64_t);
+  return (size_t)(8 + 2 * (t + 1) + scan_scratch_elems(t + 1)) * sizeof(uint64_t);
 }
 
 // per tile: number of run heads and position of the first head
@@ -1099,50 +1229,10 @@ void rle_count_kernel(const K *__restrict__ in, u64 n, u64 *__restrict__ tile_cn
   }
 }
 
-// single workgroup: exclusive scan of tile counts, suffix-min of first heads
-__global__ __launch_bounds__(1024)
-void rle_tile_scan_kernel(u64 *__restrict__ tile_offs, u64 *__restrict__ tile_next, u64 num_tiles, u64 n,
-                          u64 *__restrict__ total) {
-  __shared__ u64 s_tmp[1024 / 64 + 1];
-  __shared__ u64 s_carry;
-  u64 carry = 0;
-  for (u64 c = 0; c < num_tiles; c += 1024) {
-    const u64 t = c + threadIdx.x;
-    const u64 v = (t < num_tiles) ? tile_offs[t] : 0ull;
-    u64 tot;
-    const u64 e = block_excl_scan<1024, u64>(v, s_tmp, &tot);
-    if (t < num_tiles) tile_offs[t] = carry + e;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) { tile_offs[num_tiles] = carry; *total = carry; }
-
-  // backwards: tile_next[t] = min(first head of tiles >= t), tile_next[num_tiles] = n
-  if (threadIdx.x == 0) { tile_next[num_tiles] = n; s_carry = n; }
-  __syncthreads();
-  const u64 chunks = (num_tiles + 1023) / 1024;
-  for (u64 ci = 0; ci < chunks; ci++) {
-    const u64 c_end = num_tiles - ci * 1024;                 // exclusive end of this chunk
-    const bool has  = (threadIdx.x < c_end);
-    const u64 t     = has ? (c_end - 1 - threadIdx.x) : 0;   // reversed: thread 0 takes the last tile
-    u64 x = has ? tile_next[t] : RL_INF;
-    // inclusive min-scan over the reversed order
-    const u32 lane = lane_id(), w = wave_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const u64 y = __shfl_up(x, d);
-      if ((int)lane >= d) x = (y < x) ? y : x;
-    }
-    __syncthreads();
-    if (lane == 63) s_tmp[w] = x;
-    __syncthreads();
-    u64 pre = s_carry;
-    for (u32 i = 0; i < w; i++) pre = (s_tmp[i] < pre) ? s_tmp[i] : pre;
-    x = (pre < x) ? pre : x;
-    if (has) tile_next[t] = x;
-    __syncthreads();
-    if (threadIdx.x == 1023) s_carry = x;
-    __syncthreads();
-  }
+__global__ void rle_set_tail_kernel(u64 *__restrict__ tile_offs, u64 *__restrict__ tile_next, u64 num_tiles, u64 n,
+                                    const u64 *__restrict__ total) {
+  tile_offs[num_tiles] = *total;
+  tile_next[num_tiles] = n;
 }
 
 __device__ __forceinline__ u32 rl_pad(u32 i) { return i + (i >> 4); }
@@ -1226,8 +1316,11 @@ hipError_t launch_rle_count(const void *d_sorted, uint64_t n, uint32_t key_words
     hipLaunchKernelGGL(rle_count_kernel<u64>, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
                        reinterpret_cast<const u64 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next);
   MGC_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(rle_tile_scan_kernel, dim3(1), dim3(1024), 0, st, w.tile_offs, w.tile_next, (u64)w.num_tiles,
-                     (u64)n, w.total);
+  // tile_offs: exclusive sum of the per-tile head counts; tile_next: first head at or after each tile (n past the end)
+  MGC_CHECK(scan_u64_inplace<false>(w.tile_offs, w.num_tiles, w.scratch, w.total, 0, st));
+  MGC_CHECK(scan_u64_inplace<true>(w.tile_next, w.num_tiles, w.scratch, nullptr, (u64)n, st));
+  hipLaunchKernelGGL(rle_set_tail_kernel, dim3(1), dim3(1), 0, st, w.tile_offs, w.tile_next, (u64)w.num_tiles, (u64)n,
+                     (const u64 *)w.total);
   return hipGetLastError();
 }
 
@@ -1279,6 +1372,74 @@ hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint3
   else
     hipLaunchKernelGGL(block_offsets_kernel<u64>, grid, dim3(256), 0, st, reinterpret_cast<const u64 *>(d_unique),
                        (u64)n_distinct, w_data, (u64)n_prefix, reinterpret_cast<u64 *>(d_block_start));
+  return hipGetLastError();
+}
+
+// ============================================================================
+//  Homopolymer compression (`compress`): merylInput.C:261-268 applies
+//  homopolyCompress() to every chunk of a sequence, carrying the last byte across
+//  chunks; on the whole base stream that is: drop every byte that equals
+//  (case-insensitively) the byte before it.  '.' breakers never equal a base, so runs
+//  do not merge across sequences.  Stream compaction: count, scan, emit.
+// ============================================================================
+constexpr int HP_BLOCK = 256;
+constexpr int HP_TILE  = HP_BLOCK * 16;
+
+__device__ __forceinline__ u32 hp_keep_mask(const uint8_t *__restrict__ in, u64 n, u64 pos, bool aligned, uint4 &v) {
+  v = load16(in, pos, n, aligned);
+  u32 prev = (pos == 0) ? 0x100u : ((u32)in[pos - 1] | 0x20u);
+  const u32 w[4] = { v.x, v.y, v.z, v.w };
+  u32 keep = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const u32 c = ((w[i >> 2] >> (8 * (i & 3))) & 0xFFu) | 0x20u;
+    if (c != prev && pos + i < n) keep |= 1u << i;
+    prev = c;
+  }
+  return keep;
+}
+
+__global__ __launch_bounds__(HP_BLOCK)
+void hpc_count_kernel(const uint8_t *__restrict__ in, u64 n, u64 *__restrict__ tile_cnt) {
+  __shared__ u32 s_tmp[HP_BLOCK / 64 + 1];
+  const bool aligned = ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+  uint4 v;
+  const u32 keep = hp_keep_mask(in, n, (u64)blockIdx.x * HP_TILE + (u64)threadIdx.x * 16, aligned, v);
+  u32 tot;
+  (void)block_excl_scan<HP_BLOCK, u32>(__popc(keep), s_tmp, &tot);
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(HP_BLOCK)
+void hpc_emit_kernel(const uint8_t *__restrict__ in, u64 n, const u64 *__restrict__ tile_offs, uint8_t *__restrict__ out) {
+  __shared__ u32 s_tmp[HP_BLOCK / 64 + 1];
+  const bool aligned = ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+  uint4 v;
+  const u32 keep = hp_keep_mask(in, n, (u64)blockIdx.x * HP_TILE + (u64)threadIdx.x * 16, aligned, v);
+  u32 tot;
+  const u32 base = block_excl_scan<HP_BLOCK, u32>(__popc(keep), s_tmp, &tot);
+  u64 o = tile_offs[blockIdx.x] + base;
+  const u32 w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+    if ((keep >> i) & 1u) out[o++] = (uint8_t)((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+}
+
+size_t hpc_workspace_bytes(uint64_t n) {
+  const uint64_t t = (n + HP_TILE - 1) / HP_TILE;
+  return (size_t)(8 + t + 1 + scan_scratch_elems(t + 1)) * sizeof(uint64_t);
+}
+
+// d_ws[0] receives the compressed length (device); the caller reads it back.
+hipError_t launch_homopoly_compress(const uint8_t *d_in, uint64_t n, uint8_t *d_out, void *d_ws, hipStream_t st) {
+  u64 *total = reinterpret_cast<u64 *>(d_ws);
+  if (n == 0) return hipMemsetAsync(total, 0, sizeof(u64), st);
+  const uint64_t t = (n + HP_TILE - 1) / HP_TILE;
+  u64 *tile_offs = total + 8, *scratch = tile_offs + t + 1;
+  hipLaunchKernelGGL(hpc_count_kernel, dim3((uint32_t)t), dim3(HP_BLOCK), 0, st, d_in, (u64)n, tile_offs);
+  MGC_CHECK(hipGetLastError());
+  MGC_CHECK(scan_u64_inplace<false>(tile_offs, t, scratch, total, 0, st));
+  hipLaunchKernelGGL(hpc_emit_kernel, dim3((uint32_t)t), dim3(HP_BLOCK), 0, st, d_in, (u64)n, (const u64 *)tile_offs, d_out);
   return hipGetLastError();
 }
 

@@ -179,6 +179,25 @@ def homopoly_compress(bases, last_byte=b"\0"):
     return out.raw[:n]
 
 
+def compress_stream(bases, chunk=0):
+    """`compress` applied the way the reference does (merylInput.C:245-271): every sequence of the
+    '.'-separated stream is homopolymer-compressed on its own, optionally in chunks of `chunk`
+    bytes with the _lastByte carry between chunks of one sequence."""
+    b = _as_bytes(bases)
+    out = []
+    for seq in b.split(b"."):
+        if chunk <= 0:
+            out.append(homopoly_compress(seq))
+        else:
+            last, parts = b"\0", []
+            for i in range(0, len(seq), chunk):
+                piece = seq[i:i + chunk]
+                parts.append(homopoly_compress(piece, last))
+                last = piece[-1:] if piece else b"\0"
+            out.append(b"".join(parts))
+    return b".".join(out)
+
+
 def configure_counting(k, n_kmers_estimate, memory_bytes, count_suffix_length=0,
                        page_size=4096, sizeof_count_array=3232):
     c = _Config()

@@ -342,3 +342,44 @@ def test_write_database_roundtrip(ops, oracle_lib, torch_cuda, tmp_path):
     assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn) and not hi.any()
     assert r.info.num_total == wni and r.info.num_distinct == len(wlo) and r.info.prefix_size == cfg.w_prefix
     r.close()
+
+
+def _hpc_reads(rng, n_reads):
+    # reads with long homopolymer runs (HiFi-like), N's and lower case
+    parts = []
+    for _ in range(n_reads):
+        m = int(rng.integers(5, 200))
+        sym = np.array(list("ACGTacgtN"))[rng.integers(0, 9, m)]
+        parts.append("".join(np.repeat(sym, rng.integers(1, 7, m))))
+        parts.append(".")
+    return "".join(parts)
+
+
+def test_homopoly_compress_matches_oracle(ops, oracle_lib, torch_cuda):
+    rng = np.random.default_rng(21)
+    stream = _hpc_reads(rng, 300)
+    got = ops.dev_homopoly_compress(_dev_bases(torch_cuda, stream)).cpu().numpy().tobytes()
+    assert got == oracle_lib.compress_stream(stream)
+    for s in ("", "A", "AAAA", "AaAa.", "ACGT" * 2000, "A" * 10000 + "." + "C" * 5000):
+        got = ops.dev_homopoly_compress(_dev_bases(torch_cuda, s)).cpu().numpy().tobytes()
+        assert got == oracle_lib.compress_stream(s), s[:20]
+    # unaligned view
+    big = _dev_bases(torch_cuda, "..." + stream)
+    assert ops.dev_homopoly_compress(big[3:]).cpu().numpy().tobytes() == oracle_lib.compress_stream(stream)
+
+
+@pytest.mark.parametrize("k", [21, 31, 51])
+def test_session_compress_matches_oracle(ops, oracle_lib, torch_cuda, k):
+    # BASELINE config 4 shape (k=31 compress on long reads), small: the session applies `compress` itself
+    from meryl_amd import capi
+    rng = np.random.default_rng(k)
+    stream = _hpc_reads(rng, 400)
+    cfg = capi.configure(k, len(stream), 1 << 30, homopoly_compress=1)
+    with ops.Session(cfg) as s:
+        reads = stream.split(".")
+        for r in reads[:-1]:
+            s.push_bases(r, end_of_sequence=True)               # loadBases-style: one call per sequence
+        s.count()
+        klo, khi, counts, _ = s.result_wide()
+    whi, wlo, wcn, _ = oracle_lib.count_brute(oracle_lib.compress_stream(stream), k)
+    assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)

@@ -105,6 +105,19 @@ def test_homopoly_compress(oracle_lib):
     assert oracle_lib.homopoly_compress(b"", last_byte=b"A") == b""
 
 
+def test_compress_chunk_carry_equals_whole(oracle_lib):
+    # _lastByte makes chunked compression equal to compressing the whole sequence (merylInput.C:261-268)
+    rng = np.random.default_rng(2)
+    seq = "".join(np.repeat(np.array(list("ACGTacgtN"))[rng.integers(0, 9, 400)], rng.integers(1, 6, 400)))
+    stream = seq + "." + seq[::-1] + ".AAAA.C."
+    whole = oracle_lib.compress_stream(stream)
+    for chunk in (1, 2, 7, 64):
+        assert oracle_lib.compress_stream(stream, chunk) == whole
+    assert b"AA" not in whole.upper() and b"CC" not in whole.upper()
+    # runs never merge across sequences
+    assert oracle_lib.compress_stream("AAA.AAA.") == b"A.A."
+
+
 def test_synth_reads_deterministic(oracle_lib):
     a = oracle_lib.synth_reads(2, 1_000_000, 0, 100)
     b = oracle_lib.synth_reads(2, 1_000_000, 50, 50)
