@@ -1,0 +1,48 @@
+/*
+ * meryl_seq.h -- C ABI of the sequence-file loader that feeds the count path.
+ *
+ * Replaces, for FASTA/FASTQ (plain or gzip) only, the reference's
+ *   openSequenceFile(name)                     src/meryl/merylOp.C:200
+ *   dnaSeqFile::loadBases(seq, maxLength, seqLength, endOfSequence)
+ *                                              src/meryl/merylInput.C:257
+ * (both live in the absent submodule marbl/meryl-utility, utility/src/sequence/).
+ * The contract is the one merylInput::loadBases documents
+ * (src/meryl/merylInput.H:67-70): bases only -- no headers, no qualities --
+ * of ONE sequence per call, at most max_length of them; *end_of_sequence
+ * tells whether the sequence ended inside this call; returns 0 at end of file.
+ * BAM/CRAM (vendored htslib in the reference, src/main.mk:92-140), bz2 and xz
+ * are not supported here and are refused by msr_open with a message.
+ */
+#ifndef MERYL_SEQ_H
+#define MERYL_SEQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msr_reader msr_reader;
+
+/* name "-" reads stdin.  NULL on failure; text via msr_last_error(). */
+msr_reader *msr_open(const char *name);
+void        msr_close(msr_reader *r);
+const char *msr_last_error(void);
+
+/* 1 = got something (possibly 0 bases with *end_of_sequence set for an empty
+ * sequence), 0 = end of input, <0 = malformed input. */
+int msr_load_bases(msr_reader *r, char *seq, uint64_t max_length, uint64_t *seq_length, int *end_of_sequence);
+
+/* 1 when the file name ends in .gz (the reference reserves a second loader
+ * thread for it, src/meryl/merylOp-countThreads.C:162-168). */
+int msr_is_compressed(const msr_reader *r);
+
+/* guesstimateNumberOfkmersInInput_dnaSeqFile, src/meryl/merylOp-count.C:410-433:
+ * file size x1 (plain) x3 (.gz) x3.5 (.bz2) x4 (.xz); 0 for "-". */
+uint64_t msr_guess_number_of_kmers(const char *name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

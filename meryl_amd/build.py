@@ -13,8 +13,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmeryl_gpu_count.so")
-SOURCES = ["mgc_kernels.hip", "mgc_api.cpp", "meryl_db.cpp"]
-HEADERS = ["mgc_device.h", "meryl_db.h", os.path.join("..", "..", "include", "meryl_gpu_count.h")]
+SOURCES = ["mgc_kernels.hip", "mgc_api.cpp", "meryl_db.cpp", "meryl_seq.cpp"]
+HEADERS = ["mgc_device.h", os.path.join("..", "..", "include", "meryl_gpu_count.h"),
+           os.path.join("..", "..", "include", "meryl_db.h"), os.path.join("..", "..", "include", "meryl_seq.h")]
 # -no-hip-rt: the library carries no DT_NEEDED on a particular libamdhip64; it binds to the
 # HIP runtime already in the process (torch's bundled one under Python -- two HIP/HSA runtimes
 # in one process cannot share streams or ordering -- or /opt/rocm's for the standalone CLI).
@@ -38,16 +39,38 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+CLI = os.path.join(HERE, "bin", "meryl")
+
+
+def build_cli(force=False, verbose=False):
+    """The `meryl` front end (meryl_amd/bin/meryl): links the library and the system HIP runtime."""
+    src = os.path.join(CSRC, "meryl_main.cpp")
+    if (not force and os.path.exists(CLI) and os.path.getmtime(CLI) >= os.path.getmtime(src)
+            and os.path.getmtime(CLI) >= os.path.getmtime(LIB)):
+        return CLI
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+    cmd = [hipcc(), "-O2", "-std=c++17", "-pthread", src, "-o", CLI + ".tmp", "-L" + HERE, "-lmeryl_gpu_count",
+           "-Wl,-rpath,$ORIGIN/..", "-L" + rocm_lib, "-lamdhip64", "-Wl,-rpath," + rocm_lib, "-lz"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(CLI + ".tmp", CLI)
+    return CLI
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP/C++ source into libmeryl_gpu_count.so.  Returns its path."""
+    """Compile every HIP/C++ source into libmeryl_gpu_count.so (and the CLI).  Returns the library path."""
     if not force and not _stale():
+        build_cli(False, verbose)
         return LIB
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [hipcc()] + FLAGS + ["-o", LIB + ".tmp"] + srcs
+    cmd = [hipcc()] + FLAGS + ["-o", LIB + ".tmp"] + srcs + ["-lz"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    build_cli(True, verbose)
     return LIB
 
 

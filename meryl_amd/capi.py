@@ -29,6 +29,8 @@ SYMBOLS = (
     "mdb_writer_open", "mdb_writer_add_block", "mdb_writer_close", "mdb_last_error",
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_close",
     "mdb_free", "mgc_write_database",
+    # include/meryl_seq.h
+    "msr_open", "msr_close", "msr_last_error", "msr_load_bases", "msr_is_compressed", "msr_guess_number_of_kmers",
 )
 
 
@@ -193,6 +195,12 @@ def lib():
     sig("mdb_reader_close", None, vp)
     sig("mdb_free", None, vp)
     sig("mgc_write_database", i32, vp, ctypes.c_char_p, i32)
+    sig("msr_open", vp, ctypes.c_char_p)
+    sig("msr_close", None, vp)
+    sig("msr_last_error", ctypes.c_char_p)
+    sig("msr_load_bases", i32, vp, vp, u64, P(u64), P(i32))
+    sig("msr_is_compressed", i32, vp)
+    sig("msr_guess_number_of_kmers", u64, ctypes.c_char_p)
     _lib = L
     return L
 

@@ -196,7 +196,7 @@ struct mdb_writer {
 extern "C" const char *mdb_last_error(void) { return g_db_error.c_str(); }
 
 extern "C" mdb_writer *mdb_writer_open(const char *path, uint32_t k, uint32_t w_prefix) {
-  if (!path || k == 0 || k > 64 || w_prefix < MGC_NUM_FILES_BITS || w_prefix >= 2 * k) {
+  if (!path || k == 0 || k > 64 || w_prefix < MGC_NUM_FILES_BITS || w_prefix > 2 * k) {
     db_err("mdb_writer_open: bad arguments");
     return nullptr;
   }

@@ -1,0 +1,373 @@
+// meryl_main.cpp -- `meryl` command-line front end for the MI355X count engine.
+//
+// Keeps the reference's CLI surface for the count path (north_star: `meryl count
+// k=K <reads> output <db>`): the positional word grammar of
+// src/meryl/meryl.C:30-87 and src/meryl/merylCommandBuilder.C (options :187-326,
+// operations :346-385, `output` :440-461, sequence inputs :537-549, `[ ]`
+// nesting :133-153), the stderr narrative of src/meryl/merylOp-count.C:324-401
+// (including the line Canu parses, :398-401), and the debug verbs `print` and
+// `dumpIndex` (src/meryl/meryl.C:36-46, src/meryl/merylOp-nextMer.C:665-677) on the
+// databases it writes.  Everything that is not on the count path (union-sum,
+// histogram, lookup ...) is refused with a message -- SURVEY.md section 8 marks it
+// out of scope.
+#include "../../include/meryl_db.h"
+#include "../../include/meryl_gpu_count.h"
+#include "../../include/meryl_seq.h"
+
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+#include <vector>
+
+namespace {
+
+// ---- scaledNumber / scaledUnit / scaledName [meryl-utility, not in tree] ----
+uint64_t scaledNumber(uint64_t n, uint32_t div = 1024) { for (int i = 0; i < 8 && n > 9999; i++) n /= div; return n; }
+char scaledUnit(uint64_t n, uint32_t div = 1024) {
+  const char u[] = { ' ', 'k', 'M', 'G', 'T', 'P', 'E', 'Z', 'Y' };
+  int i = 0;
+  for (; i < 8 && n > 9999; i++) n /= div;
+  return u[i];
+}
+const char *scaledName(uint64_t n, uint32_t div = 1024) {
+  const char *u[] = { "", " thousand", " million", " billion", " trillion", " quadrillion", " quintillion", "", "" };
+  int i = 0;
+  for (; i < 8 && n > 9999; i++) n /= div;
+  return u[i];
+}
+uint64_t bits64(uint64_t v) { uint64_t b = 0; while (v) { b++; v >>= 1; } return b; }
+
+bool file_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && !S_ISDIR(st.st_mode); }
+bool dir_has_index(const std::string &p) { return file_exists(p + "/merylIndex"); }
+
+enum OpKind { OP_NONE, OP_COUNT, OP_COUNT_FORWARD, OP_COUNT_REVERSE, OP_PRINT, OP_DUMPINDEX };
+
+struct Operation {
+  OpKind                   kind = OP_NONE;
+  std::vector<std::string> seq_inputs;      // sequence files (count ops)
+  std::vector<bool>        seq_compress;    // `compress` is sticky per input (merylCommandBuilder.C:237-240,546)
+  std::vector<std::string> db_inputs;       // databases (print / dumpIndex)
+  std::string              output;
+  uint64_t                 exp_num_kmers = 0;   // n=
+};
+
+struct Globals {
+  uint32_t k = 0;
+  double   memory_gb;
+  uint32_t threads;
+  int      verbosity = 2;          // sayStandard
+  bool     only_config = false;
+  bool     compress = false;       // sticky
+  Globals() {
+    const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+    memory_gb = (pages > 0 && psz > 0) ? (double)pages * (double)psz / 1024.0 / 1024.0 / 1024.0 : 16.0;
+    threads = std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 1;
+  }
+};
+
+void usage(const char *prog) {
+  fprintf(stderr,
+          "usage: %s [k=<K>] [memory=<GB>] [threads=<T>] [n=<kmers>] [compress] [-C] [-Q] [-V]\n"
+          "          count|count-forward|count-reverse <reads.fa|fq[.gz]> ... output <database.meryl>\n"
+          "       %s print <database.meryl>\n"
+          "       %s dumpIndex <database.meryl>\n"
+          "\n"
+          "  MI355X-native implementation of the `count` path of marbl/meryl.  Words are processed left to\n"
+          "  right; options apply to the operations that follow.  A leading '[' and trailing ']' group the\n"
+          "  words of one operation.  Other meryl operations are not part of this build.\n",
+          prog, prog, prog);
+}
+
+[[noreturn]] void die(const char *fmt, const char *a = "") {
+  fprintf(stderr, fmt, a);
+  fprintf(stderr, "\n");
+  exit(1);
+}
+
+// ---- the configuration narrative, merylOp-count.C:118-165,231-295,324-401 ----
+void print_configuration(const Globals &g, const Operation &op, uint64_t exp_num_kmers, const mgc_count_config &cfg) {
+  const uint32_t k = g.k;
+  fprintf(stderr, "\n");
+  fprintf(stderr, "Counting %" PRIu64 " (estimated)%s %s%s%s %u-mers from %zu input file%s:\n",             // :324-330
+          scaledNumber(exp_num_kmers), scaledName(exp_num_kmers),
+          (op.kind == OP_COUNT) ? "canonical" : "", (op.kind == OP_COUNT_FORWARD) ? "forward" : "",
+          (op.kind == OP_COUNT_REVERSE) ? "reverse" : "", k, op.seq_inputs.size(), (op.seq_inputs.size() == 1) ? "" : "s");
+  for (const std::string &n : op.seq_inputs) fprintf(stderr, "  %15s: %s\n", "sequence-file", n.c_str());            // :332-333
+
+  // SIMPLE MODE, :136-162
+  fprintf(stderr, "\n\nSIMPLE MODE\n-----------\n\n");
+  if (2 * k > 42) {
+    fprintf(stderr, "  Not possible.\n");
+  } else {
+    const uint64_t n_entries = (uint64_t)1 << (2 * k), low_bits = 16;
+    const uint64_t exp_max = (uint64_t)(0.004 * (double)exp_num_kmers), exp_bits = bits64(exp_max) + 1;
+    const uint64_t extra = (exp_bits < low_bits) ? 0 : exp_bits - low_bits;
+    const uint64_t low_mem = n_entries * low_bits, high_mem = n_entries * extra, tot = (low_mem + high_mem) / 8;
+    fprintf(stderr, "  %u-mers\n", k);
+    fprintf(stderr, "    -> %" PRIu64 " entries for counts up to %u.\n", n_entries, 65535u);
+    fprintf(stderr, "    -> %" PRIu64 " %cbits memory used\n", scaledNumber(low_mem), scaledUnit(low_mem));
+    fprintf(stderr, "\n  %" PRIu64 " input bases\n", exp_num_kmers);
+    fprintf(stderr, "    -> expected max count of %" PRIu64 ", needing %" PRIu64 " extra bits.\n", exp_max, extra);
+    if (extra > 0) fprintf(stderr, "    -> %" PRIu64 " %cbits memory used\n", scaledNumber(high_mem), scaledUnit(high_mem));
+    else           fprintf(stderr, "    -> no memory used\n");
+    fprintf(stderr, "\n  %" PRIu64 " %cB memory needed\n", scaledNumber(tot), scaledUnit(tot));
+  }
+
+  // COMPLEX MODE table, :245-293 (evaluated at expNumKmers / nBatches like findBestValues)
+  if (k > 5) {
+    const uint64_t n_est = exp_num_kmers / (cfg.n_batches ? cfg.n_batches : 1);
+    const uint32_t seg_bits = 4096 * 8, seg_bytes = 4096;
+    const uint64_t mem_used = cfg.use_simple ? UINT64_MAX : cfg.memory_used;
+    fprintf(stderr, "\n\nCOMPLEX MODE\n------------\n\n");
+    fprintf(stderr, "prefix     # of   struct   kmers/    segs/      min     data    total\n");
+    fprintf(stderr, "  bits   prefix   memory   prefix   prefix   memory   memory   memory\n");
+    fprintf(stderr, "------  -------  -------  -------  -------  -------  -------  -------\n");
+    for (uint32_t wp = 1; wp < 2 * k - 1; wp++) {
+      const uint64_t n_prefix = (uint64_t)1 << wp, kpp = n_est / n_prefix + 1, kps = seg_bits / (2 * k - wp), spp = kpp / kps + 1;
+      if (wp + bits64(spp) + bits64(seg_bytes) >= 64) break;
+      const uint64_t struct_mem = (uint64_t)3232 * n_prefix + 8 * n_prefix * spp, data_min = n_prefix * seg_bytes;
+      const uint64_t data_mem = n_prefix * spp * seg_bytes, total = struct_mem + data_mem;
+      fprintf(stderr, "%6u  %4" PRIu64 " %cP  %4" PRIu64 " %cB  %4" PRIu64 " %cM  %4" PRIu64 " %cS  %4" PRIu64 " %cB  %4" PRIu64 " %cB  %4" PRIu64 " %cB%s\n",
+              wp, scaledNumber(n_prefix), scaledUnit(n_prefix), scaledNumber(struct_mem), scaledUnit(struct_mem),
+              scaledNumber(kpp), scaledUnit(kpp), scaledNumber(spp), scaledUnit(spp),
+              scaledNumber(data_min), scaledUnit(data_min), scaledNumber(data_mem), scaledUnit(data_mem),
+              scaledNumber(total), scaledUnit(total), (wp == cfg.w_prefix && !cfg.use_simple) ? "  Best Value!" : "");
+      if (total > (uint64_t)16 * mem_used) break;
+    }
+  }
+
+  // FINAL CONFIGURATION, :390-401
+  char line[256];
+  mgc_format_configured_line(&cfg, line, sizeof(line));
+  fprintf(stderr, "\n\nFINAL CONFIGURATION\n-------------------\n\n");
+  fprintf(stderr, "Estimated to require %" PRIu64 " %cB memory out of %" PRIu64 " %cB allowed.\n",
+          scaledNumber(cfg.memory_used), scaledUnit(cfg.memory_used), scaledNumber(cfg.memory_allowed), scaledUnit(cfg.memory_allowed));
+  fprintf(stderr, "Estimated to require %u batch%s.\n", cfg.n_batches, (cfg.n_batches == 1) ? "" : "es");
+  fprintf(stderr, "\n%s\n\n", line);
+}
+
+int run_count(const Globals &g, const Operation &op) {
+  if (g.k == 0) die("ERROR: Kmer size not supplied with modifier k=<kmer-size>.");                    // merylOp-count.C:311-312
+  if (op.output.empty() && !g.only_config) die("ERROR: No output specified for count operation.");     // :314-315
+
+  uint64_t exp_num_kmers = op.exp_num_kmers;
+  if (exp_num_kmers == 0)                                                                              // :317-318
+    for (const std::string &n : op.seq_inputs) exp_num_kmers += msr_guess_number_of_kmers(n.c_str());
+
+  mgc_count_config cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.k = g.k;
+  cfg.mode = (op.kind == OP_COUNT) ? MGC_MODE_CANONICAL : (op.kind == OP_COUNT_FORWARD) ? MGC_MODE_FORWARD : MGC_MODE_REVERSE;
+  cfg.n_kmers_estimate = exp_num_kmers;
+  cfg.memory_allowed = (uint64_t)(g.memory_gb * 1024.0 * 1024.0 * 1024.0);                            // merylCommandBuilder.C:299-302
+  cfg.threads = g.threads;
+  bool any_compress = false;
+  for (bool c : op.seq_compress) any_compress = any_compress || c;
+  for (bool c : op.seq_compress)
+    if (c != any_compress) die("ERROR: `compress` must apply to all or none of the inputs of one count in this build.");
+  cfg.homopoly_compress = any_compress ? 1 : 0;
+  if (mgc_configure_counting(&cfg) != MGC_OK) die("ERROR: %s", mgc_last_error(nullptr));
+
+  if (g.verbosity > 0) print_configuration(g, op, exp_num_kmers, cfg);
+  if (g.only_config) return 0;                                                                         // -C, merylOp-countThreads.C:392-393
+
+  if (g.verbosity > 0)
+    fprintf(stderr, "Start counting with %s method.\n", cfg.use_simple ? "SIMPLE" : "THREADED");     // merylOp-nextMer.C:205-209
+
+  mgc_session *s = mgc_open(&cfg, -1);
+  if (!s) die("ERROR: %s", mgc_last_error(nullptr));
+
+  const uint64_t buf_max = 2 * 1024 * 1024;                                                            // merylOp-countThreads.C:413
+  std::vector<char> buf(buf_max);
+  uint64_t total_bases = 0;
+  for (const std::string &name : op.seq_inputs) {                                                      // loader loop, :173-203
+    msr_reader *r = msr_open(name.c_str());
+    if (!r) die("ERROR: %s", msr_last_error());
+    for (;;) {
+      uint64_t len = 0;
+      int eos = 0;
+      const int rc = msr_load_bases(r, buf.data(), buf_max, &len, &eos);
+      if (rc < 0) die("ERROR: %s", msr_last_error());
+      if (rc == 0) break;
+      if (mgc_push_bases(s, buf.data(), len, eos) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+      total_bases += len;
+    }
+    mgc_push_bases(s, nullptr, 0, 1);                                                                  // end-of-file breaker, :196
+    msr_close(r);
+  }
+
+  if (mgc_count(s) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+  mgc_result_info info;
+  mgc_get_result_info(s, &info);
+
+  if (g.verbosity > 0) {
+    fprintf(stderr, "\nInput complete.  Writing results to '%s', using %u thread%s.\n",                // :447-448
+            op.output.c_str(), g.threads, (g.threads == 1) ? "" : "s");
+  }
+  if (mgc_write_database(s, op.output.c_str(), (int)g.threads) != MGC_OK) {
+    fprintf(stderr, "ERROR: writing '%s' failed: %s %s\n", op.output.c_str(), mdb_last_error(), mgc_last_error(s));
+    exit(1);
+  }
+  mgc_close(s);
+  if (g.verbosity > 0) {
+    fprintf(stderr, "\nFinished counting.\n");                                                         // :473
+    if (g.verbosity > 2)
+      fprintf(stderr, "  %" PRIu64 " bases, %" PRIu64 " k-mer instances, %" PRIu64 " distinct k-mers, prefix bits %u.\n",
+              total_bases, info.n_instances, info.n_distinct, info.w_prefix);
+  }
+  return 0;
+}
+
+int run_print(const Operation &op) {
+  static const char acgt[4] = { 'A', 'C', 'T', 'G' };
+  for (const std::string &dbn : op.db_inputs) {
+    mdb_reader *r = mdb_reader_open(dbn.c_str());
+    if (!r) die("ERROR: %s", mdb_last_error());
+    mdb_info info;
+    mdb_reader_info(r, &info);
+    std::vector<char> kstr(info.k + 1, 0);
+    for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++) {            // ascending == `threads=1 print` order (quick-start.rst:74-77)
+      uint64_t *lo = nullptr, *hi = nullptr, n = 0;
+      uint32_t *cn = nullptr;
+      if (mdb_reader_read_file(r, ff, &lo, &hi, &cn, &n) != MGC_OK) die("ERROR: %s", mdb_last_error());
+      for (uint64_t i = 0; i < n; i++) {
+        const unsigned __int128 m = ((unsigned __int128)hi[i] << 64) | lo[i];
+        for (uint32_t b = 0; b < info.k; b++) kstr[b] = acgt[(unsigned)(m >> (2 * (info.k - 1 - b))) & 3];
+        fprintf(stdout, "%s\t%u\n", kstr.data(), cn[i]);                                               // merylOp-nextMer.C:673-676
+      }
+      mdb_free(lo); mdb_free(hi); mdb_free(cn);
+    }
+    mdb_reader_close(r);
+  }
+  return 0;
+}
+
+int run_dump_index(const Operation &op) {
+  for (const std::string &dbn : op.db_inputs) {
+    mdb_reader *r = mdb_reader_open(dbn.c_str());
+    if (!r) die("ERROR: %s", mdb_last_error());
+    mdb_info i;
+    mdb_reader_info(r, &i);
+    fprintf(stdout, "Opened '%s'.\n", dbn.c_str());                                                    // shape of usage.rst:13-19
+    fprintf(stdout, "  kmerSize       %u\n", i.k);
+    fprintf(stdout, "  prefixSize     %u\n", i.prefix_size);
+    fprintf(stdout, "  suffixSize     %u\n", i.suffix_size);
+    fprintf(stdout, "  numFilesBits   %u (%u files)\n", i.num_files_bits, 1u << i.num_files_bits);
+    fprintf(stdout, "  numBlocksBits  %u (%u blocks)\n", i.num_blocks_bits, 1u << i.num_blocks_bits);
+    fprintf(stdout, "  unique         %" PRIu64 "\n  distinct       %" PRIu64 "\n  total          %" PRIu64 "\n",
+            i.num_unique, i.num_distinct, i.num_total);
+    mdb_reader_close(r);
+  }
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  Globals g;
+  std::vector<Operation> ops;
+  int  open_op = -1;                 // index of the operation words currently attach to
+  bool expect_output_name = false;
+
+  if (argc < 2) { usage(argv[0]); return 1; }
+
+  for (int a = 1; a < argc; a++) {
+    std::string w = argv[a];
+    // one leading '[' is ignored, trailing ']'s close operations (merylCommandBuilder.C:133-153)
+    if (!w.empty() && w[0] == '[') w.erase(0, 1);
+    int closing = 0;
+    while (!w.empty() && w.back() == ']') { w.pop_back(); closing++; }
+
+    if (!w.empty()) {
+      const size_t eq = w.find('=');
+      const std::string key = (eq == std::string::npos) ? w : w.substr(0, eq);
+      const std::string val = (eq == std::string::npos) ? "" : w.substr(eq + 1);
+
+      if (expect_output_name) {                                             // `output <db>`, :440-461
+        if (open_op < 0) die("ERROR: 'output' without an operation.");
+        if (!ops[open_op].output.empty()) die("ERROR: operation already has an output ('%s').", ops[open_op].output.c_str());   // merylOp.C:256-257
+        ops[open_op].output = w;
+        expect_output_name = false;
+      }
+      // ---- options, merylCommandBuilder.C:187-326 ----
+      else if (w.compare(0, 2, "-V") == 0)   { g.verbosity += (int)w.size() - 1; }
+      else if (w == "-Q")                    { g.verbosity = 0; }
+      else if (w == "-P")                    { /* progress: accepted, unused by count (:206-209) */ }
+      else if (w == "-C")                    { g.only_config = true; }
+      else if (key == "k" && eq != std::string::npos) {
+        const uint32_t k = (uint32_t)strtoul(val.c_str(), nullptr, 10);
+        if (k == 0 || k > 64) die("ERROR: k=%s is not a valid k-mer size (1..64).", val.c_str());
+        if (g.k != 0 && g.k != k) die("ERROR: kmer size already set; cannot change it to '%s'.", val.c_str());   // :254-262
+        g.k = k;
+      }
+      else if (key == "n" && eq != std::string::npos) {                     // :265-268
+        if (open_op < 0) { ops.emplace_back(); open_op = (int)ops.size() - 1; }
+        ops[open_op].exp_num_kmers = strtoull(val.c_str(), nullptr, 10);
+      }
+      else if (key == "memory" && eq != std::string::npos)  { g.memory_gb = strtod(val.c_str(), nullptr); }       // :299-302
+      else if (key == "threads" && eq != std::string::npos) { g.threads = (uint32_t)strtoul(val.c_str(), nullptr, 10); if (!g.threads) g.threads = 1; }   // :306-310
+      else if (w == "compress")              { g.compress = true; }                                               // :237-240
+      else if (key == "count-suffix" || key == "segment") { die("ERROR: option '%s' is not supported in this build.", w.c_str()); }
+      // ---- operations, :346-385 ----
+      else if (w == "count" || w == "count-forward" || w == "count-reverse" || w == "print" || w == "dumpIndex") {
+        const OpKind kind = (w == "count") ? OP_COUNT : (w == "count-forward") ? OP_COUNT_FORWARD :
+                            (w == "count-reverse") ? OP_COUNT_REVERSE : (w == "print") ? OP_PRINT : OP_DUMPINDEX;
+        if (open_op >= 0 && ops[open_op].kind == OP_NONE) ops[open_op].kind = kind;    // `n=` came first
+        else { ops.emplace_back(); open_op = (int)ops.size() - 1; ops[open_op].kind = kind; }
+      }
+      else if (w == "output")                { expect_output_name = true; }
+      else if (w == "union" || w == "union-min" || w == "union-max" || w == "union-sum" || w == "intersect" ||
+               w == "intersect-min" || w == "intersect-max" || w == "intersect-sum" || w == "subtract" ||
+               w == "difference" || w == "symmetric-difference" || w == "histogram" || w == "statistics" ||
+               w == "less-than" || w == "greater-than" || w == "equal-to" || w == "at-least" || w == "at-most" ||
+               w == "increase" || w == "decrease" || w == "multiply" || w == "divide" || w == "modulo" ||
+               w == "distinct" || w == "word-frequency" || w == "threshold" || w == "dumpFile" || w == "printACGT") {
+        die("ERROR: operation '%s' is not part of this build (count path only).", w.c_str());
+      }
+      // ---- inputs ----
+      else if (dir_has_index(w)) {                                           // :159,506-514
+        if (open_op < 0 || (ops[open_op].kind != OP_PRINT && ops[open_op].kind != OP_DUMPINDEX))
+          die("ERROR: database input '%s' needs a print or dumpIndex operation in this build.", w.c_str());
+        ops[open_op].db_inputs.push_back(w);
+      }
+      else if (file_exists(w) || w == "-") {                                 // :537-549: only counting ops take sequence
+        if (open_op < 0 || ops[open_op].kind < OP_COUNT || ops[open_op].kind > OP_COUNT_REVERSE)
+          die("ERROR: sequence file '%s' supplied to a non-counting operation.", w.c_str());
+        ops[open_op].seq_inputs.push_back(w);
+        ops[open_op].seq_compress.push_back(g.compress);
+      }
+      else {                                                                  // meryl.C:84-86
+        fprintf(stderr, "\nCan't interpret '%s': not a meryl command, option, or recognized input file.\n\n", argv[a]);
+        usage(argv[0]);
+        return 1;
+      }
+    }
+    if (closing > 0) open_op = -1;
+  }
+  if (expect_output_name) die("ERROR: 'output' needs a database name.");
+
+  if (g.verbosity > 0) {
+    size_t n_trees = 0;
+    for (const Operation &op : ops) if (op.kind != OP_NONE) n_trees++;
+    fprintf(stderr, "\nFound %zu command tree%s.\n", n_trees, (n_trees == 1) ? "" : "s");              // meryl.C:181
+  }
+
+  int rc = 0;
+  for (const Operation &op : ops) {                                           // counting ops first, in list order (meryl.C:211-227)
+    if (op.kind >= OP_COUNT && op.kind <= OP_COUNT_REVERSE) {
+      if (op.seq_inputs.empty() && !g.only_config) die("ERROR: count operation has no sequence inputs.");
+      rc |= run_count(g, op);
+    }
+  }
+  for (const Operation &op : ops) {
+    if (op.kind == OP_PRINT)     rc |= run_print(op);
+    if (op.kind == OP_DUMPINDEX) rc |= run_dump_index(op);
+  }
+  if (g.verbosity > 0) fprintf(stderr, "\nCleaning up.\n\nBye.\n");                                    // meryl.C:268,273
+  return rc;
+}

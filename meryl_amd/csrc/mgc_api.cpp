@@ -309,16 +309,29 @@ extern "C" const char *mgc_last_error(const mgc_session *s) {
 
 extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
   if (!cfg) { set_err(nullptr, "mgc_open: NULL config"); return nullptr; }
-  if (cfg->k == 0 || cfg->k > 64 || cfg->w_prefix < MGC_NUM_FILES_BITS || cfg->w_prefix >= 2 * cfg->k ||
+  mgc_count_config eff = *cfg;
+  if (cfg->count_suffix_length) {
+    set_err(nullptr, "mgc_open: count-suffix= is not implemented");
+    return nullptr;
+  }
+  if (cfg->use_simple) {
+    // The reference switches to countSimple (merylOp-count.C:368-372): a direct-index counter
+    // whose RESULT is the same sorted (k-mer, count) stream but whose database geometry is
+    //   psbits = 2k - 6, wSuffix = min(20, psbits), wPrefix = 6 + psbits - wSuffix
+    // (merylOp-countSimple.C:172-175).  The sort-based engine below produces that stream for any
+    // k, so simple mode only changes the block geometry.
+    if (2 * cfg->k < MGC_NUM_FILES_BITS) { set_err(nullptr, "mgc_open: k=%u too small for a 64-file database", cfg->k); return nullptr; }
+    const uint32_t psbits = 2 * cfg->k - MGC_NUM_FILES_BITS;
+    const uint32_t w_suffix = (psbits > 20) ? 20 : psbits;
+    eff.w_prefix = MGC_NUM_FILES_BITS + psbits - w_suffix;
+    eff.n_prefix = (uint64_t)1 << eff.w_prefix;
+    eff.w_data   = w_suffix;
+  }
+  cfg = &eff;
+  if (cfg->k == 0 || cfg->k > 64 || cfg->w_prefix < MGC_NUM_FILES_BITS || cfg->w_prefix > 2 * cfg->k ||
       cfg->w_data != 2 * cfg->k - cfg->w_prefix) {
     set_err(nullptr, "mgc_open: config has not been through mgc_configure_counting (k=%u wPrefix=%u wData=%u)",
             cfg->k, cfg->w_prefix, cfg->w_data);
-    return nullptr;
-  }
-  if (cfg->use_simple || cfg->count_suffix_length) {
-    // The reference would pick countSimple (merylOp-count.C:368-382), which yields a
-    // different block geometry (merylOp-countSimple.C:172-175).  Not built yet.
-    set_err(nullptr, "mgc_open: simple (direct-index) mode is not implemented");
     return nullptr;
   }
 

@@ -10,13 +10,13 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADERS = [os.path.join(ROOT, "include", h) for h in ("meryl_gpu_count.h", "meryl_db.h")]
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("meryl_gpu_count.h", "meryl_db.h", "meryl_seq.h")]
 
 
 def declared_functions():
     src = "".join(open(h).read() for h in HEADERS)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(m(?:gc|db)_[a-z0-9_]+)\s*\(", src)
+    names = re.findall(r"\b(m(?:gc|db|sr)_[a-z0-9_]+)\s*\(", src)
     return sorted(set(n for n in names if not n.endswith("_cb")))
 
 

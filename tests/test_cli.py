@@ -1,0 +1,105 @@
+"""The `meryl` front end (meryl_amd/bin/meryl): grammar and narrative on CPU (config-only runs
+never touch the GPU), a full FASTQ.gz -> database -> print round trip on the GPU."""
+import gzip
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def meryl(native_lib):
+    from meryl_amd import build
+    path = build.build_cli()
+    assert os.path.exists(path)
+    return path
+
+
+def run(meryl, *args, check=True):
+    p = subprocess.run([meryl] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    if check:
+        assert p.returncode == 0, p.stderr[-2000:]
+    return p
+
+
+def test_configure_only_narrative(meryl, tmp_path):
+    fa = tmp_path / "r.fa"
+    fa.write_text(">a\n" + "ACGT" * 1000 + "\n")
+    # word order is free (src/meryl/meryl.C:58-86): options before or after the operation
+    for args in (["-C", "k=21", "memory=4", "n=4641652", "count", fa, "output", tmp_path / "db"],
+                 ["-C", "count", "output", tmp_path / "db", "k=21", "memory=4", "n=4641652", fa],
+                 ["-C", "[count", "k=21", "memory=4", "n=4641652", fa, "output", str(tmp_path / "db") + "]"]):
+        p = run(meryl, *args)
+        err = p.stderr
+        assert "Found 1 command tree." in err
+        assert re.search(r"Counting \d+ \(estimated\).* canonical 21-mers from 1 input file:", err)
+        assert "COMPLEX MODE" in err and "Best Value!" in err and "FINAL CONFIGURATION" in err
+        # the line Canu parses (src/meryl/merylOp-count.C:398-401)
+        assert re.search(r"Configured complex mode for \d+\.\d{3} GB memory per batch, and up to \d+ batch(es)?\.", err)
+        best = [l for l in err.splitlines() if "Best Value!" in l]
+        assert len(best) == 1 and best[0].split()[0] == "10"            # E. coli 1x -> wPrefix 10
+        assert "Bye." in err and not os.path.exists(tmp_path / "db")     # -C writes nothing
+    p = run(meryl, "-C", "k=21", "memory=64", "n=10000000000", "count-forward", fa, "output", tmp_path / "db")
+    assert " forward 21-mers" in p.stderr
+    assert [l for l in p.stderr.splitlines() if "Best Value!" in l][0].split()[0] == "18"
+
+
+def test_grammar_errors(meryl, tmp_path):
+    fa = tmp_path / "r.fa"
+    fa.write_text(">a\nACGT\n")
+    p = run(meryl, "count", fa, "output", tmp_path / "db", check=False)
+    assert p.returncode == 1 and "Kmer size not supplied" in p.stderr                   # merylOp-count.C:311-312
+    p = run(meryl, "k=21", "count", fa, check=False)
+    assert p.returncode == 1 and "No output specified" in p.stderr                      # :314-315
+    p = run(meryl, "k=21", "count", tmp_path / "nonexistent.fa", "output", tmp_path / "db", check=False)
+    assert p.returncode == 1 and "Can't interpret" in p.stderr                          # meryl.C:84-86
+    p = run(meryl, "k=21", "k=22", "count", fa, "output", tmp_path / "db", check=False)
+    assert p.returncode == 1 and "already set" in p.stderr                              # merylCommandBuilder.C:254-262
+    p = run(meryl, "k=21", "count", fa, "output", tmp_path / "a", "output", tmp_path / "b", check=False)
+    assert p.returncode == 1 and "already has an output" in p.stderr                    # merylOp.C:256-257
+    p = run(meryl, "union-sum", check=False)
+    assert p.returncode == 1 and "not part of this build" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_count_print_roundtrip(meryl, oracle_lib, tmp_path):
+    from meryl_amd import db
+    bases = oracle_lib.synth_reads(12, 60_000, 0, 6000).tobytes()
+    reads = [r for r in bases.decode().split(".") if r]
+    fq = tmp_path / "reads.fastq.gz"
+    with gzip.open(fq, "wt") as f:
+        for i, r in enumerate(reads[:3000]):
+            f.write("@r%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)))
+    fa = tmp_path / "reads.fasta"
+    with open(fa, "w") as f:
+        for i, r in enumerate(reads[3000:]):
+            f.write(">s%d\n%s\n%s\n" % (i, r[:70], r[70:]))          # multi-line FASTA
+    out = tmp_path / "out.meryl"
+    p = run(meryl, "k=21", "memory=2", "threads=8", "count", fq, fa, "output", out)
+    assert "Start counting with THREADED method." in p.stderr and "Finished counting." in p.stderr
+    assert len(os.listdir(out)) == 129
+    _, wlo, wcn, wni = oracle_lib.count_brute(bases, 21)
+    r = db.Reader(str(out))
+    lo, hi, cn = r.read_all()
+    assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn) and r.info.num_total == wni
+    r.close()
+    # `meryl print` text form, merylOp-nextMer.C:665-677
+    p = run(meryl, "-Q", "print", out)
+    lines = p.stdout.splitlines()
+    assert len(lines) == len(wlo)
+    want = ["%s\t%d" % (oracle_lib.kmer_to_string(0, int(l), 21), int(c)) for l, c in zip(wlo[:50], wcn[:50])]
+    assert lines[:50] == want
+    p = run(meryl, "-Q", "dumpIndex", out)
+    assert "prefixSize" in p.stdout and "numFilesBits   6 (64 files)" in p.stdout
+    # compress: same as counting the homopolymer-compressed reads
+    out2 = tmp_path / "hpc.meryl"
+    run(meryl, "-Q", "k=15", "memory=2", "compress", "count", fq, fa, "output", out2)
+    r = db.Reader(str(out2))
+    lo, hi, cn = r.read_all()
+    _, wlo2, wcn2, _ = oracle_lib.count_brute(oracle_lib.compress_stream(bases), 15)
+    assert np.array_equal(lo, wlo2) and np.array_equal(cn, wcn2)
+    r.close()

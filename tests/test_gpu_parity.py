@@ -383,3 +383,34 @@ def test_session_compress_matches_oracle(ops, oracle_lib, torch_cuda, k):
         klo, khi, counts, _ = s.result_wide()
     whi, wlo, wcn, _ = oracle_lib.count_brute(oracle_lib.compress_stream(stream), k)
     assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+
+
+@pytest.mark.parametrize("k", [3, 8, 13, 14])
+def test_simple_mode_geometry(ops, oracle_lib, torch_cuda, tmp_path, k):
+    # small k: the reference picks countSimple (merylOp-count.C:368-372) whose database geometry is
+    # wSuffix = min(20, 2k-6), wPrefix = 6 + 2k-6 - wSuffix (merylOp-countSimple.C:172-175)
+    from meryl_amd import capi, db
+    bases = oracle_lib.synth_reads(5, 30_000, 0, 2000)
+    cfg = capi.configure(k, bases.size, 8 << 30)
+    if k <= 8:
+        assert cfg.use_simple == 1             # what configureCounting decides for tiny k
+    cfg.use_simple = 1                         # (for k = 13, 14 exercise the geometry anyway)
+    psbits = 2 * k - 6
+    w_suffix = min(20, psbits)
+    blocks = []
+    path = str(tmp_path / "simple.meryl")
+    with ops.Session(cfg) as s:
+        s.push_bases_device(torch_cuda.from_numpy(bases).cuda())
+        s.count()
+        info = s.info()
+        keys, counts, bstart = s.result()
+        s.finish(lambda p, n, suf, cnt: blocks.append((p, n)), host_threads=2)
+        db.write_database(s, path, host_threads=4)
+    assert (info.w_prefix, info.w_data, info.n_prefix) == (6 + psbits - w_suffix, w_suffix, 1 << (6 + psbits - w_suffix))
+    _, wlo, wcn, _ = oracle_lib.count_brute(bases.tobytes(), k)
+    assert np.array_equal(keys, wlo) and np.array_equal(counts, wcn)
+    assert sorted(p for p, _ in blocks) == list(range(info.n_prefix)) and sum(n for _, n in blocks) == len(wlo)
+    r = db.Reader(path)
+    lo, hi, cn = r.read_all()
+    assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn) and r.info.prefix_size == info.w_prefix
+    r.close()

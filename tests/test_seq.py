@@ -1,0 +1,74 @@
+"""CPU tests of the FASTA/FASTQ(.gz) loader (include/meryl_seq.h), the stand-in for
+dnaSeqFile::loadBases of the absent meryl-utility: contract of merylInput::loadBases
+(src/meryl/merylInput.H:67-70)."""
+import ctypes
+import gzip
+import os
+
+import pytest
+
+
+def load_all(lib, path, max_len):
+    """-> list of sequences (bases only), reassembled from chunks of at most max_len"""
+    r = lib.msr_open(path.encode())
+    assert r, lib.msr_last_error()
+    buf = ctypes.create_string_buffer(max_len)
+    n = ctypes.c_uint64(0)
+    eos = ctypes.c_int(0)
+    seqs, cur = [], b""
+    while True:
+        rc = lib.msr_load_bases(r, buf, max_len, ctypes.byref(n), ctypes.byref(eos))
+        assert rc >= 0, lib.msr_last_error()
+        if rc == 0:
+            break
+        assert n.value <= max_len
+        cur += buf.raw[:n.value]
+        if eos.value:
+            seqs.append(cur)
+            cur = b""
+    assert cur == b""
+    lib.msr_close(r)
+    return seqs
+
+
+FASTA = ">r1 some description\nACGTACGT\nNNacgt\n\n>r2\nTTTT\n>empty\n>r4\nGATTACA"
+FASTQ = "@q1\nACGTN\n+\nIIIII\n@q2 x\nGGGG\nCC\n+q2\nIIII\nII\n@q3\nA\n+\n@\n"
+
+
+@pytest.mark.parametrize("max_len", [1, 3, 7, 1 << 16])
+def test_fasta_fastq_plain_and_gz(native_lib, tmp_path, max_len):
+    fa = tmp_path / "x.fasta"
+    fa.write_text(FASTA)
+    assert load_all(native_lib, str(fa), max_len) == [b"ACGTACGTNNacgt", b"TTTT", b"", b"GATTACA"]
+    fq = tmp_path / "x.fastq"
+    fq.write_text(FASTQ)
+    assert load_all(native_lib, str(fq), max_len) == [b"ACGTN", b"GGGGCC", b"A"]       # '@' as a quality is not a record
+    gz = tmp_path / "x.fastq.gz"
+    with gzip.open(gz, "wt") as f:
+        f.write(FASTQ)
+    assert load_all(native_lib, str(gz), max_len) == [b"ACGTN", b"GGGGCC", b"A"]
+    crlf = tmp_path / "crlf.fa"
+    crlf.write_bytes(FASTA.replace("\n", "\r\n").encode())
+    assert load_all(native_lib, str(crlf), max_len) == [b"ACGTACGTNNacgt", b"TTTT", b"", b"GATTACA"]
+
+
+def test_reader_errors_and_guess(native_lib, tmp_path):
+    assert not native_lib.msr_open(str(tmp_path / "missing.fa").encode())
+    assert b"cannot open" in native_lib.msr_last_error()
+    assert not native_lib.msr_open(b"reads.fq.bz2")
+    assert b"not supported" in native_lib.msr_last_error()
+    bad = tmp_path / "bad.txt"
+    bad.write_text("hello\n")
+    r = native_lib.msr_open(str(bad).encode())
+    buf = ctypes.create_string_buffer(16)
+    n, eos = ctypes.c_uint64(0), ctypes.c_int(0)
+    assert native_lib.msr_load_bases(r, buf, 16, ctypes.byref(n), ctypes.byref(eos)) < 0
+    native_lib.msr_close(r)
+    # file-size guess of merylOp-count.C:410-433
+    p = tmp_path / "g.fa"
+    p.write_text("A" * 1000)
+    assert native_lib.msr_guess_number_of_kmers(str(p).encode()) == 1000
+    pz = tmp_path / "g.fa.gz"
+    pz.write_bytes(b"x" * 100)
+    assert native_lib.msr_guess_number_of_kmers(str(pz).encode()) == 300
+    assert native_lib.msr_guess_number_of_kmers(b"-") == 0
