@@ -74,6 +74,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Libraries (RCCL prints a version banner) may write to stdout; the contract is ONE JSON line
+    # there, so everything before the final print goes to stderr.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from meryl_amd import build, capi, count
 
@@ -91,11 +97,15 @@ def main():
     build.build()
     capi.lib()
 
+    # MGC_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (partition -> all_to_all -> owner sort) even
+    # with a single rank, so that it can be exercised on a 1-GPU box
+    force_sharded = os.environ.get("MGC_BENCH_FORCE_SHARDED", "0") == "1"
     dist = None
-    if world > 1:
+    if world > 1 or force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist is not None:
@@ -111,7 +121,7 @@ def main():
     prof_acc = {"pass_ms": 0.0, "pass_launches": 0, "pass_keys": 0, "stage_ms": [0.0] * capi.NUM_STAGES}
     result = {}
 
-    if world == 1:
+    if world == 1 and not force_sharded:
         cfg = capi.configure(K, 10_000_000_000 if reads == DEFAULT_READS else n_bases, 64 << 30)
         sess = count.Session(cfg, local_rank)
         sess.push_bases_device(bases)
@@ -174,7 +184,7 @@ def main():
                 "parallelism": "1 GPU" if world == 1 else "%d GPUs: 64 files in contiguous per-rank ranges, all_to_all" % world,
             },
         }
-        if world == 1:
+        if world == 1 and not force_sharded:
             n_inst = result["n_instances"]
             line["config"]["n_instances"] = n_inst
             line["config"]["w_prefix"] = result["w_prefix"]
@@ -195,7 +205,10 @@ def main():
                                          for i in range(capi.NUM_STAGES)}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_sample_reads, os.cpu_count() or 1)
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
 
     if dist is not None:
         dist.barrier()

@@ -282,6 +282,48 @@ def owned_sort_bits(k, first_file, end_file):
     return 2 * k - 6 + int(first_file ^ (end_file - 1)).bit_length()
 
 
+EXCHANGE_CHUNK = 1 << 27          # keys per message: keeps every send/recv far below 2^31 bytes/elements
+
+
+def exchange_segments(sends, recvs, device, group=None, chunk=None):
+    """Variable-size all-to-all as explicit point-to-point segments.
+    sends: list of (peer, tensor_view) in the order the peer expects them;
+    recvs: list of (peer, tensor_view) in the matching order (per peer, the i-th send of the
+    source pairs with the i-th receive of the destination).  Segments to/from the own rank are
+    copied locally.  Long segments are cut into rounds of `chunk` rows so that no single message
+    exceeds a few GB (torch's all_to_all_single silently mishandles > 2^31-element exchanges, and a
+    10 Gbp rank would post 8 GB messages) -- each round is one grouped RCCL launch."""
+    import torch.distributed as dist
+    chunk = chunk or EXCHANGE_CHUNK
+    rank = dist.get_rank(group)
+    local_max = max([t.shape[0] for _, t in sends] + [t.shape[0] for _, t in recvs] + [0])
+    m = torch.tensor([local_max], dtype=torch.int64, device=device)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)          # same number of rounds everywhere
+    rounds = max(1, -(-int(m.item()) // chunk))
+    own_src = [t for p, t in sends if p == rank]
+    own_dst = [t for p, t in recvs if p == rank]
+    assert len(own_src) == len(own_dst)
+    for a, b in zip(own_src, own_dst):
+        b.copy_(a)
+    for j in range(rounds):
+        p2p = []
+        for peer, t in sends:
+            if peer != rank:
+                piece = t[min(t.shape[0], j * chunk):min(t.shape[0], (j + 1) * chunk)]
+                if piece.shape[0]:
+                    g = peer if group is None else dist.get_global_rank(group, peer)
+                    p2p.append(dist.P2POp(dist.isend, piece, g, group))
+        for peer, t in recvs:
+            if peer != rank:
+                piece = t[min(t.shape[0], j * chunk):min(t.shape[0], (j + 1) * chunk)]
+                if piece.shape[0]:
+                    g = peer if group is None else dist.get_global_rank(group, peer)
+                    p2p.append(dist.P2POp(dist.irecv, piece, g, group))
+        if p2p:
+            for req in dist.batch_isend_irecv(p2p):
+                req.wait()
+
+
 class HipOps:
     """The device operators count_sharded drives (all HIP, via the C-ABI)."""
     partition = staticmethod(dev_kmer_partition)
@@ -297,29 +339,51 @@ class HipOps:
 
 def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
     """Collective.  Every rank passes ITS OWN reads (uint8 tensor on its GPU);
-    returns this rank's share of the database: (unique keys int64, counts int32,
+    returns this rank's share of the database: (unique keys, counts int32,
     (first_file, end_file)).  The concatenation over ranks, in rank order, is
     the ascending (key, count) stream a single-GPU count of all reads gives.
     `ops` exists so the routing logic can be exercised without a GPU (the gloo
-    tests inject CPU stand-ins); the product default is the HIP operators."""
+    tests inject CPU stand-ins); the product default is the HIP operators.
+
+    Layout after the exchange is file-major -- for every owned file, the pieces of all source
+    ranks back to back -- so each file is one contiguous bucket that is LSB-sorted on the 2k-6
+    bits below the file bits, exactly like the single-GPU path."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
 
     keys, local_counts = ops.partition(bases, k, mode, 6)                        # grouped by file, ascending
-    # one small all-gather gives every rank the same 64-bin histogram -> same cut points
-    fc = torch.from_numpy(np.asarray(local_counts).astype(np.int64)).to(keys.device)
+    local_counts = np.asarray(local_counts).astype(np.int64)
+    # one small all-gather gives every rank the same [rank][file] histogram -> same cut points
+    fc = torch.from_numpy(local_counts).to(keys.device)
     all_counts = [torch.empty_like(fc) for _ in range(world)]
     dist.all_gather(all_counts, fc, group=group)
     per_rank = torch.stack(all_counts).cpu().numpy()                             # [world][64]
     cuts = balanced_file_ranges(per_rank.sum(axis=0), world)
 
-    send = exchange_plan(local_counts, cuts)                                     # keys to each destination
-    recv = [int(per_rank[src, cuts[rank]:cuts[rank + 1]].sum()) for src in range(world)]
-    inbox = ops.empty_keys(sum(recv), keys)
-    dist.all_to_all_single(inbox, keys, output_split_sizes=recv, input_split_sizes=send, group=group)
-    del keys
+    f0, f1 = cuts[rank], cuts[rank + 1]
+    file_total = per_rank[:, f0:f1].sum(axis=0)                                  # keys per owned file
+    file_off = np.concatenate([[0], np.cumsum(file_total)]).astype(np.int64)
+    inbox = ops.empty_keys(int(file_total.sum()), keys)
 
-    sorted_keys = ops.radix_sort(inbox, 0, owned_sort_bits(k, cuts[rank], cuts[rank + 1]))
-    uniq, cnts = ops.run_length(sorted_keys)
-    return uniq, cnts, (cuts[rank], cuts[rank + 1])
+    local_off = np.concatenate([[0], np.cumsum(local_counts)]).astype(np.int64)
+    sends, recvs = [], []
+    for dst in range(world):                                                     # per peer: files ascending
+        for f in range(cuts[dst], cuts[dst + 1]):
+            sends.append((dst, keys[int(local_off[f]):int(local_off[f + 1])]))
+    for src in range(world):
+        for f in range(f0, f1):
+            a = int(file_off[f - f0] + per_rank[:src, f].sum())
+            recvs.append((src, inbox[a:a + int(per_rank[src, f])]))
+    exchange_segments(sends, recvs, keys.device, group)
+    del keys, sends
+
+    for f in range(f0, f1):                                                      # per-file LSB sort, in place
+        a, b = int(file_off[f - f0]), int(file_off[f - f0 + 1])
+        if b > a:
+            seg = inbox[a:b]
+            out = ops.radix_sort(seg, 0, 2 * k - 6)
+            if out.data_ptr() != seg.data_ptr():
+                seg.copy_(out)
+    uniq, cnts = ops.run_length(inbox)
+    return uniq, cnts, (f0, f1)

@@ -565,7 +565,7 @@ struct RadixSmem {
   static constexpr size_t OFF_CNT   = OFF_DBASE + (size_t)R * 4;   // u32[R]
   static constexpr size_t OFF_TMP   = OFF_CNT + (size_t)R * 4;     // u32[64] scan scratch + misc
   static constexpr size_t OFF_WIN   = OFF_TMP + 64 * 4;            // u64[LB_WINDOW][R/2] look-back window (LB == 2)
-  static constexpr size_t WIN_BYTES = (LB == 2) ? ((RB == 9 && BLOCK == 512) ? 4096 : 8192) : 0;
+  static constexpr size_t WIN_BYTES = (LB >= 2) ? ((RB == 9 && BLOCK == 512) ? 4096 : 8192) : 0;
   static constexpr size_t BYTES     = OFF_WIN + WIN_BYTES;
   // workgroups per CU the LDS budget admits (160 KiB per CU), capped at 2
   static constexpr int    WG_PER_CU = (2 * BYTES <= 160 * 1024) ? 2 : 1;
@@ -682,13 +682,17 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
   if (tid < (u32)R) s_dbase[tid] = excl;
 
   // granules of this tile: publish the aggregate as early as possible
-  constexpr int G = R / 2;                              // granules per tile (two digits each)
+  // LB 1/2: two digits per granule (30-bit values, n < 2^30); LB 3: one digit per granule (62-bit values)
+  constexpr int GW = (LB == 3) ? 1 : 2;                 // digits per granule
+  constexpr int G  = R / GW;                            // granules per tile
+  constexpr u64 V62 = (1ull << 62) - 1;
   u64 *mine = status + (LOOKBACK ? tile * (u64)G + tid : 0);
   if (LOOKBACK) {
     __syncthreads();                                    // s_cnt / s_dbase visible
     if (tid < (u32)G) {
-      const u32 c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
-      status_store(mine, (tile == 0) ? st_pack(2, c0, 2, c1) : st_pack(1, c0, 1, c1));
+      const u32 c0 = s_cnt[GW * tid], c1 = (GW == 2) ? s_cnt[GW * tid + 1] : 0u;
+      const u32 fl = (tile == 0) ? 2u : 1u;
+      status_store(mine, (GW == 2) ? st_pack(fl, c0, fl, c1) : (((u64)fl << 62) | (u64)c0));
       if constexpr (LB == 1) {
         // serial walk per digit pair, four predecessors in flight per round
         u32 p0 = 0, p1 = 0;
@@ -743,7 +747,7 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
   for (int j = 0; j < KPT; j++) s_keys[(j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu)] = keys[j];
   __syncthreads();                          // keys now live in LDS only: registers are free for the look-back
 
-  if constexpr (LB == 2) {
+  if constexpr (LB >= 2) {
     // window-parallel look-back after the exchange (keys live in LDS only, registers are free):
     // all waves fetch the granules of the next LB_WINDOW predecessors with coalesced loads into
     // LDS, the R/2 digit-pair threads consume the ready prefix.
@@ -756,11 +760,13 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
     u64 *s_win = reinterpret_cast<u64 *>(smem + SM::OFF_WIN);
     u32 *s_q   = s_tmp + 40;
     u32 *s_all = s_tmp + 41;
-    u32 c0 = 0, c1 = 0, p0 = 0, p1 = 0;
+    u32 c0 = 0, c1 = 0;
+    u64 p0 = 0, p1 = 0;
     bool need0 = false, need1 = false;
     if (tid < (u32)G) {
-      c0 = s_cnt[2 * tid]; c1 = s_cnt[2 * tid + 1];
-      need0 = need1 = (tile != 0);
+      c0 = s_cnt[GW * tid]; c1 = (GW == 2) ? s_cnt[GW * tid + 1] : 0u;
+      need0 = (tile != 0);
+      need1 = (GW == 2) && (tile != 0);
     }
     if (tile != 0) {                                    // uniform
       const u32 sub = tid / G, g = tid % G;
@@ -771,7 +777,7 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
         for (int i = 0; i < LPT; i++) {
           const u32 idx = sub + (u32)(TPL * i);
           s_win[idx * G + g] = (t_next >= (u64)idx) ? status_load(status + (t_next - idx) * (u64)G + g)
-                                                    : st_pack(2, 0, 2, 0);
+                                                    : ((GW == 2) ? st_pack(2, 0, 2, 0) : (2ull << 62));
         }
         if (tid == 0) { *s_q = LB_WINDOW; *s_all = 1u; }
         __syncthreads();
@@ -779,7 +785,7 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
           u32 q = 0;
           for (; q < (u32)LB_WINDOW; q++) {
             const u64 v = s_win[q * G + tid];
-            if (((u32)v >> 30) == 0u || ((u32)(v >> 62)) == 0u) break;
+            if ((GW == 2 && ((u32)v >> 30) == 0u) || ((u32)(v >> 62)) == 0u) break;
           }
           if (q < (u32)LB_WINDOW) atomicMin(s_q, q);
         }
@@ -788,9 +794,14 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
         if (tid < (u32)G) {
           for (u32 i = 0; i < q && (need0 || need1); i++) {
             const u64 v = s_win[i * G + tid];
-            const u32 lo = (u32)v, hi = (u32)(v >> 32);
-            if (need0) { p0 += lo & 0x3FFFFFFFu; if ((lo >> 30) == 2u) need0 = false; }
-            if (need1) { p1 += hi & 0x3FFFFFFFu; if ((hi >> 30) == 2u) need1 = false; }
+            if (GW == 2) {
+              const u32 lo = (u32)v, hi = (u32)(v >> 32);
+              if (need0) { p0 += lo & 0x3FFFFFFFu; if ((lo >> 30) == 2u) need0 = false; }
+              if (need1) { p1 += hi & 0x3FFFFFFFu; if ((hi >> 30) == 2u) need1 = false; }
+            } else {
+              p0 += v & V62;
+              if ((v >> 62) == 2ull) need0 = false;
+            }
           }
           if (need0 || need1) *s_all = 0u;
         }
@@ -805,9 +816,10 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
       }
     }
     if (tid < (u32)G) {
-      if (tile != 0) status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
-      s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
-      s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
+      if (tile != 0)
+        status_store(mine, (GW == 2) ? st_pack(2, (u32)p0 + c0, 2, (u32)p1 + c1) : ((2ull << 62) | (p0 + (u64)c0)));
+      s_gbase[GW * tid] = gbase[GW * tid] + p0 - (u64)s_dbase[GW * tid];
+      if (GW == 2) s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + p1 - (u64)s_dbase[2 * tid + 1];
     }
     __syncthreads();
   }
@@ -943,12 +955,11 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
 
   K *src = reinterpret_cast<K *>(d_keys), *dst = reinterpret_cast<K *>(d_alt);
   int in_alt = 0;
-  // look-back granules hold 30-bit values: larger calls take the classic path
-  const bool lookback = (plan.mode == 0) && (n < (1ull << 30));
+  const bool lookback = (plan.mode == 0);
 
   if (lookback) {
     u64 *status = reinterpret_cast<u64 *>(body);
-    const size_t status_bytes = (size_t)num_tiles * (R / 2) * sizeof(u64);
+    const size_t status_bytes = (size_t)num_tiles * (LBK == 3 ? R : R / 2) * sizeof(u64);
     MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
     PassList pl;
     pl.n = plan.num_passes;
@@ -1011,6 +1022,8 @@ hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key
   if (ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
 #define MGC_RUN(K_, RB_, BLOCK_, KPT_)                                                                       \
   do {                                                                                                       \
+    if (n >= (1ull << 30))   /* packed look-back granules hold 30-bit values: use the wide ones */           \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 3>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
     if (plan.match == 0)                                                                                     \
       return run_passes<K_, RB_, BLOCK_, KPT_, 0, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
     if (plan.lookback == 2)                                                                                  \

@@ -58,6 +58,8 @@ def _worker(rank, world, port, k, seed, q):
             return torch.empty(int(n), dtype=torch.int64)
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if seed % 2 == 1:
+        count.EXCHANGE_CHUNK = 97                        # force many exchange rounds with ragged tails
     try:
         reads_per_rank = 300
         bases = oracle.synth_reads(seed, 20000, rank * reads_per_rank, reads_per_rank, 100, 5000, 100)

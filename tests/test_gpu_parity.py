@@ -414,3 +414,24 @@ def test_simple_mode_geometry(ops, oracle_lib, torch_cuda, tmp_path, k):
     lo, hi, cn = r.read_all()
     assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn) and r.info.prefix_size == info.w_prefix
     r.close()
+
+
+def test_sharded_path_single_rank(ops, oracle_lib, torch_cuda):
+    """The multi-GPU routine (partition -> all_gather of file counts -> all_to_all_single ->
+    owner-side sort -> run-length) on the HIP operators with a 1-rank NCCL(RCCL) group: the only
+    multi-GPU configuration a 1-GPU box can run.  Result must equal the oracle stream."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch_cuda.device("cuda", 0))
+    try:
+        for k in (21, 51):
+            bases = oracle_lib.synth_reads(13, 80_000, 0, 5000)
+            uniq, cnts, (f0, f1) = ops.count_sharded(torch_cuda.from_numpy(bases).cuda(), k)
+            whi, wlo, wcn, _ = oracle_lib.count_brute(bases.tobytes(), k)
+            assert (f0, f1) == (0, 64)
+            want = [(int(h) << 64) | int(l) for h, l in zip(whi, wlo)]
+            assert _as_int(uniq) == want
+            assert np.array_equal(cnts.cpu().numpy().view(np.uint32), wcn)
+    finally:
+        dist.destroy_process_group()
