@@ -171,6 +171,17 @@ const char  *mgc_last_error(const mgc_session *s);   /* s may be NULL: last open
  * Bases are copied; the caller may reuse the buffer on return. */
 int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int end_of_sequence);
 
+/* Out-of-core input (the analogue of writeBatch's memory-full spill,
+ * merylOp-countThreads.C:323-379, and of merylBlockWriter::finish() merging the
+ * iterations): when the bases pushed through mgc_push_bases exceed what one
+ * pass can hold in HBM, everything up to the last sequence boundary is counted
+ * and its result parked in host memory; mgc_count then merges the parked
+ * results per file, summing counts.  By default the batch size is derived from
+ * the free HBM; this call overrides it (bases per batch).  A merged result is
+ * host-resident: mgc_copy_result / mgc_finish / mgc_write_database work,
+ * mgc_get_result_device returns MGC_ESTATE. */
+int mgc_set_batch_bases(mgc_session *s, uint64_t bases_per_batch);
+
 /* Bases already resident in HBM (breakers included).  The buffer is borrowed
  * until mgc_count returns.  May be called once per session. */
 int mgc_push_bases_device(mgc_session *s, const uint8_t *d_bases, uint64_t n_bases);

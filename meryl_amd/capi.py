@@ -24,7 +24,7 @@ SYMBOLS = (
     "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_count",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_version",
-    "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress",
+    "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases",
     # include/meryl_db.h
     "mdb_writer_open", "mdb_writer_add_block", "mdb_writer_close", "mdb_last_error",
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_close",
@@ -177,6 +177,7 @@ def lib():
     sig("mgc_last_error", ctypes.c_char_p, vp)
     sig("mgc_push_bases", i32, vp, ctypes.c_char_p, sz, i32)
     sig("mgc_push_bases_device", i32, vp, vp, u64)
+    sig("mgc_set_batch_bases", i32, vp, u64)
     sig("mgc_count", i32, vp)
     sig("mgc_get_result_info", i32, vp, P(ResultInfo))
     sig("mgc_get_result_device", i32, vp, P(vp), P(vp), P(vp), P(u32))

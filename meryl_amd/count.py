@@ -166,6 +166,10 @@ class Session:
         self._keep.append(t)
         capi.check(capi.lib().mgc_push_bases_device(self._h, _ptr(t), t.numel()), "mgc_push_bases_device", self._h)
 
+    def set_batch_bases(self, n):
+        """force out-of-core batches of about n bases (default: derived from the free HBM)"""
+        capi.check(capi.lib().mgc_set_batch_bases(self._h, int(n)), "mgc_set_batch_bases", self._h)
+
     def set_profiling(self, on=True):
         capi.check(capi.lib().mgc_set_profiling(self._h, 1 if on else 0), "mgc_set_profiling", self._h)
 

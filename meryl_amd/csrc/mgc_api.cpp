@@ -280,7 +280,7 @@ struct mgc_session {
   // device arena: buffers survive between mgc_count calls (grow-only), so a
   // repeated count does not pay hipMalloc/hipFree of tens of GB every time
   struct Buf { void *p = nullptr; size_t cap = 0; };
-  enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_HPC, B_HPC_WS, B_NUM };
+  enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_HPC, B_HPC_WS, B_BASES, B_NUM };
   Buf buf[B_NUM];
   hipError_t ensure(int which, size_t bytes) {
     Buf &b = buf[which];
@@ -292,6 +292,22 @@ struct mgc_session {
     return e;
   }
   void free_arena() { for (auto &b : buf) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; } }
+
+  // out-of-core batches (the analogue of writeBatch's spill, merylOp-countThreads.C:323-379): when the
+  // pushed bases exceed what one pass can hold in HBM, everything up to the last sequence
+  // boundary is counted and its (k-mer, count) result parked in host memory; mgc_count merges
+  // the parked results per file (summing counts) like merylBlockWriter::finish() merges iterations.
+  struct BatchResult {
+    std::vector<uint64_t> lo, hi, bstart;
+    std::vector<uint32_t> counts;
+  };
+  std::vector<BatchResult> batches;
+  uint64_t  batch_limit = 0;              // bases per batch; 0 = derive from free HBM at the first push
+  bool      merged = false;               // final result lives in m_* (host) instead of d_* (device)
+  std::vector<uint64_t> m_lo, m_hi, m_bstart;
+  std::vector<uint32_t> m_counts;
+  uint64_t  total_bases = 0, total_instances = 0;
+  uint64_t  total_file_instances[MGC_NUM_FILES];
 
   // profiling
   bool        profiling = false;
@@ -355,6 +371,7 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
   if (e != hipSuccess) { set_err(nullptr, "hipStreamCreate: %s", hipGetErrorString(e)); delete s; return nullptr; }
   memset(&s->prof, 0, sizeof(s->prof));
   memset(s->file_instances, 0, sizeof(s->file_instances));
+  memset(s->total_file_instances, 0, sizeof(s->total_file_instances));
   return s;
 }
 
@@ -367,11 +384,38 @@ extern "C" void mgc_close(mgc_session *s) {
   delete s;
 }
 
+static int run_batch(mgc_session *s, size_t n_bases_in_batch);
+
+extern "C" int mgc_set_batch_bases(mgc_session *s, uint64_t bases_per_batch) {
+  if (!s) return MGC_EINVAL;
+  s->batch_limit = bases_per_batch;
+  return MGC_OK;
+}
+
 extern "C" int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int end_of_sequence) {
   if (!s || (!bases && len)) return MGC_EINVAL;
   if (s->borrowed || s->counted) { set_err(&s->err, "mgc_push_bases after device input / count"); return MGC_ESTATE; }
-  s->host_bases.insert(s->host_bases.end(), bases, bases + len);
+  if (s->batch_limit == 0) {
+    // one pass needs about: bases + X + Y (two key buffers) + distinct keys and counts + workspaces
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(s->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
+      const uint64_t per_base = 2 + 16ull * s->key_words + 6ull * s->key_words + 4;
+      s->batch_limit = (uint64_t)((double)free_b * 0.85 / (double)per_base);
+    }
+    if (s->batch_limit < (1u << 20)) s->batch_limit = 1u << 20;
+  }
+  if (len) s->host_bases.insert(s->host_bases.end(), bases, bases + len);
   if (end_of_sequence) s->host_bases.push_back('.');        // merylOp-countThreads.C:214-215
+  if (s->host_bases.size() >= s->batch_limit) {
+    // cut at the last sequence boundary: k-mers never span a breaker, so no carry is needed
+    // (and `compress` stays a per-sequence operation)
+    size_t cut = s->host_bases.size();
+    while (cut > 0 && s->host_bases[cut - 1] != '.') cut--;
+    if (cut > 0) {
+      const int rc = run_batch(s, cut);
+      if (rc != MGC_OK) return rc;
+    }
+  }
   return MGC_OK;
 }
 
@@ -424,8 +468,8 @@ struct StageTimer {
 };
 }  // namespace
 
-extern "C" int mgc_count(mgc_session *s) {
-  if (!s) return MGC_EINVAL;
+// One pass over bases that are resident in HBM (s->d_bases / s->n_bases): results stay in HBM.
+static int count_device(mgc_session *s) {
   s->free_result();
   HIP_TRY(s, hipSetDevice(s->device));
   hipStream_t st = s->stream;
@@ -436,17 +480,6 @@ extern "C" int mgc_count(mgc_session *s) {
   const uint32_t kw = s->key_words;
   const size_t   kbytes = sizeof(uint64_t) * kw;
   memset(&s->prof, 0, sizeof(s->prof));
-
-  // ---- input into HBM ----
-  if (!s->borrowed) {
-    s->n_bases = s->host_bases.size();
-    if (s->d_bases_own) { (void)hipFree(s->d_bases_own); s->d_bases_own = nullptr; }
-    if (s->n_bases) {
-      HIP_TRY(s, hipMalloc((void **)&s->d_bases_own, s->n_bases));
-      HIP_TRY(s, hipMemcpyAsync(s->d_bases_own, s->host_bases.data(), s->n_bases, hipMemcpyHostToDevice, st));
-    }
-    s->d_bases = s->d_bases_own;
-  }
 
   // ---- `compress`: homopolymer-compress the base stream on the device (merylInput.C:261-268) ----
   const uint8_t *d_bases = s->d_bases;
@@ -585,36 +618,20 @@ extern "C" int mgc_count(mgc_session *s) {
   return MGC_OK;
 }
 
-extern "C" int mgc_get_result_info(const mgc_session *s, mgc_result_info *info) {
-  if (!s || !info) return MGC_EINVAL;
-  if (!s->counted) return MGC_ESTATE;
-  info->n_bases = s->n_bases;
-  info->n_instances = s->n_instances;
-  info->n_distinct = s->n_distinct;
-  info->w_prefix = s->cfg.w_prefix;
-  info->w_data = s->cfg.w_data;
-  info->n_prefix = s->cfg.n_prefix;
-  memcpy(info->file_instances, s->file_instances, sizeof(info->file_instances));
-  return MGC_OK;
-}
-
-extern "C" int mgc_get_result_device(const mgc_session *s, const void **d_unique, const uint32_t **d_counts,
-                                     const uint64_t **d_block_start, uint32_t *key_words) {
-  if (!s) return MGC_EINVAL;
-  if (!s->counted) return MGC_ESTATE;
-  if (d_unique) *d_unique = s->d_unique;
-  if (d_counts) *d_counts = s->d_counts;
-  if (d_block_start) *d_block_start = s->d_block_start;
-  if (key_words) *key_words = s->key_words;
-  return MGC_OK;
-}
-
-extern "C" int mgc_copy_result(const mgc_session *cs, uint64_t *keys_lo, uint64_t *keys_hi, uint32_t *counts,
-                               uint64_t *block_start) {
-  mgc_session *s = const_cast<mgc_session *>(cs);
-  if (!s) return MGC_EINVAL;
-  if (!s->counted) return MGC_ESTATE;
+// bases of the host staging buffer [0, n) -> HBM (grow-only device buffer)
+static int upload_host_bases(mgc_session *s, size_t n) {
   HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, s->ensure(mgc_session::B_BASES, n));
+  s->d_bases = reinterpret_cast<const uint8_t *>(s->buf[mgc_session::B_BASES].p);
+  s->n_bases = n;
+  if (n) {
+    HIP_TRY(s, hipMemcpyAsync(s->buf[mgc_session::B_BASES].p, s->host_bases.data(), n, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));             // the staging vector may be reused right after
+  }
+  return MGC_OK;
+}
+
+static int copy_device_result(mgc_session *s, uint64_t *keys_lo, uint64_t *keys_hi, uint32_t *counts, uint64_t *block_start) {
   const uint64_t nd = s->n_distinct;
   if (nd && (keys_lo || keys_hi)) {
     if (s->key_words == 1) {
@@ -632,6 +649,166 @@ extern "C" int mgc_copy_result(const mgc_session *cs, uint64_t *keys_lo, uint64_
   if (counts && nd) HIP_TRY(s, hipMemcpy(counts, s->d_counts, sizeof(uint32_t) * nd, hipMemcpyDeviceToHost));
   if (block_start)  HIP_TRY(s, hipMemcpy(block_start, s->d_block_start, sizeof(uint64_t) * (s->cfg.n_prefix + 1), hipMemcpyDeviceToHost));
   return MGC_OK;
+}
+
+// Count the first n staged bases as one batch and park the result in host memory.
+static int run_batch(mgc_session *s, size_t n) {
+  int rc = upload_host_bases(s, n);
+  if (rc != MGC_OK) return rc;
+  rc = count_device(s);
+  if (rc != MGC_OK) return rc;
+  s->batches.emplace_back();
+  mgc_session::BatchResult &b = s->batches.back();
+  const bool wide = s->key_words == 2;
+  b.lo.resize(s->n_distinct);
+  if (wide) b.hi.resize(s->n_distinct);
+  b.counts.resize(s->n_distinct);
+  b.bstart.resize(s->cfg.n_prefix + 1);
+  rc = copy_device_result(s, b.lo.data(), wide ? b.hi.data() : nullptr, b.counts.data(), b.bstart.data());
+  if (rc != MGC_OK) return rc;
+  s->total_bases += n;
+  s->total_instances += s->n_instances;
+  for (int f = 0; f < MGC_NUM_FILES; f++) s->total_file_instances[f] += s->file_instances[f];
+  s->host_bases.erase(s->host_bases.begin(), s->host_bases.begin() + n);
+  s->counted = false;                                        // more input may follow
+  return MGC_OK;
+}
+
+// Merge the parked batch results: per file, a k-way merge by k-mer that sums the counts
+// (uint32 wrap, like the reference's value arithmetic), then the block offsets.
+static int merge_batches(mgc_session *s) {
+  const size_t nbatch = s->batches.size();
+  const uint64_t np = s->cfg.n_prefix, per_file = np / MGC_NUM_FILES;
+  const bool wide = s->key_words == 2;
+  std::vector<std::vector<uint64_t>> flo(MGC_NUM_FILES), fhi(MGC_NUM_FILES);
+  std::vector<std::vector<uint32_t>> fcn(MGC_NUM_FILES);
+  std::atomic<uint32_t> next_file(0);
+  auto worker = [&]() {
+    for (;;) {
+      const uint32_t ff = next_file.fetch_add(1);
+      if (ff >= MGC_NUM_FILES) return;
+      std::vector<uint64_t> pos(nbatch), end(nbatch);
+      for (size_t b = 0; b < nbatch; b++) { pos[b] = s->batches[b].bstart[ff * per_file]; end[b] = s->batches[b].bstart[(ff + 1) * per_file]; }
+      for (;;) {
+        bool any = false;
+        uint64_t mlo = 0, mhi = 0;
+        for (size_t b = 0; b < nbatch; b++) {
+          if (pos[b] == end[b]) continue;
+          const uint64_t lo = s->batches[b].lo[pos[b]], hi = wide ? s->batches[b].hi[pos[b]] : 0;
+          if (!any || hi < mhi || (hi == mhi && lo < mlo)) { mlo = lo; mhi = hi; any = true; }
+        }
+        if (!any) break;
+        uint32_t sum = 0;
+        for (size_t b = 0; b < nbatch; b++) {
+          if (pos[b] == end[b]) continue;
+          const uint64_t lo = s->batches[b].lo[pos[b]], hi = wide ? s->batches[b].hi[pos[b]] : 0;
+          if (lo == mlo && hi == mhi) { sum += s->batches[b].counts[pos[b]]; pos[b]++; }
+        }
+        flo[ff].push_back(mlo);
+        if (wide) fhi[ff].push_back(mhi);
+        fcn[ff].push_back(sum);
+      }
+    }
+  };
+  unsigned nthreads = s->cfg.threads ? s->cfg.threads : std::thread::hardware_concurrency();
+  nthreads = std::max(1u, std::min(nthreads, (unsigned)MGC_NUM_FILES));
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(worker);
+  worker();
+  for (auto &t : pool) t.join();
+
+  uint64_t nd = 0;
+  for (int f = 0; f < MGC_NUM_FILES; f++) nd += flo[f].size();
+  s->m_lo.clear(); s->m_hi.clear(); s->m_counts.clear();
+  s->m_lo.reserve(nd); s->m_counts.reserve(nd);
+  if (wide) s->m_hi.reserve(nd);
+  for (int f = 0; f < MGC_NUM_FILES; f++) {
+    s->m_lo.insert(s->m_lo.end(), flo[f].begin(), flo[f].end());
+    if (wide) s->m_hi.insert(s->m_hi.end(), fhi[f].begin(), fhi[f].end());
+    s->m_counts.insert(s->m_counts.end(), fcn[f].begin(), fcn[f].end());
+    std::vector<uint64_t>().swap(flo[f]); std::vector<uint64_t>().swap(fhi[f]); std::vector<uint32_t>().swap(fcn[f]);
+  }
+  // block offsets: first distinct k-mer of every prefix (the array is ascending)
+  const uint32_t w_data = s->cfg.w_data;
+  s->m_bstart.assign(np + 1, nd);
+  uint64_t i = 0;
+  for (uint64_t p = 0; p <= np; p++) {
+    if (p == np) { s->m_bstart[p] = nd; break; }
+    while (i < nd) {
+      unsigned __int128 key = wide ? (((unsigned __int128)s->m_hi[i] << 64) | s->m_lo[i]) : (unsigned __int128)s->m_lo[i];
+      if ((uint64_t)(key >> w_data) >= p) break;
+      i++;
+    }
+    s->m_bstart[p] = i;
+  }
+  s->batches.clear();
+  s->n_distinct = nd;
+  s->n_instances = s->total_instances;
+  s->n_bases = s->total_bases;
+  memcpy(s->file_instances, s->total_file_instances, sizeof(s->file_instances));
+  s->merged = true;
+  s->free_result();
+  s->counted = true;
+  return MGC_OK;
+}
+
+extern "C" int mgc_count(mgc_session *s) {
+  if (!s) return MGC_EINVAL;
+  if (s->borrowed) return count_device(s);
+  if (s->batches.empty()) {                                  // everything fits in one pass: results stay in HBM
+    int rc = upload_host_bases(s, s->host_bases.size());
+    if (rc != MGC_OK) return rc;
+    std::vector<char>().swap(s->host_bases);
+    s->merged = false;
+    return count_device(s);
+  }
+  if (!s->host_bases.empty()) {
+    int rc = run_batch(s, s->host_bases.size());
+    if (rc != MGC_OK) return rc;
+  }
+  return merge_batches(s);
+}
+
+extern "C" int mgc_get_result_info(const mgc_session *s, mgc_result_info *info) {
+  if (!s || !info) return MGC_EINVAL;
+  if (!s->counted) return MGC_ESTATE;
+  info->n_bases = s->n_bases;
+  info->n_instances = s->n_instances;
+  info->n_distinct = s->n_distinct;
+  info->w_prefix = s->cfg.w_prefix;
+  info->w_data = s->cfg.w_data;
+  info->n_prefix = s->cfg.n_prefix;
+  memcpy(info->file_instances, s->file_instances, sizeof(info->file_instances));
+  return MGC_OK;
+}
+
+extern "C" int mgc_get_result_device(const mgc_session *s, const void **d_unique, const uint32_t **d_counts,
+                                     const uint64_t **d_block_start, uint32_t *key_words) {
+  if (!s) return MGC_EINVAL;
+  if (!s->counted) return MGC_ESTATE;
+  if (s->merged) { set_err(nullptr, "the input was counted in several batches: the merged result is host-resident"); return MGC_ESTATE; }
+  if (d_unique) *d_unique = s->d_unique;
+  if (d_counts) *d_counts = s->d_counts;
+  if (d_block_start) *d_block_start = s->d_block_start;
+  if (key_words) *key_words = s->key_words;
+  return MGC_OK;
+}
+
+extern "C" int mgc_copy_result(const mgc_session *cs, uint64_t *keys_lo, uint64_t *keys_hi, uint32_t *counts,
+                               uint64_t *block_start) {
+  mgc_session *s = const_cast<mgc_session *>(cs);
+  if (!s) return MGC_EINVAL;
+  if (!s->counted) return MGC_ESTATE;
+  if (s->merged) {
+    const uint64_t nd = s->n_distinct;
+    if (keys_lo && nd) memcpy(keys_lo, s->m_lo.data(), sizeof(uint64_t) * nd);
+    if (keys_hi && nd) { if (s->key_words == 2) memcpy(keys_hi, s->m_hi.data(), sizeof(uint64_t) * nd); else memset(keys_hi, 0, sizeof(uint64_t) * nd); }
+    if (counts && nd)  memcpy(counts, s->m_counts.data(), sizeof(uint32_t) * nd);
+    if (block_start)   memcpy(block_start, s->m_bstart.data(), sizeof(uint64_t) * (s->cfg.n_prefix + 1));
+    return MGC_OK;
+  }
+  HIP_TRY(s, hipSetDevice(s->device));
+  return copy_device_result(s, keys_lo, keys_hi, counts, block_start);
 }
 
 extern "C" int mgc_finish(mgc_session *s, mgc_block_cb cb, void *ctx, int host_threads) {

@@ -435,3 +435,36 @@ def test_sharded_path_single_rank(ops, oracle_lib, torch_cuda):
             assert np.array_equal(cnts.cpu().numpy().view(np.uint32), wcn)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,compress", [(21, 0), (51, 0), (31, 1)])
+def test_out_of_core_batches_equal_single_pass(ops, oracle_lib, torch_cuda, tmp_path, k, compress):
+    # forced small batches (the memory-full spill of merylOp-countThreads.C:323-379 + the merge of
+    # merylBlockWriter::finish()): result must not depend on how the input was batched -- the
+    # invariance the reference's test-build.pl:66-74 memory sweep probes
+    from meryl_amd import capi, db
+    bases = oracle_lib.synth_reads(31, 40_000, 0, 3000).tobytes().decode()
+    reads = [r for r in bases.split(".") if r]
+    stream = ".".join(reads) + "."
+    want_stream = oracle_lib.compress_stream(stream) if compress else stream
+    whi, wlo, wcn, wni = oracle_lib.count_brute(want_stream, k)
+    cfg = capi.configure(k, len(stream), 1 << 30, homopoly_compress=compress)
+    for batch in (20_000, 150_000, 10**9):
+        path = str(tmp_path / ("b%d.meryl" % batch))
+        with ops.Session(cfg) as s:
+            s.set_batch_bases(batch)
+            for r in reads:
+                s.push_bases(r[:60], end_of_sequence=False)
+                s.push_bases(r[60:], end_of_sequence=True)
+            s.count()
+            klo, khi, counts, bstart = s.result_wide()
+            info = s.info()
+            db.write_database(s, path, host_threads=4)
+        assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn), batch
+        assert info.n_instances == wni and info.n_distinct == len(wlo)
+        pref = [(((int(h) << 64) | int(l)) >> cfg.w_data) for h, l in zip(khi, klo)]
+        assert np.array_equal(np.searchsorted(np.array(pref, dtype=np.int64), np.arange(cfg.n_prefix + 1)), bstart.astype(np.int64))
+        r = db.Reader(path)
+        lo, hi, cn = r.read_all()
+        assert np.array_equal(lo, wlo) and np.array_equal(hi, whi) and np.array_equal(cn, wcn)
+        r.close()
