@@ -196,8 +196,28 @@ extern "C" int mgc_dev_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(d_err, 0, 4, st);
   if (e != hipSuccess) return hip_rc(e, "radix_sort memset");
+  // MGC_SORT_DBG=1: per-phase cycle stamps of the scatter kernel (developer instrumentation, stderr)
+  void *dbg = nullptr;
+  const uint64_t dbg_tiles = n / 4096 + 2;
+  if (getenv("MGC_SORT_DBG")) { if (hipMalloc(&dbg, dbg_tiles * 64) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, dbg_tiles * 64); }
+  plan.dbg = dbg;
   e = mgc::launch_radix_sort(d_keys, d_alt, n, key_words, plan, d_ws, ws_bytes - 256, d_err, result_in_alt, st, nullptr);
   if (e != hipSuccess) return hip_rc(e, "radix_sort");
+  if (dbg) {
+    (void)hipStreamSynchronize(st);
+    std::vector<uint64_t> h(dbg_tiles * 8);
+    (void)hipMemcpy(h.data(), dbg, dbg_tiles * 64, hipMemcpyDeviceToHost);
+    double sum[6] = {0, 0, 0, 0, 0, 0}; uint64_t cnt = 0;
+    for (uint64_t t = 0; t < dbg_tiles; t++) {
+      if (h[t * 8] == 0 || h[t * 8 + 6] == 0) continue;
+      for (int i = 0; i < 6; i++) sum[i] += (double)(h[t * 8 + i + 1] - h[t * 8 + i]);
+      cnt++;
+    }
+    if (cnt) fprintf(stderr, "[sortdbg] tiles=%lu cycles/tile: ticket+zero=%.0f load+rank=%.0f totals+scan+publish=%.0f positions+exchange=%.0f lookback=%.0f writeout=%.0f total=%.0f\n",
+                     (unsigned long)cnt, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt,
+                     (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5]) / cnt);
+    (void)hipFree(dbg);
+  }
   uint32_t h_err = 0;
   e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -280,7 +300,8 @@ struct mgc_session {
   // device arena: buffers survive between mgc_count calls (grow-only), so a
   // repeated count does not pay hipMalloc/hipFree of tens of GB every time
   struct Buf { void *p = nullptr; size_t cap = 0; };
-  enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_HPC, B_HPC_WS, B_BASES, B_NUM };
+  enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_HPC, B_HPC_WS, B_BASES,
+         B_SUBSTART, B_GROUPS, B_GSCAN, B_CNT_TMP, B_NUM };
   Buf buf[B_NUM];
   hipError_t ensure(int which, size_t bytes) {
     Buf &b = buf[which];
@@ -524,9 +545,16 @@ static int count_device(mgc_session *s) {
   s->n_instances = N;
 
   // ---- pass 2: pack + scatter into per-file regions ----
+  // Two ways from file-grouped k-mers to the (k-mer, count) stream:
+  //   finish (default): LSB-sort only the top t bits of every file globally, then sort the low bits of
+  //                     every sub-bucket in LDS with the run-length count fused in (mgc_kernels.hip);
+  //   full   (MGC_FINISH=0, and the fallback for files with an oversized sub-bucket): LSB-sort all 2k-6
+  //                     bits globally, then the separate run-length kernels.
+  const char *fin_env = getenv("MGC_FINISH");
+  const bool use_finish = !(fin_env && fin_env[0] == '0');
   mgc::SortPlan plan;
   mgc::make_sort_plan(0, 2 * k - bucket_bits, &plan);
-  const bool odd = (plan.num_passes & 1u) != 0;
+  const bool odd = !use_finish && (plan.num_passes & 1u) != 0;
   HIP_TRY(s, s->ensure(mgc_session::B_X, kbytes * N));
   HIP_TRY(s, s->ensure(mgc_session::B_Y, kbytes * (odd ? N : max_bucket)));
   unsigned char *X = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_X].p);
@@ -544,41 +572,157 @@ static int count_device(mgc_session *s) {
   uint32_t *d_err = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(sort_ws) + sort_ws_bytes - 256);
   HIP_TRY(s, hipMemsetAsync(d_err, 0, 4, st));
 
+  const uint32_t rem_bits = 2 * k - bucket_bits;
+  const uint32_t ev_per_file = 2 * 16;                     // room for 16 passes per file
   std::vector<hipEvent_t> pass_ev;
+  std::vector<uint32_t> file_passes(nb, 0);
   if (s->profiling) {
-    pass_ev.resize((size_t)nb * plan.num_passes * 2);
+    pass_ev.resize((size_t)nb * ev_per_file);
     for (auto &e : pass_ev) (void)hipEventCreate(&e);
   }
-  tm.begin(MGC_STAGE_SORT);
   uint32_t sort_launch_groups = 0;
-  for (uint32_t b = 0; b < nb; b++) {
-    if (h_counts[b] == 0) continue;
-    void *src = X + kbytes * h_starts[b];
-    void *alt = odd ? (void *)(Y + kbytes * h_starts[b]) : (void *)Y;
-    int in_alt = 0;
-    hipEvent_t *pe = s->profiling ? &pass_ev[(size_t)b * plan.num_passes * 2] : nullptr;
-    HIP_TRY(s, mgc::launch_radix_sort(src, alt, h_counts[b], kw, plan, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe));
-    sort_launch_groups++;
-    (void)in_alt;     // odd pass count: every file ends in Y at the same offsets; even: back in X
-  }
-  tm.end(MGC_STAGE_SORT);
-  void *d_sorted = odd ? (void *)Y : (void *)X;
-
-  // ---- run-length count ----
-  HIP_TRY(s, s->ensure(mgc_session::B_RLE_WS, mgc::rle_workspace_bytes(N)));
-  void *rle_ws = s->buf[mgc_session::B_RLE_WS].p;
-  tm.begin(MGC_STAGE_RLE);
-  HIP_TRY(s, mgc::launch_rle_count(d_sorted, N, kw, rle_ws, st));
   uint64_t nd = 0;
-  HIP_TRY(s, mgc::rle_read_total(rle_ws, &nd, st));
-  s->n_distinct = nd;
-  HIP_TRY(s, s->ensure(mgc_session::B_UNIQUE, kbytes * nd));
-  HIP_TRY(s, s->ensure(mgc_session::B_COUNTS, sizeof(uint32_t) * nd));
-  s->d_unique = s->buf[mgc_session::B_UNIQUE].p;
-  s->d_counts = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_COUNTS].p);
-  HIP_TRY(s, mgc::launch_rle_emit(d_sorted, N, kw, rle_ws, s->d_unique, s->d_counts, st));
-  tm.end(MGC_STAGE_RLE);
-  s->prof.stage_launches[MGC_STAGE_RLE] = 3;
+
+  if (!use_finish) {
+    tm.begin(MGC_STAGE_SORT);
+    for (uint32_t b = 0; b < nb; b++) {
+      if (h_counts[b] == 0) continue;
+      void *src = X + kbytes * h_starts[b];
+      void *alt = odd ? (void *)(Y + kbytes * h_starts[b]) : (void *)Y;
+      int in_alt = 0;
+      hipEvent_t *pe = s->profiling ? &pass_ev[(size_t)b * ev_per_file] : nullptr;
+      HIP_TRY(s, mgc::launch_radix_sort(src, alt, h_counts[b], kw, plan, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe));
+      file_passes[b] = plan.num_passes;
+      sort_launch_groups++;
+      (void)in_alt;   // odd pass count: every file ends in Y at the same offsets; even: back in X
+    }
+    tm.end(MGC_STAGE_SORT);
+    void *d_sorted = odd ? (void *)Y : (void *)X;
+
+    // ---- run-length count ----
+    HIP_TRY(s, s->ensure(mgc_session::B_RLE_WS, mgc::rle_workspace_bytes(N)));
+    void *rle_ws = s->buf[mgc_session::B_RLE_WS].p;
+    tm.begin(MGC_STAGE_RLE);
+    HIP_TRY(s, mgc::launch_rle_count(d_sorted, N, kw, rle_ws, st));
+    HIP_TRY(s, mgc::rle_read_total(rle_ws, &nd, st));
+    s->n_distinct = nd;
+    HIP_TRY(s, s->ensure(mgc_session::B_UNIQUE, kbytes * nd));
+    HIP_TRY(s, s->ensure(mgc_session::B_COUNTS, sizeof(uint32_t) * nd));
+    s->d_unique = s->buf[mgc_session::B_UNIQUE].p;
+    s->d_counts = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_COUNTS].p);
+    HIP_TRY(s, mgc::launch_rle_emit(d_sorted, N, kw, rle_ws, s->d_unique, s->d_counts, st));
+    tm.end(MGC_STAGE_RLE);
+    s->prof.stage_launches[MGC_STAGE_RLE] = 3;
+  } else {
+    // ---- plan: per file, t top bits so that a sub-bucket holds ~target k-mers ----
+    const uint64_t target = mgc::finish_target_for(kw), cap = mgc::finish_capacity_for(kw);
+    uint32_t top_bits[MGC_NUM_FILES];
+    uint64_t gbase[MGC_NUM_FILES + 1], sbase[MGC_NUM_FILES + 1];
+    gbase[0] = sbase[0] = 0;
+    for (uint32_t b = 0; b < nb; b++) {
+      uint32_t t = 0;
+      while (t < rem_bits && t < 26 && (h_counts[b] >> t) > target) t++;
+      top_bits[b] = t;
+      const uint64_t ng = h_counts[b] ? ((uint64_t)1 << t) : 0;
+      gbase[b + 1] = gbase[b] + ng;
+      sbase[b + 1] = sbase[b] + (ng ? ng + 1 : 0);
+    }
+    const uint64_t ng_total = gbase[nb];
+    HIP_TRY(s, s->ensure(mgc_session::B_SUBSTART, sizeof(uint64_t) * (sbase[nb] + 1)));
+    HIP_TRY(s, s->ensure(mgc_session::B_GROUPS, sizeof(uint64_t) * (ng_total + 2 + MGC_NUM_FILES)));
+    HIP_TRY(s, s->ensure(mgc_session::B_GSCAN, mgc::finish_scan_scratch_bytes(ng_total + 1)));
+    HIP_TRY(s, s->ensure(mgc_session::B_CNT_TMP, sizeof(uint32_t) * N));
+    HIP_TRY(s, s->ensure(mgc_session::B_RLE_WS, mgc::rle_workspace_bytes(max_bucket)));
+    uint64_t *d_substart = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_SUBSTART].p);
+    uint64_t *d_group    = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_GROUPS].p);   // [ng_total+1], then max_sub[64]
+    uint64_t *d_maxsub   = d_group + ng_total + 1;
+    uint32_t *d_cnt_tmp  = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_CNT_TMP].p);
+    void     *rle_ws     = s->buf[mgc_session::B_RLE_WS].p;
+    HIP_TRY(s, hipMemsetAsync(d_maxsub, 0, sizeof(uint64_t) * MGC_NUM_FILES, st));
+
+    // ---- A. global LSB passes on the top bits only ----
+    tm.begin(MGC_STAGE_SORT);
+    for (uint32_t b = 0; b < nb; b++) {
+      if (h_counts[b] == 0 || top_bits[b] == 0) continue;
+      mgc::SortPlan fp;
+      mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fp);
+      void *src = X + kbytes * h_starts[b];
+      int in_alt = 0;
+      hipEvent_t *pe = s->profiling ? &pass_ev[(size_t)b * ev_per_file] : nullptr;
+      HIP_TRY(s, mgc::launch_radix_sort(src, (void *)Y, h_counts[b], kw, fp, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe));
+      if (in_alt) HIP_TRY(s, hipMemcpyAsync(src, Y, kbytes * h_counts[b], hipMemcpyDeviceToDevice, st));
+      file_passes[b] = fp.num_passes;
+      sort_launch_groups++;
+    }
+    tm.end(MGC_STAGE_SORT);
+
+    // ---- B/C. sub-bucket boundaries and the largest sub-bucket of every file ----
+    tm.begin(MGC_STAGE_RLE);
+    for (uint32_t b = 0; b < nb; b++) {
+      if (h_counts[b] == 0) continue;
+      HIP_TRY(s, mgc::launch_subbucket_bounds(X + kbytes * h_starts[b], h_counts[b], kw, rem_bits - top_bits[b], top_bits[b],
+                                              d_substart + sbase[b], d_maxsub + b, st));
+    }
+    uint64_t h_maxsub[MGC_NUM_FILES];
+    HIP_TRY(s, hipMemcpyAsync(h_maxsub, d_maxsub, sizeof(h_maxsub), hipMemcpyDeviceToHost, st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+
+    // ---- D. finish every file: LDS sort + count, or the full-sort fallback ----
+    uint64_t h_fallback_distinct[MGC_NUM_FILES];
+    bool fallback[MGC_NUM_FILES];
+    for (uint32_t b = 0; b < nb; b++) {
+      fallback[b] = false;
+      if (h_counts[b] == 0) continue;
+      const uint32_t low = rem_bits - top_bits[b];
+      void *seg = X + kbytes * h_starts[b];
+      if (h_maxsub[b] <= cap) {
+        HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_maxsub[b],
+                                           d_cnt_tmp + h_starts[b], d_group + gbase[b], st));
+      } else {
+        // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
+        fallback[b] = true;
+        if (low) {
+          // LSD order: the low bits cannot be sorted after the top bits, so the whole key is redone
+          mgc::SortPlan lp;
+          mgc::make_sort_plan(0, rem_bits, &lp);
+          int in_alt = 0;
+          HIP_TRY(s, mgc::launch_radix_sort(seg, (void *)Y, h_counts[b], kw, lp, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, nullptr));
+          if (in_alt) HIP_TRY(s, hipMemcpyAsync(seg, Y, kbytes * h_counts[b], hipMemcpyDeviceToDevice, st));
+        }
+        HIP_TRY(s, mgc::launch_rle_count(seg, h_counts[b], kw, rle_ws, st));
+        HIP_TRY(s, mgc::rle_read_total(rle_ws, &h_fallback_distinct[b], st));
+        HIP_TRY(s, hipMemsetAsync(d_group + gbase[b], 0, sizeof(uint64_t) * (gbase[b + 1] - gbase[b]), st));
+        HIP_TRY(s, hipMemcpyAsync(d_group + gbase[b], &h_fallback_distinct[b], sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(s, hipStreamSynchronize(st));
+      }
+    }
+
+    // ---- E/F. offsets of every sub-bucket in the packed result ----
+    HIP_TRY(s, mgc::launch_finish_scan(d_group, ng_total, s->buf[mgc_session::B_GSCAN].p, st));
+    HIP_TRY(s, hipMemcpyAsync(&nd, d_group + ng_total, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+    if (ng_total == 0) nd = 0;
+    s->n_distinct = nd;
+    HIP_TRY(s, s->ensure(mgc_session::B_UNIQUE, kbytes * nd));
+    HIP_TRY(s, s->ensure(mgc_session::B_COUNTS, sizeof(uint32_t) * nd));
+    s->d_unique = s->buf[mgc_session::B_UNIQUE].p;
+    s->d_counts = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_COUNTS].p);
+
+    // ---- G/H. pack ----
+    for (uint32_t b = 0; b < nb; b++) {
+      if (h_counts[b] == 0) continue;
+      void *seg = X + kbytes * h_starts[b];
+      if (!fallback[b]) {
+        HIP_TRY(s, mgc::launch_compact_groups(seg, kw, d_cnt_tmp + h_starts[b], d_substart + sbase[b], d_group + gbase[b],
+                                              gbase[b + 1] - gbase[b], s->d_unique, s->d_counts, st));
+      } else {
+        HIP_TRY(s, mgc::launch_rle_count(seg, h_counts[b], kw, rle_ws, st));
+        HIP_TRY(s, mgc::launch_rle_emit(seg, h_counts[b], kw, rle_ws, s->d_unique, s->d_counts, st, d_group + gbase[b]));
+      }
+    }
+    tm.end(MGC_STAGE_RLE);
+    s->prof.stage_launches[MGC_STAGE_RLE] = 4 * nb;
+  }
 
   // ---- block offsets ----
   HIP_TRY(s, s->ensure(mgc_session::B_BLOCKS, sizeof(uint64_t) * (c.n_prefix + 1)));
@@ -602,8 +746,8 @@ static int count_device(mgc_session *s) {
     s->prof.stage_launches[MGC_STAGE_SORT] = sort_launch_groups * (plan.num_passes + 2);
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0) continue;
-      for (uint32_t p = 0; p < plan.num_passes; p++) {
-        hipEvent_t *pe = &pass_ev[((size_t)b * plan.num_passes + p) * 2];
+      for (uint32_t p = 0; p < file_passes[b]; p++) {
+        hipEvent_t *pe = &pass_ev[(size_t)b * ev_per_file + 2 * p];
         if (hipEventElapsedTime(&ms, pe[0], pe[1]) == hipSuccess) {
           s->prof.sort_pass_ms_total += ms;
           s->prof.sort_pass_launches++;

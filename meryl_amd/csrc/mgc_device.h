@@ -35,6 +35,7 @@ struct SortPlan {
   uint32_t match;           // 0 = ballot match, 1 = LDS mask match (ranking inside a wave)
   uint32_t lookback;        // 1 = walk before the LDS exchange, 2 = window after it
   uint32_t flags;           // bit1: non-temporal key loads (experiments)
+  void    *dbg;             // optional device buffer: 8 cycle stamps per tile of the LAST pass launched
   uint32_t num_passes;
   uint32_t pass_shift[16];
   uint32_t pass_bits[16];
@@ -60,8 +61,22 @@ size_t     rle_workspace_bytes(uint64_t n);
 hipError_t launch_rle_count(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_ws, hipStream_t st);
 // after launch_rle_count + stream sync: number of distinct keys sits at ws[0]
 hipError_t rle_read_total(const void *d_ws, uint64_t *n_distinct, hipStream_t st);
+// d_out_base (device, optional): offset added to every output slot
 hipError_t launch_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_ws, void *d_unique,
-                           uint32_t *d_counts, hipStream_t st);
+                           uint32_t *d_counts, hipStream_t st, const uint64_t *d_out_base = nullptr);
+
+// ---- sub-bucket finish (LDS sort of the low bits + fused run-length count) ---------------
+uint64_t   finish_capacity_for(uint32_t key_words);     // largest sub-bucket the LDS kernels accept
+uint64_t   finish_target_for(uint32_t key_words);       // average sub-bucket size to aim for
+hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t low, uint32_t top_bits,
+                                   uint64_t *d_starts /*[2^top+1]*/, uint64_t *d_max /*atomicMax target*/, hipStream_t st);
+hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
+                              uint64_t max_sub, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct, hipStream_t st);
+size_t     finish_scan_scratch_bytes(uint64_t ng_total);
+hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
+hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,
+                                 const uint64_t *d_offs, uint64_t ng, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st);
+hipError_t launch_store_u64(uint64_t *d_dst, const uint64_t *d_src, hipStream_t st);
 
 hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,
                                 uint64_t n_prefix, uint64_t *d_block_start, hipStream_t st);

@@ -496,11 +496,23 @@ void radix_hist_kernel(const K *__restrict__ in, u64 n, PassList pl, u64 *__rest
   for (u32 i = threadIdx.x; i < np * stride; i += 256) s_h[i] = 0;
   __syncthreads();
 
-  const u64 gstride = (u64)gridDim.x * 256;
-  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += gstride) {
-    const K key = in[i];
-    for (u32 p = 0; p < np; p++)
-      atomicAdd(&s_h[p * stride + KeyOps<K>::digit(key, pl.shift[p], pl.mask[p])], 1u);
+  // 4 independent loads in flight per thread (the loop is otherwise latency-bound)
+  constexpr u32 UNR = 4;
+  const u64 gstride = (u64)gridDim.x * 256 * UNR;
+  for (u64 base = (u64)blockIdx.x * 256 * UNR; base < n; base += gstride) {
+    K key[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (u32 j = 0; j < UNR; j++) {
+      const u64 i = base + (u64)j * 256 + threadIdx.x;
+      ok[j] = i < n;
+      if (ok[j]) key[j] = in[i];
+    }
+#pragma unroll
+    for (u32 j = 0; j < UNR; j++)
+      if (ok[j])
+        for (u32 p = 0; p < np; p++)
+          atomicAdd(&s_h[p * stride + KeyOps<K>::digit(key[j], pl.shift[p], pl.mask[p])], 1u);
   }
   __syncthreads();
   for (u32 i = threadIdx.x; i < np * stride; i += 256) {
@@ -565,7 +577,7 @@ struct RadixSmem {
   static constexpr size_t OFF_CNT   = OFF_DBASE + (size_t)R * 4;   // u32[R]
   static constexpr size_t OFF_TMP   = OFF_CNT + (size_t)R * 4;     // u32[64] scan scratch + misc
   static constexpr size_t OFF_WIN   = OFF_TMP + 64 * 4;            // u64[LB_WINDOW][R/2] look-back window (LB == 2)
-  static constexpr size_t WIN_BYTES = (LB >= 2) ? ((RB == 9 && BLOCK == 512) ? 4096 : 8192) : 0;
+  static constexpr size_t WIN_BYTES = (LB == 2 || LB == 3) ? ((RB == 9 && BLOCK == 512) ? 4096 : 8192) : 0;
   static constexpr size_t BYTES     = OFF_WIN + WIN_BYTES;
   // workgroups per CU the LDS budget admits (160 KiB per CU), capped at 2
   static constexpr int    WG_PER_CU = (2 * BYTES <= 160 * 1024) ? 2 : 1;
@@ -580,8 +592,11 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
                           u32 *__restrict__ ticket, u32 *__restrict__ error_flag,
                           u32 flags,                          // bit0: XCD-chunked tile order, bit1: non-temporal key loads
                           const u64 *__restrict__ tile_offs,  // !LOOKBACK: [R][num_tiles] absolute offsets
-                          u64 num_tiles) {
+                          u64 num_tiles, u64 *__restrict__ dbg /* optional: 8 cycle stamps per tile */) {
   using SM = RadixSmem<K, RB, BLOCK, KPT, LB>;
+#define MGC_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg_t[i] = clock64(); } while (0)
+  u64 dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  MGC_STAMP(0);
   using KO = KeyOps<K>;
   constexpr int R = SM::R, NW = SM::NW, TILE = SM::TILE;
   static_assert(BLOCK >= R, "one thread per digit needed");
@@ -610,6 +625,7 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
   for (u32 i = tid; i < (u32)(NW * R * 3); i += BLOCK) s_whist[i] = 0;   // counters + match masks
   __syncthreads();
 
+  MGC_STAMP(1);
   // ---- load (wave-striped: 512 contiguous bytes per wave instruction) ----
   const u64  tile_base = tile * (u64)TILE;
   const bool full      = (tile_base + TILE <= n);
@@ -662,6 +678,7 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
   }
   __syncthreads();
 
+  MGC_STAMP(2);
   // ---- digit totals of the tile, wave-exclusive bases ----
   const u32 n_valid = full ? (u32)TILE : (u32)(n - tile_base);
   u32 count = 0;
@@ -735,6 +752,7 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
     __syncthreads();
   }
 
+  MGC_STAMP(3);
   // ---- final position of every key inside the sorted tile ----
 #pragma unroll
   for (int j = 0; j < KPT; j++) {           // ranks[] becomes positions in place (still < TILE)
@@ -746,8 +764,53 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
 #pragma unroll
   for (int j = 0; j < KPT; j++) s_keys[(j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu)] = keys[j];
   __syncthreads();                          // keys now live in LDS only: registers are free for the look-back
+  MGC_STAMP(4);
 
-  if constexpr (LB >= 2) {
+  if constexpr (LB == 4) {
+    // Look-back after the exchange (keys live in LDS, registers are free): every digit-pair thread
+    // walks its own granule column with LB4_BATCH predecessors in flight per round -- one fabric
+    // round trip (~2 us under load) retires up to LB4_BATCH tiles, no LDS staging, no barriers.
+    constexpr int LB4_BATCH = 32;
+    if (tid < (u32)G) {
+      const u32 c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+      u32 p0 = 0, p1 = 0;
+      if (tile != 0) {
+        bool need0 = true, need1 = true;
+        u64  t = tile - 1;
+        u32  spins = 0;
+        while (need0 || need1) {
+          u64 gv[LB4_BATCH];
+#pragma unroll
+          for (int i = 0; i < LB4_BATCH; i++)
+            gv[i] = (t >= (u64)i) ? status_load(status + (t - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
+          u32 used = 0;
+          bool open = true;
+#pragma unroll
+          for (int i = 0; i < LB4_BATCH; i++) {
+            const u32 lo = (u32)gv[i], hi = (u32)(gv[i] >> 32);
+            const u32 f0 = lo >> 30, f1 = hi >> 30;
+            open = open && (need0 || need1) && (f0 != 0) && (f1 != 0);
+            if (open) {
+              if (need0) { p0 += lo & 0x3FFFFFFFu; if (f0 == 2) need0 = false; }
+              if (need1) { p1 += hi & 0x3FFFFFFFu; if (f1 == 2) need1 = false; }
+              used++;
+            }
+          }
+          t -= (used <= t) ? used : t;
+          if (used == 0) {
+            if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
+      }
+      s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
+      s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
+    }
+    __syncthreads();
+  }
+
+  if constexpr (LB == 2 || LB == 3) {
     // window-parallel look-back after the exchange (keys live in LDS only, registers are free):
     // all waves fetch the granules of the next LB_WINDOW predecessors with coalesced loads into
     // LDS, the R/2 digit-pair threads consume the ready prefix.
@@ -824,6 +887,7 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
     __syncthreads();
   }
 
+  MGC_STAMP(5);
   // ---- contiguous runs leave coalesced ----
 #pragma unroll
   for (int j = 0; j < KPT; j++) {
@@ -834,6 +898,12 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
       out[s_gbase[d] + (u64)i] = key;
     }
   }
+  MGC_STAMP(6);
+  if (dbg && threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) dbg[tile * 8 + i] = dbg_t[i];
+  }
+#undef MGC_STAMP
 }
 
 // ---- classic mode: per-tile digit histogram + row scan ----------------------
@@ -911,7 +981,7 @@ void make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan) {
   plan->tile       = plan->block * plan->kpt;
   plan->mode       = mode ? 1u : 0u;
   plan->match      = env_int("MGC_SORT_MATCH", 1) ? 1u : 0u;
-  plan->lookback   = (env_int("MGC_SORT_LB", 2) == 2) ? 2u : 1u;
+  { const int lb = env_int("MGC_SORT_LB", 2); plan->lookback = (lb == 2 || lb == 4) ? (uint32_t)lb : 1u; }
   plan->flags      = (uint32_t)env_int("MGC_SORT_FLAGS", 0);
   const uint32_t nbits = (end_bit > begin_bit) ? end_bit - begin_bit : 0;
   uint32_t passes = (nbits + rb - 1) / rb;
@@ -981,7 +1051,7 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
       hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, LBK, MATCH>), dim3((uint32_t)num_tiles),
                          dim3(BLOCK), SM::BYTES, st, (const K *)src, dst, (u64)n, plan.pass_shift[p],
                          (1u << plan.pass_bits[p]) - 1u, &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, plan.flags,
-                         (const u64 *)nullptr, (u64)num_tiles);
+                         (const u64 *)nullptr, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
       K *t = src; src = dst; dst = t; in_alt ^= 1;
@@ -1004,7 +1074,7 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
       hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, 0, MATCH>), dim3((uint32_t)num_tiles), dim3(BLOCK),
                          SM0::BYTES, st, (const K *)src, dst, (u64)n, shift, dmask, (const u64 *)nullptr, (u64 *)nullptr,
-                         (u32 *)nullptr, d_error, plan.flags, tile_offs, (u64)num_tiles);
+                         (u32 *)nullptr, d_error, plan.flags, tile_offs, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
       K *t = src; src = dst; dst = t; in_alt ^= 1;
@@ -1028,6 +1098,8 @@ hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key
       return run_passes<K_, RB_, BLOCK_, KPT_, 0, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
     if (plan.lookback == 2)                                                                                  \
       return run_passes<K_, RB_, BLOCK_, KPT_, 1, 2>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+    if (plan.lookback == 4)                                                                                  \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 4>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
     return run_passes<K_, RB_, BLOCK_, KPT_, 1, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);   \
   } while (0)
   if (key_words == 2) {
@@ -1253,8 +1325,9 @@ __device__ __forceinline__ u32 rl_pad(u32 i) { return i + (i >> 4); }
 template <typename K>
 __global__ __launch_bounds__(RL_BLOCK)
 void rle_emit_kernel(const K *__restrict__ in, u64 n, const u64 *__restrict__ tile_offs,
-                     const u64 *__restrict__ tile_next, u64 out_base0, K *__restrict__ out_keys,
+                     const u64 *__restrict__ tile_next, const u64 *__restrict__ d_out_base, K *__restrict__ out_keys,
                      u32 *__restrict__ out_counts) {
+  const u64 out_base0 = d_out_base ? *d_out_base : 0ull;
   constexpr int RL_KPT = RlTile<K>::KPT, RL_TILE = RL_BLOCK * RL_KPT;
   __shared__ K s_keys[RL_TILE + 1 + (RL_TILE + 1) / 16 + 1];
   __shared__ u32 s_tmp[RL_BLOCK / 64 + 1];
@@ -1343,17 +1416,392 @@ hipError_t rle_read_total(const void *d_ws, uint64_t *n_distinct, hipStream_t st
 }
 
 hipError_t launch_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_ws, void *d_unique,
-                           uint32_t *d_counts, hipStream_t st) {
+                           uint32_t *d_counts, hipStream_t st, const uint64_t *d_out_base) {
   if (n == 0) return hipSuccess;
   RleWs w = rle_ws(d_ws, n, key_words);
   if (key_words == 2)
     hipLaunchKernelGGL(rle_emit_kernel<K128>, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
-                       reinterpret_cast<const K128 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next, (u64)0,
-                       reinterpret_cast<K128 *>(d_unique), d_counts);
+                       reinterpret_cast<const K128 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next,
+                       reinterpret_cast<const u64 *>(d_out_base), reinterpret_cast<K128 *>(d_unique), d_counts);
   else
     hipLaunchKernelGGL(rle_emit_kernel<u64>, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
-                       reinterpret_cast<const u64 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next, (u64)0,
-                       reinterpret_cast<u64 *>(d_unique), d_counts);
+                       reinterpret_cast<const u64 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next,
+                       reinterpret_cast<const u64 *>(d_out_base), reinterpret_cast<u64 *>(d_unique), d_counts);
+  return hipGetLastError();
+}
+
+// ============================================================================
+//  Sub-bucket finish: LDS sort of the low bits + fused run-length count
+// ============================================================================
+//
+// After the global LSB passes have ordered a file by its TOP t bits (below the six
+// file bits), every value of those bits is a contiguous sub-bucket of a few thousand
+// k-mers.  One workgroup loads one sub-bucket, sorts the remaining low bits with
+// stable 8-bit counting passes that never leave LDS, run-length counts it, and
+// writes the distinct k-mers in place (front of the sub-bucket's own region) plus
+// their counts to a scratch array.  A small compaction then packs all sub-buckets.
+// HBM traffic: 8 B read per instance + 12 B per distinct k-mer, instead of two more
+// 16 B/key radix passes, an 8 B histogram read and the two run-length passes.
+
+// starts[v] = first index in [0, n) whose top bits ((key >> low) & tmask) are >= v, for v in [0, ng]
+template <typename K>
+__global__ void subbucket_bounds_kernel(const K *__restrict__ keys, u64 n, u32 low, u32 tmask, u64 ng,
+                                        u64 *__restrict__ starts) {
+  const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > ng) return;
+  if (v == ng) { starts[v] = n; return; }
+  u64 lo = 0, hi = n;
+  while (lo < hi) {
+    const u64 mid = lo + ((hi - lo) >> 1);
+    if ((u64)KeyOps<K>::digit(keys[mid], low, tmask) < v) lo = mid + 1; else hi = mid;
+  }
+  starts[v] = lo;
+}
+
+// largest sub-bucket of a file -> *max_out (atomicMax), so the host can pick the kernel capacity
+__global__ void subbucket_max_kernel(const u64 *__restrict__ starts, u64 ng, u64 *__restrict__ max_out) {
+  const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 sz = (v < ng) ? (starts[v + 1] - starts[v]) : 0ull;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const u64 o = __shfl_down(sz, d); sz = (o > sz) ? o : sz; }
+  if (lane_id() == 0 && sz) atomicMax(max_out, sz);
+}
+
+template <typename K, int BLOCK, int KPT>
+struct FinishSmem {
+  static constexpr int R = 256, NW = BLOCK / 64, CAP = BLOCK * KPT;
+  static constexpr size_t RANK_BYTES = (size_t)NW * R * 12;
+  static constexpr size_t REGION0 = ((size_t)CAP * sizeof(K) > RANK_BYTES) ? (size_t)CAP * sizeof(K) : RANK_BYTES;
+  static constexpr size_t OFF_DBASE = REGION0;                        // u32[R]
+  static constexpr size_t OFF_TMP   = OFF_DBASE + (size_t)R * 4;      // u32[64]
+  static constexpr size_t OFF_FLAG  = OFF_TMP + 64 * 4;               // u8[CAP] head flags
+  static constexpr size_t OFF_HP    = OFF_FLAG + (size_t)CAP;         // u16[CAP + 1] head positions
+  static constexpr size_t BYTES     = OFF_HP + (size_t)(CAP + 2) * 2;
+};
+
+template <typename K, int BLOCK, int KPT>
+__global__ __launch_bounds__(BLOCK)
+void lds_sort_count_kernel(K *__restrict__ keys,                      // the file's segment; distinct keys are written in place
+                           const u64 *__restrict__ starts,            // [ng+1] sub-bucket offsets inside the segment
+                           u32 low_bits, u64 min_size, u64 max_size,   // this launch handles sub-buckets with min < n <= max
+                           u32 *__restrict__ cnt_tmp,                 // counts, indexed like `keys`
+                           u64 *__restrict__ group_distinct) {        // [ng]
+  using SM = FinishSmem<K, BLOCK, KPT>;
+  using KO = KeyOps<K>;
+  constexpr int R = SM::R, NW = SM::NW, CAP = SM::CAP;
+  static_assert(BLOCK >= R && CAP <= 16384, "16-bit positions, one thread per digit");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  K   *s_keys  = reinterpret_cast<K *>(smem);
+  u32 *s_whist = reinterpret_cast<u32 *>(smem);
+  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
+  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
+  unsigned char  *s_flag = smem + SM::OFF_FLAG;
+  unsigned short *s_hp   = reinterpret_cast<unsigned short *>(smem + SM::OFF_HP);
+
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const u64 g = blockIdx.x;
+  const u64 a = starts[g];
+  const u64 n64 = starts[g + 1] - a;
+  if (n64 <= min_size || n64 > max_size) {             // another launch's (or nobody's) sub-bucket
+    if (n64 == 0 && min_size == 0 && tid == 0) group_distinct[g] = 0;
+    return;
+  }
+  const u32 n = (u32)n64;
+  K *gk = keys + a;
+
+  // ---- load, wave-striped like the global passes; padding sorts to the very end ----
+  K kk[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const u32 idx = w * (64 * KPT) + (u32)j * 64 + lane;
+    kk[j] = (idx < n) ? gk[idx] : KO::pad();
+  }
+
+  // ---- stable 8-bit counting passes over the low bits, entirely in LDS ----
+  const u64 lt_mask = (1ull << lane) - 1ull;
+  const u64 lane_bit = 1ull << lane;
+  for (u32 shift = 0; shift < low_bits; shift += 8) {
+    const u32 bits  = (low_bits - shift < 8u) ? (low_bits - shift) : 8u;
+    const u32 dmask = (1u << bits) - 1u;
+    for (u32 i = tid; i < (u32)(NW * R * 3); i += BLOCK) s_whist[i] = 0;
+    __syncthreads();
+    lds_u32 *wh = (lds_u32 *)(smem) + w * R;
+    lds_u64 *mk = (lds_u64 *)(smem + (size_t)NW * R * 4) + w * R;
+    u32 ranks[KPT / 2];
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 d = KO::digit(kk[j], shift, dmask);
+      __hip_atomic_fetch_or(&mk[d], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u64 peers = __hip_atomic_load(&mk[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u32 base  = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u32 lower = __popcll(peers & lt_mask);
+      if (lower == 0) {
+        __hip_atomic_store(&wh[d], base + (u32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_store(&mk[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      if (j & 1) ranks[j / 2] |= (base + lower) << 16;
+      else       ranks[j / 2]  = (base + lower);
+    }
+    __syncthreads();
+    u32 count = 0;
+    if (tid < (u32)R) {
+      u32 acc = 0;
+#pragma unroll
+      for (int ww = 0; ww < NW; ww++) {
+        const u32 t = s_whist[ww * R + tid];
+        s_whist[ww * R + tid] = acc;
+        acc += t;
+      }
+      count = acc;
+    }
+    u32 tot;
+    const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tot);
+    if (tid < (u32)R) s_dbase[tid] = excl;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 d = KO::digit(kk[j], shift, dmask);
+      const u32 add = s_dbase[d] + s_whist[w * R + d];
+      ranks[j / 2] += (j & 1) ? (add << 16) : add;
+    }
+    __syncthreads();                                   // scratch is dead; its storage becomes s_keys
+#pragma unroll
+    for (int j = 0; j < KPT; j++) s_keys[(j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu)] = kk[j];
+    __syncthreads();
+    if (shift + 8 < low_bits) {                        // next pass ranks in the new order
+#pragma unroll
+      for (int j = 0; j < KPT; j++) kk[j] = s_keys[w * (64 * KPT) + (u32)j * 64 + lane];
+      __syncthreads();
+    }
+  }
+  if (low_bits == 0) {                                 // nothing to sort: all keys of the sub-bucket are equal bits above
+#pragma unroll
+    for (int j = 0; j < KPT; j++) s_keys[w * (64 * KPT) + (u32)j * 64 + lane] = kk[j];
+    __syncthreads();
+  }
+
+  // ---- run-length count on the sorted sub-bucket ----
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {                      // striped: conflict-free neighbour compares
+    const u32 i = (u32)j * BLOCK + tid;
+    s_flag[i] = (i < n && (i == 0 || KO::ne(s_keys[i], s_keys[i - 1]))) ? 1 : 0;
+  }
+  __syncthreads();
+  u32 myflags = 0;                                      // blocked: KPT consecutive flags per thread
+#pragma unroll
+  for (int j = 0; j < KPT; j++) myflags |= (u32)s_flag[tid * KPT + j] << j;
+  u32 d_total;
+  u32 slot = block_excl_scan<BLOCK, u32>(__popc(myflags), s_tmp, &d_total);
+#pragma unroll
+  for (int j = 0; j < KPT; j++)
+    if ((myflags >> j) & 1u) s_hp[slot++] = (unsigned short)(tid * KPT + j);
+  if (tid == 0) s_hp[d_total] = (unsigned short)n;      // CAP <= 16384 fits
+  __syncthreads();
+  for (u32 sidx = tid; sidx < d_total; sidx += BLOCK) {
+    const u32 i = s_hp[sidx];
+    gk[sidx] = s_keys[i];                               // in place: every key of this region is in LDS by now
+    cnt_tmp[a + sidx] = (u32)s_hp[sidx + 1] - i;
+  }
+  if (tid == 0) group_distinct[g] = d_total;
+}
+
+// Hash-count finish for uint64 keys: sub-buckets of real read sets are mostly duplicates (coverage),
+// so instead of sorting n keys the workgroup inserts them into an LDS hash table that counts
+// (one 64-bit CAS + one add per key, independent per key => the LDS latency overlaps), compacts
+// the D distinct entries and ranks them by brute force (D^2 / BLOCK broadcast compares; D ~ n/7).
+// EMPTY cannot collide with a key: every key of the file shares its top six bits, ~key0 does not.
+template <int BLOCK, int CAP, int SLOTS>
+__global__ __launch_bounds__(BLOCK)
+void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 max_size, u32 low_bits,
+                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct) {
+  // Inside a sub-bucket the keys differ only in their low `low_bits` (< 32) bits: the table holds
+  // 32-bit suffixes (half the LDS, 32-bit CAS and compares); the common prefix is added back on output.
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS >= 2 * CAP && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
+  constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
+  constexpr u32 EMPTY = 0xFFFFFFFFu;                   // suffixes are < 2^31
+  __shared__ u32 tk[SLOTS];
+  __shared__ u32 tc[SLOTS];
+  __shared__ __attribute__((aligned(16))) u32 dk[CAP];
+  __shared__ u32 dc[CAP];
+  __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  const u32 tid = threadIdx.x;
+  const u64 g = blockIdx.x;
+  const u64 a = starts[g];
+  const u64 n64 = starts[g + 1] - a;
+  if (n64 > max_size) return;                          // a larger-capacity launch takes it
+  if (n64 == 0) { if (tid == 0) group_distinct[g] = 0; return; }
+  const u32 n = (u32)n64;
+  u64 *gk = keys + a;
+  const u64 low_mask = (1ull << low_bits) - 1ull;
+  const u64 prefix = gk[0] & ~low_mask;
+
+  u32 kk[KPT], hh[KPT];
+  u32 pending = 0;
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const u32 idx = (u32)j * BLOCK + tid;
+    kk[j] = (idx < n) ? (u32)(gk[idx] & low_mask) : 0u;
+    hh[j] = (kk[j] * 0x9E3779B1u) >> (32 - __builtin_ctz((unsigned)SLOTS));
+    if (idx < n) pending |= 1u << j;
+  }
+#pragma unroll
+  for (int j = 0; j < SPT; j++) { tk[(u32)j * BLOCK + tid] = EMPTY; tc[(u32)j * BLOCK + tid] = 0u; }
+  __syncthreads();
+
+  // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
+  while (pending) {
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      if ((pending >> j) & 1u) {
+        const u32 old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
+        if (old == EMPTY || old == kk[j]) { atomicAdd(&tc[hh[j]], 1u); pending &= ~(1u << j); }
+        else hh[j] = (hh[j] + 1) & (u32)(SLOTS - 1);
+      }
+    }
+  }
+  __syncthreads();
+
+  // compact the occupied slots (any order)
+  u32 occ = 0;
+#pragma unroll
+  for (int j = 0; j < SPT; j++) occ |= (tc[(u32)j * BLOCK + tid] != 0u ? 1u : 0u) << j;
+  u32 D;
+  u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+#pragma unroll
+  for (int j = 0; j < SPT; j++)
+    if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
+  __syncthreads();
+
+  // rank = number of smaller distinct suffixes; dk[j..j+3] is one broadcast 16-byte read for the whole wave
+  const uint4 *dk4 = reinterpret_cast<const uint4 *>(dk);
+  for (u32 i = tid; i < D; i += BLOCK) {
+    const u32 ki = dk[i];
+    u32 r = 0;
+    const u32 d4 = D / 4;
+    for (u32 j = 0; j < d4; j++) {
+      const uint4 v = dk4[j];
+      r += (v.x < ki ? 1u : 0u) + (v.y < ki ? 1u : 0u) + (v.z < ki ? 1u : 0u) + (v.w < ki ? 1u : 0u);
+    }
+    for (u32 j = d4 * 4; j < D; j++) r += (dk[j] < ki ? 1u : 0u);
+    gk[r] = prefix | (u64)ki;                          // in place: every key of this region was read above
+    cnt_tmp[a + r] = dc[i];
+  }
+  if (tid == 0) group_distinct[g] = D;
+}
+
+// offs = exclusive scan of group_distinct (offs[ng] = total).  One wave per sub-bucket.
+template <typename K>
+__global__ __launch_bounds__(256)
+void compact_groups_kernel(const K *__restrict__ keys, const u32 *__restrict__ cnt_tmp, const u64 *__restrict__ starts,
+                           const u64 *__restrict__ offs, u64 ng, K *__restrict__ out_keys, u32 *__restrict__ out_counts) {
+  const u64 g = (u64)blockIdx.x * 4 + wave_id();
+  if (g >= ng) return;
+  const u64 dst = offs[g], d = offs[g + 1] - dst, src = starts[g];
+  for (u64 i = lane_id(); i < d; i += 64) {
+    out_keys[dst + i]   = keys[src + i];
+    out_counts[dst + i] = cnt_tmp[src + i];
+  }
+}
+
+__global__ void store_u64_kernel(u64 *__restrict__ dst, const u64 *__restrict__ src) { *dst = *src; }
+
+constexpr u64 FIN_CAP_SMALL = 256 * 16, FIN_CAP_LARGE = 1024 * 8;   // LDS: 46 KiB and 91 KiB per workgroup
+constexpr u64 FIN_CAP_HASH  = 2048;                               // hash-count kernel: 72 KiB of LDS
+
+hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t low, uint32_t top_bits,
+                                   uint64_t *d_starts, uint64_t *d_max, hipStream_t st) {
+  const uint64_t ng = (uint64_t)1 << top_bits;
+  const uint32_t tmask = (uint32_t)(ng - 1);
+  const dim3 grid((uint32_t)((ng + 1 + 255) / 256));
+  if (key_words == 2)
+    hipLaunchKernelGGL(subbucket_bounds_kernel<K128>, grid, dim3(256), 0, st, reinterpret_cast<const K128 *>(d_keys),
+                       (u64)n, low, tmask, (u64)ng, reinterpret_cast<u64 *>(d_starts));
+  else
+    hipLaunchKernelGGL(subbucket_bounds_kernel<u64>, grid, dim3(256), 0, st, reinterpret_cast<const u64 *>(d_keys),
+                       (u64)n, low, tmask, (u64)ng, reinterpret_cast<u64 *>(d_starts));
+  MGC_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(subbucket_max_kernel, dim3((uint32_t)((ng + 255) / 256)), dim3(256), 0, st,
+                     reinterpret_cast<const u64 *>(d_starts), (u64)ng, reinterpret_cast<u64 *>(d_max));
+  return hipGetLastError();
+}
+
+template <typename K, int BLOCK, int KPT>
+static hipError_t finish_launch(void *d_keys, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits, uint64_t min_size,
+                                uint64_t max_size, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct, hipStream_t st) {
+  using SM = FinishSmem<K, BLOCK, KPT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_sort_count_kernel<K, BLOCK, KPT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((lds_sort_count_kernel<K, BLOCK, KPT>), dim3((uint32_t)ng), dim3(BLOCK), SM::BYTES, st,
+                     reinterpret_cast<K *>(d_keys), reinterpret_cast<const u64 *>(d_starts), low_bits, (u64)min_size,
+                     (u64)max_size, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
+  return hipGetLastError();
+}
+
+// Sorts + counts every sub-bucket of one file segment; sub-buckets larger than FIN_CAP_SMALL use the
+// large-capacity instantiation (launched only if the file has any: max_sub tells).
+hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
+                              uint64_t max_sub, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct, hipStream_t st) {
+  if (key_words == 2) {
+    // 16-byte keys: 256x8 (2048) and 1024x8 (8192) keep LDS at 32 / 128 KiB
+    MGC_CHECK((finish_launch<K128, 256, 8>(d_keys, d_starts, ng, low_bits, 0, 2048, d_cnt_tmp, d_group_distinct, st)));
+    if (max_sub > 2048)
+      MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, ng, low_bits, 2048, 8192, d_cnt_tmp, d_group_distinct, st)));
+    return hipSuccess;
+  }
+  static const bool use_hash = !(getenv("MGC_FINISH_HASH") && getenv("MGC_FINISH_HASH")[0] == '0');
+  if (use_hash && low_bits < 32) {
+    // <= FIN_CAP_HASH keys: hash-count; larger sub-buckets: LDS radix passes in the 8192-key instantiation
+    hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2 * (int)FIN_CAP_HASH>), dim3((uint32_t)ng), dim3(256), 0, st,
+                       reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)FIN_CAP_HASH, low_bits,
+                       d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
+    MGC_CHECK(hipGetLastError());
+    if (max_sub > FIN_CAP_HASH)
+      MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, ng, low_bits, FIN_CAP_HASH, FIN_CAP_LARGE, d_cnt_tmp,
+                                             d_group_distinct, st)));
+    return hipSuccess;
+  }
+  MGC_CHECK((finish_launch<u64, 256, 16>(d_keys, d_starts, ng, low_bits, 0, FIN_CAP_SMALL, d_cnt_tmp, d_group_distinct, st)));
+  if (max_sub > FIN_CAP_SMALL)
+    MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, ng, low_bits, FIN_CAP_SMALL, FIN_CAP_LARGE, d_cnt_tmp,
+                                           d_group_distinct, st)));
+  return hipSuccess;
+}
+
+uint64_t finish_capacity_for(uint32_t key_words) { return key_words == 2 ? 8192 : FIN_CAP_LARGE; }
+uint64_t finish_target_for(uint32_t key_words) {
+  if (const char *t = getenv("MGC_FINISH_TARGET")) return strtoull(t, nullptr, 10);
+  if (key_words == 2) return 1024;
+  const char *h = getenv("MGC_FINISH_HASH");
+  return (h && h[0] == '0') ? FIN_CAP_SMALL / 2 : (FIN_CAP_HASH * 3) / 4;   // measured: 1536 beats 1024 and 2048
+}
+
+// group_distinct[0..ng_total) -> exclusive offsets in place, total at [ng_total]
+size_t finish_scan_scratch_bytes(uint64_t ng_total) { return scan_scratch_elems(ng_total + 1) * sizeof(uint64_t); }
+hipError_t launch_finish_scan(uint64_t *d_group, uint64_t ng_total, void *d_scratch, hipStream_t st) {
+  return scan_u64_inplace<false>(reinterpret_cast<u64 *>(d_group), ng_total, reinterpret_cast<u64 *>(d_scratch),
+                                 reinterpret_cast<u64 *>(d_group) + ng_total, 0, st);
+}
+
+hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,
+                                 const uint64_t *d_offs, uint64_t ng, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st) {
+  const dim3 grid((uint32_t)((ng + 3) / 4));
+  if (key_words == 2)
+    hipLaunchKernelGGL(compact_groups_kernel<K128>, grid, dim3(256), 0, st, reinterpret_cast<const K128 *>(d_keys), d_cnt_tmp,
+                       reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng,
+                       reinterpret_cast<K128 *>(d_out_keys), d_out_counts);
+  else
+    hipLaunchKernelGGL(compact_groups_kernel<u64>, grid, dim3(256), 0, st, reinterpret_cast<const u64 *>(d_keys), d_cnt_tmp,
+                       reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng,
+                       reinterpret_cast<u64 *>(d_out_keys), d_out_counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_store_u64(uint64_t *d_dst, const uint64_t *d_src, hipStream_t st) {
+  hipLaunchKernelGGL(store_u64_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<u64 *>(d_dst), reinterpret_cast<const u64 *>(d_src));
   return hipGetLastError();
 }
 

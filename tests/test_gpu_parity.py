@@ -468,3 +468,35 @@ def test_out_of_core_batches_equal_single_pass(ops, oracle_lib, torch_cuda, tmp_
         lo, hi, cn = r.read_all()
         assert np.array_equal(lo, wlo) and np.array_equal(hi, whi) and np.array_equal(cn, wcn)
         r.close()
+
+
+@pytest.mark.parametrize("k", [21, 40])
+def test_heavily_repeated_kmers_take_the_fallback(ops, oracle_lib, torch_cuda, k):
+    # one k-mer far above the LDS capacity (poly-A, a tandem repeat) next to ordinary reads: the file
+    # holding it is finished by the full sort + run-length kernels, the others by the LDS finish
+    from meryl_amd import capi
+    reads = oracle_lib.synth_reads(3, 30_000, 0, 3000).tobytes().decode()
+    stream = "A" * 40_000 + "." + "ACG" * 12_000 + "." + reads + ("T" * 25_000 + ".") * 2
+    cfg = capi.configure(k, len(stream), 1 << 30)
+    with ops.Session(cfg) as s:
+        s.push_bases(stream, end_of_sequence=False)
+        s.count()
+        klo, khi, counts, _ = s.result_wide()
+    whi, wlo, wcn, _ = oracle_lib.count_brute(stream, k)
+    assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+    assert counts.max() >= 2 * 25_000 - 2 * k                 # the poly-A/T k-mer really is that heavy
+
+
+def test_full_sort_path_still_matches(ops, oracle_lib, torch_cuda, monkeypatch):
+    # MGC_FINISH=0: LSB-sort all 2k-6 bits globally + the separate run-length kernels
+    from meryl_amd import capi
+    monkeypatch.setenv("MGC_FINISH", "0")
+    bases = oracle_lib.synth_reads(4, 200_000, 0, 20000)
+    for k in (21, 22, 51):
+        cfg = capi.configure(k, bases.size, 1 << 30)
+        with ops.Session(cfg) as s:
+            s.push_bases_device(torch_cuda.from_numpy(bases).cuda())
+            s.count()
+            klo, khi, counts, _ = s.result_wide()
+        whi, wlo, wcn, _ = oracle_lib.count_brute(bases.tobytes(), k)
+        assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
