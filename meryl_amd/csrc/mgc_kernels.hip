@@ -1610,83 +1610,144 @@ void lds_sort_count_kernel(K *__restrict__ keys,                      // the fil
 // (one 64-bit CAS + one add per key, independent per key => the LDS latency overlaps), compacts
 // the D distinct entries and ranks them by brute force (D^2 / BLOCK broadcast compares; D ~ n/7).
 // EMPTY cannot collide with a key: every key of the file shares its top six bits, ~key0 does not.
-template <int BLOCK, int CAP, int SLOTS>
-__global__ __launch_bounds__(BLOCK)
-void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 max_size, u32 low_bits,
-                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct) {
+template <int BLOCK, int CAP, int SLOTS, bool DBG>
+__global__ __launch_bounds__(BLOCK, 5)
+void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
+                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 *__restrict__ dbg) {
   // Inside a sub-bucket the keys differ only in their low `low_bits` (< 32) bits: the table holds
   // 32-bit suffixes (half the LDS, 32-bit CAS and compares); the common prefix is added back on output.
-  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS >= 2 * CAP && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
+  // Persistent workgroups: the keys of the next sub-bucket are loaded while the current one is counted
+  // (a sub-bucket is ~1K keys, so the two dependent HBM round trips would otherwise be a third of its time).
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
   constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
   constexpr u32 EMPTY = 0xFFFFFFFFu;                   // suffixes are < 2^31
-  __shared__ u32 tk[SLOTS];
-  __shared__ u32 tc[SLOTS];
+  __shared__ __attribute__((aligned(16))) u32 tk[SLOTS];
+  __shared__ __attribute__((aligned(16))) u32 tc[SLOTS];
   __shared__ __attribute__((aligned(16))) u32 dk[CAP];
   __shared__ u32 dc[CAP];
   __shared__ u32 s_tmp[BLOCK / 64 + 1];
   const u32 tid = threadIdx.x;
-  const u64 g = blockIdx.x;
-  const u64 a = starts[g];
-  const u64 n64 = starts[g + 1] - a;
-  if (n64 > max_size) return;                          // a larger-capacity launch takes it
-  if (n64 == 0) { if (tid == 0) group_distinct[g] = 0; return; }
-  const u32 n = (u32)n64;
-  u64 *gk = keys + a;
+  const u64 G = gridDim.x;
   const u64 low_mask = (1ull << low_bits) - 1ull;
-  const u64 prefix = gk[0] & ~low_mask;
 
-  u32 kk[KPT], hh[KPT];
-  u32 pending = 0;
-#pragma unroll
-  for (int j = 0; j < KPT; j++) {
-    const u32 idx = (u32)j * BLOCK + tid;
-    kk[j] = (idx < n) ? (u32)(gk[idx] & low_mask) : 0u;
-    hh[j] = (kk[j] * 0x9E3779B1u) >> (32 - __builtin_ctz((unsigned)SLOTS));
-    if (idx < n) pending |= 1u << j;
-  }
-#pragma unroll
-  for (int j = 0; j < SPT; j++) { tk[(u32)j * BLOCK + tid] = EMPTY; tc[(u32)j * BLOCK + tid] = 0u; }
-  __syncthreads();
-
-  // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
-  while (pending) {
+  auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
+    aa = 0; nn = 0;
+    if (gg < ng) { aa = starts[gg]; nn = starts[gg + 1] - aa; }
+  };
+  // only the low dword of a key is needed: the rest is the file's prefix and the sub-bucket index
+  auto load_keys = [&](u64 aa, u64 nn, u32 (&kr)[KPT]) {
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
-      if ((pending >> j) & 1u) {
-        const u32 old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
-        if (old == EMPTY || old == kk[j]) { atomicAdd(&tc[hh[j]], 1u); pending &= ~(1u << j); }
-        else hh[j] = (hh[j] + 1) & (u32)(SLOTS - 1);
+      const u32 idx = (u32)j * BLOCK + tid;
+      kr[j] = (nn <= max_size && idx < nn) ? reinterpret_cast<const u32 *>(keys + aa + idx)[0] : 0u;
+    }
+  };
+  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
+  const u64 file_base = (keys[0] >> group_shift) << group_shift;
+
+  u64 g = blockIdx.x, a, n64, na, nn;
+  u32 kcur[KPT];
+  load_bounds(g, a, n64);
+  load_keys(a, n64, kcur);
+  load_bounds(g + G, na, nn);
+
+  u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define HC_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
+  while (g < ng) {
+    u32 knext[KPT];
+    u64 nna, nnn;
+    if (DBG) t0 = __builtin_readcyclecounter();
+    load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
+    load_bounds(g + 2 * G, nna, nnn);
+
+    if (n64 == 0) {
+      if (tid == 0) group_distinct[g] = 0;
+    } else if (n64 <= max_size) {                      // larger ones: a larger-capacity launch takes them
+      const u32 n = (u32)n64;
+      const u64 prefix = file_base | (g << low_bits);
+      u32 kk[KPT], hh[KPT];
+      u32 pending = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 idx = (u32)j * BLOCK + tid;
+        kk[j] = kcur[j] & (u32)low_mask;
+        if (idx < n) pending |= 1u << j;
       }
-    }
-  }
-  __syncthreads();
-
-  // compact the occupied slots (any order)
-  u32 occ = 0;
+      // table sized to the sub-bucket (load factor <= 0.8 even if every key is distinct): the clear and the
+      // compaction below walk the table, so an oversized one costs more than the longer probes of a full one
+      u32 slots = 256;
+      while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
+      const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
+      {
+        uint4 *tk4 = reinterpret_cast<uint4 *>(tk), *tc4 = reinterpret_cast<uint4 *>(tc);
+        for (u32 i = tid; i < slots / 4; i += BLOCK) {
+          tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+          tc4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
 #pragma unroll
-  for (int j = 0; j < SPT; j++) occ |= (tc[(u32)j * BLOCK + tid] != 0u ? 1u : 0u) << j;
-  u32 D;
-  u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
-#pragma unroll
-  for (int j = 0; j < SPT; j++)
-    if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
-  __syncthreads();
+      for (int j = 0; j < KPT; j++) hh[j] = (kk[j] * 0x9E3779B1u) >> sshift;
+      __syncthreads();
+      HC_STAMP(0);
 
-  // rank = number of smaller distinct suffixes; dk[j..j+3] is one broadcast 16-byte read for the whole wave
-  const uint4 *dk4 = reinterpret_cast<const uint4 *>(dk);
-  for (u32 i = tid; i < D; i += BLOCK) {
-    const u32 ki = dk[i];
-    u32 r = 0;
-    const u32 d4 = D / 4;
-    for (u32 j = 0; j < d4; j++) {
-      const uint4 v = dk4[j];
-      r += (v.x < ki ? 1u : 0u) + (v.y < ki ? 1u : 0u) + (v.z < ki ? 1u : 0u) + (v.w < ki ? 1u : 0u);
+      // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
+      while (pending) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if ((pending >> j) & 1u) {
+            const u32 old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
+            if (old == EMPTY || old == kk[j]) { atomicAdd(&tc[hh[j]], 1u); pending &= ~(1u << j); }
+            else hh[j] = (hh[j] + 1) & smask;
+          }
+        }
+      }
+      __syncthreads();
+      HC_STAMP(1);
+
+      // compact the occupied slots (any order)
+      u32 occ = 0;
+#pragma unroll
+      for (int j = 0; j < SPT; j++) {
+        const u32 sl = (u32)j * BLOCK + tid;
+        if (sl < slots) occ |= (tc[sl] != 0u ? 1u : 0u) << j;
+      }
+      u32 D;
+      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+#pragma unroll
+      for (int j = 0; j < SPT; j++)
+        if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
+      __syncthreads();
+      HC_STAMP(2);
+
+      // rank = number of smaller distinct suffixes; dk[j..j+3] is one broadcast 16-byte read for the whole wave
+      const uint4 *dk4 = reinterpret_cast<const uint4 *>(dk);
+      u64 *gk = keys + a;
+      for (u32 i = tid; i < D; i += BLOCK) {
+        const u32 ki = dk[i];
+        u32 r = 0;
+        const u32 d4 = D / 4;
+        for (u32 j = 0; j < d4; j++) {
+          const uint4 v = dk4[j];
+          r += (v.x < ki ? 1u : 0u) + (v.y < ki ? 1u : 0u) + (v.z < ki ? 1u : 0u) + (v.w < ki ? 1u : 0u);
+        }
+        for (u32 j = d4 * 4; j < D; j++) r += (dk[j] < ki ? 1u : 0u);
+        gk[r] = prefix | (u64)ki;                      // in place: every key of this region sits in registers
+        cnt_tmp[a + r] = dc[i];
+      }
+      if (tid == 0) group_distinct[g] = D;
+      HC_STAMP(3);
+      __syncthreads();                                 // dk/dc/s_tmp are reused by the next sub-bucket
+      HC_STAMP(4);
     }
-    for (u32 j = d4 * 4; j < D; j++) r += (dk[j] < ki ? 1u : 0u);
-    gk[r] = prefix | (u64)ki;                          // in place: every key of this region was read above
-    cnt_tmp[a + r] = dc[i];
+
+#pragma unroll
+    for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
+    a = na; n64 = nn; na = nna; nn = nnn; g += G;
+    if (DBG) { ph[5] += kcur[0] & 1; HC_STAMP(6); ph[7]++; }   // [6]: wait for the prefetched keys
   }
-  if (tid == 0) group_distinct[g] = D;
+  if (DBG && tid == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
+#undef HC_STAMP
 }
 
 // offs = exclusive scan of group_distinct (offs[ng] = total).  One wave per sub-bucket.
@@ -1706,7 +1767,7 @@ void compact_groups_kernel(const K *__restrict__ keys, const u32 *__restrict__ c
 __global__ void store_u64_kernel(u64 *__restrict__ dst, const u64 *__restrict__ src) { *dst = *src; }
 
 constexpr u64 FIN_CAP_SMALL = 256 * 16, FIN_CAP_LARGE = 1024 * 8;   // LDS: 46 KiB and 91 KiB per workgroup
-constexpr u64 FIN_CAP_HASH  = 2048;                               // hash-count kernel: 72 KiB of LDS
+constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count kernel: 2048 slots, 28 KiB of LDS, 5 workgroups per CU
 
 hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t low, uint32_t top_bits,
                                    uint64_t *d_starts, uint64_t *d_max, hipStream_t st) {
@@ -1743,6 +1804,28 @@ static hipError_t finish_launch(void *d_keys, const uint64_t *d_starts, uint64_t
 
 // Sorts + counts every sub-bucket of one file segment; sub-buckets larger than FIN_CAP_SMALL use the
 // large-capacity instantiation (launched only if the file has any: max_sub tells).
+// MGC_HASH_DBG=1: per-phase cycle sums of the first 64 workgroups of the hash-count kernel, printed for a few launches
+static u64 *hash_dbg_buffer() {
+  static u64 *buf = nullptr;
+  static const bool on = getenv("MGC_HASH_DBG") != nullptr;
+  if (on && !buf) { if (hipMalloc(&buf, 64 * 8 * sizeof(u64)) != hipSuccess) buf = nullptr; }
+  return buf;
+}
+static void hash_dbg_report(hipStream_t st, uint64_t ng) {
+  u64 *buf = hash_dbg_buffer();
+  static int reports = 0;
+  if (!buf || reports >= 4) return;
+  u64 h[64 * 8];
+  if (hipStreamSynchronize(st) != hipSuccess) return;
+  if (hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+  double sum[8] = {0};
+  for (int b = 0; b < 64; b++) for (int i = 0; i < 8; i++) sum[i] += (double)h[b * 8 + i];
+  const double it = sum[7] > 0 ? sum[7] : 1;
+  fprintf(stderr, "[hash dbg] ng=%llu iters/block=%.1f cycles/iter: init=%.0f probe=%.0f compact=%.0f rank+store=%.0f sync=%.0f wait_next=%.0f\n",
+          (unsigned long long)ng, it / 64, sum[0] / it, sum[1] / it, sum[2] / it, sum[3] / it, sum[4] / it, sum[6] / it);
+  reports++;
+}
+
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t max_sub, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct, hipStream_t st) {
   if (key_words == 2) {
@@ -1755,10 +1838,18 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
   static const bool use_hash = !(getenv("MGC_FINISH_HASH") && getenv("MGC_FINISH_HASH")[0] == '0');
   if (use_hash && low_bits < 32) {
     // <= FIN_CAP_HASH keys: hash-count; larger sub-buckets: LDS radix passes in the 8192-key instantiation
-    hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2 * (int)FIN_CAP_HASH>), dim3((uint32_t)ng), dim3(256), 0, st,
-                       reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)FIN_CAP_HASH, low_bits,
-                       d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
+    static const uint32_t hgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 10u;
+    const uint32_t hgrid = ng < hgrid_max ? (uint32_t)ng : hgrid_max;
+    if (hash_dbg_buffer())
+      hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true>), dim3(hgrid), dim3(256), 0, st,
+                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), hash_dbg_buffer());
+    else
+      hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false>), dim3(hgrid), dim3(256), 0, st,
+                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), nullptr);
     MGC_CHECK(hipGetLastError());
+    hash_dbg_report(st, ng);
     if (max_sub > FIN_CAP_HASH)
       MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, ng, low_bits, FIN_CAP_HASH, FIN_CAP_LARGE, d_cnt_tmp,
                                              d_group_distinct, st)));
@@ -1776,7 +1867,7 @@ uint64_t finish_target_for(uint32_t key_words) {
   if (const char *t = getenv("MGC_FINISH_TARGET")) return strtoull(t, nullptr, 10);
   if (key_words == 2) return 1024;
   const char *h = getenv("MGC_FINISH_HASH");
-  return (h && h[0] == '0') ? FIN_CAP_SMALL / 2 : (FIN_CAP_HASH * 3) / 4;   // measured: 1536 beats 1024 and 2048
+  return (h && h[0] == '0') ? FIN_CAP_SMALL / 2 : (FIN_CAP_HASH * 3) / 4;
 }
 
 // group_distinct[0..ng_total) -> exclusive offsets in place, total at [ng_total]
