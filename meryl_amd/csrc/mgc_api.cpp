@@ -207,8 +207,17 @@ extern "C" int mgc_dev_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_
     (void)hipStreamSynchronize(st);
     std::vector<uint64_t> h(dbg_tiles * 8);
     (void)hipMemcpy(h.data(), dbg, dbg_tiles * 64, hipMemcpyDeviceToHost);
+    const bool pipe_fmt = (plan.lookback == 5 || plan.mode == 3);
+    if (pipe_fmt) {                       // pipelined kernels: per-phase cycle sums of the first 64 workgroups, last pass
+      double ps[8] = {0};
+      for (int b = 0; b < 64; b++) for (int i = 0; i < 8; i++) ps[i] += (double)h[b * 8 + i];
+      const double it = ps[7] > 0 ? ps[7] : 1;
+      fprintf(stderr, "[sortdbg pipe] tiles/wg=%.1f cycles/tile: ticket+zero=%.0f rank=%.0f totals+positions+exchange=%.0f lookback+prefetch=%.0f writeout=%.0f endsync=%.0f total=%.0f\n",
+              it / 64, ps[0] / it, ps[1] / it, ps[2] / it, ps[3] / it, ps[4] / it, ps[5] / it,
+              (ps[0] + ps[1] + ps[2] + ps[3] + ps[4] + ps[5]) / it);
+    }
     double sum[6] = {0, 0, 0, 0, 0, 0}; uint64_t cnt = 0;
-    for (uint64_t t = 0; t < dbg_tiles; t++) {
+    for (uint64_t t = 0; !pipe_fmt && t < dbg_tiles; t++) {
       if (h[t * 8] == 0 || h[t * 8 + 6] == 0) continue;
       for (int i = 0; i < 6; i++) sum[i] += (double)(h[t * 8 + i + 1] - h[t * 8 + i]);
       cnt++;
@@ -301,7 +310,7 @@ struct mgc_session {
   // repeated count does not pay hipMalloc/hipFree of tens of GB every time
   struct Buf { void *p = nullptr; size_t cap = 0; };
   enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_HPC, B_HPC_WS, B_BASES,
-         B_SUBSTART, B_GROUPS, B_GSCAN, B_CNT_TMP, B_NUM };
+         B_SUBSTART, B_GROUPS, B_GSCAN, B_CNT_TMP, B_LARGE, B_NUM };
   Buf buf[B_NUM];
   hipError_t ensure(int which, size_t bytes) {
     Buf &b = buf[which];
@@ -629,16 +638,19 @@ static int count_device(mgc_session *s) {
     }
     const uint64_t ng_total = gbase[nb];
     HIP_TRY(s, s->ensure(mgc_session::B_SUBSTART, sizeof(uint64_t) * (sbase[nb] + 1)));
-    HIP_TRY(s, s->ensure(mgc_session::B_GROUPS, sizeof(uint64_t) * (ng_total + 2 + MGC_NUM_FILES)));
+    HIP_TRY(s, s->ensure(mgc_session::B_GROUPS, sizeof(uint64_t) * (ng_total + 2 + 2 * MGC_NUM_FILES)));
+    HIP_TRY(s, s->ensure(mgc_session::B_LARGE, sizeof(uint32_t) * (ng_total + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_GSCAN, mgc::finish_scan_scratch_bytes(ng_total + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_CNT_TMP, sizeof(uint32_t) * N));
     HIP_TRY(s, s->ensure(mgc_session::B_RLE_WS, mgc::rle_workspace_bytes(max_bucket)));
     uint64_t *d_substart = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_SUBSTART].p);
     uint64_t *d_group    = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_GROUPS].p);   // [ng_total+1], then max_sub[64]
-    uint64_t *d_maxsub   = d_group + ng_total + 1;
+    uint64_t *d_maxsub   = d_group + ng_total + 1;                  // [64] largest sub-bucket, then [64] number of large ones
+    uint64_t *d_nlarge   = d_maxsub + MGC_NUM_FILES;
+    uint32_t *d_large    = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_LARGE].p);
     uint32_t *d_cnt_tmp  = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_CNT_TMP].p);
     void     *rle_ws     = s->buf[mgc_session::B_RLE_WS].p;
-    HIP_TRY(s, hipMemsetAsync(d_maxsub, 0, sizeof(uint64_t) * MGC_NUM_FILES, st));
+    HIP_TRY(s, hipMemsetAsync(d_maxsub, 0, sizeof(uint64_t) * 2 * MGC_NUM_FILES, st));
 
     // ---- A. global LSB passes on the top bits only ----
     tm.begin(MGC_STAGE_SORT);
@@ -646,6 +658,9 @@ static int count_device(mgc_session *s) {
       if (h_counts[b] == 0 || top_bits[b] == 0) continue;
       mgc::SortPlan fp;
       mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fp);
+      // the finish only needs the file grouped by its top bits (MGC_GROUP=0: full stable passes)
+      static const bool use_group = !(getenv("MGC_GROUP") && getenv("MGC_GROUP")[0] == '0');
+      if (use_group && fp.mode == 0) fp.mode = 3;
       void *src = X + kbytes * h_starts[b];
       int in_alt = 0;
       hipEvent_t *pe = s->profiling ? &pass_ev[(size_t)b * ev_per_file] : nullptr;
@@ -661,9 +676,10 @@ static int count_device(mgc_session *s) {
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0) continue;
       HIP_TRY(s, mgc::launch_subbucket_bounds(X + kbytes * h_starts[b], h_counts[b], kw, rem_bits - top_bits[b], top_bits[b],
-                                              d_substart + sbase[b], d_maxsub + b, st));
+                                              d_substart + sbase[b], d_maxsub + b, d_large + gbase[b], d_nlarge + b, st));
     }
-    uint64_t h_maxsub[MGC_NUM_FILES];
+    uint64_t h_maxsub[2 * MGC_NUM_FILES];
+    const uint64_t *h_nlarge = h_maxsub + MGC_NUM_FILES;
     HIP_TRY(s, hipMemcpyAsync(h_maxsub, d_maxsub, sizeof(h_maxsub), hipMemcpyDeviceToHost, st));
     HIP_TRY(s, hipStreamSynchronize(st));
 
@@ -676,8 +692,8 @@ static int count_device(mgc_session *s) {
       const uint32_t low = rem_bits - top_bits[b];
       void *seg = X + kbytes * h_starts[b];
       if (h_maxsub[b] <= cap) {
-        HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_maxsub[b],
-                                           d_cnt_tmp + h_starts[b], d_group + gbase[b], st));
+        HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_nlarge[b],
+                                           d_large + gbase[b], d_cnt_tmp + h_starts[b], d_group + gbase[b], st));
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
         fallback[b] = true;

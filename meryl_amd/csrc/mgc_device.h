@@ -31,7 +31,8 @@ struct SortPlan {
   uint32_t block;           // threads per workgroup
   uint32_t kpt;             // keys per thread
   uint32_t tile;            // block*kpt
-  uint32_t mode;            // 0 = onesweep (decoupled look-back), 1 = classic (tile histogram + scan)
+  uint32_t mode;            // 0 = onesweep (decoupled look-back), 1 = classic (tile histogram + scan),
+                            // 2 = hybrid (first pass classic off the shared histogram read, later passes look-back)
   uint32_t match;           // 0 = ballot match, 1 = LDS mask match (ranking inside a wave)
   uint32_t lookback;        // 1 = walk before the LDS exchange, 2 = window after it
   uint32_t flags;           // bit1: non-temporal key loads (experiments)
@@ -69,9 +70,12 @@ hipError_t launch_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words,
 uint64_t   finish_capacity_for(uint32_t key_words);     // largest sub-bucket the LDS kernels accept
 uint64_t   finish_target_for(uint32_t key_words);       // average sub-bucket size to aim for
 hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t low, uint32_t top_bits,
-                                   uint64_t *d_starts /*[2^top+1]*/, uint64_t *d_max /*atomicMax target*/, hipStream_t st);
+                                   uint64_t *d_starts /*[2^top+1]*/, uint64_t *d_max /*atomicMax target*/,
+                                   uint32_t *d_large_list /*[2^top]: sub-buckets above the small-kernel capacity*/,
+                                   uint64_t *d_large_count /*zeroed by the caller*/, hipStream_t st);
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
-                              uint64_t max_sub, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct, hipStream_t st);
+                              uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
+                              hipStream_t st);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);
 hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,

@@ -906,6 +906,425 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
 #undef MGC_STAMP
 }
 
+// ---- pipelined look-back pass (plan.lookback == 5) ----------------------------
+// Same pass as radix_scatter_kernel<.., LB, MATCH=1>, restructured so HBM never idles behind the
+// per-tile work: workgroups are persistent, take the ticket of their NEXT tile at the top of an
+// iteration, and once the keys of the current tile live in LDS (after the exchange) the registers are
+// refilled with the next tile's keys while the look-back and the write-out run.  s_waitcnt vmcnt is
+// per wave and in order, so the waves that poll the status granules (tid < R/2, the first R/128
+// waves) fetch their share of the next tile only after their walk; all other waves fetch before it.
+// A ticket held one tile ahead keeps the no-deadlock argument: the lowest unfinished tile is always
+// some workgroup's current one.  Granules: two digits per 8 bytes, n < 2^30.
+template <typename K, int RB, int BLOCK, int KPT, bool DBG>
+__global__ __launch_bounds__(BLOCK, (RadixSmem<K, RB, BLOCK, KPT, 4>::MIN_WAVES_PER_SIMD))
+void radix_scatter_pipe_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, u32 shift, u32 dmask,
+                               const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
+                               u32 *__restrict__ error_flag, u64 num_tiles, u64 *__restrict__ dbg) {
+  using SM = RadixSmem<K, RB, BLOCK, KPT, 4>;
+  using KO = KeyOps<K>;
+  constexpr int R = SM::R, NW = SM::NW, TILE = SM::TILE, G = R / 2;
+  constexpr int WALK = 8;                               // predecessor granules in flight per walker thread
+  static_assert(BLOCK >= R && G % 64 == 0, "one thread per digit; whole waves walk");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  K   *s_keys  = reinterpret_cast<K *>(smem);
+  u32 *s_whist = reinterpret_cast<u32 *>(smem);                       // aliases s_keys (see barriers)
+  u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
+  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
+  u32 *s_cnt   = reinterpret_cast<u32 *>(smem + SM::OFF_CNT);
+  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
+  const u32 tid0 = threadIdx.x;
+  u32 tid = tid0, lane = tid0 & 63u, w = tid0 >> 6;
+
+  K keys[KPT];
+  auto fetch = [&](u64 t) __attribute__((always_inline)) {
+    if (t >= num_tiles) return;
+    const u64 tile_base = t * (u64)TILE;
+    const u64 wave_off  = tile_base + (u64)w * (64 * KPT) + lane;
+    const K  *p         = in + wave_off;
+    if (tile_base + TILE <= n) {                        // every tile but the last
+#pragma unroll
+      for (int j = 0; j < KPT; j++) keys[j] = p[j * 64];
+    } else {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) keys[j] = (wave_off + (u64)j * 64 < n) ? p[j * 64] : KO::pad();
+    }
+  };
+
+  if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
+  __syncthreads();
+  u64 tile = s_tmp[32];
+  fetch(tile);
+
+  u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define PK_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
+  while (tile < num_tiles) {
+    if (DBG) t0 = __builtin_readcyclecounter();
+    // the thread coordinates are laundered once per iteration: otherwise every LDS address of the
+    // unrolled body is hoisted out of the loop and the kernel spills
+    tid = tid0;
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63u; w = tid >> 6;
+    const u64 lt_mask = (1ull << lane) - 1ull, lane_bit = 1ull << lane;
+    const bool walker = tid < (u32)G;                   // whole waves: G is a multiple of 64
+    if (tid == 0) s_tmp[33] = atomicAdd(ticket, 1u);    // published by the barrier below
+    for (u32 i = tid; i < (u32)(NW * R * 3); i += BLOCK) s_whist[i] = 0;   // counters + match masks
+    __syncthreads();
+    const u64 next = s_tmp[33];
+    PK_STAMP(0);
+    const u64 tile_base = tile * (u64)TILE;
+    const u32 n_valid   = (tile_base + TILE <= n) ? (u32)TILE : (u32)(n - tile_base);
+
+    // ---- rank inside the wave through wave-private LDS match masks (see radix_scatter_kernel) ----
+    u32 ranks[KPT / 2];
+    {
+      lds_u32 *wh = (lds_u32 *)(smem) + w * R;
+      lds_u64 *mk = (lds_u64 *)(smem + (size_t)NW * R * 4) + w * R;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 d = KO::digit(keys[j], shift, dmask);
+        __hip_atomic_fetch_or(&mk[d], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const u64 peers = __hip_atomic_load(&mk[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const u32 base  = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const u32 lower = __popcll(peers & lt_mask);
+        if (lower == 0) {
+          __hip_atomic_store(&wh[d], base + (u32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          __hip_atomic_store(&mk[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        if (j & 1) ranks[j / 2] |= (base + lower) << 16;
+        else       ranks[j / 2]  = (base + lower);
+      }
+    }
+    __syncthreads();
+    PK_STAMP(1);
+
+    // ---- digit totals of the tile, wave-exclusive bases ----
+    u32 count = 0;
+    if (tid < (u32)R) {
+      u32 acc = 0;
+#pragma unroll
+      for (int ww = 0; ww < NW; ww++) {
+        const u32 t = s_whist[ww * R + tid];
+        s_whist[ww * R + tid] = acc;
+        acc += t;
+      }
+      count = acc;
+      s_cnt[tid] = (tid == dmask) ? count - ((u32)TILE - n_valid) : count;   // padding is not published
+    }
+    u32 tile_total;
+    const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tile_total);
+    if (tid < (u32)R) s_dbase[tid] = excl;
+    __syncthreads();
+
+    // ---- publish the aggregate, then move the keys to their place in the sorted tile ----
+    u64 *mine = status + tile * (u64)G + tid;
+    u32 c0 = 0, c1 = 0;
+    if (walker) {
+      c0 = s_cnt[2 * tid]; c1 = s_cnt[2 * tid + 1];
+      const u32 fl = (tile == 0) ? 2u : 1u;
+      status_store(mine, st_pack(fl, c0, fl, c1));
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 d = KO::digit(keys[j], shift, dmask);
+      const u32 add = s_dbase[d] + s_whist[w * R + d];
+      ranks[j / 2] += (j & 1) ? (add << 16) : add;
+    }
+    __syncthreads();                          // s_whist is dead; its storage becomes s_keys
+#pragma unroll
+    for (int j = 0; j < KPT; j++) s_keys[(j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu)] = keys[j];
+    __syncthreads();                          // keys live in LDS only: the registers take the next tile
+    PK_STAMP(2);
+
+    if (!walker) {
+      fetch(next);
+    } else {
+      // flat walk over the predecessors' granules, WALK in flight per round (a two-level scheme with
+      // group sums was tried: it needs a third dependent round trip and measured 25% slower)
+      u32 p0 = 0, p1 = 0;
+      if (tile != 0) {
+        bool done = false;
+        u64  t = tile - 1;
+        u32  spins = 0;
+        while (!done) {
+          u64 gv[WALK];
+#pragma unroll
+          for (int i = 0; i < WALK; i++)
+            gv[i] = (t >= (u64)i) ? status_load(status + (t - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
+          u32 used = 0;
+          bool open = true;
+#pragma unroll
+          for (int i = 0; i < WALK; i++) {
+            const u32 lo = (u32)gv[i], hi = (u32)(gv[i] >> 32);
+            const u32 f = lo >> 30;                     // both halves of a granule carry the same flag
+            open = open && !done && (f != 0);
+            if (open) {
+              p0 += lo & 0x3FFFFFFFu; p1 += hi & 0x3FFFFFFFu;
+              if (f == 2) done = true;
+              used++;
+            }
+          }
+          t -= (used <= t) ? used : t;
+          if (used == 0) {
+            if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
+      }
+      s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
+      s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
+      fetch(next);
+    }
+    __syncthreads();
+    PK_STAMP(3);
+
+    // ---- contiguous runs leave coalesced ----
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 i = (u32)j * BLOCK + tid;
+      if (i < n_valid) {
+        const K   key = s_keys[i];
+        const u32 d   = KO::digit(key, shift, dmask);
+        out[s_gbase[d] + (u64)i] = key;
+      }
+    }
+    PK_STAMP(4);
+    __syncthreads();                          // s_keys / s_gbase are rewritten by the next iteration
+    PK_STAMP(5);
+    tile = next;
+    if (DBG) ph[7]++;
+  }
+  if (DBG && tid0 == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
+#undef PK_STAMP
+}
+
+// ---- grouping pass (plan.mode == 3; the sub-bucket finish path) -----------------------
+// The finish path does not need a sorted file, only its k-mers GROUPED by their top bits: sub-bucket
+// members may come in any order (the LDS finish counts them anyway).  A grouping pass therefore ranks
+// a tile with one returning LDS atomic per key -- no wave-private counters, no match masks, a 2 KiB
+// histogram to clear instead of 96 KiB -- and only has to respect the TILE order for the bases.
+// With two digits (d_hi:d_lo, LSD): pass 1 groups by d_lo with plain tiles; pass 2 must keep the d_lo
+// order inside a d_hi group, which holds if no tile of pass 2 mixes two d_lo values: its tiles are cut
+// at the d_lo region boundaries of pass 1's output (region table below), every region's last tile
+// being partial.  Persistent workgroups, ticket one tile ahead, next tile's keys fetched behind the
+// look-back and the write-out, as in radix_scatter_pipe_kernel.
+template <typename K, int RB, int BLOCK, int KPT>
+struct GroupSmem {
+  static constexpr int R = 1 << RB, NW = BLOCK / 64, TILE = BLOCK * KPT;
+  static constexpr size_t OFF_HIST  = (size_t)TILE * sizeof(K);       // u32[R]
+  static constexpr size_t OFF_GBASE = OFF_HIST + (size_t)R * 4;       // u64[R]
+  static constexpr size_t OFF_DBASE = OFF_GBASE + (size_t)R * 8;      // u32[R]
+  static constexpr size_t OFF_CNT   = OFF_DBASE + (size_t)R * 4;      // u32[R]
+  static constexpr size_t OFF_TMP   = OFF_CNT + (size_t)R * 4;        // u32[64]
+  static constexpr size_t OFF_INFO  = OFF_TMP + 64 * 4;               // u64[4]: key base / valid count of current+next tile
+  static constexpr size_t BYTES     = OFF_INFO + 4 * 8;
+  static constexpr int    WG_PER_CU = (2 * BYTES <= 160 * 1024) ? 2 : 1;
+  static constexpr int    MIN_WAVES_PER_SIMD = (WG_PER_CU * BLOCK) / 256;
+};
+
+// region table of a second grouping pass: regions = digit groups of the first pass (gbase_prev = its
+// exclusive digit bases, RS_MAX_RADIX entries, unused digits sit at n)
+__global__ __launch_bounds__(RS_MAX_RADIX)
+void group_regions_kernel(const u64 *__restrict__ gbase_prev, u64 n, u32 tile, u64 *__restrict__ region_start,
+                          u32 *__restrict__ region_tiles) {
+  __shared__ u32 s_tmp[RS_MAX_RADIX / 64 + 1];
+  const u32 r = threadIdx.x;
+  const u64 a = gbase_prev[r], b = (r + 1 < RS_MAX_RADIX) ? gbase_prev[r + 1] : n;
+  const u32 nt = (u32)((b - a + tile - 1) / tile);
+  u32 total;
+  const u32 e = block_excl_scan<RS_MAX_RADIX, u32>(nt, s_tmp, &total);
+  region_start[r] = a;
+  region_tiles[r] = e;
+  if (r == 0) { region_start[RS_MAX_RADIX] = n; region_tiles[RS_MAX_RADIX] = total; }
+}
+
+template <typename K, int RB, int BLOCK, int KPT, bool DBG>
+__global__ __launch_bounds__(BLOCK, (GroupSmem<K, RB, BLOCK, KPT>::MIN_WAVES_PER_SIMD))
+void radix_group_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, u32 shift, u32 dmask,
+                        const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
+                        u32 *__restrict__ error_flag, u64 num_tiles_plain,
+                        const u64 *__restrict__ region_start,   // [RS_MAX_RADIX + 1] or nullptr (plain tiles)
+                        const u32 *__restrict__ region_tiles,   // [RS_MAX_RADIX + 1] exclusive; last = total tiles
+                        u64 *__restrict__ dbg) {
+  using SM = GroupSmem<K, RB, BLOCK, KPT>;
+  using KO = KeyOps<K>;
+  constexpr int R = SM::R, TILE = SM::TILE, G = R / 2;
+  constexpr int WALK = 8;
+  static_assert(BLOCK >= RS_MAX_RADIX && G % 64 == 0 && TILE <= 65536, "one thread per region/digit; 16-bit ranks");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  K   *s_keys  = reinterpret_cast<K *>(smem);
+  u32 *s_hist  = reinterpret_cast<u32 *>(smem + SM::OFF_HIST);
+  u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
+  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
+  u32 *s_cnt   = reinterpret_cast<u32 *>(smem + SM::OFF_CNT);
+  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
+  u64 *s_info  = reinterpret_cast<u64 *>(smem + SM::OFF_INFO);
+  const u32 tid0 = threadIdx.x;
+  u32 tid = tid0, lane = tid0 & 63u, w = tid0 >> 6;
+
+  // this thread's slice of the region table stays in registers
+  const bool regions = (region_tiles != nullptr);
+  u64 rt_lo = 0, rt_hi = 0, rs = 0, re = 0, total_tiles = num_tiles_plain;
+  if (regions) {
+    if (tid0 < (u32)RS_MAX_RADIX) {
+      rt_lo = region_tiles[tid0]; rt_hi = region_tiles[tid0 + 1];
+      rs = region_start[tid0];    re = region_start[tid0 + 1];
+    }
+    total_tiles = region_tiles[RS_MAX_RADIX];
+  }
+  auto announce = [&](u64 t, int slot) __attribute__((always_inline)) {   // key range of tile t -> s_info[2*slot..]
+    if (t >= total_tiles) return;
+    if (regions) {
+      if (rt_lo <= t && t < rt_hi) {                      // exactly one thread (empty regions own no tile)
+        const u64 kb = rs + (t - rt_lo) * (u64)TILE;
+        s_info[2 * slot] = kb;
+        s_info[2 * slot + 1] = (re - kb < (u64)TILE) ? re - kb : (u64)TILE;
+      }
+    } else if (tid0 == 0) {
+      const u64 kb = t * (u64)TILE;
+      s_info[2 * slot] = kb;
+      s_info[2 * slot + 1] = (n - kb < (u64)TILE) ? n - kb : (u64)TILE;
+    }
+  };
+
+  K keys[KPT];
+  auto fetch = [&](u64 kb, u32 nv) __attribute__((always_inline)) {
+    const u32 li = w * (64 * KPT) + lane;                 // wave-striped: 512 contiguous bytes per wave instruction
+    const K  *p  = in + kb + li;
+    if (nv == (u32)TILE) {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) keys[j] = p[j * 64];
+    } else {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) if (li + (u32)j * 64 < nv) keys[j] = p[j * 64];
+    }
+  };
+
+  if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
+  __syncthreads();
+  u64 tile = s_tmp[32];
+  announce(tile, 0);
+  __syncthreads();
+  u64 kb = 0; u32 nv = 0;
+  if (tile < total_tiles) { kb = s_info[0]; nv = (u32)s_info[1]; fetch(kb, nv); }
+
+  u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define PK_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
+  while (tile < total_tiles) {
+    if (DBG) t0 = __builtin_readcyclecounter();
+    tid = tid0;
+    asm volatile("" : "+v"(tid));                         // keeps the unrolled body's LDS addresses out of the loop preheader
+    lane = tid & 63u; w = tid >> 6;
+    const bool walker = tid < (u32)G;
+    if (tid == 0) s_tmp[33] = atomicAdd(ticket, 1u);
+    if (tid < (u32)R) s_hist[tid] = 0;
+    __syncthreads();                                      // (A)
+    const u64 next = s_tmp[33];
+    announce(next, 1);                                    // read after (C)
+    PK_STAMP(0);
+
+    // ---- rank: position among the tile's keys of the same digit, in arrival order ----
+    const u32 li = w * (64 * KPT) + lane;
+    u32 ranks[KPT / 2];
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      u32 r = 0;
+      if (li + (u32)j * 64 < nv) r = atomicAdd(&s_hist[KO::digit(keys[j], shift, dmask)], 1u);
+      if (j & 1) ranks[j / 2] |= r << 16;
+      else       ranks[j / 2]  = r;
+    }
+    __syncthreads();                                      // (B)
+    PK_STAMP(1);
+
+    const u32 count = (tid < (u32)R) ? s_hist[tid] : 0u;
+    u32 tile_total;
+    const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tile_total);
+    if (tid < (u32)R) { s_cnt[tid] = count; s_dbase[tid] = excl; }
+    __syncthreads();                                      // (C)
+
+    u64 *mine = status + tile * (u64)G + tid;
+    u32 c0 = 0, c1 = 0;
+    if (walker) {
+      c0 = s_cnt[2 * tid]; c1 = s_cnt[2 * tid + 1];
+      const u32 fl = (tile == 0) ? 2u : 1u;
+      status_store(mine, st_pack(fl, c0, fl, c1));
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      if (li + (u32)j * 64 < nv) {
+        const u32 d = KO::digit(keys[j], shift, dmask);
+        const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
+        s_keys[s_dbase[d] + r] = keys[j];
+      }
+    }
+    u64 nkb = 0; u32 nnv = 0;
+    if (next < total_tiles) { nkb = s_info[2]; nnv = (u32)s_info[3]; }
+    __syncthreads();                                      // (D) keys live in LDS only
+    PK_STAMP(2);
+
+    if (!walker) {
+      if (next < total_tiles) fetch(nkb, nnv);
+    } else {
+      u32 p0 = 0, p1 = 0;
+      if (tile != 0) {
+        bool done = false;
+        u64  t = tile - 1;
+        u32  spins = 0;
+        while (!done) {
+          u64 gv[WALK];
+#pragma unroll
+          for (int i = 0; i < WALK; i++)
+            gv[i] = (t >= (u64)i) ? status_load(status + (t - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
+          u32 used = 0;
+          bool open = true;
+#pragma unroll
+          for (int i = 0; i < WALK; i++) {
+            const u32 lo = (u32)gv[i], hi = (u32)(gv[i] >> 32);
+            const u32 f = lo >> 30;
+            open = open && !done && (f != 0);
+            if (open) {
+              p0 += lo & 0x3FFFFFFFu; p1 += hi & 0x3FFFFFFFu;
+              if (f == 2) done = true;
+              used++;
+            }
+          }
+          t -= (used <= t) ? used : t;
+          if (used == 0) {
+            if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
+      }
+      s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
+      s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
+      if (next < total_tiles) fetch(nkb, nnv);
+    }
+    __syncthreads();                                      // (E)
+    PK_STAMP(3);
+
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 i = (u32)j * BLOCK + tid;
+      if (i < nv) {
+        const K   key = s_keys[i];
+        const u32 d   = KO::digit(key, shift, dmask);
+        out[s_gbase[d] + (u64)i] = key;
+      }
+    }
+    PK_STAMP(4);
+    __syncthreads();                                      // (F)
+    PK_STAMP(5);
+    tile = next; kb = nkb; nv = nnv;
+    if (DBG) ph[7]++;
+  }
+  if (DBG && tid0 == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
+#undef PK_STAMP
+  (void)kb;
+}
+
 // ---- classic mode: per-tile digit histogram + row scan ----------------------
 template <typename K, int RB, int BLOCK, int KPT>
 __global__ __launch_bounds__(BLOCK)
@@ -924,6 +1343,46 @@ void radix_tile_hist_kernel(const K *__restrict__ in, u64 n, u32 shift, u32 dmas
   }
   __syncthreads();
   for (u32 i = tid; i < (u32)R; i += BLOCK) tile_hist[(u64)i * num_tiles + blockIdx.x] = s_h[i];
+}
+
+// Hybrid mode: the per-tile histogram of the FIRST pass and the global digit histograms of the later
+// passes in one read of the keys (persistent workgroups; the later-pass counters stay in LDS until the end).
+template <typename K, int RB, int BLOCK, int KPT>
+__global__ __launch_bounds__(BLOCK)
+void radix_tile_hist_fused_kernel(const K *__restrict__ in, u64 n, u32 shift, u32 dmask, u32 *__restrict__ tile_hist,
+                                  u64 num_tiles, PassList later, u64 *__restrict__ ghist_later) {
+  constexpr int R = 1 << RB, TILE = BLOCK * KPT;
+  __shared__ u32 s_h[R];
+  __shared__ u32 s_g[(RS_MAX_PASSES - 1) * RS_MAX_RADIX];
+  const u32 tid = threadIdx.x, nl = later.n;
+  for (u32 i = tid; i < nl * RS_MAX_RADIX; i += BLOCK) s_g[i] = 0;
+  for (u64 tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    for (u32 i = tid; i < (u32)R; i += BLOCK) s_h[i] = 0;
+    __syncthreads();
+    const u64 tile_base = tile * TILE;
+    K key[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u64 idx = tile_base + (u64)j * BLOCK + tid;
+      if (idx < n) key[j] = in[idx];
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u64 idx = tile_base + (u64)j * BLOCK + tid;
+      if (idx < n) {
+        atomicAdd(&s_h[KeyOps<K>::digit(key[j], shift, dmask)], 1u);
+        for (u32 p = 0; p < nl; p++)
+          atomicAdd(&s_g[p * RS_MAX_RADIX + KeyOps<K>::digit(key[j], later.shift[p], later.mask[p])], 1u);
+      }
+    }
+    __syncthreads();
+    for (u32 i = tid; i < (u32)R; i += BLOCK) tile_hist[(u64)i * num_tiles + tile] = s_h[i];
+  }
+  __syncthreads();
+  for (u32 i = tid; i < nl * RS_MAX_RADIX; i += BLOCK) {
+    const u32 v = s_g[i];
+    if (v) atomicAdd(&ghist_later[i], (u64)v);
+  }
 }
 
 // One workgroup per digit: exclusive scan of its row of tile counts (-> u64),
@@ -948,9 +1407,15 @@ void radix_row_scan_kernel(const u32 *__restrict__ tile_hist, u64 *__restrict__ 
 // Adds the exclusive digit base (scan of row totals) to every row.
 __global__ __launch_bounds__(256)
 void radix_row_add_kernel(u64 *__restrict__ tile_offs, const u64 *__restrict__ row_total, u32 R, u64 num_tiles) {
+  __shared__ u64 s_part[4];
   const u32 d = blockIdx.y;
-  u64 base = 0;
-  for (u32 i = 0; i < d; i++) base += row_total[i];
+  u64 part = 0;
+  for (u32 i = threadIdx.x; i < d; i += 256) part += row_total[i];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_down(part, o);
+  if (lane_id() == 0) s_part[wave_id()] = part;
+  __syncthreads();
+  const u64 base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
   const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
   if (t < num_tiles) tile_offs[(u64)d * num_tiles + t] += base;
   (void)R;
@@ -979,9 +1444,9 @@ void make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan) {
   plan->block      = (uint32_t)block;
   plan->kpt        = (uint32_t)kpt;
   plan->tile       = plan->block * plan->kpt;
-  plan->mode       = mode ? 1u : 0u;
+  plan->mode       = (mode >= 1 && mode <= 3) ? (uint32_t)mode : 0u;   // 0 look-back, 1 classic, 2 hybrid, 3 grouping (finish path only)
   plan->match      = env_int("MGC_SORT_MATCH", 1) ? 1u : 0u;
-  { const int lb = env_int("MGC_SORT_LB", 2); plan->lookback = (lb == 2 || lb == 4) ? (uint32_t)lb : 1u; }
+  { const int lb = env_int("MGC_SORT_LB", 2); plan->lookback = (lb == 2 || lb == 4 || lb == 5) ? (uint32_t)lb : 1u; }
   plan->flags      = (uint32_t)env_int("MGC_SORT_FLAGS", 0);
   const uint32_t nbits = (end_bit > begin_bit) ? end_bit - begin_bit : 0;
   uint32_t passes = (nbits + rb - 1) / rb;
@@ -1001,13 +1466,26 @@ static inline uint64_t max_tiles_for(uint64_t n) { return (n + 4095) / 4096 + 1;
 size_t sort_workspace_bytes(uint64_t n) {
   // header + the larger of {look-back granules (one pass at a time), classic tile_hist + tile_offs}
   const uint64_t t = max_tiles_for(n);
-  return sizeof(SortHeader) + 1024 + (size_t)t * RS_MAX_RADIX * (sizeof(uint32_t) + sizeof(uint64_t));
+  // + grouping mode: up to RS_MAX_RADIX + 1 extra (partial) tiles of granules and the region table
+  return sizeof(SortHeader) + 1024 + (size_t)t * RS_MAX_RADIX * (sizeof(uint32_t) + sizeof(uint64_t)) +
+         (size_t)(RS_MAX_RADIX + 2) * (RS_MAX_RADIX / 2) * sizeof(uint64_t) + (size_t)(RS_MAX_RADIX + 2) * 16;
+}
+
+static int device_cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
 }
 
 template <typename K, int RB, int BLOCK, int KPT, int MATCH, int LBK>
 static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws,
                              uint32_t *d_error, int *result_in_alt, hipStream_t st, hipEvent_t *pass_events) {
-  using SM  = RadixSmem<K, RB, BLOCK, KPT, LBK>;
+  constexpr int LBO = (LBK == 5) ? 2 : LBK;             // look-back flavour of the non-pipelined kernel
+  using SM  = RadixSmem<K, RB, BLOCK, KPT, LBO>;
   using SM0 = RadixSmem<K, RB, BLOCK, KPT, 0>;
   constexpr int R = 1 << RB, TILE = BLOCK * KPT;
   SortHeader *hdr = reinterpret_cast<SortHeader *>(d_ws);
@@ -1016,8 +1494,15 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
 
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<K, RB, BLOCK, KPT, LBK, MATCH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<K, RB, BLOCK, KPT, LBO, MATCH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::BYTES);
+    if constexpr (LBK == 5)
+    {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)RadixSmem<K, RB, BLOCK, KPT, 4>::BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)RadixSmem<K, RB, BLOCK, KPT, 4>::BYTES);
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<K, RB, BLOCK, KPT, 0, MATCH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM0::BYTES);
     attr_done = true;
@@ -1029,7 +1514,7 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
 
   if (lookback) {
     u64 *status = reinterpret_cast<u64 *>(body);
-    const size_t status_bytes = (size_t)num_tiles * (LBK == 3 ? R : R / 2) * sizeof(u64);
+    const size_t status_bytes = (size_t)num_tiles * (LBO == 3 ? R : R / 2) * sizeof(u64);
     MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
     PassList pl;
     pl.n = plan.num_passes;
@@ -1048,7 +1533,126 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
     for (uint32_t p = 0; p < plan.num_passes; p++) {
       MGC_CHECK(hipMemsetAsync(status, 0, status_bytes, st));
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
-      hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, LBK, MATCH>), dim3((uint32_t)num_tiles),
+      if constexpr (LBK == 5) {
+        using SMP = RadixSmem<K, RB, BLOCK, KPT, 4>;
+        const uint64_t resident = (uint64_t)device_cu_count() * SMP::WG_PER_CU;
+        const uint32_t pgrid = (uint32_t)(num_tiles < resident ? num_tiles : resident);
+        if (plan.dbg)
+          hipLaunchKernelGGL((radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, true>), dim3(pgrid), dim3(BLOCK), SMP::BYTES, st,
+                             (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                             &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
+        else
+          hipLaunchKernelGGL((radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, false>), dim3(pgrid), dim3(BLOCK), SMP::BYTES, st,
+                             (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                             &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, (u64 *)nullptr);
+      } else {
+        hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, LBO, MATCH>), dim3((uint32_t)num_tiles),
+                           dim3(BLOCK), SM::BYTES, st, (const K *)src, dst, (u64)n, plan.pass_shift[p],
+                           (1u << plan.pass_bits[p]) - 1u, &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, plan.flags,
+                           (const u64 *)nullptr, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
+      }
+      MGC_CHECK(hipGetLastError());
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
+      K *t = src; src = dst; dst = t; in_alt ^= 1;
+    }
+  } else if (plan.mode == 3) {
+    // ---- grouping passes (finish path): see radix_group_kernel ----
+    using GS = GroupSmem<K, RB, BLOCK, KPT>;
+    static bool gattr_done = false;
+    if (!gattr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES);
+      gattr_done = true;
+    }
+    const uint64_t max_tiles = num_tiles + RS_MAX_RADIX + 1;          // region-aligned tiles: one partial tile per region
+    u64 *status = reinterpret_cast<u64 *>(body);
+    const size_t status_bytes = (size_t)max_tiles * (R / 2) * sizeof(u64);
+    u64 *region_start = reinterpret_cast<u64 *>(body + ((status_bytes + 255) / 256) * 256);
+    u32 *region_tiles = reinterpret_cast<u32 *>(region_start + RS_MAX_RADIX + 1);
+    MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
+    PassList pl;
+    pl.n = plan.num_passes;
+    for (uint32_t p = 0; p < plan.num_passes; p++) {
+      pl.shift[p] = plan.pass_shift[p];
+      pl.mask[p]  = (1u << plan.pass_bits[p]) - 1u;
+    }
+    uint64_t hgrid = (n + 256 * 16 - 1) / (256 * 16);
+    if (hgrid > 2048) hgrid = 2048;
+    hipLaunchKernelGGL(radix_hist_kernel<K>, dim3((uint32_t)hgrid), dim3(256), 0, st, (const K *)src, (u64)n, pl,
+                       &hdr->ghist[0][0]);
+    MGC_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(plan.num_passes), dim3(RS_MAX_RADIX), 0, st,
+                       &hdr->ghist[0][0], &hdr->gbase[0][0]);
+    MGC_CHECK(hipGetLastError());
+    const uint64_t resident = (uint64_t)device_cu_count() * GS::WG_PER_CU;
+    for (uint32_t p = 0; p < plan.num_passes; p++) {
+      if (p == 1) {
+        hipLaunchKernelGGL(group_regions_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, &hdr->gbase[0][0], (u64)n, (u32)TILE,
+                           region_start, region_tiles);
+        MGC_CHECK(hipGetLastError());
+      }
+      MGC_CHECK(hipMemsetAsync(status, 0, status_bytes, st));
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
+      const uint64_t tiles_bound = (p == 0) ? num_tiles : max_tiles;
+      const uint32_t pgrid = (uint32_t)(tiles_bound < resident ? tiles_bound : resident);
+      const u64 *rs = (p == 0) ? nullptr : region_start;
+      const u32 *rt = (p == 0) ? nullptr : region_tiles;
+      if (plan.dbg)
+        hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, true>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
+                           (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt,
+                           reinterpret_cast<u64 *>(plan.dbg));
+      else
+        hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
+                           (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, (u64 *)nullptr);
+      MGC_CHECK(hipGetLastError());
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
+      K *t = src; src = dst; dst = t; in_alt ^= 1;
+    }
+  } else if (plan.mode == 2) {
+    // ---- hybrid: first pass classic (its tile histograms come out of the one histogram read that
+    //      also yields the later passes' global digit counts), later passes with look-back ----
+    u32 *tile_hist = reinterpret_cast<u32 *>(body);
+    u64 *tile_offs = reinterpret_cast<u64 *>(body + (((size_t)num_tiles * R * sizeof(u32) + 255) / 256) * 256);
+    u64 *status = reinterpret_cast<u64 *>(body);
+    const size_t status_bytes = (size_t)num_tiles * (LBO == 3 ? R : R / 2) * sizeof(u64);
+    MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
+    PassList later;
+    later.n = plan.num_passes - 1;
+    for (uint32_t p = 1; p < plan.num_passes; p++) {
+      later.shift[p - 1] = plan.pass_shift[p];
+      later.mask[p - 1]  = (1u << plan.pass_bits[p]) - 1u;
+    }
+    {
+      const uint32_t shift = plan.pass_shift[0], dmask = (1u << plan.pass_bits[0]) - 1u;
+      const uint32_t hgrid = (uint32_t)(num_tiles < 512 ? num_tiles : 512);
+      hipLaunchKernelGGL((radix_tile_hist_fused_kernel<K, RB, BLOCK, KPT>), dim3(hgrid), dim3(BLOCK), 0, st,
+                         (const K *)src, (u64)n, shift, dmask, tile_hist, (u64)num_tiles, later, &hdr->ghist[1][0]);
+      MGC_CHECK(hipGetLastError());
+      hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(plan.num_passes), dim3(RS_MAX_RADIX), 0, st,
+                         &hdr->ghist[0][0], &hdr->gbase[0][0]);
+      MGC_CHECK(hipGetLastError());
+      hipLaunchKernelGGL(radix_row_scan_kernel, dim3(R), dim3(1024), 0, st, tile_hist, tile_offs,
+                         &hdr->row_total[0], (u64)num_tiles);
+      MGC_CHECK(hipGetLastError());
+      hipLaunchKernelGGL(radix_row_add_kernel, dim3((uint32_t)((num_tiles + 255) / 256), R), dim3(256), 0, st,
+                         tile_offs, &hdr->row_total[0], (u32)R, (u64)num_tiles);
+      MGC_CHECK(hipGetLastError());
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[0], st));
+      hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, 0, MATCH>), dim3((uint32_t)num_tiles), dim3(BLOCK),
+                         SM0::BYTES, st, (const K *)src, dst, (u64)n, shift, dmask, (const u64 *)nullptr, (u64 *)nullptr,
+                         (u32 *)nullptr, d_error, plan.flags, tile_offs, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
+      MGC_CHECK(hipGetLastError());
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[1], st));
+      K *t = src; src = dst; dst = t; in_alt ^= 1;
+    }
+    for (uint32_t p = 1; p < plan.num_passes; p++) {
+      MGC_CHECK(hipMemsetAsync(status, 0, status_bytes, st));
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
+      hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, LBO, MATCH>), dim3((uint32_t)num_tiles),
                          dim3(BLOCK), SM::BYTES, st, (const K *)src, dst, (u64)n, plan.pass_shift[p],
                          (1u << plan.pass_bits[p]) - 1u, &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, plan.flags,
                          (const u64 *)nullptr, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
@@ -1090,6 +1694,11 @@ hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key
   *result_in_alt = 0;
   if (n == 0 || plan.num_passes == 0) return hipSuccess;
   if (ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
+  if (plan.mode == 3 && (plan.num_passes > 2 || n >= (1ull << 30))) {
+    SortPlan stable = plan;                 // grouping is defined for one or two digits and 30-bit granule values
+    stable.mode = 0;
+    return launch_radix_sort(d_keys, d_alt, n, key_words, stable, d_ws, ws_bytes, d_error, result_in_alt, st, pass_events);
+  }
 #define MGC_RUN(K_, RB_, BLOCK_, KPT_)                                                                       \
   do {                                                                                                       \
     if (n >= (1ull << 30))   /* packed look-back granules hold 30-bit values: use the wide ones */           \
@@ -1098,6 +1707,8 @@ hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key
       return run_passes<K_, RB_, BLOCK_, KPT_, 0, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
     if (plan.lookback == 2)                                                                                  \
       return run_passes<K_, RB_, BLOCK_, KPT_, 1, 2>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+    if (plan.lookback == 5)                                                                                  \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 5>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
     if (plan.lookback == 4)                                                                                  \
       return run_passes<K_, RB_, BLOCK_, KPT_, 1, 4>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
     return run_passes<K_, RB_, BLOCK_, KPT_, 1, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);   \
@@ -1459,9 +2070,12 @@ __global__ void subbucket_bounds_kernel(const K *__restrict__ keys, u64 n, u32 l
 }
 
 // largest sub-bucket of a file -> *max_out (atomicMax), so the host can pick the kernel capacity
-__global__ void subbucket_max_kernel(const u64 *__restrict__ starts, u64 ng, u64 *__restrict__ max_out) {
+// and the list of the sub-buckets above `threshold` (the ones the large-capacity launch takes)
+__global__ void subbucket_max_kernel(const u64 *__restrict__ starts, u64 ng, u64 *__restrict__ max_out, u64 threshold,
+                                     u32 *__restrict__ list, u64 *__restrict__ list_count) {
   const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 sz = (v < ng) ? (starts[v + 1] - starts[v]) : 0ull;
+  if (sz > threshold) list[atomicAdd(list_count, 1ull)] = (u32)v;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { const u64 o = __shfl_down(sz, d); sz = (o > sz) ? o : sz; }
   if (lane_id() == 0 && sz) atomicMax(max_out, sz);
@@ -1485,7 +2099,8 @@ void lds_sort_count_kernel(K *__restrict__ keys,                      // the fil
                            const u64 *__restrict__ starts,            // [ng+1] sub-bucket offsets inside the segment
                            u32 low_bits, u64 min_size, u64 max_size,   // this launch handles sub-buckets with min < n <= max
                            u32 *__restrict__ cnt_tmp,                 // counts, indexed like `keys`
-                           u64 *__restrict__ group_distinct) {        // [ng]
+                           u64 *__restrict__ group_distinct,          // [ng]
+                           const u32 *__restrict__ list) {            // optional: the sub-buckets to take (grid = their number)
   using SM = FinishSmem<K, BLOCK, KPT>;
   using KO = KeyOps<K>;
   constexpr int R = SM::R, NW = SM::NW, CAP = SM::CAP;
@@ -1499,7 +2114,7 @@ void lds_sort_count_kernel(K *__restrict__ keys,                      // the fil
   unsigned short *s_hp   = reinterpret_cast<unsigned short *>(smem + SM::OFF_HP);
 
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
-  const u64 g = blockIdx.x;
+  const u64 g = list ? (u64)list[blockIdx.x] : (u64)blockIdx.x;
   const u64 a = starts[g];
   const u64 n64 = starts[g + 1] - a;
   if (n64 <= min_size || n64 > max_size) {             // another launch's (or nobody's) sub-bucket
@@ -1769,8 +2384,15 @@ __global__ void store_u64_kernel(u64 *__restrict__ dst, const u64 *__restrict__ 
 constexpr u64 FIN_CAP_SMALL = 256 * 16, FIN_CAP_LARGE = 1024 * 8;   // LDS: 46 KiB and 91 KiB per workgroup
 constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count kernel: 2048 slots, 28 KiB of LDS, 5 workgroups per CU
 
+static bool finish_uses_hash(uint32_t key_words, uint32_t low_bits) {
+  static const bool use_hash = !(getenv("MGC_FINISH_HASH") && getenv("MGC_FINISH_HASH")[0] == '0');
+  return key_words == 1 && use_hash && low_bits < 32;
+}
+// capacity of the first (small) launch of launch_finish_file; larger sub-buckets go on the list
+static uint64_t finish_small_capacity(uint32_t key_words, uint32_t low_bits);
+
 hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t low, uint32_t top_bits,
-                                   uint64_t *d_starts, uint64_t *d_max, hipStream_t st) {
+                                   uint64_t *d_starts, uint64_t *d_max, uint32_t *d_list, uint64_t *d_list_count, hipStream_t st) {
   const uint64_t ng = (uint64_t)1 << top_bits;
   const uint32_t tmask = (uint32_t)(ng - 1);
   const dim3 grid((uint32_t)((ng + 1 + 255) / 256));
@@ -1782,13 +2404,16 @@ hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_
                        (u64)n, low, tmask, (u64)ng, reinterpret_cast<u64 *>(d_starts));
   MGC_CHECK(hipGetLastError());
   hipLaunchKernelGGL(subbucket_max_kernel, dim3((uint32_t)((ng + 255) / 256)), dim3(256), 0, st,
-                     reinterpret_cast<const u64 *>(d_starts), (u64)ng, reinterpret_cast<u64 *>(d_max));
+                     reinterpret_cast<const u64 *>(d_starts), (u64)ng, reinterpret_cast<u64 *>(d_max),
+                     (u64)finish_small_capacity(key_words, low), d_list, reinterpret_cast<u64 *>(d_list_count));
   return hipGetLastError();
 }
 
 template <typename K, int BLOCK, int KPT>
 static hipError_t finish_launch(void *d_keys, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits, uint64_t min_size,
-                                uint64_t max_size, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct, hipStream_t st) {
+                                uint64_t max_size, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct, hipStream_t st,
+                                const uint32_t *d_list = nullptr) {
+  if (ng == 0) return hipSuccess;
   using SM = FinishSmem<K, BLOCK, KPT>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -1798,7 +2423,7 @@ static hipError_t finish_launch(void *d_keys, const uint64_t *d_starts, uint64_t
   }
   hipLaunchKernelGGL((lds_sort_count_kernel<K, BLOCK, KPT>), dim3((uint32_t)ng), dim3(BLOCK), SM::BYTES, st,
                      reinterpret_cast<K *>(d_keys), reinterpret_cast<const u64 *>(d_starts), low_bits, (u64)min_size,
-                     (u64)max_size, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
+                     (u64)max_size, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_list);
   return hipGetLastError();
 }
 
@@ -1827,16 +2452,15 @@ static void hash_dbg_report(hipStream_t st, uint64_t ng) {
 }
 
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
-                              uint64_t max_sub, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct, hipStream_t st) {
+                              uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
+                              hipStream_t st) {
   if (key_words == 2) {
     // 16-byte keys: 256x8 (2048) and 1024x8 (8192) keep LDS at 32 / 128 KiB
     MGC_CHECK((finish_launch<K128, 256, 8>(d_keys, d_starts, ng, low_bits, 0, 2048, d_cnt_tmp, d_group_distinct, st)));
-    if (max_sub > 2048)
-      MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, ng, low_bits, 2048, 8192, d_cnt_tmp, d_group_distinct, st)));
+    MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, n_large, low_bits, 2048, 8192, d_cnt_tmp, d_group_distinct, st, d_large_list)));
     return hipSuccess;
   }
-  static const bool use_hash = !(getenv("MGC_FINISH_HASH") && getenv("MGC_FINISH_HASH")[0] == '0');
-  if (use_hash && low_bits < 32) {
+  if (finish_uses_hash(key_words, low_bits)) {
     // <= FIN_CAP_HASH keys: hash-count; larger sub-buckets: LDS radix passes in the 8192-key instantiation
     static const uint32_t hgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 10u;
     const uint32_t hgrid = ng < hgrid_max ? (uint32_t)ng : hgrid_max;
@@ -1850,16 +2474,19 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                          d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), nullptr);
     MGC_CHECK(hipGetLastError());
     hash_dbg_report(st, ng);
-    if (max_sub > FIN_CAP_HASH)
-      MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, ng, low_bits, FIN_CAP_HASH, FIN_CAP_LARGE, d_cnt_tmp,
-                                             d_group_distinct, st)));
+    MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, FIN_CAP_LARGE, d_cnt_tmp,
+                                           d_group_distinct, st, d_large_list)));
     return hipSuccess;
   }
   MGC_CHECK((finish_launch<u64, 256, 16>(d_keys, d_starts, ng, low_bits, 0, FIN_CAP_SMALL, d_cnt_tmp, d_group_distinct, st)));
-  if (max_sub > FIN_CAP_SMALL)
-    MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, ng, low_bits, FIN_CAP_SMALL, FIN_CAP_LARGE, d_cnt_tmp,
-                                           d_group_distinct, st)));
+  MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_SMALL, FIN_CAP_LARGE, d_cnt_tmp,
+                                         d_group_distinct, st, d_large_list)));
   return hipSuccess;
+}
+
+static uint64_t finish_small_capacity(uint32_t key_words, uint32_t low_bits) {
+  if (key_words == 2) return 2048;
+  return finish_uses_hash(key_words, low_bits) ? FIN_CAP_HASH : FIN_CAP_SMALL;
 }
 
 uint64_t finish_capacity_for(uint32_t key_words) { return key_words == 2 ? 8192 : FIN_CAP_LARGE; }

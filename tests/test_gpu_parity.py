@@ -111,7 +111,9 @@ def test_radix_sort_matches_numpy(ops, torch_cuda, n, bits, monkeypatch):
     for mode, rb, match, kpt, block, lb in [("0", "8", "1", "16", "512", "1"), ("0", "9", "1", "16", "512", "2"),
                                             ("1", "8", "1", "16", "512", "1"), ("1", "9", "0", "16", "512", "1"),
                                             ("0", "8", "0", "16", "512", "1"), ("0", "8", "1", "8", "512", "2"),
-                                            ("0", "8", "1", "16", "1024", "2"), ("0", "9", "1", "16", "1024", "1")]:
+                                            ("0", "8", "1", "16", "1024", "2"), ("0", "9", "1", "16", "1024", "1"),
+                                            ("2", "9", "1", "16", "1024", "2"), ("2", "8", "1", "16", "512", "2"),
+                                            ("0", "9", "1", "16", "1024", "5"), ("0", "8", "1", "8", "512", "5")]:
         monkeypatch.setenv("MGC_SORT_LB", lb)
         monkeypatch.setenv("MGC_SORT_MODE", mode)
         monkeypatch.setenv("MGC_RADIX_BITS", rb)
@@ -158,6 +160,27 @@ def test_run_length_long_runs_cross_tiles(ops, torch_cuda):
     assert np.array_equal(_as_u64(u), wu) and np.array_equal(c.cpu().numpy().view(np.uint32), wc.astype(np.uint32))
 
 
+@pytest.mark.parametrize("n", [1, 1000, 16384, 16385, 300_001, 3_000_017])
+@pytest.mark.parametrize("bits", [(20, 38), (30, 36), (5, 22), (10, 19)])
+@pytest.mark.parametrize("words", [1, 2])
+def test_grouping_passes_group_by_the_selected_bits(ops, torch_cuda, n, bits, words, monkeypatch):
+    # plan.mode 3 (the finish path's passes): not a sort -- the keys come out GROUPED by bits [lo, hi), groups
+    # ascending, members in any order; skewed digits make tiny and huge regions for the region-aligned second pass
+    rng = np.random.default_rng(n * 31 + bits[0] + words)
+    lo, hi = bits
+    a = rng.integers(0, 2**62, size=(n, words), dtype=np.int64).astype(np.uint64)
+    skew = rng.random(n) < 0.4
+    a[skew, 0] &= np.uint64(~(((1 << (hi - lo)) - 1) << lo) & (2**64 - 1))     # 40% of the keys share digit 0:0
+    a[rng.random(n) < 0.2, 0] |= np.uint64(((1 << (hi - lo)) - 1) << lo)          # 20% the all-ones digit
+    monkeypatch.setenv("MGC_SORT_MODE", "3")
+    t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
+    out = ops.dev_radix_sort(t if words == 2 else t.reshape(-1), lo, hi).cpu().numpy().view(np.uint64).reshape(n, words)
+    dig = (out[:, 0] >> np.uint64(lo)) & np.uint64((1 << (hi - lo)) - 1)
+    assert np.all(dig[1:] >= dig[:-1]), (n, bits, words)
+    canon = lambda m: m[np.lexsort(m.T[::-1])]
+    assert np.array_equal(canon(out), canon(a))
+
+
 @pytest.mark.parametrize("n", [0, 1, 777, 8192, 8193, 200_003])
 @pytest.mark.parametrize("bits", [(0, 128), (0, 102), (60, 70), (64, 96), (3, 40)])
 def test_radix_sort_u128_matches_numpy(ops, torch_cuda, n, bits, monkeypatch):
@@ -169,11 +192,12 @@ def test_radix_sort_u128_matches_numpy(ops, torch_cuda, n, bits, monkeypatch):
     mask = ((1 << (hi - lo)) - 1) << lo
     order = sorted(range(n), key=lambda i: (vals[i] & mask, i))          # stable on the selected bits
     want = [vals[i] for i in order]
-    for rb, mode in (("8", "0"), ("9", "0"), ("8", "1")):
+    for rb, mode, lb in (("8", "0", "2"), ("9", "0", "2"), ("8", "1", "2"), ("9", "2", "2"), ("9", "0", "5")):
         monkeypatch.setenv("MGC_RADIX_BITS", rb)
         monkeypatch.setenv("MGC_SORT_MODE", mode)
+        monkeypatch.setenv("MGC_SORT_LB", lb)
         t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
-        assert _as_int(ops.dev_radix_sort(t, lo, hi)) == want, (n, bits, rb, mode)
+        assert _as_int(ops.dev_radix_sort(t, lo, hi)) == want, (n, bits, rb, mode, lb)
 
 
 def test_run_length_u128(ops, torch_cuda):
