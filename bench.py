@@ -64,6 +64,22 @@ def cpu_baseline(sample_reads, threads):
     }
 
 
+def pmc_traffic(reads):
+    """HBM bytes per launch of the dominant kernel from the committed PMC run of this same workload
+    (profiles/*_pmc_traffic.json, made by scripts/gpu_pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
+    rocprofv3 passes, calibrated on known-byte kernels of the same access width); None for any other workload --
+    counters cannot be collected from inside this process."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("reads_per_gpu") == reads and str(d.get("kernel", "")).startswith("radix_group_kernel"):
+            return d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,9 +210,9 @@ def main():
                 secs = prof_acc["pass_ms"] / 1e3
                 achieved = bytes_alg / secs / 1e9
                 line["roofline"] = {
-                    "kernel": "radix_scatter_kernel (one LSB radix pass)",
+                    "kernel": "radix_group_kernel (one 9-bit radix pass over a file's k-mers)",
                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(reads),
                     "launches": prof_acc["pass_launches"],
                     "avg_launch_ms": prof_acc["pass_ms"] / prof_acc["pass_launches"],
                     "algorithmic_bytes_per_launch": bytes_alg / prof_acc["pass_launches"],

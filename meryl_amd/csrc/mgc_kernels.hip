@@ -1146,11 +1146,11 @@ void radix_group_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, u3
                         u32 *__restrict__ error_flag, u64 num_tiles_plain,
                         const u64 *__restrict__ region_start,   // [RS_MAX_RADIX + 1] or nullptr (plain tiles)
                         const u32 *__restrict__ region_tiles,   // [RS_MAX_RADIX + 1] exclusive; last = total tiles
-                        u64 *__restrict__ dbg) {
+                        u32 /*flags*/, u64 *__restrict__ dbg) {
   using SM = GroupSmem<K, RB, BLOCK, KPT>;
   using KO = KeyOps<K>;
   constexpr int R = SM::R, TILE = SM::TILE, G = R / 2;
-  constexpr int WALK = 8;
+  constexpr int WALK = 16;
   static_assert(BLOCK >= RS_MAX_RADIX && G % 64 == 0 && TILE <= 65536, "one thread per region/digit; 16-bit ranks");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   K   *s_keys  = reinterpret_cast<K *>(smem);
@@ -1263,40 +1263,45 @@ void radix_group_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, u3
     __syncthreads();                                      // (D) keys live in LDS only
     PK_STAMP(2);
 
+    // Look-back.  Persistent workgroups run in step, so the ~256 tiles in flight reach this point together
+    // and the inclusive prefixes can only spread from the oldest tile on: a walker that covers WALK
+    // predecessors per round trip sees the frontier move ~2*WALK tiles per round trip.  (Measured: holding
+    // the key fetch back, or issuing the status loads ahead of it, does not shorten the walk.)
+    u32 p0 = 0, p1 = 0;
+    bool done = (tile == 0);
+    u64  wt = tile ? tile - 1 : 0;
+    u32  spins = 0;
+    u64  gv[WALK];
+    auto issue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < WALK; i++)
+        gv[i] = (wt >= (u64)i) ? status_load(status + (wt - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
+    };
+    auto consume = [&]() __attribute__((always_inline)) {
+      u32 used = 0;
+      bool open = true;
+#pragma unroll
+      for (int i = 0; i < WALK; i++) {
+        const u32 lo = (u32)gv[i], hi = (u32)(gv[i] >> 32);
+        const u32 f = lo >> 30;
+        open = open && !done && (f != 0);
+        if (open) {
+          p0 += lo & 0x3FFFFFFFu; p1 += hi & 0x3FFFFFFFu;
+          if (f == 2) done = true;
+          used++;
+        }
+      }
+      wt -= (used <= wt) ? used : wt;
+      if (used == 0) {
+        if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); done = true; }
+        else __builtin_amdgcn_s_sleep(1);
+      }
+    };
     if (!walker) {
       if (next < total_tiles) fetch(nkb, nnv);
     } else {
-      u32 p0 = 0, p1 = 0;
-      if (tile != 0) {
-        bool done = false;
-        u64  t = tile - 1;
-        u32  spins = 0;
-        while (!done) {
-          u64 gv[WALK];
-#pragma unroll
-          for (int i = 0; i < WALK; i++)
-            gv[i] = (t >= (u64)i) ? status_load(status + (t - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
-          u32 used = 0;
-          bool open = true;
-#pragma unroll
-          for (int i = 0; i < WALK; i++) {
-            const u32 lo = (u32)gv[i], hi = (u32)(gv[i] >> 32);
-            const u32 f = lo >> 30;
-            open = open && !done && (f != 0);
-            if (open) {
-              p0 += lo & 0x3FFFFFFFu; p1 += hi & 0x3FFFFFFFu;
-              if (f == 2) done = true;
-              used++;
-            }
-          }
-          t -= (used <= t) ? used : t;
-          if (used == 0) {
-            if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
-      }
+      while (!done) { issue(); consume(); }
+      if (tile != 0) status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
       s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
       s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
       if (next < total_tiles) fetch(nkb, nnv);
@@ -1602,12 +1607,12 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
       if (plan.dbg)
         hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, true>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
                            (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
-                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt,
+                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, plan.flags,
                            reinterpret_cast<u64 *>(plan.dbg));
       else
         hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
                            (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
-                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, (u64 *)nullptr);
+                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, plan.flags, (u64 *)nullptr);
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
       K *t = src; src = dst; dst = t; in_alt ^= 1;

@@ -1,0 +1,28 @@
+// Known-byte-count kernels with the library's access width (8 B per lane, 512 B per wave instruction) to calibrate
+// rocprofv3's FETCH_SIZE / WRITE_SIZE on gfx950 (MI355X_MICROARCH.md: both are uncalibrated for this width).
+//   calib_read8 : reads  N*8 bytes, writes ~nothing
+//   calib_copy8 : reads  N*8 bytes, writes N*8 bytes
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef unsigned long long u64;
+__global__ __launch_bounds__(256) void calib_read8(const u64 *in, u64 n, u64 *out) {
+  u64 acc = 0;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) acc ^= in[i];
+  if (acc == 0x1234567) out[0] = acc;
+}
+__global__ __launch_bounds__(256) void calib_copy8(const u64 *in, u64 n, u64 *out) {
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) out[i] = in[i];
+}
+int main() {
+  const u64 n = 1ull << 28;                      // 2 GiB per buffer: far beyond the 256 MiB Infinity Cache
+  u64 *a, *b;
+  hipMalloc(&a, n * 8); hipMalloc(&b, n * 8);
+  hipMemset(a, 1, n * 8); hipMemset(b, 0, n * 8);
+  for (int r = 0; r < 3; r++) {
+    calib_read8<<<4096, 256>>>(a, n, b);
+    calib_copy8<<<4096, 256>>>(a, n, b);
+  }
+  hipDeviceSynchronize();
+  printf("calib: %llu bytes per buffer\n", n * 8);
+  return 0;
+}
