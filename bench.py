@@ -130,7 +130,8 @@ def main():
 
     # ---- synthetic input, generated in HBM ----
     reads = args.reads
-    bases = count.dev_synth_reads(SEED, GENOME_LEN, rank * reads, reads, READ_LEN, 5000, 100)
+    genome_len = GENOME_LEN * world              # weak scaling: every GPU brings its own 30x share of a genome that grows with N
+    bases = count.dev_synth_reads(SEED, genome_len, rank * reads, reads, READ_LEN, 5000, 100)
     torch.cuda.synchronize()
     n_bases = bases.numel()
 
@@ -194,7 +195,7 @@ def main():
             "config": {
                 "workload": "meryl count k=21 on synthetic short reads: %d x %d bp reads per GPU (%.2f Gbp per GPU, "
                             "30x of a %d bp genome, 0.5%% substitutions, 0.01%% N), inputs resident in HBM"
-                            % (reads, READ_LEN, reads * READ_LEN / 1e9, GENOME_LEN),
+                            % (reads, READ_LEN, reads * READ_LEN / 1e9, genome_len),
                 "k": K, "reads_per_gpu": reads, "bases_per_gpu": n_bases,
                 "n_distinct": n_distinct,
                 "parallelism": "1 GPU" if world == 1 else "%d GPUs: 64 files in contiguous per-rank ranges, all_to_all" % world,

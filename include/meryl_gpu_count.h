@@ -190,6 +190,14 @@ int mgc_push_bases_device(mgc_session *s, const uint8_t *d_bases, uint64_t n_bas
  * block offsets over everything pushed.  Results stay in HBM. */
 int mgc_count(mgc_session *s);
 
+/* Owner side of a sharded (multi-GPU) count: the k-mers are already extracted (canonical 2-bit encoding, uint64 for
+ * k <= 32, {lo,hi} for k > 32) and laid out FILE-MAJOR in device memory -- file f (the top six bits of the k-mer,
+ * merylOp-countThreads.C:255-262 prefix routing restricted to the 64 output files) occupies file_counts[f] consecutive
+ * keys, files ascending; files this rank does not own have count 0.  Runs everything mgc_count runs after the
+ * partition (grouping passes, LDS finish, blocks) IN PLACE on d_keys; results are read like after mgc_count.
+ * The caller must have completed all writes to d_keys (synchronise the producing stream) before the call. */
+int mgc_count_partitioned(mgc_session *s, void *d_keys, const uint64_t *file_counts /*[64]*/, void *reserved);
+
 typedef struct mgc_result_info {
   uint64_t n_bases;
   uint64_t n_instances;           /* k-mer instances (sum of counts) */
@@ -199,6 +207,10 @@ typedef struct mgc_result_info {
   uint64_t file_instances[MGC_NUM_FILES];   /* instances per file = the 6-bit histogram */
 } mgc_result_info;
 int mgc_get_result_info(const mgc_session *s, mgc_result_info *info);
+
+/* Device-to-device copy of the result (distinct k-mers ascending, their counts) into caller-owned device buffers of
+ * n_distinct keys / counts; completes before returning.  Either pointer may be NULL. */
+int mgc_copy_result_device(mgc_session *s, void *d_keys_out, uint32_t *d_counts_out);
 
 /* Device views of the result (valid until mgc_close / the next mgc_count). */
 int mgc_get_result_device(const mgc_session *s, const void **d_unique, const uint32_t **d_counts,

@@ -10,6 +10,8 @@ Multi GPU  : `count_sharded` -- one process per GPU; every rank packs its own
              run-length counts the files it owns.
 """
 import ctypes
+import os
+import sys
 
 import numpy as np
 
@@ -176,6 +178,28 @@ class Session:
     def count(self):
         capi.check(capi.lib().mgc_count(self._h), "mgc_count", self._h)
 
+    def count_partitioned(self, keys, file_counts):
+        """Owner side of a sharded count: `keys` (int64[N] or int64[N, 2] cuda tensor) already hold canonical k-mers
+        laid out file-major, `file_counts` the 64 per-file counts; processed in place."""
+        fc = np.ascontiguousarray(np.asarray(file_counts, dtype=np.uint64))
+        assert fc.size == capi.NUM_FILES and int(fc.sum()) == keys.shape[0]
+        torch.cuda.current_stream(keys.device).synchronize()
+        capi.check(capi.lib().mgc_count_partitioned(self._h, _ptr(keys) if keys.shape[0] else None, fc.ctypes.data, None),
+                   "mgc_count_partitioned", self._h)
+
+    def result_device(self):
+        """(distinct keys, counts int32) as fresh cuda tensors (device-to-device copy)."""
+        r = self.info()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        kw = 2 if self.cfg.k > 32 else 1
+        keys = _u64(r.n_distinct * kw, dev)
+        if kw == 2:
+            keys = keys.view(r.n_distinct, 2)
+        cnts = torch.empty(r.n_distinct, dtype=torch.int32, device=dev)
+        capi.check(capi.lib().mgc_copy_result_device(self._h, _ptr(keys) if r.n_distinct else None,
+                                                     _ptr(cnts) if r.n_distinct else None), "mgc_copy_result_device", self._h)
+        return keys, cnts
+
     def info(self):
         r = capi.ResultInfo()
         capi.check(capi.lib().mgc_get_result_info(self._h, ctypes.byref(r)), "mgc_get_result_info", self._h)
@@ -328,11 +352,32 @@ def exchange_segments(sends, recvs, device, group=None, chunk=None):
                 req.wait()
 
 
+def dev_count_files(keys, file_counts, k, mode=capi.MODE_CANONICAL):
+    """(distinct keys ascending, counts int32) of k-mers already laid out file-major (`file_counts`: 64 entries).
+    Everything mgc_count does after the partition, in place on `keys` (mgc_count_partitioned)."""
+    dev = keys.device.index if keys.device.index is not None else torch.cuda.current_device()
+    s = _SESSIONS.get((k, mode, dev))
+    if s is None:                        # kept: the session's device arena is grow-only, a new one would re-malloc tens of GB
+        cfg = capi.configure(k, max(int(keys.shape[0]), 1) * max(k, 1), 64 << 30, mode)
+        s = _SESSIONS[(k, mode, dev)] = Session(cfg, dev)
+    s.count_partitioned(keys, file_counts)
+    return s.result_device()
+
+
+_SESSIONS = {}
+
+
+def release_cached_sessions():
+    """Frees the sessions (and their device arenas) dev_count_files keeps between calls."""
+    for s in _SESSIONS.values():
+        s.close()
+    _SESSIONS.clear()
+
+
 class HipOps:
     """The device operators count_sharded drives (all HIP, via the C-ABI)."""
     partition = staticmethod(dev_kmer_partition)
-    radix_sort = staticmethod(dev_radix_sort)
-    run_length = staticmethod(dev_run_length)
+    count_files = staticmethod(dev_count_files)
 
     @staticmethod
     def empty_keys(n, like):
@@ -350,13 +395,23 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
     tests inject CPU stand-ins); the product default is the HIP operators.
 
     Layout after the exchange is file-major -- for every owned file, the pieces of all source
-    ranks back to back -- so each file is one contiguous bucket that is LSB-sorted on the 2k-6
-    bits below the file bits, exactly like the single-GPU path."""
+    ranks back to back -- so each file is one contiguous bucket that goes through the grouping passes
+    and the LDS finish exactly like a file of the single-GPU path (mgc_count_partitioned)."""
     import torch.distributed as dist
+    import time as _time
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    prof = os.environ.get("MGC_SHARD_PROFILE") == "1" and torch is not None and bases.is_cuda
+    marks = []
 
+    def mark(name):
+        if prof:
+            torch.cuda.synchronize()
+            marks.append((name, _time.perf_counter()))
+
+    mark("start")
     keys, local_counts = ops.partition(bases, k, mode, 6)                        # grouped by file, ascending
+    mark("partition")
     local_counts = np.asarray(local_counts).astype(np.int64)
     # one small all-gather gives every rank the same [rank][file] histogram -> same cut points
     fc = torch.from_numpy(local_counts).to(keys.device)
@@ -379,15 +434,17 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
         for f in range(f0, f1):
             a = int(file_off[f - f0] + per_rank[:src, f].sum())
             recvs.append((src, inbox[a:a + int(per_rank[src, f])]))
+    mark("plan")
     exchange_segments(sends, recvs, keys.device, group)
     del keys, sends
+    mark("exchange")
 
-    for f in range(f0, f1):                                                      # per-file LSB sort, in place
-        a, b = int(file_off[f - f0]), int(file_off[f - f0 + 1])
-        if b > a:
-            seg = inbox[a:b]
-            out = ops.radix_sort(seg, 0, 2 * k - 6)
-            if out.data_ptr() != seg.data_ptr():
-                seg.copy_(out)
-    uniq, cnts = ops.run_length(inbox)
+    # owner side: the same grouping passes + LDS finish a single-GPU count runs after its partition
+    fc64 = np.zeros(capi.NUM_FILES, dtype=np.uint64)
+    fc64[f0:f1] = file_total
+    uniq, cnts = ops.count_files(inbox, fc64, k, mode)
+    mark("count_files")
+    if prof and rank == 0:
+        print("[shard profile] " + "  ".join("%s %.1f ms" % (n, (t - marks[i][1]) * 1e3) for i, (n, t) in enumerate(marks[1:])),
+              file=sys.stderr, flush=True)
     return uniq, cnts, (f0, f1)

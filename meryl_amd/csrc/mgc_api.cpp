@@ -499,7 +499,9 @@ struct StageTimer {
 }  // namespace
 
 // One pass over bases that are resident in HBM (s->d_bases / s->n_bases): results stay in HBM.
-static int count_device(mgc_session *s) {
+// ext_keys/ext_counts: k-mers already extracted and grouped by file by the caller (the owner side of a sharded
+// count): extraction and partition are skipped, the caller's buffer is processed in place.
+static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t *ext_counts = nullptr) {
   s->free_result();
   HIP_TRY(s, hipSetDevice(s->device));
   hipStream_t st = s->stream;
@@ -514,7 +516,7 @@ static int count_device(mgc_session *s) {
   // ---- `compress`: homopolymer-compress the base stream on the device (merylInput.C:261-268) ----
   const uint8_t *d_bases = s->d_bases;
   uint64_t n_bases = s->n_bases;
-  if (c.homopoly_compress && n_bases) {
+  if (c.homopoly_compress && n_bases && !ext_keys) {
     HIP_TRY(s, s->ensure(mgc_session::B_HPC, n_bases));
     HIP_TRY(s, s->ensure(mgc_session::B_HPC_WS, mgc::hpc_workspace_bytes(n_bases)));
     uint8_t *d_hpc = reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_HPC].p);
@@ -536,13 +538,17 @@ static int count_device(mgc_session *s) {
   HIP_TRY(s, s->ensure(mgc_session::B_META, sizeof(uint64_t) * nb * 2));
   void *part_ws = s->buf[mgc_session::B_PART_WS].p;
   uint64_t *d_counts64 = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_META].p), *d_starts = d_counts64 + nb;
-  tm.begin(MGC_STAGE_HISTOGRAM);
-  HIP_TRY(s, mgc::launch_kmer_histogram(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, part_ws, st));
-  tm.end(MGC_STAGE_HISTOGRAM);
-  s->prof.stage_launches[MGC_STAGE_HISTOGRAM] = 1;
   uint64_t h_counts[MGC_NUM_FILES], h_starts[MGC_NUM_FILES + 1];
-  HIP_TRY(s, hipMemcpyAsync(h_counts, d_counts64, sizeof(h_counts), hipMemcpyDeviceToHost, st));
-  HIP_TRY(s, hipStreamSynchronize(st));
+  if (!ext_keys) {
+    tm.begin(MGC_STAGE_HISTOGRAM);
+    HIP_TRY(s, mgc::launch_kmer_histogram(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, part_ws, st));
+    tm.end(MGC_STAGE_HISTOGRAM);
+    s->prof.stage_launches[MGC_STAGE_HISTOGRAM] = 1;
+    HIP_TRY(s, hipMemcpyAsync(h_counts, d_counts64, sizeof(h_counts), hipMemcpyDeviceToHost, st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+  } else {
+    memcpy(h_counts, ext_counts, sizeof(h_counts));
+  }
   uint64_t N = 0, max_bucket = 0;
   for (uint32_t b = 0; b < nb; b++) {
     h_starts[b] = N;
@@ -564,15 +570,17 @@ static int count_device(mgc_session *s) {
   mgc::SortPlan plan;
   mgc::make_sort_plan(0, 2 * k - bucket_bits, &plan);
   const bool odd = !use_finish && (plan.num_passes & 1u) != 0;
-  HIP_TRY(s, s->ensure(mgc_session::B_X, kbytes * N));
+  if (!ext_keys) HIP_TRY(s, s->ensure(mgc_session::B_X, kbytes * N));
   HIP_TRY(s, s->ensure(mgc_session::B_Y, kbytes * (odd ? N : max_bucket)));
-  unsigned char *X = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_X].p);
+  unsigned char *X = ext_keys ? reinterpret_cast<unsigned char *>(ext_keys) : reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_X].p);
   unsigned char *Y = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_Y].p);
-  HIP_TRY(s, hipMemcpyAsync(d_starts, h_starts, sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
-  tm.begin(MGC_STAGE_PARTITION);
-  HIP_TRY(s, mgc::launch_kmer_partition(d_bases, n_bases, k, c.mode, bucket_bits, d_starts, (void *)X, part_ws, st));
-  tm.end(MGC_STAGE_PARTITION);
-  s->prof.stage_launches[MGC_STAGE_PARTITION] = 2;
+  if (!ext_keys) {
+    HIP_TRY(s, hipMemcpyAsync(d_starts, h_starts, sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
+    tm.begin(MGC_STAGE_PARTITION);
+    HIP_TRY(s, mgc::launch_kmer_partition(d_bases, n_bases, k, c.mode, bucket_bits, d_starts, (void *)X, part_ws, st));
+    tm.end(MGC_STAGE_PARTITION);
+    s->prof.stage_launches[MGC_STAGE_PARTITION] = 2;
+  }
 
   // ---- per-file LSB radix sort of the low 2k-6 bits ----
   const size_t sort_ws_bytes = mgc::sort_workspace_bytes(max_bucket) + 256;
@@ -929,6 +937,20 @@ extern "C" int mgc_count(mgc_session *s) {
   return merge_batches(s);
 }
 
+extern "C" int mgc_count_partitioned(mgc_session *s, void *d_keys, const uint64_t *file_counts, void *stream_to_wait) {
+  if (!s || !file_counts) return MGC_EINVAL;
+  uint64_t n = 0;
+  for (int f = 0; f < MGC_NUM_FILES; f++) n += file_counts[f];
+  if (n && !d_keys) return MGC_EINVAL;
+  if (!s->host_bases.empty() || !s->batches.empty() || s->n_bases) {
+    set_err(&s->err, "mgc_count_partitioned: the session already holds pushed bases");
+    return MGC_ESTATE;
+  }
+  (void)stream_to_wait;                                       // the caller synchronises its producer stream (see count.py)
+  s->merged = false;
+  return count_device(s, d_keys, file_counts);
+}
+
 extern "C" int mgc_get_result_info(const mgc_session *s, mgc_result_info *info) {
   if (!s || !info) return MGC_EINVAL;
   if (!s->counted) return MGC_ESTATE;
@@ -939,6 +961,19 @@ extern "C" int mgc_get_result_info(const mgc_session *s, mgc_result_info *info) 
   info->w_data = s->cfg.w_data;
   info->n_prefix = s->cfg.n_prefix;
   memcpy(info->file_instances, s->file_instances, sizeof(info->file_instances));
+  return MGC_OK;
+}
+
+extern "C" int mgc_copy_result_device(mgc_session *s, void *d_keys_out, uint32_t *d_counts_out) {
+  if (!s) return MGC_EINVAL;
+  if (!s->counted) return MGC_ESTATE;
+  if (s->merged) { set_err(&s->err, "the input was counted in several batches: the merged result is host-resident"); return MGC_ESTATE; }
+  const size_t kbytes = sizeof(uint64_t) * s->key_words;
+  if (s->n_distinct) {
+    if (d_keys_out) HIP_TRY(s, hipMemcpyAsync(d_keys_out, s->d_unique, kbytes * s->n_distinct, hipMemcpyDeviceToDevice, s->stream));
+    if (d_counts_out) HIP_TRY(s, hipMemcpyAsync(d_counts_out, s->d_counts, sizeof(uint32_t) * s->n_distinct, hipMemcpyDeviceToDevice, s->stream));
+  }
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
   return MGC_OK;
 }
 

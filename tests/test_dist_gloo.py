@@ -43,14 +43,14 @@ def _worker(rank, world, port, k, seed, q):
             return torch.from_numpy(lo[order].view(np.int64).copy()), counts
 
         @staticmethod
-        def radix_sort(keys, lo_bit, hi_bit):
+        def count_files(keys, file_counts, k_, mode):
+            # stand-in for mgc_count_partitioned: the keys arrive file-major, each file's pieces back to back
             a = keys.numpy().view(np.uint64)
-            mask = np.uint64((1 << hi_bit) - 1)
-            return torch.from_numpy(a[np.argsort(a & mask, kind="stable")].view(np.int64).copy())
-
-        @staticmethod
-        def run_length(sorted_keys):
-            u, c = np.unique(sorted_keys.numpy().view(np.uint64), return_counts=True)
+            assert int(np.asarray(file_counts).sum()) == a.size
+            f = (a >> np.uint64(2 * k_ - 6)).astype(np.int64)
+            assert np.all(f[1:] >= f[:-1])                                    # file-major layout
+            assert np.array_equal(np.bincount(f, minlength=64).astype(np.uint64), np.asarray(file_counts, dtype=np.uint64))
+            u, c = np.unique(a, return_counts=True)
             return torch.from_numpy(u.view(np.int64).copy()), torch.from_numpy(c.astype(np.int32))
 
         @staticmethod

@@ -441,8 +441,8 @@ def test_simple_mode_geometry(ops, oracle_lib, torch_cuda, tmp_path, k):
 
 
 def test_sharded_path_single_rank(ops, oracle_lib, torch_cuda):
-    """The multi-GPU routine (partition -> all_gather of file counts -> all_to_all_single ->
-    owner-side sort -> run-length) on the HIP operators with a 1-rank NCCL(RCCL) group: the only
+    """The multi-GPU routine (partition -> all_gather of file counts -> file-major exchange ->
+    owner-side mgc_count_partitioned) on the HIP operators with a 1-rank NCCL(RCCL) group: the only
     multi-GPU configuration a 1-GPU box can run.  Result must equal the oracle stream."""
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -459,6 +459,28 @@ def test_sharded_path_single_rank(ops, oracle_lib, torch_cuda):
             assert np.array_equal(cnts.cpu().numpy().view(np.uint32), wcn)
     finally:
         dist.destroy_process_group()
+
+
+def test_count_partitioned_contract(ops, oracle_lib, torch_cuda):
+    # owner-side entry point: file-major keys in, same stream out as a count of the bases; refuses a session that
+    # already holds pushed bases; an empty share is a valid (empty) result
+    from meryl_amd import capi
+    k = 25
+    bases = oracle_lib.synth_reads(77, 50_000, 0, 4000)
+    keys, counts = ops.dev_kmer_partition(torch_cuda.from_numpy(bases).cuda(), k, 0, 6)
+    cfg = capi.configure(k, bases.size, 1 << 30)
+    with ops.Session(cfg) as s:
+        s.count_partitioned(keys, counts)
+        uniq, cnts = s.result_device()
+        _, wlo, wcn, wni = oracle_lib.count_brute(bases.tobytes(), k)
+        assert np.array_equal(_as_u64(uniq), wlo) and np.array_equal(cnts.cpu().numpy().view(np.uint32), wcn)
+        assert s.info().n_instances == wni
+        s.count_partitioned(keys[:0], np.zeros(64, np.uint64))                  # nothing owned
+        assert s.info().n_distinct == 0 and s.result_device()[0].numel() == 0
+    with ops.Session(cfg) as s:
+        s.push_bases("ACGTACGTACGTACGTACGTACGTACGTACGT")
+        with pytest.raises(capi.MgcError):
+            s.count_partitioned(keys, counts)
 
 
 @pytest.mark.parametrize("k,compress", [(21, 0), (51, 0), (31, 1)])
