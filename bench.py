@@ -198,7 +198,7 @@ def main():
                             % (reads, READ_LEN, reads * READ_LEN / 1e9, genome_len),
                 "k": K, "reads_per_gpu": reads, "bases_per_gpu": n_bases,
                 "n_distinct": n_distinct,
-                "parallelism": "1 GPU" if world == 1 else "%d GPUs: 64 files in contiguous per-rank ranges, all_to_all" % world,
+                "parallelism": "1 GPU" if world == 1 else "%d GPUs: 64 files in contiguous per-rank ranges, file-major point-to-point exchange overlapped with the owner-side count" % world,
             },
         }
         if world == 1 and not force_sharded:

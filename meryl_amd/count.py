@@ -313,26 +313,32 @@ def owned_sort_bits(k, first_file, end_file):
 EXCHANGE_CHUNK = 1 << 27          # keys per message: keeps every send/recv far below 2^31 bytes/elements
 
 
-def exchange_segments(sends, recvs, device, group=None, chunk=None):
+def exchange_segments(sends, recvs, device, group=None, chunk=None, max_rows=None, wait=True):
     """Variable-size all-to-all as explicit point-to-point segments.
     sends: list of (peer, tensor_view) in the order the peer expects them;
     recvs: list of (peer, tensor_view) in the matching order (per peer, the i-th send of the
     source pairs with the i-th receive of the destination).  Segments to/from the own rank are
     copied locally.  Long segments are cut into rounds of `chunk` rows so that no single message
     exceeds a few GB (torch's all_to_all_single silently mishandles > 2^31-element exchanges, and a
-    10 Gbp rank would post 8 GB messages) -- each round is one grouped RCCL launch."""
+    10 Gbp rank would post 8 GB messages) -- each round is one grouped RCCL launch.
+    max_rows: the longest segment over ALL ranks when the caller knows it (every rank must run the same
+    number of rounds); None -> one all_reduce finds it.  wait=False returns the outstanding requests
+    instead of waiting for them, so the caller can compute while the rounds are in flight."""
     import torch.distributed as dist
     chunk = chunk or EXCHANGE_CHUNK
     rank = dist.get_rank(group)
-    local_max = max([t.shape[0] for _, t in sends] + [t.shape[0] for _, t in recvs] + [0])
-    m = torch.tensor([local_max], dtype=torch.int64, device=device)
-    dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)          # same number of rounds everywhere
-    rounds = max(1, -(-int(m.item()) // chunk))
+    if max_rows is None:
+        local_max = max([t.shape[0] for _, t in sends] + [t.shape[0] for _, t in recvs] + [0])
+        m = torch.tensor([local_max], dtype=torch.int64, device=device)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)      # same number of rounds everywhere
+        max_rows = int(m.item())
+    rounds = max(1, -(-int(max_rows) // chunk))
     own_src = [t for p, t in sends if p == rank]
     own_dst = [t for p, t in recvs if p == rank]
     assert len(own_src) == len(own_dst)
     for a, b in zip(own_src, own_dst):
         b.copy_(a)
+    pending = []
     for j in range(rounds):
         p2p = []
         for peer, t in sends:
@@ -348,8 +354,13 @@ def exchange_segments(sends, recvs, device, group=None, chunk=None):
                     g = peer if group is None else dist.get_global_rank(group, peer)
                     p2p.append(dist.P2POp(dist.irecv, piece, g, group))
         if p2p:
-            for req in dist.batch_isend_irecv(p2p):
-                req.wait()
+            reqs = dist.batch_isend_irecv(p2p)
+            if wait:
+                for req in reqs:
+                    req.wait()
+            else:
+                pending.extend(reqs)
+    return pending
 
 
 def dev_count_files(keys, file_counts, k, mode=capi.MODE_CANONICAL):
@@ -426,24 +437,52 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
     inbox = ops.empty_keys(int(file_total.sum()), keys)
 
     local_off = np.concatenate([[0], np.cumsum(local_counts)]).astype(np.int64)
-    sends, recvs = [], []
-    for dst in range(world):                                                     # per peer: files ascending
-        for f in range(cuts[dst], cuts[dst + 1]):
-            sends.append((dst, keys[int(local_off[f]):int(local_off[f + 1])]))
-    for src in range(world):
-        for f in range(f0, f1):
-            a = int(file_off[f - f0] + per_rank[:src, f].sum())
-            recvs.append((src, inbox[a:a + int(per_rank[src, f])]))
     mark("plan")
-    exchange_segments(sends, recvs, keys.device, group)
-    del keys, sends
-    mark("exchange")
 
-    # owner side: the same grouping passes + LDS finish a single-GPU count runs after its partition
-    fc64 = np.zeros(capi.NUM_FILES, dtype=np.uint64)
-    fc64[f0:f1] = file_total
-    uniq, cnts = ops.count_files(inbox, fc64, k, mode)
-    mark("count_files")
+    # The exchange runs one "wave" per owned-file index: wave i carries, for every rank, the pieces of the i-th file
+    # of that rank's range.  While wave i is on the links the owner counts its file i-1 (the same grouping passes +
+    # LDS finish a single-GPU count runs after its partition), so only the first wave is exposed.  Every rank
+    # derives the same wave count and segment sizes from the gathered histogram: no further collective is needed.
+    n_waves = max(cuts[r + 1] - cuts[r] for r in range(world))
+    parts = []
+
+    def post(i):
+        sends, recvs = [], []
+        longest = 0
+        for dst in range(world):
+            f = cuts[dst] + i
+            if f < cuts[dst + 1]:
+                sends.append((dst, keys[int(local_off[f]):int(local_off[f + 1])]))
+                longest = max(longest, int(per_rank[:, f].max()))
+        f = f0 + i
+        if f < f1:
+            for src in range(world):
+                a = int(file_off[i] + per_rank[:src, f].sum())
+                recvs.append((src, inbox[a:a + int(per_rank[src, f])]))
+        return exchange_segments(sends, recvs, keys.device, group, max_rows=longest, wait=False)
+
+    def count_file(i):
+        f = f0 + i
+        if f >= f1 or file_total[i] == 0:
+            return
+        fc64 = np.zeros(capi.NUM_FILES, dtype=np.uint64)
+        fc64[f] = file_total[i]
+        parts.append(ops.count_files(inbox[int(file_off[i]):int(file_off[i + 1])], fc64, k, mode))
+
+    for i in range(n_waves + 1):
+        reqs = post(i) if i < n_waves else []
+        if i >= 1:
+            count_file(i - 1)
+        for r in reqs:
+            r.wait()
+    del keys
+    mark("exchange+count")
+    if parts:
+        uniq = torch.cat([p[0] for p in parts])
+        cnts = torch.cat([p[1] for p in parts])
+    else:
+        uniq, cnts = ops.count_files(inbox, np.zeros(capi.NUM_FILES, dtype=np.uint64), k, mode)
+    mark("concat")
     if prof and rank == 0:
         print("[shard profile] " + "  ".join("%s %.1f ms" % (n, (t - marks[i][1]) * 1e3) for i, (n, t) in enumerate(marks[1:])),
               file=sys.stderr, flush=True)
