@@ -22,6 +22,7 @@
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
+#include <chrono>
 #include <vector>
 
 namespace {
@@ -185,6 +186,7 @@ int run_count(const Globals &g, const Operation &op) {
   const uint64_t buf_max = 2 * 1024 * 1024;                                                            // merylOp-countThreads.C:413
   std::vector<char> buf(buf_max);
   uint64_t total_bases = 0;
+  const auto t_start = std::chrono::steady_clock::now();
   for (const std::string &name : op.seq_inputs) {                                                      // loader loop, :173-203
     msr_reader *r = msr_open(name.c_str());
     if (!r) die("ERROR: %s", msr_last_error());
@@ -201,7 +203,9 @@ int run_count(const Globals &g, const Operation &op) {
     msr_close(r);
   }
 
+  const auto t_loaded = std::chrono::steady_clock::now();
   if (mgc_count(s) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+  const auto t_counted = std::chrono::steady_clock::now();
   mgc_result_info info;
   mgc_get_result_info(s, &info);
 
@@ -213,7 +217,15 @@ int run_count(const Globals &g, const Operation &op) {
     fprintf(stderr, "ERROR: writing '%s' failed: %s %s\n", op.output.c_str(), mdb_last_error(), mgc_last_error(s));
     exit(1);
   }
+  const auto t_written = std::chrono::steady_clock::now();
   mgc_close(s);
+  if (g.verbosity > 2) {                                                                               // -V: where the wall clock went
+    auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double>(b - a).count();
+    };
+    fprintf(stderr, "\nTIMING  read+parse+stage %.3f s   upload+count (device) %.3f s   encode+write %.3f s\n",
+            sec(t_start, t_loaded), sec(t_loaded, t_counted), sec(t_counted, t_written));
+  }
   if (g.verbosity > 0) {
     fprintf(stderr, "\nFinished counting.\n");                                                         // :473
     if (g.verbosity > 2)

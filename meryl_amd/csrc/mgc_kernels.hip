@@ -2243,7 +2243,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
   constexpr u32 EMPTY = 0xFFFFFFFFu;                   // suffixes are < 2^31
   __shared__ __attribute__((aligned(16))) u32 tk[SLOTS];
   __shared__ __attribute__((aligned(16))) u32 tc[SLOTS];
-  __shared__ __attribute__((aligned(16))) u32 dk[CAP];
+  __shared__ __attribute__((aligned(16))) u32 dk[CAP + 16];
   __shared__ u32 dc[CAP];
   __shared__ u32 s_tmp[BLOCK / 64 + 1];
   const u32 tid = threadIdx.x;
@@ -2336,21 +2336,27 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 #pragma unroll
       for (int j = 0; j < SPT; j++)
         if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
+      if (tid < 16) dk[D + tid] = EMPTY;               // padding of the rank loop (D is block-uniform)
       __syncthreads();
       HC_STAMP(2);
 
-      // rank = number of smaller distinct suffixes; dk[j..j+3] is one broadcast 16-byte read for the whole wave
+      // rank = number of smaller distinct suffixes.  dk is padded with EMPTY (never smaller) to a multiple of 16, so
+      // the loop runs on whole 64-byte groups: four independent broadcast 16-byte LDS reads in flight per iteration
+      // (a (tried) order-preserving table with cluster-local ranks halves this phase but probes 50 % longer)
       const uint4 *dk4 = reinterpret_cast<const uint4 *>(dk);
       u64 *gk = keys + a;
+      const u32 d16 = (D + 15) / 16;
       for (u32 i = tid; i < D; i += BLOCK) {
         const u32 ki = dk[i];
-        u32 r = 0;
-        const u32 d4 = D / 4;
-        for (u32 j = 0; j < d4; j++) {
-          const uint4 v = dk4[j];
-          r += (v.x < ki ? 1u : 0u) + (v.y < ki ? 1u : 0u) + (v.z < ki ? 1u : 0u) + (v.w < ki ? 1u : 0u);
+        u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        for (u32 j = 0; j < d16; j++) {
+          const uint4 v0 = dk4[4 * j], v1 = dk4[4 * j + 1], v2 = dk4[4 * j + 2], v3 = dk4[4 * j + 3];
+          r0 += (v0.x < ki ? 1u : 0u) + (v0.y < ki ? 1u : 0u) + (v0.z < ki ? 1u : 0u) + (v0.w < ki ? 1u : 0u);
+          r1 += (v1.x < ki ? 1u : 0u) + (v1.y < ki ? 1u : 0u) + (v1.z < ki ? 1u : 0u) + (v1.w < ki ? 1u : 0u);
+          r2 += (v2.x < ki ? 1u : 0u) + (v2.y < ki ? 1u : 0u) + (v2.z < ki ? 1u : 0u) + (v2.w < ki ? 1u : 0u);
+          r3 += (v3.x < ki ? 1u : 0u) + (v3.y < ki ? 1u : 0u) + (v3.z < ki ? 1u : 0u) + (v3.w < ki ? 1u : 0u);
         }
-        for (u32 j = d4 * 4; j < D; j++) r += (dk[j] < ki ? 1u : 0u);
+        const u32 r = r0 + r1 + r2 + r3;
         gk[r] = prefix | (u64)ki;                      // in place: every key of this region sits in registers
         cnt_tmp[a + r] = dc[i];
       }

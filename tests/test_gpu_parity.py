@@ -533,6 +533,30 @@ def test_heavily_repeated_kmers_take_the_fallback(ops, oracle_lib, torch_cuda, k
     assert counts.max() >= 2 * 25_000 - 2 * k                 # the poly-A/T k-mer really is that heavy
 
 
+@pytest.mark.parametrize("k", [21, 40])
+def test_finish_capacity_boundaries(ops, oracle_lib, torch_cuda, k):
+    # one k-mer per file, repeated exactly c times, c straddling every capacity of the finish path: the hash-count
+    # kernel (1536), the small/large LDS sort (2048 for 128-bit keys, 8192) and the full-sort fallback (> 8192)
+    from meryl_amd import capi
+    rng = np.random.default_rng(k)
+    caps = [1, 2, 1151, 1152, 1153, 1535, 1536, 1537, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193, 20000]
+    firsts = ["AAA", "AAC", "AAT", "AAG", "ACA", "ACC", "ACT", "ACG", "ATA", "ATC", "ATT", "ATG", "AGA", "AGC", "AGT",
+              "AGG", "CAA", "CAC"]                          # 18 different files (top three bases), all canonical-small
+    parts = []
+    for c, f in zip(caps, firsts):
+        body = "".join("ACGT"[i] for i in rng.integers(0, 4, k - 3))
+        parts.append(((f + body)[:k - 1] + "G" + ".") * c)   # ends in G: the reverse complement starts with C.. > A..
+    stream = "".join(parts)
+    cfg = capi.configure(k, len(stream), 1 << 30)
+    with ops.Session(cfg) as s:
+        s.push_bases(stream, end_of_sequence=False)
+        s.count()
+        klo, khi, counts, _ = s.result_wide()
+    whi, wlo, wcn, _ = oracle_lib.count_brute(stream, k)
+    assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+    assert sorted(counts.tolist()) == sorted(caps)
+
+
 def test_full_sort_path_still_matches(ops, oracle_lib, torch_cuda, monkeypatch):
     # MGC_FINISH=0: LSB-sort all 2k-6 bits globally + the separate run-length kernels
     from meryl_amd import capi
