@@ -44,6 +44,7 @@ extern "C" {
 #define MGC_ESTATE       -4    /* call out of order (e.g. finish before count) */
 #define MGC_EUNSUPPORTED -5    /* valid in the reference, not implemented here yet */
 #define MGC_ETIMEOUT     -6    /* an in-kernel bounded spin expired (never hangs) */
+#define MGC_EFORMAT      -7    /* mgc_end_text: the file is not what the device parser handles (see there) */
 
 /* opCount / opCountForward / opCountReverse, src/meryl/merylOp.H:40-42 and
  * src/meryl/merylOp-countThreads.C:241-258 */
@@ -181,6 +182,23 @@ int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int end_of_seq
  * host-resident: mgc_copy_result / mgc_finish / mgc_write_database work,
  * mgc_get_result_device returns MGC_ESTATE. */
 int mgc_set_batch_bases(mgc_session *s, uint64_t bases_per_batch);
+
+/* Sequence-file TEXT instead of bases: the raw bytes of a FASTA or FASTQ file (after any decompression), in
+ * chunks of any size and alignment.  The library stages them through pinned buffers, uploads them and parses
+ * them ON THE DEVICE into the same base stream mgc_push_bases builds ('.' between sequences; headers, qualities
+ * and line ends dropped) -- the device-side replacement of dnaSeqFile::loadBases behind
+ * merylInput::loadBases (src/meryl/merylInput.C:245-271) and of the loader's chunk assembly
+ * (src/meryl/merylOp-countThreads.C:138-231).  FASTA may be multi-line; FASTQ must be strict four-line records:
+ * every '@' and '+' line start is checked on the device and mgc_end_text returns MGC_EFORMAT if the structure
+ * does not hold -- the file's output is then already rolled back and the caller feeds the file through
+ * mgc_push_bases instead (include/meryl_seq.h reads multi-line FASTQ).  Text input is counted in one batch
+ * (no out-of-core spill); it may be mixed with mgc_push_bases in one session. */
+#define MGC_TEXT_FASTA 1
+#define MGC_TEXT_FASTQ 2
+int mgc_reserve_text(mgc_session *s, uint64_t text_bytes);       /* optional: expected total, avoids regrowth */
+int mgc_begin_text(mgc_session *s, int format);
+int mgc_push_text(mgc_session *s, const char *text, size_t len);
+int mgc_end_text(mgc_session *s);
 
 /* Bases already resident in HBM (breakers included).  The buffer is borrowed
  * until mgc_count returns.  May be called once per session. */

@@ -34,6 +34,11 @@ const char *msr_last_error(void);
  * sequence), 0 = end of input, <0 = malformed input. */
 int msr_load_bases(msr_reader *r, char *seq, uint64_t max_length, uint64_t *seq_length, int *end_of_sequence);
 
+/* The file's TEXT (decompressed, otherwise untouched), up to max_length bytes per call; 0 at end of input, <0 on a
+ * read error.  For callers that parse on the device (mgc_push_text, include/meryl_gpu_count.h); not to be mixed with
+ * msr_load_bases on the same reader. */
+int64_t msr_read_text(msr_reader *r, char *buf, uint64_t max_length);
+
 /* 1 when the file name ends in .gz (the reference reserves a second loader
  * thread for it, src/meryl/merylOp-countThreads.C:162-168). */
 int msr_is_compressed(const msr_reader *r);

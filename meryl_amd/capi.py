@@ -21,7 +21,7 @@ SYMBOLS = (
     "mgc_dev_partition_workspace_bytes", "mgc_dev_kmer_histogram", "mgc_dev_kmer_partition",
     "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort",
     "mgc_dev_rle_workspace_bytes", "mgc_dev_rle_count", "mgc_dev_rle_emit", "mgc_dev_block_offsets",
-    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_count", "mgc_count_partitioned", "mgc_copy_result_device",
+    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_count", "mgc_count_partitioned", "mgc_copy_result_device",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_version",
     "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases",
@@ -30,7 +30,7 @@ SYMBOLS = (
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_close",
     "mdb_free", "mgc_write_database",
     # include/meryl_seq.h
-    "msr_open", "msr_close", "msr_last_error", "msr_load_bases", "msr_is_compressed", "msr_guess_number_of_kmers",
+    "msr_open", "msr_read_text", "msr_close", "msr_last_error", "msr_load_bases", "msr_is_compressed", "msr_guess_number_of_kmers",
 )
 
 
@@ -97,9 +97,13 @@ BLOCK_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctyp
                             ctypes.POINTER(ctypes.c_uint32))
 
 
+OK, EINVAL, ENOMEM, EHIP, ESTATE, EUNSUPPORTED, ETIMEOUT, EFORMAT = 0, -1, -2, -3, -4, -5, -6, -7
+
+
 class MgcError(RuntimeError):
     def __init__(self, rc, what, detail=""):
         self.rc = rc
+        self.code = rc
         super().__init__("%s failed rc=%d %s" % (what, rc, detail))
 
 
@@ -178,6 +182,10 @@ def lib():
     sig("mgc_push_bases", i32, vp, ctypes.c_char_p, sz, i32)
     sig("mgc_push_bases_device", i32, vp, vp, u64)
     sig("mgc_set_batch_bases", i32, vp, u64)
+    sig("mgc_reserve_text", i32, vp, u64)
+    sig("mgc_begin_text", i32, vp, i32)
+    sig("mgc_push_text", i32, vp, ctypes.c_char_p, sz)
+    sig("mgc_end_text", i32, vp)
     sig("mgc_count", i32, vp)
     sig("mgc_count_partitioned", i32, vp, vp, vp, vp)
     sig("mgc_copy_result_device", i32, vp, vp, vp)
@@ -200,6 +208,7 @@ def lib():
     sig("mgc_write_database", i32, vp, ctypes.c_char_p, i32)
     sig("msr_open", vp, ctypes.c_char_p)
     sig("msr_close", None, vp)
+    sig("msr_read_text", ctypes.c_int64, vp, vp, u64)
     sig("msr_last_error", ctypes.c_char_p)
     sig("msr_load_bases", i32, vp, vp, u64, P(u64), P(i32))
     sig("msr_is_compressed", i32, vp)

@@ -161,6 +161,19 @@ class Session:
         capi.check(capi.lib().mgc_push_bases(self._h, b, len(b), 1 if end_of_sequence else 0), "mgc_push_bases",
                    self._h)
 
+    def push_text(self, text, fmt, pieces=None):
+        """One whole sequence file as raw text (bytes/str), parsed on the device.  fmt: "fasta" | "fastq".
+        pieces: optional chunk size (the text is fed in pieces of that many bytes -- tests use odd sizes).
+        Raises MgcError(code MGC_EFORMAT) if the device parser refuses the file (its output is rolled back)."""
+        b = text.encode("ascii") if isinstance(text, str) else bytes(text)
+        L = capi.lib()
+        capi.check(L.mgc_begin_text(self._h, 1 if fmt == "fasta" else 2), "mgc_begin_text", self._h)
+        step = pieces or max(len(b), 1)
+        for i in range(0, len(b), step):
+            piece = b[i:i + step]
+            capi.check(L.mgc_push_text(self._h, piece, len(piece)), "mgc_push_text", self._h)
+        capi.check(L.mgc_end_text(self._h), "mgc_end_text", self._h)
+
     def push_bases_device(self, t):
         # the session runs on its own HIP stream: whatever produced `t` on torch's
         # stream must be complete before mgc_count reads it

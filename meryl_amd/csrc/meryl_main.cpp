@@ -187,10 +187,16 @@ int run_count(const Globals &g, const Operation &op) {
   std::vector<char> buf(buf_max);
   uint64_t total_bases = 0;
   const auto t_start = std::chrono::steady_clock::now();
-  for (const std::string &name : op.seq_inputs) {                                                      // loader loop, :173-203
+  // Input: the file's raw text goes to the device and is parsed there (mgc_push_text); files the device parser
+  // refuses (multi-line FASTQ ...) and MERYL_HOST_PARSER=1 take the host state machine of meryl_seq.cpp.
+  const bool host_parser = getenv("MERYL_HOST_PARSER") && getenv("MERYL_HOST_PARSER")[0] == '1';
+  uint64_t text_total = 0;
+  for (const std::string &name : op.seq_inputs) text_total += msr_guess_number_of_kmers(name.c_str());
+  if (!host_parser && text_total) (void)mgc_reserve_text(s, text_total);
+  auto load_on_host = [&](const std::string &name) {
     msr_reader *r = msr_open(name.c_str());
     if (!r) die("ERROR: %s", msr_last_error());
-    for (;;) {
+    for (;;) {                                                                                         // loader loop, :173-203
       uint64_t len = 0;
       int eos = 0;
       const int rc = msr_load_bases(r, buf.data(), buf_max, &len, &eos);
@@ -201,6 +207,38 @@ int run_count(const Globals &g, const Operation &op) {
     }
     mgc_push_bases(s, nullptr, 0, 1);                                                                  // end-of-file breaker, :196
     msr_close(r);
+  };
+  std::vector<char> text(host_parser ? 0 : (16u << 20));
+  for (const std::string &name : op.seq_inputs) {
+    if (host_parser) { load_on_host(name); continue; }
+    msr_reader *r = msr_open(name.c_str());
+    if (!r) die("ERROR: %s", msr_last_error());
+    bool begun = false, refused = false;
+    for (;;) {
+      const int64_t got = msr_read_text(r, text.data(), text.size());
+      if (got < 0) die("ERROR: %s", msr_last_error());
+      if (got == 0) break;
+      if (!begun) {
+        int64_t p = 0;
+        while (p < got && (text[p] == '\n' || text[p] == '\r' || text[p] == ' ' || text[p] == '\t')) p++;
+        const char c = p < got ? text[p] : '>';
+        if (c != '>' && c != '@') {
+          fprintf(stderr, "ERROR: '%s' is neither FASTA nor FASTQ (record starts with '%c')\n", name.c_str(), c);
+          exit(1);
+        }
+        if (mgc_begin_text(s, c == '@' ? MGC_TEXT_FASTQ : MGC_TEXT_FASTA) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+        begun = true;
+      }
+      if (mgc_push_text(s, text.data(), (size_t)got) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+      total_bases += (uint64_t)got;                                                                    // text bytes (reported with -V -V)
+    }
+    msr_close(r);
+    if (begun) {
+      const int rc = mgc_end_text(s);
+      if (rc == MGC_EFORMAT) refused = true;
+      else if (rc != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+    }
+    if (refused) load_on_host(name);
   }
 
   const auto t_loaded = std::chrono::steady_clock::now();

@@ -80,6 +80,23 @@ extern "C" void msr_close(msr_reader *r) {
   delete r;
 }
 
+extern "C" int64_t msr_read_text(msr_reader *r, char *buf, uint64_t max_length) {
+  if (!r || !buf) return -1;
+  if (r->st != msr_reader::AT_RECORD_START || r->in_sequence || r->pos != r->len) {
+    seq_err("msr_read_text: '" + r->name + "': raw and parsed reads cannot be mixed on one reader");
+    return -1;
+  }
+  uint64_t got = 0;
+  while (got < max_length && !r->eof) {
+    const uint64_t want = max_length - got;
+    const int n = gzread(r->gz, buf + got, (unsigned)(want > (1u << 30) ? (1u << 30) : want));
+    if (n < 0) { seq_err("msr_read_text: read error in '" + r->name + "'"); return -1; }
+    if (n == 0) { r->eof = true; break; }
+    got += (uint64_t)n;
+  }
+  return (int64_t)got;
+}
+
 extern "C" int msr_is_compressed(const msr_reader *r) { return (r && r->compressed) ? 1 : 0; }
 
 extern "C" uint64_t msr_guess_number_of_kmers(const char *name) {

@@ -310,7 +310,7 @@ struct mgc_session {
   // repeated count does not pay hipMalloc/hipFree of tens of GB every time
   struct Buf { void *p = nullptr; size_t cap = 0; };
   enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_HPC, B_HPC_WS, B_BASES,
-         B_SUBSTART, B_GROUPS, B_GSCAN, B_CNT_TMP, B_LARGE, B_NUM };
+         B_SUBSTART, B_GROUPS, B_GSCAN, B_CNT_TMP, B_LARGE, B_TEXT_OUT, B_TEXT_IN0, B_TEXT_IN1, B_TEXT_WS, B_TEXT_STATE, B_NUM };
   Buf buf[B_NUM];
   hipError_t ensure(int which, size_t bytes) {
     Buf &b = buf[which];
@@ -322,6 +322,31 @@ struct mgc_session {
     return e;
   }
   void free_arena() { for (auto &b : buf) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; } }
+  // grows a buffer whose first `keep` bytes must survive (device-to-device copy on the session stream)
+  hipError_t ensure_preserve(int which, size_t bytes, size_t keep) {
+    Buf &b = buf[which];
+    if (b.cap >= bytes) return hipSuccess;
+    size_t want = b.cap + b.cap / 2;
+    if (want < bytes) want = bytes;
+    void *np = nullptr;
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess) return e;
+    if (b.p && keep) e = hipMemcpyAsync(np, b.p, keep, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (b.p) (void)hipFree(b.p);
+    b.p = np; b.cap = want;
+    return e;
+  }
+
+  // device-side text parsing (mgc_push_text): pinned staging, two chunks in flight
+  static constexpr size_t TEXT_CHUNK = 32u << 20;
+  bool        text_mode = false, text_open = false;
+  int         text_format = 0;
+  uint64_t    text_bound = 0;            // upper bound of the parsed length so far (the device knows the exact one)
+  char       *text_pinned[2] = {nullptr, nullptr};
+  hipEvent_t  text_ev[2] = {nullptr, nullptr};
+  bool        text_ev_used[2] = {false, false};
+  uint32_t    text_next = 0;
 
   // out-of-core batches (the analogue of writeBatch's spill, merylOp-countThreads.C:323-379): when the
   // pushed bases exceed what one pass can hold in HBM, everything up to the last sequence
@@ -410,6 +435,10 @@ extern "C" void mgc_close(mgc_session *s) {
   s->free_result();
   s->free_arena();
   if (s->d_bases_own) (void)hipFree(s->d_bases_own);
+  for (int i = 0; i < 2; i++) {
+    if (s->text_pinned[i]) (void)hipHostFree(s->text_pinned[i]);
+    if (s->text_ev[i]) (void)hipEventDestroy(s->text_ev[i]);
+  }
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -436,7 +465,7 @@ extern "C" int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int
   }
   if (len) s->host_bases.insert(s->host_bases.end(), bases, bases + len);
   if (end_of_sequence) s->host_bases.push_back('.');        // merylOp-countThreads.C:214-215
-  if (s->host_bases.size() >= s->batch_limit) {
+  if (!s->text_mode && s->host_bases.size() >= s->batch_limit) {
     // cut at the last sequence boundary: k-mers never span a breaker, so no carry is needed
     // (and `compress` stays a per-sequence operation)
     size_t cut = s->host_bases.size();
@@ -446,6 +475,119 @@ extern "C" int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int
       if (rc != MGC_OK) return rc;
     }
   }
+  return MGC_OK;
+}
+
+// ---- text input, parsed on the device (include/meryl_gpu_count.h) ------------------------------
+static int text_setup(mgc_session *s) {
+  if (s->borrowed || s->counted || !s->batches.empty()) {
+    set_err(&s->err, "text input cannot follow device input, a count, or a spilled batch");
+    return MGC_ESTATE;
+  }
+  HIP_TRY(s, hipSetDevice(s->device));
+  if (!s->text_mode) {
+    HIP_TRY(s, s->ensure(mgc_session::B_TEXT_STATE, mgc::text_parse_state_bytes()));
+    HIP_TRY(s, s->ensure(mgc_session::B_TEXT_IN0, mgc_session::TEXT_CHUNK));
+    HIP_TRY(s, s->ensure(mgc_session::B_TEXT_IN1, mgc_session::TEXT_CHUNK));
+    HIP_TRY(s, s->ensure(mgc_session::B_TEXT_WS, mgc::text_parse_workspace_bytes(mgc_session::TEXT_CHUNK)));
+    HIP_TRY(s, s->ensure_preserve(mgc_session::B_TEXT_OUT, 1u << 20, 0));
+    for (int i = 0; i < 2; i++) {
+      if (!s->text_pinned[i]) HIP_TRY(s, hipHostMalloc(reinterpret_cast<void **>(&s->text_pinned[i]), mgc_session::TEXT_CHUNK, hipHostMallocDefault));
+      if (!s->text_ev[i]) HIP_TRY(s, hipEventCreateWithFlags(&s->text_ev[i], hipEventDisableTiming));
+    }
+    HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p,
+                                        reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p), 3, s->stream));
+    s->text_mode = true;
+    s->text_bound = 0;
+  }
+  return MGC_OK;
+}
+
+extern "C" int mgc_reserve_text(mgc_session *s, uint64_t text_bytes) {
+  if (!s) return MGC_EINVAL;
+  int rc = text_setup(s);
+  if (rc != MGC_OK) return rc;
+  HIP_TRY(s, s->ensure_preserve(mgc_session::B_TEXT_OUT, text_bytes + 4096, s->text_bound));
+  return MGC_OK;
+}
+
+extern "C" int mgc_begin_text(mgc_session *s, int format) {
+  if (!s || (format != MGC_TEXT_FASTA && format != MGC_TEXT_FASTQ)) return MGC_EINVAL;
+  if (s->text_open) { set_err(&s->err, "mgc_begin_text: the previous file was not ended"); return MGC_ESTATE; }
+  int rc = text_setup(s);
+  if (rc != MGC_OK) return rc;
+  HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p,
+                                      reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p), 0, s->stream));
+  s->text_format = format;
+  s->text_open = true;
+  return MGC_OK;
+}
+
+extern "C" int mgc_push_text(mgc_session *s, const char *text, size_t len) {
+  if (!s || (!text && len)) return MGC_EINVAL;
+  if (!s->text_open) { set_err(&s->err, "mgc_push_text without mgc_begin_text"); return MGC_ESTATE; }
+  HIP_TRY(s, hipSetDevice(s->device));
+  while (len) {
+    const size_t piece = len < mgc_session::TEXT_CHUNK ? len : mgc_session::TEXT_CHUNK;
+    const uint32_t b = s->text_next & 1u;
+    if (s->text_ev_used[b]) HIP_TRY(s, hipEventSynchronize(s->text_ev[b]));     // pinned + device buffer b are free again
+    memcpy(s->text_pinned[b], text, piece);
+    HIP_TRY(s, s->ensure_preserve(mgc_session::B_TEXT_OUT, s->text_bound + piece + 4096, s->text_bound));
+    uint8_t *d_in = reinterpret_cast<uint8_t *>(s->buf[b ? mgc_session::B_TEXT_IN1 : mgc_session::B_TEXT_IN0].p);
+    HIP_TRY(s, hipMemcpyAsync(d_in, s->text_pinned[b], piece, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(s, mgc::launch_text_parse(d_in, piece, s->text_format == MGC_TEXT_FASTQ, s->buf[mgc_session::B_TEXT_STATE].p,
+                                      s->buf[mgc_session::B_TEXT_WS].p,
+                                      reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p), s->stream));
+    HIP_TRY(s, hipEventRecord(s->text_ev[b], s->stream));
+    s->text_ev_used[b] = true;
+    s->text_next++;
+    s->text_bound += piece;
+    text += piece;
+    len -= piece;
+  }
+  return MGC_OK;
+}
+
+struct HostParseState { uint64_t out_len, file_start_len; uint32_t state, prev_nl, error, pad; };
+
+extern "C" int mgc_end_text(mgc_session *s) {
+  if (!s) return MGC_EINVAL;
+  if (!s->text_open) { set_err(&s->err, "mgc_end_text without mgc_begin_text"); return MGC_ESTATE; }
+  HIP_TRY(s, hipSetDevice(s->device));
+  s->text_open = false;
+  HIP_TRY(s, s->ensure_preserve(mgc_session::B_TEXT_OUT, s->text_bound + 4096, s->text_bound));
+  uint8_t *out = reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p);
+  HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p, out, 1, s->stream));
+  s->text_bound += 1;
+  HostParseState h;
+  HIP_TRY(s, hipMemcpyAsync(&h, s->buf[mgc_session::B_TEXT_STATE].p, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  if (h.error) {
+    HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p, out, 2, s->stream));
+    set_err(&s->err, "the file is not strict four-line FASTQ: feed it through mgc_push_bases (meryl_seq.h reader)");
+    return MGC_EFORMAT;
+  }
+  return MGC_OK;
+}
+
+// end of the text input: the exact parsed length comes back, host-pushed bases (if any) are appended
+static int text_finalize(mgc_session *s) {
+  if (s->text_open) { set_err(&s->err, "mgc_count: a text file is still open (mgc_end_text)"); return MGC_ESTATE; }
+  HostParseState h;
+  HIP_TRY(s, hipMemcpyAsync(&h, s->buf[mgc_session::B_TEXT_STATE].p, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  uint64_t n = h.out_len;
+  const size_t extra = s->host_bases.size();
+  if (extra) {
+    HIP_TRY(s, s->ensure_preserve(mgc_session::B_TEXT_OUT, n + extra + 4096, n));
+    HIP_TRY(s, hipMemcpyAsync(reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p) + n, s->host_bases.data(), extra,
+                              hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    n += extra;
+    std::vector<char>().swap(s->host_bases);
+  }
+  s->d_bases = reinterpret_cast<const uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p);
+  s->n_bases = n;
   return MGC_OK;
 }
 
@@ -923,6 +1065,12 @@ static int merge_batches(mgc_session *s) {
 extern "C" int mgc_count(mgc_session *s) {
   if (!s) return MGC_EINVAL;
   if (s->borrowed) return count_device(s);
+  if (s->text_mode) {
+    int rc = text_finalize(s);
+    if (rc != MGC_OK) return rc;
+    s->merged = false;
+    return count_device(s);
+  }
   if (s->batches.empty()) {                                  // everything fits in one pass: results stay in HBM
     int rc = upload_host_bases(s, s->host_bases.size());
     if (rc != MGC_OK) return rc;

@@ -90,6 +90,14 @@ size_t     hpc_workspace_bytes(uint64_t n);
 // compressed length lands in the first uint64 of the workspace
 hipError_t launch_homopoly_compress(const uint8_t *d_in, uint64_t n, uint8_t *d_out, void *d_ws, hipStream_t st);
 
+// ---- FASTA / FASTQ text -> base stream (mgc_parse.hip) ----------------------------------------
+size_t     text_parse_state_bytes();
+size_t     text_parse_workspace_bytes(uint64_t n);            // for one chunk of n text bytes
+// appends the bases of one text chunk to d_out at the running length kept in d_state
+hipError_t launch_text_parse(const uint8_t *d_text, uint64_t n, int fastq, void *d_state, void *d_ws, uint8_t *d_out, hipStream_t st);
+// what: 0 begin file, 1 end file (breaker), 2 roll the current file back, 3 reset
+hipError_t launch_text_file_op(void *d_state, uint8_t *d_out, int what, hipStream_t st);
+
 hipError_t launch_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                               uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,
                               uint8_t *d_out, hipStream_t st);

@@ -570,3 +570,93 @@ def test_full_sort_path_still_matches(ops, oracle_lib, torch_cuda, monkeypatch):
             klo, khi, counts, _ = s.result_wide()
         whi, wlo, wcn, _ = oracle_lib.count_brute(bases.tobytes(), k)
         assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+
+
+# ---------------------------------------------------------------------------------------------------
+#  text input parsed on the device (mgc_begin_text / mgc_push_text / mgc_end_text)
+# ---------------------------------------------------------------------------------------------------
+def _fasta_text(reads, width, eol, rng):
+    out = []
+    for i, r in enumerate(reads):
+        out.append(">read_%d ACGTACGT len=%d%s" % (i, len(r), eol))          # header text full of base letters
+        if width:
+            for a in range(0, len(r), width):
+                out.append(r[a:a + width] + eol)
+        else:
+            out.append(r + eol)
+        if rng.random() < 0.1:
+            out.append(eol)                                                  # stray blank line
+    return "".join(out)
+
+
+def _fastq_text(reads, eol, rng):
+    out = []
+    for i, r in enumerate(reads):
+        q = "".join(rng.choice(list("@+>IIIIF#5")) for _ in r)               # qualities starting with @ + > on purpose
+        out.append("@r%d/1 ACGT%s%s%s+%s%s%s%s" % (i, eol, r, eol, ("r%d/1" % i) if i % 3 == 0 else "", eol, q, eol))
+    return "".join(out)
+
+
+def _reads_for_text(oracle_lib, seed, n_reads, read_len=150):
+    b = oracle_lib.synth_reads(seed, 30_000, 0, n_reads, read_len, 20000, 3000).tobytes().decode()
+    reads = [r for r in b.split(".") if r]
+    reads[1] = reads[1].lower()
+    reads[2] = reads[2][:10]                                                 # shorter than k
+    reads[3] = ""                                                            # empty record
+    return reads
+
+
+@pytest.mark.parametrize("fmt,eol,width", [("fasta", "\n", 60), ("fasta", "\r\n", 70), ("fasta", "\n", 0),
+                                           ("fastq", "\n", 0), ("fastq", "\r\n", 0)])
+@pytest.mark.parametrize("pieces", [None, 1, 7, 4099, 16384, 16385])
+def test_device_text_parse_matches_oracle(ops, oracle_lib, torch_cuda, fmt, eol, width, pieces):
+    from meryl_amd import capi
+    k = 21
+    rng = np.random.default_rng(len(eol) * 100 + width + (pieces or 0))
+    reads = _reads_for_text(oracle_lib, 5 + width, 40 if pieces in (1, 7) else 400)
+    text = _fasta_text(reads, width, eol, rng) if fmt == "fasta" else _fastq_text(reads, eol, rng)
+    if pieces == 4099:
+        text = text.rstrip("\r\n")                                           # no line end after the last record
+    want_stream = ".".join(reads) + "."
+    whi, wlo, wcn, wni = oracle_lib.count_brute(want_stream, k)
+    cfg = capi.configure(k, len(text), 1 << 30)
+    with ops.Session(cfg) as s:
+        s.push_text(text, fmt, pieces)
+        s.count()
+        klo, khi, counts, _ = s.result_wide()
+        assert s.info().n_instances == wni
+    assert np.array_equal(klo, wlo) and np.array_equal(counts, wcn)
+
+
+def test_device_text_parse_large_mixed_and_refusal(ops, oracle_lib, torch_cuda):
+    # > 32 MiB of FASTQ (several staging chunks), a FASTA file and host-pushed bases in ONE session; a FASTQ file with a
+    # blank line inside is refused (MGC_EFORMAT), rolled back, and counted through the host path instead
+    from meryl_amd import capi
+    k = 31
+    rng = np.random.default_rng(1)
+    b = oracle_lib.synth_reads(9, 2_000_000, 0, 130_000, 150, 5000, 100).tobytes().decode()
+    reads = [r for r in b.split(".") if r]
+    fq = "".join("@%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads))
+    assert len(fq) > (33 << 20)
+    fa_reads = _reads_for_text(oracle_lib, 3, 300)
+    fa = _fasta_text(fa_reads, 80, "\n", rng)
+    bad_reads = _reads_for_text(oracle_lib, 4, 50)
+    bad = _fastq_text(bad_reads[:20], "\n", rng) + "\n" + _fastq_text(bad_reads[20:], "\n", rng)
+    host_reads = _reads_for_text(oracle_lib, 6, 60)
+    want_stream = ".".join(reads + fa_reads + bad_reads + host_reads) + "."
+    _, wlo, wcn, wni = oracle_lib.count_brute(want_stream, k)
+    cfg = capi.configure(k, len(fq), 4 << 30)
+    with ops.Session(cfg) as s:
+        s.push_text(fq, "fastq")
+        for r in host_reads:
+            s.push_bases(r, end_of_sequence=True)
+        s.push_text(fa, "fasta", 100_003)
+        with pytest.raises(capi.MgcError) as e:
+            s.push_text(bad, "fastq")
+        assert e.value.code == capi.EFORMAT
+        for r in bad_reads:                                                  # the caller's fallback
+            s.push_bases(r, end_of_sequence=True)
+        s.count()
+        klo, counts, _ = s.result()
+        assert s.info().n_instances == wni
+    assert np.array_equal(klo, wlo) and np.array_equal(counts, wcn)
