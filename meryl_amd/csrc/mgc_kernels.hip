@@ -484,16 +484,16 @@ struct SortHeader {                       // lives at the start of the sort work
 
 struct PassList { u32 n; u32 shift[RS_MAX_PASSES]; u32 mask[RS_MAX_PASSES]; };
 
-// Digit histograms of every pass in one read of the keys.
-template <typename K>
+// Digit histograms of every pass in one read of the keys.  NP > 0: exactly NP passes (shifts and masks stay in
+// registers, the LDS histogram is NP rows: 4 KiB for the two passes of the finish path, so eight 256-thread
+// workgroups fit a CU); NP == 0: any number of passes up to RS_MAX_PASSES.
+template <typename K, int NP>
 __global__ __launch_bounds__(256)
 void radix_hist_kernel(const K *__restrict__ in, u64 n, PassList pl, u64 *__restrict__ ghist) {
-  __shared__ u32 s_h[RS_MAX_PASSES * RS_MAX_RADIX];       // up to 16 passes x 512 digits
-  const u32 np = pl.n;
-  // row stride: 512 if any mask needs it, else 256 (keeps 16 passes of 8 bits in 16 KB... )
-  u32 stride = 256;
-  for (u32 p = 0; p < np; p++) if (pl.mask[p] > 255u) stride = 512;
-  for (u32 i = threadIdx.x; i < np * stride; i += 256) s_h[i] = 0;
+  constexpr u32 ROWS = NP ? NP : RS_MAX_PASSES;
+  __shared__ u32 s_h[ROWS * RS_MAX_RADIX];
+  const u32 np = NP ? (u32)NP : pl.n;
+  for (u32 i = threadIdx.x; i < np * RS_MAX_RADIX; i += 256) s_h[i] = 0;
   __syncthreads();
 
   // 4 independent loads in flight per thread (the loop is otherwise latency-bound)
@@ -509,15 +509,36 @@ void radix_hist_kernel(const K *__restrict__ in, u64 n, PassList pl, u64 *__rest
       if (ok[j]) key[j] = in[i];
     }
 #pragma unroll
-    for (u32 j = 0; j < UNR; j++)
-      if (ok[j])
+    for (u32 j = 0; j < UNR; j++) {
+      if (!ok[j]) continue;
+      if (NP) {
+#pragma unroll
+        for (u32 p = 0; p < ROWS; p++)
+          atomicAdd(&s_h[p * RS_MAX_RADIX + KeyOps<K>::digit(key[j], pl.shift[p], pl.mask[p])], 1u);
+      } else {
         for (u32 p = 0; p < np; p++)
-          atomicAdd(&s_h[p * stride + KeyOps<K>::digit(key[j], pl.shift[p], pl.mask[p])], 1u);
+          atomicAdd(&s_h[p * RS_MAX_RADIX + KeyOps<K>::digit(key[j], pl.shift[p], pl.mask[p])], 1u);
+      }
+    }
   }
   __syncthreads();
-  for (u32 i = threadIdx.x; i < np * stride; i += 256) {
+  for (u32 i = threadIdx.x; i < np * RS_MAX_RADIX; i += 256) {
     const u32 v = s_h[i];
-    if (v) atomicAdd(&ghist[(u64)(i / stride) * RS_MAX_RADIX + (i % stride)], (u64)v);
+    if (v) atomicAdd(&ghist[i], (u64)v);
+  }
+}
+
+template <typename K>
+static void launch_radix_hist(const K *src, u64 n, const PassList &pl, u64 *ghist, hipStream_t st) {
+  uint64_t hgrid = (n + 256 * 16 - 1) / (256 * 16);
+  if (hgrid > 2048) hgrid = 2048;
+  const dim3 g((uint32_t)hgrid), b(256);
+  switch (pl.n) {
+    case 1:  hipLaunchKernelGGL((radix_hist_kernel<K, 1>), g, b, 0, st, src, n, pl, ghist); break;
+    case 2:  hipLaunchKernelGGL((radix_hist_kernel<K, 2>), g, b, 0, st, src, n, pl, ghist); break;
+    case 3:  hipLaunchKernelGGL((radix_hist_kernel<K, 3>), g, b, 0, st, src, n, pl, ghist); break;
+    case 4:  hipLaunchKernelGGL((radix_hist_kernel<K, 4>), g, b, 0, st, src, n, pl, ghist); break;
+    default: hipLaunchKernelGGL((radix_hist_kernel<K, 0>), g, b, 0, st, src, n, pl, ghist); break;
   }
 }
 
@@ -1527,10 +1548,7 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
       pl.shift[p] = plan.pass_shift[p];
       pl.mask[p]  = (1u << plan.pass_bits[p]) - 1u;
     }
-    uint64_t hgrid = (n + 256 * 16 - 1) / (256 * 16);
-    if (hgrid > 2048) hgrid = 2048;
-    hipLaunchKernelGGL(radix_hist_kernel<K>, dim3((uint32_t)hgrid), dim3(256), 0, st, (const K *)src, (u64)n, pl,
-                       &hdr->ghist[0][0]);
+    launch_radix_hist<K>((const K *)src, (u64)n, pl, &hdr->ghist[0][0], st);
     MGC_CHECK(hipGetLastError());
     hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(plan.num_passes), dim3(RS_MAX_RADIX), 0, st,
                        &hdr->ghist[0][0], &hdr->gbase[0][0]);
@@ -1583,10 +1601,7 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
       pl.shift[p] = plan.pass_shift[p];
       pl.mask[p]  = (1u << plan.pass_bits[p]) - 1u;
     }
-    uint64_t hgrid = (n + 256 * 16 - 1) / (256 * 16);
-    if (hgrid > 2048) hgrid = 2048;
-    hipLaunchKernelGGL(radix_hist_kernel<K>, dim3((uint32_t)hgrid), dim3(256), 0, st, (const K *)src, (u64)n, pl,
-                       &hdr->ghist[0][0]);
+    launch_radix_hist<K>((const K *)src, (u64)n, pl, &hdr->ghist[0][0], st);
     MGC_CHECK(hipGetLastError());
     hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(plan.num_passes), dim3(RS_MAX_RADIX), 0, st,
                        &hdr->ghist[0][0], &hdr->gbase[0][0]);
