@@ -312,15 +312,17 @@ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 
 // Pass 2: pack + scatter.  Each workgroup owns private cursors (from pass 1),
 // so there are no global atomics and the result layout is deterministic up to
 // the order inside a (workgroup, tile, bucket) run.
-template <typename K>
-__global__ __launch_bounds__(KP_BLOCK)
+// MAXB: bucket capacity of the LDS tables (64 for the 64-file partition of the count path: 36 KiB of LDS per
+// workgroup instead of 51, i.e. four workgroups per CU instead of three; 1024 for the general operator)
+template <typename K, int MAXB>
+__global__ __launch_bounds__(KP_BLOCK, 5)
 void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
                            u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kp_dyn_smem[];
   K *s_keys = reinterpret_cast<K *>(kp_dyn_smem);                   // K[KP_TILE]
-  __shared__ u64 s_cursor[KP_MAX_BUCKETS];
-  __shared__ u32 s_cnt[KP_MAX_BUCKETS];
-  __shared__ u32 s_base[KP_MAX_BUCKETS];
+  __shared__ u64 s_cursor[MAXB];
+  __shared__ u32 s_cnt[MAXB];
+  __shared__ u32 s_base[MAXB];
   __shared__ u32 s_codes[KP_WORDS];
   __shared__ u32 s_inval[KP_WORDS];
   __shared__ u32 s_tmp[KP_BLOCK / 64 + 1];
@@ -437,18 +439,19 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
   MGC_CHECK(hipGetLastError());
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_partition_kernel<K128>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_partition_kernel<K128, 64>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_partition_kernel<K128, KP_MAX_BUCKETS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
     attr_done = true;
   }
-  if (k <= 32)
-    hipLaunchKernelGGL(kmer_partition_kernel<u64>, dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st,
-                       d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
-                       reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys));
-  else
-    hipLaunchKernelGGL(kmer_partition_kernel<K128>, dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K128), st,
-                       d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
-                       reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K128 *>(d_keys));
+#define MGC_KP_LAUNCH(K_, MAXB_)                                                                                   \
+  hipLaunchKernelGGL((kmer_partition_kernel<K_, MAXB_>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K_), st,      \
+                     d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,                                  \
+                     reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys))
+  if (k <= 32) { if (nb <= 64) MGC_KP_LAUNCH(u64, 64); else MGC_KP_LAUNCH(u64, KP_MAX_BUCKETS); }
+  else         { if (nb <= 64) MGC_KP_LAUNCH(K128, 64); else MGC_KP_LAUNCH(K128, KP_MAX_BUCKETS); }
+#undef MGC_KP_LAUNCH
   return hipGetLastError();
 }
 
