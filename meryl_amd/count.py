@@ -384,11 +384,19 @@ def dev_count_files(keys, file_counts, k, mode=capi.MODE_CANONICAL):
     if s is None:                        # kept: the session's device arena is grow-only, a new one would re-malloc tens of GB
         cfg = capi.configure(k, max(int(keys.shape[0]), 1) * max(k, 1), 64 << 30, mode)
         s = _SESSIONS[(k, mode, dev)] = Session(cfg, dev)
+    if SHARD_PROFILE is not None:
+        s.set_profiling(True)
     s.count_partitioned(keys, file_counts)
+    if SHARD_PROFILE is not None:
+        p = s.profile()
+        SHARD_PROFILE["pass_ms"] = SHARD_PROFILE.get("pass_ms", 0.0) + p.sort_pass_ms_total
+        SHARD_PROFILE["pass_launches"] = SHARD_PROFILE.get("pass_launches", 0) + p.sort_pass_launches
+        SHARD_PROFILE["pass_keys"] = SHARD_PROFILE.get("pass_keys", 0) + p.sort_pass_keys
     return s.result_device()
 
 
 _SESSIONS = {}
+SHARD_PROFILE = None        # bench.py sets this to a dict to collect the owner-side pass timings of the timed steps
 
 
 def release_cached_sessions():
