@@ -2394,6 +2394,149 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 #undef HC_STAMP
 }
 
+// Same scheme with 64-bit suffixes, for sub-buckets whose keys differ in 32..62 low bits (k from about 28 at the
+// 10 Gbp scale): 64-bit CAS, whole keys loaded, 42 KiB of LDS (3 workgroups per CU).
+template <int BLOCK, int CAP, int SLOTS>
+__global__ __launch_bounds__(BLOCK, 3)
+void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
+                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct) {
+  constexpr bool DBG = false;
+  u64 *dbg = nullptr;
+  // Inside a sub-bucket the keys differ only in their low `low_bits` (< 32) bits: the table holds
+  // 32-bit suffixes (half the LDS, 32-bit CAS and compares); the common prefix is added back on output.
+  // Persistent workgroups: the keys of the next sub-bucket are loaded while the current one is counted
+  // (a sub-bucket is ~1K keys, so the two dependent HBM round trips would otherwise be a third of its time).
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
+  constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
+  constexpr u64 EMPTY = ~0ull;                         // suffixes are < 2^63
+  __shared__ __attribute__((aligned(16))) u64 tk[SLOTS];
+  __shared__ __attribute__((aligned(16))) u32 tc[SLOTS];
+  __shared__ __attribute__((aligned(16))) u64 dk[CAP + 16];
+  __shared__ u32 dc[CAP];
+  __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  const u32 tid = threadIdx.x;
+  const u64 G = gridDim.x;
+  const u64 low_mask = (1ull << low_bits) - 1ull;
+
+  auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
+    aa = 0; nn = 0;
+    if (gg < ng) { aa = starts[gg]; nn = starts[gg + 1] - aa; }
+  };
+  // only the low dword of a key is needed: the rest is the file's prefix and the sub-bucket index
+  auto load_keys = [&](u64 aa, u64 nn, u64 (&kr)[KPT]) {
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 idx = (u32)j * BLOCK + tid;
+      kr[j] = (nn <= max_size && idx < nn) ? keys[aa + idx] : 0ull;
+    }
+  };
+  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
+  const u64 file_base = (keys[0] >> group_shift) << group_shift;
+
+  u64 g = blockIdx.x, a, n64, na, nn;
+  u64 kcur[KPT];
+  load_bounds(g, a, n64);
+  load_keys(a, n64, kcur);
+  load_bounds(g + G, na, nn);
+
+  u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define HC_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
+  while (g < ng) {
+    u64 knext[KPT];
+    u64 nna, nnn;
+    if (DBG) t0 = __builtin_readcyclecounter();
+    load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
+    load_bounds(g + 2 * G, nna, nnn);
+
+    if (n64 == 0) {
+      if (tid == 0) group_distinct[g] = 0;
+    } else if (n64 <= max_size) {                      // larger ones: a larger-capacity launch takes them
+      const u32 n = (u32)n64;
+      const u64 prefix = file_base | (g << low_bits);
+      u64 kk[KPT];
+      u32 hh[KPT];
+      u32 pending = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 idx = (u32)j * BLOCK + tid;
+        kk[j] = kcur[j] & low_mask;
+        if (idx < n) pending |= 1u << j;
+      }
+      // table sized to the sub-bucket (load factor <= 0.8 even if every key is distinct): the clear and the
+      // compaction below walk the table, so an oversized one costs more than the longer probes of a full one
+      u32 slots = 256;
+      while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
+      const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
+      {
+        for (u32 i = tid; i < slots; i += BLOCK) { tk[i] = EMPTY; tc[i] = 0u; }
+      }
+#pragma unroll
+      for (int j = 0; j < KPT; j++) hh[j] = (u32)((kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
+      __syncthreads();
+      HC_STAMP(0);
+
+      // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
+      while (pending) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if ((pending >> j) & 1u) {
+            const u64 old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
+            if (old == EMPTY || old == kk[j]) { atomicAdd(&tc[hh[j]], 1u); pending &= ~(1u << j); }
+            else hh[j] = (hh[j] + 1) & smask;
+          }
+        }
+      }
+      __syncthreads();
+      HC_STAMP(1);
+
+      // compact the occupied slots (any order)
+      u32 occ = 0;
+#pragma unroll
+      for (int j = 0; j < SPT; j++) {
+        const u32 sl = (u32)j * BLOCK + tid;
+        if (sl < slots) occ |= (tc[sl] != 0u ? 1u : 0u) << j;
+      }
+      u32 D;
+      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+#pragma unroll
+      for (int j = 0; j < SPT; j++)
+        if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
+      if (tid < 16) dk[D + tid] = EMPTY;               // padding of the rank loop (D is block-uniform)
+      __syncthreads();
+      HC_STAMP(2);
+
+      // rank = number of smaller distinct suffixes (all pairs, two 16-byte broadcast reads per iteration)
+      u64 *gk = keys + a;
+      const u32 d4 = (D + 3) / 4;
+      const ulonglong2 *dk2 = reinterpret_cast<const ulonglong2 *>(dk);
+      for (u32 i = tid; i < D; i += BLOCK) {
+        const u64 ki = dk[i];
+        u32 r0 = 0, r1 = 0;
+        for (u32 j = 0; j < d4; j++) {
+          const ulonglong2 v0 = dk2[2 * j], v1 = dk2[2 * j + 1];
+          r0 += (v0.x < ki ? 1u : 0u) + (v0.y < ki ? 1u : 0u);
+          r1 += (v1.x < ki ? 1u : 0u) + (v1.y < ki ? 1u : 0u);
+        }
+        const u32 r = r0 + r1;
+        gk[r] = prefix | ki;                           // in place: every key of this region sits in registers
+        cnt_tmp[a + r] = dc[i];
+      }
+      if (tid == 0) group_distinct[g] = D;
+      HC_STAMP(3);
+      __syncthreads();                                 // dk/dc/s_tmp are reused by the next sub-bucket
+      HC_STAMP(4);
+    }
+
+#pragma unroll
+    for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
+    a = na; n64 = nn; na = nna; nn = nnn; g += G;
+    if (DBG) { ph[5] += kcur[0] & 1; HC_STAMP(6); ph[7]++; }   // [6]: wait for the prefetched keys
+  }
+  if (DBG && tid == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
+#undef HC_STAMP
+}
+
 // offs = exclusive scan of group_distinct (offs[ng] = total).  One wave per sub-bucket.
 template <typename K>
 __global__ __launch_bounds__(256)
@@ -2415,7 +2558,8 @@ constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count 
 
 static bool finish_uses_hash(uint32_t key_words, uint32_t low_bits) {
   static const bool use_hash = !(getenv("MGC_FINISH_HASH") && getenv("MGC_FINISH_HASH")[0] == '0');
-  return key_words == 1 && use_hash && low_bits < 32;
+  static const bool use_hash64 = !(getenv("MGC_FINISH_HASH64") && getenv("MGC_FINISH_HASH64")[0] == '0');
+  return key_words == 1 && use_hash && (low_bits < 32 || (use_hash64 && low_bits <= 58));
 }
 // capacity of the first (small) launch of launch_finish_file; larger sub-buckets go on the list
 static uint64_t finish_small_capacity(uint32_t key_words, uint32_t low_bits);
@@ -2493,7 +2637,11 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     // <= FIN_CAP_HASH keys: hash-count; larger sub-buckets: LDS radix passes in the 8192-key instantiation
     static const uint32_t hgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 10u;
     const uint32_t hgrid = ng < hgrid_max ? (uint32_t)ng : hgrid_max;
-    if (hash_dbg_buffer())
+    if (low_bits >= 32)
+      hipLaunchKernelGGL((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048>), dim3(hgrid), dim3(256), 0, st,
+                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
+    else if (hash_dbg_buffer())
       hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true>), dim3(hgrid), dim3(256), 0, st,
                          reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
                          d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), hash_dbg_buffer());
