@@ -2537,6 +2537,157 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
 #undef HC_STAMP
 }
 
+// Hash-count finish for 16-byte keys (k = 33..64).  The suffix of a key inside its sub-bucket may be wider than any
+// LDS compare-and-swap, so a slot is claimed through its COUNT word instead: 0 = empty, LOCK = being written,
+// n >= 1 = valid with n instances.  A thread that finds LOCK simply stays pending for the next round (rounds, not
+// spinning: the lane holding the lock may sit in the same wave).  WIDE = the suffix needs the high word too
+// (low_bits > 64); otherwise the hi arrays are not even allocated.
+template <int BLOCK, int CAP, int SLOTS, bool WIDE>
+__global__ __launch_bounds__(BLOCK, WIDE ? 2 : 3)
+void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
+                          u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct) {
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
+  constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
+  constexpr u32 LOCK = 0xFFFFFFFFu;
+  __shared__ u64 tlo[SLOTS];
+  __shared__ u64 thi[WIDE ? SLOTS : 1];
+  __shared__ u32 tc[SLOTS];
+  __shared__ __attribute__((aligned(16))) u64 dlo[CAP + 4];
+  __shared__ __attribute__((aligned(16))) u64 dhi[WIDE ? CAP + 4 : 2];
+  __shared__ u32 dc[CAP];
+  __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  using KO = KeyOps<K128>;
+  const u32 tid = threadIdx.x;
+  const u64 G = gridDim.x;
+  const u128 low_mask = (low_bits >= 128) ? ~(u128)0 : (((u128)1 << low_bits) - 1);
+  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
+  const u128 file_base = (group_shift >= 128) ? (u128)0 : ((KO::v(keys[0]) >> group_shift) << group_shift);
+
+  auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
+    aa = 0; nn = 0;
+    if (gg < ng) { aa = starts[gg]; nn = starts[gg + 1] - aa; }
+  };
+  auto load_keys = [&](u64 aa, u64 nn, K128 (&kr)[KPT]) {
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 idx = (u32)j * BLOCK + tid;
+      if (nn <= max_size && idx < nn) kr[j] = keys[aa + idx]; else kr[j] = KO::zero();
+    }
+  };
+
+  u64 g = blockIdx.x, a, n64, na, nn;
+  K128 kcur[KPT];
+  load_bounds(g, a, n64);
+  load_keys(a, n64, kcur);
+  load_bounds(g + G, na, nn);
+
+  while (g < ng) {
+    K128 knext[KPT];
+    u64 nna, nnn;
+    load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
+    load_bounds(g + 2 * G, nna, nnn);
+
+    if (n64 == 0) {
+      if (tid == 0) group_distinct[g] = 0;
+    } else if (n64 <= max_size) {
+      const u32 n = (u32)n64;
+      const u128 prefix = file_base | ((u128)g << low_bits);
+      u64 klo[KPT], khi[KPT];
+      u32 hh[KPT];
+      u32 pending = 0;
+      u32 slots = 256;
+      while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
+      const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 idx = (u32)j * BLOCK + tid;
+        const u128 sfx = KO::v(kcur[j]) & low_mask;
+        klo[j] = (u64)sfx; khi[j] = (u64)(sfx >> 64);
+        const u64 mix = (klo[j] ^ (khi[j] * 0xD6E8FEB86659FD93ull)) * 0x9E3779B97F4A7C15ull;
+        hh[j] = (u32)(mix >> 32) >> sshift;
+        if (idx < n) pending |= 1u << j;
+      }
+      for (u32 i = tid; i < slots; i += BLOCK) tc[i] = 0u;
+      __syncthreads();
+
+      while (pending) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if ((pending >> j) & 1u) {
+            const u32 h = hh[j];
+            const u32 old = atomicCAS(&tc[h], 0u, LOCK);
+            if (old == 0u) {                           // the slot is ours: fill it, then publish it with count 1
+              tlo[h] = klo[j];
+              if (WIDE) thi[h] = khi[j];
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+              __hip_atomic_store(&tc[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              pending &= ~(1u << j);
+            } else if (old != LOCK) {                  // valid: same suffix -> count it, another one -> probe on
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              const bool same = (tlo[h] == klo[j]) && (!WIDE || thi[h] == khi[j]);
+              if (same) { atomicAdd(&tc[h], 1u); pending &= ~(1u << j); }
+              else hh[j] = (h + 1) & smask;
+            }                                          // LOCK: somebody is writing this slot; look again next round
+          }
+        }
+      }
+      __syncthreads();
+
+      // compact the occupied slots (any order)
+      u32 occ = 0;
+#pragma unroll
+      for (int j = 0; j < SPT; j++) {
+        const u32 sl = (u32)j * BLOCK + tid;
+        if (sl < slots) occ |= (tc[sl] != 0u ? 1u : 0u) << j;
+      }
+      u32 D;
+      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+#pragma unroll
+      for (int j = 0; j < SPT; j++) {
+        if ((occ >> j) & 1u) {
+          const u32 sl = (u32)j * BLOCK + tid;
+          dlo[o] = tlo[sl];
+          if (WIDE) dhi[o] = thi[sl];
+          dc[o] = tc[sl];
+          o++;
+        }
+      }
+      if (tid < 4) { dlo[D + tid] = ~0ull; if (WIDE) dhi[D + tid] = ~0ull; }
+      __syncthreads();
+
+      // rank = number of smaller distinct suffixes
+      K128 *gk = keys + a;
+      const u32 d4 = (D + 3) / 4;                      // the arrays are padded with all-ones (never smaller) to 4
+      const ulonglong2 *dlo2 = reinterpret_cast<const ulonglong2 *>(dlo);
+      const ulonglong2 *dhi2 = reinterpret_cast<const ulonglong2 *>(dhi);
+      for (u32 i = tid; i < D; i += BLOCK) {
+        const u64 li = dlo[i], hi = WIDE ? dhi[i] : 0ull;
+        u32 r0 = 0, r1 = 0;
+        for (u32 j = 0; j < d4; j++) {
+          const ulonglong2 a0 = dlo2[2 * j], a1 = dlo2[2 * j + 1];
+          if (WIDE) {
+            const ulonglong2 b0 = dhi2[2 * j], b1 = dhi2[2 * j + 1];
+            r0 += (((b0.x < hi) || (b0.x == hi && a0.x < li)) ? 1u : 0u) + (((b0.y < hi) || (b0.y == hi && a0.y < li)) ? 1u : 0u);
+            r1 += (((b1.x < hi) || (b1.x == hi && a1.x < li)) ? 1u : 0u) + (((b1.y < hi) || (b1.y == hi && a1.y < li)) ? 1u : 0u);
+          } else {
+            r0 += (a0.x < li ? 1u : 0u) + (a0.y < li ? 1u : 0u);
+            r1 += (a1.x < li ? 1u : 0u) + (a1.y < li ? 1u : 0u);
+          }
+        }
+        const u32 r = r0 + r1;
+        gk[r] = KO::mk(prefix | ((u128)hi << 64) | (u128)li);   // in place: every key of this region sits in registers
+        cnt_tmp[a + r] = dc[i];
+      }
+      if (tid == 0) group_distinct[g] = D;
+      __syncthreads();                                 // the tables are reused by the next sub-bucket
+    }
+
+#pragma unroll
+    for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
+    a = na; n64 = nn; na = nna; nn = nnn; g += G;
+  }
+}
+
 // offs = exclusive scan of group_distinct (offs[ng] = total).  One wave per sub-bucket.
 template <typename K>
 __global__ __launch_bounds__(256)
@@ -2559,6 +2710,8 @@ constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count 
 static bool finish_uses_hash(uint32_t key_words, uint32_t low_bits) {
   static const bool use_hash = !(getenv("MGC_FINISH_HASH") && getenv("MGC_FINISH_HASH")[0] == '0');
   static const bool use_hash64 = !(getenv("MGC_FINISH_HASH64") && getenv("MGC_FINISH_HASH64")[0] == '0');
+  static const bool use_hash128 = !(getenv("MGC_FINISH_HASH128") && getenv("MGC_FINISH_HASH128")[0] == '0');
+  if (key_words == 2) return use_hash && use_hash128 && low_bits <= 122;
   return key_words == 1 && use_hash && (low_bits < 32 || (use_hash64 && low_bits <= 58));
 }
 // capacity of the first (small) launch of launch_finish_file; larger sub-buckets go on the list
@@ -2627,6 +2780,21 @@ static void hash_dbg_report(hipStream_t st, uint64_t ng) {
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
                               hipStream_t st) {
+  if (key_words == 2 && finish_uses_hash(key_words, low_bits)) {
+    static const uint32_t wgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 6u;
+    const uint32_t wgrid = ng < wgrid_max ? (uint32_t)ng : wgrid_max;
+    if (low_bits > 64)
+      hipLaunchKernelGGL((hash_count128_kernel<256, (int)FIN_CAP_HASH, 2048, true>), dim3(wgrid), dim3(256), 0, st,
+                         reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
+    else
+      hipLaunchKernelGGL((hash_count128_kernel<256, (int)FIN_CAP_HASH, 2048, false>), dim3(wgrid), dim3(256), 0, st,
+                         reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
+    MGC_CHECK(hipGetLastError());
+    MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, 8192, d_cnt_tmp, d_group_distinct, st, d_large_list)));
+    return hipSuccess;
+  }
   if (key_words == 2) {
     // 16-byte keys: 256x8 (2048) and 1024x8 (8192) keep LDS at 32 / 128 KiB
     MGC_CHECK((finish_launch<K128, 256, 8>(d_keys, d_starts, ng, low_bits, 0, 2048, d_cnt_tmp, d_group_distinct, st)));
@@ -2662,15 +2830,15 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
 }
 
 static uint64_t finish_small_capacity(uint32_t key_words, uint32_t low_bits) {
-  if (key_words == 2) return 2048;
+  if (key_words == 2) return finish_uses_hash(key_words, low_bits) ? FIN_CAP_HASH : 2048;
   return finish_uses_hash(key_words, low_bits) ? FIN_CAP_HASH : FIN_CAP_SMALL;
 }
 
 uint64_t finish_capacity_for(uint32_t key_words) { return key_words == 2 ? 8192 : FIN_CAP_LARGE; }
 uint64_t finish_target_for(uint32_t key_words) {
   if (const char *t = getenv("MGC_FINISH_TARGET")) return strtoull(t, nullptr, 10);
-  if (key_words == 2) return 1024;
   const char *h = getenv("MGC_FINISH_HASH");
+  if (key_words == 2) return (h && h[0] == '0') ? 1024 : FIN_CAP_HASH / 2;     // measured at k=51: 768 beats 512 and 1152
   return (h && h[0] == '0') ? FIN_CAP_SMALL / 2 : (FIN_CAP_HASH * 3) / 4;
 }
 
