@@ -103,3 +103,32 @@ def test_cli_count_print_roundtrip(meryl, oracle_lib, tmp_path):
     _, wlo2, wcn2, _ = oracle_lib.count_brute(oracle_lib.compress_stream(bases), 15)
     assert np.array_equal(lo, wlo2) and np.array_equal(cn, wcn2)
     r.close()
+
+
+@pytest.mark.gpu
+def test_cli_device_parser_refusal_falls_back_to_host_parser(meryl, oracle_lib, tmp_path):
+    # multi-line FASTQ (sequence and qualities wrapped) is not what the device parser accepts: the CLI must notice
+    # (MGC_EFORMAT), drop that file's partial output and re-read it with the host state machine -- same database as
+    # with MERYL_HOST_PARSER=1 and as the oracle; a well-formed file in the same run still goes through the device
+    from meryl_amd import db
+    bases = oracle_lib.synth_reads(21, 50_000, 0, 2000).tobytes()
+    reads = [r for r in bases.decode().split(".") if r]
+    wrapped = tmp_path / "wrapped.fastq"
+    with open(wrapped, "w") as f:
+        for i, r in enumerate(reads[:1000]):
+            q = "@" + "I" * (len(r) - 1)                             # quality line starting with '@'
+            f.write("@w%d\n%s\n%s\n+\n%s\n%s\n" % (i, r[:80], r[80:], q[:80], q[80:]))
+    plain = tmp_path / "plain.fastq"
+    with open(plain, "w") as f:
+        for i, r in enumerate(reads[1000:]):
+            f.write("@p%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)))
+    _, wlo, wcn, wni = oracle_lib.count_brute(bases, 21)
+    for env in ({}, {"MERYL_HOST_PARSER": "1"}):
+        out = tmp_path / ("out%d.meryl" % len(env))
+        p = subprocess.run([str(meryl), "-Q", "k=21", "memory=2", "threads=4", "count", str(wrapped), str(plain), "output", str(out)],
+                           capture_output=True, text=True, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr
+        r = db.Reader(str(out))
+        lo, hi, cn = r.read_all()
+        assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn) and r.info.num_total == wni
+        r.close()
