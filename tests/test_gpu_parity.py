@@ -692,3 +692,21 @@ def test_random_inputs_match_oracle(ops, oracle_lib, torch_cuda, seed):
         klo, khi, counts, _ = s.result_wide()
         assert s.info().n_instances == wni, (seed, k, mode)
     assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn), (seed, k, mode, n_reads, read_len)
+
+
+@pytest.mark.parametrize("k,n_reads", [(21, 2_000_000), (31, 700_000), (40, 500_000)])
+def test_medium_scale_matches_threaded_port(ops, oracle_lib, torch_cuda, k, n_reads):
+    # hundreds of millions of instances: files large enough for TWO grouping passes (the region-aligned second one)
+    # and thousands of sub-buckets per file, compared k-mer by k-mer with the reference-algorithm port
+    from meryl_amd import capi
+    d = ops.dev_synth_reads(11, n_reads * 5, 0, n_reads)
+    bases = d.cpu().numpy()
+    cfg = capi.configure(k, bases.size, 8 << 30)
+    with ops.Session(cfg) as s:
+        s.push_bases_device(d)
+        s.count()
+        klo, khi, counts, _ = s.result_wide()
+        info = s.info()
+    phi, plo, pcn, pni = oracle_lib.count_threaded(bases.tobytes(), k, cfg.w_prefix, 0, threads=32)
+    assert info.n_instances == pni and info.n_distinct == len(plo)
+    assert np.array_equal(klo, plo) and np.array_equal(khi, phi) and np.array_equal(counts, pcn)
