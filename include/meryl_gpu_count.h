@@ -216,6 +216,12 @@ int mgc_count(mgc_session *s);
  * The caller must have completed all writes to d_keys (synchronise the producing stream) before the call. */
 int mgc_count_partitioned(mgc_session *s, void *d_keys, const uint64_t *file_counts /*[64]*/, void *reserved);
 
+/* The same with a finer granularity: 2^bucket_bits buckets (6..10 bits: the top bucket_bits bits of the k-mer, i.e. every
+ * file cut into 2^(bucket_bits-6) ranges), bucket-major, bucket_counts[2^bucket_bits].  A node of N GPUs routes
+ * 64*N buckets so that an owner-side bucket is as large as a single-GPU file (a whole file would be N times larger
+ * and need a third grouping pass). */
+int mgc_count_buckets(mgc_session *s, void *d_keys, uint32_t bucket_bits, const uint64_t *bucket_counts);
+
 typedef struct mgc_result_info {
   uint64_t n_bases;
   uint64_t n_instances;           /* k-mer instances (sum of counts) */

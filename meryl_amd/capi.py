@@ -21,7 +21,7 @@ SYMBOLS = (
     "mgc_dev_partition_workspace_bytes", "mgc_dev_kmer_histogram", "mgc_dev_kmer_partition",
     "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort",
     "mgc_dev_rle_workspace_bytes", "mgc_dev_rle_count", "mgc_dev_rle_emit", "mgc_dev_block_offsets",
-    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_count", "mgc_count_partitioned", "mgc_copy_result_device",
+    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_copy_result_device",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_version",
     "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases",
@@ -188,6 +188,7 @@ def lib():
     sig("mgc_end_text", i32, vp)
     sig("mgc_count", i32, vp)
     sig("mgc_count_partitioned", i32, vp, vp, vp, vp)
+    sig("mgc_count_buckets", i32, vp, vp, u32, vp)
     sig("mgc_copy_result_device", i32, vp, vp, vp)
     sig("mgc_get_result_info", i32, vp, P(ResultInfo))
     sig("mgc_get_result_device", i32, vp, P(vp), P(vp), P(vp), P(u32))

@@ -191,14 +191,16 @@ class Session:
     def count(self):
         capi.check(capi.lib().mgc_count(self._h), "mgc_count", self._h)
 
-    def count_partitioned(self, keys, file_counts):
+    def count_partitioned(self, keys, bucket_counts):
         """Owner side of a sharded count: `keys` (int64[N] or int64[N, 2] cuda tensor) already hold canonical k-mers
-        laid out file-major, `file_counts` the 64 per-file counts; processed in place."""
-        fc = np.ascontiguousarray(np.asarray(file_counts, dtype=np.uint64))
-        assert fc.size == capi.NUM_FILES and int(fc.sum()) == keys.shape[0]
+        laid out bucket-major; `bucket_counts` has 64 entries (files) or 2^b, b in 7..10 (finer ranges of the top bits);
+        processed in place."""
+        fc = np.ascontiguousarray(np.asarray(bucket_counts, dtype=np.uint64))
+        bits = int(fc.size).bit_length() - 1
+        assert fc.size == (1 << bits) and 6 <= bits <= 10 and int(fc.sum()) == keys.shape[0]
         torch.cuda.current_stream(keys.device).synchronize()
-        capi.check(capi.lib().mgc_count_partitioned(self._h, _ptr(keys) if keys.shape[0] else None, fc.ctypes.data, None),
-                   "mgc_count_partitioned", self._h)
+        capi.check(capi.lib().mgc_count_buckets(self._h, _ptr(keys) if keys.shape[0] else None, bits, fc.ctypes.data),
+                   "mgc_count_buckets", self._h)
 
     def result_device(self):
         """(distinct keys, counts int32) as fresh cuda tensors (device-to-device copy)."""
@@ -377,8 +379,9 @@ def exchange_segments(sends, recvs, device, group=None, chunk=None, max_rows=Non
 
 
 def dev_count_files(keys, file_counts, k, mode=capi.MODE_CANONICAL):
-    """(distinct keys ascending, counts int32) of k-mers already laid out file-major (`file_counts`: 64 entries).
-    Everything mgc_count does after the partition, in place on `keys` (mgc_count_partitioned)."""
+    """(distinct keys ascending, counts int32) of k-mers already laid out bucket-major (`file_counts`: 64 entries for
+    whole files, 2^b for finer buckets).  Everything mgc_count does after the partition, in place on `keys`
+    (mgc_count_buckets)."""
     dev = keys.device.index if keys.device.index is not None else torch.cuda.current_device()
     s = _SESSIONS.get((k, mode, dev))
     if s is None:                        # kept: the session's device arena is grow-only, a new one would re-malloc tens of GB
@@ -418,17 +421,28 @@ class HipOps:
         return _u64(n, like.device)
 
 
+def shard_bucket_bits(world, k):
+    """Top bits of the k-mer that route it in a `world`-rank count: 6 (the files) + ceil(log2(world)), at most 10."""
+    extra = max(0, (int(world) - 1).bit_length())
+    if os.environ.get("MGC_SHARD_BITS"):                   # experiments: the granularity of an N-rank run on fewer ranks
+        extra = int(os.environ["MGC_SHARD_BITS"]) - 6
+    return max(6, min(10, 6 + extra, 2 * int(k)))
+
+
 def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
     """Collective.  Every rank passes ITS OWN reads (uint8 tensor on its GPU);
     returns this rank's share of the database: (unique keys, counts int32,
-    (first_file, end_file)).  The concatenation over ranks, in rank order, is
+    (first_bucket, end_bucket, bucket_bits)).  The concatenation over ranks, in rank order, is
     the ascending (key, count) stream a single-GPU count of all reads gives.
     `ops` exists so the routing logic can be exercised without a GPU (the gloo
     tests inject CPU stand-ins); the product default is the HIP operators.
 
-    Layout after the exchange is file-major -- for every owned file, the pieces of all source
-    ranks back to back -- so each file is one contiguous bucket that goes through the grouping passes
-    and the LDS finish exactly like a file of the single-GPU path (mgc_count_partitioned)."""
+    The unit of routing is a BUCKET = a range of the top `bucket_bits` bits of the k-mer: the 64 files for one rank,
+    every file cut into 2, 4, 8 ... ranges for 2, 4, 8 ... ranks (shard_bucket_bits), so that an owner-side bucket
+    is as large as a single-GPU file however many GPUs feed it (a whole file would be N times larger: a third grouping
+    pass, and past 2^30 k-mers the stable wide-granule passes).  Layout after the exchange is bucket-major -- for
+    every owned bucket, the pieces of all source ranks back to back -- and each bucket goes through the grouping
+    passes and the LDS finish exactly like a file of the single-GPU path (mgc_count_buckets)."""
     import torch.distributed as dist
     import time as _time
     world = dist.get_world_size(group)
@@ -442,14 +456,16 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
             marks.append((name, _time.perf_counter()))
 
     mark("start")
-    keys, local_counts = ops.partition(bases, k, mode, 6)                        # grouped by file, ascending
+    bits = shard_bucket_bits(world, k)
+    nbk = 1 << bits
+    keys, local_counts = ops.partition(bases, k, mode, bits)                     # grouped by bucket, ascending
     mark("partition")
     local_counts = np.asarray(local_counts).astype(np.int64)
     # one small all-gather gives every rank the same [rank][file] histogram -> same cut points
     fc = torch.from_numpy(local_counts).to(keys.device)
     all_counts = [torch.empty_like(fc) for _ in range(world)]
     dist.all_gather(all_counts, fc, group=group)
-    per_rank = torch.stack(all_counts).cpu().numpy()                             # [world][64]
+    per_rank = torch.stack(all_counts).cpu().numpy()                             # [world][2^bits]
     cuts = balanced_file_ranges(per_rank.sum(axis=0), world)
 
     f0, f1 = cuts[rank], cuts[rank + 1]
@@ -460,35 +476,36 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
     local_off = np.concatenate([[0], np.cumsum(local_counts)]).astype(np.int64)
     mark("plan")
 
-    # The exchange runs one "wave" per owned-file index: wave i carries, for every rank, the pieces of the i-th file
-    # of that rank's range.  While wave i is on the links the owner counts its file i-1 (the same grouping passes +
+    # The exchange runs in waves: wave i carries, for every rank, the pieces of the i-th group of `bpw` buckets of that
+    # rank's range.  While wave i is on the links the owner counts the buckets of wave i-1 (the same grouping passes +
     # LDS finish a single-GPU count runs after its partition), so only the first wave is exposed.  Every rank
-    # derives the same wave count and segment sizes from the gathered histogram: no further collective is needed.
-    n_waves = max(cuts[r + 1] - cuts[r] for r in range(world))
+    # derives the same wave plan and segment sizes from the gathered histogram: no further collective is needed.
+    # About 16 waves per rank: fewer would expose more of the exchange, more pay the per-call host overhead more often.
+    most = max(cuts[r + 1] - cuts[r] for r in range(world))
+    bpw = max(1, -(-most // 16))
+    n_waves = -(-most // bpw)
     parts = []
 
     def post(i):
         sends, recvs = [], []
         longest = 0
         for dst in range(world):
-            f = cuts[dst] + i
-            if f < cuts[dst + 1]:
+            for f in range(cuts[dst] + i * bpw, min(cuts[dst + 1], cuts[dst] + (i + 1) * bpw)):
                 sends.append((dst, keys[int(local_off[f]):int(local_off[f + 1])]))
                 longest = max(longest, int(per_rank[:, f].max()))
-        f = f0 + i
-        if f < f1:
+        for f in range(f0 + i * bpw, min(f1, f0 + (i + 1) * bpw)):
             for src in range(world):
-                a = int(file_off[i] + per_rank[:src, f].sum())
+                a = int(file_off[f - f0] + per_rank[:src, f].sum())
                 recvs.append((src, inbox[a:a + int(per_rank[src, f])]))
         return exchange_segments(sends, recvs, keys.device, group, max_rows=longest, wait=False)
 
     def count_file(i):
-        f = f0 + i
-        if f >= f1 or file_total[i] == 0:
+        lo, hi = f0 + i * bpw, min(f1, f0 + (i + 1) * bpw)
+        if lo >= hi or file_total[lo - f0:hi - f0].sum() == 0:
             return
-        fc64 = np.zeros(capi.NUM_FILES, dtype=np.uint64)
-        fc64[f] = file_total[i]
-        parts.append(ops.count_files(inbox[int(file_off[i]):int(file_off[i + 1])], fc64, k, mode))
+        bc = np.zeros(nbk, dtype=np.uint64)
+        bc[lo:hi] = file_total[lo - f0:hi - f0]
+        parts.append(ops.count_files(inbox[int(file_off[lo - f0]):int(file_off[hi - f0])], bc, k, mode))
 
     for i in range(n_waves + 1):
         reqs = post(i) if i < n_waves else []
@@ -502,9 +519,9 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
         uniq = torch.cat([p[0] for p in parts])
         cnts = torch.cat([p[1] for p in parts])
     else:
-        uniq, cnts = ops.count_files(inbox, np.zeros(capi.NUM_FILES, dtype=np.uint64), k, mode)
+        uniq, cnts = ops.count_files(inbox, np.zeros(nbk, dtype=np.uint64), k, mode)
     mark("concat")
     if prof and rank == 0:
         print("[shard profile] " + "  ".join("%s %.1f ms" % (n, (t - marks[i][1]) * 1e3) for i, (n, t) in enumerate(marks[1:])),
               file=sys.stderr, flush=True)
-    return uniq, cnts, (f0, f1)
+    return uniq, cnts, (f0, f1, bits)

@@ -643,14 +643,16 @@ struct StageTimer {
 // One pass over bases that are resident in HBM (s->d_bases / s->n_bases): results stay in HBM.
 // ext_keys/ext_counts: k-mers already extracted and grouped by file by the caller (the owner side of a sharded
 // count): extraction and partition are skipped, the caller's buffer is processed in place.
-static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t *ext_counts = nullptr) {
+static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t *ext_counts = nullptr,
+                        uint32_t ext_bucket_bits = MGC_NUM_FILES_BITS) {
   s->free_result();
   HIP_TRY(s, hipSetDevice(s->device));
   hipStream_t st = s->stream;
   const mgc_count_config &c = s->cfg;
   const uint32_t k = c.k;
-  const uint32_t bucket_bits = MGC_NUM_FILES_BITS;
-  const uint32_t nb = MGC_NUM_FILES;
+  // buckets = the 64 files, or (sharded owner side) finer top-bit ranges of the k-mer: 2^bucket_bits of them
+  const uint32_t bucket_bits = ext_keys ? ext_bucket_bits : (uint32_t)MGC_NUM_FILES_BITS;
+  const uint32_t nb = 1u << bucket_bits;
   const uint32_t kw = s->key_words;
   const size_t   kbytes = sizeof(uint64_t) * kw;
   memset(&s->prof, 0, sizeof(s->prof));
@@ -680,23 +682,25 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   HIP_TRY(s, s->ensure(mgc_session::B_META, sizeof(uint64_t) * nb * 2));
   void *part_ws = s->buf[mgc_session::B_PART_WS].p;
   uint64_t *d_counts64 = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_META].p), *d_starts = d_counts64 + nb;
-  uint64_t h_counts[MGC_NUM_FILES], h_starts[MGC_NUM_FILES + 1];
+  std::vector<uint64_t> h_counts_v(nb), h_starts_v(nb + 1);
+  uint64_t *h_counts = h_counts_v.data(), *h_starts = h_starts_v.data();
   if (!ext_keys) {
     tm.begin(MGC_STAGE_HISTOGRAM);
     HIP_TRY(s, mgc::launch_kmer_histogram(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, part_ws, st));
     tm.end(MGC_STAGE_HISTOGRAM);
     s->prof.stage_launches[MGC_STAGE_HISTOGRAM] = 1;
-    HIP_TRY(s, hipMemcpyAsync(h_counts, d_counts64, sizeof(h_counts), hipMemcpyDeviceToHost, st));
+    HIP_TRY(s, hipMemcpyAsync(h_counts, d_counts64, sizeof(uint64_t) * nb, hipMemcpyDeviceToHost, st));
     HIP_TRY(s, hipStreamSynchronize(st));
   } else {
-    memcpy(h_counts, ext_counts, sizeof(h_counts));
+    memcpy(h_counts, ext_counts, sizeof(uint64_t) * nb);
   }
   uint64_t N = 0, max_bucket = 0;
+  memset(s->file_instances, 0, sizeof(s->file_instances));
   for (uint32_t b = 0; b < nb; b++) {
     h_starts[b] = N;
     N += h_counts[b];
     max_bucket = std::max(max_bucket, h_counts[b]);
-    s->file_instances[b] = h_counts[b];
+    s->file_instances[b >> (bucket_bits - MGC_NUM_FILES_BITS)] += h_counts[b];
   }
   h_starts[nb] = N;
   s->n_instances = N;
@@ -775,8 +779,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   } else {
     // ---- plan: per file, t top bits so that a sub-bucket holds ~target k-mers ----
     const uint64_t target = mgc::finish_target_for(kw), cap = mgc::finish_capacity_for(kw);
-    uint32_t top_bits[MGC_NUM_FILES];
-    uint64_t gbase[MGC_NUM_FILES + 1], sbase[MGC_NUM_FILES + 1];
+    std::vector<uint32_t> top_bits(nb);
+    std::vector<uint64_t> gbase(nb + 1), sbase(nb + 1);
     gbase[0] = sbase[0] = 0;
     for (uint32_t b = 0; b < nb; b++) {
       uint32_t t = 0;
@@ -788,7 +792,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     }
     const uint64_t ng_total = gbase[nb];
     HIP_TRY(s, s->ensure(mgc_session::B_SUBSTART, sizeof(uint64_t) * (sbase[nb] + 1)));
-    HIP_TRY(s, s->ensure(mgc_session::B_GROUPS, sizeof(uint64_t) * (ng_total + 2 + 2 * MGC_NUM_FILES)));
+    HIP_TRY(s, s->ensure(mgc_session::B_GROUPS, sizeof(uint64_t) * (ng_total + 2 + 2 * (uint64_t)nb)));
     HIP_TRY(s, s->ensure(mgc_session::B_LARGE, sizeof(uint32_t) * (ng_total + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_GSCAN, mgc::finish_scan_scratch_bytes(ng_total + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_CNT_TMP, sizeof(uint32_t) * N));
@@ -796,11 +800,11 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     uint64_t *d_substart = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_SUBSTART].p);
     uint64_t *d_group    = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_GROUPS].p);   // [ng_total+1], then max_sub[64]
     uint64_t *d_maxsub   = d_group + ng_total + 1;                  // [64] largest sub-bucket, then [64] number of large ones
-    uint64_t *d_nlarge   = d_maxsub + MGC_NUM_FILES;
+    uint64_t *d_nlarge   = d_maxsub + nb;
     uint32_t *d_large    = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_LARGE].p);
     uint32_t *d_cnt_tmp  = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_CNT_TMP].p);
     void     *rle_ws     = s->buf[mgc_session::B_RLE_WS].p;
-    HIP_TRY(s, hipMemsetAsync(d_maxsub, 0, sizeof(uint64_t) * 2 * MGC_NUM_FILES, st));
+    HIP_TRY(s, hipMemsetAsync(d_maxsub, 0, sizeof(uint64_t) * 2 * nb, st));
 
     // ---- A. global LSB passes on the top bits only ----
     tm.begin(MGC_STAGE_SORT);
@@ -828,14 +832,14 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       HIP_TRY(s, mgc::launch_subbucket_bounds(X + kbytes * h_starts[b], h_counts[b], kw, rem_bits - top_bits[b], top_bits[b],
                                               d_substart + sbase[b], d_maxsub + b, d_large + gbase[b], d_nlarge + b, st));
     }
-    uint64_t h_maxsub[2 * MGC_NUM_FILES];
-    const uint64_t *h_nlarge = h_maxsub + MGC_NUM_FILES;
-    HIP_TRY(s, hipMemcpyAsync(h_maxsub, d_maxsub, sizeof(h_maxsub), hipMemcpyDeviceToHost, st));
+    std::vector<uint64_t> h_maxsub(2 * (size_t)nb);
+    const uint64_t *h_nlarge = h_maxsub.data() + nb;
+    HIP_TRY(s, hipMemcpyAsync(h_maxsub.data(), d_maxsub, sizeof(uint64_t) * 2 * nb, hipMemcpyDeviceToHost, st));
     HIP_TRY(s, hipStreamSynchronize(st));
 
     // ---- D. finish every file: LDS sort + count, or the full-sort fallback ----
-    uint64_t h_fallback_distinct[MGC_NUM_FILES];
-    bool fallback[MGC_NUM_FILES];
+    std::vector<uint64_t> h_fallback_distinct(nb);
+    std::vector<char> fallback(nb);
     for (uint32_t b = 0; b < nb; b++) {
       fallback[b] = false;
       if (h_counts[b] == 0) continue;
@@ -1085,18 +1089,23 @@ extern "C" int mgc_count(mgc_session *s) {
   return merge_batches(s);
 }
 
-extern "C" int mgc_count_partitioned(mgc_session *s, void *d_keys, const uint64_t *file_counts, void *stream_to_wait) {
-  if (!s || !file_counts) return MGC_EINVAL;
+extern "C" int mgc_count_buckets(mgc_session *s, void *d_keys, uint32_t bucket_bits, const uint64_t *bucket_counts) {
+  if (!s || !bucket_counts || bucket_bits < MGC_NUM_FILES_BITS || bucket_bits > MGC_MAX_BUCKET_BITS || bucket_bits > 2 * s->cfg.k)
+    return MGC_EINVAL;
   uint64_t n = 0;
-  for (int f = 0; f < MGC_NUM_FILES; f++) n += file_counts[f];
+  for (uint32_t b = 0; b < (1u << bucket_bits); b++) n += bucket_counts[b];
   if (n && !d_keys) return MGC_EINVAL;
-  if (!s->host_bases.empty() || !s->batches.empty() || s->n_bases) {
-    set_err(&s->err, "mgc_count_partitioned: the session already holds pushed bases");
+  if (!s->host_bases.empty() || !s->batches.empty() || s->n_bases || s->text_mode) {
+    set_err(&s->err, "mgc_count_buckets: the session already holds pushed bases");
     return MGC_ESTATE;
   }
-  (void)stream_to_wait;                                       // the caller synchronises its producer stream (see count.py)
   s->merged = false;
-  return count_device(s, d_keys, file_counts);
+  return count_device(s, d_keys, bucket_counts, bucket_bits);
+}
+
+extern "C" int mgc_count_partitioned(mgc_session *s, void *d_keys, const uint64_t *file_counts, void *reserved) {
+  (void)reserved;
+  return mgc_count_buckets(s, d_keys, MGC_NUM_FILES_BITS, file_counts);
 }
 
 extern "C" int mgc_get_result_info(const mgc_session *s, mgc_result_info *info) {

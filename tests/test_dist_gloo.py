@@ -46,10 +46,12 @@ def _worker(rank, world, port, k, seed, q):
         def count_files(keys, file_counts, k_, mode):
             # stand-in for mgc_count_partitioned: the keys arrive file-major, each file's pieces back to back
             a = keys.numpy().view(np.uint64)
-            assert int(np.asarray(file_counts).sum()) == a.size
-            f = (a >> np.uint64(2 * k_ - 6)).astype(np.int64)
-            assert np.all(f[1:] >= f[:-1])                                    # file-major layout
-            assert np.array_equal(np.bincount(f, minlength=64).astype(np.uint64), np.asarray(file_counts, dtype=np.uint64))
+            fc = np.asarray(file_counts, dtype=np.uint64)
+            bits = int(fc.size).bit_length() - 1
+            assert fc.size == 1 << bits and int(fc.sum()) == a.size
+            f = (a >> np.uint64(2 * k_ - bits)).astype(np.int64)
+            assert np.all(f[1:] >= f[:-1])                                    # bucket-major layout
+            assert np.array_equal(np.bincount(f, minlength=fc.size).astype(np.uint64), fc)
             u, c = np.unique(a, return_counts=True)
             return torch.from_numpy(u.view(np.int64).copy()), torch.from_numpy(c.astype(np.int32))
 
@@ -63,8 +65,8 @@ def _worker(rank, world, port, k, seed, q):
     try:
         reads_per_rank = 300
         bases = oracle.synth_reads(seed, 20000, rank * reads_per_rank, reads_per_rank, 100, 5000, 100)
-        uniq, cnts, (f0, f1) = count.count_sharded(torch.from_numpy(bases), k, 0, ops=CpuOps)
-        q.put((rank, uniq.numpy().view(np.uint64).copy(), cnts.numpy().view(np.uint32).copy(), f0, f1))
+        uniq, cnts, (f0, f1, bits) = count.count_sharded(torch.from_numpy(bases), k, 0, ops=CpuOps)
+        q.put((rank, uniq.numpy().view(np.uint64).copy(), cnts.numpy().view(np.uint32).copy(), f0, f1, bits))
     finally:
         dist.destroy_process_group()
 
@@ -82,14 +84,16 @@ def test_count_sharded_equals_single(oracle_lib, world, k):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    # contiguous, disjoint, complete file ranges in rank order
-    assert got[0][3] == 0 and got[-1][4] == 64
+    # contiguous, disjoint, complete bucket ranges in rank order
+    bits = got[0][5]
+    assert all(g[5] == bits for g in got) and bits == 6 + (world - 1).bit_length()
+    assert got[0][3] == 0 and got[-1][4] == 1 << bits
     for a, b in zip(got, got[1:]):
         assert a[4] == b[3]
     keys = np.concatenate([g[1] for g in got])
     cnts = np.concatenate([g[2] for g in got])
-    for g in got:                                        # every key sits in its owner's file range
-        f = (g[1] >> np.uint64(2 * k - 6)).astype(np.int64)
+    for g in got:                                        # every key sits in its owner's bucket range
+        f = (g[1] >> np.uint64(2 * k - bits)).astype(np.int64)
         assert np.all((f >= g[3]) & (f < g[4]))
     all_bases = b"".join(oracle_lib.synth_reads(5, 20000, r * 300, 300, 100, 5000, 100).tobytes() for r in range(world))
     _, wlo, wcn, _ = oracle_lib.count_brute(all_bases, k)

@@ -451,14 +451,32 @@ def test_sharded_path_single_rank(ops, oracle_lib, torch_cuda):
     try:
         for k in (21, 51):
             bases = oracle_lib.synth_reads(13, 80_000, 0, 5000)
-            uniq, cnts, (f0, f1) = ops.count_sharded(torch_cuda.from_numpy(bases).cuda(), k)
+            uniq, cnts, (f0, f1, bits) = ops.count_sharded(torch_cuda.from_numpy(bases).cuda(), k)
             whi, wlo, wcn, _ = oracle_lib.count_brute(bases.tobytes(), k)
-            assert (f0, f1) == (0, 64)
+            assert (f0, f1, bits) == (0, 64, 6)
             want = [(int(h) << 64) | int(l) for h, l in zip(whi, wlo)]
             assert _as_int(uniq) == want
             assert np.array_equal(cnts.cpu().numpy().view(np.uint32), wcn)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,bits", [(21, 7), (21, 9), (31, 10), (40, 8), (8, 9)])
+def test_count_buckets_finer_than_files(ops, oracle_lib, torch_cuda, k, bits):
+    # the owner side of an N-GPU count receives 64*N buckets (ranges of the top 6 + log2 N bits): same stream out
+    from meryl_amd import capi
+    bases = oracle_lib.synth_reads(70 + bits, 60_000, 0, 6000)
+    keys, counts = ops.dev_kmer_partition(torch_cuda.from_numpy(bases).cuda(), k, 0, bits)
+    assert len(counts) == 1 << bits
+    cfg = capi.configure(k, bases.size, 1 << 30)
+    with ops.Session(cfg) as s:
+        s.count_partitioned(keys, counts)
+        uniq, cnts = s.result_device()
+        whi, wlo, wcn, wni = oracle_lib.count_brute(bases.tobytes(), k)
+        want = [(int(h) << 64) | int(l) for h, l in zip(whi, wlo)]
+        assert _as_int(uniq) == want and np.array_equal(cnts.cpu().numpy().view(np.uint32), wcn)
+        info = s.info()
+        assert info.n_instances == wni and int(np.sum(info.file_instances)) == wni
 
 
 def test_count_partitioned_contract(ops, oracle_lib, torch_cuda):
