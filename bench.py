@@ -5,18 +5,21 @@ whole job) for the `meryl count` hot path on MI355X.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R]
 
 A "step" is one full pass of the hot path (per-file histogram -> pack+scatter ->
-per-file LSB radix sort -> run-length count -> block offsets) over one batch of
-synthetic reads that is already resident in HBM when the timed region starts.
+per-file radix grouping passes on the top bits -> LDS hash-count of every sub-bucket
+-> compaction -> block offsets) over one batch of synthetic reads that is already
+resident in HBM when the timed region starts.
 Default workload = BASELINE.json configs[1]: k=21, 10 Gbp of synthetic 150 bp
 reads (30x of a 333,333,334 bp genome, 0.5 % substitutions, 0.01 % N) on one
 MI355X.  With --gpus N (launched by torch.distributed.run, one rank per GPU)
-every rank counts the same amount of its own reads (weak scaling); the 64 files
-are cut into contiguous per-rank ranges and k-mers are routed to their owner by
-one all_to_all over RCCL/xGMI.
+every rank brings the same amount of its own reads (weak scaling: 30x of a genome
+that grows with N); the 64*N top-bit buckets are cut into contiguous per-rank ranges
+and k-mers are routed to their owner in point-to-point waves over RCCL/xGMI while
+the owner counts the buckets that have arrived.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the
-radix scatter pass (algorithmic 8 B read + 8 B write per key), timed with HIP
-events on the library's own stream during the timed steps.  `cpu_baseline` is
+radix grouping pass (algorithmic 8 B read + 8 B write per key), timed with HIP
+events on the library's own stream during the timed steps; `traffic` is the PMC
+measurement committed under profiles/ for this same workload.  `cpu_baseline` is
 the CPU restatement of the reference algorithm (oracle/, kind "port") timed on
 this box's host cores over a bounded sample of the same workload shape.
 """
@@ -113,7 +116,7 @@ def main():
     build.build()
     capi.lib()
 
-    # MGC_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (partition -> all_to_all -> owner sort) even
+    # MGC_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (partition -> exchange waves -> owner-side count) even
     # with a single rank, so that it can be exercised on a 1-GPU box
     force_sharded = os.environ.get("MGC_BENCH_FORCE_SHARDED", "0") == "1"
     dist = None

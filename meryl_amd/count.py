@@ -4,10 +4,11 @@ native library (include/meryl_gpu_count.h) does all the work.
 Single GPU : `Session` (mgc_open / mgc_push_bases[_device] / mgc_count / ...)
              or the stateless `dev_*` operators on torch tensors.
 Multi GPU  : `count_sharded` -- one process per GPU; every rank packs its own
-             reads, the 64 files are split into contiguous per-rank ranges and
-             k-mers are routed to their owning rank with all_to_all_single
-             (RCCL on GPUs, gloo in the CPU tests), then each rank sorts and
-             run-length counts the files it owns.
+             reads, the 64*N top-bit buckets are split into contiguous per-rank
+             ranges and k-mers are routed to their owning rank in waves of
+             point-to-point messages (RCCL on GPUs, gloo in the CPU tests) while
+             the owner counts the buckets that have already arrived
+             (mgc_count_buckets).
 """
 import ctypes
 import os
@@ -288,7 +289,7 @@ def count_bases(bases, k, mode=capi.MODE_CANONICAL, n_estimate=None, memory_gb=4
 
 
 # ---------------------------------------------------------------------------
-# multi-GPU: contiguous file ranges per rank + all_to_all
+# multi-GPU: contiguous bucket ranges per rank + point-to-point waves
 # ---------------------------------------------------------------------------
 def balanced_file_ranges(file_counts, world):
     """Contiguous ranges of the 64 files, one per rank, cut so that every rank
