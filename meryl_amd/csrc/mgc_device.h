@@ -32,9 +32,9 @@ struct SortPlan {
   uint32_t kpt;             // keys per thread
   uint32_t tile;            // block*kpt
   uint32_t mode;            // 0 = onesweep (decoupled look-back), 1 = classic (tile histogram + scan),
-                            // 2 = hybrid (first pass classic off the shared histogram read, later passes look-back)
+                            // 3 = grouping passes (not a sort: see radix_group_kernel; at most two digits)
   uint32_t match;           // 0 = ballot match, 1 = LDS mask match (ranking inside a wave)
-  uint32_t lookback;        // 1 = walk before the LDS exchange, 2 = window after it
+  uint32_t lookback;        // 1 = walk before the LDS exchange, 2 = window after it, 5 = pipelined persistent kernel
   uint32_t flags;           // bit1: non-temporal key loads (experiments)
   void    *dbg;             // optional device buffer: 8 cycle stamps per tile of the LAST pass launched
   uint32_t num_passes;

@@ -790,50 +790,6 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
   __syncthreads();                          // keys now live in LDS only: registers are free for the look-back
   MGC_STAMP(4);
 
-  if constexpr (LB == 4) {
-    // Look-back after the exchange (keys live in LDS, registers are free): every digit-pair thread
-    // walks its own granule column with LB4_BATCH predecessors in flight per round -- one fabric
-    // round trip (~2 us under load) retires up to LB4_BATCH tiles, no LDS staging, no barriers.
-    constexpr int LB4_BATCH = 32;
-    if (tid < (u32)G) {
-      const u32 c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
-      u32 p0 = 0, p1 = 0;
-      if (tile != 0) {
-        bool need0 = true, need1 = true;
-        u64  t = tile - 1;
-        u32  spins = 0;
-        while (need0 || need1) {
-          u64 gv[LB4_BATCH];
-#pragma unroll
-          for (int i = 0; i < LB4_BATCH; i++)
-            gv[i] = (t >= (u64)i) ? status_load(status + (t - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
-          u32 used = 0;
-          bool open = true;
-#pragma unroll
-          for (int i = 0; i < LB4_BATCH; i++) {
-            const u32 lo = (u32)gv[i], hi = (u32)(gv[i] >> 32);
-            const u32 f0 = lo >> 30, f1 = hi >> 30;
-            open = open && (need0 || need1) && (f0 != 0) && (f1 != 0);
-            if (open) {
-              if (need0) { p0 += lo & 0x3FFFFFFFu; if (f0 == 2) need0 = false; }
-              if (need1) { p1 += hi & 0x3FFFFFFFu; if (f1 == 2) need1 = false; }
-              used++;
-            }
-          }
-          t -= (used <= t) ? used : t;
-          if (used == 0) {
-            if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
-      }
-      s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
-      s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
-    }
-    __syncthreads();
-  }
-
   if constexpr (LB == 2 || LB == 3) {
     // window-parallel look-back after the exchange (keys live in LDS only, registers are free):
     // all waves fetch the granules of the next LB_WINDOW predecessors with coalesced loads into
@@ -1374,46 +1330,6 @@ void radix_tile_hist_kernel(const K *__restrict__ in, u64 n, u32 shift, u32 dmas
   for (u32 i = tid; i < (u32)R; i += BLOCK) tile_hist[(u64)i * num_tiles + blockIdx.x] = s_h[i];
 }
 
-// Hybrid mode: the per-tile histogram of the FIRST pass and the global digit histograms of the later
-// passes in one read of the keys (persistent workgroups; the later-pass counters stay in LDS until the end).
-template <typename K, int RB, int BLOCK, int KPT>
-__global__ __launch_bounds__(BLOCK)
-void radix_tile_hist_fused_kernel(const K *__restrict__ in, u64 n, u32 shift, u32 dmask, u32 *__restrict__ tile_hist,
-                                  u64 num_tiles, PassList later, u64 *__restrict__ ghist_later) {
-  constexpr int R = 1 << RB, TILE = BLOCK * KPT;
-  __shared__ u32 s_h[R];
-  __shared__ u32 s_g[(RS_MAX_PASSES - 1) * RS_MAX_RADIX];
-  const u32 tid = threadIdx.x, nl = later.n;
-  for (u32 i = tid; i < nl * RS_MAX_RADIX; i += BLOCK) s_g[i] = 0;
-  for (u64 tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-    for (u32 i = tid; i < (u32)R; i += BLOCK) s_h[i] = 0;
-    __syncthreads();
-    const u64 tile_base = tile * TILE;
-    K key[KPT];
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      const u64 idx = tile_base + (u64)j * BLOCK + tid;
-      if (idx < n) key[j] = in[idx];
-    }
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      const u64 idx = tile_base + (u64)j * BLOCK + tid;
-      if (idx < n) {
-        atomicAdd(&s_h[KeyOps<K>::digit(key[j], shift, dmask)], 1u);
-        for (u32 p = 0; p < nl; p++)
-          atomicAdd(&s_g[p * RS_MAX_RADIX + KeyOps<K>::digit(key[j], later.shift[p], later.mask[p])], 1u);
-      }
-    }
-    __syncthreads();
-    for (u32 i = tid; i < (u32)R; i += BLOCK) tile_hist[(u64)i * num_tiles + tile] = s_h[i];
-  }
-  __syncthreads();
-  for (u32 i = tid; i < nl * RS_MAX_RADIX; i += BLOCK) {
-    const u32 v = s_g[i];
-    if (v) atomicAdd(&ghist_later[i], (u64)v);
-  }
-}
-
 // One workgroup per digit: exclusive scan of its row of tile counts (-> u64),
 // and the row total.
 __global__ __launch_bounds__(1024)
@@ -1473,9 +1389,9 @@ void make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan) {
   plan->block      = (uint32_t)block;
   plan->kpt        = (uint32_t)kpt;
   plan->tile       = plan->block * plan->kpt;
-  plan->mode       = (mode >= 1 && mode <= 3) ? (uint32_t)mode : 0u;   // 0 look-back, 1 classic, 2 hybrid, 3 grouping (finish path only)
+  plan->mode       = (mode == 1 || mode == 3) ? (uint32_t)mode : 0u;   // 0 look-back, 1 classic, 3 grouping (finish path only)
   plan->match      = env_int("MGC_SORT_MATCH", 1) ? 1u : 0u;
-  { const int lb = env_int("MGC_SORT_LB", 2); plan->lookback = (lb == 2 || lb == 4 || lb == 5) ? (uint32_t)lb : 1u; }
+  { const int lb = env_int("MGC_SORT_LB", 2); plan->lookback = (lb == 2 || lb == 5) ? (uint32_t)lb : 1u; }
   plan->flags      = (uint32_t)env_int("MGC_SORT_FLAGS", 0);
   const uint32_t nbits = (end_bit > begin_bit) ? end_bit - begin_bit : 0;
   uint32_t passes = (nbits + rb - 1) / rb;
@@ -1635,54 +1551,6 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
       K *t = src; src = dst; dst = t; in_alt ^= 1;
     }
-  } else if (plan.mode == 2) {
-    // ---- hybrid: first pass classic (its tile histograms come out of the one histogram read that
-    //      also yields the later passes' global digit counts), later passes with look-back ----
-    u32 *tile_hist = reinterpret_cast<u32 *>(body);
-    u64 *tile_offs = reinterpret_cast<u64 *>(body + (((size_t)num_tiles * R * sizeof(u32) + 255) / 256) * 256);
-    u64 *status = reinterpret_cast<u64 *>(body);
-    const size_t status_bytes = (size_t)num_tiles * (LBO == 3 ? R : R / 2) * sizeof(u64);
-    MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
-    PassList later;
-    later.n = plan.num_passes - 1;
-    for (uint32_t p = 1; p < plan.num_passes; p++) {
-      later.shift[p - 1] = plan.pass_shift[p];
-      later.mask[p - 1]  = (1u << plan.pass_bits[p]) - 1u;
-    }
-    {
-      const uint32_t shift = plan.pass_shift[0], dmask = (1u << plan.pass_bits[0]) - 1u;
-      const uint32_t hgrid = (uint32_t)(num_tiles < 512 ? num_tiles : 512);
-      hipLaunchKernelGGL((radix_tile_hist_fused_kernel<K, RB, BLOCK, KPT>), dim3(hgrid), dim3(BLOCK), 0, st,
-                         (const K *)src, (u64)n, shift, dmask, tile_hist, (u64)num_tiles, later, &hdr->ghist[1][0]);
-      MGC_CHECK(hipGetLastError());
-      hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(plan.num_passes), dim3(RS_MAX_RADIX), 0, st,
-                         &hdr->ghist[0][0], &hdr->gbase[0][0]);
-      MGC_CHECK(hipGetLastError());
-      hipLaunchKernelGGL(radix_row_scan_kernel, dim3(R), dim3(1024), 0, st, tile_hist, tile_offs,
-                         &hdr->row_total[0], (u64)num_tiles);
-      MGC_CHECK(hipGetLastError());
-      hipLaunchKernelGGL(radix_row_add_kernel, dim3((uint32_t)((num_tiles + 255) / 256), R), dim3(256), 0, st,
-                         tile_offs, &hdr->row_total[0], (u32)R, (u64)num_tiles);
-      MGC_CHECK(hipGetLastError());
-      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[0], st));
-      hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, 0, MATCH>), dim3((uint32_t)num_tiles), dim3(BLOCK),
-                         SM0::BYTES, st, (const K *)src, dst, (u64)n, shift, dmask, (const u64 *)nullptr, (u64 *)nullptr,
-                         (u32 *)nullptr, d_error, plan.flags, tile_offs, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
-      MGC_CHECK(hipGetLastError());
-      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[1], st));
-      K *t = src; src = dst; dst = t; in_alt ^= 1;
-    }
-    for (uint32_t p = 1; p < plan.num_passes; p++) {
-      MGC_CHECK(hipMemsetAsync(status, 0, status_bytes, st));
-      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
-      hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, LBO, MATCH>), dim3((uint32_t)num_tiles),
-                         dim3(BLOCK), SM::BYTES, st, (const K *)src, dst, (u64)n, plan.pass_shift[p],
-                         (1u << plan.pass_bits[p]) - 1u, &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, plan.flags,
-                         (const u64 *)nullptr, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
-      MGC_CHECK(hipGetLastError());
-      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
-      K *t = src; src = dst; dst = t; in_alt ^= 1;
-    }
   } else {
     // ---- classic: histogram / scan / scatter per pass ----
     u32 *tile_hist = reinterpret_cast<u32 *>(body);
@@ -1732,8 +1600,6 @@ hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key
       return run_passes<K_, RB_, BLOCK_, KPT_, 1, 2>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
     if (plan.lookback == 5)                                                                                  \
       return run_passes<K_, RB_, BLOCK_, KPT_, 1, 5>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
-    if (plan.lookback == 4)                                                                                  \
-      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 4>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
     return run_passes<K_, RB_, BLOCK_, KPT_, 1, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);   \
   } while (0)
   if (key_words == 2) {

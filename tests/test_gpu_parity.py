@@ -112,7 +112,6 @@ def test_radix_sort_matches_numpy(ops, torch_cuda, n, bits, monkeypatch):
                                             ("1", "8", "1", "16", "512", "1"), ("1", "9", "0", "16", "512", "1"),
                                             ("0", "8", "0", "16", "512", "1"), ("0", "8", "1", "8", "512", "2"),
                                             ("0", "8", "1", "16", "1024", "2"), ("0", "9", "1", "16", "1024", "1"),
-                                            ("2", "9", "1", "16", "1024", "2"), ("2", "8", "1", "16", "512", "2"),
                                             ("0", "9", "1", "16", "1024", "5"), ("0", "8", "1", "8", "512", "5")]:
         monkeypatch.setenv("MGC_SORT_LB", lb)
         monkeypatch.setenv("MGC_SORT_MODE", mode)
@@ -192,7 +191,7 @@ def test_radix_sort_u128_matches_numpy(ops, torch_cuda, n, bits, monkeypatch):
     mask = ((1 << (hi - lo)) - 1) << lo
     order = sorted(range(n), key=lambda i: (vals[i] & mask, i))          # stable on the selected bits
     want = [vals[i] for i in order]
-    for rb, mode, lb in (("8", "0", "2"), ("9", "0", "2"), ("8", "1", "2"), ("9", "2", "2"), ("9", "0", "5")):
+    for rb, mode, lb in (("8", "0", "2"), ("9", "0", "2"), ("8", "1", "2"), ("9", "0", "5")):
         monkeypatch.setenv("MGC_RADIX_BITS", rb)
         monkeypatch.setenv("MGC_SORT_MODE", mode)
         monkeypatch.setenv("MGC_SORT_LB", lb)
