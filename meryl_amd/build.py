@@ -13,7 +13,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmeryl_gpu_count.so")
-SOURCES = ["mgc_kernels.hip", "mgc_parse.hip", "mgc_api.cpp", "meryl_db.cpp", "meryl_seq.cpp"]
+SOURCES = ["mgc_kmer.hip", "mgc_sort.hip", "mgc_scan.hip", "mgc_finish.hip", "mgc_misc.hip", "mgc_parse.hip",
+           "mgc_api.cpp", "meryl_db.cpp", "meryl_seq.cpp"]
 HEADERS = ["mgc_device.h", os.path.join("..", "..", "include", "meryl_gpu_count.h"),
            os.path.join("..", "..", "include", "meryl_db.h"), os.path.join("..", "..", "include", "meryl_seq.h")]
 # -no-hip-rt: the library carries no DT_NEEDED on a particular libamdhip64; it binds to the

@@ -708,7 +708,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   // ---- pass 2: pack + scatter into per-file regions ----
   // Two ways from file-grouped k-mers to the (k-mer, count) stream:
   //   finish (default): LSB-sort only the top t bits of every file globally, then sort the low bits of
-  //                     every sub-bucket in LDS with the run-length count fused in (mgc_kernels.hip);
+  //                     every sub-bucket in LDS with the run-length count fused in (mgc_finish.hip);
   //   full   (MGC_FINISH=0, and the fallback for files with an oversized sub-bucket): LSB-sort all 2k-6
   //                     bits globally, then the separate run-length kernels.
   const char *fin_env = getenv("MGC_FINISH");

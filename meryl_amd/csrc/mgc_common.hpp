@@ -1,0 +1,107 @@
+// mgc_common.hpp -- shared by the gfx950 kernel translation units (mgc_kmer.hip, mgc_sort.hip,
+// mgc_finish.hip, mgc_scan.hip, mgc_misc.hip, mgc_parse.hip is self-contained).  Not installed.
+#pragma once
+#include "mgc_device.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace mgc {
+
+
+typedef unsigned long long u64;
+typedef unsigned int       u32;
+
+typedef unsigned __int128 u128;
+
+// 128-bit key (k in 33..64): little-endian halves, so memory order == integer order of lo|hi<<64
+struct alignas(16) K128 { u64 lo, hi; };
+
+template <typename K> struct KeyOps;
+template <> struct KeyOps<u64> {
+  static constexpr int WORDS = 1;
+  static __device__ __forceinline__ u32  digit(u64 k, u32 shift, u32 mask) { return (u32)(k >> shift) & mask; }
+  static __device__ __forceinline__ u32  bucket(u64 k, u32 shift) { return (u32)(k >> shift); }
+  static __device__ __forceinline__ u64  pad() { return ~0ull; }
+  static __device__ __forceinline__ u64  zero() { return 0ull; }
+  static __device__ __forceinline__ bool ne(u64 a, u64 b) { return a != b; }
+  static __device__ __forceinline__ bool lt(u64 a, u64 b) { return a < b; }
+  static __device__ __forceinline__ u64  prefix_floor(u64 p, u32 w_data) { return p << w_data; }
+};
+template <> struct KeyOps<K128> {
+  static constexpr int WORDS = 2;
+  static __device__ __forceinline__ u128 v(K128 k) { return ((u128)k.hi << 64) | (u128)k.lo; }
+  static __device__ __forceinline__ K128 mk(u128 x) { K128 k; k.lo = (u64)x; k.hi = (u64)(x >> 64); return k; }
+  static __device__ __forceinline__ u32  digit(K128 k, u32 shift, u32 mask) { return (u32)(v(k) >> shift) & mask; }
+  static __device__ __forceinline__ u32  bucket(K128 k, u32 shift) { return (u32)(v(k) >> shift); }
+  static __device__ __forceinline__ K128 pad() { K128 k; k.lo = ~0ull; k.hi = ~0ull; return k; }
+  static __device__ __forceinline__ K128 zero() { K128 k; k.lo = 0; k.hi = 0; return k; }
+  static __device__ __forceinline__ bool ne(K128 a, K128 b) { return (a.lo != b.lo) || (a.hi != b.hi); }
+  static __device__ __forceinline__ bool lt(K128 a, K128 b) { return (a.hi < b.hi) || (a.hi == b.hi && a.lo < b.lo); }
+  static __device__ __forceinline__ K128 prefix_floor(u64 p, u32 w_data) { return mk((u128)p << w_data); }
+};
+
+#define MGC_CHECK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return e__; } while (0)
+
+// ============================================================================
+//  Block-level helpers (wave = 64)
+// ============================================================================
+
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
+
+// Exclusive prefix sum over one value per thread.  s_tmp: >= BLOCK/64 + 1 entries.
+// Every thread of the block must call it.  Leaves the block total in *total.
+template <int BLOCK, typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T *s_tmp, T *total) {
+  constexpr int NW = BLOCK / 64;
+  const u32 lane = lane_id(), w = wave_id();
+  T x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T y = __shfl_up(x, d);
+    if ((int)lane >= d) x += y;
+  }
+  __syncthreads();                       // s_tmp may still be read from a previous call
+  if (lane == 63) s_tmp[w] = x;
+  __syncthreads();
+  T wave_base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    T t = s_tmp[i];
+    if (i < (int)w) wave_base += t;
+    tot += t;
+  }
+  *total = tot;
+  return wave_base + x - v;
+}
+
+typedef __attribute__((address_space(3))) u64 lds_u64;
+typedef __attribute__((address_space(3))) u32 lds_u32;
+
+__device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ bases, u64 pos, u64 n, bool aligned) {
+  if (aligned && pos + 16 <= n)
+    return *reinterpret_cast<const uint4 *>(bases + pos);
+  u32 w[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    w[i] = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const u64 p = pos + (u64)(i * 4 + b);
+      const u32 c = (p < n) ? (u32)bases[p] : (u32)'.';
+      w[i] |= c << (8 * b);
+    }
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---- multi-block scans over uint64 arrays, in place (mgc_scan.hip) ----
+//   exclusive sum        : a[i] <- sum_{j<i} a[j]; the total goes to *d_total (device, may be null)
+//   reverse inclusive min: a[i] <- min(a[i], ..., a[n-1], init)
+size_t     scan_scratch_elems(uint64_t n);                 // scratch uint64 entries either scan needs
+hipError_t scan_u64_exclusive(u64 *a, uint64_t n, u64 *scratch, u64 *d_total, hipStream_t st);
+hipError_t scan_u64_min_reverse(u64 *a, uint64_t n, u64 *scratch, u64 init, hipStream_t st);
+
+}  // namespace mgc

@@ -1,5 +1,5 @@
 // mgc_device.h -- internal launch interface between the C-ABI layer
-// (mgc_api.cpp) and the gfx950 kernels (mgc_kernels.hip).  Not installed.
+// (mgc_api.cpp) and the gfx950 kernels (mgc_kmer / mgc_sort / mgc_scan / mgc_finish / mgc_misc / mgc_parse .hip).  Not installed.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -8,7 +8,7 @@
 
 namespace mgc {
 
-// ---- k-mer extraction / partition (mgc_kernels.hip) -----------------------
+// ---- k-mer extraction / partition (mgc_kmer.hip) -----------------------
 constexpr int      KP_BLOCK       = 256;                 // threads per workgroup
 constexpr int      KP_ITEMS       = 16;                  // window starts per thread
 constexpr int      KP_TILE        = KP_BLOCK * KP_ITEMS; // 4096 starts per tile

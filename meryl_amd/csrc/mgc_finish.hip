@@ -1,0 +1,1043 @@
+// mgc_finish.hip -- run-length count, sub-bucket finish (LDS hash-count / sort), block offsets (gfx950).
+//
+// What each kernel replaces in the reference (paths relative to the reference root):
+//   kmer_hist_kernel / kmer_partition_kernel
+//       kmerIterator + insertKmers            src/meryl/merylOp-countThreads.C:235-280
+//       (2-bit pack A0 C1 T2 G3, reverse complement, canonical pick, prefix split;
+//        the per-bucket spin-lock + bit-packed append of merylCountArray.C:490-728
+//        becomes a histogram + lock-free scatter into per-file regions)
+//   radix_* kernels
+//       unpack + std::sort of each bucket      src/meryl/merylCountArray.C:276-289,330
+//   rle_* kernels
+//       the two run-length passes              src/meryl/merylCountArray.C:334-358
+//   block_offsets_kernel
+//       the per-prefix (prefix, nKmers) split that feeds addBlock
+//                                              src/meryl/merylCountArray.C:472-475
+//
+// All of it is integer / byte work bounded by HBM bandwidth: loads are 16 B (bases) or
+// 8 B per lane coalesced, every reorder is staged through LDS so stores leave as
+// contiguous runs, ranking uses 64-lane ballots, cross-workgroup prefixes use 8-byte
+// {flag,epoch,value} granules with agent-scope relaxed atomics (no fences needed:
+// the datum is the flag).  Wave = 64 everywhere.
+#include "mgc_common.hpp"
+
+namespace mgc {
+
+// ============================================================================
+//  Run-length count of sorted keys
+// ============================================================================
+
+constexpr int RL_BLOCK = 256;
+constexpr u64 RL_INF   = ~0ull;
+template <typename K> struct RlTile { static constexpr int KPT = 16; };   // 4096 keys per tile
+template <> struct RlTile<K128>     { static constexpr int KPT = 8;  };   // 2048 (static LDS stays < 64 KiB)
+
+// workspace: [0] total distinct, [8..): tile_offs u64[T+1], tile_next u64[T+1], scan scratch
+struct RleWs {
+  u64 *total, *tile_offs, *tile_next, *scratch;
+  u64  num_tiles;
+};
+static inline RleWs rle_ws(void *d_ws, uint64_t n, uint32_t key_words) {
+  const uint64_t tile = (uint64_t)RL_BLOCK * (key_words == 2 ? RlTile<K128>::KPT : RlTile<u64>::KPT);
+  RleWs w;
+  w.num_tiles = (n + tile - 1) / tile;
+  w.total     = reinterpret_cast<u64 *>(d_ws);
+  w.tile_offs = w.total + 8;
+  w.tile_next = w.tile_offs + w.num_tiles + 1;
+  w.scratch   = w.tile_next + w.num_tiles + 1;
+  return w;
+}
+size_t rle_workspace_bytes(uint64_t n) {
+  const uint64_t t = (n + 2047) / 2048;                // smallest tile in use
+  return (size_t)(8 + 2 * (t + 1) + scan_scratch_elems(t + 1)) * sizeof(uint64_t);
+}
+
+// per tile: number of run heads and position of the first head
+template <typename K>
+__global__ __launch_bounds__(RL_BLOCK)
+void rle_count_kernel(const K *__restrict__ in, u64 n, u64 *__restrict__ tile_cnt, u64 *__restrict__ tile_first) {
+  constexpr int KPT = RlTile<K>::KPT, TILE = RL_BLOCK * KPT;
+  __shared__ u32 s_cnt[RL_BLOCK / 64];
+  __shared__ u64 s_min[RL_BLOCK / 64];
+  const u64 tile_base = (u64)blockIdx.x * TILE;
+  u32 c = 0;
+  u64 first = RL_INF;
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const u64 idx = tile_base + (u64)j * RL_BLOCK + threadIdx.x;
+    if (idx < n) {
+      const K key = in[idx];
+      const bool head = (idx == 0) || KeyOps<K>::ne(in[idx - 1], key);
+      if (head) { c++; if (idx < first) first = idx; }
+    }
+  }
+  // wave reduce
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    c += __shfl_down(c, d);
+    const u64 o = __shfl_down(first, d);
+    first = (o < first) ? o : first;
+  }
+  if (lane_id() == 0) { s_cnt[wave_id()] = c; s_min[wave_id()] = first; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 tc = 0; u64 tf = RL_INF;
+    for (int i = 0; i < RL_BLOCK / 64; i++) { tc += s_cnt[i]; tf = (s_min[i] < tf) ? s_min[i] : tf; }
+    tile_cnt[blockIdx.x]   = tc;
+    tile_first[blockIdx.x] = tf;
+  }
+}
+
+__global__ void rle_set_tail_kernel(u64 *__restrict__ tile_offs, u64 *__restrict__ tile_next, u64 num_tiles, u64 n,
+                                    const u64 *__restrict__ total) {
+  tile_offs[num_tiles] = *total;
+  tile_next[num_tiles] = n;
+}
+
+__device__ __forceinline__ u32 rl_pad(u32 i) { return i + (i >> 4); }
+
+template <typename K>
+__global__ __launch_bounds__(RL_BLOCK)
+void rle_emit_kernel(const K *__restrict__ in, u64 n, const u64 *__restrict__ tile_offs,
+                     const u64 *__restrict__ tile_next, const u64 *__restrict__ d_out_base, K *__restrict__ out_keys,
+                     u32 *__restrict__ out_counts) {
+  const u64 out_base0 = d_out_base ? *d_out_base : 0ull;
+  constexpr int RL_KPT = RlTile<K>::KPT, RL_TILE = RL_BLOCK * RL_KPT;
+  __shared__ K s_keys[RL_TILE + 1 + (RL_TILE + 1) / 16 + 1];
+  __shared__ u32 s_tmp[RL_BLOCK / 64 + 1];
+  __shared__ u64 s_wmin[RL_BLOCK / 64];
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const u64 tile_base = (u64)blockIdx.x * RL_TILE;
+
+  // coalesced load; logical slot 0 holds the key preceding the tile
+  if (tid == 0) s_keys[rl_pad(0)] = (tile_base > 0) ? in[tile_base - 1] : KeyOps<K>::zero();
+#pragma unroll
+  for (int j = 0; j < RL_KPT; j++) {
+    const u32 i   = (u32)j * RL_BLOCK + tid;
+    const u64 idx = tile_base + i;
+    s_keys[rl_pad(i + 1)] = (idx < n) ? in[idx] : KeyOps<K>::zero();
+  }
+  __syncthreads();
+
+  // blocked: thread owns RL_KPT consecutive keys
+  K keys[RL_KPT];
+  u32 flags = 0;
+  K prev = s_keys[rl_pad(tid * RL_KPT)];
+#pragma unroll
+  for (int j = 0; j < RL_KPT; j++) {
+    const u32 i   = tid * RL_KPT + j;
+    const u64 idx = tile_base + i;
+    keys[j] = s_keys[rl_pad(i + 1)];
+    const bool head = (idx < n) && ((idx == 0) || KeyOps<K>::ne(keys[j], prev));
+    flags |= (head ? 1u : 0u) << j;
+    prev = keys[j];
+  }
+
+  const u32 c = __popc(flags);
+  u32 tile_heads;
+  const u32 slot0 = block_excl_scan<RL_BLOCK, u32>(c, s_tmp, &tile_heads);
+
+  // position of the next head after this thread's keys
+  const u64 fh = flags ? (tile_base + (u64)tid * RL_KPT + (u32)(__ffs(flags) - 1)) : RL_INF;
+  u64 x = fh;                                   // inclusive suffix-min inside the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u64 y = __shfl_down(x, d);
+    if ((int)lane + d < 64) x = (y < x) ? y : x;
+  }
+  if (lane == 0) s_wmin[w] = x;
+  __syncthreads();
+  u64 after = tile_next[blockIdx.x + 1];        // first head in any later tile (or n)
+  for (int ww = RL_BLOCK / 64 - 1; ww > (int)w; ww--) after = (s_wmin[ww] < after) ? s_wmin[ww] : after;
+  u64 e = __shfl_down(x, 1);
+  if (lane == 63) e = RL_INF;
+  u64 next = (e < after) ? e : after;
+
+  const u64 out_base = out_base0 + tile_offs[blockIdx.x] + slot0;
+#pragma unroll
+  for (int j = RL_KPT - 1; j >= 0; j--) {
+    if ((flags >> j) & 1u) {
+      const u64 idx  = tile_base + (u64)tid * RL_KPT + j;
+      const u64 slot = out_base + __popc(flags & ((1u << j) - 1u));
+      out_keys[slot]   = keys[j];
+      out_counts[slot] = (u32)(next - idx);     // wraps mod 2^32 like the reference's uint32 ++
+      next = idx;
+    }
+  }
+}
+
+hipError_t launch_rle_count(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_ws, hipStream_t st) {
+  RleWs w = rle_ws(d_ws, n, key_words);
+  if (n == 0) return hipMemsetAsync(w.total, 0, sizeof(u64), st);
+  if (key_words == 2)
+    hipLaunchKernelGGL(rle_count_kernel<K128>, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
+                       reinterpret_cast<const K128 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next);
+  else
+    hipLaunchKernelGGL(rle_count_kernel<u64>, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
+                       reinterpret_cast<const u64 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next);
+  MGC_CHECK(hipGetLastError());
+  // tile_offs: exclusive sum of the per-tile head counts; tile_next: first head at or after each tile (n past the end)
+  MGC_CHECK(scan_u64_exclusive(w.tile_offs, w.num_tiles, w.scratch, w.total, st));
+  MGC_CHECK(scan_u64_min_reverse(w.tile_next, w.num_tiles, w.scratch, (u64)n, st));
+  hipLaunchKernelGGL(rle_set_tail_kernel, dim3(1), dim3(1), 0, st, w.tile_offs, w.tile_next, (u64)w.num_tiles, (u64)n,
+                     (const u64 *)w.total);
+  return hipGetLastError();
+}
+
+hipError_t rle_read_total(const void *d_ws, uint64_t *n_distinct, hipStream_t st) {
+  MGC_CHECK(hipMemcpyAsync(n_distinct, d_ws, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  return hipStreamSynchronize(st);
+}
+
+hipError_t launch_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_ws, void *d_unique,
+                           uint32_t *d_counts, hipStream_t st, const uint64_t *d_out_base) {
+  if (n == 0) return hipSuccess;
+  RleWs w = rle_ws(d_ws, n, key_words);
+  if (key_words == 2)
+    hipLaunchKernelGGL(rle_emit_kernel<K128>, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
+                       reinterpret_cast<const K128 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next,
+                       reinterpret_cast<const u64 *>(d_out_base), reinterpret_cast<K128 *>(d_unique), d_counts);
+  else
+    hipLaunchKernelGGL(rle_emit_kernel<u64>, dim3((uint32_t)w.num_tiles), dim3(RL_BLOCK), 0, st,
+                       reinterpret_cast<const u64 *>(d_sorted), (u64)n, w.tile_offs, w.tile_next,
+                       reinterpret_cast<const u64 *>(d_out_base), reinterpret_cast<u64 *>(d_unique), d_counts);
+  return hipGetLastError();
+}
+
+// ============================================================================
+//  Sub-bucket finish: LDS sort of the low bits + fused run-length count
+// ============================================================================
+//
+// After the global LSB passes have ordered a file by its TOP t bits (below the six
+// file bits), every value of those bits is a contiguous sub-bucket of a few thousand
+// k-mers.  One workgroup loads one sub-bucket, sorts the remaining low bits with
+// stable 8-bit counting passes that never leave LDS, run-length counts it, and
+// writes the distinct k-mers in place (front of the sub-bucket's own region) plus
+// their counts to a scratch array.  A small compaction then packs all sub-buckets.
+// HBM traffic: 8 B read per instance + 12 B per distinct k-mer, instead of two more
+// 16 B/key radix passes, an 8 B histogram read and the two run-length passes.
+
+// starts[v] = first index in [0, n) whose top bits ((key >> low) & tmask) are >= v, for v in [0, ng]
+template <typename K>
+__global__ void subbucket_bounds_kernel(const K *__restrict__ keys, u64 n, u32 low, u32 tmask, u64 ng,
+                                        u64 *__restrict__ starts) {
+  const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > ng) return;
+  if (v == ng) { starts[v] = n; return; }
+  u64 lo = 0, hi = n;
+  while (lo < hi) {
+    const u64 mid = lo + ((hi - lo) >> 1);
+    if ((u64)KeyOps<K>::digit(keys[mid], low, tmask) < v) lo = mid + 1; else hi = mid;
+  }
+  starts[v] = lo;
+}
+
+// largest sub-bucket of a file -> *max_out (atomicMax), so the host can pick the kernel capacity
+// and the list of the sub-buckets above `threshold` (the ones the large-capacity launch takes)
+__global__ void subbucket_max_kernel(const u64 *__restrict__ starts, u64 ng, u64 *__restrict__ max_out, u64 threshold,
+                                     u32 *__restrict__ list, u64 *__restrict__ list_count) {
+  const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 sz = (v < ng) ? (starts[v + 1] - starts[v]) : 0ull;
+  if (sz > threshold) list[atomicAdd(list_count, 1ull)] = (u32)v;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const u64 o = __shfl_down(sz, d); sz = (o > sz) ? o : sz; }
+  if (lane_id() == 0 && sz) atomicMax(max_out, sz);
+}
+
+template <typename K, int BLOCK, int KPT>
+struct FinishSmem {
+  static constexpr int R = 256, NW = BLOCK / 64, CAP = BLOCK * KPT;
+  static constexpr size_t RANK_BYTES = (size_t)NW * R * 12;
+  static constexpr size_t REGION0 = ((size_t)CAP * sizeof(K) > RANK_BYTES) ? (size_t)CAP * sizeof(K) : RANK_BYTES;
+  static constexpr size_t OFF_DBASE = REGION0;                        // u32[R]
+  static constexpr size_t OFF_TMP   = OFF_DBASE + (size_t)R * 4;      // u32[64]
+  static constexpr size_t OFF_FLAG  = OFF_TMP + 64 * 4;               // u8[CAP] head flags
+  static constexpr size_t OFF_HP    = OFF_FLAG + (size_t)CAP;         // u16[CAP + 1] head positions
+  static constexpr size_t BYTES     = OFF_HP + (size_t)(CAP + 2) * 2;
+};
+
+template <typename K, int BLOCK, int KPT>
+__global__ __launch_bounds__(BLOCK)
+void lds_sort_count_kernel(K *__restrict__ keys,                      // the file's segment; distinct keys are written in place
+                           const u64 *__restrict__ starts,            // [ng+1] sub-bucket offsets inside the segment
+                           u32 low_bits, u64 min_size, u64 max_size,   // this launch handles sub-buckets with min < n <= max
+                           u32 *__restrict__ cnt_tmp,                 // counts, indexed like `keys`
+                           u64 *__restrict__ group_distinct,          // [ng]
+                           const u32 *__restrict__ list) {            // optional: the sub-buckets to take (grid = their number)
+  using SM = FinishSmem<K, BLOCK, KPT>;
+  using KO = KeyOps<K>;
+  constexpr int R = SM::R, NW = SM::NW, CAP = SM::CAP;
+  static_assert(BLOCK >= R && CAP <= 16384, "16-bit positions, one thread per digit");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  K   *s_keys  = reinterpret_cast<K *>(smem);
+  u32 *s_whist = reinterpret_cast<u32 *>(smem);
+  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
+  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
+  unsigned char  *s_flag = smem + SM::OFF_FLAG;
+  unsigned short *s_hp   = reinterpret_cast<unsigned short *>(smem + SM::OFF_HP);
+
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const u64 g = list ? (u64)list[blockIdx.x] : (u64)blockIdx.x;
+  const u64 a = starts[g];
+  const u64 n64 = starts[g + 1] - a;
+  if (n64 <= min_size || n64 > max_size) {             // another launch's (or nobody's) sub-bucket
+    if (n64 == 0 && min_size == 0 && tid == 0) group_distinct[g] = 0;
+    return;
+  }
+  const u32 n = (u32)n64;
+  K *gk = keys + a;
+
+  // ---- load, wave-striped like the global passes; padding sorts to the very end ----
+  K kk[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const u32 idx = w * (64 * KPT) + (u32)j * 64 + lane;
+    kk[j] = (idx < n) ? gk[idx] : KO::pad();
+  }
+
+  // ---- stable 8-bit counting passes over the low bits, entirely in LDS ----
+  const u64 lt_mask = (1ull << lane) - 1ull;
+  const u64 lane_bit = 1ull << lane;
+  for (u32 shift = 0; shift < low_bits; shift += 8) {
+    const u32 bits  = (low_bits - shift < 8u) ? (low_bits - shift) : 8u;
+    const u32 dmask = (1u << bits) - 1u;
+    for (u32 i = tid; i < (u32)(NW * R * 3); i += BLOCK) s_whist[i] = 0;
+    __syncthreads();
+    lds_u32 *wh = (lds_u32 *)(smem) + w * R;
+    lds_u64 *mk = (lds_u64 *)(smem + (size_t)NW * R * 4) + w * R;
+    u32 ranks[KPT / 2];
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 d = KO::digit(kk[j], shift, dmask);
+      __hip_atomic_fetch_or(&mk[d], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u64 peers = __hip_atomic_load(&mk[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u32 base  = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u32 lower = __popcll(peers & lt_mask);
+      if (lower == 0) {
+        __hip_atomic_store(&wh[d], base + (u32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_store(&mk[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      if (j & 1) ranks[j / 2] |= (base + lower) << 16;
+      else       ranks[j / 2]  = (base + lower);
+    }
+    __syncthreads();
+    u32 count = 0;
+    if (tid < (u32)R) {
+      u32 acc = 0;
+#pragma unroll
+      for (int ww = 0; ww < NW; ww++) {
+        const u32 t = s_whist[ww * R + tid];
+        s_whist[ww * R + tid] = acc;
+        acc += t;
+      }
+      count = acc;
+    }
+    u32 tot;
+    const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tot);
+    if (tid < (u32)R) s_dbase[tid] = excl;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 d = KO::digit(kk[j], shift, dmask);
+      const u32 add = s_dbase[d] + s_whist[w * R + d];
+      ranks[j / 2] += (j & 1) ? (add << 16) : add;
+    }
+    __syncthreads();                                   // scratch is dead; its storage becomes s_keys
+#pragma unroll
+    for (int j = 0; j < KPT; j++) s_keys[(j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu)] = kk[j];
+    __syncthreads();
+    if (shift + 8 < low_bits) {                        // next pass ranks in the new order
+#pragma unroll
+      for (int j = 0; j < KPT; j++) kk[j] = s_keys[w * (64 * KPT) + (u32)j * 64 + lane];
+      __syncthreads();
+    }
+  }
+  if (low_bits == 0) {                                 // nothing to sort: all keys of the sub-bucket are equal bits above
+#pragma unroll
+    for (int j = 0; j < KPT; j++) s_keys[w * (64 * KPT) + (u32)j * 64 + lane] = kk[j];
+    __syncthreads();
+  }
+
+  // ---- run-length count on the sorted sub-bucket ----
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {                      // striped: conflict-free neighbour compares
+    const u32 i = (u32)j * BLOCK + tid;
+    s_flag[i] = (i < n && (i == 0 || KO::ne(s_keys[i], s_keys[i - 1]))) ? 1 : 0;
+  }
+  __syncthreads();
+  u32 myflags = 0;                                      // blocked: KPT consecutive flags per thread
+#pragma unroll
+  for (int j = 0; j < KPT; j++) myflags |= (u32)s_flag[tid * KPT + j] << j;
+  u32 d_total;
+  u32 slot = block_excl_scan<BLOCK, u32>(__popc(myflags), s_tmp, &d_total);
+#pragma unroll
+  for (int j = 0; j < KPT; j++)
+    if ((myflags >> j) & 1u) s_hp[slot++] = (unsigned short)(tid * KPT + j);
+  if (tid == 0) s_hp[d_total] = (unsigned short)n;      // CAP <= 16384 fits
+  __syncthreads();
+  for (u32 sidx = tid; sidx < d_total; sidx += BLOCK) {
+    const u32 i = s_hp[sidx];
+    gk[sidx] = s_keys[i];                               // in place: every key of this region is in LDS by now
+    cnt_tmp[a + sidx] = (u32)s_hp[sidx + 1] - i;
+  }
+  if (tid == 0) group_distinct[g] = d_total;
+}
+
+// Hash-count finish for uint64 keys: sub-buckets of real read sets are mostly duplicates (coverage),
+// so instead of sorting n keys the workgroup inserts them into an LDS hash table that counts
+// (one 64-bit CAS + one add per key, independent per key => the LDS latency overlaps), compacts
+// the D distinct entries and ranks them by brute force (D^2 / BLOCK broadcast compares; D ~ n/7).
+// EMPTY cannot collide with a key: every key of the file shares its top six bits, ~key0 does not.
+template <int BLOCK, int CAP, int SLOTS, bool DBG>
+__global__ __launch_bounds__(BLOCK, 5)
+void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
+                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 *__restrict__ dbg) {
+  // Inside a sub-bucket the keys differ only in their low `low_bits` (< 32) bits: the table holds
+  // 32-bit suffixes (half the LDS, 32-bit CAS and compares); the common prefix is added back on output.
+  // Persistent workgroups: the keys of the next sub-bucket are loaded while the current one is counted
+  // (a sub-bucket is ~1K keys, so the two dependent HBM round trips would otherwise be a third of its time).
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
+  constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
+  constexpr u32 EMPTY = 0xFFFFFFFFu;                   // suffixes are < 2^31
+  __shared__ __attribute__((aligned(16))) u32 tk[SLOTS];
+  __shared__ __attribute__((aligned(16))) u32 tc[SLOTS];
+  __shared__ __attribute__((aligned(16))) u32 dk[CAP + 16];
+  __shared__ u32 dc[CAP];
+  __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  const u32 tid = threadIdx.x;
+  const u64 G = gridDim.x;
+  const u64 low_mask = (1ull << low_bits) - 1ull;
+
+  auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
+    aa = 0; nn = 0;
+    if (gg < ng) { aa = starts[gg]; nn = starts[gg + 1] - aa; }
+  };
+  // only the low dword of a key is needed: the rest is the file's prefix and the sub-bucket index
+  auto load_keys = [&](u64 aa, u64 nn, u32 (&kr)[KPT]) {
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 idx = (u32)j * BLOCK + tid;
+      kr[j] = (nn <= max_size && idx < nn) ? reinterpret_cast<const u32 *>(keys + aa + idx)[0] : 0u;
+    }
+  };
+  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
+  const u64 file_base = (keys[0] >> group_shift) << group_shift;
+
+  u64 g = blockIdx.x, a, n64, na, nn;
+  u32 kcur[KPT];
+  load_bounds(g, a, n64);
+  load_keys(a, n64, kcur);
+  load_bounds(g + G, na, nn);
+
+  u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define HC_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
+  while (g < ng) {
+    u32 knext[KPT];
+    u64 nna, nnn;
+    if (DBG) t0 = __builtin_readcyclecounter();
+    load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
+    load_bounds(g + 2 * G, nna, nnn);
+
+    if (n64 == 0) {
+      if (tid == 0) group_distinct[g] = 0;
+    } else if (n64 <= max_size) {                      // larger ones: a larger-capacity launch takes them
+      const u32 n = (u32)n64;
+      const u64 prefix = file_base | (g << low_bits);
+      u32 kk[KPT], hh[KPT];
+      u32 pending = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 idx = (u32)j * BLOCK + tid;
+        kk[j] = kcur[j] & (u32)low_mask;
+        if (idx < n) pending |= 1u << j;
+      }
+      // table sized to the sub-bucket (load factor <= 0.8 even if every key is distinct): the clear and the
+      // compaction below walk the table, so an oversized one costs more than the longer probes of a full one
+      u32 slots = 256;
+      while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
+      const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
+      {
+        uint4 *tk4 = reinterpret_cast<uint4 *>(tk), *tc4 = reinterpret_cast<uint4 *>(tc);
+        for (u32 i = tid; i < slots / 4; i += BLOCK) {
+          tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+          tc4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KPT; j++) hh[j] = (kk[j] * 0x9E3779B1u) >> sshift;
+      __syncthreads();
+      HC_STAMP(0);
+
+      // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
+      while (pending) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if ((pending >> j) & 1u) {
+            const u32 old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
+            if (old == EMPTY || old == kk[j]) { atomicAdd(&tc[hh[j]], 1u); pending &= ~(1u << j); }
+            else hh[j] = (hh[j] + 1) & smask;
+          }
+        }
+      }
+      __syncthreads();
+      HC_STAMP(1);
+
+      // compact the occupied slots (any order)
+      u32 occ = 0;
+#pragma unroll
+      for (int j = 0; j < SPT; j++) {
+        const u32 sl = (u32)j * BLOCK + tid;
+        if (sl < slots) occ |= (tc[sl] != 0u ? 1u : 0u) << j;
+      }
+      u32 D;
+      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+#pragma unroll
+      for (int j = 0; j < SPT; j++)
+        if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
+      if (tid < 16) dk[D + tid] = EMPTY;               // padding of the rank loop (D is block-uniform)
+      __syncthreads();
+      HC_STAMP(2);
+
+      // rank = number of smaller distinct suffixes.  dk is padded with EMPTY (never smaller) to a multiple of 16, so
+      // the loop runs on whole 64-byte groups: four independent broadcast 16-byte LDS reads in flight per iteration
+      // (a (tried) order-preserving table with cluster-local ranks halves this phase but probes 50 % longer)
+      const uint4 *dk4 = reinterpret_cast<const uint4 *>(dk);
+      u64 *gk = keys + a;
+      const u32 d16 = (D + 15) / 16;
+      for (u32 i = tid; i < D; i += BLOCK) {
+        const u32 ki = dk[i];
+        u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        for (u32 j = 0; j < d16; j++) {
+          const uint4 v0 = dk4[4 * j], v1 = dk4[4 * j + 1], v2 = dk4[4 * j + 2], v3 = dk4[4 * j + 3];
+          r0 += (v0.x < ki ? 1u : 0u) + (v0.y < ki ? 1u : 0u) + (v0.z < ki ? 1u : 0u) + (v0.w < ki ? 1u : 0u);
+          r1 += (v1.x < ki ? 1u : 0u) + (v1.y < ki ? 1u : 0u) + (v1.z < ki ? 1u : 0u) + (v1.w < ki ? 1u : 0u);
+          r2 += (v2.x < ki ? 1u : 0u) + (v2.y < ki ? 1u : 0u) + (v2.z < ki ? 1u : 0u) + (v2.w < ki ? 1u : 0u);
+          r3 += (v3.x < ki ? 1u : 0u) + (v3.y < ki ? 1u : 0u) + (v3.z < ki ? 1u : 0u) + (v3.w < ki ? 1u : 0u);
+        }
+        const u32 r = r0 + r1 + r2 + r3;
+        gk[r] = prefix | (u64)ki;                      // in place: every key of this region sits in registers
+        cnt_tmp[a + r] = dc[i];
+      }
+      if (tid == 0) group_distinct[g] = D;
+      HC_STAMP(3);
+      __syncthreads();                                 // dk/dc/s_tmp are reused by the next sub-bucket
+      HC_STAMP(4);
+    }
+
+#pragma unroll
+    for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
+    a = na; n64 = nn; na = nna; nn = nnn; g += G;
+    if (DBG) { ph[5] += kcur[0] & 1; HC_STAMP(6); ph[7]++; }   // [6]: wait for the prefetched keys
+  }
+  if (DBG && tid == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
+#undef HC_STAMP
+}
+
+// Same scheme with 64-bit suffixes, for sub-buckets whose keys differ in 32..62 low bits (k from about 28 at the
+// 10 Gbp scale): 64-bit CAS, whole keys loaded, 42 KiB of LDS (3 workgroups per CU).
+template <int BLOCK, int CAP, int SLOTS>
+__global__ __launch_bounds__(BLOCK, 3)
+void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
+                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct) {
+  constexpr bool DBG = false;
+  u64 *dbg = nullptr;
+  // Inside a sub-bucket the keys differ only in their low `low_bits` (< 32) bits: the table holds
+  // 32-bit suffixes (half the LDS, 32-bit CAS and compares); the common prefix is added back on output.
+  // Persistent workgroups: the keys of the next sub-bucket are loaded while the current one is counted
+  // (a sub-bucket is ~1K keys, so the two dependent HBM round trips would otherwise be a third of its time).
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
+  constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
+  constexpr u64 EMPTY = ~0ull;                         // suffixes are < 2^63
+  __shared__ __attribute__((aligned(16))) u64 tk[SLOTS];
+  __shared__ __attribute__((aligned(16))) u32 tc[SLOTS];
+  __shared__ __attribute__((aligned(16))) u64 dk[CAP + 16];
+  __shared__ u32 dc[CAP];
+  __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  const u32 tid = threadIdx.x;
+  const u64 G = gridDim.x;
+  const u64 low_mask = (1ull << low_bits) - 1ull;
+
+  auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
+    aa = 0; nn = 0;
+    if (gg < ng) { aa = starts[gg]; nn = starts[gg + 1] - aa; }
+  };
+  // only the low dword of a key is needed: the rest is the file's prefix and the sub-bucket index
+  auto load_keys = [&](u64 aa, u64 nn, u64 (&kr)[KPT]) {
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 idx = (u32)j * BLOCK + tid;
+      kr[j] = (nn <= max_size && idx < nn) ? keys[aa + idx] : 0ull;
+    }
+  };
+  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
+  const u64 file_base = (keys[0] >> group_shift) << group_shift;
+
+  u64 g = blockIdx.x, a, n64, na, nn;
+  u64 kcur[KPT];
+  load_bounds(g, a, n64);
+  load_keys(a, n64, kcur);
+  load_bounds(g + G, na, nn);
+
+  u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define HC_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
+  while (g < ng) {
+    u64 knext[KPT];
+    u64 nna, nnn;
+    if (DBG) t0 = __builtin_readcyclecounter();
+    load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
+    load_bounds(g + 2 * G, nna, nnn);
+
+    if (n64 == 0) {
+      if (tid == 0) group_distinct[g] = 0;
+    } else if (n64 <= max_size) {                      // larger ones: a larger-capacity launch takes them
+      const u32 n = (u32)n64;
+      const u64 prefix = file_base | (g << low_bits);
+      u64 kk[KPT];
+      u32 hh[KPT];
+      u32 pending = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 idx = (u32)j * BLOCK + tid;
+        kk[j] = kcur[j] & low_mask;
+        if (idx < n) pending |= 1u << j;
+      }
+      // table sized to the sub-bucket (load factor <= 0.8 even if every key is distinct): the clear and the
+      // compaction below walk the table, so an oversized one costs more than the longer probes of a full one
+      u32 slots = 256;
+      while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
+      const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
+      {
+        for (u32 i = tid; i < slots; i += BLOCK) { tk[i] = EMPTY; tc[i] = 0u; }
+      }
+#pragma unroll
+      for (int j = 0; j < KPT; j++) hh[j] = (u32)((kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
+      __syncthreads();
+      HC_STAMP(0);
+
+      // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
+      while (pending) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if ((pending >> j) & 1u) {
+            const u64 old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
+            if (old == EMPTY || old == kk[j]) { atomicAdd(&tc[hh[j]], 1u); pending &= ~(1u << j); }
+            else hh[j] = (hh[j] + 1) & smask;
+          }
+        }
+      }
+      __syncthreads();
+      HC_STAMP(1);
+
+      // compact the occupied slots (any order)
+      u32 occ = 0;
+#pragma unroll
+      for (int j = 0; j < SPT; j++) {
+        const u32 sl = (u32)j * BLOCK + tid;
+        if (sl < slots) occ |= (tc[sl] != 0u ? 1u : 0u) << j;
+      }
+      u32 D;
+      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+#pragma unroll
+      for (int j = 0; j < SPT; j++)
+        if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
+      if (tid < 16) dk[D + tid] = EMPTY;               // padding of the rank loop (D is block-uniform)
+      __syncthreads();
+      HC_STAMP(2);
+
+      // rank = number of smaller distinct suffixes (all pairs, two 16-byte broadcast reads per iteration)
+      u64 *gk = keys + a;
+      const u32 d4 = (D + 3) / 4;
+      const ulonglong2 *dk2 = reinterpret_cast<const ulonglong2 *>(dk);
+      for (u32 i = tid; i < D; i += BLOCK) {
+        const u64 ki = dk[i];
+        u32 r0 = 0, r1 = 0;
+        for (u32 j = 0; j < d4; j++) {
+          const ulonglong2 v0 = dk2[2 * j], v1 = dk2[2 * j + 1];
+          r0 += (v0.x < ki ? 1u : 0u) + (v0.y < ki ? 1u : 0u);
+          r1 += (v1.x < ki ? 1u : 0u) + (v1.y < ki ? 1u : 0u);
+        }
+        const u32 r = r0 + r1;
+        gk[r] = prefix | ki;                           // in place: every key of this region sits in registers
+        cnt_tmp[a + r] = dc[i];
+      }
+      if (tid == 0) group_distinct[g] = D;
+      HC_STAMP(3);
+      __syncthreads();                                 // dk/dc/s_tmp are reused by the next sub-bucket
+      HC_STAMP(4);
+    }
+
+#pragma unroll
+    for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
+    a = na; n64 = nn; na = nna; nn = nnn; g += G;
+    if (DBG) { ph[5] += kcur[0] & 1; HC_STAMP(6); ph[7]++; }   // [6]: wait for the prefetched keys
+  }
+  if (DBG && tid == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
+#undef HC_STAMP
+}
+
+// Hash-count finish for 16-byte keys (k = 33..64).  The suffix of a key inside its sub-bucket may be wider than any
+// LDS compare-and-swap, so a slot is claimed through its COUNT word instead: 0 = empty, LOCK = being written,
+// n >= 1 = valid with n instances.  A thread that finds LOCK simply stays pending for the next round (rounds, not
+// spinning: the lane holding the lock may sit in the same wave).  WIDE = the suffix needs the high word too
+// (low_bits > 64); otherwise the hi arrays are not even allocated.
+template <int BLOCK, int CAP, int SLOTS, bool WIDE>
+__global__ __launch_bounds__(BLOCK, WIDE ? 2 : 3)
+void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
+                          u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct) {
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
+  constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
+  constexpr u32 LOCK = 0xFFFFFFFFu;
+  __shared__ u64 tlo[SLOTS];
+  __shared__ u64 thi[WIDE ? SLOTS : 1];
+  __shared__ u32 tc[SLOTS];
+  __shared__ __attribute__((aligned(16))) u64 dlo[CAP + 4];
+  __shared__ __attribute__((aligned(16))) u64 dhi[WIDE ? CAP + 4 : 2];
+  __shared__ u32 dc[CAP];
+  __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  using KO = KeyOps<K128>;
+  const u32 tid = threadIdx.x;
+  const u64 G = gridDim.x;
+  const u128 low_mask = (low_bits >= 128) ? ~(u128)0 : (((u128)1 << low_bits) - 1);
+  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
+  const u128 file_base = (group_shift >= 128) ? (u128)0 : ((KO::v(keys[0]) >> group_shift) << group_shift);
+
+  auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
+    aa = 0; nn = 0;
+    if (gg < ng) { aa = starts[gg]; nn = starts[gg + 1] - aa; }
+  };
+  auto load_keys = [&](u64 aa, u64 nn, K128 (&kr)[KPT]) {
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 idx = (u32)j * BLOCK + tid;
+      if (nn <= max_size && idx < nn) kr[j] = keys[aa + idx]; else kr[j] = KO::zero();
+    }
+  };
+
+  u64 g = blockIdx.x, a, n64, na, nn;
+  K128 kcur[KPT];
+  load_bounds(g, a, n64);
+  load_keys(a, n64, kcur);
+  load_bounds(g + G, na, nn);
+
+  while (g < ng) {
+    K128 knext[KPT];
+    u64 nna, nnn;
+    load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
+    load_bounds(g + 2 * G, nna, nnn);
+
+    if (n64 == 0) {
+      if (tid == 0) group_distinct[g] = 0;
+    } else if (n64 <= max_size) {
+      const u32 n = (u32)n64;
+      const u128 prefix = file_base | ((u128)g << low_bits);
+      u64 klo[KPT], khi[KPT];
+      u32 hh[KPT];
+      u32 pending = 0;
+      u32 slots = 256;
+      while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
+      const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 idx = (u32)j * BLOCK + tid;
+        const u128 sfx = KO::v(kcur[j]) & low_mask;
+        klo[j] = (u64)sfx; khi[j] = (u64)(sfx >> 64);
+        const u64 mix = (klo[j] ^ (khi[j] * 0xD6E8FEB86659FD93ull)) * 0x9E3779B97F4A7C15ull;
+        hh[j] = (u32)(mix >> 32) >> sshift;
+        if (idx < n) pending |= 1u << j;
+      }
+      for (u32 i = tid; i < slots; i += BLOCK) tc[i] = 0u;
+      __syncthreads();
+
+      while (pending) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if ((pending >> j) & 1u) {
+            const u32 h = hh[j];
+            const u32 old = atomicCAS(&tc[h], 0u, LOCK);
+            if (old == 0u) {                           // the slot is ours: fill it, then publish it with count 1
+              tlo[h] = klo[j];
+              if (WIDE) thi[h] = khi[j];
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+              __hip_atomic_store(&tc[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              pending &= ~(1u << j);
+            } else if (old != LOCK) {                  // valid: same suffix -> count it, another one -> probe on
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              const bool same = (tlo[h] == klo[j]) && (!WIDE || thi[h] == khi[j]);
+              if (same) { atomicAdd(&tc[h], 1u); pending &= ~(1u << j); }
+              else hh[j] = (h + 1) & smask;
+            }                                          // LOCK: somebody is writing this slot; look again next round
+          }
+        }
+      }
+      __syncthreads();
+
+      // compact the occupied slots (any order)
+      u32 occ = 0;
+#pragma unroll
+      for (int j = 0; j < SPT; j++) {
+        const u32 sl = (u32)j * BLOCK + tid;
+        if (sl < slots) occ |= (tc[sl] != 0u ? 1u : 0u) << j;
+      }
+      u32 D;
+      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+#pragma unroll
+      for (int j = 0; j < SPT; j++) {
+        if ((occ >> j) & 1u) {
+          const u32 sl = (u32)j * BLOCK + tid;
+          dlo[o] = tlo[sl];
+          if (WIDE) dhi[o] = thi[sl];
+          dc[o] = tc[sl];
+          o++;
+        }
+      }
+      if (tid < 4) { dlo[D + tid] = ~0ull; if (WIDE) dhi[D + tid] = ~0ull; }
+      __syncthreads();
+
+      // rank = number of smaller distinct suffixes
+      K128 *gk = keys + a;
+      const u32 d4 = (D + 3) / 4;                      // the arrays are padded with all-ones (never smaller) to 4
+      const ulonglong2 *dlo2 = reinterpret_cast<const ulonglong2 *>(dlo);
+      const ulonglong2 *dhi2 = reinterpret_cast<const ulonglong2 *>(dhi);
+      for (u32 i = tid; i < D; i += BLOCK) {
+        const u64 li = dlo[i], hi = WIDE ? dhi[i] : 0ull;
+        u32 r0 = 0, r1 = 0;
+        for (u32 j = 0; j < d4; j++) {
+          const ulonglong2 a0 = dlo2[2 * j], a1 = dlo2[2 * j + 1];
+          if (WIDE) {
+            const ulonglong2 b0 = dhi2[2 * j], b1 = dhi2[2 * j + 1];
+            r0 += (((b0.x < hi) || (b0.x == hi && a0.x < li)) ? 1u : 0u) + (((b0.y < hi) || (b0.y == hi && a0.y < li)) ? 1u : 0u);
+            r1 += (((b1.x < hi) || (b1.x == hi && a1.x < li)) ? 1u : 0u) + (((b1.y < hi) || (b1.y == hi && a1.y < li)) ? 1u : 0u);
+          } else {
+            r0 += (a0.x < li ? 1u : 0u) + (a0.y < li ? 1u : 0u);
+            r1 += (a1.x < li ? 1u : 0u) + (a1.y < li ? 1u : 0u);
+          }
+        }
+        const u32 r = r0 + r1;
+        gk[r] = KO::mk(prefix | ((u128)hi << 64) | (u128)li);   // in place: every key of this region sits in registers
+        cnt_tmp[a + r] = dc[i];
+      }
+      if (tid == 0) group_distinct[g] = D;
+      __syncthreads();                                 // the tables are reused by the next sub-bucket
+    }
+
+#pragma unroll
+    for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
+    a = na; n64 = nn; na = nna; nn = nnn; g += G;
+  }
+}
+
+// offs = exclusive scan of group_distinct (offs[ng] = total).  One wave per sub-bucket.
+template <typename K>
+__global__ __launch_bounds__(256)
+void compact_groups_kernel(const K *__restrict__ keys, const u32 *__restrict__ cnt_tmp, const u64 *__restrict__ starts,
+                           const u64 *__restrict__ offs, u64 ng, K *__restrict__ out_keys, u32 *__restrict__ out_counts) {
+  const u64 g = (u64)blockIdx.x * 4 + wave_id();
+  if (g >= ng) return;
+  const u64 dst = offs[g], d = offs[g + 1] - dst, src = starts[g];
+  for (u64 i = lane_id(); i < d; i += 64) {
+    out_keys[dst + i]   = keys[src + i];
+    out_counts[dst + i] = cnt_tmp[src + i];
+  }
+}
+
+__global__ void store_u64_kernel(u64 *__restrict__ dst, const u64 *__restrict__ src) { *dst = *src; }
+
+constexpr u64 FIN_CAP_SMALL = 256 * 16, FIN_CAP_LARGE = 1024 * 8;   // LDS: 46 KiB and 91 KiB per workgroup
+constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count kernel: 2048 slots, 28 KiB of LDS, 5 workgroups per CU
+
+static bool finish_uses_hash(uint32_t key_words, uint32_t low_bits) {
+  static const bool use_hash = !(getenv("MGC_FINISH_HASH") && getenv("MGC_FINISH_HASH")[0] == '0');
+  static const bool use_hash64 = !(getenv("MGC_FINISH_HASH64") && getenv("MGC_FINISH_HASH64")[0] == '0');
+  static const bool use_hash128 = !(getenv("MGC_FINISH_HASH128") && getenv("MGC_FINISH_HASH128")[0] == '0');
+  if (key_words == 2) return use_hash && use_hash128 && low_bits <= 122;
+  return key_words == 1 && use_hash && (low_bits < 32 || (use_hash64 && low_bits <= 58));
+}
+// capacity of the first (small) launch of launch_finish_file; larger sub-buckets go on the list
+static uint64_t finish_small_capacity(uint32_t key_words, uint32_t low_bits);
+
+hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t low, uint32_t top_bits,
+                                   uint64_t *d_starts, uint64_t *d_max, uint32_t *d_list, uint64_t *d_list_count, hipStream_t st) {
+  const uint64_t ng = (uint64_t)1 << top_bits;
+  const uint32_t tmask = (uint32_t)(ng - 1);
+  const dim3 grid((uint32_t)((ng + 1 + 255) / 256));
+  if (key_words == 2)
+    hipLaunchKernelGGL(subbucket_bounds_kernel<K128>, grid, dim3(256), 0, st, reinterpret_cast<const K128 *>(d_keys),
+                       (u64)n, low, tmask, (u64)ng, reinterpret_cast<u64 *>(d_starts));
+  else
+    hipLaunchKernelGGL(subbucket_bounds_kernel<u64>, grid, dim3(256), 0, st, reinterpret_cast<const u64 *>(d_keys),
+                       (u64)n, low, tmask, (u64)ng, reinterpret_cast<u64 *>(d_starts));
+  MGC_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(subbucket_max_kernel, dim3((uint32_t)((ng + 255) / 256)), dim3(256), 0, st,
+                     reinterpret_cast<const u64 *>(d_starts), (u64)ng, reinterpret_cast<u64 *>(d_max),
+                     (u64)finish_small_capacity(key_words, low), d_list, reinterpret_cast<u64 *>(d_list_count));
+  return hipGetLastError();
+}
+
+template <typename K, int BLOCK, int KPT>
+static hipError_t finish_launch(void *d_keys, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits, uint64_t min_size,
+                                uint64_t max_size, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct, hipStream_t st,
+                                const uint32_t *d_list = nullptr) {
+  if (ng == 0) return hipSuccess;
+  using SM = FinishSmem<K, BLOCK, KPT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_sort_count_kernel<K, BLOCK, KPT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((lds_sort_count_kernel<K, BLOCK, KPT>), dim3((uint32_t)ng), dim3(BLOCK), SM::BYTES, st,
+                     reinterpret_cast<K *>(d_keys), reinterpret_cast<const u64 *>(d_starts), low_bits, (u64)min_size,
+                     (u64)max_size, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_list);
+  return hipGetLastError();
+}
+
+// Sorts + counts every sub-bucket of one file segment; sub-buckets larger than FIN_CAP_SMALL use the
+// large-capacity instantiation (launched only if the file has any: max_sub tells).
+// MGC_HASH_DBG=1: per-phase cycle sums of the first 64 workgroups of the hash-count kernel, printed for a few launches
+static u64 *hash_dbg_buffer() {
+  static u64 *buf = nullptr;
+  static const bool on = getenv("MGC_HASH_DBG") != nullptr;
+  if (on && !buf) { if (hipMalloc(&buf, 64 * 8 * sizeof(u64)) != hipSuccess) buf = nullptr; }
+  return buf;
+}
+static void hash_dbg_report(hipStream_t st, uint64_t ng) {
+  u64 *buf = hash_dbg_buffer();
+  static int reports = 0;
+  if (!buf || reports >= 4) return;
+  u64 h[64 * 8];
+  if (hipStreamSynchronize(st) != hipSuccess) return;
+  if (hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+  double sum[8] = {0};
+  for (int b = 0; b < 64; b++) for (int i = 0; i < 8; i++) sum[i] += (double)h[b * 8 + i];
+  const double it = sum[7] > 0 ? sum[7] : 1;
+  fprintf(stderr, "[hash dbg] ng=%llu iters/block=%.1f cycles/iter: init=%.0f probe=%.0f compact=%.0f rank+store=%.0f sync=%.0f wait_next=%.0f\n",
+          (unsigned long long)ng, it / 64, sum[0] / it, sum[1] / it, sum[2] / it, sum[3] / it, sum[4] / it, sum[6] / it);
+  reports++;
+}
+
+hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
+                              uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
+                              hipStream_t st) {
+  if (key_words == 2 && finish_uses_hash(key_words, low_bits)) {
+    static const uint32_t wgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 6u;
+    const uint32_t wgrid = ng < wgrid_max ? (uint32_t)ng : wgrid_max;
+    if (low_bits > 64)
+      hipLaunchKernelGGL((hash_count128_kernel<256, (int)FIN_CAP_HASH, 2048, true>), dim3(wgrid), dim3(256), 0, st,
+                         reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
+    else
+      hipLaunchKernelGGL((hash_count128_kernel<256, (int)FIN_CAP_HASH, 2048, false>), dim3(wgrid), dim3(256), 0, st,
+                         reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
+    MGC_CHECK(hipGetLastError());
+    MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, 8192, d_cnt_tmp, d_group_distinct, st, d_large_list)));
+    return hipSuccess;
+  }
+  if (key_words == 2) {
+    // 16-byte keys: 256x8 (2048) and 1024x8 (8192) keep LDS at 32 / 128 KiB
+    MGC_CHECK((finish_launch<K128, 256, 8>(d_keys, d_starts, ng, low_bits, 0, 2048, d_cnt_tmp, d_group_distinct, st)));
+    MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, n_large, low_bits, 2048, 8192, d_cnt_tmp, d_group_distinct, st, d_large_list)));
+    return hipSuccess;
+  }
+  if (finish_uses_hash(key_words, low_bits)) {
+    // <= FIN_CAP_HASH keys: hash-count; larger sub-buckets: LDS radix passes in the 8192-key instantiation
+    static const uint32_t hgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 10u;
+    const uint32_t hgrid = ng < hgrid_max ? (uint32_t)ng : hgrid_max;
+    if (low_bits >= 32)
+      hipLaunchKernelGGL((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048>), dim3(hgrid), dim3(256), 0, st,
+                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
+    else if (hash_dbg_buffer())
+      hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true>), dim3(hgrid), dim3(256), 0, st,
+                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), hash_dbg_buffer());
+    else
+      hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false>), dim3(hgrid), dim3(256), 0, st,
+                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), nullptr);
+    MGC_CHECK(hipGetLastError());
+    hash_dbg_report(st, ng);
+    MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, FIN_CAP_LARGE, d_cnt_tmp,
+                                           d_group_distinct, st, d_large_list)));
+    return hipSuccess;
+  }
+  MGC_CHECK((finish_launch<u64, 256, 16>(d_keys, d_starts, ng, low_bits, 0, FIN_CAP_SMALL, d_cnt_tmp, d_group_distinct, st)));
+  MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_SMALL, FIN_CAP_LARGE, d_cnt_tmp,
+                                         d_group_distinct, st, d_large_list)));
+  return hipSuccess;
+}
+
+static uint64_t finish_small_capacity(uint32_t key_words, uint32_t low_bits) {
+  if (key_words == 2) return finish_uses_hash(key_words, low_bits) ? FIN_CAP_HASH : 2048;
+  return finish_uses_hash(key_words, low_bits) ? FIN_CAP_HASH : FIN_CAP_SMALL;
+}
+
+uint64_t finish_capacity_for(uint32_t key_words) { return key_words == 2 ? 8192 : FIN_CAP_LARGE; }
+uint64_t finish_target_for(uint32_t key_words) {
+  if (const char *t = getenv("MGC_FINISH_TARGET")) return strtoull(t, nullptr, 10);
+  const char *h = getenv("MGC_FINISH_HASH");
+  if (key_words == 2) return (h && h[0] == '0') ? 1024 : FIN_CAP_HASH / 2;     // measured at k=51: 768 beats 512 and 1152
+  return (h && h[0] == '0') ? FIN_CAP_SMALL / 2 : (FIN_CAP_HASH * 3) / 4;
+}
+
+// group_distinct[0..ng_total) -> exclusive offsets in place, total at [ng_total]
+size_t finish_scan_scratch_bytes(uint64_t ng_total) { return scan_scratch_elems(ng_total + 1) * sizeof(uint64_t); }
+hipError_t launch_finish_scan(uint64_t *d_group, uint64_t ng_total, void *d_scratch, hipStream_t st) {
+  return scan_u64_exclusive(reinterpret_cast<u64 *>(d_group), ng_total, reinterpret_cast<u64 *>(d_scratch),
+                            reinterpret_cast<u64 *>(d_group) + ng_total, st);
+}
+
+hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,
+                                 const uint64_t *d_offs, uint64_t ng, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st) {
+  const dim3 grid((uint32_t)((ng + 3) / 4));
+  if (key_words == 2)
+    hipLaunchKernelGGL(compact_groups_kernel<K128>, grid, dim3(256), 0, st, reinterpret_cast<const K128 *>(d_keys), d_cnt_tmp,
+                       reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng,
+                       reinterpret_cast<K128 *>(d_out_keys), d_out_counts);
+  else
+    hipLaunchKernelGGL(compact_groups_kernel<u64>, grid, dim3(256), 0, st, reinterpret_cast<const u64 *>(d_keys), d_cnt_tmp,
+                       reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng,
+                       reinterpret_cast<u64 *>(d_out_keys), d_out_counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_store_u64(uint64_t *d_dst, const uint64_t *d_src, hipStream_t st) {
+  hipLaunchKernelGGL(store_u64_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<u64 *>(d_dst), reinterpret_cast<const u64 *>(d_src));
+  return hipGetLastError();
+}
+
+// ============================================================================
+//  Block offsets: first distinct key of every prefix
+// ============================================================================
+template <typename K>
+__global__ void block_offsets_kernel(const K *__restrict__ keys, u64 nd, u32 w_data, u64 n_prefix,
+                                     u64 *__restrict__ block_start) {
+  const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n_prefix) return;
+  if (p == n_prefix) { block_start[p] = nd; return; }
+  const K target = KeyOps<K>::prefix_floor(p, w_data);
+  u64 lo = 0, hi = nd;
+  while (lo < hi) {
+    const u64 mid = lo + ((hi - lo) >> 1);
+    if (KeyOps<K>::lt(keys[mid], target)) lo = mid + 1; else hi = mid;
+  }
+  block_start[p] = lo;
+}
+
+hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,
+                                uint64_t n_prefix, uint64_t *d_block_start, hipStream_t st) {
+  const uint64_t threads = n_prefix + 1;
+  const dim3 grid((uint32_t)((threads + 255) / 256));
+  if (key_words == 2)
+    hipLaunchKernelGGL(block_offsets_kernel<K128>, grid, dim3(256), 0, st, reinterpret_cast<const K128 *>(d_unique),
+                       (u64)n_distinct, w_data, (u64)n_prefix, reinterpret_cast<u64 *>(d_block_start));
+  else
+    hipLaunchKernelGGL(block_offsets_kernel<u64>, grid, dim3(256), 0, st, reinterpret_cast<const u64 *>(d_unique),
+                       (u64)n_distinct, w_data, (u64)n_prefix, reinterpret_cast<u64 *>(d_block_start));
+  return hipGetLastError();
+}
+
+
+}  // namespace mgc

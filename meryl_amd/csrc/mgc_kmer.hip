@@ -1,0 +1,372 @@
+// mgc_kmer.hip -- k-mer extraction, file histogram and partition (gfx950).
+//
+// What each kernel replaces in the reference (paths relative to the reference root):
+//   kmer_hist_kernel / kmer_partition_kernel
+//       kmerIterator + insertKmers            src/meryl/merylOp-countThreads.C:235-280
+//       (2-bit pack A0 C1 T2 G3, reverse complement, canonical pick, prefix split;
+//        the per-bucket spin-lock + bit-packed append of merylCountArray.C:490-728
+//        becomes a histogram + lock-free scatter into per-file regions)
+//   radix_* kernels
+//       unpack + std::sort of each bucket      src/meryl/merylCountArray.C:276-289,330
+//   rle_* kernels
+//       the two run-length passes              src/meryl/merylCountArray.C:334-358
+//   block_offsets_kernel
+//       the per-prefix (prefix, nKmers) split that feeds addBlock
+//                                              src/meryl/merylCountArray.C:472-475
+//
+// All of it is integer / byte work bounded by HBM bandwidth: loads are 16 B (bases) or
+// 8 B per lane coalesced, every reorder is staged through LDS so stores leave as
+// contiguous runs, ranking uses 64-lane ballots, cross-workgroup prefixes use 8-byte
+// {flag,epoch,value} granules with agent-scope relaxed atomics (no fences needed:
+// the datum is the flag).  Wave = 64 everywhere.
+#include "mgc_common.hpp"
+
+namespace mgc {
+
+// ============================================================================
+//  k-mer extraction (k <= 32, keys are uint64)
+// ============================================================================
+
+// 4 ASCII bytes (byte 0 = first base) -> 8 bits of 2-bit codes, first base most
+// significant.  code = (ascii >> 1) & 3 gives A0 C1 T2 G3 for both cases.
+__device__ __forceinline__ u32 enc4(u32 w) {
+  return (((w >> 1) & 0x03030303u) * 0x40100401u) >> 24;
+}
+// exact per-byte zero detector: 0x80 in every byte of x that is zero
+__device__ __forceinline__ u32 zero_bytes(u32 x) {
+  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+// 4 ASCII bytes -> 4-bit mask, bit 3 = byte 0 is NOT one of ACGTacgt
+__device__ __forceinline__ u32 inv4(u32 w) {
+  const u32 u = w & 0xDFDFDFDFu;                     // fold case
+  const u32 ok = zero_bytes(u ^ 0x41414141u) | zero_bytes(u ^ 0x43434343u) |
+                 zero_bytes(u ^ 0x47474747u) | zero_bytes(u ^ 0x54545454u);
+  const u32 g = ((~ok) & 0x80808080u) >> 7;
+  return ((g * 0x08040201u) >> 24) & 0xFu;
+}
+
+
+__device__ __forceinline__ void encode16(uint4 v, u32 &codes, u32 &inval) {
+  codes = (enc4(v.x) << 24) | (enc4(v.y) << 16) | (enc4(v.z) << 8) | enc4(v.w);
+  inval = (inv4(v.x) << 12) | (inv4(v.y) << 8) | (inv4(v.z) << 4) | inv4(v.w);
+}
+
+// reverse complement of a right-aligned k-mer (complement = xor 2 per base)
+__device__ __forceinline__ u64 revcomp64(u64 f, u32 key_shift /* 64-2k */) {
+  u64 x = __brevll(f ^ 0xAAAAAAAAAAAAAAAAull);       // reverses bases AND the two bits of each base
+  x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+  return x >> key_shift;
+}
+
+constexpr int KP_WORDS = KP_TILE / 16 + 4;            // 16 bases per staged word + 64-base halo
+
+// Stage one tile of bases as 2-bit codes + invalid masks in LDS.
+__device__ __forceinline__ void kp_stage_tile(const uint8_t *__restrict__ bases, u64 n, u64 tile0, bool aligned,
+                                              u32 *s_codes, u32 *s_inval) {
+  const u32 t = threadIdx.x;
+  {
+    u32 c, iv;
+    encode16(load16(bases, tile0 + (u64)t * 16, n, aligned), c, iv);
+    s_codes[t] = c; s_inval[t] = iv;
+  }
+  if (t < 4) {
+    u32 c, iv;
+    encode16(load16(bases, tile0 + (u64)KP_TILE + (u64)t * 16, n, aligned), c, iv);
+    s_codes[KP_BLOCK + t] = c; s_inval[KP_BLOCK + t] = iv;
+  }
+}
+
+// The 16 k-mers starting at tile positions threadIdx.x*16 .. +15.  Returns the
+// bit mask of positions that hold a complete k-mer.
+__device__ __forceinline__ u32 kp_thread_kmers(const u32 *s_codes, const u32 *s_inval, u32 k, int mode,
+                                               u64 (&keys)[KP_ITEMS]) {
+  const u32 t = threadIdx.x;
+  const u64 A = ((u64)s_codes[t] << 32) | (u64)s_codes[t + 1];      // bases 0..31 of the thread's window
+  const u64 B = (u64)s_codes[t + 2] << 32;                          // bases 32..47
+  const u64 I = ((u64)s_inval[t] << 48) | ((u64)s_inval[t + 1] << 32) | ((u64)s_inval[t + 2] << 16);
+  const u32 key_shift = 64 - 2 * k;
+  const u32 top_shift = 2 * k - 2;
+  u32 vmask = 0;
+  u64 r = 0;
+#pragma unroll
+  for (int j = 0; j < KP_ITEMS; j++) {
+    const u64 top = (j == 0) ? A : ((A << (2 * j)) | (B >> (64 - 2 * j)));
+    const u64 f   = top >> key_shift;
+    if (j == 0) r = revcomp64(f, key_shift);
+    else        r = (r >> 2) | ((((f & 3ull) ^ 2ull)) << top_shift);
+    const bool ok = (((I << j) >> (64 - k)) == 0ull);
+    u64 key;
+    if      (mode == 1) key = f;
+    else if (mode == 2) key = r;
+    else                key = (f < r) ? f : r;
+    keys[j] = key;
+    vmask |= (ok ? 1u : 0u) << j;
+  }
+  return vmask;
+}
+
+// Same for k in 33..64: the thread's window is 80 bases (five staged words).
+__device__ __forceinline__ u32 kp_thread_kmers(const u32 *s_codes, const u32 *s_inval, u32 k, int mode,
+                                               K128 (&keys)[KP_ITEMS]) {
+  const u32 t = threadIdx.x;
+  const u128 A = ((u128)s_codes[t] << 96) | ((u128)s_codes[t + 1] << 64) | ((u128)s_codes[t + 2] << 32) |
+                 (u128)s_codes[t + 3];                               // bases 0..63 of the window
+  const u128 B = (u128)s_codes[t + 4] << 96;                         // bases 64..79
+  const u128 I = ((u128)s_inval[t] << 112) | ((u128)s_inval[t + 1] << 96) | ((u128)s_inval[t + 2] << 80) |
+                 ((u128)s_inval[t + 3] << 64) | ((u128)s_inval[t + 4] << 48);
+  const u32 key_shift = 128 - 2 * k;
+  const u32 top_shift = 2 * k - 2;
+  u32 vmask = 0;
+  u128 r = 0;
+#pragma unroll
+  for (int j = 0; j < KP_ITEMS; j++) {
+    const u128 top = (j == 0) ? A : ((A << (2 * j)) | (B >> (128 - 2 * j)));
+    const u128 f   = top >> key_shift;
+    if (j == 0) {
+      // reverse complement: complement, reverse all 128 bits, swap the two bits of every base
+      const u128 c = f ^ (((u128)0xAAAAAAAAAAAAAAAAull << 64) | (u128)0xAAAAAAAAAAAAAAAAull);
+      u64 lo = __brevll((u64)(c >> 64)), hi = __brevll((u64)c);       // halves swap when reversed
+      lo = ((lo >> 1) & 0x5555555555555555ull) | ((lo & 0x5555555555555555ull) << 1);
+      hi = ((hi >> 1) & 0x5555555555555555ull) | ((hi & 0x5555555555555555ull) << 1);
+      r = (((u128)hi << 64) | (u128)lo) >> key_shift;
+    } else {
+      r = (r >> 2) | ((u128)(((u64)f & 3ull) ^ 2ull) << top_shift);
+    }
+    const bool ok = (((I << j) >> (128 - k)) == (u128)0);
+    u128 key;
+    if      (mode == 1) key = f;
+    else if (mode == 2) key = r;
+    else                key = (f < r) ? f : r;
+    keys[j] = KeyOps<K128>::mk(key);
+    vmask |= (ok ? 1u : 0u) << j;
+  }
+  return vmask;
+}
+
+__device__ __forceinline__ void kp_tile_range(u64 num_tiles, u64 &t_begin, u64 &t_end) {
+  const u64 per = (num_tiles + gridDim.x - 1) / gridDim.x;
+  t_begin = (u64)blockIdx.x * per;
+  t_end   = t_begin + per;
+  if (t_begin > num_tiles) t_begin = num_tiles;
+  if (t_end   > num_tiles) t_end   = num_tiles;
+}
+
+// Pass 1: per-workgroup and global per-bucket instance counts.
+template <typename K>
+__global__ __launch_bounds__(KP_BLOCK)
+void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
+                      u64 num_tiles, u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts) {
+  __shared__ u32 s_codes[KP_WORDS];
+  __shared__ u32 s_inval[KP_WORDS];
+  __shared__ u32 s_hist[KP_MAX_BUCKETS];
+
+  const u32  nb = 1u << bucket_bits;
+  const u32  bucket_shift = 2 * k - bucket_bits;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
+
+  for (u32 b = threadIdx.x; b < nb; b += KP_BLOCK) s_hist[b] = 0;
+  __syncthreads();
+
+  u64 t_begin, t_end;
+  kp_tile_range(num_tiles, t_begin, t_end);
+  u32 my_count = 0;
+
+  for (u64 tile = t_begin; tile < t_end; tile++) {
+    kp_stage_tile(bases, n, tile * KP_TILE, aligned, s_codes, s_inval);
+    __syncthreads();
+    K keys[KP_ITEMS];
+    const u32 vmask = kp_thread_kmers(s_codes, s_inval, k, mode, keys);
+    if (nb == 1) {
+      my_count += __popc(vmask);
+    } else {
+#pragma unroll
+      for (int j = 0; j < KP_ITEMS; j++)
+        if ((vmask >> j) & 1u) atomicAdd(&s_hist[KeyOps<K>::bucket(keys[j], bucket_shift)], 1u);
+    }
+    __syncthreads();
+  }
+  if (nb == 1) atomicAdd(&s_hist[0], my_count);
+  __syncthreads();
+
+  for (u32 b = threadIdx.x; b < nb; b += KP_BLOCK) {
+    const u64 v = s_hist[b];
+    block_hist[(u64)blockIdx.x * nb + b] = v;
+    if (v) atomicAdd(&bucket_counts[b], v);
+  }
+}
+
+// Turns per-workgroup counts into per-workgroup absolute write cursors
+// (one workgroup per bucket scans that bucket's column of block_hist).
+__global__ __launch_bounds__(256)
+void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 *__restrict__ bucket_starts) {
+  __shared__ u64 s_tmp[256 / 64 + 1];
+  const u32 b = blockIdx.x;
+  u64 carry = bucket_starts[b];
+  for (u32 base = 0; base < grid; base += 256 * 8) {
+    u64 v[8], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const u32 g = base + threadIdx.x * 8 + q;
+      v[q] = (g < grid) ? block_hist[(u64)g * nb + b] : 0ull;
+      sum += v[q];
+    }
+    u64 tot;
+    u64 run = carry + block_excl_scan<256, u64>(sum, s_tmp, &tot);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const u32 g = base + threadIdx.x * 8 + q;
+      if (g < grid) block_hist[(u64)g * nb + b] = run;
+      run += v[q];
+    }
+    carry += tot;
+  }
+}
+
+// Pass 2: pack + scatter.  Each workgroup owns private cursors (from pass 1),
+// so there are no global atomics and the result layout is deterministic up to
+// the order inside a (workgroup, tile, bucket) run.
+// MAXB: bucket capacity of the LDS tables (64 for the 64-file partition of the count path: 36 KiB of LDS per
+// workgroup instead of 51, i.e. four workgroups per CU instead of three; 1024 for the general operator)
+template <typename K, int MAXB>
+__global__ __launch_bounds__(KP_BLOCK, 5)
+void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
+                           u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kp_dyn_smem[];
+  K *s_keys = reinterpret_cast<K *>(kp_dyn_smem);                   // K[KP_TILE]
+  __shared__ u64 s_cursor[MAXB];
+  __shared__ u32 s_cnt[MAXB];
+  __shared__ u32 s_base[MAXB];
+  __shared__ u32 s_codes[KP_WORDS];
+  __shared__ u32 s_inval[KP_WORDS];
+  __shared__ u32 s_tmp[KP_BLOCK / 64 + 1];
+
+  const u32  nb = 1u << bucket_bits;
+  const u32  bucket_shift = 2 * k - bucket_bits;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
+  const u32  tid = threadIdx.x;
+
+  for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] = block_base[(u64)blockIdx.x * nb + b];
+
+  u64 t_begin, t_end;
+  kp_tile_range(num_tiles, t_begin, t_end);
+
+  for (u64 tile = t_begin; tile < t_end; tile++) {
+    for (u32 b = tid; b < nb; b += KP_BLOCK) s_cnt[b] = 0;
+    kp_stage_tile(bases, n, tile * KP_TILE, aligned, s_codes, s_inval);
+    __syncthreads();
+
+    K keys[KP_ITEMS];
+    const u32 vmask = kp_thread_kmers(s_codes, s_inval, k, mode, keys);
+    u32 total = 0;
+
+    if (nb == 1) {
+      // plain compaction: exclusive scan of per-thread counts
+      const u32 c = __popc(vmask);
+      const u32 base = block_excl_scan<KP_BLOCK, u32>(c, s_tmp, &total);
+      u32 o = base;
+#pragma unroll
+      for (int j = 0; j < KP_ITEMS; j++)
+        if ((vmask >> j) & 1u) s_keys[o++] = keys[j];
+      if (tid == 0) { s_base[0] = 0; s_cnt[0] = total; }
+      __syncthreads();
+    } else {
+      // rank inside the bucket with LDS atomics (order inside a bucket is free)
+      u32 ranks[KP_ITEMS];
+#pragma unroll
+      for (int j = 0; j < KP_ITEMS; j++) {
+        ranks[j] = 0;
+        if ((vmask >> j) & 1u) ranks[j] = atomicAdd(&s_cnt[KeyOps<K>::bucket(keys[j], bucket_shift)], 1u);
+      }
+      __syncthreads();
+      // exclusive scan of the bucket counts, 4 consecutive buckets per thread
+      u32 v[4], sum = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u32 b = tid * 4 + q;
+        v[q] = (b < nb) ? s_cnt[b] : 0u;
+        sum += v[q];
+      }
+      u32 run = block_excl_scan<KP_BLOCK, u32>(sum, s_tmp, &total);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u32 b = tid * 4 + q;
+        if (b < nb) s_base[b] = run;
+        run += v[q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < KP_ITEMS; j++)
+        if ((vmask >> j) & 1u) s_keys[s_base[KeyOps<K>::bucket(keys[j], bucket_shift)] + ranks[j]] = keys[j];
+      __syncthreads();
+    }
+
+    // contiguous runs per bucket leave as coalesced stores
+    for (u32 i = tid; i < total; i += KP_BLOCK) {
+      const K   key = s_keys[i];
+      const u32 b   = (nb == 1) ? 0u : KeyOps<K>::bucket(key, bucket_shift);
+      out[s_cursor[b] + (u64)(i - s_base[b])] = key;
+    }
+    __syncthreads();
+    for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] += s_cnt[b];
+    __syncthreads();
+  }
+}
+
+uint32_t kp_grid_size(uint64_t n_bases) {
+  const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
+  uint64_t g = num_tiles < 2048 ? num_tiles : 2048;
+  return (uint32_t)(g ? g : 1);
+}
+
+size_t kp_workspace_bytes(uint32_t bucket_bits) {
+  return (size_t)2048 * ((size_t)1 << bucket_bits) * sizeof(uint64_t);
+}
+
+hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
+                                 uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st) {
+  const uint32_t nb = 1u << bucket_bits;
+  MGC_CHECK(hipMemsetAsync(d_bucket_counts, 0, sizeof(uint64_t) * nb, st));
+  if (n_bases == 0) return hipSuccess;
+  const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
+  const uint32_t grid = kp_grid_size(n_bases);
+  if (k <= 32)
+    hipLaunchKernelGGL(kmer_hist_kernel<u64>, dim3(grid), dim3(KP_BLOCK), 0, st,
+                       d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
+                       reinterpret_cast<u64 *>(d_ws), reinterpret_cast<u64 *>(d_bucket_counts));
+  else
+    hipLaunchKernelGGL(kmer_hist_kernel<K128>, dim3(grid), dim3(KP_BLOCK), 0, st,
+                       d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
+                       reinterpret_cast<u64 *>(d_ws), reinterpret_cast<u64 *>(d_bucket_counts));
+  return hipGetLastError();
+}
+
+hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
+                                 uint32_t bucket_bits, const uint64_t *d_bucket_starts, void *d_keys,
+                                 void *d_ws, hipStream_t st) {
+  if (n_bases == 0) return hipSuccess;
+  const uint32_t nb = 1u << bucket_bits;
+  const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
+  const uint32_t grid = kp_grid_size(n_bases);
+  hipLaunchKernelGGL(kmer_scan_kernel, dim3(nb), dim3(256), 0, st,
+                     reinterpret_cast<u64 *>(d_ws), grid, nb, reinterpret_cast<const u64 *>(d_bucket_starts));
+  MGC_CHECK(hipGetLastError());
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_partition_kernel<K128, 64>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_partition_kernel<K128, KP_MAX_BUCKETS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
+    attr_done = true;
+  }
+#define MGC_KP_LAUNCH(K_, MAXB_)                                                                                   \
+  hipLaunchKernelGGL((kmer_partition_kernel<K_, MAXB_>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K_), st,      \
+                     d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,                                  \
+                     reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys))
+  if (k <= 32) { if (nb <= 64) MGC_KP_LAUNCH(u64, 64); else MGC_KP_LAUNCH(u64, KP_MAX_BUCKETS); }
+  else         { if (nb <= 64) MGC_KP_LAUNCH(K128, 64); else MGC_KP_LAUNCH(K128, KP_MAX_BUCKETS); }
+#undef MGC_KP_LAUNCH
+  return hipGetLastError();
+}
+
+
+}  // namespace mgc

@@ -1,0 +1,1190 @@
+// mgc_sort.hip -- radix sort / grouping passes (gfx950).
+//
+// What each kernel replaces in the reference (paths relative to the reference root):
+//   kmer_hist_kernel / kmer_partition_kernel
+//       kmerIterator + insertKmers            src/meryl/merylOp-countThreads.C:235-280
+//       (2-bit pack A0 C1 T2 G3, reverse complement, canonical pick, prefix split;
+//        the per-bucket spin-lock + bit-packed append of merylCountArray.C:490-728
+//        becomes a histogram + lock-free scatter into per-file regions)
+//   radix_* kernels
+//       unpack + std::sort of each bucket      src/meryl/merylCountArray.C:276-289,330
+//   rle_* kernels
+//       the two run-length passes              src/meryl/merylCountArray.C:334-358
+//   block_offsets_kernel
+//       the per-prefix (prefix, nKmers) split that feeds addBlock
+//                                              src/meryl/merylCountArray.C:472-475
+//
+// All of it is integer / byte work bounded by HBM bandwidth: loads are 16 B (bases) or
+// 8 B per lane coalesced, every reorder is staged through LDS so stores leave as
+// contiguous runs, ranking uses 64-lane ballots, cross-workgroup prefixes use 8-byte
+// {flag,epoch,value} granules with agent-scope relaxed atomics (no fences needed:
+// the datum is the flag).  Wave = 64 everywhere.
+#include "mgc_common.hpp"
+
+namespace mgc {
+
+// ============================================================================
+//  LSB radix sort of uint64 keys
+// ============================================================================
+//
+// One pass = one stable counting sort on a digit of <= RB bits:
+//   * keys of a tile (BLOCK*KPT consecutive keys) are loaded wave-striped, so a
+//     wave reads 512 contiguous bytes per instruction;
+//   * each wave ranks its keys with RB ballots per key (peers holding the same
+//     digit) against a wave-private LDS digit counter -- data-independent cost,
+//     stable by construction;
+//   * digit totals of the tile are prefix-summed; in ONESWEEP mode the tile's
+//     global digit bases come from a decoupled look-back over earlier tiles'
+//     8-byte status granules, in CLASSIC mode from a precomputed table;
+//   * keys are permuted through LDS into digit order and leave as contiguous
+//     runs (one run per digit), i.e. coalesced 8 B/lane stores.
+// Algorithmic HBM traffic per pass: 8 B read + 8 B write per key (ONESWEEP; the
+// digit histograms of all passes are taken in one extra 8 B/key read up front).
+
+constexpr int      RS_MAX_PASSES = 16;
+constexpr int      RS_MAX_RADIX  = 512;
+constexpr u32      RS_SPIN_LIMIT = 1u << 24;
+
+struct SortHeader {                       // lives at the start of the sort workspace
+  u64 ghist[RS_MAX_PASSES][RS_MAX_RADIX]; // digit counts per pass
+  u64 gbase[RS_MAX_PASSES][RS_MAX_RADIX]; // exclusive digit bases per pass
+  u64 row_total[RS_MAX_RADIX];            // classic mode scratch
+  u32 ticket[RS_MAX_PASSES];
+  u32 pad[16];
+};
+
+struct PassList { u32 n; u32 shift[RS_MAX_PASSES]; u32 mask[RS_MAX_PASSES]; };
+
+// Digit histograms of every pass in one read of the keys.  NP > 0: exactly NP passes (shifts and masks stay in
+// registers, the LDS histogram is NP rows: 4 KiB for the two passes of the finish path, so eight 256-thread
+// workgroups fit a CU); NP == 0: any number of passes up to RS_MAX_PASSES.
+template <typename K, int NP>
+__global__ __launch_bounds__(256)
+void radix_hist_kernel(const K *__restrict__ in, u64 n, PassList pl, u64 *__restrict__ ghist) {
+  constexpr u32 ROWS = NP ? NP : RS_MAX_PASSES;
+  __shared__ u32 s_h[ROWS * RS_MAX_RADIX];
+  const u32 np = NP ? (u32)NP : pl.n;
+  for (u32 i = threadIdx.x; i < np * RS_MAX_RADIX; i += 256) s_h[i] = 0;
+  __syncthreads();
+
+  // 4 independent loads in flight per thread (the loop is otherwise latency-bound)
+  constexpr u32 UNR = 4;
+  const u64 gstride = (u64)gridDim.x * 256 * UNR;
+  for (u64 base = (u64)blockIdx.x * 256 * UNR; base < n; base += gstride) {
+    K key[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (u32 j = 0; j < UNR; j++) {
+      const u64 i = base + (u64)j * 256 + threadIdx.x;
+      ok[j] = i < n;
+      if (ok[j]) key[j] = in[i];
+    }
+#pragma unroll
+    for (u32 j = 0; j < UNR; j++) {
+      if (!ok[j]) continue;
+      if (NP) {
+#pragma unroll
+        for (u32 p = 0; p < ROWS; p++)
+          atomicAdd(&s_h[p * RS_MAX_RADIX + KeyOps<K>::digit(key[j], pl.shift[p], pl.mask[p])], 1u);
+      } else {
+        for (u32 p = 0; p < np; p++)
+          atomicAdd(&s_h[p * RS_MAX_RADIX + KeyOps<K>::digit(key[j], pl.shift[p], pl.mask[p])], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < np * RS_MAX_RADIX; i += 256) {
+    const u32 v = s_h[i];
+    if (v) atomicAdd(&ghist[i], (u64)v);
+  }
+}
+
+template <typename K>
+static void launch_radix_hist(const K *src, u64 n, const PassList &pl, u64 *ghist, hipStream_t st) {
+  uint64_t hgrid = (n + 256 * 16 - 1) / (256 * 16);
+  if (hgrid > 2048) hgrid = 2048;
+  const dim3 g((uint32_t)hgrid), b(256);
+  switch (pl.n) {
+    case 1:  hipLaunchKernelGGL((radix_hist_kernel<K, 1>), g, b, 0, st, src, n, pl, ghist); break;
+    case 2:  hipLaunchKernelGGL((radix_hist_kernel<K, 2>), g, b, 0, st, src, n, pl, ghist); break;
+    case 3:  hipLaunchKernelGGL((radix_hist_kernel<K, 3>), g, b, 0, st, src, n, pl, ghist); break;
+    case 4:  hipLaunchKernelGGL((radix_hist_kernel<K, 4>), g, b, 0, st, src, n, pl, ghist); break;
+    default: hipLaunchKernelGGL((radix_hist_kernel<K, 0>), g, b, 0, st, src, n, pl, ghist); break;
+  }
+}
+
+// Exclusive scan over the digits of each pass (one workgroup per pass).
+__global__ __launch_bounds__(RS_MAX_RADIX)
+void radix_digit_scan_kernel(const u64 *__restrict__ ghist, u64 *__restrict__ gbase) {
+  __shared__ u64 s_tmp[RS_MAX_RADIX / 64 + 1];
+  const u32 p = blockIdx.x;
+  const u64 v = ghist[(u64)p * RS_MAX_RADIX + threadIdx.x];
+  u64 total;
+  const u64 e = block_excl_scan<RS_MAX_RADIX, u64>(v, s_tmp, &total);
+  gbase[(u64)p * RS_MAX_RADIX + threadIdx.x] = e;
+}
+
+template <int RB>
+__device__ __forceinline__ u64 match_digit(u32 d) {
+  u64 peers = ~0ull;
+#pragma unroll
+  for (int b = 0; b < RB; b++) {
+    const bool bit = (d >> b) & 1u;
+    const u64  m   = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+__device__ __forceinline__ void status_store(u64 *p, u64 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 status_load(u64 *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Look-back status granule: one 8-byte word carries TWO digits, each as
+// flag(2) | value(30); flag 1 = tile aggregate, 2 = inclusive prefix.  Half as many
+// fabric transactions as one granule per digit, and a digit pair is published by one
+// store, so no fence is needed (the datum is the flag).  Values < 2^30: the look-back
+// path handles n < 2^30 keys per sort call, larger calls take the classic path.
+__device__ __forceinline__ u64 st_pack(u32 f0, u32 v0, u32 f1, u32 v1) {
+  return ((u64)((f1 << 30) | v1) << 32) | (u64)((f0 << 30) | v0);
+}
+
+
+template <typename K, int RB, int BLOCK, int KPT, int LB = 0>
+struct RadixSmem {
+  static constexpr int R     = 1 << RB;
+  static constexpr int NW    = BLOCK / 64;
+  static constexpr int TILE  = BLOCK * KPT;
+  // region 0 is shared between the ranking scratch (wave digit counters u32[NW][R] followed by
+  // wave match masks u64[NW][R]) and the key exchange buffer
+  static constexpr size_t RANK_BYTES = (size_t)NW * R * 12;
+  static constexpr size_t REGION0 = ((size_t)TILE * sizeof(K) > RANK_BYTES) ? (size_t)TILE * sizeof(K) : RANK_BYTES;
+  static constexpr size_t OFF_GBASE = REGION0;                     // u64[R]
+  static constexpr size_t OFF_DBASE = OFF_GBASE + (size_t)R * 8;   // u32[R]
+  static constexpr size_t OFF_CNT   = OFF_DBASE + (size_t)R * 4;   // u32[R]
+  static constexpr size_t OFF_TMP   = OFF_CNT + (size_t)R * 4;     // u32[64] scan scratch + misc
+  static constexpr size_t OFF_WIN   = OFF_TMP + 64 * 4;            // u64[LB_WINDOW][R/2] look-back window (LB == 2)
+  static constexpr size_t WIN_BYTES = (LB == 2 || LB == 3) ? ((RB == 9 && BLOCK == 512) ? 4096 : 8192) : 0;
+  static constexpr size_t BYTES     = OFF_WIN + WIN_BYTES;
+  // workgroups per CU the LDS budget admits (160 KiB per CU), capped at 2
+  static constexpr int    WG_PER_CU = (2 * BYTES <= 160 * 1024) ? 2 : 1;
+  static constexpr int    MIN_WAVES_PER_SIMD = (WG_PER_CU * BLOCK) / 256;
+};
+
+template <typename K, int RB, int BLOCK, int KPT, int LB, int MATCH>
+__global__ __launch_bounds__(BLOCK, (RadixSmem<K, RB, BLOCK, KPT, LB>::MIN_WAVES_PER_SIMD))
+void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, u32 shift, u32 dmask,
+                          const u64 *__restrict__ gbase,      // LOOKBACK: exclusive digit bases of this pass
+                          u64 *__restrict__ status,           // LOOKBACK: [num_tiles][R/2] granules of this pass (zeroed)
+                          u32 *__restrict__ ticket, u32 *__restrict__ error_flag,
+                          u32 flags,                          // bit0: XCD-chunked tile order, bit1: non-temporal key loads
+                          const u64 *__restrict__ tile_offs,  // !LOOKBACK: [R][num_tiles] absolute offsets
+                          u64 num_tiles, u64 *__restrict__ dbg /* optional: 8 cycle stamps per tile */) {
+  using SM = RadixSmem<K, RB, BLOCK, KPT, LB>;
+#define MGC_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg_t[i] = clock64(); } while (0)
+  u64 dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  MGC_STAMP(0);
+  using KO = KeyOps<K>;
+  constexpr int R = SM::R, NW = SM::NW, TILE = SM::TILE;
+  static_assert(BLOCK >= R, "one thread per digit needed");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  K   *s_keys  = reinterpret_cast<K *>(smem);
+  u32 *s_whist = reinterpret_cast<u32 *>(smem);                       // aliases s_keys (see barriers)
+  u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
+  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
+  u32 *s_cnt   = reinterpret_cast<u32 *>(smem + SM::OFF_CNT);
+  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
+
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+
+  constexpr bool LOOKBACK = (LB != 0);
+  // Tile ids are tickets: every lower-numbered tile has started, hence is resident and will
+  // publish its aggregate -- the look-back cannot deadlock (spins are bounded anyway).
+  u64 tile;
+  if (LOOKBACK) {
+    if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    tile = s_tmp[32];
+  } else {
+    tile = blockIdx.x;
+  }
+
+  for (u32 i = tid; i < (u32)(NW * R * 3); i += BLOCK) s_whist[i] = 0;   // counters + match masks
+  __syncthreads();
+
+  MGC_STAMP(1);
+  // ---- load (wave-striped: 512 contiguous bytes per wave instruction) ----
+  const u64  tile_base = tile * (u64)TILE;
+  const bool full      = (tile_base + TILE <= n);
+  const u64  wave_base = tile_base + (u64)w * (64 * KPT) + lane;
+  K keys[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const u64 idx = wave_base + (u64)j * 64;
+    keys[j] = (full || idx < n) ? in[idx] : KO::pad();  // padding sorts to the end of the last digit
+  }
+  (void)flags;
+
+  // ---- rank inside the wave (stable: by lane order inside a row, rows in order) ----
+  const u64 lt_mask = (1ull << lane) - 1ull;
+  u32 ranks[KPT / 2];                                  // two 16-bit ranks per register (rank < TILE <= 2^14)
+  if (MATCH == 0) {
+    // peers by RB ballots per key: data-independent cost, VALU heavy
+    lds_u32 *wh = (lds_u32 *)(smem) + w * R;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 d     = KO::digit(keys[j], shift, dmask);
+      const u64 peers = match_digit<RB>(d);
+      const u32 lower = __popcll(peers & lt_mask);
+      const u32 base  = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (lower == 0) __hip_atomic_store(&wh[d], base + (u32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (j & 1) ranks[j / 2] |= (base + lower) << 16;
+      else       ranks[j / 2]  = (base + lower);
+    }
+  } else {
+    // peers through a wave-private LDS mask per digit: every lane ORs its lane bit into
+    // mask[digit], reads the mask back (LDS executes a wave's instructions in order), and the
+    // lowest peer bumps the running digit counter and clears the mask for the next row.
+    lds_u32 *wh = (lds_u32 *)(smem) + w * R;
+    lds_u64 *mk = (lds_u64 *)(smem + (size_t)NW * R * 4) + w * R;
+    const u64 lane_bit = 1ull << lane;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 d = KO::digit(keys[j], shift, dmask);
+      __hip_atomic_fetch_or(&mk[d], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u64 peers = __hip_atomic_load(&mk[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u32 base  = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u32 lower = __popcll(peers & lt_mask);
+      if (lower == 0) {
+        __hip_atomic_store(&wh[d], base + (u32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_store(&mk[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      if (j & 1) ranks[j / 2] |= (base + lower) << 16;
+      else       ranks[j / 2]  = (base + lower);
+    }
+  }
+  __syncthreads();
+
+  MGC_STAMP(2);
+  // ---- digit totals of the tile, wave-exclusive bases ----
+  const u32 n_valid = full ? (u32)TILE : (u32)(n - tile_base);
+  u32 count = 0;
+  if (tid < (u32)R) {
+    u32 acc = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ww++) {
+      const u32 t = s_whist[ww * R + tid];
+      s_whist[ww * R + tid] = acc;
+      acc += t;
+    }
+    count = acc;
+    // padding keys all carry the top digit; they are not published to later tiles
+    s_cnt[tid] = (tid == dmask) ? count - ((u32)TILE - n_valid) : count;
+  }
+  u32 tile_total;
+  const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tile_total);
+  if (tid < (u32)R) s_dbase[tid] = excl;
+
+  // granules of this tile: publish the aggregate as early as possible
+  // LB 1/2: two digits per granule (30-bit values, n < 2^30); LB 3: one digit per granule (62-bit values)
+  constexpr int GW = (LB == 3) ? 1 : 2;                 // digits per granule
+  constexpr int G  = R / GW;                            // granules per tile
+  constexpr u64 V62 = (1ull << 62) - 1;
+  u64 *mine = status + (LOOKBACK ? tile * (u64)G + tid : 0);
+  if (LOOKBACK) {
+    __syncthreads();                                    // s_cnt / s_dbase visible
+    if (tid < (u32)G) {
+      const u32 c0 = s_cnt[GW * tid], c1 = (GW == 2) ? s_cnt[GW * tid + 1] : 0u;
+      const u32 fl = (tile == 0) ? 2u : 1u;
+      status_store(mine, (GW == 2) ? st_pack(fl, c0, fl, c1) : (((u64)fl << 62) | (u64)c0));
+      if constexpr (LB == 1) {
+        // serial walk per digit pair, four predecessors in flight per round
+        u32 p0 = 0, p1 = 0;
+        if (tile != 0) {
+          bool need0 = true, need1 = true;
+          u64  t = tile - 1;
+          u32  spins = 0;
+          while (need0 || need1) {
+            u64 g[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              g[i] = (t >= (u64)i) ? status_load(status + (t - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
+            u32 used = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              if (need0 || need1) {
+                const u32 lo = (u32)g[i], hi = (u32)(g[i] >> 32);
+                const u32 f0 = lo >> 30, f1 = hi >> 30;
+                if (f0 == 0 || f1 == 0) break;
+                if (need0) { p0 += lo & 0x3FFFFFFFu; if (f0 == 2) need0 = false; }
+                if (need1) { p1 += hi & 0x3FFFFFFFu; if (f1 == 2) need1 = false; }
+                used++;
+              }
+            }
+            t -= (used <= t) ? used : t;
+            if (used == 0) {
+              if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); break; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+          status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
+        }
+        s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
+        s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
+      }
+    }
+    if (LB == 1) __syncthreads();
+  } else {
+    if (tid < (u32)R) s_gbase[tid] = tile_offs[(u64)tid * num_tiles + tile] - (u64)excl;
+    __syncthreads();
+  }
+
+  MGC_STAMP(3);
+  // ---- final position of every key inside the sorted tile ----
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {           // ranks[] becomes positions in place (still < TILE)
+    const u32 d = KO::digit(keys[j], shift, dmask);
+    const u32 add = s_dbase[d] + s_whist[w * R + d];
+    ranks[j / 2] += (j & 1) ? (add << 16) : add;
+  }
+  __syncthreads();                          // s_whist is dead; its storage becomes s_keys
+#pragma unroll
+  for (int j = 0; j < KPT; j++) s_keys[(j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu)] = keys[j];
+  __syncthreads();                          // keys now live in LDS only: registers are free for the look-back
+  MGC_STAMP(4);
+
+  if constexpr (LB == 2 || LB == 3) {
+    // window-parallel look-back after the exchange (keys live in LDS only, registers are free):
+    // all waves fetch the granules of the next LB_WINDOW predecessors with coalesced loads into
+    // LDS, the R/2 digit-pair threads consume the ready prefix.
+    constexpr int TPL = BLOCK / G;                      // predecessor tiles covered by one load per thread
+    constexpr int WIN0 = (int)(SM::WIN_BYTES / ((size_t)G * 8));
+    constexpr int LB_WINDOW = (WIN0 < TPL) ? TPL : WIN0;
+    constexpr int LPT = LB_WINDOW / TPL;
+    static_assert(LB_WINDOW % TPL == 0 && LPT >= 1, "window must be a multiple of the tiles one load covers");
+    static_assert((size_t)LB_WINDOW * G * 8 <= SM::WIN_BYTES, "look-back window does not fit");
+    u64 *s_win = reinterpret_cast<u64 *>(smem + SM::OFF_WIN);
+    u32 *s_q   = s_tmp + 40;
+    u32 *s_all = s_tmp + 41;
+    u32 c0 = 0, c1 = 0;
+    u64 p0 = 0, p1 = 0;
+    bool need0 = false, need1 = false;
+    if (tid < (u32)G) {
+      c0 = s_cnt[GW * tid]; c1 = (GW == 2) ? s_cnt[GW * tid + 1] : 0u;
+      need0 = (tile != 0);
+      need1 = (GW == 2) && (tile != 0);
+    }
+    if (tile != 0) {                                    // uniform
+      const u32 sub = tid / G, g = tid % G;
+      u64 t_next = tile - 1;
+      u32 spins = 0;
+      while (true) {
+#pragma unroll
+        for (int i = 0; i < LPT; i++) {
+          const u32 idx = sub + (u32)(TPL * i);
+          s_win[idx * G + g] = (t_next >= (u64)idx) ? status_load(status + (t_next - idx) * (u64)G + g)
+                                                    : ((GW == 2) ? st_pack(2, 0, 2, 0) : (2ull << 62));
+        }
+        if (tid == 0) { *s_q = LB_WINDOW; *s_all = 1u; }
+        __syncthreads();
+        if (tid < (u32)G) {
+          u32 q = 0;
+          for (; q < (u32)LB_WINDOW; q++) {
+            const u64 v = s_win[q * G + tid];
+            if ((GW == 2 && ((u32)v >> 30) == 0u) || ((u32)(v >> 62)) == 0u) break;
+          }
+          if (q < (u32)LB_WINDOW) atomicMin(s_q, q);
+        }
+        __syncthreads();
+        const u32 q = *s_q;
+        if (tid < (u32)G) {
+          for (u32 i = 0; i < q && (need0 || need1); i++) {
+            const u64 v = s_win[i * G + tid];
+            if (GW == 2) {
+              const u32 lo = (u32)v, hi = (u32)(v >> 32);
+              if (need0) { p0 += lo & 0x3FFFFFFFu; if ((lo >> 30) == 2u) need0 = false; }
+              if (need1) { p1 += hi & 0x3FFFFFFFu; if ((hi >> 30) == 2u) need1 = false; }
+            } else {
+              p0 += v & V62;
+              if ((v >> 62) == 2ull) need0 = false;
+            }
+          }
+          if (need0 || need1) *s_all = 0u;
+        }
+        __syncthreads();
+        if (*s_all) break;
+        t_next -= (q <= t_next) ? q : t_next;
+        if (q == 0) {
+          if (++spins > RS_SPIN_LIMIT) { if (tid == 0) atomicExch(error_flag, 1u); break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+      }
+    }
+    if (tid < (u32)G) {
+      if (tile != 0)
+        status_store(mine, (GW == 2) ? st_pack(2, (u32)p0 + c0, 2, (u32)p1 + c1) : ((2ull << 62) | (p0 + (u64)c0)));
+      s_gbase[GW * tid] = gbase[GW * tid] + p0 - (u64)s_dbase[GW * tid];
+      if (GW == 2) s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + p1 - (u64)s_dbase[2 * tid + 1];
+    }
+    __syncthreads();
+  }
+
+  MGC_STAMP(5);
+  // ---- contiguous runs leave coalesced ----
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const u32 i = (u32)j * BLOCK + tid;
+    if (i < n_valid) {
+      const K   key = s_keys[i];
+      const u32 d   = KO::digit(key, shift, dmask);
+      out[s_gbase[d] + (u64)i] = key;
+    }
+  }
+  MGC_STAMP(6);
+  if (dbg && threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) dbg[tile * 8 + i] = dbg_t[i];
+  }
+#undef MGC_STAMP
+}
+
+// ---- pipelined look-back pass (plan.lookback == 5) ----------------------------
+// Same pass as radix_scatter_kernel<.., LB, MATCH=1>, restructured so HBM never idles behind the
+// per-tile work: workgroups are persistent, take the ticket of their NEXT tile at the top of an
+// iteration, and once the keys of the current tile live in LDS (after the exchange) the registers are
+// refilled with the next tile's keys while the look-back and the write-out run.  s_waitcnt vmcnt is
+// per wave and in order, so the waves that poll the status granules (tid < R/2, the first R/128
+// waves) fetch their share of the next tile only after their walk; all other waves fetch before it.
+// A ticket held one tile ahead keeps the no-deadlock argument: the lowest unfinished tile is always
+// some workgroup's current one.  Granules: two digits per 8 bytes, n < 2^30.
+template <typename K, int RB, int BLOCK, int KPT, bool DBG>
+__global__ __launch_bounds__(BLOCK, (RadixSmem<K, RB, BLOCK, KPT, 4>::MIN_WAVES_PER_SIMD))
+void radix_scatter_pipe_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, u32 shift, u32 dmask,
+                               const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
+                               u32 *__restrict__ error_flag, u64 num_tiles, u64 *__restrict__ dbg) {
+  using SM = RadixSmem<K, RB, BLOCK, KPT, 4>;
+  using KO = KeyOps<K>;
+  constexpr int R = SM::R, NW = SM::NW, TILE = SM::TILE, G = R / 2;
+  constexpr int WALK = 8;                               // predecessor granules in flight per walker thread
+  static_assert(BLOCK >= R && G % 64 == 0, "one thread per digit; whole waves walk");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  K   *s_keys  = reinterpret_cast<K *>(smem);
+  u32 *s_whist = reinterpret_cast<u32 *>(smem);                       // aliases s_keys (see barriers)
+  u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
+  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
+  u32 *s_cnt   = reinterpret_cast<u32 *>(smem + SM::OFF_CNT);
+  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
+  const u32 tid0 = threadIdx.x;
+  u32 tid = tid0, lane = tid0 & 63u, w = tid0 >> 6;
+
+  K keys[KPT];
+  auto fetch = [&](u64 t) __attribute__((always_inline)) {
+    if (t >= num_tiles) return;
+    const u64 tile_base = t * (u64)TILE;
+    const u64 wave_off  = tile_base + (u64)w * (64 * KPT) + lane;
+    const K  *p         = in + wave_off;
+    if (tile_base + TILE <= n) {                        // every tile but the last
+#pragma unroll
+      for (int j = 0; j < KPT; j++) keys[j] = p[j * 64];
+    } else {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) keys[j] = (wave_off + (u64)j * 64 < n) ? p[j * 64] : KO::pad();
+    }
+  };
+
+  if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
+  __syncthreads();
+  u64 tile = s_tmp[32];
+  fetch(tile);
+
+  u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define PK_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
+  while (tile < num_tiles) {
+    if (DBG) t0 = __builtin_readcyclecounter();
+    // the thread coordinates are laundered once per iteration: otherwise every LDS address of the
+    // unrolled body is hoisted out of the loop and the kernel spills
+    tid = tid0;
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63u; w = tid >> 6;
+    const u64 lt_mask = (1ull << lane) - 1ull, lane_bit = 1ull << lane;
+    const bool walker = tid < (u32)G;                   // whole waves: G is a multiple of 64
+    if (tid == 0) s_tmp[33] = atomicAdd(ticket, 1u);    // published by the barrier below
+    for (u32 i = tid; i < (u32)(NW * R * 3); i += BLOCK) s_whist[i] = 0;   // counters + match masks
+    __syncthreads();
+    const u64 next = s_tmp[33];
+    PK_STAMP(0);
+    const u64 tile_base = tile * (u64)TILE;
+    const u32 n_valid   = (tile_base + TILE <= n) ? (u32)TILE : (u32)(n - tile_base);
+
+    // ---- rank inside the wave through wave-private LDS match masks (see radix_scatter_kernel) ----
+    u32 ranks[KPT / 2];
+    {
+      lds_u32 *wh = (lds_u32 *)(smem) + w * R;
+      lds_u64 *mk = (lds_u64 *)(smem + (size_t)NW * R * 4) + w * R;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 d = KO::digit(keys[j], shift, dmask);
+        __hip_atomic_fetch_or(&mk[d], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const u64 peers = __hip_atomic_load(&mk[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const u32 base  = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const u32 lower = __popcll(peers & lt_mask);
+        if (lower == 0) {
+          __hip_atomic_store(&wh[d], base + (u32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          __hip_atomic_store(&mk[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        if (j & 1) ranks[j / 2] |= (base + lower) << 16;
+        else       ranks[j / 2]  = (base + lower);
+      }
+    }
+    __syncthreads();
+    PK_STAMP(1);
+
+    // ---- digit totals of the tile, wave-exclusive bases ----
+    u32 count = 0;
+    if (tid < (u32)R) {
+      u32 acc = 0;
+#pragma unroll
+      for (int ww = 0; ww < NW; ww++) {
+        const u32 t = s_whist[ww * R + tid];
+        s_whist[ww * R + tid] = acc;
+        acc += t;
+      }
+      count = acc;
+      s_cnt[tid] = (tid == dmask) ? count - ((u32)TILE - n_valid) : count;   // padding is not published
+    }
+    u32 tile_total;
+    const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tile_total);
+    if (tid < (u32)R) s_dbase[tid] = excl;
+    __syncthreads();
+
+    // ---- publish the aggregate, then move the keys to their place in the sorted tile ----
+    u64 *mine = status + tile * (u64)G + tid;
+    u32 c0 = 0, c1 = 0;
+    if (walker) {
+      c0 = s_cnt[2 * tid]; c1 = s_cnt[2 * tid + 1];
+      const u32 fl = (tile == 0) ? 2u : 1u;
+      status_store(mine, st_pack(fl, c0, fl, c1));
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 d = KO::digit(keys[j], shift, dmask);
+      const u32 add = s_dbase[d] + s_whist[w * R + d];
+      ranks[j / 2] += (j & 1) ? (add << 16) : add;
+    }
+    __syncthreads();                          // s_whist is dead; its storage becomes s_keys
+#pragma unroll
+    for (int j = 0; j < KPT; j++) s_keys[(j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu)] = keys[j];
+    __syncthreads();                          // keys live in LDS only: the registers take the next tile
+    PK_STAMP(2);
+
+    if (!walker) {
+      fetch(next);
+    } else {
+      // flat walk over the predecessors' granules, WALK in flight per round (a two-level scheme with
+      // group sums was tried: it needs a third dependent round trip and measured 25% slower)
+      u32 p0 = 0, p1 = 0;
+      if (tile != 0) {
+        bool done = false;
+        u64  t = tile - 1;
+        u32  spins = 0;
+        while (!done) {
+          u64 gv[WALK];
+#pragma unroll
+          for (int i = 0; i < WALK; i++)
+            gv[i] = (t >= (u64)i) ? status_load(status + (t - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
+          u32 used = 0;
+          bool open = true;
+#pragma unroll
+          for (int i = 0; i < WALK; i++) {
+            const u32 lo = (u32)gv[i], hi = (u32)(gv[i] >> 32);
+            const u32 f = lo >> 30;                     // both halves of a granule carry the same flag
+            open = open && !done && (f != 0);
+            if (open) {
+              p0 += lo & 0x3FFFFFFFu; p1 += hi & 0x3FFFFFFFu;
+              if (f == 2) done = true;
+              used++;
+            }
+          }
+          t -= (used <= t) ? used : t;
+          if (used == 0) {
+            if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
+      }
+      s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
+      s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
+      fetch(next);
+    }
+    __syncthreads();
+    PK_STAMP(3);
+
+    // ---- contiguous runs leave coalesced ----
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 i = (u32)j * BLOCK + tid;
+      if (i < n_valid) {
+        const K   key = s_keys[i];
+        const u32 d   = KO::digit(key, shift, dmask);
+        out[s_gbase[d] + (u64)i] = key;
+      }
+    }
+    PK_STAMP(4);
+    __syncthreads();                          // s_keys / s_gbase are rewritten by the next iteration
+    PK_STAMP(5);
+    tile = next;
+    if (DBG) ph[7]++;
+  }
+  if (DBG && tid0 == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
+#undef PK_STAMP
+}
+
+// ---- grouping pass (plan.mode == 3; the sub-bucket finish path) -----------------------
+// The finish path does not need a sorted file, only its k-mers GROUPED by their top bits: sub-bucket
+// members may come in any order (the LDS finish counts them anyway).  A grouping pass therefore ranks
+// a tile with one returning LDS atomic per key -- no wave-private counters, no match masks, a 2 KiB
+// histogram to clear instead of 96 KiB -- and only has to respect the TILE order for the bases.
+// With two digits (d_hi:d_lo, LSD): pass 1 groups by d_lo with plain tiles; pass 2 must keep the d_lo
+// order inside a d_hi group, which holds if no tile of pass 2 mixes two d_lo values: its tiles are cut
+// at the d_lo region boundaries of pass 1's output (region table below), every region's last tile
+// being partial.  Persistent workgroups, ticket one tile ahead, next tile's keys fetched behind the
+// look-back and the write-out, as in radix_scatter_pipe_kernel.
+template <typename K, int RB, int BLOCK, int KPT>
+struct GroupSmem {
+  static constexpr int R = 1 << RB, NW = BLOCK / 64, TILE = BLOCK * KPT;
+  static constexpr size_t OFF_HIST  = (size_t)TILE * sizeof(K);       // u32[R]
+  static constexpr size_t OFF_GBASE = OFF_HIST + (size_t)R * 4;       // u64[R]
+  static constexpr size_t OFF_DBASE = OFF_GBASE + (size_t)R * 8;      // u32[R]
+  static constexpr size_t OFF_CNT   = OFF_DBASE + (size_t)R * 4;      // u32[R]
+  static constexpr size_t OFF_TMP   = OFF_CNT + (size_t)R * 4;        // u32[64]
+  static constexpr size_t OFF_INFO  = OFF_TMP + 64 * 4;               // u64[4]: key base / valid count of current+next tile
+  static constexpr size_t BYTES     = OFF_INFO + 4 * 8;
+  static constexpr int    WG_PER_CU = (2 * BYTES <= 160 * 1024) ? 2 : 1;
+  static constexpr int    MIN_WAVES_PER_SIMD = (WG_PER_CU * BLOCK) / 256;
+};
+
+// region table of a second grouping pass: regions = digit groups of the first pass (gbase_prev = its
+// exclusive digit bases, RS_MAX_RADIX entries, unused digits sit at n)
+__global__ __launch_bounds__(RS_MAX_RADIX)
+void group_regions_kernel(const u64 *__restrict__ gbase_prev, u64 n, u32 tile, u64 *__restrict__ region_start,
+                          u32 *__restrict__ region_tiles) {
+  __shared__ u32 s_tmp[RS_MAX_RADIX / 64 + 1];
+  const u32 r = threadIdx.x;
+  const u64 a = gbase_prev[r], b = (r + 1 < RS_MAX_RADIX) ? gbase_prev[r + 1] : n;
+  const u32 nt = (u32)((b - a + tile - 1) / tile);
+  u32 total;
+  const u32 e = block_excl_scan<RS_MAX_RADIX, u32>(nt, s_tmp, &total);
+  region_start[r] = a;
+  region_tiles[r] = e;
+  if (r == 0) { region_start[RS_MAX_RADIX] = n; region_tiles[RS_MAX_RADIX] = total; }
+}
+
+template <typename K, int RB, int BLOCK, int KPT, bool DBG>
+__global__ __launch_bounds__(BLOCK, (GroupSmem<K, RB, BLOCK, KPT>::MIN_WAVES_PER_SIMD))
+void radix_group_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, u32 shift, u32 dmask,
+                        const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
+                        u32 *__restrict__ error_flag, u64 num_tiles_plain,
+                        const u64 *__restrict__ region_start,   // [RS_MAX_RADIX + 1] or nullptr (plain tiles)
+                        const u32 *__restrict__ region_tiles,   // [RS_MAX_RADIX + 1] exclusive; last = total tiles
+                        u32 /*flags*/, u64 *__restrict__ dbg) {
+  using SM = GroupSmem<K, RB, BLOCK, KPT>;
+  using KO = KeyOps<K>;
+  constexpr int R = SM::R, TILE = SM::TILE, G = R / 2;
+  constexpr int WALK = 16;
+  static_assert(BLOCK >= RS_MAX_RADIX && G % 64 == 0 && TILE <= 65536, "one thread per region/digit; 16-bit ranks");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  K   *s_keys  = reinterpret_cast<K *>(smem);
+  u32 *s_hist  = reinterpret_cast<u32 *>(smem + SM::OFF_HIST);
+  u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
+  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
+  u32 *s_cnt   = reinterpret_cast<u32 *>(smem + SM::OFF_CNT);
+  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
+  u64 *s_info  = reinterpret_cast<u64 *>(smem + SM::OFF_INFO);
+  const u32 tid0 = threadIdx.x;
+  u32 tid = tid0, lane = tid0 & 63u, w = tid0 >> 6;
+
+  // this thread's slice of the region table stays in registers
+  const bool regions = (region_tiles != nullptr);
+  u64 rt_lo = 0, rt_hi = 0, rs = 0, re = 0, total_tiles = num_tiles_plain;
+  if (regions) {
+    if (tid0 < (u32)RS_MAX_RADIX) {
+      rt_lo = region_tiles[tid0]; rt_hi = region_tiles[tid0 + 1];
+      rs = region_start[tid0];    re = region_start[tid0 + 1];
+    }
+    total_tiles = region_tiles[RS_MAX_RADIX];
+  }
+  auto announce = [&](u64 t, int slot) __attribute__((always_inline)) {   // key range of tile t -> s_info[2*slot..]
+    if (t >= total_tiles) return;
+    if (regions) {
+      if (rt_lo <= t && t < rt_hi) {                      // exactly one thread (empty regions own no tile)
+        const u64 kb = rs + (t - rt_lo) * (u64)TILE;
+        s_info[2 * slot] = kb;
+        s_info[2 * slot + 1] = (re - kb < (u64)TILE) ? re - kb : (u64)TILE;
+      }
+    } else if (tid0 == 0) {
+      const u64 kb = t * (u64)TILE;
+      s_info[2 * slot] = kb;
+      s_info[2 * slot + 1] = (n - kb < (u64)TILE) ? n - kb : (u64)TILE;
+    }
+  };
+
+  K keys[KPT];
+  auto fetch = [&](u64 kb, u32 nv) __attribute__((always_inline)) {
+    const u32 li = w * (64 * KPT) + lane;                 // wave-striped: 512 contiguous bytes per wave instruction
+    const K  *p  = in + kb + li;
+    if (nv == (u32)TILE) {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) keys[j] = p[j * 64];
+    } else {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) if (li + (u32)j * 64 < nv) keys[j] = p[j * 64];
+    }
+  };
+
+  if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
+  __syncthreads();
+  u64 tile = s_tmp[32];
+  announce(tile, 0);
+  __syncthreads();
+  u64 kb = 0; u32 nv = 0;
+  if (tile < total_tiles) { kb = s_info[0]; nv = (u32)s_info[1]; fetch(kb, nv); }
+
+  u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define PK_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
+  while (tile < total_tiles) {
+    if (DBG) t0 = __builtin_readcyclecounter();
+    tid = tid0;
+    asm volatile("" : "+v"(tid));                         // keeps the unrolled body's LDS addresses out of the loop preheader
+    lane = tid & 63u; w = tid >> 6;
+    const bool walker = tid < (u32)G;
+    if (tid == 0) s_tmp[33] = atomicAdd(ticket, 1u);
+    if (tid < (u32)R) s_hist[tid] = 0;
+    __syncthreads();                                      // (A)
+    const u64 next = s_tmp[33];
+    announce(next, 1);                                    // read after (C)
+    PK_STAMP(0);
+
+    // ---- rank: position among the tile's keys of the same digit, in arrival order ----
+    const u32 li = w * (64 * KPT) + lane;
+    u32 ranks[KPT / 2];
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      u32 r = 0;
+      if (li + (u32)j * 64 < nv) r = atomicAdd(&s_hist[KO::digit(keys[j], shift, dmask)], 1u);
+      if (j & 1) ranks[j / 2] |= r << 16;
+      else       ranks[j / 2]  = r;
+    }
+    __syncthreads();                                      // (B)
+    PK_STAMP(1);
+
+    const u32 count = (tid < (u32)R) ? s_hist[tid] : 0u;
+    u32 tile_total;
+    const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tile_total);
+    if (tid < (u32)R) { s_cnt[tid] = count; s_dbase[tid] = excl; }
+    __syncthreads();                                      // (C)
+
+    u64 *mine = status + tile * (u64)G + tid;
+    u32 c0 = 0, c1 = 0;
+    if (walker) {
+      c0 = s_cnt[2 * tid]; c1 = s_cnt[2 * tid + 1];
+      const u32 fl = (tile == 0) ? 2u : 1u;
+      status_store(mine, st_pack(fl, c0, fl, c1));
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      if (li + (u32)j * 64 < nv) {
+        const u32 d = KO::digit(keys[j], shift, dmask);
+        const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
+        s_keys[s_dbase[d] + r] = keys[j];
+      }
+    }
+    u64 nkb = 0; u32 nnv = 0;
+    if (next < total_tiles) { nkb = s_info[2]; nnv = (u32)s_info[3]; }
+    __syncthreads();                                      // (D) keys live in LDS only
+    PK_STAMP(2);
+
+    // Look-back.  Persistent workgroups run in step, so the ~256 tiles in flight reach this point together
+    // and the inclusive prefixes can only spread from the oldest tile on: a walker that covers WALK
+    // predecessors per round trip sees the frontier move ~2*WALK tiles per round trip.  (Measured: holding
+    // the key fetch back, or issuing the status loads ahead of it, does not shorten the walk.)
+    u32 p0 = 0, p1 = 0;
+    bool done = (tile == 0);
+    u64  wt = tile ? tile - 1 : 0;
+    u32  spins = 0;
+    u64  gv[WALK];
+    auto issue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < WALK; i++)
+        gv[i] = (wt >= (u64)i) ? status_load(status + (wt - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
+    };
+    auto consume = [&]() __attribute__((always_inline)) {
+      u32 used = 0;
+      bool open = true;
+#pragma unroll
+      for (int i = 0; i < WALK; i++) {
+        const u32 lo = (u32)gv[i], hi = (u32)(gv[i] >> 32);
+        const u32 f = lo >> 30;
+        open = open && !done && (f != 0);
+        if (open) {
+          p0 += lo & 0x3FFFFFFFu; p1 += hi & 0x3FFFFFFFu;
+          if (f == 2) done = true;
+          used++;
+        }
+      }
+      wt -= (used <= wt) ? used : wt;
+      if (used == 0) {
+        if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); done = true; }
+        else __builtin_amdgcn_s_sleep(1);
+      }
+    };
+    if (!walker) {
+      if (next < total_tiles) fetch(nkb, nnv);
+    } else {
+      while (!done) { issue(); consume(); }
+      if (tile != 0) status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
+      s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
+      s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
+      if (next < total_tiles) fetch(nkb, nnv);
+    }
+    __syncthreads();                                      // (E)
+    PK_STAMP(3);
+
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 i = (u32)j * BLOCK + tid;
+      if (i < nv) {
+        const K   key = s_keys[i];
+        const u32 d   = KO::digit(key, shift, dmask);
+        out[s_gbase[d] + (u64)i] = key;
+      }
+    }
+    PK_STAMP(4);
+    __syncthreads();                                      // (F)
+    PK_STAMP(5);
+    tile = next; kb = nkb; nv = nnv;
+    if (DBG) ph[7]++;
+  }
+  if (DBG && tid0 == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
+#undef PK_STAMP
+  (void)kb;
+}
+
+// ---- classic mode: per-tile digit histogram + row scan ----------------------
+template <typename K, int RB, int BLOCK, int KPT>
+__global__ __launch_bounds__(BLOCK)
+void radix_tile_hist_kernel(const K *__restrict__ in, u64 n, u32 shift, u32 dmask, u32 *__restrict__ tile_hist,
+                            u64 num_tiles) {
+  constexpr int R = 1 << RB, TILE = BLOCK * KPT;
+  __shared__ u32 s_h[R];
+  const u32 tid = threadIdx.x;
+  for (u32 i = tid; i < (u32)R; i += BLOCK) s_h[i] = 0;
+  __syncthreads();
+  const u64 tile_base = (u64)blockIdx.x * TILE;
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const u64 idx = tile_base + (u64)j * BLOCK + tid;
+    if (idx < n) atomicAdd(&s_h[KeyOps<K>::digit(in[idx], shift, dmask)], 1u);
+  }
+  __syncthreads();
+  for (u32 i = tid; i < (u32)R; i += BLOCK) tile_hist[(u64)i * num_tiles + blockIdx.x] = s_h[i];
+}
+
+// One workgroup per digit: exclusive scan of its row of tile counts (-> u64),
+// and the row total.
+__global__ __launch_bounds__(1024)
+void radix_row_scan_kernel(const u32 *__restrict__ tile_hist, u64 *__restrict__ tile_offs, u64 *__restrict__ row_total,
+                           u64 num_tiles) {
+  __shared__ u64 s_tmp[1024 / 64 + 1];
+  const u64 row = (u64)blockIdx.x * num_tiles;
+  u64 carry = 0;
+  for (u64 c = 0; c < num_tiles; c += 1024) {
+    const u64 t = c + threadIdx.x;
+    const u64 v = (t < num_tiles) ? (u64)tile_hist[row + t] : 0ull;
+    u64 tot;
+    const u64 e = block_excl_scan<1024, u64>(v, s_tmp, &tot);
+    if (t < num_tiles) tile_offs[row + t] = carry + e;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+}
+
+// Adds the exclusive digit base (scan of row totals) to every row.
+__global__ __launch_bounds__(256)
+void radix_row_add_kernel(u64 *__restrict__ tile_offs, const u64 *__restrict__ row_total, u32 R, u64 num_tiles) {
+  __shared__ u64 s_part[4];
+  const u32 d = blockIdx.y;
+  u64 part = 0;
+  for (u32 i = threadIdx.x; i < d; i += 256) part += row_total[i];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_down(part, o);
+  if (lane_id() == 0) s_part[wave_id()] = part;
+  __syncthreads();
+  const u64 base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (t < num_tiles) tile_offs[(u64)d * num_tiles + t] += base;
+  (void)R;
+}
+
+// ---- host side ---------------------------------------------------------------
+
+static int env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+void make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan) {
+  memset(plan, 0, sizeof(*plan));
+  // defaults = the fastest measured combination on MI355X (profiles/r01 notes in DESIGN.md):
+  // 9-bit digits, one 1024-thread workgroup per CU with 16 keys per thread (16384-key tiles),
+  // LDS-mask ranking, window look-back after the exchange
+  int rb    = env_int("MGC_RADIX_BITS", 9);
+  int mode  = env_int("MGC_SORT_MODE", 0);
+  int kpt   = env_int("MGC_SORT_KPT", 16);
+  int block = env_int("MGC_SORT_BLOCK", 1024);
+  if (rb != 8 && rb != 9) rb = 8;
+  if (kpt != 8 && kpt != 16) kpt = 16;
+  if (block != 512 && block != 1024) block = 512;
+  plan->radix_bits = (uint32_t)rb;
+  plan->block      = (uint32_t)block;
+  plan->kpt        = (uint32_t)kpt;
+  plan->tile       = plan->block * plan->kpt;
+  plan->mode       = (mode == 1 || mode == 3) ? (uint32_t)mode : 0u;   // 0 look-back, 1 classic, 3 grouping (finish path only)
+  plan->match      = env_int("MGC_SORT_MATCH", 1) ? 1u : 0u;
+  { const int lb = env_int("MGC_SORT_LB", 2); plan->lookback = (lb == 2 || lb == 5) ? (uint32_t)lb : 1u; }
+  plan->flags      = (uint32_t)env_int("MGC_SORT_FLAGS", 0);
+  const uint32_t nbits = (end_bit > begin_bit) ? end_bit - begin_bit : 0;
+  uint32_t passes = (nbits + rb - 1) / rb;
+  if (passes > RS_MAX_PASSES) passes = RS_MAX_PASSES;
+  plan->num_passes = passes;
+  uint32_t bit = begin_bit;
+  for (uint32_t p = 0; p < passes; p++) {
+    uint32_t b = nbits / passes + ((p < nbits % passes) ? 1u : 0u);
+    plan->pass_shift[p] = bit;
+    plan->pass_bits[p]  = b;
+    bit += b;
+  }
+}
+
+static inline uint64_t max_tiles_for(uint64_t n) { return (n + 4095) / 4096 + 1; }   // tile >= 4096 keys
+
+size_t sort_workspace_bytes(uint64_t n) {
+  // header + the larger of {look-back granules (one pass at a time), classic tile_hist + tile_offs}
+  const uint64_t t = max_tiles_for(n);
+  // + grouping mode: up to RS_MAX_RADIX + 1 extra (partial) tiles of granules and the region table
+  return sizeof(SortHeader) + 1024 + (size_t)t * RS_MAX_RADIX * (sizeof(uint32_t) + sizeof(uint64_t)) +
+         (size_t)(RS_MAX_RADIX + 2) * (RS_MAX_RADIX / 2) * sizeof(uint64_t) + (size_t)(RS_MAX_RADIX + 2) * 16;
+}
+
+static int device_cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
+}
+
+template <typename K, int RB, int BLOCK, int KPT, int MATCH, int LBK>
+static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws,
+                             uint32_t *d_error, int *result_in_alt, hipStream_t st, hipEvent_t *pass_events) {
+  constexpr int LBO = (LBK == 5) ? 2 : LBK;             // look-back flavour of the non-pipelined kernel
+  using SM  = RadixSmem<K, RB, BLOCK, KPT, LBO>;
+  using SM0 = RadixSmem<K, RB, BLOCK, KPT, 0>;
+  constexpr int R = 1 << RB, TILE = BLOCK * KPT;
+  SortHeader *hdr = reinterpret_cast<SortHeader *>(d_ws);
+  unsigned char *body = reinterpret_cast<unsigned char *>(d_ws) + ((sizeof(SortHeader) + 255) / 256) * 256;
+  const uint64_t num_tiles = (n + TILE - 1) / TILE;
+
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<K, RB, BLOCK, KPT, LBO, MATCH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::BYTES);
+    if constexpr (LBK == 5)
+    {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)RadixSmem<K, RB, BLOCK, KPT, 4>::BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)RadixSmem<K, RB, BLOCK, KPT, 4>::BYTES);
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<K, RB, BLOCK, KPT, 0, MATCH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM0::BYTES);
+    attr_done = true;
+  }
+
+  K *src = reinterpret_cast<K *>(d_keys), *dst = reinterpret_cast<K *>(d_alt);
+  int in_alt = 0;
+  const bool lookback = (plan.mode == 0);
+
+  if (lookback) {
+    u64 *status = reinterpret_cast<u64 *>(body);
+    const size_t status_bytes = (size_t)num_tiles * (LBO == 3 ? R : R / 2) * sizeof(u64);
+    MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
+    PassList pl;
+    pl.n = plan.num_passes;
+    for (uint32_t p = 0; p < plan.num_passes; p++) {
+      pl.shift[p] = plan.pass_shift[p];
+      pl.mask[p]  = (1u << plan.pass_bits[p]) - 1u;
+    }
+    launch_radix_hist<K>((const K *)src, (u64)n, pl, &hdr->ghist[0][0], st);
+    MGC_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(plan.num_passes), dim3(RS_MAX_RADIX), 0, st,
+                       &hdr->ghist[0][0], &hdr->gbase[0][0]);
+    MGC_CHECK(hipGetLastError());
+    for (uint32_t p = 0; p < plan.num_passes; p++) {
+      MGC_CHECK(hipMemsetAsync(status, 0, status_bytes, st));
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
+      if constexpr (LBK == 5) {
+        using SMP = RadixSmem<K, RB, BLOCK, KPT, 4>;
+        const uint64_t resident = (uint64_t)device_cu_count() * SMP::WG_PER_CU;
+        const uint32_t pgrid = (uint32_t)(num_tiles < resident ? num_tiles : resident);
+        if (plan.dbg)
+          hipLaunchKernelGGL((radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, true>), dim3(pgrid), dim3(BLOCK), SMP::BYTES, st,
+                             (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                             &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
+        else
+          hipLaunchKernelGGL((radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, false>), dim3(pgrid), dim3(BLOCK), SMP::BYTES, st,
+                             (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                             &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, (u64 *)nullptr);
+      } else {
+        hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, LBO, MATCH>), dim3((uint32_t)num_tiles),
+                           dim3(BLOCK), SM::BYTES, st, (const K *)src, dst, (u64)n, plan.pass_shift[p],
+                           (1u << plan.pass_bits[p]) - 1u, &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, plan.flags,
+                           (const u64 *)nullptr, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
+      }
+      MGC_CHECK(hipGetLastError());
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
+      K *t = src; src = dst; dst = t; in_alt ^= 1;
+    }
+  } else if (plan.mode == 3) {
+    // ---- grouping passes (finish path): see radix_group_kernel ----
+    using GS = GroupSmem<K, RB, BLOCK, KPT>;
+    static bool gattr_done = false;
+    if (!gattr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES);
+      gattr_done = true;
+    }
+    const uint64_t max_tiles = num_tiles + RS_MAX_RADIX + 1;          // region-aligned tiles: one partial tile per region
+    u64 *status = reinterpret_cast<u64 *>(body);
+    const size_t status_bytes = (size_t)max_tiles * (R / 2) * sizeof(u64);
+    u64 *region_start = reinterpret_cast<u64 *>(body + ((status_bytes + 255) / 256) * 256);
+    u32 *region_tiles = reinterpret_cast<u32 *>(region_start + RS_MAX_RADIX + 1);
+    MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
+    PassList pl;
+    pl.n = plan.num_passes;
+    for (uint32_t p = 0; p < plan.num_passes; p++) {
+      pl.shift[p] = plan.pass_shift[p];
+      pl.mask[p]  = (1u << plan.pass_bits[p]) - 1u;
+    }
+    launch_radix_hist<K>((const K *)src, (u64)n, pl, &hdr->ghist[0][0], st);
+    MGC_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(plan.num_passes), dim3(RS_MAX_RADIX), 0, st,
+                       &hdr->ghist[0][0], &hdr->gbase[0][0]);
+    MGC_CHECK(hipGetLastError());
+    const uint64_t resident = (uint64_t)device_cu_count() * GS::WG_PER_CU;
+    for (uint32_t p = 0; p < plan.num_passes; p++) {
+      if (p == 1) {
+        hipLaunchKernelGGL(group_regions_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, &hdr->gbase[0][0], (u64)n, (u32)TILE,
+                           region_start, region_tiles);
+        MGC_CHECK(hipGetLastError());
+      }
+      MGC_CHECK(hipMemsetAsync(status, 0, status_bytes, st));
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
+      const uint64_t tiles_bound = (p == 0) ? num_tiles : max_tiles;
+      const uint32_t pgrid = (uint32_t)(tiles_bound < resident ? tiles_bound : resident);
+      const u64 *rs = (p == 0) ? nullptr : region_start;
+      const u32 *rt = (p == 0) ? nullptr : region_tiles;
+      if (plan.dbg)
+        hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, true>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
+                           (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, plan.flags,
+                           reinterpret_cast<u64 *>(plan.dbg));
+      else
+        hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
+                           (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, plan.flags, (u64 *)nullptr);
+      MGC_CHECK(hipGetLastError());
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
+      K *t = src; src = dst; dst = t; in_alt ^= 1;
+    }
+  } else {
+    // ---- classic: histogram / scan / scatter per pass ----
+    u32 *tile_hist = reinterpret_cast<u32 *>(body);
+    u64 *tile_offs = reinterpret_cast<u64 *>(body + (((size_t)num_tiles * R * sizeof(u32) + 255) / 256) * 256);
+    for (uint32_t p = 0; p < plan.num_passes; p++) {
+      const uint32_t shift = plan.pass_shift[p], dmask = (1u << plan.pass_bits[p]) - 1u;
+      hipLaunchKernelGGL((radix_tile_hist_kernel<K, RB, BLOCK, KPT>), dim3((uint32_t)num_tiles), dim3(BLOCK), 0, st,
+                         (const K *)src, (u64)n, shift, dmask, tile_hist, (u64)num_tiles);
+      MGC_CHECK(hipGetLastError());
+      hipLaunchKernelGGL(radix_row_scan_kernel, dim3(R), dim3(1024), 0, st, tile_hist, tile_offs,
+                         &hdr->row_total[0], (u64)num_tiles);
+      MGC_CHECK(hipGetLastError());
+      hipLaunchKernelGGL(radix_row_add_kernel, dim3((uint32_t)((num_tiles + 255) / 256), R), dim3(256), 0, st,
+                         tile_offs, &hdr->row_total[0], (u32)R, (u64)num_tiles);
+      MGC_CHECK(hipGetLastError());
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
+      hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, 0, MATCH>), dim3((uint32_t)num_tiles), dim3(BLOCK),
+                         SM0::BYTES, st, (const K *)src, dst, (u64)n, shift, dmask, (const u64 *)nullptr, (u64 *)nullptr,
+                         (u32 *)nullptr, d_error, plan.flags, tile_offs, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
+      MGC_CHECK(hipGetLastError());
+      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
+      K *t = src; src = dst; dst = t; in_alt ^= 1;
+    }
+  }
+  *result_in_alt = in_alt;
+  return hipSuccess;
+}
+
+hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan,
+                             void *d_ws, size_t ws_bytes, uint32_t *d_error, int *result_in_alt,
+                             hipStream_t st, hipEvent_t *pass_events) {
+  *result_in_alt = 0;
+  if (n == 0 || plan.num_passes == 0) return hipSuccess;
+  if (ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
+  if (plan.mode == 3 && (plan.num_passes > 2 || n >= (1ull << 30))) {
+    SortPlan stable = plan;                 // grouping is defined for one or two digits and 30-bit granule values
+    stable.mode = 0;
+    return launch_radix_sort(d_keys, d_alt, n, key_words, stable, d_ws, ws_bytes, d_error, result_in_alt, st, pass_events);
+  }
+#define MGC_RUN(K_, RB_, BLOCK_, KPT_)                                                                       \
+  do {                                                                                                       \
+    if (n >= (1ull << 30))   /* packed look-back granules hold 30-bit values: use the wide ones */           \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 3>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+    if (plan.match == 0)                                                                                     \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 0, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+    if (plan.lookback == 2)                                                                                  \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 2>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+    if (plan.lookback == 5)                                                                                  \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 5>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+    return run_passes<K_, RB_, BLOCK_, KPT_, 1, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);   \
+  } while (0)
+  if (key_words == 2) {
+    // 128-bit keys: 8 keys per thread keep the tile at 128 KiB of LDS (one workgroup per CU)
+    if (plan.radix_bits == 9) MGC_RUN(K128, 9, 1024, 8);
+    MGC_RUN(K128, 8, 1024, 8);
+  }
+  if (plan.radix_bits == 9) {
+    if (plan.block == 1024 && plan.kpt == 8) MGC_RUN(u64, 9, 1024, 8);
+    if (plan.block == 1024) MGC_RUN(u64, 9, 1024, 16);
+    if (plan.kpt == 8) MGC_RUN(u64, 9, 512, 8);
+    MGC_RUN(u64, 9, 512, 16);
+  }
+  if (plan.block == 1024 && plan.kpt == 8) MGC_RUN(u64, 8, 1024, 8);
+  if (plan.block == 1024) MGC_RUN(u64, 8, 1024, 16);
+  if (plan.kpt == 8) MGC_RUN(u64, 8, 512, 8);
+  MGC_RUN(u64, 8, 512, 16);
+#undef MGC_RUN
+}
+
+
+}  // namespace mgc

@@ -3,9 +3,11 @@
 Usage: python scripts/kres.py PATTERN"""
 import re, subprocess, sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "meryl_amd", "csrc", "mgc_kernels.hip")
-out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Rpass-analysis=kernel-resource-usage",
-                      "-o", "/tmp/kres.o", src], capture_output=True, text=True).stderr
+out = ""
+for name in ("mgc_kmer.hip", "mgc_sort.hip", "mgc_scan.hip", "mgc_finish.hip", "mgc_misc.hip", "mgc_parse.hip"):
+    src = os.path.join(root, "meryl_amd", "csrc", name)
+    out += subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Rpass-analysis=kernel-resource-usage",
+                           "-o", "/tmp/kres.o", src], capture_output=True, text=True).stderr
 cur = None
 for line in out.splitlines():
     if "error:" in line:
