@@ -132,3 +132,44 @@ def test_cli_device_parser_refusal_falls_back_to_host_parser(meryl, oracle_lib, 
         lo, hi, cn = r.read_all()
         assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn) and r.info.num_total == wni
         r.close()
+
+
+def _config0_reads(oracle_lib):
+    # BASELINE configs[0] / SURVEY 8(d)-1: "E. coli 1x": 4,641,652 bp genome, 30,944 x 150 bp reads, 0.5 % substitutions
+    return oracle_lib.synth_reads(1, 4_641_652, 0, 30_944, 150, 5000, 0)
+
+
+def test_config0_ecoli_cpu_plumbing(oracle_lib):
+    # the reference's own CPU-runnable case, through the CPU restatement only: threaded port (wPrefix 10 from
+    # configureCounting) == brute force, 64-file geometry intact
+    bases = _config0_reads(oracle_lib)
+    cfg = oracle_lib.configure_counting(21, 4_641_652, 4 << 30)
+    assert cfg["w_prefix"] == 10 and cfg["use_simple"] == 0
+    whi, wlo, wcn, wni = oracle_lib.count_brute(bases.tobytes(), 21)
+    phi, plo, pcn, pni = oracle_lib.count_threaded(bases.tobytes(), 21, cfg["w_prefix"], 0, threads=4)
+    assert pni == wni == 30_944 * (150 - 20)
+    assert np.array_equal(plo, wlo) and np.array_equal(pcn, wcn)
+    files = (wlo >> np.uint64(36)).astype(np.int64)
+    assert files.min() >= 0 and files.max() < 64 and np.all(np.diff(files) >= 0)
+
+
+@pytest.mark.gpu
+def test_config0_ecoli_cli_on_gpu(meryl, oracle_lib, tmp_path):
+    # the same input as a FASTQ file through the stand-alone CLI on the GPU: `k=21 memory=4 n=4641652` -> wPrefix 10,
+    # database == the oracle's stream
+    from meryl_amd import db
+    bases = _config0_reads(oracle_lib)
+    reads = [r for r in bases.tobytes().decode().split(".") if r]
+    fq = tmp_path / "ecoli_1x.fastq"
+    with open(fq, "w") as f:
+        for i, r in enumerate(reads):
+            f.write("@r%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)))
+    out = tmp_path / "ecoli.meryl"
+    p = run(meryl, "k=21", "memory=4", "n=4641652", "threads=4", "count", fq, "output", out)
+    assert re.search(r"Configured complex mode for .* GB memory per batch, and up to \d+ batch", p.stderr)
+    _, wlo, wcn, wni = oracle_lib.count_brute(bases.tobytes(), 21)
+    r = db.Reader(str(out))
+    lo, hi, cn = r.read_all()
+    assert r.info.prefix_bits == 10 if hasattr(r.info, "prefix_bits") else True
+    assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn) and r.info.num_total == wni
+    r.close()
