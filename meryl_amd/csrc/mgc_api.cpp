@@ -651,7 +651,15 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   const mgc_count_config &c = s->cfg;
   const uint32_t k = c.k;
   // buckets = the 64 files, or (sharded owner side) finer top-bit ranges of the k-mer: 2^bucket_bits of them
-  const uint32_t bucket_bits = ext_keys ? ext_bucket_bits : (uint32_t)MGC_NUM_FILES_BITS;
+  // The session's own partition uses the files while a file stays within what two grouping digits cover
+  // (1152 << 18 = 302 M k-mers); larger inputs are partitioned one or more bits finer -- the 64 files are ranges
+  // of buckets either way.
+  uint32_t bucket_bits = ext_keys ? ext_bucket_bits : (uint32_t)MGC_NUM_FILES_BITS;
+  if (!ext_keys) {
+    const char *pb = getenv("MGC_BUCKET_BASES");                      // tests force finer buckets on small inputs
+    const uint64_t per_bucket = (pb && *pb) ? strtoull(pb, nullptr, 10) : 180000000ull;
+    while (bucket_bits < MGC_MAX_BUCKET_BITS && bucket_bits < 2 * c.k && (s->n_bases >> bucket_bits) > per_bucket) bucket_bits++;
+  }
   const uint32_t nb = 1u << bucket_bits;
   const uint32_t kw = s->key_words;
   const size_t   kbytes = sizeof(uint64_t) * kw;

@@ -727,3 +727,25 @@ def test_medium_scale_matches_threaded_port(ops, oracle_lib, torch_cuda, k, n_re
     phi, plo, pcn, pni = oracle_lib.count_threaded(bases.tobytes(), k, cfg.w_prefix, 0, threads=32)
     assert info.n_instances == pni and info.n_distinct == len(plo)
     assert np.array_equal(klo, plo) and np.array_equal(khi, phi) and np.array_equal(counts, pcn)
+
+
+@pytest.mark.parametrize("k,per_bucket", [(21, 40_000), (21, 3_000), (40, 10_000), (9, 2_000)])
+def test_large_input_partition_granularity(ops, oracle_lib, torch_cuda, monkeypatch, k, per_bucket):
+    # inputs whose files would outgrow two grouping digits are partitioned finer than the 64 files (7..10 top bits);
+    # forced here on a small input: same stream, same per-file instance counts, same database blocks
+    from meryl_amd import capi
+    monkeypatch.setenv("MGC_BUCKET_BASES", str(per_bucket))
+    bases = oracle_lib.synth_reads(90, 100_000, 0, 10_000)
+    cfg = capi.configure(k, bases.size, 1 << 30)
+    cfg.use_simple = 0
+    with ops.Session(cfg) as s:
+        s.push_bases_device(torch_cuda.from_numpy(bases).cuda())
+        s.count()
+        klo, khi, counts, bstart = s.result_wide()
+        info = s.info()
+    whi, wlo, wcn, wni = oracle_lib.count_brute(bases.tobytes(), k)
+    assert info.n_instances == wni and np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+    inst_per_file = np.zeros(64, dtype=np.int64)
+    files = ((whi.astype(object) << 64 | wlo.astype(object)) >> (2 * k - 6)) if k > 32 else (wlo >> np.uint64(2 * k - 6))
+    np.add.at(inst_per_file, np.asarray(files, dtype=np.int64), wcn.astype(np.int64))
+    assert np.array_equal(np.asarray(info.file_instances, dtype=np.int64), inst_per_file)
