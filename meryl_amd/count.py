@@ -422,9 +422,12 @@ class HipOps:
         return _u64(n, like.device)
 
 
-def shard_bucket_bits(world, k):
-    """Top bits of the k-mer that route it in a `world`-rank count: 6 (the files) + ceil(log2(world)), at most 10."""
+def shard_bucket_bits(world, k, n_bases_local=0):
+    """Top bits of the k-mer that route it in a `world`-rank count: 6 (the files) + ceil(log2(world)), one more for every
+    doubling of the per-rank input beyond what keeps a bucket within two grouping digits (~180 M bases), at most 10."""
     extra = max(0, (int(world) - 1).bit_length())
+    while extra < 4 and (int(world) * int(n_bases_local)) >> (6 + extra) > 180_000_000:
+        extra += 1
     if os.environ.get("MGC_SHARD_BITS"):                   # experiments: the granularity of an N-rank run on fewer ranks
         extra = int(os.environ["MGC_SHARD_BITS"]) - 6
     return max(6, min(10, 6 + extra, 2 * int(k)))
@@ -457,7 +460,9 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
             marks.append((name, _time.perf_counter()))
 
     mark("start")
-    bits = shard_bucket_bits(world, k)
+    nb_local = torch.tensor([int(bases.numel())], dtype=torch.int64, device=bases.device)
+    dist.all_reduce(nb_local, op=dist.ReduceOp.MAX, group=group)                 # every rank must pick the same granularity
+    bits = shard_bucket_bits(world, k, int(nb_local.item()))
     nbk = 1 << bits
     keys, local_counts = ops.partition(bases, k, mode, bits)                     # grouped by bucket, ascending
     mark("partition")
