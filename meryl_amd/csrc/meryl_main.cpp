@@ -46,7 +46,7 @@ uint64_t bits64(uint64_t v) { uint64_t b = 0; while (v) { b++; v >>= 1; } return
 bool file_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && !S_ISDIR(st.st_mode); }
 bool dir_has_index(const std::string &p) { return file_exists(p + "/merylIndex"); }
 
-enum OpKind { OP_NONE, OP_COUNT, OP_COUNT_FORWARD, OP_COUNT_REVERSE, OP_PRINT, OP_DUMPINDEX };
+enum OpKind { OP_NONE, OP_COUNT, OP_COUNT_FORWARD, OP_COUNT_REVERSE, OP_PRINT, OP_DUMPINDEX, OP_HISTOGRAM };
 
 struct Operation {
   OpKind                   kind = OP_NONE;
@@ -297,6 +297,21 @@ int run_print(const Operation &op) {
   return 0;
 }
 
+// `meryl histogram <db>`: value <TAB> number of distinct k-mers with that value, ascending -- the histogram the count
+// path's writer stored in the master index (src/meryl/merylOp-histogram.C:20-44, quick-start.rst:144)
+int run_histogram(const Operation &op) {
+  if (op.db_inputs.size() != 1) die("ERROR: told to dump a histogram for more than one input!");
+  mdb_reader *r = mdb_reader_open(op.db_inputs[0].c_str());
+  if (!r) die("ERROR: %s", mdb_last_error());
+  mdb_info i;
+  mdb_reader_info(r, &i);
+  std::vector<uint64_t> v(i.hist_len), o(i.hist_len);
+  if (i.hist_len && mdb_reader_histogram(r, v.data(), o.data()) != 0) die("ERROR: %s", mdb_last_error());
+  for (uint64_t ii = 0; ii < i.hist_len; ii++) fprintf(stdout, "%" PRIu64 "\t%" PRIu64 "\n", v[ii], o[ii]);
+  mdb_reader_close(r);
+  return 0;
+}
+
 int run_dump_index(const Operation &op) {
   for (const std::string &dbn : op.db_inputs) {
     mdb_reader *r = mdb_reader_open(dbn.c_str());
@@ -364,16 +379,17 @@ int main(int argc, char **argv) {
       else if (w == "compress")              { g.compress = true; }                                               // :237-240
       else if (key == "count-suffix" || key == "segment") { die("ERROR: option '%s' is not supported in this build.", w.c_str()); }
       // ---- operations, :346-385 ----
-      else if (w == "count" || w == "count-forward" || w == "count-reverse" || w == "print" || w == "dumpIndex") {
+      else if (w == "count" || w == "count-forward" || w == "count-reverse" || w == "print" || w == "dumpIndex" || w == "histogram") {
         const OpKind kind = (w == "count") ? OP_COUNT : (w == "count-forward") ? OP_COUNT_FORWARD :
-                            (w == "count-reverse") ? OP_COUNT_REVERSE : (w == "print") ? OP_PRINT : OP_DUMPINDEX;
+                            (w == "count-reverse") ? OP_COUNT_REVERSE : (w == "print") ? OP_PRINT :
+                            (w == "histogram") ? OP_HISTOGRAM : OP_DUMPINDEX;
         if (open_op >= 0 && ops[open_op].kind == OP_NONE) ops[open_op].kind = kind;    // `n=` came first
         else { ops.emplace_back(); open_op = (int)ops.size() - 1; ops[open_op].kind = kind; }
       }
       else if (w == "output")                { expect_output_name = true; }
       else if (w == "union" || w == "union-min" || w == "union-max" || w == "union-sum" || w == "intersect" ||
                w == "intersect-min" || w == "intersect-max" || w == "intersect-sum" || w == "subtract" ||
-               w == "difference" || w == "symmetric-difference" || w == "histogram" || w == "statistics" ||
+               w == "difference" || w == "symmetric-difference" || w == "statistics" ||
                w == "less-than" || w == "greater-than" || w == "equal-to" || w == "at-least" || w == "at-most" ||
                w == "increase" || w == "decrease" || w == "multiply" || w == "divide" || w == "modulo" ||
                w == "distinct" || w == "word-frequency" || w == "threshold" || w == "dumpFile" || w == "printACGT") {
@@ -381,8 +397,8 @@ int main(int argc, char **argv) {
       }
       // ---- inputs ----
       else if (dir_has_index(w)) {                                           // :159,506-514
-        if (open_op < 0 || (ops[open_op].kind != OP_PRINT && ops[open_op].kind != OP_DUMPINDEX))
-          die("ERROR: database input '%s' needs a print or dumpIndex operation in this build.", w.c_str());
+        if (open_op < 0 || (ops[open_op].kind != OP_PRINT && ops[open_op].kind != OP_DUMPINDEX && ops[open_op].kind != OP_HISTOGRAM))
+          die("ERROR: database input '%s' needs a print, histogram or dumpIndex operation in this build.", w.c_str());
         ops[open_op].db_inputs.push_back(w);
       }
       else if (file_exists(w) || w == "-") {                                 // :537-549: only counting ops take sequence
@@ -417,6 +433,7 @@ int main(int argc, char **argv) {
   for (const Operation &op : ops) {
     if (op.kind == OP_PRINT)     rc |= run_print(op);
     if (op.kind == OP_DUMPINDEX) rc |= run_dump_index(op);
+    if (op.kind == OP_HISTOGRAM) rc |= run_histogram(op);
   }
   if (g.verbosity > 0) fprintf(stderr, "\nCleaning up.\n\nBye.\n");                                    // meryl.C:268,273
   return rc;

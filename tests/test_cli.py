@@ -95,6 +95,10 @@ def test_cli_count_print_roundtrip(meryl, oracle_lib, tmp_path):
     assert lines[:50] == want
     p = run(meryl, "-Q", "dumpIndex", out)
     assert "prefixSize" in p.stdout and "numFilesBits   6 (64 files)" in p.stdout
+    # `meryl histogram`: value <TAB> number of distinct k-mers with that value (merylOp-histogram.C:38-43)
+    p = run(meryl, "-Q", "histogram", out)
+    vals, occ = np.unique(wcn, return_counts=True)
+    assert p.stdout.splitlines() == ["%d\t%d" % (int(v), int(o)) for v, o in zip(vals, occ)]
     # compress: same as counting the homopolymer-compressed reads
     out2 = tmp_path / "hpc.meryl"
     run(meryl, "-Q", "k=15", "memory=2", "compress", "count", fq, fa, "output", out2)
