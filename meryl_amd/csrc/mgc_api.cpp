@@ -310,7 +310,7 @@ struct mgc_session {
   // repeated count does not pay hipMalloc/hipFree of tens of GB every time
   struct Buf { void *p = nullptr; size_t cap = 0; };
   enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_HPC, B_HPC_WS, B_BASES,
-         B_SUBSTART, B_GROUPS, B_GSCAN, B_CNT_TMP, B_LARGE, B_TEXT_OUT, B_TEXT_IN0, B_TEXT_IN1, B_TEXT_WS, B_TEXT_STATE, B_NUM };
+         B_SUBSTART, B_GROUPS, B_GSCAN, B_CNT_TMP, B_LARGE, B_NONEMPTY, B_TEXT_OUT, B_TEXT_IN0, B_TEXT_IN1, B_TEXT_WS, B_TEXT_STATE, B_NUM };
   Buf buf[B_NUM];
   hipError_t ensure(int which, size_t bytes) {
     Buf &b = buf[which];
@@ -758,8 +758,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   const size_t sort_ws_bytes = mgc::sort_workspace_bytes(max_bucket) + 256;
   HIP_TRY(s, s->ensure(mgc_session::B_SORT_WS, sort_ws_bytes));
   void *sort_ws = s->buf[mgc_session::B_SORT_WS].p;
+  // device flags: [0] look-back timeout, [1] scratch answer of the hash probe, [2] overflow of a streamed sub-bucket
   uint32_t *d_err = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(sort_ws) + sort_ws_bytes - 256);
-  HIP_TRY(s, hipMemsetAsync(d_err, 0, 4, st));
+  HIP_TRY(s, hipMemsetAsync(d_err, 0, 16, st));
 
   const uint32_t rem_bits = 2 * k - bucket_bits;
   const uint32_t ev_per_file = 2 * 16;                     // room for 16 passes per file
@@ -811,6 +812,15 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     for (uint32_t b = 0; b < nb; b++) {
       uint32_t t = 0;
       while (t < rem_bits && t < 26 && (h_counts[b] >> t) > target) t++;
+      if (c.homopoly_compress && t) {
+        // homopolymer-compressed sequence never repeats a base: every 2-bit group after the first takes 3 of its 4
+        // values, so only (3/4)^(t/2) of the 2^t top-bit patterns occur and the occupied sub-buckets are that much
+        // larger than planned: log2(4/3)/2 = 0.2075 of every key bit carries no information
+        const char *sc = getenv("MGC_HPC_BITS_SCALE");
+        const double scale = (sc && *sc) ? atof(sc) : 1.0 / (1.0 - 0.2075);
+        const uint32_t tc = (uint32_t)((double)t * scale + 0.5);
+        t = tc < rem_bits ? (tc < 26 ? tc : 26) : rem_bits;
+      }
       top_bits[b] = t;
       const uint64_t ng = h_counts[b] ? ((uint64_t)1 << t) : 0;
       gbase[b + 1] = gbase[b] + ng;
@@ -820,6 +830,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     HIP_TRY(s, s->ensure(mgc_session::B_SUBSTART, sizeof(uint64_t) * (sbase[nb] + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_GROUPS, sizeof(uint64_t) * (ng_total + 2 + 2 * (uint64_t)nb)));
     HIP_TRY(s, s->ensure(mgc_session::B_LARGE, sizeof(uint32_t) * (ng_total + 1)));
+    HIP_TRY(s, s->ensure(mgc_session::B_NONEMPTY, sizeof(uint32_t) * (ng_total + 1) + sizeof(uint64_t) * ((uint64_t)nb + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_GSCAN, mgc::finish_scan_scratch_bytes(ng_total + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_CNT_TMP, sizeof(uint32_t) * N));
     HIP_TRY(s, s->ensure(mgc_session::B_RLE_WS, mgc::rle_workspace_bytes(max_bucket)));
@@ -828,6 +839,10 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     uint64_t *d_maxsub   = d_group + ng_total + 1;                  // [64] largest sub-bucket, then [64] number of large ones
     uint64_t *d_nlarge   = d_maxsub + nb;
     uint32_t *d_large    = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_LARGE].p);
+    uint64_t *d_nzcount  = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_NONEMPTY].p);           // [nb]
+    uint32_t *d_nz       = reinterpret_cast<uint32_t *>(d_nzcount + nb + 1);                          // [ng_total]
+    HIP_TRY(s, hipMemsetAsync(d_nzcount, 0, sizeof(uint64_t) * nb, st));
+    HIP_TRY(s, hipMemsetAsync(d_group, 0, sizeof(uint64_t) * (ng_total + 1), st));                     // empty sub-buckets stay 0
     uint32_t *d_cnt_tmp  = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_CNT_TMP].p);
     void     *rle_ws     = s->buf[mgc_session::B_RLE_WS].p;
     HIP_TRY(s, hipMemsetAsync(d_maxsub, 0, sizeof(uint64_t) * 2 * nb, st));
@@ -856,11 +871,14 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0) continue;
       HIP_TRY(s, mgc::launch_subbucket_bounds(X + kbytes * h_starts[b], h_counts[b], kw, rem_bits - top_bits[b], top_bits[b],
-                                              d_substart + sbase[b], d_maxsub + b, d_large + gbase[b], d_nlarge + b, st));
+                                              d_substart + sbase[b], d_maxsub + b, d_large + gbase[b], d_nlarge + b,
+                                              d_nz + gbase[b], d_nzcount + b, st));
     }
     std::vector<uint64_t> h_maxsub(2 * (size_t)nb);
     const uint64_t *h_nlarge = h_maxsub.data() + nb;
+    std::vector<uint64_t> h_nzcount(nb);
     HIP_TRY(s, hipMemcpyAsync(h_maxsub.data(), d_maxsub, sizeof(uint64_t) * 2 * nb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(s, hipMemcpyAsync(h_nzcount.data(), d_nzcount, sizeof(uint64_t) * nb, hipMemcpyDeviceToHost, st));
     HIP_TRY(s, hipStreamSynchronize(st));
 
     // ---- D. finish every file: LDS sort + count, or the full-sort fallback ----
@@ -871,9 +889,26 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (h_counts[b] == 0) continue;
       const uint32_t low = rem_bits - top_bits[b];
       void *seg = X + kbytes * h_starts[b];
-      if (h_maxsub[b] <= cap) {
+      // a sub-bucket above the LDS capacity (a k-mer repeated thousands of times, a dense corner of the key space) can
+      // still be counted by the hash tables if its DISTINCT k-mers fit: asked before anything touches the file
+      bool stream_huge = false;
+      if (h_maxsub[b] > cap && mgc::finish_can_stream(kw, low)) {
+        uint32_t h_fail = 0;
+        HIP_TRY(s, hipMemsetAsync(d_err + 1, 0, 4, st));
+        HIP_TRY(s, mgc::launch_finish_probe(seg, kw, d_substart + sbase[b], low, h_nlarge[b], d_large + gbase[b], d_err + 1, st));
+        HIP_TRY(s, hipMemcpyAsync(&h_fail, d_err + 1, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(s, hipStreamSynchronize(st));
+        stream_huge = (h_fail == 0);
+        if (getenv("MGC_FINISH_TRACE"))
+          fprintf(stderr, "[finish] bucket %u: largest sub-bucket %llu > %llu, %s\n", b, (unsigned long long)h_maxsub[b],
+                  (unsigned long long)cap, stream_huge ? "streamed through the hash tables" : "too many distinct: stable-sort fallback");
+      }
+      if (h_maxsub[b] <= cap || stream_huge) {
         HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_nlarge[b],
-                                           d_large + gbase[b], d_cnt_tmp + h_starts[b], d_group + gbase[b], st));
+                                           d_large + gbase[b], d_cnt_tmp + h_starts[b], d_group + gbase[b], stream_huge, d_err + 2,
+                                           // the list pays off only when a good part of the 2^t grid is empty
+                                           (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b])) ? d_nz + gbase[b] : nullptr,
+                                           d_nzcount + b, st));
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
         fallback[b] = true;
@@ -928,11 +963,12 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   tm.end(MGC_STAGE_BLOCKS);
   s->prof.stage_launches[MGC_STAGE_BLOCKS] = 1;
 
-  uint32_t h_err = 0;
-  HIP_TRY(s, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
+  uint32_t h_err[3] = {0, 0, 0};
+  HIP_TRY(s, hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, st));
   if (s->profiling) (void)hipEventRecord(ev_all[1], st);
   HIP_TRY(s, hipStreamSynchronize(st));
-  if (h_err) { set_err(&s->err, "radix sort look-back timed out"); return MGC_ETIMEOUT; }
+  if (h_err[0]) { set_err(&s->err, "radix sort look-back timed out"); return MGC_ETIMEOUT; }
+  if (h_err[2]) { set_err(&s->err, "internal: a streamed sub-bucket overflowed its hash table after a successful probe"); return MGC_EHIP; }
 
   if (s->profiling) {
     float ms = 0;

@@ -72,10 +72,18 @@ uint64_t   finish_target_for(uint32_t key_words);       // average sub-bucket si
 hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t low, uint32_t top_bits,
                                    uint64_t *d_starts /*[2^top+1]*/, uint64_t *d_max /*atomicMax target*/,
                                    uint32_t *d_large_list /*[2^top]: sub-buckets above the small-kernel capacity*/,
-                                   uint64_t *d_large_count /*zeroed by the caller*/, hipStream_t st);
+                                   uint64_t *d_large_count /*zeroed by the caller*/,
+                                   uint32_t *d_nonempty_list /*[2^top]*/, uint64_t *d_nonempty_count /*zeroed by the caller*/,
+                                   hipStream_t st);
+// sub-buckets above finish_capacity_for(): can they be streamed through the hash-count tables (distinct suffixes fit)?
+bool       finish_can_stream(uint32_t key_words, uint32_t low_bits);
+hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint32_t low_bits,
+                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_file_fail /*set to 1: no*/, hipStream_t st);
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
-                              hipStream_t st);
+                              bool stream_huge, uint32_t *d_huge_fail /*set to 1 on an internal overflow*/,
+                              const uint32_t *d_nonempty_list, const uint64_t *d_nonempty_count /*the hash kernels visit only these;
+                              d_group_distinct must be zero for the others*/, hipStream_t st);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);
 hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,

@@ -234,11 +234,20 @@ __global__ void subbucket_bounds_kernel(const K *__restrict__ keys, u64 n, u32 l
 
 // largest sub-bucket of a file -> *max_out (atomicMax), so the host can pick the kernel capacity
 // and the list of the sub-buckets above `threshold` (the ones the large-capacity launch takes)
+// and the list of the non-empty ones (any order; one atomic per wave)
 __global__ void subbucket_max_kernel(const u64 *__restrict__ starts, u64 ng, u64 *__restrict__ max_out, u64 threshold,
-                                     u32 *__restrict__ list, u64 *__restrict__ list_count) {
+                                     u32 *__restrict__ list, u64 *__restrict__ list_count,
+                                     u32 *__restrict__ nz, u64 *__restrict__ nz_count) {
   const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 sz = (v < ng) ? (starts[v + 1] - starts[v]) : 0ull;
   if (sz > threshold) list[atomicAdd(list_count, 1ull)] = (u32)v;
+  {
+    const u64 m = __ballot(sz != 0);
+    u64 base = 0;
+    if (lane_id() == 0 && m) base = atomicAdd(nz_count, (u64)__popcll(m));
+    base = __shfl(base, 0);
+    if (sz) nz[base + __popcll(m & ((1ull << lane_id()) - 1ull))] = (u32)v;
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { const u64 o = __shfl_down(sz, d); sz = (o > sz) ? o : sz; }
   if (lane_id() == 0 && sz) atomicMax(max_out, sz);
@@ -388,10 +397,11 @@ void lds_sort_count_kernel(K *__restrict__ keys,                      // the fil
 // (one 64-bit CAS + one add per key, independent per key => the LDS latency overlaps), compacts
 // the D distinct entries and ranks them by brute force (D^2 / BLOCK broadcast compares; D ~ n/7).
 // EMPTY cannot collide with a key: every key of the file shares its top six bits, ~key0 does not.
-template <int BLOCK, int CAP, int SLOTS, bool DBG>
+template <int BLOCK, int CAP, int SLOTS, bool DBG, bool STREAM, bool LIST>
 __global__ __launch_bounds__(BLOCK, 5)
 void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
-                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 *__restrict__ dbg) {
+                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 huge_min, u32 *__restrict__ huge_fail,
+                       const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u64 *__restrict__ dbg) {
   // Inside a sub-bucket the keys differ only in their low `low_bits` (< 32) bits: the table holds
   // 32-bit suffixes (half the LDS, 32-bit CAS and compares); the common prefix is added back on output.
   // Persistent workgroups: the keys of the next sub-bucket are loaded while the current one is counted
@@ -404,6 +414,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
   __shared__ __attribute__((aligned(16))) u32 dk[CAP + 16];
   __shared__ u32 dc[CAP];
   __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  __shared__ u32 s_st[2];                              // streamed sub-bucket: distinct so far, overflow
   const u32 tid = threadIdx.x;
   const u64 G = gridDim.x;
   const u64 low_mask = (1ull << low_bits) - 1ull;
@@ -423,11 +434,16 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
   const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
   const u64 file_base = (keys[0] >> group_shift) << group_shift;
 
-  u64 g = blockIdx.x, a, n64, na, nn;
+  // visit only the NON-EMPTY sub-buckets (list built by subbucket_max_kernel): a sparse key space (homopolymer-
+  // compressed k-mers, small k) leaves most of the 2^t grid empty, and an empty visit still costs a memory round trip
+  const u64 np = LIST ? *nz_count : ng;
+  auto sub_at = [&](u64 pp) -> u64 { return (pp < np) ? (LIST ? (u64)nz[pp] : pp) : ng; };
+  u64 p = blockIdx.x;
+  u64 g = sub_at(p), g1 = sub_at(p + G), g2 = sub_at(p + 2 * G), a, n64, na, nn;
   u32 kcur[KPT];
   load_bounds(g, a, n64);
   load_keys(a, n64, kcur);
-  load_bounds(g + G, na, nn);
+  load_bounds(g1, na, nn);
 
   u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
 #define HC_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
@@ -436,25 +452,32 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
     u64 nna, nnn;
     if (DBG) t0 = __builtin_readcyclecounter();
     load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
-    load_bounds(g + 2 * G, nna, nnn);
+    load_bounds(g2, nna, nnn);
+    const u64 g3 = sub_at(p + 3 * G);
 
     if (n64 == 0) {
       if (tid == 0) group_distinct[g] = 0;
-    } else if (n64 <= max_size) {                      // larger ones: a larger-capacity launch takes them
-      const u32 n = (u32)n64;
+    } else if (n64 <= max_size || (STREAM && n64 > huge_min)) {   // in between: the larger-capacity LDS sort launch takes them
+      // huge: more keys than any LDS kernel holds.  The table only holds DISTINCT suffixes, so the keys are streamed
+      // through it in rounds of CAP; the caller has checked (hash_probe_kernel) that the distinct ones fit.
+      const bool huge = STREAM && n64 > max_size;
+      const u32 n = huge ? (u32)CAP : (u32)n64;
       const u64 prefix = file_base | (g << low_bits);
       u32 kk[KPT], hh[KPT];
       u32 pending = 0;
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
         const u32 idx = (u32)j * BLOCK + tid;
-        kk[j] = kcur[j] & (u32)low_mask;
-        if (idx < n) pending |= 1u << j;
+        u32 raw = kcur[j];
+        if (huge) raw = (idx < n64) ? reinterpret_cast<const u32 *>(keys + a + idx)[0] : 0u;   // first round of a streamed sub-bucket
+        kk[j] = raw & (u32)low_mask;
+        if (idx < n && (u64)idx < n64) pending |= 1u << j;
       }
       // table sized to the sub-bucket (load factor <= 0.8 even if every key is distinct): the clear and the
       // compaction below walk the table, so an oversized one costs more than the longer probes of a full one
       u32 slots = 256;
       while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
+      if (huge) slots = (u32)SLOTS;
       const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
       {
         uint4 *tk4 = reinterpret_cast<uint4 *>(tk), *tc4 = reinterpret_cast<uint4 *>(tc);
@@ -462,25 +485,45 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
           tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
           tc4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
+        if (tid < 2) s_st[tid] = 0u;
       }
-#pragma unroll
-      for (int j = 0; j < KPT; j++) hh[j] = (kk[j] * 0x9E3779B1u) >> sshift;
       __syncthreads();
       HC_STAMP(0);
 
-      // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
-      while (pending) {
+      for (u64 base = 0;;) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) hh[j] = (kk[j] * 0x9E3779B1u) >> sshift;
+        // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
+        while (pending && !(huge && __hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+#pragma unroll
+          for (int j = 0; j < KPT; j++) {
+            if ((pending >> j) & 1u) {
+              const u32 old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
+              if (old == EMPTY || old == kk[j]) {
+                atomicAdd(&tc[hh[j]], 1u);
+                pending &= ~(1u << j);
+                if (huge && old == EMPTY && atomicAdd(&s_st[0], 1u) >= (u32)CAP) s_st[1] = 1u;   // more distinct than dk/dc hold
+              }
+              else hh[j] = (hh[j] + 1) & smask;
+            }
+          }
+        }
+        base += (u64)CAP;
+        if (!huge || base >= n64 || __hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        pending = 0;                                   // next round of a streamed sub-bucket
 #pragma unroll
         for (int j = 0; j < KPT; j++) {
-          if ((pending >> j) & 1u) {
-            const u32 old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
-            if (old == EMPTY || old == kk[j]) { atomicAdd(&tc[hh[j]], 1u); pending &= ~(1u << j); }
-            else hh[j] = (hh[j] + 1) & smask;
-          }
+          const u64 idx = base + (u64)j * BLOCK + tid;
+          kk[j] = (idx < n64) ? (reinterpret_cast<const u32 *>(keys + a + idx)[0] & (u32)low_mask) : 0u;
+          if (idx < n64) pending |= 1u << j;
         }
       }
       __syncthreads();
       HC_STAMP(1);
+      if (huge && s_st[1]) {                           // cannot happen after a successful probe: reported, not silently dropped
+        if (tid == 0) { group_distinct[g] = 0; atomicExch(huge_fail, 1u); }
+        __syncthreads();
+      } else {
 
       // compact the occupied slots (any order)
       u32 occ = 0;
@@ -522,11 +565,12 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
       HC_STAMP(3);
       __syncthreads();                                 // dk/dc/s_tmp are reused by the next sub-bucket
       HC_STAMP(4);
+      }
     }
 
 #pragma unroll
     for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
-    a = na; n64 = nn; na = nna; nn = nnn; g += G;
+    a = na; n64 = nn; na = nna; nn = nnn; g = g1; g1 = g2; g2 = g3; p += G;
     if (DBG) { ph[5] += kcur[0] & 1; HC_STAMP(6); ph[7]++; }   // [6]: wait for the prefetched keys
   }
   if (DBG && tid == 0 && blockIdx.x < 64)
@@ -536,10 +580,11 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 
 // Same scheme with 64-bit suffixes, for sub-buckets whose keys differ in 32..62 low bits (k from about 28 at the
 // 10 Gbp scale): 64-bit CAS, whole keys loaded, 42 KiB of LDS (3 workgroups per CU).
-template <int BLOCK, int CAP, int SLOTS>
+template <int BLOCK, int CAP, int SLOTS, bool STREAM, bool LIST>
 __global__ __launch_bounds__(BLOCK, 3)
 void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
-                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct) {
+                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 huge_min, u32 *__restrict__ huge_fail,
+                       const u32 *__restrict__ nz, const u64 *__restrict__ nz_count) {
   constexpr bool DBG = false;
   u64 *dbg = nullptr;
   // Inside a sub-bucket the keys differ only in their low `low_bits` (< 32) bits: the table holds
@@ -554,6 +599,7 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
   __shared__ __attribute__((aligned(16))) u64 dk[CAP + 16];
   __shared__ u32 dc[CAP];
   __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  __shared__ u32 s_st[2];                              // streamed sub-bucket: distinct so far, overflow
   const u32 tid = threadIdx.x;
   const u64 G = gridDim.x;
   const u64 low_mask = (1ull << low_bits) - 1ull;
@@ -573,11 +619,16 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
   const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
   const u64 file_base = (keys[0] >> group_shift) << group_shift;
 
-  u64 g = blockIdx.x, a, n64, na, nn;
+  // visit only the NON-EMPTY sub-buckets (list built by subbucket_max_kernel): a sparse key space (homopolymer-
+  // compressed k-mers, small k) leaves most of the 2^t grid empty, and an empty visit still costs a memory round trip
+  const u64 np = LIST ? *nz_count : ng;
+  auto sub_at = [&](u64 pp) -> u64 { return (pp < np) ? (LIST ? (u64)nz[pp] : pp) : ng; };
+  u64 p = blockIdx.x;
+  u64 g = sub_at(p), g1 = sub_at(p + G), g2 = sub_at(p + 2 * G), a, n64, na, nn;
   u64 kcur[KPT];
   load_bounds(g, a, n64);
   load_keys(a, n64, kcur);
-  load_bounds(g + G, na, nn);
+  load_bounds(g1, na, nn);
 
   u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
 #define HC_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
@@ -586,12 +637,16 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
     u64 nna, nnn;
     if (DBG) t0 = __builtin_readcyclecounter();
     load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
-    load_bounds(g + 2 * G, nna, nnn);
+    load_bounds(g2, nna, nnn);
+    const u64 g3 = sub_at(p + 3 * G);
 
     if (n64 == 0) {
       if (tid == 0) group_distinct[g] = 0;
-    } else if (n64 <= max_size) {                      // larger ones: a larger-capacity launch takes them
-      const u32 n = (u32)n64;
+    } else if (n64 <= max_size || (STREAM && n64 > huge_min)) {   // in between: the larger-capacity LDS sort launch takes them
+      // huge: more keys than any LDS kernel holds.  The table only holds DISTINCT suffixes, so the keys are streamed
+      // through it in rounds of CAP; the caller has checked (hash_probe_kernel) that the distinct ones fit.
+      const bool huge = STREAM && n64 > max_size;
+      const u32 n = huge ? (u32)CAP : (u32)n64;
       const u64 prefix = file_base | (g << low_bits);
       u64 kk[KPT];
       u32 hh[KPT];
@@ -599,36 +654,58 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
         const u32 idx = (u32)j * BLOCK + tid;
-        kk[j] = kcur[j] & low_mask;
-        if (idx < n) pending |= 1u << j;
+        u64 raw = kcur[j];
+        if (huge) raw = (idx < n64) ? keys[a + idx] : 0ull;   // first round of a streamed sub-bucket
+        kk[j] = raw & low_mask;
+        if (idx < n && (u64)idx < n64) pending |= 1u << j;
       }
       // table sized to the sub-bucket (load factor <= 0.8 even if every key is distinct): the clear and the
       // compaction below walk the table, so an oversized one costs more than the longer probes of a full one
       u32 slots = 256;
       while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
+      if (huge) slots = (u32)SLOTS;
       const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
       {
         for (u32 i = tid; i < slots; i += BLOCK) { tk[i] = EMPTY; tc[i] = 0u; }
+        if (tid < 2) s_st[tid] = 0u;
       }
-#pragma unroll
-      for (int j = 0; j < KPT; j++) hh[j] = (u32)((kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
       __syncthreads();
       HC_STAMP(0);
 
-      // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
-      while (pending) {
+      for (u64 base = 0;;) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) hh[j] = (u32)((kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
+        // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
+        while (pending && !(huge && __hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+#pragma unroll
+          for (int j = 0; j < KPT; j++) {
+            if ((pending >> j) & 1u) {
+              const u64 old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
+              if (old == EMPTY || old == kk[j]) {
+                atomicAdd(&tc[hh[j]], 1u);
+                pending &= ~(1u << j);
+                if (huge && old == EMPTY && atomicAdd(&s_st[0], 1u) >= (u32)CAP) s_st[1] = 1u;   // more distinct than dk/dc hold
+              }
+              else hh[j] = (hh[j] + 1) & smask;
+            }
+          }
+        }
+        base += (u64)CAP;
+        if (!huge || base >= n64 || __hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        pending = 0;                                   // next round of a streamed sub-bucket
 #pragma unroll
         for (int j = 0; j < KPT; j++) {
-          if ((pending >> j) & 1u) {
-            const u64 old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
-            if (old == EMPTY || old == kk[j]) { atomicAdd(&tc[hh[j]], 1u); pending &= ~(1u << j); }
-            else hh[j] = (hh[j] + 1) & smask;
-          }
+          const u64 idx = base + (u64)j * BLOCK + tid;
+          kk[j] = (idx < n64) ? (keys[a + idx] & low_mask) : 0ull;
+          if (idx < n64) pending |= 1u << j;
         }
       }
       __syncthreads();
       HC_STAMP(1);
-
+      if (huge && s_st[1]) {                           // cannot happen after a successful probe: reported, not silently dropped
+        if (tid == 0) { group_distinct[g] = 0; atomicExch(huge_fail, 1u); }
+        __syncthreads();
+      } else {
       // compact the occupied slots (any order)
       u32 occ = 0;
 #pragma unroll
@@ -665,11 +742,12 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
       HC_STAMP(3);
       __syncthreads();                                 // dk/dc/s_tmp are reused by the next sub-bucket
       HC_STAMP(4);
+      }
     }
 
 #pragma unroll
     for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
-    a = na; n64 = nn; na = nna; nn = nnn; g += G;
+    a = na; n64 = nn; na = nna; nn = nnn; g = g1; g1 = g2; g2 = g3; p += G;
     if (DBG) { ph[5] += kcur[0] & 1; HC_STAMP(6); ph[7]++; }   // [6]: wait for the prefetched keys
   }
   if (DBG && tid == 0 && blockIdx.x < 64)
@@ -685,7 +763,8 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
 template <int BLOCK, int CAP, int SLOTS, bool WIDE>
 __global__ __launch_bounds__(BLOCK, WIDE ? 2 : 3)
 void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
-                          u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct) {
+                          u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
+                          const u32 *__restrict__ nz, const u64 *__restrict__ nz_count) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
   constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
   constexpr u32 LOCK = 0xFFFFFFFFu;
@@ -715,17 +794,23 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
     }
   };
 
-  u64 g = blockIdx.x, a, n64, na, nn;
+  // visit only the NON-EMPTY sub-buckets (list built by subbucket_max_kernel): a sparse key space (homopolymer-
+  // compressed k-mers, small k) leaves most of the 2^t grid empty, and an empty visit still costs a memory round trip
+  const u64 np = nz ? *nz_count : ng;
+  auto sub_at = [&](u64 pp) -> u64 { return (pp < np) ? (nz ? (u64)nz[pp] : pp) : ng; };
+  u64 p = blockIdx.x;
+  u64 g = sub_at(p), g1 = sub_at(p + G), g2 = sub_at(p + 2 * G), a, n64, na, nn;
   K128 kcur[KPT];
   load_bounds(g, a, n64);
   load_keys(a, n64, kcur);
-  load_bounds(g + G, na, nn);
+  load_bounds(g1, na, nn);
 
   while (g < ng) {
     K128 knext[KPT];
     u64 nna, nnn;
     load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
-    load_bounds(g + 2 * G, nna, nnn);
+    load_bounds(g2, nna, nnn);
+    const u64 g3 = sub_at(p + 3 * G);
 
     if (n64 == 0) {
       if (tid == 0) group_distinct[g] = 0;
@@ -824,8 +909,58 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
 
 #pragma unroll
     for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
-    a = na; n64 = nn; na = nna; nn = nnn; g += G;
+    a = na; n64 = nn; na = nna; nn = nnn; g = g1; g1 = g2; g2 = g3; p += G;
   }
+}
+
+// Would the distinct suffixes of every sub-bucket above huge_min fit the hash-count tables?  One workgroup per entry of the
+// large-sub-bucket list streams its keys through a table that only stores suffixes (no counts, nothing written back) and
+// raises *file_fail if more than CAP distinct ones turn up.  Run BEFORE the finish kernels touch the file, because the
+// alternative for such a file (stable sort of all its bits) needs its k-mers intact.
+template <typename S, int BLOCK, int CAP, int SLOTS>
+__global__ __launch_bounds__(BLOCK)
+void hash_probe_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list,
+                       u64 huge_min, u32 low_bits, u32 *__restrict__ file_fail) {
+  constexpr int KPT = CAP / BLOCK;
+  const S EMPTY = ~(S)0;
+  __shared__ S   tk[SLOTS];
+  __shared__ u32 s_st[2];
+  const u32 tid = threadIdx.x;
+  const u64 g = list[blockIdx.x];
+  const u64 a = starts[g], n64 = starts[g + 1] - a;
+  if (n64 <= huge_min) return;
+  const u64 low_mask = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
+  for (u32 i = tid; i < (u32)SLOTS; i += BLOCK) tk[i] = EMPTY;
+  if (tid < 2) s_st[tid] = 0u;
+  __syncthreads();
+  constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
+  for (u64 base = 0; base < n64; base += (u64)CAP) {
+    S   kk[KPT];
+    u32 hh[KPT], pending = 0;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u64 idx = base + (u64)j * BLOCK + tid;
+      kk[j] = (idx < n64) ? (S)(keys[a + idx] & low_mask) : (S)0;
+      hh[j] = (u32)(((u64)kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
+      if (idx < n64) pending |= 1u << j;
+    }
+    while (pending && !__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        if ((pending >> j) & 1u) {
+          const S old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
+          if (old == EMPTY || old == kk[j]) {
+            pending &= ~(1u << j);
+            if (old == EMPTY && atomicAdd(&s_st[0], 1u) >= (u32)CAP) s_st[1] = 1u;
+          }
+          else hh[j] = (hh[j] + 1) & smask;
+        }
+      }
+    }
+    if (__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+  }
+  __syncthreads();
+  if (tid == 0 && s_st[1]) atomicExch(file_fail, 1u);
 }
 
 // offs = exclusive scan of group_distinct (offs[ng] = total).  One wave per sub-bucket.
@@ -858,7 +993,8 @@ static bool finish_uses_hash(uint32_t key_words, uint32_t low_bits) {
 static uint64_t finish_small_capacity(uint32_t key_words, uint32_t low_bits);
 
 hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t low, uint32_t top_bits,
-                                   uint64_t *d_starts, uint64_t *d_max, uint32_t *d_list, uint64_t *d_list_count, hipStream_t st) {
+                                   uint64_t *d_starts, uint64_t *d_max, uint32_t *d_list, uint64_t *d_list_count,
+                                   uint32_t *d_nz, uint64_t *d_nz_count, hipStream_t st) {
   const uint64_t ng = (uint64_t)1 << top_bits;
   const uint32_t tmask = (uint32_t)(ng - 1);
   const dim3 grid((uint32_t)((ng + 1 + 255) / 256));
@@ -871,7 +1007,8 @@ hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_
   MGC_CHECK(hipGetLastError());
   hipLaunchKernelGGL(subbucket_max_kernel, dim3((uint32_t)((ng + 255) / 256)), dim3(256), 0, st,
                      reinterpret_cast<const u64 *>(d_starts), (u64)ng, reinterpret_cast<u64 *>(d_max),
-                     (u64)finish_small_capacity(key_words, low), d_list, reinterpret_cast<u64 *>(d_list_count));
+                     (u64)finish_small_capacity(key_words, low), d_list, reinterpret_cast<u64 *>(d_list_count),
+                     d_nz, reinterpret_cast<u64 *>(d_nz_count));
   return hipGetLastError();
 }
 
@@ -917,20 +1054,44 @@ static void hash_dbg_report(hipStream_t st, uint64_t ng) {
   reports++;
 }
 
+bool finish_can_stream(uint32_t key_words, uint32_t low_bits) {
+  static const bool on = !(getenv("MGC_FINISH_STREAM") && getenv("MGC_FINISH_STREAM")[0] == '0');
+  return on && key_words == 1 && finish_uses_hash(key_words, low_bits);
+}
+
+hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint32_t low_bits,
+                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_file_fail, hipStream_t st) {
+  if (n_large == 0 || key_words != 1) return hipSuccess;
+  if (low_bits < 32)
+    hipLaunchKernelGGL((hash_probe_kernel<u32, 256, (int)FIN_CAP_HASH, 2048>), dim3((uint32_t)n_large), dim3(256), 0, st,
+                       reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list,
+                       (u64)FIN_CAP_LARGE, low_bits, d_file_fail);
+  else
+    hipLaunchKernelGGL((hash_probe_kernel<u64, 256, (int)FIN_CAP_HASH, 2048>), dim3((uint32_t)n_large), dim3(256), 0, st,
+                       reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list,
+                       (u64)FIN_CAP_LARGE, low_bits, d_file_fail);
+  return hipGetLastError();
+}
+
+// stream_huge: sub-buckets above FIN_CAP_LARGE are streamed through the hash-count tables (the caller has run
+// launch_finish_probe); otherwise the file holds none (the caller checked the largest sub-bucket)
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
+                              bool stream_huge, uint32_t *d_huge_fail, const uint32_t *d_nz, const uint64_t *d_nz_count,
                               hipStream_t st) {
+  const u64 huge_min = stream_huge ? (u64)FIN_CAP_LARGE : ~0ull;
+  const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
   if (key_words == 2 && finish_uses_hash(key_words, low_bits)) {
     static const uint32_t wgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 6u;
     const uint32_t wgrid = ng < wgrid_max ? (uint32_t)ng : wgrid_max;
     if (low_bits > 64)
       hipLaunchKernelGGL((hash_count128_kernel<256, (int)FIN_CAP_HASH, 2048, true>), dim3(wgrid), dim3(256), 0, st,
                          reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc);
     else
       hipLaunchKernelGGL((hash_count128_kernel<256, (int)FIN_CAP_HASH, 2048, false>), dim3(wgrid), dim3(256), 0, st,
                          reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc);
     MGC_CHECK(hipGetLastError());
     MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, 8192, d_cnt_tmp, d_group_distinct, st, d_large_list)));
     return hipSuccess;
@@ -945,18 +1106,27 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     // <= FIN_CAP_HASH keys: hash-count; larger sub-buckets: LDS radix passes in the 8192-key instantiation
     static const uint32_t hgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 10u;
     const uint32_t hgrid = ng < hgrid_max ? (uint32_t)ng : hgrid_max;
-    if (low_bits >= 32)
-      hipLaunchKernelGGL((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048>), dim3(hgrid), dim3(256), 0, st,
-                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct));
-    else if (hash_dbg_buffer())
-      hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true>), dim3(hgrid), dim3(256), 0, st,
-                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), hash_dbg_buffer());
-    else
-      hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false>), dim3(hgrid), dim3(256), 0, st,
-                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), nullptr);
+    const bool use_list = d_nz != nullptr;
+#define MGC_HASH_LAUNCH(KERNEL, ...)                                                                                        \
+    hipLaunchKernelGGL(KERNEL, dim3(hgrid), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys),                             \
+                       reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp,           \
+                       reinterpret_cast<u64 *>(d_group_distinct), huge_min, d_huge_fail, d_nz, nzc, ##__VA_ARGS__)
+    // the common case (no streamed sub-bucket, dense grid) runs the instantiation without either feature: the kernel is
+    // VALU-bound and every extra test in its loops costs time (12 % with both compiled in)
+    if (low_bits >= 32) {
+      if (stream_huge && use_list)  MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, true, true>));
+      else if (stream_huge)         MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, true, false>));
+      else if (use_list)            MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, false, true>));
+      else                          MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, false, false>));
+    } else if (hash_dbg_buffer()) {
+      MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true, true, true>), hash_dbg_buffer());
+    } else {
+      if (stream_huge && use_list)  MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, true>), (u64 *)nullptr);
+      else if (stream_huge)         MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, false>), (u64 *)nullptr);
+      else if (use_list)            MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, true>), (u64 *)nullptr);
+      else                          MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, false>), (u64 *)nullptr);
+    }
+#undef MGC_HASH_LAUNCH
     MGC_CHECK(hipGetLastError());
     hash_dbg_report(st, ng);
     MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, FIN_CAP_LARGE, d_cnt_tmp,

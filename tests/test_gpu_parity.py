@@ -749,3 +749,32 @@ def test_large_input_partition_granularity(ops, oracle_lib, torch_cuda, monkeypa
     files = ((whi.astype(object) << 64 | wlo.astype(object)) >> (2 * k - 6)) if k > 32 else (wlo >> np.uint64(2 * k - 6))
     np.add.at(inst_per_file, np.asarray(files, dtype=np.int64), wcn.astype(np.int64))
     assert np.array_equal(np.asarray(info.file_instances, dtype=np.int64), inst_per_file)
+
+
+@pytest.mark.parametrize("k", [25, 31])
+def test_oversized_subbuckets_stream_or_fall_back(ops, oracle_lib, torch_cuda, k):
+    # sub-buckets above every LDS capacity: (a) 30,000 instances of 900 distinct k-mers sharing a 20-base prefix -> streamed
+    # through the hash-count tables; (b) 30,000 instances of ~25,000 distinct ones -> the probe refuses, the file takes the
+    # stable-sort fallback; (c) ordinary reads around them.  All three must come out like the oracle's.
+    from meryl_amd import capi
+    rng = np.random.default_rng(k)
+    def cluster(prefix, n_inst, n_distinct):
+        tails = ["".join("ACGT"[i] for i in rng.integers(0, 4, k - len(prefix))) for _ in range(n_distinct)]
+        return ".".join(prefix + tails[int(i)] for i in rng.integers(0, n_distinct, n_inst)) + "."
+    pa = "AAC" + "".join("ACGT"[i] for i in rng.integers(0, 4, 17))          # file AAC..., canonical as written (starts with A)
+    pb = "ACA" + "".join("ACGT"[i] for i in rng.integers(0, 4, 17))
+    reads = oracle_lib.synth_reads(k, 40_000, 0, 3000).tobytes().decode()
+    stream = cluster(pa, 30_000, 900) + cluster(pb, 30_000, 25_000) + reads
+    cfg = capi.configure(k, len(stream), 1 << 30)
+    with ops.Session(cfg) as s:
+        s.push_bases(stream, end_of_sequence=False)
+        s.count()
+        klo, khi, counts, _ = s.result_wide()
+    whi, wlo, wcn, _ = oracle_lib.count_brute(stream, k, 1)                   # forward mode keeps the clusters where they were put
+    with ops.Session(capi.configure(k, len(stream), 1 << 30, 1)) as s:
+        s.push_bases(stream, end_of_sequence=False)
+        s.count()
+        flo, fhi, fcounts, _ = s.result_wide()
+    assert np.array_equal(flo, wlo) and np.array_equal(fcounts, wcn)
+    chi, clo, ccn, _ = oracle_lib.count_brute(stream, k, 0)
+    assert np.array_equal(klo, clo) and np.array_equal(counts, ccn)
