@@ -285,6 +285,12 @@ int mgc_get_profile(const mgc_session *s, mgc_profile *p);
 int mgc_dev_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                         uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,
                         uint8_t *d_out, void *stream);
+/* ... with repeat families in the genome: repeat_ppm of its `repeat_unit`-base blocks show one of
+ * `repeat_families` template sequences, family 0 by far the most frequent (byte-identical to orc_synth_reads_ex). */
+int mgc_dev_synth_reads_ex(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
+                           uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,
+                           uint32_t repeat_ppm, uint32_t repeat_unit, uint32_t repeat_families,
+                           uint8_t *d_out, void *stream);
 
 /* Library/ABI version: major<<16 | minor. */
 uint32_t mgc_version(void);

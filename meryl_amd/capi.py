@@ -23,7 +23,7 @@ SYMBOLS = (
     "mgc_dev_rle_workspace_bytes", "mgc_dev_rle_count", "mgc_dev_rle_emit", "mgc_dev_block_offsets",
     "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_copy_result_device",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish",
-    "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_version",
+    "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_dev_synth_reads_ex", "mgc_version",
     "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases",
     # include/meryl_db.h
     "mdb_writer_open", "mdb_writer_add_block", "mdb_writer_close", "mdb_last_error",
@@ -176,6 +176,7 @@ def lib():
     sig("mgc_dev_homopoly_workspace_bytes", sz, u64)
     sig("mgc_dev_homopoly_compress", i32, vp, u64, vp, P(u64), vp, sz, vp)
     sig("mgc_dev_synth_reads", i32, u64, u64, u64, u64, u32, u32, u32, vp, vp)
+    sig("mgc_dev_synth_reads_ex", i32, u64, u64, u64, u64, u32, u32, u32, u32, u32, u32, vp, vp)
     sig("mgc_open", vp, P(CountConfig), i32)
     sig("mgc_close", None, vp)
     sig("mgc_last_error", ctypes.c_char_p, vp)

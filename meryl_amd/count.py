@@ -41,10 +41,11 @@ def _u64(n, device):
 # stateless device operators
 # ---------------------------------------------------------------------------
 def dev_synth_reads(seed, genome_len, first_read, n_reads, read_len=150, sub_rate_ppm=5000, n_rate_ppm=100,
-                    device="cuda"):
+                    device="cuda", repeat_ppm=0, repeat_unit=300, repeat_families=1000):
     out = torch.empty(int(n_reads) * (read_len + 1), dtype=torch.uint8, device=device)
-    capi.check(capi.lib().mgc_dev_synth_reads(seed, genome_len, first_read, n_reads, read_len, sub_rate_ppm,
-                                              n_rate_ppm, _ptr(out), _stream_ptr()), "mgc_dev_synth_reads")
+    capi.check(capi.lib().mgc_dev_synth_reads_ex(seed, genome_len, first_read, n_reads, read_len, sub_rate_ppm,
+                                                 n_rate_ppm, repeat_ppm, repeat_unit, repeat_families, _ptr(out),
+                                                 _stream_ptr()), "mgc_dev_synth_reads_ex")
     return out
 
 

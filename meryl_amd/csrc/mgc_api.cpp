@@ -276,9 +276,16 @@ extern "C" int mgc_dev_homopoly_compress(const uint8_t *d_in, uint64_t n, uint8_
 extern "C" int mgc_dev_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                                    uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm, uint8_t *d_out,
                                    void *stream) {
+  return mgc_dev_synth_reads_ex(seed, genome_len, first_read, n_reads, read_len, sub_rate_ppm, n_rate_ppm, 0, 1, 1, d_out, stream);
+}
+
+extern "C" int mgc_dev_synth_reads_ex(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
+                                      uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,
+                                      uint32_t repeat_ppm, uint32_t repeat_unit, uint32_t repeat_families,
+                                      uint8_t *d_out, void *stream) {
   if (!d_out || read_len == 0 || genome_len < read_len) return MGC_EINVAL;
   return hip_rc(mgc::launch_synth_reads(seed, genome_len, first_read, n_reads, read_len, sub_rate_ppm, n_rate_ppm,
-                                        d_out, (hipStream_t)stream), "synth_reads");
+                                        repeat_ppm, repeat_unit, repeat_families, d_out, (hipStream_t)stream), "synth_reads");
 }
 
 // ---------------------------------------------------------------------------
@@ -760,7 +767,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   void *sort_ws = s->buf[mgc_session::B_SORT_WS].p;
   // device flags: [0] look-back timeout, [1] scratch answer of the hash probe, [2] overflow of a streamed sub-bucket
   uint32_t *d_err = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(sort_ws) + sort_ws_bytes - 256);
-  HIP_TRY(s, hipMemsetAsync(d_err, 0, 16, st));
+  HIP_TRY(s, hipMemsetAsync(d_err, 0, 32, st));
 
   const uint32_t rem_bits = 2 * k - bucket_bits;
   const uint32_t ev_per_file = 2 * 16;                     // room for 16 passes per file
@@ -893,15 +900,16 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       // still be counted by the hash tables if its DISTINCT k-mers fit: asked before anything touches the file
       bool stream_huge = false;
       if (h_maxsub[b] > cap && mgc::finish_can_stream(kw, low)) {
-        uint32_t h_fail = 0;
-        HIP_TRY(s, hipMemsetAsync(d_err + 1, 0, 4, st));
-        HIP_TRY(s, mgc::launch_finish_probe(seg, kw, d_substart + sbase[b], low, h_nlarge[b], d_large + gbase[b], d_err + 1, st));
-        HIP_TRY(s, hipMemcpyAsync(&h_fail, d_err + 1, 4, hipMemcpyDeviceToHost, st));
+        uint32_t h_fail[3] = {0, 0, 0};                 // [0] answer, [2] most distinct suffixes met (diagnostics)
+        HIP_TRY(s, hipMemsetAsync(d_err + 4, 0, 12, st));
+        HIP_TRY(s, mgc::launch_finish_probe(seg, kw, d_substart + sbase[b], low, h_nlarge[b], d_large + gbase[b], d_err + 4, st));
+        HIP_TRY(s, hipMemcpyAsync(h_fail, d_err + 4, 12, hipMemcpyDeviceToHost, st));
         HIP_TRY(s, hipStreamSynchronize(st));
-        stream_huge = (h_fail == 0);
+        stream_huge = (h_fail[0] == 0);
         if (getenv("MGC_FINISH_TRACE"))
-          fprintf(stderr, "[finish] bucket %u: largest sub-bucket %llu > %llu, %s\n", b, (unsigned long long)h_maxsub[b],
-                  (unsigned long long)cap, stream_huge ? "streamed through the hash tables" : "too many distinct: stable-sort fallback");
+          fprintf(stderr, "[finish] bucket %u: largest sub-bucket %llu > %llu, up to %u distinct in one: %s\n", b,
+                  (unsigned long long)h_maxsub[b], (unsigned long long)cap, h_fail[2],
+                  stream_huge ? "streamed through the hash tables" : "too many distinct: stable-sort fallback");
       }
       if (h_maxsub[b] <= cap || stream_huge) {
         HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_nlarge[b],

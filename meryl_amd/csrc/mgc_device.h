@@ -108,6 +108,7 @@ hipError_t launch_text_file_op(void *d_state, uint8_t *d_out, int what, hipStrea
 
 hipError_t launch_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                               uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,
+                              uint32_t repeat_ppm, uint32_t repeat_unit, uint32_t repeat_families,
                               uint8_t *d_out, hipStream_t st);
 
 }  // namespace mgc

@@ -397,7 +397,7 @@ void lds_sort_count_kernel(K *__restrict__ keys,                      // the fil
 // (one 64-bit CAS + one add per key, independent per key => the LDS latency overlaps), compacts
 // the D distinct entries and ranks them by brute force (D^2 / BLOCK broadcast compares; D ~ n/7).
 // EMPTY cannot collide with a key: every key of the file shares its top six bits, ~key0 does not.
-template <int BLOCK, int CAP, int SLOTS, bool DBG, bool STREAM, bool LIST>
+template <int BLOCK, int CAP, int SLOTS, bool DBG, bool LIST>
 __global__ __launch_bounds__(BLOCK, 5)
 void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                        u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 huge_min, u32 *__restrict__ huge_fail,
@@ -457,10 +457,8 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 
     if (n64 == 0) {
       if (tid == 0) group_distinct[g] = 0;
-    } else if (n64 <= max_size || (STREAM && n64 > huge_min)) {   // in between: the larger-capacity LDS sort launch takes them
-      // huge: more keys than any LDS kernel holds.  The table only holds DISTINCT suffixes, so the keys are streamed
-      // through it in rounds of CAP; the caller has checked (hash_probe_kernel) that the distinct ones fit.
-      const bool huge = STREAM && n64 > max_size;
+    } else if (n64 <= max_size) {                      // larger ones: other launches take them
+      constexpr bool huge = false;
       const u32 n = huge ? (u32)CAP : (u32)n64;
       const u64 prefix = file_base | (g << low_bits);
       u32 kk[KPT], hh[KPT];
@@ -580,7 +578,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 
 // Same scheme with 64-bit suffixes, for sub-buckets whose keys differ in 32..62 low bits (k from about 28 at the
 // 10 Gbp scale): 64-bit CAS, whole keys loaded, 42 KiB of LDS (3 workgroups per CU).
-template <int BLOCK, int CAP, int SLOTS, bool STREAM, bool LIST>
+template <int BLOCK, int CAP, int SLOTS, bool LIST>
 __global__ __launch_bounds__(BLOCK, 3)
 void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                        u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 huge_min, u32 *__restrict__ huge_fail,
@@ -642,10 +640,8 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
 
     if (n64 == 0) {
       if (tid == 0) group_distinct[g] = 0;
-    } else if (n64 <= max_size || (STREAM && n64 > huge_min)) {   // in between: the larger-capacity LDS sort launch takes them
-      // huge: more keys than any LDS kernel holds.  The table only holds DISTINCT suffixes, so the keys are streamed
-      // through it in rounds of CAP; the caller has checked (hash_probe_kernel) that the distinct ones fit.
-      const bool huge = STREAM && n64 > max_size;
+    } else if (n64 <= max_size) {                      // larger ones: other launches take them
+      constexpr bool huge = false;
       const u32 n = huge ? (u32)CAP : (u32)n64;
       const u64 prefix = file_base | (g << low_bits);
       u64 kk[KPT];
@@ -913,6 +909,91 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
   }
 }
 
+// Hash-count of the sub-buckets that hold more keys than any LDS kernel can (a k-mer present thousands of times with
+// its error variants; one workgroup per entry of the large-sub-bucket list, entries at or below huge_min are somebody
+// else's).  The table stores DISTINCT suffixes only, so the keys are streamed through it in rounds of BLOCK*KPT; up to
+// CAP distinct ones fit (checked beforehand by hash_probe_kernel with the same geometry).  Then the same compaction,
+// all-pairs rank and in-place output as hash_count_kernel.
+template <typename S, int BLOCK, int CAP, int SLOTS>
+__global__ __launch_bounds__(BLOCK)
+void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
+                            u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
+                            u32 *__restrict__ overflow) {
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
+  constexpr int KPT = 4, SPT = SLOTS / BLOCK;
+  const S EMPTY = ~(S)0;
+  extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+  S   *tk = reinterpret_cast<S *>(hsm);                                   // [SLOTS]
+  u32 *tc = reinterpret_cast<u32 *>(hsm + sizeof(S) * SLOTS);             // [SLOTS]
+  S   *dk = reinterpret_cast<S *>(hsm + (sizeof(S) + 4) * SLOTS);         // [CAP]
+  u32 *dc = reinterpret_cast<u32 *>(hsm + (sizeof(S) + 4) * SLOTS + sizeof(S) * CAP);   // [CAP]
+  __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  __shared__ u32 s_st[2];
+  const u32 tid = threadIdx.x;
+  const u64 g = list[blockIdx.x];
+  const u64 a = starts[g], n64 = starts[g + 1] - a;
+  if (n64 <= huge_min) return;
+  const u64 low_mask = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
+  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);
+  const u64 prefix = ((keys[0] >> group_shift) << group_shift) | (g << low_bits);
+  for (u32 i = tid; i < (u32)SLOTS; i += BLOCK) { tk[i] = EMPTY; tc[i] = 0u; }
+  if (tid < 2) s_st[tid] = 0u;
+  __syncthreads();
+  constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
+  u64 *gk = keys + a;
+  for (u64 base = 0; base < n64; base += (u64)BLOCK * KPT) {
+    S   kk[KPT];
+    u32 hh[KPT], pending = 0;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u64 idx = base + (u64)j * BLOCK + tid;
+      kk[j] = (idx < n64) ? (S)(gk[idx] & low_mask) : (S)0;
+      hh[j] = (u32)(((u64)kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
+      if (idx < n64) pending |= 1u << j;
+    }
+    while (pending && !__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        if ((pending >> j) & 1u) {
+          const S old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
+          if (old == EMPTY || old == kk[j]) {
+            atomicAdd(&tc[hh[j]], 1u);
+            pending &= ~(1u << j);
+            if (old == EMPTY && atomicAdd(&s_st[0], 1u) >= (u32)CAP) s_st[1] = 1u;
+          }
+          else hh[j] = (hh[j] + 1) & smask;
+        }
+      }
+    }
+    if (__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+  }
+  __syncthreads();
+  if (s_st[1]) {                                       // cannot happen after a successful probe: reported, not dropped
+    if (tid == 0) { group_distinct[g] = 0; atomicExch(overflow, 1u); }
+    return;
+  }
+  u32 occ = 0;
+#pragma unroll
+  for (int j = 0; j < SPT; j++) occ |= (tc[(u32)j * BLOCK + tid] != 0u ? 1u : 0u) << j;
+  u32 D;
+  u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+#pragma unroll
+  for (int j = 0; j < SPT; j++)
+    if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
+  __syncthreads();
+  for (u32 i = tid; i < D; i += BLOCK) {
+    const S ki = dk[i];
+    u32 r0 = 0, r1 = 0;
+    u32 j = 0;
+    for (; j + 2 <= D; j += 2) { r0 += (dk[j] < ki) ? 1u : 0u; r1 += (dk[j + 1] < ki) ? 1u : 0u; }
+    if (j < D) r0 += (dk[j] < ki) ? 1u : 0u;
+    const u32 r = r0 + r1;
+    gk[r] = prefix | (u64)ki;                          // in place: every key of the sub-bucket went through the table
+    cnt_tmp[a + r] = dc[i];
+  }
+  if (tid == 0) group_distinct[g] = D;
+}
+
 // Would the distinct suffixes of every sub-bucket above huge_min fit the hash-count tables?  One workgroup per entry of the
 // large-sub-bucket list streams its keys through a table that only stores suffixes (no counts, nothing written back) and
 // raises *file_fail if more than CAP distinct ones turn up.  Run BEFORE the finish kernels touch the file, because the
@@ -961,6 +1042,7 @@ void hash_probe_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ sta
   }
   __syncthreads();
   if (tid == 0 && s_st[1]) atomicExch(file_fail, 1u);
+  if (tid == 0) atomicMax(file_fail + 2, s_st[0]);     // diagnostics (MGC_FINISH_TRACE): most distinct suffixes met in a huge sub-bucket
 }
 
 // offs = exclusive scan of group_distinct (offs[ng] = total).  One wave per sub-bucket.
@@ -980,6 +1062,8 @@ void compact_groups_kernel(const K *__restrict__ keys, const u32 *__restrict__ c
 __global__ void store_u64_kernel(u64 *__restrict__ dst, const u64 *__restrict__ src) { *dst = *src; }
 
 constexpr u64 FIN_CAP_SMALL = 256 * 16, FIN_CAP_LARGE = 1024 * 8;   // LDS: 46 KiB and 91 KiB per workgroup
+constexpr int HUGE_CAP32 = 6144, HUGE_SLOTS32 = 8192;            // streamed sub-buckets, 32-bit suffixes: 112 KiB of LDS
+constexpr int HUGE_CAP64 = 3072, HUGE_SLOTS64 = 4096;            // 64-bit suffixes: 84 KiB
 constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count kernel: 2048 slots, 28 KiB of LDS, 5 workgroups per CU
 
 static bool finish_uses_hash(uint32_t key_words, uint32_t low_bits) {
@@ -1063,11 +1147,11 @@ hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uin
                                uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_file_fail, hipStream_t st) {
   if (n_large == 0 || key_words != 1) return hipSuccess;
   if (low_bits < 32)
-    hipLaunchKernelGGL((hash_probe_kernel<u32, 256, (int)FIN_CAP_HASH, 2048>), dim3((uint32_t)n_large), dim3(256), 0, st,
+    hipLaunchKernelGGL((hash_probe_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>), dim3((uint32_t)n_large), dim3(1024), 0, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list,
                        (u64)FIN_CAP_LARGE, low_bits, d_file_fail);
   else
-    hipLaunchKernelGGL((hash_probe_kernel<u64, 256, (int)FIN_CAP_HASH, 2048>), dim3((uint32_t)n_large), dim3(256), 0, st,
+    hipLaunchKernelGGL((hash_probe_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>), dim3((uint32_t)n_large), dim3(1024), 0, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list,
                        (u64)FIN_CAP_LARGE, low_bits, d_file_fail);
   return hipGetLastError();
@@ -1111,24 +1195,41 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     hipLaunchKernelGGL(KERNEL, dim3(hgrid), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys),                             \
                        reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp,           \
                        reinterpret_cast<u64 *>(d_group_distinct), huge_min, d_huge_fail, d_nz, nzc, ##__VA_ARGS__)
-    // the common case (no streamed sub-bucket, dense grid) runs the instantiation without either feature: the kernel is
-    // VALU-bound and every extra test in its loops costs time (12 % with both compiled in)
+    // the dense case runs the instantiation without the list: the kernel is VALU-bound, tests in its loops cost time
     if (low_bits >= 32) {
-      if (stream_huge && use_list)  MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, true, true>));
-      else if (stream_huge)         MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, true, false>));
-      else if (use_list)            MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, false, true>));
-      else                          MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, false, false>));
+      if (use_list) MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, true>));
+      else          MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, false>));
     } else if (hash_dbg_buffer()) {
-      MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true, true, true>), hash_dbg_buffer());
+      MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true, true>), hash_dbg_buffer());
     } else {
-      if (stream_huge && use_list)  MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, true>), (u64 *)nullptr);
-      else if (stream_huge)         MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, false>), (u64 *)nullptr);
-      else if (use_list)            MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, true>), (u64 *)nullptr);
-      else                          MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, false>), (u64 *)nullptr);
+      if (use_list) MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true>), (u64 *)nullptr);
+      else          MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false>), (u64 *)nullptr);
     }
 #undef MGC_HASH_LAUNCH
     MGC_CHECK(hipGetLastError());
     hash_dbg_report(st, ng);
+    if (stream_huge && n_large) {
+      // sub-buckets above every LDS capacity: one 1024-thread workgroup each, keys streamed through a large table
+      static bool hattr = false;
+      constexpr size_t B32 = (size_t)(4 + 4) * HUGE_SLOTS32 + (size_t)(4 + 4) * HUGE_CAP32;
+      constexpr size_t B64 = (size_t)(8 + 4) * HUGE_SLOTS64 + (size_t)(8 + 4) * HUGE_CAP64;
+      if (!hattr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)B32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)B64);
+        hattr = true;
+      }
+      if (low_bits < 32)
+        hipLaunchKernelGGL((hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>), dim3((uint32_t)n_large), dim3(1024), B32, st,
+                           reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
+                           (u64)FIN_CAP_LARGE, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_huge_fail);
+      else
+        hipLaunchKernelGGL((hash_count_huge_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>), dim3((uint32_t)n_large), dim3(1024), B64, st,
+                           reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
+                           (u64)FIN_CAP_LARGE, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_huge_fail);
+      MGC_CHECK(hipGetLastError());
+    }
     MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, FIN_CAP_LARGE, d_cnt_tmp,
                                            d_group_distinct, st, d_large_list)));
     return hipSuccess;

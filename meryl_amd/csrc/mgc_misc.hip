@@ -103,8 +103,22 @@ __host__ __device__ __forceinline__ u64 splitmix64(u64 x) {
 
 struct SynthParams {
   u64 s_genome, s_read, s_error, span, first_read, total_bytes, sub_thresh, n_thresh;
-  u32 read_len;
+  u64 s_rep, rep_thresh;
+  u32 read_len, rep_unit, rep_families;
 };
+
+// repeat families: oracle_count.c synth_genome_pos, same integer arithmetic
+__device__ __forceinline__ u64 synth_genome_pos(const SynthParams &P, u64 gpos) {
+  if (P.rep_thresh == 0) return gpos;
+  const u64 blk = gpos / P.rep_unit;
+  const u64 h   = splitmix64(P.s_rep ^ blk);
+  if ((u64)(u32)h >= P.rep_thresh) return gpos;
+  const u64 u = h >> 32;
+  const u64 a = (u * u) >> 32;
+  const u64 b = (a * u) >> 32;
+  const u64 fam = (b * (u64)P.rep_families) >> 32;
+  return (1ull << 62) + fam * (u64)P.rep_unit + (gpos - blk * P.rep_unit);
+}
 
 __device__ __forceinline__ u32 synth_byte(const SynthParams &P, u64 o) {
   const u64 stride = (u64)P.read_len + 1;
@@ -116,7 +130,7 @@ __device__ __forceinline__ u32 synth_byte(const SynthParams &P, u64 o) {
   const u64 start = __umul64hi(hr, P.span);
   const bool rev  = (hr & 1ull) != 0;
   const u64 gpos  = rev ? (start + P.read_len - 1 - j) : (start + j);
-  u32 code = (u32)(splitmix64(P.s_genome ^ gpos) & 3ull);
+  u32 code = (u32)(splitmix64(P.s_genome ^ synth_genome_pos(P, gpos)) & 3ull);
   if (rev) code ^= 2u;
   const u64 he = splitmix64(P.s_error ^ (r * (u64)P.read_len + j));
   const u32 e1 = (u32)he, e2 = (u32)(he >> 32);
@@ -141,6 +155,7 @@ void synth_reads_kernel(SynthParams P, uint8_t *__restrict__ out) {
 
 hipError_t launch_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                               uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,
+                              uint32_t repeat_ppm, uint32_t repeat_unit, uint32_t repeat_families,
                               uint8_t *d_out, hipStream_t st) {
   if (n_reads == 0) return hipSuccess;
   SynthParams P;
@@ -153,6 +168,10 @@ hipError_t launch_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first
   P.total_bytes = n_reads * ((uint64_t)read_len + 1);
   P.sub_thresh  = (uint64_t)sub_rate_ppm * 4294967296ull / 1000000ull;
   P.n_thresh    = (uint64_t)n_rate_ppm * 4294967296ull / 1000000ull;
+  P.s_rep       = splitmix64(seed + 3ull * 0x632be59bd9b4e019ull);
+  P.rep_thresh  = (uint64_t)repeat_ppm * 4294967296ull / 1000000ull;
+  P.rep_unit    = repeat_unit ? repeat_unit : 1;
+  P.rep_families = repeat_families ? repeat_families : 1;
   const uint64_t threads = (P.total_bytes + 3) / 4;
   hipLaunchKernelGGL(synth_reads_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st, P, d_out);
   return hipGetLastError();

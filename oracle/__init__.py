@@ -86,6 +86,10 @@ def lib():
     L.orc_synth_reads.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                   ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
     L.orc_synth_reads.restype = ctypes.c_uint64
+    L.orc_synth_reads_ex.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    L.orc_synth_reads_ex.restype = ctypes.c_uint64
     _lib = L
     return L
 
@@ -213,9 +217,10 @@ def configure_counting(k, n_kmers_estimate, memory_bytes, count_suffix_length=0,
     return {f: getattr(c, f) for f, _ in _Config._fields_}
 
 
-def synth_reads(seed, genome_len, first_read, n_reads, read_len=150, sub_rate_ppm=5000, n_rate_ppm=100):
+def synth_reads(seed, genome_len, first_read, n_reads, read_len=150, sub_rate_ppm=5000, n_rate_ppm=100,
+                repeat_ppm=0, repeat_unit=300, repeat_families=1000):
     out = np.zeros(n_reads * (read_len + 1), dtype=np.uint8)
-    n = lib().orc_synth_reads(seed, genome_len, first_read, n_reads, read_len, sub_rate_ppm, n_rate_ppm,
-                              out.ctypes.data)
+    n = lib().orc_synth_reads_ex(seed, genome_len, first_read, n_reads, read_len, sub_rate_ppm, n_rate_ppm,
+                                 repeat_ppm, repeat_unit, repeat_families, out.ctypes.data)
     assert n == out.size
     return out

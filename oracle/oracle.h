@@ -112,6 +112,11 @@ int      orc_count_threaded_collect(const char *bases, uint64_t n, uint32_t k, i
  * generator in meryl_amd/csrc reproduces these bytes exactly. */
 uint64_t orc_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                          uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm, char *out);
+/* the same with repeat families in the genome (repeat_ppm of the `repeat_unit`-base blocks show one of
+ * `repeat_families` template sequences, cubic skew); byte-identical to mgc_dev_synth_reads_ex */
+uint64_t orc_synth_reads_ex(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
+                            uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,
+                            uint32_t repeat_ppm, uint32_t repeat_unit, uint32_t repeat_families, char *out);
 
 #ifdef __cplusplus
 }

@@ -297,9 +297,34 @@ static inline uint64_t splitmix64(uint64_t x) {
   return x ^ (x >> 31);
 }
 
+/* Repeat families ("10 % of bases in repeat families to create a count tail"): the genome is
+ * cut into blocks of `unit` bases; a block is a repeat with probability repeat_ppm/1e6 and then shows one of `families`
+ * template sequences, chosen with a cubic skew (family 0 is by far the most frequent, like an Alu). */
+static uint64_t synth_genome_pos(uint64_t gpos, uint64_t s_rep, uint64_t rep_thresh, uint32_t unit, uint32_t families) {
+  if (rep_thresh == 0) return gpos;
+  const uint64_t blk = gpos / unit;
+  const uint64_t h   = splitmix64(s_rep ^ blk);
+  if ((uint64_t)(uint32_t)h >= rep_thresh) return gpos;
+  const uint64_t u = h >> 32;                       /* 32 uniform bits -> u^3 in 32-bit fixed point */
+  const uint64_t a = (u * u) >> 32;
+  const uint64_t b = (a * u) >> 32;
+  const uint64_t fam = (b * (uint64_t)families) >> 32;
+  return (1ull << 62) + fam * (uint64_t)unit + (gpos - blk * unit);
+}
+
 uint64_t orc_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                          uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm, char *out) {
+  return orc_synth_reads_ex(seed, genome_len, first_read, n_reads, read_len, sub_rate_ppm, n_rate_ppm, 0, 1, 1, out);
+}
+
+uint64_t orc_synth_reads_ex(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
+                            uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,
+                            uint32_t repeat_ppm, uint32_t repeat_unit, uint32_t repeat_families, char *out) {
   static const char acgt[4] = { 'A', 'C', 'T', 'G' };
+  const uint64_t rep_thresh = (uint64_t)repeat_ppm * 4294967296ull / 1000000ull;
+  const uint64_t s_rep      = splitmix64(seed + 3 * 0x632be59bd9b4e019ull);
+  if (repeat_unit == 0) repeat_unit = 1;
+  if (repeat_families == 0) repeat_families = 1;
   const uint64_t span       = genome_len - read_len + 1;
   const uint64_t sub_thresh = (uint64_t)sub_rate_ppm * 4294967296ull / 1000000ull;   /* compare against 32 random bits */
   const uint64_t n_thresh   = (uint64_t)n_rate_ppm   * 4294967296ull / 1000000ull;
@@ -314,7 +339,7 @@ uint64_t orc_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read
     const int      rev   = (int)(hr & 1);
     for (uint32_t j = 0; j < read_len; j++) {
       uint64_t gpos = rev ? (start + read_len - 1 - j) : (start + j);
-      uint32_t code = (uint32_t)(splitmix64(s_genome ^ gpos) & 3);
+      uint32_t code = (uint32_t)(splitmix64(s_genome ^ synth_genome_pos(gpos, s_rep, rep_thresh, repeat_unit, repeat_families)) & 3);
       if (rev) code ^= 2;
       const uint64_t he = splitmix64(s_error ^ (r * read_len + j));
       const uint32_t e1 = (uint32_t)he;

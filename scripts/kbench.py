@@ -7,7 +7,8 @@ from meryl_amd import capi, count
 k = int(sys.argv[1]); reads = int(sys.argv[2]) if len(sys.argv) > 2 else 33_333_334
 compress = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 read_len = int(sys.argv[4]) if len(sys.argv) > 4 else 150
-bases = count.dev_synth_reads(20240917, reads * read_len // 30, 0, reads, read_len, 5000, 100)
+repeat_ppm = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # e.g. 100000 = 10 % of the genome in repeat families
+bases = count.dev_synth_reads(20240917, reads * read_len // 30, 0, reads, read_len, 5000, 100, repeat_ppm=repeat_ppm)
 torch.cuda.synchronize()
 cfg = capi.configure(k, reads * read_len, 64 << 30, homopoly_compress=compress)
 s = count.Session(cfg, 0)
@@ -19,5 +20,5 @@ for _ in range(2):
     s.count()
 torch.cuda.synchronize()
 p = s.profile(); i = s.info()
-print("k=%d compress=%d read_len=%d reads=%d: %.1f ms/step, %d instances, %d distinct, stages %s" % (k, compress, read_len, reads, (time.perf_counter() - t0) / 2 * 1e3, i.n_instances,
+print("k=%d compress=%d read_len=%d repeats=%dppm reads=%d: %.1f ms/step, %d instances, %d distinct, stages %s" % (k, compress, read_len, repeat_ppm, reads, (time.perf_counter() - t0) / 2 * 1e3, i.n_instances,
       i.n_distinct, ["%.1f" % x for x in list(p.stage_ms)[:capi.NUM_STAGES]]))

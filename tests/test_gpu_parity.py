@@ -778,3 +778,23 @@ def test_oversized_subbuckets_stream_or_fall_back(ops, oracle_lib, torch_cuda, k
     assert np.array_equal(flo, wlo) and np.array_equal(fcounts, wcn)
     chi, clo, ccn, _ = oracle_lib.count_brute(stream, k, 0)
     assert np.array_equal(klo, clo) and np.array_equal(counts, ccn)
+
+
+def test_repeat_family_reads_generator_and_count(ops, oracle_lib, torch_cuda):
+    # a genome with 10 % of its blocks in skewed repeat families creates k-mers with counts in
+    # the thousands next to ordinary ones: device generator == oracle generator byte for byte, and the count (which
+    # streams the heavy sub-buckets through the hash tables) == the oracle's
+    from meryl_amd import capi
+    args = dict(read_len=150, sub_rate_ppm=5000, n_rate_ppm=100, repeat_ppm=100_000, repeat_unit=300, repeat_families=50)
+    want = oracle_lib.synth_reads(5, 3_000_000, 7, 60_000, **args)
+    got = ops.dev_synth_reads(5, 3_000_000, 7, 60_000, **args)
+    assert np.array_equal(got.cpu().numpy(), want)
+    k = 21
+    cfg = capi.configure(k, want.size, 1 << 30)
+    with ops.Session(cfg) as s:
+        s.push_bases_device(got)
+        s.count()
+        klo, counts, _ = s.result()
+    _, wlo, wcn, _ = oracle_lib.count_brute(want.tobytes(), k)
+    assert np.array_equal(klo, wlo) and np.array_equal(counts, wcn)
+    assert counts.max() > 500                                  # the top family really is heavy
