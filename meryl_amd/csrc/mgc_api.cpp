@@ -896,24 +896,28 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (h_counts[b] == 0) continue;
       const uint32_t low = rem_bits - top_bits[b];
       void *seg = X + kbytes * h_starts[b];
-      // a sub-bucket above the LDS capacity (a k-mer repeated thousands of times, a dense corner of the key space) can
-      // still be counted by the hash tables if its DISTINCT k-mers fit: asked before anything touches the file
-      bool stream_huge = false;
-      if (h_maxsub[b] > cap && mgc::finish_can_stream(kw, low)) {
+      // sub-buckets above the persistent kernels' capacity (a k-mer repeated thousands of times, a dense corner of the key
+      // space) are streamed through a large hash table, in several suffix ranges if their distinct k-mers do not fit at once.
+      // Only a gigantic one is asked about first (one pass must do), before anything touches the file
+      bool stream = mgc::finish_can_stream(kw, low) && h_nlarge[b] > 0;
+      if (stream && h_maxsub[b] > mgc::finish_stream_max()) {
         uint32_t h_fail[3] = {0, 0, 0};                 // [0] answer, [2] most distinct suffixes met (diagnostics)
         HIP_TRY(s, hipMemsetAsync(d_err + 4, 0, 12, st));
         HIP_TRY(s, mgc::launch_finish_probe(seg, kw, d_substart + sbase[b], low, h_nlarge[b], d_large + gbase[b], d_err + 4, st));
         HIP_TRY(s, hipMemcpyAsync(h_fail, d_err + 4, 12, hipMemcpyDeviceToHost, st));
         HIP_TRY(s, hipStreamSynchronize(st));
-        stream_huge = (h_fail[0] == 0);
+        stream = (h_fail[0] == 0);
         if (getenv("MGC_FINISH_TRACE"))
           fprintf(stderr, "[finish] bucket %u: largest sub-bucket %llu > %llu, up to %u distinct in one: %s\n", b,
-                  (unsigned long long)h_maxsub[b], (unsigned long long)cap, h_fail[2],
-                  stream_huge ? "streamed through the hash tables" : "too many distinct: stable-sort fallback");
+                  (unsigned long long)h_maxsub[b], (unsigned long long)mgc::finish_stream_max(), h_fail[2],
+                  stream ? "streamed through the hash tables" : "too many distinct: stable-sort fallback");
+      } else if (getenv("MGC_FINISH_TRACE") && h_maxsub[b] > cap) {
+        fprintf(stderr, "[finish] bucket %u: largest sub-bucket %llu > %llu: %s\n", b, (unsigned long long)h_maxsub[b],
+                (unsigned long long)cap, stream ? "streamed through the hash tables" : "stable-sort fallback");
       }
-      if (h_maxsub[b] <= cap || stream_huge) {
+      if (h_maxsub[b] <= cap || stream) {
         HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_nlarge[b],
-                                           d_large + gbase[b], d_cnt_tmp + h_starts[b], d_group + gbase[b], stream_huge, d_err + 2,
+                                           d_large + gbase[b], d_cnt_tmp + h_starts[b], d_group + gbase[b], stream, (void *)Y,
                                            // the list pays off only when a good part of the 2^t grid is empty
                                            (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b])) ? d_nz + gbase[b] : nullptr,
                                            d_nzcount + b, st));
@@ -976,7 +980,6 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   if (s->profiling) (void)hipEventRecord(ev_all[1], st);
   HIP_TRY(s, hipStreamSynchronize(st));
   if (h_err[0]) { set_err(&s->err, "radix sort look-back timed out"); return MGC_ETIMEOUT; }
-  if (h_err[2]) { set_err(&s->err, "internal: a streamed sub-bucket overflowed its hash table after a successful probe"); return MGC_EHIP; }
 
   if (s->profiling) {
     float ms = 0;

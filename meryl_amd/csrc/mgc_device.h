@@ -77,11 +77,12 @@ hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_
                                    hipStream_t st);
 // sub-buckets above finish_capacity_for(): can they be streamed through the hash-count tables (distinct suffixes fit)?
 bool       finish_can_stream(uint32_t key_words, uint32_t low_bits);
+uint64_t   finish_stream_max();     // sub-buckets up to this many keys are streamed without asking the probe
 hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint32_t low_bits,
                                uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_file_fail /*set to 1: no*/, hipStream_t st);
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
-                              bool stream_huge, uint32_t *d_huge_fail /*set to 1 on an internal overflow*/,
+                              bool stream /*large list -> streaming hash-count*/, void *d_alt /*room for the file's keys*/,
                               const uint32_t *d_nonempty_list, const uint64_t *d_nonempty_count /*the hash kernels visit only these;
                               d_group_distinct must be zero for the others*/, hipStream_t st);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);

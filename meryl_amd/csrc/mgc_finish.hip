@@ -400,7 +400,7 @@ void lds_sort_count_kernel(K *__restrict__ keys,                      // the fil
 template <int BLOCK, int CAP, int SLOTS, bool DBG, bool LIST>
 __global__ __launch_bounds__(BLOCK, 5)
 void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
-                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 huge_min, u32 *__restrict__ huge_fail,
+                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
                        const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u64 *__restrict__ dbg) {
   // Inside a sub-bucket the keys differ only in their low `low_bits` (< 32) bits: the table holds
   // 32-bit suffixes (half the LDS, 32-bit CAS and compares); the common prefix is added back on output.
@@ -414,7 +414,6 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
   __shared__ __attribute__((aligned(16))) u32 dk[CAP + 16];
   __shared__ u32 dc[CAP];
   __shared__ u32 s_tmp[BLOCK / 64 + 1];
-  __shared__ u32 s_st[2];                              // streamed sub-bucket: distinct so far, overflow
   const u32 tid = threadIdx.x;
   const u64 G = gridDim.x;
   const u64 low_mask = (1ull << low_bits) - 1ull;
@@ -458,8 +457,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
     if (n64 == 0) {
       if (tid == 0) group_distinct[g] = 0;
     } else if (n64 <= max_size) {                      // larger ones: other launches take them
-      constexpr bool huge = false;
-      const u32 n = huge ? (u32)CAP : (u32)n64;
+      const u32 n = (u32)n64;
       const u64 prefix = file_base | (g << low_bits);
       u32 kk[KPT], hh[KPT];
       u32 pending = 0;
@@ -467,15 +465,13 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
       for (int j = 0; j < KPT; j++) {
         const u32 idx = (u32)j * BLOCK + tid;
         u32 raw = kcur[j];
-        if (huge) raw = (idx < n64) ? reinterpret_cast<const u32 *>(keys + a + idx)[0] : 0u;   // first round of a streamed sub-bucket
         kk[j] = raw & (u32)low_mask;
-        if (idx < n && (u64)idx < n64) pending |= 1u << j;
+        if (idx < n) pending |= 1u << j;
       }
       // table sized to the sub-bucket (load factor <= 0.8 even if every key is distinct): the clear and the
       // compaction below walk the table, so an oversized one costs more than the longer probes of a full one
       u32 slots = 256;
       while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
-      if (huge) slots = (u32)SLOTS;
       const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
       {
         uint4 *tk4 = reinterpret_cast<uint4 *>(tk), *tc4 = reinterpret_cast<uint4 *>(tc);
@@ -483,16 +479,15 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
           tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
           tc4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
-        if (tid < 2) s_st[tid] = 0u;
       }
       __syncthreads();
       HC_STAMP(0);
 
-      for (u64 base = 0;;) {
+      {
 #pragma unroll
         for (int j = 0; j < KPT; j++) hh[j] = (kk[j] * 0x9E3779B1u) >> sshift;
         // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
-        while (pending && !(huge && __hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+        while (pending) {
 #pragma unroll
           for (int j = 0; j < KPT; j++) {
             if ((pending >> j) & 1u) {
@@ -500,28 +495,15 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
               if (old == EMPTY || old == kk[j]) {
                 atomicAdd(&tc[hh[j]], 1u);
                 pending &= ~(1u << j);
-                if (huge && old == EMPTY && atomicAdd(&s_st[0], 1u) >= (u32)CAP) s_st[1] = 1u;   // more distinct than dk/dc hold
               }
               else hh[j] = (hh[j] + 1) & smask;
             }
           }
         }
-        base += (u64)CAP;
-        if (!huge || base >= n64 || __hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-        pending = 0;                                   // next round of a streamed sub-bucket
-#pragma unroll
-        for (int j = 0; j < KPT; j++) {
-          const u64 idx = base + (u64)j * BLOCK + tid;
-          kk[j] = (idx < n64) ? (reinterpret_cast<const u32 *>(keys + a + idx)[0] & (u32)low_mask) : 0u;
-          if (idx < n64) pending |= 1u << j;
-        }
       }
       __syncthreads();
       HC_STAMP(1);
-      if (huge && s_st[1]) {                           // cannot happen after a successful probe: reported, not silently dropped
-        if (tid == 0) { group_distinct[g] = 0; atomicExch(huge_fail, 1u); }
-        __syncthreads();
-      } else {
+      {
 
       // compact the occupied slots (any order)
       u32 occ = 0;
@@ -581,7 +563,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 template <int BLOCK, int CAP, int SLOTS, bool LIST>
 __global__ __launch_bounds__(BLOCK, 3)
 void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
-                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 huge_min, u32 *__restrict__ huge_fail,
+                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
                        const u32 *__restrict__ nz, const u64 *__restrict__ nz_count) {
   constexpr bool DBG = false;
   u64 *dbg = nullptr;
@@ -597,7 +579,6 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
   __shared__ __attribute__((aligned(16))) u64 dk[CAP + 16];
   __shared__ u32 dc[CAP];
   __shared__ u32 s_tmp[BLOCK / 64 + 1];
-  __shared__ u32 s_st[2];                              // streamed sub-bucket: distinct so far, overflow
   const u32 tid = threadIdx.x;
   const u64 G = gridDim.x;
   const u64 low_mask = (1ull << low_bits) - 1ull;
@@ -641,8 +622,7 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
     if (n64 == 0) {
       if (tid == 0) group_distinct[g] = 0;
     } else if (n64 <= max_size) {                      // larger ones: other launches take them
-      constexpr bool huge = false;
-      const u32 n = huge ? (u32)CAP : (u32)n64;
+      const u32 n = (u32)n64;
       const u64 prefix = file_base | (g << low_bits);
       u64 kk[KPT];
       u32 hh[KPT];
@@ -651,28 +631,25 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
       for (int j = 0; j < KPT; j++) {
         const u32 idx = (u32)j * BLOCK + tid;
         u64 raw = kcur[j];
-        if (huge) raw = (idx < n64) ? keys[a + idx] : 0ull;   // first round of a streamed sub-bucket
         kk[j] = raw & low_mask;
-        if (idx < n && (u64)idx < n64) pending |= 1u << j;
+        if (idx < n) pending |= 1u << j;
       }
       // table sized to the sub-bucket (load factor <= 0.8 even if every key is distinct): the clear and the
       // compaction below walk the table, so an oversized one costs more than the longer probes of a full one
       u32 slots = 256;
       while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
-      if (huge) slots = (u32)SLOTS;
       const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
       {
         for (u32 i = tid; i < slots; i += BLOCK) { tk[i] = EMPTY; tc[i] = 0u; }
-        if (tid < 2) s_st[tid] = 0u;
       }
       __syncthreads();
       HC_STAMP(0);
 
-      for (u64 base = 0;;) {
+      {
 #pragma unroll
         for (int j = 0; j < KPT; j++) hh[j] = (u32)((kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
         // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
-        while (pending && !(huge && __hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+        while (pending) {
 #pragma unroll
           for (int j = 0; j < KPT; j++) {
             if ((pending >> j) & 1u) {
@@ -680,28 +657,15 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
               if (old == EMPTY || old == kk[j]) {
                 atomicAdd(&tc[hh[j]], 1u);
                 pending &= ~(1u << j);
-                if (huge && old == EMPTY && atomicAdd(&s_st[0], 1u) >= (u32)CAP) s_st[1] = 1u;   // more distinct than dk/dc hold
               }
               else hh[j] = (hh[j] + 1) & smask;
             }
           }
         }
-        base += (u64)CAP;
-        if (!huge || base >= n64 || __hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-        pending = 0;                                   // next round of a streamed sub-bucket
-#pragma unroll
-        for (int j = 0; j < KPT; j++) {
-          const u64 idx = base + (u64)j * BLOCK + tid;
-          kk[j] = (idx < n64) ? (keys[a + idx] & low_mask) : 0ull;
-          if (idx < n64) pending |= 1u << j;
-        }
       }
       __syncthreads();
       HC_STAMP(1);
-      if (huge && s_st[1]) {                           // cannot happen after a successful probe: reported, not silently dropped
-        if (tid == 0) { group_distinct[g] = 0; atomicExch(huge_fail, 1u); }
-        __syncthreads();
-      } else {
+      {
       // compact the occupied slots (any order)
       u32 occ = 0;
 #pragma unroll
@@ -909,16 +873,22 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
   }
 }
 
-// Hash-count of the sub-buckets that hold more keys than any LDS kernel can (a k-mer present thousands of times with
-// its error variants; one workgroup per entry of the large-sub-bucket list, entries at or below huge_min are somebody
-// else's).  The table stores DISTINCT suffixes only, so the keys are streamed through it in rounds of BLOCK*KPT; up to
-// CAP distinct ones fit (checked beforehand by hash_probe_kernel with the same geometry).  Then the same compaction,
-// all-pairs rank and in-place output as hash_count_kernel.
+// Hash-count of the sub-buckets above the persistent kernels' capacity (a k-mer present thousands of times with its error
+// variants, a dense corner of the key space): one 1024-thread workgroup per entry of the large-sub-bucket list, entries at
+// or below huge_min are somebody else's.  The table stores DISTINCT suffixes only, so the keys are streamed through it in
+// rounds of BLOCK*KPT and any number of keys fits as long as at most CAP of them are distinct -- then one pass, the same
+// compaction and all-pairs rank as hash_count_kernel, and the output goes in place.
+// More than CAP distinct suffixes: the sub-bucket is done in several passes over ascending suffix RANGES [lo, hi], each
+// pass streaming all keys and inserting only those of its range; the ranges come out in key order, so their outputs
+// concatenate.  A range that overflows the table is shrunk by the factor the fill-up point suggests (the keys of a
+// sub-bucket are in input order, so the part streamed so far is a fair sample) and retried; a pass that leaves the table
+// less than half full widens the next range.  Later passes still need the keys, so multi-pass output goes to alt[] (the
+// sort's second buffer, free at this point) and is copied back at the end.
 template <typename S, int BLOCK, int CAP, int SLOTS>
 __global__ __launch_bounds__(BLOCK)
 void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
                             u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                            u32 *__restrict__ overflow) {
+                            u64 *__restrict__ alt) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
   constexpr int KPT = 4, SPT = SLOTS / BLOCK;
   const S EMPTY = ~(S)0;
@@ -928,7 +898,7 @@ void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ star
   S   *dk = reinterpret_cast<S *>(hsm + (sizeof(S) + 4) * SLOTS);         // [CAP]
   u32 *dc = reinterpret_cast<u32 *>(hsm + (sizeof(S) + 4) * SLOTS + sizeof(S) * CAP);   // [CAP]
   __shared__ u32 s_tmp[BLOCK / 64 + 1];
-  __shared__ u32 s_st[2];
+  __shared__ u32 s_st[3];                              // distinct in this pass, overflow, round of the overflow
   const u32 tid = threadIdx.x;
   const u64 g = list[blockIdx.x];
   const u64 a = starts[g], n64 = starts[g + 1] - a;
@@ -936,62 +906,119 @@ void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ star
   const u64 low_mask = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
   const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);
   const u64 prefix = ((keys[0] >> group_shift) << group_shift) | (g << low_bits);
-  for (u32 i = tid; i < (u32)SLOTS; i += BLOCK) { tk[i] = EMPTY; tc[i] = 0u; }
-  if (tid < 2) s_st[tid] = 0u;
-  __syncthreads();
   constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
   u64 *gk = keys + a;
-  for (u64 base = 0; base < n64; base += (u64)BLOCK * KPT) {
-    S   kk[KPT];
-    u32 hh[KPT], pending = 0;
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      const u64 idx = base + (u64)j * BLOCK + tid;
-      kk[j] = (idx < n64) ? (S)(gk[idx] & low_mask) : (S)0;
-      hh[j] = (u32)(((u64)kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
-      if (idx < n64) pending |= 1u << j;
-    }
-    while (pending && !__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+  const u64 rounds = (n64 + (u64)BLOCK * KPT - 1) / ((u64)BLOCK * KPT);
+  u64 lo = 0, hi = low_mask;                           // suffix range of this pass, inclusive
+  u64 out = 0;                                         // distinct k-mers written by the passes before
+  bool in_place = false;
+  for (;;) {
+    for (u32 i = tid; i < (u32)SLOTS; i += BLOCK) { tk[i] = EMPTY; tc[i] = 0u; }
+    if (tid < 3) s_st[tid] = 0u;
+    __syncthreads();
+    const u64 span = hi - lo;
+    for (u64 base = 0, rd = 0; base < n64; base += (u64)BLOCK * KPT, rd++) {
+      S   kk[KPT];
+      u32 hh[KPT], pending = 0;
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
-        if ((pending >> j) & 1u) {
-          const S old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
-          if (old == EMPTY || old == kk[j]) {
-            atomicAdd(&tc[hh[j]], 1u);
-            pending &= ~(1u << j);
-            if (old == EMPTY && atomicAdd(&s_st[0], 1u) >= (u32)CAP) s_st[1] = 1u;
+        const u64 idx = base + (u64)j * BLOCK + tid;
+        const u64 sfx = (idx < n64) ? (gk[idx] & low_mask) : 0ull;
+        kk[j] = (S)sfx;
+        hh[j] = (u32)((sfx * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
+        if (idx < n64 && sfx - lo <= span) pending |= 1u << j;
+      }
+      // a heavy k-mer fills whole waves with one suffix, and LDS atomics on one address serialize: the lanes that hold the
+      // first lane's suffix are counted with one add
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const bool act = (pending >> j) & 1u;
+        const u64 am = __ballot(act);
+        if (am == 0) continue;                         // wave-uniform
+        const int leader = __builtin_ctzll(am);
+        const S k0 = (S)__shfl((unsigned long long)kk[j], leader);
+        const u64 same = __ballot(act && kk[j] == k0);
+        const u32 cnt = (u32)__popcll(same);
+        if (cnt < 8) continue;                         // not worth the detour (wave-uniform)
+        if ((int)lane_id() == leader) {
+          u32 h = hh[j];
+          while (!__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            const S old = atomicCAS(&tk[h], EMPTY, k0);
+            if (old == EMPTY || old == k0) {
+              atomicAdd(&tc[h], cnt);
+              if (old == EMPTY && atomicAdd(&s_st[0], 1u) >= (u32)CAP) { s_st[2] = (u32)rd; s_st[1] = 1u; }
+              break;
+            }
+            h = (h + 1) & smask;
           }
-          else hh[j] = (hh[j] + 1) & smask;
+        }
+        if ((same >> lane_id()) & 1ull) pending &= ~(1u << j);
+      }
+      while (pending && !__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if ((pending >> j) & 1u) {
+            const S old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
+            if (old == EMPTY || old == kk[j]) {
+              atomicAdd(&tc[hh[j]], 1u);
+              pending &= ~(1u << j);
+              if (old == EMPTY && atomicAdd(&s_st[0], 1u) >= (u32)CAP) { s_st[2] = (u32)rd; s_st[1] = 1u; }
+            }
+            else hh[j] = (hh[j] + 1) & smask;
+          }
         }
       }
+      if (__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
     }
-    if (__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-  }
-  __syncthreads();
-  if (s_st[1]) {                                       // cannot happen after a successful probe: reported, not dropped
-    if (tid == 0) { group_distinct[g] = 0; atomicExch(overflow, 1u); }
-    return;
-  }
-  u32 occ = 0;
+    __syncthreads();
+    const u32 overflowed = s_st[1], at_round = s_st[2];
+    if (overflowed) {
+      // the table filled up after at_round+1 of `rounds` rounds: a range rounds/(at_round+1) times narrower would just
+      // fit, one more halving leaves room.  A one-suffix range cannot overflow, so this terminates.
+      u32 sh = 1;
+      while ((rounds >> sh) >= (u64)at_round + 1 && sh < 62) sh++;
+      hi = lo + (span >> sh);
+      __syncthreads();                                 // s_st is cleared at the top
+      continue;
+    }
+    u32 occ = 0;
 #pragma unroll
-  for (int j = 0; j < SPT; j++) occ |= (tc[(u32)j * BLOCK + tid] != 0u ? 1u : 0u) << j;
-  u32 D;
-  u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+    for (int j = 0; j < SPT; j++) occ |= (tc[(u32)j * BLOCK + tid] != 0u ? 1u : 0u) << j;
+    u32 D;
+    u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
 #pragma unroll
-  for (int j = 0; j < SPT; j++)
-    if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
-  __syncthreads();
-  for (u32 i = tid; i < D; i += BLOCK) {
-    const S ki = dk[i];
-    u32 r0 = 0, r1 = 0;
-    u32 j = 0;
-    for (; j + 2 <= D; j += 2) { r0 += (dk[j] < ki) ? 1u : 0u; r1 += (dk[j + 1] < ki) ? 1u : 0u; }
-    if (j < D) r0 += (dk[j] < ki) ? 1u : 0u;
-    const u32 r = r0 + r1;
-    gk[r] = prefix | (u64)ki;                          // in place: every key of the sub-bucket went through the table
-    cnt_tmp[a + r] = dc[i];
+    for (int j = 0; j < SPT; j++)
+      if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
+    __syncthreads();
+    // one pass over everything: every key of the sub-bucket went through the table, the output can go in place
+    in_place = (lo == 0 && hi == low_mask);
+    u64 *dst = in_place ? gk : alt + a;
+    for (u32 i = tid; i < D; i += BLOCK) {
+      const S ki = dk[i];
+      u32 r0 = 0, r1 = 0;
+      u32 j = 0;
+      for (; j + 2 <= D; j += 2) { r0 += (dk[j] < ki) ? 1u : 0u; r1 += (dk[j + 1] < ki) ? 1u : 0u; }
+      if (j < D) r0 += (dk[j] < ki) ? 1u : 0u;
+      const u64 r = out + r0 + r1;
+      dst[r] = prefix | (u64)ki;
+      cnt_tmp[a + r] = dc[i];
+    }
+    out += D;
+    if (hi == low_mask) break;
+    // next range: as wide again, wider if this one left the table mostly empty
+    u32 f = 0;
+    while (f < 4 && ((u64)(D ? D : 1u) << (f + 1)) <= (u64)CAP) f++;
+    lo = hi + 1;
+    const u64 room = low_mask - lo;                    // the widest span still possible
+    const u64 want = (span >= (room >> f)) ? room : (((span + 1) << f) - 1);
+    hi = (want >= room) ? low_mask : lo + want;
+    __syncthreads();                                   // dk/dc and s_st are reused
   }
-  if (tid == 0) group_distinct[g] = D;
+  if (!in_place) {
+    __syncthreads();                                   // all passes have read the keys; alt[] was written by this workgroup
+    for (u64 i = tid; i < out; i += BLOCK) gk[i] = alt[a + i];
+  }
+  if (tid == 0) group_distinct[g] = out;
 }
 
 // Would the distinct suffixes of every sub-bucket above huge_min fit the hash-count tables?  One workgroup per entry of the
@@ -1143,27 +1170,33 @@ bool finish_can_stream(uint32_t key_words, uint32_t low_bits) {
   return on && key_words == 1 && finish_uses_hash(key_words, low_bits);
 }
 
+// sub-buckets up to this many keys are streamed whatever they hold (in as many suffix ranges as it takes); a larger one
+// only if the probe finds that one pass will do -- a dense sub-bucket of that size is the full sort's work
+uint64_t finish_stream_max() {
+  const char *e = getenv("MGC_STREAM_MAX");             // read per call: the tests switch it
+  return (e && *e) ? strtoull(e, nullptr, 10) : ((uint64_t)1 << 22);
+}
+
 hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint32_t low_bits,
                                uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_file_fail, hipStream_t st) {
   if (n_large == 0 || key_words != 1) return hipSuccess;
   if (low_bits < 32)
     hipLaunchKernelGGL((hash_probe_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>), dim3((uint32_t)n_large), dim3(1024), 0, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list,
-                       (u64)FIN_CAP_LARGE, low_bits, d_file_fail);
+                       (u64)finish_stream_max(), low_bits, d_file_fail);
   else
     hipLaunchKernelGGL((hash_probe_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>), dim3((uint32_t)n_large), dim3(1024), 0, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list,
-                       (u64)FIN_CAP_LARGE, low_bits, d_file_fail);
+                       (u64)finish_stream_max(), low_bits, d_file_fail);
   return hipGetLastError();
 }
 
-// stream_huge: sub-buckets above FIN_CAP_LARGE are streamed through the hash-count tables (the caller has run
-// launch_finish_probe); otherwise the file holds none (the caller checked the largest sub-bucket)
+// stream: the sub-buckets on the large list go through hash_count_huge_kernel (d_alt: room for the file's keys); otherwise
+// through the LDS sort, and the file holds none above its capacity (the caller checked the largest sub-bucket)
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
-                              bool stream_huge, uint32_t *d_huge_fail, const uint32_t *d_nz, const uint64_t *d_nz_count,
+                              bool stream, void *d_alt, const uint32_t *d_nz, const uint64_t *d_nz_count,
                               hipStream_t st) {
-  const u64 huge_min = stream_huge ? (u64)FIN_CAP_LARGE : ~0ull;
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
   if (key_words == 2 && finish_uses_hash(key_words, low_bits)) {
     static const uint32_t wgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 6u;
@@ -1194,7 +1227,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
 #define MGC_HASH_LAUNCH(KERNEL, ...)                                                                                        \
     hipLaunchKernelGGL(KERNEL, dim3(hgrid), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys),                             \
                        reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp,           \
-                       reinterpret_cast<u64 *>(d_group_distinct), huge_min, d_huge_fail, d_nz, nzc, ##__VA_ARGS__)
+                       reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, ##__VA_ARGS__)
     // the dense case runs the instantiation without the list: the kernel is VALU-bound, tests in its loops cost time
     if (low_bits >= 32) {
       if (use_list) MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, true>));
@@ -1208,8 +1241,8 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
 #undef MGC_HASH_LAUNCH
     MGC_CHECK(hipGetLastError());
     hash_dbg_report(st, ng);
-    if (stream_huge && n_large) {
-      // sub-buckets above every LDS capacity: one 1024-thread workgroup each, keys streamed through a large table
+    if (stream && n_large) {
+      // sub-buckets above the small tables: one 1024-thread workgroup each, keys streamed through a large table
       static bool hattr = false;
       constexpr size_t B32 = (size_t)(4 + 4) * HUGE_SLOTS32 + (size_t)(4 + 4) * HUGE_CAP32;
       constexpr size_t B64 = (size_t)(8 + 4) * HUGE_SLOTS64 + (size_t)(8 + 4) * HUGE_CAP64;
@@ -1223,15 +1256,18 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       if (low_bits < 32)
         hipLaunchKernelGGL((hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>), dim3((uint32_t)n_large), dim3(1024), B32, st,
                            reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           (u64)FIN_CAP_LARGE, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_huge_fail);
+                           (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                           reinterpret_cast<u64 *>(d_alt));
       else
         hipLaunchKernelGGL((hash_count_huge_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>), dim3((uint32_t)n_large), dim3(1024), B64, st,
                            reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           (u64)FIN_CAP_LARGE, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_huge_fail);
+                           (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                           reinterpret_cast<u64 *>(d_alt));
       MGC_CHECK(hipGetLastError());
+    } else {
+      MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, FIN_CAP_LARGE, d_cnt_tmp,
+                                             d_group_distinct, st, d_large_list)));
     }
-    MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, FIN_CAP_LARGE, d_cnt_tmp,
-                                           d_group_distinct, st, d_large_list)));
     return hipSuccess;
   }
   MGC_CHECK((finish_launch<u64, 256, 16>(d_keys, d_starts, ng, low_bits, 0, FIN_CAP_SMALL, d_cnt_tmp, d_group_distinct, st)));

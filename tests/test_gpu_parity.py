@@ -751,33 +751,36 @@ def test_large_input_partition_granularity(ops, oracle_lib, torch_cuda, monkeypa
     assert np.array_equal(np.asarray(info.file_instances, dtype=np.int64), inst_per_file)
 
 
-@pytest.mark.parametrize("k", [25, 31])
-def test_oversized_subbuckets_stream_or_fall_back(ops, oracle_lib, torch_cuda, k):
-    # sub-buckets above every LDS capacity: (a) 30,000 instances of 900 distinct k-mers sharing a 20-base prefix -> streamed
-    # through the hash-count tables; (b) 30,000 instances of ~25,000 distinct ones -> the probe refuses, the file takes the
-    # stable-sort fallback; (c) ordinary reads around them.  All three must come out like the oracle's.
+@pytest.mark.parametrize("stream_max", [None, 20_000])
+@pytest.mark.parametrize("k", [21, 25, 31])
+def test_oversized_subbuckets_stream_in_ranges(ops, oracle_lib, torch_cuda, monkeypatch, k, stream_max):
+    # sub-buckets above every LDS capacity, each a cluster of k-mers sharing a long prefix: (a) 30,000 instances of 900
+    # distinct k-mers -> one pass through the streaming hash table; (b) 30,000 instances of ~25,000 distinct ones and
+    # (c) 120,000 of ~60,000 -> several passes over suffix ranges, shrunk and widened as the table fills; (d) one k-mer
+    # 50,000 times (whole waves holding one suffix); (e) ordinary reads around them.  k=21 takes the 32-bit-suffix kernel,
+    # 25 and 31 the 64-bit one.  With MGC_STREAM_MAX below the cluster sizes the probe is asked first: it lets (a) and (d)
+    # through and sends the files of (b) and (c) to the stable-sort fallback.  Everything must come out like the oracle's.
     from meryl_amd import capi
+    if stream_max is not None:
+        monkeypatch.setenv("MGC_STREAM_MAX", str(stream_max))
     rng = np.random.default_rng(k)
+    plen = min(20, k - 10)
     def cluster(prefix, n_inst, n_distinct):
         tails = ["".join("ACGT"[i] for i in rng.integers(0, 4, k - len(prefix))) for _ in range(n_distinct)]
         return ".".join(prefix + tails[int(i)] for i in rng.integers(0, n_distinct, n_inst)) + "."
-    pa = "AAC" + "".join("ACGT"[i] for i in rng.integers(0, 4, 17))          # file AAC..., canonical as written (starts with A)
-    pb = "ACA" + "".join("ACGT"[i] for i in rng.integers(0, 4, 17))
+    def prefix(head):
+        return head + "".join("ACGT"[i] for i in rng.integers(0, 4, plen - 3))
     reads = oracle_lib.synth_reads(k, 40_000, 0, 3000).tobytes().decode()
-    stream = cluster(pa, 30_000, 900) + cluster(pb, 30_000, 25_000) + reads
-    cfg = capi.configure(k, len(stream), 1 << 30)
-    with ops.Session(cfg) as s:
-        s.push_bases(stream, end_of_sequence=False)
-        s.count()
-        klo, khi, counts, _ = s.result_wide()
-    whi, wlo, wcn, _ = oracle_lib.count_brute(stream, k, 1)                   # forward mode keeps the clusters where they were put
-    with ops.Session(capi.configure(k, len(stream), 1 << 30, 1)) as s:
-        s.push_bases(stream, end_of_sequence=False)
-        s.count()
-        flo, fhi, fcounts, _ = s.result_wide()
-    assert np.array_equal(flo, wlo) and np.array_equal(fcounts, wcn)
-    chi, clo, ccn, _ = oracle_lib.count_brute(stream, k, 0)
-    assert np.array_equal(klo, clo) and np.array_equal(counts, ccn)
+    stream = (cluster(prefix("AAC"), 30_000, 900) + cluster(prefix("ACA"), 30_000, 25_000) + cluster(prefix("ATT"), 120_000, 60_000)
+              + cluster(prefix("AGC"), 50_000, 1) + reads)
+    for mode in (1, 0):                                     # forward mode keeps the clusters where they were put
+        with ops.Session(capi.configure(k, len(stream), 1 << 30, mode)) as s:
+            s.push_bases(stream, end_of_sequence=False)
+            s.count()
+            klo, khi, counts, _ = s.result_wide()
+        whi, wlo, wcn, _ = oracle_lib.count_brute(stream, k, mode)
+        assert np.array_equal(klo, wlo) and np.array_equal(counts, wcn)
+    assert counts.max() >= 50_000
 
 
 def test_repeat_family_reads_generator_and_count(ops, oracle_lib, torch_cuda):
