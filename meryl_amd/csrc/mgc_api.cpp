@@ -900,7 +900,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       // space) are streamed through a large hash table, in several suffix ranges if their distinct k-mers do not fit at once.
       // Only a gigantic one is asked about first (one pass must do), before anything touches the file
       bool stream = mgc::finish_can_stream(kw, low) && h_nlarge[b] > 0;
-      if (stream && h_maxsub[b] > mgc::finish_stream_max()) {
+      if (stream && h_maxsub[b] > mgc::finish_stream_max() && kw == 2) {
+        stream = false;                                 // no probe for 16-byte keys: a sub-bucket that large takes the sort
+      } else if (stream && h_maxsub[b] > mgc::finish_stream_max()) {
         uint32_t h_fail[3] = {0, 0, 0};                 // [0] answer, [2] most distinct suffixes met (diagnostics)
         HIP_TRY(s, hipMemsetAsync(d_err + 4, 0, 12, st));
         HIP_TRY(s, mgc::launch_finish_probe(seg, kw, d_substart + sbase[b], low, h_nlarge[b], d_large + gbase[b], d_err + 4, st));

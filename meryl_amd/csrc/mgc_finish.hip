@@ -873,6 +873,86 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
   }
 }
 
+// value of v in lane `lane` (wave-uniform, e.g. taken from a ballot): v_readlane, no LDS round trip
+__device__ __forceinline__ u64 read_lane_u64(u64 v, int lane) {
+  const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, lane);
+  const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), lane);
+  return ((u64)hi << 32) | (u64)lo;
+}
+
+// In-place bitonic sort of N (a power of two) LDS records by the whole workgroup: gt(i, j) = record i is larger than record j,
+// swp(i, j) exchanges them.  The all-pairs rank is D^2 compares -- 190 us for 3000 suffixes on one CU, VALU-bound -- so
+// above BLOCK distinct suffixes the compacted list is sorted instead (log^2 N steps of N/2 compare-exchanges: ~25 us).
+template <int BLOCK, typename GT, typename SWP>
+__device__ __forceinline__ void bitonic_sort_lds(u32 N, GT gt, SWP swp) {
+  for (u32 k = 2; k <= N; k <<= 1) {
+    for (u32 j = k >> 1; j > 0; j >>= 1) {
+      for (u32 t = threadIdx.x; t < N / 2; t += BLOCK) {
+        const u32 i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1));       // t with a zero inserted at j's bit
+        const u32 i1 = i0 | j;
+        const bool up = (i0 & k) == 0;
+        if (gt(i0, i1) == up) swp(i0, i1);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// r[q] += number of keys among dk[0 .. 16*d16) below ki[q], q < ni (block-uniform).  dk is 16-byte aligned and padded to a
+// multiple of 16 keys with all-ones (never smaller).  Whole 64-byte groups, several independent broadcast LDS reads in flight
+// and every group compared against all of the thread's keys: a scalar loop of dependent LDS reads is latency-bound (measured:
+// 390 us for 3000 keys by 1024 threads against 30 us this way).
+template <int NI>
+__device__ __forceinline__ void rank_below(const u32 *dk, u32 d16, const u32 (&ki)[NI], u32 (&r)[NI], u32 ni) {
+  const uint4 *p = reinterpret_cast<const uint4 *>(dk);
+  for (u32 j = 0; j < d16; j++) {
+    const uint4 v0 = p[4 * j], v1 = p[4 * j + 1], v2 = p[4 * j + 2], v3 = p[4 * j + 3];
+#pragma unroll
+    for (int q = 0; q < NI; q++) {
+      if ((u32)q < ni) {
+        const u32 k = ki[q];
+        r[q] += (v0.x < k ? 1u : 0u) + (v0.y < k ? 1u : 0u) + (v0.z < k ? 1u : 0u) + (v0.w < k ? 1u : 0u) +
+                (v1.x < k ? 1u : 0u) + (v1.y < k ? 1u : 0u) + (v1.z < k ? 1u : 0u) + (v1.w < k ? 1u : 0u) +
+                (v2.x < k ? 1u : 0u) + (v2.y < k ? 1u : 0u) + (v2.z < k ? 1u : 0u) + (v2.w < k ? 1u : 0u) +
+                (v3.x < k ? 1u : 0u) + (v3.y < k ? 1u : 0u) + (v3.z < k ? 1u : 0u) + (v3.w < k ? 1u : 0u);
+      }
+    }
+  }
+}
+template <int NI>
+__device__ __forceinline__ void rank_below(const u64 *dk, u32 d16, const u64 (&ki)[NI], u32 (&r)[NI], u32 ni) {
+  const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(dk);
+  for (u32 j = 0; j < 2 * d16; j++) {
+    const ulonglong2 v0 = p[4 * j], v1 = p[4 * j + 1], v2 = p[4 * j + 2], v3 = p[4 * j + 3];
+#pragma unroll
+    for (int q = 0; q < NI; q++) {
+      if ((u32)q < ni) {
+        const u64 k = ki[q];
+        r[q] += (v0.x < k ? 1u : 0u) + (v0.y < k ? 1u : 0u) + (v1.x < k ? 1u : 0u) + (v1.y < k ? 1u : 0u) +
+                (v2.x < k ? 1u : 0u) + (v2.y < k ? 1u : 0u) + (v3.x < k ? 1u : 0u) + (v3.y < k ? 1u : 0u);
+      }
+    }
+  }
+}
+// 128-bit keys split into dlo/dhi (WIDE) or just dlo
+template <int NI, bool WIDE>
+__device__ __forceinline__ void rank_below128(const u64 *dlo, const u64 *dhi, u32 d16, const u64 (&kl)[NI], const u64 (&kh)[NI],
+                                              u32 (&r)[NI], u32 ni) {
+  if (!WIDE) { rank_below<NI>(dlo, d16, kl, r, ni); return; }
+  const ulonglong2 *pl = reinterpret_cast<const ulonglong2 *>(dlo), *ph = reinterpret_cast<const ulonglong2 *>(dhi);
+  for (u32 j = 0; j < 4 * d16; j++) {
+    const ulonglong2 l0 = pl[2 * j], l1 = pl[2 * j + 1], h0 = ph[2 * j], h1 = ph[2 * j + 1];
+#pragma unroll
+    for (int q = 0; q < NI; q++) {
+      if ((u32)q < ni) {
+        const u64 a = kl[q], b = kh[q];
+        r[q] += (((h0.x < b) || (h0.x == b && l0.x < a)) ? 1u : 0u) + (((h0.y < b) || (h0.y == b && l0.y < a)) ? 1u : 0u) +
+                (((h1.x < b) || (h1.x == b && l1.x < a)) ? 1u : 0u) + (((h1.y < b) || (h1.y == b && l1.y < a)) ? 1u : 0u);
+      }
+    }
+  }
+}
+
 // Hash-count of the sub-buckets above the persistent kernels' capacity (a k-mer present thousands of times with its error
 // variants, a dense corner of the key space): one 1024-thread workgroup per entry of the large-sub-bucket list, entries at
 // or below huge_min are somebody else's.  The table stores DISTINCT suffixes only, so the keys are streamed through it in
@@ -880,25 +960,28 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
 // compaction and all-pairs rank as hash_count_kernel, and the output goes in place.
 // More than CAP distinct suffixes: the sub-bucket is done in several passes over ascending suffix RANGES [lo, hi], each
 // pass streaming all keys and inserting only those of its range; the ranges come out in key order, so their outputs
-// concatenate.  A range that overflows the table is shrunk by the factor the fill-up point suggests (the keys of a
-// sub-bucket are in input order, so the part streamed so far is a fair sample) and retried; a pass that leaves the table
-// less than half full widens the next range.  Later passes still need the keys, so multi-pass output goes to alt[] (the
-// sort's second buffer, free at this point) and is copied back at the end.
+// concatenate.  Every range first reaches for all that is left; when the table overflows, the range is cut at a quantile
+// of the suffixes the table then holds (a fair sample: the keys of a sub-bucket are in input order) and retried.  Later
+// passes still need the keys, so multi-pass output goes to alt[] (the sort's second buffer, free at this point) and is
+// copied back at the end.
 template <typename S, int BLOCK, int CAP, int SLOTS>
 __global__ __launch_bounds__(BLOCK)
 void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
                             u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
                             u64 *__restrict__ alt) {
-  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && (CAP & (CAP - 1)) == 0 && SLOTS >= CAP * 2 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0,
+                "table geometry");
   constexpr int KPT = 4, SPT = SLOTS / BLOCK;
   const S EMPTY = ~(S)0;
   extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
   S   *tk = reinterpret_cast<S *>(hsm);                                   // [SLOTS]
   u32 *tc = reinterpret_cast<u32 *>(hsm + sizeof(S) * SLOTS);             // [SLOTS]
-  S   *dk = reinterpret_cast<S *>(hsm + (sizeof(S) + 4) * SLOTS);         // [CAP]
-  u32 *dc = reinterpret_cast<u32 *>(hsm + (sizeof(S) + 4) * SLOTS + sizeof(S) * CAP);   // [CAP]
+  S   *dk = reinterpret_cast<S *>(hsm + (sizeof(S) + 4) * SLOTS);         // [CAP + 16]
+  u32 *dc = reinterpret_cast<u32 *>(hsm + (sizeof(S) + 4) * SLOTS + sizeof(S) * (CAP + 16));   // [CAP]
+  constexpr int IPT = CAP / BLOCK;                     // distinct suffixes ranked per thread
   __shared__ u32 s_tmp[BLOCK / 64 + 1];
   __shared__ u32 s_st[3];                              // distinct in this pass, overflow, round of the overflow
+  __shared__ u64 s_split;
   const u32 tid = threadIdx.x;
   const u64 g = list[blockIdx.x];
   const u64 a = starts[g], n64 = starts[g + 1] - a;
@@ -917,52 +1000,62 @@ void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ star
     if (tid < 3) s_st[tid] = 0u;
     __syncthreads();
     const u64 span = hi - lo;
+    // the keys of the next round are in flight while this one goes through the table (one workgroup per CU: nothing else
+    // would hide the memory round trip)
+    u64 raw[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; j++) { const u64 idx = (u64)j * BLOCK + tid; raw[j] = (idx < n64) ? gk[idx] : 0ull; }
     for (u64 base = 0, rd = 0; base < n64; base += (u64)BLOCK * KPT, rd++) {
+      u64 nxt[KPT];
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u64 idx = base + (u64)BLOCK * KPT + (u64)j * BLOCK + tid;
+        nxt[j] = (idx < n64) ? gk[idx] : 0ull;
+      }
       S   kk[KPT];
       u32 hh[KPT], pending = 0;
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
         const u64 idx = base + (u64)j * BLOCK + tid;
-        const u64 sfx = (idx < n64) ? (gk[idx] & low_mask) : 0ull;
+        const u64 sfx = raw[j] & low_mask;
+        raw[j] = nxt[j];
         kk[j] = (S)sfx;
         hh[j] = (u32)((sfx * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
         if (idx < n64 && sfx - lo <= span) pending |= 1u << j;
       }
-      // a heavy k-mer fills whole waves with one suffix, and LDS atomics on one address serialize: the lanes that hold the
-      // first lane's suffix are counted with one add
+      // a heavy k-mer fills whole waves with one suffix, and LDS atomics on one address serialize: lanes holding the
+      // same suffix as the first lane not yet looked at become one insert of their number (a few rounds: the first lane
+      // may hold an error variant)
+      u32 w[KPT];
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
-        const bool act = (pending >> j) & 1u;
-        const u64 am = __ballot(act);
-        if (am == 0) continue;                         // wave-uniform
-        const int leader = __builtin_ctzll(am);
-        const S k0 = (S)__shfl((unsigned long long)kk[j], leader);
-        const u64 same = __ballot(act && kk[j] == k0);
-        const u32 cnt = (u32)__popcll(same);
-        if (cnt < 8) continue;                         // not worth the detour (wave-uniform)
-        if ((int)lane_id() == leader) {
-          u32 h = hh[j];
-          while (!__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-            const S old = atomicCAS(&tk[h], EMPTY, k0);
-            if (old == EMPTY || old == k0) {
-              atomicAdd(&tc[h], cnt);
-              if (old == EMPTY && atomicAdd(&s_st[0], 1u) >= (u32)CAP) { s_st[2] = (u32)rd; s_st[1] = 1u; }
-              break;
-            }
-            h = (h + 1) & smask;
-          }
+        w[j] = 1u;
+        u64 rem = __ballot((pending >> j) & 1u);
+        for (int it = 0; it < 2 && rem; it++) {        // wave-uniform
+          const int leader = __builtin_ctzll(rem);
+          const S k0 = (S)read_lane_u64((u64)kk[j], leader);
+          const u64 same = __ballot(((rem >> lane_id()) & 1ull) && kk[j] == k0);
+          if ((int)lane_id() == leader) w[j] = (u32)__popcll(same);
+          else if ((same >> lane_id()) & 1ull) pending &= ~(1u << j);
+          rem &= ~same;
+          if (__popcll(same) >= 8) break;              // that was the heavy one
         }
-        if ((same >> lane_id()) & 1ull) pending &= ~(1u << j);
       }
       while (pending && !__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        // all CASes of a trip are issued before the first answer is looked at: their LDS round trips overlap
+        S old[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          old[j] = EMPTY;
+          if ((pending >> j) & 1u) old[j] = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
+        }
 #pragma unroll
         for (int j = 0; j < KPT; j++) {
           if ((pending >> j) & 1u) {
-            const S old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
-            if (old == EMPTY || old == kk[j]) {
-              atomicAdd(&tc[hh[j]], 1u);
+            if (old[j] == EMPTY || old[j] == kk[j]) {
+              atomicAdd(&tc[hh[j]], w[j]);
               pending &= ~(1u << j);
-              if (old == EMPTY && atomicAdd(&s_st[0], 1u) >= (u32)CAP) { s_st[2] = (u32)rd; s_st[1] = 1u; }
+              if (old[j] == EMPTY && atomicAdd(&s_st[0], 1u) >= (u32)CAP) { s_st[2] = (u32)rd; s_st[1] = 1u; }
             }
             else hh[j] = (hh[j] + 1) & smask;
           }
@@ -972,50 +1065,275 @@ void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ star
     }
     __syncthreads();
     const u32 overflowed = s_st[1], at_round = s_st[2];
-    if (overflowed) {
-      // the table filled up after at_round+1 of `rounds` rounds: a range rounds/(at_round+1) times narrower would just
-      // fit, one more halving leaves room.  A one-suffix range cannot overflow, so this terminates.
-      u32 sh = 1;
-      while ((rounds >> sh) >= (u64)at_round + 1 && sh < 62) sh++;
-      hi = lo + (span >> sh);
-      __syncthreads();                                 // s_st is cleared at the top
-      continue;
-    }
     u32 occ = 0;
 #pragma unroll
     for (int j = 0; j < SPT; j++) occ |= (tc[(u32)j * BLOCK + tid] != 0u ? 1u : 0u) << j;
     u32 D;
     u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+    if (overflowed) {
+      // The table filled up after x = (at_round+1)/rounds of the stream.  Its suffixes are a fair sample of the range's
+      // distinct ones (slot order is hash order, the keys are in input order), wherever in the range they cluster -- the
+      // variants of a heavy k-mer sit within 4^p of it at every scale p, so numeric halving would take one retry per bit.
+      // New upper end = the sample's quantile below which the whole stream should bring at most 0.7 CAP distinct
+      // suffixes even if everything still to come is new.  Always below the sample's maximum, so the range shrinks.
+      const u32 Ds = D < (u32)BLOCK ? D : (u32)BLOCK;
+#pragma unroll
+      for (int j = 0; j < SPT; j++)
+        if ((occ >> j) & 1u) { if (o < (u32)BLOCK) dk[o] = tk[(u32)j * BLOCK + tid]; o++; }
+      if (tid < 16) dk[Ds + tid] = EMPTY;
+      __syncthreads();
+      u64 q = ((u64)Ds * 7u * ((u64)at_round + 1)) / (10u * rounds);
+      if (q > (u64)Ds - 2) q = (u64)Ds - 2;
+      {
+        S ks[1] = {dk[tid < Ds ? tid : 0]};
+        u32 rs[1] = {0u};
+        rank_below<1>(dk, (Ds + 15) / 16, ks, rs, 1u);
+        if (tid < Ds && rs[0] == (u32)q) s_split = (u64)ks[0];
+      }
+      __syncthreads();
+      hi = s_split;
+      __syncthreads();                                 // s_st and s_split are rewritten
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < SPT; j++)
       if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
+    if (tid < 16) dk[D + tid] = EMPTY;
     __syncthreads();
     // one pass over everything: every key of the sub-bucket went through the table, the output can go in place
     in_place = (lo == 0 && hi == low_mask);
     u64 *dst = in_place ? gk : alt + a;
-    for (u32 i = tid; i < D; i += BLOCK) {
-      const S ki = dk[i];
-      u32 r0 = 0, r1 = 0;
-      u32 j = 0;
-      for (; j + 2 <= D; j += 2) { r0 += (dk[j] < ki) ? 1u : 0u; r1 += (dk[j + 1] < ki) ? 1u : 0u; }
-      if (j < D) r0 += (dk[j] < ki) ? 1u : 0u;
-      const u64 r = out + r0 + r1;
-      dst[r] = prefix | (u64)ki;
-      cnt_tmp[a + r] = dc[i];
+    if (D > (u32)BLOCK) {
+      u32 N = 2 * BLOCK;
+      while (N < D) N <<= 1;                           // <= CAP, a power of two
+      for (u32 i = D + tid; i < N; i += BLOCK) dk[i] = EMPTY;
+      __syncthreads();
+      bitonic_sort_lds<BLOCK>(N, [&](u32 x, u32 y) { return dk[x] > dk[y]; },
+                              [&](u32 x, u32 y) { const S t = dk[x]; dk[x] = dk[y]; dk[y] = t;
+                                                  const u32 c = dc[x]; dc[x] = dc[y]; dc[y] = c; });
+      for (u32 i = tid; i < D; i += BLOCK) {
+        dst[out + i] = prefix | (u64)dk[i];
+        cnt_tmp[a + out + i] = dc[i];
+      }
+    } else {
+      S   ks[IPT];
+      u32 rs[IPT];
+#pragma unroll
+      for (int q = 0; q < IPT; q++) { const u32 i = (u32)q * BLOCK + tid; ks[q] = dk[i < D ? i : 0]; rs[q] = 0u; }
+      rank_below<IPT>(dk, (D + 15) / 16, ks, rs, (D + BLOCK - 1) / BLOCK);
+#pragma unroll
+      for (int q = 0; q < IPT; q++) {
+        const u32 i = (u32)q * BLOCK + tid;
+        if (i < D) {
+          const u64 r = out + rs[q];
+          dst[r] = prefix | (u64)ks[q];
+          cnt_tmp[a + r] = dc[i];
+        }
+      }
     }
     out += D;
     if (hi == low_mask) break;
-    // next range: as wide again, wider if this one left the table mostly empty
-    u32 f = 0;
-    while (f < 4 && ((u64)(D ? D : 1u) << (f + 1)) <= (u64)CAP) f++;
-    lo = hi + 1;
-    const u64 room = low_mask - lo;                    // the widest span still possible
-    const u64 want = (span >= (room >> f)) ? room : (((span + 1) << f) - 1);
-    hi = (want >= room) ? low_mask : lo + want;
+    lo = hi + 1;                                       // next: everything that is left; an overflow will say where to cut
+    hi = low_mask;
     __syncthreads();                                   // dk/dc and s_st are reused
   }
   if (!in_place) {
     __syncthreads();                                   // all passes have read the keys; alt[] was written by this workgroup
+    for (u64 i = tid; i < out; i += BLOCK) gk[i] = alt[a + i];
+  }
+  if (tid == 0) group_distinct[g] = out;
+}
+
+// The same for 16-byte keys (k >= 33): slots are claimed through their count word as in hash_count128_kernel, lanes of a
+// wave that hold the first active lane's suffix are merged into one weighted insert, ranges are 128-bit.
+template <int BLOCK, int CAP, int SLOTS, bool WIDE>
+__global__ __launch_bounds__(BLOCK)
+void hash_count128_huge_kernel(K128 *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
+                               u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
+                               K128 *__restrict__ alt) {
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS >= CAP * 2 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
+  constexpr int KPT = 2, SPT = SLOTS / BLOCK;
+  constexpr u32 LOCK = 0xFFFFFFFFu;
+  extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+  u64 *tlo = reinterpret_cast<u64 *>(hsm);                                 // [SLOTS]
+  u64 *thi = tlo + SLOTS;                                                  // [WIDE ? SLOTS : 0]
+  u64 *dlo = thi + (WIDE ? SLOTS : 0);                                     // [CAP + 16]
+  u64 *dhi = dlo + (CAP + 16);                                             // [WIDE ? CAP + 16 : 0]
+  u32 *tc  = reinterpret_cast<u32 *>(dhi + (WIDE ? CAP + 16 : 0));         // [SLOTS]
+  constexpr int IPT = CAP / BLOCK;
+  u32 *dc  = tc + SLOTS;                                                   // [CAP]
+  __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  __shared__ u32 s_st[3];                              // distinct in this pass, overflow, round of the overflow
+  __shared__ u64 s_split[2];
+  using KO = KeyOps<K128>;
+  const u32 tid = threadIdx.x;
+  const u64 g = list[blockIdx.x];
+  const u64 a = starts[g], n64 = starts[g + 1] - a;
+  if (n64 <= huge_min) return;
+  const u128 low_mask = (low_bits >= 128) ? ~(u128)0 : (((u128)1 << low_bits) - 1);
+  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);
+  const u128 file_base = (group_shift >= 128) ? (u128)0 : ((KO::v(keys[0]) >> group_shift) << group_shift);
+  const u128 prefix = file_base | ((u128)g << low_bits);
+  constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
+  K128 *gk = keys + a;
+  const u64 rounds = (n64 + (u64)BLOCK * KPT - 1) / ((u64)BLOCK * KPT);
+  u128 lo = 0, hi = low_mask;                          // suffix range of this pass, inclusive
+  u64 out = 0;
+  bool in_place = false;
+  for (;;) {
+    for (u32 i = tid; i < (u32)SLOTS; i += BLOCK) tc[i] = 0u;
+    if (tid < 3) s_st[tid] = 0u;
+    __syncthreads();
+    const u128 span = hi - lo;
+    K128 raw[KPT];                                     // next round's keys in flight while this one goes through the table
+#pragma unroll
+    for (int j = 0; j < KPT; j++) { const u64 idx = (u64)j * BLOCK + tid; if (idx < n64) raw[j] = gk[idx]; else raw[j] = KO::zero(); }
+    for (u64 base = 0, rd = 0; base < n64; base += (u64)BLOCK * KPT, rd++) {
+      K128 nxt[KPT];
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u64 idx = base + (u64)BLOCK * KPT + (u64)j * BLOCK + tid;
+        if (idx < n64) nxt[j] = gk[idx]; else nxt[j] = KO::zero();
+      }
+      u64 klo[KPT], khi[KPT];
+      u32 hh[KPT], w[KPT], pending = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u64 idx = base + (u64)j * BLOCK + tid;
+        const u128 sfx = KO::v(raw[j]) & low_mask;
+        raw[j] = nxt[j];
+        klo[j] = (u64)sfx; khi[j] = (u64)(sfx >> 64);
+        const u64 mix = (klo[j] ^ (khi[j] * 0xD6E8FEB86659FD93ull)) * 0x9E3779B97F4A7C15ull;
+        hh[j] = (u32)(mix >> 32) >> sshift;
+        w[j] = 1u;
+        if (idx < n64 && sfx - lo <= span) pending |= 1u << j;
+      }
+      // a heavy k-mer fills whole waves with one suffix: the lanes holding the first active lane's suffix become one
+      // insert of their number
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        u64 rem = __ballot((pending >> j) & 1u);
+        for (int it = 0; it < 2 && rem; it++) {        // wave-uniform; a second try: the first lane may hold an error variant
+          const int leader = __builtin_ctzll(rem);
+          const u64 l0 = read_lane_u64(klo[j], leader), h0 = read_lane_u64(khi[j], leader);
+          const u64 same = __ballot(((rem >> lane_id()) & 1ull) && klo[j] == l0 && khi[j] == h0);
+          if ((int)lane_id() == leader) w[j] = (u32)__popcll(same);
+          else if ((same >> lane_id()) & 1ull) pending &= ~(1u << j);
+          rem &= ~same;
+          if (__popcll(same) >= 8) break;              // that was the heavy one
+        }
+      }
+      while (pending && !__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if ((pending >> j) & 1u) {
+            const u32 h = hh[j];
+            const u32 old = atomicCAS(&tc[h], 0u, LOCK);
+            if (old == 0u) {                           // the slot is ours: fill it, then publish it with its count
+              tlo[h] = klo[j];
+              if (WIDE) thi[h] = khi[j];
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+              __hip_atomic_store(&tc[h], w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              pending &= ~(1u << j);
+              if (atomicAdd(&s_st[0], 1u) >= (u32)CAP) { s_st[2] = (u32)rd; s_st[1] = 1u; }
+            } else if (old != LOCK) {                  // valid: same suffix -> count it, another one -> probe on
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              const bool same = (tlo[h] == klo[j]) && (!WIDE || thi[h] == khi[j]);
+              if (same) { atomicAdd(&tc[h], w[j]); pending &= ~(1u << j); }
+              else hh[j] = (h + 1) & smask;
+            }                                          // LOCK: somebody is writing this slot; look again next round
+          }
+        }
+      }
+      if (__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+    }
+    __syncthreads();
+    const u32 overflowed = s_st[1], at_round = s_st[2];
+    u32 occ = 0;
+#pragma unroll
+    for (int j = 0; j < SPT; j++) occ |= (tc[(u32)j * BLOCK + tid] != 0u ? 1u : 0u) << j;
+    u32 D;
+    u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+    if (overflowed) {                                  // new upper end = a quantile of the table's suffixes (see above)
+      const u32 Ds = D < (u32)BLOCK ? D : (u32)BLOCK;
+#pragma unroll
+      for (int j = 0; j < SPT; j++) {
+        if ((occ >> j) & 1u) {
+          const u32 sl = (u32)j * BLOCK + tid;
+          if (o < (u32)BLOCK) { dlo[o] = tlo[sl]; if (WIDE) dhi[o] = thi[sl]; }
+          o++;
+        }
+      }
+      if (tid < 16) { dlo[Ds + tid] = ~0ull; if (WIDE) dhi[Ds + tid] = ~0ull; }
+      __syncthreads();
+      u64 q = ((u64)Ds * 7u * ((u64)at_round + 1)) / (10u * rounds);
+      if (q > (u64)Ds - 2) q = (u64)Ds - 2;
+      {
+        const u32 i = tid < Ds ? tid : 0;
+        u64 kl[1] = {dlo[i]}, kh[1] = {WIDE ? dhi[i] : 0ull};
+        u32 rs[1] = {0u};
+        rank_below128<1, WIDE>(dlo, dhi, (Ds + 15) / 16, kl, kh, rs, 1u);
+        if (tid < Ds && rs[0] == (u32)q) { s_split[0] = kl[0]; s_split[1] = kh[0]; }
+      }
+      __syncthreads();
+      hi = ((u128)s_split[1] << 64) | (u128)s_split[0];
+      __syncthreads();
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+      if ((occ >> j) & 1u) {
+        const u32 sl = (u32)j * BLOCK + tid;
+        dlo[o] = tlo[sl];
+        if (WIDE) dhi[o] = thi[sl];
+        dc[o] = tc[sl];
+        o++;
+      }
+    }
+    if (tid < 16) { dlo[D + tid] = ~0ull; if (WIDE) dhi[D + tid] = ~0ull; }
+    __syncthreads();
+    in_place = (lo == 0 && hi == low_mask);
+    K128 *dst = in_place ? gk : alt + a;
+    if (D > (u32)BLOCK) {
+      u32 N = 2 * BLOCK;
+      while (N < D) N <<= 1;
+      for (u32 i = D + tid; i < N; i += BLOCK) { dlo[i] = ~0ull; if (WIDE) dhi[i] = ~0ull; }
+      __syncthreads();
+      bitonic_sort_lds<BLOCK>(N, [&](u32 x, u32 y) { return WIDE ? (dhi[x] > dhi[y] || (dhi[x] == dhi[y] && dlo[x] > dlo[y]))
+                                                                 : (dlo[x] > dlo[y]); },
+                              [&](u32 x, u32 y) { const u64 t = dlo[x]; dlo[x] = dlo[y]; dlo[y] = t;
+                                                  if (WIDE) { const u64 h = dhi[x]; dhi[x] = dhi[y]; dhi[y] = h; }
+                                                  const u32 c = dc[x]; dc[x] = dc[y]; dc[y] = c; });
+      for (u32 i = tid; i < D; i += BLOCK) {
+        dst[out + i] = KO::mk(prefix | ((u128)(WIDE ? dhi[i] : 0ull) << 64) | (u128)dlo[i]);
+        cnt_tmp[a + out + i] = dc[i];
+      }
+    } else {
+      u64 kl[IPT], kh[IPT];
+      u32 rs[IPT];
+#pragma unroll
+      for (int q = 0; q < IPT; q++) {
+        const u32 i = (u32)q * BLOCK + tid, ii = i < D ? i : 0;
+        kl[q] = dlo[ii]; kh[q] = WIDE ? dhi[ii] : 0ull; rs[q] = 0u;
+      }
+      rank_below128<IPT, WIDE>(dlo, dhi, (D + 15) / 16, kl, kh, rs, (D + BLOCK - 1) / BLOCK);
+#pragma unroll
+      for (int q = 0; q < IPT; q++) {
+        const u32 i = (u32)q * BLOCK + tid;
+        if (i < D) {
+          dst[out + rs[q]] = KO::mk(prefix | ((u128)kh[q] << 64) | (u128)kl[q]);
+          cnt_tmp[a + out + rs[q]] = dc[i];
+        }
+      }
+    }
+    out += D;
+    if (hi == low_mask) break;
+    lo = hi + 1;
+    hi = low_mask;
+    __syncthreads();
+  }
+  if (!in_place) {
+    __syncthreads();
     for (u64 i = tid; i < out; i += BLOCK) gk[i] = alt[a + i];
   }
   if (tid == 0) group_distinct[g] = out;
@@ -1089,8 +1407,10 @@ void compact_groups_kernel(const K *__restrict__ keys, const u32 *__restrict__ c
 __global__ void store_u64_kernel(u64 *__restrict__ dst, const u64 *__restrict__ src) { *dst = *src; }
 
 constexpr u64 FIN_CAP_SMALL = 256 * 16, FIN_CAP_LARGE = 1024 * 8;   // LDS: 46 KiB and 91 KiB per workgroup
-constexpr int HUGE_CAP32 = 6144, HUGE_SLOTS32 = 8192;            // streamed sub-buckets, 32-bit suffixes: 112 KiB of LDS
-constexpr int HUGE_CAP64 = 3072, HUGE_SLOTS64 = 4096;            // 64-bit suffixes: 84 KiB
+// streamed sub-buckets: load factor <= 0.5 -- a probe step of one lane is a loop trip of its whole wave, and at 0.75 the
+// longest chain among 64 lanes made an insert round 4x as long (scripts/gpu_huge.sh)
+constexpr int HUGE_CAP32 = 4096, HUGE_SLOTS32 = 8192;            // 32-bit suffixes: 96 KiB of LDS
+constexpr int HUGE_CAP64 = 2048, HUGE_SLOTS64 = 4096;            // 64-bit suffixes: 72 KiB
 constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count kernel: 2048 slots, 28 KiB of LDS, 5 workgroups per CU
 
 static bool finish_uses_hash(uint32_t key_words, uint32_t low_bits) {
@@ -1167,7 +1487,7 @@ static void hash_dbg_report(hipStream_t st, uint64_t ng) {
 
 bool finish_can_stream(uint32_t key_words, uint32_t low_bits) {
   static const bool on = !(getenv("MGC_FINISH_STREAM") && getenv("MGC_FINISH_STREAM")[0] == '0');
-  return on && key_words == 1 && finish_uses_hash(key_words, low_bits);
+  return on && finish_uses_hash(key_words, low_bits);
 }
 
 // sub-buckets up to this many keys are streamed whatever they hold (in as many suffix ranges as it takes); a larger one
@@ -1210,7 +1530,32 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                          reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
                          d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc);
     MGC_CHECK(hipGetLastError());
-    MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, 8192, d_cnt_tmp, d_group_distinct, st, d_large_list)));
+    if (stream && n_large) {
+      constexpr int HS = 4096, HC = 2048;
+      constexpr size_t BW = (size_t)(8 + 8 + 4) * HS + (size_t)(8 + 8) * (HC + 16) + (size_t)4 * HC;
+      constexpr size_t BN = (size_t)(8 + 4) * HS + (size_t)8 * (HC + 16) + (size_t)4 * HC;
+      static bool wattr = false;
+      if (!wattr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count128_huge_kernel<1024, HC, HS, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)BW);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count128_huge_kernel<1024, HC, HS, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)BN);
+        wattr = true;
+      }
+      if (low_bits > 64)
+        hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, true>), dim3((uint32_t)n_large), dim3(1024), BW, st,
+                           reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
+                           (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                           reinterpret_cast<K128 *>(d_alt));
+      else
+        hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, false>), dim3((uint32_t)n_large), dim3(1024), BN, st,
+                           reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
+                           (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                           reinterpret_cast<K128 *>(d_alt));
+      MGC_CHECK(hipGetLastError());
+    } else {
+      MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, 8192, d_cnt_tmp, d_group_distinct, st, d_large_list)));
+    }
     return hipSuccess;
   }
   if (key_words == 2) {
@@ -1244,8 +1589,8 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     if (stream && n_large) {
       // sub-buckets above the small tables: one 1024-thread workgroup each, keys streamed through a large table
       static bool hattr = false;
-      constexpr size_t B32 = (size_t)(4 + 4) * HUGE_SLOTS32 + (size_t)(4 + 4) * HUGE_CAP32;
-      constexpr size_t B64 = (size_t)(8 + 4) * HUGE_SLOTS64 + (size_t)(8 + 4) * HUGE_CAP64;
+      constexpr size_t B32 = (size_t)(4 + 4) * HUGE_SLOTS32 + (size_t)(4 + 4) * HUGE_CAP32 + 16 * 4;
+      constexpr size_t B64 = (size_t)(8 + 4) * HUGE_SLOTS64 + (size_t)(8 + 4) * HUGE_CAP64 + 16 * 8;
       if (!hattr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)B32);

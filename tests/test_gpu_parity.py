@@ -752,14 +752,15 @@ def test_large_input_partition_granularity(ops, oracle_lib, torch_cuda, monkeypa
 
 
 @pytest.mark.parametrize("stream_max", [None, 20_000])
-@pytest.mark.parametrize("k", [21, 25, 31])
+@pytest.mark.parametrize("k", [21, 25, 31, 35, 51])
 def test_oversized_subbuckets_stream_in_ranges(ops, oracle_lib, torch_cuda, monkeypatch, k, stream_max):
     # sub-buckets above every LDS capacity, each a cluster of k-mers sharing a long prefix: (a) 30,000 instances of 900
     # distinct k-mers -> one pass through the streaming hash table; (b) 30,000 instances of ~25,000 distinct ones and
     # (c) 120,000 of ~60,000 -> several passes over suffix ranges, shrunk and widened as the table fills; (d) one k-mer
     # 50,000 times (whole waves holding one suffix); (e) ordinary reads around them.  k=21 takes the 32-bit-suffix kernel,
-    # 25 and 31 the 64-bit one.  With MGC_STREAM_MAX below the cluster sizes the probe is asked first: it lets (a) and (d)
-    # through and sends the files of (b) and (c) to the stable-sort fallback.  Everything must come out like the oracle's.
+    # 25 and 31 the 64-bit one, 35 and 51 the 16-byte-key one (suffix within 64 bits / wider).  With MGC_STREAM_MAX below the
+    # cluster sizes the probe is asked first: it lets (a) and (d) through and sends the files of (b) and (c) to the
+    # stable-sort fallback (16-byte keys: no probe, all four files fall back).  Everything must come out like the oracle's.
     from meryl_amd import capi
     if stream_max is not None:
         monkeypatch.setenv("MGC_STREAM_MAX", str(stream_max))
@@ -779,7 +780,7 @@ def test_oversized_subbuckets_stream_in_ranges(ops, oracle_lib, torch_cuda, monk
             s.count()
             klo, khi, counts, _ = s.result_wide()
         whi, wlo, wcn, _ = oracle_lib.count_brute(stream, k, mode)
-        assert np.array_equal(klo, wlo) and np.array_equal(counts, wcn)
+        assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
     assert counts.max() >= 50_000
 
 
