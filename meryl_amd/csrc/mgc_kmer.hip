@@ -76,6 +76,17 @@ __device__ __forceinline__ void kp_stage_tile(const uint8_t *__restrict__ bases,
   }
 }
 
+// Which of the thread's 16 window starts hold a complete k-mer (k <= 32): bit j = no invalid base among bases j .. j+k-1.
+// I has bit 63-p set for an invalid base p of the 48-base window; the k-wide OR is built by doubling (5 shifted ORs for
+// any k) instead of one 64-bit shift pair per start.
+__device__ __forceinline__ u32 kp_valid_mask(u64 I, u32 k) {
+  u64 X = I;
+  u32 c = 1;
+  while (2 * c <= k) { X |= X << c; c *= 2; }
+  if (c < k) X |= X << (k - c);
+  return __brev((u32)(~X >> 48) & 0xFFFFu) >> 16;                    // start j -> bit j
+}
+
 // The 16 k-mers starting at tile positions threadIdx.x*16 .. +15.  Returns the
 // bit mask of positions that hold a complete k-mer.
 __device__ __forceinline__ u32 kp_thread_kmers(const u32 *s_codes, const u32 *s_inval, u32 k, int mode,
@@ -86,7 +97,6 @@ __device__ __forceinline__ u32 kp_thread_kmers(const u32 *s_codes, const u32 *s_
   const u64 I = ((u64)s_inval[t] << 48) | ((u64)s_inval[t + 1] << 32) | ((u64)s_inval[t + 2] << 16);
   const u32 key_shift = 64 - 2 * k;
   const u32 top_shift = 2 * k - 2;
-  u32 vmask = 0;
   u64 r = 0;
 #pragma unroll
   for (int j = 0; j < KP_ITEMS; j++) {
@@ -94,15 +104,39 @@ __device__ __forceinline__ u32 kp_thread_kmers(const u32 *s_codes, const u32 *s_
     const u64 f   = top >> key_shift;
     if (j == 0) r = revcomp64(f, key_shift);
     else        r = (r >> 2) | ((((f & 3ull) ^ 2ull)) << top_shift);
-    const bool ok = (((I << j) >> (64 - k)) == 0ull);
     u64 key;
     if      (mode == 1) key = f;
     else if (mode == 2) key = r;
     else                key = (f < r) ? f : r;
     keys[j] = key;
-    vmask |= (ok ? 1u : 0u) << j;
   }
-  return vmask;
+  return kp_valid_mask(I, k);
+}
+
+// Only the FILE (bucket) of each of those k-mers, for the histogram pass: the top bits of min(f, r) are the smaller of
+// f's and r's top bits (equal tops give the same bucket whichever is smaller), so neither the k-mer nor its reverse
+// complement is ever assembled -- f's top comes from the first bases of the window start, r's from the reverse
+// complement of the k-mer's LAST bases, all sixteen of which sit in one 32-base chunk that is reversed once.
+// bucket_bits <= 16, k <= 32, 2k >= bucket_bits.
+__device__ __forceinline__ u32 kp_thread_buckets(const u32 *s_codes, const u32 *s_inval, u32 k, int mode, u32 bucket_bits,
+                                                 u32 (&bk)[KP_ITEMS]) {
+  const u32 t = threadIdx.x;
+  const u64 A = ((u64)s_codes[t] << 32) | (u64)s_codes[t + 1];      // bases 0..31 of the thread's window
+  const u64 B = (u64)s_codes[t + 2] << 32;                          // bases 32..47
+  const u64 I = ((u64)s_inval[t] << 48) | ((u64)s_inval[t + 1] << 32) | ((u64)s_inval[t + 2] << 16);
+  const u32 m  = (bucket_bits + 1) / 2;                              // bases that decide the bucket
+  const u32 z0 = k - m;                                              // the last m bases of start j are bases z0+j .. z0+j+m-1
+  const u64 Z  = (z0 == 0) ? A : ((A << (2 * z0)) | (B >> (64 - 2 * z0)));
+  const u64 RC = revcomp64(Z, 0);                                    // base i of Z -> base 31-i, complemented
+  const u64 mmask = (1ull << (2 * m)) - 1ull;
+  const u32 odd = 2 * m - bucket_bits;
+#pragma unroll
+  for (int j = 0; j < KP_ITEMS; j++) {
+    const u32 ft = (u32)(((j == 0) ? A : (A << (2 * j))) >> (64 - bucket_bits));
+    const u32 rt = (u32)((RC >> (2 * j)) & mmask) >> odd;
+    bk[j] = (mode == 1) ? ft : (mode == 2) ? rt : (ft < rt ? ft : rt);
+  }
+  return kp_valid_mask(I, k);
 }
 
 // Same for k in 33..64: the thread's window is 80 bases (five staged words).
@@ -174,14 +208,22 @@ void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode,
   for (u64 tile = t_begin; tile < t_end; tile++) {
     kp_stage_tile(bases, n, tile * KP_TILE, aligned, s_codes, s_inval);
     __syncthreads();
-    K keys[KP_ITEMS];
-    const u32 vmask = kp_thread_kmers(s_codes, s_inval, k, mode, keys);
-    if (nb == 1) {
-      my_count += __popc(vmask);
-    } else {
+    if (sizeof(K) == 8 && nb > 1 && 2 * k >= bucket_bits) {
+      u32 bk[KP_ITEMS];
+      const u32 vmask = kp_thread_buckets(s_codes, s_inval, k, mode, bucket_bits, bk);
 #pragma unroll
       for (int j = 0; j < KP_ITEMS; j++)
-        if ((vmask >> j) & 1u) atomicAdd(&s_hist[KeyOps<K>::bucket(keys[j], bucket_shift)], 1u);
+        if ((vmask >> j) & 1u) atomicAdd(&s_hist[bk[j]], 1u);
+    } else {
+      K keys[KP_ITEMS];
+      const u32 vmask = kp_thread_kmers(s_codes, s_inval, k, mode, keys);
+      if (nb == 1) {
+        my_count += __popc(vmask);
+      } else {
+#pragma unroll
+        for (int j = 0; j < KP_ITEMS; j++)
+          if ((vmask >> j) & 1u) atomicAdd(&s_hist[KeyOps<K>::bucket(keys[j], bucket_shift)], 1u);
+      }
     }
     __syncthreads();
   }
