@@ -30,7 +30,7 @@ SYMBOLS = (
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_close",
     "mdb_free", "mgc_write_database",
     # include/meryl_seq.h
-    "msr_open", "msr_read_text", "msr_close", "msr_last_error", "msr_load_bases", "msr_is_compressed", "msr_guess_number_of_kmers",
+    "msr_open", "msr_read_text", "msr_close", "msr_last_error", "msr_load_bases", "msr_load_stream", "msr_format", "msr_is_compressed", "msr_guess_number_of_kmers",
 )
 
 
@@ -214,6 +214,8 @@ def lib():
     sig("msr_last_error", ctypes.c_char_p)
     sig("msr_load_bases", i32, vp, vp, u64, P(u64), P(i32))
     sig("msr_is_compressed", i32, vp)
+    sig("msr_format", i32, vp)
+    sig("msr_load_stream", i32, vp, vp, u64, P(u64))
     sig("msr_guess_number_of_kmers", u64, ctypes.c_char_p)
     _lib = L
     return L

@@ -74,7 +74,7 @@ struct Globals {
 void usage(const char *prog) {
   fprintf(stderr,
           "usage: %s [k=<K>] [memory=<GB>] [threads=<T>] [n=<kmers>] [compress] [-C] [-Q] [-V]\n"
-          "          count|count-forward|count-reverse <reads.fa|fq[.gz]> ... output <database.meryl>\n"
+          "          count|count-forward|count-reverse <reads.fa|fq[.gz]|sam|bam> ... output <database.meryl>\n"
           "       %s print <database.meryl>\n"
           "       %s dumpIndex <database.meryl>\n"
           "\n"
@@ -197,12 +197,11 @@ int run_count(const Globals &g, const Operation &op) {
     msr_reader *r = msr_open(name.c_str());
     if (!r) die("ERROR: %s", msr_last_error());
     for (;;) {                                                                                         // loader loop, :173-203
-      uint64_t len = 0;
-      int eos = 0;
-      const int rc = msr_load_bases(r, buf.data(), buf_max, &len, &eos);
+      uint64_t len = 0;                                                                                // 2 MiB of sequences, '.' after each
+      const int rc = msr_load_stream(r, buf.data(), buf_max, &len);
       if (rc < 0) die("ERROR: %s", msr_last_error());
       if (rc == 0) break;
-      if (mgc_push_bases(s, buf.data(), len, eos) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+      if (mgc_push_bases(s, buf.data(), len, 0) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
       total_bases += len;
     }
     mgc_push_bases(s, nullptr, 0, 1);                                                                  // end-of-file breaker, :196
@@ -213,6 +212,7 @@ int run_count(const Globals &g, const Operation &op) {
     if (host_parser) { load_on_host(name); continue; }
     msr_reader *r = msr_open(name.c_str());
     if (!r) die("ERROR: %s", msr_last_error());
+    if (msr_format(r) != MSR_FORMAT_FASTX) { msr_close(r); load_on_host(name); continue; }   // SAM/BAM records are decoded on the host
     bool begun = false, refused = false;
     for (;;) {
       const int64_t got = msr_read_text(r, text.data(), text.size());

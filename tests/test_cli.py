@@ -177,3 +177,30 @@ def test_config0_ecoli_cli_on_gpu(meryl, oracle_lib, tmp_path):
     assert r.info.prefix_bits == 10 if hasattr(r.info, "prefix_bits") else True
     assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn) and r.info.num_total == wni
     r.close()
+
+
+@pytest.mark.gpu
+def test_cli_counts_bam_sam_and_bgzipped_fastq(meryl, oracle_lib, tmp_path):
+    # the same reads as BAM (BGZF, decoded on the host), SAM text and bgzip'd FASTQ (inflated block-parallel, parsed on
+    # the device): one database each, all equal to the oracle's count of the reads; reverse-flagged and secondary
+    # records carry their SEQ as stored, a record without SEQ adds nothing
+    from meryl_amd import db
+    from test_seq_bam import bam_bytes, bgzf
+    bases = oracle_lib.synth_reads(33, 40_000, 0, 3000).tobytes()
+    reads = [r for r in bases.decode().split(".") if r]
+    recs = [("r%d" % i, (0, 16, 256, 4)[i % 4], r.upper()) for i, r in enumerate(reads)]
+    recs.insert(5, ("noseq", 4, ""))
+    bam = tmp_path / "reads.bam"
+    bam.write_bytes(bgzf(bam_bytes(recs), 5000))
+    sam = tmp_path / "reads.sam"
+    sam.write_text("@HD\tVN:1.6\n" + "".join("%s\t%d\t*\t0\t0\t*\t*\t0\t0\t%s\t*\n" % (n, f, s if s else "*") for n, f, s in recs))
+    fq = tmp_path / "reads.fastq.gz"
+    fq.write_bytes(bgzf("".join("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)) for n, _, s in recs if s).encode(), 30_000))
+    _, wlo, wcn, wni = oracle_lib.count_brute(".".join(r.upper() for r in reads) + ".", 21)
+    for src in (bam, sam, fq):
+        out = tmp_path / (src.name + ".meryl")
+        run(meryl, "-Q", "k=21", "memory=2", "threads=4", "count", src, "output", out)
+        r = db.Reader(str(out))
+        lo, hi, cn = r.read_all()
+        assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn) and r.info.num_total == wni, src.name
+        r.close()
