@@ -14,8 +14,8 @@
  * "Direct kmer counting from bam / cram") give one sequence per alignment record:
  * SEQ as stored, no record filtered by its flags -- which records the reference
  * keeps is decided inside the absent submodule, so that choice is unpinned.
- * CRAM (needs the reference genome and htslib's codecs), bz2 and xz are refused
- * by msr_open with a message.
+ * .bz2 and .xz go through `bzip2 -dc` / `xz -dc` pipes.  CRAM (needs the reference
+ * genome and htslib's codecs) is refused by msr_open with a message.
  */
 #ifndef MERYL_SEQ_H
 #define MERYL_SEQ_H

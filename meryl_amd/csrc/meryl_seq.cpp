@@ -164,6 +164,7 @@ struct BgzfSource {
 struct msr_reader {
   gzFile      gz = nullptr;
   BgzfSource *bgzf = nullptr;
+  FILE       *pipe = nullptr;        // bzip2 -dc / xz -dc (the reference's compressed-file reader pipes them too)
   std::string name;
   bool        compressed = false;
   unsigned char *buf = nullptr;
@@ -181,6 +182,7 @@ struct msr_reader {
 
   int64_t source_read(void *dst, size_t n) {
     if (bgzf) return bgzf->read(dst, n);
+    if (pipe) { const size_t got = fread(dst, 1, n, pipe); return (got == 0 && ferror(pipe)) ? -1 : (int64_t)got; }
     const int got = gzread(gz, dst, (unsigned)(n > (1u << 30) ? (1u << 30) : n));
     return got;
   }
@@ -226,13 +228,22 @@ extern "C" const char *msr_last_error(void) { return g_seq_error.c_str(); }
 extern "C" msr_reader *msr_open(const char *name) {
   if (!name || !*name) { seq_err("msr_open: empty file name"); return nullptr; }
   const std::string n(name);
-  if (ends_with(n, ".bz2") || ends_with(n, ".xz")) { seq_err("msr_open: '" + n + "': bz2/xz input is not supported (use gzip or a pipe)"); return nullptr; }
   if (ends_with(n, ".cram")) { seq_err("msr_open: '" + n + "': CRAM input is not supported (convert to BAM)"); return nullptr; }
   msr_reader *r = new msr_reader();
   r->name = n;
-  r->compressed = ends_with(n, ".gz") || ends_with(n, ".bam");
+  r->compressed = ends_with(n, ".gz") || ends_with(n, ".bam") || ends_with(n, ".bz2") || ends_with(n, ".xz");
   r->buf = (unsigned char *)malloc(r->cap);
-  if (n != "-") {                                   // BGZF (bgzip, BAM)?  then the blocks are inflated in parallel
+  if (ends_with(n, ".bz2") || ends_with(n, ".xz")) {          // through the system's decompressor
+    struct stat st;
+    if (stat(name, &st) != 0) { seq_err("msr_open: cannot open '" + n + "': " + strerror(errno)); msr_close(r); return nullptr; }
+    std::string quoted = "'";
+    for (char c : n) { if (c == '\'') quoted += "'\\''"; else quoted += c; }
+    quoted += "'";
+    const std::string cmd = std::string(ends_with(n, ".bz2") ? "bzip2" : "xz") + " -dc -- " + quoted;
+    r->pipe = popen(cmd.c_str(), "r");
+    if (!r->pipe) { seq_err("msr_open: cannot run '" + cmd + "': " + strerror(errno)); msr_close(r); return nullptr; }
+  }
+  else if (n != "-") {                                   // BGZF (bgzip, BAM)?  then the blocks are inflated in parallel
     FILE *f = fopen(name, "rb");
     if (!f) { seq_err("msr_open: cannot open '" + n + "': " + strerror(errno)); msr_close(r); return nullptr; }
     unsigned char head[64];
@@ -248,7 +259,7 @@ extern "C" msr_reader *msr_open(const char *name) {
       fclose(f);
     }
   }
-  if (!r->bgzf) {
+  if (!r->bgzf && !r->pipe) {
     r->gz = (n == "-") ? gzdopen(0, "rb") : gzopen(name, "rb");
     if (!r->gz) { seq_err("msr_open: cannot open '" + n + "': " + strerror(errno)); msr_close(r); return nullptr; }
     gzbuffer(r->gz, 1u << 20);
@@ -266,6 +277,7 @@ extern "C" msr_reader *msr_open(const char *name) {
 extern "C" void msr_close(msr_reader *r) {
   if (!r) return;
   if (r->gz) gzclose(r->gz);
+  if (r->pipe) pclose(r->pipe);
   if (r->bgzf) { if (r->bgzf->f) fclose(r->bgzf->f); delete r->bgzf; }
   free(r->buf);
   delete r;

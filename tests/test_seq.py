@@ -55,7 +55,9 @@ def test_fasta_fastq_plain_and_gz(native_lib, tmp_path, max_len):
 def test_reader_errors_and_guess(native_lib, tmp_path):
     assert not native_lib.msr_open(str(tmp_path / "missing.fa").encode())
     assert b"cannot open" in native_lib.msr_last_error()
-    assert not native_lib.msr_open(b"reads.fq.bz2")
+    assert not native_lib.msr_open(b"reads.fq.bz2")                          # no such file
+    assert b"cannot open" in native_lib.msr_last_error()
+    assert not native_lib.msr_open(b"reads.cram")
     assert b"not supported" in native_lib.msr_last_error()
     bad = tmp_path / "bad.txt"
     bad.write_text("hello\n")
@@ -72,3 +74,19 @@ def test_reader_errors_and_guess(native_lib, tmp_path):
     pz.write_bytes(b"x" * 100)
     assert native_lib.msr_guess_number_of_kmers(str(pz).encode()) == 300
     assert native_lib.msr_guess_number_of_kmers(b"-") == 0
+
+
+@pytest.mark.parametrize("max_len", [3, 1 << 16])
+def test_bz2_and_xz_through_the_system_decompressors(native_lib, tmp_path, max_len):
+    import bz2, lzma, shutil
+    if not (shutil.which("bzip2") and shutil.which("xz")):
+        pytest.skip("bzip2 / xz not installed")
+    b = tmp_path / "it's x.fastq.bz2"                                        # a name the shell must not split or expand
+    b.write_bytes(bz2.compress(FASTQ.encode()))
+    assert load_all(native_lib, str(b), max_len) == [b"ACGTN", b"GGGGCC", b"A"]
+    x = tmp_path / "x.fasta.xz"
+    x.write_bytes(lzma.compress(FASTA.encode()))
+    assert load_all(native_lib, str(x), max_len) == [b"ACGTACGTNNacgt", b"TTTT", b"", b"GATTACA"]
+    r = native_lib.msr_open(str(x).encode())
+    assert r and native_lib.msr_is_compressed(r) == 1 and native_lib.msr_format(r) == 0
+    native_lib.msr_close(r)
