@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <string>
 #include <thread>
 #include <vector>
@@ -90,8 +91,8 @@ struct BgzfSource {
   }
 
   // decode the next batch of blocks into `out`; false at end of file or on error (err set)
-  bool next_batch() {
-    out.clear(); out_pos = 0;
+  bool next_batch(std::vector<unsigned char> &out) {
+    out.clear();
     std::vector<Block> blocks;
     size_t total = 0;
     while (blocks.size() < 2048) {
@@ -144,12 +145,30 @@ struct BgzfSource {
     return true;
   }
 
+  // The batch after the one being consumed is inflated in the background: the caller's work on a batch (device upload,
+  // BAM decode) overlaps the next one's inflate.
+  std::vector<unsigned char> ahead;
+  std::future<bool> pending;
+  bool started = false, finished = false;
+
+  bool advance_batch() {                             // -> out = next batch; false at end of file or on error
+    if (finished) return false;
+    if (!started) { started = true; pending = std::async(std::launch::async, [this] { return next_batch(ahead); }); }
+    const bool ok = pending.get();
+    if (!ok) { finished = true; out.clear(); out_pos = 0; return false; }
+    out.swap(ahead);
+    out_pos = 0;
+    pending = std::async(std::launch::async, [this] { return next_batch(ahead); });
+    return true;
+  }
+  ~BgzfSource() { if (pending.valid()) pending.wait(); }
+
   // up to n bytes; 0 at end of file, -1 on error
   int64_t read(void *dst, size_t n) {
     size_t got = 0;
     while (got < n) {
       if (out_pos == out.size()) {
-        if (!next_batch()) return err.empty() ? (int64_t)got : -1;
+        if (!advance_batch()) return err.empty() ? (int64_t)got : -1;
         if (out.empty()) continue;                 // a batch of empty blocks (the EOF marker)
       }
       const size_t take = std::min(n - got, out.size() - out_pos);
@@ -278,7 +297,7 @@ extern "C" void msr_close(msr_reader *r) {
   if (!r) return;
   if (r->gz) gzclose(r->gz);
   if (r->pipe) pclose(r->pipe);
-  if (r->bgzf) { if (r->bgzf->f) fclose(r->bgzf->f); delete r->bgzf; }
+  if (r->bgzf) { FILE *f = r->bgzf->f; delete r->bgzf; if (f) fclose(f); }     // the destructor waits for the batch in flight
   free(r->buf);
   delete r;
 }
