@@ -95,7 +95,7 @@ struct BgzfSource {
     out.clear();
     std::vector<Block> blocks;
     size_t total = 0;
-    while (blocks.size() < 2048) {
+    while (blocks.size() < 512) {                     // <= 32 MiB of text per batch: enough for 16 threads, small enough to pipeline
       if (!fill_raw(18)) {
         if (raw.size() != raw_pos) { err = "truncated BGZF block header"; return false; }
         break;
