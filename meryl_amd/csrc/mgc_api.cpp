@@ -295,6 +295,8 @@ struct mgc_session {
   mgc_count_config cfg;
   int              device = -1;
   hipStream_t      stream = nullptr;
+  hipStream_t      stream2 = nullptr;    // the streaming hash-count of a file's oversized sub-buckets runs beside its persistent kernel
+  hipEvent_t       ev_fork = nullptr, ev_join = nullptr;
   std::string      err;
 
   // input
@@ -449,6 +451,11 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
   }
   e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { set_err(nullptr, "hipStreamCreate: %s", hipGetErrorString(e)); delete s; return nullptr; }
+  if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
+    set_err(nullptr, "hipStreamCreate / hipEventCreate failed"); mgc_close(s); return nullptr;
+  }
   memset(&s->prof, 0, sizeof(s->prof));
   memset(s->file_instances, 0, sizeof(s->file_instances));
   memset(s->total_file_instances, 0, sizeof(s->total_file_instances));
@@ -464,6 +471,9 @@ extern "C" void mgc_close(mgc_session *s) {
     if (s->text_pinned[i]) (void)hipHostFree(s->text_pinned[i]);
     if (s->text_ev[i]) (void)hipEventDestroy(s->text_ev[i]);
   }
+  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -889,6 +899,12 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     HIP_TRY(s, hipStreamSynchronize(st));
 
     // ---- D. finish every file: LDS sort + count, or the full-sort fallback ----
+    // The streaming kernel of a file's oversized sub-buckets goes to a second stream: it touches other sub-buckets than
+    // the persistent kernel, and one gigantic sub-bucket occupies ONE workgroup for hundreds of microseconds -- beside
+    // the persistent kernels of this and the next files that tail costs nothing (MGC_FINISH_FORK=0: same stream).
+    static const bool fork_huge = !(getenv("MGC_FINISH_FORK") && getenv("MGC_FINISH_FORK")[0] == '0');
+    hipStream_t st_huge = fork_huge ? s->stream2 : st;
+    bool forked = false, need_join = false;          // forked: stream2 is ordered after everything st holds that it must see
     std::vector<uint64_t> h_fallback_distinct(nb);
     std::vector<char> fallback(nb);
     for (uint32_t b = 0; b < nb; b++) {
@@ -918,14 +934,21 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
                 (unsigned long long)cap, stream ? "streamed through the hash tables" : "stable-sort fallback");
       }
       if (h_maxsub[b] <= cap || stream) {
+        if (stream && fork_huge && !forked) {            // everything the streaming kernels read is complete at this point of st
+          HIP_TRY(s, hipEventRecord(s->ev_fork, st));
+          HIP_TRY(s, hipStreamWaitEvent(st_huge, s->ev_fork, 0));
+          forked = need_join = true;
+        }
         HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_nlarge[b],
-                                           d_large + gbase[b], d_cnt_tmp + h_starts[b], d_group + gbase[b], stream, (void *)Y,
+                                           d_large + gbase[b], d_cnt_tmp + h_starts[b], d_group + gbase[b], stream, (void *)Y, st_huge,
                                            // the list pays off only when a good part of the 2^t grid is empty
                                            (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b])) ? d_nz + gbase[b] : nullptr,
                                            d_nzcount + b, st));
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
         fallback[b] = true;
+        if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));  // the sort below uses Y, the streaming kernels' second buffer
+        forked = false;                                            // ... and the next streaming kernel must wait for that sort
         if (low) {
           // LSD order: the low bits cannot be sorted after the top bits, so the whole key is redone
           mgc::SortPlan lp;
@@ -940,6 +963,11 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         HIP_TRY(s, hipMemcpyAsync(d_group + gbase[b], &h_fallback_distinct[b], sizeof(uint64_t), hipMemcpyHostToDevice, st));
         HIP_TRY(s, hipStreamSynchronize(st));
       }
+    }
+
+    if (need_join) {
+      HIP_TRY(s, hipEventRecord(s->ev_join, st_huge));
+      HIP_TRY(s, hipStreamWaitEvent(st, s->ev_join, 0));
     }
 
     // ---- E/F. offsets of every sub-bucket in the packed result ----

@@ -83,6 +83,7 @@ hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uin
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
                               bool stream /*large list -> streaming hash-count*/, void *d_alt /*room for the file's keys*/,
+                              hipStream_t st_huge /*where that kernel is launched (st, or a stream forked from it)*/,
                               const uint32_t *d_nonempty_list, const uint64_t *d_nonempty_count /*the hash kernels visit only these;
                               d_group_distinct must be zero for the others*/, hipStream_t st);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);

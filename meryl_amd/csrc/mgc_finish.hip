@@ -1515,7 +1515,7 @@ hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uin
 // through the LDS sort, and the file holds none above its capacity (the caller checked the largest sub-bucket)
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
-                              bool stream, void *d_alt, const uint32_t *d_nz, const uint64_t *d_nz_count,
+                              bool stream, void *d_alt, hipStream_t st_huge, const uint32_t *d_nz, const uint64_t *d_nz_count,
                               hipStream_t st) {
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
   if (key_words == 2 && finish_uses_hash(key_words, low_bits)) {
@@ -1543,12 +1543,12 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
         wattr = true;
       }
       if (low_bits > 64)
-        hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, true>), dim3((uint32_t)n_large), dim3(1024), BW, st,
+        hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, true>), dim3((uint32_t)n_large), dim3(1024), BW, st_huge,
                            reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
                            (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
                            reinterpret_cast<K128 *>(d_alt));
       else
-        hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, false>), dim3((uint32_t)n_large), dim3(1024), BN, st,
+        hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, false>), dim3((uint32_t)n_large), dim3(1024), BN, st_huge,
                            reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
                            (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
                            reinterpret_cast<K128 *>(d_alt));
@@ -1599,12 +1599,12 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
         hattr = true;
       }
       if (low_bits < 32)
-        hipLaunchKernelGGL((hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>), dim3((uint32_t)n_large), dim3(1024), B32, st,
+        hipLaunchKernelGGL((hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>), dim3((uint32_t)n_large), dim3(1024), B32, st_huge,
                            reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
                            (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
                            reinterpret_cast<u64 *>(d_alt));
       else
-        hipLaunchKernelGGL((hash_count_huge_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>), dim3((uint32_t)n_large), dim3(1024), B64, st,
+        hipLaunchKernelGGL((hash_count_huge_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>), dim3((uint32_t)n_large), dim3(1024), B64, st_huge,
                            reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
                            (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
                            reinterpret_cast<u64 *>(d_alt));
