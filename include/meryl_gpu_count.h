@@ -59,6 +59,8 @@ extern "C" {
  * Configuration -- replaces merylOperation::configureCounting
  * (src/meryl/merylOp-count.C:300-403).  Pure host arithmetic.
  * ---------------------------------------------------------------------- */
+#define MGC_MAX_COUNT_SUFFIX 32
+
 typedef struct mgc_count_config {
   /* in */
   uint32_t k;                     /* kmerTiny::merSize(), 1..64 */
@@ -66,7 +68,7 @@ typedef struct mgc_count_config {
   uint64_t n_kmers_estimate;      /* n= / guesstimateNumberOfkmersInInput (:317,449) */
   uint64_t memory_allowed;        /* memory= in bytes (merylCommandBuilder.C:299-302) */
   uint32_t threads;               /* threads= (host threads used by mgc_finish) */
-  uint32_t count_suffix_length;   /* count-suffix= length; forces simple mode (:379-382) */
+  uint32_t count_suffix_length;   /* count-suffix= length (see count_suffix below); forces simple mode (:379-382) */
   uint32_t homopoly_compress;     /* `compress` (merylInput.C:261-262) */
   uint32_t page_size;             /* 0 -> 4096 (getPageSize()) */
   uint32_t sizeof_count_array;    /* 0 -> 3232 (sizeof(merylCountArray), merylCountArray.H:44,71-74) */
@@ -77,6 +79,11 @@ typedef struct mgc_count_config {
   uint32_t w_data;                /* wData_ = 2k - wPrefix */
   uint32_t n_batches;             /* incl. the reference's post-increment quirk (:355-358) */
   uint64_t memory_used;           /* what the "Configured ... mode for %.3f GB" line prints (:398-401) */
+  /* in (at the end: added after the first layout) */
+  char     count_suffix[MGC_MAX_COUNT_SUFFIX + 4];   /* count-suffix=<bases> (merylCommandBuilder.C:271-272, merylOp.H:139-147):
+                                      only k-mers -- the canonical / forward / reverse one that is counted -- ENDING in these
+                                      bases are counted (merylOp-countSimple.C:50-58,88-93); count_suffix_length of them,
+                                      NUL-terminated; needs k - length >= 3 */
 } mgc_count_config;
 
 int mgc_configure_counting(mgc_count_config *cfg);

@@ -51,6 +51,7 @@ class CountConfig(ctypes.Structure):
         ("w_data", ctypes.c_uint32),
         ("n_batches", ctypes.c_uint32),
         ("memory_used", ctypes.c_uint64),
+        ("count_suffix", ctypes.c_char * 36),
     ]
 
 
@@ -232,7 +233,7 @@ def check(rc, what, handle=None):
 
 
 def configure(k, n_kmers_estimate, memory_bytes, mode=MODE_CANONICAL, threads=0, count_suffix_length=0,
-              homopoly_compress=0):
+              homopoly_compress=0, count_suffix=""):
     """mgc_configure_counting -> filled CountConfig."""
     c = CountConfig()
     c.k = k
@@ -240,7 +241,8 @@ def configure(k, n_kmers_estimate, memory_bytes, mode=MODE_CANONICAL, threads=0,
     c.n_kmers_estimate = int(n_kmers_estimate)
     c.memory_allowed = int(memory_bytes)
     c.threads = threads
-    c.count_suffix_length = count_suffix_length
+    c.count_suffix_length = len(count_suffix) if count_suffix else count_suffix_length
+    c.count_suffix = count_suffix.encode("ascii")
     c.homopoly_compress = homopoly_compress
     check(lib().mgc_configure_counting(ctypes.byref(c)), "mgc_configure_counting")
     return c

@@ -55,6 +55,7 @@ struct Operation {
   std::vector<std::string> db_inputs;       // databases (print / dumpIndex)
   std::string              output;
   uint64_t                 exp_num_kmers = 0;   // n=
+  std::string              count_suffix;        // count-suffix=
 };
 
 struct Globals {
@@ -102,14 +103,16 @@ void print_configuration(const Globals &g, const Operation &op, uint64_t exp_num
 
   // SIMPLE MODE, :136-162
   fprintf(stderr, "\n\nSIMPLE MODE\n-----------\n\n");
-  if (2 * k > 42) {
+  const uint32_t sl = cfg.count_suffix_length;
+  if (2 * k - 2 * sl > 42) {
     fprintf(stderr, "  Not possible.\n");
   } else {
-    const uint64_t n_entries = (uint64_t)1 << (2 * k), low_bits = 16;
+    const uint64_t n_entries = (uint64_t)1 << (2 * k - 2 * sl), low_bits = 16;
     const uint64_t exp_max = (uint64_t)(0.004 * (double)exp_num_kmers), exp_bits = bits64(exp_max) + 1;
     const uint64_t extra = (exp_bits < low_bits) ? 0 : exp_bits - low_bits;
     const uint64_t low_mem = n_entries * low_bits, high_mem = n_entries * extra, tot = (low_mem + high_mem) / 8;
-    fprintf(stderr, "  %u-mers\n", k);
+    if (sl == 0) fprintf(stderr, "  %u-mers\n", k);                                                                 // :147-150
+    else         fprintf(stderr, "  %u-mers with constant %u-mer suffix '%s'\n", k, sl, cfg.count_suffix);
     fprintf(stderr, "    -> %" PRIu64 " entries for counts up to %u.\n", n_entries, 65535u);
     fprintf(stderr, "    -> %" PRIu64 " %cbits memory used\n", scaledNumber(low_mem), scaledUnit(low_mem));
     fprintf(stderr, "\n  %" PRIu64 " input bases\n", exp_num_kmers);
@@ -172,6 +175,9 @@ int run_count(const Globals &g, const Operation &op) {
   for (bool c : op.seq_compress)
     if (c != any_compress) die("ERROR: `compress` must apply to all or none of the inputs of one count in this build.");
   cfg.homopoly_compress = any_compress ? 1 : 0;
+  if (op.count_suffix.size() > MGC_MAX_COUNT_SUFFIX) die("ERROR: %s", "count-suffix of more than 32 bases.");
+  cfg.count_suffix_length = (uint32_t)op.count_suffix.size();                                         // merylOp.H:139-147
+  memcpy(cfg.count_suffix, op.count_suffix.c_str(), op.count_suffix.size());
   if (mgc_configure_counting(&cfg) != MGC_OK) die("ERROR: %s", mgc_last_error(nullptr));
 
   if (g.verbosity > 0) print_configuration(g, op, exp_num_kmers, cfg);
@@ -377,7 +383,12 @@ int main(int argc, char **argv) {
       else if (key == "memory" && eq != std::string::npos)  { g.memory_gb = strtod(val.c_str(), nullptr); }       // :299-302
       else if (key == "threads" && eq != std::string::npos) { g.threads = (uint32_t)strtoul(val.c_str(), nullptr, 10); if (!g.threads) g.threads = 1; }   // :306-310
       else if (w == "compress")              { g.compress = true; }                                               // :237-240
-      else if (key == "count-suffix" || key == "segment") { die("ERROR: option '%s' is not supported in this build.", w.c_str()); }
+      else if (key == "count-suffix") {                                                                            // :271-272: the operation on top
+        if (open_op < 0 || ops[open_op].kind < OP_COUNT || ops[open_op].kind > OP_COUNT_REVERSE)
+          die("ERROR: option '%s' needs a counting operation before it.", w.c_str());
+        ops[open_op].count_suffix = val;
+      }
+      else if (key == "segment") { die("ERROR: option '%s' (Canu sequence stores) is not supported in this build.", w.c_str()); }
       // ---- operations, :346-385 ----
       else if (w == "count" || w == "count-forward" || w == "count-reverse" || w == "print" || w == "dumpIndex" || w == "histogram") {
         const OpKind kind = (w == "count") ? OP_COUNT : (w == "count-forward") ? OP_COUNT_FORWARD :

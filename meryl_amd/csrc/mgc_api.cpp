@@ -295,6 +295,7 @@ struct mgc_session {
   mgc_count_config cfg;
   int              device = -1;
   hipStream_t      stream = nullptr;
+  uint64_t         sfx_mask = 0, sfx_test = 0;   // count-suffix= filter (0, 0: none)
   hipStream_t      stream2 = nullptr;    // the streaming hash-count of a file's oversized sub-buckets runs beside its persistent kernel
   hipEvent_t       ev_fork = nullptr, ev_join = nullptr;
   std::string      err;
@@ -408,22 +409,43 @@ extern "C" const char *mgc_last_error(const mgc_session *s) {
 extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
   if (!cfg) { set_err(nullptr, "mgc_open: NULL config"); return nullptr; }
   mgc_count_config eff = *cfg;
-  if (cfg->count_suffix_length) {
-    set_err(nullptr, "mgc_open: count-suffix= is not implemented");
-    return nullptr;
+  uint64_t sfx_mask = 0, sfx_test = 0;
+  const uint32_t sfx_len = cfg->count_suffix_length;
+  if (sfx_len) {
+    // count-suffix=<bases>: merylOp.H:139-147 packs the string like a k-mer (2-bit codes, last base lowest);
+    // merylOp-countSimple.C:50-58 builds the mask, :88-93 tests the k-mer that is counted against it
+    if (sfx_len > MGC_MAX_COUNT_SUFFIX || strnlen(cfg->count_suffix, sizeof(cfg->count_suffix)) != sfx_len) {
+      set_err(nullptr, "mgc_open: count_suffix must hold count_suffix_length (1..%d) bases", MGC_MAX_COUNT_SUFFIX);
+      return nullptr;
+    }
+    if (cfg->k < sfx_len + 3) { set_err(nullptr, "mgc_open: count-suffix of %u bases needs k >= %u", sfx_len, sfx_len + 3); return nullptr; }
+    if (2 * cfg->k - 2 * sfx_len > 42) {            // findExpectedSimpleSize, merylOp-count.C:142-145: "Not possible."
+      set_err(nullptr, "mgc_open: count-suffix forces simple mode, which takes at most 21 free bases (k - suffix length = %u)", cfg->k - sfx_len);
+      return nullptr;
+    }
+    for (uint32_t i = 0; i < sfx_len; i++) {
+      const char ch = cfg->count_suffix[i];
+      const bool ok = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'a' || ch == 'c' || ch == 'g' || ch == 't';
+      if (!ok) { set_err(nullptr, "mgc_open: count-suffix '%s' holds something that is not ACGT", cfg->count_suffix); return nullptr; }
+      sfx_test = (sfx_test << 2) | (uint64_t)(((unsigned char)ch >> 1) & 3);        // A0 C1 T2 G3
+    }
+    sfx_mask = (sfx_len == 32) ? ~0ull : (((uint64_t)1 << (2 * sfx_len)) - 1);
+    eff.use_simple = 1;                                                               // merylOp-count.C:379-382
   }
-  if (cfg->use_simple) {
+  if (eff.use_simple) {
     // The reference switches to countSimple (merylOp-count.C:368-372): a direct-index counter
     // whose RESULT is the same sorted (k-mer, count) stream but whose database geometry is
     //   psbits = 2k - 6, wSuffix = min(20, psbits), wPrefix = 6 + psbits - wSuffix
     // (merylOp-countSimple.C:172-175).  The sort-based engine below produces that stream for any
     // k, so simple mode only changes the block geometry.
     if (2 * cfg->k < MGC_NUM_FILES_BITS) { set_err(nullptr, "mgc_open: k=%u too small for a 64-file database", cfg->k); return nullptr; }
-    const uint32_t psbits = 2 * cfg->k - MGC_NUM_FILES_BITS;
+    // A k-mer is [file][blockPrefix][suffix][count-suffix] (:140): the count-suffix bases take no part in the split, and
+    // travel at the end of every block suffix (:231-233)
+    const uint32_t psbits = 2 * cfg->k - 2 * sfx_len - MGC_NUM_FILES_BITS;
     const uint32_t w_suffix = (psbits > 20) ? 20 : psbits;
     eff.w_prefix = MGC_NUM_FILES_BITS + psbits - w_suffix;
     eff.n_prefix = (uint64_t)1 << eff.w_prefix;
-    eff.w_data   = w_suffix;
+    eff.w_data   = w_suffix + 2 * sfx_len;
   }
   cfg = &eff;
   if (cfg->k == 0 || cfg->k > 64 || cfg->w_prefix < MGC_NUM_FILES_BITS || cfg->w_prefix > 2 * cfg->k ||
@@ -441,6 +463,8 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
   }
   mgc_session *s = new mgc_session();
   s->cfg = *cfg;
+  s->sfx_mask = sfx_mask;
+  s->sfx_test = sfx_test;
   s->key_words = (cfg->k > 32) ? 2u : 1u;
   if (device >= 0) {
     e = hipSetDevice(device);
@@ -729,7 +753,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   uint64_t *h_counts = h_counts_v.data(), *h_starts = h_starts_v.data();
   if (!ext_keys) {
     tm.begin(MGC_STAGE_HISTOGRAM);
-    HIP_TRY(s, mgc::launch_kmer_histogram(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, part_ws, st));
+    HIP_TRY(s, mgc::launch_kmer_histogram(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, part_ws, st, s->sfx_mask, s->sfx_test));
     tm.end(MGC_STAGE_HISTOGRAM);
     s->prof.stage_launches[MGC_STAGE_HISTOGRAM] = 1;
     HIP_TRY(s, hipMemcpyAsync(h_counts, d_counts64, sizeof(uint64_t) * nb, hipMemcpyDeviceToHost, st));
@@ -766,7 +790,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   if (!ext_keys) {
     HIP_TRY(s, hipMemcpyAsync(d_starts, h_starts, sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
     tm.begin(MGC_STAGE_PARTITION);
-    HIP_TRY(s, mgc::launch_kmer_partition(d_bases, n_bases, k, c.mode, bucket_bits, d_starts, (void *)X, part_ws, st));
+    HIP_TRY(s, mgc::launch_kmer_partition(d_bases, n_bases, k, c.mode, bucket_bits, d_starts, (void *)X, part_ws, st,
+                                          s->sfx_mask, s->sfx_test));
     tm.end(MGC_STAGE_PARTITION);
     s->prof.stage_launches[MGC_STAGE_PARTITION] = 2;
   }

@@ -28,6 +28,7 @@ template <> struct KeyOps<u64> {
   static __device__ __forceinline__ bool ne(u64 a, u64 b) { return a != b; }
   static __device__ __forceinline__ bool lt(u64 a, u64 b) { return a < b; }
   static __device__ __forceinline__ u64  prefix_floor(u64 p, u32 w_data) { return p << w_data; }
+  static __device__ __forceinline__ u64  low64(u64 k) { return k; }
 };
 template <> struct KeyOps<K128> {
   static constexpr int WORDS = 2;
@@ -40,6 +41,7 @@ template <> struct KeyOps<K128> {
   static __device__ __forceinline__ bool ne(K128 a, K128 b) { return (a.lo != b.lo) || (a.hi != b.hi); }
   static __device__ __forceinline__ bool lt(K128 a, K128 b) { return (a.hi < b.hi) || (a.hi == b.hi && a.lo < b.lo); }
   static __device__ __forceinline__ K128 prefix_floor(u64 p, u32 w_data) { return mk((u128)p << w_data); }
+  static __device__ __forceinline__ u64  low64(K128 k) { return k.lo; }
 };
 
 #define MGC_CHECK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return e__; } while (0)

@@ -18,12 +18,14 @@ constexpr int      KP_MAX_BUCKETS = 1024;
 uint32_t kp_grid_size(uint64_t n_bases);
 size_t   kp_workspace_bytes(uint32_t bucket_bits);
 
+// sfx_mask / sfx_test: count-suffix= filter, a k-mer is kept iff (its low word & sfx_mask) == sfx_test (0, 0: keep all)
 hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
-                                 uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st);
+                                 uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st,
+                                 uint64_t sfx_mask = 0, uint64_t sfx_test = 0);
 // keys are uint64 for k <= 32, 16-byte little-endian {lo,hi} for k in 33..64 (key_words 1 / 2)
 hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                                  uint32_t bucket_bits, const uint64_t *d_bucket_starts, void *d_keys,
-                                 void *d_ws, hipStream_t st);
+                                 void *d_ws, hipStream_t st, uint64_t sfx_mask = 0, uint64_t sfx_test = 0);
 
 // ---- radix sort ------------------------------------------------------------
 struct SortPlan {

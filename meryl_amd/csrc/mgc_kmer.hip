@@ -177,6 +177,16 @@ __device__ __forceinline__ u32 kp_thread_kmers(const u32 *s_codes, const u32 *s_
   return vmask;
 }
 
+// count-suffix= (merylOp-countSimple.C:88-93): a k-mer is counted only if the one that is counted ends in the given bases
+template <typename K>
+__device__ __forceinline__ u32 kp_suffix_filter(const K (&keys)[KP_ITEMS], u32 vmask, u64 sfx_mask, u64 sfx_test) {
+  if (sfx_mask == 0) return vmask;                   // uniform
+#pragma unroll
+  for (int j = 0; j < KP_ITEMS; j++)
+    if ((KeyOps<K>::low64(keys[j]) & sfx_mask) != sfx_test) vmask &= ~(1u << j);
+  return vmask;
+}
+
 __device__ __forceinline__ void kp_tile_range(u64 num_tiles, u64 &t_begin, u64 &t_end) {
   const u64 per = (num_tiles + gridDim.x - 1) / gridDim.x;
   t_begin = (u64)blockIdx.x * per;
@@ -189,7 +199,7 @@ __device__ __forceinline__ void kp_tile_range(u64 num_tiles, u64 &t_begin, u64 &
 template <typename K>
 __global__ __launch_bounds__(KP_BLOCK)
 void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
-                      u64 num_tiles, u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts) {
+                      u64 num_tiles, u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts, u64 sfx_mask, u64 sfx_test) {
   __shared__ u32 s_codes[KP_WORDS];
   __shared__ u32 s_inval[KP_WORDS];
   __shared__ u32 s_hist[KP_MAX_BUCKETS];
@@ -208,7 +218,7 @@ void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode,
   for (u64 tile = t_begin; tile < t_end; tile++) {
     kp_stage_tile(bases, n, tile * KP_TILE, aligned, s_codes, s_inval);
     __syncthreads();
-    if (sizeof(K) == 8 && nb > 1 && 2 * k >= bucket_bits) {
+    if (sizeof(K) == 8 && nb > 1 && 2 * k >= bucket_bits && sfx_mask == 0) {
       u32 bk[KP_ITEMS];
       const u32 vmask = kp_thread_buckets(s_codes, s_inval, k, mode, bucket_bits, bk);
 #pragma unroll
@@ -216,7 +226,7 @@ void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode,
         if ((vmask >> j) & 1u) atomicAdd(&s_hist[bk[j]], 1u);
     } else {
       K keys[KP_ITEMS];
-      const u32 vmask = kp_thread_kmers(s_codes, s_inval, k, mode, keys);
+      const u32 vmask = kp_suffix_filter(keys, kp_thread_kmers(s_codes, s_inval, k, mode, keys), sfx_mask, sfx_test);
       if (nb == 1) {
         my_count += __popc(vmask);
       } else {
@@ -272,7 +282,7 @@ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 
 template <typename K, int MAXB>
 __global__ __launch_bounds__(KP_BLOCK, 5)
 void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
-                           u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out) {
+                           u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out, u64 sfx_mask, u64 sfx_test) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kp_dyn_smem[];
   K *s_keys = reinterpret_cast<K *>(kp_dyn_smem);                   // K[KP_TILE]
   __shared__ u64 s_cursor[MAXB];
@@ -298,7 +308,7 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
     __syncthreads();
 
     K keys[KP_ITEMS];
-    const u32 vmask = kp_thread_kmers(s_codes, s_inval, k, mode, keys);
+    const u32 vmask = kp_suffix_filter(keys, kp_thread_kmers(s_codes, s_inval, k, mode, keys), sfx_mask, sfx_test);
     u32 total = 0;
 
     if (nb == 1) {
@@ -365,7 +375,8 @@ size_t kp_workspace_bytes(uint32_t bucket_bits) {
 }
 
 hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
-                                 uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st) {
+                                 uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st,
+                                 uint64_t sfx_mask, uint64_t sfx_test) {
   const uint32_t nb = 1u << bucket_bits;
   MGC_CHECK(hipMemsetAsync(d_bucket_counts, 0, sizeof(uint64_t) * nb, st));
   if (n_bases == 0) return hipSuccess;
@@ -374,17 +385,17 @@ hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint3
   if (k <= 32)
     hipLaunchKernelGGL(kmer_hist_kernel<u64>, dim3(grid), dim3(KP_BLOCK), 0, st,
                        d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
-                       reinterpret_cast<u64 *>(d_ws), reinterpret_cast<u64 *>(d_bucket_counts));
+                       reinterpret_cast<u64 *>(d_ws), reinterpret_cast<u64 *>(d_bucket_counts), (u64)sfx_mask, (u64)sfx_test);
   else
     hipLaunchKernelGGL(kmer_hist_kernel<K128>, dim3(grid), dim3(KP_BLOCK), 0, st,
                        d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
-                       reinterpret_cast<u64 *>(d_ws), reinterpret_cast<u64 *>(d_bucket_counts));
+                       reinterpret_cast<u64 *>(d_ws), reinterpret_cast<u64 *>(d_bucket_counts), (u64)sfx_mask, (u64)sfx_test);
   return hipGetLastError();
 }
 
 hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                                  uint32_t bucket_bits, const uint64_t *d_bucket_starts, void *d_keys,
-                                 void *d_ws, hipStream_t st) {
+                                 void *d_ws, hipStream_t st, uint64_t sfx_mask, uint64_t sfx_test) {
   if (n_bases == 0) return hipSuccess;
   const uint32_t nb = 1u << bucket_bits;
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
@@ -403,7 +414,7 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
 #define MGC_KP_LAUNCH(K_, MAXB_)                                                                                   \
   hipLaunchKernelGGL((kmer_partition_kernel<K_, MAXB_>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K_), st,      \
                      d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,                                  \
-                     reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys))
+                     reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys), (u64)sfx_mask, (u64)sfx_test)
   if (k <= 32) { if (nb <= 64) MGC_KP_LAUNCH(u64, 64); else MGC_KP_LAUNCH(u64, KP_MAX_BUCKETS); }
   else         { if (nb <= 64) MGC_KP_LAUNCH(K128, 64); else MGC_KP_LAUNCH(K128, KP_MAX_BUCKETS); }
 #undef MGC_KP_LAUNCH

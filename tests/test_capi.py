@@ -81,6 +81,14 @@ def test_error_codes_not_exit(native_lib):
     c2.k = 21
     assert not native_lib.mgc_open(ctypes.byref(c2), -1)
     assert b"mgc_configure_counting" in native_lib.mgc_last_error(None)
+    # count-suffix= is validated before any device work too (merylOp.H:139-147, merylOp-count.C:142-145)
+    for k, sfx, msg in ((21, "ACN", b"not ACGT"), (4, "AC", b"needs k >="), (31, "ACGT", b"simple mode"), (21, "A" * 33, b"count_suffix must hold")):
+        c3 = capi.configure(k, 1000, 1 << 30)
+        c3.count_suffix_length = len(sfx)
+        c3.count_suffix = sfx[:35].encode()
+        assert not native_lib.mgc_open(ctypes.byref(c3), -1) and msg in native_lib.mgc_last_error(None), (k, sfx, native_lib.mgc_last_error(None))
+    c4 = capi.configure(21, 1000, 1 << 30, count_suffix="ac")
+    assert c4.use_simple == 1 and c4.count_suffix_length == 2
     # argument checks of the device operators happen before any launch
     assert native_lib.mgc_dev_kmer_histogram(None, 10, 0, 0, 6, None, None, 0, None) == capi.MGC_EINVAL
     assert native_lib.mgc_dev_kmer_histogram(None, 10, 65, 0, 6, None, None, 0, None) == capi.MGC_EINVAL

@@ -48,6 +48,19 @@ def test_configure_only_narrative(meryl, tmp_path):
     assert [l for l in p.stderr.splitlines() if "Best Value!" in l][0].split()[0] == "18"
 
 
+def test_count_suffix_narrative(meryl, tmp_path):
+    fa = tmp_path / "r.fa"
+    fa.write_text(">a\n" + "ACGT" * 100 + "\n")
+    p = run(meryl, "-C", "k=12", "count", "count-suffix=AC", fa, "output", tmp_path / "db")
+    assert "12-mers with constant 2-mer suffix 'AC'" in p.stderr                        # merylOp-count.C:150
+    assert "-> 1048576 entries for counts up to 65535." in p.stderr                     # 4^(12-2), :124,152
+    assert re.search(r"Configured simple mode for \d+\.\d{3} GB memory per batch, and up to \d+ batch(es)?\.", p.stderr)
+    p = run(meryl, "k=12", "count-suffix=AC", "count", fa, "output", tmp_path / "db", check=False)
+    assert p.returncode == 1 and "needs a counting operation" in p.stderr               # merylCommandBuilder.C:271-272: top of the stack
+    p = run(meryl, "k=12", "count", "segment=1/2", fa, "output", tmp_path / "db", check=False)
+    assert p.returncode == 1 and "not supported" in p.stderr
+
+
 def test_grammar_errors(meryl, tmp_path):
     fa = tmp_path / "r.fa"
     fa.write_text(">a\nACGT\n")
@@ -204,3 +217,25 @@ def test_cli_counts_bam_sam_and_bgzipped_fastq(meryl, oracle_lib, tmp_path):
         lo, hi, cn = r.read_all()
         assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn) and r.info.num_total == wni, src.name
         r.close()
+
+
+@pytest.mark.gpu
+def test_cli_count_suffix_database(meryl, oracle_lib, tmp_path):
+    # count-suffix=GA: the database holds exactly the canonical 14-mers ending in GA, in the simple-mode geometry
+    # [file 6][blockPrefix][suffix][count-suffix] of merylOp-countSimple.C:172-175,231-233
+    from meryl_amd import db
+    bases = oracle_lib.synth_reads(41, 30_000, 0, 3000).tobytes()
+    fa = tmp_path / "r.fa"
+    fa.write_text("".join(">r%d\n%s\n" % (i, r) for i, r in enumerate(bases.decode().split(".")) if r))
+    out = tmp_path / "sfx.meryl"
+    p = run(meryl, "k=14", "memory=2", "threads=4", "count", "count-suffix=GA", fa, "output", out)
+    assert "Start counting with SIMPLE method." in p.stderr
+    _, wlo, wcn, _ = oracle_lib.count_brute(bases, 14)
+    keep = (wlo & np.uint64(15)) == np.uint64((3 << 2) | 0)                              # G=3, A=0
+    r = db.Reader(str(out))
+    lo, hi, cn = r.read_all()
+    assert np.array_equal(lo, wlo[keep]) and np.array_equal(cn, wcn[keep]) and r.info.num_total == int(wcn[keep].sum())
+    assert r.info.prefix_size == 6 + (28 - 4 - 6) - min(20, 28 - 4 - 6)
+    r.close()
+    lines = run(meryl, "-Q", "print", out).stdout.splitlines()
+    assert len(lines) == int(keep.sum()) and all(l.split("\t")[0].endswith("GA") for l in lines[:200])

@@ -439,6 +439,40 @@ def test_simple_mode_geometry(ops, oracle_lib, torch_cuda, tmp_path, k):
     r.close()
 
 
+@pytest.mark.parametrize("k,suffix", [(12, "T"), (21, "AC"), (23, "GATTA"), (40, "ACGTTGCAACGTTGCAACGT"), (36, "A" * 15 + "C")])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_count_suffix_filter(ops, oracle_lib, torch_cuda, k, suffix, mode):
+    # count-suffix=<bases> (merylOp-countSimple.C:50-58,88-93): the k-mer that is counted -- canonical, forward or
+    # reverse -- is kept only if it ends in the bases; geometry psbits = 2k - 2L - 6, wSuffix = min(20, psbits),
+    # wPrefix = 6 + psbits - wSuffix, and the block suffix carries the 2L constant bits at its end (:172-175,231-233).
+    # Expected = the oracle's unfiltered count with the same test applied to its k-mers.
+    from meryl_amd import capi
+    rng = np.random.default_rng(k)
+    reads = oracle_lib.synth_reads(k, 20_000, 0, 1500).tobytes().decode()
+    rc = suffix[::-1].translate(str.maketrans("ACGT", "TGCA"))                     # the reverse k-mer ends in the suffix where the read holds this
+    planted = ".".join("".join("ACGT"[i] for i in rng.integers(0, 4, 60)) + (suffix if j % 2 else rc) + "".join("ACGT"[i] for i in rng.integers(0, 4, 60))
+                       for j in range(400)) + "."
+    stream = reads + planted                                                      # long suffixes would otherwise never occur
+    cfg = capi.configure(k, len(stream), 1 << 30, mode, count_suffix=suffix)
+    assert cfg.use_simple == 1
+    with ops.Session(cfg) as s:
+        s.push_bases(stream, end_of_sequence=False)
+        s.count()
+        klo, khi, counts, _ = s.result_wide()
+        info = s.info()
+    whi, wlo, wcn, _ = oracle_lib.count_brute(stream, k, mode)
+    code = 0
+    for ch in suffix:
+        code = (code << 2) | "ACTG".index(ch)
+    L = len(suffix)
+    keep = (wlo & np.uint64((1 << (2 * L)) - 1)) == np.uint64(code)
+    assert keep.sum() > 0
+    assert np.array_equal(klo, wlo[keep]) and np.array_equal(khi, whi[keep]) and np.array_equal(counts, wcn[keep])
+    psbits = 2 * k - 2 * L - 6
+    assert (info.w_prefix, info.w_data) == (6 + psbits - min(20, psbits), min(20, psbits) + 2 * L)
+    assert info.n_instances == int(wcn[keep].sum())
+
+
 def test_sharded_path_single_rank(ops, oracle_lib, torch_cuda):
     """The multi-GPU routine (partition -> all_gather of file counts -> file-major exchange ->
     owner-side mgc_count_partitioned) on the HIP operators with a 1-rank NCCL(RCCL) group: the only
