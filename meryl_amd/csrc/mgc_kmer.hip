@@ -280,7 +280,7 @@ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 
 // MAXB: bucket capacity of the LDS tables (64 for the 64-file partition of the count path: 36 KiB of LDS per
 // workgroup instead of 51, i.e. four workgroups per CU instead of three; 1024 for the general operator)
 template <typename K, int MAXB>
-__global__ __launch_bounds__(KP_BLOCK, 5)
+__global__ __launch_bounds__(KP_BLOCK, (sizeof(K) == 16) ? 2 : 5)      // 16-byte keys: the 64 KiB exchange tile allows two workgroups
 void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
                            u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out, u64 sfx_mask, u64 sfx_test) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kp_dyn_smem[];
