@@ -124,6 +124,7 @@ struct BgzfSource {
       for (size_t i = t; i < blocks.size(); i += threads) {
         const Block &b = blocks[i];
         const unsigned char *p = raw.data() + b.src;
+        if (b.isize == 0) continue;                  // the EOF marker (and any other empty block): nothing to produce
         inflateReset(&z);
         z.next_in = const_cast<unsigned char *>(p + b.hdr);
         z.avail_in = (unsigned)(b.csize - b.hdr - 8);

@@ -193,3 +193,33 @@ def test_load_stream_is_the_sequences_with_breakers(native_lib, tmp_path, max_le
             got += buf.raw[:n.value]
         native_lib.msr_close(r)
         assert got == want, name
+
+
+def test_bgzf_oddities(native_lib, tmp_path, monkeypatch):
+    # other extra subfields before 'BC', empty (EOF-marker) blocks in the middle of a file, a file too short to hold a
+    # BGZF header, and an empty file: all read like the plain text
+    monkeypatch.setenv("MERYL_BGZF_THREADS", "3")
+    from test_seq import FASTA
+    want = [b"ACGTACGTNNacgt", b"TTTT", b"", b"GATTACA"]
+
+    def block_with_extra(data):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        cdata = c.compress(data) + c.flush()
+        extra = b"XY" + struct.pack("<H", 3) + b"abc"                          # a foreign subfield first
+        xlen = len(extra) + 6
+        bsize = 12 + xlen + len(cdata) + 8
+        return (struct.pack("<BBBBIBBH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, xlen) + extra + b"BC" + struct.pack("<HH", 2, bsize - 1) +
+                cdata + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+    t = FASTA.encode()
+    p = tmp_path / "odd.fa.gz"
+    p.write_bytes(block_with_extra(t[:10]) + bgzf_block(b"") + bgzf_block(t[10:30]) + bgzf_block(b"") + bgzf_block(b"") + block_with_extra(t[30:]) + bgzf_block(b""))
+    assert load_all(native_lib, str(p), 1 << 16) == want
+    tiny = tmp_path / "tiny.fa"
+    tiny.write_text(">a\nAC")
+    assert load_all(native_lib, str(tiny), 16) == [b"AC"]
+    empty = tmp_path / "empty.fa"
+    empty.write_bytes(b"")
+    assert load_all(native_lib, str(empty), 16) == []
+    only_eof = tmp_path / "only_eof.bam"                                        # a BGZF file of nothing but the EOF marker is not a BAM
+    only_eof.write_bytes(bgzf_block(b""))
+    assert not native_lib.msr_open(str(only_eof).encode()) and b"not a BAM" in native_lib.msr_last_error()
