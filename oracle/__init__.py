@@ -66,6 +66,10 @@ def lib():
                                   ctypes.POINTER(u64p), ctypes.POINTER(u64p), ctypes.POINTER(u32p),
                                   u64p, u64p]
     L.orc_count_brute.restype = ctypes.c_int
+    L.orc_count_brute_suffix.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p,
+                                         ctypes.POINTER(u64p), ctypes.POINTER(u64p), ctypes.POINTER(u32p),
+                                         u64p, u64p]
+    L.orc_count_brute_suffix.restype = ctypes.c_int
     L.orc_count_threaded_collect.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
                                              ctypes.c_uint32, ctypes.c_int,
                                              ctypes.POINTER(u64p), ctypes.POINTER(u64p), ctypes.POINTER(u32p),
@@ -122,8 +126,8 @@ def enumerate_kmers(bases, k, mode=CANONICAL):
     return hi, lo
 
 
-def count_brute(bases, k, mode=CANONICAL):
-    """Brute-force count -> (keys_hi, keys_lo, counts, n_instances)."""
+def count_brute(bases, k, mode=CANONICAL, count_suffix=""):
+    """Brute-force count -> (keys_hi, keys_lo, counts, n_instances); count_suffix: only k-mers ending in these bases."""
     b = _as_bytes(bases)
     L = lib()
     hi = ctypes.POINTER(ctypes.c_uint64)()
@@ -131,8 +135,12 @@ def count_brute(bases, k, mode=CANONICAL):
     cn = ctypes.POINTER(ctypes.c_uint32)()
     nd = ctypes.c_uint64(0)
     ni = ctypes.c_uint64(0)
-    rc = L.orc_count_brute(b, len(b), k, mode, ctypes.byref(hi), ctypes.byref(lo), ctypes.byref(cn),
-                           ctypes.byref(nd), ctypes.byref(ni))
+    if count_suffix:
+        rc = L.orc_count_brute_suffix(b, len(b), k, mode, count_suffix.encode("ascii"), ctypes.byref(hi), ctypes.byref(lo),
+                                      ctypes.byref(cn), ctypes.byref(nd), ctypes.byref(ni))
+    else:
+        rc = L.orc_count_brute(b, len(b), k, mode, ctypes.byref(hi), ctypes.byref(lo), ctypes.byref(cn),
+                               ctypes.byref(nd), ctypes.byref(ni))
     if rc != 0:
         raise RuntimeError("orc_count_brute failed rc=%d" % rc)
     # hi/lo were malloc'd with n_instances entries; only the first nd are meaningful

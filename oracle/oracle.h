@@ -52,6 +52,9 @@ uint64_t orc_enumerate_kmers(const char *bases, uint64_t n, uint32_t k, int mode
 int      orc_count_brute(const char *bases, uint64_t n, uint32_t k, int mode,
                          uint64_t **keys_hi, uint64_t **keys_lo, uint32_t **counts,
                          uint64_t *n_distinct, uint64_t *n_instances);
+int      orc_count_brute_suffix(const char *bases, uint64_t n, uint32_t k, int mode, const char *count_suffix,
+                                uint64_t **keys_hi, uint64_t **keys_lo, uint32_t **counts,
+                                uint64_t *n_distinct, uint64_t *n_instances);
 void     orc_free(void *p);
 
 /* Print form of `meryl print` (merylOp-nextMer.C:665-677): "%s\t%u\n". kmer -> ACTG string. */

@@ -49,8 +49,11 @@ static orc_kmdata kmer_mask(uint32_t k) {
  *   canonical = the numerically smaller (`fmer() < rmer()`, :245-246);
  *   count-forward keeps fmer, count-reverse keeps rmer (:241,248-258).
  * ---------------------------------------------------------------------- */
-uint64_t orc_enumerate_kmers(const char *bases, uint64_t n, uint32_t k, int mode,
-                             uint64_t *out_hi, uint64_t *out_lo, uint64_t cap) {
+/* count-suffix= (merylOp-countSimple.C:50-58, 88-93): with a non-zero mask, the k-mer that would be counted is skipped
+ * unless (kmer & suffix_mask) == suffix_test. */
+static uint64_t enumerate_filtered(const char *bases, uint64_t n, uint32_t k, int mode,
+                                   orc_kmdata suffix_mask, orc_kmdata suffix_test,
+                                   uint64_t *out_hi, uint64_t *out_lo, uint64_t cap) {
   if (k == 0 || k > 64) return 0;
 
   const orc_kmdata mask = kmer_mask(k);
@@ -75,6 +78,8 @@ uint64_t orc_enumerate_kmers(const char *bases, uint64_t n, uint32_t k, int mode
     else if (mode == ORC_REVERSE) m = r;
     else                          m = (f < r) ? f : r;
 
+    if ((m & suffix_mask) != suffix_test) continue;   /* merylOp-countSimple.C:88-90 (mask 0: keeps everything) */
+
     if (cnt < cap) {
       if (out_hi) out_hi[cnt] = (uint64_t)(m >> 64);
       if (out_lo) out_lo[cnt] = (uint64_t)m;
@@ -82,6 +87,11 @@ uint64_t orc_enumerate_kmers(const char *bases, uint64_t n, uint32_t k, int mode
     cnt++;
   }
   return cnt;
+}
+
+uint64_t orc_enumerate_kmers(const char *bases, uint64_t n, uint32_t k, int mode,
+                             uint64_t *out_hi, uint64_t *out_lo, uint64_t cap) {
+  return enumerate_filtered(bases, n, k, mode, 0, 0, out_hi, out_lo, cap);
 }
 
 static int cmp_kmdata(const void *a, const void *b) {
@@ -94,13 +104,14 @@ static int cmp_kmdata(const void *a, const void *b) {
  * scan runs).  Count arithmetic follows merylCountArray.C:345-360: a uint32
  * incremented once per instance, so it wraps mod 2^32.
  * ---------------------------------------------------------------------- */
-int orc_count_brute(const char *bases, uint64_t n, uint32_t k, int mode,
-                    uint64_t **keys_hi, uint64_t **keys_lo, uint32_t **counts,
-                    uint64_t *n_distinct, uint64_t *n_instances) {
+static int count_brute_filtered(const char *bases, uint64_t n, uint32_t k, int mode,
+                                orc_kmdata suffix_mask, orc_kmdata suffix_test,
+                                uint64_t **keys_hi, uint64_t **keys_lo, uint32_t **counts,
+                                uint64_t *n_distinct, uint64_t *n_instances) {
   *keys_hi = NULL; *keys_lo = NULL; *counts = NULL; *n_distinct = 0; *n_instances = 0;
   if (k == 0 || k > 64) return -1;
 
-  uint64_t ni = orc_enumerate_kmers(bases, n, k, mode, NULL, NULL, 0);
+  uint64_t ni = enumerate_filtered(bases, n, k, mode, suffix_mask, suffix_test, NULL, NULL, 0);
   *n_instances = ni;
   if (ni == 0) return 0;
 
@@ -109,7 +120,7 @@ int orc_count_brute(const char *bases, uint64_t n, uint32_t k, int mode,
   orc_kmdata *all = (orc_kmdata *)malloc(sizeof(orc_kmdata) * ni);
   if (!hi || !lo || !all) { free(hi); free(lo); free(all); return -2; }
 
-  orc_enumerate_kmers(bases, n, k, mode, hi, lo, ni);
+  enumerate_filtered(bases, n, k, mode, suffix_mask, suffix_test, hi, lo, ni);
   for (uint64_t i = 0; i < ni; i++)
     all[i] = ((orc_kmdata)hi[i] << 64) | lo[i];
 
@@ -137,6 +148,29 @@ int orc_count_brute(const char *bases, uint64_t n, uint32_t k, int mode,
 
   *keys_hi = hi; *keys_lo = lo; *counts = cn; *n_distinct = nd;
   return 0;
+}
+
+int orc_count_brute(const char *bases, uint64_t n, uint32_t k, int mode,
+                    uint64_t **keys_hi, uint64_t **keys_lo, uint32_t **counts,
+                    uint64_t *n_distinct, uint64_t *n_instances) {
+  return count_brute_filtered(bases, n, k, mode, 0, 0, keys_hi, keys_lo, counts, n_distinct, n_instances);
+}
+
+/* `count-suffix=<bases>`: merylOp.H:139-147 packs the string with kmerTiny::addR (2-bit codes, last base in the lowest
+ * bits), merylOp-countSimple.C:50-58 builds a mask of as many base pairs, :88-93 keeps a k-mer only if its low bits equal
+ * the packed string.  (The reference then strips those bits for its direct-index table and re-appends them on output,
+ * :92,231-233 -- the database holds the full k-mer either way.) */
+int orc_count_brute_suffix(const char *bases, uint64_t n, uint32_t k, int mode, const char *count_suffix,
+                           uint64_t **keys_hi, uint64_t **keys_lo, uint32_t **counts,
+                           uint64_t *n_distinct, uint64_t *n_instances) {
+  orc_kmdata mask = 0, test = 0;
+  for (const char *p = count_suffix; p && *p; p++) {
+    const int c = orc_base_code(*p);
+    if (c < 0) return -1;
+    test = (test << 2) | (orc_kmdata)c;
+    mask = (mask << 2) | 3;
+  }
+  return count_brute_filtered(bases, n, k, mode, mask, test, keys_hi, keys_lo, counts, n_distinct, n_instances);
 }
 
 void orc_free(void *p) { free(p); }

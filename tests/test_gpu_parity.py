@@ -445,7 +445,7 @@ def test_count_suffix_filter(ops, oracle_lib, torch_cuda, k, suffix, mode):
     # count-suffix=<bases> (merylOp-countSimple.C:50-58,88-93): the k-mer that is counted -- canonical, forward or
     # reverse -- is kept only if it ends in the bases; geometry psbits = 2k - 2L - 6, wSuffix = min(20, psbits),
     # wPrefix = 6 + psbits - wSuffix, and the block suffix carries the 2L constant bits at its end (:172-175,231-233).
-    # Expected = the oracle's unfiltered count with the same test applied to its k-mers.
+    # Expected = the oracle's restatement of the filter (orc_count_brute_suffix; cross-checked in tests/test_oracle.py).
     from meryl_amd import capi
     rng = np.random.default_rng(k)
     reads = oracle_lib.synth_reads(k, 20_000, 0, 1500).tobytes().decode()
@@ -460,17 +460,13 @@ def test_count_suffix_filter(ops, oracle_lib, torch_cuda, k, suffix, mode):
         s.count()
         klo, khi, counts, _ = s.result_wide()
         info = s.info()
-    whi, wlo, wcn, _ = oracle_lib.count_brute(stream, k, mode)
-    code = 0
-    for ch in suffix:
-        code = (code << 2) | "ACTG".index(ch)
+    whi, wlo, wcn, wni = oracle_lib.count_brute(stream, k, mode, suffix)           # the oracle's restatement of the filter
+    assert len(wlo) > 0
+    assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
     L = len(suffix)
-    keep = (wlo & np.uint64((1 << (2 * L)) - 1)) == np.uint64(code)
-    assert keep.sum() > 0
-    assert np.array_equal(klo, wlo[keep]) and np.array_equal(khi, whi[keep]) and np.array_equal(counts, wcn[keep])
     psbits = 2 * k - 2 * L - 6
     assert (info.w_prefix, info.w_data) == (6 + psbits - min(20, psbits), min(20, psbits) + 2 * L)
-    assert info.n_instances == int(wcn[keep].sum())
+    assert info.n_instances == wni
 
 
 def test_sharded_path_single_rank(ops, oracle_lib, torch_cuda):

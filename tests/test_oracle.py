@@ -42,6 +42,31 @@ def test_golden_cases(oracle_lib, case):
     assert pk == ek and pc == ec
 
 
+def test_count_suffix_restatement(oracle_lib):
+    # count-suffix=<bases> (merylOp.H:139-147, merylOp-countSimple.C:50-58,88-93): the k-mer being counted is kept only if
+    # it ends in the bases.  Hand-checkable: 4-mers of ACGTAC are ACGT, CGTA, GTAC; canonical (A<C<T<G): ACGT (its own
+    # reverse complement), CGTA vs TACG -> CGTA, GTAC (palindrome).  Ending in "AC": GTAC only; in "T": ACGT only.
+    hi, lo, cn, ni = oracle_lib.count_brute("ACGTAC.", 4, oracle_lib.CANONICAL, "AC")
+    assert [oracle_lib.kmer_to_string(h, l, 4) for h, l in zip(hi, lo)] == ["GTAC"] and list(cn) == [1] and ni == 1
+    hi, lo, cn, ni = oracle_lib.count_brute("ACGTAC.", 4, oracle_lib.CANONICAL, "T")
+    assert [oracle_lib.kmer_to_string(h, l, 4) for h, l in zip(hi, lo)] == ["ACGT"] and ni == 1
+    # forward keeps CGTA (ends in A), reverse keeps TACG's ... check against a filter of the unfiltered stream, all modes
+    rng = np.random.default_rng(3)
+    bases = random_reads(rng, 200, 30, 200)
+    for k, sfx in ((7, "G"), (21, "TC"), (40, "ACGTA")):
+        code = 0
+        for ch in sfx:
+            code = (code << 2) | "ACTG".index(ch)
+        for mode in (oracle_lib.CANONICAL, oracle_lib.FORWARD, oracle_lib.REVERSE):
+            ahi, alo, acn, _ = oracle_lib.count_brute(bases, k, mode)
+            keep = (alo & np.uint64((1 << (2 * len(sfx))) - 1)) == np.uint64(code)
+            fhi, flo, fcn, fni = oracle_lib.count_brute(bases, k, mode, sfx)
+            assert np.array_equal(fhi, ahi[keep]) and np.array_equal(flo, alo[keep]) and np.array_equal(fcn, acn[keep])
+            assert fni == int(acn[keep].sum()) and keep.sum() > 0
+    with pytest.raises(RuntimeError):
+        oracle_lib.count_brute("ACGT", 3, oracle_lib.CANONICAL, "AN")
+
+
 @pytest.mark.parametrize("k,wp", [(6, 6), (16, 10), (21, 10), (21, 14), (31, 12), (32, 10), (33, 10), (51, 12), (64, 10)])
 def test_port_equals_brute(oracle_lib, k, wp):
     # the reference-algorithm restatement (buckets, bit-packed store, std::sort, RLE,
