@@ -439,11 +439,50 @@ int sam_load_bases(msr_reader *r, char *seq, uint64_t max_length, uint64_t *seq_
 }
 }  // namespace
 
+namespace {
+// BAM records that sit whole in the read buffer are decoded straight from it (no per-field calls): returns the bytes
+// written to `out` (bases + one '.' per record); stops at a record that is not complete in the buffer or does not fit.
+uint64_t bam_fast_records(msr_reader *r, char *out, uint64_t room) {
+  static const struct Pairs16 {
+    uint16_t v[256];
+    Pairs16() {
+      for (int b = 0; b < 256; b++) {
+        const unsigned char two[2] = {(unsigned char)"=ACMGRSVTWYHKDBN"[b >> 4], (unsigned char)"=ACMGRSVTWYHKDBN"[b & 15]};
+        memcpy(&v[b], two, 2);
+      }
+    }
+  } pairs;
+  uint64_t w = 0;
+  while (r->len - r->pos >= 36) {
+    const unsigned char *p = r->buf + r->pos;
+    const uint64_t block_size = (uint64_t)p[0] | ((uint64_t)p[1] << 8) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 24);
+    if (block_size < 32 || r->len - r->pos < 4 + block_size) break;
+    const unsigned char *fix = p + 4;
+    const uint64_t l_read_name = fix[8], n_cigar = (uint64_t)fix[12] | ((uint64_t)fix[13] << 8);
+    const uint64_t l_seq = (uint64_t)fix[16] | ((uint64_t)fix[17] << 8) | ((uint64_t)fix[18] << 16) | ((uint64_t)fix[19] << 24);
+    const uint64_t before = 32 + l_read_name + 4 * n_cigar, packed = (l_seq + 1) / 2;
+    if (before + packed > block_size) break;         // corrupt: let the careful path report it
+    if (l_seq + 2 > room - w) break;                 // (one spare byte: the pair table writes two at a time)
+    const unsigned char *src = fix + before;
+    char *dst = out + w;
+    for (uint64_t i = 0; i < packed; i++) memcpy(dst + 2 * i, &pairs.v[src[i]], 2);
+    w += l_seq;
+    out[w++] = '.';
+    r->pos += 4 + block_size;
+  }
+  return w;
+}
+}  // namespace
+
 extern "C" int msr_load_stream(msr_reader *r, char *buf, uint64_t max_length, uint64_t *length) {
   if (!r || !buf || !length || max_length < 2) return -1;
   uint64_t out = 0;
   *length = 0;
   while (out + 1 < max_length) {                     // room for at least one base and its breaker
+    if (r->format == MSR_FORMAT_BAM && r->bam_header_done && !r->in_sequence) {
+      out += bam_fast_records(r, buf + out, max_length - out);
+      if (out + 1 >= max_length) break;
+    }
     uint64_t n = 0;
     int eos = 0;
     const int rc = msr_load_bases(r, buf + out, max_length - out - 1, &n, &eos);
