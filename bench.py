@@ -113,8 +113,6 @@ def main():
         print("bench.py needs a GPU (no CPU fallback exists for the count path)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
-    build.build()
-    capi.lib()
 
     # MGC_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (partition -> exchange waves -> owner-side count) even
     # with a single rank, so that it can be exercised on a 1-GPU box
@@ -125,6 +123,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    # the in-tree library is normally up to date (it travels with the snapshot); if it has to be rebuilt, one rank does it
+    if local_rank == 0:
+        build.build()
+    if dist is not None:
+        dist.barrier()
+    capi.lib()
 
     def barrier():
         if dist is not None:

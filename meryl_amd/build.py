@@ -51,12 +51,13 @@ def build_cli(force=False, verbose=False):
         return CLI
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
-    cmd = [hipcc(), "-O2", "-std=c++17", "-pthread", src, "-o", CLI + ".tmp", "-L" + HERE, "-lmeryl_gpu_count",
+    tmp = "%s.tmp%d" % (CLI, os.getpid())             # several ranks may build at once: private file, atomic rename
+    cmd = [hipcc(), "-O2", "-std=c++17", "-pthread", src, "-o", tmp, "-L" + HERE, "-lmeryl_gpu_count",
            "-Wl,-rpath,$ORIGIN/..", "-L" + rocm_lib, "-lamdhip64", "-Wl,-rpath," + rocm_lib, "-lz"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(CLI + ".tmp", CLI)
+    os.replace(tmp, CLI)
     return CLI
 
 
@@ -66,11 +67,12 @@ def build(force=False, verbose=False):
         build_cli(False, verbose)
         return LIB
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [hipcc()] + FLAGS + ["-o", LIB + ".tmp"] + srcs + ["-lz"]
+    tmp = "%s.tmp%d" % (LIB, os.getpid())
+    cmd = [hipcc()] + FLAGS + ["-o", tmp] + srcs + ["-lz"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(tmp, LIB)
     build_cli(True, verbose)
     return LIB
 
