@@ -169,7 +169,7 @@ struct BgzfSource {
     size_t got = 0;
     while (got < n) {
       if (out_pos == out.size()) {
-        if (!advance_batch()) return err.empty() ? (int64_t)got : -1;
+        if (!advance_batch()) return got ? (int64_t)got : (err.empty() ? 0 : -1);   // what was read is delivered first
         if (out.empty()) continue;                 // a batch of empty blocks (the EOF marker)
       }
       const size_t take = std::min(n - got, out.size() - out_pos);
@@ -200,10 +200,36 @@ struct msr_reader {
   uint64_t    rec_skip = 0;          // bytes of the record after its sequence
   int         sam_field = 0;         // SAM: column of the next byte (0-based)
 
+  bool        failed = false;        // the byte source reported an error (as opposed to its end)
+  std::string failure;
+  bool        pipe_done = false;
+
+  // up to n bytes; 0 at the end of the input, -1 on a read / decompression error (failure says which)
   int64_t source_read(void *dst, size_t n) {
-    if (bgzf) return bgzf->read(dst, n);
-    if (pipe) { const size_t got = fread(dst, 1, n, pipe); return (got == 0 && ferror(pipe)) ? -1 : (int64_t)got; }
+    if (bgzf) {
+      const int64_t got = bgzf->read(dst, n);
+      if (got < 0) { failed = true; failure = bgzf->err; }
+      return got;
+    }
+    if (pipe_done) return 0;
+    if (pipe) {
+      const size_t got = fread(dst, 1, n, pipe);
+      if (got) return (int64_t)got;
+      const bool rd_err = ferror(pipe) != 0;
+      const int status = pclose(pipe);               // the decompressor's verdict on the file
+      pipe = nullptr; pipe_done = true;
+      if (rd_err || status != 0) { failed = true; failure = "the decompressor failed (corrupt or truncated file)"; return -1; }
+      return 0;
+    }
     const int got = gzread(gz, dst, (unsigned)(n > (1u << 30) ? (1u << 30) : n));
+    if (got <= 0) {                                  // end of file, or a stream that ended early / is damaged
+      int en = Z_OK;
+      const char *msg = gzerror(gz, &en);
+      if (got < 0 || (en != Z_OK && en != Z_STREAM_END)) {
+        failed = true; failure = std::string("zlib: ") + (msg && *msg ? msg : "read error");
+        return -1;
+      }
+    }
     return got;
   }
 
@@ -286,7 +312,7 @@ extern "C" msr_reader *msr_open(const char *name) {
   }
   // what is in it: BAM by its magic, SAM by its name or an @HD line, everything else is FASTA/FASTQ text
   r->peek();
-  if (r->bgzf && !r->bgzf->err.empty()) { seq_err("msr_open: '" + n + "': " + r->bgzf->err); msr_close(r); return nullptr; }
+  if (r->failed) { seq_err("msr_open: '" + n + "': " + r->failure); msr_close(r); return nullptr; }
   const size_t have = r->len - r->pos;
   if (have >= 4 && memcmp(r->buf + r->pos, "BAM\1", 4) == 0) r->format = MSR_FORMAT_BAM;
   else if (ends_with(n, ".sam") || ends_with(n, ".sam.gz") || (have >= 4 && memcmp(r->buf + r->pos, "@HD\t", 4) == 0)) r->format = MSR_FORMAT_SAM;
@@ -320,7 +346,7 @@ extern "C" int64_t msr_read_text(msr_reader *r, char *buf, uint64_t max_length) 
   }
   while (got < max_length && !r->eof) {
     const int64_t n = r->source_read(buf + got, max_length - got);
-    if (n < 0) { seq_err("msr_read_text: read error in '" + r->name + "'" + (r->bgzf ? ": " + r->bgzf->err : std::string())); return -1; }
+    if (n < 0) { seq_err("msr_read_text: read error in '" + r->name + "': " + r->failure); return -1; }
     if (n == 0) { r->eof = true; break; }
     got += (uint64_t)n;
   }
@@ -357,7 +383,7 @@ int bam_load_bases(msr_reader *r, char *seq, uint64_t max_length, uint64_t *seq_
     r->bam_header_done = true;
   }
   if (!r->in_sequence) {                             // start of a record
-    if (r->peek() < 0) return (r->bgzf && !r->bgzf->err.empty()) ? bad(r->bgzf->err.c_str()) : 0;
+    if (r->peek() < 0) return r->failed ? bad(r->failure.c_str()) : 0;
     uint32_t block_size;
     unsigned char fix[32];
     if (!r->get_u32(&block_size) || block_size < 32 || !r->get_bytes(fix, 32)) return bad("truncated BAM record");
@@ -411,6 +437,7 @@ int sam_load_bases(msr_reader *r, char *seq, uint64_t max_length, uint64_t *seq_
   for (;;) {
     const int c = r->peek();
     if (c < 0) {
+      if (r->failed) { seq_err("msr_load_bases: '" + r->name + "': " + r->failure); return -2; }
       if (r->in_sequence) { r->in_sequence = false; *seq_length = out; *end_of_sequence = 1; return 1; }
       return 0;
     }
@@ -506,6 +533,7 @@ extern "C" int msr_load_bases(msr_reader *r, char *seq, uint64_t max_length, uin
   for (;;) {
     const int c = r->peek();
     if (c < 0) {                                     // end of input
+      if (r->failed) { seq_err("msr_load_bases: '" + r->name + "': " + r->failure); return -2; }
       if (r->in_sequence) { r->in_sequence = false; *seq_length = out; *end_of_sequence = 1; return 1; }
       return 0;
     }

@@ -90,3 +90,41 @@ def test_bz2_and_xz_through_the_system_decompressors(native_lib, tmp_path, max_l
     r = native_lib.msr_open(str(x).encode())
     assert r and native_lib.msr_is_compressed(r) == 1 and native_lib.msr_format(r) == 0
     native_lib.msr_close(r)
+
+
+def _drain(lib, path):
+    """-> (number of sequences delivered, rc of the last call) ; rc < 0 = the loader reported an error"""
+    r = lib.msr_open(path.encode())
+    if not r:
+        return 0, -1
+    buf = ctypes.create_string_buffer(1 << 16)
+    n, eos = ctypes.c_uint64(0), ctypes.c_int(0)
+    seqs, rc = 0, 1
+    while rc > 0:
+        rc = lib.msr_load_bases(r, buf, 1 << 16, ctypes.byref(n), ctypes.byref(eos))
+        seqs += 1 if (rc > 0 and eos.value) else 0
+    lib.msr_close(r)
+    return seqs, rc
+
+
+def test_damaged_compressed_inputs_are_errors_not_short_files(native_lib, tmp_path):
+    # a .gz that stops in the middle of its stream, a .bz2 with a flipped byte: the loader must say so -- ending the
+    # input quietly would count fewer k-mers than the file holds
+    import bz2, random, shutil
+    rng = random.Random(1)
+    text = "".join(">r%d\n%s\n" % (i, "".join(rng.choice("ACGT") for _ in range(200))) for i in range(5000))
+    whole = tmp_path / "whole.fa.gz"
+    with gzip.open(whole, "wt") as f:
+        f.write(text)
+    assert _drain(native_lib, str(whole)) == (5000, 0)
+    cut = tmp_path / "cut.fa.gz"
+    cut.write_bytes(whole.read_bytes()[:whole.stat().st_size // 2])
+    seqs, rc = _drain(native_lib, str(cut))
+    assert rc < 0 and seqs < 5000 and b"cut.fa.gz" in native_lib.msr_last_error()
+    if shutil.which("bzip2"):
+        raw = bytearray(bz2.compress(text.encode()))
+        raw[len(raw) // 2] ^= 0xff
+        bad = tmp_path / "bad.fa.bz2"
+        bad.write_bytes(bytes(raw))
+        seqs, rc = _drain(native_lib, str(bad))
+        assert rc < 0 and b"bad.fa.bz2" in native_lib.msr_last_error()

@@ -223,3 +223,17 @@ def test_bgzf_oddities(native_lib, tmp_path, monkeypatch):
     only_eof = tmp_path / "only_eof.bam"                                        # a BGZF file of nothing but the EOF marker is not a BAM
     only_eof.write_bytes(bgzf_block(b""))
     assert not native_lib.msr_open(str(only_eof).encode()) and b"not a BAM" in native_lib.msr_last_error()
+
+
+def test_bgzf_damage_deep_inside_a_file_is_an_error(native_lib, tmp_path, monkeypatch):
+    # more than one batch of blocks, the damage in a later one: the sequences before it arrive, then the loader reports it
+    monkeypatch.setenv("MERYL_BGZF_THREADS", "4")
+    rng = random.Random(2)
+    text = "".join(">r%d\n%s\n" % (i, "".join(rng.choice("ACGT") for _ in range(300))) for i in range(4000))
+    raw = bytearray(bgzf(text.encode(), 1000))                                  # ~1300 blocks: three batches of 512
+    raw[len(raw) * 4 // 5] ^= 0x3c
+    p = tmp_path / "late_damage.fa.gz"
+    p.write_bytes(bytes(raw))
+    from test_seq import _drain
+    seqs, rc = _drain(native_lib, str(p))
+    assert rc < 0 and 0 < seqs < 4000 and b"late_damage" in native_lib.msr_last_error()
