@@ -237,3 +237,37 @@ def test_bgzf_damage_deep_inside_a_file_is_an_error(native_lib, tmp_path, monkey
     from test_seq import _drain
     seqs, rc = _drain(native_lib, str(p))
     assert rc < 0 and 0 < seqs < 4000 and b"late_damage" in native_lib.msr_last_error()
+
+
+def test_bam_reader_survives_corrupt_payloads(native_lib, tmp_path, monkeypatch):
+    # bit flips and truncations INSIDE the BAM payload (the BGZF wrapping stays valid, so they reach the record decoder):
+    # whatever happens -- an error, fewer or odd sequences -- the loader must come back, and never hand out more bases
+    # than it was given room for
+    monkeypatch.setenv("MERYL_BGZF_THREADS", "2")
+    rng = random.Random(11)
+    good = bam_bytes(random_records(120, 4, longest=120))
+    for trial in range(150):
+        b = bytearray(good)
+        for _ in range(rng.randrange(1, 6)):
+            i = rng.randrange(len(b))
+            b[i] ^= 1 << rng.randrange(8)
+        if trial % 5 == 0:
+            b = b[:rng.randrange(8, len(b))]
+        p = tmp_path / "fuzz.bam"
+        p.write_bytes(bgzf(bytes(b), rng.choice([200, 4000, 0xff00])))
+        r = native_lib.msr_open(str(p).encode())
+        if not r:
+            continue
+        room = rng.choice([2, 17, 4096])
+        buf = ctypes.create_string_buffer(room + 8)
+        n = ctypes.c_uint64(0)
+        calls = 0
+        while calls < 100000:
+            buf.raw = b"\xa5" * (room + 8)
+            rc = native_lib.msr_load_stream(r, buf, room, ctypes.byref(n))
+            calls += 1
+            assert n.value <= room and buf.raw[room:] == b"\xa5" * 8          # nothing written past the room given
+            if rc <= 0:
+                break
+        native_lib.msr_close(r)
+        assert calls < 100000
