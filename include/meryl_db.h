@@ -36,12 +36,44 @@ struct mgc_session;
  * geometry (merylFileWriter::initialize(wPrefix), countThreads.C:404). */
 mdb_writer *mdb_writer_open(const char *path, uint32_t k, uint32_t w_prefix);
 
+/* The same with two extensions:
+ *  label_size  bits of label stored per k-mer (0..64; 0 = none: the bytes written are then exactly the unlabelled ones).
+ *              meryl2 sets it with the global `-l <bits>` (src/meryl2/merylGlobals.C:75-77) and its count hands ONE constant
+ *              label to the writer at dump time: addCountedBlock(prefix, nKmers, suffix, counts, labels=nullptr, label)
+ *              (src/meryl2/merylCountArray.C:469-471, src/meryl2/merylOp-countThreads.C:363-367,464-468).
+ *  part / n_parts  a database written by several writers, one per rank of a sharded (multi-GPU) count: writer `part`
+ *              receives the blocks of a contiguous prefix range (ranges ascend with `part`; a range may begin or end in
+ *              the middle of a file).  It writes `0xBBBBBB.merylData.part<part>` files and a side file; once every part
+ *              is closed, ONE caller runs mdb_merge_parts, which stitches the data files (rename when a file has one
+ *              contributor, append otherwise), and writes the 64 per-file indexes and the master index.  The resulting
+ *              directory is byte-identical to what a single writer fed the same blocks produces.  n_parts = 1, part = 0
+ *              is the plain writer. */
+mdb_writer *mdb_writer_open_ex(const char *path, uint32_t k, uint32_t w_prefix, uint32_t label_size,
+                               uint32_t part, uint32_t n_parts);
+int mdb_merge_parts(const char *path, uint32_t n_parts);
+
 /* merylBlockWriter::addBlock.  May be called concurrently from several threads
  * as long as each FILE (prefix >> (w_prefix-6)) is fed by one thread with
  * ascending prefixes -- the reference's convention (countThreads.C:452-459).
  * suffix_hi may be NULL when 2k - w_prefix <= 64.  Arrays are not retained. */
 int mdb_writer_add_block(mdb_writer *w, uint64_t prefix, uint64_t n_kmers,
                          const uint64_t *suffix_lo, const uint64_t *suffix_hi, const uint32_t *counts);
+
+/* merylBlockWriter::addCountedBlock of meryl2 (src/meryl2/merylCountArray.C:469-471): per-k-mer labels, or -- labels ==
+ * NULL -- the one constant `label` for every k-mer of the block.  Only the low label_size bits are stored. */
+int mdb_writer_add_block_labelled(mdb_writer *w, uint64_t prefix, uint64_t n_kmers,
+                                  const uint64_t *suffix_lo, const uint64_t *suffix_hi, const uint32_t *counts,
+                                  const uint64_t *labels, uint64_t label);
+
+/* Blocks that are already encoded (the device encoder behind mgc_write_database): `nbytes` bytes of data file ff holding
+ * the blocks `entries` list (prefixes ascending and after everything file ff has received so far; entries[i].position
+ * is the block's offset inside `bytes`); bytes before the first entry -- or all of them when n_entries is 0 -- continue
+ * the block the previous call ended in (a block larger than the caller's copy buffer arrives in pieces).  Same threading rule as mdb_writer_add_block (one thread per file).  The value
+ * histogram of such blocks is handed over separately, once or in pieces: (value, occurrences) pairs. */
+typedef struct mdb_index_entry { uint64_t prefix, position, n_kmers; } mdb_index_entry;
+int mdb_writer_add_encoded(mdb_writer *w, uint32_t ff, const void *bytes, uint64_t nbytes,
+                           const mdb_index_entry *entries, uint64_t n_entries);
+int mdb_writer_add_histogram(mdb_writer *w, const uint64_t *values, const uint64_t *occurrences, uint64_t n_pairs);
 
 /* merylBlockWriter::finish() + ~merylFileWriter(): per-file indexes, master
  * index with the value histogram.  Frees the writer.  0 on success. */
@@ -54,6 +86,8 @@ typedef struct mdb_info {
   uint32_t prefix_size, suffix_size, num_files_bits, num_blocks_bits, flags;
   uint64_t num_unique, num_distinct, num_total;   /* histogram header */
   uint64_t hist_len;                              /* number of (value, occurrences) pairs */
+  uint32_t label_size;                            /* bits of label per k-mer (flags bits 8..15) */
+  uint32_t reserved;
 } mdb_info;
 
 mdb_reader *mdb_reader_open(const char *path);
@@ -64,12 +98,64 @@ int  mdb_reader_histogram(const mdb_reader *r, uint64_t *values, uint64_t *occur
  * Arrays are malloc'd; release with mdb_free.  keys_hi is NULL-filled (zeros) for k <= 32. */
 int  mdb_reader_read_file(mdb_reader *r, uint32_t ff, uint64_t **keys_lo, uint64_t **keys_hi,
                           uint32_t **counts, uint64_t *n_kmers);
+/* ... and their labels (zeros when the database stores none); labels may be NULL. */
+int  mdb_reader_read_file_ex(mdb_reader *r, uint32_t ff, uint64_t **keys_lo, uint64_t **keys_hi,
+                             uint32_t **counts, uint64_t **labels, uint64_t *n_kmers);
+/* The per-file index (1 << num_blocks_bits entries) and the header of the block at a data-file position: what
+ * `meryl dumpFile` prints (src/meryl/meryl.C:41-45; shape documentation/source/usage.rst:24-45). */
+typedef struct mdb_block_header {
+  uint64_t prefix, n_kmers;
+  uint32_t k_code, unary_bits, binary_bits, c_code;
+  uint64_t k1, c1, c2;
+} mdb_block_header;
+int  mdb_reader_file_index(mdb_reader *r, uint32_t ff, mdb_index_entry *entries);
+int  mdb_reader_block_header(mdb_reader *r, uint32_t ff, uint64_t position, mdb_block_header *h);
+/* One block decoded the way dumpFile lists it: for k-mer i the unary prefix delta, the accumulated top part, the two
+ * halves of the binary remainder and the value; arrays of n_kmers entries, malloc'd (mdb_free). */
+int  mdb_reader_read_block_raw(mdb_reader *r, uint32_t ff, uint64_t position, mdb_block_header *h,
+                               uint64_t **prefix_delta, uint64_t **top, uint64_t **rem_hi, uint64_t **rem_lo,
+                               uint32_t **values);
 void mdb_reader_close(mdb_reader *r);
 void mdb_free(void *p);
 
-/* Count result -> database directory: mgc_finish() feeding mdb_writer_add_block
- * from `host_threads` threads, then mdb_writer_close. */
+/* ------------------------------------------------------------------------
+ * Device-resident (k-mer, count) streams -> database files, encoded ON THE DEVICE
+ * (meryl_amd/csrc/mgc_encode.hip) -- the MI355X replacement of the 64 host threads that run
+ * countKmers + dumpCountedKmers -> merylBlockWriter::addBlock per file
+ * (src/meryl/merylOp-countThreads.C:452-459, src/meryl/merylCountArray.C:472-475): the host only copies finished
+ * file bytes out of HBM through pinned buffers and writes them.
+ *
+ * A stream is one writer (or one part of a sharded database, see mdb_writer_open_ex) fed with ascending,
+ * non-overlapping prefix ranges.  mgc_db_stream_write queues one range: d_keys/d_counts are DEVICE pointers to the
+ * n distinct k-mers (uint64, or {lo,hi} pairs for k > 32; ascending) whose prefixes lie in [prefix_begin, prefix_end)
+ * and their counts; every prefix of the range gets its block, empty ones included.  The call returns once the range
+ * is planned; encoding, the device-to-host copies and the file writes run on the stream's own threads, so the
+ * caller can go on counting (a sharded count writes the buckets of wave i while wave i+1 is exchanged and counted).
+ * The buffers must stay valid and unchanged until mgc_db_stream_sync or mgc_db_stream_close returns.
+ * Errors are sticky: the first one is returned by every later call; mgc_db_stream_error gives the text. */
+typedef struct mgc_db_stream mgc_db_stream;
+typedef struct mgc_db_write_profile {
+  double   plan_ms;        /* block offsets + sizes + histogram kernels, planning */
+  double   encode_ms;      /* device encode kernels (HIP events) */
+  double   copy_write_s;   /* wall clock of device-to-host copies + file writes (overlapped with each other) */
+  double   total_s;        /* open -> close */
+  uint64_t data_bytes;     /* bytes of .merylData written */
+  uint64_t n_kmers, n_blocks;
+} mgc_db_write_profile;
+mgc_db_stream *mgc_db_stream_open(const char *path, uint32_t k, uint32_t w_prefix, uint32_t label_size, uint64_t label,
+                                  uint32_t part, uint32_t n_parts, int host_threads, int device);
+int  mgc_db_stream_write(mgc_db_stream *d, const void *d_keys, const uint32_t *d_counts, uint64_t n,
+                         uint64_t prefix_begin, uint64_t prefix_end);
+int  mgc_db_stream_sync(mgc_db_stream *d);
+/* Waits for everything queued, closes the writer (a part: its side file; the plain writer: indexes + master index)
+ * and frees the stream.  prof may be NULL. */
+int  mgc_db_stream_close(mgc_db_stream *d, mgc_db_write_profile *prof);
+const char *mgc_db_stream_error(const mgc_db_stream *d);      /* d may be NULL: last open error of this thread */
+
+/* Count result of a session -> database directory, through a device stream (results that live in HBM; host_threads
+ * file-writer threads).  prof may be NULL. */
 int mgc_write_database(struct mgc_session *s, const char *path, int host_threads);
+int mgc_write_database_profiled(struct mgc_session *s, const char *path, int host_threads, mgc_db_write_profile *prof);
 
 #ifdef __cplusplus
 }

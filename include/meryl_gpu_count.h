@@ -84,6 +84,14 @@ typedef struct mgc_count_config {
                                       only k-mers -- the canonical / forward / reverse one that is counted -- ENDING in these
                                       bases are counted (merylOp-countSimple.C:50-58,88-93); count_suffix_length of them,
                                       NUL-terminated; needs k - length >= 3 */
+  /* in: value-labelled k-mers (meryl2).  The count hands ONE constant label to the writer when it dumps a block:
+   * addCountedBlock(prefix, nKmers, suffix, counts, labels = nullptr, label = _lConstant)
+   * (src/meryl2/merylCountArray.C:469-471, src/meryl2/merylOp-countThreads.C:363-367,464-468; `label=#<n>` sets it,
+   * src/meryl2/merylCommandBuilder-isAssign.C:124; the global `-l <bits>` fixes the width, src/meryl2/merylGlobals.C:75-77).
+   * label_size = 0: unlabelled (meryl v1 behaviour). */
+  uint32_t label_size;            /* bits of label per k-mer, 0..64 */
+  uint32_t reserved0;
+  uint64_t label_constant;
 } mgc_count_config;
 
 int mgc_configure_counting(mgc_count_config *cfg);
@@ -265,6 +273,13 @@ typedef int (*mgc_block_cb)(void *ctx, uint64_t prefix, uint64_t n_kmers,
                             const uint64_t *suffix_lo, const uint64_t *suffix_hi,
                             const uint32_t *counts);
 int mgc_finish(mgc_session *s, mgc_block_cb cb, void *ctx, int host_threads);
+
+/* The same in meryl2's addCountedBlock convention (src/meryl2/merylCountArray.C:469-471): `labels` is NULL and
+ * `label` is the session's constant label (cfg.label_constant) for every k-mer of the block. */
+typedef int (*mgc_block_cb2)(void *ctx, uint64_t prefix, uint64_t n_kmers,
+                             const uint64_t *suffix_lo, const uint64_t *suffix_hi,
+                             const uint32_t *counts, const uint64_t *labels, uint64_t label);
+int mgc_finish_labelled(mgc_session *s, mgc_block_cb2 cb, void *ctx, int host_threads);
 
 /* Per-stage device timings of the last mgc_count (HIP events on the session's
  * stream).  Enable before mgc_count. */

@@ -14,14 +14,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmeryl_gpu_count.so")
 SOURCES = ["mgc_kmer.hip", "mgc_sort.hip", "mgc_scan.hip", "mgc_finish.hip", "mgc_misc.hip", "mgc_parse.hip",
-           "mgc_api.cpp", "meryl_db.cpp", "meryl_seq.cpp"]
-HEADERS = ["mgc_device.h", os.path.join("..", "..", "include", "meryl_gpu_count.h"),
+           "mgc_encode.hip", "mgc_merge.hip",
+           "mgc_api.cpp", "mgc_stream.cpp", "meryl_db.cpp", "meryl_seq.cpp"]
+HEADERS = ["mgc_device.h", "mgc_common.hpp", "mdb_layout.h", "mgc_session.hpp",
+           os.path.join("..", "..", "include", "meryl_gpu_count.h"),
            os.path.join("..", "..", "include", "meryl_db.h"), os.path.join("..", "..", "include", "meryl_seq.h")]
+OBJDIR = os.path.join(HERE, "build")
 # -no-hip-rt: the library carries no DT_NEEDED on a particular libamdhip64; it binds to the
 # HIP runtime already in the process (torch's bundled one under Python -- two HIP/HSA runtimes
 # in one process cannot share streams or ordering -- or /opt/rocm's for the standalone CLI).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-no-hip-rt",
-         "-Wall", "-Wno-unused-function"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function"]
+LFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-no-hip-rt"]
 
 
 def hipcc():
@@ -31,13 +34,36 @@ def hipcc():
     raise RuntimeError("hipcc not found: the native library cannot be built")
 
 
+def _sources():
+    return [f for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+
+
+def _header_mtime():
+    deps = [os.path.join(CSRC, f) for f in HEADERS if os.path.exists(os.path.join(CSRC, f))]
+    deps.append(os.path.abspath(__file__))
+    return max(os.path.getmtime(d) for d in deps)
+
+
+def _obj(f):
+    return os.path.join(OBJDIR, f + ".o")
+
+
+def _stale_objects(force=False):
+    """sources whose object is missing or older than the source / any header"""
+    ht = _header_mtime()
+    out = []
+    for f in _sources():
+        o = _obj(f)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(os.path.join(CSRC, f)), ht):
+            out.append(f)
+    return out
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or _stale_objects():
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS if os.path.exists(os.path.join(CSRC, f))]
-    deps.append(os.path.abspath(__file__))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(_obj(f)) > t for f in _sources())
 
 
 CLI = os.path.join(HERE, "bin", "meryl")
@@ -62,13 +88,30 @@ def build_cli(force=False, verbose=False):
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP/C++ source into libmeryl_gpu_count.so (and the CLI).  Returns the library path."""
+    """Compile every HIP/C++ source for gfx950 (one object per source, rebuilt only when the source or a
+    header changed, in parallel) and link libmeryl_gpu_count.so (and the CLI).  Returns the library path."""
     if not force and not _stale():
         build_cli(False, verbose)
         return LIB
-    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    os.makedirs(OBJDIR, exist_ok=True)
+    todo = _stale_objects(force)
+    procs = []
+    for f in todo:
+        tmp = "%s.tmp%d" % (_obj(f), os.getpid())
+        cmd = [hipcc()] + CFLAGS + ["-c", os.path.join(CSRC, f), "-o", tmp]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((f, tmp, cmd, subprocess.Popen(cmd)))
+    failed = []
+    for f, tmp, cmd, p in procs:
+        if p.wait() != 0:
+            failed.append(f)
+        else:
+            os.replace(tmp, _obj(f))
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
     tmp = "%s.tmp%d" % (LIB, os.getpid())
-    cmd = [hipcc()] + FLAGS + ["-o", tmp] + srcs + ["-lz"]
+    cmd = [hipcc()] + LFLAGS + ["-o", tmp] + [_obj(f) for f in _sources()] + ["-lz"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

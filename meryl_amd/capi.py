@@ -22,13 +22,16 @@ SYMBOLS = (
     "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort",
     "mgc_dev_rle_workspace_bytes", "mgc_dev_rle_count", "mgc_dev_rle_emit", "mgc_dev_block_offsets",
     "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_copy_result_device",
-    "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish",
+    "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish", "mgc_finish_labelled",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_dev_synth_reads_ex", "mgc_version",
     "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases",
     # include/meryl_db.h
-    "mdb_writer_open", "mdb_writer_add_block", "mdb_writer_close", "mdb_last_error",
-    "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_close",
-    "mdb_free", "mgc_write_database",
+    "mdb_writer_open", "mdb_writer_open_ex", "mdb_merge_parts", "mdb_writer_add_block", "mdb_writer_add_block_labelled",
+    "mdb_writer_add_encoded", "mdb_writer_add_histogram", "mdb_writer_close", "mdb_last_error",
+    "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_read_file_ex",
+    "mdb_reader_file_index", "mdb_reader_block_header", "mdb_reader_read_block_raw", "mdb_reader_close",
+    "mdb_free", "mgc_write_database", "mgc_write_database_profiled",
+    "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error",
     # include/meryl_seq.h
     "msr_open", "msr_read_text", "msr_close", "msr_last_error", "msr_load_bases", "msr_load_stream", "msr_format", "msr_is_compressed", "msr_guess_number_of_kmers",
 )
@@ -52,6 +55,9 @@ class CountConfig(ctypes.Structure):
         ("n_batches", ctypes.c_uint32),
         ("memory_used", ctypes.c_uint64),
         ("count_suffix", ctypes.c_char * 36),
+        ("label_size", ctypes.c_uint32),
+        ("reserved0", ctypes.c_uint32),
+        ("label_constant", ctypes.c_uint64),
     ]
 
 
@@ -90,9 +96,39 @@ class DbInfo(ctypes.Structure):
         ("num_distinct", ctypes.c_uint64),
         ("num_total", ctypes.c_uint64),
         ("hist_len", ctypes.c_uint64),
+        ("label_size", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
     ]
 
 
+class DbWriteProfile(ctypes.Structure):
+    _fields_ = [
+        ("plan_ms", ctypes.c_double),
+        ("encode_ms", ctypes.c_double),
+        ("copy_write_s", ctypes.c_double),
+        ("total_s", ctypes.c_double),
+        ("data_bytes", ctypes.c_uint64),
+        ("n_kmers", ctypes.c_uint64),
+        ("n_blocks", ctypes.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class IndexEntry(ctypes.Structure):
+    _fields_ = [("prefix", ctypes.c_uint64), ("position", ctypes.c_uint64), ("n_kmers", ctypes.c_uint64)]
+
+
+class BlockHeader(ctypes.Structure):
+    _fields_ = [("prefix", ctypes.c_uint64), ("n_kmers", ctypes.c_uint64), ("k_code", ctypes.c_uint32),
+                ("unary_bits", ctypes.c_uint32), ("binary_bits", ctypes.c_uint32), ("c_code", ctypes.c_uint32),
+                ("k1", ctypes.c_uint64), ("c1", ctypes.c_uint64), ("c2", ctypes.c_uint64)]
+
+
+BLOCK_CB2 = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                             ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                             ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64)
 BLOCK_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
                             ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
                             ctypes.POINTER(ctypes.c_uint32))
@@ -196,19 +232,35 @@ def lib():
     sig("mgc_get_result_device", i32, vp, P(vp), P(vp), P(vp), P(u32))
     sig("mgc_copy_result", i32, vp, vp, vp, vp, vp)
     sig("mgc_finish", i32, vp, BLOCK_CB, vp, i32)
+    sig("mgc_finish_labelled", i32, vp, BLOCK_CB2, vp, i32)
     sig("mgc_set_profiling", i32, vp, i32)
     sig("mgc_get_profile", i32, vp, P(Profile))
     sig("mdb_writer_open", vp, ctypes.c_char_p, u32, u32)
+    sig("mdb_writer_open_ex", vp, ctypes.c_char_p, u32, u32, u32, u32, u32)
+    sig("mdb_merge_parts", i32, ctypes.c_char_p, u32)
     sig("mdb_writer_add_block", i32, vp, u64, u64, vp, vp, vp)
+    sig("mdb_writer_add_block_labelled", i32, vp, u64, u64, vp, vp, vp, vp, u64)
+    sig("mdb_writer_add_encoded", i32, vp, u32, vp, u64, vp, u64)
+    sig("mdb_writer_add_histogram", i32, vp, vp, vp, u64)
     sig("mdb_writer_close", i32, vp)
     sig("mdb_last_error", ctypes.c_char_p)
     sig("mdb_reader_open", vp, ctypes.c_char_p)
     sig("mdb_reader_info", i32, vp, P(DbInfo))
     sig("mdb_reader_histogram", i32, vp, vp, vp)
     sig("mdb_reader_read_file", i32, vp, u32, P(vp), P(vp), P(vp), P(u64))
+    sig("mdb_reader_read_file_ex", i32, vp, u32, P(vp), P(vp), P(vp), P(vp), P(u64))
+    sig("mdb_reader_file_index", i32, vp, u32, vp)
+    sig("mdb_reader_block_header", i32, vp, u32, u64, P(BlockHeader))
+    sig("mdb_reader_read_block_raw", i32, vp, u32, u64, P(BlockHeader), P(vp), P(vp), P(vp), P(vp), P(vp))
     sig("mdb_reader_close", None, vp)
     sig("mdb_free", None, vp)
     sig("mgc_write_database", i32, vp, ctypes.c_char_p, i32)
+    sig("mgc_write_database_profiled", i32, vp, ctypes.c_char_p, i32, P(DbWriteProfile))
+    sig("mgc_db_stream_open", vp, ctypes.c_char_p, u32, u32, u32, u64, u32, u32, i32, i32)
+    sig("mgc_db_stream_write", i32, vp, vp, vp, u64, u64, u64)
+    sig("mgc_db_stream_sync", i32, vp)
+    sig("mgc_db_stream_close", i32, vp, P(DbWriteProfile))
+    sig("mgc_db_stream_error", ctypes.c_char_p, vp)
     sig("msr_open", vp, ctypes.c_char_p)
     sig("msr_close", None, vp)
     sig("msr_read_text", ctypes.c_int64, vp, vp, u64)
@@ -233,7 +285,7 @@ def check(rc, what, handle=None):
 
 
 def configure(k, n_kmers_estimate, memory_bytes, mode=MODE_CANONICAL, threads=0, count_suffix_length=0,
-              homopoly_compress=0, count_suffix=""):
+              homopoly_compress=0, count_suffix="", label_size=0, label=0):
     """mgc_configure_counting -> filled CountConfig."""
     c = CountConfig()
     c.k = k
@@ -244,6 +296,8 @@ def configure(k, n_kmers_estimate, memory_bytes, mode=MODE_CANONICAL, threads=0,
     c.count_suffix_length = len(count_suffix) if count_suffix else count_suffix_length
     c.count_suffix = count_suffix.encode("ascii")
     c.homopoly_compress = homopoly_compress
+    c.label_size = label_size
+    c.label_constant = label
     check(lib().mgc_configure_counting(ctypes.byref(c)), "mgc_configure_counting")
     return c
 

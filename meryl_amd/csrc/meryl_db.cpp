@@ -31,10 +31,16 @@
 //       (bit0 = multiset), histogram.
 //   A9  histogram: numUnique(64) numDistinct(64) numTotal(64) nPairs(64), then
 //       (value(64), occurrences(64)) ascending by value.
+//   A10 labels (meryl2's constant count label, src/meryl2/merylCountArray.C:469-471): flags
+//       bits 8..15 hold labelSize; when it is non-zero every block carries, after its
+//       values, one labelSize-bit binary field per k-mer.  labelSize 0 writes exactly the
+//       bytes of A1..A9.
 #include "../../include/meryl_db.h"
 #include "../../include/meryl_gpu_count.h"
+#include "mdb_layout.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -43,9 +49,12 @@
 #include <mutex>
 #include <string>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <vector>
 
 namespace {
+
+using namespace mdb;
 
 thread_local std::string g_db_error;
 void db_err(const char *fmt, const char *a = "", const char *b = "") {
@@ -53,12 +62,6 @@ void db_err(const char *fmt, const char *a = "", const char *b = "") {
   snprintf(buf, sizeof(buf), fmt, a, b);
   g_db_error = buf;
 }
-
-constexpr uint64_t MAGIC_DAT1 = 0x7461446c7972656dull;   // "merylDat"
-constexpr uint64_t MAGIC_DAT2 = 0x0a3030656c694661ull;   // "aFile00\n"
-constexpr uint64_t MAGIC_IDX1 = 0x646e496c7972656dull;   // "merylInd"  (usage.rst:15)
-constexpr uint64_t MAGIC_IDX2 = 0x32302e765f5f7865ull;   // "ex__v.02"
-constexpr uint64_t STUFFED_BLOCK_BITS = 16ull * 1024 * 1024 * 8;   // default stuffedBits block
 
 // ---- MSB-first bit packing into uint64 words (stuffedBits semantics) --------
 struct BitWriter {
@@ -88,11 +91,15 @@ struct BitWriter {
   uint64_t words() const { return (pos + 63) / 64; }
 };
 
+// Every read is bounds-checked against nbits: a truncated, corrupt or foreign file sets `bad` and yields
+// zeros instead of walking off the buffer.
 struct BitReader {
   const uint64_t *w = nullptr;
   uint64_t nbits = 0, pos = 0;
+  bool bad = false;
   inline uint64_t get(uint32_t width) {
     if (width == 0) return 0;
+    if (bad || pos + width > nbits) { bad = true; return 0; }
     const uint64_t word = pos >> 6;
     const uint32_t off  = (uint32_t)(pos & 63);
     const uint32_t room = 64 - off;
@@ -109,6 +116,7 @@ struct BitReader {
   inline uint64_t get_unary() {
     uint64_t v = 0;
     for (;;) {
+      if (bad || pos >= nbits) { bad = true; return 0; }
       const uint64_t word = pos >> 6;
       const uint32_t off  = (uint32_t)(pos & 63);
       const uint64_t rest = w[word] << off;
@@ -116,6 +124,7 @@ struct BitReader {
       const uint32_t lz = (uint32_t)__builtin_clzll(rest);
       v += lz;
       pos += lz + 1;
+      if (pos > nbits) { bad = true; return 0; }
       return v;
     }
   }
@@ -125,8 +134,7 @@ struct BitReader {
 // stream, so it is cut into blocks of STUFFED_BLOCK_BITS only when it is larger.
 bool dump_stuffed(FILE *f, const BitWriter &bw) {
   const uint64_t total = bw.pos;
-  uint32_t nblocks = (uint32_t)((total + STUFFED_BLOCK_BITS - 1) / STUFFED_BLOCK_BITS);
-  if (nblocks == 0) nblocks = 1;
+  const uint32_t nblocks = (uint32_t)stuffed_sub_blocks(total);
   const uint32_t nmax = std::max<uint32_t>(64, nblocks);
   std::vector<uint64_t> bgn(nblocks), len(nblocks);
   for (uint32_t i = 0; i < nblocks; i++) {
@@ -137,7 +145,7 @@ bool dump_stuffed(FILE *f, const BitWriter &bw) {
   if (fwrite(&lenmax, 8, 1, f) != 1 || fwrite(&nblocks, 4, 1, f) != 1 || fwrite(&nmax, 4, 1, f) != 1) return false;
   if (fwrite(bgn.data(), 8, nblocks, f) != nblocks || fwrite(len.data(), 8, nblocks, f) != nblocks) return false;
   for (uint32_t i = 0; i < nblocks; i++) {
-    const uint64_t nw = (len[i] + 63) / 64, nalloc = STUFFED_BLOCK_BITS / 64;
+    const uint64_t nw = (len[i] + 63) / 64, nalloc = STUFFED_BLOCK_WORDS;
     if (fwrite(&nw, 8, 1, f) != 1 || fwrite(&nalloc, 8, 1, f) != 1) return false;
     if (nw && fwrite(bw.w.data() + bgn[i] / 64, 8, nw, f) != nw) return false;
   }
@@ -148,7 +156,7 @@ bool dump_stuffed(FILE *f, const BitWriter &bw) {
 bool load_stuffed(FILE *f, std::vector<uint64_t> &words, uint64_t &nbits) {
   uint64_t lenmax; uint32_t nblocks, nmax;
   if (fread(&lenmax, 8, 1, f) != 1 || fread(&nblocks, 4, 1, f) != 1 || fread(&nmax, 4, 1, f) != 1) return false;
-  if (nblocks == 0 || nblocks > (1u << 20)) return false;
+  if (nblocks == 0 || nblocks > (1u << 20) || lenmax == 0 || lenmax > (1ull << 40)) return false;
   std::vector<uint64_t> bgn(nblocks), len(nblocks);
   if (fread(bgn.data(), 8, nblocks, f) != nblocks || fread(len.data(), 8, nblocks, f) != nblocks) return false;
   words.clear();
@@ -157,6 +165,7 @@ bool load_stuffed(FILE *f, std::vector<uint64_t> &words, uint64_t &nbits) {
     uint64_t nw, nalloc;
     if (fread(&nw, 8, 1, f) != 1 || fread(&nalloc, 8, 1, f) != 1) return false;
     if (bgn[i] % 64 != 0 || bgn[i] != nbits) return false;        // only what dump_stuffed writes
+    if (len[i] > lenmax || nw != (len[i] + 63) / 64) return false;
     const size_t at = words.size();
     words.resize(at + nw + 2, 0);
     if (nw && fread(words.data() + at, 8, nw, f) != nw) return false;
@@ -174,14 +183,21 @@ std::string block_name(const std::string &dir, uint32_t ff, bool index) {       
   bits[6] = 0;
   return dir + "/0x" + bits + (index ? ".merylIndex" : ".merylData");
 }
+std::string part_data_name(const std::string &dir, uint32_t ff, uint32_t part) {
+  return block_name(dir, ff, false) + ".part" + std::to_string(part);
+}
+std::string part_meta_name(const std::string &dir, uint32_t part) { return dir + "/merylParts." + std::to_string(part); }
 
-struct FileIndexEntry { uint64_t prefix, position, n_kmers; };                   // A7
+typedef mdb_index_entry FileIndexEntry;                                           // A7
+
+constexpr uint64_t PART_MAGIC = 0x7472615064626d31ull;
 
 }  // namespace
 
 struct mdb_writer {
   std::string dir;
-  uint32_t k = 0, prefix_size = 0, suffix_size = 0, num_blocks_bits = 0;
+  uint32_t k = 0, prefix_size = 0, suffix_size = 0, num_blocks_bits = 0, label_size = 0;
+  uint32_t part = 0, n_parts = 1;
   uint64_t blocks_per_file = 0;
   FILE *dat[MGC_NUM_FILES];
   std::vector<FileIndexEntry> index[MGC_NUM_FILES];
@@ -189,14 +205,26 @@ struct mdb_writer {
   // histogram: small values dense, big values sparse (merylHistogram keeps the same split)
   std::vector<uint64_t> hist_small[MGC_NUM_FILES];
   std::map<uint64_t, uint64_t> hist_big[MGC_NUM_FILES];
-  uint64_t n_distinct[MGC_NUM_FILES], n_total[MGC_NUM_FILES];
-  bool failed = false;
+  std::map<uint64_t, uint64_t> hist_extra;                 // mdb_writer_add_histogram
+  // add_block runs on several threads (one per file): the first failure is kept here, under the lock, and
+  // surfaces through mdb_last_error() of whoever closes the writer
+  std::atomic<bool> failed{false};
+  std::mutex err_lock;
+  std::string first_error;
+  void fail(const char *fmt, const char *a = "", const char *b = "") {
+    db_err(fmt, a, b);
+    std::lock_guard<std::mutex> g(err_lock);
+    if (!failed.exchange(true)) first_error = g_db_error;
+  }
+  std::string data_name(uint32_t ff) const { return n_parts > 1 ? part_data_name(dir, ff, part) : block_name(dir, ff, false); }
 };
 
 extern "C" const char *mdb_last_error(void) { return g_db_error.c_str(); }
 
-extern "C" mdb_writer *mdb_writer_open(const char *path, uint32_t k, uint32_t w_prefix) {
-  if (!path || k == 0 || k > 64 || w_prefix < MGC_NUM_FILES_BITS || w_prefix > 2 * k) {
+extern "C" mdb_writer *mdb_writer_open_ex(const char *path, uint32_t k, uint32_t w_prefix, uint32_t label_size,
+                                          uint32_t part, uint32_t n_parts) {
+  if (!path || k == 0 || k > 64 || w_prefix < MGC_NUM_FILES_BITS || w_prefix > 2 * k || label_size > 64 ||
+      n_parts == 0 || part >= n_parts) {
     db_err("mdb_writer_open: bad arguments");
     return nullptr;
   }
@@ -206,36 +234,52 @@ extern "C" mdb_writer *mdb_writer_open(const char *path, uint32_t k, uint32_t w_
   w->k = k;
   w->prefix_size = w_prefix;
   w->suffix_size = 2 * k - w_prefix;
+  w->label_size = label_size;
+  w->part = part;
+  w->n_parts = n_parts;
   w->num_blocks_bits = w_prefix - MGC_NUM_FILES_BITS;
   w->blocks_per_file = 1ull << w->num_blocks_bits;
   for (int ff = 0; ff < MGC_NUM_FILES; ff++) {
-    w->dat[ff] = nullptr; w->bytes[ff] = 0; w->n_distinct[ff] = 0; w->n_total[ff] = 0;
+    w->dat[ff] = nullptr; w->bytes[ff] = 0;
     w->hist_small[ff].assign(1024, 0);
   }
   return w;
 }
 
-extern "C" int mdb_writer_add_block(mdb_writer *w, uint64_t prefix, uint64_t n, const uint64_t *slo,
-                                    const uint64_t *shi, const uint32_t *counts) {
-  if (!w || (n && (!slo || !counts))) return MGC_EINVAL;
-  if (prefix >> w->prefix_size) { db_err("add_block: prefix out of range"); return MGC_EINVAL; }
-  const uint32_t ff = (uint32_t)(prefix >> w->num_blocks_bits);          // file = top 6 bits of the prefix
+extern "C" mdb_writer *mdb_writer_open(const char *path, uint32_t k, uint32_t w_prefix) {
+  return mdb_writer_open_ex(path, k, w_prefix, 0, 0, 1);
+}
+
+namespace {
+// opens file ff's data file on first use and checks the ascending-prefix rule
+int writer_file_ready(mdb_writer *w, uint32_t ff, uint64_t prefix) {
   if (!w->dat[ff]) {
-    w->dat[ff] = fopen(block_name(w->dir, ff, false).c_str(), "wb");
-    if (!w->dat[ff]) { db_err("add_block: cannot open data file in '%s': %s", w->dir.c_str(), strerror(errno)); w->failed = true; return MGC_EINVAL; }
-    w->index[ff].reserve(w->blocks_per_file);
+    w->dat[ff] = fopen(w->data_name(ff).c_str(), "wb");
+    if (!w->dat[ff]) { w->fail("add_block: cannot open data file in '%s': %s", w->dir.c_str(), strerror(errno)); return MGC_EINVAL; }
+    setvbuf(w->dat[ff], nullptr, _IOFBF, 1 << 20);
+    w->index[ff].reserve(std::min<uint64_t>(w->blocks_per_file, 1u << 16));
   }
   if (!w->index[ff].empty() && w->index[ff].back().prefix >= prefix) { db_err("add_block: prefixes of a file must ascend"); return MGC_ESTATE; }
+  return MGC_OK;
+}
+}  // namespace
+
+extern "C" int mdb_writer_add_block_labelled(mdb_writer *w, uint64_t prefix, uint64_t n, const uint64_t *slo,
+                                             const uint64_t *shi, const uint32_t *counts, const uint64_t *labels,
+                                             uint64_t label) {
+  if (!w || (n && (!slo || !counts))) return MGC_EINVAL;
+  if (w->prefix_size < 64 && (prefix >> w->prefix_size)) { db_err("add_block: prefix out of range"); return MGC_EINVAL; }
+  const uint32_t ff = (uint32_t)(prefix >> w->num_blocks_bits);          // file = top 6 bits of the prefix
+  int rc = writer_file_ready(w, ff, prefix);
+  if (rc != MGC_OK) return rc;
 
   // A4
-  uint32_t unary_bits = 0;
-  for (uint64_t sum = 1; sum < n; sum <<= 1) unary_bits++;
-  if (unary_bits > w->suffix_size) unary_bits = w->suffix_size;
+  const uint32_t unary_bits = unary_bits_for(n, w->suffix_size);
   const uint32_t binary_bits = w->suffix_size - unary_bits;
   const bool wide = w->suffix_size > 64;
 
   BitWriter bw;
-  bw.reserve_bits(64 * 8 + n * (binary_bits + 2 + 32));
+  bw.reserve_bits(64 * 9 + n * (binary_bits + 2 + VALUE_BITS + w->label_size));
   bw.put(64, MAGIC_DAT1); bw.put(64, MAGIC_DAT2);
   bw.put(64, prefix); bw.put(64, n);
   bw.put(8, 1); bw.put(32, unary_bits); bw.put(32, binary_bits); bw.put(64, 0);
@@ -248,43 +292,84 @@ extern "C" int mdb_writer_add_block(mdb_writer *w, uint64_t prefix, uint64_t n, 
     uint64_t top;                                  // suffix >> binary_bits (fits 64 bits: unary_bits <= 64)
     if (binary_bits >= 64) top = (binary_bits == 64) ? hi : (hi >> (binary_bits - 64));
     else                   top = (binary_bits == 0) ? lo : ((lo >> binary_bits) | (wide ? (hi << (64 - binary_bits)) : 0));
+    if (top < last_hi) { db_err("add_block: suffixes of a block must ascend"); return MGC_EINVAL; }
     bw.put_unary(top - last_hi);
     last_hi = top;
     if (binary_bits <= 64) bw.put(binary_bits, lo);
     else { bw.put(binary_bits - 64, hi); bw.put(64, lo); }
   }
   // A6
-  for (uint64_t i = 0; i < n; i++) bw.put(32, counts[i]);
+  for (uint64_t i = 0; i < n; i++) bw.put(VALUE_BITS, counts[i]);
+  // A10
+  if (w->label_size)
+    for (uint64_t i = 0; i < n; i++) bw.put(w->label_size, labels ? labels[i] : label);
 
   FileIndexEntry e;
   e.prefix = prefix; e.position = w->bytes[ff]; e.n_kmers = n;
   w->index[ff].push_back(e);
-  const long before = ftell(w->dat[ff]);
-  if (!dump_stuffed(w->dat[ff], bw)) { db_err("add_block: write failed in '%s'", w->dir.c_str()); w->failed = true; return MGC_EINVAL; }
-  w->bytes[ff] += (uint64_t)(ftell(w->dat[ff]) - before);
+  if (!dump_stuffed(w->dat[ff], bw)) { w->fail("add_block: write failed in '%s': %s", w->dir.c_str(), strerror(errno)); return MGC_EINVAL; }
+  w->bytes[ff] += stuffed_bytes(bw.pos);
 
   // value histogram, per file (merged at close) -- merylBlockWriter adds every value
   std::vector<uint64_t> &hs = w->hist_small[ff];
   for (uint64_t i = 0; i < n; i++) {
     const uint64_t v = counts[i];
     if (v < hs.size()) hs[v]++; else w->hist_big[ff][v]++;
-    w->n_total[ff] += v;
   }
-  w->n_distinct[ff] += n;
   return MGC_OK;
 }
 
-extern "C" int mdb_writer_close(mdb_writer *w) {
-  if (!w) return MGC_EINVAL;
-  bool ok = !w->failed;
-  // per-file indexes (A7).  A file that received no block at all still gets its (empty)
-  // data file and an index of empty blocks, so that the directory always has 64+64+1 files.
+extern "C" int mdb_writer_add_block(mdb_writer *w, uint64_t prefix, uint64_t n, const uint64_t *slo,
+                                    const uint64_t *shi, const uint32_t *counts) {
+  return mdb_writer_add_block_labelled(w, prefix, n, slo, shi, counts, nullptr, 0);
+}
+
+extern "C" int mdb_writer_add_encoded(mdb_writer *w, uint32_t ff, const void *bytes, uint64_t nbytes,
+                                      const mdb_index_entry *entries, uint64_t n_entries) {
+  if (!w || ff >= MGC_NUM_FILES || (nbytes && !bytes) || (n_entries && !entries)) return MGC_EINVAL;
+  if (nbytes == 0) return n_entries ? MGC_EINVAL : MGC_OK;
+  for (uint64_t i = 0; i < n_entries; i++) {
+    if ((entries[i].prefix >> w->num_blocks_bits) != ff || entries[i].position >= nbytes ||
+        (i && entries[i].prefix <= entries[i - 1].prefix)) { db_err("add_encoded: bad index entries"); return MGC_EINVAL; }
+  }
+  if (n_entries) {
+    int rc = writer_file_ready(w, ff, entries[0].prefix);
+    if (rc != MGC_OK) return rc;
+  } else if (!w->dat[ff]) {                                 // no block starts here: the bytes continue the file's last block
+    db_err("add_encoded: continuation bytes for a file that holds no block yet");
+    return MGC_ESTATE;
+  }
+  if (fwrite(bytes, 1, nbytes, w->dat[ff]) != nbytes) { w->fail("add_encoded: write failed in '%s': %s", w->dir.c_str(), strerror(errno)); return MGC_EINVAL; }
+  for (uint64_t i = 0; i < n_entries; i++) {
+    FileIndexEntry e = entries[i];
+    e.position += w->bytes[ff];
+    w->index[ff].push_back(e);
+  }
+  w->bytes[ff] += nbytes;
+  return MGC_OK;
+}
+
+extern "C" int mdb_writer_add_histogram(mdb_writer *w, const uint64_t *values, const uint64_t *occ, uint64_t n_pairs) {
+  if (!w || (n_pairs && (!values || !occ))) return MGC_EINVAL;
+  std::lock_guard<std::mutex> g(w->err_lock);
+  for (uint64_t i = 0; i < n_pairs; i++) if (occ[i]) w->hist_extra[values[i]] += occ[i];
+  return MGC_OK;
+}
+
+namespace {
+
+void merged_histogram(mdb_writer *w, std::map<uint64_t, uint64_t> &hist) {
+  hist = w->hist_extra;
   for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++) {
-    if (!w->dat[ff]) {
-      for (uint64_t bb = 0; bb < w->blocks_per_file && ok; bb++)
-        ok = (mdb_writer_add_block(w, ((uint64_t)ff << w->num_blocks_bits) | bb, 0, nullptr, nullptr, nullptr) == MGC_OK);
-    }
-    if (w->dat[ff]) { if (fclose(w->dat[ff]) != 0) ok = false; w->dat[ff] = nullptr; }
+    for (size_t v = 0; v < w->hist_small[ff].size(); v++) if (w->hist_small[ff][v]) hist[v] += w->hist_small[ff][v];
+    for (auto &kv : w->hist_big[ff]) hist[kv.first] += kv.second;
+  }
+}
+
+// per-file indexes (A7) + master index (A8) + histogram (A9) from the state of a writer whose data files are complete
+bool write_indexes(mdb_writer *w) {
+  bool ok = true;
+  for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++) {
     FILE *f = fopen(block_name(w->dir, ff, true).c_str(), "wb");
     if (!f) { ok = false; continue; }
     // index slot = block number inside the file; blocks that were never added stay {prefix,0,0}
@@ -294,31 +379,143 @@ extern "C" int mdb_writer_close(mdb_writer *w) {
     if (fwrite(full.data(), sizeof(FileIndexEntry), full.size(), f) != full.size()) ok = false;
     if (fclose(f) != 0) ok = false;
   }
-  // master index (A8) + histogram (A9)
   std::map<uint64_t, uint64_t> hist;
+  merged_histogram(w, hist);
   uint64_t n_distinct = 0, n_total = 0;
-  for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++) {
-    for (size_t v = 0; v < w->hist_small[ff].size(); v++) if (w->hist_small[ff][v]) hist[v] += w->hist_small[ff][v];
-    for (auto &kv : w->hist_big[ff]) hist[kv.first] += kv.second;
-    n_distinct += w->n_distinct[ff];
-    n_total += w->n_total[ff];
-  }
+  for (auto &kv : hist) { n_distinct += kv.second; n_total += kv.first * kv.second; }
   BitWriter bw;
   bw.put(64, MAGIC_IDX1); bw.put(64, MAGIC_IDX2);
   bw.put(32, w->prefix_size); bw.put(32, w->suffix_size); bw.put(32, MGC_NUM_FILES_BITS); bw.put(32, w->num_blocks_bits);
-  bw.put(32, 0);
+  bw.put(32, (uint64_t)w->label_size << 8);                                       // flags: bit0 multiset, bits 8..15 labelSize (A10)
   bw.put(64, hist.count(1) ? hist[1] : 0); bw.put(64, n_distinct); bw.put(64, n_total); bw.put(64, hist.size());
   for (auto &kv : hist) { bw.put(64, kv.first); bw.put(64, kv.second); }
   FILE *f = fopen((w->dir + "/merylIndex").c_str(), "wb");
   if (!f || !dump_stuffed(f, bw)) ok = false;
   if (f && fclose(f) != 0) ok = false;
-  if (!ok && g_db_error.empty()) db_err("mdb_writer_close: I/O error in '%s'", w->dir.c_str());
+  return ok;
+}
+
+bool put_u64(FILE *f, uint64_t v) { return fwrite(&v, 8, 1, f) == 1; }
+bool get_u64(FILE *f, uint64_t &v) { return fread(&v, 8, 1, f) == 1; }
+
+}  // namespace
+
+extern "C" int mdb_writer_close(mdb_writer *w) {
+  if (!w) return MGC_EINVAL;
+  bool ok = !w->failed.load();
+  if (w->n_parts > 1) {
+    // one part of a sharded database: data files stay under their part names; the side file carries what
+    // mdb_merge_parts needs (index entries, sizes, histogram)
+    for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++)
+      if (w->dat[ff]) { if (fclose(w->dat[ff]) != 0) ok = false; w->dat[ff] = nullptr; }
+    std::map<uint64_t, uint64_t> hist;
+    merged_histogram(w, hist);
+    const std::string tmp = part_meta_name(w->dir, w->part) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    bool wok = f != nullptr;
+    if (f) {
+      wok = put_u64(f, PART_MAGIC) && put_u64(f, w->k) && put_u64(f, w->prefix_size) && put_u64(f, w->label_size) &&
+            put_u64(f, w->part) && put_u64(f, w->n_parts);
+      for (uint32_t ff = 0; ff < MGC_NUM_FILES && wok; ff++) {
+        wok = put_u64(f, w->bytes[ff]) && put_u64(f, w->index[ff].size());
+        if (wok && !w->index[ff].empty())
+          wok = fwrite(w->index[ff].data(), sizeof(FileIndexEntry), w->index[ff].size(), f) == w->index[ff].size();
+      }
+      wok = wok && put_u64(f, hist.size());
+      for (auto &kv : hist) wok = wok && put_u64(f, kv.first) && put_u64(f, kv.second);
+      if (fclose(f) != 0) wok = false;
+      if (wok && rename(tmp.c_str(), part_meta_name(w->dir, w->part).c_str()) != 0) wok = false;
+    }
+    if (!wok) { ok = false; w->fail("mdb_writer_close: cannot write the part file in '%s': %s", w->dir.c_str(), strerror(errno)); }
+  } else {
+    // A file that received no block at all still gets its (empty) data file and an index of empty blocks, so that
+    // the directory always has 64+64+1 files.
+    for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++) {
+      if (!w->dat[ff]) {
+        for (uint64_t bb = 0; bb < w->blocks_per_file && ok; bb++)
+          ok = (mdb_writer_add_block(w, ((uint64_t)ff << w->num_blocks_bits) | bb, 0, nullptr, nullptr, nullptr) == MGC_OK);
+      }
+      if (w->dat[ff]) { if (fclose(w->dat[ff]) != 0) ok = false; w->dat[ff] = nullptr; }
+    }
+    if (!write_indexes(w)) ok = false;
+  }
+  if (w->failed.load()) { std::lock_guard<std::mutex> g(w->err_lock); g_db_error = w->first_error; }
+  else if (!ok) db_err("mdb_writer_close: I/O error in '%s': %s", w->dir.c_str(), strerror(errno));
   delete w;
   return ok ? MGC_OK : MGC_EINVAL;
 }
 
+// Stitches the parts of a sharded database (mdb_writer_open_ex) into the final 64+64+1 files.
+extern "C" int mdb_merge_parts(const char *path, uint32_t n_parts) {
+  if (!path || n_parts == 0) { db_err("mdb_merge_parts: bad arguments"); return MGC_EINVAL; }
+  const std::string dir = path;
+  mdb_writer *w = nullptr;
+  struct PartFile { uint64_t bytes = 0; std::vector<FileIndexEntry> idx; };
+  std::vector<std::vector<PartFile>> parts(n_parts, std::vector<PartFile>(MGC_NUM_FILES));
+  for (uint32_t p = 0; p < n_parts; p++) {
+    FILE *f = fopen(part_meta_name(dir, p).c_str(), "rb");
+    if (!f) { db_err("mdb_merge_parts: part file missing in '%s': %s", path, strerror(errno)); delete w; return MGC_EINVAL; }
+    uint64_t magic = 0, k = 0, wp = 0, ls = 0, pp = 0, np = 0;
+    bool ok = get_u64(f, magic) && get_u64(f, k) && get_u64(f, wp) && get_u64(f, ls) && get_u64(f, pp) && get_u64(f, np) &&
+              magic == PART_MAGIC && pp == p && np == n_parts;
+    if (ok && !w) { w = mdb_writer_open_ex(path, (uint32_t)k, (uint32_t)wp, (uint32_t)ls, 0, 1); ok = w != nullptr; }
+    if (ok && (w->k != k || w->prefix_size != wp || w->label_size != ls)) ok = false;
+    for (uint32_t ff = 0; ff < MGC_NUM_FILES && ok; ff++) {
+      uint64_t ne = 0;
+      ok = get_u64(f, parts[p][ff].bytes) && get_u64(f, ne) && ne <= w->blocks_per_file;
+      if (ok && ne) { parts[p][ff].idx.resize(ne); ok = fread(parts[p][ff].idx.data(), sizeof(FileIndexEntry), ne, f) == ne; }
+    }
+    uint64_t nh = 0;
+    ok = ok && get_u64(f, nh);
+    for (uint64_t i = 0; i < nh && ok; i++) { uint64_t v = 0, o = 0; ok = get_u64(f, v) && get_u64(f, o); if (ok) w->hist_extra[v] += o; }
+    fclose(f);
+    if (!ok) { db_err("mdb_merge_parts: bad part file in '%s'", path); delete w; return MGC_EINVAL; }
+  }
+  bool ok = true;
+  std::vector<char> buf(8u << 20);
+  for (uint32_t ff = 0; ff < MGC_NUM_FILES && ok; ff++) {
+    const std::string final_name = block_name(dir, ff, false);
+    bool have_base = false;
+    FILE *out = nullptr;
+    for (uint32_t p = 0; p < n_parts && ok; p++) {
+      PartFile &pf = parts[p][ff];
+      if (pf.idx.empty()) continue;
+      if (!w->index[ff].empty() && w->index[ff].back().prefix >= pf.idx.front().prefix) { db_err("mdb_merge_parts: prefix ranges of the parts overlap in '%s'", path); ok = false; break; }
+      const std::string pname = part_data_name(dir, ff, p);
+      if (!have_base) {                                   // first contributor: its file becomes the data file
+        if (rename(pname.c_str(), final_name.c_str()) != 0) { db_err("mdb_merge_parts: rename in '%s': %s", path, strerror(errno)); ok = false; break; }
+        have_base = true;
+      } else {                                            // a file that straddles ranks: append
+        if (!out) out = fopen(final_name.c_str(), "ab");
+        FILE *in = fopen(pname.c_str(), "rb");
+        if (!out || !in) { if (in) fclose(in); db_err("mdb_merge_parts: open in '%s': %s", path, strerror(errno)); ok = false; break; }
+        uint64_t left = pf.bytes;
+        while (left && ok) {
+          const size_t want = (size_t)std::min<uint64_t>(left, buf.size());
+          if (fread(buf.data(), 1, want, in) != want || fwrite(buf.data(), 1, want, out) != want) { db_err("mdb_merge_parts: copy in '%s': %s", path, strerror(errno)); ok = false; }
+          left -= want;
+        }
+        fclose(in);
+        unlink(pname.c_str());
+      }
+      for (FileIndexEntry e : pf.idx) { e.position += w->bytes[ff]; w->index[ff].push_back(e); }
+      w->bytes[ff] += pf.bytes;
+    }
+    if (out && fclose(out) != 0) ok = false;
+  }
+  if (!ok) { delete w; return MGC_EINVAL; }
+  for (uint32_t p = 0; p < n_parts; p++) unlink(part_meta_name(dir, p).c_str());
+  // files no part contributed to get their empty blocks, then the indexes: the plain writer's close
+  for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++)
+    if (!w->index[ff].empty()) {                          // reopen for the close path's bookkeeping (nothing more is written)
+      w->dat[ff] = fopen(block_name(dir, ff, false).c_str(), "ab");
+      if (!w->dat[ff]) { db_err("mdb_merge_parts: reopen in '%s': %s", path, strerror(errno)); delete w; return MGC_EINVAL; }
+    }
+  return mdb_writer_close(w);
+}
+
 // ---------------------------------------------------------------------------
-// reader (what `meryl print` / dumpIndex need; used by the tests to round-trip)
+// reader (what `meryl print` / dumpIndex / dumpFile need; used by the tests to round-trip)
 // ---------------------------------------------------------------------------
 struct mdb_reader {
   std::string dir;
@@ -336,23 +533,37 @@ extern "C" mdb_reader *mdb_reader_open(const char *path) {
   if (!ok) { db_err("mdb_reader_open: '%s/merylIndex' is not a meryl index", path); return nullptr; }
   BitReader br; br.w = words.data(); br.nbits = nbits;
   const uint64_t m1 = br.get(64), m2 = br.get(64);
-  if (m1 != MAGIC_IDX1 || (m2 & 0x0000ffffffffffffull) != (MAGIC_IDX2 & 0x0000ffffffffffffull)) {
+  if (br.bad || m1 != MAGIC_IDX1 || (m2 & 0x0000ffffffffffffull) != (MAGIC_IDX2 & 0x0000ffffffffffffull)) {
     db_err("mdb_reader_open: bad magic in '%s/merylIndex'", path);
+    return nullptr;
+  }
+  mdb_info info;
+  memset(&info, 0, sizeof(info));
+  info.prefix_size = (uint32_t)br.get(32);
+  info.suffix_size = (uint32_t)br.get(32);
+  info.num_files_bits = (uint32_t)br.get(32);
+  info.num_blocks_bits = (uint32_t)br.get(32);
+  info.flags = (uint32_t)br.get(32);
+  info.label_size = (info.flags >> 8) & 0xffu;
+  info.k = (info.prefix_size + info.suffix_size) / 2;
+  info.num_unique = br.get(64);
+  info.num_distinct = br.get(64);
+  info.num_total = br.get(64);
+  info.hist_len = br.get(64);
+  // the sizes come from the file: check them before anything is allocated from them
+  if (br.bad || info.num_files_bits != MGC_NUM_FILES_BITS || info.prefix_size < MGC_NUM_FILES_BITS ||
+      info.num_blocks_bits != info.prefix_size - MGC_NUM_FILES_BITS || info.num_blocks_bits > 40 ||
+      ((info.prefix_size + info.suffix_size) & 1u) || info.k == 0 || info.k > 64 || info.label_size > 64 ||
+      info.hist_len > (br.nbits - br.pos) / 128) {
+    db_err("mdb_reader_open: '%s/merylIndex' holds impossible parameters (not a database this reader understands)", path);
     return nullptr;
   }
   mdb_reader *r = new mdb_reader();
   r->dir = path;
-  r->info.prefix_size = (uint32_t)br.get(32);
-  r->info.suffix_size = (uint32_t)br.get(32);
-  r->info.num_files_bits = (uint32_t)br.get(32);
-  r->info.num_blocks_bits = (uint32_t)br.get(32);
-  r->info.flags = (uint32_t)br.get(32);
-  r->info.k = (r->info.prefix_size + r->info.suffix_size) / 2;
-  r->info.num_unique = br.get(64);
-  r->info.num_distinct = br.get(64);
-  r->info.num_total = br.get(64);
-  r->info.hist_len = br.get(64);
-  for (uint64_t i = 0; i < r->info.hist_len; i++) { r->hist_v.push_back(br.get(64)); r->hist_n.push_back(br.get(64)); }
+  r->info = info;
+  r->hist_v.reserve(info.hist_len); r->hist_n.reserve(info.hist_len);
+  for (uint64_t i = 0; i < info.hist_len; i++) { r->hist_v.push_back(br.get(64)); r->hist_n.push_back(br.get(64)); }
+  if (br.bad) { db_err("mdb_reader_open: truncated histogram in '%s/merylIndex'", path); delete r; return nullptr; }
   return r;
 }
 
@@ -368,37 +579,121 @@ extern "C" int mdb_reader_histogram(const mdb_reader *r, uint64_t *values, uint6
   return MGC_OK;
 }
 
-extern "C" int mdb_reader_read_file(mdb_reader *r, uint32_t ff, uint64_t **klo, uint64_t **khi, uint32_t **cnt,
-                                    uint64_t *n_out) {
-  if (!r || ff >= MGC_NUM_FILES || !klo || !cnt || !n_out) return MGC_EINVAL;
-  *klo = nullptr; if (khi) *khi = nullptr; *cnt = nullptr; *n_out = 0;
+namespace {
+bool load_file_index(mdb_reader *r, uint32_t ff, std::vector<FileIndexEntry> &idx) {
   const uint64_t nblocks = 1ull << r->info.num_blocks_bits;
-  std::vector<FileIndexEntry> idx(nblocks);
+  idx.assign(nblocks, FileIndexEntry());
   FILE *fi = fopen(block_name(r->dir, ff, true).c_str(), "rb");
-  if (!fi || fread(idx.data(), sizeof(FileIndexEntry), nblocks, fi) != nblocks) { if (fi) fclose(fi); db_err("read_file: bad index in '%s'", r->dir.c_str()); return MGC_EINVAL; }
-  fclose(fi);
-  uint64_t total = 0;
-  for (auto &e : idx) total += e.n_kmers;
-  uint64_t *lo = (uint64_t *)malloc(8 * (total ? total : 1)), *hi = (uint64_t *)calloc(total ? total : 1, 8);
-  uint32_t *cn = (uint32_t *)malloc(4 * (total ? total : 1));
+  const bool ok = fi && fread(idx.data(), sizeof(FileIndexEntry), nblocks, fi) == nblocks;
+  if (fi) fclose(fi);
+  if (!ok) db_err("read_file: bad index in '%s'", r->dir.c_str());
+  return ok;
+}
+
+struct DecodedHeader { mdb_block_header h; bool ok; };
+DecodedHeader decode_header(BitReader &br, uint32_t suffix_size) {
+  DecodedHeader d;
+  memset(&d.h, 0, sizeof(d.h));
+  const uint64_t m1 = br.get(64), m2 = br.get(64);
+  d.h.prefix = br.get(64); d.h.n_kmers = br.get(64);
+  d.h.k_code = (uint32_t)br.get(8);
+  d.h.unary_bits = (uint32_t)br.get(32); d.h.binary_bits = (uint32_t)br.get(32);
+  d.h.k1 = br.get(64); d.h.c_code = (uint32_t)br.get(8); d.h.c1 = br.get(64); d.h.c2 = br.get(64);
+  d.ok = !br.bad && m1 == MAGIC_DAT1 && m2 == MAGIC_DAT2 && (uint64_t)d.h.unary_bits + d.h.binary_bits == suffix_size &&
+         d.h.unary_bits <= 64;
+  return d;
+}
+}  // namespace
+
+extern "C" int mdb_reader_file_index(mdb_reader *r, uint32_t ff, mdb_index_entry *entries) {
+  if (!r || ff >= MGC_NUM_FILES || !entries) return MGC_EINVAL;
+  std::vector<FileIndexEntry> idx;
+  if (!load_file_index(r, ff, idx)) return MGC_EINVAL;
+  memcpy(entries, idx.data(), sizeof(FileIndexEntry) * idx.size());
+  return MGC_OK;
+}
+
+extern "C" int mdb_reader_read_block_raw(mdb_reader *r, uint32_t ff, uint64_t position, mdb_block_header *h,
+                                         uint64_t **prefix_delta, uint64_t **top, uint64_t **rem_hi, uint64_t **rem_lo,
+                                         uint32_t **values) {
+  if (!r || ff >= MGC_NUM_FILES || !h) return MGC_EINVAL;
+  if (prefix_delta) *prefix_delta = nullptr;
+  if (top) *top = nullptr;
+  if (rem_hi) *rem_hi = nullptr;
+  if (rem_lo) *rem_lo = nullptr;
+  if (values) *values = nullptr;
   FILE *fd = fopen(block_name(r->dir, ff, false).c_str(), "rb");
-  if (!fd || !lo || !hi || !cn) { if (fd) fclose(fd); free(lo); free(hi); free(cn); db_err("read_file: cannot open data file in '%s'", r->dir.c_str()); return MGC_EINVAL; }
-  const uint32_t ss = r->info.suffix_size;
+  if (!fd) { db_err("read_block: cannot open data file in '%s'", r->dir.c_str()); return MGC_EINVAL; }
+  std::vector<uint64_t> words; uint64_t nbits = 0;
+  const bool loaded = fseek(fd, (long)position, SEEK_SET) == 0 && load_stuffed(fd, words, nbits);
+  fclose(fd);
+  if (!loaded) { db_err("read_block: no block at that position in '%s'", r->dir.c_str()); return MGC_EINVAL; }
+  BitReader br; br.w = words.data(); br.nbits = nbits;
+  DecodedHeader d = decode_header(br, r->info.suffix_size);
+  // every k-mer takes at least one bit: n_kmers beyond the block's bits is corruption, not an allocation size
+  if (!d.ok || d.h.n_kmers > nbits) { db_err("read_block: corrupt block header in '%s'", r->dir.c_str()); return MGC_EINVAL; }
+  *h = d.h;
+  const bool want_kmers = prefix_delta || top || rem_hi || rem_lo || values;
+  if (!want_kmers) return MGC_OK;
+  const uint64_t n = d.h.n_kmers, na = n ? n : 1;
+  uint64_t *pd = (uint64_t *)malloc(8 * na), *tp = (uint64_t *)malloc(8 * na), *rh = (uint64_t *)malloc(8 * na), *rl = (uint64_t *)malloc(8 * na);
+  uint32_t *vv = (uint32_t *)malloc(4 * na);
+  bool ok = pd && tp && rh && rl && vv;
+  const uint32_t bb = d.h.binary_bits;
+  uint64_t acc = 0;
+  for (uint64_t i = 0; i < n && ok; i++) {
+    const uint64_t dl = br.get_unary();
+    acc += dl;
+    pd[i] = dl; tp[i] = acc;
+    if (bb <= 64) { rh[i] = 0; rl[i] = br.get(bb); } else { rh[i] = br.get(bb - 64); rl[i] = br.get(64); }
+  }
+  for (uint64_t i = 0; i < n && ok; i++) vv[i] = (uint32_t)br.get(VALUE_BITS);
+  if (br.bad) ok = false;
+  if (!ok) { free(pd); free(tp); free(rh); free(rl); free(vv); db_err("read_block: corrupt block in '%s'", r->dir.c_str()); return MGC_EINVAL; }
+  if (prefix_delta) *prefix_delta = pd; else free(pd);
+  if (top) *top = tp; else free(tp);
+  if (rem_hi) *rem_hi = rh; else free(rh);
+  if (rem_lo) *rem_lo = rl; else free(rl);
+  if (values) *values = vv; else free(vv);
+  return MGC_OK;
+}
+
+extern "C" int mdb_reader_block_header(mdb_reader *r, uint32_t ff, uint64_t position, mdb_block_header *h) {
+  return mdb_reader_read_block_raw(r, ff, position, h, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int mdb_reader_read_file_ex(mdb_reader *r, uint32_t ff, uint64_t **klo, uint64_t **khi, uint32_t **cnt,
+                                       uint64_t **labels, uint64_t *n_out) {
+  if (!r || ff >= MGC_NUM_FILES || !klo || !cnt || !n_out) return MGC_EINVAL;
+  *klo = nullptr; if (khi) *khi = nullptr; *cnt = nullptr; if (labels) *labels = nullptr; *n_out = 0;
+  const uint64_t nblocks = 1ull << r->info.num_blocks_bits;
+  std::vector<FileIndexEntry> idx;
+  if (!load_file_index(r, ff, idx)) return MGC_EINVAL;
+  FILE *fd = fopen(block_name(r->dir, ff, false).c_str(), "rb");
+  if (!fd) { db_err("read_file: cannot open data file in '%s'", r->dir.c_str()); return MGC_EINVAL; }
+  // the index is input too: its k-mer total cannot exceed what the data file could hold at one bit per k-mer
+  struct stat st;
+  uint64_t total = 0;
+  bool ok = fstat(fileno(fd), &st) == 0;
+  for (auto &e : idx) { if (e.n_kmers > (uint64_t)st.st_size * 8) ok = false; total += e.n_kmers; }
+  if (!ok || total > (uint64_t)st.st_size * 8) { fclose(fd); db_err("read_file: index of '%s' does not fit its data file", r->dir.c_str()); return MGC_EINVAL; }
+  uint64_t *lo = (uint64_t *)malloc(8 * (total ? total : 1)), *hi = (uint64_t *)calloc(total ? total : 1, 8);
+  uint64_t *lb = (uint64_t *)calloc(total ? total : 1, 8);
+  uint32_t *cn = (uint32_t *)malloc(4 * (total ? total : 1));
+  if (!lo || !hi || !cn || !lb) { fclose(fd); free(lo); free(hi); free(cn); free(lb); db_err("read_file: out of memory for '%s'", r->dir.c_str()); return MGC_ENOMEM; }
+  const uint32_t ss = r->info.suffix_size, ls = r->info.label_size;
   uint64_t o = 0;
   std::vector<uint64_t> words;
-  bool ok = true;
   for (uint64_t bb = 0; bb < nblocks && ok; bb++) {
     const FileIndexEntry &e = idx[bb];
-    if (fseek(fd, (long)e.position, SEEK_SET) != 0) { ok = false; break; }
+    if (e.position >= (uint64_t)st.st_size || fseek(fd, (long)e.position, SEEK_SET) != 0) { ok = false; break; }
     uint64_t nbits = 0;
     if (!load_stuffed(fd, words, nbits)) { ok = false; break; }
     BitReader br; br.w = words.data(); br.nbits = nbits;
-    if (br.get(64) != MAGIC_DAT1 || br.get(64) != MAGIC_DAT2) { ok = false; break; }
-    const uint64_t prefix = br.get(64), n = br.get(64);
-    (void)br.get(8);
-    const uint32_t ub = (uint32_t)br.get(32), bb_bits = (uint32_t)br.get(32);
-    (void)br.get(64); (void)br.get(8); (void)br.get(64); (void)br.get(64);
-    if (n != e.n_kmers || prefix != e.prefix || ub + bb_bits != ss) { ok = false; break; }
+    DecodedHeader d = decode_header(br, ss);
+    const uint64_t prefix = d.h.prefix, n = d.h.n_kmers;
+    const uint32_t bb_bits = d.h.binary_bits;
+    if (!d.ok || n != e.n_kmers || prefix != e.prefix) { ok = false; break; }
     uint64_t top = 0;
     for (uint64_t i = 0; i < n; i++) {
       top += br.get_unary();
@@ -410,35 +705,22 @@ extern "C" int mdb_reader_read_file(mdb_reader *r, uint32_t ff, uint64_t **klo, 
       lo[o + i] = (uint64_t)full;
       hi[o + i] = (uint64_t)(full >> 64);
     }
-    for (uint64_t i = 0; i < n; i++) cn[o + i] = (uint32_t)br.get(32);
+    for (uint64_t i = 0; i < n; i++) cn[o + i] = (uint32_t)br.get(VALUE_BITS);
+    if (ls) for (uint64_t i = 0; i < n; i++) lb[o + i] = br.get(ls);
+    if (br.bad) { ok = false; break; }
     o += n;
   }
   fclose(fd);
-  if (!ok || o != total) { free(lo); free(hi); free(cn); db_err("read_file: corrupt block in '%s'", r->dir.c_str()); return MGC_EINVAL; }
-  *klo = lo; if (khi) *khi = hi; else free(hi); *cnt = cn; *n_out = total;
+  if (!ok || o != total) { free(lo); free(hi); free(cn); free(lb); db_err("read_file: corrupt block in '%s'", r->dir.c_str()); return MGC_EINVAL; }
+  *klo = lo; if (khi) *khi = hi; else free(hi); *cnt = cn; if (labels) *labels = lb; else free(lb); *n_out = total;
   return MGC_OK;
+}
+
+extern "C" int mdb_reader_read_file(mdb_reader *r, uint32_t ff, uint64_t **klo, uint64_t **khi, uint32_t **cnt,
+                                    uint64_t *n_out) {
+  return mdb_reader_read_file_ex(r, ff, klo, khi, cnt, nullptr, n_out);
 }
 
 extern "C" void mdb_reader_close(mdb_reader *r) { delete r; }
 extern "C" void mdb_free(void *p) { free(p); }
 
-// ---------------------------------------------------------------------------
-// count result -> database
-// ---------------------------------------------------------------------------
-namespace {
-int write_cb(void *ctx, uint64_t prefix, uint64_t n, const uint64_t *slo, const uint64_t *shi, const uint32_t *cnt) {
-  return mdb_writer_add_block((mdb_writer *)ctx, prefix, n, slo, shi, cnt);
-}
-}  // namespace
-
-extern "C" int mgc_write_database(struct mgc_session *s, const char *path, int host_threads) {
-  if (!s || !path) return MGC_EINVAL;
-  mgc_result_info info;
-  int rc = mgc_get_result_info(s, &info);
-  if (rc != MGC_OK) return rc;
-  mdb_writer *w = mdb_writer_open(path, (info.w_prefix + info.w_data) / 2, info.w_prefix);
-  if (!w) return MGC_EINVAL;
-  rc = mgc_finish(s, write_cb, w, host_threads);
-  const int rc2 = mdb_writer_close(w);
-  return rc != MGC_OK ? rc : rc2;
-}

@@ -97,6 +97,20 @@ hipError_t launch_store_u64(uint64_t *d_dst, const uint64_t *d_src, hipStream_t 
 hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,
                                 uint64_t n_prefix, uint64_t *d_block_start, hipStream_t st);
 
+// ---- database blocks encoded on the device (mgc_encode.hip; layout: mdb_layout.h) -------------------------------
+// rel_start[i] = first key >= (prefix_begin + i) << w_data for i in [0, n_blocks]
+hipError_t launch_block_offsets_range(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t w_data, uint64_t prefix_begin,
+                                      uint64_t n_blocks, uint64_t *d_rel_start, hipStream_t st);
+hipError_t launch_encode_sizes(const void *d_keys, uint32_t key_words, const uint64_t *d_bs, uint64_t n_blocks, uint32_t suffix_size,
+                               uint32_t label_size, uint64_t *d_blk_bytes, uint64_t *d_blk_vbase, uint32_t *d_blk_bb, hipStream_t st);
+hipError_t launch_encode_chunk(const void *d_keys, const uint32_t *d_counts, uint32_t key_words, const uint64_t *d_bs,
+                               const uint64_t *d_blk_pos, const uint64_t *d_blk_vbase, const uint32_t *d_blk_bb,
+                               uint64_t b0, uint64_t b1, uint64_t n_kmers_chunk, uint64_t prefix_of_block0,
+                               uint32_t suffix_size, uint32_t label_size, uint64_t label, void *d_img, hipStream_t st);
+uint32_t   value_hist_small_bins();
+hipError_t launch_value_hist(const uint32_t *d_counts, uint64_t n, uint64_t *d_hist, uint32_t *d_big_list, uint64_t big_cap,
+                             uint64_t *d_big_n, hipStream_t st);
+
 // ---- homopolymer compression -------------------------------------------------
 size_t     hpc_workspace_bytes(uint64_t n);
 // compressed length lands in the first uint64 of the workspace

@@ -1,0 +1,580 @@
+// mgc_stream.cpp -- delivery of a count result: the addBlock-convention callbacks (mgc_finish*) streamed out of HBM
+// through pinned buffers, and the database stream (include/meryl_db.h, mgc_db_stream_*) whose blocks are encoded on the
+// device (mgc_encode.hip) so that the host only moves finished file bytes.
+//
+// Reference side of this boundary: the final dump of countThreads, 64 OpenMP threads running
+// countKmers + dumpCountedKmers -> merylBlockWriter::addBlock, one file per thread, prefixes ascending, empty blocks
+// included (src/meryl/merylOp-countThreads.C:452-459, src/meryl/merylCountArray.C:472-475), then
+// merylBlockWriter::finish() / ~merylFileWriter (src/meryl/merylOp-countThreads.C:464, merylOp-nextMer.C:227).
+#include "../../include/meryl_db.h"
+#include "mdb_layout.h"
+#include "mgc_session.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <thread>
+
+using mgc::set_err;
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct DBuf {                                             // grow-only device buffer
+  void *p = nullptr; size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes < 256) bytes = 256;
+    if (cap >= bytes) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+constexpr size_t   SLOT_BYTES = 32u << 20;                // pinned copy buffers: NSLOT x SLOT_BYTES
+constexpr int      NSLOT      = 6;
+constexpr uint64_t IMG_CAP    = 512ull << 20;             // device image of one encode chunk (two of them in flight)
+
+}  // namespace
+
+// ================================================================================================
+//  database stream
+// ================================================================================================
+struct mgc_db_stream {
+  // geometry
+  uint32_t k = 0, w_prefix = 0, w_data = 0, label_size = 0, kw = 1, num_blocks_bits = 0;
+  uint64_t label = 0;
+  int      device = 0, n_threads = 1;
+  mdb_writer *w = nullptr;
+
+  hipStream_t st_enc = nullptr, st_copy = nullptr;
+  hipEvent_t  ev_enc[2] = {nullptr, nullptr}, ev_a = nullptr, ev_b = nullptr;
+  DBuf d_bs, d_bytes, d_vbase, d_bb, d_pos, d_hist, d_big, d_img[2];
+  char *pinned[NSLOT] = {nullptr};
+
+  struct Range { const void *keys; const uint32_t *counts; uint64_t n, pb, pe; };
+  struct Piece { uint32_t ff; int slot; uint64_t nbytes; std::vector<mdb_index_entry> entries; };
+
+  std::mutex mu;
+  std::condition_variable cv;
+  bool slot_busy[NSLOT] = {false};
+  int  next_slot = 0;
+  std::deque<Range> jobs;
+  uint64_t jobs_queued = 0, jobs_done = 0;
+  bool closing = false, copy_done = false;
+  std::vector<std::deque<Piece>> queues;
+  uint64_t pieces_open = 0;
+  std::thread copy_thread;
+  std::vector<std::thread> pool;
+  int status = MGC_OK;
+  std::string err;
+  uint64_t next_prefix = 0;                               // ranges must ascend
+
+  std::map<uint64_t, uint64_t> hist_acc;
+  mgc_db_write_profile prof;
+  double t_open = 0, t_first_copy = 0;
+
+  void fail_locked(int rc, const std::string &msg) { if (status == MGC_OK) { status = rc; err = msg; } }
+  void fail(int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); fail_locked(rc, msg); cv.notify_all(); }
+  int  fail_hip(hipError_t e, const char *what) {
+    fail(e == hipErrorOutOfMemory ? MGC_ENOMEM : MGC_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    return status;
+  }
+  int process(const Range &r);
+  void copy_main();
+  void pool_main(int t);
+};
+
+#define DS_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail_hip(e__, #expr); } while (0)
+
+void mgc_db_stream::pool_main(int t) {
+  for (;;) {
+    Piece pc;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return !queues[t].empty() || copy_done; });
+      if (queues[t].empty()) return;
+      pc = std::move(queues[t].front());
+      queues[t].pop_front();
+    }
+    int rc = MGC_OK;
+    std::string msg;
+    bool skip;
+    { std::lock_guard<std::mutex> g(mu); skip = status != MGC_OK; }
+    if (!skip) {
+      rc = mdb_writer_add_encoded(w, pc.ff, pinned[pc.slot], pc.nbytes, pc.entries.data(), pc.entries.size());
+      if (rc != MGC_OK) msg = std::string("writing the database: ") + mdb_last_error();
+    }
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (rc != MGC_OK) fail_locked(rc, msg);
+      slot_busy[pc.slot] = false;
+      pieces_open--;
+      prof.data_bytes += pc.nbytes;
+    }
+    cv.notify_all();
+  }
+}
+
+void mgc_db_stream::copy_main() {
+  (void)hipSetDevice(device);
+  for (;;) {
+    Range r;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return !jobs.empty() || closing; });
+      if (jobs.empty()) break;
+      r = jobs.front();
+    }
+    bool run;
+    { std::lock_guard<std::mutex> g(mu); run = status == MGC_OK; }
+    if (run) (void)process(r);
+    {
+      std::lock_guard<std::mutex> g(mu);
+      jobs.pop_front();
+      jobs_done++;
+    }
+    cv.notify_all();
+  }
+  { std::lock_guard<std::mutex> g(mu); copy_done = true; }
+  cv.notify_all();
+}
+
+int mgc_db_stream::process(const Range &r) {
+  const double t0 = now_s();
+  const uint64_t nblk = r.pe - r.pb;
+  const uint32_t ss = w_data;
+  DS_TRY(d_bs.ensure(8 * (nblk + 1)));
+  DS_TRY(d_bytes.ensure(8 * nblk));
+  DS_TRY(d_vbase.ensure(8 * nblk));
+  DS_TRY(d_bb.ensure(4 * nblk));
+  DS_TRY(d_pos.ensure(8 * nblk));
+  const uint32_t nsmall = mgc::value_hist_small_bins();
+  DS_TRY(d_hist.ensure(8 * (nsmall + 1)));
+  if (d_big.cap == 0) DS_TRY(d_big.ensure(4u << 20));
+  DS_TRY(mgc::launch_block_offsets_range(r.keys, r.n, kw, w_data, r.pb, nblk, d_bs.as<uint64_t>(), st_enc));
+  DS_TRY(mgc::launch_encode_sizes(r.keys, kw, d_bs.as<uint64_t>(), nblk, ss, label_size, d_bytes.as<uint64_t>(),
+                                  d_vbase.as<uint64_t>(), d_bb.as<uint32_t>(), st_enc));
+  std::vector<uint64_t> h_bs(nblk + 1), h_bytes(nblk), h_pos(nblk), h_hist(nsmall + 1);
+  DS_TRY(hipMemcpyAsync(h_bs.data(), d_bs.p, 8 * (nblk + 1), hipMemcpyDeviceToHost, st_enc));
+  if (nblk) DS_TRY(hipMemcpyAsync(h_bytes.data(), d_bytes.p, 8 * nblk, hipMemcpyDeviceToHost, st_enc));
+  // value histogram (A9): small values in LDS bins, the rare large ones as a list
+  for (int attempt = 0; attempt < 2; attempt++) {
+    DS_TRY(hipMemsetAsync(d_hist.p, 0, 8 * (nsmall + 1), st_enc));
+    DS_TRY(mgc::launch_value_hist(r.counts, r.n, d_hist.as<uint64_t>(), d_big.as<uint32_t>(), d_big.cap / 4,
+                                  d_hist.as<uint64_t>() + nsmall, st_enc));
+    DS_TRY(hipMemcpyAsync(h_hist.data(), d_hist.p, 8 * (nsmall + 1), hipMemcpyDeviceToHost, st_enc));
+    DS_TRY(hipStreamSynchronize(st_enc));
+    if (h_hist[nsmall] <= d_big.cap / 4) break;
+    DS_TRY(d_big.ensure(4 * h_hist[nsmall]));            // the list overflowed: once more with room for all of it
+  }
+  if (h_bs[nblk] != r.n || h_bs[0] != 0) { fail(MGC_EINVAL, "mgc_db_stream_write: keys outside the prefix range (or not ascending)"); return status; }
+  {
+    std::vector<uint32_t> big(h_hist[nsmall]);
+    if (!big.empty()) DS_TRY(hipMemcpy(big.data(), d_big.p, 4 * big.size(), hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> g(mu);
+    for (uint32_t v = 0; v < nsmall; v++) if (h_hist[v]) hist_acc[v] += h_hist[v];
+    for (uint32_t v : big) hist_acc[v]++;
+  }
+
+  // chunks: runs of blocks whose dumped bytes fit one device image (a larger single block gets an image of its own)
+  struct Chunk { uint64_t b0, b1, bytes; };
+  std::vector<Chunk> chunks;
+  for (uint64_t b = 0; b < nblk;) {
+    Chunk c; c.b0 = b; c.bytes = 0;
+    while (b < nblk && (c.bytes == 0 || c.bytes + h_bytes[b] <= IMG_CAP)) { h_pos[b] = c.bytes; c.bytes += h_bytes[b]; b++; }
+    c.b1 = b;
+    chunks.push_back(c);
+  }
+  if (nblk) DS_TRY(hipMemcpyAsync(d_pos.p, h_pos.data(), 8 * nblk, hipMemcpyHostToDevice, st_enc));
+  const double t1 = now_s();
+
+  auto encode = [&](size_t ci) -> int {
+    const Chunk &c = chunks[ci];
+    DBuf &img = d_img[ci & 1];
+    DS_TRY(img.ensure(c.bytes));
+    DS_TRY(hipMemsetAsync(img.p, 0, c.bytes, st_enc));
+    DS_TRY(hipEventRecord(ev_a, st_enc));
+    DS_TRY(mgc::launch_encode_chunk(r.keys, r.counts, kw, d_bs.as<uint64_t>(), d_pos.as<uint64_t>(), d_vbase.as<uint64_t>(),
+                                    d_bb.as<uint32_t>(), c.b0, c.b1, h_bs[c.b1] - h_bs[c.b0], r.pb, ss, label_size, label,
+                                    img.p, st_enc));
+    DS_TRY(hipEventRecord(ev_enc[ci & 1], st_enc));
+    return MGC_OK;
+  };
+
+  const uint64_t blocks_per_file = 1ull << num_blocks_bits;
+  double enc_ms = 0;
+  if (!chunks.empty() && encode(0) != MGC_OK) return status;
+  for (size_t ci = 0; ci < chunks.size(); ci++) {
+    const Chunk &c = chunks[ci];
+    DS_TRY(hipEventSynchronize(ev_enc[ci & 1]));
+    { float ms = 0; if (hipEventElapsedTime(&ms, ev_a, ev_enc[ci & 1]) == hipSuccess) enc_ms += ms; }
+    if (ci + 1 < chunks.size() && encode(ci + 1) != MGC_OK) return status;     // runs while this chunk is copied out
+    const unsigned char *img = d_img[ci & 1].as<unsigned char>();
+    auto pos_at = [&](uint64_t j) { return j < c.b1 ? h_pos[j] : c.bytes; };
+    uint64_t a = 0, bi = c.b0;                            // bi = first block that starts at or after byte a
+    while (a < c.bytes) {
+      const uint64_t cur_blk = (bi < c.b1 && h_pos[bi] == a) ? bi : bi - 1;
+      const uint32_t ff = (uint32_t)((r.pb + cur_blk) >> num_blocks_bits);
+      const uint64_t file_end_abs = ((uint64_t)ff + 1) * blocks_per_file;                  // first prefix of the next file
+      const uint64_t file_end_blk = std::min<uint64_t>(c.b1, file_end_abs > r.pb ? file_end_abs - r.pb : 0);
+      const uint64_t lim = std::min<uint64_t>(a + SLOT_BYTES, pos_at(file_end_blk));
+      uint64_t j = bi;
+      while (j < file_end_blk && pos_at(j + 1) <= lim) j++;                                // blocks bi..j-1 end inside the piece
+      uint64_t e;
+      if (a < pos_at(bi)) {                               // the piece starts inside block bi-1
+        if (pos_at(bi) <= lim) e = pos_at(j); else { e = lim; j = bi; }
+      } else if (j > bi) {
+        e = pos_at(j);
+      } else {                                            // block bi alone is larger than a copy buffer
+        e = lim; j = bi + 1;
+      }
+      Piece pc;
+      pc.ff = ff; pc.nbytes = e - a;
+      for (uint64_t jj = bi; jj < j; jj++) {
+        mdb_index_entry en;
+        en.prefix = r.pb + jj; en.position = h_pos[jj] - a; en.n_kmers = h_bs[jj + 1] - h_bs[jj];
+        pc.entries.push_back(en);
+      }
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !slot_busy[next_slot] || status != MGC_OK; });
+        if (status != MGC_OK) return status;
+        pc.slot = next_slot;
+        slot_busy[next_slot] = true;
+        next_slot = (next_slot + 1) % NSLOT;
+      }
+      hipError_t he = hipMemcpyAsync(pinned[pc.slot], img + a, pc.nbytes, hipMemcpyDeviceToHost, st_copy);
+      if (he == hipSuccess) he = hipStreamSynchronize(st_copy);
+      if (he != hipSuccess) {
+        { std::lock_guard<std::mutex> g(mu); slot_busy[pc.slot] = false; }
+        return fail_hip(he, "copying encoded blocks to the host");
+      }
+      {
+        std::lock_guard<std::mutex> g(mu);
+        pieces_open++;
+        queues[pc.ff % (uint32_t)n_threads].push_back(std::move(pc));
+      }
+      cv.notify_all();
+      a = e; bi = j;
+    }
+  }
+  const double t2 = now_s();
+  std::lock_guard<std::mutex> g(mu);
+  prof.plan_ms += (t1 - t0) * 1e3;
+  prof.encode_ms += enc_ms;
+  prof.copy_write_s += t2 - t1;
+  prof.n_kmers += r.n;
+  prof.n_blocks += nblk;
+  return MGC_OK;
+}
+
+extern "C" const char *mgc_db_stream_error(const mgc_db_stream *d) {
+  return d ? d->err.c_str() : mgc::thread_last_error().c_str();
+}
+
+extern "C" mgc_db_stream *mgc_db_stream_open(const char *path, uint32_t k, uint32_t w_prefix, uint32_t label_size, uint64_t label,
+                                             uint32_t part, uint32_t n_parts, int host_threads, int device) {
+  if (!path || k == 0 || k > 64 || w_prefix < MGC_NUM_FILES_BITS || w_prefix > 2 * k || w_prefix > 40 + MGC_NUM_FILES_BITS) {
+    set_err(nullptr, "mgc_db_stream_open: bad arguments");
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err(nullptr, "mgc_db_stream_open: no HIP device"); return nullptr; }
+  mgc_db_stream *d = new mgc_db_stream();
+  d->k = k; d->w_prefix = w_prefix; d->w_data = 2 * k - w_prefix; d->label_size = label_size; d->label = label;
+  d->kw = k > 32 ? 2u : 1u;
+  d->num_blocks_bits = w_prefix - MGC_NUM_FILES_BITS;
+  memset(&d->prof, 0, sizeof(d->prof));
+  d->t_open = now_s();
+  if (device < 0) (void)hipGetDevice(&device);
+  d->device = device;
+  if (host_threads <= 0) host_threads = (int)std::thread::hardware_concurrency();
+  d->n_threads = std::max(1, std::min(host_threads, MGC_NUM_FILES));
+  d->w = mdb_writer_open_ex(path, k, w_prefix, label_size, part, n_parts);
+  if (!d->w) { set_err(nullptr, "mgc_db_stream_open: %s", mdb_last_error()); delete d; return nullptr; }
+  bool ok = hipSetDevice(device) == hipSuccess &&
+            hipStreamCreateWithFlags(&d->st_enc, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&d->st_copy, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreate(&d->ev_enc[0]) == hipSuccess && hipEventCreate(&d->ev_enc[1]) == hipSuccess &&
+            hipEventCreate(&d->ev_a) == hipSuccess && hipEventCreate(&d->ev_b) == hipSuccess;
+  for (int i = 0; i < NSLOT && ok; i++)
+    ok = hipHostMalloc(reinterpret_cast<void **>(&d->pinned[i]), SLOT_BYTES, hipHostMallocDefault) == hipSuccess;
+  if (!ok) {
+    set_err(nullptr, "mgc_db_stream_open: HIP stream / pinned buffer setup failed");
+    d->closing = true; d->copy_done = true;
+    (void)mdb_writer_close(d->w);
+    for (int i = 0; i < NSLOT; i++) if (d->pinned[i]) (void)hipHostFree(d->pinned[i]);
+    delete d;
+    return nullptr;
+  }
+  d->queues.resize(d->n_threads);
+  d->copy_thread = std::thread([d] { d->copy_main(); });
+  for (int t = 0; t < d->n_threads; t++) d->pool.emplace_back([d, t] { d->pool_main(t); });
+  return d;
+}
+
+extern "C" int mgc_db_stream_write(mgc_db_stream *d, const void *d_keys, const uint32_t *d_counts, uint64_t n,
+                                   uint64_t prefix_begin, uint64_t prefix_end) {
+  if (!d) return MGC_EINVAL;
+  std::lock_guard<std::mutex> g(d->mu);
+  if (d->status != MGC_OK) return d->status;
+  if (prefix_begin > prefix_end || prefix_end > (1ull << d->w_prefix) || prefix_begin < d->next_prefix || (n && (!d_keys || !d_counts))) {
+    d->fail_locked(MGC_EINVAL, "mgc_db_stream_write: prefix ranges must ascend inside [0, 2^wPrefix)");
+    return d->status;
+  }
+  if (d->closing) { d->fail_locked(MGC_ESTATE, "mgc_db_stream_write after close"); return d->status; }
+  d->next_prefix = prefix_end;
+  if (prefix_begin == prefix_end) return n ? MGC_EINVAL : MGC_OK;
+  mgc_db_stream::Range r;
+  r.keys = d_keys; r.counts = d_counts; r.n = n; r.pb = prefix_begin; r.pe = prefix_end;
+  d->jobs.push_back(r);
+  d->jobs_queued++;
+  d->cv.notify_all();
+  return MGC_OK;
+}
+
+extern "C" int mgc_db_stream_sync(mgc_db_stream *d) {
+  if (!d) return MGC_EINVAL;
+  std::unique_lock<std::mutex> lk(d->mu);
+  d->cv.wait(lk, [&] { return d->jobs_done == d->jobs_queued && d->pieces_open == 0; });
+  return d->status;
+}
+
+extern "C" int mgc_db_stream_close(mgc_db_stream *d, mgc_db_write_profile *prof) {
+  if (!d) return MGC_EINVAL;
+  { std::lock_guard<std::mutex> g(d->mu); d->closing = true; }
+  d->cv.notify_all();
+  d->copy_thread.join();
+  for (auto &t : d->pool) t.join();
+  int rc = d->status;
+  if (rc == MGC_OK) {
+    std::vector<uint64_t> hv, ho;
+    for (auto &kv : d->hist_acc) { hv.push_back(kv.first); ho.push_back(kv.second); }
+    rc = mdb_writer_add_histogram(d->w, hv.data(), ho.data(), hv.size());
+  }
+  const int rc2 = mdb_writer_close(d->w);
+  if (rc == MGC_OK && rc2 != MGC_OK) { rc = rc2; d->err = std::string("closing the database: ") + mdb_last_error(); }
+  if (rc != MGC_OK) set_err(nullptr, "%s", d->err.c_str());
+  (void)hipSetDevice(d->device);
+  d->d_bs.release(); d->d_bytes.release(); d->d_vbase.release(); d->d_bb.release(); d->d_pos.release();
+  d->d_hist.release(); d->d_big.release(); d->d_img[0].release(); d->d_img[1].release();
+  for (int i = 0; i < NSLOT; i++) if (d->pinned[i]) (void)hipHostFree(d->pinned[i]);
+  for (int i = 0; i < 2; i++) if (d->ev_enc[i]) (void)hipEventDestroy(d->ev_enc[i]);
+  if (d->ev_a) (void)hipEventDestroy(d->ev_a);
+  if (d->ev_b) (void)hipEventDestroy(d->ev_b);
+  if (d->st_enc) (void)hipStreamDestroy(d->st_enc);
+  if (d->st_copy) (void)hipStreamDestroy(d->st_copy);
+  d->prof.total_s = now_s() - d->t_open;
+  if (prof) *prof = d->prof;
+  delete d;
+  return rc;
+}
+
+// ================================================================================================
+//  session result -> database
+// ================================================================================================
+namespace {
+struct WriteCtx { mdb_writer *w; };
+int write_cb2(void *ctx, uint64_t prefix, uint64_t n, const uint64_t *slo, const uint64_t *shi, const uint32_t *cnt,
+              const uint64_t *labels, uint64_t label) {
+  return mdb_writer_add_block_labelled(((WriteCtx *)ctx)->w, prefix, n, slo, shi, cnt, labels, label);
+}
+}  // namespace
+
+extern "C" int mgc_write_database_profiled(mgc_session *s, const char *path, int host_threads, mgc_db_write_profile *prof) {
+  if (!s || !path) return MGC_EINVAL;
+  if (!s->counted) { set_err(&s->err, "mgc_write_database before mgc_count"); return MGC_ESTATE; }
+  if (prof) memset(prof, 0, sizeof(*prof));
+  const mgc_count_config &c = s->cfg;
+  if (s->merged) {
+    // a result merged from out-of-core batches on the host: encoded by the host writer from the host arrays
+    const double t0 = now_s();
+    WriteCtx wc;
+    wc.w = mdb_writer_open_ex(path, c.k, c.w_prefix, c.label_size, 0, 1);
+    if (!wc.w) { set_err(&s->err, "%s", mdb_last_error()); return MGC_EINVAL; }
+    int rc = mgc_finish_labelled(s, write_cb2, &wc, host_threads);
+    const int rc2 = mdb_writer_close(wc.w);
+    if (rc == MGC_OK && rc2 != MGC_OK) { rc = rc2; set_err(&s->err, "%s", mdb_last_error()); }
+    if (prof) { prof->total_s = prof->copy_write_s = now_s() - t0; prof->n_kmers = s->n_distinct; prof->n_blocks = c.n_prefix; }
+    return rc;
+  }
+  mgc_db_stream *d = mgc_db_stream_open(path, c.k, c.w_prefix, c.label_size, c.label_constant, 0, 1, host_threads, s->device);
+  if (!d) { set_err(&s->err, "%s", mgc_db_stream_error(nullptr)); return MGC_EINVAL; }
+  int rc = mgc_db_stream_write(d, s->d_unique, s->d_counts, s->n_distinct, 0, c.n_prefix);
+  std::string msg = (rc != MGC_OK) ? std::string(mgc_db_stream_error(d)) : std::string();
+  const int rc2 = mgc_db_stream_close(d, prof);
+  if (rc == MGC_OK && rc2 != MGC_OK) { rc = rc2; msg = mgc_db_stream_error(nullptr); }
+  if (rc != MGC_OK) set_err(&s->err, "%s", msg.c_str());
+  return rc;
+}
+
+extern "C" int mgc_write_database(mgc_session *s, const char *path, int host_threads) {
+  return mgc_write_database_profiled(s, path, host_threads, nullptr);
+}
+
+// ================================================================================================
+//  mgc_finish: the addBlock convention, streamed
+// ================================================================================================
+namespace {
+
+struct PinnedBuf {
+  void *p = nullptr; size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (cap >= bytes) return hipSuccess;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 256, hipHostMallocDefault);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+};
+
+int finish_impl(mgc_session *s, mgc_block_cb cb1, mgc_block_cb2 cb2, void *ctx, int host_threads) {
+  if (!s || (!cb1 && !cb2)) return MGC_EINVAL;
+  if (!s->counted) { set_err(&s->err, "mgc_finish before mgc_count"); return MGC_ESTATE; }
+  const uint64_t np = s->cfg.n_prefix;
+  const bool wide = s->key_words == 2;
+  const uint32_t kw = s->key_words;
+  const uint64_t label = s->cfg.label_constant;
+
+  // suffix = low w_data bits of the k-mer (wDataMask, merylOp-count.C:282-286)
+  const uint32_t w_data = s->cfg.w_data;
+  const uint64_t mask_lo = (w_data >= 64) ? ~0ull : ((1ull << w_data) - 1ull);
+  const uint64_t mask_hi = (w_data <= 64) ? 0ull : ((w_data >= 128) ? ~0ull : ((1ull << (w_data - 64)) - 1ull));
+  const uint64_t per_file = np / MGC_NUM_FILES;             // firstPrefixInFile/lastPrefixInFile
+  if (host_threads <= 0) host_threads = (int)(s->cfg.threads ? s->cfg.threads : std::thread::hardware_concurrency());
+  host_threads = std::max(1, std::min(host_threads, MGC_NUM_FILES));
+
+  // block boundaries first (small); the k-mers follow file by file
+  std::vector<uint64_t> bstart_own;
+  const uint64_t *bstart;
+  if (s->merged) {
+    bstart = s->m_bstart.data();
+  } else {
+    HIP_TRY(s, hipSetDevice(s->device));
+    bstart_own.resize(np + 1);
+    HIP_TRY(s, hipMemcpy(bstart_own.data(), s->d_block_start, sizeof(uint64_t) * (np + 1), hipMemcpyDeviceToHost));
+    bstart = bstart_own.data();
+  }
+
+  auto deliver = [&](uint64_t pp, uint64_t n, const uint64_t *slo, const uint64_t *shi, const uint32_t *cn) -> int {
+    return cb2 ? cb2(ctx, pp, n, slo, shi, cn, nullptr, label) : cb1(ctx, pp, n, slo, shi, cn);
+  };
+
+  // Every worker owns one file at a time (the reference's `omp parallel for schedule(dynamic,1)` over files) and streams
+  // its k-mers out of HBM in pieces of whole blocks through two pinned buffers on its own HIP stream: the copy of piece
+  // i+1 runs while the callbacks of piece i do -- no host copy of the whole result is ever made.
+  const uint64_t piece_kmers = host_threads > 16 ? (512u << 10) : (1u << 20);
+  std::atomic<uint32_t> next_file(0);
+  std::atomic<int> status(MGC_OK);
+  std::mutex err_mu;
+  auto worker = [&]() {
+    std::vector<uint64_t> slo, shi;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    PinnedBuf pk[2], pc[2];
+    auto hip_fail = [&](hipError_t e, const char *what) {
+      std::lock_guard<std::mutex> g(err_mu);
+      set_err(&s->err, "mgc_finish: %s: %s", what, hipGetErrorString(e));
+      status.store(e == hipErrorOutOfMemory ? MGC_ENOMEM : MGC_EHIP);
+    };
+    if (!s->merged) {
+      hipError_t e = hipSetDevice(s->device);
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+      if (e != hipSuccess) { hip_fail(e, "stream setup"); return; }
+    }
+    struct Span { uint64_t p0, p1; };
+    auto plan = [&](uint64_t from, uint64_t file_end) {     // whole blocks, about piece_kmers k-mers, at least one block
+      Span sp; sp.p0 = from; sp.p1 = from;
+      uint64_t n = 0;
+      while (sp.p1 < file_end) {
+        const uint64_t nb = bstart[sp.p1 + 1] - bstart[sp.p1];
+        if (sp.p1 > from && n + nb > piece_kmers) break;
+        n += nb; sp.p1++;
+      }
+      return sp;
+    };
+    auto issue = [&](const Span &sp, int b) -> bool {       // device -> pinned buffer b
+      const uint64_t k0 = bstart[sp.p0], n = bstart[sp.p1] - k0;
+      if (n == 0) return true;
+      hipError_t e = pk[b].ensure(sizeof(uint64_t) * kw * n);
+      if (e == hipSuccess) e = pc[b].ensure(sizeof(uint32_t) * n);
+      if (e == hipSuccess) e = hipMemcpyAsync(pk[b].p, reinterpret_cast<const unsigned char *>(s->d_unique) + sizeof(uint64_t) * kw * k0,
+                                              sizeof(uint64_t) * kw * n, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(pc[b].p, s->d_counts + k0, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipEventRecord(ev[b], st);
+      if (e != hipSuccess) { hip_fail(e, "device-to-host copy"); return false; }
+      return true;
+    };
+    for (;;) {
+      const uint32_t ff = next_file.fetch_add(1);            // dynamic,1 like the reference's omp schedule
+      if (ff >= MGC_NUM_FILES || status.load() != MGC_OK) break;
+      const uint64_t f0 = ff * per_file, f1 = (ff + 1) * per_file;
+      int b = 0;
+      Span cur = plan(f0, f1);
+      if (!s->merged && !issue(cur, b)) break;
+      bool stop = false;
+      while (cur.p0 < f1 && !stop) {
+        const Span nxt = plan(cur.p1, f1);
+        if (!s->merged && nxt.p0 < f1 && !issue(nxt, b ^ 1)) { stop = true; break; }
+        const uint64_t k0 = bstart[cur.p0], n = bstart[cur.p1] - k0;
+        const uint64_t *keys = nullptr;
+        const uint32_t *cnts = nullptr;
+        if (s->merged) {
+          cnts = s->m_counts.data() + k0;
+        } else if (n) {
+          hipError_t e = hipEventSynchronize(ev[b]);
+          if (e != hipSuccess) { hip_fail(e, "device-to-host copy"); stop = true; break; }
+          keys = reinterpret_cast<const uint64_t *>(pk[b].p);
+          cnts = reinterpret_cast<const uint32_t *>(pc[b].p);
+        }
+        for (uint64_t pp = cur.p0; pp < cur.p1; pp++) {
+          const uint64_t o = bstart[pp] - k0, m = bstart[pp + 1] - bstart[pp];
+          slo.resize(m);
+          if (wide) shi.resize(m);
+          if (s->merged) {
+            for (uint64_t i = 0; i < m; i++) slo[i] = s->m_lo[k0 + o + i] & mask_lo;
+            if (wide) for (uint64_t i = 0; i < m; i++) shi[i] = s->m_hi[k0 + o + i] & mask_hi;
+          } else if (wide) {
+            for (uint64_t i = 0; i < m; i++) { slo[i] = keys[2 * (o + i)] & mask_lo; shi[i] = keys[2 * (o + i) + 1] & mask_hi; }
+          } else {
+            for (uint64_t i = 0; i < m; i++) slo[i] = keys[o + i] & mask_lo;
+          }
+          const int r = deliver(pp, m, slo.data(), wide ? shi.data() : nullptr, m ? cnts + o : nullptr);   // empty blocks too
+          if (r != 0) { status.store(r); stop = true; break; }
+        }
+        cur = nxt;
+        b ^= 1;
+      }
+      if (stop) break;
+    }
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (int i = 0; i < 2; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < host_threads; t++) pool.emplace_back(worker);
+  worker();
+  for (auto &t : pool) t.join();
+  return status.load();
+}
+
+}  // namespace
+
+extern "C" int mgc_finish(mgc_session *s, mgc_block_cb cb, void *ctx, int host_threads) {
+  return finish_impl(s, cb, nullptr, ctx, host_threads);
+}
+
+extern "C" int mgc_finish_labelled(mgc_session *s, mgc_block_cb2 cb, void *ctx, int host_threads) {
+  return finish_impl(s, nullptr, cb, ctx, host_threads);
+}

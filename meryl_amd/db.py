@@ -18,18 +18,19 @@ def _err(what):
 class Writer:
     """merylFileWriter + merylBlockWriter for the count path."""
 
-    def __init__(self, path, k, w_prefix):
-        self._h = capi.lib().mdb_writer_open(path.encode(), k, w_prefix)
+    def __init__(self, path, k, w_prefix, label_size=0, part=0, n_parts=1):
+        """part / n_parts: one writer of a sharded database (finish with merge_parts once all are closed)."""
+        self._h = capi.lib().mdb_writer_open_ex(path.encode(), k, w_prefix, label_size, part, n_parts)
         if not self._h:
             raise _err("mdb_writer_open")
 
-    def add_block(self, prefix, suffix_lo, counts, suffix_hi=None):
+    def add_block(self, prefix, suffix_lo, counts, suffix_hi=None, label=0):
         slo = np.ascontiguousarray(suffix_lo, dtype=np.uint64)
         cnt = np.ascontiguousarray(counts, dtype=np.uint32)
         shi = None if suffix_hi is None else np.ascontiguousarray(suffix_hi, dtype=np.uint64)
-        rc = capi.lib().mdb_writer_add_block(self._h, int(prefix), slo.size, slo.ctypes.data if slo.size else None,
-                                             shi.ctypes.data if shi is not None and shi.size else None,
-                                             cnt.ctypes.data if cnt.size else None)
+        rc = capi.lib().mdb_writer_add_block_labelled(self._h, int(prefix), slo.size, slo.ctypes.data if slo.size else None,
+                                                      shi.ctypes.data if shi is not None and shi.size else None,
+                                                      cnt.ctypes.data if cnt.size else None, None, int(label))
         if rc != 0:
             raise _err("mdb_writer_add_block")
 
@@ -39,6 +40,13 @@ class Writer:
             self._h = None
             if rc != 0:
                 raise _err("mdb_writer_close")
+
+
+def merge_parts(path, n_parts):
+    """Stitches the part files of a sharded database into the final 64+64+1 files (one caller, after every part closed)."""
+    rc = capi.lib().mdb_merge_parts(path.encode(), int(n_parts))
+    if rc != 0:
+        raise _err("mdb_merge_parts")
 
 
 def write_database(session, path, host_threads=8):
@@ -64,13 +72,14 @@ class Reader:
             capi.lib().mdb_reader_histogram(self._h, v.ctypes.data, o.ctypes.data)
         return v, o
 
-    def read_file(self, ff):
+    def read_file(self, ff, labels=False):
         lo = ctypes.c_void_p()
         hi = ctypes.c_void_p()
         cn = ctypes.c_void_p()
+        lb = ctypes.c_void_p()
         n = ctypes.c_uint64(0)
-        rc = capi.lib().mdb_reader_read_file(self._h, ff, ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(cn),
-                                             ctypes.byref(n))
+        rc = capi.lib().mdb_reader_read_file_ex(self._h, ff, ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(cn),
+                                                ctypes.byref(lb), ctypes.byref(n))
         if rc != 0:
             raise _err("mdb_reader_read_file")
         m = n.value
@@ -84,14 +93,29 @@ class Reader:
             capi.lib().mdb_free(p)
             return out
 
-        return take(lo, np.uint64), take(hi, np.uint64), take(cn, np.uint32)
+        out = (take(lo, np.uint64), take(hi, np.uint64), take(cn, np.uint32), take(lb, np.uint64))
+        return out if labels else out[:3]
 
-    def read_all(self):
-        los, his, cns = [], [], []
+    def read_all(self, labels=False):
+        cols = [[] for _ in range(4 if labels else 3)]
         for ff in range(64):
-            a, b, c = self.read_file(ff)
-            los.append(a); his.append(b); cns.append(c)
-        return np.concatenate(los), np.concatenate(his), np.concatenate(cns)
+            for c, a in zip(cols, self.read_file(ff, labels)):
+                c.append(a)
+        return tuple(np.concatenate(c) for c in cols)
+
+    def file_index(self, ff):
+        """(prefix, position, n_kmers) rows of file ff's index"""
+        n = 1 << self.info.num_blocks_bits
+        arr = (capi.IndexEntry * n)()
+        if capi.lib().mdb_reader_file_index(self._h, ff, arr) != 0:
+            raise _err("mdb_reader_file_index")
+        return [(e.prefix, e.position, e.n_kmers) for e in arr]
+
+    def block_header(self, ff, position):
+        h = capi.BlockHeader()
+        if capi.lib().mdb_reader_block_header(self._h, ff, position, ctypes.byref(h)) != 0:
+            raise _err("mdb_reader_block_header")
+        return h
 
     def close(self):
         if self._h:

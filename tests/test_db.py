@@ -161,3 +161,136 @@ def test_writer_rejects_bad_use(tmp_path, native_lib):
     w.close()
     with pytest.raises(db.DbError):
         db.Reader(str(tmp_path / "nonexistent"))
+
+
+def _dir_bytes(path):
+    return {n: open(os.path.join(path, n), "rb").read() for n in sorted(os.listdir(path))}
+
+
+def _blocks_of(keys, counts, k, wp):
+    w_data = 2 * k - wp
+    by_prefix = {}
+    for key, c in zip(keys, counts):
+        by_prefix.setdefault(key >> w_data, []).append((key & ((1 << w_data) - 1), int(c)))
+    return by_prefix, w_data
+
+
+def _feed(w, by_prefix, w_data, p0, p1, label=0):
+    for p in range(p0, p1):
+        items = by_prefix.get(p, [])
+        suf = [s for s, _ in items]
+        w.add_block(p, [s & 0xFFFFFFFFFFFFFFFF for s in suf], [c for _, c in items],
+                    [s >> 64 for s in suf] if w_data > 64 else None, label=label)
+
+
+@pytest.mark.parametrize("k,wp,cuts", [(21, 10, [0, 300, 1024]), (21, 12, [0, 64, 65, 2000, 4096]), (51, 9, [0, 1, 100, 511, 512]),
+                                        (16, 8, [0, 256]), (31, 10, [0, 512, 512, 1024])])
+def test_part_writers_merge_to_identical_bytes(tmp_path, native_lib, oracle_lib, k, wp, cuts):
+    """A database written by several part writers over contiguous prefix ranges (cuts in the middle of files, empty
+    ranges, one part only) and stitched by mdb_merge_parts is byte-identical to the single writer's."""
+    from meryl_amd import db
+    rng = np.random.default_rng(k + wp)
+    bases = random_reads(rng, 120, 40, 250)
+    path1, keys, counts, _ = make_db(tmp_path, oracle_lib, k, wp, bases, "single")
+    by_prefix, w_data = _blocks_of(keys, counts, k, wp)
+    pathn = str(tmp_path / "parts")
+    n_parts = len(cuts) - 1
+    for part in reversed(range(n_parts)):                # closing order does not matter
+        w = db.Writer(pathn, k, wp, part=part, n_parts=n_parts)
+        _feed(w, by_prefix, w_data, cuts[part], cuts[part + 1])
+        w.close()
+    if n_parts > 1:
+        assert any(".part" in n for n in os.listdir(pathn))
+        db.merge_parts(pathn, n_parts)
+    a, b = _dir_bytes(path1), _dir_bytes(pathn)
+    assert sorted(a) == sorted(b) and len(a) == 129
+    for n in a:
+        assert a[n] == b[n], n
+
+
+def test_merge_parts_refuses_missing_or_overlapping_parts(tmp_path, native_lib):
+    from meryl_amd import db
+    p = str(tmp_path / "bad")
+    w = db.Writer(p, 21, 10, part=0, n_parts=2)
+    w.add_block(5, [1, 2], [1, 1])
+    w.close()
+    with pytest.raises(db.DbError):
+        db.merge_parts(p, 2)                              # part 1 never written
+    w = db.Writer(p, 21, 10, part=1, n_parts=2)
+    w.add_block(4, [1], [1])                              # below part 0's last prefix, same file
+    w.close()
+    with pytest.raises(db.DbError):
+        db.merge_parts(p, 2)
+
+
+def test_labelled_database_roundtrip(tmp_path, native_lib, oracle_lib):
+    """meryl2's constant count label (addCountedBlock(..., labels=nullptr, label)): stored per k-mer in label_size bits,
+    read back by the reader; label_size 0 writes exactly the unlabelled bytes."""
+    from meryl_amd import db
+    k, wp = 21, 10
+    rng = np.random.default_rng(3)
+    bases = random_reads(rng, 80, 40, 200)
+    path0, keys, counts, _ = make_db(tmp_path, oracle_lib, k, wp, bases, "plain")
+    by_prefix, w_data = _blocks_of(keys, counts, k, wp)
+    pl = str(tmp_path / "lab")
+    w = db.Writer(pl, k, wp, label_size=7)
+    _feed(w, by_prefix, w_data, 0, 1 << wp, label=0x155)   # only the low 7 bits (0x55) are stored
+    w.close()
+    r = db.Reader(pl)
+    assert r.info.label_size == 7
+    lo, hi, cn, lb = r.read_all(labels=True)
+    assert [int(x) for x in lo] == [kk & 0xFFFFFFFFFFFFFFFF for kk in keys] and [int(c) for c in cn] == counts
+    assert np.all(lb == 0x55) and lb.size == len(keys)
+    r.close()
+    r0 = db.Reader(path0)
+    assert r0.info.label_size == 0
+    r0.close()
+    assert os.path.getsize(os.path.join(pl, "0x000000.merylData")) > os.path.getsize(os.path.join(path0, "0x000000.merylData"))
+
+
+def test_reader_rejects_truncated_and_corrupt_files(tmp_path, native_lib, oracle_lib):
+    """The reader trusts nothing on disk: truncated data, a damaged master index, absurd sizes -> DbError, no crash."""
+    from meryl_amd import db
+    import shutil
+    k, wp = 21, 10
+    rng = np.random.default_rng(9)
+    path, keys, counts, _ = make_db(tmp_path, oracle_lib, k, wp, random_reads(rng, 60, 40, 200), "ok")
+    # 1. data file cut short
+    p1 = str(tmp_path / "trunc"); shutil.copytree(path, p1)
+    f = os.path.join(p1, "0x000000.merylData")
+    data = open(f, "rb").read()
+    open(f, "wb").write(data[:len(data) // 2])
+    r = db.Reader(p1)
+    with pytest.raises(db.DbError):
+        r.read_file(0)
+    r.close()
+    # 2. block payload zeroed (unary codes never terminate)
+    p2 = str(tmp_path / "zero"); shutil.copytree(path, p2)
+    f = os.path.join(p2, "0x000000.merylData")
+    idx = np.fromfile(os.path.join(p2, "0x000000.merylIndex"), dtype=np.uint64).reshape(-1, 3)
+    big = int(np.argmax(idx[:, 2]))
+    if idx[big, 2] > 0:
+        start = int(idx[big, 1]) + 48 + 66
+        buf = bytearray(open(f, "rb").read())
+        end = int(idx[big + 1, 1]) if big + 1 < len(idx) else len(buf)
+        buf[start:end] = bytes(end - start)
+        open(f, "wb").write(bytes(buf))
+        r = db.Reader(p2)
+        with pytest.raises(db.DbError):
+            r.read_file(0)
+        r.close()
+    # 3. master index with an absurd histogram length / parameters
+    p3 = str(tmp_path / "master"); shutil.copytree(path, p3)
+    f = os.path.join(p3, "merylIndex")
+    buf = bytearray(open(f, "rb").read())
+    words = np.frombuffer(bytes(buf[48:]), dtype="<u8").copy()          # header 16+8+8 bytes, then nw, nalloc, words
+    words[7] = np.uint64(0xFFFFFFFFFFFFFF)                              # nPairs
+    open(f, "wb").write(bytes(buf[:48]) + words.tobytes())
+    with pytest.raises(db.DbError):
+        db.Reader(p3)
+    buf2 = bytearray(open(os.path.join(path, "merylIndex"), "rb").read())
+    w2 = np.frombuffer(bytes(buf2[48:]), dtype="<u8").copy()
+    w2[2] = np.uint64((200 << 32) | 3)                                  # prefixSize 200
+    open(f, "wb").write(bytes(buf2[:48]) + w2.tobytes())
+    with pytest.raises(db.DbError):
+        db.Reader(p3)
