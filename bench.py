@@ -67,6 +67,115 @@ def cpu_baseline(sample_reads, threads):
     }
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` invoked plainly: start the N ranks under torch.distributed.run (one per GPU, RCCL) and
+    relay the ONE JSON line rank 0 prints."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
+def valid_windows(bases, k, chunk=1 << 30):
+    """k-mer windows without a non-ACGT byte, computed independently of the library (torch ops on the device): the
+    positions of the invalid bytes cut the stream into runs, a run of length L holds max(0, L - k + 1) windows."""
+    import torch
+    n = bases.numel()
+    bad = []
+    for a in range(0, n, chunk):
+        b = bases[a:a + chunk] | 0x20
+        ok = (b == ord("a")) | (b == ord("c")) | (b == ord("g")) | (b == ord("t"))
+        bad.append(torch.nonzero(~ok).flatten() + a)
+        del b, ok
+    idx = torch.cat([torch.tensor([-1], device=bases.device)] + bad + [torch.tensor([n], device=bases.device)])
+    runs = idx[1:] - idx[:-1] - 1
+    return int(torch.clamp(runs - (k - 1), min=0).sum().item())
+
+
+def result_check(sess, bases, k, info):
+    """Untimed sanity check of the counted result at the judged size (the parity tests proper are tests/test_gpu_parity.py):
+    instances == valid windows of the input, distinct k-mers strictly ascending, counts sum to the instances per file."""
+    import torch
+    keys, cnts = sess.result_device()
+    out = {}
+    want = valid_windows(bases, k)
+    out["valid_windows"] = want
+    out["instances_equal_valid_windows"] = bool(info.n_instances == want)
+    out["keys_strictly_ascending"] = bool((keys[1:] > keys[:-1]).all().item()) if keys.numel() > 1 else True   # k <= 31: int64 order == uint64 order
+    c64 = cnts.to(torch.int64) & 0xFFFFFFFF
+    out["sum_counts_equals_instances"] = bool(int(c64.sum().item()) == info.n_instances)
+    bounds = torch.arange(0, 65, device=keys.device, dtype=torch.int64) << (2 * k - 6)
+    cut = torch.searchsorted(keys, bounds)
+    csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=keys.device), torch.cumsum(c64, 0)])
+    per_file = (csum[cut[1:]] - csum[cut[:-1]]).cpu().tolist()
+    out["per_file_totals_match"] = bool(per_file == [int(x) for x in info.file_instances])
+    out["distinct_ge_1"] = bool(int(c64.min().item()) >= 1) if keys.numel() else True
+    out["ok"] = all(v for kk, v in out.items() if isinstance(v, bool))
+    return out
+
+
+def e2e_run(bases, reads, threads):
+    """File -> database wall clock of the stand-alone CLI: the synthetic reads are written as a FASTQ
+    file on tmpfs, `meryl count` reads it, parses it on the device, counts, encodes the blocks on the device and writes
+    the 64-file database back to tmpfs.  Never part of `value`."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    import torch
+    from meryl_amd import build
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    st = os.statvfs(shm)
+    free = st.f_bavail * st.f_frsize
+    rec = READ_LEN * 2 + 7
+    use = reads
+    need = lambda r: r * rec * 1.45 + (1 << 30)            # FASTQ + database
+    while use > 1000 and need(use) > free * 0.8:
+        use //= 2
+    d = tempfile.mkdtemp(prefix="mgc_e2e_", dir=shm)
+    try:
+        fq = os.path.join(d, "reads.fq")
+        t0 = time.perf_counter()
+        with open(fq, "wb") as f:
+            step = 4_000_000
+            for a in range(0, use, step):
+                n = min(step, use - a)
+                r = torch.empty((n, rec), dtype=torch.uint8, device=bases.device)
+                r[:, 0] = ord("@"); r[:, 1] = ord("r"); r[:, 2] = 10
+                r[:, 3:3 + READ_LEN] = bases[a * (READ_LEN + 1):(a + n) * (READ_LEN + 1)].view(n, READ_LEN + 1)[:, :READ_LEN]
+                r[:, 3 + READ_LEN] = 10; r[:, 4 + READ_LEN] = ord("+"); r[:, 5 + READ_LEN] = 10
+                r[:, 6 + READ_LEN:6 + 2 * READ_LEN] = ord("I"); r[:, 6 + 2 * READ_LEN] = 10
+                f.write(r.cpu().numpy().tobytes())
+                del r
+        t_gen = time.perf_counter() - t0
+        dbp = os.path.join(d, "out.meryl")
+        cli = build.build_cli()
+        cmd = [cli, "-V", "k=%d" % K, "memory=64", "threads=%d" % threads, "n=10000000000", "count", fq, "output", dbp]
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"error": "meryl CLI rc=%d: %s" % (p.returncode, p.stderr[-400:])}
+        out = {"reads": use, "bases": use * READ_LEN, "fastq_bytes": os.path.getsize(fq), "wall_s": wall,
+               "threads": threads, "where": shm, "fastq_generation_s": t_gen,
+               "database_bytes": sum(os.path.getsize(os.path.join(dbp, n)) for n in os.listdir(dbp)),
+               "command": "meryl -V k=%d memory=64 threads=%d n=10000000000 count reads.fq output out.meryl" % (K, threads)}
+        m = re.search(r"TIMING(.*)", p.stderr)
+        if m:
+            for name, val in re.findall(r"([a-z+_]+)=([0-9.]+)", m.group(1)):
+                out[name + ("" if name.endswith("bytes") else "_s")] = float(val)
+        if "count" in out and out.get("count_s"):
+            pass
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def pmc_traffic(reads):
     """HBM bytes per launch of the dominant kernel from the committed PMC run of this same workload
     (profiles/*_pmc_traffic.json, made by scripts/gpu_pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
@@ -91,7 +200,12 @@ def main():
     ap.add_argument("--reads", type=int, default=DEFAULT_READS, help="reads per GPU (default = 10 Gbp)")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the untimed file -> database run of the CLI")
+    ap.add_argument("--no-check", action="store_true", help="skip the untimed result check")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     # Libraries (RCCL prints a version banner) may write to stdout; the contract is ONE JSON line
     # there, so everything before the final print goes to stderr.
@@ -161,6 +275,7 @@ def main():
                 for i in range(capi.NUM_STAGES):
                     prof_acc["stage_ms"][i] += p.stage_ms[i]
             info = sess.info()
+            result["info"] = info
             result["n_distinct"] = info.n_distinct
             result["n_instances"] = info.n_instances
             result["w_prefix"] = info.w_prefix
@@ -237,6 +352,31 @@ def main():
         if single:
             line["stage_ms_per_step"] = {capi.STAGE_NAMES[i]: prof_acc["stage_ms"][i] / args.steps
                                          for i in range(capi.NUM_STAGES)}
+            if not args.no_check:
+                line["check"] = result_check(sess, bases, K, result["info"])
+            if not args.no_e2e:
+                # device encode + write of the timed result (no file input), then the whole CLI file -> database
+                import shutil
+                import tempfile
+                shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+                dbdir = tempfile.mkdtemp(prefix="mgc_db_", dir=shm)
+                try:
+                    t0 = time.perf_counter()
+                    wp = sess.write_database(os.path.join(dbdir, "db.meryl"), min(32, os.cpu_count() or 8))
+                    wp["wall_s"] = time.perf_counter() - t0
+                    wp["vs_count_step"] = wp["wall_s"] / (ms_per_step / 1e3)
+                    line["db_write"] = wp
+                except Exception as e:                                  # reported, never fatal for the metric line
+                    line["db_write"] = {"error": str(e)[:300]}
+                finally:
+                    shutil.rmtree(dbdir, ignore_errors=True)
+                sess.close()
+                count.release_cached_sessions()
+                torch.cuda.empty_cache()
+                try:
+                    line["e2e"] = e2e_run(bases, reads, min(32, os.cpu_count() or 8))
+                except Exception as e:
+                    line["e2e"] = {"error": str(e)[:300]}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_sample_reads, os.cpu_count() or 1)
         sys.stdout.flush()

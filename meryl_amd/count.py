@@ -244,6 +244,13 @@ class Session:
                                               bstart.ctypes.data), "mgc_copy_result", self._h)
         return lo, hi, counts, bstart
 
+    def write_database(self, path, host_threads=8):
+        """Result -> database directory (blocks encoded on the device); returns the write profile as a dict."""
+        prof = capi.DbWriteProfile()
+        capi.check(capi.lib().mgc_write_database_profiled(self._h, path.encode(), host_threads, ctypes.byref(prof)),
+                   "mgc_write_database", self._h)
+        return prof.as_dict()
+
     def finish(self, callback, host_threads=1):
         """callback(prefix, n_kmers, suffix_lo uint64[n], counts uint32[n][, suffix_hi]) per block,
         addBlock order; suffix_hi is passed (5th argument) only when the callback accepts it."""
@@ -270,6 +277,49 @@ class Session:
         if err:
             raise err[0]
         capi.check(rc, "mgc_finish", self._h)
+
+
+class DbStream:
+    """Device-resident (k-mer, count) ranges -> database files, encoded on the device (mgc_db_stream_*,
+    include/meryl_db.h).  One stream = one writer, or part `part` of `n_parts` of a sharded database."""
+
+    def __init__(self, path, k, w_prefix, label_size=0, label=0, part=0, n_parts=1, host_threads=8, device=-1):
+        self._h = capi.lib().mgc_db_stream_open(path.encode(), k, w_prefix, label_size, label, part, n_parts,
+                                                host_threads, device)
+        if not self._h:
+            raise capi.MgcError(-1, "mgc_db_stream_open", capi.lib().mgc_db_stream_error(None).decode("utf-8", "replace"))
+        self._keep = []
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = capi.lib().mgc_db_stream_error(self._h if self._h else None)
+            raise capi.MgcError(rc, what, msg.decode("utf-8", "replace") if msg else "")
+
+    def write(self, keys, counts, prefix_begin, prefix_end):
+        """Queues the blocks of prefixes [prefix_begin, prefix_end): `keys` (int64[n] / int64[n, 2] cuda tensor, ascending)
+        hold exactly the distinct k-mers of that range, `counts` (int32[n]) their counts.  Asynchronous: the tensors are
+        kept alive here until sync()/close()."""
+        torch.cuda.current_stream(keys.device).synchronize()       # the stream's own HIP streams read them
+        self._keep.append((keys, counts))
+        self._check(capi.lib().mgc_db_stream_write(self._h, _ptr(keys), _ptr(counts), keys.shape[0], int(prefix_begin),
+                                                   int(prefix_end)), "mgc_db_stream_write")
+
+    def sync(self):
+        self._check(capi.lib().mgc_db_stream_sync(self._h), "mgc_db_stream_sync")
+        self._keep = []
+
+    def close(self):
+        """-> profile dict (plan_ms, encode_ms, copy_write_s, total_s, data_bytes, n_kmers, n_blocks)"""
+        if not self._h:
+            return None
+        prof = capi.DbWriteProfile()
+        h, self._h = self._h, None
+        rc = capi.lib().mgc_db_stream_close(h, ctypes.byref(prof))
+        self._keep = []
+        if rc != 0:
+            msg = capi.lib().mgc_db_stream_error(None)
+            raise capi.MgcError(rc, "mgc_db_stream_close", msg.decode("utf-8", "replace") if msg else "")
+        return prof.as_dict()
 
 
 def count_bases(bases, k, mode=capi.MODE_CANONICAL, n_estimate=None, memory_gb=4.0, device=-1, profiling=False):
@@ -422,8 +472,13 @@ class HipOps:
             return _u64(2 * n, like.device).view(int(n), 2)
         return _u64(n, like.device)
 
+    @staticmethod
+    def open_sink(path, k, w_prefix, label_size, label, part, n_parts, host_threads):
+        """where the owned (k-mer, count) ranges of a sharded count go: a device-encoding database stream"""
+        return DbStream(path, k, w_prefix, label_size, label, part, n_parts, host_threads)
 
-def shard_bucket_bits(world, k, n_bases_local=0):
+
+def shard_bucket_bits(world, k, n_bases_local=0, w_prefix=None):
     """Top bits of the k-mer that route it in a `world`-rank count: 6 (the files) + ceil(log2(world)), one more for every
     doubling of the per-rank input beyond what keeps a bucket within two grouping digits (~180 M bases), at most 10."""
     extra = max(0, (int(world) - 1).bit_length())
@@ -431,10 +486,13 @@ def shard_bucket_bits(world, k, n_bases_local=0):
         extra += 1
     if os.environ.get("MGC_SHARD_BITS"):                   # experiments: the granularity of an N-rank run on fewer ranks
         extra = int(os.environ["MGC_SHARD_BITS"]) - 6
-    return max(6, min(10, 6 + extra, 2 * int(k)))
+    bits = max(6, min(10, 6 + extra, 2 * int(k)))
+    if w_prefix is not None:                                # a database is written: rank ranges must be cut between blocks
+        bits = min(bits, int(w_prefix))
+    return bits
 
 
-def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
+def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db=None, keep_result=True):
     """Collective.  Every rank passes ITS OWN reads (uint8 tensor on its GPU);
     returns this rank's share of the database: (unique keys, counts int32,
     (first_bucket, end_bucket, bucket_bits)).  The concatenation over ranks, in rank order, is
@@ -447,7 +505,15 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
     is as large as a single-GPU file however many GPUs feed it (a whole file would be N times larger: a third grouping
     pass, and past 2^30 k-mers the stable wide-granule passes).  Layout after the exchange is bucket-major -- for
     every owned bucket, the pieces of all source ranks back to back -- and each bucket goes through the grouping
-    passes and the LDS finish exactly like a file of the single-GPU path (mgc_count_buckets)."""
+    passes and the LDS finish exactly like a file of the single-GPU path (mgc_count_buckets).
+
+    db = dict(path=..., w_prefix=..., label_size=0, label=0, host_threads=8): the ranks also WRITE THE DATABASE -- the
+    reference's final dump (merylOp-countThreads.C:452-464) spread over the ranks.  Rank r streams the blocks of its
+    bucket range into part r of the directory while later waves are still being exchanged and counted (ops.open_sink;
+    the product sink encodes the blocks on the device); after a barrier rank 0 stitches the parts (mdb_merge_parts): the
+    64+64+1 files are byte-identical to a single-GPU count of all reads.  A rank range may begin or end inside a file --
+    the cut is between two blocks, which is why the routing granularity never exceeds w_prefix bits.
+    keep_result=False drops the per-wave tensors once written (the return value then holds empty tensors)."""
     import torch.distributed as dist
     import time as _time
     world = dist.get_world_size(group)
@@ -463,7 +529,7 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
     mark("start")
     nb_local = torch.tensor([int(bases.numel())], dtype=torch.int64, device=bases.device)
     dist.all_reduce(nb_local, op=dist.ReduceOp.MAX, group=group)                 # every rank must pick the same granularity
-    bits = shard_bucket_bits(world, k, int(nb_local.item()))
+    bits = shard_bucket_bits(world, k, int(nb_local.item()), db["w_prefix"] if db else None)
     nbk = 1 << bits
     keys, local_counts = ops.partition(bases, k, mode, bits)                     # grouped by bucket, ascending
     mark("partition")
@@ -476,6 +542,12 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
     cuts = balanced_file_ranges(per_rank.sum(axis=0), world)
 
     f0, f1 = cuts[rank], cuts[rank + 1]
+    sink = None
+    if db is not None:
+        sink = ops.open_sink(db["path"], k, db["w_prefix"], db.get("label_size", 0), db.get("label", 0), rank, world,
+                             db.get("host_threads", 8))
+        blocks_per_bucket = 1 << (db["w_prefix"] - bits)
+    n_local_distinct = 0
     file_total = per_rank[:, f0:f1].sum(axis=0)                                  # keys per owned file
     file_off = np.concatenate([[0], np.cumsum(file_total)]).astype(np.int64)
     inbox = ops.empty_keys(int(file_total.sum()), keys)
@@ -507,12 +579,23 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
         return exchange_segments(sends, recvs, keys.device, group, max_rows=longest, wait=False)
 
     def count_file(i):
+        nonlocal n_local_distinct
         lo, hi = f0 + i * bpw, min(f1, f0 + (i + 1) * bpw)
-        if lo >= hi or file_total[lo - f0:hi - f0].sum() == 0:
+        if lo >= hi:
+            return
+        if file_total[lo - f0:hi - f0].sum() == 0:
+            if sink is not None:                          # the range still gets its (empty) blocks
+                e = ops.empty_keys(0, inbox)
+                sink.write(e, torch.empty(0, dtype=torch.int32, device=e.device), lo * blocks_per_bucket, hi * blocks_per_bucket)
             return
         bc = np.zeros(nbk, dtype=np.uint64)
         bc[lo:hi] = file_total[lo - f0:hi - f0]
-        parts.append(ops.count_files(inbox[int(file_off[lo - f0]):int(file_off[hi - f0])], bc, k, mode))
+        part = ops.count_files(inbox[int(file_off[lo - f0]):int(file_off[hi - f0])], bc, k, mode)
+        n_local_distinct += int(part[0].shape[0])
+        if sink is not None:
+            sink.write(part[0], part[1], lo * blocks_per_bucket, hi * blocks_per_bucket)
+        if keep_result or sink is None:
+            parts.append(part)
 
     for i in range(n_waves + 1):
         reqs = post(i) if i < n_waves else []
@@ -526,8 +609,19 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps):
         uniq = torch.cat([p[0] for p in parts])
         cnts = torch.cat([p[1] for p in parts])
     else:
-        uniq, cnts = ops.count_files(inbox, np.zeros(nbk, dtype=np.uint64), k, mode)
+        uniq = ops.empty_keys(0, inbox)
+        cnts = torch.empty(0, dtype=torch.int32, device=uniq.device)
     mark("concat")
+    if sink is not None:
+        db["profile"] = sink.close()                      # waits for this rank's files
+        db["n_distinct_local"] = n_local_distinct
+        if world > 1:
+            dist.barrier(group=group)
+            if rank == 0:
+                from . import db as _db
+                _db.merge_parts(db["path"], world)
+            dist.barrier(group=group)
+        mark("database")
     if prof and rank == 0:
         print("[shard profile] " + "  ".join("%s %.1f ms" % (n, (t - marks[i][1]) * 1e3) for i, (n, t) in enumerate(marks[1:])),
               file=sys.stderr, flush=True)

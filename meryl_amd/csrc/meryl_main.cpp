@@ -257,7 +257,8 @@ int run_count(const Globals &g, const Operation &op) {
     fprintf(stderr, "\nInput complete.  Writing results to '%s', using %u thread%s.\n",                // :447-448
             op.output.c_str(), g.threads, (g.threads == 1) ? "" : "s");
   }
-  if (mgc_write_database(s, op.output.c_str(), (int)g.threads) != MGC_OK) {
+  mgc_db_write_profile wprof;
+  if (mgc_write_database_profiled(s, op.output.c_str(), (int)g.threads, &wprof) != MGC_OK) {
     fprintf(stderr, "ERROR: writing '%s' failed: %s %s\n", op.output.c_str(), mdb_last_error(), mgc_last_error(s));
     exit(1);
   }
@@ -267,8 +268,10 @@ int run_count(const Globals &g, const Operation &op) {
     auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double>(b - a).count();
     };
-    fprintf(stderr, "\nTIMING  read+parse+stage %.3f s   upload+count (device) %.3f s   encode+write %.3f s\n",
-            sec(t_start, t_loaded), sec(t_loaded, t_counted), sec(t_counted, t_written));
+    fprintf(stderr, "\nTIMING  read+parse+stage=%.3f s   count=%.3f s   encode+write=%.3f s   (device encode=%.4f s, copy+write=%.3f s, "
+                    "database_bytes=%" PRIu64 ")\n",
+            sec(t_start, t_loaded), sec(t_loaded, t_counted), sec(t_counted, t_written), wprof.encode_ms / 1e3,
+            wprof.copy_write_s, wprof.data_bytes);
   }
   if (g.verbosity > 0) {
     fprintf(stderr, "\nFinished counting.\n");                                                         // :473

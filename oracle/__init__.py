@@ -79,6 +79,9 @@ def lib():
                                      ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                      u64p, u64p]
     L.orc_count_threaded.restype = ctypes.c_int
+    L.orc_count_threaded_digest.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                            ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, u64p, u64p]
+    L.orc_count_threaded_digest.restype = ctypes.c_int
     L.orc_free.argtypes = [ctypes.c_void_p]
     L.orc_free.restype = None
     L.orc_kmer_to_string.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_char_p]
@@ -176,6 +179,50 @@ def time_threaded(bases, k, w_prefix, mode=CANONICAL, threads=0):
     if rc != 0:
         raise RuntimeError("orc_count_threaded failed rc=%d" % rc)
     return nd.value, ni.value
+
+
+DIGEST_C1, DIGEST_C2, DIGEST_C3 = 0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9
+
+
+def digest_threaded(bases, k, w_prefix, mode=CANONICAL, threads=0):
+    """The port's result as per-file digests -> (uint64[64, 4], n_distinct, n_instances).  `bases` may be a uint8 numpy
+    array (used in place: no 10 GB copy).  Columns: n_distinct, sum counts, sum (x*C1)*count,
+    sum ((x^C2)*(x|1))*count, x = lo ^ hi*C3, arithmetic mod 2^64."""
+    if isinstance(bases, np.ndarray) and bases.dtype == np.uint8 and bases.flags["C_CONTIGUOUS"]:
+        ptr, n, keep = bases.ctypes.data, bases.size, bases
+    else:
+        keep = _as_bytes(bases)
+        ptr, n = ctypes.cast(ctypes.c_char_p(keep), ctypes.c_void_p), len(keep)
+    out = np.zeros((64, 4), dtype=np.uint64)
+    nd = ctypes.c_uint64(0)
+    ni = ctypes.c_uint64(0)
+    rc = lib().orc_count_threaded_digest(ptr, n, k, mode, w_prefix, threads, out.ctypes.data, ctypes.byref(nd), ctypes.byref(ni))
+    del keep
+    if rc != 0:
+        raise RuntimeError("orc_count_threaded_digest failed rc=%d" % rc)
+    return out, nd.value, ni.value
+
+
+def digest_arrays(lo, hi, counts, k):
+    """The same digests from (lo, hi, counts) numpy arrays (ascending keys): the checker's own reference of the sums."""
+    M = (1 << 64) - 1
+    out = np.zeros((64, 4), dtype=np.uint64)
+    lo = lo.astype(np.uint64); hi = hi.astype(np.uint64); c = counts.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x = lo ^ (hi * np.uint64(DIGEST_C3))
+        a = (x * np.uint64(DIGEST_C1)) * c
+        b = ((x ^ np.uint64(DIGEST_C2)) * (x | np.uint64(1))) * c
+        if 2 * k - 6 >= 64:
+            f = (hi >> np.uint64(2 * k - 6 - 64)).astype(np.int64)
+        else:
+            f = ((lo >> np.uint64(2 * k - 6)) | ((hi << np.uint64(64 - (2 * k - 6))) if 2 * k > 64 else np.uint64(0))).astype(np.int64)
+        for ff in range(64):
+            m = f == ff
+            out[ff, 0] = int(m.sum())
+            out[ff, 1] = int(c[m].sum(dtype=np.uint64)) & M
+            out[ff, 2] = int(a[m].sum(dtype=np.uint64)) & M
+            out[ff, 3] = int(b[m].sum(dtype=np.uint64)) & M
+    return out
 
 
 def kmer_to_string(hi, lo, k):

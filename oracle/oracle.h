@@ -107,6 +107,12 @@ int      orc_count_threaded_collect(const char *bases, uint64_t n, uint32_t k, i
                                     uint64_t **keys_hi, uint64_t **keys_lo, uint32_t **counts,
                                     uint64_t *n_distinct, uint64_t *n_instances);
 
+/* Per-file digests of the port's result (64 x 4 uint64, all sums mod 2^64): n_distinct, sum of counts,
+ * sum (x*C1)*count, sum ((x^C2)*(x|1))*count, with x = lo ^ hi*C3 -- the full-size
+ * parity test takes the same sums of the GPU result without ever materialising the port's 14 GB of output. */
+int      orc_count_threaded_digest(const char *bases, uint64_t n, uint32_t k, int mode, uint32_t w_prefix, int threads,
+                                   uint64_t *out, uint64_t *n_distinct, uint64_t *n_instances);
+
 /* Deterministic synthetic reads (splitmix64 counter PRNG): a
  * random genome of `genome_len` bases from `seed`, `n_reads` reads of
  * `read_len` sampled uniformly from both strands with `sub_rate_ppm`

@@ -52,21 +52,55 @@ struct CountArray {
     return segs[seg] + (bit % seg_bits) / 64;
   }
 
-  /* append the low `width` bits of v; a value may straddle words and segments
-   * (the 1/2/3-word and cross-segment cases of merylCountArray.C:490-728) */
+  inline uint64_t *seg_ptr(uint64_t seg) {            /* addSegment, merylCountArray.C:254-270 (zeroed here) */
+    while (seg >= segs.size())
+      segs.push_back((uint64_t *)calloc(seg_bits / 64, sizeof(uint64_t)));
+    return segs[seg];
+  }
+
+  /* append the low `width` bits of v.  Structure of merylCountArray::add (merylCountArray.C:490-728): one
+   * division pair locates segment and bit, then the value lands in one, two or three words of this segment
+   * (:553-623), or is split between the last word(s) of this segment and the first of the next (:628-725).
+   * The caller masks v to `width` bits (insertKmers' wDataMask, merylOp-countThreads.C:250,255). */
   inline void add(kmdata v) {
-    uint32_t left = width;
-    while (left > 0) {
-      uint64_t *w    = word(n_bits);
-      uint32_t  off  = (uint32_t)((n_bits % seg_bits) % 64);
-      uint32_t  room = 64 - off;
-      uint64_t  in_seg_left = seg_bits - (n_bits % seg_bits);
-      if (room > in_seg_left) room = (uint32_t)in_seg_left;
-      uint32_t  take = (left < room) ? left : room;
-      uint64_t  piece = (uint64_t)(v >> (left - take)) & ((take == 64) ? ~0ull : ((1ull << take) - 1));
-      *w |= piece << (64 - off - take);
-      n_bits += take;
-      left   -= take;
+    const uint64_t nb      = n_bits;
+    const uint64_t seg     = nb / seg_bits;                         /* :497 */
+    const uint64_t seg_pos = nb % seg_bits;                         /* :498 */
+    n_bits += width;                                                /* :500 */
+    const uint32_t word     = (uint32_t)(seg_pos / 64);             /* :505 */
+    const uint32_t word_bgn = (uint32_t)(seg_pos % 64);             /* :506 */
+    const uint32_t word_end = word_bgn + width;                     /* :507 */
+    uint64_t *S = seg_ptr(seg);
+    if (seg_pos + width <= seg_bits) {                              /* sameSeg, :541 */
+      if (word_end <= 64) {                                         /* oneWord, :572-576 */
+        S[word] |= (uint64_t)(v << (64 - word_end));
+      } else if (word_end <= 128) {                                 /* twoWord, :578-597 */
+        const uint32_t end_bits = width - (64 - word_bgn);
+        S[word]     |= (uint64_t)(v >> end_bits);
+        S[word + 1]  = (uint64_t)(v << (64 - end_bits));
+      } else {                                                      /* thrWord, :600-621 */
+        const uint32_t end_bits = width - 64 - (64 - word_bgn);
+        S[word]     |= (uint64_t)(v >> (64 + end_bits));
+        S[word + 1]  = (uint64_t)(v >> end_bits);
+        S[word + 2]  = (uint64_t)(v << (64 - end_bits));
+      }
+    } else {                                                        /* the value continues in the next segment, :628-725 */
+      const uint32_t this_bits = (uint32_t)(seg_bits - seg_pos);
+      const uint32_t next_bits = width - this_bits;
+      uint64_t *N = seg_ptr(seg + 1);
+      S = segs[seg];                                                /* seg_ptr may have grown the vector */
+      if (this_bits <= 64) {                                        /* oneThis, :682-689 */
+        S[word] |= (uint64_t)(v >> (width - this_bits));
+      } else {                                                      /* twoThis, :691-701 */
+        S[word]     |= (uint64_t)(v >> (next_bits + 64));
+        S[word + 1]  = (uint64_t)(v >> next_bits);
+      }
+      if (next_bits <= 64) {                                        /* oneNext, :705-709 */
+        N[0] = (uint64_t)(v << (64 - next_bits));
+      } else {                                                      /* twoNext, :711-717 */
+        N[0] = (uint64_t)(v >> (next_bits - 64));
+        N[1] = (uint64_t)(v << (128 - next_bits));
+      }
     }
   }
 
@@ -223,6 +257,40 @@ int orc_count_threaded(const char *bases, uint64_t n, uint32_t k, int mode,
   if (n_distinct)  *n_distinct  = distinct.load();
   if (n_instances) *n_instances = added.load();
   return 0;
+}
+
+namespace {
+/* per-file digests of the (k-mer, count) stream: what the full-size parity test compares with the same sums taken on
+ * the GPU result (tests/test_gpu_parity.py); all arithmetic wraps mod 2^64 */
+struct Digest { uint32_t w_data, file_shift; uint64_t v[64][4]; };
+const uint64_t DG_C1 = 0x9E3779B97F4A7C15ull, DG_C2 = 0xC2B2AE3D27D4EB4Full, DG_C3 = 0x165667B19E3779F9ull;
+void digest_cb(void *ctx, uint64_t prefix, uint64_t nk, const kmdata *s, const kmvalu *c) {
+  Digest *D = (Digest *)ctx;               /* one thread per file (merylOp-countThreads.C:452-459): no locking needed */
+  uint64_t *d = D->v[prefix >> D->file_shift];            /* file = top six bits of the prefix */
+  for (uint64_t i = 0; i < nk; i++) {
+    const kmdata key = ((kmdata)prefix << D->w_data) | s[i];
+    const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
+    const uint64_t x = lo ^ (hi * DG_C3), cnt = (uint64_t)c[i];
+    d[0] += 1;
+    d[1] += cnt;
+    d[2] += (x * DG_C1) * cnt;
+    d[3] += ((x ^ DG_C2) * (x | 1ull)) * cnt;
+  }
+}
+}  // namespace
+
+/* out[64][4]: per file n_distinct, sum of counts, sum (x*C1)*count, sum ((x^C2)*(x|1))*count, x = lo ^ hi*C3 */
+extern "C"
+int orc_count_threaded_digest(const char *bases, uint64_t n, uint32_t k, int mode, uint32_t w_prefix, int threads,
+                              uint64_t *out, uint64_t *n_distinct, uint64_t *n_instances) {
+  Digest *D = new Digest();
+  memset(D->v, 0, sizeof(D->v));
+  D->w_data = 2 * k - w_prefix;
+  D->file_shift = w_prefix - 6;
+  int rc = orc_count_threaded(bases, n, k, mode, w_prefix, threads, digest_cb, D, n_distinct, n_instances);
+  memcpy(out, D->v, sizeof(D->v));
+  delete D;
+  return rc;
 }
 
 namespace {

@@ -347,6 +347,94 @@ def test_full_size_properties(ops, torch_cuda):
     assert sum(info.file_instances) == info.n_instances
 
 
+def device_digests(torch, keys, counts, k):
+    """per-file digests of a device result, the same sums oracle.digest_threaded takes (mod 2^64; torch int64 wraps)"""
+    import oracle
+
+    def s64(v):
+        return v - (1 << 64) if v >= (1 << 63) else v
+    if keys.dim() == 2:
+        lo, hi = keys[:, 0], keys[:, 1]
+        x = lo ^ (hi * s64(oracle.DIGEST_C3))
+    else:
+        lo, hi = keys, None
+        x = lo
+    c = counts.to(torch.int64) & 0xFFFFFFFF
+    cols = [torch.ones_like(c), c, (x * s64(oracle.DIGEST_C1)) * c, ((x ^ s64(oracle.DIGEST_C2)) * (x | 1)) * c]
+    # file boundaries: first key of file f = f << (2k-6)
+    n = keys.shape[0]
+    fb = 2 * k - 6
+    if hi is None:
+        bounds = torch.arange(0, 65, device=keys.device, dtype=torch.int64) << fb
+        if fb + 6 == 64:                                       # k = 32: the top files have the sign bit set, compare unsigned
+            cut = torch.searchsorted(lo ^ (-(1 << 63)), bounds ^ (-(1 << 63)))
+            cut[64] = n
+        else:
+            cut = torch.searchsorted(lo, bounds)
+    else:
+        f = (hi >> (fb - 64)) if fb >= 64 else (((lo >> fb) & ((1 << (64 - fb)) - 1)) | (hi << (64 - fb)))
+        cut = torch.searchsorted(f.contiguous(), torch.arange(0, 65, device=keys.device, dtype=torch.int64))
+    out = np.zeros((64, 4), dtype=np.uint64)
+    for j, col in enumerate(cols):
+        cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=keys.device), torch.cumsum(col, 0)])
+        out[:, j] = (cs[cut[1:]] - cs[cut[:-1]]).cpu().numpy().view(np.uint64)
+        del cs
+    return out
+
+
+@pytest.mark.parametrize("k,n_reads", [(21, 300_000), (31, 200_000), (51, 200_000)])
+def test_device_digests_equal_port_digests_small(ops, oracle_lib, torch_cuda, k, n_reads):
+    """the digest machinery of the full-size test, at a size where the arrays themselves are compared too"""
+    from meryl_amd import capi
+    d = ops.dev_synth_reads(4, 2_000_000, 0, n_reads)
+    cfg = capi.configure(k, d.numel(), 4 << 30)
+    with ops.Session(cfg) as s:
+        s.push_bases_device(d)
+        s.count()
+        info = s.info()
+        keys, counts = s.result_device()
+        lo, hi, cn, _ = s.result_wide()
+    got = device_digests(torch_cuda, keys, counts, k)
+    assert np.array_equal(got, oracle_lib.digest_arrays(lo, hi, cn, k))
+    want, nd, ni = oracle_lib.digest_threaded(d.cpu().numpy(), k, cfg.w_prefix, threads=8)
+    assert (nd, ni) == (info.n_distinct, info.n_instances)
+    assert np.array_equal(got, want)
+
+
+def test_config1_full_size_matches_threaded_port(ops, oracle_lib, torch_cuda):
+    """BASELINE config 1 AT ITS JUDGED SIZE -- k=21, 66,666,667 x 150 bp reads = 10 Gbp, wPrefix 18, the bench.py workload --
+    against the reference-algorithm port (oracle_port.cpp: 2 MiB chunks, spin-locked bit-packed prefix buckets, std::sort,
+    run-length count, 64-file dump) run on the host cores over the SAME bytes: every one of the 64 files must agree in
+    its number of distinct k-mers, its total count and two 64-bit weighted key sums.  ~26 GB of host RAM, a few minutes."""
+    import psutil
+    from meryl_amd import capi
+    n_reads = int(os.environ.get("MGC_TEST_FULL_READS", "66666667"))
+    if psutil.virtual_memory().available < (60 << 30) * n_reads / 66666667 + (4 << 30):
+        pytest.skip("not enough host memory for the port at this size")
+    k = 21
+    d = ops.dev_synth_reads(2, 333_333_334, 0, n_reads)
+    cfg = capi.configure(k, 10_000_000_000, 64 << 30)
+    assert cfg.w_prefix == 18
+    with ops.Session(cfg) as s:
+        s.push_bases_device(d)
+        s.count()
+        info = s.info()
+        keys, counts = s.result_device()
+    got = device_digests(torch_cuda, keys, counts, k)
+    assert bool((keys[1:] > keys[:-1]).all().item())
+    del keys, counts
+    host = d.cpu().numpy()
+    del d
+    torch_cuda.cuda.empty_cache()
+    want, nd, ni = oracle_lib.digest_threaded(host, k, cfg.w_prefix, threads=min(32, os.cpu_count() or 8))
+    assert ni == info.n_instances, (ni, info.n_instances)
+    assert nd == info.n_distinct, (nd, info.n_distinct)
+    assert np.array_equal(got[:, 0], want[:, 0]), "distinct k-mers per file differ"
+    assert np.array_equal(got[:, 1], want[:, 1]), "total counts per file differ"
+    assert np.array_equal(got, want), "weighted key sums differ"
+    assert [int(x) for x in info.file_instances] == [int(x) for x in want[:, 1]]
+
+
 def test_write_database_roundtrip(ops, oracle_lib, torch_cuda, tmp_path):
     # count on the GPU -> 64-file database on disk -> read back == oracle stream
     from meryl_amd import capi, db
