@@ -73,6 +73,12 @@ int mdb_writer_add_block_labelled(mdb_writer *w, uint64_t prefix, uint64_t n_kme
 typedef struct mdb_index_entry { uint64_t prefix, position, n_kmers; } mdb_index_entry;
 int mdb_writer_add_encoded(mdb_writer *w, uint32_t ff, const void *bytes, uint64_t nbytes,
                            const mdb_index_entry *entries, uint64_t n_entries);
+/* The same in two steps, so that many threads can write ONE file at once: reserve (same ordering rule as above, no data)
+ * registers the index entries and returns the file offset the nbytes belong at; mdb_writer_write_at then puts them
+ * there with pwrite -- thread-safe, in any order, from any thread. */
+int mdb_writer_reserve_encoded(mdb_writer *w, uint32_t ff, uint64_t nbytes, const mdb_index_entry *entries,
+                               uint64_t n_entries, uint64_t *file_offset);
+int mdb_writer_write_at(mdb_writer *w, uint32_t ff, uint64_t file_offset, const void *bytes, uint64_t nbytes);
 int mdb_writer_add_histogram(mdb_writer *w, const uint64_t *values, const uint64_t *occurrences, uint64_t n_pairs);
 
 /* merylBlockWriter::finish() + ~merylFileWriter(): per-file indexes, master

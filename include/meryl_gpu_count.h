@@ -214,6 +214,9 @@ int mgc_reserve_text(mgc_session *s, uint64_t text_bytes);       /* optional: ex
 int mgc_begin_text(mgc_session *s, int format);
 int mgc_push_text(mgc_session *s, const char *text, size_t len);
 int mgc_end_text(mgc_session *s);
+/* One whole UNCOMPRESSED FASTA/FASTQ file (format 0 = tell from the first record): begin + push + end in one call, the
+ * file read by `reader_threads` threads (0 = default) straight into pinned upload buffers.  Return codes as mgc_end_text. */
+int mgc_push_text_file(mgc_session *s, const char *path, int format, int reader_threads);
 
 /* Bases already resident in HBM (breakers included).  The buffer is borrowed
  * until mgc_count returns.  May be called once per session. */

@@ -21,13 +21,13 @@ SYMBOLS = (
     "mgc_dev_partition_workspace_bytes", "mgc_dev_kmer_histogram", "mgc_dev_kmer_partition",
     "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort",
     "mgc_dev_rle_workspace_bytes", "mgc_dev_rle_count", "mgc_dev_rle_emit", "mgc_dev_block_offsets",
-    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_copy_result_device",
+    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_push_text_file", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_copy_result_device",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish", "mgc_finish_labelled",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_dev_synth_reads_ex", "mgc_version",
     "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases",
     # include/meryl_db.h
     "mdb_writer_open", "mdb_writer_open_ex", "mdb_merge_parts", "mdb_writer_add_block", "mdb_writer_add_block_labelled",
-    "mdb_writer_add_encoded", "mdb_writer_add_histogram", "mdb_writer_close", "mdb_last_error",
+    "mdb_writer_add_encoded", "mdb_writer_reserve_encoded", "mdb_writer_write_at", "mdb_writer_add_histogram", "mdb_writer_close", "mdb_last_error",
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_read_file_ex",
     "mdb_reader_file_index", "mdb_reader_block_header", "mdb_reader_read_block_raw", "mdb_reader_close",
     "mdb_free", "mgc_write_database", "mgc_write_database_profiled",
@@ -224,6 +224,7 @@ def lib():
     sig("mgc_begin_text", i32, vp, i32)
     sig("mgc_push_text", i32, vp, ctypes.c_char_p, sz)
     sig("mgc_end_text", i32, vp)
+    sig("mgc_push_text_file", i32, vp, ctypes.c_char_p, i32, i32)
     sig("mgc_count", i32, vp)
     sig("mgc_count_partitioned", i32, vp, vp, vp, vp)
     sig("mgc_count_buckets", i32, vp, vp, u32, vp)
@@ -241,6 +242,8 @@ def lib():
     sig("mdb_writer_add_block", i32, vp, u64, u64, vp, vp, vp)
     sig("mdb_writer_add_block_labelled", i32, vp, u64, u64, vp, vp, vp, vp, u64)
     sig("mdb_writer_add_encoded", i32, vp, u32, vp, u64, vp, u64)
+    sig("mdb_writer_reserve_encoded", i32, vp, u32, u64, vp, u64, P(u64))
+    sig("mdb_writer_write_at", i32, vp, u32, u64, vp, u64)
     sig("mdb_writer_add_histogram", i32, vp, vp, vp, u64)
     sig("mdb_writer_close", i32, vp)
     sig("mdb_last_error", ctypes.c_char_p)

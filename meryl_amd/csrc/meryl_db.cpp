@@ -48,6 +48,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
@@ -132,22 +133,38 @@ struct BitReader {
 
 // A2: dump one stuffedBits object.  Fields never straddle our single logical
 // stream, so it is cut into blocks of STUFFED_BLOCK_BITS only when it is larger.
-bool dump_stuffed(FILE *f, const BitWriter &bw) {
+void dump_stuffed(std::vector<unsigned char> &out, const BitWriter &bw) {
   const uint64_t total = bw.pos;
   const uint32_t nblocks = (uint32_t)stuffed_sub_blocks(total);
   const uint32_t nmax = std::max<uint32_t>(64, nblocks);
-  std::vector<uint64_t> bgn(nblocks), len(nblocks);
-  for (uint32_t i = 0; i < nblocks; i++) {
-    bgn[i] = (uint64_t)i * STUFFED_BLOCK_BITS;
-    len[i] = std::min<uint64_t>(STUFFED_BLOCK_BITS, total - bgn[i]);
-  }
+  out.resize(stuffed_bytes(total));
+  unsigned char *o = out.data();
+  auto put = [&](const void *p, size_t n) { memcpy(o, p, n); o += n; };
   const uint64_t lenmax = STUFFED_BLOCK_BITS;
-  if (fwrite(&lenmax, 8, 1, f) != 1 || fwrite(&nblocks, 4, 1, f) != 1 || fwrite(&nmax, 4, 1, f) != 1) return false;
-  if (fwrite(bgn.data(), 8, nblocks, f) != nblocks || fwrite(len.data(), 8, nblocks, f) != nblocks) return false;
+  put(&lenmax, 8); put(&nblocks, 4); put(&nmax, 4);
+  for (uint32_t i = 0; i < nblocks; i++) { const uint64_t bgn = (uint64_t)i * STUFFED_BLOCK_BITS; put(&bgn, 8); }
   for (uint32_t i = 0; i < nblocks; i++) {
-    const uint64_t nw = (len[i] + 63) / 64, nalloc = STUFFED_BLOCK_WORDS;
-    if (fwrite(&nw, 8, 1, f) != 1 || fwrite(&nalloc, 8, 1, f) != 1) return false;
-    if (nw && fwrite(bw.w.data() + bgn[i] / 64, 8, nw, f) != nw) return false;
+    const uint64_t len = std::min<uint64_t>(STUFFED_BLOCK_BITS, total - (uint64_t)i * STUFFED_BLOCK_BITS);
+    put(&len, 8);
+  }
+  for (uint32_t i = 0; i < nblocks; i++) {
+    const uint64_t bgn = (uint64_t)i * STUFFED_BLOCK_BITS, len = std::min<uint64_t>(STUFFED_BLOCK_BITS, total - bgn);
+    const uint64_t nw = (len + 63) / 64, nalloc = STUFFED_BLOCK_WORDS;
+    put(&nw, 8); put(&nalloc, 8);
+    if (nw) put(bw.w.data() + bgn / 64, 8 * nw);
+  }
+}
+bool dump_stuffed(FILE *f, const BitWriter &bw) {
+  std::vector<unsigned char> buf;
+  dump_stuffed(buf, bw);
+  return fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+}
+bool pwrite_all(int fd, const void *p, uint64_t n, uint64_t off) {
+  const unsigned char *c = reinterpret_cast<const unsigned char *>(p);
+  while (n) {
+    const ssize_t r = pwrite(fd, c, n, (off_t)off);
+    if (r < 0) { if (errno == EINTR) continue; return false; }
+    c += r; n -= (uint64_t)r; off += (uint64_t)r;
   }
   return true;
 }
@@ -199,7 +216,7 @@ struct mdb_writer {
   uint32_t k = 0, prefix_size = 0, suffix_size = 0, num_blocks_bits = 0, label_size = 0;
   uint32_t part = 0, n_parts = 1;
   uint64_t blocks_per_file = 0;
-  FILE *dat[MGC_NUM_FILES];
+  int dat[MGC_NUM_FILES];                                  // data files: every write is a pwrite at an explicit offset
   std::vector<FileIndexEntry> index[MGC_NUM_FILES];
   uint64_t bytes[MGC_NUM_FILES];
   // histogram: small values dense, big values sparse (merylHistogram keeps the same split)
@@ -240,7 +257,7 @@ extern "C" mdb_writer *mdb_writer_open_ex(const char *path, uint32_t k, uint32_t
   w->num_blocks_bits = w_prefix - MGC_NUM_FILES_BITS;
   w->blocks_per_file = 1ull << w->num_blocks_bits;
   for (int ff = 0; ff < MGC_NUM_FILES; ff++) {
-    w->dat[ff] = nullptr; w->bytes[ff] = 0;
+    w->dat[ff] = -1; w->bytes[ff] = 0;
     w->hist_small[ff].assign(1024, 0);
   }
   return w;
@@ -253,10 +270,9 @@ extern "C" mdb_writer *mdb_writer_open(const char *path, uint32_t k, uint32_t w_
 namespace {
 // opens file ff's data file on first use and checks the ascending-prefix rule
 int writer_file_ready(mdb_writer *w, uint32_t ff, uint64_t prefix) {
-  if (!w->dat[ff]) {
-    w->dat[ff] = fopen(w->data_name(ff).c_str(), "wb");
-    if (!w->dat[ff]) { w->fail("add_block: cannot open data file in '%s': %s", w->dir.c_str(), strerror(errno)); return MGC_EINVAL; }
-    setvbuf(w->dat[ff], nullptr, _IOFBF, 1 << 20);
+  if (w->dat[ff] < 0) {
+    w->dat[ff] = open(w->data_name(ff).c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (w->dat[ff] < 0) { w->fail("add_block: cannot open data file in '%s': %s", w->dir.c_str(), strerror(errno)); return MGC_EINVAL; }
     w->index[ff].reserve(std::min<uint64_t>(w->blocks_per_file, 1u << 16));
   }
   if (!w->index[ff].empty() && w->index[ff].back().prefix >= prefix) { db_err("add_block: prefixes of a file must ascend"); return MGC_ESTATE; }
@@ -307,8 +323,10 @@ extern "C" int mdb_writer_add_block_labelled(mdb_writer *w, uint64_t prefix, uin
   FileIndexEntry e;
   e.prefix = prefix; e.position = w->bytes[ff]; e.n_kmers = n;
   w->index[ff].push_back(e);
-  if (!dump_stuffed(w->dat[ff], bw)) { w->fail("add_block: write failed in '%s': %s", w->dir.c_str(), strerror(errno)); return MGC_EINVAL; }
-  w->bytes[ff] += stuffed_bytes(bw.pos);
+  std::vector<unsigned char> dump;
+  dump_stuffed(dump, bw);
+  if (!pwrite_all(w->dat[ff], dump.data(), dump.size(), w->bytes[ff])) { w->fail("add_block: write failed in '%s': %s", w->dir.c_str(), strerror(errno)); return MGC_EINVAL; }
+  w->bytes[ff] += dump.size();
 
   // value histogram, per file (merged at close) -- merylBlockWriter adds every value
   std::vector<uint64_t> &hs = w->hist_small[ff];
@@ -324,9 +342,9 @@ extern "C" int mdb_writer_add_block(mdb_writer *w, uint64_t prefix, uint64_t n, 
   return mdb_writer_add_block_labelled(w, prefix, n, slo, shi, counts, nullptr, 0);
 }
 
-extern "C" int mdb_writer_add_encoded(mdb_writer *w, uint32_t ff, const void *bytes, uint64_t nbytes,
-                                      const mdb_index_entry *entries, uint64_t n_entries) {
-  if (!w || ff >= MGC_NUM_FILES || (nbytes && !bytes) || (n_entries && !entries)) return MGC_EINVAL;
+extern "C" int mdb_writer_reserve_encoded(mdb_writer *w, uint32_t ff, uint64_t nbytes, const mdb_index_entry *entries,
+                                          uint64_t n_entries, uint64_t *file_offset) {
+  if (!w || ff >= MGC_NUM_FILES || !file_offset || (n_entries && !entries)) return MGC_EINVAL;
   if (nbytes == 0) return n_entries ? MGC_EINVAL : MGC_OK;
   for (uint64_t i = 0; i < n_entries; i++) {
     if ((entries[i].prefix >> w->num_blocks_bits) != ff || entries[i].position >= nbytes ||
@@ -335,18 +353,33 @@ extern "C" int mdb_writer_add_encoded(mdb_writer *w, uint32_t ff, const void *by
   if (n_entries) {
     int rc = writer_file_ready(w, ff, entries[0].prefix);
     if (rc != MGC_OK) return rc;
-  } else if (!w->dat[ff]) {                                 // no block starts here: the bytes continue the file's last block
+  } else if (w->dat[ff] < 0) {                              // no block starts here: the bytes continue the file's last block
     db_err("add_encoded: continuation bytes for a file that holds no block yet");
     return MGC_ESTATE;
   }
-  if (fwrite(bytes, 1, nbytes, w->dat[ff]) != nbytes) { w->fail("add_encoded: write failed in '%s': %s", w->dir.c_str(), strerror(errno)); return MGC_EINVAL; }
   for (uint64_t i = 0; i < n_entries; i++) {
     FileIndexEntry e = entries[i];
     e.position += w->bytes[ff];
     w->index[ff].push_back(e);
   }
+  *file_offset = w->bytes[ff];
   w->bytes[ff] += nbytes;
   return MGC_OK;
+}
+
+extern "C" int mdb_writer_write_at(mdb_writer *w, uint32_t ff, uint64_t file_offset, const void *bytes, uint64_t nbytes) {
+  if (!w || ff >= MGC_NUM_FILES || (nbytes && !bytes) || w->dat[ff] < 0) return MGC_EINVAL;
+  if (!pwrite_all(w->dat[ff], bytes, nbytes, file_offset)) { w->fail("add_encoded: write failed in '%s': %s", w->dir.c_str(), strerror(errno)); return MGC_EINVAL; }
+  return MGC_OK;
+}
+
+extern "C" int mdb_writer_add_encoded(mdb_writer *w, uint32_t ff, const void *bytes, uint64_t nbytes,
+                                      const mdb_index_entry *entries, uint64_t n_entries) {
+  if (nbytes && !bytes) return MGC_EINVAL;
+  uint64_t off = 0;
+  int rc = mdb_writer_reserve_encoded(w, ff, nbytes, entries, n_entries, &off);
+  if (rc != MGC_OK || nbytes == 0) return rc;
+  return mdb_writer_write_at(w, ff, off, bytes, nbytes);
 }
 
 extern "C" int mdb_writer_add_histogram(mdb_writer *w, const uint64_t *values, const uint64_t *occ, uint64_t n_pairs) {
@@ -407,7 +440,7 @@ extern "C" int mdb_writer_close(mdb_writer *w) {
     // one part of a sharded database: data files stay under their part names; the side file carries what
     // mdb_merge_parts needs (index entries, sizes, histogram)
     for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++)
-      if (w->dat[ff]) { if (fclose(w->dat[ff]) != 0) ok = false; w->dat[ff] = nullptr; }
+      if (w->dat[ff] >= 0) { if (close(w->dat[ff]) != 0) ok = false; w->dat[ff] = -1; }
     std::map<uint64_t, uint64_t> hist;
     merged_histogram(w, hist);
     const std::string tmp = part_meta_name(w->dir, w->part) + ".tmp";
@@ -431,11 +464,11 @@ extern "C" int mdb_writer_close(mdb_writer *w) {
     // A file that received no block at all still gets its (empty) data file and an index of empty blocks, so that
     // the directory always has 64+64+1 files.
     for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++) {
-      if (!w->dat[ff]) {
+      if (w->dat[ff] < 0) {
         for (uint64_t bb = 0; bb < w->blocks_per_file && ok; bb++)
           ok = (mdb_writer_add_block(w, ((uint64_t)ff << w->num_blocks_bits) | bb, 0, nullptr, nullptr, nullptr) == MGC_OK);
       }
-      if (w->dat[ff]) { if (fclose(w->dat[ff]) != 0) ok = false; w->dat[ff] = nullptr; }
+      if (w->dat[ff] >= 0) { if (close(w->dat[ff]) != 0) ok = false; w->dat[ff] = -1; }
     }
     if (!write_indexes(w)) ok = false;
   }
@@ -508,8 +541,8 @@ extern "C" int mdb_merge_parts(const char *path, uint32_t n_parts) {
   // files no part contributed to get their empty blocks, then the indexes: the plain writer's close
   for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++)
     if (!w->index[ff].empty()) {                          // reopen for the close path's bookkeeping (nothing more is written)
-      w->dat[ff] = fopen(block_name(dir, ff, false).c_str(), "ab");
-      if (!w->dat[ff]) { db_err("mdb_merge_parts: reopen in '%s': %s", path, strerror(errno)); delete w; return MGC_EINVAL; }
+      w->dat[ff] = open(block_name(dir, ff, false).c_str(), O_WRONLY);
+      if (w->dat[ff] < 0) { db_err("mdb_merge_parts: reopen in '%s': %s", path, strerror(errno)); delete w; return MGC_EINVAL; }
     }
   return mdb_writer_close(w);
 }

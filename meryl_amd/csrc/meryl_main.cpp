@@ -14,6 +14,7 @@
 #include "../../include/meryl_gpu_count.h"
 #include "../../include/meryl_seq.h"
 
+#include <algorithm>
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +46,12 @@ uint64_t bits64(uint64_t v) { uint64_t b = 0; while (v) { b++; v >>= 1; } return
 
 bool file_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && !S_ISDIR(st.st_mode); }
 bool dir_has_index(const std::string &p) { return file_exists(p + "/merylIndex"); }
+
+bool has_compressed_suffix(const std::string &n) {
+  for (const char *suf : { ".gz", ".bz2", ".xz", ".bgz", ".bgzf", ".zst" })
+    if (n.size() > strlen(suf) && n.compare(n.size() - strlen(suf), strlen(suf), suf) == 0) return true;
+  return false;
+}
 
 enum OpKind { OP_NONE, OP_COUNT, OP_COUNT_FORWARD, OP_COUNT_REVERSE, OP_PRINT, OP_DUMPINDEX, OP_HISTOGRAM };
 
@@ -219,6 +226,16 @@ int run_count(const Globals &g, const Operation &op) {
     msr_reader *r = msr_open(name.c_str());
     if (!r) die("ERROR: %s", msr_last_error());
     if (msr_format(r) != MSR_FORMAT_FASTX) { msr_close(r); load_on_host(name); continue; }   // SAM/BAM records are decoded on the host
+    if (name != "-" && !has_compressed_suffix(name)) {
+      // plain text: the library reads the file itself, several threads straight into its pinned upload buffers
+      msr_close(r);
+      const int rc = mgc_push_text_file(s, name.c_str(), 0, (int)std::min<uint32_t>(g.threads, 6));
+      if (rc == MGC_EFORMAT) load_on_host(name);
+      else if (rc != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+      struct stat fst;
+      if (stat(name.c_str(), &fst) == 0) total_bases += (uint64_t)fst.st_size;
+      continue;
+    }
     bool begun = false, refused = false;
     for (;;) {
       const int64_t got = msr_read_text(r, text.data(), text.size());

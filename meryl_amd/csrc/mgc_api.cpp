@@ -11,6 +11,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
+#include <condition_variable>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -459,6 +464,23 @@ extern "C" int mgc_begin_text(mgc_session *s, int format) {
   return MGC_OK;
 }
 
+// one piece (<= TEXT_CHUNK bytes, in pinned memory) -> device input buffer b -> parse kernels; returns once they are queued
+static int text_submit(mgc_session *s, const char *pinned_src, size_t piece) {
+  const uint32_t b = s->text_next & 1u;
+  if (s->text_ev_used[b]) HIP_TRY(s, hipEventSynchronize(s->text_ev[b]));       // device buffer b (and its previous source) are free again
+  HIP_TRY(s, s->ensure_preserve(mgc_session::B_TEXT_OUT, s->text_bound + piece + 4096, s->text_bound));
+  uint8_t *d_in = reinterpret_cast<uint8_t *>(s->buf[b ? mgc_session::B_TEXT_IN1 : mgc_session::B_TEXT_IN0].p);
+  HIP_TRY(s, hipMemcpyAsync(d_in, pinned_src, piece, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(s, mgc::launch_text_parse(d_in, piece, s->text_format == MGC_TEXT_FASTQ, s->buf[mgc_session::B_TEXT_STATE].p,
+                                    s->buf[mgc_session::B_TEXT_WS].p,
+                                    reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p), s->stream));
+  HIP_TRY(s, hipEventRecord(s->text_ev[b], s->stream));
+  s->text_ev_used[b] = true;
+  s->text_next++;
+  s->text_bound += piece;
+  return MGC_OK;
+}
+
 extern "C" int mgc_push_text(mgc_session *s, const char *text, size_t len) {
   if (!s || (!text && len)) return MGC_EINVAL;
   if (!s->text_open) { set_err(&s->err, "mgc_push_text without mgc_begin_text"); return MGC_ESTATE; }
@@ -468,20 +490,113 @@ extern "C" int mgc_push_text(mgc_session *s, const char *text, size_t len) {
     const uint32_t b = s->text_next & 1u;
     if (s->text_ev_used[b]) HIP_TRY(s, hipEventSynchronize(s->text_ev[b]));     // pinned + device buffer b are free again
     memcpy(s->text_pinned[b], text, piece);
-    HIP_TRY(s, s->ensure_preserve(mgc_session::B_TEXT_OUT, s->text_bound + piece + 4096, s->text_bound));
-    uint8_t *d_in = reinterpret_cast<uint8_t *>(s->buf[b ? mgc_session::B_TEXT_IN1 : mgc_session::B_TEXT_IN0].p);
-    HIP_TRY(s, hipMemcpyAsync(d_in, s->text_pinned[b], piece, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(s, mgc::launch_text_parse(d_in, piece, s->text_format == MGC_TEXT_FASTQ, s->buf[mgc_session::B_TEXT_STATE].p,
-                                      s->buf[mgc_session::B_TEXT_WS].p,
-                                      reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p), s->stream));
-    HIP_TRY(s, hipEventRecord(s->text_ev[b], s->stream));
-    s->text_ev_used[b] = true;
-    s->text_next++;
-    s->text_bound += piece;
+    const int rc = text_submit(s, s->text_pinned[b], piece);
+    if (rc != MGC_OK) return rc;
     text += piece;
     len -= piece;
   }
   return MGC_OK;
+}
+
+// A whole uncompressed FASTA/FASTQ file: `reader_threads` threads pread() 32 MiB chunks straight into a ring of pinned
+// buffers (no intermediate copy), the calling thread uploads and parses them in file order.  A 20 GB FASTQ on tmpfs is
+// otherwise bound by ONE thread's read()+memcpy (measured 11 GB/s, 1.8 s of a 3 s file -> database run).
+extern "C" int mgc_push_text_file(mgc_session *s, const char *path, int format, int reader_threads) {
+  if (!s || !path) return MGC_EINVAL;
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) { set_err(&s->err, "mgc_push_text_file: cannot open '%s': %s", path, strerror(errno)); return MGC_EINVAL; }
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); set_err(&s->err, "mgc_push_text_file: '%s' is not a regular file", path); return MGC_EINVAL; }
+  const uint64_t size = (uint64_t)st.st_size;
+  if (format == 0) {                                        // sniff: first byte that is not white space
+    char head[4096];
+    const ssize_t got = pread(fd, head, sizeof(head), 0);
+    char c = '>';
+    for (ssize_t i = 0; i < got; i++) if (head[i] != '\n' && head[i] != '\r' && head[i] != ' ' && head[i] != '\t') { c = head[i]; break; }
+    if (c != '>' && c != '@') { close(fd); set_err(&s->err, "'%s' is neither FASTA nor FASTQ (record starts with '%c')", path, c); return MGC_EFORMAT; }
+    format = (c == '@') ? MGC_TEXT_FASTQ : MGC_TEXT_FASTA;
+  }
+  int rc = mgc_begin_text(s, format);
+  if (rc != MGC_OK) { close(fd); return rc; }
+
+  constexpr int R = 8;                                      // ring of pinned chunks: up to R-2 chunks of read-ahead
+  const size_t CH = mgc_session::TEXT_CHUNK;
+  const uint64_t nchunks = (size + CH - 1) / CH;
+  if (reader_threads <= 0) reader_threads = 8;
+  reader_threads = (int)std::min<uint64_t>((uint64_t)std::min(reader_threads, R - 2), nchunks ? nchunks : 1);
+  char *ring[R] = {nullptr};
+  bool hip_ok = true;
+  for (int i = 0; i < R && (uint64_t)i < nchunks && hip_ok; i++)
+    hip_ok = hipHostMalloc(reinterpret_cast<void **>(&ring[i]), CH, hipHostMallocDefault) == hipSuccess;
+  if (!hip_ok) {
+    for (int i = 0; i < R; i++) if (ring[i]) (void)hipHostFree(ring[i]);
+    close(fd);
+    set_err(&s->err, "mgc_push_text_file: pinned buffers: out of memory");
+    return MGC_ENOMEM;
+  }
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t free_gen[R], ready_chunk[R];                     // slot i may be filled with chunk c iff free_gen[i] == c / R
+  size_t   ready_len[R];
+  for (int i = 0; i < R; i++) { free_gen[i] = 0; ready_chunk[i] = ~0ull; ready_len[i] = 0; }
+  std::atomic<uint64_t> next_chunk(0);
+  bool abort_all = false, read_failed = false;
+  auto reader = [&]() {
+    for (;;) {
+      const uint64_t c = next_chunk.fetch_add(1);
+      if (c >= nchunks) return;
+      const int slot = (int)(c % R);
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return abort_all || free_gen[slot] == c / R; });
+        if (abort_all) return;
+      }
+      const uint64_t off = c * CH;
+      const size_t want = (size_t)std::min<uint64_t>(CH, size - off);
+      size_t have = 0;
+      bool ok = true;
+      while (have < want) {
+        const ssize_t r = pread(fd, ring[slot] + have, want - have, (off_t)(off + have));
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) { ok = false; break; }                  // an error, or the file shrank under us
+        have += (size_t)r;
+      }
+      std::lock_guard<std::mutex> g(mu);
+      if (!ok) { read_failed = true; abort_all = true; }
+      ready_chunk[slot] = c; ready_len[slot] = have;
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> readers;
+  for (int t = 0; t < reader_threads; t++) readers.emplace_back(reader);
+  for (uint64_t c = 0; c < nchunks && rc == MGC_OK; c++) {
+    const int slot = (int)(c % R);
+    size_t len = 0;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return abort_all || ready_chunk[slot] == c; });
+      if (abort_all) break;
+      len = ready_len[slot];
+    }
+    // text_submit first waits for the parse of chunk c-2 (same device buffer): after that the pinned slot of chunk c-2
+    // has been read by its upload and goes back to the readers
+    rc = text_submit(s, ring[slot], len);
+    if (c >= 2) {
+      std::lock_guard<std::mutex> g(mu);
+      free_gen[(c - 2) % R]++;
+      cv.notify_all();
+    }
+  }
+  { std::lock_guard<std::mutex> g(mu); if (rc != MGC_OK) abort_all = true; cv.notify_all(); }
+  // the last uploads still read from the ring
+  for (int b = 0; b < 2; b++) if (s->text_ev_used[b]) (void)hipEventSynchronize(s->text_ev[b]);
+  { std::lock_guard<std::mutex> g(mu); abort_all = abort_all || true; cv.notify_all(); }
+  for (auto &t : readers) t.join();
+  for (int i = 0; i < R; i++) if (ring[i]) (void)hipHostFree(ring[i]);
+  close(fd);
+  if (read_failed) { set_err(&s->err, "mgc_push_text_file: reading '%s' failed: %s", path, strerror(errno)); rc = MGC_EINVAL; }
+  const int rc_end = mgc_end_text(s);                       // closes the file in every case (rolls it back on MGC_EFORMAT)
+  return rc != MGC_OK ? rc : rc_end;
 }
 
 struct HostParseState { uint64_t out_len, file_start_len; uint32_t state, prev_nl, error, pad; };

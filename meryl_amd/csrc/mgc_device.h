@@ -98,9 +98,9 @@ hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint3
                                 uint64_t n_prefix, uint64_t *d_block_start, hipStream_t st);
 
 // ---- database blocks encoded on the device (mgc_encode.hip; layout: mdb_layout.h) -------------------------------
-// rel_start[i] = first key >= (prefix_begin + i) << w_data for i in [0, n_blocks]
+// rel_start[i] = first key >= (prefix_begin + i) << w_data for i in [0, n_blocks] (n_prefix_total = 2^wPrefix)
 hipError_t launch_block_offsets_range(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t w_data, uint64_t prefix_begin,
-                                      uint64_t n_blocks, uint64_t *d_rel_start, hipStream_t st);
+                                      uint64_t n_blocks, uint64_t n_prefix_total, uint64_t *d_rel_start, hipStream_t st);
 hipError_t launch_encode_sizes(const void *d_keys, uint32_t key_words, const uint64_t *d_bs, uint64_t n_blocks, uint32_t suffix_size,
                                uint32_t label_size, uint64_t *d_blk_bytes, uint64_t *d_blk_vbase, uint32_t *d_blk_bb, hipStream_t st);
 hipError_t launch_encode_chunk(const void *d_keys, const uint32_t *d_counts, uint32_t key_words, const uint64_t *d_bs,

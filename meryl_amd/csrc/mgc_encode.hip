@@ -43,13 +43,15 @@ template <> struct SufOps<K128> {
 };
 
 // ---- block starts of a prefix range -------------------------------------------------------------
-// rel_start[i] = first key >= (prefix_begin + i) << w_data, i in [0, n_blocks]; keys hold only prefixes of the range
+// rel_start[i] = first key >= (prefix_begin + i) << w_data, i in [0, n_blocks].  The keys are supposed to hold only prefixes
+// of the range: the caller checks rel_start[0] == 0 and rel_start[n_blocks] == n (the last boundary is searched too unless
+// it is the end of the key space, whose floor does not fit the key type when 2k is a multiple of 64)
 template <typename K>
 __global__ void block_offsets_range_kernel(const K *__restrict__ keys, u64 n, u32 w_data, u64 prefix_begin, u64 n_blocks,
-                                           u64 *__restrict__ rel_start) {
+                                           u64 n_prefix_total, u64 *__restrict__ rel_start) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n_blocks) return;
-  if (i == n_blocks) { rel_start[i] = n; return; }
+  if (i == n_blocks && prefix_begin + i >= n_prefix_total) { rel_start[i] = n; return; }
   const K target = KeyOps<K>::prefix_floor(prefix_begin + i, w_data);
   u64 lo = 0, hi = n;
   while (lo < hi) {
@@ -244,14 +246,14 @@ void value_hist_kernel(const u32 *__restrict__ counts, u64 n, u64 *__restrict__ 
 
 // ---- launchers -----------------------------------------------------------------------------------
 hipError_t launch_block_offsets_range(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t w_data, uint64_t prefix_begin,
-                                      uint64_t n_blocks, uint64_t *d_rel_start, hipStream_t st) {
+                                      uint64_t n_blocks, uint64_t n_prefix_total, uint64_t *d_rel_start, hipStream_t st) {
   const dim3 grid((uint32_t)((n_blocks + 1 + 255) / 256));
   if (key_words == 2)
     hipLaunchKernelGGL(block_offsets_range_kernel<K128>, grid, dim3(256), 0, st, reinterpret_cast<const K128 *>(d_keys), (u64)n,
-                       w_data, (u64)prefix_begin, (u64)n_blocks, reinterpret_cast<u64 *>(d_rel_start));
+                       w_data, (u64)prefix_begin, (u64)n_blocks, (u64)n_prefix_total, reinterpret_cast<u64 *>(d_rel_start));
   else
     hipLaunchKernelGGL(block_offsets_range_kernel<u64>, grid, dim3(256), 0, st, reinterpret_cast<const u64 *>(d_keys), (u64)n,
-                       w_data, (u64)prefix_begin, (u64)n_blocks, reinterpret_cast<u64 *>(d_rel_start));
+                       w_data, (u64)prefix_begin, (u64)n_blocks, (u64)n_prefix_total, reinterpret_cast<u64 *>(d_rel_start));
   return hipGetLastError();
 }
 

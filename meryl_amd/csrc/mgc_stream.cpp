@@ -40,7 +40,7 @@ struct DBuf {                                             // grow-only device bu
 };
 
 constexpr size_t   SLOT_BYTES = 32u << 20;                // pinned copy buffers: NSLOT x SLOT_BYTES
-constexpr int      NSLOT      = 6;
+constexpr int      NSLOT      = 16;
 constexpr uint64_t IMG_CAP    = 512ull << 20;             // device image of one encode chunk (two of them in flight)
 
 }  // namespace
@@ -61,16 +61,16 @@ struct mgc_db_stream {
   char *pinned[NSLOT] = {nullptr};
 
   struct Range { const void *keys; const uint32_t *counts; uint64_t n, pb, pe; };
-  struct Piece { uint32_t ff; int slot; uint64_t nbytes; std::vector<mdb_index_entry> entries; };
+  struct Piece { uint32_t ff; int slot; uint64_t nbytes, file_offset; };
 
   std::mutex mu;
   std::condition_variable cv;
-  bool slot_busy[NSLOT] = {false};
+  bool slot_busy[NSLOT] = {false}, slot_ready[NSLOT] = {false};
   int  next_slot = 0;
   std::deque<Range> jobs;
   uint64_t jobs_queued = 0, jobs_done = 0;
   bool closing = false, copy_done = false;
-  std::vector<std::deque<Piece>> queues;
+  std::deque<Piece> queue;                                // any pool thread takes any piece: the writes are pwrites
   uint64_t pieces_open = 0;
   std::thread copy_thread;
   std::vector<std::thread> pool;
@@ -96,21 +96,32 @@ struct mgc_db_stream {
 #define DS_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail_hip(e__, #expr); } while (0)
 
 void mgc_db_stream::pool_main(int t) {
+  // the pinned copy buffers are allocated here, in parallel, while the first range is being planned and encoded
+  // (pinning half a gigabyte from one thread costs as much as writing the database)
+  (void)hipSetDevice(device);
+  for (int i = t; i < NSLOT; i += n_threads) {
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, SLOT_BYTES, hipHostMallocDefault);
+    std::lock_guard<std::mutex> g(mu);
+    if (e != hipSuccess) fail_locked(MGC_ENOMEM, std::string("pinned copy buffer: ") + hipGetErrorString(e));
+    else { pinned[i] = reinterpret_cast<char *>(p); slot_ready[i] = true; }
+    cv.notify_all();
+  }
   for (;;) {
     Piece pc;
     {
       std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return !queues[t].empty() || copy_done; });
-      if (queues[t].empty()) return;
-      pc = std::move(queues[t].front());
-      queues[t].pop_front();
+      cv.wait(lk, [&] { return !queue.empty() || copy_done; });
+      if (queue.empty()) return;
+      pc = queue.front();
+      queue.pop_front();
     }
     int rc = MGC_OK;
     std::string msg;
     bool skip;
     { std::lock_guard<std::mutex> g(mu); skip = status != MGC_OK; }
     if (!skip) {
-      rc = mdb_writer_add_encoded(w, pc.ff, pinned[pc.slot], pc.nbytes, pc.entries.data(), pc.entries.size());
+      rc = mdb_writer_write_at(w, pc.ff, pc.file_offset, pinned[pc.slot], pc.nbytes);
       if (rc != MGC_OK) msg = std::string("writing the database: ") + mdb_last_error();
     }
     {
@@ -160,7 +171,7 @@ int mgc_db_stream::process(const Range &r) {
   const uint32_t nsmall = mgc::value_hist_small_bins();
   DS_TRY(d_hist.ensure(8 * (nsmall + 1)));
   if (d_big.cap == 0) DS_TRY(d_big.ensure(4u << 20));
-  DS_TRY(mgc::launch_block_offsets_range(r.keys, r.n, kw, w_data, r.pb, nblk, d_bs.as<uint64_t>(), st_enc));
+  DS_TRY(mgc::launch_block_offsets_range(r.keys, r.n, kw, w_data, r.pb, nblk, 1ull << w_prefix, d_bs.as<uint64_t>(), st_enc));
   DS_TRY(mgc::launch_encode_sizes(r.keys, kw, d_bs.as<uint64_t>(), nblk, ss, label_size, d_bytes.as<uint64_t>(),
                                   d_vbase.as<uint64_t>(), d_bb.as<uint32_t>(), st_enc));
   std::vector<uint64_t> h_bs(nblk + 1), h_bytes(nblk), h_pos(nblk), h_hist(nsmall + 1);
@@ -239,14 +250,20 @@ int mgc_db_stream::process(const Range &r) {
       }
       Piece pc;
       pc.ff = ff; pc.nbytes = e - a;
+      std::vector<mdb_index_entry> entries;
       for (uint64_t jj = bi; jj < j; jj++) {
         mdb_index_entry en;
         en.prefix = r.pb + jj; en.position = h_pos[jj] - a; en.n_kmers = h_bs[jj + 1] - h_bs[jj];
-        pc.entries.push_back(en);
+        entries.push_back(en);
+      }
+      // the index and the file offset are fixed here, in prefix order; the bytes follow from whichever thread is free
+      if (mdb_writer_reserve_encoded(w, ff, pc.nbytes, entries.data(), entries.size(), &pc.file_offset) != MGC_OK) {
+        fail(MGC_EINVAL, std::string("writing the database: ") + mdb_last_error());
+        return status;
       }
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !slot_busy[next_slot] || status != MGC_OK; });
+        cv.wait(lk, [&] { return (slot_ready[next_slot] && !slot_busy[next_slot]) || status != MGC_OK; });
         if (status != MGC_OK) return status;
         pc.slot = next_slot;
         slot_busy[next_slot] = true;
@@ -261,7 +278,7 @@ int mgc_db_stream::process(const Range &r) {
       {
         std::lock_guard<std::mutex> g(mu);
         pieces_open++;
-        queues[pc.ff % (uint32_t)n_threads].push_back(std::move(pc));
+        queue.push_back(pc);
       }
       cv.notify_all();
       a = e; bi = j;
@@ -306,8 +323,6 @@ extern "C" mgc_db_stream *mgc_db_stream_open(const char *path, uint32_t k, uint3
             hipStreamCreateWithFlags(&d->st_copy, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&d->ev_enc[0]) == hipSuccess && hipEventCreate(&d->ev_enc[1]) == hipSuccess &&
             hipEventCreate(&d->ev_a) == hipSuccess && hipEventCreate(&d->ev_b) == hipSuccess;
-  for (int i = 0; i < NSLOT && ok; i++)
-    ok = hipHostMalloc(reinterpret_cast<void **>(&d->pinned[i]), SLOT_BYTES, hipHostMallocDefault) == hipSuccess;
   if (!ok) {
     set_err(nullptr, "mgc_db_stream_open: HIP stream / pinned buffer setup failed");
     d->closing = true; d->copy_done = true;
@@ -316,7 +331,6 @@ extern "C" mgc_db_stream *mgc_db_stream_open(const char *path, uint32_t k, uint3
     delete d;
     return nullptr;
   }
-  d->queues.resize(d->n_threads);
   d->copy_thread = std::thread([d] { d->copy_main(); });
   for (int t = 0; t < d->n_threads; t++) d->pool.emplace_back([d, t] { d->pool_main(t); });
   return d;

@@ -797,6 +797,48 @@ def test_device_text_parse_large_mixed_and_refusal(ops, oracle_lib, torch_cuda):
     assert np.array_equal(klo, wlo) and np.array_equal(counts, wcn)
 
 
+def test_push_text_file_reader_ring(ops, oracle_lib, torch_cuda, tmp_path):
+    """mgc_push_text_file: a FASTQ file of ~10 upload chunks read by several threads into the pinned ring (chunks reused,
+    last chunk partial), a one-chunk FASTA, an empty file and a refused file, against the bases pushed directly."""
+    from meryl_amd import capi
+    import ctypes
+    k = 21
+    bases = oracle_lib.synth_reads(13, 3_000_000, 0, 1_000_000, 150, 5000, 100)
+    rec = np.empty((1_000_000, 307), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r"); rec[:, 2] = 10
+    rec[:, 3:153] = bases.reshape(-1, 151)[:, :150]
+    rec[:, 153] = 10; rec[:, 154] = ord("+"); rec[:, 155] = 10; rec[:, 156:306] = ord("I"); rec[:, 306] = 10
+    fq = str(tmp_path / "reads.fq")
+    rec.tofile(fq)
+    assert os.path.getsize(fq) > 9 * (32 << 20)
+    fa_reads = [r for r in oracle_lib.synth_reads(14, 100_000, 0, 2000, 150, 5000, 100).tobytes().decode().split(".") if r]
+    fa = str(tmp_path / "reads.fa")
+    open(fa, "w").write("".join(">s%d\n%s\n%s\n" % (i, r[:70], r[70:]) for i, r in enumerate(fa_reads)))
+    empty = str(tmp_path / "empty.fa")
+    open(empty, "w").close()
+    bad = str(tmp_path / "bad.fq")
+    open(bad, "w").write("@a\nACGT\nACGT\n+\nIIII\nIIII\n")                    # multi-line FASTQ: the device parser refuses it
+    cfg = capi.configure(k, 200_000_000, 8 << 30)
+    L = capi.lib()
+    with ops.Session(cfg) as s:
+        capi.check(L.mgc_push_text_file(s._h, fq.encode(), 0, 5), "mgc_push_text_file", s._h)
+        capi.check(L.mgc_push_text_file(s._h, fa.encode(), 0, 0), "mgc_push_text_file", s._h)
+        capi.check(L.mgc_push_text_file(s._h, empty.encode(), 0, 3), "mgc_push_text_file", s._h)
+        assert L.mgc_push_text_file(s._h, bad.encode(), 0, 2) == capi.EFORMAT
+        assert L.mgc_push_text_file(s._h, str(tmp_path / "missing.fa").encode(), 0, 2) == capi.EINVAL
+        s.count()
+        got = s.result_wide()
+        info = s.info()
+    stream = torch_cuda.from_numpy(np.concatenate([bases, np.frombuffer((".".join(fa_reads) + ".").encode(), dtype=np.uint8)])).cuda()
+    with ops.Session(cfg) as s:
+        s.push_bases_device(stream)
+        s.count()
+        want = s.result_wide()
+        assert s.info().n_instances == info.n_instances
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("seed", range(48))
 def test_random_inputs_match_oracle(ops, oracle_lib, torch_cuda, seed):
     # randomised sweep over k, strand mode, read lengths, N density, repeat structure and input size: every finish
