@@ -160,6 +160,24 @@ int mgc_dev_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words, void 
 int mgc_dev_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,
                           uint64_t n_prefix, uint64_t *d_block_start, void *stream);
 
+/* Merge of two (k-mer, value) streams with distinct ascending keys -- the two-input step of the reference's k-way merge
+ * (merylOperation::nextMer, src/meryl/merylOp-nextMer.C:478-641: smallest k-mer over the inputs, values of the inputs that
+ * hold it combined) and of merylBlockWriter::finish() folding the batches a memory-limited count spilled.  Step 1 returns
+ * the output length (synchronises the stream), step 2 writes d_keys_out / d_counts_out (that many entries), with the
+ * same inputs and the workspace step 1 left.  Sums wrap mod 2^32 like the reference's kmvalu arithmetic. */
+#define MGC_MERGE_UNION_SUM     0     /* opUnionSum      src/meryl/merylOp-nextMer.C:572-579 */
+#define MGC_MERGE_UNION_MIN     1     /* opUnionMin      :560-565 */
+#define MGC_MERGE_UNION_MAX     2     /* opUnionMax      :566-571 */
+#define MGC_MERGE_INTERSECT_SUM 3     /* opIntersectSum  :604-612 (k-mers in BOTH inputs) */
+#define MGC_MERGE_INTERSECT_MIN 4     /* opIntersectMin  :586-594 */
+#define MGC_MERGE_INTERSECT_MAX 5     /* opIntersectMax  :595-603 */
+size_t mgc_dev_merge_workspace_bytes(uint64_t na, uint64_t nb);
+int mgc_dev_merge_count(const void *d_keys_a, uint64_t na, const void *d_keys_b, uint64_t nb, uint32_t key_words, int op,
+                        void *d_workspace, size_t workspace_bytes, uint64_t *n_out, void *stream);
+int mgc_dev_merge_emit(const void *d_keys_a, const uint32_t *d_counts_a, uint64_t na,
+                       const void *d_keys_b, const uint32_t *d_counts_b, uint64_t nb, uint32_t key_words, int op,
+                       void *d_workspace, size_t workspace_bytes, void *d_keys_out, uint32_t *d_counts_out, void *stream);
+
 /* Homopolymer compression of a base stream (the `compress` word: merylInput.C:
  * 237-240,261-268 calls homopolyCompress() on every chunk loadBases returns,
  * carrying the last byte across chunks of a sequence).  Drops every byte equal,
@@ -187,15 +205,14 @@ const char  *mgc_last_error(const mgc_session *s);   /* s may be NULL: last open
  * Bases are copied; the caller may reuse the buffer on return. */
 int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int end_of_sequence);
 
-/* Out-of-core input (the analogue of writeBatch's memory-full spill,
- * merylOp-countThreads.C:323-379, and of merylBlockWriter::finish() merging the
- * iterations): when the bases pushed through mgc_push_bases exceed what one
- * pass can hold in HBM, everything up to the last sequence boundary is counted
- * and its result parked in host memory; mgc_count then merges the parked
- * results per file, summing counts.  By default the batch size is derived from
- * the free HBM; this call overrides it (bases per batch).  A merged result is
- * host-resident: mgc_copy_result / mgc_finish / mgc_write_database work,
- * mgc_get_result_device returns MGC_ESTATE. */
+/* Out-of-core input (the analogue of writeBatch's memory-full spill, merylOp-countThreads.C:323-379, and of
+ * merylBlockWriter::finish() merging the iterations): bases pushed from the host travel through two pinned buffers
+ * (asynchronous uploads) into a staging buffer in HBM; when the staged bases -- pushed or parsed from text -- reach
+ * what one pass can hold, everything up to the last sequence boundary is counted as one BATCH by a worker thread
+ * while the caller keeps pushing into a second staging buffer, and the batch's (k-mer, count) result is merged ON THE
+ * DEVICE into the running result of the earlier batches (counts summed).  The final result is device-resident like
+ * a single pass's: every result call works the same.  By default the batch size is derived from the free HBM at the
+ * first input; this call overrides it (bases per batch). */
 int mgc_set_batch_bases(mgc_session *s, uint64_t bases_per_batch);
 
 /* Sequence-file TEXT instead of bases: the raw bytes of a FASTA or FASTQ file (after any decompression), in
@@ -206,8 +223,9 @@ int mgc_set_batch_bases(mgc_session *s, uint64_t bases_per_batch);
  * (src/meryl/merylOp-countThreads.C:138-231).  FASTA may be multi-line; FASTQ must be strict four-line records:
  * every '@' and '+' line start is checked on the device and mgc_end_text returns MGC_EFORMAT if the structure
  * does not hold -- the file's output is then already rolled back and the caller feeds the file through
- * mgc_push_bases instead (include/meryl_seq.h reads multi-line FASTQ).  Text input is counted in one batch
- * (no out-of-core spill); it may be mixed with mgc_push_bases in one session. */
+ * mgc_push_bases instead (include/meryl_seq.h reads multi-line FASTQ).  Text input is batched like pushed bases
+ * (a batch may be cut inside a file: if such a file is refused AFTER part of it was counted, mgc_end_text returns
+ * MGC_EINVAL instead of MGC_EFORMAT -- nothing can be rolled back then); it may be mixed with mgc_push_bases. */
 #define MGC_TEXT_FASTA 1
 #define MGC_TEXT_FASTQ 2
 int mgc_reserve_text(mgc_session *s, uint64_t text_bytes);       /* optional: expected total, avoids regrowth */
@@ -299,6 +317,9 @@ typedef struct mgc_profile {
   uint32_t sort_pass_launches;
   uint64_t sort_pass_keys;         /* keys moved by those launches (sum of n per launch) */
   double   total_ms;
+  double   merge_ms;               /* out-of-core: device merges of batch results into the running result (all batches) */
+  uint32_t n_batches;              /* batches the input was counted in (1 = single pass) */
+  uint32_t reserved;
 } mgc_profile;
 int mgc_set_profiling(mgc_session *s, int enable);
 int mgc_get_profile(const mgc_session *s, mgc_profile *p);

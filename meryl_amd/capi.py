@@ -24,6 +24,7 @@ SYMBOLS = (
     "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_push_text_file", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_copy_result_device",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish", "mgc_finish_labelled",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_dev_synth_reads_ex", "mgc_version",
+    "mgc_dev_merge_workspace_bytes", "mgc_dev_merge_count", "mgc_dev_merge_emit",
     "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases",
     # include/meryl_db.h
     "mdb_writer_open", "mdb_writer_open_ex", "mdb_merge_parts", "mdb_writer_add_block", "mdb_writer_add_block_labelled",
@@ -81,6 +82,9 @@ class Profile(ctypes.Structure):
         ("sort_pass_launches", ctypes.c_uint32),
         ("sort_pass_keys", ctypes.c_uint64),
         ("total_ms", ctypes.c_double),
+        ("merge_ms", ctypes.c_double),
+        ("n_batches", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
     ]
 
 
@@ -210,6 +214,9 @@ def lib():
     sig("mgc_dev_rle_count", i32, vp, u64, u32, vp, sz, P(u64), vp)
     sig("mgc_dev_rle_emit", i32, vp, u64, u32, vp, sz, vp, vp, vp)
     sig("mgc_dev_block_offsets", i32, vp, u64, u32, u32, u64, vp, vp)
+    sig("mgc_dev_merge_workspace_bytes", sz, u64, u64)
+    sig("mgc_dev_merge_count", i32, vp, u64, vp, u64, u32, i32, vp, sz, P(u64), vp)
+    sig("mgc_dev_merge_emit", i32, vp, vp, u64, vp, vp, u64, u32, i32, vp, sz, vp, vp, vp)
     sig("mgc_dev_homopoly_workspace_bytes", sz, u64)
     sig("mgc_dev_homopoly_compress", i32, vp, u64, vp, P(u64), vp, sz, vp)
     sig("mgc_dev_synth_reads", i32, u64, u64, u64, u64, u32, u32, u32, vp, vp)

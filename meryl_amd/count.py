@@ -128,6 +128,31 @@ def dev_run_length(sorted_keys):
     return uniq, cnts
 
 
+MERGE_OPS = {"union-sum": 0, "union-min": 1, "union-max": 2, "intersect-sum": 3, "intersect-min": 4, "intersect-max": 5}
+
+
+def dev_merge(keys_a, counts_a, keys_b, counts_b, op="union-sum"):
+    """Two (k-mer, value) streams with distinct ascending keys (int64[N] / int64[N, 2] cuda tensors, int32 values) ->
+    their union / intersection with combined values (mgc_dev_merge_*)."""
+    L = capi.lib()
+    kw = 2 if keys_a.dim() == 2 else 1
+    na, nb = keys_a.shape[0], keys_b.shape[0]
+    dev = keys_a.device
+    ws_bytes = L.mgc_dev_merge_workspace_bytes(na, nb)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    n = ctypes.c_uint64(0)
+    code = MERGE_OPS[op]
+    capi.check(L.mgc_dev_merge_count(_ptr(keys_a), na, _ptr(keys_b), nb, kw, code, _ptr(ws), ws_bytes, ctypes.byref(n),
+                                     _stream_ptr()), "mgc_dev_merge_count")
+    out_k = _u64(n.value * kw, dev)
+    if kw == 2:
+        out_k = out_k.view(n.value, 2)
+    out_c = torch.empty(n.value, dtype=torch.int32, device=dev)
+    capi.check(L.mgc_dev_merge_emit(_ptr(keys_a), _ptr(counts_a), na, _ptr(keys_b), _ptr(counts_b), nb, kw, code, _ptr(ws),
+                                    ws_bytes, _ptr(out_k), _ptr(out_c), _stream_ptr()), "mgc_dev_merge_emit")
+    return out_k, out_c
+
+
 def dev_block_offsets(unique, w_data, n_prefix):
     out = _u64(n_prefix + 1, unique.device)
     kw = 2 if unique.dim() == 2 else 1

@@ -53,7 +53,7 @@ bool has_compressed_suffix(const std::string &n) {
   return false;
 }
 
-enum OpKind { OP_NONE, OP_COUNT, OP_COUNT_FORWARD, OP_COUNT_REVERSE, OP_PRINT, OP_DUMPINDEX, OP_HISTOGRAM };
+enum OpKind { OP_NONE, OP_COUNT, OP_COUNT_FORWARD, OP_COUNT_REVERSE, OP_PRINT, OP_DUMPINDEX, OP_HISTOGRAM, OP_DUMPFILE };
 
 struct Operation {
   OpKind                   kind = OP_NONE;
@@ -63,6 +63,7 @@ struct Operation {
   std::string              output;
   uint64_t                 exp_num_kmers = 0;   // n=
   std::string              count_suffix;        // count-suffix=
+  uint64_t                 label = 0;           // label=#<n> (meryl2: the constant label of a count, merylCommandBuilder-isAssign.C:124)
 };
 
 struct Globals {
@@ -72,6 +73,7 @@ struct Globals {
   int      verbosity = 2;          // sayStandard
   bool     only_config = false;
   bool     compress = false;       // sticky
+  uint32_t label_size = 0;         // -l <bits> (meryl2: kmerTiny::setLabelSize, merylGlobals.C:75-77)
   Globals() {
     const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
     memory_gb = (pages > 0 && psz > 0) ? (double)pages * (double)psz / 1024.0 / 1024.0 / 1024.0 : 16.0;
@@ -81,15 +83,16 @@ struct Globals {
 
 void usage(const char *prog) {
   fprintf(stderr,
-          "usage: %s [k=<K>] [memory=<GB>] [threads=<T>] [n=<kmers>] [compress] [-C] [-Q] [-V]\n"
-          "          count|count-forward|count-reverse <reads.fa|fq[.gz]|sam|bam> ... output <database.meryl>\n"
+          "usage: %s [k=<K>] [memory=<GB>] [threads=<T>] [n=<kmers>] [compress] [-l <label-bits>] [-C] [-Q] [-V]\n"
+          "          count|count-forward|count-reverse [label=#<n>] <reads.fa|fq[.gz]|sam|bam> ... output <database.meryl>\n"
           "       %s print <database.meryl>\n"
           "       %s dumpIndex <database.meryl>\n"
+          "       %s dumpFile <database.meryl>/0x######\n"
           "\n"
           "  MI355X-native implementation of the `count` path of marbl/meryl.  Words are processed left to\n"
           "  right; options apply to the operations that follow.  A leading '[' and trailing ']' group the\n"
           "  words of one operation.  Other meryl operations are not part of this build.\n",
-          prog, prog, prog);
+          prog, prog, prog, prog);
 }
 
 [[noreturn]] void die(const char *fmt, const char *a = "") {
@@ -185,6 +188,8 @@ int run_count(const Globals &g, const Operation &op) {
   if (op.count_suffix.size() > MGC_MAX_COUNT_SUFFIX) die("ERROR: %s", "count-suffix of more than 32 bases.");
   cfg.count_suffix_length = (uint32_t)op.count_suffix.size();                                         // merylOp.H:139-147
   memcpy(cfg.count_suffix, op.count_suffix.c_str(), op.count_suffix.size());
+  cfg.label_size = g.label_size;                                                                      // meryl2: every k-mer of a count
+  cfg.label_constant = op.label;                                                                      // carries one constant label
   if (mgc_configure_counting(&cfg) != MGC_OK) die("ERROR: %s", mgc_last_error(nullptr));
 
   if (g.verbosity > 0) print_configuration(g, op, exp_num_kmers, cfg);
@@ -308,15 +313,22 @@ int run_print(const Operation &op) {
     mdb_reader_info(r, &info);
     std::vector<char> kstr(info.k + 1, 0);
     for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++) {            // ascending == `threads=1 print` order (quick-start.rst:74-77)
-      uint64_t *lo = nullptr, *hi = nullptr, n = 0;
+      uint64_t *lo = nullptr, *hi = nullptr, *lb = nullptr, n = 0;
       uint32_t *cn = nullptr;
-      if (mdb_reader_read_file(r, ff, &lo, &hi, &cn, &n) != MGC_OK) die("ERROR: %s", mdb_last_error());
+      if (mdb_reader_read_file_ex(r, ff, &lo, &hi, &cn, &lb, &n) != MGC_OK) die("ERROR: %s", mdb_last_error());
+      char lbits[72];
       for (uint64_t i = 0; i < n; i++) {
         const unsigned __int128 m = ((unsigned __int128)hi[i] << 64) | lo[i];
         for (uint32_t b = 0; b < info.k; b++) kstr[b] = acgt[(unsigned)(m >> (2 * (info.k - 1 - b))) & 3];
-        fprintf(stdout, "%s\t%u\n", kstr.data(), cn[i]);                                               // merylOp-nextMer.C:673-676
+        if (info.label_size == 0) {
+          fprintf(stdout, "%s\t%u\n", kstr.data(), cn[i]);                                             // merylOp-nextMer.C:673-676
+        } else {                                                                                       // meryl2: + the label in binary
+          for (uint32_t b = 0; b < info.label_size; b++) lbits[b] = ((lb[i] >> (info.label_size - 1 - b)) & 1) ? '1' : '0';
+          lbits[info.label_size] = 0;                                                                  // (src/meryl2/merylOp-nextMer.C:36-43)
+          fprintf(stdout, "%s\t%u\t%s\n", kstr.data(), cn[i], lbits);
+        }
       }
-      mdb_free(lo); mdb_free(hi); mdb_free(cn);
+      mdb_free(lo); mdb_free(hi); mdb_free(cn); mdb_free(lb);
     }
     mdb_reader_close(r);
   }
@@ -338,6 +350,56 @@ int run_histogram(const Operation &op) {
   return 0;
 }
 
+// `meryl dumpFile <db>/0x######`: the three tables of documentation/source/usage.rst:24-45 (src/meryl/meryl.C:41-45) --
+// the file's index, every block's header, every k-mer as stored (unary prefix delta, accumulated prefix, the two halves
+// of the binary remainder, value).
+int run_dump_file(const Operation &op) {
+  for (const std::string &arg : op.db_inputs) {
+    const size_t slash = arg.find_last_of('/');
+    const std::string dbn = (slash == std::string::npos) ? "." : arg.substr(0, slash);
+    std::string base = (slash == std::string::npos) ? arg : arg.substr(slash + 1);
+    const size_t dot = base.find('.');
+    if (dot != std::string::npos) base.erase(dot);                                                    // 0x000000.merylData is fine too
+    if (base.size() != 8 || base.compare(0, 2, "0x") != 0) die("ERROR: dumpFile wants <database>/0x###### (six binary digits), not '%s'.", arg.c_str());
+    uint32_t ff = 0;
+    for (int i = 2; i < 8; i++) { if (base[i] != '0' && base[i] != '1') die("ERROR: bad file name '%s'.", arg.c_str()); ff = (ff << 1) | (uint32_t)(base[i] - '0'); }
+    mdb_reader *r = mdb_reader_open(dbn.c_str());
+    if (!r) die("ERROR: %s", mdb_last_error());
+    mdb_info info;
+    mdb_reader_info(r, &info);
+    const uint64_t nblocks = (uint64_t)1 << info.num_blocks_bits;
+    std::vector<mdb_index_entry> idx(nblocks);
+    if (mdb_reader_file_index(r, ff, idx.data()) != MGC_OK) die("ERROR: %s", mdb_last_error());
+    fprintf(stdout, "\n    prefix    blkPos    nKmers\n---------- --------- ---------\n");
+    for (const mdb_index_entry &e : idx) fprintf(stdout, "0x%08" PRIx64 " %9" PRIu64 " %9" PRIu64 "\n", e.prefix, e.position, e.n_kmers);
+    fprintf(stdout, "\n            prefix   nKmers kCode uBits bBits                 k1 cCode                 c1                 c2\n"
+                    "------------------ -------- ----- ----- ----- ------------------ ----- ------------------ ------------------\n");
+    for (const mdb_index_entry &e : idx) {
+      mdb_block_header h;
+      if (mdb_reader_block_header(r, ff, e.position, &h) != MGC_OK) die("ERROR: %s", mdb_last_error());
+      if (h.prefix != e.prefix) continue;                                                              // an index slot no block was written for
+      fprintf(stdout, "0x%016" PRIx64 " %8" PRIu64 " %5u %5u %5u 0x%016" PRIx64 " %5u 0x%016" PRIx64 " 0x%016" PRIx64 "\n",
+              h.prefix, h.n_kmers, h.k_code, h.unary_bits, h.binary_bits, h.k1, h.c_code, h.c1, h.c2);
+    }
+    fprintf(stdout, "\n kmerIdx prefixDelta      prefix |--- suffix-size and both suffixes ---|    value\n"
+                    "-------- ----------- ----------- -- ---------------- -- ---------------- --------\n");
+    for (const mdb_index_entry &e : idx) {
+      mdb_block_header h;
+      uint64_t *pd = nullptr, *tp = nullptr, *rh = nullptr, *rl = nullptr;
+      uint32_t *vv = nullptr;
+      if (mdb_reader_read_block_raw(r, ff, e.position, &h, &pd, &tp, &rh, &rl, &vv) != MGC_OK) die("ERROR: %s", mdb_last_error());
+      if (h.prefix != e.prefix) h.n_kmers = 0;
+      const uint32_t hi_bits = h.binary_bits > 64 ? h.binary_bits - 64 : 0, lo_bits = h.binary_bits > 64 ? 64 : h.binary_bits;
+      for (uint64_t i = 0; i < h.n_kmers; i++)
+        fprintf(stdout, "%8" PRIu64 " %11" PRIu64 " %011" PRIx64 " %2u %016" PRIx64 " %2u %016" PRIx64 " %8u\n",
+                i, pd[i], tp[i], hi_bits, rh[i], lo_bits, rl[i], vv[i]);
+      mdb_free(pd); mdb_free(tp); mdb_free(rh); mdb_free(rl); mdb_free(vv);
+    }
+    mdb_reader_close(r);
+  }
+  return 0;
+}
+
 int run_dump_index(const Operation &op) {
   for (const std::string &dbn : op.db_inputs) {
     mdb_reader *r = mdb_reader_open(dbn.c_str());
@@ -350,6 +412,7 @@ int run_dump_index(const Operation &op) {
     fprintf(stdout, "  suffixSize     %u\n", i.suffix_size);
     fprintf(stdout, "  numFilesBits   %u (%u files)\n", i.num_files_bits, 1u << i.num_files_bits);
     fprintf(stdout, "  numBlocksBits  %u (%u blocks)\n", i.num_blocks_bits, 1u << i.num_blocks_bits);
+    if (i.label_size) fprintf(stdout, "  labelSize      %u\n", i.label_size);
     fprintf(stdout, "  unique         %" PRIu64 "\n  distinct       %" PRIu64 "\n  total          %" PRIu64 "\n",
             i.num_unique, i.num_distinct, i.num_total);
     mdb_reader_close(r);
@@ -390,6 +453,17 @@ int main(int argc, char **argv) {
       else if (w == "-Q")                    { g.verbosity = 0; }
       else if (w == "-P")                    { /* progress: accepted, unused by count (:206-209) */ }
       else if (w == "-C")                    { g.only_config = true; }
+      else if (w == "-l") {                                                  // meryl2 global: label width in bits
+        if (a + 1 >= argc) die("ERROR: -l needs the label size in bits.");
+        g.label_size = (uint32_t)strtoul(argv[++a], nullptr, 10);
+        if (g.label_size > 64) die("ERROR: label size of more than 64 bits.");
+      }
+      else if (key == "label" && eq != std::string::npos) {                  // label=#<n>: the count's constant label
+        if (open_op < 0 || ops[open_op].kind < OP_COUNT || ops[open_op].kind > OP_COUNT_REVERSE)
+          die("ERROR: option '%s' needs a counting operation before it.", w.c_str());
+        if (val.empty() || val[0] != '#') die("ERROR: a count takes a constant label, label=#<integer>, not '%s'.", w.c_str());
+        ops[open_op].label = strtoull(val.c_str() + 1, nullptr, 0);
+      }
       else if (key == "k" && eq != std::string::npos) {
         const uint32_t k = (uint32_t)strtoul(val.c_str(), nullptr, 10);
         if (k == 0 || k > 64) die("ERROR: k=%s is not a valid k-mer size (1..64).", val.c_str());
@@ -410,10 +484,14 @@ int main(int argc, char **argv) {
       }
       else if (key == "segment") { die("ERROR: option '%s' (Canu sequence stores) is not supported in this build.", w.c_str()); }
       // ---- operations, :346-385 ----
-      else if (w == "count" || w == "count-forward" || w == "count-reverse" || w == "print" || w == "dumpIndex" || w == "histogram") {
+      else if (open_op >= 0 && ops[open_op].kind == OP_DUMPFILE && ops[open_op].db_inputs.empty()) {
+        ops[open_op].db_inputs.push_back(w);                                 // <database>/0x######
+      }
+      else if (w == "count" || w == "count-forward" || w == "count-reverse" || w == "print" || w == "dumpIndex" || w == "histogram" ||
+               w == "dumpFile") {
         const OpKind kind = (w == "count") ? OP_COUNT : (w == "count-forward") ? OP_COUNT_FORWARD :
                             (w == "count-reverse") ? OP_COUNT_REVERSE : (w == "print") ? OP_PRINT :
-                            (w == "histogram") ? OP_HISTOGRAM : OP_DUMPINDEX;
+                            (w == "histogram") ? OP_HISTOGRAM : (w == "dumpFile") ? OP_DUMPFILE : OP_DUMPINDEX;
         if (open_op >= 0 && ops[open_op].kind == OP_NONE) ops[open_op].kind = kind;    // `n=` came first
         else { ops.emplace_back(); open_op = (int)ops.size() - 1; ops[open_op].kind = kind; }
       }
@@ -423,7 +501,7 @@ int main(int argc, char **argv) {
                w == "difference" || w == "symmetric-difference" || w == "statistics" ||
                w == "less-than" || w == "greater-than" || w == "equal-to" || w == "at-least" || w == "at-most" ||
                w == "increase" || w == "decrease" || w == "multiply" || w == "divide" || w == "modulo" ||
-               w == "distinct" || w == "word-frequency" || w == "threshold" || w == "dumpFile" || w == "printACGT") {
+               w == "distinct" || w == "word-frequency" || w == "threshold" || w == "printACGT") {
         die("ERROR: operation '%s' is not part of this build (count path only).", w.c_str());
       }
       // ---- inputs ----
@@ -465,6 +543,7 @@ int main(int argc, char **argv) {
     if (op.kind == OP_PRINT)     rc |= run_print(op);
     if (op.kind == OP_DUMPINDEX) rc |= run_dump_index(op);
     if (op.kind == OP_HISTOGRAM) rc |= run_histogram(op);
+    if (op.kind == OP_DUMPFILE)  rc |= run_dump_file(op);
   }
   if (g.verbosity > 0) fprintf(stderr, "\nCleaning up.\n\nBye.\n");                                    // meryl.C:268,273
   return rc;

@@ -253,6 +253,26 @@ extern "C" int mgc_dev_block_offsets(const void *d_unique, uint64_t n_distinct, 
                                           (hipStream_t)stream), "block_offsets");
 }
 
+extern "C" size_t mgc_dev_merge_workspace_bytes(uint64_t na, uint64_t nb) { return mgc::merge_workspace_bytes(na, nb); }
+
+extern "C" int mgc_dev_merge_count(const void *dA, uint64_t na, const void *dB, uint64_t nb, uint32_t key_words, int op, void *d_ws,
+                                   size_t ws_bytes, uint64_t *n_out, void *stream) {
+  if (!n_out || !d_ws || ws_bytes < mgc::merge_workspace_bytes(na, nb) || (na && !dA) || (nb && !dB) ||
+      (key_words != 1 && key_words != 2) || op < 0 || op > 5) return MGC_EINVAL;
+  hipError_t e = mgc::launch_merge_count(dA, na, dB, nb, key_words, op, d_ws, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_rc(e, "merge_count");
+  return hip_rc(mgc::merge_read_total(d_ws, n_out, (hipStream_t)stream), "merge_count sync");
+}
+
+extern "C" int mgc_dev_merge_emit(const void *dA, const uint32_t *cA, uint64_t na, const void *dB, const uint32_t *cB, uint64_t nb,
+                                  uint32_t key_words, int op, void *d_ws, size_t ws_bytes, void *d_keys_out, uint32_t *d_counts_out,
+                                  void *stream) {
+  if (!d_ws || ws_bytes < mgc::merge_workspace_bytes(na, nb) || (na && (!dA || !cA)) || (nb && (!dB || !cB)) ||
+      (key_words != 1 && key_words != 2) || op < 0 || op > 5) return MGC_EINVAL;
+  return hip_rc(mgc::launch_merge_emit(dA, cA, na, dB, cB, nb, key_words, op, d_ws, d_keys_out, d_counts_out, (hipStream_t)stream),
+                "merge_emit");
+}
+
 extern "C" size_t mgc_dev_homopoly_workspace_bytes(uint64_t n) { return mgc::hpc_workspace_bytes(n); }
 
 extern "C" int mgc_dev_homopoly_compress(const uint8_t *d_in, uint64_t n, uint8_t *d_out, uint64_t *n_out, void *d_ws,
@@ -356,6 +376,7 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
     (void)hipGetDevice(&s->device);
   }
   e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_in, hipStreamNonBlocking);
   if (e != hipSuccess) { set_err(nullptr, "hipStreamCreate: %s", hipGetErrorString(e)); delete s; return nullptr; }
   if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -370,13 +391,18 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
 
 extern "C" void mgc_close(mgc_session *s) {
   if (!s) return;
+  if (s->worker_active) { s->worker.join(); s->worker_active = false; }
+  (void)hipSetDevice(s->device);
+  if (s->st_in) (void)hipStreamSynchronize(s->st_in);
   s->free_result();
   s->free_arena();
-  if (s->d_bases_own) (void)hipFree(s->d_bases_own);
   for (int i = 0; i < 2; i++) {
     if (s->text_pinned[i]) (void)hipHostFree(s->text_pinned[i]);
     if (s->text_ev[i]) (void)hipEventDestroy(s->text_ev[i]);
+    if (s->pin[i]) (void)hipHostFree(s->pin[i]);
+    if (s->pin_ev[i]) (void)hipEventDestroy(s->pin_ev[i]);
   }
+  if (s->st_in) (void)hipStreamDestroy(s->st_in);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
@@ -384,7 +410,12 @@ extern "C" void mgc_close(mgc_session *s) {
   delete s;
 }
 
-static int run_batch(mgc_session *s, size_t n_bases_in_batch);
+// ---------------------------------------------------------------------------------------------------------------
+//  Input staging (see mgc_session.hpp): one device-resident base stream per batch, double buffered
+// ---------------------------------------------------------------------------------------------------------------
+struct HostParseState { uint64_t out_len, file_start_len; uint32_t state, prev_nl, error, pad; };
+
+static int count_staged_batch(mgc_session *s, int which, uint64_t n);      // count stage[which][0, n) and merge it into R
 
 extern "C" int mgc_set_batch_bases(mgc_session *s, uint64_t bases_per_batch) {
   if (!s) return MGC_EINVAL;
@@ -392,28 +423,125 @@ extern "C" int mgc_set_batch_bases(mgc_session *s, uint64_t bases_per_batch) {
   return MGC_OK;
 }
 
-extern "C" int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int end_of_sequence) {
-  if (!s || (!bases && len)) return MGC_EINVAL;
-  if (s->borrowed || s->counted) { set_err(&s->err, "mgc_push_bases after device input / count"); return MGC_ESTATE; }
+static inline int stage_id(int which) { return which ? mgc_session::B_STAGE1 : mgc_session::B_STAGE0; }
+static inline uint8_t *stage_ptr(mgc_session *s, int which) { return reinterpret_cast<uint8_t *>(s->buf[stage_id(which)].p); }
+
+// first input of a session: streams, parse state, the batch size
+static int input_setup(mgc_session *s) {
+  if (s->borrowed || s->counted) { set_err(&s->err, "input after device input / count"); return MGC_ESTATE; }
+  HIP_TRY(s, hipSetDevice(s->device));
+  if (s->state_ready) return MGC_OK;
   if (s->batch_limit == 0) {
-    // one pass needs about: bases + X + Y (two key buffers) + distinct keys and counts + workspaces
+    // one pass holds, per base: the two staging buffers, a key (8/16 B per instance) in X, 4 B of count scratch, the
+    // distinct k-mers with their counts, the ping-pong buffer of the largest file -- about 20 (34) B with slack; the
+    // rest of the HBM is left to the running result of earlier batches and its merge target
     size_t free_b = 0, total_b = 0;
-    if (hipSetDevice(s->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
-      const uint64_t per_base = 2 + 16ull * s->key_words + 6ull * s->key_words + 4;
-      s->batch_limit = (uint64_t)((double)free_b * 0.85 / (double)per_base);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
+      const uint64_t per_base = 6 + 14ull * s->key_words;
+      s->batch_limit = (uint64_t)((double)free_b * 0.70 / (double)per_base);
     }
     if (s->batch_limit < (1u << 20)) s->batch_limit = 1u << 20;
   }
-  if (len) s->host_bases.insert(s->host_bases.end(), bases, bases + len);
-  if (end_of_sequence) s->host_bases.push_back('.');        // merylOp-countThreads.C:214-215
-  if (!s->text_mode && s->host_bases.size() >= s->batch_limit) {
-    // cut at the last sequence boundary: k-mers never span a breaker, so no carry is needed
-    // (and `compress` stays a per-sequence operation)
-    size_t cut = s->host_bases.size();
-    while (cut > 0 && s->host_bases[cut - 1] != '.') cut--;
-    if (cut > 0) {
-      const int rc = run_batch(s, cut);
-      if (rc != MGC_OK) return rc;
+  HIP_TRY(s, s->ensure(mgc_session::B_TEXT_STATE, mgc::text_parse_state_bytes() + 64));
+  HIP_TRY(s, s->ensure_preserve(stage_id(s->fill), 1u << 20, 0, s->st_in));
+  HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p, stage_ptr(s, s->fill), 3, s->st_in));
+  s->state_ready = true;
+  return MGC_OK;
+}
+
+// the device knows the exact length of the staged stream; bring the host's copy up to date (synchronises st_in)
+static int resolve_length(mgc_session *s, HostParseState *out = nullptr) {
+  HostParseState h;
+  HIP_TRY(s, hipMemcpyAsync(&h, s->buf[mgc_session::B_TEXT_STATE].p, sizeof(h), hipMemcpyDeviceToHost, s->st_in));
+  HIP_TRY(s, hipStreamSynchronize(s->st_in));
+  s->fill_len = h.out_len;
+  s->len_inexact = false;
+  if (out) *out = h;
+  return MGC_OK;
+}
+
+static int join_worker(mgc_session *s) {
+  if (s->worker_active) {
+    s->worker.join();
+    s->worker_active = false;
+    if (s->worker_rc != MGC_OK) return s->worker_rc;
+  }
+  return s->worker_rc;
+}
+
+// host-pushed bases collected in the current pinned chunk -> stage[fill] (asynchronous; the other chunk takes over)
+static int flush_pinned(mgc_session *s) {
+  if (s->pin_len == 0) return MGC_OK;
+  if (s->len_inexact) { const int rc = resolve_length(s); if (rc != MGC_OK) return rc; }
+  const int c = s->pin_cur;
+  HIP_TRY(s, s->ensure_preserve(stage_id(s->fill), s->fill_len + s->pin_len + 4096, s->fill_len, s->st_in));
+  HIP_TRY(s, hipMemcpyAsync(stage_ptr(s, s->fill) + s->fill_len, s->pin[c], s->pin_len, hipMemcpyHostToDevice, s->st_in));
+  s->fill_len += s->pin_len;
+  HIP_TRY(s, mgc::launch_text_set_len(s->buf[mgc_session::B_TEXT_STATE].p, s->fill_len, 0, s->st_in));
+  HIP_TRY(s, hipEventRecord(s->pin_ev[c], s->st_in));
+  s->pin_used[c] = true;
+  s->pin_len = 0;
+  s->pin_cur = c ^ 1;
+  if (s->pin_used[s->pin_cur]) HIP_TRY(s, hipEventSynchronize(s->pin_ev[s->pin_cur]));     // that chunk's upload has read it
+  return MGC_OK;
+}
+
+// The staged stream has reached the batch size: everything up to the last sequence boundary becomes a batch, counted by
+// the worker thread while the caller goes on filling the other staging buffer (k-mers never span a breaker, so no
+// carry is needed, and `compress` stays a per-sequence operation).
+static int cut_batch(mgc_session *s) {
+  int rc = flush_pinned(s);
+  if (rc != MGC_OK) return rc;
+  HostParseState h;
+  rc = resolve_length(s, &h);
+  if (rc != MGC_OK) return rc;
+  if (s->text_open && h.error) return MGC_OK;              // the open file is about to be refused and rolled back: not now
+  if (s->fill_len < s->batch_limit) return MGC_OK;         // the bound was pessimistic
+  uint64_t *d_last = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_TEXT_STATE].p) +
+                                                  ((mgc::text_parse_state_bytes() + 7) / 8) * 8);
+  uint64_t cut = 0;
+  HIP_TRY(s, mgc::launch_last_breaker(stage_ptr(s, s->fill), s->fill_len, d_last, s->st_in));
+  HIP_TRY(s, hipMemcpyAsync(&cut, d_last, sizeof(cut), hipMemcpyDeviceToHost, s->st_in));
+  HIP_TRY(s, hipStreamSynchronize(s->st_in));
+  if (cut == 0) return MGC_OK;                              // one sequence longer than a batch: keep staging
+  rc = join_worker(s);                                      // the previous batch is done: its staging buffer is free, R is stable
+  if (rc != MGC_OK) return rc;
+  const uint64_t tail = s->fill_len - cut;
+  const int other = s->fill ^ 1;
+  HIP_TRY(s, s->ensure_preserve(stage_id(other), tail + (1u << 20), 0, s->st_in));
+  if (tail) HIP_TRY(s, hipMemcpyAsync(stage_ptr(s, other), stage_ptr(s, s->fill) + cut, tail, hipMemcpyDeviceToDevice, s->st_in));
+  HIP_TRY(s, mgc::launch_text_set_len(s->buf[mgc_session::B_TEXT_STATE].p, tail, s->text_open ? 1 : 0, s->st_in));
+  HIP_TRY(s, hipStreamSynchronize(s->st_in));
+  if (s->text_open) s->text_cut_in_file = true;
+  const int which = s->fill;
+  s->fill = other;
+  s->fill_len = tail;
+  s->worker_rc = MGC_OK;
+  s->worker_active = true;
+  s->worker = std::thread([s, which, cut] { s->worker_rc = count_staged_batch(s, which, cut); });
+  return MGC_OK;
+}
+
+extern "C" int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int end_of_sequence) {
+  if (!s || (!bases && len)) return MGC_EINVAL;
+  int rc = input_setup(s);
+  if (rc != MGC_OK) return rc;
+  if (s->text_open) { set_err(&s->err, "mgc_push_bases while a text file is open (mgc_end_text first)"); return MGC_ESTATE; }
+  s->input_seen = true;
+  for (int i = 0; i < 2; i++) {
+    if (!s->pin[i]) HIP_TRY(s, hipHostMalloc(reinterpret_cast<void **>(&s->pin[i]), mgc_session::PIN_CHUNK, hipHostMallocDefault));
+    if (!s->pin_ev[i]) HIP_TRY(s, hipEventCreateWithFlags(&s->pin_ev[i], hipEventDisableTiming));
+  }
+  const char breaker = '.';                                  // merylOp-countThreads.C:214-215
+  for (int part = 0; part < 2; part++) {
+    const char *src = part ? &breaker : bases;
+    size_t left = part ? (end_of_sequence ? 1 : 0) : len;
+    while (left) {
+      const size_t take = std::min(left, mgc_session::PIN_CHUNK - s->pin_len);
+      memcpy(s->pin[s->pin_cur] + s->pin_len, src, take);
+      s->pin_len += take; src += take; left -= take;
+      if (s->pin_len == mgc_session::PIN_CHUNK) { rc = flush_pinned(s); if (rc != MGC_OK) return rc; }
+      if (s->fill_len + s->pin_len >= s->batch_limit) { rc = cut_batch(s); if (rc != MGC_OK) return rc; }
     }
   }
   return MGC_OK;
@@ -421,25 +549,16 @@ extern "C" int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int
 
 // ---- text input, parsed on the device (include/meryl_gpu_count.h) ------------------------------
 static int text_setup(mgc_session *s) {
-  if (s->borrowed || s->counted || !s->batches.empty()) {
-    set_err(&s->err, "text input cannot follow device input, a count, or a spilled batch");
-    return MGC_ESTATE;
-  }
-  HIP_TRY(s, hipSetDevice(s->device));
-  if (!s->text_mode) {
-    HIP_TRY(s, s->ensure(mgc_session::B_TEXT_STATE, mgc::text_parse_state_bytes()));
+  int rc = input_setup(s);
+  if (rc != MGC_OK) return rc;
+  if (!s->text_pinned[0]) {
     HIP_TRY(s, s->ensure(mgc_session::B_TEXT_IN0, mgc_session::TEXT_CHUNK));
     HIP_TRY(s, s->ensure(mgc_session::B_TEXT_IN1, mgc_session::TEXT_CHUNK));
     HIP_TRY(s, s->ensure(mgc_session::B_TEXT_WS, mgc::text_parse_workspace_bytes(mgc_session::TEXT_CHUNK)));
-    HIP_TRY(s, s->ensure_preserve(mgc_session::B_TEXT_OUT, 1u << 20, 0));
     for (int i = 0; i < 2; i++) {
       if (!s->text_pinned[i]) HIP_TRY(s, hipHostMalloc(reinterpret_cast<void **>(&s->text_pinned[i]), mgc_session::TEXT_CHUNK, hipHostMallocDefault));
       if (!s->text_ev[i]) HIP_TRY(s, hipEventCreateWithFlags(&s->text_ev[i], hipEventDisableTiming));
     }
-    HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p,
-                                        reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p), 3, s->stream));
-    s->text_mode = true;
-    s->text_bound = 0;
   }
   return MGC_OK;
 }
@@ -448,7 +567,9 @@ extern "C" int mgc_reserve_text(mgc_session *s, uint64_t text_bytes) {
   if (!s) return MGC_EINVAL;
   int rc = text_setup(s);
   if (rc != MGC_OK) return rc;
-  HIP_TRY(s, s->ensure_preserve(mgc_session::B_TEXT_OUT, text_bytes + 4096, s->text_bound));
+  // no more than a batch (plus what a chunk can add before the cut is noticed) is ever staged at once
+  const uint64_t want = std::min<uint64_t>(text_bytes, s->batch_limit + 2 * mgc_session::TEXT_CHUNK) + 4096;
+  HIP_TRY(s, s->ensure_preserve(stage_id(s->fill), want, s->fill_len, s->st_in));
   return MGC_OK;
 }
 
@@ -457,10 +578,13 @@ extern "C" int mgc_begin_text(mgc_session *s, int format) {
   if (s->text_open) { set_err(&s->err, "mgc_begin_text: the previous file was not ended"); return MGC_ESTATE; }
   int rc = text_setup(s);
   if (rc != MGC_OK) return rc;
-  HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p,
-                                      reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p), 0, s->stream));
+  rc = flush_pinned(s);                                     // host-pushed bases come first in the stream
+  if (rc != MGC_OK) return rc;
+  HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p, stage_ptr(s, s->fill), 0, s->st_in));
   s->text_format = format;
   s->text_open = true;
+  s->text_cut_in_file = false;
+  s->input_seen = true;
   return MGC_OK;
 }
 
@@ -468,16 +592,17 @@ extern "C" int mgc_begin_text(mgc_session *s, int format) {
 static int text_submit(mgc_session *s, const char *pinned_src, size_t piece) {
   const uint32_t b = s->text_next & 1u;
   if (s->text_ev_used[b]) HIP_TRY(s, hipEventSynchronize(s->text_ev[b]));       // device buffer b (and its previous source) are free again
-  HIP_TRY(s, s->ensure_preserve(mgc_session::B_TEXT_OUT, s->text_bound + piece + 4096, s->text_bound));
+  HIP_TRY(s, s->ensure_preserve(stage_id(s->fill), s->fill_len + piece + 4096, s->fill_len, s->st_in));
   uint8_t *d_in = reinterpret_cast<uint8_t *>(s->buf[b ? mgc_session::B_TEXT_IN1 : mgc_session::B_TEXT_IN0].p);
-  HIP_TRY(s, hipMemcpyAsync(d_in, pinned_src, piece, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(s, hipMemcpyAsync(d_in, pinned_src, piece, hipMemcpyHostToDevice, s->st_in));
   HIP_TRY(s, mgc::launch_text_parse(d_in, piece, s->text_format == MGC_TEXT_FASTQ, s->buf[mgc_session::B_TEXT_STATE].p,
-                                    s->buf[mgc_session::B_TEXT_WS].p,
-                                    reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p), s->stream));
-  HIP_TRY(s, hipEventRecord(s->text_ev[b], s->stream));
+                                    s->buf[mgc_session::B_TEXT_WS].p, stage_ptr(s, s->fill), s->st_in));
+  HIP_TRY(s, hipEventRecord(s->text_ev[b], s->st_in));
   s->text_ev_used[b] = true;
   s->text_next++;
-  s->text_bound += piece;
+  s->fill_len += piece;                                     // an upper bound: headers, qualities and line ends are dropped
+  s->len_inexact = true;
+  if (s->fill_len >= s->batch_limit) return cut_batch(s);
   return MGC_OK;
 }
 
@@ -599,52 +724,36 @@ extern "C" int mgc_push_text_file(mgc_session *s, const char *path, int format, 
   return rc != MGC_OK ? rc : rc_end;
 }
 
-struct HostParseState { uint64_t out_len, file_start_len; uint32_t state, prev_nl, error, pad; };
-
 extern "C" int mgc_end_text(mgc_session *s) {
   if (!s) return MGC_EINVAL;
   if (!s->text_open) { set_err(&s->err, "mgc_end_text without mgc_begin_text"); return MGC_ESTATE; }
   HIP_TRY(s, hipSetDevice(s->device));
   s->text_open = false;
-  HIP_TRY(s, s->ensure_preserve(mgc_session::B_TEXT_OUT, s->text_bound + 4096, s->text_bound));
-  uint8_t *out = reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p);
-  HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p, out, 1, s->stream));
-  s->text_bound += 1;
+  HIP_TRY(s, s->ensure_preserve(stage_id(s->fill), s->fill_len + 4096, s->fill_len, s->st_in));
+  HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p, stage_ptr(s, s->fill), 1, s->st_in));
   HostParseState h;
-  HIP_TRY(s, hipMemcpyAsync(&h, s->buf[mgc_session::B_TEXT_STATE].p, sizeof(h), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  int rc = resolve_length(s, &h);
+  if (rc != MGC_OK) return rc;
   if (h.error) {
-    HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p, out, 2, s->stream));
+    if (s->text_cut_in_file) {
+      // part of this file went into a batch that is already counted: it cannot be taken back
+      set_err(&s->err, "the file stops being strict four-line FASTQ after part of it was counted (input larger than one batch): "
+                       "convert it, or feed it through mgc_push_bases from the start");
+      return MGC_EINVAL;
+    }
+    HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p, stage_ptr(s, s->fill), 2, s->st_in));
+    rc = resolve_length(s);
+    if (rc != MGC_OK) return rc;
     set_err(&s->err, "the file is not strict four-line FASTQ: feed it through mgc_push_bases (meryl_seq.h reader)");
     return MGC_EFORMAT;
   }
-  return MGC_OK;
-}
-
-// end of the text input: the exact parsed length comes back, host-pushed bases (if any) are appended
-static int text_finalize(mgc_session *s) {
-  if (s->text_open) { set_err(&s->err, "mgc_count: a text file is still open (mgc_end_text)"); return MGC_ESTATE; }
-  HostParseState h;
-  HIP_TRY(s, hipMemcpyAsync(&h, s->buf[mgc_session::B_TEXT_STATE].p, sizeof(h), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
-  uint64_t n = h.out_len;
-  const size_t extra = s->host_bases.size();
-  if (extra) {
-    HIP_TRY(s, s->ensure_preserve(mgc_session::B_TEXT_OUT, n + extra + 4096, n));
-    HIP_TRY(s, hipMemcpyAsync(reinterpret_cast<uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p) + n, s->host_bases.data(), extra,
-                              hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(s, hipStreamSynchronize(s->stream));
-    n += extra;
-    std::vector<char>().swap(s->host_bases);
-  }
-  s->d_bases = reinterpret_cast<const uint8_t *>(s->buf[mgc_session::B_TEXT_OUT].p);
-  s->n_bases = n;
+  if (s->fill_len >= s->batch_limit) return cut_batch(s);
   return MGC_OK;
 }
 
 extern "C" int mgc_push_bases_device(mgc_session *s, const uint8_t *d_bases, uint64_t n_bases) {
   if (!s || (!d_bases && n_bases)) return MGC_EINVAL;
-  if (s->borrowed || !s->host_bases.empty() || s->counted) { set_err(&s->err, "device input must be the only input"); return MGC_ESTATE; }
+  if (s->borrowed || s->input_seen || s->counted) { set_err(&s->err, "device input must be the only input"); return MGC_ESTATE; }
   s->d_bases = d_bases;
   s->n_bases = n_bases;
   s->borrowed = true;
@@ -1053,21 +1162,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     for (auto &e : pass_ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ev_all[0]); (void)hipEventDestroy(ev_all[1]);
   }
-  s->counted = true;
-  return MGC_OK;
-}
-
-// bases of the host staging buffer [0, n) -> HBM (grow-only device buffer)
-static int upload_host_bases(mgc_session *s, size_t n) {
-  HIP_TRY(s, hipSetDevice(s->device));
-  HIP_TRY(s, s->ensure(mgc_session::B_BASES, n));
-  s->d_bases = reinterpret_cast<const uint8_t *>(s->buf[mgc_session::B_BASES].p);
-  s->n_bases = n;
-  if (n) {
-    HIP_TRY(s, hipMemcpyAsync(s->buf[mgc_session::B_BASES].p, s->host_bases.data(), n, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(s, hipStreamSynchronize(s->stream));             // the staging vector may be reused right after
-  }
-  return MGC_OK;
+  return MGC_OK;                                             // the caller marks the session counted (a batch is not the result yet)
 }
 
 static int copy_device_result(mgc_session *s, uint64_t *keys_lo, uint64_t *keys_hi, uint32_t *counts, uint64_t *block_start) {
@@ -1090,132 +1185,107 @@ static int copy_device_result(mgc_session *s, uint64_t *keys_lo, uint64_t *keys_
   return MGC_OK;
 }
 
-// Count the first n staged bases as one batch and park the result in host memory.
-static int run_batch(mgc_session *s, size_t n) {
-  int rc = upload_host_bases(s, n);
-  if (rc != MGC_OK) return rc;
-  rc = count_device(s);
-  if (rc != MGC_OK) return rc;
-  s->batches.emplace_back();
-  mgc_session::BatchResult &b = s->batches.back();
-  b.kw = s->key_words;
-  b.n_distinct = s->n_distinct;
-  HIP_TRY(s, b.keys.alloc((size_t)b.kw * b.n_distinct));
-  HIP_TRY(s, b.counts.alloc(b.n_distinct));
-  HIP_TRY(s, b.bstart.alloc(s->cfg.n_prefix + 1));
-  if (b.n_distinct) {
-    HIP_TRY(s, hipMemcpyAsync(b.keys.p, s->d_unique, sizeof(uint64_t) * b.kw * b.n_distinct, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(s, hipMemcpyAsync(b.counts.p, s->d_counts, sizeof(uint32_t) * b.n_distinct, hipMemcpyDeviceToHost, s->stream));
+// The (k-mer, count) result count_device just left in the arena joins the running result R of the earlier batches:
+// a device merge (mgc_merge.hip) that sums the counts of k-mers both hold (uint32 wrap, like the reference's value
+// arithmetic) -- the analogue of merylBlockWriter::finish() merging the spilled iterations.
+static int merge_into_r(mgc_session *s) {
+  const uint32_t kw = s->key_words;
+  const size_t kbytes = sizeof(uint64_t) * kw;
+  hipStream_t st = s->stream;
+  const uint64_t nd = s->n_distinct;
+  if (!s->have_r) {                                          // first batch: its result simply becomes R
+    std::swap(s->buf[mgc_session::B_UNIQUE], s->buf[mgc_session::B_RK]);
+    std::swap(s->buf[mgc_session::B_COUNTS], s->buf[mgc_session::B_RC]);
+    s->r_n = nd;
+    s->have_r = true;
+  } else {
+    hipEvent_t e0, e1;
+    HIP_TRY(s, hipEventCreate(&e0)); HIP_TRY(s, hipEventCreate(&e1));
+    HIP_TRY(s, hipEventRecord(e0, st));
+    HIP_TRY(s, s->ensure(mgc_session::B_MERGE_WS, mgc::merge_workspace_bytes(s->r_n, nd)));
+    void *ws = s->buf[mgc_session::B_MERGE_WS].p;
+    const void *rk = s->buf[mgc_session::B_RK].p;
+    const uint32_t *rc_ = reinterpret_cast<const uint32_t *>(s->buf[mgc_session::B_RC].p);
+    const void *bk = s->buf[mgc_session::B_UNIQUE].p;
+    const uint32_t *bc = reinterpret_cast<const uint32_t *>(s->buf[mgc_session::B_COUNTS].p);
+    uint64_t n_new = 0;
+    HIP_TRY(s, mgc::launch_merge_count(rk, s->r_n, bk, nd, kw, 0, ws, st));
+    HIP_TRY(s, mgc::merge_read_total(ws, &n_new, st));
+    HIP_TRY(s, s->ensure(mgc_session::B_R2K, kbytes * n_new));
+    HIP_TRY(s, s->ensure(mgc_session::B_R2C, sizeof(uint32_t) * n_new));
+    HIP_TRY(s, mgc::launch_merge_emit(rk, rc_, s->r_n, bk, bc, nd, kw, 0, ws, s->buf[mgc_session::B_R2K].p,
+                                      reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_R2C].p), st));
+    HIP_TRY(s, hipEventRecord(e1, st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) s->merge_ms += ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    std::swap(s->buf[mgc_session::B_RK], s->buf[mgc_session::B_R2K]);
+    std::swap(s->buf[mgc_session::B_RC], s->buf[mgc_session::B_R2C]);
+    s->r_n = n_new;
   }
-  HIP_TRY(s, hipMemcpyAsync(b.bstart.p, s->d_block_start, sizeof(uint64_t) * (s->cfg.n_prefix + 1), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
-  s->total_bases += n;
-  s->total_instances += s->n_instances;
-  for (int f = 0; f < MGC_NUM_FILES; f++) s->total_file_instances[f] += s->file_instances[f];
-  s->host_bases.erase(s->host_bases.begin(), s->host_bases.begin() + n);
-  s->counted = false;                                        // more input may follow
+  s->free_result();
   return MGC_OK;
 }
 
-// Merge the parked batch results: per file, a k-way merge by k-mer that sums the counts
-// (uint32 wrap, like the reference's value arithmetic), then the block offsets.
-static int merge_batches(mgc_session *s) {
-  const size_t nbatch = s->batches.size();
-  const uint64_t np = s->cfg.n_prefix, per_file = np / MGC_NUM_FILES;
-  const bool wide = s->key_words == 2;
-  std::vector<std::vector<uint64_t>> flo(MGC_NUM_FILES), fhi(MGC_NUM_FILES);
-  std::vector<std::vector<uint32_t>> fcn(MGC_NUM_FILES);
-  std::atomic<uint32_t> next_file(0);
-  auto worker = [&]() {
-    for (;;) {
-      const uint32_t ff = next_file.fetch_add(1);
-      if (ff >= MGC_NUM_FILES) return;
-      std::vector<uint64_t> pos(nbatch), end(nbatch);
-      for (size_t b = 0; b < nbatch; b++) { pos[b] = s->batches[b].bstart.p[ff * per_file]; end[b] = s->batches[b].bstart.p[(ff + 1) * per_file]; }
-      for (;;) {
-        bool any = false;
-        uint64_t mlo = 0, mhi = 0;
-        for (size_t b = 0; b < nbatch; b++) {
-          if (pos[b] == end[b]) continue;
-          const uint64_t lo = s->batches[b].lo(pos[b]), hi = s->batches[b].hi(pos[b]);
-          if (!any || hi < mhi || (hi == mhi && lo < mlo)) { mlo = lo; mhi = hi; any = true; }
-        }
-        if (!any) break;
-        uint32_t sum = 0;
-        for (size_t b = 0; b < nbatch; b++) {
-          if (pos[b] == end[b]) continue;
-          const uint64_t lo = s->batches[b].lo(pos[b]), hi = s->batches[b].hi(pos[b]);
-          if (lo == mlo && hi == mhi) { sum += s->batches[b].counts.p[pos[b]]; pos[b]++; }
-        }
-        flo[ff].push_back(mlo);
-        if (wide) fhi[ff].push_back(mhi);
-        fcn[ff].push_back(sum);
-      }
-    }
-  };
-  unsigned nthreads = s->cfg.threads ? s->cfg.threads : std::thread::hardware_concurrency();
-  nthreads = std::max(1u, std::min(nthreads, (unsigned)MGC_NUM_FILES));
-  std::vector<std::thread> pool;
-  for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(worker);
-  worker();
-  for (auto &t : pool) t.join();
+// one batch: stage[which][0, n) -> count -> merge into R.  Runs on the worker thread while the caller stages the next batch.
+static int count_staged_batch(mgc_session *s, int which, uint64_t n) {
+  s->d_bases = stage_ptr(s, which);
+  s->n_bases = n;
+  int rc = count_device(s);
+  if (rc != MGC_OK) return rc;
+  s->total_bases += n;
+  s->total_instances += s->n_instances;
+  for (int f = 0; f < MGC_NUM_FILES; f++) s->total_file_instances[f] += s->file_instances[f];
+  s->n_batches++;
+  return merge_into_r(s);
+}
 
-  uint64_t nd = 0;
-  for (int f = 0; f < MGC_NUM_FILES; f++) nd += flo[f].size();
-  s->m_lo.clear(); s->m_hi.clear(); s->m_counts.clear();
-  s->m_lo.reserve(nd); s->m_counts.reserve(nd);
-  if (wide) s->m_hi.reserve(nd);
-  for (int f = 0; f < MGC_NUM_FILES; f++) {
-    s->m_lo.insert(s->m_lo.end(), flo[f].begin(), flo[f].end());
-    if (wide) s->m_hi.insert(s->m_hi.end(), fhi[f].begin(), fhi[f].end());
-    s->m_counts.insert(s->m_counts.end(), fcn[f].begin(), fcn[f].end());
-    std::vector<uint64_t>().swap(flo[f]); std::vector<uint64_t>().swap(fhi[f]); std::vector<uint32_t>().swap(fcn[f]);
-  }
-  // block offsets: first distinct k-mer of every prefix (the array is ascending)
-  const uint32_t w_data = s->cfg.w_data;
-  s->m_bstart.assign(np + 1, nd);
-  uint64_t i = 0;
-  for (uint64_t p = 0; p <= np; p++) {
-    if (p == np) { s->m_bstart[p] = nd; break; }
-    while (i < nd) {
-      unsigned __int128 key = wide ? (((unsigned __int128)s->m_hi[i] << 64) | s->m_lo[i]) : (unsigned __int128)s->m_lo[i];
-      if ((uint64_t)(key >> w_data) >= p) break;
-      i++;
-    }
-    s->m_bstart[p] = i;
-  }
-  s->batches.clear();
-  s->n_distinct = nd;
+// the merged result of all batches becomes the session's result (device-resident, like a single pass's)
+static int finalize_from_r(mgc_session *s) {
+  hipStream_t st = s->stream;
+  s->n_distinct = s->r_n;
   s->n_instances = s->total_instances;
   s->n_bases = s->total_bases;
   memcpy(s->file_instances, s->total_file_instances, sizeof(s->file_instances));
-  s->merged = true;
-  s->free_result();
-  s->counted = true;
+  s->d_unique = s->buf[mgc_session::B_RK].p;
+  s->d_counts = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_RC].p);
+  HIP_TRY(s, s->ensure(mgc_session::B_BLOCKS, sizeof(uint64_t) * (s->cfg.n_prefix + 1)));
+  s->d_block_start = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_BLOCKS].p);
+  HIP_TRY(s, mgc::launch_block_offsets(s->d_unique, s->n_distinct, s->key_words, s->cfg.w_data, s->cfg.n_prefix, s->d_block_start, st));
+  HIP_TRY(s, hipStreamSynchronize(st));
+  s->prof.merge_ms = s->merge_ms;
+  s->prof.n_batches = s->n_batches;
   return MGC_OK;
 }
 
 extern "C" int mgc_count(mgc_session *s) {
   if (!s) return MGC_EINVAL;
-  if (s->borrowed) return count_device(s);
-  if (s->text_mode) {
-    int rc = text_finalize(s);
-    if (rc != MGC_OK) return rc;
-    s->merged = false;
-    return count_device(s);
+  if (s->borrowed) {                                         // the caller's device buffer: every call counts it again
+    const int rc = count_device(s);
+    if (rc == MGC_OK) s->counted = true;
+    return rc;
   }
-  if (s->batches.empty()) {                                  // everything fits in one pass: results stay in HBM
-    int rc = upload_host_bases(s, s->host_bases.size());
-    if (rc != MGC_OK) return rc;
-    std::vector<char>().swap(s->host_bases);
-    s->merged = false;
-    return count_device(s);
+  if (s->counted) return MGC_OK;                             // nothing can have been pushed since: the result stands
+  if (s->text_open) { set_err(&s->err, "mgc_count: a text file is still open (mgc_end_text)"); return MGC_ESTATE; }
+  int rc = MGC_OK;
+  if (!s->state_ready) { rc = input_setup(s); if (rc != MGC_OK) return rc; }     // nothing was pushed: an empty stream
+  rc = flush_pinned(s);
+  if (rc == MGC_OK) rc = resolve_length(s);
+  const int wrc = join_worker(s);
+  if (rc == MGC_OK) rc = wrc;
+  if (rc != MGC_OK) return rc;
+  if (!s->have_r) {                                          // everything fits in one pass
+    s->d_bases = stage_ptr(s, s->fill);
+    s->n_bases = s->fill_len;
+    rc = count_device(s);
+    s->prof.n_batches = 1;
+  } else {
+    if (s->fill_len) rc = count_staged_batch(s, s->fill, s->fill_len);
+    if (rc == MGC_OK) rc = finalize_from_r(s);
   }
-  if (!s->host_bases.empty()) {
-    int rc = run_batch(s, s->host_bases.size());
-    if (rc != MGC_OK) return rc;
-  }
-  return merge_batches(s);
+  if (rc == MGC_OK) s->counted = true;
+  return rc;
 }
 
 extern "C" int mgc_count_buckets(mgc_session *s, void *d_keys, uint32_t bucket_bits, const uint64_t *bucket_counts) {
@@ -1224,12 +1294,13 @@ extern "C" int mgc_count_buckets(mgc_session *s, void *d_keys, uint32_t bucket_b
   uint64_t n = 0;
   for (uint32_t b = 0; b < (1u << bucket_bits); b++) n += bucket_counts[b];
   if (n && !d_keys) return MGC_EINVAL;
-  if (!s->host_bases.empty() || !s->batches.empty() || s->n_bases || s->text_mode) {
+  if (s->input_seen || s->borrowed) {
     set_err(&s->err, "mgc_count_buckets: the session already holds pushed bases");
     return MGC_ESTATE;
   }
-  s->merged = false;
-  return count_device(s, d_keys, bucket_counts, bucket_bits);
+  const int rc = count_device(s, d_keys, bucket_counts, bucket_bits);
+  if (rc == MGC_OK) s->counted = true;
+  return rc;
 }
 
 extern "C" int mgc_count_partitioned(mgc_session *s, void *d_keys, const uint64_t *file_counts, void *reserved) {
@@ -1253,7 +1324,6 @@ extern "C" int mgc_get_result_info(const mgc_session *s, mgc_result_info *info) 
 extern "C" int mgc_copy_result_device(mgc_session *s, void *d_keys_out, uint32_t *d_counts_out) {
   if (!s) return MGC_EINVAL;
   if (!s->counted) return MGC_ESTATE;
-  if (s->merged) { set_err(&s->err, "the input was counted in several batches: the merged result is host-resident"); return MGC_ESTATE; }
   const size_t kbytes = sizeof(uint64_t) * s->key_words;
   if (s->n_distinct) {
     if (d_keys_out) HIP_TRY(s, hipMemcpyAsync(d_keys_out, s->d_unique, kbytes * s->n_distinct, hipMemcpyDeviceToDevice, s->stream));
@@ -1267,7 +1337,6 @@ extern "C" int mgc_get_result_device(const mgc_session *s, const void **d_unique
                                      const uint64_t **d_block_start, uint32_t *key_words) {
   if (!s) return MGC_EINVAL;
   if (!s->counted) return MGC_ESTATE;
-  if (s->merged) { set_err(nullptr, "the input was counted in several batches: the merged result is host-resident"); return MGC_ESTATE; }
   if (d_unique) *d_unique = s->d_unique;
   if (d_counts) *d_counts = s->d_counts;
   if (d_block_start) *d_block_start = s->d_block_start;
@@ -1280,14 +1349,6 @@ extern "C" int mgc_copy_result(const mgc_session *cs, uint64_t *keys_lo, uint64_
   mgc_session *s = const_cast<mgc_session *>(cs);
   if (!s) return MGC_EINVAL;
   if (!s->counted) return MGC_ESTATE;
-  if (s->merged) {
-    const uint64_t nd = s->n_distinct;
-    if (keys_lo && nd) memcpy(keys_lo, s->m_lo.data(), sizeof(uint64_t) * nd);
-    if (keys_hi && nd) { if (s->key_words == 2) memcpy(keys_hi, s->m_hi.data(), sizeof(uint64_t) * nd); else memset(keys_hi, 0, sizeof(uint64_t) * nd); }
-    if (counts && nd)  memcpy(counts, s->m_counts.data(), sizeof(uint32_t) * nd);
-    if (block_start)   memcpy(block_start, s->m_bstart.data(), sizeof(uint64_t) * (s->cfg.n_prefix + 1));
-    return MGC_OK;
-  }
   HIP_TRY(s, hipSetDevice(s->device));
   return copy_device_result(s, keys_lo, keys_hi, counts, block_start);
 }

@@ -111,6 +111,17 @@ uint32_t   value_hist_small_bins();
 hipError_t launch_value_hist(const uint32_t *d_counts, uint64_t n, uint64_t *d_hist, uint32_t *d_big_list, uint64_t big_cap,
                              uint64_t *d_big_n, hipStream_t st);
 
+// ---- merge of two sorted distinct (k-mer, value) streams (mgc_merge.hip) ----------------------------------------
+// op: 0 union-sum, 1 union-min, 2 union-max, 3 intersect-sum, 4 intersect-min, 5 intersect-max
+size_t     merge_workspace_bytes(uint64_t na, uint64_t nb);
+hipError_t launch_merge_count(const void *dA, uint64_t na, const void *dB, uint64_t nb, uint32_t key_words, int op, void *d_ws,
+                              hipStream_t st);
+hipError_t merge_read_total(const void *d_ws, uint64_t *n_out, hipStream_t st);       // synchronises the stream
+hipError_t launch_merge_emit(const void *dA, const uint32_t *cA, uint64_t na, const void *dB, const uint32_t *cB, uint64_t nb,
+                             uint32_t key_words, int op, void *d_ws, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st);
+// *d_out <- 1 + index of the last '.' in bases[0, n), 0 if none
+hipError_t launch_last_breaker(const uint8_t *d_bases, uint64_t n, uint64_t *d_out, hipStream_t st);
+
 // ---- homopolymer compression -------------------------------------------------
 size_t     hpc_workspace_bytes(uint64_t n);
 // compressed length lands in the first uint64 of the workspace
@@ -123,6 +134,9 @@ size_t     text_parse_workspace_bytes(uint64_t n);            // for one chunk o
 hipError_t launch_text_parse(const uint8_t *d_text, uint64_t n, int fastq, void *d_state, void *d_ws, uint8_t *d_out, hipStream_t st);
 // what: 0 begin file, 1 end file (breaker), 2 roll the current file back, 3 reset
 hipError_t launch_text_file_op(void *d_state, uint8_t *d_out, int what, hipStream_t st);
+// the stream now holds new_len bytes (bases appended by a plain copy, or the tail kept after a batch was cut off);
+// rebase_file: the open file's rollback point moves to 0 (what it wrote before the cut is gone)
+hipError_t launch_text_set_len(void *d_state, uint64_t new_len, int rebase_file, hipStream_t st);
 
 hipError_t launch_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                               uint32_t read_len, uint32_t sub_rate_ppm, uint32_t n_rate_ppm,

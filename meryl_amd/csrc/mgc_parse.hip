@@ -328,6 +328,17 @@ __global__ void text_file_kernel(ParseState *ps, u8 *out, int what) {
   }
 }
 
+__global__ void text_set_len_kernel(ParseState *ps, u64 new_len, int rebase_file) {
+  ps->out_len = new_len;
+  if (rebase_file) ps->file_start_len = 0;
+  else if (ps->file_start_len > new_len) ps->file_start_len = new_len;
+}
+
+hipError_t launch_text_set_len(void *d_state, uint64_t new_len, int rebase_file, hipStream_t st) {
+  hipLaunchKernelGGL(text_set_len_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<ParseState *>(d_state), (u64)new_len, rebase_file);
+  return hipGetLastError();
+}
+
 size_t text_parse_state_bytes() { return sizeof(ParseState); }
 size_t text_parse_workspace_bytes(uint64_t n) {
   const uint64_t ntiles = (n + PT_TILE - 1) / PT_TILE;

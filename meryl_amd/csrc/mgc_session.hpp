@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace mgc {
@@ -45,9 +46,7 @@ struct mgc_session {
   hipEvent_t       ev_fork = nullptr, ev_join = nullptr;
   std::string      err;
 
-  // input
-  std::vector<char> host_bases;          // mgc_push_bases accumulates here (pinned staging is a later round)
-  uint8_t          *d_bases_own = nullptr;
+  // input: what count_device reads (a staging buffer of this session, or the caller's device buffer)
   const uint8_t    *d_bases = nullptr;
   uint64_t          n_bases = 0;
   bool              borrowed = false;
@@ -64,8 +63,9 @@ struct mgc_session {
   // device arena: buffers survive between mgc_count calls (grow-only), so a
   // repeated count does not pay hipMalloc/hipFree of tens of GB every time
   struct Buf { void *p = nullptr; size_t cap = 0; };
-  enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_HPC, B_HPC_WS, B_BASES,
-         B_SUBSTART, B_GROUPS, B_GSCAN, B_CNT_TMP, B_LARGE, B_NONEMPTY, B_TEXT_OUT, B_TEXT_IN0, B_TEXT_IN1, B_TEXT_WS, B_TEXT_STATE, B_NUM };
+  enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_HPC, B_HPC_WS,
+         B_SUBSTART, B_GROUPS, B_GSCAN, B_CNT_TMP, B_LARGE, B_NONEMPTY, B_STAGE0, B_STAGE1, B_TEXT_IN0, B_TEXT_IN1, B_TEXT_WS,
+         B_TEXT_STATE, B_RK, B_RC, B_R2K, B_R2C, B_MERGE_WS, B_NUM };
   Buf buf[B_NUM];
   hipError_t ensure(int which, size_t bytes) {
     Buf &b = buf[which];
@@ -77,8 +77,8 @@ struct mgc_session {
     return e;
   }
   void free_arena() { for (auto &b : buf) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; } }
-  // grows a buffer whose first `keep` bytes must survive (device-to-device copy on the session stream)
-  hipError_t ensure_preserve(int which, size_t bytes, size_t keep) {
+  // grows a buffer whose first `keep` bytes must survive (device-to-device copy on stream `on`, synchronised)
+  hipError_t ensure_preserve(int which, size_t bytes, size_t keep, hipStream_t on) {
     Buf &b = buf[which];
     if (b.cap >= bytes) return hipSuccess;
     size_t want = b.cap + b.cap / 2;
@@ -86,56 +86,57 @@ struct mgc_session {
     void *np = nullptr;
     hipError_t e = hipMalloc(&np, want);
     if (e != hipSuccess) return e;
-    if (b.p && keep) e = hipMemcpyAsync(np, b.p, keep, hipMemcpyDeviceToDevice, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (b.p && keep) e = hipMemcpyAsync(np, b.p, keep, hipMemcpyDeviceToDevice, on);
+    if (e == hipSuccess) e = hipStreamSynchronize(on);
     if (b.p) (void)hipFree(b.p);
     b.p = np; b.cap = want;
     return e;
   }
 
-  // device-side text parsing (mgc_push_text): pinned staging, two chunks in flight
+  // ---- input staging -------------------------------------------------------------------------------------------
+  // Everything pushed (bases from the host, text parsed on the device) lands in ONE base stream in HBM, stage[fill],
+  // '.' after every sequence.  The device-side parse state (B_TEXT_STATE) holds the stream's length: text chunks
+  // advance it on the device, plain appends set it; the host's fill_len is exact unless text was parsed since the last
+  // read-back (len_inexact) -- then it is an upper bound.  All of it runs on st_in, a stream of its own, so that
+  // uploads and parsing overlap the count of the previous batch (which runs on `stream`, from the worker thread).
   static constexpr size_t TEXT_CHUNK = 32u << 20;
-  bool        text_mode = false, text_open = false;
+  static constexpr size_t PIN_CHUNK  = 32u << 20;
+  hipStream_t st_in = nullptr;
+  bool        state_ready = false;       // parse state allocated and reset
+  int         fill = 0;
+  uint64_t    fill_len = 0;
+  bool        len_inexact = false;
+  bool        input_seen = false;
+  // text
+  bool        text_open = false, text_cut_in_file = false;
   int         text_format = 0;
-  uint64_t    text_bound = 0;            // upper bound of the parsed length so far (the device knows the exact one)
   char       *text_pinned[2] = {nullptr, nullptr};
   hipEvent_t  text_ev[2] = {nullptr, nullptr};
   bool        text_ev_used[2] = {false, false};
   uint32_t    text_next = 0;
+  // host-pushed bases: two pinned chunks, the upload of one overlaps the filling of the other
+  char       *pin[2] = {nullptr, nullptr};
+  size_t      pin_len = 0;
+  int         pin_cur = 0;
+  hipEvent_t  pin_ev[2] = {nullptr, nullptr};
+  bool        pin_used[2] = {false, false};
 
-  // out-of-core batches (the analogue of writeBatch's spill, merylOp-countThreads.C:323-379): when the
-  // pushed bases exceed what one pass can hold in HBM, everything up to the last sequence
-  // boundary is counted and its (k-mer, count) result parked in host memory; mgc_count merges
-  // the parked results per file (summing counts) like merylBlockWriter::finish() merges iterations.
-  // parked batch results live in PINNED host memory and are filled by asynchronous copies on the session stream
-  // (pageable copies run at a fifth of the PCIe rate); keys stay interleaved {lo[,hi]} exactly as on the device
-  template <typename T> struct Pinned {
-    T *p = nullptr; size_t n = 0;
-    Pinned() = default;
-    Pinned(const Pinned &) = delete;
-    Pinned &operator=(const Pinned &) = delete;
-    Pinned(Pinned &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
-    ~Pinned() { if (p) (void)hipHostFree(p); }
-    hipError_t alloc(size_t count) {
-      n = count;
-      return hipHostMalloc(reinterpret_cast<void **>(&p), (count ? count : 1) * sizeof(T), hipHostMallocDefault);
-    }
-  };
-  struct BatchResult {
-    Pinned<uint64_t> keys, bstart;        // keys: key_words x n_distinct
-    Pinned<uint32_t> counts;
-    uint64_t n_distinct = 0;
-    uint32_t kw = 1;
-    uint64_t lo(uint64_t i) const { return keys.p[kw * i]; }
-    uint64_t hi(uint64_t i) const { return kw == 2 ? keys.p[2 * i + 1] : 0ull; }
-  };
-  std::vector<BatchResult> batches;
-  uint64_t  batch_limit = 0;              // bases per batch; 0 = derive from free HBM at the first push
-  bool      merged = false;               // final result lives in m_* (host) instead of d_* (device)
-  std::vector<uint64_t> m_lo, m_hi, m_bstart;
-  std::vector<uint32_t> m_counts;
-  uint64_t  total_bases = 0, total_instances = 0;
-  uint64_t  total_file_instances[MGC_NUM_FILES];
+  // ---- out-of-core batches (the analogue of writeBatch's spill, merylOp-countThreads.C:323-379, and of
+  // merylBlockWriter::finish() merging the iterations) ---------------------------------------------------------
+  // When the staged bases reach batch_limit, everything up to the last sequence boundary is counted as one batch by
+  // the WORKER thread while the caller keeps pushing into the other staging buffer; the batch's (k-mer, count) result
+  // is merged ON THE DEVICE into the running result R (mgc_merge.hip), which stays in HBM -- nothing is parked on the
+  // host, and the final result is device-resident like a single-pass one.
+  uint64_t    batch_limit = 0;            // bases per batch; 0 = derive from free HBM at the first input
+  bool        have_r = false;
+  uint64_t    r_n = 0;                    // distinct k-mers in R (buffers B_RK / B_RC)
+  uint64_t    total_bases = 0, total_instances = 0;
+  uint64_t    total_file_instances[MGC_NUM_FILES];
+  uint32_t    n_batches = 0;
+  double      merge_ms = 0;
+  std::thread worker;
+  bool        worker_active = false;      // a batch is being counted (join before touching count state)
+  int         worker_rc = MGC_OK;
 
   // profiling
   bool        profiling = false;

@@ -396,31 +396,11 @@ extern "C" int mgc_db_stream_close(mgc_db_stream *d, mgc_db_write_profile *prof)
 // ================================================================================================
 //  session result -> database
 // ================================================================================================
-namespace {
-struct WriteCtx { mdb_writer *w; };
-int write_cb2(void *ctx, uint64_t prefix, uint64_t n, const uint64_t *slo, const uint64_t *shi, const uint32_t *cnt,
-              const uint64_t *labels, uint64_t label) {
-  return mdb_writer_add_block_labelled(((WriteCtx *)ctx)->w, prefix, n, slo, shi, cnt, labels, label);
-}
-}  // namespace
-
 extern "C" int mgc_write_database_profiled(mgc_session *s, const char *path, int host_threads, mgc_db_write_profile *prof) {
   if (!s || !path) return MGC_EINVAL;
   if (!s->counted) { set_err(&s->err, "mgc_write_database before mgc_count"); return MGC_ESTATE; }
   if (prof) memset(prof, 0, sizeof(*prof));
   const mgc_count_config &c = s->cfg;
-  if (s->merged) {
-    // a result merged from out-of-core batches on the host: encoded by the host writer from the host arrays
-    const double t0 = now_s();
-    WriteCtx wc;
-    wc.w = mdb_writer_open_ex(path, c.k, c.w_prefix, c.label_size, 0, 1);
-    if (!wc.w) { set_err(&s->err, "%s", mdb_last_error()); return MGC_EINVAL; }
-    int rc = mgc_finish_labelled(s, write_cb2, &wc, host_threads);
-    const int rc2 = mdb_writer_close(wc.w);
-    if (rc == MGC_OK && rc2 != MGC_OK) { rc = rc2; set_err(&s->err, "%s", mdb_last_error()); }
-    if (prof) { prof->total_s = prof->copy_write_s = now_s() - t0; prof->n_kmers = s->n_distinct; prof->n_blocks = c.n_prefix; }
-    return rc;
-  }
   mgc_db_stream *d = mgc_db_stream_open(path, c.k, c.w_prefix, c.label_size, c.label_constant, 0, 1, host_threads, s->device);
   if (!d) { set_err(&s->err, "%s", mgc_db_stream_error(nullptr)); return MGC_EINVAL; }
   int rc = mgc_db_stream_write(d, s->d_unique, s->d_counts, s->n_distinct, 0, c.n_prefix);
@@ -469,16 +449,10 @@ int finish_impl(mgc_session *s, mgc_block_cb cb1, mgc_block_cb2 cb2, void *ctx, 
   host_threads = std::max(1, std::min(host_threads, MGC_NUM_FILES));
 
   // block boundaries first (small); the k-mers follow file by file
-  std::vector<uint64_t> bstart_own;
-  const uint64_t *bstart;
-  if (s->merged) {
-    bstart = s->m_bstart.data();
-  } else {
-    HIP_TRY(s, hipSetDevice(s->device));
-    bstart_own.resize(np + 1);
-    HIP_TRY(s, hipMemcpy(bstart_own.data(), s->d_block_start, sizeof(uint64_t) * (np + 1), hipMemcpyDeviceToHost));
-    bstart = bstart_own.data();
-  }
+  std::vector<uint64_t> bstart_own(np + 1);
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipMemcpy(bstart_own.data(), s->d_block_start, sizeof(uint64_t) * (np + 1), hipMemcpyDeviceToHost));
+  const uint64_t *bstart = bstart_own.data();
 
   auto deliver = [&](uint64_t pp, uint64_t n, const uint64_t *slo, const uint64_t *shi, const uint32_t *cn) -> int {
     return cb2 ? cb2(ctx, pp, n, slo, shi, cn, nullptr, label) : cb1(ctx, pp, n, slo, shi, cn);
@@ -501,7 +475,7 @@ int finish_impl(mgc_session *s, mgc_block_cb cb1, mgc_block_cb2 cb2, void *ctx, 
       set_err(&s->err, "mgc_finish: %s: %s", what, hipGetErrorString(e));
       status.store(e == hipErrorOutOfMemory ? MGC_ENOMEM : MGC_EHIP);
     };
-    if (!s->merged) {
+    {
       hipError_t e = hipSetDevice(s->device);
       if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
@@ -537,17 +511,15 @@ int finish_impl(mgc_session *s, mgc_block_cb cb1, mgc_block_cb2 cb2, void *ctx, 
       const uint64_t f0 = ff * per_file, f1 = (ff + 1) * per_file;
       int b = 0;
       Span cur = plan(f0, f1);
-      if (!s->merged && !issue(cur, b)) break;
+      if (!issue(cur, b)) break;
       bool stop = false;
       while (cur.p0 < f1 && !stop) {
         const Span nxt = plan(cur.p1, f1);
-        if (!s->merged && nxt.p0 < f1 && !issue(nxt, b ^ 1)) { stop = true; break; }
+        if (nxt.p0 < f1 && !issue(nxt, b ^ 1)) { stop = true; break; }
         const uint64_t k0 = bstart[cur.p0], n = bstart[cur.p1] - k0;
         const uint64_t *keys = nullptr;
         const uint32_t *cnts = nullptr;
-        if (s->merged) {
-          cnts = s->m_counts.data() + k0;
-        } else if (n) {
+        if (n) {
           hipError_t e = hipEventSynchronize(ev[b]);
           if (e != hipSuccess) { hip_fail(e, "device-to-host copy"); stop = true; break; }
           keys = reinterpret_cast<const uint64_t *>(pk[b].p);
@@ -557,10 +529,7 @@ int finish_impl(mgc_session *s, mgc_block_cb cb1, mgc_block_cb2 cb2, void *ctx, 
           const uint64_t o = bstart[pp] - k0, m = bstart[pp + 1] - bstart[pp];
           slo.resize(m);
           if (wide) shi.resize(m);
-          if (s->merged) {
-            for (uint64_t i = 0; i < m; i++) slo[i] = s->m_lo[k0 + o + i] & mask_lo;
-            if (wide) for (uint64_t i = 0; i < m; i++) shi[i] = s->m_hi[k0 + o + i] & mask_hi;
-          } else if (wide) {
+          if (wide) {
             for (uint64_t i = 0; i < m; i++) { slo[i] = keys[2 * (o + i)] & mask_lo; shi[i] = keys[2 * (o + i) + 1] & mask_hi; }
           } else {
             for (uint64_t i = 0; i < m; i++) slo[i] = keys[o + i] & mask_lo;

@@ -294,3 +294,62 @@ def test_reader_rejects_truncated_and_corrupt_files(tmp_path, native_lib, oracle
     open(f, "wb").write(bytes(buf2[:48]) + w2.tobytes())
     with pytest.raises(db.DbError):
         db.Reader(p3)
+
+
+def _cli():
+    from meryl_amd import build
+    return build.build_cli()
+
+
+def test_cli_dumpfile_print_and_doc_size_bound(tmp_path, native_lib):
+    """`meryl dumpFile <db>/0x######` (src/meryl/meryl.C:41-45) prints the three tables of usage.rst:24-45; the doc's own
+    example -- suffixSize 104, blocks of 22363 and 16486 k-mers at blkPos 0 / 345448 / 601248 -- bounds the layout
+    assumptions A2-A6: our encoding of blocks of those sizes lands within 0.1 % of the documented block sizes."""
+    import subprocess
+    from meryl_amd import db
+    k, wp = 57, 10                                            # 2k - wp = 104 = the example's suffixSize
+    rng = np.random.default_rng(1)
+    path = str(tmp_path / "doc.meryl")
+    w = db.Writer(path, k, wp)
+    wl = db.Writer(path + ".labelled", k, wp, label_size=3)
+    sizes = [22363, 16486, 17345]
+    blocks = []
+    for p, n in enumerate(sizes):
+        hi = np.sort(rng.integers(0, 1 << 40, n, dtype=np.uint64))      # suffix = hi:lo, 104 bits
+        lo = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+        cn = rng.integers(1, 9, n).astype(np.uint32)
+        w.add_block(p, lo, cn, hi)
+        wl.add_block(p, lo, cn, hi, label=5)
+        blocks.append((lo, hi, cn))
+    for p in range(len(sizes), 16):                           # addBlock is called for every prefix of a file, empty ones too
+        w.add_block(p, [], [], [])
+        wl.add_block(p, [], [], [])
+    w.close()
+    wl.close()
+    out = subprocess.run([_cli(), "-Q", "dumpFile", path + "/0x000000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.split("\n")
+    i0 = lines.index("---------- --------- ---------")
+    idx = [l.split() for l in lines[i0 + 1:i0 + 1 + 16]]
+    assert [int(r[2]) for r in idx[:4]] == sizes + [0] and idx[0][0] == "0x00000000" and int(idx[0][1]) == 0
+    pos = [int(r[1]) for r in idx]
+    for got, doc in ((pos[1] - pos[0], 345448), (pos[2] - pos[1], 601248 - 345448)):
+        assert abs(got - doc) / doc < 1e-3, (got, doc)        # usage.rst:29-31
+    i1 = [i for i, l in enumerate(lines) if l.startswith("------------------ --------")][0]
+    h0 = lines[i1 + 1].split()
+    assert h0 == ["0x0000000000000000", "22363", "1", "15", "89", "0x0000000000000000", "1", "0x0000000000000000", "0x0000000000000000"]   # usage.rst:36
+    i2 = [i for i, l in enumerate(lines) if l.startswith("-------- -----------")][0]
+    lo, hi, cn = blocks[0]
+    suffix0 = (int(hi[0]) << 64) | int(lo[0])
+    f = lines[i2 + 1].split()
+    top = suffix0 >> 89
+    assert int(f[0]) == 0 and int(f[1]) == top and int(f[2], 16) == top and int(f[3]) == 25 and int(f[5]) == 64
+    assert int(f[4], 16) == (suffix0 >> 64) & ((1 << 25) - 1) and int(f[6], 16) == suffix0 & ((1 << 64) - 1) and int(f[7]) == int(cn[0])
+    assert sum(1 for l in lines[i2 + 1:] if l.strip()) == sum(sizes)
+    # print: k-mer, value, label in binary (meryl2's third column)
+    pr = subprocess.run([_cli(), "-Q", "print", path + ".labelled"], stdout=subprocess.PIPE, text=True)
+    first = pr.stdout.split("\n")[0].split("\t")
+    assert len(first[0]) == k and int(first[1]) == int(cn[0]) and first[2] == "101"
+    assert len(subprocess.run([_cli(), "-Q", "print", path], stdout=subprocess.PIPE, text=True).stdout.split("\n")[0].split("\t")) == 2
+    di = subprocess.run([_cli(), "-Q", "dumpIndex", path + ".labelled"], stdout=subprocess.PIPE, text=True).stdout
+    assert "prefixSize     10" in di and "suffixSize     104" in di and "labelSize      3" in di

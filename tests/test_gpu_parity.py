@@ -651,6 +651,125 @@ def test_out_of_core_batches_equal_single_pass(ops, oracle_lib, torch_cuda, tmp_
         r.close()
 
 
+def _np_merge(a_lo, a_hi, a_c, b_lo, b_hi, b_c, op):
+    """numpy statement of the two-input merge (python ints as keys: small inputs)"""
+    A = {(int(h) << 64) | int(l): int(c) for l, h, c in zip(a_lo, a_hi, a_c)}
+    B = {(int(h) << 64) | int(l): int(c) for l, h, c in zip(b_lo, b_hi, b_c)}
+    f = {"sum": lambda x, y: (x + y) & 0xFFFFFFFF, "min": min, "max": max}[op.split("-")[1]]
+    if op.startswith("union"):
+        keys = sorted(set(A) | set(B))
+        return keys, [f(A[k], B[k]) if (k in A and k in B) else A.get(k, B.get(k)) for k in keys]
+    keys = sorted(set(A) & set(B))
+    return keys, [f(A[k], B[k]) for k in keys]
+
+
+@pytest.mark.parametrize("kw,na,nb,overlap", [(1, 0, 0, 0), (1, 1, 0, 0), (1, 0, 5, 0), (1, 3000, 3000, 0.5), (1, 50_000, 70_000, 0.3),
+                                               (1, 2048, 2048, 1.0), (1, 10_000, 3, 0.0), (2, 40_000, 30_000, 0.4), (2, 5000, 5000, 1.0),
+                                               (1, 100_000, 100_000, 0.0)])
+def test_device_merge_matches_numpy(ops, torch_cuda, kw, na, nb, overlap):
+    """mgc_dev_merge_* (merge path, duplicate pairs across thread and tile borders, empty inputs, one input inside the
+    other) against a set-based statement, for the six operations."""
+    rng = np.random.default_rng(na * 7 + nb + kw)
+
+    def mk(n, pool):
+        idx = np.sort(rng.choice(pool.shape[0], n, replace=False)) if n else np.zeros(0, np.int64)
+        return pool[idx]
+    n_pool = max(1, int((na + nb) * (1.0 - overlap / 2)) + 8)
+    if overlap == 1.0:
+        n_pool = max(na, nb, 1)
+    lo = rng.integers(0, 1 << 62, n_pool, dtype=np.uint64)
+    hi = rng.integers(0, 1 << 30, n_pool, dtype=np.uint64) if kw == 2 else np.zeros(n_pool, np.uint64)
+    if kw == 2 and n_pool > 100:
+        hi[: n_pool // 2] = hi[0]                                # runs with equal high words: the low word decides
+    order = np.lexsort((lo, hi))
+    pool = np.stack([lo[order], hi[order]], axis=1)
+    keep = np.ones(n_pool, bool); keep[1:] = np.any(pool[1:] != pool[:-1], axis=1)
+    pool = pool[keep]
+    na, nb = min(na, pool.shape[0]), min(nb, pool.shape[0])
+    a, b = mk(na, pool), mk(nb, pool)
+    ac = rng.integers(1, 0xFFFFFFFF, na, dtype=np.uint64).astype(np.uint32)
+    bc = rng.integers(1, 1000, nb).astype(np.uint32)
+
+    def dev(x, c):
+        if kw == 2:
+            k_ = torch_cuda.from_numpy(np.ascontiguousarray(x).view(np.int64).copy()).cuda().view(-1, 2)
+        else:
+            k_ = torch_cuda.from_numpy(np.ascontiguousarray(x[:, 0]).view(np.int64).copy()).cuda()
+        return k_, torch_cuda.from_numpy(c.view(np.int32).copy()).cuda()
+    ka, ca = dev(a, ac)
+    kb, cb = dev(b, bc)
+    for op in ops.MERGE_OPS:
+        ok, oc = ops.dev_merge(ka, ca, kb, cb, op)
+        wk, wc = _np_merge(a[:, 0], a[:, 1], ac, b[:, 0], b[:, 1], bc, op)
+        gk = ok.cpu().numpy().view(np.uint64)
+        got = [(int(r[1]) << 64) | int(r[0]) for r in gk.reshape(-1, 2)] if kw == 2 else [int(x) for x in gk]
+        assert got == wk, op
+        assert [int(x) for x in oc.cpu().numpy().view(np.uint32)] == wc, op
+
+
+@pytest.mark.parametrize("k,compress", [(51, 0), (21, 0), (31, 1)])
+def test_out_of_core_three_plus_batches_device_merge(ops, oracle_lib, torch_cuda, tmp_path, k, compress):
+    """BASELINE config 5's mechanics at test size: >= 3 forced batches, each counted by the worker thread while the next
+    one is staged through the pinned upload buffers, merged on the device into the running result -- equal to the
+    single pass, device-resident (result_device works), with the merge time reported; the same through the text path
+    (batches cut inside a FASTQ file) and with host-pushed and text input mixed."""
+    from meryl_amd import capi
+    bases = oracle_lib.synth_reads(17, 300_000, 0, 60_000, 150, 5000, 100)          # 9 Mbp
+    d = torch_cuda.from_numpy(bases).cuda()
+    cfg = capi.configure(k, bases.size, 4 << 30, homopoly_compress=compress)
+    with ops.Session(cfg) as s:
+        s.push_bases_device(d)
+        s.count()
+        want = s.result_wide()
+        want_info = s.info()
+    raw = bases.tobytes()
+    # 1. host pushes in 1 MB pieces that do not end at sequence boundaries
+    with ops.Session(cfg) as s:
+        s.set_batch_bases(2_000_000)
+        for i in range(0, len(raw), 1_000_003):
+            s.push_bases(raw[i:i + 1_000_003], end_of_sequence=False)
+        s.count()
+        got = s.result_wide()
+        info = s.info()
+        p = s.profile()
+        kd, cd = s.result_device()
+        s.count()                                                  # a second count keeps the result (nothing new was pushed)
+        assert s.info().n_distinct == info.n_distinct
+    assert p.n_batches >= 4 and p.merge_ms > 0
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    assert info.n_instances == want_info.n_instances and list(info.file_instances) == list(want_info.file_instances)
+    assert kd.shape[0] == info.n_distinct and int(cd.to(torch_cuda.int64).sum().item()) == info.n_instances
+    # 2. the same reads as FASTQ text: batches are cut inside the file
+    reads = [r for r in raw.decode().split(".") if r]
+    fq = "".join("@%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads))
+    with ops.Session(cfg) as s:
+        s.set_batch_bases(2_500_000)
+        s.push_text(fq, "fastq", 3_000_017)
+        s.count()
+        got = s.result_wide()
+        assert s.profile().n_batches >= 3
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    # 3. mixed: half pushed from the host, half as text, then more host bases; a refused file in the middle
+    half = len(reads) // 2
+    fq2 = "".join("@%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads[half:half + half // 2]))
+    bad = "@x\nACGT\nACGT\n+\nIIIIIIII\n"
+    with ops.Session(cfg) as s:
+        s.set_batch_bases(1_500_000)
+        s.push_bases(".".join(reads[:half]) + ".", end_of_sequence=False)
+        s.push_text(fq2, "fastq", 1 << 20)
+        with pytest.raises(capi.MgcError) as e:
+            s.push_text(bad, "fastq")
+        assert e.value.code == capi.EFORMAT
+        for r in reads[half + half // 2:]:
+            s.push_bases(r, end_of_sequence=True)
+        s.count()
+        got = s.result_wide()
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("k", [21, 40])
 def test_heavily_repeated_kmers_take_the_fallback(ops, oracle_lib, torch_cuda, k):
     # one k-mer far above the LDS capacity (poly-A, a tandem repeat) next to ordinary reads: the file
