@@ -24,6 +24,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "meryl_gpu_count.h"   /* MGC_MERGE_* */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -162,6 +164,13 @@ const char *mgc_db_stream_error(const mgc_db_stream *d);      /* d may be NULL: 
  * file-writer threads).  prof may be NULL. */
 int mgc_write_database(struct mgc_session *s, const char *path, int host_threads);
 int mgc_write_database_profiled(struct mgc_session *s, const char *path, int host_threads, mgc_db_write_profile *prof);
+
+/* `union-sum` and friends over whole databases (op = MGC_MERGE_* of include/meryl_gpu_count.h): the reference streams the
+ * 64 file slices of its inputs through merylOperation::nextMer (src/meryl/merylOp-nextMer.C:418-683, slices
+ * src/meryl/meryl.C:250-263); here every slice is decoded by host threads, merged two inputs at a time on the device,
+ * encoded on the device and written to `output` (geometry of the first input).  All inputs must hold the same k.
+ * Text of a failure: mgc_db_stream_error(NULL). */
+int mgc_db_merge(const char *const *inputs, uint32_t n_inputs, int op, const char *output, int device, int host_threads);
 
 #ifdef __cplusplus
 }

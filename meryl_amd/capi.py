@@ -32,7 +32,7 @@ SYMBOLS = (
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_read_file_ex",
     "mdb_reader_file_index", "mdb_reader_block_header", "mdb_reader_read_block_raw", "mdb_reader_close",
     "mdb_free", "mgc_write_database", "mgc_write_database_profiled",
-    "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error",
+    "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_merge",
     # include/meryl_seq.h
     "msr_open", "msr_read_text", "msr_close", "msr_last_error", "msr_load_bases", "msr_load_stream", "msr_format", "msr_is_compressed", "msr_guess_number_of_kmers",
 )

@@ -53,13 +53,19 @@ bool has_compressed_suffix(const std::string &n) {
   return false;
 }
 
-enum OpKind { OP_NONE, OP_COUNT, OP_COUNT_FORWARD, OP_COUNT_REVERSE, OP_PRINT, OP_DUMPINDEX, OP_HISTOGRAM, OP_DUMPFILE };
+enum OpKind { OP_NONE, OP_COUNT, OP_COUNT_FORWARD, OP_COUNT_REVERSE, OP_PRINT, OP_DUMPINDEX, OP_HISTOGRAM, OP_DUMPFILE, OP_MERGE };
+
+struct InputRef { std::string path; int child = -1; };      // a database on the command line, or the output of a child operation
 
 struct Operation {
   OpKind                   kind = OP_NONE;
   std::vector<std::string> seq_inputs;      // sequence files (count ops)
   std::vector<bool>        seq_compress;    // `compress` is sticky per input (merylCommandBuilder.C:237-240,546)
-  std::vector<std::string> db_inputs;       // databases (print / dumpIndex)
+  std::vector<InputRef>    inputs;          // databases and child operations, in command-line order
+  std::vector<std::string> db_inputs;       // ... resolved to database paths once the children have run
+  std::string              word;            // the operation as typed
+  int                      merge_op = -1;   // MGC_MERGE_* (OP_MERGE)
+  int                      parent = -1;
   std::string              output;
   uint64_t                 exp_num_kmers = 0;   // n=
   std::string              count_suffix;        // count-suffix=
@@ -88,11 +94,13 @@ void usage(const char *prog) {
           "       %s print <database.meryl>\n"
           "       %s dumpIndex <database.meryl>\n"
           "       %s dumpFile <database.meryl>/0x######\n"
+          "       %s union-sum|union-min|union-max|intersect-sum|intersect-min|intersect-max <db | [operation]> ... output <db>\n"
           "\n"
           "  MI355X-native implementation of the `count` path of marbl/meryl.  Words are processed left to\n"
           "  right; options apply to the operations that follow.  A leading '[' and trailing ']' group the\n"
-          "  words of one operation.  Other meryl operations are not part of this build.\n",
-          prog, prog, prog, prog);
+          "  words of one operation; an operation inside another one's brackets is its input.  Other meryl operations are\n"
+          "  not part of this build.\n",
+          prog, prog, prog, prog, prog);
 }
 
 [[noreturn]] void die(const char *fmt, const char *a = "") {
@@ -201,6 +209,8 @@ int run_count(const Globals &g, const Operation &op) {
   mgc_session *s = mgc_open(&cfg, -1);
   if (!s) die("ERROR: %s", mgc_last_error(nullptr));
 
+  if (getenv("MERYL_BATCH_BASES") && *getenv("MERYL_BATCH_BASES"))                                    // tests: force out-of-core batches
+    mgc_set_batch_bases(s, strtoull(getenv("MERYL_BATCH_BASES"), nullptr, 10));
   const uint64_t buf_max = 2 * 1024 * 1024;                                                            // merylOp-countThreads.C:413
   std::vector<char> buf(buf_max);
   uint64_t total_bases = 0;
@@ -285,7 +295,6 @@ int run_count(const Globals &g, const Operation &op) {
     exit(1);
   }
   const auto t_written = std::chrono::steady_clock::now();
-  mgc_close(s);
   if (g.verbosity > 2) {                                                                               // -V: where the wall clock went
     auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double>(b - a).count();
@@ -295,6 +304,13 @@ int run_count(const Globals &g, const Operation &op) {
             sec(t_start, t_loaded), sec(t_loaded, t_counted), sec(t_counted, t_written), wprof.encode_ms / 1e3,
             wprof.copy_write_s, wprof.data_bytes);
   }
+  if (g.verbosity > 2) {
+    mgc_profile cp;
+    if (mgc_get_profile(s, &cp) == MGC_OK && cp.n_batches > 1)
+      fprintf(stderr, "        counted in %u batches (memory-full spills, merylOp-countThreads.C:323-379), merged on the device in %.1f ms\n",
+              cp.n_batches, cp.merge_ms);
+  }
+  mgc_close(s);
   if (g.verbosity > 0) {
     fprintf(stderr, "\nFinished counting.\n");                                                         // :473
     if (g.verbosity > 2)
@@ -420,19 +436,47 @@ int run_dump_index(const Operation &op) {
   return 0;
 }
 
+// `union-sum a.meryl b.meryl [count ... output c.meryl] output u.meryl` and the five related operations
+// (merylOp-nextMer.C:560-612): the inputs -- databases named on the command line, and the outputs of child operations,
+// which ran first (meryl.C:211-227 turns a finished count into a pass-through over its new database) -- are merged on
+// the device, file slice by file slice (mgc_db_merge).
+int run_merge(const Globals &g, const std::vector<Operation> &ops, const Operation &op) {
+  if (op.output.empty()) die("ERROR: operation '%s' needs an 'output <database>' in this build.", op.word.c_str());
+  std::vector<std::string> inputs;
+  for (const InputRef &in : op.inputs) inputs.push_back(in.child >= 0 ? ops[in.child].output : in.path);
+  if (inputs.empty()) die("ERROR: operation '%s' has no inputs.", op.word.c_str());
+  for (const std::string &n : inputs) if (!dir_has_index(n)) die("ERROR: input '%s' is not a meryl database.", n.c_str());
+  std::vector<const char *> names;
+  for (const std::string &n : inputs) names.push_back(n.c_str());
+  if (g.verbosity > 0) {
+    fprintf(stderr, "\nPROCESSING %s of %zu database%s into '%s'.\n", op.word.c_str(), inputs.size(), inputs.size() == 1 ? "" : "s", op.output.c_str());
+    for (const std::string &n : inputs) fprintf(stderr, "  %15s: %s\n", "database", n.c_str());
+  }
+  if (mgc_db_merge(names.data(), (uint32_t)names.size(), op.merge_op, op.output.c_str(), -1, (int)g.threads) != MGC_OK)
+    die("ERROR: %s", mgc_db_stream_error(nullptr));
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
   Globals g;
   std::vector<Operation> ops;
-  int  open_op = -1;                 // index of the operation words currently attach to
+  std::vector<int> stack;            // merylCommandBuilder's _opStack: words attach to the operation on top
   bool expect_output_name = false;
 
   if (argc < 2) { usage(argv[0]); return 1; }
 
+  auto top = [&]() -> int { return stack.empty() ? -1 : stack.back(); };
+  auto is_counting = [&](int i) { return i >= 0 && ops[i].kind >= OP_COUNT && ops[i].kind <= OP_COUNT_REVERSE; };
+  auto ensure_top = [&]() {                                                   // initialize(), :163-174: an empty root operation
+    if (stack.empty()) { ops.emplace_back(); stack.push_back((int)ops.size() - 1); }
+  };
+
   for (int a = 1; a < argc; a++) {
     std::string w = argv[a];
-    // one leading '[' is ignored, trailing ']'s close operations (merylCommandBuilder.C:133-153)
+    // one leading '[' is ignored, trailing ']'s pop operations off the stack once the word is processed
+    // (merylCommandBuilder.C:86-93,129-157)
     if (!w.empty() && w[0] == '[') w.erase(0, 1);
     int closing = 0;
     while (!w.empty() && w.back() == ']') { w.pop_back(); closing++; }
@@ -441,11 +485,14 @@ int main(int argc, char **argv) {
       const size_t eq = w.find('=');
       const std::string key = (eq == std::string::npos) ? w : w.substr(0, eq);
       const std::string val = (eq == std::string::npos) ? "" : w.substr(eq + 1);
+      const int merge_code = (w == "union-sum") ? MGC_MERGE_UNION_SUM : (w == "union-min") ? MGC_MERGE_UNION_MIN :
+                             (w == "union-max") ? MGC_MERGE_UNION_MAX : (w == "intersect-sum") ? MGC_MERGE_INTERSECT_SUM :
+                             (w == "intersect-min") ? MGC_MERGE_INTERSECT_MIN : (w == "intersect-max") ? MGC_MERGE_INTERSECT_MAX : -1;
 
       if (expect_output_name) {                                             // `output <db>`, :440-461
-        if (open_op < 0) die("ERROR: 'output' without an operation.");
-        if (!ops[open_op].output.empty()) die("ERROR: operation already has an output ('%s').", ops[open_op].output.c_str());   // merylOp.C:256-257
-        ops[open_op].output = w;
+        if (top() < 0 || ops[top()].kind == OP_NONE) die("ERROR: 'output' without an operation.");
+        if (!ops[top()].output.empty()) die("ERROR: operation already has an output ('%s').", ops[top()].output.c_str());   // merylOp.C:256-257
+        ops[top()].output = w;
         expect_output_name = false;
       }
       // ---- options, merylCommandBuilder.C:187-326 ----
@@ -459,10 +506,9 @@ int main(int argc, char **argv) {
         if (g.label_size > 64) die("ERROR: label size of more than 64 bits.");
       }
       else if (key == "label" && eq != std::string::npos) {                  // label=#<n>: the count's constant label
-        if (open_op < 0 || ops[open_op].kind < OP_COUNT || ops[open_op].kind > OP_COUNT_REVERSE)
-          die("ERROR: option '%s' needs a counting operation before it.", w.c_str());
+        if (!is_counting(top())) die("ERROR: option '%s' needs a counting operation before it.", w.c_str());
         if (val.empty() || val[0] != '#') die("ERROR: a count takes a constant label, label=#<integer>, not '%s'.", w.c_str());
-        ops[open_op].label = strtoull(val.c_str() + 1, nullptr, 0);
+        ops[top()].label = strtoull(val.c_str() + 1, nullptr, 0);
       }
       else if (key == "k" && eq != std::string::npos) {
         const uint32_t k = (uint32_t)strtoul(val.c_str(), nullptr, 10);
@@ -470,51 +516,67 @@ int main(int argc, char **argv) {
         if (g.k != 0 && g.k != k) die("ERROR: kmer size already set; cannot change it to '%s'.", val.c_str());   // :254-262
         g.k = k;
       }
-      else if (key == "n" && eq != std::string::npos) {                     // :265-268
-        if (open_op < 0) { ops.emplace_back(); open_op = (int)ops.size() - 1; }
-        ops[open_op].exp_num_kmers = strtoull(val.c_str(), nullptr, 10);
+      else if (key == "n" && eq != std::string::npos) {                     // :265-268: the operation on top
+        ensure_top();
+        ops[top()].exp_num_kmers = strtoull(val.c_str(), nullptr, 10);
       }
       else if (key == "memory" && eq != std::string::npos)  { g.memory_gb = strtod(val.c_str(), nullptr); }       // :299-302
       else if (key == "threads" && eq != std::string::npos) { g.threads = (uint32_t)strtoul(val.c_str(), nullptr, 10); if (!g.threads) g.threads = 1; }   // :306-310
       else if (w == "compress")              { g.compress = true; }                                               // :237-240
-      else if (key == "count-suffix") {                                                                            // :271-272: the operation on top
-        if (open_op < 0 || ops[open_op].kind < OP_COUNT || ops[open_op].kind > OP_COUNT_REVERSE)
-          die("ERROR: option '%s' needs a counting operation before it.", w.c_str());
-        ops[open_op].count_suffix = val;
+      else if (key == "count-suffix") {                                                                            // :271-272
+        if (!is_counting(top())) die("ERROR: option '%s' needs a counting operation before it.", w.c_str());
+        ops[top()].count_suffix = val;
       }
       else if (key == "segment") { die("ERROR: option '%s' (Canu sequence stores) is not supported in this build.", w.c_str()); }
-      // ---- operations, :346-385 ----
-      else if (open_op >= 0 && ops[open_op].kind == OP_DUMPFILE && ops[open_op].db_inputs.empty()) {
-        ops[open_op].db_inputs.push_back(w);                                 // <database>/0x######
+      else if (top() >= 0 && ops[top()].kind == OP_DUMPFILE && ops[top()].inputs.empty()) {
+        InputRef in; in.path = w;
+        ops[top()].inputs.push_back(in);                                     // <database>/0x######
       }
+      // ---- operations, :346-439 ----
       else if (w == "count" || w == "count-forward" || w == "count-reverse" || w == "print" || w == "dumpIndex" || w == "histogram" ||
-               w == "dumpFile") {
+               w == "dumpFile" || merge_code >= 0) {
         const OpKind kind = (w == "count") ? OP_COUNT : (w == "count-forward") ? OP_COUNT_FORWARD :
                             (w == "count-reverse") ? OP_COUNT_REVERSE : (w == "print") ? OP_PRINT :
-                            (w == "histogram") ? OP_HISTOGRAM : (w == "dumpFile") ? OP_DUMPFILE : OP_DUMPINDEX;
-        if (open_op >= 0 && ops[open_op].kind == OP_NONE) ops[open_op].kind = kind;    // `n=` came first
-        else { ops.emplace_back(); open_op = (int)ops.size() - 1; ops[open_op].kind = kind; }
+                            (w == "histogram") ? OP_HISTOGRAM : (w == "dumpFile") ? OP_DUMPFILE :
+                            (w == "dumpIndex") ? OP_DUMPINDEX : OP_MERGE;
+        ensure_top();
+        if (is_counting(top())) { stack.pop_back(); ensure_top(); }         // :391-407: a counting operation takes no operation as input
+        if (ops[top()].kind != OP_NONE) {                                    // :412-421: a new operation, input of the one on top
+          const int parent = top();
+          ops.emplace_back();
+          const int me = (int)ops.size() - 1;
+          if (ops[parent].kind == OP_DUMPINDEX || ops[parent].kind == OP_DUMPFILE)
+            die("ERROR: operation '%s' cannot be the input of a debug operation.", w.c_str());
+          InputRef in; in.child = me;
+          ops[parent].inputs.push_back(in);
+          ops[me].parent = parent;
+          stack.push_back(me);
+        }
+        ops[top()].kind = kind;                                              // :422-431 (or it replaces the empty operation on top)
+        ops[top()].word = w;
+        ops[top()].merge_op = merge_code;
       }
       else if (w == "output")                { expect_output_name = true; }
-      else if (w == "union" || w == "union-min" || w == "union-max" || w == "union-sum" || w == "intersect" ||
-               w == "intersect-min" || w == "intersect-max" || w == "intersect-sum" || w == "subtract" ||
+      else if (w == "union" || w == "intersect" || w == "subtract" ||
                w == "difference" || w == "symmetric-difference" || w == "statistics" ||
-               w == "less-than" || w == "greater-than" || w == "equal-to" || w == "at-least" || w == "at-most" ||
-               w == "increase" || w == "decrease" || w == "multiply" || w == "divide" || w == "modulo" ||
-               w == "distinct" || w == "word-frequency" || w == "threshold" || w == "printACGT") {
-        die("ERROR: operation '%s' is not part of this build (count path only).", w.c_str());
+               w == "less-than" || w == "greater-than" || w == "equal-to" || w == "not-equal-to" || w == "at-least" || w == "at-most" ||
+               w == "increase" || w == "decrease" || w == "multiply" || w == "divide" || w == "divide-round" || w == "modulo" ||
+               w == "distinct" || w == "word-frequency" || w == "threshold" || w == "printACGT" || w == "compare" ||
+               w == "noise" || w == "ploidy") {
+        die("ERROR: operation '%s' is not part of this build (count path, union-sum and its five relatives only).", w.c_str());
       }
       // ---- inputs ----
       else if (dir_has_index(w)) {                                           // :159,506-514
-        if (open_op < 0 || (ops[open_op].kind != OP_PRINT && ops[open_op].kind != OP_DUMPINDEX && ops[open_op].kind != OP_HISTOGRAM))
-          die("ERROR: database input '%s' needs a print, histogram or dumpIndex operation in this build.", w.c_str());
-        ops[open_op].db_inputs.push_back(w);
+        const int t = top();
+        if (t < 0 || (ops[t].kind != OP_PRINT && ops[t].kind != OP_DUMPINDEX && ops[t].kind != OP_HISTOGRAM && ops[t].kind != OP_MERGE))
+          die("ERROR: database input '%s' needs a print, histogram, dumpIndex or union/intersect operation before it.", w.c_str());
+        InputRef in; in.path = w;
+        ops[t].inputs.push_back(in);
       }
       else if (file_exists(w) || w == "-") {                                 // :537-549: only counting ops take sequence
-        if (open_op < 0 || ops[open_op].kind < OP_COUNT || ops[open_op].kind > OP_COUNT_REVERSE)
-          die("ERROR: sequence file '%s' supplied to a non-counting operation.", w.c_str());
-        ops[open_op].seq_inputs.push_back(w);
-        ops[open_op].seq_compress.push_back(g.compress);
+        if (!is_counting(top())) die("ERROR: sequence file '%s' supplied to a non-counting operation.", w.c_str());
+        ops[top()].seq_inputs.push_back(w);
+        ops[top()].seq_compress.push_back(g.compress);
       }
       else {                                                                  // meryl.C:84-86
         fprintf(stderr, "\nCan't interpret '%s': not a meryl command, option, or recognized input file.\n\n", argv[a]);
@@ -522,13 +584,13 @@ int main(int argc, char **argv) {
         return 1;
       }
     }
-    if (closing > 0) open_op = -1;
+    for (; closing > 0 && !stack.empty(); closing--) stack.pop_back();       // terminateOperation(), :86-93
   }
   if (expect_output_name) die("ERROR: 'output' needs a database name.");
 
   if (g.verbosity > 0) {
     size_t n_trees = 0;
-    for (const Operation &op : ops) if (op.kind != OP_NONE) n_trees++;
+    for (const Operation &op : ops) if (op.kind != OP_NONE && op.parent < 0) n_trees++;
     fprintf(stderr, "\nFound %zu command tree%s.\n", n_trees, (n_trees == 1) ? "" : "s");              // meryl.C:181
   }
 
@@ -539,7 +601,20 @@ int main(int argc, char **argv) {
       rc |= run_count(g, op);
     }
   }
-  for (const Operation &op : ops) {
+  if (g.only_config) {                                                        // -C: configure, report, stop (merylOp-countThreads.C:392-393)
+    if (g.verbosity > 0) fprintf(stderr, "\nCleaning up.\n\nBye.\n");
+    return rc;
+  }
+  // the other operations bottom-up: children were appended after their parents, so reverse list order runs a child
+  // before the operation that reads its output
+  for (size_t i = ops.size(); i-- > 0;)
+    if (ops[i].kind == OP_MERGE) rc |= run_merge(g, ops, ops[i]);
+  for (Operation &op : ops) {
+    if (op.kind != OP_PRINT && op.kind != OP_DUMPINDEX && op.kind != OP_HISTOGRAM && op.kind != OP_DUMPFILE) continue;
+    for (const InputRef &in : op.inputs) {
+      if (in.child >= 0 && ops[in.child].output.empty()) die("ERROR: the input operation of '%s' needs an output in this build.", op.word.c_str());
+      op.db_inputs.push_back(in.child >= 0 ? ops[in.child].output : in.path);
+    }
     if (op.kind == OP_PRINT)     rc |= run_print(op);
     if (op.kind == OP_DUMPINDEX) rc |= run_dump_index(op);
     if (op.kind == OP_HISTOGRAM) rc |= run_histogram(op);

@@ -561,3 +561,122 @@ extern "C" int mgc_finish(mgc_session *s, mgc_block_cb cb, void *ctx, int host_t
 extern "C" int mgc_finish_labelled(mgc_session *s, mgc_block_cb2 cb, void *ctx, int host_threads) {
   return finish_impl(s, nullptr, cb, ctx, host_threads);
 }
+
+// ================================================================================================
+//  union-sum & friends over whole databases
+// ================================================================================================
+// The reference streams the 64 file slices of its inputs through merylOperation::nextMer -- smallest k-mer over the
+// inputs, values of the inputs that hold it combined (src/meryl/merylOp-nextMer.C:418-683; one slice per thread,
+// src/meryl/meryl.C:250-263).  Here a slice is decoded by host threads (one per input), merged two inputs at a time on the
+// device (mgc_merge.hip), encoded on the device and written by the database stream -- the same merge that folds the
+// batches of an out-of-core count.
+extern "C" int mgc_db_merge(const char *const *inputs, uint32_t n_inputs, int op, const char *output, int device, int host_threads) {
+  if (!inputs || n_inputs == 0 || !output || op < MGC_MERGE_UNION_SUM || op > MGC_MERGE_INTERSECT_MAX) {
+    set_err(nullptr, "mgc_db_merge: bad arguments");
+    return MGC_EINVAL;
+  }
+  std::vector<mdb_reader *> rd(n_inputs, nullptr);
+  auto close_all = [&]() { for (mdb_reader *r : rd) if (r) mdb_reader_close(r); };
+  mdb_info first;
+  memset(&first, 0, sizeof(first));
+  for (uint32_t i = 0; i < n_inputs; i++) {
+    rd[i] = inputs[i] ? mdb_reader_open(inputs[i]) : nullptr;
+    if (!rd[i]) { set_err(nullptr, "mgc_db_merge: %s", mdb_last_error()); close_all(); return MGC_EINVAL; }
+    mdb_info inf;
+    mdb_reader_info(rd[i], &inf);
+    if (i == 0) first = inf;
+    else if (inf.k != first.k) {
+      set_err(nullptr, "mgc_db_merge: '%s' holds %u-mers, '%s' %u-mers", inputs[i], inf.k, inputs[0], first.k);   // merylOp.C: kmer size mismatch
+      close_all();
+      return MGC_EINVAL;
+    }
+  }
+  const uint32_t k = first.k, w_prefix = first.prefix_size, kw = k > 32 ? 2u : 1u;
+  if (device < 0) (void)hipGetDevice(&device);
+  mgc_db_stream *d = mgc_db_stream_open(output, k, w_prefix, 0, 0, 0, 1, host_threads, device);
+  if (!d) { close_all(); return MGC_EINVAL; }
+  int rc = MGC_OK;
+  std::string msg;
+  auto hip_fail = [&](hipError_t e, const char *what) {
+    rc = (e == hipErrorOutOfMemory) ? MGC_ENOMEM : MGC_EHIP;
+    msg = std::string("mgc_db_merge: ") + what + ": " + hipGetErrorString(e);
+  };
+#define MG_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { hip_fail(e__, #expr); goto done; } } while (0)
+  {
+    hipStream_t st = nullptr;
+    std::vector<DBuf> in_k(n_inputs), in_c(n_inputs);
+    DBuf acc_k[2], acc_c[2], ws;
+    const uint64_t blocks_per_file = 1ull << (w_prefix - MGC_NUM_FILES_BITS);
+    MG_TRY(hipSetDevice(device));
+    MG_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (uint32_t ff = 0; ff < MGC_NUM_FILES && rc == MGC_OK; ff++) {
+      // decode the slice of every input (host threads), interleaving {lo, hi} for 16-byte keys
+      std::vector<std::vector<uint64_t>> hk(n_inputs);
+      std::vector<uint32_t *> hc(n_inputs, nullptr);
+      std::vector<uint64_t> hn(n_inputs, 0);
+      std::vector<int> rrc(n_inputs, MGC_OK);
+      std::vector<std::string> rmsg(n_inputs);
+      {
+        std::vector<std::thread> th;
+        for (uint32_t i = 0; i < n_inputs; i++)
+          th.emplace_back([&, i]() {
+            uint64_t *lo = nullptr, *hi = nullptr;
+            rrc[i] = mdb_reader_read_file_ex(rd[i], ff, &lo, &hi, &hc[i], nullptr, &hn[i]);
+            if (rrc[i] != MGC_OK) { rmsg[i] = mdb_last_error(); return; }
+            hk[i].resize((size_t)kw * hn[i]);
+            if (kw == 1) { if (hn[i]) memcpy(hk[i].data(), lo, 8 * hn[i]); }
+            else for (uint64_t j = 0; j < hn[i]; j++) { hk[i][2 * j] = lo[j]; hk[i][2 * j + 1] = hi[j]; }
+            mdb_free(lo); mdb_free(hi);
+          });
+        for (auto &t : th) t.join();
+      }
+      for (uint32_t i = 0; i < n_inputs; i++)
+        if (rrc[i] != MGC_OK && rc == MGC_OK) { rc = rrc[i]; msg = "mgc_db_merge: " + rmsg[i]; }
+      if (rc == MGC_OK) {
+        for (uint32_t i = 0; i < n_inputs; i++) {
+          MG_TRY(in_k[i].ensure(8 * (size_t)kw * hn[i]));
+          MG_TRY(in_c[i].ensure(4 * hn[i]));
+          if (hn[i]) {
+            MG_TRY(hipMemcpyAsync(in_k[i].p, hk[i].data(), 8 * (size_t)kw * hn[i], hipMemcpyHostToDevice, st));
+            MG_TRY(hipMemcpyAsync(in_c[i].p, hc[i], 4 * hn[i], hipMemcpyHostToDevice, st));
+          }
+        }
+        MG_TRY(hipStreamSynchronize(st));
+      }
+      for (uint32_t i = 0; i < n_inputs; i++) mdb_free(hc[i]);
+      if (rc != MGC_OK) break;
+      // fold the inputs pairwise: ((in0 op in1) op in2) ...
+      const void *cur_k = in_k[0].p;
+      const uint32_t *cur_c = in_c[0].as<uint32_t>();
+      uint64_t cur_n = hn[0];
+      for (uint32_t i = 1; i < n_inputs; i++) {
+        const int t = (int)(i & 1u);
+        MG_TRY(ws.ensure(mgc::merge_workspace_bytes(cur_n, hn[i])));
+        uint64_t n_new = 0;
+        MG_TRY(mgc::launch_merge_count(cur_k, cur_n, in_k[i].p, hn[i], kw, op, ws.p, st));
+        MG_TRY(mgc::merge_read_total(ws.p, &n_new, st));
+        MG_TRY(acc_k[t].ensure(8 * (size_t)kw * n_new));
+        MG_TRY(acc_c[t].ensure(4 * n_new));
+        MG_TRY(mgc::launch_merge_emit(cur_k, cur_c, cur_n, in_k[i].p, in_c[i].as<uint32_t>(), hn[i], kw, op, ws.p, acc_k[t].p,
+                                      acc_c[t].as<uint32_t>(), st));
+        MG_TRY(hipStreamSynchronize(st));
+        cur_k = acc_k[t].p; cur_c = acc_c[t].as<uint32_t>(); cur_n = n_new;
+      }
+      rc = mgc_db_stream_write(d, cur_k, cur_c, cur_n, (uint64_t)ff * blocks_per_file, ((uint64_t)ff + 1) * blocks_per_file);
+      if (rc == MGC_OK) rc = mgc_db_stream_sync(d);         // the buffers are reused for the next slice
+      if (rc != MGC_OK) msg = std::string("mgc_db_merge: ") + mgc_db_stream_error(d);
+    }
+  done:
+    for (auto &b : in_k) b.release();
+    for (auto &b : in_c) b.release();
+    for (int t = 0; t < 2; t++) { acc_k[t].release(); acc_c[t].release(); }
+    ws.release();
+    if (st) (void)hipStreamDestroy(st);
+  }
+#undef MG_TRY
+  close_all();
+  const int rc2 = mgc_db_stream_close(d, nullptr);
+  if (rc == MGC_OK && rc2 != MGC_OK) { rc = rc2; msg = mgc_db_stream_error(nullptr); }
+  if (rc != MGC_OK) set_err(nullptr, "%s", msg.c_str());
+  return rc;
+}

@@ -19,8 +19,8 @@ def meryl(native_lib):
     return path
 
 
-def run(meryl, *args, check=True):
-    p = subprocess.run([meryl] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+def run(meryl, *args, check=True, env=None):
+    p = subprocess.run([meryl] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
     if check:
         assert p.returncode == 0, p.stderr[-2000:]
     return p
@@ -74,8 +74,14 @@ def test_grammar_errors(meryl, tmp_path):
     assert p.returncode == 1 and "already set" in p.stderr                              # merylCommandBuilder.C:254-262
     p = run(meryl, "k=21", "count", fa, "output", tmp_path / "a", "output", tmp_path / "b", check=False)
     assert p.returncode == 1 and "already has an output" in p.stderr                    # merylOp.C:256-257
-    p = run(meryl, "union-sum", check=False)
+    p = run(meryl, "union", check=False)
     assert p.returncode == 1 and "not part of this build" in p.stderr
+    p = run(meryl, "union-sum", "output", tmp_path / "u", check=False)
+    assert p.returncode == 1 and "has no inputs" in p.stderr
+    p = run(meryl, "union-sum", tmp_path, check=False)                                  # a directory that is no database
+    assert p.returncode == 1 and "Can't interpret" in p.stderr
+    p = run(meryl, "k=21", "count", "label=7", fa, "output", tmp_path / "db", check=False)
+    assert p.returncode == 1 and "label=#<integer>" in p.stderr                         # meryl2: label=#<n>
 
 
 @pytest.mark.gpu
@@ -239,3 +245,101 @@ def test_cli_count_suffix_database(meryl, oracle_lib, tmp_path):
     r.close()
     lines = run(meryl, "-Q", "print", out).stdout.splitlines()
     assert len(lines) == int(keep.sum()) and all(l.split("\t")[0].endswith("GA") for l in lines[:200])
+
+
+@pytest.mark.gpu
+def test_cli_union_sum_tree_and_relatives(meryl, oracle_lib, tmp_path):
+    """`union-sum [count a output A] [count b output B] C.meryl output U`: the counts run first and become inputs
+    (meryl.C:211-227), the merge is the reference's 64-slice streaming merge (merylOp-nextMer.C:418-683) done on the
+    device; union-sum of the parts of a read set == one count of all of it; min/max/intersect against numpy."""
+    from meryl_amd import db
+    k = 21
+    sets = [oracle_lib.synth_reads(21, 80_000, i * 4000, 4000).tobytes() for i in range(3)]
+    fas = []
+    for i, b in enumerate(sets):
+        fa = tmp_path / ("part%d.fa" % i)
+        fa.write_text("".join(">r%d\n%s\n" % (j, r) for j, r in enumerate(b.decode().split(".")) if r))
+        fas.append(fa)
+    c = tmp_path / "C.meryl"
+    run(meryl, "-Q", "k=%d" % k, "memory=2", "count", fas[2], "output", c)
+    u = tmp_path / "U.meryl"
+    run(meryl, "-Q", "k=%d" % k, "memory=2", "union-sum", "[count", fas[0], "output", str(tmp_path / "A.meryl") + "]",
+        "[count", fas[1], "output", str(tmp_path / "B.meryl") + "]", c, "output", u)
+    assert len(os.listdir(u)) == 129
+    _, wlo, wcn, _ = oracle_lib.count_brute(b"".join(sets), k)
+    r = db.Reader(str(u))
+    lo, hi, cn = r.read_all()
+    hv, ho = r.histogram()
+    r.close()
+    assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn)
+    vals, occ = np.unique(wcn, return_counts=True)
+    assert {int(a): int(b) for a, b in zip(hv, ho)} == {int(a): int(b) for a, b in zip(vals, occ)}
+    per = []
+    for name in ("A", "B", "C"):
+        r = db.Reader(str(tmp_path / (name + ".meryl")))
+        l, _, c_ = r.read_all()
+        r.close()
+        per.append(dict(zip((int(x) for x in l), (int(x) for x in c_))))
+    for word, setop, f in (("union-min", set.union, min), ("union-max", set.union, max), ("intersect-sum", set.intersection, sum),
+                           ("intersect-min", set.intersection, min), ("intersect-max", set.intersection, max)):
+        out = tmp_path / (word + ".meryl")
+        run(meryl, "-Q", word, tmp_path / "A.meryl", tmp_path / "B.meryl", tmp_path / "C.meryl", "output", out)
+        keys = sorted(setop(*[set(d) for d in per]))
+        want = [f([d[x] for d in per if x in d]) for x in keys]
+        r = db.Reader(str(out))
+        l, _, c_ = r.read_all()
+        r.close()
+        assert [int(x) for x in l] == keys and [int(x) for x in c_] == want, word
+    # print over a child operation
+    p = run(meryl, "-Q", "print", "[union-min", tmp_path / "A.meryl", tmp_path / "B.meryl", "output", str(tmp_path / "pm.meryl") + "]")
+    assert len(p.stdout.strip().split("\n")) == len(set(per[0]) | set(per[1]))
+    p = run(meryl, "union-sum", tmp_path / "A.meryl", u, "output", tmp_path / "bad.meryl", check=False)
+    assert p.returncode == 0                                                            # same k: fine
+    run(meryl, "-Q", "k=15", "memory=2", "count", fas[0], "output", tmp_path / "k15.meryl")
+    p = run(meryl, "union-sum", tmp_path / "A.meryl", tmp_path / "k15.meryl", "output", tmp_path / "bad2.meryl", check=False)
+    assert p.returncode == 1 and "15-mers" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_labels_and_dumpfile(meryl, oracle_lib, tmp_path):
+    """meryl2's `-l <bits>` + `label=#<n>` on a count: every k-mer carries the constant label; print shows it in binary;
+    dumpFile lists the blocks of a counted database."""
+    from meryl_amd import db
+    bases = oracle_lib.synth_reads(5, 30_000, 0, 2000).tobytes()
+    fa = tmp_path / "r.fa"
+    fa.write_text("".join(">r%d\n%s\n" % (j, r) for j, r in enumerate(bases.decode().split(".")) if r))
+    out = tmp_path / "lab.meryl"
+    run(meryl, "-Q", "-l", "6", "k=21", "memory=1", "count", "label=#37", fa, "output", out)
+    _, wlo, wcn, _ = oracle_lib.count_brute(bases, 21)
+    r = db.Reader(str(out))
+    assert r.info.label_size == 6
+    lo, hi, cn, lb = r.read_all(labels=True)
+    r.close()
+    assert np.array_equal(lo, wlo) and np.array_equal(cn, wcn) and np.all(lb == 37)
+    first = run(meryl, "-Q", "print", out).stdout.split("\n")[0].split("\t")
+    assert first[2] == "100101" and int(first[1]) == int(wcn[0])
+    d = run(meryl, "-Q", "dumpFile", str(out) + "/0x000000").stdout
+    assert "prefix    blkPos    nKmers" in d and "kmerIdx prefixDelta" in d
+    n_file0 = int(np.sum((wlo >> np.uint64(36)) == 0))
+    tail = d.split("-------- ----------- ----------- --")[1].split("\n")[1:]
+    assert sum(1 for l in tail if l.strip()) == n_file0
+
+
+@pytest.mark.gpu
+def test_cli_out_of_core_text_input(meryl, oracle_lib, tmp_path):
+    """A FASTQ larger than the batch size through the CLI's default (device parser) path: batches are cut inside the file,
+    merged on the device, same database as the single pass (the text path used to have no batching)."""
+    bases = oracle_lib.synth_reads(8, 200_000, 0, 40_000).tobytes()
+    reads = [r for r in bases.decode().split(".") if r]
+    fq = tmp_path / "r.fq"
+    fq.write_text("".join("@%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads)))
+    one = tmp_path / "one.meryl"
+    run(meryl, "-Q", "k=31", "memory=2", "count", fq, "output", one)
+    env = dict(os.environ, MERYL_BATCH_BASES="1500000")
+    many = tmp_path / "many.meryl"
+    p = run(meryl, "-V", "k=31", "memory=2", "count", fq, "output", many, env=env)
+    assert "batches" in p.stderr
+    names = sorted(os.listdir(one))
+    assert sorted(os.listdir(many)) == names
+    for n in names:
+        assert open(os.path.join(one, n), "rb").read() == open(os.path.join(many, n), "rb").read(), n
