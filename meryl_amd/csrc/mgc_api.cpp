@@ -403,6 +403,7 @@ extern "C" void mgc_close(mgc_session *s) {
     if (s->pin_ev[i]) (void)hipEventDestroy(s->pin_ev[i]);
   }
   if (s->st_in) (void)hipStreamDestroy(s->st_in);
+  for (hipEvent_t e : s->hist_ev) if (e) (void)hipEventDestroy(e);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
@@ -991,18 +992,49 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     HIP_TRY(s, hipMemsetAsync(d_maxsub, 0, sizeof(uint64_t) * 2 * nb, st));
 
     // ---- A. global LSB passes on the top bits only ----
-    tm.begin(MGC_STAGE_SORT);
+    // the finish only needs the file grouped by its top bits (MGC_GROUP=0: full stable passes)
+    static const bool use_group = !(getenv("MGC_GROUP") && getenv("MGC_GROUP")[0] == '0');
+    // The digit histograms of ALL files are taken ahead of the passes, on the second stream: that read of every key is
+    // pure streaming and runs beside the latency-bound grouping passes of the files before it (one 256-thread
+    // histogram workgroup fits next to the 1024-thread grouping workgroup on every CU) instead of in front of each
+    // file's passes (MGC_HIST_AHEAD=0: per file, on the session stream).
+    static const bool hist_ahead = !(getenv("MGC_HIST_AHEAD") && getenv("MGC_HIST_AHEAD")[0] == '0');
+    std::vector<mgc::SortPlan> fplan(nb);
+    std::vector<char> prepared(nb, 0);
+    const size_t hdr_bytes = mgc::sort_header_bytes();
+    unsigned char *d_hdrs = nullptr;
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0 || top_bits[b] == 0) continue;
-      mgc::SortPlan fp;
-      mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fp);
-      // the finish only needs the file grouped by its top bits (MGC_GROUP=0: full stable passes)
-      static const bool use_group = !(getenv("MGC_GROUP") && getenv("MGC_GROUP")[0] == '0');
-      if (use_group && fp.mode == 0) fp.mode = 3;
+      mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fplan[b]);
+      if (use_group && fplan[b].mode == 0) fplan[b].mode = 3;
+    }
+    tm.begin(MGC_STAGE_SORT);
+    if (hist_ahead && s->stream2) {
+      HIP_TRY(s, s->ensure(mgc_session::B_SORT_HDRS, hdr_bytes * nb));
+      d_hdrs = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_SORT_HDRS].p);
+      if (s->hist_ev.size() < nb) {
+        const size_t have = s->hist_ev.size();
+        s->hist_ev.resize(nb, nullptr);
+        for (size_t i = have; i < nb; i++) HIP_TRY(s, hipEventCreateWithFlags(&s->hist_ev[i], hipEventDisableTiming));
+      }
+      HIP_TRY(s, hipEventRecord(s->ev_fork, st));              // the keys are in place at this point of the session stream
+      HIP_TRY(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+      for (uint32_t b = 0; b < nb; b++) {
+        if (h_counts[b] == 0 || top_bits[b] == 0 || !mgc::sort_plan_groups(fplan[b], h_counts[b])) continue;
+        HIP_TRY(s, mgc::launch_group_prepare(X + kbytes * h_starts[b], h_counts[b], kw, fplan[b], d_hdrs + hdr_bytes * b, s->stream2));
+        HIP_TRY(s, hipEventRecord(s->hist_ev[b], s->stream2));
+        prepared[b] = 1;
+      }
+    }
+    for (uint32_t b = 0; b < nb; b++) {
+      if (h_counts[b] == 0 || top_bits[b] == 0) continue;
+      const mgc::SortPlan &fp = fplan[b];
       void *src = X + kbytes * h_starts[b];
       int in_alt = 0;
       hipEvent_t *pe = s->profiling ? &pass_ev[(size_t)b * ev_per_file] : nullptr;
-      HIP_TRY(s, mgc::launch_radix_sort(src, (void *)Y, h_counts[b], kw, fp, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe));
+      if (prepared[b]) HIP_TRY(s, hipStreamWaitEvent(st, s->hist_ev[b], 0));
+      HIP_TRY(s, mgc::launch_radix_sort(src, (void *)Y, h_counts[b], kw, fp, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe,
+                                        prepared[b] ? (void *)(d_hdrs + hdr_bytes * b) : nullptr));
       if (in_alt) HIP_TRY(s, hipMemcpyAsync(src, Y, kbytes * h_counts[b], hipMemcpyDeviceToDevice, st));
       file_passes[b] = fp.num_passes;
       sort_launch_groups++;

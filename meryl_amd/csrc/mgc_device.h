@@ -57,7 +57,12 @@ struct SortTiming {           // optional per-pass event timing
 // device uint32 the kernels set on a look-back timeout (checked by the caller).
 hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan,
                              void *d_ws, size_t ws_bytes, uint32_t *d_error, int *result_in_alt,
-                             hipStream_t st, hipEvent_t *pass_events /* 2 per pass or null */);
+                             hipStream_t st, hipEvent_t *pass_events /* 2 per pass or null */,
+                             void *d_prepared = nullptr /* header launch_group_prepare filled for these keys and this plan */);
+// grouping passes (plan.mode == 3): the digit histograms can be taken ahead of time, on another stream
+size_t     sort_header_bytes();
+bool       sort_plan_groups(const SortPlan &plan, uint64_t n);
+hipError_t launch_group_prepare(const void *d_keys, uint64_t n, uint32_t key_words, const SortPlan &plan, void *d_hdr, hipStream_t st);
 
 // ---- run-length count ------------------------------------------------------
 size_t     rle_workspace_bytes(uint64_t n);

@@ -992,14 +992,33 @@ static int device_cu_count() {
   return cus;
 }
 
+// digit histograms + exclusive digit bases of a file's grouping passes into `hdr` (tickets zeroed)
+template <typename K>
+static hipError_t group_prepare(const K *src, uint64_t n, const SortPlan &plan, SortHeader *hdr, hipStream_t st) {
+  MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
+  PassList pl;
+  pl.n = plan.num_passes;
+  for (uint32_t p = 0; p < plan.num_passes; p++) {
+    pl.shift[p] = plan.pass_shift[p];
+    pl.mask[p]  = (1u << plan.pass_bits[p]) - 1u;
+  }
+  launch_radix_hist<K>(src, (u64)n, pl, &hdr->ghist[0][0], st);
+  MGC_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(plan.num_passes), dim3(RS_MAX_RADIX), 0, st,
+                     &hdr->ghist[0][0], &hdr->gbase[0][0]);
+  return hipGetLastError();
+}
+
 template <typename K, int RB, int BLOCK, int KPT, int MATCH, int LBK>
 static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws,
-                             uint32_t *d_error, int *result_in_alt, hipStream_t st, hipEvent_t *pass_events) {
+                             uint32_t *d_error, int *result_in_alt, hipStream_t st, hipEvent_t *pass_events,
+                             void *d_prepared = nullptr) {
   constexpr int LBO = (LBK == 5) ? 2 : LBK;             // look-back flavour of the non-pipelined kernel
   using SM  = RadixSmem<K, RB, BLOCK, KPT, LBO>;
   using SM0 = RadixSmem<K, RB, BLOCK, KPT, 0>;
   constexpr int R = 1 << RB, TILE = BLOCK * KPT;
-  SortHeader *hdr = reinterpret_cast<SortHeader *>(d_ws);
+  // the grouping passes can take their digit histograms from a header prepared ahead of time (launch_group_prepare)
+  SortHeader *hdr = (d_prepared && plan.mode == 3) ? reinterpret_cast<SortHeader *>(d_prepared) : reinterpret_cast<SortHeader *>(d_ws);
   unsigned char *body = reinterpret_cast<unsigned char *>(d_ws) + ((sizeof(SortHeader) + 255) / 256) * 256;
   const uint64_t num_tiles = (n + TILE - 1) / TILE;
 
@@ -1079,18 +1098,7 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
     const size_t status_bytes = (size_t)max_tiles * (R / 2) * sizeof(u64);
     u64 *region_start = reinterpret_cast<u64 *>(body + ((status_bytes + 255) / 256) * 256);
     u32 *region_tiles = reinterpret_cast<u32 *>(region_start + RS_MAX_RADIX + 1);
-    MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
-    PassList pl;
-    pl.n = plan.num_passes;
-    for (uint32_t p = 0; p < plan.num_passes; p++) {
-      pl.shift[p] = plan.pass_shift[p];
-      pl.mask[p]  = (1u << plan.pass_bits[p]) - 1u;
-    }
-    launch_radix_hist<K>((const K *)src, (u64)n, pl, &hdr->ghist[0][0], st);
-    MGC_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(plan.num_passes), dim3(RS_MAX_RADIX), 0, st,
-                       &hdr->ghist[0][0], &hdr->gbase[0][0]);
-    MGC_CHECK(hipGetLastError());
+    if (!d_prepared) MGC_CHECK(group_prepare<K>((const K *)src, n, plan, hdr, st));
     const uint64_t resident = (uint64_t)device_cu_count() * GS::WG_PER_CU;
     for (uint32_t p = 0; p < plan.num_passes; p++) {
       if (p == 1) {
@@ -1145,28 +1153,43 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
   return hipSuccess;
 }
 
+size_t sort_header_bytes() { return ((sizeof(SortHeader) + 255) / 256) * 256; }
+
+// true when launch_radix_sort would run this plan as grouping passes (and can therefore use a prepared header)
+bool sort_plan_groups(const SortPlan &plan, uint64_t n) { return plan.mode == 3 && plan.num_passes <= 2 && n < (1ull << 30) && n > 0; }
+
+// The histogram half of a file's grouping passes, launched ahead of time (on another stream): reads every key once
+// (8/16 B per key) -- pure streaming, so it fills the HBM bandwidth the latency-bound grouping passes of the files
+// before it leave idle (one 256-thread workgroup of it fits beside the 1024-thread grouping workgroup on every CU).
+hipError_t launch_group_prepare(const void *d_keys, uint64_t n, uint32_t key_words, const SortPlan &plan, void *d_hdr, hipStream_t st) {
+  if (!sort_plan_groups(plan, n)) return hipErrorInvalidValue;
+  if (key_words == 2) return group_prepare<K128>(reinterpret_cast<const K128 *>(d_keys), n, plan, reinterpret_cast<SortHeader *>(d_hdr), st);
+  return group_prepare<u64>(reinterpret_cast<const u64 *>(d_keys), n, plan, reinterpret_cast<SortHeader *>(d_hdr), st);
+}
+
 hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan,
                              void *d_ws, size_t ws_bytes, uint32_t *d_error, int *result_in_alt,
-                             hipStream_t st, hipEvent_t *pass_events) {
+                             hipStream_t st, hipEvent_t *pass_events, void *d_prepared) {
   *result_in_alt = 0;
   if (n == 0 || plan.num_passes == 0) return hipSuccess;
   if (ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
   if (plan.mode == 3 && (plan.num_passes > 2 || n >= (1ull << 30))) {
     SortPlan stable = plan;                 // grouping is defined for one or two digits and 30-bit granule values
     stable.mode = 0;
-    return launch_radix_sort(d_keys, d_alt, n, key_words, stable, d_ws, ws_bytes, d_error, result_in_alt, st, pass_events);
+    return launch_radix_sort(d_keys, d_alt, n, key_words, stable, d_ws, ws_bytes, d_error, result_in_alt, st, pass_events, nullptr);
   }
+  if (!sort_plan_groups(plan, n)) d_prepared = nullptr;
 #define MGC_RUN(K_, RB_, BLOCK_, KPT_)                                                                       \
   do {                                                                                                       \
     if (n >= (1ull << 30))   /* packed look-back granules hold 30-bit values: use the wide ones */           \
-      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 3>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 3>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events, d_prepared); \
     if (plan.match == 0)                                                                                     \
-      return run_passes<K_, RB_, BLOCK_, KPT_, 0, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 0, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events, d_prepared); \
     if (plan.lookback == 2)                                                                                  \
-      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 2>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 2>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events, d_prepared); \
     if (plan.lookback == 5)                                                                                  \
-      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 5>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events); \
-    return run_passes<K_, RB_, BLOCK_, KPT_, 1, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);   \
+      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 5>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events, d_prepared); \
+    return run_passes<K_, RB_, BLOCK_, KPT_, 1, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events, d_prepared);   \
   } while (0)
   if (key_words == 2) {
     // 128-bit keys: 8 keys per thread keep the tile at 128 KiB of LDS (one workgroup per CU)
