@@ -165,6 +165,8 @@ def e2e_run(bases, reads, threads):
                "threads": threads, "where": shm, "fastq_generation_s": t_gen,
                "database_bytes": sum(os.path.getsize(os.path.join(dbp, n)) for n in os.listdir(dbp)),
                "command": "meryl -V k=%d memory=64 threads=%d n=10000000000 count reads.fq output out.meryl" % (K, threads)}
+        if os.environ.get("MGC_IO_TRACE"):
+            out["io_trace"] = [l for l in p.stderr.splitlines() if l.startswith("[io]")]
         m = re.search(r"TIMING(.*)", p.stderr)
         if m:
             for name, val in re.findall(r"([a-z+_]+)=([0-9.]+)", m.group(1)):

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -695,18 +696,25 @@ extern "C" int mgc_push_text_file(mgc_session *s, const char *path, int format, 
   };
   std::vector<std::thread> readers;
   for (int t = 0; t < reader_threads; t++) readers.emplace_back(reader);
+  const bool trace = getenv("MGC_IO_TRACE") != nullptr;
+  double t_wait = 0, t_submit = 0;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (uint64_t c = 0; c < nchunks && rc == MGC_OK; c++) {
     const int slot = (int)(c % R);
     size_t len = 0;
+    const double t0 = now();
     {
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&] { return abort_all || ready_chunk[slot] == c; });
       if (abort_all) break;
       len = ready_len[slot];
     }
+    const double t1 = now();
+    t_wait += t1 - t0;
     // text_submit first waits for the parse of chunk c-2 (same device buffer): after that the pinned slot of chunk c-2
     // has been read by its upload and goes back to the readers
     rc = text_submit(s, ring[slot], len);
+    t_submit += now() - t1;
     if (c >= 2) {
       std::lock_guard<std::mutex> g(mu);
       free_gen[(c - 2) % R]++;
@@ -720,6 +728,8 @@ extern "C" int mgc_push_text_file(mgc_session *s, const char *path, int format, 
   for (auto &t : readers) t.join();
   for (int i = 0; i < R; i++) if (ring[i]) (void)hipHostFree(ring[i]);
   close(fd);
+  if (trace) fprintf(stderr, "[io] text file %.2f GB in %llu chunks, %d readers: waiting for readers %.3f s, upload+parse submit (incl. waits for the device) %.3f s\n",
+                     size / 1e9, (unsigned long long)nchunks, reader_threads, t_wait, t_submit);
   if (read_failed) { set_err(&s->err, "mgc_push_text_file: reading '%s' failed: %s", path, strerror(errno)); rc = MGC_EINVAL; }
   const int rc_end = mgc_end_text(s);                       // closes the file in every case (rolls it back on MGC_EFORMAT)
   return rc != MGC_OK ? rc : rc_end;
@@ -997,8 +1007,10 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     // The digit histograms of ALL files are taken ahead of the passes, on the second stream: that read of every key is
     // pure streaming and runs beside the latency-bound grouping passes of the files before it (one 256-thread
     // histogram workgroup fits next to the 1024-thread grouping workgroup on every CU) instead of in front of each
-    // file's passes (MGC_HIST_AHEAD=0: per file, on the session stream).
-    static const bool hist_ahead = !(getenv("MGC_HIST_AHEAD") && getenv("MGC_HIST_AHEAD")[0] == '0');
+    // file's passes.  MEASURED (profiles/r02c: 10 Gbp, k=21): the extra streaming traffic slows the grouping passes more
+    // (0.585 -> 0.655 ms per launch) than the 16 ms it hides -- 178.7 vs 184.5 ms per step -- so it stays OFF unless
+    // MGC_HIST_AHEAD=1.
+    static const bool hist_ahead = getenv("MGC_HIST_AHEAD") && getenv("MGC_HIST_AHEAD")[0] == '1';
     std::vector<mgc::SortPlan> fplan(nb);
     std::vector<char> prepared(nb, 0);
     const size_t hdr_bytes = mgc::sort_header_bytes();

@@ -222,11 +222,12 @@ int mgc_db_stream::process(const Range &r) {
   };
 
   const uint64_t blocks_per_file = 1ull << num_blocks_bits;
-  double enc_ms = 0;
+  double enc_ms = 0, t_slot = 0, t_copy = 0, t_encwait = 0;
+  uint64_t n_pieces = 0;
   if (!chunks.empty() && encode(0) != MGC_OK) return status;
   for (size_t ci = 0; ci < chunks.size(); ci++) {
     const Chunk &c = chunks[ci];
-    DS_TRY(hipEventSynchronize(ev_enc[ci & 1]));
+    { const double tw = now_s(); DS_TRY(hipEventSynchronize(ev_enc[ci & 1])); t_encwait += now_s() - tw; }
     { float ms = 0; if (hipEventElapsedTime(&ms, ev_a, ev_enc[ci & 1]) == hipSuccess) enc_ms += ms; }
     if (ci + 1 < chunks.size() && encode(ci + 1) != MGC_OK) return status;     // runs while this chunk is copied out
     const unsigned char *img = d_img[ci & 1].as<unsigned char>();
@@ -261,6 +262,7 @@ int mgc_db_stream::process(const Range &r) {
         fail(MGC_EINVAL, std::string("writing the database: ") + mdb_last_error());
         return status;
       }
+      const double ts0 = now_s();
       {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return (slot_ready[next_slot] && !slot_busy[next_slot]) || status != MGC_OK; });
@@ -269,8 +271,10 @@ int mgc_db_stream::process(const Range &r) {
         slot_busy[next_slot] = true;
         next_slot = (next_slot + 1) % NSLOT;
       }
+      const double ts1 = now_s();
       hipError_t he = hipMemcpyAsync(pinned[pc.slot], img + a, pc.nbytes, hipMemcpyDeviceToHost, st_copy);
       if (he == hipSuccess) he = hipStreamSynchronize(st_copy);
+      t_slot += ts1 - ts0; t_copy += now_s() - ts1; n_pieces++;
       if (he != hipSuccess) {
         { std::lock_guard<std::mutex> g(mu); slot_busy[pc.slot] = false; }
         return fail_hip(he, "copying encoded blocks to the host");
@@ -285,6 +289,9 @@ int mgc_db_stream::process(const Range &r) {
     }
   }
   const double t2 = now_s();
+  if (getenv("MGC_IO_TRACE"))
+    fprintf(stderr, "[io] db range: %llu pieces in %zu chunks: waiting for a free pinned slot %.3f s, device-to-host copies %.3f s, "
+                    "waiting for the encoder %.3f s, plan %.3f s\n", (unsigned long long)n_pieces, chunks.size(), t_slot, t_copy, t_encwait, t1 - t0);
   std::lock_guard<std::mutex> g(mu);
   prof.plan_ms += (t1 - t0) * 1e3;
   prof.encode_ms += enc_ms;
