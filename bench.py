@@ -40,30 +40,37 @@ SEED = 2
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(sample_reads, threads):
-    """Reference-algorithm port (oracle/oracle_port.cpp) on the host cores.
-    Sample keeps the workload's shape (150 bp reads at 30x) on a smaller genome."""
+def cpu_baseline(sample_reads, threads, dev_bases=None):
+    """Reference-algorithm port (oracle/oracle_port.cpp: 2 MiB chunks, spin-locked bit-packed prefix buckets with the
+    reference's one/two/three-word add, std::sort, run-length count, 64-file dump) on the host cores, over a bounded
+    sample of the SAME workload: the first `sample_reads` reads of the same 333 Mbp genome with the workload's
+    geometry (wPrefix 18) -- coverage per k-mer is lower than in the whole run, which favours the CPU's distinct/s.
+    Every thread count tried is reported; `value` is the best one."""
     import oracle
     oracle.build()
-    genome = max(READ_LEN * 4, sample_reads * READ_LEN // 30)
-    bases = oracle.synth_reads(SEED, genome, 0, sample_reads, READ_LEN, 5000, 100).tobytes()
+    if dev_bases is not None:                                         # the very bytes the GPU counted (first reads of rank 0)
+        bases = dev_bases[:sample_reads * (READ_LEN + 1)].cpu().numpy()
+    else:
+        bases = oracle.synth_reads(SEED, GENOME_LEN, 0, sample_reads, READ_LEN, 5000, 100)
     cfg = oracle.configure_counting(K, 10_000_000_000, 64 << 30)      # the workload's geometry (wPrefix 18)
-    # the reference's spin-locked buckets do not scale to every core count: time a few
-    # thread counts (all <= the box's cores) and report the best one
+    # the reference's spin-locked buckets do not scale to every core count: time a few thread counts (all <= the
+    # box's cores) and report every one
+    tried = []
     best = None
-    for th in sorted({min(threads, t) for t in (16, 64, threads)}):
+    for th in sorted({max(1, min(threads, t)) for t in (16, 64, threads)}):
         t0 = time.perf_counter()
-        nd, ni = oracle.time_threaded(bases, K, cfg["w_prefix"], oracle.CANONICAL, th)
+        _, nd, ni = oracle.digest_threaded(bases, K, cfg["w_prefix"], oracle.CANONICAL, th)
         dt = time.perf_counter() - t0
+        tried.append({"threads": th, "seconds": dt, "distinct_per_s": nd / dt, "instances_per_s": ni / dt})
         if best is None or dt < best[0]:
             best = (dt, th, nd, ni)
-    dt, threads, nd, ni = best
+    dt, th, nd, ni = best
     return {
-        "value": nd / dt, "unit": "distinct k-mers/s", "cores": threads, "kind": "port",
-        "sample": "%d x %d bp reads at 30x of a %d bp synthetic genome (%.2f Gbp), k=%d, wPrefix=%d; "
-                  "%d instances, %d distinct in %.2f s (%.3g instances/s)"
-                  % (sample_reads, READ_LEN, genome, len(bases) / 1e9, K, cfg["w_prefix"], ni, nd, dt, ni / dt),
-        "instances_per_s": ni / dt, "seconds": dt,
+        "value": nd / dt, "unit": "distinct k-mers/s", "cores": th, "kind": "port",
+        "sample": "the first %d x %d bp reads of the workload (%.2f Gbp of the %d bp genome's reads), k=%d, wPrefix=%d; "
+                  "%d instances, %d distinct in %.2f s (%.3g instances/s) on %d threads"
+                  % (sample_reads, READ_LEN, bases.size / 1e9, GENOME_LEN, K, cfg["w_prefix"], ni, nd, dt, ni / dt, th),
+        "instances_per_s": ni / dt, "seconds": dt, "threads_tried": tried, "host_cores": os.cpu_count(),
     }
 
 
@@ -190,8 +197,8 @@ def pmc_traffic(reads):
         except (OSError, ValueError):
             continue
         if d.get("reads_per_gpu") == reads and str(d.get("kernel", "")).startswith("radix_group_kernel"):
-            return d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"]
-    return None
+            return d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"], "profiles/" + os.path.basename(f)
+    return None, None
 
 
 def main():
@@ -200,7 +207,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=DEFAULT_READS, help="reads per GPU (default = 10 Gbp)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=1_500_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=14_000_000, help="reads of the workload the CPU port counts (2.1 Gbp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the untimed file -> database run of the CLI")
     ap.add_argument("--no-check", action="store_true", help="skip the untimed result check")
@@ -327,7 +334,7 @@ def main():
                             % (reads, READ_LEN, reads * READ_LEN / 1e9, genome_len),
                 "k": K, "reads_per_gpu": reads, "bases_per_gpu": n_bases,
                 "n_distinct": n_distinct,
-                "parallelism": "1 GPU" if world == 1 else "%d GPUs: 64 files in contiguous per-rank ranges, file-major point-to-point exchange overlapped with the owner-side count" % world,
+                "parallelism": "1 GPU" if world == 1 else "%d GPUs: the top-bit buckets (64 files x ranges) in contiguous per-rank ranges, bucket-major point-to-point waves overlapped with the owner-side count" % world,
             },
         }
         single = world == 1 and not force_sharded
@@ -344,7 +351,8 @@ def main():
                 line["roofline"] = {
                     "kernel": "radix_group_kernel (one 9-bit radix pass over a file's k-mers)",
                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(reads) if single else None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(reads)[0] if single else None,
+                    "traffic_source": (pmc_traffic(reads)[1] or "none: no committed PMC run of this workload") if single else None,
                     "measured": "HIP events around every pass launch of the timed steps" if single else
                                 "HIP events around every pass launch of rank 0's owner-side count in one extra untimed step",
                     "launches": prof_acc["pass_launches"],
@@ -380,7 +388,7 @@ def main():
                 except Exception as e:
                     line["e2e"] = {"error": str(e)[:300]}
             if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_sample_reads, os.cpu_count() or 1)
+                line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_reads, reads), os.cpu_count() or 1, bases)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)

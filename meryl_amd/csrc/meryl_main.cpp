@@ -244,7 +244,7 @@ int run_count(const Globals &g, const Operation &op) {
     if (name != "-" && !has_compressed_suffix(name)) {
       // plain text: the library reads the file itself, several threads straight into its pinned upload buffers
       msr_close(r);
-      const int rc = mgc_push_text_file(s, name.c_str(), 0, (int)std::min<uint32_t>(g.threads, 6));
+      const int rc = mgc_push_text_file(s, name.c_str(), 0, (int)std::min<uint32_t>(g.threads, 16));
       if (rc == MGC_EFORMAT) load_on_host(name);
       else if (rc != MGC_OK) die("ERROR: %s", mgc_last_error(s));
       struct stat fst;

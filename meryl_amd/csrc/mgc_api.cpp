@@ -403,6 +403,7 @@ extern "C" void mgc_close(mgc_session *s) {
     if (s->pin[i]) (void)hipHostFree(s->pin[i]);
     if (s->pin_ev[i]) (void)hipEventDestroy(s->pin_ev[i]);
   }
+  for (char *&p : s->text_ring) if (p) { (void)hipHostFree(p); p = nullptr; }
   if (s->st_in) (void)hipStreamDestroy(s->st_in);
   for (hipEvent_t e : s->hist_ev) if (e) (void)hipEventDestroy(e);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -434,13 +435,14 @@ static int input_setup(mgc_session *s) {
   HIP_TRY(s, hipSetDevice(s->device));
   if (s->state_ready) return MGC_OK;
   if (s->batch_limit == 0) {
-    // one pass holds, per base: the two staging buffers, a key (8/16 B per instance) in X, 4 B of count scratch, the
-    // distinct k-mers with their counts, the ping-pong buffer of the largest file -- about 20 (34) B with slack; the
-    // rest of the HBM is left to the running result of earlier batches and its merge target
+    // One pass holds, per base: the staged base, 0.87 k-mer instances of 8 (16) B in X, 4 B of count scratch each, the
+    // distinct k-mers with their counts (about a seventh of the instances at 30x), the ping-pong buffer of the largest
+    // file -- measured 13 B per base at k=21 (130 GB for 10 Gbp: DESIGN.md section 2), 16 (30) B with slack.  A fifth of
+    // the HBM stays free for the running result of earlier batches and its merge target.
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
-      const uint64_t per_base = 6 + 14ull * s->key_words;
-      s->batch_limit = (uint64_t)((double)free_b * 0.70 / (double)per_base);
+      const uint64_t per_base = 2 + 14ull * s->key_words;
+      s->batch_limit = (uint64_t)((double)free_b * 0.80 / (double)per_base);
     }
     if (s->batch_limit < (1u << 20)) s->batch_limit = 1u << 20;
   }
@@ -646,38 +648,55 @@ extern "C" int mgc_push_text_file(mgc_session *s, const char *path, int format, 
   int rc = mgc_begin_text(s, format);
   if (rc != MGC_OK) { close(fd); return rc; }
 
-  constexpr int R = 8;                                      // ring of pinned chunks: up to R-2 chunks of read-ahead
+  // Readers and ring: measured on the 2 x 64-core box (scripts/e2e_cli.py, 20.5 GB FASTQ on tmpfs): 6 readers / 8 slots keep
+  // the uploader waiting 1.7 s, 16 readers / 24 slots 0.01 s (the loop then runs at the 0.5 s of upload + parse).  The pinned
+  // slots are allocated by the readers themselves, in parallel, on first use, and stay with the session for the next file.
+  constexpr int RMAX = mgc_session::TEXT_RING_MAX;
+  if (reader_threads <= 0) reader_threads = 16;
+  if (const char *e = getenv("MGC_TEXT_READERS")) reader_threads = atoi(e);
+  reader_threads = std::max(1, std::min(reader_threads, RMAX - 8));
+  int R = reader_threads + 8;                               // up to R-2 chunks of read-ahead
+  if (const char *e = getenv("MGC_TEXT_RING")) R = std::max(4, std::min(RMAX, atoi(e)));
   const size_t CH = mgc_session::TEXT_CHUNK;
   const uint64_t nchunks = (size + CH - 1) / CH;
-  if (reader_threads <= 0) reader_threads = 8;
-  reader_threads = (int)std::min<uint64_t>((uint64_t)std::min(reader_threads, R - 2), nchunks ? nchunks : 1);
-  char *ring[R] = {nullptr};
-  bool hip_ok = true;
-  for (int i = 0; i < R && (uint64_t)i < nchunks && hip_ok; i++)
-    hip_ok = hipHostMalloc(reinterpret_cast<void **>(&ring[i]), CH, hipHostMallocDefault) == hipSuccess;
-  if (!hip_ok) {
-    for (int i = 0; i < R; i++) if (ring[i]) (void)hipHostFree(ring[i]);
-    close(fd);
-    set_err(&s->err, "mgc_push_text_file: pinned buffers: out of memory");
-    return MGC_ENOMEM;
-  }
+  reader_threads = (int)std::min<uint64_t>((uint64_t)std::max(1, std::min(reader_threads, R - 2)), nchunks ? nchunks : 1);
+  char **ring = s->text_ring;
+  std::atomic<bool> alloc_failed(false);
   std::mutex mu;
   std::condition_variable cv;
-  uint64_t free_gen[R], ready_chunk[R];                     // slot i may be filled with chunk c iff free_gen[i] == c / R
-  size_t   ready_len[R];
+  uint64_t free_gen[RMAX], ready_chunk[RMAX];               // slot i may be filled with chunk c iff free_gen[i] == c / R
+  size_t   ready_len[RMAX];
+  std::vector<double> t_pread(64, 0.0), t_slotwait(64, 0.0);
+  std::atomic<int> reader_ids(0);
   for (int i = 0; i < R; i++) { free_gen[i] = 0; ready_chunk[i] = ~0ull; ready_len[i] = 0; }
   std::atomic<uint64_t> next_chunk(0);
   bool abort_all = false, read_failed = false;
   auto reader = [&]() {
+    const int me = reader_ids.fetch_add(1) & 63;
+    auto rnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (;;) {
       const uint64_t c = next_chunk.fetch_add(1);
       if (c >= nchunks) return;
       const int slot = (int)(c % R);
+      const double w0 = rnow();
       {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return abort_all || free_gen[slot] == c / R; });
         if (abort_all) return;
       }
+      if (!ring[slot]) {                                    // first use of this slot (exactly one reader gets here per slot)
+        (void)hipSetDevice(s->device);
+        if (hipHostMalloc(reinterpret_cast<void **>(&ring[slot]), CH, hipHostMallocDefault) != hipSuccess) {
+          ring[slot] = nullptr;
+          alloc_failed.store(true);
+          std::lock_guard<std::mutex> g(mu);
+          read_failed = true; abort_all = true;
+          cv.notify_all();
+          return;
+        }
+      }
+      const double w1 = rnow();
+      t_slotwait[me] += w1 - w0;
       const uint64_t off = c * CH;
       const size_t want = (size_t)std::min<uint64_t>(CH, size - off);
       size_t have = 0;
@@ -688,6 +707,7 @@ extern "C" int mgc_push_text_file(mgc_session *s, const char *path, int format, 
         if (r <= 0) { ok = false; break; }                  // an error, or the file shrank under us
         have += (size_t)r;
       }
+      t_pread[me] += rnow() - w1;
       std::lock_guard<std::mutex> g(mu);
       if (!ok) { read_failed = true; abort_all = true; }
       ready_chunk[slot] = c; ready_len[slot] = have;
@@ -726,10 +746,15 @@ extern "C" int mgc_push_text_file(mgc_session *s, const char *path, int format, 
   for (int b = 0; b < 2; b++) if (s->text_ev_used[b]) (void)hipEventSynchronize(s->text_ev[b]);
   { std::lock_guard<std::mutex> g(mu); abort_all = abort_all || true; cv.notify_all(); }
   for (auto &t : readers) t.join();
-  for (int i = 0; i < R; i++) if (ring[i]) (void)hipHostFree(ring[i]);
   close(fd);
-  if (trace) fprintf(stderr, "[io] text file %.2f GB in %llu chunks, %d readers: waiting for readers %.3f s, upload+parse submit (incl. waits for the device) %.3f s\n",
-                     size / 1e9, (unsigned long long)nchunks, reader_threads, t_wait, t_submit);
+  if (alloc_failed.load()) { set_err(&s->err, "mgc_push_text_file: pinned buffers: out of memory"); (void)mgc_end_text(s); return MGC_ENOMEM; }
+  if (trace) {
+    double sp = 0, sw = 0;
+    for (int i = 0; i < 64; i++) { sp += t_pread[i]; sw += t_slotwait[i]; }
+    fprintf(stderr, "[io] text file %.2f GB in %llu chunks, %d readers, ring %d: waiting for readers %.3f s, upload+parse submit (incl. waits "
+                    "for the device) %.3f s; readers: %.3f s in pread (%.1f GB/s each), %.3f s waiting for a free slot\n",
+            size / 1e9, (unsigned long long)nchunks, reader_threads, R, t_wait, t_submit, sp, sp > 0 ? size / 1e9 / sp : 0.0, sw);
+  }
   if (read_failed) { set_err(&s->err, "mgc_push_text_file: reading '%s' failed: %s", path, strerror(errno)); rc = MGC_EINVAL; }
   const int rc_end = mgc_end_text(s);                       // closes the file in every case (rolls it back on MGC_EFORMAT)
   return rc != MGC_OK ? rc : rc_end;

@@ -115,6 +115,8 @@ struct mgc_session {
   hipEvent_t  text_ev[2] = {nullptr, nullptr};
   bool        text_ev_used[2] = {false, false};
   uint32_t    text_next = 0;
+  static constexpr int TEXT_RING_MAX = 64;
+  char       *text_ring[TEXT_RING_MAX] = {nullptr};      // mgc_push_text_file's pinned read-ahead slots (allocated on first use)
   // host-pushed bases: two pinned chunks, the upload of one overlaps the filling of the other
   char       *pin[2] = {nullptr, nullptr};
   size_t      pin_len = 0;

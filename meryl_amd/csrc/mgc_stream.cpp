@@ -41,7 +41,7 @@ struct DBuf {                                             // grow-only device bu
 
 constexpr size_t   SLOT_BYTES = 32u << 20;                // pinned copy buffers: NSLOT x SLOT_BYTES
 constexpr int      NSLOT      = 16;
-constexpr uint64_t IMG_CAP    = 512ull << 20;             // device image of one encode chunk (two of them in flight)
+constexpr uint64_t IMG_CAP    = 1024ull << 20;            // device image of one encode chunk (two of them in flight): ~10 files at 10 Gbp
 
 }  // namespace
 
@@ -232,7 +232,12 @@ int mgc_db_stream::process(const Range &r) {
     if (ci + 1 < chunks.size() && encode(ci + 1) != MGC_OK) return status;     // runs while this chunk is copied out
     const unsigned char *img = d_img[ci & 1].as<unsigned char>();
     auto pos_at = [&](uint64_t j) { return j < c.b1 ? h_pos[j] : c.bytes; };
+    // 1. cut the chunk into pieces (whole blocks where possible, never across files) and fix every piece's place in its
+    //    file -- index entries and offsets are reserved here, in prefix order
+    struct PieceDesc { uint64_t a; Piece pc; };
+    std::vector<std::vector<PieceDesc>> by_file;          // pieces of the chunk's files, file-major
     uint64_t a = 0, bi = c.b0;                            // bi = first block that starts at or after byte a
+    uint32_t last_ff = ~0u;
     while (a < c.bytes) {
       const uint64_t cur_blk = (bi < c.b1 && h_pos[bi] == a) ? bi : bi - 1;
       const uint32_t ff = (uint32_t)((r.pb + cur_blk) >> num_blocks_bits);
@@ -249,43 +254,58 @@ int mgc_db_stream::process(const Range &r) {
       } else {                                            // block bi alone is larger than a copy buffer
         e = lim; j = bi + 1;
       }
-      Piece pc;
-      pc.ff = ff; pc.nbytes = e - a;
+      PieceDesc pd;
+      pd.a = a;
+      pd.pc.ff = ff; pd.pc.nbytes = e - a; pd.pc.slot = -1; pd.pc.file_offset = 0;
       std::vector<mdb_index_entry> entries;
       for (uint64_t jj = bi; jj < j; jj++) {
         mdb_index_entry en;
         en.prefix = r.pb + jj; en.position = h_pos[jj] - a; en.n_kmers = h_bs[jj + 1] - h_bs[jj];
         entries.push_back(en);
       }
-      // the index and the file offset are fixed here, in prefix order; the bytes follow from whichever thread is free
-      if (mdb_writer_reserve_encoded(w, ff, pc.nbytes, entries.data(), entries.size(), &pc.file_offset) != MGC_OK) {
+      if (mdb_writer_reserve_encoded(w, ff, pd.pc.nbytes, entries.data(), entries.size(), &pd.pc.file_offset) != MGC_OK) {
         fail(MGC_EINVAL, std::string("writing the database: ") + mdb_last_error());
         return status;
       }
-      const double ts0 = now_s();
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return (slot_ready[next_slot] && !slot_busy[next_slot]) || status != MGC_OK; });
-        if (status != MGC_OK) return status;
-        pc.slot = next_slot;
-        slot_busy[next_slot] = true;
-        next_slot = (next_slot + 1) % NSLOT;
-      }
-      const double ts1 = now_s();
-      hipError_t he = hipMemcpyAsync(pinned[pc.slot], img + a, pc.nbytes, hipMemcpyDeviceToHost, st_copy);
-      if (he == hipSuccess) he = hipStreamSynchronize(st_copy);
-      t_slot += ts1 - ts0; t_copy += now_s() - ts1; n_pieces++;
-      if (he != hipSuccess) {
-        { std::lock_guard<std::mutex> g(mu); slot_busy[pc.slot] = false; }
-        return fail_hip(he, "copying encoded blocks to the host");
-      }
-      {
-        std::lock_guard<std::mutex> g(mu);
-        pieces_open++;
-        queue.push_back(pc);
-      }
-      cv.notify_all();
+      if (ff != last_ff) { by_file.emplace_back(); last_ff = ff; }
+      by_file.back().push_back(pd);
       a = e; bi = j;
+    }
+    // 2. copy them out round-robin over the chunk's files: writes to ONE file serialise in the kernel (inode lock:
+    //    6-8 GB/s on tmpfs whatever the thread count), writes to different files do not
+    size_t left = 0;
+    for (auto &v : by_file) left += v.size();
+    std::vector<size_t> next(by_file.size(), 0);
+    while (left) {
+      for (size_t fi = 0; fi < by_file.size(); fi++) {
+        if (next[fi] >= by_file[fi].size()) continue;
+        PieceDesc &pd = by_file[fi][next[fi]++];
+        left--;
+        Piece pc = pd.pc;
+        const double ts0 = now_s();
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return (slot_ready[next_slot] && !slot_busy[next_slot]) || status != MGC_OK; });
+          if (status != MGC_OK) return status;
+          pc.slot = next_slot;
+          slot_busy[next_slot] = true;
+          next_slot = (next_slot + 1) % NSLOT;
+        }
+        const double ts1 = now_s();
+        hipError_t he = hipMemcpyAsync(pinned[pc.slot], img + pd.a, pc.nbytes, hipMemcpyDeviceToHost, st_copy);
+        if (he == hipSuccess) he = hipStreamSynchronize(st_copy);
+        t_slot += ts1 - ts0; t_copy += now_s() - ts1; n_pieces++;
+        if (he != hipSuccess) {
+          { std::lock_guard<std::mutex> g(mu); slot_busy[pc.slot] = false; }
+          return fail_hip(he, "copying encoded blocks to the host");
+        }
+        {
+          std::lock_guard<std::mutex> g(mu);
+          pieces_open++;
+          queue.push_back(pc);
+        }
+        cv.notify_all();
+      }
     }
   }
   const double t2 = now_s();

@@ -1,0 +1,49 @@
+"""File -> database runs of the stand-alone CLI on one synthetic FASTQ (the bench's e2e workload), under several I/O settings.
+usage: python scripts/e2e_cli.py [reads] -- writes /dev/shm/mgc_e2e/reads.fq once, runs `meryl count` per setting."""
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from meryl_amd import build, count  # noqa: E402
+
+reads = int(sys.argv[1]) if len(sys.argv) > 1 else 66_666_667
+L = 150
+d = "/dev/shm/mgc_e2e"
+shutil.rmtree(d, ignore_errors=True)
+os.makedirs(d)
+bases = count.dev_synth_reads(2, 333_333_334, 0, reads, L, 5000, 100)
+rec = 2 * L + 7
+fq = os.path.join(d, "reads.fq")
+with open(fq, "wb") as f:
+    step = 4_000_000
+    for a in range(0, reads, step):
+        n = min(step, reads - a)
+        r = torch.empty((n, rec), dtype=torch.uint8, device=bases.device)
+        r[:, 0] = ord("@"); r[:, 1] = ord("r"); r[:, 2] = 10
+        r[:, 3:3 + L] = bases[a * (L + 1):(a + n) * (L + 1)].view(n, L + 1)[:, :L]
+        r[:, 3 + L] = 10; r[:, 4 + L] = ord("+"); r[:, 5 + L] = 10
+        r[:, 6 + L:6 + 2 * L] = ord("I"); r[:, 6 + 2 * L] = 10
+        f.write(r.cpu().numpy().tobytes())
+del bases
+torch.cuda.empty_cache()
+cli = build.build_cli()
+settings = [{}, {"MGC_TEXT_READERS": "16", "MGC_TEXT_RING": "24"}, {"MGC_TEXT_READERS": "2", "MGC_TEXT_RING": "8"},
+            {"MERYL_HOST_PARSER_NONE": "1", "MGC_TEXT_READERS": "32", "MGC_TEXT_RING": "48"}]
+for env_add in settings:
+    out = os.path.join(d, "out.meryl")
+    shutil.rmtree(out, ignore_errors=True)
+    env = dict(os.environ, MGC_IO_TRACE="1", **env_add)
+    t0 = time.perf_counter()
+    p = subprocess.run([cli, "-V", "k=21", "memory=64", "threads=32", "n=10000000000", "count", fq, "output", out],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    wall = time.perf_counter() - t0
+    print("==", env_add, "rc", p.returncode, "wall %.3f s" % wall)
+    for l in p.stderr.splitlines():
+        if l.startswith("[io]") or l.startswith("TIMING") or "batches" in l:
+            print("   ", l)
+shutil.rmtree(d, ignore_errors=True)
