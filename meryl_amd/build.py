@@ -14,11 +14,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmeryl_gpu_count.so")
 SOURCES = ["mgc_kmer.hip", "mgc_sort.hip", "mgc_scan.hip", "mgc_finish.hip", "mgc_misc.hip", "mgc_parse.hip",
-           "mgc_encode.hip", "mgc_merge.hip",
+           "mgc_encode.hip", "mgc_merge.hip", "mgc_lookup.hip",
            "mgc_api.cpp", "mgc_stream.cpp", "meryl_db.cpp", "meryl_seq.cpp"]
 HEADERS = ["mgc_device.h", "mgc_common.hpp", "mdb_layout.h", "mgc_session.hpp",
            os.path.join("..", "..", "include", "meryl_gpu_count.h"),
-           os.path.join("..", "..", "include", "meryl_db.h"), os.path.join("..", "..", "include", "meryl_seq.h")]
+           os.path.join("..", "..", "include", "meryl_db.h"), os.path.join("..", "..", "include", "meryl_seq.h"),
+           os.path.join("..", "..", "include", "meryl_lookup.h")]
 OBJDIR = os.path.join(HERE, "build")
 # -no-hip-rt: the library carries no DT_NEEDED on a particular libamdhip64; it binds to the
 # HIP runtime already in the process (torch's bundled one under Python -- two HIP/HSA runtimes

@@ -33,6 +33,9 @@ SYMBOLS = (
     "mdb_reader_file_index", "mdb_reader_block_header", "mdb_reader_read_block_raw", "mdb_reader_close",
     "mdb_free", "mgc_write_database", "mgc_write_database_profiled",
     "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_merge",
+    # include/meryl_lookup.h
+    "mgc_lookup_load", "mgc_lookup_from_device", "mgc_lookup_free", "mgc_lookup_get_info", "mgc_lookup_error",
+    "mgc_lookup_values", "mgc_lookup_stream", "mgc_lookup_existence",
     # include/meryl_seq.h
     "msr_open", "msr_read_text", "msr_close", "msr_last_error", "msr_load_bases", "msr_load_stream", "msr_format", "msr_is_compressed", "msr_guess_number_of_kmers",
 )
@@ -118,6 +121,11 @@ class DbWriteProfile(ctypes.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class LookupInfo(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_uint32), ("key_words", ctypes.c_uint32), ("index_bits", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("n_kmers", ctypes.c_uint64), ("n_kmers_in_db", ctypes.c_uint64), ("device_bytes", ctypes.c_uint64)]
 
 
 class IndexEntry(ctypes.Structure):
@@ -271,6 +279,14 @@ def lib():
     sig("mgc_db_stream_sync", i32, vp)
     sig("mgc_db_stream_close", i32, vp, P(DbWriteProfile))
     sig("mgc_db_stream_error", ctypes.c_char_p, vp)
+    sig("mgc_lookup_load", vp, ctypes.c_char_p, u64, u64, i32, i32)
+    sig("mgc_lookup_from_device", vp, vp, vp, u64, u32, u64, u64, i32)
+    sig("mgc_lookup_free", None, vp)
+    sig("mgc_lookup_get_info", i32, vp, P(LookupInfo))
+    sig("mgc_lookup_error", ctypes.c_char_p)
+    sig("mgc_lookup_values", i32, vp, vp, u64, vp, vp)
+    sig("mgc_lookup_stream", i32, vp, vp, u64, vp, vp)
+    sig("mgc_lookup_existence", i32, vp, vp, u64, vp, u64, vp, vp, vp)
     sig("msr_open", vp, ctypes.c_char_p)
     sig("msr_close", None, vp)
     sig("msr_read_text", ctypes.c_int64, vp, vp, u64)

@@ -1,0 +1,89 @@
+"""GPU tests of the exact lookup table (include/meryl_lookup.h): merylExactLookup's load / value
+as meryl-lookup uses them (src/meryl-lookup/meryl-lookup.C:36-100, existence.C:63-82), against a dictionary built
+from the oracle's counts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _keys_tensor(torch, lo, hi, k):
+    if k > 32:
+        return torch.from_numpy(np.stack([lo, hi], axis=1).view(np.int64).copy()).cuda()
+    return torch.from_numpy(lo.view(np.int64).copy()).cuda()
+
+
+@pytest.mark.parametrize("k", [21, 31, 51, 8])
+def test_lookup_values_stream_and_existence(native_lib, oracle_lib, tmp_path, k):
+    import torch
+    from meryl_amd import capi, count, lookup
+    bases = oracle_lib.synth_reads(41, 150_000, 0, 20_000, 150, 5000, 2000)          # plenty of N
+    whi, wlo, wcn, _ = oracle_lib.count_brute(bases.tobytes(), k)
+    table = {(int(h) << 64) | int(l): int(c) for h, l, c in zip(whi, wlo, wcn)}
+    cfg = capi.configure(k, bases.size, 1 << 30)
+    d = torch.from_numpy(bases).cuda()
+    with count.Session(cfg, 0) as s:
+        s.push_bases_device(d)
+        s.count()
+        keys, cnts = s.result_device()
+        s.write_database(str(tmp_path / "db"), 4)
+    for src in ("device", "file"):
+        lk = lookup.Lookup.from_device(keys, cnts, k) if src == "device" else lookup.Lookup.load(str(tmp_path / "db"))
+        assert lk.info.n_kmers == len(wlo) == lk.info.n_kmers_in_db and lk.info.k == k
+        # 1. value(): every stored k-mer, and k-mers that are not there
+        got = lk.values(keys).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, wcn)
+        rng = np.random.default_rng(k)
+        qlo = rng.integers(0, 1 << 62, 5000, dtype=np.uint64) & np.uint64((1 << min(2 * k, 64)) - 1 if 2 * k < 64 else 0xFFFFFFFFFFFFFFFF)
+        qhi = (rng.integers(0, 1 << 62, 5000, dtype=np.uint64) & np.uint64((1 << (2 * k - 64)) - 1)) if k > 32 else np.zeros(5000, np.uint64)
+        got = lk.values(_keys_tensor(torch, qlo, qhi, k)).cpu().numpy().view(np.uint32)
+        want = [table.get((int(h) << 64) | int(l), 0) for h, l in zip(qhi, qlo)]
+        assert [int(x) for x in got] == want
+        # 2. every window of a base stream: reads the table was built from, plus foreign sequence
+        other = oracle_lib.synth_reads(77, 50_000, 0, 300, 150, 5000, 100)
+        stream = np.concatenate([bases[:60_000], other])
+        ehi, elo = oracle_lib.enumerate_kmers(stream.tobytes(), k, 0)                  # canonical k-mers in input order
+        vals = lk.stream(torch.from_numpy(stream).cuda()).cpu().numpy().view(np.uint32)
+        # positions of valid windows, independently: k consecutive ACGT
+        ok = np.isin(stream, np.frombuffer(b"ACGTacgt", dtype=np.uint8))
+        run = np.zeros(stream.size + 1, dtype=np.int64)
+        run[1:] = np.cumsum(~ok)
+        starts = np.nonzero(run[k:] - run[:-k] == 0)[0]
+        assert starts.size == elo.size
+        want = np.zeros(stream.size, dtype=np.uint32)
+        want[starts] = [table.get((int(h) << 64) | int(l), 0) for h, l in zip(ehi, elo)]
+        assert np.array_equal(vals, want)
+        # 3. -existence: per sequence (read + its breaker) total k-mers and k-mers found
+        seq_start = np.concatenate([[0], np.nonzero(stream == ord("."))[0] + 1])
+        if seq_start[-1] != stream.size:
+            seq_start = np.append(seq_start, stream.size)
+        tot, fnd = lk.existence(torch.from_numpy(stream).cuda(), seq_start)
+        sid = np.searchsorted(seq_start, starts, side="right") - 1
+        wt = np.bincount(sid, minlength=seq_start.size - 1)
+        wf = np.bincount(sid, weights=(want[starts] > 0), minlength=seq_start.size - 1).astype(np.int64)
+        assert np.array_equal(tot.astype(np.int64), wt) and np.array_equal(fnd.astype(np.int64), wf)
+        assert fnd[:100].sum() == tot[:100].sum() and fnd.sum() < tot.sum()           # own reads all found, foreign ones not
+        lk.close()
+    # 4. the value filter of load (-min / -max): only k-mers with 2 <= value <= 5
+    for lk in (lookup.Lookup.load(str(tmp_path / "db"), 2, 5), lookup.Lookup.from_device(keys, cnts, k, 2, 5)):
+        keep = (wcn >= 2) & (wcn <= 5)
+        assert lk.info.n_kmers == int(keep.sum()) and lk.info.n_kmers_in_db == len(wlo)
+        got = lk.values(keys).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, np.where(keep, wcn, 0))
+        lk.close()
+
+
+def test_lookup_tiny_and_empty(native_lib):
+    import torch
+    from meryl_amd import lookup
+    keys = torch.tensor([5, 9, 1 << 40], dtype=torch.int64).cuda()
+    cnts = torch.tensor([1, 2, 3], dtype=torch.int32).cuda()
+    with lookup.Lookup.from_device(keys, cnts, 21) as lk:
+        assert lk.info.index_bits == 0 and lk.info.n_kmers == 3
+        q = torch.tensor([0, 5, 6, 9, 1 << 40, (1 << 40) + 1], dtype=torch.int64).cuda()
+        assert lk.values(q).cpu().tolist() == [0, 1, 0, 2, 3, 0]
+    empty = torch.empty(0, dtype=torch.int64).cuda()
+    with lookup.Lookup.from_device(empty, torch.empty(0, dtype=torch.int32).cuda(), 32) as lk:
+        assert lk.info.n_kmers == 0
+        assert lk.values(torch.tensor([7], dtype=torch.int64).cuda()).cpu().tolist() == [0]
+        assert lk.stream(torch.from_numpy(np.frombuffer(b"ACGT" * 20, dtype=np.uint8).copy()).cuda()).sum().item() == 0
