@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADERS = [os.path.join(ROOT, "include", h) for h in ("meryl_gpu_count.h", "meryl_db.h", "meryl_seq.h")]
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("meryl_gpu_count.h", "meryl_db.h", "meryl_seq.h", "meryl_lookup.h")]
 
 
 def declared_functions():
