@@ -15,6 +15,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <cstdarg>
@@ -396,6 +397,7 @@ extern "C" void mgc_close(mgc_session *s) {
   (void)hipSetDevice(s->device);
   if (s->st_in) (void)hipStreamSynchronize(s->st_in);
   s->free_result();
+  s->free_garbage();
   s->free_arena();
   for (int i = 0; i < 2; i++) {
     if (s->text_pinned[i]) (void)hipHostFree(s->text_pinned[i]);
@@ -464,9 +466,13 @@ static int resolve_length(mgc_session *s, HostParseState *out = nullptr) {
   return MGC_OK;
 }
 
+static double io_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 static int join_worker(mgc_session *s) {
   if (s->worker_active) {
+    const double t0 = io_now();
     s->worker.join();
+    s->tr_join += io_now() - t0;
     s->worker_active = false;
     if (s->worker_rc != MGC_OK) return s->worker_rc;
   }
@@ -542,10 +548,15 @@ extern "C" int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int
     size_t left = part ? (end_of_sequence ? 1 : 0) : len;
     while (left) {
       const size_t take = std::min(left, mgc_session::PIN_CHUNK - s->pin_len);
+      const double t0 = io_now();
       memcpy(s->pin[s->pin_cur] + s->pin_len, src, take);
+      const double t1 = io_now();
+      s->tr_memcpy += t1 - t0;
       s->pin_len += take; src += take; left -= take;
       if (s->pin_len == mgc_session::PIN_CHUNK) { rc = flush_pinned(s); if (rc != MGC_OK) return rc; }
-      if (s->fill_len + s->pin_len >= s->batch_limit) { rc = cut_batch(s); if (rc != MGC_OK) return rc; }
+      const double t2 = io_now();
+      s->tr_flush += t2 - t1;
+      if (s->fill_len + s->pin_len >= s->batch_limit) { rc = cut_batch(s); if (rc != MGC_OK) return rc; s->tr_cut += io_now() - t2; }
     }
   }
   return MGC_OK;
@@ -648,6 +659,27 @@ extern "C" int mgc_push_text_file(mgc_session *s, const char *path, int format, 
   int rc = mgc_begin_text(s, format);
   if (rc != MGC_OK) { close(fd); return rc; }
 
+  // MGC_TEXT_MMAP=1: no reader threads at all -- the file is mapped and every 32 MiB piece is handed to hipMemcpyAsync
+  // straight from the mapping (the runtime pins pageable sources on the fly: 56 GB/s for a 1 GiB pageable buffer on this
+  // box, scripts/pcie_bench.py); the page cache IS the upload buffer.
+  if (const char *mm = getenv("MGC_TEXT_MMAP")) if (mm[0] == '1' && size > 0) {
+    void *map = mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0);
+    if (map != MAP_FAILED) {
+      (void)madvise(map, size, MADV_SEQUENTIAL);
+      const size_t CHm = mgc_session::TEXT_CHUNK;
+      const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+      for (uint64_t off = 0; off < size && rc == MGC_OK; off += CHm)
+        rc = text_submit(s, reinterpret_cast<const char *>(map) + off, (size_t)std::min<uint64_t>(CHm, size - off));
+      for (int b = 0; b < 2; b++) if (s->text_ev_used[b]) (void)hipEventSynchronize(s->text_ev[b]);
+      if (getenv("MGC_IO_TRACE"))
+        fprintf(stderr, "[io] text file %.2f GB uploaded from its mapping in %.3f s\n", size / 1e9,
+                std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
+      munmap(map, size);
+      close(fd);
+      const int rc_end = mgc_end_text(s);
+      return rc != MGC_OK ? rc : rc_end;
+    }
+  }
   // Readers and ring: measured on the 2 x 64-core box (scripts/e2e_cli.py, 20.5 GB FASTQ on tmpfs): 6 readers / 8 slots keep
   // the uploader waiting 1.7 s, 16 readers / 24 slots 0.01 s (the loop then runs at the 0.5 s of upload + parse).  The pinned
   // slots are allocated by the readers themselves, in parallel, on first use, and stay with the session for the next file.
@@ -1354,6 +1386,12 @@ extern "C" int mgc_count(mgc_session *s) {
     if (rc == MGC_OK) rc = finalize_from_r(s);
   }
   if (rc == MGC_OK) s->counted = true;
+  s->free_garbage();
+  if (getenv("MGC_IO_TRACE") && s->input_seen)
+    fprintf(stderr, "[io] host pushes: memcpy into pinned %.3f s, flush (grow + async upload + wait for the other chunk) %.3f s, batch cuts %.3f s "
+                    "(of which waiting for the worker %.3f s), staging-buffer growth %.3f s; %u batches, device merges %.1f ms; "
+                    "arena hipMalloc/hipFree %.3f s for %.1f GB\n",
+            s->tr_memcpy, s->tr_flush, s->tr_cut, s->tr_join, s->tr_grow, s->n_batches, s->merge_ms, s->tr_alloc, s->tr_alloc_bytes / 1e9);
   return rc;
 }
 

@@ -5,6 +5,7 @@
 #include "../../include/meryl_gpu_count.h"
 #include "mgc_device.h"
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -68,31 +69,46 @@ struct mgc_session {
          B_SUBSTART, B_GROUPS, B_GSCAN, B_CNT_TMP, B_LARGE, B_NONEMPTY, B_STAGE0, B_STAGE1, B_TEXT_IN0, B_TEXT_IN1, B_TEXT_WS,
          B_TEXT_STATE, B_RK, B_RC, B_R2K, B_R2C, B_MERGE_WS, B_SORT_HDRS, B_NUM };
   Buf buf[B_NUM];
+  double tr_alloc = 0;                   // seconds inside hipMalloc / hipFree of the arena (MGC_IO_TRACE)
+  uint64_t tr_alloc_bytes = 0;
   hipError_t ensure(int which, size_t bytes) {
     Buf &b = buf[which];
     if (bytes < 256) bytes = 256;
     if (b.cap >= bytes) return hipSuccess;
+    const auto t0 = std::chrono::steady_clock::now();
     if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
     hipError_t e = hipMalloc(&b.p, bytes);
     if (e == hipSuccess) b.cap = bytes;
+    tr_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    tr_alloc_bytes += bytes;
     return e;
   }
   void free_arena() { for (auto &b : buf) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; } }
-  // grows a buffer whose first `keep` bytes must survive (device-to-device copy on stream `on`, synchronised)
+  // Grows a staging buffer whose first `keep` bytes must survive (device-to-device copy on stream `on`, synchronised).
+  // Growth is by 4x up to the batch size, and the old buffer is NOT freed here: hipFree waits for the whole device -- i.e.
+  // for the batch the worker thread is counting -- and twenty growth steps of that cost 4.9 of the 5.2 s a 6 Gbp host
+  // push took (profiles/r02i).  The old buffers go when the count is done (free_garbage).
+  std::vector<void *> garbage;
   hipError_t ensure_preserve(int which, size_t bytes, size_t keep, hipStream_t on) {
     Buf &b = buf[which];
     if (b.cap >= bytes) return hipSuccess;
-    size_t want = b.cap + b.cap / 2;
+    struct Tm { double *acc; double t0; static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+                Tm(double *a) : acc(a), t0(now()) {} ~Tm() { *acc += now() - t0; } } tm_(&tr_grow);
+    size_t want = b.cap * 4;
+    const size_t full = batch_limit ? (size_t)batch_limit + 4 * PIN_CHUNK : 0;       // what a whole batch needs
+    if (full && want > full && full >= bytes) want = full;
     if (want < bytes) want = bytes;
     void *np = nullptr;
     hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess && want > bytes) { want = bytes; e = hipMalloc(&np, want); }
     if (e != hipSuccess) return e;
     if (b.p && keep) e = hipMemcpyAsync(np, b.p, keep, hipMemcpyDeviceToDevice, on);
     if (e == hipSuccess) e = hipStreamSynchronize(on);
-    if (b.p) (void)hipFree(b.p);
+    if (b.p) garbage.push_back(b.p);
     b.p = np; b.cap = want;
     return e;
   }
+  void free_garbage() { for (void *p : garbage) (void)hipFree(p); garbage.clear(); }
 
   // ---- input staging -------------------------------------------------------------------------------------------
   // Everything pushed (bases from the host, text parsed on the device) lands in ONE base stream in HBM, stage[fill],
@@ -138,6 +154,7 @@ struct mgc_session {
   uint32_t    n_batches = 0;
   double      merge_ms = 0;
   std::thread worker;
+  double      tr_memcpy = 0, tr_flush = 0, tr_cut = 0, tr_join = 0, tr_grow = 0;   // MGC_IO_TRACE: where the pushing thread's time went
   bool        worker_active = false;      // a batch is being counted (join before touching count state)
   int         worker_rc = MGC_OK;
 
