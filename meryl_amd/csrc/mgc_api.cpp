@@ -885,8 +885,11 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   uint32_t bucket_bits = ext_keys ? ext_bucket_bits : (uint32_t)MGC_NUM_FILES_BITS;
   if (!ext_keys) {
     const char *pb = getenv("MGC_BUCKET_BASES");                      // tests force finer buckets on small inputs
-    const uint64_t per_bucket = (pb && *pb) ? strtoull(pb, nullptr, 10) : 180000000ull;
-    while (bucket_bits < MGC_MAX_BUCKET_BITS && bucket_bits < 2 * c.k && (s->n_bases >> bucket_bits) > per_bucket) bucket_bits++;
+    // `compress`: two dense-rank digits cover 3^10 sub-buckets (below), i.e. buckets of up to 68 M k-mers, and the digits
+    // are whole bases, so the buckets get finer two bits at a time
+    const uint64_t per_bucket = (pb && *pb) ? strtoull(pb, nullptr, 10) : (c.homopoly_compress ? 60000000ull : 180000000ull);
+    const uint32_t step = c.homopoly_compress ? 2u : 1u;
+    while (bucket_bits + step <= MGC_MAX_BUCKET_BITS && bucket_bits + step <= 2 * c.k && (s->n_bases >> bucket_bits) > per_bucket) bucket_bits += step;
   }
   const uint32_t nb = 1u << bucket_bits;
   const uint32_t kw = s->key_words;
@@ -1018,12 +1021,24 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     // ---- plan: per file, t top bits so that a sub-bucket holds ~target k-mers ----
     const uint64_t target = mgc::finish_target_for(kw), cap = mgc::finish_capacity_for(kw);
     std::vector<uint32_t> top_bits(nb);
+    std::vector<char> hpc_digits(nb, 0);
     std::vector<uint64_t> gbase(nb + 1), sbase(nb + 1);
     gbase[0] = sbase[0] = 0;
+    // `compress`: the grouping digits are dense ranks of five homopolymer-free bases (make_hpc_group_plan): 10 key bits
+    // hold 243 patterns, 20 bits 59049.  Needs the remaining bits to be whole bases (the 64 files, or an even number of
+    // bucket bits) and the bucket to fit 59049 sub-buckets; otherwise the generic bit digits below (MGC_HPC_DIGITS=0: always).
+    static const bool hpc_on = !(getenv("MGC_HPC_DIGITS") && getenv("MGC_HPC_DIGITS")[0] == '0');
+    const bool hpc_ok = hpc_on && c.homopoly_compress && (rem_bits % 2 == 0) && bucket_bits >= 2;
     for (uint32_t b = 0; b < nb; b++) {
       uint32_t t = 0;
+      if (hpc_ok && h_counts[b] > target) {                            // sub-buckets average `target` k-mers or fewer
+        if (h_counts[b] <= 243ull * target && rem_bits >= 10) t = 10;
+        else if (h_counts[b] <= 59049ull * target && rem_bits >= 20) t = 20;
+        if (t) hpc_digits[b] = 1;                                      // else (tiny k, gigantic bucket): generic path
+      }
+      if (!hpc_digits[b])
       while (t < rem_bits && t < 26 && (h_counts[b] >> t) > target) t++;
-      if (c.homopoly_compress && t) {
+      if (c.homopoly_compress && t && !hpc_digits[b]) {
         // homopolymer-compressed sequence never repeats a base: every 2-bit group after the first takes 3 of its 4
         // values, so only (3/4)^(t/2) of the 2^t top-bit patterns occur and the occupied sub-buckets are that much
         // larger than planned: log2(4/3)/2 = 0.2075 of every key bit carries no information
@@ -1074,6 +1089,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     unsigned char *d_hdrs = nullptr;
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0 || top_bits[b] == 0) continue;
+      if (hpc_digits[b]) { mgc::make_hpc_group_plan(rem_bits - top_bits[b], top_bits[b] / 10, &fplan[b]); continue; }
       mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fplan[b]);
       if (use_group && fplan[b].mode == 0) fplan[b].mode = 3;
     }

@@ -18,10 +18,27 @@ typedef unsigned __int128 u128;
 // 128-bit key (k in 33..64): little-endian halves, so memory order == integer order of lo|hi<<64
 struct alignas(16) K128 { u64 lo, hi; };
 
+// Dense rank of five bases that never repeat the base before them (homopolymer-compressed sequence): x = 12 key bits, the
+// top two = the base before the five.  Order preserving: d_i = c_i - (c_i > previous base) in {0, 1, 2}, rank = sum d_i 3^(4-i).
+constexpr u32 HPC_DIGIT_MASK = 0xFFFFFFFFu;          // passed as a pass's "mask": the digit is hpc_digit() of the 12 bits at `shift`
+__device__ __forceinline__ u32 hpc_digit(u32 x) {
+  u32 prev = (x >> 10) & 3u, d = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    const u32 c = (x >> (8 - 2 * i)) & 3u;
+    d = d * 3u + (c - (c > prev ? 1u : 0u));
+    prev = c;
+  }
+  return d;                                            // <= 242 for valid input, <= 363 for any input (bins exist up to 511)
+}
+
 template <typename K> struct KeyOps;
 template <> struct KeyOps<u64> {
   static constexpr int WORDS = 1;
-  static __device__ __forceinline__ u32  digit(u64 k, u32 shift, u32 mask) { return (u32)(k >> shift) & mask; }
+  static __device__ __forceinline__ u32  digit(u64 k, u32 shift, u32 mask) {
+    if (mask == HPC_DIGIT_MASK) return hpc_digit((u32)(k >> shift) & 0xFFFu);
+    return (u32)(k >> shift) & mask;
+  }
   static __device__ __forceinline__ u32  bucket(u64 k, u32 shift) { return (u32)(k >> shift); }
   static __device__ __forceinline__ u64  pad() { return ~0ull; }
   static __device__ __forceinline__ u64  zero() { return 0ull; }
@@ -34,7 +51,10 @@ template <> struct KeyOps<K128> {
   static constexpr int WORDS = 2;
   static __device__ __forceinline__ u128 v(K128 k) { return ((u128)k.hi << 64) | (u128)k.lo; }
   static __device__ __forceinline__ K128 mk(u128 x) { K128 k; k.lo = (u64)x; k.hi = (u64)(x >> 64); return k; }
-  static __device__ __forceinline__ u32  digit(K128 k, u32 shift, u32 mask) { return (u32)(v(k) >> shift) & mask; }
+  static __device__ __forceinline__ u32  digit(K128 k, u32 shift, u32 mask) {
+    if (mask == HPC_DIGIT_MASK) return hpc_digit((u32)(v(k) >> shift) & 0xFFFu);
+    return (u32)(v(k) >> shift) & mask;
+  }
   static __device__ __forceinline__ u32  bucket(K128 k, u32 shift) { return (u32)(v(k) >> shift); }
   static __device__ __forceinline__ K128 pad() { K128 k; k.lo = ~0ull; k.hi = ~0ull; return k; }
   static __device__ __forceinline__ K128 zero() { K128 k; k.lo = 0; k.hi = 0; return k; }

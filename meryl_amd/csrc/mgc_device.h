@@ -38,6 +38,7 @@ struct SortPlan {
   uint32_t match;           // 0 = ballot match, 1 = LDS mask match (ranking inside a wave)
   uint32_t lookback;        // 1 = walk before the LDS exchange, 2 = window after it, 5 = pipelined persistent kernel
   uint32_t flags;           // bit1: non-temporal key loads (experiments)
+  uint32_t hpc;             // digits are DENSE RANKS of five homopolymer-free bases (make_hpc_group_plan), not bit fields
   void    *dbg;             // optional device buffer: 8 cycle stamps per tile of the LAST pass launched
   uint32_t num_passes;
   uint32_t pass_shift[16];
@@ -47,6 +48,13 @@ struct SortPlan {
 // Chooses digit widths for bits [begin_bit, end_bit); honours MGC_RADIX_BITS /
 // MGC_SORT_MODE / MGC_SORT_KPT environment overrides (bench experiments).
 void   make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan);
+// Grouping plan for homopolymer-compressed k-mers (`compress`): no base equals the one before it, so five bases after a
+// known base take 3^5 = 243 of their 1024 bit patterns.  A digit is the dense, ORDER-PRESERVING rank of five bases given
+// the base before them (10 key bits -> 0..242): `passes` (1 or 2) digits cover the 10*passes key bits above `low_bit`
+// (which must be a whole number of bases above bit 0, with one more base above the top digit).  Grouping by these
+// digits orders the keys exactly as grouping by the bits would, over 3^(5*passes) occupied sub-buckets instead of a
+// 4^(5*passes) grid that is 94 % empty -- two digits do what took three stable passes.
+void   make_hpc_group_plan(uint32_t low_bit, uint32_t passes, SortPlan *plan);
 size_t sort_workspace_bytes(uint64_t n);
 
 struct SortTiming {           // optional per-pass event timing

@@ -972,6 +972,18 @@ void make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan) {
   }
 }
 
+void make_hpc_group_plan(uint32_t low_bit, uint32_t passes, SortPlan *plan) {
+  make_sort_plan(0, 18, plan);                       // tile shape, look-back flavour, env overrides
+  plan->radix_bits = 9;                              // 243 of the 512 bins are used
+  plan->mode = 3;
+  plan->hpc = 1;
+  plan->num_passes = passes;
+  for (uint32_t p = 0; p < passes; p++) { plan->pass_shift[p] = low_bit + 10 * p; plan->pass_bits[p] = 10; }
+}
+
+// the `mask` argument of a pass's kernels
+static inline u32 plan_mask(const SortPlan &plan, uint32_t p) { return plan.hpc ? HPC_DIGIT_MASK : (1u << plan.pass_bits[p]) - 1u; }
+
 static inline uint64_t max_tiles_for(uint64_t n) { return (n + 4095) / 4096 + 1; }   // tile >= 4096 keys
 
 size_t sort_workspace_bytes(uint64_t n) {
@@ -1000,7 +1012,7 @@ static hipError_t group_prepare(const K *src, uint64_t n, const SortPlan &plan, 
   pl.n = plan.num_passes;
   for (uint32_t p = 0; p < plan.num_passes; p++) {
     pl.shift[p] = plan.pass_shift[p];
-    pl.mask[p]  = (1u << plan.pass_bits[p]) - 1u;
+    pl.mask[p]  = plan_mask(plan, p);
   }
   launch_radix_hist<K>(src, (u64)n, pl, &hdr->ghist[0][0], st);
   MGC_CHECK(hipGetLastError());
@@ -1050,7 +1062,7 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
     pl.n = plan.num_passes;
     for (uint32_t p = 0; p < plan.num_passes; p++) {
       pl.shift[p] = plan.pass_shift[p];
-      pl.mask[p]  = (1u << plan.pass_bits[p]) - 1u;
+      pl.mask[p]  = plan_mask(plan, p);
     }
     launch_radix_hist<K>((const K *)src, (u64)n, pl, &hdr->ghist[0][0], st);
     MGC_CHECK(hipGetLastError());
@@ -1066,16 +1078,16 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
         const uint32_t pgrid = (uint32_t)(num_tiles < resident ? num_tiles : resident);
         if (plan.dbg)
           hipLaunchKernelGGL((radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, true>), dim3(pgrid), dim3(BLOCK), SMP::BYTES, st,
-                             (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                             (const K *)src, dst, (u64)n, plan.pass_shift[p], plan_mask(plan, p),
                              &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
         else
           hipLaunchKernelGGL((radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, false>), dim3(pgrid), dim3(BLOCK), SMP::BYTES, st,
-                             (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                             (const K *)src, dst, (u64)n, plan.pass_shift[p], plan_mask(plan, p),
                              &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, (u64 *)nullptr);
       } else {
         hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, LBO, MATCH>), dim3((uint32_t)num_tiles),
                            dim3(BLOCK), SM::BYTES, st, (const K *)src, dst, (u64)n, plan.pass_shift[p],
-                           (1u << plan.pass_bits[p]) - 1u, &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, plan.flags,
+                           plan_mask(plan, p), &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, plan.flags,
                            (const u64 *)nullptr, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
       }
       MGC_CHECK(hipGetLastError());
@@ -1114,12 +1126,12 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
       const u32 *rt = (p == 0) ? nullptr : region_tiles;
       if (plan.dbg)
         hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, true>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
-                           (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                           (const K *)src, dst, (u64)n, plan.pass_shift[p], plan_mask(plan, p),
                            &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, plan.flags,
                            reinterpret_cast<u64 *>(plan.dbg));
       else
         hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
-                           (const K *)src, dst, (u64)n, plan.pass_shift[p], (1u << plan.pass_bits[p]) - 1u,
+                           (const K *)src, dst, (u64)n, plan.pass_shift[p], plan_mask(plan, p),
                            &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, plan.flags, (u64 *)nullptr);
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
@@ -1130,7 +1142,7 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
     u32 *tile_hist = reinterpret_cast<u32 *>(body);
     u64 *tile_offs = reinterpret_cast<u64 *>(body + (((size_t)num_tiles * R * sizeof(u32) + 255) / 256) * 256);
     for (uint32_t p = 0; p < plan.num_passes; p++) {
-      const uint32_t shift = plan.pass_shift[p], dmask = (1u << plan.pass_bits[p]) - 1u;
+      const uint32_t shift = plan.pass_shift[p], dmask = plan_mask(plan, p);
       hipLaunchKernelGGL((radix_tile_hist_kernel<K, RB, BLOCK, KPT>), dim3((uint32_t)num_tiles), dim3(BLOCK), 0, st,
                          (const K *)src, (u64)n, shift, dmask, tile_hist, (u64)num_tiles);
       MGC_CHECK(hipGetLastError());
@@ -1173,6 +1185,7 @@ hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key
   *result_in_alt = 0;
   if (n == 0 || plan.num_passes == 0) return hipSuccess;
   if (ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
+  if (plan.hpc && !(plan.mode == 3 && plan.num_passes <= 2 && n < (1ull << 30))) return hipErrorInvalidValue;
   if (plan.mode == 3 && (plan.num_passes > 2 || n >= (1ull << 30))) {
     SortPlan stable = plan;                 // grouping is defined for one or two digits and 30-bit granule values
     stable.mode = 0;

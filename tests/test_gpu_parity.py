@@ -496,6 +496,34 @@ def test_session_compress_matches_oracle(ops, oracle_lib, torch_cuda, k):
     assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
 
 
+@pytest.mark.parametrize("k,mode,reads,read_len", [(31, 0, 300, 5000), (21, 1, 6000, 150), (51, 0, 400, 4000), (31, 2, 6000, 5000),
+                                                    (16, 0, 1500, 2000), (31, 0, 40, 2000)])
+def test_compress_dense_rank_digits_match_oracle(ops, oracle_lib, torch_cuda, k, mode, reads, read_len):
+    """`compress` at sizes where files are grouped by DENSE-RANK digits (make_hpc_group_plan: five homopolymer-free bases ->
+    0..242): one digit (files of a few thousand to 280 K k-mers) and two digits (larger), 8- and 16-byte keys, all three
+    strand modes, plus a size below the first digit -- against the oracle's compress + brute-force count; and equal to
+    the generic bit-digit path (MGC_HPC_DIGITS=0 is read once per process, so that comparison is the oracle's)."""
+    from meryl_amd import capi
+    bases = oracle_lib.synth_reads(90 + k, max(4 * read_len, reads * read_len // 8), 0, reads, read_len, 3000, 300)
+    # homopolymer runs so that compression really shortens the reads: stretch some bases
+    raw = bases.tobytes().decode()
+    stretched = raw.replace("AC", "AAAC").replace("GT", "GTTT")
+    want_stream = oracle_lib.compress_stream(stretched)
+    whi, wlo, wcn, wni = oracle_lib.count_brute(want_stream, k, mode)
+    cfg = capi.configure(k, len(stretched), 2 << 30, mode, homopoly_compress=1)
+    d = torch_cuda.from_numpy(np.frombuffer(stretched.encode(), dtype=np.uint8).copy()).cuda()
+    with ops.Session(cfg) as s:
+        s.push_bases_device(d)
+        s.count()
+        klo, khi, counts, _ = s.result_wide()
+        info = s.info()
+    assert info.n_instances == wni
+    assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+    per_file = max(info.file_instances)
+    if reads * read_len >= 1_000_000:
+        assert per_file > 1152                                   # the digits were in play (one digit above 1152, two above 280 K per file)
+
+
 @pytest.mark.parametrize("k", [3, 8, 13, 14])
 def test_simple_mode_geometry(ops, oracle_lib, torch_cuda, tmp_path, k):
     # small k: the reference picks countSimple (merylOp-count.C:368-372) whose database geometry is
