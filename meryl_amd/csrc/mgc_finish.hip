@@ -715,26 +715,28 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
 #undef HC_STAMP
 }
 
-// Hash-count finish for 16-byte keys (k = 33..64).  The suffix of a key inside its sub-bucket may be wider than any
-// LDS compare-and-swap, so a slot is claimed through its COUNT word instead: 0 = empty, LOCK = being written,
-// n >= 1 = valid with n instances.  A thread that finds LOCK simply stays pending for the next round (rounds, not
-// spinning: the lane holding the lock may sit in the same wave).  WIDE = the suffix needs the high word too
-// (low_bits > 64); otherwise the hi arrays are not even allocated.
+// Hash-count finish for 16-byte keys (k = 33..64).  The suffix of a key inside its sub-bucket may be wider than any LDS
+// compare-and-swap, so the table does not hold suffixes at all: the sub-bucket's suffixes are first staged in LDS (every
+// thread writes its own, one barrier), and a table slot holds the INDEX of the key that claimed it -- one 32-bit CAS per
+// probe, the claimant's suffix is complete before anybody can look at it, no lock word, no fences, no rounds.  (The first
+// version claimed a slot through its count word and published it with release/acquire fences: 153.6 ms of finish per 5 Gbp at
+// k=51, two workgroups per CU; this one aliases the compacted output onto the staging arrays, packs index and count into
+// one slot word and fits four: 103 ms with separate index/count words and three workgroups.)
+// WIDE = the suffix needs the high word too (low_bits > 64); otherwise the hi arrays are not even allocated.
 template <int BLOCK, int CAP, int SLOTS, bool WIDE>
-__global__ __launch_bounds__(BLOCK, WIDE ? 2 : 3)
+__global__ __launch_bounds__(BLOCK, 4)
 void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                           u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
                           const u32 *__restrict__ nz, const u64 *__restrict__ nz_count) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
   constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
-  constexpr u32 LOCK = 0xFFFFFFFFu;
-  __shared__ u64 tlo[SLOTS];
-  __shared__ u64 thi[WIDE ? SLOTS : 1];
-  __shared__ u32 tc[SLOTS];
-  __shared__ __attribute__((aligned(16))) u64 dlo[CAP + 4];
+  static_assert(CAP < 0xFFFF, "slot words hold a 16-bit key index and a 16-bit count");
+  constexpr u32 EMPTY = 0x0000FFFFu;                                  // count 0, no claimant
+  __shared__ __attribute__((aligned(16))) u64 dlo[CAP + 4];           // staged suffixes, later the compacted distinct ones
   __shared__ __attribute__((aligned(16))) u64 dhi[WIDE ? CAP + 4 : 2];
-  __shared__ u32 dc[CAP];
-  __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  __shared__ u32 tw[SLOTS];                                           // slot -> instances << 16 | index of the claiming key;
+  __shared__ u32 s_tmp[BLOCK / 64 + 1];                               //   later dc[]: counts of the compacted suffixes
+  u32 *dc = tw;                                                       // 33 KiB of LDS in all: four workgroups per CU
   using KO = KeyOps<K128>;
   const u32 tid = threadIdx.x;
   const u64 G = gridDim.x;
@@ -790,9 +792,13 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
         klo[j] = (u64)sfx; khi[j] = (u64)(sfx >> 64);
         const u64 mix = (klo[j] ^ (khi[j] * 0xD6E8FEB86659FD93ull)) * 0x9E3779B97F4A7C15ull;
         hh[j] = (u32)(mix >> 32) >> sshift;
-        if (idx < n) pending |= 1u << j;
+        if (idx < n) {                                 // stage the suffix: complete before the first probe (barrier below)
+          pending |= 1u << j;
+          dlo[idx] = klo[j];
+          if (WIDE) dhi[idx] = khi[j];
+        }
       }
-      for (u32 i = tid; i < slots; i += BLOCK) tc[i] = 0u;
+      for (u32 i = tid; i < slots; i += BLOCK) tw[i] = EMPTY;
       __syncthreads();
 
       while (pending) {
@@ -800,40 +806,39 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
         for (int j = 0; j < KPT; j++) {
           if ((pending >> j) & 1u) {
             const u32 h = hh[j];
-            const u32 old = atomicCAS(&tc[h], 0u, LOCK);
-            if (old == 0u) {                           // the slot is ours: fill it, then publish it with count 1
-              tlo[h] = klo[j];
-              if (WIDE) thi[h] = khi[j];
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-              __hip_atomic_store(&tc[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              pending &= ~(1u << j);
-            } else if (old != LOCK) {                  // valid: same suffix -> count it, another one -> probe on
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-              const bool same = (tlo[h] == klo[j]) && (!WIDE || thi[h] == khi[j]);
-              if (same) { atomicAdd(&tc[h], 1u); pending &= ~(1u << j); }
-              else hh[j] = (h + 1) & smask;
-            }                                          // LOCK: somebody is writing this slot; look again next round
+            const u32 me = (u32)j * BLOCK + tid;
+            const u32 old = atomicCAS(&tw[h], EMPTY, (1u << 16) | me);                  // claim it with count 1
+            if (old == EMPTY) { pending &= ~(1u << j); continue; }
+            const u32 rep = old & 0xFFFFu;                                               // the claimant's suffix was staged before the barrier
+            if ((dlo[rep] == klo[j]) && (!WIDE || dhi[rep] == khi[j])) { atomicAdd(&tw[h], 1u << 16); pending &= ~(1u << j); }
+            else hh[j] = (h + 1) & smask;
           }
         }
       }
       __syncthreads();
 
-      // compact the occupied slots (any order)
+      // compact the occupied slots (any order): gather into registers, then overwrite the staging arrays
       u32 occ = 0;
+      u64 glo[SPT], ghi[SPT];
+      u32 gc[SPT];
 #pragma unroll
       for (int j = 0; j < SPT; j++) {
         const u32 sl = (u32)j * BLOCK + tid;
-        if (sl < slots) occ |= (tc[sl] != 0u ? 1u : 0u) << j;
+        glo[j] = 0; ghi[j] = 0; gc[j] = 0;
+        if (sl < slots) {
+          const u32 w = tw[sl];
+          if (w != EMPTY) { const u32 rep = w & 0xFFFFu; occ |= 1u << j; glo[j] = dlo[rep]; if (WIDE) ghi[j] = dhi[rep]; gc[j] = w >> 16; }
+        }
       }
       u32 D;
-      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);    // (its barriers also end every read of dlo/dhi/tw above)
+      __syncthreads();
 #pragma unroll
       for (int j = 0; j < SPT; j++) {
         if ((occ >> j) & 1u) {
-          const u32 sl = (u32)j * BLOCK + tid;
-          dlo[o] = tlo[sl];
-          if (WIDE) dhi[o] = thi[sl];
-          dc[o] = tc[sl];
+          dlo[o] = glo[j];
+          if (WIDE) dhi[o] = ghi[j];
+          dc[o] = gc[j];
           o++;
         }
       }
@@ -861,6 +866,136 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
         }
         const u32 r = r0 + r1;
         gk[r] = KO::mk(prefix | ((u128)hi << 64) | (u128)li);   // in place: every key of this region sits in registers
+        cnt_tmp[a + r] = dc[i];
+      }
+      if (tid == 0) group_distinct[g] = D;
+      __syncthreads();                                 // the tables are reused by the next sub-bucket
+    }
+
+#pragma unroll
+    for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
+    a = na; n64 = nn; na = nna; nn = nnn; g = g1; g1 = g2; g2 = g3; p += G;
+  }
+}
+
+// The same index-claimed table for 8-byte keys whose suffix does not fit 32 bits (low_bits 32..58: k = 28..32, `compress`):
+// the first version of this kernel kept 64-bit suffixes in the table (64-bit LDS CAS, 42 KiB, three workgroups per CU);
+// staged suffixes + one 32-bit slot word need 21 KiB.
+template <int BLOCK, int CAP, int SLOTS, bool LIST>
+__global__ __launch_bounds__(BLOCK, 5)
+void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
+                          u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
+                          const u32 *__restrict__ nz, const u64 *__restrict__ nz_count) {
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0 && CAP < 0xFFFF, "table geometry");
+  constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
+  constexpr u32 EMPTY = 0x0000FFFFu;
+  __shared__ __attribute__((aligned(16))) u64 dk[CAP + 16];           // staged suffixes, later the compacted distinct ones
+  __shared__ u32 tw[SLOTS];                                           // instances << 16 | index of the claiming key; later dc[]
+  __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  u32 *dc = tw;
+  const u32 tid = threadIdx.x;
+  const u64 G = gridDim.x;
+  const u64 low_mask = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
+  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
+  const u64 file_base = (group_shift >= 64) ? 0ull : ((keys[0] >> group_shift) << group_shift);
+
+  auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
+    aa = 0; nn = 0;
+    if (gg < ng) { aa = starts[gg]; nn = starts[gg + 1] - aa; }
+  };
+  auto load_keys = [&](u64 aa, u64 nn, u64 (&kr)[KPT]) {
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 idx = (u32)j * BLOCK + tid;
+      kr[j] = (nn <= max_size && idx < nn) ? keys[aa + idx] : 0ull;
+    }
+  };
+  const u64 np = LIST ? *nz_count : ng;
+  auto sub_at = [&](u64 pp) -> u64 { return (pp < np) ? (LIST ? (u64)nz[pp] : pp) : ng; };
+  u64 p = blockIdx.x;
+  u64 g = sub_at(p), g1 = sub_at(p + G), g2 = sub_at(p + 2 * G), a, n64, na, nn;
+  u64 kcur[KPT];
+  load_bounds(g, a, n64);
+  load_keys(a, n64, kcur);
+  load_bounds(g1, na, nn);
+
+  while (g < ng) {
+    u64 knext[KPT];
+    u64 nna, nnn;
+    load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
+    load_bounds(g2, nna, nnn);
+    const u64 g3 = sub_at(p + 3 * G);
+
+    if (n64 == 0) {
+      if (tid == 0) group_distinct[g] = 0;
+    } else if (n64 <= max_size) {
+      const u32 n = (u32)n64;
+      const u64 prefix = file_base | (g << low_bits);
+      u64 kk[KPT];
+      u32 hh[KPT];
+      u32 pending = 0;
+      u32 slots = 256;
+      while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
+      const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 idx = (u32)j * BLOCK + tid;
+        kk[j] = kcur[j] & low_mask;
+        hh[j] = (u32)((kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
+        if (idx < n) { pending |= 1u << j; dk[idx] = kk[j]; }
+      }
+      for (u32 i = tid; i < slots; i += BLOCK) tw[i] = EMPTY;
+      __syncthreads();
+
+      while (pending) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if ((pending >> j) & 1u) {
+            const u32 h = hh[j];
+            const u32 old = atomicCAS(&tw[h], EMPTY, (1u << 16) | ((u32)j * BLOCK + tid));
+            if (old == EMPTY) { pending &= ~(1u << j); continue; }
+            if (dk[old & 0xFFFFu] == kk[j]) { atomicAdd(&tw[h], 1u << 16); pending &= ~(1u << j); }
+            else hh[j] = (h + 1) & smask;
+          }
+        }
+      }
+      __syncthreads();
+
+      u32 occ = 0;
+      u64 gk_[SPT];
+      u32 gc[SPT];
+#pragma unroll
+      for (int j = 0; j < SPT; j++) {
+        const u32 sl = (u32)j * BLOCK + tid;
+        gk_[j] = 0; gc[j] = 0;
+        if (sl < slots) {
+          const u32 w = tw[sl];
+          if (w != EMPTY) { occ |= 1u << j; gk_[j] = dk[w & 0xFFFFu]; gc[j] = w >> 16; }
+        }
+      }
+      u32 D;
+      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
+      __syncthreads();                                 // every read of dk / tw above is done
+#pragma unroll
+      for (int j = 0; j < SPT; j++)
+        if ((occ >> j) & 1u) { dk[o] = gk_[j]; dc[o] = gc[j]; o++; }
+      if (tid < 16) dk[D + tid] = ~0ull;               // padding of the rank loop (D is block-uniform)
+      __syncthreads();
+
+      // rank = number of smaller distinct suffixes (all pairs, two 16-byte broadcast reads per iteration)
+      u64 *gk = keys + a;
+      const u32 d4 = (D + 3) / 4;
+      const ulonglong2 *dk2 = reinterpret_cast<const ulonglong2 *>(dk);
+      for (u32 i = tid; i < D; i += BLOCK) {
+        const u64 ki = dk[i];
+        u32 r0 = 0, r1 = 0;
+        for (u32 j = 0; j < d4; j++) {
+          const ulonglong2 v0 = dk2[2 * j], v1 = dk2[2 * j + 1];
+          r0 += (v0.x < ki ? 1u : 0u) + (v0.y < ki ? 1u : 0u);
+          r1 += (v1.x < ki ? 1u : 0u) + (v1.y < ki ? 1u : 0u);
+        }
+        const u32 r = r0 + r1;
+        gk[r] = prefix | ki;                           // in place: every key of this region sits in registers
         cnt_tmp[a + r] = dc[i];
       }
       if (tid == 0) group_distinct[g] = D;
@@ -1519,7 +1654,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               hipStream_t st) {
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
   if (key_words == 2 && finish_uses_hash(key_words, low_bits)) {
-    static const uint32_t wgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 6u;
+    static const uint32_t wgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 4u;     // four workgroups per CU
     const uint32_t wgrid = ng < wgrid_max ? (uint32_t)ng : wgrid_max;
     if (low_bits > 64)
       hipLaunchKernelGGL((hash_count128_kernel<256, (int)FIN_CAP_HASH, 2048, true>), dim3(wgrid), dim3(256), 0, st,
@@ -1574,7 +1709,11 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                        reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp,           \
                        reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, ##__VA_ARGS__)
     // the dense case runs the instantiation without the list: the kernel is VALU-bound, tests in its loops cost time
-    if (low_bits >= 32) {
+    static const bool idx64 = !(getenv("MGC_FINISH_HASH64I") && getenv("MGC_FINISH_HASH64I")[0] == '0');
+    if (low_bits >= 32 && idx64) {
+      if (use_list) MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, true>));
+      else          MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, false>));
+    } else if (low_bits >= 32) {
       if (use_list) MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, true>));
       else          MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, false>));
     } else if (hash_dbg_buffer()) {
