@@ -407,13 +407,13 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
   // Persistent workgroups: the keys of the next sub-bucket are loaded while the current one is counted
   // (a sub-bucket is ~1K keys, so the two dependent HBM round trips would otherwise be a third of its time).
   static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
-  constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
+  constexpr int KPT = CAP / BLOCK;
   constexpr u32 EMPTY = 0xFFFFFFFFu;                   // suffixes are < 2^31
   __shared__ __attribute__((aligned(16))) u32 tk[SLOTS];
   __shared__ __attribute__((aligned(16))) u32 tc[SLOTS];
   __shared__ __attribute__((aligned(16))) u32 dk[CAP + 16];
   __shared__ u32 dc[CAP];
-  __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  __shared__ u32 s_nd;                                 // distinct suffixes of the sub-bucket: the claimers of empty slots count themselves
   const u32 tid = threadIdx.x;
   const u64 G = gridDim.x;
   const u64 low_mask = (1ull << low_bits) - 1ull;
@@ -479,6 +479,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
           tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
           tc4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
+        if (tid == 0) s_nd = 0;
       }
       __syncthreads();
       HC_STAMP(0);
@@ -492,7 +493,22 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
           for (int j = 0; j < KPT; j++) {
             if ((pending >> j) & 1u) {
               const u32 old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
-              if (old == EMPTY || old == kk[j]) {
+              const bool won = (old == EMPTY);
+              // The lanes that claimed an empty slot hold a suffix nobody has seen before: they append it (and its slot)
+              // to the compact list right here -- one LDS atomic per wave and round for all of them -- so that no pass
+              // over the table and no scan is needed afterwards.
+              const u64 wm = __ballot(won);
+              if (won) {
+                const u32 lane = tid & 63u;
+                const int leader = __builtin_ctzll(wm);
+                u32 base = 0;
+                if ((int)lane == leader) base = atomicAdd(&s_nd, (u32)__popcll(wm));
+                base = (u32)__builtin_amdgcn_readlane((int)base, leader);
+                const u32 pos = base + (u32)__popcll(wm & ((1ull << lane) - 1ull));
+                dk[pos] = kk[j];
+                dc[pos] = hh[j];
+              }
+              if (won || old == kk[j]) {
                 atomicAdd(&tc[hh[j]], 1u);
                 pending &= ~(1u << j);
               }
@@ -505,18 +521,9 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
       HC_STAMP(1);
       {
 
-      // compact the occupied slots (any order)
-      u32 occ = 0;
-#pragma unroll
-      for (int j = 0; j < SPT; j++) {
-        const u32 sl = (u32)j * BLOCK + tid;
-        if (sl < slots) occ |= (tc[sl] != 0u ? 1u : 0u) << j;
-      }
-      u32 D;
-      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
-#pragma unroll
-      for (int j = 0; j < SPT; j++)
-        if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
+      // the compact list is already there (any order): only the counts are still in the table
+      const u32 D = s_nd;
+      for (u32 i = tid; i < D; i += BLOCK) dc[i] = tc[dc[i]];
       if (tid < 16) dk[D + tid] = EMPTY;               // padding of the rank loop (D is block-uniform)
       __syncthreads();
       HC_STAMP(2);
