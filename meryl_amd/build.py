@@ -88,11 +88,33 @@ def build_cli(force=False, verbose=False):
     return CLI
 
 
+LOOKUP_CLI = os.path.join(HERE, "bin", "meryl-lookup")
+
+
+def build_lookup_cli(force=False, verbose=False):
+    """`meryl-lookup -existence` (meryl_amd/bin/meryl-lookup): links the library and the system HIP runtime."""
+    src = os.path.join(CSRC, "meryl_lookup_main.cpp")
+    if (not force and os.path.exists(LOOKUP_CLI) and os.path.getmtime(LOOKUP_CLI) >= os.path.getmtime(src)
+            and os.path.getmtime(LOOKUP_CLI) >= os.path.getmtime(LIB)):
+        return LOOKUP_CLI
+    os.makedirs(os.path.dirname(LOOKUP_CLI), exist_ok=True)
+    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+    tmp = "%s.tmp%d" % (LOOKUP_CLI, os.getpid())
+    cmd = [hipcc(), "-O2", "-std=c++17", "-pthread", src, "-o", tmp, "-L" + HERE, "-lmeryl_gpu_count",
+           "-Wl,-rpath,$ORIGIN/..", "-L" + rocm_lib, "-lamdhip64", "-Wl,-rpath," + rocm_lib, "-lz"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(tmp, LOOKUP_CLI)
+    return LOOKUP_CLI
+
+
 def build(force=False, verbose=False):
     """Compile every HIP/C++ source for gfx950 (one object per source, rebuilt only when the source or a
     header changed, in parallel) and link libmeryl_gpu_count.so (and the CLI).  Returns the library path."""
     if not force and not _stale():
         build_cli(False, verbose)
+        build_lookup_cli(False, verbose)
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     todo = _stale_objects(force)
@@ -118,6 +140,7 @@ def build(force=False, verbose=False):
     subprocess.check_call(cmd)
     os.replace(tmp, LIB)
     build_cli(True, verbose)
+    build_lookup_cli(True, verbose)
     return LIB
 
 

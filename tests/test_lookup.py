@@ -87,3 +87,42 @@ def test_lookup_tiny_and_empty(native_lib):
         assert lk.info.n_kmers == 0
         assert lk.values(torch.tensor([7], dtype=torch.int64).cuda()).cpu().tolist() == [0]
         assert lk.stream(torch.from_numpy(np.frombuffer(b"ACGT" * 20, dtype=np.uint8).copy()).cuda()).sum().item() == 0
+
+
+def test_meryl_lookup_existence_cli(native_lib, oracle_lib, tmp_path):
+    """`meryl-lookup -existence -sequence X -mers A B` (src/meryl-lookup/existence.C:48-132): per sequence its k-mers and how
+    many of them each database holds -- against a dictionary of the oracle's counts; -min filters the table."""
+    import subprocess
+    from meryl_amd import build
+    k = 21
+    reads_a = [r for r in oracle_lib.synth_reads(51, 60_000, 0, 3000).tobytes().decode().split(".") if r]
+    reads_b = [r for r in oracle_lib.synth_reads(52, 60_000, 0, 3000).tobytes().decode().split(".") if r]
+    fa, fb = tmp_path / "a.fa", tmp_path / "b.fq"
+    fa.write_text("".join(">a%d some description\n%s\n%s\n" % (i, r[:60], r[60:]) for i, r in enumerate(reads_a)))
+    fb.write_text("".join("@b%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads_b)))
+    meryl = build.build_cli()
+    lookup = build.build_lookup_cli()
+    for f, dbn in ((fa, "A"), (fb, "B")):
+        subprocess.run([meryl, "-Q", "k=%d" % k, "memory=1", "count", str(f), "output", str(tmp_path / (dbn + ".meryl"))], check=True)
+    tables = []
+    for reads in (reads_a, reads_b):
+        _, lo, cn, _ = oracle_lib.count_brute(".".join(reads) + ".", k)
+        tables.append(dict(zip((int(x) for x in lo), (int(c) for c in cn))))
+    query = reads_a[:40] + reads_b[:40] + ["ACGTNACGT", "A" * 30]
+    q = tmp_path / "q.fa"
+    q.write_text("".join(">q%d\n%s\n" % (i, r) for i, r in enumerate(query)))
+    for vmin in (0, 3):
+        args = [lookup, "-existence", "-sequence", str(q), "-mers", str(tmp_path / "A.meryl"), str(tmp_path / "B.meryl")]
+        if vmin:
+            args += ["-min", str(vmin)]
+        p = subprocess.run(args, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        rows = [l.split("\t") for l in p.stdout.strip().split("\n")]
+        assert len(rows) == len(query)
+        for i, (row, seq) in enumerate(zip(rows, query)):
+            _, klo = oracle_lib.enumerate_kmers(seq + ".", k, 0)
+            want = [str(len(klo))]
+            for t in tables:
+                kept = {key for key, c in t.items() if c >= max(vmin, 1)}
+                want += [str(len(kept)), str(sum(1 for x in klo if int(x) in kept))]
+            assert row == ["q%d" % i] + want, (i, row, want)
