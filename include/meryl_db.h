@@ -172,6 +172,36 @@ int mgc_write_database_profiled(struct mgc_session *s, const char *path, int hos
  * Text of a failure: mgc_db_stream_error(NULL). */
 int mgc_db_merge(const char *const *inputs, uint32_t n_inputs, int op, const char *output, int device, int host_threads);
 
+/* ONE count spread over the GPUs of a node, from one process (meryl_amd/csrc/mgc_node.cpp): rank r's reads are the
+ * n_bases[r] bytes at d_bases[r] on device devices[r] (the base stream mgc_push_bases takes; with cfg->homopoly_compress
+ * every rank's stream must hold whole sequences).  Every rank extracts the k-mers of its reads, the k-mers travel over
+ * xGMI (peer copies, in waves that overlap with counting) to the rank that owns their range of the k-mer space, the
+ * owners count and write disjoint prefix ranges, and the parts are stitched: the directory at db_path is
+ * byte-identical to what one device gives for the concatenated input.  The reference has no counterpart -- its
+ * node-scale recipe is "count pieces, then union-sum" (src/meryl/merylOp-count.C:251-268); this is what replaces it.
+ * devices == NULL: rank r uses device r modulo the visible devices; several ranks MAY share a device (that is how a
+ * one-GPU box tests the whole plan).  cfg must have been through mgc_configure_counting for the TOTAL input;
+ * count-suffix is not supported here.  Failure text: mgc_last_error(NULL).
+ * (The one-process-per-GPU form over RCCL is meryl_amd/count.py:count_sharded.) */
+typedef struct mgc_node_profile {
+  uint32_t n_ranks, bucket_bits;
+  uint64_t n_bases, n_instances, n_distinct, data_bytes;
+  double   partition_s;        /* slowest rank: histogram + partition of its reads */
+  double   exchange_count_s;   /* slowest rank: pulls + grouping + finish + handing blocks to the writer */
+  double   close_s;            /* slowest rank: waiting for its part's files */
+  double   merge_parts_s, total_s;
+} mgc_node_profile;
+int mgc_count_node(const mgc_count_config *cfg, uint32_t n_ranks, const int *devices,
+                   const uint8_t *const *d_bases, const uint64_t *n_bases,
+                   const char *db_path, int host_threads, mgc_node_profile *prof);
+
+/* The same for input that went through ONE session (pushed bases, parsed text, files -- the CLI's `gpus=N`): the staged
+ * stream (mgc_staged_bases) is cut into n_ranks slices overlapping by k-1 bases -- no k-mer lost or doubled wherever the
+ * cut falls; `compress` is applied before cutting -- the slices move to their devices and mgc_count_node runs.  The
+ * session itself counts nothing and can only be closed afterwards.  Failure text: mgc_last_error(s). */
+int mgc_count_node_staged(struct mgc_session *s, uint32_t n_ranks, const int *devices, const char *db_path,
+                          int host_threads, mgc_node_profile *prof);
+
 #ifdef __cplusplus
 }
 #endif

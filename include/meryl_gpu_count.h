@@ -240,6 +240,12 @@ int mgc_push_text_file(mgc_session *s, const char *path, int format, int reader_
  * until mgc_count returns.  May be called once per session. */
 int mgc_push_bases_device(mgc_session *s, const uint8_t *d_bases, uint64_t n_bases);
 
+/* The base stream staged so far -- everything pushed (host bases, parsed text, files), breakers included, resident
+ * on the session's device -- without counting it: for callers that route the bases themselves (the `gpus=` option
+ * of the CLI hands slices of it to mgc_count_node).  The view is valid until the next push, mgc_count or
+ * mgc_close.  MGC_ESTATE once a batch has been counted out of core (the early bases are gone by then). */
+int mgc_staged_bases(mgc_session *s, const uint8_t **d_bases, uint64_t *n_bases);
+
 /* Runs histogram -> partition -> per-file radix sort -> run-length count ->
  * block offsets over everything pushed.  Results stay in HBM. */
 int mgc_count(mgc_session *s);

@@ -21,7 +21,7 @@ SYMBOLS = (
     "mgc_dev_partition_workspace_bytes", "mgc_dev_kmer_histogram", "mgc_dev_kmer_partition",
     "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort",
     "mgc_dev_rle_workspace_bytes", "mgc_dev_rle_count", "mgc_dev_rle_emit", "mgc_dev_block_offsets",
-    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_push_text_file", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_copy_result_device",
+    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_staged_bases", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_push_text_file", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_copy_result_device",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish", "mgc_finish_labelled",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_dev_synth_reads_ex", "mgc_version",
     "mgc_dev_merge_workspace_bytes", "mgc_dev_merge_count", "mgc_dev_merge_emit",
@@ -32,7 +32,7 @@ SYMBOLS = (
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_read_file_ex",
     "mdb_reader_file_index", "mdb_reader_block_header", "mdb_reader_read_block_raw", "mdb_reader_close",
     "mdb_free", "mgc_write_database", "mgc_write_database_profiled",
-    "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_merge",
+    "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_merge", "mgc_count_node", "mgc_count_node_staged",
     # include/meryl_lookup.h
     "mgc_lookup_load", "mgc_lookup_from_device", "mgc_lookup_free", "mgc_lookup_get_info", "mgc_lookup_error",
     "mgc_lookup_values", "mgc_lookup_stream", "mgc_lookup_existence",
@@ -106,6 +106,25 @@ class DbInfo(ctypes.Structure):
         ("label_size", ctypes.c_uint32),
         ("reserved", ctypes.c_uint32),
     ]
+
+
+class NodeProfile(ctypes.Structure):
+    _fields_ = [
+        ("n_ranks", ctypes.c_uint32),
+        ("bucket_bits", ctypes.c_uint32),
+        ("n_bases", ctypes.c_uint64),
+        ("n_instances", ctypes.c_uint64),
+        ("n_distinct", ctypes.c_uint64),
+        ("data_bytes", ctypes.c_uint64),
+        ("partition_s", ctypes.c_double),
+        ("exchange_count_s", ctypes.c_double),
+        ("close_s", ctypes.c_double),
+        ("merge_parts_s", ctypes.c_double),
+        ("total_s", ctypes.c_double),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class DbWriteProfile(ctypes.Structure):
@@ -279,6 +298,10 @@ def lib():
     sig("mgc_db_stream_sync", i32, vp)
     sig("mgc_db_stream_close", i32, vp, P(DbWriteProfile))
     sig("mgc_db_stream_error", ctypes.c_char_p, vp)
+    sig("mgc_db_merge", i32, P(ctypes.c_char_p), u32, i32, ctypes.c_char_p, i32, i32)
+    sig("mgc_count_node", i32, P(CountConfig), u32, P(ctypes.c_int), P(vp), P(u64), ctypes.c_char_p, i32, P(NodeProfile))
+    sig("mgc_staged_bases", i32, vp, P(vp), P(u64))
+    sig("mgc_count_node_staged", i32, vp, u32, P(ctypes.c_int), ctypes.c_char_p, i32, P(NodeProfile))
     sig("mgc_lookup_load", vp, ctypes.c_char_p, u64, u64, i32, i32)
     sig("mgc_lookup_from_device", vp, vp, vp, u64, u32, u64, u64, i32)
     sig("mgc_lookup_free", None, vp)

@@ -128,6 +128,24 @@ def dev_run_length(sorted_keys):
     return uniq, cnts
 
 
+def count_node(cfg, bases, path, devices=None, host_threads=8):
+    """mgc_count_node: ONE count over several ranks of this process -- bases[r] is rank r's reads (uint8 cuda tensor,
+    on the device the rank runs on; ranks may share a device) -> the database at `path`, byte-identical to a
+    single-device count of the concatenation.  Returns the profile as a dict."""
+    n = len(bases)
+    ptrs = (ctypes.c_void_p * n)(*[int(b.data_ptr()) if b.numel() else None for b in bases])
+    lens = (ctypes.c_uint64 * n)(*[int(b.numel()) for b in bases])
+    if devices is None:
+        devices = [b.device.index if b.device.index is not None else torch.cuda.current_device() for b in bases]
+    devs = (ctypes.c_int * n)(*[int(d) for d in devices])
+    prof = capi.NodeProfile()
+    torch.cuda.synchronize()
+    rc = capi.lib().mgc_count_node(ctypes.byref(cfg), n, devs, ptrs, lens, os.fsencode(path), host_threads, ctypes.byref(prof))
+    if rc != 0:
+        raise RuntimeError("mgc_count_node failed rc=%d: %s" % (rc, (capi.lib().mgc_last_error(None) or b"").decode()))
+    return prof.as_dict()
+
+
 MERGE_OPS = {"union-sum": 0, "union-min": 1, "union-max": 2, "intersect-sum": 3, "intersect-min": 4, "intersect-max": 5}
 
 

@@ -79,6 +79,7 @@ struct Globals {
   int      verbosity = 2;          // sayStandard
   bool     only_config = false;
   bool     compress = false;       // sticky
+  uint32_t gpus = 1;               // gpus=<N> (this build only): ranks of ONE count spread over the node's devices
   uint32_t label_size = 0;         // -l <bits> (meryl2: kmerTiny::setLabelSize, merylGlobals.C:75-77)
   Globals() {
     const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
@@ -89,7 +90,7 @@ struct Globals {
 
 void usage(const char *prog) {
   fprintf(stderr,
-          "usage: %s [k=<K>] [memory=<GB>] [threads=<T>] [n=<kmers>] [compress] [-l <label-bits>] [-C] [-Q] [-V]\n"
+          "usage: %s [k=<K>] [memory=<GB>] [threads=<T>] [gpus=<N>] [n=<kmers>] [compress] [-l <label-bits>] [-C] [-Q] [-V]\n"
           "          count|count-forward|count-reverse [label=#<n>] <reads.fa|fq[.gz]|sam|bam> ... output <database.meryl>\n"
           "       %s print <database.meryl>\n"
           "       %s dumpIndex <database.meryl>\n"
@@ -211,6 +212,10 @@ int run_count(const Globals &g, const Operation &op) {
 
   if (getenv("MERYL_BATCH_BASES") && *getenv("MERYL_BATCH_BASES"))                                    // tests: force out-of-core batches
     mgc_set_batch_bases(s, strtoull(getenv("MERYL_BATCH_BASES"), nullptr, 10));
+  if (g.gpus > 1) {
+    if (cfg.count_suffix_length) die("ERROR: %s", "count-suffix= and gpus= cannot be combined.");
+    mgc_set_batch_bases(s, ~0ull >> 2);                       // the whole input is staged; the ranks do the counting
+  }
   const uint64_t buf_max = 2 * 1024 * 1024;                                                            // merylOp-countThreads.C:413
   std::vector<char> buf(buf_max);
   uint64_t total_bases = 0;
@@ -280,6 +285,27 @@ int run_count(const Globals &g, const Operation &op) {
   }
 
   const auto t_loaded = std::chrono::steady_clock::now();
+  if (g.gpus > 1) {                                           // one count over the node: k-mer ranges to ranks, one database
+    if (g.verbosity > 0)
+      fprintf(stderr, "\nInput complete.  Counting on %u ranks and writing results to '%s', using %u thread%s.\n",
+              g.gpus, op.output.c_str(), g.threads, (g.threads == 1) ? "" : "s");
+    mgc_node_profile np;
+    if (mgc_count_node_staged(s, g.gpus, nullptr, op.output.c_str(), (int)g.threads, &np) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+    const auto t_done = std::chrono::steady_clock::now();
+    if (g.verbosity > 2)
+      fprintf(stderr, "\nTIMING  read+parse+stage=%.3f s   node count+write=%.3f s   (ranks=%u, routing bits=%u, partition=%.3f s, "
+                      "exchange+count=%.3f s, files=%.3f s, stitch=%.3f s, database_bytes=%" PRIu64 ")\n",
+              std::chrono::duration<double>(t_loaded - t_start).count(), std::chrono::duration<double>(t_done - t_loaded).count(),
+              np.n_ranks, np.bucket_bits, np.partition_s, np.exchange_count_s, np.close_s, np.merge_parts_s, np.data_bytes);
+    mgc_close(s);
+    if (g.verbosity > 0) {
+      fprintf(stderr, "\nFinished counting.\n");
+      if (g.verbosity > 2)
+        fprintf(stderr, "  %" PRIu64 " bases, %" PRIu64 " k-mer instances, %" PRIu64 " distinct k-mers, prefix bits %u.\n",
+                total_bases, np.n_instances, np.n_distinct, cfg.w_prefix);
+    }
+    return 0;
+  }
   if (mgc_count(s) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
   const auto t_counted = std::chrono::steady_clock::now();
   mgc_result_info info;
@@ -521,6 +547,10 @@ int main(int argc, char **argv) {
         ops[top()].exp_num_kmers = strtoull(val.c_str(), nullptr, 10);
       }
       else if (key == "memory" && eq != std::string::npos)  { g.memory_gb = strtod(val.c_str(), nullptr); }       // :299-302
+      else if (key == "gpus" && eq != std::string::npos) {                                  // this build only (no reference counterpart)
+        g.gpus = (uint32_t)strtoul(val.c_str(), nullptr, 10);
+        if (g.gpus < 1 || g.gpus > 64) die("ERROR: %s", "gpus= takes 1..64.");
+      }
       else if (key == "threads" && eq != std::string::npos) { g.threads = (uint32_t)strtoul(val.c_str(), nullptr, 10); if (!g.threads) g.threads = 1; }   // :306-310
       else if (w == "compress")              { g.compress = true; }                                               // :237-240
       else if (key == "count-suffix") {                                                                            // :271-272

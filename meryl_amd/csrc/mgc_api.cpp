@@ -309,6 +309,27 @@ extern "C" const char *mgc_last_error(const mgc_session *s) {
   return s ? s->err.c_str() : mgc::thread_last_error().c_str();
 }
 
+// The block geometry a count really uses: the configuration's, or -- in simple mode -- countSimple's.
+bool mgc::effective_geometry(mgc_count_config *c) {
+  const uint32_t sfx_len = c->count_suffix_length;
+  if (c->use_simple) {
+    // The reference switches to countSimple (merylOp-count.C:368-372): a direct-index counter
+    // whose RESULT is the same sorted (k-mer, count) stream but whose database geometry is
+    //   psbits = 2k - 6, wSuffix = min(20, psbits), wPrefix = 6 + psbits - wSuffix
+    // (merylOp-countSimple.C:172-175).  The sort-based engine produces that stream for any
+    // k, so simple mode only changes the block geometry.
+    if (2 * c->k < MGC_NUM_FILES_BITS + 2 * sfx_len) { set_err(nullptr, "mgc_open: k=%u too small for a 64-file database", c->k); return false; }
+    // A k-mer is [file][blockPrefix][suffix][count-suffix] (:140): the count-suffix bases take no part in the split, and
+    // travel at the end of every block suffix (:231-233)
+    const uint32_t psbits = 2 * c->k - 2 * sfx_len - MGC_NUM_FILES_BITS;
+    const uint32_t w_suffix = (psbits > 20) ? 20 : psbits;
+    c->w_prefix = MGC_NUM_FILES_BITS + psbits - w_suffix;
+    c->n_prefix = (uint64_t)1 << c->w_prefix;
+    c->w_data   = w_suffix + 2 * sfx_len;
+  }
+  return true;
+}
+
 extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
   if (!cfg) { set_err(nullptr, "mgc_open: NULL config"); return nullptr; }
   mgc_count_config eff = *cfg;
@@ -336,21 +357,7 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
     sfx_mask = (sfx_len == 32) ? ~0ull : (((uint64_t)1 << (2 * sfx_len)) - 1);
     eff.use_simple = 1;                                                               // merylOp-count.C:379-382
   }
-  if (eff.use_simple) {
-    // The reference switches to countSimple (merylOp-count.C:368-372): a direct-index counter
-    // whose RESULT is the same sorted (k-mer, count) stream but whose database geometry is
-    //   psbits = 2k - 6, wSuffix = min(20, psbits), wPrefix = 6 + psbits - wSuffix
-    // (merylOp-countSimple.C:172-175).  The sort-based engine below produces that stream for any
-    // k, so simple mode only changes the block geometry.
-    if (2 * cfg->k < MGC_NUM_FILES_BITS) { set_err(nullptr, "mgc_open: k=%u too small for a 64-file database", cfg->k); return nullptr; }
-    // A k-mer is [file][blockPrefix][suffix][count-suffix] (:140): the count-suffix bases take no part in the split, and
-    // travel at the end of every block suffix (:231-233)
-    const uint32_t psbits = 2 * cfg->k - 2 * sfx_len - MGC_NUM_FILES_BITS;
-    const uint32_t w_suffix = (psbits > 20) ? 20 : psbits;
-    eff.w_prefix = MGC_NUM_FILES_BITS + psbits - w_suffix;
-    eff.n_prefix = (uint64_t)1 << eff.w_prefix;
-    eff.w_data   = w_suffix + 2 * sfx_len;
-  }
+  if (!mgc::effective_geometry(&eff)) return nullptr;
   cfg = &eff;
   if (cfg->k == 0 || cfg->k > 64 || cfg->w_prefix < MGC_NUM_FILES_BITS || cfg->w_prefix > 2 * cfg->k ||
       cfg->w_data != 2 * cfg->k - cfg->w_prefix) {
@@ -1409,6 +1416,24 @@ extern "C" int mgc_count(mgc_session *s) {
                     "arena hipMalloc/hipFree %.3f s for %.1f GB\n",
             s->tr_memcpy, s->tr_flush, s->tr_cut, s->tr_join, s->tr_grow, s->n_batches, s->merge_ms, s->tr_alloc, s->tr_alloc_bytes / 1e9);
   return rc;
+}
+
+extern "C" int mgc_staged_bases(mgc_session *s, const uint8_t **d_bases, uint64_t *n_bases) {
+  if (!s || !d_bases || !n_bases) return MGC_EINVAL;
+  if (s->borrowed) { *d_bases = s->d_bases; *n_bases = s->n_bases; return MGC_OK; }
+  if (s->text_open) { set_err(&s->err, "mgc_staged_bases: a text file is still open (mgc_end_text)"); return MGC_ESTATE; }
+  if (s->counted || s->have_r || s->n_batches) { set_err(&s->err, "mgc_staged_bases: part of the input has already been counted"); return MGC_ESTATE; }
+  int rc = MGC_OK;
+  if (!s->state_ready) { rc = input_setup(s); if (rc != MGC_OK) return rc; }
+  rc = flush_pinned(s);
+  if (rc == MGC_OK) rc = resolve_length(s);
+  const int wrc = join_worker(s);
+  if (rc == MGC_OK) rc = wrc;
+  if (rc != MGC_OK) return rc;
+  HIP_TRY(s, hipStreamSynchronize(s->st_in));
+  *d_bases = stage_ptr(s, s->fill);
+  *n_bases = s->fill_len;
+  return MGC_OK;
 }
 
 extern "C" int mgc_count_buckets(mgc_session *s, void *d_keys, uint32_t bucket_bits, const uint64_t *bucket_counts) {

@@ -16,6 +16,8 @@
 namespace mgc {
 // last error of the calling thread (mgc_last_error(NULL)); defined in mgc_api.cpp
 std::string &thread_last_error();
+// simple mode swaps the configured block geometry for countSimple's (mgc_api.cpp); false + thread error when k is too small
+bool effective_geometry(mgc_count_config *c);
 
 inline void set_err(std::string *dst, const char *fmt, ...) {
   char buf[512];

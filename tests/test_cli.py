@@ -343,3 +343,29 @@ def test_cli_out_of_core_text_input(meryl, oracle_lib, tmp_path):
     assert sorted(os.listdir(many)) == names
     for n in names:
         assert open(os.path.join(one, n), "rb").read() == open(os.path.join(many, n), "rb").read(), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,extra", [(21, ()), (31, ("compress",)), (51, ("-l", "5"))])
+def test_cli_gpus_option_writes_the_single_device_database(meryl, oracle_lib, tmp_path, k, extra):
+    """`gpus=N`: the input is read and parsed through one session, its base stream cut into N slices that overlap by k-1
+    bases (cuts fall inside reads -- and, with `compress`, inside the compressed stream), and the ranks of
+    mgc_count_node count and write ONE database: the same 129 files as without the option, for 2, 3 and 7 ranks on
+    whatever devices the box has."""
+    bases = oracle_lib.synth_reads(31, 150_000, 0, 20_000, 150 if not extra or extra[0] != "compress" else 1500).tobytes()
+    reads = [r for r in bases.decode().split(".") if r]
+    fa = tmp_path / "r.fa"
+    fa.write_text("".join(">%d\n%s\n" % (i, r) for i, r in enumerate(reads)))
+    one = tmp_path / "one.meryl"
+    run(meryl, "-Q", *extra, "k=%d" % k, "memory=2", "count", fa, "output", one)
+    names = sorted(os.listdir(one))
+    assert len(names) == 129
+    for n_ranks in (2, 3, 7):
+        out = tmp_path / ("g%d.meryl" % n_ranks)
+        p = run(meryl, "-V", *extra, "k=%d" % k, "memory=2", "gpus=%d" % n_ranks, "count", fa, "output", out)
+        assert "ranks=%d" % n_ranks in p.stderr
+        assert sorted(os.listdir(out)) == names
+        for n in names:
+            assert open(os.path.join(one, n), "rb").read() == open(os.path.join(out, n), "rb").read(), (n_ranks, n)
+    bad = run(meryl, "k=21", "gpus=2", "count", "count-suffix=ACG", fa, "output", tmp_path / "bad.meryl", check=False)
+    assert bad.returncode != 0 and "gpus=" in bad.stderr

@@ -241,3 +241,60 @@ def test_forced_sharded_single_rank_database_equals_unsharded(tmp_path, native_l
         os.environ.pop("MGC_SHARD_BITS", None)
         count.release_cached_sessions()
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,compress,label_size,ranks", [(21, 0, 0, (1, 2, 3)), (51, 0, 7, (4,)), (31, 1, 0, (2, 5)), (16, 0, 0, (8,)), (10, 0, 0, (3,))])
+def test_count_node_virtual_ranks_database_equals_single_device(tmp_path, native_lib, oracle_lib, k, compress, label_size, ranks):
+    """mgc_count_node -- the in-process node count: per-rank extraction, owner PULLS over peer copies in waves, owner-side
+    count, device-encoded parts, stitch -- with several ranks placed on the one GPU of the test box: the 129 files
+    must be the bytes a single session writes for the concatenated reads (which holds the oracle's counts).  Rank
+    slices are cut at read boundaries and deliberately unequal (one rank gets no reads at all when there are >= 3)."""
+    import torch
+    from meryl_amd import capi, count, db
+    n_reads, rl = 60_000, (3000 if compress else 150)
+    if compress:
+        n_reads = 3000
+    bases = oracle_lib.synth_reads(21, 300_000, 0, n_reads, rl, 5000, 100)
+    cfg = capi.configure(k, 3_000_000_000, 64 << 30, homopoly_compress=compress, label_size=label_size, label=0x55)
+    d = torch.from_numpy(bases).cuda()
+    with count.Session(cfg, 0) as s:
+        s.push_bases_device(d)
+        s.count()
+        s.write_database(str(tmp_path / "one"), 8)
+        info = s.info()
+    rec = rl + 1
+    for n in ranks:
+        w = np.array([1.0 + (i * 7) % 5 for i in range(n)])
+        if n >= 3:
+            w[1] = 0.0                                                     # a rank without reads still owns a range
+        cuts = np.concatenate([[0], np.floor(np.cumsum(w) / w.sum() * n_reads).astype(np.int64)]) * rec
+        cuts[-1] = d.numel()
+        slices = [d[int(cuts[i]):int(cuts[i + 1])] for i in range(n)]
+        out = str(tmp_path / ("node%d" % n))
+        prof = count.count_node(cfg, slices, out, devices=[0] * n, host_threads=4)
+        _assert_same_dirs(str(tmp_path / "one"), out)
+        assert prof["n_ranks"] == n and prof["n_distinct"] == info.n_distinct and prof["n_instances"] == info.n_instances
+        assert not [f for f in os.listdir(out) if "part" in f.lower()]
+    text = bases.tobytes()
+    if compress:
+        text = oracle_lib.compress_stream(text)
+    hi_w, lo_w, cn_w, _ = oracle_lib.count_threaded(text, k, cfg.w_prefix, threads=2)
+    r = db.Reader(str(tmp_path / ("node%d" % ranks[-1])))
+    lo, hi, cn, _ = r.read_all(labels=True)
+    r.close()
+    assert np.array_equal(lo, lo_w) and np.array_equal(hi, hi_w) and np.array_equal(cn, cn_w)
+
+
+def test_count_node_rejects_bad_arguments(tmp_path, native_lib):
+    import torch
+    from meryl_amd import capi, count
+    d = torch.zeros(1000, dtype=torch.uint8, device="cuda") + 65
+    cfg = capi.configure(21, 1000, 1 << 30)
+    with pytest.raises(RuntimeError, match="device"):
+        count.count_node(cfg, [d], str(tmp_path / "x"), devices=[99])
+    cfg2 = capi.configure(21, 1000, 1 << 30, count_suffix="ACG")
+    with pytest.raises(RuntimeError, match="count-suffix"):
+        count.count_node(cfg2, [d], str(tmp_path / "y"), devices=[0])
+    cfg3 = capi.configure(4, 1000, 1 << 30)                                # 8 bits of k-mer: at most 256 ranges to route
+    with pytest.raises(RuntimeError, match="ranges of the k-mer space"):
+        count.count_node(cfg3, [d] * 257, str(tmp_path / "z"), devices=[0] * 257)

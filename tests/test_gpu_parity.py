@@ -435,6 +435,36 @@ def test_config1_full_size_matches_threaded_port(ops, oracle_lib, torch_cuda):
     assert [int(x) for x in info.file_instances] == [int(x) for x in want[:, 1]]
 
 
+@pytest.mark.parametrize("shape", ["config3_repeats", "config4_hifi_compress", "config5_k51"])
+def test_other_baseline_configs_single_gpu_leg_matches_port(ops, oracle_lib, torch_cuda, shape):
+    """The single-GPU legs of BASELINE configs 3-5 with THEIR read shapes at a size the threaded port does in seconds
+    (60-90 Mbp): k=21 on reads from a genome with 10 % of its bases in repeat families (heavy sub-buckets -> the streaming
+    finish), k=31 `compress` on 20 kb reads (dense-rank digits, 64-bit suffix finish), k=51 with a label (16-byte keys,
+    index-claimed 128-bit finish) -- per-file digests against the port run on the same bytes."""
+    from meryl_amd import capi
+    if shape == "config3_repeats":
+        k, compress, d = 21, 0, ops.dev_synth_reads(3, 3_000_000, 0, 600_000, 150, 5000, 100, repeat_ppm=100_000)
+    elif shape == "config4_hifi_compress":
+        k, compress, d = 31, 1, ops.dev_synth_reads(4, 2_000_000, 0, 3000, 20_000, 1000, 100)
+    else:
+        k, compress, d = 51, 0, ops.dev_synth_reads(5, 1_800_000, 0, 600_000, 150, 5000, 100)
+    cfg = capi.configure(k, d.numel(), 8 << 30, homopoly_compress=compress, label_size=(8 if k == 51 else 0), label=7)
+    with ops.Session(cfg) as s:
+        s.push_bases_device(d)
+        s.count()
+        info = s.info()
+        keys, counts = s.result_device()
+    got = device_digests(torch_cuda, keys, counts, k)
+    host = d.cpu().numpy()
+    if compress:
+        host = np.frombuffer(oracle_lib.compress_stream(host.tobytes()), dtype=np.uint8).copy()
+    want, nd, ni = oracle_lib.digest_threaded(host, k, cfg.w_prefix, threads=16)
+    assert (nd, ni) == (info.n_distinct, info.n_instances)
+    assert np.array_equal(got, want)
+    if shape == "config3_repeats":
+        assert int(counts.max().item()) > 2000                   # the repeat families really produced heavy k-mers
+
+
 def test_write_database_roundtrip(ops, oracle_lib, torch_cuda, tmp_path):
     # count on the GPU -> 64-file database on disk -> read back == oracle stream
     from meryl_amd import capi, db
