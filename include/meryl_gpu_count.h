@@ -326,6 +326,12 @@ typedef struct mgc_profile {
   double   merge_ms;               /* out-of-core: device merges of batch results into the running result (all batches) */
   uint32_t n_batches;              /* batches the input was counted in (1 = single pass) */
   uint32_t reserved;
+  /* the same pass launches split by position: [0] a file's first pass, [1] its later passes -- with their ALGORITHMIC
+   * bytes (key bytes read + written; narrowed files: 8 + 4 in the first pass, 4 + 4 in the second) */
+  double   pass_ms[2];
+  uint64_t pass_bytes[2];
+  uint64_t pass_keys[2];
+  uint32_t pass_launches[2];
 } mgc_profile;
 int mgc_set_profiling(mgc_session *s, int enable);
 int mgc_get_profile(const mgc_session *s, mgc_profile *p);

@@ -88,6 +88,10 @@ class Profile(ctypes.Structure):
         ("merge_ms", ctypes.c_double),
         ("n_batches", ctypes.c_uint32),
         ("reserved", ctypes.c_uint32),
+        ("pass_ms", ctypes.c_double * 2),
+        ("pass_bytes", ctypes.c_uint64 * 2),
+        ("pass_keys", ctypes.c_uint64 * 2),
+        ("pass_launches", ctypes.c_uint32 * 2),
     ]
 
 

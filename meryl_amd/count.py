@@ -490,6 +490,10 @@ def dev_count_files(keys, file_counts, k, mode=capi.MODE_CANONICAL):
         SHARD_PROFILE["pass_ms"] = SHARD_PROFILE.get("pass_ms", 0.0) + p.sort_pass_ms_total
         SHARD_PROFILE["pass_launches"] = SHARD_PROFILE.get("pass_launches", 0) + p.sort_pass_launches
         SHARD_PROFILE["pass_keys"] = SHARD_PROFILE.get("pass_keys", 0) + p.sort_pass_keys
+        SHARD_PROFILE["pass_bytes"] = SHARD_PROFILE.get("pass_bytes", 0) + p.pass_bytes[0] + p.pass_bytes[1]
+        for i in range(2):
+            bp = SHARD_PROFILE.setdefault("by_pass", [{"ms": 0.0, "launches": 0, "keys": 0, "bytes": 0} for _ in range(2)])[i]
+            bp["ms"] += p.pass_ms[i]; bp["launches"] += p.pass_launches[i]; bp["keys"] += p.pass_keys[i]; bp["bytes"] += p.pass_bytes[i]
     return s.result_device()
 
 

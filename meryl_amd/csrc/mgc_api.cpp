@@ -87,7 +87,7 @@ void best_prefix_size(const mgc_count_config &c, uint64_t n_est, uint64_t mem_al
 
 }  // namespace
 
-extern "C" uint32_t mgc_version(void) { return (0u << 16) | 2u; }
+extern "C" uint32_t mgc_version(void) { return (0u << 16) | 3u; }
 
 extern "C" int mgc_configure_counting(mgc_count_config *c) {
   if (!c) return MGC_EINVAL;
@@ -987,6 +987,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   const uint32_t ev_per_file = 2 * 16;                     // room for 16 passes per file
   std::vector<hipEvent_t> pass_ev;
   std::vector<uint32_t> file_passes(nb, 0);
+  std::vector<char> narrowed(nb, 0);                       // files whose grouping passes ran on 32-bit words
   if (s->profiling) {
     pass_ev.resize((size_t)nb * ev_per_file);
     for (auto &e : pass_ev) (void)hipEventCreate(&e);
@@ -1092,6 +1093,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     static const bool hist_ahead = getenv("MGC_HIST_AHEAD") && getenv("MGC_HIST_AHEAD")[0] == '1';
     std::vector<mgc::SortPlan> fplan(nb);
     std::vector<char> prepared(nb, 0);
+    // narrow[b]: the file's k-mers travel as 32-bit words from the first grouping pass on (mgc::launch_group_narrow)
+    std::vector<char> narrow(nb, 0);
     const size_t hdr_bytes = mgc::sort_header_bytes();
     unsigned char *d_hdrs = nullptr;
     for (uint32_t b = 0; b < nb; b++) {
@@ -1099,6 +1102,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (hpc_digits[b]) { mgc::make_hpc_group_plan(rem_bits - top_bits[b], top_bits[b] / 10, &fplan[b]); continue; }
       mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fplan[b]);
       if (use_group && fplan[b].mode == 0) fplan[b].mode = 3;
+      const uint32_t low = rem_bits - top_bits[b];
+      narrow[b] = !hist_ahead && low < 32 && mgc::finish_can_stream(kw, low) && mgc::sort_plan_narrows(fplan[b], h_counts[b], kw);
     }
     tm.begin(MGC_STAGE_SORT);
     if (hist_ahead && s->stream2) {
@@ -1124,6 +1129,13 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       void *src = X + kbytes * h_starts[b];
       int in_alt = 0;
       hipEvent_t *pe = s->profiling ? &pass_ev[(size_t)b * ev_per_file] : nullptr;
+      if (narrow[b]) {                                       // X (8 B) -> Y (4 B) -> front of X (4 B); boundaries included
+        HIP_TRY(s, mgc::launch_group_narrow(src, (void *)Y, h_counts[b], fp, sort_ws, sort_ws_bytes - 256, d_err, d_substart + sbase[b], st, pe));
+        file_passes[b] = 2;
+        narrowed[b] = 1;
+        sort_launch_groups++;
+        continue;
+      }
       if (prepared[b]) HIP_TRY(s, hipStreamWaitEvent(st, s->hist_ev[b], 0));
       HIP_TRY(s, mgc::launch_radix_sort(src, (void *)Y, h_counts[b], kw, fp, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe,
                                         prepared[b] ? (void *)(d_hdrs + hdr_bytes * b) : nullptr));
@@ -1137,6 +1149,10 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     tm.begin(MGC_STAGE_RLE);
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0) continue;
+      if (narrow[b])
+        HIP_TRY(s, mgc::launch_subbucket_max(d_substart + sbase[b], kw, rem_bits - top_bits[b], top_bits[b], d_maxsub + b,
+                                             d_large + gbase[b], d_nlarge + b, d_nz + gbase[b], d_nzcount + b, st));
+      else
       HIP_TRY(s, mgc::launch_subbucket_bounds(X + kbytes * h_starts[b], h_counts[b], kw, rem_bits - top_bits[b], top_bits[b],
                                               d_substart + sbase[b], d_maxsub + b, d_large + gbase[b], d_nlarge + b,
                                               d_nz + gbase[b], d_nzcount + b, st));
@@ -1175,7 +1191,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       } else if (stream && h_maxsub[b] > mgc::finish_stream_max()) {
         uint32_t h_fail[3] = {0, 0, 0};                 // [0] answer, [2] most distinct suffixes met (diagnostics)
         HIP_TRY(s, hipMemsetAsync(d_err + 4, 0, 12, st));
-        HIP_TRY(s, mgc::launch_finish_probe(seg, kw, d_substart + sbase[b], low, h_nlarge[b], d_large + gbase[b], d_err + 4, st));
+        HIP_TRY(s, mgc::launch_finish_probe(seg, kw, d_substart + sbase[b], low, h_nlarge[b], d_large + gbase[b], d_err + 4, st, narrow[b] != 0));
         HIP_TRY(s, hipMemcpyAsync(h_fail, d_err + 4, 12, hipMemcpyDeviceToHost, st));
         HIP_TRY(s, hipStreamSynchronize(st));
         stream = (h_fail[0] == 0);
@@ -1186,6 +1202,14 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       } else if (getenv("MGC_FINISH_TRACE") && h_maxsub[b] > cap) {
         fprintf(stderr, "[finish] bucket %u: largest sub-bucket %llu > %llu: %s\n", b, (unsigned long long)h_maxsub[b],
                 (unsigned long long)cap, stream ? "streamed through the hash tables" : "stable-sort fallback");
+      }
+      if (narrow[b] && h_nlarge[b] > 0 && !stream) {
+        // an oversized sub-bucket that cannot be streamed: the LDS sort / the stable-sort fallback want whole k-mers back
+        if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));   // Y is the streaming kernels' second buffer
+        forked = false;
+        HIP_TRY(s, mgc::launch_widen_groups(seg, d_substart + sbase[b], gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, low, (void *)Y, st));
+        HIP_TRY(s, hipMemcpyAsync(seg, Y, kbytes * h_counts[b], hipMemcpyDeviceToDevice, st));
+        narrow[b] = 0;
       }
       if (h_maxsub[b] <= cap || stream) {
         const bool on_second = alt_files && (b & 1u);
@@ -1198,7 +1222,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
                                            d_large + gbase[b], d_cnt_tmp + h_starts[b], d_group + gbase[b], stream, (void *)Y, st_huge,
                                            // the list pays off only when a good part of the 2^t grid is empty
                                            (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b])) ? d_nz + gbase[b] : nullptr,
-                                           d_nzcount + b, on_second ? s->stream2 : st));
+                                           d_nzcount + b, on_second ? s->stream2 : st, narrow[b] != 0));
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
         fallback[b] = true;
@@ -1240,7 +1264,11 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0) continue;
       void *seg = X + kbytes * h_starts[b];
-      if (!fallback[b]) {
+      if (narrow[b]) {
+        HIP_TRY(s, mgc::launch_compact_groups_narrow(seg, d_cnt_tmp + h_starts[b], d_substart + sbase[b], d_group + gbase[b],
+                                                     gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, rem_bits - top_bits[b],
+                                                     s->d_unique, s->d_counts, st));
+      } else if (!fallback[b]) {
         HIP_TRY(s, mgc::launch_compact_groups(seg, kw, d_cnt_tmp + h_starts[b], d_substart + sbase[b], d_group + gbase[b],
                                               gbase[b + 1] - gbase[b], s->d_unique, s->d_counts, st));
       } else {
@@ -1280,6 +1308,11 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
           s->prof.sort_pass_ms_total += ms;
           s->prof.sort_pass_launches++;
           s->prof.sort_pass_keys += h_counts[b];
+          const int pi = p ? 1 : 0;
+          s->prof.pass_ms[pi] += ms;
+          s->prof.pass_launches[pi]++;
+          s->prof.pass_keys[pi] += h_counts[b];
+          s->prof.pass_bytes[pi] += h_counts[b] * ((size_t)b < narrowed.size() && narrowed[b] ? (p ? 8u : 12u) : 2u * kbytes);
         }
       }
     }

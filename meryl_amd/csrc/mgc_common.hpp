@@ -47,6 +47,14 @@ template <> struct KeyOps<u64> {
   static __device__ __forceinline__ u64  prefix_floor(u64 p, u32 w_data) { return p << w_data; }
   static __device__ __forceinline__ u64  low64(u64 k) { return k; }
 };
+// narrowed keys of the two-digit grouping path (mgc_sort.hip, launch_group_narrow): what is left of a k-mer once its
+// bucket and its first grouping digit are known from where it lies -- at most 32 bits
+template <> struct KeyOps<u32> {
+  static constexpr int WORDS = 1;
+  static __device__ __forceinline__ u32  digit(u32 k, u32 shift, u32 mask) { return (k >> shift) & mask; }
+  static __device__ __forceinline__ u32  pad() { return ~0u; }
+  static __device__ __forceinline__ bool ne(u32 a, u32 b) { return a != b; }
+};
 template <> struct KeyOps<K128> {
   static constexpr int WORDS = 2;
   static __device__ __forceinline__ u128 v(K128 k) { return ((u128)k.hi << 64) | (u128)k.lo; }

@@ -71,6 +71,13 @@ hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key
 size_t     sort_header_bytes();
 bool       sort_plan_groups(const SortPlan &plan, uint64_t n);
 hipError_t launch_group_prepare(const void *d_keys, uint64_t n, uint32_t key_words, const SortPlan &plan, void *d_hdr, hipStream_t st);
+// Two grouping passes with NARROWED keys: uint64 keys whose bits above the first digit fit 32 bits leave the first pass as
+// uint32 words without that digit (its value is where the key lies), the second pass and the finish move half the bytes,
+// and the sub-bucket boundaries fall out of the second pass's look-back granules.  d_keys: uint64[n] in, uint32[n] out
+// (over its first half); d_alt: room for n uint32; d_sub_starts: 2^(pass_bits[0] + pass_bits[1]) + 1 entries.
+bool       sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words);
+hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
+                               uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events /* 4 or null */);
 
 // ---- run-length count ------------------------------------------------------
 size_t     rle_workspace_bytes(uint64_t n);
@@ -90,21 +97,31 @@ hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_
                                    uint64_t *d_large_count /*zeroed by the caller*/,
                                    uint32_t *d_nonempty_list /*[2^top]*/, uint64_t *d_nonempty_count /*zeroed by the caller*/,
                                    hipStream_t st);
+hipError_t launch_subbucket_max(const uint64_t *d_starts, uint32_t key_words, uint32_t low, uint32_t top_bits, uint64_t *d_max,
+                                uint32_t *d_large_list, uint64_t *d_large_count, uint32_t *d_nonempty_list, uint64_t *d_nonempty_count,
+                                hipStream_t st);          // the list half of launch_subbucket_bounds (boundaries already known)
 // sub-buckets above finish_capacity_for(): can they be streamed through the hash-count tables (distinct suffixes fit)?
 bool       finish_can_stream(uint32_t key_words, uint32_t low_bits);
 uint64_t   finish_stream_max();     // sub-buckets up to this many keys are streamed without asking the probe
 hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint32_t low_bits,
-                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_file_fail /*set to 1: no*/, hipStream_t st);
+                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_file_fail /*set to 1: no*/, hipStream_t st,
+                               bool narrow = false /*d_keys: uint32 narrowed keys*/);
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
                               bool stream /*large list -> streaming hash-count*/, void *d_alt /*room for the file's keys*/,
                               hipStream_t st_huge /*where that kernel is launched (st, or a stream forked from it)*/,
                               const uint32_t *d_nonempty_list, const uint64_t *d_nonempty_count /*the hash kernels visit only these;
-                              d_group_distinct must be zero for the others*/, hipStream_t st);
+                              d_group_distinct must be zero for the others*/, hipStream_t st,
+                              bool narrow = false /*d_keys/d_alt: uint32 narrowed keys; the distinct SUFFIXES go back in place*/);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);
 hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,
                                  const uint64_t *d_offs, uint64_t ng, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st);
+// narrowed files: k-mer = base | sub-bucket << low_bits | suffix
+hipError_t launch_compact_groups_narrow(const void *d_keys32, const uint32_t *d_cnt_tmp, const uint64_t *d_starts, const uint64_t *d_offs,
+                                        uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st);
+hipError_t launch_widen_groups(const void *d_keys32, const uint64_t *d_starts, uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out64,
+                               hipStream_t st);
 hipError_t launch_store_u64(uint64_t *d_dst, const uint64_t *d_src, hipStream_t st);
 
 hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,

@@ -397,7 +397,9 @@ void lds_sort_count_kernel(K *__restrict__ keys,                      // the fil
 // (one 64-bit CAS + one add per key, independent per key => the LDS latency overlaps), compacts
 // the D distinct entries and ranks them by brute force (D^2 / BLOCK broadcast compares; D ~ n/7).
 // EMPTY cannot collide with a key: every key of the file shares its top six bits, ~key0 does not.
-template <int BLOCK, int CAP, int SLOTS, bool DBG, bool LIST>
+// NARROW: the sub-buckets hold 32-bit narrowed keys (launch_group_narrow) -- u32 loads, and the distinct SUFFIXES go back
+// in place as u32 (compact_groups_narrow_kernel puts the prefix back when it packs the result).
+template <int BLOCK, int CAP, int SLOTS, bool DBG, bool LIST, bool NARROW = false>
 __global__ __launch_bounds__(BLOCK, 5)
 void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                        u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
@@ -427,11 +429,12 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
       const u32 idx = (u32)j * BLOCK + tid;
-      kr[j] = (nn <= max_size && idx < nn) ? reinterpret_cast<const u32 *>(keys + aa + idx)[0] : 0u;
+      if constexpr (NARROW) kr[j] = (nn <= max_size && idx < nn) ? reinterpret_cast<const u32 *>(keys)[aa + idx] : 0u;
+      else                  kr[j] = (nn <= max_size && idx < nn) ? reinterpret_cast<const u32 *>(keys + aa + idx)[0] : 0u;
     }
   };
   const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
-  const u64 file_base = (keys[0] >> group_shift) << group_shift;
+  const u64 file_base = NARROW ? 0ull : (keys[0] >> group_shift) << group_shift;
 
   // visit only the NON-EMPTY sub-buckets (list built by subbucket_max_kernel): a sparse key space (homopolymer-
   // compressed k-mers, small k) leaves most of the 2^t grid empty, and an empty visit still costs a memory round trip
@@ -545,7 +548,8 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
           r3 += (v3.x < ki ? 1u : 0u) + (v3.y < ki ? 1u : 0u) + (v3.z < ki ? 1u : 0u) + (v3.w < ki ? 1u : 0u);
         }
         const u32 r = r0 + r1 + r2 + r3;
-        gk[r] = prefix | (u64)ki;                      // in place: every key of this region sits in registers
+        if constexpr (NARROW) reinterpret_cast<u32 *>(keys)[a + r] = ki;
+        else                  gk[r] = prefix | (u64)ki;  // in place: every key of this region sits in registers
         cnt_tmp[a + r] = dc[i];
       }
       if (tid == 0) group_distinct[g] = D;
@@ -1106,11 +1110,12 @@ __device__ __forceinline__ void rank_below128(const u64 *dlo, const u64 *dhi, u3
 // of the suffixes the table then holds (a fair sample: the keys of a sub-bucket are in input order) and retried.  Later
 // passes still need the keys, so multi-pass output goes to alt[] (the sort's second buffer, free at this point) and is
 // copied back at the end.
-template <typename S, int BLOCK, int CAP, int SLOTS>
+// KT = u32: narrowed keys in (launch_group_narrow), distinct suffixes out (u32, no prefix).
+template <typename S, int BLOCK, int CAP, int SLOTS, typename KT = u64>
 __global__ __launch_bounds__(BLOCK)
-void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
+void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
                             u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                            u64 *__restrict__ alt) {
+                            KT *__restrict__ alt) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && (CAP & (CAP - 1)) == 0 && SLOTS >= CAP * 2 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0,
                 "table geometry");
   constexpr int KPT = 4, SPT = SLOTS / BLOCK;
@@ -1130,9 +1135,9 @@ void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ star
   if (n64 <= huge_min) return;
   const u64 low_mask = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
   const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);
-  const u64 prefix = ((keys[0] >> group_shift) << group_shift) | (g << low_bits);
+  const u64 prefix = (sizeof(KT) == 8) ? ((((u64)keys[0] >> group_shift) << group_shift) | (g << low_bits)) : 0ull;
   constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
-  u64 *gk = keys + a;
+  KT *gk = keys + a;
   const u64 rounds = (n64 + (u64)BLOCK * KPT - 1) / ((u64)BLOCK * KPT);
   u64 lo = 0, hi = low_mask;                           // suffix range of this pass, inclusive
   u64 out = 0;                                         // distinct k-mers written by the passes before
@@ -1146,13 +1151,13 @@ void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ star
     // would hide the memory round trip)
     u64 raw[KPT];
 #pragma unroll
-    for (int j = 0; j < KPT; j++) { const u64 idx = (u64)j * BLOCK + tid; raw[j] = (idx < n64) ? gk[idx] : 0ull; }
+    for (int j = 0; j < KPT; j++) { const u64 idx = (u64)j * BLOCK + tid; raw[j] = (idx < n64) ? (u64)gk[idx] : 0ull; }
     for (u64 base = 0, rd = 0; base < n64; base += (u64)BLOCK * KPT, rd++) {
       u64 nxt[KPT];
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
         const u64 idx = base + (u64)BLOCK * KPT + (u64)j * BLOCK + tid;
-        nxt[j] = (idx < n64) ? gk[idx] : 0ull;
+        nxt[j] = (idx < n64) ? (u64)gk[idx] : 0ull;
       }
       S   kk[KPT];
       u32 hh[KPT], pending = 0;
@@ -1244,7 +1249,7 @@ void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ star
     __syncthreads();
     // one pass over everything: every key of the sub-bucket went through the table, the output can go in place
     in_place = (lo == 0 && hi == low_mask);
-    u64 *dst = in_place ? gk : alt + a;
+    KT *dst = in_place ? gk : alt + a;
     if (D > (u32)BLOCK) {
       u32 N = 2 * BLOCK;
       while (N < D) N <<= 1;                           // <= CAP, a power of two
@@ -1254,7 +1259,7 @@ void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ star
                               [&](u32 x, u32 y) { const S t = dk[x]; dk[x] = dk[y]; dk[y] = t;
                                                   const u32 c = dc[x]; dc[x] = dc[y]; dc[y] = c; });
       for (u32 i = tid; i < D; i += BLOCK) {
-        dst[out + i] = prefix | (u64)dk[i];
+        dst[out + i] = (KT)(prefix | (u64)dk[i]);
         cnt_tmp[a + out + i] = dc[i];
       }
     } else {
@@ -1268,7 +1273,7 @@ void hash_count_huge_kernel(u64 *__restrict__ keys, const u64 *__restrict__ star
         const u32 i = (u32)q * BLOCK + tid;
         if (i < D) {
           const u64 r = out + rs[q];
-          dst[r] = prefix | (u64)ks[q];
+          dst[r] = (KT)(prefix | (u64)ks[q]);
           cnt_tmp[a + r] = dc[i];
         }
       }
@@ -1485,9 +1490,9 @@ void hash_count128_huge_kernel(K128 *__restrict__ keys, const u64 *__restrict__ 
 // large-sub-bucket list streams its keys through a table that only stores suffixes (no counts, nothing written back) and
 // raises *file_fail if more than CAP distinct ones turn up.  Run BEFORE the finish kernels touch the file, because the
 // alternative for such a file (stable sort of all its bits) needs its k-mers intact.
-template <typename S, int BLOCK, int CAP, int SLOTS>
+template <typename S, int BLOCK, int CAP, int SLOTS, typename KT = u64>
 __global__ __launch_bounds__(BLOCK)
-void hash_probe_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list,
+void hash_probe_kernel(const KT *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list,
                        u64 huge_min, u32 low_bits, u32 *__restrict__ file_fail) {
   constexpr int KPT = CAP / BLOCK;
   const S EMPTY = ~(S)0;
@@ -1508,7 +1513,7 @@ void hash_probe_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ sta
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
       const u64 idx = base + (u64)j * BLOCK + tid;
-      kk[j] = (idx < n64) ? (S)(keys[a + idx] & low_mask) : (S)0;
+      kk[j] = (idx < n64) ? (S)((u64)keys[a + idx] & low_mask) : (S)0;
       hh[j] = (u32)(((u64)kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
       if (idx < n64) pending |= 1u << j;
     }
@@ -1546,6 +1551,32 @@ void compact_groups_kernel(const K *__restrict__ keys, const u32 *__restrict__ c
   }
 }
 
+// narrowed files: the finish left 32-bit suffixes; the k-mer is  base | sub-bucket << low_bits | suffix
+__global__ __launch_bounds__(256)
+void compact_groups_narrow_kernel(const u32 *__restrict__ keys32, const u32 *__restrict__ cnt_tmp, const u64 *__restrict__ starts,
+                                  const u64 *__restrict__ offs, u64 ng, u64 base, u32 low_bits, u64 *__restrict__ out_keys,
+                                  u32 *__restrict__ out_counts) {
+  const u64 g = (u64)blockIdx.x * 4 + wave_id();
+  if (g >= ng) return;
+  const u64 dst = offs[g], d = offs[g + 1] - dst, src = starts[g], pre = base | (g << low_bits);
+  for (u64 i = lane_id(); i < d; i += 64) {
+    out_keys[dst + i]   = pre | (u64)keys32[src + i];
+    out_counts[dst + i] = cnt_tmp[src + i];
+  }
+}
+
+// back to whole k-mers (a narrowed file that turns out to need a path that wants them: the LDS sort of an oversized
+// sub-bucket, the stable-sort fallback)
+__global__ __launch_bounds__(256)
+void widen_groups_kernel(const u32 *__restrict__ keys32, const u64 *__restrict__ starts, u64 ng, u64 base, u32 low_bits,
+                         u64 *__restrict__ out) {
+  const u64 g = (u64)blockIdx.x * 4 + wave_id();
+  if (g >= ng) return;
+  const u64 a = starts[g], e = starts[g + 1], pre = base | (g << low_bits);
+  const u32 low_mask = (low_bits >= 32) ? ~0u : ((1u << low_bits) - 1u);
+  for (u64 i = a + lane_id(); i < e; i += 64) out[i] = pre | (u64)(keys32[i] & low_mask);
+}
+
 __global__ void store_u64_kernel(u64 *__restrict__ dst, const u64 *__restrict__ src) { *dst = *src; }
 
 constexpr u64 FIN_CAP_SMALL = 256 * 16, FIN_CAP_LARGE = 1024 * 8;   // LDS: 46 KiB and 91 KiB per workgroup
@@ -1578,6 +1609,13 @@ hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_
     hipLaunchKernelGGL(subbucket_bounds_kernel<u64>, grid, dim3(256), 0, st, reinterpret_cast<const u64 *>(d_keys),
                        (u64)n, low, tmask, (u64)ng, reinterpret_cast<u64 *>(d_starts));
   MGC_CHECK(hipGetLastError());
+  return launch_subbucket_max(d_starts, key_words, low, top_bits, d_max, d_list, d_list_count, d_nz, d_nz_count, st);
+}
+
+// the second half of launch_subbucket_bounds on its own: for files whose boundaries came with the grouping passes
+hipError_t launch_subbucket_max(const uint64_t *d_starts, uint32_t key_words, uint32_t low, uint32_t top_bits, uint64_t *d_max,
+                                uint32_t *d_list, uint64_t *d_list_count, uint32_t *d_nz, uint64_t *d_nz_count, hipStream_t st) {
+  const uint64_t ng = (uint64_t)1 << top_bits;
   hipLaunchKernelGGL(subbucket_max_kernel, dim3((uint32_t)((ng + 255) / 256)), dim3(256), 0, st,
                      reinterpret_cast<const u64 *>(d_starts), (u64)ng, reinterpret_cast<u64 *>(d_max),
                      (u64)finish_small_capacity(key_words, low), d_list, reinterpret_cast<u64 *>(d_list_count),
@@ -1640,8 +1678,15 @@ uint64_t finish_stream_max() {
 }
 
 hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint32_t low_bits,
-                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_file_fail, hipStream_t st) {
+                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_file_fail, hipStream_t st, bool narrow) {
   if (n_large == 0 || key_words != 1) return hipSuccess;
+  if (narrow) {
+    if (low_bits >= 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((hash_probe_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32, u32>), dim3((uint32_t)n_large), dim3(1024), 0, st,
+                       reinterpret_cast<const u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list,
+                       (u64)finish_stream_max(), low_bits, d_file_fail);
+    return hipGetLastError();
+  }
   if (low_bits < 32)
     hipLaunchKernelGGL((hash_probe_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>), dim3((uint32_t)n_large), dim3(1024), 0, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list,
@@ -1658,8 +1703,39 @@ hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uin
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
                               bool stream, void *d_alt, hipStream_t st_huge, const uint32_t *d_nz, const uint64_t *d_nz_count,
-                              hipStream_t st) {
+                              hipStream_t st, bool narrow) {
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
+  if (narrow) {
+    // narrowed keys (u32): the 32-bit hash-count kernel and the streaming kernel have u32-storage instantiations; anything
+    // else wants whole k-mers -- the caller widens the file first (launch_widen_groups)
+    if (key_words != 1 || low_bits >= 32 || !finish_uses_hash(key_words, low_bits) || (n_large && !stream)) return hipErrorInvalidValue;
+    static const uint32_t hgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 10u;
+    const uint32_t hgrid = ng < hgrid_max ? (uint32_t)ng : hgrid_max;
+    if (d_nz)
+      hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, true>), dim3(hgrid), dim3(256), 0, st,
+                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, (u64 *)nullptr);
+    else
+      hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, true>), dim3(hgrid), dim3(256), 0, st,
+                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, (u64 *)nullptr);
+    MGC_CHECK(hipGetLastError());
+    if (n_large) {
+      constexpr size_t B32 = (size_t)(4 + 4) * HUGE_SLOTS32 + (size_t)(4 + 4) * HUGE_CAP32 + 16 * 4;
+      static bool nattr = false;
+      if (!nattr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32, u32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)B32);
+        nattr = true;
+      }
+      hipLaunchKernelGGL((hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32, u32>), dim3((uint32_t)n_large), dim3(1024), B32, st_huge,
+                         reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
+                         (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                         reinterpret_cast<u32 *>(d_alt));
+      MGC_CHECK(hipGetLastError());
+    }
+    return hipSuccess;
+  }
   if (key_words == 2 && finish_uses_hash(key_words, low_bits)) {
     static const uint32_t wgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 4u;     // four workgroups per CU
     const uint32_t wgrid = ng < wgrid_max ? (uint32_t)ng : wgrid_max;
@@ -1798,6 +1874,21 @@ hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const u
     hipLaunchKernelGGL(compact_groups_kernel<u64>, grid, dim3(256), 0, st, reinterpret_cast<const u64 *>(d_keys), d_cnt_tmp,
                        reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng,
                        reinterpret_cast<u64 *>(d_out_keys), d_out_counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_compact_groups_narrow(const void *d_keys32, const uint32_t *d_cnt_tmp, const uint64_t *d_starts, const uint64_t *d_offs,
+                                        uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st) {
+  hipLaunchKernelGGL(compact_groups_narrow_kernel, dim3((uint32_t)((ng + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const u32 *>(d_keys32),
+                     d_cnt_tmp, reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng, (u64)base, low_bits,
+                     reinterpret_cast<u64 *>(d_out_keys), d_out_counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_widen_groups(const void *d_keys32, const uint64_t *d_starts, uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out64,
+                               hipStream_t st) {
+  hipLaunchKernelGGL(widen_groups_kernel, dim3((uint32_t)((ng + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const u32 *>(d_keys32),
+                     reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)base, low_bits, reinterpret_cast<u64 *>(d_out64));
   return hipGetLastError();
 }
 

@@ -21,6 +21,8 @@
 // the datum is the flag).  Wave = 64 everywhere.
 #include "mgc_common.hpp"
 
+#include <algorithm>
+
 namespace mgc {
 
 // ============================================================================
@@ -685,14 +687,20 @@ void group_regions_kernel(const u64 *__restrict__ gbase_prev, u64 n, u32 tile, u
   if (r == 0) { region_start[RS_MAX_RADIX] = n; region_tiles[RS_MAX_RADIX] = total; }
 }
 
-template <typename K, int RB, int BLOCK, int KPT, bool DBG>
+// NARROW (u64 keys only): the keys leave as 32-bit words WITHOUT the digit of this pass -- ((key >> (shift + digit_bits))
+// << shift) | low `shift` bits -- because where a key lies now tells its digit (launch_group_narrow): every later pass and
+// the finish move half the bytes.
+template <typename K, bool NARROW> struct GroupOut { typedef K type; };
+template <> struct GroupOut<u64, true> { typedef u32 type; };
+
+template <typename K, int RB, int BLOCK, int KPT, bool DBG, bool NARROW = false>
 __global__ __launch_bounds__(BLOCK, (GroupSmem<K, RB, BLOCK, KPT>::MIN_WAVES_PER_SIMD))
-void radix_group_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, u32 shift, u32 dmask,
+void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::type *__restrict__ out, u64 n, u32 shift, u32 dmask,
                         const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
                         u32 *__restrict__ error_flag, u64 num_tiles_plain,
                         const u64 *__restrict__ region_start,   // [RS_MAX_RADIX + 1] or nullptr (plain tiles)
                         const u32 *__restrict__ region_tiles,   // [RS_MAX_RADIX + 1] exclusive; last = total tiles
-                        u32 /*flags*/, u64 *__restrict__ dbg) {
+                        u32 digit_bits /* NARROW only */, u64 *__restrict__ dbg) {
   using SM = GroupSmem<K, RB, BLOCK, KPT>;
   using KO = KeyOps<K>;
   constexpr int R = SM::R, TILE = SM::TILE, G = R / 2;
@@ -861,7 +869,8 @@ void radix_group_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, u3
       if (i < nv) {
         const K   key = s_keys[i];
         const u32 d   = KO::digit(key, shift, dmask);
-        out[s_gbase[d] + (u64)i] = key;
+        if constexpr (NARROW) out[s_gbase[d] + (u64)i] = (u32)((key >> (shift + digit_bits)) << shift) | ((u32)key & ((1u << shift) - 1u));
+        else                  out[s_gbase[d] + (u64)i] = key;
       }
     }
     PK_STAMP(4);
@@ -1163,6 +1172,87 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
   }
   *result_in_alt = in_alt;
   return hipSuccess;
+}
+
+// ---- two grouping passes with narrowed keys (the finish path of k-mers that leave <= 32 bits below their first digit) ----
+// Sub-bucket v = (digit of pass 1 : digit of pass 0).  Pass 1's tiles never mix two pass-0 digits (regions), its output is
+// ordered by (pass-1 digit, tile), so sub-bucket v starts at  gbase1[d1] + the inclusive prefix of d1 at the last tile
+// before region d0  -- which is exactly what the look-back granules of pass 1 hold once the pass is over: the boundaries
+// come for free, no key has to be looked at (the keys do not even hold d0 any more).
+__global__ void narrow_bounds_kernel(const u64 *__restrict__ status, const u32 *__restrict__ region_tiles,
+                                     const u64 *__restrict__ gbase1, u64 n, u32 b0, u64 ng, u64 *__restrict__ starts) {
+  const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > ng) return;
+  if (v == ng) { starts[v] = n; return; }
+  const u32 d1 = (u32)(v >> b0), d0 = (u32)v & ((1u << b0) - 1u);
+  const u32 tiles_before = region_tiles[d0];
+  u64 before = 0;
+  if (tiles_before) {
+    const u64 g = status[(u64)(tiles_before - 1) * (RS_MAX_RADIX / 2) + (d1 >> 1)];
+    before = (u64)(((d1 & 1u) ? (u32)(g >> 32) : (u32)g) & 0x3FFFFFFFu);
+  }
+  starts[v] = gbase1[d1] + before;
+}
+
+bool sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words) {
+  const char *e = getenv("MGC_NARROW");                     // read per call: the tests switch it
+  const bool on = !(e && e[0] == '0');
+  return on && key_words == 1 && plan.mode == 3 && !plan.hpc && plan.num_passes == 2 && plan.radix_bits == 9 && n > 0 && n < (1ull << 30) &&
+         plan.pass_shift[1] == plan.pass_shift[0] + plan.pass_bits[0] && plan.pass_shift[0] + plan.pass_bits[1] <= 32;
+}
+
+// d_keys: u64[n] in; u32[n] out over its first half (grouped by the plan's two digits, each key = (bits above digit 0)
+// << pass_shift[0] | the low pass_shift[0] bits, truncated to 32 bits).  d_alt: room for n u32.  d_sub_starts: 2^(b0+b1) + 1.
+hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
+                               uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events) {
+  if (!sort_plan_narrows(plan, n, 1) || ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
+  constexpr int RB = 9, BLOCK = 1024, KPT0 = 16, KPT1 = 32, R = 1 << RB;
+  using GS0 = GroupSmem<u64, RB, BLOCK, KPT0>;
+  using GS1 = GroupSmem<u32, RB, BLOCK, KPT1>;
+  constexpr uint64_t TILE0 = (uint64_t)BLOCK * KPT0, TILE1 = (uint64_t)BLOCK * KPT1;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u32, RB, BLOCK, KPT1, false, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS1::BYTES);
+    attr_done = true;
+  }
+  SortHeader *hdr = reinterpret_cast<SortHeader *>(d_ws);
+  unsigned char *body = reinterpret_cast<unsigned char *>(d_ws) + ((sizeof(SortHeader) + 255) / 256) * 256;
+  const uint64_t tiles0 = (n + TILE0 - 1) / TILE0, tiles1_max = (n + TILE1 - 1) / TILE1 + RS_MAX_RADIX + 1;
+  u64 *status = reinterpret_cast<u64 *>(body);
+  const size_t status_bytes = (size_t)std::max(tiles0, tiles1_max) * (R / 2) * sizeof(u64);
+  u64 *region_start = reinterpret_cast<u64 *>(body + ((status_bytes + 255) / 256) * 256);
+  u32 *region_tiles = reinterpret_cast<u32 *>(region_start + RS_MAX_RADIX + 1);
+  const u32 s0 = plan.pass_shift[0], b0 = plan.pass_bits[0], b1 = plan.pass_bits[1];
+  MGC_CHECK(group_prepare<u64>(reinterpret_cast<const u64 *>(d_keys), n, plan, hdr, st));
+  const uint64_t cus = (uint64_t)device_cu_count();
+
+  MGC_CHECK(hipMemsetAsync(status, 0, (size_t)tiles0 * (R / 2) * sizeof(u64), st));
+  if (pass_events) MGC_CHECK(hipEventRecord(pass_events[0], st));
+  hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true>), dim3((uint32_t)std::min(tiles0, cus * GS0::WG_PER_CU)), dim3(BLOCK),
+                     GS0::BYTES, st, reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, s0, (1u << b0) - 1u,
+                     &hdr->gbase[0][0], status, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                     b0, (u64 *)nullptr);
+  MGC_CHECK(hipGetLastError());
+  if (pass_events) MGC_CHECK(hipEventRecord(pass_events[1], st));
+
+  hipLaunchKernelGGL(group_regions_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, &hdr->gbase[0][0], (u64)n, (u32)TILE1, region_start, region_tiles);
+  MGC_CHECK(hipGetLastError());
+  MGC_CHECK(hipMemsetAsync(status, 0, (size_t)tiles1_max * (R / 2) * sizeof(u64), st));
+  if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2], st));
+  hipLaunchKernelGGL((radix_group_kernel<u32, RB, BLOCK, KPT1, false, false>), dim3((uint32_t)std::min(tiles1_max, cus * GS1::WG_PER_CU)), dim3(BLOCK),
+                     GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, s0, (1u << b1) - 1u,
+                     &hdr->gbase[1][0], status, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
+                     0u, (u64 *)nullptr);
+  MGC_CHECK(hipGetLastError());
+  if (pass_events) MGC_CHECK(hipEventRecord(pass_events[3], st));
+
+  const u64 ng = (u64)1 << (b0 + b1);
+  hipLaunchKernelGGL(narrow_bounds_kernel, dim3((uint32_t)((ng + 1 + 255) / 256)), dim3(256), 0, st, status, region_tiles,
+                     &hdr->gbase[1][0], (u64)n, b0, ng, reinterpret_cast<u64 *>(d_sub_starts));
+  return hipGetLastError();
 }
 
 size_t sort_header_bytes() { return ((sizeof(SortHeader) + 255) / 256) * 256; }

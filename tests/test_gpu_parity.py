@@ -1088,9 +1088,37 @@ def test_large_input_partition_granularity(ops, oracle_lib, torch_cuda, monkeypa
     assert np.array_equal(np.asarray(info.file_instances, dtype=np.int64), inst_per_file)
 
 
+@pytest.mark.parametrize("k,target,narrow", [(21, 1, "1"), (21, 1, "0"), (21, 6, "1"), (19, 3, "1"), (22, 2, "1"), (24, 2, "1"), (26, 2, "1"), (16, 1, "1")])
+def test_narrowed_grouping_passes(ops, oracle_lib, torch_cuda, monkeypatch, k, target, narrow):
+    """Two grouping digits on a small input (MGC_FINISH_TARGET makes the sub-buckets tiny, so the plan needs 15-17 top bits):
+    k <= ~25 then takes the NARROWED passes -- the first pass drops its digit and writes 32-bit words, the second groups those,
+    the sub-bucket boundaries come from its look-back granules, the hash-count reads and writes u32 and the packing step
+    puts the prefixes back -- and must give the oracle's stream, like the wide passes (MGC_NARROW=0; k=26 leaves 34 bits
+    below the first digit and stays wide by itself)."""
+    from meryl_amd import capi
+    monkeypatch.setenv("MGC_FINISH_TARGET", str(target))
+    monkeypatch.setenv("MGC_NARROW", narrow)
+    bases = oracle_lib.synth_reads(200 + k, 300_000, 0, 40_000)
+    for mode in (0, 1):
+        cfg = capi.configure(k, bases.size, 1 << 30, mode)
+        cfg.use_simple = 0
+        with ops.Session(cfg) as s:
+            s.set_profiling(True)
+            s.push_bases_device(torch_cuda.from_numpy(bases).cuda())
+            s.count()
+            klo, khi, counts, bstart = s.result_wide()
+            prof = s.profile()
+            info = s.info()
+        whi, wlo, wcn, wni = oracle_lib.count_threaded(bases.tobytes(), k, cfg.w_prefix, mode, threads=8)
+        assert info.n_instances == wni
+        assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+        assert prof.sort_pass_launches > 100                        # two passes for (nearly) every file
+
+
+@pytest.mark.parametrize("target", [None, 8])
 @pytest.mark.parametrize("stream_max", [None, 20_000])
 @pytest.mark.parametrize("k", [21, 25, 31, 35, 51])
-def test_oversized_subbuckets_stream_in_ranges(ops, oracle_lib, torch_cuda, monkeypatch, k, stream_max):
+def test_oversized_subbuckets_stream_in_ranges(ops, oracle_lib, torch_cuda, monkeypatch, k, stream_max, target):
     # sub-buckets above every LDS capacity, each a cluster of k-mers sharing a long prefix: (a) 30,000 instances of 900
     # distinct k-mers -> one pass through the streaming hash table; (b) 30,000 instances of ~25,000 distinct ones and
     # (c) 120,000 of ~60,000 -> several passes over suffix ranges, shrunk and widened as the table fills; (d) one k-mer
@@ -1101,6 +1129,10 @@ def test_oversized_subbuckets_stream_in_ranges(ops, oracle_lib, torch_cuda, monk
     from meryl_amd import capi
     if stream_max is not None:
         monkeypatch.setenv("MGC_STREAM_MAX", str(stream_max))
+    if target is not None:                                  # two grouping digits: k=21 takes the narrowed passes, whose streaming
+        if k not in (21, 25):                               # kernel and probe read 32-bit words and whose refused files are widened
+            pytest.skip("the narrowed passes are a k <= 25 matter")
+        monkeypatch.setenv("MGC_FINISH_TARGET", str(target))
     rng = np.random.default_rng(k)
     plen = min(20, k - 10)
     def cluster(prefix, n_inst, n_distinct):
