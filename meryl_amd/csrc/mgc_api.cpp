@@ -930,8 +930,18 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   uint64_t *d_counts64 = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_META].p), *d_starts = d_counts64 + nb;
   std::vector<uint64_t> h_counts_v(nb), h_starts_v(nb + 1);
   uint64_t *h_counts = h_counts_v.data(), *h_starts = h_starts_v.data();
+  // The narrowed grouping passes (k <= ~25, below) group a file by its TOP digit first when that digit's histogram is at
+  // hand: the file histogram then counts fifteen top bits instead of six (one kernel, same read of the bases) and the
+  // 8 B/k-mer digit-histogram read of every file goes away.
+  const uint64_t *d_fine = nullptr;
   if (!ext_keys) {
     tm.begin(MGC_STAGE_HISTOGRAM);
+    if (kw == 1 && n_bases >= (1u << 22) && mgc::kmer_histogram_fine_ok(k, bucket_bits, s->sfx_mask)) {
+      HIP_TRY(s, s->ensure(mgc_session::B_FINE, sizeof(uint64_t) << 15));
+      uint64_t *fine = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_FINE].p);
+      HIP_TRY(s, mgc::launch_kmer_histogram_fine(d_bases, n_bases, k, c.mode, d_counts64, fine, part_ws, st));
+      d_fine = fine;
+    } else
     HIP_TRY(s, mgc::launch_kmer_histogram(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, part_ws, st, s->sfx_mask, s->sfx_test));
     tm.end(MGC_STAGE_HISTOGRAM);
     s->prof.stage_launches[MGC_STAGE_HISTOGRAM] = 1;
@@ -1095,6 +1105,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     std::vector<char> prepared(nb, 0);
     // narrow[b]: the file's k-mers travel as 32-bit words from the first grouping pass on (mgc::launch_group_narrow)
     std::vector<char> narrow(nb, 0);
+    std::vector<uint32_t> tr_a(nb, 0), tr_b(nb, 0);        // ... and in which order its sub-buckets lie (mgc::tr_index)
     const size_t hdr_bytes = mgc::sort_header_bytes();
     unsigned char *d_hdrs = nullptr;
     for (uint32_t b = 0; b < nb; b++) {
@@ -1130,7 +1141,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       int in_alt = 0;
       hipEvent_t *pe = s->profiling ? &pass_ev[(size_t)b * ev_per_file] : nullptr;
       if (narrow[b]) {                                       // X (8 B) -> Y (4 B) -> front of X (4 B); boundaries included
-        HIP_TRY(s, mgc::launch_group_narrow(src, (void *)Y, h_counts[b], fp, sort_ws, sort_ws_bytes - 256, d_err, d_substart + sbase[b], st, pe));
+        HIP_TRY(s, mgc::launch_group_narrow(src, (void *)Y, h_counts[b], fp, sort_ws, sort_ws_bytes - 256, d_err, d_substart + sbase[b], st, pe,
+                                            d_fine ? d_fine + (size_t)b * 512 : nullptr, &tr_a[b], &tr_b[b]));
         file_passes[b] = 2;
         narrowed[b] = 1;
         sort_launch_groups++;
@@ -1203,15 +1215,18 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         fprintf(stderr, "[finish] bucket %u: largest sub-bucket %llu > %llu: %s\n", b, (unsigned long long)h_maxsub[b],
                 (unsigned long long)cap, stream ? "streamed through the hash tables" : "stable-sort fallback");
       }
+      bool unordered = false;
       if (narrow[b] && h_nlarge[b] > 0 && !stream) {
         // an oversized sub-bucket that cannot be streamed: the LDS sort / the stable-sort fallback want whole k-mers back
         if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));   // Y is the streaming kernels' second buffer
         forked = false;
-        HIP_TRY(s, mgc::launch_widen_groups(seg, d_substart + sbase[b], gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, low, (void *)Y, st));
+        HIP_TRY(s, mgc::launch_widen_groups(seg, d_substart + sbase[b], gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, low, (void *)Y, st,
+                                            tr_a[b], tr_b[b]));
         HIP_TRY(s, hipMemcpyAsync(seg, Y, kbytes * h_counts[b], hipMemcpyDeviceToDevice, st));
         narrow[b] = 0;
+        unordered = tr_a[b] != 0;      // grouped, but not in key order: only the stable sort of all bits can take it from here
       }
-      if (h_maxsub[b] <= cap || stream) {
+      if ((h_maxsub[b] <= cap || stream) && !unordered) {
         const bool on_second = alt_files && (b & 1u);
         if ((stream || on_second) && fork_huge && !forked) {   // everything the forked kernels read is complete at this point of st
           HIP_TRY(s, hipEventRecord(s->ev_fork, st));
@@ -1222,13 +1237,13 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
                                            d_large + gbase[b], d_cnt_tmp + h_starts[b], d_group + gbase[b], stream, (void *)Y, st_huge,
                                            // the list pays off only when a good part of the 2^t grid is empty
                                            (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b])) ? d_nz + gbase[b] : nullptr,
-                                           d_nzcount + b, on_second ? s->stream2 : st, narrow[b] != 0));
+                                           d_nzcount + b, on_second ? s->stream2 : st, narrow[b] != 0, tr_a[b], tr_b[b]));
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
         fallback[b] = true;
         if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));  // the sort below uses Y, the streaming kernels' second buffer
         forked = false;                                            // ... and the next streaming kernel must wait for that sort
-        if (low) {
+        if (low || unordered) {
           // LSD order: the low bits cannot be sorted after the top bits, so the whole key is redone
           mgc::SortPlan lp;
           mgc::make_sort_plan(0, rem_bits, &lp);
@@ -1267,7 +1282,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (narrow[b]) {
         HIP_TRY(s, mgc::launch_compact_groups_narrow(seg, d_cnt_tmp + h_starts[b], d_substart + sbase[b], d_group + gbase[b],
                                                      gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, rem_bits - top_bits[b],
-                                                     s->d_unique, s->d_counts, st));
+                                                     s->d_unique, s->d_counts, st, tr_a[b], tr_b[b]));
       } else if (!fallback[b]) {
         HIP_TRY(s, mgc::launch_compact_groups(seg, kw, d_cnt_tmp + h_starts[b], d_substart + sbase[b], d_group + gbase[b],
                                               gbase[b + 1] - gbase[b], s->d_unique, s->d_counts, st));

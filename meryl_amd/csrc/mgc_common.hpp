@@ -72,6 +72,10 @@ template <> struct KeyOps<K128> {
   static __device__ __forceinline__ u64  low64(K128 k) { return k.lo; }
 };
 
+// Sub-bucket index of a narrowed file in PHYSICAL order -> the top bits its k-mers hold (launch_group_narrow: with the high
+// digit first the file ends up ordered by (low digit : high digit)); a = 0: the same thing.
+__device__ __forceinline__ u64 tr_index(u64 p, u32 a, u32 b) { return a ? (((p & ((1ull << a) - 1ull)) << b) | (p >> a)) : p; }
+
 #define MGC_CHECK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return e__; } while (0)
 
 // ============================================================================

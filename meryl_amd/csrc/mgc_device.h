@@ -19,6 +19,10 @@ uint32_t kp_grid_size(uint64_t n_bases);
 size_t   kp_workspace_bytes(uint32_t bucket_bits);
 
 // sfx_mask / sfx_test: count-suffix= filter, a k-mer is kept iff (its low word & sfx_mask) == sfx_test (0, 0: keep all)
+// the same + the k-mers per (file, next nine bits) into d_fine_hist[2^15] (the first digit of the narrowed grouping passes)
+bool       kmer_histogram_fine_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask);
+hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint64_t *d_bucket_counts,
+                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st);
 hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                                  uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st,
                                  uint64_t sfx_mask = 0, uint64_t sfx_test = 0);
@@ -76,8 +80,11 @@ hipError_t launch_group_prepare(const void *d_keys, uint64_t n, uint32_t key_wor
 // and the sub-bucket boundaries fall out of the second pass's look-back granules.  d_keys: uint64[n] in, uint32[n] out
 // (over its first half); d_alt: room for n uint32; d_sub_starts: 2^(pass_bits[0] + pass_bits[1]) + 1 entries.
 bool       sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words);
+// d_fine (512 counts of the file's top nine bits, launch_kmer_histogram_fine) or nullptr: see mgc_sort.hip -- with it
+// nobody reads the keys for a digit histogram, and the sub-buckets come out in the order tr_index(., *tr_a, *tr_b) describes.
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
-                               uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events /* 4 or null */);
+                               uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events /* 4 or null */,
+                               const uint64_t *d_fine, uint32_t *tr_a, uint32_t *tr_b);
 
 // ---- run-length count ------------------------------------------------------
 size_t     rle_workspace_bytes(uint64_t n);
@@ -112,16 +119,18 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               hipStream_t st_huge /*where that kernel is launched (st, or a stream forked from it)*/,
                               const uint32_t *d_nonempty_list, const uint64_t *d_nonempty_count /*the hash kernels visit only these;
                               d_group_distinct must be zero for the others*/, hipStream_t st,
-                              bool narrow = false /*d_keys/d_alt: uint32 narrowed keys; the distinct SUFFIXES go back in place*/);
+                              bool narrow = false /*d_keys/d_alt: uint32 narrowed keys; the distinct SUFFIXES go back in place*/,
+                              uint32_t tr_a = 0, uint32_t tr_b = 0 /*narrow: launch_group_narrow's*/);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);
 hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,
                                  const uint64_t *d_offs, uint64_t ng, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st);
 // narrowed files: k-mer = base | sub-bucket << low_bits | suffix
 hipError_t launch_compact_groups_narrow(const void *d_keys32, const uint32_t *d_cnt_tmp, const uint64_t *d_starts, const uint64_t *d_offs,
-                                        uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st);
+                                        uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st,
+                                        uint32_t tr_a, uint32_t tr_b);
 hipError_t launch_widen_groups(const void *d_keys32, const uint64_t *d_starts, uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out64,
-                               hipStream_t st);
+                               hipStream_t st, uint32_t tr_a, uint32_t tr_b);      // tr_a != 0: the result is NOT in key order
 hipError_t launch_store_u64(uint64_t *d_dst, const uint64_t *d_src, hipStream_t st);
 
 hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,

@@ -403,7 +403,8 @@ template <int BLOCK, int CAP, int SLOTS, bool DBG, bool LIST, bool NARROW = fals
 __global__ __launch_bounds__(BLOCK, 5)
 void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                        u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                       const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u64 *__restrict__ dbg) {
+                       const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u64 *__restrict__ dbg,
+                       u32 tr_a = 0, u32 tr_b = 0 /* NARROW: tr_index() of the sub-bucket numbers */) {
   // Inside a sub-bucket the keys differ only in their low `low_bits` (< 32) bits: the table holds
   // 32-bit suffixes (half the LDS, 32-bit CAS and compares); the common prefix is added back on output.
   // Persistent workgroups: the keys of the next sub-bucket are loaded while the current one is counted
@@ -458,7 +459,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
     const u64 g3 = sub_at(p + 3 * G);
 
     if (n64 == 0) {
-      if (tid == 0) group_distinct[g] = 0;
+      if (tid == 0) group_distinct[NARROW ? tr_index(g, tr_a, tr_b) : g] = 0;
     } else if (n64 <= max_size) {                      // larger ones: other launches take them
       const u32 n = (u32)n64;
       const u64 prefix = file_base | (g << low_bits);
@@ -552,7 +553,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
         else                  gk[r] = prefix | (u64)ki;  // in place: every key of this region sits in registers
         cnt_tmp[a + r] = dc[i];
       }
-      if (tid == 0) group_distinct[g] = D;
+      if (tid == 0) group_distinct[NARROW ? tr_index(g, tr_a, tr_b) : g] = D;
       HC_STAMP(3);
       __syncthreads();                                 // dk/dc/s_tmp are reused by the next sub-bucket
       HC_STAMP(4);
@@ -1115,7 +1116,7 @@ template <typename S, int BLOCK, int CAP, int SLOTS, typename KT = u64>
 __global__ __launch_bounds__(BLOCK)
 void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
                             u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                            KT *__restrict__ alt) {
+                            KT *__restrict__ alt, u32 tr_a = 0, u32 tr_b = 0 /* KT = u32: tr_index() of the sub-bucket numbers */) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && (CAP & (CAP - 1)) == 0 && SLOTS >= CAP * 2 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0,
                 "table geometry");
   constexpr int KPT = 4, SPT = SLOTS / BLOCK;
@@ -1288,7 +1289,7 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
     __syncthreads();                                   // all passes have read the keys; alt[] was written by this workgroup
     for (u64 i = tid; i < out; i += BLOCK) gk[i] = alt[a + i];
   }
-  if (tid == 0) group_distinct[g] = out;
+  if (tid == 0) group_distinct[(sizeof(KT) == 4) ? tr_index(g, tr_a, tr_b) : g] = out;
 }
 
 // The same for 16-byte keys (k >= 33): slots are claimed through their count word as in hash_count128_kernel, lanes of a
@@ -1555,10 +1556,11 @@ void compact_groups_kernel(const K *__restrict__ keys, const u32 *__restrict__ c
 __global__ __launch_bounds__(256)
 void compact_groups_narrow_kernel(const u32 *__restrict__ keys32, const u32 *__restrict__ cnt_tmp, const u64 *__restrict__ starts,
                                   const u64 *__restrict__ offs, u64 ng, u64 base, u32 low_bits, u64 *__restrict__ out_keys,
-                                  u32 *__restrict__ out_counts) {
+                                  u32 *__restrict__ out_counts, u32 tr_a, u32 tr_b) {
   const u64 g = (u64)blockIdx.x * 4 + wave_id();
   if (g >= ng) return;
-  const u64 dst = offs[g], d = offs[g + 1] - dst, src = starts[g], pre = base | (g << low_bits);
+  const u64 gt = tr_index(g, tr_a, tr_b);              // offs[] and the k-mers' top bits go by the real sub-bucket number
+  const u64 dst = offs[gt], d = offs[gt + 1] - dst, src = starts[g], pre = base | (gt << low_bits);
   for (u64 i = lane_id(); i < d; i += 64) {
     out_keys[dst + i]   = pre | (u64)keys32[src + i];
     out_counts[dst + i] = cnt_tmp[src + i];
@@ -1569,10 +1571,10 @@ void compact_groups_narrow_kernel(const u32 *__restrict__ keys32, const u32 *__r
 // sub-bucket, the stable-sort fallback)
 __global__ __launch_bounds__(256)
 void widen_groups_kernel(const u32 *__restrict__ keys32, const u64 *__restrict__ starts, u64 ng, u64 base, u32 low_bits,
-                         u64 *__restrict__ out) {
+                         u64 *__restrict__ out, u32 tr_a, u32 tr_b) {
   const u64 g = (u64)blockIdx.x * 4 + wave_id();
   if (g >= ng) return;
-  const u64 a = starts[g], e = starts[g + 1], pre = base | (g << low_bits);
+  const u64 a = starts[g], e = starts[g + 1], pre = base | (tr_index(g, tr_a, tr_b) << low_bits);
   const u32 low_mask = (low_bits >= 32) ? ~0u : ((1u << low_bits) - 1u);
   for (u64 i = a + lane_id(); i < e; i += 64) out[i] = pre | (u64)(keys32[i] & low_mask);
 }
@@ -1703,7 +1705,7 @@ hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uin
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
                               bool stream, void *d_alt, hipStream_t st_huge, const uint32_t *d_nz, const uint64_t *d_nz_count,
-                              hipStream_t st, bool narrow) {
+                              hipStream_t st, bool narrow, uint32_t tr_a, uint32_t tr_b) {
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
   if (narrow) {
     // narrowed keys (u32): the 32-bit hash-count kernel and the streaming kernel have u32-storage instantiations; anything
@@ -1714,11 +1716,11 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     if (d_nz)
       hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, true>), dim3(hgrid), dim3(256), 0, st,
                          reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, (u64 *)nullptr);
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, (u64 *)nullptr, tr_a, tr_b);
     else
       hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, true>), dim3(hgrid), dim3(256), 0, st,
                          reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, (u64 *)nullptr);
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, (u64 *)nullptr, tr_a, tr_b);
     MGC_CHECK(hipGetLastError());
     if (n_large) {
       constexpr size_t B32 = (size_t)(4 + 4) * HUGE_SLOTS32 + (size_t)(4 + 4) * HUGE_CAP32 + 16 * 4;
@@ -1731,7 +1733,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       hipLaunchKernelGGL((hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32, u32>), dim3((uint32_t)n_large), dim3(1024), B32, st_huge,
                          reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
                          (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
-                         reinterpret_cast<u32 *>(d_alt));
+                         reinterpret_cast<u32 *>(d_alt), tr_a, tr_b);
       MGC_CHECK(hipGetLastError());
     }
     return hipSuccess;
@@ -1878,17 +1880,18 @@ hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const u
 }
 
 hipError_t launch_compact_groups_narrow(const void *d_keys32, const uint32_t *d_cnt_tmp, const uint64_t *d_starts, const uint64_t *d_offs,
-                                        uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st) {
+                                        uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st,
+                                        uint32_t tr_a, uint32_t tr_b) {
   hipLaunchKernelGGL(compact_groups_narrow_kernel, dim3((uint32_t)((ng + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const u32 *>(d_keys32),
                      d_cnt_tmp, reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng, (u64)base, low_bits,
-                     reinterpret_cast<u64 *>(d_out_keys), d_out_counts);
+                     reinterpret_cast<u64 *>(d_out_keys), d_out_counts, tr_a, tr_b);
   return hipGetLastError();
 }
 
 hipError_t launch_widen_groups(const void *d_keys32, const uint64_t *d_starts, uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out64,
-                               hipStream_t st) {
+                               hipStream_t st, uint32_t tr_a, uint32_t tr_b) {
   hipLaunchKernelGGL(widen_groups_kernel, dim3((uint32_t)((ng + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const u32 *>(d_keys32),
-                     reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)base, low_bits, reinterpret_cast<u64 *>(d_out64));
+                     reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)base, low_bits, reinterpret_cast<u64 *>(d_out64), tr_a, tr_b);
   return hipGetLastError();
 }
 

@@ -119,8 +119,7 @@ __device__ __forceinline__ u32 kp_thread_kmers(const u32 *s_codes, const u32 *s_
 // complement of the k-mer's LAST bases, all sixteen of which sit in one 32-base chunk that is reversed once.
 // bucket_bits <= 16, k <= 32, 2k >= bucket_bits.
 __device__ __forceinline__ u32 kp_thread_buckets(const u32 *s_codes, const u32 *s_inval, u32 k, int mode, u32 bucket_bits,
-                                                 u32 (&bk)[KP_ITEMS]) {
-  const u32 t = threadIdx.x;
+                                                 u32 (&bk)[KP_ITEMS], const u32 t = threadIdx.x) {
   const u64 A = ((u64)s_codes[t] << 32) | (u64)s_codes[t + 1];      // bases 0..31 of the thread's window
   const u64 B = (u64)s_codes[t + 2] << 32;                          // bases 32..47
   const u64 I = ((u64)s_inval[t] << 48) | ((u64)s_inval[t + 1] << 32) | ((u64)s_inval[t + 2] << 16);
@@ -244,6 +243,75 @@ void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode,
     const u64 v = s_hist[b];
     block_hist[(u64)blockIdx.x * nb + b] = v;
     if (v) atomicAdd(&bucket_counts[b], v);
+  }
+}
+
+// kmer_hist_kernel for the narrowed grouping path (mgc_sort.hip, launch_group_narrow): besides the per-file counts it
+// takes the histogram of the file AND the next nine bits of every k-mer -- the digit a file's first grouping pass
+// groups by -- so that no pass has to read the file's k-mers just to size its digit regions (the 8 B/k-mer
+// radix_hist_kernel read).  2^15 LDS counters = 128 KiB, hence ONE 1024-thread workgroup per CU standing for NV = 4
+// workgroups of kmer_hist_kernel (slices of 256 threads, each with the tile range and the block_hist row the partition
+// kernel expects from workgroup blockIdx.x * NV + slice); the next tile's bases are loaded while the current one is counted.
+// k <= 32, 2k >= 15, no count-suffix, 64 buckets.
+constexpr int KH_NV = 4, KH_FINE_BITS = 15;
+__global__ __launch_bounds__(KP_BLOCK * KH_NV)
+void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u64 num_tiles, u32 vgrid,
+                           u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts, u64 *__restrict__ fine_hist) {
+  extern __shared__ __attribute__((aligned(16))) u32 kh_fine[];      // [1 << KH_FINE_BITS]
+  __shared__ u32 s_codes[2][KH_NV][KP_WORDS];
+  __shared__ u32 s_inval[2][KH_NV][KP_WORDS];
+  __shared__ u32 s_hist[KH_NV][64];
+  const u32 tid = threadIdx.x, v = tid >> 8, t = tid & 255u;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
+  for (u32 i = tid; i < (1u << KH_FINE_BITS); i += KP_BLOCK * KH_NV) kh_fine[i] = 0;
+  if (tid < KH_NV * 64) (&s_hist[0][0])[tid] = 0;
+
+  const u64 per = (num_tiles + vgrid - 1) / vgrid;                   // kp_tile_range of the virtual workgroup
+  const u64 vwg = (u64)blockIdx.x * KH_NV + v;
+  u64 t_begin = vwg * per, t_end = t_begin + per;
+  if (t_begin > num_tiles) t_begin = num_tiles;
+  if (t_end > num_tiles) t_end = num_tiles;
+  if (vwg >= vgrid) t_begin = t_end = num_tiles;
+
+  uint4 cur = make_uint4(0, 0, 0, 0), halo = make_uint4(0, 0, 0, 0);
+  auto fetch = [&](u64 tile) {
+    if (tile >= t_end) return;
+    cur = load16(bases, tile * KP_TILE + (u64)t * 16, n, aligned);
+    if (t < 4) halo = load16(bases, tile * KP_TILE + (u64)KP_TILE + (u64)t * 16, n, aligned);
+  };
+  fetch(t_begin);
+  __syncthreads();
+  for (u64 it = 0; it < per; it++) {
+    const u64 tile = t_begin + it;
+    const u32 buf = (u32)it & 1u;
+    const bool active = tile < t_end;
+    if (active) {
+      u32 c, iv;
+      encode16(cur, c, iv);
+      s_codes[buf][v][t] = c; s_inval[buf][v][t] = iv;
+      if (t < 4) { encode16(halo, c, iv); s_codes[buf][v][KP_BLOCK + t] = c; s_inval[buf][v][KP_BLOCK + t] = iv; }
+    }
+    __syncthreads();
+    fetch(tile + 1);                                                 // in flight behind the counting below
+    if (active) {
+      u32 bk[KP_ITEMS];
+      const u32 vmask = kp_thread_buckets(s_codes[buf][v], s_inval[buf][v], k, mode, KH_FINE_BITS, bk, t);
+#pragma unroll
+      for (int j = 0; j < KP_ITEMS; j++)
+        if ((vmask >> j) & 1u) { atomicAdd(&kh_fine[bk[j]], 1u); atomicAdd(&s_hist[v][bk[j] >> (KH_FINE_BITS - 6)], 1u); }
+    }
+  }
+  __syncthreads();
+  if (tid < KH_NV * 64) {
+    const u32 vv = tid >> 6, b = tid & 63u;
+    const u64 w = (u64)blockIdx.x * KH_NV + vv;
+    const u64 c = s_hist[vv][b];
+    if (w < vgrid) block_hist[w * 64 + b] = c;
+    if (c) atomicAdd(&bucket_counts[b], c);
+  }
+  for (u32 i = tid; i < (1u << KH_FINE_BITS); i += KP_BLOCK * KH_NV) {
+    const u32 c = kh_fine[i];
+    if (c) atomicAdd(&fine_hist[i], (u64)c);
   }
 }
 
@@ -390,6 +458,31 @@ hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint3
     hipLaunchKernelGGL(kmer_hist_kernel<K128>, dim3(grid), dim3(KP_BLOCK), 0, st,
                        d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
                        reinterpret_cast<u64 *>(d_ws), reinterpret_cast<u64 *>(d_bucket_counts), (u64)sfx_mask, (u64)sfx_test);
+  return hipGetLastError();
+}
+
+bool kmer_histogram_fine_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask) {
+  const char *e = getenv("MGC_FINE_HIST");
+  return !(e && e[0] == '0') && k <= 32 && 2 * k >= (uint32_t)KH_FINE_BITS + 2 && bucket_bits == 6 && sfx_mask == 0;
+}
+
+// launch_kmer_histogram + d_fine_hist[2^15] (zeroed here): k-mers per (file, next nine bits)
+hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint64_t *d_bucket_counts,
+                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st) {
+  MGC_CHECK(hipMemsetAsync(d_bucket_counts, 0, sizeof(uint64_t) * 64, st));
+  MGC_CHECK(hipMemsetAsync(d_fine_hist, 0, sizeof(uint64_t) << KH_FINE_BITS, st));
+  if (n_bases == 0) return hipSuccess;
+  const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
+  const uint32_t vgrid = kp_grid_size(n_bases);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(u32) << KH_FINE_BITS));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kmer_hist_fine_kernel, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) << KH_FINE_BITS, st,
+                     d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
+                     reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
   return hipGetLastError();
 }
 

@@ -693,14 +693,21 @@ void group_regions_kernel(const u64 *__restrict__ gbase_prev, u64 n, u32 tile, u
 template <typename K, bool NARROW> struct GroupOut { typedef K type; };
 template <> struct GroupOut<u64, true> { typedef u32 type; };
 
-template <typename K, int RB, int BLOCK, int KPT, bool DBG, bool NARROW = false>
+// HIST2: the pass also takes the histogram of ANOTHER digit (the next pass's) of the keys it reads -- 512 LDS counters per
+// workgroup, flushed with global atomics at the end -- so that nobody has to read the keys for it.
+struct GroupExtra { u32 digit_bits /* NARROW */; u32 shift2, mask2; u64 *ghist2 /* HIST2 */; };
+
+template <typename K, int RB, int BLOCK, int KPT, bool DBG, bool NARROW = false, bool HIST2 = false>
 __global__ __launch_bounds__(BLOCK, (GroupSmem<K, RB, BLOCK, KPT>::MIN_WAVES_PER_SIMD))
 void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::type *__restrict__ out, u64 n, u32 shift, u32 dmask,
                         const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
                         u32 *__restrict__ error_flag, u64 num_tiles_plain,
                         const u64 *__restrict__ region_start,   // [RS_MAX_RADIX + 1] or nullptr (plain tiles)
                         const u32 *__restrict__ region_tiles,   // [RS_MAX_RADIX + 1] exclusive; last = total tiles
-                        u32 digit_bits /* NARROW only */, u64 *__restrict__ dbg) {
+                        GroupExtra ex, u64 *__restrict__ dbg) {
+  const u32 digit_bits = ex.digit_bits;
+  __shared__ u32 s_h2[HIST2 ? RS_MAX_RADIX : 1];
+  if (HIST2) { for (u32 i = threadIdx.x; i < (u32)RS_MAX_RADIX; i += BLOCK) s_h2[i] = 0; }
   using SM = GroupSmem<K, RB, BLOCK, KPT>;
   using KO = KeyOps<K>;
   constexpr int R = SM::R, TILE = SM::TILE, G = R / 2;
@@ -784,7 +791,9 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
       u32 r = 0;
-      if (li + (u32)j * 64 < nv) r = atomicAdd(&s_hist[KO::digit(keys[j], shift, dmask)], 1u);
+      if (li + (u32)j * 64 < nv) {
+        r = atomicAdd(&s_hist[KO::digit(keys[j], shift, dmask)], 1u);
+      }
       if (j & 1) ranks[j / 2] |= r << 16;
       else       ranks[j / 2]  = r;
     }
@@ -853,6 +862,11 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     };
     if (!walker) {
       if (next < total_tiles) fetch(nkb, nnv);
+      // the waves that do not walk would only wait now: they count the other digit of the tile's keys (in LDS, in digit
+      // order since the exchange) -- LDS work in the shadow of the look-back
+      if constexpr (HIST2) {
+        for (u32 i = tid - (u32)G; i < nv; i += (u32)(BLOCK - G)) atomicAdd(&s_h2[KO::digit(s_keys[i], ex.shift2, ex.mask2)], 1u);
+      }
     } else {
       while (!done) { issue(); consume(); }
       if (tile != 0) status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
@@ -869,7 +883,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
       if (i < nv) {
         const K   key = s_keys[i];
         const u32 d   = KO::digit(key, shift, dmask);
-        if constexpr (NARROW) out[s_gbase[d] + (u64)i] = (u32)((key >> (shift + digit_bits)) << shift) | ((u32)key & ((1u << shift) - 1u));
+        if constexpr (NARROW) out[s_gbase[d] + (u64)i] = (u32)(((key >> (shift + digit_bits)) << shift) | (key & ((1ull << shift) - 1ull)));
         else                  out[s_gbase[d] + (u64)i] = key;
       }
     }
@@ -883,6 +897,10 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
 #undef PK_STAMP
   (void)kb;
+  if constexpr (HIST2) {
+    __syncthreads();
+    for (u32 i = tid0; i < (u32)RS_MAX_RADIX; i += BLOCK) { const u32 c = s_h2[i]; if (c) atomicAdd(&ex.ghist2[i], (u64)c); }
+  }
 }
 
 // ---- classic mode: per-tile digit histogram + row scan ----------------------
@@ -1136,12 +1154,12 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
       if (plan.dbg)
         hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, true>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
                            (const K *)src, dst, (u64)n, plan.pass_shift[p], plan_mask(plan, p),
-                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, plan.flags,
+                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, GroupExtra{0u, 0u, 0u, nullptr},
                            reinterpret_cast<u64 *>(plan.dbg));
       else
         hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
                            (const K *)src, dst, (u64)n, plan.pass_shift[p], plan_mask(plan, p),
-                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, plan.flags, (u64 *)nullptr);
+                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
       K *t = src; src = dst; dst = t; in_alt ^= 1;
@@ -1198,13 +1216,33 @@ bool sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words) {
   const char *e = getenv("MGC_NARROW");                     // read per call: the tests switch it
   const bool on = !(e && e[0] == '0');
   return on && key_words == 1 && plan.mode == 3 && !plan.hpc && plan.num_passes == 2 && plan.radix_bits == 9 && n > 0 && n < (1ull << 30) &&
-         plan.pass_shift[1] == plan.pass_shift[0] + plan.pass_bits[0] && plan.pass_shift[0] + plan.pass_bits[1] <= 32;
+         plan.pass_shift[1] == plan.pass_shift[0] + plan.pass_bits[0] &&
+         plan.pass_shift[0] + std::max(plan.pass_bits[0], plan.pass_bits[1]) <= 32;     // whichever digit goes first, the rest fits a word
 }
 
-// d_keys: u64[n] in; u32[n] out over its first half (grouped by the plan's two digits, each key = (bits above digit 0)
-// << pass_shift[0] | the low pass_shift[0] bits, truncated to 32 bits).  d_alt: room for n u32.  d_sub_starts: 2^(b0+b1) + 1.
+// 512 counts of a file's top nine bits (kmer_hist_fine_kernel) -> the histogram of its top `bits` bits
+__global__ __launch_bounds__(RS_MAX_RADIX)
+void fine_to_ghist_kernel(const u64 *__restrict__ fine, u32 bits, u64 *__restrict__ ghist) {
+  __shared__ u64 s_f[RS_MAX_RADIX];
+  const u32 x = threadIdx.x;
+  s_f[x] = fine[x];
+  __syncthreads();
+  const u32 span = 1u << (9 - bits);
+  u64 c = 0;
+  if (x < (1u << bits)) for (u32 i = 0; i < span; i++) c += s_f[x * span + i];
+  ghist[x] = c;
+}
+
+// d_keys: u64[n] in; u32[n] out over its first half (grouped by the plan's two digits, each key without the digit of the
+// FIRST pass, truncated to 32 bits).  d_alt: room for n u32.  d_sub_starts: 2^(b0+b1) + 1, in PHYSICAL order.
+// d_fine == nullptr: the low digit first (LSD; one read of the keys for both digit histograms); physical order = key order.
+// d_fine (the 512 counts of this file's top nine bits, kmer_hist_fine_kernel): the HIGH digit first -- its histogram comes
+// from d_fine, the low digit's is taken by the first pass itself, nobody reads the keys for a histogram -- and the
+// physical order is (low digit : high digit): sub-bucket p holds the k-mers whose top bits are
+// ((p & (2^*tr_a - 1)) << *tr_b) | (p >> *tr_a)  (*tr_a = 0: p itself).
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
-                               uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events) {
+                               uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events,
+                               const uint64_t *d_fine, uint32_t *tr_a, uint32_t *tr_b) {
   if (!sort_plan_narrows(plan, n, 1) || ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
   constexpr int RB = 9, BLOCK = 1024, KPT0 = 16, KPT1 = 32, R = 1 << RB;
   using GS0 = GroupSmem<u64, RB, BLOCK, KPT0>;
@@ -1212,9 +1250,11 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
   constexpr uint64_t TILE0 = (uint64_t)BLOCK * KPT0, TILE1 = (uint64_t)BLOCK * KPT1;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, false, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u32, RB, BLOCK, KPT1, false, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u32, RB, BLOCK, KPT1, false, false, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS1::BYTES);
     attr_done = true;
   }
@@ -1225,33 +1265,56 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
   const size_t status_bytes = (size_t)std::max(tiles0, tiles1_max) * (R / 2) * sizeof(u64);
   u64 *region_start = reinterpret_cast<u64 *>(body + ((status_bytes + 255) / 256) * 256);
   u32 *region_tiles = reinterpret_cast<u32 *>(region_start + RS_MAX_RADIX + 1);
-  const u32 s0 = plan.pass_shift[0], b0 = plan.pass_bits[0], b1 = plan.pass_bits[1];
-  MGC_CHECK(group_prepare<u64>(reinterpret_cast<const u64 *>(d_keys), n, plan, hdr, st));
+  const u32 low = plan.pass_shift[0], b_lo = plan.pass_bits[0], b_hi = plan.pass_bits[1];
+  const bool msd = d_fine != nullptr;
+  // first pass: digit A at shA (bA bits), dropped from the keys; second pass: digit B -- after the drop it sits at `low`
+  const u32 bA = msd ? b_hi : b_lo, bB = msd ? b_lo : b_hi, shA = msd ? low + b_lo : low;
+  *tr_a = msd ? bA : 0u; *tr_b = bB;
   const uint64_t cus = (uint64_t)device_cu_count();
 
+  if (msd) {
+    MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
+    hipLaunchKernelGGL(fine_to_ghist_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, reinterpret_cast<const u64 *>(d_fine), bA, &hdr->ghist[0][0]);
+    MGC_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, &hdr->ghist[0][0], &hdr->gbase[0][0]);
+    MGC_CHECK(hipGetLastError());
+  } else {
+    MGC_CHECK(group_prepare<u64>(reinterpret_cast<const u64 *>(d_keys), n, plan, hdr, st));   // rows 0 / 1 = low / high digit = A / B
+  }
   MGC_CHECK(hipMemsetAsync(status, 0, (size_t)tiles0 * (R / 2) * sizeof(u64), st));
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[0], st));
-  hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true>), dim3((uint32_t)std::min(tiles0, cus * GS0::WG_PER_CU)), dim3(BLOCK),
-                     GS0::BYTES, st, reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, s0, (1u << b0) - 1u,
-                     &hdr->gbase[0][0], status, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
-                     b0, (u64 *)nullptr);
+  const dim3 grid0((uint32_t)std::min(tiles0, cus * GS0::WG_PER_CU));
+  if (msd)
+    hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
+                       reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                       &hdr->gbase[0][0], status, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                       GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0]}, (u64 *)nullptr);
+  else
+    hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, false>), grid0, dim3(BLOCK), GS0::BYTES, st,
+                       reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                       &hdr->gbase[0][0], status, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                       GroupExtra{bA, 0u, 0u, nullptr}, (u64 *)nullptr);
   MGC_CHECK(hipGetLastError());
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[1], st));
 
+  if (msd) {
+    hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, &hdr->ghist[1][0], &hdr->gbase[1][0]);
+    MGC_CHECK(hipGetLastError());
+  }
   hipLaunchKernelGGL(group_regions_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, &hdr->gbase[0][0], (u64)n, (u32)TILE1, region_start, region_tiles);
   MGC_CHECK(hipGetLastError());
   MGC_CHECK(hipMemsetAsync(status, 0, (size_t)tiles1_max * (R / 2) * sizeof(u64), st));
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2], st));
-  hipLaunchKernelGGL((radix_group_kernel<u32, RB, BLOCK, KPT1, false, false>), dim3((uint32_t)std::min(tiles1_max, cus * GS1::WG_PER_CU)), dim3(BLOCK),
-                     GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, s0, (1u << b1) - 1u,
+  hipLaunchKernelGGL((radix_group_kernel<u32, RB, BLOCK, KPT1, false, false, false>), dim3((uint32_t)std::min(tiles1_max, cus * GS1::WG_PER_CU)), dim3(BLOCK),
+                     GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
                      &hdr->gbase[1][0], status, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
-                     0u, (u64 *)nullptr);
+                     GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
   MGC_CHECK(hipGetLastError());
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[3], st));
 
-  const u64 ng = (u64)1 << (b0 + b1);
+  const u64 ng = (u64)1 << (bA + bB);
   hipLaunchKernelGGL(narrow_bounds_kernel, dim3((uint32_t)((ng + 1 + 255) / 256)), dim3(256), 0, st, status, region_tiles,
-                     &hdr->gbase[1][0], (u64)n, b0, ng, reinterpret_cast<u64 *>(d_sub_starts));
+                     &hdr->gbase[1][0], (u64)n, bA, ng, reinterpret_cast<u64 *>(d_sub_starts));
   return hipGetLastError();
 }
 

@@ -1088,16 +1088,21 @@ def test_large_input_partition_granularity(ops, oracle_lib, torch_cuda, monkeypa
     assert np.array_equal(np.asarray(info.file_instances, dtype=np.int64), inst_per_file)
 
 
+@pytest.mark.parametrize("fine", ["1", "0"])
 @pytest.mark.parametrize("k,target,narrow", [(21, 1, "1"), (21, 1, "0"), (21, 6, "1"), (19, 3, "1"), (22, 2, "1"), (24, 2, "1"), (26, 2, "1"), (16, 1, "1")])
-def test_narrowed_grouping_passes(ops, oracle_lib, torch_cuda, monkeypatch, k, target, narrow):
+def test_narrowed_grouping_passes(ops, oracle_lib, torch_cuda, monkeypatch, k, target, narrow, fine):
     """Two grouping digits on a small input (MGC_FINISH_TARGET makes the sub-buckets tiny, so the plan needs 15-17 top bits):
     k <= ~25 then takes the NARROWED passes -- the first pass drops its digit and writes 32-bit words, the second groups those,
     the sub-bucket boundaries come from its look-back granules, the hash-count reads and writes u32 and the packing step
     puts the prefixes back -- and must give the oracle's stream, like the wide passes (MGC_NARROW=0; k=26 leaves 34 bits
-    below the first digit and stays wide by itself)."""
+    below the first digit and stays wide by itself).  fine = "1": the file histogram counts fifteen top bits, the HIGH digit goes
+    first with its histogram taken from there, the first pass counts the low digit as it goes, and the sub-buckets lie in
+    (low digit : high digit) order -- the hash-count, the streaming kernel and the packing step translate the numbers;
+    fine = "0": low digit first off one histogram read of the keys (what the owner side of a sharded count runs)."""
     from meryl_amd import capi
     monkeypatch.setenv("MGC_FINISH_TARGET", str(target))
     monkeypatch.setenv("MGC_NARROW", narrow)
+    monkeypatch.setenv("MGC_FINE_HIST", fine)
     bases = oracle_lib.synth_reads(200 + k, 300_000, 0, 40_000)
     for mode in (0, 1):
         cfg = capi.configure(k, bases.size, 1 << 30, mode)
@@ -1115,7 +1120,7 @@ def test_narrowed_grouping_passes(ops, oracle_lib, torch_cuda, monkeypatch, k, t
         assert prof.sort_pass_launches > 100                        # two passes for (nearly) every file
 
 
-@pytest.mark.parametrize("target", [None, 8])
+@pytest.mark.parametrize("target", [None, 8, -8])
 @pytest.mark.parametrize("stream_max", [None, 20_000])
 @pytest.mark.parametrize("k", [21, 25, 31, 35, 51])
 def test_oversized_subbuckets_stream_in_ranges(ops, oracle_lib, torch_cuda, monkeypatch, k, stream_max, target):
@@ -1132,7 +1137,9 @@ def test_oversized_subbuckets_stream_in_ranges(ops, oracle_lib, torch_cuda, monk
     if target is not None:                                  # two grouping digits: k=21 takes the narrowed passes, whose streaming
         if k not in (21, 25):                               # kernel and probe read 32-bit words and whose refused files are widened
             pytest.skip("the narrowed passes are a k <= 25 matter")
-        monkeypatch.setenv("MGC_FINISH_TARGET", str(target))
+        monkeypatch.setenv("MGC_FINISH_TARGET", str(abs(target)))
+        if target < 0:                                      # low digit first (no fifteen-bit file histogram): widened files stay in key order
+            monkeypatch.setenv("MGC_FINE_HIST", "0")
     rng = np.random.default_rng(k)
     plen = min(20, k - 10)
     def cluster(prefix, n_inst, n_distinct):
