@@ -936,7 +936,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   const uint64_t *d_fine = nullptr;
   if (!ext_keys) {
     tm.begin(MGC_STAGE_HISTOGRAM);
-    if (kw == 1 && n_bases >= (1u << 22) && mgc::kmer_histogram_fine_ok(k, bucket_bits, s->sfx_mask)) {
+    // (two digits cover at most 18 bits: beyond 2k - 6 = 41 nothing narrows and the fifteen-bit histogram would go unused)
+    if (kw == 1 && n_bases >= (1u << 22) && 2 * k - bucket_bits <= 41 && mgc::kmer_histogram_fine_ok(k, bucket_bits, s->sfx_mask)) {
       HIP_TRY(s, s->ensure(mgc_session::B_FINE, sizeof(uint64_t) << 15));
       uint64_t *fine = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_FINE].p);
       HIP_TRY(s, mgc::launch_kmer_histogram_fine(d_bases, n_bases, k, c.mode, d_counts64, fine, part_ws, st));

@@ -235,22 +235,36 @@ __global__ void subbucket_bounds_kernel(const K *__restrict__ keys, u64 n, u32 l
 // largest sub-bucket of a file -> *max_out (atomicMax), so the host can pick the kernel capacity
 // and the list of the sub-buckets above `threshold` (the ones the large-capacity launch takes)
 // and the list of the non-empty ones (any order; one atomic per wave)
-__global__ void subbucket_max_kernel(const u64 *__restrict__ starts, u64 ng, u64 *__restrict__ max_out, u64 threshold,
-                                     u32 *__restrict__ list, u64 *__restrict__ list_count,
-                                     u32 *__restrict__ nz, u64 *__restrict__ nz_count) {
+__global__ __launch_bounds__(256)
+void subbucket_max_kernel(const u64 *__restrict__ starts, u64 ng, u64 *__restrict__ max_out, u64 threshold,
+                          u32 *__restrict__ list, u64 *__restrict__ list_count,
+                          u32 *__restrict__ nz, u64 *__restrict__ nz_count) {
+  // one atomic per WORKGROUP on the shared counters (a file has 2^18 sub-buckets: one per wave was 4096 atomics on one address)
+  __shared__ u32 s_cnt[4];
+  __shared__ u64 s_max[4];
+  __shared__ u64 s_base;
   const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 sz = (v < ng) ? (starts[v + 1] - starts[v]) : 0ull;
   if (sz > threshold) list[atomicAdd(list_count, 1ull)] = (u32)v;
-  {
-    const u64 m = __ballot(sz != 0);
-    u64 base = 0;
-    if (lane_id() == 0 && m) base = atomicAdd(nz_count, (u64)__popcll(m));
-    base = __shfl(base, 0);
-    if (sz) nz[base + __popcll(m & ((1ull << lane_id()) - 1ull))] = (u32)v;
-  }
+  const u64 m = __ballot(sz != 0);
+  u64 mx = sz;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { const u64 o = __shfl_down(sz, d); sz = (o > sz) ? o : sz; }
-  if (lane_id() == 0 && sz) atomicMax(max_out, sz);
+  for (int d = 32; d >= 1; d >>= 1) { const u64 o = __shfl_down(mx, d); mx = (o > mx) ? o : mx; }
+  if (lane_id() == 0) { s_cnt[wave_id()] = (u32)__popcll(m); s_max[wave_id()] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    u64 bm = s_max[0];
+    for (int w = 1; w < 4; w++) bm = s_max[w] > bm ? s_max[w] : bm;
+    s_base = total ? atomicAdd(nz_count, (u64)total) : 0ull;
+    if (bm) atomicMax(max_out, bm);
+  }
+  __syncthreads();
+  if (sz) {
+    u64 pos = s_base + __popcll(m & ((1ull << lane_id()) - 1ull));
+    for (u32 w = 0; w < wave_id(); w++) pos += s_cnt[w];
+    nz[pos] = (u32)v;
+  }
 }
 
 template <typename K, int BLOCK, int KPT>

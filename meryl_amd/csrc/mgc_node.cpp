@@ -148,8 +148,12 @@ void phase_count(Node &nd, uint32_t r, hipStream_t st_copy) {
     file_off[f - f0 + 1] = file_off[f - f0] + tot[f - f0];
   }
   DevMem mem;
-  void *inbox = nullptr;
+  void *inbox = nullptr, *res_keys = nullptr, *res_counts = nullptr;
   ND_HIP(mem.alloc(&inbox, file_off[f1 - f0] * kb));
+  // the counted waves stay here until the writer is closed: a wave has at most as many distinct k-mers as k-mers, so its
+  // result fits at its own offset (one allocation for all waves -- hipMalloc beside running kernels is slow)
+  ND_HIP(mem.alloc(&res_keys, file_off[f1 - f0] * kb));
+  ND_HIP(mem.alloc(&res_counts, file_off[f1 - f0] * sizeof(uint32_t)));
   mgc_count_config cfg = nd.cfg;
   cfg.homopoly_compress = 0;                    // the owner side sees k-mers, never bases
   mgc_session *sess = mgc_open(&cfg, me.device);
@@ -198,7 +202,8 @@ void phase_count(Node &nd, uint32_t r, hipStream_t st_copy) {
       if (rc == MGC_OK) rc = mgc_get_result_info(sess, &info);
       if (rc != MGC_OK) { nd.fail("rank %u: mgc_count_buckets: %d %s", r, rc, mgc_last_error(sess)); ok = false; return; }
       ndist = info.n_distinct;
-      if (!hip_ok(mem.alloc(&ok_keys, ndist * kb), "hipMalloc(wave keys)") || !hip_ok(mem.alloc(&ok_counts, ndist * 4), "hipMalloc(wave counts)")) return;
+      ok_keys = (char *)res_keys + file_off[lo - f0] * kb;
+      ok_counts = (char *)res_counts + file_off[lo - f0] * sizeof(uint32_t);
       rc = mgc_copy_result_device(sess, ok_keys, (uint32_t *)ok_counts);
       if (rc != MGC_OK) { nd.fail("rank %u: mgc_copy_result_device: %d %s", r, rc, mgc_last_error(sess)); ok = false; return; }
       me.n_distinct += ndist;
