@@ -413,8 +413,10 @@ void lds_sort_count_kernel(K *__restrict__ keys,                      // the fil
 // EMPTY cannot collide with a key: every key of the file shares its top six bits, ~key0 does not.
 // NARROW: the sub-buckets hold 32-bit narrowed keys (launch_group_narrow) -- u32 loads, and the distinct SUFFIXES go back
 // in place as u32 (compact_groups_narrow_kernel puts the prefix back when it packs the result).
-template <int BLOCK, int CAP, int SLOTS, bool DBG, bool LIST, bool NARROW = false>
-__global__ __launch_bounds__(BLOCK, 5)
+// BINRANK: the distinct suffixes are ordered by a counting sort on their top eight bits (BLOCK bins, one per thread) and a
+// brute-force rank inside the bin -- O(D) for spread suffixes -- instead of the all-pairs rank (D^2 / BLOCK compares per thread).
+template <int BLOCK, int CAP, int SLOTS, bool DBG, bool LIST, bool NARROW = false, bool BINRANK = true>
+__global__ __launch_bounds__(BLOCK, 7)
 void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                        u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
                        const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u64 *__restrict__ dbg,
@@ -427,10 +429,13 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
   constexpr int KPT = CAP / BLOCK;
   constexpr u32 EMPTY = 0xFFFFFFFFu;                   // suffixes are < 2^31
   __shared__ __attribute__((aligned(16))) u32 tk[SLOTS];
-  __shared__ __attribute__((aligned(16))) u32 tc[SLOTS];
+  __shared__ __attribute__((aligned(16))) u32 tc[SLOTS / 2];   // counts, two 16-bit halves per word (a count is <= CAP): 26 KiB of LDS in all, six workgroups per CU
   __shared__ __attribute__((aligned(16))) u32 dk[CAP + 16];
-  __shared__ u32 dc[CAP];
+  __shared__ unsigned short dc[CAP];                   // slot of a claimed suffix, later its count: both below 2^16
   __shared__ u32 s_nd;                                 // distinct suffixes of the sub-bucket: the claimers of empty slots count themselves
+  __shared__ u32 s_bin[BINRANK ? BLOCK + 1 : 1];
+  __shared__ u32 s_scan[BLOCK / 64 + 1];
+  static_assert(!BINRANK || BLOCK == 256, "one bin per thread, eight bits");
   const u32 tid = threadIdx.x;
   const u64 G = gridDim.x;
   const u64 low_mask = (1ull << low_bits) - 1ull;
@@ -495,7 +500,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
         uint4 *tk4 = reinterpret_cast<uint4 *>(tk), *tc4 = reinterpret_cast<uint4 *>(tc);
         for (u32 i = tid; i < slots / 4; i += BLOCK) {
           tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
-          tc4[i] = make_uint4(0u, 0u, 0u, 0u);
+          if (i < slots / 8) tc4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
         if (tid == 0) s_nd = 0;
       }
@@ -524,10 +529,10 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
                 base = (u32)__builtin_amdgcn_readlane((int)base, leader);
                 const u32 pos = base + (u32)__popcll(wm & ((1ull << lane) - 1ull));
                 dk[pos] = kk[j];
-                dc[pos] = hh[j];
+                dc[pos] = (unsigned short)hh[j];
               }
               if (won || old == kk[j]) {
-                atomicAdd(&tc[hh[j]], 1u);
+                atomicAdd(&tc[hh[j] >> 1], (hh[j] & 1u) ? 0x10000u : 1u);
                 pending &= ~(1u << j);
               }
               else hh[j] = (hh[j] + 1) & smask;
@@ -541,7 +546,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 
       // the compact list is already there (any order): only the counts are still in the table
       const u32 D = s_nd;
-      for (u32 i = tid; i < D; i += BLOCK) dc[i] = tc[dc[i]];
+      for (u32 i = tid; i < D; i += BLOCK) { const u32 h = dc[i]; dc[i] = (unsigned short)((tc[h >> 1] >> ((h & 1u) * 16u)) & 0xFFFFu); }
       if (tid < 16) dk[D + tid] = EMPTY;               // padding of the rank loop (D is block-uniform)
       __syncthreads();
       HC_STAMP(2);
@@ -552,6 +557,41 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
       const uint4 *dk4 = reinterpret_cast<const uint4 *>(dk);
       u64 *gk = keys + a;
       const u32 d16 = (D + 15) / 16;
+      if constexpr (BINRANK) {
+        const u32 bshift = low_bits > 8 ? low_bits - 8 : 0;
+        s_bin[tid] = 0;
+        __syncthreads();
+        u32 li[KPT];
+#pragma unroll
+        for (int q = 0; q < KPT; q++) {
+          const u32 i = (u32)q * BLOCK + tid;
+          li[q] = 0;
+          if (i < D) li[q] = atomicAdd(&s_bin[dk[i] >> bshift], 1u);
+        }
+        __syncthreads();
+        u32 tot;
+        const u32 e = block_excl_scan<BLOCK, u32>(s_bin[tid], s_scan, &tot);
+        s_bin[tid] = e;
+        if (tid == 0) s_bin[BLOCK] = D;
+        __syncthreads();
+        // the table is dead (its counts went to dc): it holds the suffixes in bin order now, the count words hold where each came from
+        unsigned short *ix = reinterpret_cast<unsigned short *>(tc);
+#pragma unroll
+        for (int q = 0; q < KPT; q++) {
+          const u32 i = (u32)q * BLOCK + tid;
+          if (i < D) { const u32 kq = dk[i]; const u32 pos = s_bin[kq >> bshift] + li[q]; tk[pos] = kq; ix[pos] = (unsigned short)i; }
+        }
+        __syncthreads();
+        for (u32 pidx = tid; pidx < D; pidx += BLOCK) {
+          const u32 ki = tk[pidx];
+          const u32 b = ki >> bshift, lo = s_bin[b], hi = s_bin[b + 1];
+          u32 r = lo;
+          for (u32 q = lo; q < hi; q++) r += (tk[q] < ki) ? 1u : 0u;
+          if constexpr (NARROW) reinterpret_cast<u32 *>(keys)[a + r] = ki;
+          else                  gk[r] = prefix | (u64)ki;
+          cnt_tmp[a + r] = dc[ix[pidx]];
+        }
+      } else
       for (u32 i = tid; i < D; i += BLOCK) {
         const u32 ki = dk[i];
         u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;
@@ -1600,7 +1640,7 @@ constexpr u64 FIN_CAP_SMALL = 256 * 16, FIN_CAP_LARGE = 1024 * 8;   // LDS: 46 K
 // longest chain among 64 lanes made an insert round 4x as long (scripts/gpu_huge.sh)
 constexpr int HUGE_CAP32 = 4096, HUGE_SLOTS32 = 8192;            // 32-bit suffixes: 96 KiB of LDS
 constexpr int HUGE_CAP64 = 2048, HUGE_SLOTS64 = 4096;            // 64-bit suffixes: 72 KiB
-constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count kernel: 2048 slots, 28 KiB of LDS, 5 workgroups per CU
+constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count kernel: 2048 slots, 26 KiB of LDS, 6 workgroups per CU
 
 static bool finish_uses_hash(uint32_t key_words, uint32_t low_bits) {
   static const bool use_hash = !(getenv("MGC_FINISH_HASH") && getenv("MGC_FINISH_HASH")[0] == '0');
@@ -1725,16 +1765,16 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     // narrowed keys (u32): the 32-bit hash-count kernel and the streaming kernel have u32-storage instantiations; anything
     // else wants whole k-mers -- the caller widens the file first (launch_widen_groups)
     if (key_words != 1 || low_bits >= 32 || !finish_uses_hash(key_words, low_bits) || (n_large && !stream)) return hipErrorInvalidValue;
-    static const uint32_t hgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 10u;
+    static const uint32_t hgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 14u;
     const uint32_t hgrid = ng < hgrid_max ? (uint32_t)ng : hgrid_max;
-    if (d_nz)
-      hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, true>), dim3(hgrid), dim3(256), 0, st,
-                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, (u64 *)nullptr, tr_a, tr_b);
-    else
-      hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, true>), dim3(hgrid), dim3(256), 0, st,
-                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, (u64 *)nullptr, tr_a, tr_b);
+    static const bool binrank = !(getenv("MGC_HASH_BINRANK") && getenv("MGC_HASH_BINRANK")[0] == '0');
+#define MGC_NARROW_LAUNCH(LIST_, BIN_)                                                                                                   \
+    hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, LIST_, true, BIN_>), dim3(hgrid), dim3(256), 0, st,       \
+                       reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, \
+                       d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, (u64 *)nullptr, tr_a, tr_b)
+    if (d_nz) { if (binrank) MGC_NARROW_LAUNCH(true, true);  else MGC_NARROW_LAUNCH(true, false); }
+    else      { if (binrank) MGC_NARROW_LAUNCH(false, true); else MGC_NARROW_LAUNCH(false, false); }
+#undef MGC_NARROW_LAUNCH
     MGC_CHECK(hipGetLastError());
     if (n_large) {
       constexpr size_t B32 = (size_t)(4 + 4) * HUGE_SLOTS32 + (size_t)(4 + 4) * HUGE_CAP32 + 16 * 4;
@@ -1800,7 +1840,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
   }
   if (finish_uses_hash(key_words, low_bits)) {
     // <= FIN_CAP_HASH keys: hash-count; larger sub-buckets: LDS radix passes in the 8192-key instantiation
-    static const uint32_t hgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 10u;
+    static const uint32_t hgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 14u;
     const uint32_t hgrid = ng < hgrid_max ? (uint32_t)ng : hgrid_max;
     const bool use_list = d_nz != nullptr;
 #define MGC_HASH_LAUNCH(KERNEL, ...)                                                                                        \
@@ -1818,8 +1858,11 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     } else if (hash_dbg_buffer()) {
       MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true, true>), hash_dbg_buffer());
     } else {
-      if (use_list) MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true>), (u64 *)nullptr);
-      else          MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false>), (u64 *)nullptr);
+      static const bool binrank = !(getenv("MGC_HASH_BINRANK") && getenv("MGC_HASH_BINRANK")[0] == '0');
+      if (use_list) { if (binrank) MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, false, true>), (u64 *)nullptr);
+                      else         MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, false, false>), (u64 *)nullptr); }
+      else          { if (binrank) MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, false, true>), (u64 *)nullptr);
+                      else         MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, false, false>), (u64 *)nullptr); }
     }
 #undef MGC_HASH_LAUNCH
     MGC_CHECK(hipGetLastError());
