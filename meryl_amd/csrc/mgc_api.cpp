@@ -1118,6 +1118,27 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       narrow[b] = !hist_ahead && low < 32 && mgc::finish_can_stream(kw, low) && mgc::sort_plan_narrows(fplan[b], h_counts[b], kw);
     }
     tm.begin(MGC_STAGE_SORT);
+    // high digit first: the headers of all narrowed files in one launch, their look-back granules zeroed in one memset
+    std::vector<size_t> nws_off(nb + 1, 0);
+    unsigned char *d_nws = nullptr, *d_nhdrs = nullptr;
+    if (d_fine && nb <= 64) {
+      unsigned char bits_a[64] = {0}, on[64] = {0};
+      bool any = false;
+      for (uint32_t b = 0; b < nb; b++) {
+        nws_off[b + 1] = nws_off[b];
+        if (!narrow[b]) continue;
+        on[b] = 1; bits_a[b] = (unsigned char)fplan[b].pass_bits[1]; any = true;
+        nws_off[b + 1] += (mgc::narrow_scratch_bytes(h_counts[b]) + 255) / 256 * 256;
+      }
+      if (any) {
+        HIP_TRY(s, s->ensure(mgc_session::B_SORT_HDRS, hdr_bytes * nb));
+        HIP_TRY(s, s->ensure(mgc_session::B_NARROW_WS, nws_off[nb]));
+        d_nhdrs = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_SORT_HDRS].p);
+        d_nws = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_NARROW_WS].p);
+        HIP_TRY(s, mgc::launch_narrow_prepare(d_fine, nb, bits_a, on, d_nhdrs, st));
+        HIP_TRY(s, hipMemsetAsync(d_nws, 0, nws_off[nb], st));
+      }
+    }
     if (hist_ahead && s->stream2) {
       HIP_TRY(s, s->ensure(mgc_session::B_SORT_HDRS, hdr_bytes * nb));
       d_hdrs = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_SORT_HDRS].p);
@@ -1143,7 +1164,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       hipEvent_t *pe = s->profiling ? &pass_ev[(size_t)b * ev_per_file] : nullptr;
       if (narrow[b]) {                                       // X (8 B) -> Y (4 B) -> front of X (4 B); boundaries included
         HIP_TRY(s, mgc::launch_group_narrow(src, (void *)Y, h_counts[b], fp, sort_ws, sort_ws_bytes - 256, d_err, d_substart + sbase[b], st, pe,
-                                            d_fine ? d_fine + (size_t)b * 512 : nullptr, &tr_a[b], &tr_b[b]));
+                                            d_nhdrs ? (void *)(d_nhdrs + hdr_bytes * b) : nullptr, d_nws ? (void *)(d_nws + nws_off[b]) : nullptr,
+                                            &tr_a[b], &tr_b[b]));
         file_passes[b] = 2;
         narrowed[b] = 1;
         sort_launch_groups++;

@@ -80,11 +80,18 @@ hipError_t launch_group_prepare(const void *d_keys, uint64_t n, uint32_t key_wor
 // and the sub-bucket boundaries fall out of the second pass's look-back granules.  d_keys: uint64[n] in, uint32[n] out
 // (over its first half); d_alt: room for n uint32; d_sub_starts: 2^(pass_bits[0] + pass_bits[1]) + 1 entries.
 bool       sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words);
-// d_fine (512 counts of the file's top nine bits, launch_kmer_histogram_fine) or nullptr: see mgc_sort.hip -- with it
-// nobody reads the keys for a digit histogram, and the sub-buckets come out in the order tr_index(., *tr_a, *tr_b) describes.
+// The high-digit-first form (files of a session with the fifteen-bit file histogram): launch_narrow_prepare fills one
+// header per file (nb <= 64, sort_header_bytes() apart) from d_fine; every file then gets its header and a scratch area of
+// narrow_scratch_bytes(n) whose first narrow_zero_bytes(n) bytes the caller has zeroed.  See mgc_sort.hip: nobody reads the
+// keys for a digit histogram, and the sub-buckets come out in the order tr_index(., *tr_a, *tr_b) describes.
+// d_prepared / d_scratch == nullptr: low digit first off one histogram read, scratch in d_ws, sub-buckets in key order.
+size_t     narrow_scratch_bytes(uint64_t n);
+size_t     narrow_zero_bytes(uint64_t n);
+hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsigned char *bits_a, const unsigned char *on, void *d_hdrs,
+                                 hipStream_t st);
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events /* 4 or null */,
-                               const uint64_t *d_fine, uint32_t *tr_a, uint32_t *tr_b);
+                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b);
 
 // ---- run-length count ------------------------------------------------------
 size_t     rle_workspace_bytes(uint64_t n);

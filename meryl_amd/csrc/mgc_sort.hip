@@ -1220,34 +1220,90 @@ bool sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words) {
          plan.pass_shift[0] + std::max(plan.pass_bits[0], plan.pass_bits[1]) <= 32;     // whichever digit goes first, the rest fits a word
 }
 
-// 512 counts of a file's top nine bits (kmer_hist_fine_kernel) -> the histogram of its top `bits` bits
+// ---- the small per-file steps of the high-digit-first form, batched over all files (a launch per file and step costs more idle
+// time than the steps themselves: ~8 us each, ten of them per file) ----
+struct NarrowPrep { unsigned char bits_a[64]; unsigned char on[64]; };
+
+// one workgroup per file: header cleared, histogram of the file's top bits_a[f] bits from the 512 fine counts, its exclusive scan
 __global__ __launch_bounds__(RS_MAX_RADIX)
-void fine_to_ghist_kernel(const u64 *__restrict__ fine, u32 bits, u64 *__restrict__ ghist) {
+void narrow_prepare_kernel(const u64 *__restrict__ fine, NarrowPrep prep, unsigned char *__restrict__ hdrs, u32 hdr_stride) {
   __shared__ u64 s_f[RS_MAX_RADIX];
-  const u32 x = threadIdx.x;
-  s_f[x] = fine[x];
+  __shared__ u64 s_tmp[RS_MAX_RADIX / 64 + 1];
+  const u32 f = blockIdx.x, x = threadIdx.x;
+  if (!prep.on[f]) return;
+  SortHeader *hdr = reinterpret_cast<SortHeader *>(hdrs + (size_t)f * hdr_stride);
+  u32 *w = reinterpret_cast<u32 *>(hdr);
+  for (u32 i = x; i < sizeof(SortHeader) / 4; i += RS_MAX_RADIX) w[i] = 0;
+  s_f[x] = fine[(size_t)f * RS_MAX_RADIX + x];
   __syncthreads();
-  const u32 span = 1u << (9 - bits);
+  const u32 bits = prep.bits_a[f], span = 1u << (9 - bits);
   u64 c = 0;
   if (x < (1u << bits)) for (u32 i = 0; i < span; i++) c += s_f[x * span + i];
-  ghist[x] = c;
+  u64 total;
+  const u64 e = block_excl_scan<RS_MAX_RADIX, u64>(c, s_tmp, &total);
+  hdr->ghist[0][x] = c;
+  hdr->gbase[0][x] = e;
+}
+
+// between the two passes: exclusive scan of the second digit's histogram (taken by the first pass) + the region table
+__global__ __launch_bounds__(RS_MAX_RADIX)
+void narrow_mid_kernel(SortHeader *__restrict__ hdr, u64 n, u32 tile, u64 *__restrict__ region_start, u32 *__restrict__ region_tiles) {
+  __shared__ u64 s_tmp[RS_MAX_RADIX / 64 + 1];
+  __shared__ u32 s_tmp32[RS_MAX_RADIX / 64 + 1];
+  const u32 r = threadIdx.x;
+  u64 total;
+  const u64 e = block_excl_scan<RS_MAX_RADIX, u64>(hdr->ghist[1][r], s_tmp, &total);
+  hdr->gbase[1][r] = e;
+  const u64 a = hdr->gbase[0][r], b = (r + 1 < RS_MAX_RADIX) ? hdr->gbase[0][r + 1] : n;
+  const u32 nt = (u32)((b - a + tile - 1) / tile);
+  u32 tt;
+  const u32 et = block_excl_scan<RS_MAX_RADIX, u32>(nt, s_tmp32, &tt);
+  region_start[r] = a;
+  region_tiles[r] = et;
+  if (r == 0) { region_start[RS_MAX_RADIX] = n; region_tiles[RS_MAX_RADIX] = tt; }
+}
+
+// per-file scratch of the batched form: [status of pass A][status of pass B][region table]
+size_t narrow_scratch_bytes(uint64_t n) {
+  const uint64_t tiles0 = (n + 16384 - 1) / 16384, tiles1_max = (n + 32768 - 1) / 32768 + RS_MAX_RADIX + 1;
+  return (size_t)(tiles0 + tiles1_max) * (RS_MAX_RADIX / 2) * sizeof(u64) + (size_t)(RS_MAX_RADIX + 2) * 16 + 512;
+}
+static size_t narrow_status_bytes(uint64_t n) {            // the part of it that must be zero before the passes
+  const uint64_t tiles0 = (n + 16384 - 1) / 16384, tiles1_max = (n + 32768 - 1) / 32768 + RS_MAX_RADIX + 1;
+  return (size_t)(tiles0 + tiles1_max) * (RS_MAX_RADIX / 2) * sizeof(u64);
+}
+
+// headers of all files at once (files with on[f] = 0 are skipped); d_hdrs: nb x sort_header_bytes()
+hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsigned char *bits_a, const unsigned char *on, void *d_hdrs,
+                                 hipStream_t st) {
+  if (nb > 64) return hipErrorInvalidValue;
+  NarrowPrep prep;
+  memset(&prep, 0, sizeof(prep));
+  memcpy(prep.bits_a, bits_a, nb);
+  memcpy(prep.on, on, nb);
+  hipLaunchKernelGGL(narrow_prepare_kernel, dim3(nb), dim3(RS_MAX_RADIX), 0, st, reinterpret_cast<const u64 *>(d_fine), prep,
+                     reinterpret_cast<unsigned char *>(d_hdrs), (u32)sort_header_bytes());
+  return hipGetLastError();
 }
 
 // d_keys: u64[n] in; u32[n] out over its first half (grouped by the plan's two digits, each key without the digit of the
 // FIRST pass, truncated to 32 bits).  d_alt: room for n u32.  d_sub_starts: 2^(b0+b1) + 1, in PHYSICAL order.
-// d_fine == nullptr: the low digit first (LSD; one read of the keys for both digit histograms); physical order = key order.
-// d_fine (the 512 counts of this file's top nine bits, kmer_hist_fine_kernel): the HIGH digit first -- its histogram comes
-// from d_fine, the low digit's is taken by the first pass itself, nobody reads the keys for a histogram -- and the
-// physical order is (low digit : high digit): sub-bucket p holds the k-mers whose top bits are
+// d_prepared == nullptr: the low digit first (LSD; one read of the keys for both digit histograms, scratch = d_ws); physical
+// order = key order.
+// d_prepared (this file's header from launch_narrow_prepare, i.e. the histogram of its HIGH digit taken from the fifteen-bit
+// file histogram) + d_scratch (narrow_scratch_bytes(n), its status part zeroed by the caller): the high digit goes first, the
+// low digit's histogram is taken by the first pass itself -- nobody reads the keys for a histogram -- and the physical order
+// is (low digit : high digit): sub-bucket p holds the k-mers whose top bits are
 // ((p & (2^*tr_a - 1)) << *tr_b) | (p >> *tr_a)  (*tr_a = 0: p itself).
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events,
-                               const uint64_t *d_fine, uint32_t *tr_a, uint32_t *tr_b) {
+                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b) {
   if (!sort_plan_narrows(plan, n, 1) || ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
   constexpr int RB = 9, BLOCK = 1024, KPT0 = 16, KPT1 = 32, R = 1 << RB;
   using GS0 = GroupSmem<u64, RB, BLOCK, KPT0>;
   using GS1 = GroupSmem<u32, RB, BLOCK, KPT1>;
   constexpr uint64_t TILE0 = (uint64_t)BLOCK * KPT0, TILE1 = (uint64_t)BLOCK * KPT1;
+  static_assert(TILE0 == 16384 && TILE1 == 32768, "narrow_scratch_bytes");
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, false>),
@@ -1258,65 +1314,71 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS1::BYTES);
     attr_done = true;
   }
-  SortHeader *hdr = reinterpret_cast<SortHeader *>(d_ws);
-  unsigned char *body = reinterpret_cast<unsigned char *>(d_ws) + ((sizeof(SortHeader) + 255) / 256) * 256;
+  const bool msd = d_prepared != nullptr && d_scratch != nullptr;
   const uint64_t tiles0 = (n + TILE0 - 1) / TILE0, tiles1_max = (n + TILE1 - 1) / TILE1 + RS_MAX_RADIX + 1;
-  u64 *status = reinterpret_cast<u64 *>(body);
-  const size_t status_bytes = (size_t)std::max(tiles0, tiles1_max) * (R / 2) * sizeof(u64);
-  u64 *region_start = reinterpret_cast<u64 *>(body + ((status_bytes + 255) / 256) * 256);
+  SortHeader *hdr;
+  u64 *status_a, *status_b, *region_start;
+  if (msd) {
+    hdr = reinterpret_cast<SortHeader *>(d_prepared);
+    status_a = reinterpret_cast<u64 *>(d_scratch);
+    status_b = status_a + (size_t)tiles0 * (R / 2);
+    region_start = status_b + (size_t)tiles1_max * (R / 2);
+  } else {
+    hdr = reinterpret_cast<SortHeader *>(d_ws);
+    unsigned char *body = reinterpret_cast<unsigned char *>(d_ws) + ((sizeof(SortHeader) + 255) / 256) * 256;
+    status_a = status_b = reinterpret_cast<u64 *>(body);
+    const size_t status_bytes = (size_t)std::max(tiles0, tiles1_max) * (R / 2) * sizeof(u64);
+    region_start = reinterpret_cast<u64 *>(body + ((status_bytes + 255) / 256) * 256);
+  }
   u32 *region_tiles = reinterpret_cast<u32 *>(region_start + RS_MAX_RADIX + 1);
   const u32 low = plan.pass_shift[0], b_lo = plan.pass_bits[0], b_hi = plan.pass_bits[1];
-  const bool msd = d_fine != nullptr;
   // first pass: digit A at shA (bA bits), dropped from the keys; second pass: digit B -- after the drop it sits at `low`
   const u32 bA = msd ? b_hi : b_lo, bB = msd ? b_lo : b_hi, shA = msd ? low + b_lo : low;
   *tr_a = msd ? bA : 0u; *tr_b = bB;
   const uint64_t cus = (uint64_t)device_cu_count();
 
-  if (msd) {
-    MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
-    hipLaunchKernelGGL(fine_to_ghist_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, reinterpret_cast<const u64 *>(d_fine), bA, &hdr->ghist[0][0]);
-    MGC_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, &hdr->ghist[0][0], &hdr->gbase[0][0]);
-    MGC_CHECK(hipGetLastError());
-  } else {
+  if (!msd) {
     MGC_CHECK(group_prepare<u64>(reinterpret_cast<const u64 *>(d_keys), n, plan, hdr, st));   // rows 0 / 1 = low / high digit = A / B
+    MGC_CHECK(hipMemsetAsync(status_a, 0, (size_t)tiles0 * (R / 2) * sizeof(u64), st));
   }
-  MGC_CHECK(hipMemsetAsync(status, 0, (size_t)tiles0 * (R / 2) * sizeof(u64), st));
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[0], st));
   const dim3 grid0((uint32_t)std::min(tiles0, cus * GS0::WG_PER_CU));
   if (msd)
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
-                       &hdr->gbase[0][0], status, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                       &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
                        GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0]}, (u64 *)nullptr);
   else
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, false>), grid0, dim3(BLOCK), GS0::BYTES, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
-                       &hdr->gbase[0][0], status, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                       &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
                        GroupExtra{bA, 0u, 0u, nullptr}, (u64 *)nullptr);
   MGC_CHECK(hipGetLastError());
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[1], st));
 
   if (msd) {
-    hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, &hdr->ghist[1][0], &hdr->gbase[1][0]);
+    hipLaunchKernelGGL(narrow_mid_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, hdr, (u64)n, (u32)TILE1, region_start, region_tiles);
     MGC_CHECK(hipGetLastError());
+  } else {
+    hipLaunchKernelGGL(group_regions_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, &hdr->gbase[0][0], (u64)n, (u32)TILE1, region_start, region_tiles);
+    MGC_CHECK(hipGetLastError());
+    MGC_CHECK(hipMemsetAsync(status_b, 0, (size_t)tiles1_max * (R / 2) * sizeof(u64), st));
   }
-  hipLaunchKernelGGL(group_regions_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, &hdr->gbase[0][0], (u64)n, (u32)TILE1, region_start, region_tiles);
-  MGC_CHECK(hipGetLastError());
-  MGC_CHECK(hipMemsetAsync(status, 0, (size_t)tiles1_max * (R / 2) * sizeof(u64), st));
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2], st));
   hipLaunchKernelGGL((radix_group_kernel<u32, RB, BLOCK, KPT1, false, false, false>), dim3((uint32_t)std::min(tiles1_max, cus * GS1::WG_PER_CU)), dim3(BLOCK),
                      GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
-                     &hdr->gbase[1][0], status, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
+                     &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
                      GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
   MGC_CHECK(hipGetLastError());
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[3], st));
 
   const u64 ng = (u64)1 << (bA + bB);
-  hipLaunchKernelGGL(narrow_bounds_kernel, dim3((uint32_t)((ng + 1 + 255) / 256)), dim3(256), 0, st, status, region_tiles,
+  hipLaunchKernelGGL(narrow_bounds_kernel, dim3((uint32_t)((ng + 1 + 255) / 256)), dim3(256), 0, st, status_b, region_tiles,
                      &hdr->gbase[1][0], (u64)n, bA, ng, reinterpret_cast<u64 *>(d_sub_starts));
   return hipGetLastError();
 }
+
+size_t narrow_zero_bytes(uint64_t n) { return narrow_status_bytes(n); }
 
 size_t sort_header_bytes() { return ((sizeof(SortHeader) + 255) / 256) * 256; }
 

@@ -1,12 +1,11 @@
 #!/bin/bash
 mkdir -p gpurun_out
 {
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "narrowed or oversized or sparse or medium_scale or session_matches or repeat" 2>&1 | tail -3
-for g in 1792 3584; do
-MGC_HASH_GRID=$g timeout 600 python bench.py --steps 3 --warmup 1 --no-e2e --no-cpu-baseline 2>&1 | tail -1 | python -c "
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "narrowed or oversized or sparse or medium_scale or session_matches or repeat or out_of_core" 2>&1 | tail -3
+timeout 600 python bench.py --steps 3 --warmup 1 --no-e2e --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']
-print('grid $g ms', d['ms_per_step'], 'stages', d['stage_ms_per_step'], 'check', d.get('check', {}).get('ok'))"
-done
+print('ms', d['ms_per_step'], 'stages', d['stage_ms_per_step'], 'check', d.get('check', {}).get('ok'))
+print('passA', r['avg_launch_ms'], 'passB', r['second_pass']['avg_launch_ms'])"
 } > gpurun_out/r02u.log 2>&1
 tail -8 gpurun_out/r02u.log
