@@ -654,6 +654,31 @@ def test_count_buckets_finer_than_files(ops, oracle_lib, torch_cuda, k, bits):
         assert info.n_instances == wni and int(np.sum(info.file_instances)) == wni
 
 
+@pytest.mark.parametrize("k,bits", [(21, 6), (21, 8), (21, 9), (19, 9), (24, 7)])
+def test_count_buckets_two_digit_buckets_take_the_narrowed_passes(ops, oracle_lib, torch_cuda, k, bits):
+    """The owner side of a sharded count at a size where a bucket needs TWO grouping digits (2 M reads: 1-4 M k-mers per
+    bucket): no base stream, hence no fifteen-bit histogram -- the narrowed passes run low digit first off one histogram read
+    of the keys, with bucket prefixes wider than the six file bits put back by the packing step.  Per-file digests against the
+    threaded port."""
+    from meryl_amd import capi
+    d = ops.dev_synth_reads(300 + bits, 10_000_000, 0, 2_000_000)
+    keys, counts = ops.dev_kmer_partition(d, k, 0, bits)
+    cfg = capi.configure(k, d.numel(), 8 << 30)
+    with ops.Session(cfg) as s:
+        s.set_profiling(True)
+        s.count_partitioned(keys, counts)
+        uniq, cnts = s.result_device()
+        info = s.info()
+        prof = s.profile()
+    assert prof.pass_launches[1] > 0                                          # two digits really
+    if k <= 21:
+        assert prof.pass_bytes[0] < 14 * prof.pass_keys[0]                    # ... and (nearly all buckets) narrowed: 8 B in, 4 B out
+    got = device_digests(torch_cuda, uniq, cnts, k)
+    want, nd, ni = oracle_lib.digest_threaded(d.cpu().numpy(), k, cfg.w_prefix, threads=16)
+    assert (nd, ni) == (info.n_distinct, info.n_instances)
+    assert np.array_equal(got, want)
+
+
 def test_count_partitioned_contract(ops, oracle_lib, torch_cuda):
     # owner-side entry point: file-major keys in, same stream out as a count of the bases; refuses a session that
     # already holds pushed bases; an empty share is a valid (empty) result
