@@ -711,7 +711,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
   using SM = GroupSmem<K, RB, BLOCK, KPT>;
   using KO = KeyOps<K>;
   constexpr int R = SM::R, TILE = SM::TILE, G = R / 2;
-  constexpr int WALK = 16;
+  constexpr int WALK = (sizeof(K) == 4) ? 8 : 16;      // 32 words per thread leave registers for eight granules in flight, not sixteen (no spills)
   static_assert(BLOCK >= RS_MAX_RADIX && G % 64 == 0 && TILE <= 65536, "one thread per region/digit; 16-bit ranks");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   K   *s_keys  = reinterpret_cast<K *>(smem);
@@ -749,16 +749,29 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     }
   };
 
+  // Loads are wave-striped 16-byte vectors (VEC keys per lane and instruction: 1 KiB contiguous per wave instruction).  Fewer,
+  // wider loads matter beyond issue slots: the walkers' granule loads queue behind the prefetch of the other twelve waves in
+  // the CU's own memory pipeline, by INSTRUCTION -- with 4-byte loads of 32-bit words the look-back took 45 K cycles per tile
+  // instead of 17 K (profiles/r02x_groupdbg.log).  Key j of a thread is element idx_of(j) of the tile; order inside a tile is free.
+  constexpr int VEC = (sizeof(K) < 16 && KPT % (16 / sizeof(K)) == 0) ? (int)(16 / sizeof(K)) : 1;
+  struct __attribute__((aligned(4))) KVec { K v[VEC]; };     // 4-byte alignment is all a file / region start guarantees
+  auto idx_of = [&](int j) __attribute__((always_inline)) -> u32 {
+    return w * (u32)(64 * KPT) + ((u32)(j / VEC) * 64u + lane) * (u32)VEC + (u32)(j % VEC);
+  };
   K keys[KPT];
   auto fetch = [&](u64 kb, u32 nv) __attribute__((always_inline)) {
-    const u32 li = w * (64 * KPT) + lane;                 // wave-striped: 512 contiguous bytes per wave instruction
-    const K  *p  = in + kb + li;
-    if (nv == (u32)TILE) {
+    const K *base = in + kb;
 #pragma unroll
-      for (int j = 0; j < KPT; j++) keys[j] = p[j * 64];
-    } else {
+    for (int g = 0; g < KPT / VEC; g++) {
+      const u32 first = idx_of(g * VEC);
+      if (nv == (u32)TILE || first + (u32)VEC <= nv) {
+        const KVec q = *reinterpret_cast<const KVec *>(base + first);
 #pragma unroll
-      for (int j = 0; j < KPT; j++) if (li + (u32)j * 64 < nv) keys[j] = p[j * 64];
+        for (int c = 0; c < VEC; c++) keys[g * VEC + c] = q.v[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < VEC; c++) if (first + (u32)c < nv) keys[g * VEC + c] = base[first + c];
+      }
     }
   };
 
@@ -786,12 +799,11 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     PK_STAMP(0);
 
     // ---- rank: position among the tile's keys of the same digit, in arrival order ----
-    const u32 li = w * (64 * KPT) + lane;
     u32 ranks[KPT / 2];
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
       u32 r = 0;
-      if (li + (u32)j * 64 < nv) {
+      if (idx_of(j) < nv) {
         r = atomicAdd(&s_hist[KO::digit(keys[j], shift, dmask)], 1u);
       }
       if (j & 1) ranks[j / 2] |= r << 16;
@@ -815,7 +827,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     }
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
-      if (li + (u32)j * 64 < nv) {
+      if (idx_of(j) < nv) {
         const u32 d = KO::digit(keys[j], shift, dmask);
         const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
         s_keys[s_dbase[d] + r] = keys[j];
@@ -1264,12 +1276,13 @@ void narrow_mid_kernel(SortHeader *__restrict__ hdr, u64 n, u32 tile, u64 *__res
 }
 
 // per-file scratch of the batched form: [status of pass A][status of pass B][region table]
+constexpr uint64_t NARROW_TILE0 = 16384, NARROW_TILE1 = 24576;   // keys per tile of the first / second pass (launch_group_narrow)
 size_t narrow_scratch_bytes(uint64_t n) {
-  const uint64_t tiles0 = (n + 16384 - 1) / 16384, tiles1_max = (n + 32768 - 1) / 32768 + RS_MAX_RADIX + 1;
+  const uint64_t tiles0 = (n + NARROW_TILE0 - 1) / NARROW_TILE0, tiles1_max = (n + NARROW_TILE1 - 1) / NARROW_TILE1 + RS_MAX_RADIX + 1;
   return (size_t)(tiles0 + tiles1_max) * (RS_MAX_RADIX / 2) * sizeof(u64) + (size_t)(RS_MAX_RADIX + 2) * 16 + 512;
 }
 static size_t narrow_status_bytes(uint64_t n) {            // the part of it that must be zero before the passes
-  const uint64_t tiles0 = (n + 16384 - 1) / 16384, tiles1_max = (n + 32768 - 1) / 32768 + RS_MAX_RADIX + 1;
+  const uint64_t tiles0 = (n + NARROW_TILE0 - 1) / NARROW_TILE0, tiles1_max = (n + NARROW_TILE1 - 1) / NARROW_TILE1 + RS_MAX_RADIX + 1;
   return (size_t)(tiles0 + tiles1_max) * (RS_MAX_RADIX / 2) * sizeof(u64);
 }
 
@@ -1299,11 +1312,11 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events,
                                void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b) {
   if (!sort_plan_narrows(plan, n, 1) || ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
-  constexpr int RB = 9, BLOCK = 1024, KPT0 = 16, KPT1 = 32, R = 1 << RB;
+  constexpr int RB = 9, BLOCK = 1024, KPT0 = 16, KPT1 = 24, R = 1 << RB;
   using GS0 = GroupSmem<u64, RB, BLOCK, KPT0>;
   using GS1 = GroupSmem<u32, RB, BLOCK, KPT1>;
   constexpr uint64_t TILE0 = (uint64_t)BLOCK * KPT0, TILE1 = (uint64_t)BLOCK * KPT1;
-  static_assert(TILE0 == 16384 && TILE1 == 32768, "narrow_scratch_bytes");
+  static_assert(TILE0 == NARROW_TILE0 && TILE1 == NARROW_TILE1, "narrow_scratch_bytes");
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, false>),
@@ -1343,7 +1356,29 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
   }
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[0], st));
   const dim3 grid0((uint32_t)std::min(tiles0, cus * GS0::WG_PER_CU));
-  if (msd)
+  // MGC_GROUP_DBG=1: per-phase cycle sums of the first 64 workgroups of both passes, printed for the first two files (developer
+  // instrumentation; the instrumented instantiations run instead of the plain ones for those files)
+  static int dbg_reports = getenv("MGC_GROUP_DBG") ? 2 : 0;
+  static u64 *dbg_buf = nullptr;
+  const bool dbg = msd && dbg_reports > 0;
+  if (dbg && !dbg_buf) {
+    static bool dattr = false;
+    if (!dattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, true, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u32, RB, BLOCK, KPT1, true, false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS1::BYTES);
+      dattr = true;
+    }
+    if (hipMalloc(&dbg_buf, 2 * 64 * 8 * sizeof(u64)) != hipSuccess) dbg_buf = nullptr;
+  }
+  if (dbg && dbg_buf) MGC_CHECK(hipMemsetAsync(dbg_buf, 0, 2 * 64 * 8 * sizeof(u64), st));
+  if (dbg && dbg_buf)
+    hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, true, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
+                       reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                       &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                       GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0]}, dbg_buf);
+  else if (msd)
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                        &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
@@ -1365,6 +1400,12 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
     MGC_CHECK(hipMemsetAsync(status_b, 0, (size_t)tiles1_max * (R / 2) * sizeof(u64), st));
   }
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2], st));
+  if (dbg && dbg_buf)
+    hipLaunchKernelGGL((radix_group_kernel<u32, RB, BLOCK, KPT1, true, false, false>), dim3((uint32_t)std::min(tiles1_max, cus * GS1::WG_PER_CU)), dim3(BLOCK),
+                       GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
+                       &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
+                       GroupExtra{0u, 0u, 0u, nullptr}, dbg_buf + 64 * 8);
+  else
   hipLaunchKernelGGL((radix_group_kernel<u32, RB, BLOCK, KPT1, false, false, false>), dim3((uint32_t)std::min(tiles1_max, cus * GS1::WG_PER_CU)), dim3(BLOCK),
                      GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
                      &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
@@ -1375,7 +1416,24 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
   const u64 ng = (u64)1 << (bA + bB);
   hipLaunchKernelGGL(narrow_bounds_kernel, dim3((uint32_t)((ng + 1 + 255) / 256)), dim3(256), 0, st, status_b, region_tiles,
                      &hdr->gbase[1][0], (u64)n, bA, ng, reinterpret_cast<u64 *>(d_sub_starts));
-  return hipGetLastError();
+  MGC_CHECK(hipGetLastError());
+  if (dbg && dbg_buf) {
+    dbg_reports--;
+    u64 h[2 * 64 * 8];
+    MGC_CHECK(hipStreamSynchronize(st));
+    MGC_CHECK(hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost));
+    for (int pass = 0; pass < 2; pass++) {
+      double ps[8] = {0};
+      for (int b = 0; b < 64; b++) for (int i = 0; i < 8; i++) ps[i] += (double)h[(pass * 64 + b) * 8 + i];
+      const double it = ps[7] > 0 ? ps[7] : 1;
+      fprintf(stderr, "[groupdbg] %s pass, %llu keys, %d-key tiles, tiles/wg=%.1f cycles/tile: ticket+zero=%.0f rank=%.0f scan+exchange=%.0f "
+                      "lookback(+prefetch%s)=%.0f writeout=%.0f endsync=%.0f total=%.0f\n",
+              pass ? "second (u32 -> u32)" : "first (u64 -> u32)", (unsigned long long)n, pass ? (int)TILE1 : (int)TILE0, it / 64,
+              ps[0] / it, ps[1] / it, ps[2] / it, pass ? "" : ", low-digit count", ps[3] / it, ps[4] / it, ps[5] / it,
+              (ps[0] + ps[1] + ps[2] + ps[3] + ps[4] + ps[5]) / it);
+    }
+  }
+  return hipSuccess;
 }
 
 size_t narrow_zero_bytes(uint64_t n) { return narrow_status_bytes(n); }
