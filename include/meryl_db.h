@@ -195,6 +195,14 @@ int mgc_count_node(const mgc_count_config *cfg, uint32_t n_ranks, const int *dev
                    const uint8_t *const *d_bases, const uint64_t *n_bases,
                    const char *db_path, int host_threads, mgc_node_profile *prof);
 
+/* The routing plan of mgc_count_node on its own (host arithmetic only, no device needed): *bucket_bits = the top bits of the k-mer
+ * that route it for n_ranks ranks whose largest input is max_rank_bases (6 + ceil(log2 n_ranks), more for very large inputs, at
+ * most 10 and at most w_prefix); with bucket_totals[2^*bucket_bits] (k-mers per bucket over all ranks) also cuts[n_ranks + 1]: rank r
+ * owns buckets [cuts[r], cuts[r+1]) -- contiguous, every rank at least one, balanced by k-mers.  MGC_EINVAL when the ranks
+ * outnumber the routable ranges. */
+int mgc_node_plan(uint32_t n_ranks, uint32_t k, uint64_t max_rank_bases, uint32_t w_prefix, uint32_t *bucket_bits,
+                  const uint64_t *bucket_totals, uint32_t *cuts);
+
 /* The same for input that went through ONE session (pushed bases, parsed text, files -- the CLI's `gpus=N`): the staged
  * stream (mgc_staged_bases) is cut into n_ranks slices overlapping by k-1 bases -- no k-mer lost or doubled wherever the
  * cut falls; `compress` is applied before cutting -- the slices move to their devices and mgc_count_node runs.  The

@@ -32,7 +32,7 @@ SYMBOLS = (
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_read_file_ex",
     "mdb_reader_file_index", "mdb_reader_block_header", "mdb_reader_read_block_raw", "mdb_reader_close",
     "mdb_free", "mgc_write_database", "mgc_write_database_profiled",
-    "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_merge", "mgc_count_node", "mgc_count_node_staged",
+    "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_merge", "mgc_count_node", "mgc_count_node_staged", "mgc_node_plan",
     # include/meryl_lookup.h
     "mgc_lookup_load", "mgc_lookup_from_device", "mgc_lookup_free", "mgc_lookup_get_info", "mgc_lookup_error",
     "mgc_lookup_values", "mgc_lookup_stream", "mgc_lookup_existence",
@@ -306,6 +306,7 @@ def lib():
     sig("mgc_count_node", i32, P(CountConfig), u32, P(ctypes.c_int), P(vp), P(u64), ctypes.c_char_p, i32, P(NodeProfile))
     sig("mgc_staged_bases", i32, vp, P(vp), P(u64))
     sig("mgc_count_node_staged", i32, vp, u32, P(ctypes.c_int), ctypes.c_char_p, i32, P(NodeProfile))
+    sig("mgc_node_plan", i32, u32, u32, u64, u32, P(u32), P(u64), P(u32))
     sig("mgc_lookup_load", vp, ctypes.c_char_p, u64, u64, i32, i32)
     sig("mgc_lookup_from_device", vp, vp, vp, u64, u32, u64, u64, i32)
     sig("mgc_lookup_free", None, vp)

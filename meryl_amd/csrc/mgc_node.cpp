@@ -316,6 +316,22 @@ extern "C" int mgc_count_node(const mgc_count_config *cfg, uint32_t n_ranks, con
   return MGC_OK;
 }
 
+// The routing plan mgc_count_node derives, on its own (pure host arithmetic: which bucket granularity, which contiguous bucket
+// range every rank owns) -- for callers that want to know where a k-mer will be counted, and for the CPU tests that hold it
+// against the RCCL launcher's plan (meryl_amd/count.py: shard_bucket_bits, balanced_file_ranges).
+extern "C" int mgc_node_plan(uint32_t n_ranks, uint32_t k, uint64_t max_rank_bases, uint32_t w_prefix, uint32_t *bucket_bits,
+                             const uint64_t *bucket_totals, uint32_t *cuts) {
+  if (!n_ranks || !bucket_bits || k < 1 || k > 64) return MGC_EINVAL;
+  *bucket_bits = bucket_bits_for(n_ranks, k, max_rank_bases, w_prefix);
+  if ((1u << *bucket_bits) < n_ranks) return MGC_EINVAL;
+  if (bucket_totals && cuts) {
+    const std::vector<uint64_t> total(bucket_totals, bucket_totals + (1u << *bucket_bits));
+    const std::vector<uint32_t> c = balanced_ranges(total, n_ranks);
+    for (uint32_t r = 0; r <= n_ranks; r++) cuts[r] = c[r];
+  }
+  return MGC_OK;
+}
+
 // The CLI's gpus=N: everything was read and parsed through ONE session (device parser, pinned ring); its staged base
 // stream is cut into n_ranks slices that overlap by k-1 bases -- a window starting in the last k-1 bases of slice r-1
 // is incomplete there and complete in slice r, so no k-mer is lost or counted twice wherever the cut falls --

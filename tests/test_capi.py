@@ -122,3 +122,38 @@ def test_product_never_imports_oracle():
                     if re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M) or "liboracle" in txt or "oracle.h" in txt:
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_node_plan_equals_the_rccl_launchers_plan(native_lib):
+    """mgc_count_node (one process, peer copies) and count_sharded (one process per GPU, RCCL) must route alike: the C++
+    plan -- bucket granularity and the balanced contiguous bucket ranges -- against the Python launcher's on random histograms,
+    skewed ones (everything in one bucket, empty tails) and the refusal when ranks outnumber the routable ranges."""
+    import ctypes
+    from meryl_amd import count
+    rng = np.random.default_rng(5)
+    L = native_lib
+    for trial in range(300):
+        n = int(rng.integers(1, 65))
+        k = int(rng.choice([4, 8, 16, 21, 31, 51]))
+        w_prefix = int(rng.integers(6, min(2 * k, 24) + 1))
+        max_bases = int(rng.choice([0, 10 ** 6, 10 ** 10, 3 * 10 ** 10, 10 ** 11]))
+        bits = ctypes.c_uint32(0)
+        want_bits = count.shard_bucket_bits(n, k, max_bases, w_prefix)
+        rc = L.mgc_node_plan(n, k, max_bases, w_prefix, ctypes.byref(bits), None, None)
+        if (1 << want_bits) < n:
+            assert rc != 0
+            continue
+        assert rc == 0 and bits.value == want_bits, (n, k, max_bases, w_prefix, bits.value, want_bits)
+        nb = 1 << want_bits
+        shape = trial % 4
+        if shape == 0:
+            tot = rng.integers(0, 10 ** 9, nb).astype(np.uint64)
+        elif shape == 1:
+            tot = np.zeros(nb, np.uint64); tot[int(rng.integers(0, nb))] = 10 ** 12
+        elif shape == 2:
+            tot = (rng.pareto(1.2, nb) * 1e6).astype(np.uint64)
+        else:
+            tot = np.zeros(nb, np.uint64); tot[:nb // 3] = rng.integers(1, 10 ** 6, nb // 3).astype(np.uint64)
+        cuts = (ctypes.c_uint32 * (n + 1))()
+        assert L.mgc_node_plan(n, k, max_bases, w_prefix, ctypes.byref(bits), tot.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), cuts) == 0
+        assert list(cuts) == [int(c) for c in count.balanced_file_ranges(tot, n)]
