@@ -82,11 +82,10 @@ hipError_t launch_group_prepare(const void *d_keys, uint64_t n, uint32_t key_wor
 bool       sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words);
 // The high-digit-first form (files of a session with the fifteen-bit file histogram): launch_narrow_prepare fills one
 // header per file (nb <= 64, sort_header_bytes() apart) from d_fine; every file then gets its header and a scratch area of
-// narrow_scratch_bytes(n) whose first narrow_zero_bytes(n) bytes the caller has zeroed.  See mgc_sort.hip: nobody reads the
+// narrow_scratch_bytes(n) that the caller has zeroed.  See mgc_sort.hip: nobody reads the
 // keys for a digit histogram, and the sub-buckets come out in the order tr_index(., *tr_a, *tr_b) describes.
 // d_prepared / d_scratch == nullptr: low digit first off one histogram read, scratch in d_ws, sub-buckets in key order.
 size_t     narrow_scratch_bytes(uint64_t n);
-size_t     narrow_zero_bytes(uint64_t n);
 hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsigned char *bits_a, const unsigned char *on, void *d_hdrs,
                                  hipStream_t st);
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,

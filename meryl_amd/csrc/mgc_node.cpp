@@ -158,9 +158,10 @@ void phase_count(Node &nd, uint32_t r, hipStream_t st_copy) {
   cfg.homopoly_compress = 0;                    // the owner side sees k-mers, never bases
   mgc_session *sess = mgc_open(&cfg, me.device);
   if (!sess) { nd.fail("rank %u: mgc_open: %s", r, mgc_last_error(nullptr)); return; }
+  struct SessionGuard { mgc_session *s; ~SessionGuard() { if (s) mgc_close(s); } } sess_guard{sess};   // closed whichever way this ends
   mgc_db_stream *ds = mgc_db_stream_open(nd.path.c_str(), cfg.k, cfg.w_prefix, cfg.label_size, cfg.label_constant, r, n,
                                          nd.host_threads, me.device);
-  if (!ds) { nd.fail("rank %u: %s", r, mgc_db_stream_error(nullptr)); mgc_close(sess); return; }
+  if (!ds) { nd.fail("rank %u: %s", r, mgc_db_stream_error(nullptr)); return; }
   const uint64_t blocks_per_bucket = 1ull << (cfg.w_prefix - nd.bits);
 
   uint32_t most = 0;
@@ -223,7 +224,6 @@ void phase_count(Node &nd, uint32_t r, hipStream_t st_copy) {
   if (crc != MGC_OK && ok) nd.fail("rank %u: mgc_db_stream_close: %s", r, mgc_db_stream_error(nullptr));
   me.t_close = now_s() - t1;
   for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-  mgc_close(sess);
 }
 
 void rank_main(Node &nd, uint32_t r) {

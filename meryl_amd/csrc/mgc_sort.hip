@@ -1281,10 +1281,6 @@ size_t narrow_scratch_bytes(uint64_t n) {
   const uint64_t tiles0 = (n + NARROW_TILE0 - 1) / NARROW_TILE0, tiles1_max = (n + NARROW_TILE1 - 1) / NARROW_TILE1 + RS_MAX_RADIX + 1;
   return (size_t)(tiles0 + tiles1_max) * (RS_MAX_RADIX / 2) * sizeof(u64) + (size_t)(RS_MAX_RADIX + 2) * 16 + 512;
 }
-static size_t narrow_status_bytes(uint64_t n) {            // the part of it that must be zero before the passes
-  const uint64_t tiles0 = (n + NARROW_TILE0 - 1) / NARROW_TILE0, tiles1_max = (n + NARROW_TILE1 - 1) / NARROW_TILE1 + RS_MAX_RADIX + 1;
-  return (size_t)(tiles0 + tiles1_max) * (RS_MAX_RADIX / 2) * sizeof(u64);
-}
 
 // headers of all files at once (files with on[f] = 0 are skipped); d_hdrs: nb x sort_header_bytes()
 hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsigned char *bits_a, const unsigned char *on, void *d_hdrs,
@@ -1435,8 +1431,6 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
   }
   return hipSuccess;
 }
-
-size_t narrow_zero_bytes(uint64_t n) { return narrow_status_bytes(n); }
 
 size_t sort_header_bytes() { return ((sizeof(SortHeader) + 255) / 256) * 256; }
 
