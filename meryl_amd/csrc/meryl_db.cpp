@@ -695,6 +695,60 @@ extern "C" int mdb_reader_block_header(mdb_reader *r, uint32_t ff, uint64_t posi
   return mdb_reader_read_block_raw(r, ff, position, h, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
+namespace {
+// One stuffedBits object that lies in memory (the whole data file is read at once): its logical bit stream as a word
+// pointer.  The common case -- one sub-block, every data block below 16 MiB -- is decoded IN PLACE (the words are 8-byte aligned
+// because every field of the layout is a multiple of 8 bytes); a longer object is gathered into `gather`.  `avail` = bytes from
+// `at` to the end of the buffer (which carries 16 bytes of slack for two-word reads).
+bool stuffed_in_memory(const unsigned char *at, uint64_t avail, std::vector<uint64_t> &gather, const uint64_t **words, uint64_t *nbits) {
+  if (avail < 16) return false;
+  uint64_t lenmax; uint32_t nblocks;
+  memcpy(&lenmax, at, 8); memcpy(&nblocks, at + 8, 4);
+  if (nblocks == 0 || nblocks > (1u << 20) || lenmax == 0 || lenmax > (1ull << 40)) return false;
+  const uint64_t head = 16 + 16ull * nblocks;
+  if (avail < head + 16) return false;
+  const unsigned char *bgn = at + 16, *len = at + 16 + 8ull * nblocks, *q = at + head;
+  uint64_t total = 0;
+  if (nblocks > 1) gather.clear();
+  for (uint32_t i = 0; i < nblocks; i++) {
+    uint64_t b, l, nw;
+    memcpy(&b, bgn + 8ull * i, 8); memcpy(&l, len + 8ull * i, 8);
+    if ((uint64_t)(q - at) + 16 > avail) return false;
+    memcpy(&nw, q, 8);
+    q += 16;
+    if (b % 64 != 0 || b != total || l > lenmax || nw != (l + 63) / 64) return false;    // only what dump_stuffed writes
+    if ((uint64_t)(q - at) + 8 * nw > avail) return false;
+    if (nblocks == 1) *words = reinterpret_cast<const uint64_t *>(q);
+    else gather.insert(gather.end(), reinterpret_cast<const uint64_t *>(q), reinterpret_cast<const uint64_t *>(q) + nw);
+    q += 8 * nw;
+    total += l;
+    if (i + 1 < nblocks && l % 64 != 0) return false;
+  }
+  if (nblocks > 1) { gather.push_back(0); gather.push_back(0); *words = gather.data(); }
+  *nbits = total;
+  return true;
+}
+
+// MSB-first bit cursor without per-call bookkeeping: the caller checks `pos` against the stream length once per k-mer
+struct FastBits {
+  const uint64_t *w; uint64_t pos;
+  inline uint64_t peek() const {
+    const uint64_t i = pos >> 6; const uint32_t off = (uint32_t)(pos & 63);
+    return off ? ((w[i] << off) | (w[i + 1] >> (64 - off))) : w[i];
+  }
+  inline uint64_t get(uint32_t width) { const uint64_t v = peek() >> (64 - width); pos += width; return v; }   // width 1..64
+  inline uint64_t unary(uint64_t limit) {            // zeros before the next one bit; pos = limit + 1 when the stream runs out first
+    uint64_t v = 0;
+    for (;;) {
+      const uint64_t x = peek();
+      if (x) { const uint32_t lz = (uint32_t)__builtin_clzll(x); pos += lz + 1; return v + lz; }
+      v += 64; pos += 64;
+      if (pos > limit) { pos = limit + 1; return v; }
+    }
+  }
+};
+}  // namespace
+
 extern "C" int mdb_reader_read_file_ex(mdb_reader *r, uint32_t ff, uint64_t **klo, uint64_t **khi, uint32_t **cnt,
                                        uint64_t **labels, uint64_t *n_out) {
   if (!r || ff >= MGC_NUM_FILES || !klo || !cnt || !n_out) return MGC_EINVAL;
@@ -702,48 +756,74 @@ extern "C" int mdb_reader_read_file_ex(mdb_reader *r, uint32_t ff, uint64_t **kl
   const uint64_t nblocks = 1ull << r->info.num_blocks_bits;
   std::vector<FileIndexEntry> idx;
   if (!load_file_index(r, ff, idx)) return MGC_EINVAL;
-  FILE *fd = fopen(block_name(r->dir, ff, false).c_str(), "rb");
-  if (!fd) { db_err("read_file: cannot open data file in '%s'", r->dir.c_str()); return MGC_EINVAL; }
-  // the index is input too: its k-mer total cannot exceed what the data file could hold at one bit per k-mer
+  // the whole data file in one read (a file of the 10 Gbp database is ~100 MB); blocks are decoded where they lie
+  const int fd = open(block_name(r->dir, ff, false).c_str(), O_RDONLY);
+  if (fd < 0) { db_err("read_file: cannot open data file in '%s'", r->dir.c_str()); return MGC_EINVAL; }
   struct stat st;
+  bool ok = fstat(fd, &st) == 0;
+  const uint64_t fsize = ok ? (uint64_t)st.st_size : 0;
+  // the index is input too: its k-mer total cannot exceed what the data file could hold at one bit per k-mer
   uint64_t total = 0;
-  bool ok = fstat(fileno(fd), &st) == 0;
-  for (auto &e : idx) { if (e.n_kmers > (uint64_t)st.st_size * 8) ok = false; total += e.n_kmers; }
-  if (!ok || total > (uint64_t)st.st_size * 8) { fclose(fd); db_err("read_file: index of '%s' does not fit its data file", r->dir.c_str()); return MGC_EINVAL; }
-  uint64_t *lo = (uint64_t *)malloc(8 * (total ? total : 1)), *hi = (uint64_t *)calloc(total ? total : 1, 8);
-  uint64_t *lb = (uint64_t *)calloc(total ? total : 1, 8);
-  uint32_t *cn = (uint32_t *)malloc(4 * (total ? total : 1));
-  if (!lo || !hi || !cn || !lb) { fclose(fd); free(lo); free(hi); free(cn); free(lb); db_err("read_file: out of memory for '%s'", r->dir.c_str()); return MGC_ENOMEM; }
+  for (auto &e : idx) { if (e.n_kmers > fsize * 8) ok = false; total += e.n_kmers; }
+  if (!ok || total > fsize * 8) { close(fd); db_err("read_file: index of '%s' does not fit its data file", r->dir.c_str()); return MGC_EINVAL; }
+  unsigned char *file = (unsigned char *)malloc(fsize + 16);
+  if (!file) { close(fd); db_err("read_file: out of memory for '%s'", r->dir.c_str()); return MGC_ENOMEM; }
+  for (uint64_t got = 0; got < fsize && ok;) {
+    const ssize_t n = pread(fd, file + got, fsize - got, (off_t)got);
+    if (n < 0 && errno == EINTR) continue;
+    if (n <= 0) ok = false; else got += (uint64_t)n;
+  }
+  close(fd);
+  memset(file + fsize, 0, 16);
   const uint32_t ss = r->info.suffix_size, ls = r->info.label_size;
+  const bool wide = 2 * r->info.k > 64;
+  uint64_t *lo = (uint64_t *)malloc(8 * (total ? total : 1)), *hi = (uint64_t *)calloc(total ? total : 1, 8);
+  uint64_t *lb = (uint64_t *)calloc(total ? total : 1, 8);           // untouched (lazily zero) pages unless the database holds labels / k > 32
+  uint32_t *cn = (uint32_t *)malloc(4 * (total ? total : 1));
+  if (!ok || !lo || !hi || !cn || !lb) {
+    free(file); free(lo); free(hi); free(cn); free(lb);
+    db_err(ok ? "read_file: out of memory for '%s'" : "read_file: cannot read the data file in '%s'", r->dir.c_str());
+    return ok ? MGC_ENOMEM : MGC_EINVAL;
+  }
   uint64_t o = 0;
-  std::vector<uint64_t> words;
+  std::vector<uint64_t> gather;
   for (uint64_t bb = 0; bb < nblocks && ok; bb++) {
     const FileIndexEntry &e = idx[bb];
-    if (e.position >= (uint64_t)st.st_size || fseek(fd, (long)e.position, SEEK_SET) != 0) { ok = false; break; }
-    uint64_t nbits = 0;
-    if (!load_stuffed(fd, words, nbits)) { ok = false; break; }
-    BitReader br; br.w = words.data(); br.nbits = nbits;
+    const uint64_t *words = nullptr; uint64_t nbits = 0;
+    if (e.position >= fsize || (e.position & 7) || !stuffed_in_memory(file + e.position, fsize + 16 - e.position, gather, &words, &nbits)) { ok = false; break; }
+    BitReader br; br.w = words; br.nbits = nbits;
     DecodedHeader d = decode_header(br, ss);
     const uint64_t prefix = d.h.prefix, n = d.h.n_kmers;
     const uint32_t bb_bits = d.h.binary_bits;
-    if (!d.ok || n != e.n_kmers || prefix != e.prefix) { ok = false; break; }
+    if (!d.ok || n != e.n_kmers || prefix != e.prefix || o + n > total) { ok = false; break; }
+    FastBits fb{words, br.pos};
     uint64_t top = 0;
-    for (uint64_t i = 0; i < n; i++) {
-      top += br.get_unary();
-      // suffix = top << bb_bits | binary ; full k-mer = prefix << ss | suffix  (128-bit)
-      unsigned __int128 suf;
-      if (bb_bits <= 64) suf = ((unsigned __int128)top << bb_bits) | (bb_bits ? br.get(bb_bits) : 0);
-      else { const uint64_t h = br.get(bb_bits - 64), l = br.get(64); suf = ((unsigned __int128)top << bb_bits) | ((unsigned __int128)h << 64) | l; }
-      const unsigned __int128 full = ((unsigned __int128)prefix << ss) | suf;
-      lo[o + i] = (uint64_t)full;
-      hi[o + i] = (uint64_t)(full >> 64);
+    if (!wide && bb_bits >= 1 && bb_bits <= 64) {                        // k <= 32: the k-mer is one word
+      const uint64_t pre = ss < 64 ? prefix << ss : 0;
+      for (uint64_t i = 0; i < n; i++) {
+        top += fb.unary(nbits);
+        if (fb.pos + bb_bits > nbits) { ok = false; break; }
+        lo[o + i] = pre | (bb_bits < 64 ? top << bb_bits : 0) | fb.get(bb_bits);
+      }
+    } else {
+      for (uint64_t i = 0; i < n; i++) {
+        top += fb.unary(nbits);
+        if (fb.pos + bb_bits > nbits) { ok = false; break; }
+        // suffix = top << bb_bits | binary ; full k-mer = prefix << ss | suffix  (128-bit)
+        unsigned __int128 suf = (unsigned __int128)top << bb_bits;
+        if (bb_bits > 64) { const uint64_t h = fb.get(bb_bits - 64), l = fb.get(64); suf |= ((unsigned __int128)h << 64) | l; }
+        else if (bb_bits) suf |= fb.get(bb_bits);
+        const unsigned __int128 full = ((unsigned __int128)prefix << ss) | suf;
+        lo[o + i] = (uint64_t)full;
+        hi[o + i] = (uint64_t)(full >> 64);
+      }
     }
-    for (uint64_t i = 0; i < n; i++) cn[o + i] = (uint32_t)br.get(VALUE_BITS);
-    if (ls) for (uint64_t i = 0; i < n; i++) lb[o + i] = br.get(ls);
-    if (br.bad) { ok = false; break; }
+    if (!ok || fb.pos + n * (uint64_t)(VALUE_BITS + ls) > nbits) { ok = false; break; }
+    for (uint64_t i = 0; i < n; i++) cn[o + i] = (uint32_t)fb.get(VALUE_BITS);
+    if (ls) for (uint64_t i = 0; i < n; i++) lb[o + i] = fb.get(ls);
     o += n;
   }
-  fclose(fd);
+  free(file);
   if (!ok || o != total) { free(lo); free(hi); free(cn); free(lb); db_err("read_file: corrupt block in '%s'", r->dir.c_str()); return MGC_EINVAL; }
   *klo = lo; if (khi) *khi = hi; else free(hi); *cnt = cn; if (labels) *labels = lb; else free(lb); *n_out = total;
   return MGC_OK;
