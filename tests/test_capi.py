@@ -101,6 +101,35 @@ def test_error_codes_not_exit(native_lib):
     assert native_lib.mgc_dev_radix_sort(None, None, 0, 2, 0, 128, None, 0, ctypes.byref(ia), None) == capi.MGC_OK
 
 
+def test_node_count_argument_checks_need_no_device(native_lib):
+    """mgc_count_node / mgc_count_node_staged / mgc_staged_bases / mgc_node_plan refuse bad arguments with a code and a message
+    before any device work (this box has no GPU: anything that got past the checks would fail differently)."""
+    from meryl_amd import capi
+    L = native_lib
+    cfg = capi.configure(21, 1000, 1 << 30)
+    one = (ctypes.c_void_p * 1)(None)
+    n1 = (ctypes.c_uint64 * 1)(0)
+    assert L.mgc_count_node(None, 1, None, one, n1, b"/tmp/x", 1, None) == capi.MGC_EINVAL
+    assert L.mgc_count_node(ctypes.byref(cfg), 0, None, one, n1, b"/tmp/x", 1, None) == capi.MGC_EINVAL
+    assert L.mgc_count_node(ctypes.byref(cfg), 1, None, one, n1, None, 1, None) == capi.MGC_EINVAL
+    sfx = capi.configure(21, 1000, 1 << 30, count_suffix="ACG")
+    assert L.mgc_count_node(ctypes.byref(sfx), 1, None, one, n1, b"/tmp/x", 1, None) == capi.MGC_EINVAL
+    assert b"count-suffix" in L.mgc_last_error(None)
+    raw = capi.CountConfig()
+    raw.k = 21
+    assert L.mgc_count_node(ctypes.byref(raw), 1, None, one, n1, b"/tmp/x", 1, None) == capi.MGC_EINVAL
+    assert b"mgc_configure_counting" in L.mgc_last_error(None)
+    assert L.mgc_count_node_staged(None, 2, None, b"/tmp/x", 1, None) == capi.MGC_EINVAL
+    p = ctypes.c_void_p()
+    n = ctypes.c_uint64(0)
+    assert L.mgc_staged_bases(None, ctypes.byref(p), ctypes.byref(n)) == capi.MGC_EINVAL
+    bits = ctypes.c_uint32(0)
+    assert L.mgc_node_plan(0, 21, 0, 18, ctypes.byref(bits), None, None) == capi.MGC_EINVAL
+    assert L.mgc_node_plan(2, 0, 0, 18, ctypes.byref(bits), None, None) == capi.MGC_EINVAL
+    assert L.mgc_node_plan(100, 21, 0, 6, ctypes.byref(bits), None, None) == capi.MGC_EINVAL      # 64 ranges, 100 ranks
+    assert L.mgc_node_plan(8, 21, 10 ** 10, 18, ctypes.byref(bits), None, None) == 0 and bits.value == 9
+
+
 def test_workspace_sizes_monotone(native_lib):
     prev = 0
     for n in (0, 1, 4096, 10**6, 10**9):
