@@ -186,3 +186,30 @@ def test_node_plan_equals_the_rccl_launchers_plan(native_lib):
         cuts = (ctypes.c_uint32 * (n + 1))()
         assert L.mgc_node_plan(n, k, max_bases, w_prefix, ctypes.byref(bits), tot.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), cuts) == 0
         assert list(cuts) == [int(c) for c in count.balanced_file_ranges(tot, n)]
+
+
+def test_staged_slices_with_k_minus_1_overlap_lose_and_double_nothing(oracle_lib):
+    """The cutting rule of mgc_count_node_staged (slice r = [cut_r - (k-1), cut_{r+1}), cuts anywhere in the stream -- inside reads,
+    inside '.' runs, within k-1 bases of either end), restated in Python and held against the oracle: the k-mer counts of the
+    slices add up to the counts of the whole stream, for every k and rank count tried."""
+    import collections
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        k = int(rng.choice([3, 5, 8, 13, 21, 31]))
+        parts = []
+        for _ in range(int(rng.integers(1, 30))):
+            parts.append("".join("ACGTN"[i] for i in rng.choice(5, int(rng.integers(0, 3 * k)), p=[.24, .24, .24, .24, .04])))
+            parts.append("." * int(rng.integers(1, 4)))
+        stream = "".join(parts)
+        n = len(stream)
+        for n_ranks in (1, 2, 3, 7, 16):
+            total = collections.Counter()
+            for r in range(n_ranks):
+                cut, end = n * r // n_ranks, n * (r + 1) // n_ranks
+                a = cut - (k - 1) if (r and cut >= k - 1) else 0
+                hi, lo, cn, _ = oracle_lib.count_brute(stream[a:end], k)
+                for h, l, c in zip(hi, lo, cn):
+                    total[(int(h), int(l))] += int(c)
+            hi, lo, cn, _ = oracle_lib.count_brute(stream, k)
+            want = {(int(h), int(l)): int(c) for h, l, c in zip(hi, lo, cn)}
+            assert dict(total) == want, (k, n_ranks, stream)
