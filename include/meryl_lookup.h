@@ -39,6 +39,12 @@ typedef struct mgc_lookup_info {
  * threads, uploaded and indexed on `device` (< 0: current).  NULL on failure; text via mgc_lookup_error(). */
 mgc_lookup *mgc_lookup_load(const char *db_path, uint64_t min_value, uint64_t max_value, int device, int host_threads);
 
+/* merylExactLookup::estimateMemoryUsage (src/meryl-lookup/meryl-lookup.C:62-73): what mgc_lookup_load of this database with this
+ * value filter will hold on the device, WITHOUT loading it and without a device -- the number of k-mers kept comes from the
+ * database's own value histogram (exact), the bytes from the table's layout (8 or 16 B per k-mer + 4 B per value + the top-bits
+ * index).  0 on success; text of a failure: mgc_lookup_error(). */
+int mgc_lookup_estimate(const char *db_path, uint64_t min_value, uint64_t max_value, mgc_lookup_info *info);
+
 /* The same from a (k-mer, value) stream that is already in HBM (distinct, ascending: a count session's result, a merge):
  * no file round trip.  The arrays are copied. */
 mgc_lookup *mgc_lookup_from_device(const void *d_keys, const uint32_t *d_values, uint64_t n, uint32_t k,

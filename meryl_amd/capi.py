@@ -34,7 +34,7 @@ SYMBOLS = (
     "mdb_free", "mgc_write_database", "mgc_write_database_profiled",
     "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_merge", "mgc_count_node", "mgc_count_node_staged", "mgc_node_plan",
     # include/meryl_lookup.h
-    "mgc_lookup_load", "mgc_lookup_from_device", "mgc_lookup_free", "mgc_lookup_get_info", "mgc_lookup_error",
+    "mgc_lookup_load", "mgc_lookup_estimate", "mgc_lookup_from_device", "mgc_lookup_free", "mgc_lookup_get_info", "mgc_lookup_error",
     "mgc_lookup_values", "mgc_lookup_stream", "mgc_lookup_existence",
     # include/meryl_seq.h
     "msr_open", "msr_read_text", "msr_close", "msr_last_error", "msr_load_bases", "msr_load_stream", "msr_format", "msr_is_compressed", "msr_guess_number_of_kmers",
@@ -308,6 +308,7 @@ def lib():
     sig("mgc_count_node_staged", i32, vp, u32, P(ctypes.c_int), ctypes.c_char_p, i32, P(NodeProfile))
     sig("mgc_node_plan", i32, u32, u32, u64, u32, P(u32), P(u64), P(u32))
     sig("mgc_lookup_load", vp, ctypes.c_char_p, u64, u64, i32, i32)
+    sig("mgc_lookup_estimate", i32, ctypes.c_char_p, u64, u64, P(LookupInfo))
     sig("mgc_lookup_from_device", vp, vp, vp, u64, u32, u64, u64, i32)
     sig("mgc_lookup_free", None, vp)
     sig("mgc_lookup_get_info", i32, vp, P(LookupInfo))

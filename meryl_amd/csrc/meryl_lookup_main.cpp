@@ -71,7 +71,8 @@ int main(int argc, char **argv) {
   std::string seq_name, out_name;
   std::vector<std::string> dbs;
   uint64_t vmin = 0, vmax = UINT64_MAX;
-  bool existence = false;
+  bool existence = false, estimate = false;
+  double max_memory_gb = 0.0;                                 // -memory: 0 = whatever the device has
   for (int a = 1; a < argc; a++) {
     const std::string w = argv[a];
     if (w == "-existence") existence = true;
@@ -80,16 +81,35 @@ int main(int argc, char **argv) {
     else if (w == "-min" && a + 1 < argc) vmin = strtoull(argv[++a], nullptr, 10);
     else if (w == "-max" && a + 1 < argc) vmax = strtoull(argv[++a], nullptr, 10);
     else if (w == "-threads" && a + 1 < argc) ++a;
-    else if (w == "-memory" && a + 1 < argc) ++a;
+    else if (w == "-memory" && a + 1 < argc) max_memory_gb = strtod(argv[++a], nullptr);
+    else if (w == "-estimate") estimate = true;
     else if (w == "-mers") { while (a + 1 < argc && argv[a + 1][0] != '-') dbs.push_back(argv[++a]); }
     else if (w == "-dump" || w == "-include" || w == "-exclude" || w == "-bed" || w == "-bed-runs" || w == "-wig-count" || w == "-wig-depth")
       die("ERROR: mode '%s' is not part of this build (-existence only).", w.c_str());
     else die("ERROR: unknown option '%s'.", w.c_str());
   }
-  if (!existence || seq_name.empty() || dbs.empty()) {
-    fprintf(stderr, "usage: %s -existence -sequence <in.fa|fq[.gz]> -mers <db.meryl> [...] [-min v] [-max v] [-output out.tsv]\n", argv[0]);
+  if (!existence || (seq_name.empty() && !estimate) || dbs.empty()) {
+    fprintf(stderr, "usage: %s -existence -sequence <in.fa|fq[.gz]> -mers <db.meryl> [...] [-min v] [-max v] [-memory GB] [-estimate] [-output out.tsv]\n", argv[0]);
     return 1;
   }
+
+  // meryl-lookup.C:62-87: the memory every table will need, BEFORE anything is loaded (here: device memory, from the databases'
+  // own value histograms -- no device is touched); -estimate stops after the report, -memory is the limit it is held against
+  double required_gb = 0.0;
+  for (const std::string &d : dbs) {
+    fprintf(stderr, "\nEstimating memory usage for '%s'.\n", d.c_str());
+    mgc_lookup_info est;
+    if (mgc_lookup_estimate(d.c_str(), vmin, vmax, &est) != MGC_OK) die("ERROR: %s", mgc_lookup_error());
+    fprintf(stderr, "  %" PRIu64 " of %" PRIu64 " %u-mers kept, %.3f GB of device memory.\n", est.n_kmers, est.n_kmers_in_db, est.k,
+            (double)est.device_bytes / 1024.0 / 1024.0 / 1024.0);
+    required_gb += (double)est.device_bytes / 1024.0 / 1024.0 / 1024.0;
+  }
+  fprintf(stderr, "\nMemory required:  %.3f GB\n", required_gb);
+  if (max_memory_gb > 0.0) {
+    fprintf(stderr, "Memory limit:     %.3f GB\n", max_memory_gb);
+    if (required_gb > max_memory_gb) { fprintf(stderr, "\nNot enough memory to load databases.  Increase -memory.\n"); return 1; }
+  }
+  if (estimate) { fprintf(stderr, "\nStopping after memory estimated reported; -estimate option enabled.\n"); return 0; }
 
   msr_reader *r = msr_open(seq_name.c_str());
   if (!r) die("ERROR: %s", msr_last_error());

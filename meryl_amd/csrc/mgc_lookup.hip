@@ -186,9 +186,40 @@ extern "C" void mgc_lookup_free(mgc_lookup *t) {
 #define LK_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { lk_err(std::string(#expr) + ": " + hipGetErrorString(e__)); mgc_lookup_free(t); return nullptr; } } while (0)
 
 // keys/values already on the device (filtered, owned by the table): build the index
-static mgc_lookup *lookup_finish(mgc_lookup *t) {
+static uint32_t lookup_index_bits(uint32_t k, uint64_t n) {
   uint32_t bits = 0;
-  while (bits < 2 * t->k && bits < 28 && (t->n >> (bits + 2)) > 0) bits++;       // ~4 k-mers per index entry
+  while (bits < 2 * k && bits < 28 && (n >> (bits + 2)) > 0) bits++;             // ~4 k-mers per index entry
+  return bits;
+}
+
+extern "C" int mgc_lookup_estimate(const char *db_path, uint64_t min_value, uint64_t max_value, mgc_lookup_info *info) {
+  if (!db_path || !info) { lk_err("mgc_lookup_estimate: bad arguments"); return MGC_EINVAL; }
+  mdb_reader *r = mdb_reader_open(db_path);
+  if (!r) { lk_err(std::string("mgc_lookup_estimate: ") + mdb_last_error()); return MGC_EINVAL; }
+  mdb_info di;
+  mdb_reader_info(r, &di);
+  std::vector<uint64_t> values(di.hist_len ? di.hist_len : 1), occ(di.hist_len ? di.hist_len : 1);
+  if (di.hist_len && mdb_reader_histogram(r, values.data(), occ.data()) != 0) {
+    lk_err(std::string("mgc_lookup_estimate: ") + mdb_last_error());
+    mdb_reader_close(r);
+    return MGC_EINVAL;
+  }
+  mdb_reader_close(r);
+  uint64_t n_db = 0, n = 0;
+  for (uint64_t i = 0; i < di.hist_len; i++) {
+    n_db += occ[i];
+    if (values[i] >= min_value && values[i] <= max_value) n += occ[i];
+  }
+  memset(info, 0, sizeof(*info));
+  info->k = di.k; info->key_words = di.k > 32 ? 2u : 1u;
+  info->index_bits = lookup_index_bits(di.k, n);
+  info->n_kmers = n; info->n_kmers_in_db = n_db;
+  info->device_bytes = (sizeof(uint64_t) * info->key_words + sizeof(uint32_t)) * n + sizeof(uint64_t) * ((1ull << info->index_bits) + 1);
+  return MGC_OK;
+}
+
+static mgc_lookup *lookup_finish(mgc_lookup *t) {
+  const uint32_t bits = lookup_index_bits(t->k, t->n);
   t->index_bits = bits;
   t->shift = 2 * t->k - bits;
   const uint64_t entries = (1ull << bits) + 1;

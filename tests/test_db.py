@@ -353,3 +353,50 @@ def test_cli_dumpfile_print_and_doc_size_bound(tmp_path, native_lib):
     assert len(subprocess.run([_cli(), "-Q", "print", path], stdout=subprocess.PIPE, text=True).stdout.split("\n")[0].split("\t")) == 2
     di = subprocess.run([_cli(), "-Q", "dumpIndex", path + ".labelled"], stdout=subprocess.PIPE, text=True).stdout
     assert "prefixSize     10" in di and "suffixSize     104" in di and "labelSize      3" in di
+
+
+@pytest.mark.parametrize("k,label_size", [(21, 0), (40, 6)])
+def test_lookup_estimate_needs_no_device(native_lib, tmp_path, k, label_size):
+    """merylExactLookup::estimateMemoryUsage as meryl-lookup uses it before loading (meryl-lookup.C:62-87): k-mers kept by the value
+    filter from the database's own histogram, bytes from the table layout -- on a box without a GPU -- and the CLI's -estimate /
+    -memory report on top of it."""
+    import ctypes
+    import subprocess
+    from meryl_amd import build, capi, db
+    rng = np.random.default_rng(k)
+    wp = 8
+    n = 5000
+    keys = sorted({int(x) for x in rng.integers(0, 1 << 62, n)} if k <= 32 else
+                  {(int(a) << 40) | int(b) for a, b in zip(rng.integers(0, 1 << 40, n), rng.integers(0, 1 << 40, n))})
+    keys = [x & ((1 << (2 * k)) - 1) for x in keys]
+    keys = sorted(set(keys))
+    counts = rng.integers(1, 40, len(keys)).astype(np.uint32)
+    w = db.Writer(str(tmp_path / "d.meryl"), k, wp, label_size)
+    wd = 2 * k - wp
+    by_prefix = {}
+    for x, c in zip(keys, counts):
+        by_prefix.setdefault(x >> wd, []).append((x & ((1 << wd) - 1), int(c)))
+    for p in range(1 << wp):
+        rows = by_prefix.get(p, [])
+        lo = np.array([s & ((1 << 64) - 1) for s, _ in rows], dtype=np.uint64)
+        hi = np.array([s >> 64 for s, _ in rows], dtype=np.uint64)
+        w.add_block(p, lo, np.array([c for _, c in rows], dtype=np.uint32), hi if wd > 64 else None, label=3)
+    w.close()
+    L = native_lib
+    for vmin, vmax in ((0, 2 ** 64 - 1), (5, 20), (39, 39), (100, 200)):
+        info = capi.LookupInfo()
+        assert L.mgc_lookup_estimate(str(tmp_path / "d.meryl").encode(), vmin, vmax, ctypes.byref(info)) == 0
+        kept = int(np.sum((counts >= vmin) & (counts <= vmax)))
+        assert (info.k, info.n_kmers_in_db, info.n_kmers) == (k, len(keys), kept)
+        kw = 2 if k > 32 else 1
+        assert info.key_words == kw and info.device_bytes == (8 * kw + 4) * kept + 8 * ((1 << info.index_bits) + 1)
+    assert L.mgc_lookup_estimate(str(tmp_path / "nope").encode(), 0, 1, ctypes.byref(capi.LookupInfo())) != 0
+    cli = build.build_lookup_cli()
+    p = subprocess.run([cli, "-existence", "-estimate", "-mers", str(tmp_path / "d.meryl"), "-min", "5", "-max", "20", "-memory", "1"],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert "Memory required:" in p.stderr and "Memory limit:     1.000 GB" in p.stderr and "-estimate option enabled" in p.stderr
+    assert "%d of %d %d-mers kept" % (int(np.sum((counts >= 5) & (counts <= 20))), len(keys), k) in p.stderr
+    p = subprocess.run([cli, "-existence", "-estimate", "-mers", str(tmp_path / "d.meryl"), "-memory", "0.00001"],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1 and "Not enough memory" in p.stderr

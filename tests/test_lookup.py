@@ -126,3 +126,4 @@ def test_meryl_lookup_existence_cli(native_lib, oracle_lib, tmp_path):
                 kept = {key for key, c in t.items() if c >= max(vmin, 1)}
                 want += [str(len(kept)), str(sum(1 for x in klo if int(x) in kept))]
             assert row == ["q%d" % i] + want, (i, row, want)
+
