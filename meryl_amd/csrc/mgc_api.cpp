@@ -934,13 +934,22 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   // hand: the file histogram then counts fifteen top bits instead of six (one kernel, same read of the bases) and the
   // 8 B/k-mer digit-histogram read of every file goes away.
   const uint64_t *d_fine = nullptr;
+  uint32_t *d_fine_rows = nullptr;
+  uint32_t local_chunks = 0, local_per_chunk = 0, local_vgrid = 0;
   if (!ext_keys) {
     tm.begin(MGC_STAGE_HISTOGRAM);
     // (two digits cover at most 18 bits: beyond 2k - 6 = 41 nothing narrows and the fifteen-bit histogram would go unused)
     if (kw == 1 && n_bases >= (1u << 22) && 2 * k - bucket_bits <= 41 && mgc::kmer_histogram_fine_ok(k, bucket_bits, s->sfx_mask)) {
       HIP_TRY(s, s->ensure(mgc_session::B_FINE, sizeof(uint64_t) << 15));
       uint64_t *fine = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_FINE].p);
-      HIP_TRY(s, mgc::launch_kmer_histogram_fine(d_bases, n_bases, k, c.mode, d_counts64, fine, part_ws, st));
+      // ... and per CHUNK of the partition's output too (64 MB at 10 Gbp): the first grouping pass of every file then runs
+      // chunk-local, without look-back (mgc_sort.hip, radix_group_local_kernel; MGC_GROUP_LOCAL=0: the look-back kernel)
+      if (mgc::group_local_enabled()) {
+        local_chunks = mgc::kmer_histogram_fine_chunks(n_bases, &local_per_chunk, &local_vgrid);
+        HIP_TRY(s, s->ensure(mgc_session::B_FINE_ROWS, (sizeof(uint32_t) << 15) * (size_t)local_chunks));
+        d_fine_rows = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_FINE_ROWS].p);
+      }
+      HIP_TRY(s, mgc::launch_kmer_histogram_fine(d_bases, n_bases, k, c.mode, d_counts64, fine, part_ws, st, d_fine_rows));
       d_fine = fine;
     } else
     HIP_TRY(s, mgc::launch_kmer_histogram(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, part_ws, st, s->sfx_mask, s->sfx_test));
@@ -1055,8 +1064,11 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         else if (h_counts[b] <= 59049ull * target && rem_bits >= 20) t = 20;
         if (t) hpc_digits[b] = 1;                                      // else (tiny k, gigantic bucket): generic path
       }
-      if (!hpc_digits[b])
-      while (t < rem_bits && t < 26 && (h_counts[b] >> t) > target) t++;
+      if (!hpc_digits[b]) {
+        while (t < rem_bits && t < 26 && (h_counts[b] >> t) > target) t++;
+        // tests reach the large-input plans (two nine-bit digits, 18-bit suffixes at k = 21) on small inputs
+        if (const char *mt = getenv("MGC_FINISH_MIN_TOP")) { const uint32_t m = (uint32_t)atoi(mt); if (h_counts[b] && t < m) t = m < rem_bits ? m : rem_bits; }
+      }
       if (c.homopoly_compress && t && !hpc_digits[b]) {
         // homopolymer-compressed sequence never repeats a base: every 2-bit group after the first takes 3 of its 4
         // values, so only (3/4)^(t/2) of the 2^t top-bit patterns occur and the occupied sub-buckets are that much
@@ -1137,6 +1149,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         d_nws = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_NARROW_WS].p);
         HIP_TRY(s, mgc::launch_narrow_prepare(d_fine, nb, bits_a, on, d_nhdrs, st));
         HIP_TRY(s, hipMemsetAsync(d_nws, 0, nws_off[nb], st));
+        if (d_fine_rows) HIP_TRY(s, mgc::launch_fine_rows_scan(d_fine_rows, local_chunks, nb, bits_a, on, st));
       }
     }
     if (hist_ahead && s->stream2) {
@@ -1163,9 +1176,12 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       int in_alt = 0;
       hipEvent_t *pe = s->profiling ? &pass_ev[(size_t)b * ev_per_file] : nullptr;
       if (narrow[b]) {                                       // X (8 B) -> Y (4 B) -> front of X (4 B); boundaries included
+        mgc::GroupLocal gl;
+        gl.d_rows = d_fine_rows; gl.d_block_base = reinterpret_cast<const uint64_t *>(part_ws);
+        gl.n_chunks = local_chunks; gl.vgrid = local_vgrid; gl.per_chunk = local_per_chunk; gl.file = b; gl.file_start = h_starts[b];
         HIP_TRY(s, mgc::launch_group_narrow(src, (void *)Y, h_counts[b], fp, sort_ws, sort_ws_bytes - 256, d_err, d_substart + sbase[b], st, pe,
                                             d_nhdrs ? (void *)(d_nhdrs + hdr_bytes * b) : nullptr, d_nws ? (void *)(d_nws + nws_off[b]) : nullptr,
-                                            &tr_a[b], &tr_b[b]));
+                                            &tr_a[b], &tr_b[b], (d_nhdrs && d_fine_rows) ? &gl : nullptr));
         file_passes[b] = 2;
         narrowed[b] = 1;
         sort_launch_groups++;

@@ -21,8 +21,11 @@ size_t   kp_workspace_bytes(uint32_t bucket_bits);
 // sfx_mask / sfx_test: count-suffix= filter, a k-mer is kept iff (its low word & sfx_mask) == sfx_test (0, 0: keep all)
 // the same + the k-mers per (file, next nine bits) into d_fine_hist[2^15] (the first digit of the narrowed grouping passes)
 bool       kmer_histogram_fine_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask);
+// d_fine_rows (optional): [kmer_histogram_fine_chunks()][2^15] uint32 -- the same counts per CHUNK (the k-mers that
+// *per_chunk consecutive partition workgroups will write): what the chunk-local first grouping pass needs (mgc_sort.hip)
+uint32_t   kmer_histogram_fine_chunks(uint64_t n_bases, uint32_t *per_chunk, uint32_t *vgrid);
 hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint64_t *d_bucket_counts,
-                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st);
+                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st, uint32_t *d_fine_rows = nullptr);
 hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                                  uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st,
                                  uint64_t sfx_mask = 0, uint64_t sfx_test = 0);
@@ -88,9 +91,21 @@ bool       sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_word
 size_t     narrow_scratch_bytes(uint64_t n);
 hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsigned char *bits_a, const unsigned char *on, void *d_hdrs,
                                  hipStream_t st);
+// Chunk-local first pass (no look-back): the file was written by this session's own partition, so the k-mers of every
+// (chunk, digit) are known from the fifteen-bit histogram's per-chunk rows.  launch_fine_rows_scan turns the rows into
+// exclusive prefixes over the chunks for all files at once; `local` then names the file for launch_group_narrow.
+struct GroupLocal {
+  const uint32_t *d_rows;        // scanned rows
+  const uint64_t *d_block_base;  // the partition's cursors (its workspace after launch_kmer_partition): [vgrid][64]
+  uint32_t n_chunks, vgrid, per_chunk, file;
+  uint64_t file_start;           // absolute index of the file's first k-mer in the partition's output
+};
+bool       group_local_enabled();
+hipError_t launch_fine_rows_scan(uint32_t *d_rows, uint32_t n_chunks, uint32_t nb, const unsigned char *bits_a, const unsigned char *on,
+                                 hipStream_t st);
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events /* 4 or null */,
-                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b);
+                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, const GroupLocal *local = nullptr);
 
 // ---- run-length count ------------------------------------------------------
 size_t     rle_workspace_bytes(uint64_t n);

@@ -624,6 +624,155 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 #undef HC_STAMP
 }
 
+// Bitmap-count finish for narrowed files whose sub-bucket suffixes are at most LB (16 or 18) bits wide -- the judged
+// k = 21 workload: 36 bits below the file, 18 of them grouped away.  A suffix that short is its own perfect hash:
+//   A. every key sets ITS bit in a 2^LB-bit LDS bitmap (one non-returning LDS atomic, no probing, no table to size);
+//   B. one pass over the bitmap -- GPT 16-byte groups per thread -- gives the number of set bits before every group
+//      (u16 prefix per group), the distinct count D, and emits the distinct suffixes ASCENDING straight into place: a set
+//      bit's rank is its position in the bitmap order, so nothing is ever sorted or ranked by comparison;
+//   C. every key finds its rank again (group prefix + popcount below its bit) and adds one to counts[rank];
+//   D. the counts leave, and every key clears the word it set (the bitmap is all zero again: no 32 KiB clear per sub-bucket).
+// O(n + 2^LB / 32) work per sub-bucket against the hash kernel's probe / compact / rank phases; replaces
+// countSingleKmers' sort + run-length passes (merylCountArray.C:323-365) for these files like hash_count_kernel does.
+// Logical group G = t * GPT + g lives at physical group G ^ ((G >> LOG_GPT) & (GPT - 1)): thread t reads its GPT groups with
+// 16-byte LDS loads, and without the swizzle all lanes of an instruction would sit GPT * 16 bytes apart on two bank quads.
+template <int BLOCK, int CAP, int LB, bool LIST>
+__global__ __launch_bounds__(BLOCK, (LB > 16 ? 4 : 6))
+void bitmap_count_kernel(u32 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
+                         u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
+                         const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u32 tr_a, u32 tr_b) {
+  constexpr int KPT = CAP / BLOCK;
+  constexpr int NGRP = 1 << (LB - 7);                  // 128-bit groups of the bitmap
+  constexpr int GPT = NGRP / BLOCK;                    // groups per thread in the scan (8 for LB = 18, 2 for LB = 16)
+  constexpr int LOG_GPT = (GPT == 8) ? 3 : (GPT == 4) ? 2 : (GPT == 2) ? 1 : 0;
+  static_assert(CAP % BLOCK == 0 && NGRP % BLOCK == 0 && (1 << LOG_GPT) == GPT && CAP < 65536, "bitmap geometry");
+  __shared__ uint4 bm4[NGRP];
+  __shared__ __attribute__((aligned(16))) unsigned short pre[NGRP];
+  __shared__ u32 cnt[CAP / 2 + 2];                     // two 16-bit counts per word (a count is <= CAP)
+  __shared__ u32 s_scan[BLOCK / 64 + 1];
+  u32 *bm = reinterpret_cast<u32 *>(bm4);
+  const u32 tid = threadIdx.x;
+  const u64 G = gridDim.x;
+  const u32 low_mask = (low_bits >= 32) ? 0xFFFFFFFFu : ((1u << low_bits) - 1u);
+  auto phys = [](u32 g) -> u32 { return g ^ ((g >> LOG_GPT) & (u32)(GPT - 1)); };
+
+  for (u32 i = tid; i < (u32)NGRP; i += BLOCK) bm4[i] = make_uint4(0u, 0u, 0u, 0u);
+
+  auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
+    aa = 0; nn = 0;
+    if (gg < ng) { aa = starts[gg]; nn = starts[gg + 1] - aa; }
+  };
+  auto load_keys = [&](u64 aa, u64 nn, u32 (&kr)[KPT]) {
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 idx = (u32)j * BLOCK + tid;
+      kr[j] = (nn <= max_size && idx < nn) ? keys[aa + idx] : 0u;
+    }
+  };
+  const u64 np = LIST ? *nz_count : ng;
+  auto sub_at = [&](u64 pp) -> u64 { return (pp < np) ? (LIST ? (u64)nz[pp] : pp) : ng; };
+  u64 p = blockIdx.x;
+  u64 g = sub_at(p), g1 = sub_at(p + G), g2 = sub_at(p + 2 * G), a, n64, na, nn;
+  u32 kcur[KPT];
+  load_bounds(g, a, n64);
+  load_keys(a, n64, kcur);
+  load_bounds(g1, na, nn);
+  __syncthreads();                                     // the bitmap is clear
+
+  while (g < ng) {
+    u32 knext[KPT];
+    u64 nna, nnn;
+    load_keys(na, nn, knext);                          // in flight while this sub-bucket is counted
+    load_bounds(g2, nna, nnn);
+    const u64 g3 = sub_at(p + 3 * G);
+
+    if (n64 == 0) {
+      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
+    } else if (n64 <= max_size) {
+      const u32 n = (u32)n64;
+      u32 wa[KPT];                                     // LDS word of the key's bit; ~0: no key
+      // ---- A. set ----
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 idx = (u32)j * BLOCK + tid;
+        const u32 s = kcur[j] & low_mask;
+        kcur[j] = s;
+        wa[j] = ~0u;
+        if (idx < n) {
+          wa[j] = phys(s >> 7) * 4u + ((s >> 5) & 3u);
+          atomicOr(&bm[wa[j]], 1u << (s & 31u));
+        }
+      }
+      __syncthreads();
+      // ---- B. prefix popcounts, distinct suffixes out in ascending order ----
+      u32 gpre[GPT + 1], run = 0;
+#pragma unroll
+      for (int q = 0; q < GPT; q++) {
+        const uint4 v = bm4[phys(tid * GPT + q)];
+        gpre[q] = run;
+        run += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+      }
+      gpre[GPT] = run;
+      // block scan with ONE barrier: s_scan was last read three barriers ago
+      u32 incl = run;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(incl, d); if ((int)(tid & 63u) >= d) incl += y; }
+      if ((tid & 63u) == 63u) s_scan[tid >> 6] = incl;
+      __syncthreads();
+      u32 D = 0, base = incl - run;
+#pragma unroll
+      for (int i = 0; i < BLOCK / 64; i++) { const u32 t = s_scan[i]; if (i < (int)(tid >> 6)) base += t; D += t; }
+#pragma unroll
+      for (int q = 0; q < GPT; q++) pre[tid * GPT + q] = (unsigned short)(base + gpre[q]);
+      if (run) {                                       // few groups hold anything (D of 2^LB bits): those are read again
+#pragma unroll
+        for (int q = 0; q < GPT; q++) {
+          if (gpre[q + 1] == gpre[q]) continue;
+          const uint4 v = bm4[phys(tid * GPT + q)];
+          u32 r = base + gpre[q];
+          const u32 w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            u32 w = w4[c];
+            while (w) {
+              const u32 b = (u32)__builtin_ctz(w);
+              keys[a + r++] = (((tid * GPT + (u32)q) * 4u + (u32)c) << 5) | b;   // in place: the sub-bucket's keys sit in registers
+              w &= w - 1u;
+            }
+          }
+        }
+      }
+      for (u32 i = tid; i < (D + 1) / 2; i += BLOCK) cnt[i] = 0;
+      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
+      __syncthreads();
+      // ---- C. count ----
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        if (wa[j] != ~0u) {
+          const u32 s = kcur[j];
+          const uint4 v = bm4[wa[j] >> 2];
+          const u64 lo = ((u64)v.y << 32) | (u64)v.x, hi = ((u64)v.w << 32) | (u64)v.z;
+          const u32 pos = s & 127u;
+          u32 r = pre[s >> 7];
+          if (pos < 64u) r += (u32)__popcll(lo & ((1ull << pos) - 1ull));
+          else           r += (u32)__popcll(lo) + (u32)__popcll(hi & ((1ull << (pos - 64u)) - 1ull));
+          atomicAdd(&cnt[r >> 1], (r & 1u) ? 0x10000u : 1u);
+        }
+      }
+      __syncthreads();
+      // ---- D. counts out, bitmap back to zero ----
+      for (u32 i = tid; i < D; i += BLOCK) cnt_tmp[a + i] = (cnt[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) if (wa[j] != ~0u) bm[wa[j]] = 0u;
+      __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
+    a = na; n64 = nn; na = nna; nn = nnn; g = g1; g1 = g2; g2 = g3; p += G;
+  }
+}
+
 // Same scheme with 64-bit suffixes, for sub-buckets whose keys differ in 32..62 low bits (k from about 28 at the
 // 10 Gbp scale): 64-bit CAS, whole keys loaded, 42 KiB of LDS (3 workgroups per CU).
 template <int BLOCK, int CAP, int SLOTS, bool LIST>
@@ -1772,8 +1921,19 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, LIST_, true, BIN_>), dim3(hgrid), dim3(256), 0, st,       \
                        reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, \
                        d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, (u64 *)nullptr, tr_a, tr_b)
-    if (d_nz) { if (binrank) MGC_NARROW_LAUNCH(true, true);  else MGC_NARROW_LAUNCH(true, false); }
-    else      { if (binrank) MGC_NARROW_LAUNCH(false, true); else MGC_NARROW_LAUNCH(false, false); }
+    // suffixes of at most 18 bits (k = 21 at the 10 Gbp scale): the bitmap-count kernel (MGC_FINISH_BITMAP=0: hash-count)
+    static const bool use_bitmap = !(getenv("MGC_FINISH_BITMAP") && getenv("MGC_FINISH_BITMAP")[0] == '0');
+    static const uint32_t bgrid_per_cu = getenv("MGC_BITMAP_GRID") ? (uint32_t)atoi(getenv("MGC_BITMAP_GRID")) : 0u;
+#define MGC_BITMAP_LAUNCH(LB_, LIST_, PER_CU_)                                                                                           \
+    do { const uint32_t bmax = 256u * (bgrid_per_cu ? bgrid_per_cu : (uint32_t)(PER_CU_));                                              \
+         hipLaunchKernelGGL((bitmap_count_kernel<256, (int)FIN_CAP_HASH, LB_, LIST_>), dim3(ng < bmax ? (uint32_t)ng : bmax), dim3(256), 0, st, \
+                       reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, \
+                       d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b); } while (0)
+    if (use_bitmap && low_bits <= 16)      { if (d_nz) MGC_BITMAP_LAUNCH(16, true, 12); else MGC_BITMAP_LAUNCH(16, false, 12); }
+    else if (use_bitmap && low_bits <= 18) { if (d_nz) MGC_BITMAP_LAUNCH(18, true, 4);  else MGC_BITMAP_LAUNCH(18, false, 4); }
+    else if (d_nz) { if (binrank) MGC_NARROW_LAUNCH(true, true);  else MGC_NARROW_LAUNCH(true, false); }
+    else           { if (binrank) MGC_NARROW_LAUNCH(false, true); else MGC_NARROW_LAUNCH(false, false); }
+#undef MGC_BITMAP_LAUNCH
 #undef MGC_NARROW_LAUNCH
     MGC_CHECK(hipGetLastError());
     if (n_large) {

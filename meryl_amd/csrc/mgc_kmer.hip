@@ -256,7 +256,8 @@ void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode,
 constexpr int KH_NV = 4, KH_FINE_BITS = 15;
 __global__ __launch_bounds__(KP_BLOCK * KH_NV)
 void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u64 num_tiles, u32 vgrid,
-                           u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts, u64 *__restrict__ fine_hist) {
+                           u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts, u64 *__restrict__ fine_hist,
+                           u32 *__restrict__ fine_rows /* [gridDim.x][2^15]: this workgroup's own counts (chunk-local first pass), or null */) {
   extern __shared__ __attribute__((aligned(16))) u32 kh_fine[];      // [1 << KH_FINE_BITS]
   __shared__ u32 s_codes[2][KH_NV][KP_WORDS];
   __shared__ u32 s_inval[2][KH_NV][KP_WORDS];
@@ -312,6 +313,7 @@ void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
   for (u32 i = tid; i < (1u << KH_FINE_BITS); i += KP_BLOCK * KH_NV) {
     const u32 c = kh_fine[i];
     if (c) atomicAdd(&fine_hist[i], (u64)c);
+    if (fine_rows) fine_rows[((u64)blockIdx.x << KH_FINE_BITS) + i] = c;
   }
 }
 
@@ -467,8 +469,15 @@ bool kmer_histogram_fine_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask)
 }
 
 // launch_kmer_histogram + d_fine_hist[2^15] (zeroed here): k-mers per (file, next nine bits)
+uint32_t kmer_histogram_fine_chunks(uint64_t n_bases, uint32_t *per_chunk, uint32_t *vgrid) {
+  const uint32_t vg = kp_grid_size(n_bases);
+  if (per_chunk) *per_chunk = KH_NV;
+  if (vgrid) *vgrid = vg;
+  return (vg + KH_NV - 1) / KH_NV;
+}
+
 hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint64_t *d_bucket_counts,
-                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st) {
+                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st, uint32_t *d_fine_rows) {
   MGC_CHECK(hipMemsetAsync(d_bucket_counts, 0, sizeof(uint64_t) * 64, st));
   MGC_CHECK(hipMemsetAsync(d_fine_hist, 0, sizeof(uint64_t) << KH_FINE_BITS, st));
   if (n_bases == 0) return hipSuccess;
@@ -482,7 +491,7 @@ hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, 
   }
   hipLaunchKernelGGL(kmer_hist_fine_kernel, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) << KH_FINE_BITS, st,
                      d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
-                     reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
+                     reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), d_fine_rows);
   return hipGetLastError();
 }
 

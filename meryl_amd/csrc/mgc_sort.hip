@@ -915,6 +915,159 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
   }
 }
 
+// ---- chunk-local first grouping pass (no look-back) -----------------------------------------------------------------
+// The file a session's own partition wrote is a concatenation of CHUNKS: workgroup w of kmer_partition_kernel leaves its
+// k-mers of file f as one contiguous run, the runs lie in workgroup order, and kmer_hist_fine_kernel -- one workgroup per
+// KH_NV partition workgroups -- has counted exactly those k-mers by (file, next nine bits).  So for every (chunk, digit)
+// the number of k-mers is known BEFORE the pass runs (fine_rows, turned into exclusive prefixes over the chunks by
+// fine_rows_scan_kernel): a workgroup that takes one chunk owns a private cursor per digit for the whole chunk and never
+// has to ask another workgroup anything -- no tickets, no status granules, no look-back (19 K of the look-back kernel's
+// 39 K cycles per tile).  Per tile: rank with one returning LDS atomic per key, scan of the 512 counts,
+// exchange through LDS, contiguous runs out at the cursors, cursors advance.  The next tile's keys are fetched behind the
+// write-out.  NARROW / HIST2 as in radix_group_kernel.  Replaces the same reference code (unpackSuffixes + std::sort,
+// merylCountArray.C:276-289,330 -- top bits only).
+struct NarrowPrep { unsigned char bits_a[64]; unsigned char on[64]; };   // per file: bits of its first (high) digit, narrowed at all
+
+struct LocalArgs {
+  const u32 *rows;            // [n_chunks][1 << 15] exclusive prefixes over the chunks (fine_rows_scan_kernel)
+  const u64 *block_base;      // kmer_scan_kernel's cursors: [vgrid][64], absolute key index of partition workgroup g's run of file f
+  u32 vgrid, per_chunk;       // partition workgroups, and how many of them make a chunk (KH_NV)
+  u32 file;                   // f
+  u32 span_shift;             // 9 - digit bits: the digit's first fine column is d << span_shift
+  u64 file_start;             // absolute key index of the file's first k-mer
+};
+
+template <typename K, int RB, int BLOCK, int KPT, bool NARROW, bool HIST2>
+__global__ __launch_bounds__(BLOCK, (GroupSmem<K, RB, BLOCK, KPT>::MIN_WAVES_PER_SIMD))
+void radix_group_local_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::type *__restrict__ out, u64 n, u32 shift, u32 dmask,
+                              const u64 *__restrict__ gbase, LocalArgs la, GroupExtra ex) {
+  using SM = GroupSmem<K, RB, BLOCK, KPT>;
+  using KO = KeyOps<K>;
+  constexpr int R = SM::R, TILE = SM::TILE;
+  static_assert(BLOCK >= R && TILE <= 65536, "one thread per digit; 16-bit ranks");
+  __shared__ u32 s_h2[HIST2 ? RS_MAX_RADIX : 1];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  K   *s_keys  = reinterpret_cast<K *>(smem);
+  u32 *s_hist  = reinterpret_cast<u32 *>(smem + SM::OFF_HIST);
+  u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
+  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
+  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
+  const u32 tid0 = threadIdx.x;
+  u32 tid = tid0, lane = tid0 & 63u, w = tid0 >> 6;
+  const u32 digit_bits = ex.digit_bits;
+  if (HIST2) { for (u32 i = tid; i < (u32)RS_MAX_RADIX; i += BLOCK) s_h2[i] = 0; }
+
+  // the chunk's key range inside the file, this thread's digit cursor
+  const u32 c = blockIdx.x, g0 = c * la.per_chunk, g1 = g0 + la.per_chunk;
+  const u64 cs = (g0 < la.vgrid) ? la.block_base[(u64)g0 * 64 + la.file] - la.file_start : n;
+  const u64 ce = (g1 < la.vgrid) ? la.block_base[(u64)g1 * 64 + la.file] - la.file_start : n;
+  u64 cursor = 0;
+  if (tid < (u32)R && tid <= dmask)
+    cursor = gbase[tid] + (u64)la.rows[((u64)c << 15) + ((u64)la.file << 9) + ((u64)tid << la.span_shift)];
+
+  constexpr int VEC = (sizeof(K) < 16 && KPT % (16 / sizeof(K)) == 0) ? (int)(16 / sizeof(K)) : 1;
+  struct __attribute__((aligned(4))) KVec { K v[VEC]; };
+  auto idx_of = [&](int j) __attribute__((always_inline)) -> u32 {
+    return w * (u32)(64 * KPT) + ((u32)(j / VEC) * 64u + lane) * (u32)VEC + (u32)(j % VEC);
+  };
+  K keys[KPT];
+  auto fetch = [&](u64 kb, u32 nv) __attribute__((always_inline)) {
+    const K *base = in + kb;
+#pragma unroll
+    for (int g = 0; g < KPT / VEC; g++) {
+      const u32 first = idx_of(g * VEC);
+      if (nv == (u32)TILE || first + (u32)VEC <= nv) {
+        const KVec q = *reinterpret_cast<const KVec *>(base + first);
+#pragma unroll
+        for (int cc = 0; cc < VEC; cc++) keys[g * VEC + cc] = q.v[cc];
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < VEC; cc++) if (first + (u32)cc < nv) keys[g * VEC + cc] = base[first + cc];
+      }
+    }
+  };
+
+  u64 kb = cs;
+  u32 nv = (ce > kb) ? (u32)((ce - kb < (u64)TILE) ? ce - kb : (u64)TILE) : 0u;
+  if (nv) fetch(kb, nv);
+  while (nv) {
+    tid = tid0;
+    asm volatile("" : "+v"(tid));                         // keeps the unrolled body's LDS addresses out of the loop preheader
+    lane = tid & 63u; w = tid >> 6;
+    if (tid < (u32)R) s_hist[tid] = 0;
+    __syncthreads();                                      // (A)
+    u32 ranks[KPT / 2];
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      u32 r = 0;
+      if (idx_of(j) < nv) {
+        r = atomicAdd(&s_hist[KO::digit(keys[j], shift, dmask)], 1u);
+      }
+      if (j & 1) ranks[j / 2] |= r << 16;
+      else       ranks[j / 2]  = r;
+    }
+    __syncthreads();                                      // (B)
+    const u32 count = (tid < (u32)R) ? s_hist[tid] : 0u;
+    u32 tile_total;
+    const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tile_total);
+    if (tid < (u32)R) { s_dbase[tid] = excl; s_gbase[tid] = cursor - (u64)excl; cursor += (u64)count; }
+    __syncthreads();                                      // (C)
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      if (idx_of(j) < nv) {
+        const u32 d = KO::digit(keys[j], shift, dmask);
+        const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
+        s_keys[s_dbase[d] + r] = keys[j];
+      }
+    }
+    __syncthreads();                                      // (D) keys live in LDS only: the registers take the next tile
+    const u64 nkb = kb + (u64)TILE;
+    const u32 nnv = (ce > nkb) ? (u32)((ce - nkb < (u64)TILE) ? ce - nkb : (u64)TILE) : 0u;
+    if (nnv) fetch(nkb, nnv);
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 i = (u32)j * BLOCK + tid;
+      if (i < nv) {
+        const K   key = s_keys[i];
+        const u32 d   = KO::digit(key, shift, dmask);
+        if constexpr (HIST2) atomicAdd(&s_h2[KO::digit(key, ex.shift2, ex.mask2)], 1u);
+        if constexpr (NARROW) out[s_gbase[d] + (u64)i] = (u32)(((key >> (shift + digit_bits)) << shift) | (key & ((1ull << shift) - 1ull)));
+        else                  out[s_gbase[d] + (u64)i] = key;
+      }
+    }
+    __syncthreads();                                      // (F) s_keys / s_gbase are rewritten by the next iteration
+    kb = nkb; nv = nnv;
+  }
+  if constexpr (HIST2) {
+    __syncthreads();
+    for (u32 i = tid; i < (u32)RS_MAX_RADIX; i += BLOCK) { const u32 cnt2 = s_h2[i]; if (cnt2) atomicAdd(&ex.ghist2[i], (u64)cnt2); }
+  }
+}
+
+// fine_rows[chunk][file << 9 | nine bits] (k-mer counts per chunk, kmer_hist_fine_kernel) -> for every file that is `on`,
+// at the first fine column of each of its 2^bits_a[f] digits: the k-mers of that (file, digit) in the chunks BEFORE this one.
+__global__ __launch_bounds__(256)
+void fine_rows_scan_kernel(u32 *__restrict__ rows, u32 n_chunks, NarrowPrep prep) {
+  const u32 col = blockIdx.x * 256u + threadIdx.x;       // 0 .. 2^15
+  const u32 f = col >> 9;
+  if (!prep.on[f]) return;
+  const u32 span = 1u << (9u - prep.bits_a[f]);
+  if (col & (span - 1u)) return;
+  u32 acc = 0;
+  for (u32 b0 = 0; b0 < n_chunks; b0 += 8) {
+    u32 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      v[q] = 0;
+      if (b0 + q < n_chunks) for (u32 i = 0; i < span; i++) v[q] += rows[((u64)(b0 + q) << 15) + col + i];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (b0 + q < n_chunks) { rows[((u64)(b0 + q) << 15) + col] = acc; acc += v[q]; }
+    }
+  }
+}
+
 // ---- classic mode: per-tile digit histogram + row scan ----------------------
 template <typename K, int RB, int BLOCK, int KPT>
 __global__ __launch_bounds__(BLOCK)
@@ -1234,7 +1387,6 @@ bool sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words) {
 
 // ---- the small per-file steps of the high-digit-first form, batched over all files (a launch per file and step costs more idle
 // time than the steps themselves: ~8 us each, ten of them per file) ----
-struct NarrowPrep { unsigned char bits_a[64]; unsigned char on[64]; };
 
 // one workgroup per file: header cleared, histogram of the file's top bits_a[f] bits from the 512 fine counts, its exclusive scan
 __global__ __launch_bounds__(RS_MAX_RADIX)
@@ -1304,9 +1456,25 @@ hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsi
 // low digit's histogram is taken by the first pass itself -- nobody reads the keys for a histogram -- and the physical order
 // is (low digit : high digit): sub-bucket p holds the k-mers whose top bits are
 // ((p & (2^*tr_a - 1)) << *tr_b) | (p >> *tr_a)  (*tr_a = 0: p itself).
+bool group_local_enabled() {
+  const char *e = getenv("MGC_GROUP_LOCAL");                // read per call: the tests switch it
+  return !(e && e[0] == '0');
+}
+
+hipError_t launch_fine_rows_scan(uint32_t *d_rows, uint32_t n_chunks, uint32_t nb, const unsigned char *bits_a, const unsigned char *on,
+                                 hipStream_t st) {
+  if (nb > 64) return hipErrorInvalidValue;
+  NarrowPrep prep;
+  memset(&prep, 0, sizeof(prep));
+  memcpy(prep.bits_a, bits_a, nb);
+  memcpy(prep.on, on, nb);
+  hipLaunchKernelGGL(fine_rows_scan_kernel, dim3((1u << 15) / 256u), dim3(256), 0, st, d_rows, n_chunks, prep);
+  return hipGetLastError();
+}
+
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events,
-                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b) {
+                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, const GroupLocal *local) {
   if (!sort_plan_narrows(plan, n, 1) || ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
   constexpr int RB = 9, BLOCK = 1024, KPT0 = 16, KPT1 = 24, R = 1 << RB;
   using GS0 = GroupSmem<u64, RB, BLOCK, KPT0>;
@@ -1369,6 +1537,33 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
     if (hipMalloc(&dbg_buf, 2 * 64 * 8 * sizeof(u64)) != hipSuccess) dbg_buf = nullptr;
   }
   if (dbg && dbg_buf) MGC_CHECK(hipMemsetAsync(dbg_buf, 0, 2 * 64 * 8 * sizeof(u64), st));
+  if (msd && local && !(dbg && dbg_buf)) {
+    // chunk-local first pass: one workgroup per chunk, private digit cursors, no look-back (radix_group_local_kernel).
+    // MGC_LOCAL_KPT=8: 8192-key tiles, two workgroups per CU (one's LDS phases beside the other's memory phases)
+    using GL8 = GroupSmem<u64, RB, BLOCK, 8>;
+    static bool lattr = false;
+    if (!lattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_local_kernel<u64, RB, BLOCK, KPT0, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_local_kernel<u64, RB, BLOCK, 8, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL8::BYTES);
+      lattr = true;
+    }
+    static const int lkpt = getenv("MGC_LOCAL_KPT") ? atoi(getenv("MGC_LOCAL_KPT")) : 16;
+    LocalArgs la;
+    la.rows = local->d_rows; la.block_base = reinterpret_cast<const u64 *>(local->d_block_base);
+    la.vgrid = local->vgrid; la.per_chunk = local->per_chunk; la.file = local->file; la.span_shift = 9u - bA;
+    la.file_start = local->file_start;
+    const GroupExtra gx{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0]};
+    if (lkpt == 8)
+      hipLaunchKernelGGL((radix_group_local_kernel<u64, RB, BLOCK, 8, true, true>), dim3(local->n_chunks), dim3(BLOCK), GL8::BYTES, st,
+                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                         &hdr->gbase[0][0], la, gx);
+    else
+      hipLaunchKernelGGL((radix_group_local_kernel<u64, RB, BLOCK, KPT0, true, true>), dim3(local->n_chunks), dim3(BLOCK), GS0::BYTES, st,
+                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                         &hdr->gbase[0][0], la, gx);
+  } else
   if (dbg && dbg_buf)
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, true, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
