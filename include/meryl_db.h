@@ -160,8 +160,53 @@ int  mgc_db_stream_sync(mgc_db_stream *d);
 int  mgc_db_stream_close(mgc_db_stream *d, mgc_db_write_profile *prof);
 const char *mgc_db_stream_error(const mgc_db_stream *d);      /* d may be NULL: last open error of this thread */
 
-/* Count result of a session -> database directory, through a device stream (results that live in HBM; host_threads
- * file-writer threads).  prof may be NULL. */
+/* mgc_db_stream_queued: ranges queued so far (the number of the last one).  mgc_db_stream_wait_buffers: ranges 1 .. upto
+ * have been encoded and copied out of their device buffers, which may be reused; the file writes of the copied pieces may
+ * still be running. */
+uint64_t mgc_db_stream_queued(mgc_db_stream *d);
+int  mgc_db_stream_wait_buffers(mgc_db_stream *d, uint64_t upto);
+
+/* ------------------------------------------------------------------------
+ * Sorted runs of partial results -- the spill of an out-of-core count.
+ *
+ * What it replaces: merylOperation::countThreads writes every bucket of a full memory as an ITERATION of the output
+ * files (writeBatch, src/meryl/merylOp-countThreads.C:285-380, finishBatch :362) and merylBlockWriter::finish() merges
+ * the iterations of every file at the end (:461-464; the merge itself is in the absent meryl-utility): the size of a count
+ * is bounded by disk, not by memory.  Here a batch's (k-mer, count) result is a RUN: ascending distinct k-mers with their
+ * counts.  A run stays in HBM while the store's device budget lasts and is parked in pinned host DRAM otherwise (one
+ * asynchronous device-to-host copy behind the next batch's count).  At the end the runs are merged ONCE: the k-mer space is
+ * walked in slices (top min(w_prefix, 14) bits), consecutive slices are gathered into chunks that fit the device, every
+ * run's piece of the chunk is uploaded (host runs) or used in place (device runs), the pieces are merged pairwise on the
+ * device (counts of equal k-mers add, uint32 wrap like the reference's value arithmetic) and the merged chunk goes to
+ * the database stream -- uploads of chunk i+1 overlap the encode + write of chunk i.  Nothing is rewritten per batch.
+ * The sharded / node counts park one run per (batch, wave) on the owner and merge the owner's prefix range the same way.
+ *
+ * device_budget_bytes: bytes of runs that may stay in HBM (0: every run goes to the host; ~0: no limit).
+ * chunk_bytes: device memory the final merge may use for its buffers (0: a quarter of the free HBM, at most 24 GiB).
+ * Environment (tests): MGC_OOC_BUDGET, MGC_OOC_CHUNK override both.  Failure text: mgc_runs_error(). */
+typedef struct mgc_runs mgc_runs;
+typedef struct mgc_runs_profile {
+  uint32_t n_runs, n_host_runs;
+  uint64_t n_entries;          /* (k-mer, count) pairs over all runs */
+  uint64_t device_bytes, host_bytes;
+  uint64_t n_merged;           /* distinct k-mers delivered by mgc_runs_write so far */
+  uint32_t n_chunks;
+  double   spill_s;            /* wall clock of the device-to-host copies (incl. pinning the host memory) */
+  double   upload_s, merge_ms, deliver_s;
+  uint64_t peak_hbm_bytes;     /* device memory in use (all of the process) at its highest sampled point */
+} mgc_runs_profile;
+mgc_runs *mgc_runs_open(uint32_t k, uint32_t w_prefix, int device, uint64_t device_budget_bytes, uint64_t chunk_bytes);
+/* copies the n ascending distinct k-mers at d_keys (uint64, or {lo,hi} for k > 32) and their counts into a new run;
+ * `stream`: where they were produced.  Returns when the source may be overwritten. */
+int  mgc_runs_add(mgc_runs *r, const void *d_keys, const uint32_t *d_counts, uint64_t n, void *stream);
+/* merges all runs over prefixes [prefix_begin, prefix_end) into d (ranges ascending, see mgc_db_stream_write) */
+int  mgc_runs_write(mgc_runs *r, mgc_db_stream *d, uint64_t prefix_begin, uint64_t prefix_end);
+int  mgc_runs_get_profile(const mgc_runs *r, mgc_runs_profile *p);
+const char *mgc_runs_error(const mgc_runs *r);                 /* r may be NULL: last open error of this thread */
+void mgc_runs_close(mgc_runs *r);
+
+/* Count result of a session -> database directory, through a device stream (results that live in HBM, or -- out of
+ * core -- in the session's runs; host_threads file-writer threads).  prof may be NULL. */
 int mgc_write_database(struct mgc_session *s, const char *path, int host_threads);
 int mgc_write_database_profiled(struct mgc_session *s, const char *path, int host_threads, mgc_db_write_profile *prof);
 

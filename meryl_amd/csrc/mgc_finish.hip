@@ -628,9 +628,10 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 // k = 21 workload: 36 bits below the file, 18 of them grouped away.  A suffix that short is its own perfect hash:
 //   A. every key sets ITS bit in a 2^LB-bit LDS bitmap (one non-returning LDS atomic, no probing, no table to size);
 //   B. one pass over the bitmap -- GPT 16-byte groups per thread -- gives the number of set bits before every group
-//      (u16 prefix per group), the distinct count D, and emits the distinct suffixes ASCENDING straight into place: a set
-//      bit's rank is its position in the bitmap order, so nothing is ever sorted or ranked by comparison;
-//   C. every key finds its rank again (group prefix + popcount below its bit) and adds one to counts[rank];
+//      (u16 prefix per group) and the distinct count D: a set bit's rank is its position in the bitmap order, so nothing
+//      is ever sorted or ranked by comparison;
+//   C. every key finds its rank (group prefix + popcount below its bit) and adds one to counts[rank]; the ONE instance
+//      of every suffix that found its bit clear in A also writes the suffix out, in place at its rank: ascending;
 //   D. the counts leave, and every key clears the word it set (the bitmap is all zero again: no 32 KiB clear per sub-bucket).
 // O(n + 2^LB / 32) work per sub-bucket against the hash kernel's probe / compact / rank phases; replaces
 // countSingleKmers' sort + run-length passes (merylCountArray.C:323-365) for these files like hash_count_kernel does.
@@ -690,8 +691,10 @@ void bitmap_count_kernel(u32 *__restrict__ keys, const u64 *__restrict__ starts,
       if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
     } else if (n64 <= max_size) {
       const u32 n = (u32)n64;
-      u32 wa[KPT];                                     // LDS word of the key's bit; ~0: no key
-      // ---- A. set ----
+      u32 *gk = keys + a;                              // a file holds fewer than 2^30 keys: 32-bit offsets from here on
+      u32 *gc = cnt_tmp + a;
+      u32 wa[KPT];                                     // LDS word of the key's bit | first << 31; ~0: no key
+      // ---- A. set; the instance that finds its bit clear is the one that will write the suffix out ----
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
         const u32 idx = (u32)j * BLOCK + tid;
@@ -699,20 +702,20 @@ void bitmap_count_kernel(u32 *__restrict__ keys, const u64 *__restrict__ starts,
         kcur[j] = s;
         wa[j] = ~0u;
         if (idx < n) {
-          wa[j] = phys(s >> 7) * 4u + ((s >> 5) & 3u);
-          atomicOr(&bm[wa[j]], 1u << (s & 31u));
+          const u32 wd = phys(s >> 7) * 4u + ((s >> 5) & 3u), bit = 1u << (s & 31u);
+          const u32 old = atomicOr(&bm[wd], bit);
+          wa[j] = wd | ((old & bit) ? 0u : 0x80000000u);
         }
       }
       __syncthreads();
-      // ---- B. prefix popcounts, distinct suffixes out in ascending order ----
-      u32 gpre[GPT + 1], run = 0;
+      // ---- B. set bits before every 128-bit group ----
+      u32 gpre[GPT], run = 0;
 #pragma unroll
       for (int q = 0; q < GPT; q++) {
         const uint4 v = bm4[phys(tid * GPT + q)];
         gpre[q] = run;
         run += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
       }
-      gpre[GPT] = run;
       // block scan with ONE barrier: s_scan was last read three barriers ago
       u32 incl = run;
 #pragma unroll
@@ -724,46 +727,31 @@ void bitmap_count_kernel(u32 *__restrict__ keys, const u64 *__restrict__ starts,
       for (int i = 0; i < BLOCK / 64; i++) { const u32 t = s_scan[i]; if (i < (int)(tid >> 6)) base += t; D += t; }
 #pragma unroll
       for (int q = 0; q < GPT; q++) pre[tid * GPT + q] = (unsigned short)(base + gpre[q]);
-      if (run) {                                       // few groups hold anything (D of 2^LB bits): those are read again
-#pragma unroll
-        for (int q = 0; q < GPT; q++) {
-          if (gpre[q + 1] == gpre[q]) continue;
-          const uint4 v = bm4[phys(tid * GPT + q)];
-          u32 r = base + gpre[q];
-          const u32 w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int c = 0; c < 4; c++) {
-            u32 w = w4[c];
-            while (w) {
-              const u32 b = (u32)__builtin_ctz(w);
-              keys[a + r++] = (((tid * GPT + (u32)q) * 4u + (u32)c) << 5) | b;   // in place: the sub-bucket's keys sit in registers
-              w &= w - 1u;
-            }
-          }
-        }
-      }
       for (u32 i = tid; i < (D + 1) / 2; i += BLOCK) cnt[i] = 0;
       if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
       __syncthreads();
-      // ---- C. count ----
+      // ---- C. rank = set bits below the key's own: the count goes there, and (first instance) the suffix goes out in place ----
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
         if (wa[j] != ~0u) {
           const u32 s = kcur[j];
-          const uint4 v = bm4[wa[j] >> 2];
-          const u64 lo = ((u64)v.y << 32) | (u64)v.x, hi = ((u64)v.w << 32) | (u64)v.z;
+          const uint4 v = bm4[(wa[j] & 0x7FFFFFFFu) >> 2];
           const u32 pos = s & 127u;
-          u32 r = pre[s >> 7];
-          if (pos < 64u) r += (u32)__popcll(lo & ((1ull << pos) - 1ull));
-          else           r += (u32)__popcll(lo) + (u32)__popcll(hi & ((1ull << (pos - 64u)) - 1ull));
+          // words wholly below the bit count in full, the bit's own word below the bit
+          const u32 m0 = pos >= 32u ? ~0u : ((1u << (pos & 31u)) - 1u);
+          const u32 m1 = pos >= 64u ? ~0u : (pos >= 32u ? ((1u << (pos & 31u)) - 1u) : 0u);
+          const u32 m2 = pos >= 96u ? ~0u : (pos >= 64u ? ((1u << (pos & 31u)) - 1u) : 0u);
+          const u32 m3 = pos >= 96u ? ((1u << (pos & 31u)) - 1u) : 0u;
+          const u32 r = (u32)pre[s >> 7] + __popc(v.x & m0) + __popc(v.y & m1) + __popc(v.z & m2) + __popc(v.w & m3);
           atomicAdd(&cnt[r >> 1], (r & 1u) ? 0x10000u : 1u);
+          if (wa[j] & 0x80000000u) gk[r] = s;          // in place: the sub-bucket's keys sit in registers
         }
       }
       __syncthreads();
       // ---- D. counts out, bitmap back to zero ----
-      for (u32 i = tid; i < D; i += BLOCK) cnt_tmp[a + i] = (cnt[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+      for (u32 i = tid; i < D; i += BLOCK) gc[i] = (cnt[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
 #pragma unroll
-      for (int j = 0; j < KPT; j++) if (wa[j] != ~0u) bm[wa[j]] = 0u;
+      for (int j = 0; j < KPT; j++) if (wa[j] != ~0u) bm[wa[j] & 0x7FFFFFFFu] = 0u;
       __syncthreads();
     }
 
@@ -1921,8 +1909,11 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, LIST_, true, BIN_>), dim3(hgrid), dim3(256), 0, st,       \
                        reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, \
                        d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, (u64 *)nullptr, tr_a, tr_b)
-    // suffixes of at most 18 bits (k = 21 at the 10 Gbp scale): the bitmap-count kernel (MGC_FINISH_BITMAP=0: hash-count)
-    static const bool use_bitmap = !(getenv("MGC_FINISH_BITMAP") && getenv("MGC_FINISH_BITMAP")[0] == '0');
+    // suffixes of at most 18 bits (k = 21 at the 10 Gbp scale): the bitmap-count kernel, with MGC_FINISH_BITMAP=1.  Measured
+    // (profiles/r03b_*): finish stage 39.3 ms per 10 Gbp against the hash-count's 39.8 -- both VALU-issue-bound, the bitmap's
+    // scan of 2^18 bits per sub-bucket costs what the hash table's probing and ranking cost -- so the hash-count stays the default.
+    const char *bme = getenv("MGC_FINISH_BITMAP");                  // read per call: the tests switch it
+    const bool use_bitmap = bme && bme[0] == '1';
     static const uint32_t bgrid_per_cu = getenv("MGC_BITMAP_GRID") ? (uint32_t)atoi(getenv("MGC_BITMAP_GRID")) : 0u;
 #define MGC_BITMAP_LAUNCH(LB_, LIST_, PER_CU_)                                                                                           \
     do { const uint32_t bmax = 256u * (bgrid_per_cu ? bgrid_per_cu : (uint32_t)(PER_CU_));                                              \

@@ -935,9 +935,10 @@ struct LocalArgs {
   u32 file;                   // f
   u32 span_shift;             // 9 - digit bits: the digit's first fine column is d << span_shift
   u64 file_start;             // absolute key index of the file's first k-mer
+  u32 dbg;                    // MGC_LOCAL_DBG (measurements only, WRONG results): 1 no global writes, 2 no ranking / exchange (straight copy), 4 no HIST2
 };
 
-template <typename K, int RB, int BLOCK, int KPT, bool NARROW, bool HIST2>
+template <typename K, int RB, int BLOCK, int KPT, bool NARROW, bool HIST2, bool PREF = false>
 __global__ __launch_bounds__(BLOCK, (GroupSmem<K, RB, BLOCK, KPT>::MIN_WAVES_PER_SIMD))
 void radix_group_local_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::type *__restrict__ out, u64 n, u32 shift, u32 dmask,
                               const u64 *__restrict__ gbase, LocalArgs la, GroupExtra ex) {
@@ -970,8 +971,8 @@ void radix_group_local_kernel(const K *__restrict__ in, typename GroupOut<K, NAR
   auto idx_of = [&](int j) __attribute__((always_inline)) -> u32 {
     return w * (u32)(64 * KPT) + ((u32)(j / VEC) * 64u + lane) * (u32)VEC + (u32)(j % VEC);
   };
-  K keys[KPT];
-  auto fetch = [&](u64 kb, u32 nv) __attribute__((always_inline)) {
+  K keys[KPT], knext[PREF ? KPT : 1];
+  auto fetch_into = [&](K *dst, u64 kb, u32 nv) __attribute__((always_inline)) {
     const K *base = in + kb;
 #pragma unroll
     for (int g = 0; g < KPT / VEC; g++) {
@@ -979,13 +980,14 @@ void radix_group_local_kernel(const K *__restrict__ in, typename GroupOut<K, NAR
       if (nv == (u32)TILE || first + (u32)VEC <= nv) {
         const KVec q = *reinterpret_cast<const KVec *>(base + first);
 #pragma unroll
-        for (int cc = 0; cc < VEC; cc++) keys[g * VEC + cc] = q.v[cc];
+        for (int cc = 0; cc < VEC; cc++) dst[g * VEC + cc] = q.v[cc];
       } else {
 #pragma unroll
-        for (int cc = 0; cc < VEC; cc++) if (first + (u32)cc < nv) keys[g * VEC + cc] = base[first + cc];
+        for (int cc = 0; cc < VEC; cc++) if (first + (u32)cc < nv) dst[g * VEC + cc] = base[first + cc];
       }
     }
   };
+  auto fetch = [&](u64 kb, u32 nv) __attribute__((always_inline)) { fetch_into(keys, kb, nv); };
 
   u64 kb = cs;
   u32 nv = (ce > kb) ? (u32)((ce - kb < (u64)TILE) ? ce - kb : (u64)TILE) : 0u;
@@ -994,6 +996,22 @@ void radix_group_local_kernel(const K *__restrict__ in, typename GroupOut<K, NAR
     tid = tid0;
     asm volatile("" : "+v"(tid));                         // keeps the unrolled body's LDS addresses out of the loop preheader
     lane = tid & 63u; w = tid >> 6;
+    const u64 nkb = kb + (u64)TILE;
+    const u32 nnv = (ce > nkb) ? (u32)((ce - nkb < (u64)TILE) ? ce - nkb : (u64)TILE) : 0u;
+    // PREF: the next tile's keys travel into a second set of registers behind the WHOLE of this tile's work -- fetching a
+    // tile takes as long as ranking, exchanging and writing one (r03a: the look-back was never the bound, the fetch was)
+    if constexpr (PREF) { if (nnv) fetch_into(knext, nkb, nnv); }
+    if (la.dbg & 2u) {                                    // measurement: what a straight 8 -> 4 byte copy of the chunk costs
+#pragma unroll
+      for (int j = 0; j < KPT; j++)
+        if (idx_of(j) < nv) out[cs + (kb - cs) + idx_of(j)] = (typename GroupOut<K, NARROW>::type)keys[j];
+      if constexpr (PREF) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) keys[j] = knext[j];
+      } else { if (nnv) fetch(nkb, nnv); }
+      kb = nkb; nv = nnv;
+      continue;
+    }
     if (tid < (u32)R) s_hist[tid] = 0;
     __syncthreads();                                      // (A)
     u32 ranks[KPT / 2];
@@ -1021,21 +1039,24 @@ void radix_group_local_kernel(const K *__restrict__ in, typename GroupOut<K, NAR
       }
     }
     __syncthreads();                                      // (D) keys live in LDS only: the registers take the next tile
-    const u64 nkb = kb + (u64)TILE;
-    const u32 nnv = (ce > nkb) ? (u32)((ce - nkb < (u64)TILE) ? ce - nkb : (u64)TILE) : 0u;
-    if (nnv) fetch(nkb, nnv);
+    if constexpr (!PREF) { if (nnv) fetch(nkb, nnv); }
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
       const u32 i = (u32)j * BLOCK + tid;
       if (i < nv) {
         const K   key = s_keys[i];
         const u32 d   = KO::digit(key, shift, dmask);
-        if constexpr (HIST2) atomicAdd(&s_h2[KO::digit(key, ex.shift2, ex.mask2)], 1u);
+        if constexpr (HIST2) { if (!(la.dbg & 4u)) atomicAdd(&s_h2[KO::digit(key, ex.shift2, ex.mask2)], 1u); }
+        if (la.dbg & 1u) continue;
         if constexpr (NARROW) out[s_gbase[d] + (u64)i] = (u32)(((key >> (shift + digit_bits)) << shift) | (key & ((1ull << shift) - 1ull)));
         else                  out[s_gbase[d] + (u64)i] = key;
       }
     }
     __syncthreads();                                      // (F) s_keys / s_gbase are rewritten by the next iteration
+    if constexpr (PREF) {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) keys[j] = knext[j];
+    }
     kb = nkb; nv = nnv;
   }
   if constexpr (HIST2) {
@@ -1457,8 +1478,11 @@ hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsi
 // is (low digit : high digit): sub-bucket p holds the k-mers whose top bits are
 // ((p & (2^*tr_a - 1)) << *tr_b) | (p >> *tr_a)  (*tr_a = 0: p itself).
 bool group_local_enabled() {
+  // Measured (profiles/r03a_*, r03b_*): 0.498 ms per 135 M k-mers against the look-back kernel's 0.490 -- the look-back was
+  // never the bound (nor was the exposed fetch: prefetching a whole tile ahead gives 0.485) -- so the default stays the
+  // look-back kernel, which needs no per-chunk histogram rows; MGC_GROUP_LOCAL=1 runs this one.
   const char *e = getenv("MGC_GROUP_LOCAL");                // read per call: the tests switch it
-  return !(e && e[0] == '0');
+  return e && e[0] == '1';
 }
 
 hipError_t launch_fine_rows_scan(uint32_t *d_rows, uint32_t n_chunks, uint32_t nb, const unsigned char *bits_a, const unsigned char *on,
@@ -1549,13 +1573,40 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL8::BYTES);
       lattr = true;
     }
+    using GL512 = GroupSmem<u64, RB, 512, 16>;
+    static bool lattr2 = false;
+    if (!lattr2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_local_kernel<u64, RB, BLOCK, KPT0, true, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_local_kernel<u64, RB, 512, 16, true, true, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL512::BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_local_kernel<u64, RB, 512, 16, true, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL512::BYTES);
+      lattr2 = true;
+    }
+    // MGC_LOCAL_KPT: 16 (default) one 1024 x 16 workgroup per CU; 8: 1024 x 8, two per CU; 512: 512 x 16, two per CU;
+    // 17 / 513: the same as 16 / 512 with the next tile prefetched into a second register set at the top of the loop
     static const int lkpt = getenv("MGC_LOCAL_KPT") ? atoi(getenv("MGC_LOCAL_KPT")) : 16;
     LocalArgs la;
     la.rows = local->d_rows; la.block_base = reinterpret_cast<const u64 *>(local->d_block_base);
     la.vgrid = local->vgrid; la.per_chunk = local->per_chunk; la.file = local->file; la.span_shift = 9u - bA;
     la.file_start = local->file_start;
+    static const uint32_t ldbg = getenv("MGC_LOCAL_DBG") ? (uint32_t)atoi(getenv("MGC_LOCAL_DBG")) : 0u;
+    la.dbg = ldbg;
     const GroupExtra gx{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0]};
-    if (lkpt == 8)
+    if (lkpt == 17)
+      hipLaunchKernelGGL((radix_group_local_kernel<u64, RB, BLOCK, KPT0, true, true, true>), dim3(local->n_chunks), dim3(BLOCK), GS0::BYTES, st,
+                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                         &hdr->gbase[0][0], la, gx);
+    else if (lkpt == 512)
+      hipLaunchKernelGGL((radix_group_local_kernel<u64, RB, 512, 16, true, true, false>), dim3(local->n_chunks), dim3(512), GL512::BYTES, st,
+                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                         &hdr->gbase[0][0], la, gx);
+    else if (lkpt == 513)
+      hipLaunchKernelGGL((radix_group_local_kernel<u64, RB, 512, 16, true, true, true>), dim3(local->n_chunks), dim3(512), GL512::BYTES, st,
+                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                         &hdr->gbase[0][0], la, gx);
+    else if (lkpt == 8)
       hipLaunchKernelGGL((radix_group_local_kernel<u64, RB, BLOCK, 8, true, true>), dim3(local->n_chunks), dim3(BLOCK), GL8::BYTES, st,
                          reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                          &hdr->gbase[0][0], la, gx);

@@ -383,6 +383,19 @@ extern "C" int mgc_db_stream_write(mgc_db_stream *d, const void *d_keys, const u
   return MGC_OK;
 }
 
+extern "C" uint64_t mgc_db_stream_queued(mgc_db_stream *d) {
+  if (!d) return 0;
+  std::lock_guard<std::mutex> g(d->mu);
+  return d->jobs_queued;
+}
+
+extern "C" int mgc_db_stream_wait_buffers(mgc_db_stream *d, uint64_t upto) {
+  if (!d) return MGC_EINVAL;
+  std::unique_lock<std::mutex> lk(d->mu);
+  d->cv.wait(lk, [&] { return d->jobs_done >= upto || d->jobs_done == d->jobs_queued; });
+  return d->status;
+}
+
 extern "C" int mgc_db_stream_sync(mgc_db_stream *d) {
   if (!d) return MGC_EINVAL;
   std::unique_lock<std::mutex> lk(d->mu);

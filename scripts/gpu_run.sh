@@ -24,7 +24,7 @@ for v in "${VARS[@]}"; do
   [ -z "$v" ] && continue
   name=${v%%:*}; envs=${v#*:}
   echo "== bench $name [$envs] $BENCH_ARGS"
-  ( IFS=','; for e in $envs; do [ -n "$e" ] && export "$e"; done; timeout 600 python bench.py $BENCH_ARGS > $OUT/bench_$name.json 2> $OUT/bench_$name.err )
+  ( IFS=','; for e in $envs; do [ -n "$e" ] && export "$e"; done; unset IFS; timeout 600 python bench.py $BENCH_ARGS > $OUT/bench_$name.json 2> $OUT/bench_$name.err )
   echo "exit $?"
   python - "$OUT/bench_$name.json" <<'PY'
 import json, sys
