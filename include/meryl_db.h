@@ -204,6 +204,8 @@ int  mgc_runs_write(mgc_runs *r, mgc_db_stream *d, uint64_t prefix_begin, uint64
 int  mgc_runs_get_profile(const mgc_runs *r, mgc_runs_profile *p);
 const char *mgc_runs_error(const mgc_runs *r);                 /* r may be NULL: last open error of this thread */
 void mgc_runs_close(mgc_runs *r);
+/* the run store of a session that counted in batches (zeros when it counted in one pass) */
+int  mgc_get_runs_profile(const struct mgc_session *s, mgc_runs_profile *p);
 
 /* Count result of a session -> database directory, through a device stream (results that live in HBM, or -- out of
  * core -- in the session's runs; host_threads file-writer threads).  prof may be NULL. */
@@ -235,10 +237,24 @@ typedef struct mgc_node_profile {
   double   exchange_count_s;   /* slowest rank: pulls + grouping + finish + handing blocks to the writer */
   double   close_s;            /* slowest rank: waiting for its part's files */
   double   merge_parts_s, total_s;
+  uint32_t n_batches, n_host_runs; /* batches every rank's reads were counted in; parked waves that went to host DRAM */
+  uint64_t host_run_bytes;
+  double   merge_runs_s;           /* slowest rank: merging its parked waves into its part (batches > 1) */
+  uint64_t peak_hbm_bytes;         /* highest sampled device memory in use on any rank's device (batches > 1) */
 } mgc_node_profile;
 int mgc_count_node(const mgc_count_config *cfg, uint32_t n_ranks, const int *devices,
                    const uint8_t *const *d_bases, const uint64_t *n_bases,
                    const char *db_path, int host_threads, mgc_node_profile *prof);
+/* The same with BATCHES (the node form of writeBatch's spill, merylOp-countThreads.C:323-379): no rank ever holds the
+ * k-mers of more than batch_bases of its bases at once.  The routing plan comes from one histogram of ALL reads; then,
+ * batch by batch, every rank partitions the next slice of its base stream (slices overlap by k-1 bases), the owners pull
+ * and count their waves and park every counted wave as a run (include: mgc_runs_*; HBM first, pinned host DRAM beyond
+ * the budget); after the last batch every owner merges its runs once into its part of the database.  batch_bases = 0:
+ * derived from the free HBM (one batch when everything fits -- then this IS mgc_count_node, waves streamed to the writer
+ * as they are counted).  MGC_NODE_BATCH_BASES overrides (tests). */
+int mgc_count_node_batched(const mgc_count_config *cfg, uint32_t n_ranks, const int *devices,
+                           const uint8_t *const *d_bases, const uint64_t *n_bases, uint64_t batch_bases,
+                           const char *db_path, int host_threads, mgc_node_profile *prof);
 
 /* The routing plan of mgc_count_node on its own (host arithmetic only, no device needed): *bucket_bits = the top bits of the k-mer
  * that route it for n_ranks ranks whose largest input is max_rank_bases (6 + ceil(log2 n_ranks), more for very large inputs, at

@@ -206,14 +206,24 @@ const char  *mgc_last_error(const mgc_session *s);   /* s may be NULL: last open
 int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int end_of_sequence);
 
 /* Out-of-core input (the analogue of writeBatch's memory-full spill, merylOp-countThreads.C:323-379, and of
- * merylBlockWriter::finish() merging the iterations): bases pushed from the host travel through two pinned buffers
- * (asynchronous uploads) into a staging buffer in HBM; when the staged bases -- pushed or parsed from text -- reach
- * what one pass can hold, everything up to the last sequence boundary is counted as one BATCH by a worker thread
- * while the caller keeps pushing into a second staging buffer, and the batch's (k-mer, count) result is merged ON THE
- * DEVICE into the running result of the earlier batches (counts summed).  The final result is device-resident like
- * a single pass's: every result call works the same.  By default the batch size is derived from the free HBM at the
- * first input; this call overrides it (bases per batch). */
+ * merylBlockWriter::finish() merging the iterations, :461-464): bases pushed from the host travel through two pinned
+ * buffers (asynchronous uploads) into a staging buffer in HBM; when the staged bases -- pushed or parsed from text --
+ * reach what one pass can hold, everything up to the last sequence boundary is counted as one BATCH by a worker thread
+ * while the caller keeps pushing into a second staging buffer.  A batch's (k-mer, count) result is parked as a sorted
+ * RUN -- in HBM while the result budget lasts, in pinned host DRAM otherwise (include/meryl_db.h, mgc_runs_*) -- and the
+ * runs are merged ONCE, when the count ends:
+ *   - every run still in HBM and their merge fits: one device-resident result, every result call works as after a
+ *     single pass;
+ *   - otherwise the result is OUT OF CORE (mgc_result_out_of_core() == 1; mgc_get_result_info reports n_distinct = 0
+ *     until it has been delivered): mgc_write_database and mgc_finish / mgc_finish_labelled merge the runs chunk by
+ *     chunk into the consumer, the calls that hand out the whole result (mgc_copy_result*, mgc_get_result_device)
+ *     return MGC_ESTATE.  The result may be larger than HBM; host DRAM bounds it.
+ * By default the batch size is derived from the free HBM at the first input (mgc_set_batch_bases overrides it: bases per
+ * batch) and the runs may keep 60 % of the HBM that is free when the first batch has been counted
+ * (mgc_set_result_budget: bytes; 0 restores the default). */
 int mgc_set_batch_bases(mgc_session *s, uint64_t bases_per_batch);
+int mgc_set_result_budget(mgc_session *s, uint64_t device_bytes);
+int mgc_result_out_of_core(const mgc_session *s);
 
 /* Sequence-file TEXT instead of bases: the raw bytes of a FASTA or FASTQ file (after any decompression), in
  * chunks of any size and alignment.  The library stages them through pinned buffers, uploads them and parses

@@ -25,14 +25,15 @@ SYMBOLS = (
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish", "mgc_finish_labelled",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_dev_synth_reads_ex", "mgc_version",
     "mgc_dev_merge_workspace_bytes", "mgc_dev_merge_count", "mgc_dev_merge_emit",
-    "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases",
+    "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases", "mgc_set_result_budget", "mgc_result_out_of_core",
     # include/meryl_db.h
     "mdb_writer_open", "mdb_writer_open_ex", "mdb_merge_parts", "mdb_writer_add_block", "mdb_writer_add_block_labelled",
     "mdb_writer_add_encoded", "mdb_writer_reserve_encoded", "mdb_writer_write_at", "mdb_writer_add_histogram", "mdb_writer_close", "mdb_last_error",
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_read_file_ex",
     "mdb_reader_file_index", "mdb_reader_block_header", "mdb_reader_read_block_raw", "mdb_reader_close",
     "mdb_free", "mgc_write_database", "mgc_write_database_profiled",
-    "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_merge", "mgc_count_node", "mgc_count_node_staged", "mgc_node_plan",
+    "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_stream_queued", "mgc_db_stream_wait_buffers",
+    "mgc_runs_open", "mgc_runs_add", "mgc_runs_write", "mgc_runs_get_profile", "mgc_runs_error", "mgc_runs_close", "mgc_get_runs_profile", "mgc_db_merge", "mgc_count_node", "mgc_count_node_batched", "mgc_count_node_staged", "mgc_node_plan",
     # include/meryl_lookup.h
     "mgc_lookup_load", "mgc_lookup_estimate", "mgc_lookup_from_device", "mgc_lookup_free", "mgc_lookup_get_info", "mgc_lookup_error",
     "mgc_lookup_values", "mgc_lookup_stream", "mgc_lookup_existence",
@@ -125,6 +126,11 @@ class NodeProfile(ctypes.Structure):
         ("close_s", ctypes.c_double),
         ("merge_parts_s", ctypes.c_double),
         ("total_s", ctypes.c_double),
+        ("n_batches", ctypes.c_uint32),
+        ("n_host_runs", ctypes.c_uint32),
+        ("host_run_bytes", ctypes.c_uint64),
+        ("merge_runs_s", ctypes.c_double),
+        ("peak_hbm_bytes", ctypes.c_uint64),
     ]
 
     def as_dict(self):
@@ -140,6 +146,22 @@ class DbWriteProfile(ctypes.Structure):
         ("data_bytes", ctypes.c_uint64),
         ("n_kmers", ctypes.c_uint64),
         ("n_blocks", ctypes.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class RunsProfile(ctypes.Structure):
+    _fields_ = [
+        ("n_runs", ctypes.c_uint32), ("n_host_runs", ctypes.c_uint32),
+        ("n_entries", ctypes.c_uint64),
+        ("device_bytes", ctypes.c_uint64), ("host_bytes", ctypes.c_uint64),
+        ("n_merged", ctypes.c_uint64),
+        ("n_chunks", ctypes.c_uint32),
+        ("spill_s", ctypes.c_double),
+        ("upload_s", ctypes.c_double), ("merge_ms", ctypes.c_double), ("deliver_s", ctypes.c_double),
+        ("peak_hbm_bytes", ctypes.c_uint64),
     ]
 
     def as_dict(self):
@@ -258,6 +280,17 @@ def lib():
     sig("mgc_push_bases", i32, vp, ctypes.c_char_p, sz, i32)
     sig("mgc_push_bases_device", i32, vp, vp, u64)
     sig("mgc_set_batch_bases", i32, vp, u64)
+    sig("mgc_set_result_budget", i32, vp, u64)
+    sig("mgc_result_out_of_core", i32, vp)
+    sig("mgc_get_runs_profile", i32, vp, P(RunsProfile))
+    sig("mgc_runs_open", vp, u32, u32, i32, u64, u64)
+    sig("mgc_runs_add", i32, vp, vp, vp, u64, vp)
+    sig("mgc_runs_write", i32, vp, vp, u64, u64)
+    sig("mgc_runs_get_profile", i32, vp, P(RunsProfile))
+    sig("mgc_runs_error", ctypes.c_char_p, vp)
+    sig("mgc_runs_close", None, vp)
+    sig("mgc_db_stream_queued", u64, vp)
+    sig("mgc_db_stream_wait_buffers", i32, vp, u64)
     sig("mgc_reserve_text", i32, vp, u64)
     sig("mgc_begin_text", i32, vp, i32)
     sig("mgc_push_text", i32, vp, ctypes.c_char_p, sz)
@@ -304,6 +337,7 @@ def lib():
     sig("mgc_db_stream_error", ctypes.c_char_p, vp)
     sig("mgc_db_merge", i32, P(ctypes.c_char_p), u32, i32, ctypes.c_char_p, i32, i32)
     sig("mgc_count_node", i32, P(CountConfig), u32, P(ctypes.c_int), P(vp), P(u64), ctypes.c_char_p, i32, P(NodeProfile))
+    sig("mgc_count_node_batched", i32, P(CountConfig), u32, P(ctypes.c_int), P(vp), P(u64), u64, ctypes.c_char_p, i32, P(NodeProfile))
     sig("mgc_staged_bases", i32, vp, P(vp), P(u64))
     sig("mgc_count_node_staged", i32, vp, u32, P(ctypes.c_int), ctypes.c_char_p, i32, P(NodeProfile))
     sig("mgc_node_plan", i32, u32, u32, u64, u32, P(u32), P(u64), P(u32))

@@ -128,10 +128,11 @@ def dev_run_length(sorted_keys):
     return uniq, cnts
 
 
-def count_node(cfg, bases, path, devices=None, host_threads=8):
-    """mgc_count_node: ONE count over several ranks of this process -- bases[r] is rank r's reads (uint8 cuda tensor,
-    on the device the rank runs on; ranks may share a device) -> the database at `path`, byte-identical to a
-    single-device count of the concatenation.  Returns the profile as a dict."""
+def count_node(cfg, bases, path, devices=None, host_threads=8, batch_bases=0):
+    """mgc_count_node[_batched]: ONE count over several ranks of this process -- bases[r] is rank r's reads (uint8 cuda
+    tensor, on the device the rank runs on; ranks may share a device) -> the database at `path`, byte-identical to a
+    single-device count of the concatenation.  batch_bases: no rank holds the k-mers of more of its bases at once (0: from
+    the free HBM).  Returns the profile as a dict."""
     n = len(bases)
     ptrs = (ctypes.c_void_p * n)(*[int(b.data_ptr()) if b.numel() else None for b in bases])
     lens = (ctypes.c_uint64 * n)(*[int(b.numel()) for b in bases])
@@ -140,7 +141,8 @@ def count_node(cfg, bases, path, devices=None, host_threads=8):
     devs = (ctypes.c_int * n)(*[int(d) for d in devices])
     prof = capi.NodeProfile()
     torch.cuda.synchronize()
-    rc = capi.lib().mgc_count_node(ctypes.byref(cfg), n, devs, ptrs, lens, os.fsencode(path), host_threads, ctypes.byref(prof))
+    rc = capi.lib().mgc_count_node_batched(ctypes.byref(cfg), n, devs, ptrs, lens, int(batch_bases), os.fsencode(path), host_threads,
+                                           ctypes.byref(prof))
     if rc != 0:
         raise RuntimeError("mgc_count_node failed rc=%d: %s" % (rc, (capi.lib().mgc_last_error(None) or b"").decode()))
     return prof.as_dict()
@@ -229,6 +231,19 @@ class Session:
     def set_batch_bases(self, n):
         """force out-of-core batches of about n bases (default: derived from the free HBM)"""
         capi.check(capi.lib().mgc_set_batch_bases(self._h, int(n)), "mgc_set_batch_bases", self._h)
+
+    def set_result_budget(self, nbytes):
+        """bytes of batch results (runs) that may stay in HBM; beyond it they are parked in pinned host DRAM"""
+        capi.check(capi.lib().mgc_set_result_budget(self._h, int(nbytes)), "mgc_set_result_budget", self._h)
+
+    def out_of_core(self):
+        """True when the counted result exists only as runs (stream it: write_database / finish)"""
+        return bool(capi.lib().mgc_result_out_of_core(self._h))
+
+    def runs_profile(self):
+        p = capi.RunsProfile()
+        capi.check(capi.lib().mgc_get_runs_profile(self._h, ctypes.byref(p)), "mgc_get_runs_profile", self._h)
+        return p.as_dict()
 
     def set_profiling(self, on=True):
         capi.check(capi.lib().mgc_set_profiling(self._h, 1 if on else 0), "mgc_set_profiling", self._h)
@@ -320,6 +335,38 @@ class Session:
         if err:
             raise err[0]
         capi.check(rc, "mgc_finish", self._h)
+
+
+class Runs:
+    """Sorted runs of partial (k-mer, count) results (mgc_runs_*, include/meryl_db.h): parked in HBM within
+    `device_budget` bytes, in pinned host DRAM beyond it; write() merges them once into a database stream."""
+
+    def __init__(self, k, w_prefix, device=-1, device_budget=0xFFFFFFFFFFFFFFFF, chunk_bytes=0):
+        self._h = capi.lib().mgc_runs_open(k, w_prefix, device, device_budget, chunk_bytes)
+        if not self._h:
+            raise capi.MgcError(-1, "mgc_runs_open", (capi.lib().mgc_runs_error(None) or b"").decode("utf-8", "replace"))
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise capi.MgcError(rc, what, (capi.lib().mgc_runs_error(self._h) or b"").decode("utf-8", "replace"))
+
+    def add(self, keys, counts):
+        """keys: int64[n] / int64[n, 2] cuda tensor (ascending, distinct), counts int32[n]; copied before the call returns"""
+        torch.cuda.current_stream(keys.device).synchronize()
+        self._check(capi.lib().mgc_runs_add(self._h, _ptr(keys), _ptr(counts), keys.shape[0], None), "mgc_runs_add")
+
+    def write(self, stream, prefix_begin, prefix_end):
+        self._check(capi.lib().mgc_runs_write(self._h, stream._h, int(prefix_begin), int(prefix_end)), "mgc_runs_write")
+
+    def profile(self):
+        p = capi.RunsProfile()
+        self._check(capi.lib().mgc_runs_get_profile(self._h, ctypes.byref(p)), "mgc_runs_get_profile")
+        return p.as_dict()
+
+    def close(self):
+        if self._h:
+            capi.lib().mgc_runs_close(self._h)
+            self._h = None
 
 
 class DbStream:

@@ -8,6 +8,7 @@
 #include "../../include/meryl_gpu_count.h"
 #include "mgc_device.h"
 #include "mgc_session.hpp"
+#include "mgc_runs.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -406,6 +407,8 @@ extern "C" void mgc_close(mgc_session *s) {
   s->free_result();
   s->free_garbage();
   s->free_arena();
+  delete s->runs;
+  s->runs = nullptr;
   for (int i = 0; i < 2; i++) {
     if (s->text_pinned[i]) (void)hipHostFree(s->text_pinned[i]);
     if (s->text_ev[i]) (void)hipEventDestroy(s->text_ev[i]);
@@ -1396,50 +1399,29 @@ static int copy_device_result(mgc_session *s, uint64_t *keys_lo, uint64_t *keys_
   return MGC_OK;
 }
 
-// The (k-mer, count) result count_device just left in the arena joins the running result R of the earlier batches:
-// a device merge (mgc_merge.hip) that sums the counts of k-mers both hold (uint32 wrap, like the reference's value
-// arithmetic) -- the analogue of merylBlockWriter::finish() merging the spilled iterations.
-static int merge_into_r(mgc_session *s) {
-  const uint32_t kw = s->key_words;
-  const size_t kbytes = sizeof(uint64_t) * kw;
-  hipStream_t st = s->stream;
-  const uint64_t nd = s->n_distinct;
-  if (!s->have_r) {                                          // first batch: its result simply becomes R
-    std::swap(s->buf[mgc_session::B_UNIQUE], s->buf[mgc_session::B_RK]);
-    std::swap(s->buf[mgc_session::B_COUNTS], s->buf[mgc_session::B_RC]);
-    s->r_n = nd;
-    s->have_r = true;
-  } else {
-    hipEvent_t e0, e1;
-    HIP_TRY(s, hipEventCreate(&e0)); HIP_TRY(s, hipEventCreate(&e1));
-    HIP_TRY(s, hipEventRecord(e0, st));
-    HIP_TRY(s, s->ensure(mgc_session::B_MERGE_WS, mgc::merge_workspace_bytes(s->r_n, nd)));
-    void *ws = s->buf[mgc_session::B_MERGE_WS].p;
-    const void *rk = s->buf[mgc_session::B_RK].p;
-    const uint32_t *rc_ = reinterpret_cast<const uint32_t *>(s->buf[mgc_session::B_RC].p);
-    const void *bk = s->buf[mgc_session::B_UNIQUE].p;
-    const uint32_t *bc = reinterpret_cast<const uint32_t *>(s->buf[mgc_session::B_COUNTS].p);
-    uint64_t n_new = 0;
-    HIP_TRY(s, mgc::launch_merge_count(rk, s->r_n, bk, nd, kw, 0, ws, st));
-    HIP_TRY(s, mgc::merge_read_total(ws, &n_new, st));
-    HIP_TRY(s, s->ensure(mgc_session::B_R2K, kbytes * n_new));
-    HIP_TRY(s, s->ensure(mgc_session::B_R2C, sizeof(uint32_t) * n_new));
-    HIP_TRY(s, mgc::launch_merge_emit(rk, rc_, s->r_n, bk, bc, nd, kw, 0, ws, s->buf[mgc_session::B_R2K].p,
-                                      reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_R2C].p), st));
-    HIP_TRY(s, hipEventRecord(e1, st));
-    HIP_TRY(s, hipStreamSynchronize(st));
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) s->merge_ms += ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    std::swap(s->buf[mgc_session::B_RK], s->buf[mgc_session::B_R2K]);
-    std::swap(s->buf[mgc_session::B_RC], s->buf[mgc_session::B_R2C]);
-    s->r_n = n_new;
+// The (k-mer, count) result count_device just left in the arena is parked as a RUN (mgc_runs.cpp): in HBM while the
+// store's device budget lasts, in pinned host DRAM otherwise.  Nothing is merged here -- the runs are merged once, when
+// the count ends (the analogue of writeBatch's iterations and merylBlockWriter::finish() merging them,
+// merylOp-countThreads.C:323-379,461-464).
+static int park_batch_result(mgc_session *s) {
+  if (!s->runs) {
+    // Runs may take what the count itself leaves free: the arena (grow-only, sized by the batches) and the staging buffers are
+    // allocated by now, and the final merge frees the arena before it allocates anything.
+    uint64_t budget = s->result_budget;
+    if (budget == 0) {
+      size_t free_b = 0, total_b = 0;
+      budget = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? (uint64_t)((double)free_b * 0.6) : 0;
+    }
+    s->runs = new mgc_runs(s->cfg.k, s->cfg.w_prefix, s->device, budget, 0);
   }
+  const int rc = s->runs->add(s->d_unique, s->d_counts, s->n_distinct, s->stream);
+  if (rc != MGC_OK) s->err = s->runs->err;
+  s->have_r = true;
   s->free_result();
-  return MGC_OK;
+  return rc;
 }
 
-// one batch: stage[which][0, n) -> count -> merge into R.  Runs on the worker thread while the caller stages the next batch.
+// one batch: stage[which][0, n) -> count -> park.  Runs on the worker thread while the caller stages the next batch.
 static int count_staged_batch(mgc_session *s, int which, uint64_t n) {
   s->d_bases = stage_ptr(s, which);
   s->n_bases = n;
@@ -1449,24 +1431,45 @@ static int count_staged_batch(mgc_session *s, int which, uint64_t n) {
   s->total_instances += s->n_instances;
   for (int f = 0; f < MGC_NUM_FILES; f++) s->total_file_instances[f] += s->file_instances[f];
   s->n_batches++;
-  return merge_into_r(s);
+  return park_batch_result(s);
 }
 
-// the merged result of all batches becomes the session's result (device-resident, like a single pass's)
-static int finalize_from_r(mgc_session *s) {
+// All batches are counted.  If every run is still in HBM and their merge fits beside them, the runs collapse into ONE
+// device-resident result -- then the session looks like a single pass's (every result call works).  Otherwise the result
+// is OUT OF CORE: it exists only as the runs, and is delivered by streaming (mgc_write_database, mgc_finish*), which merge
+// chunk by chunk; the calls that hand out the whole result refuse (MGC_ESTATE).
+static int finalize_from_runs(mgc_session *s) {
   hipStream_t st = s->stream;
-  s->n_distinct = s->r_n;
   s->n_instances = s->total_instances;
   s->n_bases = s->total_bases;
   memcpy(s->file_instances, s->total_file_instances, sizeof(s->file_instances));
-  s->d_unique = s->buf[mgc_session::B_RK].p;
-  s->d_counts = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_RC].p);
-  HIP_TRY(s, s->ensure(mgc_session::B_BLOCKS, sizeof(uint64_t) * (s->cfg.n_prefix + 1)));
-  s->d_block_start = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_BLOCKS].p);
-  HIP_TRY(s, mgc::launch_block_offsets(s->d_unique, s->n_distinct, s->key_words, s->cfg.w_data, s->cfg.n_prefix, s->d_block_start, st));
-  HIP_TRY(s, hipStreamSynchronize(st));
-  s->prof.merge_ms = s->merge_ms;
+  HIP_TRY(s, hipStreamSynchronize(s->st_in));
+  s->free_arena();                                            // the count's buffers: the merge gets their room
+  s->state_ready = false;
+  mgc_runs *r = s->runs;
+  const size_t esz = sizeof(uint64_t) * s->key_words + sizeof(uint32_t);
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const bool force_ooc = getenv("MGC_OOC_FORCE") && getenv("MGC_OOC_FORCE")[0] == '1';
+  const bool fits = r->all_on_device() && !force_ooc && (uint64_t)free_b > r->entries() * esz + (64ull << 20);
   s->prof.n_batches = s->n_batches;
+  if (fits) {
+    const void *k = nullptr; const uint32_t *c = nullptr; uint64_t n = 0;
+    const int rc = r->collapse(&k, &c, &n);
+    if (rc != MGC_OK) { s->err = r->err; return rc; }
+    s->n_distinct = n;
+    s->d_unique = const_cast<void *>(k);
+    s->d_counts = const_cast<uint32_t *>(c);
+    HIP_TRY(s, s->ensure(mgc_session::B_BLOCKS, sizeof(uint64_t) * (s->cfg.n_prefix + 1)));
+    s->d_block_start = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_BLOCKS].p);
+    HIP_TRY(s, mgc::launch_block_offsets(s->d_unique, s->n_distinct, s->key_words, s->cfg.w_data, s->cfg.n_prefix, s->d_block_start, st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+  } else {
+    s->ooc = true;
+    s->n_distinct = 0;                                        // known once the runs have been merged (delivery)
+  }
+  s->merge_ms = r->prof.merge_ms;
+  s->prof.merge_ms = s->merge_ms;
   return MGC_OK;
 }
 
@@ -1493,7 +1496,7 @@ extern "C" int mgc_count(mgc_session *s) {
     s->prof.n_batches = 1;
   } else {
     if (s->fill_len) rc = count_staged_batch(s, s->fill, s->fill_len);
-    if (rc == MGC_OK) rc = finalize_from_r(s);
+    if (rc == MGC_OK) rc = finalize_from_runs(s);
   }
   if (rc == MGC_OK) s->counted = true;
   s->free_garbage();
@@ -1556,9 +1559,30 @@ extern "C" int mgc_get_result_info(const mgc_session *s, mgc_result_info *info) 
   return MGC_OK;
 }
 
+static int refuse_ooc(mgc_session *s, const char *what) {
+  set_err(&s->err, "%s: the result is out of core (larger than the device holds): stream it with mgc_write_database / mgc_finish", what);
+  return MGC_ESTATE;
+}
+
+extern "C" int mgc_result_out_of_core(const mgc_session *s) { return (s && s->counted && s->ooc) ? 1 : 0; }
+
+extern "C" int mgc_set_result_budget(mgc_session *s, uint64_t device_bytes) {
+  if (!s) return MGC_EINVAL;
+  s->result_budget = device_bytes;
+  return MGC_OK;
+}
+
+extern "C" int mgc_get_runs_profile(const mgc_session *s, mgc_runs_profile *p) {
+  if (!s || !p) return MGC_EINVAL;
+  memset(p, 0, sizeof(*p));
+  if (s->runs) *p = s->runs->prof;
+  return MGC_OK;
+}
+
 extern "C" int mgc_copy_result_device(mgc_session *s, void *d_keys_out, uint32_t *d_counts_out) {
   if (!s) return MGC_EINVAL;
   if (!s->counted) return MGC_ESTATE;
+  if (s->ooc) return refuse_ooc(s, "mgc_copy_result_device");
   const size_t kbytes = sizeof(uint64_t) * s->key_words;
   if (s->n_distinct) {
     if (d_keys_out) HIP_TRY(s, hipMemcpyAsync(d_keys_out, s->d_unique, kbytes * s->n_distinct, hipMemcpyDeviceToDevice, s->stream));
@@ -1572,6 +1596,7 @@ extern "C" int mgc_get_result_device(const mgc_session *s, const void **d_unique
                                      const uint64_t **d_block_start, uint32_t *key_words) {
   if (!s) return MGC_EINVAL;
   if (!s->counted) return MGC_ESTATE;
+  if (s->ooc) return refuse_ooc(const_cast<mgc_session *>(s), "mgc_get_result_device");
   if (d_unique) *d_unique = s->d_unique;
   if (d_counts) *d_counts = s->d_counts;
   if (d_block_start) *d_block_start = s->d_block_start;
@@ -1584,6 +1609,7 @@ extern "C" int mgc_copy_result(const mgc_session *cs, uint64_t *keys_lo, uint64_
   mgc_session *s = const_cast<mgc_session *>(cs);
   if (!s) return MGC_EINVAL;
   if (!s->counted) return MGC_ESTATE;
+  if (s->ooc) return refuse_ooc(s, "mgc_copy_result");
   HIP_TRY(s, hipSetDevice(s->device));
   return copy_device_result(s, keys_lo, keys_hi, counts, block_start);
 }

@@ -13,6 +13,7 @@
 // one-GPU box run the whole plan that way).
 #include "../../include/meryl_db.h"
 #include "mgc_session.hpp"
+#include "mgc_runs.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -43,18 +44,27 @@ struct Barrier {
 
 struct Rank {
   int device = 0;
-  const uint8_t *d_bases = nullptr; uint64_t n_bases = 0;
-  void *d_keys = nullptr;                       // this rank's k-mers, bucket-major (read by the owners' peer copies)
-  std::vector<uint64_t> counts, off;            // per bucket: k-mers, start (in k-mers) inside d_keys
+  const uint8_t *d_bases = nullptr; uint64_t n_bases = 0;   // this rank's reads (after `compress`: d_own)
+  void *d_own = nullptr;                        // the homopolymer-compressed copy, if one was made
+  std::vector<uint64_t> total;                  // per bucket: k-mers of ALL of this rank's reads (the routing plan's input)
+  void *d_keys = nullptr;                       // the current batch's k-mers, bucket-major (read by the owners' peer copies)
+  std::vector<uint64_t> counts, off;            // per bucket, current batch: k-mers, start (in k-mers) inside d_keys
   uint64_t n_distinct = 0, n_instances = 0;
   mgc_db_write_profile wp{};
-  double t_partition = 0, t_count = 0, t_close = 0;
+  mgc_runs_profile rp{};
+  double t_partition = 0, t_count = 0, t_close = 0, t_merge = 0;
+  // owner side, alive over all batches
+  mgc_session *sess = nullptr;
+  mgc_db_stream *ds = nullptr;
+  mgc_runs *runs = nullptr;                     // batches > 1: every counted wave is parked here, merged when the last batch is done
 };
 
 struct Node {
   mgc_count_config cfg{};
   uint32_t n = 1, bits = 6, kw = 1;
   std::string path; int host_threads = 8;
+  uint64_t batch_bases = 0;                     // bases of one rank's batch; 0: derive from the free HBM
+  uint32_t n_batches = 1;
   std::vector<Rank> ranks;
   std::vector<uint32_t> cuts;                   // n + 1 bucket cut points
   Barrier bar;
@@ -105,20 +115,49 @@ struct DevMem {                                 // frees what a phase allocated,
   hipError_t alloc(void **out, size_t bytes) { hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 256)); if (e == hipSuccess) p.push_back(*out); return e; }
 };
 
-void phase_partition(Node &nd, uint32_t r, hipStream_t st) {
+// once per rank: `compress` (the rank's whole sequences), the bucket histogram of ALL its reads -- every rank needs the same
+// routing plan for every batch, so the plan comes from the whole input, not from the first batch
+void phase_prepare(Node &nd, uint32_t r, hipStream_t st) {
+  Rank &me = nd.ranks[r];
+  const uint32_t nbk = 1u << nd.bits;
+  DevMem tmp;
+  if (nd.cfg.homopoly_compress && me.n_bases) {
+    void *ws = nullptr;
+    const size_t wsb = mgc_dev_homopoly_workspace_bytes(me.n_bases);
+    ND_HIP(hipMalloc(&me.d_own, me.n_bases)); ND_HIP(tmp.alloc(&ws, wsb));
+    uint64_t n_out = 0;
+    ND_MGC(mgc_dev_homopoly_compress(me.d_bases, me.n_bases, (uint8_t *)me.d_own, &n_out, ws, wsb, st), nullptr);
+    me.d_bases = (const uint8_t *)me.d_own; me.n_bases = n_out;
+  }
+  const size_t wsb = mgc_dev_partition_workspace_bytes(nd.bits);
+  void *ws = nullptr, *d_counts = nullptr;
+  ND_HIP(tmp.alloc(&ws, wsb)); ND_HIP(tmp.alloc(&d_counts, sizeof(uint64_t) * nbk));
+  ND_MGC(mgc_dev_kmer_histogram(me.d_bases, me.n_bases, nd.cfg.k, nd.cfg.mode, nd.bits, (uint64_t *)d_counts, ws, wsb, st), nullptr);
+  me.total.assign(nbk, 0);
+  ND_HIP(hipMemcpyAsync(me.total.data(), d_counts, sizeof(uint64_t) * nbk, hipMemcpyDeviceToHost, st));
+  ND_HIP(hipStreamSynchronize(st));
+  for (uint32_t b = 0; b < nbk; b++) me.n_instances += me.total[b];
+}
+
+// Batch b of a rank's reads: [cut_b - (k-1), cut_{b+1}) of its base stream -- a window that starts in the last k-1 bases of
+// batch b-1 is incomplete there and complete here, so the cut may fall anywhere, also inside a read, and no k-mer is lost or
+// counted twice (the rule mgc_count_node_staged cuts its rank slices by).
+void batch_range(const Node &nd, const Rank &me, uint32_t b, uint64_t *a, uint64_t *len) {
+  const uint64_t n = me.n_bases, k = nd.cfg.k;
+  const uint64_t cut = (uint64_t)((unsigned __int128)n * b / nd.n_batches), end = (uint64_t)((unsigned __int128)n * (b + 1) / nd.n_batches);
+  *a = (b && cut >= k - 1) ? cut - (k - 1) : 0;     // cut < k-1: the earlier batches are shorter than a k-mer, hold no window
+  *len = end - *a;
+  if (b && cut < k - 1 && end < k) *len = 0;       // (still no complete window)
+}
+
+void phase_partition(Node &nd, uint32_t r, uint32_t batch, hipStream_t st) {
   Rank &me = nd.ranks[r];
   const uint32_t nbk = 1u << nd.bits;
   const double t0 = now_s();
   DevMem tmp;
-  const uint8_t *bases = me.d_bases; uint64_t nb = me.n_bases;
-  if (nd.cfg.homopoly_compress && nb) {         // `compress`: this rank's reads (whole sequences) on their own
-    void *out = nullptr, *ws = nullptr;
-    const size_t wsb = mgc_dev_homopoly_workspace_bytes(nb);
-    ND_HIP(tmp.alloc(&out, nb)); ND_HIP(tmp.alloc(&ws, wsb));
-    uint64_t n_out = 0;
-    ND_MGC(mgc_dev_homopoly_compress(bases, nb, (uint8_t *)out, &n_out, ws, wsb, st), nullptr);
-    bases = (const uint8_t *)out; nb = n_out;
-  }
+  uint64_t a = 0, nb = 0;
+  batch_range(nd, me, batch, &a, &nb);
+  const uint8_t *bases = me.d_bases + a;
   const size_t wsb = mgc_dev_partition_workspace_bytes(nd.bits);
   void *ws = nullptr, *d_counts = nullptr;
   ND_HIP(tmp.alloc(&ws, wsb)); ND_HIP(tmp.alloc(&d_counts, sizeof(uint64_t) * nbk));
@@ -128,12 +167,30 @@ void phase_partition(Node &nd, uint32_t r, hipStream_t st) {
   ND_HIP(hipStreamSynchronize(st));
   me.off.assign(nbk + 1, 0);
   for (uint32_t b = 0; b < nbk; b++) me.off[b + 1] = me.off[b] + me.counts[b];
-  me.n_instances = me.off[nbk];
   ND_HIP(hipMemcpyAsync(d_counts, me.off.data(), sizeof(uint64_t) * nbk, hipMemcpyHostToDevice, st));     // now the starts
-  ND_HIP(hipMalloc(&me.d_keys, std::max<uint64_t>(me.n_instances * nd.kw * 8, 256)));
+  ND_HIP(hipMalloc(&me.d_keys, std::max<uint64_t>(me.off[nbk] * nd.kw * 8, 256)));
   ND_MGC(mgc_dev_kmer_partition(bases, nb, nd.cfg.k, nd.cfg.mode, nd.bits, (const uint64_t *)d_counts, me.d_keys, ws, wsb, st), nullptr);
   ND_HIP(hipStreamSynchronize(st));
-  me.t_partition = now_s() - t0;
+  me.t_partition += now_s() - t0;
+}
+
+// owner side, once: the session that counts the waves, this rank's part of the database, the run store (several batches)
+void owner_open(Node &nd, uint32_t r) {
+  Rank &me = nd.ranks[r];
+  mgc_count_config cfg = nd.cfg;
+  cfg.homopoly_compress = 0;                    // the owner side sees k-mers, never bases
+  me.sess = mgc_open(&cfg, me.device);
+  if (!me.sess) { nd.fail("rank %u: mgc_open: %s", r, mgc_last_error(nullptr)); return; }
+  me.ds = mgc_db_stream_open(nd.path.c_str(), cfg.k, cfg.w_prefix, cfg.label_size, cfg.label_constant, r, nd.n, nd.host_threads, me.device);
+  if (!me.ds) { nd.fail("rank %u: %s", r, mgc_db_stream_error(nullptr)); return; }
+  if (nd.n_batches > 1) {
+    // the parked waves share the device with a batch's k-mers, inbox and count arena: a third of what is free now may stay
+    // in HBM, the rest goes to pinned host DRAM (MGC_OOC_BUDGET overrides)
+    size_t free_b = 0, total_b = 0;
+    const uint64_t budget = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? (uint64_t)free_b / 3 : 0;
+    me.runs = mgc_runs_open(cfg.k, cfg.w_prefix, me.device, budget, 0);
+    if (!me.runs) nd.fail("rank %u: %s", r, mgc_runs_error(nullptr));
+  }
 }
 
 void phase_count(Node &nd, uint32_t r, hipStream_t st_copy) {
@@ -150,23 +207,28 @@ void phase_count(Node &nd, uint32_t r, hipStream_t st_copy) {
   DevMem mem;
   void *inbox = nullptr, *res_keys = nullptr, *res_counts = nullptr;
   ND_HIP(mem.alloc(&inbox, file_off[f1 - f0] * kb));
-  // the counted waves stay here until the writer is closed: a wave has at most as many distinct k-mers as k-mers, so its
-  // result fits at its own offset (one allocation for all waves -- hipMalloc beside running kernels is slow)
-  ND_HIP(mem.alloc(&res_keys, file_off[f1 - f0] * kb));
-  ND_HIP(mem.alloc(&res_counts, file_off[f1 - f0] * sizeof(uint32_t)));
-  mgc_count_config cfg = nd.cfg;
-  cfg.homopoly_compress = 0;                    // the owner side sees k-mers, never bases
-  mgc_session *sess = mgc_open(&cfg, me.device);
-  if (!sess) { nd.fail("rank %u: mgc_open: %s", r, mgc_last_error(nullptr)); return; }
-  struct SessionGuard { mgc_session *s; ~SessionGuard() { if (s) mgc_close(s); } } sess_guard{sess};   // closed whichever way this ends
-  mgc_db_stream *ds = mgc_db_stream_open(nd.path.c_str(), cfg.k, cfg.w_prefix, cfg.label_size, cfg.label_constant, r, n,
-                                         nd.host_threads, me.device);
-  if (!ds) { nd.fail("rank %u: %s", r, mgc_db_stream_error(nullptr)); return; }
-  const uint64_t blocks_per_bucket = 1ull << (cfg.w_prefix - nd.bits);
-
+  // one batch: the counted waves stay here until the writer is closed (a wave has at most as many distinct k-mers as k-mers,
+  // so its result fits at its own offset; one allocation for all waves -- hipMalloc beside running kernels is slow).
+  // Several batches: a wave's result is parked in the run store at once, so one wave's room is enough.
+  const bool direct = nd.n_batches == 1;
   uint32_t most = 0;
   for (uint32_t q = 0; q < n; q++) most = std::max(most, nd.cuts[q + 1] - nd.cuts[q]);
   const uint32_t bpw = std::max(1u, (most + 15) / 16), n_waves = (most + bpw - 1) / bpw;
+  uint64_t res_entries = file_off[f1 - f0];
+  if (!direct) {
+    res_entries = 0;
+    for (uint32_t i = 0; i < n_waves; i++) {
+      const uint32_t lo = std::min(f1, f0 + i * bpw), hi = std::min(f1, f0 + (i + 1) * bpw);
+      res_entries = std::max(res_entries, file_off[hi - f0] - file_off[lo - f0]);
+    }
+  }
+  ND_HIP(mem.alloc(&res_keys, res_entries * kb));
+  ND_HIP(mem.alloc(&res_counts, res_entries * sizeof(uint32_t)));
+  mgc_session *sess = me.sess;
+  mgc_db_stream *ds = me.ds;
+  const mgc_count_config &cfg = nd.cfg;
+  const uint64_t blocks_per_bucket = 1ull << (cfg.w_prefix - nd.bits);
+
   std::vector<hipEvent_t> ev(n_waves, nullptr);
   bool ok = true;
   auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess && ok) { nd.fail("rank %u: %s -> %s", r, what, hipGetErrorString(e)); ok = false; } return e == hipSuccess; };
@@ -203,27 +265,58 @@ void phase_count(Node &nd, uint32_t r, hipStream_t st_copy) {
       if (rc == MGC_OK) rc = mgc_get_result_info(sess, &info);
       if (rc != MGC_OK) { nd.fail("rank %u: mgc_count_buckets: %d %s", r, rc, mgc_last_error(sess)); ok = false; return; }
       ndist = info.n_distinct;
-      ok_keys = (char *)res_keys + file_off[lo - f0] * kb;
-      ok_counts = (char *)res_counts + file_off[lo - f0] * sizeof(uint32_t);
+      const uint64_t at = direct ? file_off[lo - f0] : 0;
+      ok_keys = (char *)res_keys + at * kb;
+      ok_counts = (char *)res_counts + at * sizeof(uint32_t);
       rc = mgc_copy_result_device(sess, ok_keys, (uint32_t *)ok_counts);
       if (rc != MGC_OK) { nd.fail("rank %u: mgc_copy_result_device: %d %s", r, rc, mgc_last_error(sess)); ok = false; return; }
-      me.n_distinct += ndist;
+      if (direct) me.n_distinct += ndist;
     }
-    const int rc = mgc_db_stream_write(ds, ok_keys, (const uint32_t *)ok_counts, ndist, lo * blocks_per_bucket, hi * blocks_per_bucket);
-    if (rc != MGC_OK) { nd.fail("rank %u: mgc_db_stream_write: %s", r, mgc_db_stream_error(ds)); ok = false; }
+    if (direct) {
+      const int rc = mgc_db_stream_write(ds, ok_keys, (const uint32_t *)ok_counts, ndist, lo * blocks_per_bucket, hi * blocks_per_bucket);
+      if (rc != MGC_OK) { nd.fail("rank %u: mgc_db_stream_write: %s", r, mgc_db_stream_error(ds)); ok = false; }
+    } else if (ndist) {
+      const int rc = mgc_runs_add(me.runs, ok_keys, (const uint32_t *)ok_counts, ndist, nullptr);
+      if (rc != MGC_OK) { nd.fail("rank %u: mgc_runs_add: %s", r, mgc_runs_error(me.runs)); ok = false; }
+    }
   };
 
   for (uint32_t i = 0; i <= n_waves && ok && !nd.failed.load(); i++) {
     if (i < n_waves) pull(i);                   // wave i goes onto the links ...
-    if (i >= 1 && ok) count_wave(i - 1);        // ... while wave i-1 is grouped, counted and handed to the writer
+    if (i >= 1 && ok) count_wave(i - 1);        // ... while wave i-1 is grouped, counted and handed to the writer / parked
   }
   (void)hipStreamSynchronize(st_copy);
-  me.t_count = now_s() - t0;
-  const double t1 = now_s();
-  const int crc = mgc_db_stream_close(ds, &me.wp);        // waits for this rank's files; the wave buffers live until here
-  if (crc != MGC_OK && ok) nd.fail("rank %u: mgc_db_stream_close: %s", r, mgc_db_stream_error(nullptr));
-  me.t_close = now_s() - t1;
+  if (direct) {                                 // the wave buffers must outlive the writer's reads
+    const double t1 = now_s();
+    const int crc = mgc_db_stream_close(ds, &me.wp);        // waits for this rank's files
+    me.ds = nullptr;
+    if (crc != MGC_OK && ok) nd.fail("rank %u: mgc_db_stream_close: %s", r, mgc_db_stream_error(nullptr));
+    me.t_close = now_s() - t1;
+  }
+  me.t_count += now_s() - t0 - me.t_close;
   for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+}
+
+// several batches: every wave of every batch sits in the run store -- merge this rank's prefix range once, into its part
+void owner_finish(Node &nd, uint32_t r) {
+  Rank &me = nd.ranks[r];
+  if (nd.n_batches > 1 && me.runs && me.ds && !nd.failed.load()) {
+    const double t0 = now_s();
+    const uint64_t bpb = 1ull << (nd.cfg.w_prefix - nd.bits);
+    const int rc = mgc_runs_write(me.runs, me.ds, (uint64_t)nd.cuts[r] * bpb, (uint64_t)nd.cuts[r + 1] * bpb);
+    if (rc != MGC_OK) nd.fail("rank %u: mgc_runs_write: %s", r, mgc_runs_error(me.runs));
+    (void)mgc_runs_get_profile(me.runs, &me.rp);
+    me.n_distinct = me.rp.n_merged;
+    me.t_merge = now_s() - t0;
+    const double t1 = now_s();
+    const int crc = mgc_db_stream_close(me.ds, &me.wp);
+    me.ds = nullptr;
+    if (crc != MGC_OK) nd.fail("rank %u: mgc_db_stream_close: %s", r, mgc_db_stream_error(nullptr));
+    me.t_close = now_s() - t1;
+  }
+  if (me.ds) { (void)mgc_db_stream_close(me.ds, nullptr); me.ds = nullptr; }     // a failed run: release the writer
+  if (me.runs) { mgc_runs_close(me.runs); me.runs = nullptr; }
+  if (me.sess) { mgc_close(me.sess); me.sess = nullptr; }
 }
 
 void rank_main(Node &nd, uint32_t r) {
@@ -241,18 +334,37 @@ void rank_main(Node &nd, uint32_t r) {
   }
   if (!up) nd.fail("rank %u: device %d / stream setup failed", r, me.device);
 
-  if (!nd.failed.load()) phase_partition(nd, r, st);
-  nd.bar.wait();                                // every partition is complete and its histogram published
+  if (!nd.failed.load()) phase_prepare(nd, r, st);
+  nd.bar.wait();                                // every rank's histogram of ALL its reads is published
   if (!nd.failed.load() && r == 0) {
     const uint32_t nbk = 1u << nd.bits;
     std::vector<uint64_t> total(nbk, 0);
-    for (const Rank &q : nd.ranks) for (uint32_t b = 0; b < nbk; b++) total[b] += q.counts[b];
+    uint64_t max_nb = 0;
+    for (const Rank &q : nd.ranks) { for (uint32_t b = 0; b < nbk; b++) total[b] += q.total[b]; max_nb = std::max(max_nb, q.n_bases); }
     nd.cuts = balanced_ranges(total, nd.n);
+    // Batches: a rank holds, per base of a batch, its k-mers (8/16 B), as owner an inbox of about as many, a result copy and the
+    // count arena (4 B of counts + the ping-pong file) -- 2 + 28 (52) B with slack; 60 % of the free HBM may go there.
+    uint64_t batch = nd.batch_bases;
+    if (const char *e = getenv("MGC_NODE_BATCH_BASES")) batch = strtoull(e, nullptr, 10);
+    if (batch == 0) {
+      size_t free_b = 0, total_b = 0;
+      batch = ~0ull;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) batch = (uint64_t)((double)free_b * 0.6 / (double)(2 + 26ull * nd.kw));
+    }
+    if (batch < 1024) batch = 1024;
+    nd.n_batches = (uint32_t)std::max<uint64_t>(1, (max_nb + batch - 1) / batch);
   }
   nd.bar.wait();
-  if (!nd.failed.load()) phase_count(nd, r, st_copy);
-  nd.bar.wait();                                // nobody reads this rank's k-mers any more
-  if (me.d_keys) { (void)hipFree(me.d_keys); me.d_keys = nullptr; }
+  if (!nd.failed.load()) owner_open(nd, r);
+  for (uint32_t b = 0; b < nd.n_batches; b++) {
+    if (!nd.failed.load()) phase_partition(nd, r, b, st);
+    nd.bar.wait();                              // every partition of this batch is complete and its histogram published
+    if (!nd.failed.load()) phase_count(nd, r, st_copy);
+    nd.bar.wait();                              // nobody reads this rank's k-mers any more
+    if (me.d_keys) { (void)hipFree(me.d_keys); me.d_keys = nullptr; }
+  }
+  owner_finish(nd, r);
+  if (me.d_own) { (void)hipFree(me.d_own); me.d_own = nullptr; }
   if (st) (void)hipStreamDestroy(st);
   if (st_copy) (void)hipStreamDestroy(st_copy);
 }
@@ -262,6 +374,12 @@ void rank_main(Node &nd, uint32_t r) {
 extern "C" int mgc_count_node(const mgc_count_config *cfg, uint32_t n_ranks, const int *devices,
                               const uint8_t *const *d_bases, const uint64_t *n_bases,
                               const char *db_path, int host_threads, mgc_node_profile *prof) {
+  return mgc_count_node_batched(cfg, n_ranks, devices, d_bases, n_bases, 0, db_path, host_threads, prof);
+}
+
+extern "C" int mgc_count_node_batched(const mgc_count_config *cfg, uint32_t n_ranks, const int *devices,
+                                      const uint8_t *const *d_bases, const uint64_t *n_bases, uint64_t batch_bases,
+                                      const char *db_path, int host_threads, mgc_node_profile *prof) {
   if (!cfg || !n_ranks || !d_bases || !n_bases || !db_path) { set_err(nullptr, "mgc_count_node: bad arguments"); return MGC_EINVAL; }
   if (cfg->count_suffix_length) { set_err(nullptr, "mgc_count_node: count-suffix is a single-device option"); return MGC_EINVAL; }
   mgc_count_config eff = *cfg;
@@ -277,6 +395,7 @@ extern "C" int mgc_count_node(const mgc_count_config *cfg, uint32_t n_ranks, con
 
   Node nd;
   nd.cfg = *cfg; nd.n = n_ranks; nd.kw = cfg->k > 32 ? 2 : 1; nd.path = db_path; nd.host_threads = std::max(1, host_threads);
+  nd.batch_bases = batch_bases;
   nd.ranks.resize(n_ranks);
   uint64_t max_nb = 0, total_bases = 0;
   for (uint32_t r = 0; r < n_ranks; r++) {
@@ -312,6 +431,12 @@ extern "C" int mgc_count_node(const mgc_count_config *cfg, uint32_t n_ranks, con
       prof->close_s = std::max(prof->close_s, q.t_close);
     }
     prof->merge_parts_s = t2 - t1; prof->total_s = t2 - t0;
+    prof->n_batches = nd.n_batches;
+    for (const Rank &q : nd.ranks) {
+      prof->n_host_runs += q.rp.n_host_runs; prof->host_run_bytes += q.rp.host_bytes;
+      prof->merge_runs_s = std::max(prof->merge_runs_s, q.t_merge);
+      prof->peak_hbm_bytes = std::max<uint64_t>(prof->peak_hbm_bytes, q.rp.peak_hbm_bytes);
+    }
   }
   return MGC_OK;
 }

@@ -146,11 +146,13 @@ struct mgc_session {
   // merylBlockWriter::finish() merging the iterations) ---------------------------------------------------------
   // When the staged bases reach batch_limit, everything up to the last sequence boundary is counted as one batch by
   // the WORKER thread while the caller keeps pushing into the other staging buffer; the batch's (k-mer, count) result
-  // is merged ON THE DEVICE into the running result R (mgc_merge.hip), which stays in HBM -- nothing is parked on the
-  // host, and the final result is device-resident like a single-pass one.
+  // is parked as a sorted run -- in HBM while there is room, in pinned host DRAM otherwise -- and the runs are merged once,
+  // at the end (mgc_runs.cpp): into one device-resident result when that fits, chunk by chunk into the consumer otherwise.
   uint64_t    batch_limit = 0;            // bases per batch; 0 = derive from free HBM at the first input
-  bool        have_r = false;
-  uint64_t    r_n = 0;                    // distinct k-mers in R (buffers B_RK / B_RC)
+  bool        have_r = false;             // at least one batch result has been parked
+  struct mgc_runs *runs = nullptr;        // the parked batch results (mgc_runs.cpp)
+  bool        ooc = false;                // counted, and the result exists only as runs (too large to collapse into HBM)
+  uint64_t    result_budget = 0;          // bytes of runs that may stay in HBM; 0 = 60 % of what is free at the first batch's end
   uint64_t    total_bases = 0, total_instances = 0;
   uint64_t    total_file_instances[MGC_NUM_FILES];
   uint32_t    n_batches = 0;

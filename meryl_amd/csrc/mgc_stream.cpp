@@ -9,6 +9,7 @@
 #include "../../include/meryl_db.h"
 #include "mdb_layout.h"
 #include "mgc_session.hpp"
+#include "mgc_runs.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -443,8 +444,19 @@ extern "C" int mgc_write_database_profiled(mgc_session *s, const char *path, int
   const mgc_count_config &c = s->cfg;
   mgc_db_stream *d = mgc_db_stream_open(path, c.k, c.w_prefix, c.label_size, c.label_constant, 0, 1, host_threads, s->device);
   if (!d) { set_err(&s->err, "%s", mgc_db_stream_error(nullptr)); return MGC_EINVAL; }
-  int rc = mgc_db_stream_write(d, s->d_unique, s->d_counts, s->n_distinct, 0, c.n_prefix);
-  std::string msg = (rc != MGC_OK) ? std::string(mgc_db_stream_error(d)) : std::string();
+  int rc;
+  std::string msg;
+  if (s->ooc) {
+    // out of core: the runs are merged chunk by chunk straight into the stream (merylBlockWriter::finish() merging the
+    // iterations, merylOp-countThreads.C:461-464)
+    const uint64_t before = s->runs->prof.n_merged;
+    rc = s->runs->write(d, 0, c.n_prefix);
+    if (rc != MGC_OK) msg = s->runs->err;
+    else s->n_distinct = s->runs->prof.n_merged - before;
+  } else {
+    rc = mgc_db_stream_write(d, s->d_unique, s->d_counts, s->n_distinct, 0, c.n_prefix);
+    if (rc != MGC_OK) msg = mgc_db_stream_error(d);
+  }
   const int rc2 = mgc_db_stream_close(d, prof);
   if (rc == MGC_OK && rc2 != MGC_OK) { rc = rc2; msg = mgc_db_stream_error(nullptr); }
   if (rc != MGC_OK) set_err(&s->err, "%s", msg.c_str());
@@ -472,9 +484,11 @@ struct PinnedBuf {
   ~PinnedBuf() { if (p) (void)hipHostFree(p); }
 };
 
-int finish_impl(mgc_session *s, mgc_block_cb cb1, mgc_block_cb2 cb2, void *ctx, int host_threads) {
-  if (!s || (!cb1 && !cb2)) return MGC_EINVAL;
-  if (!s->counted) { set_err(&s->err, "mgc_finish before mgc_count"); return MGC_ESTATE; }
+// the blocks of prefixes [pb, pe): n_keys ascending distinct k-mers + counts in device memory, bstart[i] = first k-mer of
+// prefix pb + i (relative to the view, pe - pb + 1 entries, host)
+struct ResultView { const void *d_keys; const uint32_t *d_counts; uint64_t pb, pe; const uint64_t *bstart; };
+
+int deliver_view(mgc_session *s, const ResultView &view, mgc_block_cb cb1, mgc_block_cb2 cb2, void *ctx, int host_threads) {
   const uint64_t np = s->cfg.n_prefix;
   const bool wide = s->key_words == 2;
   const uint32_t kw = s->key_words;
@@ -487,12 +501,8 @@ int finish_impl(mgc_session *s, mgc_block_cb cb1, mgc_block_cb2 cb2, void *ctx, 
   const uint64_t per_file = np / MGC_NUM_FILES;             // firstPrefixInFile/lastPrefixInFile
   if (host_threads <= 0) host_threads = (int)(s->cfg.threads ? s->cfg.threads : std::thread::hardware_concurrency());
   host_threads = std::max(1, std::min(host_threads, MGC_NUM_FILES));
-
-  // block boundaries first (small); the k-mers follow file by file
-  std::vector<uint64_t> bstart_own(np + 1);
   HIP_TRY(s, hipSetDevice(s->device));
-  HIP_TRY(s, hipMemcpy(bstart_own.data(), s->d_block_start, sizeof(uint64_t) * (np + 1), hipMemcpyDeviceToHost));
-  const uint64_t *bstart = bstart_own.data();
+  const uint64_t *bstart = view.bstart - view.pb;           // indexed by absolute prefix
 
   auto deliver = [&](uint64_t pp, uint64_t n, const uint64_t *slo, const uint64_t *shi, const uint32_t *cn) -> int {
     return cb2 ? cb2(ctx, pp, n, slo, shi, cn, nullptr, label) : cb1(ctx, pp, n, slo, shi, cn);
@@ -538,9 +548,9 @@ int finish_impl(mgc_session *s, mgc_block_cb cb1, mgc_block_cb2 cb2, void *ctx, 
       if (n == 0) return true;
       hipError_t e = pk[b].ensure(sizeof(uint64_t) * kw * n);
       if (e == hipSuccess) e = pc[b].ensure(sizeof(uint32_t) * n);
-      if (e == hipSuccess) e = hipMemcpyAsync(pk[b].p, reinterpret_cast<const unsigned char *>(s->d_unique) + sizeof(uint64_t) * kw * k0,
+      if (e == hipSuccess) e = hipMemcpyAsync(pk[b].p, reinterpret_cast<const unsigned char *>(view.d_keys) + sizeof(uint64_t) * kw * k0,
                                               sizeof(uint64_t) * kw * n, hipMemcpyDeviceToHost, st);
-      if (e == hipSuccess) e = hipMemcpyAsync(pc[b].p, s->d_counts + k0, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(pc[b].p, view.d_counts + k0, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipEventRecord(ev[b], st);
       if (e != hipSuccess) { hip_fail(e, "device-to-host copy"); return false; }
       return true;
@@ -548,7 +558,8 @@ int finish_impl(mgc_session *s, mgc_block_cb cb1, mgc_block_cb2 cb2, void *ctx, 
     for (;;) {
       const uint32_t ff = next_file.fetch_add(1);            // dynamic,1 like the reference's omp schedule
       if (ff >= MGC_NUM_FILES || status.load() != MGC_OK) break;
-      const uint64_t f0 = ff * per_file, f1 = (ff + 1) * per_file;
+      const uint64_t f0 = std::max<uint64_t>(ff * per_file, view.pb), f1 = std::min<uint64_t>((ff + 1) * per_file, view.pe);
+      if (f0 >= f1) continue;                                // the view holds nothing of this file
       int b = 0;
       Span cur = plan(f0, f1);
       if (!issue(cur, b)) break;
@@ -590,6 +601,61 @@ int finish_impl(mgc_session *s, mgc_block_cb cb1, mgc_block_cb2 cb2, void *ctx, 
   worker();
   for (auto &t : pool) t.join();
   return status.load();
+}
+
+// out-of-core results: every merged chunk of the runs is delivered like a (partial) device result -- synchronously, so a
+// chunk's buffers are free again when put() returns.  Chunks ascend, so every file still sees its prefixes in order.
+struct CallbackSink : mgc::RunSink {
+  mgc_session *s; mgc_block_cb cb1; mgc_block_cb2 cb2; void *ctx; int host_threads;
+  void *d_bs = nullptr; size_t bs_cap = 0;
+  std::string msg;
+  uint64_t n_delivered = 0;
+  CallbackSink(mgc_session *s_, mgc_block_cb a, mgc_block_cb2 b, void *c, int t) : s(s_), cb1(a), cb2(b), ctx(c), host_threads(t) {}
+  ~CallbackSink() override { if (d_bs) (void)hipFree(d_bs); }
+  int put(const void *k, const uint32_t *c, uint64_t n, uint64_t sa, uint64_t sb, uint32_t slice_bits, uint64_t *job) override {
+    *job = 0;
+    const uint32_t sh = s->cfg.w_prefix - slice_bits;
+    const uint64_t pb = sa << sh, pe = sb << sh, nblk = pe - pb;
+    const size_t need = sizeof(uint64_t) * (nblk + 1);
+    if (bs_cap < need) {
+      if (d_bs) (void)hipFree(d_bs);
+      d_bs = nullptr; bs_cap = 0;
+      if (hipMalloc(&d_bs, need) != hipSuccess) { msg = "mgc_finish: out of device memory for the block offsets of a chunk"; return MGC_ENOMEM; }
+      bs_cap = need;
+    }
+    std::vector<uint64_t> h_bs(nblk + 1);
+    hipError_t e = mgc::launch_block_offsets_range(k, n, s->key_words, s->cfg.w_data, pb, nblk, s->cfg.n_prefix, reinterpret_cast<uint64_t *>(d_bs), s->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_bs.data(), d_bs, need, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess) { msg = std::string("mgc_finish: block offsets of a chunk: ") + hipGetErrorString(e); return MGC_EHIP; }
+    if (h_bs[0] != 0 || h_bs[nblk] != n) { msg = "mgc_finish: a merged chunk holds k-mers outside its prefix range"; return MGC_EINVAL; }
+    ResultView v{k, c, pb, pe, h_bs.data()};
+    const int rc = deliver_view(s, v, cb1, cb2, ctx, host_threads);
+    if (rc != MGC_OK) msg = s->err.empty() ? "mgc_finish: the callback stopped the delivery" : s->err;
+    n_delivered += n;
+    return rc;
+  }
+  int wait(uint64_t) override { return MGC_OK; }
+  const char *error() const override { return msg.c_str(); }
+};
+
+int finish_impl(mgc_session *s, mgc_block_cb cb1, mgc_block_cb2 cb2, void *ctx, int host_threads) {
+  if (!s || (!cb1 && !cb2)) return MGC_EINVAL;
+  if (!s->counted) { set_err(&s->err, "mgc_finish before mgc_count"); return MGC_ESTATE; }
+  const uint64_t np = s->cfg.n_prefix;
+  if (s->ooc) {
+    CallbackSink sink(s, cb1, cb2, ctx, host_threads);
+    const int rc = s->runs->deliver(0, s->runs->n_slices, sink);
+    if (rc != MGC_OK && s->err.empty()) s->err = s->runs->err;
+    if (rc == MGC_OK) s->n_distinct = sink.n_delivered;
+    return rc;
+  }
+  // block boundaries first (small); the k-mers follow file by file
+  std::vector<uint64_t> bstart_own(np + 1);
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipMemcpy(bstart_own.data(), s->d_block_start, sizeof(uint64_t) * (np + 1), hipMemcpyDeviceToHost));
+  ResultView v{s->d_unique, s->d_counts, 0, np, bstart_own.data()};
+  return deliver_view(s, v, cb1, cb2, ctx, host_threads);
 }
 
 }  // namespace

@@ -298,3 +298,44 @@ def test_count_node_rejects_bad_arguments(tmp_path, native_lib):
     cfg3 = capi.configure(4, 1000, 1 << 30)                                # 8 bits of k-mer: at most 256 ranges to route
     with pytest.raises(RuntimeError, match="ranges of the k-mer space"):
         count.count_node(cfg3, [d] * 257, str(tmp_path / "z"), devices=[0] * 257)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,compress,label_size,ranks,batch,budget", [(21, 0, 0, 4, 350_000, None), (51, 0, 8, 4, 300_000, 1), (31, 1, 0, 3, 250_000, 1),
+                                                                      (21, 0, 0, 1, 700_000, 1), (51, 0, 8, 2, 10**9, None)])
+def test_count_node_batches_park_waves_and_merge_once(tmp_path, native_lib, oracle_lib, monkeypatch, k, compress, label_size, ranks, batch, budget):
+    """mgc_count_node_batched: the node count in BATCHES -- the routing plan from one histogram of all reads, then per batch
+    partition -> pulls -> owner count, every counted wave parked in the owner's run store (budget = 1 byte: in pinned host
+    DRAM; None: in HBM), one merge per owner into its part when the last batch is done.  >= 4 batches x 4 virtual ranks on the
+    one GPU, k = 51 with a label, `compress`, batch cuts inside reads (k-1 overlap), one rank without reads: the 129 files
+    must be the single session's, byte for byte.  batch = 10^9: one batch, the waves stream to the writer as before."""
+    import torch
+    from meryl_amd import capi, count
+    if budget is not None:
+        monkeypatch.setenv("MGC_OOC_BUDGET", str(budget))
+    monkeypatch.setenv("MGC_OOC_CHUNK", "600000")
+    n_reads, rl = (2000, 3000) if compress else (40_000, 150)
+    bases = oracle_lib.synth_reads(23, 300_000, 0, n_reads, rl, 5000, 100)
+    cfg = capi.configure(k, 3_000_000_000, 64 << 30, homopoly_compress=compress, label_size=label_size, label=0x33)
+    d = torch.from_numpy(bases).cuda()
+    with count.Session(cfg, 0) as s:
+        s.push_bases_device(d)
+        s.count()
+        s.write_database(str(tmp_path / "one"), 8)
+        info = s.info()
+    rec = rl + 1
+    w = np.array([1.0 + (i * 7) % 5 for i in range(ranks)])
+    if ranks >= 3:
+        w[1] = 0.0
+    cuts = np.concatenate([[0], np.floor(np.cumsum(w) / w.sum() * n_reads).astype(np.int64)]) * rec
+    cuts[-1] = d.numel()
+    slices = [d[int(cuts[i]):int(cuts[i + 1])] for i in range(ranks)]
+    out = str(tmp_path / "node")
+    prof = count.count_node(cfg, slices, out, devices=[0] * ranks, host_threads=4, batch_bases=batch)
+    _assert_same_dirs(str(tmp_path / "one"), out)
+    assert prof["n_distinct"] == info.n_distinct and prof["n_instances"] == info.n_instances
+    if batch < 10**9:
+        assert prof["n_batches"] >= 4
+        assert (prof["n_host_runs"] > 0 and prof["host_run_bytes"] > 0) if budget == 1 else prof["n_host_runs"] == 0
+    else:
+        assert prof["n_batches"] == 1 and prof["n_host_runs"] == 0

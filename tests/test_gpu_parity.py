@@ -1236,3 +1236,99 @@ def test_bitmap_count_and_chunk_local_pass(ops, oracle_lib, torch_cuda, monkeypa
             klo, khi, counts, _ = s.result_wide()
         whi, wlo, wcn, _ = oracle_lib.count_brute(stream, k, mode)
         assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+
+
+def _dir_bytes(path):
+    import os
+    return {n: open(os.path.join(path, n), "rb").read() for n in sorted(os.listdir(path))}
+
+
+@pytest.mark.parametrize("k,label_size,budget,chunk", [(21, 0, 1, 300_000), (21, 0, 400_000, 1 << 22), (51, 8, 1, 200_000),
+                                                       (51, 0, 1 << 40, 150_000), (31, 0, 1, 0)])
+def test_run_store_spills_and_merges_once(ops, oracle_lib, torch_cuda, tmp_path, k, label_size, budget, chunk):
+    """mgc_runs_*: seven runs (the (k-mer, count) results of seven slices of a read set, one of them empty, one tiny) parked
+    with a device budget of 1 byte (every run in pinned host DRAM), a budget that holds some of them, or no limit; merged once
+    into a database stream in chunks of a few thousand entries (MGC_OOC_CHUNK-sized buffers: dozens of chunks, two- and
+    three-level merge trees, odd pieces copied along): the 129 files must equal the database of ONE count of all reads."""
+    from meryl_amd import capi, db
+    bases = oracle_lib.synth_reads(77, 60_000, 0, 6000).tobytes().decode()
+    reads = [r for r in bases.split(".") if r]
+    cfg = capi.configure(k, len(bases), 1 << 30, label_size=label_size, label=0x5A if label_size else 0)
+    cfg.use_simple = 0
+    want = str(tmp_path / "want.meryl")
+    with ops.Session(cfg) as s:
+        s.push_bases(bases, end_of_sequence=False)
+        s.count()
+        db.write_database(s, want, host_threads=4)
+        n_want = s.info().n_distinct
+    cuts = [0, 900, 900, 2500, 2503, 4000, 5200, len(reads)]
+    runs = ops.Runs(k, cfg.w_prefix, device_budget=budget, chunk_bytes=chunk)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        with ops.Session(cfg) as s:
+            s.push_bases(".".join(reads[a:b]) + ("." if b > a else ""), end_of_sequence=False)
+            s.count()
+            keys, cnts = s.result_device()
+        runs.add(keys, cnts)
+    got = str(tmp_path / "got.meryl")
+    st = ops.DbStream(got, k, cfg.w_prefix, label_size, 0x5A if label_size else 0, host_threads=4)
+    half = cfg.n_prefix // 2                                 # two calls: a store serves prefix ranges (the owner side of a sharded count)
+    runs.write(st, 0, half)
+    runs.write(st, half, cfg.n_prefix)
+    st.close()
+    p = runs.profile()
+    runs.close()
+    assert p["n_runs"] == 6 and p["n_merged"] == n_want       # the empty slice makes no run
+    assert (p["n_host_runs"] == 6) if budget == 1 else (p["n_host_runs"] == 0 if budget >= (1 << 40) else 0 < p["n_host_runs"] < 6)
+    assert chunk == 0 or p["n_chunks"] > 8
+    assert _dir_bytes(got) == _dir_bytes(want)
+
+
+@pytest.mark.parametrize("k,compress,label_size", [(21, 0, 0), (51, 0, 8), (31, 1, 0)])
+def test_out_of_core_result_larger_than_the_budget_streams_from_host_runs(ops, oracle_lib, torch_cuda, tmp_path, monkeypatch, k, compress, label_size):
+    """A count whose batch results do not fit the result budget (forced: one byte): every batch result is parked in pinned host
+    DRAM, the session's result is OUT OF CORE, and both consumers merge the runs chunk by chunk -- mgc_write_database gives the
+    single-pass database byte for byte, mgc_finish hands the callbacks the oracle's blocks, the whole-result calls refuse."""
+    from meryl_amd import capi, db
+    monkeypatch.setenv("MGC_OOC_CHUNK", "400000")
+    bases = oracle_lib.synth_reads(41, 200_000, 0, 30_000, 150, 5000, 100)           # 4.5 Mbp
+    raw = bases.tobytes()
+    cfg = capi.configure(k, bases.size, 1 << 30, homopoly_compress=compress, label_size=label_size, label=0xA5 if label_size else 0)
+    cfg.use_simple = 0
+    want = str(tmp_path / "want.meryl")
+    with ops.Session(cfg) as s:
+        s.push_bases(raw, end_of_sequence=False)
+        s.count()
+        assert not s.out_of_core()
+        db.write_database(s, want, host_threads=4)
+        wlo, whi, wcn, wbs = s.result_wide()
+        want_info = s.info()
+    got = str(tmp_path / "got.meryl")
+    with ops.Session(cfg) as s:
+        s.set_batch_bases(700_000)
+        s.set_result_budget(1)
+        for i in range(0, len(raw), 333_337):
+            s.push_bases(raw[i:i + 333_337], end_of_sequence=False)
+        s.count()
+        assert s.out_of_core() and s.profile().n_batches >= 5
+        with pytest.raises(capi.MgcError) as e:
+            s.result_wide()
+        assert e.value.code == capi.ESTATE
+        info = s.info()
+        assert info.n_instances == want_info.n_instances and list(info.file_instances) == list(want_info.file_instances)
+        db.write_database(s, got, host_threads=4)
+        assert s.info().n_distinct == want_info.n_distinct        # known once the runs have been merged
+        rp = s.runs_profile()
+        assert rp["n_host_runs"] == rp["n_runs"] >= 5 and rp["n_chunks"] > 4 and rp["host_bytes"] > 0
+        blocks = {}
+        def cb(prefix, n, slo, cnt, shi):
+            assert prefix not in blocks
+            blocks[prefix] = (slo, shi, cnt)
+        s.finish(cb, host_threads=3)                               # a second delivery: the runs are still there
+    assert _dir_bytes(got) == _dir_bytes(want)
+    assert sorted(blocks) == list(range(cfg.n_prefix))
+    mask_lo = (1 << min(cfg.w_data, 64)) - 1
+    for p in (0, 1, cfg.n_prefix // 3, cfg.n_prefix - 1):
+        a, b = int(wbs[p]), int(wbs[p + 1])
+        slo, shi, cnt = blocks[p]
+        assert np.array_equal(slo, wlo[a:b] & np.uint64(mask_lo)) and np.array_equal(cnt, wcn[a:b])
+    assert sum(len(v[2]) for v in blocks.values()) == want_info.n_distinct
