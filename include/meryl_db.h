@@ -164,6 +164,7 @@ const char *mgc_db_stream_error(const mgc_db_stream *d);      /* d may be NULL: 
  * have been encoded and copied out of their device buffers, which may be reused; the file writes of the copied pieces may
  * still be running. */
 uint64_t mgc_db_stream_queued(mgc_db_stream *d);
+uint64_t mgc_db_stream_done(mgc_db_stream *d);      /* ranges 1 .. this have left their device buffers */
 int  mgc_db_stream_wait_buffers(mgc_db_stream *d, uint64_t upto);
 
 /* ------------------------------------------------------------------------

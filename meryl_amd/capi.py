@@ -32,7 +32,7 @@ SYMBOLS = (
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_read_file_ex",
     "mdb_reader_file_index", "mdb_reader_block_header", "mdb_reader_read_block_raw", "mdb_reader_close",
     "mdb_free", "mgc_write_database", "mgc_write_database_profiled",
-    "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_stream_queued", "mgc_db_stream_wait_buffers",
+    "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_stream_queued", "mgc_db_stream_done", "mgc_db_stream_wait_buffers",
     "mgc_runs_open", "mgc_runs_add", "mgc_runs_write", "mgc_runs_get_profile", "mgc_runs_error", "mgc_runs_close", "mgc_get_runs_profile", "mgc_db_merge", "mgc_count_node", "mgc_count_node_batched", "mgc_count_node_staged", "mgc_node_plan",
     # include/meryl_lookup.h
     "mgc_lookup_load", "mgc_lookup_estimate", "mgc_lookup_from_device", "mgc_lookup_free", "mgc_lookup_get_info", "mgc_lookup_error",
@@ -290,6 +290,7 @@ def lib():
     sig("mgc_runs_error", ctypes.c_char_p, vp)
     sig("mgc_runs_close", None, vp)
     sig("mgc_db_stream_queued", u64, vp)
+    sig("mgc_db_stream_done", u64, vp)
     sig("mgc_db_stream_wait_buffers", i32, vp, u64)
     sig("mgc_reserve_text", i32, vp, u64)
     sig("mgc_begin_text", i32, vp, i32)

@@ -390,9 +390,14 @@ class DbStream:
         hold exactly the distinct k-mers of that range, `counts` (int32[n]) their counts.  Asynchronous: the tensors are
         kept alive here until sync()/close()."""
         torch.cuda.current_stream(keys.device).synchronize()       # the stream's own HIP streams read them
-        self._keep.append((keys, counts))
         self._check(capi.lib().mgc_db_stream_write(self._h, _ptr(keys), _ptr(counts), keys.shape[0], int(prefix_begin),
                                                    int(prefix_end)), "mgc_db_stream_write")
+        self._keep.append((int(capi.lib().mgc_db_stream_queued(self._h)), keys, counts))
+
+    def release_done(self):
+        """drops the tensors of the ranges that have been encoded and copied out (no waiting)"""
+        done = int(capi.lib().mgc_db_stream_done(self._h))
+        self._keep = [e for e in self._keep if e[0] > done]
 
     def sync(self):
         self._check(capi.lib().mgc_db_stream_sync(self._h), "mgc_db_stream_sync")
@@ -571,6 +576,23 @@ class HipOps:
         """where the owned (k-mer, count) ranges of a sharded count go: a device-encoding database stream"""
         return DbStream(path, k, w_prefix, label_size, label, part, n_parts, host_threads)
 
+    @staticmethod
+    def histogram(bases, k, mode, bucket_bits):
+        """k-mers per bucket of a base stream (uint64[2^bucket_bits] on the host): the routing plan's input"""
+        L = capi.lib()
+        nb = 1 << bucket_bits
+        ws_bytes = L.mgc_dev_partition_workspace_bytes(bucket_bits)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=bases.device)
+        counts = _u64(nb, bases.device)
+        capi.check(L.mgc_dev_kmer_histogram(_ptr(bases), bases.numel(), k, mode, bucket_bits, _ptr(counts), _ptr(ws), ws_bytes,
+                                            _stream_ptr()), "mgc_dev_kmer_histogram")
+        return counts.cpu().numpy().astype(np.uint64)
+
+    @staticmethod
+    def open_runs(k, w_prefix, device_budget):
+        """where the counted waves of a BATCHED sharded count wait for the last batch: a run store (HBM, then pinned host DRAM)"""
+        return Runs(k, w_prefix, device_budget=device_budget)
+
 
 def shard_bucket_bits(world, k, n_bases_local=0, w_prefix=None):
     """Top bits of the k-mer that route it in a `world`-rank count: 6 (the files) + ceil(log2(world)), one more for every
@@ -586,7 +608,22 @@ def shard_bucket_bits(world, k, n_bases_local=0, w_prefix=None):
     return bits
 
 
-def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db=None, keep_result=True):
+def batch_slices(n, n_batches, k):
+    """[(begin, end)] of the n_batches slices a base stream of n bytes is counted in: slice b = [cut_b - (k-1), cut_{b+1}) -- a
+    window that starts in the last k-1 bases of slice b-1 is incomplete there and complete here, so the cuts may fall anywhere
+    (also inside a read) and no k-mer is lost or counted twice (mgc_node.cpp:batch_range)."""
+    out = []
+    for b in range(n_batches):
+        cut, end = n * b // n_batches, n * (b + 1) // n_batches
+        a = cut - (k - 1) if (b and cut >= k - 1) else 0
+        if b and cut < k - 1 and end < k:
+            end = a
+        out.append((a, end))
+    return out
+
+
+def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db=None, keep_result=True, batch_bases=None,
+                  runs_budget=None):
     """Collective.  Every rank passes ITS OWN reads (uint8 tensor on its GPU);
     returns this rank's share of the database: (unique keys, counts int32,
     (first_bucket, end_bucket, bucket_bits)).  The concatenation over ranks, in rank order, is
@@ -607,13 +644,21 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
     the product sink encodes the blocks on the device); after a barrier rank 0 stitches the parts (mdb_merge_parts): the
     64+64+1 files are byte-identical to a single-GPU count of all reads.  A rank range may begin or end inside a file --
     the cut is between two blocks, which is why the routing granularity never exceeds w_prefix bits.
-    keep_result=False drops the per-wave tensors once written (the return value then holds empty tensors)."""
+    keep_result=False drops the per-wave tensors once written (the return value then holds empty tensors).
+
+    batch_bases (with db): the reads of every rank are counted in BATCHES of at most that many bases (the sharded form of
+    writeBatch's spill, merylOp-countThreads.C:323-379) so that a rank never holds the k-mers of all its reads: the routing
+    plan comes from one histogram of all reads; per batch every rank partitions the next slice of its stream (batch_slices:
+    k-1 overlap), the waves are exchanged and counted as before, and every counted wave is parked in the owner's run store
+    (ops.open_runs: HBM within runs_budget bytes, pinned host DRAM beyond); after the last batch every owner merges its runs
+    once into its part.  The database does not depend on the batching."""
     import torch.distributed as dist
     import time as _time
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     prof = os.environ.get("MGC_SHARD_PROFILE") == "1" and torch is not None and bases.is_cuda
     marks = []
+    stage_s = {}
 
     def mark(name):
         if prof:
@@ -623,100 +668,146 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
     mark("start")
     nb_local = torch.tensor([int(bases.numel())], dtype=torch.int64, device=bases.device)
     dist.all_reduce(nb_local, op=dist.ReduceOp.MAX, group=group)                 # every rank must pick the same granularity
-    bits = shard_bucket_bits(world, k, int(nb_local.item()), db["w_prefix"] if db else None)
+    max_local = int(nb_local.item())
+    bits = shard_bucket_bits(world, k, max_local, db["w_prefix"] if db else None)
     nbk = 1 << bits
-    keys, local_counts = ops.partition(bases, k, mode, bits)                     # grouped by bucket, ascending
-    mark("partition")
-    local_counts = np.asarray(local_counts).astype(np.int64)
-    # one small all-gather gives every rank the same [rank][file] histogram -> same cut points
-    fc = torch.from_numpy(local_counts).to(keys.device)
-    all_counts = [torch.empty_like(fc) for _ in range(world)]
-    dist.all_gather(all_counts, fc, group=group)
-    per_rank = torch.stack(all_counts).cpu().numpy()                             # [world][2^bits]
-    cuts = balanced_file_ranges(per_rank.sum(axis=0), world)
+    n_batches = 1
+    if batch_bases and db is not None:
+        n_batches = max(1, -(-max_local // int(batch_bases)))                   # the same on every rank
+    if n_batches > 1:
+        # the plan needs the histogram of ALL reads before the first batch is routed
+        full = np.asarray(ops.histogram(bases, k, mode, bits)).astype(np.int64)
+        fc = torch.from_numpy(full).to(bases.device)
+        allf = [torch.empty_like(fc) for _ in range(world)]
+        dist.all_gather(allf, fc, group=group)
+        cuts = balanced_file_ranges(torch.stack(allf).cpu().numpy().sum(axis=0), world)
+        slices = batch_slices(int(bases.numel()), n_batches, k)
+    else:
+        cuts = None
+        slices = [(0, int(bases.numel()))]
 
-    f0, f1 = cuts[rank], cuts[rank + 1]
     sink = None
-    if db is not None:
-        sink = ops.open_sink(db["path"], k, db["w_prefix"], db.get("label_size", 0), db.get("label", 0), rank, world,
-                             db.get("host_threads", 8))
-        blocks_per_bucket = 1 << (db["w_prefix"] - bits)
+    runs = None
     n_local_distinct = 0
-    file_total = per_rank[:, f0:f1].sum(axis=0)                                  # keys per owned file
-    file_off = np.concatenate([[0], np.cumsum(file_total)]).astype(np.int64)
-    inbox = ops.empty_keys(int(file_total.sum()), keys)
-
-    local_off = np.concatenate([[0], np.cumsum(local_counts)]).astype(np.int64)
-    mark("plan")
-
-    # The exchange runs in waves: wave i carries, for every rank, the pieces of the i-th group of `bpw` buckets of that
-    # rank's range.  While wave i is on the links the owner counts the buckets of wave i-1 (the same grouping passes +
-    # LDS finish a single-GPU count runs after its partition), so only the first wave is exposed.  Every rank
-    # derives the same wave plan and segment sizes from the gathered histogram: no further collective is needed.
-    # About 16 waves per rank: fewer would expose more of the exchange, more pay the per-call host overhead more often.
-    most = max(cuts[r + 1] - cuts[r] for r in range(world))
-    bpw = max(1, -(-most // 16))
-    n_waves = -(-most // bpw)
     parts = []
+    f0 = f1 = 0
+    for bi, (sa, sb) in enumerate(slices):
+        keys, local_counts = ops.partition(bases[sa:sb], k, mode, bits)              # grouped by bucket, ascending
+        mark("partition")
+        local_counts = np.asarray(local_counts).astype(np.int64)
+        # one small all-gather gives every rank the same [rank][file] histogram -> same cut points
+        fc = torch.from_numpy(local_counts).to(keys.device)
+        all_counts = [torch.empty_like(fc) for _ in range(world)]
+        dist.all_gather(all_counts, fc, group=group)
+        per_rank = torch.stack(all_counts).cpu().numpy()                             # [world][2^bits]
+        if cuts is None:
+            cuts = balanced_file_ranges(per_rank.sum(axis=0), world)
 
-    def post(i):
-        sends, recvs = [], []
-        longest = 0
-        for dst in range(world):
-            for f in range(cuts[dst] + i * bpw, min(cuts[dst + 1], cuts[dst] + (i + 1) * bpw)):
-                sends.append((dst, keys[int(local_off[f]):int(local_off[f + 1])]))
-                longest = max(longest, int(per_rank[:, f].max()))
-        for f in range(f0 + i * bpw, min(f1, f0 + (i + 1) * bpw)):
-            for src in range(world):
-                a = int(file_off[f - f0] + per_rank[:src, f].sum())
-                recvs.append((src, inbox[a:a + int(per_rank[src, f])]))
-        return exchange_segments(sends, recvs, keys.device, group, max_rows=longest, wait=False)
+        f0, f1 = cuts[rank], cuts[rank + 1]
+        if db is not None and sink is None:
+            sink = ops.open_sink(db["path"], k, db["w_prefix"], db.get("label_size", 0), db.get("label", 0), rank, world,
+                                 db.get("host_threads", 8))
+            blocks_per_bucket = 1 << (db["w_prefix"] - bits)
+            if n_batches > 1:
+                runs = ops.open_runs(k, db["w_prefix"], runs_budget if runs_budget is not None else 0xFFFFFFFFFFFFFFFF)
+        file_total = per_rank[:, f0:f1].sum(axis=0)                                  # keys per owned file
+        file_off = np.concatenate([[0], np.cumsum(file_total)]).astype(np.int64)
+        inbox = ops.empty_keys(int(file_total.sum()), keys)
 
-    def count_file(i):
-        nonlocal n_local_distinct
-        lo, hi = f0 + i * bpw, min(f1, f0 + (i + 1) * bpw)
-        if lo >= hi:
-            return
-        if file_total[lo - f0:hi - f0].sum() == 0:
-            if sink is not None:                          # the range still gets its (empty) blocks
-                e = ops.empty_keys(0, inbox)
-                sink.write(e, torch.empty(0, dtype=torch.int32, device=e.device), lo * blocks_per_bucket, hi * blocks_per_bucket)
-            return
-        bc = np.zeros(nbk, dtype=np.uint64)
-        bc[lo:hi] = file_total[lo - f0:hi - f0]
-        part = ops.count_files(inbox[int(file_off[lo - f0]):int(file_off[hi - f0])], bc, k, mode)
-        n_local_distinct += int(part[0].shape[0])
-        if sink is not None:
-            sink.write(part[0], part[1], lo * blocks_per_bucket, hi * blocks_per_bucket)
-        if keep_result or sink is None:
-            parts.append(part)
+        local_off = np.concatenate([[0], np.cumsum(local_counts)]).astype(np.int64)
+        mark("plan")
 
-    for i in range(n_waves + 1):
-        reqs = post(i) if i < n_waves else []
-        if i >= 1:
-            count_file(i - 1)
-        for r in reqs:
-            r.wait()
-    del keys
-    mark("exchange+count")
+        # The exchange runs in waves: wave i carries, for every rank, the pieces of the i-th group of `bpw` buckets of that
+        # rank's range.  While wave i is on the links the owner counts the buckets of wave i-1 (the same grouping passes +
+        # LDS finish a single-GPU count runs after its partition), so only the first wave is exposed.  Every rank
+        # derives the same wave plan and segment sizes from the gathered histogram: no further collective is needed.
+        # About 16 waves per rank: fewer would expose more of the exchange, more pay the per-call host overhead more often.
+        most = max(cuts[r + 1] - cuts[r] for r in range(world))
+        bpw = max(1, -(-most // 16))
+        n_waves = -(-most // bpw)
+
+        def post(i):
+            sends, recvs = [], []
+            longest = 0
+            for dst in range(world):
+                for f in range(cuts[dst] + i * bpw, min(cuts[dst + 1], cuts[dst] + (i + 1) * bpw)):
+                    sends.append((dst, keys[int(local_off[f]):int(local_off[f + 1])]))
+                    longest = max(longest, int(per_rank[:, f].max()))
+            for f in range(f0 + i * bpw, min(f1, f0 + (i + 1) * bpw)):
+                for src in range(world):
+                    a = int(file_off[f - f0] + per_rank[:src, f].sum())
+                    recvs.append((src, inbox[a:a + int(per_rank[src, f])]))
+            return exchange_segments(sends, recvs, keys.device, group, max_rows=longest, wait=False)
+
+        def count_file(i):
+            nonlocal n_local_distinct
+            lo, hi = f0 + i * bpw, min(f1, f0 + (i + 1) * bpw)
+            if lo >= hi:
+                return
+            if file_total[lo - f0:hi - f0].sum() == 0:
+                if sink is not None and runs is None:             # the range still gets its (empty) blocks
+                    e = ops.empty_keys(0, inbox)
+                    sink.write(e, torch.empty(0, dtype=torch.int32, device=e.device), lo * blocks_per_bucket, hi * blocks_per_bucket)
+                return
+            bc = np.zeros(nbk, dtype=np.uint64)
+            bc[lo:hi] = file_total[lo - f0:hi - f0]
+            part = ops.count_files(inbox[int(file_off[lo - f0]):int(file_off[hi - f0])], bc, k, mode)
+            if runs is not None:                                  # batched: parked (copied) until the last batch is counted
+                runs.add(part[0], part[1])
+                return
+            n_local_distinct += int(part[0].shape[0])
+            if sink is not None:
+                sink.write(part[0], part[1], lo * blocks_per_bucket, hi * blocks_per_bucket)
+                if not keep_result and hasattr(sink, "release_done"):
+                    sink.release_done()                               # the tensors of ranges that have left the device
+            if keep_result or sink is None:
+                parts.append(part)
+
+        t_first = _time.perf_counter()
+        for i in range(n_waves + 1):
+            reqs = post(i) if i < n_waves else []
+            if i >= 1:
+                count_file(i - 1)
+            for r in reqs:
+                r.wait()
+            if i == 0 and prof:
+                torch.cuda.synchronize()
+                stage_s["first_wave_exposed"] = stage_s.get("first_wave_exposed", 0.0) + _time.perf_counter() - t_first
+        del keys, inbox
+        mark("exchange+count")
+    if runs is not None:
+        runs.write(sink, f0 * blocks_per_bucket, f1 * blocks_per_bucket)
+        rp = runs.profile()
+        n_local_distinct = rp["n_merged"]
+        db["runs_profile"] = rp
+        runs.close()
+        mark("merge runs")
     if parts:
         uniq = torch.cat([p[0] for p in parts])
         cnts = torch.cat([p[1] for p in parts])
     else:
-        uniq = ops.empty_keys(0, inbox)
+        like = bases.new_empty(0, dtype=torch.int64)
+        uniq = like.view(0, 2) if k > 32 else like
         cnts = torch.empty(0, dtype=torch.int32, device=uniq.device)
     mark("concat")
     if sink is not None:
         db["profile"] = sink.close()                      # waits for this rank's files
         db["n_distinct_local"] = n_local_distinct
+        db["n_batches"] = n_batches
         if world > 1:
             dist.barrier(group=group)
+            t_st = _time.perf_counter()
             if rank == 0:
                 from . import db as _db
                 _db.merge_parts(db["path"], world)
             dist.barrier(group=group)
+            stage_s["stitch"] = _time.perf_counter() - t_st
         mark("database")
-    if prof and rank == 0:
-        print("[shard profile] " + "  ".join("%s %.1f ms" % (n, (t - marks[i][1]) * 1e3) for i, (n, t) in enumerate(marks[1:])),
-              file=sys.stderr, flush=True)
+    if prof:
+        for i, (n, t) in enumerate(marks[1:]):
+            stage_s[n] = stage_s.get(n, 0.0) + (t - marks[i][1])
+        if db is not None:
+            db["stage_s"] = stage_s
+        if rank == 0:
+            print("[shard profile] " + "  ".join("%s %.1f ms" % (n, v * 1e3) for n, v in stage_s.items()), file=sys.stderr, flush=True)
     return uniq, cnts, (f0, f1, bits)

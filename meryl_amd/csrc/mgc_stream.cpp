@@ -390,6 +390,12 @@ extern "C" uint64_t mgc_db_stream_queued(mgc_db_stream *d) {
   return d->jobs_queued;
 }
 
+extern "C" uint64_t mgc_db_stream_done(mgc_db_stream *d) {
+  if (!d) return 0;
+  std::lock_guard<std::mutex> g(d->mu);
+  return d->jobs_done;
+}
+
 extern "C" int mgc_db_stream_wait_buffers(mgc_db_stream *d, uint64_t upto) {
   if (!d) return MGC_EINVAL;
   std::unique_lock<std::mutex> lk(d->mu);

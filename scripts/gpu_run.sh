@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call, parameterised (replaces the per-experiment scripts of round 2):
 #   TAG=r03a TESTS="tests/test_gpu_parity.py -k bitmap" BENCH="default:;nobitmap:MGC_FINISH_BITMAP=0" bash scripts/gpu_run.sh
-#   TESTS   pytest arguments (empty: no tests);  BENCH  ';'-separated  name:ENV=VAL,ENV=VAL  bench.py variants
+#   TESTS   pytest arguments (empty: no tests), TESTS_K its -k expression;  BENCH  ';'-separated  name:ENV=VAL,ENV=VAL  bench.py variants
 #   BENCH_ARGS  bench.py flags of the variants (default: --steps 5 --warmup 1 --no-cpu-baseline --no-e2e)
 #   PROF=1  rocprofv3 --kernel-trace --stats of the default bench;  EXTRA  a shell command run at the end
 # Everything is wrapped in `timeout` so a wedged kernel cannot hold the box.  Output: gpurun_out/$TAG/
@@ -14,7 +14,7 @@ export TMPDIR=/tmp
 (rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -4; nproc; free -g | head -2) > $OUT/env.log 2>&1
 if [ -n "${TESTS:-}" ]; then
   echo "== pytest $TESTS"
-  timeout ${TEST_TIMEOUT:-900} python -m pytest $TESTS -m gpu -x -q -p no:cacheprovider > $OUT/pytest.log 2>&1
+  timeout ${TEST_TIMEOUT:-900} python -m pytest $TESTS ${TESTS_K:+-k "$TESTS_K"} -m gpu ${TEST_X--x} -q -p no:cacheprovider > $OUT/pytest.log 2>&1
   echo "pytest exit $?" | tee -a $OUT/pytest.log
   tail -${TEST_TAIL:-15} $OUT/pytest.log
 fi

@@ -47,6 +47,34 @@ class HostSink:
         return {}
 
 
+class HostRuns:
+    """stand-in for the run store (mgc_runs_*): parked (k-mer, count) runs, merged once into the sink by prefix range"""
+
+    def __init__(self, k, w_prefix, device_budget):
+        self.k, self.wp, self.runs, self.merged = k, w_prefix, [], 0
+
+    def add(self, keys, counts):
+        self.runs.append((keys.numpy().view(np.uint64).copy(), counts.numpy().view(np.uint32).astype(np.uint64)))
+
+    def write(self, sink, pb, pe):
+        import torch
+        allk = np.concatenate([r[0] for r in self.runs]) if self.runs else np.zeros(0, np.uint64)
+        allc = np.concatenate([r[1] for r in self.runs]) if self.runs else np.zeros(0, np.uint64)
+        u, inv = np.unique(allk, return_inverse=True)
+        c = np.zeros(u.size, dtype=np.uint64)
+        np.add.at(c, inv, allc)
+        pref = (u >> np.uint64(2 * self.k - self.wp)).astype(np.int64)
+        m = (pref >= pb) & (pref < pe)
+        self.merged += int(m.sum())
+        sink.write(torch.from_numpy(u[m].view(np.int64).copy()), torch.from_numpy((c[m] & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32).copy()), pb, pe)
+
+    def profile(self):
+        return {"n_merged": self.merged, "n_runs": len(self.runs)}
+
+    def close(self):
+        pass
+
+
 def _cpu_ops(oracle):
     import torch
 
@@ -69,12 +97,18 @@ def _cpu_ops(oracle):
         def empty_keys(n, like):
             return torch.empty(int(n), dtype=torch.int64)
 
+        @staticmethod
+        def histogram(bases, k_, mode, bucket_bits):
+            _, lo = oracle.enumerate_kmers(bases.numpy().tobytes(), k_, mode)
+            return np.bincount((lo >> np.uint64(2 * k_ - bucket_bits)).astype(np.int64), minlength=1 << bucket_bits).astype(np.uint64)
+
         open_sink = HostSink
+        open_runs = HostRuns
 
     return CpuOps
 
 
-def _worker(rank, world, port, k, wp, path, label_size, label):
+def _worker(rank, world, port, k, wp, path, label_size, label, batch_bases=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -86,20 +120,25 @@ def _worker(rank, world, port, k, wp, path, label_size, label):
     try:
         bases = oracle.synth_reads(7, 20000, rank * 250, 250, 100, 5000, 100)
         db = dict(path=path, w_prefix=wp, label_size=label_size, label=label)
-        count.count_sharded(torch.from_numpy(bases), k, 0, ops=_cpu_ops(oracle), db=db, keep_result=(rank % 2 == 0))
+        count.count_sharded(torch.from_numpy(bases), k, 0, ops=_cpu_ops(oracle), db=db, keep_result=(rank % 2 == 0), batch_bases=batch_bases)
+        if batch_bases:
+            assert db["n_batches"] >= 3
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k,wp,label_size", [(2, 21, 10, 0), (3, 16, 8, 0), (2, 31, 12, 5), (3, 21, 6, 0)])
-def test_sharded_count_writes_identical_database(tmp_path, oracle_lib, native_lib, world, k, wp, label_size):
+@pytest.mark.parametrize("world,k,wp,label_size,batch", [(2, 21, 10, 0, None), (3, 16, 8, 0, None), (2, 31, 12, 5, None), (3, 21, 6, 0, None),
+                                                         (2, 21, 10, 0, 7000), (3, 31, 12, 5, 9001)])
+def test_sharded_count_writes_identical_database(tmp_path, oracle_lib, native_lib, world, k, wp, label_size, batch):
     import torch.multiprocessing as mp
     from meryl_amd import db
     label = 0x13
     path = str(tmp_path / "sharded")
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, k, wp, path, label_size, label)) for r in range(world)]
+    # batch: every rank's reads (25,250 bases) go through the exchange in slices of that many bases cut anywhere (k-1 overlap);
+    # the counted waves wait in the owner's run store and are merged once -- same 129 files
+    procs = [ctx.Process(target=_worker, args=(r, world, port, k, wp, path, label_size, label, batch)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -1279,7 +1279,7 @@ def test_run_store_spills_and_merges_once(ops, oracle_lib, torch_cuda, tmp_path,
     runs.close()
     assert p["n_runs"] == 6 and p["n_merged"] == n_want       # the empty slice makes no run
     assert (p["n_host_runs"] == 6) if budget == 1 else (p["n_host_runs"] == 0 if budget >= (1 << 40) else 0 < p["n_host_runs"] < 6)
-    assert chunk == 0 or p["n_chunks"] > 8
+    assert chunk == 0 or p["n_chunks"] >= (8 if chunk < (1 << 20) else 2)
     assert _dir_bytes(got) == _dir_bytes(want)
 
 
