@@ -245,6 +245,13 @@ int mgc_end_text(mgc_session *s);
 /* One whole UNCOMPRESSED FASTA/FASTQ file (format 0 = tell from the first record): begin + push + end in one call, the
  * file read by `reader_threads` threads (0 = default) straight into pinned upload buffers.  Return codes as mgc_end_text. */
 int mgc_push_text_file(mgc_session *s, const char *path, int format, int reader_threads);
+/* A byte window [begin, end) of such a file -- begin at a record start (mgc_text_record_start), end = where the next reader
+ * begins (or anything >= the file size): the ranks of a node count read disjoint windows of the input, each through its
+ * own device's link.  mgc_text_record_start: the first record start at or after `offset` (FASTA: a line starting with
+ * '>'; FASTQ: a line starting with '@' whose next-but-one line starts with '+'); the file size when there is none;
+ * format 0 = sniff.  Host I/O only, no device. */
+int mgc_push_text_file_range(mgc_session *s, const char *path, int format, int reader_threads, uint64_t begin, uint64_t end);
+int mgc_text_record_start(const char *path, int format, uint64_t offset, uint64_t *start);
 
 /* Bases already resident in HBM (breakers included).  The buffer is borrowed
  * until mgc_count returns.  May be called once per session. */

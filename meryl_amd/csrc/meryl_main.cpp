@@ -14,6 +14,8 @@
 #include "../../include/meryl_gpu_count.h"
 #include "../../include/meryl_seq.h"
 
+#include <hip/hip_runtime_api.h>
+
 #include <algorithm>
 #include <cinttypes>
 #include <cstdio>
@@ -174,6 +176,180 @@ void print_configuration(const Globals &g, const Operation &op, uint64_t exp_num
   fprintf(stderr, "\n%s\n\n", line);
 }
 
+// one input of a count, or a byte window of it (a plain-text file read by one rank of a node count)
+struct InputPiece { std::string name; uint64_t begin, end; };
+
+// Input: the file's raw text goes to the device and is parsed there (mgc_push_text*); files the device parser refuses
+// (multi-line FASTQ ...), SAM/BAM and MERYL_HOST_PARSER=1 take the host state machine of meryl_seq.cpp.  Returns the
+// bytes / bases taken in (reported with -V -V).
+uint64_t load_inputs(mgc_session *s, const std::vector<InputPiece> &pieces, int reader_threads) {
+  const uint64_t buf_max = 2 * 1024 * 1024;                                                            // merylOp-countThreads.C:413
+  std::vector<char> buf(buf_max);
+  uint64_t total_bases = 0;
+  const bool host_parser = getenv("MERYL_HOST_PARSER") && getenv("MERYL_HOST_PARSER")[0] == '1';
+  auto load_on_host = [&](const std::string &name) {
+    msr_reader *r = msr_open(name.c_str());
+    if (!r) die("ERROR: %s", msr_last_error());
+    for (;;) {                                                                                         // loader loop, :173-203
+      uint64_t len = 0;                                                                                // 2 MiB of sequences, '.' after each
+      const int rc = msr_load_stream(r, buf.data(), buf_max, &len);
+      if (rc < 0) die("ERROR: %s", msr_last_error());
+      if (rc == 0) break;
+      if (mgc_push_bases(s, buf.data(), len, 0) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+      total_bases += len;
+    }
+    mgc_push_bases(s, nullptr, 0, 1);                                                                  // end-of-file breaker, :196
+    msr_close(r);
+  };
+  std::vector<char> text(host_parser ? 0 : (16u << 20));
+  for (const InputPiece &pc : pieces) {
+    const std::string &name = pc.name;
+    const bool whole = pc.begin == 0 && pc.end == ~0ull;
+    if (host_parser && whole) { load_on_host(name); continue; }
+    msr_reader *r = msr_open(name.c_str());
+    if (!r) die("ERROR: %s", msr_last_error());
+    if (msr_format(r) != MSR_FORMAT_FASTX) { msr_close(r); load_on_host(name); continue; }   // SAM/BAM records are decoded on the host
+    if (name != "-" && !has_compressed_suffix(name)) {
+      // plain text: the library reads the file itself, several threads straight into its pinned upload buffers
+      msr_close(r);
+      const int rc = whole ? mgc_push_text_file(s, name.c_str(), 0, reader_threads)
+                           : mgc_push_text_file_range(s, name.c_str(), 0, reader_threads, pc.begin, pc.end);
+      if (rc == MGC_EFORMAT && whole) load_on_host(name);
+      else if (rc == MGC_EFORMAT) die("ERROR: '%s' is not strict four-line FASTQ / FASTA: it cannot be read in windows by several ranks (gpus=1 reads it)", name.c_str());
+      else if (rc != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+      struct stat fst;
+      if (whole) { if (stat(name.c_str(), &fst) == 0) total_bases += (uint64_t)fst.st_size; }
+      else total_bases += pc.end - pc.begin;
+      continue;
+    }
+    bool begun = false, refused = false;
+    for (;;) {
+      const int64_t got = msr_read_text(r, text.data(), text.size());
+      if (got < 0) die("ERROR: %s", msr_last_error());
+      if (got == 0) break;
+      if (!begun) {
+        int64_t p = 0;
+        while (p < got && (text[p] == '\n' || text[p] == '\r' || text[p] == ' ' || text[p] == '\t')) p++;
+        const char c = p < got ? text[p] : '>';
+        if (c != '>' && c != '@') {
+          fprintf(stderr, "ERROR: '%s' is neither FASTA nor FASTQ (record starts with '%c')\n", name.c_str(), c);
+          exit(1);
+        }
+        if (mgc_begin_text(s, c == '@' ? MGC_TEXT_FASTQ : MGC_TEXT_FASTA) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+        begun = true;
+      }
+      if (mgc_push_text(s, text.data(), (size_t)got) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+      total_bases += (uint64_t)got;                                                                    // text bytes (reported with -V -V)
+    }
+    msr_close(r);
+    if (begun) {
+      const int rc = mgc_end_text(s);
+      if (rc == MGC_EFORMAT) refused = true;
+      else if (rc != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+    }
+    if (refused) load_on_host(name);
+  }
+  return total_bases;
+}
+
+// gpus=N: ONE count spread over the node's devices (this build only; the reference's node-scale recipe is "count pieces,
+// then union-sum", src/meryl/merylOp-count.C:251-268).  Every rank READS ITS OWN share of the input through its own
+// device's link -- plain-text files are cut into byte windows at record boundaries (mgc_text_record_start), inputs that
+// cannot be cut (compressed, SAM/BAM, stdin) go whole to one rank each -- and stages it on its device; then
+// mgc_count_node_batched: routing plan, per-batch partition / pulls / owner count, parked waves, one merge per owner,
+// parts stitched into the 64-file directory.
+int run_count_node(const Globals &g, const Operation &op, const mgc_count_config &cfg) {
+  if (cfg.count_suffix_length) die("ERROR: %s", "count-suffix= and gpus= cannot be combined.");
+  const uint32_t N = g.gpus;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) die("ERROR: %s", "no HIP device.");
+  const auto t_start = std::chrono::steady_clock::now();
+  // the share of every rank: windows of the plain-text files by bytes, the other inputs round-robin
+  std::vector<std::vector<InputPiece>> share(N);
+  std::vector<std::pair<std::string, uint64_t>> plain;
+  uint64_t plain_total = 0;
+  uint32_t rr = 0;
+  for (const std::string &name : op.seq_inputs) {
+    struct stat fst;
+    bool cut = false;
+    if (name != "-" && !has_compressed_suffix(name) && stat(name.c_str(), &fst) == 0 && S_ISREG(fst.st_mode) &&
+        !(getenv("MERYL_HOST_PARSER") && getenv("MERYL_HOST_PARSER")[0] == '1')) {
+      msr_reader *r = msr_open(name.c_str());
+      if (!r) die("ERROR: %s", msr_last_error());
+      cut = msr_format(r) == MSR_FORMAT_FASTX;
+      msr_close(r);
+    }
+    if (cut) { plain.emplace_back(name, (uint64_t)fst.st_size); plain_total += (uint64_t)fst.st_size; }
+    else share[rr++ % N].push_back(InputPiece{name, 0, ~0ull});
+  }
+  {
+    uint64_t file_base = 0;                                   // position of the file in the concatenation of the plain files
+    for (const auto &pf : plain) {
+      const uint64_t size = pf.second;
+      uint64_t prev = 0;
+      for (uint32_t r = 0; r < N; r++) {
+        // the rank's window of the concatenation, clipped to this file, moved up to the next record start
+        const uint64_t hi_cat = (r + 1 == N) ? plain_total : (uint64_t)((unsigned __int128)plain_total * (r + 1) / N);
+        uint64_t hi = hi_cat <= file_base ? 0 : std::min<uint64_t>(size, hi_cat - file_base);
+        if (hi > 0 && hi < size && mgc_text_record_start(pf.first.c_str(), 0, hi, &hi) != MGC_OK) die("ERROR: %s", mgc_last_error(nullptr));
+        if (hi < prev) hi = prev;
+        if (hi > prev) share[r].push_back(InputPiece{pf.first, prev, hi});
+        prev = hi;
+      }
+      file_base += size;
+    }
+  }
+  std::vector<mgc_session *> sess(N, nullptr);
+  std::vector<int> dev(N, 0);
+  std::vector<uint64_t> taken(N, 0);
+  const int readers = (int)std::max<uint32_t>(2, std::min<uint32_t>(g.threads, 16) / N);
+  for (uint32_t r = 0; r < N; r++) {
+    dev[r] = (int)(r % (uint32_t)ndev);
+    mgc_count_config rc = cfg;
+    rc.homopoly_compress = 0;                                 // the node count compresses every rank's stream itself
+    sess[r] = mgc_open(&rc, dev[r]);
+    if (!sess[r]) die("ERROR: %s", mgc_last_error(nullptr));
+    mgc_set_batch_bases(sess[r], ~0ull >> 2);                // a rank's share is staged whole; the node count batches the counting
+  }
+  {
+    std::vector<std::thread> th;
+    for (uint32_t r = 0; r < N; r++) th.emplace_back([&, r] { taken[r] = load_inputs(sess[r], share[r], readers); });
+    for (auto &t : th) t.join();
+  }
+  std::vector<const uint8_t *> ptr(N, nullptr);
+  std::vector<uint64_t> len(N, 0);
+  uint64_t total_bases = 0;
+  for (uint32_t r = 0; r < N; r++) {
+    if (mgc_staged_bases(sess[r], &ptr[r], &len[r]) != MGC_OK) die("ERROR: %s", mgc_last_error(sess[r]));
+    total_bases += taken[r];
+  }
+  const auto t_loaded = std::chrono::steady_clock::now();
+  if (g.verbosity > 0)
+    fprintf(stderr, "\nInput complete.  Counting on %u ranks and writing results to '%s', using %u thread%s.\n",
+            N, op.output.c_str(), g.threads, (g.threads == 1) ? "" : "s");
+  uint64_t batch = 0;
+  if (getenv("MERYL_BATCH_BASES") && *getenv("MERYL_BATCH_BASES")) batch = strtoull(getenv("MERYL_BATCH_BASES"), nullptr, 10);
+  mgc_node_profile np;
+  if (mgc_count_node_batched(&cfg, N, dev.data(), ptr.data(), len.data(), batch, op.output.c_str(), (int)g.threads, &np) != MGC_OK)
+    die("ERROR: %s", mgc_last_error(nullptr));
+  const auto t_done = std::chrono::steady_clock::now();
+  if (g.verbosity > 2)
+    fprintf(stderr, "\nTIMING  read+parse+stage=%.3f s (every rank its own share)   node count+write=%.3f s   (ranks=%u, routing bits=%u, "
+                    "batches=%u, partition=%.3f s, exchange+count=%.3f s, merge of parked waves=%.3f s, files=%.3f s, stitch=%.3f s, "
+                    "database_bytes=%" PRIu64 ")\n",
+            std::chrono::duration<double>(t_loaded - t_start).count(), std::chrono::duration<double>(t_done - t_loaded).count(),
+            np.n_ranks, np.bucket_bits, np.n_batches, np.partition_s, np.exchange_count_s, np.merge_runs_s, np.close_s, np.merge_parts_s,
+            np.data_bytes);
+  for (mgc_session *q : sess) mgc_close(q);
+  if (g.verbosity > 0) {
+    fprintf(stderr, "\nFinished counting.\n");
+    if (g.verbosity > 2)
+      fprintf(stderr, "  %" PRIu64 " bases, %" PRIu64 " k-mer instances, %" PRIu64 " distinct k-mers, prefix bits %u.\n",
+              total_bases, np.n_instances, np.n_distinct, cfg.w_prefix);
+  }
+  return 0;
+}
+
 int run_count(const Globals &g, const Operation &op) {
   if (g.k == 0) die("ERROR: Kmer size not supplied with modifier k=<kmer-size>.");                    // merylOp-count.C:311-312
   if (op.output.empty() && !g.only_config) die("ERROR: No output specified for count operation.");     // :314-315
@@ -207,105 +383,24 @@ int run_count(const Globals &g, const Operation &op) {
   if (g.verbosity > 0)
     fprintf(stderr, "Start counting with %s method.\n", cfg.use_simple ? "SIMPLE" : "THREADED");     // merylOp-nextMer.C:205-209
 
+  if (g.gpus > 1) return run_count_node(g, op, cfg);
+
   mgc_session *s = mgc_open(&cfg, -1);
   if (!s) die("ERROR: %s", mgc_last_error(nullptr));
 
   if (getenv("MERYL_BATCH_BASES") && *getenv("MERYL_BATCH_BASES"))                                    // tests: force out-of-core batches
     mgc_set_batch_bases(s, strtoull(getenv("MERYL_BATCH_BASES"), nullptr, 10));
-  if (g.gpus > 1) {
-    if (cfg.count_suffix_length) die("ERROR: %s", "count-suffix= and gpus= cannot be combined.");
-    mgc_set_batch_bases(s, ~0ull >> 2);                       // the whole input is staged; the ranks do the counting
-  }
-  const uint64_t buf_max = 2 * 1024 * 1024;                                                            // merylOp-countThreads.C:413
-  std::vector<char> buf(buf_max);
   uint64_t total_bases = 0;
   const auto t_start = std::chrono::steady_clock::now();
-  // Input: the file's raw text goes to the device and is parsed there (mgc_push_text); files the device parser
-  // refuses (multi-line FASTQ ...) and MERYL_HOST_PARSER=1 take the host state machine of meryl_seq.cpp.
-  const bool host_parser = getenv("MERYL_HOST_PARSER") && getenv("MERYL_HOST_PARSER")[0] == '1';
   uint64_t text_total = 0;
   for (const std::string &name : op.seq_inputs) text_total += msr_guess_number_of_kmers(name.c_str());
+  const bool host_parser = getenv("MERYL_HOST_PARSER") && getenv("MERYL_HOST_PARSER")[0] == '1';
   if (!host_parser && text_total) (void)mgc_reserve_text(s, text_total);
-  auto load_on_host = [&](const std::string &name) {
-    msr_reader *r = msr_open(name.c_str());
-    if (!r) die("ERROR: %s", msr_last_error());
-    for (;;) {                                                                                         // loader loop, :173-203
-      uint64_t len = 0;                                                                                // 2 MiB of sequences, '.' after each
-      const int rc = msr_load_stream(r, buf.data(), buf_max, &len);
-      if (rc < 0) die("ERROR: %s", msr_last_error());
-      if (rc == 0) break;
-      if (mgc_push_bases(s, buf.data(), len, 0) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
-      total_bases += len;
-    }
-    mgc_push_bases(s, nullptr, 0, 1);                                                                  // end-of-file breaker, :196
-    msr_close(r);
-  };
-  std::vector<char> text(host_parser ? 0 : (16u << 20));
-  for (const std::string &name : op.seq_inputs) {
-    if (host_parser) { load_on_host(name); continue; }
-    msr_reader *r = msr_open(name.c_str());
-    if (!r) die("ERROR: %s", msr_last_error());
-    if (msr_format(r) != MSR_FORMAT_FASTX) { msr_close(r); load_on_host(name); continue; }   // SAM/BAM records are decoded on the host
-    if (name != "-" && !has_compressed_suffix(name)) {
-      // plain text: the library reads the file itself, several threads straight into its pinned upload buffers
-      msr_close(r);
-      const int rc = mgc_push_text_file(s, name.c_str(), 0, (int)std::min<uint32_t>(g.threads, 16));
-      if (rc == MGC_EFORMAT) load_on_host(name);
-      else if (rc != MGC_OK) die("ERROR: %s", mgc_last_error(s));
-      struct stat fst;
-      if (stat(name.c_str(), &fst) == 0) total_bases += (uint64_t)fst.st_size;
-      continue;
-    }
-    bool begun = false, refused = false;
-    for (;;) {
-      const int64_t got = msr_read_text(r, text.data(), text.size());
-      if (got < 0) die("ERROR: %s", msr_last_error());
-      if (got == 0) break;
-      if (!begun) {
-        int64_t p = 0;
-        while (p < got && (text[p] == '\n' || text[p] == '\r' || text[p] == ' ' || text[p] == '\t')) p++;
-        const char c = p < got ? text[p] : '>';
-        if (c != '>' && c != '@') {
-          fprintf(stderr, "ERROR: '%s' is neither FASTA nor FASTQ (record starts with '%c')\n", name.c_str(), c);
-          exit(1);
-        }
-        if (mgc_begin_text(s, c == '@' ? MGC_TEXT_FASTQ : MGC_TEXT_FASTA) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
-        begun = true;
-      }
-      if (mgc_push_text(s, text.data(), (size_t)got) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
-      total_bases += (uint64_t)got;                                                                    // text bytes (reported with -V -V)
-    }
-    msr_close(r);
-    if (begun) {
-      const int rc = mgc_end_text(s);
-      if (rc == MGC_EFORMAT) refused = true;
-      else if (rc != MGC_OK) die("ERROR: %s", mgc_last_error(s));
-    }
-    if (refused) load_on_host(name);
-  }
+  std::vector<InputPiece> pieces;
+  for (const std::string &name : op.seq_inputs) pieces.push_back(InputPiece{name, 0, ~0ull});
+  total_bases = load_inputs(s, pieces, (int)std::min<uint32_t>(g.threads, 16));
 
   const auto t_loaded = std::chrono::steady_clock::now();
-  if (g.gpus > 1) {                                           // one count over the node: k-mer ranges to ranks, one database
-    if (g.verbosity > 0)
-      fprintf(stderr, "\nInput complete.  Counting on %u ranks and writing results to '%s', using %u thread%s.\n",
-              g.gpus, op.output.c_str(), g.threads, (g.threads == 1) ? "" : "s");
-    mgc_node_profile np;
-    if (mgc_count_node_staged(s, g.gpus, nullptr, op.output.c_str(), (int)g.threads, &np) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
-    const auto t_done = std::chrono::steady_clock::now();
-    if (g.verbosity > 2)
-      fprintf(stderr, "\nTIMING  read+parse+stage=%.3f s   node count+write=%.3f s   (ranks=%u, routing bits=%u, partition=%.3f s, "
-                      "exchange+count=%.3f s, files=%.3f s, stitch=%.3f s, database_bytes=%" PRIu64 ")\n",
-              std::chrono::duration<double>(t_loaded - t_start).count(), std::chrono::duration<double>(t_done - t_loaded).count(),
-              np.n_ranks, np.bucket_bits, np.partition_s, np.exchange_count_s, np.close_s, np.merge_parts_s, np.data_bytes);
-    mgc_close(s);
-    if (g.verbosity > 0) {
-      fprintf(stderr, "\nFinished counting.\n");
-      if (g.verbosity > 2)
-        fprintf(stderr, "  %" PRIu64 " bases, %" PRIu64 " k-mer instances, %" PRIu64 " distinct k-mers, prefix bits %u.\n",
-                total_bases, np.n_instances, np.n_distinct, cfg.w_prefix);
-    }
-    return 0;
-  }
   if (mgc_count(s) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
   const auto t_counted = std::chrono::steady_clock::now();
   mgc_result_info info;

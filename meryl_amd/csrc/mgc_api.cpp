@@ -651,21 +651,86 @@ extern "C" int mgc_push_text(mgc_session *s, const char *text, size_t len) {
 // A whole uncompressed FASTA/FASTQ file: `reader_threads` threads pread() 32 MiB chunks straight into a ring of pinned
 // buffers (no intermediate copy), the calling thread uploads and parses them in file order.  A 20 GB FASTQ on tmpfs is
 // otherwise bound by ONE thread's read()+memcpy (measured 11 GB/s, 1.8 s of a 3 s file -> database run).
+// format of a FASTA / FASTQ file from its first byte that is not white space; 0: neither
+static int sniff_text_format(int fd, char *first) {
+  char head[4096];
+  const ssize_t got = pread(fd, head, sizeof(head), 0);
+  char c = '>';
+  for (ssize_t i = 0; i < got; i++) if (head[i] != '\n' && head[i] != '\r' && head[i] != ' ' && head[i] != '\t') { c = head[i]; break; }
+  if (first) *first = c;
+  return c == '@' ? MGC_TEXT_FASTQ : (c == '>' ? MGC_TEXT_FASTA : 0);
+}
+
+// First record start at or after `offset` of a FASTA / FASTQ file -- where a reader that takes the file from the middle
+// may begin (the ranks of a node count read disjoint byte windows of the input, each through its own device's link).
+// FASTA: a line that starts with '>'.  FASTQ (four-line records): a line that starts with '@' whose next-but-one line starts
+// with '+' -- a quality line may start with '@', but then the line two below it is a sequence line, never '+'.
+extern "C" int mgc_text_record_start(const char *path, int format, uint64_t offset, uint64_t *start) {
+  if (!path || !start) return MGC_EINVAL;
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) { set_err(nullptr, "mgc_text_record_start: cannot open '%s': %s", path, strerror(errno)); return MGC_EINVAL; }
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); set_err(nullptr, "mgc_text_record_start: '%s' is not a regular file", path); return MGC_EINVAL; }
+  const uint64_t size = (uint64_t)st.st_size;
+  if (format == 0) format = sniff_text_format(fd, nullptr);
+  if (format != MGC_TEXT_FASTA && format != MGC_TEXT_FASTQ) { close(fd); set_err(nullptr, "'%s' is neither FASTA nor FASTQ", path); return MGC_EFORMAT; }
+  if (offset == 0 || offset >= size) { close(fd); *start = offset >= size ? size : 0; return MGC_OK; }
+  // line starts from offset - 1 on: the byte before a line start is '\n'
+  std::vector<char> buf(1u << 20);
+  uint64_t pos = offset - 1;                               // file position of buf[0]
+  std::vector<uint64_t> ls;                                // line starts found so far (file offsets), with their first byte
+  std::vector<char> lc;
+  uint64_t answer = size;
+  bool found = false;
+  while (!found && pos < size) {
+    const ssize_t got = pread(fd, buf.data(), buf.size(), (off_t)pos);
+    if (got <= 0) break;
+    for (ssize_t i = 0; i < got && !found; i++) {
+      if (buf[i] != '\n') continue;
+      const uint64_t line = pos + (uint64_t)i + 1;
+      if (line >= size) break;
+      char c;
+      if (i + 1 < got) c = buf[i + 1];
+      else if (pread(fd, &c, 1, (off_t)line) != 1) break;
+      if (format == MGC_TEXT_FASTA) { if (c == '>') { answer = line; found = true; } continue; }
+      ls.push_back(line); lc.push_back(c);
+      const size_t m = ls.size();
+      if (m >= 3 && lc[m - 3] == '@' && lc[m - 1] == '+') { answer = ls[m - 3]; found = true; }
+    }
+    pos += (uint64_t)got;
+  }
+  close(fd);
+  *start = found ? answer : size;
+  return MGC_OK;
+}
+
+static int push_text_file_range(mgc_session *s, const char *path, int format, int reader_threads, uint64_t range_begin, uint64_t range_end);
+
 extern "C" int mgc_push_text_file(mgc_session *s, const char *path, int format, int reader_threads) {
+  return push_text_file_range(s, path, format, reader_threads, 0, ~0ull);
+}
+
+extern "C" int mgc_push_text_file_range(mgc_session *s, const char *path, int format, int reader_threads, uint64_t begin, uint64_t end) {
+  return push_text_file_range(s, path, format, reader_threads, begin, end);
+}
+
+// bytes [range_begin, range_end) of the file (range_begin at a record start; range_end = the next reader's start, or past the end)
+static int push_text_file_range(mgc_session *s, const char *path, int format, int reader_threads, uint64_t range_begin, uint64_t range_end) {
   if (!s || !path) return MGC_EINVAL;
   const int fd = open(path, O_RDONLY);
   if (fd < 0) { set_err(&s->err, "mgc_push_text_file: cannot open '%s': %s", path, strerror(errno)); return MGC_EINVAL; }
   struct stat st;
   if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); set_err(&s->err, "mgc_push_text_file: '%s' is not a regular file", path); return MGC_EINVAL; }
-  const uint64_t size = (uint64_t)st.st_size;
   if (format == 0) {                                        // sniff: first byte that is not white space
-    char head[4096];
-    const ssize_t got = pread(fd, head, sizeof(head), 0);
-    char c = '>';
-    for (ssize_t i = 0; i < got; i++) if (head[i] != '\n' && head[i] != '\r' && head[i] != ' ' && head[i] != '\t') { c = head[i]; break; }
-    if (c != '>' && c != '@') { close(fd); set_err(&s->err, "'%s' is neither FASTA nor FASTQ (record starts with '%c')", path, c); return MGC_EFORMAT; }
-    format = (c == '@') ? MGC_TEXT_FASTQ : MGC_TEXT_FASTA;
+    char c = 0;
+    format = sniff_text_format(fd, &c);
+    if (!format) { close(fd); set_err(&s->err, "'%s' is neither FASTA nor FASTQ (record starts with '%c')", path, c); return MGC_EFORMAT; }
   }
+  const uint64_t file_size = (uint64_t)st.st_size;
+  if (range_end > file_size) range_end = file_size;
+  if (range_begin > range_end) range_begin = range_end;
+  const uint64_t base = range_begin;                        // every file offset below is relative to the window
+  const uint64_t size = range_end - range_begin;
   int rc = mgc_begin_text(s, format);
   if (rc != MGC_OK) { close(fd); return rc; }
 
@@ -673,7 +738,7 @@ extern "C" int mgc_push_text_file(mgc_session *s, const char *path, int format, 
   // straight from the mapping (the runtime pins pageable sources on the fly: 56 GB/s for a 1 GiB pageable buffer on this
   // box, scripts/pcie_bench.py); the page cache IS the upload buffer.
   if (const char *mm = getenv("MGC_TEXT_MMAP")) if (mm[0] == '1' && size > 0) {
-    void *map = mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0);
+    void *map = (base == 0) ? mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0) : MAP_FAILED;     // whole files only
     if (map != MAP_FAILED) {
       (void)madvise(map, size, MADV_SEQUENTIAL);
       const size_t CHm = mgc_session::TEXT_CHUNK;
@@ -744,7 +809,7 @@ extern "C" int mgc_push_text_file(mgc_session *s, const char *path, int format, 
       size_t have = 0;
       bool ok = true;
       while (have < want) {
-        const ssize_t r = pread(fd, ring[slot] + have, want - have, (off_t)(off + have));
+        const ssize_t r = pread(fd, ring[slot] + have, want - have, (off_t)(base + off + have));
         if (r < 0 && errno == EINTR) continue;
         if (r <= 0) { ok = false; break; }                  // an error, or the file shrank under us
         have += (size_t)r;

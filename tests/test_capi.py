@@ -213,3 +213,42 @@ def test_staged_slices_with_k_minus_1_overlap_lose_and_double_nothing(oracle_lib
             hi, lo, cn, _ = oracle_lib.count_brute(stream, k)
             want = {(int(h), int(l)): int(c) for h, l, c in zip(hi, lo, cn)}
             assert dict(total) == want, (k, n_ranks, stream)
+
+
+def test_text_record_start_finds_window_cuts(native_lib, tmp_path):
+    """mgc_text_record_start (host I/O only): the first record start at or after an offset -- where a rank of a node count
+    may begin to read its byte window of a file.  FASTQ quality lines that start with '@' or '+' must not fool it."""
+    import ctypes
+    import random
+    from meryl_amd import capi
+    L = capi.lib()
+    rnd = random.Random(5)
+    recs = []
+    for i in range(300):
+        n = rnd.randint(1, 90)
+        seq = "".join(rnd.choice("ACGTN") for _ in range(n))
+        q = "".join(rnd.choice("@+I5>") for _ in range(n))
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, seq, q))
+    fq = tmp_path / "a.fq"
+    fq.write_text("".join(recs))
+    starts, p = [], 0
+    for r in recs:
+        starts.append(p)
+        p += len(r)
+    size = p
+    out = ctypes.c_uint64(0)
+    for off in list(range(0, 400)) + [rnd.randrange(size) for _ in range(300)] + [size - 1, size, size + 10]:
+        assert L.mgc_text_record_start(str(fq).encode(), 0, off, ctypes.byref(out)) == 0
+        want = min([s for s in starts if s >= off] + [size])
+        assert out.value == want, (off, out.value, want)
+    fa = tmp_path / "a.fa"
+    frecs = [">s%d x\n%s\n%s\n" % (i, "ACGT" * rnd.randint(1, 20), "GG" * rnd.randint(1, 9)) for i in range(200)]
+    fa.write_text("".join(frecs))
+    fstarts, p = [], 0
+    for r in frecs:
+        fstarts.append(p)
+        p += len(r)
+    for off in [0, 1, 2, 50, 51] + [rnd.randrange(p) for _ in range(200)] + [p]:
+        assert L.mgc_text_record_start(str(fa).encode(), 0, off, ctypes.byref(out)) == 0
+        assert out.value == min([s for s in fstarts if s >= off] + [p]), off
+    assert L.mgc_text_record_start(str(tmp_path / "missing").encode(), 0, 5, ctypes.byref(out)) != 0

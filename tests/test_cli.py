@@ -348,22 +348,34 @@ def test_cli_out_of_core_text_input(meryl, oracle_lib, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,extra", [(21, ()), (31, ("compress",)), (51, ("-l", "5"))])
 def test_cli_gpus_option_writes_the_single_device_database(meryl, oracle_lib, tmp_path, k, extra):
-    """`gpus=N`: the input is read and parsed through one session, its base stream cut into N slices that overlap by k-1
-    bases (cuts fall inside reads -- and, with `compress`, inside the compressed stream), and the ranks of
-    mgc_count_node count and write ONE database: the same 129 files as without the option, for 2, 3 and 7 ranks on
-    whatever devices the box has."""
+    """`gpus=N`: every rank reads ITS OWN share of the input -- byte windows of the plain-text files cut at record starts
+    (FASTA here, FASTQ and a gzip'd file that goes whole to one rank below) -- stages it on its device, and the ranks of
+    mgc_count_node_batched count and write ONE database: the same 129 files as without the option, for 2, 3 and 7 ranks on
+    whatever devices the box has; with MERYL_BATCH_BASES the node count runs in batches (parked waves, one merge per owner)."""
+    import gzip
     bases = oracle_lib.synth_reads(31, 150_000, 0, 20_000, 150 if not extra or extra[0] != "compress" else 1500).tobytes()
     reads = [r for r in bases.decode().split(".") if r]
+    third = len(reads) // 3
     fa = tmp_path / "r.fa"
-    fa.write_text("".join(">%d\n%s\n" % (i, r) for i, r in enumerate(reads)))
+    fa.write_text("".join(">%d\n%s\n" % (i, r) for i, r in enumerate(reads[:third])))
+    fq = tmp_path / "r.fq"                                    # quality lines that start with '@' and '+': the window cuts must not be fooled
+    fq.write_text("".join("@%d\n%s\n+\n%s\n" % (i, r, ("@" if i % 2 else "+") + "I" * (len(r) - 1)) for i, r in enumerate(reads[third:2 * third])))
+    gz = tmp_path / "r.fa.gz"
+    with gzip.open(gz, "wt") as f:
+        f.write("".join(">%d\n%s\n" % (i, r) for i, r in enumerate(reads[2 * third:])))
     one = tmp_path / "one.meryl"
-    run(meryl, "-Q", *extra, "k=%d" % k, "memory=2", "count", fa, "output", one)
+    run(meryl, "-Q", *extra, "k=%d" % k, "memory=2", "count", fa, fq, gz, "output", one)
     names = sorted(os.listdir(one))
     assert len(names) == 129
-    for n_ranks in (2, 3, 7):
+    for n_ranks, batch in ((2, None), (3, "400000"), (7, None)):
         out = tmp_path / ("g%d.meryl" % n_ranks)
-        p = run(meryl, "-V", *extra, "k=%d" % k, "memory=2", "gpus=%d" % n_ranks, "count", fa, "output", out)
+        env = dict(os.environ)
+        if batch:
+            env["MERYL_BATCH_BASES"] = batch
+        p = run(meryl, "-V", *extra, "k=%d" % k, "memory=2", "gpus=%d" % n_ranks, "count", fa, fq, gz, "output", out, env=env)
         assert "ranks=%d" % n_ranks in p.stderr
+        if batch:
+            assert "batches=1," not in p.stderr
         assert sorted(os.listdir(out)) == names
         for n in names:
             assert open(os.path.join(one, n), "rb").read() == open(os.path.join(out, n), "rb").read(), (n_ranks, n)
