@@ -16,14 +16,23 @@ that grows with N); the 64*N top-bit buckets are cut into contiguous per-rank ra
 and k-mers are routed to their owner in point-to-point waves over RCCL/xGMI while
 the owner counts the buckets that have arrived.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the
-radix grouping pass (algorithmic 8 B read + 8 B write per key), timed with HIP
-events on the library's own stream during the timed steps; `traffic` is the PMC
-measurement committed under profiles/ for this same workload.  `cpu_baseline` is
-the CPU restatement of the reference algorithm (oracle/, kind "port") timed on
-this box's host cores over a bounded sample of the same workload shape.
+Prints ONE JSON line (rank 0), at every N:
+  roofline      the kernel with the largest share of the step's time (the sub-bucket count kernel; its fraction of the
+                step is given) priced on its algorithmic bytes and its own launch durations (HIP events on the streams it
+                is launched on); `sort_pass` keeps the radix grouping pass; `traffic` is the PMC measurement committed
+                under profiles/ for this same workload
+  check         untimed sanity check of the counted result (N > 1: reduced over the ranks, rank boundaries included)
+  db_write      the counted result -> the 64-file database (N > 1: count_sharded(db=...), every rank its part, stitched;
+                its 129 files compared with the database mgc_count_node -- the in-process peer-copy form -- writes)
+  e2e           file -> database wall clock of the stand-alone CLI (N > 1: gpus=N, every rank reading its own windows)
+  cpu_baseline  the CPU restatement of the reference algorithm (oracle/, kind "port") timed on this box's host cores over a
+                bounded sample of the same workload (rank 0)
+N > 1 on a box with ONE GPU (MGC_BENCH_ONE_DEVICE=1: every rank is told to use device 0): RCCL refuses two ranks on one
+device ("Duplicate GPU detected"), so rank 0 falls back to the peer-copy form with N virtual ranks in one process and says
+so in the line (`transport`).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -57,7 +66,7 @@ def cpu_baseline(sample_reads, threads, dev_bases=None):
     # box's cores) and report every one
     tried = []
     best = None
-    for th in sorted({max(1, min(threads, t)) for t in (16, 64, threads)}):
+    for th in sorted({max(1, min(threads, t)) for t in (16, 32, 64)}):
         t0 = time.perf_counter()
         _, nd, ni = oracle.digest_threaded(bases, K, cfg["w_prefix"], oracle.CANONICAL, th)
         dt = time.perf_counter() - t0
@@ -65,13 +74,23 @@ def cpu_baseline(sample_reads, threads, dev_bases=None):
         if best is None or dt < best[0]:
             best = (dt, th, nd, ni)
     dt, th, nd, ni = best
-    return {
+    out = {
         "value": nd / dt, "unit": "distinct k-mers/s", "cores": th, "kind": "port",
         "sample": "the first %d x %d bp reads of the workload (%.2f Gbp of the %d bp genome's reads), k=%d, wPrefix=%d; "
                   "%d instances, %d distinct in %.2f s (%.3g instances/s) on %d threads"
                   % (sample_reads, READ_LEN, bases.size / 1e9, GENOME_LEN, K, cfg["w_prefix"], ni, nd, dt, ni / dt, th),
         "instances_per_s": ni / dt, "seconds": dt, "threads_tried": tried, "host_cores": os.cpu_count(),
     }
+    # the WHOLE workload on the port (a 170 s run: scripts/cpu_full.py on the GPU box's host, committed under profiles/)
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cpu_full.json")), reverse=True):
+        try:
+            out["full_workload"] = json.load(open(f))
+            out["full_workload"]["source"] = "profiles/" + os.path.basename(f)
+            break
+        except (OSError, ValueError):
+            continue
+    return out
 
 
 def self_launch(n, argv):
@@ -104,39 +123,93 @@ def valid_windows(bases, k, chunk=1 << 30):
     return int(torch.clamp(runs - (k - 1), min=0).sum().item())
 
 
-def result_check(sess, bases, k, info):
-    """Untimed sanity check of the counted result at the judged size (the parity tests proper are tests/test_gpu_parity.py):
-    instances == valid windows of the input, distinct k-mers strictly ascending, counts sum to the instances per file."""
+def per_file_sums(keys, cnts, k):
     import torch
-    keys, cnts = sess.result_device()
-    out = {}
-    want = valid_windows(bases, k)
-    out["valid_windows"] = want
-    out["instances_equal_valid_windows"] = bool(info.n_instances == want)
-    out["keys_strictly_ascending"] = bool((keys[1:] > keys[:-1]).all().item()) if keys.numel() > 1 else True   # k <= 31: int64 order == uint64 order
     c64 = cnts.to(torch.int64) & 0xFFFFFFFF
-    out["sum_counts_equals_instances"] = bool(int(c64.sum().item()) == info.n_instances)
     bounds = torch.arange(0, 65, device=keys.device, dtype=torch.int64) << (2 * k - 6)
     cut = torch.searchsorted(keys, bounds)
     csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=keys.device), torch.cumsum(c64, 0)])
-    per_file = (csum[cut[1:]] - csum[cut[:-1]]).cpu().tolist()
-    out["per_file_totals_match"] = bool(per_file == [int(x) for x in info.file_instances])
-    out["distinct_ge_1"] = bool(int(c64.min().item()) >= 1) if keys.numel() else True
+    return (csum[cut[1:]] - csum[cut[:-1]]), c64
+
+
+def result_check(keys, cnts, bases, k, n_instances, file_instances, dist=None):
+    """Untimed sanity check of the counted result at the judged size (the parity tests proper are tests/test_gpu_parity.py):
+    instances == valid windows of the input, distinct k-mers strictly ascending, counts sum to the instances per file.
+    With `dist` the check is reduced over the ranks: windows, instances and per-file totals are summed, and the keys must
+    also ascend ACROSS the rank boundaries (rank r's last k-mer below rank r+1's first)."""
+    import torch
+    out = {}
+    want = valid_windows(bases, k)
+    per_file, c64 = per_file_sums(keys, cnts, k)
+    asc = bool((keys[1:] > keys[:-1]).all().item()) if keys.numel() > 1 else True   # k <= 31: int64 order == uint64 order
+    have = int(c64.sum().item())
+    ge1 = bool(int(c64.min().item()) >= 1) if keys.numel() else True
+    if dist is not None:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        t = torch.tensor([want, have, int(asc), int(ge1), keys.numel()], dtype=torch.int64, device=keys.device)
+        tot = t.clone()
+        dist.all_reduce(tot)
+        mn = t.clone()
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        want, have, asc, ge1 = int(tot[0]), int(tot[1]), bool(int(mn[2])), bool(int(mn[3]))
+        dist.all_reduce(per_file)
+        edge = torch.tensor([int(keys[0]) if keys.numel() else -1, int(keys[-1]) if keys.numel() else -1], dtype=torch.int64, device=keys.device)
+        edges = [torch.empty_like(edge) for _ in range(world)]
+        dist.all_gather(edges, edge)
+        last, across = -1, True
+        for e in edges:
+            if int(e[0]) < 0:
+                continue                                    # a rank without k-mers
+            across = across and int(e[0]) > last
+            last = int(e[1])
+        out["keys_ascending_across_rank_boundaries"] = bool(across)
+        out["ranks"] = world
+        fi = torch.tensor([int(x) for x in file_instances], dtype=torch.int64, device=keys.device)
+        dist.all_reduce(fi)
+        file_instances = fi.cpu().tolist()
+        n_instances = have if n_instances is None else n_instances
+    out["valid_windows"] = want
+    out["instances_equal_valid_windows"] = bool(have == want and (n_instances is None or n_instances == want))
+    out["keys_strictly_ascending"] = asc
+    out["sum_counts_equals_instances"] = bool(have == want)
+    out["per_file_totals_match"] = bool(per_file.cpu().tolist() == [int(x) for x in file_instances])
+    out["distinct_ge_1"] = ge1
     out["ok"] = all(v for kk, v in out.items() if isinstance(v, bool))
     return out
 
 
-def e2e_run(bases, reads, threads):
+def dir_digest(path):
+    """sha256 over the 129 files of a database directory (names + bytes, sorted)"""
+    h = hashlib.sha256()
+    names = sorted(os.listdir(path))
+    for n in names:
+        h.update(n.encode())
+        with open(os.path.join(path, n), "rb") as f:
+            while True:
+                b = f.read(1 << 24)
+                if not b:
+                    break
+                h.update(b)
+    return h.hexdigest(), len(names), sum(os.path.getsize(os.path.join(path, n)) for n in names)
+
+
+def shm_dir(prefix):
+    import tempfile
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    return tempfile.mkdtemp(prefix=prefix, dir=shm), shm
+
+
+def e2e_run(bases, reads, threads, gpus=1):
     """File -> database wall clock of the stand-alone CLI: the synthetic reads are written as a FASTQ
     file on tmpfs, `meryl count` reads it, parses it on the device, counts, encodes the blocks on the device and writes
-    the 64-file database back to tmpfs.  Never part of `value`."""
+    the 64-file database back to tmpfs.  gpus > 1: `gpus=N` -- every rank reads its own byte windows of the file through
+    its own device's link.  Never part of `value`."""
     import re
     import shutil
     import subprocess
-    import tempfile
     import torch
     from meryl_amd import build
-    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    d, shm = shm_dir("mgc_e2e_")
     st = os.statvfs(shm)
     free = st.f_bavail * st.f_frsize
     rec = READ_LEN * 2 + 7
@@ -144,7 +217,6 @@ def e2e_run(bases, reads, threads):
     need = lambda r: r * rec * 1.45 + (1 << 30)            # FASTQ + database
     while use > 1000 and need(use) > free * 0.8:
         use //= 2
-    d = tempfile.mkdtemp(prefix="mgc_e2e_", dir=shm)
     try:
         fq = os.path.join(d, "reads.fq")
         t0 = time.perf_counter()
@@ -162,7 +234,8 @@ def e2e_run(bases, reads, threads):
         t_gen = time.perf_counter() - t0
         dbp = os.path.join(d, "out.meryl")
         cli = build.build_cli()
-        cmd = [cli, "-V", "k=%d" % K, "memory=64", "threads=%d" % threads, "n=10000000000", "count", fq, "output", dbp]
+        cmd = [cli, "-V", "k=%d" % K, "memory=64", "threads=%d" % threads, "n=10000000000"] + (["gpus=%d" % gpus] if gpus > 1 else []) + \
+              ["count", fq, "output", dbp]
         t0 = time.perf_counter()
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         wall = time.perf_counter() - t0
@@ -171,34 +244,100 @@ def e2e_run(bases, reads, threads):
         out = {"reads": use, "bases": use * READ_LEN, "fastq_bytes": os.path.getsize(fq), "wall_s": wall,
                "threads": threads, "where": shm, "fastq_generation_s": t_gen,
                "database_bytes": sum(os.path.getsize(os.path.join(dbp, n)) for n in os.listdir(dbp)),
-               "command": "meryl -V k=%d memory=64 threads=%d n=10000000000 count reads.fq output out.meryl" % (K, threads)}
+               "command": " ".join(["meryl"] + cmd[1:-4] + ["count", "reads.fq", "output", "out.meryl"])}
         if os.environ.get("MGC_IO_TRACE"):
             out["io_trace"] = [l for l in p.stderr.splitlines() if l.startswith("[io]")]
         m = re.search(r"TIMING(.*)", p.stderr)
         if m:
             for name, val in re.findall(r"([a-z+_]+)=([0-9.]+)", m.group(1)):
                 out[name + ("" if name.endswith("bytes") else "_s")] = float(val)
-        if "count" in out and out.get("count_s"):
-            pass
+        m = re.search(r"(\d+) distinct k-mers", p.stderr)
+        if m:
+            out["n_distinct"] = int(m.group(1))
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
 
-def pmc_traffic(reads):
-    """HBM bytes per launch of the dominant kernel from the committed PMC run of this same workload
-    (profiles/*_pmc_traffic.json, made by scripts/gpu_pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
+def pmc_traffic(reads, prefix):
+    """HBM bytes per launch of a kernel (name prefix) from the committed PMC run of this same workload
+    (profiles/*_pmc_traffic.json, made by scripts/gpu_final.sh: FETCH_SIZE and WRITE_SIZE in separate
     rocprofv3 passes, calibrated on known-byte kernels of the same access width); None for any other workload --
     counters cannot be collected from inside this process."""
     import glob
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if d.get("reads_per_gpu") == reads and str(d.get("kernel", "")).startswith("radix_group_kernel"):
-            return d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"], "profiles/" + os.path.basename(f)
+        if d.get("reads_per_gpu") != reads:
+            continue
+        for name, v in d.get("all_kernels", {}).items():
+            if name.startswith(prefix) and v.get("fetch_bytes_per_launch") is not None and v.get("write_bytes_per_launch") is not None:
+                return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], "profiles/" + os.path.basename(f) + " (" + name[:60] + ")"
     return None, None
+
+
+def roofline_object(prof_acc, ms_per_step, steps, reads, single, where):
+    """`roofline` of the line: the kernel with the largest share of the step, and the grouping pass under sort_pass."""
+    bp = prof_acc["by_pass"]
+    if not bp[0]["launches"] and prof_acc["pass_launches"]:              # only the totals were collected
+        bp = [{"ms": prof_acc["pass_ms"], "launches": prof_acc["pass_launches"], "keys": prof_acc["pass_keys"],
+               "bytes": prof_acc.get("pass_bytes", 16 * prof_acc["pass_keys"])}, {"ms": 0.0, "launches": 0, "keys": 0, "bytes": 0}]
+    sort_pass = None
+    if bp[0]["launches"]:
+        # A file's FIRST grouping pass.  Algorithmic bytes = key bytes it must read and write: 8 + 8 per k-mer for the wide pass,
+        # 8 + 4 when the pass narrows its output to 32-bit words (k <= ~25: the digit a key was grouped by is dropped, the second
+        # pass then moves 4 + 4) -- the library reports them per launch.
+        achieved = bp[0]["bytes"] / (bp[0]["ms"] / 1e3) / 1e9
+        narrowed = bp[0]["bytes"] < 16 * bp[0]["keys"]
+        t, src = pmc_traffic(reads, "radix_group_kernel<unsigned long long") if single else (None, None)
+        sort_pass = {
+            "kernel": "radix_group_kernel, first pass of a file (9-bit digit; %s)" %
+                      ("8 B k-mers in, 4 B narrowed words out" if narrowed else "8 B k-mers in and out"),
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": t, "traffic_source": src, "launches": bp[0]["launches"], "avg_launch_ms": bp[0]["ms"] / bp[0]["launches"],
+            "algorithmic_bytes_per_launch": bp[0]["bytes"] / bp[0]["launches"], "keys_per_launch": bp[0]["keys"] / bp[0]["launches"],
+            "share_of_step": (bp[0]["ms"] / steps) / ms_per_step if single else None,
+        }
+        if bp[1]["launches"]:
+            a1 = bp[1]["bytes"] / (bp[1]["ms"] / 1e3) / 1e9
+            t1, src1 = pmc_traffic(reads, "radix_group_kernel<unsigned int") if single else (None, None)
+            sort_pass["second_pass"] = {"achieved": a1, "frac": a1 / HBM_PEAK_GBS, "launches": bp[1]["launches"],
+                                        "avg_launch_ms": bp[1]["ms"] / bp[1]["launches"],
+                                        "algorithmic_bytes_per_launch": bp[1]["bytes"] / bp[1]["launches"],
+                                        "traffic": t1, "traffic_source": src1,
+                                        "share_of_step": (bp[1]["ms"] / steps) / ms_per_step if single else None}
+        # the same passes priced the way SURVEY 8(d) prices a radix pass (8 + 8 B per k-mer whatever is really moved):
+        # comparable with earlier rounds' 0.47
+        eq = 16.0 * prof_acc["pass_keys"] / (prof_acc["pass_ms"] / 1e3) / 1e9
+        sort_pass["survey_accounting"] = {"bytes_per_key_per_pass": 16, "achieved": eq, "frac": eq / HBM_PEAK_GBS}
+    fin = prof_acc.get("finish")
+    if fin and fin["launches"]:
+        # The kernel with the largest share of the step: the sub-bucket count (hash_count_kernel).  Two launches run
+        # side by side on alternating streams, so the launches' own durations add up to more than the stage's wall clock.
+        achieved = fin["bytes"] / (fin["ms"] / 1e3) / 1e9
+        t, src = pmc_traffic(reads, "hash_count_kernel") if single else (None, None)
+        out = {
+            "kernel": "hash_count_kernel (sub-bucket count: 4 B narrowed keys in, distinct 4 B suffixes + 4 B counts out), one launch per file",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": t, "traffic_source": src or ("none: no committed PMC run of this workload" if single else None),
+            "measured": "HIP events around every launch, on the stream it is launched on, " + where,
+            "launches": fin["launches"], "avg_launch_ms": fin["ms"] / fin["launches"],
+            "algorithmic_bytes_per_launch": fin["bytes"] / fin["launches"], "keys_per_launch": fin["keys"] / fin["launches"],
+            "kernel_time_share_of_step": (fin["ms"] / steps) / ms_per_step if single else None,
+            "note": "VALU/LDS-issue-bound (DESIGN.md 3.4): the fraction says how far from the HBM roof the step's largest kernel runs, "
+                    "not that HBM limits it",
+            "sort_pass": sort_pass,
+        }
+        if single and prof_acc["stage_ms"][3]:
+            wall = prof_acc["stage_ms"][3] / steps                      # the finish stage's wall clock (count kernels + packing)
+            out["stage_wall_ms"] = wall
+            out["frac_on_stage_wall"] = (fin["bytes"] / fin["launches"] * (fin["launches"] / steps)) / (wall / 1e3) / 1e9 / HBM_PEAK_GBS
+        return out
+    if sort_pass:
+        sort_pass["measured"] = "HIP events around every pass launch, " + where
+    return sort_pass
 
 
 def main():
@@ -211,6 +350,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the untimed file -> database run of the CLI")
     ap.add_argument("--no-check", action="store_true", help="skip the untimed result check")
+    ap.add_argument("--no-db", action="store_true", help="skip the untimed database write (N > 1: and the node-count comparison)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -235,19 +375,39 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (no CPU fallback exists for the count path)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
+    one_device = os.environ.get("MGC_BENCH_ONE_DEVICE", "0") == "1"      # every rank on device 0 (a one-GPU box)
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
 
     # MGC_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (partition -> exchange waves -> owner-side count) even
     # with a single rank, so that it can be exercised on a 1-GPU box
     force_sharded = os.environ.get("MGC_BENCH_FORCE_SHARDED", "0") == "1"
     dist = None
+    transport = "none (one GPU)"
     if world > 1 or force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        transport = "RCCL point-to-point waves, one process per GPU"
+        if world > 1:
+            try:                                                 # two ranks on one device: RCCL says "Duplicate GPU detected"
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as e:                               # noqa: BLE001 -- whatever RCCL raises, the fallback is the same
+                why = str(e).strip().splitlines()[-1][:160] if str(e).strip() else type(e).__name__
+                transport = "peer copies between %d virtual ranks of ONE process (mgc_count_node): RCCL refused the %d ranks (%s)" % (world, world, why)
+                try:
+                    dist.destroy_process_group()
+                except Exception:                                # noqa: BLE001
+                    pass
+                dist = None
+                if rank != 0:
+                    os._exit(0)                                  # rank 0 carries the whole job in the fallback
+    node_fallback = world > 1 and dist is None
     # the in-tree library is normally up to date (it travels with the snapshot); if it has to be rebuilt, one rank does it
-    if local_rank == 0:
+    if local_rank == 0 or node_fallback:
         build.build()
     if dist is not None:
         dist.barrier()
@@ -261,17 +421,23 @@ def main():
     # ---- synthetic input, generated in HBM ----
     reads = args.reads
     genome_len = GENOME_LEN * world              # weak scaling: every GPU brings its own 30x share of a genome that grows with N
-    bases = count.dev_synth_reads(SEED, genome_len, rank * reads, reads, READ_LEN, 5000, 100)
+    ranks_here = list(range(world)) if node_fallback else [rank]
+    all_bases = [count.dev_synth_reads(SEED, genome_len, r * reads, reads, READ_LEN, 5000, 100) for r in ranks_here]
+    bases = all_bases[0]
     torch.cuda.synchronize()
     n_bases = bases.numel()
 
     prof_acc = {"pass_ms": 0.0, "pass_launches": 0, "pass_keys": 0, "stage_ms": [0.0] * capi.NUM_STAGES,
-                "by_pass": [{"ms": 0.0, "launches": 0, "keys": 0, "bytes": 0} for _ in range(2)]}
+                "by_pass": [{"ms": 0.0, "launches": 0, "keys": 0, "bytes": 0} for _ in range(2)],
+                "finish": {"ms": 0.0, "launches": 0, "keys": 0, "bytes": 0}}
     result = {}
+    single = world == 1 and not force_sharded
+    cfg = capi.configure(K, 10_000_000_000 if reads == DEFAULT_READS else n_bases * world, 64 << 30)
+    sess = None
+    node_dir = None
 
-    if world == 1 and not force_sharded:
-        cfg = capi.configure(K, 10_000_000_000 if reads == DEFAULT_READS else n_bases, 64 << 30)
-        sess = count.Session(cfg, local_rank)
+    if single:
+        sess = count.Session(cfg, dev_index)
         sess.push_bases_device(bases)
         sess.set_profiling(True)
 
@@ -286,6 +452,8 @@ def main():
                     bp = prof_acc["by_pass"][i]
                     bp["ms"] += p.pass_ms[i]; bp["launches"] += p.pass_launches[i]
                     bp["keys"] += p.pass_keys[i]; bp["bytes"] += p.pass_bytes[i]
+                fin = prof_acc["finish"]
+                fin["ms"] += p.finish_ms; fin["launches"] += p.finish_launches; fin["keys"] += p.finish_keys; fin["bytes"] += p.finish_bytes
                 for i in range(capi.NUM_STAGES):
                     prof_acc["stage_ms"][i] += p.stage_ms[i]
             info = sess.info()
@@ -293,13 +461,23 @@ def main():
             result["n_distinct"] = info.n_distinct
             result["n_instances"] = info.n_instances
             result["w_prefix"] = info.w_prefix
+    elif node_fallback:
+        node_dir, _ = shm_dir("mgc_node_")
+
+        def step(timed):
+            import shutil
+            out = os.path.join(node_dir, "db.meryl")
+            shutil.rmtree(out, ignore_errors=True)
+            result["node_profile"] = count.count_node(cfg, all_bases, out, devices=[0] * world, host_threads=min(32, os.cpu_count() or 8))
+            result["n_distinct"] = result["node_profile"]["n_distinct"]
+            result["n_instances"] = result["node_profile"]["n_instances"]
     else:
         def step(timed, profile=False):
             # per-file profiling synchronises after every owned file; it runs in ONE extra untimed step (below)
             count.SHARD_PROFILE = prof_acc if profile else None
-            uniq, cnts, _ = count.count_sharded(bases, K)
-            result["n_distinct_local"] = uniq.numel()
-            result["n_instances_local"] = int(cnts.to(torch.int64).sum().item()) if not timed else 0
+            uniq, cnts, rng = count.count_sharded(bases, K)
+            result["uniq"], result["cnts"], result["range"] = uniq, cnts, rng
+            result["n_distinct_local"] = uniq.shape[0]
 
     for _ in range(args.warmup):
         step(False)
@@ -309,8 +487,12 @@ def main():
         step(True)
     barrier()
     dt = time.perf_counter() - t0
+    stage_s = None
     if dist is not None:
+        os.environ["MGC_SHARD_PROFILE"] = "1"
+        stage_db = {}
         step(False, profile=True)        # collective: every rank runs it; rank 0's pass timings feed the roofline object
+        os.environ.pop("MGC_SHARD_PROFILE", None)
         barrier()
 
     # max over ranks, totals over ranks
@@ -322,94 +504,177 @@ def main():
         dist.all_reduce(d)
         result["n_distinct"] = int(d.item())
 
+    ms_per_step = dt / args.steps * 1e3
+    n_distinct = result["n_distinct"]
+    threads = min(32, os.cpu_count() or 8)
+    line = {
+        "metric": "distinct k-mers counted/sec (whole node)",
+        "value": n_distinct / (dt / args.steps),
+        "unit": "distinct k-mers/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": "meryl count k=21 on synthetic short reads: %d x %d bp reads per GPU (%.2f Gbp per GPU, "
+                        "30x of a %d bp genome, 0.5%% substitutions, 0.01%% N), inputs resident in HBM"
+                        % (reads, READ_LEN, reads * READ_LEN / 1e9, genome_len),
+            "k": K, "reads_per_gpu": reads, "bases_per_gpu": n_bases,
+            "n_distinct": n_distinct,
+            "parallelism": "1 GPU" if world == 1 else "%d GPUs: the top-bit buckets (64 files x ranges) in contiguous per-rank ranges, bucket-major point-to-point waves overlapped with the owner-side count" % world,
+            "transport": transport,
+        },
+    }
+    if node_fallback:
+        line["config"]["note"] = ("one-GPU box: the step is mgc_count_node with %d virtual ranks sharing the device and INCLUDES writing the "
+                                  "database; not a scaling number" % world)
+
+    # ---- check (collective at N > 1) ----
+    if not args.no_check:
+        try:
+            if single:
+                keys, cnts = sess.result_device()
+                line["check"] = result_check(keys, cnts, bases, K, result["info"].n_instances, result["info"].file_instances)
+                del keys, cnts
+            elif dist is not None:
+                fh = count.HipOps.histogram(bases, K, capi.MODE_CANONICAL, 6)       # this rank's k-mers per file, from the base stream
+                chk = result_check(result["uniq"], result["cnts"], bases, K, None, fh, dist)
+                if rank == 0:
+                    line["check"] = chk
+            else:                                                                    # node fallback: the database itself is checked below
+                want = sum(valid_windows(b, K) for b in all_bases)
+                line["check"] = {"valid_windows": want, "instances_equal_valid_windows": bool(want == result["n_instances"]),
+                                 "ok": bool(want == result["n_instances"])}
+        except Exception as e:                                                       # noqa: BLE001 -- reported, never fatal for the metric line
+            if rank == 0:
+                line["check"] = {"error": str(e)[:300], "ok": False}
+    result.pop("uniq", None); result.pop("cnts", None)
+
+    # ---- the database (untimed) ----
+    if not args.no_db:
+        import shutil
+        try:
+            if single:
+                dbdir, _ = shm_dir("mgc_db_")
+                try:
+                    t0 = time.perf_counter()
+                    wp = sess.write_database(os.path.join(dbdir, "db.meryl"), threads)
+                    wp["wall_s"] = time.perf_counter() - t0
+                    wp["vs_count_step"] = wp["wall_s"] / (ms_per_step / 1e3)
+                    line["db_write"] = wp
+                finally:
+                    shutil.rmtree(dbdir, ignore_errors=True)
+            elif dist is not None:
+                # every rank writes its part of ONE directory (rank 0 names it), rank 0 stitches; then the same reads through the
+                # in-process peer-copy form (rank 0 drives all devices) and the two directories are compared
+                name = [None]
+                if rank == 0:
+                    name[0], _ = shm_dir("mgc_sdb_")
+                dist.broadcast_object_list(name, src=0)
+                os.environ["MGC_SHARD_PROFILE"] = "1"
+                info = dict(path=os.path.join(name[0], "db.meryl"), w_prefix=cfg.w_prefix, host_threads=max(4, threads // world))
+                barrier()
+                t0 = time.perf_counter()
+                count.count_sharded(bases, K, db=info, keep_result=False)
+                barrier()
+                wall = time.perf_counter() - t0
+                os.environ.pop("MGC_SHARD_PROFILE", None)
+                stage_s = info.get("stage_s")
+                count.release_cached_sessions()
+                torch.cuda.empty_cache()
+                if rank == 0:
+                    dg, nfiles, nbytes = dir_digest(info["path"])
+                    line["db_write"] = {"wall_s": wall, "what": "count_sharded(db=...): count + device-encoded parts + stitch, one collective call",
+                                        "files": nfiles, "database_bytes": nbytes, "sha256": dg,
+                                        "rank0_stream": info.get("profile"), "vs_count_step": wall / (ms_per_step / 1e3)}
+                # the peer-copy form over the same devices needs their memory: every rank lets go of its reads first
+                keep_first = bases[:min(args.cpu_sample_reads, reads) * (READ_LEN + 1)].clone() if rank == 0 else None
+                del bases, all_bases
+                torch.cuda.empty_cache()
+                barrier()
+                if rank == 0:
+                    try:
+                        nb = []
+                        for r in range(world):
+                            with torch.cuda.device(r if not one_device else 0):
+                                nb.append(count.dev_synth_reads(SEED, genome_len, r * reads, reads, READ_LEN, 5000, 100))
+                        torch.cuda.synchronize()
+                        out = os.path.join(name[0], "node.meryl")
+                        np_ = count.count_node(cfg, nb, out, devices=[(r if not one_device else 0) for r in range(world)], host_threads=threads)
+                        dg2, _, _ = dir_digest(out)
+                        line["db_write"]["node_count"] = {k: np_[k] for k in ("total_s", "partition_s", "exchange_count_s", "close_s", "merge_parts_s",
+                                                                             "n_batches", "n_distinct", "bucket_bits")}
+                        line["db_write"]["node_count"]["sha256"] = dg2
+                        line["db_write"]["identical_to_node_count"] = bool(dg == dg2)
+                        del nb
+                    except Exception as e:                                           # noqa: BLE001
+                        line["db_write"]["node_count"] = {"error": str(e)[:300]}
+                    shutil.rmtree(name[0], ignore_errors=True)
+                    torch.cuda.empty_cache()
+                barrier()
+                bases = keep_first
+            else:
+                out = os.path.join(node_dir, "db.meryl")
+                dg, nfiles, nbytes = dir_digest(out)
+                # the same reads through ONE session
+                one = os.path.join(node_dir, "one.meryl")
+                cat = torch.cat(all_bases)
+                with count.Session(cfg, 0) as s1:
+                    s1.push_bases_device(cat)
+                    s1.count()
+                    s1.write_database(one, threads)
+                dg1, _, _ = dir_digest(one)
+                del cat
+                line["db_write"] = {"what": "mgc_count_node with %d virtual ranks on one device (part of every timed step)" % world, "files": nfiles,
+                                    "database_bytes": nbytes, "sha256": dg, "identical_to_single_session": bool(dg == dg1),
+                                    "node_profile": result.get("node_profile")}
+        except Exception as e:                                                       # noqa: BLE001
+            if rank == 0:
+                line.setdefault("db_write", {})["error"] = str(e)[:300]
+    if node_dir:
+        import shutil
+        shutil.rmtree(node_dir, ignore_errors=True)
+
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        n_distinct = result["n_distinct"]
-        line = {
-            "metric": "distinct k-mers counted/sec (whole node)",
-            "value": n_distinct / (dt / args.steps),
-            "unit": "distinct k-mers/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {
-                "workload": "meryl count k=21 on synthetic short reads: %d x %d bp reads per GPU (%.2f Gbp per GPU, "
-                            "30x of a %d bp genome, 0.5%% substitutions, 0.01%% N), inputs resident in HBM"
-                            % (reads, READ_LEN, reads * READ_LEN / 1e9, genome_len),
-                "k": K, "reads_per_gpu": reads, "bases_per_gpu": n_bases,
-                "n_distinct": n_distinct,
-                "parallelism": "1 GPU" if world == 1 else "%d GPUs: the top-bit buckets (64 files x ranges) in contiguous per-rank ranges, bucket-major point-to-point waves overlapped with the owner-side count" % world,
-            },
-        }
-        single = world == 1 and not force_sharded
         if single:
             n_inst = result["n_instances"]
             line["config"]["n_instances"] = n_inst
             line["config"]["w_prefix"] = result["w_prefix"]
             line["instances_per_s"] = n_inst / (dt / args.steps)
-        if prof_acc["pass_launches"]:                                    # N > 1: rank 0's owner-side passes
-            # The dominant kernel is a file's FIRST grouping pass.  Algorithmic bytes = key bytes it must read and write:
-            # 8 + 8 per k-mer for the wide pass, 8 + 4 when the pass narrows its output to 32-bit words (k <= ~25: the
-            # digit a key was grouped by is dropped, the second pass then moves 4 + 4) -- the library reports them per launch.
-            bp = prof_acc["by_pass"]
-            if not bp[0]["launches"]:                                    # sharded owner side: only the totals are collected
-                bp = [{"ms": prof_acc["pass_ms"], "launches": prof_acc["pass_launches"], "keys": prof_acc["pass_keys"],
-                       "bytes": prof_acc.get("pass_bytes", 16 * prof_acc["pass_keys"])}, {"ms": 0.0, "launches": 0, "keys": 0, "bytes": 0}]
-            achieved = bp[0]["bytes"] / (bp[0]["ms"] / 1e3) / 1e9
-            narrowed = bp[0]["bytes"] < 16 * bp[0]["keys"]
-            line["roofline"] = {
-                "kernel": "radix_group_kernel, first pass of a file (9-bit digit; %s)" %
-                          ("8 B k-mers in, 4 B narrowed words out" if narrowed else "8 B k-mers in and out"),
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(reads)[0] if single else None,
-                "traffic_source": (pmc_traffic(reads)[1] or "none: no committed PMC run of this workload") if single else None,
-                "measured": "HIP events around every pass launch of the timed steps" if single else
-                            "HIP events around every pass launch of rank 0's owner-side count in one extra untimed step",
-                "launches": bp[0]["launches"],
-                "avg_launch_ms": bp[0]["ms"] / bp[0]["launches"],
-                "algorithmic_bytes_per_launch": bp[0]["bytes"] / bp[0]["launches"],
-                "keys_per_launch": bp[0]["keys"] / bp[0]["launches"],
-            }
-            if bp[1]["launches"]:
-                a1 = bp[1]["bytes"] / (bp[1]["ms"] / 1e3) / 1e9
-                line["roofline"]["second_pass"] = {"achieved": a1, "frac": a1 / HBM_PEAK_GBS, "launches": bp[1]["launches"],
-                                                   "avg_launch_ms": bp[1]["ms"] / bp[1]["launches"],
-                                                   "algorithmic_bytes_per_launch": bp[1]["bytes"] / bp[1]["launches"]}
-            # the same passes priced the way SURVEY 8(d) prices a radix pass (8 + 8 B per k-mer whatever is really moved):
-            # comparable with earlier rounds' 0.47
-            eq = 16.0 * prof_acc["pass_keys"] / (prof_acc["pass_ms"] / 1e3) / 1e9
-            line["roofline"]["survey_accounting"] = {"bytes_per_key_per_pass": 16, "achieved": eq, "frac": eq / HBM_PEAK_GBS}
-        if single:
-            line["stage_ms_per_step"] = {capi.STAGE_NAMES[i]: prof_acc["stage_ms"][i] / args.steps
-                                         for i in range(capi.NUM_STAGES)}
-            if not args.no_check:
-                line["check"] = result_check(sess, bases, K, result["info"])
-            if not args.no_e2e:
-                # device encode + write of the timed result (no file input), then the whole CLI file -> database
-                import shutil
-                import tempfile
-                shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
-                dbdir = tempfile.mkdtemp(prefix="mgc_db_", dir=shm)
-                try:
-                    t0 = time.perf_counter()
-                    wp = sess.write_database(os.path.join(dbdir, "db.meryl"), min(32, os.cpu_count() or 8))
-                    wp["wall_s"] = time.perf_counter() - t0
-                    wp["vs_count_step"] = wp["wall_s"] / (ms_per_step / 1e3)
-                    line["db_write"] = wp
-                except Exception as e:                                  # reported, never fatal for the metric line
-                    line["db_write"] = {"error": str(e)[:300]}
-                finally:
-                    shutil.rmtree(dbdir, ignore_errors=True)
-                sess.close()
-                count.release_cached_sessions()
-                torch.cuda.empty_cache()
-                try:
-                    line["e2e"] = e2e_run(bases, reads, min(32, os.cpu_count() or 8))
-                except Exception as e:
-                    line["e2e"] = {"error": str(e)[:300]}
-            if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_reads, reads), os.cpu_count() or 1, bases)
+            line["stage_ms_per_step"] = {capi.STAGE_NAMES[i]: prof_acc["stage_ms"][i] / args.steps for i in range(capi.NUM_STAGES)}
+        elif stage_s:
+            line["stage_ms_one_profiled_step"] = {k: v * 1e3 for k, v in stage_s.items()}
+            line["stage_note"] = ("rank 0, the database-writing call: partition / plan / exchange+count (first_wave_exposed = the part of the "
+                                  "exchange nothing overlaps) / database (waiting for this rank's files) / stitch")
+        elif node_fallback and result.get("node_profile"):
+            npf = result["node_profile"]
+            line["stage_ms_per_step"] = {"partition": npf["partition_s"] * 1e3, "exchange+owner count": npf["exchange_count_s"] * 1e3,
+                                         "files": npf["close_s"] * 1e3, "stitch": npf["merge_parts_s"] * 1e3}
+        rf = roofline_object(prof_acc, ms_per_step, args.steps, reads, single,
+                             "over the timed steps" if single else "rank 0's owner-side count in one extra untimed step")
+        if rf:
+            line["roofline"] = rf
+        elif node_fallback:
+            line["roofline"] = {"note": "not collected in the one-process fallback (mgc_count_node owns its sessions)", "bound": "hbm",
+                                "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+
+    # ---- file -> database through the CLI, and the CPU leg (rank 0; the other ranks have let go of their memory) ----
+    if sess is not None:
+        sess.close()
+    count.release_cached_sessions()
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if not args.no_e2e and bases is not None:
+            try:
+                line["e2e"] = e2e_run(bases, min(reads, bases.numel() // (READ_LEN + 1)), threads, gpus=1 if one_device else world)
+                nd = line["e2e"].get("n_distinct")
+                if nd and line["e2e"].get("wall_s"):
+                    line["value_e2e"] = nd / line["e2e"]["wall_s"]
+                    line["value_e2e_note"] = "distinct k-mers / wall clock of `meryl count` file -> database (process start to exit), %d reads" % line["e2e"]["reads"]
+            except Exception as e:                                                   # noqa: BLE001
+                line["e2e"] = {"error": str(e)[:300]}
+        if not args.no_cpu_baseline and bases is not None:
+            line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_reads, reads, bases.numel() // (READ_LEN + 1)), os.cpu_count() or 1, bases)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)

@@ -349,6 +349,12 @@ typedef struct mgc_profile {
   uint64_t pass_bytes[2];
   uint64_t pass_keys[2];
   uint32_t pass_launches[2];
+  /* the sub-bucket count kernels (hash_count* / bitmap_count / lds_sort_count: one launch per file, on two alternating
+   * streams): sum of the launches' own durations (HIP events on the stream each is launched on), their ALGORITHMIC bytes
+   * (the keys read: 4 B narrowed, 8 / 16 B otherwise; the distinct suffixes + counts written) and keys */
+  double   finish_ms;
+  uint64_t finish_bytes, finish_keys;
+  uint32_t finish_launches, reserved2;
 } mgc_profile;
 int mgc_set_profiling(mgc_session *s, int enable);
 int mgc_get_profile(const mgc_session *s, mgc_profile *p);

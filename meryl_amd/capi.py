@@ -93,6 +93,11 @@ class Profile(ctypes.Structure):
         ("pass_bytes", ctypes.c_uint64 * 2),
         ("pass_keys", ctypes.c_uint64 * 2),
         ("pass_launches", ctypes.c_uint32 * 2),
+        ("finish_ms", ctypes.c_double),
+        ("finish_bytes", ctypes.c_uint64),
+        ("finish_keys", ctypes.c_uint64),
+        ("finish_launches", ctypes.c_uint32),
+        ("reserved2", ctypes.c_uint32),
     ]
 
 

@@ -1294,6 +1294,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     // streaming kernels stay on stream2: they share the buffer Y.
     static const bool alt_files = fork_huge && !(getenv("MGC_FINISH_ALT") && getenv("MGC_FINISH_ALT")[0] == '0');
     bool forked = false, need_join = false;          // forked: stream2 is ordered after everything st holds that it must see
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> fin_ev;       // profiling: around every file's count-kernel launch
+    uint64_t fin_keys = 0, fin_in_bytes = 0;
+    bool fin_narrow = false;
     std::vector<uint64_t> h_fallback_distinct(nb);
     std::vector<char> fallback(nb);
     for (uint32_t b = 0; b < nb; b++) {
@@ -1340,11 +1343,20 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
           HIP_TRY(s, hipStreamWaitEvent(st_huge, s->ev_fork, 0));
           forked = need_join = true;
         }
+        hipStream_t fst = on_second ? s->stream2 : st;
+        if (s->profiling) {
+          fin_ev.emplace_back(); (void)hipEventCreate(&fin_ev.back().first); (void)hipEventCreate(&fin_ev.back().second);
+          (void)hipEventRecord(fin_ev.back().first, fst);
+          fin_keys += h_counts[b];
+          fin_in_bytes += h_counts[b] * (narrow[b] ? 4u : (uint64_t)kbytes);
+          fin_narrow = fin_narrow || narrow[b];
+        }
         HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_nlarge[b],
                                            d_large + gbase[b], d_cnt_tmp + h_starts[b], d_group + gbase[b], stream, (void *)Y, st_huge,
                                            // the list pays off only when a good part of the 2^t grid is empty
                                            (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b])) ? d_nz + gbase[b] : nullptr,
-                                           d_nzcount + b, on_second ? s->stream2 : st, narrow[b] != 0, tr_a[b], tr_b[b]));
+                                           d_nzcount + b, fst, narrow[b] != 0, tr_a[b], tr_b[b]));
+        if (s->profiling) (void)hipEventRecord(fin_ev.back().second, fst);
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
         fallback[b] = true;
@@ -1400,6 +1412,16 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     }
     tm.end(MGC_STAGE_RLE);
     s->prof.stage_launches[MGC_STAGE_RLE] = 4 * nb;
+    if (s->profiling) {
+      HIP_TRY(s, hipStreamSynchronize(st));
+      for (auto &pe : fin_ev) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pe.first, pe.second) == hipSuccess) { s->prof.finish_ms += ms; s->prof.finish_launches++; }
+        (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second);
+      }
+      s->prof.finish_keys = fin_keys;
+      s->prof.finish_bytes = fin_in_bytes + nd * (fin_narrow ? 8u : (uint64_t)kbytes + 4u);
+    }
   }
 
   // ---- block offsets ----

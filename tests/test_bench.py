@@ -1,0 +1,52 @@
+"""bench.py end to end on a GPU: the N = 1 line and the N = 2 line carry every object the contract asks for.  On a one-GPU box
+the two ranks of `--gpus 2` are told to share device 0 (MGC_BENCH_ONE_DEVICE=1): RCCL refuses that, rank 0 falls back to the
+in-process peer-copy form and says so in the line; on a multi-GPU box the same command exercises real RCCL ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]                   # ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line_is_complete(native_lib):
+    d = _run(["--reads", "2000000", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "200000"])
+    assert d["n_gpus"] == 1 and d["unit"] == "distinct k-mers/s" and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["check"]["ok"] is True
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and "hash_count" in rf["kernel"]
+    assert 0 < rf["kernel_time_share_of_step"] < 1.5 and 0 < rf["sort_pass"]["frac"] < 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["db_write"]["data_bytes"] > 0 and d["e2e"]["wall_s"] > 0 and d["value_e2e"] > 0
+    assert abs(sum(d["stage_ms_per_step"].values()) - d["ms_per_step"]) < 0.5 * d["ms_per_step"]
+
+
+def test_bench_two_ranks_line_is_complete(native_lib):
+    import torch
+    one = torch.cuda.device_count() < 2
+    d = _run(["--gpus", "2", "--reads", "1500000", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "200000"],
+             {"MGC_BENCH_ONE_DEVICE": "1"} if one else None)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["check"]["ok"] is True
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["db_write"]["files"] == 129
+    if one:
+        assert "RCCL refused" in d["config"]["transport"] and d["db_write"]["identical_to_single_session"] is True
+    else:
+        assert "RCCL" in d["config"]["transport"] and d["db_write"]["identical_to_node_count"] is True
+        assert d["check"]["keys_ascending_across_rank_boundaries"] is True
+        assert 0 < d["roofline"]["frac"] < 1 and "stage_ms_one_profiled_step" in d
+    assert "roofline" in d and d["e2e"]["wall_s"] > 0
