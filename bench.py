@@ -388,23 +388,25 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         transport = "RCCL point-to-point waves, one process per GPU"
-        if world > 1:
-            try:                                                 # two ranks on one device: RCCL says "Duplicate GPU detected"
+        try:                                                     # two ranks on one device: RCCL says "Duplicate GPU detected"
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            if world > 1:
                 probe = torch.ones(1, device="cuda")
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
-            except Exception as e:                               # noqa: BLE001 -- whatever RCCL raises, the fallback is the same
-                why = str(e).strip().splitlines()[-1][:160] if str(e).strip() else type(e).__name__
-                transport = "peer copies between %d virtual ranks of ONE process (mgc_count_node): RCCL refused the %d ranks (%s)" % (world, world, why)
-                try:
-                    dist.destroy_process_group()
-                except Exception:                                # noqa: BLE001
-                    pass
-                dist = None
-                if rank != 0:
-                    os._exit(0)                                  # rank 0 carries the whole job in the fallback
+        except Exception as e:                                   # noqa: BLE001 -- whatever RCCL raises, the fallback is the same
+            if world == 1:
+                raise
+            why = str(e).strip().splitlines()[-1][:160] if str(e).strip() else type(e).__name__
+            transport = "peer copies between %d virtual ranks of ONE process (mgc_count_node): RCCL refused the %d ranks (%s)" % (world, world, why)
+            try:
+                dist.destroy_process_group()
+            except Exception:                                    # noqa: BLE001
+                pass
+            dist = None
+            if rank != 0:
+                os._exit(0)                                      # rank 0 carries the whole job in the fallback
     node_fallback = world > 1 and dist is None
     # the in-tree library is normally up to date (it travels with the snapshot); if it has to be rebuilt, one rank does it
     if local_rank == 0 or node_fallback:

@@ -86,6 +86,8 @@ int mdb_writer_add_histogram(mdb_writer *w, const uint64_t *values, const uint64
 /* merylBlockWriter::finish() + ~merylFileWriter(): per-file indexes, master
  * index with the value histogram.  Frees the writer.  0 on success. */
 int mdb_writer_close(mdb_writer *w);
+/* Frees a writer without writing the indexes (error paths: nothing that looks like a finished database is left behind). */
+void mdb_writer_discard(mdb_writer *w);
 
 const char *mdb_last_error(void);
 

@@ -28,7 +28,7 @@ SYMBOLS = (
     "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases", "mgc_set_result_budget", "mgc_result_out_of_core",
     # include/meryl_db.h
     "mdb_writer_open", "mdb_writer_open_ex", "mdb_merge_parts", "mdb_writer_add_block", "mdb_writer_add_block_labelled",
-    "mdb_writer_add_encoded", "mdb_writer_reserve_encoded", "mdb_writer_write_at", "mdb_writer_add_histogram", "mdb_writer_close", "mdb_last_error",
+    "mdb_writer_add_encoded", "mdb_writer_reserve_encoded", "mdb_writer_write_at", "mdb_writer_add_histogram", "mdb_writer_close", "mdb_writer_discard", "mdb_last_error",
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_read_file_ex",
     "mdb_reader_file_index", "mdb_reader_block_header", "mdb_reader_read_block_raw", "mdb_reader_close",
     "mdb_free", "mgc_write_database", "mgc_write_database_profiled",

@@ -433,6 +433,14 @@ bool get_u64(FILE *f, uint64_t &v) { return fread(&v, 8, 1, f) == 1; }
 
 }  // namespace
 
+// Lets go of a writer WITHOUT writing indexes or a master index (a caller whose setup failed after the writer was opened:
+// closing would leave a complete-looking empty database at the output path although the call fails).
+extern "C" void mdb_writer_discard(mdb_writer *w) {
+  if (!w) return;
+  for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++) if (w->dat[ff] >= 0) { (void)close(w->dat[ff]); w->dat[ff] = -1; }
+  delete w;
+}
+
 extern "C" int mdb_writer_close(mdb_writer *w) {
   if (!w) return MGC_EINVAL;
   bool ok = !w->failed.load();
@@ -503,6 +511,27 @@ extern "C" int mdb_merge_parts(const char *path, uint32_t n_parts) {
     for (uint64_t i = 0; i < nh && ok; i++) { uint64_t v = 0, o = 0; ok = get_u64(f, v) && get_u64(f, o); if (ok) w->hist_extra[v] += o; }
     fclose(f);
     if (!ok) { db_err("mdb_merge_parts: bad part file in '%s'", path); delete w; return MGC_EINVAL; }
+  }
+  if (!w) { db_err("mdb_merge_parts: no parts in '%s'", path); return MGC_EINVAL; }
+  // Validate EVERYTHING first (ranges ascend over the parts, every contributing data file exists with the size its side
+  // file names): nothing is renamed or appended until the whole stitch is known to be possible, so a failure here leaves
+  // the parts as they were and the call can be repeated.
+  for (uint32_t ff = 0; ff < MGC_NUM_FILES; ff++) {
+    uint64_t last = 0; bool any = false;
+    for (uint32_t p = 0; p < n_parts; p++) {
+      const PartFile &pf = parts[p][ff];
+      if (pf.idx.empty()) continue;
+      if (any && last >= pf.idx.front().prefix) { db_err("mdb_merge_parts: prefix ranges of the parts overlap in '%s'", path); delete w; return MGC_EINVAL; }
+      for (size_t i = 1; i < pf.idx.size(); i++)
+        if (pf.idx[i - 1].prefix >= pf.idx[i].prefix) { db_err("mdb_merge_parts: a part's index is not ascending in '%s'", path); delete w; return MGC_EINVAL; }
+      last = pf.idx.back().prefix; any = true;
+      struct stat st;
+      if (stat(part_data_name(dir, ff, p).c_str(), &st) != 0 || (uint64_t)st.st_size != pf.bytes) {
+        db_err("mdb_merge_parts: '%s' is missing or not of the size its part's side file names", part_data_name(dir, ff, p).c_str());
+        delete w;
+        return MGC_EINVAL;
+      }
+    }
   }
   bool ok = true;
   std::vector<char> buf(8u << 20);
@@ -615,6 +644,13 @@ extern "C" int mdb_reader_histogram(const mdb_reader *r, uint64_t *values, uint6
 namespace {
 bool load_file_index(mdb_reader *r, uint32_t ff, std::vector<FileIndexEntry> &idx) {
   const uint64_t nblocks = 1ull << r->info.num_blocks_bits;
+  // the header's block count is not trusted before the index file has been seen to hold that many entries (a hostile
+  // master index could otherwise ask for 2^40 x 24 bytes: std::bad_alloc across the extern "C" boundary)
+  struct stat ist;
+  if (stat(block_name(r->dir, ff, true).c_str(), &ist) != 0 || (uint64_t)ist.st_size < nblocks * sizeof(FileIndexEntry)) {
+    db_err("read_file: '%s' is missing or shorter than the blocks the master index names", block_name(r->dir, ff, true).c_str());
+    return false;
+  }
   idx.assign(nblocks, FileIndexEntry());
   FILE *fi = fopen(block_name(r->dir, ff, true).c_str(), "rb");
   const bool ok = fi && fread(idx.data(), sizeof(FileIndexEntry), nblocks, fi) == nblocks;
@@ -789,6 +825,9 @@ extern "C" int mdb_reader_read_file_ex(mdb_reader *r, uint32_t ff, uint64_t **kl
   std::vector<uint64_t> gather;
   for (uint64_t bb = 0; bb < nblocks && ok; bb++) {
     const FileIndexEntry &e = idx[bb];
+    // a slot the writer was never handed a block for (mdb_writer_add_block lets callers skip empty prefixes; write_indexes
+    // then leaves {prefix, 0, 0}): nothing to decode -- run_dump_file skips it the same way
+    if (e.n_kmers == 0) continue;
     const uint64_t *words = nullptr; uint64_t nbits = 0;
     if (e.position >= fsize || (e.position & 7) || !stuffed_in_memory(file + e.position, fsize + 16 - e.position, gather, &words, &nbits)) { ok = false; break; }
     BitReader br; br.w = words; br.nbits = nbits;

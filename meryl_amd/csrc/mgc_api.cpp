@@ -517,16 +517,31 @@ static int cut_batch(mgc_session *s) {
   if (rc != MGC_OK) return rc;
   if (s->text_open && h.error) return MGC_OK;              // the open file is about to be refused and rolled back: not now
   if (s->fill_len < s->batch_limit) return MGC_OK;         // the bound was pessimistic
+  if (s->fill_len < s->no_cut_below) return MGC_OK;        // no sequence boundary was found last time: look again once the stream has doubled
   uint64_t *d_last = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_TEXT_STATE].p) +
                                                   ((mgc::text_parse_state_bytes() + 7) / 8) * 8);
   uint64_t cut = 0;
   HIP_TRY(s, mgc::launch_last_breaker(stage_ptr(s, s->fill), s->fill_len, d_last, s->st_in));
   HIP_TRY(s, hipMemcpyAsync(&cut, d_last, sizeof(cut), hipMemcpyDeviceToHost, s->st_in));
   HIP_TRY(s, hipStreamSynchronize(s->st_in));
-  if (cut == 0) return MGC_OK;                              // one sequence longer than a batch: keep staging
+  uint64_t overlap = 0;
+  if (cut == 0) {
+    // One sequence longer than a batch (this used to return and re-scan the whole staged stream on every later
+    // push -- O(n^2) -- while staging grew without bound).  The reference spills inside a sequence too; here the batch is cut
+    // at the end of what is staged and the last k-1 bases are staged AGAIN in front of the next batch: a window that starts
+    // in them is incomplete in this batch and complete in the next, so no k-mer is lost or counted twice (the rule the
+    // node count cuts its slices by).  `compress` needs whole sequences: such a stream waits until it has doubled.
+    if (s->cfg.homopoly_compress || s->text_open || s->fill_len < 4ull * s->cfg.k) {
+      s->no_cut_below = s->fill_len * 2;
+      return MGC_OK;
+    }
+    cut = s->fill_len;
+    overlap = s->cfg.k - 1;
+  }
   rc = join_worker(s);                                      // the previous batch is done: its staging buffer is free, R is stable
   if (rc != MGC_OK) return rc;
-  const uint64_t tail = s->fill_len - cut;
+  const uint64_t tail = s->fill_len - cut + overlap;
+  cut -= overlap;                                           // the tail starts k-1 bases before the cut ...
   const int other = s->fill ^ 1;
   HIP_TRY(s, s->ensure_preserve(stage_id(other), tail + (1u << 20), 0, s->st_in));
   if (tail) HIP_TRY(s, hipMemcpyAsync(stage_ptr(s, other), stage_ptr(s, s->fill) + cut, tail, hipMemcpyDeviceToDevice, s->st_in));
@@ -536,6 +551,8 @@ static int cut_batch(mgc_session *s) {
   const int which = s->fill;
   s->fill = other;
   s->fill_len = tail;
+  s->no_cut_below = 0;
+  cut += overlap;                                           // ... and the batch still ends at the cut
   s->worker_rc = MGC_OK;
   s->worker_active = true;
   s->worker = std::thread([s, which, cut] { s->worker_rc = count_staged_batch(s, which, cut); });

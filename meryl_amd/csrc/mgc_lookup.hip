@@ -32,8 +32,9 @@ template <> struct LkOps<K128> {
 
 template <typename K>
 __device__ __forceinline__ u32 lk_find(const K *__restrict__ keys, const u32 *__restrict__ vals, const u64 *__restrict__ index,
-                                       u32 shift, K q) {
+                                       u32 shift, K q, u64 n_index = ~0ull /* 2^index_bits: the index holds one entry more */) {
   const u64 p = LkOps<K>::bucket(q, shift);
+  if (p >= n_index) return 0u;                        // a query with bits above 2k (queries are looked up as given): not a k-mer, not stored
   u64 lo = index[p];
   const u64 end = index[p + 1];
   u64 hi = end;
@@ -47,9 +48,10 @@ __device__ __forceinline__ u32 lk_find(const K *__restrict__ keys, const u32 *__
 template <typename K>
 __global__ __launch_bounds__(256)
 void lookup_values_kernel(const K *__restrict__ keys, const u32 *__restrict__ vals, const u64 *__restrict__ index, u32 shift,
-                          const K *__restrict__ q, u64 n, u32 *__restrict__ out) {
+                          const K *__restrict__ q, u64 n, u32 *__restrict__ out, u64 n_index) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
-  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = lk_find<K>(keys, vals, index, shift, q[i]);
+  // queries come from the caller as they are: one with bits above 2k must not index past the table
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = lk_find<K>(keys, vals, index, shift, q[i], n_index);
 }
 
 // 2-bit code of a base (A0 C1 T2 G3, reference.rst:525), -1 for anything else
@@ -371,10 +373,10 @@ extern "C" int mgc_lookup_values(const mgc_lookup *t, const void *d_kmers, uint6
   if (g > 65536) g = 65536;
   if (t->kw == 2)
     hipLaunchKernelGGL((mgc::lookup_values_kernel<mgc::K128>), dim3((uint32_t)g), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const mgc::K128 *>(t->d_keys),
-                       t->d_vals, reinterpret_cast<const mgc::u64 *>(t->d_index), t->shift, reinterpret_cast<const mgc::K128 *>(d_kmers), (mgc::u64)n, d_out);
+                       t->d_vals, reinterpret_cast<const mgc::u64 *>(t->d_index), t->shift, reinterpret_cast<const mgc::K128 *>(d_kmers), (mgc::u64)n, d_out, (mgc::u64)1 << t->index_bits);
   else
     hipLaunchKernelGGL((mgc::lookup_values_kernel<mgc::u64>), dim3((uint32_t)g), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const mgc::u64 *>(t->d_keys),
-                       t->d_vals, reinterpret_cast<const mgc::u64 *>(t->d_index), t->shift, reinterpret_cast<const mgc::u64 *>(d_kmers), (mgc::u64)n, d_out);
+                       t->d_vals, reinterpret_cast<const mgc::u64 *>(t->d_index), t->shift, reinterpret_cast<const mgc::u64 *>(d_kmers), (mgc::u64)n, d_out, (mgc::u64)1 << t->index_bits);
   return lk_rc(hipGetLastError(), "lookup_values");
 }
 

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,7 +26,11 @@ inline void set_err(std::string *dst, const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  if (dst) *dst = buf;
+  if (dst) {                                         // a session's error string is written by its worker thread and by the pushing thread
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    *dst = buf;
+  }
   thread_last_error() = buf;
 }
 }  // namespace mgc
@@ -149,6 +154,7 @@ struct mgc_session {
   // is parked as a sorted run -- in HBM while there is room, in pinned host DRAM otherwise -- and the runs are merged once,
   // at the end (mgc_runs.cpp): into one device-resident result when that fits, chunk by chunk into the consumer otherwise.
   uint64_t    batch_limit = 0;            // bases per batch; 0 = derive from free HBM at the first input
+  uint64_t    no_cut_below = 0;           // a cut found no sequence boundary: do not scan again before the stream is this long
   bool        have_r = false;             // at least one batch result has been parked
   struct mgc_runs *runs = nullptr;        // the parked batch results (mgc_runs.cpp)
   bool        ooc = false;                // counted, and the result exists only as runs (too large to collapse into HBM)

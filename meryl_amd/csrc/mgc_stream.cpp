@@ -323,7 +323,11 @@ int mgc_db_stream::process(const Range &r) {
 }
 
 extern "C" const char *mgc_db_stream_error(const mgc_db_stream *d) {
-  return d ? d->err.c_str() : mgc::thread_last_error().c_str();
+  if (!d) return mgc::thread_last_error().c_str();
+  // the stream's threads may set the (sticky, written once) error while this is read: copy it under the lock
+  std::lock_guard<std::mutex> g(const_cast<mgc_db_stream *>(d)->mu);
+  mgc::thread_last_error() = d->err;
+  return mgc::thread_last_error().c_str();
 }
 
 extern "C" mgc_db_stream *mgc_db_stream_open(const char *path, uint32_t k, uint32_t w_prefix, uint32_t label_size, uint64_t label,
@@ -354,7 +358,7 @@ extern "C" mgc_db_stream *mgc_db_stream_open(const char *path, uint32_t k, uint3
   if (!ok) {
     set_err(nullptr, "mgc_db_stream_open: HIP stream / pinned buffer setup failed");
     d->closing = true; d->copy_done = true;
-    (void)mdb_writer_close(d->w);
+    mdb_writer_discard(d->w);                               // no empty database at the output path when the open fails
     for (int i = 0; i < NSLOT; i++) if (d->pinned[i]) (void)hipHostFree(d->pinned[i]);
     delete d;
     return nullptr;
@@ -696,6 +700,13 @@ extern "C" int mgc_db_merge(const char *const *inputs, uint32_t n_inputs, int op
     if (!rd[i]) { set_err(nullptr, "mgc_db_merge: %s", mdb_last_error()); close_all(); return MGC_EINVAL; }
     mdb_info inf;
     mdb_reader_info(rd[i], &inf);
+    // the merge combines VALUES only: labels would be dropped and a multiset's repeated k-mers folded -- refuse rather than
+    // write something that silently differs
+    if (inf.label_size != 0 || (inf.flags & 1u)) {
+      set_err(nullptr, "mgc_db_merge: '%s' %s: not supported by this merge", inputs[i], inf.label_size ? "stores labels" : "is a multiset");
+      close_all();
+      return MGC_EUNSUPPORTED;
+    }
     if (i == 0) first = inf;
     else if (inf.k != first.k) {
       set_err(nullptr, "mgc_db_merge: '%s' holds %u-mers, '%s' %u-mers", inputs[i], inf.k, inputs[0], first.k);   // merylOp.C: kmer size mismatch

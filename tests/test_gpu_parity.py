@@ -1332,3 +1332,29 @@ def test_out_of_core_result_larger_than_the_budget_streams_from_host_runs(ops, o
         slo, shi, cnt = blocks[p]
         assert np.array_equal(slo, wlo[a:b] & np.uint64(mask_lo)) and np.array_equal(cnt, wcn[a:b])
     assert sum(len(v[2]) for v in blocks.values()) == want_info.n_distinct
+
+
+@pytest.mark.parametrize("k", [21, 51])
+def test_one_sequence_longer_than_a_batch_is_cut_with_overlap(ops, oracle_lib, torch_cuda, k):
+    """A chromosome-sized sequence pushed without any breaker, batches far smaller than it: the staged stream is cut at its end
+    and the last k-1 bases are staged again in front of the next batch (the reference spills inside a sequence too,
+    merylOp-countThreads.C:323-379) -- no quadratic re-scan, no unbounded staging, the single pass's result."""
+    from meryl_amd import capi
+    rng = np.random.default_rng(k)
+    seq = "".join("ACGT"[i] for i in rng.integers(0, 4, 1_500_000))
+    seq = seq[:700_000] + "N" + seq[700_001:]                              # one invalid base somewhere inside
+    stream = seq + "." + seq[:50_000] + "."
+    cfg = capi.configure(k, len(stream), 1 << 30)
+    with ops.Session(cfg) as s:
+        s.push_bases(stream, end_of_sequence=False)
+        s.count()
+        want = s.result_wide()
+    with ops.Session(cfg) as s:
+        s.set_batch_bases(200_000)
+        for i in range(0, len(stream), 70_001):
+            s.push_bases(stream[i:i + 70_001], end_of_sequence=False)
+        s.count()
+        got = s.result_wide()
+        assert s.profile().n_batches >= 6
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
