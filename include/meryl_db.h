@@ -221,6 +221,9 @@ int mgc_write_database_profiled(struct mgc_session *s, const char *path, int hos
  * encoded on the device and written to `output` (geometry of the first input).  All inputs must hold the same k.
  * Text of a failure: mgc_db_stream_error(NULL). */
 int mgc_db_merge(const char *const *inputs, uint32_t n_inputs, int op, const char *output, int device, int host_threads);
+/* The single-input operations over a whole database (value_op = MGC_VALUE_*: less-than ... not-equal-to against `constant`,
+ * increase ... modulo by it; src/meryl/merylOp-nextMer.C:490-557): k-mers whose new value is 0 are not written. */
+int mgc_db_filter(const char *input, int value_op, uint64_t constant, const char *output, int device, int host_threads);
 
 /* ONE count spread over the GPUs of a node, from one process (meryl_amd/csrc/mgc_node.cpp): rank r's reads are the
  * n_bases[r] bytes at d_bases[r] on device devices[r] (the base stream mgc_push_bases takes; with cfg->homopoly_compress

@@ -165,18 +165,48 @@ int mgc_dev_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t ke
  * hold it combined) and of merylBlockWriter::finish() folding the batches a memory-limited count spilled.  Step 1 returns
  * the output length (synchronises the stream), step 2 writes d_keys_out / d_counts_out (that many entries), with the
  * same inputs and the workspace step 1 left.  Sums wrap mod 2^32 like the reference's kmvalu arithmetic. */
-#define MGC_MERGE_UNION_SUM     0     /* opUnionSum      src/meryl/merylOp-nextMer.C:572-579 */
-#define MGC_MERGE_UNION_MIN     1     /* opUnionMin      :560-565 */
-#define MGC_MERGE_UNION_MAX     2     /* opUnionMax      :566-571 */
-#define MGC_MERGE_INTERSECT_SUM 3     /* opIntersectSum  :604-612 (k-mers in BOTH inputs) */
-#define MGC_MERGE_INTERSECT_MIN 4     /* opIntersectMin  :586-594 */
-#define MGC_MERGE_INTERSECT_MAX 5     /* opIntersectMax  :595-603 */
+#define MGC_MERGE_UNION_SUM     0     /* opUnionSum      src/meryl/merylOp-nextMer.C:571-573 (findSumCount :43-48) */
+#define MGC_MERGE_UNION_MIN     1     /* opUnionMin      :563-565 */
+#define MGC_MERGE_UNION_MAX     2     /* opUnionMax      :567-569 */
+#define MGC_MERGE_INTERSECT_SUM 3     /* opIntersectSum  :590-593 (k-mers in BOTH inputs) */
+#define MGC_MERGE_INTERSECT_MIN 4     /* opIntersectMin  :580-583 */
+#define MGC_MERGE_INTERSECT_MAX 5     /* opIntersectMax  :585-588 */
+#define MGC_MERGE_INTERSECT     6     /* opIntersect     :575-578: in both, the FIRST input's value */
+#define MGC_MERGE_SUBTRACT      7     /* opSubtract      :595-602 + subtractCount :51-62: in A; a - b while a > b, otherwise dropped */
+#define MGC_MERGE_DIFFERENCE    8     /* opDifference    :604-607: in A and not in B */
+#define MGC_MERGE_SYMMETRIC_DIFFERENCE 9  /* opSymmetricDifference :609-612: in exactly one input */
+#define MGC_MERGE_UNION        10     /* opUnion         :559-561: value = number of inputs holding the k-mer (mgc_db_merge only) */
 size_t mgc_dev_merge_workspace_bytes(uint64_t na, uint64_t nb);
 int mgc_dev_merge_count(const void *d_keys_a, uint64_t na, const void *d_keys_b, uint64_t nb, uint32_t key_words, int op,
                         void *d_workspace, size_t workspace_bytes, uint64_t *n_out, void *stream);
 int mgc_dev_merge_emit(const void *d_keys_a, const uint32_t *d_counts_a, uint64_t na,
                        const void *d_keys_b, const uint32_t *d_counts_b, uint64_t nb, uint32_t key_words, int op,
                        void *d_workspace, size_t workspace_bytes, void *d_keys_out, uint32_t *d_counts_out, void *stream);
+/* step 1 with the values at hand: MGC_MERGE_SUBTRACT needs them to know what is written (mgc_dev_merge_count refuses it) */
+int mgc_dev_merge_count_values(const void *d_keys_a, const uint32_t *d_counts_a, uint64_t na, const void *d_keys_b,
+                               const uint32_t *d_counts_b, uint64_t nb, uint32_t key_words, int op, void *d_workspace,
+                               size_t workspace_bytes, uint64_t *n_out, void *stream);
+
+/* One (k-mer, value) stream through a single-input operation of src/meryl/merylOp-nextMer.C:490-557: the value filters
+ * (the value passes or the k-mer is dropped) and the arithmetic operations (with the reference's overflow / underflow /
+ * divide-by-zero results; a k-mer whose new value is 0 is dropped, :470-474).  Two steps like the merge. */
+#define MGC_VALUE_LESS_THAN     0     /* opLessThan     :490-492  value <  constant */
+#define MGC_VALUE_GREATER_THAN  1     /* opGreaterThan  :494-496 */
+#define MGC_VALUE_AT_LEAST      2     /* opAtLeast      :498-500 */
+#define MGC_VALUE_AT_MOST       3     /* opAtMost       :502-504 */
+#define MGC_VALUE_EQUAL_TO      4     /* opEqualTo      :506-508 */
+#define MGC_VALUE_NOT_EQUAL_TO  5     /* opNotEqualTo   :510-512 */
+#define MGC_VALUE_INCREASE      6     /* opIncrease     :514-519 */
+#define MGC_VALUE_DECREASE      7     /* opDecrease     :521-526 */
+#define MGC_VALUE_MULTIPLY      8     /* opMultiply     :528-533 */
+#define MGC_VALUE_DIVIDE        9     /* opDivide       :535-540 */
+#define MGC_VALUE_DIVIDE_ROUND 10     /* opDivideRound  :541-550 */
+#define MGC_VALUE_MODULO       11     /* opModulo       :552-557 */
+size_t mgc_dev_select_workspace_bytes(uint64_t n);
+int mgc_dev_select_count(const void *d_keys, const uint32_t *d_values, uint64_t n, uint32_t key_words, int value_op, uint64_t constant,
+                         void *d_workspace, size_t workspace_bytes, uint64_t *n_out, void *stream);
+int mgc_dev_select_emit(const void *d_keys, const uint32_t *d_values, uint64_t n, uint32_t key_words, int value_op, uint64_t constant,
+                        void *d_workspace, size_t workspace_bytes, void *d_keys_out, uint32_t *d_values_out, void *stream);
 
 /* Homopolymer compression of a base stream (the `compress` word: merylInput.C:
  * 237-240,261-268 calls homopolyCompress() on every chunk loadBases returns,

@@ -24,7 +24,8 @@ SYMBOLS = (
     "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_staged_bases", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_push_text_file", "mgc_push_text_file_range", "mgc_text_record_start", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_copy_result_device",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish", "mgc_finish_labelled",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_dev_synth_reads_ex", "mgc_version",
-    "mgc_dev_merge_workspace_bytes", "mgc_dev_merge_count", "mgc_dev_merge_emit",
+    "mgc_dev_merge_workspace_bytes", "mgc_dev_merge_count", "mgc_dev_merge_count_values", "mgc_dev_merge_emit",
+    "mgc_dev_select_workspace_bytes", "mgc_dev_select_count", "mgc_dev_select_emit",
     "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases", "mgc_set_result_budget", "mgc_result_out_of_core",
     # include/meryl_db.h
     "mdb_writer_open", "mdb_writer_open_ex", "mdb_merge_parts", "mdb_writer_add_block", "mdb_writer_add_block_labelled",
@@ -33,7 +34,7 @@ SYMBOLS = (
     "mdb_reader_file_index", "mdb_reader_block_header", "mdb_reader_read_block_raw", "mdb_reader_close",
     "mdb_free", "mgc_write_database", "mgc_write_database_profiled",
     "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_stream_queued", "mgc_db_stream_done", "mgc_db_stream_wait_buffers",
-    "mgc_runs_open", "mgc_runs_add", "mgc_runs_write", "mgc_runs_get_profile", "mgc_runs_error", "mgc_runs_close", "mgc_get_runs_profile", "mgc_db_merge", "mgc_count_node", "mgc_count_node_batched", "mgc_count_node_staged", "mgc_node_plan",
+    "mgc_runs_open", "mgc_runs_add", "mgc_runs_write", "mgc_runs_get_profile", "mgc_runs_error", "mgc_runs_close", "mgc_get_runs_profile", "mgc_db_merge", "mgc_db_filter", "mgc_count_node", "mgc_count_node_batched", "mgc_count_node_staged", "mgc_node_plan",
     # include/meryl_lookup.h
     "mgc_lookup_load", "mgc_lookup_estimate", "mgc_lookup_from_device", "mgc_lookup_free", "mgc_lookup_get_info", "mgc_lookup_error",
     "mgc_lookup_values", "mgc_lookup_stream", "mgc_lookup_existence",
@@ -275,6 +276,11 @@ def lib():
     sig("mgc_dev_merge_workspace_bytes", sz, u64, u64)
     sig("mgc_dev_merge_count", i32, vp, u64, vp, u64, u32, i32, vp, sz, P(u64), vp)
     sig("mgc_dev_merge_emit", i32, vp, vp, u64, vp, vp, u64, u32, i32, vp, sz, vp, vp, vp)
+    sig("mgc_dev_merge_count_values", i32, vp, vp, u64, vp, vp, u64, u32, i32, vp, sz, P(u64), vp)
+    sig("mgc_dev_select_workspace_bytes", sz, u64)
+    sig("mgc_dev_select_count", i32, vp, vp, u64, u32, i32, u64, vp, sz, P(u64), vp)
+    sig("mgc_dev_select_emit", i32, vp, vp, u64, u32, i32, u64, vp, sz, vp, vp, vp)
+    sig("mgc_db_filter", i32, ctypes.c_char_p, i32, u64, ctypes.c_char_p, i32, i32)
     sig("mgc_dev_homopoly_workspace_bytes", sz, u64)
     sig("mgc_dev_homopoly_compress", i32, vp, u64, vp, P(u64), vp, sz, vp)
     sig("mgc_dev_synth_reads", i32, u64, u64, u64, u64, u32, u32, u32, vp, vp)

@@ -148,7 +148,8 @@ def count_node(cfg, bases, path, devices=None, host_threads=8, batch_bases=0):
     return prof.as_dict()
 
 
-MERGE_OPS = {"union-sum": 0, "union-min": 1, "union-max": 2, "intersect-sum": 3, "intersect-min": 4, "intersect-max": 5}
+MERGE_OPS = {"union-sum": 0, "union-min": 1, "union-max": 2, "intersect-sum": 3, "intersect-min": 4, "intersect-max": 5,
+             "intersect": 6, "subtract": 7, "difference": 8, "symmetric-difference": 9}
 
 
 def dev_merge(keys_a, counts_a, keys_b, counts_b, op="union-sum"):
@@ -162,8 +163,8 @@ def dev_merge(keys_a, counts_a, keys_b, counts_b, op="union-sum"):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     n = ctypes.c_uint64(0)
     code = MERGE_OPS[op]
-    capi.check(L.mgc_dev_merge_count(_ptr(keys_a), na, _ptr(keys_b), nb, kw, code, _ptr(ws), ws_bytes, ctypes.byref(n),
-                                     _stream_ptr()), "mgc_dev_merge_count")
+    capi.check(L.mgc_dev_merge_count_values(_ptr(keys_a), _ptr(counts_a), na, _ptr(keys_b), _ptr(counts_b), nb, kw, code, _ptr(ws), ws_bytes,
+                                            ctypes.byref(n), _stream_ptr()), "mgc_dev_merge_count_values")
     out_k = _u64(n.value * kw, dev)
     if kw == 2:
         out_k = out_k.view(n.value, 2)

@@ -7,9 +7,10 @@
 // nesting :133-153), the stderr narrative of src/meryl/merylOp-count.C:324-401
 // (including the line Canu parses, :398-401), and the debug verbs `print` and
 // `dumpIndex` (src/meryl/meryl.C:36-46, src/meryl/merylOp-nextMer.C:665-677) on the
-// databases it writes.  Everything that is not on the count path (union-sum,
-// histogram, lookup ...) is refused with a message -- SURVEY.md section 8 marks it
-// out of scope.
+// databases it writes.  Beyond the count path: `histogram`, `dumpFile`, the set operations over
+// databases (union[-min|-max|-sum], intersect[-min|-max|-sum], subtract, difference, symmetric-difference;
+// merylOp-nextMer.C:559-613) and the single-input value filters / arithmetic (less-than ... modulo; :490-557), all merged on
+// the device.  What stays refused: statistics, compare, ploidy, Canu sequence stores (segment=), CRAM.
 #include "../../include/meryl_db.h"
 #include "../../include/meryl_gpu_count.h"
 #include "../../include/meryl_seq.h"
@@ -55,7 +56,7 @@ bool has_compressed_suffix(const std::string &n) {
   return false;
 }
 
-enum OpKind { OP_NONE, OP_COUNT, OP_COUNT_FORWARD, OP_COUNT_REVERSE, OP_PRINT, OP_DUMPINDEX, OP_HISTOGRAM, OP_DUMPFILE, OP_MERGE };
+enum OpKind { OP_NONE, OP_COUNT, OP_COUNT_FORWARD, OP_COUNT_REVERSE, OP_PRINT, OP_DUMPINDEX, OP_HISTOGRAM, OP_DUMPFILE, OP_MERGE, OP_VALUE };
 
 struct InputRef { std::string path; int child = -1; };      // a database on the command line, or the output of a child operation
 
@@ -67,6 +68,9 @@ struct Operation {
   std::vector<std::string> db_inputs;       // ... resolved to database paths once the children have run
   std::string              word;            // the operation as typed
   int                      merge_op = -1;   // MGC_MERGE_* (OP_MERGE)
+  int                      value_op = -1;   // MGC_VALUE_* (OP_VALUE): less-than ... modulo
+  uint64_t                 constant = ~0ull;   // its threshold / constant (merylCommandBuilder.C:216-233,291-294); ~0: not given
+  double                   frac_distinct = -1, word_freq = -1;   // distinct=<f> / word-frequency=<f> thresholds (:278-289)
   int                      parent = -1;
   std::string              output;
   uint64_t                 exp_num_kmers = 0;   // n=
@@ -97,13 +101,15 @@ void usage(const char *prog) {
           "       %s print <database.meryl>\n"
           "       %s dumpIndex <database.meryl>\n"
           "       %s dumpFile <database.meryl>/0x######\n"
-          "       %s union-sum|union-min|union-max|intersect-sum|intersect-min|intersect-max <db | [operation]> ... output <db>\n"
+          "       %s union[-min|-max|-sum]|intersect[-min|-max|-sum]|subtract|difference|symmetric-difference <db | [operation]> ... output <db>\n"
+          "       %s less-than|greater-than|at-least|at-most|equal-to|not-equal-to <N | distinct=<f> | word-frequency=<f>> <db | [operation]> output <db>\n"
+          "       %s increase|decrease|multiply|divide|divide-round|modulo <N> <db | [operation]> output <db>\n"
           "\n"
           "  MI355X-native implementation of the `count` path of marbl/meryl.  Words are processed left to\n"
           "  right; options apply to the operations that follow.  A leading '[' and trailing ']' group the\n"
           "  words of one operation; an operation inside another one's brackets is its input.  Other meryl operations are\n"
           "  not part of this build.\n",
-          prog, prog, prog, prog, prog);
+          prog, prog, prog, prog, prog, prog, prog);
 }
 
 [[noreturn]] void die(const char *fmt, const char *a = "") {
@@ -578,6 +584,36 @@ int run_merge(const Globals &g, const std::vector<Operation> &ops, const Operati
   return 0;
 }
 
+// `less-than 5 a.meryl output b.meryl`, `divide 2 [count ...] output h.meryl`: the single-input operations
+// (merylOp-nextMer.C:490-557).  distinct=<f> / word-frequency=<f> turn into a threshold from the input's stored histogram
+// (initializeThreshold, :65-118).
+int run_value(const Globals &g, const std::vector<Operation> &ops, const Operation &op) {
+  if (op.output.empty()) die("ERROR: operation '%s' needs an 'output <database>' in this build.", op.word.c_str());
+  if (op.inputs.size() != 1) die("ERROR: operation '%s' takes exactly one input.", op.word.c_str());
+  const std::string in = op.inputs[0].child >= 0 ? ops[op.inputs[0].child].output : op.inputs[0].path;
+  if (!dir_has_index(in)) die("ERROR: input '%s' is not a meryl database.", in.c_str());
+  uint64_t c = op.constant;
+  if (op.frac_distinct >= 0 || op.word_freq >= 0) {
+    mdb_reader *r = mdb_reader_open(in.c_str());
+    if (!r) die("ERROR: %s", mdb_last_error());
+    mdb_info info;
+    mdb_reader_info(r, &info);
+    std::vector<uint64_t> hv(info.hist_len), ho(info.hist_len);
+    if (info.hist_len) mdb_reader_histogram(r, hv.data(), ho.data());
+    mdb_reader_close(r);
+    if (op.frac_distinct >= 0) {                                             // :104-114
+      const uint64_t target = (uint64_t)(op.frac_distinct * (double)info.num_distinct);
+      uint64_t n = 0;
+      for (uint64_t i = 0; i < info.hist_len; i++) { n += ho[i]; if (n >= target) { c = hv[i]; break; } }
+    }
+    if (op.word_freq >= 0) c = (uint64_t)(op.word_freq * (double)info.num_total);   // :116-118
+  }
+  if (c == ~0ull) die("ERROR: operation '%s' needs a number (threshold / constant).", op.word.c_str());
+  if (g.verbosity > 0) fprintf(stderr, "\nPROCESSING %s %" PRIu64 " of '%s' into '%s'.\n", op.word.c_str(), c, in.c_str(), op.output.c_str());
+  if (mgc_db_filter(in.c_str(), op.value_op, c, op.output.c_str(), -1, (int)g.threads) != MGC_OK) die("ERROR: %s", mgc_db_stream_error(nullptr));
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -608,13 +644,36 @@ int main(int argc, char **argv) {
       const std::string val = (eq == std::string::npos) ? "" : w.substr(eq + 1);
       const int merge_code = (w == "union-sum") ? MGC_MERGE_UNION_SUM : (w == "union-min") ? MGC_MERGE_UNION_MIN :
                              (w == "union-max") ? MGC_MERGE_UNION_MAX : (w == "intersect-sum") ? MGC_MERGE_INTERSECT_SUM :
-                             (w == "intersect-min") ? MGC_MERGE_INTERSECT_MIN : (w == "intersect-max") ? MGC_MERGE_INTERSECT_MAX : -1;
+                             (w == "intersect-min") ? MGC_MERGE_INTERSECT_MIN : (w == "intersect-max") ? MGC_MERGE_INTERSECT_MAX :
+                             (w == "union") ? MGC_MERGE_UNION : (w == "intersect") ? MGC_MERGE_INTERSECT :
+                             (w == "subtract") ? MGC_MERGE_SUBTRACT : (w == "difference") ? MGC_MERGE_DIFFERENCE :
+                             (w == "symmetric-difference") ? MGC_MERGE_SYMMETRIC_DIFFERENCE : -1;                 // merylCommandBuilder.C:364-378
+      const int value_code = (w == "less-than") ? MGC_VALUE_LESS_THAN : (w == "greater-than") ? MGC_VALUE_GREATER_THAN :
+                             (w == "at-least") ? MGC_VALUE_AT_LEAST : (w == "at-most") ? MGC_VALUE_AT_MOST :
+                             (w == "equal-to") ? MGC_VALUE_EQUAL_TO : (w == "not-equal-to") ? MGC_VALUE_NOT_EQUAL_TO :
+                             (w == "increase") ? MGC_VALUE_INCREASE : (w == "decrease") ? MGC_VALUE_DECREASE :
+                             (w == "multiply") ? MGC_VALUE_MULTIPLY : (w == "divide") ? MGC_VALUE_DIVIDE :
+                             (w == "divide-round") ? MGC_VALUE_DIVIDE_ROUND : (w == "modulo") ? MGC_VALUE_MODULO : -1;   // :350-362
+      const bool is_number = !w.empty() && w.find_first_not_of("0123456789") == std::string::npos;
 
       if (expect_output_name) {                                             // `output <db>`, :440-461
         if (top() < 0 || ops[top()].kind == OP_NONE) die("ERROR: 'output' without an operation.");
         if (!ops[top()].output.empty()) die("ERROR: operation already has an output ('%s').", ops[top()].output.c_str());   // merylOp.C:256-257
         ops[top()].output = w;
         expect_output_name = false;
+      }
+      // a bare number is the threshold / constant of the value operation on top ("greater-than 45", "divide 2"; :216-233)
+      else if (is_number && top() >= 0 && ops[top()].kind == OP_VALUE && ops[top()].constant == ~0ull && !file_exists(w)) {
+        ops[top()].constant = strtoull(w.c_str(), nullptr, 10);
+      }
+      else if ((key == "threshold" || key == "t") && eq != std::string::npos && top() >= 0 && ops[top()].kind == OP_VALUE) {   // :291-294
+        ops[top()].constant = strtoull(val.c_str(), nullptr, 10);
+      }
+      else if ((key == "distinct" || key == "d") && eq != std::string::npos && top() >= 0 && ops[top()].kind == OP_VALUE && ops[top()].value_op <= MGC_VALUE_NOT_EQUAL_TO) {
+        ops[top()].frac_distinct = strtod(val.c_str(), nullptr);                                                    // :278-282
+      }
+      else if ((key == "word-frequency" || key == "f") && eq != std::string::npos && top() >= 0 && ops[top()].kind == OP_VALUE && ops[top()].value_op <= MGC_VALUE_NOT_EQUAL_TO) {
+        ops[top()].word_freq = strtod(val.c_str(), nullptr);                                                        // :284-288
       }
       // ---- options, merylCommandBuilder.C:187-326 ----
       else if (w.compare(0, 2, "-V") == 0)   { g.verbosity += (int)w.size() - 1; }
@@ -659,11 +718,11 @@ int main(int argc, char **argv) {
       }
       // ---- operations, :346-439 ----
       else if (w == "count" || w == "count-forward" || w == "count-reverse" || w == "print" || w == "dumpIndex" || w == "histogram" ||
-               w == "dumpFile" || merge_code >= 0) {
+               w == "dumpFile" || merge_code >= 0 || value_code >= 0) {
         const OpKind kind = (w == "count") ? OP_COUNT : (w == "count-forward") ? OP_COUNT_FORWARD :
                             (w == "count-reverse") ? OP_COUNT_REVERSE : (w == "print") ? OP_PRINT :
                             (w == "histogram") ? OP_HISTOGRAM : (w == "dumpFile") ? OP_DUMPFILE :
-                            (w == "dumpIndex") ? OP_DUMPINDEX : OP_MERGE;
+                            (w == "dumpIndex") ? OP_DUMPINDEX : (merge_code >= 0) ? OP_MERGE : OP_VALUE;
         ensure_top();
         if (is_counting(top())) { stack.pop_back(); ensure_top(); }         // :391-407: a counting operation takes no operation as input
         if (ops[top()].kind != OP_NONE) {                                    // :412-421: a new operation, input of the one on top
@@ -680,21 +739,17 @@ int main(int argc, char **argv) {
         ops[top()].kind = kind;                                              // :422-431 (or it replaces the empty operation on top)
         ops[top()].word = w;
         ops[top()].merge_op = merge_code;
+        ops[top()].value_op = value_code;
       }
       else if (w == "output")                { expect_output_name = true; }
-      else if (w == "union" || w == "intersect" || w == "subtract" ||
-               w == "difference" || w == "symmetric-difference" || w == "statistics" ||
-               w == "less-than" || w == "greater-than" || w == "equal-to" || w == "not-equal-to" || w == "at-least" || w == "at-most" ||
-               w == "increase" || w == "decrease" || w == "multiply" || w == "divide" || w == "divide-round" || w == "modulo" ||
-               w == "distinct" || w == "word-frequency" || w == "threshold" || w == "printACGT" || w == "compare" ||
-               w == "noise" || w == "ploidy") {
-        die("ERROR: operation '%s' is not part of this build (count path, union-sum and its five relatives only).", w.c_str());
+      else if (w == "statistics" || w == "printACGT" || w == "compare" || w == "noise" || w == "ploidy") {
+        die("ERROR: operation '%s' is not part of this build (count, the set operations and the value filters / arithmetic only).", w.c_str());
       }
       // ---- inputs ----
       else if (dir_has_index(w)) {                                           // :159,506-514
         const int t = top();
-        if (t < 0 || (ops[t].kind != OP_PRINT && ops[t].kind != OP_DUMPINDEX && ops[t].kind != OP_HISTOGRAM && ops[t].kind != OP_MERGE))
-          die("ERROR: database input '%s' needs a print, histogram, dumpIndex or union/intersect operation before it.", w.c_str());
+        if (t < 0 || (ops[t].kind != OP_PRINT && ops[t].kind != OP_DUMPINDEX && ops[t].kind != OP_HISTOGRAM && ops[t].kind != OP_MERGE && ops[t].kind != OP_VALUE))
+          die("ERROR: database input '%s' needs a print, histogram, dumpIndex, set or value operation before it.", w.c_str());
         InputRef in; in.path = w;
         ops[t].inputs.push_back(in);
       }
@@ -734,6 +789,7 @@ int main(int argc, char **argv) {
   // before the operation that reads its output
   for (size_t i = ops.size(); i-- > 0;)
     if (ops[i].kind == OP_MERGE) rc |= run_merge(g, ops, ops[i]);
+    else if (ops[i].kind == OP_VALUE) rc |= run_value(g, ops, ops[i]);
   for (Operation &op : ops) {
     if (op.kind != OP_PRINT && op.kind != OP_DUMPINDEX && op.kind != OP_HISTOGRAM && op.kind != OP_DUMPFILE) continue;
     for (const InputRef &in : op.inputs) {

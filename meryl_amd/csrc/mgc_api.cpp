@@ -261,17 +261,45 @@ extern "C" size_t mgc_dev_merge_workspace_bytes(uint64_t na, uint64_t nb) { retu
 extern "C" int mgc_dev_merge_count(const void *dA, uint64_t na, const void *dB, uint64_t nb, uint32_t key_words, int op, void *d_ws,
                                    size_t ws_bytes, uint64_t *n_out, void *stream) {
   if (!n_out || !d_ws || ws_bytes < mgc::merge_workspace_bytes(na, nb) || (na && !dA) || (nb && !dB) ||
-      (key_words != 1 && key_words != 2) || op < 0 || op > 5) return MGC_EINVAL;
+      (key_words != 1 && key_words != 2) || op < 0 || op > MGC_MERGE_SYMMETRIC_DIFFERENCE || op == MGC_MERGE_SUBTRACT) return MGC_EINVAL;
   hipError_t e = mgc::launch_merge_count(dA, na, dB, nb, key_words, op, d_ws, (hipStream_t)stream);
   if (e != hipSuccess) return hip_rc(e, "merge_count");
   return hip_rc(mgc::merge_read_total(d_ws, n_out, (hipStream_t)stream), "merge_count sync");
+}
+
+extern "C" int mgc_dev_merge_count_values(const void *dA, const uint32_t *cA, uint64_t na, const void *dB, const uint32_t *cB, uint64_t nb,
+                                          uint32_t key_words, int op, void *d_ws, size_t ws_bytes, uint64_t *n_out, void *stream) {
+  if (!n_out || !d_ws || ws_bytes < mgc::merge_workspace_bytes(na, nb) || (na && (!dA || !cA)) || (nb && (!dB || !cB)) ||
+      (key_words != 1 && key_words != 2) || op < 0 || op > MGC_MERGE_SYMMETRIC_DIFFERENCE) return MGC_EINVAL;
+  hipError_t e = mgc::launch_merge_count(dA, na, dB, nb, key_words, op, d_ws, (hipStream_t)stream, cA, cB);
+  if (e != hipSuccess) return hip_rc(e, "merge_count");
+  return hip_rc(mgc::merge_read_total(d_ws, n_out, (hipStream_t)stream), "merge_count sync");
+}
+
+extern "C" size_t mgc_dev_select_workspace_bytes(uint64_t n) { return mgc::select_workspace_bytes(n); }
+
+extern "C" int mgc_dev_select_count(const void *d_keys, const uint32_t *d_values, uint64_t n, uint32_t key_words, int value_op, uint64_t constant,
+                                    void *d_ws, size_t ws_bytes, uint64_t *n_out, void *stream) {
+  if (!n_out || !d_ws || ws_bytes < mgc::select_workspace_bytes(n) || (n && (!d_keys || !d_values)) || (key_words != 1 && key_words != 2) ||
+      value_op < 0 || value_op > MGC_VALUE_MODULO) return MGC_EINVAL;
+  hipError_t e = mgc::launch_select_count(d_keys, d_values, nullptr, n, key_words, value_op, constant, d_ws, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_rc(e, "select_count");
+  return hip_rc(mgc::merge_read_total(d_ws, n_out, (hipStream_t)stream), "select_count sync");
+}
+
+extern "C" int mgc_dev_select_emit(const void *d_keys, const uint32_t *d_values, uint64_t n, uint32_t key_words, int value_op, uint64_t constant,
+                                   void *d_ws, size_t ws_bytes, void *d_keys_out, uint32_t *d_values_out, void *stream) {
+  if (!d_ws || ws_bytes < mgc::select_workspace_bytes(n) || (n && (!d_keys || !d_values)) || (key_words != 1 && key_words != 2) ||
+      value_op < 0 || value_op > MGC_VALUE_MODULO) return MGC_EINVAL;
+  return hip_rc(mgc::launch_select_emit(d_keys, d_values, nullptr, n, key_words, value_op, constant, d_ws, d_keys_out, d_values_out,
+                                        (hipStream_t)stream), "select_emit");
 }
 
 extern "C" int mgc_dev_merge_emit(const void *dA, const uint32_t *cA, uint64_t na, const void *dB, const uint32_t *cB, uint64_t nb,
                                   uint32_t key_words, int op, void *d_ws, size_t ws_bytes, void *d_keys_out, uint32_t *d_counts_out,
                                   void *stream) {
   if (!d_ws || ws_bytes < mgc::merge_workspace_bytes(na, nb) || (na && (!dA || !cA)) || (nb && (!dB || !cB)) ||
-      (key_words != 1 && key_words != 2) || op < 0 || op > 5) return MGC_EINVAL;
+      (key_words != 1 && key_words != 2) || op < 0 || op > MGC_MERGE_SYMMETRIC_DIFFERENCE) return MGC_EINVAL;
   return hip_rc(mgc::launch_merge_emit(dA, cA, na, dB, cB, nb, key_words, op, d_ws, d_keys_out, d_counts_out, (hipStream_t)stream),
                 "merge_emit");
 }

@@ -174,11 +174,22 @@ hipError_t launch_value_hist(const uint32_t *d_counts, uint64_t n, uint64_t *d_h
 // ---- merge of two sorted distinct (k-mer, value) streams (mgc_merge.hip) ----------------------------------------
 // op: 0 union-sum, 1 union-min, 2 union-max, 3 intersect-sum, 4 intersect-min, 5 intersect-max
 size_t     merge_workspace_bytes(uint64_t na, uint64_t nb);
+//     6 intersect (first input's value), 7 subtract, 8 difference, 9 symmetric-difference (mgc_merge.hip)
+// cA / cB: the values -- needed by the count pass only when what is written depends on them (op 7)
 hipError_t launch_merge_count(const void *dA, uint64_t na, const void *dB, uint64_t nb, uint32_t key_words, int op, void *d_ws,
-                              hipStream_t st);
+                              hipStream_t st, const uint32_t *cA = nullptr, const uint32_t *cB = nullptr);
 hipError_t merge_read_total(const void *d_ws, uint64_t *n_out, hipStream_t st);       // synchronises the stream
 hipError_t launch_merge_emit(const void *dA, const uint32_t *cA, uint64_t na, const void *dB, const uint32_t *cB, uint64_t nb,
                              uint32_t key_words, int op, void *d_ws, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st);
+// one stream through a value transform (fop 0..5 filters against `constant`: less-than, greater-than, at-least, at-most, equal-to,
+// not-equal-to; 6..11 arithmetic: increase, decrease, multiply, divide, divide-round, modulo; 12: keep where d_flags[i] == 1),
+// k-mers whose new value is 0 dropped; two passes like the merge (count -> merge_read_total -> emit)
+size_t     select_workspace_bytes(uint64_t n);
+hipError_t launch_select_count(const void *d_keys, const uint32_t *d_vals, const uint32_t *d_flags, uint64_t n, uint32_t key_words, int fop,
+                               uint64_t constant, void *d_ws, hipStream_t st);
+hipError_t launch_select_emit(const void *d_keys, const uint32_t *d_vals, const uint32_t *d_flags, uint64_t n, uint32_t key_words, int fop,
+                              uint64_t constant, void *d_ws, void *d_out_keys, uint32_t *d_out_vals, hipStream_t st);
+hipError_t launch_fill_u32(uint32_t *d, uint64_t n, uint32_t v, hipStream_t st);
 // *d_out <- 1 + index of the last '.' in bases[0, n), 0 if none
 hipError_t launch_last_breaker(const uint8_t *d_bases, uint64_t n, uint64_t *d_out, hipStream_t st);
 

@@ -22,13 +22,27 @@ constexpr int MG_BLOCK = 256;
 constexpr int MG_ITEMS = 8;
 constexpr int MG_TILE  = MG_BLOCK * MG_ITEMS;
 
-// ops: what the output holds and how values combine (meryl's union-* / intersect-* over two inputs)
+// ops: what the output holds and how values combine (meryl's union-* / intersect-* / set operations over two inputs,
+// src/meryl/merylOp-nextMer.C:559-613; more inputs fold from the left)
 //   0 union-sum   1 union-min   2 union-max   3 intersect-sum   4 intersect-min   5 intersect-max
-__device__ __forceinline__ bool mg_is_intersect(int op) { return op >= 3; }
+//   6 intersect (the first input's value)      7 subtract (a - b while a > b, otherwise dropped; :52-62)
+//   8 difference (in A only)                   9 symmetric-difference (in exactly one of the two)
+constexpr int MG_NUM_OPS = 10;
 __device__ __forceinline__ u32 mg_combine(int op, u32 a, u32 b) {
+  if (op == 6) return a;
+  if (op == 7) return a - b;
   const int f = op % 3;
   return f == 0 ? a + b : (f == 1 ? (a < b ? a : b) : (a > b ? a : b));       // the sum wraps mod 2^32 like kmvalu arithmetic
 }
+// an A element (dup: B holds the same k-mer) / a B element (dup: A holds it too) is written
+__device__ __forceinline__ bool mg_keep_a(int op, bool dup, u32 va, u32 vb) {
+  if (op <= 2) return true;
+  if (op <= 6) return dup;
+  if (op == 7) return !dup || va > vb;
+  return !dup;
+}
+__device__ __forceinline__ bool mg_keep_b(int op, bool dup) { return (op <= 2 || op == 9) && !dup; }
+__device__ __forceinline__ bool mg_needs_values(int op) { return op == 7; }   // whether an element is written depends on the values
 
 // number of A elements among the first d merged elements (ties: A first)
 template <typename K>
@@ -71,7 +85,7 @@ void merge_kernel(const K *__restrict__ A, const u32 *__restrict__ cA, u64 nA, c
     la = lo;
   }
   u32 lb = l0 - la;
-  const bool inter = mg_is_intersect(op);
+  const bool need_v = EMIT || mg_needs_values(op);
   // pass over the thread's elements: which are output heads, and with what value
   u32 heads = 0;
   u32 head_mask = 0;                       // bit q: element q is written
@@ -89,10 +103,11 @@ void merge_kernel(const K *__restrict__ A, const u32 *__restrict__ cA, u64 nA, c
       u64 bidx = b0 + lb;
       if (lb < nb) dup = !KeyOps<K>::ne(sB[lb], key);
       else if (bidx < nB) dup = !KeyOps<K>::ne(B[bidx], key);
-      const bool out = inter ? dup : true;
-      if (out) {
+      u32 va = 0, vb = 0;
+      if (need_v) { va = cA[a0 + la]; if (dup) vb = cB[bidx]; }
+      if (mg_keep_a(op, dup, va, vb)) {
         head_mask |= 1u << q; heads++;
-        if (EMIT) { kreg[q] = key; const u32 va = cA[a0 + la]; vreg[q] = dup ? mg_combine(op, va, cB[bidx]) : va; }
+        if (EMIT) { kreg[q] = key; vreg[q] = dup ? mg_combine(op, va, vb) : va; }
       }
       la++;
     } else {
@@ -101,8 +116,7 @@ void merge_kernel(const K *__restrict__ A, const u32 *__restrict__ cA, u64 nA, c
       bool dup = false;
       if (la > 0) dup = !KeyOps<K>::ne(sA[la - 1], key);
       else if (a0 > 0) dup = !KeyOps<K>::ne(A[a0 - 1], key);
-      const bool out = !inter && !dup;
-      if (out) {
+      if (mg_keep_b(op, dup)) {
         head_mask |= 1u << q; heads++;
         if (EMIT) { kreg[q] = key; vreg[q] = cB[b0 + lb]; }
       }
@@ -132,18 +146,19 @@ size_t merge_workspace_bytes(uint64_t na, uint64_t nb) {
 
 // pass 1: leaves the output length at ws[0] (read it with merge_read_total after the stream is synchronised)
 hipError_t launch_merge_count(const void *dA, uint64_t na, const void *dB, uint64_t nb, uint32_t key_words, int op, void *d_ws,
-                              hipStream_t st) {
+                              hipStream_t st, const uint32_t *cA, const uint32_t *cB) {
+  if (op < 0 || op >= MG_NUM_OPS || (op == 7 && ((na && !cA) || (nb && !cB)))) return hipErrorInvalidValue;
   u64 *ws = reinterpret_cast<u64 *>(d_ws);
   const uint64_t t = merge_tiles(na, nb);
   if (t == 0) return hipMemsetAsync(ws, 0, 8, st);
   u64 *tiles = ws + 8, *scratch = tiles + t + 1;
   if (key_words == 2)
     hipLaunchKernelGGL((merge_kernel<K128, false>), dim3((uint32_t)t), dim3(MG_BLOCK), 0, st, reinterpret_cast<const K128 *>(dA),
-                       (const u32 *)nullptr, (u64)na, reinterpret_cast<const K128 *>(dB), (const u32 *)nullptr, (u64)nb, op, tiles,
+                       cA, (u64)na, reinterpret_cast<const K128 *>(dB), cB, (u64)nb, op, tiles,
                        (K128 *)nullptr, (u32 *)nullptr);
   else
     hipLaunchKernelGGL((merge_kernel<u64, false>), dim3((uint32_t)t), dim3(MG_BLOCK), 0, st, reinterpret_cast<const u64 *>(dA),
-                       (const u32 *)nullptr, (u64)na, reinterpret_cast<const u64 *>(dB), (const u32 *)nullptr, (u64)nb, op, tiles,
+                       cA, (u64)na, reinterpret_cast<const u64 *>(dB), cB, (u64)nb, op, tiles,
                        (u64 *)nullptr, (u32 *)nullptr);
   MGC_CHECK(hipGetLastError());
   return scan_u64_exclusive(tiles, t, scratch, ws, st);
@@ -169,6 +184,100 @@ hipError_t launch_merge_emit(const void *dA, const uint32_t *cA, uint64_t na, co
     hipLaunchKernelGGL((merge_kernel<u64, true>), dim3((uint32_t)t), dim3(MG_BLOCK), 0, st, reinterpret_cast<const u64 *>(dA), cA,
                        (u64)na, reinterpret_cast<const u64 *>(dB), cB, (u64)nb, op, tiles, reinterpret_cast<u64 *>(d_out_keys),
                        d_out_counts);
+  return hipGetLastError();
+}
+
+// ---- one stream: values transformed, k-mers whose new value is zero dropped (order kept) ------------------------------------
+// The single-input operations of src/meryl/merylOp-nextMer.C:490-557: the value filters (less-than ... not-equal-to: the value
+// passes or becomes 0) and the arithmetic ones (increase ... modulo, with the reference's overflow / underflow / divide-by-zero
+// results); a value of 0 means "do not output" (:470-474).  fop 12: keep the k-mers whose FLAG (a second value array) is 1 --
+// the exactly-one-input test of symmetric-difference over more than two inputs.  kmvalu is 32 bits: results are truncated.
+__device__ __forceinline__ u32 sel_value(int fop, u32 v, u64 c, u32 flag) {
+  switch (fop) {
+    case 0:  return (u64)v <  c ? v : 0u;
+    case 1:  return (u64)v >  c ? v : 0u;
+    case 2:  return (u64)v >= c ? v : 0u;
+    case 3:  return (u64)v <= c ? v : 0u;
+    case 4:  return (u64)v == c ? v : 0u;
+    case 5:  return (u64)v != c ? v : 0u;
+    case 6:  return (~0ull - (u64)v < c) ? ~0u : (u32)((u64)v + c);
+    case 7:  return ((u64)v < c) ? 0u : (u32)((u64)v - c);
+    case 8:  return (v && ~0ull / (u64)v < c) ? ~0u : (u32)((u64)v * c);
+    case 9:  return c == 0 ? 0u : (u32)((u64)v / c);
+    case 10: return c == 0 ? 0u : ((u64)v < c ? 1u : (u32)(u64)__builtin_round((double)v / (double)c));
+    case 11: return c == 0 ? 0u : (u32)((u64)v % c);
+    default: return flag == 1u ? v : 0u;
+  }
+}
+
+constexpr int SL_BLOCK = 256, SL_ITEMS = 8, SL_TILE = SL_BLOCK * SL_ITEMS;
+template <typename K, bool EMIT>
+__global__ __launch_bounds__(SL_BLOCK)
+void select_kernel(const K *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ flags, u64 n, int fop, u64 c,
+                   u64 *__restrict__ tile_cnt /*EMIT: exclusive bases*/, K *__restrict__ outK, u32 *__restrict__ outC) {
+  __shared__ u32 s_tmp[SL_BLOCK / 64 + 1];
+  const u64 base = (u64)blockIdx.x * SL_TILE + (u64)threadIdx.x * SL_ITEMS;
+  u32 nv[SL_ITEMS], kept = 0;
+#pragma unroll
+  for (int q = 0; q < SL_ITEMS; q++) {
+    nv[q] = 0;
+    if (base + q < n) nv[q] = sel_value(fop, vals[base + q], c, flags ? flags[base + q] : 0u);
+    kept += nv[q] ? 1u : 0u;
+  }
+  u32 tot;
+  const u32 off = block_excl_scan<SL_BLOCK, u32>(kept, s_tmp, &tot);
+  if (!EMIT) { if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot; return; }
+  u64 o = tile_cnt[blockIdx.x] + off;
+#pragma unroll
+  for (int q = 0; q < SL_ITEMS; q++)
+    if (nv[q]) { outK[o] = keys[base + q]; outC[o] = nv[q]; o++; }
+}
+
+__global__ void fill_u32_kernel(u32 *__restrict__ p, u64 n, u32 v) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+static inline uint64_t select_tiles(uint64_t n) { return (n + SL_TILE - 1) / SL_TILE; }
+size_t select_workspace_bytes(uint64_t n) {
+  const uint64_t t = select_tiles(n);
+  return (size_t)(8 + t + 1 + scan_scratch_elems(t + 1)) * sizeof(u64) + 256;
+}
+// pass 1: the number of k-mers kept lands at ws[0] (merge_read_total reads it)
+hipError_t launch_select_count(const void *d_keys, const uint32_t *d_vals, const uint32_t *d_flags, uint64_t n, uint32_t key_words, int fop,
+                               uint64_t constant, void *d_ws, hipStream_t st) {
+  if (fop < 0 || fop > 12 || (fop == 12 && n && !d_flags)) return hipErrorInvalidValue;
+  u64 *ws = reinterpret_cast<u64 *>(d_ws);
+  const uint64_t t = select_tiles(n);
+  if (t == 0) return hipMemsetAsync(ws, 0, 8, st);
+  u64 *tiles = ws + 8, *scratch = tiles + t + 1;
+  if (key_words == 2)
+    hipLaunchKernelGGL((select_kernel<K128, false>), dim3((uint32_t)t), dim3(SL_BLOCK), 0, st, reinterpret_cast<const K128 *>(d_keys), d_vals, d_flags,
+                       (u64)n, fop, (u64)constant, tiles, (K128 *)nullptr, (u32 *)nullptr);
+  else
+    hipLaunchKernelGGL((select_kernel<u64, false>), dim3((uint32_t)t), dim3(SL_BLOCK), 0, st, reinterpret_cast<const u64 *>(d_keys), d_vals, d_flags,
+                       (u64)n, fop, (u64)constant, tiles, (u64 *)nullptr, (u32 *)nullptr);
+  MGC_CHECK(hipGetLastError());
+  return scan_u64_exclusive(tiles, t, scratch, ws, st);
+}
+hipError_t launch_select_emit(const void *d_keys, const uint32_t *d_vals, const uint32_t *d_flags, uint64_t n, uint32_t key_words, int fop,
+                              uint64_t constant, void *d_ws, void *d_out_keys, uint32_t *d_out_vals, hipStream_t st) {
+  const uint64_t t = select_tiles(n);
+  if (t == 0) return hipSuccess;
+  u64 *tiles = reinterpret_cast<u64 *>(d_ws) + 8;
+  if (key_words == 2)
+    hipLaunchKernelGGL((select_kernel<K128, true>), dim3((uint32_t)t), dim3(SL_BLOCK), 0, st, reinterpret_cast<const K128 *>(d_keys), d_vals, d_flags,
+                       (u64)n, fop, (u64)constant, tiles, reinterpret_cast<K128 *>(d_out_keys), d_out_vals);
+  else
+    hipLaunchKernelGGL((select_kernel<u64, true>), dim3((uint32_t)t), dim3(SL_BLOCK), 0, st, reinterpret_cast<const u64 *>(d_keys), d_vals, d_flags,
+                       (u64)n, fop, (u64)constant, tiles, reinterpret_cast<u64 *>(d_out_keys), d_out_vals);
+  return hipGetLastError();
+}
+hipError_t launch_fill_u32(uint32_t *d, uint64_t n, uint32_t v, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  uint64_t wgs = (n + 255) / 256;
+  if (wgs > 8192) wgs = 8192;
+  hipLaunchKernelGGL(fill_u32_kernel, dim3((uint32_t)wgs), dim3(256), 0, st, d, (u64)n, v);
   return hipGetLastError();
 }
 

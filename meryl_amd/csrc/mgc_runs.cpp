@@ -42,8 +42,27 @@ mgc_runs::mgc_runs(uint32_t k_, uint32_t w_prefix_, int device_, uint64_t budget
   memset(&prof, 0, sizeof(prof));
 }
 
+void mgc_runs::start_prealloc(size_t kb, size_t cb) {
+  if (getenv("MGC_OOC_NO_PREALLOC")) return;
+  pre_thread = std::thread([this, kb, cb] {
+    (void)hipSetDevice(device);
+    pre_k = pre_c = nullptr; pre_kb = pre_cb = 0;
+    if (hipHostMalloc(&pre_k, kb, hipHostMallocDefault) != hipSuccess) { pre_k = nullptr; (void)hipGetLastError(); return; }
+    if (hipHostMalloc(&pre_c, cb, hipHostMallocDefault) != hipSuccess) { (void)hipHostFree(pre_k); pre_k = pre_c = nullptr; (void)hipGetLastError(); return; }
+    pre_kb = kb; pre_cb = cb;
+  });
+}
+
+void mgc_runs::drop_prealloc() {
+  if (pre_thread.joinable()) pre_thread.join();
+  if (pre_k) (void)hipHostFree(pre_k);
+  if (pre_c) (void)hipHostFree(pre_c);
+  pre_k = pre_c = nullptr; pre_kb = pre_cb = 0;
+}
+
 mgc_runs::~mgc_runs() {
   (void)hipSetDevice(device);
+  drop_prealloc();
   for (Run &r : runs) free_run(r);
   for (auto &b : buf) b.release();
   d_slices.release();
@@ -113,8 +132,16 @@ int mgc_runs::add(const void *d_keys, const uint32_t *d_counts, uint64_t n, hipS
   if (!r.keys) {
     const double t0 = now_s();
     r.on_host = true;
-    hipError_t e = hipHostMalloc(&r.keys, kb, hipHostMallocDefault);
-    if (e == hipSuccess) { void *c = nullptr; e = hipHostMalloc(&c, cb, hipHostMallocDefault); r.counts = reinterpret_cast<uint32_t *>(c); }
+    hipError_t e = hipSuccess;
+    if (pre_thread.joinable()) pre_thread.join();
+    if (pre_k && pre_kb >= kb && pre_cb >= cb) {            // the buffers the helper pinned while this batch was counted
+      r.keys = pre_k; r.counts = reinterpret_cast<uint32_t *>(pre_c);
+      pre_k = pre_c = nullptr; pre_kb = pre_cb = 0;
+    } else {
+      drop_prealloc();
+      e = hipHostMalloc(&r.keys, kb, hipHostMallocDefault);
+      if (e == hipSuccess) { void *c = nullptr; e = hipHostMalloc(&c, cb, hipHostMallocDefault); r.counts = reinterpret_cast<uint32_t *>(c); }
+    }
     if (e != hipSuccess) {
       free_run(r);
       set_err(&err, "mgc_runs: %.1f GB of pinned host memory for a spilled run: %s", (kb + cb) / 1e9, hipGetErrorString(e));
@@ -129,6 +156,7 @@ int mgc_runs::add(const void *d_keys, const uint32_t *d_counts, uint64_t n, hipS
     prof.host_bytes += kb + cb;
     prof.n_host_runs++;
     prof.spill_s += now_s() - t0;
+    start_prealloc(kb + kb / 16, cb + cb / 16);             // batches are of one size: the next run will be about this large
   }
   if (r.slice[0] != 0 || r.slice[n_slices] != n) { free_run(r); set_err(&err, "mgc_runs_add: keys not ascending / beyond 2k bits"); return MGC_EINVAL; }
   prof.n_runs++;
@@ -153,6 +181,7 @@ int mgc_runs::deliver(uint64_t s0, uint64_t s1, mgc::RunSink &sink) {
   if (rc != MGC_OK) return rc;
   RN_TRY(hipSetDevice(device));
   if (s0 > s1 || s1 > n_slices) { set_err(&err, "mgc_runs: bad slice range"); return MGC_EINVAL; }
+  drop_prealloc();                                          // no more runs are coming
   const double t_begin = now_s();
   const size_t kbytes = sizeof(uint64_t) * kw;
   // chunk capacity in entries: two input sets + two ping-pong pairs = six buffers of C entries each

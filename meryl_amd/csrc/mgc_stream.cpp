@@ -686,34 +686,83 @@ extern "C" int mgc_finish_labelled(mgc_session *s, mgc_block_cb2 cb, void *ctx, 
 // src/meryl/meryl.C:250-263).  Here a slice is decoded by host threads (one per input), merged two inputs at a time on the
 // device (mgc_merge.hip), encoded on the device and written by the database stream -- the same merge that folds the
 // batches of an out-of-core count.
-extern "C" int mgc_db_merge(const char *const *inputs, uint32_t n_inputs, int op, const char *output, int device, int host_threads) {
-  if (!inputs || n_inputs == 0 || !output || op < MGC_MERGE_UNION_SUM || op > MGC_MERGE_INTERSECT_MAX) {
-    set_err(nullptr, "mgc_db_merge: bad arguments");
-    return MGC_EINVAL;
+namespace {
+// the slice (file ff) of every input decoded by host threads (one per input) and uploaded: in_k[i] / in_c[i] / hn[i]
+int load_slices(std::vector<mdb_reader *> &rd, uint32_t ff, uint32_t kw, std::vector<DBuf> &in_k, std::vector<DBuf> &in_c,
+                std::vector<uint64_t> &hn, hipStream_t st, std::string *msg) {
+  const uint32_t n_inputs = (uint32_t)rd.size();
+  std::vector<std::vector<uint64_t>> hk(n_inputs);
+  std::vector<uint32_t *> hc(n_inputs, nullptr);
+  std::vector<int> rrc(n_inputs, MGC_OK);
+  std::vector<std::string> rmsg(n_inputs);
+  hn.assign(n_inputs, 0);
+  {
+    std::vector<std::thread> th;
+    for (uint32_t i = 0; i < n_inputs; i++)
+      th.emplace_back([&, i]() {
+        uint64_t *lo = nullptr, *hi = nullptr;
+        rrc[i] = mdb_reader_read_file_ex(rd[i], ff, &lo, &hi, &hc[i], nullptr, &hn[i]);
+        if (rrc[i] != MGC_OK) { rmsg[i] = mdb_last_error(); return; }
+        hk[i].resize((size_t)kw * hn[i]);
+        if (kw == 1) { if (hn[i]) memcpy(hk[i].data(), lo, 8 * hn[i]); }
+        else for (uint64_t j = 0; j < hn[i]; j++) { hk[i][2 * j] = lo[j]; hk[i][2 * j + 1] = hi[j]; }
+        mdb_free(lo); mdb_free(hi);
+      });
+    for (auto &t : th) t.join();
   }
-  std::vector<mdb_reader *> rd(n_inputs, nullptr);
+  int rc = MGC_OK;
+  for (uint32_t i = 0; i < n_inputs; i++)
+    if (rrc[i] != MGC_OK && rc == MGC_OK) { rc = rrc[i]; *msg = rmsg[i]; }
+  hipError_t e = hipSuccess;
+  for (uint32_t i = 0; i < n_inputs && rc == MGC_OK && e == hipSuccess; i++) {
+    e = in_k[i].ensure(8 * (size_t)kw * hn[i]);
+    if (e == hipSuccess) e = in_c[i].ensure(4 * hn[i]);
+    if (e == hipSuccess && hn[i]) e = hipMemcpyAsync(in_k[i].p, hk[i].data(), 8 * (size_t)kw * hn[i], hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && hn[i]) e = hipMemcpyAsync(in_c[i].p, hc[i], 4 * hn[i], hipMemcpyHostToDevice, st);
+  }
+  if (e == hipSuccess && rc == MGC_OK) e = hipStreamSynchronize(st);
+  for (uint32_t i = 0; i < n_inputs; i++) mdb_free(hc[i]);
+  if (e != hipSuccess) { rc = (e == hipErrorOutOfMemory) ? MGC_ENOMEM : MGC_EHIP; *msg = std::string("uploading a slice: ") + hipGetErrorString(e); }
+  return rc;
+}
+
+// inputs of one k, no labels, no multisets -> readers + the first one's info; false: message in the thread error
+bool open_merge_inputs(const char *const *inputs, uint32_t n_inputs, std::vector<mdb_reader *> &rd, mdb_info *first, const char *who) {
+  rd.assign(n_inputs, nullptr);
   auto close_all = [&]() { for (mdb_reader *r : rd) if (r) mdb_reader_close(r); };
-  mdb_info first;
-  memset(&first, 0, sizeof(first));
+  memset(first, 0, sizeof(*first));
   for (uint32_t i = 0; i < n_inputs; i++) {
     rd[i] = inputs[i] ? mdb_reader_open(inputs[i]) : nullptr;
-    if (!rd[i]) { set_err(nullptr, "mgc_db_merge: %s", mdb_last_error()); close_all(); return MGC_EINVAL; }
+    if (!rd[i]) { set_err(nullptr, "%s: %s", who, mdb_last_error()); close_all(); return false; }
     mdb_info inf;
     mdb_reader_info(rd[i], &inf);
     // the merge combines VALUES only: labels would be dropped and a multiset's repeated k-mers folded -- refuse rather than
     // write something that silently differs
     if (inf.label_size != 0 || (inf.flags & 1u)) {
-      set_err(nullptr, "mgc_db_merge: '%s' %s: not supported by this merge", inputs[i], inf.label_size ? "stores labels" : "is a multiset");
+      set_err(nullptr, "%s: '%s' %s: not supported here", who, inputs[i], inf.label_size ? "stores labels" : "is a multiset");
       close_all();
-      return MGC_EUNSUPPORTED;
+      return false;
     }
-    if (i == 0) first = inf;
-    else if (inf.k != first.k) {
-      set_err(nullptr, "mgc_db_merge: '%s' holds %u-mers, '%s' %u-mers", inputs[i], inf.k, inputs[0], first.k);   // merylOp.C: kmer size mismatch
+    if (i == 0) *first = inf;
+    else if (inf.k != first->k) {
+      set_err(nullptr, "%s: '%s' holds %u-mers, '%s' %u-mers", who, inputs[i], inf.k, inputs[0], first->k);   // merylOp.C: kmer size mismatch
       close_all();
-      return MGC_EINVAL;
+      return false;
     }
   }
+  return true;
+}
+}  // namespace
+
+extern "C" int mgc_db_merge(const char *const *inputs, uint32_t n_inputs, int op, const char *output, int device, int host_threads) {
+  if (!inputs || n_inputs == 0 || !output || op < MGC_MERGE_UNION_SUM || op > MGC_MERGE_UNION) {
+    set_err(nullptr, "mgc_db_merge: bad arguments");
+    return MGC_EINVAL;
+  }
+  std::vector<mdb_reader *> rd;
+  mdb_info first;
+  if (!open_merge_inputs(inputs, n_inputs, rd, &first, "mgc_db_merge")) return MGC_EINVAL;
+  auto close_all = [&]() { for (mdb_reader *r : rd) if (r) mdb_reader_close(r); };
   const uint32_t k = first.k, w_prefix = first.prefix_size, kw = k > 32 ? 2u : 1u;
   if (device < 0) (void)hipGetDevice(&device);
   mgc_db_stream *d = mgc_db_stream_open(output, k, w_prefix, 0, 0, 0, 1, host_threads, device);
@@ -728,76 +777,125 @@ extern "C" int mgc_db_merge(const char *const *inputs, uint32_t n_inputs, int op
   {
     hipStream_t st = nullptr;
     std::vector<DBuf> in_k(n_inputs), in_c(n_inputs);
-    DBuf acc_k[2], acc_c[2], ws;
+    DBuf acc_k[2], acc_c[2], mem_k[2], mem_c[2], ones, ws;
+    std::vector<uint64_t> hn;
     const uint64_t blocks_per_file = 1ull << (w_prefix - MGC_NUM_FILES_BITS);
+    // union (value = how many inputs hold the k-mer, :559-561) = union-sum over values of one;
+    // symmetric-difference over more than two inputs (in exactly ONE input, :609-612) = the union-sum of the values
+    // filtered by "union-sum of ones == 1"; everything else folds from the left with its own two-input step
+    const bool by_membership = (op == MGC_MERGE_SYMMETRIC_DIFFERENCE && n_inputs > 2);
+    const int fold_op = (op == MGC_MERGE_UNION || by_membership) ? MGC_MERGE_UNION_SUM : op;
     MG_TRY(hipSetDevice(device));
     MG_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (uint32_t ff = 0; ff < MGC_NUM_FILES && rc == MGC_OK; ff++) {
-      // decode the slice of every input (host threads), interleaving {lo, hi} for 16-byte keys
-      std::vector<std::vector<uint64_t>> hk(n_inputs);
-      std::vector<uint32_t *> hc(n_inputs, nullptr);
-      std::vector<uint64_t> hn(n_inputs, 0);
-      std::vector<int> rrc(n_inputs, MGC_OK);
-      std::vector<std::string> rmsg(n_inputs);
-      {
-        std::vector<std::thread> th;
-        for (uint32_t i = 0; i < n_inputs; i++)
-          th.emplace_back([&, i]() {
-            uint64_t *lo = nullptr, *hi = nullptr;
-            rrc[i] = mdb_reader_read_file_ex(rd[i], ff, &lo, &hi, &hc[i], nullptr, &hn[i]);
-            if (rrc[i] != MGC_OK) { rmsg[i] = mdb_last_error(); return; }
-            hk[i].resize((size_t)kw * hn[i]);
-            if (kw == 1) { if (hn[i]) memcpy(hk[i].data(), lo, 8 * hn[i]); }
-            else for (uint64_t j = 0; j < hn[i]; j++) { hk[i][2 * j] = lo[j]; hk[i][2 * j + 1] = hi[j]; }
-            mdb_free(lo); mdb_free(hi);
-          });
-        for (auto &t : th) t.join();
-      }
-      for (uint32_t i = 0; i < n_inputs; i++)
-        if (rrc[i] != MGC_OK && rc == MGC_OK) { rc = rrc[i]; msg = "mgc_db_merge: " + rmsg[i]; }
-      if (rc == MGC_OK) {
-        for (uint32_t i = 0; i < n_inputs; i++) {
-          MG_TRY(in_k[i].ensure(8 * (size_t)kw * hn[i]));
-          MG_TRY(in_c[i].ensure(4 * hn[i]));
-          if (hn[i]) {
-            MG_TRY(hipMemcpyAsync(in_k[i].p, hk[i].data(), 8 * (size_t)kw * hn[i], hipMemcpyHostToDevice, st));
-            MG_TRY(hipMemcpyAsync(in_c[i].p, hc[i], 4 * hn[i], hipMemcpyHostToDevice, st));
-          }
+      rc = load_slices(rd, ff, kw, in_k, in_c, hn, st, &msg);
+      if (rc != MGC_OK) { msg = "mgc_db_merge: " + msg; break; }
+      // fold: values (and, for the membership forms, ones) through the same sequence of two-input steps
+      auto fold = [&](bool use_ones, DBuf (&ak)[2], DBuf (&ac)[2], const void **out_k, const uint32_t **out_c, uint64_t *out_n) -> bool {
+        uint64_t most = 0;
+        for (uint32_t i = 0; i < n_inputs; i++) most = std::max(most, hn[i]);
+        if (use_ones) {
+          hipError_t e = ones.ensure(4 * most);
+          if (e == hipSuccess) e = mgc::launch_fill_u32(ones.as<uint32_t>(), most, 1u, st);
+          if (e != hipSuccess) { hip_fail(e, "ones"); return false; }
         }
-        MG_TRY(hipStreamSynchronize(st));
-      }
-      for (uint32_t i = 0; i < n_inputs; i++) mdb_free(hc[i]);
-      if (rc != MGC_OK) break;
-      // fold the inputs pairwise: ((in0 op in1) op in2) ...
-      const void *cur_k = in_k[0].p;
-      const uint32_t *cur_c = in_c[0].as<uint32_t>();
-      uint64_t cur_n = hn[0];
-      for (uint32_t i = 1; i < n_inputs; i++) {
-        const int t = (int)(i & 1u);
-        MG_TRY(ws.ensure(mgc::merge_workspace_bytes(cur_n, hn[i])));
+        auto cof = [&](uint32_t i) -> const uint32_t * { return use_ones ? ones.as<uint32_t>() : in_c[i].as<uint32_t>(); };
+        const void *cur_k = in_k[0].p;
+        const uint32_t *cur_c = cof(0);
+        uint64_t cur_n = hn[0];
+        for (uint32_t i = 1; i < n_inputs; i++) {
+          const int t = (int)(i & 1u);
+          uint64_t n_new = 0;
+          hipError_t e = ws.ensure(mgc::merge_workspace_bytes(cur_n, hn[i]));
+          if (e == hipSuccess) e = mgc::launch_merge_count(cur_k, cur_n, in_k[i].p, hn[i], kw, fold_op, ws.p, st, cur_c, cof(i));
+          if (e == hipSuccess) e = mgc::merge_read_total(ws.p, &n_new, st);
+          if (e == hipSuccess) e = ak[t].ensure(8 * (size_t)kw * n_new);
+          if (e == hipSuccess) e = ac[t].ensure(4 * n_new);
+          if (e == hipSuccess) e = mgc::launch_merge_emit(cur_k, cur_c, cur_n, in_k[i].p, cof(i), hn[i], kw, fold_op, ws.p, ak[t].p, ac[t].as<uint32_t>(), st);
+          if (e == hipSuccess) e = hipStreamSynchronize(st);
+          if (e != hipSuccess) { hip_fail(e, "merging a slice"); return false; }
+          cur_k = ak[t].p; cur_c = ac[t].as<uint32_t>(); cur_n = n_new;
+        }
+        *out_k = cur_k; *out_c = cur_c; *out_n = cur_n;
+        return true;
+      };
+      const void *res_k = nullptr; const uint32_t *res_c = nullptr; uint64_t res_n = 0;
+      if (!fold(op == MGC_MERGE_UNION, acc_k, acc_c, &res_k, &res_c, &res_n)) break;
+      if (by_membership) {
+        const void *mk = nullptr; const uint32_t *mc = nullptr; uint64_t mn = 0;
+        if (!fold(true, mem_k, mem_c, &mk, &mc, &mn)) break;          // same k-mers as the value fold, values = inputs holding each
         uint64_t n_new = 0;
-        MG_TRY(mgc::launch_merge_count(cur_k, cur_n, in_k[i].p, hn[i], kw, op, ws.p, st));
+        DBuf &ok = in_k[0], &oc = in_c[0];                             // the first input's buffers are free by now
+        MG_TRY(ws.ensure(mgc::select_workspace_bytes(res_n)));
+        MG_TRY(mgc::launch_select_count(res_k, res_c, mc, res_n, kw, 12, 0, ws.p, st));
         MG_TRY(mgc::merge_read_total(ws.p, &n_new, st));
-        MG_TRY(acc_k[t].ensure(8 * (size_t)kw * n_new));
-        MG_TRY(acc_c[t].ensure(4 * n_new));
-        MG_TRY(mgc::launch_merge_emit(cur_k, cur_c, cur_n, in_k[i].p, in_c[i].as<uint32_t>(), hn[i], kw, op, ws.p, acc_k[t].p,
-                                      acc_c[t].as<uint32_t>(), st));
+        if (res_k == ok.p) { hip_fail(hipErrorInvalidValue, "symmetric-difference buffers"); break; }
+        MG_TRY(ok.ensure(8 * (size_t)kw * n_new));
+        MG_TRY(oc.ensure(4 * n_new));
+        MG_TRY(mgc::launch_select_emit(res_k, res_c, mc, res_n, kw, 12, 0, ws.p, ok.p, oc.as<uint32_t>(), st));
         MG_TRY(hipStreamSynchronize(st));
-        cur_k = acc_k[t].p; cur_c = acc_c[t].as<uint32_t>(); cur_n = n_new;
+        res_k = ok.p; res_c = oc.as<uint32_t>(); res_n = n_new;
       }
-      rc = mgc_db_stream_write(d, cur_k, cur_c, cur_n, (uint64_t)ff * blocks_per_file, ((uint64_t)ff + 1) * blocks_per_file);
+      rc = mgc_db_stream_write(d, res_k, res_c, res_n, (uint64_t)ff * blocks_per_file, ((uint64_t)ff + 1) * blocks_per_file);
       if (rc == MGC_OK) rc = mgc_db_stream_sync(d);         // the buffers are reused for the next slice
       if (rc != MGC_OK) msg = std::string("mgc_db_merge: ") + mgc_db_stream_error(d);
     }
   done:
     for (auto &b : in_k) b.release();
     for (auto &b : in_c) b.release();
-    for (int t = 0; t < 2; t++) { acc_k[t].release(); acc_c[t].release(); }
+    for (int t = 0; t < 2; t++) { acc_k[t].release(); acc_c[t].release(); mem_k[t].release(); mem_c[t].release(); }
+    ones.release();
     ws.release();
     if (st) (void)hipStreamDestroy(st);
   }
 #undef MG_TRY
   close_all();
+  const int rc2 = mgc_db_stream_close(d, nullptr);
+  if (rc == MGC_OK && rc2 != MGC_OK) { rc = rc2; msg = mgc_db_stream_error(nullptr); }
+  if (rc != MGC_OK) set_err(nullptr, "%s", msg.c_str());
+  return rc;
+}
+
+// The single-input operations over a whole database: less-than ... not-equal-to, increase ... modulo (MGC_VALUE_*).
+extern "C" int mgc_db_filter(const char *input, int value_op, uint64_t constant, const char *output, int device, int host_threads) {
+  if (!input || !output || value_op < MGC_VALUE_LESS_THAN || value_op > MGC_VALUE_MODULO) { set_err(nullptr, "mgc_db_filter: bad arguments"); return MGC_EINVAL; }
+  std::vector<mdb_reader *> rd;
+  mdb_info first;
+  const char *ins[1] = {input};
+  if (!open_merge_inputs(ins, 1, rd, &first, "mgc_db_filter")) return MGC_EINVAL;
+  const uint32_t k = first.k, w_prefix = first.prefix_size, kw = k > 32 ? 2u : 1u;
+  if (device < 0) (void)hipGetDevice(&device);
+  mgc_db_stream *d = mgc_db_stream_open(output, k, w_prefix, 0, 0, 0, 1, host_threads, device);
+  if (!d) { mdb_reader_close(rd[0]); return MGC_EINVAL; }
+  int rc = MGC_OK;
+  std::string msg;
+  hipStream_t st = nullptr;
+  std::vector<DBuf> in_k(1), in_c(1);
+  DBuf out_k, out_c, ws;
+  std::vector<uint64_t> hn;
+  const uint64_t blocks_per_file = 1ull << (w_prefix - MGC_NUM_FILES_BITS);
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  for (uint32_t ff = 0; ff < MGC_NUM_FILES && rc == MGC_OK && e == hipSuccess; ff++) {
+    rc = load_slices(rd, ff, kw, in_k, in_c, hn, st, &msg);
+    if (rc != MGC_OK) { msg = "mgc_db_filter: " + msg; break; }
+    uint64_t n_new = 0;
+    e = ws.ensure(mgc::select_workspace_bytes(hn[0]));
+    if (e == hipSuccess) e = mgc::launch_select_count(in_k[0].p, in_c[0].as<uint32_t>(), nullptr, hn[0], kw, value_op, constant, ws.p, st);
+    if (e == hipSuccess) e = mgc::merge_read_total(ws.p, &n_new, st);
+    if (e == hipSuccess) e = out_k.ensure(8 * (size_t)kw * n_new);
+    if (e == hipSuccess) e = out_c.ensure(4 * n_new);
+    if (e == hipSuccess) e = mgc::launch_select_emit(in_k[0].p, in_c[0].as<uint32_t>(), nullptr, hn[0], kw, value_op, constant, ws.p, out_k.p, out_c.as<uint32_t>(), st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) break;
+    rc = mgc_db_stream_write(d, out_k.p, out_c.as<uint32_t>(), n_new, (uint64_t)ff * blocks_per_file, ((uint64_t)ff + 1) * blocks_per_file);
+    if (rc == MGC_OK) rc = mgc_db_stream_sync(d);
+    if (rc != MGC_OK) msg = std::string("mgc_db_filter: ") + mgc_db_stream_error(d);
+  }
+  if (e != hipSuccess && rc == MGC_OK) { rc = (e == hipErrorOutOfMemory) ? MGC_ENOMEM : MGC_EHIP; msg = std::string("mgc_db_filter: ") + hipGetErrorString(e); }
+  in_k[0].release(); in_c[0].release(); out_k.release(); out_c.release(); ws.release();
+  if (st) (void)hipStreamDestroy(st);
+  mdb_reader_close(rd[0]);
   const int rc2 = mgc_db_stream_close(d, nullptr);
   if (rc == MGC_OK && rc2 != MGC_OK) { rc = rc2; msg = mgc_db_stream_error(nullptr); }
   if (rc != MGC_OK) set_err(nullptr, "%s", msg.c_str());

@@ -74,7 +74,7 @@ def test_grammar_errors(meryl, tmp_path):
     assert p.returncode == 1 and "already set" in p.stderr                              # merylCommandBuilder.C:254-262
     p = run(meryl, "k=21", "count", fa, "output", tmp_path / "a", "output", tmp_path / "b", check=False)
     assert p.returncode == 1 and "already has an output" in p.stderr                    # merylOp.C:256-257
-    p = run(meryl, "union", check=False)
+    p = run(meryl, "statistics", check=False)
     assert p.returncode == 1 and "not part of this build" in p.stderr
     p = run(meryl, "union-sum", "output", tmp_path / "u", check=False)
     assert p.returncode == 1 and "has no inputs" in p.stderr
@@ -290,6 +290,66 @@ def test_cli_union_sum_tree_and_relatives(meryl, oracle_lib, tmp_path):
         l, _, c_ = r.read_all()
         r.close()
         assert [int(x) for x in l] == keys and [int(x) for x in c_] == want, word
+    # the set operations proper (merylOp-nextMer.C:559-613): union counts the inputs holding a k-mer, intersect keeps the FIRST
+    # input's value, subtract takes the later inputs' values off the first's while it stays above them, difference keeps what only
+    # the first input holds, symmetric-difference what exactly one input holds -- over three inputs and over two
+    def subtract(vals):
+        v = vals[0]
+        for x in vals[1:]:
+            if v > x:
+                v -= x
+            else:
+                return 0
+        return v
+    for n_in in (3, 2):
+        ds = per[:n_in]
+        names = [tmp_path / (n + ".meryl") for n in ("A", "B", "C")[:n_in]]
+        universe = sorted(set().union(*[set(d) for d in ds]))
+        spec = {
+            "union": {x: sum(1 for d in ds if x in d) for x in universe},
+            "intersect": {x: ds[0][x] for x in universe if all(x in d for d in ds)},
+            "subtract": {x: subtract([ds[0][x]] + [d[x] for d in ds[1:] if x in d]) for x in universe if x in ds[0]},
+            "difference": {x: ds[0][x] for x in universe if x in ds[0] and not any(x in d for d in ds[1:])},
+            "symmetric-difference": {x: [d[x] for d in ds if x in d][0] for x in universe if sum(1 for d in ds if x in d) == 1},
+        }
+        for word, want in spec.items():
+            want = {x: v for x, v in want.items() if v}
+            out = tmp_path / ("%s%d.meryl" % (word, n_in))
+            run(meryl, "-Q", word, *names, "output", out)
+            r = db.Reader(str(out))
+            l, _, c_ = r.read_all()
+            r.close()
+            assert [int(x) for x in l] == sorted(want) and [int(x) for x in c_] == [want[x] for x in sorted(want)], (word, n_in)
+    # the single-input value operations (:490-557), thresholds as a bare number, threshold=, distinct= and word-frequency=
+    a = per[0]
+    vals_sorted = sorted(a.values())
+    hv_, ho_ = np.unique(np.array(vals_sorted), return_counts=True)
+    nk = 0
+    for v_, o_ in zip(hv_, ho_):                                   # initializeThreshold, :104-114
+        nk += int(o_)
+        if nk >= int(0.9 * len(a)):
+            t_distinct = int(v_)
+            break
+    t_wf = int(0.00001 * sum(a.values()))
+    cases = [(["less-than", "3"], lambda v: v if v < 3 else 0), (["greater-than", "threshold=2"], lambda v: v if v > 2 else 0),
+             (["at-least", "2"], lambda v: v if v >= 2 else 0), (["at-most", "1"], lambda v: v if v <= 1 else 0),
+             (["equal-to", "2"], lambda v: v if v == 2 else 0), (["not-equal-to", "1"], lambda v: v if v != 1 else 0),
+             (["increase", "7"], lambda v: v + 7), (["decrease", "2"], lambda v: v - 2 if v >= 2 else 0),
+             (["multiply", "3"], lambda v: v * 3), (["divide", "2"], lambda v: v // 2),
+             (["divide-round", "2"], lambda v: 1 if v < 2 else int(np.round(v / 2.0 + 1e-9 * 0))), (["modulo", "2"], lambda v: v % 2),
+             (["less-than", "distinct=0.9"], lambda v: v if v < t_distinct else 0),
+             (["greater-than", "word-frequency=0.00001"], lambda v: v if v > t_wf else 0)]
+    for i, (words, f) in enumerate(cases):
+        out = tmp_path / ("v%d.meryl" % i)
+        run(meryl, "-Q", *words, tmp_path / "A.meryl", "output", out)
+        want = {x: f(v) for x, v in a.items()}
+        if words[0] == "divide-round":                            # C round(): halves away from zero
+            want = {x: (1 if v < 2 else int(v / 2.0 + 0.5)) for x, v in a.items()}
+        want = {x: v for x, v in want.items() if v}
+        r = db.Reader(str(out))
+        l, _, c_ = r.read_all()
+        r.close()
+        assert [int(x) for x in l] == sorted(want) and [int(x) for x in c_] == [want[x] for x in sorted(want)], words
     # print over a child operation
     p = run(meryl, "-Q", "print", "[union-min", tmp_path / "A.meryl", tmp_path / "B.meryl", "output", str(tmp_path / "pm.meryl") + "]")
     assert len(p.stdout.strip().split("\n")) == len(set(per[0]) | set(per[1]))

@@ -738,6 +738,18 @@ def _np_merge(a_lo, a_hi, a_c, b_lo, b_hi, b_c, op):
     """numpy statement of the two-input merge (python ints as keys: small inputs)"""
     A = {(int(h) << 64) | int(l): int(c) for l, h, c in zip(a_lo, a_hi, a_c)}
     B = {(int(h) << 64) | int(l): int(c) for l, h, c in zip(b_lo, b_hi, b_c)}
+    if op == "intersect":                                    # merylOp-nextMer.C:575-578: the first input's value
+        keys = sorted(set(A) & set(B))
+        return keys, [A[k] for k in keys]
+    if op == "subtract":                                     # :595-602, subtractCount :51-62
+        keys = sorted(k for k in A if k not in B or A[k] > B[k])
+        return keys, [A[k] - B[k] if k in B else A[k] for k in keys]
+    if op == "difference":                                   # :604-607
+        keys = sorted(set(A) - set(B))
+        return keys, [A[k] for k in keys]
+    if op == "symmetric-difference":                         # :609-612
+        keys = sorted(set(A) ^ set(B))
+        return keys, [A[k] if k in A else B[k] for k in keys]
     f = {"sum": lambda x, y: (x + y) & 0xFFFFFFFF, "min": min, "max": max}[op.split("-")[1]]
     if op.startswith("union"):
         keys = sorted(set(A) | set(B))
@@ -772,6 +784,8 @@ def test_device_merge_matches_numpy(ops, torch_cuda, kw, na, nb, overlap):
     a, b = mk(na, pool), mk(nb, pool)
     ac = rng.integers(1, 0xFFFFFFFF, na, dtype=np.uint64).astype(np.uint32)
     bc = rng.integers(1, 1000, nb).astype(np.uint32)
+    if na > 100:
+        ac[::3] = rng.integers(1, 1000, ac[::3].size).astype(np.uint32)      # subtract: values below, equal to and above the other side's
 
     def dev(x, c):
         if kw == 2:
