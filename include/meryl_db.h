@@ -125,6 +125,13 @@ int  mdb_reader_block_header(mdb_reader *r, uint32_t ff, uint64_t position, mdb_
 int  mdb_reader_read_block_raw(mdb_reader *r, uint32_t ff, uint64_t position, mdb_block_header *h,
                                uint64_t **prefix_delta, uint64_t **top, uint64_t **rem_hi, uint64_t **rem_lo,
                                uint32_t **values);
+/* For a decoder that does not run on the host (meryl_amd/csrc/mgc_decode.hip): the raw bytes of data file ff (malloc'd, *size
+ * bytes followed by 16 zero bytes) and, for every block of its index that holds k-mers, where its stuffedBits object lies
+ * and how long it is -- every object's framing validated against the file size, out_offset = k-mers of the blocks before it.
+ * MGC_EUNSUPPORTED when an object is framed in a way only the host decoder follows (mdb_reader_read_file_ex reads it). */
+typedef struct mdb_raw_block { uint64_t object_offset, n_bits, n_sub_blocks, n_kmers, prefix, out_offset; } mdb_raw_block;
+int  mdb_reader_raw_file(mdb_reader *r, uint32_t ff, unsigned char **bytes, uint64_t *size, mdb_raw_block **blocks,
+                         uint64_t *n_blocks, uint64_t *n_kmers);
 void mdb_reader_close(mdb_reader *r);
 void mdb_free(void *p);
 

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmeryl_gpu_count.so")
 SOURCES = ["mgc_kmer.hip", "mgc_sort.hip", "mgc_scan.hip", "mgc_finish.hip", "mgc_misc.hip", "mgc_parse.hip",
-           "mgc_encode.hip", "mgc_merge.hip", "mgc_lookup.hip",
+           "mgc_encode.hip", "mgc_decode.hip", "mgc_merge.hip", "mgc_lookup.hip",
            "mgc_api.cpp", "mgc_stream.cpp", "mgc_runs.cpp", "mgc_node.cpp", "meryl_db.cpp", "meryl_seq.cpp"]
 HEADERS = ["mgc_device.h", "mgc_common.hpp", "mdb_layout.h", "mgc_session.hpp", "mgc_runs.hpp",
            os.path.join("..", "..", "include", "meryl_gpu_count.h"),

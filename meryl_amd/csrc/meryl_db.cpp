@@ -868,6 +868,68 @@ extern "C" int mdb_reader_read_file_ex(mdb_reader *r, uint32_t ff, uint64_t **kl
   return MGC_OK;
 }
 
+extern "C" int mdb_reader_raw_file(mdb_reader *r, uint32_t ff, unsigned char **bytes, uint64_t *size, mdb_raw_block **blocks,
+                                   uint64_t *n_blocks, uint64_t *n_kmers) {
+  if (!r || ff >= MGC_NUM_FILES || !bytes || !size || !blocks || !n_blocks || !n_kmers) return MGC_EINVAL;
+  *bytes = nullptr; *blocks = nullptr; *size = 0; *n_blocks = 0; *n_kmers = 0;
+  std::vector<FileIndexEntry> idx;
+  if (!load_file_index(r, ff, idx)) return MGC_EINVAL;
+  const std::string name = block_name(r->dir, ff, false);
+  struct stat st;
+  if (stat(name.c_str(), &st) != 0) { db_err("read_file: cannot stat '%s'", name.c_str()); return MGC_EINVAL; }
+  const uint64_t fsize = (uint64_t)st.st_size;
+  unsigned char *file = (unsigned char *)malloc(fsize + 16);
+  if (!file) { db_err("read_file: out of memory for '%s'", name.c_str()); return MGC_ENOMEM; }
+  memset(file + fsize, 0, 16);
+  {
+    const int fd = open(name.c_str(), O_RDONLY);
+    bool ok = fd >= 0;
+    uint64_t have = 0;
+    while (ok && have < fsize) {
+      const ssize_t got = pread(fd, file + have, (size_t)std::min<uint64_t>(fsize - have, 1ull << 30), (off_t)have);
+      if (got <= 0) ok = false; else have += (uint64_t)got;
+    }
+    if (fd >= 0) close(fd);
+    if (!ok) { free(file); db_err("read_file: cannot read '%s'", name.c_str()); return MGC_EINVAL; }
+  }
+  uint64_t nb = 0, total = 0;
+  for (const FileIndexEntry &e : idx) if (e.n_kmers) nb++;
+  mdb_raw_block *out = (mdb_raw_block *)malloc(sizeof(mdb_raw_block) * (nb ? nb : 1));
+  if (!out) { free(file); db_err("read_file: out of memory for '%s'", name.c_str()); return MGC_ENOMEM; }
+  int rc = MGC_OK;
+  uint64_t j = 0;
+  for (const FileIndexEntry &e : idx) {
+    if (!e.n_kmers) continue;
+    // the framing of the object (A2), checked the way stuffed_in_memory checks it -- but only the canonical shape (every
+    // sub-block but the last full) is handed on: then word w of the bit stream sits at stuffed_word_offset(nsb, w)
+    bool ok = e.position < fsize && !(e.position & 7) && fsize - e.position >= 48 && e.n_kmers <= fsize * 8;
+    uint64_t lenmax = 0, nbits = 0; uint32_t nsb = 0;
+    if (ok) {
+      memcpy(&lenmax, file + e.position, 8); memcpy(&nsb, file + e.position + 8, 4);
+      ok = nsb >= 1 && nsb <= (1u << 20) && e.position + 16 + 32ull * nsb <= fsize;
+    }
+    if (ok && lenmax != STUFFED_BLOCK_BITS) { rc = MGC_EUNSUPPORTED; break; }
+    for (uint32_t i = 0; i < nsb && ok; i++) {
+      uint64_t b, l, nw;
+      memcpy(&b, file + e.position + 16 + 8ull * i, 8); memcpy(&l, file + e.position + 16 + 8ull * nsb + 8ull * i, 8);
+      const uint64_t hdr = e.position + stuffed_word_offset(nsb, (uint64_t)i * STUFFED_BLOCK_WORDS) - 16;
+      ok = hdr + 16 <= fsize;
+      if (ok) { memcpy(&nw, file + hdr, 8); ok = b == (uint64_t)i * STUFFED_BLOCK_BITS && nw == (l + 63) / 64 && l <= STUFFED_BLOCK_BITS && hdr + 16 + 8 * nw <= fsize; }
+      if (ok && i + 1 < nsb && l != STUFFED_BLOCK_BITS) { rc = MGC_EUNSUPPORTED; break; }
+      nbits += l;
+    }
+    if (rc != MGC_OK) break;
+    if (!ok || total + e.n_kmers < total) { rc = MGC_EINVAL; db_err("read_file: corrupt block in '%s'", r->dir.c_str()); break; }
+    out[j].object_offset = e.position; out[j].n_bits = nbits; out[j].n_sub_blocks = nsb; out[j].n_kmers = e.n_kmers; out[j].prefix = e.prefix;
+    out[j].out_offset = total;
+    total += e.n_kmers;
+    j++;
+  }
+  if (rc != MGC_OK) { free(file); free(out); return rc; }
+  *bytes = file; *size = fsize; *blocks = out; *n_blocks = nb; *n_kmers = total;
+  return MGC_OK;
+}
+
 extern "C" int mdb_reader_read_file(mdb_reader *r, uint32_t ff, uint64_t **klo, uint64_t **khi, uint32_t **cnt,
                                     uint64_t *n_out) {
   return mdb_reader_read_file_ex(r, ff, klo, khi, cnt, nullptr, n_out);

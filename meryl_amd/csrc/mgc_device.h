@@ -171,6 +171,11 @@ uint32_t   value_hist_small_bins();
 hipError_t launch_value_hist(const uint32_t *d_counts, uint64_t n, uint64_t *d_hist, uint32_t *d_big_list, uint64_t big_cap,
                              uint64_t *d_big_n, hipStream_t st);
 
+// ---- database blocks decoded on the device (mgc_decode.hip): d_file = the data file's bytes (+ 16 bytes of slack),
+// d_blocks = mdb_raw_block[n_blocks] (include/meryl_db.h, mdb_reader_raw_file); one thread per block; *d_err != 0: a corrupt block
+hipError_t launch_decode_blocks(const void *d_file, const void *d_blocks, uint64_t n_blocks, uint32_t suffix_size, uint32_t label_size,
+                                uint32_t key_words, void *d_keys, uint32_t *d_counts, uint32_t *d_err, hipStream_t st);
+
 // ---- merge of two sorted distinct (k-mer, value) streams (mgc_merge.hip) ----------------------------------------
 // op: 0 union-sum, 1 union-min, 2 union-max, 3 intersect-sum, 4 intersect-min, 5 intersect-max
 size_t     merge_workspace_bytes(uint64_t na, uint64_t nb);

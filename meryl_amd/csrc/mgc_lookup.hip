@@ -294,6 +294,82 @@ extern "C" mgc_lookup *mgc_lookup_load(const char *db_path, uint64_t min_value, 
   mdb_reader_info(r, &info);
   mdb_reader_close(r);
   const uint32_t kw = info.k > 32 ? 2u : 1u;
+  if (host_threads <= 0) host_threads = (int)std::thread::hardware_concurrency();
+  host_threads = std::max(1, std::min(host_threads, MGC_NUM_FILES));
+  // Device decode (mgc_decode.hip): host threads only READ the 64 data files and check their framing; the bytes go to HBM as
+  // they are and every block is decoded there (one thread per block), straight into the table's arrays; the value filter is
+  // the device compaction mgc_lookup_from_device uses.  MGC_DECODE_HOST=1, or a file only the host decoder follows: below.
+  const bool host_decode = getenv("MGC_DECODE_HOST") && getenv("MGC_DECODE_HOST")[0] == '1';      // read per call: the tests switch it
+  if (!host_decode) {
+    if (device < 0) (void)hipGetDevice(&device);
+    if (hipSetDevice(device) != hipSuccess) { lk_err("mgc_lookup_load: hipSetDevice failed"); return nullptr; }
+    struct Raw { unsigned char *bytes = nullptr; uint64_t size = 0, nb = 0, n = 0; mdb_raw_block *blocks = nullptr; int rc = MGC_OK; };
+    std::vector<Raw> raw(MGC_NUM_FILES);
+    std::atomic<uint32_t> nextf(0);
+    std::mutex mu2;
+    std::string msg2;
+    auto reader = [&]() {
+      mdb_reader *rr = mdb_reader_open(db_path);
+      if (!rr) { std::lock_guard<std::mutex> g(mu2); msg2 = mdb_last_error(); for (auto &x : raw) if (x.rc == MGC_OK && !x.bytes) x.rc = MGC_EINVAL; return; }
+      for (;;) {
+        const uint32_t ff = nextf.fetch_add(1);
+        if (ff >= MGC_NUM_FILES) break;
+        Raw &x = raw[ff];
+        x.rc = mdb_reader_raw_file(rr, ff, &x.bytes, &x.size, &x.blocks, &x.nb, &x.n);
+        if (x.rc != MGC_OK && x.rc != MGC_EUNSUPPORTED) { std::lock_guard<std::mutex> g(mu2); msg2 = mdb_last_error(); }
+      }
+      mdb_reader_close(rr);
+    };
+    {
+      std::vector<std::thread> pool;
+      for (int i = 1; i < host_threads; i++) pool.emplace_back(reader);
+      reader();
+      for (auto &th : pool) th.join();
+    }
+    bool all_ok = true, hard_fail = false;
+    uint64_t total = 0, max_size = 0, max_nb = 0;
+    for (const Raw &x : raw) { all_ok = all_ok && x.rc == MGC_OK; hard_fail = hard_fail || (x.rc != MGC_OK && x.rc != MGC_EUNSUPPORTED); total += x.n; max_size = std::max(max_size, x.size); max_nb = std::max(max_nb, x.nb); }
+    auto free_raw = [&]() { for (Raw &x : raw) { mdb_free(x.bytes); mdb_free(x.blocks); x.bytes = nullptr; x.blocks = nullptr; } };
+    if (hard_fail) { free_raw(); lk_err("mgc_lookup_load: " + msg2); return nullptr; }
+    if (all_ok) {
+      const size_t kbytes = sizeof(uint64_t) * kw;
+      void *dk = nullptr, *dfile = nullptr, *dblocks = nullptr;
+      uint32_t *dv = nullptr, *derr = nullptr, h_err = 0;
+      hipError_t e = hipMalloc(&dk, kbytes * (total ? total : 1));
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dv), sizeof(uint32_t) * (total ? total : 1));
+      if (e == hipSuccess) e = hipMalloc(&dfile, max_size + 16);
+      if (e == hipSuccess) e = hipMalloc(&dblocks, sizeof(mdb_raw_block) * (max_nb ? max_nb : 1));
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&derr), 256);
+      if (e == hipSuccess) e = hipMemset(derr, 0, 4);
+      uint64_t o = 0;
+      for (uint32_t ff = 0; ff < MGC_NUM_FILES && e == hipSuccess; ff++) {
+        const Raw &x = raw[ff];
+        if (x.n) {
+          e = hipMemcpy(dfile, x.bytes, x.size + 16, hipMemcpyHostToDevice);
+          if (e == hipSuccess) e = hipMemcpy(dblocks, x.blocks, sizeof(mdb_raw_block) * x.nb, hipMemcpyHostToDevice);
+          if (e == hipSuccess) e = mgc::launch_decode_blocks(dfile, dblocks, x.nb, info.suffix_size, info.label_size, kw,
+                                                             reinterpret_cast<unsigned char *>(dk) + kbytes * o, dv + o, derr, nullptr);
+          if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        }
+        o += x.n;
+      }
+      if (e == hipSuccess) e = hipMemcpy(&h_err, derr, 4, hipMemcpyDeviceToHost);
+      free_raw();
+      if (dfile) (void)hipFree(dfile);
+      if (dblocks) (void)hipFree(dblocks);
+      if (derr) (void)hipFree(derr);
+      if (e != hipSuccess || h_err) {
+        if (dk) (void)hipFree(dk);
+        if (dv) (void)hipFree(dv);
+        lk_err(e != hipSuccess ? std::string("mgc_lookup_load: ") + hipGetErrorString(e) : std::string("mgc_lookup_load: corrupt block in '") + db_path + "' (device decoder)");
+        return nullptr;
+      }
+      mgc_lookup *t = mgc_lookup_from_device(dk, dv, total, info.k, min_value, max_value, device);
+      (void)hipFree(dk); (void)hipFree(dv);
+      return t;
+    }
+    free_raw();                                            // some file needs the host decoder: all of them take it
+  }
   // the 64 files decoded by host threads (one reader each: the reader is not shared), value filter applied on the way
   struct Part { std::vector<uint64_t> keys; std::vector<uint32_t> vals; uint64_t n_db = 0; };
   std::vector<Part> parts(MGC_NUM_FILES);
@@ -323,8 +399,6 @@ extern "C" mgc_lookup *mgc_lookup_load(const char *db_path, uint64_t min_value, 
     }
     mdb_reader_close(rr);
   };
-  if (host_threads <= 0) host_threads = (int)std::thread::hardware_concurrency();
-  host_threads = std::max(1, std::min(host_threads, MGC_NUM_FILES));
   std::vector<std::thread> pool;
   for (int i = 1; i < host_threads; i++) pool.emplace_back(worker);
   worker();

@@ -687,19 +687,32 @@ extern "C" int mgc_finish_labelled(mgc_session *s, mgc_block_cb2 cb, void *ctx, 
 // device (mgc_merge.hip), encoded on the device and written by the database stream -- the same merge that folds the
 // batches of an out-of-core count.
 namespace {
-// the slice (file ff) of every input decoded by host threads (one per input) and uploaded: in_k[i] / in_c[i] / hn[i]
+// The slice (file ff) of every input in HBM: in_k[i] / in_c[i] / hn[i].  The data file's bytes are read by one host thread per
+// input, uploaded as they are and DECODED ON THE DEVICE (mgc_decode.hip: one thread per block) -- the host only does I/O and
+// checks the framing.  MGC_DECODE_HOST=1, or a file framed in a way only the host decoder follows: decoded by the host
+// threads (65-70 M k-mers/s each) and uploaded as arrays, as before.
 int load_slices(std::vector<mdb_reader *> &rd, uint32_t ff, uint32_t kw, std::vector<DBuf> &in_k, std::vector<DBuf> &in_c,
                 std::vector<uint64_t> &hn, hipStream_t st, std::string *msg) {
   const uint32_t n_inputs = (uint32_t)rd.size();
+  const bool host_decode = getenv("MGC_DECODE_HOST") && getenv("MGC_DECODE_HOST")[0] == '1';      // read per call: the tests switch it
+  struct Raw { unsigned char *bytes = nullptr; uint64_t size = 0; mdb_raw_block *blocks = nullptr; uint64_t nb = 0; bool on_device = false; };
+  std::vector<Raw> raw(n_inputs);
   std::vector<std::vector<uint64_t>> hk(n_inputs);
   std::vector<uint32_t *> hc(n_inputs, nullptr);
   std::vector<int> rrc(n_inputs, MGC_OK);
   std::vector<std::string> rmsg(n_inputs);
+  std::vector<mdb_info> infos(n_inputs);
   hn.assign(n_inputs, 0);
   {
     std::vector<std::thread> th;
     for (uint32_t i = 0; i < n_inputs; i++)
       th.emplace_back([&, i]() {
+        mdb_reader_info(rd[i], &infos[i]);
+        if (!host_decode) {
+          const int rc = mdb_reader_raw_file(rd[i], ff, &raw[i].bytes, &raw[i].size, &raw[i].blocks, &raw[i].nb, &hn[i]);
+          if (rc == MGC_OK) { raw[i].on_device = true; return; }
+          if (rc != MGC_EUNSUPPORTED) { rrc[i] = rc; rmsg[i] = mdb_last_error(); return; }
+        }
         uint64_t *lo = nullptr, *hi = nullptr;
         rrc[i] = mdb_reader_read_file_ex(rd[i], ff, &lo, &hi, &hc[i], nullptr, &hn[i]);
         if (rrc[i] != MGC_OK) { rmsg[i] = mdb_last_error(); return; }
@@ -714,14 +727,32 @@ int load_slices(std::vector<mdb_reader *> &rd, uint32_t ff, uint32_t kw, std::ve
   for (uint32_t i = 0; i < n_inputs; i++)
     if (rrc[i] != MGC_OK && rc == MGC_OK) { rc = rrc[i]; *msg = rmsg[i]; }
   hipError_t e = hipSuccess;
+  DBuf d_file, d_blocks, d_err;
+  uint32_t h_err = 0;
+  if (rc == MGC_OK) e = d_err.ensure(256);
   for (uint32_t i = 0; i < n_inputs && rc == MGC_OK && e == hipSuccess; i++) {
     e = in_k[i].ensure(8 * (size_t)kw * hn[i]);
     if (e == hipSuccess) e = in_c[i].ensure(4 * hn[i]);
-    if (e == hipSuccess && hn[i]) e = hipMemcpyAsync(in_k[i].p, hk[i].data(), 8 * (size_t)kw * hn[i], hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && hn[i]) e = hipMemcpyAsync(in_c[i].p, hc[i], 4 * hn[i], hipMemcpyHostToDevice, st);
+    if (e != hipSuccess || !hn[i]) continue;
+    if (raw[i].on_device) {
+      e = d_file.ensure(raw[i].size + 16);
+      if (e == hipSuccess) e = d_blocks.ensure(sizeof(mdb_raw_block) * raw[i].nb);
+      if (e == hipSuccess) e = hipMemsetAsync(d_err.p, 0, 4, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_file.p, raw[i].bytes, raw[i].size + 16, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_blocks.p, raw[i].blocks, sizeof(mdb_raw_block) * raw[i].nb, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = mgc::launch_decode_blocks(d_file.p, d_blocks.p, raw[i].nb, infos[i].suffix_size, infos[i].label_size, kw, in_k[i].p,
+                                                         in_c[i].as<uint32_t>(), d_err.as<uint32_t>(), st);
+      if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err.p, 4, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);                     // d_file is reused by the next input
+      if (e == hipSuccess && h_err) { rc = MGC_EINVAL; *msg = "corrupt block in a database file (device decoder, code " + std::to_string(h_err) + ")"; }
+    } else {
+      e = hipMemcpyAsync(in_k[i].p, hk[i].data(), 8 * (size_t)kw * hn[i], hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(in_c[i].p, hc[i], 4 * hn[i], hipMemcpyHostToDevice, st);
+    }
   }
   if (e == hipSuccess && rc == MGC_OK) e = hipStreamSynchronize(st);
-  for (uint32_t i = 0; i < n_inputs; i++) mdb_free(hc[i]);
+  for (uint32_t i = 0; i < n_inputs; i++) { mdb_free(hc[i]); mdb_free(raw[i].bytes); mdb_free(raw[i].blocks); }
+  d_file.release(); d_blocks.release(); d_err.release();
   if (e != hipSuccess) { rc = (e == hipErrorOutOfMemory) ? MGC_ENOMEM : MGC_EHIP; *msg = std::string("uploading a slice: ") + hipGetErrorString(e); }
   return rc;
 }

@@ -127,3 +127,48 @@ def test_meryl_lookup_existence_cli(native_lib, oracle_lib, tmp_path):
                 want += [str(len(kept)), str(sum(1 for x in klo if int(x) in kept))]
             assert row == ["q%d" % i] + want, (i, row, want)
 
+
+
+@pytest.mark.parametrize("k,w_prefix,label_size,n", [(31, 6, 0, 2_600_000), (21, 18, 0, 300_000), (51, 8, 9, 400_000), (16, 12, 0, 50_000), (4, 6, 0, 200)])
+def test_device_block_decoder_equals_host_decoder(native_lib, tmp_path, monkeypatch, k, w_prefix, label_size, n):
+    """mgc_decode.hip against the host reader: random distinct k-mers + values -> database (device encoder) -> loaded back through
+    the DEVICE decoder (the default of mgc_lookup_load: raw file bytes uploaded, one thread per block) and through the host
+    decoder (MGC_DECODE_HOST=1).  The first case puts 2.6 M k-mers into ONE block (a stuffedBits object of several 16 MiB
+    sub-blocks); k = 51 carries labels (skipped by both); k = 4 has blocks of a handful of k-mers and empty ones."""
+    import torch
+    from meryl_amd import count, db, lookup
+    rng = np.random.default_rng(k * 7 + w_prefix)
+    bits = 2 * k
+    if k == 31:                                               # everything in prefix 0: one huge block
+        lo = np.unique(rng.integers(0, 1 << (bits - w_prefix), n, dtype=np.uint64))
+        hi = np.zeros_like(lo)
+    elif bits <= 64:
+        lo = np.unique(rng.integers(0, 1 << bits, n, dtype=np.uint64) if bits < 64 else rng.integers(0, 1 << 63, n, dtype=np.uint64))
+        hi = np.zeros_like(lo)
+    else:
+        hi = rng.integers(0, 1 << (bits - 64), n, dtype=np.uint64)
+        lo = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+        order = np.lexsort((lo, hi))
+        hi, lo = hi[order], lo[order]
+        keep = np.ones(n, bool); keep[1:] = (hi[1:] != hi[:-1]) | (lo[1:] != lo[:-1])
+        hi, lo = hi[keep], lo[keep]
+    vals = rng.integers(1, 0xFFFFFFFF, lo.size, dtype=np.uint64).astype(np.uint32)
+    vals[::5] = 1
+    keys = _keys_tensor(torch, lo, hi, k)
+    cnts = torch.from_numpy(vals.view(np.int32).copy()).cuda()
+    path = str(tmp_path / "db")
+    st = count.DbStream(path, k, w_prefix, label_size, 0x155 if label_size else 0, host_threads=4)
+    st.write(keys, cnts, 0, 1 << w_prefix)
+    st.close()
+    for host in ("0", "1"):
+        monkeypatch.setenv("MGC_DECODE_HOST", host)
+        lk = lookup.Lookup.load(path)
+        assert lk.info.n_kmers == lo.size == lk.info.n_kmers_in_db
+        got = lk.values(keys).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, vals), host
+        lk2 = lookup.Lookup.load(path, min_value=2)           # the value filter on top of either decoder
+        assert lk2.info.n_kmers == int((vals >= 2).sum())
+    r = db.Reader(path)
+    rlo, rhi, rcn = r.read_all()
+    r.close()
+    assert np.array_equal(rlo, lo) and np.array_equal(rhi, hi) and np.array_equal(rcn, vals)
