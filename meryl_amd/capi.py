@@ -31,7 +31,7 @@ SYMBOLS = (
     "mdb_writer_open", "mdb_writer_open_ex", "mdb_merge_parts", "mdb_writer_add_block", "mdb_writer_add_block_labelled",
     "mdb_writer_add_encoded", "mdb_writer_reserve_encoded", "mdb_writer_write_at", "mdb_writer_add_histogram", "mdb_writer_close", "mdb_writer_discard", "mdb_last_error",
     "mdb_reader_open", "mdb_reader_info", "mdb_reader_histogram", "mdb_reader_read_file", "mdb_reader_read_file_ex",
-    "mdb_reader_file_index", "mdb_reader_block_header", "mdb_reader_read_block_raw", "mdb_reader_close",
+    "mdb_reader_file_index", "mdb_reader_block_header", "mdb_reader_read_block_raw", "mdb_reader_raw_file", "mdb_reader_close",
     "mdb_free", "mgc_write_database", "mgc_write_database_profiled",
     "mgc_db_stream_open", "mgc_db_stream_write", "mgc_db_stream_sync", "mgc_db_stream_close", "mgc_db_stream_error", "mgc_db_stream_queued", "mgc_db_stream_done", "mgc_db_stream_wait_buffers",
     "mgc_runs_open", "mgc_runs_add", "mgc_runs_write", "mgc_runs_get_profile", "mgc_runs_error", "mgc_runs_close", "mgc_get_runs_profile", "mgc_db_merge", "mgc_db_filter", "mgc_count_node", "mgc_count_node_batched", "mgc_count_node_staged", "mgc_node_plan",
@@ -340,6 +340,7 @@ def lib():
     sig("mdb_reader_file_index", i32, vp, u32, vp)
     sig("mdb_reader_block_header", i32, vp, u32, u64, P(BlockHeader))
     sig("mdb_reader_read_block_raw", i32, vp, u32, u64, P(BlockHeader), P(vp), P(vp), P(vp), P(vp), P(vp))
+    sig("mdb_reader_raw_file", i32, vp, u32, P(vp), P(u64), P(vp), P(u64), P(u64))
     sig("mdb_reader_close", None, vp)
     sig("mdb_free", None, vp)
     sig("mgc_write_database", i32, vp, ctypes.c_char_p, i32)

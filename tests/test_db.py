@@ -400,3 +400,46 @@ def test_lookup_estimate_needs_no_device(native_lib, tmp_path, k, label_size):
     p = subprocess.run([cli, "-existence", "-estimate", "-mers", str(tmp_path / "d.meryl"), "-memory", "0.00001"],
                        capture_output=True, text=True, timeout=120)
     assert p.returncode == 1 and "Not enough memory" in p.stderr
+
+
+def test_raw_file_lists_validated_blocks(native_lib, tmp_path):
+    """mdb_reader_raw_file (what the device decoder is fed): the data file's bytes and one descriptor per block that holds k-mers --
+    object offsets = the index's positions, k-mers and output offsets add up, a truncated file is refused."""
+    import ctypes
+    from meryl_amd import capi, db
+    k, wp = 15, 8
+    rng = np.random.default_rng(3)
+    keys = np.unique(rng.integers(0, 1 << (2 * k), 20_000, dtype=np.uint64))
+    keys = keys[(keys >> np.uint64(2 * k - wp)) % np.uint64(3) != 0]          # some prefixes stay empty
+    cnt = rng.integers(1, 100, keys.size).astype(np.uint32)
+    path = str(tmp_path / "db")
+    w = db.Writer(path, k, wp)
+    w_data = 2 * k - wp
+    pref = (keys >> np.uint64(w_data)).astype(np.int64)
+    starts = np.searchsorted(pref, np.arange(0, (1 << wp) + 1))
+    for p in range(1 << wp):
+        w.add_block(p, keys[starts[p]:starts[p + 1]] & np.uint64((1 << w_data) - 1), cnt[starts[p]:starts[p + 1]])
+    w.close()
+    L = capi.lib()
+    r = db.Reader(path)
+    total = 0
+    for ff in (0, 5, 63):
+        by, sz, bl, nb, nk = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64()
+        assert L.mdb_reader_raw_file(r._h, ff, ctypes.byref(by), ctypes.byref(sz), ctypes.byref(bl), ctypes.byref(nb), ctypes.byref(nk)) == 0
+        idx = [e for e in r.file_index(ff) if e[2]]
+        desc = np.ctypeslib.as_array(ctypes.cast(bl, ctypes.POINTER(ctypes.c_uint64)), shape=(max(nb.value, 1), 6))[:nb.value].copy()
+        assert nb.value == len(idx) and nk.value == sum(e[2] for e in idx) == len(r.read_file(ff)[0])
+        assert [int(x) for x in desc[:, 0]] == [e[1] for e in idx] and [int(x) for x in desc[:, 4]] == [e[0] for e in idx]
+        assert [int(x) for x in desc[:, 5]] == list(np.cumsum([0] + [e[2] for e in idx])[:-1])
+        assert sz.value == os.path.getsize(os.path.join(path, "0x%s.merylData" % format(ff, "06b")))
+        L.mdb_free(by); L.mdb_free(bl)
+        total += nk.value
+    r.close()
+    # a data file cut short: the framing check refuses it before anything is uploaded
+    name = os.path.join(path, "0x%s.merylData" % format(5, "06b"))
+    data = open(name, "rb").read()
+    open(name, "wb").write(data[:len(data) - 40])
+    r = db.Reader(path)
+    by, sz, bl, nb, nk = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64()
+    assert L.mdb_reader_raw_file(r._h, 5, ctypes.byref(by), ctypes.byref(sz), ctypes.byref(bl), ctypes.byref(nb), ctypes.byref(nk)) != 0
+    r.close()
