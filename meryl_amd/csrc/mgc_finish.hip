@@ -1922,6 +1922,18 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                        d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b); } while (0)
     if (use_bitmap && low_bits <= 16)      { if (d_nz) MGC_BITMAP_LAUNCH(16, true, 12); else MGC_BITMAP_LAUNCH(16, false, 12); }
     else if (use_bitmap && low_bits <= 18) { if (d_nz) MGC_BITMAP_LAUNCH(18, true, 4);  else MGC_BITMAP_LAUNCH(18, false, 4); }
+    else if (hash_dbg_buffer()) {                                  // MGC_HASH_DBG=1: the instrumented instantiation (per-phase cycle stamps)
+      if (d_nz)
+        hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true, true, true, true>), dim3(hgrid), dim3(256), 0, st,
+                           reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                           d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, hash_dbg_buffer(), tr_a, tr_b);
+      else
+        hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true, false, true, true>), dim3(hgrid), dim3(256), 0, st,
+                           reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                           d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, hash_dbg_buffer(), tr_a, tr_b);
+      MGC_CHECK(hipGetLastError());
+      hash_dbg_report(st, ng);
+    }
     else if (d_nz) { if (binrank) MGC_NARROW_LAUNCH(true, true);  else MGC_NARROW_LAUNCH(true, false); }
     else           { if (binrank) MGC_NARROW_LAUNCH(false, true); else MGC_NARROW_LAUNCH(false, false); }
 #undef MGC_BITMAP_LAUNCH
