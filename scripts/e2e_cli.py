@@ -32,18 +32,24 @@ with open(fq, "wb") as f:
 del bases
 torch.cuda.empty_cache()
 cli = build.build_cli()
-settings = [{}, {"MGC_TEXT_READERS": "16", "MGC_TEXT_RING": "24"}, {"MGC_TEXT_READERS": "2", "MGC_TEXT_RING": "8"},
-            {"MERYL_HOST_PARSER_NONE": "1", "MGC_TEXT_READERS": "32", "MGC_TEXT_RING": "48"}]
-for env_add in settings:
+# every setting: (environment additions, command prefix)
+settings = [({}, []), ({"MGC_TEXT_READERS": "32", "MGC_TEXT_RING": "48"}, []), ({"MGC_TEXT_READERS": "8", "MGC_TEXT_RING": "16"}, []),
+            ({}, ["taskset", "-c", "0-63,128-191"]), ({}, ["taskset", "-c", "64-127,192-255"]),
+            ({"MGC_TEXT_MMAP": "1"}, []), ({}, [])]
+try:
+    print(subprocess.run(["numactl", "-H"], capture_output=True, text=True).stdout[:1500])
+except OSError:
+    print(subprocess.run(["lscpu"], capture_output=True, text=True).stdout[-900:])
+for env_add, prefix in settings:
     out = os.path.join(d, "out.meryl")
     shutil.rmtree(out, ignore_errors=True)
     env = dict(os.environ, MGC_IO_TRACE="1", **env_add)
     t0 = time.perf_counter()
-    p = subprocess.run([cli, "-V", "k=21", "memory=64", "threads=32", "n=10000000000", "count", fq, "output", out],
+    p = subprocess.run(prefix + [cli, "-V", "k=21", "memory=64", "threads=32", "n=10000000000", "count", fq, "output", out],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     wall = time.perf_counter() - t0
-    print("==", env_add, "rc", p.returncode, "wall %.3f s" % wall)
+    print("==", env_add, " ".join(prefix), "rc", p.returncode, "wall %.3f s" % wall)
     for l in p.stderr.splitlines():
-        if l.startswith("[io]") or l.startswith("TIMING") or "batches" in l:
-            print("   ", l)
+        if l.startswith("[io] text") or l.startswith("TIMING") or "batches" in l:
+            print("   ", l[:330])
 shutil.rmtree(d, ignore_errors=True)
