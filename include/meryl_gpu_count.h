@@ -252,6 +252,10 @@ int mgc_push_bases(mgc_session *s, const char *bases, size_t len, int end_of_seq
  * batch) and the runs may keep 60 % of the HBM that is free when the first batch has been counted
  * (mgc_set_result_budget: bytes; 0 restores the default). */
 int mgc_set_batch_bases(mgc_session *s, uint64_t bases_per_batch);
+/* Optional, right after mgc_open: about how many bases will be pushed.  The count's largest buffer is then allocated by a
+ * helper thread while the caller reads and uploads its input (a first large hipMalloc is slow, and nothing needs the
+ * memory before mgc_count).  Ignored when the input is expected to take batches; a wrong estimate only costs time. */
+int mgc_prepare(mgc_session *s, uint64_t expected_bases);
 int mgc_set_result_budget(mgc_session *s, uint64_t device_bytes);
 int mgc_result_out_of_core(const mgc_session *s);
 

@@ -26,7 +26,7 @@ SYMBOLS = (
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_dev_synth_reads_ex", "mgc_version",
     "mgc_dev_merge_workspace_bytes", "mgc_dev_merge_count", "mgc_dev_merge_count_values", "mgc_dev_merge_emit",
     "mgc_dev_select_workspace_bytes", "mgc_dev_select_count", "mgc_dev_select_emit",
-    "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases", "mgc_set_result_budget", "mgc_result_out_of_core",
+    "mgc_dev_homopoly_workspace_bytes", "mgc_dev_homopoly_compress", "mgc_set_batch_bases", "mgc_prepare", "mgc_set_result_budget", "mgc_result_out_of_core",
     # include/meryl_db.h
     "mdb_writer_open", "mdb_writer_open_ex", "mdb_merge_parts", "mdb_writer_add_block", "mdb_writer_add_block_labelled",
     "mdb_writer_add_encoded", "mdb_writer_reserve_encoded", "mdb_writer_write_at", "mdb_writer_add_histogram", "mdb_writer_close", "mdb_writer_discard", "mdb_last_error",
@@ -291,6 +291,7 @@ def lib():
     sig("mgc_push_bases", i32, vp, ctypes.c_char_p, sz, i32)
     sig("mgc_push_bases_device", i32, vp, vp, u64)
     sig("mgc_set_batch_bases", i32, vp, u64)
+    sig("mgc_prepare", i32, vp, u64)
     sig("mgc_set_result_budget", i32, vp, u64)
     sig("mgc_result_out_of_core", i32, vp)
     sig("mgc_get_runs_profile", i32, vp, P(RunsProfile))

@@ -402,6 +402,19 @@ int run_count(const Globals &g, const Operation &op) {
   for (const std::string &name : op.seq_inputs) text_total += msr_guess_number_of_kmers(name.c_str());
   const bool host_parser = getenv("MERYL_HOST_PARSER") && getenv("MERYL_HOST_PARSER")[0] == '1';
   if (!host_parser && text_total) (void)mgc_reserve_text(s, text_total);
+  {
+    // bases to expect: a FASTQ file is at most half sequence, anything else at most all of it (compressed: the reference's factors)
+    uint64_t expect = 0;
+    for (const std::string &name : op.seq_inputs) {
+      uint64_t e = msr_guess_number_of_kmers(name.c_str());
+      if (name != "-" && !has_compressed_suffix(name)) {
+        FILE *f = fopen(name.c_str(), "rb");
+        if (f) { const int c = fgetc(f); fclose(f); if (c == '@') e /= 2; }
+      }
+      expect += e;
+    }
+    if (expect && cfg.count_suffix_length == 0) (void)mgc_prepare(s, expect + 4096);
+  }
   std::vector<InputPiece> pieces;
   for (const std::string &name : op.seq_inputs) pieces.push_back(InputPiece{name, 0, ~0ull});
   total_bases = load_inputs(s, pieces, (int)std::min<uint32_t>(g.threads, 16));

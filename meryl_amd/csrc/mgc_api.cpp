@@ -15,6 +15,7 @@
 #include <cerrno>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -427,9 +428,14 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
   return s;
 }
 
+static void join_prepare(mgc_session *s) {
+  if (s->prep_active) { s->prep_thread.join(); s->prep_active = false; }
+}
+
 extern "C" void mgc_close(mgc_session *s) {
   if (!s) return;
   if (s->worker_active) { s->worker.join(); s->worker_active = false; }
+  join_prepare(s);
   (void)hipSetDevice(s->device);
   if (s->st_in) (void)hipStreamSynchronize(s->st_in);
   s->free_result();
@@ -440,10 +446,12 @@ extern "C" void mgc_close(mgc_session *s) {
   for (int i = 0; i < 2; i++) {
     if (s->text_pinned[i]) (void)hipHostFree(s->text_pinned[i]);
     if (s->text_ev[i]) (void)hipEventDestroy(s->text_ev[i]);
+    if (s->up_ev[i]) (void)hipEventDestroy(s->up_ev[i]);
     if (s->pin[i]) (void)hipHostFree(s->pin[i]);
     if (s->pin_ev[i]) (void)hipEventDestroy(s->pin_ev[i]);
   }
   for (char *&p : s->text_ring) if (p) { (void)hipHostFree(p); p = nullptr; }
+  if (s->st_up) { (void)hipStreamSynchronize(s->st_up); (void)hipStreamDestroy(s->st_up); }
   if (s->st_in) (void)hipStreamDestroy(s->st_in);
   for (hipEvent_t e : s->hist_ev) if (e) (void)hipEventDestroy(e);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -459,6 +467,29 @@ extern "C" void mgc_close(mgc_session *s) {
 struct HostParseState { uint64_t out_len, file_start_len; uint32_t state, prev_nl, error, pad; };
 
 static int count_staged_batch(mgc_session *s, int which, uint64_t n);      // count stage[which][0, n) and merge it into R
+
+// The count's largest buffer (the k-mer instances, 8 / 16 B per base at most) is allocated NOW, by a helper thread, while the
+// caller reads and uploads its input: a first large hipMalloc is the slowest single thing a freshly started process does
+// (0.3 s for 100 GB on a quiet device, seconds when another process has just released that much), and until the count starts
+// nobody needs the memory.  Only when the whole input is expected to fit one pass; a wrong estimate costs a re-allocation,
+// never a wrong result.
+extern "C" int mgc_prepare(mgc_session *s, uint64_t expected_bases) {
+  if (!s) return MGC_EINVAL;
+  if (s->borrowed || s->counted || s->prep_active || expected_bases == 0) return MGC_OK;
+  HIP_TRY(s, hipSetDevice(s->device));
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MGC_OK;
+  const uint64_t per_base = 2 + 14ull * s->key_words;
+  if (s->batch_limit && expected_bases > s->batch_limit) return MGC_OK;
+  if ((double)expected_bases * (double)per_base > 0.8 * (double)free_b) return MGC_OK;       // batches: their arena is sized by the first one
+  const size_t bytes = sizeof(uint64_t) * s->key_words * expected_bases;
+  s->prep_active = true;
+  s->prep_thread = std::thread([s, bytes] {
+    (void)hipSetDevice(s->device);
+    if (s->ensure(mgc_session::B_X, bytes) != hipSuccess) (void)hipGetLastError();           // the count will say so itself
+  });
+  return MGC_OK;
+}
 
 extern "C" int mgc_set_batch_bases(mgc_session *s, uint64_t bases_per_batch) {
   if (!s) return MGC_EINVAL;
@@ -625,9 +656,11 @@ static int text_setup(mgc_session *s) {
     HIP_TRY(s, s->ensure(mgc_session::B_TEXT_IN0, mgc_session::TEXT_CHUNK));
     HIP_TRY(s, s->ensure(mgc_session::B_TEXT_IN1, mgc_session::TEXT_CHUNK));
     HIP_TRY(s, s->ensure(mgc_session::B_TEXT_WS, mgc::text_parse_workspace_bytes(mgc_session::TEXT_CHUNK)));
+    if (!s->st_up) HIP_TRY(s, hipStreamCreateWithFlags(&s->st_up, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) {
       if (!s->text_pinned[i]) HIP_TRY(s, hipHostMalloc(reinterpret_cast<void **>(&s->text_pinned[i]), mgc_session::TEXT_CHUNK, hipHostMallocDefault));
       if (!s->text_ev[i]) HIP_TRY(s, hipEventCreateWithFlags(&s->text_ev[i], hipEventDisableTiming));
+      if (!s->up_ev[i]) HIP_TRY(s, hipEventCreateWithFlags(&s->up_ev[i], hipEventDisableTiming));
     }
   }
   return MGC_OK;
@@ -664,7 +697,11 @@ static int text_submit(mgc_session *s, const char *pinned_src, size_t piece) {
   if (s->text_ev_used[b]) HIP_TRY(s, hipEventSynchronize(s->text_ev[b]));       // device buffer b (and its previous source) are free again
   HIP_TRY(s, s->ensure_preserve(stage_id(s->fill), s->fill_len + piece + 4096, s->fill_len, s->st_in));
   uint8_t *d_in = reinterpret_cast<uint8_t *>(s->buf[b ? mgc_session::B_TEXT_IN1 : mgc_session::B_TEXT_IN0].p);
-  HIP_TRY(s, hipMemcpyAsync(d_in, pinned_src, piece, hipMemcpyHostToDevice, s->st_in));
+  // the copy runs on its own stream, so that chunk c travels while chunk c-1 is parsed (one stream did them in turn: 0.56 ms
+  // of copy + 0.4 ms of parse per 32 MiB, 0.6 s of the 20 GB file -> database run; profiles/r03m_e2e_io.txt)
+  HIP_TRY(s, hipMemcpyAsync(d_in, pinned_src, piece, hipMemcpyHostToDevice, s->st_up));
+  HIP_TRY(s, hipEventRecord(s->up_ev[b], s->st_up));
+  HIP_TRY(s, hipStreamWaitEvent(s->st_in, s->up_ev[b], 0));
   HIP_TRY(s, mgc::launch_text_parse(d_in, piece, s->text_format == MGC_TEXT_FASTQ, s->buf[mgc_session::B_TEXT_STATE].p,
                                     s->buf[mgc_session::B_TEXT_WS].p, stage_ptr(s, s->fill), s->st_in));
   HIP_TRY(s, hipEventRecord(s->text_ev[b], s->st_in));
@@ -993,6 +1030,7 @@ struct StageTimer {
 // count): extraction and partition are skipped, the caller's buffer is processed in place.
 static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t *ext_counts = nullptr,
                         uint32_t ext_bucket_bits = MGC_NUM_FILES_BITS) {
+  join_prepare(s);
   s->free_result();
   HIP_TRY(s, hipSetDevice(s->device));
   hipStream_t st = s->stream;
@@ -1202,7 +1240,6 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     HIP_TRY(s, s->ensure(mgc_session::B_LARGE, sizeof(uint32_t) * (ng_total + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_NONEMPTY, sizeof(uint32_t) * (ng_total + 1) + sizeof(uint64_t) * ((uint64_t)nb + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_GSCAN, mgc::finish_scan_scratch_bytes(ng_total + 1)));
-    HIP_TRY(s, s->ensure(mgc_session::B_CNT_TMP, sizeof(uint32_t) * N));
     HIP_TRY(s, s->ensure(mgc_session::B_RLE_WS, mgc::rle_workspace_bytes(max_bucket)));
     uint64_t *d_substart = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_SUBSTART].p);
     uint64_t *d_group    = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_GROUPS].p);   // [ng_total+1], then max_sub[64]
@@ -1213,7 +1250,6 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     uint32_t *d_nz       = reinterpret_cast<uint32_t *>(d_nzcount + nb + 1);                          // [ng_total]
     HIP_TRY(s, hipMemsetAsync(d_nzcount, 0, sizeof(uint64_t) * nb, st));
     HIP_TRY(s, hipMemsetAsync(d_group, 0, sizeof(uint64_t) * (ng_total + 1), st));                     // empty sub-buckets stay 0
-    uint32_t *d_cnt_tmp  = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_CNT_TMP].p);
     void     *rle_ws     = s->buf[mgc_session::B_RLE_WS].p;
     HIP_TRY(s, hipMemsetAsync(d_maxsub, 0, sizeof(uint64_t) * 2 * nb, st));
 
@@ -1241,6 +1277,24 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (use_group && fplan[b].mode == 0) fplan[b].mode = 3;
       const uint32_t low = rem_bits - top_bits[b];
       narrow[b] = !hist_ahead && low < 32 && mgc::finish_can_stream(kw, low) && mgc::sort_plan_narrows(fplan[b], h_counts[b], kw);
+    }
+    // Where the counts of a file's distinct k-mers wait for the packing step (one uint32 per k-mer instance position).  A NARROWED
+    // file keeps 4-byte words in the front half of its 8-byte region from the first grouping pass on: the back half is free and
+    // takes the counts -- no buffer of its own (35 GB of the 123 GB arena at 10 Gbp; a large first hipMalloc is the slowest thing
+    // a freshly started process does, profiles/r03m_e2e_io.txt).  The other files share B_CNT_TMP; a narrowed file that has to be
+    // widened back later (a sub-bucket nothing can stream) gets a buffer of its own then.
+    std::vector<uint32_t *> cnt_ptr(nb, nullptr);
+    std::deque<DevBuf> cnt_extra;                           // (a deque: DevBuf owns its pointer and must not be relocated)
+    {
+      uint64_t wide_total = 0;
+      for (uint32_t b = 0; b < nb; b++) if (!narrow[b]) wide_total += h_counts[b];
+      HIP_TRY(s, s->ensure(mgc_session::B_CNT_TMP, sizeof(uint32_t) * wide_total));
+      uint32_t *wide = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_CNT_TMP].p);
+      uint64_t at = 0;
+      for (uint32_t b = 0; b < nb; b++) {
+        if (narrow[b]) cnt_ptr[b] = reinterpret_cast<uint32_t *>(X + kbytes * h_starts[b]) + h_counts[b];
+        else { cnt_ptr[b] = wide + at; at += h_counts[b]; }
+      }
     }
     tm.begin(MGC_STAGE_SORT);
     // high digit first: the headers of all narrowed files in one launch, their look-back granules zeroed in one memset
@@ -1380,6 +1434,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         HIP_TRY(s, hipMemcpyAsync(seg, Y, kbytes * h_counts[b], hipMemcpyDeviceToDevice, st));
         narrow[b] = 0;
         unordered = tr_a[b] != 0;      // grouped, but not in key order: only the stable sort of all bits can take it from here
+        cnt_extra.emplace_back();      // the back half of its region holds k-mers again: counts of its own
+        HIP_TRY(s, cnt_extra.back().alloc(sizeof(uint32_t) * h_counts[b]));
+        cnt_ptr[b] = cnt_extra.back().as<uint32_t>();
       }
       if ((h_maxsub[b] <= cap || stream) && !unordered) {
         const bool on_second = alt_files && (b & 1u);
@@ -1397,7 +1454,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
           fin_narrow = fin_narrow || narrow[b];
         }
         HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_nlarge[b],
-                                           d_large + gbase[b], d_cnt_tmp + h_starts[b], d_group + gbase[b], stream, (void *)Y, st_huge,
+                                           d_large + gbase[b], cnt_ptr[b], d_group + gbase[b], stream, (void *)Y, st_huge,
                                            // the list pays off only when a good part of the 2^t grid is empty
                                            (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b])) ? d_nz + gbase[b] : nullptr,
                                            d_nzcount + b, fst, narrow[b] != 0, tr_a[b], tr_b[b]));
@@ -1444,11 +1501,11 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (h_counts[b] == 0) continue;
       void *seg = X + kbytes * h_starts[b];
       if (narrow[b]) {
-        HIP_TRY(s, mgc::launch_compact_groups_narrow(seg, d_cnt_tmp + h_starts[b], d_substart + sbase[b], d_group + gbase[b],
+        HIP_TRY(s, mgc::launch_compact_groups_narrow(seg, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b],
                                                      gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, rem_bits - top_bits[b],
                                                      s->d_unique, s->d_counts, st, tr_a[b], tr_b[b]));
       } else if (!fallback[b]) {
-        HIP_TRY(s, mgc::launch_compact_groups(seg, kw, d_cnt_tmp + h_starts[b], d_substart + sbase[b], d_group + gbase[b],
+        HIP_TRY(s, mgc::launch_compact_groups(seg, kw, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b],
                                               gbase[b + 1] - gbase[b], s->d_unique, s->d_counts, st));
       } else {
         HIP_TRY(s, mgc::launch_rle_count(seg, h_counts[b], kw, rle_ws, st));

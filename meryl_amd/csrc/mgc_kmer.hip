@@ -434,6 +434,89 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
   }
 }
 
+// kmer_partition_kernel with WRITE COMBINING (64 buckets, 8-byte keys): every global store is a whole, aligned 128-byte line.
+// A workgroup's run for a file starts wherever its private cursor says, so the plain kernel writes, per tile and file, a
+// run of ~55 keys whose first and last line are partial -- and a partial line costs the memory system as much as a whole
+// one (scripts/ubench/scatter.hip: 256-byte runs with odd starts run at 3.25 TB/s, aligned ones at 4.97).  Here the keys of
+// a file that do not complete a line (< 16 of them) STAY IN LDS: the tile array is laid out per file as [carry | new keys],
+// the leading whole lines go out, the tail is copied to a small carry buffer and becomes the head of the file's segment in
+// the next tile.  Only a workgroup's first line per file (its cursor is not aligned) and its last (the flush) are partial:
+// two per (workgroup, file) instead of two per (tile, file).  The output is byte for byte the plain kernel's: the same keys
+// in the same order at the same positions, written later.
+constexpr int KPC_LINE = 16;                           // 8-byte keys per 128-byte line
+__global__ __launch_bounds__(KP_BLOCK, 5)
+void kmer_partition_wc_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u64 num_tiles,
+                              const u64 *__restrict__ block_base, u64 *__restrict__ out) {
+  constexpr u32 NB = 64;                                        // LDS tile: KP_TILE + NB * KPC_LINE keys
+  extern __shared__ __attribute__((aligned(16))) unsigned char kp_dyn_smem[];
+  u64 *s_keys = reinterpret_cast<u64 *>(kp_dyn_smem);                // u64[CAP]: per file [carry | new]
+  __shared__ u64 s_carry[NB * KPC_LINE];
+  __shared__ u64 s_cursor[NB];                                       // global position of the first pending key of every file
+  __shared__ u32 s_cnt[NB], s_base[NB], s_rem[NB], s_outn[NB];
+  __shared__ u32 s_codes[KP_WORDS];
+  __shared__ u32 s_inval[KP_WORDS];
+  __shared__ u32 s_tmp[KP_BLOCK / 64 + 1];
+  const u32  bucket_shift = 2 * k - 6;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
+  const u32  tid = threadIdx.x;
+  if (tid < NB) { s_cursor[tid] = block_base[(u64)blockIdx.x * NB + tid]; s_rem[tid] = 0; }
+
+  u64 t_begin, t_end;
+  kp_tile_range(num_tiles, t_begin, t_end);
+  for (u64 tile = t_begin; tile <= t_end; tile++) {
+    const bool flush = tile == t_end;                                // one more round: whatever is pending goes out
+    if (tid < NB) s_cnt[tid] = 0;
+    u64 keys[KP_ITEMS];
+    u32 vmask = 0;
+    if (!flush) kp_stage_tile(bases, n, tile * KP_TILE, aligned, s_codes, s_inval);
+    __syncthreads();
+    u32 ranks[KP_ITEMS];
+    if (!flush) {
+      vmask = kp_thread_kmers(s_codes, s_inval, k, mode, keys);
+#pragma unroll
+      for (int j = 0; j < KP_ITEMS; j++) {
+        ranks[j] = 0;
+        if ((vmask >> j) & 1u) ranks[j] = atomicAdd(&s_cnt[KeyOps<u64>::bucket(keys[j], bucket_shift)], 1u);
+      }
+    }
+    __syncthreads();
+    // segment of file f = its pending keys + its new ones; how much of it goes out now
+    u32 seg = 0, total;
+    if (tid < NB) seg = s_rem[tid] + s_cnt[tid];
+    const u32 excl = block_excl_scan<KP_BLOCK, u32>(seg, s_tmp, &total);
+    if (tid < NB) {
+      s_base[tid] = excl;
+      const u32 mis = (u32)(s_cursor[tid] & (u64)(KPC_LINE - 1));
+      u32 head = mis ? (KPC_LINE - mis) : 0u;
+      if (head > seg) head = seg;
+      const u32 outn = flush ? seg : head + ((seg - head) / KPC_LINE) * KPC_LINE;
+      s_outn[tid] = outn;
+    }
+    __syncthreads();
+    // pending keys to the head of their file's segment, new keys behind them
+    for (u32 i = tid; i < NB * KPC_LINE; i += KP_BLOCK) {
+      const u32 f = i / KPC_LINE, j = i % KPC_LINE;
+      if (j < s_rem[f]) s_keys[s_base[f] + j] = s_carry[i];
+    }
+    if (!flush) {
+#pragma unroll
+      for (int j = 0; j < KP_ITEMS; j++)
+        if ((vmask >> j) & 1u) { const u32 f = KeyOps<u64>::bucket(keys[j], bucket_shift); s_keys[s_base[f] + s_rem[f] + ranks[j]] = keys[j]; }
+    }
+    __syncthreads();
+    // whole lines leave; the tail of every segment is the next round's pending part
+    for (u32 i = tid; i < total; i += KP_BLOCK) {
+      const u64 key = s_keys[i];
+      const u32 f = KeyOps<u64>::bucket(key, bucket_shift), idx = i - s_base[f], outn = s_outn[f];
+      if (idx < outn) out[s_cursor[f] + (u64)idx] = key;
+      else            s_carry[f * KPC_LINE + (idx - outn)] = key;
+    }
+    __syncthreads();
+    if (tid < NB) { const u32 sg = s_rem[tid] + s_cnt[tid]; s_cursor[tid] += s_outn[tid]; s_rem[tid] = sg - s_outn[tid]; }
+    __syncthreads();
+  }
+}
+
 uint32_t kp_grid_size(uint64_t n_bases) {
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
   uint64_t g = num_tiles < 2048 ? num_tiles : 2048;
@@ -512,6 +595,14 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_partition_kernel<K128, KP_MAX_BUCKETS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
     attr_done = true;
+  }
+  // 64 files, 8-byte keys, no count-suffix filter: the write-combining form (MGC_PARTITION_WC=0: the plain kernel)
+  static const bool use_wc = !(getenv("MGC_PARTITION_WC") && getenv("MGC_PARTITION_WC")[0] == '0');
+  if (use_wc && k <= 32 && nb == 64 && sfx_mask == 0) {
+    constexpr size_t wc_bytes = (size_t)(KP_TILE + 64 * KPC_LINE) * sizeof(u64);
+    hipLaunchKernelGGL(kmer_partition_wc_kernel, dim3(grid), dim3(KP_BLOCK), wc_bytes, st, d_bases, (u64)n_bases, k, mode, (u64)num_tiles,
+                       reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys));
+    return hipGetLastError();
   }
 #define MGC_KP_LAUNCH(K_, MAXB_)                                                                                   \
   hipLaunchKernelGGL((kmer_partition_kernel<K_, MAXB_>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K_), st,      \

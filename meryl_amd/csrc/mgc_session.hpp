@@ -136,6 +136,8 @@ struct mgc_session {
   int         text_format = 0;
   char       *text_pinned[2] = {nullptr, nullptr};
   hipEvent_t  text_ev[2] = {nullptr, nullptr};
+  hipStream_t st_up = nullptr;           // text chunks are UPLOADED here while the previous chunk is parsed on st_in
+  hipEvent_t  up_ev[2] = {nullptr, nullptr};
   bool        text_ev_used[2] = {false, false};
   uint32_t    text_next = 0;
   static constexpr int TEXT_RING_MAX = 64;
@@ -167,6 +169,10 @@ struct mgc_session {
   double      tr_memcpy = 0, tr_flush = 0, tr_cut = 0, tr_join = 0, tr_grow = 0;   // MGC_IO_TRACE: where the pushing thread's time went
   bool        worker_active = false;      // a batch is being counted (join before touching count state)
   int         worker_rc = MGC_OK;
+
+  // mgc_prepare: the count's largest buffers allocated by a helper thread while the input is still being read
+  std::thread prep_thread;
+  bool        prep_active = false;
 
   // profiling
   bool        profiling = false;

@@ -31,11 +31,24 @@ with open(fq, "wb") as f:
         f.write(r.cpu().numpy().tobytes())
 del bases
 torch.cuda.empty_cache()
+if os.environ.get("E2E_WARM") == "1":                        # read the file once before anybody times anything
+    t0 = time.perf_counter()
+    subprocess.run("cat %s > /dev/null" % fq, shell=True)
+    print("warm read of the file: %.2f s" % (time.perf_counter() - t0))
+if os.environ.get("E2E_SETTLE") == "1":                      # does a big allocation in THIS process absorb the next process's slow first hipMalloc?
+    t0 = time.perf_counter()
+    x = torch.empty(110 << 30, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    del x
+    torch.cuda.empty_cache()
+    print("settle: 110 GB allocated in %.3f s, freed in %.3f s" % (t1 - t0, time.perf_counter() - t1))
 cli = build.build_cli()
 # every setting: (environment additions, command prefix)
-settings = [({}, []), ({"MGC_TEXT_READERS": "32", "MGC_TEXT_RING": "48"}, []), ({"MGC_TEXT_READERS": "8", "MGC_TEXT_RING": "16"}, []),
-            ({}, ["taskset", "-c", "0-63,128-191"]), ({}, ["taskset", "-c", "64-127,192-255"]),
-            ({"MGC_TEXT_MMAP": "1"}, []), ({}, [])]
+settings = [({}, []), ({}, []), ({"MGC_PARTITION_WC": "0"}, [])]
+if os.environ.get("E2E_MORE") == "1":
+    settings += [({"MGC_TEXT_READERS": "32", "MGC_TEXT_RING": "48"}, []), ({"MGC_TEXT_READERS": "8", "MGC_TEXT_RING": "16"}, []),
+                 ({}, ["taskset", "-c", "0-63,128-191"]), ({}, ["taskset", "-c", "64-127,192-255"]), ({"MGC_TEXT_MMAP": "1"}, [])]
 try:
     print(subprocess.run(["numactl", "-H"], capture_output=True, text=True).stdout[:1500])
 except OSError:
