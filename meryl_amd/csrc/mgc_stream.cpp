@@ -41,8 +41,13 @@ struct DBuf {                                             // grow-only device bu
 };
 
 constexpr size_t   SLOT_BYTES = 32u << 20;                // pinned copy buffers: NSLOT x SLOT_BYTES
-constexpr int      NSLOT      = 16;
-constexpr uint64_t IMG_CAP    = 1024ull << 20;            // device image of one encode chunk (two of them in flight): ~10 files at 10 Gbp
+constexpr int      NSLOT_MAX  = 64;
+// writes to ONE file serialise in the kernel, so the writers' parallelism is the number of files a chunk spans: a 2 GiB image
+// holds ~20 files at 10 Gbp (MGC_DB_IMG_MB / MGC_DB_SLOTS override; r02: 1 GiB and 16 slots)
+inline uint64_t img_cap() { static const uint64_t v = (getenv("MGC_DB_IMG_MB") ? strtoull(getenv("MGC_DB_IMG_MB"), nullptr, 10) : 2048ull) << 20; return v; }
+inline int      n_slot()  { static const int v = std::max(4, std::min(NSLOT_MAX, getenv("MGC_DB_SLOTS") ? atoi(getenv("MGC_DB_SLOTS")) : 32)); return v; }
+#define NSLOT n_slot()
+#define IMG_CAP img_cap()
 
 }  // namespace
 
@@ -59,14 +64,14 @@ struct mgc_db_stream {
   hipStream_t st_enc = nullptr, st_copy = nullptr;
   hipEvent_t  ev_enc[2] = {nullptr, nullptr}, ev_a = nullptr, ev_b = nullptr;
   DBuf d_bs, d_bytes, d_vbase, d_bb, d_pos, d_hist, d_big, d_img[2];
-  char *pinned[NSLOT] = {nullptr};
+  char *pinned[NSLOT_MAX] = {nullptr};
 
   struct Range { const void *keys; const uint32_t *counts; uint64_t n, pb, pe; };
   struct Piece { uint32_t ff; int slot; uint64_t nbytes, file_offset; };
 
   std::mutex mu;
   std::condition_variable cv;
-  bool slot_busy[NSLOT] = {false}, slot_ready[NSLOT] = {false};
+  bool slot_busy[NSLOT_MAX] = {false}, slot_ready[NSLOT_MAX] = {false};
   int  next_slot = 0;
   std::deque<Range> jobs;
   uint64_t jobs_queued = 0, jobs_done = 0;

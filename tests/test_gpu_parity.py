@@ -1230,7 +1230,8 @@ def test_bitmap_count_and_chunk_local_pass(ops, oracle_lib, torch_cuda, monkeypa
     from meryl_amd import capi
     monkeypatch.setenv("MGC_FINISH_MIN_TOP", str(min_top))
     monkeypatch.setenv("MGC_GROUP_LOCAL", local)
-    monkeypatch.setenv("MGC_FINISH_BITMAP", local)           # both experimental kernels on, or both off (the default plan at this size)
+    monkeypatch.setenv("MGC_FINISH_BITMAP", local)           # the experimental kernels on, or off (the default plan at this size)
+    monkeypatch.setenv("MGC_PARTITION_WC", local)            # ... the write-combining partition with them
     rng = np.random.default_rng(k * 100 + min_top)
     plen = (6 + min_top + 1) // 2 + 1                      # bases that fix the file and the sub-bucket
     def cluster(head, n_inst, n_distinct):
