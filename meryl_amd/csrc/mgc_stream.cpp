@@ -42,10 +42,11 @@ struct DBuf {                                             // grow-only device bu
 
 constexpr size_t   SLOT_BYTES = 32u << 20;                // pinned copy buffers: NSLOT x SLOT_BYTES
 constexpr int      NSLOT_MAX  = 64;
-// writes to ONE file serialise in the kernel, so the writers' parallelism is the number of files a chunk spans: a 2 GiB image
-// holds ~20 files at 10 Gbp (MGC_DB_IMG_MB / MGC_DB_SLOTS override; r02: 1 GiB and 16 slots)
-inline uint64_t img_cap() { static const uint64_t v = (getenv("MGC_DB_IMG_MB") ? strtoull(getenv("MGC_DB_IMG_MB"), nullptr, 10) : 2048ull) << 20; return v; }
-inline int      n_slot()  { static const int v = std::max(4, std::min(NSLOT_MAX, getenv("MGC_DB_SLOTS") ? atoi(getenv("MGC_DB_SLOTS")) : 32)); return v; }
+// device image of one encode chunk (two in flight; ~10 files at 10 Gbp) and pinned copy slots.  MEASURED (profiles/r03o_e2e_db.txt,
+// 6.75 GB database): 1 GiB / 16 slots 0.51 s, 2 GiB / 32 slots 0.67 s, 4 GiB / 48 slots 0.86 s -- pinning more slots costs more
+// than the extra files in flight give (MGC_DB_IMG_MB / MGC_DB_SLOTS override)
+inline uint64_t img_cap() { static const uint64_t v = (getenv("MGC_DB_IMG_MB") ? strtoull(getenv("MGC_DB_IMG_MB"), nullptr, 10) : 1024ull) << 20; return v; }
+inline int      n_slot()  { static const int v = std::max(4, std::min(NSLOT_MAX, getenv("MGC_DB_SLOTS") ? atoi(getenv("MGC_DB_SLOTS")) : 16)); return v; }
 #define NSLOT n_slot()
 #define IMG_CAP img_cap()
 
