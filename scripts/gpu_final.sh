@@ -3,7 +3,7 @@
 # TAG=r02 bash scripts/gpu_final.sh  -> gpurun_out/$TAG_final/{bench_full.json,kernel_stats.csv,pmc_traffic.json}
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 OUT=gpurun_out/${TAG}_final
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -11,7 +11,7 @@ echo "== default bench (the driver's command)"
 timeout 1500 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err
 echo "bench exit $?"; cut -c1-2500 $OUT/bench_full.json; tail -3 $OUT/bench_full.err
 echo "== rocprofv3 kernel stats of the same workload"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o full -- python bench.py --no-cpu-baseline --no-e2e --no-check > $OUT/prof_bench.json 2> $OUT/prof_bench.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o full -- python bench.py --no-cpu-baseline --no-e2e --no-check --no-db > $OUT/prof_bench.json 2> $OUT/prof_bench.err
 echo "rocprof exit $?"
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null; head -16 $OUT/kernel_stats.csv
 echo "== PMC traffic (separate passes, kernel-trace only, calibrated)"
@@ -19,7 +19,7 @@ hipcc --offload-arch=gfx950 -O3 -o /tmp/calib scripts/ubench/calib.hip 2> $OUT/c
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/calib_$c -o c -- /tmp/calib > $OUT/calib_$c.log 2>&1
   echo "calib $c exit $?"
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/bench_$c -o b -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-check > $OUT/bench_$c.json 2> $OUT/bench_$c.err
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/bench_$c -o b -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-check --no-db > $OUT/bench_$c.json 2> $OUT/bench_$c.err
   echo "bench $c exit $?"
 done
 OUT=$OUT python - <<'PY'
