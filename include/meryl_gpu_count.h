@@ -388,7 +388,8 @@ typedef struct mgc_profile {
    * (the keys read: 4 B narrowed, 8 / 16 B otherwise; the distinct suffixes + counts written) and keys */
   double   finish_ms;
   uint64_t finish_bytes, finish_keys;
-  uint32_t finish_launches, reserved2;
+  uint32_t finish_launches;
+  uint32_t wide_msd_files;         /* files whose WHOLE keys took the high-digit-first grouping passes (mgc_device.h, launch_group_wide) */
 } mgc_profile;
 int mgc_set_profiling(mgc_session *s, int enable);
 int mgc_get_profile(const mgc_session *s, mgc_profile *p);

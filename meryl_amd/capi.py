@@ -98,7 +98,7 @@ class Profile(ctypes.Structure):
         ("finish_bytes", ctypes.c_uint64),
         ("finish_keys", ctypes.c_uint64),
         ("finish_launches", ctypes.c_uint32),
-        ("reserved2", ctypes.c_uint32),
+        ("wide_msd_files", ctypes.c_uint32),
     ]
 
 

@@ -1089,8 +1089,12 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   uint32_t local_chunks = 0, local_per_chunk = 0, local_vgrid = 0;
   if (!ext_keys) {
     tm.begin(MGC_STAGE_HISTOGRAM);
-    // (two digits cover at most 18 bits: beyond 2k - 6 = 41 nothing narrows and the fifteen-bit histogram would go unused)
-    if (kw == 1 && n_bases >= (1u << 22) && 2 * k - bucket_bits <= 41 && mgc::kmer_histogram_fine_ok(k, bucket_bits, s->sfx_mask)) {
+    // (two digits cover at most 18 bits: beyond 2k - 6 = 41 nothing narrows -- the files' WHOLE keys then take the same
+    // high-digit-first passes, mgc::launch_group_wide, 16-byte keys included; MGC_WIDE_MSD=0: low digit first off a histogram
+    // read of the keys, as `compress` always does: its digits are dense ranks)
+    const char *wme = getenv("MGC_WIDE_MSD");                        // read per call: the tests switch it
+    const bool wide_msd_on = !(wme && wme[0] == '0') && !c.homopoly_compress;
+    if (n_bases >= (1u << 22) && ((kw == 1 && 2 * k - bucket_bits <= 41) || wide_msd_on) && mgc::kmer_histogram_fine_ok(k, bucket_bits, s->sfx_mask)) {
       HIP_TRY(s, s->ensure(mgc_session::B_FINE, sizeof(uint64_t) << 15));
       uint64_t *fine = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_FINE].p);
       // ... and per CHUNK of the partition's output too (64 MB at 10 Gbp): the first grouping pass of every file then runs
@@ -1267,6 +1271,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     std::vector<char> prepared(nb, 0);
     // narrow[b]: the file's k-mers travel as 32-bit words from the first grouping pass on (mgc::launch_group_narrow)
     std::vector<char> narrow(nb, 0);
+    // wide_msd[b]: the file's whole keys take the high-digit-first passes (mgc::launch_group_wide)
+    std::vector<char> wide_msd(nb, 0);
     std::vector<uint32_t> tr_a(nb, 0), tr_b(nb, 0);        // ... and in which order its sub-buckets lie (mgc::tr_index)
     const size_t hdr_bytes = mgc::sort_header_bytes();
     unsigned char *d_hdrs = nullptr;
@@ -1277,6 +1283,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (use_group && fplan[b].mode == 0) fplan[b].mode = 3;
       const uint32_t low = rem_bits - top_bits[b];
       narrow[b] = !hist_ahead && low < 32 && mgc::finish_can_stream(kw, low) && mgc::sort_plan_narrows(fplan[b], h_counts[b], kw);
+      // (only the hash-count kernels translate the sub-bucket numbers of whole keys)
+      wide_msd[b] = !narrow[b] && !hist_ahead && d_fine && nb <= 64 && mgc::finish_can_stream(kw, low) &&
+                    mgc::sort_plan_wide_msd(fplan[b], h_counts[b]);
     }
     // Where the counts of a file's distinct k-mers wait for the packing step (one uint32 per k-mer instance position).  A NARROWED
     // file keeps 4-byte words in the front half of its 8-byte region from the first grouping pass on: the back half is free and
@@ -1305,9 +1314,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       bool any = false;
       for (uint32_t b = 0; b < nb; b++) {
         nws_off[b + 1] = nws_off[b];
-        if (!narrow[b]) continue;
+        if (!narrow[b] && !wide_msd[b]) continue;
         on[b] = 1; bits_a[b] = (unsigned char)fplan[b].pass_bits[1]; any = true;
-        nws_off[b + 1] += (mgc::narrow_scratch_bytes(h_counts[b]) + 255) / 256 * 256;
+        nws_off[b + 1] += ((narrow[b] ? mgc::narrow_scratch_bytes(h_counts[b]) : mgc::wide_scratch_bytes(h_counts[b], kw)) + 255) / 256 * 256;
       }
       if (any) {
         HIP_TRY(s, s->ensure(mgc_session::B_SORT_HDRS, hdr_bytes * nb));
@@ -1354,6 +1363,15 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         sort_launch_groups++;
         continue;
       }
+      if (wide_msd[b] && d_nhdrs) {                          // X -> Y -> X, whole keys; boundaries included
+        HIP_TRY(s, mgc::launch_group_wide(src, (void *)Y, h_counts[b], kw, fp, d_err, d_substart + sbase[b], st, pe,
+                                          (void *)(d_nhdrs + hdr_bytes * b), (void *)(d_nws + nws_off[b]), &tr_a[b], &tr_b[b]));
+        file_passes[b] = 2;
+        sort_launch_groups++;
+        s->prof.wide_msd_files++;
+        continue;
+      }
+      wide_msd[b] = 0;
       if (prepared[b]) HIP_TRY(s, hipStreamWaitEvent(st, s->hist_ev[b], 0));
       HIP_TRY(s, mgc::launch_radix_sort(src, (void *)Y, h_counts[b], kw, fp, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe,
                                         prepared[b] ? (void *)(d_hdrs + hdr_bytes * b) : nullptr));
@@ -1367,7 +1385,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     tm.begin(MGC_STAGE_RLE);
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0) continue;
-      if (narrow[b])
+      if (narrow[b] || wide_msd[b])
         HIP_TRY(s, mgc::launch_subbucket_max(d_substart + sbase[b], kw, rem_bits - top_bits[b], top_bits[b], d_maxsub + b,
                                              d_large + gbase[b], d_nlarge + b, d_nz + gbase[b], d_nzcount + b, st));
       else
@@ -1438,6 +1456,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         HIP_TRY(s, cnt_extra.back().alloc(sizeof(uint32_t) * h_counts[b]));
         cnt_ptr[b] = cnt_extra.back().as<uint32_t>();
       }
+      // whole keys in (low digit : high digit) order whose oversized sub-buckets nothing streams: the stable sort of all bits
+      if (wide_msd[b] && h_nlarge[b] > 0 && !stream) unordered = true;
       if ((h_maxsub[b] <= cap || stream) && !unordered) {
         const bool on_second = alt_files && (b & 1u);
         if ((stream || on_second) && fork_huge && !forked) {   // everything the forked kernels read is complete at this point of st
@@ -1506,7 +1526,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
                                                      s->d_unique, s->d_counts, st, tr_a[b], tr_b[b]));
       } else if (!fallback[b]) {
         HIP_TRY(s, mgc::launch_compact_groups(seg, kw, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b],
-                                              gbase[b + 1] - gbase[b], s->d_unique, s->d_counts, st));
+                                              gbase[b + 1] - gbase[b], s->d_unique, s->d_counts, st, tr_a[b], tr_b[b]));
       } else {
         HIP_TRY(s, mgc::launch_rle_count(seg, h_counts[b], kw, rle_ws, st));
         HIP_TRY(s, mgc::launch_rle_emit(seg, h_counts[b], kw, rle_ws, s->d_unique, s->d_counts, st, d_group + gbase[b]));

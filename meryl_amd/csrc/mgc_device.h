@@ -107,6 +107,18 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events /* 4 or null */,
                                void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, const GroupLocal *local = nullptr);
 
+// The same high-digit-first form for WHOLE keys (8-byte keys that leave more than 32 bits below their first digit: k = 27..32
+// at the 10 Gbp scale; every 16-byte key): the high digit's histogram comes from the fifteen-bit file histogram
+// (launch_narrow_prepare), the first pass counts the low digit as it goes, the boundaries fall out of the second pass's
+// look-back granules -- neither the 8/16 B per k-mer digit-histogram read nor the boundary search over the grouped keys
+// happens.  d_keys: n keys in, the grouped keys out (same place); d_alt: room for n keys; d_scratch: wide_scratch_bytes(n,
+// key_words), zeroed by the caller; sub-buckets in tr_index(., *tr_a, *tr_b) order.
+bool       sort_plan_wide_msd(const SortPlan &plan, uint64_t n);
+size_t     wide_scratch_bytes(uint64_t n, uint32_t key_words);
+hipError_t launch_group_wide(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan, uint32_t *d_error,
+                             uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events /* 4 or null */, void *d_prepared,
+                             void *d_scratch, uint32_t *tr_a, uint32_t *tr_b);
+
 // ---- run-length count ------------------------------------------------------
 size_t     rle_workspace_bytes(uint64_t n);
 hipError_t launch_rle_count(const void *d_sorted, uint64_t n, uint32_t key_words, void *d_ws, hipStream_t st);
@@ -141,11 +153,12 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               const uint32_t *d_nonempty_list, const uint64_t *d_nonempty_count /*the hash kernels visit only these;
                               d_group_distinct must be zero for the others*/, hipStream_t st,
                               bool narrow = false /*d_keys/d_alt: uint32 narrowed keys; the distinct SUFFIXES go back in place*/,
-                              uint32_t tr_a = 0, uint32_t tr_b = 0 /*narrow: launch_group_narrow's*/);
+                              uint32_t tr_a = 0, uint32_t tr_b = 0 /*launch_group_narrow's / launch_group_wide's (whole keys: hash paths only)*/);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);
 hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,
-                                 const uint64_t *d_offs, uint64_t ng, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st);
+                                 const uint64_t *d_offs, uint64_t ng, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st,
+                                 uint32_t tr_a = 0, uint32_t tr_b = 0 /*launch_group_wide's: d_offs goes by tr_index(sub-bucket)*/);
 // narrowed files: k-mer = base | sub-bucket << low_bits | suffix
 hipError_t launch_compact_groups_narrow(const void *d_keys32, const uint32_t *d_cnt_tmp, const uint64_t *d_starts, const uint64_t *d_offs,
                                         uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st,

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(BLOCK, 7)
 void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                        u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
                        const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u64 *__restrict__ dbg,
-                       u32 tr_a = 0, u32 tr_b = 0 /* NARROW: tr_index() of the sub-bucket numbers */) {
+                       u32 tr_a = 0, u32 tr_b = 0 /* tr_index() of the sub-bucket numbers */) {
   // Inside a sub-bucket the keys differ only in their low `low_bits` (< 32) bits: the table holds
   // 32-bit suffixes (half the LDS, 32-bit CAS and compares); the common prefix is added back on output.
   // Persistent workgroups: the keys of the next sub-bucket are loaded while the current one is counted
@@ -478,10 +478,10 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
     const u64 g3 = sub_at(p + 3 * G);
 
     if (n64 == 0) {
-      if (tid == 0) group_distinct[NARROW ? tr_index(g, tr_a, tr_b) : g] = 0;
+      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
     } else if (n64 <= max_size) {                      // larger ones: other launches take them
       const u32 n = (u32)n64;
-      const u64 prefix = file_base | (g << low_bits);
+      const u64 prefix = file_base | (tr_index(g, tr_a, tr_b) << low_bits);
       u32 kk[KPT], hh[KPT];
       u32 pending = 0;
 #pragma unroll
@@ -607,7 +607,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
         else                  gk[r] = prefix | (u64)ki;  // in place: every key of this region sits in registers
         cnt_tmp[a + r] = dc[i];
       }
-      if (tid == 0) group_distinct[NARROW ? tr_index(g, tr_a, tr_b) : g] = D;
+      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
       HC_STAMP(3);
       __syncthreads();                                 // dk/dc/s_tmp are reused by the next sub-bucket
       HC_STAMP(4);
@@ -767,7 +767,7 @@ template <int BLOCK, int CAP, int SLOTS, bool LIST>
 __global__ __launch_bounds__(BLOCK, 3)
 void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                        u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                       const u32 *__restrict__ nz, const u64 *__restrict__ nz_count) {
+                       const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u32 tr_a = 0, u32 tr_b = 0 /* sub-buckets in tr_index() order (high digit first, launch_group_wide) */) {
   constexpr bool DBG = false;
   u64 *dbg = nullptr;
   // Inside a sub-bucket the keys differ only in their low `low_bits` (< 32) bits: the table holds
@@ -823,10 +823,10 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
     const u64 g3 = sub_at(p + 3 * G);
 
     if (n64 == 0) {
-      if (tid == 0) group_distinct[g] = 0;
+      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
     } else if (n64 <= max_size) {                      // larger ones: other launches take them
       const u32 n = (u32)n64;
-      const u64 prefix = file_base | (g << low_bits);
+      const u64 prefix = file_base | (tr_index(g, tr_a, tr_b) << low_bits);
       u64 kk[KPT];
       u32 hh[KPT];
       u32 pending = 0;
@@ -901,7 +901,7 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
         gk[r] = prefix | ki;                           // in place: every key of this region sits in registers
         cnt_tmp[a + r] = dc[i];
       }
-      if (tid == 0) group_distinct[g] = D;
+      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
       HC_STAMP(3);
       __syncthreads();                                 // dk/dc/s_tmp are reused by the next sub-bucket
       HC_STAMP(4);
@@ -926,11 +926,12 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
 // k=51, two workgroups per CU; this one aliases the compacted output onto the staging arrays, packs index and count into
 // one slot word and fits four: 103 ms with separate index/count words and three workgroups.)
 // WIDE = the suffix needs the high word too (low_bits > 64); otherwise the hi arrays are not even allocated.
+constexpr int H128_SMALL_WAVES = 7;                               // hash_count128_kernel<.., 768, ..>: workgroups per CU asked for
 template <int BLOCK, int CAP, int SLOTS, bool WIDE>
-__global__ __launch_bounds__(BLOCK, 4)
+__global__ __launch_bounds__(BLOCK, (CAP <= 768 ? H128_SMALL_WAVES : 4))
 void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                           u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                          const u32 *__restrict__ nz, const u64 *__restrict__ nz_count) {
+                          const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u32 tr_a = 0, u32 tr_b = 0 /* sub-buckets in tr_index() order (high digit first, launch_group_wide) */) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
   constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
   static_assert(CAP < 0xFFFF, "slot words hold a 16-bit key index and a 16-bit count");
@@ -978,10 +979,10 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
     const u64 g3 = sub_at(p + 3 * G);
 
     if (n64 == 0) {
-      if (tid == 0) group_distinct[g] = 0;
+      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
     } else if (n64 <= max_size) {
       const u32 n = (u32)n64;
-      const u128 prefix = file_base | ((u128)g << low_bits);
+      const u128 prefix = file_base | ((u128)tr_index(g, tr_a, tr_b) << low_bits);
       u64 klo[KPT], khi[KPT];
       u32 hh[KPT];
       u32 pending = 0;
@@ -1071,7 +1072,7 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
         gk[r] = KO::mk(prefix | ((u128)hi << 64) | (u128)li);   // in place: every key of this region sits in registers
         cnt_tmp[a + r] = dc[i];
       }
-      if (tid == 0) group_distinct[g] = D;
+      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
       __syncthreads();                                 // the tables are reused by the next sub-bucket
     }
 
@@ -1088,7 +1089,7 @@ template <int BLOCK, int CAP, int SLOTS, bool LIST>
 __global__ __launch_bounds__(BLOCK, 5)
 void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                           u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                          const u32 *__restrict__ nz, const u64 *__restrict__ nz_count) {
+                          const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u32 tr_a = 0, u32 tr_b = 0 /* sub-buckets in tr_index() order (high digit first, launch_group_wide) */) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0 && CAP < 0xFFFF, "table geometry");
   constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
   constexpr u32 EMPTY = 0x0000FFFFu;
@@ -1130,10 +1131,10 @@ void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
     const u64 g3 = sub_at(p + 3 * G);
 
     if (n64 == 0) {
-      if (tid == 0) group_distinct[g] = 0;
+      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
     } else if (n64 <= max_size) {
       const u32 n = (u32)n64;
-      const u64 prefix = file_base | (g << low_bits);
+      const u64 prefix = file_base | (tr_index(g, tr_a, tr_b) << low_bits);
       u64 kk[KPT];
       u32 hh[KPT];
       u32 pending = 0;
@@ -1201,7 +1202,7 @@ void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
         gk[r] = prefix | ki;                           // in place: every key of this region sits in registers
         cnt_tmp[a + r] = dc[i];
       }
-      if (tid == 0) group_distinct[g] = D;
+      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
       __syncthreads();                                 // the tables are reused by the next sub-bucket
     }
 
@@ -1307,7 +1308,7 @@ template <typename S, int BLOCK, int CAP, int SLOTS, typename KT = u64>
 __global__ __launch_bounds__(BLOCK)
 void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
                             u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                            KT *__restrict__ alt, u32 tr_a = 0, u32 tr_b = 0 /* KT = u32: tr_index() of the sub-bucket numbers */) {
+                            KT *__restrict__ alt, u32 tr_a = 0, u32 tr_b = 0 /* tr_index() of the sub-bucket numbers */) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && (CAP & (CAP - 1)) == 0 && SLOTS >= CAP * 2 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0,
                 "table geometry");
   constexpr int KPT = 4, SPT = SLOTS / BLOCK;
@@ -1327,7 +1328,7 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
   if (n64 <= huge_min) return;
   const u64 low_mask = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
   const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);
-  const u64 prefix = (sizeof(KT) == 8) ? ((((u64)keys[0] >> group_shift) << group_shift) | (g << low_bits)) : 0ull;
+  const u64 prefix = (sizeof(KT) == 8) ? ((((u64)keys[0] >> group_shift) << group_shift) | (tr_index(g, tr_a, tr_b) << low_bits)) : 0ull;
   constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
   KT *gk = keys + a;
   const u64 rounds = (n64 + (u64)BLOCK * KPT - 1) / ((u64)BLOCK * KPT);
@@ -1480,7 +1481,7 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
     __syncthreads();                                   // all passes have read the keys; alt[] was written by this workgroup
     for (u64 i = tid; i < out; i += BLOCK) gk[i] = alt[a + i];
   }
-  if (tid == 0) group_distinct[(sizeof(KT) == 4) ? tr_index(g, tr_a, tr_b) : g] = out;
+  if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = out;
 }
 
 // The same for 16-byte keys (k >= 33): slots are claimed through their count word as in hash_count128_kernel, lanes of a
@@ -1489,7 +1490,7 @@ template <int BLOCK, int CAP, int SLOTS, bool WIDE>
 __global__ __launch_bounds__(BLOCK)
 void hash_count128_huge_kernel(K128 *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
                                u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                               K128 *__restrict__ alt) {
+                               K128 *__restrict__ alt, u32 tr_a = 0, u32 tr_b = 0) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS >= CAP * 2 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
   constexpr int KPT = 2, SPT = SLOTS / BLOCK;
   constexpr u32 LOCK = 0xFFFFFFFFu;
@@ -1512,7 +1513,7 @@ void hash_count128_huge_kernel(K128 *__restrict__ keys, const u64 *__restrict__ 
   const u128 low_mask = (low_bits >= 128) ? ~(u128)0 : (((u128)1 << low_bits) - 1);
   const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);
   const u128 file_base = (group_shift >= 128) ? (u128)0 : ((KO::v(keys[0]) >> group_shift) << group_shift);
-  const u128 prefix = file_base | ((u128)g << low_bits);
+  const u128 prefix = file_base | ((u128)tr_index(g, tr_a, tr_b) << low_bits);
   constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
   K128 *gk = keys + a;
   const u64 rounds = (n64 + (u64)BLOCK * KPT - 1) / ((u64)BLOCK * KPT);
@@ -1675,7 +1676,7 @@ void hash_count128_huge_kernel(K128 *__restrict__ keys, const u64 *__restrict__ 
     __syncthreads();
     for (u64 i = tid; i < out; i += BLOCK) gk[i] = alt[a + i];
   }
-  if (tid == 0) group_distinct[g] = out;
+  if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = out;
 }
 
 // Would the distinct suffixes of every sub-bucket above huge_min fit the hash-count tables?  One workgroup per entry of the
@@ -1733,10 +1734,11 @@ void hash_probe_kernel(const KT *__restrict__ keys, const u64 *__restrict__ star
 template <typename K>
 __global__ __launch_bounds__(256)
 void compact_groups_kernel(const K *__restrict__ keys, const u32 *__restrict__ cnt_tmp, const u64 *__restrict__ starts,
-                           const u64 *__restrict__ offs, u64 ng, K *__restrict__ out_keys, u32 *__restrict__ out_counts) {
+                           const u64 *__restrict__ offs, u64 ng, K *__restrict__ out_keys, u32 *__restrict__ out_counts, u32 tr_a, u32 tr_b) {
   const u64 g = (u64)blockIdx.x * 4 + wave_id();
   if (g >= ng) return;
-  const u64 dst = offs[g], d = offs[g + 1] - dst, src = starts[g];
+  const u64 gt = tr_index(g, tr_a, tr_b);              // offs[] goes by the real sub-bucket number (whole keys: nothing to put back)
+  const u64 dst = offs[gt], d = offs[gt + 1] - dst, src = starts[g];
   for (u64 i = lane_id(); i < d; i += 64) {
     out_keys[dst + i]   = keys[src + i];
     out_counts[dst + i] = cnt_tmp[src + i];
@@ -1778,6 +1780,12 @@ constexpr u64 FIN_CAP_SMALL = 256 * 16, FIN_CAP_LARGE = 1024 * 8;   // LDS: 46 K
 constexpr int HUGE_CAP32 = 4096, HUGE_SLOTS32 = 8192;            // 32-bit suffixes: 96 KiB of LDS
 constexpr int HUGE_CAP64 = 2048, HUGE_SLOTS64 = 4096;            // 64-bit suffixes: 72 KiB
 constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count kernel: 2048 slots, 26 KiB of LDS, 6 workgroups per CU
+
+// 16-byte keys: capacity of the hash-count kernel's instantiation in use (hash_count128_kernel: 768 / 1536)
+static uint64_t fin_cap_hash128() {
+  static const uint64_t cap = (getenv("MGC_HASH128_CAP") && atoi(getenv("MGC_HASH128_CAP")) == 1536) ? 1536 : 768;
+  return cap;
+}
 
 static bool finish_uses_hash(uint32_t key_words, uint32_t low_bits) {
   static const bool use_hash = !(getenv("MGC_FINISH_HASH") && getenv("MGC_FINISH_HASH")[0] == '0');
@@ -1955,17 +1963,26 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     }
     return hipSuccess;
   }
+  // whole keys in (low digit : high digit) order (launch_group_wide): only the hash-count kernels translate the sub-bucket numbers
+  if (tr_a && !(finish_uses_hash(key_words, low_bits) && (n_large == 0 || stream))) return hipErrorInvalidValue;
   if (key_words == 2 && finish_uses_hash(key_words, low_bits)) {
     static const uint32_t wgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 4u;     // four workgroups per CU
     const uint32_t wgrid = ng < wgrid_max ? (uint32_t)ng : wgrid_max;
-    if (low_bits > 64)
-      hipLaunchKernelGGL((hash_count128_kernel<256, (int)FIN_CAP_HASH, 2048, true>), dim3(wgrid), dim3(256), 0, st,
-                         reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc);
-    else
-      hipLaunchKernelGGL((hash_count128_kernel<256, (int)FIN_CAP_HASH, 2048, false>), dim3(wgrid), dim3(256), 0, st,
-                         reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc);
+    const u64 cap128 = fin_cap_hash128();
+#define MGC_H128_LAUNCH(CAP_, SLOTS_, WIDE_, GRID_)                                                                                      \
+    hipLaunchKernelGGL((hash_count128_kernel<256, CAP_, SLOTS_, WIDE_>), dim3(GRID_), dim3(256), 0, st,                                  \
+                       reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, cap128, low_bits,             \
+                       d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b)
+    if (cap128 == 768) {
+      // sub-buckets of 320..640 k-mers (finish_target_for): three keys per thread instead of six -- fewer idle unrolled slots,
+      // half the registers and LDS, twice the workgroups per CU
+      static const uint32_t sgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * (uint32_t)H128_SMALL_WAVES;
+      const uint32_t sgrid = ng < sgrid_max ? (uint32_t)ng : sgrid_max;
+      if (low_bits > 64) MGC_H128_LAUNCH(768, 1024, true, sgrid); else MGC_H128_LAUNCH(768, 1024, false, sgrid);
+    } else {
+      if (low_bits > 64) MGC_H128_LAUNCH(1536, 2048, true, wgrid); else MGC_H128_LAUNCH(1536, 2048, false, wgrid);
+    }
+#undef MGC_H128_LAUNCH
     MGC_CHECK(hipGetLastError());
     if (stream && n_large) {
       constexpr int HS = 4096, HC = 2048;
@@ -1982,16 +1999,16 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       if (low_bits > 64)
         hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, true>), dim3((uint32_t)n_large), dim3(1024), BW, st_huge,
                            reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
-                           reinterpret_cast<K128 *>(d_alt));
+                           cap128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                           reinterpret_cast<K128 *>(d_alt), tr_a, tr_b);
       else
         hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, false>), dim3((uint32_t)n_large), dim3(1024), BN, st_huge,
                            reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
-                           reinterpret_cast<K128 *>(d_alt));
+                           cap128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                           reinterpret_cast<K128 *>(d_alt), tr_a, tr_b);
       MGC_CHECK(hipGetLastError());
     } else {
-      MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, 8192, d_cnt_tmp, d_group_distinct, st, d_large_list)));
+      MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, n_large, low_bits, cap128, 8192, d_cnt_tmp, d_group_distinct, st, d_large_list)));
     }
     return hipSuccess;
   }
@@ -2013,19 +2030,19 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     // the dense case runs the instantiation without the list: the kernel is VALU-bound, tests in its loops cost time
     static const bool idx64 = !(getenv("MGC_FINISH_HASH64I") && getenv("MGC_FINISH_HASH64I")[0] == '0');
     if (low_bits >= 32 && idx64) {
-      if (use_list) MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, true>));
-      else          MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, false>));
+      if (use_list) MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, true>), tr_a, tr_b);
+      else          MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, false>), tr_a, tr_b);
     } else if (low_bits >= 32) {
-      if (use_list) MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, true>));
-      else          MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, false>));
+      if (use_list) MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, true>), tr_a, tr_b);
+      else          MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, false>), tr_a, tr_b);
     } else if (hash_dbg_buffer()) {
-      MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true, true>), hash_dbg_buffer());
+      MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true, true>), hash_dbg_buffer(), tr_a, tr_b);
     } else {
       static const bool binrank = !(getenv("MGC_HASH_BINRANK") && getenv("MGC_HASH_BINRANK")[0] == '0');
-      if (use_list) { if (binrank) MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, false, true>), (u64 *)nullptr);
-                      else         MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, false, false>), (u64 *)nullptr); }
-      else          { if (binrank) MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, false, true>), (u64 *)nullptr);
-                      else         MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, false, false>), (u64 *)nullptr); }
+      if (use_list) { if (binrank) MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, false, true>), (u64 *)nullptr, tr_a, tr_b);
+                      else         MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, false, false>), (u64 *)nullptr, tr_a, tr_b); }
+      else          { if (binrank) MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, false, true>), (u64 *)nullptr, tr_a, tr_b);
+                      else         MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, false, false>), (u64 *)nullptr, tr_a, tr_b); }
     }
 #undef MGC_HASH_LAUNCH
     MGC_CHECK(hipGetLastError());
@@ -2046,12 +2063,12 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
         hipLaunchKernelGGL((hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>), dim3((uint32_t)n_large), dim3(1024), B32, st_huge,
                            reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
                            (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
-                           reinterpret_cast<u64 *>(d_alt));
+                           reinterpret_cast<u64 *>(d_alt), tr_a, tr_b);
       else
         hipLaunchKernelGGL((hash_count_huge_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>), dim3((uint32_t)n_large), dim3(1024), B64, st_huge,
                            reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
                            (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
-                           reinterpret_cast<u64 *>(d_alt));
+                           reinterpret_cast<u64 *>(d_alt), tr_a, tr_b);
       MGC_CHECK(hipGetLastError());
     } else {
       MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, FIN_CAP_LARGE, d_cnt_tmp,
@@ -2066,7 +2083,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
 }
 
 static uint64_t finish_small_capacity(uint32_t key_words, uint32_t low_bits) {
-  if (key_words == 2) return finish_uses_hash(key_words, low_bits) ? FIN_CAP_HASH : 2048;
+  if (key_words == 2) return finish_uses_hash(key_words, low_bits) ? fin_cap_hash128() : 2048;
   return finish_uses_hash(key_words, low_bits) ? FIN_CAP_HASH : FIN_CAP_SMALL;
 }
 
@@ -2074,7 +2091,8 @@ uint64_t finish_capacity_for(uint32_t key_words) { return key_words == 2 ? 8192 
 uint64_t finish_target_for(uint32_t key_words) {
   if (const char *t = getenv("MGC_FINISH_TARGET")) return strtoull(t, nullptr, 10);
   const char *h = getenv("MGC_FINISH_HASH");
-  if (key_words == 2) return (h && h[0] == '0') ? 1024 : FIN_CAP_HASH / 2;     // measured at k=51: 768 beats 512 and 1152
+  // (1536-key tables, measured at k=51: 768 beats 512 and 1152; 768-key tables: 640 keeps the Poisson tail inside)
+  if (key_words == 2) return (h && h[0] == '0') ? 1024 : (fin_cap_hash128() == 768 ? 640 : 768);
   return (h && h[0] == '0') ? FIN_CAP_SMALL / 2 : (FIN_CAP_HASH * 3) / 4;
 }
 
@@ -2086,16 +2104,17 @@ hipError_t launch_finish_scan(uint64_t *d_group, uint64_t ng_total, void *d_scra
 }
 
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,
-                                 const uint64_t *d_offs, uint64_t ng, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st) {
+                                 const uint64_t *d_offs, uint64_t ng, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st,
+                                 uint32_t tr_a, uint32_t tr_b) {
   const dim3 grid((uint32_t)((ng + 3) / 4));
   if (key_words == 2)
     hipLaunchKernelGGL(compact_groups_kernel<K128>, grid, dim3(256), 0, st, reinterpret_cast<const K128 *>(d_keys), d_cnt_tmp,
                        reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng,
-                       reinterpret_cast<K128 *>(d_out_keys), d_out_counts);
+                       reinterpret_cast<K128 *>(d_out_keys), d_out_counts, tr_a, tr_b);
   else
     hipLaunchKernelGGL(compact_groups_kernel<u64>, grid, dim3(256), 0, st, reinterpret_cast<const u64 *>(d_keys), d_cnt_tmp,
                        reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng,
-                       reinterpret_cast<u64 *>(d_out_keys), d_out_counts);
+                       reinterpret_cast<u64 *>(d_out_keys), d_out_counts, tr_a, tr_b);
   return hipGetLastError();
 }
 

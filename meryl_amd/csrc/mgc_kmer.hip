@@ -138,6 +138,35 @@ __device__ __forceinline__ u32 kp_thread_buckets(const u32 *s_codes, const u32 *
   return kp_valid_mask(I, k);
 }
 
+// kp_thread_buckets for k in 33..64 (80-base windows, five staged words): the forward tops still come from the window's first
+// bases; the last m bases of the sixteen starts (bases z0 .. z0+m+14, z0 = k - m >= 25) sit in one 32-base chunk cut from
+// words z0/16 .. -- reversed once, as above.  The valid mask is the k-wide OR of the invalid-base bits, by doubling, on
+// 128 bits.  bucket_bits <= 16.
+__device__ __forceinline__ u32 kp_thread_buckets_wide(const u32 *s_codes, const u32 *s_inval, u32 k, int mode, u32 bucket_bits,
+                                                      u32 (&bk)[KP_ITEMS], const u32 t) {
+  const u64 A  = ((u64)s_codes[t] << 32) | (u64)s_codes[t + 1];      // bases 0..31 of the thread's window
+  const u32 m  = (bucket_bits + 1) / 2, z0 = k - m;
+  const u32 q  = z0 >> 4, r = z0 & 15u;                              // q <= 3: words q, q+1 always exist
+  const u64 H  = ((u64)s_codes[t + q] << 32) | (u64)s_codes[t + q + 1];
+  const u64 L  = (q + 2 <= 4) ? ((u64)s_codes[t + q + 2] << 32) : 0ull;   // (q = 3: r <= 8, the 23 bases needed all come from H)
+  const u64 Z  = r ? ((H << (2 * r)) | (L >> (64 - 2 * r))) : H;      // bases z0 .. z0+31
+  const u64 RC = revcomp64(Z, 0);
+  const u64 mmask = (1ull << (2 * m)) - 1ull;
+  const u32 odd = 2 * m - bucket_bits;
+#pragma unroll
+  for (int j = 0; j < KP_ITEMS; j++) {
+    const u32 ft = (u32)(((j == 0) ? A : (A << (2 * j))) >> (64 - bucket_bits));
+    const u32 rt = (u32)((RC >> (2 * j)) & mmask) >> odd;
+    bk[j] = (mode == 1) ? ft : (mode == 2) ? rt : (ft < rt ? ft : rt);
+  }
+  u128 X = ((u128)s_inval[t] << 112) | ((u128)s_inval[t + 1] << 96) | ((u128)s_inval[t + 2] << 80) |
+           ((u128)s_inval[t + 3] << 64) | ((u128)s_inval[t + 4] << 48);
+  u32 c = 1;
+  while (2 * c <= k) { X |= X << c; c *= 2; }
+  if (c < k) X |= X << (k - c);
+  return __brev((u32)(~X >> 112) & 0xFFFFu) >> 16;                   // start j -> bit j
+}
+
 // Same for k in 33..64: the thread's window is 80 bases (five staged words).
 __device__ __forceinline__ u32 kp_thread_kmers(const u32 *s_codes, const u32 *s_inval, u32 k, int mode,
                                                K128 (&keys)[KP_ITEMS]) {
@@ -252,7 +281,7 @@ void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode,
 // radix_hist_kernel read).  2^15 LDS counters = 128 KiB, hence ONE 1024-thread workgroup per CU standing for NV = 4
 // workgroups of kmer_hist_kernel (slices of 256 threads, each with the tile range and the block_hist row the partition
 // kernel expects from workgroup blockIdx.x * NV + slice); the next tile's bases are loaded while the current one is counted.
-// k <= 32, 2k >= 15, no count-suffix, 64 buckets.
+// k <= 64 (k > 32: kp_thread_buckets_wide), 2k >= 17, no count-suffix, 64 buckets.
 constexpr int KH_NV = 4, KH_FINE_BITS = 15;
 __global__ __launch_bounds__(KP_BLOCK * KH_NV)
 void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u64 num_tiles, u32 vgrid,
@@ -296,7 +325,8 @@ void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
     fetch(tile + 1);                                                 // in flight behind the counting below
     if (active) {
       u32 bk[KP_ITEMS];
-      const u32 vmask = kp_thread_buckets(s_codes[buf][v], s_inval[buf][v], k, mode, KH_FINE_BITS, bk, t);
+      const u32 vmask = (k > 32) ? kp_thread_buckets_wide(s_codes[buf][v], s_inval[buf][v], k, mode, KH_FINE_BITS, bk, t)
+                                 : kp_thread_buckets(s_codes[buf][v], s_inval[buf][v], k, mode, KH_FINE_BITS, bk, t);
 #pragma unroll
       for (int j = 0; j < KP_ITEMS; j++)
         if ((vmask >> j) & 1u) { atomicAdd(&kh_fine[bk[j]], 1u); atomicAdd(&s_hist[v][bk[j] >> (KH_FINE_BITS - 6)], 1u); }
@@ -548,7 +578,7 @@ hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint3
 
 bool kmer_histogram_fine_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask) {
   const char *e = getenv("MGC_FINE_HIST");
-  return !(e && e[0] == '0') && k <= 32 && 2 * k >= (uint32_t)KH_FINE_BITS + 2 && bucket_bits == 6 && sfx_mask == 0;
+  return !(e && e[0] == '0') && k <= 64 && 2 * k >= (uint32_t)KH_FINE_BITS + 2 && bucket_bits == 6 && sfx_mask == 0;
 }
 
 // launch_kmer_histogram + d_fine_hist[2^15] (zeroed here): k-mers per (file, next nine bits)

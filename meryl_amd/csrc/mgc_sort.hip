@@ -1678,6 +1678,76 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
   return hipSuccess;
 }
 
+// ---- the same two passes for WHOLE keys (mgc_device.h, launch_group_wide) ----
+bool sort_plan_wide_msd(const SortPlan &plan, uint64_t n) {
+  const char *e = getenv("MGC_WIDE_MSD");                   // read per call: the tests switch it
+  const bool on = !(e && e[0] == '0');
+  return on && plan.mode == 3 && !plan.hpc && plan.num_passes == 2 && plan.radix_bits == 9 && n > 0 && n < (1ull << 30) &&
+         plan.pass_shift[1] == plan.pass_shift[0] + plan.pass_bits[0];
+}
+
+static inline uint64_t wide_tile(uint32_t key_words) { return key_words == 2 ? 1024u * 8u : 1024u * 16u; }
+size_t wide_scratch_bytes(uint64_t n, uint32_t key_words) {
+  const uint64_t tile = wide_tile(key_words);
+  const uint64_t tiles0 = (n + tile - 1) / tile, tiles1_max = tiles0 + RS_MAX_RADIX + 1;
+  return (size_t)(tiles0 + tiles1_max) * (RS_MAX_RADIX / 2) * sizeof(u64) + (size_t)(RS_MAX_RADIX + 2) * 16 + 512;
+}
+
+template <typename K, int KPT>
+static hipError_t group_wide(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, uint32_t *d_error, uint64_t *d_sub_starts,
+                             hipStream_t st, hipEvent_t *pass_events, void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b) {
+  constexpr int RB = 9, BLOCK = 1024, R = 1 << RB;
+  using GS = GroupSmem<K, RB, BLOCK, KPT>;
+  constexpr uint64_t TILE = (uint64_t)BLOCK * KPT;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES);
+    attr_done = true;
+  }
+  const uint64_t tiles0 = (n + TILE - 1) / TILE, tiles1_max = tiles0 + RS_MAX_RADIX + 1;
+  SortHeader *hdr = reinterpret_cast<SortHeader *>(d_prepared);
+  u64 *status_a = reinterpret_cast<u64 *>(d_scratch);
+  u64 *status_b = status_a + (size_t)tiles0 * (R / 2);
+  u64 *region_start = status_b + (size_t)tiles1_max * (R / 2);
+  u32 *region_tiles = reinterpret_cast<u32 *>(region_start + RS_MAX_RADIX + 1);
+  // the keys stay whole: digit A (high) at shA, digit B (low) at `low`, both where the plan put them
+  const u32 low = plan.pass_shift[0], bB = plan.pass_bits[0], bA = plan.pass_bits[1], shA = low + bB;
+  *tr_a = bA; *tr_b = bB;
+  const uint64_t resident = (uint64_t)device_cu_count() * GS::WG_PER_CU;
+
+  if (pass_events) MGC_CHECK(hipEventRecord(pass_events[0], st));
+  hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, true>), dim3((uint32_t)std::min(tiles0, resident)), dim3(BLOCK), GS::BYTES, st,
+                     reinterpret_cast<const K *>(d_keys), reinterpret_cast<K *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                     &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                     GroupExtra{0u, low, (1u << bB) - 1u, &hdr->ghist[1][0]}, (u64 *)nullptr);
+  MGC_CHECK(hipGetLastError());
+  if (pass_events) MGC_CHECK(hipEventRecord(pass_events[1], st));
+  hipLaunchKernelGGL(narrow_mid_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, hdr, (u64)n, (u32)TILE, region_start, region_tiles);
+  MGC_CHECK(hipGetLastError());
+  if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2], st));
+  hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, false>), dim3((uint32_t)std::min(tiles1_max, resident)), dim3(BLOCK), GS::BYTES, st,
+                     reinterpret_cast<const K *>(d_alt), reinterpret_cast<K *>(d_keys), (u64)n, low, (1u << bB) - 1u,
+                     &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)tiles0, region_start, region_tiles,
+                     GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
+  MGC_CHECK(hipGetLastError());
+  if (pass_events) MGC_CHECK(hipEventRecord(pass_events[3], st));
+  const u64 ng = (u64)1 << (bA + bB);
+  hipLaunchKernelGGL(narrow_bounds_kernel, dim3((uint32_t)((ng + 1 + 255) / 256)), dim3(256), 0, st, status_b, region_tiles,
+                     &hdr->gbase[1][0], (u64)n, bA, ng, reinterpret_cast<u64 *>(d_sub_starts));
+  return hipGetLastError();
+}
+
+hipError_t launch_group_wide(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan, uint32_t *d_error,
+                             uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events, void *d_prepared, void *d_scratch,
+                             uint32_t *tr_a, uint32_t *tr_b) {
+  if (!sort_plan_wide_msd(plan, n) || !d_prepared || !d_scratch) return hipErrorInvalidValue;
+  if (key_words == 2) return group_wide<K128, 8>(d_keys, d_alt, n, plan, d_error, d_sub_starts, st, pass_events, d_prepared, d_scratch, tr_a, tr_b);
+  return group_wide<u64, 16>(d_keys, d_alt, n, plan, d_error, d_sub_starts, st, pass_events, d_prepared, d_scratch, tr_a, tr_b);
+}
+
 size_t sort_header_bytes() { return ((sizeof(SortHeader) + 255) / 256) * 256; }
 
 // true when launch_radix_sort would run this plan as grouping passes (and can therefore use a prepared header)

@@ -1128,7 +1128,8 @@ def test_large_input_partition_granularity(ops, oracle_lib, torch_cuda, monkeypa
 
 
 @pytest.mark.parametrize("fine", ["1", "0"])
-@pytest.mark.parametrize("k,target,narrow", [(21, 1, "1"), (21, 1, "0"), (21, 6, "1"), (19, 3, "1"), (22, 2, "1"), (24, 2, "1"), (26, 2, "1"), (16, 1, "1")])
+@pytest.mark.parametrize("k,target,narrow", [(21, 1, "1"), (21, 1, "0"), (21, 6, "1"), (19, 3, "1"), (22, 2, "1"), (24, 2, "1"), (26, 2, "1"), (16, 1, "1"),
+                                             (28, 2, "1"), (31, 2, "1"), (32, 1, "1"), (33, 2, "1"), (40, 1, "1"), (51, 2, "1"), (64, 2, "1")])
 def test_narrowed_grouping_passes(ops, oracle_lib, torch_cuda, monkeypatch, k, target, narrow, fine):
     """Two grouping digits on a small input (MGC_FINISH_TARGET makes the sub-buckets tiny, so the plan needs 15-17 top bits):
     k <= ~25 then takes the NARROWED passes -- the first pass drops its digit and writes 32-bit words, the second groups those,
@@ -1137,7 +1138,10 @@ def test_narrowed_grouping_passes(ops, oracle_lib, torch_cuda, monkeypatch, k, t
     below the first digit and stays wide by itself).  fine = "1": the file histogram counts fifteen top bits, the HIGH digit goes
     first with its histogram taken from there, the first pass counts the low digit as it goes, and the sub-buckets lie in
     (low digit : high digit) order -- the hash-count, the streaming kernel and the packing step translate the numbers;
-    fine = "0": low digit first off one histogram read of the keys (what the owner side of a sharded count runs)."""
+    fine = "0": low digit first off one histogram read of the keys (what the owner side of a sharded count runs).
+    k >= 26 (more than 32 bits below the first digit) and the 16-byte keys of k > 32 keep WHOLE keys; with fine = "1" they take the
+    same high-digit-first passes (launch_group_wide: 128-bit fifteen-bit histogram for k > 32, low digit counted by the first
+    pass, boundaries from the granules, the 64-bit / 128-bit hash-count kernels and the packing step translating the numbers)."""
     from meryl_amd import capi
     monkeypatch.setenv("MGC_FINISH_TARGET", str(target))
     monkeypatch.setenv("MGC_NARROW", narrow)
@@ -1157,6 +1161,8 @@ def test_narrowed_grouping_passes(ops, oracle_lib, torch_cuda, monkeypatch, k, t
         assert info.n_instances == wni
         assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
         assert prof.sort_pass_launches > 100                        # two passes for (nearly) every file
+        if k >= 26 or narrow == "0":                                # whole keys: high digit first too, when that histogram is there
+            assert (prof.wide_msd_files > 50) == (fine == "1"), prof.wide_msd_files
 
 
 @pytest.mark.parametrize("target", [None, 8, -8])
@@ -1174,8 +1180,8 @@ def test_oversized_subbuckets_stream_in_ranges(ops, oracle_lib, torch_cuda, monk
     if stream_max is not None:
         monkeypatch.setenv("MGC_STREAM_MAX", str(stream_max))
     if target is not None:                                  # two grouping digits: k=21 takes the narrowed passes, whose streaming
-        if k not in (21, 25):                               # kernel and probe read 32-bit words and whose refused files are widened
-            pytest.skip("the narrowed passes are a k <= 25 matter")
+        # kernel and probe read 32-bit words and whose refused files are widened; the others keep whole keys, high digit first
+        # (target > 0): their streaming kernels translate the sub-bucket numbers, their refused files take the stable sort
         monkeypatch.setenv("MGC_FINISH_TARGET", str(abs(target)))
         if target < 0:                                      # low digit first (no fifteen-bit file histogram): widened files stay in key order
             monkeypatch.setenv("MGC_FINE_HIST", "0")
