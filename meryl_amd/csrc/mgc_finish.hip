@@ -926,8 +926,8 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
 // k=51, two workgroups per CU; this one aliases the compacted output onto the staging arrays, packs index and count into
 // one slot word and fits four: 103 ms with separate index/count words and three workgroups.)
 // WIDE = the suffix needs the high word too (low_bits > 64); otherwise the hi arrays are not even allocated.
-constexpr int H128_SMALL_WAVES = 7;                               // hash_count128_kernel<.., 768, ..>: workgroups per CU asked for
-template <int BLOCK, int CAP, int SLOTS, bool WIDE>
+constexpr int H128_SMALL_WAVES = 6;                               // hash_count128_kernel<.., 768, ..>: workgroups per CU asked for
+template <int BLOCK, int CAP, int SLOTS, bool WIDE, bool BINRANK = true>
 __global__ __launch_bounds__(BLOCK, (CAP <= 768 ? H128_SMALL_WAVES : 4))
 void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                           u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
@@ -940,6 +940,9 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
   __shared__ __attribute__((aligned(16))) u64 dhi[WIDE ? CAP + 4 : 2];
   __shared__ u32 tw[SLOTS];                                           // slot -> instances << 16 | index of the claiming key;
   __shared__ u32 s_tmp[BLOCK / 64 + 1];                               //   later dc[]: counts of the compacted suffixes
+  __shared__ u32 s_bin[BINRANK ? BLOCK + 1 : 1];                      // BINRANK: as in hash_count64i_kernel
+  __shared__ unsigned short s_ix[BINRANK ? CAP : 1];
+  static_assert(!BINRANK || BLOCK == 256, "one bin per thread");
   u32 *dc = tw;                                                       // 33 KiB of LDS in all: four workgroups per CU
   using KO = KeyOps<K128>;
   const u32 tid = threadIdx.x;
@@ -1054,6 +1057,47 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
       const u32 d4 = (D + 3) / 4;                      // the arrays are padded with all-ones (never smaller) to 4
       const ulonglong2 *dlo2 = reinterpret_cast<const ulonglong2 *>(dlo);
       const ulonglong2 *dhi2 = reinterpret_cast<const ulonglong2 *>(dhi);
+      if constexpr (BINRANK) {
+        const u32 bshift = low_bits > 8 ? low_bits - 8 : 0;
+        auto bin_of = [&](u32 i) -> u32 {
+          if (WIDE) return (u32)(((((u128)dhi[i]) << 64) | (u128)dlo[i]) >> bshift);
+          return (u32)(dlo[i] >> bshift);
+        };
+        s_bin[tid] = 0;
+        __syncthreads();
+        u32 lr[KPT];
+#pragma unroll
+        for (int q = 0; q < KPT; q++) {
+          const u32 i = (u32)q * BLOCK + tid;
+          lr[q] = 0;
+          if (i < D) lr[q] = atomicAdd(&s_bin[bin_of(i)], 1u);
+        }
+        __syncthreads();
+        u32 tot;
+        const u32 e = block_excl_scan<BLOCK, u32>(s_bin[tid], s_tmp, &tot);
+        s_bin[tid] = e;
+        if (tid == 0) s_bin[BLOCK] = D;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < KPT; q++) {
+          const u32 i = (u32)q * BLOCK + tid;
+          if (i < D) s_ix[s_bin[bin_of(i)] + lr[q]] = (unsigned short)i;
+        }
+        __syncthreads();
+        for (u32 pidx = tid; pidx < D; pidx += BLOCK) {
+          const u32 i = s_ix[pidx];
+          const u64 li = dlo[i], hi = WIDE ? dhi[i] : 0ull;
+          const u32 b = bin_of(i), lo = s_bin[b], hi_ = s_bin[b + 1];
+          u32 r = lo;
+          for (u32 q = lo; q < hi_; q++) {
+            const u32 j = s_ix[q];
+            const u64 lj = dlo[j], hj = WIDE ? dhi[j] : 0ull;
+            r += ((hj < hi) || (hj == hi && lj < li)) ? 1u : 0u;
+          }
+          gk[r] = KO::mk(prefix | ((u128)hi << 64) | (u128)li);
+          cnt_tmp[a + r] = dc[i];
+        }
+      } else
       for (u32 i = tid; i < D; i += BLOCK) {
         const u64 li = dlo[i], hi = WIDE ? dhi[i] : 0ull;
         u32 r0 = 0, r1 = 0;
@@ -1085,7 +1129,7 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
 // The same index-claimed table for 8-byte keys whose suffix does not fit 32 bits (low_bits 32..58: k = 28..32, `compress`):
 // the first version of this kernel kept 64-bit suffixes in the table (64-bit LDS CAS, 42 KiB, three workgroups per CU);
 // staged suffixes + one 32-bit slot word need 21 KiB.
-template <int BLOCK, int CAP, int SLOTS, bool LIST>
+template <int BLOCK, int CAP, int SLOTS, bool LIST, bool BINRANK = true>
 __global__ __launch_bounds__(BLOCK, 5)
 void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                           u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
@@ -1096,6 +1140,11 @@ void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
   __shared__ __attribute__((aligned(16))) u64 dk[CAP + 16];           // staged suffixes, later the compacted distinct ones
   __shared__ u32 tw[SLOTS];                                           // instances << 16 | index of the claiming key; later dc[]
   __shared__ u32 s_tmp[BLOCK / 64 + 1];
+  // BINRANK: the distinct suffixes are binned by their top eight bits (a counting sort of their INDICES); a suffix's rank is
+  // its bin's start + the smaller ones inside the bin -- D * D / 256 compares instead of D * D
+  __shared__ u32 s_bin[BINRANK ? BLOCK + 1 : 1];
+  __shared__ unsigned short s_ix[BINRANK ? CAP : 1];
+  static_assert(!BINRANK || BLOCK == 256, "one bin per thread");
   u32 *dc = tw;
   const u32 tid = threadIdx.x;
   const u64 G = gridDim.x;
@@ -1190,6 +1239,39 @@ void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
       u64 *gk = keys + a;
       const u32 d4 = (D + 3) / 4;
       const ulonglong2 *dk2 = reinterpret_cast<const ulonglong2 *>(dk);
+      if constexpr (BINRANK) {
+        const u32 bshift = low_bits > 8 ? low_bits - 8 : 0;
+        s_bin[tid] = 0;
+        __syncthreads();
+        u32 li[KPT];
+#pragma unroll
+        for (int q = 0; q < KPT; q++) {
+          const u32 i = (u32)q * BLOCK + tid;
+          li[q] = 0;
+          if (i < D) li[q] = atomicAdd(&s_bin[(u32)(dk[i] >> bshift)], 1u);
+        }
+        __syncthreads();
+        u32 tot;
+        const u32 e = block_excl_scan<BLOCK, u32>(s_bin[tid], s_tmp, &tot);
+        s_bin[tid] = e;
+        if (tid == 0) s_bin[BLOCK] = D;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < KPT; q++) {
+          const u32 i = (u32)q * BLOCK + tid;
+          if (i < D) s_ix[s_bin[(u32)(dk[i] >> bshift)] + li[q]] = (unsigned short)i;
+        }
+        __syncthreads();
+        for (u32 pidx = tid; pidx < D; pidx += BLOCK) {
+          const u32 i = s_ix[pidx];
+          const u64 ki = dk[i];
+          const u32 b = (u32)(ki >> bshift), lo = s_bin[b], hi = s_bin[b + 1];
+          u32 r = lo;
+          for (u32 q = lo; q < hi; q++) r += (dk[s_ix[q]] < ki) ? 1u : 0u;
+          gk[r] = prefix | ki;
+          cnt_tmp[a + r] = dc[i];
+        }
+      } else
       for (u32 i = tid; i < D; i += BLOCK) {
         const u64 ki = dk[i];
         u32 r0 = 0, r1 = 0;
@@ -1969,10 +2051,13 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     static const uint32_t wgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 4u;     // four workgroups per CU
     const uint32_t wgrid = ng < wgrid_max ? (uint32_t)ng : wgrid_max;
     const u64 cap128 = fin_cap_hash128();
-#define MGC_H128_LAUNCH(CAP_, SLOTS_, WIDE_, GRID_)                                                                                      \
-    hipLaunchKernelGGL((hash_count128_kernel<256, CAP_, SLOTS_, WIDE_>), dim3(GRID_), dim3(256), 0, st,                                  \
+    static const bool binrank128 = !(getenv("MGC_HASH_BINRANK") && getenv("MGC_HASH_BINRANK")[0] == '0');
+#define MGC_H128_LAUNCH_(CAP_, SLOTS_, WIDE_, GRID_, BIN_)                                                                               \
+    hipLaunchKernelGGL((hash_count128_kernel<256, CAP_, SLOTS_, WIDE_, BIN_>), dim3(GRID_), dim3(256), 0, st,                            \
                        reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, cap128, low_bits,             \
                        d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b)
+#define MGC_H128_LAUNCH(CAP_, SLOTS_, WIDE_, GRID_) do { if (binrank128) MGC_H128_LAUNCH_(CAP_, SLOTS_, WIDE_, GRID_, true);              \
+                                                         else            MGC_H128_LAUNCH_(CAP_, SLOTS_, WIDE_, GRID_, false); } while (0)
     if (cap128 == 768) {
       // sub-buckets of 320..640 k-mers (finish_target_for): three keys per thread instead of six -- fewer idle unrolled slots,
       // half the registers and LDS, twice the workgroups per CU
@@ -1983,6 +2068,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       if (low_bits > 64) MGC_H128_LAUNCH(1536, 2048, true, wgrid); else MGC_H128_LAUNCH(1536, 2048, false, wgrid);
     }
 #undef MGC_H128_LAUNCH
+#undef MGC_H128_LAUNCH_
     MGC_CHECK(hipGetLastError());
     if (stream && n_large) {
       constexpr int HS = 4096, HC = 2048;
@@ -2030,8 +2116,11 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     // the dense case runs the instantiation without the list: the kernel is VALU-bound, tests in its loops cost time
     static const bool idx64 = !(getenv("MGC_FINISH_HASH64I") && getenv("MGC_FINISH_HASH64I")[0] == '0');
     if (low_bits >= 32 && idx64) {
-      if (use_list) MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, true>), tr_a, tr_b);
-      else          MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, false>), tr_a, tr_b);
+      static const bool binrank64 = !(getenv("MGC_HASH_BINRANK") && getenv("MGC_HASH_BINRANK")[0] == '0');
+      if (use_list) { if (binrank64) MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, true, true>), tr_a, tr_b);
+                      else           MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, true, false>), tr_a, tr_b); }
+      else          { if (binrank64) MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, false, true>), tr_a, tr_b);
+                      else           MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, false, false>), tr_a, tr_b); }
     } else if (low_bits >= 32) {
       if (use_list) MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, true>), tr_a, tr_b);
       else          MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, false>), tr_a, tr_b);
