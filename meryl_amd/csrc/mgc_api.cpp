@@ -1520,13 +1520,15 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0) continue;
       void *seg = X + kbytes * h_starts[b];
+      // a sparse sub-bucket grid (`compress`: 59049 of 2^20): only the non-empty ones are visited
+      const uint32_t *nzl = (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b])) ? d_nz + gbase[b] : nullptr;
       if (narrow[b]) {
         HIP_TRY(s, mgc::launch_compact_groups_narrow(seg, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b],
                                                      gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, rem_bits - top_bits[b],
-                                                     s->d_unique, s->d_counts, st, tr_a[b], tr_b[b]));
+                                                     s->d_unique, s->d_counts, st, tr_a[b], tr_b[b], nzl, h_nzcount[b]));
       } else if (!fallback[b]) {
         HIP_TRY(s, mgc::launch_compact_groups(seg, kw, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b],
-                                              gbase[b + 1] - gbase[b], s->d_unique, s->d_counts, st, tr_a[b], tr_b[b]));
+                                              gbase[b + 1] - gbase[b], s->d_unique, s->d_counts, st, tr_a[b], tr_b[b], nzl, h_nzcount[b]));
       } else {
         HIP_TRY(s, mgc::launch_rle_count(seg, h_counts[b], kw, rle_ws, st));
         HIP_TRY(s, mgc::launch_rle_emit(seg, h_counts[b], kw, rle_ws, s->d_unique, s->d_counts, st, d_group + gbase[b]));

@@ -158,11 +158,12 @@ size_t     finish_scan_scratch_bytes(uint64_t ng_total);
 hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,
                                  const uint64_t *d_offs, uint64_t ng, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st,
-                                 uint32_t tr_a = 0, uint32_t tr_b = 0 /*launch_group_wide's: d_offs goes by tr_index(sub-bucket)*/);
+                                 uint32_t tr_a = 0, uint32_t tr_b = 0 /*launch_group_wide's: d_offs goes by tr_index(sub-bucket)*/,
+                                 const uint32_t *d_nonempty_list = nullptr, uint64_t n_nonempty = 0 /*visit only these (host count)*/);
 // narrowed files: k-mer = base | sub-bucket << low_bits | suffix
 hipError_t launch_compact_groups_narrow(const void *d_keys32, const uint32_t *d_cnt_tmp, const uint64_t *d_starts, const uint64_t *d_offs,
                                         uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st,
-                                        uint32_t tr_a, uint32_t tr_b);
+                                        uint32_t tr_a, uint32_t tr_b, const uint32_t *d_nonempty_list = nullptr, uint64_t n_nonempty = 0);
 hipError_t launch_widen_groups(const void *d_keys32, const uint64_t *d_starts, uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out64,
                                hipStream_t st, uint32_t tr_a, uint32_t tr_b);      // tr_a != 0: the result is NOT in key order
 hipError_t launch_store_u64(uint64_t *d_dst, const uint64_t *d_src, hipStream_t st);

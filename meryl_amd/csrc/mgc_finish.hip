@@ -1816,9 +1816,11 @@ void hash_probe_kernel(const KT *__restrict__ keys, const u64 *__restrict__ star
 template <typename K>
 __global__ __launch_bounds__(256)
 void compact_groups_kernel(const K *__restrict__ keys, const u32 *__restrict__ cnt_tmp, const u64 *__restrict__ starts,
-                           const u64 *__restrict__ offs, u64 ng, K *__restrict__ out_keys, u32 *__restrict__ out_counts, u32 tr_a, u32 tr_b) {
-  const u64 g = (u64)blockIdx.x * 4 + wave_id();
-  if (g >= ng) return;
+                           const u64 *__restrict__ offs, u64 ng, K *__restrict__ out_keys, u32 *__restrict__ out_counts, u32 tr_a, u32 tr_b,
+                           const u32 *__restrict__ nz, u64 n_nz /* the non-empty sub-buckets only (a sparse grid: `compress`), or null */) {
+  u64 g = (u64)blockIdx.x * 4 + wave_id();
+  if (nz) { if (g >= n_nz) return; g = nz[g]; }
+  else if (g >= ng) return;
   const u64 gt = tr_index(g, tr_a, tr_b);              // offs[] goes by the real sub-bucket number (whole keys: nothing to put back)
   const u64 dst = offs[gt], d = offs[gt + 1] - dst, src = starts[g];
   for (u64 i = lane_id(); i < d; i += 64) {
@@ -1831,9 +1833,10 @@ void compact_groups_kernel(const K *__restrict__ keys, const u32 *__restrict__ c
 __global__ __launch_bounds__(256)
 void compact_groups_narrow_kernel(const u32 *__restrict__ keys32, const u32 *__restrict__ cnt_tmp, const u64 *__restrict__ starts,
                                   const u64 *__restrict__ offs, u64 ng, u64 base, u32 low_bits, u64 *__restrict__ out_keys,
-                                  u32 *__restrict__ out_counts, u32 tr_a, u32 tr_b) {
-  const u64 g = (u64)blockIdx.x * 4 + wave_id();
-  if (g >= ng) return;
+                                  u32 *__restrict__ out_counts, u32 tr_a, u32 tr_b, const u32 *__restrict__ nz, u64 n_nz) {
+  u64 g = (u64)blockIdx.x * 4 + wave_id();
+  if (nz) { if (g >= n_nz) return; g = nz[g]; }
+  else if (g >= ng) return;
   const u64 gt = tr_index(g, tr_a, tr_b);              // offs[] and the k-mers' top bits go by the real sub-bucket number
   const u64 dst = offs[gt], d = offs[gt + 1] - dst, src = starts[g], pre = base | (gt << low_bits);
   for (u64 i = lane_id(); i < d; i += 64) {
@@ -2194,25 +2197,27 @@ hipError_t launch_finish_scan(uint64_t *d_group, uint64_t ng_total, void *d_scra
 
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,
                                  const uint64_t *d_offs, uint64_t ng, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st,
-                                 uint32_t tr_a, uint32_t tr_b) {
-  const dim3 grid((uint32_t)((ng + 3) / 4));
+                                 uint32_t tr_a, uint32_t tr_b, const uint32_t *d_nz, uint64_t n_nz) {
+  const dim3 grid((uint32_t)(((d_nz ? n_nz : ng) + 3) / 4));
+  if (d_nz && n_nz == 0) return hipSuccess;
   if (key_words == 2)
     hipLaunchKernelGGL(compact_groups_kernel<K128>, grid, dim3(256), 0, st, reinterpret_cast<const K128 *>(d_keys), d_cnt_tmp,
                        reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng,
-                       reinterpret_cast<K128 *>(d_out_keys), d_out_counts, tr_a, tr_b);
+                       reinterpret_cast<K128 *>(d_out_keys), d_out_counts, tr_a, tr_b, d_nz, (u64)n_nz);
   else
     hipLaunchKernelGGL(compact_groups_kernel<u64>, grid, dim3(256), 0, st, reinterpret_cast<const u64 *>(d_keys), d_cnt_tmp,
                        reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng,
-                       reinterpret_cast<u64 *>(d_out_keys), d_out_counts, tr_a, tr_b);
+                       reinterpret_cast<u64 *>(d_out_keys), d_out_counts, tr_a, tr_b, d_nz, (u64)n_nz);
   return hipGetLastError();
 }
 
 hipError_t launch_compact_groups_narrow(const void *d_keys32, const uint32_t *d_cnt_tmp, const uint64_t *d_starts, const uint64_t *d_offs,
                                         uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st,
-                                        uint32_t tr_a, uint32_t tr_b) {
-  hipLaunchKernelGGL(compact_groups_narrow_kernel, dim3((uint32_t)((ng + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const u32 *>(d_keys32),
+                                        uint32_t tr_a, uint32_t tr_b, const uint32_t *d_nz, uint64_t n_nz) {
+  if (d_nz && n_nz == 0) return hipSuccess;
+  hipLaunchKernelGGL(compact_groups_narrow_kernel, dim3((uint32_t)(((d_nz ? n_nz : ng) + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const u32 *>(d_keys32),
                      d_cnt_tmp, reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng, (u64)base, low_bits,
-                     reinterpret_cast<u64 *>(d_out_keys), d_out_counts, tr_a, tr_b);
+                     reinterpret_cast<u64 *>(d_out_keys), d_out_counts, tr_a, tr_b, d_nz, (u64)n_nz);
   return hipGetLastError();
 }
 

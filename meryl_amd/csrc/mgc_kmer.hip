@@ -279,8 +279,8 @@ void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode,
 // takes the histogram of the file AND the next nine bits of every k-mer -- the digit a file's first grouping pass
 // groups by -- so that no pass has to read the file's k-mers just to size its digit regions (the 8 B/k-mer
 // radix_hist_kernel read).  2^15 LDS counters = 128 KiB, hence ONE 1024-thread workgroup per CU standing for NV = 4
-// workgroups of kmer_hist_kernel (slices of 256 threads, each with the tile range and the block_hist row the partition
-// kernel expects from workgroup blockIdx.x * NV + slice); the next tile's bases are loaded while the current one is counted.
+// workgroups of kmer_hist_kernel (their tile ranges and the block_hist rows the partition kernel expects from workgroups
+// blockIdx.x * NV ..), taken one after the other; the next tiles' bases are loaded while the current ones are counted.
 // k <= 64 (k > 32: kp_thread_buckets_wide), 2k >= 17, no count-suffix, 64 buckets.
 constexpr int KH_NV = 4, KH_FINE_BITS = 15;
 __global__ __launch_bounds__(KP_BLOCK * KH_NV)
@@ -290,56 +290,69 @@ void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
   extern __shared__ __attribute__((aligned(16))) u32 kh_fine[];      // [1 << KH_FINE_BITS]
   __shared__ u32 s_codes[2][KH_NV][KP_WORDS];
   __shared__ u32 s_inval[2][KH_NV][KP_WORDS];
-  __shared__ u32 s_hist[KH_NV][64];
+  __shared__ u32 s_prev[64];
   const u32 tid = threadIdx.x, v = tid >> 8, t = tid & 255u;
   const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
   for (u32 i = tid; i < (1u << KH_FINE_BITS); i += KP_BLOCK * KH_NV) kh_fine[i] = 0;
-  if (tid < KH_NV * 64) (&s_hist[0][0])[tid] = 0;
+  if (tid < 64) s_prev[tid] = 0;
 
-  const u64 per = (num_tiles + vgrid - 1) / vgrid;                   // kp_tile_range of the virtual workgroup
-  const u64 vwg = (u64)blockIdx.x * KH_NV + v;
-  u64 t_begin = vwg * per, t_end = t_begin + per;
-  if (t_begin > num_tiles) t_begin = num_tiles;
-  if (t_end > num_tiles) t_end = num_tiles;
-  if (vwg >= vgrid) t_begin = t_end = num_tiles;
+  // The workgroup takes its KH_NV virtual workgroups ONE AFTER THE OTHER, all 1024 threads on one of them (slice v: every
+  // KH_NV-th tile of its range): a k-mer costs ONE LDS atomic -- the fifteen-bit counter -- and the per-file counts of a
+  // virtual workgroup (the row the partition kernel's cursors come from) are the growth of the 64 file sums of that table
+  // while it was counted: 32 reads per thread and virtual workgroup instead of a second, conflict-ridden atomic per k-mer.
+  const u64 per = (num_tiles + vgrid - 1) / vgrid;                   // kp_tile_range of a virtual workgroup
+  for (u32 vv = 0; vv < (u32)KH_NV; vv++) {
+    const u64 vwg = (u64)blockIdx.x * KH_NV + vv;
+    u64 t_begin = vwg * per, t_end = t_begin + per;
+    if (t_begin > num_tiles) t_begin = num_tiles;
+    if (t_end > num_tiles) t_end = num_tiles;
+    if (vwg >= vgrid) t_begin = t_end = num_tiles;
 
-  uint4 cur = make_uint4(0, 0, 0, 0), halo = make_uint4(0, 0, 0, 0);
-  auto fetch = [&](u64 tile) {
-    if (tile >= t_end) return;
-    cur = load16(bases, tile * KP_TILE + (u64)t * 16, n, aligned);
-    if (t < 4) halo = load16(bases, tile * KP_TILE + (u64)KP_TILE + (u64)t * 16, n, aligned);
-  };
-  fetch(t_begin);
-  __syncthreads();
-  for (u64 it = 0; it < per; it++) {
-    const u64 tile = t_begin + it;
-    const u32 buf = (u32)it & 1u;
-    const bool active = tile < t_end;
-    if (active) {
-      u32 c, iv;
-      encode16(cur, c, iv);
-      s_codes[buf][v][t] = c; s_inval[buf][v][t] = iv;
-      if (t < 4) { encode16(halo, c, iv); s_codes[buf][v][KP_BLOCK + t] = c; s_inval[buf][v][KP_BLOCK + t] = iv; }
+    uint4 cur = make_uint4(0, 0, 0, 0), halo = make_uint4(0, 0, 0, 0);
+    auto fetch = [&](u64 tile) {
+      if (tile >= t_end) return;
+      cur = load16(bases, tile * KP_TILE + (u64)t * 16, n, aligned);
+      if (t < 4) halo = load16(bases, tile * KP_TILE + (u64)KP_TILE + (u64)t * 16, n, aligned);
+    };
+    fetch(t_begin + v);
+    __syncthreads();                                                 // (the table is cleared / the sums below are taken)
+    const u64 rounds = (t_end - t_begin + KH_NV - 1) / KH_NV;
+    for (u64 it = 0; it < rounds; it++) {
+      const u64 tile = t_begin + it * KH_NV + v;
+      const u32 buf = (u32)it & 1u;
+      const bool active = tile < t_end;
+      if (active) {
+        u32 c, iv;
+        encode16(cur, c, iv);
+        s_codes[buf][v][t] = c; s_inval[buf][v][t] = iv;
+        if (t < 4) { encode16(halo, c, iv); s_codes[buf][v][KP_BLOCK + t] = c; s_inval[buf][v][KP_BLOCK + t] = iv; }
+      }
+      __syncthreads();
+      fetch(tile + KH_NV);                                           // in flight behind the counting below
+      if (active) {
+        u32 bk[KP_ITEMS];
+        const u32 vmask = (k > 32) ? kp_thread_buckets_wide(s_codes[buf][v], s_inval[buf][v], k, mode, KH_FINE_BITS, bk, t)
+                                   : kp_thread_buckets(s_codes[buf][v], s_inval[buf][v], k, mode, KH_FINE_BITS, bk, t);
+#pragma unroll
+        for (int j = 0; j < KP_ITEMS; j++)
+          if ((vmask >> j) & 1u) atomicAdd(&kh_fine[bk[j]], 1u);
+      }
     }
     __syncthreads();
-    fetch(tile + 1);                                                 // in flight behind the counting below
-    if (active) {
-      u32 bk[KP_ITEMS];
-      const u32 vmask = (k > 32) ? kp_thread_buckets_wide(s_codes[buf][v], s_inval[buf][v], k, mode, KH_FINE_BITS, bk, t)
-                                 : kp_thread_buckets(s_codes[buf][v], s_inval[buf][v], k, mode, KH_FINE_BITS, bk, t);
-#pragma unroll
-      for (int j = 0; j < KP_ITEMS; j++)
-        if ((vmask >> j) & 1u) { atomicAdd(&kh_fine[bk[j]], 1u); atomicAdd(&s_hist[v][bk[j] >> (KH_FINE_BITS - 6)], 1u); }
+    {                                                                // 64 files x 16 threads: the file sums so far
+      const u32 f = tid >> 4, l = tid & 15u;
+      u32 sum = 0;
+      for (u32 i = l; i < (1u << (KH_FINE_BITS - 6)); i += 16) sum += kh_fine[(f << (KH_FINE_BITS - 6)) + i];
+      sum += __shfl_xor(sum, 8); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 1);
+      if (l == 0) {
+        const u32 c = sum - s_prev[f];
+        s_prev[f] = sum;
+        if (vwg < vgrid) block_hist[vwg * 64 + f] = c;
+        if (c) atomicAdd(&bucket_counts[f], (u64)c);
+      }
     }
   }
   __syncthreads();
-  if (tid < KH_NV * 64) {
-    const u32 vv = tid >> 6, b = tid & 63u;
-    const u64 w = (u64)blockIdx.x * KH_NV + vv;
-    const u64 c = s_hist[vv][b];
-    if (w < vgrid) block_hist[w * 64 + b] = c;
-    if (c) atomicAdd(&bucket_counts[b], c);
-  }
   for (u32 i = tid; i < (1u << KH_FINE_BITS); i += KP_BLOCK * KH_NV) {
     const u32 c = kh_fine[i];
     if (c) atomicAdd(&fine_hist[i], (u64)c);
