@@ -1085,6 +1085,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   // hand: the file histogram then counts fifteen top bits instead of six (one kernel, same read of the bases) and the
   // 8 B/k-mer digit-histogram read of every file goes away.
   const uint64_t *d_fine = nullptr;
+  const uint64_t *d_fine_hpc = nullptr;                              // `compress`: the dense-rank form of that histogram
   uint32_t *d_fine_rows = nullptr;
   uint32_t local_chunks = 0, local_per_chunk = 0, local_vgrid = 0;
   if (!ext_keys) {
@@ -1106,6 +1107,13 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       }
       HIP_TRY(s, mgc::launch_kmer_histogram_fine(d_bases, n_bases, k, c.mode, d_counts64, fine, part_ws, st, d_fine_rows));
       d_fine = fine;
+    } else if (c.homopoly_compress && n_bases >= (1u << 22) && (2 * k - bucket_bits) % 2 == 0 && 2 * k - bucket_bits >= 20 &&
+               !(getenv("MGC_HPC_DIGITS") && getenv("MGC_HPC_DIGITS")[0] == '0') && mgc::kmer_histogram_hpc_ok(k, bucket_bits, s->sfx_mask)) {
+      // `compress`: k-mers per (bucket, dense-rank digit below it) -- the buckets' high digit goes first as well (MGC_HPC_MSD=0: off)
+      HIP_TRY(s, s->ensure(mgc_session::B_FINE, sizeof(uint64_t) * std::max<size_t>((size_t)1 << 15, mgc::kmer_histogram_hpc_entries(bucket_bits))));
+      uint64_t *fine = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_FINE].p);
+      HIP_TRY(s, mgc::launch_kmer_histogram_hpc(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, fine, part_ws, st));
+      d_fine_hpc = fine;
     } else
     HIP_TRY(s, mgc::launch_kmer_histogram(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, part_ws, st, s->sfx_mask, s->sfx_test));
     tm.end(MGC_STAGE_HISTOGRAM);
@@ -1278,7 +1286,14 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     unsigned char *d_hdrs = nullptr;
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0 || top_bits[b] == 0) continue;
-      if (hpc_digits[b]) { mgc::make_hpc_group_plan(rem_bits - top_bits[b], top_bits[b] / 10, &fplan[b]); continue; }
+      if (hpc_digits[b]) {
+        mgc::make_hpc_group_plan(rem_bits - top_bits[b], top_bits[b] / 10, &fplan[b]);
+        // (sub-bucket numbers made of dense ranks are no key bits: the kernels that put a k-mer's top bits back from its sub-bucket
+        // number -- 32-bit suffixes -- stay with the low digit first)
+        wide_msd[b] = d_fine_hpc && nb <= 256 && !hist_ahead && top_bits[b] == 20 && (kw == 2 || rem_bits - top_bits[b] >= 32) &&
+                      mgc::finish_can_stream(kw, rem_bits - top_bits[b]) && mgc::sort_plan_wide_msd(fplan[b], h_counts[b]);
+        continue;
+      }
       mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fplan[b]);
       if (use_group && fplan[b].mode == 0) fplan[b].mode = 3;
       const uint32_t low = rem_bits - top_bits[b];
@@ -1326,6 +1341,24 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         HIP_TRY(s, mgc::launch_narrow_prepare(d_fine, nb, bits_a, on, d_nhdrs, st));
         HIP_TRY(s, hipMemsetAsync(d_nws, 0, nws_off[nb], st));
         if (d_fine_rows) HIP_TRY(s, mgc::launch_fine_rows_scan(d_fine_rows, local_chunks, nb, bits_a, on, st));
+      }
+    }
+    if (d_fine_hpc && nb <= 256) {
+      uint64_t on[4] = {0, 0, 0, 0};
+      bool any = false;
+      for (uint32_t b = 0; b < nb; b++) {
+        nws_off[b + 1] = nws_off[b];
+        if (!wide_msd[b]) continue;
+        on[b >> 6] |= 1ull << (b & 63u); any = true;
+        nws_off[b + 1] += (mgc::wide_scratch_bytes(h_counts[b], kw) + 255) / 256 * 256;
+      }
+      if (any) {
+        HIP_TRY(s, s->ensure(mgc_session::B_SORT_HDRS, hdr_bytes * nb));
+        HIP_TRY(s, s->ensure(mgc_session::B_NARROW_WS, nws_off[nb]));
+        d_nhdrs = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_SORT_HDRS].p);
+        d_nws = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_NARROW_WS].p);
+        HIP_TRY(s, mgc::launch_hpc_prepare(d_fine_hpc, bucket_bits, on, d_nhdrs, st));
+        HIP_TRY(s, hipMemsetAsync(d_nws, 0, nws_off[nb], st));
       }
     }
     if (hist_ahead && s->stream2) {
@@ -1477,7 +1510,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
                                            d_large + gbase[b], cnt_ptr[b], d_group + gbase[b], stream, (void *)Y, st_huge,
                                            // the list pays off only when a good part of the 2^t grid is empty
                                            (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b])) ? d_nz + gbase[b] : nullptr,
-                                           d_nzcount + b, fst, narrow[b] != 0, tr_a[b], tr_b[b]));
+                                           d_nzcount + b, fst, narrow[b] != 0, tr_a[b], tr_b[b], h_maxsub[b]));
         if (s->profiling) (void)hipEventRecord(fin_ev.back().second, fst);
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way

@@ -21,6 +21,12 @@ size_t   kp_workspace_bytes(uint32_t bucket_bits);
 // sfx_mask / sfx_test: count-suffix= filter, a k-mer is kept iff (its low word & sfx_mask) == sfx_test (0, 0: keep all)
 // the same + the k-mers per (file, next nine bits) into d_fine_hist[2^15] (the first digit of the narrowed grouping passes)
 bool       kmer_histogram_fine_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask);
+// `compress`: the same histogram over dense ranks -- k-mers per (bucket, dense-rank digit of the five bases below the bucket's),
+// d_fine_hist[kmer_histogram_hpc_entries(bucket_bits)], bucket_bits 6 or 8 (mgc_kmer.hip)
+bool       kmer_histogram_hpc_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask);
+uint32_t   kmer_histogram_hpc_entries(uint32_t bucket_bits);
+hipError_t launch_kmer_histogram_hpc(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint32_t bucket_bits,
+                                     uint64_t *d_bucket_counts, uint64_t *d_fine_hist, void *d_ws, hipStream_t st);
 // d_fine_rows (optional): [kmer_histogram_fine_chunks()][2^15] uint32 -- the same counts per CHUNK (the k-mers that
 // *per_chunk consecutive partition workgroups will write): what the chunk-local first grouping pass needs (mgc_sort.hip)
 uint32_t   kmer_histogram_fine_chunks(uint64_t n_bases, uint32_t *per_chunk, uint32_t *vgrid);
@@ -113,7 +119,10 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
 // look-back granules -- neither the 8/16 B per k-mer digit-histogram read nor the boundary search over the grouped keys
 // happens.  d_keys: n keys in, the grouped keys out (same place); d_alt: room for n keys; d_scratch: wide_scratch_bytes(n,
 // key_words), zeroed by the caller; sub-buckets in tr_index(., *tr_a, *tr_b) order.
+// `compress`: the plan's digits are dense ranks (make_hpc_group_plan, two digits); the headers then come from
+// launch_hpc_prepare (the histogram of launch_kmer_histogram_hpc; `on`: one bit per bucket, nb <= 256)
 bool       sort_plan_wide_msd(const SortPlan &plan, uint64_t n);
+hipError_t launch_hpc_prepare(const uint64_t *d_fine_hpc, uint32_t bucket_bits, const uint64_t on[4], void *d_hdrs, hipStream_t st);
 size_t     wide_scratch_bytes(uint64_t n, uint32_t key_words);
 hipError_t launch_group_wide(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan, uint32_t *d_error,
                              uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events /* 4 or null */, void *d_prepared,
@@ -153,7 +162,8 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               const uint32_t *d_nonempty_list, const uint64_t *d_nonempty_count /*the hash kernels visit only these;
                               d_group_distinct must be zero for the others*/, hipStream_t st,
                               bool narrow = false /*d_keys/d_alt: uint32 narrowed keys; the distinct SUFFIXES go back in place*/,
-                              uint32_t tr_a = 0, uint32_t tr_b = 0 /*launch_group_narrow's / launch_group_wide's (whole keys: hash paths only)*/);
+                              uint32_t tr_a = 0, uint32_t tr_b = 0 /*launch_group_narrow's / launch_group_wide's (whole keys: hash paths only)*/,
+                              uint64_t max_sub = 0 /*the file's largest sub-bucket, if known: small files take smaller tables*/);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);
 hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,

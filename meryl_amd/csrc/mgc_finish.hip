@@ -798,8 +798,6 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
       kr[j] = (nn <= max_size && idx < nn) ? keys[aa + idx] : 0ull;
     }
   };
-  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
-  const u64 file_base = (keys[0] >> group_shift) << group_shift;
 
   // visit only the NON-EMPTY sub-buckets (list built by subbucket_max_kernel): a sparse key space (homopolymer-
   // compressed k-mers, small k) leaves most of the 2^t grid empty, and an empty visit still costs a memory round trip
@@ -826,7 +824,7 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
       if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
     } else if (n64 <= max_size) {                      // larger ones: other launches take them
       const u32 n = (u32)n64;
-      const u64 prefix = file_base | (tr_index(g, tr_a, tr_b) << low_bits);
+      const u64 prefix = kcur[0] & ~low_mask;   // (every thread that writes a distinct k-mer holds a key of its own: tid < D <= n)
       u64 kk[KPT];
       u32 hh[KPT];
       u32 pending = 0;
@@ -948,8 +946,6 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
   const u32 tid = threadIdx.x;
   const u64 G = gridDim.x;
   const u128 low_mask = (low_bits >= 128) ? ~(u128)0 : (((u128)1 << low_bits) - 1);
-  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
-  const u128 file_base = (group_shift >= 128) ? (u128)0 : ((KO::v(keys[0]) >> group_shift) << group_shift);
 
   auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
     aa = 0; nn = 0;
@@ -985,7 +981,7 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
       if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
     } else if (n64 <= max_size) {
       const u32 n = (u32)n64;
-      const u128 prefix = file_base | ((u128)tr_index(g, tr_a, tr_b) << low_bits);
+      const u128 prefix = KO::v(kcur[0]) & ~low_mask;   // (every thread that writes a distinct k-mer holds a key of its own: tid < D <= n)
       u64 klo[KPT], khi[KPT];
       u32 hh[KPT];
       u32 pending = 0;
@@ -1130,7 +1126,7 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
 // the first version of this kernel kept 64-bit suffixes in the table (64-bit LDS CAS, 42 KiB, three workgroups per CU);
 // staged suffixes + one 32-bit slot word need 21 KiB.
 template <int BLOCK, int CAP, int SLOTS, bool LIST, bool BINRANK = true>
-__global__ __launch_bounds__(BLOCK, 5)
+__global__ __launch_bounds__(BLOCK, (CAP <= 768 ? 7 : 5))
 void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                           u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
                           const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u32 tr_a = 0, u32 tr_b = 0 /* sub-buckets in tr_index() order (high digit first, launch_group_wide) */) {
@@ -1149,8 +1145,6 @@ void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
   const u32 tid = threadIdx.x;
   const u64 G = gridDim.x;
   const u64 low_mask = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
-  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);          // ng is a power of two
-  const u64 file_base = (group_shift >= 64) ? 0ull : ((keys[0] >> group_shift) << group_shift);
 
   auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
     aa = 0; nn = 0;
@@ -1183,7 +1177,7 @@ void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
       if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
     } else if (n64 <= max_size) {
       const u32 n = (u32)n64;
-      const u64 prefix = file_base | (tr_index(g, tr_a, tr_b) << low_bits);
+      const u64 prefix = kcur[0] & ~low_mask;   // (every thread that writes a distinct k-mer holds a key of its own: tid < D <= n)
       u64 kk[KPT];
       u32 hh[KPT];
       u32 pending = 0;
@@ -1409,8 +1403,7 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
   const u64 a = starts[g], n64 = starts[g + 1] - a;
   if (n64 <= huge_min) return;
   const u64 low_mask = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
-  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);
-  const u64 prefix = (sizeof(KT) == 8) ? ((((u64)keys[0] >> group_shift) << group_shift) | (tr_index(g, tr_a, tr_b) << low_bits)) : 0ull;
+  const u64 prefix = (sizeof(KT) == 8) ? ((u64)keys[a] & ~low_mask) : 0ull;   // whole keys: the sub-bucket's first key tells (read before anything is written)
   constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
   KT *gk = keys + a;
   const u64 rounds = (n64 + (u64)BLOCK * KPT - 1) / ((u64)BLOCK * KPT);
@@ -1593,9 +1586,7 @@ void hash_count128_huge_kernel(K128 *__restrict__ keys, const u64 *__restrict__ 
   const u64 a = starts[g], n64 = starts[g + 1] - a;
   if (n64 <= huge_min) return;
   const u128 low_mask = (low_bits >= 128) ? ~(u128)0 : (((u128)1 << low_bits) - 1);
-  const u32 group_shift = low_bits + (u32)__builtin_ctzll(ng);
-  const u128 file_base = (group_shift >= 128) ? (u128)0 : ((KO::v(keys[0]) >> group_shift) << group_shift);
-  const u128 prefix = file_base | ((u128)tr_index(g, tr_a, tr_b) << low_bits);
+  const u128 prefix = KO::v(keys[a]) & ~low_mask;
   constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
   K128 *gk = keys + a;
   const u64 rounds = (n64 + (u64)BLOCK * KPT - 1) / ((u64)BLOCK * KPT);
@@ -1989,7 +1980,7 @@ hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uin
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
                               bool stream, void *d_alt, hipStream_t st_huge, const uint32_t *d_nz, const uint64_t *d_nz_count,
-                              hipStream_t st, bool narrow, uint32_t tr_a, uint32_t tr_b) {
+                              hipStream_t st, bool narrow, uint32_t tr_a, uint32_t tr_b, uint64_t max_sub) {
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
   if (narrow) {
     // narrowed keys (u32): the 32-bit hash-count kernel and the streaming kernel have u32-storage instantiations; anything
@@ -2120,6 +2111,21 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     static const bool idx64 = !(getenv("MGC_FINISH_HASH64I") && getenv("MGC_FINISH_HASH64I")[0] == '0');
     if (low_bits >= 32 && idx64) {
       static const bool binrank64 = !(getenv("MGC_HASH_BINRANK") && getenv("MGC_HASH_BINRANK")[0] == '0');
+      // a file whose LARGEST sub-bucket holds at most 768 k-mers (`compress`: 59049 sub-buckets per bucket, a few hundred k-mers
+      // each): three keys per thread instead of six -- fewer idle unrolled slots, half the LDS, seven workgroups per CU
+      static const bool small64 = !(getenv("MGC_HASH64_SMALL") && getenv("MGC_HASH64_SMALL")[0] == '0');
+      if (small64 && binrank64 && max_sub && max_sub <= 768 && n_large == 0) {
+        static const uint32_t sgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 7u;
+        const uint32_t sgrid = ng < sgrid_max ? (uint32_t)ng : sgrid_max;
+        if (use_list)
+          hipLaunchKernelGGL((hash_count64i_kernel<256, 768, 1024, true, true>), dim3(sgrid), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys),
+                             reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)768, low_bits, d_cnt_tmp,
+                             reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b);
+        else
+          hipLaunchKernelGGL((hash_count64i_kernel<256, 768, 1024, false, true>), dim3(sgrid), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys),
+                             reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)768, low_bits, d_cnt_tmp,
+                             reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b);
+      } else
       if (use_list) { if (binrank64) MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, true, true>), tr_a, tr_b);
                       else           MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, true, false>), tr_a, tr_b); }
       else          { if (binrank64) MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, false, true>), tr_a, tr_b);

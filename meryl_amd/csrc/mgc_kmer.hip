@@ -117,7 +117,7 @@ __device__ __forceinline__ u32 kp_thread_kmers(const u32 *s_codes, const u32 *s_
 // f's and r's top bits (equal tops give the same bucket whichever is smaller), so neither the k-mer nor its reverse
 // complement is ever assembled -- f's top comes from the first bases of the window start, r's from the reverse
 // complement of the k-mer's LAST bases, all sixteen of which sit in one 32-base chunk that is reversed once.
-// bucket_bits <= 16, k <= 32, 2k >= bucket_bits.
+// bucket_bits <= 18, k <= 32, 2k >= bucket_bits.
 __device__ __forceinline__ u32 kp_thread_buckets(const u32 *s_codes, const u32 *s_inval, u32 k, int mode, u32 bucket_bits,
                                                  u32 (&bk)[KP_ITEMS], const u32 t = threadIdx.x) {
   const u64 A = ((u64)s_codes[t] << 32) | (u64)s_codes[t + 1];      // bases 0..31 of the thread's window
@@ -141,7 +141,7 @@ __device__ __forceinline__ u32 kp_thread_buckets(const u32 *s_codes, const u32 *
 // kp_thread_buckets for k in 33..64 (80-base windows, five staged words): the forward tops still come from the window's first
 // bases; the last m bases of the sixteen starts (bases z0 .. z0+m+14, z0 = k - m >= 25) sit in one 32-base chunk cut from
 // words z0/16 .. -- reversed once, as above.  The valid mask is the k-wide OR of the invalid-base bits, by doubling, on
-// 128 bits.  bucket_bits <= 16.
+// 128 bits.  bucket_bits <= 18.
 __device__ __forceinline__ u32 kp_thread_buckets_wide(const u32 *s_codes, const u32 *s_inval, u32 k, int mode, u32 bucket_bits,
                                                       u32 (&bk)[KP_ITEMS], const u32 t) {
   const u64 A  = ((u64)s_codes[t] << 32) | (u64)s_codes[t + 1];      // bases 0..31 of the thread's window
@@ -283,18 +283,39 @@ void kmer_hist_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode,
 // blockIdx.x * NV ..), taken one after the other; the next tiles' bases are loaded while the current ones are counted.
 // k <= 64 (k > 32: kp_thread_buckets_wide), 2k >= 17, no count-suffix, 64 buckets.
 constexpr int KH_NV = 4, KH_FINE_BITS = 15;
+
+// `compress` (HB > 0): the table is indexed by the DENSE RANK of the k-mer's first HB homopolymer-free bases -- the bucket's
+// bases (bucket_bits / 2 of them) and the five of the digit a bucket's first grouping pass goes by (hpc_digit, mgc_common.hpp:
+// rank = rank of the bucket's bases * 243 + digit).  4 * 3^(HB-1) counters: 8748 (64 buckets) or 26244 (256 buckets).
+__host__ __device__ constexpr u32 hpc_table_size(int hb) { u32 t = 4; for (int i = 1; i < hb; i++) t *= 3; return t; }
+template <int HB>
+__device__ __forceinline__ u32 hpc_dense_rank(u32 x) {               // x: 2 * HB bits, first base most significant
+  u32 prev = (x >> (2 * HB - 2)) & 3u, r = prev;
+#pragma unroll
+  for (int i = 1; i < HB; i++) {
+    const u32 c = (x >> (2 * (HB - 1 - i))) & 3u;
+    r = r * 3u + (c - (c > prev ? 1u : 0u));
+    prev = c;
+  }
+  return r;
+}
+
+template <int HB>
 __global__ __launch_bounds__(KP_BLOCK * KH_NV)
 void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u64 num_tiles, u32 vgrid,
                            u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts, u64 *__restrict__ fine_hist,
                            u32 *__restrict__ fine_rows /* [gridDim.x][2^15]: this workgroup's own counts (chunk-local first pass), or null */) {
-  extern __shared__ __attribute__((aligned(16))) u32 kh_fine[];      // [1 << KH_FINE_BITS]
+  constexpr u32 TABLE = HB ? hpc_table_size(HB) : (1u << KH_FINE_BITS);
+  constexpr u32 NBK = HB ? (1u << (2 * (HB - 5))) : 64u;              // buckets: 64 files, or 2^bucket_bits
+  constexpr u32 IDX_BITS = HB ? 2u * HB : (u32)KH_FINE_BITS;          // top bits of the k-mer that index the table
+  extern __shared__ __attribute__((aligned(16))) u32 kh_fine[];      // [TABLE]
   __shared__ u32 s_codes[2][KH_NV][KP_WORDS];
   __shared__ u32 s_inval[2][KH_NV][KP_WORDS];
-  __shared__ u32 s_prev[64];
+  __shared__ u32 s_prev[NBK];
   const u32 tid = threadIdx.x, v = tid >> 8, t = tid & 255u;
   const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
-  for (u32 i = tid; i < (1u << KH_FINE_BITS); i += KP_BLOCK * KH_NV) kh_fine[i] = 0;
-  if (tid < 64) s_prev[tid] = 0;
+  for (u32 i = tid; i < TABLE; i += KP_BLOCK * KH_NV) kh_fine[i] = 0;
+  if (tid < NBK) s_prev[tid] = 0;
 
   // The workgroup takes its KH_NV virtual workgroups ONE AFTER THE OTHER, all 1024 threads on one of them (slice v: every
   // KH_NV-th tile of its range): a k-mer costs ONE LDS atomic -- the fifteen-bit counter -- and the per-file counts of a
@@ -331,32 +352,45 @@ void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
       fetch(tile + KH_NV);                                           // in flight behind the counting below
       if (active) {
         u32 bk[KP_ITEMS];
-        const u32 vmask = (k > 32) ? kp_thread_buckets_wide(s_codes[buf][v], s_inval[buf][v], k, mode, KH_FINE_BITS, bk, t)
-                                   : kp_thread_buckets(s_codes[buf][v], s_inval[buf][v], k, mode, KH_FINE_BITS, bk, t);
+        const u32 vmask = (k > 32) ? kp_thread_buckets_wide(s_codes[buf][v], s_inval[buf][v], k, mode, IDX_BITS, bk, t)
+                                   : kp_thread_buckets(s_codes[buf][v], s_inval[buf][v], k, mode, IDX_BITS, bk, t);
 #pragma unroll
         for (int j = 0; j < KP_ITEMS; j++)
-          if ((vmask >> j) & 1u) atomicAdd(&kh_fine[bk[j]], 1u);
+          if ((vmask >> j) & 1u) {
+            if constexpr (HB > 0) { const u32 r = hpc_dense_rank<HB>(bk[j]); atomicAdd(&kh_fine[r < TABLE ? r : TABLE - 1u], 1u); }
+            else atomicAdd(&kh_fine[bk[j]], 1u);
+          }
       }
     }
     __syncthreads();
-    {                                                                // 64 files x 16 threads: the file sums so far
-      const u32 f = tid >> 4, l = tid & 15u;
+    {                                                                // NBK buckets x TPB threads: the bucket sums so far
+      constexpr u32 TPB = (u32)(KP_BLOCK * KH_NV) / NBK;             // 16 (64 buckets) or 4 (256)
+      const u32 f = tid / TPB, l = tid % TPB;
       u32 sum = 0;
-      for (u32 i = l; i < (1u << (KH_FINE_BITS - 6)); i += 16) sum += kh_fine[(f << (KH_FINE_BITS - 6)) + i];
-      sum += __shfl_xor(sum, 8); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 1);
+      if constexpr (HB > 0) {
+        constexpr int BB = HB - 5;                                   // bases of a bucket
+        bool ok = true;                                              // (a bucket that repeats a base holds no k-mer)
+#pragma unroll
+        for (int i = 1; i < BB; i++) ok = ok && (((f >> (2 * (BB - 1 - i))) & 3u) != ((f >> (2 * (BB - i))) & 3u));
+        if (ok) { const u32 r0 = hpc_dense_rank<BB>(f) * 243u; for (u32 i = l; i < 243u; i += TPB) sum += kh_fine[r0 + i]; }
+      } else {
+        for (u32 i = l; i < (1u << (KH_FINE_BITS - 6)); i += TPB) sum += kh_fine[(f << (KH_FINE_BITS - 6)) + i];
+      }
+#pragma unroll
+      for (u32 o = TPB / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
       if (l == 0) {
         const u32 c = sum - s_prev[f];
         s_prev[f] = sum;
-        if (vwg < vgrid) block_hist[vwg * 64 + f] = c;
+        if (vwg < vgrid) block_hist[vwg * NBK + f] = c;
         if (c) atomicAdd(&bucket_counts[f], (u64)c);
       }
     }
   }
   __syncthreads();
-  for (u32 i = tid; i < (1u << KH_FINE_BITS); i += KP_BLOCK * KH_NV) {
+  for (u32 i = tid; i < TABLE; i += KP_BLOCK * KH_NV) {
     const u32 c = kh_fine[i];
     if (c) atomicAdd(&fine_hist[i], (u64)c);
-    if (fine_rows) fine_rows[((u64)blockIdx.x << KH_FINE_BITS) + i] = c;
+    if (HB == 0 && fine_rows) fine_rows[((u64)blockIdx.x << KH_FINE_BITS) + i] = c;
   }
 }
 
@@ -611,13 +645,49 @@ hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, 
   const uint32_t vgrid = kp_grid_size(n_bases);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(u32) << KH_FINE_BITS));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kmer_hist_fine_kernel, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) << KH_FINE_BITS, st,
+  hipLaunchKernelGGL(kmer_hist_fine_kernel<0>, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) << KH_FINE_BITS, st,
                      d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
                      reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), d_fine_rows);
+  return hipGetLastError();
+}
+
+// `compress`: the same kernel with the table indexed by dense ranks (kmer_hist_fine_kernel<HB>): bucket_bits 6 or 8,
+// d_fine_hist[kmer_histogram_hpc_entries(bucket_bits)] = k-mers per (bucket, first grouping digit of the bucket)
+bool kmer_histogram_hpc_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask) {
+  const char *e = getenv("MGC_HPC_MSD");                             // read per call: the tests switch it
+  return !(e && e[0] == '0') && (bucket_bits == 6 || bucket_bits == 8) && k <= 64 && 2 * k >= bucket_bits + 10 + 2 && sfx_mask == 0;
+}
+uint32_t kmer_histogram_hpc_entries(uint32_t bucket_bits) { return hpc_table_size((int)(bucket_bits / 2 + 5)); }
+
+hipError_t launch_kmer_histogram_hpc(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint32_t bucket_bits,
+                                     uint64_t *d_bucket_counts, uint64_t *d_fine_hist, void *d_ws, hipStream_t st) {
+  if (bucket_bits != 6 && bucket_bits != 8) return hipErrorInvalidValue;
+  const uint32_t entries = kmer_histogram_hpc_entries(bucket_bits);
+  MGC_CHECK(hipMemsetAsync(d_bucket_counts, 0, sizeof(uint64_t) << bucket_bits, st));
+  MGC_CHECK(hipMemsetAsync(d_fine_hist, 0, sizeof(uint64_t) * entries, st));
+  if (n_bases == 0) return hipSuccess;
+  const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
+  const uint32_t vgrid = kp_grid_size(n_bases);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(u32) * hpc_table_size(8)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(u32) * hpc_table_size(9)));
+    attr_done = true;
+  }
+  if (bucket_bits == 6)
+    hipLaunchKernelGGL(kmer_hist_fine_kernel<8>, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
+                       d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
+                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), (u32 *)nullptr);
+  else
+    hipLaunchKernelGGL(kmer_hist_fine_kernel<9>, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
+                       d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
+                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), (u32 *)nullptr);
   return hipGetLastError();
 }
 

@@ -1388,7 +1388,10 @@ __global__ void narrow_bounds_kernel(const u64 *__restrict__ status, const u32 *
   const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (v > ng) return;
   if (v == ng) { starts[v] = n; return; }
-  const u32 d1 = (u32)(v >> b0), d0 = (u32)v & ((1u << b0) - 1u);
+  u32 d1 = (u32)(v >> b0), d0 = (u32)v & ((1u << b0) - 1u);
+  // dense-rank digits (`compress`) live in ten-bit fields but stay below 364: nothing lies at or beyond a digit >= RS_MAX_RADIX
+  if (d1 >= (u32)RS_MAX_RADIX) { starts[v] = n; return; }
+  if (d0 > (u32)RS_MAX_RADIX) d0 = RS_MAX_RADIX;
   const u32 tiles_before = region_tiles[d0];
   u64 before = 0;
   if (tiles_before) {
@@ -1682,8 +1685,39 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
 bool sort_plan_wide_msd(const SortPlan &plan, uint64_t n) {
   const char *e = getenv("MGC_WIDE_MSD");                   // read per call: the tests switch it
   const bool on = !(e && e[0] == '0');
-  return on && plan.mode == 3 && !plan.hpc && plan.num_passes == 2 && plan.radix_bits == 9 && n > 0 && n < (1ull << 30) &&
+  return on && plan.mode == 3 && plan.num_passes == 2 && plan.radix_bits == 9 && n > 0 && n < (1ull << 30) &&
          plan.pass_shift[1] == plan.pass_shift[0] + plan.pass_bits[0];
+}
+
+// one workgroup per bucket: header cleared, histogram of the bucket's high dense-rank digit from the dense-rank table, its scan
+struct HpcPrep { u32 bucket_bits; u64 on[4]; };
+__global__ __launch_bounds__(RS_MAX_RADIX)
+void hpc_prepare_kernel(const u64 *__restrict__ fine, HpcPrep prep, unsigned char *__restrict__ hdrs, u32 hdr_stride) {
+  __shared__ u64 s_tmp[RS_MAX_RADIX / 64 + 1];
+  const u32 b = blockIdx.x, x = threadIdx.x;
+  if (!((prep.on[b >> 6] >> (b & 63u)) & 1ull)) return;
+  SortHeader *hdr = reinterpret_cast<SortHeader *>(hdrs + (size_t)b * hdr_stride);
+  u32 *w = reinterpret_cast<u32 *>(hdr);
+  for (u32 i = x; i < sizeof(SortHeader) / 4; i += RS_MAX_RADIX) w[i] = 0;
+  const u32 bb = prep.bucket_bits / 2;                       // dense rank of the bucket's bases (a bucket with k-mers repeats none)
+  u32 prev = (b >> (2 * bb - 2)) & 3u, r = prev;
+  for (u32 i = 1; i < bb; i++) { const u32 c = (b >> (2 * (bb - 1 - i))) & 3u; r = r * 3u + (c - (c > prev ? 1u : 0u)); prev = c; }
+  const u64 c = (x < 243u) ? fine[(size_t)r * 243u + x] : 0ull;
+  __syncthreads();                                           // (the header is cleared)
+  u64 total;
+  const u64 e = block_excl_scan<RS_MAX_RADIX, u64>(c, s_tmp, &total);
+  hdr->ghist[0][x] = c;
+  hdr->gbase[0][x] = e;
+}
+
+hipError_t launch_hpc_prepare(const uint64_t *d_fine_hpc, uint32_t bucket_bits, const uint64_t on[4], void *d_hdrs, hipStream_t st) {
+  if (bucket_bits != 6 && bucket_bits != 8) return hipErrorInvalidValue;
+  HpcPrep prep;
+  prep.bucket_bits = bucket_bits;
+  for (int i = 0; i < 4; i++) prep.on[i] = on[i];
+  hipLaunchKernelGGL(hpc_prepare_kernel, dim3(1u << bucket_bits), dim3(RS_MAX_RADIX), 0, st, reinterpret_cast<const u64 *>(d_fine_hpc), prep,
+                     reinterpret_cast<unsigned char *>(d_hdrs), (u32)sort_header_bytes());
+  return hipGetLastError();
 }
 
 static inline uint64_t wide_tile(uint32_t key_words) { return key_words == 2 ? 1024u * 8u : 1024u * 16u; }
@@ -1714,22 +1748,24 @@ static hipError_t group_wide(void *d_keys, void *d_alt, uint64_t n, const SortPl
   u64 *region_start = status_b + (size_t)tiles1_max * (R / 2);
   u32 *region_tiles = reinterpret_cast<u32 *>(region_start + RS_MAX_RADIX + 1);
   // the keys stay whole: digit A (high) at shA, digit B (low) at `low`, both where the plan put them
+  // (`compress`: dense-rank digits in ten-bit fields -- the kernels take the digit with hpc_digit(), the sub-bucket numbers keep the fields)
   const u32 low = plan.pass_shift[0], bB = plan.pass_bits[0], bA = plan.pass_bits[1], shA = low + bB;
+  const u32 maskA = plan_mask(plan, 1), maskB = plan_mask(plan, 0);
   *tr_a = bA; *tr_b = bB;
   const uint64_t resident = (uint64_t)device_cu_count() * GS::WG_PER_CU;
 
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[0], st));
   hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, true>), dim3((uint32_t)std::min(tiles0, resident)), dim3(BLOCK), GS::BYTES, st,
-                     reinterpret_cast<const K *>(d_keys), reinterpret_cast<K *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                     reinterpret_cast<const K *>(d_keys), reinterpret_cast<K *>(d_alt), (u64)n, shA, maskA,
                      &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
-                     GroupExtra{0u, low, (1u << bB) - 1u, &hdr->ghist[1][0]}, (u64 *)nullptr);
+                     GroupExtra{0u, low, maskB, &hdr->ghist[1][0]}, (u64 *)nullptr);
   MGC_CHECK(hipGetLastError());
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[1], st));
   hipLaunchKernelGGL(narrow_mid_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, hdr, (u64)n, (u32)TILE, region_start, region_tiles);
   MGC_CHECK(hipGetLastError());
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2], st));
   hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, false>), dim3((uint32_t)std::min(tiles1_max, resident)), dim3(BLOCK), GS::BYTES, st,
-                     reinterpret_cast<const K *>(d_alt), reinterpret_cast<K *>(d_keys), (u64)n, low, (1u << bB) - 1u,
+                     reinterpret_cast<const K *>(d_alt), reinterpret_cast<K *>(d_keys), (u64)n, low, maskB,
                      &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)tiles0, region_start, region_tiles,
                      GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
   MGC_CHECK(hipGetLastError());

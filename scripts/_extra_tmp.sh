@@ -1,4 +1,4 @@
-O=gpurun_out/r03x
+O=gpurun_out/r03z
 run() { name=$1; shift
   timeout 400 python scripts/kbench.py "$@" > $O/kb_$name.json 2> $O/kb_$name.err; echo "$name exit $?"
   python - $O/kb_$name.json <<'PY'
@@ -9,4 +9,5 @@ except Exception as e: print("  no line", e)
 PY
 }
 run k31c 31 250000 1 20000
-run k51 51
+MGC_HASH64_SMALL=0 run k31c_big 31 250000 1 20000
+run k31 31

@@ -554,6 +554,41 @@ def test_compress_dense_rank_digits_match_oracle(ops, oracle_lib, torch_cuda, k,
         assert per_file > 1152                                   # the digits were in play (one digit above 1152, two above 280 K per file)
 
 
+@pytest.mark.parametrize("msd", ["1", "0"])
+@pytest.mark.parametrize("k,bucket_bases", [(31, None), (31, 200_000), (51, None), (51, 200_000), (21, None), (28, 200_000)])
+def test_compress_high_digit_first(ops, oracle_lib, torch_cuda, monkeypatch, k, bucket_bases, msd):
+    """`compress` with two dense-rank digits per bucket and the HIGH digit first (MGC_HPC_MSD=1, the default): the bucket histogram
+    counts (bucket, digit below it) by the dense rank of the k-mer's first 8 / 9 bases (64 / 256 buckets), the first grouping
+    pass takes its histogram from there and counts the low digit as it goes, the boundaries come from the second pass's
+    granules, the 64-bit / 128-bit hash-count kernels keep every k-mer's own top bits (sub-bucket numbers made of dense ranks
+    are no key bits).  k = 21 (16-bit suffixes) and k = 28 with 256 buckets (28-bit) go to the 32-bit kernel, which rebuilds the
+    top bits from the number: they stay with the low digit first.  MGC_HPC_MSD=0: the low digit first off a histogram read, everywhere.  Against the oracle."""
+    from meryl_amd import capi
+    monkeypatch.setenv("MGC_HPC_MSD", msd)
+    if bucket_bases:                                        # 256 buckets on a small input, and sub-buckets small enough for two digits
+        monkeypatch.setenv("MGC_BUCKET_BASES", str(bucket_bases))
+        monkeypatch.setenv("MGC_FINISH_TARGET", "100")
+    reads, read_len = 3000, 5000
+    bases = oracle_lib.synth_reads(190 + k, reads * read_len // 8, 0, reads, read_len, 3000, 300)
+    stretched = bases.tobytes().decode().replace("AC", "AAAC").replace("GT", "GTTT")
+    want_stream = oracle_lib.compress_stream(stretched)
+    for mode in (0, 1):
+        whi, wlo, wcn, wni = oracle_lib.count_brute(want_stream, k, mode)
+        cfg = capi.configure(k, len(stretched), 2 << 30, mode, homopoly_compress=1)
+        d = torch_cuda.from_numpy(np.frombuffer(stretched.encode(), dtype=np.uint8).copy()).cuda()
+        with ops.Session(cfg) as s:
+            s.set_profiling(True)
+            s.push_bases_device(d)
+            s.count()
+            klo, khi, counts, _ = s.result_wide()
+            info = s.info()
+            prof = s.profile()
+        assert info.n_instances == wni
+        assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+        below = 2 * k - (8 if bucket_bases else 6) - 20             # key bits below the two digits
+        assert (prof.wide_msd_files > 0) == (msd == "1" and (k > 32 or below >= 32)), prof.wide_msd_files
+
+
 @pytest.mark.parametrize("k", [3, 8, 13, 14])
 def test_simple_mode_geometry(ops, oracle_lib, torch_cuda, tmp_path, k):
     # small k: the reference picks countSimple (merylOp-count.C:368-372) whose database geometry is
