@@ -20,7 +20,7 @@ for set in \
   timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o p$i -- $CMD > $OUT/p$i.log 2>&1
   echo "pmc set $i ($set) exit $?"
 done
-OUT=$OUT python - <<'PY'
+OUT=$OUT CMD_DESC="$CMD" python - <<'PY'
 import csv, glob, collections, json, os
 OUT = os.environ["OUT"]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -44,7 +44,7 @@ for k, d in sorted(agg.items()):
     if m.get("SQ_LDS_IDX_ACTIVE"):
         m["lds_bank_conflict_frac"] = m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"]
     res[k] = m
-json.dump({"source": "scripts/gpu_pmc_kernels.sh: rocprofv3 --kernel-trace --pmc <SQ sets> over one step of the 10 Gbp bench; per-launch means",
+json.dump({"source": "scripts/gpu_pmc_kernels.sh: rocprofv3 --kernel-trace --pmc <SQ sets>, each set in its own run of `%s`; per-launch means" % os.environ.get("CMD_DESC", "python bench.py --steps 1 --warmup 0 (the 10 Gbp step)"),
            "kernels": res}, open(OUT + "/pmc_sq.json", "w"), indent=1)
 with open(OUT + "/pmc_sq.txt", "w") as out:
     for k, m in res.items():
