@@ -1857,9 +1857,12 @@ constexpr int HUGE_CAP32 = 4096, HUGE_SLOTS32 = 8192;            // 32-bit suffi
 constexpr int HUGE_CAP64 = 2048, HUGE_SLOTS64 = 4096;            // 64-bit suffixes: 72 KiB
 constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count kernel: 2048 slots, 26 KiB of LDS, 6 workgroups per CU
 
-// 16-byte keys: capacity of the hash-count kernel's instantiation in use (hash_count128_kernel: 768 / 1536)
+// 16-byte keys: capacity of the hash-count kernel (hash_count128_kernel).  1536-key tables with sub-buckets of up to 1152 k-mers;
+// a file whose largest sub-bucket holds at most 768 takes the 768-key instantiation (launch_finish_file).  MGC_HASH128_CAP=768:
+// every file through the small tables, sub-buckets of up to 640 (measured at k = 51, 5 Gbp, with the bin-rank in: 138.3 ms against
+// 128.3 -- fewer, larger sub-buckets amortise the per-sub-bucket barriers and scans now that the rank no longer grows with D^2).
 static uint64_t fin_cap_hash128() {
-  static const uint64_t cap = (getenv("MGC_HASH128_CAP") && atoi(getenv("MGC_HASH128_CAP")) == 1536) ? 1536 : 768;
+  static const uint64_t cap = (getenv("MGC_HASH128_CAP") && atoi(getenv("MGC_HASH128_CAP")) == 768) ? 768 : 1536;
   return cap;
 }
 
@@ -2045,16 +2048,19 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     static const uint32_t wgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 4u;     // four workgroups per CU
     const uint32_t wgrid = ng < wgrid_max ? (uint32_t)ng : wgrid_max;
     const u64 cap128 = fin_cap_hash128();
+    static const bool small128 = !(getenv("MGC_HASH128_SMALL") && getenv("MGC_HASH128_SMALL")[0] == '0');
+    const bool small = cap128 == 768 || (small128 && max_sub && max_sub <= 768 && n_large == 0);
+    const u64 msize = small ? (u64)768 : cap128;
     static const bool binrank128 = !(getenv("MGC_HASH_BINRANK") && getenv("MGC_HASH_BINRANK")[0] == '0');
 #define MGC_H128_LAUNCH_(CAP_, SLOTS_, WIDE_, GRID_, BIN_)                                                                               \
     hipLaunchKernelGGL((hash_count128_kernel<256, CAP_, SLOTS_, WIDE_, BIN_>), dim3(GRID_), dim3(256), 0, st,                            \
-                       reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, cap128, low_bits,             \
+                       reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, msize, low_bits,              \
                        d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b)
 #define MGC_H128_LAUNCH(CAP_, SLOTS_, WIDE_, GRID_) do { if (binrank128) MGC_H128_LAUNCH_(CAP_, SLOTS_, WIDE_, GRID_, true);              \
                                                          else            MGC_H128_LAUNCH_(CAP_, SLOTS_, WIDE_, GRID_, false); } while (0)
-    if (cap128 == 768) {
-      // sub-buckets of 320..640 k-mers (finish_target_for): three keys per thread instead of six -- fewer idle unrolled slots,
-      // half the registers and LDS, twice the workgroups per CU
+    if (small) {
+      // no sub-bucket above 768 k-mers: three keys per thread instead of six -- fewer idle unrolled slots, half the registers and
+      // LDS, six workgroups per CU instead of four
       static const uint32_t sgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * (uint32_t)H128_SMALL_WAVES;
       const uint32_t sgrid = ng < sgrid_max ? (uint32_t)ng : sgrid_max;
       if (low_bits > 64) MGC_H128_LAUNCH(768, 1024, true, sgrid); else MGC_H128_LAUNCH(768, 1024, false, sgrid);
@@ -2189,8 +2195,8 @@ uint64_t finish_capacity_for(uint32_t key_words) { return key_words == 2 ? 8192 
 uint64_t finish_target_for(uint32_t key_words) {
   if (const char *t = getenv("MGC_FINISH_TARGET")) return strtoull(t, nullptr, 10);
   const char *h = getenv("MGC_FINISH_HASH");
-  // (1536-key tables, measured at k=51: 768 beats 512 and 1152; 768-key tables: 640 keeps the Poisson tail inside)
-  if (key_words == 2) return (h && h[0] == '0') ? 1024 : (fin_cap_hash128() == 768 ? 640 : 768);
+  // (768-key tables: 640 keeps the Poisson tail inside)
+  if (key_words == 2) return (h && h[0] == '0') ? 1024 : (fin_cap_hash128() == 768 ? 640 : (FIN_CAP_HASH * 3) / 4);
   return (h && h[0] == '0') ? FIN_CAP_SMALL / 2 : (FIN_CAP_HASH * 3) / 4;
 }
 
