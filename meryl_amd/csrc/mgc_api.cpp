@@ -1250,7 +1250,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     HIP_TRY(s, s->ensure(mgc_session::B_SUBSTART, sizeof(uint64_t) * (sbase[nb] + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_GROUPS, sizeof(uint64_t) * (ng_total + 2 + 2 * (uint64_t)nb)));
     HIP_TRY(s, s->ensure(mgc_session::B_LARGE, sizeof(uint32_t) * (ng_total + 1)));
-    HIP_TRY(s, s->ensure(mgc_session::B_NONEMPTY, sizeof(uint32_t) * (ng_total + 1) + sizeof(uint64_t) * ((uint64_t)nb + 1)));
+    HIP_TRY(s, s->ensure(mgc_session::B_NONEMPTY, sizeof(uint32_t) * (ng_total + 1) + sizeof(uint64_t) * 2 * ((uint64_t)nb + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_GSCAN, mgc::finish_scan_scratch_bytes(ng_total + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_RLE_WS, mgc::rle_workspace_bytes(max_bucket)));
     uint64_t *d_substart = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_SUBSTART].p);
@@ -1259,8 +1259,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     uint64_t *d_nlarge   = d_maxsub + nb;
     uint32_t *d_large    = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_LARGE].p);
     uint64_t *d_nzcount  = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_NONEMPTY].p);           // [nb]
-    uint32_t *d_nz       = reinterpret_cast<uint32_t *>(d_nzcount + nb + 1);                          // [ng_total]
-    HIP_TRY(s, hipMemsetAsync(d_nzcount, 0, sizeof(uint64_t) * nb, st));
+    uint64_t *d_retrycnt = d_nzcount + nb + 1;                                                        // [nb] hash_count_multi_kernel's retry lists
+    uint32_t *d_nz       = reinterpret_cast<uint32_t *>(d_retrycnt + nb + 1);                         // [ng_total] (a dense file's part: its retry list)
+    HIP_TRY(s, hipMemsetAsync(d_nzcount, 0, sizeof(uint64_t) * 2 * ((size_t)nb + 1), st));
     HIP_TRY(s, hipMemsetAsync(d_group, 0, sizeof(uint64_t) * (ng_total + 1), st));                     // empty sub-buckets stay 0
     void     *rle_ws     = s->buf[mgc_session::B_RLE_WS].p;
     HIP_TRY(s, hipMemsetAsync(d_maxsub, 0, sizeof(uint64_t) * 2 * nb, st));
@@ -1444,6 +1445,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     // streaming kernels stay on stream2: they share the buffer Y.
     static const bool alt_files = fork_huge && !(getenv("MGC_FINISH_ALT") && getenv("MGC_FINISH_ALT")[0] == '0');
     bool forked = false, need_join = false;          // forked: stream2 is ordered after everything st holds that it must see
+    // tests run the dense-grid instantiations of the count kernels on small inputs (whose 2^t grids are mostly empty)
+    const bool finish_nolist = getenv("MGC_FINISH_NOLIST") && getenv("MGC_FINISH_NOLIST")[0] == '1';
     std::vector<std::pair<hipEvent_t, hipEvent_t>> fin_ev;       // profiling: around every file's count-kernel launch
     uint64_t fin_keys = 0, fin_in_bytes = 0;
     bool fin_narrow = false;
@@ -1509,8 +1512,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_nlarge[b],
                                            d_large + gbase[b], cnt_ptr[b], d_group + gbase[b], stream, (void *)Y, st_huge,
                                            // the list pays off only when a good part of the 2^t grid is empty
-                                           (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b])) ? d_nz + gbase[b] : nullptr,
-                                           d_nzcount + b, fst, narrow[b] != 0, tr_a[b], tr_b[b], h_maxsub[b]));
+                                           (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b]) && !finish_nolist) ? d_nz + gbase[b] : nullptr,
+                                           d_nzcount + b, fst, narrow[b] != 0, tr_a[b], tr_b[b], h_maxsub[b], h_counts[b],
+                                           d_nz + gbase[b], d_retrycnt + b));
         if (s->profiling) (void)hipEventRecord(fin_ev.back().second, fst);
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
@@ -1554,7 +1558,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (h_counts[b] == 0) continue;
       void *seg = X + kbytes * h_starts[b];
       // a sparse sub-bucket grid (`compress`: 59049 of 2^20): only the non-empty ones are visited
-      const uint32_t *nzl = (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b])) ? d_nz + gbase[b] : nullptr;
+      const uint32_t *nzl = (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b]) && !finish_nolist) ? d_nz + gbase[b] : nullptr;
       if (narrow[b]) {
         HIP_TRY(s, mgc::launch_compact_groups_narrow(seg, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b],
                                                      gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, rem_bits - top_bits[b],

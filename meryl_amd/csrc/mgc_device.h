@@ -163,7 +163,10 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               d_group_distinct must be zero for the others*/, hipStream_t st,
                               bool narrow = false /*d_keys/d_alt: uint32 narrowed keys; the distinct SUFFIXES go back in place*/,
                               uint32_t tr_a = 0, uint32_t tr_b = 0 /*launch_group_narrow's / launch_group_wide's (whole keys: hash paths only)*/,
-                              uint64_t max_sub = 0 /*the file's largest sub-bucket, if known: small files take smaller tables*/);
+                              uint64_t max_sub = 0 /*the file's largest sub-bucket, if known: small files take smaller tables*/,
+                              uint64_t n_keys = 0 /*keys of the file, if known: the narrowed hash-count takes several sub-buckets per iteration by their average*/,
+                              uint32_t *d_retry_list = nullptr /*[ng] + a zeroed counter: with both, dense narrowed files take hash_count_multi_kernel*/,
+                              uint64_t *d_retry_count = nullptr);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);
 hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,

@@ -624,6 +624,294 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 #undef HC_STAMP
 }
 
+// Hash-count over R PHYSICALLY CONSECUTIVE sub-buckets of a narrowed file per workgroup iteration (round 4; replaces
+// countSingleKmers' sort + run-length passes, merylCountArray.C:323-365, like hash_count_kernel does).  Why: at the judged
+// scale a sub-bucket holds ~516 k-mers of which ~70 are distinct -- 2 keys per thread, per-distinct phases on a quarter
+// of the lanes, and every barrier, scan and loop header of an iteration paid per 516 keys (r03_pmc_sq.json: 39 of 64
+// lanes active, 238 VALU instructions per thread and sub-bucket).  Here
+//   * the R sub-buckets [g0, g0 + R) are one contiguous key range; a key's LOCAL sub-bucket number (position against the
+//     R - 1 inner boundaries) becomes TAGB tag bits above its suffix: composite = tag << low_bits | suffix, so one table,
+//     one compact list and one rank serve all R, and the distinct keys of sub-bucket j are the ranks
+//     [Dpre_j, Dpre_{j+1}) -- they go back in place to start_j + (rank - Dpre_j) exactly where the one-at-a-time
+//     kernel leaves them (compact_groups_narrow_kernel is unchanged);
+//   * a table entry is composite << 11 | count (composite <= 20 bits + 1 so that EMPTY = all ones is no entry, a count
+//     <= CAP < 2^11): the claiming CAS deposits count 1, a duplicate adds 1 to the same word -- no second array, no
+//     16-bit halves sharing a bank, and entry order == key order, so the bin-rank compares whole words;
+//   * the claimers append their SLOT to the compact list (u16); counts are read with the entry afterwards;
+//   * the 256-bin counting sort of the distinct entries is scanned by ONE wave (four bins per lane) while the other
+//     three clear the table and the bin counters of the NEXT iteration (double-buffered by iteration parity): four
+//     workgroup barriers per iteration, none at its top or its end;
+//   * PREFETCH THAT PREFETCHES: the next range's keys and the bounds of the one after it are vector loads issued only
+//     after everything the previous iteration loaded has been consumed into registers.  (The older kernels issue the
+//     next keys first and then touch the current ones: with the loads in conditional blocks the compiler's wait for the
+//     OLD registers is s_waitcnt vmcnt(0), i.e. for the loads it has just issued -- MGC_HASH_DBG showed 6-8 K cycles
+//     of "clear" per iteration that were this wait -- and their bounds come by scalar loads whose lgkmcnt the first
+//     LDS barrier has to drain.)
+// A range whose R sub-buckets together exceed CAP is not counted here: its sub-buckets of 1 .. max_size keys go on the
+// retry list, which the one-at-a-time kernel (its non-empty-list instantiation) walks right after this launch; the
+// > max_size ones belong to the streaming launch as before.
+#ifndef HCM_WAVES
+#define HCM_WAVES 8
+#endif
+template <int BLOCK, int CAP, int SLOTS, int R, bool DBG, bool RF = false>
+__global__ __launch_bounds__(BLOCK, HCM_WAVES)
+void hash_count_multi_kernel(u32 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
+                             u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 *__restrict__ dbg,
+                             u32 tr_a, u32 tr_b, u32 *__restrict__ retry_list, u64 *__restrict__ retry_count) {
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 4 >= CAP * 5 && SLOTS % (4 * BLOCK) == 0 && CAP % BLOCK == 0, "table geometry");
+  static_assert(BLOCK == 256 && R >= 1 && R <= 4, "one bin per thread; at most two tag bits");
+  constexpr int KPT = CAP / BLOCK;
+  constexpr u32 TAGB = R == 1 ? 0u : (R == 2 ? 1u : 2u);
+  constexpr u32 CNTB = 11u, CNT_MASK = (1u << CNTB) - 1u;
+  static_assert(CAP <= (int)CNT_MASK, "a count must fit its field");
+  constexpr u32 EMPTY = 0xFFFFFFFFu;
+  __shared__ __attribute__((aligned(16))) u32 tk[SLOTS];            // composite << 11 | count
+  __shared__ __attribute__((aligned(16))) u32 srt[CAP];             // the distinct entries in bin order
+  __shared__ unsigned short lst[CAP];                               // slots of the claimed entries, in claim order
+  __shared__ __attribute__((aligned(16))) u32 s_bin[2][BLOCK + 4];  // bin counts -> starts; [BLOCK] = D
+  __shared__ u32 s_nd;
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u64 G = gridDim.x;
+  const u32 low_mask = (u32)((1ull << low_bits) - 1ull);
+  const u32 bshift = low_bits + TAGB - 8u;                          // the launcher guarantees 8 <= low_bits + TAGB <= 20
+  const u64 nsuper = (ng + R - 1) / R;
+
+  // bounds of super-bucket P as ONE vector load: lane l holds starts[g0 + min(l, R)] (clamped to ng); past the end: zeros
+  auto load_bvec = [&](u64 P) -> u64 {
+    if (P >= nsuper) return 0ull;
+    const u64 gl = P * R + (lane < (u32)R ? lane : (u32)R);
+    return starts[gl < ng ? gl : ng];
+  };
+  auto rdlane64 = [&](u64 v, int l) -> u64 {
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+  };
+  // first key a0, relative boundaries b[1..R] (b[R] = all its keys), saturated to 32 bits
+  auto unpack_bounds = [&](u64 bv, u64 &a0, u32 (&b)[R + 1]) {
+    a0 = rdlane64(bv, 0);
+    b[0] = 0;
+#pragma unroll
+    for (int j = 1; j <= R; j++) {
+      const u64 d = rdlane64(bv, j) - a0;
+      b[j] = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)d;
+    }
+  };
+  auto load_keys = [&](u64 a0, u32 n, u32 (&kr)[KPT]) {
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 *src = keys + a0 + (u32)j * BLOCK;     // (uniform base + one lane offset: no 64-bit address per slot)
+      kr[j] = (n <= (u32)CAP && (u32)j * BLOCK + tid < n) ? src[tid] : 0u;
+    }
+  };
+  auto slots_for = [&](u32 n) -> u32 {
+    u32 s = 256;
+    while (s < n + n / 4 && s < (u32)SLOTS) s <<= 1;
+    return s;
+  };
+  // comp[] of a range from its loaded keys and its inner boundaries
+  auto tag_keys = [&](const u32 (&kr)[KPT], const u32 (&b)[R + 1], u32 (&cp)[KPT]) {
+    const u32 b1 = (R >= 2) ? b[1] : 0u, b2 = (R >= 3) ? b[2] : 0u, b3 = (R >= 4) ? b[3] : 0u;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const u32 idx = (u32)j * BLOCK + tid;
+      u32 tag = 0;
+      if (R >= 2) tag += (idx >= b1) ? 1u : 0u;
+      if (R >= 3) tag += (idx >= b2) ? 1u : 0u;
+      if (R >= 4) tag += (idx >= b3) ? 1u : 0u;
+      cp[j] = (kr[j] & low_mask) | (tag << low_bits);
+      asm volatile("" : "+v"(cp[j]) :: "memory");     // consumed HERE: nothing newer is in flight when the wait for it runs
+    }
+  };
+
+  u64 P = blockIdx.x;
+  u64 a0, a0n;
+  u32 bc[R + 1], bn[R + 1];
+  u32 kcur[KPT], comp[KPT];
+  unpack_bounds(load_bvec(P), a0, bc);
+  load_keys(a0, bc[R], kcur);
+  u64 bvec = load_bvec(P + G);
+  tag_keys(kcur, bc, comp);
+  unpack_bounds(bvec, a0n, bn);
+  load_keys(a0n, bn[R], kcur);                         // the second range's keys and the third's bounds: in flight
+  bvec = load_bvec(P + 2 * G);
+  u32 par = 0;
+  u32 cleared = (u32)SLOTS;                             // tk[0, cleared) is EMPTY whenever an insert phase begins
+  {
+    uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
+    for (u32 i = tid; i < (u32)SLOTS / 4; i += BLOCK) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+    s_bin[0][tid] = 0; s_bin[1][tid] = 0;
+    if (tid == 0) s_nd = 0;
+  }
+  __syncthreads();
+
+  u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define HC_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
+  while (P < nsuper) {
+    if (DBG) t0 = __builtin_readcyclecounter();
+    const u64 g0 = P * R;
+    const u32 nsub = (u32)((ng - g0 < (u64)R) ? ng - g0 : (u64)R);
+    const u32 n = bc[R];
+    const bool active = n != 0 && n <= (u32)CAP;
+    const u32 slots = slots_for(n);
+    if (active) {
+      u32 hh[KPT];
+      u32 pending = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) if ((u32)j * BLOCK + tid < n) pending |= 1u << j;
+      const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
+      if (slots > cleared) {                           // (the range the last clear had been sized for was not counted)
+        uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
+        for (u32 i = tid; i < (u32)SLOTS / 4; i += BLOCK) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+        __syncthreads();
+      }
+      HC_STAMP(0);
+#pragma unroll
+      for (int j = 0; j < KPT; j++) hh[j] = (comp[j] * 0x9E3779B1u) >> sshift;
+      // linear probing; one probe step of every still-pending key per round
+      while (pending) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if ((pending >> j) & 1u) {
+            if constexpr (RF) {
+              // read first: most keys are repeats of a suffix the table already holds (coverage) -- they cost one plain LDS
+              // read and ONE atomic (the add); only a key that finds its slot empty issues the compare-and-swap
+              u32 old = tk[hh[j]];
+              bool won = false;
+              if (old == EMPTY) {
+                old = atomicCAS(&tk[hh[j]], EMPTY, (comp[j] << CNTB) | 1u);
+                won = (old == EMPTY);
+                if (won) lst[atomicAdd(&s_nd, 1u)] = (unsigned short)hh[j];
+              }
+              const bool dup = (old >> CNTB) == comp[j];
+              if (dup) atomicAdd(&tk[hh[j]], 1u);
+              if (won || dup) pending &= ~(1u << j);
+              else hh[j] = (hh[j] + 1) & smask;
+            } else {
+            const u32 old = atomicCAS(&tk[hh[j]], EMPTY, (comp[j] << CNTB) | 1u);
+            const bool won = (old == EMPTY);
+            // a suffix nobody has seen: its slot joins the compact list (the compiler aggregates the add per wave: one LDS
+            // atomic by the first active lane, mbcnt offsets for the others)
+            if (won) lst[atomicAdd(&s_nd, 1u)] = (unsigned short)hh[j];
+            const bool dup = (old >> CNTB) == comp[j];
+            if (dup) atomicAdd(&tk[hh[j]], 1u);
+            if (won || dup) pending &= ~(1u << j);
+            else hh[j] = (hh[j] + 1) & smask;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      HC_STAMP(1);
+    }
+
+    // Once per iteration, after its insert phase (the registers of the probe loop are dead, the stores of the previous
+    // iteration long acknowledged -- they count in vmcnt like the loads): the NEXT range's keys, loaded a whole iteration
+    // ago, take the place of this range's in comp[]; only then the keys of the range after it and the bounds of the one after
+    // that are issued.
+    const u32 b1 = (R >= 2) ? bc[1] : 0u, b2 = (R >= 3) ? bc[2] : 0u, b3 = (R >= 4) ? bc[3] : 0u;
+    const u64 a = a0;
+    const u32 nslots = bn[R] <= (u32)CAP ? slots_for(bn[R]) : 256u;  // what the next insert phase needs cleared
+    tag_keys(kcur, bn, comp);
+    a0 = a0n;
+#pragma unroll
+    for (int j = 0; j <= R; j++) bc[j] = bn[j];
+    unpack_bounds(bvec, a0n, bn);
+    load_keys(a0n, bn[R], kcur);
+    bvec = load_bvec(P + 3 * G);
+    HC_STAMP(6);
+
+    if (active) {
+      // the distinct entries into 256 bins by their top eight bits (tag first): one returning LDS atomic each
+      const u32 D = s_nd;
+      const bool big = D > (u32)BLOCK;                 // more distinct suffixes than threads (low-coverage input): staged through LDS
+      u32 ent = 0, li = 0;
+      if (!big) {
+        if (tid < D) { ent = tk[lst[tid]]; li = atomicAdd(&s_bin[par][ent >> (CNTB + bshift)], 1u); }
+      } else {
+        for (u32 i = tid; i < D; i += BLOCK) {
+          const u32 e = tk[lst[i]];
+          srt[i] = e;
+          lst[i] = (unsigned short)atomicAdd(&s_bin[par][e >> (CNTB + bshift)], 1u);
+        }
+      }
+      __syncthreads();
+      HC_STAMP(2);
+      if (tid < 64) {                                  // one wave scans the 256 bin counts: four per lane
+        uint4 c = reinterpret_cast<uint4 *>(s_bin[par])[tid];
+        const u32 s4 = c.x + c.y + c.z + c.w;
+        u32 x = s4;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+        const u32 e0 = x - s4;
+        reinterpret_cast<uint4 *>(s_bin[par])[tid] = make_uint4(e0, e0 + c.x, e0 + c.x + c.y, e0 + c.x + c.y + c.z);
+        if (tid == 63) s_bin[par][BLOCK] = x;
+      } else {
+        // ... the other three clear what the NEXT insert phase uses (tk, lst and s_nd are dead by now; with more distinct
+        // suffixes than threads the table takes the sorted entries first and is cleared at the end)
+        uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
+        if (!big) for (u32 i = tid - 64; i < nslots / 4; i += BLOCK - 64) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+        for (u32 i = tid - 64; i < BLOCK; i += BLOCK - 64) s_bin[par ^ 1u][i] = 0;
+        if (tid == 64) s_nd = 0;
+      }
+      cleared = nslots;
+      __syncthreads();
+      if (!big) {
+        if (tid < D) srt[s_bin[par][ent >> (CNTB + bshift)] + li] = ent;
+      } else {
+        for (u32 i = tid; i < D; i += BLOCK) { const u32 e = srt[i]; tk[s_bin[par][e >> (CNTB + bshift)] + lst[i]] = e; }
+      }
+      __syncthreads();
+      HC_STAMP(3);
+
+      // rank inside the bin, then back in place: sub-bucket j's distinct suffixes ascending from its own start
+      const u32 *sb = s_bin[par];
+      const u32 *sorted = big ? tk : srt;
+      u32 *kout = keys + a;
+      u32 *cout = cnt_tmp + a;
+      for (u32 p = tid; p < D; p += BLOCK) {
+        const u32 e = sorted[p];
+        const u32 b = e >> (CNTB + bshift), lo = sb[b], hi = sb[b + 1];
+        u32 r = lo;
+        for (u32 q = lo; q < hi; q++) r += (sorted[q] < e) ? 1u : 0u;
+        const u32 tag = (R >= 2) ? (e >> (CNTB + low_bits)) : 0u;
+        u32 dest = r;
+        if (R >= 2) {
+          const u32 sb_base = (tag == 0) ? 0u : ((tag == 1) ? b1 : ((tag == 2) ? b2 : b3));
+          dest = sb_base + (r - sb[tag << (8u - TAGB)]);
+        }
+        kout[dest] = (e >> CNTB) & low_mask;
+        cout[dest] = e & CNT_MASK;
+      }
+      if (tid < nsub) {
+        const u32 dlo = sb[tid << (8u - TAGB)];
+        const u32 dhi = (tid + 1 == (1u << TAGB)) ? D : sb[(tid + 1) << (8u - TAGB)];
+        group_distinct[tr_index(g0 + tid, tr_a, tr_b)] = dhi - dlo;
+      }
+      if (big) {                                       // the table held the sorted entries: cleared now, behind two more barriers
+        __syncthreads();
+        uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
+        for (u32 i = tid; i < nslots / 4; i += BLOCK) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+        __syncthreads();
+      }
+      par ^= 1u;                                       // (srt and this parity's bin table are next written three barriers on)
+      HC_STAMP(4);
+    } else if (tid < nsub) {
+      // empty range: zeros; a range above the table: its sub-buckets one at a time, by the kernel that walks the retry list
+      const u32 lo = (tid == 0) ? 0u : ((tid == 1) ? b1 : ((tid == 2) ? b2 : b3));
+      const u32 hi = (tid + 1 == nsub) ? n : ((tid == 0) ? b1 : ((tid == 1) ? b2 : b3));
+      u64 nj = hi - lo;
+      if (n == 0xFFFFFFFFu) nj = starts[g0 + tid + 1] - starts[g0 + tid];   // (saturated: the exact size)
+      if (nj == 0) group_distinct[tr_index(g0 + tid, tr_a, tr_b)] = 0;
+      else if (nj <= max_size) retry_list[atomicAdd((unsigned long long *)retry_count, 1ull)] = (u32)(g0 + tid);
+    }
+    P += G;
+    if (DBG) ph[7]++;
+  }
+  if (DBG && tid == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
+#undef HC_STAMP
+}
+
 // Bitmap-count finish for narrowed files whose sub-bucket suffixes are at most LB (16 or 18) bits wide -- the judged
 // k = 21 workload: 36 bits below the file, 18 of them grouped away.  A suffix that short is its own perfect hash:
 //   A. every key sets ITS bit in a 2^LB-bit LDS bitmap (one non-returning LDS atomic, no probing, no table to size);
@@ -1983,7 +2271,8 @@ hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uin
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
                               bool stream, void *d_alt, hipStream_t st_huge, const uint32_t *d_nz, const uint64_t *d_nz_count,
-                              hipStream_t st, bool narrow, uint32_t tr_a, uint32_t tr_b, uint64_t max_sub) {
+                              hipStream_t st, bool narrow, uint32_t tr_a, uint32_t tr_b, uint64_t max_sub, uint64_t n_keys,
+                              uint32_t *d_retry_list, uint64_t *d_retry_count) {
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
   if (narrow) {
     // narrowed keys (u32): the 32-bit hash-count kernel and the streaming kernel have u32-storage instantiations; anything
@@ -2007,7 +2296,48 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
          hipLaunchKernelGGL((bitmap_count_kernel<256, (int)FIN_CAP_HASH, LB_, LIST_>), dim3(ng < bmax ? (uint32_t)ng : bmax), dim3(256), 0, st, \
                        reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, \
                        d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b); } while (0)
-    if (use_bitmap && low_bits <= 16)      { if (d_nz) MGC_BITMAP_LAUNCH(16, true, 12); else MGC_BITMAP_LAUNCH(16, false, 12); }
+    // Round 4: R physically consecutive sub-buckets per iteration with packed key|count entries (hash_count_multi_kernel):
+    // dense grids whose tagged suffix fits 20 bits.  R from the file's average sub-bucket (MGC_HASH_MULTI=0: the kernel above;
+    // 1/2/3/4: that R whatever the average).
+    const char *mue = getenv("MGC_HASH_MULTI");                    // read per call: the tests switch it
+    const int multi_env = (mue && *mue) ? atoi(mue) : -1;
+    int multi_r = 0;
+    if (multi_env != 0 && !d_nz && !use_bitmap && ng >= 4 && d_retry_list && d_retry_count) {
+      const uint64_t avg = n_keys ? n_keys / ng : FIN_CAP_HASH;
+      multi_r = multi_env > 0 ? multi_env : (avg <= 340 ? 4 : (avg <= 690 ? 2 : 1));
+      const uint32_t tagb = multi_r == 1 ? 0u : (multi_r == 2 ? 1u : 2u);
+      if (multi_r > 4 || multi_r == 3 || low_bits + tagb < 8 || low_bits + tagb > 20) multi_r = 0;
+    }
+    if (multi_r) {
+      static const uint32_t mgrid_per_cu = getenv("MGC_HASH_MULTI_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_MULTI_GRID")) : 16u;
+      const uint64_t nsuper = (ng + (uint64_t)multi_r - 1) / (uint64_t)multi_r;
+      u64 *dbgb = hash_dbg_buffer();
+      static const bool multi_rf = getenv("MGC_HASH_RF") && getenv("MGC_HASH_RF")[0] == '1';
+#define MGC_MULTI_LAUNCH(CAP_, SLOTS_, R_, DBG_) do { if (multi_rf) MGC_MULTI_LAUNCH_(CAP_, SLOTS_, R_, DBG_, true); else MGC_MULTI_LAUNCH_(CAP_, SLOTS_, R_, DBG_, false); } while (0)
+#define MGC_MULTI_LAUNCH_(CAP_, SLOTS_, R_, DBG_, RF_)                                                                                         \
+      do { static_assert((CAP_) == (int)FIN_CAP_HASH, "a joint range must not hold a sub-bucket of the streaming launch");           \
+           const uint64_t gmax = 256ull * mgrid_per_cu;                                                                                      \
+           hipLaunchKernelGGL((hash_count_multi_kernel<256, CAP_, SLOTS_, R_, DBG_, RF_>), dim3((uint32_t)(nsuper < gmax ? nsuper : gmax)),   \
+                       dim3(256), 0, st, reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng,              \
+                       (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), dbgb, tr_a, tr_b,             \
+                       d_retry_list, reinterpret_cast<u64 *>(d_retry_count)); } while (0)
+      if (dbgb && multi_r == 2) MGC_MULTI_LAUNCH(1536, 2048, 2, true);
+      else if (multi_r == 1)    MGC_MULTI_LAUNCH(1536, 2048, 1, false);
+      else if (multi_r == 2)    MGC_MULTI_LAUNCH(1536, 2048, 2, false);
+      else                      MGC_MULTI_LAUNCH(1536, 2048, 4, false);
+#undef MGC_MULTI_LAUNCH
+#undef MGC_MULTI_LAUNCH_
+      MGC_CHECK(hipGetLastError());
+      if (dbgb && multi_r == 2) hash_dbg_report(st, ng);
+      // the sub-buckets of ranges above the table (retry list, usually empty): one at a time
+      { const uint32_t rgrid = ng < 256u * 7u ? (uint32_t)ng : 256u * 7u;
+        hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, true, true>), dim3(rgrid), dim3(256), 0, st,
+                           reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
+                           d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_retry_list, reinterpret_cast<const u64 *>(d_retry_count),
+                           (u64 *)nullptr, tr_a, tr_b);
+        MGC_CHECK(hipGetLastError()); }
+    }
+    else if (use_bitmap && low_bits <= 16) { if (d_nz) MGC_BITMAP_LAUNCH(16, true, 12); else MGC_BITMAP_LAUNCH(16, false, 12); }
     else if (use_bitmap && low_bits <= 18) { if (d_nz) MGC_BITMAP_LAUNCH(18, true, 4);  else MGC_BITMAP_LAUNCH(18, false, 4); }
     else if (hash_dbg_buffer()) {                                  // MGC_HASH_DBG=1: the instrumented instantiation (per-phase cycle stamps)
       if (d_nz)

@@ -1294,6 +1294,43 @@ def test_bitmap_count_and_chunk_local_pass(ops, oracle_lib, torch_cuda, monkeypa
         assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
 
 
+@pytest.mark.parametrize("multi", [None, "1", "2", "3", "4", "0"])
+@pytest.mark.parametrize("k,min_top,nolist", [(19, 14, "0"), (21, 18, "1"), (20, 16, "1"), (17, 14, "0"), (15, 12, "0"), (13, 12, "0"), (12, 12, "0")])
+def test_hash_count_multi_subbuckets_per_iteration(ops, oracle_lib, torch_cuda, monkeypatch, k, min_top, nolist, multi):
+    """hash_count_multi_kernel (round 4): R physically consecutive sub-buckets of a narrowed file counted in one workgroup
+    iteration through one table of  tag << low_bits | suffix  keys with the count packed into the entry.  MGC_HASH_MULTI
+    forces R (None: chosen from the file's average sub-bucket; "0": the one-at-a-time kernel), MGC_FINISH_NOLIST the dense-grid
+    launch on a sparse small input.  Suffix widths 18 (k = 19 / 20 / 21: the judged plan's), 14, 12, 8 and 6 bits (below 8
+    tagged bits the launcher falls back to the one-at-a-time kernel); sub-buckets of 1 .. 1536 keys next to ordinary reads --
+    a range holding the 1536-key cluster and anything else exceeds the table and is redone one sub-bucket at a time --
+    1537 and 3000 keys (the streaming launch's), 1 .. all-distinct suffixes, one k-mer 700 times."""
+    from meryl_amd import capi
+    monkeypatch.setenv("MGC_FINISH_MIN_TOP", str(min_top))
+    monkeypatch.setenv("MGC_FINISH_NOLIST", nolist)
+    if multi is not None:
+        monkeypatch.setenv("MGC_HASH_MULTI", multi)
+    rng = np.random.default_rng(k * 100 + min_top)
+    plen = min(k - 1, (6 + min_top + 1) // 2 + 1)          # bases that fix the file and the sub-bucket
+    def cluster(head, n_inst, n_distinct):
+        pre = head + "".join("ACGT"[i] for i in rng.integers(0, 4, plen - len(head)))
+        n_distinct = min(n_distinct, 4 ** (k - plen))
+        tails = ["".join("ACGT"[i] for i in rng.integers(0, 4, k - plen)) for _ in range(n_distinct)]
+        return ".".join(pre + tails[int(i)] for i in rng.integers(0, n_distinct, n_inst)) + "."
+    reads = oracle_lib.synth_reads(k, 400_000, 0, 30_000).tobytes().decode()      # 4.5 Mbases: the fifteen-bit histogram is on
+    stream = (cluster("AAC", 1536, 1536) + cluster("ACA", 1536, 7) + cluster("ATT", 1535, 400) + cluster("AGC", 1537, 300)
+              + cluster("CAT", 3000, 900) + cluster("CCG", 1, 1) + cluster("AAT", 700, 1) + cluster("ACC", 1200, 1200)
+              + cluster("AGG", 64, 64) + cluster("CTA", 1000, 30) + cluster("GGA", 770, 500) + cluster("GGA", 760, 3) + reads)
+    for mode in (1, 0):                                     # forward mode keeps the clusters where they were put
+        cfg = capi.configure(k, len(stream), 1 << 30, mode)
+        cfg.use_simple = 0
+        with ops.Session(cfg) as s:
+            s.push_bases(stream, end_of_sequence=False)
+            s.count()
+            klo, khi, counts, _ = s.result_wide()
+        whi, wlo, wcn, _ = oracle_lib.count_brute(stream, k, mode)
+        assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+
+
 def _dir_bytes(path):
     import os
     return {n: open(os.path.join(path, n), "rb").read() for n in sorted(os.listdir(path))}
