@@ -473,6 +473,10 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
     u32 knext[KPT];
     u64 nna, nnn;
     if (DBG) t0 = __builtin_readcyclecounter();
+    // (everything the previous iteration loaded is consumed BEFORE the next loads are issued: with the loads in conditional
+    // blocks the compiler's wait for the old registers is vmcnt(0) -- issued after the new loads it would wait for THEM)
+#pragma unroll
+    for (int j = 0; j < KPT; j++) asm volatile("" : "+v"(kcur[j]) :: "memory");
     load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
     load_bounds(g2, nna, nnn);
     const u64 g3 = sub_at(p + 3 * G);
@@ -653,7 +657,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 #ifndef HCM_WAVES
 #define HCM_WAVES 8
 #endif
-template <int BLOCK, int CAP, int SLOTS, int R, bool DBG, bool RF = false>
+template <int BLOCK, int CAP, int SLOTS, int R, bool DBG, bool LEAN = true>
 __global__ __launch_bounds__(BLOCK, HCM_WAVES)
 void hash_count_multi_kernel(u32 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                              u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 *__restrict__ dbg,
@@ -696,11 +700,17 @@ void hash_count_multi_kernel(u32 *__restrict__ keys, const u64 *__restrict__ sta
       b[j] = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)d;
     }
   };
+  // (uniform guards, lanes past the end re-read the last key: no per-lane predicate, no 64-bit address per slot)
   auto load_keys = [&](u64 a0, u32 n, u32 (&kr)[KPT]) {
+    const bool fits = n <= (u32)CAP;
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
-      const u32 *src = keys + a0 + (u32)j * BLOCK;     // (uniform base + one lane offset: no 64-bit address per slot)
-      kr[j] = (n <= (u32)CAP && (u32)j * BLOCK + tid < n) ? src[tid] : 0u;
+      kr[j] = 0u;
+      if (fits && (u32)j * BLOCK < n) {
+        const u32 *src = keys + a0 + (u32)j * BLOCK;
+        const u32 last = n - 1u - (u32)j * BLOCK;
+        kr[j] = src[tid < last ? tid : last];
+      }
     }
   };
   auto slots_for = [&](u32 n) -> u32 {
@@ -755,9 +765,6 @@ void hash_count_multi_kernel(u32 *__restrict__ keys, const u64 *__restrict__ sta
     const u32 slots = slots_for(n);
     if (active) {
       u32 hh[KPT];
-      u32 pending = 0;
-#pragma unroll
-      for (int j = 0; j < KPT; j++) if ((u32)j * BLOCK + tid < n) pending |= 1u << j;
       const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
       if (slots > cleared) {                           // (the range the last clear had been sized for was not counted)
         uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
@@ -765,40 +772,74 @@ void hash_count_multi_kernel(u32 *__restrict__ keys, const u64 *__restrict__ sta
         __syncthreads();
       }
       HC_STAMP(0);
+      // The kernel is instruction-issue-bound (VALU and SALU both near one per cycle and CU, r04c_pmc): the insert is
+      // written for few instructions.  First probe of every key straight-line, slot after slot under uniform guards (only
+      // the last slot is partial); a claim is only NOTED (won) -- the claimed slots join the compact list after the loop with
+      // one LDS atomic per wave instead of a returning atomic, a wait and a store inside every slot; the few keys whose
+      // first slot held another suffix go round the generic loop.
+      if constexpr (!LEAN) {                           // (the first form: list appends inside the probe loop; kept for A/B)
+        u32 pending = 0;
 #pragma unroll
-      for (int j = 0; j < KPT; j++) hh[j] = (comp[j] * 0x9E3779B1u) >> sshift;
-      // linear probing; one probe step of every still-pending key per round
-      while (pending) {
+        for (int j = 0; j < KPT; j++) { hh[j] = (comp[j] * 0x9E3779B1u) >> sshift; if ((u32)j * BLOCK + tid < n) pending |= 1u << j; }
+        while (pending) {
 #pragma unroll
-        for (int j = 0; j < KPT; j++) {
-          if ((pending >> j) & 1u) {
-            if constexpr (RF) {
-              // read first: most keys are repeats of a suffix the table already holds (coverage) -- they cost one plain LDS
-              // read and ONE atomic (the add); only a key that finds its slot empty issues the compare-and-swap
-              u32 old = tk[hh[j]];
-              bool won = false;
-              if (old == EMPTY) {
-                old = atomicCAS(&tk[hh[j]], EMPTY, (comp[j] << CNTB) | 1u);
-                won = (old == EMPTY);
-                if (won) lst[atomicAdd(&s_nd, 1u)] = (unsigned short)hh[j];
-              }
+          for (int j = 0; j < KPT; j++) {
+            if ((pending >> j) & 1u) {
+              const u32 old = atomicCAS(&tk[hh[j]], EMPTY, (comp[j] << CNTB) | 1u);
+              const bool w = (old == EMPTY);
+              if (w) lst[atomicAdd(&s_nd, 1u)] = (unsigned short)hh[j];
               const bool dup = (old >> CNTB) == comp[j];
               if (dup) atomicAdd(&tk[hh[j]], 1u);
-              if (won || dup) pending &= ~(1u << j);
+              if (w || dup) pending &= ~(1u << j);
               else hh[j] = (hh[j] + 1) & smask;
-            } else {
-            const u32 old = atomicCAS(&tk[hh[j]], EMPTY, (comp[j] << CNTB) | 1u);
-            const bool won = (old == EMPTY);
-            // a suffix nobody has seen: its slot joins the compact list (the compiler aggregates the add per wave: one LDS
-            // atomic by the first active lane, mbcnt offsets for the others)
-            if (won) lst[atomicAdd(&s_nd, 1u)] = (unsigned short)hh[j];
-            const bool dup = (old >> CNTB) == comp[j];
-            if (dup) atomicAdd(&tk[hh[j]], 1u);
-            if (won || dup) pending &= ~(1u << j);
-            else hh[j] = (hh[j] + 1) & smask;
             }
           }
         }
+      } else {
+      u32 won = 0, pending = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        hh[j] = (comp[j] * 0x9E3779B1u) >> sshift;
+        if ((u32)j * BLOCK < n) {
+          const bool act = (u32)j * BLOCK + tid < n;
+          u32 old = 0xFFFFF7FFu;                       // (neither EMPTY nor any suffix)
+          if (act) old = atomicCAS(&tk[hh[j]], EMPTY, (comp[j] << CNTB) | 1u);
+          const bool w = old == EMPTY, dup = (old >> CNTB) == comp[j];
+          if (dup) atomicAdd(&tk[hh[j]], 1u);
+          won |= w ? (1u << j) : 0u;
+          pending |= (act && !w && !dup) ? (1u << j) : 0u;
+        }
+      }
+      while (pending) {                                // linear probing, one step of every still-pending key per round
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if ((pending >> j) & 1u) {
+            hh[j] = (hh[j] + 1) & smask;
+            const u32 old = atomicCAS(&tk[hh[j]], EMPTY, (comp[j] << CNTB) | 1u);
+            const bool w = old == EMPTY, dup = (old >> CNTB) == comp[j];
+            if (dup) atomicAdd(&tk[hh[j]], 1u);
+            if (w) won |= 1u << j;
+            if (w || dup) pending &= ~(1u << j);
+          }
+        }
+      }
+      {
+        u64 wm[KPT];
+        u32 tot = 0;
+#pragma unroll
+        for (int j = 0; j < KPT; j++) { wm[j] = __ballot((won >> j) & 1u); tot += (u32)__popcll(wm[j]); }
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&s_nd, tot);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if (wm[j]) {
+            if ((won >> j) & 1u)
+              lst[base + __builtin_amdgcn_mbcnt_hi((u32)(wm[j] >> 32), __builtin_amdgcn_mbcnt_lo((u32)wm[j], 0u))] = (unsigned short)hh[j];
+            base += (u32)__popcll(wm[j]);
+          }
+        }
+      }
       }
       __syncthreads();
       HC_STAMP(1);
@@ -971,6 +1012,10 @@ void bitmap_count_kernel(u32 *__restrict__ keys, const u64 *__restrict__ starts,
   while (g < ng) {
     u32 knext[KPT];
     u64 nna, nnn;
+    // (everything the previous iteration loaded is consumed BEFORE the next loads are issued: with the loads in conditional
+    // blocks the compiler's wait for the old registers is vmcnt(0) -- issued after the new loads it would wait for THEM)
+#pragma unroll
+    for (int j = 0; j < KPT; j++) asm volatile("" : "+v"(kcur[j]) :: "memory");
     load_keys(na, nn, knext);                          // in flight while this sub-bucket is counted
     load_bounds(g2, nna, nnn);
     const u64 g3 = sub_at(p + 3 * G);
@@ -1104,6 +1149,10 @@ void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts,
     u64 knext[KPT];
     u64 nna, nnn;
     if (DBG) t0 = __builtin_readcyclecounter();
+    // (everything the previous iteration loaded is consumed BEFORE the next loads are issued: with the loads in conditional
+    // blocks the compiler's wait for the old registers is vmcnt(0) -- issued after the new loads it would wait for THEM)
+#pragma unroll
+    for (int j = 0; j < KPT; j++) asm volatile("" : "+v"(kcur[j]) :: "memory");
     load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
     load_bounds(g2, nna, nnn);
     const u64 g3 = sub_at(p + 3 * G);
@@ -1261,6 +1310,10 @@ void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ start
   while (g < ng) {
     K128 knext[KPT];
     u64 nna, nnn;
+    // (everything the previous iteration loaded is consumed BEFORE the next loads are issued: with the loads in conditional
+    // blocks the compiler's wait for the old registers is vmcnt(0) -- issued after the new loads it would wait for THEM)
+#pragma unroll
+    for (int j = 0; j < KPT; j++) { asm volatile("" : "+v"(kcur[j].lo) :: "memory"); asm volatile("" : "+v"(kcur[j].hi) :: "memory"); }
     load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
     load_bounds(g2, nna, nnn);
     const u64 g3 = sub_at(p + 3 * G);
@@ -1457,6 +1510,10 @@ void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
   while (g < ng) {
     u64 knext[KPT];
     u64 nna, nnn;
+    // (everything the previous iteration loaded is consumed BEFORE the next loads are issued: with the loads in conditional
+    // blocks the compiler's wait for the old registers is vmcnt(0) -- issued after the new loads it would wait for THEM)
+#pragma unroll
+    for (int j = 0; j < KPT; j++) asm volatile("" : "+v"(kcur[j]) :: "memory");
     load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
     load_bounds(g2, nna, nnn);
     const u64 g3 = sub_at(p + 3 * G);
@@ -2306,13 +2363,15 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       const uint64_t avg = n_keys ? n_keys / ng : FIN_CAP_HASH;
       multi_r = multi_env > 0 ? multi_env : (avg <= 340 ? 4 : (avg <= 690 ? 2 : 1));
       const uint32_t tagb = multi_r == 1 ? 0u : (multi_r == 2 ? 1u : 2u);
-      if (multi_r > 4 || multi_r == 3 || low_bits + tagb < 8 || low_bits + tagb > 20) multi_r = 0;
+      if (multi_env < 0 && multi_r > 1 && low_bits + tagb > 20) multi_r = (multi_r == 4 && low_bits + 1 <= 20) ? 2 : 1;   // fewer tag bits
+      const uint32_t tagb2 = multi_r == 1 ? 0u : (multi_r == 2 ? 1u : 2u);
+      if (multi_r > 4 || multi_r == 3 || low_bits + tagb2 < 8 || low_bits + tagb2 > 20) multi_r = 0;
     }
     if (multi_r) {
       static const uint32_t mgrid_per_cu = getenv("MGC_HASH_MULTI_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_MULTI_GRID")) : 16u;
       const uint64_t nsuper = (ng + (uint64_t)multi_r - 1) / (uint64_t)multi_r;
       u64 *dbgb = hash_dbg_buffer();
-      static const bool multi_rf = getenv("MGC_HASH_RF") && getenv("MGC_HASH_RF")[0] == '1';
+      static const bool multi_rf = !(getenv("MGC_HASH_LEAN") && getenv("MGC_HASH_LEAN")[0] == '0');
 #define MGC_MULTI_LAUNCH(CAP_, SLOTS_, R_, DBG_) do { if (multi_rf) MGC_MULTI_LAUNCH_(CAP_, SLOTS_, R_, DBG_, true); else MGC_MULTI_LAUNCH_(CAP_, SLOTS_, R_, DBG_, false); } while (0)
 #define MGC_MULTI_LAUNCH_(CAP_, SLOTS_, R_, DBG_, RF_)                                                                                         \
       do { static_assert((CAP_) == (int)FIN_CAP_HASH, "a joint range must not hold a sub-bucket of the streaming launch");           \

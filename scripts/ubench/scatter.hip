@@ -11,15 +11,24 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-template <typename OUT, int KPT, int MODE>   // MODE 0 scatter aligned, 1 scatter with odd run starts, 2 streaming writes, 3 reads only
+// FLAGS (round 4): 1 = a workgroup takes CONSECUTIVE tiles (the chunk-local pass's order: both halves of a straddled line come
+// from the same CU, one tile apart) instead of tiles blockIdx.x, blockIdx.x + grid, ...; 2 = nontemporal loads of the input
+// stream (it should not push the open output lines out of the XCD's L2); 4 = nontemporal stores.
+template <typename OUT, int KPT, int MODE, int FLAGS = 0>   // MODE 0 scatter aligned, 1 scatter with odd run starts, 2 streaming writes, 3 reads only
 __global__ __launch_bounds__(1024) void pass_kernel(const u64 *__restrict__ in, OUT *__restrict__ out, u64 n, u64 region, u32 skew) {
   constexpr u32 TILE = 1024 * KPT, L = TILE / 512;
   const u64 tiles = n / TILE;
   u64 acc = 0;
-  for (u64 t = blockIdx.x; t < tiles; t += gridDim.x) {
+  const u64 per = (tiles + gridDim.x - 1) / gridDim.x;
+  const u64 t_begin = (FLAGS & 1) ? blockIdx.x * per : blockIdx.x, t_step = (FLAGS & 1) ? 1 : gridDim.x;
+  const u64 t_end = (FLAGS & 1) ? (t_begin + per < tiles ? t_begin + per : tiles) : tiles;
+  for (u64 t = t_begin; t < t_end; t += t_step) {
     u64 k[KPT];
 #pragma unroll
-    for (int j = 0; j < KPT; j++) k[j] = in[t * TILE + (u64)j * 1024 + threadIdx.x];
+    for (int j = 0; j < KPT; j++) {
+      const u64 *p = in + t * TILE + (u64)j * 1024 + threadIdx.x;
+      k[j] = (FLAGS & 2) ? __builtin_nontemporal_load(p) : *p;
+    }
     if (MODE == 3) {
 #pragma unroll
       for (int j = 0; j < KPT; j++) acc ^= k[j];
@@ -32,21 +41,22 @@ __global__ __launch_bounds__(1024) void pass_kernel(const u64 *__restrict__ in, 
       u64 pos;
       if (MODE == 2) pos = t * TILE + i;
       else           pos = (u64)d * region + t * L + w + (MODE == 1 ? (u64)(d * skew) % 29 : 0);
-      out[pos] = (OUT)k[j];
+      if (FLAGS & 4) __builtin_nontemporal_store((OUT)k[j], out + pos);
+      else           out[pos] = (OUT)k[j];
     }
   }
   if (MODE == 3 && acc == 0x1234567) out[0] = (OUT)acc;
 }
 
-template <typename OUT, int KPT, int MODE>
+template <typename OUT, int KPT, int MODE, int FLAGS = 0>
 static void run(const char *what, const u64 *in, void *out, u64 n) {
   constexpr u32 TILE = 1024 * KPT;
   const u64 tiles = n / TILE, region = tiles * (TILE / 512) + 64;
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
-  pass_kernel<OUT, KPT, MODE><<<256, 1024>>>(in, (OUT *)out, n, region, 7);
+  pass_kernel<OUT, KPT, MODE, FLAGS><<<256, 1024>>>(in, (OUT *)out, n, region, 7);
   hipEventRecord(a);
-  for (int r = 0; r < 5; r++) pass_kernel<OUT, KPT, MODE><<<256, 1024>>>(in, (OUT *)out, n, region, 7);
+  for (int r = 0; r < 5; r++) pass_kernel<OUT, KPT, MODE, FLAGS><<<256, 1024>>>(in, (OUT *)out, n, region, 7);
   hipEventRecord(b);
   hipEventSynchronize(b);
   float ms = 0;
@@ -66,6 +76,14 @@ int main() {
   run<u32, 8, 0>("8 B in, 4 B out, 512 runs per tile", in, out, n);
   run<u32, 16, 0>("8 B in, 4 B out, 512 runs per tile", in, out, n);
   run<u32, 16, 1>("8 B in, 4 B out, 512 runs per tile, odd run starts", in, out, n);
+  run<u32, 16, 1, 1>("  odd starts, consecutive tiles per workgroup", in, out, n);
+  run<u32, 16, 1, 2>("  odd starts, nt loads", in, out, n);
+  run<u32, 16, 1, 3>("  odd starts, consecutive tiles + nt loads", in, out, n);
+  run<u32, 16, 1, 4>("  odd starts, nt stores", in, out, n);
+  run<u32, 16, 1, 6>("  odd starts, nt loads + nt stores", in, out, n);
+  run<u32, 16, 1, 7>("  odd starts, consecutive tiles + nt loads + nt stores", in, out, n);
+  run<u32, 16, 0, 2>("  aligned, nt loads", in, out, n);
+  run<u32, 16, 0, 6>("  aligned, nt loads + nt stores", in, out, n);
   run<u32, 32, 0>("8 B in, 4 B out, 512 runs per tile", in, out, n);
   run<u32, 32, 1>("8 B in, 4 B out, 512 runs per tile, odd run starts", in, out, n);
   run<u32, 64, 0>("8 B in, 4 B out, 512 runs per tile", in, out, n);
