@@ -49,24 +49,31 @@ SEED = 2
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(sample_reads, threads, dev_bases=None):
-    """Reference-algorithm port (oracle/oracle_port.cpp: 2 MiB chunks, spin-locked bit-packed prefix buckets with the
-    reference's one/two/three-word add, std::sort, run-length count, 64-file dump) on the host cores, over a bounded
-    sample of the SAME workload: the first `sample_reads` reads of the same 333 Mbp genome with the workload's
-    geometry (wPrefix 18) -- coverage per k-mer is lower than in the whole run, which favours the CPU's distinct/s.
-    Every thread count tried is reported; `value` is the best one."""
+def cpu_baseline(sample_reads, threads, dev_bases=None, whole=False):
+    """The CPU leg: the restatement of the reference's threaded algorithm (oracle/oracle_port.cpp: 2 MiB chunks, spin-locked
+    bit-packed prefix buckets with the reference's one/two/three-word add, std::sort, run-length count, 64-file dump) on
+    this box's host cores.  It is a RESTATEMENT (kind "port"), never reference meryl itself -- the genuine binary cannot be
+    built here (its utility library is an absent submodule).
+    whole=True (the default at N = 1): the WHOLE workload, the very bytes the GPU counted, at ONE thread count -- 16, the
+    best of 16 / 32 / 64 on this kind of box (profiles/r03_cpu_full.json: 146 / 158 / 165 s; the port gets slower with
+    more threads because of the reference's spin-locked buckets); MGC_CPU_THREADS overrides it.
+    whole=False: a bounded sample (the first `sample_reads` reads; lower coverage per k-mer than the whole run, which
+    favours the CPU's distinct/s) at 16 / 32 / 64 threads, best reported."""
     import oracle
     oracle.build()
     if dev_bases is not None:                                         # the very bytes the GPU counted (first reads of rank 0)
-        bases = dev_bases[:sample_reads * (READ_LEN + 1)].cpu().numpy()
+        bases = (dev_bases if whole else dev_bases[:sample_reads * (READ_LEN + 1)]).cpu().numpy()
     else:
         bases = oracle.synth_reads(SEED, GENOME_LEN, 0, sample_reads, READ_LEN, 5000, 100)
+    n_reads = bases.size // (READ_LEN + 1)
     cfg = oracle.configure_counting(K, 10_000_000_000, 64 << 30)      # the workload's geometry (wPrefix 18)
-    # the reference's spin-locked buckets do not scale to every core count: time a few thread counts (all <= the
-    # box's cores) and report every one
     tried = []
     best = None
-    for th in sorted({max(1, min(threads, t)) for t in (16, 32, 64)}):
+    if whole:
+        counts = [max(1, min(threads, int(os.environ.get("MGC_CPU_THREADS", "16"))))]
+    else:
+        counts = sorted({max(1, min(threads, t)) for t in (16, 32, 64)})
+    for th in counts:
         t0 = time.perf_counter()
         _, nd, ni = oracle.digest_threaded(bases, K, cfg["w_prefix"], oracle.CANONICAL, th)
         dt = time.perf_counter() - t0
@@ -76,20 +83,25 @@ def cpu_baseline(sample_reads, threads, dev_bases=None):
     dt, th, nd, ni = best
     out = {
         "value": nd / dt, "unit": "distinct k-mers/s", "cores": th, "kind": "port",
-        "sample": "the first %d x %d bp reads of the workload (%.2f Gbp of the %d bp genome's reads), k=%d, wPrefix=%d; "
-                  "%d instances, %d distinct in %.2f s (%.3g instances/s) on %d threads"
-                  % (sample_reads, READ_LEN, bases.size / 1e9, GENOME_LEN, K, cfg["w_prefix"], ni, nd, dt, ni / dt, th),
+        "kind_note": "a restatement of the reference's threaded count (oracle/oracle_port.cpp), timed here; NOT reference meryl "
+                     "(unbuildable in this tree).  Thread count = the best of 16/32/64 measured on this kind of box "
+                     "(profiles/r03_cpu_full.json): the restated spin-locked buckets get slower beyond 16 threads",
+        "sample": ("the WHOLE workload (%d x %d bp reads, %.2f Gbp), the bytes the GPU counted" % (n_reads, READ_LEN, bases.size / 1e9) if whole else
+                   "the first %d x %d bp reads of the workload (%.2f Gbp of the %d bp genome's reads)" % (n_reads, READ_LEN, bases.size / 1e9, GENOME_LEN))
+                  + ", k=%d, wPrefix=%d; %d instances, %d distinct in %.2f s (%.3g instances/s) on %d threads" % (K, cfg["w_prefix"], ni, nd, dt, ni / dt, th),
+        "whole_workload": bool(whole),
         "instances_per_s": ni / dt, "seconds": dt, "threads_tried": tried, "host_cores": os.cpu_count(),
     }
-    # the WHOLE workload on the port (a 170 s run: scripts/cpu_full.py on the GPU box's host, committed under profiles/)
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cpu_full.json")), reverse=True):
-        try:
-            out["full_workload"] = json.load(open(f))
-            out["full_workload"]["source"] = "profiles/" + os.path.basename(f)
-            break
-        except (OSError, ValueError):
-            continue
+    if not whole:
+        # the WHOLE workload on the port (scripts/cpu_full.py on the GPU box's host, committed under profiles/)
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cpu_full.json")), reverse=True):
+            try:
+                out["full_workload"] = json.load(open(f))
+                out["full_workload"]["source"] = "profiles/" + os.path.basename(f)
+                break
+            except (OSError, ValueError):
+                continue
     return out
 
 
@@ -323,12 +335,12 @@ def roofline_object(prof_acc, ms_per_step, steps, reads, single, where):
         sort_pass["survey_accounting"] = {"bytes_per_key_per_pass": 16, "achieved": eq, "frac": eq / HBM_PEAK_GBS}
     fin = prof_acc.get("finish")
     if fin and fin["launches"]:
-        # The kernel with the largest share of the step: the sub-bucket count (hash_count_kernel).  Two launches run
+        # The kernel with the largest share of the step's KERNEL time: the sub-bucket count (hash_count_multi_kernel since round 4).  Two launches run
         # side by side on alternating streams, so the launches' own durations add up to more than the stage's wall clock.
         achieved = fin["bytes"] / (fin["ms"] / 1e3) / 1e9
-        t, src = pmc_traffic(reads, "hash_count_kernel") if single else (None, None)
+        t, src = pmc_traffic(reads, "hash_count_multi_kernel") if single else (None, None)
         out = {
-            "kernel": "hash_count_kernel (sub-bucket count: 4 B narrowed keys in, distinct 4 B suffixes + 4 B counts out), one launch per file",
+            "kernel": "hash_count_multi_kernel / hash_count_kernel (sub-bucket count: 4 B narrowed keys in, distinct 4 B suffixes + 4 B counts out), one launch per file",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": t, "traffic_source": src or ("none: no committed PMC run of this workload" if single else None),
             "measured": "HIP events around every launch, on the stream it is launched on, " + where,
@@ -360,10 +372,25 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the untimed file -> database run of the CLI")
     ap.add_argument("--no-check", action="store_true", help="skip the untimed result check")
     ap.add_argument("--no-db", action="store_true", help="skip the untimed database write (N > 1: and the node-count comparison)")
+    ap.add_argument("--cpu-sample", action="store_true", help="CPU leg over the bounded sample (three thread counts) instead of the whole workload")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
+    # Wall-clock guard of the UNTIMED legs (check, database, node-count comparison, CLI end to end, CPU leg): a leg that
+    # would start beyond the budget (or could not finish inside it by its estimate) is skipped and named in the line --
+    # a SCALE run at N = 8 must not sink under its own untimed tail.  The timed steps are never skipped.
+    t_begin = time.perf_counter()
+    budget_s = float(os.environ.get("MGC_BENCH_BUDGET_S", "600"))
+    legs_s, skipped = {}, {}
+
+    def leg_ok(name, estimate_s):
+        spent = time.perf_counter() - t_begin
+        if spent + estimate_s > budget_s:
+            skipped[name] = "%.0f s spent + ~%.0f s estimated > budget %.0f s (MGC_BENCH_BUDGET_S)" % (spent, estimate_s, budget_s)
+            return False
+        return True
 
     # Libraries (RCCL prints a version banner) may write to stdout; the contract is ONE JSON line
     # there, so everything before the final print goes to stderr.
@@ -492,6 +519,19 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    # The sharded forms hand their results back as torch tensors while the library holds its own arena: torch's caching
+    # allocator keeps growing for a step or two (a step that makes it hipMalloc another 70 GB lasts 1.3 s instead of
+    # 0.19 -- scripts/fsh_trace.py).  That is the harness's memory settling, not the path: up to three more untimed steps
+    # until the pool stops growing (every rank runs the same number: the decision is reduced over the ranks).
+    if not single:
+        for _ in range(3):
+            before = torch.cuda.memory_reserved()
+            step(False)
+            grew = torch.tensor([1 if torch.cuda.memory_reserved() > before else 0], dtype=torch.int32, device="cuda")
+            if dist is not None:
+                dist.all_reduce(grew, op=dist.ReduceOp.MAX)
+            if not int(grew.item()):
+                break
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -540,8 +580,19 @@ def main():
         line["config"]["note"] = ("one-GPU box: the step is mgc_count_node with %d virtual ranks sharing the device and INCLUDES writing the "
                                   "database; not a scaling number" % world)
 
+    legs_s["setup+input+warmup+timed_steps"] = time.perf_counter() - t_begin
+    # (collective legs: every rank decides alike -- rank 0's clock, broadcast)
+    def leg_ok_all(name, estimate_s):
+        ok = leg_ok(name, estimate_s) if rank == 0 else True
+        if dist is not None:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+            dist.broadcast(flag, src=0)
+            ok = bool(flag.item())
+        return ok
+
     # ---- check (collective at N > 1) ----
-    if not args.no_check:
+    if not args.no_check and leg_ok_all("check", 10 if world == 1 else 30):
+        t_leg = time.perf_counter()
         try:
             if single:
                 keys, cnts = sess.result_device()
@@ -559,10 +610,12 @@ def main():
         except Exception as e:                                                       # noqa: BLE001 -- reported, never fatal for the metric line
             if rank == 0:
                 line["check"] = {"error": str(e)[:300], "ok": False}
+        legs_s["check"] = time.perf_counter() - t_leg
     result.pop("uniq", None); result.pop("cnts", None)
 
     # ---- the database (untimed) ----
-    if not args.no_db:
+    if not args.no_db and leg_ok_all("db_write", 10 if world == 1 else 60):
+        t_leg = time.perf_counter()
         import shutil
         try:
             if single:
@@ -603,7 +656,10 @@ def main():
                 del bases, all_bases
                 torch.cuda.empty_cache()
                 barrier()
-                if rank == 0:
+                if rank == 0 and not leg_ok("db_write.node_count", 90 + 15 * world):
+                    line["db_write"]["node_count"] = {"skipped": skipped["db_write.node_count"]}
+                    shutil.rmtree(name[0], ignore_errors=True)
+                elif rank == 0:
                     try:
                         nb = []
                         for r in range(world):
@@ -642,6 +698,7 @@ def main():
         except Exception as e:                                                       # noqa: BLE001
             if rank == 0:
                 line.setdefault("db_write", {})["error"] = str(e)[:300]
+        legs_s["db_write"] = time.perf_counter() - t_leg
     if node_dir:
         import shutil
         shutil.rmtree(node_dir, ignore_errors=True)
@@ -666,8 +723,38 @@ def main():
         if rf:
             line["roofline"] = rf
         elif node_fallback:
-            line["roofline"] = {"note": "not collected in the one-process fallback (mgc_count_node owns its sessions)", "bound": "hbm",
-                                "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+            # mgc_count_node owns its sessions: the kernels' launch durations are measured in ONE session counting rank 0's
+            # reads on the same device (the same kernels on the same per-GPU workload)
+            try:
+                acc1 = {"pass_ms": 0.0, "pass_launches": 0, "pass_keys": 0, "stage_ms": [0.0] * capi.NUM_STAGES,
+                        "by_pass": [{"ms": 0.0, "launches": 0, "keys": 0, "bytes": 0} for _ in range(2)],
+                        "finish": {"ms": 0.0, "launches": 0, "keys": 0, "bytes": 0}}
+                with count.Session(cfg, dev_index) as s1:
+                    s1.push_bases_device(all_bases[0])
+                    s1.set_profiling(True)
+                    s1.count()
+                    t1 = time.perf_counter()
+                    for _ in range(2):
+                        s1.count()
+                        p1 = s1.profile()
+                        acc1["pass_ms"] += p1.sort_pass_ms_total; acc1["pass_launches"] += p1.sort_pass_launches; acc1["pass_keys"] += p1.sort_pass_keys
+                        for i in range(2):
+                            bp = acc1["by_pass"][i]
+                            bp["ms"] += p1.pass_ms[i]; bp["launches"] += p1.pass_launches[i]; bp["keys"] += p1.pass_keys[i]; bp["bytes"] += p1.pass_bytes[i]
+                        f1 = acc1["finish"]
+                        f1["ms"] += p1.finish_ms; f1["launches"] += p1.finish_launches; f1["keys"] += p1.finish_keys; f1["bytes"] += p1.finish_bytes
+                        for i in range(capi.NUM_STAGES):
+                            acc1["stage_ms"][i] += p1.stage_ms[i]
+                    torch.cuda.synchronize()
+                    ms1 = (time.perf_counter() - t1) / 2 * 1e3
+                rf = roofline_object(acc1, ms1, 2, reads, True, "in one single-session count of rank 0's reads on the same device "
+                                     "(2 steps; the one-process fallback's mgc_count_node owns its sessions)")
+                if rf:
+                    rf["single_session_ms_per_step"] = ms1
+                    line["roofline"] = rf
+            except Exception as e:                                                   # noqa: BLE001
+                line["roofline"] = {"error": str(e)[:300], "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": None, "traffic": None}
 
     # ---- file -> database through the CLI, and the CPU leg (rank 0; the other ranks have let go of their memory) ----
     if sess is not None:
@@ -675,7 +762,8 @@ def main():
     count.release_cached_sessions()
     torch.cuda.empty_cache()
     if rank == 0:
-        if not args.no_e2e and bases is not None:
+        if not args.no_e2e and bases is not None and leg_ok("e2e", 45 if world == 1 else 60 + 20 * world):
+            t_leg = time.perf_counter()
             try:
                 line["e2e"] = e2e_run(bases, min(reads, bases.numel() // (READ_LEN + 1)), threads, gpus=1 if one_device else world)
                 nd = line["e2e"].get("n_distinct")
@@ -684,8 +772,22 @@ def main():
                     line["value_e2e_note"] = "distinct k-mers / wall clock of `meryl count` file -> database (process start to exit), %d reads" % line["e2e"]["reads"]
             except Exception as e:                                                   # noqa: BLE001
                 line["e2e"] = {"error": str(e)[:300]}
-        if not args.no_cpu_baseline and bases is not None:
-            line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_reads, reads, bases.numel() // (READ_LEN + 1)), os.cpu_count() or 1, bases)
+            legs_s["e2e"] = time.perf_counter() - t_leg
+        # the CPU leg: rank 0 at N = 1 only (the harness's rule); the whole workload at the best thread count when the budget
+        # allows its ~150-170 s, else the bounded sample
+        if not args.no_cpu_baseline and bases is not None and world == 1:
+            sample = min(args.cpu_sample_reads, reads, bases.numel() // (READ_LEN + 1))
+            whole = (not args.cpu_sample) and leg_ok("cpu_baseline.whole_workload", 175.0 * reads / DEFAULT_READS)
+            if whole or leg_ok("cpu_baseline.sample", 100.0 * sample / 14_000_000):
+                t_leg = time.perf_counter()
+                line["cpu_baseline"] = cpu_baseline(sample, os.cpu_count() or 1, bases, whole=whole)
+                legs_s["cpu_baseline"] = time.perf_counter() - t_leg
+        elif not args.no_cpu_baseline and world > 1:
+            skipped["cpu_baseline"] = "reported at N = 1 only"
+        legs_s["total"] = time.perf_counter() - t_begin
+        line["legs_s"] = {k: round(v, 3) for k, v in legs_s.items()}
+        line["legs_skipped"] = skipped
+        line["legs_budget_s"] = budget_s
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)

@@ -436,6 +436,7 @@ int run_count(const Globals &g, const Operation &op) {
     exit(1);
   }
   const auto t_written = std::chrono::steady_clock::now();
+  mgc_get_result_info(s, &info);                       // (an out-of-core result knows its distinct k-mers only once the runs are merged)
   if (g.verbosity > 2) {                                                                               // -V: where the wall clock went
     auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double>(b - a).count();
@@ -680,11 +681,14 @@ int main(int argc, char **argv) {
         expect_output_name = false;
       }
       // a bare number is the threshold / constant of the value operation on top ("greater-than 45", "divide 2"; :216-233)
-      else if (is_number && top() >= 0 && ops[top()].kind == OP_VALUE && ops[top()].constant == ~0ull && !file_exists(w)) {
+      // (the reference takes an all-digits word as the number whenever the operation wants one, before it is ever looked at
+      // as a file name -- a database directory called "5" cannot be an input of `less-than`)
+      else if (is_number && top() >= 0 && ops[top()].kind == OP_VALUE && ops[top()].constant == ~0ull) {
         ops[top()].constant = strtoull(w.c_str(), nullptr, 10);
       }
-      else if ((key == "threshold" || key == "t") && eq != std::string::npos && top() >= 0 && ops[top()].kind == OP_VALUE) {   // :291-294
-        ops[top()].constant = strtoull(val.c_str(), nullptr, 10);
+      // threshold= / t= set the THRESHOLD only (setThreshold, :291-294): the arithmetic operations' constant is not touched
+      else if ((key == "threshold" || key == "t") && eq != std::string::npos && top() >= 0 && ops[top()].kind == OP_VALUE) {
+        if (ops[top()].value_op <= MGC_VALUE_NOT_EQUAL_TO) ops[top()].constant = strtoull(val.c_str(), nullptr, 10);
       }
       else if ((key == "distinct" || key == "d") && eq != std::string::npos && top() >= 0 && ops[top()].kind == OP_VALUE && ops[top()].value_op <= MGC_VALUE_NOT_EQUAL_TO) {
         ops[top()].frac_distinct = strtod(val.c_str(), nullptr);                                                    // :278-282

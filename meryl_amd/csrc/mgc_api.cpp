@@ -1703,7 +1703,14 @@ static int finalize_from_runs(mgc_session *s) {
   s->prof.n_batches = s->n_batches;
   if (fits) {
     const void *k = nullptr; const uint32_t *c = nullptr; uint64_t n = 0;
-    const int rc = r->collapse(&k, &c, &n);
+    int rc = r->collapse(&k, &c, &n);
+    if (rc == MGC_ENOMEM) {                                   // (hipMemGetInfo is an estimate: fragmentation) the store is consistent: out of core
+      s->ooc = true;
+      s->n_distinct = 0;
+      s->merge_ms = r->prof.merge_ms;
+      s->prof.merge_ms = s->merge_ms;
+      return MGC_OK;
+    }
     if (rc != MGC_OK) { s->err = r->err; return rc; }
     s->n_distinct = n;
     s->d_unique = const_cast<void *>(k);

@@ -21,8 +21,11 @@
 namespace mgc {
 
 struct BitWin {                                        // MSB-first cursor over the logical words of one stuffedBits object
-  const unsigned char *obj; u64 nsb, wi; u64 w0, w1; u32 off;
-  __device__ __forceinline__ u64 word(u64 i) const { return *reinterpret_cast<const u64 *>(obj + mdb::stuffed_word_offset(nsb, i)); }
+  const unsigned char *obj; u64 nsb, wi, nw; u64 w0, w1; u32 off;
+  // (the window always holds word wi + 1 as well: beyond the object's last logical word it is zero, never a load -- the
+  // last object of a file ends where the upload ends, and a bit length that is a whole number of sub-blocks would
+  // otherwise step over a sub-block header that does not exist)
+  __device__ __forceinline__ u64 word(u64 i) const { return i < nw ? *reinterpret_cast<const u64 *>(obj + mdb::stuffed_word_offset(nsb, i)) : 0ull; }
   __device__ __forceinline__ void seek(u64 pos) { wi = pos >> 6; off = (u32)(pos & 63); w0 = word(wi); w1 = word(wi + 1); }
   __device__ __forceinline__ u64 peek() const { return off ? ((w0 << off) | (w1 >> (64 - off))) : w0; }
   __device__ __forceinline__ void skip(u32 n) {        // n <= 64
@@ -41,7 +44,7 @@ void decode_blocks_kernel(const unsigned char *__restrict__ file, const mdb_raw_
   if (b >= n_blocks) return;
   const mdb_raw_block d = blocks[b];
   BitWin bw;
-  bw.obj = file + d.object_offset; bw.nsb = d.n_sub_blocks;
+  bw.obj = file + d.object_offset; bw.nsb = d.n_sub_blocks; bw.nw = (d.n_bits + 63) >> 6;
   bw.seek(0);
   const u64 nbits = d.n_bits;
   // header (A4)

@@ -115,6 +115,9 @@ int mgc_runs::add(const void *d_keys, const uint32_t *d_counts, uint64_t n, hipS
   RN_TRY(hipMemcpyAsync(r.slice.data(), d_slices.p, sizeof(uint64_t) * (n_slices + 1), hipMemcpyDeviceToHost, st));
   const size_t kb = sizeof(uint64_t) * kw * n, cb = sizeof(uint32_t) * n;
   const bool to_device = dev_budget == ~0ull || prof.device_bytes + kb + cb <= dev_budget;
+#define RN_TRY_RUN(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { free_run(r);                                          \
+    set_err(&err, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__));                                           \
+    return (e__ == hipErrorOutOfMemory) ? MGC_ENOMEM : MGC_EHIP; } } while (0)
   if (to_device) {
     hipError_t e = hipMalloc(&r.keys, kb);
     if (e == hipSuccess) { void *c = nullptr; e = hipMalloc(&c, cb); r.counts = reinterpret_cast<uint32_t *>(c); }
@@ -123,9 +126,9 @@ int mgc_runs::add(const void *d_keys, const uint32_t *d_counts, uint64_t n, hipS
       free_run(r);
       r.keys = nullptr; r.counts = nullptr;
     } else {
-      RN_TRY(hipMemcpyAsync(r.keys, d_keys, kb, hipMemcpyDeviceToDevice, st));
-      RN_TRY(hipMemcpyAsync(r.counts, d_counts, cb, hipMemcpyDeviceToDevice, st));
-      RN_TRY(hipStreamSynchronize(st));
+      RN_TRY_RUN(hipMemcpyAsync(r.keys, d_keys, kb, hipMemcpyDeviceToDevice, st));
+      RN_TRY_RUN(hipMemcpyAsync(r.counts, d_counts, cb, hipMemcpyDeviceToDevice, st));
+      RN_TRY_RUN(hipStreamSynchronize(st));
       prof.device_bytes += kb + cb;
     }
   }
@@ -147,17 +150,18 @@ int mgc_runs::add(const void *d_keys, const uint32_t *d_counts, uint64_t n, hipS
       set_err(&err, "mgc_runs: %.1f GB of pinned host memory for a spilled run: %s", (kb + cb) / 1e9, hipGetErrorString(e));
       return MGC_ENOMEM;
     }
-    RN_TRY(hipEventRecord(ev_src, st));
-    RN_TRY(hipStreamWaitEvent(st_copy, ev_src, 0));
-    RN_TRY(hipMemcpyAsync(r.keys, d_keys, kb, hipMemcpyDeviceToHost, st_copy));
-    RN_TRY(hipMemcpyAsync(r.counts, d_counts, cb, hipMemcpyDeviceToHost, st_copy));
-    RN_TRY(hipStreamSynchronize(st_copy));
-    RN_TRY(hipStreamSynchronize(st));
+    RN_TRY_RUN(hipEventRecord(ev_src, st));
+    RN_TRY_RUN(hipStreamWaitEvent(st_copy, ev_src, 0));
+    RN_TRY_RUN(hipMemcpyAsync(r.keys, d_keys, kb, hipMemcpyDeviceToHost, st_copy));
+    RN_TRY_RUN(hipMemcpyAsync(r.counts, d_counts, cb, hipMemcpyDeviceToHost, st_copy));
+    RN_TRY_RUN(hipStreamSynchronize(st_copy));
+    RN_TRY_RUN(hipStreamSynchronize(st));
     prof.host_bytes += kb + cb;
     prof.n_host_runs++;
     prof.spill_s += now_s() - t0;
     start_prealloc(kb + kb / 16, cb + cb / 16);             // batches are of one size: the next run will be about this large
   }
+#undef RN_TRY_RUN
   if (r.slice[0] != 0 || r.slice[n_slices] != n) { free_run(r); set_err(&err, "mgc_runs_add: keys not ascending / beyond 2k bits"); return MGC_EINVAL; }
   prof.n_runs++;
   prof.n_entries += n;
@@ -327,26 +331,56 @@ int mgc_runs::collapse(const void **keys, const uint32_t **counts, uint64_t *n) 
   for (const Run &r : runs) if (r.on_host) { set_err(&err, "mgc_runs: collapse with runs on the host"); return MGC_ESTATE; }
   const size_t kbytes = sizeof(uint64_t) * kw;
   const double t0 = now_s();
+  uint32_t pair_merges = 0;
   while (runs.size() > 1) {
     std::vector<Run> next;
-    for (size_t i = 0; i < runs.size(); i += 2) {
+    // any failure below leaves the store CONSISTENT: the merged outputs so far, the odd run moved over, and the runs
+    // not yet merged (the inputs already merged are freed and dropped) -- every k-mer is still in exactly one run, so
+    // the caller can deliver out of core instead (finalize_from_runs) or retry
+    size_t i = 0;
+    auto keep_survivors = [&]() {
+      for (size_t j = i; j < runs.size(); j++) if (runs[j].keys) next.push_back(std::move(runs[j]));
+      runs.swap(next);
+      // a merged output has no slice table yet (delivery needs one per run)
+      for (Run &r : runs) {
+        if (r.slice.size() == (size_t)n_slices + 1 || r.on_host || !r.keys) continue;
+        r.slice.assign(n_slices + 1, 0);
+        if (d_slices.ensure(sizeof(uint64_t) * (n_slices + 1)) != hipSuccess) continue;
+        if (mgc::launch_block_offsets_range(r.keys, r.n, kw, 2 * k - slice_bits, 0, n_slices, n_slices, d_slices.as<uint64_t>(), st_mg) != hipSuccess) continue;
+        (void)hipMemcpyAsync(r.slice.data(), d_slices.p, sizeof(uint64_t) * (n_slices + 1), hipMemcpyDeviceToHost, st_mg);
+        (void)hipStreamSynchronize(st_mg);
+      }
+    };
+#define RN_TRY_KEEP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { free_run(o); keep_survivors();                     \
+      set_err(&err, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__));                                         \
+      return (e__ == hipErrorOutOfMemory) ? MGC_ENOMEM : MGC_EHIP; } } while (0)
+    for (; i < runs.size(); i += 2) {
       if (i + 1 >= runs.size()) { next.push_back(std::move(runs[i])); continue; }
       Run &a = runs[i], &b = runs[i + 1];
       Run o;
-      RN_TRY(buf[B_WS].ensure(mgc::merge_workspace_bytes(a.n, b.n)));
-      RN_TRY(mgc::launch_merge_count(a.keys, a.n, b.keys, b.n, kw, 0, buf[B_WS].p, st_mg));
+      RN_TRY_KEEP(buf[B_WS].ensure(mgc::merge_workspace_bytes(a.n, b.n)));
+      RN_TRY_KEEP(mgc::launch_merge_count(a.keys, a.n, b.keys, b.n, kw, 0, buf[B_WS].p, st_mg));
       uint64_t n_out = 0;
-      RN_TRY(mgc::merge_read_total(buf[B_WS].p, &n_out, st_mg));
+      RN_TRY_KEEP(mgc::merge_read_total(buf[B_WS].p, &n_out, st_mg));
       hipError_t e = hipMalloc(&o.keys, std::max<size_t>(kbytes * n_out, 256));
       if (e == hipSuccess) { void *c = nullptr; e = hipMalloc(&c, std::max<size_t>(sizeof(uint32_t) * n_out, 256)); o.counts = reinterpret_cast<uint32_t *>(c); }
-      if (e != hipSuccess) { free_run(o); for (Run &r : next) runs.push_back(std::move(r)); set_err(&err, "mgc_runs: merging the runs in HBM: %s", hipGetErrorString(e)); return MGC_ENOMEM; }
-      RN_TRY(mgc::launch_merge_emit(a.keys, a.counts, a.n, b.keys, b.counts, b.n, kw, 0, buf[B_WS].p, o.keys, o.counts, st_mg));
-      RN_TRY(hipStreamSynchronize(st_mg));
+      // tests: the n-th pair merge of this call "runs out of memory" (the fragmentation case hipMemGetInfo cannot foresee)
+      if (const char *fe = getenv("MGC_RUNS_FAIL_MERGE")) { if (e == hipSuccess && ++pair_merges == (uint32_t)atoi(fe)) e = hipErrorOutOfMemory; }
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        free_run(o);
+        keep_survivors();
+        set_err(&err, "mgc_runs: merging the runs in HBM: %s", hipGetErrorString(e));
+        return MGC_ENOMEM;
+      }
+      RN_TRY_KEEP(mgc::launch_merge_emit(a.keys, a.counts, a.n, b.keys, b.counts, b.n, kw, 0, buf[B_WS].p, o.keys, o.counts, st_mg));
+      RN_TRY_KEEP(hipStreamSynchronize(st_mg));
       sample_hbm();
       o.n = n_out;
       free_run(a); free_run(b);
       next.push_back(std::move(o));
     }
+#undef RN_TRY_KEEP
     runs.swap(next);
   }
   prof.merge_ms += (now_s() - t0) * 1e3;

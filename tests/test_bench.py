@@ -29,9 +29,23 @@ def test_bench_single_gpu_line_is_complete(native_lib):
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and "hash_count" in rf["kernel"]
     assert 0 < rf["kernel_time_share_of_step"] < 1.5 and 0 < rf["sort_pass"]["frac"] < 1
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert cb["whole_workload"] is True and "restatement" in cb["kind_note"] and "WHOLE workload" in cb["sample"]   # every byte the GPU counted
     assert d["db_write"]["data_bytes"] > 0 and d["e2e"]["wall_s"] > 0 and d["value_e2e"] > 0
     assert abs(sum(d["stage_ms_per_step"].values()) - d["ms_per_step"]) < 0.5 * d["ms_per_step"]
+    # the wall-clock guard of the untimed legs: every leg timed, nothing skipped inside the default budget
+    assert d["legs_budget_s"] == 600 and d["legs_skipped"] == {}
+    assert {"check", "db_write", "e2e", "cpu_baseline", "total"} <= set(d["legs_s"]) and d["legs_s"]["total"] < 600
+
+
+def test_bench_budget_guard_skips_legs_and_says_so(native_lib):
+    # a budget the untimed tail cannot meet: the timed steps and the roofline still come, the legs are named as skipped
+    d = _run(["--reads", "2000000", "--steps", "2", "--warmup", "1"], {"MGC_BENCH_BUDGET_S": "1"})
+    assert d["value"] > 0 and 0 < d["roofline"]["frac"] < 1
+    for leg in ("check", "db_write", "e2e", "cpu_baseline.whole_workload", "cpu_baseline.sample"):
+        assert leg in d["legs_skipped"] and "budget" in d["legs_skipped"][leg]
+    assert "check" not in d and "e2e" not in d and "cpu_baseline" not in d
 
 
 def test_bench_two_ranks_line_is_complete(native_lib):
@@ -41,12 +55,12 @@ def test_bench_two_ranks_line_is_complete(native_lib):
              {"MGC_BENCH_ONE_DEVICE": "1"} if one else None)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["check"]["ok"] is True
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
-    assert d["db_write"]["files"] == 129
+    assert "cpu_baseline" not in d and d["legs_skipped"]["cpu_baseline"] == "reported at N = 1 only"
+    assert d["db_write"]["files"] == 129 and d["legs_s"]["total"] > 0
     if one:
         assert "RCCL refused" in d["config"]["transport"] and d["db_write"]["identical_to_single_session"] is True
     else:
         assert "RCCL" in d["config"]["transport"] and d["db_write"]["identical_to_node_count"] is True
         assert d["check"]["keys_ascending_across_rank_boundaries"] is True
         assert 0 < d["roofline"]["frac"] < 1 and "stage_ms_one_profiled_step" in d
-    assert "roofline" in d and d["e2e"]["wall_s"] > 0
+    assert 0 < d["roofline"]["frac"] < 1 and d["e2e"]["wall_s"] > 0       # (the one-process fallback measures it in a single session)

@@ -1427,6 +1427,37 @@ def test_out_of_core_result_larger_than_the_budget_streams_from_host_runs(ops, o
     assert sum(len(v[2]) for v in blocks.values()) == want_info.n_distinct
 
 
+@pytest.mark.parametrize("fail_at", [1, 2, 3])
+def test_collapse_that_runs_out_of_memory_falls_back_to_out_of_core(ops, oracle_lib, torch_cuda, tmp_path, monkeypatch, fail_at):
+    """when the pairwise merge of device-resident runs cannot get memory half way (hipMemGetInfo is only an
+    estimate), the run store must stay consistent -- merged outputs + the runs not merged yet, every k-mer in exactly one
+    run, slice tables complete -- and the count must end as an OUT-OF-CORE result that delivers the single-pass database,
+    instead of failing with null run pointers left behind.  MGC_RUNS_FAIL_MERGE makes the n-th pair merge fail."""
+    from meryl_amd import capi, db
+    monkeypatch.setenv("MGC_OOC_CHUNK", "400000")
+    bases = oracle_lib.synth_reads(43, 200_000, 0, 30_000, 150, 5000, 100)           # 4.5 Mbp
+    raw = bases.tobytes()
+    cfg = capi.configure(21, bases.size, 1 << 30)
+    cfg.use_simple = 0
+    want = str(tmp_path / "want.meryl")
+    with ops.Session(cfg) as s:
+        s.push_bases(raw, end_of_sequence=False)
+        s.count()
+        db.write_database(s, want, host_threads=4)
+        want_info = s.info()
+    got = str(tmp_path / "got.meryl")
+    monkeypatch.setenv("MGC_RUNS_FAIL_MERGE", str(fail_at))
+    with ops.Session(cfg) as s:
+        s.set_batch_bases(700_000)                                 # >= 5 runs, all in HBM: collapse() is taken
+        for i in range(0, len(raw), 333_337):
+            s.push_bases(raw[i:i + 333_337], end_of_sequence=False)
+        s.count()
+        assert s.out_of_core() and s.profile().n_batches >= 5
+        db.write_database(s, got, host_threads=4)
+        assert s.info().n_distinct == want_info.n_distinct
+    assert _dir_bytes(got) == _dir_bytes(want)
+
+
 @pytest.mark.parametrize("k", [21, 51])
 def test_one_sequence_longer_than_a_batch_is_cut_with_overlap(ops, oracle_lib, torch_cuda, k):
     """A chromosome-sized sequence pushed without any breaker, batches far smaller than it: the staged stream is cut at its end
