@@ -272,6 +272,10 @@ def e2e_run(bases, reads, threads, gpus=1):
         if m:
             for name, val in re.findall(r"([a-z+_]+)=([0-9.]+)", m.group(1)):
                 out[name + ("" if name.endswith("bytes") else "_s")] = float(val)
+        if all(x in out for x in ("startup_s", "read+parse+stage_s", "count_s", "encode+write_s")):
+            # what the wall clock holds beyond the CLI's own stamps: exec + dynamic loading before main(), and the
+            # process exit after the last write (the arena and the pinned rings are not torn down: _exit)
+            out["before_main_and_exit_s"] = wall - (out["startup_s"] + out["read+parse+stage_s"] + out["count_s"] + out["encode+write_s"])
         m = re.search(r"(\d+) distinct k-mers", p.stderr)
         if m:
             out["n_distinct"] = int(m.group(1))

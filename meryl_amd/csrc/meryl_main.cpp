@@ -30,6 +30,9 @@
 #include <vector>
 
 namespace {
+// wall-clock stamp of static initialisation (just before main()): what lies before the input is read -- the HIP runtime, the
+// device, the session's streams -- is reported on its own in the -V TIMING line
+const std::chrono::steady_clock::time_point g_t_main = std::chrono::steady_clock::now();
 
 // ---- scaledNumber / scaledUnit / scaledName [meryl-utility, not in tree] ----
 uint64_t scaledNumber(uint64_t n, uint32_t div = 1024) { for (int i = 0; i < 8 && n > 9999; i++) n /= div; return n; }
@@ -442,9 +445,9 @@ int run_count(const Globals &g, const Operation &op) {
       return std::chrono::duration<double>(b - a).count();
     };
     fprintf(stderr, "\nTIMING  read+parse+stage=%.3f s   count=%.3f s   encode+write=%.3f s   (device encode=%.4f s, copy+write=%.3f s, "
-                    "database_bytes=%" PRIu64 ")\n",
+                    "database_bytes=%" PRIu64 ")   startup=%.3f s (main -> session open: HIP runtime, device, streams)\n",
             sec(t_start, t_loaded), sec(t_loaded, t_counted), sec(t_counted, t_written), wprof.encode_ms / 1e3,
-            wprof.copy_write_s, wprof.data_bytes);
+            wprof.copy_write_s, wprof.data_bytes, sec(g_t_main, t_start));
   }
   if (g.verbosity > 2) {
     mgc_profile cp;

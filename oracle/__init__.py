@@ -82,6 +82,10 @@ def lib():
     L.orc_count_threaded_digest.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
                                             ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, u64p, u64p]
     L.orc_count_threaded_digest.restype = ctypes.c_int
+    L.orc_count_threaded_digest_collect.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                                    ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, u64p, u64p, ctypes.c_uint64,
+                                                    ctypes.c_void_p, ctypes.POINTER(u64p), ctypes.POINTER(u64p), ctypes.POINTER(u32p)]
+    L.orc_count_threaded_digest_collect.restype = ctypes.c_int
     L.orc_free.argtypes = [ctypes.c_void_p]
     L.orc_free.restype = None
     L.orc_kmer_to_string.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_char_p]
@@ -201,6 +205,38 @@ def digest_threaded(bases, k, w_prefix, mode=CANONICAL, threads=0):
     if rc != 0:
         raise RuntimeError("orc_count_threaded_digest failed rc=%d" % rc)
     return out, nd.value, ni.value
+
+
+def digest_collect_threaded(bases, k, w_prefix, files, mode=CANONICAL, threads=0):
+    """digest_threaded plus the (k-mer, count) streams of the files in `files` themselves ->
+    (uint64[64, 4], n_distinct, n_instances, {file: (keys_hi, keys_lo, counts)})."""
+    if isinstance(bases, np.ndarray) and bases.dtype == np.uint8 and bases.flags["C_CONTIGUOUS"]:
+        ptr, n, keep = bases.ctypes.data, bases.size, bases
+    else:
+        keep = _as_bytes(bases)
+        ptr, n = ctypes.cast(ctypes.c_char_p(keep), ctypes.c_void_p), len(keep)
+    out = np.zeros((64, 4), dtype=np.uint64)
+    fs = np.zeros(65, dtype=np.uint64)
+    nd = ctypes.c_uint64(0)
+    ni = ctypes.c_uint64(0)
+    hi = ctypes.POINTER(ctypes.c_uint64)()
+    lo = ctypes.POINTER(ctypes.c_uint64)()
+    cn = ctypes.POINTER(ctypes.c_uint32)()
+    mask = 0
+    for f in files:
+        mask |= 1 << int(f)
+    rc = lib().orc_count_threaded_digest_collect(ptr, n, k, mode, w_prefix, threads, out.ctypes.data, ctypes.byref(nd), ctypes.byref(ni),
+                                                 mask, fs.ctypes.data, ctypes.byref(hi), ctypes.byref(lo), ctypes.byref(cn))
+    del keep
+    if rc != 0:
+        raise RuntimeError("orc_count_threaded_digest_collect failed rc=%d" % rc)
+    total = int(fs[64])
+    ahi, alo, acn = _take(hi, total, np.uint64), _take(lo, total, np.uint64), _take(cn, total, np.uint32)
+    got = {}
+    for f in files:
+        a, b = int(fs[int(f)]), int(fs[int(f) + 1])
+        got[int(f)] = (ahi[a:b], alo[a:b], acn[a:b])
+    return out, nd.value, ni.value, got
 
 
 def digest_arrays(lo, hi, counts, k):

@@ -294,6 +294,63 @@ int orc_count_threaded_digest(const char *bases, uint64_t n, uint32_t k, int mod
 }
 
 namespace {
+/* digests of every file AND the k-mers themselves of the files in `mask` (the full-size parity test compares four whole
+ * files element by element beside the 64 digests) */
+struct DigestSome {
+  Digest D; uint64_t mask; uint32_t w_prefix;
+  std::vector<std::vector<kmdata>> keys;     /* per prefix, filled for masked files only */
+  std::vector<std::vector<kmvalu>> counts;
+};
+void digest_some_cb(void *ctx, uint64_t prefix, uint64_t nk, const kmdata *s, const kmvalu *c) {
+  DigestSome *S = (DigestSome *)ctx;
+  digest_cb(&S->D, prefix, nk, s, c);
+  if (!((S->mask >> (prefix >> S->D.file_shift)) & 1ull)) return;
+  S->keys[prefix].resize(nk);
+  S->counts[prefix].assign(c, c + nk);
+  for (uint64_t i = 0; i < nk; i++) S->keys[prefix][i] = ((kmdata)prefix << S->D.w_data) | s[i];
+}
+}  // namespace
+
+/* as orc_count_threaded_digest; plus, for the files whose bit is set in file_mask, their (k-mer, count) stream in ascending
+ * order: file_start[65] (entries of the masked files before file f; unmasked files are empty), malloc'ed arrays the caller frees */
+extern "C"
+int orc_count_threaded_digest_collect(const char *bases, uint64_t n, uint32_t k, int mode, uint32_t w_prefix, int threads,
+                                      uint64_t *out, uint64_t *n_distinct, uint64_t *n_instances, uint64_t file_mask,
+                                      uint64_t *file_start, uint64_t **keys_hi, uint64_t **keys_lo, uint32_t **counts) {
+  *keys_hi = *keys_lo = nullptr; *counts = nullptr;
+  DigestSome *S = new DigestSome();
+  memset(S->D.v, 0, sizeof(S->D.v));
+  S->D.w_data = 2 * k - w_prefix;
+  S->D.file_shift = w_prefix - 6;
+  S->mask = file_mask; S->w_prefix = w_prefix;
+  S->keys.resize((uint64_t)1 << w_prefix);
+  S->counts.resize((uint64_t)1 << w_prefix);
+  int rc = orc_count_threaded(bases, n, k, mode, w_prefix, threads, digest_some_cb, S, n_distinct, n_instances);
+  memcpy(out, S->D.v, sizeof(S->D.v));
+  if (rc == 0) {
+    uint64_t total = 0;
+    const uint64_t per_file = (uint64_t)1 << (w_prefix - 6);
+    for (uint64_t f = 0; f < 64; f++) {
+      file_start[f] = total;
+      for (uint64_t pp = f * per_file; pp < (f + 1) * per_file; pp++) total += S->keys[pp].size();
+    }
+    file_start[64] = total;
+    uint64_t *hi = (uint64_t *)malloc(8 * (total ? total : 1)), *lo = (uint64_t *)malloc(8 * (total ? total : 1));
+    uint32_t *cn = (uint32_t *)malloc(4 * (total ? total : 1));
+    uint64_t o = 0;
+    for (size_t pp = 0; pp < S->keys.size(); pp++)
+      for (size_t i = 0; i < S->keys[pp].size(); i++, o++) {
+        hi[o] = (uint64_t)(S->keys[pp][i] >> 64);
+        lo[o] = (uint64_t)S->keys[pp][i];
+        cn[o] = S->counts[pp][i];
+      }
+    *keys_hi = hi; *keys_lo = lo; *counts = cn;
+  }
+  delete S;
+  return rc;
+}
+
+namespace {
 struct Collect {
   uint32_t w_data;
   std::vector<std::vector<kmdata>> keys;     /* per prefix */

@@ -405,7 +405,8 @@ def test_config1_full_size_matches_threaded_port(ops, oracle_lib, torch_cuda):
     """BASELINE config 1 AT ITS JUDGED SIZE -- k=21, 66,666,667 x 150 bp reads = 10 Gbp, wPrefix 18, the bench.py workload --
     against the reference-algorithm port (oracle_port.cpp: 2 MiB chunks, spin-locked bit-packed prefix buckets, std::sort,
     run-length count, 64-file dump) run on the host cores over the SAME bytes: every one of the 64 files must agree in
-    its number of distinct k-mers, its total count and two 64-bit weighted key sums.  ~26 GB of host RAM, a few minutes."""
+    its number of distinct k-mers, its total count and two 64-bit weighted key sums; four whole files (0, 21, 42, 63) are
+    compared element by element as well.  ~30 GB of host RAM, a few minutes."""
     import psutil
     from meryl_amd import capi
     n_reads = int(os.environ.get("MGC_TEST_FULL_READS", "66666667"))
@@ -422,17 +423,34 @@ def test_config1_full_size_matches_threaded_port(ops, oracle_lib, torch_cuda):
         keys, counts = s.result_device()
     got = device_digests(torch_cuda, keys, counts, k)
     assert bool((keys[1:] > keys[:-1]).all().item())
+    # four whole files are also compared ELEMENT BY ELEMENT with the port's stream (the first, the last, two in between):
+    # their device slices stay, the rest of the result goes
+    whole = (0, 21, 42, 63)
+    bounds = torch_cuda.tensor([f << (2 * k - 6) for f in range(65)], dtype=torch_cuda.int64, device="cuda")
+    cut = torch_cuda.searchsorted(keys, bounds).cpu().numpy()
+    kept = {f: (keys[int(cut[f]):int(cut[f + 1])].clone(), counts[int(cut[f]):int(cut[f + 1])].clone()) for f in whole}
     del keys, counts
     host = d.cpu().numpy()
     del d
     torch_cuda.cuda.empty_cache()
-    want, nd, ni = oracle_lib.digest_threaded(host, k, cfg.w_prefix, threads=min(32, os.cpu_count() or 8))
+    want, nd, ni, files = oracle_lib.digest_collect_threaded(host, k, cfg.w_prefix, whole, threads=16)
     assert ni == info.n_instances, (ni, info.n_instances)
     assert nd == info.n_distinct, (nd, info.n_distinct)
     assert np.array_equal(got[:, 0], want[:, 0]), "distinct k-mers per file differ"
     assert np.array_equal(got[:, 1], want[:, 1]), "total counts per file differ"
     assert np.array_equal(got, want), "weighted key sums differ"
     assert [int(x) for x in info.file_instances] == [int(x) for x in want[:, 1]]
+    for f in whole:
+        _, plo, pcn = files[f]
+        dk, dc = kept[f]
+        assert dk.shape[0] == plo.shape[0] == int(want[f, 0]) > 0, (f, dk.shape[0], plo.shape[0])
+        step = 1 << 26
+        for a in range(0, plo.shape[0], step):                    # chunked: the port's arrays go up piece by piece
+            assert torch_cuda.equal(dk[a:a + step], torch_cuda.from_numpy(plo[a:a + step].view(np.int64)).cuda()), "k-mers of file %d differ" % f
+            assert torch_cuda.equal(dc[a:a + step].to(torch_cuda.int64) & 0xFFFFFFFF,
+                                    torch_cuda.from_numpy(pcn[a:a + step].astype(np.int64)).cuda()), "counts of file %d differ" % f
+    if n_reads >= 66666667:
+        assert sum(kept[f][0].shape[0] for f in whole) > 20_000_000       # (file 0 alone holds a few percent of the distinct k-mers)
 
 
 @pytest.mark.parametrize("shape", ["config3_repeats", "config4_hifi_compress", "config5_k51"])
@@ -1329,6 +1347,113 @@ def test_hash_count_multi_subbuckets_per_iteration(ops, oracle_lib, torch_cuda, 
             klo, khi, counts, _ = s.result_wide()
         whi, wlo, wcn, _ = oracle_lib.count_brute(stream, k, mode)
         assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+
+
+# every count_device switch that is read per call (a process-wide static one cannot vary inside one test process)
+_GRID_SWITCHES = {
+    "MGC_NARROW": ["0"], "MGC_FINE_HIST": ["0"], "MGC_WIDE_MSD": ["0"], "MGC_GROUP_LOCAL": ["1"], "MGC_PARTITION_WC": ["1"],
+    "MGC_FINISH_BITMAP": ["1"], "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"],
+    "MGC_FINISH_TARGET": ["1", "4", "64", "700"], "MGC_FINISH_MIN_TOP": ["10", "14", "17", "18"], "MGC_STREAM_MAX": ["2000", "20000"],
+    "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"],
+}
+
+
+def test_hypothesis_grid_over_configurations_and_switches(ops, oracle_lib, torch_cuda):
+    """count_device has more code paths than one 48-seed sweep of one shape visits -- (k, strand mode,
+    compress, batches, input size and repeat structure) x a random subset of the per-call MGC_* switches, drawn by
+    hypothesis (derandomised: the same 40 examples every run), each compared element by element with orc_count_brute."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    from meryl_amd import capi
+
+    switch = st.dictionaries(st.sampled_from(sorted(_GRID_SWITCHES)), st.integers(0, 3), max_size=4)
+    shape = st.tuples(st.sampled_from([9, 13, 15, 16, 19, 20, 21, 22, 24, 26, 28, 31, 32, 33, 40, 51, 64]), st.integers(0, 2), st.booleans(),
+                      st.sampled_from([None, None, 600_000, 1_700_000]), st.sampled_from(["small", "big", "big"]), st.booleans(),
+                      st.integers(0, 1 << 20))
+    seen = []
+
+    @settings(max_examples=40, deadline=None, derandomize=True, database=None,
+              suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large, HealthCheck.function_scoped_fixture])
+    @given(shape, switch)
+    def run(sh, sw):
+        k, mode, compress, batch, size, clusters, seed = sh
+        n_reads = 2_000 if size == "small" else 30_000                 # 0.3 / 4.5 Mbases: the fifteen-bit histogram is on above 2^22
+        text = oracle_lib.synth_reads(seed, 400_000, 0, n_reads, 150, 5000, 100).tobytes().decode()
+        if clusters:                                                   # heavy sub-buckets: one k-mer 3000 times, 2500 instances of 900
+            rng = np.random.default_rng(seed)
+            head = "".join("ACGT"[i] for i in rng.integers(0, 4, min(k - 1, 14)))
+            tails = ["".join("ACGT"[i] for i in rng.integers(0, 4, k - len(head))) for _ in range(900)]
+            text = ".".join(head + tails[0] for _ in range(3000)) + "." + ".".join(head + tails[int(i)] for i in rng.integers(0, 900, 2500)) + "." + text
+        env = {name: _GRID_SWITCHES[name][i % len(_GRID_SWITCHES[name])] for name, i in sw.items()}
+        old = {name: os.environ.get(name) for name in env}
+        os.environ.update(env)
+        try:
+            cfg = capi.configure(k, len(text), 1 << 30, mode, homopoly_compress=int(compress))
+            cfg.use_simple = 0
+            with ops.Session(cfg) as s:
+                if batch:
+                    s.set_batch_bases(batch)
+                    for a in range(0, len(text), 500_003):
+                        s.push_bases(text[a:a + 500_003], end_of_sequence=False)
+                else:
+                    s.push_bases(text, end_of_sequence=False)
+                s.count()
+                klo, khi, counts, _ = s.result_wide()
+        finally:
+            for name, v in old.items():
+                if v is None:
+                    os.environ.pop(name, None)
+                else:
+                    os.environ[name] = v
+        ref = oracle_lib.compress_stream(text.encode()).decode() if compress else text
+        whi, wlo, wcn, _ = oracle_lib.count_brute(ref, k, mode)
+        assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn), (sh, env)
+        seen.append((k, mode, compress, bool(batch), size, tuple(sorted(env))))
+
+    run()
+    assert len(seen) >= 30 and len({x[0] for x in seen}) >= 8 and any(x[2] for x in seen) and any(x[3] for x in seen)
+
+
+def test_config4_shape_spills_through_real_host_runs(ops, oracle_lib, torch_cuda, tmp_path):
+    """BASELINE config 4's mechanics with the DEFAULT budgets -- not a forced one-byte budget: 3 Gbp of
+    20 kb reads, k = 31 `compress`, counted in five batches whose results leave HBM for pinned host DRAM once 1.5 GB of
+    them are parked there (the default budget is the free HBM: reaching it takes a 20 Gbp run, profiles/r03_ooc_k51_20g.json);
+    the out-of-core database is compared file by file (digests of the decoded k-mers) with the threaded port run
+    on the same homopolymer-compressed bytes.  Needs ~40 GB of host memory."""
+    import psutil
+    from meryl_amd import capi, db
+    n_reads = int(os.environ.get("MGC_TEST_OOC_READS", "150000"))                      # x 20 kb = 3 Gbp
+    if psutil.virtual_memory().available < (60 << 30) * n_reads / 150000:
+        pytest.skip("not enough host memory for the port at this size")
+    k = 31
+    d = ops.dev_synth_reads(44, 100_000_000, 0, n_reads, 20_000, 1000, 100)
+    cfg = capi.configure(k, d.numel(), 64 << 30, homopoly_compress=1)
+    out = str(tmp_path / "ooc.meryl")
+    with ops.Session(cfg) as s:
+        s.set_batch_bases(d.numel() // 5 + 1)                      # five batches
+        s.set_result_budget(3 << 29)                               # 1.5 GB of batch results may stay in HBM: the later ones really leave it
+        raw = d.cpu().numpy()
+        step = 1 << 28
+        for a in range(0, raw.size, step):                          # (host pushes: a device buffer is the only input of its session)
+            s.push_bases(raw[a:a + step].tobytes(), end_of_sequence=False)
+        s.count()
+        assert s.out_of_core() and s.profile().n_batches >= 5
+        info = s.info()
+        db.write_database(s, out, host_threads=16)
+        rp = s.runs_profile()
+        assert rp["n_host_runs"] >= 2 and rp["n_runs"] >= 5 and rp["host_bytes"] > (1 << 30)   # gigabytes REALLY spilled to pinned host DRAM
+        nd = s.info().n_distinct
+    host = np.frombuffer(oracle_lib.compress_stream(raw.tobytes()), dtype=np.uint8).copy()
+    del d, raw
+    torch_cuda.cuda.empty_cache()
+    want, wnd, wni = oracle_lib.digest_threaded(host, k, cfg.w_prefix, threads=16)
+    assert (wnd, wni) == (nd, info.n_instances)
+    r = db.Reader(out)
+    got = np.zeros((64, 4), dtype=np.uint64)
+    for f in range(64):
+        lo, hi, cn = r.read_file(f)[:3]
+        got[f] = oracle_lib.digest_arrays(lo, hi, cn, k)[f]
+    r.close()
+    assert np.array_equal(got, want)
 
 
 def _dir_bytes(path):

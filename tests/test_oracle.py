@@ -149,3 +149,17 @@ def test_synth_reads_deterministic(oracle_lib):
     assert a.size == 100 * 151 and np.array_equal(a[50 * 151:], b)
     assert set(np.unique(a).tolist()) <= set(b"ACGTN.")
     assert (a[150::151] == ord(".")).all()
+
+
+def test_digest_collect_threaded_agrees_with_digest_and_collect(oracle_lib):
+    """the full-size parity test's checker: digests of all 64 files + the streams of a few whole files from ONE port run"""
+    import oracle
+    b = oracle.synth_reads(3, 50_000, 0, 3000, 150, 5000, 100)
+    cfg = oracle.configure_counting(21, b.size, 1 << 30)
+    d1, nd1, ni1 = oracle.digest_threaded(b, 21, cfg["w_prefix"], threads=4)
+    d2, nd2, ni2, files = oracle.digest_collect_threaded(b, 21, cfg["w_prefix"], (0, 21, 63), threads=4)
+    assert np.array_equal(d1, d2) and (nd1, ni1) == (nd2, ni2)
+    hi, lo, cn, _ = oracle.count_threaded(b, 21, cfg["w_prefix"], threads=4)
+    for f in (0, 21, 63):
+        m = (lo >> np.uint64(36)) == f
+        assert np.array_equal(files[f][1], lo[m]) and np.array_equal(files[f][2], cn[m]) and not files[f][0].any()
