@@ -1633,6 +1633,227 @@ void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
   }
 }
 
+// hash_count64i_kernel rebuilt the way hash_count_multi_kernel was (round 4; dense grids; replaces countSingleKmers' sort +
+// run-length passes, merylCountArray.C:323-365, for suffixes of 32..58 bits: k = 28..32 and `compress`): the same
+// index-claimed table (count << 16 | index of the claiming key's staged suffix) and the same results, but
+//   * the claimed slots are NOTED and appended to a compact list after the insert with one LDS atomic per wave: no pass
+//     over the whole table, no workgroup scan, no compaction copy;
+//   * the bin-rank sorts the ENTRIES (count | index) by their suffix's top eight bits: the bins are scanned by one wave
+//     while the other three clear the table for the next sub-bucket; the sorted entries take the place of the list;
+//   * six workgroup barriers per sub-bucket instead of fourteen;
+//   * the next sub-bucket's keys, loaded a whole iteration earlier, are consumed into registers right after the insert
+//     phase, BEFORE the loads of the one after it are issued (a wait for old registers behind new loads waits for the new
+//     loads), and the bounds come by one vector load instead of scalar loads the first barrier has to drain.
+template <int BLOCK, int CAP, int SLOTS>
+__global__ __launch_bounds__(BLOCK, (CAP <= 768 ? 6 : 5))       // (seven: 72 registers and a spill -- a scratch reload waits on vmcnt like the prefetch)
+void hash_count64m_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
+                          u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u32 tr_a, u32 tr_b) {
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % (4 * BLOCK) == 0 && CAP % BLOCK == 0 && CAP < 0xFFFF, "table geometry");
+  static_assert(BLOCK == 256, "one bin per thread");
+  constexpr int KPT = CAP / BLOCK;
+  constexpr u32 EMPTY = 0x0000FFFFu;
+  __shared__ __attribute__((aligned(16))) u64 dk[CAP];                // staged suffixes of the sub-bucket
+  __shared__ __attribute__((aligned(16))) u32 tw[SLOTS];              // instances << 16 | index of the claiming key
+  __shared__ __attribute__((aligned(16))) u32 srt[CAP];               // first the claimed slots (u16 list), then the entries in bin order
+  __shared__ __attribute__((aligned(16))) u32 s_bin[2][BLOCK + 4];    // bin counts -> starts; [BLOCK] = D
+  __shared__ u32 s_nd;
+  unsigned short *lst = reinterpret_cast<unsigned short *>(srt);
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u64 G = gridDim.x;
+  const u64 low_mask = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
+  const u32 bshift = low_bits > 8 ? low_bits - 8 : 0;
+
+  auto load_bvec = [&](u64 g) -> u64 {                              // lane 0: starts[g], the others: starts[g + 1]
+    if (g >= ng) return 0ull;
+    return starts[g + (lane ? 1u : 0u)];
+  };
+  auto rdlane64 = [&](u64 v, int l) -> u64 {
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+  };
+  auto unpack_bounds = [&](u64 bv, u64 &a0, u32 &n) {
+    a0 = rdlane64(bv, 0);
+    const u64 d = rdlane64(bv, 1) - a0;
+    n = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)d;
+  };
+  auto load_keys = [&](u64 a0, u32 n, u64 (&kr)[KPT]) {
+    const bool fits = (u64)n <= max_size;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      kr[j] = 0ull;
+      if (fits && (u32)j * BLOCK < n) {
+        const u64 *src = keys + a0 + (u32)j * BLOCK;
+        const u32 last = n - 1u - (u32)j * BLOCK;
+        kr[j] = src[tid < last ? tid : last];
+      }
+    }
+  };
+  auto slots_for = [&](u32 n) -> u32 {
+    u32 s = 256;
+    while (s < n + n / 4 && s < (u32)SLOTS) s <<= 1;
+    return s;
+  };
+
+  u64 P = blockIdx.x;
+  u64 a0, a0n;
+  u32 nc, nn;
+  u64 kcur[KPT], kk[KPT], prefix;
+  unpack_bounds(load_bvec(P), a0, nc);
+  load_keys(a0, nc, kcur);
+  u64 bvec = load_bvec(P + G);
+  prefix = kcur[0] & ~low_mask;
+#pragma unroll
+  for (int j = 0; j < KPT; j++) { kk[j] = kcur[j] & low_mask; asm volatile("" : "+v"(kk[j]) :: "memory"); }
+  unpack_bounds(bvec, a0n, nn);
+  load_keys(a0n, nn, kcur);
+  bvec = load_bvec(P + 2 * G);
+  u32 par = 0;
+  u32 cleared = (u32)SLOTS;                            // tw[0, cleared) is EMPTY whenever an insert phase begins
+  {
+    uint4 *tw4 = reinterpret_cast<uint4 *>(tw);
+    for (u32 i = tid; i < (u32)SLOTS / 4; i += BLOCK) tw4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+    s_bin[0][tid] = 0; s_bin[1][tid] = 0;
+    if (tid == 0) s_nd = 0;
+  }
+  __syncthreads();
+
+  while (P < ng) {
+    const u32 n = nc;
+    const bool active = n != 0 && (u64)n <= max_size;
+    const u32 slots = slots_for(n);
+    if (active) {
+      u32 hh[KPT];
+      const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
+      if (slots > cleared) {
+        uint4 *tw4 = reinterpret_cast<uint4 *>(tw);
+        for (u32 i = tid; i < (u32)SLOTS / 4; i += BLOCK) tw4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+      }
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        hh[j] = (u32)((kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
+        if ((u32)j * BLOCK + tid < n) dk[(u32)j * BLOCK + tid] = kk[j];
+      }
+      __syncthreads();                                 // the suffixes are staged: a probe compares with the claimer's
+      u32 won = 0, pending = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        if ((u32)j * BLOCK < n) {
+          const bool act = (u32)j * BLOCK + tid < n;
+          u32 old = 0;                                 // (index 0 with count 0: no entry looks like it)
+          if (act) old = atomicCAS(&tw[hh[j]], EMPTY, (1u << 16) | ((u32)j * BLOCK + tid));
+          const bool w = act && old == EMPTY;
+          const bool dup = act && !w && dk[old & 0xFFFFu] == kk[j];
+          if (dup) atomicAdd(&tw[hh[j]], 1u << 16);
+          won |= w ? (1u << j) : 0u;
+          pending |= (act && !w && !dup) ? (1u << j) : 0u;
+        }
+      }
+      while (pending) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if ((pending >> j) & 1u) {
+            hh[j] = (hh[j] + 1) & smask;
+            const u32 old = atomicCAS(&tw[hh[j]], EMPTY, (1u << 16) | ((u32)j * BLOCK + tid));
+            const bool w = old == EMPTY;
+            const bool dup = !w && dk[old & 0xFFFFu] == kk[j];
+            if (dup) atomicAdd(&tw[hh[j]], 1u << 16);
+            if (w) won |= 1u << j;
+            if (w || dup) pending &= ~(1u << j);
+          }
+        }
+      }
+      {
+        u64 wm[KPT];
+        u32 tot = 0;
+#pragma unroll
+        for (int j = 0; j < KPT; j++) { wm[j] = __ballot((won >> j) & 1u); tot += (u32)__popcll(wm[j]); }
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&s_nd, tot);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+          if (wm[j]) {
+            if ((won >> j) & 1u)
+              lst[base + __builtin_amdgcn_mbcnt_hi((u32)(wm[j] >> 32), __builtin_amdgcn_mbcnt_lo((u32)wm[j], 0u))] = (unsigned short)hh[j];
+            base += (u32)__popcll(wm[j]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    // the next sub-bucket's keys (loaded a whole iteration ago) take the place of this one's in kk[]; only then the keys of
+    // the one after it and the bounds of the one after that are issued
+    const u64 a = a0, prefix_cur = prefix;
+    const u32 nslots = (u64)nn <= max_size ? slots_for(nn) : 256u;
+    prefix = kcur[0] & ~low_mask;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) { kk[j] = kcur[j] & low_mask; asm volatile("" : "+v"(kk[j]) :: "memory"); }
+    a0 = a0n; nc = nn;
+    unpack_bounds(bvec, a0n, nn);
+    load_keys(a0n, nn, kcur);
+    bvec = load_bvec(P + 3 * G);
+
+    if (active) {
+      const u32 D = s_nd;
+      u32 wq[KPT], li[KPT];
+#pragma unroll
+      for (int q = 0; q < KPT; q++) {
+        wq[q] = 0; li[q] = 0;
+        if ((u32)q * BLOCK < D) {
+          const u32 i = (u32)q * BLOCK + tid;
+          if (i < D) { wq[q] = tw[lst[i]]; li[q] = atomicAdd(&s_bin[par][(u32)(dk[wq[q] & 0xFFFFu] >> bshift)], 1u); }
+        }
+      }
+      __syncthreads();
+      if (tid < 64) {                                  // one wave scans the 256 bin counts: four per lane
+        uint4 c = reinterpret_cast<uint4 *>(s_bin[par])[tid];
+        const u32 s4 = c.x + c.y + c.z + c.w;
+        u32 x = s4;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+        const u32 e0 = x - s4;
+        reinterpret_cast<uint4 *>(s_bin[par])[tid] = make_uint4(e0, e0 + c.x, e0 + c.x + c.y, e0 + c.x + c.y + c.z);
+        if (tid == 63) s_bin[par][BLOCK] = x;
+      } else {                                         // ... the other three clear what the next insert phase uses
+        uint4 *tw4 = reinterpret_cast<uint4 *>(tw);
+        for (u32 i = tid - 64; i < nslots / 4; i += BLOCK - 64) tw4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+        for (u32 i = tid - 64; i < BLOCK; i += BLOCK - 64) s_bin[par ^ 1u][i] = 0;
+        if (tid == 64) s_nd = 0;
+      }
+      cleared = nslots;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < KPT; q++) {
+        if ((u32)q * BLOCK < D) {
+          const u32 i = (u32)q * BLOCK + tid;
+          if (i < D) srt[s_bin[par][(u32)(dk[wq[q] & 0xFFFFu] >> bshift)] + li[q]] = wq[q];
+        }
+      }
+      __syncthreads();
+      // rank inside the bin, then back in place (every key of this region is staged in LDS)
+      const u32 *sb = s_bin[par];
+      u64 *gk = keys + a;
+      u32 *cout = cnt_tmp + a;
+      for (u32 p = tid; p < D; p += BLOCK) {
+        const u32 w = srt[p];
+        const u64 ki = dk[w & 0xFFFFu];
+        const u32 b = (u32)(ki >> bshift), lo = sb[b], hi = sb[b + 1];
+        u32 r = lo;
+        for (u32 q = lo; q < hi; q++) r += (dk[srt[q] & 0xFFFFu] < ki) ? 1u : 0u;
+        gk[r] = prefix_cur | ki;
+        cout[r] = w >> 16;
+      }
+      if (tid == 0) group_distinct[tr_index(P, tr_a, tr_b)] = D;
+      par ^= 1u;
+      __syncthreads();                                 // dk and the list are rewritten by the next sub-bucket
+    } else if (tid == 0 && n == 0) {
+      group_distinct[tr_index(P, tr_a, tr_b)] = 0;     // (larger than max_size: the streaming launch owns it)
+    }
+    P += G;
+  }
+}
+
 // value of v in lane `lane` (wave-uniform, e.g. taken from a ballot): v_readlane, no LDS round trip
 __device__ __forceinline__ u64 read_lane_u64(u64 v, int lane) {
   const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, lane);
@@ -2509,6 +2730,21 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       // a file whose LARGEST sub-bucket holds at most 768 k-mers (`compress`: 59049 sub-buckets per bucket, a few hundred k-mers
       // each): three keys per thread instead of six -- fewer idle unrolled slots, half the LDS, seven workgroups per CU
       static const bool small64 = !(getenv("MGC_HASH64_SMALL") && getenv("MGC_HASH64_SMALL")[0] == '0');
+      const char *m64 = getenv("MGC_HASH64M");                       // read per call: the tests switch it
+      const bool use_64m = !(m64 && m64[0] == '0') && !use_list && binrank64 && low_bits <= 58;
+      if (use_64m && small64 && max_sub && max_sub <= 768 && n_large == 0) {
+        static const uint32_t sgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 12u;
+        const uint32_t sgrid = ng < sgrid_max ? (uint32_t)ng : sgrid_max;
+        hipLaunchKernelGGL((hash_count64m_kernel<256, 768, 1024>), dim3(sgrid), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys),
+                           reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)768, low_bits, d_cnt_tmp,
+                           reinterpret_cast<u64 *>(d_group_distinct), tr_a, tr_b);
+      } else if (use_64m) {
+        static const uint32_t mgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 10u;
+        const uint32_t mgrid = ng < mgrid_max ? (uint32_t)ng : mgrid_max;
+        hipLaunchKernelGGL((hash_count64m_kernel<256, (int)FIN_CAP_HASH, 2048>), dim3(mgrid), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys),
+                           reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp,
+                           reinterpret_cast<u64 *>(d_group_distinct), tr_a, tr_b);
+      } else
       if (small64 && binrank64 && max_sub && max_sub <= 768 && n_large == 0) {
         static const uint32_t sgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 7u;
         const uint32_t sgrid = ng < sgrid_max ? (uint32_t)ng : sgrid_max;

@@ -426,7 +426,9 @@ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 
 // the order inside a (workgroup, tile, bucket) run.
 // MAXB: bucket capacity of the LDS tables (64 for the 64-file partition of the count path: 36 KiB of LDS per
 // workgroup instead of 51, i.e. four workgroups per CU instead of three; 1024 for the general operator)
-template <typename K, int MAXB>
+// DBG (measurements only, WRONG results; MGC_PART_DBG): 1 = every key leaves as 4 bytes (what a narrower key layout could buy on
+// the write side), 2 = no global stores at all (the kernel's compute + read floor)
+template <typename K, int MAXB, int DBG = 0>
 __global__ __launch_bounds__(KP_BLOCK, (sizeof(K) == 16) ? 2 : 5)      // 16-byte keys: the 64 KiB exchange tile allows two workgroups
 void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
                            u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out, u64 sfx_mask, u64 sfx_test) {
@@ -503,7 +505,9 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
     for (u32 i = tid; i < total; i += KP_BLOCK) {
       const K   key = s_keys[i];
       const u32 b   = (nb == 1) ? 0u : KeyOps<K>::bucket(key, bucket_shift);
-      out[s_cursor[b] + (u64)(i - s_base[b])] = key;
+      if constexpr (DBG == 1 && sizeof(K) == 8) reinterpret_cast<u32 *>(out)[s_cursor[b] + (u64)(i - s_base[b])] = (u32)key;
+      else if constexpr (DBG == 2) { if (KeyOps<K>::low64(key) == 0x123456789ABCDEFull) out[0] = key; }
+      else out[s_cursor[b] + (u64)(i - s_base[b])] = key;
     }
     __syncthreads();
     for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] += s_cnt[b];
@@ -724,6 +728,15 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
   hipLaunchKernelGGL((kmer_partition_kernel<K_, MAXB_>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K_), st,      \
                      d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,                                  \
                      reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys), (u64)sfx_mask, (u64)sfx_test)
+  if (const char *pd = getenv("MGC_PART_DBG")) if (k <= 32 && nb <= 64 && (pd[0] == '1' || pd[0] == '2')) {
+    if (pd[0] == '1')
+      hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, 1>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
+                         bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)sfx_mask, (u64)sfx_test);
+    else
+      hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, 2>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
+                         bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)sfx_mask, (u64)sfx_test);
+    return hipGetLastError();
+  }
   if (k <= 32) { if (nb <= 64) MGC_KP_LAUNCH(u64, 64); else MGC_KP_LAUNCH(u64, KP_MAX_BUCKETS); }
   else         { if (nb <= 64) MGC_KP_LAUNCH(K128, 64); else MGC_KP_LAUNCH(K128, KP_MAX_BUCKETS); }
 #undef MGC_KP_LAUNCH

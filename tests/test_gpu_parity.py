@@ -1349,6 +1349,41 @@ def test_hash_count_multi_subbuckets_per_iteration(ops, oracle_lib, torch_cuda, 
         assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
 
 
+@pytest.mark.parametrize("m64", ["1", "0"])
+@pytest.mark.parametrize("k,compress,min_top", [(28, 0, 14), (31, 0, 16), (32, 0, 12), (31, 1, None), (30, 0, 18)])
+def test_hash_count64m_dense_grids(ops, oracle_lib, torch_cuda, monkeypatch, k, compress, min_top, m64):
+    """hash_count64m_kernel (round 4: the 64-bit-suffix count rebuilt like hash_count_multi_kernel -- noted claims, entries
+    sorted by bin, prefetch consumed before the next loads) on the dense-grid launch (MGC_FINISH_NOLIST on a small input),
+    both instantiations (sub-buckets up to 768 / 1536 keys), against the one it replaces (MGC_HASH64M=0) and the oracle:
+    clusters of 1 .. 1536 keys with 1 .. all-distinct suffixes, more distinct suffixes than threads (low coverage), an
+    oversized one for the streaming launch."""
+    from meryl_amd import capi
+    monkeypatch.setenv("MGC_FINISH_NOLIST", "1")
+    monkeypatch.setenv("MGC_HASH64M", m64)
+    if min_top is not None:
+        monkeypatch.setenv("MGC_FINISH_MIN_TOP", str(min_top))
+    rng = np.random.default_rng(k * 7 + (min_top or 0))
+    plen = 13
+    def cluster(head, n_inst, n_distinct):
+        pre = head + "".join("ACGT"[i] for i in rng.integers(0, 4, plen - len(head)))
+        tails = ["".join("ACGT"[i] for i in rng.integers(0, 4, k - plen)) for _ in range(n_distinct)]
+        return ".".join(pre + tails[int(i)] for i in rng.integers(0, n_distinct, n_inst)) + "."
+    reads = oracle_lib.synth_reads(k, 400_000, 0, 30_000).tobytes().decode()
+    stream = (cluster("AAC", 1536, 1536) + cluster("ACA", 1536, 7) + cluster("ATT", 760, 700) + cluster("AGC", 1537, 300)
+              + cluster("CAT", 3000, 900) + cluster("CCG", 1, 1) + cluster("AAT", 700, 1) + cluster("ACC", 1200, 1200)
+              + cluster("AGG", 64, 64) + cluster("CTA", 1000, 30) + reads)
+    for mode in (1, 0):
+        cfg = capi.configure(k, len(stream), 1 << 30, mode, homopoly_compress=compress)
+        cfg.use_simple = 0
+        with ops.Session(cfg) as s:
+            s.push_bases(stream, end_of_sequence=False)
+            s.count()
+            klo, khi, counts, _ = s.result_wide()
+        ref = oracle_lib.compress_stream(stream.encode()).decode() if compress else stream
+        whi, wlo, wcn, _ = oracle_lib.count_brute(ref, k, mode)
+        assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+
+
 # every count_device switch that is read per call (a process-wide static one cannot vary inside one test process)
 _GRID_SWITCHES = {
     "MGC_NARROW": ["0"], "MGC_FINE_HIST": ["0"], "MGC_WIDE_MSD": ["0"], "MGC_GROUP_LOCAL": ["1"], "MGC_PARTITION_WC": ["1"],
