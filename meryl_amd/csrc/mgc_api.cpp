@@ -1149,14 +1149,21 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   HIP_TRY(s, s->ensure(mgc_session::B_Y, kbytes * (odd ? N : max_bucket)));
   unsigned char *X = ext_keys ? reinterpret_cast<unsigned char *>(ext_keys) : reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_X].p);
   unsigned char *Y = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_Y].p);
-  if (!ext_keys) {
+  // The partition is launched once the plan of the files is known (below): when every file takes the narrowed passes its
+  // k-mers leave as 5 bytes (u32 + u8 per file) instead of 8 -- the file's first grouping pass puts them together again.
+  bool partition_done = false;
+  auto run_partition = [&](bool soa) -> int {
+    if (ext_keys || partition_done) return MGC_OK;
+    partition_done = true;
     HIP_TRY(s, hipMemcpyAsync(d_starts, h_starts, sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
     tm.begin(MGC_STAGE_PARTITION);
     HIP_TRY(s, mgc::launch_kmer_partition(d_bases, n_bases, k, c.mode, bucket_bits, d_starts, (void *)X, part_ws, st,
-                                          s->sfx_mask, s->sfx_test));
+                                          s->sfx_mask, s->sfx_test, soa ? d_counts64 : nullptr));
     tm.end(MGC_STAGE_PARTITION);
     s->prof.stage_launches[MGC_STAGE_PARTITION] = 2;
-  }
+    return MGC_OK;
+  };
+  uint32_t soa_hi_mask = 0;                                  // nonzero: the files lie in the 5-byte layout
 
   // ---- per-file LSB radix sort of the low 2k-6 bits ----
   const size_t sort_ws_bytes = mgc::sort_workspace_bytes(max_bucket) + 256;
@@ -1179,6 +1186,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   uint64_t nd = 0;
 
   if (!use_finish) {
+    { const int prc = run_partition(false); if (prc != MGC_OK) return prc; }
     tm.begin(MGC_STAGE_SORT);
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0) continue;
@@ -1303,6 +1311,19 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       wide_msd[b] = !narrow[b] && !hist_ahead && d_fine && nb <= 64 && mgc::finish_can_stream(kw, low) &&
                     mgc::sort_plan_wide_msd(fplan[b], h_counts[b]);
     }
+    {
+      // 5-byte layout: 8-byte keys with 33..40 bits below the file (k = 20..23), every non-empty file on the narrowed passes with
+      // the high digit first off the fifteen-bit histogram (the look-back kernel: the chunk-local one and the instrumented one read
+      // whole keys).  MGC_SOA5=0: whole keys.
+      const char *se = getenv("MGC_SOA5");                            // read per call: the tests switch it
+      bool soa = !(se && se[0] == '0') && !ext_keys && kw == 1 && nb == 64 && d_fine && rem_bits > 32 && rem_bits <= 40 && s->sfx_mask == 0 &&
+                 !d_fine_rows && !getenv("MGC_GROUP_DBG") && !getenv("MGC_PART_DBG") &&
+                 !(getenv("MGC_PARTITION_WC") && getenv("MGC_PARTITION_WC")[0] == '1');
+      for (uint32_t b = 0; b < nb && soa; b++) if (h_counts[b] && !(narrow[b] && top_bits[b])) soa = false;
+      if (soa) soa_hi_mask = (1u << (rem_bits - 32)) - 1u;
+      const int prc = run_partition(soa);
+      if (prc != MGC_OK) return prc;
+    }
     // Where the counts of a file's distinct k-mers wait for the packing step (one uint32 per k-mer instance position).  A NARROWED
     // file keeps 4-byte words in the front half of its 8-byte region from the first grouping pass on: the back half is free and
     // takes the counts -- no buffer of its own (35 GB of the 123 GB arena at 10 Gbp; a large first hipMalloc is the slowest thing
@@ -1391,7 +1412,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         gl.n_chunks = local_chunks; gl.vgrid = local_vgrid; gl.per_chunk = local_per_chunk; gl.file = b; gl.file_start = h_starts[b];
         HIP_TRY(s, mgc::launch_group_narrow(src, (void *)Y, h_counts[b], fp, sort_ws, sort_ws_bytes - 256, d_err, d_substart + sbase[b], st, pe,
                                             d_nhdrs ? (void *)(d_nhdrs + hdr_bytes * b) : nullptr, d_nws ? (void *)(d_nws + nws_off[b]) : nullptr,
-                                            &tr_a[b], &tr_b[b], (d_nhdrs && d_fine_rows) ? &gl : nullptr));
+                                            &tr_a[b], &tr_b[b], (d_nhdrs && d_fine_rows) ? &gl : nullptr, soa_hi_mask));
         file_passes[b] = 2;
         narrowed[b] = 1;
         sort_launch_groups++;
@@ -1617,7 +1638,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
           s->prof.pass_ms[pi] += ms;
           s->prof.pass_launches[pi]++;
           s->prof.pass_keys[pi] += h_counts[b];
-          s->prof.pass_bytes[pi] += h_counts[b] * ((size_t)b < narrowed.size() && narrowed[b] ? (p ? 8u : 12u) : 2u * kbytes);
+          s->prof.pass_bytes[pi] += h_counts[b] * ((size_t)b < narrowed.size() && narrowed[b] ? (p ? 8u : (soa_hi_mask ? 9u : 12u)) : 2u * kbytes);
         }
       }
     }

@@ -38,7 +38,9 @@ hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint3
 // keys are uint64 for k <= 32, 16-byte little-endian {lo,hi} for k in 33..64 (key_words 1 / 2)
 hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                                  uint32_t bucket_bits, const uint64_t *d_bucket_starts, void *d_keys,
-                                 void *d_ws, hipStream_t st, uint64_t sfx_mask = 0, uint64_t sfx_test = 0);
+                                 void *d_ws, hipStream_t st, uint64_t sfx_mask = 0, uint64_t sfx_test = 0,
+                                 const uint64_t *d_soa_counts = nullptr /*64 buckets, 8-byte keys, <= 40 bits below the file: a file's region =
+                                 u32[count] low words + u8[count] bits 32..39 (5 bytes per k-mer; launch_group_narrow(soa_hi_mask))*/);
 
 // ---- radix sort ------------------------------------------------------------
 struct SortPlan {
@@ -111,7 +113,9 @@ hipError_t launch_fine_rows_scan(uint32_t *d_rows, uint32_t n_chunks, uint32_t n
                                  hipStream_t st);
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events /* 4 or null */,
-                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, const GroupLocal *local = nullptr);
+                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, const GroupLocal *local = nullptr,
+                               uint32_t soa_hi_mask = 0 /*nonzero: d_keys is the 5-byte layout of launch_kmer_partition(d_soa_counts); the mask of
+                               the u8 array's payload bits (bits 32.. of the k-mer below the file)*/);
 
 // The same high-digit-first form for WHOLE keys (8-byte keys that leave more than 32 bits below their first digit: k = 27..32
 // at the 10 Gbp scale; every 16-byte key): the high digit's histogram comes from the fifteen-bit file histogram

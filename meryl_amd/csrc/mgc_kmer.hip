@@ -428,10 +428,16 @@ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 
 // workgroup instead of 51, i.e. four workgroups per CU instead of three; 1024 for the general operator)
 // DBG (measurements only, WRONG results; MGC_PART_DBG): 1 = every key leaves as 4 bytes (what a narrower key layout could buy on
 // the write side), 2 = no global stores at all (the kernel's compute + read floor)
-template <typename K, int MAXB, int DBG = 0>
-__global__ __launch_bounds__(KP_BLOCK, (sizeof(K) == 16) ? 2 : 5)      // 16-byte keys: the 64 KiB exchange tile allows two workgroups
+// SOA (round 4; 8-byte keys whose bits below the file fit 40: k <= 23): a file's region holds its k-mers as a u32 array (low
+// words) followed by a u8 array (bits 32..39) -- 5 bytes per k-mer instead of 8 leave this kernel and enter the file's first
+// grouping pass (radix_group_kernel<SOA>), which only ever needed 36 of the 64 bits (the file is where the k-mer lies).
+// Measured with the debug forms above (profiles/r04j_part_dbg.txt): 8-byte stores cost 10.4 of this kernel's 27.6 ms,
+// 4-byte stores 3.5.  soa_starts / soa_counts: first k-mer and number of k-mers of every file.
+template <typename K, int MAXB, int DBG = 0, bool SOA = false>
+__global__ __launch_bounds__(KP_BLOCK, (sizeof(K) == 16) ? 2 : (SOA ? 4 : 5))   // 16-byte keys: the 64 KiB exchange tile allows two workgroups; SOA: no spill, LDS allows four anyway
 void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
-                           u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out, u64 sfx_mask, u64 sfx_test) {
+                           u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out, u64 sfx_mask, u64 sfx_test,
+                           const u64 *__restrict__ soa_starts = nullptr, const u64 *__restrict__ soa_counts = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kp_dyn_smem[];
   K *s_keys = reinterpret_cast<K *>(kp_dyn_smem);                   // K[KP_TILE]
   __shared__ u64 s_cursor[MAXB];
@@ -447,6 +453,10 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
   const u32  tid = threadIdx.x;
 
   for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] = block_base[(u64)blockIdx.x * nb + b];
+  __shared__ u64 s_fstart[SOA ? MAXB : 1], s_fhi[SOA ? MAXB : 1];   // SOA: first k-mer of the file; byte offset of its u8 array
+  if constexpr (SOA) {
+    for (u32 b = tid; b < nb; b += KP_BLOCK) { s_fstart[b] = soa_starts[b]; s_fhi[b] = 8ull * soa_starts[b] + 4ull * soa_counts[b]; }
+  }
 
   u64 t_begin, t_end;
   kp_tile_range(num_tiles, t_begin, t_end);
@@ -505,7 +515,15 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
     for (u32 i = tid; i < total; i += KP_BLOCK) {
       const K   key = s_keys[i];
       const u32 b   = (nb == 1) ? 0u : KeyOps<K>::bucket(key, bucket_shift);
-      if constexpr (DBG == 1 && sizeof(K) == 8) reinterpret_cast<u32 *>(out)[s_cursor[b] + (u64)(i - s_base[b])] = (u32)key;
+      if constexpr (SOA && sizeof(K) == 8) {
+        // (the high bytes four at a time -- a quad of consecutive tile positions lies in one file except where two files
+        // meet: one unaligned 4-byte store instead of four byte stores -- measured SLOWER: 28.4 ms against 25.2, the
+        // hardware splits a byte-aligned dword store anyway and the quad loop reads the tile from LDS once more)
+        const u64 rel = s_cursor[b] + (u64)(i - s_base[b]) - s_fstart[b];
+        reinterpret_cast<u32 *>(out + s_fstart[b])[rel] = (u32)KeyOps<K>::low64(key);
+        reinterpret_cast<uint8_t *>(out)[s_fhi[b] + rel] = (uint8_t)(KeyOps<K>::low64(key) >> 32);
+      }
+      else if constexpr (DBG == 1 && sizeof(K) == 8) reinterpret_cast<u32 *>(out)[s_cursor[b] + (u64)(i - s_base[b])] = (u32)key;
       else if constexpr (DBG == 2) { if (KeyOps<K>::low64(key) == 0x123456789ABCDEFull) out[0] = key; }
       else out[s_cursor[b] + (u64)(i - s_base[b])] = key;
     }
@@ -697,7 +715,7 @@ hipError_t launch_kmer_histogram_hpc(const uint8_t *d_bases, uint64_t n_bases, u
 
 hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                                  uint32_t bucket_bits, const uint64_t *d_bucket_starts, void *d_keys,
-                                 void *d_ws, hipStream_t st, uint64_t sfx_mask, uint64_t sfx_test) {
+                                 void *d_ws, hipStream_t st, uint64_t sfx_mask, uint64_t sfx_test, const uint64_t *d_soa_counts) {
   if (n_bases == 0) return hipSuccess;
   const uint32_t nb = 1u << bucket_bits;
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
@@ -728,6 +746,13 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
   hipLaunchKernelGGL((kmer_partition_kernel<K_, MAXB_>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K_), st,      \
                      d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,                                  \
                      reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys), (u64)sfx_mask, (u64)sfx_test)
+  if (d_soa_counts) {                                                 // 5-byte layout (kmer_partition_soa_ok)
+    if (!(k <= 32 && nb == 64 && sfx_mask == 0)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, 0, true>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
+                       bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)0, (u64)0,
+                       reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
+    return hipGetLastError();
+  }
   if (const char *pd = getenv("MGC_PART_DBG")) if (k <= 32 && nb <= 64 && (pd[0] == '1' || pd[0] == '2')) {
     if (pd[0] == '1')
       hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, 1>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,

@@ -696,10 +696,13 @@ template <> struct GroupOut<u64, true> { typedef u32 type; };
 // HIST2: the pass also takes the histogram of ANOTHER digit (the next pass's) of the keys it reads -- 512 LDS counters per
 // workgroup, flushed with global atomics at the end -- so that nobody has to read the keys for it.
 struct GroupExtra { u32 digit_bits /* NARROW */; u32 shift2, mask2; u64 *ghist2 /* HIST2 */;
-                    u32 dbg = 0 /* MGC_GROUP_RD (measurements only, WRONG results): 1 = the tile fetch reads 4 of every key's 8 bytes */; };
+                    u32 dbg = 0 /* MGC_GROUP_RD (measurements only, WRONG results): 1 = the tile fetch reads 4 of every key's 8 bytes */;
+                    u32 soa_hi_mask = 0 /* SOA: payload bits of the u8 array */; };
 static u32 group_dbg_flags() { const char *e = getenv("MGC_GROUP_RD"); return (e && *e) ? (u32)atoi(e) : 0u; }
 
-template <typename K, int RB, int BLOCK, int KPT, bool DBG, bool NARROW = false, bool HIST2 = false>
+// SOA (u64 keys): `in` is the 5-byte layout kmer_partition_kernel<SOA> leaves -- u32 in[n] low words, then u8[n] bits 32..39 --
+// and a key is put together as it is fetched: four keys per lane and group from one 16-byte and one 4-byte load.
+template <typename K, int RB, int BLOCK, int KPT, bool DBG, bool NARROW = false, bool HIST2 = false, bool SOA = false>
 __global__ __launch_bounds__(BLOCK, (GroupSmem<K, RB, BLOCK, KPT>::MIN_WAVES_PER_SIMD))
 void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::type *__restrict__ out, u64 n, u32 shift, u32 dmask,
                         const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
@@ -755,13 +758,36 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
   // wider loads matter beyond issue slots: the walkers' granule loads queue behind the prefetch of the other twelve waves in
   // the CU's own memory pipeline, by INSTRUCTION -- with 4-byte loads of 32-bit words the look-back took 45 K cycles per tile
   // instead of 17 K (profiles/r02x_groupdbg.log).  Key j of a thread is element idx_of(j) of the tile; order inside a tile is free.
-  constexpr int VEC = (sizeof(K) < 16 && KPT % (16 / sizeof(K)) == 0) ? (int)(16 / sizeof(K)) : 1;
+  static_assert(!SOA || (sizeof(K) == 8 && KPT % 4 == 0), "the 5-byte layout holds 8-byte keys");
+  constexpr int VEC = SOA ? 4 : ((sizeof(K) < 16 && KPT % (16 / sizeof(K)) == 0) ? (int)(16 / sizeof(K)) : 1);
   struct __attribute__((aligned(4))) KVec { K v[VEC]; };     // 4-byte alignment is all a file / region start guarantees
   auto idx_of = [&](int j) __attribute__((always_inline)) -> u32 {
     return w * (u32)(64 * KPT) + ((u32)(j / VEC) * 64u + lane) * (u32)VEC + (u32)(j % VEC);
   };
   K keys[KPT];
   auto fetch = [&](u64 kb, u32 nv) __attribute__((always_inline)) {
+    if constexpr (SOA) {
+      struct __attribute__((aligned(4))) LVec { u32 v[4]; };
+      struct __attribute__((packed, aligned(1))) HWord { u32 v; };
+      const u32 *lo32 = reinterpret_cast<const u32 *>(in) + kb;
+      const uint8_t *hi8 = reinterpret_cast<const uint8_t *>(in) + 4ull * n + kb;
+      const u32 hm = ex.soa_hi_mask;
+#pragma unroll
+      for (int g = 0; g < KPT / 4; g++) {
+        const u32 first = idx_of(g * 4);
+        if (nv == (u32)TILE || first + 4u <= nv) {
+          const LVec l = *reinterpret_cast<const LVec *>(lo32 + first);
+          const u32 h = reinterpret_cast<const HWord *>(hi8 + first)->v;
+#pragma unroll
+          for (int c = 0; c < 4; c++) keys[g * 4 + c] = (K)((u64)l.v[c] | ((u64)((h >> (8 * c)) & hm) << 32));
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+            if (first + (u32)c < nv) keys[g * 4 + c] = (K)((u64)lo32[first + c] | ((u64)((u32)hi8[first + c] & hm) << 32));
+        }
+      }
+      return;
+    }
     const K *base = in + kb;
 #pragma unroll
     for (int g = 0; g < KPT / VEC; g++) {
@@ -1510,7 +1536,7 @@ hipError_t launch_fine_rows_scan(uint32_t *d_rows, uint32_t n_chunks, uint32_t n
 
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events,
-                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, const GroupLocal *local) {
+                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, const GroupLocal *local, uint32_t soa_hi_mask) {
   if (!sort_plan_narrows(plan, n, 1) || ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
   constexpr int RB = 9, BLOCK = 1024, KPT0 = 16, KPT1 = 24, R = 1 << RB;
   using GS0 = GroupSmem<u64, RB, BLOCK, KPT0>;
@@ -1573,6 +1599,7 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
     if (hipMalloc(&dbg_buf, 2 * 64 * 8 * sizeof(u64)) != hipSuccess) dbg_buf = nullptr;
   }
   if (dbg && dbg_buf) MGC_CHECK(hipMemsetAsync(dbg_buf, 0, 2 * 64 * 8 * sizeof(u64), st));
+  if (soa_hi_mask && (!msd || local || (dbg && dbg_buf))) return hipErrorInvalidValue;   // the 5-byte layout: look-back kernel, high digit first
   if (msd && local && !(dbg && dbg_buf)) {
     // chunk-local first pass: one workgroup per chunk, private digit cursors, no look-back (radix_group_local_kernel).
     // MGC_LOCAL_KPT=8: 8192-key tiles, two workgroups per CU (one's LDS phases beside the other's memory phases)
@@ -1632,6 +1659,18 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                        &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
                        GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0]}, dbg_buf);
+  else if (msd && soa_hi_mask) {
+    static bool sattr = false;
+    if (!sattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
+      sattr = true;
+    }
+    hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
+                       reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                       &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                       GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], 0u, soa_hi_mask}, (u64 *)nullptr);
+  }
   else if (msd)
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,

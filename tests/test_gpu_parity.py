@@ -1389,7 +1389,7 @@ _GRID_SWITCHES = {
     "MGC_NARROW": ["0"], "MGC_FINE_HIST": ["0"], "MGC_WIDE_MSD": ["0"], "MGC_GROUP_LOCAL": ["1"], "MGC_PARTITION_WC": ["1"],
     "MGC_FINISH_BITMAP": ["1"], "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"],
     "MGC_FINISH_TARGET": ["1", "4", "64", "700"], "MGC_FINISH_MIN_TOP": ["10", "14", "17", "18"], "MGC_STREAM_MAX": ["2000", "20000"],
-    "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"],
+    "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"], "MGC_HASH64M": ["0"],
 }
 
 
