@@ -268,6 +268,9 @@ def e2e_run(bases, reads, threads, gpus=1):
                "command": " ".join(["meryl"] + cmd[1:-4] + ["count", "reads.fq", "output", "out.meryl"])}
         if os.environ.get("MGC_IO_TRACE"):
             out["io_trace"] = [l for l in p.stderr.splitlines() if l.startswith("[io]")]
+        m = re.search(r"count on the device: ([0-9.]+) ms", p.stderr)
+        if m:
+            out["count_on_device_s"] = float(m.group(1)) / 1e3
         m = re.search(r"TIMING(.*)", p.stderr)
         if m:
             for name, val in re.findall(r"([a-z+_]+)=([0-9.]+)", m.group(1)):

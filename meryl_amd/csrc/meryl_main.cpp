@@ -424,6 +424,7 @@ int run_count(const Globals &g, const Operation &op) {
   total_bases = load_inputs(s, pieces, (int)std::min<uint32_t>(g.threads, 16));
 
   const auto t_loaded = std::chrono::steady_clock::now();
+  if (g.verbosity > 2) (void)mgc_set_profiling(s, 1);           // -V: the device's own clock of the count beside the wall clock
   if (mgc_count(s) != MGC_OK) die("ERROR: %s", mgc_last_error(s));
   const auto t_counted = std::chrono::steady_clock::now();
   mgc_result_info info;
@@ -451,6 +452,10 @@ int run_count(const Globals &g, const Operation &op) {
   }
   if (g.verbosity > 2) {
     mgc_profile cp;
+    if (mgc_get_profile(s, &cp) == MGC_OK && cp.total_ms > 0)
+      fprintf(stderr, "        count on the device: %.1f ms (histogram %.1f, partition %.1f, grouping passes %.1f, sub-bucket count + packing %.1f); "
+                      "the rest of count= is the host's: buffers the input did not size, the first launches, synchronisations\n",
+              cp.total_ms, cp.stage_ms[MGC_STAGE_HISTOGRAM], cp.stage_ms[MGC_STAGE_PARTITION], cp.stage_ms[MGC_STAGE_SORT], cp.stage_ms[MGC_STAGE_RLE]);
     if (mgc_get_profile(s, &cp) == MGC_OK && cp.n_batches > 1)
       fprintf(stderr, "        counted in %u batches (memory-full spills, merylOp-countThreads.C:323-379), merged on the device in %.1f ms\n",
               cp.n_batches, cp.merge_ms);

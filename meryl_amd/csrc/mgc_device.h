@@ -250,4 +250,6 @@ hipError_t launch_synth_reads(uint64_t seed, uint64_t genome_len, uint64_t first
                               uint32_t repeat_ppm, uint32_t repeat_unit, uint32_t repeat_families,
                               uint8_t *d_out, hipStream_t st);
 
+// code objects load lazily at the first launch of a kernel of their translation unit: these touch one kernel each
+hipError_t warm_kmer(); hipError_t warm_sort(); hipError_t warm_finish(); hipError_t warm_encode(); hipError_t warm_scan();
 }  // namespace mgc

@@ -316,4 +316,7 @@ hipError_t launch_value_hist(const uint32_t *d_counts, uint64_t n, uint64_t *d_h
   return hipGetLastError();
 }
 
+
+hipError_t warm_encode() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&value_hist_kernel)); }
+
 }  // namespace mgc

@@ -2902,4 +2902,7 @@ hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint3
 }
 
 
+
+hipError_t warm_finish() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&store_u64_kernel)); }
+
 }  // namespace mgc

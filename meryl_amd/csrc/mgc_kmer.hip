@@ -769,4 +769,9 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
 }
 
 
+
+// (code objects load lazily, at the first launch of any kernel of a translation unit: a fresh process pays that inside its
+// first count.  warm_*: touch one kernel per unit -- mgc_prepare's helper thread does it while the input is being read)
+hipError_t warm_kmer() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&kmer_scan_kernel)); }
+
 }  // namespace mgc

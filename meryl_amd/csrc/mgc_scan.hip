@@ -160,4 +160,6 @@ hipError_t scan_u64_min_reverse(u64 *a, uint64_t n, u64 *scratch, u64 init, hipS
 }
 
 
+
+hipError_t warm_scan() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&scan_store_total_kernel)); }
 }  // namespace mgc

@@ -1890,4 +1890,7 @@ hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key
 }
 
 
+
+hipError_t warm_sort() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&narrow_mid_kernel)); }
+
 }  // namespace mgc
