@@ -2496,7 +2496,7 @@ static u64 *hash_dbg_buffer() {
   if (on && !buf) { if (hipMalloc(&buf, 64 * 8 * sizeof(u64)) != hipSuccess) buf = nullptr; }
   return buf;
 }
-static void hash_dbg_report(hipStream_t st, uint64_t ng) {
+static void hash_dbg_report(hipStream_t st, uint64_t ng, bool multi = false) {
   u64 *buf = hash_dbg_buffer();
   static int reports = 0;
   if (!buf || reports >= 4) return;
@@ -2506,6 +2506,10 @@ static void hash_dbg_report(hipStream_t st, uint64_t ng) {
   double sum[8] = {0};
   for (int b = 0; b < 64; b++) for (int i = 0; i < 8; i++) sum[i] += (double)h[b * 8 + i];
   const double it = sum[7] > 0 ? sum[7] : 1;
+  if (multi)     // hash_count_multi_kernel's stamps: [0] table sizing, [1] insert + list append, [6] next range consumed + loads issued, [2] bin counts, [3] scan + scatter, [4] rank + store
+    fprintf(stderr, "[hash dbg multi] ng=%llu iters/block=%.1f cycles/iter: setup=%.0f insert=%.0f prefetch_advance=%.0f bin=%.0f scan+scatter=%.0f rank+store=%.0f\n",
+            (unsigned long long)ng, it / 64, sum[0] / it, sum[1] / it, sum[6] / it, sum[2] / it, sum[3] / it, sum[4] / it);
+  else
   fprintf(stderr, "[hash dbg] ng=%llu iters/block=%.1f cycles/iter: init=%.0f probe=%.0f compact=%.0f rank+store=%.0f sync=%.0f wait_next=%.0f\n",
           (unsigned long long)ng, it / 64, sum[0] / it, sum[1] / it, sum[2] / it, sum[3] / it, sum[4] / it, sum[6] / it);
   reports++;
@@ -2608,7 +2612,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
 #undef MGC_MULTI_LAUNCH
 #undef MGC_MULTI_LAUNCH_
       MGC_CHECK(hipGetLastError());
-      if (dbgb && multi_r == 2) hash_dbg_report(st, ng);
+      if (dbgb && multi_r == 2) hash_dbg_report(st, ng, true);
       // the sub-buckets of ranges above the table (retry list, usually empty): one at a time
       { const uint32_t rgrid = ng < 256u * 7u ? (uint32_t)ng : 256u * 7u;
         hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, true, true>), dim3(rgrid), dim3(256), 0, st,
