@@ -316,13 +316,16 @@ def roofline_object(prof_acc, ms_per_step, steps, reads, single, where):
     if bp[0]["launches"]:
         # A file's FIRST grouping pass.  Algorithmic bytes = key bytes it must read and write: 8 + 8 per k-mer for the wide pass,
         # 8 + 4 when the pass narrows its output to 32-bit words (k <= ~25: the digit a key was grouped by is dropped, the second
-        # pass then moves 4 + 4) -- the library reports them per launch.
+        # pass then moves 4 + 4), 5 + 4 when the partition left the file in the 5-byte layout (k = 20..23) -- the library reports
+        # them per launch.
         achieved = bp[0]["bytes"] / (bp[0]["ms"] / 1e3) / 1e9
         narrowed = bp[0]["bytes"] < 16 * bp[0]["keys"]
         t, src = pmc_traffic(reads, "radix_group_kernel<unsigned long long") if single else (None, None)
+        per_key = bp[0]["bytes"] / max(1, bp[0]["keys"])
         sort_pass = {
             "kernel": "radix_group_kernel, first pass of a file (9-bit digit; %s)" %
-                      ("8 B k-mers in, 4 B narrowed words out" if narrowed else "8 B k-mers in and out"),
+                      (("5 B k-mers (u32 + u8 arrays per file) in, 4 B narrowed words out" if per_key < 10 else "8 B k-mers in, 4 B narrowed words out")
+                       if narrowed else "8 B k-mers in and out"),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": t, "traffic_source": src, "launches": bp[0]["launches"], "avg_launch_ms": bp[0]["ms"] / bp[0]["launches"],
             "algorithmic_bytes_per_launch": bp[0]["bytes"] / bp[0]["launches"], "keys_per_launch": bp[0]["keys"] / bp[0]["launches"],

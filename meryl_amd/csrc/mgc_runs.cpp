@@ -106,6 +106,7 @@ int mgc_runs::add(const void *d_keys, const uint32_t *d_counts, uint64_t n, hipS
   int rc = setup();
   if (rc != MGC_OK) return rc;
   RN_TRY(hipSetDevice(device));
+  (void)hipGetLastError();                                 // (a stale error of this thread is not this call's)
   Run r;
   r.n = n;
   // where every slice of the k-mer space begins in this run
