@@ -2613,8 +2613,9 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
 #undef MGC_MULTI_LAUNCH_
       MGC_CHECK(hipGetLastError());
       if (dbgb && multi_r == 2) hash_dbg_report(st, ng, true);
-      // the sub-buckets of ranges above the table (retry list, usually empty): one at a time
-      { const uint32_t rgrid = ng < 256u * 7u ? (uint32_t)ng : 256u * 7u;
+      // the sub-buckets of ranges above the table (retry list, usually short): one at a time.  (R = 1: a range is one sub-bucket,
+      // the list stays empty -- no launch: queued behind the other stream's persistent kernel an empty one still lasted 170 us)
+      if (multi_r > 1) { const uint32_t rgrid = ng < 256u * 7u ? (uint32_t)ng : 256u * 7u;
         hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, true, true>), dim3(rgrid), dim3(256), 0, st,
                            reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
                            d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_retry_list, reinterpret_cast<const u64 *>(d_retry_count),
