@@ -1633,9 +1633,10 @@ void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
   }
 }
 
-// hash_count64i_kernel rebuilt the way hash_count_multi_kernel was (round 4; dense grids; replaces countSingleKmers' sort +
-// run-length passes, merylCountArray.C:323-365, for suffixes of 32..58 bits: k = 28..32 and `compress`): the same
-// index-claimed table (count << 16 | index of the claiming key's staged suffix) and the same results, but
+// hash_count64i_kernel / hash_count128_kernel rebuilt the way hash_count_multi_kernel was (round 4; replaces countSingleKmers'
+// sort + run-length passes, merylCountArray.C:323-365, for suffixes that do not fit the packed 32-bit table: 8-byte keys with
+// 32..58-bit suffixes -- k = 28..32, `compress` -- and 16-byte keys, k = 33..64): the same index-claimed table
+// (count << 16 | index of the claiming key's staged suffix) and the same results, but
 //   * the claimed slots are NOTED and appended to a compact list after the insert with one LDS atomic per wave: no pass
 //     over the whole table, no workgroup scan, no compaction copy;
 //   * the bin-rank sorts the ENTRIES (count | index) by their suffix's top eight bits: the bins are scanned by one wave
@@ -1644,45 +1645,65 @@ void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
 //   * the next sub-bucket's keys, loaded a whole iteration earlier, are consumed into registers right after the insert
 //     phase, BEFORE the loads of the one after it are issued (a wait for old registers behind new loads waits for the new
 //     loads), and the bounds come by one vector load instead of scalar loads the first barrier has to drain.
-template <int BLOCK, int CAP, int SLOTS>
-__global__ __launch_bounds__(BLOCK, (CAP <= 768 ? 6 : 5))       // (seven: 72 registers and a spill -- a scratch reload waits on vmcnt like the prefetch)
-void hash_count64m_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
-                          u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u32 tr_a, u32 tr_b) {
+// KT = u64 | K128; WIDE (K128 only): the suffix needs the high word (low_bits > 64).  LIST: only the non-empty sub-buckets
+// are visited (sparse grids: `compress`) -- their numbers are prefetched one more iteration ahead than their bounds.
+template <typename KT, int BLOCK, int CAP, int SLOTS, bool WIDE, bool LIST>
+__global__ __launch_bounds__(BLOCK, (sizeof(KT) == 16 ? (CAP <= 768 ? 5 : 4) : (CAP <= 768 ? 6 : 5)))
+void hash_countw_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
+                        u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
+                        const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u32 tr_a, u32 tr_b) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % (4 * BLOCK) == 0 && CAP % BLOCK == 0 && CAP < 0xFFFF, "table geometry");
   static_assert(BLOCK == 256, "one bin per thread");
+  constexpr bool K16 = sizeof(KT) == 16;
+  static_assert(K16 || !WIDE, "WIDE is a property of 16-byte keys");
   constexpr int KPT = CAP / BLOCK;
   constexpr u32 EMPTY = 0x0000FFFFu;
-  __shared__ __attribute__((aligned(16))) u64 dk[CAP];                // staged suffixes of the sub-bucket
+  __shared__ __attribute__((aligned(16))) u64 dlo[CAP];               // staged suffixes of the sub-bucket (low words)
+  __shared__ __attribute__((aligned(16))) u64 dhi[WIDE ? CAP : 2];    //   ... high words
   __shared__ __attribute__((aligned(16))) u32 tw[SLOTS];              // instances << 16 | index of the claiming key
   __shared__ __attribute__((aligned(16))) u32 srt[CAP];               // first the claimed slots (u16 list), then the entries in bin order
-  __shared__ __attribute__((aligned(16))) u32 s_bin[2][BLOCK + 4];    // bin counts -> starts; [BLOCK] = D
+  // (the bin counters are double-buffered by iteration parity -- the idle waves of the scan phase zero the next iteration's --
+  // except where that kilobyte costs a workgroup per CU: 16-byte keys with 1536-key tables, 40 KiB; they are zeroed at the top)
+  constexpr bool DB = !(WIDE && CAP > 768);
+  __shared__ __attribute__((aligned(16))) u32 s_bin[DB ? 2 : 1][BLOCK + 4];    // bin counts -> starts; [BLOCK] = D
   __shared__ u32 s_nd;
   unsigned short *lst = reinterpret_cast<unsigned short *>(srt);
   const u32 tid = threadIdx.x, lane = tid & 63u;
   const u64 G = gridDim.x;
-  const u64 low_mask = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
+  const u64 mask_lo = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
+  const u64 mask_hi = (low_bits <= 64) ? 0ull : ((low_bits >= 128) ? ~0ull : ((1ull << (low_bits - 64)) - 1ull));
   const u32 bshift = low_bits > 8 ? low_bits - 8 : 0;
+  const u64 np = LIST ? *nz_count : ng;                               // iterations: list entries, or every sub-bucket
 
-  auto load_bvec = [&](u64 g) -> u64 {                              // lane 0: starts[g], the others: starts[g + 1]
-    if (g >= ng) return 0ull;
-    return starts[g + (lane ? 1u : 0u)];
+  auto bin_of = [&](u64 lo, u64 hi) -> u32 {                          // top eight bits of the suffix
+    if (WIDE) return bshift >= 64 ? (u32)(hi >> (bshift - 64)) : (u32)((hi << (64 - bshift)) | (lo >> bshift));   // (WIDE: bshift >= 57)
+    return (u32)(lo >> bshift);
   };
   auto rdlane64 = [&](u64 v, int l) -> u64 {
     const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
     return ((u64)hi << 32) | lo;
+  };
+  // the sub-bucket iteration Q visits (LIST: a vector load, uniform over the wave; ng: none)
+  auto load_g = [&](u64 Q) -> u32 {
+    if (Q >= np) return 0xFFFFFFFFu;
+    return LIST ? nz[Q] : (u32)Q;
+  };
+  auto load_bvec = [&](u32 g) -> u64 {                                // lane 0: starts[g], the others: starts[g + 1]
+    if (g == 0xFFFFFFFFu) return 0ull;
+    return starts[(u64)g + (lane ? 1u : 0u)];
   };
   auto unpack_bounds = [&](u64 bv, u64 &a0, u32 &n) {
     a0 = rdlane64(bv, 0);
     const u64 d = rdlane64(bv, 1) - a0;
     n = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)d;
   };
-  auto load_keys = [&](u64 a0, u32 n, u64 (&kr)[KPT]) {
+  auto load_keys = [&](u64 a0, u32 n, KT (&kr)[KPT]) {
     const bool fits = (u64)n <= max_size;
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
-      kr[j] = 0ull;
+      if constexpr (K16) { kr[j].lo = 0ull; kr[j].hi = 0ull; } else kr[j] = 0ull;
       if (fits && (u32)j * BLOCK < n) {
-        const u64 *src = keys + a0 + (u32)j * BLOCK;
+        const KT *src = keys + a0 + (u32)j * BLOCK;
         const u32 last = n - 1u - (u32)j * BLOCK;
         kr[j] = src[tid < last ? tid : last];
       }
@@ -1693,31 +1714,45 @@ void hash_count64m_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
     while (s < n + n / 4 && s < (u32)SLOTS) s <<= 1;
     return s;
   };
+  u64 klo[KPT], khi[K16 ? KPT : 1], pre_lo = 0, pre_hi = 0;           // the suffixes being counted; the k-mers' common top bits
+  KT kcur[KPT];
+  auto consume = [&]() {                                              // kcur -> klo/khi + prefix; nothing newer is in flight when its wait runs
+    if constexpr (K16) { pre_lo = kcur[0].lo & ~mask_lo; pre_hi = kcur[0].hi & ~mask_hi; }
+    else pre_lo = kcur[0] & ~mask_lo;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      if constexpr (K16) {
+        klo[j] = kcur[j].lo & mask_lo; khi[j] = kcur[j].hi & mask_hi;
+        asm volatile("" : "+v"(klo[j]) :: "memory"); asm volatile("" : "+v"(khi[j]) :: "memory");
+      } else { klo[j] = kcur[j] & mask_lo; asm volatile("" : "+v"(klo[j]) :: "memory"); }
+    }
+  };
 
   u64 P = blockIdx.x;
+  // pipeline: g of P, P+G, P+2G in scalars; gv = g of P+3G (vector register); bvec = bounds of P+2G; kcur = keys of P+G
+  u32 g0 = (u32)__builtin_amdgcn_readfirstlane((int)load_g(P)), g1 = (u32)__builtin_amdgcn_readfirstlane((int)load_g(P + G)),
+      g2 = (u32)__builtin_amdgcn_readfirstlane((int)load_g(P + 2 * G));
   u64 a0, a0n;
   u32 nc, nn;
-  u64 kcur[KPT], kk[KPT], prefix;
-  unpack_bounds(load_bvec(P), a0, nc);
+  unpack_bounds(load_bvec(g0), a0, nc);
   load_keys(a0, nc, kcur);
-  u64 bvec = load_bvec(P + G);
-  prefix = kcur[0] & ~low_mask;
-#pragma unroll
-  for (int j = 0; j < KPT; j++) { kk[j] = kcur[j] & low_mask; asm volatile("" : "+v"(kk[j]) :: "memory"); }
+  u64 bvec = load_bvec(g1);
+  consume();
   unpack_bounds(bvec, a0n, nn);
   load_keys(a0n, nn, kcur);
-  bvec = load_bvec(P + 2 * G);
+  bvec = load_bvec(g2);
+  u32 gv = load_g(P + 3 * G);
   u32 par = 0;
   u32 cleared = (u32)SLOTS;                            // tw[0, cleared) is EMPTY whenever an insert phase begins
   {
     uint4 *tw4 = reinterpret_cast<uint4 *>(tw);
     for (u32 i = tid; i < (u32)SLOTS / 4; i += BLOCK) tw4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
-    s_bin[0][tid] = 0; s_bin[1][tid] = 0;
+    s_bin[0][tid] = 0; if constexpr (DB) s_bin[1][tid] = 0;
     if (tid == 0) s_nd = 0;
   }
   __syncthreads();
 
-  while (P < ng) {
+  while (P < np) {
     const u32 n = nc;
     const bool active = n != 0 && (u64)n <= max_size;
     const u32 slots = slots_for(n);
@@ -1730,19 +1765,22 @@ void hash_count64m_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
       }
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
-        hh[j] = (u32)((kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
-        if ((u32)j * BLOCK + tid < n) dk[(u32)j * BLOCK + tid] = kk[j];
+        const u64 mix = K16 ? (klo[j] ^ (khi[K16 ? j : 0] * 0xD6E8FEB86659FD93ull)) * 0x9E3779B97F4A7C15ull : klo[j] * 0x9E3779B97F4A7C15ull;
+        hh[j] = (u32)(mix >> 32) >> sshift;
+        if ((u32)j * BLOCK + tid < n) { dlo[(u32)j * BLOCK + tid] = klo[j]; if (WIDE) dhi[(u32)j * BLOCK + tid] = khi[K16 ? j : 0]; }
       }
+      if constexpr (!DB) s_bin[0][tid] = 0;
       __syncthreads();                                 // the suffixes are staged: a probe compares with the claimer's
+      auto same = [&](u32 rep, int j) -> bool { return dlo[rep] == klo[j] && (!WIDE || dhi[rep] == khi[K16 ? j : 0]); };
       u32 won = 0, pending = 0;
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
         if ((u32)j * BLOCK < n) {
           const bool act = (u32)j * BLOCK + tid < n;
-          u32 old = 0;                                 // (index 0 with count 0: no entry looks like it)
+          u32 old = 0;
           if (act) old = atomicCAS(&tw[hh[j]], EMPTY, (1u << 16) | ((u32)j * BLOCK + tid));
           const bool w = act && old == EMPTY;
-          const bool dup = act && !w && dk[old & 0xFFFFu] == kk[j];
+          const bool dup = act && !w && same(old & 0xFFFFu, j);
           if (dup) atomicAdd(&tw[hh[j]], 1u << 16);
           won |= w ? (1u << j) : 0u;
           pending |= (act && !w && !dup) ? (1u << j) : 0u;
@@ -1755,7 +1793,7 @@ void hash_count64m_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
             hh[j] = (hh[j] + 1) & smask;
             const u32 old = atomicCAS(&tw[hh[j]], EMPTY, (1u << 16) | ((u32)j * BLOCK + tid));
             const bool w = old == EMPTY;
-            const bool dup = !w && dk[old & 0xFFFFu] == kk[j];
+            const bool dup = !w && same(old & 0xFFFFu, j);
             if (dup) atomicAdd(&tw[hh[j]], 1u << 16);
             if (w) won |= 1u << j;
             if (w || dup) pending &= ~(1u << j);
@@ -1782,17 +1820,18 @@ void hash_count64m_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
       __syncthreads();
     }
 
-    // the next sub-bucket's keys (loaded a whole iteration ago) take the place of this one's in kk[]; only then the keys of
-    // the one after it and the bounds of the one after that are issued
-    const u64 a = a0, prefix_cur = prefix;
+    // the next sub-bucket's keys (loaded a whole iteration ago) take the place of this one's in klo/khi; only then the keys of
+    // the one after it, the bounds of the one after that and (LIST) the number of the one after that are issued
+    const u64 a = a0, pre_lo_cur = pre_lo, pre_hi_cur = pre_hi;
+    const u32 g_cur = g0;
     const u32 nslots = (u64)nn <= max_size ? slots_for(nn) : 256u;
-    prefix = kcur[0] & ~low_mask;
-#pragma unroll
-    for (int j = 0; j < KPT; j++) { kk[j] = kcur[j] & low_mask; asm volatile("" : "+v"(kk[j]) :: "memory"); }
+    consume();
     a0 = a0n; nc = nn;
+    g0 = g1; g1 = g2; g2 = (u32)__builtin_amdgcn_readfirstlane((int)gv);
     unpack_bounds(bvec, a0n, nn);
     load_keys(a0n, nn, kcur);
-    bvec = load_bvec(P + 3 * G);
+    bvec = load_bvec(g2);
+    gv = load_g(P + 4 * G);
 
     if (active) {
       const u32 D = s_nd;
@@ -1802,7 +1841,11 @@ void hash_count64m_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
         wq[q] = 0; li[q] = 0;
         if ((u32)q * BLOCK < D) {
           const u32 i = (u32)q * BLOCK + tid;
-          if (i < D) { wq[q] = tw[lst[i]]; li[q] = atomicAdd(&s_bin[par][(u32)(dk[wq[q] & 0xFFFFu] >> bshift)], 1u); }
+          if (i < D) {
+            wq[q] = tw[lst[i]];
+            const u32 rep = wq[q] & 0xFFFFu;
+            li[q] = atomicAdd(&s_bin[par][bin_of(dlo[rep], WIDE ? dhi[rep] : 0ull)], 1u);
+          }
         }
       }
       __syncthreads();
@@ -1818,7 +1861,7 @@ void hash_count64m_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
       } else {                                         // ... the other three clear what the next insert phase uses
         uint4 *tw4 = reinterpret_cast<uint4 *>(tw);
         for (u32 i = tid - 64; i < nslots / 4; i += BLOCK - 64) tw4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
-        for (u32 i = tid - 64; i < BLOCK; i += BLOCK - 64) s_bin[par ^ 1u][i] = 0;
+        if constexpr (DB) for (u32 i = tid - 64; i < BLOCK; i += BLOCK - 64) s_bin[par ^ 1u][i] = 0;
         if (tid == 64) s_nd = 0;
       }
       cleared = nslots;
@@ -1827,28 +1870,33 @@ void hash_count64m_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts
       for (int q = 0; q < KPT; q++) {
         if ((u32)q * BLOCK < D) {
           const u32 i = (u32)q * BLOCK + tid;
-          if (i < D) srt[s_bin[par][(u32)(dk[wq[q] & 0xFFFFu] >> bshift)] + li[q]] = wq[q];
+          if (i < D) { const u32 rep = wq[q] & 0xFFFFu; srt[s_bin[par][bin_of(dlo[rep], WIDE ? dhi[rep] : 0ull)] + li[q]] = wq[q]; }
         }
       }
       __syncthreads();
       // rank inside the bin, then back in place (every key of this region is staged in LDS)
       const u32 *sb = s_bin[par];
-      u64 *gk = keys + a;
+      KT *gk = keys + a;
       u32 *cout = cnt_tmp + a;
       for (u32 p = tid; p < D; p += BLOCK) {
-        const u32 w = srt[p];
-        const u64 ki = dk[w & 0xFFFFu];
-        const u32 b = (u32)(ki >> bshift), lo = sb[b], hi = sb[b + 1];
+        const u32 w = srt[p], rep = w & 0xFFFFu;
+        const u64 kl = dlo[rep], kh = WIDE ? dhi[rep] : 0ull;
+        const u32 b = bin_of(kl, kh), lo = sb[b], hi = sb[b + 1];
         u32 r = lo;
-        for (u32 q = lo; q < hi; q++) r += (dk[srt[q] & 0xFFFFu] < ki) ? 1u : 0u;
-        gk[r] = prefix_cur | ki;
+        for (u32 q = lo; q < hi; q++) {
+          const u32 rq = srt[q] & 0xFFFFu;
+          const u64 ql = dlo[rq], qh = WIDE ? dhi[rq] : 0ull;
+          r += ((WIDE && qh < kh) || ((!WIDE || qh == kh) && ql < kl)) ? 1u : 0u;
+        }
+        if constexpr (K16) { KT o; o.lo = pre_lo_cur | kl; o.hi = pre_hi_cur | kh; gk[r] = o; }
+        else gk[r] = pre_lo_cur | kl;
         cout[r] = w >> 16;
       }
-      if (tid == 0) group_distinct[tr_index(P, tr_a, tr_b)] = D;
-      par ^= 1u;
-      __syncthreads();                                 // dk and the list are rewritten by the next sub-bucket
-    } else if (tid == 0 && n == 0) {
-      group_distinct[tr_index(P, tr_a, tr_b)] = 0;     // (larger than max_size: the streaming launch owns it)
+      if (tid == 0) group_distinct[tr_index(g_cur, tr_a, tr_b)] = D;
+      if constexpr (DB) par ^= 1u;
+      __syncthreads();                                 // the staged suffixes and the list are rewritten by the next sub-bucket
+    } else if (tid == 0 && n == 0 && g_cur != 0xFFFFFFFFu) {
+      group_distinct[tr_index(g_cur, tr_a, tr_b)] = 0; // (larger than max_size: the streaming launch owns it)
     }
     P += G;
   }
@@ -2673,6 +2721,24 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                        d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b)
 #define MGC_H128_LAUNCH(CAP_, SLOTS_, WIDE_, GRID_) do { if (binrank128) MGC_H128_LAUNCH_(CAP_, SLOTS_, WIDE_, GRID_, true);              \
                                                          else            MGC_H128_LAUNCH_(CAP_, SLOTS_, WIDE_, GRID_, false); } while (0)
+    const char *m128 = getenv("MGC_HASH128M");                       // read per call: the tests switch it
+    if (!(m128 && m128[0] == '0') && binrank128) {                  // round 4: hash_countw_kernel (noted claims, sorted entries, prefetch consumed first)
+#define MGC_W128_LAUNCH(CAP_, SLOTS_, WIDE_, LIST_, GRID_)                                                                               \
+      hipLaunchKernelGGL((hash_countw_kernel<K128, 256, CAP_, SLOTS_, WIDE_, LIST_>), dim3(GRID_), dim3(256), 0, st,                     \
+                         reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, msize, low_bits,            \
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b)
+      const uint32_t g128_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * (small ? 12u : 8u);
+      const uint32_t g128 = ng < g128_max ? (uint32_t)ng : g128_max;
+      const bool lst128 = d_nz != nullptr, wide128 = low_bits > 64;
+      if (small) {
+        if (wide128) { if (lst128) MGC_W128_LAUNCH(768, 1024, true, true, g128);  else MGC_W128_LAUNCH(768, 1024, true, false, g128); }
+        else         { if (lst128) MGC_W128_LAUNCH(768, 1024, false, true, g128); else MGC_W128_LAUNCH(768, 1024, false, false, g128); }
+      } else {
+        if (wide128) { if (lst128) MGC_W128_LAUNCH(1536, 2048, true, true, g128);  else MGC_W128_LAUNCH(1536, 2048, true, false, g128); }
+        else         { if (lst128) MGC_W128_LAUNCH(1536, 2048, false, true, g128); else MGC_W128_LAUNCH(1536, 2048, false, false, g128); }
+      }
+#undef MGC_W128_LAUNCH
+    } else
     if (small) {
       // no sub-bucket above 768 k-mers: three keys per thread instead of six -- fewer idle unrolled slots, half the registers and
       // LDS, six workgroups per CU instead of four
@@ -2736,20 +2802,21 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       // each): three keys per thread instead of six -- fewer idle unrolled slots, half the LDS, seven workgroups per CU
       static const bool small64 = !(getenv("MGC_HASH64_SMALL") && getenv("MGC_HASH64_SMALL")[0] == '0');
       const char *m64 = getenv("MGC_HASH64M");                       // read per call: the tests switch it
-      const bool use_64m = !(m64 && m64[0] == '0') && !use_list && binrank64 && low_bits <= 58;
+      const bool use_64m = !(m64 && m64[0] == '0') && binrank64 && low_bits <= 58;
+#define MGC_W64_LAUNCH(CAP_, SLOTS_, LIST_, GRID_, MS_)                                                                                  \
+      hipLaunchKernelGGL((hash_countw_kernel<u64, 256, CAP_, SLOTS_, false, LIST_>), dim3(GRID_), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys), \
+                         reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)(MS_), low_bits, d_cnt_tmp,                             \
+                         reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b)
       if (use_64m && small64 && max_sub && max_sub <= 768 && n_large == 0) {
         static const uint32_t sgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 12u;
         const uint32_t sgrid = ng < sgrid_max ? (uint32_t)ng : sgrid_max;
-        hipLaunchKernelGGL((hash_count64m_kernel<256, 768, 1024>), dim3(sgrid), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys),
-                           reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)768, low_bits, d_cnt_tmp,
-                           reinterpret_cast<u64 *>(d_group_distinct), tr_a, tr_b);
+        if (use_list) MGC_W64_LAUNCH(768, 1024, true, sgrid, 768); else MGC_W64_LAUNCH(768, 1024, false, sgrid, 768);
       } else if (use_64m) {
         static const uint32_t mgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 10u;
         const uint32_t mgrid = ng < mgrid_max ? (uint32_t)ng : mgrid_max;
-        hipLaunchKernelGGL((hash_count64m_kernel<256, (int)FIN_CAP_HASH, 2048>), dim3(mgrid), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys),
-                           reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp,
-                           reinterpret_cast<u64 *>(d_group_distinct), tr_a, tr_b);
+        if (use_list) MGC_W64_LAUNCH((int)FIN_CAP_HASH, 2048, true, mgrid, FIN_CAP_HASH); else MGC_W64_LAUNCH((int)FIN_CAP_HASH, 2048, false, mgrid, FIN_CAP_HASH);
       } else
+#undef MGC_W64_LAUNCH
       if (small64 && binrank64 && max_sub && max_sub <= 768 && n_large == 0) {
         static const uint32_t sgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 7u;
         const uint32_t sgrid = ng < sgrid_max ? (uint32_t)ng : sgrid_max;

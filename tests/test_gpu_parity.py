@@ -1349,17 +1349,21 @@ def test_hash_count_multi_subbuckets_per_iteration(ops, oracle_lib, torch_cuda, 
         assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
 
 
-@pytest.mark.parametrize("m64", ["1", "0"])
-@pytest.mark.parametrize("k,compress,min_top", [(28, 0, 14), (31, 0, 16), (32, 0, 12), (31, 1, None), (30, 0, 18)])
-def test_hash_count64m_dense_grids(ops, oracle_lib, torch_cuda, monkeypatch, k, compress, min_top, m64):
-    """hash_count64m_kernel (round 4: the 64-bit-suffix count rebuilt like hash_count_multi_kernel -- noted claims, entries
-    sorted by bin, prefetch consumed before the next loads) on the dense-grid launch (MGC_FINISH_NOLIST on a small input),
-    both instantiations (sub-buckets up to 768 / 1536 keys), against the one it replaces (MGC_HASH64M=0) and the oracle:
-    clusters of 1 .. 1536 keys with 1 .. all-distinct suffixes, more distinct suffixes than threads (low coverage), an
-    oversized one for the streaming launch."""
+@pytest.mark.parametrize("m64,nolist", [("1", "1"), ("1", "0"), ("0", "1")])
+@pytest.mark.parametrize("k,compress,min_top", [(28, 0, 14), (31, 0, 16), (32, 0, 12), (31, 1, None), (30, 0, 18),
+                                                (33, 0, 14), (40, 0, 16), (51, 0, 12), (64, 0, 18), (51, 1, None)])
+def test_hash_countw_kernel_dense_and_sparse_grids(ops, oracle_lib, torch_cuda, monkeypatch, k, compress, min_top, m64, nolist):
+    """hash_countw_kernel (round 4: the index-claimed count of 64-bit suffixes and of 16-byte keys rebuilt like
+    hash_count_multi_kernel -- noted claims, entries sorted by bin, prefetch consumed before the next loads) on the dense-grid
+    launch (MGC_FINISH_NOLIST on a small input) and on the sparse one (the list of non-empty sub-buckets, their numbers
+    prefetched one iteration further ahead), every instantiation (8- / 16-byte keys, suffix within 64 bits / wider, sub-buckets
+    up to 768 / 1536 keys), against the kernels it replaces (MGC_HASH64M=0 / MGC_HASH128M=0) and the oracle: clusters of
+    1 .. 1536 keys with 1 .. all-distinct suffixes, more distinct suffixes than threads (low coverage), an oversized one for
+    the streaming launch."""
     from meryl_amd import capi
-    monkeypatch.setenv("MGC_FINISH_NOLIST", "1")
+    monkeypatch.setenv("MGC_FINISH_NOLIST", nolist)
     monkeypatch.setenv("MGC_HASH64M", m64)
+    monkeypatch.setenv("MGC_HASH128M", m64)
     if min_top is not None:
         monkeypatch.setenv("MGC_FINISH_MIN_TOP", str(min_top))
     rng = np.random.default_rng(k * 7 + (min_top or 0))
@@ -1389,7 +1393,7 @@ _GRID_SWITCHES = {
     "MGC_NARROW": ["0"], "MGC_FINE_HIST": ["0"], "MGC_WIDE_MSD": ["0"], "MGC_GROUP_LOCAL": ["1"], "MGC_PARTITION_WC": ["1"],
     "MGC_FINISH_BITMAP": ["1"], "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"],
     "MGC_FINISH_TARGET": ["1", "4", "64", "700"], "MGC_FINISH_MIN_TOP": ["10", "14", "17", "18"], "MGC_STREAM_MAX": ["2000", "20000"],
-    "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"], "MGC_HASH64M": ["0"],
+    "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"], "MGC_HASH64M": ["0"], "MGC_HASH128M": ["0"],
 }
 
 
