@@ -274,18 +274,26 @@ extern "C" const char *msr_last_error(void) { return g_seq_error.c_str(); }
 extern "C" msr_reader *msr_open(const char *name) {
   if (!name || !*name) { seq_err("msr_open: empty file name"); return nullptr; }
   const std::string n(name);
-  if (ends_with(n, ".cram")) { seq_err("msr_open: '" + n + "': CRAM input is not supported (convert to BAM)"); return nullptr; }
+  // CRAM (README.md:11 of the reference names it; its htslib call sites are in the absent submodule): decoded by `samtools view`
+  // when that binary is on the PATH -- the records arrive as SAM text and take the SAM path (SEQ of every record as stored) --
+  // and refused with a message otherwise
+  const bool cram = ends_with(n, ".cram");
+  if (cram && system("command -v samtools > /dev/null 2>&1") != 0) {
+    seq_err("msr_open: '" + n + "': CRAM input is not supported without `samtools` on the PATH (it is decoded through `samtools view`); convert to BAM");
+    return nullptr;
+  }
   msr_reader *r = new msr_reader();
   r->name = n;
-  r->compressed = ends_with(n, ".gz") || ends_with(n, ".bam") || ends_with(n, ".bz2") || ends_with(n, ".xz");
+  r->compressed = ends_with(n, ".gz") || ends_with(n, ".bam") || ends_with(n, ".bz2") || ends_with(n, ".xz") || cram;
   r->buf = (unsigned char *)malloc(r->cap);
-  if (ends_with(n, ".bz2") || ends_with(n, ".xz")) {          // through the system's decompressor
+  if (ends_with(n, ".bz2") || ends_with(n, ".xz") || cram) {  // through the system's decompressor / decoder
     struct stat st;
     if (stat(name, &st) != 0) { seq_err("msr_open: cannot open '" + n + "': " + strerror(errno)); msr_close(r); return nullptr; }
     std::string quoted = "'";
     for (char c : n) { if (c == '\'') quoted += "'\\''"; else quoted += c; }
     quoted += "'";
-    const std::string cmd = std::string(ends_with(n, ".bz2") ? "bzip2" : "xz") + " -dc -- " + quoted;
+    const std::string cmd = cram ? "samtools view -h -- " + quoted
+                                 : std::string(ends_with(n, ".bz2") ? "bzip2" : "xz") + " -dc -- " + quoted;
     r->pipe = popen(cmd.c_str(), "r");
     if (!r->pipe) { seq_err("msr_open: cannot run '" + cmd + "': " + strerror(errno)); msr_close(r); return nullptr; }
   }
@@ -315,7 +323,7 @@ extern "C" msr_reader *msr_open(const char *name) {
   if (r->failed) { seq_err("msr_open: '" + n + "': " + r->failure); msr_close(r); return nullptr; }
   const size_t have = r->len - r->pos;
   if (have >= 4 && memcmp(r->buf + r->pos, "BAM\1", 4) == 0) r->format = MSR_FORMAT_BAM;
-  else if (ends_with(n, ".sam") || ends_with(n, ".sam.gz") || (have >= 4 && memcmp(r->buf + r->pos, "@HD\t", 4) == 0)) r->format = MSR_FORMAT_SAM;
+  else if (cram || ends_with(n, ".sam") || ends_with(n, ".sam.gz") || (have >= 4 && memcmp(r->buf + r->pos, "@HD\t", 4) == 0)) r->format = MSR_FORMAT_SAM;
   else if (ends_with(n, ".bam")) { seq_err("msr_open: '" + n + "' is not a BAM file (no BAM magic)"); msr_close(r); return nullptr; }
   return r;
 }

@@ -57,8 +57,8 @@ def test_reader_errors_and_guess(native_lib, tmp_path):
     assert b"cannot open" in native_lib.msr_last_error()
     assert not native_lib.msr_open(b"reads.fq.bz2")                          # no such file
     assert b"cannot open" in native_lib.msr_last_error()
-    assert not native_lib.msr_open(b"reads.cram")
-    assert b"not supported" in native_lib.msr_last_error()
+    assert not native_lib.msr_open(b"reads.cram")                            # no samtools on the PATH (or no such file)
+    assert b"CRAM" in native_lib.msr_last_error() or b"cannot open" in native_lib.msr_last_error()
     bad = tmp_path / "bad.txt"
     bad.write_text("hello\n")
     r = native_lib.msr_open(str(bad).encode())
@@ -128,3 +128,26 @@ def test_damaged_compressed_inputs_are_errors_not_short_files(native_lib, tmp_pa
         bad.write_bytes(bytes(raw))
         seqs, rc = _drain(native_lib, str(bad))
         assert rc < 0 and b"bad.fa.bz2" in native_lib.msr_last_error()
+
+
+def test_cram_goes_through_samtools_view_when_it_is_there(native_lib, tmp_path, monkeypatch):
+    """CRAM: decoded by `samtools view -h` when the binary exists -- a stand-in script on the
+    PATH plays it here (the image has no samtools) and prints SAM records, which take the SAM path: SEQ of every record as stored."""
+    import os
+    import stat
+    fake = tmp_path / "bin"
+    fake.mkdir()
+    tool = fake / "samtools"
+    tool.write_text("#!/bin/sh\n[ \"$1\" = view ] || exit 2\nprintf '@HD\\tVN:1.6\\n@SQ\\tSN:c\\tLN:100\\n'\n"
+                    "printf 'r1\\t0\\tc\\t1\\t60\\t8M\\t*\\t0\\t0\\tACGTACGT\\tIIIIIIII\\n'\n"
+                    "printf 'r2\\t4\\t*\\t0\\t0\\t*\\t*\\t0\\t0\\t*\\t*\\n'\n"
+                    "printf 'r3\\t16\\tc\\t9\\t60\\t5M\\t*\\t0\\t0\\tGGNCC\\tIIIII\\n'\n")
+    tool.chmod(tool.stat().st_mode | stat.S_IXUSR | stat.S_IXGRP | stat.S_IXOTH)
+    cram = tmp_path / "reads.cram"
+    cram.write_bytes(b"CRAM\x03\x00 not a real container: the stand-in never reads it")
+    monkeypatch.setenv("PATH", str(fake) + os.pathsep + os.environ.get("PATH", ""))
+    assert load_all(native_lib, str(cram), 64) == [b"ACGTACGT", b"", b"GGNCC"]     # (an absent SEQ is an empty sequence, as for SAM / BAM)
+    # without the binary: refused, and the message says why
+    monkeypatch.setenv("PATH", str(tmp_path / "nowhere"))
+    assert not native_lib.msr_open(str(cram).encode())
+    assert b"samtools" in native_lib.msr_last_error() and b"CRAM" in native_lib.msr_last_error()
