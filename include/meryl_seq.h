@@ -15,7 +15,8 @@
  * SEQ as stored, no record filtered by its flags -- which records the reference
  * keeps is decided inside the absent submodule, so that choice is unpinned.
  * .bz2 and .xz go through `bzip2 -dc` / `xz -dc` pipes.  CRAM (needs the reference
- * genome and htslib's codecs) is refused by msr_open with a message.
+ * genome and htslib's codecs) goes through a `samtools view -h` pipe and the SAM path
+ * when that binary is on the PATH; without it msr_open refuses the file with a message.
  */
 #ifndef MERYL_SEQ_H
 #define MERYL_SEQ_H

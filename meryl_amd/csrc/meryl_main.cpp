@@ -10,7 +10,7 @@
 // databases it writes.  Beyond the count path: `histogram`, `dumpFile`, the set operations over
 // databases (union[-min|-max|-sum], intersect[-min|-max|-sum], subtract, difference, symmetric-difference;
 // merylOp-nextMer.C:559-613) and the single-input value filters / arithmetic (less-than ... modulo; :490-557), all merged on
-// the device.  What stays refused: statistics, compare, ploidy, Canu sequence stores (segment=), CRAM.
+// the device.  What stays refused: statistics, compare, ploidy, Canu sequence stores (segment=); CRAM only when no `samtools` is on the PATH.
 #include "../../include/meryl_db.h"
 #include "../../include/meryl_gpu_count.h"
 #include "../../include/meryl_seq.h"
