@@ -696,9 +696,7 @@ template <> struct GroupOut<u64, true> { typedef u32 type; };
 // HIST2: the pass also takes the histogram of ANOTHER digit (the next pass's) of the keys it reads -- 512 LDS counters per
 // workgroup, flushed with global atomics at the end -- so that nobody has to read the keys for it.
 struct GroupExtra { u32 digit_bits /* NARROW */; u32 shift2, mask2; u64 *ghist2 /* HIST2 */;
-                    u32 dbg = 0 /* MGC_GROUP_RD (measurements only, WRONG results): 1 = the tile fetch reads 4 of every key's 8 bytes */;
                     u32 soa_hi_mask = 0 /* SOA: payload bits of the u8 array */; };
-static u32 group_dbg_flags() { const char *e = getenv("MGC_GROUP_RD"); return (e && *e) ? (u32)atoi(e) : 0u; }
 
 // SOA (u64 keys): `in` is the 5-byte layout kmer_partition_kernel<SOA> leaves -- u32 in[n] low words, then u8[n] bits 32..39 --
 // and a key is put together as it is fetched: four keys per lane and group from one 16-byte and one 4-byte load.
@@ -792,13 +790,6 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
 #pragma unroll
     for (int g = 0; g < KPT / VEC; g++) {
       const u32 first = idx_of(g * VEC);
-      if constexpr (sizeof(K) == 8) if (ex.dbg & 1u) {     // (what a 5-byte key layout could buy on the read side: half the bytes fetched)
-        struct __attribute__((aligned(4))) HVec { u32 v[VEC]; };
-        const HVec h = *reinterpret_cast<const HVec *>(reinterpret_cast<const u32 *>(base) + first);
-#pragma unroll
-        for (int c = 0; c < VEC; c++) keys[g * VEC + c] = (K)h.v[c] * 0x100000001ull;
-        continue;
-      }
       if (nv == (u32)TILE || first + (u32)VEC <= nv) {
         const KVec q = *reinterpret_cast<const KVec *>(base + first);
 #pragma unroll
@@ -1669,13 +1660,13 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                        &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
-                       GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], 0u, soa_hi_mask}, (u64 *)nullptr);
+                       GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask}, (u64 *)nullptr);
   }
   else if (msd)
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                        &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
-                       GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], group_dbg_flags()}, (u64 *)nullptr);
+                       GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0]}, (u64 *)nullptr);
   else
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, false>), grid0, dim3(BLOCK), GS0::BYTES, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
