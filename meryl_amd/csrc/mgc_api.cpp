@@ -1158,6 +1158,10 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   bool partition_done = false;
   auto run_partition = [&](bool soa) -> int {
     if (ext_keys || partition_done) return MGC_OK;
+    if (getenv("MGC_PART_DBG")) {                            // (its k-mers are garbage by design: only the bare partition operator may run it)
+      set_err(&s->err, "MGC_PART_DBG is a measurement-only form of the partition (scripts/part_dbg.py): unset it to count");
+      return MGC_EINVAL;
+    }
     partition_done = true;
     HIP_TRY(s, hipMemcpyAsync(d_starts, h_starts, sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
     tm.begin(MGC_STAGE_PARTITION);
