@@ -454,6 +454,9 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
 
   for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] = block_base[(u64)blockIdx.x * nb + b];
   __shared__ u64 s_fstart[SOA ? MAXB : 1], s_fhi[SOA ? MAXB : 1];   // SOA: first k-mer of the file; byte offset of its u8 array
+  // where tile position 0 WOULD go for every bucket (bucket's cursor minus its first tile position), as byte addresses: a
+  // k-mer at tile position i of bucket b goes to s_ob[b] + i * (bytes per k-mer) -- one LDS read and one add per store
+  __shared__ u64 s_ob[MAXB], s_ob_hi[SOA ? MAXB : 1];
   if constexpr (SOA) {
     for (u32 b = tid; b < nb; b += KP_BLOCK) { s_fstart[b] = soa_starts[b]; s_fhi[b] = 8ull * soa_starts[b] + 4ull * soa_counts[b]; }
   }
@@ -478,7 +481,7 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
 #pragma unroll
       for (int j = 0; j < KP_ITEMS; j++)
         if ((vmask >> j) & 1u) s_keys[o++] = keys[j];
-      if (tid == 0) { s_base[0] = 0; s_cnt[0] = total; }
+      if (tid == 0) { s_base[0] = 0; s_cnt[0] = total; s_ob[0] = reinterpret_cast<u64>(out) + (u64)sizeof(K) * s_cursor[0]; }
       __syncthreads();
     } else {
       // rank inside the bucket with LDS atomics (order inside a bucket is free)
@@ -501,7 +504,16 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const u32 b = tid * 4 + q;
-        if (b < nb) s_base[b] = run;
+        if (b < nb) {
+          s_base[b] = run;
+          if constexpr (SOA && sizeof(K) == 8) {
+            const u64 rel0 = s_cursor[b] - s_fstart[b] - (u64)run;             // (wraps below zero when run > what lies before: added back with i)
+            s_ob[b]    = reinterpret_cast<u64>(out) + 8ull * s_fstart[b] + 4ull * rel0;
+            s_ob_hi[b] = reinterpret_cast<u64>(out) + s_fhi[b] + rel0;
+          } else {
+            s_ob[b] = reinterpret_cast<u64>(out) + (u64)sizeof(K) * (s_cursor[b] - (u64)run);
+          }
+        }
         run += v[q];
       }
       __syncthreads();
@@ -519,13 +531,12 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
         // (the high bytes four at a time -- a quad of consecutive tile positions lies in one file except where two files
         // meet: one unaligned 4-byte store instead of four byte stores -- measured SLOWER: 28.4 ms against 25.2, the
         // hardware splits a byte-aligned dword store anyway and the quad loop reads the tile from LDS once more)
-        const u64 rel = s_cursor[b] + (u64)(i - s_base[b]) - s_fstart[b];
-        reinterpret_cast<u32 *>(out + s_fstart[b])[rel] = (u32)KeyOps<K>::low64(key);
-        reinterpret_cast<uint8_t *>(out)[s_fhi[b] + rel] = (uint8_t)(KeyOps<K>::low64(key) >> 32);
+        *reinterpret_cast<u32 *>(s_ob[b] + 4ull * i) = (u32)KeyOps<K>::low64(key);
+        *reinterpret_cast<uint8_t *>(s_ob_hi[b] + (u64)i) = (uint8_t)(KeyOps<K>::low64(key) >> 32);
       }
       else if constexpr (DBG == 1 && sizeof(K) == 8) reinterpret_cast<u32 *>(out)[s_cursor[b] + (u64)(i - s_base[b])] = (u32)key;
       else if constexpr (DBG == 2) { if (KeyOps<K>::low64(key) == 0x123456789ABCDEFull) out[0] = key; }
-      else out[s_cursor[b] + (u64)(i - s_base[b])] = key;
+      else *reinterpret_cast<K *>(s_ob[b] + (u64)sizeof(K) * i) = key;
     }
     __syncthreads();
     for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] += s_cnt[b];
