@@ -418,6 +418,8 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_in, hipStreamNonBlocking);
   if (e != hipSuccess) { set_err(nullptr, "hipStreamCreate: %s", hipGetErrorString(e)); delete s; return nullptr; }
   if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&s->stream3, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_join2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
     set_err(nullptr, "hipStreamCreate / hipEventCreate failed"); mgc_close(s); return nullptr;
@@ -455,6 +457,9 @@ extern "C" void mgc_close(mgc_session *s) {
   if (s->st_in) (void)hipStreamDestroy(s->st_in);
   for (hipEvent_t e : s->hist_ev) if (e) (void)hipEventDestroy(e);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  if (s->ev_join2) (void)hipEventDestroy(s->ev_join2);
+  if (s->stream3) (void)hipStreamDestroy(s->stream3);
+  if (s->h_stats) (void)hipHostFree(s->h_stats);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -1264,23 +1269,25 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     }
     const uint64_t ng_total = gbase[nb];
     HIP_TRY(s, s->ensure(mgc_session::B_SUBSTART, sizeof(uint64_t) * (sbase[nb] + 1)));
-    HIP_TRY(s, s->ensure(mgc_session::B_GROUPS, sizeof(uint64_t) * (ng_total + 2 + 2 * (uint64_t)nb)));
+    HIP_TRY(s, s->ensure(mgc_session::B_GROUPS, sizeof(uint64_t) * (ng_total + 2 + 3 * (uint64_t)nb)));
     HIP_TRY(s, s->ensure(mgc_session::B_LARGE, sizeof(uint32_t) * (ng_total + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_NONEMPTY, sizeof(uint32_t) * (ng_total + 1) + sizeof(uint64_t) * 2 * ((uint64_t)nb + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_GSCAN, mgc::finish_scan_scratch_bytes(ng_total + 1)));
     HIP_TRY(s, s->ensure(mgc_session::B_RLE_WS, mgc::rle_workspace_bytes(max_bucket)));
     uint64_t *d_substart = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_SUBSTART].p);
-    uint64_t *d_group    = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_GROUPS].p);   // [ng_total+1], then max_sub[64]
-    uint64_t *d_maxsub   = d_group + ng_total + 1;                  // [64] largest sub-bucket, then [64] number of large ones
-    uint64_t *d_nlarge   = d_maxsub + nb;
+    uint64_t *d_group    = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_GROUPS].p);   // [ng_total+1], then the files' statistics
+    // per file, three words side by side (one small copy brings a file's back): [0] its largest sub-bucket, [1] how many are
+    // above the persistent kernels' capacity, [2] how many are not empty
+    uint64_t *d_stats    = d_group + ng_total + 1;
+    auto d_maxsub  = [&](uint32_t b) { return d_stats + 3 * (size_t)b; };
+    auto d_nlarge  = [&](uint32_t b) { return d_stats + 3 * (size_t)b + 1; };
+    auto d_nzcount = [&](uint32_t b) { return d_stats + 3 * (size_t)b + 2; };
     uint32_t *d_large    = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_LARGE].p);
-    uint64_t *d_nzcount  = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_NONEMPTY].p);           // [nb]
-    uint64_t *d_retrycnt = d_nzcount + nb + 1;                                                        // [nb] hash_count_multi_kernel's retry lists
+    uint64_t *d_retrycnt = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_NONEMPTY].p) + nb + 1;  // [nb] hash_count_multi_kernel's retry lists
     uint32_t *d_nz       = reinterpret_cast<uint32_t *>(d_retrycnt + nb + 1);                         // [ng_total] (a dense file's part: its retry list)
-    HIP_TRY(s, hipMemsetAsync(d_nzcount, 0, sizeof(uint64_t) * 2 * ((size_t)nb + 1), st));
-    HIP_TRY(s, hipMemsetAsync(d_group, 0, sizeof(uint64_t) * (ng_total + 1), st));                     // empty sub-buckets stay 0
+    HIP_TRY(s, hipMemsetAsync(s->buf[mgc_session::B_NONEMPTY].p, 0, sizeof(uint64_t) * 2 * ((size_t)nb + 1), st));
+    HIP_TRY(s, hipMemsetAsync(d_group, 0, sizeof(uint64_t) * (ng_total + 1 + 3 * (size_t)nb), st));   // empty sub-buckets stay 0
     void     *rle_ws     = s->buf[mgc_session::B_RLE_WS].p;
-    HIP_TRY(s, hipMemsetAsync(d_maxsub, 0, sizeof(uint64_t) * 2 * nb, st));
 
     // ---- A. global LSB passes on the top bits only ----
     // the finish only needs the file grouped by its top bits (MGC_GROUP=0: full stable passes)
@@ -1408,13 +1415,43 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         prepared[b] = 1;
       }
     }
-    for (uint32_t b = 0; b < nb; b++) {
-      if (h_counts[b] == 0 || top_bits[b] == 0) continue;
+    // Stage after stage (default), or pipelined (MGC_PIPE=1): the passes of all files go to the session stream back to back and a
+    // file's count kernel starts on a second / third stream as soon as its statistics are back (one 24-byte copy and an event
+    // per file), beside the grouping passes of the files after it; the host stays PIPE_AHEAD files ahead with the passes.  What
+    // cannot go beside the passes stays on the session stream, in order: the sort's second buffer Y belongs to the passes, so
+    // the streaming count of oversized sub-buckets gets a buffer of its own.
+    // MEASURED (profiles/r04y_pipe_ab.txt: 10 Gbp, k = 21, same box, twice each): pipelined 127.8 / 128.1 ms per step, stage
+    // after stage 119.9 / 119.3 -- the count kernels' LDS and HBM traffic slows the grouping passes by more than the overlap
+    // hides (the same answer MGC_HIST_AHEAD got in round 2) -- so it stays OFF.
+    const char *pipe_env = getenv("MGC_PIPE");                       // read per call: the tests switch it
+    const bool pipe = pipe_env && pipe_env[0] == '1' && !hist_ahead && s->stream2 && s->stream3 && nb > 1;
+    static const uint32_t pipe_ahead = getenv("MGC_PIPE_AHEAD") ? (uint32_t)atoi(getenv("MGC_PIPE_AHEAD")) : 2u;
+    if (s->hist_ev.size() < nb) {
+      const size_t have = s->hist_ev.size();
+      s->hist_ev.resize(nb, nullptr);
+      for (size_t i = have; i < nb; i++) HIP_TRY(s, hipEventCreateWithFlags(&s->hist_ev[i], hipEventDisableTiming));
+    }
+    if (s->h_stats_cap < 3 * (size_t)nb) {
+      if (s->h_stats) { (void)hipHostFree(s->h_stats); s->h_stats = nullptr; s->h_stats_cap = 0; }
+      HIP_TRY(s, hipHostMalloc(reinterpret_cast<void **>(&s->h_stats), sizeof(uint64_t) * 3 * (size_t)nb, hipHostMallocDefault));
+      s->h_stats_cap = 3 * (size_t)nb;
+    }
+    unsigned char *huge_alt = Y;
+    if (pipe) {
+      HIP_TRY(s, s->ensure(mgc_session::B_HUGE_ALT, kbytes * max_bucket));
+      huge_alt = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_HUGE_ALT].p);
+    }
+
+    // ---- A + B/C of one file: its grouping passes, then its sub-bucket boundaries and its largest sub-bucket ----
+    auto group_file = [&](uint32_t b) -> int {
+      if (h_counts[b] == 0) return MGC_OK;
       const mgc::SortPlan &fp = fplan[b];
       void *src = X + kbytes * h_starts[b];
       int in_alt = 0;
       hipEvent_t *pe = s->profiling ? &pass_ev[(size_t)b * ev_per_file] : nullptr;
-      if (narrow[b]) {                                       // X (8 B) -> Y (4 B) -> front of X (4 B); boundaries included
+      if (top_bits[b] == 0) {
+        // (a file of one sub-bucket: nothing to group)
+      } else if (narrow[b]) {                                // X (8 B) -> Y (4 B) -> front of X (4 B); boundaries included
         mgc::GroupLocal gl;
         gl.d_rows = d_fine_rows; gl.d_block_base = reinterpret_cast<const uint64_t *>(part_ws);
         gl.n_chunks = local_chunks; gl.vgrid = local_vgrid; gl.per_chunk = local_per_chunk; gl.file = b; gl.file_start = h_starts[b];
@@ -1424,56 +1461,63 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         file_passes[b] = 2;
         narrowed[b] = 1;
         sort_launch_groups++;
-        continue;
-      }
-      if (wide_msd[b] && d_nhdrs) {                          // X -> Y -> X, whole keys; boundaries included
+      } else if (wide_msd[b] && d_nhdrs) {                   // X -> Y -> X, whole keys; boundaries included
         HIP_TRY(s, mgc::launch_group_wide(src, (void *)Y, h_counts[b], kw, fp, d_err, d_substart + sbase[b], st, pe,
                                           (void *)(d_nhdrs + hdr_bytes * b), (void *)(d_nws + nws_off[b]), &tr_a[b], &tr_b[b]));
         file_passes[b] = 2;
         sort_launch_groups++;
         s->prof.wide_msd_files++;
-        continue;
+      } else {
+        wide_msd[b] = 0;
+        if (prepared[b]) HIP_TRY(s, hipStreamWaitEvent(st, s->hist_ev[b], 0));
+        HIP_TRY(s, mgc::launch_radix_sort(src, (void *)Y, h_counts[b], kw, fp, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe,
+                                          prepared[b] ? (void *)(d_hdrs + hdr_bytes * b) : nullptr));
+        if (in_alt) HIP_TRY(s, hipMemcpyAsync(src, Y, kbytes * h_counts[b], hipMemcpyDeviceToDevice, st));
+        file_passes[b] = fp.num_passes;
+        sort_launch_groups++;
       }
-      wide_msd[b] = 0;
-      if (prepared[b]) HIP_TRY(s, hipStreamWaitEvent(st, s->hist_ev[b], 0));
-      HIP_TRY(s, mgc::launch_radix_sort(src, (void *)Y, h_counts[b], kw, fp, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe,
-                                        prepared[b] ? (void *)(d_hdrs + hdr_bytes * b) : nullptr));
-      if (in_alt) HIP_TRY(s, hipMemcpyAsync(src, Y, kbytes * h_counts[b], hipMemcpyDeviceToDevice, st));
-      file_passes[b] = fp.num_passes;
-      sort_launch_groups++;
-    }
-    tm.end(MGC_STAGE_SORT);
-
-    // ---- B/C. sub-bucket boundaries and the largest sub-bucket of every file ----
-    tm.begin(MGC_STAGE_RLE);
-    for (uint32_t b = 0; b < nb; b++) {
-      if (h_counts[b] == 0) continue;
       if (narrow[b] || wide_msd[b])
-        HIP_TRY(s, mgc::launch_subbucket_max(d_substart + sbase[b], kw, rem_bits - top_bits[b], top_bits[b], d_maxsub + b,
-                                             d_large + gbase[b], d_nlarge + b, d_nz + gbase[b], d_nzcount + b, st));
+        HIP_TRY(s, mgc::launch_subbucket_max(d_substart + sbase[b], kw, rem_bits - top_bits[b], top_bits[b], d_maxsub(b),
+                                             d_large + gbase[b], d_nlarge(b), d_nz + gbase[b], d_nzcount(b), st));
       else
-      HIP_TRY(s, mgc::launch_subbucket_bounds(X + kbytes * h_starts[b], h_counts[b], kw, rem_bits - top_bits[b], top_bits[b],
-                                              d_substart + sbase[b], d_maxsub + b, d_large + gbase[b], d_nlarge + b,
-                                              d_nz + gbase[b], d_nzcount + b, st));
-    }
-    std::vector<uint64_t> h_maxsub(2 * (size_t)nb);
-    const uint64_t *h_nlarge = h_maxsub.data() + nb;
-    std::vector<uint64_t> h_nzcount(nb);
-    HIP_TRY(s, hipMemcpyAsync(h_maxsub.data(), d_maxsub, sizeof(uint64_t) * 2 * nb, hipMemcpyDeviceToHost, st));
-    HIP_TRY(s, hipMemcpyAsync(h_nzcount.data(), d_nzcount, sizeof(uint64_t) * nb, hipMemcpyDeviceToHost, st));
-    HIP_TRY(s, hipStreamSynchronize(st));
+        HIP_TRY(s, mgc::launch_subbucket_bounds(src, h_counts[b], kw, rem_bits - top_bits[b], top_bits[b],
+                                                d_substart + sbase[b], d_maxsub(b), d_large + gbase[b], d_nlarge(b),
+                                                d_nz + gbase[b], d_nzcount(b), st));
+      return MGC_OK;
+    };
+    std::vector<uint64_t> h_maxsub(nb, 0), h_nlarge(nb, 0), h_nzcount(nb, 0);
+    uint32_t grouped = 0;                                    // files [0, grouped) have their passes on the session stream
+    auto group_upto = [&](uint32_t end) -> int {
+      for (; grouped < end && grouped < nb; grouped++) {
+        const int rc = group_file(grouped);
+        if (rc != MGC_OK) return rc;
+        if (pipe) {
+          HIP_TRY(s, hipMemcpyAsync(s->h_stats + 3 * (size_t)grouped, d_stats + 3 * (size_t)grouped, sizeof(uint64_t) * 3, hipMemcpyDeviceToHost, st));
+          HIP_TRY(s, hipEventRecord(s->hist_ev[grouped], st));
+        }
+        if (grouped + 1 == nb) {                             // (the statistics kernels are a few microseconds each: counted with the passes)
+          tm.end(MGC_STAGE_SORT);
+          tm.begin(MGC_STAGE_RLE);
+          if (!pipe) HIP_TRY(s, hipMemcpyAsync(s->h_stats, d_stats, sizeof(uint64_t) * 3 * (size_t)nb, hipMemcpyDeviceToHost, st));
+        }
+      }
+      return MGC_OK;
+    };
 
     // ---- D. finish every file: LDS sort + count, or the full-sort fallback ----
     // The streaming kernel of a file's oversized sub-buckets goes to a second stream: it touches other sub-buckets than
     // the persistent kernel, and one gigantic sub-bucket occupies ONE workgroup for hundreds of microseconds -- beside
     // the persistent kernels of this and the next files that tail costs nothing (MGC_FINISH_FORK=0: same stream).
-    static const bool fork_huge = !(getenv("MGC_FINISH_FORK") && getenv("MGC_FINISH_FORK")[0] == '0');
+    static const bool fork_huge_env = !(getenv("MGC_FINISH_FORK") && getenv("MGC_FINISH_FORK")[0] == '0');
+    const bool fork_huge = fork_huge_env || pipe;
     hipStream_t st_huge = fork_huge ? s->stream2 : st;
     // The persistent kernels of odd files go to the second stream too, so that the tail of one file's launch overlaps the
     // head of the next: finish stage 58.5 -> 54.2 ms per 10 Gbp (MGC_FINISH_ALT=0: all on the session stream).  All
-    // streaming kernels stay on stream2: they share the buffer Y.
-    static const bool alt_files = fork_huge && !(getenv("MGC_FINISH_ALT") && getenv("MGC_FINISH_ALT")[0] == '0');
+    // streaming kernels stay on stream2: they share one second buffer.
+    static const bool alt_files_env = !(getenv("MGC_FINISH_ALT") && getenv("MGC_FINISH_ALT")[0] == '0');
+    const bool alt_files = fork_huge && alt_files_env;
     bool forked = false, need_join = false;          // forked: stream2 is ordered after everything st holds that it must see
+    bool used3 = false;                              // pipelined: the third stream holds work the session stream must wait for
     // tests run the dense-grid instantiations of the count kernels on small inputs (whose 2^t grids are mostly empty)
     const bool finish_nolist = getenv("MGC_FINISH_NOLIST") && getenv("MGC_FINISH_NOLIST")[0] == '1';
     std::vector<std::pair<hipEvent_t, hipEvent_t>> fin_ev;       // profiling: around every file's count-kernel launch
@@ -1481,9 +1525,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     bool fin_narrow = false;
     std::vector<uint64_t> h_fallback_distinct(nb);
     std::vector<char> fallback(nb);
-    for (uint32_t b = 0; b < nb; b++) {
+    auto finish_file = [&](uint32_t b) -> int {
       fallback[b] = false;
-      if (h_counts[b] == 0) continue;
+      if (h_counts[b] == 0) return MGC_OK;
       const uint32_t low = rem_bits - top_bits[b];
       void *seg = X + kbytes * h_starts[b];
       // sub-buckets above the persistent kernels' capacity (a k-mer repeated thousands of times, a dense corner of the key
@@ -1510,7 +1554,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       bool unordered = false;
       if (narrow[b] && h_nlarge[b] > 0 && !stream) {
         // an oversized sub-bucket that cannot be streamed: the LDS sort / the stable-sort fallback want whole k-mers back
-        if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));   // Y is the streaming kernels' second buffer
+        if (need_join && !pipe) HIP_TRY(s, hipStreamSynchronize(st_huge));   // Y is the streaming kernels' second buffer
         forked = false;
         HIP_TRY(s, mgc::launch_widen_groups(seg, d_substart + sbase[b], gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, low, (void *)Y, st,
                                             tr_a[b], tr_b[b]));
@@ -1524,13 +1568,29 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       // whole keys in (low digit : high digit) order whose oversized sub-buckets nothing streams: the stable sort of all bits
       if (wide_msd[b] && h_nlarge[b] > 0 && !stream) unordered = true;
       if ((h_maxsub[b] <= cap || stream) && !unordered) {
-        const bool on_second = alt_files && (b & 1u);
-        if ((stream || on_second) && fork_huge && !forked) {   // everything the forked kernels read is complete at this point of st
-          HIP_TRY(s, hipEventRecord(s->ev_fork, st));
-          HIP_TRY(s, hipStreamWaitEvent(st_huge, s->ev_fork, 0));
-          forked = need_join = true;
+        hipStream_t fst;
+        if (pipe) {
+          // a file that was just widened on the session stream is counted there, behind it; the others beside the passes
+          const bool here = !narrowed[b] ? false : !narrow[b];
+          fst = here ? st : ((alt_files_env && (b & 1u)) ? s->stream2 : s->stream3);
+          if (fst != st) {
+            HIP_TRY(s, hipStreamWaitEvent(fst, s->hist_ev[b], 0));
+            if (fst == s->stream3) used3 = true; else need_join = true;
+          }
+          if (stream) {                                  // (ordered after the file's widening too, if it had one: recorded now)
+            if (here) { HIP_TRY(s, hipEventRecord(s->ev_fork, st)); HIP_TRY(s, hipStreamWaitEvent(st_huge, s->ev_fork, 0)); }
+            else HIP_TRY(s, hipStreamWaitEvent(st_huge, s->hist_ev[b], 0));
+            need_join = true;
+          }
+        } else {
+          const bool on_second = alt_files && (b & 1u);
+          if ((stream || on_second) && fork_huge && !forked) {   // everything the forked kernels read is complete at this point of st
+            HIP_TRY(s, hipEventRecord(s->ev_fork, st));
+            HIP_TRY(s, hipStreamWaitEvent(st_huge, s->ev_fork, 0));
+            forked = need_join = true;
+          }
+          fst = on_second ? s->stream2 : st;
         }
-        hipStream_t fst = on_second ? s->stream2 : st;
         if (s->profiling) {
           fin_ev.emplace_back(); (void)hipEventCreate(&fin_ev.back().first); (void)hipEventCreate(&fin_ev.back().second);
           (void)hipEventRecord(fin_ev.back().first, fst);
@@ -1539,16 +1599,16 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
           fin_narrow = fin_narrow || narrow[b];
         }
         HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_nlarge[b],
-                                           d_large + gbase[b], cnt_ptr[b], d_group + gbase[b], stream, (void *)Y, st_huge,
+                                           d_large + gbase[b], cnt_ptr[b], d_group + gbase[b], stream, (void *)huge_alt, st_huge,
                                            // the list pays off only when a good part of the 2^t grid is empty
                                            (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b]) && !finish_nolist) ? d_nz + gbase[b] : nullptr,
-                                           d_nzcount + b, fst, narrow[b] != 0, tr_a[b], tr_b[b], h_maxsub[b], h_counts[b],
+                                           d_nzcount(b), fst, narrow[b] != 0, tr_a[b], tr_b[b], h_maxsub[b], h_counts[b],
                                            d_nz + gbase[b], d_retrycnt + b));
         if (s->profiling) (void)hipEventRecord(fin_ev.back().second, fst);
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
         fallback[b] = true;
-        if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));  // the sort below uses Y, the streaming kernels' second buffer
+        if (need_join && !pipe) HIP_TRY(s, hipStreamSynchronize(st_huge));  // the sort below uses Y, the streaming kernels' second buffer
         forked = false;                                            // ... and the next streaming kernel must wait for that sort
         if (low || unordered) {
           // LSD order: the low bits cannot be sorted after the top bits, so the whole key is redone
@@ -1564,11 +1624,25 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         HIP_TRY(s, hipMemcpyAsync(d_group + gbase[b], &h_fallback_distinct[b], sizeof(uint64_t), hipMemcpyHostToDevice, st));
         HIP_TRY(s, hipStreamSynchronize(st));
       }
+      return MGC_OK;
+    };
+
+    for (uint32_t b = 0; b < nb; b++) {
+      { const int rc = group_upto(pipe ? b + 1 + pipe_ahead : nb); if (rc != MGC_OK) return rc; }
+      if (pipe) HIP_TRY(s, hipEventSynchronize(s->hist_ev[b]));
+      else if (b == 0) HIP_TRY(s, hipStreamSynchronize(st));
+      h_maxsub[b] = s->h_stats[3 * (size_t)b]; h_nlarge[b] = s->h_stats[3 * (size_t)b + 1]; h_nzcount[b] = s->h_stats[3 * (size_t)b + 2];
+      const int rc = finish_file(b);
+      if (rc != MGC_OK) return rc;
     }
 
     if (need_join) {
       HIP_TRY(s, hipEventRecord(s->ev_join, st_huge));
       HIP_TRY(s, hipStreamWaitEvent(st, s->ev_join, 0));
+    }
+    if (used3) {
+      HIP_TRY(s, hipEventRecord(s->ev_join2, s->stream3));
+      HIP_TRY(s, hipStreamWaitEvent(st, s->ev_join2, 0));
     }
 
     // ---- E/F. offsets of every sub-bucket in the packed result ----

@@ -1349,6 +1349,43 @@ def test_hash_count_multi_subbuckets_per_iteration(ops, oracle_lib, torch_cuda, 
         assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
 
 
+@pytest.mark.parametrize("k,compress,min_top,stream_max", [(21, 0, 17, None), (21, 0, 10, "2000"), (19, 0, 14, None), (31, 0, 16, None),
+                                                            (31, 1, None, None), (51, 0, 12, "2000"), (24, 0, 18, None)])
+def test_pipelined_count_equals_the_oracle(ops, oracle_lib, torch_cuda, monkeypatch, k, compress, min_top, stream_max):
+    """MGC_PIPE=1 (round 4, measured slower and therefore off: profiles/r04y_pipe_ab.txt): a file's count kernel on a second /
+    third stream beside the grouping passes of the files after it, its statistics fetched per file, the streaming count of
+    oversized sub-buckets in a buffer of its own.  Narrowed files, whole 8- and 16-byte keys, `compress`; sub-buckets above the
+    persistent kernels' capacity (streaming launch), above MGC_STREAM_MAX (probe, widening, stable-sort fallback on the session
+    stream between the queued passes), empty files in forward mode."""
+    from meryl_amd import capi
+    monkeypatch.setenv("MGC_PIPE", "1")
+    if min_top is not None:
+        monkeypatch.setenv("MGC_FINISH_MIN_TOP", str(min_top))
+    if stream_max is not None:
+        monkeypatch.setenv("MGC_STREAM_MAX", stream_max)
+    rng = np.random.default_rng(k * 7 + (min_top or 0))
+    plen = min(k - 1, (6 + (min_top or 16) + 1) // 2 + 1)
+    def cluster(head, n_inst, n_distinct):
+        pre = head + "".join("ACGT"[i] for i in rng.integers(0, 4, plen - len(head)))
+        n_distinct = min(n_distinct, 4 ** (k - plen))
+        tails = ["".join("ACGT"[i] for i in rng.integers(0, 4, k - plen)) for _ in range(n_distinct)]
+        return ".".join(pre + tails[int(i)] for i in rng.integers(0, n_distinct, n_inst)) + "."
+    reads = oracle_lib.synth_reads(k + 1, 400_000, 0, 30_000).tobytes().decode()
+    stream = (cluster("AAC", 1536, 1536) + cluster("AGC", 1537, 300) + cluster("CAT", 3000, 900) + cluster("CCG", 5000, 4000)
+              + cluster("AAT", 9000, 1) + cluster("GTA", 2500, 2500) + cluster("TTG", 1, 1) + reads)
+    for mode in (1, 0):
+        cfg = capi.configure(k, len(stream), 1 << 30, mode, homopoly_compress=compress)
+        cfg.use_simple = 0
+        want = oracle_lib.count_brute(oracle_lib.compress_stream(stream) if compress else stream, k, mode)
+        for _ in range(2):                                  # twice through one session: the events and the pinned statistics are reused
+            with ops.Session(cfg) as s:
+                s.push_bases(stream, end_of_sequence=False)
+                s.count()
+                klo, khi, counts, _ = s.result_wide()
+            whi, wlo, wcn, _ = want
+            assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+
+
 @pytest.mark.parametrize("m64,nolist", [("1", "1"), ("1", "0"), ("0", "1")])
 @pytest.mark.parametrize("k,compress,min_top", [(28, 0, 14), (31, 0, 16), (32, 0, 12), (31, 1, None), (30, 0, 18),
                                                 (33, 0, 14), (40, 0, 16), (51, 0, 12), (64, 0, 18), (51, 1, None)])
@@ -1393,7 +1430,7 @@ _GRID_SWITCHES = {
     "MGC_NARROW": ["0"], "MGC_FINE_HIST": ["0"], "MGC_WIDE_MSD": ["0"], "MGC_GROUP_LOCAL": ["1"], "MGC_PARTITION_WC": ["1"],
     "MGC_FINISH_BITMAP": ["1"], "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"],
     "MGC_FINISH_TARGET": ["1", "4", "64", "700"], "MGC_FINISH_MIN_TOP": ["10", "14", "17", "18"], "MGC_STREAM_MAX": ["2000", "20000"],
-    "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"], "MGC_HASH64M": ["0"], "MGC_HASH128M": ["0"],
+    "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"], "MGC_HASH64M": ["0"], "MGC_HASH128M": ["0"], "MGC_PIPE": ["1"],
 }
 
 
