@@ -1097,6 +1097,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   const uint64_t *d_fine_hpc = nullptr;                              // `compress`: the dense-rank form of that histogram
   uint32_t *d_fine_rows = nullptr;
   uint32_t local_chunks = 0, local_per_chunk = 0, local_vgrid = 0;
+  // MGC_SOA_WC=1: the first pass of 5-byte files chunk-local with write combining (mgc_sort.hip, radix_group5wc_kernel) -- it wants
+  // the per-chunk rows of the fifteen-bit histogram too (read per call: the tests switch it)
+  const bool soa_wc = getenv("MGC_SOA_WC") && getenv("MGC_SOA_WC")[0] == '1';
   if (!ext_keys) {
     tm.begin(MGC_STAGE_HISTOGRAM);
     // (two digits cover at most 18 bits: beyond 2k - 6 = 41 nothing narrows -- the files' WHOLE keys then take the same
@@ -1109,7 +1112,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       uint64_t *fine = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_FINE].p);
       // ... and per CHUNK of the partition's output too (64 MB at 10 Gbp): the first grouping pass of every file then runs
       // chunk-local, without look-back (mgc_sort.hip, radix_group_local_kernel; MGC_GROUP_LOCAL=0: the look-back kernel)
-      if (mgc::group_local_enabled()) {
+      if (mgc::group_local_enabled() || soa_wc) {
         local_chunks = mgc::kmer_histogram_fine_chunks(n_bases, &local_per_chunk, &local_vgrid);
         HIP_TRY(s, s->ensure(mgc_session::B_FINE_ROWS, (sizeof(uint32_t) << 15) * (size_t)local_chunks));
         d_fine_rows = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_FINE_ROWS].p);
@@ -1332,7 +1335,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       // whole keys).  MGC_SOA5=0: whole keys.
       const char *se = getenv("MGC_SOA5");                            // read per call: the tests switch it
       bool soa = !(se && se[0] == '0') && !ext_keys && kw == 1 && nb == 64 && d_fine && rem_bits > 32 && rem_bits <= 40 && s->sfx_mask == 0 &&
-                 !d_fine_rows && !getenv("MGC_GROUP_DBG") && !getenv("MGC_PART_DBG") &&
+                 (!d_fine_rows || soa_wc) && !getenv("MGC_GROUP_DBG") && !getenv("MGC_PART_DBG") &&
                  !(getenv("MGC_PARTITION_WC") && getenv("MGC_PARTITION_WC")[0] == '1');
       for (uint32_t b = 0; b < nb && soa; b++) if (h_counts[b] && !(narrow[b] && top_bits[b])) soa = false;
       if (soa) soa_hi_mask = (1u << (rem_bits - 32)) - 1u;
@@ -1476,11 +1479,15 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         file_passes[b] = fp.num_passes;
         sort_launch_groups++;
       }
+      return MGC_OK;
+    };
+    auto stats_file = [&](uint32_t b) -> int {
+      if (h_counts[b] == 0) return MGC_OK;
       if (narrow[b] || wide_msd[b])
         HIP_TRY(s, mgc::launch_subbucket_max(d_substart + sbase[b], kw, rem_bits - top_bits[b], top_bits[b], d_maxsub(b),
                                              d_large + gbase[b], d_nlarge(b), d_nz + gbase[b], d_nzcount(b), st));
       else
-        HIP_TRY(s, mgc::launch_subbucket_bounds(src, h_counts[b], kw, rem_bits - top_bits[b], top_bits[b],
+        HIP_TRY(s, mgc::launch_subbucket_bounds(X + kbytes * h_starts[b], h_counts[b], kw, rem_bits - top_bits[b], top_bits[b],
                                                 d_substart + sbase[b], d_maxsub(b), d_large + gbase[b], d_nlarge(b),
                                                 d_nz + gbase[b], d_nzcount(b), st));
       return MGC_OK;
@@ -1492,13 +1499,17 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         const int rc = group_file(grouped);
         if (rc != MGC_OK) return rc;
         if (pipe) {
+          { const int rc2 = stats_file(grouped); if (rc2 != MGC_OK) return rc2; }
           HIP_TRY(s, hipMemcpyAsync(s->h_stats + 3 * (size_t)grouped, d_stats + 3 * (size_t)grouped, sizeof(uint64_t) * 3, hipMemcpyDeviceToHost, st));
           HIP_TRY(s, hipEventRecord(s->hist_ev[grouped], st));
         }
-        if (grouped + 1 == nb) {                             // (the statistics kernels are a few microseconds each: counted with the passes)
+        if (grouped + 1 == nb) {
           tm.end(MGC_STAGE_SORT);
           tm.begin(MGC_STAGE_RLE);
-          if (!pipe) HIP_TRY(s, hipMemcpyAsync(s->h_stats, d_stats, sizeof(uint64_t) * 3 * (size_t)nb, hipMemcpyDeviceToHost, st));
+          if (!pipe) {                                       // the small statistics kernels of all files back to back: they run beside each other
+            for (uint32_t b = 0; b < nb; b++) { const int rc2 = stats_file(b); if (rc2 != MGC_OK) return rc2; }
+            HIP_TRY(s, hipMemcpyAsync(s->h_stats, d_stats, sizeof(uint64_t) * 3 * (size_t)nb, hipMemcpyDeviceToHost, st));
+          }
         }
       }
       return MGC_OK;

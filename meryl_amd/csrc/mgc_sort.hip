@@ -941,6 +941,218 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
   }
 }
 
+// ---- first grouping pass of a file in the 5-byte layout, TWO workgroups per CU (round 4; measured slower, MGC_SOA_2WG=1) ----
+// radix_group_kernel<u64, 9, 1024, 16, NARROW, HIST2, SOA> exchanges whole 8-byte keys through LDS: 128 KiB per 16384-key tile,
+// one workgroup per CU, whose phases (fetch, rank, scan, exchange, look-back, write-out) run one after the other with nothing
+// else resident to fill the gaps (waves parked 58-66 %, nothing saturated).  Halving the tile loses on the write
+// side (runs of 16 words).  This kernel keeps the 16384-key tile and exchanges the NARROWED 32-bit words instead -- 64 KiB --
+// so that two workgroups share a CU: a key's digit is not in its word, so the write-out goes by digit instead of by position
+// (wave w owns digits 32w .. 32w+31, contiguous in LDS; every store instruction is one digit's run, as in the exchange order).
+// A k-mer stays (u32 low word, u8 high byte) in registers -- 20 VGPRs per 16 keys instead of 32 -- and the whole kernel fits the
+// 64 VGPRs two 1024-thread workgroups per CU leave, without the register prefetch across the look-back (the other workgroup is
+// the latency hiding).  Same tickets, status granules, look-back, HIST2 and output as the kernel it would replace; bit-exact
+// (test_five_byte_first_pass_two_workgroups_per_cu) and 5 % SLOWER (0.568 against 0.541 ms per 135 M k-mers): with the chunk-local
+// kernel's two-workgroup forms (round 3) the third measurement that says a pass is bound by what a CU's LDS and memory pipeline
+// put through, not by what is resident to wait on them.  Off.  Restates the same reference code (unpackSuffixes + std::sort,
+// merylCountArray.C:276-289,330 -- top bits only).
+struct Group5Smem {
+  static constexpr int R = 512, BLOCK = 1024, KPT = 16, TILE = BLOCK * KPT;
+  static constexpr size_t OFF_HIST  = (size_t)TILE * 4;                // u32[R]   tile histogram (counts stay until the next tile)
+  static constexpr size_t OFF_GBASE = OFF_HIST + (size_t)R * 4;        // u64[R]
+  static constexpr size_t OFF_DBASE = OFF_GBASE + (size_t)R * 8;       // u32[R]
+  static constexpr size_t OFF_H2    = OFF_DBASE + (size_t)R * 4;       // u32[R]   the other digit's histogram (HIST2)
+  static constexpr size_t OFF_TMP   = OFF_H2 + (size_t)R * 4;          // u32[64]
+  static constexpr size_t OFF_INFO  = OFF_TMP + 64 * 4;                // u64[4]
+  static constexpr size_t BYTES     = OFF_INFO + 4 * 8;
+  static_assert(2 * BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+#ifndef G5_WAVES
+#define G5_WAVES 8
+#endif
+__global__ __launch_bounds__(1024, G5_WAVES)
+void radix_group5_kernel(const u32 *__restrict__ in_lo, const uint8_t *__restrict__ in_hi, u32 *__restrict__ out, u64 n, u32 shift,
+                         u32 dmask, const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
+                         u32 *__restrict__ error_flag, u64 total_tiles, GroupExtra ex) {
+  using SM = Group5Smem;
+  constexpr int R = SM::R, BLOCK = SM::BLOCK, KPT = SM::KPT, TILE = SM::TILE, G = R / 2, WALK = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32 *s_words = reinterpret_cast<u32 *>(smem);
+  u32 *s_hist  = reinterpret_cast<u32 *>(smem + SM::OFF_HIST);
+  u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
+  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
+  u32 *s_h2    = reinterpret_cast<u32 *>(smem + SM::OFF_H2);
+  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
+  const u32 tid0 = threadIdx.x;
+  u32 tid = tid0, lane = tid0 & 63u, w = tid0 >> 6;
+  if (tid0 < (u32)R) s_h2[tid0] = 0;
+  const u32 hm = ex.soa_hi_mask;
+  const u32 wmask = shift >= 32u ? 0xFFFFFFFFu : ((1u << shift) - 1u);      // the word a k-mer leaves as: its bits below the digit
+
+  // key j of a thread is element idx_of(j) of the tile: four consecutive keys per lane and load group, wave-striped
+  auto idx_of = [&](int j) __attribute__((always_inline)) -> u32 {
+    return w * (u32)(64 * KPT) + ((u32)(j / 4) * 64u + lane) * 4u + (u32)(j % 4);
+  };
+  u32 lo[KPT], hi4[KPT / 4];                                  // hi4[g]: the high bytes of keys 4g .. 4g+3, one per byte
+  struct __attribute__((aligned(4))) LVec { u32 v[4]; };
+  struct __attribute__((packed, aligned(1))) HWord { u32 v; };
+  // A group that starts inside the tile is loaded whole: up to three words past the file's last k-mer (its own high-byte array
+  // lies there) and three bytes past its last high byte (the region is 8 bytes per k-mer); idx_of(j) < nv says which ones count.
+  auto fetch = [&](u64 kb, u32 nv) __attribute__((always_inline)) {
+    const u32 *lo32 = in_lo + kb;
+    const uint8_t *hi8 = in_hi + kb;
+#pragma unroll
+    for (int g = 0; g < KPT / 4; g++) {
+      const u32 first = idx_of(g * 4);
+      if (first < nv) {
+        const LVec l = *reinterpret_cast<const LVec *>(lo32 + first);
+        hi4[g] = reinterpret_cast<const HWord *>(hi8 + first)->v;
+#pragma unroll
+        for (int c = 0; c < 4; c++) lo[g * 4 + c] = l.v[c];
+      }
+    }
+  };
+  auto digit_of = [&](int j) __attribute__((always_inline)) -> u32 {
+    const u64 key = (u64)lo[j] | ((u64)((hi4[j / 4] >> (8 * (j % 4))) & hm) << 32);
+    return (u32)(key >> shift) & dmask;
+  };
+
+  if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
+  __syncthreads();
+  u64 tile = (u64)(u32)__builtin_amdgcn_readfirstlane((int)s_tmp[32]);        // tile numbers and counts are uniform: scalar registers
+  u32 nv = 0;
+  if (tile < total_tiles) { nv = (n - tile * (u64)TILE < (u64)TILE) ? (u32)(n - tile * (u64)TILE) : (u32)TILE; fetch(tile * (u64)TILE, nv); }
+
+  while (tile < total_tiles) {
+    tid = tid0;
+    asm volatile("" : "+v"(tid));                         // keeps the unrolled body's LDS addresses out of the loop preheader
+    lane = tid & 63u; w = tid >> 6;
+    const bool walker = tid < (u32)G;
+    if (tid == 0) s_tmp[33] = atomicAdd(ticket, 1u);
+    if (tid < (u32)R) s_hist[tid] = 0;
+    __syncthreads();                                      // (A)
+    const u64 next = (u64)(u32)__builtin_amdgcn_readfirstlane((int)s_tmp[33]);
+    const u64 nkb = next * (u64)TILE;
+    const u32 nnv = (next < total_tiles) ? ((n - nkb < (u64)TILE) ? (u32)(n - nkb) : (u32)TILE) : 0u;
+
+    // ---- rank: position among the tile's keys of the same digit, in arrival order ----
+    // (a whole tile takes the branch-free body: sixteen returning atomics in flight, not one per basic block)
+    u32 ranks[KPT / 2];
+    if (nv == (u32)TILE) {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 r = atomicAdd(&s_hist[digit_of(j)], 1u);
+        if (j & 1) ranks[j / 2] |= r << 16;
+        else       ranks[j / 2]  = r;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        u32 r = 0;
+        if (idx_of(j) < nv) r = atomicAdd(&s_hist[digit_of(j)], 1u);
+        if (j & 1) ranks[j / 2] |= r << 16;
+        else       ranks[j / 2]  = r;
+      }
+    }
+    // the exchange works the digits out again from the packed high bytes: sixteen unpacked ones kept across the scan cost sixteen registers
+#pragma unroll
+    for (int g = 0; g < KPT / 4; g++) asm volatile("" : "+v"(hi4[g]));
+    __syncthreads();                                      // (B)
+
+    const u32 count = (tid < (u32)R) ? s_hist[tid] : 0u;
+    u32 tile_total;
+    const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tile_total);
+    if (tid < (u32)R) s_dbase[tid] = excl;
+    __syncthreads();                                      // (C)
+
+    u64 *mine = status + tile * (u64)G + tid;
+    u32 c0 = 0, c1 = 0;
+    if (walker) {
+      c0 = s_hist[2 * tid]; c1 = s_hist[2 * tid + 1];
+      const u32 fl = (tile == 0) ? 2u : 1u;
+      status_store(mine, st_pack(fl, c0, fl, c1));
+    }
+    if (nv == (u32)TILE) {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
+        s_words[s_dbase[digit_of(j)] + r] = lo[j] & wmask;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        if (idx_of(j) < nv) {
+          const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
+          s_words[s_dbase[digit_of(j)] + r] = lo[j] & wmask;
+        }
+      }
+    }
+    __syncthreads();                                      // (D) the tile's words live in LDS only
+
+    // ---- look-back (as radix_group_kernel's), the next tile's fetch and the other digit's histogram in its shadow ----
+    u32 p0 = 0, p1 = 0;
+    if (!walker) {
+      for (u32 i = tid - (u32)G; i < nv; i += (u32)(BLOCK - G)) atomicAdd(&s_h2[(s_words[i] >> ex.shift2) & ex.mask2], 1u);
+    } else {
+      bool done = (tile == 0);
+      u64  wt = tile ? tile - 1 : 0;
+      u32  spins = 0;
+      while (!done) {
+        u64 gv[WALK];
+#pragma unroll
+        for (int i = 0; i < WALK; i++)
+          gv[i] = (wt >= (u64)i) ? status_load(status + (wt - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
+        u32 used = 0;
+        bool open = true;
+#pragma unroll
+        for (int i = 0; i < WALK; i++) {
+          const u32 l = (u32)gv[i], h = (u32)(gv[i] >> 32);
+          const u32 f = l >> 30;
+          open = open && !done && (f != 0);
+          if (open) {
+            p0 += l & 0x3FFFFFFFu; p1 += h & 0x3FFFFFFFu;
+            if (f == 2) done = true;
+            used++;
+          }
+        }
+        wt -= (used <= wt) ? used : wt;
+        if (used == 0) {
+          if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); done = true; }
+          else __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (tile != 0) status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
+      s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0;
+      s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1;
+    }
+    __syncthreads();                                      // (E)
+    // the next tile's k-mers travel behind the write-out and the top of the next iteration; the other workgroup of the CU has
+    // the rest of the latency (one fetch site, nothing carried across the look-back: 64 VGPRs without spills)
+    if (next < total_tiles) fetch(nkb, nnv);
+
+    // ---- write-out by digit: wave w owns digits 32w .. 32w+31; lane l < 32 holds digit 32w+l's run ----
+    {
+      u32 bs = 0, bc = 0, bgl = 0, bgh = 0;
+      if (lane < 32u) {
+        const u32 d = w * 32u + lane;
+        const u64 g = s_gbase[d];
+        bs = s_dbase[d]; bc = s_hist[d]; bgl = (u32)g; bgh = (u32)(g >> 32);
+      }
+#pragma unroll 2
+      for (int b = 0; b < 32; b++) {                        // (128 scalars at once do not fit)
+        const u32 st_ = (u32)__builtin_amdgcn_readlane((int)bs, b), c = (u32)__builtin_amdgcn_readlane((int)bc, b);
+        const u64 g = (u64)(u32)__builtin_amdgcn_readlane((int)bgl, b) | ((u64)(u32)__builtin_amdgcn_readlane((int)bgh, b) << 32);
+#pragma unroll 1
+        for (u32 o = lane; o < c; o += 64u) out[g + (u64)o] = s_words[st_ + o];      // (one trip unless a digit holds > 64 of the tile's keys)
+      }
+    }
+    __syncthreads();                                      // (F)
+    tile = next; nv = nnv;
+  }
+  __syncthreads();
+  if (tid0 < (u32)R) { const u32 c = s_h2[tid0]; if (c) atomicAdd(&ex.ghist2[tid0], (u64)c); }
+}
+
 // ---- chunk-local first grouping pass (no look-back) -----------------------------------------------------------------
 // The file a session's own partition wrote is a concatenation of CHUNKS: workgroup w of kmer_partition_kernel leaves its
 // k-mers of file f as one contiguous run, the runs lie in workgroup order, and kmer_hist_fine_kernel -- one workgroup per
@@ -1089,6 +1301,211 @@ void radix_group_local_kernel(const K *__restrict__ in, typename GroupOut<K, NAR
     __syncthreads();
     for (u32 i = tid; i < (u32)RS_MAX_RADIX; i += BLOCK) { const u32 cnt2 = s_h2[i]; if (cnt2) atomicAdd(&ex.ghist2[i], (u64)cnt2); }
   }
+}
+
+// ---- chunk-local first pass of a file in the 5-byte layout with WRITE COMBINING (round 4; measured slower, MGC_SOA_WC=1) ----
+// MEASURED (profiles/r04ab_soa_wc_ab.txt): bit-exact, and 0.557 ms per 135 M k-mers against the look-back kernel's 0.541 on one box,
+// 0.579 against 0.556 on another (write-out one digit after the other, then eight digits' LDS reads in flight together: the same) --
+// every store a whole line, and no faster: the partial lines are not what holds the real pass at the micro-benchmark's
+// odd-start time.  Off.
+// scripts/ubench/scatter.hip: a pass's access pattern with no compute runs at 0.340 ms per 135 M k-mers when every run starts
+// on a 128-byte line and at 0.535 ms when runs start anywhere -- where the look-back pass (0.54 ms) sits.  A run starts
+// anywhere because a digit's cursor is wherever the previous tile left it.  This kernel makes every store a whole line:
+// a workgroup owns a CHUNK of the file (radix_group_local_kernel's private cursors: no tickets, no look-back), and the words
+// of a digit that do not fill a line wait in LDS (at most 31 per digit, 512 x 32 words = 64 KiB) for the chunk's next tile.
+// That fits beside the tile only because the exchange holds the NARROWED 32-bit words (64 KiB per 16384-key tile, as in
+// radix_group5_kernel), and the write-out goes by digit: wave w owns digits 32w .. 32w+31 (lane l < 32 keeps digit 32w+l's
+// cursor, pending count, tile count and exchange offset in registers), per digit one store of the whole lines that are now
+// complete -- pending words first, then the tile's -- and one LDS move of the rest.  Only a chunk's first line and its last
+// one per digit are partial.  Same output, HIST2 and reference code restated as radix_group_kernel (unpackSuffixes + std::sort,
+// merylCountArray.C:276-289,330 -- top bits only).
+struct Group5WcSmem {
+  static constexpr int R = 512, BLOCK = 1024, KPT = 16, TILE = BLOCK * KPT, LINE = 32;
+  static constexpr size_t OFF_CARRY = (size_t)TILE * 4;                       // u32[R * LINE]  pending words of every digit
+  static constexpr size_t OFF_HIST  = OFF_CARRY + (size_t)R * LINE * 4;      // u32[R]
+  static constexpr size_t OFF_DBASE = OFF_HIST + (size_t)R * 4;              // u32[R]
+  static constexpr size_t OFF_H2    = OFF_DBASE + (size_t)R * 4;             // u32[R]
+  static constexpr size_t OFF_TMP   = OFF_H2 + (size_t)R * 4;                // u32[64]
+  static constexpr size_t BYTES     = OFF_TMP + 64 * 4;
+  static_assert(BYTES <= 160 * 1024, "one workgroup per CU");
+};
+
+__global__ __launch_bounds__(1024, 4)
+void radix_group5wc_kernel(const u32 *__restrict__ in_lo, const uint8_t *__restrict__ in_hi, u32 *__restrict__ out, u64 n, u32 shift,
+                           u32 dmask, const u64 *__restrict__ gbase, LocalArgs la, GroupExtra ex) {
+  using SM = Group5WcSmem;
+  constexpr int R = SM::R, BLOCK = SM::BLOCK, KPT = SM::KPT, TILE = SM::TILE, LINE = SM::LINE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32 *s_words = reinterpret_cast<u32 *>(smem);                 // (s_words[TILE + 32 d + i] = pending word i of digit d)
+  u32 *s_hist  = reinterpret_cast<u32 *>(smem + SM::OFF_HIST);
+  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
+  u32 *s_h2    = reinterpret_cast<u32 *>(smem + SM::OFF_H2);
+  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
+  const u32 tid0 = threadIdx.x;
+  u32 tid = tid0, lane = tid0 & 63u, w = tid0 >> 6;
+  if (tid0 < (u32)R) s_h2[tid0] = 0;
+  const u32 hm = ex.soa_hi_mask;
+  const u32 wmask = shift >= 32u ? 0xFFFFFFFFu : ((1u << shift) - 1u);
+
+  // the chunk's key range inside the file; the digit this thread owns (lanes 0..31 of wave w: digit 32w + lane) and its cursor
+  const u32 c = blockIdx.x, g0 = c * la.per_chunk, g1 = g0 + la.per_chunk;
+  const u64 cs = (g0 < la.vgrid) ? la.block_base[(u64)g0 * 64 + la.file] - la.file_start : n;
+  const u64 ce = (g1 < la.vgrid) ? la.block_base[(u64)g1 * 64 + la.file] - la.file_start : n;
+  const bool own = (tid0 & 63u) < 32u;
+  const u32 d_own = (tid0 >> 6) * 32u + (tid0 & 31u);
+  u32 cur = 0, pend = 0;                                        // where the digit's next word goes (file-relative), words waiting in LDS
+  if (own && d_own <= dmask)
+    cur = (u32)gbase[d_own] + la.rows[((u64)c << 15) + ((u64)la.file << 9) + ((u64)d_own << la.span_shift)];
+
+  auto idx_of = [&](int j) __attribute__((always_inline)) -> u32 {
+    return w * (u32)(64 * KPT) + ((u32)(j / 4) * 64u + lane) * 4u + (u32)(j % 4);
+  };
+  u32 lo[KPT], hi4[KPT / 4];
+  struct __attribute__((aligned(4))) LVec { u32 v[4]; };
+  struct __attribute__((packed, aligned(1))) HWord { u32 v; };
+  auto fetch = [&](u64 kb, u32 nv) __attribute__((always_inline)) {      // (a group that starts inside the tile is loaded whole: radix_group5_kernel)
+    const u32 *lo32 = in_lo + kb;
+    const uint8_t *hi8 = in_hi + kb;
+#pragma unroll
+    for (int g = 0; g < KPT / 4; g++) {
+      const u32 first = idx_of(g * 4);
+      if (first < nv) {
+        const LVec l = *reinterpret_cast<const LVec *>(lo32 + first);
+        hi4[g] = reinterpret_cast<const HWord *>(hi8 + first)->v;
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) lo[g * 4 + cc] = l.v[cc];
+      }
+    }
+  };
+  auto digit_of = [&](int j) __attribute__((always_inline)) -> u32 {
+    const u64 key = (u64)lo[j] | ((u64)((hi4[j / 4] >> (8 * (j % 4))) & hm) << 32);
+    return (u32)(key >> shift) & dmask;
+  };
+
+  u64 kb = cs;
+  u32 nv = (ce > kb) ? (u32)((ce - kb < (u64)TILE) ? ce - kb : (u64)TILE) : 0u;
+  if (nv) fetch(kb, nv);
+  while (nv) {
+    tid = tid0;
+    asm volatile("" : "+v"(tid));                         // keeps the unrolled body's LDS addresses out of the loop preheader
+    lane = tid & 63u; w = tid >> 6;
+    const u64 nkb = kb + (u64)TILE;
+    const u32 nnv = (ce > nkb) ? (u32)((ce - nkb < (u64)TILE) ? ce - nkb : (u64)TILE) : 0u;
+    if (tid < (u32)R) s_hist[tid] = 0;
+    __syncthreads();                                      // (A)
+
+    u32 ranks[KPT / 2];
+    if (nv == (u32)TILE) {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 r = atomicAdd(&s_hist[digit_of(j)], 1u);
+        if (j & 1) ranks[j / 2] |= r << 16;
+        else       ranks[j / 2]  = r;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        u32 r = 0;
+        if (idx_of(j) < nv) r = atomicAdd(&s_hist[digit_of(j)], 1u);
+        if (j & 1) ranks[j / 2] |= r << 16;
+        else       ranks[j / 2]  = r;
+      }
+    }
+    __syncthreads();                                      // (B)
+
+    const u32 cnt = own ? s_hist[d_own] : 0u;             // (threads in digit order: the scan over the threads is the scan over the digits)
+    u32 tile_total;
+    const u32 excl = block_excl_scan<BLOCK, u32>(cnt, s_tmp, &tile_total);
+    if (own) s_dbase[d_own] = excl;
+    __syncthreads();                                      // (C)
+
+    // exchange: the narrowed word to its digit's run; the other digit (the second pass's) is counted from the registers
+    if (nv == (u32)TILE) {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
+        const u32 word = lo[j] & wmask;
+        s_words[s_dbase[digit_of(j)] + r] = word;
+        atomicAdd(&s_h2[(word >> ex.shift2) & ex.mask2], 1u);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        if (idx_of(j) < nv) {
+          const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
+          const u32 word = lo[j] & wmask;
+          s_words[s_dbase[digit_of(j)] + r] = word;
+          atomicAdd(&s_h2[(word >> ex.shift2) & ex.mask2], 1u);
+        }
+      }
+    }
+    __syncthreads();                                      // (D) the tile's words live in LDS only: the registers take the next tile
+    if (nnv) fetch(nkb, nnv);
+
+    // ---- write-out by digit: whole lines only.  Eight digits at a time: their LDS reads in flight together, then their
+    // stores, then the reads and the writes of what stays behind (one digit after the other the wave sat out two LDS round
+    // trips per digit: r04ab) ----
+    {
+      const u32 ws = (u32)__builtin_amdgcn_readfirstlane((int)w);
+#pragma unroll 1
+      for (int g8 = 0; g8 < 32; g8 += 8) {
+        u32 P[8], CC[8], NW[8], REM[8], FP[8], FT[8], TOT[8], val[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int b = g8 + i;
+          P[i]  = (u32)__builtin_amdgcn_readlane((int)cur, b);  CC[i] = (u32)__builtin_amdgcn_readlane((int)pend, b);
+          const u32 C = (u32)__builtin_amdgcn_readlane((int)cnt, b), ST = (u32)__builtin_amdgcn_readlane((int)excl, b);
+          TOT[i] = CC[i] + C;
+          const u32 end = P[i] + TOT[i], aend = end & ~(u32)(LINE - 1);
+          NW[i]  = (aend > P[i]) ? aend - P[i] : 0u;      // words that leave now: up to the last line boundary the digit has reached
+          REM[i] = TOT[i] - NW[i];                        // < LINE: what waits for the next tile
+          FP[i]  = (u32)TILE + (ws * 32u + (u32)b) * (u32)LINE;   // word o of the digit's queue: pending ones first, then the tile's
+          FT[i]  = ST - CC[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {                     // (a lane beyond the queue reads its first word: always a valid address)
+          const u32 o = (lane < TOT[i]) ? lane : 0u;
+          val[i] = s_words[o + ((o < CC[i]) ? FP[i] : FT[i])];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          if (lane < NW[i]) out[(u64)P[i] + lane] = val[i];
+          if (NW[i] > 64u) {                              // (a digit with more than 64 of the tile's keys: the rest of its lines)
+#pragma unroll 1
+            for (u32 o0 = 64u; o0 < NW[i]; o0 += 64u) {
+              const u32 o = o0 + lane;
+              if (o < NW[i]) out[(u64)P[i] + o] = s_words[o + ((o < CC[i]) ? FP[i] : FT[i])];
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const u32 o = NW[i] + ((lane < REM[i]) ? lane : 0u);
+          const u32 oo = (o < TOT[i]) ? o : 0u;
+          val[i] = s_words[oo + ((oo < CC[i]) ? FP[i] : FT[i])];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          if (lane < REM[i]) s_words[FP[i] + lane] = val[i];
+          if (lane == (u32)(g8 + i)) { cur = P[i] + NW[i]; pend = REM[i]; }
+        }
+      }
+    }
+    __syncthreads();                                      // (F)
+    kb = nkb; nv = nnv;
+  }
+  // the chunk's last words of every digit: one partial line each
+  {
+    const u32 ws = (u32)__builtin_amdgcn_readfirstlane((int)(tid0 >> 6));
+    const u32 l = tid0 & 63u;
+#pragma unroll 1
+    for (int b = 0; b < 32; b++) {
+      const u32 P = (u32)__builtin_amdgcn_readlane((int)cur, b), CC = (u32)__builtin_amdgcn_readlane((int)pend, b);
+      if (l < CC) out[(u64)P + l] = s_words[(u32)TILE + (ws * 32u + (u32)b) * (u32)LINE + l];
+    }
+  }
+  __syncthreads();
+  if (tid0 < (u32)R) { const u32 c2 = s_h2[tid0]; if (c2) atomicAdd(&ex.ghist2[tid0], (u64)c2); }
 }
 
 // fine_rows[chunk][file << 9 | nine bits] (k-mer counts per chunk, kmer_hist_fine_kernel) -> for every file that is `on`,
@@ -1590,7 +2007,25 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
     if (hipMalloc(&dbg_buf, 2 * 64 * 8 * sizeof(u64)) != hipSuccess) dbg_buf = nullptr;
   }
   if (dbg && dbg_buf) MGC_CHECK(hipMemsetAsync(dbg_buf, 0, 2 * 64 * 8 * sizeof(u64), st));
-  if (soa_hi_mask && (!msd || local || (dbg && dbg_buf))) return hipErrorInvalidValue;   // the 5-byte layout: look-back kernel, high digit first
+  if (soa_hi_mask && (!msd || (dbg && dbg_buf))) return hipErrorInvalidValue;   // the 5-byte layout: high digit first
+  if (msd && local && soa_hi_mask) {
+    // chunk-local with write combining (radix_group5wc_kernel): the caller kept the per-chunk histogram rows for it (MGC_SOA_WC=1)
+    if (n >> 32) return hipErrorInvalidValue;
+    static bool wattr = false;
+    if (!wattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group5wc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)Group5WcSmem::BYTES);
+      wattr = true;
+    }
+    LocalArgs la;
+    la.rows = local->d_rows; la.block_base = reinterpret_cast<const u64 *>(local->d_block_base);
+    la.vgrid = local->vgrid; la.per_chunk = local->per_chunk; la.file = local->file; la.span_shift = 9u - bA;
+    la.file_start = local->file_start; la.dbg = 0;
+    hipLaunchKernelGGL(radix_group5wc_kernel, dim3(local->n_chunks), dim3(BLOCK), Group5WcSmem::BYTES, st,
+                       reinterpret_cast<const u32 *>(d_keys), reinterpret_cast<const uint8_t *>(d_keys) + 4ull * n,
+                       reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u, &hdr->gbase[0][0], la,
+                       GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask});
+  } else
   if (msd && local && !(dbg && dbg_buf)) {
     // chunk-local first pass: one workgroup per chunk, private digit cursors, no look-back (radix_group_local_kernel).
     // MGC_LOCAL_KPT=8: 8192-key tiles, two workgroups per CU (one's LDS phases beside the other's memory phases)
@@ -1650,6 +2085,23 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                        &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
                        GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0]}, dbg_buf);
+  else if (msd && soa_hi_mask && getenv("MGC_SOA_2WG") && getenv("MGC_SOA_2WG")[0] == '1') {   // (read per call: the tests switch it)
+    // two workgroups per CU: the narrowed words go through LDS, not the whole keys (radix_group5_kernel).  MEASURED
+    // (profiles/r04aa_soa2wg_ab.txt, same box, twice each): 0.568 / 0.569 ms per launch of 135 M k-mers against 0.541 / 0.541 for
+    // one workgroup per CU with the register prefetch -- step 120.5 / 120.7 against 118.3 / 118.7 ms -- so it stays OFF.
+    static bool s5attr = false;
+    if (!s5attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)Group5Smem::BYTES);
+      s5attr = true;
+    }
+    static_assert(Group5Smem::TILE == (int)NARROW_TILE0, "narrow_scratch_bytes");
+    const dim3 grid5((uint32_t)std::min(tiles0, cus * 2));
+    hipLaunchKernelGGL(radix_group5_kernel, grid5, dim3(BLOCK), Group5Smem::BYTES, st, reinterpret_cast<const u32 *>(d_keys),
+                       reinterpret_cast<const uint8_t *>(d_keys) + 4ull * n, reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                       &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0,
+                       GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask});
+  }
   else if (msd && soa_hi_mask) {
     static bool sattr = false;
     if (!sattr) {

@@ -1158,6 +1158,36 @@ def test_medium_scale_matches_threaded_port(ops, oracle_lib, torch_cuda, k, n_re
     assert np.array_equal(klo, plo) and np.array_equal(khi, phi) and np.array_equal(counts, pcn)
 
 
+@pytest.mark.parametrize("variant", ["one", "two", "wc"])
+@pytest.mark.parametrize("k,n_reads,mode", [(21, 700_000, 0), (20, 300_000, 1), (23, 300_000, 0), (22, 50_000, 2)])
+def test_five_byte_first_pass_variants(ops, oracle_lib, torch_cuda, monkeypatch, k, n_reads, mode, variant):
+    """The first grouping pass of a file in the 5-byte layout, three kernels, k-mer by k-mer against the threaded port:
+    "one" (default): radix_group_kernel<..., SOA>, whole keys through LDS, one workgroup per CU, look-back;
+    "two" (MGC_SOA_2WG=1): radix_group5_kernel, the narrowed 32-bit words through LDS (64 KiB per 16384-key tile), two workgroups
+    per CU, write-out by digit -- measured 5 % slower;
+    "wc" (MGC_SOA_WC=1): radix_group5wc_kernel, chunk-local (private cursors off the per-chunk histogram rows, no look-back) with
+    write combining: a digit's words that do not fill a 128-byte line wait in LDS for the chunk's next tile, every store a whole line.
+    k = 20..23 (34..40 bits below the file), files of 0.1 .. 1.4 M k-mers (partial last tiles, chunks of a few tiles down to
+    chunks smaller than a tile), all three strand modes."""
+    from meryl_amd import capi
+    if variant == "two":
+        monkeypatch.setenv("MGC_SOA_2WG", "1")
+    if variant == "wc":
+        monkeypatch.setenv("MGC_SOA_WC", "1")
+    d = ops.dev_synth_reads(70 + k, n_reads * 5, 0, n_reads)
+    bases = d.cpu().numpy()
+    cfg = capi.configure(k, bases.size, 8 << 30, mode)
+    cfg.use_simple = 0
+    with ops.Session(cfg) as s:
+        s.push_bases_device(d)
+        s.count()
+        klo, khi, counts, _ = s.result_wide()
+        info = s.info()
+    phi, plo, pcn, pni = oracle_lib.count_threaded(bases.tobytes(), k, cfg.w_prefix, mode, threads=32)
+    assert info.n_instances == pni and info.n_distinct == len(plo)
+    assert np.array_equal(klo, plo) and np.array_equal(khi, phi) and np.array_equal(counts, pcn)
+
+
 @pytest.mark.parametrize("k,per_bucket", [(21, 40_000), (21, 3_000), (40, 10_000), (9, 2_000)])
 def test_large_input_partition_granularity(ops, oracle_lib, torch_cuda, monkeypatch, k, per_bucket):
     # inputs whose files would outgrow two grouping digits are partitioned finer than the 64 files (7..10 top bits);
@@ -1430,7 +1460,7 @@ _GRID_SWITCHES = {
     "MGC_NARROW": ["0"], "MGC_FINE_HIST": ["0"], "MGC_WIDE_MSD": ["0"], "MGC_GROUP_LOCAL": ["1"], "MGC_PARTITION_WC": ["1"],
     "MGC_FINISH_BITMAP": ["1"], "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"],
     "MGC_FINISH_TARGET": ["1", "4", "64", "700"], "MGC_FINISH_MIN_TOP": ["10", "14", "17", "18"], "MGC_STREAM_MAX": ["2000", "20000"],
-    "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"], "MGC_HASH64M": ["0"], "MGC_HASH128M": ["0"], "MGC_PIPE": ["1"],
+    "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"], "MGC_HASH64M": ["0"], "MGC_HASH128M": ["0"], "MGC_PIPE": ["1"], "MGC_SOA_2WG": ["1"], "MGC_SOA_WC": ["1"],
 }
 
 
