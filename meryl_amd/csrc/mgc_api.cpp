@@ -1099,7 +1099,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   uint32_t local_chunks = 0, local_per_chunk = 0, local_vgrid = 0;
   // MGC_SOA_WC=1: the first pass of 5-byte files chunk-local with write combining (mgc_sort.hip, radix_group5wc_kernel) -- it wants
   // the per-chunk rows of the fifteen-bit histogram too (read per call: the tests switch it)
-  const bool soa_wc = getenv("MGC_SOA_WC") && getenv("MGC_SOA_WC")[0] == '1';
+  const bool soa_wc = getenv("MGC_SOA_WC") && (getenv("MGC_SOA_WC")[0] == '1' || getenv("MGC_SOA_WC")[0] == '2');
   if (!ext_keys) {
     tm.begin(MGC_STAGE_HISTOGRAM);
     // (two digits cover at most 18 bits: beyond 2k - 6 = 41 nothing narrows -- the files' WHOLE keys then take the same

@@ -1319,21 +1319,30 @@ void radix_group_local_kernel(const K *__restrict__ in, typename GroupOut<K, NAR
 // complete -- pending words first, then the tile's -- and one LDS move of the rest.  Only a chunk's first line and its last
 // one per digit are partial.  Same output, HIST2 and reference code restated as radix_group_kernel (unpackSuffixes + std::sort,
 // merylCountArray.C:276-289,330 -- top bits only).
+// <KPT, LINE, MINW>: <16, 32, 4> is the kernel measured above (16384-key tiles, whole 128-byte lines, one workgroup per CU);
+// <8, 16, 8> = 8192-key tiles and pending HALF lines (512 x 16 words = 32 KiB): 72 KiB per workgroup, TWO per CU, every store an
+// aligned 64-byte half line (MGC_SOA_WC=2; 60 VGPRs, no scratch).  Bit-exact, and MEASURED with the round's last GPU seconds
+// (profiles/r04ad_soa_wc2.txt): 0.80 ms per launch of 135 M k-mers against 0.54 - 0.56.  Not analysed (no budget left); the one
+// difference to the micro-benchmark's 0.409 ms for aligned 64-byte runs that stands out: there the two halves of a line arrive
+// back to back, here one 8192-key tile apart.  Off.
+template <int KPT_, int LINE_>
 struct Group5WcSmem {
-  static constexpr int R = 512, BLOCK = 1024, KPT = 16, TILE = BLOCK * KPT, LINE = 32;
+  static constexpr int R = 512, BLOCK = 1024, KPT = KPT_, TILE = BLOCK * KPT, LINE = LINE_;
   static constexpr size_t OFF_CARRY = (size_t)TILE * 4;                       // u32[R * LINE]  pending words of every digit
   static constexpr size_t OFF_HIST  = OFF_CARRY + (size_t)R * LINE * 4;      // u32[R]
   static constexpr size_t OFF_DBASE = OFF_HIST + (size_t)R * 4;              // u32[R]
   static constexpr size_t OFF_H2    = OFF_DBASE + (size_t)R * 4;             // u32[R]
   static constexpr size_t OFF_TMP   = OFF_H2 + (size_t)R * 4;                // u32[64]
   static constexpr size_t BYTES     = OFF_TMP + 64 * 4;
-  static_assert(BYTES <= 160 * 1024, "one workgroup per CU");
+  static_assert(BYTES <= 160 * 1024, "one workgroup per CU at least");
 };
 
-__global__ __launch_bounds__(1024, 4)
+template <int KPT_, int LINE_, int MINW>
+__global__ __launch_bounds__(1024, MINW)
 void radix_group5wc_kernel(const u32 *__restrict__ in_lo, const uint8_t *__restrict__ in_hi, u32 *__restrict__ out, u64 n, u32 shift,
                            u32 dmask, const u64 *__restrict__ gbase, LocalArgs la, GroupExtra ex) {
-  using SM = Group5WcSmem;
+  using SM = Group5WcSmem<KPT_, LINE_>;
+  static_assert(MINW == 4 || 2 * SM::BYTES <= 160 * 1024, "two workgroups per CU");
   constexpr int R = SM::R, BLOCK = SM::BLOCK, KPT = SM::KPT, TILE = SM::TILE, LINE = SM::LINE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32 *s_words = reinterpret_cast<u32 *>(smem);                 // (s_words[TILE + 32 d + i] = pending word i of digit d)
@@ -2011,20 +2020,30 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
   if (msd && local && soa_hi_mask) {
     // chunk-local with write combining (radix_group5wc_kernel): the caller kept the per-chunk histogram rows for it (MGC_SOA_WC=1)
     if (n >> 32) return hipErrorInvalidValue;
+    using W1 = Group5WcSmem<16, 32>;
+    using W2 = Group5WcSmem<8, 16>;
     static bool wattr = false;
     if (!wattr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group5wc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)Group5WcSmem::BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group5wc_kernel<16, 32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)W1::BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group5wc_kernel<8, 16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)W2::BYTES);
       wattr = true;
     }
     LocalArgs la;
     la.rows = local->d_rows; la.block_base = reinterpret_cast<const u64 *>(local->d_block_base);
     la.vgrid = local->vgrid; la.per_chunk = local->per_chunk; la.file = local->file; la.span_shift = 9u - bA;
     la.file_start = local->file_start; la.dbg = 0;
-    hipLaunchKernelGGL(radix_group5wc_kernel, dim3(local->n_chunks), dim3(BLOCK), Group5WcSmem::BYTES, st,
-                       reinterpret_cast<const u32 *>(d_keys), reinterpret_cast<const uint8_t *>(d_keys) + 4ull * n,
-                       reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u, &hdr->gbase[0][0], la,
-                       GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask});
+    const GroupExtra gx{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask};
+    const char *wce = getenv("MGC_SOA_WC");                 // "2": half lines, 8192-key tiles, two workgroups per CU
+    if (wce && wce[0] == '2')
+      hipLaunchKernelGGL((radix_group5wc_kernel<8, 16, 8>), dim3(local->n_chunks), dim3(BLOCK), W2::BYTES, st,
+                         reinterpret_cast<const u32 *>(d_keys), reinterpret_cast<const uint8_t *>(d_keys) + 4ull * n,
+                         reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u, &hdr->gbase[0][0], la, gx);
+    else
+      hipLaunchKernelGGL((radix_group5wc_kernel<16, 32, 4>), dim3(local->n_chunks), dim3(BLOCK), W1::BYTES, st,
+                         reinterpret_cast<const u32 *>(d_keys), reinterpret_cast<const uint8_t *>(d_keys) + 4ull * n,
+                         reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u, &hdr->gbase[0][0], la, gx);
   } else
   if (msd && local && !(dbg && dbg_buf)) {
     // chunk-local first pass: one workgroup per chunk, private digit cursors, no look-back (radix_group_local_kernel).

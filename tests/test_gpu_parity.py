@@ -1158,7 +1158,7 @@ def test_medium_scale_matches_threaded_port(ops, oracle_lib, torch_cuda, k, n_re
     assert np.array_equal(klo, plo) and np.array_equal(khi, phi) and np.array_equal(counts, pcn)
 
 
-@pytest.mark.parametrize("variant", ["one", "two", "wc"])
+@pytest.mark.parametrize("variant", ["one", "two", "wc", "wc2"])
 @pytest.mark.parametrize("k,n_reads,mode", [(21, 700_000, 0), (20, 300_000, 1), (23, 300_000, 0), (22, 50_000, 2)])
 def test_five_byte_first_pass_variants(ops, oracle_lib, torch_cuda, monkeypatch, k, n_reads, mode, variant):
     """The first grouping pass of a file in the 5-byte layout, three kernels, k-mer by k-mer against the threaded port:
@@ -1166,7 +1166,8 @@ def test_five_byte_first_pass_variants(ops, oracle_lib, torch_cuda, monkeypatch,
     "two" (MGC_SOA_2WG=1): radix_group5_kernel, the narrowed 32-bit words through LDS (64 KiB per 16384-key tile), two workgroups
     per CU, write-out by digit -- measured 5 % slower;
     "wc" (MGC_SOA_WC=1): radix_group5wc_kernel, chunk-local (private cursors off the per-chunk histogram rows, no look-back) with
-    write combining: a digit's words that do not fill a 128-byte line wait in LDS for the chunk's next tile, every store a whole line.
+    write combining: a digit's words that do not fill a 128-byte line wait in LDS for the chunk's next tile, every store a whole line;
+    "wc2" (MGC_SOA_WC=2): the same with 8192-key tiles and pending half lines, two workgroups per CU -- measured much slower.
     k = 20..23 (34..40 bits below the file), files of 0.1 .. 1.4 M k-mers (partial last tiles, chunks of a few tiles down to
     chunks smaller than a tile), all three strand modes."""
     from meryl_amd import capi
@@ -1174,6 +1175,8 @@ def test_five_byte_first_pass_variants(ops, oracle_lib, torch_cuda, monkeypatch,
         monkeypatch.setenv("MGC_SOA_2WG", "1")
     if variant == "wc":
         monkeypatch.setenv("MGC_SOA_WC", "1")
+    if variant == "wc2":                                   # half lines, 8192-key tiles, two workgroups per CU
+        monkeypatch.setenv("MGC_SOA_WC", "2")
     d = ops.dev_synth_reads(70 + k, n_reads * 5, 0, n_reads)
     bases = d.cpu().numpy()
     cfg = capi.configure(k, bases.size, 8 << 30, mode)
