@@ -23,7 +23,8 @@ __device__ __forceinline__ u32 mix(u32 x) {            // (cheap and good enough
 // PHASES bit 0: rank, 1: scan + exchange, 2: second-digit atomics in the exchange, 3: read-out.  SEQ: digit = position / 32
 // (every wave instruction hits 2 counters: no bank conflicts, heavy same-address traffic) instead of a random digit.
 template <int PHASES, bool SEQ>
-__global__ __launch_bounds__(BLOCK) void rank_kernel(u32 tiles_per_wg, u32 *__restrict__ sink) {
+__global__ __launch_bounds__(BLOCK, 8) void rank_kernel   // (64 VGPRs: two workgroups must fit a CU)
+(u32 tiles_per_wg, u32 *__restrict__ sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32 *s_words = reinterpret_cast<u32 *>(smem);
   u32 *s_hist  = s_words + TILE;
