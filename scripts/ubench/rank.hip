@@ -7,7 +7,8 @@
 // Sweeps: which phases run, random against conflict-free digits, one against two workgroups per CU (the dynamic LDS size decides).
 // Prints cycles per tile and the time 135 M keys (one file of the judged workload: 32.2 tiles per CU) would take.
 //   hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/rank scripts/ubench/rank.hip && /tmp/rank
-// Written at the end of round 4, after the GPU budget was spent: compiled, NOT RUN yet.
+// Written at the end of round 4, after the GPU budget was spent: compiled, NOT RUN yet (at the 64-VGPR bound three of the
+// instantiations spill 8-12 dwords: keep an eye on that when reading their numbers).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef unsigned long long u64;
