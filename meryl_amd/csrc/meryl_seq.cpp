@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <future>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -203,6 +204,7 @@ struct msr_reader {
   bool        failed = false;        // the byte source reported an error (as opposed to its end)
   std::string failure;
   bool        pipe_done = false;
+  bool        pipe_is_cram = false;  // the pipe is `samtools view` (its failures are mostly a missing reference, not a damaged file)
 
   // up to n bytes; 0 at the end of the input, -1 on a read / decompression error (failure says which)
   int64_t source_read(void *dst, size_t n) {
@@ -218,7 +220,12 @@ struct msr_reader {
       const bool rd_err = ferror(pipe) != 0;
       const int status = pclose(pipe);               // the decompressor's verdict on the file
       pipe = nullptr; pipe_done = true;
-      if (rd_err || status != 0) { failed = true; failure = "the decompressor failed (corrupt or truncated file)"; return -1; }
+      if (rd_err || status != 0) {
+        failed = true;
+        failure = pipe_is_cram ? "`samtools view` failed (reference not found?  set REF_PATH / REF_CACHE, or convert with `samtools view -b -T ref.fa`; corrupt or truncated file?)"
+                               : "the decompressor failed (corrupt or truncated file)";
+        return -1;
+      }
       return 0;
     }
     const int got = gzread(gz, dst, (unsigned)(n > (1u << 30) ? (1u << 30) : n));
@@ -278,7 +285,17 @@ extern "C" msr_reader *msr_open(const char *name) {
   // when that binary is on the PATH -- the records arrive as SAM text and take the SAM path (SEQ of every record as stored) --
   // and refused with a message otherwise
   const bool cram = ends_with(n, ".cram");
-  if (cram && system("command -v samtools > /dev/null 2>&1") != 0) {
+  auto have_samtools = []() -> bool {                      // probed only when a CRAM file is opened, and again only if PATH changed
+    static std::mutex mu;
+    static std::string probed_path;
+    static bool probed = false, have = false;
+    std::lock_guard<std::mutex> lk(mu);
+    const char *pe = getenv("PATH");
+    const std::string path = pe ? pe : "";
+    if (!probed || path != probed_path) { have = system("command -v samtools > /dev/null 2>&1") == 0; probed = true; probed_path = path; }
+    return have;
+  };
+  if (cram && !have_samtools()) {
     seq_err("msr_open: '" + n + "': CRAM input is not supported without `samtools` on the PATH (it is decoded through `samtools view`); convert to BAM");
     return nullptr;
   }
@@ -295,6 +312,7 @@ extern "C" msr_reader *msr_open(const char *name) {
     const std::string cmd = cram ? "samtools view -h -- " + quoted
                                  : std::string(ends_with(n, ".bz2") ? "bzip2" : "xz") + " -dc -- " + quoted;
     r->pipe = popen(cmd.c_str(), "r");
+    r->pipe_is_cram = cram;
     if (!r->pipe) { seq_err("msr_open: cannot run '" + cmd + "': " + strerror(errno)); msr_close(r); return nullptr; }
   }
   else if (n != "-") {                                   // BGZF (bgzip, BAM)?  then the blocks are inflated in parallel

@@ -192,37 +192,8 @@ extern "C" int mgc_dev_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(d_err, 0, 4, st);
   if (e != hipSuccess) return hip_rc(e, "radix_sort memset");
-  // MGC_SORT_DBG=1: per-phase cycle stamps of the scatter kernel (developer instrumentation, stderr)
-  void *dbg = nullptr;
-  const uint64_t dbg_tiles = n / 4096 + 2;
-  if (getenv("MGC_SORT_DBG")) { if (hipMalloc(&dbg, dbg_tiles * 64) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, dbg_tiles * 64); }
-  plan.dbg = dbg;
   e = mgc::launch_radix_sort(d_keys, d_alt, n, key_words, plan, d_ws, ws_bytes - 256, d_err, result_in_alt, st, nullptr);
   if (e != hipSuccess) return hip_rc(e, "radix_sort");
-  if (dbg) {
-    (void)hipStreamSynchronize(st);
-    std::vector<uint64_t> h(dbg_tiles * 8);
-    (void)hipMemcpy(h.data(), dbg, dbg_tiles * 64, hipMemcpyDeviceToHost);
-    const bool pipe_fmt = (plan.lookback == 5 || plan.mode == 3);
-    if (pipe_fmt) {                       // pipelined kernels: per-phase cycle sums of the first 64 workgroups, last pass
-      double ps[8] = {0};
-      for (int b = 0; b < 64; b++) for (int i = 0; i < 8; i++) ps[i] += (double)h[b * 8 + i];
-      const double it = ps[7] > 0 ? ps[7] : 1;
-      fprintf(stderr, "[sortdbg pipe] tiles/wg=%.1f cycles/tile: ticket+zero=%.0f rank=%.0f totals+positions+exchange=%.0f lookback+prefetch=%.0f writeout=%.0f endsync=%.0f total=%.0f\n",
-              it / 64, ps[0] / it, ps[1] / it, ps[2] / it, ps[3] / it, ps[4] / it, ps[5] / it,
-              (ps[0] + ps[1] + ps[2] + ps[3] + ps[4] + ps[5]) / it);
-    }
-    double sum[6] = {0, 0, 0, 0, 0, 0}; uint64_t cnt = 0;
-    for (uint64_t t = 0; !pipe_fmt && t < dbg_tiles; t++) {
-      if (h[t * 8] == 0 || h[t * 8 + 6] == 0) continue;
-      for (int i = 0; i < 6; i++) sum[i] += (double)(h[t * 8 + i + 1] - h[t * 8 + i]);
-      cnt++;
-    }
-    if (cnt) fprintf(stderr, "[sortdbg] tiles=%lu cycles/tile: ticket+zero=%.0f load+rank=%.0f totals+scan+publish=%.0f positions+exchange=%.0f lookback=%.0f writeout=%.0f total=%.0f\n",
-                     (unsigned long)cnt, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt,
-                     (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5]) / cnt);
-    (void)hipFree(dbg);
-  }
   uint32_t h_err = 0;
   e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -418,8 +389,6 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_in, hipStreamNonBlocking);
   if (e != hipSuccess) { set_err(nullptr, "hipStreamCreate: %s", hipGetErrorString(e)); delete s; return nullptr; }
   if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&s->stream3, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&s->ev_join2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
     set_err(nullptr, "hipStreamCreate / hipEventCreate failed"); mgc_close(s); return nullptr;
@@ -455,10 +424,7 @@ extern "C" void mgc_close(mgc_session *s) {
   for (char *&p : s->text_ring) if (p) { (void)hipHostFree(p); p = nullptr; }
   if (s->st_up) { (void)hipStreamSynchronize(s->st_up); (void)hipStreamDestroy(s->st_up); }
   if (s->st_in) (void)hipStreamDestroy(s->st_in);
-  for (hipEvent_t e : s->hist_ev) if (e) (void)hipEventDestroy(e);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-  if (s->ev_join2) (void)hipEventDestroy(s->ev_join2);
-  if (s->stream3) (void)hipStreamDestroy(s->stream3);
   if (s->h_stats) (void)hipHostFree(s->h_stats);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
@@ -825,27 +791,6 @@ static int push_text_file_range(mgc_session *s, const char *path, int format, in
   int rc = mgc_begin_text(s, format);
   if (rc != MGC_OK) { close(fd); return rc; }
 
-  // MGC_TEXT_MMAP=1: no reader threads at all -- the file is mapped and every 32 MiB piece is handed to hipMemcpyAsync
-  // straight from the mapping (the runtime pins pageable sources on the fly: 56 GB/s for a 1 GiB pageable buffer on this
-  // box, scripts/pcie_bench.py); the page cache IS the upload buffer.
-  if (const char *mm = getenv("MGC_TEXT_MMAP")) if (mm[0] == '1' && size > 0) {
-    void *map = (base == 0) ? mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0) : MAP_FAILED;     // whole files only
-    if (map != MAP_FAILED) {
-      (void)madvise(map, size, MADV_SEQUENTIAL);
-      const size_t CHm = mgc_session::TEXT_CHUNK;
-      const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-      for (uint64_t off = 0; off < size && rc == MGC_OK; off += CHm)
-        rc = text_submit(s, reinterpret_cast<const char *>(map) + off, (size_t)std::min<uint64_t>(CHm, size - off));
-      for (int b = 0; b < 2; b++) if (s->text_ev_used[b]) (void)hipEventSynchronize(s->text_ev[b]);
-      if (getenv("MGC_IO_TRACE"))
-        fprintf(stderr, "[io] text file %.2f GB uploaded from its mapping in %.3f s\n", size / 1e9,
-                std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
-      munmap(map, size);
-      close(fd);
-      const int rc_end = mgc_end_text(s);
-      return rc != MGC_OK ? rc : rc_end;
-    }
-  }
   // Readers and ring: measured on the 2 x 64-core box (scripts/e2e_cli.py, 20.5 GB FASTQ on tmpfs): 6 readers / 8 slots keep
   // the uploader waiting 1.7 s, 16 readers / 24 slots 0.01 s (the loop then runs at the 0.5 s of upload + parse).  The pinned
   // slots are allocated by the readers themselves, in parallel, on first use, and stay with the session for the next file.
@@ -1095,11 +1040,6 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   // 8 B/k-mer digit-histogram read of every file goes away.
   const uint64_t *d_fine = nullptr;
   const uint64_t *d_fine_hpc = nullptr;                              // `compress`: the dense-rank form of that histogram
-  uint32_t *d_fine_rows = nullptr;
-  uint32_t local_chunks = 0, local_per_chunk = 0, local_vgrid = 0;
-  // MGC_SOA_WC=1: the first pass of 5-byte files chunk-local with write combining (mgc_sort.hip, radix_group5wc_kernel) -- it wants
-  // the per-chunk rows of the fifteen-bit histogram too (read per call: the tests switch it)
-  const bool soa_wc = getenv("MGC_SOA_WC") && (getenv("MGC_SOA_WC")[0] == '1' || getenv("MGC_SOA_WC")[0] == '2');
   if (!ext_keys) {
     tm.begin(MGC_STAGE_HISTOGRAM);
     // (two digits cover at most 18 bits: beyond 2k - 6 = 41 nothing narrows -- the files' WHOLE keys then take the same
@@ -1110,14 +1050,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     if (n_bases >= (1u << 22) && ((kw == 1 && 2 * k - bucket_bits <= 41) || wide_msd_on) && mgc::kmer_histogram_fine_ok(k, bucket_bits, s->sfx_mask)) {
       HIP_TRY(s, s->ensure(mgc_session::B_FINE, sizeof(uint64_t) << 15));
       uint64_t *fine = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_FINE].p);
-      // ... and per CHUNK of the partition's output too (64 MB at 10 Gbp): the first grouping pass of every file then runs
-      // chunk-local, without look-back (mgc_sort.hip, radix_group_local_kernel; MGC_GROUP_LOCAL=0: the look-back kernel)
-      if (mgc::group_local_enabled() || soa_wc) {
-        local_chunks = mgc::kmer_histogram_fine_chunks(n_bases, &local_per_chunk, &local_vgrid);
-        HIP_TRY(s, s->ensure(mgc_session::B_FINE_ROWS, (sizeof(uint32_t) << 15) * (size_t)local_chunks));
-        d_fine_rows = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_FINE_ROWS].p);
-      }
-      HIP_TRY(s, mgc::launch_kmer_histogram_fine(d_bases, n_bases, k, c.mode, d_counts64, fine, part_ws, st, d_fine_rows));
+      HIP_TRY(s, mgc::launch_kmer_histogram_fine(d_bases, n_bases, k, c.mode, d_counts64, fine, part_ws, st));
       d_fine = fine;
     } else if (c.homopoly_compress && n_bases >= (1u << 22) && (2 * k - bucket_bits) % 2 == 0 && 2 * k - bucket_bits >= 20 &&
                !(getenv("MGC_HPC_DIGITS") && getenv("MGC_HPC_DIGITS")[0] == '0') && mgc::kmer_histogram_hpc_ok(k, bucket_bits, s->sfx_mask)) {
@@ -1166,10 +1099,6 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   bool partition_done = false;
   auto run_partition = [&](bool soa) -> int {
     if (ext_keys || partition_done) return MGC_OK;
-    if (getenv("MGC_PART_DBG")) {                            // (its k-mers are garbage by design: only the bare partition operator may run it)
-      set_err(&s->err, "MGC_PART_DBG is a measurement-only form of the partition (scripts/part_dbg.py): unset it to count");
-      return MGC_EINVAL;
-    }
     partition_done = true;
     HIP_TRY(s, hipMemcpyAsync(d_starts, h_starts, sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
     tm.begin(MGC_STAGE_PARTITION);
@@ -1260,8 +1189,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         // homopolymer-compressed sequence never repeats a base: every 2-bit group after the first takes 3 of its 4
         // values, so only (3/4)^(t/2) of the 2^t top-bit patterns occur and the occupied sub-buckets are that much
         // larger than planned: log2(4/3)/2 = 0.2075 of every key bit carries no information
-        const char *sc = getenv("MGC_HPC_BITS_SCALE");
-        const double scale = (sc && *sc) ? atof(sc) : 1.0 / (1.0 - 0.2075);
+        const double scale = 1.0 / (1.0 - 0.2075);
         const uint32_t tc = (uint32_t)((double)t * scale + 0.5);
         t = tc < rem_bits ? (tc < 26 ? tc : 26) : rem_bits;
       }
@@ -1293,50 +1221,38 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     void     *rle_ws     = s->buf[mgc_session::B_RLE_WS].p;
 
     // ---- A. global LSB passes on the top bits only ----
-    // the finish only needs the file grouped by its top bits (MGC_GROUP=0: full stable passes)
-    static const bool use_group = !(getenv("MGC_GROUP") && getenv("MGC_GROUP")[0] == '0');
-    // The digit histograms of ALL files are taken ahead of the passes, on the second stream: that read of every key is
-    // pure streaming and runs beside the latency-bound grouping passes of the files before it (one 256-thread
-    // histogram workgroup fits next to the 1024-thread grouping workgroup on every CU) instead of in front of each
-    // file's passes.  MEASURED (profiles/r02c: 10 Gbp, k=21): the extra streaming traffic slows the grouping passes more
-    // (0.585 -> 0.655 ms per launch) than the 16 ms it hides -- 178.7 vs 184.5 ms per step -- so it stays OFF unless
-    // MGC_HIST_AHEAD=1.
-    static const bool hist_ahead = getenv("MGC_HIST_AHEAD") && getenv("MGC_HIST_AHEAD")[0] == '1';
+    // the finish only needs the file grouped by its top bits
     std::vector<mgc::SortPlan> fplan(nb);
-    std::vector<char> prepared(nb, 0);
     // narrow[b]: the file's k-mers travel as 32-bit words from the first grouping pass on (mgc::launch_group_narrow)
     std::vector<char> narrow(nb, 0);
     // wide_msd[b]: the file's whole keys take the high-digit-first passes (mgc::launch_group_wide)
     std::vector<char> wide_msd(nb, 0);
     std::vector<uint32_t> tr_a(nb, 0), tr_b(nb, 0);        // ... and in which order its sub-buckets lie (mgc::tr_index)
     const size_t hdr_bytes = mgc::sort_header_bytes();
-    unsigned char *d_hdrs = nullptr;
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0 || top_bits[b] == 0) continue;
       if (hpc_digits[b]) {
         mgc::make_hpc_group_plan(rem_bits - top_bits[b], top_bits[b] / 10, &fplan[b]);
         // (sub-bucket numbers made of dense ranks are no key bits: the kernels that put a k-mer's top bits back from its sub-bucket
         // number -- 32-bit suffixes -- stay with the low digit first)
-        wide_msd[b] = d_fine_hpc && nb <= 256 && !hist_ahead && top_bits[b] == 20 && (kw == 2 || rem_bits - top_bits[b] >= 32) &&
+        wide_msd[b] = d_fine_hpc && nb <= 256 && top_bits[b] == 20 && (kw == 2 || rem_bits - top_bits[b] >= 32) &&
                       mgc::finish_can_stream(kw, rem_bits - top_bits[b]) && mgc::sort_plan_wide_msd(fplan[b], h_counts[b]);
         continue;
       }
       mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fplan[b]);
-      if (use_group && fplan[b].mode == 0) fplan[b].mode = 3;
+      if (fplan[b].mode == 0) fplan[b].mode = 3;
       const uint32_t low = rem_bits - top_bits[b];
-      narrow[b] = !hist_ahead && low < 32 && mgc::finish_can_stream(kw, low) && mgc::sort_plan_narrows(fplan[b], h_counts[b], kw);
+      narrow[b] = low < 32 && mgc::finish_can_stream(kw, low) && mgc::sort_plan_narrows(fplan[b], h_counts[b], kw);
       // (only the hash-count kernels translate the sub-bucket numbers of whole keys)
-      wide_msd[b] = !narrow[b] && !hist_ahead && d_fine && nb <= 64 && mgc::finish_can_stream(kw, low) &&
+      wide_msd[b] = !narrow[b] && d_fine && nb <= 64 && mgc::finish_can_stream(kw, low) &&
                     mgc::sort_plan_wide_msd(fplan[b], h_counts[b]);
     }
     {
       // 5-byte layout: 8-byte keys with 33..40 bits below the file (k = 20..23), every non-empty file on the narrowed passes with
-      // the high digit first off the fifteen-bit histogram (the look-back kernel: the chunk-local one and the instrumented one read
-      // whole keys).  MGC_SOA5=0: whole keys.
+      // the high digit first off the fifteen-bit histogram (the instrumented instantiation reads whole keys).  MGC_SOA5=0: whole keys.
       const char *se = getenv("MGC_SOA5");                            // read per call: the tests switch it
       bool soa = !(se && se[0] == '0') && !ext_keys && kw == 1 && nb == 64 && d_fine && rem_bits > 32 && rem_bits <= 40 && s->sfx_mask == 0 &&
-                 (!d_fine_rows || soa_wc) && !getenv("MGC_GROUP_DBG") && !getenv("MGC_PART_DBG") &&
-                 !(getenv("MGC_PARTITION_WC") && getenv("MGC_PARTITION_WC")[0] == '1');
+                 !getenv("MGC_GROUP_DBG");
       for (uint32_t b = 0; b < nb && soa; b++) if (h_counts[b] && !(narrow[b] && top_bits[b])) soa = false;
       if (soa) soa_hi_mask = (1u << (rem_bits - 32)) - 1u;
       const int prc = run_partition(soa);
@@ -1380,7 +1296,6 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         d_nws = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_NARROW_WS].p);
         HIP_TRY(s, mgc::launch_narrow_prepare(d_fine, nb, bits_a, on, d_nhdrs, st));
         HIP_TRY(s, hipMemsetAsync(d_nws, 0, nws_off[nb], st));
-        if (d_fine_rows) HIP_TRY(s, mgc::launch_fine_rows_scan(d_fine_rows, local_chunks, nb, bits_a, on, st));
       }
     }
     if (d_fine_hpc && nb <= 256) {
@@ -1401,49 +1316,16 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         HIP_TRY(s, hipMemsetAsync(d_nws, 0, nws_off[nb], st));
       }
     }
-    if (hist_ahead && s->stream2) {
-      HIP_TRY(s, s->ensure(mgc_session::B_SORT_HDRS, hdr_bytes * nb));
-      d_hdrs = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_SORT_HDRS].p);
-      if (s->hist_ev.size() < nb) {
-        const size_t have = s->hist_ev.size();
-        s->hist_ev.resize(nb, nullptr);
-        for (size_t i = have; i < nb; i++) HIP_TRY(s, hipEventCreateWithFlags(&s->hist_ev[i], hipEventDisableTiming));
-      }
-      HIP_TRY(s, hipEventRecord(s->ev_fork, st));              // the keys are in place at this point of the session stream
-      HIP_TRY(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
-      for (uint32_t b = 0; b < nb; b++) {
-        if (h_counts[b] == 0 || top_bits[b] == 0 || !mgc::sort_plan_groups(fplan[b], h_counts[b])) continue;
-        HIP_TRY(s, mgc::launch_group_prepare(X + kbytes * h_starts[b], h_counts[b], kw, fplan[b], d_hdrs + hdr_bytes * b, s->stream2));
-        HIP_TRY(s, hipEventRecord(s->hist_ev[b], s->stream2));
-        prepared[b] = 1;
-      }
-    }
-    // Stage after stage (default), or pipelined (MGC_PIPE=1): the passes of all files go to the session stream back to back and a
-    // file's count kernel starts on a second / third stream as soon as its statistics are back (one 24-byte copy and an event
-    // per file), beside the grouping passes of the files after it; the host stays PIPE_AHEAD files ahead with the passes.  What
-    // cannot go beside the passes stays on the session stream, in order: the sort's second buffer Y belongs to the passes, so
-    // the streaming count of oversized sub-buckets gets a buffer of its own.
-    // MEASURED (profiles/r04y_pipe_ab.txt: 10 Gbp, k = 21, same box, twice each): pipelined 127.8 / 128.1 ms per step, stage
-    // after stage 119.9 / 119.3 -- the count kernels' LDS and HBM traffic slows the grouping passes by more than the overlap
-    // hides (the same answer MGC_HIST_AHEAD got in round 2) -- so it stays OFF.
-    const char *pipe_env = getenv("MGC_PIPE");                       // read per call: the tests switch it
-    const bool pipe = pipe_env && pipe_env[0] == '1' && !hist_ahead && s->stream2 && s->stream3 && nb > 1;
-    static const uint32_t pipe_ahead = getenv("MGC_PIPE_AHEAD") ? (uint32_t)atoi(getenv("MGC_PIPE_AHEAD")) : 2u;
-    if (s->hist_ev.size() < nb) {
-      const size_t have = s->hist_ev.size();
-      s->hist_ev.resize(nb, nullptr);
-      for (size_t i = have; i < nb; i++) HIP_TRY(s, hipEventCreateWithFlags(&s->hist_ev[i], hipEventDisableTiming));
-    }
+    // Stage after stage: the passes of all files go to the session stream back to back, one synchronisation brings the files'
+    // statistics back, then the count kernels run.  (A pipelined form -- a file's count kernel on another stream as soon as its
+    // statistics are back, beside the passes of the files after it -- was built in round 4, measured slower and removed in round 5:
+    // profiles/r04y_pipe_ab.txt, DESIGN_HISTORY.md.)
     if (s->h_stats_cap < 3 * (size_t)nb) {
       if (s->h_stats) { (void)hipHostFree(s->h_stats); s->h_stats = nullptr; s->h_stats_cap = 0; }
       HIP_TRY(s, hipHostMalloc(reinterpret_cast<void **>(&s->h_stats), sizeof(uint64_t) * 3 * (size_t)nb, hipHostMallocDefault));
       s->h_stats_cap = 3 * (size_t)nb;
     }
     unsigned char *huge_alt = Y;
-    if (pipe) {
-      HIP_TRY(s, s->ensure(mgc_session::B_HUGE_ALT, kbytes * max_bucket));
-      huge_alt = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_HUGE_ALT].p);
-    }
 
     // ---- A + B/C of one file: its grouping passes, then its sub-bucket boundaries and its largest sub-bucket ----
     auto group_file = [&](uint32_t b) -> int {
@@ -1455,12 +1337,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (top_bits[b] == 0) {
         // (a file of one sub-bucket: nothing to group)
       } else if (narrow[b]) {                                // X (8 B) -> Y (4 B) -> front of X (4 B); boundaries included
-        mgc::GroupLocal gl;
-        gl.d_rows = d_fine_rows; gl.d_block_base = reinterpret_cast<const uint64_t *>(part_ws);
-        gl.n_chunks = local_chunks; gl.vgrid = local_vgrid; gl.per_chunk = local_per_chunk; gl.file = b; gl.file_start = h_starts[b];
         HIP_TRY(s, mgc::launch_group_narrow(src, (void *)Y, h_counts[b], fp, sort_ws, sort_ws_bytes - 256, d_err, d_substart + sbase[b], st, pe,
                                             d_nhdrs ? (void *)(d_nhdrs + hdr_bytes * b) : nullptr, d_nws ? (void *)(d_nws + nws_off[b]) : nullptr,
-                                            &tr_a[b], &tr_b[b], (d_nhdrs && d_fine_rows) ? &gl : nullptr, soa_hi_mask));
+                                            &tr_a[b], &tr_b[b], soa_hi_mask));
         file_passes[b] = 2;
         narrowed[b] = 1;
         sort_launch_groups++;
@@ -1472,9 +1351,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         s->prof.wide_msd_files++;
       } else {
         wide_msd[b] = 0;
-        if (prepared[b]) HIP_TRY(s, hipStreamWaitEvent(st, s->hist_ev[b], 0));
-        HIP_TRY(s, mgc::launch_radix_sort(src, (void *)Y, h_counts[b], kw, fp, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe,
-                                          prepared[b] ? (void *)(d_hdrs + hdr_bytes * b) : nullptr));
+        HIP_TRY(s, mgc::launch_radix_sort(src, (void *)Y, h_counts[b], kw, fp, sort_ws, sort_ws_bytes - 256, d_err, &in_alt, st, pe));
         if (in_alt) HIP_TRY(s, hipMemcpyAsync(src, Y, kbytes * h_counts[b], hipMemcpyDeviceToDevice, st));
         file_passes[b] = fp.num_passes;
         sort_launch_groups++;
@@ -1498,18 +1375,12 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       for (; grouped < end && grouped < nb; grouped++) {
         const int rc = group_file(grouped);
         if (rc != MGC_OK) return rc;
-        if (pipe) {
-          { const int rc2 = stats_file(grouped); if (rc2 != MGC_OK) return rc2; }
-          HIP_TRY(s, hipMemcpyAsync(s->h_stats + 3 * (size_t)grouped, d_stats + 3 * (size_t)grouped, sizeof(uint64_t) * 3, hipMemcpyDeviceToHost, st));
-          HIP_TRY(s, hipEventRecord(s->hist_ev[grouped], st));
-        }
         if (grouped + 1 == nb) {
           tm.end(MGC_STAGE_SORT);
           tm.begin(MGC_STAGE_RLE);
-          if (!pipe) {                                       // the small statistics kernels of all files back to back: they run beside each other
-            for (uint32_t b = 0; b < nb; b++) { const int rc2 = stats_file(b); if (rc2 != MGC_OK) return rc2; }
-            HIP_TRY(s, hipMemcpyAsync(s->h_stats, d_stats, sizeof(uint64_t) * 3 * (size_t)nb, hipMemcpyDeviceToHost, st));
-          }
+          // the small statistics kernels of all files back to back: they run beside each other
+          for (uint32_t b = 0; b < nb; b++) { const int rc2 = stats_file(b); if (rc2 != MGC_OK) return rc2; }
+          HIP_TRY(s, hipMemcpyAsync(s->h_stats, d_stats, sizeof(uint64_t) * 3 * (size_t)nb, hipMemcpyDeviceToHost, st));
         }
       }
       return MGC_OK;
@@ -1518,17 +1389,14 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     // ---- D. finish every file: LDS sort + count, or the full-sort fallback ----
     // The streaming kernel of a file's oversized sub-buckets goes to a second stream: it touches other sub-buckets than
     // the persistent kernel, and one gigantic sub-bucket occupies ONE workgroup for hundreds of microseconds -- beside
-    // the persistent kernels of this and the next files that tail costs nothing (MGC_FINISH_FORK=0: same stream).
-    static const bool fork_huge_env = !(getenv("MGC_FINISH_FORK") && getenv("MGC_FINISH_FORK")[0] == '0');
-    const bool fork_huge = fork_huge_env || pipe;
+    // the persistent kernels of this and the next files that tail costs nothing.
+    const bool fork_huge = s->stream2 != nullptr;
     hipStream_t st_huge = fork_huge ? s->stream2 : st;
     // The persistent kernels of odd files go to the second stream too, so that the tail of one file's launch overlaps the
-    // head of the next: finish stage 58.5 -> 54.2 ms per 10 Gbp (MGC_FINISH_ALT=0: all on the session stream).  All
-    // streaming kernels stay on stream2: they share one second buffer.
-    static const bool alt_files_env = !(getenv("MGC_FINISH_ALT") && getenv("MGC_FINISH_ALT")[0] == '0');
-    const bool alt_files = fork_huge && alt_files_env;
+    // head of the next: finish stage 58.5 -> 54.2 ms per 10 Gbp.  All streaming kernels stay on stream2: they share one
+    // second buffer.
+    const bool alt_files = fork_huge;
     bool forked = false, need_join = false;          // forked: stream2 is ordered after everything st holds that it must see
-    bool used3 = false;                              // pipelined: the third stream holds work the session stream must wait for
     // tests run the dense-grid instantiations of the count kernels on small inputs (whose 2^t grids are mostly empty)
     const bool finish_nolist = getenv("MGC_FINISH_NOLIST") && getenv("MGC_FINISH_NOLIST")[0] == '1';
     std::vector<std::pair<hipEvent_t, hipEvent_t>> fin_ev;       // profiling: around every file's count-kernel launch
@@ -1565,7 +1433,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       bool unordered = false;
       if (narrow[b] && h_nlarge[b] > 0 && !stream) {
         // an oversized sub-bucket that cannot be streamed: the LDS sort / the stable-sort fallback want whole k-mers back
-        if (need_join && !pipe) HIP_TRY(s, hipStreamSynchronize(st_huge));   // Y is the streaming kernels' second buffer
+        if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));   // Y is the streaming kernels' second buffer
         forked = false;
         HIP_TRY(s, mgc::launch_widen_groups(seg, d_substart + sbase[b], gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, low, (void *)Y, st,
                                             tr_a[b], tr_b[b]));
@@ -1580,20 +1448,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (wide_msd[b] && h_nlarge[b] > 0 && !stream) unordered = true;
       if ((h_maxsub[b] <= cap || stream) && !unordered) {
         hipStream_t fst;
-        if (pipe) {
-          // a file that was just widened on the session stream is counted there, behind it; the others beside the passes
-          const bool here = !narrowed[b] ? false : !narrow[b];
-          fst = here ? st : ((alt_files_env && (b & 1u)) ? s->stream2 : s->stream3);
-          if (fst != st) {
-            HIP_TRY(s, hipStreamWaitEvent(fst, s->hist_ev[b], 0));
-            if (fst == s->stream3) used3 = true; else need_join = true;
-          }
-          if (stream) {                                  // (ordered after the file's widening too, if it had one: recorded now)
-            if (here) { HIP_TRY(s, hipEventRecord(s->ev_fork, st)); HIP_TRY(s, hipStreamWaitEvent(st_huge, s->ev_fork, 0)); }
-            else HIP_TRY(s, hipStreamWaitEvent(st_huge, s->hist_ev[b], 0));
-            need_join = true;
-          }
-        } else {
+        {
           const bool on_second = alt_files && (b & 1u);
           if ((stream || on_second) && fork_huge && !forked) {   // everything the forked kernels read is complete at this point of st
             HIP_TRY(s, hipEventRecord(s->ev_fork, st));
@@ -1619,7 +1474,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
         fallback[b] = true;
-        if (need_join && !pipe) HIP_TRY(s, hipStreamSynchronize(st_huge));  // the sort below uses Y, the streaming kernels' second buffer
+        if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));  // the sort below uses Y, the streaming kernels' second buffer
         forked = false;                                            // ... and the next streaming kernel must wait for that sort
         if (low || unordered) {
           // LSD order: the low bits cannot be sorted after the top bits, so the whole key is redone
@@ -1639,9 +1494,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     };
 
     for (uint32_t b = 0; b < nb; b++) {
-      { const int rc = group_upto(pipe ? b + 1 + pipe_ahead : nb); if (rc != MGC_OK) return rc; }
-      if (pipe) HIP_TRY(s, hipEventSynchronize(s->hist_ev[b]));
-      else if (b == 0) HIP_TRY(s, hipStreamSynchronize(st));
+      { const int rc = group_upto(nb); if (rc != MGC_OK) return rc; }
+      if (b == 0) HIP_TRY(s, hipStreamSynchronize(st));
       h_maxsub[b] = s->h_stats[3 * (size_t)b]; h_nlarge[b] = s->h_stats[3 * (size_t)b + 1]; h_nzcount[b] = s->h_stats[3 * (size_t)b + 2];
       const int rc = finish_file(b);
       if (rc != MGC_OK) return rc;
@@ -1650,10 +1504,6 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     if (need_join) {
       HIP_TRY(s, hipEventRecord(s->ev_join, st_huge));
       HIP_TRY(s, hipStreamWaitEvent(st, s->ev_join, 0));
-    }
-    if (used3) {
-      HIP_TRY(s, hipEventRecord(s->ev_join2, s->stream3));
-      HIP_TRY(s, hipStreamWaitEvent(st, s->ev_join2, 0));
     }
 
     // ---- E/F. offsets of every sub-bucket in the packed result ----

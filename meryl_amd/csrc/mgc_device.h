@@ -27,11 +27,8 @@ bool       kmer_histogram_hpc_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_
 uint32_t   kmer_histogram_hpc_entries(uint32_t bucket_bits);
 hipError_t launch_kmer_histogram_hpc(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint32_t bucket_bits,
                                      uint64_t *d_bucket_counts, uint64_t *d_fine_hist, void *d_ws, hipStream_t st);
-// d_fine_rows (optional): [kmer_histogram_fine_chunks()][2^15] uint32 -- the same counts per CHUNK (the k-mers that
-// *per_chunk consecutive partition workgroups will write): what the chunk-local first grouping pass needs (mgc_sort.hip)
-uint32_t   kmer_histogram_fine_chunks(uint64_t n_bases, uint32_t *per_chunk, uint32_t *vgrid);
 hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint64_t *d_bucket_counts,
-                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st, uint32_t *d_fine_rows = nullptr);
+                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st);
 hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                                  uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st,
                                  uint64_t sfx_mask = 0, uint64_t sfx_test = 0);
@@ -44,24 +41,18 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
 
 // ---- radix sort ------------------------------------------------------------
 struct SortPlan {
-  uint32_t radix_bits;      // digit width of the kernel template in use (8 or 9)
-  uint32_t block;           // threads per workgroup
-  uint32_t kpt;             // keys per thread
+  uint32_t radix_bits;      // digit width (9)
+  uint32_t block;           // threads per workgroup (1024)
+  uint32_t kpt;             // keys per thread (16; 16-byte keys: 8)
   uint32_t tile;            // block*kpt
-  uint32_t mode;            // 0 = onesweep (decoupled look-back), 1 = classic (tile histogram + scan),
-                            // 3 = grouping passes (not a sort: see radix_group_kernel; at most two digits)
-  uint32_t match;           // 0 = ballot match, 1 = LDS mask match (ranking inside a wave)
-  uint32_t lookback;        // 1 = walk before the LDS exchange, 2 = window after it, 5 = pipelined persistent kernel
-  uint32_t flags;           // bit1: non-temporal key loads (experiments)
+  uint32_t mode;            // 0 = stable sort (decoupled look-back), 3 = grouping passes (not a sort: see radix_group_kernel; at most two digits)
   uint32_t hpc;             // digits are DENSE RANKS of five homopolymer-free bases (make_hpc_group_plan), not bit fields
-  void    *dbg;             // optional device buffer: 8 cycle stamps per tile of the LAST pass launched
   uint32_t num_passes;
   uint32_t pass_shift[16];
   uint32_t pass_bits[16];
 };
 
-// Chooses digit widths for bits [begin_bit, end_bit); honours MGC_RADIX_BITS /
-// MGC_SORT_MODE / MGC_SORT_KPT environment overrides (bench experiments).
+// Chooses digit widths for bits [begin_bit, end_bit) (MGC_SORT_MODE=3: grouping passes through the bare sort operator, for tests).
 void   make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan);
 // Grouping plan for homopolymer-compressed k-mers (`compress`): no base equals the one before it, so five bases after a
 // known base take 3^5 = 243 of their 1024 bit patterns.  A digit is the dense, ORDER-PRESERVING rank of five bases given
@@ -72,20 +63,12 @@ void   make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan);
 void   make_hpc_group_plan(uint32_t low_bit, uint32_t passes, SortPlan *plan);
 size_t sort_workspace_bytes(uint64_t n);
 
-struct SortTiming {           // optional per-pass event timing
-  hipEvent_t *ev;             // 2*num_passes events, or nullptr
-};
-
 // Sorts n keys; returns where the result is via *result_in_alt.  d_error is a
 // device uint32 the kernels set on a look-back timeout (checked by the caller).
 hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan,
                              void *d_ws, size_t ws_bytes, uint32_t *d_error, int *result_in_alt,
-                             hipStream_t st, hipEvent_t *pass_events /* 2 per pass or null */,
-                             void *d_prepared = nullptr /* header launch_group_prepare filled for these keys and this plan */);
-// grouping passes (plan.mode == 3): the digit histograms can be taken ahead of time, on another stream
+                             hipStream_t st, hipEvent_t *pass_events /* 2 per pass or null */);
 size_t     sort_header_bytes();
-bool       sort_plan_groups(const SortPlan &plan, uint64_t n);
-hipError_t launch_group_prepare(const void *d_keys, uint64_t n, uint32_t key_words, const SortPlan &plan, void *d_hdr, hipStream_t st);
 // Two grouping passes with NARROWED keys: uint64 keys whose bits above the first digit fit 32 bits leave the first pass as
 // uint32 words without that digit (its value is where the key lies), the second pass and the finish move half the bytes,
 // and the sub-bucket boundaries fall out of the second pass's look-back granules.  d_keys: uint64[n] in, uint32[n] out
@@ -99,21 +82,9 @@ bool       sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_word
 size_t     narrow_scratch_bytes(uint64_t n);
 hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsigned char *bits_a, const unsigned char *on, void *d_hdrs,
                                  hipStream_t st);
-// Chunk-local first pass (no look-back): the file was written by this session's own partition, so the k-mers of every
-// (chunk, digit) are known from the fifteen-bit histogram's per-chunk rows.  launch_fine_rows_scan turns the rows into
-// exclusive prefixes over the chunks for all files at once; `local` then names the file for launch_group_narrow.
-struct GroupLocal {
-  const uint32_t *d_rows;        // scanned rows
-  const uint64_t *d_block_base;  // the partition's cursors (its workspace after launch_kmer_partition): [vgrid][64]
-  uint32_t n_chunks, vgrid, per_chunk, file;
-  uint64_t file_start;           // absolute index of the file's first k-mer in the partition's output
-};
-bool       group_local_enabled();
-hipError_t launch_fine_rows_scan(uint32_t *d_rows, uint32_t n_chunks, uint32_t nb, const unsigned char *bits_a, const unsigned char *on,
-                                 hipStream_t st);
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events /* 4 or null */,
-                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, const GroupLocal *local = nullptr,
+                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b,
                                uint32_t soa_hi_mask = 0 /*nonzero: d_keys is the 5-byte layout of launch_kmer_partition(d_soa_counts); the mask of
                                the u8 array's payload bits (bits 32.. of the k-mer below the file)*/);
 

@@ -413,9 +413,9 @@ void lds_sort_count_kernel(K *__restrict__ keys,                      // the fil
 // EMPTY cannot collide with a key: every key of the file shares its top six bits, ~key0 does not.
 // NARROW: the sub-buckets hold 32-bit narrowed keys (launch_group_narrow) -- u32 loads, and the distinct SUFFIXES go back
 // in place as u32 (compact_groups_narrow_kernel puts the prefix back when it packs the result).
-// BINRANK: the distinct suffixes are ordered by a counting sort on their top eight bits (BLOCK bins, one per thread) and a
-// brute-force rank inside the bin -- O(D) for spread suffixes -- instead of the all-pairs rank (D^2 / BLOCK compares per thread).
-template <int BLOCK, int CAP, int SLOTS, bool DBG, bool LIST, bool NARROW = false, bool BINRANK = true>
+// The distinct suffixes are ordered by a counting sort on their top eight bits (BLOCK bins, one per thread) and a brute-force rank
+// inside the bin -- O(D) for spread suffixes (the all-pairs rank of round 1, D^2 / BLOCK compares per thread, was removed in round 5).
+template <int BLOCK, int CAP, int SLOTS, bool DBG, bool LIST, bool NARROW = false>
 __global__ __launch_bounds__(BLOCK, 7)
 void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                        u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
@@ -433,9 +433,9 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
   __shared__ __attribute__((aligned(16))) u32 dk[CAP + 16];
   __shared__ unsigned short dc[CAP];                   // slot of a claimed suffix, later its count: both below 2^16
   __shared__ u32 s_nd;                                 // distinct suffixes of the sub-bucket: the claimers of empty slots count themselves
-  __shared__ u32 s_bin[BINRANK ? BLOCK + 1 : 1];
+  __shared__ u32 s_bin[BLOCK + 1];
   __shared__ u32 s_scan[BLOCK / 64 + 1];
-  static_assert(!BINRANK || BLOCK == 256, "one bin per thread, eight bits");
+  static_assert(BLOCK == 256, "one bin per thread, eight bits");
   const u32 tid = threadIdx.x;
   const u64 G = gridDim.x;
   const u64 low_mask = (1ull << low_bits) - 1ull;
@@ -555,13 +555,8 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
       __syncthreads();
       HC_STAMP(2);
 
-      // rank = number of smaller distinct suffixes.  dk is padded with EMPTY (never smaller) to a multiple of 16, so
-      // the loop runs on whole 64-byte groups: four independent broadcast 16-byte LDS reads in flight per iteration
-      // (a (tried) order-preserving table with cluster-local ranks halves this phase but probes 50 % longer)
-      const uint4 *dk4 = reinterpret_cast<const uint4 *>(dk);
       u64 *gk = keys + a;
-      const u32 d16 = (D + 15) / 16;
-      if constexpr (BINRANK) {
+      {
         const u32 bshift = low_bits > 8 ? low_bits - 8 : 0;
         s_bin[tid] = 0;
         __syncthreads();
@@ -595,21 +590,6 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
           else                  gk[r] = prefix | (u64)ki;
           cnt_tmp[a + r] = dc[ix[pidx]];
         }
-      } else
-      for (u32 i = tid; i < D; i += BLOCK) {
-        const u32 ki = dk[i];
-        u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        for (u32 j = 0; j < d16; j++) {
-          const uint4 v0 = dk4[4 * j], v1 = dk4[4 * j + 1], v2 = dk4[4 * j + 2], v3 = dk4[4 * j + 3];
-          r0 += (v0.x < ki ? 1u : 0u) + (v0.y < ki ? 1u : 0u) + (v0.z < ki ? 1u : 0u) + (v0.w < ki ? 1u : 0u);
-          r1 += (v1.x < ki ? 1u : 0u) + (v1.y < ki ? 1u : 0u) + (v1.z < ki ? 1u : 0u) + (v1.w < ki ? 1u : 0u);
-          r2 += (v2.x < ki ? 1u : 0u) + (v2.y < ki ? 1u : 0u) + (v2.z < ki ? 1u : 0u) + (v2.w < ki ? 1u : 0u);
-          r3 += (v3.x < ki ? 1u : 0u) + (v3.y < ki ? 1u : 0u) + (v3.z < ki ? 1u : 0u) + (v3.w < ki ? 1u : 0u);
-        }
-        const u32 r = r0 + r1 + r2 + r3;
-        if constexpr (NARROW) reinterpret_cast<u32 *>(keys)[a + r] = ki;
-        else                  gk[r] = prefix | (u64)ki;  // in place: every key of this region sits in registers
-        cnt_tmp[a + r] = dc[i];
       }
       if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
       HC_STAMP(3);
@@ -657,7 +637,7 @@ void hash_count_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u
 #ifndef HCM_WAVES
 #define HCM_WAVES 8
 #endif
-template <int BLOCK, int CAP, int SLOTS, int R, bool DBG, bool LEAN = true>
+template <int BLOCK, int CAP, int SLOTS, int R, bool DBG>
 __global__ __launch_bounds__(BLOCK, HCM_WAVES)
 void hash_count_multi_kernel(u32 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                              u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 *__restrict__ dbg,
@@ -777,25 +757,7 @@ void hash_count_multi_kernel(u32 *__restrict__ keys, const u64 *__restrict__ sta
       // the last slot is partial); a claim is only NOTED (won) -- the claimed slots join the compact list after the loop with
       // one LDS atomic per wave instead of a returning atomic, a wait and a store inside every slot; the few keys whose
       // first slot held another suffix go round the generic loop.
-      if constexpr (!LEAN) {                           // (the first form: list appends inside the probe loop; kept for A/B)
-        u32 pending = 0;
-#pragma unroll
-        for (int j = 0; j < KPT; j++) { hh[j] = (comp[j] * 0x9E3779B1u) >> sshift; if ((u32)j * BLOCK + tid < n) pending |= 1u << j; }
-        while (pending) {
-#pragma unroll
-          for (int j = 0; j < KPT; j++) {
-            if ((pending >> j) & 1u) {
-              const u32 old = atomicCAS(&tk[hh[j]], EMPTY, (comp[j] << CNTB) | 1u);
-              const bool w = (old == EMPTY);
-              if (w) lst[atomicAdd(&s_nd, 1u)] = (unsigned short)hh[j];
-              const bool dup = (old >> CNTB) == comp[j];
-              if (dup) atomicAdd(&tk[hh[j]], 1u);
-              if (w || dup) pending &= ~(1u << j);
-              else hh[j] = (hh[j] + 1) & smask;
-            }
-          }
-        }
-      } else {
+      {
       u32 won = 0, pending = 0;
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
@@ -953,687 +915,11 @@ void hash_count_multi_kernel(u32 *__restrict__ keys, const u64 *__restrict__ sta
 #undef HC_STAMP
 }
 
-// Bitmap-count finish for narrowed files whose sub-bucket suffixes are at most LB (16 or 18) bits wide -- the judged
-// k = 21 workload: 36 bits below the file, 18 of them grouped away.  A suffix that short is its own perfect hash:
-//   A. every key sets ITS bit in a 2^LB-bit LDS bitmap (one non-returning LDS atomic, no probing, no table to size);
-//   B. one pass over the bitmap -- GPT 16-byte groups per thread -- gives the number of set bits before every group
-//      (u16 prefix per group) and the distinct count D: a set bit's rank is its position in the bitmap order, so nothing
-//      is ever sorted or ranked by comparison;
-//   C. every key finds its rank (group prefix + popcount below its bit) and adds one to counts[rank]; the ONE instance
-//      of every suffix that found its bit clear in A also writes the suffix out, in place at its rank: ascending;
-//   D. the counts leave, and every key clears the word it set (the bitmap is all zero again: no 32 KiB clear per sub-bucket).
-// O(n + 2^LB / 32) work per sub-bucket against the hash kernel's probe / compact / rank phases; replaces
-// countSingleKmers' sort + run-length passes (merylCountArray.C:323-365) for these files like hash_count_kernel does.
-// Logical group G = t * GPT + g lives at physical group G ^ ((G >> LOG_GPT) & (GPT - 1)): thread t reads its GPT groups with
-// 16-byte LDS loads, and without the swizzle all lanes of an instruction would sit GPT * 16 bytes apart on two bank quads.
-template <int BLOCK, int CAP, int LB, bool LIST>
-__global__ __launch_bounds__(BLOCK, (LB > 16 ? 4 : 6))
-void bitmap_count_kernel(u32 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
-                         u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                         const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u32 tr_a, u32 tr_b) {
-  constexpr int KPT = CAP / BLOCK;
-  constexpr int NGRP = 1 << (LB - 7);                  // 128-bit groups of the bitmap
-  constexpr int GPT = NGRP / BLOCK;                    // groups per thread in the scan (8 for LB = 18, 2 for LB = 16)
-  constexpr int LOG_GPT = (GPT == 8) ? 3 : (GPT == 4) ? 2 : (GPT == 2) ? 1 : 0;
-  static_assert(CAP % BLOCK == 0 && NGRP % BLOCK == 0 && (1 << LOG_GPT) == GPT && CAP < 65536, "bitmap geometry");
-  __shared__ uint4 bm4[NGRP];
-  __shared__ __attribute__((aligned(16))) unsigned short pre[NGRP];
-  __shared__ u32 cnt[CAP / 2 + 2];                     // two 16-bit counts per word (a count is <= CAP)
-  __shared__ u32 s_scan[BLOCK / 64 + 1];
-  u32 *bm = reinterpret_cast<u32 *>(bm4);
-  const u32 tid = threadIdx.x;
-  const u64 G = gridDim.x;
-  const u32 low_mask = (low_bits >= 32) ? 0xFFFFFFFFu : ((1u << low_bits) - 1u);
-  auto phys = [](u32 g) -> u32 { return g ^ ((g >> LOG_GPT) & (u32)(GPT - 1)); };
+// (Round 5: the kernels hash_countw_kernel replaced -- hash_count64_kernel with 64-bit suffixes in the table, hash_count64i_kernel and
+// hash_count128_kernel with the index-claimed table and a pass over it -- and the bitmap-count kernel, measured equal to the hash-count
+// in round 3, were removed: DESIGN_HISTORY.md, profiles/r03a_*, r04k_*, r04v_*.)
 
-  for (u32 i = tid; i < (u32)NGRP; i += BLOCK) bm4[i] = make_uint4(0u, 0u, 0u, 0u);
-
-  auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
-    aa = 0; nn = 0;
-    if (gg < ng) { aa = starts[gg]; nn = starts[gg + 1] - aa; }
-  };
-  auto load_keys = [&](u64 aa, u64 nn, u32 (&kr)[KPT]) {
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      const u32 idx = (u32)j * BLOCK + tid;
-      kr[j] = (nn <= max_size && idx < nn) ? keys[aa + idx] : 0u;
-    }
-  };
-  const u64 np = LIST ? *nz_count : ng;
-  auto sub_at = [&](u64 pp) -> u64 { return (pp < np) ? (LIST ? (u64)nz[pp] : pp) : ng; };
-  u64 p = blockIdx.x;
-  u64 g = sub_at(p), g1 = sub_at(p + G), g2 = sub_at(p + 2 * G), a, n64, na, nn;
-  u32 kcur[KPT];
-  load_bounds(g, a, n64);
-  load_keys(a, n64, kcur);
-  load_bounds(g1, na, nn);
-  __syncthreads();                                     // the bitmap is clear
-
-  while (g < ng) {
-    u32 knext[KPT];
-    u64 nna, nnn;
-    // (everything the previous iteration loaded is consumed BEFORE the next loads are issued: with the loads in conditional
-    // blocks the compiler's wait for the old registers is vmcnt(0) -- issued after the new loads it would wait for THEM)
-#pragma unroll
-    for (int j = 0; j < KPT; j++) asm volatile("" : "+v"(kcur[j]) :: "memory");
-    load_keys(na, nn, knext);                          // in flight while this sub-bucket is counted
-    load_bounds(g2, nna, nnn);
-    const u64 g3 = sub_at(p + 3 * G);
-
-    if (n64 == 0) {
-      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
-    } else if (n64 <= max_size) {
-      const u32 n = (u32)n64;
-      u32 *gk = keys + a;                              // a file holds fewer than 2^30 keys: 32-bit offsets from here on
-      u32 *gc = cnt_tmp + a;
-      u32 wa[KPT];                                     // LDS word of the key's bit | first << 31; ~0: no key
-      // ---- A. set; the instance that finds its bit clear is the one that will write the suffix out ----
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        const u32 idx = (u32)j * BLOCK + tid;
-        const u32 s = kcur[j] & low_mask;
-        kcur[j] = s;
-        wa[j] = ~0u;
-        if (idx < n) {
-          const u32 wd = phys(s >> 7) * 4u + ((s >> 5) & 3u), bit = 1u << (s & 31u);
-          const u32 old = atomicOr(&bm[wd], bit);
-          wa[j] = wd | ((old & bit) ? 0u : 0x80000000u);
-        }
-      }
-      __syncthreads();
-      // ---- B. set bits before every 128-bit group ----
-      u32 gpre[GPT], run = 0;
-#pragma unroll
-      for (int q = 0; q < GPT; q++) {
-        const uint4 v = bm4[phys(tid * GPT + q)];
-        gpre[q] = run;
-        run += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-      }
-      // block scan with ONE barrier: s_scan was last read three barriers ago
-      u32 incl = run;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(incl, d); if ((int)(tid & 63u) >= d) incl += y; }
-      if ((tid & 63u) == 63u) s_scan[tid >> 6] = incl;
-      __syncthreads();
-      u32 D = 0, base = incl - run;
-#pragma unroll
-      for (int i = 0; i < BLOCK / 64; i++) { const u32 t = s_scan[i]; if (i < (int)(tid >> 6)) base += t; D += t; }
-#pragma unroll
-      for (int q = 0; q < GPT; q++) pre[tid * GPT + q] = (unsigned short)(base + gpre[q]);
-      for (u32 i = tid; i < (D + 1) / 2; i += BLOCK) cnt[i] = 0;
-      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
-      __syncthreads();
-      // ---- C. rank = set bits below the key's own: the count goes there, and (first instance) the suffix goes out in place ----
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        if (wa[j] != ~0u) {
-          const u32 s = kcur[j];
-          const uint4 v = bm4[(wa[j] & 0x7FFFFFFFu) >> 2];
-          const u32 pos = s & 127u;
-          // words wholly below the bit count in full, the bit's own word below the bit
-          const u32 m0 = pos >= 32u ? ~0u : ((1u << (pos & 31u)) - 1u);
-          const u32 m1 = pos >= 64u ? ~0u : (pos >= 32u ? ((1u << (pos & 31u)) - 1u) : 0u);
-          const u32 m2 = pos >= 96u ? ~0u : (pos >= 64u ? ((1u << (pos & 31u)) - 1u) : 0u);
-          const u32 m3 = pos >= 96u ? ((1u << (pos & 31u)) - 1u) : 0u;
-          const u32 r = (u32)pre[s >> 7] + __popc(v.x & m0) + __popc(v.y & m1) + __popc(v.z & m2) + __popc(v.w & m3);
-          atomicAdd(&cnt[r >> 1], (r & 1u) ? 0x10000u : 1u);
-          if (wa[j] & 0x80000000u) gk[r] = s;          // in place: the sub-bucket's keys sit in registers
-        }
-      }
-      __syncthreads();
-      // ---- D. counts out, bitmap back to zero ----
-      for (u32 i = tid; i < D; i += BLOCK) gc[i] = (cnt[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
-#pragma unroll
-      for (int j = 0; j < KPT; j++) if (wa[j] != ~0u) bm[wa[j] & 0x7FFFFFFFu] = 0u;
-      __syncthreads();
-    }
-
-#pragma unroll
-    for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
-    a = na; n64 = nn; na = nna; nn = nnn; g = g1; g1 = g2; g2 = g3; p += G;
-  }
-}
-
-// Same scheme with 64-bit suffixes, for sub-buckets whose keys differ in 32..62 low bits (k from about 28 at the
-// 10 Gbp scale): 64-bit CAS, whole keys loaded, 42 KiB of LDS (3 workgroups per CU).
-template <int BLOCK, int CAP, int SLOTS, bool LIST>
-__global__ __launch_bounds__(BLOCK, 3)
-void hash_count64_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
-                       u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                       const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u32 tr_a = 0, u32 tr_b = 0 /* sub-buckets in tr_index() order (high digit first, launch_group_wide) */) {
-  constexpr bool DBG = false;
-  u64 *dbg = nullptr;
-  // Inside a sub-bucket the keys differ only in their low `low_bits` (< 32) bits: the table holds
-  // 32-bit suffixes (half the LDS, 32-bit CAS and compares); the common prefix is added back on output.
-  // Persistent workgroups: the keys of the next sub-bucket are loaded while the current one is counted
-  // (a sub-bucket is ~1K keys, so the two dependent HBM round trips would otherwise be a third of its time).
-  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
-  constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
-  constexpr u64 EMPTY = ~0ull;                         // suffixes are < 2^63
-  __shared__ __attribute__((aligned(16))) u64 tk[SLOTS];
-  __shared__ __attribute__((aligned(16))) u32 tc[SLOTS];
-  __shared__ __attribute__((aligned(16))) u64 dk[CAP + 16];
-  __shared__ u32 dc[CAP];
-  __shared__ u32 s_tmp[BLOCK / 64 + 1];
-  const u32 tid = threadIdx.x;
-  const u64 G = gridDim.x;
-  const u64 low_mask = (1ull << low_bits) - 1ull;
-
-  auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
-    aa = 0; nn = 0;
-    if (gg < ng) { aa = starts[gg]; nn = starts[gg + 1] - aa; }
-  };
-  // only the low dword of a key is needed: the rest is the file's prefix and the sub-bucket index
-  auto load_keys = [&](u64 aa, u64 nn, u64 (&kr)[KPT]) {
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      const u32 idx = (u32)j * BLOCK + tid;
-      kr[j] = (nn <= max_size && idx < nn) ? keys[aa + idx] : 0ull;
-    }
-  };
-
-  // visit only the NON-EMPTY sub-buckets (list built by subbucket_max_kernel): a sparse key space (homopolymer-
-  // compressed k-mers, small k) leaves most of the 2^t grid empty, and an empty visit still costs a memory round trip
-  const u64 np = LIST ? *nz_count : ng;
-  auto sub_at = [&](u64 pp) -> u64 { return (pp < np) ? (LIST ? (u64)nz[pp] : pp) : ng; };
-  u64 p = blockIdx.x;
-  u64 g = sub_at(p), g1 = sub_at(p + G), g2 = sub_at(p + 2 * G), a, n64, na, nn;
-  u64 kcur[KPT];
-  load_bounds(g, a, n64);
-  load_keys(a, n64, kcur);
-  load_bounds(g1, na, nn);
-
-  u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
-#define HC_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
-  while (g < ng) {
-    u64 knext[KPT];
-    u64 nna, nnn;
-    if (DBG) t0 = __builtin_readcyclecounter();
-    // (everything the previous iteration loaded is consumed BEFORE the next loads are issued: with the loads in conditional
-    // blocks the compiler's wait for the old registers is vmcnt(0) -- issued after the new loads it would wait for THEM)
-#pragma unroll
-    for (int j = 0; j < KPT; j++) asm volatile("" : "+v"(kcur[j]) :: "memory");
-    load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
-    load_bounds(g2, nna, nnn);
-    const u64 g3 = sub_at(p + 3 * G);
-
-    if (n64 == 0) {
-      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
-    } else if (n64 <= max_size) {                      // larger ones: other launches take them
-      const u32 n = (u32)n64;
-      const u64 prefix = kcur[0] & ~low_mask;   // (every thread that writes a distinct k-mer holds a key of its own: tid < D <= n)
-      u64 kk[KPT];
-      u32 hh[KPT];
-      u32 pending = 0;
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        const u32 idx = (u32)j * BLOCK + tid;
-        u64 raw = kcur[j];
-        kk[j] = raw & low_mask;
-        if (idx < n) pending |= 1u << j;
-      }
-      // table sized to the sub-bucket (load factor <= 0.8 even if every key is distinct): the clear and the
-      // compaction below walk the table, so an oversized one costs more than the longer probes of a full one
-      u32 slots = 256;
-      while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
-      const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
-      {
-        for (u32 i = tid; i < slots; i += BLOCK) { tk[i] = EMPTY; tc[i] = 0u; }
-      }
-      __syncthreads();
-      HC_STAMP(0);
-
-      {
-#pragma unroll
-        for (int j = 0; j < KPT; j++) hh[j] = (u32)((kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
-        // linear probing; one probe step of every still-pending key per round, so the CASes of a round overlap
-        while (pending) {
-#pragma unroll
-          for (int j = 0; j < KPT; j++) {
-            if ((pending >> j) & 1u) {
-              const u64 old = atomicCAS(&tk[hh[j]], EMPTY, kk[j]);
-              if (old == EMPTY || old == kk[j]) {
-                atomicAdd(&tc[hh[j]], 1u);
-                pending &= ~(1u << j);
-              }
-              else hh[j] = (hh[j] + 1) & smask;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      HC_STAMP(1);
-      {
-      // compact the occupied slots (any order)
-      u32 occ = 0;
-#pragma unroll
-      for (int j = 0; j < SPT; j++) {
-        const u32 sl = (u32)j * BLOCK + tid;
-        if (sl < slots) occ |= (tc[sl] != 0u ? 1u : 0u) << j;
-      }
-      u32 D;
-      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
-#pragma unroll
-      for (int j = 0; j < SPT; j++)
-        if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
-      if (tid < 16) dk[D + tid] = EMPTY;               // padding of the rank loop (D is block-uniform)
-      __syncthreads();
-      HC_STAMP(2);
-
-      // rank = number of smaller distinct suffixes (all pairs, two 16-byte broadcast reads per iteration)
-      u64 *gk = keys + a;
-      const u32 d4 = (D + 3) / 4;
-      const ulonglong2 *dk2 = reinterpret_cast<const ulonglong2 *>(dk);
-      for (u32 i = tid; i < D; i += BLOCK) {
-        const u64 ki = dk[i];
-        u32 r0 = 0, r1 = 0;
-        for (u32 j = 0; j < d4; j++) {
-          const ulonglong2 v0 = dk2[2 * j], v1 = dk2[2 * j + 1];
-          r0 += (v0.x < ki ? 1u : 0u) + (v0.y < ki ? 1u : 0u);
-          r1 += (v1.x < ki ? 1u : 0u) + (v1.y < ki ? 1u : 0u);
-        }
-        const u32 r = r0 + r1;
-        gk[r] = prefix | ki;                           // in place: every key of this region sits in registers
-        cnt_tmp[a + r] = dc[i];
-      }
-      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
-      HC_STAMP(3);
-      __syncthreads();                                 // dk/dc/s_tmp are reused by the next sub-bucket
-      HC_STAMP(4);
-      }
-    }
-
-#pragma unroll
-    for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
-    a = na; n64 = nn; na = nna; nn = nnn; g = g1; g1 = g2; g2 = g3; p += G;
-    if (DBG) { ph[5] += kcur[0] & 1; HC_STAMP(6); ph[7]++; }   // [6]: wait for the prefetched keys
-  }
-  if (DBG && tid == 0 && blockIdx.x < 64)
-    for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
-#undef HC_STAMP
-}
-
-// Hash-count finish for 16-byte keys (k = 33..64).  The suffix of a key inside its sub-bucket may be wider than any LDS
-// compare-and-swap, so the table does not hold suffixes at all: the sub-bucket's suffixes are first staged in LDS (every
-// thread writes its own, one barrier), and a table slot holds the INDEX of the key that claimed it -- one 32-bit CAS per
-// probe, the claimant's suffix is complete before anybody can look at it, no lock word, no fences, no rounds.  (The first
-// version claimed a slot through its count word and published it with release/acquire fences: 153.6 ms of finish per 5 Gbp at
-// k=51, two workgroups per CU; this one aliases the compacted output onto the staging arrays, packs index and count into
-// one slot word and fits four: 103 ms with separate index/count words and three workgroups.)
-// WIDE = the suffix needs the high word too (low_bits > 64); otherwise the hi arrays are not even allocated.
-constexpr int H128_SMALL_WAVES = 6;                               // hash_count128_kernel<.., 768, ..>: workgroups per CU asked for
-template <int BLOCK, int CAP, int SLOTS, bool WIDE, bool BINRANK = true>
-__global__ __launch_bounds__(BLOCK, (CAP <= 768 ? H128_SMALL_WAVES : 4))
-void hash_count128_kernel(K128 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
-                          u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                          const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u32 tr_a = 0, u32 tr_b = 0 /* sub-buckets in tr_index() order (high digit first, launch_group_wide) */) {
-  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
-  constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
-  static_assert(CAP < 0xFFFF, "slot words hold a 16-bit key index and a 16-bit count");
-  constexpr u32 EMPTY = 0x0000FFFFu;                                  // count 0, no claimant
-  __shared__ __attribute__((aligned(16))) u64 dlo[CAP + 4];           // staged suffixes, later the compacted distinct ones
-  __shared__ __attribute__((aligned(16))) u64 dhi[WIDE ? CAP + 4 : 2];
-  __shared__ u32 tw[SLOTS];                                           // slot -> instances << 16 | index of the claiming key;
-  __shared__ u32 s_tmp[BLOCK / 64 + 1];                               //   later dc[]: counts of the compacted suffixes
-  __shared__ u32 s_bin[BINRANK ? BLOCK + 1 : 1];                      // BINRANK: as in hash_count64i_kernel
-  __shared__ unsigned short s_ix[BINRANK ? CAP : 1];
-  static_assert(!BINRANK || BLOCK == 256, "one bin per thread");
-  u32 *dc = tw;                                                       // 33 KiB of LDS in all: four workgroups per CU
-  using KO = KeyOps<K128>;
-  const u32 tid = threadIdx.x;
-  const u64 G = gridDim.x;
-  const u128 low_mask = (low_bits >= 128) ? ~(u128)0 : (((u128)1 << low_bits) - 1);
-
-  auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
-    aa = 0; nn = 0;
-    if (gg < ng) { aa = starts[gg]; nn = starts[gg + 1] - aa; }
-  };
-  auto load_keys = [&](u64 aa, u64 nn, K128 (&kr)[KPT]) {
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      const u32 idx = (u32)j * BLOCK + tid;
-      if (nn <= max_size && idx < nn) kr[j] = keys[aa + idx]; else kr[j] = KO::zero();
-    }
-  };
-
-  // visit only the NON-EMPTY sub-buckets (list built by subbucket_max_kernel): a sparse key space (homopolymer-
-  // compressed k-mers, small k) leaves most of the 2^t grid empty, and an empty visit still costs a memory round trip
-  const u64 np = nz ? *nz_count : ng;
-  auto sub_at = [&](u64 pp) -> u64 { return (pp < np) ? (nz ? (u64)nz[pp] : pp) : ng; };
-  u64 p = blockIdx.x;
-  u64 g = sub_at(p), g1 = sub_at(p + G), g2 = sub_at(p + 2 * G), a, n64, na, nn;
-  K128 kcur[KPT];
-  load_bounds(g, a, n64);
-  load_keys(a, n64, kcur);
-  load_bounds(g1, na, nn);
-
-  while (g < ng) {
-    K128 knext[KPT];
-    u64 nna, nnn;
-    // (everything the previous iteration loaded is consumed BEFORE the next loads are issued: with the loads in conditional
-    // blocks the compiler's wait for the old registers is vmcnt(0) -- issued after the new loads it would wait for THEM)
-#pragma unroll
-    for (int j = 0; j < KPT; j++) { asm volatile("" : "+v"(kcur[j].lo) :: "memory"); asm volatile("" : "+v"(kcur[j].hi) :: "memory"); }
-    load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
-    load_bounds(g2, nna, nnn);
-    const u64 g3 = sub_at(p + 3 * G);
-
-    if (n64 == 0) {
-      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
-    } else if (n64 <= max_size) {
-      const u32 n = (u32)n64;
-      const u128 prefix = KO::v(kcur[0]) & ~low_mask;   // (every thread that writes a distinct k-mer holds a key of its own: tid < D <= n)
-      u64 klo[KPT], khi[KPT];
-      u32 hh[KPT];
-      u32 pending = 0;
-      u32 slots = 256;
-      while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
-      const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        const u32 idx = (u32)j * BLOCK + tid;
-        const u128 sfx = KO::v(kcur[j]) & low_mask;
-        klo[j] = (u64)sfx; khi[j] = (u64)(sfx >> 64);
-        const u64 mix = (klo[j] ^ (khi[j] * 0xD6E8FEB86659FD93ull)) * 0x9E3779B97F4A7C15ull;
-        hh[j] = (u32)(mix >> 32) >> sshift;
-        if (idx < n) {                                 // stage the suffix: complete before the first probe (barrier below)
-          pending |= 1u << j;
-          dlo[idx] = klo[j];
-          if (WIDE) dhi[idx] = khi[j];
-        }
-      }
-      for (u32 i = tid; i < slots; i += BLOCK) tw[i] = EMPTY;
-      __syncthreads();
-
-      while (pending) {
-#pragma unroll
-        for (int j = 0; j < KPT; j++) {
-          if ((pending >> j) & 1u) {
-            const u32 h = hh[j];
-            const u32 me = (u32)j * BLOCK + tid;
-            const u32 old = atomicCAS(&tw[h], EMPTY, (1u << 16) | me);                  // claim it with count 1
-            if (old == EMPTY) { pending &= ~(1u << j); continue; }
-            const u32 rep = old & 0xFFFFu;                                               // the claimant's suffix was staged before the barrier
-            if ((dlo[rep] == klo[j]) && (!WIDE || dhi[rep] == khi[j])) { atomicAdd(&tw[h], 1u << 16); pending &= ~(1u << j); }
-            else hh[j] = (h + 1) & smask;
-          }
-        }
-      }
-      __syncthreads();
-
-      // compact the occupied slots (any order): gather into registers, then overwrite the staging arrays
-      u32 occ = 0;
-      u64 glo[SPT], ghi[SPT];
-      u32 gc[SPT];
-#pragma unroll
-      for (int j = 0; j < SPT; j++) {
-        const u32 sl = (u32)j * BLOCK + tid;
-        glo[j] = 0; ghi[j] = 0; gc[j] = 0;
-        if (sl < slots) {
-          const u32 w = tw[sl];
-          if (w != EMPTY) { const u32 rep = w & 0xFFFFu; occ |= 1u << j; glo[j] = dlo[rep]; if (WIDE) ghi[j] = dhi[rep]; gc[j] = w >> 16; }
-        }
-      }
-      u32 D;
-      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);    // (its barriers also end every read of dlo/dhi/tw above)
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < SPT; j++) {
-        if ((occ >> j) & 1u) {
-          dlo[o] = glo[j];
-          if (WIDE) dhi[o] = ghi[j];
-          dc[o] = gc[j];
-          o++;
-        }
-      }
-      if (tid < 4) { dlo[D + tid] = ~0ull; if (WIDE) dhi[D + tid] = ~0ull; }
-      __syncthreads();
-
-      // rank = number of smaller distinct suffixes
-      K128 *gk = keys + a;
-      const u32 d4 = (D + 3) / 4;                      // the arrays are padded with all-ones (never smaller) to 4
-      const ulonglong2 *dlo2 = reinterpret_cast<const ulonglong2 *>(dlo);
-      const ulonglong2 *dhi2 = reinterpret_cast<const ulonglong2 *>(dhi);
-      if constexpr (BINRANK) {
-        const u32 bshift = low_bits > 8 ? low_bits - 8 : 0;
-        auto bin_of = [&](u32 i) -> u32 {
-          if (WIDE) return (u32)(((((u128)dhi[i]) << 64) | (u128)dlo[i]) >> bshift);
-          return (u32)(dlo[i] >> bshift);
-        };
-        s_bin[tid] = 0;
-        __syncthreads();
-        u32 lr[KPT];
-#pragma unroll
-        for (int q = 0; q < KPT; q++) {
-          const u32 i = (u32)q * BLOCK + tid;
-          lr[q] = 0;
-          if (i < D) lr[q] = atomicAdd(&s_bin[bin_of(i)], 1u);
-        }
-        __syncthreads();
-        u32 tot;
-        const u32 e = block_excl_scan<BLOCK, u32>(s_bin[tid], s_tmp, &tot);
-        s_bin[tid] = e;
-        if (tid == 0) s_bin[BLOCK] = D;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < KPT; q++) {
-          const u32 i = (u32)q * BLOCK + tid;
-          if (i < D) s_ix[s_bin[bin_of(i)] + lr[q]] = (unsigned short)i;
-        }
-        __syncthreads();
-        for (u32 pidx = tid; pidx < D; pidx += BLOCK) {
-          const u32 i = s_ix[pidx];
-          const u64 li = dlo[i], hi = WIDE ? dhi[i] : 0ull;
-          const u32 b = bin_of(i), lo = s_bin[b], hi_ = s_bin[b + 1];
-          u32 r = lo;
-          for (u32 q = lo; q < hi_; q++) {
-            const u32 j = s_ix[q];
-            const u64 lj = dlo[j], hj = WIDE ? dhi[j] : 0ull;
-            r += ((hj < hi) || (hj == hi && lj < li)) ? 1u : 0u;
-          }
-          gk[r] = KO::mk(prefix | ((u128)hi << 64) | (u128)li);
-          cnt_tmp[a + r] = dc[i];
-        }
-      } else
-      for (u32 i = tid; i < D; i += BLOCK) {
-        const u64 li = dlo[i], hi = WIDE ? dhi[i] : 0ull;
-        u32 r0 = 0, r1 = 0;
-        for (u32 j = 0; j < d4; j++) {
-          const ulonglong2 a0 = dlo2[2 * j], a1 = dlo2[2 * j + 1];
-          if (WIDE) {
-            const ulonglong2 b0 = dhi2[2 * j], b1 = dhi2[2 * j + 1];
-            r0 += (((b0.x < hi) || (b0.x == hi && a0.x < li)) ? 1u : 0u) + (((b0.y < hi) || (b0.y == hi && a0.y < li)) ? 1u : 0u);
-            r1 += (((b1.x < hi) || (b1.x == hi && a1.x < li)) ? 1u : 0u) + (((b1.y < hi) || (b1.y == hi && a1.y < li)) ? 1u : 0u);
-          } else {
-            r0 += (a0.x < li ? 1u : 0u) + (a0.y < li ? 1u : 0u);
-            r1 += (a1.x < li ? 1u : 0u) + (a1.y < li ? 1u : 0u);
-          }
-        }
-        const u32 r = r0 + r1;
-        gk[r] = KO::mk(prefix | ((u128)hi << 64) | (u128)li);   // in place: every key of this region sits in registers
-        cnt_tmp[a + r] = dc[i];
-      }
-      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
-      __syncthreads();                                 // the tables are reused by the next sub-bucket
-    }
-
-#pragma unroll
-    for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
-    a = na; n64 = nn; na = nna; nn = nnn; g = g1; g1 = g2; g2 = g3; p += G;
-  }
-}
-
-// The same index-claimed table for 8-byte keys whose suffix does not fit 32 bits (low_bits 32..58: k = 28..32, `compress`):
-// the first version of this kernel kept 64-bit suffixes in the table (64-bit LDS CAS, 42 KiB, three workgroups per CU);
-// staged suffixes + one 32-bit slot word need 21 KiB.
-template <int BLOCK, int CAP, int SLOTS, bool LIST, bool BINRANK = true>
-__global__ __launch_bounds__(BLOCK, (CAP <= 768 ? 7 : 5))
-void hash_count64i_kernel(u64 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
-                          u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                          const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u32 tr_a = 0, u32 tr_b = 0 /* sub-buckets in tr_index() order (high digit first, launch_group_wide) */) {
-  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0 && CAP < 0xFFFF, "table geometry");
-  constexpr int KPT = CAP / BLOCK, SPT = SLOTS / BLOCK;
-  constexpr u32 EMPTY = 0x0000FFFFu;
-  __shared__ __attribute__((aligned(16))) u64 dk[CAP + 16];           // staged suffixes, later the compacted distinct ones
-  __shared__ u32 tw[SLOTS];                                           // instances << 16 | index of the claiming key; later dc[]
-  __shared__ u32 s_tmp[BLOCK / 64 + 1];
-  // BINRANK: the distinct suffixes are binned by their top eight bits (a counting sort of their INDICES); a suffix's rank is
-  // its bin's start + the smaller ones inside the bin -- D * D / 256 compares instead of D * D
-  __shared__ u32 s_bin[BINRANK ? BLOCK + 1 : 1];
-  __shared__ unsigned short s_ix[BINRANK ? CAP : 1];
-  static_assert(!BINRANK || BLOCK == 256, "one bin per thread");
-  u32 *dc = tw;
-  const u32 tid = threadIdx.x;
-  const u64 G = gridDim.x;
-  const u64 low_mask = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
-
-  auto load_bounds = [&](u64 gg, u64 &aa, u64 &nn) {
-    aa = 0; nn = 0;
-    if (gg < ng) { aa = starts[gg]; nn = starts[gg + 1] - aa; }
-  };
-  auto load_keys = [&](u64 aa, u64 nn, u64 (&kr)[KPT]) {
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      const u32 idx = (u32)j * BLOCK + tid;
-      kr[j] = (nn <= max_size && idx < nn) ? keys[aa + idx] : 0ull;
-    }
-  };
-  const u64 np = LIST ? *nz_count : ng;
-  auto sub_at = [&](u64 pp) -> u64 { return (pp < np) ? (LIST ? (u64)nz[pp] : pp) : ng; };
-  u64 p = blockIdx.x;
-  u64 g = sub_at(p), g1 = sub_at(p + G), g2 = sub_at(p + 2 * G), a, n64, na, nn;
-  u64 kcur[KPT];
-  load_bounds(g, a, n64);
-  load_keys(a, n64, kcur);
-  load_bounds(g1, na, nn);
-
-  while (g < ng) {
-    u64 knext[KPT];
-    u64 nna, nnn;
-    // (everything the previous iteration loaded is consumed BEFORE the next loads are issued: with the loads in conditional
-    // blocks the compiler's wait for the old registers is vmcnt(0) -- issued after the new loads it would wait for THEM)
-#pragma unroll
-    for (int j = 0; j < KPT; j++) asm volatile("" : "+v"(kcur[j]) :: "memory");
-    load_keys(na, nn, knext);                          // in flight while this sub-bucket is processed
-    load_bounds(g2, nna, nnn);
-    const u64 g3 = sub_at(p + 3 * G);
-
-    if (n64 == 0) {
-      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = 0;
-    } else if (n64 <= max_size) {
-      const u32 n = (u32)n64;
-      const u64 prefix = kcur[0] & ~low_mask;   // (every thread that writes a distinct k-mer holds a key of its own: tid < D <= n)
-      u64 kk[KPT];
-      u32 hh[KPT];
-      u32 pending = 0;
-      u32 slots = 256;
-      while (slots < n + n / 4 && slots < (u32)SLOTS) slots <<= 1;
-      const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        const u32 idx = (u32)j * BLOCK + tid;
-        kk[j] = kcur[j] & low_mask;
-        hh[j] = (u32)((kk[j] * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
-        if (idx < n) { pending |= 1u << j; dk[idx] = kk[j]; }
-      }
-      for (u32 i = tid; i < slots; i += BLOCK) tw[i] = EMPTY;
-      __syncthreads();
-
-      while (pending) {
-#pragma unroll
-        for (int j = 0; j < KPT; j++) {
-          if ((pending >> j) & 1u) {
-            const u32 h = hh[j];
-            const u32 old = atomicCAS(&tw[h], EMPTY, (1u << 16) | ((u32)j * BLOCK + tid));
-            if (old == EMPTY) { pending &= ~(1u << j); continue; }
-            if (dk[old & 0xFFFFu] == kk[j]) { atomicAdd(&tw[h], 1u << 16); pending &= ~(1u << j); }
-            else hh[j] = (h + 1) & smask;
-          }
-        }
-      }
-      __syncthreads();
-
-      u32 occ = 0;
-      u64 gk_[SPT];
-      u32 gc[SPT];
-#pragma unroll
-      for (int j = 0; j < SPT; j++) {
-        const u32 sl = (u32)j * BLOCK + tid;
-        gk_[j] = 0; gc[j] = 0;
-        if (sl < slots) {
-          const u32 w = tw[sl];
-          if (w != EMPTY) { occ |= 1u << j; gk_[j] = dk[w & 0xFFFFu]; gc[j] = w >> 16; }
-        }
-      }
-      u32 D;
-      u32 o = block_excl_scan<BLOCK, u32>(__popc(occ), s_tmp, &D);
-      __syncthreads();                                 // every read of dk / tw above is done
-#pragma unroll
-      for (int j = 0; j < SPT; j++)
-        if ((occ >> j) & 1u) { dk[o] = gk_[j]; dc[o] = gc[j]; o++; }
-      if (tid < 16) dk[D + tid] = ~0ull;               // padding of the rank loop (D is block-uniform)
-      __syncthreads();
-
-      // rank = number of smaller distinct suffixes (all pairs, two 16-byte broadcast reads per iteration)
-      u64 *gk = keys + a;
-      const u32 d4 = (D + 3) / 4;
-      const ulonglong2 *dk2 = reinterpret_cast<const ulonglong2 *>(dk);
-      if constexpr (BINRANK) {
-        const u32 bshift = low_bits > 8 ? low_bits - 8 : 0;
-        s_bin[tid] = 0;
-        __syncthreads();
-        u32 li[KPT];
-#pragma unroll
-        for (int q = 0; q < KPT; q++) {
-          const u32 i = (u32)q * BLOCK + tid;
-          li[q] = 0;
-          if (i < D) li[q] = atomicAdd(&s_bin[(u32)(dk[i] >> bshift)], 1u);
-        }
-        __syncthreads();
-        u32 tot;
-        const u32 e = block_excl_scan<BLOCK, u32>(s_bin[tid], s_tmp, &tot);
-        s_bin[tid] = e;
-        if (tid == 0) s_bin[BLOCK] = D;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < KPT; q++) {
-          const u32 i = (u32)q * BLOCK + tid;
-          if (i < D) s_ix[s_bin[(u32)(dk[i] >> bshift)] + li[q]] = (unsigned short)i;
-        }
-        __syncthreads();
-        for (u32 pidx = tid; pidx < D; pidx += BLOCK) {
-          const u32 i = s_ix[pidx];
-          const u64 ki = dk[i];
-          const u32 b = (u32)(ki >> bshift), lo = s_bin[b], hi = s_bin[b + 1];
-          u32 r = lo;
-          for (u32 q = lo; q < hi; q++) r += (dk[s_ix[q]] < ki) ? 1u : 0u;
-          gk[r] = prefix | ki;
-          cnt_tmp[a + r] = dc[i];
-        }
-      } else
-      for (u32 i = tid; i < D; i += BLOCK) {
-        const u64 ki = dk[i];
-        u32 r0 = 0, r1 = 0;
-        for (u32 j = 0; j < d4; j++) {
-          const ulonglong2 v0 = dk2[2 * j], v1 = dk2[2 * j + 1];
-          r0 += (v0.x < ki ? 1u : 0u) + (v0.y < ki ? 1u : 0u);
-          r1 += (v1.x < ki ? 1u : 0u) + (v1.y < ki ? 1u : 0u);
-        }
-        const u32 r = r0 + r1;
-        gk[r] = prefix | ki;                           // in place: every key of this region sits in registers
-        cnt_tmp[a + r] = dc[i];
-      }
-      if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
-      __syncthreads();                                 // the tables are reused by the next sub-bucket
-    }
-
-#pragma unroll
-    for (int j = 0; j < KPT; j++) kcur[j] = knext[j];
-    a = na; n64 = nn; na = nna; nn = nnn; g = g1; g1 = g2; g2 = g3; p += G;
-  }
-}
-
-// hash_count64i_kernel / hash_count128_kernel rebuilt the way hash_count_multi_kernel was (round 4; replaces countSingleKmers'
+// The index-claimed table of rounds 2-3 rebuilt the way hash_count_multi_kernel was (round 4; replaces countSingleKmers'
 // sort + run-length passes, merylCountArray.C:323-365, for suffixes that do not fit the packed 32-bit table: 8-byte keys with
 // 32..58-bit suffixes -- k = 28..32, `compress` -- and 16-byte keys, k = 33..64): the same index-claimed table
 // (count << 16 | index of the claiming key's staged suffix) and the same results, but
@@ -2471,21 +1757,15 @@ constexpr int HUGE_CAP32 = 4096, HUGE_SLOTS32 = 8192;            // 32-bit suffi
 constexpr int HUGE_CAP64 = 2048, HUGE_SLOTS64 = 4096;            // 64-bit suffixes: 72 KiB
 constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count kernel: 2048 slots, 26 KiB of LDS, 6 workgroups per CU
 
-// 16-byte keys: capacity of the hash-count kernel (hash_count128_kernel).  1536-key tables with sub-buckets of up to 1152 k-mers;
-// a file whose largest sub-bucket holds at most 768 takes the 768-key instantiation (launch_finish_file).  MGC_HASH128_CAP=768:
-// every file through the small tables, sub-buckets of up to 640 (measured at k = 51, 5 Gbp, with the bin-rank in: 138.3 ms against
-// 128.3 -- fewer, larger sub-buckets amortise the per-sub-bucket barriers and scans now that the rank no longer grows with D^2).
-static uint64_t fin_cap_hash128() {
-  static const uint64_t cap = (getenv("MGC_HASH128_CAP") && atoi(getenv("MGC_HASH128_CAP")) == 768) ? 768 : 1536;
-  return cap;
-}
+// 16-byte keys: the same 1536-key tables (sub-buckets of up to 1152 k-mers); a file whose largest sub-bucket holds at most 768 takes
+// the 768-key instantiation (launch_finish_file)
+constexpr u64 FIN_CAP_HASH128 = 1536;
 
+// which files the hash-count kernels take: 8-byte keys with suffixes of up to 58 bits (the packed 32-bit table below 32, the
+// index-claimed table of hash_countw_kernel above), 16-byte keys with suffixes of up to 122 bits
 static bool finish_uses_hash(uint32_t key_words, uint32_t low_bits) {
-  static const bool use_hash = !(getenv("MGC_FINISH_HASH") && getenv("MGC_FINISH_HASH")[0] == '0');
-  static const bool use_hash64 = !(getenv("MGC_FINISH_HASH64") && getenv("MGC_FINISH_HASH64")[0] == '0');
-  static const bool use_hash128 = !(getenv("MGC_FINISH_HASH128") && getenv("MGC_FINISH_HASH128")[0] == '0');
-  if (key_words == 2) return use_hash && use_hash128 && low_bits <= 122;
-  return key_words == 1 && use_hash && (low_bits < 32 || (use_hash64 && low_bits <= 58));
+  if (key_words == 2) return low_bits <= 122;
+  return key_words == 1 && low_bits <= 58;
 }
 // capacity of the first (small) launch of launch_finish_file; larger sub-buckets go on the list
 static uint64_t finish_small_capacity(uint32_t key_words, uint32_t low_bits);
@@ -2564,8 +1844,7 @@ static void hash_dbg_report(hipStream_t st, uint64_t ng, bool multi = false) {
 }
 
 bool finish_can_stream(uint32_t key_words, uint32_t low_bits) {
-  static const bool on = !(getenv("MGC_FINISH_STREAM") && getenv("MGC_FINISH_STREAM")[0] == '0');
-  return on && finish_uses_hash(key_words, low_bits);
+  return finish_uses_hash(key_words, low_bits);
 }
 
 // sub-buckets up to this many keys are streamed whatever they hold (in as many suffix ranges as it takes); a larger one
@@ -2604,35 +1883,25 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               hipStream_t st, bool narrow, uint32_t tr_a, uint32_t tr_b, uint64_t max_sub, uint64_t n_keys,
                               uint32_t *d_retry_list, uint64_t *d_retry_count) {
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
+  const bool use_list = d_nz != nullptr;
   if (narrow) {
-    // narrowed keys (u32): the 32-bit hash-count kernel and the streaming kernel have u32-storage instantiations; anything
+    // narrowed keys (u32): the 32-bit hash-count kernels and the streaming kernel have u32-storage instantiations; anything
     // else wants whole k-mers -- the caller widens the file first (launch_widen_groups)
-    if (key_words != 1 || low_bits >= 32 || !finish_uses_hash(key_words, low_bits) || (n_large && !stream)) return hipErrorInvalidValue;
-    static const uint32_t hgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 14u;
-    const uint32_t hgrid = ng < hgrid_max ? (uint32_t)ng : hgrid_max;
-    static const bool binrank = !(getenv("MGC_HASH_BINRANK") && getenv("MGC_HASH_BINRANK")[0] == '0');
-#define MGC_NARROW_LAUNCH(LIST_, BIN_)                                                                                                   \
-    hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, LIST_, true, BIN_>), dim3(hgrid), dim3(256), 0, st,       \
+    if (key_words != 1 || low_bits >= 32 || (n_large && !stream)) return hipErrorInvalidValue;
+    const uint32_t hgrid = ng < 256u * 14u ? (uint32_t)ng : 256u * 14u;
+#define MGC_NARROW_LAUNCH(DBG_, LIST_, DBGBUF_)                                                                                          \
+    hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, DBG_, LIST_, true>), dim3(hgrid), dim3(256), 0, st,              \
                        reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, \
-                       d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, (u64 *)nullptr, tr_a, tr_b)
-    // suffixes of at most 18 bits (k = 21 at the 10 Gbp scale): the bitmap-count kernel, with MGC_FINISH_BITMAP=1.  Measured
-    // (profiles/r03b_*): finish stage 39.3 ms per 10 Gbp against the hash-count's 39.8 -- both VALU-issue-bound, the bitmap's
-    // scan of 2^18 bits per sub-bucket costs what the hash table's probing and ranking cost -- so the hash-count stays the default.
-    const char *bme = getenv("MGC_FINISH_BITMAP");                  // read per call: the tests switch it
-    const bool use_bitmap = bme && bme[0] == '1';
-    static const uint32_t bgrid_per_cu = getenv("MGC_BITMAP_GRID") ? (uint32_t)atoi(getenv("MGC_BITMAP_GRID")) : 0u;
-#define MGC_BITMAP_LAUNCH(LB_, LIST_, PER_CU_)                                                                                           \
-    do { const uint32_t bmax = 256u * (bgrid_per_cu ? bgrid_per_cu : (uint32_t)(PER_CU_));                                              \
-         hipLaunchKernelGGL((bitmap_count_kernel<256, (int)FIN_CAP_HASH, LB_, LIST_>), dim3(ng < bmax ? (uint32_t)ng : bmax), dim3(256), 0, st, \
-                       reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, \
-                       d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b); } while (0)
-    // Round 4: R physically consecutive sub-buckets per iteration with packed key|count entries (hash_count_multi_kernel):
-    // dense grids whose tagged suffix fits 20 bits.  R from the file's average sub-bucket (MGC_HASH_MULTI=0: the kernel above;
-    // 1/2/3/4: that R whatever the average).
+                       d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, DBGBUF_, tr_a, tr_b)
+    // R physically consecutive sub-buckets per iteration with packed key|count entries (hash_count_multi_kernel): dense grids
+    // whose tagged suffix fits 20 bits.  R from the file's average sub-bucket (MGC_HASH_MULTI=0: the one-at-a-time kernel;
+    // 1/2/4: that R whatever the average -- tests).  Measured at 10 Gbp (profiles/r05a: MGC_HASH_MULTI=2 on every file): R = 2
+    // on files whose sub-buckets average more than 690 k-mers sends most ranges to the retry list (they exceed the 1536-key
+    // table): 68 ms of count stage against 29 -- R = 1 there is the table's size, not the heuristic's choice.
     const char *mue = getenv("MGC_HASH_MULTI");                    // read per call: the tests switch it
     const int multi_env = (mue && *mue) ? atoi(mue) : -1;
     int multi_r = 0;
-    if (multi_env != 0 && !d_nz && !use_bitmap && ng >= 4 && d_retry_list && d_retry_count) {
+    if (multi_env != 0 && !d_nz && ng >= 4 && d_retry_list && d_retry_count) {
       const uint64_t avg = n_keys ? n_keys / ng : FIN_CAP_HASH;
       multi_r = multi_env > 0 ? multi_env : (avg <= 340 ? 4 : (avg <= 690 ? 2 : 1));
       const uint32_t tagb = multi_r == 1 ? 0u : (multi_r == 2 ? 1u : 2u);
@@ -2640,53 +1909,38 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       const uint32_t tagb2 = multi_r == 1 ? 0u : (multi_r == 2 ? 1u : 2u);
       if (multi_r > 4 || multi_r == 3 || low_bits + tagb2 < 8 || low_bits + tagb2 > 20) multi_r = 0;
     }
+    u64 *dbgb = hash_dbg_buffer();                                   // MGC_HASH_DBG=1: the instrumented instantiations (per-phase cycle stamps)
     if (multi_r) {
-      static const uint32_t mgrid_per_cu = getenv("MGC_HASH_MULTI_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_MULTI_GRID")) : 16u;
       const uint64_t nsuper = (ng + (uint64_t)multi_r - 1) / (uint64_t)multi_r;
-      u64 *dbgb = hash_dbg_buffer();
-      static const bool multi_rf = !(getenv("MGC_HASH_LEAN") && getenv("MGC_HASH_LEAN")[0] == '0');
-#define MGC_MULTI_LAUNCH(CAP_, SLOTS_, R_, DBG_) do { if (multi_rf) MGC_MULTI_LAUNCH_(CAP_, SLOTS_, R_, DBG_, true); else MGC_MULTI_LAUNCH_(CAP_, SLOTS_, R_, DBG_, false); } while (0)
-#define MGC_MULTI_LAUNCH_(CAP_, SLOTS_, R_, DBG_, RF_)                                                                                         \
-      do { static_assert((CAP_) == (int)FIN_CAP_HASH, "a joint range must not hold a sub-bucket of the streaming launch");           \
-           const uint64_t gmax = 256ull * mgrid_per_cu;                                                                                      \
-           hipLaunchKernelGGL((hash_count_multi_kernel<256, CAP_, SLOTS_, R_, DBG_, RF_>), dim3((uint32_t)(nsuper < gmax ? nsuper : gmax)),   \
+#define MGC_MULTI_LAUNCH(R_, DBG_)                                                                                                       \
+      do { const uint64_t gmax = 256ull * 16ull;                                                                                        \
+           hipLaunchKernelGGL((hash_count_multi_kernel<256, (int)FIN_CAP_HASH, 2048, R_, DBG_>), dim3((uint32_t)(nsuper < gmax ? nsuper : gmax)), \
                        dim3(256), 0, st, reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng,              \
                        (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), dbgb, tr_a, tr_b,             \
                        d_retry_list, reinterpret_cast<u64 *>(d_retry_count)); } while (0)
-      if (dbgb && multi_r == 2) MGC_MULTI_LAUNCH(1536, 2048, 2, true);
-      else if (multi_r == 1)    MGC_MULTI_LAUNCH(1536, 2048, 1, false);
-      else if (multi_r == 2)    MGC_MULTI_LAUNCH(1536, 2048, 2, false);
-      else                      MGC_MULTI_LAUNCH(1536, 2048, 4, false);
+      if (dbgb && multi_r == 2) MGC_MULTI_LAUNCH(2, true);
+      else if (multi_r == 1)    MGC_MULTI_LAUNCH(1, false);
+      else if (multi_r == 2)    MGC_MULTI_LAUNCH(2, false);
+      else                      MGC_MULTI_LAUNCH(4, false);
 #undef MGC_MULTI_LAUNCH
-#undef MGC_MULTI_LAUNCH_
       MGC_CHECK(hipGetLastError());
       if (dbgb && multi_r == 2) hash_dbg_report(st, ng, true);
       // the sub-buckets of ranges above the table (retry list, usually short): one at a time.  (R = 1: a range is one sub-bucket,
       // the list stays empty -- no launch: queued behind the other stream's persistent kernel an empty one still lasted 170 us)
       if (multi_r > 1) { const uint32_t rgrid = ng < 256u * 7u ? (uint32_t)ng : 256u * 7u;
-        hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, true, true>), dim3(rgrid), dim3(256), 0, st,
+        hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, true>), dim3(rgrid), dim3(256), 0, st,
                            reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
                            d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_retry_list, reinterpret_cast<const u64 *>(d_retry_count),
                            (u64 *)nullptr, tr_a, tr_b);
         MGC_CHECK(hipGetLastError()); }
     }
-    else if (use_bitmap && low_bits <= 16) { if (d_nz) MGC_BITMAP_LAUNCH(16, true, 12); else MGC_BITMAP_LAUNCH(16, false, 12); }
-    else if (use_bitmap && low_bits <= 18) { if (d_nz) MGC_BITMAP_LAUNCH(18, true, 4);  else MGC_BITMAP_LAUNCH(18, false, 4); }
-    else if (hash_dbg_buffer()) {                                  // MGC_HASH_DBG=1: the instrumented instantiation (per-phase cycle stamps)
-      if (d_nz)
-        hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true, true, true, true>), dim3(hgrid), dim3(256), 0, st,
-                           reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                           d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, hash_dbg_buffer(), tr_a, tr_b);
-      else
-        hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true, false, true, true>), dim3(hgrid), dim3(256), 0, st,
-                           reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits,
-                           d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, hash_dbg_buffer(), tr_a, tr_b);
+    else if (dbgb) {
+      if (use_list) MGC_NARROW_LAUNCH(true, true, dbgb); else MGC_NARROW_LAUNCH(true, false, dbgb);
       MGC_CHECK(hipGetLastError());
       hash_dbg_report(st, ng);
     }
-    else if (d_nz) { if (binrank) MGC_NARROW_LAUNCH(true, true);  else MGC_NARROW_LAUNCH(true, false); }
-    else           { if (binrank) MGC_NARROW_LAUNCH(false, true); else MGC_NARROW_LAUNCH(false, false); }
-#undef MGC_BITMAP_LAUNCH
+    else if (use_list) MGC_NARROW_LAUNCH(false, true, (u64 *)nullptr);
+    else               MGC_NARROW_LAUNCH(false, false, (u64 *)nullptr);
 #undef MGC_NARROW_LAUNCH
     MGC_CHECK(hipGetLastError());
     if (n_large) {
@@ -2707,49 +1961,26 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
   }
   // whole keys in (low digit : high digit) order (launch_group_wide): only the hash-count kernels translate the sub-bucket numbers
   if (tr_a && !(finish_uses_hash(key_words, low_bits) && (n_large == 0 || stream))) return hipErrorInvalidValue;
+  // a file whose LARGEST sub-bucket holds at most 768 k-mers (`compress`: 59049 sub-buckets per bucket, a few hundred k-mers each):
+  // three keys per thread instead of six -- fewer idle unrolled slots, half the LDS, more workgroups per CU
+  const bool small = max_sub && max_sub <= 768 && n_large == 0;
   if (key_words == 2 && finish_uses_hash(key_words, low_bits)) {
-    static const uint32_t wgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 4u;     // four workgroups per CU
-    const uint32_t wgrid = ng < wgrid_max ? (uint32_t)ng : wgrid_max;
-    const u64 cap128 = fin_cap_hash128();
-    static const bool small128 = !(getenv("MGC_HASH128_SMALL") && getenv("MGC_HASH128_SMALL")[0] == '0');
-    const bool small = cap128 == 768 || (small128 && max_sub && max_sub <= 768 && n_large == 0);
-    const u64 msize = small ? (u64)768 : cap128;
-    static const bool binrank128 = !(getenv("MGC_HASH_BINRANK") && getenv("MGC_HASH_BINRANK")[0] == '0');
-#define MGC_H128_LAUNCH_(CAP_, SLOTS_, WIDE_, GRID_, BIN_)                                                                               \
-    hipLaunchKernelGGL((hash_count128_kernel<256, CAP_, SLOTS_, WIDE_, BIN_>), dim3(GRID_), dim3(256), 0, st,                            \
+    const u64 msize = small ? (u64)768 : FIN_CAP_HASH128;
+#define MGC_W128_LAUNCH(CAP_, SLOTS_, WIDE_, LIST_, GRID_)                                                                               \
+    hipLaunchKernelGGL((hash_countw_kernel<K128, 256, CAP_, SLOTS_, WIDE_, LIST_>), dim3(GRID_), dim3(256), 0, st,                       \
                        reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, msize, low_bits,              \
                        d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b)
-#define MGC_H128_LAUNCH(CAP_, SLOTS_, WIDE_, GRID_) do { if (binrank128) MGC_H128_LAUNCH_(CAP_, SLOTS_, WIDE_, GRID_, true);              \
-                                                         else            MGC_H128_LAUNCH_(CAP_, SLOTS_, WIDE_, GRID_, false); } while (0)
-    const char *m128 = getenv("MGC_HASH128M");                       // read per call: the tests switch it
-    if (!(m128 && m128[0] == '0') && binrank128) {                  // round 4: hash_countw_kernel (noted claims, sorted entries, prefetch consumed first)
-#define MGC_W128_LAUNCH(CAP_, SLOTS_, WIDE_, LIST_, GRID_)                                                                               \
-      hipLaunchKernelGGL((hash_countw_kernel<K128, 256, CAP_, SLOTS_, WIDE_, LIST_>), dim3(GRID_), dim3(256), 0, st,                     \
-                         reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, msize, low_bits,            \
-                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b)
-      const uint32_t g128_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * (small ? 12u : 8u);
-      const uint32_t g128 = ng < g128_max ? (uint32_t)ng : g128_max;
-      const bool lst128 = d_nz != nullptr, wide128 = low_bits > 64;
-      if (small) {
-        if (wide128) { if (lst128) MGC_W128_LAUNCH(768, 1024, true, true, g128);  else MGC_W128_LAUNCH(768, 1024, true, false, g128); }
-        else         { if (lst128) MGC_W128_LAUNCH(768, 1024, false, true, g128); else MGC_W128_LAUNCH(768, 1024, false, false, g128); }
-      } else {
-        if (wide128) { if (lst128) MGC_W128_LAUNCH(1536, 2048, true, true, g128);  else MGC_W128_LAUNCH(1536, 2048, true, false, g128); }
-        else         { if (lst128) MGC_W128_LAUNCH(1536, 2048, false, true, g128); else MGC_W128_LAUNCH(1536, 2048, false, false, g128); }
-      }
-#undef MGC_W128_LAUNCH
-    } else
+    const uint32_t g128_max = 256u * (small ? 12u : 8u);
+    const uint32_t g128 = ng < g128_max ? (uint32_t)ng : g128_max;
+    const bool wide128 = low_bits > 64;
     if (small) {
-      // no sub-bucket above 768 k-mers: three keys per thread instead of six -- fewer idle unrolled slots, half the registers and
-      // LDS, six workgroups per CU instead of four
-      static const uint32_t sgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * (uint32_t)H128_SMALL_WAVES;
-      const uint32_t sgrid = ng < sgrid_max ? (uint32_t)ng : sgrid_max;
-      if (low_bits > 64) MGC_H128_LAUNCH(768, 1024, true, sgrid); else MGC_H128_LAUNCH(768, 1024, false, sgrid);
+      if (wide128) { if (use_list) MGC_W128_LAUNCH(768, 1024, true, true, g128);  else MGC_W128_LAUNCH(768, 1024, true, false, g128); }
+      else         { if (use_list) MGC_W128_LAUNCH(768, 1024, false, true, g128); else MGC_W128_LAUNCH(768, 1024, false, false, g128); }
     } else {
-      if (low_bits > 64) MGC_H128_LAUNCH(1536, 2048, true, wgrid); else MGC_H128_LAUNCH(1536, 2048, false, wgrid);
+      if (wide128) { if (use_list) MGC_W128_LAUNCH(1536, 2048, true, true, g128);  else MGC_W128_LAUNCH(1536, 2048, true, false, g128); }
+      else         { if (use_list) MGC_W128_LAUNCH(1536, 2048, false, true, g128); else MGC_W128_LAUNCH(1536, 2048, false, false, g128); }
     }
-#undef MGC_H128_LAUNCH
-#undef MGC_H128_LAUNCH_
+#undef MGC_W128_LAUNCH
     MGC_CHECK(hipGetLastError());
     if (stream && n_large) {
       constexpr int HS = 4096, HC = 2048;
@@ -2766,16 +1997,16 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       if (low_bits > 64)
         hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, true>), dim3((uint32_t)n_large), dim3(1024), BW, st_huge,
                            reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           cap128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                           FIN_CAP_HASH128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
                            reinterpret_cast<K128 *>(d_alt), tr_a, tr_b);
       else
         hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, false>), dim3((uint32_t)n_large), dim3(1024), BN, st_huge,
                            reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           cap128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                           FIN_CAP_HASH128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
                            reinterpret_cast<K128 *>(d_alt), tr_a, tr_b);
       MGC_CHECK(hipGetLastError());
     } else {
-      MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, n_large, low_bits, cap128, 8192, d_cnt_tmp, d_group_distinct, st, d_large_list)));
+      MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH128, 8192, d_cnt_tmp, d_group_distinct, st, d_large_list)));
     }
     return hipSuccess;
   }
@@ -2786,68 +2017,35 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     return hipSuccess;
   }
   if (finish_uses_hash(key_words, low_bits)) {
-    // <= FIN_CAP_HASH keys: hash-count; larger sub-buckets: LDS radix passes in the 8192-key instantiation
-    static const uint32_t hgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 14u;
-    const uint32_t hgrid = ng < hgrid_max ? (uint32_t)ng : hgrid_max;
-    const bool use_list = d_nz != nullptr;
-#define MGC_HASH_LAUNCH(KERNEL, ...)                                                                                        \
-    hipLaunchKernelGGL(KERNEL, dim3(hgrid), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys),                             \
-                       reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp,           \
-                       reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, ##__VA_ARGS__)
-    // the dense case runs the instantiation without the list: the kernel is VALU-bound, tests in its loops cost time
-    static const bool idx64 = !(getenv("MGC_FINISH_HASH64I") && getenv("MGC_FINISH_HASH64I")[0] == '0');
-    if (low_bits >= 32 && idx64) {
-      static const bool binrank64 = !(getenv("MGC_HASH_BINRANK") && getenv("MGC_HASH_BINRANK")[0] == '0');
-      // a file whose LARGEST sub-bucket holds at most 768 k-mers (`compress`: 59049 sub-buckets per bucket, a few hundred k-mers
-      // each): three keys per thread instead of six -- fewer idle unrolled slots, half the LDS, seven workgroups per CU
-      static const bool small64 = !(getenv("MGC_HASH64_SMALL") && getenv("MGC_HASH64_SMALL")[0] == '0');
-      const char *m64 = getenv("MGC_HASH64M");                       // read per call: the tests switch it
-      const bool use_64m = !(m64 && m64[0] == '0') && binrank64 && low_bits <= 58;
+    // <= FIN_CAP_HASH keys: hash-count; larger sub-buckets: streamed, or LDS radix passes in the 8192-key instantiation
+    if (low_bits >= 32) {
 #define MGC_W64_LAUNCH(CAP_, SLOTS_, LIST_, GRID_, MS_)                                                                                  \
       hipLaunchKernelGGL((hash_countw_kernel<u64, 256, CAP_, SLOTS_, false, LIST_>), dim3(GRID_), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys), \
                          reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)(MS_), low_bits, d_cnt_tmp,                             \
                          reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b)
-      if (use_64m && small64 && max_sub && max_sub <= 768 && n_large == 0) {
-        static const uint32_t sgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 12u;
-        const uint32_t sgrid = ng < sgrid_max ? (uint32_t)ng : sgrid_max;
+      if (small) {
+        const uint32_t sgrid = ng < 256u * 12u ? (uint32_t)ng : 256u * 12u;
         if (use_list) MGC_W64_LAUNCH(768, 1024, true, sgrid, 768); else MGC_W64_LAUNCH(768, 1024, false, sgrid, 768);
-      } else if (use_64m) {
-        static const uint32_t mgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 10u;
-        const uint32_t mgrid = ng < mgrid_max ? (uint32_t)ng : mgrid_max;
+      } else {
+        const uint32_t mgrid = ng < 256u * 10u ? (uint32_t)ng : 256u * 10u;
         if (use_list) MGC_W64_LAUNCH((int)FIN_CAP_HASH, 2048, true, mgrid, FIN_CAP_HASH); else MGC_W64_LAUNCH((int)FIN_CAP_HASH, 2048, false, mgrid, FIN_CAP_HASH);
-      } else
+      }
 #undef MGC_W64_LAUNCH
-      if (small64 && binrank64 && max_sub && max_sub <= 768 && n_large == 0) {
-        static const uint32_t sgrid_max = getenv("MGC_HASH_GRID") ? (uint32_t)atoi(getenv("MGC_HASH_GRID")) : 256u * 7u;
-        const uint32_t sgrid = ng < sgrid_max ? (uint32_t)ng : sgrid_max;
-        if (use_list)
-          hipLaunchKernelGGL((hash_count64i_kernel<256, 768, 1024, true, true>), dim3(sgrid), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys),
-                             reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)768, low_bits, d_cnt_tmp,
-                             reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b);
-        else
-          hipLaunchKernelGGL((hash_count64i_kernel<256, 768, 1024, false, true>), dim3(sgrid), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys),
-                             reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)768, low_bits, d_cnt_tmp,
-                             reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b);
-      } else
-      if (use_list) { if (binrank64) MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, true, true>), tr_a, tr_b);
-                      else           MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, true, false>), tr_a, tr_b); }
-      else          { if (binrank64) MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, false, true>), tr_a, tr_b);
-                      else           MGC_HASH_LAUNCH((hash_count64i_kernel<256, (int)FIN_CAP_HASH, 2048, false, false>), tr_a, tr_b); }
-    } else if (low_bits >= 32) {
-      if (use_list) MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, true>), tr_a, tr_b);
-      else          MGC_HASH_LAUNCH((hash_count64_kernel<256, (int)FIN_CAP_HASH, 2048, false>), tr_a, tr_b);
-    } else if (hash_dbg_buffer()) {
-      MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, true, true>), hash_dbg_buffer(), tr_a, tr_b);
     } else {
-      static const bool binrank = !(getenv("MGC_HASH_BINRANK") && getenv("MGC_HASH_BINRANK")[0] == '0');
-      if (use_list) { if (binrank) MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, false, true>), (u64 *)nullptr, tr_a, tr_b);
-                      else         MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, true, false, false>), (u64 *)nullptr, tr_a, tr_b); }
-      else          { if (binrank) MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, false, true>), (u64 *)nullptr, tr_a, tr_b);
-                      else         MGC_HASH_LAUNCH((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, false, false, false, false>), (u64 *)nullptr, tr_a, tr_b); }
-    }
+      const uint32_t hgrid = ng < 256u * 14u ? (uint32_t)ng : 256u * 14u;
+      u64 *dbgb = hash_dbg_buffer();
+#define MGC_HASH_LAUNCH(DBG_, LIST_)                                                                                                     \
+      hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, DBG_, LIST_, false>), dim3(hgrid), dim3(256), 0, st,           \
+                         reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, \
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, dbgb, tr_a, tr_b)
+      if (dbgb)          { if (use_list) MGC_HASH_LAUNCH(true, true); else MGC_HASH_LAUNCH(true, false); }
+      else if (use_list) MGC_HASH_LAUNCH(false, true);
+      else               MGC_HASH_LAUNCH(false, false);
 #undef MGC_HASH_LAUNCH
+      MGC_CHECK(hipGetLastError());
+      hash_dbg_report(st, ng);
+    }
     MGC_CHECK(hipGetLastError());
-    hash_dbg_report(st, ng);
     if (stream && n_large) {
       // sub-buckets above the small tables: one 1024-thread workgroup each, keys streamed through a large table
       static bool hattr = false;
@@ -2884,17 +2082,14 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
 }
 
 static uint64_t finish_small_capacity(uint32_t key_words, uint32_t low_bits) {
-  if (key_words == 2) return finish_uses_hash(key_words, low_bits) ? fin_cap_hash128() : 2048;
+  if (key_words == 2) return finish_uses_hash(key_words, low_bits) ? FIN_CAP_HASH128 : 2048;
   return finish_uses_hash(key_words, low_bits) ? FIN_CAP_HASH : FIN_CAP_SMALL;
 }
 
 uint64_t finish_capacity_for(uint32_t key_words) { return key_words == 2 ? 8192 : FIN_CAP_LARGE; }
 uint64_t finish_target_for(uint32_t key_words) {
-  if (const char *t = getenv("MGC_FINISH_TARGET")) return strtoull(t, nullptr, 10);
-  const char *h = getenv("MGC_FINISH_HASH");
-  // (768-key tables: 640 keeps the Poisson tail inside)
-  if (key_words == 2) return (h && h[0] == '0') ? 1024 : (fin_cap_hash128() == 768 ? 640 : (FIN_CAP_HASH * 3) / 4);
-  return (h && h[0] == '0') ? FIN_CAP_SMALL / 2 : (FIN_CAP_HASH * 3) / 4;
+  if (const char *t = getenv("MGC_FINISH_TARGET")) return strtoull(t, nullptr, 10);      // (read per call: tests make the sub-buckets tiny)
+  return key_words == 2 ? (FIN_CAP_HASH128 * 3) / 4 : (FIN_CAP_HASH * 3) / 4;
 }
 
 // group_distinct[0..ng_total) -> exclusive offsets in place, total at [ng_total]

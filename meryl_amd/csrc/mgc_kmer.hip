@@ -303,8 +303,7 @@ __device__ __forceinline__ u32 hpc_dense_rank(u32 x) {               // x: 2 * H
 template <int HB>
 __global__ __launch_bounds__(KP_BLOCK * KH_NV)
 void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u64 num_tiles, u32 vgrid,
-                           u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts, u64 *__restrict__ fine_hist,
-                           u32 *__restrict__ fine_rows /* [gridDim.x][2^15]: this workgroup's own counts (chunk-local first pass), or null */) {
+                           u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts, u64 *__restrict__ fine_hist) {
   constexpr u32 TABLE = HB ? hpc_table_size(HB) : (1u << KH_FINE_BITS);
   constexpr u32 NBK = HB ? (1u << (2 * (HB - 5))) : 64u;              // buckets: 64 files, or 2^bucket_bits
   constexpr u32 IDX_BITS = HB ? 2u * HB : (u32)KH_FINE_BITS;          // top bits of the k-mer that index the table
@@ -390,7 +389,6 @@ void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
   for (u32 i = tid; i < TABLE; i += KP_BLOCK * KH_NV) {
     const u32 c = kh_fine[i];
     if (c) atomicAdd(&fine_hist[i], (u64)c);
-    if (HB == 0 && fine_rows) fine_rows[((u64)blockIdx.x << KH_FINE_BITS) + i] = c;
   }
 }
 
@@ -426,14 +424,12 @@ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 
 // the order inside a (workgroup, tile, bucket) run.
 // MAXB: bucket capacity of the LDS tables (64 for the 64-file partition of the count path: 36 KiB of LDS per
 // workgroup instead of 51, i.e. four workgroups per CU instead of three; 1024 for the general operator)
-// DBG (measurements only, WRONG results; MGC_PART_DBG): 1 = every key leaves as 4 bytes (what a narrower key layout could buy on
-// the write side), 2 = no global stores at all (the kernel's compute + read floor)
 // SOA (round 4; 8-byte keys whose bits below the file fit 40: k <= 23): a file's region holds its k-mers as a u32 array (low
 // words) followed by a u8 array (bits 32..39) -- 5 bytes per k-mer instead of 8 leave this kernel and enter the file's first
 // grouping pass (radix_group_kernel<SOA>), which only ever needed 36 of the 64 bits (the file is where the k-mer lies).
 // Measured with the debug forms above (profiles/r04j_part_dbg.txt): 8-byte stores cost 10.4 of this kernel's 27.6 ms,
 // 4-byte stores 3.5.  soa_starts / soa_counts: first k-mer and number of k-mers of every file.
-template <typename K, int MAXB, int DBG = 0, bool SOA = false>
+template <typename K, int MAXB, bool SOA = false>
 __global__ __launch_bounds__(KP_BLOCK, (sizeof(K) == 16) ? 2 : (SOA ? 4 : 5))   // 16-byte keys: the 64 KiB exchange tile allows two workgroups; SOA: no spill, LDS allows four anyway
 void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
                            u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out, u64 sfx_mask, u64 sfx_test,
@@ -455,8 +451,12 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
   for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] = block_base[(u64)blockIdx.x * nb + b];
   __shared__ u64 s_fstart[SOA ? MAXB : 1], s_fhi[SOA ? MAXB : 1];   // SOA: first k-mer of the file; byte offset of its u8 array
   // where tile position 0 WOULD go for every bucket (bucket's cursor minus its first tile position), as byte addresses: a
-  // k-mer at tile position i of bucket b goes to s_ob[b] + i * (bytes per k-mer) -- one LDS read and one add per store
-  __shared__ u64 s_ob[MAXB], s_ob_hi[SOA ? MAXB : 1];
+  // k-mer at tile position i of bucket b goes to s_ob[b] + i * (bytes per k-mer) -- one LDS read and one add per store.  Only
+  // the 64-bucket instantiations keep the table (A/B-measured there, commit 400e59a); with 1024 buckets its 8 KiB would cost a
+  // workgroup per CU, and the address comes from s_cursor / s_base instead
+  constexpr bool OB = MAXB <= 64;
+  __shared__ u64 s_ob[OB ? MAXB : 1], s_ob_hi[SOA ? MAXB : 1];
+  static_assert(!SOA || OB, "the 5-byte layout is a 64-file layout");
   if constexpr (SOA) {
     for (u32 b = tid; b < nb; b += KP_BLOCK) { s_fstart[b] = soa_starts[b]; s_fhi[b] = 8ull * soa_starts[b] + 4ull * soa_counts[b]; }
   }
@@ -481,7 +481,7 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
 #pragma unroll
       for (int j = 0; j < KP_ITEMS; j++)
         if ((vmask >> j) & 1u) s_keys[o++] = keys[j];
-      if (tid == 0) { s_base[0] = 0; s_cnt[0] = total; s_ob[0] = reinterpret_cast<u64>(out) + (u64)sizeof(K) * s_cursor[0]; }
+      if (tid == 0) { s_base[0] = 0; s_cnt[0] = total; if constexpr (OB) s_ob[0] = reinterpret_cast<u64>(out) + (u64)sizeof(K) * s_cursor[0]; }
       __syncthreads();
     } else {
       // rank inside the bucket with LDS atomics (order inside a bucket is free)
@@ -510,7 +510,7 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
             const u64 rel0 = s_cursor[b] - s_fstart[b] - (u64)run;             // (wraps below zero when run > what lies before: added back with i)
             s_ob[b]    = reinterpret_cast<u64>(out) + 8ull * s_fstart[b] + 4ull * rel0;
             s_ob_hi[b] = reinterpret_cast<u64>(out) + s_fhi[b] + rel0;
-          } else {
+          } else if constexpr (OB) {
             s_ob[b] = reinterpret_cast<u64>(out) + (u64)sizeof(K) * (s_cursor[b] - (u64)run);
           }
         }
@@ -534,95 +534,11 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
         *reinterpret_cast<u32 *>(s_ob[b] + 4ull * i) = (u32)KeyOps<K>::low64(key);
         *reinterpret_cast<uint8_t *>(s_ob_hi[b] + (u64)i) = (uint8_t)(KeyOps<K>::low64(key) >> 32);
       }
-      else if constexpr (DBG == 1 && sizeof(K) == 8) reinterpret_cast<u32 *>(out)[s_cursor[b] + (u64)(i - s_base[b])] = (u32)key;
-      else if constexpr (DBG == 2) { if (KeyOps<K>::low64(key) == 0x123456789ABCDEFull) out[0] = key; }
-      else *reinterpret_cast<K *>(s_ob[b] + (u64)sizeof(K) * i) = key;
+      else if constexpr (OB) *reinterpret_cast<K *>(s_ob[b] + (u64)sizeof(K) * i) = key;
+      else out[s_cursor[b] + (u64)(i - s_base[b])] = key;
     }
     __syncthreads();
     for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] += s_cnt[b];
-    __syncthreads();
-  }
-}
-
-// kmer_partition_kernel with WRITE COMBINING (64 buckets, 8-byte keys): every global store is a whole, aligned 128-byte line.
-// A workgroup's run for a file starts wherever its private cursor says, so the plain kernel writes, per tile and file, a
-// run of ~55 keys whose first and last line are partial -- and a partial line costs the memory system as much as a whole
-// one (scripts/ubench/scatter.hip: 256-byte runs with odd starts run at 3.25 TB/s, aligned ones at 4.97).  Here the keys of
-// a file that do not complete a line (< 16 of them) STAY IN LDS: the tile array is laid out per file as [carry | new keys],
-// the leading whole lines go out, the tail is copied to a small carry buffer and becomes the head of the file's segment in
-// the next tile.  Only a workgroup's first line per file (its cursor is not aligned) and its last (the flush) are partial:
-// two per (workgroup, file) instead of two per (tile, file).  The output is byte for byte the plain kernel's: the same keys
-// in the same order at the same positions, written later.
-constexpr int KPC_LINE = 16;                           // 8-byte keys per 128-byte line
-__global__ __launch_bounds__(KP_BLOCK, 5)
-void kmer_partition_wc_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u64 num_tiles,
-                              const u64 *__restrict__ block_base, u64 *__restrict__ out) {
-  constexpr u32 NB = 64;                                        // LDS tile: KP_TILE + NB * KPC_LINE keys
-  extern __shared__ __attribute__((aligned(16))) unsigned char kp_dyn_smem[];
-  u64 *s_keys = reinterpret_cast<u64 *>(kp_dyn_smem);                // u64[CAP]: per file [carry | new]
-  __shared__ u64 s_carry[NB * KPC_LINE];
-  __shared__ u64 s_cursor[NB];                                       // global position of the first pending key of every file
-  __shared__ u32 s_cnt[NB], s_base[NB], s_rem[NB], s_outn[NB];
-  __shared__ u32 s_codes[KP_WORDS];
-  __shared__ u32 s_inval[KP_WORDS];
-  __shared__ u32 s_tmp[KP_BLOCK / 64 + 1];
-  const u32  bucket_shift = 2 * k - 6;
-  const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
-  const u32  tid = threadIdx.x;
-  if (tid < NB) { s_cursor[tid] = block_base[(u64)blockIdx.x * NB + tid]; s_rem[tid] = 0; }
-
-  u64 t_begin, t_end;
-  kp_tile_range(num_tiles, t_begin, t_end);
-  for (u64 tile = t_begin; tile <= t_end; tile++) {
-    const bool flush = tile == t_end;                                // one more round: whatever is pending goes out
-    if (tid < NB) s_cnt[tid] = 0;
-    u64 keys[KP_ITEMS];
-    u32 vmask = 0;
-    if (!flush) kp_stage_tile(bases, n, tile * KP_TILE, aligned, s_codes, s_inval);
-    __syncthreads();
-    u32 ranks[KP_ITEMS];
-    if (!flush) {
-      vmask = kp_thread_kmers(s_codes, s_inval, k, mode, keys);
-#pragma unroll
-      for (int j = 0; j < KP_ITEMS; j++) {
-        ranks[j] = 0;
-        if ((vmask >> j) & 1u) ranks[j] = atomicAdd(&s_cnt[KeyOps<u64>::bucket(keys[j], bucket_shift)], 1u);
-      }
-    }
-    __syncthreads();
-    // segment of file f = its pending keys + its new ones; how much of it goes out now
-    u32 seg = 0, total;
-    if (tid < NB) seg = s_rem[tid] + s_cnt[tid];
-    const u32 excl = block_excl_scan<KP_BLOCK, u32>(seg, s_tmp, &total);
-    if (tid < NB) {
-      s_base[tid] = excl;
-      const u32 mis = (u32)(s_cursor[tid] & (u64)(KPC_LINE - 1));
-      u32 head = mis ? (KPC_LINE - mis) : 0u;
-      if (head > seg) head = seg;
-      const u32 outn = flush ? seg : head + ((seg - head) / KPC_LINE) * KPC_LINE;
-      s_outn[tid] = outn;
-    }
-    __syncthreads();
-    // pending keys to the head of their file's segment, new keys behind them
-    for (u32 i = tid; i < NB * KPC_LINE; i += KP_BLOCK) {
-      const u32 f = i / KPC_LINE, j = i % KPC_LINE;
-      if (j < s_rem[f]) s_keys[s_base[f] + j] = s_carry[i];
-    }
-    if (!flush) {
-#pragma unroll
-      for (int j = 0; j < KP_ITEMS; j++)
-        if ((vmask >> j) & 1u) { const u32 f = KeyOps<u64>::bucket(keys[j], bucket_shift); s_keys[s_base[f] + s_rem[f] + ranks[j]] = keys[j]; }
-    }
-    __syncthreads();
-    // whole lines leave; the tail of every segment is the next round's pending part
-    for (u32 i = tid; i < total; i += KP_BLOCK) {
-      const u64 key = s_keys[i];
-      const u32 f = KeyOps<u64>::bucket(key, bucket_shift), idx = i - s_base[f], outn = s_outn[f];
-      if (idx < outn) out[s_cursor[f] + (u64)idx] = key;
-      else            s_carry[f * KPC_LINE + (idx - outn)] = key;
-    }
-    __syncthreads();
-    if (tid < NB) { const u32 sg = s_rem[tid] + s_cnt[tid]; s_cursor[tid] += s_outn[tid]; s_rem[tid] = sg - s_outn[tid]; }
     __syncthreads();
   }
 }
@@ -662,15 +578,8 @@ bool kmer_histogram_fine_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask)
 }
 
 // launch_kmer_histogram + d_fine_hist[2^15] (zeroed here): k-mers per (file, next nine bits)
-uint32_t kmer_histogram_fine_chunks(uint64_t n_bases, uint32_t *per_chunk, uint32_t *vgrid) {
-  const uint32_t vg = kp_grid_size(n_bases);
-  if (per_chunk) *per_chunk = KH_NV;
-  if (vgrid) *vgrid = vg;
-  return (vg + KH_NV - 1) / KH_NV;
-}
-
 hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint64_t *d_bucket_counts,
-                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st, uint32_t *d_fine_rows) {
+                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st) {
   MGC_CHECK(hipMemsetAsync(d_bucket_counts, 0, sizeof(uint64_t) * 64, st));
   MGC_CHECK(hipMemsetAsync(d_fine_hist, 0, sizeof(uint64_t) << KH_FINE_BITS, st));
   if (n_bases == 0) return hipSuccess;
@@ -684,7 +593,7 @@ hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, 
   }
   hipLaunchKernelGGL(kmer_hist_fine_kernel<0>, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) << KH_FINE_BITS, st,
                      d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
-                     reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), d_fine_rows);
+                     reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
   return hipGetLastError();
 }
 
@@ -716,11 +625,11 @@ hipError_t launch_kmer_histogram_hpc(const uint8_t *d_bases, uint64_t n_bases, u
   if (bucket_bits == 6)
     hipLaunchKernelGGL(kmer_hist_fine_kernel<8>, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
                        d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
-                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), (u32 *)nullptr);
+                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
   else
     hipLaunchKernelGGL(kmer_hist_fine_kernel<9>, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
                        d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
-                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), (u32 *)nullptr);
+                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
   return hipGetLastError();
 }
 
@@ -742,35 +651,15 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
     attr_done = true;
   }
-  // 64 files, 8-byte keys, no count-suffix filter: the write-combining form, with MGC_PARTITION_WC=1.  MEASURED (profiles/r03n_*):
-  // 34.4 ms per 10 Gbp against the plain kernel's 27.1 -- the second LDS array and the carry copies cost three workgroups
-  // per CU instead of five and more LDS traffic than the whole lines save -- so the plain kernel stays the default.
-  const char *wce = getenv("MGC_PARTITION_WC");                       // read per call: the tests switch it
-  const bool use_wc = wce && wce[0] == '1';
-  if (use_wc && k <= 32 && nb == 64 && sfx_mask == 0) {
-    constexpr size_t wc_bytes = (size_t)(KP_TILE + 64 * KPC_LINE) * sizeof(u64);
-    hipLaunchKernelGGL(kmer_partition_wc_kernel, dim3(grid), dim3(KP_BLOCK), wc_bytes, st, d_bases, (u64)n_bases, k, mode, (u64)num_tiles,
-                       reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys));
-    return hipGetLastError();
-  }
 #define MGC_KP_LAUNCH(K_, MAXB_)                                                                                   \
   hipLaunchKernelGGL((kmer_partition_kernel<K_, MAXB_>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K_), st,      \
                      d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,                                  \
                      reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys), (u64)sfx_mask, (u64)sfx_test)
   if (d_soa_counts) {                                                 // 5-byte layout (kmer_partition_soa_ok)
     if (!(k <= 32 && nb == 64 && sfx_mask == 0)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, 0, true>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
+    hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, true>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
                        bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)0, (u64)0,
                        reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
-    return hipGetLastError();
-  }
-  if (const char *pd = getenv("MGC_PART_DBG")) if (k <= 32 && nb <= 64 && (pd[0] == '1' || pd[0] == '2')) {
-    if (pd[0] == '1')
-      hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, 1>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
-                         bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)sfx_mask, (u64)sfx_test);
-    else
-      hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, 2>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
-                         bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)sfx_mask, (u64)sfx_test);
     return hipGetLastError();
   }
   if (k <= 32) { if (nb <= 64) MGC_KP_LAUNCH(u64, 64); else MGC_KP_LAUNCH(u64, KP_MAX_BUCKETS); }

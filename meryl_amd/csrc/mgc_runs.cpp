@@ -43,7 +43,6 @@ mgc_runs::mgc_runs(uint32_t k_, uint32_t w_prefix_, int device_, uint64_t budget
 }
 
 void mgc_runs::start_prealloc(size_t kb, size_t cb) {
-  if (getenv("MGC_OOC_NO_PREALLOC")) return;
   pre_thread = std::thread([this, kb, cb] {
     (void)hipSetDevice(device);
     pre_k = pre_c = nullptr; pre_kb = pre_cb = 0;
@@ -339,22 +338,28 @@ int mgc_runs::collapse(const void **keys, const uint32_t **counts, uint64_t *n) 
     // not yet merged (the inputs already merged are freed and dropped) -- every k-mer is still in exactly one run, so
     // the caller can deliver out of core instead (finalize_from_runs) or retry
     size_t i = 0;
-    auto keep_survivors = [&]() {
+    // returns false when a merged output could not get a valid slice table: the store is then NOT deliverable (a run with an
+    // all-zero table would look empty in every slice and its k-mers would be dropped silently) -- the caller must fail
+    auto keep_survivors = [&]() -> bool {
       for (size_t j = i; j < runs.size(); j++) if (runs[j].keys) next.push_back(std::move(runs[j]));
       runs.swap(next);
+      bool ok = true;
       // a merged output has no slice table yet (delivery needs one per run)
       for (Run &r : runs) {
         if (r.slice.size() == (size_t)n_slices + 1 || r.on_host || !r.keys) continue;
         r.slice.assign(n_slices + 1, 0);
-        if (d_slices.ensure(sizeof(uint64_t) * (n_slices + 1)) != hipSuccess) continue;
-        if (mgc::launch_block_offsets_range(r.keys, r.n, kw, 2 * k - slice_bits, 0, n_slices, n_slices, d_slices.as<uint64_t>(), st_mg) != hipSuccess) continue;
-        (void)hipMemcpyAsync(r.slice.data(), d_slices.p, sizeof(uint64_t) * (n_slices + 1), hipMemcpyDeviceToHost, st_mg);
-        (void)hipStreamSynchronize(st_mg);
+        bool got = d_slices.ensure(sizeof(uint64_t) * (n_slices + 1)) == hipSuccess &&
+                   mgc::launch_block_offsets_range(r.keys, r.n, kw, 2 * k - slice_bits, 0, n_slices, n_slices, d_slices.as<uint64_t>(), st_mg) == hipSuccess &&
+                   hipMemcpyAsync(r.slice.data(), d_slices.p, sizeof(uint64_t) * (n_slices + 1), hipMemcpyDeviceToHost, st_mg) == hipSuccess &&
+                   hipStreamSynchronize(st_mg) == hipSuccess;
+        if (got && !(r.slice[0] == 0 && r.slice[n_slices] == r.n)) got = false;          // (the check add() makes)
+        if (!got) { (void)hipGetLastError(); ok = false; }
       }
+      return ok;
     };
-#define RN_TRY_KEEP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { free_run(o); keep_survivors();                     \
-      set_err(&err, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__));                                         \
-      return (e__ == hipErrorOutOfMemory) ? MGC_ENOMEM : MGC_EHIP; } } while (0)
+#define RN_TRY_KEEP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { free_run(o); const bool ks__ = keep_survivors();  \
+      set_err(&err, "%s:%d: %s -> %s%s", __FILE__, __LINE__, #expr, hipGetErrorString(e__), ks__ ? "" : " (and a merged run has no slice table)"); \
+      return (e__ == hipErrorOutOfMemory && ks__) ? MGC_ENOMEM : MGC_EHIP; } } while (0)
     for (; i < runs.size(); i += 2) {
       if (i + 1 >= runs.size()) { next.push_back(std::move(runs[i])); continue; }
       Run &a = runs[i], &b = runs[i + 1];
@@ -370,7 +375,10 @@ int mgc_runs::collapse(const void **keys, const uint32_t **counts, uint64_t *n) 
       if (e != hipSuccess) {
         (void)hipGetLastError();
         free_run(o);
-        keep_survivors();
+        if (!keep_survivors()) {                             // not a consistent store: no out-of-core delivery from it
+          set_err(&err, "mgc_runs: merging the runs in HBM: %s, and a merged run could not get its slice table", hipGetErrorString(e));
+          return MGC_EHIP;
+        }
         set_err(&err, "mgc_runs: merging the runs in HBM: %s", hipGetErrorString(e));
         return MGC_ENOMEM;
       }

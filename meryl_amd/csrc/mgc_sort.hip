@@ -50,7 +50,6 @@ constexpr u32      RS_SPIN_LIMIT = 1u << 24;
 struct SortHeader {                       // lives at the start of the sort workspace
   u64 ghist[RS_MAX_PASSES][RS_MAX_RADIX]; // digit counts per pass
   u64 gbase[RS_MAX_PASSES][RS_MAX_RADIX]; // exclusive digit bases per pass
-  u64 row_total[RS_MAX_RADIX];            // classic mode scratch
   u32 ticket[RS_MAX_PASSES];
   u32 pad[16];
 };
@@ -126,18 +125,6 @@ void radix_digit_scan_kernel(const u64 *__restrict__ ghist, u64 *__restrict__ gb
   gbase[(u64)p * RS_MAX_RADIX + threadIdx.x] = e;
 }
 
-template <int RB>
-__device__ __forceinline__ u64 match_digit(u32 d) {
-  u64 peers = ~0ull;
-#pragma unroll
-  for (int b = 0; b < RB; b++) {
-    const bool bit = (d >> b) & 1u;
-    const u64  m   = __ballot(bit);
-    peers &= bit ? m : ~m;
-  }
-  return peers;
-}
-
 __device__ __forceinline__ void status_store(u64 *p, u64 v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -155,7 +142,7 @@ __device__ __forceinline__ u64 st_pack(u32 f0, u32 v0, u32 f1, u32 v1) {
 }
 
 
-template <typename K, int RB, int BLOCK, int KPT, int LB = 0>
+template <typename K, int RB, int BLOCK, int KPT, int LB>
 struct RadixSmem {
   static constexpr int R     = 1 << RB;
   static constexpr int NW    = BLOCK / 64;
@@ -169,26 +156,22 @@ struct RadixSmem {
   static constexpr size_t OFF_CNT   = OFF_DBASE + (size_t)R * 4;   // u32[R]
   static constexpr size_t OFF_TMP   = OFF_CNT + (size_t)R * 4;     // u32[64] scan scratch + misc
   static constexpr size_t OFF_WIN   = OFF_TMP + 64 * 4;            // u64[LB_WINDOW][R/2] look-back window (LB == 2)
-  static constexpr size_t WIN_BYTES = (LB == 2 || LB == 3) ? ((RB == 9 && BLOCK == 512) ? 4096 : 8192) : 0;
+  static constexpr size_t WIN_BYTES = 8192;
   static constexpr size_t BYTES     = OFF_WIN + WIN_BYTES;
   // workgroups per CU the LDS budget admits (160 KiB per CU), capped at 2
   static constexpr int    WG_PER_CU = (2 * BYTES <= 160 * 1024) ? 2 : 1;
   static constexpr int    MIN_WAVES_PER_SIMD = (WG_PER_CU * BLOCK) / 256;
 };
 
-template <typename K, int RB, int BLOCK, int KPT, int LB, int MATCH>
+// LB 2: two digits per look-back granule (30-bit values, n < 2^30); LB 3: one digit per granule (62-bit values)
+template <typename K, int RB, int BLOCK, int KPT, int LB>
 __global__ __launch_bounds__(BLOCK, (RadixSmem<K, RB, BLOCK, KPT, LB>::MIN_WAVES_PER_SIMD))
 void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, u32 shift, u32 dmask,
-                          const u64 *__restrict__ gbase,      // LOOKBACK: exclusive digit bases of this pass
-                          u64 *__restrict__ status,           // LOOKBACK: [num_tiles][R/2] granules of this pass (zeroed)
-                          u32 *__restrict__ ticket, u32 *__restrict__ error_flag,
-                          u32 flags,                          // bit0: XCD-chunked tile order, bit1: non-temporal key loads
-                          const u64 *__restrict__ tile_offs,  // !LOOKBACK: [R][num_tiles] absolute offsets
-                          u64 num_tiles, u64 *__restrict__ dbg /* optional: 8 cycle stamps per tile */) {
+                          const u64 *__restrict__ gbase,      // exclusive digit bases of this pass
+                          u64 *__restrict__ status,           // [num_tiles][R/2 or R] granules of this pass (zeroed)
+                          u32 *__restrict__ ticket, u32 *__restrict__ error_flag) {
+  static_assert(LB == 2 || LB == 3, "window look-back with packed or wide granules");
   using SM = RadixSmem<K, RB, BLOCK, KPT, LB>;
-#define MGC_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg_t[i] = clock64(); } while (0)
-  u64 dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  MGC_STAMP(0);
   using KO = KeyOps<K>;
   constexpr int R = SM::R, NW = SM::NW, TILE = SM::TILE;
   static_assert(BLOCK >= R, "one thread per digit needed");
@@ -202,22 +185,15 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
 
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
 
-  constexpr bool LOOKBACK = (LB != 0);
   // Tile ids are tickets: every lower-numbered tile has started, hence is resident and will
   // publish its aggregate -- the look-back cannot deadlock (spins are bounded anyway).
-  u64 tile;
-  if (LOOKBACK) {
-    if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
-    __syncthreads();
-    tile = s_tmp[32];
-  } else {
-    tile = blockIdx.x;
-  }
+  if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const u64 tile = s_tmp[32];
 
   for (u32 i = tid; i < (u32)(NW * R * 3); i += BLOCK) s_whist[i] = 0;   // counters + match masks
   __syncthreads();
 
-  MGC_STAMP(1);
   // ---- load (wave-striped: 512 contiguous bytes per wave instruction) ----
   const u64  tile_base = tile * (u64)TILE;
   const bool full      = (tile_base + TILE <= n);
@@ -228,25 +204,11 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
     const u64 idx = wave_base + (u64)j * 64;
     keys[j] = (full || idx < n) ? in[idx] : KO::pad();  // padding sorts to the end of the last digit
   }
-  (void)flags;
 
   // ---- rank inside the wave (stable: by lane order inside a row, rows in order) ----
   const u64 lt_mask = (1ull << lane) - 1ull;
   u32 ranks[KPT / 2];                                  // two 16-bit ranks per register (rank < TILE <= 2^14)
-  if (MATCH == 0) {
-    // peers by RB ballots per key: data-independent cost, VALU heavy
-    lds_u32 *wh = (lds_u32 *)(smem) + w * R;
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      const u32 d     = KO::digit(keys[j], shift, dmask);
-      const u64 peers = match_digit<RB>(d);
-      const u32 lower = __popcll(peers & lt_mask);
-      const u32 base  = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      if (lower == 0) __hip_atomic_store(&wh[d], base + (u32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      if (j & 1) ranks[j / 2] |= (base + lower) << 16;
-      else       ranks[j / 2]  = (base + lower);
-    }
-  } else {
+  {
     // peers through a wave-private LDS mask per digit: every lane ORs its lane bit into
     // mask[digit], reads the mask back (LDS executes a wave's instructions in order), and the
     // lowest peer bumps the running digit counter and clears the mask for the next row.
@@ -270,7 +232,6 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
   }
   __syncthreads();
 
-  MGC_STAMP(2);
   // ---- digit totals of the tile, wave-exclusive bases ----
   const u32 n_valid = full ? (u32)TILE : (u32)(n - tile_base);
   u32 count = 0;
@@ -291,60 +252,17 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
   if (tid < (u32)R) s_dbase[tid] = excl;
 
   // granules of this tile: publish the aggregate as early as possible
-  // LB 1/2: two digits per granule (30-bit values, n < 2^30); LB 3: one digit per granule (62-bit values)
   constexpr int GW = (LB == 3) ? 1 : 2;                 // digits per granule
   constexpr int G  = R / GW;                            // granules per tile
   constexpr u64 V62 = (1ull << 62) - 1;
-  u64 *mine = status + (LOOKBACK ? tile * (u64)G + tid : 0);
-  if (LOOKBACK) {
-    __syncthreads();                                    // s_cnt / s_dbase visible
-    if (tid < (u32)G) {
-      const u32 c0 = s_cnt[GW * tid], c1 = (GW == 2) ? s_cnt[GW * tid + 1] : 0u;
-      const u32 fl = (tile == 0) ? 2u : 1u;
-      status_store(mine, (GW == 2) ? st_pack(fl, c0, fl, c1) : (((u64)fl << 62) | (u64)c0));
-      if constexpr (LB == 1) {
-        // serial walk per digit pair, four predecessors in flight per round
-        u32 p0 = 0, p1 = 0;
-        if (tile != 0) {
-          bool need0 = true, need1 = true;
-          u64  t = tile - 1;
-          u32  spins = 0;
-          while (need0 || need1) {
-            u64 g[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-              g[i] = (t >= (u64)i) ? status_load(status + (t - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
-            u32 used = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-              if (need0 || need1) {
-                const u32 lo = (u32)g[i], hi = (u32)(g[i] >> 32);
-                const u32 f0 = lo >> 30, f1 = hi >> 30;
-                if (f0 == 0 || f1 == 0) break;
-                if (need0) { p0 += lo & 0x3FFFFFFFu; if (f0 == 2) need0 = false; }
-                if (need1) { p1 += hi & 0x3FFFFFFFu; if (f1 == 2) need1 = false; }
-                used++;
-              }
-            }
-            t -= (used <= t) ? used : t;
-            if (used == 0) {
-              if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); break; }
-              __builtin_amdgcn_s_sleep(1);
-            }
-          }
-          status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
-        }
-        s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
-        s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
-      }
-    }
-    if (LB == 1) __syncthreads();
-  } else {
-    if (tid < (u32)R) s_gbase[tid] = tile_offs[(u64)tid * num_tiles + tile] - (u64)excl;
-    __syncthreads();
+  u64 *mine = status + tile * (u64)G + tid;
+  __syncthreads();                                      // s_cnt / s_dbase visible
+  if (tid < (u32)G) {
+    const u32 c0 = s_cnt[GW * tid], c1 = (GW == 2) ? s_cnt[GW * tid + 1] : 0u;
+    const u32 fl = (tile == 0) ? 2u : 1u;
+    status_store(mine, (GW == 2) ? st_pack(fl, c0, fl, c1) : (((u64)fl << 62) | (u64)c0));
   }
 
-  MGC_STAMP(3);
   // ---- final position of every key inside the sorted tile ----
 #pragma unroll
   for (int j = 0; j < KPT; j++) {           // ranks[] becomes positions in place (still < TILE)
@@ -356,9 +274,8 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
 #pragma unroll
   for (int j = 0; j < KPT; j++) s_keys[(j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu)] = keys[j];
   __syncthreads();                          // keys now live in LDS only: registers are free for the look-back
-  MGC_STAMP(4);
 
-  if constexpr (LB == 2 || LB == 3) {
+  {
     // window-parallel look-back after the exchange (keys live in LDS only, registers are free):
     // all waves fetch the granules of the next LB_WINDOW predecessors with coalesced loads into
     // LDS, the R/2 digit-pair threads consume the ready prefix.
@@ -435,7 +352,6 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
     __syncthreads();
   }
 
-  MGC_STAMP(5);
   // ---- contiguous runs leave coalesced ----
 #pragma unroll
   for (int j = 0; j < KPT; j++) {
@@ -446,205 +362,6 @@ void radix_scatter_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, 
       out[s_gbase[d] + (u64)i] = key;
     }
   }
-  MGC_STAMP(6);
-  if (dbg && threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < 7; i++) dbg[tile * 8 + i] = dbg_t[i];
-  }
-#undef MGC_STAMP
-}
-
-// ---- pipelined look-back pass (plan.lookback == 5) ----------------------------
-// Same pass as radix_scatter_kernel<.., LB, MATCH=1>, restructured so HBM never idles behind the
-// per-tile work: workgroups are persistent, take the ticket of their NEXT tile at the top of an
-// iteration, and once the keys of the current tile live in LDS (after the exchange) the registers are
-// refilled with the next tile's keys while the look-back and the write-out run.  s_waitcnt vmcnt is
-// per wave and in order, so the waves that poll the status granules (tid < R/2, the first R/128
-// waves) fetch their share of the next tile only after their walk; all other waves fetch before it.
-// A ticket held one tile ahead keeps the no-deadlock argument: the lowest unfinished tile is always
-// some workgroup's current one.  Granules: two digits per 8 bytes, n < 2^30.
-template <typename K, int RB, int BLOCK, int KPT, bool DBG>
-__global__ __launch_bounds__(BLOCK, (RadixSmem<K, RB, BLOCK, KPT, 4>::MIN_WAVES_PER_SIMD))
-void radix_scatter_pipe_kernel(const K *__restrict__ in, K *__restrict__ out, u64 n, u32 shift, u32 dmask,
-                               const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
-                               u32 *__restrict__ error_flag, u64 num_tiles, u64 *__restrict__ dbg) {
-  using SM = RadixSmem<K, RB, BLOCK, KPT, 4>;
-  using KO = KeyOps<K>;
-  constexpr int R = SM::R, NW = SM::NW, TILE = SM::TILE, G = R / 2;
-  constexpr int WALK = 8;                               // predecessor granules in flight per walker thread
-  static_assert(BLOCK >= R && G % 64 == 0, "one thread per digit; whole waves walk");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  K   *s_keys  = reinterpret_cast<K *>(smem);
-  u32 *s_whist = reinterpret_cast<u32 *>(smem);                       // aliases s_keys (see barriers)
-  u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
-  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
-  u32 *s_cnt   = reinterpret_cast<u32 *>(smem + SM::OFF_CNT);
-  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
-  const u32 tid0 = threadIdx.x;
-  u32 tid = tid0, lane = tid0 & 63u, w = tid0 >> 6;
-
-  K keys[KPT];
-  auto fetch = [&](u64 t) __attribute__((always_inline)) {
-    if (t >= num_tiles) return;
-    const u64 tile_base = t * (u64)TILE;
-    const u64 wave_off  = tile_base + (u64)w * (64 * KPT) + lane;
-    const K  *p         = in + wave_off;
-    if (tile_base + TILE <= n) {                        // every tile but the last
-#pragma unroll
-      for (int j = 0; j < KPT; j++) keys[j] = p[j * 64];
-    } else {
-#pragma unroll
-      for (int j = 0; j < KPT; j++) keys[j] = (wave_off + (u64)j * 64 < n) ? p[j * 64] : KO::pad();
-    }
-  };
-
-  if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
-  __syncthreads();
-  u64 tile = s_tmp[32];
-  fetch(tile);
-
-  u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
-#define PK_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
-  while (tile < num_tiles) {
-    if (DBG) t0 = __builtin_readcyclecounter();
-    // the thread coordinates are laundered once per iteration: otherwise every LDS address of the
-    // unrolled body is hoisted out of the loop and the kernel spills
-    tid = tid0;
-    asm volatile("" : "+v"(tid));
-    lane = tid & 63u; w = tid >> 6;
-    const u64 lt_mask = (1ull << lane) - 1ull, lane_bit = 1ull << lane;
-    const bool walker = tid < (u32)G;                   // whole waves: G is a multiple of 64
-    if (tid == 0) s_tmp[33] = atomicAdd(ticket, 1u);    // published by the barrier below
-    for (u32 i = tid; i < (u32)(NW * R * 3); i += BLOCK) s_whist[i] = 0;   // counters + match masks
-    __syncthreads();
-    const u64 next = s_tmp[33];
-    PK_STAMP(0);
-    const u64 tile_base = tile * (u64)TILE;
-    const u32 n_valid   = (tile_base + TILE <= n) ? (u32)TILE : (u32)(n - tile_base);
-
-    // ---- rank inside the wave through wave-private LDS match masks (see radix_scatter_kernel) ----
-    u32 ranks[KPT / 2];
-    {
-      lds_u32 *wh = (lds_u32 *)(smem) + w * R;
-      lds_u64 *mk = (lds_u64 *)(smem + (size_t)NW * R * 4) + w * R;
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        const u32 d = KO::digit(keys[j], shift, dmask);
-        __hip_atomic_fetch_or(&mk[d], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        const u64 peers = __hip_atomic_load(&mk[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        const u32 base  = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        const u32 lower = __popcll(peers & lt_mask);
-        if (lower == 0) {
-          __hip_atomic_store(&wh[d], base + (u32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          __hip_atomic_store(&mk[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-        if (j & 1) ranks[j / 2] |= (base + lower) << 16;
-        else       ranks[j / 2]  = (base + lower);
-      }
-    }
-    __syncthreads();
-    PK_STAMP(1);
-
-    // ---- digit totals of the tile, wave-exclusive bases ----
-    u32 count = 0;
-    if (tid < (u32)R) {
-      u32 acc = 0;
-#pragma unroll
-      for (int ww = 0; ww < NW; ww++) {
-        const u32 t = s_whist[ww * R + tid];
-        s_whist[ww * R + tid] = acc;
-        acc += t;
-      }
-      count = acc;
-      s_cnt[tid] = (tid == dmask) ? count - ((u32)TILE - n_valid) : count;   // padding is not published
-    }
-    u32 tile_total;
-    const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tile_total);
-    if (tid < (u32)R) s_dbase[tid] = excl;
-    __syncthreads();
-
-    // ---- publish the aggregate, then move the keys to their place in the sorted tile ----
-    u64 *mine = status + tile * (u64)G + tid;
-    u32 c0 = 0, c1 = 0;
-    if (walker) {
-      c0 = s_cnt[2 * tid]; c1 = s_cnt[2 * tid + 1];
-      const u32 fl = (tile == 0) ? 2u : 1u;
-      status_store(mine, st_pack(fl, c0, fl, c1));
-    }
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      const u32 d = KO::digit(keys[j], shift, dmask);
-      const u32 add = s_dbase[d] + s_whist[w * R + d];
-      ranks[j / 2] += (j & 1) ? (add << 16) : add;
-    }
-    __syncthreads();                          // s_whist is dead; its storage becomes s_keys
-#pragma unroll
-    for (int j = 0; j < KPT; j++) s_keys[(j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu)] = keys[j];
-    __syncthreads();                          // keys live in LDS only: the registers take the next tile
-    PK_STAMP(2);
-
-    if (!walker) {
-      fetch(next);
-    } else {
-      // flat walk over the predecessors' granules, WALK in flight per round (a two-level scheme with
-      // group sums was tried: it needs a third dependent round trip and measured 25% slower)
-      u32 p0 = 0, p1 = 0;
-      if (tile != 0) {
-        bool done = false;
-        u64  t = tile - 1;
-        u32  spins = 0;
-        while (!done) {
-          u64 gv[WALK];
-#pragma unroll
-          for (int i = 0; i < WALK; i++)
-            gv[i] = (t >= (u64)i) ? status_load(status + (t - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
-          u32 used = 0;
-          bool open = true;
-#pragma unroll
-          for (int i = 0; i < WALK; i++) {
-            const u32 lo = (u32)gv[i], hi = (u32)(gv[i] >> 32);
-            const u32 f = lo >> 30;                     // both halves of a granule carry the same flag
-            open = open && !done && (f != 0);
-            if (open) {
-              p0 += lo & 0x3FFFFFFFu; p1 += hi & 0x3FFFFFFFu;
-              if (f == 2) done = true;
-              used++;
-            }
-          }
-          t -= (used <= t) ? used : t;
-          if (used == 0) {
-            if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
-      }
-      s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
-      s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
-      fetch(next);
-    }
-    __syncthreads();
-    PK_STAMP(3);
-
-    // ---- contiguous runs leave coalesced ----
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      const u32 i = (u32)j * BLOCK + tid;
-      if (i < n_valid) {
-        const K   key = s_keys[i];
-        const u32 d   = KO::digit(key, shift, dmask);
-        out[s_gbase[d] + (u64)i] = key;
-      }
-    }
-    PK_STAMP(4);
-    __syncthreads();                          // s_keys / s_gbase are rewritten by the next iteration
-    PK_STAMP(5);
-    tile = next;
-    if (DBG) ph[7]++;
-  }
-  if (DBG && tid0 == 0 && blockIdx.x < 64)
-    for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
-#undef PK_STAMP
 }
 
 // ---- grouping pass (plan.mode == 3; the sub-bucket finish path) -----------------------
@@ -941,661 +658,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
   }
 }
 
-// ---- first grouping pass of a file in the 5-byte layout, TWO workgroups per CU (round 4; measured slower, MGC_SOA_2WG=1) ----
-// radix_group_kernel<u64, 9, 1024, 16, NARROW, HIST2, SOA> exchanges whole 8-byte keys through LDS: 128 KiB per 16384-key tile,
-// one workgroup per CU, whose phases (fetch, rank, scan, exchange, look-back, write-out) run one after the other with nothing
-// else resident to fill the gaps (waves parked 58-66 %, nothing saturated).  Halving the tile loses on the write
-// side (runs of 16 words).  This kernel keeps the 16384-key tile and exchanges the NARROWED 32-bit words instead -- 64 KiB --
-// so that two workgroups share a CU: a key's digit is not in its word, so the write-out goes by digit instead of by position
-// (wave w owns digits 32w .. 32w+31, contiguous in LDS; every store instruction is one digit's run, as in the exchange order).
-// A k-mer stays (u32 low word, u8 high byte) in registers -- 20 VGPRs per 16 keys instead of 32 -- and the whole kernel fits the
-// 64 VGPRs two 1024-thread workgroups per CU leave, without the register prefetch across the look-back (the other workgroup is
-// the latency hiding).  Same tickets, status granules, look-back, HIST2 and output as the kernel it would replace; bit-exact
-// (test_five_byte_first_pass_two_workgroups_per_cu) and 5 % SLOWER (0.568 against 0.541 ms per 135 M k-mers): with the chunk-local
-// kernel's two-workgroup forms (round 3) the third measurement that says a pass is bound by what a CU's LDS and memory pipeline
-// put through, not by what is resident to wait on them.  Off.  Restates the same reference code (unpackSuffixes + std::sort,
-// merylCountArray.C:276-289,330 -- top bits only).
-struct Group5Smem {
-  static constexpr int R = 512, BLOCK = 1024, KPT = 16, TILE = BLOCK * KPT;
-  static constexpr size_t OFF_HIST  = (size_t)TILE * 4;                // u32[R]   tile histogram (counts stay until the next tile)
-  static constexpr size_t OFF_GBASE = OFF_HIST + (size_t)R * 4;        // u64[R]
-  static constexpr size_t OFF_DBASE = OFF_GBASE + (size_t)R * 8;       // u32[R]
-  static constexpr size_t OFF_H2    = OFF_DBASE + (size_t)R * 4;       // u32[R]   the other digit's histogram (HIST2)
-  static constexpr size_t OFF_TMP   = OFF_H2 + (size_t)R * 4;          // u32[64]
-  static constexpr size_t OFF_INFO  = OFF_TMP + 64 * 4;                // u64[4]
-  static constexpr size_t BYTES     = OFF_INFO + 4 * 8;
-  static_assert(2 * BYTES <= 160 * 1024, "two workgroups per CU");
-};
-
-#ifndef G5_WAVES
-#define G5_WAVES 8
-#endif
-__global__ __launch_bounds__(1024, G5_WAVES)
-void radix_group5_kernel(const u32 *__restrict__ in_lo, const uint8_t *__restrict__ in_hi, u32 *__restrict__ out, u64 n, u32 shift,
-                         u32 dmask, const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
-                         u32 *__restrict__ error_flag, u64 total_tiles, GroupExtra ex) {
-  using SM = Group5Smem;
-  constexpr int R = SM::R, BLOCK = SM::BLOCK, KPT = SM::KPT, TILE = SM::TILE, G = R / 2, WALK = 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32 *s_words = reinterpret_cast<u32 *>(smem);
-  u32 *s_hist  = reinterpret_cast<u32 *>(smem + SM::OFF_HIST);
-  u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
-  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
-  u32 *s_h2    = reinterpret_cast<u32 *>(smem + SM::OFF_H2);
-  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
-  const u32 tid0 = threadIdx.x;
-  u32 tid = tid0, lane = tid0 & 63u, w = tid0 >> 6;
-  if (tid0 < (u32)R) s_h2[tid0] = 0;
-  const u32 hm = ex.soa_hi_mask;
-  const u32 wmask = shift >= 32u ? 0xFFFFFFFFu : ((1u << shift) - 1u);      // the word a k-mer leaves as: its bits below the digit
-
-  // key j of a thread is element idx_of(j) of the tile: four consecutive keys per lane and load group, wave-striped
-  auto idx_of = [&](int j) __attribute__((always_inline)) -> u32 {
-    return w * (u32)(64 * KPT) + ((u32)(j / 4) * 64u + lane) * 4u + (u32)(j % 4);
-  };
-  u32 lo[KPT], hi4[KPT / 4];                                  // hi4[g]: the high bytes of keys 4g .. 4g+3, one per byte
-  struct __attribute__((aligned(4))) LVec { u32 v[4]; };
-  struct __attribute__((packed, aligned(1))) HWord { u32 v; };
-  // A group that starts inside the tile is loaded whole: up to three words past the file's last k-mer (its own high-byte array
-  // lies there) and three bytes past its last high byte (the region is 8 bytes per k-mer); idx_of(j) < nv says which ones count.
-  auto fetch = [&](u64 kb, u32 nv) __attribute__((always_inline)) {
-    const u32 *lo32 = in_lo + kb;
-    const uint8_t *hi8 = in_hi + kb;
-#pragma unroll
-    for (int g = 0; g < KPT / 4; g++) {
-      const u32 first = idx_of(g * 4);
-      if (first < nv) {
-        const LVec l = *reinterpret_cast<const LVec *>(lo32 + first);
-        hi4[g] = reinterpret_cast<const HWord *>(hi8 + first)->v;
-#pragma unroll
-        for (int c = 0; c < 4; c++) lo[g * 4 + c] = l.v[c];
-      }
-    }
-  };
-  auto digit_of = [&](int j) __attribute__((always_inline)) -> u32 {
-    const u64 key = (u64)lo[j] | ((u64)((hi4[j / 4] >> (8 * (j % 4))) & hm) << 32);
-    return (u32)(key >> shift) & dmask;
-  };
-
-  if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
-  __syncthreads();
-  u64 tile = (u64)(u32)__builtin_amdgcn_readfirstlane((int)s_tmp[32]);        // tile numbers and counts are uniform: scalar registers
-  u32 nv = 0;
-  if (tile < total_tiles) { nv = (n - tile * (u64)TILE < (u64)TILE) ? (u32)(n - tile * (u64)TILE) : (u32)TILE; fetch(tile * (u64)TILE, nv); }
-
-  while (tile < total_tiles) {
-    tid = tid0;
-    asm volatile("" : "+v"(tid));                         // keeps the unrolled body's LDS addresses out of the loop preheader
-    lane = tid & 63u; w = tid >> 6;
-    const bool walker = tid < (u32)G;
-    if (tid == 0) s_tmp[33] = atomicAdd(ticket, 1u);
-    if (tid < (u32)R) s_hist[tid] = 0;
-    __syncthreads();                                      // (A)
-    const u64 next = (u64)(u32)__builtin_amdgcn_readfirstlane((int)s_tmp[33]);
-    const u64 nkb = next * (u64)TILE;
-    const u32 nnv = (next < total_tiles) ? ((n - nkb < (u64)TILE) ? (u32)(n - nkb) : (u32)TILE) : 0u;
-
-    // ---- rank: position among the tile's keys of the same digit, in arrival order ----
-    // (a whole tile takes the branch-free body: sixteen returning atomics in flight, not one per basic block)
-    u32 ranks[KPT / 2];
-    if (nv == (u32)TILE) {
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        const u32 r = atomicAdd(&s_hist[digit_of(j)], 1u);
-        if (j & 1) ranks[j / 2] |= r << 16;
-        else       ranks[j / 2]  = r;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        u32 r = 0;
-        if (idx_of(j) < nv) r = atomicAdd(&s_hist[digit_of(j)], 1u);
-        if (j & 1) ranks[j / 2] |= r << 16;
-        else       ranks[j / 2]  = r;
-      }
-    }
-    // the exchange works the digits out again from the packed high bytes: sixteen unpacked ones kept across the scan cost sixteen registers
-#pragma unroll
-    for (int g = 0; g < KPT / 4; g++) asm volatile("" : "+v"(hi4[g]));
-    __syncthreads();                                      // (B)
-
-    const u32 count = (tid < (u32)R) ? s_hist[tid] : 0u;
-    u32 tile_total;
-    const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tile_total);
-    if (tid < (u32)R) s_dbase[tid] = excl;
-    __syncthreads();                                      // (C)
-
-    u64 *mine = status + tile * (u64)G + tid;
-    u32 c0 = 0, c1 = 0;
-    if (walker) {
-      c0 = s_hist[2 * tid]; c1 = s_hist[2 * tid + 1];
-      const u32 fl = (tile == 0) ? 2u : 1u;
-      status_store(mine, st_pack(fl, c0, fl, c1));
-    }
-    if (nv == (u32)TILE) {
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
-        s_words[s_dbase[digit_of(j)] + r] = lo[j] & wmask;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        if (idx_of(j) < nv) {
-          const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
-          s_words[s_dbase[digit_of(j)] + r] = lo[j] & wmask;
-        }
-      }
-    }
-    __syncthreads();                                      // (D) the tile's words live in LDS only
-
-    // ---- look-back (as radix_group_kernel's), the next tile's fetch and the other digit's histogram in its shadow ----
-    u32 p0 = 0, p1 = 0;
-    if (!walker) {
-      for (u32 i = tid - (u32)G; i < nv; i += (u32)(BLOCK - G)) atomicAdd(&s_h2[(s_words[i] >> ex.shift2) & ex.mask2], 1u);
-    } else {
-      bool done = (tile == 0);
-      u64  wt = tile ? tile - 1 : 0;
-      u32  spins = 0;
-      while (!done) {
-        u64 gv[WALK];
-#pragma unroll
-        for (int i = 0; i < WALK; i++)
-          gv[i] = (wt >= (u64)i) ? status_load(status + (wt - i) * (u64)G + tid) : st_pack(2, 0, 2, 0);
-        u32 used = 0;
-        bool open = true;
-#pragma unroll
-        for (int i = 0; i < WALK; i++) {
-          const u32 l = (u32)gv[i], h = (u32)(gv[i] >> 32);
-          const u32 f = l >> 30;
-          open = open && !done && (f != 0);
-          if (open) {
-            p0 += l & 0x3FFFFFFFu; p1 += h & 0x3FFFFFFFu;
-            if (f == 2) done = true;
-            used++;
-          }
-        }
-        wt -= (used <= wt) ? used : wt;
-        if (used == 0) {
-          if (++spins > RS_SPIN_LIMIT) { atomicExch(error_flag, 1u); done = true; }
-          else __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      if (tile != 0) status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
-      s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0;
-      s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1;
-    }
-    __syncthreads();                                      // (E)
-    // the next tile's k-mers travel behind the write-out and the top of the next iteration; the other workgroup of the CU has
-    // the rest of the latency (one fetch site, nothing carried across the look-back: 64 VGPRs without spills)
-    if (next < total_tiles) fetch(nkb, nnv);
-
-    // ---- write-out by digit: wave w owns digits 32w .. 32w+31; lane l < 32 holds digit 32w+l's run ----
-    {
-      u32 bs = 0, bc = 0, bgl = 0, bgh = 0;
-      if (lane < 32u) {
-        const u32 d = w * 32u + lane;
-        const u64 g = s_gbase[d];
-        bs = s_dbase[d]; bc = s_hist[d]; bgl = (u32)g; bgh = (u32)(g >> 32);
-      }
-#pragma unroll 2
-      for (int b = 0; b < 32; b++) {                        // (128 scalars at once do not fit)
-        const u32 st_ = (u32)__builtin_amdgcn_readlane((int)bs, b), c = (u32)__builtin_amdgcn_readlane((int)bc, b);
-        const u64 g = (u64)(u32)__builtin_amdgcn_readlane((int)bgl, b) | ((u64)(u32)__builtin_amdgcn_readlane((int)bgh, b) << 32);
-#pragma unroll 1
-        for (u32 o = lane; o < c; o += 64u) out[g + (u64)o] = s_words[st_ + o];      // (one trip unless a digit holds > 64 of the tile's keys)
-      }
-    }
-    __syncthreads();                                      // (F)
-    tile = next; nv = nnv;
-  }
-  __syncthreads();
-  if (tid0 < (u32)R) { const u32 c = s_h2[tid0]; if (c) atomicAdd(&ex.ghist2[tid0], (u64)c); }
-}
-
-// ---- chunk-local first grouping pass (no look-back) -----------------------------------------------------------------
-// The file a session's own partition wrote is a concatenation of CHUNKS: workgroup w of kmer_partition_kernel leaves its
-// k-mers of file f as one contiguous run, the runs lie in workgroup order, and kmer_hist_fine_kernel -- one workgroup per
-// KH_NV partition workgroups -- has counted exactly those k-mers by (file, next nine bits).  So for every (chunk, digit)
-// the number of k-mers is known BEFORE the pass runs (fine_rows, turned into exclusive prefixes over the chunks by
-// fine_rows_scan_kernel): a workgroup that takes one chunk owns a private cursor per digit for the whole chunk and never
-// has to ask another workgroup anything -- no tickets, no status granules, no look-back (19 K of the look-back kernel's
-// 39 K cycles per tile).  Per tile: rank with one returning LDS atomic per key, scan of the 512 counts,
-// exchange through LDS, contiguous runs out at the cursors, cursors advance.  The next tile's keys are fetched behind the
-// write-out.  NARROW / HIST2 as in radix_group_kernel.  Replaces the same reference code (unpackSuffixes + std::sort,
-// merylCountArray.C:276-289,330 -- top bits only).
 struct NarrowPrep { unsigned char bits_a[64]; unsigned char on[64]; };   // per file: bits of its first (high) digit, narrowed at all
-
-struct LocalArgs {
-  const u32 *rows;            // [n_chunks][1 << 15] exclusive prefixes over the chunks (fine_rows_scan_kernel)
-  const u64 *block_base;      // kmer_scan_kernel's cursors: [vgrid][64], absolute key index of partition workgroup g's run of file f
-  u32 vgrid, per_chunk;       // partition workgroups, and how many of them make a chunk (KH_NV)
-  u32 file;                   // f
-  u32 span_shift;             // 9 - digit bits: the digit's first fine column is d << span_shift
-  u64 file_start;             // absolute key index of the file's first k-mer
-  u32 dbg;                    // MGC_LOCAL_DBG (measurements only, WRONG results): 1 no global writes, 2 no ranking / exchange (straight copy), 4 no HIST2
-};
-
-template <typename K, int RB, int BLOCK, int KPT, bool NARROW, bool HIST2, bool PREF = false>
-__global__ __launch_bounds__(BLOCK, (GroupSmem<K, RB, BLOCK, KPT>::MIN_WAVES_PER_SIMD))
-void radix_group_local_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::type *__restrict__ out, u64 n, u32 shift, u32 dmask,
-                              const u64 *__restrict__ gbase, LocalArgs la, GroupExtra ex) {
-  using SM = GroupSmem<K, RB, BLOCK, KPT>;
-  using KO = KeyOps<K>;
-  constexpr int R = SM::R, TILE = SM::TILE;
-  static_assert(BLOCK >= R && TILE <= 65536, "one thread per digit; 16-bit ranks");
-  __shared__ u32 s_h2[HIST2 ? RS_MAX_RADIX : 1];
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  K   *s_keys  = reinterpret_cast<K *>(smem);
-  u32 *s_hist  = reinterpret_cast<u32 *>(smem + SM::OFF_HIST);
-  u64 *s_gbase = reinterpret_cast<u64 *>(smem + SM::OFF_GBASE);
-  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
-  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
-  const u32 tid0 = threadIdx.x;
-  u32 tid = tid0, lane = tid0 & 63u, w = tid0 >> 6;
-  const u32 digit_bits = ex.digit_bits;
-  if (HIST2) { for (u32 i = tid; i < (u32)RS_MAX_RADIX; i += BLOCK) s_h2[i] = 0; }
-
-  // the chunk's key range inside the file, this thread's digit cursor
-  const u32 c = blockIdx.x, g0 = c * la.per_chunk, g1 = g0 + la.per_chunk;
-  const u64 cs = (g0 < la.vgrid) ? la.block_base[(u64)g0 * 64 + la.file] - la.file_start : n;
-  const u64 ce = (g1 < la.vgrid) ? la.block_base[(u64)g1 * 64 + la.file] - la.file_start : n;
-  u64 cursor = 0;
-  if (tid < (u32)R && tid <= dmask)
-    cursor = gbase[tid] + (u64)la.rows[((u64)c << 15) + ((u64)la.file << 9) + ((u64)tid << la.span_shift)];
-
-  constexpr int VEC = (sizeof(K) < 16 && KPT % (16 / sizeof(K)) == 0) ? (int)(16 / sizeof(K)) : 1;
-  struct __attribute__((aligned(4))) KVec { K v[VEC]; };
-  auto idx_of = [&](int j) __attribute__((always_inline)) -> u32 {
-    return w * (u32)(64 * KPT) + ((u32)(j / VEC) * 64u + lane) * (u32)VEC + (u32)(j % VEC);
-  };
-  K keys[KPT], knext[PREF ? KPT : 1];
-  auto fetch_into = [&](K *dst, u64 kb, u32 nv) __attribute__((always_inline)) {
-    const K *base = in + kb;
-#pragma unroll
-    for (int g = 0; g < KPT / VEC; g++) {
-      const u32 first = idx_of(g * VEC);
-      if (nv == (u32)TILE || first + (u32)VEC <= nv) {
-        const KVec q = *reinterpret_cast<const KVec *>(base + first);
-#pragma unroll
-        for (int cc = 0; cc < VEC; cc++) dst[g * VEC + cc] = q.v[cc];
-      } else {
-#pragma unroll
-        for (int cc = 0; cc < VEC; cc++) if (first + (u32)cc < nv) dst[g * VEC + cc] = base[first + cc];
-      }
-    }
-  };
-  auto fetch = [&](u64 kb, u32 nv) __attribute__((always_inline)) { fetch_into(keys, kb, nv); };
-
-  u64 kb = cs;
-  u32 nv = (ce > kb) ? (u32)((ce - kb < (u64)TILE) ? ce - kb : (u64)TILE) : 0u;
-  if (nv) fetch(kb, nv);
-  while (nv) {
-    tid = tid0;
-    asm volatile("" : "+v"(tid));                         // keeps the unrolled body's LDS addresses out of the loop preheader
-    lane = tid & 63u; w = tid >> 6;
-    const u64 nkb = kb + (u64)TILE;
-    const u32 nnv = (ce > nkb) ? (u32)((ce - nkb < (u64)TILE) ? ce - nkb : (u64)TILE) : 0u;
-    // PREF: the next tile's keys travel into a second set of registers behind the WHOLE of this tile's work -- fetching a
-    // tile takes as long as ranking, exchanging and writing one (r03a: the look-back was never the bound, the fetch was)
-    if constexpr (PREF) { if (nnv) fetch_into(knext, nkb, nnv); }
-    if (la.dbg & 2u) {                                    // measurement: what a straight 8 -> 4 byte copy of the chunk costs
-#pragma unroll
-      for (int j = 0; j < KPT; j++)
-        if (idx_of(j) < nv) out[cs + (kb - cs) + idx_of(j)] = (typename GroupOut<K, NARROW>::type)keys[j];
-      if constexpr (PREF) {
-#pragma unroll
-        for (int j = 0; j < KPT; j++) keys[j] = knext[j];
-      } else { if (nnv) fetch(nkb, nnv); }
-      kb = nkb; nv = nnv;
-      continue;
-    }
-    if (tid < (u32)R) s_hist[tid] = 0;
-    __syncthreads();                                      // (A)
-    u32 ranks[KPT / 2];
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      u32 r = 0;
-      if (idx_of(j) < nv) {
-        r = atomicAdd(&s_hist[KO::digit(keys[j], shift, dmask)], 1u);
-      }
-      if (j & 1) ranks[j / 2] |= r << 16;
-      else       ranks[j / 2]  = r;
-    }
-    __syncthreads();                                      // (B)
-    const u32 count = (tid < (u32)R) ? s_hist[tid] : 0u;
-    u32 tile_total;
-    const u32 excl = block_excl_scan<BLOCK, u32>(count, s_tmp, &tile_total);
-    if (tid < (u32)R) { s_dbase[tid] = excl; s_gbase[tid] = cursor - (u64)excl; cursor += (u64)count; }
-    __syncthreads();                                      // (C)
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      if (idx_of(j) < nv) {
-        const u32 d = KO::digit(keys[j], shift, dmask);
-        const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
-        s_keys[s_dbase[d] + r] = keys[j];
-      }
-    }
-    __syncthreads();                                      // (D) keys live in LDS only: the registers take the next tile
-    if constexpr (!PREF) { if (nnv) fetch(nkb, nnv); }
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      const u32 i = (u32)j * BLOCK + tid;
-      if (i < nv) {
-        const K   key = s_keys[i];
-        const u32 d   = KO::digit(key, shift, dmask);
-        if constexpr (HIST2) { if (!(la.dbg & 4u)) atomicAdd(&s_h2[KO::digit(key, ex.shift2, ex.mask2)], 1u); }
-        if (la.dbg & 1u) continue;
-        if constexpr (NARROW) out[s_gbase[d] + (u64)i] = (u32)(((key >> (shift + digit_bits)) << shift) | (key & ((1ull << shift) - 1ull)));
-        else                  out[s_gbase[d] + (u64)i] = key;
-      }
-    }
-    __syncthreads();                                      // (F) s_keys / s_gbase are rewritten by the next iteration
-    if constexpr (PREF) {
-#pragma unroll
-      for (int j = 0; j < KPT; j++) keys[j] = knext[j];
-    }
-    kb = nkb; nv = nnv;
-  }
-  if constexpr (HIST2) {
-    __syncthreads();
-    for (u32 i = tid; i < (u32)RS_MAX_RADIX; i += BLOCK) { const u32 cnt2 = s_h2[i]; if (cnt2) atomicAdd(&ex.ghist2[i], (u64)cnt2); }
-  }
-}
-
-// ---- chunk-local first pass of a file in the 5-byte layout with WRITE COMBINING (round 4; measured slower, MGC_SOA_WC=1) ----
-// MEASURED (profiles/r04ab_soa_wc_ab.txt): bit-exact, and 0.557 ms per 135 M k-mers against the look-back kernel's 0.541 on one box,
-// 0.579 against 0.556 on another (write-out one digit after the other, then eight digits' LDS reads in flight together: the same) --
-// every store a whole line, and no faster: the partial lines are not what holds the real pass at the micro-benchmark's
-// odd-start time.  Off.
-// scripts/ubench/scatter.hip: a pass's access pattern with no compute runs at 0.340 ms per 135 M k-mers when every run starts
-// on a 128-byte line and at 0.535 ms when runs start anywhere -- where the look-back pass (0.54 ms) sits.  A run starts
-// anywhere because a digit's cursor is wherever the previous tile left it.  This kernel makes every store a whole line:
-// a workgroup owns a CHUNK of the file (radix_group_local_kernel's private cursors: no tickets, no look-back), and the words
-// of a digit that do not fill a line wait in LDS (at most 31 per digit, 512 x 32 words = 64 KiB) for the chunk's next tile.
-// That fits beside the tile only because the exchange holds the NARROWED 32-bit words (64 KiB per 16384-key tile, as in
-// radix_group5_kernel), and the write-out goes by digit: wave w owns digits 32w .. 32w+31 (lane l < 32 keeps digit 32w+l's
-// cursor, pending count, tile count and exchange offset in registers), per digit one store of the whole lines that are now
-// complete -- pending words first, then the tile's -- and one LDS move of the rest.  Only a chunk's first line and its last
-// one per digit are partial.  Same output, HIST2 and reference code restated as radix_group_kernel (unpackSuffixes + std::sort,
-// merylCountArray.C:276-289,330 -- top bits only).
-// <KPT, LINE, MINW>: <16, 32, 4> is the kernel measured above (16384-key tiles, whole 128-byte lines, one workgroup per CU);
-// <8, 16, 8> = 8192-key tiles and pending HALF lines (512 x 16 words = 32 KiB): 72 KiB per workgroup, TWO per CU, every store an
-// aligned 64-byte half line (MGC_SOA_WC=2; 60 VGPRs, no scratch).  Bit-exact, and MEASURED with the round's last GPU seconds
-// (profiles/r04ad_soa_wc2.txt): 0.80 ms per launch of 135 M k-mers against 0.54 - 0.56.  Not analysed (no budget left); the one
-// difference to the micro-benchmark's 0.409 ms for aligned 64-byte runs that stands out: there the two halves of a line arrive
-// back to back, here one 8192-key tile apart.  Off.
-template <int KPT_, int LINE_>
-struct Group5WcSmem {
-  static constexpr int R = 512, BLOCK = 1024, KPT = KPT_, TILE = BLOCK * KPT, LINE = LINE_;
-  static constexpr size_t OFF_CARRY = (size_t)TILE * 4;                       // u32[R * LINE]  pending words of every digit
-  static constexpr size_t OFF_HIST  = OFF_CARRY + (size_t)R * LINE * 4;      // u32[R]
-  static constexpr size_t OFF_DBASE = OFF_HIST + (size_t)R * 4;              // u32[R]
-  static constexpr size_t OFF_H2    = OFF_DBASE + (size_t)R * 4;             // u32[R]
-  static constexpr size_t OFF_TMP   = OFF_H2 + (size_t)R * 4;                // u32[64]
-  static constexpr size_t BYTES     = OFF_TMP + 64 * 4;
-  static_assert(BYTES <= 160 * 1024, "one workgroup per CU at least");
-};
-
-template <int KPT_, int LINE_, int MINW>
-__global__ __launch_bounds__(1024, MINW)
-void radix_group5wc_kernel(const u32 *__restrict__ in_lo, const uint8_t *__restrict__ in_hi, u32 *__restrict__ out, u64 n, u32 shift,
-                           u32 dmask, const u64 *__restrict__ gbase, LocalArgs la, GroupExtra ex) {
-  using SM = Group5WcSmem<KPT_, LINE_>;
-  static_assert(MINW == 4 || 2 * SM::BYTES <= 160 * 1024, "two workgroups per CU");
-  constexpr int R = SM::R, BLOCK = SM::BLOCK, KPT = SM::KPT, TILE = SM::TILE, LINE = SM::LINE;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32 *s_words = reinterpret_cast<u32 *>(smem);                 // (s_words[TILE + 32 d + i] = pending word i of digit d)
-  u32 *s_hist  = reinterpret_cast<u32 *>(smem + SM::OFF_HIST);
-  u32 *s_dbase = reinterpret_cast<u32 *>(smem + SM::OFF_DBASE);
-  u32 *s_h2    = reinterpret_cast<u32 *>(smem + SM::OFF_H2);
-  u32 *s_tmp   = reinterpret_cast<u32 *>(smem + SM::OFF_TMP);
-  const u32 tid0 = threadIdx.x;
-  u32 tid = tid0, lane = tid0 & 63u, w = tid0 >> 6;
-  if (tid0 < (u32)R) s_h2[tid0] = 0;
-  const u32 hm = ex.soa_hi_mask;
-  const u32 wmask = shift >= 32u ? 0xFFFFFFFFu : ((1u << shift) - 1u);
-
-  // the chunk's key range inside the file; the digit this thread owns (lanes 0..31 of wave w: digit 32w + lane) and its cursor
-  const u32 c = blockIdx.x, g0 = c * la.per_chunk, g1 = g0 + la.per_chunk;
-  const u64 cs = (g0 < la.vgrid) ? la.block_base[(u64)g0 * 64 + la.file] - la.file_start : n;
-  const u64 ce = (g1 < la.vgrid) ? la.block_base[(u64)g1 * 64 + la.file] - la.file_start : n;
-  const bool own = (tid0 & 63u) < 32u;
-  const u32 d_own = (tid0 >> 6) * 32u + (tid0 & 31u);
-  u32 cur = 0, pend = 0;                                        // where the digit's next word goes (file-relative), words waiting in LDS
-  if (own && d_own <= dmask)
-    cur = (u32)gbase[d_own] + la.rows[((u64)c << 15) + ((u64)la.file << 9) + ((u64)d_own << la.span_shift)];
-
-  auto idx_of = [&](int j) __attribute__((always_inline)) -> u32 {
-    return w * (u32)(64 * KPT) + ((u32)(j / 4) * 64u + lane) * 4u + (u32)(j % 4);
-  };
-  u32 lo[KPT], hi4[KPT / 4];
-  struct __attribute__((aligned(4))) LVec { u32 v[4]; };
-  struct __attribute__((packed, aligned(1))) HWord { u32 v; };
-  auto fetch = [&](u64 kb, u32 nv) __attribute__((always_inline)) {      // (a group that starts inside the tile is loaded whole: radix_group5_kernel)
-    const u32 *lo32 = in_lo + kb;
-    const uint8_t *hi8 = in_hi + kb;
-#pragma unroll
-    for (int g = 0; g < KPT / 4; g++) {
-      const u32 first = idx_of(g * 4);
-      if (first < nv) {
-        const LVec l = *reinterpret_cast<const LVec *>(lo32 + first);
-        hi4[g] = reinterpret_cast<const HWord *>(hi8 + first)->v;
-#pragma unroll
-        for (int cc = 0; cc < 4; cc++) lo[g * 4 + cc] = l.v[cc];
-      }
-    }
-  };
-  auto digit_of = [&](int j) __attribute__((always_inline)) -> u32 {
-    const u64 key = (u64)lo[j] | ((u64)((hi4[j / 4] >> (8 * (j % 4))) & hm) << 32);
-    return (u32)(key >> shift) & dmask;
-  };
-
-  u64 kb = cs;
-  u32 nv = (ce > kb) ? (u32)((ce - kb < (u64)TILE) ? ce - kb : (u64)TILE) : 0u;
-  if (nv) fetch(kb, nv);
-  while (nv) {
-    tid = tid0;
-    asm volatile("" : "+v"(tid));                         // keeps the unrolled body's LDS addresses out of the loop preheader
-    lane = tid & 63u; w = tid >> 6;
-    const u64 nkb = kb + (u64)TILE;
-    const u32 nnv = (ce > nkb) ? (u32)((ce - nkb < (u64)TILE) ? ce - nkb : (u64)TILE) : 0u;
-    if (tid < (u32)R) s_hist[tid] = 0;
-    __syncthreads();                                      // (A)
-
-    u32 ranks[KPT / 2];
-    if (nv == (u32)TILE) {
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        const u32 r = atomicAdd(&s_hist[digit_of(j)], 1u);
-        if (j & 1) ranks[j / 2] |= r << 16;
-        else       ranks[j / 2]  = r;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        u32 r = 0;
-        if (idx_of(j) < nv) r = atomicAdd(&s_hist[digit_of(j)], 1u);
-        if (j & 1) ranks[j / 2] |= r << 16;
-        else       ranks[j / 2]  = r;
-      }
-    }
-    __syncthreads();                                      // (B)
-
-    const u32 cnt = own ? s_hist[d_own] : 0u;             // (threads in digit order: the scan over the threads is the scan over the digits)
-    u32 tile_total;
-    const u32 excl = block_excl_scan<BLOCK, u32>(cnt, s_tmp, &tile_total);
-    if (own) s_dbase[d_own] = excl;
-    __syncthreads();                                      // (C)
-
-    // exchange: the narrowed word to its digit's run; the other digit (the second pass's) is counted from the registers
-    if (nv == (u32)TILE) {
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
-        const u32 word = lo[j] & wmask;
-        s_words[s_dbase[digit_of(j)] + r] = word;
-        atomicAdd(&s_h2[(word >> ex.shift2) & ex.mask2], 1u);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        if (idx_of(j) < nv) {
-          const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
-          const u32 word = lo[j] & wmask;
-          s_words[s_dbase[digit_of(j)] + r] = word;
-          atomicAdd(&s_h2[(word >> ex.shift2) & ex.mask2], 1u);
-        }
-      }
-    }
-    __syncthreads();                                      // (D) the tile's words live in LDS only: the registers take the next tile
-    if (nnv) fetch(nkb, nnv);
-
-    // ---- write-out by digit: whole lines only.  Eight digits at a time: their LDS reads in flight together, then their
-    // stores, then the reads and the writes of what stays behind (one digit after the other the wave sat out two LDS round
-    // trips per digit: r04ab) ----
-    {
-      const u32 ws = (u32)__builtin_amdgcn_readfirstlane((int)w);
-#pragma unroll 1
-      for (int g8 = 0; g8 < 32; g8 += 8) {
-        u32 P[8], CC[8], NW[8], REM[8], FP[8], FT[8], TOT[8], val[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const int b = g8 + i;
-          P[i]  = (u32)__builtin_amdgcn_readlane((int)cur, b);  CC[i] = (u32)__builtin_amdgcn_readlane((int)pend, b);
-          const u32 C = (u32)__builtin_amdgcn_readlane((int)cnt, b), ST = (u32)__builtin_amdgcn_readlane((int)excl, b);
-          TOT[i] = CC[i] + C;
-          const u32 end = P[i] + TOT[i], aend = end & ~(u32)(LINE - 1);
-          NW[i]  = (aend > P[i]) ? aend - P[i] : 0u;      // words that leave now: up to the last line boundary the digit has reached
-          REM[i] = TOT[i] - NW[i];                        // < LINE: what waits for the next tile
-          FP[i]  = (u32)TILE + (ws * 32u + (u32)b) * (u32)LINE;   // word o of the digit's queue: pending ones first, then the tile's
-          FT[i]  = ST - CC[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {                     // (a lane beyond the queue reads its first word: always a valid address)
-          const u32 o = (lane < TOT[i]) ? lane : 0u;
-          val[i] = s_words[o + ((o < CC[i]) ? FP[i] : FT[i])];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          if (lane < NW[i]) out[(u64)P[i] + lane] = val[i];
-          if (NW[i] > 64u) {                              // (a digit with more than 64 of the tile's keys: the rest of its lines)
-#pragma unroll 1
-            for (u32 o0 = 64u; o0 < NW[i]; o0 += 64u) {
-              const u32 o = o0 + lane;
-              if (o < NW[i]) out[(u64)P[i] + o] = s_words[o + ((o < CC[i]) ? FP[i] : FT[i])];
-            }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const u32 o = NW[i] + ((lane < REM[i]) ? lane : 0u);
-          const u32 oo = (o < TOT[i]) ? o : 0u;
-          val[i] = s_words[oo + ((oo < CC[i]) ? FP[i] : FT[i])];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          if (lane < REM[i]) s_words[FP[i] + lane] = val[i];
-          if (lane == (u32)(g8 + i)) { cur = P[i] + NW[i]; pend = REM[i]; }
-        }
-      }
-    }
-    __syncthreads();                                      // (F)
-    kb = nkb; nv = nnv;
-  }
-  // the chunk's last words of every digit: one partial line each
-  {
-    const u32 ws = (u32)__builtin_amdgcn_readfirstlane((int)(tid0 >> 6));
-    const u32 l = tid0 & 63u;
-#pragma unroll 1
-    for (int b = 0; b < 32; b++) {
-      const u32 P = (u32)__builtin_amdgcn_readlane((int)cur, b), CC = (u32)__builtin_amdgcn_readlane((int)pend, b);
-      if (l < CC) out[(u64)P + l] = s_words[(u32)TILE + (ws * 32u + (u32)b) * (u32)LINE + l];
-    }
-  }
-  __syncthreads();
-  if (tid0 < (u32)R) { const u32 c2 = s_h2[tid0]; if (c2) atomicAdd(&ex.ghist2[tid0], (u64)c2); }
-}
-
-// fine_rows[chunk][file << 9 | nine bits] (k-mer counts per chunk, kmer_hist_fine_kernel) -> for every file that is `on`,
-// at the first fine column of each of its 2^bits_a[f] digits: the k-mers of that (file, digit) in the chunks BEFORE this one.
-__global__ __launch_bounds__(256)
-void fine_rows_scan_kernel(u32 *__restrict__ rows, u32 n_chunks, NarrowPrep prep) {
-  const u32 col = blockIdx.x * 256u + threadIdx.x;       // 0 .. 2^15
-  const u32 f = col >> 9;
-  if (!prep.on[f]) return;
-  const u32 span = 1u << (9u - prep.bits_a[f]);
-  if (col & (span - 1u)) return;
-  u32 acc = 0;
-  for (u32 b0 = 0; b0 < n_chunks; b0 += 8) {
-    u32 v[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      v[q] = 0;
-      if (b0 + q < n_chunks) for (u32 i = 0; i < span; i++) v[q] += rows[((u64)(b0 + q) << 15) + col + i];
-    }
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      if (b0 + q < n_chunks) { rows[((u64)(b0 + q) << 15) + col] = acc; acc += v[q]; }
-    }
-  }
-}
-
-// ---- classic mode: per-tile digit histogram + row scan ----------------------
-template <typename K, int RB, int BLOCK, int KPT>
-__global__ __launch_bounds__(BLOCK)
-void radix_tile_hist_kernel(const K *__restrict__ in, u64 n, u32 shift, u32 dmask, u32 *__restrict__ tile_hist,
-                            u64 num_tiles) {
-  constexpr int R = 1 << RB, TILE = BLOCK * KPT;
-  __shared__ u32 s_h[R];
-  const u32 tid = threadIdx.x;
-  for (u32 i = tid; i < (u32)R; i += BLOCK) s_h[i] = 0;
-  __syncthreads();
-  const u64 tile_base = (u64)blockIdx.x * TILE;
-#pragma unroll
-  for (int j = 0; j < KPT; j++) {
-    const u64 idx = tile_base + (u64)j * BLOCK + tid;
-    if (idx < n) atomicAdd(&s_h[KeyOps<K>::digit(in[idx], shift, dmask)], 1u);
-  }
-  __syncthreads();
-  for (u32 i = tid; i < (u32)R; i += BLOCK) tile_hist[(u64)i * num_tiles + blockIdx.x] = s_h[i];
-}
-
-// One workgroup per digit: exclusive scan of its row of tile counts (-> u64),
-// and the row total.
-__global__ __launch_bounds__(1024)
-void radix_row_scan_kernel(const u32 *__restrict__ tile_hist, u64 *__restrict__ tile_offs, u64 *__restrict__ row_total,
-                           u64 num_tiles) {
-  __shared__ u64 s_tmp[1024 / 64 + 1];
-  const u64 row = (u64)blockIdx.x * num_tiles;
-  u64 carry = 0;
-  for (u64 c = 0; c < num_tiles; c += 1024) {
-    const u64 t = c + threadIdx.x;
-    const u64 v = (t < num_tiles) ? (u64)tile_hist[row + t] : 0ull;
-    u64 tot;
-    const u64 e = block_excl_scan<1024, u64>(v, s_tmp, &tot);
-    if (t < num_tiles) tile_offs[row + t] = carry + e;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
-}
-
-// Adds the exclusive digit base (scan of row totals) to every row.
-__global__ __launch_bounds__(256)
-void radix_row_add_kernel(u64 *__restrict__ tile_offs, const u64 *__restrict__ row_total, u32 R, u64 num_tiles) {
-  __shared__ u64 s_part[4];
-  const u32 d = blockIdx.y;
-  u64 part = 0;
-  for (u32 i = threadIdx.x; i < d; i += 256) part += row_total[i];
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) part += __shfl_down(part, o);
-  if (lane_id() == 0) s_part[wave_id()] = part;
-  __syncthreads();
-  const u64 base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-  const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (t < num_tiles) tile_offs[(u64)d * num_tiles + t] += base;
-  (void)R;
-}
 
 // ---- host side ---------------------------------------------------------------
 
@@ -1606,24 +669,16 @@ static int env_int(const char *name, int dflt) {
 
 void make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan) {
   memset(plan, 0, sizeof(*plan));
-  // defaults = the fastest measured combination on MI355X (profiles/r01 notes in DESIGN.md):
-  // 9-bit digits, one 1024-thread workgroup per CU with 16 keys per thread (16384-key tiles),
-  // LDS-mask ranking, window look-back after the exchange
-  int rb    = env_int("MGC_RADIX_BITS", 9);
-  int mode  = env_int("MGC_SORT_MODE", 0);
-  int kpt   = env_int("MGC_SORT_KPT", 16);
-  int block = env_int("MGC_SORT_BLOCK", 1024);
-  if (rb != 8 && rb != 9) rb = 8;
-  if (kpt != 8 && kpt != 16) kpt = 16;
-  if (block != 512 && block != 1024) block = 512;
-  plan->radix_bits = (uint32_t)rb;
-  plan->block      = (uint32_t)block;
-  plan->kpt        = (uint32_t)kpt;
+  // the fastest measured combination on MI355X (profiles/r01*, DESIGN_HISTORY.md): nine-bit digits, one 1024-thread workgroup
+  // per CU with 16 keys per thread (8 for 16-byte keys), LDS-mask ranking, window look-back after the exchange.  The other
+  // shapes (eight-bit digits, 512-thread workgroups, ballot ranking, serial and pipelined look-back, the classic
+  // histogram / scan / scatter form) were measured in rounds 1-2 and removed in round 5.
+  plan->radix_bits = 9;
+  plan->block      = 1024;
+  plan->kpt        = 16;
   plan->tile       = plan->block * plan->kpt;
-  plan->mode       = (mode == 1 || mode == 3) ? (uint32_t)mode : 0u;   // 0 look-back, 1 classic, 3 grouping (finish path only)
-  plan->match      = env_int("MGC_SORT_MATCH", 1) ? 1u : 0u;
-  { const int lb = env_int("MGC_SORT_LB", 2); plan->lookback = (lb == 2 || lb == 5) ? (uint32_t)lb : 1u; }
-  plan->flags      = (uint32_t)env_int("MGC_SORT_FLAGS", 0);
+  plan->mode       = (env_int("MGC_SORT_MODE", 0) == 3) ? 3u : 0u;     // 0 stable sort, 3 grouping passes (tests reach them through the bare operator)
+  const uint32_t rb = plan->radix_bits;
   const uint32_t nbits = (end_bit > begin_bit) ? end_bit - begin_bit : 0;
   uint32_t passes = (nbits + rb - 1) / rb;
   if (passes > RS_MAX_PASSES) passes = RS_MAX_PASSES;
@@ -1686,42 +741,29 @@ static hipError_t group_prepare(const K *src, uint64_t n, const SortPlan &plan, 
   return hipGetLastError();
 }
 
-template <typename K, int RB, int BLOCK, int KPT, int MATCH, int LBK>
+// LB 2: packed granules (n < 2^30); LB 3: wide granules
+template <typename K, int KPT, int LB>
 static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws,
-                             uint32_t *d_error, int *result_in_alt, hipStream_t st, hipEvent_t *pass_events,
-                             void *d_prepared = nullptr) {
-  constexpr int LBO = (LBK == 5) ? 2 : LBK;             // look-back flavour of the non-pipelined kernel
-  using SM  = RadixSmem<K, RB, BLOCK, KPT, LBO>;
-  using SM0 = RadixSmem<K, RB, BLOCK, KPT, 0>;
+                             uint32_t *d_error, int *result_in_alt, hipStream_t st, hipEvent_t *pass_events) {
+  constexpr int RB = 9, BLOCK = 1024;
+  using SM = RadixSmem<K, RB, BLOCK, KPT, LB>;
   constexpr int R = 1 << RB, TILE = BLOCK * KPT;
-  // the grouping passes can take their digit histograms from a header prepared ahead of time (launch_group_prepare)
-  SortHeader *hdr = (d_prepared && plan.mode == 3) ? reinterpret_cast<SortHeader *>(d_prepared) : reinterpret_cast<SortHeader *>(d_ws);
+  SortHeader *hdr = reinterpret_cast<SortHeader *>(d_ws);
   unsigned char *body = reinterpret_cast<unsigned char *>(d_ws) + ((sizeof(SortHeader) + 255) / 256) * 256;
   const uint64_t num_tiles = (n + TILE - 1) / TILE;
 
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<K, RB, BLOCK, KPT, LBO, MATCH>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::BYTES);
-    if constexpr (LBK == 5)
-    {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)RadixSmem<K, RB, BLOCK, KPT, 4>::BYTES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)RadixSmem<K, RB, BLOCK, KPT, 4>::BYTES);
-    }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<K, RB, BLOCK, KPT, 0, MATCH>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM0::BYTES);
-    attr_done = true;
-  }
-
   K *src = reinterpret_cast<K *>(d_keys), *dst = reinterpret_cast<K *>(d_alt);
   int in_alt = 0;
-  const bool lookback = (plan.mode == 0);
 
-  if (lookback) {
+  if (plan.mode != 3) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_scatter_kernel<K, RB, BLOCK, KPT, LB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::BYTES);
+      attr_done = true;
+    }
     u64 *status = reinterpret_cast<u64 *>(body);
-    const size_t status_bytes = (size_t)num_tiles * (LBO == 3 ? R : R / 2) * sizeof(u64);
+    const size_t status_bytes = (size_t)num_tiles * (LB == 3 ? R : R / 2) * sizeof(u64);
     MGC_CHECK(hipMemsetAsync(hdr, 0, sizeof(SortHeader), st));
     PassList pl;
     pl.n = plan.num_passes;
@@ -1737,36 +779,19 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
     for (uint32_t p = 0; p < plan.num_passes; p++) {
       MGC_CHECK(hipMemsetAsync(status, 0, status_bytes, st));
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
-      if constexpr (LBK == 5) {
-        using SMP = RadixSmem<K, RB, BLOCK, KPT, 4>;
-        const uint64_t resident = (uint64_t)device_cu_count() * SMP::WG_PER_CU;
-        const uint32_t pgrid = (uint32_t)(num_tiles < resident ? num_tiles : resident);
-        if (plan.dbg)
-          hipLaunchKernelGGL((radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, true>), dim3(pgrid), dim3(BLOCK), SMP::BYTES, st,
-                             (const K *)src, dst, (u64)n, plan.pass_shift[p], plan_mask(plan, p),
-                             &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
-        else
-          hipLaunchKernelGGL((radix_scatter_pipe_kernel<K, RB, BLOCK, KPT, false>), dim3(pgrid), dim3(BLOCK), SMP::BYTES, st,
-                             (const K *)src, dst, (u64)n, plan.pass_shift[p], plan_mask(plan, p),
-                             &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, (u64 *)nullptr);
-      } else {
-        hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, LBO, MATCH>), dim3((uint32_t)num_tiles),
-                           dim3(BLOCK), SM::BYTES, st, (const K *)src, dst, (u64)n, plan.pass_shift[p],
-                           plan_mask(plan, p), &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, plan.flags,
-                           (const u64 *)nullptr, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
-      }
+      hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, LB>), dim3((uint32_t)num_tiles),
+                         dim3(BLOCK), SM::BYTES, st, (const K *)src, dst, (u64)n, plan.pass_shift[p],
+                         plan_mask(plan, p), &hdr->gbase[p][0], status, &hdr->ticket[p], d_error);
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
       K *t = src; src = dst; dst = t; in_alt ^= 1;
     }
-  } else if (plan.mode == 3) {
+  } else {
     // ---- grouping passes (finish path): see radix_group_kernel ----
     using GS = GroupSmem<K, RB, BLOCK, KPT>;
     static bool gattr_done = false;
     if (!gattr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES);
       gattr_done = true;
     }
@@ -1775,7 +800,7 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
     const size_t status_bytes = (size_t)max_tiles * (R / 2) * sizeof(u64);
     u64 *region_start = reinterpret_cast<u64 *>(body + ((status_bytes + 255) / 256) * 256);
     u32 *region_tiles = reinterpret_cast<u32 *>(region_start + RS_MAX_RADIX + 1);
-    if (!d_prepared) MGC_CHECK(group_prepare<K>((const K *)src, n, plan, hdr, st));
+    MGC_CHECK(group_prepare<K>((const K *)src, n, plan, hdr, st));
     const uint64_t resident = (uint64_t)device_cu_count() * GS::WG_PER_CU;
     for (uint32_t p = 0; p < plan.num_passes; p++) {
       if (p == 1) {
@@ -1789,38 +814,9 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
       const uint32_t pgrid = (uint32_t)(tiles_bound < resident ? tiles_bound : resident);
       const u64 *rs = (p == 0) ? nullptr : region_start;
       const u32 *rt = (p == 0) ? nullptr : region_tiles;
-      if (plan.dbg)
-        hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, true>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
-                           (const K *)src, dst, (u64)n, plan.pass_shift[p], plan_mask(plan, p),
-                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, GroupExtra{0u, 0u, 0u, nullptr},
-                           reinterpret_cast<u64 *>(plan.dbg));
-      else
-        hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
-                           (const K *)src, dst, (u64)n, plan.pass_shift[p], plan_mask(plan, p),
-                           &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
-      MGC_CHECK(hipGetLastError());
-      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
-      K *t = src; src = dst; dst = t; in_alt ^= 1;
-    }
-  } else {
-    // ---- classic: histogram / scan / scatter per pass ----
-    u32 *tile_hist = reinterpret_cast<u32 *>(body);
-    u64 *tile_offs = reinterpret_cast<u64 *>(body + (((size_t)num_tiles * R * sizeof(u32) + 255) / 256) * 256);
-    for (uint32_t p = 0; p < plan.num_passes; p++) {
-      const uint32_t shift = plan.pass_shift[p], dmask = plan_mask(plan, p);
-      hipLaunchKernelGGL((radix_tile_hist_kernel<K, RB, BLOCK, KPT>), dim3((uint32_t)num_tiles), dim3(BLOCK), 0, st,
-                         (const K *)src, (u64)n, shift, dmask, tile_hist, (u64)num_tiles);
-      MGC_CHECK(hipGetLastError());
-      hipLaunchKernelGGL(radix_row_scan_kernel, dim3(R), dim3(1024), 0, st, tile_hist, tile_offs,
-                         &hdr->row_total[0], (u64)num_tiles);
-      MGC_CHECK(hipGetLastError());
-      hipLaunchKernelGGL(radix_row_add_kernel, dim3((uint32_t)((num_tiles + 255) / 256), R), dim3(256), 0, st,
-                         tile_offs, &hdr->row_total[0], (u32)R, (u64)num_tiles);
-      MGC_CHECK(hipGetLastError());
-      if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p], st));
-      hipLaunchKernelGGL((radix_scatter_kernel<K, RB, BLOCK, KPT, 0, MATCH>), dim3((uint32_t)num_tiles), dim3(BLOCK),
-                         SM0::BYTES, st, (const K *)src, dst, (u64)n, shift, dmask, (const u64 *)nullptr, (u64 *)nullptr,
-                         (u32 *)nullptr, d_error, plan.flags, tile_offs, (u64)num_tiles, reinterpret_cast<u64 *>(plan.dbg));
+      hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false>), dim3(pgrid), dim3(BLOCK), GS::BYTES, st,
+                         (const K *)src, dst, (u64)n, plan.pass_shift[p], plan_mask(plan, p),
+                         &hdr->gbase[p][0], status, &hdr->ticket[p], d_error, (u64)num_tiles, rs, rt, GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
       MGC_CHECK(hipGetLastError());
       if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2 * p + 1], st));
       K *t = src; src = dst; dst = t; in_alt ^= 1;
@@ -1932,28 +928,9 @@ hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsi
 // low digit's histogram is taken by the first pass itself -- nobody reads the keys for a histogram -- and the physical order
 // is (low digit : high digit): sub-bucket p holds the k-mers whose top bits are
 // ((p & (2^*tr_a - 1)) << *tr_b) | (p >> *tr_a)  (*tr_a = 0: p itself).
-bool group_local_enabled() {
-  // Measured (profiles/r03a_*, r03b_*): 0.498 ms per 135 M k-mers against the look-back kernel's 0.490 -- the look-back was
-  // never the bound (nor was the exposed fetch: prefetching a whole tile ahead gives 0.485) -- so the default stays the
-  // look-back kernel, which needs no per-chunk histogram rows; MGC_GROUP_LOCAL=1 runs this one.
-  const char *e = getenv("MGC_GROUP_LOCAL");                // read per call: the tests switch it
-  return e && e[0] == '1';
-}
-
-hipError_t launch_fine_rows_scan(uint32_t *d_rows, uint32_t n_chunks, uint32_t nb, const unsigned char *bits_a, const unsigned char *on,
-                                 hipStream_t st) {
-  if (nb > 64) return hipErrorInvalidValue;
-  NarrowPrep prep;
-  memset(&prep, 0, sizeof(prep));
-  memcpy(prep.bits_a, bits_a, nb);
-  memcpy(prep.on, on, nb);
-  hipLaunchKernelGGL(fine_rows_scan_kernel, dim3((1u << 15) / 256u), dim3(256), 0, st, d_rows, n_chunks, prep);
-  return hipGetLastError();
-}
-
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events,
-                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, const GroupLocal *local, uint32_t soa_hi_mask) {
+                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, uint32_t soa_hi_mask) {
   if (!sort_plan_narrows(plan, n, 1) || ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
   constexpr int RB = 9, BLOCK = 1024, KPT0 = 16, KPT1 = 24, R = 1 << RB;
   using GS0 = GroupSmem<u64, RB, BLOCK, KPT0>;
@@ -2017,110 +994,11 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
   }
   if (dbg && dbg_buf) MGC_CHECK(hipMemsetAsync(dbg_buf, 0, 2 * 64 * 8 * sizeof(u64), st));
   if (soa_hi_mask && (!msd || (dbg && dbg_buf))) return hipErrorInvalidValue;   // the 5-byte layout: high digit first
-  if (msd && local && soa_hi_mask) {
-    // chunk-local with write combining (radix_group5wc_kernel): the caller kept the per-chunk histogram rows for it (MGC_SOA_WC=1)
-    if (n >> 32) return hipErrorInvalidValue;
-    using W1 = Group5WcSmem<16, 32>;
-    using W2 = Group5WcSmem<8, 16>;
-    static bool wattr = false;
-    if (!wattr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group5wc_kernel<16, 32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)W1::BYTES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group5wc_kernel<8, 16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)W2::BYTES);
-      wattr = true;
-    }
-    LocalArgs la;
-    la.rows = local->d_rows; la.block_base = reinterpret_cast<const u64 *>(local->d_block_base);
-    la.vgrid = local->vgrid; la.per_chunk = local->per_chunk; la.file = local->file; la.span_shift = 9u - bA;
-    la.file_start = local->file_start; la.dbg = 0;
-    const GroupExtra gx{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask};
-    const char *wce = getenv("MGC_SOA_WC");                 // "2": half lines, 8192-key tiles, two workgroups per CU
-    if (wce && wce[0] == '2')
-      hipLaunchKernelGGL((radix_group5wc_kernel<8, 16, 8>), dim3(local->n_chunks), dim3(BLOCK), W2::BYTES, st,
-                         reinterpret_cast<const u32 *>(d_keys), reinterpret_cast<const uint8_t *>(d_keys) + 4ull * n,
-                         reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u, &hdr->gbase[0][0], la, gx);
-    else
-      hipLaunchKernelGGL((radix_group5wc_kernel<16, 32, 4>), dim3(local->n_chunks), dim3(BLOCK), W1::BYTES, st,
-                         reinterpret_cast<const u32 *>(d_keys), reinterpret_cast<const uint8_t *>(d_keys) + 4ull * n,
-                         reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u, &hdr->gbase[0][0], la, gx);
-  } else
-  if (msd && local && !(dbg && dbg_buf)) {
-    // chunk-local first pass: one workgroup per chunk, private digit cursors, no look-back (radix_group_local_kernel).
-    // MGC_LOCAL_KPT=8: 8192-key tiles, two workgroups per CU (one's LDS phases beside the other's memory phases)
-    using GL8 = GroupSmem<u64, RB, BLOCK, 8>;
-    static bool lattr = false;
-    if (!lattr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_local_kernel<u64, RB, BLOCK, KPT0, true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_local_kernel<u64, RB, BLOCK, 8, true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL8::BYTES);
-      lattr = true;
-    }
-    using GL512 = GroupSmem<u64, RB, 512, 16>;
-    static bool lattr2 = false;
-    if (!lattr2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_local_kernel<u64, RB, BLOCK, KPT0, true, true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_local_kernel<u64, RB, 512, 16, true, true, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL512::BYTES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_local_kernel<u64, RB, 512, 16, true, true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL512::BYTES);
-      lattr2 = true;
-    }
-    // MGC_LOCAL_KPT: 16 (default) one 1024 x 16 workgroup per CU; 8: 1024 x 8, two per CU; 512: 512 x 16, two per CU;
-    // 17 / 513: the same as 16 / 512 with the next tile prefetched into a second register set at the top of the loop
-    static const int lkpt = getenv("MGC_LOCAL_KPT") ? atoi(getenv("MGC_LOCAL_KPT")) : 16;
-    LocalArgs la;
-    la.rows = local->d_rows; la.block_base = reinterpret_cast<const u64 *>(local->d_block_base);
-    la.vgrid = local->vgrid; la.per_chunk = local->per_chunk; la.file = local->file; la.span_shift = 9u - bA;
-    la.file_start = local->file_start;
-    static const uint32_t ldbg = getenv("MGC_LOCAL_DBG") ? (uint32_t)atoi(getenv("MGC_LOCAL_DBG")) : 0u;
-    la.dbg = ldbg;
-    const GroupExtra gx{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0]};
-    if (lkpt == 17)
-      hipLaunchKernelGGL((radix_group_local_kernel<u64, RB, BLOCK, KPT0, true, true, true>), dim3(local->n_chunks), dim3(BLOCK), GS0::BYTES, st,
-                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
-                         &hdr->gbase[0][0], la, gx);
-    else if (lkpt == 512)
-      hipLaunchKernelGGL((radix_group_local_kernel<u64, RB, 512, 16, true, true, false>), dim3(local->n_chunks), dim3(512), GL512::BYTES, st,
-                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
-                         &hdr->gbase[0][0], la, gx);
-    else if (lkpt == 513)
-      hipLaunchKernelGGL((radix_group_local_kernel<u64, RB, 512, 16, true, true, true>), dim3(local->n_chunks), dim3(512), GL512::BYTES, st,
-                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
-                         &hdr->gbase[0][0], la, gx);
-    else if (lkpt == 8)
-      hipLaunchKernelGGL((radix_group_local_kernel<u64, RB, BLOCK, 8, true, true>), dim3(local->n_chunks), dim3(BLOCK), GL8::BYTES, st,
-                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
-                         &hdr->gbase[0][0], la, gx);
-    else
-      hipLaunchKernelGGL((radix_group_local_kernel<u64, RB, BLOCK, KPT0, true, true>), dim3(local->n_chunks), dim3(BLOCK), GS0::BYTES, st,
-                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
-                         &hdr->gbase[0][0], la, gx);
-  } else
   if (dbg && dbg_buf)
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, true, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                        &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
                        GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0]}, dbg_buf);
-  else if (msd && soa_hi_mask && getenv("MGC_SOA_2WG") && getenv("MGC_SOA_2WG")[0] == '1') {   // (read per call: the tests switch it)
-    // two workgroups per CU: the narrowed words go through LDS, not the whole keys (radix_group5_kernel).  MEASURED
-    // (profiles/r04aa_soa2wg_ab.txt, same box, twice each): 0.568 / 0.569 ms per launch of 135 M k-mers against 0.541 / 0.541 for
-    // one workgroup per CU with the register prefetch -- step 120.5 / 120.7 against 118.3 / 118.7 ms -- so it stays OFF.
-    static bool s5attr = false;
-    if (!s5attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)Group5Smem::BYTES);
-      s5attr = true;
-    }
-    static_assert(Group5Smem::TILE == (int)NARROW_TILE0, "narrow_scratch_bytes");
-    const dim3 grid5((uint32_t)std::min(tiles0, cus * 2));
-    hipLaunchKernelGGL(radix_group5_kernel, grid5, dim3(BLOCK), Group5Smem::BYTES, st, reinterpret_cast<const u32 *>(d_keys),
-                       reinterpret_cast<const uint8_t *>(d_keys) + 4ull * n, reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
-                       &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0,
-                       GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask});
-  }
   else if (msd && soa_hi_mask) {
     static bool sattr = false;
     if (!sattr) {
@@ -2296,21 +1174,9 @@ hipError_t launch_group_wide(void *d_keys, void *d_alt, uint64_t n, uint32_t key
 
 size_t sort_header_bytes() { return ((sizeof(SortHeader) + 255) / 256) * 256; }
 
-// true when launch_radix_sort would run this plan as grouping passes (and can therefore use a prepared header)
-bool sort_plan_groups(const SortPlan &plan, uint64_t n) { return plan.mode == 3 && plan.num_passes <= 2 && n < (1ull << 30) && n > 0; }
-
-// The histogram half of a file's grouping passes, launched ahead of time (on another stream): reads every key once
-// (8/16 B per key) -- pure streaming, so it fills the HBM bandwidth the latency-bound grouping passes of the files
-// before it leave idle (one 256-thread workgroup of it fits beside the 1024-thread grouping workgroup on every CU).
-hipError_t launch_group_prepare(const void *d_keys, uint64_t n, uint32_t key_words, const SortPlan &plan, void *d_hdr, hipStream_t st) {
-  if (!sort_plan_groups(plan, n)) return hipErrorInvalidValue;
-  if (key_words == 2) return group_prepare<K128>(reinterpret_cast<const K128 *>(d_keys), n, plan, reinterpret_cast<SortHeader *>(d_hdr), st);
-  return group_prepare<u64>(reinterpret_cast<const u64 *>(d_keys), n, plan, reinterpret_cast<SortHeader *>(d_hdr), st);
-}
-
 hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan,
                              void *d_ws, size_t ws_bytes, uint32_t *d_error, int *result_in_alt,
-                             hipStream_t st, hipEvent_t *pass_events, void *d_prepared) {
+                             hipStream_t st, hipEvent_t *pass_events) {
   *result_in_alt = 0;
   if (n == 0 || plan.num_passes == 0) return hipSuccess;
   if (ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
@@ -2318,37 +1184,15 @@ hipError_t launch_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key
   if (plan.mode == 3 && (plan.num_passes > 2 || n >= (1ull << 30))) {
     SortPlan stable = plan;                 // grouping is defined for one or two digits and 30-bit granule values
     stable.mode = 0;
-    return launch_radix_sort(d_keys, d_alt, n, key_words, stable, d_ws, ws_bytes, d_error, result_in_alt, st, pass_events, nullptr);
+    return launch_radix_sort(d_keys, d_alt, n, key_words, stable, d_ws, ws_bytes, d_error, result_in_alt, st, pass_events);
   }
-  if (!sort_plan_groups(plan, n)) d_prepared = nullptr;
-#define MGC_RUN(K_, RB_, BLOCK_, KPT_)                                                                       \
-  do {                                                                                                       \
-    if (n >= (1ull << 30))   /* packed look-back granules hold 30-bit values: use the wide ones */           \
-      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 3>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events, d_prepared); \
-    if (plan.match == 0)                                                                                     \
-      return run_passes<K_, RB_, BLOCK_, KPT_, 0, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events, d_prepared); \
-    if (plan.lookback == 2)                                                                                  \
-      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 2>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events, d_prepared); \
-    if (plan.lookback == 5)                                                                                  \
-      return run_passes<K_, RB_, BLOCK_, KPT_, 1, 5>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events, d_prepared); \
-    return run_passes<K_, RB_, BLOCK_, KPT_, 1, 1>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events, d_prepared);   \
-  } while (0)
+  // packed look-back granules hold 30-bit values: larger calls use the wide ones; 16-byte keys: 8 per thread keep the tile at 128 KiB
   if (key_words == 2) {
-    // 128-bit keys: 8 keys per thread keep the tile at 128 KiB of LDS (one workgroup per CU)
-    if (plan.radix_bits == 9) MGC_RUN(K128, 9, 1024, 8);
-    MGC_RUN(K128, 8, 1024, 8);
+    if (n >= (1ull << 30)) return run_passes<K128, 8, 3>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);
+    return run_passes<K128, 8, 2>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);
   }
-  if (plan.radix_bits == 9) {
-    if (plan.block == 1024 && plan.kpt == 8) MGC_RUN(u64, 9, 1024, 8);
-    if (plan.block == 1024) MGC_RUN(u64, 9, 1024, 16);
-    if (plan.kpt == 8) MGC_RUN(u64, 9, 512, 8);
-    MGC_RUN(u64, 9, 512, 16);
-  }
-  if (plan.block == 1024 && plan.kpt == 8) MGC_RUN(u64, 8, 1024, 8);
-  if (plan.block == 1024) MGC_RUN(u64, 8, 1024, 16);
-  if (plan.kpt == 8) MGC_RUN(u64, 8, 512, 8);
-  MGC_RUN(u64, 8, 512, 16);
-#undef MGC_RUN
+  if (n >= (1ull << 30)) return run_passes<u64, 16, 3>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);
+  return run_passes<u64, 16, 2>(d_keys, d_alt, n, plan, d_ws, d_error, result_in_alt, st, pass_events);
 }
 
 

@@ -44,9 +44,9 @@ constexpr size_t   SLOT_BYTES = 32u << 20;                // pinned copy buffers
 constexpr int      NSLOT_MAX  = 64;
 // device image of one encode chunk (two in flight; ~10 files at 10 Gbp) and pinned copy slots.  MEASURED (profiles/r03o_e2e_db.txt,
 // 6.75 GB database): 1 GiB / 16 slots 0.51 s, 2 GiB / 32 slots 0.67 s, 4 GiB / 48 slots 0.86 s -- pinning more slots costs more
-// than the extra files in flight give (MGC_DB_IMG_MB / MGC_DB_SLOTS override)
-inline uint64_t img_cap() { static const uint64_t v = (getenv("MGC_DB_IMG_MB") ? strtoull(getenv("MGC_DB_IMG_MB"), nullptr, 10) : 1024ull) << 20; return v; }
-inline int      n_slot()  { static const int v = std::max(4, std::min(NSLOT_MAX, getenv("MGC_DB_SLOTS") ? atoi(getenv("MGC_DB_SLOTS")) : 16)); return v; }
+// than the extra files in flight give (profiles/r03o_e2e_db.txt, r03p_e2e_db2.txt: other image and slot sizes)
+inline uint64_t img_cap() { return 1024ull << 20; }
+inline int      n_slot()  { return std::min(NSLOT_MAX, 16); }
 #define NSLOT n_slot()
 #define IMG_CAP img_cap()
 

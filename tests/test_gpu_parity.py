@@ -107,21 +107,10 @@ def test_radix_sort_matches_numpy(ops, torch_cuda, n, bits, monkeypatch):
     mask = np.uint64(((1 << (hi - lo)) - 1) << lo) if hi - lo < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
     # stable sort on the selected bits == numpy stable argsort on the masked key
     want = a[np.argsort((a & mask) >> np.uint64(lo), kind="stable")]
-    # every kernel variant: look-back / classic, 8 / 9-bit digits, ballot / LDS-mask ranking, tile shapes
-    for mode, rb, match, kpt, block, lb in [("0", "8", "1", "16", "512", "1"), ("0", "9", "1", "16", "512", "2"),
-                                            ("1", "8", "1", "16", "512", "1"), ("1", "9", "0", "16", "512", "1"),
-                                            ("0", "8", "0", "16", "512", "1"), ("0", "8", "1", "8", "512", "2"),
-                                            ("0", "8", "1", "16", "1024", "2"), ("0", "9", "1", "16", "1024", "1"),
-                                            ("0", "9", "1", "16", "1024", "5"), ("0", "8", "1", "8", "512", "5")]:
-        monkeypatch.setenv("MGC_SORT_LB", lb)
-        monkeypatch.setenv("MGC_SORT_MODE", mode)
-        monkeypatch.setenv("MGC_RADIX_BITS", rb)
-        monkeypatch.setenv("MGC_SORT_MATCH", match)
-        monkeypatch.setenv("MGC_SORT_KPT", kpt)
-        monkeypatch.setenv("MGC_SORT_BLOCK", block)
-        t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
-        out = _as_u64(ops.dev_radix_sort(t, lo, hi))
-        assert np.array_equal(out, want), (n, bits, mode, rb, match, kpt, block, lb)
+    # (one shape since round 5: nine-bit digits, 1024 x 16 tiles, LDS-mask ranking, window look-back)
+    t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
+    out = _as_u64(ops.dev_radix_sort(t, lo, hi))
+    assert np.array_equal(out, want), (n, bits)
 
 
 def test_radix_sort_skewed_digits(ops, torch_cuda):
@@ -130,12 +119,9 @@ def test_radix_sort_skewed_digits(ops, torch_cuda):
     for a in (np.zeros(n, np.uint64), np.full(n, 0xFFFFFFFFFFFFFFFF, np.uint64),
               np.arange(n, dtype=np.uint64), np.arange(n, dtype=np.uint64)[::-1].copy(),
               (np.arange(n, dtype=np.uint64) % np.uint64(2)) << np.uint64(35)):
-        for match in ("0", "1"):
-            os.environ["MGC_SORT_MATCH"] = match
-            t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
-            out = _as_u64(ops.dev_radix_sort(t, 0, 64))
-            assert np.array_equal(out, np.sort(a, kind="stable"))
-        os.environ.pop("MGC_SORT_MATCH", None)
+        t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
+        out = _as_u64(ops.dev_radix_sort(t, 0, 64))
+        assert np.array_equal(out, np.sort(a, kind="stable"))
 
 
 @pytest.mark.parametrize("n,card", [(0, 1), (1, 1), (5000, 1), (5000, 5000), (300_001, 1000), (1_000_000, 50_000)])
@@ -191,12 +177,8 @@ def test_radix_sort_u128_matches_numpy(ops, torch_cuda, n, bits, monkeypatch):
     mask = ((1 << (hi - lo)) - 1) << lo
     order = sorted(range(n), key=lambda i: (vals[i] & mask, i))          # stable on the selected bits
     want = [vals[i] for i in order]
-    for rb, mode, lb in (("8", "0", "2"), ("9", "0", "2"), ("8", "1", "2"), ("9", "0", "5")):
-        monkeypatch.setenv("MGC_RADIX_BITS", rb)
-        monkeypatch.setenv("MGC_SORT_MODE", mode)
-        monkeypatch.setenv("MGC_SORT_LB", lb)
-        t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
-        assert _as_int(ops.dev_radix_sort(t, lo, hi)) == want, (n, bits, rb, mode, lb)
+    t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
+    assert _as_int(ops.dev_radix_sort(t, lo, hi)) == want, (n, bits)
 
 
 def test_run_length_u128(ops, torch_cuda):
@@ -1158,25 +1140,13 @@ def test_medium_scale_matches_threaded_port(ops, oracle_lib, torch_cuda, k, n_re
     assert np.array_equal(klo, plo) and np.array_equal(khi, phi) and np.array_equal(counts, pcn)
 
 
-@pytest.mark.parametrize("variant", ["one", "two", "wc", "wc2"])
 @pytest.mark.parametrize("k,n_reads,mode", [(21, 700_000, 0), (20, 300_000, 1), (23, 300_000, 0), (22, 50_000, 2)])
-def test_five_byte_first_pass_variants(ops, oracle_lib, torch_cuda, monkeypatch, k, n_reads, mode, variant):
-    """The first grouping pass of a file in the 5-byte layout, three kernels, k-mer by k-mer against the threaded port:
-    "one" (default): radix_group_kernel<..., SOA>, whole keys through LDS, one workgroup per CU, look-back;
-    "two" (MGC_SOA_2WG=1): radix_group5_kernel, the narrowed 32-bit words through LDS (64 KiB per 16384-key tile), two workgroups
-    per CU, write-out by digit -- measured 5 % slower;
-    "wc" (MGC_SOA_WC=1): radix_group5wc_kernel, chunk-local (private cursors off the per-chunk histogram rows, no look-back) with
-    write combining: a digit's words that do not fill a 128-byte line wait in LDS for the chunk's next tile, every store a whole line;
-    "wc2" (MGC_SOA_WC=2): the same with 8192-key tiles and pending half lines, two workgroups per CU -- measured much slower.
-    k = 20..23 (34..40 bits below the file), files of 0.1 .. 1.4 M k-mers (partial last tiles, chunks of a few tiles down to
-    chunks smaller than a tile), all three strand modes."""
+def test_five_byte_layout_first_pass(ops, oracle_lib, torch_cuda, k, n_reads, mode):
+    """The first grouping pass of a file in the 5-byte layout (radix_group_kernel<..., SOA>: u32 + u8 arrays in, whole keys through
+    LDS, one workgroup per CU, look-back), k-mer by k-mer against the threaded port.  k = 20..23 (34..40 bits below the file), files
+    of 0.1 .. 1.4 M k-mers (partial last tiles), all three strand modes.  (The three other first-pass kernels of round 4 -- two
+    workgroups per CU, chunk-local write combining with whole and with half lines -- were measured slower and removed in round 5.)"""
     from meryl_amd import capi
-    if variant == "two":
-        monkeypatch.setenv("MGC_SOA_2WG", "1")
-    if variant == "wc":
-        monkeypatch.setenv("MGC_SOA_WC", "1")
-    if variant == "wc2":                                   # half lines, 8192-key tiles, two workgroups per CU
-        monkeypatch.setenv("MGC_SOA_WC", "2")
     d = ops.dev_synth_reads(70 + k, n_reads * 5, 0, n_reads)
     bases = d.cpu().numpy()
     cfg = capi.configure(k, bases.size, 8 << 30, mode)
@@ -1311,19 +1281,15 @@ def test_repeat_family_reads_generator_and_count(ops, oracle_lib, torch_cuda):
     assert counts.max() > 500                                  # the top family really is heavy
 
 
-@pytest.mark.parametrize("local", ["1", "0"])
 @pytest.mark.parametrize("k,min_top", [(21, 18), (21, 17), (20, 18), (20, 17), (19, 16), (17, 17)])
-def test_bitmap_count_and_chunk_local_pass(ops, oracle_lib, torch_cuda, monkeypatch, k, min_top, local):
+def test_judged_plan_on_a_small_input_with_planted_clusters(ops, oracle_lib, torch_cuda, monkeypatch, k, min_top):
     """The plan of the judged workload on a small input (MGC_FINISH_MIN_TOP forces two grouping digits, so a k = 21 file keeps
-    18-bit suffixes): the first grouping pass runs chunk-local off the per-chunk fifteen-bit histogram rows (no look-back;
-    MGC_GROUP_LOCAL=0: the look-back kernel), the sub-buckets are counted by the bitmap kernel (suffixes <= 18 bits; <= 16 bits:
-    its small instantiation).  Clusters of k-mers sharing their top bits make sub-buckets of 1 .. 1536 keys (the kernel's
-    capacity), 1537 and 3000 (the streaming kernel's), with 1 .. all-distinct suffixes; ordinary reads fill the rest."""
+    18-bit suffixes): 5-byte layout, look-back passes, hash-count kernels.  Clusters of k-mers sharing their top bits make
+    sub-buckets of 1 .. 1536 keys (the persistent kernels' capacity), 1537 and 3000 (the streaming kernel's), with 1 ..
+    all-distinct suffixes; ordinary reads fill the rest.  (Round 3's chunk-local pass, bitmap count and write-combining partition,
+    which this test used to switch on, were measured equal or slower and removed in round 5.)"""
     from meryl_amd import capi
     monkeypatch.setenv("MGC_FINISH_MIN_TOP", str(min_top))
-    monkeypatch.setenv("MGC_GROUP_LOCAL", local)
-    monkeypatch.setenv("MGC_FINISH_BITMAP", local)           # the experimental kernels on, or off (the default plan at this size)
-    monkeypatch.setenv("MGC_PARTITION_WC", local)            # ... the write-combining partition with them
     rng = np.random.default_rng(k * 100 + min_top)
     plen = (6 + min_top + 1) // 2 + 1                      # bases that fix the file and the sub-bucket
     def cluster(head, n_inst, n_distinct):
@@ -1382,58 +1348,19 @@ def test_hash_count_multi_subbuckets_per_iteration(ops, oracle_lib, torch_cuda, 
         assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
 
 
-@pytest.mark.parametrize("k,compress,min_top,stream_max", [(21, 0, 17, None), (21, 0, 10, "2000"), (19, 0, 14, None), (31, 0, 16, None),
-                                                            (31, 1, None, None), (51, 0, 12, "2000"), (24, 0, 18, None)])
-def test_pipelined_count_equals_the_oracle(ops, oracle_lib, torch_cuda, monkeypatch, k, compress, min_top, stream_max):
-    """MGC_PIPE=1 (round 4, measured slower and therefore off: profiles/r04y_pipe_ab.txt): a file's count kernel on a second /
-    third stream beside the grouping passes of the files after it, its statistics fetched per file, the streaming count of
-    oversized sub-buckets in a buffer of its own.  Narrowed files, whole 8- and 16-byte keys, `compress`; sub-buckets above the
-    persistent kernels' capacity (streaming launch), above MGC_STREAM_MAX (probe, widening, stable-sort fallback on the session
-    stream between the queued passes), empty files in forward mode."""
-    from meryl_amd import capi
-    monkeypatch.setenv("MGC_PIPE", "1")
-    if min_top is not None:
-        monkeypatch.setenv("MGC_FINISH_MIN_TOP", str(min_top))
-    if stream_max is not None:
-        monkeypatch.setenv("MGC_STREAM_MAX", stream_max)
-    rng = np.random.default_rng(k * 7 + (min_top or 0))
-    plen = min(k - 1, (6 + (min_top or 16) + 1) // 2 + 1)
-    def cluster(head, n_inst, n_distinct):
-        pre = head + "".join("ACGT"[i] for i in rng.integers(0, 4, plen - len(head)))
-        n_distinct = min(n_distinct, 4 ** (k - plen))
-        tails = ["".join("ACGT"[i] for i in rng.integers(0, 4, k - plen)) for _ in range(n_distinct)]
-        return ".".join(pre + tails[int(i)] for i in rng.integers(0, n_distinct, n_inst)) + "."
-    reads = oracle_lib.synth_reads(k + 1, 400_000, 0, 30_000).tobytes().decode()
-    stream = (cluster("AAC", 1536, 1536) + cluster("AGC", 1537, 300) + cluster("CAT", 3000, 900) + cluster("CCG", 5000, 4000)
-              + cluster("AAT", 9000, 1) + cluster("GTA", 2500, 2500) + cluster("TTG", 1, 1) + reads)
-    for mode in (1, 0):
-        cfg = capi.configure(k, len(stream), 1 << 30, mode, homopoly_compress=compress)
-        cfg.use_simple = 0
-        want = oracle_lib.count_brute(oracle_lib.compress_stream(stream) if compress else stream, k, mode)
-        for _ in range(2):                                  # twice through one session: the events and the pinned statistics are reused
-            with ops.Session(cfg) as s:
-                s.push_bases(stream, end_of_sequence=False)
-                s.count()
-                klo, khi, counts, _ = s.result_wide()
-            whi, wlo, wcn, _ = want
-            assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
-
-
-@pytest.mark.parametrize("m64,nolist", [("1", "1"), ("1", "0"), ("0", "1")])
+@pytest.mark.parametrize("nolist", ["1", "0"])
 @pytest.mark.parametrize("k,compress,min_top", [(28, 0, 14), (31, 0, 16), (32, 0, 12), (31, 1, None), (30, 0, 18),
                                                 (33, 0, 14), (40, 0, 16), (51, 0, 12), (64, 0, 18), (51, 1, None)])
-def test_hash_countw_kernel_dense_and_sparse_grids(ops, oracle_lib, torch_cuda, monkeypatch, k, compress, min_top, m64, nolist):
+def test_hash_countw_kernel_dense_and_sparse_grids(ops, oracle_lib, torch_cuda, monkeypatch, k, compress, min_top, nolist):
     """hash_countw_kernel (round 4: the index-claimed count of 64-bit suffixes and of 16-byte keys rebuilt like
     hash_count_multi_kernel -- noted claims, entries sorted by bin, prefetch consumed before the next loads) on the dense-grid
     launch (MGC_FINISH_NOLIST on a small input) and on the sparse one (the list of non-empty sub-buckets, their numbers
     prefetched one iteration further ahead), every instantiation (8- / 16-byte keys, suffix within 64 bits / wider, sub-buckets
-    up to 768 / 1536 keys), against the kernels it replaces (MGC_HASH64M=0 / MGC_HASH128M=0) and the oracle: clusters of
+    up to 768 / 1536 keys), against the oracle: clusters of
     1 .. 1536 keys with 1 .. all-distinct suffixes, more distinct suffixes than threads (low coverage), an oversized one for
     the streaming launch."""
     from meryl_amd import capi
     monkeypatch.setenv("MGC_FINISH_NOLIST", nolist)
-    monkeypatch.setenv("MGC_HASH64M", m64)
-    monkeypatch.setenv("MGC_HASH128M", m64)
     if min_top is not None:
         monkeypatch.setenv("MGC_FINISH_MIN_TOP", str(min_top))
     rng = np.random.default_rng(k * 7 + (min_top or 0))
@@ -1460,10 +1387,10 @@ def test_hash_countw_kernel_dense_and_sparse_grids(ops, oracle_lib, torch_cuda, 
 
 # every count_device switch that is read per call (a process-wide static one cannot vary inside one test process)
 _GRID_SWITCHES = {
-    "MGC_NARROW": ["0"], "MGC_FINE_HIST": ["0"], "MGC_WIDE_MSD": ["0"], "MGC_GROUP_LOCAL": ["1"], "MGC_PARTITION_WC": ["1"],
-    "MGC_FINISH_BITMAP": ["1"], "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"],
+    "MGC_NARROW": ["0"], "MGC_FINE_HIST": ["0"], "MGC_WIDE_MSD": ["0"],
+    "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"],
     "MGC_FINISH_TARGET": ["1", "4", "64", "700"], "MGC_FINISH_MIN_TOP": ["10", "14", "17", "18"], "MGC_STREAM_MAX": ["2000", "20000"],
-    "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"], "MGC_HASH64M": ["0"], "MGC_HASH128M": ["0"], "MGC_PIPE": ["1"], "MGC_SOA_2WG": ["1"], "MGC_SOA_WC": ["1"],
+    "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"],
 }
 
 
