@@ -1109,6 +1109,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     return MGC_OK;
   };
   uint32_t soa_hi_mask = 0;                                  // nonzero: the files lie in the 5-byte layout
+  std::vector<char> file_k96(nb, 0), k96_passes(nb, 0);      // files that lie as 12-byte K96 records (k = 33..51; below); ... and whose passes moved them
 
   // ---- per-file LSB radix sort of the low 2k-6 bits ----
   const size_t sort_ws_bytes = mgc::sort_workspace_bytes(max_bucket) + 256;
@@ -1255,7 +1256,14 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
                  !getenv("MGC_GROUP_DBG");
       for (uint32_t b = 0; b < nb && soa; b++) if (h_counts[b] && !(narrow[b] && top_bits[b])) soa = false;
       if (soa) soa_hi_mask = (1u << (rem_bits - 32)) - 1u;
-      const int prc = run_partition(soa);
+      // K96 records (round 5): 16-byte keys with at most 96 bits below the file (k = 33..51), every non-empty file on the whole-key
+      // high-digit-first passes: 12 of the 16 bytes leave the partition, go through both passes and into the count kernel
+      // (mgc_common.hpp K96; the region of a file stays 16 bytes per k-mer, so a file can be widened back in place).  MGC_K96=0: whole keys.
+      const char *k96e = getenv("MGC_K96");                           // read per call: the tests switch it
+      bool k96 = !(k96e && k96e[0] == '0') && !ext_keys && kw == 2 && nb == 64 && d_fine && rem_bits <= 96 && s->sfx_mask == 0 && !c.homopoly_compress;
+      for (uint32_t b = 0; b < nb && k96; b++) if (h_counts[b] && !(wide_msd[b] && top_bits[b])) k96 = false;
+      if (k96) for (uint32_t b = 0; b < nb; b++) file_k96[b] = h_counts[b] != 0;
+      const int prc = run_partition(soa || k96);
       if (prc != MGC_OK) return prc;
     }
     // Where the counts of a file's distinct k-mers wait for the packing step (one uint32 per k-mer instance position).  A NARROWED
@@ -1345,8 +1353,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         sort_launch_groups++;
       } else if (wide_msd[b] && d_nhdrs) {                   // X -> Y -> X, whole keys; boundaries included
         HIP_TRY(s, mgc::launch_group_wide(src, (void *)Y, h_counts[b], kw, fp, d_err, d_substart + sbase[b], st, pe,
-                                          (void *)(d_nhdrs + hdr_bytes * b), (void *)(d_nws + nws_off[b]), &tr_a[b], &tr_b[b]));
+                                          (void *)(d_nhdrs + hdr_bytes * b), (void *)(d_nws + nws_off[b]), &tr_a[b], &tr_b[b], file_k96[b] != 0));
         file_passes[b] = 2;
+        k96_passes[b] = file_k96[b];
         sort_launch_groups++;
         s->prof.wide_msd_files++;
       } else {
@@ -1430,6 +1439,16 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         fprintf(stderr, "[finish] bucket %u: largest sub-bucket %llu > %llu: %s\n", b, (unsigned long long)h_maxsub[b],
                 (unsigned long long)cap, stream ? "streamed through the hash tables" : "stable-sort fallback");
       }
+      if (file_k96[b] && h_nlarge[b] > 0 && !stream) {
+        // K96 records with an oversized sub-bucket that nothing streams: the LDS sort / the stable-sort fallback want whole 16-byte
+        // k-mers -- the file is widened in its own (16 bytes per k-mer) region, through Y, and goes on as a launch_group_wide file
+        if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));   // Y is the streaming kernels' second buffer
+        forked = false;
+        const unsigned __int128 fb = (unsigned __int128)b << rem_bits;
+        HIP_TRY(s, mgc::launch_widen_k96(seg, h_counts[b], (uint64_t)fb, (uint64_t)(fb >> 64), (void *)Y, st));
+        HIP_TRY(s, hipMemcpyAsync(seg, Y, kbytes * h_counts[b], hipMemcpyDeviceToDevice, st));
+        file_k96[b] = 0;
+      }
       bool unordered = false;
       if (narrow[b] && h_nlarge[b] > 0 && !stream) {
         // an oversized sub-bucket that cannot be streamed: the LDS sort / the stable-sort fallback want whole k-mers back
@@ -1461,7 +1480,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
           fin_ev.emplace_back(); (void)hipEventCreate(&fin_ev.back().first); (void)hipEventCreate(&fin_ev.back().second);
           (void)hipEventRecord(fin_ev.back().first, fst);
           fin_keys += h_counts[b];
-          fin_in_bytes += h_counts[b] * (narrow[b] ? 4u : (uint64_t)kbytes);
+          fin_in_bytes += h_counts[b] * (narrow[b] ? 4u : (file_k96[b] ? 12u : (uint64_t)kbytes));
           fin_narrow = fin_narrow || narrow[b];
         }
         HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_nlarge[b],
@@ -1469,7 +1488,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
                                            // the list pays off only when a good part of the 2^t grid is empty
                                            (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b]) && !finish_nolist) ? d_nz + gbase[b] : nullptr,
                                            d_nzcount(b), fst, narrow[b] != 0, tr_a[b], tr_b[b], h_maxsub[b], h_counts[b],
-                                           d_nz + gbase[b], d_retrycnt + b));
+                                           d_nz + gbase[b], d_retrycnt + b, file_k96[b] != 0));
         if (s->profiling) (void)hipEventRecord(fin_ev.back().second, fst);
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
@@ -1527,6 +1546,10 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         HIP_TRY(s, mgc::launch_compact_groups_narrow(seg, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b],
                                                      gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, rem_bits - top_bits[b],
                                                      s->d_unique, s->d_counts, st, tr_a[b], tr_b[b], nzl, h_nzcount[b]));
+      } else if (!fallback[b] && file_k96[b]) {
+        const unsigned __int128 fb = (unsigned __int128)b << rem_bits;
+        HIP_TRY(s, mgc::launch_compact_groups_k96(seg, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b], gbase[b + 1] - gbase[b],
+                                                  (uint64_t)fb, (uint64_t)(fb >> 64), s->d_unique, s->d_counts, st, tr_a[b], tr_b[b], nzl, h_nzcount[b]));
       } else if (!fallback[b]) {
         HIP_TRY(s, mgc::launch_compact_groups(seg, kw, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b],
                                               gbase[b + 1] - gbase[b], s->d_unique, s->d_counts, st, tr_a[b], tr_b[b], nzl, h_nzcount[b]));
@@ -1581,7 +1604,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
           s->prof.pass_ms[pi] += ms;
           s->prof.pass_launches[pi]++;
           s->prof.pass_keys[pi] += h_counts[b];
-          s->prof.pass_bytes[pi] += h_counts[b] * ((size_t)b < narrowed.size() && narrowed[b] ? (p ? 8u : (soa_hi_mask ? 9u : 12u)) : 2u * kbytes);
+          s->prof.pass_bytes[pi] += h_counts[b] * ((size_t)b < narrowed.size() && narrowed[b] ? (p ? 8u : (soa_hi_mask ? 9u : 12u)) : (k96_passes[b] ? 24u : 2u * kbytes));
         }
       }
     }

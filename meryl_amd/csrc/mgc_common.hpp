@@ -72,6 +72,29 @@ template <> struct KeyOps<K128> {
   static __device__ __forceinline__ u64  low64(K128 k) { return k.lo; }
 };
 
+// 96-bit key (round 5): what a k-mer of k = 33..51 holds BELOW ITS FILE (2k - 6 <= 96 bits) -- the file is where the k-mer lies, so
+// the partition, both whole-key grouping passes and the count kernel move 12 bytes per k-mer instead of 16 (the reference never
+// stores more than the suffix bits either: merylCountArray.C:490-728, _sWidth-bit append).  w[0] least significant; 4-byte aligned.
+struct alignas(4) K96 { u32 w[3]; };
+template <> struct KeyOps<K96> {
+  static constexpr int WORDS = 2;
+  static __device__ __forceinline__ u128 v(K96 k) { return ((u128)k.w[2] << 64) | ((u128)k.w[1] << 32) | (u128)k.w[0]; }
+  static __device__ __forceinline__ K96  mk(u128 x) { K96 k; k.w[0] = (u32)x; k.w[1] = (u32)(x >> 32); k.w[2] = (u32)(x >> 64); return k; }
+  static __device__ __forceinline__ u32  digit(K96 k, u32 shift, u32 mask) {
+    // (a digit is at most 12 bits: the two words it can touch)
+    const u32 wi = shift >> 5, sh = shift & 31u;            // (uniform: selects, no indexed registers)
+    const u32 lo_w = wi == 0 ? k.w[0] : (wi == 1 ? k.w[1] : k.w[2]);
+    const u32 hi_w = wi == 0 ? k.w[1] : (wi == 1 ? k.w[2] : 0u);
+    const u32 x = (u32)((((u64)hi_w << 32) | (u64)lo_w) >> sh);
+    if (mask == HPC_DIGIT_MASK) return hpc_digit(x & 0xFFFu);
+    return x & mask;
+  }
+  static __device__ __forceinline__ K96  pad() { K96 k; k.w[0] = k.w[1] = k.w[2] = ~0u; return k; }
+  static __device__ __forceinline__ K96  zero() { K96 k; k.w[0] = k.w[1] = k.w[2] = 0u; return k; }
+  static __device__ __forceinline__ bool ne(K96 a, K96 b) { return a.w[0] != b.w[0] || a.w[1] != b.w[1] || a.w[2] != b.w[2]; }
+  static __device__ __forceinline__ u64  low64(K96 k) { return ((u64)k.w[1] << 32) | (u64)k.w[0]; }
+};
+
 // Sub-bucket index of a narrowed file in PHYSICAL order -> the top bits its k-mers hold (launch_group_narrow: with the high
 // digit first the file ends up ordered by (low digit : high digit)); a = 0: the same thing.
 __device__ __forceinline__ u64 tr_index(u64 p, u32 a, u32 b) { return a ? (((p & ((1ull << a) - 1ull)) << b) | (p >> a)) : p; }

@@ -101,7 +101,8 @@ hipError_t launch_hpc_prepare(const uint64_t *d_fine_hpc, uint32_t bucket_bits, 
 size_t     wide_scratch_bytes(uint64_t n, uint32_t key_words);
 hipError_t launch_group_wide(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan, uint32_t *d_error,
                              uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events /* 4 or null */, void *d_prepared,
-                             void *d_scratch, uint32_t *tr_a, uint32_t *tr_b);
+                             void *d_scratch, uint32_t *tr_a, uint32_t *tr_b,
+                             bool k96 = false /* d_keys / d_alt hold 12-byte K96 records (launch_kmer_partition(d_soa_counts) at k = 33..51) */);
 
 // ---- run-length count ------------------------------------------------------
 size_t     rle_workspace_bytes(uint64_t n);
@@ -141,7 +142,8 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               uint64_t max_sub = 0 /*the file's largest sub-bucket, if known: small files take smaller tables*/,
                               uint64_t n_keys = 0 /*keys of the file, if known: the narrowed hash-count takes several sub-buckets per iteration by their average*/,
                               uint32_t *d_retry_list = nullptr /*[ng] + a zeroed counter: with both, dense narrowed files take hash_count_multi_kernel*/,
-                              uint64_t *d_retry_count = nullptr);
+                              uint64_t *d_retry_count = nullptr,
+                              bool k96 = false /*d_keys: 12-byte K96 records (key_words 2, no oversized sub-buckets: n_large == 0)*/);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);
 hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,
@@ -152,6 +154,11 @@ hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const u
 hipError_t launch_compact_groups_narrow(const void *d_keys32, const uint32_t *d_cnt_tmp, const uint64_t *d_starts, const uint64_t *d_offs,
                                         uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st,
                                         uint32_t tr_a, uint32_t tr_b, const uint32_t *d_nonempty_list = nullptr, uint64_t n_nonempty = 0);
+// K96 records (k = 33..51: the bits below the file, 12 bytes) -> whole 16-byte k-mers; base_lo / base_hi: the file's bits in their place
+hipError_t launch_compact_groups_k96(const void *d_keys96, const uint32_t *d_cnt_tmp, const uint64_t *d_starts, const uint64_t *d_offs,
+                                     uint64_t ng, uint64_t base_lo, uint64_t base_hi, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st,
+                                     uint32_t tr_a, uint32_t tr_b, const uint32_t *d_nonempty_list = nullptr, uint64_t n_nonempty = 0);
+hipError_t launch_widen_k96(const void *d_keys96, uint64_t n, uint64_t base_lo, uint64_t base_hi, void *d_out128, hipStream_t st);
 hipError_t launch_widen_groups(const void *d_keys32, const uint64_t *d_starts, uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out64,
                                hipStream_t st, uint32_t tr_a, uint32_t tr_b);      // tr_a != 0: the result is NOT in key order
 hipError_t launch_store_u64(uint64_t *d_dst, const uint64_t *d_src, hipStream_t st);

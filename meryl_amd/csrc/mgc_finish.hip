@@ -934,14 +934,15 @@ void hash_count_multi_kernel(u32 *__restrict__ keys, const u64 *__restrict__ sta
 // KT = u64 | K128; WIDE (K128 only): the suffix needs the high word (low_bits > 64).  LIST: only the non-empty sub-buckets
 // are visited (sparse grids: `compress`) -- their numbers are prefetched one more iteration ahead than their bounds.
 template <typename KT, int BLOCK, int CAP, int SLOTS, bool WIDE, bool LIST>
-__global__ __launch_bounds__(BLOCK, (sizeof(KT) == 16 ? (CAP <= 768 ? 5 : 4) : (CAP <= 768 ? 6 : 5)))
+__global__ __launch_bounds__(BLOCK, (sizeof(KT) >= 12 ? (CAP <= 768 ? 5 : 4) : (CAP <= 768 ? 6 : 5)))
 void hash_countw_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size, u32 low_bits,
                         u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
                         const u32 *__restrict__ nz, const u64 *__restrict__ nz_count, u32 tr_a, u32 tr_b) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS * 3 >= CAP * 4 && SLOTS % (4 * BLOCK) == 0 && CAP % BLOCK == 0 && CAP < 0xFFFF, "table geometry");
   static_assert(BLOCK == 256, "one bin per thread");
-  constexpr bool K16 = sizeof(KT) == 16;
-  static_assert(K16 || !WIDE, "WIDE is a property of 16-byte keys");
+  constexpr bool K16 = sizeof(KT) >= 12;               // two-word suffixes: K128, or K96 (12-byte records: the bits below the file)
+  constexpr bool IS96 = sizeof(KT) == 12;
+  static_assert(K16 || !WIDE, "WIDE is a property of 16- and 12-byte keys");
   constexpr int KPT = CAP / BLOCK;
   constexpr u32 EMPTY = 0x0000FFFFu;
   __shared__ __attribute__((aligned(16))) u64 dlo[CAP];               // staged suffixes of the sub-bucket (low words)
@@ -987,7 +988,7 @@ void hash_countw_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, u
     const bool fits = (u64)n <= max_size;
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
-      if constexpr (K16) { kr[j].lo = 0ull; kr[j].hi = 0ull; } else kr[j] = 0ull;
+      if constexpr (IS96) { kr[j].w[0] = 0u; kr[j].w[1] = 0u; kr[j].w[2] = 0u; } else if constexpr (K16) { kr[j].lo = 0ull; kr[j].hi = 0ull; } else kr[j] = 0ull;
       if (fits && (u32)j * BLOCK < n) {
         const KT *src = keys + a0 + (u32)j * BLOCK;
         const u32 last = n - 1u - (u32)j * BLOCK;
@@ -1003,11 +1004,15 @@ void hash_countw_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, u
   u64 klo[KPT], khi[K16 ? KPT : 1], pre_lo = 0, pre_hi = 0;           // the suffixes being counted; the k-mers' common top bits
   KT kcur[KPT];
   auto consume = [&]() {                                              // kcur -> klo/khi + prefix; nothing newer is in flight when its wait runs
-    if constexpr (K16) { pre_lo = kcur[0].lo & ~mask_lo; pre_hi = kcur[0].hi & ~mask_hi; }
+    if constexpr (IS96) { pre_lo = KeyOps<K96>::low64(kcur[0]) & ~mask_lo; pre_hi = (u64)kcur[0].w[2] & ~mask_hi; }
+    else if constexpr (K16) { pre_lo = kcur[0].lo & ~mask_lo; pre_hi = kcur[0].hi & ~mask_hi; }
     else pre_lo = kcur[0] & ~mask_lo;
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
-      if constexpr (K16) {
+      if constexpr (IS96) {
+        klo[j] = KeyOps<K96>::low64(kcur[j]) & mask_lo; khi[j] = (u64)kcur[j].w[2] & mask_hi;
+        asm volatile("" : "+v"(klo[j]) :: "memory"); asm volatile("" : "+v"(khi[j]) :: "memory");
+      } else if constexpr (K16) {
         klo[j] = kcur[j].lo & mask_lo; khi[j] = kcur[j].hi & mask_hi;
         asm volatile("" : "+v"(klo[j]) :: "memory"); asm volatile("" : "+v"(khi[j]) :: "memory");
       } else { klo[j] = kcur[j] & mask_lo; asm volatile("" : "+v"(klo[j]) :: "memory"); }
@@ -1174,7 +1179,8 @@ void hash_countw_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, u
           const u64 ql = dlo[rq], qh = WIDE ? dhi[rq] : 0ull;
           r += ((WIDE && qh < kh) || ((!WIDE || qh == kh) && ql < kl)) ? 1u : 0u;
         }
-        if constexpr (K16) { KT o; o.lo = pre_lo_cur | kl; o.hi = pre_hi_cur | kh; gk[r] = o; }
+        if constexpr (IS96) { KT o; const u64 ol = pre_lo_cur | kl; o.w[0] = (u32)ol; o.w[1] = (u32)(ol >> 32); o.w[2] = (u32)(pre_hi_cur | kh); gk[r] = o; }
+        else if constexpr (K16) { KT o; o.lo = pre_lo_cur | kl; o.hi = pre_hi_cur | kh; gk[r] = o; }
         else gk[r] = pre_lo_cur | kl;
         cout[r] = w >> 16;
       }
@@ -1461,11 +1467,11 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
 
 // The same for 16-byte keys (k >= 33): slots are claimed through their count word as in hash_count128_kernel, lanes of a
 // wave that hold the first active lane's suffix are merged into one weighted insert, ranges are 128-bit.
-template <int BLOCK, int CAP, int SLOTS, bool WIDE>
+template <int BLOCK, int CAP, int SLOTS, bool WIDE, typename KT = K128>   // KT: K128, or 12-byte K96 records
 __global__ __launch_bounds__(BLOCK)
-void hash_count128_huge_kernel(K128 *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
+void hash_count128_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
                                u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                               K128 *__restrict__ alt, u32 tr_a = 0, u32 tr_b = 0) {
+                               KT *__restrict__ alt, u32 tr_a = 0, u32 tr_b = 0) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS >= CAP * 2 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
   constexpr int KPT = 2, SPT = SLOTS / BLOCK;
   constexpr u32 LOCK = 0xFFFFFFFFu;
@@ -1480,7 +1486,7 @@ void hash_count128_huge_kernel(K128 *__restrict__ keys, const u64 *__restrict__ 
   __shared__ u32 s_tmp[BLOCK / 64 + 1];
   __shared__ u32 s_st[3];                              // distinct in this pass, overflow, round of the overflow
   __shared__ u64 s_split[2];
-  using KO = KeyOps<K128>;
+  using KO = KeyOps<KT>;
   const u32 tid = threadIdx.x;
   const u64 g = list[blockIdx.x];
   const u64 a = starts[g], n64 = starts[g + 1] - a;
@@ -1488,7 +1494,7 @@ void hash_count128_huge_kernel(K128 *__restrict__ keys, const u64 *__restrict__ 
   const u128 low_mask = (low_bits >= 128) ? ~(u128)0 : (((u128)1 << low_bits) - 1);
   const u128 prefix = KO::v(keys[a]) & ~low_mask;
   constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
-  K128 *gk = keys + a;
+  KT *gk = keys + a;
   const u64 rounds = (n64 + (u64)BLOCK * KPT - 1) / ((u64)BLOCK * KPT);
   u128 lo = 0, hi = low_mask;                          // suffix range of this pass, inclusive
   u64 out = 0;
@@ -1498,11 +1504,11 @@ void hash_count128_huge_kernel(K128 *__restrict__ keys, const u64 *__restrict__ 
     if (tid < 3) s_st[tid] = 0u;
     __syncthreads();
     const u128 span = hi - lo;
-    K128 raw[KPT];                                     // next round's keys in flight while this one goes through the table
+    KT raw[KPT];                                     // next round's keys in flight while this one goes through the table
 #pragma unroll
     for (int j = 0; j < KPT; j++) { const u64 idx = (u64)j * BLOCK + tid; if (idx < n64) raw[j] = gk[idx]; else raw[j] = KO::zero(); }
     for (u64 base = 0, rd = 0; base < n64; base += (u64)BLOCK * KPT, rd++) {
-      K128 nxt[KPT];
+      KT nxt[KPT];
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
         const u64 idx = base + (u64)BLOCK * KPT + (u64)j * BLOCK + tid;
@@ -1606,7 +1612,7 @@ void hash_count128_huge_kernel(K128 *__restrict__ keys, const u64 *__restrict__ 
     if (tid < 16) { dlo[D + tid] = ~0ull; if (WIDE) dhi[D + tid] = ~0ull; }
     __syncthreads();
     in_place = (lo == 0 && hi == low_mask);
-    K128 *dst = in_place ? gk : alt + a;
+    KT *dst = in_place ? gk : alt + a;
     if (D > (u32)BLOCK) {
       u32 N = 2 * BLOCK;
       while (N < D) N <<= 1;
@@ -1721,6 +1727,33 @@ void compact_groups_kernel(const K *__restrict__ keys, const u32 *__restrict__ c
 }
 
 // narrowed files: the finish left 32-bit suffixes; the k-mer is  base | sub-bucket << low_bits | suffix
+// K96 records (the bits below the file) -> whole 16-byte k-mers: `base` = the file's bits, in their place (bits 2k-6 .. of the k-mer)
+__global__ __launch_bounds__(256)
+void compact_groups_k96_kernel(const K96 *__restrict__ keys, const u32 *__restrict__ cnt_tmp, const u64 *__restrict__ starts,
+                               const u64 *__restrict__ offs, u64 ng, u64 base_lo, u64 base_hi, K128 *__restrict__ out_keys,
+                               u32 *__restrict__ out_counts, u32 tr_a, u32 tr_b, const u32 *__restrict__ nz, u64 n_nz) {
+  u64 g = (u64)blockIdx.x * 4 + wave_id();
+  if (nz) { if (g >= n_nz) return; g = nz[g]; }
+  else if (g >= ng) return;
+  const u64 gt = tr_index(g, tr_a, tr_b);
+  const u64 dst = offs[gt], d = offs[gt + 1] - dst, src = starts[g];
+  for (u64 i = lane_id(); i < d; i += 64) {
+    const K96 q = keys[src + i];
+    K128 o; o.lo = KeyOps<K96>::low64(q) | base_lo; o.hi = (u64)q.w[2] | base_hi;
+    out_keys[dst + i]   = o;
+    out_counts[dst + i] = cnt_tmp[src + i];
+  }
+}
+// a whole file of K96 records -> 16-byte keys (for the paths that want whole k-mers: streaming count, stable-sort fallback)
+__global__ __launch_bounds__(256)
+void widen_k96_kernel(const K96 *__restrict__ in, u64 n, u64 base_lo, u64 base_hi, K128 *__restrict__ out) {
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+    const K96 q = in[i];
+    K128 o; o.lo = KeyOps<K96>::low64(q) | base_lo; o.hi = (u64)q.w[2] | base_hi;
+    out[i] = o;
+  }
+}
+
 __global__ __launch_bounds__(256)
 void compact_groups_narrow_kernel(const u32 *__restrict__ keys32, const u32 *__restrict__ cnt_tmp, const u64 *__restrict__ starts,
                                   const u64 *__restrict__ offs, u64 ng, u64 base, u32 low_bits, u64 *__restrict__ out_keys,
@@ -1881,8 +1914,55 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
                               bool stream, void *d_alt, hipStream_t st_huge, const uint32_t *d_nz, const uint64_t *d_nz_count,
                               hipStream_t st, bool narrow, uint32_t tr_a, uint32_t tr_b, uint64_t max_sub, uint64_t n_keys,
-                              uint32_t *d_retry_list, uint64_t *d_retry_count) {
+                              uint32_t *d_retry_list, uint64_t *d_retry_count, bool k96) {
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
+  if (k96) {
+    // 12-byte K96 records: the persistent hash-count, and the streaming count of oversized sub-buckets (a file whose oversized
+    // sub-buckets nothing streams is widened to 16-byte keys by the caller first)
+    if (key_words != 2 || narrow || (n_large && !stream) || !finish_uses_hash(key_words, low_bits)) return hipErrorInvalidValue;
+    const bool small96 = max_sub && max_sub <= 768 && n_large == 0;
+    const u64 msize = small96 ? (u64)768 : FIN_CAP_HASH128;
+    const bool lst = d_nz != nullptr, wide = low_bits > 64;
+    const uint32_t gmax = 256u * (small96 ? 12u : 8u), g96 = ng < gmax ? (uint32_t)ng : gmax;
+#define MGC_W96_LAUNCH(CAP_, SLOTS_, WIDE_, LIST_)                                                                                       \
+    hipLaunchKernelGGL((hash_countw_kernel<K96, 256, CAP_, SLOTS_, WIDE_, LIST_>), dim3(g96), dim3(256), 0, st,                          \
+                       reinterpret_cast<K96 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, msize, low_bits,               \
+                       d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), d_nz, nzc, tr_a, tr_b)
+    if (small96) {
+      if (wide) { if (lst) MGC_W96_LAUNCH(768, 1024, true, true);  else MGC_W96_LAUNCH(768, 1024, true, false); }
+      else      { if (lst) MGC_W96_LAUNCH(768, 1024, false, true); else MGC_W96_LAUNCH(768, 1024, false, false); }
+    } else {
+      if (wide) { if (lst) MGC_W96_LAUNCH(1536, 2048, true, true);  else MGC_W96_LAUNCH(1536, 2048, true, false); }
+      else      { if (lst) MGC_W96_LAUNCH(1536, 2048, false, true); else MGC_W96_LAUNCH(1536, 2048, false, false); }
+    }
+#undef MGC_W96_LAUNCH
+    MGC_CHECK(hipGetLastError());
+    if (n_large) {
+      constexpr int HS = 4096, HC = 2048;
+      constexpr size_t BW = (size_t)(8 + 8 + 4) * HS + (size_t)(8 + 8) * (HC + 16) + (size_t)4 * HC;
+      constexpr size_t BN = (size_t)(8 + 4) * HS + (size_t)8 * (HC + 16) + (size_t)4 * HC;
+      static bool w96attr = false;
+      if (!w96attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count128_huge_kernel<1024, HC, HS, true, K96>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)BW);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count128_huge_kernel<1024, HC, HS, false, K96>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)BN);
+        w96attr = true;
+      }
+      if (wide)
+        hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, true, K96>), dim3((uint32_t)n_large), dim3(1024), BW, st_huge,
+                           reinterpret_cast<K96 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
+                           FIN_CAP_HASH128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                           reinterpret_cast<K96 *>(d_alt), tr_a, tr_b);
+      else
+        hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, false, K96>), dim3((uint32_t)n_large), dim3(1024), BN, st_huge,
+                           reinterpret_cast<K96 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
+                           FIN_CAP_HASH128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                           reinterpret_cast<K96 *>(d_alt), tr_a, tr_b);
+      MGC_CHECK(hipGetLastError());
+    }
+    return hipSuccess;
+  }
   const bool use_list = d_nz != nullptr;
   if (narrow) {
     // narrowed keys (u32): the 32-bit hash-count kernels and the streaming kernel have u32-storage instantiations; anything
@@ -2122,6 +2202,24 @@ hipError_t launch_compact_groups_narrow(const void *d_keys32, const uint32_t *d_
   hipLaunchKernelGGL(compact_groups_narrow_kernel, dim3((uint32_t)(((d_nz ? n_nz : ng) + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const u32 *>(d_keys32),
                      d_cnt_tmp, reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng, (u64)base, low_bits,
                      reinterpret_cast<u64 *>(d_out_keys), d_out_counts, tr_a, tr_b, d_nz, (u64)n_nz);
+  return hipGetLastError();
+}
+
+hipError_t launch_compact_groups_k96(const void *d_keys96, const uint32_t *d_cnt_tmp, const uint64_t *d_starts, const uint64_t *d_offs,
+                                     uint64_t ng, uint64_t base_lo, uint64_t base_hi, void *d_out_keys, uint32_t *d_out_counts, hipStream_t st,
+                                     uint32_t tr_a, uint32_t tr_b, const uint32_t *d_nz, uint64_t n_nz) {
+  if (d_nz && n_nz == 0) return hipSuccess;
+  hipLaunchKernelGGL(compact_groups_k96_kernel, dim3((uint32_t)(((d_nz ? n_nz : ng) + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const K96 *>(d_keys96),
+                     d_cnt_tmp, reinterpret_cast<const u64 *>(d_starts), reinterpret_cast<const u64 *>(d_offs), (u64)ng, (u64)base_lo, (u64)base_hi,
+                     reinterpret_cast<K128 *>(d_out_keys), d_out_counts, tr_a, tr_b, d_nz, (u64)n_nz);
+  return hipGetLastError();
+}
+
+hipError_t launch_widen_k96(const void *d_keys96, uint64_t n, uint64_t base_lo, uint64_t base_hi, void *d_out128, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const uint64_t g = (n + 255) / 256;
+  hipLaunchKernelGGL(widen_k96_kernel, dim3((uint32_t)(g < 256u * 32u ? g : 256u * 32u)), dim3(256), 0, st, reinterpret_cast<const K96 *>(d_keys96), (u64)n,
+                     (u64)base_lo, (u64)base_hi, reinterpret_cast<K128 *>(d_out128));
   return hipGetLastError();
 }
 

@@ -300,10 +300,12 @@ __device__ __forceinline__ u32 hpc_dense_rank(u32 x) {               // x: 2 * H
   return r;
 }
 
-template <int HB>
+template <int HB, int KC = 0>                         // KC: k as a compile-time constant, canonical mode (kmer_partition_kernel)
 __global__ __launch_bounds__(KP_BLOCK * KH_NV)
-void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u64 num_tiles, u32 vgrid,
+void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, int mode_arg, u64 num_tiles, u32 vgrid,
                            u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts, u64 *__restrict__ fine_hist) {
+  const u32 k = KC ? (u32)KC : k_arg;
+  const int mode = KC ? 0 : mode_arg;
   constexpr u32 TABLE = HB ? hpc_table_size(HB) : (1u << KH_FINE_BITS);
   constexpr u32 NBK = HB ? (1u << (2 * (HB - 5))) : 64u;              // buckets: 64 files, or 2^bucket_bits
   constexpr u32 IDX_BITS = HB ? 2u * HB : (u32)KH_FINE_BITS;          // top bits of the k-mer that index the table
@@ -427,13 +429,24 @@ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 
 // SOA (round 4; 8-byte keys whose bits below the file fit 40: k <= 23): a file's region holds its k-mers as a u32 array (low
 // words) followed by a u8 array (bits 32..39) -- 5 bytes per k-mer instead of 8 leave this kernel and enter the file's first
 // grouping pass (radix_group_kernel<SOA>), which only ever needed 36 of the 64 bits (the file is where the k-mer lies).
-// Measured with the debug forms above (profiles/r04j_part_dbg.txt): 8-byte stores cost 10.4 of this kernel's 27.6 ms,
+// Measured with the debug forms of round 4 (profiles/r04j_part_dbg.txt): 8-byte stores cost 10.4 of this kernel's 27.6 ms,
 // 4-byte stores 3.5.  soa_starts / soa_counts: first k-mer and number of k-mers of every file.
-template <typename K, int MAXB, bool SOA = false>
+// SOA with 16-byte keys (round 5; k = 33..51: at most 96 bits below the file): a file's region holds its k-mers as 12-byte K96
+// records (mgc_common.hpp) -- 12 of the 16 bytes leave this kernel and go through both grouping passes and the count.
+// KC (round 5): k as a COMPILE-TIME constant for the k of the BASELINE configs (21, 31, 51), canonical mode, the 64 files, no
+// count-suffix filter -- every shift of the sixteen unrolled window extractions (key_shift, top_shift, the reverse complement's)
+// is then an immediate and the 64-bit (k > 32: 128-bit) variable shifts on a 32-bit ALU go away; KC = 0: k, mode and bucket_bits
+// are the run-time arguments.
+template <typename K, int MAXB, bool SOA = false, int KC = 0>
 __global__ __launch_bounds__(KP_BLOCK, (sizeof(K) == 16) ? 2 : (SOA ? 4 : 5))   // 16-byte keys: the 64 KiB exchange tile allows two workgroups; SOA: no spill, LDS allows four anyway
-void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int mode, u32 bucket_bits,
-                           u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out, u64 sfx_mask, u64 sfx_test,
+void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, int mode_arg, u32 bucket_bits_arg,
+                           u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out, u64 sfx_mask_arg, u64 sfx_test,
                            const u64 *__restrict__ soa_starts = nullptr, const u64 *__restrict__ soa_counts = nullptr) {
+  const u32 k = KC ? (u32)KC : k_arg;
+  const int mode = KC ? 0 : mode_arg;
+  const u32 bucket_bits = KC ? 6u : bucket_bits_arg;
+  const u64 sfx_mask = KC ? 0ull : sfx_mask_arg;
+  static_assert(KC == 0 || MAXB == 64, "the constant-k forms are 64-file forms");
   extern __shared__ __attribute__((aligned(16))) unsigned char kp_dyn_smem[];
   K *s_keys = reinterpret_cast<K *>(kp_dyn_smem);                   // K[KP_TILE]
   __shared__ u64 s_cursor[MAXB];
@@ -458,7 +471,7 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
   __shared__ u64 s_ob[OB ? MAXB : 1], s_ob_hi[SOA ? MAXB : 1];
   static_assert(!SOA || OB, "the 5-byte layout is a 64-file layout");
   if constexpr (SOA) {
-    for (u32 b = tid; b < nb; b += KP_BLOCK) { s_fstart[b] = soa_starts[b]; s_fhi[b] = 8ull * soa_starts[b] + 4ull * soa_counts[b]; }
+    for (u32 b = tid; b < nb; b += KP_BLOCK) { s_fstart[b] = soa_starts[b]; if constexpr (sizeof(K) == 8) s_fhi[b] = 8ull * soa_starts[b] + 4ull * soa_counts[b]; }
   }
 
   u64 t_begin, t_end;
@@ -510,6 +523,9 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
             const u64 rel0 = s_cursor[b] - s_fstart[b] - (u64)run;             // (wraps below zero when run > what lies before: added back with i)
             s_ob[b]    = reinterpret_cast<u64>(out) + 8ull * s_fstart[b] + 4ull * rel0;
             s_ob_hi[b] = reinterpret_cast<u64>(out) + s_fhi[b] + rel0;
+          } else if constexpr (SOA) {                                          // K96 records at the start of the file's 16-byte-per-k-mer region
+            const u64 rel0 = s_cursor[b] - s_fstart[b] - (u64)run;
+            s_ob[b] = reinterpret_cast<u64>(out) + 16ull * s_fstart[b] + 12ull * rel0;
           } else if constexpr (OB) {
             s_ob[b] = reinterpret_cast<u64>(out) + (u64)sizeof(K) * (s_cursor[b] - (u64)run);
           }
@@ -534,6 +550,10 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
         *reinterpret_cast<u32 *>(s_ob[b] + 4ull * i) = (u32)KeyOps<K>::low64(key);
         *reinterpret_cast<uint8_t *>(s_ob_hi[b] + (u64)i) = (uint8_t)(KeyOps<K>::low64(key) >> 32);
       }
+      else if constexpr (SOA) {
+        K96 o; o.w[0] = (u32)key.lo; o.w[1] = (u32)(key.lo >> 32); o.w[2] = (u32)key.hi;
+        *reinterpret_cast<K96 *>(s_ob[b] + 12ull * i) = o;
+      }
       else if constexpr (OB) *reinterpret_cast<K *>(s_ob[b] + (u64)sizeof(K) * i) = key;
       else out[s_cursor[b] + (u64)(i - s_base[b])] = key;
     }
@@ -541,6 +561,13 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k, int 
     for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] += s_cnt[b];
     __syncthreads();
   }
+}
+
+// the constant-k instantiations (KC): canonical counts at the k of the BASELINE configs; MGC_KMER_CONST_K=0: the generic kernels
+static int kmer_const_k(uint32_t k, int mode) {
+  const char *e = getenv("MGC_KMER_CONST_K");                         // read per call: the tests switch it
+  if ((e && e[0] == '0') || mode != 0) return 0;
+  return (k == 21 || k == 31 || k == 51) ? (int)k : 0;
 }
 
 uint32_t kp_grid_size(uint64_t n_bases) {
@@ -589,11 +616,21 @@ hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, 
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(u32) << KH_FINE_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel<0, 21>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(u32) << KH_FINE_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel<0, 31>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(u32) << KH_FINE_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel<0, 51>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(u32) << KH_FINE_BITS));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kmer_hist_fine_kernel<0>, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) << KH_FINE_BITS, st,
-                     d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
-                     reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
+#define MGC_KH_LAUNCH(KC_)                                                                                                             \
+  hipLaunchKernelGGL((kmer_hist_fine_kernel<0, KC_>), dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) << KH_FINE_BITS, st, \
+                     d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),                             \
+                     reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist))
+  const int kc = kmer_const_k(k, mode);
+  if (kc == 21) MGC_KH_LAUNCH(21); else if (kc == 31) MGC_KH_LAUNCH(31); else if (kc == 51) MGC_KH_LAUNCH(51); else MGC_KH_LAUNCH(0);
+#undef MGC_KH_LAUNCH
   return hipGetLastError();
 }
 
@@ -649,21 +686,57 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_partition_kernel<K128, KP_MAX_BUCKETS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_partition_kernel<K128, 64, false, 51>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
     attr_done = true;
   }
 #define MGC_KP_LAUNCH(K_, MAXB_)                                                                                   \
   hipLaunchKernelGGL((kmer_partition_kernel<K_, MAXB_>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K_), st,      \
                      d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,                                  \
                      reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys), (u64)sfx_mask, (u64)sfx_test)
-  if (d_soa_counts) {                                                 // 5-byte layout (kmer_partition_soa_ok)
-    if (!(k <= 32 && nb == 64 && sfx_mask == 0)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, true>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
-                       bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)0, (u64)0,
-                       reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
+  if (d_soa_counts && k > 32) {                                       // K96 records (k = 33..51)
+    if (!(k <= 51 && nb == 64 && sfx_mask == 0)) return hipErrorInvalidValue;
+    static bool a96 = false;
+    if (!a96) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_partition_kernel<K128, 64, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_partition_kernel<K128, 64, true, 51>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
+      a96 = true;
+    }
+    if (kmer_const_k(k, mode) == 51)
+      hipLaunchKernelGGL((kmer_partition_kernel<K128, 64, true, 51>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K128), st, d_bases, (u64)n_bases, k, mode,
+                         bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K128 *>(d_keys), (u64)0, (u64)0,
+                         reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
+    else
+      hipLaunchKernelGGL((kmer_partition_kernel<K128, 64, true>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K128), st, d_bases, (u64)n_bases, k, mode,
+                         bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K128 *>(d_keys), (u64)0, (u64)0,
+                         reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
     return hipGetLastError();
   }
-  if (k <= 32) { if (nb <= 64) MGC_KP_LAUNCH(u64, 64); else MGC_KP_LAUNCH(u64, KP_MAX_BUCKETS); }
-  else         { if (nb <= 64) MGC_KP_LAUNCH(K128, 64); else MGC_KP_LAUNCH(K128, KP_MAX_BUCKETS); }
+  if (d_soa_counts) {                                                 // 5-byte layout (kmer_partition_soa_ok)
+    if (!(k <= 32 && nb == 64 && sfx_mask == 0)) return hipErrorInvalidValue;
+    if (kmer_const_k(k, mode) == 21)
+      hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, true, 21>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
+                         bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)0, (u64)0,
+                         reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
+    else
+      hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, true>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
+                         bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)0, (u64)0,
+                         reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
+    return hipGetLastError();
+  }
+#define MGC_KPC_LAUNCH(K_, KC_)                                                                                    \
+  hipLaunchKernelGGL((kmer_partition_kernel<K_, 64, false, KC_>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K_), st, \
+                     d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,                                  \
+                     reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys), (u64)0, (u64)0)
+  const int kc = (nb == 64 && sfx_mask == 0) ? kmer_const_k(k, mode) : 0;
+  if (kc == 21)      MGC_KPC_LAUNCH(u64, 21);
+  else if (kc == 31) MGC_KPC_LAUNCH(u64, 31);
+  else if (kc == 51) MGC_KPC_LAUNCH(K128, 51);
+  else if (k <= 32) { if (nb <= 64) MGC_KP_LAUNCH(u64, 64); else MGC_KP_LAUNCH(u64, KP_MAX_BUCKETS); }
+  else              { if (nb <= 64) MGC_KP_LAUNCH(K128, 64); else MGC_KP_LAUNCH(K128, KP_MAX_BUCKETS); }
+#undef MGC_KPC_LAUNCH
 #undef MGC_KP_LAUNCH
   return hipGetLastError();
 }

@@ -474,7 +474,8 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
   // the CU's own memory pipeline, by INSTRUCTION -- with 4-byte loads of 32-bit words the look-back took 45 K cycles per tile
   // instead of 17 K (profiles/r02x_groupdbg.log).  Key j of a thread is element idx_of(j) of the tile; order inside a tile is free.
   static_assert(!SOA || (sizeof(K) == 8 && KPT % 4 == 0), "the 5-byte layout holds 8-byte keys");
-  constexpr int VEC = SOA ? 4 : ((sizeof(K) < 16 && KPT % (16 / sizeof(K)) == 0) ? (int)(16 / sizeof(K)) : 1);
+  // (12-byte K96 records: four per lane and group = three 16-byte loads)
+  constexpr int VEC = SOA ? 4 : (sizeof(K) == 12 ? (KPT % 4 == 0 ? 4 : 1) : ((sizeof(K) < 16 && KPT % (16 / sizeof(K)) == 0) ? (int)(16 / sizeof(K)) : 1));
   struct __attribute__((aligned(4))) KVec { K v[VEC]; };     // 4-byte alignment is all a file / region start guarantees
   auto idx_of = [&](int j) __attribute__((always_inline)) -> u32 {
     return w * (u32)(64 * KPT) + ((u32)(j / VEC) * 64u + lane) * (u32)VEC + (u32)(j % VEC);
@@ -1166,8 +1167,11 @@ static hipError_t group_wide(void *d_keys, void *d_alt, uint64_t n, const SortPl
 
 hipError_t launch_group_wide(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan, uint32_t *d_error,
                              uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events, void *d_prepared, void *d_scratch,
-                             uint32_t *tr_a, uint32_t *tr_b) {
+                             uint32_t *tr_a, uint32_t *tr_b, bool k96) {
   if (!sort_plan_wide_msd(plan, n) || !d_prepared || !d_scratch) return hipErrorInvalidValue;
+  // 12-byte K96 records (k = 33..51, the bits below the file): 12288-key tiles (144 KiB of LDS)
+  if (k96) return key_words == 2 ? group_wide<K96, 12>(d_keys, d_alt, n, plan, d_error, d_sub_starts, st, pass_events, d_prepared, d_scratch, tr_a, tr_b)
+                                 : hipErrorInvalidValue;
   if (key_words == 2) return group_wide<K128, 8>(d_keys, d_alt, n, plan, d_error, d_sub_starts, st, pass_events, d_prepared, d_scratch, tr_a, tr_b);
   return group_wide<u64, 16>(d_keys, d_alt, n, plan, d_error, d_sub_starts, st, pass_events, d_prepared, d_scratch, tr_a, tr_b);
 }
