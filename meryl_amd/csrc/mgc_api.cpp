@@ -1030,7 +1030,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
 
   // ---- pass 1: per-file histogram ----
   HIP_TRY(s, s->ensure(mgc_session::B_PART_WS, mgc::kp_workspace_bytes(bucket_bits)));
-  HIP_TRY(s, s->ensure(mgc_session::B_META, sizeof(uint64_t) * nb * 2));
+  HIP_TRY(s, s->ensure(mgc_session::B_META, sizeof(uint64_t) * nb * 3));        // counts, starts, per-file K96 flags
   void *part_ws = s->buf[mgc_session::B_PART_WS].p;
   uint64_t *d_counts64 = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_META].p), *d_starts = d_counts64 + nb;
   std::vector<uint64_t> h_counts_v(nb), h_starts_v(nb + 1);
@@ -1097,13 +1097,16 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   // The partition is launched once the plan of the files is known (below): when every file takes the narrowed passes its
   // k-mers leave as 5 bytes (u32 + u8 per file) instead of 8 -- the file's first grouping pass puts them together again.
   bool partition_done = false;
-  auto run_partition = [&](bool soa) -> int {
+  std::vector<uint64_t> h_k96flags(nb, 0);                   // (lives until the partition's copy has been issued and the stream synchronised)
+  auto run_partition = [&](bool soa, bool k96 = false) -> int {
     if (ext_keys || partition_done) return MGC_OK;
     partition_done = true;
     HIP_TRY(s, hipMemcpyAsync(d_starts, h_starts, sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
+    uint64_t *d_k96flags = d_starts + nb;
+    if (k96) HIP_TRY(s, hipMemcpyAsync(d_k96flags, h_k96flags.data(), sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
     tm.begin(MGC_STAGE_PARTITION);
     HIP_TRY(s, mgc::launch_kmer_partition(d_bases, n_bases, k, c.mode, bucket_bits, d_starts, (void *)X, part_ws, st,
-                                          s->sfx_mask, s->sfx_test, soa ? d_counts64 : nullptr));
+                                          s->sfx_mask, s->sfx_test, k96 ? d_k96flags : (soa ? d_counts64 : nullptr)));
     tm.end(MGC_STAGE_PARTITION);
     s->prof.stage_launches[MGC_STAGE_PARTITION] = 2;
     return MGC_OK;
@@ -1261,9 +1264,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       // (mgc_common.hpp K96; the region of a file stays 16 bytes per k-mer, so a file can be widened back in place).  MGC_K96=0: whole keys.
       const char *k96e = getenv("MGC_K96");                           // read per call: the tests switch it
       bool k96 = !(k96e && k96e[0] == '0') && !ext_keys && kw == 2 && nb == 64 && d_fine && rem_bits <= 96 && s->sfx_mask == 0 && !c.homopoly_compress;
-      for (uint32_t b = 0; b < nb && k96; b++) if (h_counts[b] && !(wide_msd[b] && top_bits[b])) k96 = false;
-      if (k96) for (uint32_t b = 0; b < nb; b++) file_k96[b] = h_counts[b] != 0;
-      const int prc = run_partition(soa || k96);
+      bool any96 = false;                                             // per file: the ones on the two-digit whole-key passes (a small file keeps 16-byte keys)
+      for (uint32_t b = 0; b < nb && k96; b++) if (h_counts[b] && wide_msd[b] && top_bits[b]) { file_k96[b] = 1; h_k96flags[b] = 1; any96 = true; }
+      const int prc = run_partition(soa, k96 && any96);
       if (prc != MGC_OK) return prc;
     }
     // Where the counts of a file's distinct k-mers wait for the packing step (one uint32 per k-mer instance position).  A NARROWED

@@ -431,8 +431,9 @@ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 
 // grouping pass (radix_group_kernel<SOA>), which only ever needed 36 of the 64 bits (the file is where the k-mer lies).
 // Measured with the debug forms of round 4 (profiles/r04j_part_dbg.txt): 8-byte stores cost 10.4 of this kernel's 27.6 ms,
 // 4-byte stores 3.5.  soa_starts / soa_counts: first k-mer and number of k-mers of every file.
-// SOA with 16-byte keys (round 5; k = 33..51: at most 96 bits below the file): a file's region holds its k-mers as 12-byte K96
-// records (mgc_common.hpp) -- 12 of the 16 bytes leave this kernel and go through both grouping passes and the count.
+// SOA with 16-byte keys (round 5; k = 33..51: at most 96 bits below the file): the region of a file f with soa_counts[f] != 0 (a
+// per-file FLAG here, not a count) holds its k-mers as 12-byte K96 records (mgc_common.hpp) -- 12 of the 16 bytes leave this kernel
+// and go through both grouping passes and the count; the other files (too small for two grouping digits) keep 16-byte keys.
 // KC (round 5): k as a COMPILE-TIME constant for the k of the BASELINE configs (21, 31, 51), canonical mode, the 64 files, no
 // count-suffix filter -- every shift of the sixteen unrolled window extractions (key_shift, top_shift, the reverse complement's)
 // is then an immediate and the 64-bit (k > 32: 128-bit) variable shifts on a 32-bit ALU go away; KC = 0: k, mode and bucket_bits
@@ -471,7 +472,11 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
   __shared__ u64 s_ob[OB ? MAXB : 1], s_ob_hi[SOA ? MAXB : 1];
   static_assert(!SOA || OB, "the 5-byte layout is a 64-file layout");
   if constexpr (SOA) {
-    for (u32 b = tid; b < nb; b += KP_BLOCK) { s_fstart[b] = soa_starts[b]; if constexpr (sizeof(K) == 8) s_fhi[b] = 8ull * soa_starts[b] + 4ull * soa_counts[b]; }
+    for (u32 b = tid; b < nb; b += KP_BLOCK) {
+      s_fstart[b] = soa_starts[b];
+      if constexpr (sizeof(K) == 8) s_fhi[b] = 8ull * soa_starts[b] + 4ull * soa_counts[b];
+      else                          s_fhi[b] = soa_counts[b];                  // K96 flag of the file
+    }
   }
 
   u64 t_begin, t_end;
@@ -525,7 +530,8 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
             s_ob_hi[b] = reinterpret_cast<u64>(out) + s_fhi[b] + rel0;
           } else if constexpr (SOA) {                                          // K96 records at the start of the file's 16-byte-per-k-mer region
             const u64 rel0 = s_cursor[b] - s_fstart[b] - (u64)run;
-            s_ob[b] = reinterpret_cast<u64>(out) + 16ull * s_fstart[b] + 12ull * rel0;
+            // (bit 0 of the address word carries the file's K96 flag: one LDS read per store, as in the other layouts)
+            s_ob[b] = (reinterpret_cast<u64>(out) + 16ull * s_fstart[b] + (s_fhi[b] ? 12ull : 16ull) * rel0) | (s_fhi[b] ? 1ull : 0ull);
           } else if constexpr (OB) {
             s_ob[b] = reinterpret_cast<u64>(out) + (u64)sizeof(K) * (s_cursor[b] - (u64)run);
           }
@@ -551,8 +557,13 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
         *reinterpret_cast<uint8_t *>(s_ob_hi[b] + (u64)i) = (uint8_t)(KeyOps<K>::low64(key) >> 32);
       }
       else if constexpr (SOA) {
+        // the low twelve bytes are the same in both layouts; a 16-byte file's k-mer gets its top word too
+        const u64 ob = s_ob[b];
+        const bool f96 = (ob & 1ull) != 0;
+        const u64 addr = (ob & ~1ull) + (u64)(f96 ? 12u : 16u) * i;
         K96 o; o.w[0] = (u32)key.lo; o.w[1] = (u32)(key.lo >> 32); o.w[2] = (u32)key.hi;
-        *reinterpret_cast<K96 *>(s_ob[b] + 12ull * i) = o;
+        *reinterpret_cast<K96 *>(addr) = o;
+        if (!f96) *reinterpret_cast<u32 *>(addr + 12ull) = (u32)(key.hi >> 32);
       }
       else if constexpr (OB) *reinterpret_cast<K *>(s_ob[b] + (u64)sizeof(K) * i) = key;
       else out[s_cursor[b] + (u64)(i - s_base[b])] = key;

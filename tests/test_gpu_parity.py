@@ -1532,6 +1532,50 @@ def test_config4_shape_spills_through_real_host_runs(ops, oracle_lib, torch_cuda
     assert np.array_equal(got, want)
 
 
+def test_config5_shape_spills_through_real_host_runs(ops, oracle_lib, torch_cuda, tmp_path):
+    """BASELINE config 5's mechanics with the DEFAULT budgets -- k = 51 with an 8-bit constant value label, 150 bp
+    reads, 3 Gbp counted in five batches (12-byte K96 records below the file on the way: this size takes two grouping digits)
+    whose results (16-byte k-mers + counts) leave HBM for pinned host DRAM once 1.5 GB of them are parked there; the labelled
+    out-of-core database is compared file by file (digests of the decoded k-mers, every label) with the threaded port run on
+    the same bytes.  The counterpart of test_config4_shape_spills_through_real_host_runs; needs ~50 GB of host memory."""
+    import psutil
+    from meryl_amd import capi, db
+    n_reads = int(os.environ.get("MGC_TEST_OOC51_READS", "20000000"))                  # x 150 bp = 3 Gbp
+    if psutil.virtual_memory().available < (70 << 30) * n_reads / 20000000:
+        pytest.skip("not enough host memory for the port at this size")
+    k, label = 51, 0xA5
+    d = ops.dev_synth_reads(55, 100_000_000, 0, n_reads)
+    cfg = capi.configure(k, d.numel(), 64 << 30, label_size=8, label=label)
+    out = str(tmp_path / "ooc51.meryl")
+    with ops.Session(cfg) as s:
+        s.set_batch_bases(d.numel() // 5 + 1)                      # five batches
+        s.set_result_budget(3 << 29)                               # 1.5 GB of batch results may stay in HBM: the later ones really leave it
+        raw = d.cpu().numpy()
+        step = 1 << 28
+        for a in range(0, raw.size, step):                          # (host pushes: a device buffer is the only input of its session)
+            s.push_bases(raw[a:a + step].tobytes(), end_of_sequence=False)
+        s.count()
+        assert s.out_of_core() and s.profile().n_batches >= 5
+        info = s.info()
+        db.write_database(s, out, host_threads=16)
+        rp = s.runs_profile()
+        assert rp["n_host_runs"] >= 2 and rp["n_runs"] >= 5 and rp["host_bytes"] > (1 << 30)   # gigabytes REALLY spilled to pinned host DRAM
+        nd = s.info().n_distinct
+    del d
+    torch_cuda.cuda.empty_cache()
+    want, wnd, wni = oracle_lib.digest_threaded(raw, k, cfg.w_prefix, threads=16)
+    assert (wnd, wni) == (nd, info.n_instances)
+    r = db.Reader(out)
+    assert r.info.label_size == 8
+    got = np.zeros((64, 4), dtype=np.uint64)
+    for f in range(64):
+        lo, hi, cn, lb = r.read_file(f, labels=True)
+        got[f] = oracle_lib.digest_arrays(lo, hi, cn, k)[f]
+        assert lb.size == lo.size and bool(np.all(lb == label)), "labels of file %d" % f
+    r.close()
+    assert np.array_equal(got, want)
+
+
 def _dir_bytes(path):
     import os
     return {n: open(os.path.join(path, n), "rb").read() for n in sorted(os.listdir(path))}
