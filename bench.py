@@ -287,11 +287,13 @@ def e2e_run(bases, reads, threads, gpus=1):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def pmc_traffic(reads, prefix):
-    """HBM bytes per launch of a kernel (name prefix) from the committed PMC run of this same workload
-    (profiles/*_pmc_traffic.json, made by scripts/gpu_final.sh: FETCH_SIZE and WRITE_SIZE in separate
-    rocprofv3 passes, calibrated on known-byte kernels of the same access width); None for any other workload --
-    counters cannot be collected from inside this process."""
+def pmc_traffic(reads, prefix, also=()):
+    """HBM bytes per launch of a kernel from the committed PMC run of this same workload (profiles/*_pmc_traffic.json, made by
+    scripts/gpu_final.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, calibrated on known-byte kernels of the same
+    access width); None for any other workload -- counters cannot be collected from inside this process.
+    The mean over ALL instantiations whose name starts with `prefix`, weighted by their launches (so that it describes the same
+    launches as algorithmic_bytes_per_launch: VERDICT r4 item 9); `also`: further name prefixes whose bytes belong to the same
+    launch of the library (the retry / streaming kernels of a file's count) -- added to the numerator only."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
@@ -300,9 +302,19 @@ def pmc_traffic(reads, prefix):
             continue
         if d.get("reads_per_gpu") != reads:
             continue
+        total, launches, names = 0.0, 0, []
         for name, v in d.get("all_kernels", {}).items():
-            if name.startswith(prefix) and v.get("fetch_bytes_per_launch") is not None and v.get("write_bytes_per_launch") is not None:
-                return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], "profiles/" + os.path.basename(f) + " (" + name[:60] + ")"
+            if v.get("fetch_bytes_per_launch") is None or v.get("write_bytes_per_launch") is None or not v.get("launches"):
+                continue
+            if name.startswith(prefix):
+                total += (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
+                launches += v["launches"]
+                names.append(name[:48])
+            elif any(name.startswith(a) for a in also):
+                total += (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
+        if launches:
+            return total / launches, "profiles/%s (launch-weighted mean of %d instantiation%s: %s)" % (
+                os.path.basename(f), len(names), "" if len(names) == 1 else "s", "; ".join(names))
     return None, None
 
 
@@ -348,7 +360,7 @@ def roofline_object(prof_acc, ms_per_step, steps, reads, single, where):
         # The kernel with the largest share of the step's KERNEL time: the sub-bucket count (hash_count_multi_kernel since round 4).  Two launches run
         # side by side on alternating streams, so the launches' own durations add up to more than the stage's wall clock.
         achieved = fin["bytes"] / (fin["ms"] / 1e3) / 1e9
-        t, src = pmc_traffic(reads, "hash_count_multi_kernel") if single else (None, None)
+        t, src = pmc_traffic(reads, "hash_count_multi_kernel", also=("hash_count_kernel", "hash_count_huge_kernel")) if single else (None, None)
         out = {
             "kernel": "hash_count_multi_kernel / hash_count_kernel (sub-bucket count: 4 B narrowed keys in, distinct 4 B suffixes + 4 B counts out), one launch per file",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -187,6 +187,7 @@ extern "C" int mgc_dev_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_
   if (!d_keys || !d_alt || !d_ws || ws_bytes < mgc::sort_workspace_bytes(n) + 256) return MGC_EINVAL;
   mgc::SortPlan plan;
   mgc::make_sort_plan(begin_bit, end_bit, &plan);
+  if (const char *sm = getenv("MGC_SORT_MODE")) if (atoi(sm) == 3) plan.mode = 3;      // tests reach the grouping passes through this bare operator
   // the last 256 bytes of the workspace hold the look-back error word
   uint32_t *d_err = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_ws) + mgc::sort_workspace_bytes(n));
   hipStream_t st = (hipStream_t)stream;
@@ -396,6 +397,7 @@ extern "C" mgc_session *mgc_open(const mgc_count_config *cfg, int device) {
   memset(&s->prof, 0, sizeof(s->prof));
   memset(s->file_instances, 0, sizeof(s->file_instances));
   memset(s->total_file_instances, 0, sizeof(s->total_file_instances));
+  s->sw = mgc::read_switches();                              // the environment is read here, once per session
   return s;
 }
 
@@ -796,10 +798,8 @@ static int push_text_file_range(mgc_session *s, const char *path, int format, in
   // slots are allocated by the readers themselves, in parallel, on first use, and stay with the session for the next file.
   constexpr int RMAX = mgc_session::TEXT_RING_MAX;
   if (reader_threads <= 0) reader_threads = 16;
-  if (const char *e = getenv("MGC_TEXT_READERS")) reader_threads = atoi(e);
   reader_threads = std::max(1, std::min(reader_threads, RMAX - 8));
   int R = reader_threads + 8;                               // up to R-2 chunks of read-ahead
-  if (const char *e = getenv("MGC_TEXT_RING")) R = std::max(4, std::min(RMAX, atoi(e)));
   const size_t CH = mgc_session::TEXT_CHUNK;
   const uint64_t nchunks = (size + CH - 1) / CH;
   reader_threads = (int)std::min<uint64_t>((uint64_t)std::max(1, std::min(reader_threads, R - 2)), nchunks ? nchunks : 1);
@@ -989,6 +989,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   HIP_TRY(s, hipSetDevice(s->device));
   hipStream_t st = s->stream;
   const mgc_count_config &c = s->cfg;
+  const mgc::Switches &sw = s->sw;
   const uint32_t k = c.k;
   // buckets = the 64 files, or (sharded owner side) finer top-bit ranges of the k-mer: 2^bucket_bits of them
   // The session's own partition uses the files while a file stays within what two grouping digits cover
@@ -996,10 +997,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   // of buckets either way.
   uint32_t bucket_bits = ext_keys ? ext_bucket_bits : (uint32_t)MGC_NUM_FILES_BITS;
   if (!ext_keys) {
-    const char *pb = getenv("MGC_BUCKET_BASES");                      // tests force finer buckets on small inputs
     // `compress`: two dense-rank digits cover 3^10 sub-buckets (below), i.e. buckets of up to 68 M k-mers, and the digits
     // are whole bases, so the buckets get finer two bits at a time
-    const uint64_t per_bucket = (pb && *pb) ? strtoull(pb, nullptr, 10) : (c.homopoly_compress ? 60000000ull : 180000000ull);
+    const uint64_t per_bucket = sw.bucket_bases ? sw.bucket_bases /* tests force finer buckets on small inputs */ : (c.homopoly_compress ? 60000000ull : 180000000ull);
     const uint32_t step = c.homopoly_compress ? 2u : 1u;
     while (bucket_bits + step <= MGC_MAX_BUCKET_BITS && bucket_bits + step <= 2 * c.k && (s->n_bases >> bucket_bits) > per_bucket) bucket_bits += step;
   }
@@ -1045,15 +1045,14 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     // (two digits cover at most 18 bits: beyond 2k - 6 = 41 nothing narrows -- the files' WHOLE keys then take the same
     // high-digit-first passes, mgc::launch_group_wide, 16-byte keys included; MGC_WIDE_MSD=0: low digit first off a histogram
     // read of the keys, as `compress` always does: its digits are dense ranks)
-    const char *wme = getenv("MGC_WIDE_MSD");                        // read per call: the tests switch it
-    const bool wide_msd_on = !(wme && wme[0] == '0') && !c.homopoly_compress;
-    if (n_bases >= (1u << 22) && ((kw == 1 && 2 * k - bucket_bits <= 41) || wide_msd_on) && mgc::kmer_histogram_fine_ok(k, bucket_bits, s->sfx_mask)) {
+    const bool wide_msd_on = sw.wide_msd && !c.homopoly_compress;
+    if (n_bases >= (1u << 22) && ((kw == 1 && 2 * k - bucket_bits <= 41) || wide_msd_on) && mgc::kmer_histogram_fine_ok(k, bucket_bits, s->sfx_mask, sw)) {
       HIP_TRY(s, s->ensure(mgc_session::B_FINE, sizeof(uint64_t) << 15));
       uint64_t *fine = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_FINE].p);
-      HIP_TRY(s, mgc::launch_kmer_histogram_fine(d_bases, n_bases, k, c.mode, d_counts64, fine, part_ws, st));
+      HIP_TRY(s, mgc::launch_kmer_histogram_fine(d_bases, n_bases, k, c.mode, d_counts64, fine, part_ws, st, sw.const_k));
       d_fine = fine;
     } else if (c.homopoly_compress && n_bases >= (1u << 22) && (2 * k - bucket_bits) % 2 == 0 && 2 * k - bucket_bits >= 20 &&
-               !(getenv("MGC_HPC_DIGITS") && getenv("MGC_HPC_DIGITS")[0] == '0') && mgc::kmer_histogram_hpc_ok(k, bucket_bits, s->sfx_mask)) {
+               sw.hpc_digits && mgc::kmer_histogram_hpc_ok(k, bucket_bits, s->sfx_mask, sw)) {
       // `compress`: k-mers per (bucket, dense-rank digit below it) -- the buckets' high digit goes first as well (MGC_HPC_MSD=0: off)
       HIP_TRY(s, s->ensure(mgc_session::B_FINE, sizeof(uint64_t) * std::max<size_t>((size_t)1 << 15, mgc::kmer_histogram_hpc_entries(bucket_bits))));
       uint64_t *fine = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_FINE].p);
@@ -1085,8 +1084,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   //                     every sub-bucket in LDS with the run-length count fused in (mgc_finish.hip);
   //   full   (MGC_FINISH=0, and the fallback for files with an oversized sub-bucket): LSB-sort all 2k-6
   //                     bits globally, then the separate run-length kernels.
-  const char *fin_env = getenv("MGC_FINISH");
-  const bool use_finish = !(fin_env && fin_env[0] == '0');
+  const bool use_finish = sw.finish;
   mgc::SortPlan plan;
   mgc::make_sort_plan(0, 2 * k - bucket_bits, &plan);
   const bool odd = !use_finish && (plan.num_passes & 1u) != 0;
@@ -1106,7 +1104,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     if (k96) HIP_TRY(s, hipMemcpyAsync(d_k96flags, h_k96flags.data(), sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
     tm.begin(MGC_STAGE_PARTITION);
     HIP_TRY(s, mgc::launch_kmer_partition(d_bases, n_bases, k, c.mode, bucket_bits, d_starts, (void *)X, part_ws, st,
-                                          s->sfx_mask, s->sfx_test, k96 ? d_k96flags : (soa ? d_counts64 : nullptr)));
+                                          s->sfx_mask, s->sfx_test, k96 ? d_k96flags : (soa ? d_counts64 : nullptr), sw.const_k));
     tm.end(MGC_STAGE_PARTITION);
     s->prof.stage_launches[MGC_STAGE_PARTITION] = 2;
     return MGC_OK;
@@ -1167,7 +1165,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     s->prof.stage_launches[MGC_STAGE_RLE] = 3;
   } else {
     // ---- plan: per file, t top bits so that a sub-bucket holds ~target k-mers ----
-    const uint64_t target = mgc::finish_target_for(kw), cap = mgc::finish_capacity_for(kw);
+    const uint64_t target = mgc::finish_target_for(kw, sw), cap = mgc::finish_capacity_for(kw);
     std::vector<uint32_t> top_bits(nb);
     std::vector<char> hpc_digits(nb, 0);
     std::vector<uint64_t> gbase(nb + 1), sbase(nb + 1);
@@ -1175,8 +1173,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     // `compress`: the grouping digits are dense ranks of five homopolymer-free bases (make_hpc_group_plan): 10 key bits
     // hold 243 patterns, 20 bits 59049.  Needs the remaining bits to be whole bases (the 64 files, or an even number of
     // bucket bits) and the bucket to fit 59049 sub-buckets; otherwise the generic bit digits below (MGC_HPC_DIGITS=0: always).
-    static const bool hpc_on = !(getenv("MGC_HPC_DIGITS") && getenv("MGC_HPC_DIGITS")[0] == '0');
-    const bool hpc_ok = hpc_on && c.homopoly_compress && (rem_bits % 2 == 0) && bucket_bits >= 2;
+    const bool hpc_ok = sw.hpc_digits && c.homopoly_compress && (rem_bits % 2 == 0) && bucket_bits >= 2;
     for (uint32_t b = 0; b < nb; b++) {
       uint32_t t = 0;
       if (hpc_ok && h_counts[b] > target) {                            // sub-buckets average `target` k-mers or fewer
@@ -1187,7 +1184,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (!hpc_digits[b]) {
         while (t < rem_bits && t < 26 && (h_counts[b] >> t) > target) t++;
         // tests reach the large-input plans (two nine-bit digits, 18-bit suffixes at k = 21) on small inputs
-        if (const char *mt = getenv("MGC_FINISH_MIN_TOP")) { const uint32_t m = (uint32_t)atoi(mt); if (h_counts[b] && t < m) t = m < rem_bits ? m : rem_bits; }
+        if (sw.min_top) { const uint32_t m = sw.min_top; if (h_counts[b] && t < m) t = m < rem_bits ? m : rem_bits; }
       }
       if (c.homopoly_compress && t && !hpc_digits[b]) {
         // homopolymer-compressed sequence never repeats a base: every 2-bit group after the first takes 3 of its 4
@@ -1240,30 +1237,28 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         // (sub-bucket numbers made of dense ranks are no key bits: the kernels that put a k-mer's top bits back from its sub-bucket
         // number -- 32-bit suffixes -- stay with the low digit first)
         wide_msd[b] = d_fine_hpc && nb <= 256 && top_bits[b] == 20 && (kw == 2 || rem_bits - top_bits[b] >= 32) &&
-                      mgc::finish_can_stream(kw, rem_bits - top_bits[b]) && mgc::sort_plan_wide_msd(fplan[b], h_counts[b]);
+                      mgc::finish_can_stream(kw, rem_bits - top_bits[b]) && mgc::sort_plan_wide_msd(fplan[b], h_counts[b], sw.wide_msd);
         continue;
       }
       mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fplan[b]);
       if (fplan[b].mode == 0) fplan[b].mode = 3;
       const uint32_t low = rem_bits - top_bits[b];
-      narrow[b] = low < 32 && mgc::finish_can_stream(kw, low) && mgc::sort_plan_narrows(fplan[b], h_counts[b], kw);
+      narrow[b] = low < 32 && mgc::finish_can_stream(kw, low) && mgc::sort_plan_narrows(fplan[b], h_counts[b], kw, sw.narrow);
       // (only the hash-count kernels translate the sub-bucket numbers of whole keys)
       wide_msd[b] = !narrow[b] && d_fine && nb <= 64 && mgc::finish_can_stream(kw, low) &&
-                    mgc::sort_plan_wide_msd(fplan[b], h_counts[b]);
+                    mgc::sort_plan_wide_msd(fplan[b], h_counts[b], sw.wide_msd);
     }
     {
       // 5-byte layout: 8-byte keys with 33..40 bits below the file (k = 20..23), every non-empty file on the narrowed passes with
       // the high digit first off the fifteen-bit histogram (the instrumented instantiation reads whole keys).  MGC_SOA5=0: whole keys.
-      const char *se = getenv("MGC_SOA5");                            // read per call: the tests switch it
-      bool soa = !(se && se[0] == '0') && !ext_keys && kw == 1 && nb == 64 && d_fine && rem_bits > 32 && rem_bits <= 40 && s->sfx_mask == 0 &&
-                 !getenv("MGC_GROUP_DBG");
+      bool soa = sw.soa5 && !ext_keys && kw == 1 && nb == 64 && d_fine && rem_bits > 32 && rem_bits <= 40 && s->sfx_mask == 0 &&
+                 !sw.group_dbg;
       for (uint32_t b = 0; b < nb && soa; b++) if (h_counts[b] && !(narrow[b] && top_bits[b])) soa = false;
       if (soa) soa_hi_mask = (1u << (rem_bits - 32)) - 1u;
       // K96 records (round 5): 16-byte keys with at most 96 bits below the file (k = 33..51), every non-empty file on the whole-key
       // high-digit-first passes: 12 of the 16 bytes leave the partition, go through both passes and into the count kernel
       // (mgc_common.hpp K96; the region of a file stays 16 bytes per k-mer, so a file can be widened back in place).  MGC_K96=0: whole keys.
-      const char *k96e = getenv("MGC_K96");                           // read per call: the tests switch it
-      bool k96 = !(k96e && k96e[0] == '0') && !ext_keys && kw == 2 && nb == 64 && d_fine && rem_bits <= 96 && s->sfx_mask == 0 && !c.homopoly_compress;
+      bool k96 = sw.k96 && !ext_keys && kw == 2 && nb == 64 && d_fine && rem_bits <= 96 && s->sfx_mask == 0 && !c.homopoly_compress;
       bool any96 = false;                                             // per file: the ones on the two-digit whole-key passes (a small file keeps 16-byte keys)
       for (uint32_t b = 0; b < nb && k96; b++) if (h_counts[b] && wide_msd[b] && top_bits[b]) { file_k96[b] = 1; h_k96flags[b] = 1; any96 = true; }
       const int prc = run_partition(soa, k96 && any96);
@@ -1350,7 +1345,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       } else if (narrow[b]) {                                // X (8 B) -> Y (4 B) -> front of X (4 B); boundaries included
         HIP_TRY(s, mgc::launch_group_narrow(src, (void *)Y, h_counts[b], fp, sort_ws, sort_ws_bytes - 256, d_err, d_substart + sbase[b], st, pe,
                                             d_nhdrs ? (void *)(d_nhdrs + hdr_bytes * b) : nullptr, d_nws ? (void *)(d_nws + nws_off[b]) : nullptr,
-                                            &tr_a[b], &tr_b[b], soa_hi_mask));
+                                            &tr_a[b], &tr_b[b], soa_hi_mask, sw.group_dbg));
         file_passes[b] = 2;
         narrowed[b] = 1;
         sort_launch_groups++;
@@ -1410,7 +1405,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     const bool alt_files = fork_huge;
     bool forked = false, need_join = false;          // forked: stream2 is ordered after everything st holds that it must see
     // tests run the dense-grid instantiations of the count kernels on small inputs (whose 2^t grids are mostly empty)
-    const bool finish_nolist = getenv("MGC_FINISH_NOLIST") && getenv("MGC_FINISH_NOLIST")[0] == '1';
+    const bool finish_nolist = sw.nolist;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> fin_ev;       // profiling: around every file's count-kernel launch
     uint64_t fin_keys = 0, fin_in_bytes = 0;
     bool fin_narrow = false;
@@ -1425,20 +1420,20 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       // space) are streamed through a large hash table, in several suffix ranges if their distinct k-mers do not fit at once.
       // Only a gigantic one is asked about first (one pass must do), before anything touches the file
       bool stream = mgc::finish_can_stream(kw, low) && h_nlarge[b] > 0;
-      if (stream && h_maxsub[b] > mgc::finish_stream_max() && kw == 2) {
+      if (stream && h_maxsub[b] > sw.stream_max && kw == 2) {
         stream = false;                                 // no probe for 16-byte keys: a sub-bucket that large takes the sort
-      } else if (stream && h_maxsub[b] > mgc::finish_stream_max()) {
+      } else if (stream && h_maxsub[b] > sw.stream_max) {
         uint32_t h_fail[3] = {0, 0, 0};                 // [0] answer, [2] most distinct suffixes met (diagnostics)
         HIP_TRY(s, hipMemsetAsync(d_err + 4, 0, 12, st));
-        HIP_TRY(s, mgc::launch_finish_probe(seg, kw, d_substart + sbase[b], low, h_nlarge[b], d_large + gbase[b], d_err + 4, st, narrow[b] != 0));
+        HIP_TRY(s, mgc::launch_finish_probe(seg, kw, d_substart + sbase[b], low, h_nlarge[b], d_large + gbase[b], d_err + 4, st, sw.stream_max, narrow[b] != 0));
         HIP_TRY(s, hipMemcpyAsync(h_fail, d_err + 4, 12, hipMemcpyDeviceToHost, st));
         HIP_TRY(s, hipStreamSynchronize(st));
         stream = (h_fail[0] == 0);
-        if (getenv("MGC_FINISH_TRACE"))
+        if (sw.finish_trace)
           fprintf(stderr, "[finish] bucket %u: largest sub-bucket %llu > %llu, up to %u distinct in one: %s\n", b,
-                  (unsigned long long)h_maxsub[b], (unsigned long long)mgc::finish_stream_max(), h_fail[2],
+                  (unsigned long long)h_maxsub[b], (unsigned long long)sw.stream_max, h_fail[2],
                   stream ? "streamed through the hash tables" : "too many distinct: stable-sort fallback");
-      } else if (getenv("MGC_FINISH_TRACE") && h_maxsub[b] > cap) {
+      } else if (sw.finish_trace && h_maxsub[b] > cap) {
         fprintf(stderr, "[finish] bucket %u: largest sub-bucket %llu > %llu: %s\n", b, (unsigned long long)h_maxsub[b],
                 (unsigned long long)cap, stream ? "streamed through the hash tables" : "stable-sort fallback");
       }
@@ -1491,7 +1486,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
                                            // the list pays off only when a good part of the 2^t grid is empty
                                            (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b]) && !finish_nolist) ? d_nz + gbase[b] : nullptr,
                                            d_nzcount(b), fst, narrow[b] != 0, tr_a[b], tr_b[b], h_maxsub[b], h_counts[b],
-                                           d_nz + gbase[b], d_retrycnt + b, file_k96[b] != 0));
+                                           d_nz + gbase[b], d_retrycnt + b, file_k96[b] != 0, sw.hash_multi, sw.hash_dbg));
         if (s->profiling) (void)hipEventRecord(fin_ev.back().second, fst);
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
@@ -1691,8 +1686,7 @@ static int finalize_from_runs(mgc_session *s) {
   const size_t esz = sizeof(uint64_t) * s->key_words + sizeof(uint32_t);
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
-  const bool force_ooc = getenv("MGC_OOC_FORCE") && getenv("MGC_OOC_FORCE")[0] == '1';
-  const bool fits = r->all_on_device() && !force_ooc && (uint64_t)free_b > r->entries() * esz + (64ull << 20);
+  const bool fits = r->all_on_device() && (uint64_t)free_b > r->entries() * esz + (64ull << 20);
   s->prof.n_batches = s->n_batches;
   if (fits) {
     const void *k = nullptr; const uint32_t *c = nullptr; uint64_t n = 0;

@@ -8,6 +8,34 @@
 
 namespace mgc {
 
+// ---- switches ----------------------------------------------------------------
+// Every MGC_* environment switch of the count path (tests and A/B measurements; the defaults are the shipped plan), read ONCE:
+// mgc_open reads them into the session (mgc_session::sw), the bare mgc_dev_* operators per call -- nothing below reads the
+// environment on its own.
+struct Switches {
+  bool fine_hist = true;        // MGC_FINE_HIST=0: no fifteen-bit file histogram (every file's digit histogram by a read of its keys)
+  bool hpc_msd = true;          // MGC_HPC_MSD=0: `compress`, low digit first everywhere
+  bool hpc_digits = true;       // MGC_HPC_DIGITS=0: `compress` with plain bit digits
+  bool const_k = true;          // MGC_KMER_CONST_K=0: the front-end kernels with run-time k only
+  bool narrow = true;           // MGC_NARROW=0: no 32-bit words after the first grouping pass
+  bool wide_msd = true;         // MGC_WIDE_MSD=0: whole keys low digit first off a histogram read
+  bool soa5 = true;             // MGC_SOA5=0: no 5-byte layout (k = 20..23)
+  bool k96 = true;              // MGC_K96=0: no 12-byte records (k = 33..51)
+  bool finish = true;           // MGC_FINISH=0: stable sort of all bits + run-length kernels
+  bool nolist = false;          // MGC_FINISH_NOLIST=1: the dense-grid instantiations of the count kernels whatever the grid holds
+  bool finish_trace = false;    // MGC_FINISH_TRACE: what happens to oversized sub-buckets, on stderr
+  bool group_dbg = false;       // MGC_GROUP_DBG: per-phase cycle sums of the grouping passes (instrumented instantiations)
+  bool hash_dbg = false;        // MGC_HASH_DBG: per-phase cycle sums of the count kernels
+  int  hash_multi = -1;         // MGC_HASH_MULTI: sub-buckets per iteration of hash_count_multi_kernel (-1: by the file's average; 0: off)
+  uint32_t min_top = 0;         // MGC_FINISH_MIN_TOP: at least that many grouping bits per file (tests reach the large-input plans)
+  uint64_t finish_target = 0;   // MGC_FINISH_TARGET: k-mers per sub-bucket the plan aims at (0: the kernels' default)
+  uint64_t stream_max = (uint64_t)1 << 22;   // MGC_STREAM_MAX: sub-buckets up to this many keys are streamed without asking the probe
+  uint64_t bucket_bases = 0;    // MGC_BUCKET_BASES: bases per partition bucket above which the partition gets finer (0: default)
+};
+Switches read_switches();
+
+
+
 // ---- k-mer extraction / partition (mgc_kmer.hip) -----------------------
 constexpr int      KP_BLOCK       = 256;                 // threads per workgroup
 constexpr int      KP_ITEMS       = 16;                  // window starts per thread
@@ -20,15 +48,15 @@ size_t   kp_workspace_bytes(uint32_t bucket_bits);
 
 // sfx_mask / sfx_test: count-suffix= filter, a k-mer is kept iff (its low word & sfx_mask) == sfx_test (0, 0: keep all)
 // the same + the k-mers per (file, next nine bits) into d_fine_hist[2^15] (the first digit of the narrowed grouping passes)
-bool       kmer_histogram_fine_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask);
+bool       kmer_histogram_fine_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask, const Switches &sw);
 // `compress`: the same histogram over dense ranks -- k-mers per (bucket, dense-rank digit of the five bases below the bucket's),
 // d_fine_hist[kmer_histogram_hpc_entries(bucket_bits)], bucket_bits 6 or 8 (mgc_kmer.hip)
-bool       kmer_histogram_hpc_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask);
+bool       kmer_histogram_hpc_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask, const Switches &sw);
 uint32_t   kmer_histogram_hpc_entries(uint32_t bucket_bits);
 hipError_t launch_kmer_histogram_hpc(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint32_t bucket_bits,
                                      uint64_t *d_bucket_counts, uint64_t *d_fine_hist, void *d_ws, hipStream_t st);
 hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint64_t *d_bucket_counts,
-                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st);
+                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st, bool const_k = true /*Switches::const_k*/);
 hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                                  uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st,
                                  uint64_t sfx_mask = 0, uint64_t sfx_test = 0);
@@ -37,7 +65,8 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
                                  uint32_t bucket_bits, const uint64_t *d_bucket_starts, void *d_keys,
                                  void *d_ws, hipStream_t st, uint64_t sfx_mask = 0, uint64_t sfx_test = 0,
                                  const uint64_t *d_soa_counts = nullptr /*64 buckets, 8-byte keys, <= 40 bits below the file: a file's region =
-                                 u32[count] low words + u8[count] bits 32..39 (5 bytes per k-mer; launch_group_narrow(soa_hi_mask))*/);
+                                 u32[count] low words + u8[count] bits 32..39 (5 bytes per k-mer; launch_group_narrow(soa_hi_mask))*/,
+                                 bool const_k = true /*Switches::const_k*/);
 
 // ---- radix sort ------------------------------------------------------------
 struct SortPlan {
@@ -52,7 +81,7 @@ struct SortPlan {
   uint32_t pass_bits[16];
 };
 
-// Chooses digit widths for bits [begin_bit, end_bit) (MGC_SORT_MODE=3: grouping passes through the bare sort operator, for tests).
+// Chooses digit widths for bits [begin_bit, end_bit); mode 0 (the caller sets 3 for grouping passes).
 void   make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan);
 // Grouping plan for homopolymer-compressed k-mers (`compress`): no base equals the one before it, so five bases after a
 // known base take 3^5 = 243 of their 1024 bit patterns.  A digit is the dense, ORDER-PRESERVING rank of five bases given
@@ -73,7 +102,7 @@ size_t     sort_header_bytes();
 // uint32 words without that digit (its value is where the key lies), the second pass and the finish move half the bytes,
 // and the sub-bucket boundaries fall out of the second pass's look-back granules.  d_keys: uint64[n] in, uint32[n] out
 // (over its first half); d_alt: room for n uint32; d_sub_starts: 2^(pass_bits[0] + pass_bits[1]) + 1 entries.
-bool       sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words);
+bool       sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words, bool on = true /*Switches::narrow*/);
 // The high-digit-first form (files of a session with the fifteen-bit file histogram): launch_narrow_prepare fills one
 // header per file (nb <= 64, sort_header_bytes() apart) from d_fine; every file then gets its header and a scratch area of
 // narrow_scratch_bytes(n) that the caller has zeroed.  See mgc_sort.hip: nobody reads the
@@ -86,7 +115,8 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events /* 4 or null */,
                                void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b,
                                uint32_t soa_hi_mask = 0 /*nonzero: d_keys is the 5-byte layout of launch_kmer_partition(d_soa_counts); the mask of
-                               the u8 array's payload bits (bits 32.. of the k-mer below the file)*/);
+                               the u8 array's payload bits (bits 32.. of the k-mer below the file)*/,
+                               bool group_dbg = false /*Switches::group_dbg*/);
 
 // The same high-digit-first form for WHOLE keys (8-byte keys that leave more than 32 bits below their first digit: k = 27..32
 // at the 10 Gbp scale; every 16-byte key): the high digit's histogram comes from the fifteen-bit file histogram
@@ -96,7 +126,7 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
 // key_words), zeroed by the caller; sub-buckets in tr_index(., *tr_a, *tr_b) order.
 // `compress`: the plan's digits are dense ranks (make_hpc_group_plan, two digits); the headers then come from
 // launch_hpc_prepare (the histogram of launch_kmer_histogram_hpc; `on`: one bit per bucket, nb <= 256)
-bool       sort_plan_wide_msd(const SortPlan &plan, uint64_t n);
+bool       sort_plan_wide_msd(const SortPlan &plan, uint64_t n, bool on = true /*Switches::wide_msd*/);
 hipError_t launch_hpc_prepare(const uint64_t *d_fine_hpc, uint32_t bucket_bits, const uint64_t on[4], void *d_hdrs, hipStream_t st);
 size_t     wide_scratch_bytes(uint64_t n, uint32_t key_words);
 hipError_t launch_group_wide(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan, uint32_t *d_error,
@@ -115,7 +145,7 @@ hipError_t launch_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words,
 
 // ---- sub-bucket finish (LDS sort of the low bits + fused run-length count) ---------------
 uint64_t   finish_capacity_for(uint32_t key_words);     // largest sub-bucket the LDS kernels accept
-uint64_t   finish_target_for(uint32_t key_words);       // average sub-bucket size to aim for
+uint64_t   finish_target_for(uint32_t key_words, const Switches &sw);       // average sub-bucket size to aim for
 hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t low, uint32_t top_bits,
                                    uint64_t *d_starts /*[2^top+1]*/, uint64_t *d_max /*atomicMax target*/,
                                    uint32_t *d_large_list /*[2^top]: sub-buckets above the small-kernel capacity*/,
@@ -127,10 +157,9 @@ hipError_t launch_subbucket_max(const uint64_t *d_starts, uint32_t key_words, ui
                                 hipStream_t st);          // the list half of launch_subbucket_bounds (boundaries already known)
 // sub-buckets above finish_capacity_for(): can they be streamed through the hash-count tables (distinct suffixes fit)?
 bool       finish_can_stream(uint32_t key_words, uint32_t low_bits);
-uint64_t   finish_stream_max();     // sub-buckets up to this many keys are streamed without asking the probe
 hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint32_t low_bits,
                                uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_file_fail /*set to 1: no*/, hipStream_t st,
-                               bool narrow = false /*d_keys: uint32 narrowed keys*/);
+                               uint64_t stream_max /*Switches::stream_max*/, bool narrow = false /*d_keys: uint32 narrowed keys*/);
 hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits,
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
                               bool stream /*large list -> streaming hash-count*/, void *d_alt /*room for the file's keys*/,
@@ -143,7 +172,8 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               uint64_t n_keys = 0 /*keys of the file, if known: the narrowed hash-count takes several sub-buckets per iteration by their average*/,
                               uint32_t *d_retry_list = nullptr /*[ng] + a zeroed counter: with both, dense narrowed files take hash_count_multi_kernel*/,
                               uint64_t *d_retry_count = nullptr,
-                              bool k96 = false /*d_keys: 12-byte K96 records (key_words 2, no oversized sub-buckets: n_large == 0)*/);
+                              bool k96 = false /*d_keys: 12-byte K96 records (key_words 2; oversized sub-buckets only with `stream`)*/,
+                              int hash_multi = -1 /*Switches::hash_multi*/, bool hash_dbg = false /*Switches::hash_dbg*/);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);
 hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,

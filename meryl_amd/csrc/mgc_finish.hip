@@ -1851,14 +1851,14 @@ static hipError_t finish_launch(void *d_keys, const uint64_t *d_starts, uint64_t
 // Sorts + counts every sub-bucket of one file segment; sub-buckets larger than FIN_CAP_SMALL use the
 // large-capacity instantiation (launched only if the file has any: max_sub tells).
 // MGC_HASH_DBG=1: per-phase cycle sums of the first 64 workgroups of the hash-count kernel, printed for a few launches
-static u64 *hash_dbg_buffer() {
+static u64 *hash_dbg_buffer(bool on) {
   static u64 *buf = nullptr;
-  static const bool on = getenv("MGC_HASH_DBG") != nullptr;
-  if (on && !buf) { if (hipMalloc(&buf, 64 * 8 * sizeof(u64)) != hipSuccess) buf = nullptr; }
+  if (!on) return nullptr;
+  if (!buf) { if (hipMalloc(&buf, 64 * 8 * sizeof(u64)) != hipSuccess) buf = nullptr; }
   return buf;
 }
 static void hash_dbg_report(hipStream_t st, uint64_t ng, bool multi = false) {
-  u64 *buf = hash_dbg_buffer();
+  u64 *buf = hash_dbg_buffer(true);
   static int reports = 0;
   if (!buf || reports >= 4) return;
   u64 h[64 * 8];
@@ -1880,31 +1880,24 @@ bool finish_can_stream(uint32_t key_words, uint32_t low_bits) {
   return finish_uses_hash(key_words, low_bits);
 }
 
-// sub-buckets up to this many keys are streamed whatever they hold (in as many suffix ranges as it takes); a larger one
-// only if the probe finds that one pass will do -- a dense sub-bucket of that size is the full sort's work
-uint64_t finish_stream_max() {
-  const char *e = getenv("MGC_STREAM_MAX");             // read per call: the tests switch it
-  return (e && *e) ? strtoull(e, nullptr, 10) : ((uint64_t)1 << 22);
-}
-
 hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint32_t low_bits,
-                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_file_fail, hipStream_t st, bool narrow) {
+                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_file_fail, hipStream_t st, uint64_t stream_max, bool narrow) {
   if (n_large == 0 || key_words != 1) return hipSuccess;
   if (narrow) {
     if (low_bits >= 32) return hipErrorInvalidValue;
     hipLaunchKernelGGL((hash_probe_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32, u32>), dim3((uint32_t)n_large), dim3(1024), 0, st,
                        reinterpret_cast<const u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list,
-                       (u64)finish_stream_max(), low_bits, d_file_fail);
+                       (u64)stream_max, low_bits, d_file_fail);
     return hipGetLastError();
   }
   if (low_bits < 32)
     hipLaunchKernelGGL((hash_probe_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>), dim3((uint32_t)n_large), dim3(1024), 0, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list,
-                       (u64)finish_stream_max(), low_bits, d_file_fail);
+                       (u64)stream_max, low_bits, d_file_fail);
   else
     hipLaunchKernelGGL((hash_probe_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>), dim3((uint32_t)n_large), dim3(1024), 0, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list,
-                       (u64)finish_stream_max(), low_bits, d_file_fail);
+                       (u64)stream_max, low_bits, d_file_fail);
   return hipGetLastError();
 }
 
@@ -1914,7 +1907,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
                               bool stream, void *d_alt, hipStream_t st_huge, const uint32_t *d_nz, const uint64_t *d_nz_count,
                               hipStream_t st, bool narrow, uint32_t tr_a, uint32_t tr_b, uint64_t max_sub, uint64_t n_keys,
-                              uint32_t *d_retry_list, uint64_t *d_retry_count, bool k96) {
+                              uint32_t *d_retry_list, uint64_t *d_retry_count, bool k96, int hash_multi, bool hash_dbg) {
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
   if (k96) {
     // 12-byte K96 records: the persistent hash-count, and the streaming count of oversized sub-buckets (a file whose oversized
@@ -1978,8 +1971,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     // 1/2/4: that R whatever the average -- tests).  Measured at 10 Gbp (profiles/r05a: MGC_HASH_MULTI=2 on every file): R = 2
     // on files whose sub-buckets average more than 690 k-mers sends most ranges to the retry list (they exceed the 1536-key
     // table): 68 ms of count stage against 29 -- R = 1 there is the table's size, not the heuristic's choice.
-    const char *mue = getenv("MGC_HASH_MULTI");                    // read per call: the tests switch it
-    const int multi_env = (mue && *mue) ? atoi(mue) : -1;
+    const int multi_env = hash_multi;
     int multi_r = 0;
     if (multi_env != 0 && !d_nz && ng >= 4 && d_retry_list && d_retry_count) {
       const uint64_t avg = n_keys ? n_keys / ng : FIN_CAP_HASH;
@@ -1989,7 +1981,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       const uint32_t tagb2 = multi_r == 1 ? 0u : (multi_r == 2 ? 1u : 2u);
       if (multi_r > 4 || multi_r == 3 || low_bits + tagb2 < 8 || low_bits + tagb2 > 20) multi_r = 0;
     }
-    u64 *dbgb = hash_dbg_buffer();                                   // MGC_HASH_DBG=1: the instrumented instantiations (per-phase cycle stamps)
+    u64 *dbgb = hash_dbg_buffer(hash_dbg);                           // MGC_HASH_DBG=1: the instrumented instantiations (per-phase cycle stamps)
     if (multi_r) {
       const uint64_t nsuper = (ng + (uint64_t)multi_r - 1) / (uint64_t)multi_r;
 #define MGC_MULTI_LAUNCH(R_, DBG_)                                                                                                       \
@@ -2113,7 +2105,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
 #undef MGC_W64_LAUNCH
     } else {
       const uint32_t hgrid = ng < 256u * 14u ? (uint32_t)ng : 256u * 14u;
-      u64 *dbgb = hash_dbg_buffer();
+      u64 *dbgb = hash_dbg_buffer(hash_dbg);
 #define MGC_HASH_LAUNCH(DBG_, LIST_)                                                                                                     \
       hipLaunchKernelGGL((hash_count_kernel<256, (int)FIN_CAP_HASH, 2048, DBG_, LIST_, false>), dim3(hgrid), dim3(256), 0, st,           \
                          reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)FIN_CAP_HASH, low_bits, \
@@ -2123,7 +2115,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       else               MGC_HASH_LAUNCH(false, false);
 #undef MGC_HASH_LAUNCH
       MGC_CHECK(hipGetLastError());
-      hash_dbg_report(st, ng);
+      if (dbgb) hash_dbg_report(st, ng);
     }
     MGC_CHECK(hipGetLastError());
     if (stream && n_large) {
@@ -2167,8 +2159,8 @@ static uint64_t finish_small_capacity(uint32_t key_words, uint32_t low_bits) {
 }
 
 uint64_t finish_capacity_for(uint32_t key_words) { return key_words == 2 ? 8192 : FIN_CAP_LARGE; }
-uint64_t finish_target_for(uint32_t key_words) {
-  if (const char *t = getenv("MGC_FINISH_TARGET")) return strtoull(t, nullptr, 10);      // (read per call: tests make the sub-buckets tiny)
+uint64_t finish_target_for(uint32_t key_words, const Switches &sw) {
+  if (sw.finish_target) return sw.finish_target;              // (tests make the sub-buckets tiny)
   return key_words == 2 ? (FIN_CAP_HASH128 * 3) / 4 : (FIN_CAP_HASH * 3) / 4;
 }
 
@@ -2267,6 +2259,25 @@ hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint3
 }
 
 
+
+// Every MGC_* switch of the count path, from the environment (mgc_device.h: once per session / per bare-operator call)
+Switches read_switches() {
+  Switches sw;
+  auto off = [](const char *n) { const char *e = getenv(n); return e && e[0] == '0'; };
+  auto on1 = [](const char *n) { const char *e = getenv(n); return e && e[0] == '1'; };
+  auto num = [](const char *n, uint64_t d) { const char *e = getenv(n); return (e && *e) ? strtoull(e, nullptr, 10) : d; };
+  sw.fine_hist = !off("MGC_FINE_HIST"); sw.hpc_msd = !off("MGC_HPC_MSD"); sw.hpc_digits = !off("MGC_HPC_DIGITS");
+  sw.const_k = !off("MGC_KMER_CONST_K"); sw.narrow = !off("MGC_NARROW"); sw.wide_msd = !off("MGC_WIDE_MSD");
+  sw.soa5 = !off("MGC_SOA5"); sw.k96 = !off("MGC_K96"); sw.finish = !off("MGC_FINISH");
+  sw.nolist = on1("MGC_FINISH_NOLIST");
+  sw.finish_trace = getenv("MGC_FINISH_TRACE") != nullptr; sw.group_dbg = getenv("MGC_GROUP_DBG") != nullptr; sw.hash_dbg = getenv("MGC_HASH_DBG") != nullptr;
+  { const char *e = getenv("MGC_HASH_MULTI"); sw.hash_multi = (e && *e) ? atoi(e) : -1; }
+  sw.min_top = (uint32_t)num("MGC_FINISH_MIN_TOP", 0);
+  sw.finish_target = num("MGC_FINISH_TARGET", 0);
+  sw.stream_max = num("MGC_STREAM_MAX", (uint64_t)1 << 22);
+  sw.bucket_bases = num("MGC_BUCKET_BASES", 0);
+  return sw;
+}
 
 hipError_t warm_finish() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&store_u64_kernel)); }
 

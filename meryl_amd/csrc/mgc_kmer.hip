@@ -574,10 +574,9 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
   }
 }
 
-// the constant-k instantiations (KC): canonical counts at the k of the BASELINE configs; MGC_KMER_CONST_K=0: the generic kernels
-static int kmer_const_k(uint32_t k, int mode) {
-  const char *e = getenv("MGC_KMER_CONST_K");                         // read per call: the tests switch it
-  if ((e && e[0] == '0') || mode != 0) return 0;
+// the constant-k instantiations (KC): canonical counts at the k of the BASELINE configs (on: Switches::const_k)
+static int kmer_const_k(uint32_t k, int mode, bool on) {
+  if (!on || mode != 0) return 0;
   return (k == 21 || k == 31 || k == 51) ? (int)k : 0;
 }
 
@@ -610,14 +609,13 @@ hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint3
   return hipGetLastError();
 }
 
-bool kmer_histogram_fine_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask) {
-  const char *e = getenv("MGC_FINE_HIST");
-  return !(e && e[0] == '0') && k <= 64 && 2 * k >= (uint32_t)KH_FINE_BITS + 2 && bucket_bits == 6 && sfx_mask == 0;
+bool kmer_histogram_fine_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask, const Switches &sw) {
+  return sw.fine_hist && k <= 64 && 2 * k >= (uint32_t)KH_FINE_BITS + 2 && bucket_bits == 6 && sfx_mask == 0;
 }
 
 // launch_kmer_histogram + d_fine_hist[2^15] (zeroed here): k-mers per (file, next nine bits)
 hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint64_t *d_bucket_counts,
-                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st) {
+                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st, bool const_k) {
   MGC_CHECK(hipMemsetAsync(d_bucket_counts, 0, sizeof(uint64_t) * 64, st));
   MGC_CHECK(hipMemsetAsync(d_fine_hist, 0, sizeof(uint64_t) << KH_FINE_BITS, st));
   if (n_bases == 0) return hipSuccess;
@@ -639,7 +637,7 @@ hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, 
   hipLaunchKernelGGL((kmer_hist_fine_kernel<0, KC_>), dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) << KH_FINE_BITS, st, \
                      d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),                             \
                      reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist))
-  const int kc = kmer_const_k(k, mode);
+  const int kc = kmer_const_k(k, mode, const_k);
   if (kc == 21) MGC_KH_LAUNCH(21); else if (kc == 31) MGC_KH_LAUNCH(31); else if (kc == 51) MGC_KH_LAUNCH(51); else MGC_KH_LAUNCH(0);
 #undef MGC_KH_LAUNCH
   return hipGetLastError();
@@ -647,9 +645,8 @@ hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, 
 
 // `compress`: the same kernel with the table indexed by dense ranks (kmer_hist_fine_kernel<HB>): bucket_bits 6 or 8,
 // d_fine_hist[kmer_histogram_hpc_entries(bucket_bits)] = k-mers per (bucket, first grouping digit of the bucket)
-bool kmer_histogram_hpc_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask) {
-  const char *e = getenv("MGC_HPC_MSD");                             // read per call: the tests switch it
-  return !(e && e[0] == '0') && (bucket_bits == 6 || bucket_bits == 8) && k <= 64 && 2 * k >= bucket_bits + 10 + 2 && sfx_mask == 0;
+bool kmer_histogram_hpc_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask, const Switches &sw) {
+  return sw.hpc_msd && (bucket_bits == 6 || bucket_bits == 8) && k <= 64 && 2 * k >= bucket_bits + 10 + 2 && sfx_mask == 0;
 }
 uint32_t kmer_histogram_hpc_entries(uint32_t bucket_bits) { return hpc_table_size((int)(bucket_bits / 2 + 5)); }
 
@@ -683,7 +680,7 @@ hipError_t launch_kmer_histogram_hpc(const uint8_t *d_bases, uint64_t n_bases, u
 
 hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                                  uint32_t bucket_bits, const uint64_t *d_bucket_starts, void *d_keys,
-                                 void *d_ws, hipStream_t st, uint64_t sfx_mask, uint64_t sfx_test, const uint64_t *d_soa_counts) {
+                                 void *d_ws, hipStream_t st, uint64_t sfx_mask, uint64_t sfx_test, const uint64_t *d_soa_counts, bool const_k) {
   if (n_bases == 0) return hipSuccess;
   const uint32_t nb = 1u << bucket_bits;
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
@@ -715,7 +712,7 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KP_TILE * sizeof(K128)));
       a96 = true;
     }
-    if (kmer_const_k(k, mode) == 51)
+    if (kmer_const_k(k, mode, const_k) == 51)
       hipLaunchKernelGGL((kmer_partition_kernel<K128, 64, true, 51>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K128), st, d_bases, (u64)n_bases, k, mode,
                          bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K128 *>(d_keys), (u64)0, (u64)0,
                          reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
@@ -727,7 +724,7 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
   }
   if (d_soa_counts) {                                                 // 5-byte layout (kmer_partition_soa_ok)
     if (!(k <= 32 && nb == 64 && sfx_mask == 0)) return hipErrorInvalidValue;
-    if (kmer_const_k(k, mode) == 21)
+    if (kmer_const_k(k, mode, const_k) == 21)
       hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, true, 21>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
                          bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)0, (u64)0,
                          reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
@@ -741,7 +738,7 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
   hipLaunchKernelGGL((kmer_partition_kernel<K_, 64, false, KC_>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K_), st, \
                      d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,                                  \
                      reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys), (u64)0, (u64)0)
-  const int kc = (nb == 64 && sfx_mask == 0) ? kmer_const_k(k, mode) : 0;
+  const int kc = (nb == 64 && sfx_mask == 0) ? kmer_const_k(k, mode, const_k) : 0;
   if (kc == 21)      MGC_KPC_LAUNCH(u64, 21);
   else if (kc == 31) MGC_KPC_LAUNCH(u64, 31);
   else if (kc == 51) MGC_KPC_LAUNCH(K128, 51);

@@ -345,7 +345,6 @@ void rank_main(Node &nd, uint32_t r) {
     // Batches: a rank holds, per base of a batch, its k-mers (8/16 B), as owner an inbox of about as many, a result copy and the
     // count arena (4 B of counts + the ping-pong file) -- 2 + 28 (52) B with slack; 60 % of the free HBM may go there.
     uint64_t batch = nd.batch_bases;
-    if (const char *e = getenv("MGC_NODE_BATCH_BASES")) batch = strtoull(e, nullptr, 10);
     if (batch == 0) {
       size_t free_b = 0, total_b = 0;
       batch = ~0ull;

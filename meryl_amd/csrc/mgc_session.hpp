@@ -50,6 +50,7 @@ struct mgc_session {
   int              device = -1;
   hipStream_t      stream = nullptr;
   uint64_t         sfx_mask = 0, sfx_test = 0;   // count-suffix= filter (0, 0: none)
+  mgc::Switches    sw;                   // the MGC_* switches of the count path, read once by mgc_open (mgc_device.h)
   hipStream_t      stream2 = nullptr;    // the streaming hash-count of a file's oversized sub-buckets runs beside its persistent kernel
   hipEvent_t       ev_fork = nullptr, ev_join = nullptr;
   uint64_t        *h_stats = nullptr;    // pinned: per file {largest sub-bucket, oversized sub-buckets, non-empty sub-buckets}

@@ -663,11 +663,6 @@ struct NarrowPrep { unsigned char bits_a[64]; unsigned char on[64]; };   // per 
 
 // ---- host side ---------------------------------------------------------------
 
-static int env_int(const char *name, int dflt) {
-  const char *s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
-}
-
 void make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan) {
   memset(plan, 0, sizeof(*plan));
   // the fastest measured combination on MI355X (profiles/r01*, DESIGN_HISTORY.md): nine-bit digits, one 1024-thread workgroup
@@ -678,7 +673,7 @@ void make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan) {
   plan->block      = 1024;
   plan->kpt        = 16;
   plan->tile       = plan->block * plan->kpt;
-  plan->mode       = (env_int("MGC_SORT_MODE", 0) == 3) ? 3u : 0u;     // 0 stable sort, 3 grouping passes (tests reach them through the bare operator)
+  plan->mode       = 0;                                                 // 0 stable sort; the caller sets 3 for grouping passes
   const uint32_t rb = plan->radix_bits;
   const uint32_t nbits = (end_bit > begin_bit) ? end_bit - begin_bit : 0;
   uint32_t passes = (nbits + rb - 1) / rb;
@@ -850,9 +845,7 @@ __global__ void narrow_bounds_kernel(const u64 *__restrict__ status, const u32 *
   starts[v] = gbase1[d1] + before;
 }
 
-bool sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words) {
-  const char *e = getenv("MGC_NARROW");                     // read per call: the tests switch it
-  const bool on = !(e && e[0] == '0');
+bool sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words, bool on) {
   return on && key_words == 1 && plan.mode == 3 && !plan.hpc && plan.num_passes == 2 && plan.radix_bits == 9 && n > 0 && n < (1ull << 30) &&
          plan.pass_shift[1] == plan.pass_shift[0] + plan.pass_bits[0] &&
          plan.pass_shift[0] + std::max(plan.pass_bits[0], plan.pass_bits[1]) <= 32;     // whichever digit goes first, the rest fits a word
@@ -931,7 +924,7 @@ hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsi
 // ((p & (2^*tr_a - 1)) << *tr_b) | (p >> *tr_a)  (*tr_a = 0: p itself).
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events,
-                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, uint32_t soa_hi_mask) {
+                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, uint32_t soa_hi_mask, bool group_dbg) {
   if (!sort_plan_narrows(plan, n, 1) || ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
   constexpr int RB = 9, BLOCK = 1024, KPT0 = 16, KPT1 = 24, R = 1 << RB;
   using GS0 = GroupSmem<u64, RB, BLOCK, KPT0>;
@@ -979,9 +972,9 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
   const dim3 grid0((uint32_t)std::min(tiles0, cus * GS0::WG_PER_CU));
   // MGC_GROUP_DBG=1: per-phase cycle sums of the first 64 workgroups of both passes, printed for the first two files (developer
   // instrumentation; the instrumented instantiations run instead of the plain ones for those files)
-  static int dbg_reports = getenv("MGC_GROUP_DBG") ? 2 : 0;
+  static int dbg_reports = 2;
   static u64 *dbg_buf = nullptr;
-  const bool dbg = msd && dbg_reports > 0;
+  const bool dbg = group_dbg && msd && dbg_reports > 0;
   if (dbg && !dbg_buf) {
     static bool dattr = false;
     if (!dattr) {
@@ -1071,9 +1064,7 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
 }
 
 // ---- the same two passes for WHOLE keys (mgc_device.h, launch_group_wide) ----
-bool sort_plan_wide_msd(const SortPlan &plan, uint64_t n) {
-  const char *e = getenv("MGC_WIDE_MSD");                   // read per call: the tests switch it
-  const bool on = !(e && e[0] == '0');
+bool sort_plan_wide_msd(const SortPlan &plan, uint64_t n, bool on) {
   return on && plan.mode == 3 && plan.num_passes == 2 && plan.radix_bits == 9 && n > 0 && n < (1ull << 30) &&
          plan.pass_shift[1] == plan.pass_shift[0] + plan.pass_bits[0];
 }

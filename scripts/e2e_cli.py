@@ -45,13 +45,12 @@ if os.environ.get("E2E_SETTLE") == "1":                      # does a big alloca
     print("settle: 110 GB allocated in %.3f s, freed in %.3f s" % (t1 - t0, time.perf_counter() - t1))
 cli = build.build_cli()
 # every setting: (environment additions, command prefix)
-settings = [({}, []), ({"MGC_DB_IMG_MB": "512", "MGC_DB_SLOTS": "16"}, []), ({"MGC_DB_IMG_MB": "1024", "MGC_DB_SLOTS": "8"}, []),
-            ({"MGC_DB_IMG_MB": "1024", "MGC_DB_SLOTS": "24"}, []), ({"MGC_DB_IMG_MB": "256", "MGC_DB_SLOTS": "12"}, [])]
+settings = [({}, [])]      # (rounds 2-3 swept the database image / slot sizes and the reader ring here: profiles/r03o_*, r03p_*; the switches are gone)
 if os.environ.get("E2E_SETTINGS"):                            # "A=1,B=2;C=3;" -> one run per ';'-separated environment set (empty = defaults)
     settings = [(dict(kv.split("=", 1) for kv in grp.split(",") if kv), []) for grp in os.environ["E2E_SETTINGS"].split(";")]
 if os.environ.get("E2E_MORE") == "1":
-    settings += [({"MGC_TEXT_READERS": "32", "MGC_TEXT_RING": "48"}, []), ({"MGC_TEXT_READERS": "8", "MGC_TEXT_RING": "16"}, []),
-                 ({}, ["taskset", "-c", "0-63,128-191"]), ({}, ["taskset", "-c", "64-127,192-255"]), ({"MGC_TEXT_MMAP": "1"}, [])]
+    settings += [
+                 ({}, ["taskset", "-c", "0-63,128-191"]), ({}, ["taskset", "-c", "64-127,192-255"])]
 try:
     print(subprocess.run(["numactl", "-H"], capture_output=True, text=True).stdout[:1500])
 except OSError:

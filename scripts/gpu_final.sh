@@ -39,6 +39,11 @@ cf, cw = load("calib_FETCH_SIZE"), load("calib_WRITE_SIZE")
 fr, wc = mean(cf, "calib_read8", "FETCH_SIZE"), mean(cw, "calib_copy8", "WRITE_SIZE")
 fs = N8 / (fr * 1024) if fr else 1.0          # true bytes per reported KiB (MI355X_MICROARCH.md: calibrate per access width)
 ws = N8 / (wc * 1024) if wc else 1.0
+# round 5: the same 2 GiB read with 4-, 16- and 1-byte loads, written with 4- and 1-byte stores -- the scales per width
+widths = {}
+for nm, ctr, agg in (("read4", "FETCH_SIZE", cf), ("read16", "FETCH_SIZE", cf), ("read1", "FETCH_SIZE", cf), ("copy4", "WRITE_SIZE", cw), ("write1", "WRITE_SIZE", cw)):
+    v = mean(agg, "calib_" + nm, ctr)
+    widths[nm] = {"counter_KiB": v, "scale": (N8 / (v * 1024)) if v else None}
 bf, bw = load("bench_FETCH_SIZE"), load("bench_WRITE_SIZE")
 kernels = {}
 for k in sorted({k for (k, _) in list(bf) + list(bw)}):
@@ -50,12 +55,12 @@ dom = [k for k in kernels if k.startswith("radix_group_kernel<unsigned long long
 out = {"source": "scripts/gpu_final.sh (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-check)",
        "reads_per_gpu": 66666667, "kernel": dom[0] if dom else None,
        "calibration": {"bytes_per_buffer": N8, "fetch_scale_read8": fs, "write_scale_copy8": ws,
-                       "calib_read8_FETCH_SIZE_KiB": fr, "calib_copy8_WRITE_SIZE_KiB": wc},
+                       "calib_read8_FETCH_SIZE_KiB": fr, "calib_copy8_WRITE_SIZE_KiB": wc, "by_access_width": widths},
        "fetch_bytes_per_launch": kernels[dom[0]]["fetch_bytes_per_launch"] if dom else None,
        "write_bytes_per_launch": kernels[dom[0]]["write_bytes_per_launch"] if dom else None,
        "launches": kernels[dom[0]]["launches"] if dom else 0, "all_kernels": kernels}
 json.dump(out, open(OUT + "/pmc_traffic.json", "w"), indent=1)
-print("fetch scale %.3f write scale %.3f" % (fs, ws))
+print("fetch scale %.3f write scale %.3f" % (fs, ws), "by width:", {k: (round(v["scale"], 3) if v["scale"] else None) for k, v in widths.items()})
 for k, v in kernels.items():
     if v["launches"] and any(x in k for x in ("radix", "hash", "kmer", "compact", "encode", "merge")):
         print(k[:70].ljust(70), v["launches"], "fetch %.3e" % (v["fetch_bytes_per_launch"] or 0), "write %.3e" % (v["write_bytes_per_launch"] or 0))
