@@ -422,59 +422,6 @@ def test_device_digests_equal_port_digests_small(ops, oracle_lib, torch_cuda, k,
     assert np.array_equal(got, want)
 
 
-def test_config1_full_size_matches_threaded_port(ops, oracle_lib, torch_cuda):
-    """BASELINE config 1 AT ITS JUDGED SIZE -- k=21, 66,666,667 x 150 bp reads = 10 Gbp, wPrefix 18, the bench.py workload --
-    against the reference-algorithm port (oracle_port.cpp: 2 MiB chunks, spin-locked bit-packed prefix buckets, std::sort,
-    run-length count, 64-file dump) run on the host cores over the SAME bytes: every one of the 64 files must agree in
-    its number of distinct k-mers, its total count and two 64-bit weighted key sums; four whole files (0, 21, 42, 63) are
-    compared element by element as well.  ~30 GB of host RAM, a few minutes."""
-    from meryl_amd import capi
-    n_reads = _config1_reads()
-    if "thread" not in _CONFIG1_PORT:
-        pytest.skip("not enough host memory for the port at this size")
-    k = 21
-    d = ops.dev_synth_reads(2, 333_333_334, 0, n_reads)
-    cfg = capi.configure(k, 10_000_000_000, 64 << 30)
-    assert cfg.w_prefix == 18
-    with ops.Session(cfg) as s:
-        s.push_bases_device(d)
-        s.count()
-        info = s.info()
-        keys, counts = s.result_device()
-    got = device_digests(torch_cuda, keys, counts, k)
-    assert bool((keys[1:] > keys[:-1]).all().item())
-    # four whole files are also compared ELEMENT BY ELEMENT with the port's stream (the first, the last, two in between):
-    # their device slices stay, the rest of the result goes
-    whole = _CONFIG1_WHOLE
-    bounds = torch_cuda.tensor([f << (2 * k - 6) for f in range(65)], dtype=torch_cuda.int64, device="cuda")
-    cut = torch_cuda.searchsorted(keys, bounds).cpu().numpy()
-    kept = {f: (keys[int(cut[f]):int(cut[f + 1])].clone(), counts[int(cut[f]):int(cut[f + 1])].clone()) for f in whole}
-    del keys, counts
-    del d
-    torch_cuda.cuda.empty_cache()
-    _CONFIG1_PORT["thread"].join()                              # (started with this module's first test: _config1_port_ahead)
-    if "error" in _CONFIG1_PORT["box"]:
-        raise _CONFIG1_PORT["box"]["error"]
-    want, nd, ni, files = _CONFIG1_PORT["box"]["result"]
-    assert ni == info.n_instances, (ni, info.n_instances)
-    assert nd == info.n_distinct, (nd, info.n_distinct)
-    assert np.array_equal(got[:, 0], want[:, 0]), "distinct k-mers per file differ"
-    assert np.array_equal(got[:, 1], want[:, 1]), "total counts per file differ"
-    assert np.array_equal(got, want), "weighted key sums differ"
-    assert [int(x) for x in info.file_instances] == [int(x) for x in want[:, 1]]
-    for f in whole:
-        _, plo, pcn = files[f]
-        dk, dc = kept[f]
-        assert dk.shape[0] == plo.shape[0] == int(want[f, 0]) > 0, (f, dk.shape[0], plo.shape[0])
-        step = 1 << 26
-        for a in range(0, plo.shape[0], step):                    # chunked: the port's arrays go up piece by piece
-            assert torch_cuda.equal(dk[a:a + step], torch_cuda.from_numpy(plo[a:a + step].view(np.int64)).cuda()), "k-mers of file %d differ" % f
-            assert torch_cuda.equal(dc[a:a + step].to(torch_cuda.int64) & 0xFFFFFFFF,
-                                    torch_cuda.from_numpy(pcn[a:a + step].astype(np.int64)).cuda()), "counts of file %d differ" % f
-    if n_reads >= 66666667:
-        assert sum(kept[f][0].shape[0] for f in whole) > 20_000_000       # (file 0 alone holds a few percent of the distinct k-mers)
-
-
 @pytest.mark.parametrize("shape", ["config3_repeats", "config4_hifi_compress", "config5_k51"])
 def test_other_baseline_configs_single_gpu_leg_matches_port(ops, oracle_lib, torch_cuda, shape):
     """The single-GPU legs of BASELINE configs 3-5 with THEIR read shapes at a size the threaded port does in seconds
@@ -1727,3 +1674,57 @@ def test_one_sequence_longer_than_a_batch_is_cut_with_overlap(ops, oracle_lib, t
         assert s.profile().n_batches >= 6
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
+
+
+# (the last test of the module: its CPU side has been running in the background since the first one -- _config1_port_ahead)
+def test_config1_full_size_matches_threaded_port(ops, oracle_lib, torch_cuda):
+    """BASELINE config 1 AT ITS JUDGED SIZE -- k=21, 66,666,667 x 150 bp reads = 10 Gbp, wPrefix 18, the bench.py workload --
+    against the reference-algorithm port (oracle_port.cpp: 2 MiB chunks, spin-locked bit-packed prefix buckets, std::sort,
+    run-length count, 64-file dump) run on the host cores over the SAME bytes: every one of the 64 files must agree in
+    its number of distinct k-mers, its total count and two 64-bit weighted key sums; four whole files (0, 21, 42, 63) are
+    compared element by element as well.  ~30 GB of host RAM, a few minutes."""
+    from meryl_amd import capi
+    n_reads = _config1_reads()
+    if "thread" not in _CONFIG1_PORT:
+        pytest.skip("not enough host memory for the port at this size")
+    k = 21
+    d = ops.dev_synth_reads(2, 333_333_334, 0, n_reads)
+    cfg = capi.configure(k, 10_000_000_000, 64 << 30)
+    assert cfg.w_prefix == 18
+    with ops.Session(cfg) as s:
+        s.push_bases_device(d)
+        s.count()
+        info = s.info()
+        keys, counts = s.result_device()
+    got = device_digests(torch_cuda, keys, counts, k)
+    assert bool((keys[1:] > keys[:-1]).all().item())
+    # four whole files are also compared ELEMENT BY ELEMENT with the port's stream (the first, the last, two in between):
+    # their device slices stay, the rest of the result goes
+    whole = _CONFIG1_WHOLE
+    bounds = torch_cuda.tensor([f << (2 * k - 6) for f in range(65)], dtype=torch_cuda.int64, device="cuda")
+    cut = torch_cuda.searchsorted(keys, bounds).cpu().numpy()
+    kept = {f: (keys[int(cut[f]):int(cut[f + 1])].clone(), counts[int(cut[f]):int(cut[f + 1])].clone()) for f in whole}
+    del keys, counts
+    del d
+    torch_cuda.cuda.empty_cache()
+    _CONFIG1_PORT["thread"].join()                              # (started with this module's first test: _config1_port_ahead)
+    if "error" in _CONFIG1_PORT["box"]:
+        raise _CONFIG1_PORT["box"]["error"]
+    want, nd, ni, files = _CONFIG1_PORT["box"]["result"]
+    assert ni == info.n_instances, (ni, info.n_instances)
+    assert nd == info.n_distinct, (nd, info.n_distinct)
+    assert np.array_equal(got[:, 0], want[:, 0]), "distinct k-mers per file differ"
+    assert np.array_equal(got[:, 1], want[:, 1]), "total counts per file differ"
+    assert np.array_equal(got, want), "weighted key sums differ"
+    assert [int(x) for x in info.file_instances] == [int(x) for x in want[:, 1]]
+    for f in whole:
+        _, plo, pcn = files[f]
+        dk, dc = kept[f]
+        assert dk.shape[0] == plo.shape[0] == int(want[f, 0]) > 0, (f, dk.shape[0], plo.shape[0])
+        step = 1 << 26
+        for a in range(0, plo.shape[0], step):                    # chunked: the port's arrays go up piece by piece
+            assert torch_cuda.equal(dk[a:a + step], torch_cuda.from_numpy(plo[a:a + step].view(np.int64)).cuda()), "k-mers of file %d differ" % f
+            assert torch_cuda.equal(dc[a:a + step].to(torch_cuda.int64) & 0xFFFFFFFF,
+                                    torch_cuda.from_numpy(pcn[a:a + step].astype(np.int64)).cuda()), "counts of file %d differ" % f
+    if n_reads >= 66666667:
+        assert sum(kept[f][0].shape[0] for f in whole) > 20_000_000       # (file 0 alone holds a few percent of the distinct k-mers)
