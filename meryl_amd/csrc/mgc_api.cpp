@@ -1056,7 +1056,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       // `compress`: k-mers per (bucket, dense-rank digit below it) -- the buckets' high digit goes first as well (MGC_HPC_MSD=0: off)
       HIP_TRY(s, s->ensure(mgc_session::B_FINE, sizeof(uint64_t) * std::max<size_t>((size_t)1 << 15, mgc::kmer_histogram_hpc_entries(bucket_bits))));
       uint64_t *fine = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_FINE].p);
-      HIP_TRY(s, mgc::launch_kmer_histogram_hpc(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, fine, part_ws, st));
+      HIP_TRY(s, mgc::launch_kmer_histogram_hpc(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, fine, part_ws, st, sw.const_k));
       d_fine_hpc = fine;
     } else
     HIP_TRY(s, mgc::launch_kmer_histogram(d_bases, n_bases, k, c.mode, bucket_bits, d_counts64, part_ws, st, s->sfx_mask, s->sfx_test));

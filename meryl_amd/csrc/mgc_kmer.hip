@@ -438,16 +438,16 @@ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 
 // count-suffix filter -- every shift of the sixteen unrolled window extractions (key_shift, top_shift, the reverse complement's)
 // is then an immediate and the 64-bit (k > 32: 128-bit) variable shifts on a 32-bit ALU go away; KC = 0: k, mode and bucket_bits
 // are the run-time arguments.
-template <typename K, int MAXB, bool SOA = false, int KC = 0>
+template <typename K, int MAXB, bool SOA = false, int KC = 0, int BB = 6>   // BB: the bucket bits of a constant-k form (6: the files; 8: `compress` at 5 Gbp and beyond)
 __global__ __launch_bounds__(KP_BLOCK, (sizeof(K) == 16) ? 2 : (SOA ? 4 : 5))   // 16-byte keys: the 64 KiB exchange tile allows two workgroups; SOA: no spill, LDS allows four anyway
 void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, int mode_arg, u32 bucket_bits_arg,
                            u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out, u64 sfx_mask_arg, u64 sfx_test,
                            const u64 *__restrict__ soa_starts = nullptr, const u64 *__restrict__ soa_counts = nullptr) {
   const u32 k = KC ? (u32)KC : k_arg;
   const int mode = KC ? 0 : mode_arg;
-  const u32 bucket_bits = KC ? 6u : bucket_bits_arg;
+  const u32 bucket_bits = KC ? (u32)BB : bucket_bits_arg;
   const u64 sfx_mask = KC ? 0ull : sfx_mask_arg;
-  static_assert(KC == 0 || MAXB == 64, "the constant-k forms are 64-file forms");
+  static_assert(KC == 0 || MAXB >= (1 << BB), "the buckets of a constant-k form fit its tables");
   extern __shared__ __attribute__((aligned(16))) unsigned char kp_dyn_smem[];
   K *s_keys = reinterpret_cast<K *>(kp_dyn_smem);                   // K[KP_TILE]
   __shared__ u64 s_cursor[MAXB];
@@ -651,7 +651,7 @@ bool kmer_histogram_hpc_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask, 
 uint32_t kmer_histogram_hpc_entries(uint32_t bucket_bits) { return hpc_table_size((int)(bucket_bits / 2 + 5)); }
 
 hipError_t launch_kmer_histogram_hpc(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint32_t bucket_bits,
-                                     uint64_t *d_bucket_counts, uint64_t *d_fine_hist, void *d_ws, hipStream_t st) {
+                                     uint64_t *d_bucket_counts, uint64_t *d_fine_hist, void *d_ws, hipStream_t st, bool const_k) {
   if (bucket_bits != 6 && bucket_bits != 8) return hipErrorInvalidValue;
   const uint32_t entries = kmer_histogram_hpc_entries(bucket_bits);
   MGC_CHECK(hipMemsetAsync(d_bucket_counts, 0, sizeof(uint64_t) << bucket_bits, st));
@@ -665,9 +665,22 @@ hipError_t launch_kmer_histogram_hpc(const uint8_t *d_bases, uint64_t n_bases, u
                               (int)(sizeof(u32) * hpc_table_size(8)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(u32) * hpc_table_size(9)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel<8, 31>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(u32) * hpc_table_size(8)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel<9, 31>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(u32) * hpc_table_size(9)));
     attr_done = true;
   }
-  if (bucket_bits == 6)
+  const bool k31 = kmer_const_k(k, mode, const_k) == 31;
+  if (k31 && bucket_bits == 6)
+    hipLaunchKernelGGL((kmer_hist_fine_kernel<8, 31>), dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
+                       d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
+                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
+  else if (k31)
+    hipLaunchKernelGGL((kmer_hist_fine_kernel<9, 31>), dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
+                       d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
+                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
+  else if (bucket_bits == 6)
     hipLaunchKernelGGL(kmer_hist_fine_kernel<8>, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
                        d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
                        reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
@@ -739,7 +752,10 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
                      d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,                                  \
                      reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys), (u64)0, (u64)0)
   const int kc = (nb == 64 && sfx_mask == 0) ? kmer_const_k(k, mode, const_k) : 0;
-  if (kc == 21)      MGC_KPC_LAUNCH(u64, 21);
+  if (nb == 256 && sfx_mask == 0 && kmer_const_k(k, mode, const_k) == 31)          // (k = 31 `compress` beyond ~4 Gbp: 256 buckets, 4 KiB of tables instead of 16)
+    hipLaunchKernelGGL((kmer_partition_kernel<u64, 256, false, 31, 8>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st,
+                       d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)0, (u64)0);
+  else if (kc == 21) MGC_KPC_LAUNCH(u64, 21);
   else if (kc == 31) MGC_KPC_LAUNCH(u64, 31);
   else if (kc == 51) MGC_KPC_LAUNCH(K128, 51);
   else if (k <= 32) { if (nb <= 64) MGC_KP_LAUNCH(u64, 64); else MGC_KP_LAUNCH(u64, KP_MAX_BUCKETS); }

@@ -4,7 +4,7 @@
 #   the forced-sharded step, the other configs' single-GPU legs.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 export TMPDIR=/tmp
 TAG=$TAG bash scripts/gpu_final.sh > gpurun_out/${TAG}_final.log 2>&1; tail -30 gpurun_out/${TAG}_final.log
 TAG=${TAG}_sq bash scripts/gpu_pmc_kernels.sh > gpurun_out/${TAG}_sq.log 2>&1; tail -3 gpurun_out/${TAG}_sq.log
@@ -16,3 +16,4 @@ for a in "k21 21" "k31 31" "k31c 31 250000 1 20000" "k51 51"; do set -- $a; n=$1
   python -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1], round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['stage_ms_per_step'].items()})" $O/kb_$n.json
 done
 cat $O/kb_k21.json $O/kb_k31.json $O/kb_k31c.json $O/kb_k51.json > $O/kbench.jsonl
+TAG=$TAG bash scripts/gpu_pmc_legs.sh > gpurun_out/${TAG}_pmc_legs.log 2>&1; tail -25 gpurun_out/${TAG}_pmc_legs.log
