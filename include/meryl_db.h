@@ -264,7 +264,7 @@ int mgc_count_node(const mgc_count_config *cfg, uint32_t n_ranks, const int *dev
  * and count their waves and park every counted wave as a run (include: mgc_runs_*; HBM first, pinned host DRAM beyond
  * the budget); after the last batch every owner merges its runs once into its part of the database.  batch_bases = 0:
  * derived from the free HBM (one batch when everything fits -- then this IS mgc_count_node, waves streamed to the writer
- * as they are counted).  MGC_NODE_BATCH_BASES overrides (tests). */
+ * as they are counted). */
 int mgc_count_node_batched(const mgc_count_config *cfg, uint32_t n_ranks, const int *devices,
                            const uint8_t *const *d_bases, const uint64_t *n_bases, uint64_t batch_bases,
                            const char *db_path, int host_threads, mgc_node_profile *prof);
