@@ -91,6 +91,29 @@ def dev_kmer_partition(bases, k, mode=capi.MODE_CANONICAL, bucket_bits=6):
     return keys, h_counts
 
 
+def dev_kmer_histogram_keep(bases, k, mode=capi.MODE_CANONICAL, bucket_bits=6):
+    """k-mers per bucket of a base stream -> (uint64[2^bucket_bits] on the host, token).  The token keeps the per-workgroup
+    histogram rows the partition kernel takes its private cursors from (dev_kmer_partition_into)."""
+    L = capi.lib()
+    nb = 1 << bucket_bits
+    ws_bytes = L.mgc_dev_partition_workspace_bytes(bucket_bits)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=bases.device)
+    counts = _u64(nb, bases.device)
+    capi.check(L.mgc_dev_kmer_histogram(_ptr(bases), bases.numel(), k, mode, bucket_bits, _ptr(counts), _ptr(ws), ws_bytes,
+                                        _stream_ptr()), "mgc_dev_kmer_histogram")
+    return counts.cpu().numpy().astype(np.uint64), (bases, k, mode, bucket_bits, ws, ws_bytes)
+
+
+def dev_kmer_partition_into(token, starts, out):
+    """The partition of dev_kmer_histogram_keep's base stream with EXPLICIT bucket starts (key indices into `out`, any order,
+    gaps allowed): bucket b's k-mers land at out[starts[b] : starts[b] + count[b]].  What lets a sharded count write the
+    buckets a rank owns itself straight into its inbox instead of copying them there (count_sharded)."""
+    bases, k, mode, bucket_bits, ws, ws_bytes = token
+    d_starts = torch.from_numpy(np.asarray(starts, dtype=np.uint64).astype(np.int64)).to(bases.device)
+    capi.check(capi.lib().mgc_dev_kmer_partition(_ptr(bases), bases.numel(), k, mode, bucket_bits, _ptr(d_starts), _ptr(out),
+                                                 _ptr(ws), ws_bytes, _stream_ptr()), "mgc_dev_kmer_partition")
+
+
 def dev_radix_sort(keys, begin_bit, end_bit):
     """Sorts keys on bits [begin_bit, end_bit): an int64[N] cuda tensor (as uint64) or an
     int64[N, 2] tensor of {lo, hi} rows (128-bit keys).  Returns the sorted tensor."""
@@ -564,6 +587,8 @@ def release_cached_sessions():
 class HipOps:
     """The device operators count_sharded drives (all HIP, via the C-ABI)."""
     partition = staticmethod(dev_kmer_partition)
+    histogram_keep = staticmethod(dev_kmer_histogram_keep)
+    partition_into = staticmethod(dev_kmer_partition_into)
     count_files = staticmethod(dev_count_files)
 
     @staticmethod
@@ -692,12 +717,16 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
     n_local_distinct = 0
     parts = []
     f0 = f1 = 0
+    proto = bases.new_empty((0, 2) if k > 32 else (0,), dtype=torch.int64)       # (the shape of a key tensor: {lo, hi} rows for k > 32)
     for bi, (sa, sb) in enumerate(slices):
-        keys, local_counts = ops.partition(bases[sa:sb], k, mode, bits)              # grouped by bucket, ascending
-        mark("partition")
+        # Histogram first, partition after the plan (round 5): the partition takes explicit bucket starts, so the buckets this rank
+        # OWNS go straight to their place in its inbox -- no copy to itself (35 ms of a 10 Gbp rank at one GPU, 1/world of the
+        # exchange on a node) -- and the others into a compact send area in front of it.
+        local_counts, tok = ops.histogram_keep(bases[sa:sb], k, mode, bits)
+        mark("histogram")
         local_counts = np.asarray(local_counts).astype(np.int64)
         # one small all-gather gives every rank the same [rank][file] histogram -> same cut points
-        fc = torch.from_numpy(local_counts).to(keys.device)
+        fc = torch.from_numpy(local_counts).to(bases.device)
         all_counts = [torch.empty_like(fc) for _ in range(world)]
         dist.all_gather(all_counts, fc, group=group)
         per_rank = torch.stack(all_counts).cpu().numpy()                             # [world][2^bits]
@@ -713,10 +742,19 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
                 runs = ops.open_runs(k, db["w_prefix"], runs_budget if runs_budget is not None else 0xFFFFFFFFFFFFFFFF)
         file_total = per_rank[:, f0:f1].sum(axis=0)                                  # keys per owned file
         file_off = np.concatenate([[0], np.cumsum(file_total)]).astype(np.int64)
-        inbox = ops.empty_keys(int(file_total.sum()), keys)
-
-        local_off = np.concatenate([[0], np.cumsum(local_counts)]).astype(np.int64)
+        send_counts = local_counts.copy()
+        send_counts[f0:f1] = 0                                                       # what leaves this rank
+        n_send = int(send_counts.sum())
+        local_off = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)   # send area: the other ranks' buckets, ascending
+        starts = local_off[:-1].copy()
+        for f in range(f0, f1):                                                      # own buckets: behind the earlier ranks' pieces in the inbox
+            starts[f] = n_send + int(file_off[f - f0]) + int(per_rank[:rank, f].sum())
+        buf = ops.empty_keys(n_send + int(file_total.sum()), proto)
         mark("plan")
+        ops.partition_into(tok, starts, buf)
+        del tok
+        keys, inbox = buf[:n_send], buf[n_send:]
+        mark("partition")
 
         # The exchange runs in waves: wave i carries, for every rank, the pieces of the i-th group of `bpw` buckets of that
         # rank's range.  While wave i is on the links the owner counts the buckets of wave i-1 (the same grouping passes +
@@ -732,10 +770,13 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
             longest = 0
             for dst in range(world):
                 for f in range(cuts[dst] + i * bpw, min(cuts[dst + 1], cuts[dst] + (i + 1) * bpw)):
-                    sends.append((dst, keys[int(local_off[f]):int(local_off[f + 1])]))
+                    if dst != rank:                                                  # (the own pieces are in the inbox already)
+                        sends.append((dst, keys[int(local_off[f]):int(local_off[f + 1])]))
                     longest = max(longest, int(per_rank[:, f].max()))
             for f in range(f0 + i * bpw, min(f1, f0 + (i + 1) * bpw)):
                 for src in range(world):
+                    if src == rank:
+                        continue
                     a = int(file_off[f - f0] + per_rank[:src, f].sum())
                     recvs.append((src, inbox[a:a + int(per_rank[src, f])]))
             return exchange_segments(sends, recvs, keys.device, group, max_rows=longest, wait=False)
@@ -774,7 +815,7 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
             if i == 0 and prof:
                 torch.cuda.synchronize()
                 stage_s["first_wave_exposed"] = stage_s.get("first_wave_exposed", 0.0) + _time.perf_counter() - t_first
-        del keys, inbox
+        del keys, inbox, buf
         mark("exchange+count")
     if runs is not None:
         runs.write(sink, f0 * blocks_per_bucket, f1 * blocks_per_bucket)

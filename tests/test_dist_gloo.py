@@ -43,6 +43,24 @@ def _worker(rank, world, port, k, seed, q):
             return torch.from_numpy(lo[order].view(np.int64).copy()), counts
 
         @staticmethod
+        def histogram_keep(bases, k_, mode, bucket_bits):
+            _, lo = oracle.enumerate_kmers(bases.numpy().tobytes(), k_, mode)
+            b = (lo >> np.uint64(2 * k_ - bucket_bits)).astype(np.int64)
+            order = np.argsort(b, kind="stable")
+            counts = np.bincount(b, minlength=1 << bucket_bits).astype(np.uint64)
+            return counts, (lo[order], counts)
+
+        @staticmethod
+        def partition_into(token, starts, out):                      # bucket b's k-mers at out[starts[b] : starts[b] + count[b]]
+            keys, counts = token
+            o = out.numpy().view(np.uint64)
+            at = 0
+            for b, c in enumerate(counts):
+                c = int(c)
+                o[int(starts[b]):int(starts[b]) + c] = keys[at:at + c]
+                at += c
+
+        @staticmethod
         def count_files(keys, file_counts, k_, mode):
             # stand-in for mgc_count_partitioned: the keys arrive file-major, each file's pieces back to back
             a = keys.numpy().view(np.uint64)
