@@ -1465,7 +1465,7 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
   if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = out;
 }
 
-// The same for 16-byte keys (k >= 33): slots are claimed through their count word as in hash_count128_kernel, lanes of a
+// The same for 16-byte keys (k >= 33) and 12-byte K96 records: slots are claimed through their count word, lanes of a
 // wave that hold the first active lane's suffix are merged into one weighted insert, ranges are 128-bit.
 template <int BLOCK, int CAP, int SLOTS, bool WIDE, typename KT = K128>   // KT: K128, or 12-byte K96 records
 __global__ __launch_bounds__(BLOCK)
