@@ -22,6 +22,28 @@ def test_pmc_traffic_of_the_judged_workload_is_committed():
     assert b.pmc_traffic(12345, "hash_count_multi_kernel") == (None, None)      # counters of another workload are never borrowed
 
 
+def test_pmc_traffic_is_the_launch_weighted_mean_over_instantiations(tmp_path, monkeypatch):
+    """`roofline.traffic` must describe the launches `algorithmic_bytes_per_launch` describes -- every
+    instantiation of the kernel weighted by its launches, plus the bytes of the retry / streaming kernels of the same file launch
+    (numerator only); a synthetic counter file makes the arithmetic checkable."""
+    import json
+    b = _bench()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r99_pmc_traffic.json").write_text(json.dumps({"reads_per_gpu": 777, "all_kernels": {
+        "hash_count_multi_kernel<256, 1536, 2048, 1, false>": {"launches": 45, "fetch_bytes_per_launch": 600.0, "write_bytes_per_launch": 200.0},
+        "hash_count_multi_kernel<256, 1536, 2048, 2, false>": {"launches": 15, "fetch_bytes_per_launch": 300.0, "write_bytes_per_launch": 100.0},
+        "hash_count_huge_kernel<unsigned int>": {"launches": 30, "fetch_bytes_per_launch": 10.0, "write_bytes_per_launch": 2.0},
+        "radix_group_kernel<unsigned int, 9>": {"launches": 64, "fetch_bytes_per_launch": 5.0, "write_bytes_per_launch": 5.0},
+        "never_launched<1>": {"launches": 0, "fetch_bytes_per_launch": None, "write_bytes_per_launch": None}}}))
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    t, src = b.pmc_traffic(777, "hash_count_multi_kernel", also=("hash_count_kernel", "hash_count_huge_kernel"))
+    assert abs(t - (45 * 800.0 + 15 * 400.0 + 30 * 12.0) / 60) < 1e-9 and "2 instantiations" in src
+    t1, _ = b.pmc_traffic(777, "hash_count_multi_kernel")
+    assert abs(t1 - (45 * 800.0 + 15 * 400.0) / 60) < 1e-9
+    assert b.pmc_traffic(777, "no_such_kernel") == (None, None)
+
+
 def test_roofline_object_arithmetic():
     b = _bench()
     steps, ms_per_step = 3, 120.0
