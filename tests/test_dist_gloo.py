@@ -89,7 +89,7 @@ def _worker(rank, world, port, k, seed, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k", [(2, 21), (3, 16), (2, 31)])
+@pytest.mark.parametrize("world,k", [(2, 21), (3, 16), (2, 31), (1, 21)])
 def test_count_sharded_equals_single(oracle_lib, world, k):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
