@@ -390,6 +390,12 @@ typedef struct mgc_profile {
   uint64_t finish_bytes, finish_keys;
   uint32_t finish_launches;
   uint32_t wide_msd_files;         /* files whose WHOLE keys took the high-digit-first grouping passes (mgc_device.h, launch_group_wide) */
+  /* round 6: which plans the files took */
+  uint32_t stream_files;           /* files on the distinct-sized count (hash_count_stream_kernel) and its coarser sub-buckets */
+  uint32_t k96_files;              /* files that lay as 12-byte K96 records (k = 33..51) */
+  uint32_t k96_widened_files;      /* ... of which widened back to 16-byte keys (an oversized sub-bucket nothing streams) */
+  uint64_t stream_retries;         /* sub-buckets with more distinct suffixes than that kernel's table holds (counted by its retry launch) */
+  double   probe_ratio;            /* distinct / instances of the probe file that chose between the plans (0: no probe ran) */
 } mgc_profile;
 int mgc_set_profiling(mgc_session *s, int enable);
 int mgc_get_profile(const mgc_session *s, mgc_profile *p);

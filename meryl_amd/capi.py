@@ -99,6 +99,11 @@ class Profile(ctypes.Structure):
         ("finish_keys", ctypes.c_uint64),
         ("finish_launches", ctypes.c_uint32),
         ("wide_msd_files", ctypes.c_uint32),
+        ("stream_files", ctypes.c_uint32),
+        ("k96_files", ctypes.c_uint32),
+        ("k96_widened_files", ctypes.c_uint32),
+        ("stream_retries", ctypes.c_uint64),
+        ("probe_ratio", ctypes.c_double),
     ]
 
 

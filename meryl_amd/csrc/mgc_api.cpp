@@ -1170,6 +1170,14 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     std::vector<char> hpc_digits(nb, 0);
     std::vector<uint64_t> gbase(nb + 1), sbase(nb + 1);
     gbase[0] = sbase[0] = 0;
+    // fstream[b] (round 6): the file takes the DISTINCT-sized count (hash_count_stream_kernel: up to 4094 keys per sub-bucket streamed
+    // through a table that holds ~1280 distinct suffixes) and with it one grouping bit fewer -- sub-buckets of 1152..2304 k-mers on
+    // average instead of 576..1152, so that a file of up to 302 M k-mers groups by an eight-bit first digit (256-byte runs out of
+    // the 16384-key tiles instead of 128-byte ones).  Narrowed files whose suffix fits the packed entry (8..20 bits).
+    std::vector<char> fstream(nb, 0);
+    std::vector<uint32_t> top_str(nb, 0);                              // the candidate: grouping bits under that plan (0: none)
+    const bool stream_on = sw.hash_stream != 0 && kw == 1 && !c.homopoly_compress;
+    const uint64_t starget = mgc::finish_stream_target(sw);
     // `compress`: the grouping digits are dense ranks of five homopolymer-free bases (make_hpc_group_plan): 10 key bits
     // hold 243 patterns, 20 bits 59049.  Needs the remaining bits to be whole bases (the 64 files, or an even number of
     // bucket bits) and the bucket to fit 59049 sub-buckets; otherwise the generic bit digits below (MGC_HPC_DIGITS=0: always).
@@ -1185,6 +1193,14 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         while (t < rem_bits && t < 26 && (h_counts[b] >> t) > target) t++;
         // tests reach the large-input plans (two nine-bit digits, 18-bit suffixes at k = 21) on small inputs
         if (sw.min_top) { const uint32_t m = sw.min_top; if (h_counts[b] && t < m) t = m < rem_bits ? m : rem_bits; }
+        if (stream_on && h_counts[b]) {
+          uint32_t ts = 0;
+          while (ts < rem_bits && ts < 26 && (h_counts[b] >> ts) > starget) ts++;
+          if (sw.min_top) { const uint32_t m = sw.min_top; if (ts < m) ts = m < rem_bits ? m : rem_bits; }
+          if (rem_bits - ts > 20) ts = rem_bits - 20;                  // the suffix has to fit the packed entry
+          // (a plan that does not coarsen the file keeps the kernels it has -- unless MGC_HASH_STREAM=1 asks for the new one)
+          if (ts >= 1 && ts <= t && ts <= 18 && mgc::finish_stream_ok(kw, rem_bits - ts) && (ts < t || sw.hash_stream > 0)) top_str[b] = ts;
+        }
       }
       if (c.homopoly_compress && t && !hpc_digits[b]) {
         // homopolymer-compressed sequence never repeats a base: every 2-bit group after the first takes 3 of its 4
@@ -1195,31 +1211,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         t = tc < rem_bits ? (tc < 26 ? tc : 26) : rem_bits;
       }
       top_bits[b] = t;
-      const uint64_t ng = h_counts[b] ? ((uint64_t)1 << t) : 0;
-      gbase[b + 1] = gbase[b] + ng;
-      sbase[b + 1] = sbase[b] + (ng ? ng + 1 : 0);
     }
-    const uint64_t ng_total = gbase[nb];
-    HIP_TRY(s, s->ensure(mgc_session::B_SUBSTART, sizeof(uint64_t) * (sbase[nb] + 1)));
-    HIP_TRY(s, s->ensure(mgc_session::B_GROUPS, sizeof(uint64_t) * (ng_total + 2 + 3 * (uint64_t)nb)));
-    HIP_TRY(s, s->ensure(mgc_session::B_LARGE, sizeof(uint32_t) * (ng_total + 1)));
-    HIP_TRY(s, s->ensure(mgc_session::B_NONEMPTY, sizeof(uint32_t) * (ng_total + 1) + sizeof(uint64_t) * 2 * ((uint64_t)nb + 1)));
-    HIP_TRY(s, s->ensure(mgc_session::B_GSCAN, mgc::finish_scan_scratch_bytes(ng_total + 1)));
-    HIP_TRY(s, s->ensure(mgc_session::B_RLE_WS, mgc::rle_workspace_bytes(max_bucket)));
-    uint64_t *d_substart = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_SUBSTART].p);
-    uint64_t *d_group    = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_GROUPS].p);   // [ng_total+1], then the files' statistics
-    // per file, three words side by side (one small copy brings a file's back): [0] its largest sub-bucket, [1] how many are
-    // above the persistent kernels' capacity, [2] how many are not empty
-    uint64_t *d_stats    = d_group + ng_total + 1;
-    auto d_maxsub  = [&](uint32_t b) { return d_stats + 3 * (size_t)b; };
-    auto d_nlarge  = [&](uint32_t b) { return d_stats + 3 * (size_t)b + 1; };
-    auto d_nzcount = [&](uint32_t b) { return d_stats + 3 * (size_t)b + 2; };
-    uint32_t *d_large    = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_LARGE].p);
-    uint64_t *d_retrycnt = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_NONEMPTY].p) + nb + 1;  // [nb] hash_count_multi_kernel's retry lists
-    uint32_t *d_nz       = reinterpret_cast<uint32_t *>(d_retrycnt + nb + 1);                         // [ng_total] (a dense file's part: its retry list)
-    HIP_TRY(s, hipMemsetAsync(s->buf[mgc_session::B_NONEMPTY].p, 0, sizeof(uint64_t) * 2 * ((size_t)nb + 1), st));
-    HIP_TRY(s, hipMemsetAsync(d_group, 0, sizeof(uint64_t) * (ng_total + 1 + 3 * (size_t)nb), st));   // empty sub-buckets stay 0
-    void     *rle_ws     = s->buf[mgc_session::B_RLE_WS].p;
 
     // ---- A. global LSB passes on the top bits only ----
     // the finish only needs the file grouped by its top bits
@@ -1247,7 +1239,64 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       // (only the hash-count kernels translate the sub-bucket numbers of whole keys)
       wide_msd[b] = !narrow[b] && d_fine && nb <= 64 && mgc::finish_can_stream(kw, low) &&
                     mgc::sort_plan_wide_msd(fplan[b], h_counts[b], sw.wide_msd);
+      if (top_str[b]) {                                      // the coarser plan stays a candidate if the file narrows under BOTH plans
+        mgc::SortPlan sp;
+        mgc::make_sort_plan(rem_bits - top_str[b], rem_bits, &sp);
+        if (sp.mode == 0) sp.mode = 3;
+        if (!(narrow[b] && mgc::finish_can_stream(kw, rem_bits - top_str[b]) && mgc::sort_plan_narrows(sp, h_counts[b], kw, sw.narrow)))
+          top_str[b] = 0;
+      }
     }
+    // a file's sub-bucket tables are laid out for the FINER of its two plans (2^top_bits slots); ngf(b) of them are in use
+    for (uint32_t b = 0; b < nb; b++) {
+      const uint64_t ng = h_counts[b] ? ((uint64_t)1 << top_bits[b]) : 0;
+      gbase[b + 1] = gbase[b] + ng;
+      sbase[b + 1] = sbase[b] + (ng ? ng + 1 : 0);
+    }
+    auto ngf = [&](uint32_t b) -> uint64_t { return h_counts[b] ? ((uint64_t)1 << top_bits[b]) : 0; };
+    auto take_stream_plan = [&](uint32_t b) {                // the candidate becomes the file's plan (narrow[] / wide_msd[] stay as they are)
+      fstream[b] = 1; top_bits[b] = top_str[b];
+      mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fplan[b]);
+      if (fplan[b].mode == 0) fplan[b].mode = 3;
+      s->prof.stream_files++;
+    };
+    // Which plan?  The distinct-sized count pays off when a sub-bucket's distinct suffixes are few against its keys (measured at
+    // 10 Gbp, profiles/r06_coverage_ab.txt: D / N = 0.14 -> -3.6 ms, 0.24 -> -1.5, 0.45 -> +3, 0.72 -> +50: above its table the retry
+    // launch counts the sub-bucket a second time), and D / N is not known before something has been counted: ONE file -- the PROBE
+    // file, the smallest one that is still a fair sample -- goes through its passes and its count first, on the finer plan; its
+    // distinct / instances ratio (one 8-byte copy) decides for the others.  MGC_HASH_STREAM=1: every candidate, no probe; 0: none.
+    int probe = -1;
+    {
+      bool any_cand = false;
+      for (uint32_t b = 0; b < nb; b++) any_cand = any_cand || top_str[b] != 0;
+      if (any_cand && sw.hash_stream > 0) { for (uint32_t b = 0; b < nb; b++) if (top_str[b]) take_stream_plan(b); }
+      else if (any_cand) {
+        uint64_t best = ~0ull;
+        for (uint32_t b = 0; b < nb; b++)
+          if (h_counts[b] >= max_bucket / 16 && h_counts[b] >= 4096 && h_counts[b] < best) { best = h_counts[b]; probe = (int)b; }
+      }
+    }
+    const uint64_t ng_total = gbase[nb];
+    HIP_TRY(s, s->ensure(mgc_session::B_SUBSTART, sizeof(uint64_t) * (sbase[nb] + 1)));
+    HIP_TRY(s, s->ensure(mgc_session::B_GROUPS, sizeof(uint64_t) * (ng_total + 2 + 3 * (uint64_t)nb)));
+    HIP_TRY(s, s->ensure(mgc_session::B_LARGE, sizeof(uint32_t) * (ng_total + 1)));
+    HIP_TRY(s, s->ensure(mgc_session::B_NONEMPTY, sizeof(uint32_t) * (ng_total + 1) + sizeof(uint64_t) * 2 * ((uint64_t)nb + 1)));
+    HIP_TRY(s, s->ensure(mgc_session::B_GSCAN, mgc::finish_scan_scratch_bytes(ng_total + 1)));
+    HIP_TRY(s, s->ensure(mgc_session::B_RLE_WS, mgc::rle_workspace_bytes(max_bucket)));
+    uint64_t *d_substart = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_SUBSTART].p);
+    uint64_t *d_group    = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_GROUPS].p);   // [ng_total+1], then the files' statistics
+    // per file, three words side by side (one small copy brings a file's back): [0] its largest sub-bucket, [1] how many are
+    // above the persistent kernels' capacity, [2] how many are not empty
+    uint64_t *d_stats    = d_group + ng_total + 1;
+    auto d_maxsub  = [&](uint32_t b) { return d_stats + 3 * (size_t)b; };
+    auto d_nlarge  = [&](uint32_t b) { return d_stats + 3 * (size_t)b + 1; };
+    auto d_nzcount = [&](uint32_t b) { return d_stats + 3 * (size_t)b + 2; };
+    uint32_t *d_large    = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_LARGE].p);
+    uint64_t *d_retrycnt = reinterpret_cast<uint64_t *>(s->buf[mgc_session::B_NONEMPTY].p) + nb + 1;  // [nb] retry lists of the count kernels
+    uint32_t *d_nz       = reinterpret_cast<uint32_t *>(d_retrycnt + nb + 1);                         // [ng_total] (a dense file's part: its retry list)
+    HIP_TRY(s, hipMemsetAsync(s->buf[mgc_session::B_NONEMPTY].p, 0, sizeof(uint64_t) * 2 * ((size_t)nb + 1), st));
+    HIP_TRY(s, hipMemsetAsync(d_group, 0, sizeof(uint64_t) * (ng_total + 1 + 3 * (size_t)nb), st));   // empty sub-buckets stay 0
+    void     *rle_ws     = s->buf[mgc_session::B_RLE_WS].p;
     {
       // 5-byte layout: 8-byte keys with 33..40 bits below the file (k = 20..23), every non-empty file on the narrowed passes with
       // the high digit first off the fifteen-bit histogram (the instrumented instantiation reads whole keys).  MGC_SOA5=0: whole keys.
@@ -1286,13 +1335,23 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     // high digit first: the headers of all narrowed files in one launch, their look-back granules zeroed in one memset
     std::vector<size_t> nws_off(nb + 1, 0);
     unsigned char *d_nws = nullptr, *d_nhdrs = nullptr;
-    if (d_fine && nb <= 64) {
+    // (with a probe file: its header first, the others' once their plan is known)
+    auto prepare_headers = [&](int only, int skip) -> int {
       unsigned char bits_a[64] = {0}, on[64] = {0};
+      bool any = false;
+      for (uint32_t b = 0; b < nb; b++) {
+        if ((!narrow[b] && !wide_msd[b]) || (only >= 0 && (int)b != only) || (int)b == skip) continue;
+        on[b] = 1; bits_a[b] = (unsigned char)fplan[b].pass_bits[1]; any = true;
+      }
+      if (any) HIP_TRY(s, mgc::launch_narrow_prepare(d_fine, nb, bits_a, on, d_nhdrs, st));
+      return MGC_OK;
+    };
+    if (d_fine && nb <= 64) {
       bool any = false;
       for (uint32_t b = 0; b < nb; b++) {
         nws_off[b + 1] = nws_off[b];
         if (!narrow[b] && !wide_msd[b]) continue;
-        on[b] = 1; bits_a[b] = (unsigned char)fplan[b].pass_bits[1]; any = true;
+        any = true;
         nws_off[b + 1] += ((narrow[b] ? mgc::narrow_scratch_bytes(h_counts[b]) : mgc::wide_scratch_bytes(h_counts[b], kw)) + 255) / 256 * 256;
       }
       if (any) {
@@ -1300,7 +1359,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         HIP_TRY(s, s->ensure(mgc_session::B_NARROW_WS, nws_off[nb]));
         d_nhdrs = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_SORT_HDRS].p);
         d_nws = reinterpret_cast<unsigned char *>(s->buf[mgc_session::B_NARROW_WS].p);
-        HIP_TRY(s, mgc::launch_narrow_prepare(d_fine, nb, bits_a, on, d_nhdrs, st));
+        { const int prc = prepare_headers(probe >= 0 ? probe : -1, -1); if (prc != MGC_OK) return prc; }
         HIP_TRY(s, hipMemsetAsync(d_nws, 0, nws_off[nb], st));
       }
     }
@@ -1369,7 +1428,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (h_counts[b] == 0) return MGC_OK;
       if (narrow[b] || wide_msd[b])
         HIP_TRY(s, mgc::launch_subbucket_max(d_substart + sbase[b], kw, rem_bits - top_bits[b], top_bits[b], d_maxsub(b),
-                                             d_large + gbase[b], d_nlarge(b), d_nz + gbase[b], d_nzcount(b), st));
+                                             d_large + gbase[b], d_nlarge(b), d_nz + gbase[b], d_nzcount(b), st,
+                                             fstream[b] ? mgc::finish_stream_capacity() : 0));
       else
         HIP_TRY(s, mgc::launch_subbucket_bounds(X + kbytes * h_starts[b], h_counts[b], kw, rem_bits - top_bits[b], top_bits[b],
                                                 d_substart + sbase[b], d_maxsub(b), d_large + gbase[b], d_nlarge(b),
@@ -1380,13 +1440,12 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     uint32_t grouped = 0;                                    // files [0, grouped) have their passes on the session stream
     auto group_upto = [&](uint32_t end) -> int {
       for (; grouped < end && grouped < nb; grouped++) {
-        const int rc = group_file(grouped);
-        if (rc != MGC_OK) return rc;
+        if ((int)grouped != probe) { const int rc = group_file(grouped); if (rc != MGC_OK) return rc; }   // (the probe file went first)
         if (grouped + 1 == nb) {
           tm.end(MGC_STAGE_SORT);
           tm.begin(MGC_STAGE_RLE);
           // the small statistics kernels of all files back to back: they run beside each other
-          for (uint32_t b = 0; b < nb; b++) { const int rc2 = stats_file(b); if (rc2 != MGC_OK) return rc2; }
+          for (uint32_t b = 0; b < nb; b++) { if ((int)b == probe) continue; const int rc2 = stats_file(b); if (rc2 != MGC_OK) return rc2; }
           HIP_TRY(s, hipMemcpyAsync(s->h_stats, d_stats, sizeof(uint64_t) * 3 * (size_t)nb, hipMemcpyDeviceToHost, st));
         }
       }
@@ -1452,11 +1511,13 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         // an oversized sub-bucket that cannot be streamed: the LDS sort / the stable-sort fallback want whole k-mers back
         if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));   // Y is the streaming kernels' second buffer
         forked = false;
-        HIP_TRY(s, mgc::launch_widen_groups(seg, d_substart + sbase[b], gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, low, (void *)Y, st,
+        HIP_TRY(s, mgc::launch_widen_groups(seg, d_substart + sbase[b], ngf(b), (uint64_t)b << rem_bits, low, (void *)Y, st,
                                             tr_a[b], tr_b[b]));
         HIP_TRY(s, hipMemcpyAsync(seg, Y, kbytes * h_counts[b], hipMemcpyDeviceToDevice, st));
         narrow[b] = 0;
         unordered = tr_a[b] != 0;      // grouped, but not in key order: only the stable sort of all bits can take it from here
+        // (the coarser plan's oversized list was cut at ITS capacity: the whole-key kernels would miss the sub-buckets in between)
+        if (fstream[b]) { fstream[b] = 0; unordered = true; }
         cnt_extra.emplace_back();      // the back half of its region holds k-mers again: counts of its own
         HIP_TRY(s, cnt_extra.back().alloc(sizeof(uint32_t) * h_counts[b]));
         cnt_ptr[b] = cnt_extra.back().as<uint32_t>();
@@ -1481,12 +1542,14 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
           fin_in_bytes += h_counts[b] * (narrow[b] ? 4u : (file_k96[b] ? 12u : (uint64_t)kbytes));
           fin_narrow = fin_narrow || narrow[b];
         }
-        HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], gbase[b + 1] - gbase[b], low, h_nlarge[b],
+        HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], ngf(b), low, h_nlarge[b],
                                            d_large + gbase[b], cnt_ptr[b], d_group + gbase[b], stream, (void *)huge_alt, st_huge,
                                            // the list pays off only when a good part of the 2^t grid is empty
-                                           (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b]) && !finish_nolist) ? d_nz + gbase[b] : nullptr,
+                                           (4 * h_nzcount[b] < 3 * ngf(b) && !finish_nolist) ? d_nz + gbase[b] : nullptr,
                                            d_nzcount(b), fst, narrow[b] != 0, tr_a[b], tr_b[b], h_maxsub[b], h_counts[b],
-                                           d_nz + gbase[b], d_retrycnt + b, file_k96[b] != 0, sw.hash_multi, sw.hash_dbg));
+                                           // (the distinct-sized count's retry list: behind the file's oversized list -- a sub-bucket is on one of them at most)
+                                           fstream[b] ? d_large + gbase[b] + h_nlarge[b] : d_nz + gbase[b], d_retrycnt + b, file_k96[b] != 0,
+                                           sw.hash_multi, sw.hash_dbg, fstream[b] ? mgc::finish_stream_capacity() : 0));
         if (s->profiling) (void)hipEventRecord(fin_ev.back().second, fst);
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
@@ -1510,9 +1573,36 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       return MGC_OK;
     };
 
+    if (probe >= 0) {
+      // the probe file: passes, statistics, count -- then its distinct / instances ratio chooses the others' plan
+      const uint32_t pb = (uint32_t)probe;
+      { const int rc = group_file(pb); if (rc != MGC_OK) return rc; }
+      { const int rc = stats_file(pb); if (rc != MGC_OK) return rc; }
+      HIP_TRY(s, hipMemcpyAsync(s->h_stats + 3 * (size_t)pb, d_stats + 3 * (size_t)pb, sizeof(uint64_t) * 3, hipMemcpyDeviceToHost, st));
+      HIP_TRY(s, hipStreamSynchronize(st));
+      h_maxsub[pb] = s->h_stats[3 * (size_t)pb]; h_nlarge[pb] = s->h_stats[3 * (size_t)pb + 1]; h_nzcount[pb] = s->h_stats[3 * (size_t)pb + 2];
+      { const int rc = finish_file(pb); if (rc != MGC_OK) return rc; }
+      if (need_join) {
+        HIP_TRY(s, hipEventRecord(s->ev_join, st_huge));
+        HIP_TRY(s, hipStreamWaitEvent(st, s->ev_join, 0));
+      }
+      forked = false;                                        // (the second stream has to be ordered behind the other files' passes again)
+      uint64_t h_pd = 0;
+      HIP_TRY(s, mgc::launch_sum_u64(d_group + gbase[pb], gbase[pb + 1] - gbase[pb], d_group + ng_total, st));
+      HIP_TRY(s, hipMemcpyAsync(&h_pd, d_group + ng_total, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(s, hipStreamSynchronize(st));
+      const double ratio = (double)h_pd / (double)h_counts[pb];
+      s->prof.probe_ratio = ratio;
+      if (sw.finish_trace) fprintf(stderr, "[finish] probe file %u: %llu distinct of %llu k-mers (%.3f): the other files take the %s plan\n", pb,
+                                   (unsigned long long)h_pd, (unsigned long long)h_counts[pb], ratio, ratio <= 0.30 ? "distinct-sized" : "finer");
+      if (ratio <= 0.30) for (uint32_t b = 0; b < nb; b++) if (b != pb && top_str[b]) take_stream_plan(b);
+      if (d_fine && nb <= 64 && d_nhdrs) { const int prc = prepare_headers(-1, probe); if (prc != MGC_OK) return prc; }
+    }
+    bool stats_back = false;
     for (uint32_t b = 0; b < nb; b++) {
       { const int rc = group_upto(nb); if (rc != MGC_OK) return rc; }
-      if (b == 0) HIP_TRY(s, hipStreamSynchronize(st));
+      if (!stats_back) { HIP_TRY(s, hipStreamSynchronize(st)); stats_back = true; }
+      if ((int)b == probe) continue;
       h_maxsub[b] = s->h_stats[3 * (size_t)b]; h_nlarge[b] = s->h_stats[3 * (size_t)b + 1]; h_nzcount[b] = s->h_stats[3 * (size_t)b + 2];
       const int rc = finish_file(b);
       if (rc != MGC_OK) return rc;
@@ -1521,6 +1611,25 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     if (need_join) {
       HIP_TRY(s, hipEventRecord(s->ev_join, st_huge));
       HIP_TRY(s, hipStreamWaitEvent(st, s->ev_join, 0));
+    }
+
+    // the sub-buckets hash_count_stream_kernel could not hold (more distinct suffixes than its table: low coverage, D ~ N): their
+    // numbers are on the device -- one small copy brings the counts back, the files that have any get the retry launch
+    {
+      bool any_stream = false;
+      for (uint32_t b = 0; b < nb; b++) any_stream = any_stream || (fstream[b] && !fallback[b] && h_counts[b]);
+      if (any_stream) {
+        std::vector<uint64_t> h_retry(nb, 0);
+        HIP_TRY(s, hipMemcpyAsync(h_retry.data(), d_retrycnt, sizeof(uint64_t) * nb, hipMemcpyDeviceToHost, st));
+        HIP_TRY(s, hipStreamSynchronize(st));
+        for (uint32_t b = 0; b < nb; b++) {
+          if (!fstream[b] || fallback[b] || h_retry[b] == 0) continue;
+          s->prof.stream_retries += h_retry[b];
+          HIP_TRY(s, mgc::launch_finish_retry(X + kbytes * h_starts[b], d_substart + sbase[b], ngf(b), rem_bits - top_bits[b],
+                                              cnt_ptr[b], d_group + gbase[b], tr_a[b], tr_b[b], d_large + gbase[b] + h_nlarge[b], d_retrycnt + b,
+                                              h_retry[b], mgc::finish_stream_capacity(), st));
+        }
+      }
     }
 
     // ---- E/F. offsets of every sub-bucket in the packed result ----
@@ -1539,18 +1648,18 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (h_counts[b] == 0) continue;
       void *seg = X + kbytes * h_starts[b];
       // a sparse sub-bucket grid (`compress`: 59049 of 2^20): only the non-empty ones are visited
-      const uint32_t *nzl = (4 * h_nzcount[b] < 3 * (gbase[b + 1] - gbase[b]) && !finish_nolist) ? d_nz + gbase[b] : nullptr;
+      const uint32_t *nzl = (4 * h_nzcount[b] < 3 * ngf(b) && !finish_nolist) ? d_nz + gbase[b] : nullptr;
       if (narrow[b]) {
         HIP_TRY(s, mgc::launch_compact_groups_narrow(seg, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b],
-                                                     gbase[b + 1] - gbase[b], (uint64_t)b << rem_bits, rem_bits - top_bits[b],
+                                                     ngf(b), (uint64_t)b << rem_bits, rem_bits - top_bits[b],
                                                      s->d_unique, s->d_counts, st, tr_a[b], tr_b[b], nzl, h_nzcount[b]));
       } else if (!fallback[b] && file_k96[b]) {
         const unsigned __int128 fb = (unsigned __int128)b << rem_bits;
-        HIP_TRY(s, mgc::launch_compact_groups_k96(seg, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b], gbase[b + 1] - gbase[b],
+        HIP_TRY(s, mgc::launch_compact_groups_k96(seg, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b], ngf(b),
                                                   (uint64_t)fb, (uint64_t)(fb >> 64), s->d_unique, s->d_counts, st, tr_a[b], tr_b[b], nzl, h_nzcount[b]));
       } else if (!fallback[b]) {
         HIP_TRY(s, mgc::launch_compact_groups(seg, kw, cnt_ptr[b], d_substart + sbase[b], d_group + gbase[b],
-                                              gbase[b + 1] - gbase[b], s->d_unique, s->d_counts, st, tr_a[b], tr_b[b], nzl, h_nzcount[b]));
+                                              ngf(b), s->d_unique, s->d_counts, st, tr_a[b], tr_b[b], nzl, h_nzcount[b]));
       } else {
         HIP_TRY(s, mgc::launch_rle_count(seg, h_counts[b], kw, rle_ws, st));
         HIP_TRY(s, mgc::launch_rle_emit(seg, h_counts[b], kw, rle_ws, s->d_unique, s->d_counts, st, d_group + gbase[b]));

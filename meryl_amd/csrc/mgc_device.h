@@ -27,6 +27,8 @@ struct Switches {
   bool group_dbg = false;       // MGC_GROUP_DBG: per-phase cycle sums of the grouping passes (instrumented instantiations)
   bool hash_dbg = false;        // MGC_HASH_DBG: per-phase cycle sums of the count kernels
   int  hash_multi = -1;         // MGC_HASH_MULTI: sub-buckets per iteration of hash_count_multi_kernel (-1: by the file's average; 0: off)
+  int  hash_stream = -1;        // MGC_HASH_STREAM: the distinct-sized count (hash_count_stream_kernel) and its coarser file plan (-1: where the probe
+                                // file's distinct / instances ratio allows it; 0: off; 1: on every file whose suffix fits, whatever the ratio)
   uint32_t min_top = 0;         // MGC_FINISH_MIN_TOP: at least that many grouping bits per file (tests reach the large-input plans)
   uint64_t finish_target = 0;   // MGC_FINISH_TARGET: k-mers per sub-bucket the plan aims at (0: the kernels' default)
   uint64_t stream_max = (uint64_t)1 << 22;   // MGC_STREAM_MAX: sub-buckets up to this many keys are streamed without asking the probe
@@ -146,6 +148,13 @@ hipError_t launch_rle_emit(const void *d_sorted, uint64_t n, uint32_t key_words,
 // ---- sub-bucket finish (LDS sort of the low bits + fused run-length count) ---------------
 uint64_t   finish_capacity_for(uint32_t key_words);     // largest sub-bucket the LDS kernels accept
 uint64_t   finish_target_for(uint32_t key_words, const Switches &sw);       // average sub-bucket size to aim for
+// The distinct-sized count (hash_count_stream_kernel, round 6): narrowed files whose suffix fits its packed entry take sub-buckets of
+// up to finish_stream_capacity() keys (twice the others' average); its table holds finish_stream_distinct() distinct suffixes, a
+// sub-bucket with more goes on the retry list (launch_finish_retry).
+bool       finish_stream_ok(uint32_t key_words, uint32_t low_bits);
+uint64_t   finish_stream_capacity();
+uint64_t   finish_stream_target(const Switches &sw);
+uint64_t   finish_stream_distinct();
 hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_words, uint32_t low, uint32_t top_bits,
                                    uint64_t *d_starts /*[2^top+1]*/, uint64_t *d_max /*atomicMax target*/,
                                    uint32_t *d_large_list /*[2^top]: sub-buckets above the small-kernel capacity*/,
@@ -154,7 +163,8 @@ hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_
                                    hipStream_t st);
 hipError_t launch_subbucket_max(const uint64_t *d_starts, uint32_t key_words, uint32_t low, uint32_t top_bits, uint64_t *d_max,
                                 uint32_t *d_large_list, uint64_t *d_large_count, uint32_t *d_nonempty_list, uint64_t *d_nonempty_count,
-                                hipStream_t st);          // the list half of launch_subbucket_bounds (boundaries already known)
+                                hipStream_t st, uint64_t small_cap = 0 /*0: the capacity of the kernels (key_words, low) selects*/);
+                                // the list half of launch_subbucket_bounds (boundaries already known)
 // sub-buckets above finish_capacity_for(): can they be streamed through the hash-count tables (distinct suffixes fit)?
 bool       finish_can_stream(uint32_t key_words, uint32_t low_bits);
 hipError_t launch_finish_probe(const void *d_keys, uint32_t key_words, const uint64_t *d_starts, uint32_t low_bits,
@@ -173,7 +183,13 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               uint32_t *d_retry_list = nullptr /*[ng] + a zeroed counter: with both, dense narrowed files take hash_count_multi_kernel*/,
                               uint64_t *d_retry_count = nullptr,
                               bool k96 = false /*d_keys: 12-byte K96 records (key_words 2; oversized sub-buckets only with `stream`)*/,
-                              int hash_multi = -1 /*Switches::hash_multi*/, bool hash_dbg = false /*Switches::hash_dbg*/);
+                              int hash_multi = -1 /*Switches::hash_multi*/, bool hash_dbg = false /*Switches::hash_dbg*/,
+                              uint64_t stream_cap = 0 /*nonzero (narrowed dense files, finish_stream_ok): hash_count_stream_kernel counts the
+                              sub-buckets of up to that many keys; the ones with too many distinct suffixes go on d_retry_list*/);
+// the sub-buckets hash_count_stream_kernel put on the retry list (their number is on the device: the caller brings it back first)
+hipError_t launch_finish_retry(void *d_keys32, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits, uint32_t *d_cnt_tmp,
+                               uint64_t *d_group_distinct, uint32_t tr_a, uint32_t tr_b, const uint32_t *d_retry_list,
+                               const uint64_t *d_retry_count, uint64_t n_retry, uint64_t stream_cap, hipStream_t st);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);
 hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,
@@ -192,6 +208,7 @@ hipError_t launch_widen_k96(const void *d_keys96, uint64_t n, uint64_t base_lo, 
 hipError_t launch_widen_groups(const void *d_keys32, const uint64_t *d_starts, uint64_t ng, uint64_t base, uint32_t low_bits, void *d_out64,
                                hipStream_t st, uint32_t tr_a, uint32_t tr_b);      // tr_a != 0: the result is NOT in key order
 hipError_t launch_store_u64(uint64_t *d_dst, const uint64_t *d_src, hipStream_t st);
+hipError_t launch_sum_u64(const uint64_t *d_in, uint64_t n, uint64_t *d_out, hipStream_t st);    // *d_out <- sum of d_in[0, n)
 
 hipError_t launch_block_offsets(const void *d_unique, uint64_t n_distinct, uint32_t key_words, uint32_t w_data,
                                 uint64_t n_prefix, uint64_t *d_block_start, hipStream_t st);

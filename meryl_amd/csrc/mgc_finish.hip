@@ -915,6 +915,308 @@ void hash_count_multi_kernel(u32 *__restrict__ keys, const u64 *__restrict__ sta
 #undef HC_STAMP
 }
 
+// Hash-count with the table sized by DISTINCT suffixes and the keys STREAMED through it in chunks (round 6; replaces
+// countSingleKmers' sort + run-length passes, merylCountArray.C:323-365, like the kernels above).  Why: hash_count_multi_kernel
+// holds all keys of an iteration in registers and sizes its table for all of them being distinct (CAP = 1536 keys), which pins the
+// file plan at sub-buckets of <= 1152 k-mers on average -- 17 or 18 grouping bits, i.e. a nine-bit first digit (128-byte runs) on
+// the large files -- although at the judged 30x a 1030-key sub-bucket holds ~140 distinct suffixes (profiles/r06_gate_distinct.json:
+// D/N = 0.137; p99.99 of D at 2066-key sub-buckets = 652).  Here
+//   * one iteration counts ONE sub-bucket of up to max_size (<= 4094) keys: its keys come in 1..3 chunks of <= BLOCK * KPC keys,
+//     evenly cut; chunk c + 1 (or the first chunk of the next sub-bucket) is in flight while chunk c is inserted -- the same
+//     consume-before-issue order as hash_count_multi_kernel -- and all chunks claim / add into ONE table, no barrier between them;
+//   * a table entry is suffix << 12 | count (suffix <= 20 bits, a count <= 4094 so that EMPTY = all ones is no entry): the claiming
+//     CAS deposits count 1, a duplicate adds 1, entry order == suffix order;
+//   * the table holds SLOTS entries and the claim list DCAP of them -- capacity in DISTINCT suffixes.  A sub-bucket that claims more
+//     (low coverage: D ~ N), or whose probes run long because the table fills, raises s_ovf: nothing of it is written, its number
+//     goes on the retry list, and the LIST instantiation (SLOTS = 8192, DCAP >= max_size: cannot overflow) counts it afterwards;
+//   * the per-distinct phases are hash_count_multi_kernel's (256 bins by the top eight suffix bits, one-wave scan with the table
+//     cleared in its shadow, rank inside the bin) with up to TWO entries per thread in registers (D <= 512), staged through LDS above.
+// LIST: visit the sub-buckets visit[0 .. *visit_count) (a sparse grid's non-empty list; the retry list); otherwise all ng.
+// retry_list == nullptr: the retry launch itself.
+template <int BLOCK, int KPC, int SLOTS, int DCAP, bool LIST, bool DBG>
+__global__ __launch_bounds__(BLOCK, (SLOTS <= 2048 ? 8 : 2))
+void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size_, u32 low_bits,
+                              u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 *__restrict__ dbg,
+                              u32 tr_a, u32 tr_b, const u32 *__restrict__ visit, const u64 *__restrict__ visit_count,
+                              u32 *__restrict__ retry_list, u64 *__restrict__ retry_count) {
+  static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS % (4 * BLOCK) == 0 && DCAP <= SLOTS && DCAP <= 65536 && BLOCK == 256, "table geometry");
+  constexpr u32 CNTB = 12u, CNT_MASK = (1u << CNTB) - 1u, EMPTY = 0xFFFFFFFFu;
+  constexpr u32 CH = (u32)(BLOCK * KPC);
+  constexpr u32 PROBE_MAX = 64u;                                     // probe steps of one key beyond which the table counts as full
+  __shared__ __attribute__((aligned(16))) u32 tk[SLOTS];            // suffix << 12 | count
+  __shared__ __attribute__((aligned(16))) u32 srt[DCAP];            // the distinct entries in bin order
+  __shared__ unsigned short lst[DCAP];                              // slots of the claimed entries, in claim order
+  __shared__ __attribute__((aligned(16))) u32 s_bin[2][BLOCK + 4];  // bin counts -> starts; [BLOCK] = D
+  __shared__ u32 s_nd, s_ovf;
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u32 G = gridDim.x;
+  const u32 low_mask = (u32)((1ull << low_bits) - 1ull);
+  const u32 bshift = low_bits - 8u;                                 // the launcher guarantees 8 <= low_bits <= 20
+  const u32 np = (u32)(LIST ? *visit_count : ng);                   // (a narrowed file: fewer than 2^30 keys, at most 2^18 sub-buckets)
+  const u32 max_size = (u32)max_size_;
+
+  // bounds of sub-bucket g (at position P of the visit order) as ONE vector load of 32-bit values (a narrowed file holds fewer
+  // than 2^30 keys): lane 0 its start, every other lane its end; past the end of the visit order: zeros
+  auto load_starts = [&](u32 P, u32 g) -> u32 {
+    if (P >= np) return 0u;
+    return (u32)starts[g + (lane ? 1u : 0u)];
+  };
+  auto unpack_bounds = [&](u32 bv, u32 &a, u32 &n) {
+    a = (u32)__builtin_amdgcn_readlane((int)bv, 0);
+    n = (u32)__builtin_amdgcn_readlane((int)bv, 1) - a;
+  };
+  // LIST: the number of the sub-bucket at position P (one load, the same address in every lane)
+  auto load_gnum = [&](u32 P) -> u32 { return (LIST && P < np) ? visit[P] : 0u; };
+  // chunks of an n-key sub-bucket: 1..3 of them, evenly cut, whole rows of BLOCK keys (n <= max_size <= 4094 < 3 * CH); 0: not
+  // counted here (empty, or above max_size: the streaming launch's)
+  auto chunk_size = [&](u32 n) -> u32 {
+    if (n == 0u || n > max_size) return 0u;
+    u32 per = n;
+    if (n > 2u * CH) per = ((n + 2u) * 43691u) >> 17;              // ceil(n / 3)
+    else if (n > CH) per = (n + 1u) >> 1;
+    return (per + (u32)BLOCK - 1u) & ~((u32)BLOCK - 1u);
+  };
+  // (uniform guards, lanes past the end re-read the last key: no per-lane predicate, no 64-bit address per slot)
+  auto load_chunk = [&](u32 a, u32 cnt, u32 (&kr)[KPC]) {
+    const u32 *src = keys + a;
+#pragma unroll
+    for (int j = 0; j < KPC; j++) {
+      kr[j] = 0u;
+      if ((u32)j * BLOCK < cnt) {
+        const u32 last = cnt - 1u;
+        const u32 idx = (u32)j * BLOCK + tid;
+        kr[j] = src[idx < last ? idx : last];
+      }
+    }
+  };
+  auto slots_for = [&](u32 n) -> u32 {                              // (2n: D is not known, the keys bound it)
+    if (2u * n <= 256u) return 256u;
+    const u32 s = 1u << (32 - __builtin_clz(2u * n - 1u));
+    return s < (u32)SLOTS ? s : (u32)SLOTS;
+  };
+
+  u32 P = blockIdx.x;
+  u32 a0, a1, g0, g1, n0, n1;                                       // the current sub-bucket, the next one
+  u32 kcur[KPC], comp[KPC];
+  // in flight from one sub-bucket's end to the next: the bounds of the sub-bucket at P + 2G (its number: gb) and, LIST, the number
+  // of the one at P + 3G -- consumed at ONE point, right before the loads of that round are issued (a wait behind newer loads
+  // would wait for them)
+  g0 = LIST ? (u32)__builtin_amdgcn_readfirstlane((int)load_gnum(P)) : P;
+  g1 = LIST ? (u32)__builtin_amdgcn_readfirstlane((int)load_gnum(P + G)) : P + G;
+  u32 gb = LIST ? (u32)__builtin_amdgcn_readfirstlane((int)load_gnum(P + 2 * G)) : P + 2 * G;
+  unpack_bounds(load_starts(P, g0), a0, n0);
+  unpack_bounds(load_starts(P + G, g1), a1, n1);
+  u32 csz = chunk_size(n0), off = 0;                                // the current chunk: keys [off, off + csz) of the current sub-bucket
+  load_chunk(a0, csz < n0 ? csz : n0, kcur);                        // (csz == 0: nothing)
+  u32 bvec = load_starts(P + 2 * G, gb);
+  u32 gv = load_gnum(P + 3 * G);
+  u32 par = 0;
+  u32 cleared = (u32)SLOTS;                                         // tk[0, cleared) is EMPTY whenever an insert phase begins
+  {
+    uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
+    for (u32 i = tid; i < (u32)SLOTS / 4; i += BLOCK) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+    s_bin[0][tid] = 0; s_bin[1][tid] = 0;
+    if (tid == 0) { s_nd = 0; s_ovf = 0; }
+  }
+  __syncthreads();
+
+  u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define HC_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
+  // ONE loop over chunks (one load site: the loads of the next chunk land in the registers the consumed one has left, whichever
+  // sub-bucket it belongs to -- two load sites merged by copies would wait for the loads they had just issued)
+  while (P < np) {
+    if (DBG) t0 = __builtin_readcyclecounter();
+    const bool active = csz != 0u;
+    const u32 rest = n0 - off;
+    const u32 cnt = active ? (rest < csz ? rest : csz) : 0u;
+    const bool last = !active || rest <= csz;
+    const u32 slots = slots_for(n0);
+    const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
+    // the chunk that was loaded a whole chunk ago is consumed into comp[]; only then the next one is issued (a wait for old
+    // registers behind new loads would wait for the new loads: hash_count_multi_kernel)
+#pragma unroll
+    for (int j = 0; j < KPC; j++) {
+      comp[j] = kcur[j] & low_mask;
+      asm volatile("" : "+v"(comp[j]) :: "memory");
+    }
+    const u32 ncs = chunk_size(n1);
+    u32 a2 = 0, n2 = 0, g2 = 0, g3 = 0;
+    if (last) {                                                     // (uniform) everything the last round loaded is consumed here ...
+      unpack_bounds(bvec, a2, n2);
+      g2 = gb;
+      g3 = LIST ? (u32)__builtin_amdgcn_readfirstlane((int)gv) : P + 3 * G;
+    }
+    {
+      const u32 la = last ? a1 : a0 + off + csz;
+      const u32 lrest = last ? n1 : rest - csz, lcs = last ? ncs : csz;
+      load_chunk(la, lrest < lcs ? lrest : lcs, kcur);
+    }
+    if (last) {                                                     // ... and this round's are issued
+      bvec = load_starts(P + 3 * G, g3);
+      gb = g3;
+      if (LIST) gv = load_gnum(P + 4 * G);
+    }
+    HC_STAMP(6);
+    if (active) {
+      if (off == 0u && slots > cleared) {                           // (the sub-bucket the last clear had been sized for was not counted)
+        uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
+        for (u32 i = tid; i < (u32)SLOTS / 4; i += BLOCK) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+        __syncthreads();
+      }
+      HC_STAMP(0);
+      u32 hh[KPC];
+      u32 won = 0, pending = 0;
+#pragma unroll
+      for (int j = 0; j < KPC; j++) {
+        hh[j] = (comp[j] * 0x9E3779B1u) >> sshift;
+        if ((u32)j * BLOCK < cnt) {
+          const bool act = (u32)j * BLOCK + tid < cnt;
+          u32 old = 0u;
+          if (act) old = atomicCAS(&tk[hh[j]], EMPTY, (comp[j] << CNTB) | 1u);
+          const bool w = act && old == EMPTY, dup = act && !w && (old >> CNTB) == comp[j];   // (EMPTY >> 12 IS the all-ones suffix)
+          if (dup) atomicAdd(&tk[hh[j]], 1u);
+          won |= w ? (1u << j) : 0u;
+          pending |= (act && !w && !dup) ? (1u << j) : 0u;
+        }
+      }
+      u32 steps = 0;
+      while (pending) {                                // linear probing, one step of every still-pending key per round
+#pragma unroll
+        for (int j = 0; j < KPC; j++) {
+          if ((pending >> j) & 1u) {
+            hh[j] = (hh[j] + 1) & smask;
+            const u32 old = atomicCAS(&tk[hh[j]], EMPTY, (comp[j] << CNTB) | 1u);
+            const bool w = old == EMPTY, dup = !w && (old >> CNTB) == comp[j];
+            if (dup) atomicAdd(&tk[hh[j]], 1u);
+            if (w) won |= 1u << j;
+            if (w || dup) pending &= ~(1u << j);
+          }
+        }
+        if (++steps > PROBE_MAX) { s_ovf = 1u; pending = 0; }       // the table is (nearly) full: more distinct suffixes than it holds
+      }
+      {
+        u64 wm[KPC];
+        u32 tot = 0;
+#pragma unroll
+        for (int j = 0; j < KPC; j++) { wm[j] = __ballot((won >> j) & 1u); tot += (u32)__popcll(wm[j]); }
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&s_nd, tot);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        if (base + tot > (u32)DCAP) { if (lane == 0) s_ovf = 1u; }  // more distinct suffixes than the list holds
+        else {
+#pragma unroll
+          for (int j = 0; j < KPC; j++) {
+            if (wm[j]) {
+              if ((won >> j) & 1u)
+                lst[base + __builtin_amdgcn_mbcnt_hi((u32)(wm[j] >> 32), __builtin_amdgcn_mbcnt_lo((u32)wm[j], 0u))] = (unsigned short)hh[j];
+              base += (u32)__popcll(wm[j]);
+            }
+          }
+        }
+      }
+      HC_STAMP(1);
+    }
+    if (!last) { off += csz; continue; }               // the sub-bucket's next chunk (no barrier: one table, atomics only)
+
+    // ---- the sub-bucket's last chunk is in: its distinct suffixes, ascending, back in place ----
+    const u32 a = a0, g = g0, n = n0;
+    const u32 nslots = slots_for(n1);                  // what the next insert phase needs cleared
+    if (active) __syncthreads();                       // every insert and every list append of the sub-bucket is done
+    a0 = a1; n0 = n1; g0 = g1; off = 0; csz = ncs;
+    a1 = a2; n1 = n2; g1 = g2;
+    if (active) {
+      const bool ovf = s_ovf != 0u;
+      const u32 D = s_nd;
+      if (!ovf) {
+        // the distinct entries into 256 bins by their top eight bits: one returning LDS atomic each
+        const bool big = D > 2u * (u32)BLOCK;          // more than two per thread (low-coverage input): staged through LDS
+        u32 ent0 = 0, ent1 = 0, li0 = 0, li1 = 0;
+        if (!big) {
+          if (tid < D)              { ent0 = tk[lst[tid]];              li0 = atomicAdd(&s_bin[par][ent0 >> (CNTB + bshift)], 1u); }
+          if (tid + (u32)BLOCK < D) { ent1 = tk[lst[tid + (u32)BLOCK]]; li1 = atomicAdd(&s_bin[par][ent1 >> (CNTB + bshift)], 1u); }
+        } else {
+          for (u32 i = tid; i < D; i += BLOCK) {
+            const u32 e = tk[lst[i]];
+            srt[i] = e;
+            lst[i] = (unsigned short)atomicAdd(&s_bin[par][e >> (CNTB + bshift)], 1u);
+          }
+        }
+        __syncthreads();
+        HC_STAMP(2);
+        if (tid < 64) {                                // one wave scans the 256 bin counts: four per lane
+          uint4 c = reinterpret_cast<uint4 *>(s_bin[par])[tid];
+          const u32 s4 = c.x + c.y + c.z + c.w;
+          u32 x = s4;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+          const u32 e0 = x - s4;
+          reinterpret_cast<uint4 *>(s_bin[par])[tid] = make_uint4(e0, e0 + c.x, e0 + c.x + c.y, e0 + c.x + c.y + c.z);
+          if (tid == 63) s_bin[par][BLOCK] = x;
+        } else {
+          // ... the other three clear what the NEXT insert phase uses (tk, lst and s_nd are dead by now; staged: the table takes
+          // the sorted entries first and is cleared at the end)
+          uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
+          if (!big) for (u32 i = tid - 64; i < nslots / 4; i += BLOCK - 64) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+          for (u32 i = tid - 64; i < BLOCK; i += BLOCK - 64) s_bin[par ^ 1u][i] = 0;
+          if (tid == 64) s_nd = 0;
+        }
+        cleared = nslots;
+        __syncthreads();
+        if (!big) {
+          if (tid < D)              srt[s_bin[par][ent0 >> (CNTB + bshift)] + li0] = ent0;
+          if (tid + (u32)BLOCK < D) srt[s_bin[par][ent1 >> (CNTB + bshift)] + li1] = ent1;
+        } else {
+          for (u32 i = tid; i < D; i += BLOCK) { const u32 e = srt[i]; tk[s_bin[par][e >> (CNTB + bshift)] + lst[i]] = e; }
+        }
+        __syncthreads();
+        HC_STAMP(3);
+
+        // rank inside the bin, then back in place: the distinct suffixes ascending from the sub-bucket's own start
+        const u32 *sb = s_bin[par];
+        const u32 *sorted = big ? tk : srt;
+        u32 *kout = keys + a;
+        u32 *cout = cnt_tmp + a;
+        for (u32 p = tid; p < D; p += BLOCK) {
+          const u32 e = sorted[p];
+          const u32 b = e >> (CNTB + bshift), lo = sb[b], hi = sb[b + 1];
+          u32 r = lo;
+          for (u32 q = lo; q < hi; q++) r += (sorted[q] < e) ? 1u : 0u;
+          kout[r] = e >> CNTB;
+          cout[r] = e & CNT_MASK;
+        }
+        if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
+        if (big) {                                     // the table held the sorted entries: cleared now, behind two more barriers
+          __syncthreads();
+          uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
+          for (u32 i = tid; i < nslots / 4; i += BLOCK) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+          __syncthreads();
+        }
+        par ^= 1u;                                     // (srt and this parity's bin table are next written three barriers on)
+        HC_STAMP(4);
+      } else {
+        // more distinct suffixes than the table or the list holds: nothing is written, the retry launch takes the sub-bucket
+        __syncthreads();                               // (everybody has read s_ovf and s_nd)
+        uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
+        for (u32 i = tid; i < (u32)SLOTS / 4; i += BLOCK) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+        if (tid == 0) {
+          s_nd = 0; s_ovf = 0;
+          if (retry_list) retry_list[atomicAdd((unsigned long long *)retry_count, 1ull)] = g;
+          else            group_distinct[tr_index(g, tr_a, tr_b)] = 0; // (the retry launch: DCAP >= max_size, does not happen)
+        }
+        cleared = (u32)SLOTS;
+        __syncthreads();
+      }
+    } else if (n == 0u && tid == 0) {
+      group_distinct[tr_index(g, tr_a, tr_b)] = 0;     // (larger than max_size: the streaming launch's)
+    }
+    P += G;
+    if (DBG) ph[7]++;
+  }
+  if (DBG && tid == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 8; i++) dbg[blockIdx.x * 8 + i] = ph[i];
+#undef HC_STAMP
+}
+
 // (Round 5: the kernels hash_countw_kernel replaced -- hash_count64_kernel with 64-bit suffixes in the table, hash_count64i_kernel and
 // hash_count128_kernel with the index-claimed table and a pass over it -- and the bitmap-count kernel, measured equal to the hash-count
 // in round 3, were removed: DESIGN_HISTORY.md, profiles/r03a_*, r04k_*, r04v_*.)
@@ -1789,6 +2091,10 @@ constexpr u64 FIN_CAP_SMALL = 256 * 16, FIN_CAP_LARGE = 1024 * 8;   // LDS: 46 K
 constexpr int HUGE_CAP32 = 4096, HUGE_SLOTS32 = 8192;            // 32-bit suffixes: 96 KiB of LDS
 constexpr int HUGE_CAP64 = 2048, HUGE_SLOTS64 = 4096;            // 64-bit suffixes: 72 KiB
 constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count kernel: 2048 slots, 26 KiB of LDS, 6 workgroups per CU
+// hash_count_stream_kernel: sub-buckets of up to 4094 keys (a 12-bit count, all ones excluded) in chunks of <= 1536; 2048-entry table
+// and room for 1280 distinct suffixes (17.6 KiB of LDS, eight workgroups per CU); the retry instantiation: 8192 entries, 58 KiB
+constexpr u64 FIN_CAP_STREAM = 4094;
+constexpr int FIN_STREAM_KPC = 6, FIN_STREAM_SLOTS = 2048, FIN_STREAM_DCAP = 1280, FIN_STREAM_RETRY_SLOTS = 8192, FIN_STREAM_RETRY_DCAP = 4096;
 
 // 16-byte keys: the same 1536-key tables (sub-buckets of up to 1152 k-mers); a file whose largest sub-bucket holds at most 768 takes
 // the 768-key instantiation (launch_finish_file)
@@ -1821,11 +2127,12 @@ hipError_t launch_subbucket_bounds(const void *d_keys, uint64_t n, uint32_t key_
 
 // the second half of launch_subbucket_bounds on its own: for files whose boundaries came with the grouping passes
 hipError_t launch_subbucket_max(const uint64_t *d_starts, uint32_t key_words, uint32_t low, uint32_t top_bits, uint64_t *d_max,
-                                uint32_t *d_list, uint64_t *d_list_count, uint32_t *d_nz, uint64_t *d_nz_count, hipStream_t st) {
+                                uint32_t *d_list, uint64_t *d_list_count, uint32_t *d_nz, uint64_t *d_nz_count, hipStream_t st,
+                                uint64_t small_cap) {
   const uint64_t ng = (uint64_t)1 << top_bits;
   hipLaunchKernelGGL(subbucket_max_kernel, dim3((uint32_t)((ng + 255) / 256)), dim3(256), 0, st,
                      reinterpret_cast<const u64 *>(d_starts), (u64)ng, reinterpret_cast<u64 *>(d_max),
-                     (u64)finish_small_capacity(key_words, low), d_list, reinterpret_cast<u64 *>(d_list_count),
+                     (u64)(small_cap ? small_cap : finish_small_capacity(key_words, low)), d_list, reinterpret_cast<u64 *>(d_list_count),
                      d_nz, reinterpret_cast<u64 *>(d_nz_count));
   return hipGetLastError();
 }
@@ -1907,8 +2214,12 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               uint64_t n_large, const uint32_t *d_large_list, uint32_t *d_cnt_tmp, uint64_t *d_group_distinct,
                               bool stream, void *d_alt, hipStream_t st_huge, const uint32_t *d_nz, const uint64_t *d_nz_count,
                               hipStream_t st, bool narrow, uint32_t tr_a, uint32_t tr_b, uint64_t max_sub, uint64_t n_keys,
-                              uint32_t *d_retry_list, uint64_t *d_retry_count, bool k96, int hash_multi, bool hash_dbg) {
+                              uint32_t *d_retry_list, uint64_t *d_retry_count, bool k96, int hash_multi, bool hash_dbg,
+                              uint64_t stream_cap) {
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
+  if (stream_cap && !(narrow && d_retry_list && d_retry_count && finish_stream_ok(key_words, low_bits) &&
+                      stream_cap <= FIN_CAP_STREAM && (n_large == 0 || stream)))
+    return hipErrorInvalidValue;
   if (k96) {
     // 12-byte K96 records: the persistent hash-count, and the streaming count of oversized sub-buckets (a file whose oversized
     // sub-buckets nothing streams is widened to 16-byte keys by the caller first)
@@ -1982,7 +2293,30 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       if (multi_r > 4 || multi_r == 3 || low_bits + tagb2 < 8 || low_bits + tagb2 > 20) multi_r = 0;
     }
     u64 *dbgb = hash_dbg_buffer(hash_dbg);                           // MGC_HASH_DBG=1: the instrumented instantiations (per-phase cycle stamps)
-    if (multi_r) {
+    if (stream_cap) {
+      // the distinct-sized count: one sub-bucket of up to stream_cap keys per iteration, streamed through a 2048-entry table
+      // in chunks; sub-buckets with more distinct suffixes than it holds land on the retry list (launch_finish_retry)
+      const uint64_t gmax = 256ull * 16ull;
+      const dim3 sgrid((uint32_t)(ng < gmax ? ng : gmax));
+      if (use_list)
+        hipLaunchKernelGGL((hash_count_stream_kernel<256, FIN_STREAM_KPC, FIN_STREAM_SLOTS, FIN_STREAM_DCAP, true, false>), sgrid, dim3(256), 0, st,
+                           reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)stream_cap, low_bits,
+                           d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), (u64 *)nullptr, tr_a, tr_b, d_nz, nzc,
+                           d_retry_list, reinterpret_cast<u64 *>(d_retry_count));
+      else if (dbgb)
+        hipLaunchKernelGGL((hash_count_stream_kernel<256, FIN_STREAM_KPC, FIN_STREAM_SLOTS, FIN_STREAM_DCAP, false, true>), sgrid, dim3(256), 0, st,
+                           reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)stream_cap, low_bits,
+                           d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), dbgb, tr_a, tr_b, (const u32 *)nullptr, (const u64 *)nullptr,
+                           d_retry_list, reinterpret_cast<u64 *>(d_retry_count));
+      else
+        hipLaunchKernelGGL((hash_count_stream_kernel<256, FIN_STREAM_KPC, FIN_STREAM_SLOTS, FIN_STREAM_DCAP, false, false>), sgrid, dim3(256), 0, st,
+                           reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)stream_cap, low_bits,
+                           d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), (u64 *)nullptr, tr_a, tr_b, (const u32 *)nullptr,
+                           (const u64 *)nullptr, d_retry_list, reinterpret_cast<u64 *>(d_retry_count));
+      MGC_CHECK(hipGetLastError());
+      if (dbgb && !use_list) hash_dbg_report(st, ng, true);
+    }
+    else if (multi_r) {
       const uint64_t nsuper = (ng + (uint64_t)multi_r - 1) / (uint64_t)multi_r;
 #define MGC_MULTI_LAUNCH(R_, DBG_)                                                                                                       \
       do { const uint64_t gmax = 256ull * 16ull;                                                                                        \
@@ -2025,7 +2359,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       }
       hipLaunchKernelGGL((hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32, u32>), dim3((uint32_t)n_large), dim3(1024), B32, st_huge,
                          reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                         (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                         (u64)(stream_cap ? stream_cap : FIN_CAP_HASH), low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
                          reinterpret_cast<u32 *>(d_alt), tr_a, tr_b);
       MGC_CHECK(hipGetLastError());
     }
@@ -2153,6 +2487,30 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
   return hipSuccess;
 }
 
+// the retry list of hash_count_stream_kernel: the same kernel with a table no sub-bucket of up to FIN_CAP_STREAM keys can overflow
+hipError_t launch_finish_retry(void *d_keys32, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits, uint32_t *d_cnt_tmp,
+                               uint64_t *d_group_distinct, uint32_t tr_a, uint32_t tr_b, const uint32_t *d_retry_list,
+                               const uint64_t *d_retry_count, uint64_t n_retry, uint64_t stream_cap, hipStream_t st) {
+  if (n_retry == 0) return hipSuccess;
+  if (!finish_stream_ok(1, low_bits) || stream_cap == 0 || stream_cap > FIN_CAP_STREAM) return hipErrorInvalidValue;
+  static_assert(FIN_STREAM_RETRY_DCAP >= (int)FIN_CAP_STREAM, "the retry table holds every suffix of a sub-bucket");
+  const uint64_t gmax = 256ull * 2ull;
+  hipLaunchKernelGGL((hash_count_stream_kernel<256, FIN_STREAM_KPC, FIN_STREAM_RETRY_SLOTS, FIN_STREAM_RETRY_DCAP, true, false>),
+                     dim3((uint32_t)(n_retry < gmax ? n_retry : gmax)), dim3(256), 0, st, reinterpret_cast<u32 *>(d_keys32),
+                     reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)stream_cap, low_bits, d_cnt_tmp,
+                     reinterpret_cast<u64 *>(d_group_distinct), (u64 *)nullptr, tr_a, tr_b, d_retry_list,
+                     reinterpret_cast<const u64 *>(d_retry_count), (u32 *)nullptr, (u64 *)nullptr);
+  return hipGetLastError();
+}
+
+bool     finish_stream_ok(uint32_t key_words, uint32_t low_bits) { return key_words == 1 && low_bits >= 8 && low_bits <= 20; }
+uint64_t finish_stream_capacity() { return FIN_CAP_STREAM; }
+uint64_t finish_stream_distinct() { return FIN_STREAM_DCAP; }
+uint64_t finish_stream_target(const Switches &sw) {
+  if (sw.finish_target) return sw.finish_target;              // (tests make the sub-buckets tiny)
+  return (FIN_CAP_HASH * 3) / 2;                              // 2304: twice the others' average; +7 sigma of a file's sub-buckets stays below the capacity
+}
+
 static uint64_t finish_small_capacity(uint32_t key_words, uint32_t low_bits) {
   if (key_words == 2) return finish_uses_hash(key_words, low_bits) ? FIN_CAP_HASH128 : 2048;
   return finish_uses_hash(key_words, low_bits) ? FIN_CAP_HASH : FIN_CAP_SMALL;
@@ -2222,6 +2580,23 @@ hipError_t launch_widen_groups(const void *d_keys32, const uint64_t *d_starts, u
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256)
+void sum_u64_kernel(const u64 *__restrict__ in, u64 n, u64 *__restrict__ out) {
+  u64 v = 0;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) v += in[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
+  if (lane_id() == 0 && v) atomicAdd((unsigned long long *)out, v);
+}
+hipError_t launch_sum_u64(const uint64_t *d_in, uint64_t n, uint64_t *d_out, hipStream_t st) {
+  MGC_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint64_t), st));
+  if (n == 0) return hipSuccess;
+  const uint64_t blocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(sum_u64_kernel, dim3((uint32_t)(blocks < 256 ? blocks : 256)), dim3(256), 0, st, reinterpret_cast<const u64 *>(d_in),
+                     (u64)n, reinterpret_cast<u64 *>(d_out));
+  return hipGetLastError();
+}
+
 hipError_t launch_store_u64(uint64_t *d_dst, const uint64_t *d_src, hipStream_t st) {
   hipLaunchKernelGGL(store_u64_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<u64 *>(d_dst), reinterpret_cast<const u64 *>(d_src));
   return hipGetLastError();
@@ -2272,6 +2647,7 @@ Switches read_switches() {
   sw.nolist = on1("MGC_FINISH_NOLIST");
   sw.finish_trace = getenv("MGC_FINISH_TRACE") != nullptr; sw.group_dbg = getenv("MGC_GROUP_DBG") != nullptr; sw.hash_dbg = getenv("MGC_HASH_DBG") != nullptr;
   { const char *e = getenv("MGC_HASH_MULTI"); sw.hash_multi = (e && *e) ? atoi(e) : -1; }
+  { const char *e = getenv("MGC_HASH_STREAM"); sw.hash_stream = (e && *e) ? atoi(e) : -1; }
   sw.min_top = (uint32_t)num("MGC_FINISH_MIN_TOP", 0);
   sw.finish_target = num("MGC_FINISH_TARGET", 0);
   sw.stream_max = num("MGC_STREAM_MAX", (uint64_t)1 << 22);

@@ -1335,6 +1335,59 @@ def test_hash_count_multi_subbuckets_per_iteration(ops, oracle_lib, torch_cuda, 
         assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
 
 
+@pytest.mark.parametrize("stream", ["1", None, "0"])
+@pytest.mark.parametrize("k,min_top,nolist", [(21, 16, "1"), (21, 17, "1"), (20, 14, "0"), (19, 18, "1"), (17, 14, "0"), (14, 12, "0"), (13, 12, "0")])
+def test_hash_count_stream_kernel_distinct_sized_table(ops, oracle_lib, torch_cuda, monkeypatch, k, min_top, nolist, stream):
+    """hash_count_stream_kernel (round 6): ONE sub-bucket of up to 4094 keys per workgroup iteration, its keys
+    streamed in chunks through a 2048-entry table that is sized by DISTINCT suffixes (1280 of them); a sub-bucket with more goes
+    on the retry list and is counted by the 8192-entry instantiation (launch_finish_retry).  MGC_HASH_STREAM=1 puts every narrowed
+    file whose suffix fits (8..20 bits) on that kernel (None: the plan's own choice -- on a small input the older kernels; "0":
+    off), MGC_FINISH_NOLIST the dense-grid launch on a sparse small input (otherwise the non-empty list is walked).  Suffix widths
+    20 / 19 (the judged plan's), 18, 15, 12, 10 and 8 bits; sub-buckets of one, two and three chunks: 4094 keys with 5 distinct
+    suffixes, 4094 all distinct (retry), 4095 (the streaming launch's), 3000 with 900, 2600 with 1280 and with 1290 distinct (the
+    list's capacity and just above), 1536 / 1537 keys, one k-mer 4000 times (a 12-bit count), next to ordinary reads at
+    ~1x coverage (D ~ N: the low-coverage case)."""
+    from meryl_amd import capi
+    monkeypatch.setenv("MGC_FINISH_MIN_TOP", str(min_top))
+    monkeypatch.setenv("MGC_FINISH_NOLIST", nolist)
+    if stream is not None:
+        monkeypatch.setenv("MGC_HASH_STREAM", stream)
+    rng = np.random.default_rng(k * 100 + min_top)
+    plen = min(k - 1, (6 + min_top + 1) // 2 + 1)          # bases that fix the file and the sub-bucket
+    def cluster(head, n_inst, n_distinct):
+        pre = head + "".join("ACGT"[i] for i in rng.integers(0, 4, plen - len(head)))
+        n_distinct = min(n_distinct, 4 ** (k - plen))
+        tails = set()
+        while len(tails) < n_distinct:
+            tails.add("".join("ACGT"[i] for i in rng.integers(0, 4, k - plen)))
+        tails = sorted(tails)
+        picks = list(range(n_distinct)) + [int(i) for i in rng.integers(0, n_distinct, max(0, n_inst - n_distinct))]
+        return ".".join(pre + tails[i] for i in picks[:n_inst]) + "."
+    reads = oracle_lib.synth_reads(k, 4_000_000, 0, 30_000).tobytes().decode()    # 4.5 Mbases at ~1x: the fifteen-bit histogram is on
+    stream_text = (cluster("AAC", 4094, 5) + cluster("ACA", 4094, 4094) + cluster("ATT", 4095, 400) + cluster("AGC", 3000, 900)
+                   + cluster("CAT", 2600, 1280) + cluster("CCG", 2600, 1290) + cluster("AAT", 4000, 1) + cluster("ACC", 1536, 1536)
+                   + cluster("AGG", 1537, 64) + cluster("CTA", 1, 1) + cluster("GGA", 2049, 1100) + cluster("GGA", 760, 3) + reads)
+    for mode in (1, 0):                                     # forward mode keeps the clusters where they were put
+        cfg = capi.configure(k, len(stream_text), 1 << 30, mode)
+        cfg.use_simple = 0
+        with ops.Session(cfg) as s:
+            s.set_profiling(True)
+            s.push_bases(stream_text, end_of_sequence=False)
+            s.count()
+            klo, khi, counts, _ = s.result_wide()
+            prof = s.profile()
+        whi, wlo, wcn, _ = oracle_lib.count_brute(stream_text, k, mode)
+        assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+        low = 2 * k - 6 - min_top
+        if stream == "1" and 8 <= low <= 20:
+            assert prof.stream_files > 0, (prof.stream_files, low)
+            if mode == 1 and k - plen >= 6:
+                assert prof.stream_retries >= 1, prof.stream_retries     # the all-distinct 4094-key cluster at least
+        if stream == "0":
+            assert prof.stream_files == 0 and prof.stream_retries == 0
+
+
+
 @pytest.mark.parametrize("nolist", ["1", "0"])
 @pytest.mark.parametrize("k,compress,min_top", [(28, 0, 14), (31, 0, 16), (32, 0, 12), (31, 1, None), (30, 0, 18),
                                                 (33, 0, 14), (40, 0, 16), (51, 0, 12), (64, 0, 18), (51, 1, None)])
@@ -1375,7 +1428,7 @@ def test_hash_countw_kernel_dense_and_sparse_grids(ops, oracle_lib, torch_cuda, 
 # every count_device switch that is read per call (a process-wide static one cannot vary inside one test process)
 _GRID_SWITCHES = {
     "MGC_NARROW": ["0"], "MGC_FINE_HIST": ["0"], "MGC_WIDE_MSD": ["0"],
-    "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"],
+    "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_HASH_STREAM": ["1", "0"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"],
     "MGC_FINISH_TARGET": ["1", "4", "64", "700"], "MGC_FINISH_MIN_TOP": ["10", "14", "17", "18"], "MGC_STREAM_MAX": ["2000", "20000"],
     "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"], "MGC_K96": ["0"], "MGC_KMER_CONST_K": ["0"],
 }
