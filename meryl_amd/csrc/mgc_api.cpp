@@ -1404,7 +1404,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       } else if (narrow[b]) {                                // X (8 B) -> Y (4 B) -> front of X (4 B); boundaries included
         HIP_TRY(s, mgc::launch_group_narrow(src, (void *)Y, h_counts[b], fp, sort_ws, sort_ws_bytes - 256, d_err, d_substart + sbase[b], st, pe,
                                             d_nhdrs ? (void *)(d_nhdrs + hdr_bytes * b) : nullptr, d_nws ? (void *)(d_nws + nws_off[b]) : nullptr,
-                                            &tr_a[b], &tr_b[b], soa_hi_mask, sw.group_dbg));
+                                            &tr_a[b], &tr_b[b], soa_hi_mask, sw.group_dbg, sw.group_pipe));
         file_passes[b] = 2;
         narrowed[b] = 1;
         sort_launch_groups++;

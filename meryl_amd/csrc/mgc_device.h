@@ -20,6 +20,7 @@ struct Switches {
   bool narrow = true;           // MGC_NARROW=0: no 32-bit words after the first grouping pass
   bool wide_msd = true;         // MGC_WIDE_MSD=0: whole keys low digit first off a histogram read
   bool soa5 = true;             // MGC_SOA5=0: no 5-byte layout (k = 20..23)
+  bool group_pipe = true;       // MGC_GROUP_PIPE=0: the narrowed grouping passes fetch the next tile inside the look-back phase (round 5's form)
   bool k96 = true;              // MGC_K96=0: no 12-byte records (k = 33..51)
   bool finish = true;           // MGC_FINISH=0: stable sort of all bits + run-length kernels
   bool nolist = false;          // MGC_FINISH_NOLIST=1: the dense-grid instantiations of the count kernels whatever the grid holds
@@ -118,7 +119,8 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                                void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b,
                                uint32_t soa_hi_mask = 0 /*nonzero: d_keys is the 5-byte layout of launch_kmer_partition(d_soa_counts); the mask of
                                the u8 array's payload bits (bits 32.. of the k-mer below the file)*/,
-                               bool group_dbg = false /*Switches::group_dbg*/);
+                               bool group_dbg = false /*Switches::group_dbg*/,
+                               bool pipe = true /*Switches::group_pipe: the fetch a whole tile ahead (the 5-byte first pass, the second pass)*/);
 
 // The same high-digit-first form for WHOLE keys (8-byte keys that leave more than 32 bits below their first digit: k = 27..32
 // at the 10 Gbp scale; every 16-byte key): the high digit's histogram comes from the fifteen-bit file histogram

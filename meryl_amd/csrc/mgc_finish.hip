@@ -2643,7 +2643,7 @@ Switches read_switches() {
   auto num = [](const char *n, uint64_t d) { const char *e = getenv(n); return (e && *e) ? strtoull(e, nullptr, 10) : d; };
   sw.fine_hist = !off("MGC_FINE_HIST"); sw.hpc_msd = !off("MGC_HPC_MSD"); sw.hpc_digits = !off("MGC_HPC_DIGITS");
   sw.const_k = !off("MGC_KMER_CONST_K"); sw.narrow = !off("MGC_NARROW"); sw.wide_msd = !off("MGC_WIDE_MSD");
-  sw.soa5 = !off("MGC_SOA5"); sw.k96 = !off("MGC_K96"); sw.finish = !off("MGC_FINISH");
+  sw.group_pipe = !off("MGC_GROUP_PIPE"); sw.soa5 = !off("MGC_SOA5"); sw.k96 = !off("MGC_K96"); sw.finish = !off("MGC_FINISH");
   sw.nolist = on1("MGC_FINISH_NOLIST");
   sw.finish_trace = getenv("MGC_FINISH_TRACE") != nullptr; sw.group_dbg = getenv("MGC_GROUP_DBG") != nullptr; sw.hash_dbg = getenv("MGC_HASH_DBG") != nullptr;
   { const char *e = getenv("MGC_HASH_MULTI"); sw.hash_multi = (e && *e) ? atoi(e) : -1; }

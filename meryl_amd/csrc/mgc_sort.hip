@@ -417,7 +417,12 @@ struct GroupExtra { u32 digit_bits /* NARROW */; u32 shift2, mask2; u64 *ghist2 
 
 // SOA (u64 keys): `in` is the 5-byte layout kmer_partition_kernel<SOA> leaves -- u32 in[n] low words, then u8[n] bits 32..39 --
 // and a key is put together as it is fetched: four keys per lane and group from one 16-byte and one 4-byte load.
-template <typename K, int RB, int BLOCK, int KPT, bool DBG, bool NARROW = false, bool HIST2 = false, bool SOA = false>
+// PIPE (round 6; the 5-byte first pass and the 32-bit second pass): the tile AFTER the next one is fetched -- into registers, in the
+// form it has in memory (5 / 4 bytes per key) -- as soon as the current tile has left its registers for LDS, a WHOLE tile ahead:
+// the fetch of a tile runs beside the ranking, the scan, the exchange, the look-back and the write-out of the tile before it instead of
+// inside that tile's look-back phase (where the persistent workgroups, in step because of the look-back chain, all asked the memory
+// system at the same time and left it idle for the other two thirds of a tile's time: DESIGN.md 3.3).  Tickets run two tiles ahead.
+template <typename K, int RB, int BLOCK, int KPT, bool DBG, bool NARROW = false, bool HIST2 = false, bool SOA = false, bool PIPE = false>
 __global__ __launch_bounds__(BLOCK, (GroupSmem<K, RB, BLOCK, KPT>::MIN_WAVES_PER_SIMD))
 void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::type *__restrict__ out, u64 n, u32 shift, u32 dmask,
                         const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
@@ -431,7 +436,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
   using SM = GroupSmem<K, RB, BLOCK, KPT>;
   using KO = KeyOps<K>;
   constexpr int R = SM::R, TILE = SM::TILE, G = R / 2;
-  constexpr int WALK = (sizeof(K) == 4) ? 8 : 16;      // 32 words per thread leave registers for eight granules in flight, not sixteen (no spills)
+  constexpr int WALK = (sizeof(K) == 4 || PIPE) ? 8 : 16;      // 32 words per thread leave registers for eight granules in flight, not sixteen (no spills)
   static_assert(BLOCK >= RS_MAX_RADIX && G % 64 == 0 && TILE <= 65536, "one thread per region/digit; 16-bit ranks");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   K   *s_keys  = reinterpret_cast<K *>(smem);
@@ -519,13 +524,84 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     }
   };
 
+  // PIPE: a tile in the form it has in memory -- SOA: per group of four keys four low words + one word of high bytes; u32: the words
+  static_assert(!PIPE || SOA || sizeof(K) == 4, "the pipelined fetch holds 5-byte or 4-byte keys");
+  constexpr int RAWN = PIPE ? (SOA ? KPT + KPT / 4 : KPT) : 1;
+  u32 raw[RAWN];
+#pragma unroll
+  for (int i = 0; i < RAWN; i++) raw[i] = 0u;
+  auto fetch_raw = [&](u64 kb, u32 nv) __attribute__((always_inline)) {
+    if constexpr (PIPE && SOA) {
+      struct __attribute__((aligned(4))) LVec { u32 v[4]; };
+      struct __attribute__((packed, aligned(1))) HWord { u32 v; };
+      const u32 *lo32 = reinterpret_cast<const u32 *>(in) + kb;
+      const uint8_t *hi8 = reinterpret_cast<const uint8_t *>(in) + 4ull * n + kb;
+#pragma unroll
+      for (int g = 0; g < KPT / 4; g++) {
+        const u32 first = idx_of(g * 4);
+        if (nv == (u32)TILE || first + 4u <= nv) {
+          const LVec l = *reinterpret_cast<const LVec *>(lo32 + first);
+#pragma unroll
+          for (int c = 0; c < 4; c++) raw[g * 5 + c] = l.v[c];
+          raw[g * 5 + 4] = reinterpret_cast<const HWord *>(hi8 + first)->v;
+        } else {
+          u32 h = 0;
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+            if (first + (u32)c < nv) { raw[g * 5 + c] = lo32[first + c]; h |= (u32)hi8[first + c] << (8 * c); }
+          raw[g * 5 + 4] = h;
+        }
+      }
+    } else if constexpr (PIPE) {
+      const u32 *base = reinterpret_cast<const u32 *>(in) + kb;
+      struct __attribute__((aligned(4))) WVec { u32 v[4]; };
+      static_assert(!PIPE || SOA || KPT % 4 == 0, "four words per load");
+#pragma unroll
+      for (int g = 0; g < KPT / 4; g++) {
+        const u32 first = idx_of(g * 4);
+        if (nv == (u32)TILE || first + 4u <= nv) {
+          const WVec q = *reinterpret_cast<const WVec *>(base + first);
+#pragma unroll
+          for (int c = 0; c < 4; c++) raw[g * 4 + c] = q.v[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; c++) if (first + (u32)c < nv) raw[g * 4 + c] = base[first + c];
+        }
+      }
+    }
+  };
+  auto assemble = [&]() __attribute__((always_inline)) {
+    if constexpr (PIPE && SOA) {
+      const u32 hm = ex.soa_hi_mask;
+#pragma unroll
+      for (int g = 0; g < KPT / 4; g++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) keys[g * 4 + c] = (K)((u64)raw[g * 5 + c] | ((u64)((raw[g * 5 + 4] >> (8 * c)) & hm) << 32));
+    } else if constexpr (PIPE) {
+#pragma unroll
+      for (int j = 0; j < KPT; j++) keys[j] = (K)raw[j];
+    }
+  };
+
   if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
   __syncthreads();
   u64 tile = s_tmp[32];
   announce(tile, 0);
   __syncthreads();
   u64 kb = 0; u32 nv = 0;
-  if (tile < total_tiles) { kb = s_info[0]; nv = (u32)s_info[1]; fetch(kb, nv); }
+  u64 tile1 = 0, kb1 = 0; u32 nv1 = 0;                    // PIPE: the tile after the current one (its keys in flight / in raw[])
+  if constexpr (!PIPE) {
+    if (tile < total_tiles) { kb = s_info[0]; nv = (u32)s_info[1]; fetch(kb, nv); }
+  } else {
+    if (tile < total_tiles) { kb = s_info[0]; nv = (u32)s_info[1]; fetch_raw(kb, nv); assemble(); }
+    if (tid == 0) s_tmp[33] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    tile1 = s_tmp[33];
+    announce(tile1, 1);
+    __syncthreads();
+    if (tile1 < total_tiles) { kb1 = s_info[2]; nv1 = (u32)s_info[3]; fetch_raw(kb1, nv1); }
+    __syncthreads();                                      // (s_tmp[33] and s_info[2..3] are written again at the top of the loop)
+  }
 
   u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
 #define PK_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
@@ -617,7 +693,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
       }
     };
     if (!walker) {
-      if (next < total_tiles) fetch(nkb, nnv);
+      if constexpr (!PIPE) { if (next < total_tiles) fetch(nkb, nnv); }
       // the waves that do not walk would only wait now: they count the other digit of the tile's keys (in LDS, in digit
       // order since the exchange) -- LDS work in the shadow of the look-back
       if constexpr (HIST2) {
@@ -628,10 +704,16 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
       if (tile != 0) status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
       s_gbase[2 * tid]     = gbase[2 * tid]     + (u64)p0 - (u64)s_dbase[2 * tid];
       s_gbase[2 * tid + 1] = gbase[2 * tid + 1] + (u64)p1 - (u64)s_dbase[2 * tid + 1];
-      if (next < total_tiles) fetch(nkb, nnv);
+      if constexpr (!PIPE) { if (next < total_tiles) fetch(nkb, nnv); }
     }
     __syncthreads();                                      // (E)
     PK_STAMP(3);
+    if constexpr (PIPE) {
+      // the tile fetched a whole tile ago leaves raw[] for keys[] (nothing newer is in flight when the wait for it runs: the
+      // write-out's stores come AFTER this point), and the tile after it is asked for
+      if (tile1 < total_tiles) assemble();
+      if (next < total_tiles) fetch_raw(nkb, nnv);
+    }
 
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
@@ -646,7 +728,8 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     PK_STAMP(4);
     __syncthreads();                                      // (F)
     PK_STAMP(5);
-    tile = next; kb = nkb; nv = nnv;
+    if constexpr (PIPE) { tile = tile1; kb = kb1; nv = nv1; tile1 = next; kb1 = nkb; nv1 = nnv; }
+    else                { tile = next; kb = nkb; nv = nnv; }
     if (DBG) ph[7]++;
   }
   if (DBG && tid0 == 0 && blockIdx.x < 64)
@@ -924,7 +1007,7 @@ hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsi
 // ((p & (2^*tr_a - 1)) << *tr_b) | (p >> *tr_a)  (*tr_a = 0: p itself).
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events,
-                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, uint32_t soa_hi_mask, bool group_dbg) {
+                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, uint32_t soa_hi_mask, bool group_dbg, bool pipe) {
   if (!sort_plan_narrows(plan, n, 1) || ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
   constexpr int RB = 9, BLOCK = 1024, KPT0 = 16, KPT1 = 24, R = 1 << RB;
   using GS0 = GroupSmem<u64, RB, BLOCK, KPT0>;
@@ -1000,6 +1083,18 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
       sattr = true;
     }
+    static bool spattr = false;
+    if (pipe && !spattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
+      spattr = true;
+    }
+    if (pipe)
+      hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
+                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                         &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                         GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask}, (u64 *)nullptr);
+    else
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                        &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
@@ -1032,6 +1127,18 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                        GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
                        &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
                        GroupExtra{0u, 0u, 0u, nullptr}, dbg_buf + 64 * 8);
+  else if (pipe && getenv("MGC_GROUP_PIPE2")) {
+    static bool ppattr = false;
+    if (!ppattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u32, RB, BLOCK, KPT1, false, false, false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS1::BYTES);
+      ppattr = true;
+    }
+    hipLaunchKernelGGL((radix_group_kernel<u32, RB, BLOCK, KPT1, false, false, false, false, true>), dim3((uint32_t)std::min(tiles1_max, cus * GS1::WG_PER_CU)), dim3(BLOCK),
+                       GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
+                       &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
+                       GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
+  }
   else
   hipLaunchKernelGGL((radix_group_kernel<u32, RB, BLOCK, KPT1, false, false, false>), dim3((uint32_t)std::min(tiles1_max, cus * GS1::WG_PER_CU)), dim3(BLOCK),
                      GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
