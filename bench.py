@@ -17,10 +17,11 @@ and k-mers are routed to their owner in point-to-point waves over RCCL/xGMI whil
 the owner counts the buckets that have arrived.
 
 Prints ONE JSON line (rank 0), at every N:
-  roofline      the kernel with the largest share of the step's time (the sub-bucket count kernel; its fraction of the
-                step is given) priced on its algorithmic bytes and its own launch durations (HIP events on the streams it
-                is launched on); `sort_pass` keeps the radix grouping pass; `traffic` is the PMC measurement committed
-                under profiles/ for this same workload
+  roofline      the kernel family with the largest WALL-CLOCK share of the step (computed from the stage clocks, not asserted: the
+                first grouping pass on the judged workload) priced on its algorithmic bytes and its own launch durations (HIP
+                events on the stream it is launched on); the other families -- second pass, sub-bucket count, partition,
+                histogram -- under `kernels`, the grouping passes also under `sort_pass`; `traffic` is the PMC measurement
+                committed under profiles/ for this same workload
   check         untimed sanity check of the counted result (N > 1: reduced over the ranks, rank boundaries included)
   db_write      the counted result -> the 64-file database (N > 1: count_sharded(db=...), every rank its part, stitched;
                 its 129 files compared with the database mgc_count_node -- the in-process peer-copy form -- writes)
@@ -319,68 +320,87 @@ def pmc_traffic(reads, prefix, also=()):
 
 
 def roofline_object(prof_acc, ms_per_step, steps, reads, single, where):
-    """`roofline` of the line: the kernel with the largest share of the step, and the grouping pass under sort_pass."""
+    """`roofline` of the line: the kernel family with the LARGEST WALL SHARE of the step -- computed, not asserted.
+    A family's wall clock per step: the grouping passes and the front-end kernels run back to back on the session stream, so the sum
+    of their launch durations IS their wall clock; the count kernels of consecutive files overlap on two streams, so their wall
+    clock is the count stage's own (HIP events on the session stream) minus the packing tail the library times separately
+    (`pack_ms`) -- never the sum of their launch durations, which exceeds it.  Every family is priced on its ALGORITHMIC bytes; the
+    others stay in `kernels`, the grouping passes also under `sort_pass` (the key earlier rounds' lines carry)."""
     bp = prof_acc["by_pass"]
     if not bp[0]["launches"] and prof_acc["pass_launches"]:              # only the totals were collected
         bp = [{"ms": prof_acc["pass_ms"], "launches": prof_acc["pass_launches"], "keys": prof_acc["pass_keys"],
                "bytes": prof_acc.get("pass_bytes", 16 * prof_acc["pass_keys"])}, {"ms": 0.0, "launches": 0, "keys": 0, "bytes": 0}]
-    sort_pass = None
+    fams = {}
+
+    def family(key, kernel, wall_ms_total, bytes_total, launches, launch_ms_total, traffic_prefix, also=(), note=None, keys=None):
+        if not launches or wall_ms_total <= 0:
+            return
+        achieved = bytes_total / (launch_ms_total / 1e3) / 1e9        # on the launches' own durations (HIP events on their stream)
+        t, src = pmc_traffic(reads, traffic_prefix, also=also) if single else (None, None)
+        f = {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+             "traffic": t, "traffic_source": src or ("none: no committed PMC run of this workload" if single else None),
+             "launches": launches, "avg_launch_ms": launch_ms_total / launches,
+             "algorithmic_bytes_per_launch": bytes_total / launches,
+             "wall_ms_per_step": wall_ms_total / steps, "share_of_step": (wall_ms_total / steps) / ms_per_step if single else None}
+        if keys:
+            f["keys_per_launch"] = keys / launches
+        if abs(wall_ms_total - launch_ms_total) > 1e-9:
+            # launches that overlap on two streams: the fraction on the family's WALL clock beside the one on the launches' own
+            f["frac_on_wall"] = bytes_total / (wall_ms_total / 1e3) / 1e9 / HBM_PEAK_GBS
+            f["launch_ms_sum_per_step"] = launch_ms_total / steps
+        if note:
+            f["note"] = note
+        fams[key] = f
+
     if bp[0]["launches"]:
-        # A file's FIRST grouping pass.  Algorithmic bytes = key bytes it must read and write: 8 + 8 per k-mer for the wide pass,
-        # 8 + 4 when the pass narrows its output to 32-bit words (k <= ~25: the digit a key was grouped by is dropped, the second
-        # pass then moves 4 + 4), 5 + 4 when the partition left the file in the 5-byte layout (k = 20..23) -- the library reports
-        # them per launch.
-        achieved = bp[0]["bytes"] / (bp[0]["ms"] / 1e3) / 1e9
-        narrowed = bp[0]["bytes"] < 16 * bp[0]["keys"]
-        t, src = pmc_traffic(reads, "radix_group_kernel<unsigned long long") if single else (None, None)
+        # A file's FIRST grouping pass.  Algorithmic bytes = the key bytes it must read and write (the library reports them per
+        # launch): 5 + 4 per k-mer from the 5-byte layout (k = 20..23), 8 + 4 when only the output is narrowed, 8 + 8 / 12 + 12 /
+        # 16 + 16 for whole keys.
         per_key = bp[0]["bytes"] / max(1, bp[0]["keys"])
-        sort_pass = {
-            "kernel": "radix_group_kernel, first pass of a file (9-bit digit; %s)" %
-                      (("5 B k-mers (u32 + u8 arrays per file) in, 4 B narrowed words out" if per_key < 10 else "8 B k-mers in, 4 B narrowed words out")
-                       if narrowed else "8 B k-mers in and out"),
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": t, "traffic_source": src, "launches": bp[0]["launches"], "avg_launch_ms": bp[0]["ms"] / bp[0]["launches"],
-            "algorithmic_bytes_per_launch": bp[0]["bytes"] / bp[0]["launches"], "keys_per_launch": bp[0]["keys"] / bp[0]["launches"],
-            "share_of_step": (bp[0]["ms"] / steps) / ms_per_step if single else None,
-        }
-        if bp[1]["launches"]:
-            a1 = bp[1]["bytes"] / (bp[1]["ms"] / 1e3) / 1e9
-            t1, src1 = pmc_traffic(reads, "radix_group_kernel<unsigned int") if single else (None, None)
-            sort_pass["second_pass"] = {"achieved": a1, "frac": a1 / HBM_PEAK_GBS, "launches": bp[1]["launches"],
-                                        "avg_launch_ms": bp[1]["ms"] / bp[1]["launches"],
-                                        "algorithmic_bytes_per_launch": bp[1]["bytes"] / bp[1]["launches"],
-                                        "traffic": t1, "traffic_source": src1,
-                                        "share_of_step": (bp[1]["ms"] / steps) / ms_per_step if single else None}
-        # the same passes priced the way SURVEY 8(d) prices a radix pass (8 + 8 B per k-mer whatever is really moved):
-        # comparable with earlier rounds' 0.47
-        eq = 16.0 * prof_acc["pass_keys"] / (prof_acc["pass_ms"] / 1e3) / 1e9
-        sort_pass["survey_accounting"] = {"bytes_per_key_per_pass": 16, "achieved": eq, "frac": eq / HBM_PEAK_GBS}
+        narrowed = bp[0]["bytes"] < 16 * bp[0]["keys"]
+        family("first_pass", "radix_group_kernel, first pass of a file (%s)" %
+               (("5 B k-mers (u32 + u8 arrays per file) in, 4 B narrowed words out" if per_key < 10 else "8 B k-mers in, 4 B narrowed words out")
+                if narrowed else "whole keys in and out"),
+               bp[0]["ms"], bp[0]["bytes"], bp[0]["launches"], bp[0]["ms"], "radix_group_kernel<unsigned long long", keys=bp[0]["keys"])
+    if bp[1]["launches"]:
+        family("second_pass", "radix_group_kernel, second pass of a file", bp[1]["ms"], bp[1]["bytes"], bp[1]["launches"], bp[1]["ms"],
+               "radix_group_kernel<unsigned int", keys=bp[1]["keys"])
     fin = prof_acc.get("finish")
     if fin and fin["launches"]:
-        # The kernel with the largest share of the step's KERNEL time: the sub-bucket count (hash_count_multi_kernel since round 4).  Two launches run
-        # side by side on alternating streams, so the launches' own durations add up to more than the stage's wall clock.
-        achieved = fin["bytes"] / (fin["ms"] / 1e3) / 1e9
-        t, src = pmc_traffic(reads, "hash_count_multi_kernel", also=("hash_count_kernel", "hash_count_huge_kernel")) if single else (None, None)
-        out = {
-            "kernel": "hash_count_multi_kernel / hash_count_kernel (sub-bucket count: 4 B narrowed keys in, distinct 4 B suffixes + 4 B counts out), one launch per file",
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": t, "traffic_source": src or ("none: no committed PMC run of this workload" if single else None),
-            "measured": "HIP events around every launch, on the stream it is launched on, " + where,
-            "launches": fin["launches"], "avg_launch_ms": fin["ms"] / fin["launches"],
-            "algorithmic_bytes_per_launch": fin["bytes"] / fin["launches"], "keys_per_launch": fin["keys"] / fin["launches"],
-            "kernel_time_share_of_step": (fin["ms"] / steps) / ms_per_step if single else None,
-            "note": "VALU/LDS-issue-bound (DESIGN.md 3.4): the fraction says how far from the HBM roof the step's largest kernel runs, "
-                    "not that HBM limits it",
-            "sort_pass": sort_pass,
-        }
-        if single and prof_acc["stage_ms"][3]:
-            wall = prof_acc["stage_ms"][3] / steps                      # the finish stage's wall clock (count kernels + packing)
-            out["stage_wall_ms"] = wall
-            out["frac_on_stage_wall"] = (fin["bytes"] / fin["launches"] * (fin["launches"] / steps)) / (wall / 1e3) / 1e9 / HBM_PEAK_GBS
-        return out
-    if sort_pass:
-        sort_pass["measured"] = "HIP events around every pass launch, " + where
-    return sort_pass
+        stage_wall = prof_acc["stage_ms"][3]                              # the count stage on the session stream (count kernels + packing)
+        wall = stage_wall - prof_acc.get("pack_ms", 0.0) if (single and stage_wall) else fin["ms"]
+        if wall <= 0:
+            wall = fin["ms"]
+        family("count", "hash_count_stream_kernel / hash_count_multi_kernel / hash_count_kernel (sub-bucket count: 4 B narrowed keys in, "
+               "distinct 4 B suffixes + 4 B counts out), one launch per file on two alternating streams",
+               wall, fin["bytes"], fin["launches"], fin["ms"], "hash_count_stream_kernel",
+               also=("hash_count_multi_kernel", "hash_count_kernel", "hash_count_huge_kernel"), keys=fin["keys"],
+               note="VALU/LDS-issue-bound (DESIGN.md 3.4): the fraction says how far from the HBM roof the kernel runs, not that HBM limits it")
+    if single and prof_acc.get("partition_bytes") and prof_acc["stage_ms"][1]:
+        family("partition", "kmer_partition_kernel (bases in, k-mers out in the files' layout)", prof_acc["stage_ms"][1], prof_acc["partition_bytes"],
+               steps, prof_acc["stage_ms"][1], "kmer_partition_kernel")
+    if single and prof_acc.get("hist_bytes") and prof_acc["stage_ms"][0]:
+        family("histogram", "kmer_hist_fine_kernel (bases in, fifteen-bit file histogram out)", prof_acc["stage_ms"][0], prof_acc["hist_bytes"],
+               steps, prof_acc["stage_ms"][0], "kmer_hist_fine_kernel")
+    if not fams:
+        return None
+    top = max(fams, key=lambda kk: fams[kk]["wall_ms_per_step"])
+    out = dict(fams[top])
+    out["dominant"] = top
+    out["dominant_by"] = "largest wall-clock share of the step among the kernel families (per-stage wall clock; overlapped launches never summed)"
+    out["measured"] = "HIP events around every launch, on the stream it is launched on, " + where
+    out["kernels"] = {kk: v for kk, v in fams.items() if kk != top}
+    if "first_pass" in fams:
+        sp = dict(fams["first_pass"])
+        if "second_pass" in fams:
+            sp["second_pass"] = dict(fams["second_pass"])
+        # the same passes priced the way SURVEY 8(d) prices a radix pass (8 + 8 B per k-mer whatever is really moved): comparable
+        # with earlier rounds' figures, not a roofline
+        if prof_acc["pass_ms"]:
+            eq = 16.0 * prof_acc["pass_keys"] / (prof_acc["pass_ms"] / 1e3) / 1e9
+            sp["survey_accounting"] = {"bytes_per_key_per_pass": 16, "achieved": eq, "frac": eq / HBM_PEAK_GBS}
+        out["sort_pass"] = sp
+    return out
 
 
 def main():
@@ -516,6 +536,10 @@ def main():
                 fin["ms"] += p.finish_ms; fin["launches"] += p.finish_launches; fin["keys"] += p.finish_keys; fin["bytes"] += p.finish_bytes
                 for i in range(capi.NUM_STAGES):
                     prof_acc["stage_ms"][i] += p.stage_ms[i]
+                prof_acc["pack_ms"] = prof_acc.get("pack_ms", 0.0) + p.pack_ms
+                prof_acc["partition_bytes"] = prof_acc.get("partition_bytes", 0) + p.partition_bytes
+                prof_acc["hist_bytes"] = prof_acc.get("hist_bytes", 0) + p.hist_bytes
+                prof_acc["plan"] = {"stream_files": p.stream_files, "stream_retries": p.stream_retries, "probe_ratio": p.probe_ratio}
             info = sess.info()
             result["info"] = info
             result["n_distinct"] = info.n_distinct
@@ -732,6 +756,8 @@ def main():
             line["config"]["w_prefix"] = result["w_prefix"]
             line["instances_per_s"] = n_inst / (dt / args.steps)
             line["stage_ms_per_step"] = {capi.STAGE_NAMES[i]: prof_acc["stage_ms"][i] / args.steps for i in range(capi.NUM_STAGES)}
+            if prof_acc.get("plan"):
+                line["config"]["file_plan"] = prof_acc["plan"]      # files on the distinct-sized count, its retries, the probe file's D / N
         elif stage_s:
             line["stage_ms_one_profiled_step"] = {k: v * 1e3 for k, v in stage_s.items()}
             line["stage_note"] = ("rank 0, the database-writing call: partition / plan / exchange+count (first_wave_exposed = the part of the "
@@ -767,6 +793,9 @@ def main():
                         f1["ms"] += p1.finish_ms; f1["launches"] += p1.finish_launches; f1["keys"] += p1.finish_keys; f1["bytes"] += p1.finish_bytes
                         for i in range(capi.NUM_STAGES):
                             acc1["stage_ms"][i] += p1.stage_ms[i]
+                        acc1["pack_ms"] = acc1.get("pack_ms", 0.0) + p1.pack_ms
+                        acc1["partition_bytes"] = acc1.get("partition_bytes", 0) + p1.partition_bytes
+                        acc1["hist_bytes"] = acc1.get("hist_bytes", 0) + p1.hist_bytes
                     torch.cuda.synchronize()
                     ms1 = (time.perf_counter() - t1) / 2 * 1e3
                 rf = roofline_object(acc1, ms1, 2, reads, True, "in one single-session count of rank 0's reads on the same device "

@@ -143,6 +143,14 @@ int mgc_dev_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words
                        uint32_t begin_bit, uint32_t end_bit,
                        void *d_workspace, size_t workspace_bytes,
                        int *result_in_alt, void *stream);
+/* The GROUPING passes the count path uses on a file's top bits (not a sort): the keys come out grouped by bits
+ * [begin_bit, end_bit), groups ascending, members in ANY order (unstable).  Defined for ranges of at most two digits
+ * (18 bits) and n < 2^30; anything else takes the stable sort above.  Same arguments and workspace.  Replaces the top-bit
+ * part of unpackSuffixes + std::sort (merylCountArray.C:276-289,330), which the sub-bucket count does not need ordered. */
+int mgc_dev_radix_group(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words,
+                        uint32_t begin_bit, uint32_t end_bit,
+                        void *d_workspace, size_t workspace_bytes,
+                        int *result_in_alt, void *stream);
 
 /* Run-length count of a sorted key array (countSingleKmers' two passes,
  * merylCountArray.C:334-358).  Step 1 returns the number of distinct keys
@@ -396,6 +404,11 @@ typedef struct mgc_profile {
   uint32_t k96_widened_files;      /* ... of which widened back to 16-byte keys (an oversized sub-bucket nothing streams) */
   uint64_t stream_retries;         /* sub-buckets with more distinct suffixes than that kernel's table holds (counted by its retry launch) */
   double   probe_ratio;            /* distinct / instances of the probe file that chose between the plans (0: no probe ran) */
+  /* what the rest of the count stage lasts (offsets of the sub-buckets in the packed result + the packing kernels of all files), on
+   * the session stream behind the count kernels: stage_ms[MGC_STAGE_RLE] - pack_ms = the wall clock of the count kernels themselves */
+  double   pack_ms;
+  uint64_t hist_bytes;             /* ALGORITHMIC bytes of the histogram kernel (the bases read) ... */
+  uint64_t partition_bytes;        /* ... and of the partition (the bases read + the k-mers written in the layout the files take: 5 / 8 / 12 / 16 B) */
 } mgc_profile;
 int mgc_set_profiling(mgc_session *s, int enable);
 int mgc_get_profile(const mgc_session *s, mgc_profile *p);

@@ -19,7 +19,7 @@ STAGE_NAMES = ("histogram", "partition", "sort", "rle", "blocks")
 SYMBOLS = (
     "mgc_configure_counting", "mgc_format_configured_line",
     "mgc_dev_partition_workspace_bytes", "mgc_dev_kmer_histogram", "mgc_dev_kmer_partition",
-    "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort",
+    "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort", "mgc_dev_radix_group",
     "mgc_dev_rle_workspace_bytes", "mgc_dev_rle_count", "mgc_dev_rle_emit", "mgc_dev_block_offsets",
     "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_staged_bases", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_push_text_file", "mgc_push_text_file_range", "mgc_text_record_start", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_copy_result_device",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish", "mgc_finish_labelled",
@@ -104,6 +104,9 @@ class Profile(ctypes.Structure):
         ("k96_widened_files", ctypes.c_uint32),
         ("stream_retries", ctypes.c_uint64),
         ("probe_ratio", ctypes.c_double),
+        ("pack_ms", ctypes.c_double),
+        ("hist_bytes", ctypes.c_uint64),
+        ("partition_bytes", ctypes.c_uint64),
     ]
 
 
@@ -274,6 +277,7 @@ def lib():
     sig("mgc_dev_kmer_partition", i32, vp, u64, u32, i32, u32, vp, vp, vp, sz, vp)
     sig("mgc_dev_sort_workspace_bytes", sz, u64)
     sig("mgc_dev_radix_sort", i32, vp, vp, u64, u32, u32, u32, vp, sz, P(i32), vp)
+    sig("mgc_dev_radix_group", i32, vp, vp, u64, u32, u32, u32, vp, sz, P(i32), vp)
     sig("mgc_dev_rle_workspace_bytes", sz, u64)
     sig("mgc_dev_rle_count", i32, vp, u64, u32, vp, sz, P(u64), vp)
     sig("mgc_dev_rle_emit", i32, vp, u64, u32, vp, sz, vp, vp, vp)

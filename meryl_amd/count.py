@@ -101,22 +101,36 @@ def dev_kmer_histogram_keep(bases, k, mode=capi.MODE_CANONICAL, bucket_bits=6):
     counts = _u64(nb, bases.device)
     capi.check(L.mgc_dev_kmer_histogram(_ptr(bases), bases.numel(), k, mode, bucket_bits, _ptr(counts), _ptr(ws), ws_bytes,
                                         _stream_ptr()), "mgc_dev_kmer_histogram")
-    return counts.cpu().numpy().astype(np.uint64), (bases, k, mode, bucket_bits, ws, ws_bytes)
+    h_counts = counts.cpu().numpy().astype(np.uint64)
+    return h_counts, (bases, k, mode, bucket_bits, ws, ws_bytes, h_counts)
 
 
 def dev_kmer_partition_into(token, starts, out):
     """The partition of dev_kmer_histogram_keep's base stream with EXPLICIT bucket starts (key indices into `out`, any order,
     gaps allowed): bucket b's k-mers land at out[starts[b] : starts[b] + count[b]].  What lets a sharded count write the
     buckets a rank owns itself straight into its inbox instead of copying them there (count_sharded)."""
-    bases, k, mode, bucket_bits, ws, ws_bytes = token
-    d_starts = torch.from_numpy(np.asarray(starts, dtype=np.uint64).astype(np.int64)).to(bases.device)
+    bases, k, mode, bucket_bits, ws, ws_bytes, h_counts = token
+    starts = np.asarray(starts, dtype=np.uint64)
+    # a wrong plan would be a silent out-of-bounds scatter on the device: the shape of `out` and every bucket's range are checked here
+    if starts.shape != h_counts.shape:
+        raise ValueError("dev_kmer_partition_into: %d starts for %d buckets" % (starts.size, h_counts.size))
+    want_dim = 2 if k > 32 else 1
+    if out.dtype != torch.int64 or out.dim() != want_dim or (want_dim == 2 and out.shape[1] != 2) or not out.is_contiguous():
+        raise ValueError("dev_kmer_partition_into: out must be a contiguous int64[N%s] tensor for k = %d" % (", 2" if want_dim == 2 else "", k))
+    if out.device != bases.device:
+        raise ValueError("dev_kmer_partition_into: out lives on %s, the bases on %s" % (out.device, bases.device))
+    nz = h_counts > 0
+    if nz.any() and int((starts[nz] + h_counts[nz]).max()) > int(out.shape[0]):
+        raise ValueError("dev_kmer_partition_into: a bucket ends at key %d, out holds %d" % (int((starts[nz] + h_counts[nz]).max()), int(out.shape[0])))
+    d_starts = torch.from_numpy(starts.astype(np.int64)).to(bases.device)
     capi.check(capi.lib().mgc_dev_kmer_partition(_ptr(bases), bases.numel(), k, mode, bucket_bits, _ptr(d_starts), _ptr(out),
                                                  _ptr(ws), ws_bytes, _stream_ptr()), "mgc_dev_kmer_partition")
 
 
-def dev_radix_sort(keys, begin_bit, end_bit):
+def dev_radix_sort(keys, begin_bit, end_bit, group=False):
     """Sorts keys on bits [begin_bit, end_bit): an int64[N] cuda tensor (as uint64) or an
-    int64[N, 2] tensor of {lo, hi} rows (128-bit keys).  Returns the sorted tensor."""
+    int64[N, 2] tensor of {lo, hi} rows (128-bit keys).  Returns the sorted tensor.
+    group=True: the count path's grouping passes (mgc_dev_radix_group): grouped by those bits, members in any order."""
     L = capi.lib()
     kw = 2 if keys.dim() == 2 else 1
     n = keys.shape[0]
@@ -126,8 +140,9 @@ def dev_radix_sort(keys, begin_bit, end_bit):
     ws_bytes = L.mgc_dev_sort_workspace_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=keys.device)
     in_alt = ctypes.c_int(0)
-    capi.check(L.mgc_dev_radix_sort(_ptr(keys), _ptr(alt), n, kw, begin_bit, end_bit, _ptr(ws), ws_bytes,
-                                    ctypes.byref(in_alt), _stream_ptr()), "mgc_dev_radix_sort")
+    op = L.mgc_dev_radix_group if group else L.mgc_dev_radix_sort
+    capi.check(op(_ptr(keys), _ptr(alt), n, kw, begin_bit, end_bit, _ptr(ws), ws_bytes,
+                  ctypes.byref(in_alt), _stream_ptr()), "mgc_dev_radix_group" if group else "mgc_dev_radix_sort")
     return alt if in_alt.value else keys
 
 
@@ -499,6 +514,45 @@ def owned_sort_bits(k, first_file, end_file):
 EXCHANGE_CHUNK = 1 << 27          # keys per message: keeps every send/recv far below 2^31 bytes/elements
 
 
+def _host_staged(t, group=None):
+    """CUDA tensors over a backend that only moves host memory (gloo): two ranks sharing ONE device can run the real plan with the
+    real HIP operators -- RCCL refuses duplicate GPUs, gloo does not (tests/test_dist_one_gpu.py) -- through pinned-less host
+    copies.  Never taken on the product path (backend nccl = RCCL)."""
+    import torch.distributed as dist
+    return bool(getattr(t, "is_cuda", False)) and dist.get_backend(group) != "nccl"
+
+
+class _StagedRecv:
+    """an irecv into a host buffer + the copy to its device destination once it has arrived"""
+    def __init__(self, req, host, dst):
+        self.req, self.host, self.dst = req, host, dst
+
+    def wait(self):
+        self.req.wait()
+        self.dst.copy_(self.host)
+
+
+def _all_reduce(t, op, group):
+    import torch.distributed as dist
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def _all_gather(outs, t, group):
+    import torch.distributed as dist
+    if _host_staged(t, group):
+        hs = [o.cpu() for o in outs]
+        dist.all_gather(hs, t.cpu(), group=group)
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+    else:
+        dist.all_gather(outs, t, group=group)
+
+
 def exchange_segments(sends, recvs, device, group=None, chunk=None, max_rows=None, wait=True):
     """Variable-size all-to-all as explicit point-to-point segments.
     sends: list of (peer, tensor_view) in the order the peer expects them;
@@ -516,7 +570,7 @@ def exchange_segments(sends, recvs, device, group=None, chunk=None, max_rows=Non
     if max_rows is None:
         local_max = max([t.shape[0] for _, t in sends] + [t.shape[0] for _, t in recvs] + [0])
         m = torch.tensor([local_max], dtype=torch.int64, device=device)
-        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)      # same number of rounds everywhere
+        _all_reduce(m, dist.ReduceOp.MAX, group)                   # same number of rounds everywhere
         max_rows = int(m.item())
     rounds = max(1, -(-int(max_rows) // chunk))
     own_src = [t for p, t in sends if p == rank]
@@ -525,22 +579,38 @@ def exchange_segments(sends, recvs, device, group=None, chunk=None, max_rows=Non
     for a, b in zip(own_src, own_dst):
         b.copy_(a)
     pending = []
+    staged = any(_host_staged(t, group) for _, t in sends + recvs)
     for j in range(rounds):
         p2p = []
+        landing = []                                              # staged receives: (index in p2p, host buffer, device destination)
         for peer, t in sends:
             if peer != rank:
                 piece = t[min(t.shape[0], j * chunk):min(t.shape[0], (j + 1) * chunk)]
                 if piece.shape[0]:
                     g = peer if group is None else dist.get_global_rank(group, peer)
-                    p2p.append(dist.P2POp(dist.isend, piece, g, group))
+                    p2p.append(dist.P2POp(dist.isend, piece.cpu() if staged else piece, g, group))
         for peer, t in recvs:
             if peer != rank:
                 piece = t[min(t.shape[0], j * chunk):min(t.shape[0], (j + 1) * chunk)]
                 if piece.shape[0]:
                     g = peer if group is None else dist.get_global_rank(group, peer)
-                    p2p.append(dist.P2POp(dist.irecv, piece, g, group))
+                    if staged:
+                        host = torch.empty(piece.shape, dtype=piece.dtype)
+                        landing.append((len(p2p), host, piece))
+                        p2p.append(dist.P2POp(dist.irecv, host, g, group))
+                    else:
+                        p2p.append(dist.P2POp(dist.irecv, piece, g, group))
         if p2p:
-            reqs = dist.batch_isend_irecv(p2p)
+            reqs = list(dist.batch_isend_irecv(p2p))
+            if staged and len(reqs) == len(p2p):                  # (one request per operation: gloo)
+                for idx, host, dst in landing:
+                    reqs[idx] = _StagedRecv(reqs[idx], host, dst)
+            elif staged:                                          # a backend that coalesces the batch: wait, then land everything
+                for req in reqs:
+                    req.wait()
+                for _, host, dst in landing:
+                    dst.copy_(host)
+                reqs = []
             if wait:
                 for req in reqs:
                     req.wait()
@@ -554,10 +624,16 @@ def dev_count_files(keys, file_counts, k, mode=capi.MODE_CANONICAL):
     whole files, 2^b for finer buckets).  Everything mgc_count does after the partition, in place on `keys`
     (mgc_count_buckets)."""
     dev = keys.device.index if keys.device.index is not None else torch.cuda.current_device()
-    s = _SESSIONS.get((k, mode, dev))
+    # A session reads the MGC_* switches ONCE, when it is opened (mgc_open): the cache is keyed by their current values too, so
+    # that a switch set between two sharded counts of one process opens a new session instead of being silently ignored.
+    env = tuple(sorted((n, v) for n, v in os.environ.items() if n.startswith("MGC_")))
+    key = (k, mode, dev, env)
+    s = _SESSIONS.get(key)
     if s is None:                        # kept: the session's device arena is grow-only, a new one would re-malloc tens of GB
+        for old in [kk for kk in _SESSIONS if kk[:3] == key[:3]]:      # (the same shape under other switches: its arena goes first)
+            _SESSIONS.pop(old).close()
         cfg = capi.configure(k, max(int(keys.shape[0]), 1) * max(k, 1), 64 << 30, mode)
-        s = _SESSIONS[(k, mode, dev)] = Session(cfg, dev)
+        s = _SESSIONS[key] = Session(cfg, dev)
     if SHARD_PROFILE is not None:
         s.set_profiling(True)
     s.count_partitioned(keys, file_counts)
@@ -693,7 +769,7 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
 
     mark("start")
     nb_local = torch.tensor([int(bases.numel())], dtype=torch.int64, device=bases.device)
-    dist.all_reduce(nb_local, op=dist.ReduceOp.MAX, group=group)                 # every rank must pick the same granularity
+    _all_reduce(nb_local, dist.ReduceOp.MAX, group)                              # every rank must pick the same granularity
     max_local = int(nb_local.item())
     bits = shard_bucket_bits(world, k, max_local, db["w_prefix"] if db else None)
     nbk = 1 << bits
@@ -705,7 +781,7 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
         full = np.asarray(ops.histogram(bases, k, mode, bits)).astype(np.int64)
         fc = torch.from_numpy(full).to(bases.device)
         allf = [torch.empty_like(fc) for _ in range(world)]
-        dist.all_gather(allf, fc, group=group)
+        _all_gather(allf, fc, group)
         cuts = balanced_file_ranges(torch.stack(allf).cpu().numpy().sum(axis=0), world)
         slices = batch_slices(int(bases.numel()), n_batches, k)
     else:
@@ -728,7 +804,7 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
         # one small all-gather gives every rank the same [rank][file] histogram -> same cut points
         fc = torch.from_numpy(local_counts).to(bases.device)
         all_counts = [torch.empty_like(fc) for _ in range(world)]
-        dist.all_gather(all_counts, fc, group=group)
+        _all_gather(all_counts, fc, group)
         per_rank = torch.stack(all_counts).cpu().numpy()                             # [world][2^bits]
         if cuts is None:
             cuts = balanced_file_ranges(per_rank.sum(axis=0), world)

@@ -179,15 +179,29 @@ extern "C" int mgc_dev_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, 
 
 extern "C" size_t mgc_dev_sort_workspace_bytes(uint64_t n) { return mgc::sort_workspace_bytes(n) + 256; }
 
+static int dev_radix_passes(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, uint32_t begin_bit, uint32_t end_bit, void *d_ws,
+                           size_t ws_bytes, int *result_in_alt, void *stream, bool group);
+
 extern "C" int mgc_dev_radix_sort(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, uint32_t begin_bit,
                                   uint32_t end_bit, void *d_ws, size_t ws_bytes, int *result_in_alt, void *stream) {
+  return dev_radix_passes(d_keys, d_alt, n, key_words, begin_bit, end_bit, d_ws, ws_bytes, result_in_alt, stream, false);
+}
+// the grouping passes of the count path as a bare operator (its own entry point: an environment switch inside mgc_dev_radix_sort
+// used to change that operator's contract -- ADVICE r5)
+extern "C" int mgc_dev_radix_group(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, uint32_t begin_bit,
+                                   uint32_t end_bit, void *d_ws, size_t ws_bytes, int *result_in_alt, void *stream) {
+  return dev_radix_passes(d_keys, d_alt, n, key_words, begin_bit, end_bit, d_ws, ws_bytes, result_in_alt, stream, true);
+}
+
+static int dev_radix_passes(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, uint32_t begin_bit, uint32_t end_bit, void *d_ws,
+                           size_t ws_bytes, int *result_in_alt, void *stream, bool group) {
   if (!result_in_alt || begin_bit > end_bit || (key_words != 1 && key_words != 2) || end_bit > 64 * key_words) return MGC_EINVAL;
   *result_in_alt = 0;
   if (n == 0 || begin_bit == end_bit) return MGC_OK;
   if (!d_keys || !d_alt || !d_ws || ws_bytes < mgc::sort_workspace_bytes(n) + 256) return MGC_EINVAL;
   mgc::SortPlan plan;
   mgc::make_sort_plan(begin_bit, end_bit, &plan);
-  if (const char *sm = getenv("MGC_SORT_MODE")) if (atoi(sm) == 3) plan.mode = 3;      // tests reach the grouping passes through this bare operator
+  if (group) plan.mode = 3;
   // the last 256 bytes of the workspace hold the look-back error word
   uint32_t *d_err = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d_ws) + mgc::sort_workspace_bytes(n));
   hipStream_t st = (hipStream_t)stream;
@@ -1106,6 +1120,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     HIP_TRY(s, mgc::launch_kmer_partition(d_bases, n_bases, k, c.mode, bucket_bits, d_starts, (void *)X, part_ws, st,
                                           s->sfx_mask, s->sfx_test, k96 ? d_k96flags : (soa ? d_counts64 : nullptr), sw.const_k));
     tm.end(MGC_STAGE_PARTITION);
+    s->prof.hist_bytes = n_bases;
+    s->prof.partition_bytes = n_bases;
+    for (uint32_t b = 0; b < nb; b++) s->prof.partition_bytes += h_counts[b] * (soa ? 5u : ((k96 && h_k96flags[b]) ? 12u : (uint64_t)kbytes));
     s->prof.stage_launches[MGC_STAGE_PARTITION] = 2;
     return MGC_OK;
   };
@@ -1309,7 +1326,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       // (mgc_common.hpp K96; the region of a file stays 16 bytes per k-mer, so a file can be widened back in place).  MGC_K96=0: whole keys.
       bool k96 = sw.k96 && !ext_keys && kw == 2 && nb == 64 && d_fine && rem_bits <= 96 && s->sfx_mask == 0 && !c.homopoly_compress;
       bool any96 = false;                                             // per file: the ones on the two-digit whole-key passes (a small file keeps 16-byte keys)
-      for (uint32_t b = 0; b < nb && k96; b++) if (h_counts[b] && wide_msd[b] && top_bits[b]) { file_k96[b] = 1; h_k96flags[b] = 1; any96 = true; }
+      for (uint32_t b = 0; b < nb && k96; b++) if (h_counts[b] && wide_msd[b] && top_bits[b]) { file_k96[b] = 1; h_k96flags[b] = 1; any96 = true; s->prof.k96_files++; }
       const int prc = run_partition(soa, k96 && any96);
       if (prc != MGC_OK) return prc;
     }
@@ -1505,6 +1522,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         HIP_TRY(s, mgc::launch_widen_k96(seg, h_counts[b], (uint64_t)fb, (uint64_t)(fb >> 64), (void *)Y, st));
         HIP_TRY(s, hipMemcpyAsync(seg, Y, kbytes * h_counts[b], hipMemcpyDeviceToDevice, st));
         file_k96[b] = 0;
+        s->prof.k96_widened_files++;
       }
       bool unordered = false;
       if (narrow[b] && h_nlarge[b] > 0 && !stream) {
@@ -1633,6 +1651,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     }
 
     // ---- E/F. offsets of every sub-bucket in the packed result ----
+    hipEvent_t ev_pack[2] = {nullptr, nullptr};
+    if (s->profiling) { (void)hipEventCreate(&ev_pack[0]); (void)hipEventCreate(&ev_pack[1]); (void)hipEventRecord(ev_pack[0], st); }
     HIP_TRY(s, mgc::launch_finish_scan(d_group, ng_total, s->buf[mgc_session::B_GSCAN].p, st));
     HIP_TRY(s, hipMemcpyAsync(&nd, d_group + ng_total, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(s, hipStreamSynchronize(st));
@@ -1665,10 +1685,13 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         HIP_TRY(s, mgc::launch_rle_emit(seg, h_counts[b], kw, rle_ws, s->d_unique, s->d_counts, st, d_group + gbase[b]));
       }
     }
+    if (s->profiling) (void)hipEventRecord(ev_pack[1], st);
     tm.end(MGC_STAGE_RLE);
     s->prof.stage_launches[MGC_STAGE_RLE] = 4 * nb;
     if (s->profiling) {
       HIP_TRY(s, hipStreamSynchronize(st));
+      { float pms = 0; if (hipEventElapsedTime(&pms, ev_pack[0], ev_pack[1]) == hipSuccess) s->prof.pack_ms = pms; }
+      (void)hipEventDestroy(ev_pack[0]); (void)hipEventDestroy(ev_pack[1]);
       for (auto &pe : fin_ev) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, pe.first, pe.second) == hipSuccess) { s->prof.finish_ms += ms; s->prof.finish_launches++; }

@@ -299,7 +299,7 @@ extern "C" mgc_lookup *mgc_lookup_load(const char *db_path, uint64_t min_value, 
   // Device decode (mgc_decode.hip): host threads only READ the 64 data files and check their framing; the bytes go to HBM as
   // they are and every block is decoded there (one thread per block), straight into the table's arrays; the value filter is
   // the device compaction mgc_lookup_from_device uses.  MGC_DECODE_HOST=1, or a file only the host decoder follows: below.
-  const bool host_decode = getenv("MGC_DECODE_HOST") && getenv("MGC_DECODE_HOST")[0] == '1';      // read per call: the tests switch it
+  const bool host_decode = getenv("MGC_DECODE_HOST") && getenv("MGC_DECODE_HOST")[0] == '1';      // once per table load (tests switch it between loads)
   if (!host_decode) {
     if (device < 0) (void)hipGetDevice(&device);
     if (hipSetDevice(device) != hipSuccess) { lk_err("mgc_lookup_load: hipSetDevice failed"); return nullptr; }

@@ -332,6 +332,7 @@ int mgc_runs::collapse(const void **keys, const uint32_t **counts, uint64_t *n) 
   const size_t kbytes = sizeof(uint64_t) * kw;
   const double t0 = now_s();
   uint32_t pair_merges = 0;
+  const uint32_t fail_merge_at = (uint32_t)env_u64("MGC_RUNS_FAIL_MERGE", 0);   // tests (read once per collapse): the n-th pair merge "runs out of memory"
   while (runs.size() > 1) {
     std::vector<Run> next;
     // any failure below leaves the store CONSISTENT: the merged outputs so far, the odd run moved over, and the runs
@@ -371,7 +372,7 @@ int mgc_runs::collapse(const void **keys, const uint32_t **counts, uint64_t *n) 
       hipError_t e = hipMalloc(&o.keys, std::max<size_t>(kbytes * n_out, 256));
       if (e == hipSuccess) { void *c = nullptr; e = hipMalloc(&c, std::max<size_t>(sizeof(uint32_t) * n_out, 256)); o.counts = reinterpret_cast<uint32_t *>(c); }
       // tests: the n-th pair merge of this call "runs out of memory" (the fragmentation case hipMemGetInfo cannot foresee)
-      if (const char *fe = getenv("MGC_RUNS_FAIL_MERGE")) { if (e == hipSuccess && ++pair_merges == (uint32_t)atoi(fe)) e = hipErrorOutOfMemory; }
+      if (fail_merge_at && e == hipSuccess && ++pair_merges == fail_merge_at) e = hipErrorOutOfMemory;
       if (e != hipSuccess) {
         (void)hipGetLastError();
         free_run(o);

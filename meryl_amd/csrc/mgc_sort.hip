@@ -417,12 +417,15 @@ struct GroupExtra { u32 digit_bits /* NARROW */; u32 shift2, mask2; u64 *ghist2 
 
 // SOA (u64 keys): `in` is the 5-byte layout kmer_partition_kernel<SOA> leaves -- u32 in[n] low words, then u8[n] bits 32..39 --
 // and a key is put together as it is fetched: four keys per lane and group from one 16-byte and one 4-byte load.
-// PIPE (round 6; the 5-byte first pass and the 32-bit second pass): the tile AFTER the next one is fetched -- into registers, in the
-// form it has in memory (5 / 4 bytes per key) -- as soon as the current tile has left its registers for LDS, a WHOLE tile ahead:
-// the fetch of a tile runs beside the ranking, the scan, the exchange, the look-back and the write-out of the tile before it instead of
-// inside that tile's look-back phase (where the persistent workgroups, in step because of the look-back chain, all asked the memory
-// system at the same time and left it idle for the other two thirds of a tile's time: DESIGN.md 3.3).  Tickets run two tiles ahead.
-template <typename K, int RB, int BLOCK, int KPT, bool DBG, bool NARROW = false, bool HIST2 = false, bool SOA = false, bool PIPE = false>
+// PIPE (round 6; the 5-byte first pass): the tile AFTER the next one is fetched -- into registers, in the form it has in memory (5 bytes
+// per key: 20 registers for 16 keys) -- a WHOLE tile ahead: its loads are issued behind the write-out of the current tile and are consumed
+// behind the look-back of the NEXT one, so they are in flight beside a tile's ranking, scan and exchange as well (round 5's form asks for
+// the next tile at the start of the look-back and waits for it at the next ranking: the persistent workgroups, in step because of the
+// look-back chain, left the read side of the memory system idle for a third of a tile's time).  Tickets run two tiles ahead.
+// Measured (profiles/r06_pipe_ab.txt): first pass 0.545 -> 0.465 ms per launch.  The 32-bit second pass LOSES with the same change
+// (0.355 -> 0.385 / 0.45 ms at 20 words per thread: its walkers' wait for the staged words also waits for the granule they have just
+// published -- stores count in vmcnt on gfx9 -- and 24 + 24 words per thread do not fit the register file): it keeps round 5's form.
+template <typename K, int RB, int BLOCK, int KPT, bool DBG, bool NARROW = false, bool HIST2 = false, bool SOA = false, int PIPE = 0 /* 1: the next fetch before the write-out; 2: after it */>
 __global__ __launch_bounds__(BLOCK, (GroupSmem<K, RB, BLOCK, KPT>::MIN_WAVES_PER_SIMD))
 void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::type *__restrict__ out, u64 n, u32 shift, u32 dmask,
                         const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
@@ -712,7 +715,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
       // the tile fetched a whole tile ago leaves raw[] for keys[] (nothing newer is in flight when the wait for it runs: the
       // write-out's stores come AFTER this point), and the tile after it is asked for
       if (tile1 < total_tiles) assemble();
-      if (next < total_tiles) fetch_raw(nkb, nnv);
+      if (PIPE == 1 && next < total_tiles) fetch_raw(nkb, nnv);
     }
 
 #pragma unroll
@@ -726,6 +729,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
       }
     }
     PK_STAMP(4);
+    if constexpr (PIPE == 2) { if (next < total_tiles) fetch_raw(nkb, nnv); }
     __syncthreads();                                      // (F)
     PK_STAMP(5);
     if constexpr (PIPE) { tile = tile1; kb = kb1; nv = nv1; tile1 = next; kb1 = nkb; nv1 = nnv; }
@@ -1025,7 +1029,8 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
     attr_done = true;
   }
   const bool msd = d_prepared != nullptr && d_scratch != nullptr;
-  const uint64_t tiles0 = (n + TILE0 - 1) / TILE0, tiles1_max = (n + TILE1 - 1) / TILE1 + RS_MAX_RADIX + 1;
+  const uint64_t tile1 = TILE1;
+  const uint64_t tiles0 = (n + TILE0 - 1) / TILE0, tiles1_max = (n + tile1 - 1) / tile1 + RS_MAX_RADIX + 1;
   SortHeader *hdr;
   u64 *status_a, *status_b, *region_start;
   if (msd) {
@@ -1085,12 +1090,12 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
     }
     static bool spattr = false;
     if (pipe && !spattr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true, true, true>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true, true, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
       spattr = true;
     }
     if (pipe)
-      hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
+      hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true, true, 2>), grid0, dim3(BLOCK), GS0::BYTES, st,
                          reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                          &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
                          GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask}, (u64 *)nullptr);
@@ -1127,18 +1132,6 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                        GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
                        &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
                        GroupExtra{0u, 0u, 0u, nullptr}, dbg_buf + 64 * 8);
-  else if (pipe && getenv("MGC_GROUP_PIPE2")) {
-    static bool ppattr = false;
-    if (!ppattr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u32, RB, BLOCK, KPT1, false, false, false, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS1::BYTES);
-      ppattr = true;
-    }
-    hipLaunchKernelGGL((radix_group_kernel<u32, RB, BLOCK, KPT1, false, false, false, false, true>), dim3((uint32_t)std::min(tiles1_max, cus * GS1::WG_PER_CU)), dim3(BLOCK),
-                       GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
-                       &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
-                       GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
-  }
   else
   hipLaunchKernelGGL((radix_group_kernel<u32, RB, BLOCK, KPT1, false, false, false>), dim3((uint32_t)std::min(tiles1_max, cus * GS1::WG_PER_CU)), dim3(BLOCK),
                      GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
@@ -1207,6 +1200,8 @@ hipError_t launch_hpc_prepare(const uint64_t *d_fine_hpc, uint32_t bucket_bits, 
   return hipGetLastError();
 }
 
+// (the look-back scratch is sized for the SMALLEST tile of any whole-key instantiation of a key width: K128 8192 keys, K96 12288 --
+// group_wide asserts that its tile is not smaller)
 static inline uint64_t wide_tile(uint32_t key_words) { return key_words == 2 ? 1024u * 8u : 1024u * 16u; }
 size_t wide_scratch_bytes(uint64_t n, uint32_t key_words) {
   const uint64_t tile = wide_tile(key_words);
@@ -1220,6 +1215,7 @@ static hipError_t group_wide(void *d_keys, void *d_alt, uint64_t n, const SortPl
   constexpr int RB = 9, BLOCK = 1024, R = 1 << RB;
   using GS = GroupSmem<K, RB, BLOCK, KPT>;
   constexpr uint64_t TILE = (uint64_t)BLOCK * KPT;
+  static_assert(TILE >= (sizeof(K) >= 12 ? 1024u * 8u : 1024u * 16u), "wide_scratch_bytes sizes the granules for tiles of at least wide_tile() keys");
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, true>),

@@ -697,10 +697,11 @@ namespace {
 // input, uploaded as they are and DECODED ON THE DEVICE (mgc_decode.hip: one thread per block) -- the host only does I/O and
 // checks the framing.  MGC_DECODE_HOST=1, or a file framed in a way only the host decoder follows: decoded by the host
 // threads (65-70 M k-mers/s each) and uploaded as arrays, as before.
+// MGC_DECODE_HOST=1 (tests): read ONCE per merge / filter operation, by its entry point
+bool decode_on_host() { const char *e = getenv("MGC_DECODE_HOST"); return e && e[0] == '1'; }
 int load_slices(std::vector<mdb_reader *> &rd, uint32_t ff, uint32_t kw, std::vector<DBuf> &in_k, std::vector<DBuf> &in_c,
-                std::vector<uint64_t> &hn, hipStream_t st, std::string *msg) {
+                std::vector<uint64_t> &hn, hipStream_t st, std::string *msg, bool host_decode) {
   const uint32_t n_inputs = (uint32_t)rd.size();
-  const bool host_decode = getenv("MGC_DECODE_HOST") && getenv("MGC_DECODE_HOST")[0] == '1';      // read per call: the tests switch it
   struct Raw { unsigned char *bytes = nullptr; uint64_t size = 0; mdb_raw_block *blocks = nullptr; uint64_t nb = 0; bool on_device = false; };
   std::vector<Raw> raw(n_inputs);
   std::vector<std::vector<uint64_t>> hk(n_inputs);
@@ -822,10 +823,11 @@ extern "C" int mgc_db_merge(const char *const *inputs, uint32_t n_inputs, int op
     // filtered by "union-sum of ones == 1"; everything else folds from the left with its own two-input step
     const bool by_membership = (op == MGC_MERGE_SYMMETRIC_DIFFERENCE && n_inputs > 2);
     const int fold_op = (op == MGC_MERGE_UNION || by_membership) ? MGC_MERGE_UNION_SUM : op;
+    const bool host_decode = decode_on_host();
     MG_TRY(hipSetDevice(device));
     MG_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (uint32_t ff = 0; ff < MGC_NUM_FILES && rc == MGC_OK; ff++) {
-      rc = load_slices(rd, ff, kw, in_k, in_c, hn, st, &msg);
+      rc = load_slices(rd, ff, kw, in_k, in_c, hn, st, &msg, host_decode);
       if (rc != MGC_OK) { msg = "mgc_db_merge: " + msg; break; }
       // fold: values (and, for the membership forms, ones) through the same sequence of two-input steps
       auto fold = [&](bool use_ones, DBuf (&ak)[2], DBuf (&ac)[2], const void **out_k, const uint32_t **out_c, uint64_t *out_n) -> bool {
@@ -913,8 +915,9 @@ extern "C" int mgc_db_filter(const char *input, int value_op, uint64_t constant,
   const uint64_t blocks_per_file = 1ull << (w_prefix - MGC_NUM_FILES_BITS);
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  const bool host_decode = decode_on_host();
   for (uint32_t ff = 0; ff < MGC_NUM_FILES && rc == MGC_OK && e == hipSuccess; ff++) {
-    rc = load_slices(rd, ff, kw, in_k, in_c, hn, st, &msg);
+    rc = load_slices(rd, ff, kw, in_k, in_c, hn, st, &msg, host_decode);
     if (rc != MGC_OK) { msg = "mgc_db_filter: " + msg; break; }
     uint64_t n_new = 0;
     e = ws.ensure(mgc::select_workspace_bytes(hn[0]));

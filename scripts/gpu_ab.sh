@@ -14,8 +14,9 @@ for r in $(seq 1 ${ROUNDS:-3}); do
 import json, sys
 try:
     d = json.load(open(sys.argv[1])); r = d["roofline"]; sp = r.get("sort_pass", {})
-    print("%-10s %7.2f ms  %s  pass1 %.4f pass2 %.4f count %.4f" % (sys.argv[2], d["ms_per_step"], {k: round(v, 2) for k, v in d["stage_ms_per_step"].items()},
-          sp.get("avg_launch_ms", 0), sp.get("second_pass", {}).get("avg_launch_ms", 0), r.get("avg_launch_ms", 0)))
+    cnt = r if r.get("dominant") == "count" else r.get("kernels", {}).get("count", {})
+    print("%-10s %7.2f ms  %s  pass1 %.4f pass2 %.4f count %.4f (wall %.2f)" % (sys.argv[2], d["ms_per_step"], {k: round(v, 2) for k, v in d["stage_ms_per_step"].items()},
+          sp.get("avg_launch_ms", 0), sp.get("second_pass", {}).get("avg_launch_ms", 0), cnt.get("avg_launch_ms", 0), cnt.get("wall_ms_per_step", 0)))
 except Exception as e:
     print(sys.argv[2], "no bench line:", e)
 PY

@@ -27,8 +27,18 @@ def test_bench_single_gpu_line_is_complete(native_lib):
     assert d["n_gpus"] == 1 and d["unit"] == "distinct k-mers/s" and d["value"] > 0 and d["higher_is_better"] is True
     assert d["check"]["ok"] is True
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and "hash_count" in rf["kernel"]
-    assert 0 < rf["kernel_time_share_of_step"] < 1.5 and 0 < rf["sort_pass"]["frac"] < 1
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
+    # the dominant family is COMPUTED: the one with the largest wall share; every family's wall share stays inside its stage's
+    fams = dict(rf["kernels"]); fams[rf["dominant"]] = rf
+    assert {"first_pass", "count", "partition", "histogram"} <= set(fams)
+    assert all(fams[rf["dominant"]]["wall_ms_per_step"] >= f["wall_ms_per_step"] for f in fams.values())
+    st = d["stage_ms_per_step"]
+    stage_of = {"first_pass": "sort", "second_pass": "sort", "count": "rle", "partition": "partition", "histogram": "histogram"}
+    for name, f in fams.items():
+        assert 0 < f["frac"] < 1 and 0 < f["share_of_step"] < 1, (name, f)
+        assert f["wall_ms_per_step"] <= st[stage_of[name]] * 1.02 + 1e-6, (name, f["wall_ms_per_step"], st)
+    assert fams["first_pass"]["wall_ms_per_step"] + fams.get("second_pass", {"wall_ms_per_step": 0})["wall_ms_per_step"] <= st["sort"] * 1.02
+    assert 0 < rf["sort_pass"]["frac"] < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
     assert cb["whole_workload"] is True and "restatement" in cb["kind_note"] and "WHOLE workload" in cb["sample"]   # every byte the GPU counted

@@ -45,6 +45,9 @@ def test_pmc_traffic_is_the_launch_weighted_mean_over_instantiations(tmp_path, m
 
 
 def test_roofline_object_arithmetic():
+    """the dominant kernel family is COMPUTED from wall-clock shares -- passes by the sum of their launches (one
+    stream, back to back), the count kernels by their stage's wall clock minus the packing tail (their launches overlap on two
+    streams: the sum of the launch durations exceeds the stage) -- and no family's share exceeds its stage's."""
     b = _bench()
     steps, ms_per_step = 3, 120.0
     keys = 135_000_000
@@ -52,19 +55,36 @@ def test_roofline_object_arithmetic():
                        {"ms": 0.33 * 192, "launches": 192, "keys": keys * 192, "bytes": 8 * keys * 192}],
            "pass_ms": 0.87 * 192, "pass_launches": 384, "pass_keys": 2 * keys * 192, "pass_bytes": 17 * keys * 192,
            "finish": {"ms": 0.63 * 192, "launches": 192, "keys": keys * 192, "bytes": 688_000_000 * 192},
-           "stage_ms": [23.0, 74.0, 170.0, 86.0, 0.3]}
+           "stage_ms": [18.0, 63.0, 170.0, 86.0, 0.3], "pack_ms": 17.0,
+           "partition_bytes": 3 * (10_066_666_717 + 5 * 8_648_000_000), "hist_bytes": 3 * 10_066_666_717}
     r = b.roofline_object(acc, ms_per_step, steps, 66666667, True, "over the timed steps")
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and "hash_count_multi_kernel" in r["kernel"]
-    assert abs(r["achieved"] - 688_000_000 / 0.63e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
-    assert abs(r["avg_launch_ms"] - 0.63) < 1e-9 and r["traffic"] and r["traffic_source"].startswith("profiles/")
-    assert abs(r["kernel_time_share_of_step"] - (0.63 * 64) / 120.0) < 1e-9
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0
+    # 64 first passes of 0.54 ms = 34.6 ms per step: more than the count stage's 86 / 3 - 17 / 3 = 23 ms, the second pass's 21.1, the partition's 21
+    assert r["dominant"] == "first_pass" and "5 B k-mers" in r["kernel"] and set(r["kernels"]) == {"second_pass", "count", "partition", "histogram"}
+    assert abs(r["achieved"] - 9 * keys / 0.54e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert abs(r["wall_ms_per_step"] - 0.54 * 64) < 1e-9 and abs(r["share_of_step"] - 0.54 * 64 / 120.0) < 1e-9
+    assert r["traffic"] and r["traffic_source"].startswith("profiles/")
+    cnt = r["kernels"]["count"]
+    assert abs(cnt["achieved"] - 688_000_000 / 0.63e-3 / 1e9) < 1e-6 and abs(cnt["avg_launch_ms"] - 0.63) < 1e-9
+    assert abs(cnt["wall_ms_per_step"] - (86.0 - 17.0) / 3) < 1e-9                    # the stage's wall clock minus the packing tail ...
+    assert cnt["launch_ms_sum_per_step"] > cnt["wall_ms_per_step"]                     # ... not the sum of the overlapped launches
+    assert abs(cnt["frac_on_wall"] - 688_000_000 * 64 / ((86.0 - 17.0) / 3 * 1e-3) / 1e9 / 8000.0) < 1e-9
+    stage_of = {"first_pass": 2, "second_pass": 2, "count": 3, "partition": 1, "histogram": 0}
+    fams = dict(r["kernels"], first_pass=r)
+    for name, f in fams.items():
+        assert f["wall_ms_per_step"] <= acc["stage_ms"][stage_of[name]] / steps + 1e-9, name
+    assert abs(fams["partition"]["achieved"] - (10_066_666_717 + 5 * 8_648_000_000) / 21e-3 / 1e9) < 1e-3
     sp = r["sort_pass"]
     assert "5 B k-mers" in sp["kernel"] and abs(sp["achieved"] - 9 * keys / 0.54e-3 / 1e9) < 1e-6
     assert abs(sp["second_pass"]["achieved"] - 8 * keys / 0.33e-3 / 1e9) < 1e-6
     assert sp["survey_accounting"]["bytes_per_key_per_pass"] == 16
+    # a count stage that dominates (round 4's shape) is found too
+    acc_c = dict(acc, stage_ms=[18.0, 63.0, 170.0, 140.0, 0.3])
+    rc = b.roofline_object(acc_c, ms_per_step, steps, 66666667, True, "over the timed steps")
+    assert rc["dominant"] == "count" and "hash_count" in rc["kernel"] and "first_pass" in rc["kernels"]
     # N > 1 (not the single-session form): no traffic is borrowed, no share of a step is claimed
     r2 = b.roofline_object(acc, ms_per_step, steps, 66666667, False, "over the timed steps")
-    assert r2["traffic"] is None and r2["kernel_time_share_of_step"] is None and r2["sort_pass"]["traffic"] is None
+    assert r2["traffic"] is None and r2["share_of_step"] is None and r2["sort_pass"]["traffic"] is None
     # only the totals of the passes were collected (the sharded forms): one pass entry, priced on the reported bytes
     acc3 = dict(acc, by_pass=[{"ms": 0.0, "launches": 0, "keys": 0, "bytes": 0}] * 2, finish=None)
     r3 = b.roofline_object(acc3, ms_per_step, steps, 66666667, False, "over the timed steps")

@@ -196,9 +196,8 @@ def test_grouping_passes_group_by_the_selected_bits(ops, torch_cuda, n, bits, wo
     skew = rng.random(n) < 0.4
     a[skew, 0] &= np.uint64(~(((1 << (hi - lo)) - 1) << lo) & (2**64 - 1))     # 40% of the keys share digit 0:0
     a[rng.random(n) < 0.2, 0] |= np.uint64(((1 << (hi - lo)) - 1) << lo)          # 20% the all-ones digit
-    monkeypatch.setenv("MGC_SORT_MODE", "3")
     t = torch_cuda.from_numpy(a.view(np.int64).copy()).cuda()
-    out = ops.dev_radix_sort(t if words == 2 else t.reshape(-1), lo, hi).cpu().numpy().view(np.uint64).reshape(n, words)
+    out = ops.dev_radix_sort(t if words == 2 else t.reshape(-1), lo, hi, group=True).cpu().numpy().view(np.uint64).reshape(n, words)
     dig = (out[:, 0] >> np.uint64(lo)) & np.uint64((1 << (hi - lo)) - 1)
     assert np.all(dig[1:] >= dig[:-1]), (n, bits, words)
     canon = lambda m: m[np.lexsort(m.T[::-1])]
@@ -1386,6 +1385,34 @@ def test_hash_count_stream_kernel_distinct_sized_table(ops, oracle_lib, torch_cu
         if stream == "0":
             assert prof.stream_files == 0 and prof.stream_retries == 0
 
+
+
+def test_k96_file_with_a_subbucket_nothing_streams_is_widened(ops, oracle_lib, torch_cuda, monkeypatch):
+    """the per-file K96 selection (12-byte records below the file, k = 33..51) and its widening fallback -- a file that
+    holds a sub-bucket above the tables which the streaming kernels may not take (here: larger than MGC_STREAM_MAX with 16-byte
+    keys) goes back to 16-byte keys in place (launch_widen_k96) and through the stable sort -- asserted to have RUN (profile
+    counters k96_files / k96_widened_files), and compared with the oracle.  One 51-mer 3000 times in a file of ordinary reads."""
+    from meryl_amd import capi
+    k = 51
+    monkeypatch.setenv("MGC_FINISH_MIN_TOP", "12")          # two grouping digits on a small input: the whole-key high-digit-first passes
+    monkeypatch.setenv("MGC_STREAM_MAX", "2000")
+    rng = np.random.default_rng(51)
+    heavy = "AC" + "".join("ACGT"[i] for i in rng.integers(0, 4, k - 2))
+    reads = oracle_lib.synth_reads(k, 400_000, 0, 30_000).tobytes().decode()      # 4.5 Mbases: the fifteen-bit histogram is on
+    text = ".".join([heavy] * 3000) + "." + reads
+    cfg = capi.configure(k, len(text), 1 << 30, 1)          # forward mode keeps the heavy k-mer where it was put
+    cfg.use_simple = 0
+    with ops.Session(cfg) as s:
+        s.set_profiling(True)
+        s.push_bases(text, end_of_sequence=False)
+        s.count()
+        klo, khi, counts, _ = s.result_wide()
+        prof = s.profile()
+    whi, wlo, wcn, _ = oracle_lib.count_brute(text, k, 1)
+    assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+    assert counts.max() >= 3000
+    assert prof.k96_files > 32, prof.k96_files
+    assert prof.k96_widened_files >= 1, prof.k96_widened_files
 
 
 @pytest.mark.parametrize("nolist", ["1", "0"])
