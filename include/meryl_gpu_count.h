@@ -135,6 +135,12 @@ int mgc_dev_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint32_t k,
                            uint32_t bucket_bits, const uint64_t *d_bucket_starts,
                            void *d_keys, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* mgc_dev_kmer_histogram + the k-mers per top FIFTEEN bits (d_fine_hist: uint64[2^15], zeroed here), one pass over the bases;
+ * bucket_bits 6..8.  What a sharded count's senders run: the bucket counts feed the routing plan, the workspace rows the
+ * partition, the fifteen-bit histogram -- summed over the ranks -- the owners' first grouping digit (mgc_count_buckets_into). */
+int mgc_dev_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint32_t bucket_bits,
+                                uint64_t *d_bucket_counts, uint64_t *d_fine_hist, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* LSB radix sort of keys (key_words 1 or 2) on bits [begin_bit, end_bit).
  * Ping-pongs between d_keys and d_alt (both n keys); *result_in_alt tells
  * where the sorted keys ended up. */
@@ -322,6 +328,17 @@ int mgc_count_partitioned(mgc_session *s, void *d_keys, const uint64_t *file_cou
  * 64*N buckets so that an owner-side bucket is as large as a single-GPU file (a whole file would be N times larger
  * and need a third grouping pass). */
 int mgc_count_buckets(mgc_session *s, void *d_keys, uint32_t bucket_bits, const uint64_t *bucket_counts);
+/* ... and the packed result -- distinct k-mers ascending, their counts -- written STRAIGHT into the caller's device buffers when
+ * it fits (capacity in k-mers; *n_distinct tells): the waves of a sharded count are counted into one pre-sized result instead of
+ * being copied out of the session and concatenated (the reference's threads hand their blocks to ONE writer the same way,
+ * merylOp-countThreads.C:452-459).  *n_distinct > capacity: nothing was written there, the result is in the session (read it with
+ * mgc_copy_result_device) -- the caller grows its buffer.  The session's result views point into the caller's buffers until the
+ * next count. */
+int mgc_count_buckets_into(mgc_session *s, void *d_keys, uint32_t bucket_bits, const uint64_t *bucket_counts,
+                           void *d_out_keys, uint32_t *d_out_counts, uint64_t capacity, uint64_t *n_distinct,
+                           const uint64_t *d_fine_hist /* optional (device, uint64[2^15]): k-mers per top FIFTEEN bits over ALL ranks'
+                           reads of this batch (mgc_dev_kmer_histogram_fine, summed) -- with bucket_bits <= 8 the owner's grouping passes
+                           take their first digit's histogram from it instead of reading the keys for one */);
 
 typedef struct mgc_result_info {
   uint64_t n_bases;

@@ -19,9 +19,9 @@ STAGE_NAMES = ("histogram", "partition", "sort", "rle", "blocks")
 SYMBOLS = (
     "mgc_configure_counting", "mgc_format_configured_line",
     "mgc_dev_partition_workspace_bytes", "mgc_dev_kmer_histogram", "mgc_dev_kmer_partition",
-    "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort", "mgc_dev_radix_group",
+    "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort", "mgc_dev_radix_group", "mgc_dev_kmer_histogram_fine",
     "mgc_dev_rle_workspace_bytes", "mgc_dev_rle_count", "mgc_dev_rle_emit", "mgc_dev_block_offsets",
-    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_staged_bases", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_push_text_file", "mgc_push_text_file_range", "mgc_text_record_start", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_copy_result_device",
+    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_staged_bases", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_push_text_file", "mgc_push_text_file_range", "mgc_text_record_start", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_count_buckets_into", "mgc_copy_result_device",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish", "mgc_finish_labelled",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_dev_synth_reads_ex", "mgc_version",
     "mgc_dev_merge_workspace_bytes", "mgc_dev_merge_count", "mgc_dev_merge_count_values", "mgc_dev_merge_emit",
@@ -323,6 +323,8 @@ def lib():
     sig("mgc_count", i32, vp)
     sig("mgc_count_partitioned", i32, vp, vp, vp, vp)
     sig("mgc_count_buckets", i32, vp, vp, u32, vp)
+    sig("mgc_count_buckets_into", i32, vp, vp, u32, vp, vp, vp, u64, P(u64), vp)
+    sig("mgc_dev_kmer_histogram_fine", i32, vp, u64, u32, i32, u32, vp, vp, vp, sz, vp)
     sig("mgc_copy_result_device", i32, vp, vp, vp)
     sig("mgc_get_result_info", i32, vp, P(ResultInfo))
     sig("mgc_get_result_device", i32, vp, P(vp), P(vp), P(vp), P(u32))

@@ -99,17 +99,25 @@ def dev_kmer_histogram_keep(bases, k, mode=capi.MODE_CANONICAL, bucket_bits=6):
     ws_bytes = L.mgc_dev_partition_workspace_bytes(bucket_bits)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=bases.device)
     counts = _u64(nb, bases.device)
-    capi.check(L.mgc_dev_kmer_histogram(_ptr(bases), bases.numel(), k, mode, bucket_bits, _ptr(counts), _ptr(ws), ws_bytes,
-                                        _stream_ptr()), "mgc_dev_kmer_histogram")
+    fine = None
+    if 6 <= bucket_bits <= 8 and 2 * k >= 17 and os.environ.get("MGC_SHARD_FINE", "1") != "0":
+        # ... and the k-mers per top FIFTEEN bits in the same pass: summed over the ranks they are the first grouping digit of every
+        # owner-side bucket (count_sharded -> mgc_count_buckets_into), so that the owner does not read its keys for a histogram
+        fine = _u64(1 << 15, bases.device)
+        capi.check(L.mgc_dev_kmer_histogram_fine(_ptr(bases), bases.numel(), k, mode, bucket_bits, _ptr(counts), _ptr(fine), _ptr(ws), ws_bytes,
+                                                 _stream_ptr()), "mgc_dev_kmer_histogram_fine")
+    else:
+        capi.check(L.mgc_dev_kmer_histogram(_ptr(bases), bases.numel(), k, mode, bucket_bits, _ptr(counts), _ptr(ws), ws_bytes,
+                                            _stream_ptr()), "mgc_dev_kmer_histogram")
     h_counts = counts.cpu().numpy().astype(np.uint64)
-    return h_counts, (bases, k, mode, bucket_bits, ws, ws_bytes, h_counts)
+    return h_counts, (bases, k, mode, bucket_bits, ws, ws_bytes, h_counts, fine)
 
 
 def dev_kmer_partition_into(token, starts, out):
     """The partition of dev_kmer_histogram_keep's base stream with EXPLICIT bucket starts (key indices into `out`, any order,
     gaps allowed): bucket b's k-mers land at out[starts[b] : starts[b] + count[b]].  What lets a sharded count write the
     buckets a rank owns itself straight into its inbox instead of copying them there (count_sharded)."""
-    bases, k, mode, bucket_bits, ws, ws_bytes, h_counts = token
+    bases, k, mode, bucket_bits, ws, ws_bytes, h_counts = token[:7]
     starts = np.asarray(starts, dtype=np.uint64)
     # a wrong plan would be a silent out-of-bounds scatter on the device: the shape of `out` and every bucket's range are checked here
     if starts.shape != h_counts.shape:
@@ -300,6 +308,24 @@ class Session:
         torch.cuda.current_stream(keys.device).synchronize()
         capi.check(capi.lib().mgc_count_buckets(self._h, _ptr(keys) if keys.shape[0] else None, bits, fc.ctypes.data),
                    "mgc_count_buckets", self._h)
+
+    def count_partitioned_into(self, keys, bucket_counts, out_keys, out_counts, fine=None):
+        """count_partitioned with the packed result written straight into out_keys / out_counts (pre-sized cuda tensors) when it
+        fits; returns (n_distinct, fitted).  fine: int64[2^15] cuda tensor, the k-mers per top fifteen bits over all ranks."""
+        fc = np.ascontiguousarray(np.asarray(bucket_counts, dtype=np.uint64))
+        nb = fc.size
+        bits = int(nb).bit_length() - 1
+        assert nb == 1 << bits and nb >= 64
+        assert int(fc.sum()) == int(keys.shape[0])
+        cap = int(out_keys.shape[0])
+        assert out_counts.shape[0] >= cap and out_counts.dtype == torch.int32 and out_keys.dtype == torch.int64 and out_keys.is_contiguous()
+        torch.cuda.current_stream(keys.device).synchronize()
+        n = ctypes.c_uint64(0)
+        capi.check(capi.lib().mgc_count_buckets_into(self._h, _ptr(keys) if keys.shape[0] else None, bits, fc.ctypes.data,
+                                                     _ptr(out_keys) if cap else None, _ptr(out_counts) if cap else None, cap, ctypes.byref(n),
+                                                     _ptr(fine) if fine is not None else None),
+                   "mgc_count_buckets_into", self._h)
+        return int(n.value), int(n.value) <= cap
 
     def result_device(self):
         """(distinct keys, counts int32) as fresh cuda tensors (device-to-device copy)."""
@@ -619,10 +645,12 @@ def exchange_segments(sends, recvs, device, group=None, chunk=None, max_rows=Non
     return pending
 
 
-def dev_count_files(keys, file_counts, k, mode=capi.MODE_CANONICAL):
+def dev_count_files(keys, file_counts, k, mode=capi.MODE_CANONICAL, out=None, fine=None):
     """(distinct keys ascending, counts int32) of k-mers already laid out bucket-major (`file_counts`: 64 entries for
     whole files, 2^b for finer buckets).  Everything mgc_count does after the partition, in place on `keys`
-    (mgc_count_buckets)."""
+    (mgc_count_buckets).  out = (keys tensor, counts tensor): the free tail of a pre-sized result -- the packed result is written
+    there when it fits and VIEWS of it are returned (mgc_count_buckets_into: no copy out of the session, nothing to concatenate).
+    fine: the k-mers per top fifteen bits over all ranks' reads (int64[2^15] on the device): the first grouping digit of every bucket."""
     dev = keys.device.index if keys.device.index is not None else torch.cuda.current_device()
     # A session reads the MGC_* switches ONCE, when it is opened (mgc_open): the cache is keyed by their current values too, so
     # that a switch set between two sharded counts of one process opens a new session instead of being silently ignored.
@@ -636,7 +664,14 @@ def dev_count_files(keys, file_counts, k, mode=capi.MODE_CANONICAL):
         s = _SESSIONS[key] = Session(cfg, dev)
     if SHARD_PROFILE is not None:
         s.set_profiling(True)
-    s.count_partitioned(keys, file_counts)
+    fitted = False
+    if out is not None:
+        n_out, fitted = s.count_partitioned_into(keys, file_counts, out[0], out[1], fine)
+    elif fine is not None:
+        empty_k = keys[:0]
+        s.count_partitioned_into(keys, file_counts, empty_k, torch.empty(0, dtype=torch.int32, device=keys.device), fine)
+    else:
+        s.count_partitioned(keys, file_counts)
     if SHARD_PROFILE is not None:
         p = s.profile()
         SHARD_PROFILE["pass_ms"] = SHARD_PROFILE.get("pass_ms", 0.0) + p.sort_pass_ms_total
@@ -646,6 +681,10 @@ def dev_count_files(keys, file_counts, k, mode=capi.MODE_CANONICAL):
         for i in range(2):
             bp = SHARD_PROFILE.setdefault("by_pass", [{"ms": 0.0, "launches": 0, "keys": 0, "bytes": 0} for _ in range(2)])[i]
             bp["ms"] += p.pass_ms[i]; bp["launches"] += p.pass_launches[i]; bp["keys"] += p.pass_keys[i]; bp["bytes"] += p.pass_bytes[i]
+    if out is not None:
+        if fitted:                       # the packing kernels wrote the caller's buffers (the count ends synchronised): views, no copy
+            return out[0][:n_out], out[1][:n_out]
+        return s.result_device()         # (did not fit: the caller grows its result and takes this copy)
     return s.result_device()
 
 
@@ -666,6 +705,10 @@ class HipOps:
     histogram_keep = staticmethod(dev_kmer_histogram_keep)
     partition_into = staticmethod(dev_kmer_partition_into)
     count_files = staticmethod(dev_count_files)
+
+    @staticmethod
+    def count_files_into(keys, file_counts, k, mode, out, fine=None):
+        return dev_count_files(keys, file_counts, k, mode, out=out, fine=fine)
 
     @staticmethod
     def empty_keys(n, like):
@@ -792,6 +835,11 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
     runs = None
     n_local_distinct = 0
     parts = []
+    # ONE pre-sized result for the waves of an unbatched count (operators that can write into it: the HIP ones): sized after the
+    # first wave from its distinct / instances ratio (+ 6 %), grown in the rare case a later wave does not fit.  Without it every
+    # wave's result was copied out of the session and all of them concatenated at the end: 18 ms of a 10 Gbp rank's 147.
+    res = {"k": None, "c": None, "at": 0, "inst": 0}
+    into = getattr(ops, "count_files_into", None)
     f0 = f1 = 0
     proto = bases.new_empty((0, 2) if k > 32 else (0,), dtype=torch.int64)       # (the shape of a key tensor: {lo, hi} rows for k > 32)
     for bi, (sa, sb) in enumerate(slices):
@@ -801,6 +849,10 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
         local_counts, tok = ops.histogram_keep(bases[sa:sb], k, mode, bits)
         mark("histogram")
         local_counts = np.asarray(local_counts).astype(np.int64)
+        # the senders' fifteen-bit histograms, summed: every owner's first grouping digit (HIP operators; buckets of up to 8 bits)
+        fine = tok[7] if (isinstance(tok, tuple) and len(tok) > 7) else None
+        if fine is not None and world > 1:
+            _all_reduce(fine, dist.ReduceOp.SUM, group)
         # one small all-gather gives every rank the same [rank][file] histogram -> same cut points
         fc = torch.from_numpy(local_counts).to(bases.device)
         all_counts = [torch.empty_like(fc) for _ in range(world)]
@@ -869,7 +921,30 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
                 return
             bc = np.zeros(nbk, dtype=np.uint64)
             bc[lo:hi] = file_total[lo - f0:hi - f0]
-            part = ops.count_files(inbox[int(file_off[lo - f0]):int(file_off[hi - f0])], bc, k, mode)
+            seg = inbox[int(file_off[lo - f0]):int(file_off[hi - f0])]
+            if into is not None and runs is None and res["k"] is not None:
+                part = into(seg, bc, k, mode, (res["k"][res["at"]:], res["c"][res["at"]:]), fine)
+                if part[0].data_ptr() != res["k"][res["at"]:].data_ptr():        # did not fit: grow, then take the copy
+                    need = res["at"] + int(part[0].shape[0])
+                    left = int(file_total[hi - f0:].sum())
+                    cap = need + int(left * 1.25 * need / max(1, res["inst"] + int(seg.shape[0]))) + 4096
+                    nk, nc = ops.empty_keys(cap, proto), torch.empty(cap, dtype=torch.int32, device=seg.device)
+                    nk[:res["at"]] = res["k"][:res["at"]]; nc[:res["at"]] = res["c"][:res["at"]]
+                    nk[res["at"]:need] = part[0]; nc[res["at"]:need] = part[1]
+                    res["k"], res["c"] = nk, nc
+                    part = (nk[res["at"]:need], nc[res["at"]:need])
+                res["at"] += int(part[0].shape[0]); res["inst"] += int(seg.shape[0])
+            else:
+                part = ops.count_files(seg, bc, k, mode, fine=fine) if fine is not None else ops.count_files(seg, bc, k, mode)
+                if into is not None and runs is None:
+                    # the first counted wave sizes the result: its distinct / instances ratio over everything this rank owns
+                    total = int(file_total.sum())
+                    d0, n0 = int(part[0].shape[0]), max(1, int(seg.shape[0]))
+                    cap = d0 + int((total - n0) * 1.06 * d0 / n0) + 4096
+                    res["k"], res["c"] = ops.empty_keys(cap, proto), torch.empty(cap, dtype=torch.int32, device=seg.device)
+                    res["k"][:d0] = part[0]; res["c"][:d0] = part[1]
+                    part = (res["k"][:d0], res["c"][:d0])
+                    res["at"], res["inst"] = d0, n0
             if runs is not None:                                  # batched: parked (copied) until the last batch is counted
                 runs.add(part[0], part[1])
                 return
@@ -900,7 +975,9 @@ def count_sharded(bases, k, mode=capi.MODE_CANONICAL, group=None, ops=HipOps, db
         db["runs_profile"] = rp
         runs.close()
         mark("merge runs")
-    if parts:
+    if res["k"] is not None and parts:                     # the waves were counted into ONE result: nothing to concatenate
+        uniq, cnts = res["k"][:res["at"]], res["c"][:res["at"]]
+    elif parts:
         uniq = torch.cat([p[0] for p in parts])
         cnts = torch.cat([p[1] for p in parts])
     else:

@@ -177,6 +177,17 @@ extern "C" int mgc_dev_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, 
                                            (hipStream_t)stream), "kmer_partition");
 }
 
+// the histogram of a sharded count's senders: k-mers per bucket (2^bucket_bits, 6..8) for the routing plan + the per-workgroup rows
+// mgc_dev_kmer_partition takes its cursors from + k-mers per top FIFTEEN bits (d_fine_hist[2^15]) for the owners' first grouping digit
+extern "C" int mgc_dev_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint32_t bucket_bits,
+                                           uint64_t *d_bucket_counts, uint64_t *d_fine_hist, void *d_ws, size_t ws_bytes, void *stream) {
+  if (!key_args_ok(k, mode, bucket_bits) || !mgc::kmer_histogram_fine_bits_ok(k, bucket_bits)) return MGC_EINVAL;
+  if ((!d_bases && n_bases) || !d_bucket_counts || !d_fine_hist || !d_ws || ws_bytes < mgc::kp_workspace_bytes(bucket_bits)) return MGC_EINVAL;
+  const mgc::Switches sw = mgc::read_switches();
+  return hip_rc(mgc::launch_kmer_histogram_fine(d_bases, n_bases, k, mode, d_bucket_counts, d_fine_hist, d_ws, (hipStream_t)stream,
+                                                sw.const_k, bucket_bits), "kmer_histogram_fine");
+}
+
 extern "C" size_t mgc_dev_sort_workspace_bytes(uint64_t n) { return mgc::sort_workspace_bytes(n) + 256; }
 
 static int dev_radix_passes(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, uint32_t begin_bit, uint32_t end_bit, void *d_ws,
@@ -1080,7 +1091,16 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     HIP_TRY(s, hipStreamSynchronize(st));
   } else {
     memcpy(h_counts, ext_counts, sizeof(uint64_t) * nb);
+    // the owner side of a sharded count: the senders' fifteen-bit histograms, summed over the ranks (mgc_count_buckets_into), give
+    // every bucket's first grouping digit -- 15 - bucket_bits bits of it -- so that nobody reads the keys for a histogram here either
+    uint64_t n_ext = 0;
+    for (uint32_t b = 0; b < nb; b++) n_ext += h_counts[b];
+    const bool wide_msd_on = sw.wide_msd && !c.homopoly_compress;
+    if (s->ext_fine && sw.fine_hist && bucket_bits <= 8 && n_ext >= (1u << 22) && s->sfx_mask == 0 && !c.homopoly_compress &&
+        2 * k >= 15 + 2 && ((kw == 1 && 2 * k - bucket_bits <= 41) || wide_msd_on))
+      d_fine = s->ext_fine;
   }
+  const uint32_t fine_bits = 15u - bucket_bits;              // bits of a bucket's first digit the fifteen-bit histogram knows (9 for the 64 files)
   uint64_t N = 0, max_bucket = 0;
   memset(s->file_instances, 0, sizeof(s->file_instances));
   for (uint32_t b = 0; b < nb; b++) {
@@ -1239,6 +1259,17 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     std::vector<char> wide_msd(nb, 0);
     std::vector<uint32_t> tr_a(nb, 0), tr_b(nb, 0);        // ... and in which order its sub-buckets lie (mgc::tr_index)
     const size_t hdr_bytes = mgc::sort_header_bytes();
+    // msd_ok[b]: the histogram of the bucket's HIGH digit is at hand (the fifteen-bit histogram holds fine_bits bits below the bucket:
+    // a plan whose high digit is wider gives bits to the low one; a low digit that would pass nine bits keeps the low digit first)
+    std::vector<char> msd_ok(nb, 1);
+    auto fit_split = [&](uint32_t b) {
+      mgc::SortPlan &fp = fplan[b];
+      if (!d_fine || fp.num_passes != 2 || fp.hpc || fp.pass_bits[1] <= fine_bits) return;
+      const uint32_t t = fp.pass_bits[0] + fp.pass_bits[1];
+      if (t - fine_bits > 9) { msd_ok[b] = 0; return; }
+      fp.pass_bits[1] = fine_bits; fp.pass_bits[0] = t - fine_bits;
+      fp.pass_shift[1] = fp.pass_shift[0] + fp.pass_bits[0];
+    };
     for (uint32_t b = 0; b < nb; b++) {
       if (h_counts[b] == 0 || top_bits[b] == 0) continue;
       if (hpc_digits[b]) {
@@ -1251,10 +1282,11 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       }
       mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fplan[b]);
       if (fplan[b].mode == 0) fplan[b].mode = 3;
+      fit_split(b);
       const uint32_t low = rem_bits - top_bits[b];
       narrow[b] = low < 32 && mgc::finish_can_stream(kw, low) && mgc::sort_plan_narrows(fplan[b], h_counts[b], kw, sw.narrow);
       // (only the hash-count kernels translate the sub-bucket numbers of whole keys)
-      wide_msd[b] = !narrow[b] && d_fine && nb <= 64 && mgc::finish_can_stream(kw, low) &&
+      wide_msd[b] = !narrow[b] && d_fine && nb <= 256 && msd_ok[b] && mgc::finish_can_stream(kw, low) &&
                     mgc::sort_plan_wide_msd(fplan[b], h_counts[b], sw.wide_msd);
       if (top_str[b]) {                                      // the coarser plan stays a candidate if the file narrows under BOTH plans
         mgc::SortPlan sp;
@@ -1275,6 +1307,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       fstream[b] = 1; top_bits[b] = top_str[b];
       mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fplan[b]);
       if (fplan[b].mode == 0) fplan[b].mode = 3;
+      msd_ok[b] = 1;
+      fit_split(b);
       s->prof.stream_files++;
     };
     // Which plan?  The distinct-sized count pays off when a sub-bucket's distinct suffixes are few against its keys (measured at
@@ -1354,20 +1388,20 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     unsigned char *d_nws = nullptr, *d_nhdrs = nullptr;
     // (with a probe file: its header first, the others' once their plan is known)
     auto prepare_headers = [&](int only, int skip) -> int {
-      unsigned char bits_a[64] = {0}, on[64] = {0};
+      unsigned char bits_a[256] = {0}, on[256] = {0};
       bool any = false;
       for (uint32_t b = 0; b < nb; b++) {
-        if ((!narrow[b] && !wide_msd[b]) || (only >= 0 && (int)b != only) || (int)b == skip) continue;
+        if ((!narrow[b] && !wide_msd[b]) || !msd_ok[b] || (only >= 0 && (int)b != only) || (int)b == skip) continue;
         on[b] = 1; bits_a[b] = (unsigned char)fplan[b].pass_bits[1]; any = true;
       }
       if (any) HIP_TRY(s, mgc::launch_narrow_prepare(d_fine, nb, bits_a, on, d_nhdrs, st));
       return MGC_OK;
     };
-    if (d_fine && nb <= 64) {
+    if (d_fine && nb <= 256) {
       bool any = false;
       for (uint32_t b = 0; b < nb; b++) {
         nws_off[b + 1] = nws_off[b];
-        if (!narrow[b] && !wide_msd[b]) continue;
+        if ((!narrow[b] && !wide_msd[b]) || !msd_ok[b]) continue;
         any = true;
         nws_off[b + 1] += ((narrow[b] ? mgc::narrow_scratch_bytes(h_counts[b]) : mgc::wide_scratch_bytes(h_counts[b], kw)) + 255) / 256 * 256;
       }
@@ -1419,8 +1453,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (top_bits[b] == 0) {
         // (a file of one sub-bucket: nothing to group)
       } else if (narrow[b]) {                                // X (8 B) -> Y (4 B) -> front of X (4 B); boundaries included
+        const bool msd = d_nhdrs && d_nws && msd_ok[b];
         HIP_TRY(s, mgc::launch_group_narrow(src, (void *)Y, h_counts[b], fp, sort_ws, sort_ws_bytes - 256, d_err, d_substart + sbase[b], st, pe,
-                                            d_nhdrs ? (void *)(d_nhdrs + hdr_bytes * b) : nullptr, d_nws ? (void *)(d_nws + nws_off[b]) : nullptr,
+                                            msd ? (void *)(d_nhdrs + hdr_bytes * b) : nullptr, msd ? (void *)(d_nws + nws_off[b]) : nullptr,
                                             &tr_a[b], &tr_b[b], soa_hi_mask, sw.group_dbg, sw.group_pipe));
         file_passes[b] = 2;
         narrowed[b] = 1;
@@ -1614,7 +1649,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (sw.finish_trace) fprintf(stderr, "[finish] probe file %u: %llu distinct of %llu k-mers (%.3f): the other files take the %s plan\n", pb,
                                    (unsigned long long)h_pd, (unsigned long long)h_counts[pb], ratio, ratio <= 0.30 ? "distinct-sized" : "finer");
       if (ratio <= 0.30) for (uint32_t b = 0; b < nb; b++) if (b != pb && top_str[b]) take_stream_plan(b);
-      if (d_fine && nb <= 64 && d_nhdrs) { const int prc = prepare_headers(-1, probe); if (prc != MGC_OK) return prc; }
+      if (d_fine && nb <= 256 && d_nhdrs) { const int prc = prepare_headers(-1, probe); if (prc != MGC_OK) return prc; }
     }
     bool stats_back = false;
     for (uint32_t b = 0; b < nb; b++) {
@@ -1658,10 +1693,16 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     HIP_TRY(s, hipStreamSynchronize(st));
     if (ng_total == 0) nd = 0;
     s->n_distinct = nd;
-    HIP_TRY(s, s->ensure(mgc_session::B_UNIQUE, kbytes * nd));
-    HIP_TRY(s, s->ensure(mgc_session::B_COUNTS, sizeof(uint32_t) * nd));
-    s->d_unique = s->buf[mgc_session::B_UNIQUE].p;
-    s->d_counts = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_COUNTS].p);
+    if (s->ext_out_keys && s->ext_out_counts && nd <= s->ext_out_cap) {
+      // (mgc_count_buckets_into: the packing kernels write the caller's pre-sized result -- no copy out of the arena afterwards)
+      s->d_unique = s->ext_out_keys;
+      s->d_counts = s->ext_out_counts;
+    } else {
+      HIP_TRY(s, s->ensure(mgc_session::B_UNIQUE, kbytes * nd));
+      HIP_TRY(s, s->ensure(mgc_session::B_COUNTS, sizeof(uint32_t) * nd));
+      s->d_unique = s->buf[mgc_session::B_UNIQUE].p;
+      s->d_counts = reinterpret_cast<uint32_t *>(s->buf[mgc_session::B_COUNTS].p);
+    }
 
     // ---- G/H. pack ----
     for (uint32_t b = 0; b < nb; b++) {
@@ -1912,6 +1953,22 @@ extern "C" int mgc_count_buckets(mgc_session *s, void *d_keys, uint32_t bucket_b
   }
   const int rc = count_device(s, d_keys, bucket_counts, bucket_bits);
   if (rc == MGC_OK) s->counted = true;
+  return rc;
+}
+
+// ... with the packed result written straight to the caller's buffers when it fits (capacity in k-mers): the waves of a sharded
+// count land in ONE pre-sized result instead of being copied out of the session and concatenated.  *n_distinct > capacity: the
+// result stayed in the session (mgc_copy_result_device / mgc_get_result_device as usual).
+extern "C" int mgc_count_buckets_into(mgc_session *s, void *d_keys, uint32_t bucket_bits, const uint64_t *bucket_counts,
+                                      void *d_out_keys, uint32_t *d_out_counts, uint64_t capacity, uint64_t *n_distinct,
+                                      const uint64_t *d_fine_hist) {
+  if (!s || !n_distinct || (capacity && (!d_out_keys || !d_out_counts))) return MGC_EINVAL;
+  s->ext_out_keys = d_out_keys; s->ext_out_counts = d_out_counts; s->ext_out_cap = capacity;
+  s->ext_fine = d_fine_hist;
+  const int rc = mgc_count_buckets(s, d_keys, bucket_bits, bucket_counts);
+  s->ext_out_keys = nullptr; s->ext_out_counts = nullptr; s->ext_out_cap = 0;
+  s->ext_fine = nullptr;
+  if (rc == MGC_OK) *n_distinct = s->n_distinct;
   return rc;
 }
 

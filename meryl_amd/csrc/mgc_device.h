@@ -59,7 +59,10 @@ uint32_t   kmer_histogram_hpc_entries(uint32_t bucket_bits);
 hipError_t launch_kmer_histogram_hpc(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint32_t bucket_bits,
                                      uint64_t *d_bucket_counts, uint64_t *d_fine_hist, void *d_ws, hipStream_t st, bool const_k = true /*Switches::const_k*/);
 hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint64_t *d_bucket_counts,
-                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st, bool const_k = true /*Switches::const_k*/);
+                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st, bool const_k = true /*Switches::const_k*/,
+                                      uint32_t bucket_bits = 6 /*6..8: d_bucket_counts[2^bucket_bits] and the per-workgroup rows the partition
+                                      takes its cursors from go by that many top bits (a sharded count's senders); d_fine_hist stays 2^15*/);
+bool       kmer_histogram_fine_bits_ok(uint32_t k, uint32_t bucket_bits);
 hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
                                  uint32_t bucket_bits, uint64_t *d_bucket_counts, void *d_ws, hipStream_t st,
                                  uint64_t sfx_mask = 0, uint64_t sfx_test = 0);

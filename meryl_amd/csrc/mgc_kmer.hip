@@ -303,7 +303,8 @@ __device__ __forceinline__ u32 hpc_dense_rank(u32 x) {               // x: 2 * H
 template <int HB, int KC = 0>                         // KC: k as a compile-time constant, canonical mode (kmer_partition_kernel)
 __global__ __launch_bounds__(KP_BLOCK * KH_NV)
 void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, int mode_arg, u64 num_tiles, u32 vgrid,
-                           u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts, u64 *__restrict__ fine_hist) {
+                           u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts, u64 *__restrict__ fine_hist,
+                           u32 fbits = 6 /* HB == 0: the buckets of the per-workgroup rows and of bucket_counts are the top fbits (6..8) bits */) {
   const u32 k = KC ? (u32)KC : k_arg;
   const int mode = KC ? 0 : mode_arg;
   constexpr u32 TABLE = HB ? hpc_table_size(HB) : (1u << KH_FINE_BITS);
@@ -312,11 +313,11 @@ void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
   extern __shared__ __attribute__((aligned(16))) u32 kh_fine[];      // [TABLE]
   __shared__ u32 s_codes[2][KH_NV][KP_WORDS];
   __shared__ u32 s_inval[2][KH_NV][KP_WORDS];
-  __shared__ u32 s_prev[NBK];
+  __shared__ u32 s_prev[HB ? NBK : 256u];
   const u32 tid = threadIdx.x, v = tid >> 8, t = tid & 255u;
   const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
   for (u32 i = tid; i < TABLE; i += KP_BLOCK * KH_NV) kh_fine[i] = 0;
-  if (tid < NBK) s_prev[tid] = 0;
+  if (tid < (HB ? NBK : 256u)) s_prev[tid] = 0;
 
   // The workgroup takes its KH_NV virtual workgroups ONE AFTER THE OTHER, all 1024 threads on one of them (slice v: every
   // KH_NV-th tile of its range): a k-mer costs ONE LDS atomic -- the fifteen-bit counter -- and the per-file counts of a
@@ -368,22 +369,35 @@ void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
       constexpr u32 TPB = (u32)(KP_BLOCK * KH_NV) / NBK;             // 16 (64 buckets) or 4 (256)
       const u32 f = tid / TPB, l = tid % TPB;
       u32 sum = 0;
+      (void)f; (void)l; (void)sum;
       if constexpr (HB > 0) {
         constexpr int BB = HB - 5;                                   // bases of a bucket
         bool ok = true;                                              // (a bucket that repeats a base holds no k-mer)
 #pragma unroll
         for (int i = 1; i < BB; i++) ok = ok && (((f >> (2 * (BB - 1 - i))) & 3u) != ((f >> (2 * (BB - i))) & 3u));
         if (ok) { const u32 r0 = hpc_dense_rank<BB>(f) * 243u; for (u32 i = l; i < 243u; i += TPB) sum += kh_fine[r0 + i]; }
-      } else {
-        for (u32 i = l; i < (1u << (KH_FINE_BITS - 6)); i += TPB) sum += kh_fine[(f << (KH_FINE_BITS - 6)) + i];
       }
+      if constexpr (HB > 0) {
 #pragma unroll
-      for (u32 o = TPB / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-      if (l == 0) {
-        const u32 c = sum - s_prev[f];
-        s_prev[f] = sum;
-        if (vwg < vgrid) block_hist[vwg * NBK + f] = c;
-        if (c) atomicAdd(&bucket_counts[f], (u64)c);
+        for (u32 o = TPB / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (l == 0) {
+          const u32 c = sum - s_prev[f];
+          s_prev[f] = sum;
+          if (vwg < vgrid) block_hist[vwg * NBK + f] = c;
+          if (c) atomicAdd(&bucket_counts[f], (u64)c);
+        }
+      } else {
+        // 2^fbits buckets x (1024 >> fbits) threads (the 64 files: 16 threads each; finer buckets of a sharded count: 8 or 4)
+        const u32 tpb = (u32)(KP_BLOCK * KH_NV) >> fbits, fr = tid / tpb, lr = tid % tpb, per_bucket = 1u << (KH_FINE_BITS - fbits);
+        u32 rs = 0;
+        for (u32 i = lr; i < per_bucket; i += tpb) rs += kh_fine[(fr << (KH_FINE_BITS - fbits)) + i];
+        for (u32 o = tpb / 2; o > 0; o >>= 1) rs += __shfl_xor(rs, o);
+        if (lr == 0) {
+          const u32 c = rs - s_prev[fr];
+          s_prev[fr] = rs;
+          if (vwg < vgrid) block_hist[(vwg << fbits) + fr] = c;
+          if (c) atomicAdd(&bucket_counts[fr], (u64)c);
+        }
       }
     }
   }
@@ -612,11 +626,14 @@ hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint3
 bool kmer_histogram_fine_ok(uint32_t k, uint32_t bucket_bits, uint64_t sfx_mask, const Switches &sw) {
   return sw.fine_hist && k <= 64 && 2 * k >= (uint32_t)KH_FINE_BITS + 2 && bucket_bits == 6 && sfx_mask == 0;
 }
+// (the bare operator of a sharded count's senders: buckets of 6..8 bits)
+bool kmer_histogram_fine_bits_ok(uint32_t k, uint32_t bucket_bits) { return k <= 64 && 2 * k >= (uint32_t)KH_FINE_BITS + 2 && bucket_bits >= 6 && bucket_bits <= 8; }
 
 // launch_kmer_histogram + d_fine_hist[2^15] (zeroed here): k-mers per (file, next nine bits)
 hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode, uint64_t *d_bucket_counts,
-                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st, bool const_k) {
-  MGC_CHECK(hipMemsetAsync(d_bucket_counts, 0, sizeof(uint64_t) * 64, st));
+                                      uint64_t *d_fine_hist, void *d_ws, hipStream_t st, bool const_k, uint32_t bucket_bits) {
+  if (bucket_bits < 6 || bucket_bits > 8) return hipErrorInvalidValue;
+  MGC_CHECK(hipMemsetAsync(d_bucket_counts, 0, sizeof(uint64_t) << bucket_bits, st));
   MGC_CHECK(hipMemsetAsync(d_fine_hist, 0, sizeof(uint64_t) << KH_FINE_BITS, st));
   if (n_bases == 0) return hipSuccess;
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
@@ -636,7 +653,7 @@ hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, 
 #define MGC_KH_LAUNCH(KC_)                                                                                                             \
   hipLaunchKernelGGL((kmer_hist_fine_kernel<0, KC_>), dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) << KH_FINE_BITS, st, \
                      d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),                             \
-                     reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist))
+                     reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), bucket_bits)
   const int kc = kmer_const_k(k, mode, const_k);
   if (kc == 21) MGC_KH_LAUNCH(21); else if (kc == 31) MGC_KH_LAUNCH(31); else if (kc == 51) MGC_KH_LAUNCH(51); else MGC_KH_LAUNCH(0);
 #undef MGC_KH_LAUNCH

@@ -66,6 +66,9 @@ struct mgc_session {
   bool      counted = false;
   uint64_t  n_instances = 0, n_distinct = 0;
   uint64_t  file_instances[MGC_NUM_FILES];
+  // owner side of a sharded count (mgc_count_buckets_into): where the packed result goes when it fits -- the caller's buffers
+  void     *ext_out_keys = nullptr; uint32_t *ext_out_counts = nullptr; uint64_t ext_out_cap = 0;
+  const uint64_t *ext_fine = nullptr;     // ... and the senders' summed fifteen-bit histogram (the first grouping digit of every bucket)
   void     *d_unique = nullptr;           // uint64[D] (k <= 32) or {lo,hi}[D] (k > 32)
   uint32_t *d_counts = nullptr;
   uint64_t *d_block_start = nullptr;

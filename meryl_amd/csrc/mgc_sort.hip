@@ -746,7 +746,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
   }
 }
 
-struct NarrowPrep { unsigned char bits_a[64]; unsigned char on[64]; };   // per file: bits of its first (high) digit, narrowed at all
+struct NarrowPrep { unsigned char bits_a[256]; unsigned char on[256]; };   // per bucket: bits of its first (high) digit, narrowed at all
 
 // ---- host side ---------------------------------------------------------------
 
@@ -942,8 +942,10 @@ bool sort_plan_narrows(const SortPlan &plan, uint64_t n, uint32_t key_words, boo
 // time than the steps themselves: ~8 us each, ten of them per file) ----
 
 // one workgroup per file: header cleared, histogram of the file's top bits_a[f] bits from the 512 fine counts, its exclusive scan
+// fb: fine holds 2^fb counts per bucket (the fifteen-bit histogram of 2^(15 - fb) buckets: 9 for the 64 files, 8 / 7 for the 128 / 256
+// buckets of a sharded count); bits_a[f] <= fb
 __global__ __launch_bounds__(RS_MAX_RADIX)
-void narrow_prepare_kernel(const u64 *__restrict__ fine, NarrowPrep prep, unsigned char *__restrict__ hdrs, u32 hdr_stride) {
+void narrow_prepare_kernel(const u64 *__restrict__ fine, NarrowPrep prep, unsigned char *__restrict__ hdrs, u32 hdr_stride, u32 fb) {
   __shared__ u64 s_f[RS_MAX_RADIX];
   __shared__ u64 s_tmp[RS_MAX_RADIX / 64 + 1];
   const u32 f = blockIdx.x, x = threadIdx.x;
@@ -951,9 +953,9 @@ void narrow_prepare_kernel(const u64 *__restrict__ fine, NarrowPrep prep, unsign
   SortHeader *hdr = reinterpret_cast<SortHeader *>(hdrs + (size_t)f * hdr_stride);
   u32 *w = reinterpret_cast<u32 *>(hdr);
   for (u32 i = x; i < sizeof(SortHeader) / 4; i += RS_MAX_RADIX) w[i] = 0;
-  s_f[x] = fine[(size_t)f * RS_MAX_RADIX + x];
+  s_f[x] = (x < (1u << fb)) ? fine[((size_t)f << fb) + x] : 0ull;
   __syncthreads();
-  const u32 bits = prep.bits_a[f], span = 1u << (9 - bits);
+  const u32 bits = prep.bits_a[f], span = 1u << (fb - bits);
   u64 c = 0;
   if (x < (1u << bits)) for (u32 i = 0; i < span; i++) c += s_f[x * span + i];
   u64 total;
@@ -990,13 +992,15 @@ size_t narrow_scratch_bytes(uint64_t n) {
 // headers of all files at once (files with on[f] = 0 are skipped); d_hdrs: nb x sort_header_bytes()
 hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsigned char *bits_a, const unsigned char *on, void *d_hdrs,
                                  hipStream_t st) {
-  if (nb > 64) return hipErrorInvalidValue;
+  if (nb != 64 && nb != 128 && nb != 256) return hipErrorInvalidValue;
+  const u32 fb = nb == 64 ? 9u : (nb == 128 ? 8u : 7u);
   NarrowPrep prep;
   memset(&prep, 0, sizeof(prep));
   memcpy(prep.bits_a, bits_a, nb);
   memcpy(prep.on, on, nb);
+  for (uint32_t b = 0; b < nb; b++) if (prep.on[b] && prep.bits_a[b] > fb) return hipErrorInvalidValue;
   hipLaunchKernelGGL(narrow_prepare_kernel, dim3(nb), dim3(RS_MAX_RADIX), 0, st, reinterpret_cast<const u64 *>(d_fine), prep,
-                     reinterpret_cast<unsigned char *>(d_hdrs), (u32)sort_header_bytes());
+                     reinterpret_cast<unsigned char *>(d_hdrs), (u32)sort_header_bytes(), fb);
   return hipGetLastError();
 }
 
