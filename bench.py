@@ -106,6 +106,24 @@ def cpu_baseline(sample_reads, threads, dev_bases=None, whole=False):
     return out
 
 
+def hbm_model(reads, world, read_len=READ_LEN, k=K, distinct_ratio=0.16):
+    """Peak HBM of ONE rank of the sharded count, in bytes, by buffer: asserted against the device's memory BEFORE
+    anything is allocated, so that a configuration that cannot fit is refused with a message instead of taking the node down.
+    Upper bounds: every read yields read_len - k + 1 k-mers; a rank owns 1/world of all k-mers (the cuts balance instances)."""
+    n_bases = reads * (read_len + 1)
+    n_kmers = reads * max(0, read_len - k + 1)
+    key = 16 if k > 32 else 8
+    m = {"bases": n_bases,
+         "send_area": key * n_kmers * (world - 1) // max(1, world),      # the other ranks' buckets, compact (partition with explicit starts)
+         "inbox": key * n_kmers,                                         # what this rank owns, bucket-major (its own pieces written in place)
+         "owner_pass_buffer": 2 * key * n_kmers // 64,                   # the grouping passes' ping-pong: one bucket (as large as a 1-GPU file) + tables
+         "result": int((key + 4) * distinct_ratio * 1.06 * n_kmers) if world > 1 else int((key + 4) * distinct_ratio * 1.06 * n_kmers),
+         "database_stream": 3 << 30,                                     # encoded images + pinned staging of the part writer
+         "histograms_and_tables": 1 << 30}
+    m["total"] = sum(m.values())
+    return m
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` invoked plainly: start the N ranks under torch.distributed.run (one per GPU, RCCL) and
     relay the ONE JSON line rank 0 prints."""
@@ -498,8 +516,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- synthetic input, generated in HBM ----
+    # ---- the per-rank memory model, checked before anything is allocated (N > 1 and the forced-sharded form) ----
     reads = args.reads
+    mem_model = None
+    if world > 1 or force_sharded:
+        mem_model = hbm_model(reads, world if not node_fallback else 1)
+        if node_fallback:                                    # N virtual ranks share ONE device
+            mem_model = {kk: v * world for kk, v in hbm_model(reads, world).items()}
+        free_b, total_b = torch.cuda.mem_get_info()
+        if mem_model["total"] > 0.94 * total_b:
+            print("bench.py: %d reads per GPU on %d rank(s) need ~%.0f GB of HBM per device by the model of DESIGN.md 4 (%s), the device has %.0f GB: "
+                  "refusing before anything is allocated (use --reads)" % (reads, world, mem_model["total"] / 1e9,
+                  ", ".join("%s %.1f" % (kk, v / 1e9) for kk, v in mem_model.items() if kk != "total"), total_b / 1e9), file=sys.stderr)
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(2)
+
+    # ---- synthetic input, generated in HBM ----
     genome_len = GENOME_LEN * world              # weak scaling: every GPU brings its own 30x share of a genome that grows with N
     ranks_here = list(range(world)) if node_fallback else [rank]
     all_bases = [count.dev_synth_reads(SEED, genome_len, r * reads, reads, READ_LEN, 5000, 100) for r in ranks_here]
@@ -622,6 +655,9 @@ def main():
             "transport": transport,
         },
     }
+    if mem_model:
+        line["config"]["hbm_model_gb_per_rank"] = {kk: round(v / 1e9, 2) for kk, v in mem_model.items()}
+        line["config"]["hbm_peak_allocated_gb"] = round(torch.cuda.max_memory_allocated() / 1e9, 2)       # torch's own (the library's arena is not in it)
     if node_fallback:
         line["config"]["note"] = ("one-GPU box: the step is mgc_count_node with %d virtual ranks sharing the device and INCLUDES writing the "
                                   "database; not a scaling number" % world)

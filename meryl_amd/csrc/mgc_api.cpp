@@ -1351,8 +1351,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     {
       // 5-byte layout: 8-byte keys with 33..40 bits below the file (k = 20..23), every non-empty file on the narrowed passes with
       // the high digit first off the fifteen-bit histogram (the instrumented instantiation reads whole keys).  MGC_SOA5=0: whole keys.
-      bool soa = sw.soa5 && !ext_keys && kw == 1 && nb == 64 && d_fine && rem_bits > 32 && rem_bits <= 40 && s->sfx_mask == 0 &&
-                 !sw.group_dbg;
+      bool soa = sw.soa5 && !ext_keys && kw == 1 && nb == 64 && d_fine && rem_bits > 32 && rem_bits <= 40 && s->sfx_mask == 0;
       for (uint32_t b = 0; b < nb && soa; b++) if (h_counts[b] && !(narrow[b] && top_bits[b])) soa = false;
       if (soa) soa_hi_mask = (1u << (rem_bits - 32)) - 1u;
       // K96 records (round 5): 16-byte keys with at most 96 bits below the file (k = 33..51), every non-empty file on the whole-key

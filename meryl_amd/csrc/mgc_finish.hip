@@ -1066,6 +1066,8 @@ void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ st
       HC_STAMP(0);
       u32 hh[KPC];
       u32 won = 0, pending = 0;
+      // (the first probes issued back to back and their answers looked at afterwards -- six independent atomics in flight per thread
+      // -- was measured SLOWER: 0.595 against 0.566 ms per launch, profiles/r06_ab_runs.txt: the kernel is issue-bound, not latency-bound)
 #pragma unroll
       for (int j = 0; j < KPC; j++) {
         hh[j] = (comp[j] * 0x9E3779B1u) >> sshift;

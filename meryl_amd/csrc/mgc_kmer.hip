@@ -386,8 +386,18 @@ void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
           if (vwg < vgrid) block_hist[vwg * NBK + f] = c;
           if (c) atomicAdd(&bucket_counts[f], (u64)c);
         }
+      } else if (fbits == 6) {                                       // the 64 files: 16 threads each (compile-time shapes: the session's own path)
+        for (u32 i = l; i < (1u << (KH_FINE_BITS - 6)); i += TPB) sum += kh_fine[(f << (KH_FINE_BITS - 6)) + i];
+#pragma unroll
+        for (u32 o = TPB / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (l == 0) {
+          const u32 c = sum - s_prev[f];
+          s_prev[f] = sum;
+          if (vwg < vgrid) block_hist[vwg * NBK + f] = c;
+          if (c) atomicAdd(&bucket_counts[f], (u64)c);
+        }
       } else {
-        // 2^fbits buckets x (1024 >> fbits) threads (the 64 files: 16 threads each; finer buckets of a sharded count: 8 or 4)
+        // 2^fbits buckets x (1024 >> fbits) threads: the finer buckets of a sharded count's senders (8 or 4 threads each)
         const u32 tpb = (u32)(KP_BLOCK * KH_NV) >> fbits, fr = tid / tpb, lr = tid % tpb, per_bucket = 1u << (KH_FINE_BITS - fbits);
         u32 rs = 0;
         for (u32 i = lr; i < per_bucket; i += tpb) rs += kh_fine[(fr << (KH_FINE_BITS - fbits)) + i];
@@ -496,9 +506,24 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
   u64 t_begin, t_end;
   kp_tile_range(num_tiles, t_begin, t_end);
 
+  // the next tile's bases are in flight (registers: 16 bytes per thread + the halo of the first four) while this tile is ranked,
+  // exchanged and written: a tile's 4 KB used to be asked for at the top of its own iteration (round 6)
+  uint4 nx = make_uint4(0, 0, 0, 0), nx_halo = make_uint4(0, 0, 0, 0);
+  auto prefetch = [&](u64 tile) __attribute__((always_inline)) {
+    if (tile >= t_end) return;
+    nx = load16(bases, tile * KP_TILE + (u64)tid * 16, n, aligned);
+    if (tid < 4) nx_halo = load16(bases, tile * KP_TILE + (u64)KP_TILE + (u64)tid * 16, n, aligned);
+  };
+  prefetch(t_begin);
   for (u64 tile = t_begin; tile < t_end; tile++) {
     for (u32 b = tid; b < nb; b += KP_BLOCK) s_cnt[b] = 0;
-    kp_stage_tile(bases, n, tile * KP_TILE, aligned, s_codes, s_inval);
+    {
+      u32 c, iv;
+      encode16(nx, c, iv);
+      s_codes[tid] = c; s_inval[tid] = iv;
+      if (tid < 4) { encode16(nx_halo, c, iv); s_codes[KP_BLOCK + tid] = c; s_inval[KP_BLOCK + tid] = iv; }
+    }
+    prefetch(tile + 1);
     __syncthreads();
 
     K keys[KP_ITEMS];

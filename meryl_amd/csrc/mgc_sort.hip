@@ -1079,8 +1079,28 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
     if (hipMalloc(&dbg_buf, 2 * 64 * 8 * sizeof(u64)) != hipSuccess) dbg_buf = nullptr;
   }
   if (dbg && dbg_buf) MGC_CHECK(hipMemsetAsync(dbg_buf, 0, 2 * 64 * 8 * sizeof(u64), st));
-  if (soa_hi_mask && (!msd || (dbg && dbg_buf))) return hipErrorInvalidValue;   // the 5-byte layout: high digit first
-  if (dbg && dbg_buf)
+  if (soa_hi_mask && !msd) return hipErrorInvalidValue;   // the 5-byte layout: high digit first
+  if (dbg && dbg_buf && soa_hi_mask) {                     // the shipped first pass, instrumented: 5-byte layout, the fetch a whole tile ahead (or not)
+    static bool dsattr = false;
+    if (!dsattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, true, true, true, true, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, RB, BLOCK, KPT0, true, true, true, true, 0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
+      dsattr = true;
+    }
+    if (pipe)
+      hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, true, true, true, true, 2>), grid0, dim3(BLOCK), GS0::BYTES, st,
+                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                         &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                         GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask}, dbg_buf);
+    else
+      hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, true, true, true, true, 0>), grid0, dim3(BLOCK), GS0::BYTES, st,
+                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                         &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                         GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask}, dbg_buf);
+  }
+  else if (dbg && dbg_buf)
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, true, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                        &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
@@ -1159,7 +1179,7 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
       const double it = ps[7] > 0 ? ps[7] : 1;
       fprintf(stderr, "[groupdbg] %s pass, %llu keys, %d-key tiles, tiles/wg=%.1f cycles/tile: ticket+zero=%.0f rank=%.0f scan+exchange=%.0f "
                       "lookback(+prefetch%s)=%.0f writeout=%.0f endsync=%.0f total=%.0f\n",
-              pass ? "second (u32 -> u32)" : "first (u64 -> u32)", (unsigned long long)n, pass ? (int)TILE1 : (int)TILE0, it / 64,
+              pass ? "second (u32 -> u32)" : (soa_hi_mask ? (pipe ? "first (5 B -> u32, fetch a tile ahead)" : "first (5 B -> u32)") : "first (u64 -> u32)"), (unsigned long long)n, pass ? (int)TILE1 : (int)TILE0, it / 64,
               ps[0] / it, ps[1] / it, ps[2] / it, pass ? "" : ", low-digit count", ps[3] / it, ps[4] / it, ps[5] / it,
               (ps[0] + ps[1] + ps[2] + ps[3] + ps[4] + ps[5]) / it);
     }
