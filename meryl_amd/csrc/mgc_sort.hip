@@ -1033,7 +1033,7 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
     attr_done = true;
   }
   const bool msd = d_prepared != nullptr && d_scratch != nullptr;
-  const uint64_t tile1 = TILE1;
+  const uint64_t tile1 = TILE1;    // (28 words per thread -- 28672-word tiles, the most the register file takes -- measured equal: r06_ab_runs.txt)
   const uint64_t tiles0 = (n + TILE0 - 1) / TILE0, tiles1_max = (n + tile1 - 1) / tile1 + RS_MAX_RADIX + 1;
   SortHeader *hdr;
   u64 *status_a, *status_b, *region_start;
@@ -1143,7 +1143,7 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[1], st));
 
   if (msd) {
-    hipLaunchKernelGGL(narrow_mid_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, hdr, (u64)n, (u32)TILE1, region_start, region_tiles);
+    hipLaunchKernelGGL(narrow_mid_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, hdr, (u64)n, (u32)tile1, region_start, region_tiles);
     MGC_CHECK(hipGetLastError());
   } else {
     hipLaunchKernelGGL(group_regions_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, &hdr->gbase[0][0], (u64)n, (u32)TILE1, region_start, region_tiles);
