@@ -1024,9 +1024,16 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
   if (!ext_keys) {
     // `compress`: two dense-rank digits cover 3^10 sub-buckets (below), i.e. buckets of up to 68 M k-mers, and the digits
     // are whole bases, so the buckets get finer two bits at a time
-    const uint64_t per_bucket = sw.bucket_bases ? sw.bucket_bases /* tests force finer buckets on small inputs */ : (c.homopoly_compress ? 60000000ull : 180000000ull);
+    // (`compress` buckets are uneven -- a canonical k-mer starts with A or C twice as often as with G or T, and 36 of the 64 / 108 of the
+    // 256 bucket prefixes repeat no base -- so the largest bucket of a 10 Gbp input at 256 buckets holds ~100 M k-mers: above the 68 M of the
+    // index-claimed tables.  Round 6: such a bucket keeps its two dense-rank digits and is counted by the distinct-sized kernel,
+    // sub-buckets of up to 2304 k-mers on average, instead of falling back to the stable sort: hpc_stream[] below.)
+    auto per_bucket = [&](uint32_t) -> uint64_t {
+      if (sw.bucket_bases) return sw.bucket_bases;            // tests force finer buckets on small inputs
+      return c.homopoly_compress ? 60000000ull : 180000000ull;
+    };
     const uint32_t step = c.homopoly_compress ? 2u : 1u;
-    while (bucket_bits + step <= MGC_MAX_BUCKET_BITS && bucket_bits + step <= 2 * c.k && (s->n_bases >> bucket_bits) > per_bucket) bucket_bits += step;
+    while (bucket_bits + step <= MGC_MAX_BUCKET_BITS && bucket_bits + step <= 2 * c.k && (s->n_bases >> bucket_bits) > per_bucket(bucket_bits)) bucket_bits += step;
   }
   const uint32_t nb = 1u << bucket_bits;
   const uint32_t kw = s->key_words;
@@ -1219,11 +1226,19 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     // hold 243 patterns, 20 bits 59049.  Needs the remaining bits to be whole bases (the 64 files, or an even number of
     // bucket bits) and the bucket to fit 59049 sub-buckets; otherwise the generic bit digits below (MGC_HPC_DIGITS=0: always).
     const bool hpc_ok = sw.hpc_digits && c.homopoly_compress && (rem_bits % 2 == 0) && bucket_bits >= 2;
+    // hpc_stream[b] (round 6): a two-digit `compress` bucket whose sub-buckets average more than the index-claimed tables take counts
+    // its whole 8-byte k-mers with the distinct-sized kernel (64-bit entries): everything the high-digit-first passes of such a
+    // bucket need is known here (the dense-rank histogram is at hand, the suffix has 32..52 bits), so the plan is final at once
+    const bool hpc_stream_ok = hpc_ok && sw.hash_stream != 0 && sw.hash_stream != 2 && kw == 1 && d_fine_hpc && nb <= 256 && sw.wide_msd &&
+                               rem_bits >= 20 + 32 && mgc::finish_stream_ok(kw, rem_bits - 20, false);
+    std::vector<char> hpc_stream(nb, 0), hpc_cand(nb, 0);
     for (uint32_t b = 0; b < nb; b++) {
       uint32_t t = 0;
       if (hpc_ok && h_counts[b] > target) {                            // sub-buckets average `target` k-mers or fewer
         if (h_counts[b] <= 243ull * target && rem_bits >= 10) t = 10;
         else if (h_counts[b] <= 59049ull * target && rem_bits >= 20) t = 20;
+        else if (hpc_stream_ok && h_counts[b] <= 59049ull * starget && h_counts[b] < (1ull << 30)) { t = 20; hpc_stream[b] = 1; }
+        if (t == 20 && sw.hash_stream == 1 && hpc_stream_ok && h_counts[b] < (1ull << 30)) hpc_stream[b] = 1;   // (tests, A/B: every two-digit bucket)
         if (t) hpc_digits[b] = 1;                                      // else (tiny k, gigantic bucket): generic path
       }
       if (!hpc_digits[b]) {
@@ -1234,9 +1249,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
           uint32_t ts = 0;
           while (ts < rem_bits && ts < 26 && (h_counts[b] >> ts) > starget) ts++;
           if (sw.min_top) { const uint32_t m = sw.min_top; if (ts < m) ts = m < rem_bits ? m : rem_bits; }
-          if (rem_bits - ts > 20) ts = rem_bits - 20;                  // the suffix has to fit the packed entry
-          // (a plan that does not coarsen the file keeps the kernels it has -- unless MGC_HASH_STREAM=1 asks for the new one)
-          if (ts >= 1 && ts <= t && ts <= 18 && mgc::finish_stream_ok(kw, rem_bits - ts) && (ts < t || sw.hash_stream > 0)) top_str[b] = ts;
+          top_str[b] = ts;                                             // (clamped and validated once the file's kind of passes is known: below)
         }
       }
       if (c.homopoly_compress && t && !hpc_digits[b]) {
@@ -1278,6 +1291,9 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         // number -- 32-bit suffixes -- stay with the low digit first)
         wide_msd[b] = d_fine_hpc && nb <= 256 && top_bits[b] == 20 && (kw == 2 || rem_bits - top_bits[b] >= 32) &&
                       mgc::finish_can_stream(kw, rem_bits - top_bits[b]) && mgc::sort_plan_wide_msd(fplan[b], h_counts[b], sw.wide_msd);
+        // (above the index-claimed tables' reach: the distinct-sized count whatever the coverage; below: a candidate the probe file decides on)
+        if (hpc_stream[b] && wide_msd[b]) { fstream[b] = 1; s->prof.stream_files++; }
+        else if (hpc_stream_ok && wide_msd[b] && top_bits[b] == 20 && h_counts[b] < (1ull << 30)) hpc_cand[b] = 1;
         continue;
       }
       mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fplan[b]);
@@ -1288,12 +1304,27 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       // (only the hash-count kernels translate the sub-bucket numbers of whole keys)
       wide_msd[b] = !narrow[b] && d_fine && nb <= 256 && msd_ok[b] && mgc::finish_can_stream(kw, low) &&
                     mgc::sort_plan_wide_msd(fplan[b], h_counts[b], sw.wide_msd);
-      if (top_str[b]) {                                      // the coarser plan stays a candidate if the file narrows under BOTH plans
-        mgc::SortPlan sp;
-        mgc::make_sort_plan(rem_bits - top_str[b], rem_bits, &sp);
-        if (sp.mode == 0) sp.mode = 3;
-        if (!(narrow[b] && mgc::finish_can_stream(kw, rem_bits - top_str[b]) && mgc::sort_plan_narrows(sp, h_counts[b], kw, sw.narrow)))
-          top_str[b] = 0;
+      if (top_str[b]) {
+        // the coarser plan stays a candidate if the file narrows under BOTH plans, its suffix then has to fit the packed 32-bit entry
+        // (20 bits) -- or if its whole 8-byte k-mers take the high-digit-first passes under both (k = 24..32: 64-bit entries, 52 bits)
+        uint32_t ts = top_str[b];
+        const uint32_t t = top_bits[b], max_low = narrow[b] ? 20u : 52u;
+        if (rem_bits - ts > max_low) ts = rem_bits - max_low;
+        // (a plan that does not coarsen the file keeps the kernels it has -- unless MGC_HASH_STREAM=1 asks for the new one)
+        bool ok = ts >= 1 && ts <= t && ts <= 18 && (ts < t || sw.hash_stream == 1) && (narrow[b] || (wide_msd[b] && kw == 1 && sw.hash_stream != 2)) &&
+                  h_counts[b] < (1ull << 32) && mgc::finish_stream_ok(kw, rem_bits - ts, narrow[b] != 0) && mgc::finish_can_stream(kw, rem_bits - ts);
+        if (ok) {
+          mgc::SortPlan sp;
+          mgc::make_sort_plan(rem_bits - ts, rem_bits, &sp);
+          if (sp.mode == 0) sp.mode = 3;
+          if (narrow[b]) ok = mgc::sort_plan_narrows(sp, h_counts[b], kw, sw.narrow);
+          else {
+            // (whole keys need the high digit's histogram at hand under the coarser plan as well: fit_split's test)
+            const bool split_ok = !(d_fine && sp.num_passes == 2 && sp.pass_bits[1] > fine_bits && ts - fine_bits > 9);
+            ok = split_ok && mgc::sort_plan_wide_msd(sp, h_counts[b], sw.wide_msd);
+          }
+        }
+        top_str[b] = ok ? ts : 0;
       }
     }
     // a file's sub-bucket tables are laid out for the FINER of its two plans (2^top_bits slots); ngf(b) of them are in use
@@ -1319,8 +1350,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     int probe = -1;
     {
       bool any_cand = false;
-      for (uint32_t b = 0; b < nb; b++) any_cand = any_cand || top_str[b] != 0;
-      if (any_cand && sw.hash_stream > 0) { for (uint32_t b = 0; b < nb; b++) if (top_str[b]) take_stream_plan(b); }
+      for (uint32_t b = 0; b < nb; b++) any_cand = any_cand || top_str[b] != 0 || hpc_cand[b] != 0;
+      if (any_cand && sw.hash_stream == 1) { for (uint32_t b = 0; b < nb; b++) if (top_str[b]) take_stream_plan(b); }
       else if (any_cand) {
         uint64_t best = ~0ull;
         for (uint32_t b = 0; b < nb; b++)
@@ -1647,7 +1678,10 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       s->prof.probe_ratio = ratio;
       if (sw.finish_trace) fprintf(stderr, "[finish] probe file %u: %llu distinct of %llu k-mers (%.3f): the other files take the %s plan\n", pb,
                                    (unsigned long long)h_pd, (unsigned long long)h_counts[pb], ratio, ratio <= 0.30 ? "distinct-sized" : "finer");
-      if (ratio <= 0.30) for (uint32_t b = 0; b < nb; b++) if (b != pb && top_str[b]) take_stream_plan(b);
+      if (ratio <= 0.30) for (uint32_t b = 0; b < nb; b++) {
+        if (b != pb && top_str[b]) take_stream_plan(b);
+        else if (b != pb && hpc_cand[b] && !fstream[b]) { fstream[b] = 1; s->prof.stream_files++; }   // (`compress`: the same digits, the other count kernel)
+      }
       if (d_fine && nb <= 256 && d_nhdrs) { const int prc = prepare_headers(-1, probe); if (prc != MGC_OK) return prc; }
     }
     bool stats_back = false;
@@ -1679,7 +1713,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
           s->prof.stream_retries += h_retry[b];
           HIP_TRY(s, mgc::launch_finish_retry(X + kbytes * h_starts[b], d_substart + sbase[b], ngf(b), rem_bits - top_bits[b],
                                               cnt_ptr[b], d_group + gbase[b], tr_a[b], tr_b[b], d_large + gbase[b] + h_nlarge[b], d_retrycnt + b,
-                                              h_retry[b], mgc::finish_stream_capacity(), st));
+                                              h_retry[b], mgc::finish_stream_capacity(), st, narrow[b] != 0, (void *)huge_alt));
         }
       }
     }

@@ -30,6 +30,7 @@ struct Switches {
   int  hash_multi = -1;         // MGC_HASH_MULTI: sub-buckets per iteration of hash_count_multi_kernel (-1: by the file's average; 0: off)
   int  hash_stream = -1;        // MGC_HASH_STREAM: the distinct-sized count (hash_count_stream_kernel) and its coarser file plan (-1: where the probe
                                 // file's distinct / instances ratio allows it; 0: off; 1: on every file whose suffix fits, whatever the ratio)
+                                // 2: like -1, but only on narrowed files -- not on whole 8-byte k-mers (k = 24..32: the 64-bit-entry instantiation))
   uint32_t min_top = 0;         // MGC_FINISH_MIN_TOP: at least that many grouping bits per file (tests reach the large-input plans)
   uint64_t finish_target = 0;   // MGC_FINISH_TARGET: k-mers per sub-bucket the plan aims at (0: the kernels' default)
   uint64_t stream_max = (uint64_t)1 << 22;   // MGC_STREAM_MAX: sub-buckets up to this many keys are streamed without asking the probe
@@ -156,7 +157,9 @@ uint64_t   finish_target_for(uint32_t key_words, const Switches &sw);       // a
 // The distinct-sized count (hash_count_stream_kernel, round 6): narrowed files whose suffix fits its packed entry take sub-buckets of
 // up to finish_stream_capacity() keys (twice the others' average); its table holds finish_stream_distinct() distinct suffixes, a
 // sub-bucket with more goes on the retry list (launch_finish_retry).
-bool       finish_stream_ok(uint32_t key_words, uint32_t low_bits);
+// Whole 8-byte k-mers on the high-digit-first passes (k = 24..32, `compress`; narrow = false) take the same kernel with 64-bit entries
+// (suffixes of up to 52 bits); their retry list goes through the streaming kernel of the oversized sub-buckets.
+bool       finish_stream_ok(uint32_t key_words, uint32_t low_bits, bool narrow = true);
 uint64_t   finish_stream_capacity();
 uint64_t   finish_stream_target(const Switches &sw);
 uint64_t   finish_stream_distinct();
@@ -194,7 +197,8 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
 // the sub-buckets hash_count_stream_kernel put on the retry list (their number is on the device: the caller brings it back first)
 hipError_t launch_finish_retry(void *d_keys32, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits, uint32_t *d_cnt_tmp,
                                uint64_t *d_group_distinct, uint32_t tr_a, uint32_t tr_b, const uint32_t *d_retry_list,
-                               const uint64_t *d_retry_count, uint64_t n_retry, uint64_t stream_cap, hipStream_t st);
+                               const uint64_t *d_retry_count, uint64_t n_retry, uint64_t stream_cap, hipStream_t st,
+                               bool narrow = true /*false: d_keys32 holds whole 8-byte k-mers*/, void *d_alt = nullptr /*whole k-mers: room for the file's keys*/);
 size_t     finish_scan_scratch_bytes(uint64_t ng_total);
 hipError_t launch_finish_scan(uint64_t *d_group /*[ng_total+1]*/, uint64_t ng_total, void *d_scratch, hipStream_t st);
 hipError_t launch_compact_groups(const void *d_keys, uint32_t key_words, const uint32_t *d_cnt_tmp, const uint64_t *d_starts,

@@ -933,25 +933,28 @@ void hash_count_multi_kernel(u32 *__restrict__ keys, const u64 *__restrict__ sta
 //     cleared in its shadow, rank inside the bin) with up to TWO entries per thread in registers (D <= 512), staged through LDS above.
 // LIST: visit the sub-buckets visit[0 .. *visit_count) (a sparse grid's non-empty list; the retry list); otherwise all ng.
 // retry_list == nullptr: the retry launch itself.
-template <int BLOCK, int KPC, int SLOTS, int DCAP, bool LIST, bool DBG>
-__global__ __launch_bounds__(BLOCK, (SLOTS <= 2048 ? 8 : 2))
-void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size_, u32 low_bits,
+template <typename KT, int BLOCK, int KPC, int SLOTS, int DCAP, bool LIST, bool DBG>
+__global__ __launch_bounds__(BLOCK, (sizeof(KT) == 8 ? (SLOTS <= 2048 ? 5 : 1) : (SLOTS <= 2048 ? 8 : 2)))
+void hash_count_stream_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, u64 ng, u64 max_size_, u32 low_bits,
                               u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct, u64 *__restrict__ dbg,
                               u32 tr_a, u32 tr_b, const u32 *__restrict__ visit, const u64 *__restrict__ visit_count,
                               u32 *__restrict__ retry_list, u64 *__restrict__ retry_count) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS % (4 * BLOCK) == 0 && DCAP <= SLOTS && DCAP <= 65536 && BLOCK == 256, "table geometry");
-  constexpr u32 CNTB = 12u, CNT_MASK = (1u << CNTB) - 1u, EMPTY = 0xFFFFFFFFu;
+  static_assert(sizeof(KT) == 4 || sizeof(KT) == 8, "32-bit words of a narrowed file, or whole 8-byte k-mers");
+  constexpr bool W64 = sizeof(KT) == 8;                               // whole k-mers: 64-bit entries, the bits above the suffix put back on the way out
+  constexpr u32 CNTB = 12u, CNT_MASK = (1u << CNTB) - 1u;
+  constexpr KT EMPTY = (KT)~(KT)0;
   constexpr u32 CH = (u32)(BLOCK * KPC);
   constexpr u32 PROBE_MAX = 64u;                                     // probe steps of one key beyond which the table counts as full
-  __shared__ __attribute__((aligned(16))) u32 tk[SLOTS];            // suffix << 12 | count
-  __shared__ __attribute__((aligned(16))) u32 srt[DCAP];            // the distinct entries in bin order
+  __shared__ __attribute__((aligned(16))) KT tk[SLOTS];             // suffix << 12 | count
+  __shared__ __attribute__((aligned(16))) KT srt[DCAP];             // the distinct entries in bin order
   __shared__ unsigned short lst[DCAP];                              // slots of the claimed entries, in claim order
   __shared__ __attribute__((aligned(16))) u32 s_bin[2][BLOCK + 4];  // bin counts -> starts; [BLOCK] = D
   __shared__ u32 s_nd, s_ovf;
   const u32 tid = threadIdx.x, lane = tid & 63u;
   const u32 G = gridDim.x;
-  const u32 low_mask = (u32)((1ull << low_bits) - 1ull);
-  const u32 bshift = low_bits - 8u;                                 // the launcher guarantees 8 <= low_bits <= 20
+  const KT  low_mask = (KT)((1ull << low_bits) - 1ull);
+  const u32 bshift = low_bits - 8u;                                 // the launcher guarantees 8 <= low_bits <= 20 (whole k-mers: <= 52)
   const u32 np = (u32)(LIST ? *visit_count : ng);                   // (a narrowed file: fewer than 2^30 keys, at most 2^18 sub-buckets)
   const u32 max_size = (u32)max_size_;
 
@@ -977,11 +980,11 @@ void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ st
     return (per + (u32)BLOCK - 1u) & ~((u32)BLOCK - 1u);
   };
   // (uniform guards, lanes past the end re-read the last key: no per-lane predicate, no 64-bit address per slot)
-  auto load_chunk = [&](u32 a, u32 cnt, u32 (&kr)[KPC]) {
-    const u32 *src = keys + a;
+  auto load_chunk = [&](u32 a, u32 cnt, KT (&kr)[KPC]) {
+    const KT *src = keys + a;
 #pragma unroll
     for (int j = 0; j < KPC; j++) {
-      kr[j] = 0u;
+      kr[j] = (KT)0;
       if ((u32)j * BLOCK < cnt) {
         const u32 last = cnt - 1u;
         const u32 idx = (u32)j * BLOCK + tid;
@@ -997,7 +1000,8 @@ void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ st
 
   u32 P = blockIdx.x;
   u32 a0, a1, g0, g1, n0, n1;                                       // the current sub-bucket, the next one
-  u32 kcur[KPC], comp[KPC];
+  KT  kcur[KPC], comp[KPC];
+  KT  pre = (KT)0;                                                   // W64: the current sub-bucket's bits above the suffix
   // in flight from one sub-bucket's end to the next: the bounds of the sub-bucket at P + 2G (its number: gb) and, LIST, the number
   // of the one at P + 3G -- consumed at ONE point, right before the loads of that round are issued (a wait behind newer loads
   // would wait for them)
@@ -1012,9 +1016,12 @@ void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ st
   u32 gv = load_gnum(P + 3 * G);
   u32 par = 0;
   u32 cleared = (u32)SLOTS;                                         // tk[0, cleared) is EMPTY whenever an insert phase begins
+  // (EMPTY is all ones in either width: the table is cleared as 16-byte vectors of ones, `slots` counted in entries)
+  constexpr u32 E16 = 16u / (u32)sizeof(KT);                        // entries per 16-byte vector
+  constexpr u32 ONES = 0xFFFFFFFFu;
   {
     uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
-    for (u32 i = tid; i < (u32)SLOTS / 4; i += BLOCK) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+    for (u32 i = tid; i < (u32)SLOTS / E16; i += BLOCK) tk4[i] = make_uint4(ONES, ONES, ONES, ONES);
     s_bin[0][tid] = 0; s_bin[1][tid] = 0;
     if (tid == 0) { s_nd = 0; s_ovf = 0; }
   }
@@ -1034,6 +1041,7 @@ void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ st
     const u32 smask = slots - 1, sshift = 32 - (u32)__builtin_ctz(slots);
     // the chunk that was loaded a whole chunk ago is consumed into comp[]; only then the next one is issued (a wait for old
     // registers behind new loads would wait for the new loads: hash_count_multi_kernel)
+    if constexpr (W64) { if (off == 0u) pre = kcur[0] & ~low_mask; }   // (every lane holds a key of the sub-bucket: lanes past the end re-read the last one)
 #pragma unroll
     for (int j = 0; j < KPC; j++) {
       comp[j] = kcur[j] & low_mask;
@@ -1060,7 +1068,7 @@ void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ st
     if (active) {
       if (off == 0u && slots > cleared) {                           // (the sub-bucket the last clear had been sized for was not counted)
         uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
-        for (u32 i = tid; i < (u32)SLOTS / 4; i += BLOCK) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+        for (u32 i = tid; i < (u32)SLOTS / E16; i += BLOCK) tk4[i] = make_uint4(ONES, ONES, ONES, ONES);
         __syncthreads();
       }
       HC_STAMP(0);
@@ -1070,13 +1078,14 @@ void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ st
       // -- was measured SLOWER: 0.595 against 0.566 ms per launch, profiles/r06_ab_runs.txt: the kernel is issue-bound, not latency-bound)
 #pragma unroll
       for (int j = 0; j < KPC; j++) {
-        hh[j] = (comp[j] * 0x9E3779B1u) >> sshift;
+        if constexpr (W64) hh[j] = ((((u32)comp[j]) ^ ((u32)(comp[j] >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u) >> sshift;   // (suffixes of <= 52 bits: the high word holds <= 20)
+        else               hh[j] = (comp[j] * 0x9E3779B1u) >> sshift;
         if ((u32)j * BLOCK < cnt) {
           const bool act = (u32)j * BLOCK + tid < cnt;
-          u32 old = 0u;
-          if (act) old = atomicCAS(&tk[hh[j]], EMPTY, (comp[j] << CNTB) | 1u);
+          KT old = (KT)0;
+          if (act) old = atomicCAS(&tk[hh[j]], EMPTY, (KT)((comp[j] << CNTB) | (KT)1));
           const bool w = act && old == EMPTY, dup = act && !w && (old >> CNTB) == comp[j];   // (EMPTY >> 12 IS the all-ones suffix)
-          if (dup) atomicAdd(&tk[hh[j]], 1u);
+          if (dup) atomicAdd(reinterpret_cast<u32 *>(&tk[hh[j]]), 1u);                        // (the count: the low twelve bits of the entry's low word)
           won |= w ? (1u << j) : 0u;
           pending |= (act && !w && !dup) ? (1u << j) : 0u;
         }
@@ -1087,9 +1096,9 @@ void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ st
         for (int j = 0; j < KPC; j++) {
           if ((pending >> j) & 1u) {
             hh[j] = (hh[j] + 1) & smask;
-            const u32 old = atomicCAS(&tk[hh[j]], EMPTY, (comp[j] << CNTB) | 1u);
+            const KT old = atomicCAS(&tk[hh[j]], EMPTY, (KT)((comp[j] << CNTB) | (KT)1));
             const bool w = old == EMPTY, dup = !w && (old >> CNTB) == comp[j];
-            if (dup) atomicAdd(&tk[hh[j]], 1u);
+            if (dup) atomicAdd(reinterpret_cast<u32 *>(&tk[hh[j]]), 1u);
             if (w) won |= 1u << j;
             if (w || dup) pending &= ~(1u << j);
           }
@@ -1132,15 +1141,16 @@ void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ st
       if (!ovf) {
         // the distinct entries into 256 bins by their top eight bits: one returning LDS atomic each
         const bool big = D > 2u * (u32)BLOCK;          // more than two per thread (low-coverage input): staged through LDS
-        u32 ent0 = 0, ent1 = 0, li0 = 0, li1 = 0;
+        KT  ent0 = 0, ent1 = 0;
+        u32 li0 = 0, li1 = 0;
         if (!big) {
-          if (tid < D)              { ent0 = tk[lst[tid]];              li0 = atomicAdd(&s_bin[par][ent0 >> (CNTB + bshift)], 1u); }
-          if (tid + (u32)BLOCK < D) { ent1 = tk[lst[tid + (u32)BLOCK]]; li1 = atomicAdd(&s_bin[par][ent1 >> (CNTB + bshift)], 1u); }
+          if (tid < D)              { ent0 = tk[lst[tid]];              li0 = atomicAdd(&s_bin[par][(u32)(ent0 >> (CNTB + bshift))], 1u); }
+          if (tid + (u32)BLOCK < D) { ent1 = tk[lst[tid + (u32)BLOCK]]; li1 = atomicAdd(&s_bin[par][(u32)(ent1 >> (CNTB + bshift))], 1u); }
         } else {
           for (u32 i = tid; i < D; i += BLOCK) {
-            const u32 e = tk[lst[i]];
+            const KT e = tk[lst[i]];
             srt[i] = e;
-            lst[i] = (unsigned short)atomicAdd(&s_bin[par][e >> (CNTB + bshift)], 1u);
+            lst[i] = (unsigned short)atomicAdd(&s_bin[par][(u32)(e >> (CNTB + bshift))], 1u);
           }
         }
         __syncthreads();
@@ -1158,39 +1168,40 @@ void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ st
           // ... the other three clear what the NEXT insert phase uses (tk, lst and s_nd are dead by now; staged: the table takes
           // the sorted entries first and is cleared at the end)
           uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
-          if (!big) for (u32 i = tid - 64; i < nslots / 4; i += BLOCK - 64) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+          if (!big) for (u32 i = tid - 64; i < nslots / E16; i += BLOCK - 64) tk4[i] = make_uint4(ONES, ONES, ONES, ONES);
           for (u32 i = tid - 64; i < BLOCK; i += BLOCK - 64) s_bin[par ^ 1u][i] = 0;
           if (tid == 64) s_nd = 0;
         }
         cleared = nslots;
         __syncthreads();
         if (!big) {
-          if (tid < D)              srt[s_bin[par][ent0 >> (CNTB + bshift)] + li0] = ent0;
-          if (tid + (u32)BLOCK < D) srt[s_bin[par][ent1 >> (CNTB + bshift)] + li1] = ent1;
+          if (tid < D)              srt[s_bin[par][(u32)(ent0 >> (CNTB + bshift))] + li0] = ent0;
+          if (tid + (u32)BLOCK < D) srt[s_bin[par][(u32)(ent1 >> (CNTB + bshift))] + li1] = ent1;
         } else {
-          for (u32 i = tid; i < D; i += BLOCK) { const u32 e = srt[i]; tk[s_bin[par][e >> (CNTB + bshift)] + lst[i]] = e; }
+          for (u32 i = tid; i < D; i += BLOCK) { const KT e = srt[i]; tk[s_bin[par][(u32)(e >> (CNTB + bshift))] + lst[i]] = e; }
         }
         __syncthreads();
         HC_STAMP(3);
 
         // rank inside the bin, then back in place: the distinct suffixes ascending from the sub-bucket's own start
         const u32 *sb = s_bin[par];
-        const u32 *sorted = big ? tk : srt;
-        u32 *kout = keys + a;
+        const KT *sorted = big ? tk : srt;
+        KT *kout = keys + a;
         u32 *cout = cnt_tmp + a;
         for (u32 p = tid; p < D; p += BLOCK) {
-          const u32 e = sorted[p];
-          const u32 b = e >> (CNTB + bshift), lo = sb[b], hi = sb[b + 1];
+          const KT  e = sorted[p];
+          const u32 b = (u32)(e >> (CNTB + bshift)), lo = sb[b], hi = sb[b + 1];
           u32 r = lo;
           for (u32 q = lo; q < hi; q++) r += (sorted[q] < e) ? 1u : 0u;
-          kout[r] = e >> CNTB;
-          cout[r] = e & CNT_MASK;
+          if constexpr (W64) kout[r] = pre | (e >> CNTB);
+          else               kout[r] = e >> CNTB;
+          cout[r] = (u32)e & CNT_MASK;
         }
         if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = D;
         if (big) {                                     // the table held the sorted entries: cleared now, behind two more barriers
           __syncthreads();
           uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
-          for (u32 i = tid; i < nslots / 4; i += BLOCK) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+          for (u32 i = tid; i < nslots / E16; i += BLOCK) tk4[i] = make_uint4(ONES, ONES, ONES, ONES);
           __syncthreads();
         }
         par ^= 1u;                                     // (srt and this parity's bin table are next written three barriers on)
@@ -1199,7 +1210,7 @@ void hash_count_stream_kernel(u32 *__restrict__ keys, const u64 *__restrict__ st
         // more distinct suffixes than the table or the list holds: nothing is written, the retry launch takes the sub-bucket
         __syncthreads();                               // (everybody has read s_ovf and s_nd)
         uint4 *tk4 = reinterpret_cast<uint4 *>(tk);
-        for (u32 i = tid; i < (u32)SLOTS / 4; i += BLOCK) tk4[i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+        for (u32 i = tid; i < (u32)SLOTS / E16; i += BLOCK) tk4[i] = make_uint4(ONES, ONES, ONES, ONES);
         if (tid == 0) {
           s_nd = 0; s_ovf = 0;
           if (retry_list) retry_list[atomicAdd((unsigned long long *)retry_count, 1ull)] = g;
@@ -2097,6 +2108,8 @@ constexpr u64 FIN_CAP_HASH  = 1536;                               // hash-count 
 // and room for 1280 distinct suffixes (17.6 KiB of LDS, eight workgroups per CU); the retry instantiation: 8192 entries, 58 KiB
 constexpr u64 FIN_CAP_STREAM = 4094;
 constexpr int FIN_STREAM_KPC = 6, FIN_STREAM_SLOTS = 2048, FIN_STREAM_DCAP = 1280, FIN_STREAM_RETRY_SLOTS = 8192, FIN_STREAM_RETRY_DCAP = 4096;
+// ... on whole 8-byte k-mers (64-bit entries): 2048 entries and room for 1024 distinct suffixes: 28.3 KiB, five workgroups per CU
+constexpr int FIN_STREAM64_DCAP = 1024;
 
 // 16-byte keys: the same 1536-key tables (sub-buckets of up to 1152 k-mers); a file whose largest sub-bucket holds at most 768 takes
 // the 768-key instantiation (launch_finish_file)
@@ -2219,7 +2232,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               uint32_t *d_retry_list, uint64_t *d_retry_count, bool k96, int hash_multi, bool hash_dbg,
                               uint64_t stream_cap) {
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
-  if (stream_cap && !(narrow && d_retry_list && d_retry_count && finish_stream_ok(key_words, low_bits) &&
+  if (stream_cap && !(d_retry_list && d_retry_count && finish_stream_ok(key_words, low_bits, narrow) && !k96 && n_keys < (1ull << 32) &&
                       stream_cap <= FIN_CAP_STREAM && (n_large == 0 || stream)))
     return hipErrorInvalidValue;
   if (k96) {
@@ -2301,17 +2314,17 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       const uint64_t gmax = 256ull * 16ull;
       const dim3 sgrid((uint32_t)(ng < gmax ? ng : gmax));
       if (use_list)
-        hipLaunchKernelGGL((hash_count_stream_kernel<256, FIN_STREAM_KPC, FIN_STREAM_SLOTS, FIN_STREAM_DCAP, true, false>), sgrid, dim3(256), 0, st,
+        hipLaunchKernelGGL((hash_count_stream_kernel<u32, 256, FIN_STREAM_KPC, FIN_STREAM_SLOTS, FIN_STREAM_DCAP, true, false>), sgrid, dim3(256), 0, st,
                            reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)stream_cap, low_bits,
                            d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), (u64 *)nullptr, tr_a, tr_b, d_nz, nzc,
                            d_retry_list, reinterpret_cast<u64 *>(d_retry_count));
       else if (dbgb)
-        hipLaunchKernelGGL((hash_count_stream_kernel<256, FIN_STREAM_KPC, FIN_STREAM_SLOTS, FIN_STREAM_DCAP, false, true>), sgrid, dim3(256), 0, st,
+        hipLaunchKernelGGL((hash_count_stream_kernel<u32, 256, FIN_STREAM_KPC, FIN_STREAM_SLOTS, FIN_STREAM_DCAP, false, true>), sgrid, dim3(256), 0, st,
                            reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)stream_cap, low_bits,
                            d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), dbgb, tr_a, tr_b, (const u32 *)nullptr, (const u64 *)nullptr,
                            d_retry_list, reinterpret_cast<u64 *>(d_retry_count));
       else
-        hipLaunchKernelGGL((hash_count_stream_kernel<256, FIN_STREAM_KPC, FIN_STREAM_SLOTS, FIN_STREAM_DCAP, false, false>), sgrid, dim3(256), 0, st,
+        hipLaunchKernelGGL((hash_count_stream_kernel<u32, 256, FIN_STREAM_KPC, FIN_STREAM_SLOTS, FIN_STREAM_DCAP, false, false>), sgrid, dim3(256), 0, st,
                            reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)stream_cap, low_bits,
                            d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), (u64 *)nullptr, tr_a, tr_b, (const u32 *)nullptr,
                            (const u64 *)nullptr, d_retry_list, reinterpret_cast<u64 *>(d_retry_count));
@@ -2426,7 +2439,22 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
   }
   if (finish_uses_hash(key_words, low_bits)) {
     // <= FIN_CAP_HASH keys: hash-count; larger sub-buckets: streamed, or LDS radix passes in the 8192-key instantiation
-    if (low_bits >= 32) {
+    if (stream_cap) {
+      // the distinct-sized count on whole 8-byte k-mers (k = 24..32, `compress`): 64-bit entries suffix << 12 | count, the bits above the
+      // suffix put back on the way out; sub-buckets with more distinct suffixes than the table holds land on the retry list
+      const uint64_t gmax = 256ull * 10ull;
+      const dim3 sgrid((uint32_t)(ng < gmax ? ng : gmax));
+      if (use_list)
+        hipLaunchKernelGGL((hash_count_stream_kernel<u64, 256, FIN_STREAM_KPC, FIN_STREAM_SLOTS, FIN_STREAM64_DCAP, true, false>), sgrid, dim3(256), 0, st,
+                           reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)stream_cap, low_bits,
+                           d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), (u64 *)nullptr, tr_a, tr_b, d_nz, nzc,
+                           d_retry_list, reinterpret_cast<u64 *>(d_retry_count));
+      else
+        hipLaunchKernelGGL((hash_count_stream_kernel<u64, 256, FIN_STREAM_KPC, FIN_STREAM_SLOTS, FIN_STREAM64_DCAP, false, false>), sgrid, dim3(256), 0, st,
+                           reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)stream_cap, low_bits,
+                           d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), (u64 *)nullptr, tr_a, tr_b, (const u32 *)nullptr,
+                           (const u64 *)nullptr, d_retry_list, reinterpret_cast<u64 *>(d_retry_count));
+    } else if (low_bits >= 32) {
 #define MGC_W64_LAUNCH(CAP_, SLOTS_, LIST_, GRID_, MS_)                                                                                  \
       hipLaunchKernelGGL((hash_countw_kernel<u64, 256, CAP_, SLOTS_, false, LIST_>), dim3(GRID_), dim3(256), 0, st, reinterpret_cast<u64 *>(d_keys), \
                          reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)(MS_), low_bits, d_cnt_tmp,                             \
@@ -2469,12 +2497,12 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
       if (low_bits < 32)
         hipLaunchKernelGGL((hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>), dim3((uint32_t)n_large), dim3(1024), B32, st_huge,
                            reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                           (u64)(stream_cap ? stream_cap : FIN_CAP_HASH), low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
                            reinterpret_cast<u64 *>(d_alt), tr_a, tr_b);
       else
         hipLaunchKernelGGL((hash_count_huge_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>), dim3((uint32_t)n_large), dim3(1024), B64, st_huge,
                            reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           (u64)FIN_CAP_HASH, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                           (u64)(stream_cap ? stream_cap : FIN_CAP_HASH), low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
                            reinterpret_cast<u64 *>(d_alt), tr_a, tr_b);
       MGC_CHECK(hipGetLastError());
     } else {
@@ -2492,12 +2520,36 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
 // the retry list of hash_count_stream_kernel: the same kernel with a table no sub-bucket of up to FIN_CAP_STREAM keys can overflow
 hipError_t launch_finish_retry(void *d_keys32, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits, uint32_t *d_cnt_tmp,
                                uint64_t *d_group_distinct, uint32_t tr_a, uint32_t tr_b, const uint32_t *d_retry_list,
-                               const uint64_t *d_retry_count, uint64_t n_retry, uint64_t stream_cap, hipStream_t st) {
+                               const uint64_t *d_retry_count, uint64_t n_retry, uint64_t stream_cap, hipStream_t st, bool narrow, void *d_alt) {
   if (n_retry == 0) return hipSuccess;
-  if (!finish_stream_ok(1, low_bits) || stream_cap == 0 || stream_cap > FIN_CAP_STREAM) return hipErrorInvalidValue;
+  if (!finish_stream_ok(1, low_bits, narrow) || stream_cap == 0 || stream_cap > FIN_CAP_STREAM) return hipErrorInvalidValue;
+  if (!narrow) {
+    // whole 8-byte k-mers: a table for 4094 distinct 64-bit entries does not fit a workgroup's static LDS -- the sub-buckets on the
+    // list go through the streaming kernel of the oversized ones, one workgroup each (huge_min = 0: every listed sub-bucket)
+    if (!d_alt) return hipErrorInvalidValue;
+    constexpr size_t B32 = (size_t)(4 + 4) * HUGE_SLOTS32 + (size_t)(4 + 4) * HUGE_CAP32 + 16 * 4;
+    constexpr size_t B64 = (size_t)(8 + 4) * HUGE_SLOTS64 + (size_t)(8 + 4) * HUGE_CAP64 + 16 * 8;
+    static bool rattr = false;
+    if (!rattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)B32);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)B64);
+      rattr = true;
+    }
+    if (low_bits < 32)
+      hipLaunchKernelGGL((hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>), dim3((uint32_t)n_retry), dim3(1024), B32, st,
+                         reinterpret_cast<u64 *>(d_keys32), reinterpret_cast<const u64 *>(d_starts), d_retry_list, (u64)ng, (u64)0, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), reinterpret_cast<u64 *>(d_alt), tr_a, tr_b);
+    else
+      hipLaunchKernelGGL((hash_count_huge_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>), dim3((uint32_t)n_retry), dim3(1024), B64, st,
+                         reinterpret_cast<u64 *>(d_keys32), reinterpret_cast<const u64 *>(d_starts), d_retry_list, (u64)ng, (u64)0, low_bits,
+                         d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), reinterpret_cast<u64 *>(d_alt), tr_a, tr_b);
+    return hipGetLastError();
+  }
   static_assert(FIN_STREAM_RETRY_DCAP >= (int)FIN_CAP_STREAM, "the retry table holds every suffix of a sub-bucket");
   const uint64_t gmax = 256ull * 2ull;
-  hipLaunchKernelGGL((hash_count_stream_kernel<256, FIN_STREAM_KPC, FIN_STREAM_RETRY_SLOTS, FIN_STREAM_RETRY_DCAP, true, false>),
+  hipLaunchKernelGGL((hash_count_stream_kernel<u32, 256, FIN_STREAM_KPC, FIN_STREAM_RETRY_SLOTS, FIN_STREAM_RETRY_DCAP, true, false>),
                      dim3((uint32_t)(n_retry < gmax ? n_retry : gmax)), dim3(256), 0, st, reinterpret_cast<u32 *>(d_keys32),
                      reinterpret_cast<const u64 *>(d_starts), (u64)ng, (u64)stream_cap, low_bits, d_cnt_tmp,
                      reinterpret_cast<u64 *>(d_group_distinct), (u64 *)nullptr, tr_a, tr_b, d_retry_list,
@@ -2505,7 +2557,7 @@ hipError_t launch_finish_retry(void *d_keys32, const uint64_t *d_starts, uint64_
   return hipGetLastError();
 }
 
-bool     finish_stream_ok(uint32_t key_words, uint32_t low_bits) { return key_words == 1 && low_bits >= 8 && low_bits <= 20; }
+bool     finish_stream_ok(uint32_t key_words, uint32_t low_bits, bool narrow) { return key_words == 1 && low_bits >= 8 && low_bits <= (narrow ? 20u : 52u); }
 uint64_t finish_stream_capacity() { return FIN_CAP_STREAM; }
 uint64_t finish_stream_distinct() { return FIN_STREAM_DCAP; }
 uint64_t finish_stream_target(const Switches &sw) {

@@ -575,6 +575,47 @@ def test_compress_high_digit_first(ops, oracle_lib, torch_cuda, monkeypatch, k, 
         assert (prof.wide_msd_files > 0) == (msd == "1" and (k > 32 or below >= 32)), prof.wide_msd_files
 
 
+@pytest.mark.parametrize("k,bucket_bases,target,stream", [(31, None, None, "1"), (31, 200_000, "100", "1"), (32, 200_000, "100", "1"), (30, 200_000, "40", "1"),
+                                                            (31, 200_000, "100", None), (31, 200_000, "100", "2")])
+def test_compress_two_digit_buckets_on_the_distinct_sized_count(ops, oracle_lib, torch_cuda, monkeypatch, k, bucket_bases, target, stream):
+    """Round 6: a `compress` bucket with two dense-rank digits counts its whole 8-byte k-mers with hash_count_stream_kernel<u64>
+    (64-bit entries suffix << 12 | count, the sparse grid's non-empty list walked, the k-mer's own top bits put back) -- always when
+    its sub-buckets average more than the index-claimed tables take, otherwise where the probe file's distinct / instances ratio
+    allows it.  MGC_HASH_STREAM=1: every two-digit bucket; None: the probe's choice (~1x coverage here: the older kernels); 2: never.
+    64 and 256 buckets, k = 30..32 (suffixes of 32..38 bits), both strand modes, against the oracle's compress + brute-force count."""
+    from meryl_amd import capi
+    if stream is not None:
+        monkeypatch.setenv("MGC_HASH_STREAM", stream)
+    if bucket_bases:
+        monkeypatch.setenv("MGC_BUCKET_BASES", str(bucket_bases))
+    if target:
+        monkeypatch.setenv("MGC_FINISH_TARGET", target)
+    reads, read_len = 3000, 5000
+    bases = oracle_lib.synth_reads(290 + k, reads * read_len // 8, 0, reads, read_len, 3000, 300)
+    stretched = bases.tobytes().decode().replace("AC", "AAAC").replace("GT", "GTTT")
+    # a heavy k-mer (a count above one chunk), and a region read 40 times (sub-buckets with many instances of few suffixes)
+    heavy = stretched[1000:1000 + 3 * k]
+    stretched = stretched + "." + ".".join([heavy] * 2500) + "." + ".".join([stretched[50_000:52_000]] * 40) + "."
+    want_stream = oracle_lib.compress_stream(stretched)
+    for mode in (0, 1):
+        whi, wlo, wcn, wni = oracle_lib.count_brute(want_stream, k, mode)
+        cfg = capi.configure(k, len(stretched), 2 << 30, mode, homopoly_compress=1)
+        d = torch_cuda.from_numpy(np.frombuffer(stretched.encode(), dtype=np.uint8).copy()).cuda()
+        with ops.Session(cfg) as s:
+            s.set_profiling(True)
+            s.push_bases_device(d)
+            s.count()
+            klo, khi, counts, _ = s.result_wide()
+            info = s.info()
+            prof = s.profile()
+        assert info.n_instances == wni
+        assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+        if stream == "1":
+            assert prof.stream_files > 0, prof.stream_files
+        if stream == "2":
+            assert prof.stream_files == 0, prof.stream_files
+
+
 @pytest.mark.parametrize("k", [3, 8, 13, 14])
 def test_simple_mode_geometry(ops, oracle_lib, torch_cuda, tmp_path, k):
     # small k: the reference picks countSimple (merylOp-count.C:368-372) whose database geometry is
@@ -1335,7 +1376,8 @@ def test_hash_count_multi_subbuckets_per_iteration(ops, oracle_lib, torch_cuda, 
 
 
 @pytest.mark.parametrize("stream", ["1", None, "0"])
-@pytest.mark.parametrize("k,min_top,nolist", [(21, 16, "1"), (21, 17, "1"), (20, 14, "0"), (19, 18, "1"), (17, 14, "0"), (14, 12, "0"), (13, 12, "0")])
+@pytest.mark.parametrize("k,min_top,nolist", [(21, 16, "1"), (21, 17, "1"), (20, 14, "0"), (19, 18, "1"), (17, 14, "0"), (14, 12, "0"), (13, 12, "0"),
+                                              (31, 16, "1"), (31, 14, "0"), (28, 17, "1"), (32, 16, "0"), (32, 12, "1")])
 def test_hash_count_stream_kernel_distinct_sized_table(ops, oracle_lib, torch_cuda, monkeypatch, k, min_top, nolist, stream):
     """hash_count_stream_kernel (round 6): ONE sub-bucket of up to 4094 keys per workgroup iteration, its keys
     streamed in chunks through a 2048-entry table that is sized by DISTINCT suffixes (1280 of them); a sub-bucket with more goes
@@ -1345,7 +1387,9 @@ def test_hash_count_stream_kernel_distinct_sized_table(ops, oracle_lib, torch_cu
     20 / 19 (the judged plan's), 18, 15, 12, 10 and 8 bits; sub-buckets of one, two and three chunks: 4094 keys with 5 distinct
     suffixes, 4094 all distinct (retry), 4095 (the streaming launch's), 3000 with 900, 2600 with 1280 and with 1290 distinct (the
     list's capacity and just above), 1536 / 1537 keys, one k-mer 4000 times (a 12-bit count), next to ordinary reads at
-    ~1x coverage (D ~ N: the low-coverage case)."""
+    ~1x coverage (D ~ N: the low-coverage case).  k = 28 / 31 / 32: whole 8-byte k-mers on the high-digit-first passes take the
+    64-bit-entry instantiation (suffixes of 33 / 40 / 42 / 46 bits, the bits above the suffix put back on the way out; its retry list
+    goes through the streaming kernel of the oversized sub-buckets)."""
     from meryl_amd import capi
     monkeypatch.setenv("MGC_FINISH_MIN_TOP", str(min_top))
     monkeypatch.setenv("MGC_FINISH_NOLIST", nolist)
@@ -1378,7 +1422,7 @@ def test_hash_count_stream_kernel_distinct_sized_table(ops, oracle_lib, torch_cu
         whi, wlo, wcn, _ = oracle_lib.count_brute(stream_text, k, mode)
         assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
         low = 2 * k - 6 - min_top
-        if stream == "1" and 8 <= low <= 20:
+        if stream == "1" and (8 <= low <= 20 or (k >= 28 and 32 <= low <= 52)):
             assert prof.stream_files > 0, (prof.stream_files, low)
             if mode == 1 and k - plen >= 6:
                 assert prof.stream_retries >= 1, prof.stream_retries     # the all-distinct 4094-key cluster at least
@@ -1455,7 +1499,7 @@ def test_hash_countw_kernel_dense_and_sparse_grids(ops, oracle_lib, torch_cuda, 
 # every count_device switch that is read per call (a process-wide static one cannot vary inside one test process)
 _GRID_SWITCHES = {
     "MGC_NARROW": ["0"], "MGC_FINE_HIST": ["0"], "MGC_WIDE_MSD": ["0"],
-    "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_HASH_STREAM": ["1", "0"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"],
+    "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_HASH_STREAM": ["1", "0", "2"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"],
     "MGC_FINISH_TARGET": ["1", "4", "64", "700"], "MGC_FINISH_MIN_TOP": ["10", "14", "17", "18"], "MGC_STREAM_MAX": ["2000", "20000"],
     "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"], "MGC_K96": ["0"], "MGC_KMER_CONST_K": ["0"],
 }
