@@ -425,7 +425,11 @@ struct GroupExtra { u32 digit_bits /* NARROW */; u32 shift2, mask2; u64 *ghist2 
 // Measured (profiles/r06_pipe_ab.txt): first pass 0.545 -> 0.465 ms per launch.  The 32-bit second pass LOSES with the same change
 // (0.355 -> 0.385 / 0.45 ms at 20 words per thread: its walkers' wait for the staged words also waits for the granule they have just
 // published -- stores count in vmcnt on gfx9 -- and 24 + 24 words per thread do not fit the register file): it keeps round 5's form.
-template <typename K, int RB, int BLOCK, int KPT, bool DBG, bool NARROW = false, bool HIST2 = false, bool SOA = false, int PIPE = 0 /* 1: the next fetch before the write-out; 2: after it */>
+// HPCD (round 6; `compress`): both digits are dense ranks (hpc_digit: ~30 VALU instructions, taken three times per key and pass plus once
+// for HIST2 -- the whole-key passes of `compress` were VALU-bound at 0.357 ms per 69 M keys against 0.266 ms for plain bit digits): the
+// 4096 ranks of the twelve bits a digit is taken from lie in 8 KiB of LDS behind the tile, a digit is one 16-bit LDS read.
+template <typename K, int RB, int BLOCK, int KPT, bool DBG, bool NARROW = false, bool HIST2 = false, bool SOA = false, int PIPE = 0 /* 1: the next fetch before the write-out; 2: after it */,
+          bool HPCD = false>
 __global__ __launch_bounds__(BLOCK, (GroupSmem<K, RB, BLOCK, KPT>::MIN_WAVES_PER_SIMD))
 void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::type *__restrict__ out, u64 n, u32 shift, u32 dmask,
                         const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
@@ -451,6 +455,17 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
   u64 *s_info  = reinterpret_cast<u64 *>(smem + SM::OFF_INFO);
   const u32 tid0 = threadIdx.x;
   u32 tid = tid0, lane = tid0 & 63u, w = tid0 >> 6;
+  static_assert(!HPCD || SM::BYTES + 8192 <= 160 * 1024, "the rank table lies behind the tile");
+  unsigned short *s_rank = reinterpret_cast<unsigned short *>(smem + (HPCD ? SM::BYTES : 0));
+  if constexpr (HPCD) { for (u32 i = tid0; i < 4096u; i += BLOCK) s_rank[i] = (unsigned short)hpc_digit(i); }   // (in place at the first barrier below)
+  auto dig  = [&](const K &key) __attribute__((always_inline)) -> u32 {
+    if constexpr (HPCD) return (u32)s_rank[KO::digit(key, shift, 0xFFFu)];
+    else return KO::digit(key, shift, dmask);
+  };
+  auto dig2 = [&](const K &key) __attribute__((always_inline)) -> u32 {
+    if constexpr (HPCD) return (u32)s_rank[KO::digit(key, ex.shift2, 0xFFFu)];
+    else return KO::digit(key, ex.shift2, ex.mask2);
+  };
 
   // this thread's slice of the region table stays in registers
   const bool regions = (region_tiles != nullptr);
@@ -623,14 +638,17 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
 
     // ---- rank: position among the tile's keys of the same digit, in arrival order ----
     u32 ranks[KPT / 2];
+    u32 dgs[HPCD ? KPT / 2 : 1];                          // HPCD: the digits stay in registers for the exchange (one table read less per key)
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
-      u32 r = 0;
+      u32 r = 0, d = 0;
       if (idx_of(j) < nv) {
-        r = atomicAdd(&s_hist[KO::digit(keys[j], shift, dmask)], 1u);
+        d = dig(keys[j]);
+        r = atomicAdd(&s_hist[d], 1u);
       }
       if (j & 1) ranks[j / 2] |= r << 16;
       else       ranks[j / 2]  = r;
+      if constexpr (HPCD) { if (j & 1) dgs[j / 2] |= d << 16; else dgs[j / 2] = d; }
     }
     __syncthreads();                                      // (B)
     PK_STAMP(1);
@@ -651,7 +669,9 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
       if (idx_of(j) < nv) {
-        const u32 d = KO::digit(keys[j], shift, dmask);
+        u32 d;
+        if constexpr (HPCD) d = (j & 1) ? (dgs[j / 2] >> 16) : (dgs[j / 2] & 0xFFFFu);
+        else d = dig(keys[j]);
         const u32 r = (j & 1) ? (ranks[j / 2] >> 16) : (ranks[j / 2] & 0xFFFFu);
         s_keys[s_dbase[d] + r] = keys[j];
       }
@@ -700,7 +720,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
       // the waves that do not walk would only wait now: they count the other digit of the tile's keys (in LDS, in digit
       // order since the exchange) -- LDS work in the shadow of the look-back
       if constexpr (HIST2) {
-        for (u32 i = tid - (u32)G; i < nv; i += (u32)(BLOCK - G)) atomicAdd(&s_h2[KO::digit(s_keys[i], ex.shift2, ex.mask2)], 1u);
+        for (u32 i = tid - (u32)G; i < nv; i += (u32)(BLOCK - G)) atomicAdd(&s_h2[dig2(s_keys[i])], 1u);
       }
     } else {
       while (!done) { issue(); consume(); }
@@ -723,7 +743,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
       const u32 i = (u32)j * BLOCK + tid;
       if (i < nv) {
         const K   key = s_keys[i];
-        const u32 d   = KO::digit(key, shift, dmask);
+        const u32 d   = dig(key);
         if constexpr (NARROW) out[s_gbase[d] + (u64)i] = (u32)(((key >> (shift + digit_bits)) << shift) | (key & ((1ull << shift) - 1ull)));
         else                  out[s_gbase[d] + (u64)i] = key;
       }
@@ -1240,12 +1260,21 @@ static hipError_t group_wide(void *d_keys, void *d_alt, uint64_t n, const SortPl
   using GS = GroupSmem<K, RB, BLOCK, KPT>;
   constexpr uint64_t TILE = (uint64_t)BLOCK * KPT;
   static_assert(TILE >= (sizeof(K) >= 12 ? 1024u * 8u : 1024u * 16u), "wide_scratch_bytes sizes the granules for tiles of at least wide_tile() keys");
+  // `compress` (dense-rank digits): the instantiations with the rank table in LDS -- where 8 KiB are left behind the tile
+  constexpr bool HPC_TAB = GS::BYTES + 8192 <= 160 * 1024;
+  const bool hpcd = HPC_TAB && plan.hpc && plan_mask(plan, 0) == HPC_DIGIT_MASK && plan_mask(plan, 1) == HPC_DIGIT_MASK;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES);
+    if constexpr (HPC_TAB) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, true, false, 0, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES + 8192);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, false, false, 0, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES + 8192);
+    }
     attr_done = true;
   }
   const uint64_t tiles0 = (n + TILE - 1) / TILE, tiles1_max = tiles0 + RS_MAX_RADIX + 1;
@@ -1262,6 +1291,14 @@ static hipError_t group_wide(void *d_keys, void *d_alt, uint64_t n, const SortPl
   const uint64_t resident = (uint64_t)device_cu_count() * GS::WG_PER_CU;
 
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[0], st));
+  if constexpr (HPC_TAB) {
+    if (hpcd)
+      hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, true, false, 0, true>), dim3((uint32_t)std::min(tiles0, resident)), dim3(BLOCK), GS::BYTES + 8192, st,
+                         reinterpret_cast<const K *>(d_keys), reinterpret_cast<K *>(d_alt), (u64)n, shA, maskA,
+                         &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                         GroupExtra{0u, low, maskB, &hdr->ghist[1][0]}, (u64 *)nullptr);
+  }
+  if (!hpcd)
   hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, true>), dim3((uint32_t)std::min(tiles0, resident)), dim3(BLOCK), GS::BYTES, st,
                      reinterpret_cast<const K *>(d_keys), reinterpret_cast<K *>(d_alt), (u64)n, shA, maskA,
                      &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
@@ -1271,6 +1308,14 @@ static hipError_t group_wide(void *d_keys, void *d_alt, uint64_t n, const SortPl
   hipLaunchKernelGGL(narrow_mid_kernel, dim3(1), dim3(RS_MAX_RADIX), 0, st, hdr, (u64)n, (u32)TILE, region_start, region_tiles);
   MGC_CHECK(hipGetLastError());
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2], st));
+  if constexpr (HPC_TAB) {
+    if (hpcd)
+      hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, false, false, 0, true>), dim3((uint32_t)std::min(tiles1_max, resident)), dim3(BLOCK), GS::BYTES + 8192, st,
+                         reinterpret_cast<const K *>(d_alt), reinterpret_cast<K *>(d_keys), (u64)n, low, maskB,
+                         &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)tiles0, region_start, region_tiles,
+                         GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
+  }
+  if (!hpcd)
   hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, false>), dim3((uint32_t)std::min(tiles1_max, resident)), dim3(BLOCK), GS::BYTES, st,
                      reinterpret_cast<const K *>(d_alt), reinterpret_cast<K *>(d_keys), (u64)n, low, maskB,
                      &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)tiles0, region_start, region_tiles,
