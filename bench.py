@@ -306,6 +306,97 @@ def e2e_run(bases, reads, threads, gpus=1):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def _gz_members(args):
+    """one worker of e2e_compressed_run: a byte range of the FASTQ file -> gzip members / BGZF blocks (zlib level 1)"""
+    import struct
+    import zlib
+    path, a, b, kind = args
+    with open(path, "rb") as f:
+        f.seek(a)
+        data = f.read(b - a)
+    if kind == "gz":                                     # one gzip member per worker range: gunzip / gzread read the concatenation as ONE stream
+        c = zlib.compressobj(1, zlib.DEFLATED, 31)
+        return c.compress(data) + c.flush()
+    out = []
+    for i in range(0, len(data), 0xff00):                # BGZF (SAMv1 4.1): <= 64 KiB members with their compressed size in a 'BC' extra field
+        d = data[i:i + 0xff00]
+        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+        cd = c.compress(d) + c.flush()
+        bs = 12 + 6 + len(cd) + 8
+        out.append(struct.pack("<BBBBIBBH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6) + b"BC" + struct.pack("<HH", 2, bs - 1) + cd +
+                   struct.pack("<II", zlib.crc32(d) & 0xffffffff, len(d)))
+    return b"".join(out)
+
+
+def e2e_compressed_run(bases, reads, threads):
+    """real inputs are .fastq.gz.  The same reads (a bounded sample: the single zlib stream of a .gz is host-serial)
+    as one gzip stream and as BGZF (bgzip: independent <= 64 KiB members, inflated block-parallel), each through the stand-alone CLI:
+    wall clock, and the rate at which uncompressed text arrives on the device (read + inflate + upload + parse).  Never part of `value`."""
+    import multiprocessing
+    import re
+    import shutil
+    import subprocess
+    import torch
+    from meryl_amd import build
+    d, shm = shm_dir("mgc_e2ez_")
+    rec = READ_LEN * 2 + 7
+    try:
+        fq = os.path.join(d, "reads.fq")
+        with open(fq, "wb") as f:
+            step = 2_000_000
+            for a in range(0, reads, step):
+                n = min(step, reads - a)
+                r = torch.empty((n, rec), dtype=torch.uint8, device=bases.device)
+                r[:, 0] = ord("@"); r[:, 1] = ord("r"); r[:, 2] = 10
+                r[:, 3:3 + READ_LEN] = bases[a * (READ_LEN + 1):(a + n) * (READ_LEN + 1)].view(n, READ_LEN + 1)[:, :READ_LEN]
+                r[:, 3 + READ_LEN] = 10; r[:, 4 + READ_LEN] = ord("+"); r[:, 5 + READ_LEN] = 10
+                r[:, 6 + READ_LEN:6 + 2 * READ_LEN] = ord("I"); r[:, 6 + 2 * READ_LEN] = 10
+                f.write(r.cpu().numpy().tobytes())
+                del r
+        size = os.path.getsize(fq)
+        procs = max(1, min(32, (os.cpu_count() or 2) // 2))
+        per = ((size // procs) // rec + 1) * rec                            # whole records per worker
+        ranges = [(fq, a, min(a + per, size)) for a in range(0, size, per)]
+        out = {"reads": reads, "bases": reads * READ_LEN, "fastq_bytes": size, "threads": threads, "where": shm,
+               "note": "a bounded sample of the workload's reads (zlib level 1); `text_GBps` = uncompressed FASTQ bytes / the CLI's read + inflate + upload + parse phase"}
+        cli = build.build_cli()
+        for kind, name in (("gz", "reads.gz.fq.gz"), ("bgzf", "reads.bgzf.fq.gz")):
+            t0 = time.perf_counter()
+            path = os.path.join(d, name)
+            with multiprocessing.get_context("fork").Pool(procs) as pool, open(path, "wb") as f:
+                for piece in pool.imap(_gz_members, [r + (kind,) for r in ranges]):
+                    f.write(piece)
+                if kind == "bgzf":
+                    f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))   # the BGZF end-of-file block
+            t_make = time.perf_counter() - t0
+            subprocess.run("cat %s > /dev/null" % path, shell=True)
+            dbp = os.path.join(d, "out_%s.meryl" % kind)
+            cmd = [cli, "-V", "k=%d" % K, "memory=64", "threads=%d" % threads, "n=%d" % (reads * READ_LEN), "count", path, "output", dbp]
+            t0 = time.perf_counter()
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            wall = time.perf_counter() - t0
+            o = {"file_bytes": os.path.getsize(path), "made_in_s": round(t_make, 2), "wall_s": wall}
+            if p.returncode != 0:
+                o["error"] = "meryl CLI rc=%d: %s" % (p.returncode, p.stderr[-300:])
+            else:
+                m = re.search(r"TIMING(.*)", p.stderr)
+                if m:
+                    for nm, val in re.findall(r"([a-z+_]+)=([0-9.]+)", m.group(1)):
+                        o[nm + ("" if nm.endswith("bytes") else "_s")] = float(val)
+                rd = o.get("read+parse+stage_s")
+                if rd:
+                    o["text_GBps"] = size / rd / 1e9
+                m = re.search(r"(\d+) distinct k-mers", p.stderr)
+                if m:
+                    o["n_distinct"] = int(m.group(1))
+            out["gz" if kind == "gz" else "bgzf"] = o
+            shutil.rmtree(dbp, ignore_errors=True)
+            os.remove(path)
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def pmc_traffic(reads, prefix, also=()):
     """HBM bytes per launch of a kernel from the committed PMC run of this same workload (profiles/*_pmc_traffic.json, made by
     scripts/gpu_final.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, calibrated on known-byte kernels of the same
@@ -860,6 +951,15 @@ def main():
             except Exception as e:                                                   # noqa: BLE001
                 line["e2e"] = {"error": str(e)[:300]}
             legs_s["e2e"] = time.perf_counter() - t_leg
+        # ... and compressed inputs (one gzip stream; BGZF): a tenth of the reads -- the single stream inflates at a few hundred MB/s
+        if not args.no_e2e and bases is not None and world == 1 and leg_ok("e2e_compressed", 60):
+            t_leg = time.perf_counter()
+            try:
+                zreads = max(1000, min(reads, bases.numel() // (READ_LEN + 1)) // 10)
+                line["e2e_compressed"] = e2e_compressed_run(bases, zreads, threads)
+            except Exception as e:                                                   # noqa: BLE001
+                line["e2e_compressed"] = {"error": str(e)[:300]}
+            legs_s["e2e_compressed"] = time.perf_counter() - t_leg
         # the CPU leg: rank 0 at N = 1 only (the harness's rule); the whole workload at the best thread count when the budget
         # allows its ~150-170 s, else the bounded sample
         if not args.no_cpu_baseline and bases is not None and world == 1:

@@ -300,6 +300,14 @@ int mgc_push_text_file(mgc_session *s, const char *path, int format, int reader_
  * format 0 = sniff.  Host I/O only, no device. */
 int mgc_push_text_file_range(mgc_session *s, const char *path, int format, int reader_threads, uint64_t begin, uint64_t end);
 int mgc_text_record_start(const char *path, int format, uint64_t offset, uint64_t *start);
+/* One whole BGZF file of FASTA/FASTQ text (bgzip: independent gzip members of <= 64 KiB with their compressed size in a 'BC' extra
+ * field, SAMv1 4.1): mapped, its blocks inflated by `threads` threads (0 = default) straight into the pinned upload buffers, uploaded
+ * and parsed in order.  The reference reads every compressed input through ONE decoder (its second loader thread,
+ * src/meryl/merylOp-countThreads.C:162-168).  MGC_EFORMAT: not BGZF / a corrupt block / neither FASTA nor strict FASTQ (nothing of
+ * the file stays in the session unless part of it was already counted as a batch).  mgc_is_bgzf_file: 1 when the file starts with a
+ * BGZF block (host I/O only). */
+int mgc_push_text_bgzf_file(mgc_session *s, const char *path, int format, int threads);
+int mgc_is_bgzf_file(const char *path);
 
 /* Bases already resident in HBM (breakers included).  The buffer is borrowed
  * until mgc_count returns.  May be called once per session. */

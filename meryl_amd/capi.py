@@ -21,7 +21,7 @@ SYMBOLS = (
     "mgc_dev_partition_workspace_bytes", "mgc_dev_kmer_histogram", "mgc_dev_kmer_partition",
     "mgc_dev_sort_workspace_bytes", "mgc_dev_radix_sort", "mgc_dev_radix_group", "mgc_dev_kmer_histogram_fine",
     "mgc_dev_rle_workspace_bytes", "mgc_dev_rle_count", "mgc_dev_rle_emit", "mgc_dev_block_offsets",
-    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_staged_bases", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_push_text_file", "mgc_push_text_file_range", "mgc_text_record_start", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_count_buckets_into", "mgc_copy_result_device",
+    "mgc_open", "mgc_close", "mgc_last_error", "mgc_push_bases", "mgc_push_bases_device", "mgc_staged_bases", "mgc_reserve_text", "mgc_begin_text", "mgc_push_text", "mgc_end_text", "mgc_push_text_file", "mgc_push_text_file_range", "mgc_text_record_start", "mgc_push_text_bgzf_file", "mgc_is_bgzf_file", "mgc_count", "mgc_count_partitioned", "mgc_count_buckets", "mgc_count_buckets_into", "mgc_copy_result_device",
     "mgc_get_result_info", "mgc_get_result_device", "mgc_copy_result", "mgc_finish", "mgc_finish_labelled",
     "mgc_set_profiling", "mgc_get_profile", "mgc_dev_synth_reads", "mgc_dev_synth_reads_ex", "mgc_version",
     "mgc_dev_merge_workspace_bytes", "mgc_dev_merge_count", "mgc_dev_merge_count_values", "mgc_dev_merge_emit",
@@ -319,6 +319,8 @@ def lib():
     sig("mgc_end_text", i32, vp)
     sig("mgc_push_text_file", i32, vp, ctypes.c_char_p, i32, i32)
     sig("mgc_push_text_file_range", i32, vp, ctypes.c_char_p, i32, i32, u64, u64)
+    sig("mgc_push_text_bgzf_file", i32, vp, ctypes.c_char_p, i32, i32)
+    sig("mgc_is_bgzf_file", i32, ctypes.c_char_p)
     sig("mgc_text_record_start", i32, ctypes.c_char_p, i32, u64, P(u64))
     sig("mgc_count", i32, vp)
     sig("mgc_count_partitioned", i32, vp, vp, vp, vp)

@@ -192,6 +192,7 @@ struct InputPiece { std::string name; uint64_t begin, end; };
 // Input: the file's raw text goes to the device and is parsed there (mgc_push_text*); files the device parser refuses
 // (multi-line FASTQ ...), SAM/BAM and MERYL_HOST_PARSER=1 take the host state machine of meryl_seq.cpp.  Returns the
 // bytes / bases taken in (reported with -V -V).
+int g_inflate_threads = 16;                                  // threads= of the command line: the BGZF inflaters (readers of plain text: at most 16)
 uint64_t load_inputs(mgc_session *s, const std::vector<InputPiece> &pieces, int reader_threads) {
   const uint64_t buf_max = 2 * 1024 * 1024;                                                            // merylOp-countThreads.C:413
   std::vector<char> buf(buf_max);
@@ -230,6 +231,18 @@ uint64_t load_inputs(mgc_session *s, const std::vector<InputPiece> &pieces, int 
       struct stat fst;
       if (whole) { if (stat(name.c_str(), &fst) == 0) total_bases += (uint64_t)fst.st_size; }
       else total_bases += pc.end - pc.begin;
+      continue;
+    }
+    if (name != "-" && whole && mgc_is_bgzf_file(name.c_str()) && !getenv("MERYL_BGZF_GENERIC")) {
+      // BGZF (bgzip'd FASTA / FASTQ): the library maps the file and inflates its blocks with several threads straight into its pinned
+      // upload buffers (MERYL_BGZF_GENERIC=1: through the generic reader below, as every other compressed input)
+      msr_close(r);
+      const char *bt = getenv("MERYL_BGZF_THREADS");
+      const int rc = mgc_push_text_bgzf_file(s, name.c_str(), 0, bt ? atoi(bt) : std::max(reader_threads, g_inflate_threads));
+      if (rc == MGC_EFORMAT) load_on_host(name);
+      else if (rc != MGC_OK) die("ERROR: %s", mgc_last_error(s));
+      struct stat fst;
+      if (stat(name.c_str(), &fst) == 0) total_bases += (uint64_t)fst.st_size * 3;             // (text bytes, as the reference guesses them for .gz)
       continue;
     }
     bool begun = false, refused = false;
@@ -421,6 +434,7 @@ int run_count(const Globals &g, const Operation &op) {
   }
   std::vector<InputPiece> pieces;
   for (const std::string &name : op.seq_inputs) pieces.push_back(InputPiece{name, 0, ~0ull});
+  g_inflate_threads = (int)g.threads;
   total_bases = load_inputs(s, pieces, (int)std::min<uint32_t>(g.threads, 16));
 
   const auto t_loaded = std::chrono::steady_clock::now();

@@ -28,6 +28,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <zlib.h>
 
 namespace mgc {
 std::string &thread_last_error() {
@@ -455,6 +456,7 @@ extern "C" void mgc_close(mgc_session *s) {
   if (s->h_stats) (void)hipHostFree(s->h_stats);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
+  for (int i = 0; i < mgc_session::HUGE_EXTRA; i++) if (s->stream_h[i]) (void)hipStreamDestroy(s->stream_h[i]);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -925,6 +927,197 @@ static int push_text_file_range(mgc_session *s, const char *path, int format, in
   }
   if (read_failed) { set_err(&s->err, "mgc_push_text_file: reading '%s' failed: %s", path, strerror(errno)); rc = MGC_EINVAL; }
   const int rc_end = mgc_end_text(s);                       // closes the file in every case (rolls it back on MGC_EFORMAT)
+  return rc != MGC_OK ? rc : rc_end;
+}
+
+// ---- a BGZF file (bgzip'd FASTA / FASTQ: independent gzip members of <= 64 KiB of text, their compressed size in a 'BC' extra field,
+// SAMv1 4.1) inflated by `threads` threads STRAIGHT into the pinned upload ring (round 6) ----
+// Through the generic reader (meryl_seq.cpp: BgzfSource -> msr_read_text -> mgc_push_text) the text of a batch of blocks was copied twice
+// by the calling thread (out of the inflater's batch, into the pinned buffer) behind batches of 32 MiB whose threads were spawned per
+// batch: 4 GB/s of text with 32 threads (profiles/r06w: bench.py e2e_compressed).  Here the file is mapped, its blocks are indexed in one
+// walk over the headers, chunks of <= TEXT_CHUNK of text are handed to persistent worker threads that inflate block after block into the
+// chunk's ring slot, and the calling thread uploads and parses the chunks in order (push_text_file_range's ring).
+namespace {
+struct BgzfBlock { uint64_t off; uint32_t csize, hdr, isize; };
+// size of the BGZF block at p (n >= 18 bytes there), its header length; 0: not a BGZF block
+static size_t bgzf_block_at(const unsigned char *p, size_t n, uint32_t *hdr) {
+  if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+  const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8);
+  if (12 + xlen > n) return 0;
+  size_t o = 12;
+  while (o + 4 <= 12 + xlen) {
+    const size_t slen = (size_t)p[o + 2] | ((size_t)p[o + 3] << 8);
+    if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) { *hdr = (uint32_t)(12 + xlen); return ((size_t)p[o + 4] | ((size_t)p[o + 5] << 8)) + 1; }
+    o += 4 + slen;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" int mgc_is_bgzf_file(const char *path) {
+  if (!path) return 0;
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return 0;
+  unsigned char head[64];
+  const ssize_t got = pread(fd, head, sizeof(head), 0);
+  close(fd);
+  uint32_t hdr = 0;
+  return (got >= 18 && bgzf_block_at(head, (size_t)got, &hdr) != 0) ? 1 : 0;
+}
+
+extern "C" int mgc_push_text_bgzf_file(mgc_session *s, const char *path, int format, int threads) {
+  if (!s || !path) return MGC_EINVAL;
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) { set_err(&s->err, "mgc_push_text_bgzf_file: cannot open '%s': %s", path, strerror(errno)); return MGC_EINVAL; }
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 28) { close(fd); set_err(&s->err, "mgc_push_text_bgzf_file: '%s' is not a regular BGZF file", path); return MGC_EINVAL; }
+  const size_t fsize = (size_t)st.st_size;
+  const unsigned char *map = reinterpret_cast<const unsigned char *>(mmap(nullptr, fsize, PROT_READ, MAP_SHARED, fd, 0));
+  if (map == MAP_FAILED) { close(fd); set_err(&s->err, "mgc_push_text_bgzf_file: mmap of '%s' failed: %s", path, strerror(errno)); return MGC_EINVAL; }
+  auto unmap = [&]() { munmap(const_cast<unsigned char *>(map), fsize); close(fd); };
+  // ---- index: one walk over the block headers; chunks of whole blocks, <= TEXT_CHUNK of text each ----
+  const size_t CH = mgc_session::TEXT_CHUNK;
+  std::vector<BgzfBlock> blocks;
+  struct Chunk { size_t first, last; size_t text; };
+  std::vector<Chunk> chunks;
+  {
+    size_t off = 0, text = 0, first = 0;
+    while (off < fsize) {
+      uint32_t hdr = 0;
+      const size_t bs = bgzf_block_at(map + off, fsize - off, &hdr);
+      if (bs == 0 || off + bs > fsize || bs < (size_t)hdr + 8) { unmap(); set_err(&s->err, "'%s': not a BGZF block at offset %zu (plain gzip data, or a truncated file)", path, off); return MGC_EFORMAT; }
+      const unsigned char *e = map + off + bs;
+      const uint32_t isize = (uint32_t)e[-4] | ((uint32_t)e[-3] << 8) | ((uint32_t)e[-2] << 16) | ((uint32_t)e[-1] << 24);
+      if (isize > 65536) { unmap(); set_err(&s->err, "'%s': corrupt BGZF block at offset %zu (ISIZE %u)", path, off, isize); return MGC_EFORMAT; }
+      if (text + isize > CH) { chunks.push_back({first, blocks.size(), text}); first = blocks.size(); text = 0; }
+      blocks.push_back({(uint64_t)off, (uint32_t)bs, hdr, isize});
+      text += isize;
+      off += bs;
+    }
+    if (blocks.size() > first) chunks.push_back({first, blocks.size(), text});
+  }
+  auto inflate_block = [&](z_stream &z, const BgzfBlock &b, unsigned char *dst) -> bool {
+    if (b.isize == 0) return true;                             // the end-of-file marker (and any other empty block)
+    const unsigned char *p = map + b.off;
+    if (inflateReset(&z) != Z_OK) return false;
+    z.next_in = const_cast<unsigned char *>(p + b.hdr);
+    z.avail_in = b.csize - b.hdr - 8;
+    z.next_out = dst;
+    z.avail_out = b.isize;
+    const int zr = inflate(&z, Z_FINISH);
+    const uint32_t want = (uint32_t)p[b.csize - 8] | ((uint32_t)p[b.csize - 7] << 8) | ((uint32_t)p[b.csize - 6] << 16) | ((uint32_t)p[b.csize - 5] << 24);
+    return zr == Z_STREAM_END && z.avail_out == 0 && (uint32_t)crc32(0L, dst, b.isize) == want;
+  };
+  if (format == 0) {                                            // sniff: the first byte of text that is not white space
+    char c = 0;
+    z_stream z; memset(&z, 0, sizeof(z));
+    std::vector<unsigned char> tmp(65536);
+    if (inflateInit2(&z, -15) != Z_OK) { unmap(); set_err(&s->err, "zlib: inflateInit2 failed"); return MGC_ENOMEM; }
+    for (size_t i = 0; i < blocks.size() && !c; i++) {
+      if (!inflate_block(z, blocks[i], tmp.data())) { inflateEnd(&z); unmap(); set_err(&s->err, "'%s': BGZF block %zu failed to inflate (corrupt file)", path, i); return MGC_EFORMAT; }
+      for (uint32_t j = 0; j < blocks[i].isize; j++) if (tmp[j] != '\n' && tmp[j] != '\r' && tmp[j] != ' ' && tmp[j] != '\t') { c = (char)tmp[j]; break; }
+    }
+    inflateEnd(&z);
+    format = c == '@' ? MGC_TEXT_FASTQ : (c == '>' ? MGC_TEXT_FASTA : 0);
+    if (!format) { unmap(); set_err(&s->err, "'%s' is neither FASTA nor FASTQ (record starts with '%c')", path, c ? c : '?'); return MGC_EFORMAT; }
+  }
+  int rc = mgc_begin_text(s, format);
+  if (rc != MGC_OK) { unmap(); return rc; }
+
+  constexpr int RMAX = mgc_session::TEXT_RING_MAX;
+  if (threads <= 0) threads = 16;
+  threads = std::max(1, std::min(threads, RMAX - 8));
+  const int R = threads + 8;
+  const uint64_t nchunks = chunks.size();
+  threads = (int)std::min<uint64_t>((uint64_t)std::max(1, std::min(threads, R - 2)), nchunks ? nchunks : 1);
+  char **ring = s->text_ring;
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t free_gen[RMAX], ready_chunk[RMAX];                 // slot i may be filled with chunk c iff free_gen[i] == c / R
+  for (int i = 0; i < R; i++) { free_gen[i] = 0; ready_chunk[i] = ~0ull; }
+  std::atomic<uint64_t> next_chunk(0);
+  bool abort_all = false, failed = false, alloc_failed = false;
+  std::atomic<uint64_t> bad_block(~0ull);
+  auto worker = [&]() {
+    z_stream z; memset(&z, 0, sizeof(z));
+    if (inflateInit2(&z, -15) != Z_OK) { std::lock_guard<std::mutex> g(mu); failed = abort_all = true; cv.notify_all(); return; }
+    for (;;) {
+      const uint64_t c = next_chunk.fetch_add(1);
+      if (c >= nchunks) break;
+      const int slot = (int)(c % R);
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return abort_all || free_gen[slot] == c / R; });
+        if (abort_all) break;
+      }
+      if (!ring[slot]) {                                      // first use of this slot (exactly one worker gets here per slot)
+        (void)hipSetDevice(s->device);
+        if (hipHostMalloc(reinterpret_cast<void **>(&ring[slot]), CH, hipHostMallocDefault) != hipSuccess) {
+          ring[slot] = nullptr;
+          std::lock_guard<std::mutex> g(mu);
+          alloc_failed = failed = abort_all = true;
+          cv.notify_all();
+          break;
+        }
+      }
+      bool ok = true;
+      size_t at = 0;
+      for (size_t i = chunks[c].first; i < chunks[c].last && ok; i++) {
+        ok = inflate_block(z, blocks[i], reinterpret_cast<unsigned char *>(ring[slot]) + at);
+        if (!ok) bad_block.store(i);
+        at += blocks[i].isize;
+      }
+      std::lock_guard<std::mutex> g(mu);
+      if (!ok) { failed = abort_all = true; }
+      ready_chunk[slot] = c;
+      cv.notify_all();
+    }
+    inflateEnd(&z);
+  };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; t++) pool.emplace_back(worker);
+  const bool trace = getenv("MGC_IO_TRACE") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_wait = 0, t_submit = 0;
+  uint64_t text_total = 0;
+  for (uint64_t c = 0; c < nchunks && rc == MGC_OK; c++) {
+    const int slot = (int)(c % R);
+    const double t0 = now();
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return abort_all || ready_chunk[slot] == c; });
+      if (abort_all) break;
+    }
+    const double t1 = now();
+    t_wait += t1 - t0;
+    if (chunks[c].text) rc = text_submit(s, ring[slot], chunks[c].text);       // (a chunk of empty blocks: the end-of-file marker)
+    text_total += chunks[c].text;
+    t_submit += now() - t1;
+    if (c >= 2) { std::lock_guard<std::mutex> g(mu); free_gen[(c - 2) % R]++; cv.notify_all(); }
+  }
+  { std::lock_guard<std::mutex> g(mu); if (rc != MGC_OK) abort_all = true; cv.notify_all(); }
+  for (int b = 0; b < 2; b++) if (s->text_ev_used[b]) (void)hipEventSynchronize(s->text_ev[b]);   // the last uploads still read from the ring
+  { std::lock_guard<std::mutex> g(mu); abort_all = true; cv.notify_all(); }
+  for (auto &t : pool) t.join();
+  unmap();
+  if (trace)
+    fprintf(stderr, "[io] BGZF file %.2f GB -> %.2f GB of text in %llu chunks (%zu blocks), %d inflaters, ring %d: waiting for the inflaters %.3f s, "
+                    "upload+parse submit (incl. waits for the device) %.3f s\n", fsize / 1e9, text_total / 1e9, (unsigned long long)nchunks, blocks.size(),
+            threads, R, t_wait, t_submit);
+  if (alloc_failed) { set_err(&s->err, "mgc_push_text_bgzf_file: pinned buffers: out of memory"); (void)mgc_end_text(s); return MGC_ENOMEM; }
+  if (failed) {
+    // what the file has put into the stream is taken back (as for a file that stops being strict FASTQ), unless part of it already went
+    // into a counted batch
+    const unsigned long long bb = (unsigned long long)bad_block.load();
+    s->text_open = false;
+    if (s->text_cut_in_file) { set_err(&s->err, "'%s': BGZF block %llu failed to inflate after part of the file was counted (input larger than one batch)", path, bb); return MGC_EINVAL; }
+    HIP_TRY(s, mgc::launch_text_file_op(s->buf[mgc_session::B_TEXT_STATE].p, stage_ptr(s, s->fill), 2, s->st_in));
+    const int rrc = resolve_length(s);
+    if (rrc != MGC_OK) return rrc;
+    set_err(&s->err, "'%s': BGZF block %llu failed to inflate (corrupt file)", path, bb);
+    return MGC_EFORMAT;
+  }
+  const int rc_end = mgc_end_text(s);                        // closes the file in every case (rolls it back on MGC_EFORMAT)
   return rc != MGC_OK ? rc : rc_end;
 }
 
@@ -1545,6 +1738,46 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     // second buffer.
     const bool alt_files = fork_huge;
     bool forked = false, need_join = false;          // forked: stream2 is ordered after everything st holds that it must see
+    // Round 6: the streaming kernels of different files on up to FOUR streams, each with a second buffer of its own.  One gigantic
+    // sub-bucket (a repeat family's k-mers: 266 K keys at 30x of a 10 % repeat genome) occupies ONE workgroup for ~600 us; with every
+    // file's streaming launch queued on one stream those tails added up to 39 ms of a 57 ms count stage (profiles/r06y: BASELINE config 3's
+    // read shape at 10 Gbp) while the device had room for all of them at once.  MGC_HUGE_STREAMS=1: one stream (round 5).
+    constexpr int NH = 1 + mgc_session::HUGE_EXTRA;
+    hipStream_t hstream[NH];
+    unsigned char *halt[NH];
+    int n_huge_streams = 1, huge_next = 0;
+    hstream[0] = st_huge; halt[0] = Y;
+    auto huge_sync_all = [&]() -> int {               // (the host waits for every streaming kernel: Y and its siblings are free)
+      for (int i = 0; i < n_huge_streams; i++) HIP_TRY(s, hipStreamSynchronize(hstream[i]));
+      return MGC_OK;
+    };
+    auto huge_join_all = [&]() -> int {               // (st is ordered behind every streaming kernel)
+      for (int i = 0; i < n_huge_streams; i++) {
+        HIP_TRY(s, hipEventRecord(s->ev_join, hstream[i]));
+        HIP_TRY(s, hipStreamWaitEvent(st, s->ev_join, 0));
+      }
+      return MGC_OK;
+    };
+    // (The streams are created on first need, behind all the others: HIP maps streams onto a few hardware queues in creation order, and
+    // three more of them created at mgc_open put the two count streams on ONE queue -- their kernels no longer ran side by side, the
+    // judged count stage went 25.4 -> 28.8 ms, profiles/r06_ab_runs.txt r06z.  Needed only where several files hold a GIGANTIC sub-bucket:
+    // the many slightly oversized ones of an ordinary file -- 615 of up to 1946 keys in a dense file of the judged workload -- are short.)
+    auto huge_setup = [&]() -> int {                  // once the files' statistics are back
+      uint32_t files_gigantic = 0;
+      for (uint32_t b = 0; b < nb; b++) if (h_counts[b] && s->h_stats[3 * (size_t)b + 1] != 0 && s->h_stats[3 * (size_t)b] > 16384) files_gigantic++;
+      const int want = (int)std::min<uint64_t>((uint64_t)sw.huge_streams, (uint64_t)NH);
+      if (!fork_huge || want <= 1 || files_gigantic < 2) return MGC_OK;
+      for (int i = 1; i < want; i++) {
+        if (!s->stream_h[i - 1] && hipStreamCreateWithFlags(&s->stream_h[i - 1], hipStreamNonBlocking) != hipSuccess) { s->stream_h[i - 1] = nullptr; (void)hipGetLastError(); }
+        if (!s->stream_h[i - 1]) break;
+        const int id = mgc_session::B_Y2 + (i - 1);
+        HIP_TRY(s, s->ensure(id, kbytes * max_bucket));
+        hstream[i] = s->stream_h[i - 1];
+        halt[i] = reinterpret_cast<unsigned char *>(s->buf[id].p);
+        n_huge_streams = i + 1;
+      }
+      return MGC_OK;
+    };
     // tests run the dense-grid instantiations of the count kernels on small inputs (whose 2^t grids are mostly empty)
     const bool finish_nolist = sw.nolist;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> fin_ev;       // profiling: around every file's count-kernel launch
@@ -1581,7 +1814,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       if (file_k96[b] && h_nlarge[b] > 0 && !stream) {
         // K96 records with an oversized sub-bucket that nothing streams: the LDS sort / the stable-sort fallback want whole 16-byte
         // k-mers -- the file is widened in its own (16 bytes per k-mer) region, through Y, and goes on as a launch_group_wide file
-        if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));   // Y is the streaming kernels' second buffer
+        if (need_join) { const int jr = huge_sync_all(); if (jr != MGC_OK) return jr; }   // Y is the streaming kernels' second buffer
         forked = false;
         const unsigned __int128 fb = (unsigned __int128)b << rem_bits;
         HIP_TRY(s, mgc::launch_widen_k96(seg, h_counts[b], (uint64_t)fb, (uint64_t)(fb >> 64), (void *)Y, st));
@@ -1592,7 +1825,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       bool unordered = false;
       if (narrow[b] && h_nlarge[b] > 0 && !stream) {
         // an oversized sub-bucket that cannot be streamed: the LDS sort / the stable-sort fallback want whole k-mers back
-        if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));   // Y is the streaming kernels' second buffer
+        if (need_join) { const int jr = huge_sync_all(); if (jr != MGC_OK) return jr; }   // Y is the streaming kernels' second buffer
         forked = false;
         HIP_TRY(s, mgc::launch_widen_groups(seg, d_substart + sbase[b], ngf(b), (uint64_t)b << rem_bits, low, (void *)Y, st,
                                             tr_a[b], tr_b[b]));
@@ -1613,11 +1846,12 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
           const bool on_second = alt_files && (b & 1u);
           if ((stream || on_second) && fork_huge && !forked) {   // everything the forked kernels read is complete at this point of st
             HIP_TRY(s, hipEventRecord(s->ev_fork, st));
-            HIP_TRY(s, hipStreamWaitEvent(st_huge, s->ev_fork, 0));
+            for (int i = 0; i < n_huge_streams; i++) HIP_TRY(s, hipStreamWaitEvent(hstream[i], s->ev_fork, 0));
             forked = need_join = true;
           }
           fst = on_second ? s->stream2 : st;
         }
+        const int hsel = (stream && h_nlarge[b] > 0 && n_huge_streams > 1) ? (huge_next++ % n_huge_streams) : 0;
         if (s->profiling) {
           fin_ev.emplace_back(); (void)hipEventCreate(&fin_ev.back().first); (void)hipEventCreate(&fin_ev.back().second);
           (void)hipEventRecord(fin_ev.back().first, fst);
@@ -1626,7 +1860,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
           fin_narrow = fin_narrow || narrow[b];
         }
         HIP_TRY(s, mgc::launch_finish_file(seg, kw, d_substart + sbase[b], ngf(b), low, h_nlarge[b],
-                                           d_large + gbase[b], cnt_ptr[b], d_group + gbase[b], stream, (void *)huge_alt, st_huge,
+                                           d_large + gbase[b], cnt_ptr[b], d_group + gbase[b], stream, (void *)halt[hsel], hstream[hsel],
                                            // the list pays off only when a good part of the 2^t grid is empty
                                            (4 * h_nzcount[b] < 3 * ngf(b) && !finish_nolist) ? d_nz + gbase[b] : nullptr,
                                            d_nzcount(b), fst, narrow[b] != 0, tr_a[b], tr_b[b], h_maxsub[b], h_counts[b],
@@ -1637,7 +1871,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
         fallback[b] = true;
-        if (need_join) HIP_TRY(s, hipStreamSynchronize(st_huge));  // the sort below uses Y, the streaming kernels' second buffer
+        if (need_join) { const int jr = huge_sync_all(); if (jr != MGC_OK) return jr; }   // the sort below uses Y, the streaming kernels' second buffer
         forked = false;                                            // ... and the next streaming kernel must wait for that sort
         if (low || unordered) {
           // LSD order: the low bits cannot be sorted after the top bits, so the whole key is redone
@@ -1665,10 +1899,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       HIP_TRY(s, hipStreamSynchronize(st));
       h_maxsub[pb] = s->h_stats[3 * (size_t)pb]; h_nlarge[pb] = s->h_stats[3 * (size_t)pb + 1]; h_nzcount[pb] = s->h_stats[3 * (size_t)pb + 2];
       { const int rc = finish_file(pb); if (rc != MGC_OK) return rc; }
-      if (need_join) {
-        HIP_TRY(s, hipEventRecord(s->ev_join, st_huge));
-        HIP_TRY(s, hipStreamWaitEvent(st, s->ev_join, 0));
-      }
+      if (need_join) { const int jr = huge_join_all(); if (jr != MGC_OK) return jr; }
       forked = false;                                        // (the second stream has to be ordered behind the other files' passes again)
       uint64_t h_pd = 0;
       HIP_TRY(s, mgc::launch_sum_u64(d_group + gbase[pb], gbase[pb + 1] - gbase[pb], d_group + ng_total, st));
@@ -1687,17 +1918,17 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     bool stats_back = false;
     for (uint32_t b = 0; b < nb; b++) {
       { const int rc = group_upto(nb); if (rc != MGC_OK) return rc; }
-      if (!stats_back) { HIP_TRY(s, hipStreamSynchronize(st)); stats_back = true; }
+      if (!stats_back) {
+        HIP_TRY(s, hipStreamSynchronize(st)); stats_back = true;
+        const int hrc = huge_setup(); if (hrc != MGC_OK) return hrc;
+      }
       if ((int)b == probe) continue;
       h_maxsub[b] = s->h_stats[3 * (size_t)b]; h_nlarge[b] = s->h_stats[3 * (size_t)b + 1]; h_nzcount[b] = s->h_stats[3 * (size_t)b + 2];
       const int rc = finish_file(b);
       if (rc != MGC_OK) return rc;
     }
 
-    if (need_join) {
-      HIP_TRY(s, hipEventRecord(s->ev_join, st_huge));
-      HIP_TRY(s, hipStreamWaitEvent(st, s->ev_join, 0));
-    }
+    if (need_join) { const int jr = huge_join_all(); if (jr != MGC_OK) return jr; }
 
     // the sub-buckets hash_count_stream_kernel could not hold (more distinct suffixes than its table: low coverage, D ~ N): their
     // numbers are on the device -- one small copy brings the counts back, the files that have any get the retry launch

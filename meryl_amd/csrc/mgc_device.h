@@ -34,6 +34,7 @@ struct Switches {
   uint32_t min_top = 0;         // MGC_FINISH_MIN_TOP: at least that many grouping bits per file (tests reach the large-input plans)
   uint64_t finish_target = 0;   // MGC_FINISH_TARGET: k-mers per sub-bucket the plan aims at (0: the kernels' default)
   uint64_t stream_max = (uint64_t)1 << 22;   // MGC_STREAM_MAX: sub-buckets up to this many keys are streamed without asking the probe
+  uint32_t huge_streams = 4;    // MGC_HUGE_STREAMS: streams the streaming kernels of oversized sub-buckets are spread over (1..4)
   uint64_t bucket_bases = 0;    // MGC_BUCKET_BASES: bases per partition bucket above which the partition gets finer (0: default)
 };
 Switches read_switches();

@@ -2706,6 +2706,7 @@ Switches read_switches() {
   sw.finish_target = num("MGC_FINISH_TARGET", 0);
   sw.stream_max = num("MGC_STREAM_MAX", (uint64_t)1 << 22);
   sw.bucket_bases = num("MGC_BUCKET_BASES", 0);
+  sw.huge_streams = (uint32_t)num("MGC_HUGE_STREAMS", 4);
   return sw;
 }
 

@@ -51,6 +51,8 @@ struct mgc_session {
   hipStream_t      stream = nullptr;
   uint64_t         sfx_mask = 0, sfx_test = 0;   // count-suffix= filter (0, 0: none)
   mgc::Switches    sw;                   // the MGC_* switches of the count path, read once by mgc_open (mgc_device.h)
+  static constexpr int HUGE_EXTRA = 3;
+  hipStream_t      stream_h[HUGE_EXTRA] = {nullptr, nullptr, nullptr};   // more streams for the streaming kernels of oversized sub-buckets (count_device)
   hipStream_t      stream2 = nullptr;    // the streaming hash-count of a file's oversized sub-buckets runs beside its persistent kernel
   hipEvent_t       ev_fork = nullptr, ev_join = nullptr;
   uint64_t        *h_stats = nullptr;    // pinned: per file {largest sub-bucket, oversized sub-buckets, non-empty sub-buckets}
@@ -79,7 +81,7 @@ struct mgc_session {
   struct Buf { void *p = nullptr; size_t cap = 0; };
   enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_HPC, B_HPC_WS,
          B_SUBSTART, B_GROUPS, B_GSCAN, B_CNT_TMP, B_LARGE, B_NONEMPTY, B_STAGE0, B_STAGE1, B_TEXT_IN0, B_TEXT_IN1, B_TEXT_WS,
-         B_TEXT_STATE, B_RK, B_RC, B_R2K, B_R2C, B_MERGE_WS, B_SORT_HDRS, B_FINE, B_NARROW_WS, B_NUM };
+         B_TEXT_STATE, B_RK, B_RC, B_R2K, B_R2C, B_MERGE_WS, B_SORT_HDRS, B_FINE, B_NARROW_WS, B_Y2, B_Y3, B_Y4, B_NUM };
   Buf buf[B_NUM];
   double tr_alloc = 0;                   // seconds inside hipMalloc / hipFree of the arena (MGC_IO_TRACE)
   uint64_t tr_alloc_bytes = 0;

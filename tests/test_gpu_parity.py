@@ -1117,6 +1117,74 @@ def test_push_text_file_reader_ring(ops, oracle_lib, torch_cuda, tmp_path):
         assert np.array_equal(a, b)
 
 
+def test_push_text_bgzf_file_inflates_into_the_ring(ops, oracle_lib, torch_cuda, tmp_path):
+    """mgc_push_text_bgzf_file (round 6): a bgzip'd FASTQ of several upload chunks (blocks of mixed sizes, empty blocks in the middle, the
+    end-of-file marker) inflated by several threads straight into the pinned ring, a one-chunk bgzip'd FASTA, then the ways out: a
+    corrupted block (CRC) and a plain .gz are refused with MGC_EFORMAT and leave nothing behind, a bgzip'd multi-line FASTQ is refused
+    by the device parser -- against the bases pushed directly."""
+    import sys
+    import zlib
+    from meryl_amd import capi
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_seq_bam import bgzf, bgzf_block
+    k = 21
+    n = 400_000
+    bases = oracle_lib.synth_reads(15, 3_000_000, 0, n, 150, 5000, 100)
+    rec = np.empty((n, 307), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r"); rec[:, 2] = 10
+    rec[:, 3:153] = bases.reshape(-1, 151)[:, :150]
+    rec[:, 153] = 10; rec[:, 154] = ord("+"); rec[:, 155] = 10; rec[:, 156:306] = ord("I"); rec[:, 306] = 10
+    text = rec.tobytes()                                                  # 123 MB: four upload chunks
+    def fast_block(d):
+        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+        cd = c.compress(d) + c.flush()
+        import struct
+        return (struct.pack("<BBBBIBBH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(cd) + 8 - 1) + cd +
+                struct.pack("<II", zlib.crc32(d) & 0xffffffff, len(d)))
+    rng = np.random.default_rng(7)
+    pieces, at = [], 0
+    while at < len(text):
+        ln = int(rng.integers(1, 0xff00)) if rng.random() < 0.05 else 0xff00
+        pieces.append(fast_block(text[at:at + ln])); at += ln
+        if rng.random() < 0.01:
+            pieces.append(fast_block(b""))                               # an empty block in the middle
+    fq = str(tmp_path / "reads.fq.gz")
+    open(fq, "wb").write(b"".join(pieces) + bgzf_block(b""))
+    fa_reads = [r for r in oracle_lib.synth_reads(16, 100_000, 0, 2000, 150, 5000, 100).tobytes().decode().split(".") if r]
+    fa = str(tmp_path / "reads.fa.gz")
+    open(fa, "wb").write(bgzf("".join(">s%d\n%s\n%s\n" % (i, r[:70], r[70:]) for i, r in enumerate(fa_reads)).encode(), 20_000))
+    bad = bytearray(b"".join(pieces[:40]) + bgzf_block(b""))
+    bad[len(pieces[0]) + len(pieces[1]) + 40] ^= 0x55                     # a flipped byte inside the third block's deflate data
+    corrupt = str(tmp_path / "corrupt.fq.gz")
+    open(corrupt, "wb").write(bytes(bad))
+    plain = str(tmp_path / "plain.fq.gz")
+    import gzip
+    open(plain, "wb").write(gzip.compress(text[:100_000]))
+    multi = str(tmp_path / "multi.fq.gz")
+    open(multi, "wb").write(bgzf(b"@a\nACGT\nACGT\n+\nIIII\nIIII\n"))
+    L = capi.lib()
+    assert L.mgc_is_bgzf_file(fq.encode()) == 1 and L.mgc_is_bgzf_file(plain.encode()) == 0 and L.mgc_is_bgzf_file(str(tmp_path / "none").encode()) == 0
+    cfg = capi.configure(k, 200_000_000, 8 << 30)
+    with ops.Session(cfg) as s:
+        assert L.mgc_push_text_bgzf_file(s._h, corrupt.encode(), 0, 3) == capi.EFORMAT
+        capi.check(L.mgc_push_text_bgzf_file(s._h, fq.encode(), 0, 5), "mgc_push_text_bgzf_file", s._h)
+        assert L.mgc_push_text_bgzf_file(s._h, plain.encode(), 0, 2) == capi.EFORMAT
+        capi.check(L.mgc_push_text_bgzf_file(s._h, fa.encode(), 0, 0), "mgc_push_text_bgzf_file", s._h)
+        assert L.mgc_push_text_bgzf_file(s._h, multi.encode(), 0, 2) == capi.EFORMAT
+        assert L.mgc_push_text_bgzf_file(s._h, str(tmp_path / "missing.gz").encode(), 0, 2) == capi.EINVAL
+        s.count()
+        got = s.result_wide()
+        info = s.info()
+    stream = torch_cuda.from_numpy(np.concatenate([bases, np.frombuffer((".".join(fa_reads) + ".").encode(), dtype=np.uint8)])).cuda()
+    with ops.Session(cfg) as s:
+        s.push_bases_device(stream)
+        s.count()
+        want = s.result_wide()
+        assert s.info().n_instances == info.n_instances
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("seed", range(48))
 def test_random_inputs_match_oracle(ops, oracle_lib, torch_cuda, seed):
     # randomised sweep over k, strand mode, read lengths, N density, repeat structure and input size: every finish
@@ -1499,7 +1567,7 @@ def test_hash_countw_kernel_dense_and_sparse_grids(ops, oracle_lib, torch_cuda, 
 # every count_device switch that is read per call (a process-wide static one cannot vary inside one test process)
 _GRID_SWITCHES = {
     "MGC_NARROW": ["0"], "MGC_FINE_HIST": ["0"], "MGC_WIDE_MSD": ["0"],
-    "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_HASH_STREAM": ["1", "0", "2"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"],
+    "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_HASH_STREAM": ["1", "0", "2"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"], "MGC_HUGE_STREAMS": ["1", "2"],
     "MGC_FINISH_TARGET": ["1", "4", "64", "700"], "MGC_FINISH_MIN_TOP": ["10", "14", "17", "18"], "MGC_STREAM_MAX": ["2000", "20000"],
     "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"], "MGC_K96": ["0"], "MGC_KMER_CONST_K": ["0"],
 }
@@ -1575,10 +1643,16 @@ def test_config4_shape_spills_through_real_host_runs(ops, oracle_lib, torch_cuda
     d = ops.dev_synth_reads(44, 100_000_000, 0, n_reads, 20_000, 1000, 100)
     cfg = capi.configure(k, d.numel(), 64 << 30, homopoly_compress=1)
     out = str(tmp_path / "ooc.meryl")
+    raw = d.cpu().numpy()
+    host = np.frombuffer(oracle_lib.compress_stream(raw.tobytes()), dtype=np.uint8).copy()
+    # (the threaded port -- 16 CPU threads, ~45 s -- runs beside the device's batches instead of after them)
+    import threading
+    port = {}
+    th = threading.Thread(target=lambda: port.update(r=oracle_lib.digest_threaded(host, k, cfg.w_prefix, threads=16)))
+    th.start()
     with ops.Session(cfg) as s:
         s.set_batch_bases(d.numel() // 5 + 1)                      # five batches
         s.set_result_budget(3 << 29)                               # 1.5 GB of batch results may stay in HBM: the later ones really leave it
-        raw = d.cpu().numpy()
         step = 1 << 28
         for a in range(0, raw.size, step):                          # (host pushes: a device buffer is the only input of its session)
             s.push_bases(raw[a:a + step].tobytes(), end_of_sequence=False)
@@ -1589,10 +1663,10 @@ def test_config4_shape_spills_through_real_host_runs(ops, oracle_lib, torch_cuda
         rp = s.runs_profile()
         assert rp["n_host_runs"] >= 2 and rp["n_runs"] >= 5 and rp["host_bytes"] > (1 << 30)   # gigabytes REALLY spilled to pinned host DRAM
         nd = s.info().n_distinct
-    host = np.frombuffer(oracle_lib.compress_stream(raw.tobytes()), dtype=np.uint8).copy()
     del d, raw
     torch_cuda.cuda.empty_cache()
-    want, wnd, wni = oracle_lib.digest_threaded(host, k, cfg.w_prefix, threads=16)
+    th.join()
+    want, wnd, wni = port["r"]
     assert (wnd, wni) == (nd, info.n_instances)
     r = db.Reader(out)
     got = np.zeros((64, 4), dtype=np.uint64)
@@ -1618,10 +1692,14 @@ def test_config5_shape_spills_through_real_host_runs(ops, oracle_lib, torch_cuda
     d = ops.dev_synth_reads(55, 100_000_000, 0, n_reads)
     cfg = capi.configure(k, d.numel(), 64 << 30, label_size=8, label=label)
     out = str(tmp_path / "ooc51.meryl")
+    raw = d.cpu().numpy()
+    import threading
+    port = {}
+    th = threading.Thread(target=lambda: port.update(r=oracle_lib.digest_threaded(raw, k, cfg.w_prefix, threads=16)))   # (beside the device's batches)
+    th.start()
     with ops.Session(cfg) as s:
         s.set_batch_bases(d.numel() // 5 + 1)                      # five batches
         s.set_result_budget(3 << 29)                               # 1.5 GB of batch results may stay in HBM: the later ones really leave it
-        raw = d.cpu().numpy()
         step = 1 << 28
         for a in range(0, raw.size, step):                          # (host pushes: a device buffer is the only input of its session)
             s.push_bases(raw[a:a + step].tobytes(), end_of_sequence=False)
@@ -1634,7 +1712,8 @@ def test_config5_shape_spills_through_real_host_runs(ops, oracle_lib, torch_cuda
         nd = s.info().n_distinct
     del d
     torch_cuda.cuda.empty_cache()
-    want, wnd, wni = oracle_lib.digest_threaded(raw, k, cfg.w_prefix, threads=16)
+    th.join()
+    want, wnd, wni = port["r"]
     assert (wnd, wni) == (nd, info.n_instances)
     r = db.Reader(out)
     assert r.info.label_size == 8
