@@ -1745,6 +1745,8 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     constexpr int NH = 1 + mgc_session::HUGE_EXTRA;
     hipStream_t hstream[NH];
     unsigned char *halt[NH];
+    void *hws[NH] = {nullptr, nullptr, nullptr, nullptr};     // the sliced count of gigantic sub-buckets: one plan workspace per stream (launch_finish_file)
+    const size_t hws_bytes = mgc::finish_huge_workspace_bytes(max_bucket);
     int n_huge_streams = 1, huge_next = 0;
     hstream[0] = st_huge; halt[0] = Y;
     auto huge_sync_all = [&]() -> int {               // (the host waits for every streaming kernel: Y and its siblings are free)
@@ -1765,6 +1767,10 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     auto huge_setup = [&]() -> int {                  // once the files' statistics are back
       uint32_t files_gigantic = 0;
       for (uint32_t b = 0; b < nb; b++) if (h_counts[b] && s->h_stats[3 * (size_t)b + 1] != 0 && s->h_stats[3 * (size_t)b] > 16384) files_gigantic++;
+      if (files_gigantic && sw.huge_slices) {
+        HIP_TRY(s, s->ensure(mgc_session::B_HWS0, hws_bytes));
+        hws[0] = s->buf[mgc_session::B_HWS0].p;
+      }
       const int want = (int)std::min<uint64_t>((uint64_t)sw.huge_streams, (uint64_t)NH);
       if (!fork_huge || want <= 1 || files_gigantic < 2) return MGC_OK;
       for (int i = 1; i < want; i++) {
@@ -1774,6 +1780,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         HIP_TRY(s, s->ensure(id, kbytes * max_bucket));
         hstream[i] = s->stream_h[i - 1];
         halt[i] = reinterpret_cast<unsigned char *>(s->buf[id].p);
+        if (sw.huge_slices) { HIP_TRY(s, s->ensure(mgc_session::B_HWS0 + i, hws_bytes)); hws[i] = s->buf[mgc_session::B_HWS0 + i].p; }
         n_huge_streams = i + 1;
       }
       return MGC_OK;
@@ -1866,7 +1873,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
                                            d_nzcount(b), fst, narrow[b] != 0, tr_a[b], tr_b[b], h_maxsub[b], h_counts[b],
                                            // (the distinct-sized count's retry list: behind the file's oversized list -- a sub-bucket is on one of them at most)
                                            fstream[b] ? d_large + gbase[b] + h_nlarge[b] : d_nz + gbase[b], d_retrycnt + b, file_k96[b] != 0,
-                                           sw.hash_multi, sw.hash_dbg, fstream[b] ? mgc::finish_stream_capacity() : 0));
+                                           sw.hash_multi, sw.hash_dbg, fstream[b] ? mgc::finish_stream_capacity() : 0, hws[hsel], hws_bytes, max_bucket, d_err));
         if (s->profiling) (void)hipEventRecord(fin_ev.back().second, fst);
       } else {
         // a sub-bucket does not fit in LDS (heavily repeated k-mers): finish this file the long way
@@ -1929,6 +1936,18 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     }
 
     if (need_join) { const int jr = huge_join_all(); if (jr != MGC_OK) return jr; }
+    if (sw.finish_trace && hws[0]) {                          // what the LAST sliced file on every streaming stream did (diagnostics)
+      HIP_TRY(s, hipStreamSynchronize(st));
+      for (int i = 0; i < n_huge_streams; i++) {
+        if (!hws[i]) continue;
+        std::vector<uint32_t> w(hws_bytes / 4);
+        HIP_TRY(s, hipMemcpy(w.data(), hws[i], hws_bytes / 4 * 4, hipMemcpyDeviceToHost));
+        const uint32_t max_gig = (uint32_t)(max_bucket / 65536 + 2);
+        uint32_t dense = 0;
+        for (uint32_t q = 0; q < w[0] && q < max_gig; q++) dense += w[64 + 2 * (size_t)max_gig + q] ? 1u : 0u;
+        fprintf(stderr, "[finish] sliced count, stream %d: the last file had %u sub-buckets cut into %u slices; %u of them dense (counted by ranges)\n", i, w[0], w[1], dense);
+      }
+    }
 
     // the sub-buckets hash_count_stream_kernel could not hold (more distinct suffixes than its table: low coverage, D ~ N): their
     // numbers are on the device -- one small copy brings the counts back, the files that have any get the retry launch

@@ -34,6 +34,7 @@ struct Switches {
   uint32_t min_top = 0;         // MGC_FINISH_MIN_TOP: at least that many grouping bits per file (tests reach the large-input plans)
   uint64_t finish_target = 0;   // MGC_FINISH_TARGET: k-mers per sub-bucket the plan aims at (0: the kernels' default)
   uint64_t stream_max = (uint64_t)1 << 22;   // MGC_STREAM_MAX: sub-buckets up to this many keys are streamed without asking the probe
+  bool     huge_slices = true;  // MGC_HUGE_SLICES=0: a gigantic sub-bucket (above 65536 keys) is streamed by ONE workgroup (round 5)
   uint32_t huge_streams = 4;    // MGC_HUGE_STREAMS: streams the streaming kernels of oversized sub-buckets are spread over (1..4)
   uint64_t bucket_bases = 0;    // MGC_BUCKET_BASES: bases per partition bucket above which the partition gets finer (0: default)
 };
@@ -194,7 +195,11 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               bool k96 = false /*d_keys: 12-byte K96 records (key_words 2; oversized sub-buckets only with `stream`)*/,
                               int hash_multi = -1 /*Switches::hash_multi*/, bool hash_dbg = false /*Switches::hash_dbg*/,
                               uint64_t stream_cap = 0 /*nonzero (narrowed dense files, finish_stream_ok): hash_count_stream_kernel counts the
-                              sub-buckets of up to that many keys; the ones with too many distinct suffixes go on d_retry_list*/);
+                              sub-buckets of up to that many keys; the ones with too many distinct suffixes go on d_retry_list*/,
+                              void *d_huge_ws = nullptr, size_t huge_ws_bytes = 0, uint64_t huge_ws_keys = 0, uint32_t *d_error = nullptr /*(d_error: the count's look-back / chain time-out flag) finish_huge_workspace_bytes(huge_ws_keys >= n_keys), one per stream the streaming
+                              kernels run on: with it (8-byte and narrowed keys) a GIGANTIC sub-bucket -- above 65536 keys -- is counted in slices by
+                              many workgroups instead of one*/);
+size_t     finish_huge_workspace_bytes(uint64_t n_keys);
 // the sub-buckets hash_count_stream_kernel put on the retry list (their number is on the device: the caller brings it back first)
 hipError_t launch_finish_retry(void *d_keys32, const uint64_t *d_starts, uint64_t ng, uint32_t low_bits, uint32_t *d_cnt_tmp,
                                uint64_t *d_group_distinct, uint32_t tr_a, uint32_t tr_b, const uint32_t *d_retry_list,

@@ -1601,11 +1601,58 @@ __device__ __forceinline__ void rank_below128(const u64 *dlo, const u64 *dhi, u3
 // passes still need the keys, so multi-pass output goes to alt[] (the sort's second buffer, free at this point) and is
 // copied back at the end.
 // KT = u32: narrowed keys in (launch_group_narrow), distinct suffixes out (u32, no prefix).
-template <typename S, int BLOCK, int CAP, int SLOTS, typename KT = u64>
-__global__ __launch_bounds__(BLOCK)
-void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
-                            u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                            KT *__restrict__ alt, u32 tr_a = 0, u32 tr_b = 0 /* tr_index() of the sub-bucket numbers */) {
+//
+// GIGANTIC sub-buckets, in SLICES (round 6).  One workgroup streams ~0.45 keys per ns; a satellite family (one 171-base unit in 3 % of the
+// genome: sub-buckets of 1.44 M instances of a few hundred distinct k-mers) kept ONE workgroup busy for 3 ms per sub-bucket and the count
+// stage of a 10 Gbp step at 252 ms instead of 25 (profiles/r06_heavy_ab.txt); a human genome's alpha satellites are ten times that.  A
+// sub-bucket above HUGE_SLICE_MIN keys is cut into slices of HUGE_SLICE keys (huge_plan_kernel):
+//   MODE 1  one workgroup per SLICE: the same streaming passes over the slice's keys; the slice's distinct suffixes and their counts go
+//           to alt[] as (suffix, count) pairs, packed behind the other slices' at the sub-bucket's place (a slice whose pairs would
+//           not fit half its keys -- little repeats: a DENSE sub-bucket -- marks the sub-bucket; the keys are untouched);
+//   MODE 2  one workgroup per sub-bucket: the same passes over the PAIRS, every insert adding the pair's count; the result goes in
+//           place (the keys are no longer needed), ascending, as in MODE 0;
+//   MODE 3  a marked (dense) sub-bucket -- the junction of a repeat with unique sequence: 1.75 M keys with 10^5 distinct suffixes, 30
+//           passes of ONE workgroup over all of them, 120 ms -- by HUGE_RANGES workgroups, each streaming all keys and counting one
+//           RANGE of the suffix space; a range's place in the output comes down a chain over the ranges in ascending order (work
+//           items are taken by ticket, so a range's predecessor has always started); outputs go to alt[] (the others still read
+//           the keys) and huge_copy_back_kernel brings them home.
+// MODE 0 skips what the plan has cut (more than huge_max keys in at most HUGE_WMAX slices).
+constexpr u32 HUGE_SLICE = 32768, HUGE_SLICE_MIN = 65536, HUGE_WMAX = 8192, HUGE_RANGES = 64;
+struct HugeSliced {                       // device-side plan of one file's gigantic sub-buckets (huge_plan_kernel writes, MODE 1 / 2 / 3 read)
+  u32 *counters;                          // [0] sub-buckets cut, [1] slices, [2] MODE 3's ticket, [3] MODE 1's ticket
+  u32 *gig_g, *gig_pairs, *gig_fail, *gig_dist;   // per cut sub-bucket: its number, pairs its slices left, 1 = dense (MODE 3), distinct k-mers MODE 3 found
+  u32 *slice_g, *slice_j, *slice_q;       // per slice: sub-bucket, index inside it, index of the cut sub-bucket
+  u64 *chain;                             // [max_gig][HUGE_RANGES]: bit 63 set = the range is done, below: distinct k-mers up to and including it
+  u32 *error;                             // a chain wait that timed out (the count then ends with MGC_ETIMEOUT)
+  u32 max_gig, max_slices;
+};
+__device__ __forceinline__ bool huge_is_cut(u64 n, u64 huge_max) { return huge_max != 0 && n > huge_max && (n + HUGE_SLICE - 1) / HUGE_SLICE <= (u64)HUGE_WMAX; }
+// a cut sub-bucket of n keys: W slices of equal length (no ragged tail: a slice's pairs have to fit half its keys)
+__device__ __forceinline__ u32 huge_slices(u64 n) { return (u32)((n + HUGE_SLICE - 1) / HUGE_SLICE); }
+__device__ __forceinline__ u64 huge_slice_len(u64 n) { const u64 W = huge_slices(n); return (n + W - 1) / W; }
+
+__global__ __launch_bounds__(256)
+void huge_plan_kernel(const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 n_list, u64 huge_max, HugeSliced hs) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_list) return;
+  const u64 g = list[i];
+  const u64 n = starts[g + 1] - starts[g];
+  if (!huge_is_cut(n, huge_max)) return;
+  const u32 W = huge_slices(n);
+  const u32 q = atomicAdd(&hs.counters[0], 1u);
+  const u32 first = atomicAdd(&hs.counters[1], W);
+  if (q >= hs.max_gig || first + W > hs.max_slices) return;            // (sized for the file: cannot happen; the single-workgroup form would be skipped too -- see launch)
+  hs.gig_g[q] = (u32)g;
+  for (u32 j = 0; j < W; j++) { hs.slice_g[first + j] = (u32)g; hs.slice_j[first + j] = j; hs.slice_q[first + j] = q; }
+}
+
+// (the body of the kernel below: `work` = the list entry (MODE 0), the slice item (MODE 1), the cut sub-bucket (MODE 2), the
+// (cut sub-bucket, range) item (MODE 3))
+template <typename S, int BLOCK, int CAP, int SLOTS, typename KT, int MODE>
+__device__ __forceinline__
+void hash_count_huge_body(u32 work, KT *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
+                          u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
+                          KT *__restrict__ alt, u32 tr_a, u32 tr_b, u64 huge_max, const HugeSliced &hs) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && (CAP & (CAP - 1)) == 0 && SLOTS >= CAP * 2 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0,
                 "table geometry");
   constexpr int KPT = 4, SPT = SLOTS / BLOCK;
@@ -1619,16 +1666,69 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
   __shared__ u32 s_tmp[BLOCK / 64 + 1];
   __shared__ u32 s_st[3];                              // distinct in this pass, overflow, round of the overflow
   __shared__ u64 s_split;
+  __shared__ u64 s_base;
   const u32 tid = threadIdx.x;
-  const u64 g = list[blockIdx.x];
-  const u64 a = starts[g], n64 = starts[g + 1] - a;
-  if (n64 <= huge_min) return;
+  u64 g, a, n64;                                       // the sub-bucket, where its keys (MODE 2: pairs) begin, how many of them this workgroup streams
+  u64 a_sub = 0;                                       // MODE 1: where the whole sub-bucket begins
+  u32 cq = 0, rr = 0;                                  // MODE 1 / 2 / 3: the cut sub-bucket; MODE 3: the range
   const u64 low_mask = (low_bits >= 64) ? ~0ull : ((1ull << low_bits) - 1ull);
-  const u64 prefix = (sizeof(KT) == 8) ? ((u64)keys[a] & ~low_mask) : 0ull;   // whole keys: the sub-bucket's first key tells (read before anything is written)
+  u64 range_lo = 0, range_hi = low_mask;               // the suffixes this workgroup counts (MODE 3: one of HUGE_RANGES equal parts)
+  if constexpr (MODE == 0) {
+    g = list[work];
+    a = starts[g]; n64 = starts[g + 1] - a;
+    if (n64 <= huge_min) return;
+    if (huge_is_cut(n64, huge_max)) return;
+  } else if constexpr (MODE == 1) {
+    const u32 item = work;
+    if (item >= hs.counters[1] || item >= hs.max_slices) return;
+    g = hs.slice_g[item]; cq = hs.slice_q[item];
+    a_sub = starts[g];
+    const u64 nall = starts[g + 1] - a_sub, len = huge_slice_len(nall), off = (u64)hs.slice_j[item] * len;
+    a = a_sub + off; n64 = nall - off < len ? nall - off : len;
+  } else if constexpr (MODE == 2) {
+    cq = work;
+    if (cq >= hs.counters[0] || cq >= hs.max_gig || hs.gig_fail[cq]) return;
+    g = hs.gig_g[cq];
+    a = starts[g];
+    n64 = hs.gig_pairs[cq];                             // pairs to stream: alt[a + 2 i], alt[a + 2 i + 1]
+  } else {
+    cq = work / HUGE_RANGES; rr = work % HUGE_RANGES;
+    if (cq >= hs.counters[0] || cq >= hs.max_gig || !hs.gig_fail[cq]) return;
+    g = hs.gig_g[cq];
+    a = starts[g]; n64 = starts[g + 1] - a;
+    // equal parts of the suffix space (a part may be empty when there are fewer suffixes than parts)
+    const unsigned __int128 span = (unsigned __int128)low_mask + 1;
+    range_lo = (u64)((span * rr) / HUGE_RANGES);
+    const u64 next_lo = (u64)((span * (rr + 1)) / HUGE_RANGES);
+    range_hi = next_lo - 1;
+    if (next_lo == range_lo) n64 = 0;                  // (nothing to stream: the chain is still passed on below)
+  }
+  const u64 prefix = (sizeof(KT) == 8 && MODE != 1) ? ((u64)keys[starts[g]] & ~low_mask) : 0ull;   // whole keys: the sub-bucket's first key tells (read before anything is written)
   constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
   KT *gk = keys + a;
   const u64 rounds = (n64 + (u64)BLOCK * KPT - 1) / ((u64)BLOCK * KPT);
-  u64 lo = 0, hi = low_mask;                           // suffix range of this pass, inclusive
+  u64 lo = range_lo, hi = range_hi;                    // suffix range of this pass, inclusive
+  u64 chain_base = 0;                                  // MODE 3: distinct k-mers of the ranges below this one (known from the first emit on)
+  bool chain_known = MODE != 3 || rr == 0;
+  auto chain_wait = [&]() __attribute__((always_inline)) {
+    if constexpr (MODE == 3) {
+      if (chain_known) return;
+      if (tid == 0) {
+        const u64 *c = hs.chain + (u64)cq * HUGE_RANGES + (rr - 1);
+        u64 v = 0;
+        u32 spins = 0;
+        while (!((v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63)) {
+          if (++spins > (1u << 26)) { atomicExch(hs.error, 1u); break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        s_base = v & ~(1ull << 63);
+      }
+      __syncthreads();
+      chain_base = s_base;
+      chain_known = true;
+      __syncthreads();
+    }
+  };
   u64 out = 0;                                         // distinct k-mers written by the passes before
   bool in_place = false;
   for (;;) {
@@ -1636,36 +1736,49 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
     if (tid < 3) s_st[tid] = 0u;
     __syncthreads();
     const u64 span = hi - lo;
+    u64 rd = 0;
+    // MODE 0 / 1 / 3: a stream of n64 keys; MODE 2: of (suffix, count) pairs in alt[] at the sub-bucket's place
+    {
+    const u64 sn = n64;                                                  // items of the stream
+    const KT *src = MODE == 2 ? alt + a : gk;                            // MODE 2: pair i = src[2 i], src[2 i + 1]
     // the keys of the next round are in flight while this one goes through the table (one workgroup per CU: nothing else
     // would hide the memory round trip)
     u64 raw[KPT];
+    u32 rwt[KPT];
 #pragma unroll
-    for (int j = 0; j < KPT; j++) { const u64 idx = (u64)j * BLOCK + tid; raw[j] = (idx < n64) ? (u64)gk[idx] : 0ull; }
-    for (u64 base = 0, rd = 0; base < n64; base += (u64)BLOCK * KPT, rd++) {
+    for (int j = 0; j < KPT; j++) {
+      const u64 idx = (u64)j * BLOCK + tid;
+      if constexpr (MODE == 2) { raw[j] = (idx < sn) ? (u64)src[2 * idx] : 0ull; rwt[j] = (idx < sn) ? (u32)src[2 * idx + 1] : 0u; }
+      else { raw[j] = (idx < sn) ? (u64)src[idx] : 0ull; rwt[j] = 1u; }
+    }
+    for (u64 base = 0; base < sn; base += (u64)BLOCK * KPT, rd++) {
       u64 nxt[KPT];
+      u32 nwt[KPT];
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
         const u64 idx = base + (u64)BLOCK * KPT + (u64)j * BLOCK + tid;
-        nxt[j] = (idx < n64) ? (u64)gk[idx] : 0ull;
+        if constexpr (MODE == 2) { nxt[j] = (idx < sn) ? (u64)src[2 * idx] : 0ull; nwt[j] = (idx < sn) ? (u32)src[2 * idx + 1] : 0u; }
+        else { nxt[j] = (idx < sn) ? (u64)src[idx] : 0ull; nwt[j] = 1u; }
       }
       S   kk[KPT];
       u32 hh[KPT], pending = 0;
+      u32 w[KPT];
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
         const u64 idx = base + (u64)j * BLOCK + tid;
         const u64 sfx = raw[j] & low_mask;
-        raw[j] = nxt[j];
+        w[j] = rwt[j];
+        raw[j] = nxt[j]; rwt[j] = nwt[j];
         kk[j] = (S)sfx;
         hh[j] = (u32)((sfx * 0x9E3779B97F4A7C15ull) >> 32) >> sshift;
-        if (idx < n64 && sfx - lo <= span) pending |= 1u << j;
+        if (idx < sn && sfx - lo <= span) pending |= 1u << j;
       }
       // a heavy k-mer fills whole waves with one suffix, and LDS atomics on one address serialize: lanes holding the
       // same suffix as the first lane not yet looked at become one insert of their number (a few rounds: the first lane
-      // may hold an error variant)
-      u32 w[KPT];
+      // may hold an error variant).  (MODE 2: the pairs of a slice are distinct suffixes: nothing to merge.)
+      if constexpr (MODE != 2) {
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
-        w[j] = 1u;
         u64 rem = __ballot((pending >> j) & 1u);
         for (int it = 0; it < 2 && rem; it++) {        // wave-uniform
           const int leader = __builtin_ctzll(rem);
@@ -1676,6 +1789,7 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
           rem &= ~same;
           if (__popcll(same) >= 8) break;              // that was the heavy one
         }
+      }
       }
       while (pending && !__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
         // all CASes of a trip are issued before the first answer is looked at: their LDS round trips overlap
@@ -1698,6 +1812,7 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
         }
       }
       if (__hip_atomic_load(&s_st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+    }
     }
     __syncthreads();
     const u32 overflowed = s_st[1], at_round = s_st[2];
@@ -1736,9 +1851,25 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
       if ((occ >> j) & 1u) { dk[o] = tk[(u32)j * BLOCK + tid]; dc[o] = tc[(u32)j * BLOCK + tid]; o++; }
     if (tid < 16) dk[D + tid] = EMPTY;
     __syncthreads();
+    u64 emit_at = out;                                  // where this pass's results begin
+    if constexpr (MODE == 1) {
+      // the slice's pairs must fit half its keys (otherwise little repeats -- a dense sub-bucket: MODE 3's): then all slices' pairs fit
+      // the sub-bucket's place in alt[], packed in the order the passes of the slices come by
+      if (2 * (out + D) > n64) { if (tid == 0) hs.gig_fail[cq] = 1u; return; }
+      if (tid == 0) s_base = (u64)atomicAdd(&hs.gig_pairs[cq], D);
+      __syncthreads();
+      emit_at = s_base;
+      __syncthreads();
+    }
+    if constexpr (MODE == 3) { chain_wait(); emit_at = chain_base + out; }
     // one pass over everything: every key of the sub-bucket went through the table, the output can go in place
-    in_place = (lo == 0 && hi == low_mask);
-    KT *dst = in_place ? gk : alt + a;
+    // (MODE 2: always -- the input is the pairs in alt[]; MODE 1: never -- pairs, to alt[]; MODE 3: never -- the other ranges read the keys)
+    in_place = MODE == 2 || (MODE == 0 && lo == 0 && hi == low_mask);
+    KT *dst = MODE == 1 ? alt + a_sub : (in_place ? gk : alt + a);
+    auto emit = [&](u64 r, u64 sfx, u32 c) __attribute__((always_inline)) {
+      if constexpr (MODE == 1) { dst[2 * r] = (KT)sfx; dst[2 * r + 1] = (KT)c; }
+      else { dst[r] = (KT)(prefix | sfx); cnt_tmp[a + r] = c; }
+    };
     if (D > (u32)BLOCK) {
       u32 N = 2 * BLOCK;
       while (N < D) N <<= 1;                           // <= CAP, a power of two
@@ -1747,10 +1878,7 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
       bitonic_sort_lds<BLOCK>(N, [&](u32 x, u32 y) { return dk[x] > dk[y]; },
                               [&](u32 x, u32 y) { const S t = dk[x]; dk[x] = dk[y]; dk[y] = t;
                                                   const u32 c = dc[x]; dc[x] = dc[y]; dc[y] = c; });
-      for (u32 i = tid; i < D; i += BLOCK) {
-        dst[out + i] = (KT)(prefix | (u64)dk[i]);
-        cnt_tmp[a + out + i] = dc[i];
-      }
+      for (u32 i = tid; i < D; i += BLOCK) emit(emit_at + i, (u64)dk[i], dc[i]);
     } else {
       S   ks[IPT];
       u32 rs[IPT];
@@ -1760,24 +1888,58 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
 #pragma unroll
       for (int q = 0; q < IPT; q++) {
         const u32 i = (u32)q * BLOCK + tid;
-        if (i < D) {
-          const u64 r = out + rs[q];
-          dst[r] = (KT)(prefix | (u64)ks[q]);
-          cnt_tmp[a + r] = dc[i];
-        }
+        if (i < D) emit(emit_at + rs[q], (u64)ks[q], dc[i]);
       }
     }
     out += D;
-    if (hi == low_mask) break;
+    if (hi == range_hi) break;
     lo = hi + 1;                                       // next: everything that is left; an overflow will say where to cut
-    hi = low_mask;
+    hi = range_hi;
     __syncthreads();                                   // dk/dc and s_st are reused
+  }
+  if constexpr (MODE == 1) return;
+  if constexpr (MODE == 3) {
+    // pass the chain on: the distinct k-mers up to and including this range; the last range knows the sub-bucket's
+    chain_wait();
+    if (tid == 0) {
+      const u64 total = chain_base + out;
+      __hip_atomic_store(hs.chain + (u64)cq * HUGE_RANGES + rr, total | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (rr == HUGE_RANGES - 1) { hs.gig_dist[cq] = (u32)total; group_distinct[tr_index(g, tr_a, tr_b)] = total; }
+    }
+    return;
   }
   if (!in_place) {
     __syncthreads();                                   // all passes have read the keys; alt[] was written by this workgroup
     for (u64 i = tid; i < out; i += BLOCK) gk[i] = alt[a + i];
   }
   if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = out;
+}
+
+// MODE 0 / 2: one workgroup per list entry / cut sub-bucket.  MODE 1 / 3: the plan lives on the device -- how many slices, how many
+// dense sub-buckets, the host does not know -- so a SMALL grid of workgroups takes work items by ticket until none is left (a launch
+// sized for the worst case was thousands of 1024-thread workgroups with 96 KiB of LDS each that looked at a counter and left: 1 ms per
+// file, profiles/r06_heavy_ab.txt).  MODE 3's chain stays safe: a ticket is only ever held by a running workgroup.
+template <typename S, int BLOCK, int CAP, int SLOTS, typename KT = u64, int MODE = 0>
+__global__ __launch_bounds__(BLOCK)
+void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
+                            u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
+                            KT *__restrict__ alt, u32 tr_a = 0, u32 tr_b = 0 /* tr_index() of the sub-bucket numbers */,
+                            u64 huge_max = 0 /* MODE 0: sub-buckets above it belong to the sliced form */,
+                            HugeSliced hs = HugeSliced()) {
+  if constexpr (MODE == 0 || MODE == 2) {
+    hash_count_huge_body<S, BLOCK, CAP, SLOTS, KT, MODE>(blockIdx.x, keys, starts, list, ng, huge_min, low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, huge_max, hs);
+  } else {
+    __shared__ u32 s_ticket;
+    for (;;) {
+      __syncthreads();                                 // (everything of the item before has left shared memory)
+      if (threadIdx.x == 0) s_ticket = atomicAdd(&hs.counters[MODE == 1 ? 3 : 2], 1u);
+      __syncthreads();
+      const u32 item = s_ticket;
+      const u32 limit = MODE == 1 ? hs.counters[1] : hs.counters[0] * HUGE_RANGES;
+      if (item >= limit) return;
+      hash_count_huge_body<S, BLOCK, CAP, SLOTS, KT, MODE>(item, keys, starts, list, ng, huge_min, low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, huge_max, hs);
+    }
+  }
 }
 
 // The same for 16-byte keys (k >= 33) and 12-byte K96 records: slots are claimed through their count word, lanes of a
@@ -2198,6 +2360,74 @@ static void hash_dbg_report(hipStream_t st, uint64_t ng, bool multi = false) {
   reports++;
 }
 
+// ---- the streaming count of a file's oversized sub-buckets: the plain launch, or -- the file holds a gigantic one and the caller
+// brought a workspace -- plan + slices + merge, the range-parallel form for the dense ones, the single-workgroup form for the rest ----
+size_t finish_huge_workspace_bytes(uint64_t n_keys) {
+  const uint64_t max_gig = n_keys / HUGE_SLICE_MIN + 2, max_slices = n_keys / HUGE_SLICE + max_gig + 2;
+  return 256 + sizeof(u32) * (4 * max_gig + 3 * max_slices) + 8 + sizeof(u64) * max_gig * HUGE_RANGES;
+}
+// MODE 3 left a dense sub-bucket's k-mers in alt[] (its other ranges were still reading the keys): home, now that all of them are done
+template <typename KT>
+__global__ __launch_bounds__(1024)
+void huge_copy_back_kernel(KT *__restrict__ keys, const KT *__restrict__ alt, const u64 *__restrict__ starts, HugeSliced hs) {
+  const u32 q = blockIdx.x;
+  if (q >= hs.counters[0] || q >= hs.max_gig || !hs.gig_fail[q]) return;
+  const u64 a = starts[hs.gig_g[q]];
+  const u32 d = hs.gig_dist[q];
+  for (u32 i = threadIdx.x; i < d; i += 1024) keys[a + i] = alt[a + i];
+}
+template <typename S, int CAP, int SLOTS, typename KT>
+static hipError_t launch_huge(KT *keys, const u64 *starts, const u32 *list, u64 n_large, u64 ng, u64 huge_min, u32 low_bits, u32 *cnt_tmp,
+                              u64 *group_distinct, KT *alt, u32 tr_a, u32 tr_b, size_t smem, hipStream_t st, u64 max_sub, u64 n_keys,
+                              void *ws, size_t ws_bytes, u64 ws_keys, u32 *d_error) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<S, 1024, CAP, SLOTS, KT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<S, 1024, CAP, SLOTS, KT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<S, 1024, CAP, SLOTS, KT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<S, 1024, CAP, SLOTS, KT, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  if (n_large == 0) return hipSuccess;
+  // (the workspace is laid out for ws_keys keys, the largest file of the count: the same layout for every file)
+  const bool sliced = ws && d_error && max_sub > (u64)HUGE_SLICE_MIN && n_keys && n_keys <= ws_keys && ws_bytes >= finish_huge_workspace_bytes(ws_keys);
+  if (!sliced) {
+    hipLaunchKernelGGL((hash_count_huge_kernel<S, 1024, CAP, SLOTS, KT, 0>), dim3((uint32_t)n_large), dim3(1024), smem, st, keys, starts, list, ng, huge_min,
+                       low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, (u64)0, HugeSliced());
+    return hipGetLastError();
+  }
+  HugeSliced hs;
+  hs.max_gig = (u32)(ws_keys / HUGE_SLICE_MIN + 2);
+  hs.max_slices = (u32)(ws_keys / HUGE_SLICE + hs.max_gig + 2);
+  u32 *w = reinterpret_cast<u32 *>(ws);
+  hs.counters = w;
+  hs.gig_g = w + 64; hs.gig_pairs = hs.gig_g + hs.max_gig; hs.gig_fail = hs.gig_pairs + hs.max_gig; hs.gig_dist = hs.gig_fail + hs.max_gig;
+  hs.slice_g = hs.gig_dist + hs.max_gig; hs.slice_j = hs.slice_g + hs.max_slices; hs.slice_q = hs.slice_j + hs.max_slices;
+  hs.chain = reinterpret_cast<u64 *>((reinterpret_cast<uintptr_t>(hs.slice_q + hs.max_slices) + 7) & ~(uintptr_t)7);
+  hs.error = d_error;
+  MGC_CHECK(hipMemsetAsync(ws, 0, finish_huge_workspace_bytes(ws_keys), st));
+  hipLaunchKernelGGL(huge_plan_kernel, dim3((uint32_t)((n_large + 255) / 256)), dim3(256), 0, st, starts, list, n_large, (u64)HUGE_SLICE_MIN, hs);
+  MGC_CHECK(hipGetLastError());
+  const uint32_t sgrid = (uint32_t)std::min<u64>(512, std::min<u64>((u64)hs.max_slices, n_keys / HUGE_SLICE + n_keys / HUGE_SLICE_MIN + 4));   // (by ticket)
+  const uint32_t ggrid = (uint32_t)std::min<u64>(std::min<u64>(n_large, (u64)hs.max_gig), n_keys / HUGE_SLICE_MIN + 1);
+  // the slices first: they are the long pole
+  hipLaunchKernelGGL((hash_count_huge_kernel<S, 1024, CAP, SLOTS, KT, 1>), dim3(sgrid), dim3(1024), smem, st, keys, starts, list, ng, huge_min,
+                     low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, (u64)0, hs);
+  MGC_CHECK(hipGetLastError());
+  hipLaunchKernelGGL((hash_count_huge_kernel<S, 1024, CAP, SLOTS, KT, 0>), dim3((uint32_t)n_large), dim3(1024), smem, st, keys, starts, list, ng, huge_min,
+                     low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, (u64)HUGE_SLICE_MIN, hs);
+  MGC_CHECK(hipGetLastError());
+  hipLaunchKernelGGL((hash_count_huge_kernel<S, 1024, CAP, SLOTS, KT, 2>), dim3(ggrid), dim3(1024), smem, st, keys, starts, list, ng, huge_min,
+                     low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, (u64)0, hs);
+  MGC_CHECK(hipGetLastError());
+  // ... and the dense ones (their slices' pairs did not fit): HUGE_RANGES workgroups each, by ticket; then their k-mers home from alt[]
+  hipLaunchKernelGGL((hash_count_huge_kernel<S, 1024, CAP, SLOTS, KT, 3>), dim3(256), dim3(1024), smem, st, keys, starts, list, ng, huge_min,
+                     low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, (u64)0, hs);
+  MGC_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(huge_copy_back_kernel<KT>, dim3(ggrid), dim3(1024), 0, st, keys, (const KT *)alt, starts, hs);
+  return hipGetLastError();
+}
+
 bool finish_can_stream(uint32_t key_words, uint32_t low_bits) {
   return finish_uses_hash(key_words, low_bits);
 }
@@ -2230,7 +2460,7 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
                               bool stream, void *d_alt, hipStream_t st_huge, const uint32_t *d_nz, const uint64_t *d_nz_count,
                               hipStream_t st, bool narrow, uint32_t tr_a, uint32_t tr_b, uint64_t max_sub, uint64_t n_keys,
                               uint32_t *d_retry_list, uint64_t *d_retry_count, bool k96, int hash_multi, bool hash_dbg,
-                              uint64_t stream_cap) {
+                              uint64_t stream_cap, void *d_huge_ws, size_t huge_ws_bytes, uint64_t huge_ws_keys, uint32_t *d_error) {
   const u64 *nzc = reinterpret_cast<const u64 *>(d_nz_count);
   if (stream_cap && !(d_retry_list && d_retry_count && finish_stream_ok(key_words, low_bits, narrow) && !k96 && n_keys < (1ull << 32) &&
                       stream_cap <= FIN_CAP_STREAM && (n_large == 0 || stream)))
@@ -2366,17 +2596,9 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     MGC_CHECK(hipGetLastError());
     if (n_large) {
       constexpr size_t B32 = (size_t)(4 + 4) * HUGE_SLOTS32 + (size_t)(4 + 4) * HUGE_CAP32 + 16 * 4;
-      static bool nattr = false;
-      if (!nattr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32, u32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)B32);
-        nattr = true;
-      }
-      hipLaunchKernelGGL((hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32, u32>), dim3((uint32_t)n_large), dim3(1024), B32, st_huge,
-                         reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                         (u64)(stream_cap ? stream_cap : FIN_CAP_HASH), low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
-                         reinterpret_cast<u32 *>(d_alt), tr_a, tr_b);
-      MGC_CHECK(hipGetLastError());
+      MGC_CHECK((launch_huge<u32, HUGE_CAP32, HUGE_SLOTS32, u32>(reinterpret_cast<u32 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)n_large,
+                 (u64)ng, (u64)(stream_cap ? stream_cap : FIN_CAP_HASH), low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                 reinterpret_cast<u32 *>(d_alt), tr_a, tr_b, B32, st_huge, (u64)max_sub, (u64)n_keys, d_huge_ws, huge_ws_bytes, (u64)huge_ws_keys, d_error)));
     }
     return hipSuccess;
   }
@@ -2484,27 +2706,16 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
     MGC_CHECK(hipGetLastError());
     if (stream && n_large) {
       // sub-buckets above the small tables: one 1024-thread workgroup each, keys streamed through a large table
-      static bool hattr = false;
       constexpr size_t B32 = (size_t)(4 + 4) * HUGE_SLOTS32 + (size_t)(4 + 4) * HUGE_CAP32 + 16 * 4;
       constexpr size_t B64 = (size_t)(8 + 4) * HUGE_SLOTS64 + (size_t)(8 + 4) * HUGE_CAP64 + 16 * 8;
-      if (!hattr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)B32);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count_huge_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)B64);
-        hattr = true;
-      }
       if (low_bits < 32)
-        hipLaunchKernelGGL((hash_count_huge_kernel<u32, 1024, HUGE_CAP32, HUGE_SLOTS32>), dim3((uint32_t)n_large), dim3(1024), B32, st_huge,
-                           reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           (u64)(stream_cap ? stream_cap : FIN_CAP_HASH), low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
-                           reinterpret_cast<u64 *>(d_alt), tr_a, tr_b);
+        MGC_CHECK((launch_huge<u32, HUGE_CAP32, HUGE_SLOTS32, u64>(reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)n_large,
+                   (u64)ng, (u64)(stream_cap ? stream_cap : FIN_CAP_HASH), low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                   reinterpret_cast<u64 *>(d_alt), tr_a, tr_b, B32, st_huge, (u64)max_sub, (u64)n_keys, d_huge_ws, huge_ws_bytes, (u64)huge_ws_keys, d_error)));
       else
-        hipLaunchKernelGGL((hash_count_huge_kernel<u64, 1024, HUGE_CAP64, HUGE_SLOTS64>), dim3((uint32_t)n_large), dim3(1024), B64, st_huge,
-                           reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           (u64)(stream_cap ? stream_cap : FIN_CAP_HASH), low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
-                           reinterpret_cast<u64 *>(d_alt), tr_a, tr_b);
-      MGC_CHECK(hipGetLastError());
+        MGC_CHECK((launch_huge<u64, HUGE_CAP64, HUGE_SLOTS64, u64>(reinterpret_cast<u64 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)n_large,
+                   (u64)ng, (u64)(stream_cap ? stream_cap : FIN_CAP_HASH), low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
+                   reinterpret_cast<u64 *>(d_alt), tr_a, tr_b, B64, st_huge, (u64)max_sub, (u64)n_keys, d_huge_ws, huge_ws_bytes, (u64)huge_ws_keys, d_error)));
     } else {
       MGC_CHECK((finish_launch<u64, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH, FIN_CAP_LARGE, d_cnt_tmp,
                                              d_group_distinct, st, d_large_list)));
@@ -2707,6 +2918,7 @@ Switches read_switches() {
   sw.stream_max = num("MGC_STREAM_MAX", (uint64_t)1 << 22);
   sw.bucket_bases = num("MGC_BUCKET_BASES", 0);
   sw.huge_streams = (uint32_t)num("MGC_HUGE_STREAMS", 4);
+  sw.huge_slices = !off("MGC_HUGE_SLICES");
   return sw;
 }
 

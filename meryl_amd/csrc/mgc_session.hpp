@@ -81,7 +81,7 @@ struct mgc_session {
   struct Buf { void *p = nullptr; size_t cap = 0; };
   enum { B_PART_WS, B_META, B_X, B_Y, B_SORT_WS, B_RLE_WS, B_UNIQUE, B_COUNTS, B_BLOCKS, B_HPC, B_HPC_WS,
          B_SUBSTART, B_GROUPS, B_GSCAN, B_CNT_TMP, B_LARGE, B_NONEMPTY, B_STAGE0, B_STAGE1, B_TEXT_IN0, B_TEXT_IN1, B_TEXT_WS,
-         B_TEXT_STATE, B_RK, B_RC, B_R2K, B_R2C, B_MERGE_WS, B_SORT_HDRS, B_FINE, B_NARROW_WS, B_Y2, B_Y3, B_Y4, B_NUM };
+         B_TEXT_STATE, B_RK, B_RC, B_R2K, B_R2C, B_MERGE_WS, B_SORT_HDRS, B_FINE, B_NARROW_WS, B_Y2, B_Y3, B_Y4, B_HWS0, B_HWS1, B_HWS2, B_HWS3, B_NUM };
   Buf buf[B_NUM];
   double tr_alloc = 0;                   // seconds inside hipMalloc / hipFree of the arena (MGC_IO_TRACE)
   uint64_t tr_alloc_bytes = 0;

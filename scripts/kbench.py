@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One bench line for another k / read shape than the judged workload (BASELINE configs 3-5, single-GPU legs), in the
 format of bench.py with the `roofline` object of the dominant grouping/sort pass.
-usage: python scripts/kbench.py K [reads] [compress 0|1] [read_len] [repeat_ppm] [label_bits]"""
+usage: python scripts/kbench.py K [reads] [compress 0|1] [read_len] [repeat_ppm] [label_bits] [repeat_unit] [repeat_families]"""
 import json
 import sys
 import time
@@ -15,8 +15,10 @@ compress = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 read_len = int(sys.argv[4]) if len(sys.argv) > 4 else 150
 repeat_ppm = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # e.g. 100000 = 10 % of the genome in repeat families
 label_bits = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+repeat_unit = int(sys.argv[7]) if len(sys.argv) > 7 else 300        # bases per repeat block; families: how many different units (1: one satellite)
+repeat_families = int(sys.argv[8]) if len(sys.argv) > 8 else 1000
 steps = 3
-bases = count.dev_synth_reads(20240917, reads * read_len // 30, 0, reads, read_len, 5000, 100, repeat_ppm=repeat_ppm)
+bases = count.dev_synth_reads(20240917, reads * read_len // 30, 0, reads, read_len, 5000, 100, repeat_ppm=repeat_ppm, repeat_unit=repeat_unit, repeat_families=repeat_families)
 torch.cuda.synchronize()
 cfg = capi.configure(k, reads * read_len, 64 << 30, homopoly_compress=compress, label_size=label_bits, label=5)
 s = count.Session(cfg, 0)

@@ -1499,6 +1499,45 @@ def test_hash_count_stream_kernel_distinct_sized_table(ops, oracle_lib, torch_cu
 
 
 
+@pytest.mark.parametrize("k,min_top,slices", [(21, 16, "1"), (21, 16, "0"), (26, 14, "1"), (31, 16, "1"), (28, 17, "1"), (16, 12, "1")])
+def test_gigantic_subbuckets_are_counted_in_slices(ops, oracle_lib, torch_cuda, monkeypatch, k, min_top, slices):
+    """Round 6: a sub-bucket above 65536 keys (a satellite family: millions of instances of a few hundred k-mers) is cut into slices
+    of <= 32768 keys, every slice counted by its own workgroup into (suffix, count) pairs, the pairs merged by one workgroup
+    (hash_count_huge_kernel MODE 1 / 2, huge_plan_kernel) -- instead of ONE workgroup streaming all of it.  Sub-buckets of 70 K keys
+    with 20 distinct suffixes (three slices), 200 K with 3000 (several passes per slice and in the merge), 66 K of ONE k-mer, 100 K
+    that are all distinct and 300 K with 80 K distinct (DENSE: the slices' pairs do not fit half their keys -- 64 workgroups count a
+    range of the suffix space each, MODE 3, a chain carries the ranges' places, huge_copy_back_kernel brings the result home),
+    40 K (oversized, not cut), next to ordinary reads; narrowed files (k = 16, 21, 26) and whole 8-byte k-mers
+    (k = 28, 31); MGC_HUGE_SLICES=0: round 5's form.  Against the oracle."""
+    from meryl_amd import capi
+    monkeypatch.setenv("MGC_FINISH_MIN_TOP", str(min_top))
+    monkeypatch.setenv("MGC_HUGE_SLICES", slices)
+    rng = np.random.default_rng(k * 7 + min_top)
+    plen = min(k - 1, (6 + min_top + 1) // 2 + 1)          # bases that fix the file and the sub-bucket
+    def cluster(head, n_inst, n_distinct):
+        pre = head + "".join("ACGT"[i] for i in rng.integers(0, 4, plen - len(head)))
+        n_distinct = min(n_distinct, 4 ** (k - plen))
+        tails = set()
+        while len(tails) < n_distinct:
+            tails.add("".join("ACGT"[i] for i in rng.integers(0, 4, k - plen)))
+        tails = sorted(tails)
+        picks = np.concatenate([np.arange(n_distinct), rng.integers(0, n_distinct, max(0, n_inst - n_distinct))])[:n_inst]
+        rng.shuffle(picks)
+        return ".".join(pre + tails[int(i)] for i in picks) + "."
+    reads = oracle_lib.synth_reads(k, 4_000_000, 0, 30_000).tobytes().decode()    # 4.5 Mbases: the fifteen-bit histogram is on
+    text = (cluster("AAC", 70_000, 20) + cluster("ACA", 200_000, 3000) + cluster("ATT", 66_000, 1) + cluster("AGC", 100_000, 100_000)
+            + cluster("CAT", 40_000, 700) + cluster("AAC", 90_000, 5) + cluster("GGT", 300_000, 80_000) + reads)
+    for mode in (0, 1):                                     # forward mode keeps the clusters where they were put
+        cfg = capi.configure(k, len(text), 1 << 30, mode)
+        cfg.use_simple = 0
+        with ops.Session(cfg) as s:
+            s.push_bases(text, end_of_sequence=False)
+            s.count()
+            klo, khi, counts, _ = s.result_wide()
+        whi, wlo, wcn, _ = oracle_lib.count_brute(text, k, mode)
+        assert np.array_equal(klo, wlo) and np.array_equal(khi, whi) and np.array_equal(counts, wcn)
+
+
 def test_k96_file_with_a_subbucket_nothing_streams_is_widened(ops, oracle_lib, torch_cuda, monkeypatch):
     """the per-file K96 selection (12-byte records below the file, k = 33..51) and its widening fallback -- a file that
     holds a sub-bucket above the tables which the streaming kernels may not take (here: larger than MGC_STREAM_MAX with 16-byte
@@ -1567,7 +1606,7 @@ def test_hash_countw_kernel_dense_and_sparse_grids(ops, oracle_lib, torch_cuda, 
 # every count_device switch that is read per call (a process-wide static one cannot vary inside one test process)
 _GRID_SWITCHES = {
     "MGC_NARROW": ["0"], "MGC_FINE_HIST": ["0"], "MGC_WIDE_MSD": ["0"],
-    "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_HASH_STREAM": ["1", "0", "2"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"], "MGC_HUGE_STREAMS": ["1", "2"],
+    "MGC_HASH_MULTI": ["0", "1", "2", "4"], "MGC_HASH_STREAM": ["1", "0", "2"], "MGC_FINISH_NOLIST": ["1"], "MGC_FINISH": ["0"], "MGC_HUGE_STREAMS": ["1", "2"], "MGC_HUGE_SLICES": ["0"],
     "MGC_FINISH_TARGET": ["1", "4", "64", "700"], "MGC_FINISH_MIN_TOP": ["10", "14", "17", "18"], "MGC_STREAM_MAX": ["2000", "20000"],
     "MGC_BUCKET_BASES": ["3000", "40000"], "MGC_HPC_MSD": ["0"], "MGC_SOA5": ["0"], "MGC_K96": ["0"], "MGC_KMER_CONST_K": ["0"],
 }
