@@ -49,7 +49,7 @@ constexpr int      KP_TILE        = KP_BLOCK * KP_ITEMS; // 4096 starts per tile
 constexpr int      KP_MAX_BUCKETS = 1024;
 
 // Persistent grid size used by both passes (they must agree).
-uint32_t kp_grid_size(uint64_t n_bases);
+uint32_t kp_grid_size(uint64_t n_bases, uint32_t bucket_bits);   // rows of the per-workgroup histogram (virtual workgroups)
 size_t   kp_workspace_bytes(uint32_t bucket_bits);
 
 // sfx_mask / sfx_test: count-suffix= filter, a k-mer is kept iff (its low word & sfx_mask) == sfx_test (0, 0: keep all)

@@ -1618,11 +1618,15 @@ __device__ __forceinline__ void rank_below128(const u64 *dlo, const u64 *dhi, u3
 //           the keys) and huge_copy_back_kernel brings them home.
 // MODE 0 skips what the plan has cut (more than huge_max keys in at most HUGE_WMAX slices).
 constexpr u32 HUGE_SLICE = 32768, HUGE_SLICE_MIN = 65536, HUGE_WMAX = 8192, HUGE_RANGES = 64;
+// a slice with more distinct suffixes than 1/8 of its keys marks the sub-bucket DENSE: the merge of the pairs is ONE workgroup's work,
+// it has to stay small (with 1/2: 1.3 ms per launch at k = 31, profiles/r06_heavy_ab.txt)
+constexpr u32 HUGE_DENSE_DIV = 8;
 struct HugeSliced {                       // device-side plan of one file's gigantic sub-buckets (huge_plan_kernel writes, MODE 1 / 2 / 3 read)
   u32 *counters;                          // [0] sub-buckets cut, [1] slices, [2] MODE 3's ticket, [3] MODE 1's ticket
   u32 *gig_g, *gig_pairs, *gig_fail, *gig_dist;   // per cut sub-bucket: its number, pairs its slices left, 1 = dense (MODE 3), distinct k-mers MODE 3 found
   u32 *slice_g, *slice_j, *slice_q;       // per slice: sub-bucket, index inside it, index of the cut sub-bucket
   u64 *chain;                             // [max_gig][HUGE_RANGES]: bit 63 set = the range is done, below: distinct k-mers up to and including it
+  u64 *split;                             // [max_gig][HUGE_RANGES][2]: the largest suffix of a range (low, high word) -- quantiles of a sample (huge_split_kernel)
   u32 *error;                             // a chain wait that timed out (the count then ends with MGC_ETIMEOUT)
   u32 max_gig, max_slices;
 };
@@ -1632,7 +1636,8 @@ __device__ __forceinline__ u32 huge_slices(u64 n) { return (u32)((n + HUGE_SLICE
 __device__ __forceinline__ u64 huge_slice_len(u64 n) { const u64 W = huge_slices(n); return (n + W - 1) / W; }
 
 __global__ __launch_bounds__(256)
-void huge_plan_kernel(const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 n_list, u64 huge_max, HugeSliced hs) {
+void huge_plan_kernel(const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 n_list, u64 huge_max, HugeSliced hs,
+                      u32 mark_dense = 0 /* 16-byte keys: every cut sub-bucket is counted by ranges (MODE 3), no slices */) {
   const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_list) return;
   const u64 g = list[i];
@@ -1643,7 +1648,52 @@ void huge_plan_kernel(const u64 *__restrict__ starts, const u32 *__restrict__ li
   const u32 first = atomicAdd(&hs.counters[1], W);
   if (q >= hs.max_gig || first + W > hs.max_slices) return;            // (sized for the file: cannot happen; the single-workgroup form would be skipped too -- see launch)
   hs.gig_g[q] = (u32)g;
+  if (mark_dense) { hs.gig_fail[q] = 1u; return; }
   for (u32 j = 0; j < W; j++) { hs.slice_g[first + j] = (u32)g; hs.slice_j[first + j] = j; hs.slice_q[first + j] = q; }
+}
+
+// The ranges of MODE 3 are QUANTILES of a sample, not equal parts of the suffix space: the suffixes of a sub-bucket cluster (the k-mers
+// at a repeat's edge share their first p bases: at k = 51 all 10^5 distinct suffixes of such a sub-bucket lie in 4^-20 of the space, i.e.
+// in ONE of 64 equal parts -- the first form of MODE 3 left one workgroup with all the work: 30 ms per launch, profiles/r06_heavy_ab.txt).
+// One workgroup per dense sub-bucket: HUGE_SAMPLE suffixes at equal strides, bitonic sort in LDS, every (HUGE_SAMPLE / HUGE_RANGES)-th
+// one is the largest suffix of its range; the last range ends at the mask.  Equal splitters (a heavy k-mer) make empty ranges.
+constexpr u32 HUGE_SAMPLE = 4096;
+__device__ __forceinline__ u128 huge_suffix128(u32 k, u128 m) { return (u128)k & m; }
+__device__ __forceinline__ u128 huge_suffix128(u64 k, u128 m) { return (u128)k & m; }
+__device__ __forceinline__ u128 huge_suffix128(const K128 &k, u128 m) { return KeyOps<K128>::v(k) & m; }
+__device__ __forceinline__ u128 huge_suffix128(const K96 &k, u128 m) { return KeyOps<K96>::v(k) & m; }
+template <typename KT>
+__global__ __launch_bounds__(1024)
+void huge_split_kernel(const KT *__restrict__ keys, const u64 *__restrict__ starts, u32 low_bits, HugeSliced hs) {
+  __shared__ u64 slo[HUGE_SAMPLE], shi[HUGE_SAMPLE];
+  const u32 q = blockIdx.x;
+  if (q >= hs.counters[0] || q >= hs.max_gig || !hs.gig_fail[q]) return;
+  const u64 g = hs.gig_g[q], a = starts[g], n = starts[g + 1] - a;
+  const u128 low_mask = (low_bits >= 128) ? ~(u128)0 : (((u128)1 << low_bits) - 1);
+  for (u32 i = threadIdx.x; i < HUGE_SAMPLE; i += 1024) {
+    const u64 idx = (u64)(((u128)i * n) / HUGE_SAMPLE);
+    const u128 sfx = huge_suffix128(keys[a + idx], low_mask);
+    slo[i] = (u64)sfx; shi[i] = (u64)(sfx >> 64);
+  }
+  __syncthreads();
+  bitonic_sort_lds<1024>(HUGE_SAMPLE, [&](u32 x, u32 y) { return shi[x] > shi[y] || (shi[x] == shi[y] && slo[x] > slo[y]); },
+                         [&](u32 x, u32 y) { const u64 t = slo[x]; slo[x] = slo[y]; slo[y] = t; const u64 h = shi[x]; shi[x] = shi[y]; shi[y] = h; });
+  if (threadIdx.x < HUGE_RANGES) {
+    const u32 r = threadIdx.x;
+    u64 *o = hs.split + ((u64)q * HUGE_RANGES + r) * 2;
+    if (r == HUGE_RANGES - 1) { o[0] = (u64)low_mask; o[1] = (u64)(low_mask >> 64); }
+    else { const u32 i = (r + 1) * (HUGE_SAMPLE / HUGE_RANGES) - 1; o[0] = slo[i]; o[1] = shi[i]; }
+  }
+}
+// range r of cut sub-bucket q: [lo, hi] inclusive; false: empty
+__device__ __forceinline__ bool huge_range(const HugeSliced &hs, u32 q, u32 r, u128 &lo, u128 &hi) {
+  const u64 *o = hs.split + ((u64)q * HUGE_RANGES + r) * 2;
+  hi = ((u128)o[1] << 64) | (u128)o[0];
+  if (r == 0) { lo = 0; return true; }
+  const u128 prev = ((u128)o[-1] << 64) | (u128)o[-2];
+  if (prev >= hi) return false;
+  lo = prev + 1;
+  return true;
 }
 
 // (the body of the kernel below: `work` = the list entry (MODE 0), the slice item (MODE 1), the cut sub-bucket (MODE 2), the
@@ -1696,12 +1746,10 @@ void hash_count_huge_body(u32 work, KT *__restrict__ keys, const u64 *__restrict
     if (cq >= hs.counters[0] || cq >= hs.max_gig || !hs.gig_fail[cq]) return;
     g = hs.gig_g[cq];
     a = starts[g]; n64 = starts[g + 1] - a;
-    // equal parts of the suffix space (a part may be empty when there are fewer suffixes than parts)
-    const unsigned __int128 span = (unsigned __int128)low_mask + 1;
-    range_lo = (u64)((span * rr) / HUGE_RANGES);
-    const u64 next_lo = (u64)((span * (rr + 1)) / HUGE_RANGES);
-    range_hi = next_lo - 1;
-    if (next_lo == range_lo) n64 = 0;                  // (nothing to stream: the chain is still passed on below)
+    // the range: between two quantiles of the sub-bucket's sample (huge_split_kernel); an empty one still passes the chain on
+    u128 rl, rh;
+    if (huge_range(hs, cq, rr, rl, rh)) { range_lo = (u64)rl; range_hi = (u64)rh; }
+    else { range_lo = 1; range_hi = 0; n64 = 0; }
   }
   const u64 prefix = (sizeof(KT) == 8 && MODE != 1) ? ((u64)keys[starts[g]] & ~low_mask) : 0ull;   // whole keys: the sub-bucket's first key tells (read before anything is written)
   constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
@@ -1709,7 +1757,7 @@ void hash_count_huge_body(u32 work, KT *__restrict__ keys, const u64 *__restrict
   const u64 rounds = (n64 + (u64)BLOCK * KPT - 1) / ((u64)BLOCK * KPT);
   u64 lo = range_lo, hi = range_hi;                    // suffix range of this pass, inclusive
   u64 chain_base = 0;                                  // MODE 3: distinct k-mers of the ranges below this one (known from the first emit on)
-  bool chain_known = MODE != 3 || rr == 0;
+  bool chain_known = MODE != 3 || rr == 0, chain_sent = false;
   auto chain_wait = [&]() __attribute__((always_inline)) {
     if constexpr (MODE == 3) {
       if (chain_known) return;
@@ -1855,13 +1903,21 @@ void hash_count_huge_body(u32 work, KT *__restrict__ keys, const u64 *__restrict
     if constexpr (MODE == 1) {
       // the slice's pairs must fit half its keys (otherwise little repeats -- a dense sub-bucket: MODE 3's): then all slices' pairs fit
       // the sub-bucket's place in alt[], packed in the order the passes of the slices come by
-      if (2 * (out + D) > n64) { if (tid == 0) hs.gig_fail[cq] = 1u; return; }
+      if (HUGE_DENSE_DIV * (out + D) > n64) { if (tid == 0) hs.gig_fail[cq] = 1u; return; }
       if (tid == 0) s_base = (u64)atomicAdd(&hs.gig_pairs[cq], D);
       __syncthreads();
       emit_at = s_base;
       __syncthreads();
     }
-    if constexpr (MODE == 3) { chain_wait(); emit_at = chain_base + out; }
+    if constexpr (MODE == 3) {
+      chain_wait(); emit_at = chain_base + out;
+      // the range's LAST pass: its total is known before anything is sorted or written -- the chain moves on now, the next ranges
+      // do not wait for this one's sort and stores (published at the end, the chain was 64 sorts long: 4 ms per dense sub-bucket)
+      if (hi == range_hi && !chain_sent) {
+        if (tid == 0) __hip_atomic_store(hs.chain + (u64)cq * HUGE_RANGES + rr, (chain_base + out + D) | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        chain_sent = true;
+      }
+    }
     // one pass over everything: every key of the sub-bucket went through the table, the output can go in place
     // (MODE 2: always -- the input is the pairs in alt[]; MODE 1: never -- pairs, to alt[]; MODE 3: never -- the other ranges read the keys)
     in_place = MODE == 2 || (MODE == 0 && lo == 0 && hi == low_mask);
@@ -1903,7 +1959,7 @@ void hash_count_huge_body(u32 work, KT *__restrict__ keys, const u64 *__restrict
     chain_wait();
     if (tid == 0) {
       const u64 total = chain_base + out;
-      __hip_atomic_store(hs.chain + (u64)cq * HUGE_RANGES + rr, total | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!chain_sent) __hip_atomic_store(hs.chain + (u64)cq * HUGE_RANGES + rr, total | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (rr == HUGE_RANGES - 1) { hs.gig_dist[cq] = (u32)total; group_distinct[tr_index(g, tr_a, tr_b)] = total; }
     }
     return;
@@ -1944,11 +2000,14 @@ void hash_count_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ start
 
 // The same for 16-byte keys (k >= 33) and 12-byte K96 records: slots are claimed through their count word, lanes of a
 // wave that hold the first active lane's suffix are merged into one weighted insert, ranges are 128-bit.
-template <int BLOCK, int CAP, int SLOTS, bool WIDE, typename KT = K128>   // KT: K128, or 12-byte K96 records
-__global__ __launch_bounds__(BLOCK)
-void hash_count128_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
-                               u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
-                               KT *__restrict__ alt, u32 tr_a = 0, u32 tr_b = 0) {
+// MODE 1 / 2 / 3 (round 6): a GIGANTIC sub-bucket (above HUGE_SLICE_MIN keys: huge_plan_kernel cuts it, MODE 0 leaves it alone) in slices
+// + merge, the dense ones by HUGE_RANGES workgroups over quantile ranges of the suffix space -- hash_count_huge_kernel's three modes
+// with 128-bit suffixes; a (suffix, count) pair is two records in alt[].
+template <int BLOCK, int CAP, int SLOTS, bool WIDE, typename KT, int MODE>   // KT: K128, or 12-byte K96 records
+__device__ __forceinline__
+void hash_count128_huge_body(u32 work, KT *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
+                             u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
+                             KT *__restrict__ alt, u32 tr_a, u32 tr_b, u64 huge_max, const HugeSliced &hs) {
   static_assert((SLOTS & (SLOTS - 1)) == 0 && SLOTS >= CAP * 2 && SLOTS % BLOCK == 0 && CAP % BLOCK == 0, "table geometry");
   constexpr int KPT = 2, SPT = SLOTS / BLOCK;
   constexpr u32 LOCK = 0xFFFFFFFFu;
@@ -1963,33 +2022,89 @@ void hash_count128_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ st
   __shared__ u32 s_tmp[BLOCK / 64 + 1];
   __shared__ u32 s_st[3];                              // distinct in this pass, overflow, round of the overflow
   __shared__ u64 s_split[2];
+  __shared__ u64 s_base;
   using KO = KeyOps<KT>;
   const u32 tid = threadIdx.x;
-  const u64 g = list[blockIdx.x];
-  const u64 a = starts[g], n64 = starts[g + 1] - a;
-  if (n64 <= huge_min) return;
   const u128 low_mask = (low_bits >= 128) ? ~(u128)0 : (((u128)1 << low_bits) - 1);
-  const u128 prefix = KO::v(keys[a]) & ~low_mask;
+  u64 g, a, n64;
+  u64 a_sub = 0;                                       // MODE 1: where the whole sub-bucket begins
+  u32 cq = 0, rr = 0;                                  // MODE 1 / 2 / 3: the cut sub-bucket; MODE 3: the range
+  u128 range_lo = 0, range_hi = low_mask;
+  if constexpr (MODE == 0) {
+    g = list[work];
+    a = starts[g]; n64 = starts[g + 1] - a;
+    if (n64 <= huge_min) return;
+    if (huge_is_cut(n64, huge_max)) return;
+  } else if constexpr (MODE == 1) {                    // a slice: (suffix, count) pairs -- two records each -- to alt[], packed per sub-bucket
+    if (work >= hs.counters[1] || work >= hs.max_slices) return;
+    g = hs.slice_g[work]; cq = hs.slice_q[work];
+    a_sub = starts[g];
+    const u64 nall = starts[g + 1] - a_sub, len = huge_slice_len(nall), off = (u64)hs.slice_j[work] * len;
+    a = a_sub + off; n64 = nall - off < len ? nall - off : len;
+  } else if constexpr (MODE == 2) {                    // the merge of a sub-bucket's pairs
+    cq = work;
+    if (cq >= hs.counters[0] || cq >= hs.max_gig || hs.gig_fail[cq]) return;
+    g = hs.gig_g[cq];
+    a = starts[g];
+    n64 = hs.gig_pairs[cq];
+  } else {
+    cq = work / HUGE_RANGES; rr = work % HUGE_RANGES;
+    if (cq >= hs.counters[0] || cq >= hs.max_gig || !hs.gig_fail[cq]) return;
+    g = hs.gig_g[cq];
+    a = starts[g]; n64 = starts[g + 1] - a;
+    // the range: between two quantiles of the sub-bucket's sample (huge_split_kernel); an empty one still passes the chain on
+    if (!huge_range(hs, cq, rr, range_lo, range_hi)) { range_lo = 1; range_hi = 0; n64 = 0; }
+  }
+  const u128 prefix = MODE == 1 ? (u128)0 : (KO::v(keys[starts[g]]) & ~low_mask);
   constexpr u32 smask = SLOTS - 1, sshift = 32 - __builtin_ctz((unsigned)SLOTS);
   KT *gk = keys + a;
   const u64 rounds = (n64 + (u64)BLOCK * KPT - 1) / ((u64)BLOCK * KPT);
-  u128 lo = 0, hi = low_mask;                          // suffix range of this pass, inclusive
+  u128 lo = range_lo, hi = range_hi;                   // suffix range of this pass, inclusive
   u64 out = 0;
   bool in_place = false;
+  u64 chain_base = 0;                                  // MODE 3: distinct k-mers of the ranges below this one
+  bool chain_known = MODE != 3 || rr == 0, chain_sent = false;
+  auto chain_wait = [&]() __attribute__((always_inline)) {
+    if constexpr (MODE == 3) {
+      if (chain_known) return;
+      if (tid == 0) {
+        const u64 *c = hs.chain + (u64)cq * HUGE_RANGES + (rr - 1);
+        u64 v = 0;
+        u32 spins = 0;
+        while (!((v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63)) {
+          if (++spins > (1u << 26)) { atomicExch(hs.error, 1u); break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        s_base = v & ~(1ull << 63);
+      }
+      __syncthreads();
+      chain_base = s_base;
+      chain_known = true;
+      __syncthreads();
+    }
+  };
   for (;;) {
     for (u32 i = tid; i < (u32)SLOTS; i += BLOCK) tc[i] = 0u;
     if (tid < 3) s_st[tid] = 0u;
     __syncthreads();
     const u128 span = hi - lo;
+    const KT *src = MODE == 2 ? alt + a : gk;         // MODE 2: pair i = src[2 i] (the suffix), src[2 i + 1] (its count)
     KT raw[KPT];                                     // next round's keys in flight while this one goes through the table
+    u32 rwt[KPT];
 #pragma unroll
-    for (int j = 0; j < KPT; j++) { const u64 idx = (u64)j * BLOCK + tid; if (idx < n64) raw[j] = gk[idx]; else raw[j] = KO::zero(); }
+    for (int j = 0; j < KPT; j++) {
+      const u64 idx = (u64)j * BLOCK + tid;
+      raw[j] = KO::zero(); rwt[j] = 1u;
+      if (idx < n64) { if constexpr (MODE == 2) { raw[j] = src[2 * idx]; rwt[j] = (u32)KO::v(src[2 * idx + 1]); } else raw[j] = src[idx]; }
+    }
     for (u64 base = 0, rd = 0; base < n64; base += (u64)BLOCK * KPT, rd++) {
       KT nxt[KPT];
+      u32 nwt[KPT];
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
         const u64 idx = base + (u64)BLOCK * KPT + (u64)j * BLOCK + tid;
-        if (idx < n64) nxt[j] = gk[idx]; else nxt[j] = KO::zero();
+        nxt[j] = KO::zero(); nwt[j] = 1u;
+        if (idx < n64) { if constexpr (MODE == 2) { nxt[j] = src[2 * idx]; nwt[j] = (u32)KO::v(src[2 * idx + 1]); } else nxt[j] = src[idx]; }
       }
       u64 klo[KPT], khi[KPT];
       u32 hh[KPT], w[KPT], pending = 0;
@@ -1997,15 +2112,16 @@ void hash_count128_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ st
       for (int j = 0; j < KPT; j++) {
         const u64 idx = base + (u64)j * BLOCK + tid;
         const u128 sfx = KO::v(raw[j]) & low_mask;
-        raw[j] = nxt[j];
+        w[j] = rwt[j];
+        raw[j] = nxt[j]; rwt[j] = nwt[j];
         klo[j] = (u64)sfx; khi[j] = (u64)(sfx >> 64);
         const u64 mix = (klo[j] ^ (khi[j] * 0xD6E8FEB86659FD93ull)) * 0x9E3779B97F4A7C15ull;
         hh[j] = (u32)(mix >> 32) >> sshift;
-        w[j] = 1u;
         if (idx < n64 && sfx - lo <= span) pending |= 1u << j;
       }
       // a heavy k-mer fills whole waves with one suffix: the lanes holding the first active lane's suffix become one
-      // insert of their number
+      // insert of their number (MODE 2: the pairs of a slice are distinct suffixes -- little to merge)
+      if constexpr (MODE != 2)
 #pragma unroll
       for (int j = 0; j < KPT; j++) {
         u64 rem = __ballot((pending >> j) & 1u);
@@ -2088,8 +2204,27 @@ void hash_count128_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ st
     }
     if (tid < 16) { dlo[D + tid] = ~0ull; if (WIDE) dhi[D + tid] = ~0ull; }
     __syncthreads();
-    in_place = (lo == 0 && hi == low_mask);
-    KT *dst = in_place ? gk : alt + a;
+    u64 emit_at = out;
+    if constexpr (MODE == 1) {
+      if (HUGE_DENSE_DIV * (out + D) > n64) { if (tid == 0) hs.gig_fail[cq] = 1u; return; }
+      if (tid == 0) s_base = (u64)atomicAdd(&hs.gig_pairs[cq], D);
+      __syncthreads();
+      emit_at = s_base;
+      __syncthreads();
+    }
+    if constexpr (MODE == 3) {
+      chain_wait(); emit_at = chain_base + out;
+      if (hi == range_hi && !chain_sent) {             // (the range's last pass: the chain moves on before the sort and the stores)
+        if (tid == 0) __hip_atomic_store(hs.chain + (u64)cq * HUGE_RANGES + rr, (chain_base + out + D) | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        chain_sent = true;
+      }
+    }
+    in_place = MODE == 2 || (MODE == 0 && lo == 0 && hi == low_mask);
+    KT *dst = MODE == 1 ? alt + a_sub : (in_place ? gk : alt + a);
+    auto emit = [&](u64 r, u128 sfx, u32 c) __attribute__((always_inline)) {
+      if constexpr (MODE == 1) { dst[2 * r] = KO::mk(sfx); dst[2 * r + 1] = KO::mk((u128)c); }
+      else { dst[r] = KO::mk(prefix | sfx); cnt_tmp[a + r] = c; }
+    };
     if (D > (u32)BLOCK) {
       u32 N = 2 * BLOCK;
       while (N < D) N <<= 1;
@@ -2101,8 +2236,7 @@ void hash_count128_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ st
                                                   if (WIDE) { const u64 h = dhi[x]; dhi[x] = dhi[y]; dhi[y] = h; }
                                                   const u32 c = dc[x]; dc[x] = dc[y]; dc[y] = c; });
       for (u32 i = tid; i < D; i += BLOCK) {
-        dst[out + i] = KO::mk(prefix | ((u128)(WIDE ? dhi[i] : 0ull) << 64) | (u128)dlo[i]);
-        cnt_tmp[a + out + i] = dc[i];
+        emit(emit_at + i, ((u128)(WIDE ? dhi[i] : 0ull) << 64) | (u128)dlo[i], dc[i]);
       }
     } else {
       u64 kl[IPT], kh[IPT];
@@ -2117,22 +2251,51 @@ void hash_count128_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ st
       for (int q = 0; q < IPT; q++) {
         const u32 i = (u32)q * BLOCK + tid;
         if (i < D) {
-          dst[out + rs[q]] = KO::mk(prefix | ((u128)kh[q] << 64) | (u128)kl[q]);
-          cnt_tmp[a + out + rs[q]] = dc[i];
+          emit(emit_at + rs[q], ((u128)kh[q] << 64) | (u128)kl[q], dc[i]);
         }
       }
     }
     out += D;
-    if (hi == low_mask) break;
+    if (hi == range_hi) break;
     lo = hi + 1;
-    hi = low_mask;
+    hi = range_hi;
     __syncthreads();
+  }
+  if constexpr (MODE == 1) return;
+  if constexpr (MODE == 3) {
+    chain_wait();
+    if (tid == 0) {
+      const u64 total = chain_base + out;
+      if (!chain_sent) __hip_atomic_store(hs.chain + (u64)cq * HUGE_RANGES + rr, total | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (rr == HUGE_RANGES - 1) { hs.gig_dist[cq] = (u32)total; group_distinct[tr_index(g, tr_a, tr_b)] = total; }
+    }
+    return;
   }
   if (!in_place) {
     __syncthreads();
     for (u64 i = tid; i < out; i += BLOCK) gk[i] = alt[a + i];
   }
   if (tid == 0) group_distinct[tr_index(g, tr_a, tr_b)] = out;
+}
+
+template <int BLOCK, int CAP, int SLOTS, bool WIDE, typename KT = K128, int MODE = 0>
+__global__ __launch_bounds__(BLOCK)
+void hash_count128_huge_kernel(KT *__restrict__ keys, const u64 *__restrict__ starts, const u32 *__restrict__ list, u64 ng,
+                               u64 huge_min, u32 low_bits, u32 *__restrict__ cnt_tmp, u64 *__restrict__ group_distinct,
+                               KT *__restrict__ alt, u32 tr_a = 0, u32 tr_b = 0, u64 huge_max = 0, HugeSliced hs = HugeSliced()) {
+  if constexpr (MODE == 0 || MODE == 2) {
+    hash_count128_huge_body<BLOCK, CAP, SLOTS, WIDE, KT, MODE>(blockIdx.x, keys, starts, list, ng, huge_min, low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, huge_max, hs);
+  } else {
+    __shared__ u32 s_ticket;
+    for (;;) {                                         // work by ticket from a small grid (hash_count_huge_kernel)
+      __syncthreads();
+      if (threadIdx.x == 0) s_ticket = atomicAdd(&hs.counters[MODE == 1 ? 3 : 2], 1u);
+      __syncthreads();
+      const u32 item = s_ticket;
+      if (item >= (MODE == 1 ? hs.counters[1] : hs.counters[0] * HUGE_RANGES)) return;
+      hash_count128_huge_body<BLOCK, CAP, SLOTS, WIDE, KT, MODE>(item, keys, starts, list, ng, huge_min, low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, huge_max, hs);
+    }
+  }
 }
 
 // Would the distinct suffixes of every sub-bucket above huge_min fit the hash-count tables?  One workgroup per entry of the
@@ -2364,7 +2527,7 @@ static void hash_dbg_report(hipStream_t st, uint64_t ng, bool multi = false) {
 // brought a workspace -- plan + slices + merge, the range-parallel form for the dense ones, the single-workgroup form for the rest ----
 size_t finish_huge_workspace_bytes(uint64_t n_keys) {
   const uint64_t max_gig = n_keys / HUGE_SLICE_MIN + 2, max_slices = n_keys / HUGE_SLICE + max_gig + 2;
-  return 256 + sizeof(u32) * (4 * max_gig + 3 * max_slices) + 8 + sizeof(u64) * max_gig * HUGE_RANGES;
+  return 256 + sizeof(u32) * (4 * max_gig + 3 * max_slices) + 8 + sizeof(u64) * max_gig * HUGE_RANGES * 3;
 }
 // MODE 3 left a dense sub-bucket's k-mers in alt[] (its other ranges were still reading the keys): home, now that all of them are done
 template <typename KT>
@@ -2404,9 +2567,10 @@ static hipError_t launch_huge(KT *keys, const u64 *starts, const u32 *list, u64 
   hs.gig_g = w + 64; hs.gig_pairs = hs.gig_g + hs.max_gig; hs.gig_fail = hs.gig_pairs + hs.max_gig; hs.gig_dist = hs.gig_fail + hs.max_gig;
   hs.slice_g = hs.gig_dist + hs.max_gig; hs.slice_j = hs.slice_g + hs.max_slices; hs.slice_q = hs.slice_j + hs.max_slices;
   hs.chain = reinterpret_cast<u64 *>((reinterpret_cast<uintptr_t>(hs.slice_q + hs.max_slices) + 7) & ~(uintptr_t)7);
+  hs.split = hs.chain + (size_t)hs.max_gig * HUGE_RANGES;
   hs.error = d_error;
   MGC_CHECK(hipMemsetAsync(ws, 0, finish_huge_workspace_bytes(ws_keys), st));
-  hipLaunchKernelGGL(huge_plan_kernel, dim3((uint32_t)((n_large + 255) / 256)), dim3(256), 0, st, starts, list, n_large, (u64)HUGE_SLICE_MIN, hs);
+  hipLaunchKernelGGL(huge_plan_kernel, dim3((uint32_t)((n_large + 255) / 256)), dim3(256), 0, st, starts, list, n_large, (u64)HUGE_SLICE_MIN, hs, 0u);
   MGC_CHECK(hipGetLastError());
   const uint32_t sgrid = (uint32_t)std::min<u64>(512, std::min<u64>((u64)hs.max_slices, n_keys / HUGE_SLICE + n_keys / HUGE_SLICE_MIN + 4));   // (by ticket)
   const uint32_t ggrid = (uint32_t)std::min<u64>(std::min<u64>(n_large, (u64)hs.max_gig), n_keys / HUGE_SLICE_MIN + 1);
@@ -2420,9 +2584,67 @@ static hipError_t launch_huge(KT *keys, const u64 *starts, const u32 *list, u64 
   hipLaunchKernelGGL((hash_count_huge_kernel<S, 1024, CAP, SLOTS, KT, 2>), dim3(ggrid), dim3(1024), smem, st, keys, starts, list, ng, huge_min,
                      low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, (u64)0, hs);
   MGC_CHECK(hipGetLastError());
-  // ... and the dense ones (their slices' pairs did not fit): HUGE_RANGES workgroups each, by ticket; then their k-mers home from alt[]
+  // ... and the dense ones (their slices' pairs did not fit): quantiles of a sample, HUGE_RANGES workgroups each, by ticket; then their k-mers home from alt[]
+  hipLaunchKernelGGL(huge_split_kernel<KT>, dim3(ggrid), dim3(1024), 0, st, (const KT *)keys, starts, low_bits, hs);
+  MGC_CHECK(hipGetLastError());
   hipLaunchKernelGGL((hash_count_huge_kernel<S, 1024, CAP, SLOTS, KT, 3>), dim3(256), dim3(1024), smem, st, keys, starts, list, ng, huge_min,
                      low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, (u64)0, hs);
+  MGC_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(huge_copy_back_kernel<KT>, dim3(ggrid), dim3(1024), 0, st, keys, (const KT *)alt, starts, hs);
+  return hipGetLastError();
+}
+
+// the same for 16-byte keys / K96 records (a pair = two records: the suffix, the count)
+template <bool WIDE, typename KT>
+static hipError_t launch_huge128(KT *keys, const u64 *starts, const u32 *list, u64 n_large, u64 ng, u64 huge_min, u32 low_bits, u32 *cnt_tmp,
+                                 u64 *group_distinct, KT *alt, u32 tr_a, u32 tr_b, hipStream_t st, u64 max_sub, u64 n_keys,
+                                 void *ws, size_t ws_bytes, u64 ws_keys, u32 *d_error) {
+  constexpr int HS = 4096, HC = 2048;
+  constexpr size_t smem = WIDE ? (size_t)(8 + 8 + 4) * HS + (size_t)(8 + 8) * (HC + 16) + (size_t)4 * HC
+                               : (size_t)(8 + 4) * HS + (size_t)8 * (HC + 16) + (size_t)4 * HC;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count128_huge_kernel<1024, HC, HS, WIDE, KT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count128_huge_kernel<1024, HC, HS, WIDE, KT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count128_huge_kernel<1024, HC, HS, WIDE, KT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count128_huge_kernel<1024, HC, HS, WIDE, KT, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  if (n_large == 0) return hipSuccess;
+  const bool sliced = ws && d_error && max_sub > (u64)HUGE_SLICE_MIN && n_keys && n_keys <= ws_keys && ws_bytes >= finish_huge_workspace_bytes(ws_keys);
+  if (!sliced) {
+    hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, WIDE, KT, 0>), dim3((uint32_t)n_large), dim3(1024), smem, st, keys, starts, list, ng, huge_min,
+                       low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, (u64)0, HugeSliced());
+    return hipGetLastError();
+  }
+  HugeSliced hs;
+  hs.max_gig = (u32)(ws_keys / HUGE_SLICE_MIN + 2);
+  hs.max_slices = (u32)(ws_keys / HUGE_SLICE + hs.max_gig + 2);
+  u32 *w = reinterpret_cast<u32 *>(ws);
+  hs.counters = w;
+  hs.gig_g = w + 64; hs.gig_pairs = hs.gig_g + hs.max_gig; hs.gig_fail = hs.gig_pairs + hs.max_gig; hs.gig_dist = hs.gig_fail + hs.max_gig;
+  hs.slice_g = hs.gig_dist + hs.max_gig; hs.slice_j = hs.slice_g + hs.max_slices; hs.slice_q = hs.slice_j + hs.max_slices;
+  hs.chain = reinterpret_cast<u64 *>((reinterpret_cast<uintptr_t>(hs.slice_q + hs.max_slices) + 7) & ~(uintptr_t)7);
+  hs.split = hs.chain + (size_t)hs.max_gig * HUGE_RANGES;
+  hs.error = d_error;
+  MGC_CHECK(hipMemsetAsync(ws, 0, finish_huge_workspace_bytes(ws_keys), st));
+  hipLaunchKernelGGL(huge_plan_kernel, dim3((uint32_t)((n_large + 255) / 256)), dim3(256), 0, st, starts, list, n_large, (u64)HUGE_SLICE_MIN, hs, 0u);
+  MGC_CHECK(hipGetLastError());
+  const uint32_t sgrid = (uint32_t)std::min<u64>(512, std::min<u64>((u64)hs.max_slices, n_keys / HUGE_SLICE + n_keys / HUGE_SLICE_MIN + 4));   // (by ticket)
+  hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, WIDE, KT, 1>), dim3(sgrid), dim3(1024), smem, st, keys, starts, list, ng, huge_min,
+                     low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, (u64)0, hs);
+  MGC_CHECK(hipGetLastError());
+  const uint32_t ggrid = (uint32_t)std::min<u64>(std::min<u64>(n_large, (u64)hs.max_gig), n_keys / HUGE_SLICE_MIN + 1);
+  hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, WIDE, KT, 2>), dim3(ggrid), dim3(1024), smem, st, keys, starts, list, ng, huge_min,
+                     low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, (u64)0, hs);
+  MGC_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(huge_split_kernel<KT>, dim3(ggrid), dim3(1024), 0, st, (const KT *)keys, starts, low_bits, hs);
+  MGC_CHECK(hipGetLastError());
+  hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, WIDE, KT, 3>), dim3(256), dim3(1024), smem, st, keys, starts, list, ng, huge_min,
+                     low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, (u64)0, hs);
+  MGC_CHECK(hipGetLastError());
+  hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, WIDE, KT, 0>), dim3((uint32_t)n_large), dim3(1024), smem, st, keys, starts, list, ng, huge_min,
+                     low_bits, cnt_tmp, group_distinct, alt, tr_a, tr_b, (u64)HUGE_SLICE_MIN, hs);
   MGC_CHECK(hipGetLastError());
   hipLaunchKernelGGL(huge_copy_back_kernel<KT>, dim3(ggrid), dim3(1024), 0, st, keys, (const KT *)alt, starts, hs);
   return hipGetLastError();
@@ -2487,28 +2709,14 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
 #undef MGC_W96_LAUNCH
     MGC_CHECK(hipGetLastError());
     if (n_large) {
-      constexpr int HS = 4096, HC = 2048;
-      constexpr size_t BW = (size_t)(8 + 8 + 4) * HS + (size_t)(8 + 8) * (HC + 16) + (size_t)4 * HC;
-      constexpr size_t BN = (size_t)(8 + 4) * HS + (size_t)8 * (HC + 16) + (size_t)4 * HC;
-      static bool w96attr = false;
-      if (!w96attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count128_huge_kernel<1024, HC, HS, true, K96>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)BW);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count128_huge_kernel<1024, HC, HS, false, K96>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)BN);
-        w96attr = true;
-      }
       if (wide)
-        hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, true, K96>), dim3((uint32_t)n_large), dim3(1024), BW, st_huge,
-                           reinterpret_cast<K96 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           FIN_CAP_HASH128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
-                           reinterpret_cast<K96 *>(d_alt), tr_a, tr_b);
+        MGC_CHECK((launch_huge128<true, K96>(reinterpret_cast<K96 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)n_large, (u64)ng,
+                   FIN_CAP_HASH128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), reinterpret_cast<K96 *>(d_alt), tr_a, tr_b, st_huge,
+                   (u64)max_sub, (u64)n_keys, d_huge_ws, huge_ws_bytes, (u64)huge_ws_keys, d_error)));
       else
-        hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, false, K96>), dim3((uint32_t)n_large), dim3(1024), BN, st_huge,
-                           reinterpret_cast<K96 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           FIN_CAP_HASH128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
-                           reinterpret_cast<K96 *>(d_alt), tr_a, tr_b);
-      MGC_CHECK(hipGetLastError());
+        MGC_CHECK((launch_huge128<false, K96>(reinterpret_cast<K96 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)n_large, (u64)ng,
+                   FIN_CAP_HASH128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), reinterpret_cast<K96 *>(d_alt), tr_a, tr_b, st_huge,
+                   (u64)max_sub, (u64)n_keys, d_huge_ws, huge_ws_bytes, (u64)huge_ws_keys, d_error)));
     }
     return hipSuccess;
   }
@@ -2626,28 +2834,14 @@ hipError_t launch_finish_file(void *d_keys, uint32_t key_words, const uint64_t *
 #undef MGC_W128_LAUNCH
     MGC_CHECK(hipGetLastError());
     if (stream && n_large) {
-      constexpr int HS = 4096, HC = 2048;
-      constexpr size_t BW = (size_t)(8 + 8 + 4) * HS + (size_t)(8 + 8) * (HC + 16) + (size_t)4 * HC;
-      constexpr size_t BN = (size_t)(8 + 4) * HS + (size_t)8 * (HC + 16) + (size_t)4 * HC;
-      static bool wattr = false;
-      if (!wattr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count128_huge_kernel<1024, HC, HS, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)BW);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_count128_huge_kernel<1024, HC, HS, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)BN);
-        wattr = true;
-      }
       if (low_bits > 64)
-        hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, true>), dim3((uint32_t)n_large), dim3(1024), BW, st_huge,
-                           reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           FIN_CAP_HASH128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
-                           reinterpret_cast<K128 *>(d_alt), tr_a, tr_b);
+        MGC_CHECK((launch_huge128<true, K128>(reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)n_large, (u64)ng,
+                   FIN_CAP_HASH128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), reinterpret_cast<K128 *>(d_alt), tr_a, tr_b, st_huge,
+                   (u64)max_sub, (u64)n_keys, d_huge_ws, huge_ws_bytes, (u64)huge_ws_keys, d_error)));
       else
-        hipLaunchKernelGGL((hash_count128_huge_kernel<1024, HC, HS, false>), dim3((uint32_t)n_large), dim3(1024), BN, st_huge,
-                           reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)ng,
-                           FIN_CAP_HASH128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct),
-                           reinterpret_cast<K128 *>(d_alt), tr_a, tr_b);
-      MGC_CHECK(hipGetLastError());
+        MGC_CHECK((launch_huge128<false, K128>(reinterpret_cast<K128 *>(d_keys), reinterpret_cast<const u64 *>(d_starts), d_large_list, (u64)n_large, (u64)ng,
+                   FIN_CAP_HASH128, low_bits, d_cnt_tmp, reinterpret_cast<u64 *>(d_group_distinct), reinterpret_cast<K128 *>(d_alt), tr_a, tr_b, st_huge,
+                   (u64)max_sub, (u64)n_keys, d_huge_ws, huge_ws_bytes, (u64)huge_ws_keys, d_error)));
     } else {
       MGC_CHECK((finish_launch<K128, 1024, 8>(d_keys, d_starts, n_large, low_bits, FIN_CAP_HASH128, 8192, d_cnt_tmp, d_group_distinct, st, d_large_list)));
     }

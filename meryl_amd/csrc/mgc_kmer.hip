@@ -215,9 +215,9 @@ __device__ __forceinline__ u32 kp_suffix_filter(const K (&keys)[KP_ITEMS], u32 v
   return vmask;
 }
 
-__device__ __forceinline__ void kp_tile_range(u64 num_tiles, u64 &t_begin, u64 &t_end) {
-  const u64 per = (num_tiles + gridDim.x - 1) / gridDim.x;
-  t_begin = (u64)blockIdx.x * per;
+__device__ __forceinline__ void kp_tile_range(u64 num_tiles, u64 &t_begin, u64 &t_end, u32 vwg = blockIdx.x, u32 vgrid = gridDim.x) {
+  const u64 per = (num_tiles + vgrid - 1) / vgrid;
+  t_begin = (u64)vwg * per;
   t_end   = t_begin + per;
   if (t_begin > num_tiles) t_begin = num_tiles;
   if (t_end   > num_tiles) t_end   = num_tiles;
@@ -304,7 +304,8 @@ template <int HB, int KC = 0>                         // KC: k as a compile-time
 __global__ __launch_bounds__(KP_BLOCK * KH_NV)
 void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, int mode_arg, u64 num_tiles, u32 vgrid,
                            u64 *__restrict__ block_hist, u64 *__restrict__ bucket_counts, u64 *__restrict__ fine_hist,
-                           u32 fbits = 6 /* HB == 0: the buckets of the per-workgroup rows and of bucket_counts are the top fbits (6..8) bits */) {
+                           u32 fbits = 6 /* HB == 0: the buckets of the per-workgroup rows and of bucket_counts are the top fbits (6..8) bits */,
+                           u32 nvp = KH_NV /* virtual workgroups (rows) this workgroup takes, one after the other */) {
   const u32 k = KC ? (u32)KC : k_arg;
   const int mode = KC ? 0 : mode_arg;
   constexpr u32 TABLE = HB ? hpc_table_size(HB) : (1u << KH_FINE_BITS);
@@ -324,8 +325,8 @@ void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
   // virtual workgroup (the row the partition kernel's cursors come from) are the growth of the 64 file sums of that table
   // while it was counted: 32 reads per thread and virtual workgroup instead of a second, conflict-ridden atomic per k-mer.
   const u64 per = (num_tiles + vgrid - 1) / vgrid;                   // kp_tile_range of a virtual workgroup
-  for (u32 vv = 0; vv < (u32)KH_NV; vv++) {
-    const u64 vwg = (u64)blockIdx.x * KH_NV + vv;
+  for (u32 vv = 0; vv < nvp; vv++) {
+    const u64 vwg = (u64)blockIdx.x * nvp + vv;
     u64 t_begin = vwg * per, t_end = t_begin + per;
     if (t_begin > num_tiles) t_begin = num_tiles;
     if (t_end > num_tiles) t_end = num_tiles;
@@ -466,7 +467,8 @@ template <typename K, int MAXB, bool SOA = false, int KC = 0, int BB = 6>   // B
 __global__ __launch_bounds__(KP_BLOCK, (sizeof(K) == 16) ? 2 : (SOA ? 4 : 5))   // 16-byte keys: the 64 KiB exchange tile allows two workgroups; SOA: no spill, LDS allows four anyway
 void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, int mode_arg, u32 bucket_bits_arg,
                            u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out, u64 sfx_mask_arg, u64 sfx_test,
-                           const u64 *__restrict__ soa_starts = nullptr, const u64 *__restrict__ soa_counts = nullptr) {
+                           const u64 *__restrict__ soa_starts = nullptr, const u64 *__restrict__ soa_counts = nullptr,
+                           u32 vgrid = 0 /* rows of block_base = virtual workgroups (0: one per workgroup) */) {
   const u32 k = KC ? (u32)KC : k_arg;
   const int mode = KC ? 0 : mode_arg;
   const u32 bucket_bits = KC ? (u32)BB : bucket_bits_arg;
@@ -486,7 +488,6 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
   const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
   const u32  tid = threadIdx.x;
 
-  for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] = block_base[(u64)blockIdx.x * nb + b];
   __shared__ u64 s_fstart[SOA ? MAXB : 1], s_fhi[SOA ? MAXB : 1];   // SOA: first k-mer of the file; byte offset of its u8 array
   // where tile position 0 WOULD go for every bucket (bucket's cursor minus its first tile position), as byte addresses: a
   // k-mer at tile position i of bucket b goes to s_ob[b] + i * (bytes per k-mer) -- one LDS read and one add per store.  Only
@@ -503,8 +504,18 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
     }
   }
 
+  // VIRTUAL workgroups (round 6): the input is cut into vgrid (up to 16384) consecutive ranges with a row of cursors each; the
+  // workgroups of the launch (2048 of them, all resident) take them in turn -- blockIdx.x, + gridDim.x, ... -- so that at any time
+  // the ranges being written are ~2048 CONSECUTIVE ones: their k-mers go to ~67 MB per file instead of being spread over the file's
+  // whole region.  With one range per workgroup every workgroup wrote at its own place in all 64 files at once -- 2048 x 128 write
+  // fronts 264 KB apart, i.e. every 2 MiB page of the 43 GB output was being written all the time, and the kernel lasted 20.1 or
+  // 23.5 ms depending on how the process's physical memory happened to be laid out (profiles/r06_ab_runs.txt).
+  const u32 nvirt = vgrid ? vgrid : gridDim.x;
+  for (u32 vwg = blockIdx.x; vwg < nvirt; vwg += gridDim.x) {
+  __syncthreads();                                                   // (the cursors of the range before are no longer read)
+  for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] = block_base[(u64)vwg * nb + b];
   u64 t_begin, t_end;
-  kp_tile_range(num_tiles, t_begin, t_end);
+  kp_tile_range(num_tiles, t_begin, t_end, vwg, nvirt);
 
   // the next tile's bases are in flight (registers: 16 bytes per thread + the halo of the first four) while this tile is ranked,
   // exchanged and written: a tile's 4 KB used to be asked for at the top of its own iteration (round 6)
@@ -611,6 +622,7 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
     for (u32 b = tid; b < nb; b += KP_BLOCK) s_cursor[b] += s_cnt[b];
     __syncthreads();
   }
+  }
 }
 
 // the constant-k instantiations (KC): canonical counts at the k of the BASELINE configs (on: Switches::const_k)
@@ -619,14 +631,23 @@ static int kmer_const_k(uint32_t k, int mode, bool on) {
   return (k == 21 || k == 31 || k == 51) ? (int)k : 0;
 }
 
-uint32_t kp_grid_size(uint64_t n_bases) {
+// rows of the per-workgroup histogram = VIRTUAL workgroups = consecutive ranges of the input (kmer_partition_kernel): up to
+// KP_VGRID (buckets of more than eight bits: 2048, their rows are 8 KiB each); the kernels launch at most KP_PHYS workgroups
+constexpr uint32_t KP_VGRID = 16384, KP_PHYS = 2048;
+static uint32_t kp_vgrid_max(uint32_t bucket_bits) {
+  static const uint32_t env = [] { const char *e = getenv("MGC_PART_VGRID"); return (e && *e) ? (uint32_t)atoi(e) : 0u; }();   // (A/B: 2048 = one range per workgroup)
+  if (bucket_bits > 8) return KP_PHYS;
+  return (env >= 256 && env <= KP_VGRID) ? env : KP_VGRID;
+}
+uint32_t kp_grid_size(uint64_t n_bases, uint32_t bucket_bits) {
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
-  uint64_t g = num_tiles < 2048 ? num_tiles : 2048;
+  const uint64_t vmax = kp_vgrid_max(bucket_bits);
+  uint64_t g = num_tiles < vmax ? num_tiles : vmax;
   return (uint32_t)(g ? g : 1);
 }
 
 size_t kp_workspace_bytes(uint32_t bucket_bits) {
-  return (size_t)2048 * ((size_t)1 << bucket_bits) * sizeof(uint64_t);
+  return (size_t)(bucket_bits > 8 ? KP_PHYS : KP_VGRID) * ((size_t)1 << bucket_bits) * sizeof(uint64_t);
 }
 
 hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint32_t k, int mode,
@@ -636,7 +657,7 @@ hipError_t launch_kmer_histogram(const uint8_t *d_bases, uint64_t n_bases, uint3
   MGC_CHECK(hipMemsetAsync(d_bucket_counts, 0, sizeof(uint64_t) * nb, st));
   if (n_bases == 0) return hipSuccess;
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
-  const uint32_t grid = kp_grid_size(n_bases);
+  const uint32_t grid = kp_grid_size(n_bases, bucket_bits);              // one workgroup per row (virtual workgroup)
   if (k <= 32)
     hipLaunchKernelGGL(kmer_hist_kernel<u64>, dim3(grid), dim3(KP_BLOCK), 0, st,
                        d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,
@@ -662,7 +683,8 @@ hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, 
   MGC_CHECK(hipMemsetAsync(d_fine_hist, 0, sizeof(uint64_t) << KH_FINE_BITS, st));
   if (n_bases == 0) return hipSuccess;
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
-  const uint32_t vgrid = kp_grid_size(n_bases);
+  const uint32_t vgrid = kp_grid_size(n_bases, bucket_bits);
+  const uint32_t nvp = std::max<uint32_t>((uint32_t)KH_NV, (vgrid + 511u) / 512u);     // <= 512 workgroups (each clears and flushes a 128 KiB table), nvp rows each
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -676,9 +698,9 @@ hipError_t launch_kmer_histogram_fine(const uint8_t *d_bases, uint64_t n_bases, 
     attr_done = true;
   }
 #define MGC_KH_LAUNCH(KC_)                                                                                                             \
-  hipLaunchKernelGGL((kmer_hist_fine_kernel<0, KC_>), dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) << KH_FINE_BITS, st, \
+  hipLaunchKernelGGL((kmer_hist_fine_kernel<0, KC_>), dim3((vgrid + nvp - 1) / nvp), dim3(KP_BLOCK * KH_NV), sizeof(u32) << KH_FINE_BITS, st, \
                      d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),                             \
-                     reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), bucket_bits)
+                     reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), bucket_bits, nvp)
   const int kc = kmer_const_k(k, mode, const_k);
   if (kc == 21) MGC_KH_LAUNCH(21); else if (kc == 31) MGC_KH_LAUNCH(31); else if (kc == 51) MGC_KH_LAUNCH(51); else MGC_KH_LAUNCH(0);
 #undef MGC_KH_LAUNCH
@@ -700,7 +722,8 @@ hipError_t launch_kmer_histogram_hpc(const uint8_t *d_bases, uint64_t n_bases, u
   MGC_CHECK(hipMemsetAsync(d_fine_hist, 0, sizeof(uint64_t) * entries, st));
   if (n_bases == 0) return hipSuccess;
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
-  const uint32_t vgrid = kp_grid_size(n_bases);
+  const uint32_t vgrid = kp_grid_size(n_bases, bucket_bits);
+  const uint32_t nvp = std::max<uint32_t>((uint32_t)KH_NV, (vgrid + 511u) / 512u);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kmer_hist_fine_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -715,21 +738,21 @@ hipError_t launch_kmer_histogram_hpc(const uint8_t *d_bases, uint64_t n_bases, u
   }
   const bool k31 = kmer_const_k(k, mode, const_k) == 31;
   if (k31 && bucket_bits == 6)
-    hipLaunchKernelGGL((kmer_hist_fine_kernel<8, 31>), dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
+    hipLaunchKernelGGL((kmer_hist_fine_kernel<8, 31>), dim3((vgrid + nvp - 1) / nvp), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
                        d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
-                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
+                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), 6u, nvp);
   else if (k31)
-    hipLaunchKernelGGL((kmer_hist_fine_kernel<9, 31>), dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
+    hipLaunchKernelGGL((kmer_hist_fine_kernel<9, 31>), dim3((vgrid + nvp - 1) / nvp), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
                        d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
-                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
+                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), 6u, nvp);
   else if (bucket_bits == 6)
-    hipLaunchKernelGGL(kmer_hist_fine_kernel<8>, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
+    hipLaunchKernelGGL(kmer_hist_fine_kernel<8>, dim3((vgrid + nvp - 1) / nvp), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
                        d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
-                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
+                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), 6u, nvp);
   else
-    hipLaunchKernelGGL(kmer_hist_fine_kernel<9>, dim3((vgrid + KH_NV - 1) / KH_NV), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
+    hipLaunchKernelGGL(kmer_hist_fine_kernel<9>, dim3((vgrid + nvp - 1) / nvp), dim3(KP_BLOCK * KH_NV), sizeof(u32) * entries, st,
                        d_bases, (u64)n_bases, k, mode, (u64)num_tiles, vgrid, reinterpret_cast<u64 *>(d_ws),
-                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist));
+                       reinterpret_cast<u64 *>(d_bucket_counts), reinterpret_cast<u64 *>(d_fine_hist), 6u, nvp);
   return hipGetLastError();
 }
 
@@ -739,9 +762,10 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
   if (n_bases == 0) return hipSuccess;
   const uint32_t nb = 1u << bucket_bits;
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
-  const uint32_t grid = kp_grid_size(n_bases);
+  const uint32_t rows = kp_grid_size(n_bases, bucket_bits);                // virtual workgroups: rows of cursors
+  const uint32_t grid = rows < KP_PHYS ? rows : KP_PHYS;                 // workgroups launched: they take the rows in turn
   hipLaunchKernelGGL(kmer_scan_kernel, dim3(nb), dim3(256), 0, st,
-                     reinterpret_cast<u64 *>(d_ws), grid, nb, reinterpret_cast<const u64 *>(d_bucket_starts));
+                     reinterpret_cast<u64 *>(d_ws), rows, nb, reinterpret_cast<const u64 *>(d_bucket_starts));
   MGC_CHECK(hipGetLastError());
   static bool attr_done = false;
   if (!attr_done) {
@@ -756,7 +780,7 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
 #define MGC_KP_LAUNCH(K_, MAXB_)                                                                                   \
   hipLaunchKernelGGL((kmer_partition_kernel<K_, MAXB_>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K_), st,      \
                      d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,                                  \
-                     reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys), (u64)sfx_mask, (u64)sfx_test)
+                     reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys), (u64)sfx_mask, (u64)sfx_test, (const u64 *)nullptr, (const u64 *)nullptr, rows)
   if (d_soa_counts && k > 32) {                                       // K96 records (k = 33..51)
     if (!(k <= 51 && nb == 64 && sfx_mask == 0)) return hipErrorInvalidValue;
     static bool a96 = false;
@@ -770,11 +794,11 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
     if (kmer_const_k(k, mode, const_k) == 51)
       hipLaunchKernelGGL((kmer_partition_kernel<K128, 64, true, 51>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K128), st, d_bases, (u64)n_bases, k, mode,
                          bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K128 *>(d_keys), (u64)0, (u64)0,
-                         reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
+                         reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts), rows);
     else
       hipLaunchKernelGGL((kmer_partition_kernel<K128, 64, true>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K128), st, d_bases, (u64)n_bases, k, mode,
                          bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K128 *>(d_keys), (u64)0, (u64)0,
-                         reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
+                         reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts), rows);
     return hipGetLastError();
   }
   if (d_soa_counts) {                                                 // 5-byte layout (kmer_partition_soa_ok)
@@ -782,21 +806,21 @@ hipError_t launch_kmer_partition(const uint8_t *d_bases, uint64_t n_bases, uint3
     if (kmer_const_k(k, mode, const_k) == 21)
       hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, true, 21>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
                          bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)0, (u64)0,
-                         reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
+                         reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts), rows);
     else
       hipLaunchKernelGGL((kmer_partition_kernel<u64, 64, true>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st, d_bases, (u64)n_bases, k, mode,
                          bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)0, (u64)0,
-                         reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts));
+                         reinterpret_cast<const u64 *>(d_bucket_starts), reinterpret_cast<const u64 *>(d_soa_counts), rows);
     return hipGetLastError();
   }
 #define MGC_KPC_LAUNCH(K_, KC_)                                                                                    \
   hipLaunchKernelGGL((kmer_partition_kernel<K_, 64, false, KC_>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(K_), st, \
                      d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles,                                  \
-                     reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys), (u64)0, (u64)0)
+                     reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<K_ *>(d_keys), (u64)0, (u64)0, (const u64 *)nullptr, (const u64 *)nullptr, rows)
   const int kc = (nb == 64 && sfx_mask == 0) ? kmer_const_k(k, mode, const_k) : 0;
   if (nb == 256 && sfx_mask == 0 && kmer_const_k(k, mode, const_k) == 31)          // (k = 31 `compress` beyond ~4 Gbp: 256 buckets, 4 KiB of tables instead of 16)
     hipLaunchKernelGGL((kmer_partition_kernel<u64, 256, false, 31, 8>), dim3(grid), dim3(KP_BLOCK), KP_TILE * sizeof(u64), st,
-                       d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)0, (u64)0);
+                       d_bases, (u64)n_bases, k, mode, bucket_bits, (u64)num_tiles, reinterpret_cast<const u64 *>(d_ws), reinterpret_cast<u64 *>(d_keys), (u64)0, (u64)0, (const u64 *)nullptr, (const u64 *)nullptr, rows);
   else if (kc == 21) MGC_KPC_LAUNCH(u64, 21);
   else if (kc == 31) MGC_KPC_LAUNCH(u64, 31);
   else if (kc == 51) MGC_KPC_LAUNCH(K128, 51);

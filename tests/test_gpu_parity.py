@@ -1499,7 +1499,8 @@ def test_hash_count_stream_kernel_distinct_sized_table(ops, oracle_lib, torch_cu
 
 
 
-@pytest.mark.parametrize("k,min_top,slices", [(21, 16, "1"), (21, 16, "0"), (26, 14, "1"), (31, 16, "1"), (28, 17, "1"), (16, 12, "1")])
+@pytest.mark.parametrize("k,min_top,slices", [(21, 16, "1"), (21, 16, "0"), (26, 14, "1"), (31, 16, "1"), (28, 17, "1"), (16, 12, "1"),
+                                              (51, 12, "1"), (40, 12, "1"), (64, 12, "1"), (51, 12, "0")])
 def test_gigantic_subbuckets_are_counted_in_slices(ops, oracle_lib, torch_cuda, monkeypatch, k, min_top, slices):
     """Round 6: a sub-bucket above 65536 keys (a satellite family: millions of instances of a few hundred k-mers) is cut into slices
     of <= 32768 keys, every slice counted by its own workgroup into (suffix, count) pairs, the pairs merged by one workgroup
@@ -1507,8 +1508,8 @@ def test_gigantic_subbuckets_are_counted_in_slices(ops, oracle_lib, torch_cuda, 
     with 20 distinct suffixes (three slices), 200 K with 3000 (several passes per slice and in the merge), 66 K of ONE k-mer, 100 K
     that are all distinct and 300 K with 80 K distinct (DENSE: the slices' pairs do not fit half their keys -- 64 workgroups count a
     range of the suffix space each, MODE 3, a chain carries the ranges' places, huge_copy_back_kernel brings the result home),
-    40 K (oversized, not cut), next to ordinary reads; narrowed files (k = 16, 21, 26) and whole 8-byte k-mers
-    (k = 28, 31); MGC_HUGE_SLICES=0: round 5's form.  Against the oracle."""
+    40 K (oversized, not cut), next to ordinary reads; narrowed files (k = 16, 21, 26), whole 8-byte k-mers (k = 28, 31), K96
+    records (k = 40, 51) and 16-byte keys (k = 64: ranges only); MGC_HUGE_SLICES=0: round 5's form.  Against the oracle."""
     from meryl_amd import capi
     monkeypatch.setenv("MGC_FINISH_MIN_TOP", str(min_top))
     monkeypatch.setenv("MGC_HUGE_SLICES", slices)
@@ -1525,8 +1526,12 @@ def test_gigantic_subbuckets_are_counted_in_slices(ops, oracle_lib, torch_cuda, 
         rng.shuffle(picks)
         return ".".join(pre + tails[int(i)] for i in picks) + "."
     reads = oracle_lib.synth_reads(k, 4_000_000, 0, 30_000).tobytes().decode()    # 4.5 Mbases: the fifteen-bit histogram is on
-    text = (cluster("AAC", 70_000, 20) + cluster("ACA", 200_000, 3000) + cluster("ATT", 66_000, 1) + cluster("AGC", 100_000, 100_000)
-            + cluster("CAT", 40_000, 700) + cluster("AAC", 90_000, 5) + cluster("GGT", 300_000, 80_000) + reads)
+    if k <= 32:
+        text = (cluster("AAC", 70_000, 20) + cluster("ACA", 200_000, 3000) + cluster("ATT", 66_000, 1) + cluster("AGC", 100_000, 100_000)
+                + cluster("CAT", 40_000, 700) + cluster("AAC", 90_000, 5) + cluster("GGT", 300_000, 80_000) + reads)
+    else:       # 16-byte keys / K96 records: every cut sub-bucket is counted by ranges (hash_count128_huge_kernel MODE 3)
+        text = (cluster("AAC", 70_000, 20) + cluster("ATT", 66_000, 1) + cluster("AGC", 80_000, 80_000) + cluster("CAT", 40_000, 700)
+                + cluster("GGT", 150_000, 30_000) + reads)
     for mode in (0, 1):                                     # forward mode keeps the clusters where they were put
         cfg = capi.configure(k, len(text), 1 << 30, mode)
         cfg.use_simple = 0
