@@ -504,12 +504,10 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
     }
   }
 
-  // VIRTUAL workgroups (round 6): the input is cut into vgrid (up to 16384) consecutive ranges with a row of cursors each; the
-  // workgroups of the launch (2048 of them, all resident) take them in turn -- blockIdx.x, + gridDim.x, ... -- so that at any time
-  // the ranges being written are ~2048 CONSECUTIVE ones: their k-mers go to ~67 MB per file instead of being spread over the file's
-  // whole region.  With one range per workgroup every workgroup wrote at its own place in all 64 files at once -- 2048 x 128 write
-  // fronts 264 KB apart, i.e. every 2 MiB page of the 43 GB output was being written all the time, and the kernel lasted 20.1 or
-  // 23.5 ms depending on how the process's physical memory happened to be laid out (profiles/r06_ab_runs.txt).
+  // VIRTUAL workgroups (round 6): the input is cut into vgrid consecutive ranges with a row of cursors each; the workgroups of the
+  // launch take them in turn -- blockIdx.x, + gridDim.x, ....  By default vgrid == gridDim.x (one range per workgroup: every workgroup
+  // writes at its own place in all 64 files, 2048 x 128 write fronts 264 KB apart over the whole 43 GB output).  With 16384 ranges
+  // (MGC_PART_VGRID) the ranges being written at any time are ~2048 CONSECUTIVE ones, ~67 MB per file: measured equal (kp_vgrid_max).
   const u32 nvirt = vgrid ? vgrid : gridDim.x;
   for (u32 vwg = blockIdx.x; vwg < nvirt; vwg += gridDim.x) {
   __syncthreads();                                                   // (the cursors of the range before are no longer read)
@@ -635,9 +633,12 @@ static int kmer_const_k(uint32_t k, int mode, bool on) {
 // KP_VGRID (buckets of more than eight bits: 2048, their rows are 8 KiB each); the kernels launch at most KP_PHYS workgroups
 constexpr uint32_t KP_VGRID = 16384, KP_PHYS = 2048;
 static uint32_t kp_vgrid_max(uint32_t bucket_bits) {
-  static const uint32_t env = [] { const char *e = getenv("MGC_PART_VGRID"); return (e && *e) ? (uint32_t)atoi(e) : 0u; }();   // (A/B: 2048 = one range per workgroup)
+  // default: one range per workgroup.  MGC_PART_VGRID=16384 (A/B, profiles/r06_ab_runs.txt r06v2 / r06v9): partition 20.2 -> 19.9 ms, histogram
+  // 6.0 -> 6.1, the step equal -- the 23.5 ms this was built against turned out to be a property of one BOX (every process on it), not of
+  // the memory layout of a process
+  static const uint32_t env = [] { const char *e = getenv("MGC_PART_VGRID"); return (e && *e) ? (uint32_t)atoi(e) : 0u; }();
   if (bucket_bits > 8) return KP_PHYS;
-  return (env >= 256 && env <= KP_VGRID) ? env : KP_VGRID;
+  return (env >= 256 && env <= KP_VGRID) ? env : KP_PHYS;
 }
 uint32_t kp_grid_size(uint64_t n_bases, uint32_t bucket_bits) {
   const uint64_t num_tiles = (n_bases + KP_TILE - 1) / KP_TILE;
