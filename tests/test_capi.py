@@ -136,7 +136,8 @@ def test_workspace_sizes_monotone(native_lib):
         w = native_lib.mgc_dev_sort_workspace_bytes(n)
         assert w >= prev
         prev = w
-    assert native_lib.mgc_dev_partition_workspace_bytes(6) == 2048 * 64 * 8
+    assert native_lib.mgc_dev_partition_workspace_bytes(6) == 16384 * 64 * 8      # rows for up to 16384 virtual workgroups (MGC_PART_VGRID)
+    assert native_lib.mgc_dev_partition_workspace_bytes(10) == 2048 * 1024 * 8
     assert native_lib.mgc_dev_rle_workspace_bytes(0) > 0
 
 
