@@ -45,7 +45,8 @@ def _worker(rank, world, port, k, wp, path, label_size, label, compress, n_reads
         db = dict(path=path, w_prefix=wp, label_size=label_size, label=label, host_threads=4)
         uniq, cnts, rng = count.count_sharded(bases, k, capi.MODE_CANONICAL, ops=count.HipOps, db=db, keep_result=(rank == 0),
                                               batch_bases=batch_bases)
-        assert rng[2] == min(6 + (world - 1).bit_length(), wp)                       # bucket-granular routing
+        bits = int(env["MGC_SHARD_BITS"]) if "MGC_SHARD_BITS" in env else 6 + (world - 1).bit_length()
+        assert rng[2] == min(bits, wp)                                               # bucket-granular routing
         if batch_bases:
             assert db["n_batches"] >= 2
         if rank == 0 and not batch_bases:
@@ -62,6 +63,8 @@ def _worker(rank, world, port, k, wp, path, label_size, label, compress, n_reads
     (2, 31, 0, 1, 400, 8_000, None, {}),                                        # k = 31 `compress` on long reads
     (2, 51, 8, 0, 30_000, 150, None, {}),                                       # k = 51 (16-byte keys) with an 8-bit constant label
     (2, 21, 0, 0, 40_000, 150, 1_500_000, {}),                                  # batched: waves parked in the owner's run store
+    (2, 21, 0, 0, 40_000, 150, None, {"MGC_SHARD_BITS": "9"}),                     # the granularity of an EIGHT-rank run (512 buckets: no fifteen-bit histogram on the owner side)
+    (3, 21, 0, 0, 30_000, 150, None, {"MGC_SHARD_BITS": "9", "MGC_FINISH_MIN_TOP": "14"}),   # ... with the owner's two-digit plan
 ])
 def test_sharded_count_with_hip_operators_on_one_gpu(tmp_path, native_lib, world, k, label_size, compress, n_reads, read_len, batch, env):
     import torch
