@@ -1679,7 +1679,7 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         const bool msd = d_nhdrs && d_nws && msd_ok[b];
         HIP_TRY(s, mgc::launch_group_narrow(src, (void *)Y, h_counts[b], fp, sort_ws, sort_ws_bytes - 256, d_err, d_substart + sbase[b], st, pe,
                                             msd ? (void *)(d_nhdrs + hdr_bytes * b) : nullptr, msd ? (void *)(d_nws + nws_off[b]) : nullptr,
-                                            &tr_a[b], &tr_b[b], soa_hi_mask, sw.group_dbg, sw.group_pipe));
+                                            &tr_a[b], &tr_b[b], soa_hi_mask, sw.group_dbg, sw.group_pipe, sw.pass_stagger));
         file_passes[b] = 2;
         narrowed[b] = 1;
         sort_launch_groups++;

@@ -26,6 +26,7 @@ struct Switches {
   bool nolist = false;          // MGC_FINISH_NOLIST=1: the dense-grid instantiations of the count kernels whatever the grid holds
   bool finish_trace = false;    // MGC_FINISH_TRACE: what happens to oversized sub-buckets, on stderr
   bool group_dbg = false;       // MGC_GROUP_DBG: per-phase cycle sums of the grouping passes (instrumented instantiations)
+  uint32_t pass_stagger = 8;    // MGC_PASS_STAGGER: groups the 5-byte first pass's workgroups start in (0 / 1: together; mgc_sort.hip, STAGGER)
   bool hash_dbg = false;        // MGC_HASH_DBG: per-phase cycle sums of the count kernels
   int  hash_multi = -1;         // MGC_HASH_MULTI: sub-buckets per iteration of hash_count_multi_kernel (-1: by the file's average; 0: off)
   int  hash_stream = -1;        // MGC_HASH_STREAM: the distinct-sized count (hash_count_stream_kernel) and its coarser file plan (-1: where the probe
@@ -126,7 +127,8 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                                uint32_t soa_hi_mask = 0 /*nonzero: d_keys is the 5-byte layout of launch_kmer_partition(d_soa_counts); the mask of
                                the u8 array's payload bits (bits 32.. of the k-mer below the file)*/,
                                bool group_dbg = false /*Switches::group_dbg*/,
-                               bool pipe = true /*Switches::group_pipe: the fetch a whole tile ahead (the 5-byte first pass, the second pass)*/);
+                               bool pipe = true /*Switches::group_pipe: the fetch a whole tile ahead (the 5-byte first pass, the second pass)*/,
+                               uint32_t stagger = 0 /*Switches::pass_stagger: the first pass's workgroups start in that many groups, a tile's time shared between them*/);
 
 // The same high-digit-first form for WHOLE keys (8-byte keys that leave more than 32 bits below their first digit: k = 27..32
 // at the 10 Gbp scale; every 16-byte key): the high digit's histogram comes from the fifteen-bit file histogram

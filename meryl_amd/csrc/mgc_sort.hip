@@ -413,7 +413,8 @@ template <> struct GroupOut<u64, true> { typedef u32 type; };
 // HIST2: the pass also takes the histogram of ANOTHER digit (the next pass's) of the keys it reads -- 512 LDS counters per
 // workgroup, flushed with global atomics at the end -- so that nobody has to read the keys for it.
 struct GroupExtra { u32 digit_bits /* NARROW */; u32 shift2, mask2; u64 *ghist2 /* HIST2 */;
-                    u32 soa_hi_mask = 0 /* SOA: payload bits of the u8 array */; };
+                    u32 soa_hi_mask = 0 /* SOA: payload bits of the u8 array */;
+                    u32 stagger_groups = 0, stagger_cycles = 0 /* STAGGER below: groups, cycles between two groups' starts */; };
 
 // SOA (u64 keys): `in` is the 5-byte layout kmer_partition_kernel<SOA> leaves -- u32 in[n] low words, then u8[n] bits 32..39 --
 // and a key is put together as it is fetched: four keys per lane and group from one 16-byte and one 4-byte load.
@@ -468,7 +469,9 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
   };
 
   // this thread's slice of the region table stays in registers
-  const bool regions = (region_tiles != nullptr);
+  // (a narrowing pass is a first pass: plain tiles -- known at compile time, so that the region slice below costs it no registers: the
+  // 5-byte pass spilled them and reloaded them at the top of every tile behind an s_waitcnt vmcnt(0), i.e. behind its own prefetch)
+  const bool regions = !NARROW && (region_tiles != nullptr);
   u64 rt_lo = 0, rt_hi = 0, rs = 0, re = 0, total_tiles = num_tiles_plain;
   if (regions) {
     if (tid0 < (u32)RS_MAX_RADIX) {
@@ -477,18 +480,17 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     }
     total_tiles = region_tiles[RS_MAX_RADIX];
   }
+  // (values, not branches over the captured variables: the two-branch form made the compiler select between the ADDRESSES of `re` and
+  // `n` -- both in scratch for it, 40 bytes per thread -- and the announcing thread's wave reloaded them behind an s_waitcnt vmcnt(0),
+  // i.e. behind its write-out stores, at the top of every tile: round 6, found in the ISA)
   auto announce = [&](u64 t, int slot) __attribute__((always_inline)) {   // key range of tile t -> s_info[2*slot..]
     if (t >= total_tiles) return;
-    if (regions) {
-      if (rt_lo <= t && t < rt_hi) {                      // exactly one thread (empty regions own no tile)
-        const u64 kb = rs + (t - rt_lo) * (u64)TILE;
-        s_info[2 * slot] = kb;
-        s_info[2 * slot + 1] = (re - kb < (u64)TILE) ? re - kb : (u64)TILE;
-      }
-    } else if (tid0 == 0) {
-      const u64 kb = t * (u64)TILE;
+    const bool mine = regions ? (rt_lo <= t && t < rt_hi) : (tid0 == 0);   // exactly one thread (empty regions own no tile)
+    const u64  kb   = regions ? rs + (t - rt_lo) * (u64)TILE : t * (u64)TILE;
+    const u64  endk = regions ? re : n;
+    if (mine) {
       s_info[2 * slot] = kb;
-      s_info[2 * slot + 1] = (n - kb < (u64)TILE) ? n - kb : (u64)TILE;
+      s_info[2 * slot + 1] = (endk - kb < (u64)TILE) ? endk - kb : (u64)TILE;
     }
   };
 
@@ -601,7 +603,26 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     }
   };
 
-  if (tid == 0) s_tmp[32] = atomicAdd(ticket, 1u);
+  // STAGGER (round 6; the 5-byte first pass): the persistent workgroups start in ex.stagger_groups groups, group g a g/P-th of a
+  // tile's time behind group 0, and stay apart -- nothing but the look-back couples them, and it only asks that earlier tiles are not
+  // behind.  Started together the ~256 workgroups run in step: a tile's walkers then find nothing but aggregates among their
+  // predecessors and the inclusive prefixes spread from the oldest tile on; apart, the tiles of the groups ahead have their prefixes
+  // out.  The first tiles are handed out statically in the order in which they will be processed (burst i * P + g = iteration i of
+  // group g; a ticket taken while another group sleeps would put a LATER tile in front of its predecessors: measured, +9 %), the
+  // tickets continue behind them.  Measured (profiles/r06_ab_runs.txt, r06x_rb8b): first pass 0.453 -> 0.444 ms per launch.
+  const bool stag = ex.stagger_groups > 1u && gridDim.x % (8u * ex.stagger_groups) == 0u;
+  u32 st_g = 0, st_r = 0, st_w = 0, tk_off = 0;
+  if (stag) {
+    st_g = (blockIdx.x >> 3) % ex.stagger_groups;          // (consecutive workgroups go to the eight XCDs in turn: every group on all of them)
+    st_r = ((blockIdx.x >> 3) / ex.stagger_groups) * 8u + (blockIdx.x & 7u);
+    st_w = gridDim.x / ex.stagger_groups;
+    tk_off = (PIPE ? 3u : 2u) * gridDim.x;
+    if (st_g) {
+      const u64 c0 = __builtin_readcyclecounter(), want = (u64)st_g * ex.stagger_cycles;
+      while (__builtin_readcyclecounter() - c0 < want) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  if (tid == 0) s_tmp[32] = stag ? st_g * st_w + st_r : atomicAdd(ticket, 1u);
   __syncthreads();
   u64 tile = s_tmp[32];
   announce(tile, 0);
@@ -612,7 +633,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     if (tile < total_tiles) { kb = s_info[0]; nv = (u32)s_info[1]; fetch(kb, nv); }
   } else {
     if (tile < total_tiles) { kb = s_info[0]; nv = (u32)s_info[1]; fetch_raw(kb, nv); assemble(); }
-    if (tid == 0) s_tmp[33] = atomicAdd(ticket, 1u);
+    if (tid == 0) s_tmp[33] = stag ? (ex.stagger_groups + st_g) * st_w + st_r : atomicAdd(ticket, 1u);
     __syncthreads();
     tile1 = s_tmp[33];
     announce(tile1, 1);
@@ -620,6 +641,8 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     if (tile1 < total_tiles) { kb1 = s_info[2]; nv1 = (u32)s_info[3]; fetch_raw(kb1, nv1); }
     __syncthreads();                                      // (s_tmp[33] and s_info[2..3] are written again at the top of the loop)
   }
+  // the ticket of the tile after those (from now on taken in the shadow of the look-back, below)
+  if (tid == 0) s_tmp[34] = stag ? ((PIPE ? 2u : 1u) * ex.stagger_groups + st_g) * st_w + st_r : atomicAdd(ticket, 1u);
 
   u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
 #define PK_STAMP(i) do { if (DBG) { const u64 t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; } } while (0)
@@ -629,10 +652,9 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     asm volatile("" : "+v"(tid));                         // keeps the unrolled body's LDS addresses out of the loop preheader
     lane = tid & 63u; w = tid >> 6;
     const bool walker = tid < (u32)G;
-    if (tid == 0) s_tmp[33] = atomicAdd(ticket, 1u);
     if (tid < (u32)R) s_hist[tid] = 0;
     __syncthreads();                                      // (A)
-    const u64 next = s_tmp[33];
+    const u64 next = s_tmp[34];
     announce(next, 1);                                    // read after (C)
     PK_STAMP(0);
 
@@ -716,12 +738,19 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
       }
     };
     if (!walker) {
+      // the last thread asks for the ticket of the tile after `next` here and hands it over before (E) (read behind the next (A)): its
+      // wave's wait for the answer -- vmcnt is in order: also for what the wave has in flight -- lies in the shadow of the look-back
+      // (until round 6 tid 0 asked at the top of the loop and the whole workgroup waited at (A) behind that wave's write-out stores and,
+      // PIPE, the prefetch it had just issued: ~2 K cycles per tile)
+      u32 tk_pre = 0;
+      if (tid == (u32)BLOCK - 1u) tk_pre = atomicAdd(ticket, 1u) + tk_off;
       if constexpr (!PIPE) { if (next < total_tiles) fetch(nkb, nnv); }
       // the waves that do not walk would only wait now: they count the other digit of the tile's keys (in LDS, in digit
       // order since the exchange) -- LDS work in the shadow of the look-back
       if constexpr (HIST2) {
         for (u32 i = tid - (u32)G; i < nv; i += (u32)(BLOCK - G)) atomicAdd(&s_h2[dig2(s_keys[i])], 1u);
       }
+      if (tid == (u32)BLOCK - 1u) s_tmp[34] = tk_pre;
     } else {
       while (!done) { issue(); consume(); }
       if (tile != 0) status_store(mine, st_pack(2, p0 + c0, 2, p1 + c1));
@@ -935,7 +964,8 @@ static hipError_t run_passes(void *d_keys, void *d_alt, uint64_t n, const SortPl
 // before region d0  -- which is exactly what the look-back granules of pass 1 hold once the pass is over: the boundaries
 // come for free, no key has to be looked at (the keys do not even hold d0 any more).
 __global__ void narrow_bounds_kernel(const u64 *__restrict__ status, const u32 *__restrict__ region_tiles,
-                                     const u64 *__restrict__ gbase1, u64 n, u32 b0, u64 ng, u64 *__restrict__ starts) {
+                                     const u64 *__restrict__ gbase1, u64 n, u32 b0, u64 ng, u64 *__restrict__ starts,
+                                     u32 granules /* per tile: half the digits of the pass's instantiation */) {
   const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (v > ng) return;
   if (v == ng) { starts[v] = n; return; }
@@ -946,7 +976,8 @@ __global__ void narrow_bounds_kernel(const u64 *__restrict__ status, const u32 *
   const u32 tiles_before = region_tiles[d0];
   u64 before = 0;
   if (tiles_before) {
-    const u64 g = status[(u64)(tiles_before - 1) * (RS_MAX_RADIX / 2) + (d1 >> 1)];
+    if ((d1 >> 1) >= granules) { starts[v] = n; return; }   // (a digit the pass's instantiation does not have: nothing lies there)
+    const u64 g = status[(u64)(tiles_before - 1) * granules + (d1 >> 1)];
     before = (u64)(((d1 & 1u) ? (u32)(g >> 32) : (u32)g) & 0x3FFFFFFFu);
   }
   starts[v] = gbase1[d1] + before;
@@ -1004,6 +1035,7 @@ void narrow_mid_kernel(SortHeader *__restrict__ hdr, u64 n, u32 tile, u64 *__res
 
 // per-file scratch of the batched form: [status of pass A][status of pass B][region table]
 constexpr uint64_t NARROW_TILE0 = 16384, NARROW_TILE1 = 24576;   // keys per tile of the first / second pass (launch_group_narrow)
+constexpr uint32_t NARROW_TILE0_CYCLES = 31000;                 // a first-pass tile's time (MGC_GROUP_DBG): the staggered groups share it
 size_t narrow_scratch_bytes(uint64_t n) {
   const uint64_t tiles0 = (n + NARROW_TILE0 - 1) / NARROW_TILE0, tiles1_max = (n + NARROW_TILE1 - 1) / NARROW_TILE1 + RS_MAX_RADIX + 1;
   return (size_t)(tiles0 + tiles1_max) * (RS_MAX_RADIX / 2) * sizeof(u64) + (size_t)(RS_MAX_RADIX + 2) * 16 + 512;
@@ -1035,7 +1067,7 @@ hipError_t launch_narrow_prepare(const uint64_t *d_fine, uint32_t nb, const unsi
 // ((p & (2^*tr_a - 1)) << *tr_b) | (p >> *tr_a)  (*tr_a = 0: p itself).
 hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, void *d_ws, size_t ws_bytes,
                                uint32_t *d_error, uint64_t *d_sub_starts, hipStream_t st, hipEvent_t *pass_events,
-                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, uint32_t soa_hi_mask, bool group_dbg, bool pipe) {
+                               void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b, uint32_t soa_hi_mask, bool group_dbg, bool pipe, uint32_t stagger) {
   if (!sort_plan_narrows(plan, n, 1) || ws_bytes < sort_workspace_bytes(n)) return hipErrorInvalidValue;
   constexpr int RB = 9, BLOCK = 1024, KPT0 = 16, KPT1 = 24, R = 1 << RB;
   using GS0 = GroupSmem<u64, RB, BLOCK, KPT0>;
@@ -1100,6 +1132,9 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
   }
   if (dbg && dbg_buf) MGC_CHECK(hipMemsetAsync(dbg_buf, 0, 2 * 64 * 8 * sizeof(u64), st));
   if (soa_hi_mask && !msd) return hipErrorInvalidValue;   // the 5-byte layout: high digit first
+  GroupExtra ex_first{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask};
+  if (stagger > 1u && soa_hi_mask && pipe) { ex_first.stagger_groups = stagger; ex_first.stagger_cycles = NARROW_TILE0_CYCLES / stagger; }
+  const GroupExtra ex_second{0u, 0u, 0u, nullptr};
   if (dbg && dbg_buf && soa_hi_mask) {                     // the shipped first pass, instrumented: 5-byte layout, the fetch a whole tile ahead (or not)
     static bool dsattr = false;
     if (!dsattr) {
@@ -1113,12 +1148,12 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
       hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, true, true, true, true, 2>), grid0, dim3(BLOCK), GS0::BYTES, st,
                          reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                          &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
-                         GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask}, dbg_buf);
+                         ex_first, dbg_buf);
     else
       hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, true, true, true, true, 0>), grid0, dim3(BLOCK), GS0::BYTES, st,
                          reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                          &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
-                         GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask}, dbg_buf);
+                         ex_first, dbg_buf);
   }
   else if (dbg && dbg_buf)
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, true, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
@@ -1138,16 +1173,31 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS0::BYTES);
       spattr = true;
     }
-    if (pipe)
+    if (pipe && bA <= 8u) {
+      // an eight-bit first digit (the plan of the judged files): 256 counters, 128 walkers and look-back rows of 128 granules instead of
+      // 512 / 256 / 256 -- half the status traffic, two more waves for the low digit's count
+      using GS08 = GroupSmem<u64, 8, BLOCK, KPT0>;
+      static bool r8attr = false;
+      if (!r8attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u64, 8, BLOCK, KPT0, false, true, true, true, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS08::BYTES);
+        r8attr = true;
+      }
+      hipLaunchKernelGGL((radix_group_kernel<u64, 8, BLOCK, KPT0, false, true, true, true, 2>), grid0, dim3(BLOCK), GS08::BYTES, st,
+                         reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
+                         &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                         ex_first, (u64 *)nullptr);
+    }
+    else if (pipe)
       hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true, true, 2>), grid0, dim3(BLOCK), GS0::BYTES, st,
                          reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                          &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
-                         GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask}, (u64 *)nullptr);
+                         ex_first, (u64 *)nullptr);
     else
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
                        reinterpret_cast<const u64 *>(d_keys), reinterpret_cast<u32 *>(d_alt), (u64)n, shA, (1u << bA) - 1u,
                        &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
-                       GroupExtra{bA, low, (1u << bB) - 1u, &hdr->ghist[1][0], soa_hi_mask}, (u64 *)nullptr);
+                       ex_first, (u64 *)nullptr);
   }
   else if (msd)
     hipLaunchKernelGGL((radix_group_kernel<u64, RB, BLOCK, KPT0, false, true, true>), grid0, dim3(BLOCK), GS0::BYTES, st,
@@ -1171,22 +1221,37 @@ hipError_t launch_group_narrow(void *d_keys, void *d_alt, uint64_t n, const Sort
     MGC_CHECK(hipMemsetAsync(status_b, 0, (size_t)tiles1_max * (R / 2) * sizeof(u64), st));
   }
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2], st));
+  u32 granules1 = (u32)(R / 2);                             // granules per tile of the second pass's status rows (narrow_bounds_kernel)
   if (dbg && dbg_buf)
     hipLaunchKernelGGL((radix_group_kernel<u32, RB, BLOCK, KPT1, true, false, false>), dim3((uint32_t)std::min(tiles1_max, cus * GS1::WG_PER_CU)), dim3(BLOCK),
                        GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
                        &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
-                       GroupExtra{0u, 0u, 0u, nullptr}, dbg_buf + 64 * 8);
+                       ex_second, dbg_buf + 64 * 8);
+  else if (bB <= 8u) {                                      // an eight-bit digit: half the counters, walkers and granules (as in the first pass)
+    using GS18 = GroupSmem<u32, 8, BLOCK, KPT1>;
+    static bool r8attr1 = false;
+    if (!r8attr1) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<u32, 8, BLOCK, KPT1, false, false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS18::BYTES);
+      r8attr1 = true;
+    }
+    granules1 = 128u;
+    hipLaunchKernelGGL((radix_group_kernel<u32, 8, BLOCK, KPT1, false, false, false>), dim3((uint32_t)std::min(tiles1_max, cus * GS18::WG_PER_CU)), dim3(BLOCK),
+                       GS18::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
+                       &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
+                       ex_second, (u64 *)nullptr);
+  }
   else
   hipLaunchKernelGGL((radix_group_kernel<u32, RB, BLOCK, KPT1, false, false, false>), dim3((uint32_t)std::min(tiles1_max, cus * GS1::WG_PER_CU)), dim3(BLOCK),
                      GS1::BYTES, st, reinterpret_cast<const u32 *>(d_alt), reinterpret_cast<u32 *>(d_keys), (u64)n, low, (1u << bB) - 1u,
                      &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)((n + TILE1 - 1) / TILE1), region_start, region_tiles,
-                     GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
+                     ex_second, (u64 *)nullptr);
   MGC_CHECK(hipGetLastError());
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[3], st));
 
   const u64 ng = (u64)1 << (bA + bB);
   hipLaunchKernelGGL(narrow_bounds_kernel, dim3((uint32_t)((ng + 1 + 255) / 256)), dim3(256), 0, st, status_b, region_tiles,
-                     &hdr->gbase[1][0], (u64)n, bA, ng, reinterpret_cast<u64 *>(d_sub_starts));
+                     &hdr->gbase[1][0], (u64)n, bA, ng, reinterpret_cast<u64 *>(d_sub_starts), granules1);
   MGC_CHECK(hipGetLastError());
   if (dbg && dbg_buf) {
     dbg_reports--;
@@ -1324,7 +1389,7 @@ static hipError_t group_wide(void *d_keys, void *d_alt, uint64_t n, const SortPl
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[3], st));
   const u64 ng = (u64)1 << (bA + bB);
   hipLaunchKernelGGL(narrow_bounds_kernel, dim3((uint32_t)((ng + 1 + 255) / 256)), dim3(256), 0, st, status_b, region_tiles,
-                     &hdr->gbase[1][0], (u64)n, bA, ng, reinterpret_cast<u64 *>(d_sub_starts));
+                     &hdr->gbase[1][0], (u64)n, bA, ng, reinterpret_cast<u64 *>(d_sub_starts), (u32)(R / 2));
   return hipGetLastError();
 }
 
