@@ -1318,15 +1318,17 @@ size_t wide_scratch_bytes(uint64_t n, uint32_t key_words) {
   return (size_t)(tiles0 + tiles1_max) * (RS_MAX_RADIX / 2) * sizeof(u64) + (size_t)(RS_MAX_RADIX + 2) * 16 + 512;
 }
 
-template <typename K, int KPT>
-static hipError_t group_wide(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, uint32_t *d_error, uint64_t *d_sub_starts,
-                             hipStream_t st, hipEvent_t *pass_events, void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b) {
-  constexpr int RB = 9, BLOCK = 1024, R = 1 << RB;
+// RB: 9, or 8 where both digits have at most eight bits (plain bit digits only): half the counters, walkers and look-back granules
+template <typename K, int KPT, int RB>
+static hipError_t group_wide_rb(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, uint32_t *d_error, uint64_t *d_sub_starts,
+                                hipStream_t st, hipEvent_t *pass_events, void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b) {
+  constexpr int BLOCK = 1024, R = 1 << RB;
   using GS = GroupSmem<K, RB, BLOCK, KPT>;
   constexpr uint64_t TILE = (uint64_t)BLOCK * KPT;
   static_assert(TILE >= (sizeof(K) >= 12 ? 1024u * 8u : 1024u * 16u), "wide_scratch_bytes sizes the granules for tiles of at least wide_tile() keys");
   // `compress` (dense-rank digits): the instantiations with the rank table in LDS -- where 8 KiB are left behind the tile
-  constexpr bool HPC_TAB = GS::BYTES + 8192 <= 160 * 1024;
+  constexpr bool HPC_TAB = RB == 9 && GS::BYTES + 8192 <= 160 * 1024;
+  if (RB != 9 && (plan.hpc || plan.pass_bits[0] > (u32)RB || plan.pass_bits[1] > (u32)RB)) return hipErrorInvalidValue;
   const bool hpcd = HPC_TAB && plan.hpc && plan_mask(plan, 0) == HPC_DIGIT_MASK && plan_mask(plan, 1) == HPC_DIGIT_MASK;
   static bool attr_done = false;
   if (!attr_done) {
@@ -1391,6 +1393,14 @@ static hipError_t group_wide(void *d_keys, void *d_alt, uint64_t n, const SortPl
   hipLaunchKernelGGL(narrow_bounds_kernel, dim3((uint32_t)((ng + 1 + 255) / 256)), dim3(256), 0, st, status_b, region_tiles,
                      &hdr->gbase[1][0], (u64)n, bA, ng, reinterpret_cast<u64 *>(d_sub_starts), (u32)(R / 2));
   return hipGetLastError();
+}
+
+template <typename K, int KPT>
+static hipError_t group_wide(void *d_keys, void *d_alt, uint64_t n, const SortPlan &plan, uint32_t *d_error, uint64_t *d_sub_starts,
+                             hipStream_t st, hipEvent_t *pass_events, void *d_prepared, void *d_scratch, uint32_t *tr_a, uint32_t *tr_b) {
+  if (!plan.hpc && plan.pass_bits[0] <= 8u && plan.pass_bits[1] <= 8u)
+    return group_wide_rb<K, KPT, 8>(d_keys, d_alt, n, plan, d_error, d_sub_starts, st, pass_events, d_prepared, d_scratch, tr_a, tr_b);
+  return group_wide_rb<K, KPT, 9>(d_keys, d_alt, n, plan, d_error, d_sub_starts, st, pass_events, d_prepared, d_scratch, tr_a, tr_b);
 }
 
 hipError_t launch_group_wide(void *d_keys, void *d_alt, uint64_t n, uint32_t key_words, const SortPlan &plan, uint32_t *d_error,
