@@ -464,7 +464,7 @@ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 
 // is then an immediate and the 64-bit (k > 32: 128-bit) variable shifts on a 32-bit ALU go away; KC = 0: k, mode and bucket_bits
 // are the run-time arguments.
 template <typename K, int MAXB, bool SOA = false, int KC = 0, int BB = 6>   // BB: the bucket bits of a constant-k form (6: the files; 8: `compress` at 5 Gbp and beyond)
-__global__ __launch_bounds__(KP_BLOCK, (sizeof(K) == 16) ? 2 : (SOA ? 4 : 5))   // 16-byte keys: the 64 KiB exchange tile allows two workgroups; SOA: no spill, LDS allows four anyway
+__global__ __launch_bounds__(KP_BLOCK, (sizeof(K) == 16) ? 2 : 4)   // 16-byte keys: the 64 KiB exchange tile allows two workgroups; 8-byte: four (five left 96 VGPRs: 20 spilled at constant k)
 void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, int mode_arg, u32 bucket_bits_arg,
                            u64 num_tiles, const u64 *__restrict__ block_base, K *__restrict__ out, u64 sfx_mask_arg, u64 sfx_test,
                            const u64 *__restrict__ soa_starts = nullptr, const u64 *__restrict__ soa_counts = nullptr,
