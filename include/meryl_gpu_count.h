@@ -427,6 +427,7 @@ typedef struct mgc_profile {
   uint32_t stream_files;           /* files on the distinct-sized count (hash_count_stream_kernel) and its coarser sub-buckets */
   uint32_t k96_files;              /* files that lay as 12-byte K96 records (k = 33..51) */
   uint32_t k96_widened_files;      /* ... of which widened back to 16-byte keys (an oversized sub-bucket nothing streams) */
+  uint32_t hpc_mixed_files;        /* `compress` buckets grouped by a dense-rank high digit + the plain eight bits of four bases (3^9 sub-buckets) */
   uint64_t stream_retries;         /* sub-buckets with more distinct suffixes than that kernel's table holds (counted by its retry launch) */
   double   probe_ratio;            /* distinct / instances of the probe file that chose between the plans (0: no probe ran) */
   /* what the rest of the count stage lasts (offsets of the sub-buckets in the packed result + the packing kernels of all files), on

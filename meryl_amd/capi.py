@@ -102,6 +102,7 @@ class Profile(ctypes.Structure):
         ("stream_files", ctypes.c_uint32),
         ("k96_files", ctypes.c_uint32),
         ("k96_widened_files", ctypes.c_uint32),
+        ("hpc_mixed_files", ctypes.c_uint32),
         ("stream_retries", ctypes.c_uint64),
         ("probe_ratio", ctypes.c_double),
         ("pack_ms", ctypes.c_double),

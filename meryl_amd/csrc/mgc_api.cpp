@@ -1425,6 +1425,11 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
     const bool hpc_stream_ok = hpc_ok && sw.hash_stream != 0 && sw.hash_stream != 2 && kw == 1 && d_fine_hpc && nb <= 256 && sw.wide_msd &&
                                rem_bits >= 20 + 32 && mgc::finish_stream_ok(kw, rem_bits - 20, false);
     std::vector<char> hpc_stream(nb, 0), hpc_cand(nb, 0);
+    // hpc_mixed[b]: a candidate bucket of a size at which 3^9 sub-buckets (dense-rank high digit + the plain eight bits of four bases:
+    // make_hpc_mixed_plan) average what the distinct-sized count likes (0.3 .. 1 of its target: 700 .. 2304 k-mers) -- 3^10 of them hold a few hundred k-mers
+    // each at 5 Gbp and the count kernel's per-sub-bucket steps dominate.  Taken where the probe says coverage is high.
+    std::vector<char> hpc_mixed(nb, 0);
+    const bool hpc_mixed_ok = hpc_stream_ok && rem_bits >= 18 + 32 && mgc::finish_stream_ok(kw, rem_bits - 18, false) && mgc::finish_can_stream(kw, rem_bits - 18);
     for (uint32_t b = 0; b < nb; b++) {
       uint32_t t = 0;
       if (hpc_ok && h_counts[b] > target) {                            // sub-buckets average `target` k-mers or fewer
@@ -1487,6 +1492,17 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
         // (above the index-claimed tables' reach: the distinct-sized count whatever the coverage; below: a candidate the probe file decides on)
         if (hpc_stream[b] && wide_msd[b]) { fstream[b] = 1; s->prof.stream_files++; }
         else if (hpc_stream_ok && wide_msd[b] && top_bits[b] == 20 && h_counts[b] < (1ull << 30)) hpc_cand[b] = 1;
+        if ((hpc_cand[b] || (fstream[b] && sw.hash_stream == 1)) && hpc_mixed_ok && h_counts[b] >= 19683ull * (starget * 3 / 10) &&
+            h_counts[b] <= 19683ull * starget) {
+          mgc::SortPlan mp;
+          mgc::make_hpc_mixed_plan(rem_bits - 18, &mp);
+          hpc_mixed[b] = mgc::sort_plan_wide_msd(mp, h_counts[b], sw.wide_msd) ? 1 : 0;
+          if (hpc_mixed[b] && sw.hash_stream == 1) {                   // (tests, A/B: no probe)
+            top_bits[b] = 18; fplan[b] = mp; s->prof.hpc_mixed_files++;
+            if (!fstream[b]) { fstream[b] = 1; s->prof.stream_files++; }
+            hpc_mixed[b] = 0; hpc_cand[b] = 0;
+          }
+        }
         continue;
       }
       mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fplan[b]);
@@ -1527,6 +1543,11 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
       sbase[b + 1] = sbase[b] + (ng ? ng + 1 : 0);
     }
     auto ngf = [&](uint32_t b) -> uint64_t { return h_counts[b] ? ((uint64_t)1 << top_bits[b]) : 0; };
+    auto take_mixed_plan = [&](uint32_t b) {
+      top_bits[b] = 18;
+      mgc::make_hpc_mixed_plan(rem_bits - 18, &fplan[b]);
+      s->prof.hpc_mixed_files++;
+    };
     auto take_stream_plan = [&](uint32_t b) {                // the candidate becomes the file's plan (narrow[] / wide_msd[] stay as they are)
       fstream[b] = 1; top_bits[b] = top_str[b];
       mgc::make_sort_plan(rem_bits - top_bits[b], rem_bits, &fplan[b]);
@@ -1918,7 +1939,10 @@ static int count_device(mgc_session *s, void *ext_keys = nullptr, const uint64_t
                                    (unsigned long long)h_pd, (unsigned long long)h_counts[pb], ratio, ratio <= 0.30 ? "distinct-sized" : "finer");
       if (ratio <= 0.30) for (uint32_t b = 0; b < nb; b++) {
         if (b != pb && top_str[b]) take_stream_plan(b);
-        else if (b != pb && hpc_cand[b] && !fstream[b]) { fstream[b] = 1; s->prof.stream_files++; }   // (`compress`: the same digits, the other count kernel)
+        else if (b != pb && hpc_cand[b] && !fstream[b]) {      // (`compress`: the other count kernel, on 3^9 sub-buckets where the bucket's size asks for them)
+          fstream[b] = 1; s->prof.stream_files++;
+          if (hpc_mixed[b]) take_mixed_plan(b);
+        }
       }
       if (d_fine && nb <= 256 && d_nhdrs) { const int prc = prepare_headers(-1, probe); if (prc != MGC_OK) return prc; }
     }

@@ -85,7 +85,7 @@ struct SortPlan {
   uint32_t kpt;             // keys per thread (16; 16-byte keys: 8)
   uint32_t tile;            // block*kpt
   uint32_t mode;            // 0 = stable sort (decoupled look-back), 3 = grouping passes (not a sort: see radix_group_kernel; at most two digits)
-  uint32_t hpc;             // digits are DENSE RANKS of five homopolymer-free bases (make_hpc_group_plan), not bit fields
+  uint32_t hpc;             // 1: digits are DENSE RANKS of five homopolymer-free bases (make_hpc_group_plan), not bit fields; 2: only the high digit is
   uint32_t num_passes;
   uint32_t pass_shift[16];
   uint32_t pass_bits[16];
@@ -100,6 +100,9 @@ void   make_sort_plan(uint32_t begin_bit, uint32_t end_bit, SortPlan *plan);
 // digits orders the keys exactly as grouping by the bits would, over 3^(5*passes) occupied sub-buckets instead of a
 // 4^(5*passes) grid that is 94 % empty -- two digits do what took three stable passes.
 void   make_hpc_group_plan(uint32_t low_bit, uint32_t passes, SortPlan *plan);
+// ... and the two-digit form whose LOW digit is the plain eight bits of four bases (81 of 256 patterns): 18 key bits above `low_bit`,
+// 3^9 = 19683 occupied sub-buckets of a 2^18 grid (SortPlan::hpc == 2)
+void   make_hpc_mixed_plan(uint32_t low_bit, SortPlan *plan);
 size_t sort_workspace_bytes(uint64_t n);
 
 // Sorts n keys; returns where the result is via *result_in_alt.  d_error is a

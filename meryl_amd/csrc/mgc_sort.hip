@@ -430,7 +430,7 @@ struct GroupExtra { u32 digit_bits /* NARROW */; u32 shift2, mask2; u64 *ghist2 
 // for HIST2 -- the whole-key passes of `compress` were VALU-bound at 0.357 ms per 69 M keys against 0.266 ms for plain bit digits): the
 // 4096 ranks of the twelve bits a digit is taken from lie in 8 KiB of LDS behind the tile, a digit is one 16-bit LDS read.
 template <typename K, int RB, int BLOCK, int KPT, bool DBG, bool NARROW = false, bool HIST2 = false, bool SOA = false, int PIPE = 0 /* 1: the next fetch before the write-out; 2: after it */,
-          bool HPCD = false>
+          int HPCD = 0 /* 1: both digits are dense ranks; 2: only this pass's (the other digit, HIST2's, is a plain bit field) */>
 __global__ __launch_bounds__(BLOCK, (GroupSmem<K, RB, BLOCK, KPT>::MIN_WAVES_PER_SIMD))
 void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::type *__restrict__ out, u64 n, u32 shift, u32 dmask,
                         const u64 *__restrict__ gbase, u64 *__restrict__ status, u32 *__restrict__ ticket,
@@ -464,7 +464,7 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
     else return KO::digit(key, shift, dmask);
   };
   auto dig2 = [&](const K &key) __attribute__((always_inline)) -> u32 {
-    if constexpr (HPCD) return (u32)s_rank[KO::digit(key, ex.shift2, 0xFFFu)];
+    if constexpr (HPCD == 1) return (u32)s_rank[KO::digit(key, ex.shift2, 0xFFFu)];
     else return KO::digit(key, ex.shift2, ex.mask2);
   };
 
@@ -833,8 +833,19 @@ void make_hpc_group_plan(uint32_t low_bit, uint32_t passes, SortPlan *plan) {
   for (uint32_t p = 0; p < passes; p++) { plan->pass_shift[p] = low_bit + 10 * p; plan->pass_bits[p] = 10; }
 }
 
-// the `mask` argument of a pass's kernels
-static inline u32 plan_mask(const SortPlan &plan, uint32_t p) { return plan.hpc ? HPC_DIGIT_MASK : (1u << plan.pass_bits[p]) - 1u; }
+// `compress`, a bucket of 14..45 M k-mers on the distinct-sized count: the HIGH digit a dense rank of five bases (243 values), the LOW
+// one the plain eight bits of the four bases below them (81 of 256 patterns occur): 19683 occupied sub-buckets instead of 59049
+void make_hpc_mixed_plan(uint32_t low_bit, SortPlan *plan) {
+  make_hpc_group_plan(low_bit, 2, plan);
+  plan->hpc = 2;
+  plan->pass_shift[0] = low_bit;     plan->pass_bits[0] = 8;
+  plan->pass_shift[1] = low_bit + 8; plan->pass_bits[1] = 10;
+}
+
+// the `mask` argument of a pass's kernels (hpc == 2: only the high digit of the two is a dense rank)
+static inline u32 plan_mask(const SortPlan &plan, uint32_t p) {
+  return (plan.hpc == 1 || (plan.hpc == 2 && p == 1)) ? HPC_DIGIT_MASK : (1u << plan.pass_bits[p]) - 1u;
+}
 
 static inline uint64_t max_tiles_for(uint64_t n) { return (n + 4095) / 4096 + 1; }   // tile >= 4096 keys
 
@@ -1330,6 +1341,9 @@ static hipError_t group_wide_rb(void *d_keys, void *d_alt, uint64_t n, const Sor
   constexpr bool HPC_TAB = RB == 9 && GS::BYTES + 8192 <= 160 * 1024;
   if (RB != 9 && (plan.hpc || plan.pass_bits[0] > (u32)RB || plan.pass_bits[1] > (u32)RB)) return hipErrorInvalidValue;
   const bool hpcd = HPC_TAB && plan.hpc && plan_mask(plan, 0) == HPC_DIGIT_MASK && plan_mask(plan, 1) == HPC_DIGIT_MASK;
+  // (make_hpc_mixed_plan: the high digit from the rank table, the low one a plain eight-bit field -- its pass is the eight-bit instantiation)
+  const bool mixed = HPC_TAB && plan.hpc == 2 && plan.pass_bits[0] <= 8u;
+  using GS8 = GroupSmem<K, 8, BLOCK, KPT>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, true>),
@@ -1337,10 +1351,14 @@ static hipError_t group_wide_rb(void *d_keys, void *d_alt, uint64_t n, const Sor
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES);
     if constexpr (HPC_TAB) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, true, false, 0, true>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, true, false, 0, 1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES + 8192);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, false, false, 0, true>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, false, false, 0, 1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES + 8192);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, RB, BLOCK, KPT, false, false, true, false, 0, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS::BYTES + 8192);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel<K, 8, BLOCK, KPT, false, false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS8::BYTES);
     }
     attr_done = true;
   }
@@ -1360,12 +1378,19 @@ static hipError_t group_wide_rb(void *d_keys, void *d_alt, uint64_t n, const Sor
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[0], st));
   if constexpr (HPC_TAB) {
     if (hpcd)
-      hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, true, false, 0, true>), dim3((uint32_t)std::min(tiles0, resident)), dim3(BLOCK), GS::BYTES + 8192, st,
+      hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, true, false, 0, 1>), dim3((uint32_t)std::min(tiles0, resident)), dim3(BLOCK), GS::BYTES + 8192, st,
                          reinterpret_cast<const K *>(d_keys), reinterpret_cast<K *>(d_alt), (u64)n, shA, maskA,
                          &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
                          GroupExtra{0u, low, maskB, &hdr->ghist[1][0]}, (u64 *)nullptr);
   }
-  if (!hpcd)
+  if constexpr (HPC_TAB) {
+    if (mixed)
+      hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, true, false, 0, 2>), dim3((uint32_t)std::min(tiles0, resident)), dim3(BLOCK), GS::BYTES + 8192, st,
+                         reinterpret_cast<const K *>(d_keys), reinterpret_cast<K *>(d_alt), (u64)n, shA, maskA,
+                         &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
+                         GroupExtra{0u, low, maskB, &hdr->ghist[1][0]}, (u64 *)nullptr);
+  }
+  if (!hpcd && !mixed)
   hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, true>), dim3((uint32_t)std::min(tiles0, resident)), dim3(BLOCK), GS::BYTES, st,
                      reinterpret_cast<const K *>(d_keys), reinterpret_cast<K *>(d_alt), (u64)n, shA, maskA,
                      &hdr->gbase[0][0], status_a, &hdr->ticket[0], d_error, (u64)tiles0, (const u64 *)nullptr, (const u32 *)nullptr,
@@ -1377,12 +1402,22 @@ static hipError_t group_wide_rb(void *d_keys, void *d_alt, uint64_t n, const Sor
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[2], st));
   if constexpr (HPC_TAB) {
     if (hpcd)
-      hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, false, false, 0, true>), dim3((uint32_t)std::min(tiles1_max, resident)), dim3(BLOCK), GS::BYTES + 8192, st,
+      hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, false, false, 0, 1>), dim3((uint32_t)std::min(tiles1_max, resident)), dim3(BLOCK), GS::BYTES + 8192, st,
                          reinterpret_cast<const K *>(d_alt), reinterpret_cast<K *>(d_keys), (u64)n, low, maskB,
                          &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)tiles0, region_start, region_tiles,
                          GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
   }
-  if (!hpcd)
+  u32 granules1 = (u32)(R / 2);
+  if constexpr (HPC_TAB) {
+    if (mixed) {
+      granules1 = 128u;
+      hipLaunchKernelGGL((radix_group_kernel<K, 8, BLOCK, KPT, false, false, false>), dim3((uint32_t)std::min(tiles1_max, resident)), dim3(BLOCK), GS8::BYTES, st,
+                         reinterpret_cast<const K *>(d_alt), reinterpret_cast<K *>(d_keys), (u64)n, low, maskB,
+                         &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)tiles0, region_start, region_tiles,
+                         GroupExtra{0u, 0u, 0u, nullptr}, (u64 *)nullptr);
+    }
+  }
+  if (!hpcd && !mixed)
   hipLaunchKernelGGL((radix_group_kernel<K, RB, BLOCK, KPT, false, false, false>), dim3((uint32_t)std::min(tiles1_max, resident)), dim3(BLOCK), GS::BYTES, st,
                      reinterpret_cast<const K *>(d_alt), reinterpret_cast<K *>(d_keys), (u64)n, low, maskB,
                      &hdr->gbase[1][0], status_b, &hdr->ticket[1], d_error, (u64)tiles0, region_start, region_tiles,
@@ -1391,7 +1426,7 @@ static hipError_t group_wide_rb(void *d_keys, void *d_alt, uint64_t n, const Sor
   if (pass_events) MGC_CHECK(hipEventRecord(pass_events[3], st));
   const u64 ng = (u64)1 << (bA + bB);
   hipLaunchKernelGGL(narrow_bounds_kernel, dim3((uint32_t)((ng + 1 + 255) / 256)), dim3(256), 0, st, status_b, region_tiles,
-                     &hdr->gbase[1][0], (u64)n, bA, ng, reinterpret_cast<u64 *>(d_sub_starts), (u32)(R / 2));
+                     &hdr->gbase[1][0], (u64)n, bA, ng, reinterpret_cast<u64 *>(d_sub_starts), granules1);
   return hipGetLastError();
 }
 

@@ -576,7 +576,9 @@ def test_compress_high_digit_first(ops, oracle_lib, torch_cuda, monkeypatch, k, 
 
 
 @pytest.mark.parametrize("k,bucket_bases,target,stream", [(31, None, None, "1"), (31, 200_000, "100", "1"), (32, 200_000, "100", "1"), (30, 200_000, "40", "1"),
-                                                            (31, 200_000, "100", None), (31, 200_000, "100", "2")])
+                                                            (31, 200_000, "100", None), (31, 200_000, "100", "2"),
+                                                            # buckets of 0.3 .. 1 x 19683 x target k-mers: the dense-rank high digit + plain low digit (3^9 sub-buckets)
+                                                            (31, None, "24", "1"), (32, None, "20", "1"), (30, 200_000, "6", "1"), (31, 200_000, "8", "1")])
 def test_compress_two_digit_buckets_on_the_distinct_sized_count(ops, oracle_lib, torch_cuda, monkeypatch, k, bucket_bases, target, stream):
     """Round 6: a `compress` bucket with two dense-rank digits counts its whole 8-byte k-mers with hash_count_stream_kernel<u64>
     (64-bit entries suffix << 12 | count, the sparse grid's non-empty list walked, the k-mer's own top bits put back) -- always when
@@ -614,6 +616,8 @@ def test_compress_two_digit_buckets_on_the_distinct_sized_count(ops, oracle_lib,
             assert prof.stream_files > 0, prof.stream_files
         if stream == "2":
             assert prof.stream_files == 0, prof.stream_files
+        if target in ("24", "20", "6", "8"):
+            assert prof.hpc_mixed_files > 0, (prof.hpc_mixed_files, prof.stream_files)
 
 
 @pytest.mark.parametrize("k", [3, 8, 13, 14])
