@@ -315,7 +315,16 @@ void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
   __shared__ u32 s_codes[2][KH_NV][KP_WORDS];
   __shared__ u32 s_inval[2][KH_NV][KP_WORDS];
   __shared__ u32 s_prev[HB ? NBK : 256u];
+  // `compress` (round 6): the dense rank of the k-mer's first HB bases from two tables -- rank of the bucket's bases * 243, and
+  // hpc_digit of the five bases below them given the bucket's last base (twelve bits) -- instead of HB dependent compare /
+  // multiply-add steps per k-mer (hpc_dense_rank<9>: ~45 VALU instructions, the kernel was VALU-bound: 5.9 against 3.1 ms per 5 Gbp)
+  __shared__ unsigned short s_r5[HB ? 4096 : 1];
+  __shared__ unsigned short s_rb[HB ? NBK : 1];
   const u32 tid = threadIdx.x, v = tid >> 8, t = tid & 255u;
+  if constexpr (HB > 0) {
+    for (u32 i = tid; i < 4096u; i += KP_BLOCK * KH_NV) s_r5[i] = (unsigned short)hpc_digit(i);
+    if (tid < NBK) s_rb[tid] = (unsigned short)(hpc_dense_rank<HB - 5>(tid) * 243u);
+  }
   const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
   for (u32 i = tid; i < TABLE; i += KP_BLOCK * KH_NV) kh_fine[i] = 0;
   if (tid < (HB ? NBK : 256u)) s_prev[tid] = 0;
@@ -360,7 +369,7 @@ void kmer_hist_fine_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
 #pragma unroll
         for (int j = 0; j < KP_ITEMS; j++)
           if ((vmask >> j) & 1u) {
-            if constexpr (HB > 0) { const u32 r = hpc_dense_rank<HB>(bk[j]); atomicAdd(&kh_fine[r < TABLE ? r : TABLE - 1u], 1u); }
+            if constexpr (HB > 0) { const u32 r = (u32)s_rb[bk[j] >> 10] + (u32)s_r5[bk[j] & 0xFFFu]; atomicAdd(&kh_fine[r < TABLE ? r : TABLE - 1u], 1u); }
             else atomicAdd(&kh_fine[bk[j]], 1u);
           }
       }
