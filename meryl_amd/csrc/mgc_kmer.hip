@@ -472,6 +472,19 @@ void kmer_scan_kernel(u64 *__restrict__ block_hist, u32 grid, u32 nb, const u64 
 // count-suffix filter -- every shift of the sixteen unrolled window extractions (key_shift, top_shift, the reverse complement's)
 // is then an immediate and the 64-bit (k > 32: 128-bit) variable shifts on a 32-bit ALU go away; KC = 0: k, mode and bucket_bits
 // are the run-time arguments.
+// Stores through an address that comes out of LDS as an integer (the per-file output cursors): a plain pointer cast makes it a GENERIC
+// pointer and the store a flat_store -- issued to the LDS pipeline as well as to memory, and counted in lgkmcnt, so that the barrier
+// behind the write-out also waits for it (round 6, from the ISA: the partition's two stores per k-mer were its only flat instructions).
+typedef __attribute__((address_space(1))) u32     kp_gu32;
+typedef __attribute__((address_space(1))) uint8_t kp_gu8;
+typedef __attribute__((address_space(1))) u64     kp_gu64;
+typedef u32 kp_u32x3 __attribute__((ext_vector_type(3)));
+typedef __attribute__((address_space(1))) __attribute__((aligned(4))) kp_u32x3 kp_gu32x3;
+__device__ __forceinline__ void kp_gstore32(u64 addr, u32 v)     { *reinterpret_cast<kp_gu32 *>(addr) = v; }
+__device__ __forceinline__ void kp_gstore8(u64 addr, uint8_t v)  { *reinterpret_cast<kp_gu8 *>(addr) = v; }
+__device__ __forceinline__ void kp_gstore64(u64 addr, u64 v)     { *reinterpret_cast<kp_gu64 *>(addr) = v; }
+__device__ __forceinline__ void kp_gstore96(u64 addr, u32 a, u32 b, u32 c) { kp_u32x3 v; v.x = a; v.y = b; v.z = c; *reinterpret_cast<kp_gu32x3 *>(addr) = v; }
+
 template <typename K, int MAXB, bool SOA = false, int KC = 0, int BB = 6>   // BB: the bucket bits of a constant-k form (6: the files; 8: `compress` at 5 Gbp and beyond)
 __global__ __launch_bounds__(KP_BLOCK, (sizeof(K) == 16) ? 2 : 4)   // 16-byte keys: the 64 KiB exchange tile allows two workgroups; 8-byte: four (five left 96 VGPRs: 20 spilled at constant k)
 void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, int mode_arg, u32 bucket_bits_arg,
@@ -610,19 +623,21 @@ void kmer_partition_kernel(const uint8_t *__restrict__ bases, u64 n, u32 k_arg, 
         // (the high bytes four at a time -- a quad of consecutive tile positions lies in one file except where two files
         // meet: one unaligned 4-byte store instead of four byte stores -- measured SLOWER: 28.4 ms against 25.2, the
         // hardware splits a byte-aligned dword store anyway and the quad loop reads the tile from LDS once more)
-        *reinterpret_cast<u32 *>(s_ob[b] + 4ull * i) = (u32)KeyOps<K>::low64(key);
-        *reinterpret_cast<uint8_t *>(s_ob_hi[b] + (u64)i) = (uint8_t)(KeyOps<K>::low64(key) >> 32);
+        kp_gstore32(s_ob[b] + 4ull * i, (u32)KeyOps<K>::low64(key));
+        kp_gstore8(s_ob_hi[b] + (u64)i, (uint8_t)(KeyOps<K>::low64(key) >> 32));
       }
       else if constexpr (SOA) {
         // the low twelve bytes are the same in both layouts; a 16-byte file's k-mer gets its top word too
         const u64 ob = s_ob[b];
         const bool f96 = (ob & 1ull) != 0;
         const u64 addr = (ob & ~1ull) + (u64)(f96 ? 12u : 16u) * i;
-        K96 o; o.w[0] = (u32)key.lo; o.w[1] = (u32)(key.lo >> 32); o.w[2] = (u32)key.hi;
-        *reinterpret_cast<K96 *>(addr) = o;
-        if (!f96) *reinterpret_cast<u32 *>(addr + 12ull) = (u32)(key.hi >> 32);
+        kp_gstore96(addr, (u32)key.lo, (u32)(key.lo >> 32), (u32)key.hi);
+        if (!f96) kp_gstore32(addr + 12ull, (u32)(key.hi >> 32));
       }
-      else if constexpr (OB) *reinterpret_cast<K *>(s_ob[b] + (u64)sizeof(K) * i) = key;
+      else if constexpr (OB) {
+        if constexpr (sizeof(K) == 8) kp_gstore64(s_ob[b] + 8ull * i, (u64)KeyOps<K>::low64(key));
+        else *reinterpret_cast<K *>(s_ob[b] + (u64)sizeof(K) * i) = key;
+      }
       else out[s_cursor[b] + (u64)(i - s_base[b])] = key;
     }
     __syncthreads();
