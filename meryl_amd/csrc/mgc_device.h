@@ -26,7 +26,9 @@ struct Switches {
   bool nolist = false;          // MGC_FINISH_NOLIST=1: the dense-grid instantiations of the count kernels whatever the grid holds
   bool finish_trace = false;    // MGC_FINISH_TRACE: what happens to oversized sub-buckets, on stderr
   bool group_dbg = false;       // MGC_GROUP_DBG: per-phase cycle sums of the grouping passes (instrumented instantiations)
-  uint32_t pass_stagger = 8;    // MGC_PASS_STAGGER: groups the 5-byte first pass's workgroups start in (0 / 1: together; mgc_sort.hip, STAGGER)
+  uint32_t pass_stagger = 0;    // MGC_PASS_STAGGER: groups the 5-byte first pass's workgroups start in (0 / 1: together -- the default: the
+                                // staggered start hands the first tiles out statically, which is only safe while ALL workgroups of the launch are
+                                // resident, i.e. while nothing else holds CUs of the device; mgc_sort.hip, STAGGER)
   bool hash_dbg = false;        // MGC_HASH_DBG: per-phase cycle sums of the count kernels
   int  hash_multi = -1;         // MGC_HASH_MULTI: sub-buckets per iteration of hash_count_multi_kernel (-1: by the file's average; 0: off)
   int  hash_stream = -1;        // MGC_HASH_STREAM: the distinct-sized count (hash_count_stream_kernel) and its coarser file plan (-1: where the probe

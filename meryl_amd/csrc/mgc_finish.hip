@@ -3113,7 +3113,7 @@ Switches read_switches() {
   sw.bucket_bases = num("MGC_BUCKET_BASES", 0);
   sw.huge_streams = (uint32_t)num("MGC_HUGE_STREAMS", 4);
   sw.huge_slices = !off("MGC_HUGE_SLICES");
-  sw.pass_stagger = (uint32_t)num("MGC_PASS_STAGGER", 8);
+  sw.pass_stagger = (uint32_t)num("MGC_PASS_STAGGER", 0);
   return sw;
 }
 

@@ -610,6 +610,9 @@ void radix_group_kernel(const K *__restrict__ in, typename GroupOut<K, NARROW>::
   // out.  The first tiles are handed out statically in the order in which they will be processed (burst i * P + g = iteration i of
   // group g; a ticket taken while another group sleeps would put a LATER tile in front of its predecessors: measured, +9 %), the
   // tickets continue behind them.  Measured (profiles/r06_ab_runs.txt, r06x_rb8b): first pass 0.453 -> 0.444 ms per launch.
+  // OPT-IN (MGC_PASS_STAGGER=8), not the default: with tickets a workgroup that is not resident yet holds no tile, so the walkers only
+  // ever wait for workgroups that run; a static hand-out gives tiles to workgroups that may still wait for a CU -- another process or
+  // session holding part of the device -- and the running ones would spin for them until the spin limit (MGC_ETIMEOUT).
   const bool stag = ex.stagger_groups > 1u && gridDim.x % (8u * ex.stagger_groups) == 0u;
   u32 st_g = 0, st_r = 0, st_w = 0, tk_off = 0;
   if (stag) {
